@@ -1,0 +1,639 @@
+/*
+ * segjuncs_oracle.c -- CPU oracle (TEST INFRASTRUCTURE, see thj_oracle.h) for
+ * the split-segment junction / small-indel search of TopHat's segment_juncs.
+ *
+ * Plain-C restatement of DaehwanKimLab/tophat v2.1.2 src/segment_juncs.cpp:
+ *   find_gaps                         :3293-3650
+ *   juncs_from_ref_segs<RecordSegmentJuncs> (POINT_DIR_BOTH)  :2052-2377, :1669-1696
+ *   find_insertions_and_deletions     :2807-2942
+ *   detect_small_insertion/deletion   :2470-2627
+ *   simpleSplitAlignment              :2390-2456
+ *   map_read_to_contig                :2946-2973
+ * Colour-space (`if (color)`) branches are out of scope and omitted.
+ *
+ * PARITY: unpinned by the reference's own tests (none exist for this
+ * boundary); see oracle/README.md for what it was checked against.
+ */
+#include "thj_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------- utils */
+
+typedef struct { orc_junction* v; int64_t n, cap; } jvec;
+typedef struct { orc_insertion* v; int64_t n, cap; } ivec;
+
+static int jpush(jvec* a, orc_junction j)
+{
+    if (a->n == a->cap) {
+        int64_t nc = a->cap ? a->cap * 2 : 1024;
+        orc_junction* nv = (orc_junction*)realloc(a->v, (size_t)nc * sizeof *nv);
+        if (!nv) return -1;
+        a->v = nv; a->cap = nc;
+    }
+    a->v[a->n++] = j;
+    return 0;
+}
+
+static int ipush(ivec* a, orc_insertion j)
+{
+    if (a->n == a->cap) {
+        int64_t nc = a->cap ? a->cap * 2 : 1024;
+        orc_insertion* nv = (orc_insertion*)realloc(a->v, (size_t)nc * sizeof *nv);
+        if (!nv) return -1;
+        a->v = nv; a->cap = nc;
+    }
+    a->v[a->n++] = j;
+    return 0;
+}
+
+/* Junction::operator< (junctions.h:39-57): refid, left, right as uint32, then
+ * antisense (false before true). skip_count is always 0 for RecordSegmentJuncs
+ * so skip_count_lt (junctions.h:70-78) reduces to this. */
+static int jcmp(const void* pa, const void* pb)
+{
+    const orc_junction* a = (const orc_junction*)pa;
+    const orc_junction* b = (const orc_junction*)pb;
+    if (a->ref_id != b->ref_id) return a->ref_id < b->ref_id ? -1 : 1;
+    if (a->left != b->left) return a->left < b->left ? -1 : 1;
+    if (a->right != b->right) return a->right < b->right ? -1 : 1;
+    if (a->antisense != b->antisense) return a->antisense < b->antisense ? -1 : 1;
+    return 0;
+}
+
+static int64_t junique(orc_junction* v, int64_t n)
+{
+    if (n == 0) return 0;
+    qsort(v, (size_t)n, sizeof *v, jcmp);
+    int64_t w = 1;
+    for (int64_t i = 1; i < n; ++i)
+        if (jcmp(&v[i], &v[w - 1]) != 0) v[w++] = v[i];
+    return w;
+}
+
+/* Insertion::operator< (insertions.h:52-67) compares refid, left and only the
+ * LENGTH of the sequence, so std::set keeps the first one inserted among
+ * equal-length insertions at one place.  `prio` is the insertion order. */
+static int icmp(const void* pa, const void* pb)
+{
+    const orc_insertion* a = (const orc_insertion*)pa;
+    const orc_insertion* b = (const orc_insertion*)pb;
+    if (a->ref_id != b->ref_id) return a->ref_id < b->ref_id ? -1 : 1;
+    if (a->left != b->left) return a->left < b->left ? -1 : 1;
+    size_t la = strlen(a->seq), lb = strlen(b->seq);
+    if (la != lb) return la < lb ? -1 : 1;
+    if (a->prio != b->prio) return a->prio < b->prio ? -1 : 1;
+    return 0;
+}
+
+static int64_t iunique(orc_insertion* v, int64_t n)
+{
+    if (n == 0) return 0;
+    qsort(v, (size_t)n, sizeof *v, icmp);
+    int64_t w = 1;
+    for (int64_t i = 1; i < n; ++i) {
+        const orc_insertion* p = &v[w - 1];
+        if (v[i].ref_id == p->ref_id && v[i].left == p->left && strlen(v[i].seq) == strlen(p->seq))
+            continue; /* an earlier (lower prio) one is already kept */
+        v[w++] = v[i];
+    }
+    return w;
+}
+
+static const char* contig(const orc_genome* g, uint32_t ref_id, int64_t* len)
+{
+    if (ref_id == 0 || (int64_t)ref_id > g->n_contigs) { *len = 0; return NULL; }
+    *len = g->len[ref_id - 1];
+    return g->seq[ref_id - 1];
+}
+
+/* reads.cpp:189-207 reverse_complement(string&): anything not ACGT becomes N. */
+static void revcomp(const char* in, int n, char* out)
+{
+    for (int i = 0; i < n; ++i) {
+        char c = in[n - 1 - i], o;
+        switch (c) {
+        case 'A': o = 'T'; break;
+        case 'T': o = 'A'; break;
+        case 'C': o = 'G'; break;
+        case 'G': o = 'C'; break;
+        default:  o = 'N'; break;
+        }
+        out[i] = o;
+    }
+}
+
+/* SeqAn Dna5 -> Dna conversion used by the window copies: value & 3, so N (4)
+ * becomes A (SeqAn-1.4.2/seqan/basic/alphabet_residue.h:873-876, used at
+ * segment_juncs.cpp:2157 and :2499). */
+static char n_to_a(char c) { return c == 'N' ? 'A' : c; }
+
+/* ------------------------------------------- juncs_from_ref_segs (BOTH) */
+
+static const char* const DONORS[3]    = { "GT", "GC", "AT" };  /* segment_juncs.cpp:3618-3649 */
+static const char* const ACCEPTORS[3] = { "AG", "AG", "AC" };
+
+static void rc2(const char* d, char* o) { revcomp(d, 2, o); }
+
+int orc_window_scan(const orc_params* p, const orc_genome* g, uint32_t ref_id,
+                    int32_t seg_left, int32_t seg_right, int antisense,
+                    const char* support, int support_len,
+                    orc_junction* out, int cap)
+{
+    int n_out = 0;
+    int64_t ref_len;
+    const char* ref = contig(g, ref_id, &ref_len);
+    if (!ref) return 0;                                   /* :2105-2108 */
+
+    /* library-type strand rules, :2110-2138 */
+    int skip_fwd = 0, skip_rev = 0;
+    if (p->library_type == 2) {            /* FR_FIRSTSTRAND */
+        if (p->read_side == 1) { if (antisense) skip_rev = 1; else skip_fwd = 1; }
+        else if (p->read_side == 2) { if (antisense) skip_fwd = 1; else skip_rev = 1; }
+    }
+    if (p->library_type == 3) {            /* FR_SECONDSTRAND */
+        if (p->read_side == 1) { if (antisense) skip_fwd = 1; else skip_rev = 1; }
+        else if (p->read_side == 2) { if (antisense) skip_rev = 1; else skip_fwd = 1; }
+    }
+
+    /* :2154 */
+    if (seg_left < 0 || seg_right >= (int)ref_len - 1) return 0;
+
+    int seg_len = seg_right - seg_left;
+    int read_len = support_len;
+    /* The reference indexes seg_str[read_len-2] and seg_str[seg_len-read_len+i]
+     * unguarded; with the distances find_gaps admits seg_len >= read_len + min
+     * intron always holds.  Guarded here so the oracle has no UB. */
+    if (read_len < 2 || read_len > 128 || seg_len < read_len) return 0;
+
+    for (int m = 0; m < 3; ++m) {
+        const char* donor = DONORS[m];
+        const char* acceptor = ACCEPTORS[m];
+        char rev_donor[2], rev_acceptor[2];
+        rc2(donor, rev_donor);                 /* :2073-2076 */
+        rc2(acceptor, rev_acceptor);
+
+        int to = read_len - 2;                 /* :2167-2172 */
+        uint8_t left_mm[128], right_mm[128];
+        memset(left_mm, 0, sizeof left_mm);
+        memset(right_mm, 0, sizeof right_mm);
+
+        /* :2187-2203 prefix mismatches of the support read against the window start */
+        {
+            int num = 0;
+            for (int i = 0; i < read_len - 1; ++i) {
+                if (n_to_a(ref[seg_left + i]) != support[i]) ++num;
+                left_mm[i] = (uint8_t)num;
+                if (num > 2) { to = i; break; }
+            }
+        }
+        /* :2205-2218 suffix mismatches against the window end; entries below the
+         * break index stay 0 */
+        {
+            int num = 0;
+            for (int i = read_len - 1; i >= 0; --i) {
+                if (n_to_a(ref[seg_left + i + (seg_len - read_len)]) != support[i]) ++num;
+                right_mm[i] = (uint8_t)num;
+                if (num > 2) break;
+            }
+        }
+
+        /* :2240-2289 */
+        for (int i = 0; i <= to; ++i) {
+            char c0 = n_to_a(ref[seg_left + i]), c1 = n_to_a(ref[seg_left + i + 1]);
+            int is_don = (c0 == donor[0] && c1 == donor[1]);
+            int is_racc = (c0 == rev_acceptor[0] && c1 == rev_acceptor[1]);
+            if ((!skip_fwd && is_don) || (!skip_rev && is_racc)) {
+                const char* partner = is_don ? acceptor : rev_donor;
+                int lm = i > 0 ? left_mm[i - 1] : 0;
+                if (lm + right_mm[i] <= 2) {
+                    int pos = seg_len - (read_len - i) - 2;
+                    char p0 = n_to_a(ref[seg_left + pos]), p1 = n_to_a(ref[seg_left + pos + 1]);
+                    if (p0 == partner[0] && p1 == partner[1]) {
+                        /* RecordSegmentJuncs::record :1681-1695: Junction(ref,
+                         * donor-1, acceptor+2, antisense); fwd lists -> '+',
+                         * rev lists -> '-'.  In an all-BOTH call the two lists
+                         * grow together, so the size check at :1681 never
+                         * drops anything and motifs.unique() is skipped
+                         * (:2339-2340): each accepted i is one junction. */
+                        if (n_out < cap) {
+                            orc_junction j;
+                            j.ref_id = ref_id;
+                            j.left = (uint32_t)(seg_left + i - 1);
+                            j.right = (uint32_t)(seg_left + pos + 2);
+                            j.antisense = is_don ? 0u : 1u;
+                            out[n_out++] = j;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    return n_out;
+}
+
+/* -------------------------------------------------- simpleSplitAlignment */
+
+int orc_simple_split(const char* shorter, const char* left_ref, const char* right_ref,
+                     int len, int* min_err)
+{
+    /* segment_juncs.cpp:2390-2456 */
+    unsigned short before[512], after[512];
+    if (len > 512) len = 512;
+    for (int idx = len - 1; idx >= 0; --idx) {
+        unsigned short prev = idx < len - 1 ? before[idx + 1] : 0;
+        unsigned short cur = (right_ref[idx] == 'N' || shorter[idx] == 'N' || right_ref[idx] != shorter[idx]) ? 1 : 0;
+        before[idx] = (unsigned short)(prev + cur);
+    }
+    for (int idx = 0; idx < len; ++idx) {
+        unsigned short prev = idx > 0 ? after[idx - 1] : 0;
+        unsigned short cur = (left_ref[idx] == 'N' || shorter[idx] == 'N' || left_ref[idx] != shorter[idx]) ? 1 : 0;
+        after[idx] = (unsigned short)(prev + cur);
+    }
+    int best = len + 1, best_pos = -1;
+    for (int pos = 1; pos < len; ++pos) {
+        int e = before[pos] + after[pos - 1];
+        if (e < best) { best = e; best_pos = pos; }   /* ties keep the first (bestInsertPositions[0]) */
+    }
+    *min_err = best;
+    return best_pos;
+}
+
+/* ----------------------------------------------------- map_read_to_contig */
+
+int orc_map_read_to_contig(const char* ctg, int contig_len, const char* read, int read_len)
+{
+    /* segment_juncs.cpp:2946-2973 */
+    int pos = -1, mismatch = 3;
+    for (int i = 0; i < contig_len - read_len; ++i) {
+        int t = 0;
+        for (int j = 0; j < read_len; ++j) {
+            if (ctg[i + j] != read[j]) ++t;
+            if (t >= mismatch) break;
+        }
+        if (t < mismatch) { pos = i; mismatch = t; }
+    }
+    return pos;
+}
+
+/* --------------------------------------------- small insertions/deletions */
+
+typedef struct {
+    const orc_params* p;
+    const orc_genome* g;
+    jvec juncs, dels;
+    ivec ins;
+    int64_t n_windows, n_indel_pairs, n_rescue_pairs;
+    uint64_t prio;
+} ctx_t;
+
+static int is_anti(const orc_hit* h) { return (h->flags & ORC_HIT_ANTISENSE) != 0; }
+static int is_end(const orc_hit* h) { return (h->flags & ORC_HIT_END) != 0; }
+
+/* detect_small_deletion, segment_juncs.cpp:2557-2627 */
+static void detect_small_deletion(ctx_t* c, const char* rd, int read_length,
+                                  const orc_hit* lh, const orc_hit* rh)
+{
+    int64_t ref_len;
+    const char* ref = contig(c->g, lh->ref_id, &ref_len);
+    if (!ref) return;
+    if (lh->left < 0) return;
+    if (rh->right < read_length) return;
+    int discrepancy = (rh->right - lh->left) - read_length;
+    /* seqan::infix clamps to the string end; shorter than read_length -> return (:2589) */
+    if ((int64_t)lh->left + read_length > ref_len) return;
+    if ((int64_t)rh->right > ref_len) return;
+    const char* lg = ref + lh->left;                 /* Dna5: N stays N */
+    const char* rg = ref + rh->right - read_length;
+    int min_err = -1;
+    int pos = orc_simple_split(rd, lg, rg, read_length, &min_err);
+    if (pos < 0) return;  /* reference asserts size>0; read_length>=2 always here */
+    int adjustment = 0;
+    if ((int)lh->read_len + (int)rh->read_len >= read_length) adjustment = -1;
+    if (min_err <= (int)lh->edit_dist + (int)rh->edit_dist + adjustment) {
+        orc_junction d;
+        d.ref_id = lh->ref_id;
+        d.left = (uint32_t)(lh->left + pos - 1);
+        d.right = (uint32_t)(lh->left + pos + discrepancy);
+        d.antisense = 0;
+        jpush(&c->dels, d);
+    }
+}
+
+/* detect_small_insertion, segment_juncs.cpp:2470-2543 */
+static void detect_small_insertion(ctx_t* c, const char* rd, int read_length,
+                                   const orc_hit* lh, const orc_hit* rh)
+{
+    int64_t ref_len;
+    const char* ref = contig(c->g, lh->ref_id, &ref_len);
+    if (!ref) return;
+    if (lh->left < 0) return;
+    int discrepancy = read_length - (rh->right - lh->left);
+    int64_t gb = lh->left, ge = rh->right;
+    if (ge > ref_len) ge = ref_len;              /* infix clamps */
+    int glen = (int)(ge - gb);
+    if (glen < 0) glen = 0;
+    if (glen > read_length) return;              /* cannot happen (discrepancy>0); guard */
+    char genomic[512];
+    if (glen > 512) return;
+    for (int i = 0; i < glen; ++i) genomic[i] = n_to_a(ref[gb + i]);   /* DnaString: N->A (:2499) */
+    const char* left_read = rd;                          /* infix(read, 0, glen) */
+    const char* right_read = rd + read_length - glen;    /* infix(read, read_length-glen, read_length) */
+    int min_err = -1;
+    int pos = orc_simple_split(genomic, left_read, right_read, glen, &min_err);
+    if (pos < 0) return;                                 /* :2514-2515 */
+    int adjustment = 0;
+    if ((int)lh->read_len + (int)rh->read_len >= read_length) adjustment = -1;
+    if (min_err <= (int)lh->edit_dist + (int)rh->edit_dist + adjustment &&
+        pos + discrepancy <= glen) {
+        orc_insertion ins;
+        memset(&ins, 0, sizeof ins);
+        ins.ref_id = lh->ref_id;
+        ins.left = (uint32_t)(lh->left + pos - 1);
+        int n = discrepancy < 15 ? discrepancy : 15;
+        memcpy(ins.seq, left_read + pos, (size_t)n);
+        ins.seq[n] = 0;
+        ins.prio = c->prio++;
+        ipush(&c->ins, ins);
+    }
+}
+
+/* find_insertions_and_deletions, segment_juncs.cpp:2807-2942 */
+static void find_indels(ctx_t* c, const orc_batch* b, int r)
+{
+    int nseg = b->nseg;
+    if (nseg < 2) return;                                   /* :2815-2818 */
+    const int64_t* so = b->seg_off + (int64_t)r * nseg;
+    const char* seq = b->bases + b->read_off[r];
+    int seq_len = (int)(b->read_off[r + 1] - b->read_off[r]);
+    int L = c->p->segment_length;
+
+    for (int i = 0; i + 2 < nseg; ++i) {                    /* :2856: i < size-2 */
+        int64_t lb = so[i], le = so[i + 1], rb = so[i + 1], re = so[i + 2];
+        if (lb == le || rb == re) return;                   /* :2869-2870 (return, not continue) */
+
+        /* read.seq.substr(i*L, 2L), :2881 */
+        char full[512], rc[512];
+        int start = i * L;
+        if (start > seq_len) return;  /* std::substr would throw; unreachable for valid input */
+        int plen = seq_len - start < 2 * L ? seq_len - start : 2 * L;
+        if (plen > 512) plen = 512;
+        memcpy(full, seq + start, (size_t)plen);
+        revcomp(full, plen, rc);      /* seqan::reverseComplement on String<char>, :2883 */
+
+        for (int64_t li = lb; li < le; ++li)
+            for (int64_t ri = rb; ri < re; ++ri) {
+                const orc_hit* lh = &b->hits[li];
+                const orc_hit* rh = &b->hits[ri];
+                if (lh->ref_id != rh->ref_id) continue;          /* :2901 */
+                if (is_anti(lh) != is_anti(rh)) continue;        /* :2904 */
+                const char* mod = full;
+                if (is_anti(lh)) { const orc_hit* t = lh; lh = rh; rh = t; mod = rc; }  /* :2914-2920 */
+                int apparent = rh->right - lh->left;
+                int disc = apparent - plen;
+                if (disc > 0 && disc <= c->p->max_deletion_length) {
+                    c->n_indel_pairs++;
+                    detect_small_deletion(c, mod, plen, lh, rh);
+                }
+                if (disc < 0 && disc >= -c->p->max_insertion_length) {
+                    c->n_indel_pairs++;
+                    detect_small_insertion(c, mod, plen, lh, rh);
+                }
+            }
+    }
+}
+
+/* ---------------------------------------------------------------- find_gaps */
+
+#define MAXH 4096
+
+typedef struct { orc_hit* v; int n, cap; } hlist;
+
+static void hl_push(hlist* l, orc_hit h)
+{
+    if (l->n == l->cap) {
+        l->cap = l->cap ? l->cap * 2 : 16;
+        l->v = (orc_hit*)realloc(l->v, (size_t)l->cap * sizeof(orc_hit));
+    }
+    l->v[l->n++] = h;
+}
+
+/* find_gaps, segment_juncs.cpp:3293-3650 */
+static void find_gaps(ctx_t* c, const orc_batch* b, int r)
+{
+    const orc_params* p = c->p;
+    int nseg = b->nseg;
+    if (nseg == 0) return;
+    const int64_t* so = b->seg_off + (int64_t)r * nseg;
+    const char* seq = b->bases + b->read_off[r];
+    int seq_len = (int)(b->read_off[r + 1] - b->read_off[r]);
+    int L = p->segment_length;
+
+    /* local, mutable copy of hits_for_read */
+    hlist* segs = (hlist*)calloc((size_t)nseg, sizeof(hlist));
+    for (int s = 0; s < nseg; ++s)
+        for (int64_t k = so[s]; k < so[s + 1]; ++k) hl_push(&segs[s], b->hits[k]);
+
+    int last_segment = nseg - 1;                       /* :3304-3313 */
+    while (last_segment > 0) {
+        if (segs[last_segment].n) break;
+        --last_segment;
+    }
+    int size = last_segment + 1;                       /* hits_for_read.resize */
+    int first_segment = 0;
+    if (last_segment == first_segment &&
+        (segs[0].n == 0 || is_end(&segs[0].v[0])))     /* :3316-3318 */
+        goto done;
+
+    /* :3320-3348 partner lookup: the mate's full-read hits if present, else the
+     * mate's last-segment hits; both streams are consumed in id order, so this
+     * is an id join -- the batch carries the result as mate_hits. */
+    {
+        int has_partner = 0;
+        const orc_hit* mate = NULL; int n_mate = 0;
+        if (b->mate_off) {
+            n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]);
+            mate = b->mate_hits + b->mate_off[r];
+            has_partner = n_mate > 0;
+        }
+
+        /* :3359-3393 is there an intra-read partner between first and last segment? */
+        int check_partner = 1;
+        if (first_segment != last_segment) {
+            for (int i = 0; i < segs[0].n && check_partner; ++i) {
+                const orc_hit* lh = &segs[0].v[i];
+                for (int j = 0; j < segs[last_segment].n; ++j) {
+                    const orc_hit* rh = &segs[last_segment].v[j];
+                    if (lh->ref_id == rh->ref_id && is_anti(lh) == is_anti(rh)) {
+                        int dist = is_anti(lh) ? lh->left - rh->right : rh->left - lh->right;
+                        if (dist >= p->min_segment_intron && dist < p->max_segment_intron) {
+                            check_partner = 0;
+                            break;
+                        }
+                    }
+                }
+            }
+        }
+
+        if (check_partner && has_partner) {                 /* :3395-3492 mate-anchored rescue */
+            for (int s = first_segment + 1; s < size; ++s) segs[s].n = 0;   /* :3398-3401 */
+            char rcread[1024];
+            int rl = seq_len < 1024 ? seq_len : 1024;
+            revcomp(seq, rl, rcread);
+            /* NB the reference pushes into hits_for_read[last_segment] while
+             * iterating left_segment_hits = hits_for_read[0]; when
+             * last_segment == 0 those are the same vector, but then s == size-1
+             * for every hit below and no window is produced, so the pushes are
+             * unobservable.  We iterate over the original seg-0 count only. */
+            int n_left = segs[0].n;
+            int check_read_len = 15 < L - p->segment_mismatches - 3 ? 15 : L - p->segment_mismatches - 3; /* :3451 */
+            for (int l = 0; l < n_left; ++l) {
+                orc_hit lh = segs[0].v[l];
+                for (int m = 0; m < n_mate; ++m) {
+                    const orc_hit* rh = &mate[m];
+                    if (lh.ref_id != rh->ref_id || is_anti(&lh) == is_anti(rh)) continue;   /* :3414 */
+                    /* :3423 `dist < min && dist >= max` is never true: no filter */
+                    int64_t ref_len;
+                    const char* ref = contig(c->g, rh->ref_id, &ref_len);
+                    if (!ref) continue; /* reference would dereference NULL; unreachable for consistent input */
+                    int part_seq_len = p->inner_dist_std_dev > p->inner_dist_mean ? p->inner_dist_std_dev - p->inner_dist_mean : 0;
+                    int flanking_seq_len = p->inner_dist_mean + p->inner_dist_std_dev;
+                    int64_t left;
+                    if (is_anti(rh)) {                                            /* :3431-3440 */
+                        if (flanking_seq_len <= rh->left) left = rh->left - flanking_seq_len;
+                        else break;
+                    } else {                                                       /* :3441-3450 */
+                        if (part_seq_len <= rh->right) left = rh->right - part_seq_len;
+                        else break;
+                    }
+                    int64_t fe = left + flanking_seq_len + part_seq_len;
+                    if (fe > ref_len) fe = ref_len;                               /* infix clamps */
+                    int flen = (int)(fe - left);
+                    if (flen < 0) flen = 0;
+                    if (check_read_len < 1 || check_read_len > rl) continue;     /* guard: infix would be invalid */
+                    const char* fwd_read = seq + rl - check_read_len;             /* :3452 */
+                    const char* rev_read = rcread;                                /* :3453 */
+                    c->n_rescue_pairs++;
+                    /* Dna5String -> String<char>: N stays 'N' and equals a read 'N' (:2958) */
+                    int fwd_pos = orc_map_read_to_contig(ref + left, flen, fwd_read, check_read_len);
+                    if (fwd_pos >= 0) {                                            /* :3456-3462 */
+                        orc_hit h; memset(&h, 0, sizeof h);
+                        h.ref_id = rh->ref_id; h.left = (int32_t)(left + fwd_pos);
+                        h.right = h.left + check_read_len; h.flags = ORC_HIT_END;
+                        h.read_len = (uint8_t)check_read_len;
+                        hl_push(&segs[last_segment], h);
+                    }
+                    int rev_pos = orc_map_read_to_contig(ref + left, flen, rev_read, check_read_len);
+                    if (rev_pos >= 0) {                                            /* :3464-3472 */
+                        orc_hit h; memset(&h, 0, sizeof h);
+                        h.ref_id = rh->ref_id; h.left = (int32_t)(left + rev_pos);
+                        h.right = h.left + check_read_len; h.flags = ORC_HIT_END | ORC_HIT_ANTISENSE;
+                        h.read_len = (uint8_t)check_read_len;
+                        hl_push(&segs[last_segment], h);
+                    }
+                }
+            }
+        }
+    }
+
+    /* :3499-3506 multihit cap (bowtie2 only) */
+    if (p->bowtie2)
+        for (int s = 0; s < size; ++s)
+            if (segs[s].n > p->max_seg_multihits) goto done;
+
+    /* :3508-3617 */
+    for (int s = 0; s < size; ++s) {
+        for (int h = 0; h < segs[s].n; ++h) {
+            int found_right_seg_partner = (s == size - 1);
+            const orc_hit* bh = &segs[s].v[h];
+            const orc_hit* drs[MAXH]; int n_drs = 0;
+            const orc_hit* rrs[MAXH]; int n_rrs = 0;
+
+            if (s < size - 1) {
+                for (int k = 0; k < segs[s + 1].n; ++k) {
+                    const orc_hit* rh = &segs[s + 1].v[k];
+                    if (is_anti(bh) != is_anti(rh) || bh->ref_id != rh->ref_id) continue;
+                    if ((is_anti(bh) && rh->right == bh->left) ||
+                        (!is_anti(bh) && bh->right == rh->left)) {
+                        found_right_seg_partner = 1;
+                        break;
+                    }
+                    int dist = is_anti(bh) ? bh->left - rh->right : rh->left - bh->right;
+                    if (dist >= p->min_segment_intron && dist < p->max_segment_intron && n_drs < MAXH)
+                        drs[n_drs++] = rh;
+                }
+            }
+            if (!found_right_seg_partner && s < size - 2) {
+                for (int k = 0; k < segs[s + 2].n; ++k) {
+                    const orc_hit* rrh = &segs[s + 2].v[k];
+                    if (is_anti(bh) != is_anti(rrh) || bh->ref_id != rrh->ref_id) continue;
+                    int dist = is_anti(bh) ? bh->left - rrh->right : rrh->left - bh->right;
+                    if (dist >= p->min_segment_intron + L && dist < p->max_segment_intron + L && n_rrs < MAXH)
+                        rrs[n_rrs++] = rrh;
+                }
+            }
+            if (!found_right_seg_partner && (n_drs > 0 || n_rrs > 0)) {
+                const int look_bp = 8;
+                const orc_hit** d = n_rrs > 0 ? rrs : drs;
+                int nd = n_rrs > 0 ? n_rrs : n_drs;
+                for (int k = 0; k < nd; ++k) {
+                    /* seq.substr((s+1)*L - 8, 16 [+L]) :3583-3586 */
+                    int start = (s + 1) * L - look_bp;
+                    int want = n_rrs <= 0 ? look_bp * 2 : L + look_bp * 2;
+                    if (start < 0 || start > seq_len) continue;   /* std::substr would throw */
+                    int slen = seq_len - start < want ? seq_len - start : want;
+                    char support[256], tmp[256];
+                    if (slen > 255) slen = 255;
+                    memcpy(support, seq + start, (size_t)slen);
+                    int32_t wl, wr;
+                    if (!is_anti(bh)) {                          /* :3589-3594 */
+                        wl = bh->right - look_bp; if (wl < 0) wl = 0;
+                        wr = d[k]->left + look_bp;
+                    } else {                                      /* :3596-3604 */
+                        revcomp(support, slen, tmp);
+                        memcpy(support, tmp, (size_t)slen);
+                        wl = d[k]->right - look_bp;
+                        wr = bh->left + look_bp;
+                    }
+                    c->n_windows++;
+                    orc_junction tmpj[3 * 128];
+                    int n = orc_window_scan(p, c->g, bh->ref_id, wl, wr, is_anti(bh), support, slen, tmpj, 3 * 128);
+                    for (int q = 0; q < n; ++q) jpush(&c->juncs, tmpj[q]);
+                }
+            }
+        }
+    }
+
+done:
+    for (int s = 0; s < nseg; ++s) free(segs[s].v);
+    free(segs);
+}
+
+/* ------------------------------------------------------------------ batch */
+
+int orc_segjuncs_batch(const orc_params* p, const orc_genome* g, const orc_batch* b, orc_events* out)
+{
+    ctx_t c;
+    memset(&c, 0, sizeof c);
+    c.p = p; c.g = g;
+    memset(out, 0, sizeof *out);
+    for (int r = 0; r < b->n_reads; ++r) {
+        /* process_next_hit_group :4094-4118 (and the orphan branch :3996-4011):
+         * indels first, then gaps, on the same hits_for_read */
+        find_indels(&c, b, r);
+        find_gaps(&c, b, r);
+    }
+    out->n_juncs = junique(c.juncs.v, c.juncs.n);       out->juncs = c.juncs.v;
+    out->n_deletions = junique(c.dels.v, c.dels.n);     out->deletions = c.dels.v;
+    out->n_insertions = iunique(c.ins.v, c.ins.n);      out->insertions = c.ins.v;
+    out->n_windows = c.n_windows;
+    out->n_indel_pairs = c.n_indel_pairs;
+    out->n_rescue_pairs = c.n_rescue_pairs;
+    return 0;
+}
+
+void orc_events_free(orc_events* e)
+{
+    free(e->juncs); free(e->deletions); free(e->insertions);
+    memset(e, 0, sizeof *e);
+}

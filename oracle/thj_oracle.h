@@ -1,0 +1,126 @@
+/*
+ * thj_oracle.h -- CPU oracle for the TopHat splice-junction hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (tophat_amd/, the
+ * C-ABI library, the drop-in binaries) may include, link or call this code.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and only as the checker.
+ *
+ * It is an independent plain-C restatement of the reference algorithm
+ * (DaehwanKimLab/tophat v2.1.2, src/segment_juncs.cpp and
+ * src/long_spanning_reads.cpp); every function cites the reference lines it
+ * follows.  It deliberately uses a different data representation from the
+ * device path (ASCII genome and reads, byte-at-a-time loops) so that agreement
+ * between the two is evidence, not tautology.
+ *
+ * PARITY PINNING STATUS: see oracle/README.md.  The reference's own tests hold
+ * no fixture for this boundary and the reference cannot
+ * be built in this image without stand-ins for Boost / autotools output, so
+ * formally: "parity unpinned".  oracle/README.md describes the informal
+ * differential checks that were run against a survey-stage scratch build.
+ */
+#ifndef THJ_ORACLE_H
+#define THJ_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One segment (or mate) alignment, the fields of BowtieHit (bwt_map.h:36-536)
+ * that the hot path reads.  `right` is BowtieHit::right() (bwt_map.h:213-243)
+ * and `read_len` BowtieHit::read_len() (bwt_map.h:141-163), both evaluated by
+ * the host parser from the CIGAR. Same 16-byte layout as thj_hit in include/thj.h. */
+typedef struct {
+    uint32_t ref_id;     /* 1-based, @SQ order (bwt_map.h:608-632) */
+    int32_t  left;
+    int32_t  right;
+    uint8_t  flags;      /* bit0 antisense_align, bit1 end() */
+    uint8_t  edit_dist;
+    uint8_t  mismatches;
+    uint8_t  read_len;
+} orc_hit;
+
+#define ORC_HIT_ANTISENSE 1u
+#define ORC_HIT_END       2u
+
+typedef struct {
+    int32_t segment_length;        /* common.cpp:121 */
+    int32_t segment_mismatches;    /* common.cpp:122 */
+    int32_t min_segment_intron;    /* common.cpp:115 */
+    int32_t max_segment_intron;    /* common.cpp:116 */
+    int32_t max_insertion_length;  /* common.cpp:98 */
+    int32_t max_deletion_length;   /* common.cpp:99 */
+    int32_t max_seg_multihits;     /* common.cpp:135 */
+    int32_t inner_dist_mean;       /* common.cpp:101 */
+    int32_t inner_dist_std_dev;    /* common.cpp:102 */
+    int32_t library_type;          /* common.h:155-167: 0 none,1 fr-unstranded,2 fr-firststrand,3 fr-secondstrand,... */
+    int32_t bowtie2;               /* common.cpp:79 */
+    int32_t read_side;             /* segments.h:13-18: 1 = READ_LEFT, 2 = READ_RIGHT */
+} orc_params;
+
+/* Genome as ASCII: seq[i] is contig with ref_id i+1 (upper-case ACGT, anything
+ * else already folded to 'N' as SeqAn's char->Dna5 conversion does), or NULL
+ * when the FASTA has no record for that @SQ entry (segment_juncs.cpp:2105-2108). */
+typedef struct {
+    int32_t        n_contigs;
+    const char**   seq;
+    const int64_t* len;
+} orc_genome;
+
+/* A batch of reads of one side with their per-segment hit lists, i.e. the
+ * sequence of hits_for_read vectors that look_for_hit_group /
+ * process_next_hit_group (segment_juncs.cpp:3823-4123) hand to the finders, in
+ * visiting (= increasing read id) order. */
+typedef struct {
+    int32_t         n_reads;
+    int32_t         nseg;
+    const uint32_t* read_id;       /* [n_reads] */
+    const int64_t*  read_off;      /* [n_reads+1] into bases */
+    const char*     bases;         /* ASCII read sequences, as ReadStream returns them */
+    const int64_t*  seg_off;       /* [n_reads*nseg+1] CSR into hits, index r*nseg+s */
+    const orc_hit*  hits;
+    const int64_t*  mate_off;      /* [n_reads+1] CSR into mate_hits (may be NULL = no mates) */
+    const orc_hit*  mate_hits;     /* partner_hit_group of find_gaps (segment_juncs.cpp:3321-3348) */
+} orc_batch;
+
+typedef struct { uint32_t ref_id, left, right, antisense; } orc_junction;   /* junctions.h:27-57 */
+typedef struct { uint32_t ref_id, left; char seq[16]; uint64_t prio; } orc_insertion; /* insertions.h:31-67 */
+
+typedef struct {
+    orc_junction*  juncs;       int64_t n_juncs;       /* sorted unique (junctions.h:39-57 order) */
+    orc_junction*  deletions;   int64_t n_deletions;   /* sorted unique, antisense always 0 */
+    orc_insertion* insertions;  int64_t n_insertions;  /* sorted by (ref,left,len); first inserted wins */
+    int64_t n_windows;          /* RefSeg windows scanned (statistic) */
+    int64_t n_indel_pairs;      /* hit pairs sent to detect_small_* (statistic) */
+    int64_t n_rescue_pairs;     /* (hit, mate-hit) pairs scanned by map_read_to_contig (statistic) */
+} orc_events;
+
+/* Runs find_insertions_and_deletions + find_gaps over every read of the batch
+ * (the per-read body of process_next_hit_group, segment_juncs.cpp:4094-4118,
+ * fusion search off).  Returns 0, or <0 on allocation failure. */
+int  orc_segjuncs_batch(const orc_params* p, const orc_genome* g, const orc_batch* b, orc_events* out);
+void orc_events_free(orc_events* e);
+
+/* Primitive entry points, exposed so kernels can be checked one at a time. */
+
+/* juncs_from_ref_segs<RecordSegmentJuncs>, POINT_DIR_BOTH, one window, all three
+ * motif pairs (segment_juncs.cpp:2052-2377, :3618-3649).  Appends to out[],
+ * returns the number appended (<= cap). */
+int orc_window_scan(const orc_params* p, const orc_genome* g, uint32_t ref_id,
+                    int32_t seg_left, int32_t seg_right, int antisense,
+                    const char* support, int support_len,
+                    orc_junction* out, int cap);
+
+/* simpleSplitAlignment (segment_juncs.cpp:2390-2456): returns the FIRST best
+ * insert position (or -1 when len<2) and the mismatch count through *min_err. */
+int orc_simple_split(const char* shorter, const char* left_ref, const char* right_ref,
+                     int len, int* min_err);
+
+/* map_read_to_contig (segment_juncs.cpp:2946-2973). */
+int orc_map_read_to_contig(const char* contig, int contig_len, const char* read, int read_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""ctypes binding of the CPU oracle (oracle/liborc.so).  Test infrastructure only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from tophat_amd.batch import Events, JUNC_DTYPE, SegBatch
+from tophat_amd.params import Params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_DIR = os.path.join(ROOT, "oracle")
+
+
+def _lib():
+    so = os.path.join(ORC_DIR, "liborc.so")
+    srcs = [os.path.join(ORC_DIR, f) for f in os.listdir(ORC_DIR) if f.endswith((".c", ".h"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", ORC_DIR, "-s"])
+    return C.CDLL(so)
+
+
+class OrcParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "segment_length", "segment_mismatches", "min_segment_intron", "max_segment_intron",
+        "max_insertion_length", "max_deletion_length", "max_seg_multihits", "inner_dist_mean",
+        "inner_dist_std_dev", "library_type", "bowtie2", "read_side")]
+
+
+class OrcGenome(C.Structure):
+    _fields_ = [("n_contigs", C.c_int32), ("seq", C.POINTER(C.c_char_p)), ("len", C.POINTER(C.c_int64))]
+
+
+class OrcBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("nseg", C.c_int32), ("read_id", C.c_void_p), ("read_off", C.c_void_p),
+                ("bases", C.c_void_p), ("seg_off", C.c_void_p), ("hits", C.c_void_p),
+                ("mate_off", C.c_void_p), ("mate_hits", C.c_void_p)]
+
+
+class OrcIns(C.Structure):
+    _fields_ = [("ref_id", C.c_uint32), ("left", C.c_uint32), ("seq", C.c_char * 16), ("prio", C.c_uint64)]
+
+
+class OrcEvents(C.Structure):
+    _fields_ = [("juncs", C.c_void_p), ("n_juncs", C.c_int64), ("deletions", C.c_void_p), ("n_deletions", C.c_int64),
+                ("insertions", C.POINTER(OrcIns)), ("n_insertions", C.c_int64),
+                ("n_windows", C.c_int64), ("n_indel_pairs", C.c_int64), ("n_rescue_pairs", C.c_int64)]
+
+
+def orc_params(p: Params) -> OrcParams:
+    o = OrcParams()
+    for n, _ in OrcParams._fields_:
+        setattr(o, n, int(getattr(p, n)))
+    return o
+
+
+class Genome:
+    """ASCII genome for the oracle.  seqs[i] is ref_id i+1; None = no FASTA record."""
+
+    def __init__(self, seqs: Sequence[Optional[str]]):
+        self.seqs = list(seqs)
+        self._bufs = [None if s is None else s.encode() for s in self.seqs]
+        n = len(self.seqs)
+        self._arr = (C.c_char_p * n)(*self._bufs)
+        self._len = (C.c_int64 * n)(*[0 if s is None else len(s) for s in self.seqs])
+        self.c = OrcGenome(n, C.cast(self._arr, C.POINTER(C.c_char_p)), C.cast(self._len, C.POINTER(C.c_int64)))
+
+
+def fold_genome_char(s: str) -> str:
+    """char -> Dna5 as SeqAn does when loading the FASTA: acgt upper-cased, all else N."""
+    return "".join(c if c in "ACGT" else "N" for c in s.upper())
+
+
+def segjuncs(p: Params, g: Genome, b: SegBatch) -> Events:
+    lib = _lib()
+    ob = OrcBatch()
+    ob.n_reads, ob.nseg = b.n_reads, b.nseg
+    keep = [np.ascontiguousarray(b.read_id, dtype=np.uint32), np.ascontiguousarray(b.read_off, dtype=np.int64),
+            np.ascontiguousarray(b.bases, dtype=np.uint8), np.ascontiguousarray(b.seg_off, dtype=np.int64),
+            np.ascontiguousarray(b.hits)]
+    ob.read_id, ob.read_off, ob.bases, ob.seg_off, ob.hits = [a.ctypes.data for a in keep]
+    if b.mate_off is not None:
+        keep += [np.ascontiguousarray(b.mate_off, dtype=np.int64), np.ascontiguousarray(b.mate_hits)]
+        ob.mate_off, ob.mate_hits = keep[-2].ctypes.data, keep[-1].ctypes.data
+    ev = OrcEvents()
+    op = orc_params(p)
+    rc = lib.orc_segjuncs_batch(C.byref(op), C.byref(g.c), C.byref(ob), C.byref(ev))
+    assert rc == 0
+
+    def jarr(ptr, n):
+        if n == 0:
+            return np.zeros(0, dtype=JUNC_DTYPE)
+        buf = (C.c_char * (n * 16)).from_address(ptr)
+        return np.frombuffer(buf, dtype=JUNC_DTYPE).copy()
+
+    out = Events(jarr(ev.juncs, ev.n_juncs), jarr(ev.deletions, ev.n_deletions),
+                 [(int(ev.insertions[i].ref_id), int(ev.insertions[i].left), ev.insertions[i].seq.decode())
+                  for i in range(ev.n_insertions)],
+                 {"windows": int(ev.n_windows), "indel_pairs": int(ev.n_indel_pairs),
+                  "rescue_pairs": int(ev.n_rescue_pairs)})
+    lib.orc_events_free(C.byref(ev))
+    return out

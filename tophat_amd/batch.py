@@ -1,0 +1,198 @@
+"""Host-side batch model for the segment_juncs / long_spanning_reads hot path.
+
+A `SegBatch` is the sequence of `hits_for_read` vectors that the reference's
+stream synchroniser hands to its per-read finders, flattened to SoA arrays:
+
+* reference: look_for_hit_group / process_next_hit_group
+  (segment_juncs.cpp:3823-4123) walk `nseg` id-sorted hit streams from the last
+  segment backwards.  Tracing the recursion (including the EOF call with
+  insert_id 0, whose observation_order is VMAXINT32, bwt_map.h:556-561) shows
+  that every read id that has a hit in ANY segment stream is visited exactly
+  once, in increasing id order, with the hits of each segment it has;
+  find_insertions_and_deletions + find_gaps run for a visited read unless its
+  highest mapped segment is segment 0 (`curr_file > 0`, :3994-4012), and the
+  partner streams consumed by find_gaps (:3321-3348) reduce to an id join.
+  `build_seg_batch` implements exactly that visiting set.
+
+Layouts (all little-endian, C-contiguous):
+  HIT_DTYPE   16 B/hit  {ref_id u32, left i32, right i32, flags u8, edit_dist u8,
+                         mismatches u8, read_len u8}   == thj_hit (include/thj.h)
+  seg_off     u32[n_reads*nseg+1]  CSR over hits, index r*nseg+s
+  mate_off    u32[n_reads+1]       CSR over mate_hits
+  read_off    i64[n_reads+1]       into `bases` (ASCII, as ReadStream returns it)
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+HIT_DTYPE = np.dtype([
+    ("ref_id", "<u4"), ("left", "<i4"), ("right", "<i4"),
+    ("flags", "u1"), ("edit_dist", "u1"), ("mismatches", "u1"), ("read_len", "u1"),
+])
+assert HIT_DTYPE.itemsize == 16
+
+HIT_ANTISENSE = 1
+HIT_END = 2
+
+
+@dataclass
+class SegBatch:
+    nseg: int
+    read_id: np.ndarray            # u32[n]
+    read_off: np.ndarray           # i64[n+1]
+    bases: np.ndarray              # u8[...]
+    seg_off: np.ndarray            # u32[n*nseg+1]
+    hits: np.ndarray               # HIT_DTYPE[...]
+    mate_off: Optional[np.ndarray] = None   # u32[n+1]
+    mate_hits: Optional[np.ndarray] = None  # HIT_DTYPE[...]
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.read_id.shape[0])
+
+    def read_seq(self, r: int) -> str:
+        return self.bases[self.read_off[r]:self.read_off[r + 1]].tobytes().decode()
+
+    def seg_hits(self, r: int, s: int) -> np.ndarray:
+        k = r * self.nseg + s
+        return self.hits[self.seg_off[k]:self.seg_off[k + 1]]
+
+
+# One parsed alignment record of a segment / read map, before grouping.
+# (read_id, ref_id, left, right, antisense, end, mismatches, edit_dist, read_len)
+HitRec = Tuple[int, int, int, int, bool, bool, int, int, int]
+
+
+def hit_tuple_to_struct(h: HitRec) -> tuple:
+    _, ref_id, left, right, anti, end, mm, ed, rl = h
+    return (ref_id, left, right, (HIT_ANTISENSE if anti else 0) | (HIT_END if end else 0),
+            ed & 0xFF, mm & 0xFF, min(rl, 255))
+
+
+def group_by_id(recs: Iterable[HitRec]) -> Dict[int, List[HitRec]]:
+    """HitStream::next_read_hits (bwt_map.h:1155-1220): consecutive records with
+    equal insert_id form one group.  Files are id-sorted, so a dict keyed by id
+    preserving file order within the id is equivalent."""
+    out: Dict[int, List[HitRec]] = {}
+    for h in recs:
+        out.setdefault(h[0], []).append(h)
+    return out
+
+
+def build_seg_batch(seg_recs: Sequence[Iterable[HitRec]],
+                    reads: Dict[int, str],
+                    mate_map_recs: Optional[Iterable[HitRec]] = None,
+                    mate_lastseg_recs: Optional[Iterable[HitRec]] = None) -> SegBatch:
+    """seg_recs[s] = records of segment-s map in file order; reads = id -> sequence.
+
+    mate_map_recs / mate_lastseg_recs are the mate side's full-read map and
+    last-segment map (the `partner_hit_stream` / `seg_partner_hit_stream` of
+    find_gaps): the mate group is the full-read group when one exists for the id,
+    otherwise the last-segment group (segment_juncs.cpp:3324-3348)."""
+    nseg = len(seg_recs)
+    groups = [group_by_id(r) for r in seg_recs]
+    ids = sorted(set().union(*[g.keys() for g in groups])) if groups else []
+    mate_full = group_by_id(mate_map_recs) if mate_map_recs is not None else {}
+    mate_last = group_by_id(mate_lastseg_recs) if mate_lastseg_recs is not None else {}
+    have_mates = mate_map_recs is not None or mate_lastseg_recs is not None
+
+    read_id: List[int] = []
+    read_off = [0]
+    bases = bytearray()
+    seg_off = [0]
+    hits: List[tuple] = []
+    mate_off = [0]
+    mate_hits: List[tuple] = []
+    for rid in ids:
+        if rid == 0:
+            continue  # insert_id 0 is "no group" (bwt_map.h:1174-1176)
+        top = max(s for s in range(nseg) if rid in groups[s])
+        if top == 0:
+            continue  # only find_fusions runs for these (segment_juncs.cpp:3994-4028)
+        if rid not in reads:
+            raise KeyError("could not get read# %d from stream" % rid)  # :3352-3356
+        read_id.append(rid)
+        seq = reads[rid]
+        bases += seq.encode()
+        read_off.append(len(bases))
+        for s in range(nseg):
+            for h in groups[s].get(rid, ()):
+                hits.append(hit_tuple_to_struct(h))
+            seg_off.append(len(hits))
+        if have_mates:
+            mg = mate_full.get(rid) or mate_last.get(rid) or ()
+            for h in mg:
+                mate_hits.append(hit_tuple_to_struct(h))
+            mate_off.append(len(mate_hits))
+    b = SegBatch(
+        nseg=nseg,
+        read_id=np.asarray(read_id, dtype=np.uint32),
+        read_off=np.asarray(read_off, dtype=np.int64),
+        bases=np.frombuffer(bytes(bases), dtype=np.uint8).copy(),
+        seg_off=np.asarray(seg_off, dtype=np.uint32),
+        hits=np.array(hits, dtype=HIT_DTYPE) if hits else np.zeros(0, dtype=HIT_DTYPE),
+    )
+    if have_mates:
+        b.mate_off = np.asarray(mate_off, dtype=np.uint32)
+        b.mate_hits = np.array(mate_hits, dtype=HIT_DTYPE) if mate_hits else np.zeros(0, dtype=HIT_DTYPE)
+    return b
+
+
+# ----------------------------------------------------------------- events
+
+JUNC_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<u4"), ("right", "<u4"), ("antisense", "<u4")])
+
+
+@dataclass
+class Events:
+    """Sorted-unique outputs of one segment_juncs pass (one side, one batch)."""
+    juncs: np.ndarray                       # JUNC_DTYPE, junctions.h:39-57 order
+    deletions: np.ndarray                   # JUNC_DTYPE (antisense always 0)
+    insertions: List[Tuple[int, int, str]] = field(default_factory=list)  # (ref_id, left, seq)
+    stats: Dict[str, int] = field(default_factory=dict)
+
+
+def merge_events(a: Events, b: Events) -> Events:
+    """Merge in the order the reference inserts into its sets: `a` first.
+    Junction/deletion = set union (segment_juncs.cpp:4911-4916); Insertion's
+    ordering ignores sequence content (insertions.h:52-67) so the earlier one
+    of equal (ref,left,len) survives."""
+    def u(x, y):
+        if len(x) == 0:
+            return y.copy()
+        if len(y) == 0:
+            return x.copy()
+        z = np.concatenate([x, y])
+        z = np.unique(z)
+        order = np.lexsort((z["antisense"], z["right"], z["left"], z["ref_id"]))
+        return z[order]
+    seen = {}
+    for ins in list(a.insertions) + list(b.insertions):
+        k = (ins[0], ins[1], len(ins[2]))
+        if k not in seen:
+            seen[k] = ins
+    ins = [seen[k] for k in sorted(seen)]
+    st = dict(a.stats)
+    for k, v in b.stats.items():
+        st[k] = st.get(k, 0) + v
+    return Events(u(a.juncs, b.juncs), u(a.deletions, b.deletions), ins, st)
+
+
+def write_segment_files(ev: Events, ref_names: Sequence[str],
+                        juncs_path: str, ins_path: str, del_path: str, fus_path: Optional[str] = None) -> None:
+    """The four text outputs, formats of segment_juncs.cpp:5035-5095."""
+    with open(juncs_path, "w") as f:
+        for j in ev.juncs:
+            f.write("%s\t%d\t%d\t%c\n" % (ref_names[j["ref_id"] - 1], np.int32(j["left"]), np.int32(j["right"]),
+                                          "-" if j["antisense"] else "+"))
+    with open(del_path, "w") as f:
+        for j in ev.deletions:
+            f.write("%s\t%d\t%d\n" % (ref_names[j["ref_id"] - 1], np.int32(j["left"]) + 1, np.int32(j["right"])))
+    with open(ins_path, "w") as f:
+        for (ref, left, seq) in ev.insertions:
+            f.write("%s\t%d\t%d\t%s\n" % (ref_names[ref - 1], left, left, seq))
+    if fus_path:
+        open(fus_path, "w").close()

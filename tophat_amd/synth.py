@@ -1,0 +1,343 @@
+"""Seeded synthetic workloads for the junction-discovery hot path.
+
+Two generators:
+
+* `make_case` (pure Python, small): genome with planted GT-AG / GC-AG / AT-AC
+  introns on both strands and N runs, single/paired reads that span 0-2
+  junctions or carry a small indel, and *directly synthesised* id-sorted segment
+  maps (bowtie is not in this image): a segment is "mapped" where the truth puts
+  it when it has <= `segment_mismatches` mismatches against the contiguous
+  genome there, including segments that overhang a junction by a few bases.
+  Used by the tests, the golden fixtures and the differential checks.
+
+* `make_device_workload` (torch, any device): the BASELINE.json config shapes at
+  scale (millions of reads) built with tensor ops so bench.py can synthesise the
+  batch directly in HBM.  See bench.py.
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+from .batch import HitRec
+from .samtext import md_nm
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def revcomp(s: str) -> str:
+    return "".join(COMP.get(c, "N") for c in reversed(s))
+
+
+@dataclass
+class Gene:
+    ref: int                 # 0-based contig index
+    exons: List[Tuple[int, int]]   # half-open genome intervals, increasing
+    strand: str              # '+' or '-': strand of the transcript (motif orientation)
+
+
+@dataclass
+class SynthCase:
+    names: List[str]
+    seqs: List[str]
+    genes: List[Gene]
+    read_len: int
+    seg_len: int
+    reads: Dict[str, Dict[int, str]] = field(default_factory=dict)          # side -> id -> seq
+    quals: Dict[str, Dict[int, str]] = field(default_factory=dict)
+    seg_sam: Dict[str, List[List[str]]] = field(default_factory=dict)        # side -> [seg] -> SAM lines
+    seg_recs: Dict[str, List[List[HitRec]]] = field(default_factory=dict)    # side -> [seg] -> HitRec
+    full_sam: Dict[str, List[str]] = field(default_factory=dict)             # side -> full-read map SAM lines
+    full_recs: Dict[str, List[HitRec]] = field(default_factory=dict)
+    truth_juncs: set = field(default_factory=set)                            # (ref_id, left, right, strand)
+
+    @property
+    def nseg(self) -> int:
+        return max(1, self.read_len // self.seg_len)
+
+
+MOTIFS = [("GT", "AG")] * 18 + [("GC", "AG")] * 1 + [("AT", "AC")] * 1
+
+
+def _plant(seq: List[str], start: int, end: int, strand: str, rng: random.Random) -> None:
+    """Make [start,end) look like an intron of `strand`."""
+    d, a = rng.choice(MOTIFS)
+    if strand == "+":
+        seq[start:start + 2] = list(d)
+        seq[end - 2:end] = list(a)
+    else:
+        seq[start:start + 2] = list(revcomp(a))
+        seq[end - 2:end] = list(revcomp(d))
+
+
+def make_genome(rng: random.Random, contig_lens: Sequence[int], n_genes: int,
+                intron_range=(60, 3000), exon_range=(30, 400), n_runs: int = 2):
+    names = ["chr%s" % (i + 1) for i in range(len(contig_lens))]
+    seqs = [[rng.choice("ACGT") for _ in range(n)] for n in contig_lens]
+    genes: List[Gene] = []
+    for ci, n in enumerate(contig_lens):
+        pos = 300
+        while pos < n - 8000 and len([g for g in genes if g.ref == ci]) < n_genes:
+            strand = rng.choice("+-")
+            nex = rng.randint(2, 5)
+            exons = []
+            p = pos
+            for e in range(nex):
+                el = rng.randint(*exon_range) if 0 < e < nex - 1 else rng.randint(150, 500)
+                exons.append((p, p + el))
+                p += el
+                if e < nex - 1:
+                    il = int(rng.uniform(intron_range[0] ** 0.5, intron_range[1] ** 0.5) ** 2)
+                    _plant(seqs[ci], p, p + il, strand, rng)
+                    p += il
+            genes.append(Gene(ci, exons, strand))
+            pos = p + rng.randint(200, 1500)
+        for _ in range(n_runs):
+            s = rng.randint(0, max(0, n - 200))
+            ln = rng.randint(5, 60)
+            seqs[ci][s:s + ln] = ["N"] * ln
+    return names, ["".join(s) for s in seqs], genes
+
+
+def _mutate(rng: random.Random, s: str, rate: float) -> str:
+    out = list(s)
+    for i in range(len(out)):
+        if rng.random() < rate:
+            out[i] = rng.choice([c for c in "ACGT" if c != out[i]])
+    return "".join(out)
+
+
+def _tx_to_genome(exons, t):
+    """transcript offset -> genome coordinate"""
+    for (a, b) in exons:
+        if t < b - a:
+            return a + t
+        t -= b - a
+    return exons[-1][1] + t
+
+
+def _place_piece(gseq: str, exons, t0: int, ln: int, piece: str, max_mm: int, overhang: int):
+    """Try to place transcript interval [t0,t0+ln) contiguously on the genome
+    the way a short-read mapper would: wholly inside one exon, or overhanging a
+    junction by <= `overhang` bases at either end.  Returns (pos, nm) or None."""
+    cum = 0
+    for (a, b) in exons:
+        el = b - a
+        if t0 >= cum and t0 + ln <= cum + el:
+            pos = a + (t0 - cum)
+            break
+        # overhang at the right end of this exon
+        if t0 >= cum and t0 < cum + el and t0 + ln - (cum + el) <= overhang:
+            pos = a + (t0 - cum)
+            break
+        # overhang at the left end of this exon
+        if t0 < cum and cum - t0 <= overhang and t0 + ln <= cum + el and t0 + ln > cum:
+            pos = a - (cum - t0)
+            break
+        cum += el
+    else:
+        return None
+    if pos < 0 or pos + ln > len(gseq):
+        return None
+    ref = gseq[pos:pos + ln]
+    nm = sum(1 for r, q in zip(ref, piece) if r != q)
+    if nm > max_mm:
+        return None
+    return pos, nm
+
+
+def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int = 300,
+              read_len: int = 100, seg_len: int = 25, paired: bool = False,
+              err: float = 0.01, indel_frac: float = 0.08, n_frac: float = 0.02,
+              genes_per_contig: int = 12, intron_range=(60, 3000), inner_mean: int = 50,
+              inner_sd: int = 20, repeat_frac: float = 0.0, drop_seg_frac: float = 0.03,
+              overhang: int = 3) -> SynthCase:
+    rng = random.Random(seed)
+    names, seqs, genes = make_genome(rng, contig_lens, genes_per_contig, intron_range)
+    # optional planted repeats -> multihits
+    repeats: List[Tuple[int, int, int]] = []
+    if repeat_frac > 0:
+        seqs_l = [list(s) for s in seqs]
+        for _ in range(max(1, int(len(genes) * repeat_frac))):
+            g = rng.choice(genes)
+            a, b = g.exons[0]
+            unit = seqs[g.ref][a + 20:a + 20 + 60]
+            for _k in range(rng.randint(1, 3)):
+                ci = rng.randrange(len(seqs))
+                p = rng.randint(0, len(seqs[ci]) - 100)
+                if any(ex[0] - 100 < p < ex[1] + 100 for gg in genes if gg.ref == ci for ex in gg.exons):
+                    continue
+                seqs_l[ci][p:p + 60] = list(unit)
+                repeats.append((g.ref, a + 20, 60))
+                repeats.append((ci, p, 60))
+        seqs = ["".join(s) for s in seqs_l]
+    case = SynthCase(names, seqs, genes, read_len, seg_len)
+    nseg = case.nseg
+    for g in genes:
+        for (e0, e1) in zip(g.exons[:-1], g.exons[1:]):
+            case.truth_juncs.add((g.ref + 1, e0[1] - 1, e1[0], g.strand))
+
+    sides = ["left", "right"] if paired else ["left"]
+    for sd in sides:
+        case.reads[sd] = {}
+        case.quals[sd] = {}
+        case.seg_sam[sd] = [[] for _ in range(nseg)]
+        case.seg_recs[sd] = [[] for _ in range(nseg)]
+        case.full_sam[sd] = []
+        case.full_recs[sd] = []
+
+    def emit(sd: str, rid: int, frag_exons, t0: int, anti: bool, gref: int, with_indel: bool):
+        """fragment = transcript interval [t0, t0+read_len) of the exon chain."""
+        gseq = seqs[gref]
+        tx = "".join(gseq[a:b] for (a, b) in frag_exons)
+        F = tx[t0:t0 + read_len]
+        if len(F) < read_len:
+            return False
+        indel = None
+        if with_indel:
+            kb = rng.randint(1, max(1, nseg - 1))
+            p = max(3, min(read_len - 5, kb * seg_len + rng.randint(-3, 3)))
+            if rng.random() < 0.5:
+                k = rng.randint(1, 3)      # insertion in the read
+                F = (F[:p] + "".join(rng.choice("ACGT") for _ in range(k)) + F[p:])[:read_len]
+                indel = ("I", p, k)
+            else:
+                k = rng.randint(1, 3)      # deletion from the read
+                ext = tx[t0 + read_len:t0 + read_len + k]
+                if len(ext) == k:
+                    F = F[:p] + F[p + k:] + ext
+                    indel = ("D", p, k)
+        F = _mutate(rng, F, err)
+        if rng.random() < n_frac:
+            i = rng.randrange(read_len)
+            F = F[:i] + "N" + F[i + 1:]
+        seq = revcomp(F) if anti else F
+        case.reads[sd][rid] = seq
+        case.quals[sd][rid] = "I" * read_len
+        # segment maps
+        for k in range(nseg):
+            s0 = k * seg_len
+            s1 = read_len if k == nseg - 1 else (k + 1) * seg_len
+            if rng.random() < drop_seg_frac:
+                continue
+            if anti:
+                f0, f1 = read_len - s1, read_len - s0
+            else:
+                f0, f1 = s0, s1
+            piece = F[f0:f1]
+            # transcript offset of this piece, accounting for the indel; a segment
+            # that overlaps the indel by a couple of bases can still map (with
+            # mismatches) anchored on either side of it
+            offs = [f0]
+            if indel:
+                kind, p, kk = indel
+                sh = -kk if kind == "I" else kk
+                if f0 >= p + (kk if kind == "I" else 0):
+                    offs = [f0 + sh]
+                elif f1 > p:
+                    offs = [f0, f0 + sh]
+            placed = None
+            for off in offs:
+                cand = _place_piece(gseq, frag_exons, t0 + off, f1 - f0, piece, 2, overhang)
+                if cand is not None and (placed is None or cand[1] < placed[1]):
+                    placed = cand
+            if placed is None:
+                continue
+            pos, nm = placed
+            places = [(gref, pos, nm)]
+            for (rc_, rp, rl_) in repeats:   # multihits through planted repeats
+                for (oc, op, ol) in repeats:
+                    if (oc, op) != (rc_, rp) and rc_ == gref and rp <= pos and pos + (f1 - f0) <= rp + rl_ and ol == rl_:
+                        q = op + (pos - rp)
+                        ref2 = seqs[oc][q:q + (f1 - f0)]
+                        nm2 = sum(1 for r_, q_ in zip(ref2, piece) if r_ != q_)
+                        if len(ref2) == f1 - f0 and nm2 <= 2 and (oc, q, nm2) not in places:
+                            places.append((oc, q, nm2))
+            for (pc, pp, pnm) in places:
+                refs = seqs[pc][pp:pp + (f1 - f0)]
+                nm_, md = md_nm(refs, piece)
+                flag = 16 if anti else 0
+                qn = "%d|%d:%d:%d" % (rid, s0, k, nseg)
+                case.seg_sam[sd][k].append("%s\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\n" % (
+                    qn, flag, names[pc], pp + 1, f1 - f0, piece, "I" * (f1 - f0), nm_, md))
+                case.seg_recs[sd][k].append((rid, pc + 1, pp, pp + (f1 - f0), anti, k == nseg - 1, nm_, nm_, f1 - f0))
+        # full-read map: only when the fragment is unspliced and indel-free
+        if not indel:
+            placed = _place_piece(gseq, frag_exons, t0, read_len, F, 2, 0)
+            if placed is not None:
+                pos, nm = placed
+                nm_, md = md_nm(gseq[pos:pos + read_len], F)
+                case.full_sam[sd].append("%d\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\n" % (
+                    rid, 16 if anti else 0, names[gref], pos + 1, read_len, F, "I" * read_len, nm_, md))
+                case.full_recs[sd].append((rid, gref + 1, pos, pos + read_len, anti, True, nm_, nm_, read_len))
+        return True
+
+    rid = 0
+    attempts = 0
+    while rid < n_reads and attempts < n_reads * 20:
+        attempts += 1
+        g = rng.choice(genes)
+        tlen = sum(b - a for a, b in g.exons)
+        frag_len = 2 * read_len + max(0, int(rng.gauss(inner_mean, inner_sd))) if paired else read_len
+        if tlen < frag_len + 2:
+            continue
+        # bias starts so that many reads span a junction
+        if rng.random() < 0.6:
+            j = rng.randrange(len(g.exons) - 1)
+            cum = sum(b - a for a, b in g.exons[:j + 1])
+            t0 = cum - rng.randint(3, read_len - 3)
+            if paired and rng.random() < 0.5:
+                t0 -= frag_len - read_len
+        else:
+            t0 = rng.randint(0, tlen - frag_len)
+        t0 = max(0, min(t0, tlen - frag_len))
+        rid += 1
+        if paired:
+            # FR library: left read sense at the fragment start, right read antisense at the end
+            flip = rng.random() < 0.5
+            l_anti, r_anti = (True, False) if flip else (False, True)
+            l_t0, r_t0 = (t0 + frag_len - read_len, t0) if flip else (t0, t0 + frag_len - read_len)
+            emit("left", rid, g.exons, l_t0, l_anti, g.ref, rng.random() < indel_frac)
+            emit("right", rid, g.exons, r_t0, r_anti, g.ref, rng.random() < indel_frac)
+        else:
+            emit("left", rid, g.exons, t0, rng.random() < 0.5, g.ref, rng.random() < indel_frac)
+    return case
+
+
+def write_case(case: SynthCase, d: str) -> Dict[str, object]:
+    """Write the files the reference binaries take (text-SAM twins, FASTQ, FASTA, header)."""
+    import os
+    from .samtext import sam_header
+    os.makedirs(d, exist_ok=True)
+    hdr = sam_header(case.names, [len(s) for s in case.seqs])
+    paths: Dict[str, object] = {}
+    with open(os.path.join(d, "hdr.sam"), "w") as f:
+        f.write(hdr)
+    paths["hdr"] = os.path.join(d, "hdr.sam")
+    with open(os.path.join(d, "ref.fa"), "w") as f:
+        for n, s in zip(case.names, case.seqs):
+            f.write(">%s\n" % n)
+            for i in range(0, len(s), 60):
+                f.write(s[i:i + 60] + "\n")
+    paths["ref"] = os.path.join(d, "ref.fa")
+    for sd in case.reads:
+        fq = os.path.join(d, "%s.fq" % sd)
+        with open(fq, "w") as f:
+            for rid in sorted(case.reads[sd]):
+                f.write("@%d\n%s\n+\n%s\n" % (rid, case.reads[sd][rid], case.quals[sd][rid]))
+        paths["%s_fq" % sd] = fq
+        segs = []
+        for k, lines in enumerate(case.seg_sam[sd]):
+            p = os.path.join(d, "%s_seg%d.sam" % (sd, k + 1))
+            with open(p, "w") as f:
+                f.write(hdr)
+                f.writelines(lines)
+            segs.append(p)
+        paths["%s_segs" % sd] = segs
+        p = os.path.join(d, "%s_map.sam" % sd)
+        with open(p, "w") as f:
+            f.write(hdr)
+            f.writelines(case.full_sam[sd])
+        paths["%s_map" % sd] = p
+    return paths
