@@ -1,0 +1,204 @@
+/*
+ * thj.h -- C ABI of libthj_hip.so: the MI355X-native junction-discovery hot path
+ * that sits behind TopHat's `segment_juncs` and `long_spanning_reads` binaries.
+ *
+ * The reference (DaehwanKimLab/tophat v2.1.2) has no plugin / FFI surface for
+ * this path: its boundary is process + argv + files (tophat.py:3070-3129 and
+ * :3133-3200).  The drop-in executables keep that boundary; this header is the
+ * thin C ABI between their C++ host code and the HIP kernels, and it is what a
+ * binding in any other host language would bind.  Each entry point names the
+ * reference code it replaces.
+ *
+ * Conventions: extern "C"; plain pointers and sizes; every function returns 0
+ * on success and a negative THJ_E* code on failure with a message available
+ * from thj_last_error() (thread-local); opaque handles; caller-owned buffers;
+ * one context per (host thread, device); no global state.  Functions whose
+ * name ends in _async only enqueue work on the context's HIP stream.
+ * Pointers documented as DEVICE pointers must be HIP device allocations on the
+ * context's device (e.g. hipMalloc or a torch tensor's data_ptr()).
+ */
+#ifndef THJ_H
+#define THJ_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THJ_OK            0
+#define THJ_EINVAL       -1   /* bad argument / unsupported parameter value */
+#define THJ_ENOMEM       -2
+#define THJ_EHIP         -3   /* a HIP runtime call failed */
+#define THJ_EOVERFLOW    -4   /* an event table filled up; re-configure larger and re-run */
+#define THJ_ESTATE       -5   /* call sequence violated (e.g. run before genome upload) */
+
+typedef struct thj_ctx thj_ctx;
+
+/* One alignment record: the fields of BowtieHit (bwt_map.h:36-536) the path
+ * reads, produced by BAMHitFactory::get_hit_from_buf (bwt_map.cpp:1101-1452).
+ * `right` = BowtieHit::right() (bwt_map.h:213-243), `read_len` =
+ * BowtieHit::read_len() (bwt_map.h:141-163). 16 bytes. */
+typedef struct {
+    uint32_t ref_id;      /* 1-based, @SQ order of --sam-header (bwt_map.h:608-632) */
+    int32_t  left;
+    int32_t  right;
+    uint8_t  flags;       /* THJ_HIT_* */
+    uint8_t  edit_dist;
+    uint8_t  mismatches;
+    uint8_t  read_len;
+} thj_hit;
+
+#define THJ_HIT_ANTISENSE 1u   /* BowtieHit::antisense_align() */
+#define THJ_HIT_END       2u   /* BowtieHit::end() (bwt_map.cpp:1133-1140) */
+
+/* The globals of common.cpp:79-180 that change hot-path results (SURVEY.md
+ * Appendix A).  All int32, same order as tophat_amd/params.py. */
+typedef struct {
+    int32_t segment_length;
+    int32_t segment_mismatches;
+    int32_t min_segment_intron;
+    int32_t max_segment_intron;
+    int32_t max_insertion_length;
+    int32_t max_deletion_length;
+    int32_t max_seg_multihits;
+    int32_t inner_dist_mean;
+    int32_t inner_dist_std_dev;
+    int32_t library_type;          /* common.h:155-167 */
+    int32_t bowtie2;
+    int32_t read_side;             /* segments.h:13-18: 1 READ_LEFT, 2 READ_RIGHT */
+    int32_t min_report_intron;
+    int32_t max_report_intron;
+    int32_t min_anchor_len;
+    int32_t read_mismatches;
+    int32_t read_gap_length;
+    int32_t read_edit_dist;
+    int32_t bowtie2_max_penalty;
+    int32_t bowtie2_min_penalty;
+    int32_t bowtie2_penalty_for_N;
+    int32_t bowtie2_read_gap_open;
+    int32_t bowtie2_read_gap_cont;
+    int32_t bowtie2_ref_gap_open;
+    int32_t bowtie2_ref_gap_cont;
+} thj_params;
+
+/* Fills `p` with the defaults of common.cpp:79-180. */
+void thj_params_default(thj_params* p);
+
+const char* thj_last_error(void);
+const char* thj_version(void);
+
+/* ------------------------------------------------------------ context */
+
+/* `stream` is a hipStream_t to launch on (e.g. torch's current stream) or NULL
+ * to let the context create its own non-blocking stream. */
+int  thj_ctx_create(int device, void* stream, thj_ctx** out);
+void thj_ctx_destroy(thj_ctx* ctx);
+int  thj_ctx_sync(thj_ctx* ctx);            /* hipStreamSynchronize on the context stream */
+void* thj_ctx_stream(thj_ctx* ctx);         /* the hipStream_t in use */
+
+/* ------------------------------------------------------------- genome */
+/* Replaces RefSequenceTable + get_seqs (bwt_map.h:579-788,
+ * segment_juncs.cpp:64-88): the whole reference as one HBM-resident array of
+ * 32-byte blocks of 64 bases {lo bit-plane, hi bit-plane, N-mask, 0}; A=00 C=01
+ * G=10 T=11, N has lo=hi=0 and its N-mask bit set, so dropping the mask gives the
+ * Dna5->Dna "N becomes A" view the window copies use (segment_juncs.cpp:2157)
+ * and keeping it gives the Dna5 view (:2417, long_spanning_reads.cpp:1146).
+ * Contig i (ref_id i+1) starts at block contig_blk[i]; one zero guard block
+ * follows every contig.  lens[i] == 0 marks an @SQ entry with no FASTA record
+ * (rt.get_seq() == NULL, segment_juncs.cpp:2105-2108). */
+
+/* Number of 32-byte blocks the packed genome needs. */
+int thj_genome_layout(int32_t n_contigs, const int64_t* lens, uint32_t* contig_blk /*[n_contigs+1]*/,
+                      int64_t* n_blocks);
+/* Packs ASCII contigs (acgtACGT, anything else = N; seqs[i] may be NULL when
+ * lens[i]==0) into `blocks` (4*n_blocks uint64, host memory). */
+int thj_genome_pack(int32_t n_contigs, const char* const* seqs, const int64_t* lens,
+                    const uint32_t* contig_blk, uint64_t* blocks, int64_t n_blocks);
+/* Copies a packed genome to the device (H2D) and keeps it resident. */
+int thj_genome_upload(thj_ctx* ctx, const uint64_t* blocks, int64_t n_blocks,
+                      const uint32_t* contig_blk, const int64_t* lens, int32_t n_contigs);
+/* Adopts an already device-resident packed genome (DEVICE pointer `d_blocks`,
+ * not owned); contig_blk/lens are host arrays. */
+int thj_genome_adopt(thj_ctx* ctx, const void* d_blocks, int64_t n_blocks,
+                     const uint32_t* contig_blk, const int64_t* lens, int32_t n_contigs);
+
+/* -------------------------------------------------------------- reads */
+/* Replaces ReadStream::getRead's product (reads.cpp:528-630): read r becomes
+ * 3*W uint64 {lo[W], hi[W], N[W]} bit-planes (base i = bit i%64 of word i/64)
+ * plus its length.  Characters other than ACGT are N. */
+int thj_reads_pack(int64_t n_reads, const int64_t* read_off, const char* bases,
+                   int32_t words_per_plane, uint64_t* planes /*[n*3*W]*/, uint16_t* lens /*[n]*/);
+
+/* ------------------------------------------------ segment_juncs batch */
+/* The hits_for_read vectors that look_for_hit_group / process_next_hit_group
+ * (segment_juncs.cpp:3823-4123) hand to the finders, for reads in visiting
+ * (increasing id) order.  All array pointers are DEVICE pointers. */
+typedef struct {
+    int32_t n_reads;
+    int32_t nseg;                /* number of segment maps (hits_for_read.size()) */
+    int32_t words_per_plane;     /* W of thj_reads_pack */
+    int32_t reserved;
+    const uint32_t* seg_off;     /* [n_reads*nseg+1] CSR into hits, index r*nseg+s */
+    const thj_hit*  hits;
+    const uint64_t* read_planes; /* [n_reads*3*W] */
+    const uint16_t* read_len;    /* [n_reads] */
+    const uint32_t* mate_off;    /* [n_reads+1] CSR into mate_hits, or NULL: no mates */
+    const thj_hit*  mate_hits;   /* partner_hit_group of find_gaps (segment_juncs.cpp:3321-3348) */
+    uint32_t ordinal_base;       /* visiting ordinal of read 0 (first-inserted-wins priority of
+                                    std::set<Insertion>, insertions.h:52-67) */
+    uint32_t reserved2;
+} thj_seg_batch;
+
+/* Convenience: allocates device memory for a batch given HOST arrays, copies
+ * (H2D, on the context stream) and returns a device-resident descriptor that
+ * thj_batch_free releases.  n_hits / n_mate_hits are the CSR totals. */
+int thj_batch_upload(thj_ctx* ctx, const thj_seg_batch* host, int64_t n_hits, int64_t n_mate_hits,
+                     thj_seg_batch** out);
+int thj_batch_free(thj_ctx* ctx, thj_seg_batch* dev);
+
+/* Capacity (entries, rounded up to a power of two) of the device event tables;
+ * default 1<<24 junctions, 1<<20 each for deletions and insertions.  Resets. */
+int thj_segjuncs_configure(thj_ctx* ctx, int64_t junc_capacity, int64_t indel_capacity);
+/* Empties the event tables (start of a segment_juncs run). */
+int thj_segjuncs_reset_async(thj_ctx* ctx);
+/* find_insertions_and_deletions + find_gaps + juncs_from_ref_segs<RecordSegmentJuncs>
+ * x {GT-AG, GC-AG, AT-AC} (segment_juncs.cpp:2807-2942, :3293-3650, :2052-2377)
+ * for every read of the batch; events accumulate in the context's tables the
+ * way the reference accumulates into its std::sets (:4911-4916). */
+int thj_segjuncs_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch* dev_batch);
+
+typedef struct { uint32_t ref_id, left, right, antisense; } thj_junction;   /* junctions.h:27-57 */
+typedef struct { uint32_t ref_id, left; char seq[8]; uint64_t prio; } thj_insertion; /* insertions.h:31-67 */
+
+typedef struct {
+    int64_t n_juncs, n_deletions, n_insertions;
+    int64_t n_windows;        /* RefSeg windows scanned */
+    int64_t n_indel_pairs;    /* hit pairs sent to detect_small_insertion/deletion */
+    int64_t n_rescue_pairs;   /* (hit, mate hit) pairs scanned by map_read_to_contig */
+    int64_t n_overflow_blocks;/* workgroups that fell back to un-queued processing */
+    int64_t n_hits_read;      /* thj_hit records the kernels were handed */
+} thj_segjuncs_counts;
+
+/* Compacts + sorts the tables into the order of the reference's sets
+ * (junctions.h:39-57; insertions.h:52-67) and synchronises the stream.
+ * Returns THJ_EOVERFLOW if a table overflowed during the runs. */
+int thj_segjuncs_finish(thj_ctx* ctx, thj_segjuncs_counts* counts);
+/* Copies the sorted events to host arrays sized from thj_segjuncs_finish's counts. */
+int thj_segjuncs_download(thj_ctx* ctx, thj_junction* juncs, thj_junction* deletions, thj_insertion* insertions);
+/* DEVICE pointers to the sorted packed 64-bit event keys after finish (for
+ * on-device merging / RCCL all-gather): kind 0 junctions, 1 deletions. */
+int thj_segjuncs_device_keys(thj_ctx* ctx, int kind, const uint64_t** d_keys, int64_t* n);
+/* Inserts packed keys (DEVICE pointer) produced by another context/rank into this
+ * context's table: the merge step of segment_juncs.cpp:4911-4916 across GPUs. */
+int thj_segjuncs_merge_keys_async(thj_ctx* ctx, int kind, const uint64_t* d_keys, int64_t n);
+
+/* Average duration (ms) of the dominant kernel (`thj_k_segjuncs`) over the
+ * launches since the last call, measured with HIP events on the context
+ * stream; also returns the launch count.  Enables event recording when
+ * `enable` != 0. */
+int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* THJ_H */

@@ -1,0 +1,101 @@
+// hostsim.cpp -- TEST-ONLY: compiles tophat_amd/csrc/thj_core.h for the CPU and
+// runs the per-read logic serially, so the bit-parallel formulations can be
+// checked against the oracle without a GPU.  Never linked into libthj_hip.so
+// and never used by the product path, bench.py or smoke().
+#include "../../include/thj.h"
+#include "../../tophat_amd/csrc/thj_core.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace thj;
+
+struct Collect {
+    std::vector<thj_junction> juncs, dels;
+    struct Ins { uint32_t ref, left; int len; uint32_t seq; u64 prio; };
+    std::vector<Ins> ins;
+    void junction(uint32_t ref, uint32_t l, uint32_t r, bool a) { juncs.push_back({ref, l, r, a ? 1u : 0u}); }
+    void deletion(uint32_t ref, uint32_t l, uint32_t r) { dels.push_back({ref, l, r, 0u}); }
+    void insertion(uint32_t ref, uint32_t l, int len, uint32_t seq, u64 prio) { ins.push_back({ref, l, len, seq, prio}); }
+};
+
+struct ExecSink {
+    const Genome& g; const Params& p; const ReadView& v; Collect& c; uint32_t ordinal;
+    int64_t n_windows = 0, n_indels = 0;
+    void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
+        ++n_windows;
+        window_exec(g, p, v, ref, wl, wr, anti, start, slen, c);
+    }
+    void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) {
+        ++n_indels;
+        indel_exec(g, p, v, i, lidx, ridx, anti, plen, is_del, ins_prio(ordinal, i, li, ri), c);
+    }
+};
+
+extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
+                                const int32_t* contig_len, int32_t n_contigs, const thj_seg_batch* b,
+                                thj_junction** juncs, int64_t* n_juncs, thj_junction** dels, int64_t* n_dels,
+                                uint32_t** ins /* 6 u32 per insertion: ref,left,len,seq,prio_lo,prio_hi */, int64_t* n_ins,
+                                int64_t* stats /* windows, indel pairs, rescue pairs */) {
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    Params p;
+    static_assert(sizeof(Params) == sizeof(thj_params), "params layout");
+    memcpy(&p, tp, sizeof p);
+    Collect c;
+    int64_t nw = 0, ni = 0, nr = 0;
+    std::vector<int32_t> slots;
+    for (int32_t r = 0; r < b->n_reads; ++r) {
+        ReadView v;
+        v.hits = (const Hit*)b->hits;
+        v.so = b->seg_off + (int64_t)r * b->nseg;
+        v.nseg = b->nseg;
+        v.W = b->words_per_plane;
+        v.rp = (const u64*)b->read_planes + (int64_t)r * 3 * v.W;
+        v.rl = b->read_len[r];
+        v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+        if (b->mate_off) {
+            v.mate = (const Hit*)b->mate_hits + b->mate_off[r];
+            v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]);
+        }
+        ExecSink sink{g, p, v, c, b->ordinal_base + (uint32_t)r};
+        indels_enumerate(p, v, sink);
+        bool wants;
+        if (gaps_prepare(p, v, wants)) {
+            if (wants) {
+                int n_left = rv_count_raw(v, 0);
+                slots.assign((size_t)2 * n_left * v.n_mate, SLOT_NONE);
+                for (int l = 0; l < n_left; ++l)
+                    for (int m = 0; m < v.n_mate; ++m) {
+                        rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m],
+                                    slots[2 * (l * v.n_mate + m)], slots[2 * (l * v.n_mate + m) + 1]);
+                        if (slots[2 * (l * v.n_mate + m)] != SLOT_BREAK &&
+                            !(v.hits[v.so[0] + l].ref_id != v.mate[m].ref_id ||
+                              hit_anti(v.hits[v.so[0] + l]) == hit_anti(v.mate[m])))
+                            ++nr;
+                    }
+                v.slots = slots.data();
+                v.rescue = true;
+            }
+            gaps_enumerate(p, v, sink);
+        }
+        nw += sink.n_windows; ni += sink.n_indels;
+    }
+    *n_juncs = (int64_t)c.juncs.size();
+    *juncs = (thj_junction*)malloc(sizeof(thj_junction) * (c.juncs.size() + 1));
+    memcpy(*juncs, c.juncs.data(), sizeof(thj_junction) * c.juncs.size());
+    *n_dels = (int64_t)c.dels.size();
+    *dels = (thj_junction*)malloc(sizeof(thj_junction) * (c.dels.size() + 1));
+    memcpy(*dels, c.dels.data(), sizeof(thj_junction) * c.dels.size());
+    *n_ins = (int64_t)c.ins.size();
+    *ins = (uint32_t*)malloc(sizeof(uint32_t) * 6 * (c.ins.size() + 1));
+    for (size_t k = 0; k < c.ins.size(); ++k) {
+        uint32_t* o = *ins + 6 * k;
+        o[0] = c.ins[k].ref; o[1] = c.ins[k].left; o[2] = (uint32_t)c.ins[k].len; o[3] = c.ins[k].seq;
+        o[4] = (uint32_t)(c.ins[k].prio & 0xffffffffu); o[5] = (uint32_t)(c.ins[k].prio >> 32);
+    }
+    stats[0] = nw; stats[1] = ni; stats[2] = nr;
+    return 0;
+}
+
+extern "C" void hostsim_free(void* p) { free(p); }

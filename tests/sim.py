@@ -1,0 +1,67 @@
+"""ctypes binding of tests/hostsim (CPU build of the kernel-logic header).  Test-only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from tophat_amd import host
+from tophat_amd.batch import Events, JUNC_DTYPE, SegBatch
+from tophat_amd.params import Params
+
+HS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+
+
+def lib():
+    so = os.path.join(HS_DIR, "libhostsim.so")
+    subprocess.check_call(["make", "-C", HS_DIR, "-s"])
+    l = C.CDLL(so)
+    l.thj_last_error.restype = C.c_char_p
+    return l
+
+
+def sort_events(j, d, ins_raw) -> Events:
+    def su(a):
+        if len(a) == 0:
+            return a
+        a = np.unique(a)
+        return a[np.lexsort((a["antisense"], a["right"], a["left"], a["ref_id"]))]
+    best = {}
+    for (ref, left, ln, seq, prio) in ins_raw:
+        k = (ref, left, ln)
+        if k not in best or prio < best[k][0]:
+            best[k] = (prio, seq)
+    ins = [(k[0], k[1], host.decode_ins_seq(best[k][1], k[2])) for k in sorted(best)]
+    return Events(su(j), su(d), ins, {})
+
+
+def segjuncs(p: Params, seqs, b: SegBatch, ordinal_base: int = 0) -> Events:
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    cb, keep, _, _ = host.host_cbatch(b, ordinal_base, lib=l)
+    clen = g.lens.astype(np.int32)
+    cp = p.as_ctypes()
+    pj, pd, pi = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nj, nd, ni = C.c_int64(), C.c_int64(), C.c_int64()
+    stats = (C.c_int64 * 3)()
+    rc = l.hostsim_segjuncs(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
+                            C.c_void_p(clen.ctypes.data), g.n_contigs, C.byref(cb),
+                            C.byref(pj), C.byref(nj), C.byref(pd), C.byref(nd), C.byref(pi), C.byref(ni), stats)
+    assert rc == 0
+
+    def arr(ptr, n):
+        if n == 0:
+            return np.zeros(0, dtype=JUNC_DTYPE)
+        return np.frombuffer((C.c_char * (n * 16)).from_address(ptr.value), dtype=JUNC_DTYPE).copy()
+    j, d = arr(pj, nj.value), arr(pd, nd.value)
+    raw = []
+    if ni.value:
+        a = np.frombuffer((C.c_char * (ni.value * 24)).from_address(pi.value), dtype=np.uint32).reshape(-1, 6)
+        raw = [(int(x[0]), int(x[1]), int(x[2]), int(x[3]), int(x[4]) | (int(x[5]) << 32)) for x in a]
+    for ptr in (pj, pd, pi):
+        l.hostsim_free(ptr)
+    ev = sort_events(j, d, raw)
+    ev.stats = {"windows": stats[0], "indel_pairs": stats[1], "rescue_pairs": stats[2]}
+    return ev

@@ -1,0 +1,536 @@
+// thj_core.h -- bit-parallel building blocks of the junction-discovery kernels.
+//
+// Everything here is a pure function of its arguments (loads through const
+// pointers, results through a caller-supplied sink), written once and compiled
+// for gfx950 by hipcc as __device__ code.  The same header also compiles as
+// plain C++ so that tests/hostsim can single-step the logic on a CPU; that
+// build is test-only and is never linked into libthj_hip.so.
+//
+// Data model (see include/thj.h): genome = 32-byte blocks of 64 bases
+// {lo plane, hi plane, N mask, 0}; reads = {lo[W], hi[W], N[W]} planes.  With
+// bases as bit-planes a whole splice-window comparison is a handful of 64-bit
+// XOR / AND / popcount operations per thread -- no per-base loops, no MFMA.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define THJ_HD __host__ __device__ __forceinline__
+#else
+#define THJ_HD inline
+#endif
+
+namespace thj {
+
+typedef unsigned long long u64;
+
+// ---- bit helpers ---------------------------------------------------------
+THJ_HD int popc(u64 x) { return __builtin_popcountll(x); }
+THJ_HD int ctz(u64 x) { return __builtin_ctzll(x); }   // x != 0
+THJ_HD int clz(u64 x) { return __builtin_clzll(x); }   // x != 0
+THJ_HD u64 lowmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // n >= 0
+THJ_HD u64 brev64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+// x >> s | y << (64 - s) for s in [0, 63] without the undefined 64-bit shift
+THJ_HD u64 funnel(u64 x, u64 y, unsigned s) { return (x >> s) | ((y << 1) << (63u - s)); }
+
+// ---- records ---------------------------------------------------------------
+struct Hit {            // == thj_hit, 16 bytes
+    uint32_t ref_id;
+    int32_t left;
+    int32_t right;
+    uint32_t meta;      // flags | edit_dist<<8 | mismatches<<16 | read_len<<24
+};
+THJ_HD bool hit_anti(const Hit& h) { return (h.meta & 1u) != 0; }
+THJ_HD bool hit_end(const Hit& h) { return (h.meta & 2u) != 0; }
+THJ_HD int hit_ed(const Hit& h) { return (int)((h.meta >> 8) & 0xFF); }
+THJ_HD int hit_rlen(const Hit& h) { return (int)((h.meta >> 24) & 0xFF); }
+
+struct Genome {
+    const u64* blocks;            // 4 u64 per 64-base block
+    const uint32_t* contig_blk;   // [n_contigs+1]
+    const int32_t* contig_len;    // [n_contigs]; 0 = no sequence
+    int32_t n_contigs;
+};
+
+struct Params {          // == thj_params (include/thj.h)
+    int32_t segment_length, segment_mismatches, min_segment_intron, max_segment_intron;
+    int32_t max_insertion_length, max_deletion_length, max_seg_multihits;
+    int32_t inner_dist_mean, inner_dist_std_dev, library_type, bowtie2, read_side;
+    int32_t min_report_intron, max_report_intron, min_anchor_len;
+    int32_t read_mismatches, read_gap_length, read_edit_dist;
+    int32_t bowtie2_max_penalty, bowtie2_min_penalty, bowtie2_penalty_for_N;
+    int32_t bowtie2_read_gap_open, bowtie2_read_gap_cont, bowtie2_ref_gap_open, bowtie2_ref_gap_cont;
+};
+
+struct Planes { u64 lo, hi, nm; };
+
+// 64 bases of contig `ref_id` (1-based) starting at `pos` (>= 0).
+THJ_HD Planes g_fetch(const Genome& g, uint32_t ref_id, int64_t pos) {
+    u64 gpos = (u64)g.contig_blk[ref_id - 1] * 64ull + (u64)pos;
+    const u64* p = g.blocks + (gpos >> 6) * 4;
+    unsigned s = (unsigned)(gpos & 63);
+    Planes r;
+    r.lo = funnel(p[0], p[4], s);
+    r.hi = funnel(p[1], p[5], s);
+    r.nm = funnel(p[2], p[6], s);
+    return r;
+}
+THJ_HD int32_t g_len(const Genome& g, uint32_t ref_id) {
+    return (ref_id == 0 || (int32_t)ref_id > g.n_contigs) ? 0 : g.contig_len[ref_id - 1];
+}
+
+// `len` (1..64) bases of a read starting at `start`; rp = this read's planes.
+THJ_HD Planes r_fetch(const u64* rp, int W, int start, int len) {
+    int w = start >> 6;
+    unsigned s = (unsigned)(start & 63);
+    Planes r;
+    u64 m = lowmask(len);
+    bool two = (w + 1 < W);
+    r.lo = funnel(rp[w], two ? rp[w + 1] : 0, s) & m;
+    r.hi = funnel(rp[W + w], two ? rp[W + w + 1] : 0, s) & m;
+    r.nm = funnel(rp[2 * W + w], two ? rp[2 * W + w + 1] : 0, s) & m;
+    return r;
+}
+
+// reverse complement of a `len`-base piece; N stays N (reads.cpp:189-207,
+// seqan::reverseComplement on String<char>).
+THJ_HD Planes rc_piece(Planes a, int len) {
+    u64 m = lowmask(len);
+    u64 l = ~a.lo & ~a.nm & m, h = ~a.hi & ~a.nm & m, n = a.nm & m;
+    Planes r;
+    r.lo = brev64(l) >> (64 - len);
+    r.hi = brev64(h) >> (64 - len);
+    r.nm = brev64(n) >> (64 - len);
+    return r;
+}
+
+// ---- juncs_from_ref_segs<RecordSegmentJuncs>, POINT_DIR_BOTH ----------------
+// One RefSeg window, all three motif pairs fused (segment_juncs.cpp:2052-2377 x
+// :3618-3649).  Only the two window ends are touched.  Sink: junction(ref,left,right,anti).
+template <class Sink>
+THJ_HD void window_scan(const Genome& g, const Params& p, uint32_t ref_id, int32_t seg_left, int32_t seg_right,
+                        bool antisense, Planes sup, int read_len, Sink& sink) {
+    int32_t clen = g_len(g, ref_id);
+    if (clen == 0) return;                                        // :2105-2108
+    if (seg_left < 0 || seg_right >= clen - 1) return;            // :2154
+    int seg_len = seg_right - seg_left;
+    if (read_len < 2 || read_len > 62 || seg_len < read_len) return;
+    if ((int64_t)seg_left + seg_len - read_len - 2 < 0) return;   // unreachable: find_gaps windows span >= min intron
+
+    bool skip_fwd = false, skip_rev = false;                      // :2110-2138
+    if (p.library_type == 2) {
+        if (p.read_side == 1) { if (antisense) skip_rev = true; else skip_fwd = true; }
+        else if (p.read_side == 2) { if (antisense) skip_fwd = true; else skip_rev = true; }
+    }
+    if (p.library_type == 3) {
+        if (p.read_side == 1) { if (antisense) skip_fwd = true; else skip_rev = true; }
+        else if (p.read_side == 2) { if (antisense) skip_rev = true; else skip_fwd = true; }
+    }
+
+    Planes gl = g_fetch(g, ref_id, seg_left);                                  // window start (N -> A: mask ignored)
+    Planes gr = g_fetch(g, ref_id, (int64_t)seg_left + seg_len - read_len - 2); // window end, 2 bases early
+
+    u64 M = lowmask(read_len);
+    // left_mismatches[]: loop runs i in [0, read_len-1) and stops at the third mismatch (:2187-2203)
+    u64 mL = ((gl.lo ^ sup.lo) | (gl.hi ^ sup.hi) | sup.nm) & lowmask(read_len - 1);
+    int to = read_len - 2;
+    {
+        u64 t = mL;
+        t &= t - 1;
+        t &= t - 1;
+        if (t) to = ctz(t);
+    }
+    // right_mismatches[]: from the top down, stops at the third mismatch and leaves
+    // the entries below it at 0 (:2205-2218)
+    u64 mR = (((gr.lo >> 2) ^ sup.lo) | ((gr.hi >> 2) ^ sup.hi) | sup.nm) & M;
+    int t3 = -1;
+    {
+        u64 u = mR;
+        if (u) u &= ~(1ull << (63 - clz(u)));
+        if (u) u &= ~(1ull << (63 - clz(u)));
+        if (u) t3 = 63 - clz(u);
+    }
+
+    // dinucleotide masks: bit i set <=> bases (i, i+1) spell the dinucleotide
+    u64 lA = ~gl.lo & ~gl.hi, lC = gl.lo & ~gl.hi, lG = ~gl.lo & gl.hi, lT = gl.lo & gl.hi;
+    u64 rA = ~gr.lo & ~gr.hi, rC = gr.lo & ~gr.hi, rG = ~gr.lo & gr.hi, rT = gr.lo & gr.hi;
+    u64 l_GT = lG & (lT >> 1), l_GC = lG & (lC >> 1), l_AT = lA & (lT >> 1), l_CT = lC & (lT >> 1);
+    u64 r_AG = rA & (rG >> 1), r_AC = rA & (rC >> 1), r_GC = rG & (rC >> 1), r_AT = rA & (rT >> 1);
+    // partner sits at window offset pos = seg_len-(read_len-i)-2, i.e. index i of `gr`
+    u64 fwd = (l_GT & r_AG) | (l_GC & r_AG) | (l_AT & r_AC);     // donor..acceptor
+    u64 rev = (l_CT & r_AC) | (l_CT & r_GC) | (l_GT & r_AT);     // rc(acceptor)..rc(donor)
+    if (skip_fwd) fwd = 0;
+    if (skip_rev) rev = 0;
+    u64 range = lowmask(to + 1);
+    u64 cand = (fwd | rev) & range;
+    while (cand) {
+        int i = ctz(cand);
+        cand &= cand - 1;
+        int lm = popc(mL & lowmask(i));                           // left_mismatches[i-1]
+        int rm = i > t3 ? popc(mR >> i) : (i == t3 ? 3 : 0);      // right_mismatches[i]
+        if (lm + rm <= 2) {
+            bool is_fwd = ((fwd >> i) & 1ull) != 0;
+            // RecordSegmentJuncs::record :1681-1695
+            sink.junction(ref_id, (uint32_t)(seg_left + i - 1), (uint32_t)(seg_left + seg_len - read_len + i),
+                          !is_fwd);
+        }
+    }
+}
+
+// ---- simpleSplitAlignment (segment_juncs.cpp:2390-2456) ----------------------
+// mL/mR: mismatch masks of the shorter sequence against the left-/right-anchored
+// reference.  Returns the first best insert position, -1 if len < 2.
+THJ_HD int split_bits(u64 mL, u64 mR, int len, int& min_err) {
+    int best = len + 1, bp = -1;
+    if (len >= 2) {
+        int e = popc((mR & lowmask(len)) >> 1) + (int)(mL & 1ull);
+        for (int p = 1; p < len; ++p) {
+            if (e < best) { best = e; bp = p; }
+            e += (int)((mL >> p) & 1ull) - (int)((mR >> p) & 1ull);
+        }
+    }
+    min_err = best;
+    return bp;
+}
+
+// detect_small_deletion (segment_juncs.cpp:2557-2627). rd = read piece (rc'd when antisense).
+template <class Sink>
+THJ_HD void small_deletion(const Genome& g, Planes rd, int plen, const Hit& lh, const Hit& rh, Sink& sink) {
+    int32_t clen = g_len(g, lh.ref_id);
+    if (clen == 0) return;
+    if (lh.left < 0) return;
+    if (rh.right < plen) return;
+    int disc = (rh.right - lh.left) - plen;
+    if ((int64_t)lh.left + plen > clen) return;
+    if (rh.right > clen) return;
+    Planes lg = g_fetch(g, lh.ref_id, lh.left);
+    Planes rg = g_fetch(g, lh.ref_id, (int64_t)rh.right - plen);
+    u64 M = lowmask(plen);
+    u64 mL = ((lg.lo ^ rd.lo) | (lg.hi ^ rd.hi) | lg.nm | rd.nm) & M;    // 'N' on either side is an error
+    u64 mR = ((rg.lo ^ rd.lo) | (rg.hi ^ rd.hi) | rg.nm | rd.nm) & M;
+    int min_err;
+    int pos = split_bits(mL, mR, plen, min_err);
+    if (pos < 0) return;
+    int adj = (hit_rlen(lh) + hit_rlen(rh) >= plen) ? -1 : 0;
+    if (min_err <= hit_ed(lh) + hit_ed(rh) + adj)
+        sink.deletion(lh.ref_id, (uint32_t)(lh.left + pos - 1), (uint32_t)(lh.left + pos + disc));
+}
+
+// detect_small_insertion (segment_juncs.cpp:2470-2543).
+template <class Sink>
+THJ_HD void small_insertion(const Genome& g, Planes rd, int plen, const Hit& lh, const Hit& rh, u64 prio, Sink& sink) {
+    int32_t clen = g_len(g, lh.ref_id);
+    if (clen == 0) return;
+    if (lh.left < 0) return;
+    int disc = plen - (rh.right - lh.left);
+    int64_t ge = rh.right;
+    if (ge > clen) ge = clen;
+    int glen = (int)(ge - lh.left);
+    if (glen < 0) glen = 0;
+    if (glen > plen || glen > 64) return;
+    Planes gg = g_fetch(g, lh.ref_id, lh.left);          // DnaString: N -> A, mask ignored
+    u64 M = lowmask(glen);
+    // left_read = rd[0:glen], right_read = rd[plen-glen:plen]
+    int sh = plen - glen;
+    u64 mL = ((gg.lo ^ rd.lo) | (gg.hi ^ rd.hi) | rd.nm) & M;
+    u64 mR = ((gg.lo ^ (rd.lo >> sh)) | (gg.hi ^ (rd.hi >> sh)) | (rd.nm >> sh)) & M;
+    int min_err;
+    int pos = split_bits(mL, mR, glen, min_err);
+    if (pos < 0) return;
+    int adj = (hit_rlen(lh) + hit_rlen(rh) >= plen) ? -1 : 0;
+    if (min_err <= hit_ed(lh) + hit_ed(rh) + adj && pos + disc <= glen) {
+        // inserted bases left_read[pos : pos+disc], 3 bits per base (A,C,G,T,N = 0..4)
+        uint32_t seq = 0;
+        for (int k = 0; k < disc; ++k) {
+            int b = pos + k;
+            uint32_t c = ((rd.nm >> b) & 1ull) ? 4u : (uint32_t)(((rd.lo >> b) & 1ull) | (((rd.hi >> b) & 1ull) << 1));
+            seq |= c << (3 * k);
+        }
+        sink.insertion(lh.ref_id, (uint32_t)(lh.left + pos - 1), disc, seq, prio);
+    }
+}
+
+// ---- map_read_to_contig over the mate's flank (segment_juncs.cpp:2946-2973) ---
+// Returns the first offset with the minimal Hamming distance (< 3), or -1.
+THJ_HD int flank_scan(const Genome& g, uint32_t ref_id, int64_t left, int flen, Planes rd, int rlen) {
+    int pos = -1, best = 3;
+    int n_off = flen - rlen;                      // loop is i < contig_len - read_len
+    u64 m = lowmask(rlen);
+    int span = 64 - rlen + 1;                     // offsets served by one 64-base fetch
+    for (int cs = 0; cs < n_off; cs += span) {
+        Planes c = g_fetch(g, ref_id, left + cs);
+        int lim = n_off - cs < span ? n_off - cs : span;
+        for (int j = 0; j < lim; ++j) {
+            u64 x = (((c.lo >> j) ^ rd.lo) | ((c.hi >> j) ^ rd.hi) | ((c.nm >> j) ^ rd.nm)) & m;  // 'N'=='N' matches
+            int t = popc(x);
+            if (t < best) { best = t; pos = cs + j; }
+        }
+        if (best == 0) break;                     // nothing can replace a perfect match
+    }
+    return pos;
+}
+
+enum { SLOT_NONE = -1, SLOT_BREAK = -2 };
+
+// One (left hit, mate hit) pair of the mate-anchored rescue (segment_juncs.cpp:3406-3492).
+// Writes the two pseudo-hit lefts (fwd, rev) or SLOT_NONE; fwd = SLOT_BREAK when the
+// reference `break`s out of the mate loop at this pair.  rp = the read's planes.
+THJ_HD void rescue_pair(const Genome& g, const Params& p, const u64* rp, int W, int rl, const Hit& lh, const Hit& rh,
+                        int32_t& fwd_left, int32_t& rev_left) {
+    fwd_left = SLOT_NONE;
+    rev_left = SLOT_NONE;
+    if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) return;      // :3414
+    int32_t clen = g_len(g, rh.ref_id);
+    if (clen == 0) return;
+    int part = p.inner_dist_std_dev > p.inner_dist_mean ? p.inner_dist_std_dev - p.inner_dist_mean : 0;
+    int flank = p.inner_dist_mean + p.inner_dist_std_dev;
+    int64_t left;
+    if (hit_anti(rh)) {
+        if (flank <= rh.left) left = rh.left - flank; else { fwd_left = SLOT_BREAK; return; }
+    } else {
+        if (part <= rh.right) left = rh.right - part; else { fwd_left = SLOT_BREAK; return; }
+    }
+    int64_t fe = left + flank + part;
+    if (fe > clen) fe = clen;
+    int flen = (int)(fe - left);
+    if (flen < 0) flen = 0;
+    int cl = p.segment_length - p.segment_mismatches - 3;
+    if (cl > 15) cl = 15;                                                      // :3451
+    if (cl < 1 || cl > rl) return;
+    Planes fwd = r_fetch(rp, W, rl - cl, cl);     // last cl bases of the read
+    Planes rev = rc_piece(fwd, cl);               // first cl bases of its reverse complement
+    int fp = flank_scan(g, rh.ref_id, left, flen, fwd, cl);
+    if (fp >= 0) fwd_left = (int32_t)(left + fp);
+    int rvp = flank_scan(g, rh.ref_id, left, flen, rev, cl);
+    if (rvp >= 0) rev_left = (int32_t)(left + rvp);
+}
+
+// ---- per-read view of hits_for_read -------------------------------------------
+struct ReadView {
+    const Hit* hits;          // batch hits
+    const uint32_t* so;       // this read's nseg+1 CSR offsets
+    int nseg;
+    const u64* rp;            // read planes
+    int W;
+    int rl;                   // read length
+    // mates / rescue
+    const Hit* mate;          // this read's mate hits (may be null)
+    int n_mate;
+    const int32_t* slots;     // this read's rescue slots [n_left*n_mate*2], or null
+    // derived by prepare()
+    int size;                 // hits_for_read.size() after the trailing-empty trim
+    bool rescue;              // segments 1.. replaced by the pseudo-hit list in `size-1`
+    int check_len;
+};
+
+THJ_HD int rv_count_raw(const ReadView& v, int s) { return (int)(v.so[s + 1] - v.so[s]); }
+
+// Iterate the effective hit list of segment s; f(const Hit&) returns false to stop.
+template <class F>
+THJ_HD void rv_foreach(const ReadView& v, int s, F f) {
+    if (!v.rescue || s == 0) {
+        for (uint32_t k = v.so[s]; k < v.so[s + 1]; ++k) {
+            Hit h = v.hits[k];
+            if (!f(h)) return;
+        }
+        return;
+    }
+    if (s != v.size - 1) return;            // cleared (:3398-3401)
+    int n_left = rv_count_raw(v, 0);
+    for (int l = 0; l < n_left; ++l)
+        for (int m = 0; m < v.n_mate; ++m) {
+            int32_t a = v.slots[2 * (l * v.n_mate + m)];
+            int32_t b = v.slots[2 * (l * v.n_mate + m) + 1];
+            if (a == SLOT_BREAK) break;
+            if (a >= 0) {
+                Hit h; h.ref_id = v.mate[m].ref_id; h.left = a; h.right = a + v.check_len;
+                h.meta = 2u | ((uint32_t)v.check_len << 24);
+                if (!f(h)) return;
+            }
+            if (b >= 0) {
+                Hit h; h.ref_id = v.mate[m].ref_id; h.left = b; h.right = b + v.check_len;
+                h.meta = 3u | ((uint32_t)v.check_len << 24);
+                if (!f(h)) return;
+            }
+        }
+}
+
+THJ_HD int rv_count(const ReadView& v, int s) {
+    int n = 0;
+    rv_foreach(v, s, [&](const Hit&) { ++n; return true; });
+    return n;
+}
+
+// The head of find_gaps (segment_juncs.cpp:3304-3393): trailing-empty trim, the
+// single-segment early return and the rescue decision.  Returns false when
+// find_gaps returns before doing anything.  Does not need the rescue slots.
+THJ_HD bool gaps_prepare(const Params& p, ReadView& v, bool& wants_rescue) {
+    wants_rescue = false;
+    v.rescue = false;
+    v.check_len = p.segment_length - p.segment_mismatches - 3;
+    if (v.check_len > 15) v.check_len = 15;
+    if (v.nseg == 0) return false;
+    int last = v.nseg - 1;
+    while (last > 0 && rv_count_raw(v, last) == 0) --last;
+    v.size = last + 1;
+    if (last == 0) {
+        if (rv_count_raw(v, 0) == 0) return false;
+        Hit h0 = v.hits[v.so[0]];
+        if (hit_end(h0)) return false;                                        // :3316-3318
+    }
+    bool check_partner = true;
+    if (last != 0) {
+        for (uint32_t i = v.so[0]; i < v.so[1] && check_partner; ++i) {
+            Hit lh = v.hits[i];
+            for (uint32_t j = v.so[last]; j < v.so[last + 1]; ++j) {
+                Hit rh = v.hits[j];
+                if (lh.ref_id == rh.ref_id && hit_anti(lh) == hit_anti(rh)) {
+                    int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
+                    if (dist >= p.min_segment_intron && dist < p.max_segment_intron) { check_partner = false; break; }
+                }
+            }
+        }
+    }
+    wants_rescue = check_partner && v.n_mate > 0;
+    return true;
+}
+
+// The body of find_gaps after the rescue (segment_juncs.cpp:3499-3617).
+// Sink: window(ref, wl, wr, antisense, support_start, support_len).
+template <class Sink>
+THJ_HD void gaps_enumerate(const Params& p, const ReadView& v, Sink& sink) {
+    const int L = p.segment_length;
+    if (p.bowtie2)                                                            // :3499-3506
+        for (int s = 0; s < v.size; ++s) {
+            int n = (!v.rescue || s == 0) ? rv_count_raw(v, s) : rv_count(v, s);
+            if (n > p.max_seg_multihits) return;
+        }
+    for (int s = 0; s < v.size; ++s) {
+        rv_foreach(v, s, [&](const Hit& bh) {
+            bool found = (s == v.size - 1);
+            int n_drs = 0, n_rrs = 0;
+            const bool banti = hit_anti(bh);
+            if (s < v.size - 1) {
+                rv_foreach(v, s + 1, [&](const Hit& rh) {
+                    if (banti != hit_anti(rh) || bh.ref_id != rh.ref_id) return true;
+                    if ((banti && rh.right == bh.left) || (!banti && bh.right == rh.left)) { found = true; return false; }
+                    int dist = banti ? bh.left - rh.right : rh.left - bh.right;
+                    if (dist >= p.min_segment_intron && dist < p.max_segment_intron) ++n_drs;
+                    return true;
+                });
+            }
+            if (!found && s < v.size - 2) {
+                rv_foreach(v, s + 2, [&](const Hit& rrh) {
+                    if (banti != hit_anti(rrh) || bh.ref_id != rrh.ref_id) return true;
+                    int dist = banti ? bh.left - rrh.right : rrh.left - bh.right;
+                    if (dist >= p.min_segment_intron + L && dist < p.max_segment_intron + L) ++n_rrs;
+                    return true;
+                });
+            }
+            if (!found && (n_drs > 0 || n_rrs > 0)) {
+                const bool use_rrs = n_rrs > 0;
+                const int lo = p.min_segment_intron + (use_rrs ? L : 0);
+                const int hi = p.max_segment_intron + (use_rrs ? L : 0);
+                const int start = (s + 1) * L - 8;                            // :3583-3586
+                int slen = use_rrs ? L + 16 : 16;
+                if (slen > v.rl - start) slen = v.rl - start;
+                if (start >= 0 && slen >= 0) {
+                    rv_foreach(v, use_rrs ? s + 2 : s + 1, [&](const Hit& d) {
+                        if (banti != hit_anti(d) || bh.ref_id != d.ref_id) return true;
+                        int dist = banti ? bh.left - d.right : d.left - bh.right;
+                        if (dist < lo || dist >= hi) return true;
+                        int32_t wl, wr;
+                        if (!banti) { wl = bh.right - 8; if (wl < 0) wl = 0; wr = d.left + 8; }   // :3589-3594
+                        else { wl = d.right - 8; wr = bh.left + 8; }                              // :3596-3604
+                        sink.window(bh.ref_id, wl, wr, banti, start, slen);
+                        return true;
+                    });
+                }
+            }
+            return true;
+        });
+    }
+}
+
+// find_insertions_and_deletions (segment_juncs.cpp:2807-2942) pair enumeration.
+// Sink: indel(i, left_idx, right_idx, li, ri, antisense, plen, is_deletion)
+// with left/right already swapped for antisense pairs (:2914-2920).
+template <class Sink>
+THJ_HD void indels_enumerate(const Params& p, const ReadView& v, Sink& sink) {
+    const int L = p.segment_length;
+    if (v.nseg < 2) return;
+    for (int i = 0; i + 2 < v.nseg; ++i) {                                    // :2856
+        uint32_t lb = v.so[i], le = v.so[i + 1], re = v.so[i + 2];
+        if (lb == le || le == re) return;                                     // :2869-2870
+        int start = i * L;
+        if (start > v.rl) return;
+        int plen = v.rl - start < 2 * L ? v.rl - start : 2 * L;
+        for (uint32_t li = lb; li < le; ++li) {
+            Hit lh = v.hits[li];
+            for (uint32_t ri = le; ri < re; ++ri) {
+                Hit rh = v.hits[ri];
+                if (lh.ref_id != rh.ref_id) continue;
+                bool anti = hit_anti(lh);
+                if (anti != hit_anti(rh)) continue;
+                int apparent = anti ? lh.right - rh.left : rh.right - lh.left;
+                int disc = apparent - plen;
+                bool is_del = disc > 0 && disc <= p.max_deletion_length;
+                bool is_ins = disc < 0 && disc >= -p.max_insertion_length;
+                if (is_del || is_ins)
+                    sink.indel(i, anti ? ri : li, anti ? li : ri, (int)(li - lb), (int)(ri - le), anti, plen, is_del);
+            }
+        }
+    }
+}
+
+// Execute one indel task: fetch the 2L read piece, rc when antisense, run the detector.
+template <class Sink>
+THJ_HD void indel_exec(const Genome& g, const Params& p, const ReadView& v, int i, uint32_t lidx, uint32_t ridx,
+                       bool anti, int plen, bool is_del, u64 prio, Sink& sink) {
+    Planes rd = r_fetch(v.rp, v.W, i * p.segment_length, plen);
+    if (anti) rd = rc_piece(rd, plen);
+    Hit lh = v.hits[lidx], rh = v.hits[ridx];
+    if (is_del) small_deletion(g, rd, plen, lh, rh, sink);
+    else small_insertion(g, rd, plen, lh, rh, prio, sink);
+}
+
+// Execute one window task.
+template <class Sink>
+THJ_HD void window_exec(const Genome& g, const Params& p, const ReadView& v, uint32_t ref_id, int32_t wl, int32_t wr,
+                        bool anti, int start, int slen, Sink& sink) {
+    if (slen < 2) return;
+    Planes sup = r_fetch(v.rp, v.W, start, slen);
+    if (anti) sup = rc_piece(sup, slen);                                       // :3598-3601
+    window_scan(g, p, ref_id, wl, wr, anti, sup, slen, sink);
+}
+
+// insertion priority = visiting order inside one batch: read ordinal, segment pair, li, ri
+THJ_HD u64 ins_prio(uint32_t ordinal, int i, int li, int ri) {
+    if (li > 63) li = 63;     // bowtie2 runs with -k 41 (tophat.py:2294): never reached in practice
+    if (ri > 63) ri = 63;
+    return ((u64)ordinal << 15) | ((u64)(i & 7) << 12) | ((u64)li << 6) | (u64)ri;
+}
+
+// ---- packed event keys ------------------------------------------------------
+// junction/deletion: [gpos(left)+1 : 34][right-left : 29][antisense : 1]; sorts like
+// Junction::operator< (junctions.h:39-57) because contigs are laid out in ref_id order.
+THJ_HD u64 junc_key(const Genome& g, uint32_t ref_id, uint32_t left, uint32_t right, bool anti) {
+    u64 gpos = (u64)g.contig_blk[ref_id - 1] * 64ull + (u64)(int64_t)(int32_t)left + 1ull;
+    u64 len = (u64)(right - left) & ((1ull << 29) - 1);
+    return (gpos << 30) | (len << 1) | (anti ? 1ull : 0ull);
+}
+// insertion key: [gpos(left)+1 : 34][len : 4]; value: [prio : 44][seq : 20] (atomicMin => first wins)
+THJ_HD u64 ins_key(const Genome& g, uint32_t ref_id, uint32_t left, int len) {
+    u64 gpos = (u64)g.contig_blk[ref_id - 1] * 64ull + (u64)(int64_t)(int32_t)left + 1ull;
+    return (gpos << 4) | (u64)(len & 15);
+}
+
+}  // namespace thj

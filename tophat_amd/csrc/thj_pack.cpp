@@ -1,0 +1,109 @@
+// thj_pack.cpp -- host-side packers of the C ABI (include/thj.h): genome ->
+// 64-base bit-plane blocks, reads -> bit-planes, parameter defaults, error text.
+// Replaces the data-preparation half of get_seqs (segment_juncs.cpp:64-88) and
+// ReadStream (reads.cpp:528-630) -- the parsing half lives in the drop-in
+// binaries.  Pure host C++; no device code.
+#include "../../include/thj.h"
+#include "thj_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+static thread_local char g_err[512] = "";
+
+void thj_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* thj_last_error(void) { return g_err; }
+extern "C" const char* thj_version(void) { return "thj-hip 0.1 (gfx950)"; }
+
+extern "C" void thj_params_default(thj_params* p) {
+    // common.cpp:79-180
+    memset(p, 0, sizeof *p);
+    p->segment_length = 25; p->segment_mismatches = 2;
+    p->min_segment_intron = 50; p->max_segment_intron = 500000;
+    p->max_insertion_length = 3; p->max_deletion_length = 3;
+    p->max_seg_multihits = 40;
+    p->inner_dist_mean = 200; p->inner_dist_std_dev = 20;
+    p->library_type = 0; p->bowtie2 = 1; p->read_side = 1;
+    p->min_report_intron = 50; p->max_report_intron = 500000; p->min_anchor_len = 8;
+    p->read_mismatches = 2; p->read_gap_length = 2; p->read_edit_dist = 2;
+    p->bowtie2_max_penalty = 6; p->bowtie2_min_penalty = 2; p->bowtie2_penalty_for_N = 1;
+    p->bowtie2_read_gap_open = 5; p->bowtie2_read_gap_cont = 3;
+    p->bowtie2_ref_gap_open = 5; p->bowtie2_ref_gap_cont = 3;
+}
+
+extern "C" int thj_genome_layout(int32_t n_contigs, const int64_t* lens, uint32_t* contig_blk, int64_t* n_blocks) {
+    if (n_contigs < 0 || !lens || !contig_blk || !n_blocks) { thj_set_error("thj_genome_layout: null argument"); return THJ_EINVAL; }
+    int64_t b = 0;
+    for (int32_t i = 0; i < n_contigs; ++i) {
+        if (lens[i] < 0 || lens[i] > 0x7fffffff) { thj_set_error("contig %d length %lld unsupported", i, (long long)lens[i]); return THJ_EINVAL; }
+        contig_blk[i] = (uint32_t)b;
+        b += (lens[i] + 63) / 64 + 1;       // one zero guard block after every contig
+        if (b > 0xfffffff0ll) { thj_set_error("genome too large for 32-bit block index"); return THJ_EINVAL; }
+    }
+    contig_blk[n_contigs] = (uint32_t)b;
+    *n_blocks = b + 1;                      // and one at the very end for the funnel's second load
+    return THJ_OK;
+}
+
+static inline int base_code(char c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;
+    }
+}
+
+extern "C" int thj_genome_pack(int32_t n_contigs, const char* const* seqs, const int64_t* lens,
+                               const uint32_t* contig_blk, uint64_t* blocks, int64_t n_blocks) {
+    if (!blocks || !contig_blk || !lens) { thj_set_error("thj_genome_pack: null argument"); return THJ_EINVAL; }
+    memset(blocks, 0, (size_t)n_blocks * 32);
+    for (int32_t c = 0; c < n_contigs; ++c) {
+        if (lens[c] == 0) continue;
+        if (!seqs || !seqs[c]) { thj_set_error("contig %d has a length but no sequence", c); return THJ_EINVAL; }
+        const char* s = seqs[c];
+        uint64_t* out = blocks + (uint64_t)contig_blk[c] * 4;
+        int64_t n = lens[c];
+        for (int64_t b0 = 0; b0 < n; b0 += 64) {
+            uint64_t lo = 0, hi = 0, nm = 0;
+            int lim = n - b0 < 64 ? (int)(n - b0) : 64;
+            for (int k = 0; k < lim; ++k) {
+                int code = base_code(s[b0 + k]);
+                if (code == 4) nm |= 1ull << k;
+                else { lo |= (uint64_t)(code & 1) << k; hi |= (uint64_t)(code >> 1) << k; }
+            }
+            uint64_t* blk = out + (b0 >> 6) * 4;
+            blk[0] = lo; blk[1] = hi; blk[2] = nm; blk[3] = 0;
+        }
+    }
+    return THJ_OK;
+}
+
+extern "C" int thj_reads_pack(int64_t n_reads, const int64_t* read_off, const char* bases,
+                              int32_t W, uint64_t* planes, uint16_t* lens) {
+    if (!read_off || !bases || !planes || !lens || W < 1) { thj_set_error("thj_reads_pack: bad argument"); return THJ_EINVAL; }
+    for (int64_t r = 0; r < n_reads; ++r) {
+        int64_t n = read_off[r + 1] - read_off[r];
+        if (n < 0 || n > (int64_t)W * 64) { thj_set_error("read %lld length %lld exceeds %d bases", (long long)r, (long long)n, W * 64); return THJ_EINVAL; }
+        lens[r] = (uint16_t)n;
+        uint64_t* rp = planes + r * 3 * W;
+        memset(rp, 0, (size_t)(3 * W) * 8);
+        const char* s = bases + read_off[r];
+        for (int64_t k = 0; k < n; ++k) {
+            int code = base_code(s[k]);
+            // reads keep their case in the reference; prep_reads emits upper-case ACGTN
+            int w = (int)(k >> 6), b = (int)(k & 63);
+            if (code == 4) rp[2 * W + w] |= 1ull << b;
+            else { rp[w] |= (uint64_t)(code & 1) << b; rp[W + w] |= (uint64_t)(code >> 1) << b; }
+        }
+    }
+    return THJ_OK;
+}

@@ -1,0 +1,262 @@
+"""ctypes binding of the C ABI in include/thj.h (libthj_hip.so).
+
+Host-side mirror used by bench.py, the tests and smoke(); the drop-in C++
+binaries call the same ABI directly.  There is no fallback: if the HIP library
+is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .batch import Events, HIT_DTYPE, JUNC_DTYPE, SegBatch
+from .params import CParams, Params
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libthj_hip.so")
+
+INS_CODE = "ACGTN"
+
+
+class ThjError(RuntimeError):
+    pass
+
+
+class CSegBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("nseg", C.c_int32), ("words_per_plane", C.c_int32), ("reserved", C.c_int32),
+                ("seg_off", C.c_void_p), ("hits", C.c_void_p), ("read_planes", C.c_void_p), ("read_len", C.c_void_p),
+                ("mate_off", C.c_void_p), ("mate_hits", C.c_void_p), ("ordinal_base", C.c_uint32),
+                ("reserved2", C.c_uint32)]
+
+
+class CJunction(C.Structure):
+    _fields_ = [("ref_id", C.c_uint32), ("left", C.c_uint32), ("right", C.c_uint32), ("antisense", C.c_uint32)]
+
+
+class CInsertion(C.Structure):
+    _fields_ = [("ref_id", C.c_uint32), ("left", C.c_uint32), ("seq", C.c_char * 8), ("prio", C.c_uint64)]
+
+
+class CCounts(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("n_juncs", "n_deletions", "n_insertions", "n_windows", "n_indel_pairs",
+                                         "n_rescue_pairs", "n_overflow_blocks", "n_hits_read")]
+
+
+ABI_SYMBOLS = [
+    "thj_params_default", "thj_last_error", "thj_version",
+    "thj_ctx_create", "thj_ctx_destroy", "thj_ctx_sync", "thj_ctx_stream",
+    "thj_genome_layout", "thj_genome_pack", "thj_genome_upload", "thj_genome_adopt",
+    "thj_reads_pack",
+    "thj_batch_upload", "thj_batch_free",
+    "thj_segjuncs_configure", "thj_segjuncs_reset_async", "thj_segjuncs_run_async",
+    "thj_segjuncs_finish", "thj_segjuncs_download", "thj_segjuncs_device_keys",
+    "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
+]
+
+_lib = None
+
+
+def load_lib(path: Optional[str] = None):
+    """Loads libthj_hip.so; raises ThjError if it is not built (run __graft_entry__.build())."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ThjError("HIP extension %s not built; run `python -c 'import __graft_entry__ as g; g.build()'`" % p)
+    lib = C.CDLL(p)
+    lib.thj_last_error.restype = C.c_char_p
+    lib.thj_version.restype = C.c_char_p
+    if hasattr(lib, "thj_ctx_stream"):
+        lib.thj_ctx_stream.restype = C.c_void_p
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int, what: str):
+    if rc != 0:
+        raise ThjError("%s failed (%d): %s" % (what, rc, lib.thj_last_error().decode()))
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class PackedGenome:
+    def __init__(self, blocks: np.ndarray, contig_blk: np.ndarray, lens: np.ndarray):
+        self.blocks, self.contig_blk, self.lens = blocks, contig_blk, lens
+
+    @property
+    def n_blocks(self) -> int:
+        return self.blocks.shape[0] // 4
+
+    @property
+    def n_contigs(self) -> int:
+        return self.lens.shape[0]
+
+    def decode_gpos(self, gpos: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        """global base coordinate -> (ref_id 1-based, pos)"""
+        starts = self.contig_blk[:-1].astype(np.int64) * 64
+        idx = np.searchsorted(starts, gpos, side="right") - 1
+        return (idx + 1).astype(np.uint32), (gpos - starts[idx]).astype(np.int64)
+
+
+def pack_genome(seqs: Sequence[Optional[str]], lib=None) -> PackedGenome:
+    lib = lib or load_lib()
+    n = len(seqs)
+    lens = np.array([0 if s is None else len(s) for s in seqs], dtype=np.int64)
+    contig_blk = np.zeros(n + 1, dtype=np.uint32)
+    nb = C.c_int64()
+    _check(lib, lib.thj_genome_layout(n, _ptr(lens), _ptr(contig_blk), C.byref(nb)), "thj_genome_layout")
+    blocks = np.zeros(nb.value * 4, dtype=np.uint64)
+    bufs = [None if s is None else s.encode() for s in seqs]
+    arr = (C.c_char_p * n)(*bufs)
+    _check(lib, lib.thj_genome_pack(n, arr, _ptr(lens), _ptr(contig_blk), _ptr(blocks), nb), "thj_genome_pack")
+    return PackedGenome(blocks, contig_blk, lens)
+
+
+def words_per_plane(max_len: int) -> int:
+    return max(1, (int(max_len) + 63) // 64)
+
+
+def pack_reads(b: SegBatch, W: Optional[int] = None, lib=None) -> Tuple[np.ndarray, np.ndarray, int]:
+    lib = lib or load_lib()
+    n = b.n_reads
+    lens_ = np.diff(b.read_off) if n else np.zeros(0, dtype=np.int64)
+    if W is None:
+        W = words_per_plane(int(lens_.max()) if n else 1)
+    planes = np.zeros(n * 3 * W, dtype=np.uint64)
+    lens = np.zeros(n, dtype=np.uint16)
+    bases = np.ascontiguousarray(b.bases, dtype=np.uint8)
+    off = np.ascontiguousarray(b.read_off, dtype=np.int64)
+    _check(lib, lib.thj_reads_pack(C.c_int64(n), _ptr(off), _ptr(bases), W, _ptr(planes), _ptr(lens)), "thj_reads_pack")
+    return planes, lens, W
+
+
+def host_cbatch(b: SegBatch, ordinal_base: int = 0, lib=None):
+    """CSegBatch whose pointers are HOST numpy arrays (+ the arrays, to keep them alive)."""
+    planes, lens, W = pack_reads(b, lib=lib)
+    keep = [np.ascontiguousarray(b.seg_off, dtype=np.uint32), np.ascontiguousarray(b.hits), planes, lens]
+    cb = CSegBatch()
+    cb.n_reads, cb.nseg, cb.words_per_plane = b.n_reads, b.nseg, W
+    cb.seg_off, cb.hits, cb.read_planes, cb.read_len = [a.ctypes.data for a in keep]
+    if b.mate_off is not None:
+        keep += [np.ascontiguousarray(b.mate_off, dtype=np.uint32), np.ascontiguousarray(b.mate_hits)]
+        cb.mate_off = keep[-2].ctypes.data
+        cb.mate_hits = keep[-1].ctypes.data if len(keep[-1]) else keep[-2].ctypes.data
+    cb.ordinal_base = ordinal_base
+    n_mate = 0 if b.mate_hits is None else len(b.mate_hits)
+    return cb, keep, len(b.hits), n_mate
+
+
+def decode_ins_seq(code: int, length: int) -> str:
+    return "".join(INS_CODE[(code >> (3 * k)) & 7] for k in range(length))
+
+
+class Context:
+    """One (host thread, device) context: resident genome, event tables, stream."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_lib()
+        self._ctx = C.c_void_p()
+        _check(self.lib, self.lib.thj_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._ctx)),
+               "thj_ctx_create")
+        self.genome: Optional[PackedGenome] = None
+        self._batches: List[C.c_void_p] = []
+
+    def close(self):
+        if self._ctx:
+            for b in self._batches:
+                self.lib.thj_batch_free(self._ctx, b)
+            self._batches = []
+            self.lib.thj_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        _check(self.lib, self.lib.thj_ctx_sync(self._ctx), "thj_ctx_sync")
+
+    def upload_genome(self, g: PackedGenome):
+        _check(self.lib, self.lib.thj_genome_upload(self._ctx, _ptr(g.blocks), C.c_int64(g.n_blocks), _ptr(g.contig_blk),
+                                                    _ptr(g.lens), g.n_contigs), "thj_genome_upload")
+        self.genome = g
+
+    def adopt_genome(self, d_blocks: int, g: PackedGenome):
+        _check(self.lib, self.lib.thj_genome_adopt(self._ctx, C.c_void_p(d_blocks), C.c_int64(g.n_blocks),
+                                                   _ptr(g.contig_blk), _ptr(g.lens), g.n_contigs), "thj_genome_adopt")
+        self.genome = g
+
+    def upload_batch(self, b: SegBatch, ordinal_base: int = 0) -> C.c_void_p:
+        cb, keep, nh, nm = host_cbatch(b, ordinal_base, self.lib)
+        out = C.c_void_p()
+        _check(self.lib, self.lib.thj_batch_upload(self._ctx, C.byref(cb), C.c_int64(nh), C.c_int64(nm), C.byref(out)),
+               "thj_batch_upload")
+        self.sync()
+        self._batches.append(out)
+        return out
+
+    def free_batch(self, h: C.c_void_p):
+        self._batches = [b for b in self._batches if b.value != h.value]
+        _check(self.lib, self.lib.thj_batch_free(self._ctx, h), "thj_batch_free")
+
+    def configure(self, junc_capacity: int, indel_capacity: int):
+        _check(self.lib, self.lib.thj_segjuncs_configure(self._ctx, C.c_int64(junc_capacity), C.c_int64(indel_capacity)),
+               "thj_segjuncs_configure")
+
+    def reset(self):
+        _check(self.lib, self.lib.thj_segjuncs_reset_async(self._ctx), "thj_segjuncs_reset_async")
+
+    def run(self, p: Params, batch):
+        """batch: handle from upload_batch, or a CSegBatch of DEVICE pointers."""
+        cp = p.as_ctypes()
+        arg = C.byref(batch) if isinstance(batch, CSegBatch) else batch
+        _check(self.lib, self.lib.thj_segjuncs_run_async(self._ctx, C.byref(cp), arg), "thj_segjuncs_run_async")
+
+    def finish(self) -> CCounts:
+        cnt = CCounts()
+        _check(self.lib, self.lib.thj_segjuncs_finish(self._ctx, C.byref(cnt)), "thj_segjuncs_finish")
+        return cnt
+
+    def download(self, cnt: CCounts) -> Events:
+        j = np.zeros(cnt.n_juncs, dtype=JUNC_DTYPE)
+        d = np.zeros(cnt.n_deletions, dtype=JUNC_DTYPE)
+        ins = (CInsertion * max(1, cnt.n_insertions))()
+        _check(self.lib, self.lib.thj_segjuncs_download(self._ctx, _ptr(j), _ptr(d), ins), "thj_segjuncs_download")
+        il = [(int(ins[k].ref_id), int(ins[k].left), ins[k].seq.decode()) for k in range(cnt.n_insertions)]
+        stats = {"windows": cnt.n_windows, "indel_pairs": cnt.n_indel_pairs, "rescue_pairs": cnt.n_rescue_pairs,
+                 "overflow_blocks": cnt.n_overflow_blocks, "hits_read": cnt.n_hits_read}
+        return Events(j, d, il, stats)
+
+    def segjuncs(self, runs: Sequence[Tuple[Params, object]]) -> Events:
+        """reset; run every (params, batch); finish; download -- one segment_juncs pass."""
+        self.reset()
+        for p, b in runs:
+            self.run(p, b)
+        return self.download(self.finish())
+
+    def profile(self, enable: bool = True) -> Tuple[float, int]:
+        ms = C.c_double()
+        n = C.c_int64()
+        _check(self.lib, self.lib.thj_profile_segjuncs(self._ctx, 1 if enable else 0, C.byref(ms), C.byref(n)),
+               "thj_profile_segjuncs")
+        return ms.value, n.value
+
+    def device_keys(self, kind: int) -> Tuple[int, int]:
+        p = C.c_void_p()
+        n = C.c_int64()
+        _check(self.lib, self.lib.thj_segjuncs_device_keys(self._ctx, kind, C.byref(p), C.byref(n)),
+               "thj_segjuncs_device_keys")
+        return (p.value or 0), n.value
+
+    def merge_keys(self, kind: int, d_keys: int, n: int):
+        _check(self.lib, self.lib.thj_segjuncs_merge_keys_async(self._ctx, kind, C.c_void_p(d_keys), C.c_int64(n)),
+               "thj_segjuncs_merge_keys_async")
