@@ -1,0 +1,65 @@
+"""CPU: the C-ABI library loads and exports every symbol include/thj.h declares; host packers work."""
+import re
+import os
+
+import numpy as np
+
+import orc
+from tophat_amd import host
+from tophat_amd.params import Params, CParams
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    lib = host.load_lib()
+    hdr = open(os.path.join(ROOT, "include", "thj.h")).read()
+    declared = set(re.findall(r"\b(thj_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), "libthj_hip.so does not export %s" % sym
+    assert set(host.ABI_SYMBOLS) <= declared
+
+
+def test_params_default_match_reference_defaults():
+    lib = host.load_lib()
+    c = CParams()
+    lib.thj_params_default(host.C.byref(c))
+    d = Params().as_ctypes()
+    for name, _ in CParams._fields_:
+        assert getattr(c, name) == getattr(d, name), name
+
+
+def test_genome_and_read_packing_roundtrip():
+    lib = host.load_lib()
+    rng = np.random.default_rng(1)
+    seqs = ["".join(rng.choice(list("ACGTN"), size=n, p=[.24, .24, .24, .24, .04])) for n in (1, 63, 64, 65, 1000)]
+    seqs.insert(2, None)
+    g = host.pack_genome(seqs, lib=lib)
+    blk = g.blocks.reshape(-1, 4)
+    for ci, s in enumerate(seqs):
+        if s is None:
+            assert g.lens[ci] == 0
+            continue
+        b0 = int(g.contig_blk[ci])
+        for i, ch in enumerate(s):
+            w = blk[b0 + i // 64]
+            lo, hi, nm = (int(w[0]) >> (i % 64)) & 1, (int(w[1]) >> (i % 64)) & 1, (int(w[2]) >> (i % 64)) & 1
+            got = "N" if nm else "ACGT"[lo | (hi << 1)]
+            assert got == ch
+        # guard block after the contig is zero
+        assert not blk[b0 + (len(s) + 63) // 64].any()
+
+
+def test_no_device_gives_loud_error():
+    import pytest
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    with pytest.raises(host.ThjError):
+        host.Context(0)

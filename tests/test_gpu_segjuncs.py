@@ -1,0 +1,139 @@
+"""GPU parity: the HIP path through the C ABI against the CPU oracle (bit-exact)."""
+import numpy as np
+import pytest
+
+import orc
+from tophat_amd import host
+from tophat_amd.batch import merge_events
+from tophat_amd.params import Params
+from tophat_amd.synth import make_case
+from util import CASES, assert_events_equal, case_batches
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return host.load_lib()   # fails loudly when the extension is missing
+
+
+def _run_case(cfg, n_reads, chunk=None):
+    case = make_case(seed=cfg["seed"], paired=cfg["paired"], read_len=cfg["read_len"], seg_len=cfg["seg_len"],
+                     n_reads=n_reads, **cfg.get("gen", {}))
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    og = orc.Genome(seqs)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        want = None
+        runs = []
+        base = 0
+        for side, b in case_batches(case, cfg["paired"]):
+            p = Params(segment_length=cfg["seg_len"], read_side=side, **cfg["extra"])
+            e = orc.segjuncs(p, og, b)
+            want = e if want is None else merge_events(want, e)
+            runs.append((p, ctx.upload_batch(b, ordinal_base=base)))
+            base += b.n_reads
+        got = ctx.segjuncs(runs)
+        return got, want
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "seed%d_%s_rl%d_L%d" % (c["seed"], "pe" if c["paired"] else "se", c["read_len"], c["seg_len"]))
+def test_segjuncs_matches_oracle(lib, cfg):
+    got, want = _run_case(cfg, 600)
+    assert len(want.juncs) > 5
+    assert_events_equal(got, want)
+    assert got.stats["windows"] == want.stats["windows"]
+    assert got.stats["indel_pairs"] == want.stats["indel_pairs"]
+    assert got.stats["rescue_pairs"] == want.stats["rescue_pairs"]
+
+
+def test_rerun_is_idempotent(lib):
+    """reset + run twice gives the same events; running the same batch twice without a
+    reset adds nothing (set semantics of the reference's std::set merges)."""
+    cfg = CASES[2]
+    case = make_case(seed=21, paired=True, read_len=100, seg_len=25, n_reads=400)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        runs = []
+        for side, b in case_batches(case, True):
+            runs.append((Params(read_side=side, **cfg["extra"]), ctx.upload_batch(b)))
+        a = ctx.segjuncs(runs)
+        b2 = ctx.segjuncs(runs + runs)
+        assert_events_equal(a, b2)
+
+
+def test_empty_and_ragged(lib):
+    """empty batch, reads with no hits in most segments, a contig missing from the FASTA"""
+    from tophat_amd.batch import build_seg_batch
+    case = make_case(seed=5, n_reads=200, drop_seg_frac=0.5)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    og = orc.Genome(seqs)
+    b = build_seg_batch(case.seg_recs["left"], case.reads["left"])
+    p = Params()
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        got = ctx.segjuncs([(p, ctx.upload_batch(b))])
+        assert_events_equal(got, orc.segjuncs(p, og, b))
+        empty = build_seg_batch([[] for _ in range(4)], {})
+        got = ctx.segjuncs([(p, ctx.upload_batch(empty))])
+        assert len(got.juncs) == 0 and len(got.deletions) == 0 and not got.insertions
+    # @SQ entry without sequence: every window on it is skipped (segment_juncs.cpp:2105-2108)
+    seqs2 = [None] + seqs
+    og2 = orc.Genome(seqs2)
+    recs = [[(h[0], h[1] + 1) + h[2:] for h in seg] for seg in case.seg_recs["left"]]
+    recs[0] = recs[0] + [(h[0], 1) + h[2:] for h in case.seg_recs["left"][0][:20]]
+    recs = [sorted(seg, key=lambda h: h[0]) for seg in recs]
+    b2 = build_seg_batch(recs, case.reads["left"])
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs2))
+        got = ctx.segjuncs([(p, ctx.upload_batch(b2))])
+        assert_events_equal(got, orc.segjuncs(p, og2, b2))
+
+
+def test_queue_overflow_fallback(lib):
+    """A tile whose tasks exceed the LDS queue falls back to un-queued execution with identical results."""
+    from tophat_amd.batch import HIT_DTYPE, SegBatch
+    rng = np.random.default_rng(3)
+    L, nseg, n_reads, mh = 25, 4, 256, 12
+    glen = 400000
+    seq = "".join(rng.choice(list("ACGT"), size=glen))
+    # every read: mh hits in seg 0 and mh hits in seg 1 at intron distance -> mh*mh windows per read
+    hits, seg_off, bases, read_off = [], [0], bytearray(), [0]
+    for r in range(n_reads):
+        base = 1000 + r * 1200
+        for k in range(mh):
+            hits.append((1, base + k * 3, base + k * 3 + L, 0, 0, 0, L))
+        seg_off.append(len(hits))
+        for k in range(mh):
+            hits.append((1, base + 300 + k * 5, base + 300 + k * 5 + L, 0, 0, 0, L))
+        seg_off.append(len(hits))
+        seg_off.append(len(hits))
+        seg_off.append(len(hits))
+        bases += seq[base:base + 100].encode()
+        read_off.append(len(bases))
+    b = SegBatch(nseg, np.arange(1, n_reads + 1, dtype=np.uint32), np.array(read_off, dtype=np.int64),
+                 np.frombuffer(bytes(bases), dtype=np.uint8).copy(), np.array(seg_off, dtype=np.uint32),
+                 np.array(hits, dtype=HIT_DTYPE))
+    p = Params()
+    og = orc.Genome([seq])
+    want = orc.segjuncs(p, og, b)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        got = ctx.segjuncs([(p, ctx.upload_batch(b))])
+    assert got.stats["overflow_blocks"] >= 1
+    assert want.stats["windows"] == n_reads * mh * mh
+    assert_events_equal(got, want)
+
+
+def test_missing_genome_fails_loudly(lib):
+    case = make_case(seed=2, n_reads=50)
+    from tophat_amd.batch import build_seg_batch
+    b = build_seg_batch(case.seg_recs["left"], case.reads["left"])
+    with host.Context(0) as ctx:
+        h = ctx.upload_batch(b)
+        with pytest.raises(host.ThjError):
+            ctx.run(Params(), h)          # no genome resident -> error, never a fallback
+        with pytest.raises(host.ThjError):
+            ctx.upload_genome(host.pack_genome(["ACGT" * 100]))
+            ctx.run(Params(segment_length=64), h)   # unsupported parameter -> error

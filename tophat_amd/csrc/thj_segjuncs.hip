@@ -1,0 +1,789 @@
+// thj_segjuncs.hip -- gfx950 kernels + C ABI for the segment_juncs hot path.
+//
+// Kernel plan for one batch of reads (one thj_segjuncs_run_async call):
+//   thj_k_rescue_count   1 thread / read   head of find_gaps: does the read take the
+//                                          mate-anchored rescue?  -> #(hit, mate-hit) pairs
+//   hipcub ExclusiveSum                    pair slots CSR
+//   thj_k_rescue_scan    1 thread / pair   map_read_to_contig over the mate flank, bit-parallel
+//   thj_k_segjuncs       1 thread / read   (the dominant kernel) phase A: stream the read's hit
+//                                          records, enumerate RefSeg windows and indel pairs into
+//                                          an LDS task queue; phase B: one thread per queued task
+//                                          fetches the two 64-base window ends + the support read
+//                                          and does the whole motif/mismatch scan with 64-bit
+//                                          plane arithmetic; events go to HBM hash tables
+//                                          (set semantics of the reference's std::sets).
+// thj_segjuncs_finish: thj_k_compact (table -> dense keys) + hipcub radix sort.
+//
+// No MFMA: this is integer compare / popcount work bound by HBM record streaming.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/thj.h"
+#include "thj_core.h"
+#include "thj_internal.h"
+
+using namespace thj;
+
+static_assert(sizeof(thj_hit) == 16 && sizeof(Hit) == 16, "hit layout");
+static_assert(sizeof(thj_params) == sizeof(Params), "params layout");
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            thj_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return THJ_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------ tables
+
+static constexpr u64 EMPTY = ~0ull;
+
+enum { CNT_JUNC = 0, CNT_DEL, CNT_INS, CNT_WINDOWS, CNT_INDEL_PAIRS, CNT_RESCUE_PAIRS, CNT_OVF_BLOCKS, CNT_HITS, CNT_N };
+
+struct Tables {
+    u64* junc; u64 junc_mask;
+    u64* del;  u64 del_mask;
+    u64* ins_key; u64* ins_val; u64 ins_mask;
+    unsigned int* ovf;              // [3] table-full flags
+    unsigned long long* cnt;        // [CNT_N]
+};
+
+__device__ __forceinline__ u64 mix64(u64 x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+
+// Insert into an open-addressing set; idempotent, so re-emitting an event is harmless.
+__device__ __forceinline__ void set_insert(u64* tab, u64 mask, u64 key, unsigned long long* count, unsigned int* ovf) {
+    u64 h = mix64(key) & mask;
+    for (u64 probe = 0; probe <= mask; ++probe) {
+        u64 cur = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return;
+        if (cur == EMPTY) {
+            u64 old = atomicCAS((unsigned long long*)&tab[h], EMPTY, key);
+            if (old == EMPTY) {
+                unsigned long long c = atomicAdd(count, 1ull);
+                if (c + 1 > (mask + 1) - ((mask + 1) >> 2)) atomicExch(ovf, 1u);   // > 75 % full
+                return;
+            }
+            if (old == key) return;
+        }
+        h = (h + 1) & mask;
+    }
+    atomicExch(ovf, 1u);
+}
+
+__device__ __forceinline__ void map_insert_min(u64* keys, u64* vals, u64 mask, u64 key, u64 val,
+                                               unsigned long long* count, unsigned int* ovf) {
+    u64 h = mix64(key) & mask;
+    for (u64 probe = 0; probe <= mask; ++probe) {
+        u64 cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == EMPTY) {
+            u64 old = atomicCAS((unsigned long long*)&keys[h], EMPTY, key);
+            if (old == EMPTY) {
+                unsigned long long c = atomicAdd(count, 1ull);
+                if (c + 1 > (mask + 1) - ((mask + 1) >> 2)) atomicExch(ovf, 1u);
+                cur = key;
+            } else cur = old;
+        }
+        if (cur == key) { atomicMin((unsigned long long*)&vals[h], val); return; }
+        h = (h + 1) & mask;
+    }
+    atomicExch(ovf, 1u);
+}
+
+struct EventSink {
+    const Genome& g;
+    const Tables& t;
+    __device__ __forceinline__ void junction(uint32_t ref, uint32_t l, uint32_t r, bool a) {
+        set_insert(t.junc, t.junc_mask, junc_key(g, ref, l, r, a), &t.cnt[CNT_JUNC], &t.ovf[0]);
+    }
+    __device__ __forceinline__ void deletion(uint32_t ref, uint32_t l, uint32_t r) {
+        set_insert(t.del, t.del_mask, junc_key(g, ref, l, r, false), &t.cnt[CNT_DEL], &t.ovf[1]);
+    }
+    __device__ __forceinline__ void insertion(uint32_t ref, uint32_t l, int len, uint32_t seq, u64 prio) {
+        map_insert_min(t.ins_key, t.ins_val, t.ins_mask, ins_key(g, ref, l, len), (prio << 20) | (u64)(seq & 0xFFFFFu),
+                       &t.cnt[CNT_INS], &t.ovf[2]);
+    }
+};
+
+// ------------------------------------------------------------------ batch view
+
+struct DevBatch {
+    int32_t n_reads, nseg, W, pad;
+    const uint32_t* seg_off;
+    const Hit* hits;
+    const u64* planes;
+    const uint16_t* read_len;
+    const uint32_t* mate_off;
+    const Hit* mate_hits;
+    uint32_t ordinal_base, pad2;
+};
+static_assert(sizeof(DevBatch) == sizeof(thj_seg_batch), "batch layout");
+
+__device__ __forceinline__ ReadView make_view(const DevBatch& b, int r) {
+    ReadView v;
+    v.hits = b.hits;
+    v.so = b.seg_off + (size_t)r * b.nseg;
+    v.nseg = b.nseg;
+    v.W = b.W;
+    v.rp = b.planes + (size_t)r * 3 * b.W;
+    v.rl = b.read_len[r];
+    v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+    if (b.mate_off) {
+        uint32_t m0 = b.mate_off[r], m1 = b.mate_off[r + 1];
+        v.mate = b.mate_hits + m0;
+        v.n_mate = (int)(m1 - m0);
+    }
+    v.size = 0; v.rescue = false; v.check_len = 0;
+    return v;
+}
+
+// ------------------------------------------------------------------ rescue
+
+__global__ __launch_bounds__(256) void thj_k_rescue_count(Params p, DevBatch b, uint32_t* npairs) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= b.n_reads) return;
+    ReadView v = make_view(b, r);
+    bool wants = false;
+    uint32_t n = 0;
+    if (gaps_prepare(p, v, wants) && wants) n = (uint32_t)rv_count_raw(v, 0) * (uint32_t)v.n_mate;
+    npairs[r] = n;
+}
+
+__global__ __launch_bounds__(256) void thj_k_rescue_scan(Genome g, Params p, DevBatch b, const uint32_t* pair_off,
+                                                         int32_t* slots, unsigned long long* cnt) {
+    const uint32_t total = pair_off[b.n_reads];
+    unsigned int local = 0;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
+        // read owning pair k: last r with pair_off[r] <= k
+        int lo = 0, hi = b.n_reads;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (pair_off[mid] <= k) lo = mid; else hi = mid;
+        }
+        int r = lo;
+        ReadView v = make_view(b, r);
+        uint32_t j = k - pair_off[r];
+        int l = (int)(j / (uint32_t)v.n_mate), m = (int)(j % (uint32_t)v.n_mate);
+        Hit lh = v.hits[v.so[0] + l];
+        Hit rh = v.mate[m];
+        int32_t f, rv;
+        rescue_pair(g, p, v.rp, v.W, v.rl, lh, rh, f, rv);
+        slots[2 * (size_t)k] = f;
+        slots[2 * (size_t)k + 1] = rv;
+        if (f != SLOT_BREAK && lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) ++local;
+    }
+    if (local) atomicAdd(&cnt[CNT_RESCUE_PAIRS], (unsigned long long)local);
+}
+
+// ------------------------------------------------------------------ main kernel
+
+static constexpr int TPB = 256;
+static constexpr int QCAP = 1024;
+
+struct Queue {
+    uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d;
+    unsigned int* n;
+};
+
+struct QueueSink {
+    Queue q;
+    uint32_t rloc;
+    unsigned int n_windows, n_indels;
+    __device__ __forceinline__ void push(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        unsigned int k = atomicAdd(q.n, 1u);
+        if (k < (unsigned)QCAP) { q.a[k] = a; q.b[k] = b; q.c[k] = c; q.d[k] = d; }
+    }
+    __device__ __forceinline__ void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
+        ++n_windows;
+        push(rloc | (anti ? 1u << 9 : 0u) | ((uint32_t)start << 10) | ((uint32_t)slen << 18), ref, (uint32_t)wl, (uint32_t)wr);
+    }
+    __device__ __forceinline__ void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) {
+        ++n_indels;
+        push(rloc | (1u << 8) | (anti ? 1u << 9 : 0u) | (is_del ? 1u << 10 : 0u) | ((uint32_t)i << 11) | ((uint32_t)plen << 14),
+             lidx, ridx, (uint32_t)li | ((uint32_t)ri << 16));
+    }
+};
+
+// Un-queued execution (overflow fallback): tasks run in the enumerating thread.
+struct InlineSink {
+    const Genome& g; const Params& p; const ReadView& v; EventSink& ev; uint32_t ordinal;
+    __device__ __forceinline__ void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
+        window_exec(g, p, v, ref, wl, wr, anti, start, slen, ev);
+    }
+    __device__ __forceinline__ void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) {
+        indel_exec(g, p, v, i, lidx, ridx, anti, plen, is_del, ins_prio(ordinal, i, li, ri), ev);
+    }
+};
+
+__global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBatch b, Tables t,
+                                                      const uint32_t* pair_off, const int32_t* slots) {
+    __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP];
+    __shared__ unsigned int q_n;
+    __shared__ unsigned int s_stat[4];
+    const int tid = threadIdx.x;
+    if (tid < 4) s_stat[tid] = 0;
+    EventSink ev{g, t};
+    const int n_tiles = (b.n_reads + TPB - 1) / TPB;
+    // consecutive tiles go to consecutive workgroups (-> different XCDs): every XCD's L2
+    // streams its own contiguous slices of the hit array, the genome lines are shared by L3.
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        if (tid == 0) q_n = 0;
+        __syncthreads();
+        const int r = tile * TPB + tid;
+        unsigned int nw = 0, ni = 0, nh = 0;
+        ReadView v;
+        bool active = r < b.n_reads;
+        bool do_gaps = false;
+        if (active) {
+            v = make_view(b, r);
+            nh = v.so[v.nseg] - v.so[0];
+            QueueSink qs{{q_a, q_b, q_c, q_d, &q_n}, (uint32_t)tid, 0u, 0u};
+            indels_enumerate(p, v, qs);
+            bool wants = false;
+            do_gaps = gaps_prepare(p, v, wants);
+            if (do_gaps) {
+                if (wants) { v.slots = slots + 2 * (size_t)pair_off[r]; v.rescue = true; }
+                gaps_enumerate(p, v, qs);
+            }
+            nw = qs.n_windows; ni = qs.n_indels;
+        }
+        if (nw) atomicAdd(&s_stat[0], nw);
+        if (ni) atomicAdd(&s_stat[1], ni);
+        if (nh) atomicAdd(&s_stat[2], nh);
+        __syncthreads();
+        const unsigned int total = q_n;
+        const unsigned int nq = total < (unsigned)QCAP ? total : (unsigned)QCAP;
+        for (unsigned int k = tid; k < nq; k += TPB) {
+            const uint32_t a = q_a[k];
+            const int tr = tile * TPB + (int)(a & 0xFF);
+            ReadView tv = make_view(b, tr);
+            const bool anti = (a >> 9) & 1u;
+            if (a & (1u << 8)) {
+                const bool is_del = (a >> 10) & 1u;
+                const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 127u);
+                const uint32_t d = q_d[k];
+                indel_exec(g, p, tv, i, q_b[k], q_c[k], anti, plen, is_del,
+                           ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(d & 0xFFFF), (int)(d >> 16)), ev);
+            } else {
+                const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 63u);
+                window_exec(g, p, tv, q_b[k], (int32_t)q_c[k], (int32_t)q_d[k], anti, start, slen, ev);
+            }
+        }
+        if (total > (unsigned)QCAP) {
+            // the queue overflowed (multihit-heavy tile): redo this tile un-queued.  Events are
+            // set inserts / atomicMin, so re-emitting the ones already done is harmless.
+            if (tid == 0) atomicAdd(&s_stat[3], 1u);
+            if (active) {
+                InlineSink is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                indels_enumerate(p, v, is);
+                if (do_gaps) gaps_enumerate(p, v, is);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd(&t.cnt[CNT_HITS], (unsigned long long)s_stat[2]);
+        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+    }
+}
+
+// ------------------------------------------------------------------ finish
+
+__global__ __launch_bounds__(256) void thj_k_compact(const u64* tab, const u64* vals, u64 cap, u64* out_keys,
+                                                     u64* out_vals, unsigned long long* out_n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
+        u64 k = tab[i];
+        if (k != EMPTY) {
+            unsigned long long pos = atomicAdd(out_n, 1ull);   // hipcc folds this into one atomic per wave
+            out_keys[pos] = k;
+            if (vals) out_vals[pos] = vals[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void thj_k_merge_keys(u64* tab, u64 mask, const u64* keys, int64_t n,
+                                                        unsigned long long* count, unsigned int* ovf) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        set_insert(tab, mask, keys[i], count, ovf);
+}
+
+// ------------------------------------------------------------------ context
+
+struct thj_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // genome
+    const u64* d_blocks = nullptr; bool own_blocks = false;
+    uint32_t* d_contig_blk = nullptr; int32_t* d_contig_len = nullptr;
+    std::vector<uint32_t> h_contig_blk; std::vector<int64_t> h_lens;
+    int32_t n_contigs = 0; int64_t n_blocks = 0;
+    // tables
+    int64_t junc_cap = 0, indel_cap = 0;
+    u64 *d_junc = nullptr, *d_del = nullptr, *d_ins_key = nullptr, *d_ins_val = nullptr;
+    unsigned int* d_ovf = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    // sorted outputs
+    u64 *d_junc_sorted = nullptr, *d_del_sorted = nullptr, *d_ins_key_sorted = nullptr, *d_ins_val_sorted = nullptr;
+    u64 *d_tmp_keys = nullptr, *d_tmp_vals = nullptr;
+    int64_t out_cap_junc = 0, out_cap_indel = 0;
+    unsigned long long* d_out_n = nullptr;      // [3]
+    unsigned long long* h_pinned = nullptr;     // [16] pinned staging
+    void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    int64_t n_junc = 0, n_del = 0, n_ins = 0;
+    // rescue scratch
+    uint32_t* d_npairs = nullptr; uint32_t* d_pair_off = nullptr; int64_t pairs_cap_reads = 0;
+    int32_t* d_slots = nullptr; int64_t slots_cap = 0;
+    void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<hipEvent_t> event_pool;
+};
+
+static int next_pow2(int64_t x, int64_t* out) {
+    int64_t p = 1024;
+    while (p < x) p <<= 1;
+    *out = p;
+    return 0;
+}
+
+static int free_tables(thj_ctx* c) {
+    hipFree(c->d_junc); hipFree(c->d_del); hipFree(c->d_ins_key); hipFree(c->d_ins_val);
+    hipFree(c->d_junc_sorted); hipFree(c->d_del_sorted); hipFree(c->d_ins_key_sorted); hipFree(c->d_ins_val_sorted);
+    hipFree(c->d_tmp_keys); hipFree(c->d_tmp_vals); hipFree(c->d_sort_tmp);
+    c->d_junc = c->d_del = c->d_ins_key = c->d_ins_val = nullptr;
+    c->d_junc_sorted = c->d_del_sorted = c->d_ins_key_sorted = c->d_ins_val_sorted = nullptr;
+    c->d_tmp_keys = c->d_tmp_vals = nullptr; c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+    return 0;
+}
+
+static int alloc_tables(thj_ctx* c, int64_t junc_cap, int64_t indel_cap) {
+    free_tables(c);
+    next_pow2(junc_cap, &c->junc_cap);
+    next_pow2(indel_cap, &c->indel_cap);
+    HIPCHK(hipMalloc(&c->d_junc, (size_t)c->junc_cap * 8));
+    HIPCHK(hipMalloc(&c->d_del, (size_t)c->indel_cap * 8));
+    HIPCHK(hipMalloc(&c->d_ins_key, (size_t)c->indel_cap * 8));
+    HIPCHK(hipMalloc(&c->d_ins_val, (size_t)c->indel_cap * 8));
+    // a table never holds more than 75 % + one wave of entries
+    c->out_cap_junc = c->junc_cap; c->out_cap_indel = c->indel_cap;
+    HIPCHK(hipMalloc(&c->d_junc_sorted, (size_t)c->out_cap_junc * 8));
+    HIPCHK(hipMalloc(&c->d_tmp_keys, (size_t)c->out_cap_junc * 8));
+    HIPCHK(hipMalloc(&c->d_del_sorted, (size_t)c->out_cap_indel * 8));
+    HIPCHK(hipMalloc(&c->d_ins_key_sorted, (size_t)c->out_cap_indel * 8));
+    HIPCHK(hipMalloc(&c->d_ins_val_sorted, (size_t)c->out_cap_indel * 8));
+    HIPCHK(hipMalloc(&c->d_tmp_vals, (size_t)c->out_cap_indel * 8));
+    size_t need = 0, need2 = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, (const u64*)nullptr, (u64*)nullptr, (int64_t)c->out_cap_junc, 0, 64, c->stream));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need2, (const u64*)nullptr, (u64*)nullptr, (const u64*)nullptr, (u64*)nullptr,
+                                              (int64_t)c->out_cap_indel, 0, 64, c->stream));
+    c->sort_tmp_bytes = need > need2 ? need : need2;
+    HIPCHK(hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
+    return THJ_OK;
+}
+
+static int reset_tables_async(thj_ctx* c) {
+    HIPCHK(hipMemsetAsync(c->d_junc, 0xFF, (size_t)c->junc_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_del, 0xFF, (size_t)c->indel_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ins_key, 0xFF, (size_t)c->indel_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ins_val, 0xFF, (size_t)c->indel_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ovf, 0, 4 * sizeof(unsigned int), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(unsigned long long), c->stream));
+    c->n_junc = c->n_del = c->n_ins = 0;
+    return THJ_OK;
+}
+
+extern "C" int thj_ctx_create(int device, void* stream, thj_ctx** out) {
+    if (!out) { thj_set_error("thj_ctx_create: null out"); return THJ_EINVAL; }
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) { thj_set_error("device %d not present (%d devices)", device, ndev); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(device));
+    thj_ctx* c = new thj_ctx();
+    c->device = device;
+    if (stream) c->stream = (hipStream_t)stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+    HIPCHK(hipMalloc(&c->d_ovf, 4 * sizeof(unsigned int)));
+    HIPCHK(hipMalloc(&c->d_cnt, CNT_N * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&c->d_out_n, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc(&c->h_pinned, 32 * sizeof(unsigned long long)));
+    int rc = alloc_tables(c, 1ll << 24, 1ll << 20);
+    if (rc) { delete c; return rc; }
+    rc = reset_tables_async(c);
+    if (rc) { delete c; return rc; }
+    *out = c;
+    return THJ_OK;
+}
+
+extern "C" void thj_ctx_destroy(thj_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_tables(c);
+    if (c->own_blocks) hipFree((void*)c->d_blocks);
+    hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
+    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n);
+    hipHostFree(c->h_pinned);
+    hipFree(c->d_npairs); hipFree(c->d_pair_off); hipFree(c->d_slots); hipFree(c->d_scan_tmp);
+    for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto e : c->event_pool) hipEventDestroy(e);
+    if (c->own_stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int thj_ctx_sync(thj_ctx* c) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return THJ_OK;
+}
+
+extern "C" void* thj_ctx_stream(thj_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+static int set_contigs(thj_ctx* c, const uint32_t* contig_blk, const int64_t* lens, int32_t n_contigs, int64_t n_blocks) {
+    hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
+    c->d_contig_blk = nullptr; c->d_contig_len = nullptr;
+    c->h_contig_blk.assign(contig_blk, contig_blk + n_contigs + 1);
+    c->h_lens.assign(lens, lens + n_contigs);
+    std::vector<int32_t> l32(n_contigs > 0 ? n_contigs : 1);
+    for (int32_t i = 0; i < n_contigs; ++i) {
+        if (lens[i] < 0 || lens[i] > 0x7fffffff) { thj_set_error("contig %d length unsupported", i); return THJ_EINVAL; }
+        l32[i] = (int32_t)lens[i];
+    }
+    HIPCHK(hipMalloc(&c->d_contig_blk, (size_t)(n_contigs + 1) * 4));
+    HIPCHK(hipMalloc(&c->d_contig_len, (size_t)(n_contigs > 0 ? n_contigs : 1) * 4));
+    HIPCHK(hipMemcpyAsync(c->d_contig_blk, contig_blk, (size_t)(n_contigs + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_contig_len, l32.data(), (size_t)n_contigs * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_contigs = n_contigs; c->n_blocks = n_blocks;
+    return THJ_OK;
+}
+
+extern "C" int thj_genome_upload(thj_ctx* c, const uint64_t* blocks, int64_t n_blocks, const uint32_t* contig_blk,
+                                 const int64_t* lens, int32_t n_contigs) {
+    if (!c || !blocks || !contig_blk || !lens || n_blocks <= 0) { thj_set_error("thj_genome_upload: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->own_blocks) hipFree((void*)c->d_blocks);
+    c->d_blocks = nullptr; c->own_blocks = false;
+    u64* d = nullptr;
+    HIPCHK(hipMalloc(&d, (size_t)n_blocks * 32));
+    HIPCHK(hipMemcpyAsync(d, blocks, (size_t)n_blocks * 32, hipMemcpyHostToDevice, c->stream));
+    c->d_blocks = d; c->own_blocks = true;
+    return set_contigs(c, contig_blk, lens, n_contigs, n_blocks);
+}
+
+extern "C" int thj_genome_adopt(thj_ctx* c, const void* d_blocks, int64_t n_blocks, const uint32_t* contig_blk,
+                                const int64_t* lens, int32_t n_contigs) {
+    if (!c || !d_blocks || !contig_blk || !lens) { thj_set_error("thj_genome_adopt: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->own_blocks) hipFree((void*)c->d_blocks);
+    c->d_blocks = (const u64*)d_blocks; c->own_blocks = false;
+    return set_contigs(c, contig_blk, lens, n_contigs, n_blocks);
+}
+
+// ------------------------------------------------------------------ batches
+
+struct OwnedBatch {
+    thj_seg_batch desc;        // device pointers; MUST be the first member
+    void* ptrs[6];
+};
+
+extern "C" int thj_batch_upload(thj_ctx* c, const thj_seg_batch* h, int64_t n_hits, int64_t n_mate_hits, thj_seg_batch** out) {
+    if (!c || !h || !out) { thj_set_error("thj_batch_upload: null argument"); return THJ_EINVAL; }
+    if (h->n_reads < 0 || h->nseg < 1 || h->nseg > 8 || h->words_per_plane < 1) { thj_set_error("thj_batch_upload: bad shape (nseg must be 1..8)"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    OwnedBatch* ob = new OwnedBatch();
+    memset(ob, 0, sizeof *ob);
+    ob->desc = *h;
+    const int64_t n = h->n_reads;
+    const size_t sizes[6] = {(size_t)(n * h->nseg + 1) * 4, (size_t)n_hits * 16, (size_t)n * 3 * h->words_per_plane * 8,
+                             (size_t)n * 2, h->mate_off ? (size_t)(n + 1) * 4 : 0, h->mate_off ? (size_t)n_mate_hits * 16 : 0};
+    const void* src[6] = {h->seg_off, h->hits, h->read_planes, h->read_len, h->mate_off, h->mate_hits};
+    for (int i = 0; i < 6; ++i) {
+        if (i >= 4 && !h->mate_off) { ob->ptrs[i] = nullptr; continue; }
+        HIPCHK(hipMalloc(&ob->ptrs[i], sizes[i] ? sizes[i] : 16));
+        if (sizes[i]) HIPCHK(hipMemcpyAsync(ob->ptrs[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
+    }
+    ob->desc.seg_off = (const uint32_t*)ob->ptrs[0];
+    ob->desc.hits = (const thj_hit*)ob->ptrs[1];
+    ob->desc.read_planes = (const uint64_t*)ob->ptrs[2];
+    ob->desc.read_len = (const uint16_t*)ob->ptrs[3];
+    ob->desc.mate_off = (const uint32_t*)ob->ptrs[4];
+    ob->desc.mate_hits = (const thj_hit*)ob->ptrs[5];
+    HIPCHK(hipStreamSynchronize(c->stream));     // host buffers may be released by the caller
+    *out = &ob->desc;
+    return THJ_OK;
+}
+
+extern "C" int thj_batch_free(thj_ctx* c, thj_seg_batch* dev) {
+    if (!c || !dev) return THJ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    OwnedBatch* ob = (OwnedBatch*)dev;
+    for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]);
+    delete ob;
+    return THJ_OK;
+}
+
+// ------------------------------------------------------------------ run
+
+extern "C" int thj_segjuncs_configure(thj_ctx* c, int64_t junc_capacity, int64_t indel_capacity) {
+    if (!c || junc_capacity < 1 || indel_capacity < 1) { thj_set_error("thj_segjuncs_configure: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc = alloc_tables(c, junc_capacity, indel_capacity);
+    if (rc) return rc;
+    return reset_tables_async(c);
+}
+
+extern "C" int thj_segjuncs_reset_async(thj_ctx* c) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return reset_tables_async(c);
+}
+
+static int check_params(const thj_params* p, const thj_seg_batch* b) {
+    if (p->segment_length < 10 || p->segment_length > 32) {
+        thj_set_error("segment_length %d unsupported by the device path (10..32: a 2L read piece and an L+16 support "
+                      "read must fit one 64-bit plane word)", p->segment_length);
+        return THJ_EINVAL;
+    }
+    if (p->max_insertion_length > 6 || p->max_insertion_length < 0) { thj_set_error("max_insertion_length %d unsupported (0..6)", p->max_insertion_length); return THJ_EINVAL; }
+    if (p->max_deletion_length < 0 || p->max_deletion_length > 1000000) { thj_set_error("max_deletion_length out of range"); return THJ_EINVAL; }
+    if (p->max_segment_intron + p->segment_length + 64 >= (1 << 29)) { thj_set_error("max_segment_intron too large for the packed key"); return THJ_EINVAL; }
+    if (b->nseg < 1 || b->nseg > 8) { thj_set_error("nseg %d unsupported (1..8)", b->nseg); return THJ_EINVAL; }
+    if (b->words_per_plane < 1 || b->words_per_plane > 4) { thj_set_error("words_per_plane %d unsupported (1..4)", b->words_per_plane); return THJ_EINVAL; }
+    if (b->n_reads < 0 || (int64_t)b->n_reads + b->ordinal_base >= (1ll << 29)) { thj_set_error("batch too large: read ordinals must stay below 2^29"); return THJ_EINVAL; }
+    return THJ_OK;
+}
+
+static hipEvent_t get_event(thj_ctx* c) {
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db) {
+    if (!c || !tp || !db) { thj_set_error("thj_segjuncs_run_async: null argument"); return THJ_EINVAL; }
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    int rc = check_params(tp, db);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if (db->n_reads == 0) return THJ_OK;
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    Params p;
+    memcpy(&p, tp, sizeof p);
+    DevBatch b;
+    memcpy(&b, db, sizeof b);
+    Tables t{c->d_junc, (u64)c->junc_cap - 1, c->d_del, (u64)c->indel_cap - 1, c->d_ins_key, c->d_ins_val,
+             (u64)c->indel_cap - 1, c->d_ovf, c->d_cnt};
+    const int n = b.n_reads;
+
+    if (b.mate_off) {
+        if (c->pairs_cap_reads < n) {
+            hipFree(c->d_npairs); hipFree(c->d_pair_off); hipFree(c->d_scan_tmp);
+            c->d_npairs = c->d_pair_off = nullptr; c->d_scan_tmp = nullptr;
+            HIPCHK(hipMalloc(&c->d_npairs, (size_t)(n + 1) * 4));
+            HIPCHK(hipMalloc(&c->d_pair_off, (size_t)(n + 1) * 4));
+            size_t need = 0;
+            HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, (uint32_t*)nullptr, (uint32_t*)nullptr, n + 1, c->stream));
+            HIPCHK(hipMalloc(&c->d_scan_tmp, need ? need : 16));
+            c->scan_tmp_bytes = need;
+            c->pairs_cap_reads = n;
+        }
+        HIPCHK(hipMemsetAsync(c->d_npairs + n, 0, 4, c->stream));
+        hipLaunchKernelGGL(thj_k_rescue_count, dim3((n + 255) / 256), dim3(256), 0, c->stream, p, b, c->d_npairs);
+        size_t tmp = c->scan_tmp_bytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_scan_tmp, tmp, c->d_npairs, c->d_pair_off, n + 1, c->stream));
+        HIPCHK(hipMemcpyAsync(&c->h_pinned[16], c->d_pair_off + n, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const int64_t total = (int64_t)(*(uint32_t*)&c->h_pinned[16]);
+        if (total > c->slots_cap) {
+            hipFree(c->d_slots);
+            c->d_slots = nullptr;
+            c->slots_cap = total + total / 4 + 1024;
+            HIPCHK(hipMalloc(&c->d_slots, (size_t)c->slots_cap * 8));
+        }
+        if (total > 0) {
+            int64_t blocks = (total + 255) / 256;
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL(thj_k_rescue_scan, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b,
+                               (const uint32_t*)c->d_pair_off, c->d_slots, c->d_cnt);
+        }
+        if (!c->d_slots) { c->slots_cap = 1024; HIPCHK(hipMalloc(&c->d_slots, (size_t)c->slots_cap * 8)); }
+    }
+
+    const int n_tiles = (n + TPB - 1) / TPB;
+    int grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;       // 256 CUs x 8 resident workgroups, grid-stride the rest
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profile) { e0 = get_event(c); e1 = get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
+    hipLaunchKernelGGL(thj_k_segjuncs, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t,
+                       (const uint32_t*)c->d_pair_off, (const int32_t*)c->d_slots);
+    if (c->profile) { HIPCHK(hipEventRecord(e1, c->stream)); c->prof_events.emplace_back(e0, e1); }
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_profile_segjuncs(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double sum = 0;
+    for (auto& pr : c->prof_events) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+        c->event_pool.push_back(pr.first);
+        c->event_pool.push_back(pr.second);
+    }
+    if (launches) *launches = (int64_t)c->prof_events.size();
+    if (avg_ms) *avg_ms = c->prof_events.empty() ? 0.0 : sum / (double)c->prof_events.size();
+    c->prof_events.clear();
+    c->profile = enable != 0;
+    return THJ_OK;
+}
+
+extern "C" int thj_segjuncs_merge_keys_async(thj_ctx* c, int kind, const uint64_t* d_keys, int64_t n) {
+    if (!c || (kind != 0 && kind != 1) || (n > 0 && !d_keys)) { thj_set_error("thj_segjuncs_merge_keys_async: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (n <= 0) return THJ_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (kind == 0)
+        hipLaunchKernelGGL(thj_k_merge_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_junc, (u64)c->junc_cap - 1,
+                           (const u64*)d_keys, n, &c->d_cnt[CNT_JUNC], &c->d_ovf[0]);
+    else
+        hipLaunchKernelGGL(thj_k_merge_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_del, (u64)c->indel_cap - 1,
+                           (const u64*)d_keys, n, &c->d_cnt[CNT_DEL], &c->d_ovf[1]);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_out_n, 0, 4 * sizeof(unsigned long long), c->stream));
+    auto blocks_for = [](int64_t cap) { int64_t b = (cap + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b); };
+    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->junc_cap)), dim3(256), 0, c->stream, (const u64*)c->d_junc,
+                       (const u64*)nullptr, (u64)c->junc_cap, c->d_tmp_keys, (u64*)nullptr, &c->d_out_n[0]);
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[0], c->d_out_n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[4], c->d_ovf, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[8], c->d_cnt, CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const unsigned int* ovf = (const unsigned int*)&c->h_pinned[4];
+    if (ovf[0] || ovf[1] || ovf[2]) {
+        thj_set_error("event table overflow (junc=%u del=%u ins=%u): call thj_segjuncs_configure with larger capacities and re-run",
+                      ovf[0], ovf[1], ovf[2]);
+        return THJ_EOVERFLOW;
+    }
+    c->n_junc = (int64_t)c->h_pinned[0];
+    size_t tmp = c->sort_tmp_bytes;
+    if (c->n_junc > 0)
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_junc_sorted, c->n_junc, 0, 64, c->stream));
+    // deletions
+    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_del,
+                       (const u64*)nullptr, (u64)c->indel_cap, c->d_tmp_keys, (u64*)nullptr, &c->d_out_n[1]);
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[1], c->d_out_n + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_del = (int64_t)c->h_pinned[1];
+    tmp = c->sort_tmp_bytes;
+    if (c->n_del > 0)
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_del_sorted, c->n_del, 0, 64, c->stream));
+    // insertions
+    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_ins_key,
+                       (const u64*)c->d_ins_val, (u64)c->indel_cap, c->d_tmp_keys, c->d_tmp_vals, &c->d_out_n[2]);
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[2], c->d_out_n + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_ins = (int64_t)c->h_pinned[2];
+    tmp = c->sort_tmp_bytes;
+    if (c->n_ins > 0)
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_ins_key_sorted,
+                                                  (const u64*)c->d_tmp_vals, c->d_ins_val_sorted, c->n_ins, 0, 64, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (counts) {
+        const unsigned long long* cnt = &c->h_pinned[8];
+        counts->n_juncs = c->n_junc; counts->n_deletions = c->n_del; counts->n_insertions = c->n_ins;
+        counts->n_windows = (int64_t)cnt[CNT_WINDOWS]; counts->n_indel_pairs = (int64_t)cnt[CNT_INDEL_PAIRS];
+        counts->n_rescue_pairs = (int64_t)cnt[CNT_RESCUE_PAIRS]; counts->n_overflow_blocks = (int64_t)cnt[CNT_OVF_BLOCKS];
+        counts->n_hits_read = (int64_t)cnt[CNT_HITS];
+    }
+    return THJ_OK;
+}
+
+extern "C" int thj_segjuncs_device_keys(thj_ctx* c, int kind, const uint64_t** d_keys, int64_t* n) {
+    if (!c || !d_keys || !n || (kind != 0 && kind != 1)) { thj_set_error("thj_segjuncs_device_keys: bad argument"); return THJ_EINVAL; }
+    *d_keys = kind == 0 ? (const uint64_t*)c->d_junc_sorted : (const uint64_t*)c->d_del_sorted;
+    *n = kind == 0 ? c->n_junc : c->n_del;
+    return THJ_OK;
+}
+
+static void decode_gpos(const thj_ctx* c, uint64_t gpos1, uint32_t* ref_id, uint32_t* pos) {
+    // gpos1 = contig_blk[ref-1]*64 + pos + 1, pos >= -1
+    int64_t gp = (int64_t)gpos1 - 1;
+    int lo = 0, hi = c->n_contigs;      // last contig whose start <= gp (+1 tolerance for pos = -1)
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if ((int64_t)c->h_contig_blk[mid] * 64 <= gp + 1) lo = mid; else hi = mid;
+    }
+    // pos = -1 of contig k would alias the guard block of contig k-1; guard blocks make that unambiguous
+    *ref_id = (uint32_t)lo + 1;
+    *pos = (uint32_t)(int32_t)(gp - (int64_t)c->h_contig_blk[lo] * 64);
+}
+
+extern "C" int thj_segjuncs_download(thj_ctx* c, thj_junction* juncs, thj_junction* dels, thj_insertion* ins) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<uint64_t> k, v;
+    auto get = [&](const u64* d, int64_t n, std::vector<uint64_t>& h) -> int {
+        h.resize((size_t)n);
+        if (n) HIPCHK(hipMemcpyAsync(h.data(), d, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return THJ_OK;
+    };
+    int rc;
+    if (c->n_junc && !juncs) { thj_set_error("null juncs buffer"); return THJ_EINVAL; }
+    if ((rc = get(c->d_junc_sorted, c->n_junc, k))) return rc;
+    for (int64_t i = 0; i < c->n_junc; ++i) {
+        uint32_t ref, pos;
+        decode_gpos(c, k[i] >> 30, &ref, &pos);
+        uint32_t len = (uint32_t)((k[i] >> 1) & ((1ull << 29) - 1));
+        juncs[i].ref_id = ref; juncs[i].left = pos; juncs[i].right = pos + len; juncs[i].antisense = (uint32_t)(k[i] & 1);
+    }
+    if (c->n_del && !dels) { thj_set_error("null deletions buffer"); return THJ_EINVAL; }
+    if ((rc = get(c->d_del_sorted, c->n_del, k))) return rc;
+    for (int64_t i = 0; i < c->n_del; ++i) {
+        uint32_t ref, pos;
+        decode_gpos(c, k[i] >> 30, &ref, &pos);
+        uint32_t len = (uint32_t)((k[i] >> 1) & ((1ull << 29) - 1));
+        dels[i].ref_id = ref; dels[i].left = pos; dels[i].right = pos + len; dels[i].antisense = 0;
+    }
+    if (c->n_ins && !ins) { thj_set_error("null insertions buffer"); return THJ_EINVAL; }
+    if ((rc = get(c->d_ins_key_sorted, c->n_ins, k))) return rc;
+    if ((rc = get(c->d_ins_val_sorted, c->n_ins, v))) return rc;
+    static const char code[8] = {'A', 'C', 'G', 'T', 'N', '?', '?', '?'};
+    for (int64_t i = 0; i < c->n_ins; ++i) {
+        uint32_t ref, pos;
+        decode_gpos(c, k[i] >> 4, &ref, &pos);
+        int len = (int)(k[i] & 15);
+        memset(&ins[i], 0, sizeof ins[i]);
+        ins[i].ref_id = ref; ins[i].left = pos;
+        uint32_t seq = (uint32_t)(v[i] & 0xFFFFFu);
+        for (int b = 0; b < len && b < 7; ++b) ins[i].seq[b] = code[(seq >> (3 * b)) & 7];
+        ins[i].prio = v[i] >> 20;
+    }
+    return THJ_OK;
+}
