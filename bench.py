@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- read-pairs/s through the MI355X junction-discovery hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--pairs P]
+
+A "step" is one pass of the hot path over one batch of synthetic paired reads
+whose inputs (packed genome, hit records, read planes) are already resident in
+HBM: reset the event tables, run the left-side batch, run the right-side
+batch, compact + sort the event sets (= one `segment_juncs` invocation on a
+batch).  N>1: one process per GPU (torch.distributed, backend nccl = RCCL), the
+genome replicated, read pairs sharded (weak scaling: every rank gets `--pairs`
+pairs), and one all-gather of the per-rank junction/deletion key sets over
+xGMI, merged into every rank's table (segment_juncs.cpp:4911-4916 across GPUs).
+
+Prints ONE JSON line (rank 0).  `value` = pairs processed by all ranks / time.
+`roofline` = algorithmic bytes of the dominant kernel (thj_k_segjuncs) per
+launch / its average duration from HIP events recorded on the launch stream,
+against the 8 TB/s HBM peak.  `cpu_baseline` = the plain-C oracle (a port, 1
+core) timed on a bounded sample of the same workload on this box's host.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from tophat_amd import host  # noqa: E402
+from tophat_amd.params import Params, READ_LEFT, READ_RIGHT  # noqa: E402
+from tophat_amd.synth import make_device_workload, make_scale_genome  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+CHR20_LEN = 64_444_167         # GRCh38 chr20 length (BASELINE.json configs[1])
+
+
+def cbatch_from_tensors(w, ordinal_base=0) -> host.CSegBatch:
+    cb = host.CSegBatch()
+    cb.n_reads, cb.nseg, cb.words_per_plane = w["n_reads"], w["nseg"], w["W"]
+    cb.seg_off = w["seg_off"].data_ptr()
+    cb.hits = w["hits"].data_ptr()
+    cb.read_planes = w["planes"].data_ptr()
+    cb.read_len = w["read_len"].data_ptr()
+    cb.mate_off = w["mate_off"].data_ptr()
+    cb.mate_hits = w["mate_hits"].data_ptr()
+    cb.ordinal_base = ordinal_base
+    return cb
+
+
+def sample_segbatch(w, m):
+    """First m reads of a device workload as a host SegBatch (ASCII reads) for the oracle."""
+    from tophat_amd.batch import HIT_DTYPE, SegBatch
+    nseg, W = w["nseg"], w["W"]
+    m = min(m, w["n_reads"])
+    so = w["seg_off"][:m * nseg + 1].cpu().numpy().astype(np.uint32)
+    hits = w["hits"][:int(so[-1])].cpu().numpy().astype(np.int32)
+    mo = w["mate_off"][:m + 1].cpu().numpy().astype(np.uint32)
+    mh = w["mate_hits"][:int(mo[-1])].cpu().numpy().astype(np.int32)
+    pl = w["planes"][:m * 3 * W].cpu().numpy().view(np.uint64).reshape(m, 3, W)
+    rl = w["read_len"][:m].cpu().numpy().astype(np.int64)
+    L = int(rl.max()) if m else 0
+    bits = np.arange(64, dtype=np.uint64)
+    lo = ((pl[:, 0, :, None] >> bits) & 1).reshape(m, -1)[:, :L]
+    hi = ((pl[:, 1, :, None] >> bits) & 1).reshape(m, -1)[:, :L]
+    nm = ((pl[:, 2, :, None] >> bits) & 1).reshape(m, -1)[:, :L]
+    codes = (lo + 2 * hi).astype(np.uint8)
+    asc = np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
+    asc[nm == 1] = ord("N")
+    read_off = np.zeros(m + 1, dtype=np.int64)
+    read_off[1:] = np.cumsum(rl)
+    if m and (rl == L).all():
+        bases = np.ascontiguousarray(asc).reshape(-1)
+    else:
+        bases = np.concatenate([asc[i, :rl[i]] for i in range(m)]) if m else np.zeros(0, dtype=np.uint8)
+    return SegBatch(nseg, np.arange(1, m + 1, dtype=np.uint32), read_off, bases, so,
+                    np.ascontiguousarray(hits).view(HIT_DTYPE).reshape(-1),
+                    mo, np.ascontiguousarray(mh).view(HIT_DTYPE).reshape(-1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (BASELINE config 2: 10 M)")
+    ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
+    ap.add_argument("--introns", type=int, default=20000)
+    ap.add_argument("--exon-len", type=int, default=300)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- workload: BASELINE.json configs[1] shape (per GPU) --------------------------------
+    t_gen = time.time()
+    seqs, genes = make_scale_genome(1, [args.genome_len], args.introns, exon_len=args.exon_len)
+    lib = host.load_lib()
+    strs = [s.tobytes().decode() for s in seqs]
+    pg = host.pack_genome(strs, lib=lib)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = host.Context(local_rank, stream=stream.cuda_stream)
+    ctx.upload_genome(pg)
+    w = make_device_workload(100 + rank, seqs, genes, None, args.pairs, dev, read_len=100, seg_len=25,
+                             inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    p_left = Params(read_side=READ_LEFT, inner_dist_mean=50, inner_dist_std_dev=20)
+    p_right = Params(read_side=READ_RIGHT, inner_dist_mean=50, inner_dist_std_dev=20)
+    cb_left = cbatch_from_tensors(w["left"], 0)
+    cb_right = cbatch_from_tensors(w["right"], 0)   # per-side ordinals: sides are merged left-first
+    ctx.configure(1 << 22, 1 << 20)
+
+    def allgather_merge():
+        """one all-gather of the sorted per-rank key sets over RCCL, merged into every table"""
+        import torch.distributed as dist
+        for kind in (0, 1):
+            ptr, n = ctx.device_keys(kind)
+            nt = torch.tensor([n], dtype=torch.int64, device=dev)
+            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(sizes, nt)
+            mx = max(int(s.item()) for s in sizes)
+            if mx == 0:
+                continue
+            mine = torch.zeros(mx, dtype=torch.int64, device=dev)
+            if n:
+                ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpyAsync(
+                    ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(n * 8), 3,
+                    ctypes.c_void_p(stream.cuda_stream))
+            stream.synchronize()
+            gathered = [torch.empty(mx, dtype=torch.int64, device=dev) for _ in range(world)]
+            dist.all_gather(gathered, mine)
+            torch.cuda.synchronize()
+            for r_, t_ in enumerate(gathered):
+                if r_ != rank and int(sizes[r_].item()):
+                    ctx.merge_keys(kind, t_.data_ptr(), int(sizes[r_].item()))
+        return ctx.finish()
+
+    def step():
+        ctx.reset()
+        ctx.run(p_left, cb_left)
+        ctx.run(p_right, cb_right)
+        cnt = ctx.finish()
+        if world > 1:
+            cnt = allgather_merge()
+        return cnt
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        cnt = step()
+    ctx.profile(True)
+    barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        cnt = step()
+    barrier()
+    elapsed = time.time() - t0
+    kern_ms, launches = ctx.profile(False)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- roofline of the dominant kernel (thj_k_segjuncs), per launch ------------------------
+    # algorithmic bytes (DESIGN.md "Roofline"): 16 B per hit record + 4 B per (read, segment) CSR
+    # offset + per RefSeg window 2 x 64 B genome lines + 38 B of support-read planes + per indel
+    # pair 64 B genome + 38 B read + 8 B per event emitted.  Counters come from the kernel itself.
+    n_launch = 2  # left + right per step
+    hits = cnt.n_hits_read / n_launch
+    csr = 4.0 * (args.pairs * w["left"]["nseg"] + 1)
+    rl_bytes = (100 + 3) // 4 + (100 + 7) // 8
+    alg = 16.0 * hits + csr + (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
+        + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
+    achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            import orc
+            m = min(args.cpu_sample, args.pairs)
+            og = orc.Genome(strs)
+            sb_l, sb_r = sample_segbatch(w["left"], m), sample_segbatch(w["right"], m)
+            t1 = time.time()
+            e_l = orc.segjuncs(p_left, og, sb_l)
+            e_r = orc.segjuncs(p_right, og, sb_r)
+            dt = time.time() - t1
+            cpu = {"value": m / dt, "unit": "read-pairs/s", "cores": 1, "kind": "port",
+                   "sample": "first %d pairs of the same synthetic batch, segment_juncs stage, oracle/liborc.so (plain C, 1 thread), %.1f s" % (m, dt)}
+        result = {
+            "metric": "paired reads/sec through segment_juncs+long_spanning_reads; junctions.bed diff=0",
+            "value": args.pairs * world * args.steps / elapsed,
+            "unit": "read-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 bit-planes (integer compare/popcount)", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d x 2x100 bp PE synthetic vs %d bp chr20-sized genome per GPU; "
+                                   "stage coverage: segment_juncs (gap/indel/rescue/window kernels + event dedup/sort"
+                                   "%s); long_spanning_reads stage not yet on device" % (
+                                       args.pairs, args.genome_len, " + RCCL key all-gather" if world > 1 else ""),
+                       "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
+                       "parallelism": "reads sharded x%d, genome replicated" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms, "launches": launches,
+                         "algorithmic_bytes_per_launch": alg},
+            "cpu_baseline": cpu,
+            "events": {"junctions": cnt.n_juncs, "deletions": cnt.n_deletions, "insertions": cnt.n_insertions,
+                       "windows_per_step": cnt.n_windows, "rescue_pairs_per_step": cnt.n_rescue_pairs,
+                       "overflow_blocks": cnt.n_overflow_blocks},
+            "gen_seconds": t_gen,
+        }
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

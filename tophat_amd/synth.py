@@ -341,3 +341,167 @@ def write_case(case: SynthCase, d: str) -> Dict[str, object]:
             f.writelines(case.full_sam[sd])
         paths["%s_map" % sd] = p
     return paths
+
+
+# ---------------------------------------------------------------------------
+# Scale generator (torch; runs on any device).  BASELINE.json config shapes.
+# ---------------------------------------------------------------------------
+
+def make_scale_genome(seed: int, contig_lens: Sequence[int], n_introns: int, intron_min: int = 70,
+                      intron_max: int = 200000, exon_len: int = 600):
+    """Random ACGT contigs with as many planted two-exon genes (exon-intron-exon) as fit, up to
+    n_introns: intron lengths log-uniform in [intron_min, intron_max], motifs GT-AG 90 % / GC-AG 7 % /
+    AT-AC 3 %, both strands.  Returns (list of uint8 ASCII numpy arrays, gene table int64[n,4] =
+    (contig, exon1_start, intron_start, intron_end))."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    seqs = []
+    genes = []
+    per = [int(round(n_introns * l / float(sum(contig_lens)))) for l in contig_lens]
+    comp = {ord("A"): ord("T"), ord("C"): ord("G"), ord("G"): ord("C"), ord("T"): ord("A")}
+    for ci, n in enumerate(contig_lens):
+        s = lut[rng.integers(0, 4, size=n, dtype=np.uint8)]
+        want = max(1, per[ci])
+        lens = np.exp(rng.uniform(np.log(intron_min), np.log(intron_max), size=want)).astype(np.int64)
+        pos = 1000
+        for il in lens:
+            if pos + 2 * exon_len + il + 1000 > n:
+                break
+            d0 = pos + exon_len            # first intron base
+            a1 = d0 + int(il)              # first base after the intron
+            u = rng.random()
+            don, acc = (b"GT", b"AG") if u < 0.90 else ((b"GC", b"AG") if u < 0.97 else (b"AT", b"AC"))
+            if rng.random() < 0.5:
+                s[d0:d0 + 2] = np.frombuffer(don, dtype=np.uint8)
+                s[a1 - 2:a1] = np.frombuffer(acc, dtype=np.uint8)
+            else:   # minus-strand gene: rc(acceptor) .. rc(donor)
+                s[d0:d0 + 2] = np.array([comp[acc[1]], comp[acc[0]]], dtype=np.uint8)
+                s[a1 - 2:a1] = np.array([comp[don[1]], comp[don[0]]], dtype=np.uint8)
+            genes.append((ci, pos, d0, a1))
+            pos = a1 + exon_len + 200
+        # a few N runs
+        for _ in range(5):
+            st = int(rng.integers(0, max(1, n - 2000)))
+            s[st:st + 1000] = ord("N")
+        seqs.append(s)
+    return seqs, np.array(genes, dtype=np.int64).reshape(-1, 4)
+
+
+def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int, device, read_len: int = 100,
+                         seg_len: int = 25, inner_mean: float = 50.0, inner_sd: float = 20.0, err: float = 0.01,
+                         exon_len: int = 600, chunk: int = 1 << 20):
+    """Synthesises both sides of `n_pairs` paired reads directly as device-resident thj_seg_batch arrays
+    (torch tensors).  Model: a fragment of 2*read_len + max(0, N(inner_mean, inner_sd)) bases drawn
+    uniformly from a gene's two-exon transcript; left read = its first read_len bases (sense), right
+    read = reverse complement of its last read_len bases; half of the pairs are flipped.  A segment is
+    mapped (one hit) where the truth puts it when it lies wholly in one exon and has <= 2 substitution
+    errors; segments that straddle the junction are unmapped.  The mate group of a read is the mate's
+    full-read hit when the mate is unspliced with <= 2 errors, else the mate's last-segment hit.
+    Returns {side: dict of tensors} with the field names of thj_seg_batch."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    nseg = max(1, read_len // seg_len)
+    W = (read_len + 63) // 64
+    # genome codes on device, concatenated, for base lookup
+    import numpy as np
+    code_lut = np.full(256, 4, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        code_lut[c] = i
+    offs = np.zeros(len(seqs_ascii) + 1, dtype=np.int64)
+    for i, s in enumerate(seqs_ascii):
+        offs[i + 1] = offs[i] + len(s)
+    gcodes = torch.empty(int(offs[-1]), dtype=torch.uint8, device=device)
+    for i, s in enumerate(seqs_ascii):
+        gcodes[int(offs[i]):int(offs[i + 1])] = torch.from_numpy(code_lut[s]).to(device)
+    coff = torch.from_numpy(offs).to(device)
+    genes_t = torch.from_numpy(genes).to(device)
+    E = exon_len
+    out = {}
+    sides = ("left", "right")
+    bufs = {sd: dict(planes=torch.zeros((n_pairs, 3 * W), dtype=torch.int64, device=device),
+                     read_len=torch.full((n_pairs,), read_len, dtype=torch.int16, device=device),
+                     seg_mapped=torch.zeros((n_pairs, nseg), dtype=torch.bool, device=device),
+                     seg_hits=torch.zeros((n_pairs, nseg, 4), dtype=torch.int32, device=device),
+                     full_ok=torch.zeros((n_pairs,), dtype=torch.bool, device=device),
+                     full_hit=torch.zeros((n_pairs, 4), dtype=torch.int32, device=device)) for sd in sides}
+    ar = torch.arange(read_len, device=device)
+    bitw = (torch.ones(64, dtype=torch.int64, device=device) << torch.arange(64, device=device))
+    for c0 in range(0, n_pairs, chunk):
+        n = min(chunk, n_pairs - c0)
+        gi = torch.randint(0, genes_t.shape[0], (n,), generator=g, device=device)
+        gene = genes_t[gi]                                   # contig, exon1_start, intron_start, intron_end
+        inner = torch.clamp(torch.randn(n, generator=g, device=device) * inner_sd + inner_mean, min=0).to(torch.int64)
+        frag = 2 * read_len + inner
+        t0 = (torch.rand(n, generator=g, device=device) * (2 * E - frag).clamp(min=1).to(torch.float32)).to(torch.int64)
+        flip = torch.rand(n, generator=g, device=device) < 0.5
+        ex1, d0, a1, ctg = gene[:, 1], gene[:, 2], gene[:, 3], gene[:, 0]
+        for sd in sides:
+            first = (sd == "left")
+            # which end of the fragment this read takes, and its strand
+            at_start = torch.where(flip, torch.tensor(not first, device=device), torch.tensor(first, device=device))
+            anti = ~at_start
+            ft0 = torch.where(at_start, t0, t0 + frag - read_len)      # transcript offset of the forward piece F
+            tpos = ft0[:, None] + ar[None, :]                           # (n, rl) transcript coords of F
+            gpos = torch.where(tpos < E, ex1[:, None] + tpos, a1[:, None] + (tpos - E))
+            F = gcodes[(coff[ctg][:, None] + gpos)]
+            # substitution errors
+            errm = torch.rand((n, read_len), generator=g, device=device) < err
+            sub = torch.randint(1, 4, (n, read_len), generator=g, device=device, dtype=torch.uint8)
+            isn = F == 4
+            Fm = torch.where(errm & ~isn, (F + sub) & 3, F)
+            mism = (errm & ~isn) | isn            # an N in the genome mismatches any read base we emit (A)
+            Fm = torch.where(isn, torch.zeros_like(Fm), Fm)
+            # read as sequenced
+            seq = torch.where(anti[:, None], (3 - Fm).flip(1), Fm)
+            pad = torch.zeros((n, W * 64), dtype=torch.int64, device=device)
+            pad[:, :read_len] = seq.to(torch.int64)
+            pw = pad.view(n, W, 64)
+            lo = ((pw & 1) * bitw).sum(-1)
+            hi = (((pw >> 1) & 1) * bitw).sum(-1)
+            b = bufs[sd]
+            b["planes"][c0:c0 + n, 0:W] = lo
+            b["planes"][c0:c0 + n, W:2 * W] = hi
+            # segments: segment k of the read covers F[f0:f1]
+            cm = torch.cumsum(mism.to(torch.int32), 1)
+            cm = torch.cat([torch.zeros((n, 1), dtype=torch.int32, device=device), cm], 1)
+            for k in range(nseg):
+                s0, s1 = k * seg_len, (read_len if k == nseg - 1 else (k + 1) * seg_len)
+                f0 = torch.where(anti, torch.tensor(read_len - s1, device=device), torch.tensor(s0, device=device))
+                ln = s1 - s0
+                ts = ft0 + f0
+                inside = (ts + ln <= E) | (ts >= E)
+                nm = cm.gather(1, (f0 + ln)[:, None]).squeeze(1) - cm.gather(1, f0[:, None]).squeeze(1)
+                ok = inside & (nm <= 2)
+                left = torch.where(ts < E, ex1 + ts, a1 + (ts - E))
+                meta = anti.to(torch.int32) | (2 if k == nseg - 1 else 0) | (nm << 8) | (nm << 16) | (ln << 24)
+                b["seg_mapped"][c0:c0 + n, k] = ok
+                b["seg_hits"][c0:c0 + n, k, 0] = (ctg + 1).to(torch.int32)
+                b["seg_hits"][c0:c0 + n, k, 1] = left.to(torch.int32)
+                b["seg_hits"][c0:c0 + n, k, 2] = (left + ln).to(torch.int32)
+                b["seg_hits"][c0:c0 + n, k, 3] = meta.to(torch.int32)
+            nm_all = cm[:, read_len]
+            unspliced = (ft0 + read_len <= E) | (ft0 >= E)
+            b["full_ok"][c0:c0 + n] = unspliced & (nm_all <= 2)
+            fl = torch.where(ft0 < E, ex1 + ft0, a1 + (ft0 - E))
+            b["full_hit"][c0:c0 + n, 0] = (ctg + 1).to(torch.int32)
+            b["full_hit"][c0:c0 + n, 1] = fl.to(torch.int32)
+            b["full_hit"][c0:c0 + n, 2] = (fl + read_len).to(torch.int32)
+            b["full_hit"][c0:c0 + n, 3] = (anti.to(torch.int32) | 2 | (nm_all << 8) | (nm_all << 16) | (read_len << 24)).to(torch.int32)
+    del gcodes
+    for sd in sides:
+        b = bufs[sd]
+        other = bufs["right" if sd == "left" else "left"]
+        mapped = b["seg_mapped"].reshape(-1)
+        seg_off = torch.zeros(n_pairs * nseg + 1, dtype=torch.int32, device=device)
+        seg_off[1:] = torch.cumsum(mapped.to(torch.int32), 0)
+        hits = b["seg_hits"].reshape(-1, 4)[mapped].contiguous()
+        m_has = other["full_ok"] | other["seg_mapped"][:, nseg - 1]
+        mate_off = torch.zeros(n_pairs + 1, dtype=torch.int32, device=device)
+        mate_off[1:] = torch.cumsum(m_has.to(torch.int32), 0)
+        mh = torch.where(other["full_ok"][:, None], other["full_hit"], other["seg_hits"][:, nseg - 1, :])[m_has].contiguous()
+        out[sd] = dict(n_reads=n_pairs, nseg=nseg, W=W, seg_off=seg_off, hits=hits,
+                       planes=b["planes"].reshape(-1).contiguous(), read_len=b["read_len"],
+                       mate_off=mate_off, mate_hits=mh)
+    return out
