@@ -120,6 +120,72 @@ int orc_simple_split(const char* shorter, const char* left_ref, const char* righ
 /* map_read_to_contig (segment_juncs.cpp:2946-2973). */
 int orc_map_read_to_contig(const char* contig, int contig_len, const char* read, int read_len);
 
+
+/* ===================== long_spanning_reads (spanning_oracle.c) ===================== */
+
+/* CigarOpCode values of bwt_map.h:36-55 */
+enum { ORC_MATCH = 1, ORC_mATCH = 2, ORC_INS = 3, ORC_iNS = 4, ORC_DEL = 5, ORC_dEL = 6,
+       ORC_REF_SKIP = 11, ORC_rEF_SKIP = 12, ORC_SOFT_CLIP = 13, ORC_HARD_CLIP = 14, ORC_PAD = 15 };
+#define ORC_CIG(op, len) (((uint32_t)(op) << 28) | ((uint32_t)(len) & 0x0FFFFFFFu))
+#define ORC_CIG_OP(c)  ((int)((c) >> 28))
+#define ORC_CIG_LEN(c) ((uint32_t)((c) & 0x0FFFFFFFu))
+
+/* A segment alignment with its CIGAR (BowtieHit, bwt_map.h:36-536), 32 bytes.
+ * Same layout as thj_span_hit in include/thj.h. */
+typedef struct {
+    uint32_t ref_id;
+    int32_t  left;
+    uint8_t  flags;        /* bit0 antisense_align, bit1 end(), bit2 antisense_splice */
+    uint8_t  mismatches;
+    uint8_t  edit_dist;
+    uint8_t  n_cigar;      /* 1..5 */
+    uint32_t cigar[5];     /* ORC_CIG(op, len) */
+} orc_span_hit;
+#define ORC_HIT_ANTISENSE_SPLICE 4u
+
+typedef struct {
+    int32_t segment_length;
+    int32_t max_insertion_length, max_deletion_length;
+    int32_t min_report_intron, max_report_intron;
+    int32_t max_seg_multihits;
+    int32_t read_mismatches, read_gap_length, read_edit_dist;
+    int32_t bowtie2;
+    int32_t bowtie2_max_penalty, bowtie2_min_penalty, bowtie2_penalty_for_N;
+    int32_t bowtie2_read_gap_open, bowtie2_read_gap_cont, bowtie2_ref_gap_open, bowtie2_ref_gap_cont;
+} orc_span_params;
+
+typedef struct {
+    int32_t         n_reads, nseg;
+    const int64_t*  read_off;      /* [n_reads+1] into bases / quals */
+    const char*     bases;
+    const char*     quals;         /* phred+33 as in the FASTQ */
+    const int64_t*  seg_off;       /* [n_reads*nseg+1] */
+    const orc_span_hit* hits;      /* per (read, segment): contig hits then spliced hits
+                                      (long_spanning_reads.cpp:2706-2765, :87-163) */
+} orc_span_batch;
+
+typedef struct { uint32_t ref_id, left; char seq[16]; } orc_ins_in;
+
+typedef struct {
+    int32_t  read_idx;
+    uint32_t ref_id;
+    int32_t  left;
+    uint8_t  antisense, antisense_splice, mismatches, edit_dist;
+    int32_t  n_cigar;
+    uint32_t cigar[24];
+    int32_t  AS, XM, XO, XG;
+    char     md[96];
+} orc_aln;
+
+/* join_segments_for_read + sort/unique + filters + bowtie_sam_extra for every read of the batch
+ * (JoinSegmentsWorker::operator(), long_spanning_reads.cpp:2669-2845), fusion search off.
+ * juncs must be sorted by Junction::operator< (junctions.h:39-57) and hold the deletions too
+ * (long_spanning_reads.cpp:2897-2944); insertions sorted by (ref,left,len).  *out is malloc'd. */
+int orc_spanning_batch(const orc_span_params* p, const orc_genome* g, const orc_span_batch* b,
+                       const orc_junction* juncs, int64_t n_juncs, const orc_ins_in* ins, int64_t n_ins,
+                       orc_aln** out, int64_t* n_out);
+void orc_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

@@ -103,3 +103,60 @@ def segjuncs(p: Params, g: Genome, b: SegBatch) -> Events:
                   "rescue_pairs": int(ev.n_rescue_pairs)})
     lib.orc_events_free(C.byref(ev))
     return out
+
+
+# ---------------------------------------------------------------- long_spanning_reads
+
+class OrcSpanParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "segment_length", "max_insertion_length", "max_deletion_length", "min_report_intron", "max_report_intron",
+        "max_seg_multihits", "read_mismatches", "read_gap_length", "read_edit_dist", "bowtie2",
+        "bowtie2_max_penalty", "bowtie2_min_penalty", "bowtie2_penalty_for_N",
+        "bowtie2_read_gap_open", "bowtie2_read_gap_cont", "bowtie2_ref_gap_open", "bowtie2_ref_gap_cont")]
+
+
+class OrcSpanBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("nseg", C.c_int32), ("read_off", C.c_void_p), ("bases", C.c_void_p),
+                ("quals", C.c_void_p), ("seg_off", C.c_void_p), ("hits", C.c_void_p)]
+
+
+class OrcInsIn(C.Structure):
+    _fields_ = [("ref_id", C.c_uint32), ("left", C.c_uint32), ("seq", C.c_char * 16)]
+
+
+class OrcAln(C.Structure):
+    _fields_ = [("read_idx", C.c_int32), ("ref_id", C.c_uint32), ("left", C.c_int32),
+                ("antisense", C.c_uint8), ("antisense_splice", C.c_uint8), ("mismatches", C.c_uint8), ("edit_dist", C.c_uint8),
+                ("n_cigar", C.c_int32), ("cigar", C.c_uint32 * 24),
+                ("AS", C.c_int32), ("XM", C.c_int32), ("XO", C.c_int32), ("XG", C.c_int32), ("md", C.c_char * 96)]
+
+
+def spanning(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> list:
+    """-> list of tophat_amd.batch.Aln in output order"""
+    from tophat_amd.batch import Aln
+    lib = _lib()
+    op = OrcSpanParams()
+    for n, _ in OrcSpanParams._fields_:
+        setattr(op, n, int(getattr(p, n)))
+    ob = OrcSpanBatch()
+    ob.n_reads, ob.nseg = b.n_reads, b.nseg
+    keep = [np.ascontiguousarray(b.read_off, dtype=np.int64), np.ascontiguousarray(b.bases, dtype=np.uint8),
+            np.ascontiguousarray(b.quals, dtype=np.uint8), np.ascontiguousarray(b.seg_off, dtype=np.int64),
+            np.ascontiguousarray(b.hits)]
+    ob.read_off, ob.bases, ob.quals, ob.seg_off, ob.hits = [a.ctypes.data for a in keep]
+    j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
+    ins = (OrcInsIn * max(1, len(insertions)))()
+    for k, (ref, left, seq) in enumerate(insertions):
+        ins[k].ref_id, ins[k].left, ins[k].seq = ref, left, seq.encode()
+    out = C.POINTER(OrcAln)()
+    n_out = C.c_int64()
+    rc = lib.orc_spanning_batch(C.byref(op), C.byref(g.c), C.byref(ob), C.c_void_p(j.ctypes.data), C.c_int64(len(j)),
+                                ins, C.c_int64(len(insertions)), C.byref(out), C.byref(n_out))
+    assert rc == 0
+    res = []
+    for k in range(n_out.value):
+        a = out[k]
+        res.append(Aln(a.read_idx, a.ref_id, a.left, bool(a.antisense), bool(a.antisense_splice), a.mismatches, a.edit_dist,
+                       tuple(a.cigar[i] for i in range(a.n_cigar)), a.AS, a.XM, a.XO, a.XG, a.md.decode()))
+    lib.orc_free(out)
+    return res

@@ -63,11 +63,11 @@ class SegBatch:
 
 # One parsed alignment record of a segment / read map, before grouping.
 # (read_id, ref_id, left, right, antisense, end, mismatches, edit_dist, read_len)
-HitRec = Tuple[int, int, int, int, bool, bool, int, int, int]
+HitRec = tuple   # + optional (cigar [(op,len)...], antisense_splice) for long_spanning_reads
 
 
 def hit_tuple_to_struct(h: HitRec) -> tuple:
-    _, ref_id, left, right, anti, end, mm, ed, rl = h
+    _, ref_id, left, right, anti, end, mm, ed, rl = h[:9]
     return (ref_id, left, right, (HIT_ANTISENSE if anti else 0) | (HIT_END if end else 0),
             ed & 0xFF, mm & 0xFF, min(rl, 255))
 
@@ -196,3 +196,123 @@ def write_segment_files(ev: Events, ref_names: Sequence[str],
             f.write("%s\t%d\t%d\t%s\n" % (ref_names[ref - 1], left, left, seq))
     if fus_path:
         open(fus_path, "w").close()
+
+
+# ------------------------------------------------------- long_spanning_reads
+
+SPAN_HIT_DTYPE = np.dtype([
+    ("ref_id", "<u4"), ("left", "<i4"),
+    ("flags", "u1"), ("mismatches", "u1"), ("edit_dist", "u1"), ("n_cigar", "u1"),
+    ("cigar", "<u4", (5,)),
+])
+assert SPAN_HIT_DTYPE.itemsize == 32
+HIT_ANTISENSE_SPLICE = 4
+
+CIG_MATCH, CIG_INS, CIG_DEL, CIG_REF_SKIP, CIG_SOFT_CLIP = 1, 3, 5, 11, 13   # bwt_map.h:36-55
+CIG_CHARS = {1: "M", 2: "m", 3: "I", 4: "i", 5: "D", 6: "d", 11: "N", 12: "n", 13: "S"}
+
+
+def cig_pack(op: int, length: int) -> int:
+    return ((op & 0xF) << 28) | (length & 0x0FFFFFFF)
+
+
+def cigar_string(cigar: Sequence[int]) -> str:
+    """print_bamhit / GBamRecord::set_cigar: letters are upper-cased in the BAM record"""
+    return "".join("%d%s" % (c & 0x0FFFFFFF, CIG_CHARS[c >> 28].upper()) for c in cigar)
+
+
+@dataclass
+class SpanBatch:
+    """Per-read segment hit lists for long_spanning_reads: for each read that has a hit in the
+    first segment map, segment s holds the contig hits then the spliced hits of that segment
+    (long_spanning_reads.cpp:2706-2765 and :87-163)."""
+    nseg: int
+    read_id: np.ndarray            # u32[n]
+    read_off: np.ndarray           # i64[n+1]
+    bases: np.ndarray              # u8
+    quals: np.ndarray              # u8 (phred+33), same offsets
+    seg_off: np.ndarray            # u32[n*nseg+1]
+    hits: np.ndarray               # SPAN_HIT_DTYPE
+
+    @property
+    def n_reads(self) -> int:
+        return int(self.read_id.shape[0])
+
+
+def span_hit_struct(h: HitRec) -> tuple:
+    _, ref_id, left, _right, anti, end, mm, ed, _rl = h[:9]
+    cigar = h[9] if len(h) > 9 else [(CIG_MATCH, _rl)]
+    asp = bool(h[10]) if len(h) > 10 else False
+    if len(cigar) > 5:
+        raise ValueError("segment hit with %d CIGAR ops (device path supports <= 5)" % len(cigar))
+    cig = [cig_pack(o, n) for (o, n) in cigar] + [0] * (5 - len(cigar))
+    return (ref_id, left, (HIT_ANTISENSE if anti else 0) | (HIT_END if end else 0) | (HIT_ANTISENSE_SPLICE if asp else 0),
+            mm & 0xFF, ed & 0xFF, len(cigar), cig)
+
+
+def build_span_batch(seg_recs: Sequence[Iterable[HitRec]], reads: Dict[int, str], quals: Dict[int, str],
+                     spliced_recs: Optional[Sequence[Iterable[HitRec]]] = None) -> SpanBatch:
+    nseg = len(seg_recs)
+    groups = [group_by_id(r) for r in seg_recs]
+    sgroups = [group_by_id(r) for r in spliced_recs] if spliced_recs else [{} for _ in range(nseg)]
+    ids = sorted(set(groups[0].keys()) | set(sgroups[0].keys())) if nseg else []
+    read_id, read_off, seg_off, hits = [], [0], [0], []
+    bases, qs = bytearray(), bytearray()
+    for rid in ids:
+        if rid == 0:
+            continue
+        if rid not in reads:
+            raise KeyError("could not get read # %d from stream" % rid)      # long_spanning_reads.cpp:2832-2836
+        read_id.append(rid)
+        bases += reads[rid].encode()
+        qs += quals[rid].encode()
+        read_off.append(len(bases))
+        for s in range(nseg):
+            for h in list(groups[s].get(rid, ())) + list(sgroups[s].get(rid, ())):
+                hits.append(span_hit_struct(h))
+            seg_off.append(len(hits))
+    return SpanBatch(nseg, np.asarray(read_id, dtype=np.uint32), np.asarray(read_off, dtype=np.int64),
+                     np.frombuffer(bytes(bases), dtype=np.uint8).copy(), np.frombuffer(bytes(qs), dtype=np.uint8).copy(),
+                     np.asarray(seg_off, dtype=np.uint32),
+                     np.array(hits, dtype=SPAN_HIT_DTYPE) if hits else np.zeros(0, dtype=SPAN_HIT_DTYPE))
+
+
+@dataclass
+class Aln:
+    """One output record of long_spanning_reads, the fields print_bamhit writes (bwt_map.cpp:1888-2093)."""
+    read_idx: int
+    ref_id: int
+    left: int
+    antisense: bool
+    antisense_splice: bool
+    mismatches: int
+    edit_dist: int
+    cigar: Tuple[int, ...]
+    AS: int
+    XM: int
+    XO: int
+    XG: int
+    MD: str
+
+    def sam_fields(self, read_id: int, ref_names: Sequence[str]) -> tuple:
+        """(QNAME, FLAG, RNAME, POS, CIGAR, tags...) as in the BAM record"""
+        indel = sum(c & 0x0FFFFFFF for c in self.cigar if (c >> 28) in (3, 4, 5, 6))
+        tags = ["AS:i:%d" % self.AS, "XM:i:%d" % self.XM, "XO:i:%d" % self.XO, "XG:i:%d" % self.XG,
+                "MD:Z:%s" % self.MD, "NM:i:%d" % (self.mismatches + indel)]
+        if any((c >> 28) in (11, 12) for c in self.cigar):
+            tags.append("XS:A:%s" % ("-" if self.antisense_splice else "+"))
+        return (str(read_id), 16 if self.antisense else 0, ref_names[self.ref_id - 1], self.left + 1,
+                cigar_string(self.cigar)) + tuple(tags)
+
+
+def events_to_span_inputs(ev: Events):
+    """Junction + deletion sets merged the way long_spanning_reads loads them
+    (long_spanning_reads.cpp:2897-2944: a deletion line `left+1, right` becomes Junction(left, right, '+'))
+    and the insertion list."""
+    j = ev.juncs
+    if len(ev.deletions):
+        j = np.concatenate([j, ev.deletions])
+    if len(j):
+        j = np.unique(j)
+        j = j[np.lexsort((j["antisense"], j["right"], j["left"], j["ref_id"]))]
+    return j, list(ev.insertions)

@@ -53,9 +53,14 @@ def parse_sam_hits(path: str, ref_ids: Dict[str, int], max_report_intron: int = 
             if rname == "*" or (flag & 4):
                 continue
             nm = 0
+            xs_minus = False
             for tag in t[11:]:
                 if tag.startswith("NM:i:"):
                     nm = int(tag[5:])
+                elif tag.startswith("XS:A:"):
+                    xs_minus = tag[5:6] == "-"
+            ops = []
+            spliced = False
             mism = nm & 0xFF
             right = pos - 1
             read_len = 0
@@ -66,6 +71,11 @@ def parse_sam_hits(path: str, ref_ids: Dict[str, int], max_report_intron: int = 
                 if n <= 0:
                     ok = False
                     break
+                opcode = {"M": 1, "I": 3, "D": 5, "N": 11, "S": 13, "H": 14, "P": 15}.get(op)
+                if opcode is not None and op != "H":
+                    ops.append((opcode, n))
+                if op == "N":
+                    spliced = True
                 if op == "M":
                     right += n
                     read_len += n
@@ -93,7 +103,8 @@ def parse_sam_hits(path: str, ref_ids: Dict[str, int], max_report_intron: int = 
                 continue
             if rnext not in ("*", "=", rname):
                 continue
-            yield (rid, ref_ids[rname], pos - 1, right, bool(flag & 0x10), end, mism, (mism + gap) & 0xFF, read_len)
+            yield (rid, ref_ids[rname], pos - 1, right, bool(flag & 0x10), end, mism, (mism + gap) & 0xFF, read_len,
+                   ops, xs_minus and spliced)   # antisense_splice only kept for spliced hits (bwt_map.cpp:1419-1448)
 
 
 def read_fastq(path: str) -> Dict[int, str]:

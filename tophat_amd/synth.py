@@ -147,12 +147,36 @@ def _place_piece(gseq: str, exons, t0: int, ln: int, piece: str, max_mm: int, ov
     return pos, nm
 
 
+def _place_spliced(gseq: str, exons, t0: int, ln: int, piece: str):
+    """Transcript interval [t0,t0+ln) that crosses exactly one exon-exon junction ->
+    (pos, a_len, gap, b_len, nm, ref_bases) or None."""
+    cum = 0
+    for i, (a, b) in enumerate(exons):
+        el = b - a
+        if cum <= t0 < cum + el:
+            a_len = cum + el - t0
+            if a_len >= ln or i + 1 >= len(exons):
+                return None
+            b_len = ln - a_len
+            na, nb = exons[i + 1]
+            if b_len > nb - na:
+                return None
+            pos = a + (t0 - cum)
+            ref = gseq[pos:pos + a_len] + gseq[na:na + b_len]
+            nm = sum(1 for r, q in zip(ref, piece) if r != q)
+            if nm > 2:
+                return None
+            return pos, a_len, na - b, b_len, nm, ref
+        cum += el
+    return None
+
+
 def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int = 300,
               read_len: int = 100, seg_len: int = 25, paired: bool = False,
               err: float = 0.01, indel_frac: float = 0.08, n_frac: float = 0.02,
               genes_per_contig: int = 12, intron_range=(60, 3000), inner_mean: int = 50,
               inner_sd: int = 20, repeat_frac: float = 0.0, drop_seg_frac: float = 0.03,
-              overhang: int = 3) -> SynthCase:
+              overhang: int = 3, spliced_seg_frac: float = 0.0, boundary_bias: float = 0.0) -> SynthCase:
     rng = random.Random(seed)
     names, seqs, genes = make_genome(rng, contig_lens, genes_per_contig, intron_range)
     # optional planted repeats -> multihits
@@ -187,7 +211,7 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
         case.full_sam[sd] = []
         case.full_recs[sd] = []
 
-    def emit(sd: str, rid: int, frag_exons, t0: int, anti: bool, gref: int, with_indel: bool):
+    def emit(sd: str, rid: int, frag_exons, t0: int, anti: bool, gref: int, with_indel: bool, gene_strand: str = "+"):
         """fragment = transcript interval [t0, t0+read_len) of the exon chain."""
         gseq = seqs[gref]
         tx = "".join(gseq[a:b] for (a, b) in frag_exons)
@@ -243,6 +267,20 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
                 if cand is not None and (placed is None or cand[1] < placed[1]):
                     placed = cand
             if placed is None:
+                # a segment that straddles a junction: optionally emit the spliced alignment the
+                # junction-db mapping (juncs_db + bowtie + SplicedBAMHitFactory) would produce
+                if spliced_seg_frac > 0 and not indel and rng.random() < spliced_seg_frac:
+                    sp = _place_spliced(gseq, frag_exons, t0 + f0, f1 - f0, piece)
+                    if sp is not None:
+                        spos, a_len, gap, b_len, snm, sref = sp
+                        nm_, md = md_nm(sref, piece)
+                        flag = 16 if anti else 0
+                        qn = "%d|%d:%d:%d" % (rid, s0, k, nseg)
+                        xs = "-" if gene_strand == "-" else "+"
+                        case.seg_sam[sd][k].append("%s\t%d\t%s\t%d\t255\t%dM%dN%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\tXS:A:%s\n" % (
+                            qn, flag, names[gref], spos + 1, a_len, gap, b_len, piece, "I" * (f1 - f0), nm_, md, xs))
+                        case.seg_recs[sd][k].append((rid, gref + 1, spos, spos + a_len + gap + b_len, anti, k == nseg - 1, nm_, nm_,
+                                                     f1 - f0, [(1, a_len), (11, gap), (1, b_len)], xs == "-"))
                 continue
             pos, nm = placed
             places = [(gref, pos, nm)]
@@ -261,7 +299,7 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
                 qn = "%d|%d:%d:%d" % (rid, s0, k, nseg)
                 case.seg_sam[sd][k].append("%s\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\n" % (
                     qn, flag, names[pc], pp + 1, f1 - f0, piece, "I" * (f1 - f0), nm_, md))
-                case.seg_recs[sd][k].append((rid, pc + 1, pp, pp + (f1 - f0), anti, k == nseg - 1, nm_, nm_, f1 - f0))
+                case.seg_recs[sd][k].append((rid, pc + 1, pp, pp + (f1 - f0), anti, k == nseg - 1, nm_, nm_, f1 - f0, [(1, f1 - f0)], False))
         # full-read map: only when the fragment is unspliced and indel-free
         if not indel:
             placed = _place_piece(gseq, frag_exons, t0, read_len, F, 2, 0)
@@ -270,7 +308,7 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
                 nm_, md = md_nm(gseq[pos:pos + read_len], F)
                 case.full_sam[sd].append("%d\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\n" % (
                     rid, 16 if anti else 0, names[gref], pos + 1, read_len, F, "I" * read_len, nm_, md))
-                case.full_recs[sd].append((rid, gref + 1, pos, pos + read_len, anti, True, nm_, nm_, read_len))
+                case.full_recs[sd].append((rid, gref + 1, pos, pos + read_len, anti, True, nm_, nm_, read_len, [(1, read_len)], False))
         return True
 
     rid = 0
@@ -286,7 +324,11 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
         if rng.random() < 0.6:
             j = rng.randrange(len(g.exons) - 1)
             cum = sum(b - a for a, b in g.exons[:j + 1])
-            t0 = cum - rng.randint(3, read_len - 3)
+            if rng.random() < boundary_bias:     # junction within +-4 of a segment boundary
+                kb = rng.randint(1, max(1, nseg - 1))
+                t0 = cum - (kb * seg_len + rng.randint(-4, 4))
+            else:
+                t0 = cum - rng.randint(3, read_len - 3)
             if paired and rng.random() < 0.5:
                 t0 -= frag_len - read_len
         else:
@@ -298,10 +340,10 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
             flip = rng.random() < 0.5
             l_anti, r_anti = (True, False) if flip else (False, True)
             l_t0, r_t0 = (t0 + frag_len - read_len, t0) if flip else (t0, t0 + frag_len - read_len)
-            emit("left", rid, g.exons, l_t0, l_anti, g.ref, rng.random() < indel_frac)
-            emit("right", rid, g.exons, r_t0, r_anti, g.ref, rng.random() < indel_frac)
+            emit("left", rid, g.exons, l_t0, l_anti, g.ref, rng.random() < indel_frac, g.strand)
+            emit("right", rid, g.exons, r_t0, r_anti, g.ref, rng.random() < indel_frac, g.strand)
         else:
-            emit("left", rid, g.exons, t0, rng.random() < 0.5, g.ref, rng.random() < indel_frac)
+            emit("left", rid, g.exons, t0, rng.random() < 0.5, g.ref, rng.random() < indel_frac, g.strand)
     return case
 
 
