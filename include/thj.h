@@ -198,6 +198,84 @@ int thj_segjuncs_merge_keys_async(thj_ctx* ctx, int kind, const uint64_t* d_keys
  * `enable` != 0. */
 int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches);
 
+
+/* --------------------------------------------------- long_spanning_reads */
+
+/* CigarOpCode values of bwt_map.h:36-55, packed as (op << 28) | length. */
+#define THJ_CIG_MATCH     1u
+#define THJ_CIG_INS       3u
+#define THJ_CIG_DEL       5u
+#define THJ_CIG_REF_SKIP 11u
+#define THJ_CIG_SOFT_CLIP 13u
+
+/* A segment alignment with its CIGAR: BowtieHit as produced by BAMHitFactory /
+ * SplicedBAMHitFactory (bwt_map.cpp:1101-1452, :1469-1770). 32 bytes. */
+typedef struct {
+    uint32_t ref_id;
+    int32_t  left;
+    uint8_t  flags;        /* THJ_HIT_ANTISENSE | THJ_HIT_END | THJ_HIT_ANTISENSE_SPLICE */
+    uint8_t  mismatches;
+    uint8_t  edit_dist;
+    uint8_t  n_cigar;      /* 1..5 */
+    uint32_t cigar[5];
+} thj_span_hit;
+#define THJ_HIT_ANTISENSE_SPLICE 4u
+
+/* Per-read segment hit lists of JoinSegmentsWorker (long_spanning_reads.cpp:2669-2845):
+ * for every read with a hit in the first segment map, segment s holds the contig
+ * hits then the spliced hits (:2706-2765, :87-163).  DEVICE pointers. */
+typedef struct {
+    int32_t n_reads;
+    int32_t nseg;
+    int32_t words_per_plane;
+    int32_t qual_stride;         /* bytes between consecutive reads' quality strings */
+    const uint32_t*     seg_off;     /* [n_reads*nseg+1] */
+    const thj_span_hit* hits;
+    const uint64_t*     read_planes; /* [n_reads*3*W] (thj_reads_pack) */
+    const uint16_t*     read_len;
+    const uint8_t*      quals;       /* phred+33, qual_stride bytes per read */
+} thj_span_batch;
+
+/* One output record: the fields print_bamhit + bowtie_sam_extra write
+ * (bwt_map.cpp:1888-2093, :2467-2648). 128 bytes. */
+typedef struct {
+    uint32_t read_idx;     /* index of the read in its batch */
+    uint32_t ref_id;
+    int32_t  left;         /* POS - 1 */
+    uint8_t  flags;        /* THJ_HIT_ANTISENSE (-> FLAG 0x10) | THJ_HIT_ANTISENSE_SPLICE (-> XS:A:-) */
+    uint8_t  mismatches;   /* NM = mismatches + indel lengths */
+    uint8_t  edit_dist;
+    uint8_t  n_cigar;
+    int16_t  AS;
+    uint8_t  XM, XO, XG, md_len;
+    uint16_t order;        /* rank among the read's records (BowtieHit::operator<, bwt_map.h:180-207) */
+    uint32_t cigar[16];
+    char     md[40];       /* MD:Z value, md_len characters */
+} thj_aln;
+
+/* The junction (+deletion) and insertion sets long_spanning_reads loads from its list
+ * files (long_spanning_reads.cpp:2897-2980).  juncs: sorted unique in Junction::operator<
+ * order, deletions already merged in as Junction(left, right, '+'); insertions: n_ins rows
+ * of 4 uint32 {ref_id, left, length, bases 3 bits each (A,C,G,T,N = 0..4)} sorted by
+ * (ref_id, left, length).  HOST pointers. */
+int thj_span_sets_upload(thj_ctx* ctx, const thj_junction* juncs, int64_t n_juncs, const uint32_t* insertions, int64_t n_ins);
+/* Same, taken device-to-device from the context's own finished segment_juncs tables. */
+int thj_span_sets_from_segjuncs(thj_ctx* ctx);
+
+int thj_span_batch_upload(thj_ctx* ctx, const thj_span_batch* host, int64_t n_hits, thj_span_batch** out);
+int thj_span_batch_free(thj_ctx* ctx, thj_span_batch* dev);
+
+int thj_span_reset_async(thj_ctx* ctx);
+/* join_segments_for_read + sort/unique + filters + bowtie_sam_extra for every read of the
+ * batch (long_spanning_reads.cpp:2612-2667, :2767-2831); records accumulate in HBM. */
+int thj_span_run_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* dev_batch);
+/* Orders the records as the reference's BAM (batch order of reads, operator< inside a
+ * read) and synchronises.  THJ_EOVERFLOW when a device limit was hit (message says which). */
+int thj_span_finish(thj_ctx* ctx, int64_t* n_alns);
+int thj_span_download(thj_ctx* ctx, thj_aln* out);
+/* Average thj_k_stitch duration (ms) since the last call, HIP events on the context stream. */
+int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,3 +99,42 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
 }
 
 extern "C" void hostsim_free(void* p) { free(p); }
+
+// ---------------------------------------------------------------- long_spanning_reads
+#include "../../tophat_amd/csrc/thj_span_core.h"
+
+struct VecSink {
+    std::vector<OutAln>* v;
+    void emit(const OutAln& o) { v->push_back(o); }
+};
+
+extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
+                                const int32_t* contig_len, int32_t n_contigs,
+                                int32_t n_reads, int32_t nseg, int32_t W, const uint32_t* seg_off, const void* hits,
+                                const uint64_t* planes, const uint16_t* read_len, const uint8_t* quals, int32_t qual_stride,
+                                const thj_junction* juncs, int64_t n_juncs,
+                                const uint32_t* ins /* 4 u32 each: ref,left,len,seq3 */, int64_t n_ins,
+                                void** out, int64_t* n_out, int64_t* status_counts /* [3] */) {
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    Params p;
+    memcpy(&p, tp, sizeof p);
+    std::vector<u64> jk((size_t)n_juncs), ik((size_t)n_ins);
+    std::vector<uint32_t> iseq((size_t)n_ins);
+    for (int64_t i = 0; i < n_juncs; ++i) jk[i] = junc_key(g, juncs[i].ref_id, juncs[i].left, juncs[i].right, juncs[i].antisense != 0);
+    for (int64_t i = 0; i < n_ins; ++i) { ik[i] = ins_key(g, ins[4 * i], ins[4 * i + 1], (int)ins[4 * i + 2]); iseq[i] = ins[4 * i + 3]; }
+    for (int64_t i = 1; i < n_juncs; ++i) if (jk[i] <= jk[i - 1]) return -10;   // must already be sorted unique
+    for (int64_t i = 1; i < n_ins; ++i) if (ik[i] <= ik[i - 1]) return -11;
+    SpanSets S{jk.data(), n_juncs, ik.data(), iseq.data(), n_ins};
+    std::vector<OutAln> res;
+    VecSink sink{&res};
+    status_counts[0] = status_counts[1] = status_counts[2] = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        int st = span_read(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                           read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+        status_counts[st]++;
+    }
+    *n_out = (int64_t)res.size();
+    *out = malloc(sizeof(OutAln) * (res.size() + 1));
+    memcpy(*out, res.data(), sizeof(OutAln) * res.size());
+    return 0;
+}

@@ -65,3 +65,28 @@ def segjuncs(p: Params, seqs, b: SegBatch, ordinal_base: int = 0) -> Events:
     ev = sort_events(j, d, raw)
     ev.stats = {"windows": stats[0], "indel_pairs": stats[1], "rescue_pairs": stats[2]}
     return ev
+
+
+def spanning(p: Params, seqs, b, juncs, insertions):
+    """-> (list of Aln, status counts) from the CPU build of thj_span_core.h"""
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    d = host.pack_span_batch(b, lib=l)
+    clen = g.lens.astype(np.int32)
+    cp = p.as_ctypes()
+    j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
+    t = host._ins_table(insertions)
+    out = C.c_void_p()
+    n_out = C.c_int64()
+    st = (C.c_int64 * 3)()
+    rc = l.hostsim_spanning(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
+                            C.c_void_p(clen.ctypes.data), g.n_contigs, d["n_reads"], d["nseg"], d["W"],
+                            C.c_void_p(d["seg_off"].ctypes.data), C.c_void_p(d["hits"].ctypes.data),
+                            C.c_void_p(d["planes"].ctypes.data), C.c_void_p(d["read_len"].ctypes.data),
+                            C.c_void_p(d["quals"].ctypes.data), d["qual_stride"],
+                            C.c_void_p(j.ctypes.data), C.c_int64(len(j)), C.c_void_p(t.ctypes.data), C.c_int64(len(insertions)),
+                            C.byref(out), C.byref(n_out), st)
+    assert rc == 0, rc
+    a = np.frombuffer((C.c_char * (max(1, n_out.value) * 128)).from_address(out.value), dtype=host.ALN_DTYPE)[:n_out.value].copy()
+    l.hostsim_free(out)
+    return host.alns_from_array(a), list(st)

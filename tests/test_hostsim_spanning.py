@@ -1,0 +1,44 @@
+"""CPU: long_spanning_reads kernel logic (thj_span_core.h compiled for the host) against the plain-C oracle."""
+import pytest
+
+import orc
+import sim
+from tophat_amd.batch import build_seg_batch, build_span_batch, events_to_span_inputs
+from tophat_amd.params import Params
+from tophat_amd.synth import make_case
+
+SPAN_CASES = [
+    dict(seed=1, read_len=100, seg_len=25, extra={}, gen=dict(boundary_bias=0.6)),
+    dict(seed=2, read_len=76, seg_len=25, extra={}, gen=dict(boundary_bias=0.6, spliced_seg_frac=0.8)),
+    dict(seed=3, read_len=150, seg_len=25, extra=dict(read_mismatches=4, read_edit_dist=4, read_gap_length=3),
+         gen=dict(boundary_bias=0.5, spliced_seg_frac=0.9, err=0.02, repeat_frac=0.3)),
+    dict(seed=4, read_len=100, seg_len=20, extra=dict(min_report_intron=30, max_report_intron=2500),
+         gen=dict(boundary_bias=0.7, spliced_seg_frac=0.5, n_frac=0.2, indel_frac=0.25)),
+    dict(seed=5, read_len=50, seg_len=25, extra={}, gen=dict(boundary_bias=0.8, indel_frac=0.3)),
+    dict(seed=6, read_len=100, seg_len=25, extra={}, gen=dict(boundary_bias=0.6, indel_frac=0.5, n_frac=0.3)),
+]
+
+
+def span_inputs(cfg, n_reads=400):
+    case = make_case(seed=cfg["seed"], paired=False, read_len=cfg["read_len"], seg_len=cfg["seg_len"], n_reads=n_reads,
+                     **cfg.get("gen", {}))
+    p = Params(segment_length=cfg["seg_len"], **cfg["extra"])
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    g = orc.Genome(seqs)
+    # host parsing rule: spliced records longer than max_report_intron are dropped (bwt_map.cpp:1341-1345)
+    recs = [[h for h in seg if not any(o == 11 and n > p.max_report_intron for o, n in h[9])] for seg in case.seg_recs["left"]]
+    ev = orc.segjuncs(p, g, build_seg_batch(recs, case.reads["left"]))
+    juncs, ins = events_to_span_inputs(ev)
+    sb = build_span_batch(recs, case.reads["left"], case.quals["left"])
+    return case, p, seqs, g, sb, juncs, ins
+
+
+@pytest.mark.parametrize("cfg", SPAN_CASES, ids=lambda c: "seed%d_rl%d_L%d" % (c["seed"], c["read_len"], c["seg_len"]))
+def test_span_logic_matches_oracle(cfg):
+    case, p, seqs, g, sb, juncs, ins = span_inputs(cfg)
+    want = orc.spanning(p, g, sb, juncs, ins)
+    got, status = sim.spanning(p, seqs, sb, juncs, ins)
+    assert status[1] == 0 and status[2] == 0
+    assert len(want) > 50
+    assert any(any((c >> 28) == 11 for c in a.cigar) for a in want), "no spliced alignment in the case"
+    assert got == want

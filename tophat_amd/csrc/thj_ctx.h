@@ -1,0 +1,64 @@
+// thj_ctx.h -- the context object shared by the translation units of libthj_hip.so (internal)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "thj_core.h"
+#include "thj_internal.h"
+
+using thj::u64;
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            thj_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return THJ_EHIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+struct thj_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // genome
+    const u64* d_blocks = nullptr; bool own_blocks = false;
+    uint32_t* d_contig_blk = nullptr; int32_t* d_contig_len = nullptr;
+    std::vector<uint32_t> h_contig_blk; std::vector<int64_t> h_lens;
+    int32_t n_contigs = 0; int64_t n_blocks = 0;
+    // tables
+    int64_t junc_cap = 0, indel_cap = 0;
+    u64 *d_junc = nullptr, *d_del = nullptr, *d_ins_key = nullptr, *d_ins_val = nullptr;
+    unsigned int* d_ovf = nullptr;
+    unsigned long long* d_cnt = nullptr;
+    // sorted outputs
+    u64 *d_junc_sorted = nullptr, *d_del_sorted = nullptr, *d_ins_key_sorted = nullptr, *d_ins_val_sorted = nullptr;
+    u64 *d_tmp_keys = nullptr, *d_tmp_vals = nullptr;
+    int64_t out_cap_junc = 0, out_cap_indel = 0;
+    unsigned long long* d_out_n = nullptr;      // [3]
+    unsigned long long* h_pinned = nullptr;     // [16] pinned staging
+    void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    int64_t n_junc = 0, n_del = 0, n_ins = 0;
+    // rescue scratch
+    uint32_t* d_npairs = nullptr; uint32_t* d_pair_off = nullptr; int64_t pairs_cap_reads = 0;
+    int32_t* d_slots = nullptr; int64_t slots_cap = 0;
+    void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
+    // long_spanning_reads (thj_span.hip)
+    u64* d_span_junc = nullptr; int64_t n_span_junc = 0; int64_t cap_span_junc = 0;
+    u64* d_span_ins_key = nullptr; uint32_t* d_span_ins_seq = nullptr; int64_t n_span_ins = 0; int64_t cap_span_ins = 0;
+    void* d_aln_pool = nullptr; void* d_aln_sorted = nullptr; int64_t aln_cap = 0;
+    u64* d_aln_keys = nullptr; u64* d_aln_keys2 = nullptr; uint32_t* d_aln_idx = nullptr; uint32_t* d_aln_idx2 = nullptr;
+    void* d_aln_sort_tmp = nullptr; size_t aln_sort_tmp_bytes = 0;
+    unsigned long long* d_aln_count = nullptr; unsigned int* d_span_status = nullptr;
+    int64_t n_alns = 0;
+    bool span_profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;
+    // profiling
+    bool profile = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<hipEvent_t> event_pool;
+};
+hipEvent_t thj_get_event(struct thj_ctx* c);
+void thj_span_free(struct thj_ctx* c);

@@ -32,14 +32,7 @@ using namespace thj;
 static_assert(sizeof(thj_hit) == 16 && sizeof(Hit) == 16, "hit layout");
 static_assert(sizeof(thj_params) == sizeof(Params), "params layout");
 
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e__ = (expr);                                                              \
-        if (e__ != hipSuccess) {                                                              \
-            thj_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
-            return THJ_EHIP;                                                                  \
-        }                                                                                     \
-    } while (0)
+
 
 // ------------------------------------------------------------------ tables
 
@@ -322,37 +315,8 @@ __global__ __launch_bounds__(256) void thj_k_merge_keys(u64* tab, u64 mask, cons
 
 // ------------------------------------------------------------------ context
 
-struct thj_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    // genome
-    const u64* d_blocks = nullptr; bool own_blocks = false;
-    uint32_t* d_contig_blk = nullptr; int32_t* d_contig_len = nullptr;
-    std::vector<uint32_t> h_contig_blk; std::vector<int64_t> h_lens;
-    int32_t n_contigs = 0; int64_t n_blocks = 0;
-    // tables
-    int64_t junc_cap = 0, indel_cap = 0;
-    u64 *d_junc = nullptr, *d_del = nullptr, *d_ins_key = nullptr, *d_ins_val = nullptr;
-    unsigned int* d_ovf = nullptr;
-    unsigned long long* d_cnt = nullptr;
-    // sorted outputs
-    u64 *d_junc_sorted = nullptr, *d_del_sorted = nullptr, *d_ins_key_sorted = nullptr, *d_ins_val_sorted = nullptr;
-    u64 *d_tmp_keys = nullptr, *d_tmp_vals = nullptr;
-    int64_t out_cap_junc = 0, out_cap_indel = 0;
-    unsigned long long* d_out_n = nullptr;      // [3]
-    unsigned long long* h_pinned = nullptr;     // [16] pinned staging
-    void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
-    int64_t n_junc = 0, n_del = 0, n_ins = 0;
-    // rescue scratch
-    uint32_t* d_npairs = nullptr; uint32_t* d_pair_off = nullptr; int64_t pairs_cap_reads = 0;
-    int32_t* d_slots = nullptr; int64_t slots_cap = 0;
-    void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
-    // profiling
-    bool profile = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
-    std::vector<hipEvent_t> event_pool;
-};
+#include "thj_ctx.h"
+
 
 static int next_pow2(int64_t x, int64_t* out) {
     int64_t p = 1024;
@@ -439,6 +403,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n);
     hipHostFree(c->h_pinned);
     hipFree(c->d_npairs); hipFree(c->d_pair_off); hipFree(c->d_slots); hipFree(c->d_scan_tmp);
+    thj_span_free(c);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -570,7 +535,7 @@ static int check_params(const thj_params* p, const thj_seg_batch* b) {
     return THJ_OK;
 }
 
-static hipEvent_t get_event(thj_ctx* c) {
+hipEvent_t thj_get_event(thj_ctx* c) {
     if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
     hipEvent_t e;
     hipEventCreate(&e);
@@ -630,7 +595,7 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     const int n_tiles = (n + TPB - 1) / TPB;
     int grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;       // 256 CUs x 8 resident workgroups, grid-stride the rest
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profile) { e0 = get_event(c); e1 = get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
+    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
     hipLaunchKernelGGL(thj_k_segjuncs, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t,
                        (const uint32_t*)c->d_pair_off, (const int32_t*)c->d_slots);
     if (c->profile) { HIPCHK(hipEventRecord(e1, c->stream)); c->prof_events.emplace_back(e0, e1); }

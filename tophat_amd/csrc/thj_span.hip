@@ -1,0 +1,365 @@
+// thj_span.hip -- gfx950 kernel + C ABI for the long_spanning_reads hot path.
+//
+//   thj_k_stitch   1 thread / read   DFS over one hit per segment (dfs_seg_hits), closure of every
+//                                    adjacent pair through the sorted junction / insertion key arrays
+//                                    (merge_chain), edit-distance consistency, sort/unique/filter and
+//                                    the AS/XM/XO/XG/MD pass (bowtie_sam_extra); 128-byte records are
+//                                    appended to an HBM pool.
+//   thj_span_finish: hipcub radix sort of (read_idx, order) keys + thj_k_gather -> output order of
+//                    the reference's BAM (read order, BowtieHit::operator< inside a read).
+// Integer / bit-plane work; no MFMA.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/thj.h"
+#include "thj_span_core.h"
+#include "thj_ctx.h"
+
+using namespace thj;
+
+static_assert(sizeof(thj_span_hit) == 32 && sizeof(SpanHit) == 32, "span hit layout");
+static_assert(sizeof(thj_aln) == 128 && sizeof(OutAln) == 128, "aln layout");
+
+struct DevSpanBatch {
+    int32_t n_reads, nseg, W, qual_stride;
+    const uint32_t* seg_off;
+    const SpanHit* hits;
+    const u64* planes;
+    const uint16_t* read_len;
+    const uint8_t* quals;
+};
+static_assert(sizeof(DevSpanBatch) == sizeof(thj_span_batch), "span batch layout");
+
+struct PoolSink {
+    OutAln* pool; unsigned long long* count; unsigned long long cap; unsigned int* status;
+    __device__ __forceinline__ void emit(const OutAln& o) {
+        unsigned long long pos = atomicAdd(count, 1ull);
+        if (pos < cap) pool[pos] = o; else atomicExch(&status[3], 1u);
+    }
+};
+
+__global__ __launch_bounds__(128) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < b.n_reads; r += gridDim.x * blockDim.x) {
+        int st = span_read(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                           (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        if (st) atomicAdd(&sink.status[st], 1u);
+    }
+}
+
+__global__ __launch_bounds__(256) void thj_k_aln_keys(const OutAln* pool, int64_t n, u64* keys, uint32_t* idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = ((u64)pool[i].read_idx << 16) | (u64)pool[i].order;
+        idx[i] = (uint32_t)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void thj_k_gather(const uint4* pool, const uint32_t* idx, int64_t n, uint4* out) {
+    // one 128-byte record = 8 x 16 B; 8 consecutive lanes move one record
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 8; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = pool[(int64_t)idx[i >> 3] * 8 + (i & 7)];
+}
+
+__global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u64* vals, int64_t n, u64* okeys, uint32_t* oseq) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        okeys[i] = keys[i];
+        oseq[i] = (uint32_t)(vals[i] & 0xFFFFFu);
+    }
+}
+
+void thj_span_free(thj_ctx* c) {
+    hipFree(c->d_span_junc); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq);
+    hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_aln_keys2);
+    hipFree(c->d_aln_idx); hipFree(c->d_aln_idx2); hipFree(c->d_aln_sort_tmp);
+    hipFree(c->d_aln_count); hipFree(c->d_span_status);
+    for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+}
+
+static int ensure_span_state(thj_ctx* c) {
+    if (!c->d_aln_count) {
+        HIPCHK(hipMalloc(&c->d_aln_count, 8));
+        HIPCHK(hipMalloc(&c->d_span_status, 4 * sizeof(unsigned int)));
+        HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 8, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_span_status, 0, 16, c->stream));
+    }
+    return THJ_OK;
+}
+
+static int ensure_sets_cap(thj_ctx* c, int64_t nj, int64_t ni) {
+    if (nj + 1 > c->cap_span_junc) {
+        hipFree(c->d_span_junc); c->d_span_junc = nullptr;
+        c->cap_span_junc = nj + nj / 4 + 1024;
+        HIPCHK(hipMalloc(&c->d_span_junc, (size_t)c->cap_span_junc * 8));
+    }
+    if (ni + 1 > c->cap_span_ins) {
+        hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); c->d_span_ins_key = nullptr; c->d_span_ins_seq = nullptr;
+        c->cap_span_ins = ni + ni / 4 + 1024;
+        HIPCHK(hipMalloc(&c->d_span_ins_key, (size_t)c->cap_span_ins * 8));
+        HIPCHK(hipMalloc(&c->d_span_ins_seq, (size_t)c->cap_span_ins * 4));
+    }
+    return THJ_OK;
+}
+
+static u64 host_junc_key(const thj_ctx* c, uint32_t ref, uint32_t left, uint32_t right, bool anti) {
+    Genome g{nullptr, c->h_contig_blk.data(), nullptr, c->n_contigs};
+    return junc_key(g, ref, left, right, anti);
+}
+
+extern "C" int thj_span_sets_upload(thj_ctx* c, const thj_junction* juncs, int64_t n_juncs, const uint32_t* ins, int64_t n_ins) {
+    if (!c || (n_juncs > 0 && !juncs) || (n_ins > 0 && !ins)) { thj_set_error("thj_span_sets_upload: bad argument"); return THJ_EINVAL; }
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<u64> jk((size_t)n_juncs), ik((size_t)n_ins);
+    std::vector<uint32_t> iseq((size_t)n_ins);
+    Genome g{nullptr, c->h_contig_blk.data(), nullptr, c->n_contigs};
+    for (int64_t i = 0; i < n_juncs; ++i) {
+        const thj_junction& j = juncs[i];
+        if (j.ref_id == 0 || (int32_t)j.ref_id > c->n_contigs) { thj_set_error("junction %lld: ref_id %u out of range", (long long)i, j.ref_id); return THJ_EINVAL; }
+        if ((uint32_t)(j.right - j.left) >= (1u << 29)) { thj_set_error("junction %lld longer than 2^29", (long long)i); return THJ_EINVAL; }
+        jk[i] = junc_key(g, j.ref_id, j.left, j.right, j.antisense != 0);
+        if (i && jk[i] <= jk[i - 1]) { thj_set_error("junctions must be sorted unique in Junction::operator< order (entry %lld)", (long long)i); return THJ_EINVAL; }
+    }
+    for (int64_t i = 0; i < n_ins; ++i) {
+        uint32_t ref = ins[4 * i], left = ins[4 * i + 1], len = ins[4 * i + 2];
+        if (ref == 0 || (int32_t)ref > c->n_contigs || len == 0 || len > 6) { thj_set_error("insertion %lld invalid (length must be 1..6)", (long long)i); return THJ_EINVAL; }
+        ik[i] = ins_key(g, ref, left, (int)len);
+        iseq[i] = ins[4 * i + 3];
+        if (i && ik[i] <= ik[i - 1]) { thj_set_error("insertions must be sorted unique by (ref,left,len) (entry %lld)", (long long)i); return THJ_EINVAL; }
+    }
+    int rc = ensure_sets_cap(c, n_juncs, n_ins);
+    if (rc) return rc;
+    if (n_juncs) HIPCHK(hipMemcpyAsync(c->d_span_junc, jk.data(), (size_t)n_juncs * 8, hipMemcpyHostToDevice, c->stream));
+    if (n_ins) {
+        HIPCHK(hipMemcpyAsync(c->d_span_ins_key, ik.data(), (size_t)n_ins * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_span_ins_seq, iseq.data(), (size_t)n_ins * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_span_junc = n_juncs; c->n_span_ins = n_ins;
+    return THJ_OK;
+}
+
+extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
+    // junction set := sorted union of the context's junction and deletion keys (what
+    // long_spanning_reads.cpp:2897-2944 builds from the .juncs and .deletions files);
+    // insertion set := the sorted insertion keys + their sequences.  Device to device.
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    const int64_t nj = c->n_junc + c->n_del, ni = c->n_ins;
+    int rc = ensure_sets_cap(c, nj, ni);
+    if (rc) return rc;
+    if (nj) {
+        // concatenate into tmp, sort, unique
+        HIPCHK(hipMemcpyAsync(c->d_tmp_keys, c->d_junc_sorted, (size_t)c->n_junc * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (c->n_del) HIPCHK(hipMemcpyAsync(c->d_tmp_keys + c->n_junc, c->d_del_sorted, (size_t)c->n_del * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (nj > c->out_cap_junc) { thj_set_error("junction+deletion set exceeds table capacity"); return THJ_EOVERFLOW; }
+        // sort into d_junc (the hash table is no longer needed after finish; it is reset by the next run)
+        u64* sorted = c->d_junc;
+        size_t tmp = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, sorted, nj, 0, 64, c->stream));
+        size_t need = 0;
+        HIPCHK(hipcub::DeviceSelect::Unique(nullptr, need, (const u64*)sorted, c->d_span_junc, c->d_out_n + 3, nj, c->stream));
+        void* dtmp = c->d_sort_tmp;
+        void* extra = nullptr;
+        if (need > c->sort_tmp_bytes) { HIPCHK(hipMalloc(&extra, need)); dtmp = extra; }
+        HIPCHK(hipcub::DeviceSelect::Unique(dtmp, need, (const u64*)sorted, c->d_span_junc, c->d_out_n + 3, nj, c->stream));
+        HIPCHK(hipMemcpyAsync(&c->h_pinned[20], c->d_out_n + 3, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (extra) hipFree(extra);
+        c->n_span_junc = (int64_t)c->h_pinned[20];
+        // the table memory was used as scratch: mark it dirty so the next segjuncs pass must reset first
+        HIPCHK(hipMemsetAsync(c->d_junc, 0xFF, (size_t)c->junc_cap * 8, c->stream));
+        HIPCHK(hipMemsetAsync(&c->d_cnt[0], 0, 8, c->stream));
+    } else c->n_span_junc = 0;
+    if (ni) {
+        int64_t blocks = (ni + 255) / 256; if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(thj_k_ins_split, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const u64*)c->d_ins_key_sorted,
+                           (const u64*)c->d_ins_val_sorted, ni, c->d_span_ins_key, c->d_span_ins_seq);
+    }
+    c->n_span_ins = ni;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return THJ_OK;
+}
+
+struct OwnedSpanBatch {
+    thj_span_batch desc;     // first member
+    void* ptrs[5];
+};
+
+extern "C" int thj_span_batch_upload(thj_ctx* c, const thj_span_batch* h, int64_t n_hits, thj_span_batch** out) {
+    if (!c || !h || !out) { thj_set_error("thj_span_batch_upload: null argument"); return THJ_EINVAL; }
+    if (h->n_reads < 0 || h->nseg < 1 || h->nseg > SPAN_MAXSEG || h->words_per_plane < 1 || h->words_per_plane > 4 || h->qual_stride < 0) {
+        thj_set_error("thj_span_batch_upload: bad shape (nseg 1..8, words_per_plane 1..4)"); return THJ_EINVAL;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    OwnedSpanBatch* ob = new OwnedSpanBatch();
+    memset(ob, 0, sizeof *ob);
+    ob->desc = *h;
+    const int64_t n = h->n_reads;
+    const size_t sizes[5] = {(size_t)(n * h->nseg + 1) * 4, (size_t)n_hits * 32, (size_t)n * 3 * h->words_per_plane * 8,
+                             (size_t)n * 2, (size_t)n * h->qual_stride};
+    const void* src[5] = {h->seg_off, h->hits, h->read_planes, h->read_len, h->quals};
+    for (int i = 0; i < 5; ++i) {
+        HIPCHK(hipMalloc(&ob->ptrs[i], sizes[i] ? sizes[i] : 16));
+        if (sizes[i]) HIPCHK(hipMemcpyAsync(ob->ptrs[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
+    }
+    ob->desc.seg_off = (const uint32_t*)ob->ptrs[0];
+    ob->desc.hits = (const thj_span_hit*)ob->ptrs[1];
+    ob->desc.read_planes = (const uint64_t*)ob->ptrs[2];
+    ob->desc.read_len = (const uint16_t*)ob->ptrs[3];
+    ob->desc.quals = (const uint8_t*)ob->ptrs[4];
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = &ob->desc;
+    return THJ_OK;
+}
+
+extern "C" int thj_span_batch_free(thj_ctx* c, thj_span_batch* dev) {
+    if (!c || !dev) return THJ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    OwnedSpanBatch* ob = (OwnedSpanBatch*)dev;
+    for (int i = 0; i < 5; ++i) hipFree(ob->ptrs[i]);
+    delete ob;
+    return THJ_OK;
+}
+
+extern "C" int thj_span_reset_async(thj_ctx* c) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_span_state(c);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_span_status, 0, 16, c->stream));
+    c->n_alns = 0;
+    return THJ_OK;
+}
+
+static int ensure_pool(thj_ctx* c, int64_t want) {
+    if (want <= c->aln_cap) return THJ_OK;
+    // grow, preserving what earlier runs of this pass appended
+    HIPCHK(hipStreamSynchronize(c->stream));
+    int64_t ncap = want + want / 2 + 4096;
+    void* np_ = nullptr;
+    HIPCHK(hipMalloc(&np_, (size_t)ncap * 128));
+    if (c->d_aln_pool) {
+        unsigned long long cur = 0;
+        HIPCHK(hipMemcpy(&cur, c->d_aln_count, 8, hipMemcpyDeviceToHost));
+        if ((int64_t)cur > c->aln_cap) cur = (unsigned long long)c->aln_cap;
+        if (cur) HIPCHK(hipMemcpy(np_, c->d_aln_pool, (size_t)cur * 128, hipMemcpyDeviceToDevice));
+        hipFree(c->d_aln_pool);
+    }
+    c->d_aln_pool = np_;
+    hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_aln_keys2); hipFree(c->d_aln_idx); hipFree(c->d_aln_idx2);
+    hipFree(c->d_aln_sort_tmp);
+    c->d_aln_sorted = nullptr; c->d_aln_keys = c->d_aln_keys2 = nullptr; c->d_aln_idx = c->d_aln_idx2 = nullptr; c->d_aln_sort_tmp = nullptr;
+    HIPCHK(hipMalloc(&c->d_aln_sorted, (size_t)ncap * 128));
+    HIPCHK(hipMalloc(&c->d_aln_keys, (size_t)ncap * 8));
+    HIPCHK(hipMalloc(&c->d_aln_keys2, (size_t)ncap * 8));
+    HIPCHK(hipMalloc(&c->d_aln_idx, (size_t)ncap * 4));
+    HIPCHK(hipMalloc(&c->d_aln_idx2, (size_t)ncap * 4));
+    size_t need = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const u64*)nullptr, (u64*)nullptr, (const uint32_t*)nullptr,
+                                              (uint32_t*)nullptr, ncap, 0, 48, c->stream));
+    HIPCHK(hipMalloc(&c->d_aln_sort_tmp, need ? need : 16));
+    c->aln_sort_tmp_bytes = need;
+    c->aln_cap = ncap;
+    return THJ_OK;
+}
+
+static int check_span_params(const thj_params* p, const thj_span_batch* b) {
+    if (p->segment_length < 10 || p->segment_length > 64) { thj_set_error("segment_length %d unsupported by the stitch kernel (10..64)", p->segment_length); return THJ_EINVAL; }
+    if (p->max_insertion_length < 0 || p->max_insertion_length > 6) { thj_set_error("max_insertion_length %d unsupported (0..6)", p->max_insertion_length); return THJ_EINVAL; }
+    if (p->max_report_intron + 64 >= (1 << 29)) { thj_set_error("max_report_intron too large for the packed key"); return THJ_EINVAL; }
+    if (b->nseg < 1 || b->nseg > SPAN_MAXSEG) { thj_set_error("nseg %d unsupported (1..8)", b->nseg); return THJ_EINVAL; }
+    if (b->words_per_plane < 1 || b->words_per_plane > 4) { thj_set_error("words_per_plane %d unsupported (1..4)", b->words_per_plane); return THJ_EINVAL; }
+    if ((int64_t)b->n_reads >= (1ll << 31)) { thj_set_error("batch too large"); return THJ_EINVAL; }
+    return THJ_OK;
+}
+
+extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db) {
+    if (!c || !tp || !db) { thj_set_error("thj_span_run_async: null argument"); return THJ_EINVAL; }
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    int rc = check_span_params(tp, db);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = ensure_span_state(c))) return rc;
+    if (db->n_reads == 0) return THJ_OK;
+    if ((rc = ensure_sets_cap(c, c->n_span_junc, c->n_span_ins))) return rc;
+    // room for two records per read of this batch on top of what the pass already holds
+    if ((rc = ensure_pool(c, c->n_alns + 2 * (int64_t)db->n_reads + 1024))) return rc;
+    c->n_alns += 2 * (int64_t)db->n_reads;      // reservation watermark (actual count read back at finish)
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    Params p; memcpy(&p, tp, sizeof p);
+    DevSpanBatch b; memcpy(&b, db, sizeof b);
+    SpanSets S{c->d_span_junc, c->n_span_junc, c->d_span_ins_key, c->d_span_ins_seq, c->n_span_ins};
+    PoolSink sink{(OutAln*)c->d_aln_pool, c->d_aln_count, (unsigned long long)c->aln_cap, c->d_span_status};
+    int64_t blocks = ((int64_t)b.n_reads + 127) / 128;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->span_profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
+    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)blocks), dim3(128), 0, c->stream, g, p, S, b, sink);
+    if (c->span_profile) { HIPCHK(hipEventRecord(e1, c->stream)); c->span_prof_events.emplace_back(e0, e1); }
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_span_state(c);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[24], c->d_aln_count, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[26], c->d_span_status, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const unsigned int* st = (const unsigned int*)&c->h_pinned[26];
+    if (st[3]) { thj_set_error("alignment pool overflow: more than two spliced alignments per read on average"); return THJ_EOVERFLOW; }
+    if (st[SPAN_TOO_MANY_JOINED]) {
+        thj_set_error("%u read(s) have more than %d distinct joined alignments (device limit)", st[SPAN_TOO_MANY_JOINED], SPAN_MAXJOIN);
+        return THJ_EOVERFLOW;
+    }
+    if (st[SPAN_MD_OVERFLOW]) { thj_set_error("%u alignment(s) need an MD string longer than 40 characters (device limit)", st[SPAN_MD_OVERFLOW]); return THJ_EOVERFLOW; }
+    const int64_t n = (int64_t)c->h_pinned[24];
+    c->n_alns = n;
+    if (n > 0) {
+        int64_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(thj_k_aln_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const OutAln*)c->d_aln_pool, n, c->d_aln_keys, c->d_aln_idx);
+        size_t tmp = c->aln_sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_aln_sort_tmp, tmp, (const u64*)c->d_aln_keys, c->d_aln_keys2,
+                                                  (const uint32_t*)c->d_aln_idx, c->d_aln_idx2, n, 0, 48, c->stream));
+        int64_t gb = (n * 8 + 255) / 256; if (gb > 4096) gb = 4096;
+        hipLaunchKernelGGL(thj_k_gather, dim3((unsigned)gb), dim3(256), 0, c->stream, (const uint4*)c->d_aln_pool,
+                           (const uint32_t*)c->d_aln_idx2, n, (uint4*)c->d_aln_sorted);
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    if (n_alns) *n_alns = n;
+    return THJ_OK;
+}
+
+extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
+    if (!c || (c->n_alns > 0 && !out)) { thj_set_error("thj_span_download: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->n_alns > 0) HIPCHK(hipMemcpyAsync(out, c->d_aln_sorted, (size_t)c->n_alns * 128, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return THJ_OK;
+}
+
+extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    double sum = 0;
+    for (auto& pr : c->span_prof_events) {
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+        sum += ms;
+        c->event_pool.push_back(pr.first);
+        c->event_pool.push_back(pr.second);
+    }
+    if (launches) *launches = (int64_t)c->span_prof_events.size();
+    if (avg_ms) *avg_ms = c->span_prof_events.empty() ? 0.0 : sum / (double)c->span_prof_events.size();
+    c->span_prof_events.clear();
+    c->span_profile = enable != 0;
+    return THJ_OK;
+}

@@ -1,0 +1,606 @@
+// thj_span_core.h -- per-read logic of the long_spanning_reads kernel.
+//
+// Host+device like thj_core.h: compiled by hipcc into thj_k_stitch, and by g++ into
+// tests/hostsim for single-stepping on a CPU (test-only).  Re-designed for the GPU:
+//   * the chain's sequence is never materialised: it is the read's bit-planes, or their
+//     reverse complement, addressed by offset;
+//   * the junction / insertion sets are sorted arrays of packed 64-bit keys searched
+//     with lower/upper_bound instead of std::set walks (long_spanning_reads.cpp:1311,
+//     :1019-1020);
+//   * mismatch re-counts, the edit-distance consistency check and the AS/XM/MD pass are
+//     64-base plane XOR + popcount.
+// Reference: long_spanning_reads.cpp:805-2038 (merge_chain), :2045-2099 (valid_hit),
+// :2101-2220, :2222-2610 (dfs_seg_hits), :2612-2667, bwt_map.cpp:2349-2648.
+#pragma once
+#include "thj_core.h"
+
+namespace thj {
+
+enum { OP_MATCH = 1, OP_mATCH = 2, OP_INS = 3, OP_iNS = 4, OP_DEL = 5, OP_dEL = 6, OP_REF_SKIP = 11, OP_rEF_SKIP = 12,
+       OP_SOFT_CLIP = 13 };
+THJ_HD uint32_t cig(int op, uint32_t len) { return ((uint32_t)op << 28) | (len & 0x0FFFFFFFu); }
+THJ_HD int cig_op(uint32_t c) { return (int)(c >> 28); }
+THJ_HD uint32_t cig_len(uint32_t c) { return c & 0x0FFFFFFFu; }
+THJ_HD bool op_is_match(int op) { return op == OP_MATCH || op == OP_mATCH; }
+
+struct SpanHit {            // == thj_span_hit, 32 bytes
+    uint32_t ref_id;
+    int32_t left;
+    uint32_t meta;          // flags | mismatches<<8 | edit_dist<<16 | n_cigar<<24
+    uint32_t cigar[5];
+};
+enum { SH_ANTI = 1, SH_END = 2, SH_ASPLICE = 4 };
+
+static constexpr int SPAN_MAXC = 16;      // cigar ops of a joined alignment
+static constexpr int SPAN_MAXSEG = 8;
+static constexpr int SPAN_MAXJOIN = 16;   // distinct joined alignments kept per read
+
+struct Aln {                // working form of a (partially) joined BowtieHit
+    uint32_t ref_id;
+    int32_t left;
+    int32_t n;
+    uint32_t c[SPAN_MAXC];
+    uint8_t anti, asplice, mm, ed;
+    int32_t rlen;           // read bases covered (sum of the segments' seq lengths)
+    int32_t valid;          // 0 = BowtieHit()
+};
+
+THJ_HD int aln_right(const Aln& h) {
+    int r = h.left;
+    for (int i = 0; i < h.n; ++i) {
+        int op = cig_op(h.c[i]);
+        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) r += (int)cig_len(h.c[i]);
+    }
+    return r;
+}
+THJ_HD int aln_read_len(const Aln& h) {
+    int l = 0;
+    for (int i = 0; i < h.n; ++i) {
+        int op = cig_op(h.c[i]);
+        if (op == OP_MATCH || op == OP_INS || op == OP_SOFT_CLIP) l += (int)cig_len(h.c[i]);
+    }
+    return l;
+}
+THJ_HD bool aln_spliced(const Aln& h) {
+    for (int i = 0; i < h.n; ++i) if (cig_op(h.c[i]) == OP_REF_SKIP) return true;
+    return false;
+}
+THJ_HD int cig_gap_len(const uint32_t* c, int n) {
+    int g = 0;
+    for (int i = 0; i < n; ++i) { int op = cig_op(c[i]); if (op == OP_INS || op == OP_DEL) g += (int)cig_len(c[i]); }
+    return g;
+}
+
+struct SpanSets {
+    const u64* junc_keys;  int64_t n_juncs;      // junc_key() order == Junction::operator<
+    const u64* ins_keys;   const uint32_t* ins_seq; int64_t n_ins;   // ins_key() order; seq 3 bits/base
+};
+
+THJ_HD int64_t lower_bound_u64(const u64* a, int64_t n, u64 k) {   // first i with a[i] >= k
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { int64_t m = (lo + hi) >> 1; if (a[m] < k) lo = m + 1; else hi = m; }
+    return lo;
+}
+THJ_HD int64_t upper_bound_u64(const u64* a, int64_t n, u64 k) {   // first i with a[i] > k
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { int64_t m = (lo + hi) >> 1; if (a[m] <= k) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// The chain's sequence in genome-forward orientation: the read, or its reverse complement.
+struct SeqView {
+    u64 w[3 * 4];            // planes lo[W], hi[W], nm[W] (W <= 4)
+    int W, len;
+};
+THJ_HD SeqView seq_forward(const u64* rp, int W, int rl) {
+    SeqView s; s.W = W; s.len = rl;
+    for (int i = 0; i < 3 * W; ++i) s.w[i] = rp[i];
+    return s;
+}
+THJ_HD SeqView seq_revcomp(const u64* rp, int W, int rl) {
+    SeqView s; s.W = W; s.len = rl;
+    // piecewise: output base i = complement of input base rl-1-i
+    for (int w = 0; w < W; ++w) {
+        int start = w * 64;
+        int len = rl - start; if (len > 64) len = 64;
+        if (len <= 0) { s.w[w] = s.w[W + w] = s.w[2 * W + w] = 0; continue; }
+        Planes p = r_fetch(rp, W, rl - start - len, len);   // input bases [rl-start-len, rl-start)
+        Planes q = rc_piece(p, len);
+        s.w[w] = q.lo; s.w[W + w] = q.hi; s.w[2 * W + w] = q.nm;
+    }
+    return s;
+}
+THJ_HD Planes seq_fetch(const SeqView& s, int start, int len) { return r_fetch(s.w, s.W, start, len); }
+// base code 0..3, 4 = N
+THJ_HD int seq_code(const SeqView& s, int i) {
+    int w = i >> 6, b = i & 63;
+    if ((s.w[2 * s.W + w] >> b) & 1ull) return 4;
+    return (int)(((s.w[w] >> b) & 1ull) | (((s.w[s.W + w] >> b) & 1ull) << 1));
+}
+THJ_HD int plane_code(const Planes& p, int b) {
+    if ((p.nm >> b) & 1ull) return 4;
+    return (int)(((p.lo >> b) & 1ull) | (((p.hi >> b) & 1ull) << 1));
+}
+
+// Dna5 mismatch mask of up to 64 bases: N equals N, N differs from a base
+THJ_HD u64 dna5_mism(const Planes& a, const Planes& b, int len) {
+    return ((a.lo ^ b.lo) | (a.hi ^ b.hi) | (a.nm ^ b.nm)) & lowmask(len);
+}
+
+// ---- check_editdist_consistency (bwt_map.cpp:2349-2465) ------------------------------------
+THJ_HD bool check_editdist(const Genome& g, const Aln& h, const SeqView& sv) {
+    if (g_len(g, h.ref_id) == 0) return false;
+    int pos_seq = 0;
+    int64_t pos_ref = h.left;
+    int mismatch = 0, n_mism = 0;
+    for (int i = 0; i < h.n; ++i) {
+        int op = cig_op(h.c[i]);
+        int len = (int)cig_len(h.c[i]);
+        if (op == OP_MATCH) {
+            for (int o = 0; o < len; o += 64) {
+                int l = len - o < 64 ? len - o : 64;
+                if (pos_seq + o + l > sv.len) l = sv.len - pos_seq - o;
+                if (l <= 0) break;
+                Planes r = g_fetch(g, h.ref_id, pos_ref + o);
+                Planes s = seq_fetch(sv, pos_seq + o, l);
+                mismatch += popc(dna5_mism(r, s, l));
+                n_mism += popc(r.nm & s.nm & lowmask(l));
+            }
+            pos_seq += len; pos_ref += len;
+        } else if (op == OP_INS) pos_seq += len;
+        else if (op == OP_DEL || op == OP_REF_SKIP) pos_ref += len;
+    }
+    return mismatch == (int)h.mm || mismatch + n_mism == (int)h.mm;
+}
+
+// ---- merge_chain (long_spanning_reads.cpp:805-2038), fusion_dir == FUSION_NOTHING ----------
+// chain[0..n) ordered left to right; seq = the chain's forward-orientation sequence.
+THJ_HD bool merge_chain(const Genome& g, const Params& p, const SpanSets& S, const SeqView& sv, Aln* chain, int n,
+                        Aln& out) {
+    const int left = chain[0].left;
+    int antisense = chain[0].anti;
+    int old_read_length = 0;
+    for (int i = 0; i < n; ++i) old_read_length += aln_read_len(chain[i]);
+    {   // :843-891
+        int num_fusions = 0;
+        for (int k = 1; k < n; ++k) {
+            if (chain[k - 1].ref_id != chain[k].ref_id) ++num_fusions;
+            else {
+                int gap = chain[k].left - aln_right(chain[k - 1]);
+                int maxi = p.max_report_intron < 10000000 ? p.max_report_intron : 10000000;
+                if (gap < -p.max_insertion_length ||
+                    (gap > p.max_deletion_length && (gap < p.min_report_intron || gap > maxi)))
+                    ++num_fusions;
+            }
+            if (num_fusions >= 2) return false;
+        }
+    }
+    int pi = 0, ci = 1;
+    int P = chain[0].rlen;            // read bases covered by chain[0..pi]
+    while (ci < n) {
+        Aln& prev = chain[pi];
+        Aln& curr = chain[ci];
+        antisense = prev.anti;
+        if (!(op_is_match(cig_op(prev.c[prev.n - 1])) || op_is_match(cig_op(curr.c[0])))) return false;   // :924-928
+        const bool psp = aln_spliced(prev), csp = aln_spliced(curr);
+        if (psp && csp && prev.asplice != curr.asplice) return false;                                      // :936-943
+        bool found = false;
+        int anti_closure = psp ? prev.asplice : curr.asplice;
+        uint32_t nc[SPAN_MAXC + 8]; int nn = 0;
+        int new_left = -1, mismatch = 0;
+        const int prev_end_len = (int)cig_len(prev.c[prev.n - 1]);
+        const int curr_front_len = (int)cig_len(curr.c[0]);
+        if (prev.ref_id != curr.ref_id) return false;      // check_fusion with an empty fusion set (:1596-1818)
+        const uint32_t ref = prev.ref_id;
+        const int prev_right = aln_right(prev);
+        const int lbnd = prev_right - 4, rbnd = curr.left + 4;
+        const int dist = curr.left - prev_right;
+        if (dist < 0 && dist >= -p.max_insertion_length && prev.anti == curr.anti) {
+            // ---- insertion closure :1010-1306
+            if (g_len(g, ref) == 0) return false;
+            int64_t lb = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)lbnd, 0));
+            int64_t ub = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)rbnd, p.max_insertion_length));
+            const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
+            for (; lb < ub; ++lb) {
+                const u64 k = S.ins_keys[lb];
+                const int ilen = (int)(k & 15);
+                const int ileft = (int)((int64_t)(k >> 4) - 1 - (int64_t)cbase);
+                if (ilen != prev_right - curr.left) continue;
+                const int itpr = prev_right - ileft - 1;
+                const int clti = ileft - curr.left + 1;
+                if (itpr > prev_end_len || clti > curr_front_len) continue;
+                const uint32_t iseq = S.ins_seq[lb];
+                int trm = 0, ins_mm = 0;
+                if (itpr > 0) {
+                    Planes rf = g_fetch(g, ref, (int64_t)ileft + 1);       // ref[ileft+1, prev_right)
+                    for (int ri = 0; ri < itpr; ++ri) {
+                        int r = plane_code(rf, ri);
+                        int o = seq_code(sv, P - itpr + ri);
+                        if (r == 4 || r != o) ++trm;
+                        if (ri < ilen) {
+                            int ic = (int)((iseq >> (3 * ri)) & 7u);
+                            if (ic == 4 || ic != o) { ++ins_mm; break; }
+                        } else {
+                            int r2 = plane_code(rf, ri - ilen);
+                            if (r2 == 4 || r2 != o) --trm;
+                        }
+                    }
+                }
+                if (clti > 0) {
+                    Planes rf = g_fetch(g, ref, curr.left);                 // ref[curr.left, ileft+1)
+                    for (int ri = 0; ri < clti; ++ri) {
+                        int sp = clti - ri - 1, ip = ilen - ri - 1;
+                        int r = plane_code(rf, sp);
+                        int o = seq_code(sv, P + sp);
+                        if (r == 4 || r != o) ++trm;
+                        if (ri < ilen) {
+                            int ic = (int)((iseq >> (3 * ip)) & 7u);
+                            if (ic == 4 || ic != o) { ++ins_mm; break; }
+                        } else {
+                            int r2 = plane_code(rf, sp + ilen);
+                            if (r2 == 4 || r2 != o) --trm;
+                        }
+                    }
+                }
+                if (found) return false;                                                   // :1243-1247
+                if (ins_mm == 0) {
+                    mismatch = -trm;
+                    found = true;
+                    new_left = prev.left;
+                    nn = prev.n;
+                    for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
+                    uint32_t bl = (cig_len(nc[nn - 1]) - (uint32_t)itpr) & 0x0FFFFFFFu;
+                    if (bl == 0) --nn; else nc[nn - 1] = cig(cig_op(nc[nn - 1]), bl);
+                    nc[nn++] = cig(OP_INS, (uint32_t)ilen);
+                    uint32_t fl = (cig_len(curr.c[0]) + (uint32_t)(itpr - ilen)) & 0x0FFFFFFFu;
+                    for (int q = fl > 0 ? 0 : 1; q < curr.n; ++q) {
+                        if (nn >= SPAN_MAXC + 8) return false;
+                        nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), fl) : curr.c[q];
+                    }
+                }
+            }
+            if (!found) return false;
+        } else if (dist > 0 && dist <= p.max_report_intron && prev.anti == curr.anti) {
+            // ---- junction / deletion closure :1311-1591
+            if (g_len(g, ref) == 0) return false;
+            int64_t lb = upper_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true));
+            int64_t ub = lower_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false));
+            const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
+            int best_diff = 0xff;
+            for (; lb < ub; ++lb) {
+                const u64 k = S.junc_keys[lb];
+                const int jl = (int)((int64_t)(k >> 30) - 1 - (int64_t)cbase);
+                const int jr = jl + (int)((k >> 1) & ((1ull << 29) - 1));
+                const int janti = (int)(k & 1ull);
+                const int dtl = jl - prev_right + 1, dtr = jr - curr.left;
+                if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
+                if (dtl > curr_front_len || -dtl > prev_end_len) continue;
+                int new_mm = 0, old_mm = 0;
+                if (dtl > 0) {
+                    Planes nr = g_fetch(g, ref, prev_right);      // new_cmp = ref[prev_right, jl+1)
+                    Planes orf = g_fetch(g, ref, curr.left);      // old_cmp = ref[curr.left, jr)
+                    for (int i = 0; i < dtl; ++i) {
+                        int s = seq_code(sv, P + i);               // curr.seq[i]; raw char vs Dna5: N == N
+                        if (s != plane_code(nr, i)) ++new_mm;
+                        if (s != plane_code(orf, i)) ++old_mm;
+                    }
+                } else if (dtl < 0) {
+                    int ad = -dtl;
+                    Planes nr = g_fetch(g, ref, jr);               // new_cmp = ref[jr, curr.left)
+                    Planes orf = g_fetch(g, ref, (int64_t)jl + 1); // old_cmp = ref[jl+1, prev_right)
+                    for (int i = 0; i < ad; ++i) {
+                        int s = seq_code(sv, P - ad + i);
+                        if (s != plane_code(nr, i)) ++new_mm;
+                        if (s != plane_code(orf, i)) ++old_mm;
+                    }
+                }
+                int diff = new_mm - old_mm;
+                if (diff >= best_diff || new_mm >= 2) continue;
+                best_diff = diff;
+                new_left = prev.left;
+                nn = prev.n;
+                for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
+                int nlb = (int)cig_len(nc[nn - 1]) + dtl;
+                int nrf = (int)cig_len(curr.c[0]) - dtr;
+                if (nlb > 0) nc[nn - 1] = cig(cig_op(nc[nn - 1]), (uint32_t)nlb); else --nn;
+                uint32_t skip = (uint32_t)(jr - jl - 1);
+                if (skip <= (uint32_t)p.max_deletion_length) {
+                    nc[nn++] = cig(OP_DEL, skip);
+                    anti_closure = psp ? prev.asplice : curr.asplice;
+                } else {
+                    nc[nn++] = cig(OP_REF_SKIP, skip);
+                    anti_closure = janti;
+                }
+                for (int q = nrf > 0 ? 0 : 1; q < curr.n; ++q) {
+                    if (nn >= SPAN_MAXC + 8) return false;
+                    nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), (uint32_t)nrf) : curr.c[q];
+                }
+                mismatch = best_diff;
+                found = true;
+            }
+            if (!found) return false;
+        } else if (!(dist == 0 && prev.anti == curr.anti))
+            return false;                                   // check_fusion, empty fusion set
+
+        if (found) {                                        // :1822-1870
+            if (nn > SPAN_MAXC) return false;               // capacity (documented limit)
+            Aln m;
+            int mismatches = (int)prev.mm + (int)curr.mm + mismatch;
+            m.ref_id = prev.ref_id; m.left = new_left; m.n = nn;
+            for (int q = 0; q < nn; ++q) m.c[q] = nc[q];
+            m.anti = (uint8_t)antisense; m.asplice = (uint8_t)anti_closure;
+            m.mm = (uint8_t)mismatches;
+            m.ed = (uint8_t)(mismatches + cig_gap_len(nc, nn));
+            m.rlen = prev.rlen + curr.rlen; m.valid = 1;
+            P += curr.rlen;
+            chain[pi] = m;
+            for (int q = ci; q + 1 < n; ++q) chain[q] = chain[q + 1];
+            --n;
+            ci = pi + 1;
+            continue;
+        }
+        P += curr.rlen;
+        ++pi; ++ci;
+    }
+    // :1888-1944
+    bool saw_as = false, saw_s = false;
+    int num_mm = 0;
+    out.n = 0;
+    for (int s = 0; s < n; ++s) {
+        num_mm += chain[s].mm;
+        if (aln_spliced(chain[s])) {
+            if (chain[s].asplice) { if (saw_s) return false; saw_as = true; }
+            else { if (saw_as) return false; saw_s = true; }
+        }
+        int b0 = 0;
+        if (out.n > 0 && cig_op(out.c[out.n - 1]) == cig_op(chain[s].c[0])) {
+            out.c[out.n - 1] = cig(cig_op(out.c[out.n - 1]), cig_len(out.c[out.n - 1]) + cig_len(chain[s].c[0]));
+            b0 = 1;
+        }
+        for (int b = b0; b < chain[s].n; ++b) { if (out.n >= SPAN_MAXC) return false; out.c[out.n++] = chain[s].c[b]; }
+    }
+    out.ref_id = chain[0].ref_id; out.left = left;
+    out.anti = (uint8_t)antisense; out.asplice = saw_as ? 1 : 0;
+    out.mm = (uint8_t)num_mm; out.ed = (uint8_t)(num_mm + cig_gap_len(out.c, out.n));
+    out.rlen = sv.len; out.valid = 1;
+    if (aln_read_len(out) != old_read_length || !check_editdist(g, out, sv)) return false;   // :2014-2033
+    return true;
+}
+
+// valid_hit (long_spanning_reads.cpp:2045-2099)
+THJ_HD bool valid_hit(const Params& p, const Aln& h) {
+    if (!h.valid) return false;
+    for (int i = 1; i < h.n; ++i) {
+        int cop = cig_op(h.c[i]), pop = cig_op(h.c[i - 1]);
+        uint32_t len = cig_len(h.c[i]);
+        if (!op_is_match(cop) && !op_is_match(pop)) return false;
+        if (cop == OP_INS && len > (uint32_t)p.max_insertion_length) return false;
+        if (cop == OP_DEL && len > (uint32_t)p.max_deletion_length) return false;
+        if (cop == OP_REF_SKIP && len < (uint32_t)p.min_report_intron) return false;
+    }
+    return op_is_match(cig_op(h.c[0])) && op_is_match(cig_op(h.c[h.n - 1]));
+}
+
+THJ_HD Aln aln_from_hit(const SpanHit& h, int seg, int L, int rl) {
+    Aln a;
+    a.ref_id = h.ref_id; a.left = h.left;
+    a.n = (int)(h.meta >> 24); if (a.n > 5) a.n = 5;
+    for (int i = 0; i < a.n; ++i) a.c[i] = h.cigar[i];
+    a.anti = (h.meta & SH_ANTI) ? 1 : 0; a.asplice = (h.meta & SH_ASPLICE) ? 1 : 0;
+    a.mm = (uint8_t)((h.meta >> 8) & 0xFF); a.ed = (uint8_t)((h.meta >> 16) & 0xFF);
+    int st = seg * L; if (st > rl) st = rl;
+    int ln = (h.meta & SH_END) ? rl - st : L; if (ln > rl - st) ln = rl - st;
+    a.rlen = ln; a.valid = 1;
+    return a;
+}
+
+// BowtieHit::operator< and == (bwt_map.h:167-207) for one read's joined hits
+THJ_HD bool aln_less(const Aln& a, const Aln& b) {
+    if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+    if (a.left != b.left) return a.left < b.left;
+    if (a.anti != b.anti) return a.anti < b.anti;
+    if (a.mm != b.mm) return a.mm < b.mm;
+    if (a.ed != b.ed) return a.ed < b.ed;
+    if (a.n != b.n) return a.n < b.n;
+    for (int i = 0; i < a.n; ++i)
+        if (a.c[i] != b.c[i]) {
+            int oa = cig_op(a.c[i]), ob = cig_op(b.c[i]);
+            return oa < ob || (oa == ob && cig_len(a.c[i]) < cig_len(b.c[i]));
+        }
+    return false;
+}
+THJ_HD bool aln_eq(const Aln& a, const Aln& b) {
+    if (a.ref_id != b.ref_id || a.anti != b.anti || a.left != b.left || a.asplice != b.asplice || a.ed != b.ed || a.n != b.n)
+        return false;
+    for (int i = 0; i < a.n; ++i) if (a.c[i] != b.c[i]) return false;
+    return true;
+}
+
+struct OutAln {             // == thj_aln, 128 bytes
+    uint32_t read_idx;
+    uint32_t ref_id;
+    int32_t left;
+    uint8_t flags, mismatches, edit_dist, n_cigar;
+    int16_t AS;
+    uint8_t XM, XO, XG, md_len;
+    uint16_t order;         // position among the read's output records
+    uint32_t cigar[SPAN_MAXC];
+    char md[40];
+};
+
+THJ_HD int put_int(char* dst, int cap, int pos, int v) {
+    char tmp[12]; int n = 0;
+    if (v == 0) tmp[n++] = '0';
+    while (v > 0) { tmp[n++] = (char)('0' + v % 10); v /= 10; }
+    while (n > 0 && pos < cap) dst[pos++] = tmp[--n];
+    return n > 0 ? cap + 1 : pos;        // cap+1 signals overflow
+}
+
+// bowtie_sam_extra (bwt_map.cpp:2467-2648).  qual = this read's phred+33 bytes; qual_rev: the
+// joined hit's qual is the reversed read qual (merge_chain :1966-1978).  Returns false when the
+// MD string does not fit.
+THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqView& sv, const uint8_t* qual, int qlen,
+                      bool qual_rev, OutAln& o) {
+    static const char B[5] = {'A', 'C', 'G', 'T', 'N'};
+    int pos_seq = 0, pos_mm = 0, mismatch = 0, opens = 0, conts = 0, AS = 0, ml = 0;
+    int64_t pos_ref = h.left;
+    const int cap = (int)sizeof(o.md);
+    for (int i = 0; i < h.n && ml <= cap; ++i) {
+        int op = cig_op(h.c[i]);
+        int len = (int)cig_len(h.c[i]);
+        if (op == OP_MATCH) {
+            for (int off = 0; off < len && ml <= cap; off += 64) {
+                int l = len - off < 64 ? len - off : 64;
+                if (pos_seq + off + l > sv.len) l = sv.len - pos_seq - off;
+                if (l <= 0) break;
+                Planes r = g_fetch(g, h.ref_id, pos_ref + off);
+                Planes s = seq_fetch(sv, pos_seq + off, l);
+                u64 mm = dna5_mism(r, s, l);
+                u64 bothn = r.nm & s.nm & lowmask(l);
+                AS -= p.bowtie2_penalty_for_N * popc(bothn);        // matching N: still penalised (:2552-2556)
+                int last = 0;
+                while (mm) {
+                    int b = ctz(mm);
+                    mm &= mm - 1;
+                    ++mismatch;
+                    int sp = pos_seq + off + b;
+                    if (sp < qlen) {
+                        if (((r.nm | s.nm) >> b) & 1ull) AS -= p.bowtie2_penalty_for_N;
+                        else {
+                            int q = (int)qual[qual_rev ? qlen - 1 - sp : sp] - 33; if (q > 40) q = 40;
+                            // int(min + (max-min)*q/40.0): exact in integers (the fraction is a multiple of 1/40)
+                            AS -= p.bowtie2_min_penalty + ((p.bowtie2_max_penalty - p.bowtie2_min_penalty) * q) / 40;
+                        }
+                    }
+                    pos_mm += b - last;
+                    ml = put_int(o.md, cap, ml, pos_mm);
+                    if (ml < cap) o.md[ml] = B[plane_code(r, b)];
+                    ++ml;
+                    pos_mm = 0; last = b + 1;
+                }
+                pos_mm += l - last;
+            }
+            pos_seq += len; pos_ref += len;
+        } else if (op == OP_INS) {
+            pos_seq += len;
+            AS -= p.bowtie2_read_gap_open + p.bowtie2_read_gap_cont * len;
+            ++opens; conts += len;
+        } else if (op == OP_DEL) {
+            AS -= p.bowtie2_ref_gap_open + p.bowtie2_ref_gap_cont * len;
+            ++opens; conts += len;
+            ml = put_int(o.md, cap, ml, pos_mm);
+            if (ml < cap) o.md[ml] = '^';
+            ++ml;
+            Planes r = g_fetch(g, h.ref_id, pos_ref);
+            for (int k = 0; k < len && k < 64; ++k) { if (ml < cap) o.md[ml] = B[plane_code(r, k)]; ++ml; }
+            pos_ref += len; pos_mm = 0;
+        } else if (op == OP_REF_SKIP) pos_ref += len;
+    }
+    if (ml <= cap) ml = put_int(o.md, cap, ml, pos_mm);
+    if (ml > cap) return false;
+    o.md_len = (uint8_t)ml;
+    for (int k = ml; k < cap; ++k) o.md[k] = 0;
+    o.AS = (int16_t)AS; o.XM = (uint8_t)mismatch; o.XO = (uint8_t)opens; o.XG = (uint8_t)conts;
+    return true;
+}
+
+enum { SPAN_OK = 0, SPAN_TOO_MANY_JOINED = 1, SPAN_MD_OVERFLOW = 2 };
+
+// One read: JoinSegmentsWorker body (long_spanning_reads.cpp:2767-2831).  Emits through
+// sink.emit(const OutAln&) in output order; returns a SPAN_* status.
+template <class Sink>
+THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, const uint32_t* so, int nseg,
+                     const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+    if (so[1] == so[0]) return SPAN_OK;                         // worker iterates over first-segment groups
+    int nsegs = 0;
+    while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;   // look_right stops at the first empty segment (:151)
+    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
+    if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;    // :2777-2785
+    if (p.bowtie2)
+        for (int s = 0; s < nsegs; ++s)
+            if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;   // :2625-2632
+    const int L = p.segment_length;
+    Aln joined[SPAN_MAXJOIN]; int nj = 0;
+    int status = SPAN_OK;
+    SeqView fwd = seq_forward(rp, W, rl);
+    SeqView rev = seq_revcomp(rp, W, rl);
+    uint32_t idx[SPAN_MAXSEG];
+    Aln stack[SPAN_MAXSEG];
+    for (uint32_t i0 = so[0]; i0 < so[1]; ++i0) {                // :2634-2664
+        stack[0] = aln_from_hit(hits[i0], 0, L, rl);
+        int num_try = 10000;
+        int depth = 1;
+        idx[1] = so[1];
+        // iterative dfs_seg_hits (:2222-2610, fusion_search == false)
+        while (depth >= 1) {
+            if (num_try <= 0) break;
+            if (depth == nsegs) {
+                --num_try;
+                // merge_segment_chain :2101-2220
+                Aln bh;
+                bool ok;
+                if (nsegs > 1) {
+                    Aln chain[SPAN_MAXSEG];
+                    const bool anti = stack[0].anti;
+                    for (int q = 0; q < nsegs; ++q) chain[q] = anti ? stack[nsegs - 1 - q] : stack[q];
+                    ok = merge_chain(g, p, S, anti ? rev : fwd, chain, nsegs, bh);
+                } else { bh = stack[0]; ok = true; }
+                if (ok && valid_hit(p, bh)) {
+                    if (nj < SPAN_MAXJOIN) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED;
+                }
+                --depth;
+                continue;
+            }
+            if (idx[depth] >= so[depth + 1]) { --depth; continue; }
+            const SpanHit sh = hits[idx[depth]++];
+            Aln cand = aln_from_hit(sh, depth, L, rl);
+            const Aln& prev = stack[depth - 1];
+            bool okc = false;
+            if (prev.ref_id == cand.ref_id && prev.anti == cand.anti) {
+                int dist = prev.anti ? prev.left - aln_right(cand) : cand.left - aln_right(prev);   // :2352-2378, :2531-2556
+                okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+            }
+            if (okc) {
+                stack[depth] = cand;
+                ++depth;
+                if (depth < nsegs) idx[depth] = so[depth];
+            }
+        }
+    }
+    // sort + unique (:2805-2807): insertion sort (stable; what std::sort does below 16 elements)
+    for (int i = 1; i < nj; ++i) {
+        Aln t = joined[i]; int k = i;
+        while (k > 0 && aln_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
+        joined[k] = t;
+    }
+    int w = 0;
+    for (int i = 0; i < nj; ++i) if (w == 0 || !aln_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];
+    nj = w;
+    uint16_t order = 0;
+    for (int i = 0; i < nj; ++i) {
+        const Aln& h = joined[i];
+        int gapl = (uint8_t)(h.ed - h.mm);
+        if ((int)h.mm > p.read_mismatches || gapl > p.read_gap_length || (int)h.ed > p.read_edit_dist) continue;   // :2810-2813
+        OutAln o;
+        o.read_idx = read_idx; o.ref_id = h.ref_id; o.left = h.left;
+        o.flags = (uint8_t)((h.anti ? 1 : 0) | (h.asplice ? 4 : 0));
+        o.mismatches = h.mm; o.edit_dist = h.ed; o.n_cigar = (uint8_t)h.n;
+        for (int q = 0; q < SPAN_MAXC; ++q) o.cigar[q] = q < h.n ? h.c[q] : 0;
+        o.order = order++;
+        // merge_chain :1966-1978: qual reversed when the joined sequence differs from the read;
+        // a single-segment hit carries the BAM record's own SEQ/QUAL (reversed when antisense)
+        bool qrev;
+        const SeqView& sv = h.anti ? rev : fwd;
+        if (nsegs == 1) qrev = h.anti;
+        else {
+            bool same = true;
+            for (int q = 0; q < 3 * W; ++q) if (sv.w[q] != fwd.w[q]) same = false;
+            qrev = !same;
+        }
+        if (!sam_extra(g, p, h, sv, qual, rl, qrev, o)) { status = SPAN_MD_OVERFLOW; continue; }
+        sink.emit(o);
+    }
+    return status;
+}
+
+}  // namespace thj

@@ -260,3 +260,128 @@ class Context:
     def merge_keys(self, kind: int, d_keys: int, n: int):
         _check(self.lib, self.lib.thj_segjuncs_merge_keys_async(self._ctx, kind, C.c_void_p(d_keys), C.c_int64(n)),
                "thj_segjuncs_merge_keys_async")
+
+
+# ------------------------------------------------------------------ long_spanning_reads
+
+from .batch import Aln, SpanBatch  # noqa: E402
+
+ALN_DTYPE = np.dtype([
+    ("read_idx", "<u4"), ("ref_id", "<u4"), ("left", "<i4"),
+    ("flags", "u1"), ("mismatches", "u1"), ("edit_dist", "u1"), ("n_cigar", "u1"),
+    ("AS", "<i2"), ("XM", "u1"), ("XO", "u1"), ("XG", "u1"), ("md_len", "u1"), ("order", "<u2"),
+    ("cigar", "<u4", (16,)), ("md", "S40"),
+])
+assert ALN_DTYPE.itemsize == 128
+
+
+class CSpanBatch(C.Structure):
+    _fields_ = [("n_reads", C.c_int32), ("nseg", C.c_int32), ("words_per_plane", C.c_int32), ("qual_stride", C.c_int32),
+                ("seg_off", C.c_void_p), ("hits", C.c_void_p), ("read_planes", C.c_void_p), ("read_len", C.c_void_p),
+                ("quals", C.c_void_p)]
+
+
+def encode_ins_seq(seq: str) -> int:
+    v = 0
+    for k, ch in enumerate(seq):
+        v |= (INS_CODE.index(ch) if ch in INS_CODE else 4) << (3 * k)
+    return v
+
+
+def pack_span_batch(b: SpanBatch, lib=None):
+    """-> dict of contiguous HOST arrays in the thj_span_batch layout"""
+    lib = lib or load_lib()
+    n = b.n_reads
+    lens_ = np.diff(b.read_off) if n else np.zeros(0, dtype=np.int64)
+    mx = int(lens_.max()) if n else 1
+    W = words_per_plane(mx)
+    planes = np.zeros(n * 3 * W, dtype=np.uint64)
+    lens = np.zeros(n, dtype=np.uint16)
+    bases = np.ascontiguousarray(b.bases, dtype=np.uint8)
+    off = np.ascontiguousarray(b.read_off, dtype=np.int64)
+    _check(lib, lib.thj_reads_pack(C.c_int64(n), _ptr(off), _ptr(bases), W, _ptr(planes), _ptr(lens)), "thj_reads_pack")
+    stride = (mx + 3) // 4 * 4
+    quals = np.zeros(n * stride, dtype=np.uint8)
+    for r in range(n):
+        quals[r * stride:r * stride + lens_[r]] = b.quals[off[r]:off[r + 1]]
+    return dict(n_reads=n, nseg=b.nseg, W=W, qual_stride=stride, seg_off=np.ascontiguousarray(b.seg_off, dtype=np.uint32),
+                hits=np.ascontiguousarray(b.hits), planes=planes, read_len=lens, quals=quals)
+
+
+def alns_from_array(a: np.ndarray) -> List[Aln]:
+    out = []
+    for x in a:
+        n = int(x["n_cigar"])
+        out.append(Aln(int(x["read_idx"]), int(x["ref_id"]), int(x["left"]), bool(x["flags"] & 1), bool(x["flags"] & 4),
+                       int(x["mismatches"]), int(x["edit_dist"]), tuple(int(c) for c in x["cigar"][:n]),
+                       int(x["AS"]), int(x["XM"]), int(x["XO"]), int(x["XG"]), x["md"][:int(x["md_len"])].decode()))
+    return out
+
+
+def _ins_table(insertions) -> np.ndarray:
+    t = np.zeros((max(1, len(insertions)), 4), dtype=np.uint32)
+    for k, (ref, left, seq) in enumerate(insertions):
+        t[k] = (ref, left, len(seq), encode_ins_seq(seq))
+    return t
+
+
+def _span_methods():
+    def upload_span_sets(self, juncs: np.ndarray, insertions):
+        j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
+        t = _ins_table(insertions)
+        _check(self.lib, self.lib.thj_span_sets_upload(self._ctx, _ptr(j), C.c_int64(len(j)), _ptr(t), C.c_int64(len(insertions))),
+               "thj_span_sets_upload")
+
+    def span_sets_from_segjuncs(self):
+        _check(self.lib, self.lib.thj_span_sets_from_segjuncs(self._ctx), "thj_span_sets_from_segjuncs")
+
+    def upload_span_batch(self, b: SpanBatch):
+        d = pack_span_batch(b, self.lib)
+        cb = CSpanBatch()
+        cb.n_reads, cb.nseg, cb.words_per_plane, cb.qual_stride = d["n_reads"], d["nseg"], d["W"], d["qual_stride"]
+        cb.seg_off, cb.hits, cb.read_planes, cb.read_len, cb.quals = [d[k].ctypes.data for k in ("seg_off", "hits", "planes", "read_len", "quals")]
+        out = C.c_void_p()
+        _check(self.lib, self.lib.thj_span_batch_upload(self._ctx, C.byref(cb), C.c_int64(len(d["hits"])), C.byref(out)),
+               "thj_span_batch_upload")
+        self._span_batches = getattr(self, "_span_batches", []) + [out]
+        return out
+
+    def span_reset(self):
+        _check(self.lib, self.lib.thj_span_reset_async(self._ctx), "thj_span_reset_async")
+
+    def span_run(self, p: Params, batch):
+        cp = p.as_ctypes()
+        arg = C.byref(batch) if isinstance(batch, CSpanBatch) else batch
+        _check(self.lib, self.lib.thj_span_run_async(self._ctx, C.byref(cp), arg), "thj_span_run_async")
+
+    def span_finish(self) -> int:
+        n = C.c_int64()
+        _check(self.lib, self.lib.thj_span_finish(self._ctx, C.byref(n)), "thj_span_finish")
+        return n.value
+
+    def span_download(self, n: int) -> np.ndarray:
+        a = np.zeros(max(1, n), dtype=ALN_DTYPE)
+        _check(self.lib, self.lib.thj_span_download(self._ctx, _ptr(a)), "thj_span_download")
+        return a[:n]
+
+    def spanning(self, p: Params, batches) -> List[Aln]:
+        self.span_reset()
+        for b in batches:
+            self.span_run(p, b)
+        return alns_from_array(self.span_download(self.span_finish()))
+
+    def profile_span(self, enable: bool = True):
+        ms = C.c_double()
+        n = C.c_int64()
+        _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, C.byref(ms), C.byref(n)), "thj_profile_span")
+        return ms.value, n.value
+
+    for f in (upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
+              span_download, spanning, profile_span):
+        setattr(Context, f.__name__, f)
+
+
+_span_methods()
+
+ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
+                "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span"]
