@@ -85,6 +85,35 @@ def sample_segbatch(w, m):
                     mo, np.ascontiguousarray(mh).view(HIT_DTYPE).reshape(-1))
 
 
+def sample_spanbatch(w, m):
+    """First m reads of a device workload as a host SpanBatch for the oracle."""
+    from tophat_amd.batch import SPAN_HIT_DTYPE, SpanBatch
+    sb = sample_segbatch(w, m)
+    nseg = w["nseg"]
+    m = sb.n_reads
+    so = w["span_off"][:m * nseg + 1].cpu().numpy().astype(np.uint32)
+    hits = w["span_hits"][:int(so[-1])].cpu().numpy().astype(np.int32)
+    st = w["qual_stride"]
+    q = w["quals"][:m * st].cpu().numpy().reshape(m, st)
+    rl = np.diff(sb.read_off)
+    L = int(rl.max()) if m else 0
+    quals = np.ascontiguousarray(q[:, :L]).reshape(-1) if m and (rl == L).all() else \
+        np.concatenate([q[i, :rl[i]] for i in range(m)])
+    return SpanBatch(nseg, sb.read_id, sb.read_off, sb.bases, quals, so,
+                     np.ascontiguousarray(hits).view(SPAN_HIT_DTYPE).reshape(-1))
+
+
+def span_cbatch_from_tensors(w) -> host.CSpanBatch:
+    cb = host.CSpanBatch()
+    cb.n_reads, cb.nseg, cb.words_per_plane, cb.qual_stride = w["n_reads"], w["nseg"], w["W"], w["qual_stride"]
+    cb.seg_off = w["span_off"].data_ptr()
+    cb.hits = w["span_hits"].data_ptr()
+    cb.read_planes = w["planes"].data_ptr()
+    cb.read_len = w["read_len"].data_ptr()
+    cb.quals = w["quals"].data_ptr()
+    return cb
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,43 +153,71 @@ def main():
     t_gen = time.time() - t_gen
     p_left = Params(read_side=READ_LEFT, inner_dist_mean=50, inner_dist_std_dev=20)
     p_right = Params(read_side=READ_RIGHT, inner_dist_mean=50, inner_dist_std_dev=20)
-    cb_left = cbatch_from_tensors(w["left"], 0)
-    cb_right = cbatch_from_tensors(w["right"], 0)   # per-side ordinals: sides are merged left-first
+    p_span = Params()
+    # first-inserted-wins priority of std::set<Insertion>: all left reads (rank order) before all right reads
+    cb_left = cbatch_from_tensors(w["left"], rank * args.pairs)
+    cb_right = cbatch_from_tensors(w["right"], world * args.pairs + rank * args.pairs)
+    sp_left = span_cbatch_from_tensors(w["left"])
+    sp_right = span_cbatch_from_tensors(w["right"])
     ctx.configure(1 << 22, 1 << 20)
+    hip = ctypes.cdll.LoadLibrary("libamdhip64.so")
+
+    def d2d(dst_tensor, src_ptr, nbytes):
+        if nbytes:
+            hip.hipMemcpyAsync(ctypes.c_void_p(dst_tensor.data_ptr()), ctypes.c_void_p(src_ptr), ctypes.c_size_t(nbytes), 3,
+                               ctypes.c_void_p(stream.cuda_stream))
 
     def allgather_merge():
-        """one all-gather of the sorted per-rank key sets over RCCL, merged into every table"""
+        """ONE exchange step: all-gather the sorted per-rank event key sets over RCCL/xGMI and merge them into
+        every rank's tables (segment_juncs.cpp:4911-4916 across GPUs)."""
         import torch.distributed as dist
-        for kind in (0, 1):
-            ptr, n = ctx.device_keys(kind)
-            nt = torch.tensor([n], dtype=torch.int64, device=dev)
-            sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(sizes, nt)
-            mx = max(int(s.item()) for s in sizes)
-            if mx == 0:
+        jp, jn = ctx.device_keys(0)
+        dp, dn = ctx.device_keys(1)
+        ik, iv, inn = ctx.device_insertions()
+        nt = torch.tensor([jn, dn, inn], dtype=torch.int64, device=dev)
+        sizes = torch.zeros((world, 3), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, nt)
+        sizes = sizes.cpu()
+        mx = int((sizes[:, 0] + sizes[:, 1] + 2 * sizes[:, 2]).max())
+        if mx == 0:
+            return ctx.finish()
+        mine = torch.zeros(mx, dtype=torch.int64, device=dev)
+        d2d(mine[0:], jp, jn * 8)
+        d2d(mine[jn:], dp, dn * 8)
+        d2d(mine[jn + dn:], ik, inn * 8)
+        d2d(mine[jn + dn + inn:], iv, inn * 8)
+        stream.synchronize()
+        gathered = torch.empty((world, mx), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(gathered, mine)
+        torch.cuda.synchronize()
+        for r_ in range(world):
+            if r_ == rank:
                 continue
-            mine = torch.zeros(mx, dtype=torch.int64, device=dev)
-            if n:
-                ctypes.cdll.LoadLibrary("libamdhip64.so").hipMemcpyAsync(
-                    ctypes.c_void_p(mine.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(n * 8), 3,
-                    ctypes.c_void_p(stream.cuda_stream))
-            stream.synchronize()
-            gathered = [torch.empty(mx, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(gathered, mine)
-            torch.cuda.synchronize()
-            for r_, t_ in enumerate(gathered):
-                if r_ != rank and int(sizes[r_].item()):
-                    ctx.merge_keys(kind, t_.data_ptr(), int(sizes[r_].item()))
-        return ctx.finish()
+            a, b_, c_ = (int(x) for x in sizes[r_])
+            base = gathered[r_].data_ptr()
+            ctx.merge_keys(0, base, a)
+            ctx.merge_keys(1, base + 8 * a, b_)
+            ctx.merge_insertions(base + 8 * (a + b_), base + 8 * (a + b_ + c_), c_)
+        cnt2 = ctx.finish()
+        del gathered
+        return cnt2
 
     def step():
+        # ---- segment_juncs stage
         ctx.reset()
         ctx.run(p_left, cb_left)
         ctx.run(p_right, cb_right)
         cnt = ctx.finish()
         if world > 1:
-            cnt = allgather_merge()
-        return cnt
+            cnt2 = allgather_merge()
+            cnt.n_juncs, cnt.n_deletions, cnt.n_insertions = cnt2.n_juncs, cnt2.n_deletions, cnt2.n_insertions
+        # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
+        ctx.span_sets_from_segjuncs()
+        ctx.span_reset()
+        ctx.span_run(p_span, sp_left)
+        ctx.span_run(p_span, sp_right)
+        n_alns = ctx.span_finish()
+        return cnt, n_alns
 
     def barrier():
         if world > 1:
@@ -169,47 +226,68 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        cnt = step()
+        cnt, n_alns = step()
     ctx.profile(True)
+    ctx.profile_span(True)
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
-        cnt = step()
+        cnt, n_alns = step()
     barrier()
     elapsed = time.time() - t0
     kern_ms, launches = ctx.profile(False)
+    span_ms, span_launches = ctx.profile_span(False)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # ---- roofline of the dominant kernel (thj_k_segjuncs), per launch ------------------------
-    # algorithmic bytes (DESIGN.md "Roofline"): 16 B per hit record + 4 B per (read, segment) CSR
-    # offset + per RefSeg window 2 x 64 B genome lines + 38 B of support-read planes + per indel
-    # pair 64 B genome + 38 B read + 8 B per event emitted.  Counters come from the kernel itself.
-    n_launch = 2  # left + right per step
-    hits = cnt.n_hits_read / n_launch
-    csr = 4.0 * (args.pairs * w["left"]["nseg"] + 1)
-    rl_bytes = (100 + 3) // 4 + (100 + 7) // 8
-    alg = 16.0 * hits + csr + (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
+    # ---- roofline, per launch (one launch = one side's batch of `pairs` reads); DESIGN.md "Roofline" ---------
+    rl_bytes = (100 + 3) // 4 + (100 + 7) // 8            # packed read: 2-bit bases + N mask
+    n_launch = 2
+    nseg = w["left"]["nseg"]
+    # thj_k_segjuncs: 16 B per hit record + 4 B per (read, segment) CSR offset + per RefSeg window two 64-B genome
+    # lines and the read + per indel pair one genome line and the read + 8 B per distinct event emitted
+    seg_alg = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1) \
+        + (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
-    achieved = alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # thj_k_stitch: 32 B per hit record + CSR + the read once + per output record two 64-B genome lines (consistency
+    # check + MD pass share them), one 64-B line of junction keys per closure and the 128-B record itself
+    span_hits = float(int(w["left"]["span_off"][-1]) + int(w["right"]["span_off"][-1])) / n_launch
+    span_alg = 32.0 * span_hits + 4.0 * (args.pairs * nseg + 1) + args.pairs * rl_bytes \
+        + (n_alns / n_launch) * (128 + 64 + 128)
+    kernels = [
+        {"kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms, "launches": launches, "algorithmic_bytes_per_launch": seg_alg,
+         "achieved": seg_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0},
+        {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms, "launches": span_launches, "algorithmic_bytes_per_launch": span_alg,
+         "achieved": span_alg / (span_ms * 1e-3) / 1e9 if span_ms > 0 else 0.0},
+    ]
+    dom = max(kernels, key=lambda k: k["avg_kernel_ms"])
 
     result = None
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline:
             import orc
+            from tophat_amd.batch import events_to_span_inputs, merge_events
             m = min(args.cpu_sample, args.pairs)
             og = orc.Genome(strs)
             sb_l, sb_r = sample_segbatch(w["left"], m), sample_segbatch(w["right"], m)
+            sp_l, sp_r = sample_spanbatch(w["left"], m), sample_spanbatch(w["right"], m)
             t1 = time.time()
             e_l = orc.segjuncs(p_left, og, sb_l)
             e_r = orc.segjuncs(p_right, og, sb_r)
-            dt = time.time() - t1
+            jj, ii = events_to_span_inputs(merge_events(e_l, e_r))
+            t2 = time.time()
+            lib_o = orc._lib()
+            n_rec = orc.spanning_count(p_span, og, sp_l, jj, ii) + orc.spanning_count(p_span, og, sp_r, jj, ii)
+            t3 = time.time()
+            dt = t3 - t1
             cpu = {"value": m / dt, "unit": "read-pairs/s", "cores": 1, "kind": "port",
-                   "sample": "first %d pairs of the same synthetic batch, segment_juncs stage, oracle/liborc.so (plain C, 1 thread), %.1f s" % (m, dt)}
+                   "sample": "first %d pairs of the same synthetic batch through both stages with oracle/liborc.so "
+                             "(plain-C restatement, 1 thread): segment_juncs %.1f s + long_spanning_reads %.1f s, %d records" % (
+                                 m, t2 - t1, t3 - t2, n_rec)}
         result = {
             "metric": "paired reads/sec through segment_juncs+long_spanning_reads; junctions.bed diff=0",
             "value": args.pairs * world * args.steps / elapsed,
@@ -217,21 +295,23 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64 bit-planes (integer compare/popcount)", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x 2x100 bp PE synthetic vs %d bp chr20-sized genome per GPU; "
-                                   "stage coverage: segment_juncs (gap/indel/rescue/window kernels + event dedup/sort"
-                                   "%s); long_spanning_reads stage not yet on device" % (
-                                       args.pairs, args.genome_len, " + RCCL key all-gather" if world > 1 else ""),
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d x 2x100 bp PE synthetic vs %d bp chr20-sized genome per GPU, inputs "
+                                   "resident in HBM; both stages on device: segment_juncs (rescue/gap/indel/window kernels, "
+                                   "event dedup+sort%s) then long_spanning_reads (stitch kernel fed device-to-device with the "
+                                   "junction set, record ordering)" % (args.pairs, args.genome_len,
+                                                                      ", RCCL all-gather of event keys" if world > 1 else ""),
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
                        "parallelism": "reads sharded x%d, genome replicated" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms, "launches": launches,
-                         "algorithmic_bytes_per_launch": alg},
+            "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                         "avg_kernel_ms": dom["avg_kernel_ms"], "launches": dom["launches"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+            "kernels": kernels,
             "cpu_baseline": cpu,
             "events": {"junctions": cnt.n_juncs, "deletions": cnt.n_deletions, "insertions": cnt.n_insertions,
                        "windows_per_step": cnt.n_windows, "rescue_pairs_per_step": cnt.n_rescue_pairs,
-                       "overflow_blocks": cnt.n_overflow_blocks},
+                       "overflow_blocks": cnt.n_overflow_blocks, "spanning_records_per_step": n_alns},
             "gen_seconds": t_gen,
         }
         print(json.dumps(result))

@@ -192,6 +192,12 @@ int thj_segjuncs_device_keys(thj_ctx* ctx, int kind, const uint64_t** d_keys, in
  * context's table: the merge step of segment_juncs.cpp:4911-4916 across GPUs. */
 int thj_segjuncs_merge_keys_async(thj_ctx* ctx, int kind, const uint64_t* d_keys, int64_t n);
 
+/* The sorted insertion table after finish: packed keys and values (value = first-wins
+ * priority << 20 | bases), DEVICE pointers; and its merge counterpart (atomicMin on the
+ * value = "earlier insertion wins", insertions.h:52-67 + std::set::insert). */
+int thj_segjuncs_device_insertions(thj_ctx* ctx, const uint64_t** d_keys, const uint64_t** d_vals, int64_t* n);
+int thj_segjuncs_merge_insertions_async(thj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, int64_t n);
+
 /* Average duration (ms) of the dominant kernel (`thj_k_segjuncs`) over the
  * launches since the last call, measured with HIP events on the context
  * stream; also returns the launch count.  Enables event recording when

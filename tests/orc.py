@@ -160,3 +160,29 @@ def spanning(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> list:
                        tuple(a.cigar[i] for i in range(a.n_cigar)), a.AS, a.XM, a.XO, a.XG, a.md.decode()))
     lib.orc_free(out)
     return res
+
+
+def spanning_count(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> int:
+    """Runs the spanning oracle and returns only the record count (bench.py's cpu_baseline leg:
+    avoids building Python objects for millions of records)."""
+    lib = _lib()
+    op = OrcSpanParams()
+    for n, _ in OrcSpanParams._fields_:
+        setattr(op, n, int(getattr(p, n)))
+    ob = OrcSpanBatch()
+    ob.n_reads, ob.nseg = b.n_reads, b.nseg
+    keep = [np.ascontiguousarray(b.read_off, dtype=np.int64), np.ascontiguousarray(b.bases, dtype=np.uint8),
+            np.ascontiguousarray(b.quals, dtype=np.uint8), np.ascontiguousarray(b.seg_off, dtype=np.int64),
+            np.ascontiguousarray(b.hits)]
+    ob.read_off, ob.bases, ob.quals, ob.seg_off, ob.hits = [a.ctypes.data for a in keep]
+    j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
+    ins = (OrcInsIn * max(1, len(insertions)))()
+    for k, (ref, left, seq) in enumerate(insertions):
+        ins[k].ref_id, ins[k].left, ins[k].seq = ref, left, seq.encode()
+    out = C.POINTER(OrcAln)()
+    n_out = C.c_int64()
+    rc = lib.orc_spanning_batch(C.byref(op), C.byref(g.c), C.byref(ob), C.c_void_p(j.ctypes.data), C.c_int64(len(j)),
+                                ins, C.c_int64(len(insertions)), C.byref(out), C.byref(n_out))
+    assert rc == 0
+    lib.orc_free(out)
+    return int(n_out.value)

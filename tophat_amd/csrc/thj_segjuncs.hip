@@ -313,6 +313,12 @@ __global__ __launch_bounds__(256) void thj_k_merge_keys(u64* tab, u64 mask, cons
         set_insert(tab, mask, keys[i], count, ovf);
 }
 
+__global__ __launch_bounds__(256) void thj_k_merge_ins(u64* keys, u64* vals, u64 mask, const u64* in_keys, const u64* in_vals,
+                                                       int64_t n, unsigned long long* count, unsigned int* ovf) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        map_insert_min(keys, vals, mask, in_keys[i], in_vals[i], count, ovf);
+}
+
 // ------------------------------------------------------------------ context
 
 #include "thj_ctx.h"
@@ -634,6 +640,24 @@ extern "C" int thj_segjuncs_merge_keys_async(thj_ctx* c, int kind, const uint64_
     else
         hipLaunchKernelGGL(thj_k_merge_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_del, (u64)c->indel_cap - 1,
                            (const u64*)d_keys, n, &c->d_cnt[CNT_DEL], &c->d_ovf[1]);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_segjuncs_device_insertions(thj_ctx* c, const uint64_t** d_keys, const uint64_t** d_vals, int64_t* n) {
+    if (!c || !d_keys || !d_vals || !n) { thj_set_error("thj_segjuncs_device_insertions: bad argument"); return THJ_EINVAL; }
+    *d_keys = (const uint64_t*)c->d_ins_key_sorted; *d_vals = (const uint64_t*)c->d_ins_val_sorted; *n = c->n_ins;
+    return THJ_OK;
+}
+
+extern "C" int thj_segjuncs_merge_insertions_async(thj_ctx* c, const uint64_t* d_keys, const uint64_t* d_vals, int64_t n) {
+    if (!c || (n > 0 && (!d_keys || !d_vals))) { thj_set_error("thj_segjuncs_merge_insertions_async: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (n <= 0) return THJ_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(thj_k_merge_ins, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_ins_key, c->d_ins_val,
+                       (u64)c->indel_cap - 1, (const u64*)d_keys, (const u64*)d_vals, n, &c->d_cnt[CNT_INS], &c->d_ovf[2]);
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }

@@ -54,6 +54,7 @@ ABI_SYMBOLS = [
     "thj_segjuncs_configure", "thj_segjuncs_reset_async", "thj_segjuncs_run_async",
     "thj_segjuncs_finish", "thj_segjuncs_download", "thj_segjuncs_device_keys",
     "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
+    "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
 ]
 
 _lib = None
@@ -256,6 +257,16 @@ class Context:
         _check(self.lib, self.lib.thj_segjuncs_device_keys(self._ctx, kind, C.byref(p), C.byref(n)),
                "thj_segjuncs_device_keys")
         return (p.value or 0), n.value
+
+    def device_insertions(self) -> Tuple[int, int, int]:
+        k, v, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        _check(self.lib, self.lib.thj_segjuncs_device_insertions(self._ctx, C.byref(k), C.byref(v), C.byref(n)),
+               "thj_segjuncs_device_insertions")
+        return (k.value or 0), (v.value or 0), n.value
+
+    def merge_insertions(self, d_keys: int, d_vals: int, n: int):
+        _check(self.lib, self.lib.thj_segjuncs_merge_insertions_async(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_vals), C.c_int64(n)),
+               "thj_segjuncs_merge_insertions_async")
 
     def merge_keys(self, kind: int, d_keys: int, n: int):
         _check(self.lib, self.lib.thj_segjuncs_merge_keys_async(self._ctx, kind, C.c_void_p(d_keys), C.c_int64(n)),

@@ -393,8 +393,8 @@ def make_scale_genome(seed: int, contig_lens: Sequence[int], n_introns: int, int
                       intron_max: int = 200000, exon_len: int = 600):
     """Random ACGT contigs with as many planted two-exon genes (exon-intron-exon) as fit, up to
     n_introns: intron lengths log-uniform in [intron_min, intron_max], motifs GT-AG 90 % / GC-AG 7 % /
-    AT-AC 3 %, both strands.  Returns (list of uint8 ASCII numpy arrays, gene table int64[n,4] =
-    (contig, exon1_start, intron_start, intron_end))."""
+    AT-AC 3 %, both strands.  Returns (list of uint8 ASCII numpy arrays, gene table int64[n,5] =
+    (contig, exon1_start, intron_start, intron_end, minus_strand))."""
     import numpy as np
     rng = np.random.default_rng(seed)
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -414,20 +414,21 @@ def make_scale_genome(seed: int, contig_lens: Sequence[int], n_introns: int, int
             a1 = d0 + int(il)              # first base after the intron
             u = rng.random()
             don, acc = (b"GT", b"AG") if u < 0.90 else ((b"GC", b"AG") if u < 0.97 else (b"AT", b"AC"))
-            if rng.random() < 0.5:
+            minus = rng.random() >= 0.5
+            if not minus:
                 s[d0:d0 + 2] = np.frombuffer(don, dtype=np.uint8)
                 s[a1 - 2:a1] = np.frombuffer(acc, dtype=np.uint8)
             else:   # minus-strand gene: rc(acceptor) .. rc(donor)
                 s[d0:d0 + 2] = np.array([comp[acc[1]], comp[acc[0]]], dtype=np.uint8)
                 s[a1 - 2:a1] = np.array([comp[don[1]], comp[don[0]]], dtype=np.uint8)
-            genes.append((ci, pos, d0, a1))
+            genes.append((ci, pos, d0, a1, int(minus)))
             pos = a1 + exon_len + 200
         # a few N runs
         for _ in range(5):
             st = int(rng.integers(0, max(1, n - 2000)))
             s[st:st + 1000] = ord("N")
         seqs.append(s)
-    return seqs, np.array(genes, dtype=np.int64).reshape(-1, 4)
+    return seqs, np.array(genes, dtype=np.int64).reshape(-1, 5)
 
 
 def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int, device, read_len: int = 100,
@@ -466,6 +467,8 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
                      read_len=torch.full((n_pairs,), read_len, dtype=torch.int16, device=device),
                      seg_mapped=torch.zeros((n_pairs, nseg), dtype=torch.bool, device=device),
                      seg_hits=torch.zeros((n_pairs, nseg, 4), dtype=torch.int32, device=device),
+                     span_mapped=torch.zeros((n_pairs, nseg), dtype=torch.bool, device=device),
+                     span_hits=torch.zeros((n_pairs, nseg, 8), dtype=torch.int32, device=device),
                      full_ok=torch.zeros((n_pairs,), dtype=torch.bool, device=device),
                      full_hit=torch.zeros((n_pairs, 4), dtype=torch.int32, device=device)) for sd in sides}
     ar = torch.arange(read_len, device=device)
@@ -478,7 +481,7 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
         frag = 2 * read_len + inner
         t0 = (torch.rand(n, generator=g, device=device) * (2 * E - frag).clamp(min=1).to(torch.float32)).to(torch.int64)
         flip = torch.rand(n, generator=g, device=device) < 0.5
-        ex1, d0, a1, ctg = gene[:, 1], gene[:, 2], gene[:, 3], gene[:, 0]
+        ex1, d0, a1, ctg, gminus = gene[:, 1], gene[:, 2], gene[:, 3], gene[:, 0], gene[:, 4]
         for sd in sides:
             first = (sd == "left")
             # which end of the fragment this read takes, and its strand
@@ -523,6 +526,27 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
                 b["seg_hits"][c0:c0 + n, k, 1] = left.to(torch.int32)
                 b["seg_hits"][c0:c0 + n, k, 2] = (left + ln).to(torch.int32)
                 b["seg_hits"][c0:c0 + n, k, 3] = meta.to(torch.int32)
+                # long_spanning_reads input: the contig hit, or -- for a segment that straddles the
+                # junction -- the spliced hit the junction-db mapping step would deliver (aM gN bM, XS)
+                strad = ~inside
+                a_len = (E - ts).clamp(min=1, max=ln - 1)
+                sp_ok = strad & (nm <= 2)
+                flags = anti.to(torch.int32) | (2 if k == nseg - 1 else 0)
+                flags = torch.where(strad, flags | (gminus.to(torch.int32) << 2), flags)
+                ncig = torch.where(strad, torch.tensor(3, device=device), torch.tensor(1, device=device)).to(torch.int32)
+                smeta = flags | (nm << 8) | (nm << 16) | (ncig << 24)
+                sl = ex1 + ts
+                c0_ = torch.where(strad, (1 << 28) | a_len, torch.tensor((1 << 28) | ln, device=device))
+                c1_ = torch.where(strad, (11 << 28) | (a1 - d0), torch.zeros_like(ts))
+                c2_ = torch.where(strad, (1 << 28) | (ln - a_len), torch.zeros_like(ts))
+                b["span_mapped"][c0:c0 + n, k] = ok | sp_ok
+                sh = b["span_hits"]
+                sh[c0:c0 + n, k, 0] = (ctg + 1).to(torch.int32)
+                sh[c0:c0 + n, k, 1] = torch.where(strad, sl, left).to(torch.int32)
+                sh[c0:c0 + n, k, 2] = smeta.to(torch.int32)
+                sh[c0:c0 + n, k, 3] = c0_.to(torch.int64).to(torch.int32)
+                sh[c0:c0 + n, k, 4] = c1_.to(torch.int64).to(torch.int32)
+                sh[c0:c0 + n, k, 5] = c2_.to(torch.int64).to(torch.int32)
             nm_all = cm[:, read_len]
             unspliced = (ft0 + read_len <= E) | (ft0 >= E)
             b["full_ok"][c0:c0 + n] = unspliced & (nm_all <= 2)
@@ -543,7 +567,13 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
         mate_off = torch.zeros(n_pairs + 1, dtype=torch.int32, device=device)
         mate_off[1:] = torch.cumsum(m_has.to(torch.int32), 0)
         mh = torch.where(other["full_ok"][:, None], other["full_hit"], other["seg_hits"][:, nseg - 1, :])[m_has].contiguous()
+        smapped = b["span_mapped"].reshape(-1)
+        span_off = torch.zeros(n_pairs * nseg + 1, dtype=torch.int32, device=device)
+        span_off[1:] = torch.cumsum(smapped.to(torch.int32), 0)
+        span_hits = b["span_hits"].reshape(-1, 8)[smapped].contiguous()
+        quals = torch.full((n_pairs * read_len,), ord("I"), dtype=torch.uint8, device=device)
         out[sd] = dict(n_reads=n_pairs, nseg=nseg, W=W, seg_off=seg_off, hits=hits,
+                       span_off=span_off, span_hits=span_hits, quals=quals, qual_stride=read_len,
                        planes=b["planes"].reshape(-1).contiguous(), read_len=b["read_len"],
                        mate_off=mate_off, mate_hits=mh)
     return out
