@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Mints the fixtures under tests/golden/ (inputs + expected outputs).
+
+Expected outputs come from the survey-stage scratch build of the reference binaries ($REFBIN, default
+/tmp/refbuild/src) -- a build that needed stand-in headers for Boost / config.h (see oracle/README.md), so these
+fixtures are regression data for the oracle, not a formal pin.  Inputs are produced by tophat_amd.synth (seeded).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from tophat_amd.bamio import read_bam  # noqa: E402
+from tophat_amd.synth import make_case, write_case  # noqa: E402
+
+REFBIN = os.environ.get("REFBIN", "/tmp/refbuild/src")
+
+CASES = {
+    "se100": dict(gen=dict(seed=101, paired=False, read_len=100, seg_len=25, n_reads=160, boundary_bias=0.5,
+                           spliced_seg_frac=0.5, contig_lens=(30000,), genes_per_contig=6, indel_frac=0.15), opts=[]),
+    "pe76": dict(gen=dict(seed=102, paired=True, read_len=76, seg_len=25, n_reads=120, boundary_bias=0.4,
+                          contig_lens=(24000, 12000), genes_per_contig=4, n_frac=0.1),
+                 opts=["--inner-dist-mean", "50", "--inner-dist-std-dev", "20"]),
+    "se150_multihit": dict(gen=dict(seed=103, paired=False, read_len=150, seg_len=25, n_reads=120, boundary_bias=0.5,
+                                    spliced_seg_frac=0.8, repeat_frac=0.5, contig_lens=(30000,), genes_per_contig=6),
+                           opts=["--library-type", "fr-firststrand"]),
+}
+
+
+def main():
+    for name, cfg in CASES.items():
+        d = os.path.join(HERE, name)
+        if os.path.exists(d):
+            shutil.rmtree(d)
+        case = make_case(**cfg["gen"])
+        paths = write_case(case, d)
+        seg = [os.path.join(REFBIN, "segment_juncs"), "--no-coverage-search", "--no-microexon-search", "--segment-length",
+               str(cfg["gen"]["seg_len"]), "--sam-header", paths["hdr"]] + cfg["opts"]
+        outs = [os.path.join(d, "expected.%s" % k) for k in ("juncs", "insertions", "deletions", "fusions")]
+        seg += [paths["ref"]] + outs + [paths["left_fq"], paths["left_map"], ",".join(paths["left_segs"])]
+        if cfg["gen"]["paired"]:
+            seg += [paths["right_fq"], paths["right_map"], ",".join(paths["right_segs"])]
+        subprocess.run(seg, check=True, capture_output=True)
+        os.remove(outs[3])
+        for sd in (("left", "right") if cfg["gen"]["paired"] else ("left",)):
+            bam = os.path.join(d, "span_%s.bam" % sd)
+            lsr = [os.path.join(REFBIN, "long_spanning_reads"), "--segment-length", str(cfg["gen"]["seg_len"]),
+                   "--sam-header", paths["hdr"], paths["ref"], paths["%s_fq" % sd], outs[0], outs[1], outs[2], "/dev/null",
+                   bam, ",".join(paths["%s_segs" % sd])]
+            subprocess.run(lsr, check=True, capture_output=True)
+            _, recs = read_bam(bam)
+            with open(os.path.join(d, "expected.span_%s.sam" % sd), "w") as f:
+                for r in recs:
+                    f.write("\t".join(str(x) for x in r) + "\n")
+            os.remove(bam)
+            if os.path.exists(bam + ".index"):
+                os.remove(bam + ".index")
+        with open(os.path.join(d, "options.txt"), "w") as f:
+            f.write(" ".join(cfg["opts"]) + "\n")
+            f.write("segment_length=%d paired=%d\n" % (cfg["gen"]["seg_len"], cfg["gen"]["paired"]))
+        print(name, sum(os.path.getsize(os.path.join(d, x)) for x in os.listdir(d)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""Loading the fixtures under tests/golden/ through the host parsing rules (tophat_amd.samtext)."""
+import os
+
+from tophat_amd.batch import build_seg_batch, build_span_batch
+from tophat_amd.params import LIBRARY_TYPES, Params, READ_LEFT, READ_RIGHT
+from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+
+
+def read_fastq_quals(path):
+    out = {}
+    with open(path) as f:
+        while True:
+            h = f.readline()
+            if not h:
+                break
+            f.readline()
+            f.readline()
+            out[int(h[1:].split()[0])] = f.readline().strip()
+    return out
+
+
+def load(name):
+    d = os.path.join(GOLD, name)
+    opts = open(os.path.join(d, "options.txt")).read().split("\n")
+    argv = opts[0].split()
+    kv = dict(x.split("=") for x in opts[1].split())
+    p = Params(segment_length=int(kv["segment_length"]))
+    i = 0
+    while i < len(argv):
+        if argv[i] == "--inner-dist-mean":
+            p.inner_dist_mean = int(argv[i + 1])
+        elif argv[i] == "--inner-dist-std-dev":
+            p.inner_dist_std_dev = int(argv[i + 1])
+        elif argv[i] == "--library-type":
+            p.library_type = LIBRARY_TYPES[argv[i + 1]]
+        i += 2
+    names, _ = parse_header(os.path.join(d, "hdr.sam"))
+    fa_names, fa_seqs = read_fasta(os.path.join(d, "ref.fa"))
+    seqs = [dict(zip(fa_names, fa_seqs)).get(n) for n in names]
+    ref_ids = {n: i + 1 for i, n in enumerate(names)}
+    paired = kv["paired"] == "1"
+    nseg = len([f for f in os.listdir(d) if f.startswith("left_seg")])
+    sides = {}
+    for sd in (("left", "right") if paired else ("left",)):
+        sides[sd] = dict(
+            reads=read_fastq(os.path.join(d, "%s.fq" % sd)), quals=read_fastq_quals(os.path.join(d, "%s.fq" % sd)),
+            segs=[list(parse_sam_hits(os.path.join(d, "%s_seg%d.sam" % (sd, k + 1)), ref_ids, p.max_report_intron)) for k in range(nseg)],
+            full=list(parse_sam_hits(os.path.join(d, "%s_map.sam" % sd), ref_ids, p.max_report_intron)))
+    seg_batches, span_batches = [], {}
+    for sd, side in (("left", READ_LEFT), ("right", READ_RIGHT)):
+        if sd not in sides:
+            continue
+        other = "right" if sd == "left" else "left"
+        if paired:
+            b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1])
+        else:
+            b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"])
+        seg_batches.append((side, b))
+        span_batches[sd] = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], sides[sd]["quals"])
+    exp = {k: open(os.path.join(d, "expected.%s" % k)).read() for k in ("juncs", "insertions", "deletions")}
+    exp_span = {}
+    for sd in sides:
+        rows = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
+        # (QNAME FLAG RNAME POS CIGAR tags...) -- drop MAPQ/SEQ/QUAL columns
+        exp_span[sd] = [(r[0], int(r[1]), r[2], int(r[3]), r[5]) + r[8:] for r in rows]
+    return dict(p=p, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp=exp, exp_span=exp_span)
+
+
+def events_text(ev, names, tmp_path):
+    from tophat_amd.batch import write_segment_files
+    f = {k: str(tmp_path / ("got." + k)) for k in ("juncs", "insertions", "deletions")}
+    write_segment_files(ev, names, f["juncs"], f["insertions"], f["deletions"])
+    return {k: open(v).read() for k, v in f.items()}

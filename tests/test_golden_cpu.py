@@ -1,0 +1,33 @@
+"""CPU: oracle and kernel logic against the committed fixtures (tests/golden/, see make_golden.py for provenance)."""
+import copy
+
+import pytest
+
+import orc
+import sim
+from golden_util import CASES, events_text, load
+from tophat_amd.batch import events_to_span_inputs, merge_events
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_and_kernel_logic_reproduce_fixture(name, tmp_path):
+    c = load(name)
+    seqs = [None if s is None else orc.fold_genome_char(s) for s in c["seqs"]]
+    g = orc.Genome(seqs)
+    ev = ev2 = None
+    for side, b in c["seg_batches"]:
+        p = copy.copy(c["p"])
+        p.read_side = side
+        e = orc.segjuncs(p, g, b)
+        e2 = sim.segjuncs(p, seqs, b)
+        ev = e if ev is None else merge_events(ev, e)
+        ev2 = e2 if ev2 is None else merge_events(ev2, e2)
+    assert events_text(ev, c["names"], tmp_path) == c["exp"]
+    assert events_text(ev2, c["names"], tmp_path) == c["exp"]
+    juncs, ins = events_to_span_inputs(ev)
+    for sd, sb in c["span_batches"].items():
+        want = c["exp_span"][sd]
+        got = [a.sam_fields(int(sb.read_id[a.read_idx]), c["names"]) for a in orc.spanning(c["p"], g, sb, juncs, ins)]
+        assert got == want
+        got2, st = sim.spanning(c["p"], seqs, sb, juncs, ins)
+        assert [a.sam_fields(int(sb.read_id[a.read_idx]), c["names"]) for a in got2] == want
