@@ -58,7 +58,7 @@ def main():
             with open(os.path.join(d, "expected.span_%s.sam" % sd), "w") as f:
                 for r in recs:
                     f.write("\t".join(str(x) for x in r) + "\n")
-            os.remove(bam)
+            os.rename(bam, os.path.join(d, "expected.span_%s.bam" % sd))     # byte-level BAM encoding fixture (B8)
             if os.path.exists(bam + ".index"):
                 os.remove(bam + ".index")
         with open(os.path.join(d, "options.txt"), "w") as f:

@@ -1,0 +1,162 @@
+// segment_juncs -- MI355X-native drop-in for TopHat's segment_juncs (same argv + files; tophat.py:3097-3112,
+// parsed like segment_juncs.cpp:5186-5364).  Host C++ over the C ABI in include/thj.h; all per-read work runs in
+// the HIP kernels of libthj_hip.so.  Split-segment search, small indels and the paired-end rescue are supported;
+// coverage / microexon / butterfly / fusion searches are refused loudly.
+#include "thj_hostio.h"
+
+using namespace thjh;
+
+static void print_usage() {
+    fprintf(stderr, "Usage:   segment_juncs <ref.fa> <segment.juncs> <segment.insertions> <segment.deletions> <segment.fusions> "
+                    "<left_reads.fq> <left_reads.bwtout> <left_seg1.bwtout,...,segN.bwtout> "
+                    "[right_reads.fq right_reads.bwtout right_seg1.bwtout,...,right_segN.bwtout]\n");
+}
+
+static const char* CODE = "ACGTN";
+
+struct SideInput {
+    std::string reads, map;
+    std::vector<std::string> segs;
+};
+
+// One side (segment_juncs.cpp:4776-4905): walk the nseg id-sorted segment maps in increasing id order -- the
+// visiting order of look_for_hit_group (segment_juncs.cpp:3823-4123; derivation in tophat_amd/batch.py) --
+// join the mate's maps by id (find_gaps :3321-3348), batch, run.
+static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, const SideInput* mate, int read_side,
+                     uint32_t& ordinal, size_t batch_reads) {
+    const int nseg = (int)in.segs.size();
+    if (nseg <= 1) return;                                  // segment_juncs.cpp:4752 (`size() > 1`)
+    std::vector<HitStream> st((size_t)nseg);
+    for (int s = 0; s < nseg; ++s)
+        if (!st[(size_t)s].open(in.segs[(size_t)s], rt, o.p)) die("Error opening SAM file %s\n", in.segs[(size_t)s].c_str());
+    HitStream mate_full, mate_last;
+    bool have_mate = false;
+    if (mate && !mate->segs.empty()) {
+        bool a = !mate->map.empty() && mate_full.open(mate->map, rt, o.p);
+        bool b = mate_last.open(mate->segs.back(), rt, o.p);
+        have_mate = a || b;
+    }
+    ReadStream reads;
+    if (!reads.open(in.reads, o.zpacker)) die("Error: cannot open %s for reading\n", in.reads.c_str());
+
+    thj_params p = o.p;
+    p.read_side = read_side;
+    std::vector<uint32_t> seg_off, mate_off;
+    std::vector<thj_hit> hits, mate_hits;
+    std::vector<int64_t> read_off;
+    std::string bases;
+    size_t max_len = 0;
+    auto reset = [&]() { seg_off.assign(1, 0); mate_off.assign(1, 0); hits.clear(); mate_hits.clear(); read_off.assign(1, 0); bases.clear(); max_len = 0; };
+    auto flush = [&]() {
+        int64_t n = (int64_t)read_off.size() - 1;
+        if (n == 0) return;
+        int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
+        std::vector<uint64_t> planes((size_t)n * 3 * W);
+        std::vector<uint16_t> lens((size_t)n);
+        if (thj_reads_pack(n, read_off.data(), bases.data(), W, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
+        thj_seg_batch hb{};
+        hb.n_reads = (int32_t)n; hb.nseg = nseg; hb.words_per_plane = W;
+        hb.seg_off = seg_off.data(); hb.hits = hits.data(); hb.read_planes = planes.data(); hb.read_len = lens.data();
+        if (have_mate) { hb.mate_off = mate_off.data(); hb.mate_hits = mate_hits.data(); }
+        hb.ordinal_base = ordinal;
+        thj_seg_batch* dev = nullptr;
+        if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
+        if (thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+        if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+        ordinal += (uint32_t)n;
+        reset();
+    };
+    reset();
+    std::vector<std::vector<Hit>> grp((size_t)nseg);
+    std::vector<Hit> mg;
+    for (;;) {
+        uint32_t id = 0;
+        for (int s = 0; s < nseg; ++s) { uint32_t g = st[(size_t)s].next_group_id(); if (g && (id == 0 || g < id)) id = g; }
+        if (id == 0) break;
+        int top = -1;
+        for (int s = 0; s < nseg; ++s) {
+            grp[(size_t)s].clear();
+            if (st[(size_t)s].next_group_id() == id) { st[(size_t)s].next_group(grp[(size_t)s]); top = s; }
+        }
+        if (top <= 0) continue;                 // only find_fusions runs for these (segment_juncs.cpp:3994-4028)
+        Read rd;
+        if (!reads.get(id, rd)) die("Error: could not get read# %d from stream!", (int)id);
+        for (int s = 0; s < nseg; ++s) { for (auto& h : grp[(size_t)s]) hits.push_back(h.h16); seg_off.push_back((uint32_t)hits.size()); }
+        if (have_mate) {
+            mg.clear();
+            while (mate_full.next_group_id() && mate_full.next_group_id() < id) mate_full.skip_group();
+            if (mate_full.next_group_id() == id) mate_full.next_group(mg);
+            else {
+                while (mate_last.next_group_id() && mate_last.next_group_id() < id) mate_last.skip_group();
+                if (mate_last.next_group_id() == id) mate_last.next_group(mg);
+            }
+            for (auto& h : mg) mate_hits.push_back(h.h16);
+            mate_off.push_back((uint32_t)mate_hits.size());
+        }
+        bases += rd.seq;
+        read_off.push_back((int64_t)bases.size());
+        if (rd.seq.size() > max_len) max_len = rd.seq.size();
+        if (read_off.size() - 1 >= batch_reads) flush();
+    }
+    flush();
+}
+
+int main(int argc, char** argv) {
+    fprintf(stderr, "segment_juncs (MI355X-native, %s)\n---------------------------\n", thj_version());
+    Opts o;
+    int rc = parse_options(argc, argv, o, print_usage);
+    if (rc) return rc;
+    std::vector<std::string> pos;
+    for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
+    if (pos.size() < 8 || (pos.size() > 8 && pos.size() < 11)) { print_usage(); return 1; }
+    if (o.color) die("Error: colour-space reads are not supported by this build\n");
+    if (o.fusion_search) die("Error: --fusion-search is not supported by this build yet\n");
+    if (!o.no_coverage_search || !o.no_microexon_search || o.butterfly_search)
+        die("Error: coverage / microexon / butterfly searches are not supported by this build yet; "
+            "run with --no-coverage-search --no-microexon-search (what tophat passes for reads of >= 3 segments)\n");
+    SideInput left{pos[5], pos[6], split(pos[7], ',')}, right;
+    if (pos.size() >= 11) right = SideInput{pos[8], pos[9], split(pos[10], ',')};
+    if (left.segs.empty()) { fprintf(stderr, "No hits to process, exiting\n"); return 0; }      // segment_juncs.cpp:4724-4728
+
+    FILE* fj = fopen(pos[1].c_str(), "w"); if (!fj) die("Error: cannot open %s for writing\n", pos[1].c_str());
+    FILE* fi = fopen(pos[2].c_str(), "w"); if (!fi) die("Error: cannot open %s for writing\n", pos[2].c_str());
+    FILE* fd = fopen(pos[3].c_str(), "w"); if (!fd) die("Error: cannot open %s for writing\n", pos[3].c_str());
+    FILE* ff = fopen(pos[4].c_str(), "w"); if (!ff) die("Error: cannot open %s for writing\n", pos[4].c_str());
+
+    RefTable rt;
+    rt.load_sam_header(o.sam_header);
+    fprintf(stderr, "Loading reference sequences...\n");
+    rt.load_fasta(pos[0]);
+
+    int device = getenv("THJ_DEVICE") ? atoi(getenv("THJ_DEVICE")) : 0;
+    thj_ctx* ctx = nullptr;
+    if (thj_ctx_create(device, nullptr, &ctx)) die("Error: %s\n", thj_last_error());
+    rt.upload(ctx);
+    if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+    size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
+    uint32_t ordinal = 0;
+    fprintf(stderr, ">> Performing segment-search:\n");
+    run_side(ctx, o, rt, left, right.segs.empty() ? nullptr : &right, 1, ordinal, batch_reads);
+    if (!right.segs.empty()) run_side(ctx, o, rt, right, &left, 2, ordinal, batch_reads);
+
+    thj_segjuncs_counts n{};
+    if (thj_segjuncs_finish(ctx, &n)) die("Error: %s\n", thj_last_error());
+    std::vector<thj_junction> j((size_t)n.n_juncs + 1), d((size_t)n.n_deletions + 1);
+    std::vector<thj_insertion> ins((size_t)n.n_insertions + 1);
+    if (thj_segjuncs_download(ctx, j.data(), d.data(), ins.data())) die("Error: %s\n", thj_last_error());
+    fprintf(stderr, "\tfound %ld potential split-segment junctions\n", (long)n.n_juncs);
+    fprintf(stderr, "\tfound %ld potential small deletions\n", (long)n.n_deletions);
+    fprintf(stderr, "\tfound %ld potential small insertions\n", (long)n.n_insertions);
+    // writers: segment_juncs.cpp:5035-5095
+    for (int64_t i = 0; i < n.n_juncs; ++i)
+        fprintf(fj, "%s\t%d\t%d\t%c\n", rt.names[j[(size_t)i].ref_id - 1].c_str(), (int)j[(size_t)i].left, (int)j[(size_t)i].right, j[(size_t)i].antisense ? '-' : '+');
+    for (int64_t i = 0; i < n.n_deletions; ++i)
+        fprintf(fd, "%s\t%d\t%d\n", rt.names[d[(size_t)i].ref_id - 1].c_str(), (int)d[(size_t)i].left + 1, (int)d[(size_t)i].right);
+    for (int64_t i = 0; i < n.n_insertions; ++i)
+        fprintf(fi, "%s\t%d\t%d\t%s\n", rt.names[ins[(size_t)i].ref_id - 1].c_str(), (int)ins[(size_t)i].left, (int)ins[(size_t)i].left, ins[(size_t)i].seq);
+    fclose(fj); fclose(fi); fclose(fd); fclose(ff);
+    fprintf(stderr, "Reported %d total potential splices\n", (int)n.n_juncs);
+    thj_ctx_destroy(ctx);
+    (void)CODE;
+    return 0;
+}

@@ -1,0 +1,715 @@
+// thj_hostio.h -- host side of the drop-in binaries: option table, reference table, FASTA/FASTQ/BAM/SAM readers,
+// hit parsing, id-grouped hit streams, text + BAM writers.  Plain C++17 + zlib, no device code; the executables
+// call the kernels only through include/thj.h.
+//
+// Behavioural sources (reference v2.1.2, src/): common.cpp:262-422,:459-720 (options); bwt_map.h:579-788
+// (RefSequenceTable); segment_juncs.cpp:64-88 (get_seqs); reads.cpp:94-188,:528-630 (read fetch);
+// bwt_map.cpp:1101-1452 (BAMHitFactory::get_hit_from_buf); bwt_map.h:1155-1220 (HitStream::next_read_hits);
+// common.cpp:1000-1173 + common.h:401-627 (GBamRecord / GBamWriter); samtools-0.1.18 bgzf.c (BGZF framing).
+#pragma once
+#include <getopt.h>
+#include <stdint.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../../include/thj.h"
+
+namespace thjh {
+
+[[noreturn]] inline void die(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    exit(1);
+}
+
+// ------------------------------------------------------------------ options (common.cpp:79-180, :262-720)
+struct Opts {
+    thj_params p;
+    bool no_coverage_search = false, no_microexon_search = false, butterfly_search = false, fusion_search = false;
+    bool color = false, bowtie2 = true;
+    int num_threads = 1;
+    std::string sam_header, ium_reads, zpacker;
+};
+
+enum {
+    O_FASTA = 127, O_FASTQ, O_MIN_ANCHOR, O_SAM_HEADER, O_RG_ID, O_SPLICE_MM, O_VERBOSE, O_INNER_MEAN, O_INNER_SD, O_OUTDIR,
+    O_GENE_FILTER, O_GTF, O_MAX_MULTIHITS, O_SUPPRESS, O_MAX_SEG_MULTIHITS, O_NO_CLOSURE, O_NO_COVERAGE, O_NO_MICROEXON,
+    O_SEG_LEN, O_SEG_MM, O_READ_MM, O_READ_GAP, O_READ_ED, O_READ_REALIGN_ED, O_MIN_CLOSURE_EXON, O_MIN_CLOSURE_INTRON,
+    O_MAX_CLOSURE_INTRON, O_MIN_COV_INTRON, O_MAX_COV_INTRON, O_MIN_SEG_INTRON, O_MAX_SEG_INTRON, O_MIN_REP_INTRON,
+    O_MAX_REP_INTRON, O_MIN_ISO, O_IUM, O_BUTTERFLY, O_SOLEXA, O_PHRED64, O_QUALS, O_INT_QUALS, O_COLOR, O_LIBTYPE,
+    O_MAX_DEL, O_MAX_INS, O_THREADS, O_ZPACKER, O_SAMTOOLS, O_AUX_OUT, O_STD_OUT, O_INDEX_OUT, O_GTF_JUNCS, O_FLT_READS,
+    O_FLT_HITS, O_FLT_SIDE, O_SECONDARY, O_DISCORDANT, O_MIXED, O_FUSION, O_FUSION_ANCHOR, O_FUSION_MIN_DIST,
+    O_FUSION_READ_MM, O_FUSION_MULTIREADS, O_FUSION_MULTIPAIRS, O_FUSION_IGNORE, O_FUSION_NO_RESOLVE, O_BOWTIE1,
+    O_B2_MIN_SCORE, O_B2_MAX_PEN, O_B2_MIN_PEN, O_B2_N_PEN, O_B2_RDG_OPEN, O_B2_RDG_CONT, O_B2_RFG_OPEN, O_B2_RFG_CONT,
+    O_B2_SCOREFLT
+};
+
+inline int parse_int(int lower, const char* msg) {
+    char* e = nullptr;
+    long v = strtol(optarg, &e, 10);
+    if (e == optarg || *e != 0 || v < lower) die("%s\n", msg);        // parseIntOpt, common.cpp:186-204
+    return (int)v;
+}
+
+// Accepts every option of the shared table (the driver passes its full params.cmd() to every binary,
+// tophat.py:824-900); unknown option => usage + exit status 1 (common.cpp:714-716).
+inline int parse_options(int argc, char** argv, Opts& o, void (*usage)()) {
+    static const struct option lo[] = {
+        {"fasta", 0, 0, O_FASTA}, {"fastq", 0, 0, O_FASTQ}, {"min-anchor", 1, 0, O_MIN_ANCHOR}, {"sam-header", 1, 0, O_SAM_HEADER},
+        {"rg-id", 1, 0, O_RG_ID}, {"splice-mismatches", 1, 0, O_SPLICE_MM}, {"verbose", 0, 0, O_VERBOSE},
+        {"inner-dist-mean", 1, 0, O_INNER_MEAN}, {"inner-dist-std-dev", 1, 0, O_INNER_SD}, {"output-dir", 1, 0, O_OUTDIR},
+        {"gene-filter", 1, 0, O_GENE_FILTER}, {"gtf-annotations", 1, 0, O_GTF}, {"max-multihits", 1, 0, O_MAX_MULTIHITS},
+        {"suppress-hits", 0, 0, O_SUPPRESS}, {"max-seg-multihits", 1, 0, O_MAX_SEG_MULTIHITS}, {"no-closure-search", 0, 0, O_NO_CLOSURE},
+        {"no-coverage-search", 0, 0, O_NO_COVERAGE}, {"no-microexon-search", 0, 0, O_NO_MICROEXON}, {"segment-length", 1, 0, O_SEG_LEN},
+        {"segment-mismatches", 1, 0, O_SEG_MM}, {"read-mismatches", 1, 0, O_READ_MM}, {"read-gap-length", 1, 0, O_READ_GAP},
+        {"read-edit-dist", 1, 0, O_READ_ED}, {"read-realign-edit-dist", 1, 0, O_READ_REALIGN_ED}, {"min-closure-exon", 1, 0, O_MIN_CLOSURE_EXON},
+        {"min-closure-intron", 1, 0, O_MIN_CLOSURE_INTRON}, {"max-closure-intron", 1, 0, O_MAX_CLOSURE_INTRON},
+        {"min-coverage-intron", 1, 0, O_MIN_COV_INTRON}, {"max-coverage-intron", 1, 0, O_MAX_COV_INTRON},
+        {"min-segment-intron", 1, 0, O_MIN_SEG_INTRON}, {"max-segment-intron", 1, 0, O_MAX_SEG_INTRON},
+        {"min-report-intron", 1, 0, O_MIN_REP_INTRON}, {"max-report-intron", 1, 0, O_MAX_REP_INTRON},
+        {"min-isoform-fraction", 1, 0, O_MIN_ISO}, {"ium-reads", 1, 0, O_IUM}, {"butterfly-search", 0, 0, O_BUTTERFLY},
+        {"solexa-quals", 0, 0, O_SOLEXA}, {"phred64-quals", 0, 0, O_PHRED64}, {"quals", 0, 0, O_QUALS}, {"integer-quals", 0, 0, O_INT_QUALS},
+        {"color", 0, 0, O_COLOR}, {"library-type", 1, 0, O_LIBTYPE}, {"max-deletion-length", 1, 0, O_MAX_DEL},
+        {"max-insertion-length", 1, 0, O_MAX_INS}, {"num-threads", 1, 0, O_THREADS}, {"zpacker", 1, 0, O_ZPACKER},
+        {"samtools", 1, 0, O_SAMTOOLS}, {"aux-outfile", 1, 0, O_AUX_OUT}, {"outfile", 1, 0, O_STD_OUT}, {"index-outfile", 1, 0, O_INDEX_OUT},
+        {"gtf-juncs", 1, 0, O_GTF_JUNCS}, {"flt-reads", 1, 0, O_FLT_READS}, {"flt-hits", 1, 0, O_FLT_HITS}, {"flt-side", 1, 0, O_FLT_SIDE},
+        {"report-secondary-alignments", 0, 0, O_SECONDARY}, {"report-discordant-pair-alignments", 0, 0, O_DISCORDANT},
+        {"report-mixed-alignments", 0, 0, O_MIXED}, {"fusion-search", 0, 0, O_FUSION}, {"fusion-anchor-length", 1, 0, O_FUSION_ANCHOR},
+        {"fusion-min-dist", 1, 0, O_FUSION_MIN_DIST}, {"fusion-read-mismatches", 1, 0, O_FUSION_READ_MM},
+        {"fusion-multireads", 1, 0, O_FUSION_MULTIREADS}, {"fusion-multipairs", 1, 0, O_FUSION_MULTIPAIRS},
+        {"fusion-ignore-chromosomes", 1, 0, O_FUSION_IGNORE}, {"fusion-do-not-resolve-conflicts", 0, 0, O_FUSION_NO_RESOLVE},
+        {"bowtie1", 0, 0, O_BOWTIE1}, {"bowtie2-min-score", 1, 0, O_B2_MIN_SCORE}, {"bowtie2-max-penalty", 1, 0, O_B2_MAX_PEN},
+        {"bowtie2-min-penalty", 1, 0, O_B2_MIN_PEN}, {"bowtie2-penalty-for-N", 1, 0, O_B2_N_PEN},
+        {"bowtie2-read-gap-open", 1, 0, O_B2_RDG_OPEN}, {"bowtie2-read-gap-cont", 1, 0, O_B2_RDG_CONT},
+        {"bowtie2-ref-gap-open", 1, 0, O_B2_RFG_OPEN}, {"bowtie2-ref-gap-cont", 1, 0, O_B2_RFG_CONT}, {0, 0, 0, 0}};
+    thj_params_default(&o.p);
+    int c, idx = 0;
+    while ((c = getopt_long(argc, argv, "QCp:z:N:w:W:", lo, &idx)) != -1) {
+        switch (c) {
+        case O_MIN_ANCHOR: o.p.min_anchor_len = parse_int(3, "--min-anchor arg must be at least 3"); break;
+        case O_SAM_HEADER: o.sam_header = optarg; break;
+        case O_INNER_MEAN: o.p.inner_dist_mean = parse_int(-1024, "--inner-dist-mean arg must be at least -1024"); break;
+        case O_INNER_SD: o.p.inner_dist_std_dev = parse_int(0, "--inner-dist-std-dev arg must be at least 0"); break;
+        case O_MAX_SEG_MULTIHITS: o.p.max_seg_multihits = parse_int(1, "--max-seg-multihits arg must be at least 1"); break;
+        case O_NO_COVERAGE: o.no_coverage_search = true; break;
+        case O_NO_MICROEXON: o.no_microexon_search = true; break;
+        case O_BUTTERFLY: o.butterfly_search = true; break;
+        case O_SEG_LEN: o.p.segment_length = parse_int(4, "--segment-length arg must be at least 4"); break;
+        case O_SEG_MM: o.p.segment_mismatches = parse_int(0, "--segment-mismatches arg must be at least 0"); break;
+        case 'N': case O_READ_MM: o.p.read_mismatches = parse_int(0, "--read-mismatches arg must be at least 0"); break;
+        case O_READ_GAP: o.p.read_gap_length = parse_int(0, "--read-gap-length arg must be at least 0"); break;
+        case O_READ_ED: o.p.read_edit_dist = parse_int(0, "--read-edit-dist arg must be at least 0"); break;
+        case O_MIN_SEG_INTRON: o.p.min_segment_intron = parse_int(1, "--min-segment-intron arg must be at least 1"); break;
+        case O_MAX_SEG_INTRON: o.p.max_segment_intron = parse_int(1, "--max-segment-intron arg must be at least 1"); break;
+        case O_MIN_REP_INTRON: o.p.min_report_intron = parse_int(1, "--min-report-intron arg must be at least 1"); break;
+        case O_MAX_REP_INTRON: o.p.max_report_intron = parse_int(1, "--max-report-intron arg must be at least 1"); break;
+        case O_IUM: o.ium_reads = optarg; break;
+        case 'C': case O_COLOR: o.color = true; break;
+        case O_LIBTYPE:
+            if (!strcmp(optarg, "fr-unstranded")) o.p.library_type = 1;
+            else if (!strcmp(optarg, "fr-firststrand")) o.p.library_type = 2;
+            else if (!strcmp(optarg, "fr-secondstrand")) o.p.library_type = 3;
+            else if (!strcmp(optarg, "ff-unstranded")) o.p.library_type = 4;
+            else if (!strcmp(optarg, "ff-firststrand")) o.p.library_type = 5;
+            else if (!strcmp(optarg, "ff-secondstrand")) o.p.library_type = 6;
+            break;
+        case O_MAX_DEL: o.p.max_deletion_length = parse_int(0, "--max-deletion-length must be at least 0"); break;
+        case O_MAX_INS: o.p.max_insertion_length = parse_int(0, "--max-insertion-length must be at least 0"); break;
+        case 'p': case O_THREADS: o.num_threads = parse_int(1, "-p/--num-threads must be at least 1"); break;
+        case 'z': case O_ZPACKER: o.zpacker = optarg; break;
+        case O_FUSION: o.fusion_search = true; break;
+        case O_BOWTIE1: o.bowtie2 = false; o.p.bowtie2 = 0; break;
+        case O_B2_MAX_PEN: o.p.bowtie2_max_penalty = parse_int(0, "--bowtie2-max-penalty must be at least 0"); break;
+        case O_B2_MIN_PEN: o.p.bowtie2_min_penalty = parse_int(0, "--bowtie2-min-penalty must be at least 0"); break;
+        case O_B2_N_PEN: o.p.bowtie2_penalty_for_N = parse_int(0, "--bowtie2-penalty-for-N must be at least 0"); break;
+        case O_B2_RDG_OPEN: o.p.bowtie2_read_gap_open = parse_int(0, "--bowtie2-read-gap-open must be at least 0"); break;
+        case O_B2_RDG_CONT: o.p.bowtie2_read_gap_cont = parse_int(0, "--bowtie2-read-gap-cont must be at least 0"); break;
+        case O_B2_RFG_OPEN: o.p.bowtie2_ref_gap_open = parse_int(0, "--bowtie2-ref-gap-open must be at least 0"); break;
+        case O_B2_RFG_CONT: o.p.bowtie2_ref_gap_cont = parse_int(0, "--bowtie2-ref-gap-cont must be at least 0"); break;
+        case '?': case ':': usage(); return 1;
+        default: break;      // accepted, irrelevant to this path
+        }
+    }
+    return 0;
+}
+
+inline std::vector<std::string> split(const std::string& s, char sep) {      // tokenize.cpp
+    std::vector<std::string> out;
+    size_t i = 0;
+    while (i <= s.size()) {
+        size_t j = s.find(sep, i);
+        if (j == std::string::npos) j = s.size();
+        if (j > i) out.push_back(s.substr(i, j - i));
+        i = j + 1;
+    }
+    return out;
+}
+inline std::string file_ext(const std::string& f) {
+    size_t d = f.rfind('.');
+    if (d == std::string::npos) return "";
+    std::string e = f.substr(d + 1);
+    for (auto& c : e) c = (char)tolower(c);
+    return e;
+}
+
+// ------------------------------------------------------------------ reference table (bwt_map.h:579-788)
+struct RefTable {
+    std::vector<std::string> names;                 // id-1 -> name, @SQ order then FASTA-only names
+    std::unordered_map<std::string, uint32_t> ids;
+    std::vector<std::string> seqs;                  // id-1 -> folded sequence ("" = none)
+    std::string header_text;                        // the '@' lines of --sam-header, verbatim
+    std::vector<std::pair<std::string, uint32_t>> sq;   // @SQ (name, LN) in file order: the BAM header targets
+
+    uint32_t get_id(const std::string& name) {
+        auto it = ids.find(name);
+        if (it != ids.end()) return it->second;
+        names.push_back(name);
+        seqs.emplace_back();
+        ids[name] = (uint32_t)names.size();
+        return (uint32_t)names.size();
+    }
+    void load_sam_header(const std::string& fn) {
+        if (fn.empty()) return;
+        FILE* f = fopen(fn.c_str(), "r");
+        if (!f) die("Failed to open SAM header file %s\n", fn.c_str());
+        char* line = nullptr; size_t cap = 0; ssize_t n;
+        while ((n = getline(&line, &cap, f)) > 0) {
+            if (line[0] != '@') break;
+            std::string l(line, (size_t)n);
+            if (l.back() != '\n') l.push_back('\n');
+            header_text += l;
+            if (!strncmp(line, "@SQ", 3)) {
+                std::string sn; uint32_t ln = 0;
+                for (auto& tok : split(l.substr(0, l.size() - 1), '\t')) {
+                    if (!tok.compare(0, 3, "SN:")) sn = tok.substr(3);
+                    else if (!tok.compare(0, 3, "LN:")) ln = (uint32_t)atoll(tok.c_str() + 3);
+                }
+                if (!sn.empty()) { get_id(sn); sq.emplace_back(sn, ln); }
+            }
+        }
+        free(line);
+        fclose(f);
+    }
+    // get_seqs (segment_juncs.cpp:64-88): names cut at the first blank; sequences folded to ACGTN
+    void load_fasta(const std::string& fn) {
+        FILE* f = fopen(fn.c_str(), "r");
+        if (!f) die("Error: cannot open %s for reading\n", fn.c_str());
+        char* line = nullptr; size_t cap = 0; ssize_t n;
+        std::string* cur = nullptr;
+        while ((n = getline(&line, &cap, f)) > 0) {
+            if (line[0] == '>') {
+                std::string name(line + 1, (size_t)n - 1);
+                size_t e = name.find_first_of(" \t\r\n");
+                if (e != std::string::npos) name.resize(e);
+                uint32_t id = get_id(name);
+                cur = &seqs[id - 1];
+                cur->clear();
+            } else if (cur) {
+                for (ssize_t i = 0; i < n; ++i) {
+                    char c = line[i];
+                    if (c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
+                    switch (c) { case 'a': case 'A': c = 'A'; break; case 'c': case 'C': c = 'C'; break;
+                                 case 'g': case 'G': c = 'G'; break; case 't': case 'T': c = 'T'; break; default: c = 'N'; }
+                    cur->push_back(c);
+                }
+            }
+        }
+        free(line);
+        fclose(f);
+    }
+    // pack + upload through the C ABI
+    void upload(thj_ctx* ctx) {
+        int32_t n = (int32_t)names.size();
+        std::vector<int64_t> lens(n); std::vector<const char*> ptrs(n);
+        for (int32_t i = 0; i < n; ++i) { lens[i] = (int64_t)seqs[i].size(); ptrs[i] = seqs[i].empty() ? nullptr : seqs[i].data(); }
+        std::vector<uint32_t> blk(n + 1);
+        int64_t nb = 0;
+        if (thj_genome_layout(n, lens.data(), blk.data(), &nb)) die("Error: %s\n", thj_last_error());
+        std::vector<uint64_t> blocks((size_t)nb * 4);
+        if (thj_genome_pack(n, ptrs.data(), lens.data(), blk.data(), blocks.data(), nb)) die("Error: %s\n", thj_last_error());
+        if (thj_genome_upload(ctx, blocks.data(), nb, blk.data(), lens.data(), n)) die("Error: %s\n", thj_last_error());
+    }
+};
+
+// ------------------------------------------------------------------ BAM / SAM record reader
+struct AlnRec {
+    std::string qname, rname, rnext;     // names ("*" when unset)
+    int32_t pos = -1;                    // 0-based
+    uint32_t flag = 0;
+    std::vector<std::pair<char, uint32_t>> cigar;
+    std::string seq, qual;               // qual as phred+33 text
+    int nm = 0; bool has_nm = false;
+    char xs = 0;
+    bool has_xf = false;
+};
+
+class AlnReader {
+    gzFile gz_ = nullptr;       // BGZF is a multi-member gzip stream: zlib walks the members for us
+    FILE* txt_ = nullptr;
+    bool bam_ = false;
+    std::vector<std::string> targets_;
+    char* line_ = nullptr; size_t cap_ = 0;
+    std::vector<uint8_t> buf_;
+    void rd(void* dst, int n, const char* fn) { if (gzread(gz_, dst, (unsigned)n) != n) die("Error: truncated BAM file %s\n", fn); }
+public:
+    std::string fname;
+    bool open(const std::string& fn) {
+        fname = fn;
+        if (file_ext(fn) == "sam") {                 // bwt_map.cpp:170-175
+            txt_ = fopen(fn.c_str(), "r");
+            return txt_ != nullptr;
+        }
+        bam_ = true;
+        gz_ = gzopen(fn.c_str(), "rb");
+        if (!gz_) return false;
+        gzbuffer(gz_, 1 << 20);
+        char magic[4];
+        if (gzread(gz_, magic, 4) != 4 || memcmp(magic, "BAM\1", 4)) die("Error: %s is not a BAM file\n", fn.c_str());
+        int32_t l_text, n_ref;
+        rd(&l_text, 4, fn.c_str());
+        std::vector<char> t((size_t)l_text + 1);
+        if (l_text) rd(t.data(), l_text, fn.c_str());
+        rd(&n_ref, 4, fn.c_str());
+        for (int i = 0; i < n_ref; ++i) {
+            int32_t l_name, l_ref;
+            rd(&l_name, 4, fn.c_str());
+            std::vector<char> nm((size_t)l_name + 1);
+            rd(nm.data(), l_name, fn.c_str());
+            rd(&l_ref, 4, fn.c_str());
+            targets_.emplace_back(nm.data());
+        }
+        return true;
+    }
+    void close() { if (gz_) gzclose(gz_); if (txt_) fclose(txt_); gz_ = nullptr; txt_ = nullptr; free(line_); line_ = nullptr; }
+    ~AlnReader() { close(); }
+
+    bool next(AlnRec& r) {
+        r = AlnRec();
+        if (bam_) {
+            int32_t bs;
+            int got = gzread(gz_, &bs, 4);
+            if (got != 4) return false;
+            buf_.resize((size_t)bs);
+            rd(buf_.data(), bs, fname.c_str());
+            const uint8_t* d = buf_.data();
+            int32_t tid, pos, mtid; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
+            memcpy(&tid, d, 4); memcpy(&pos, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4);
+            memcpy(&l_seq, d + 16, 4); memcpy(&mtid, d + 20, 4);
+            uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF;
+            r.flag = flag_nc >> 16; r.pos = pos;
+            r.rname = tid >= 0 && tid < (int)targets_.size() ? targets_[tid] : "*";
+            r.rnext = mtid < 0 ? "*" : (mtid == tid ? "=" : (mtid < (int)targets_.size() ? targets_[mtid] : "*"));
+            size_t p = 32;
+            r.qname.assign((const char*)d + p, l_rn ? l_rn - 1 : 0); p += l_rn;
+            static const char CIG[] = "MIDNSHP=X";
+            for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + p, 4); p += 4; r.cigar.emplace_back(CIG[c & 0xF], c >> 4); }
+            static const char SEQ[] = "=ACMGRSVTWYHKDBN";
+            r.seq.resize((size_t)l_seq); r.qual.resize((size_t)l_seq);
+            for (int i = 0; i < l_seq; ++i) r.seq[i] = SEQ[(d[p + (i >> 1)] >> ((i & 1) ? 0 : 4)) & 0xF];
+            p += (size_t)(l_seq + 1) / 2;
+            for (int i = 0; i < l_seq; ++i) r.qual[i] = (char)(d[p + i] + 33);
+            p += (size_t)l_seq;
+            while (p + 3 <= (size_t)bs) {                       // bam_aux_get for NM / XS / XF
+                char t0 = (char)d[p], t1 = (char)d[p + 1], ty = (char)d[p + 2];
+                p += 3;
+                long long iv = 0; bool isint = false;
+                switch (ty) {
+                case 'A': if (t0 == 'X' && t1 == 'S') r.xs = (char)d[p]; p += 1; break;
+                case 'c': iv = (int8_t)d[p]; isint = true; p += 1; break;
+                case 'C': iv = d[p]; isint = true; p += 1; break;
+                case 's': { int16_t v; memcpy(&v, d + p, 2); iv = v; isint = true; p += 2; break; }
+                case 'S': { uint16_t v; memcpy(&v, d + p, 2); iv = v; isint = true; p += 2; break; }
+                case 'i': { int32_t v; memcpy(&v, d + p, 4); iv = v; isint = true; p += 4; break; }
+                case 'I': { uint32_t v; memcpy(&v, d + p, 4); iv = v; isint = true; p += 4; break; }
+                case 'f': p += 4; break;
+                case 'd': p += 8; break;
+                case 'Z': case 'H': if (t0 == 'X' && t1 == 'F') r.has_xf = true; while (p < (size_t)bs && d[p]) ++p; ++p; break;
+                case 'B': { char st = (char)d[p]; int32_t cnt; memcpy(&cnt, d + p + 1, 4); int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                            p += 5 + (size_t)cnt * sz; break; }
+                default: p = (size_t)bs; break;
+                }
+                if (isint && t0 == 'N' && t1 == 'M') { r.nm = (int)iv; r.has_nm = true; }
+            }
+            return true;
+        }
+        ssize_t n;
+        while ((n = getline(&line_, &cap_, txt_)) > 0) {
+            if (line_[0] == '@') continue;
+            std::string l(line_, (size_t)n);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            if (l.empty()) continue;
+            std::vector<std::string> t;
+            size_t i = 0;
+            while (i <= l.size()) { size_t j = l.find('\t', i); if (j == std::string::npos) j = l.size(); t.push_back(l.substr(i, j - i)); i = j + 1; }
+            if (t.size() < 11) die("Error: malformed SAM line in %s\n", fname.c_str());
+            r.qname = t[0]; r.flag = (uint32_t)atoi(t[1].c_str()); r.rname = t[2]; r.pos = atoi(t[3].c_str()) - 1;
+            r.rnext = t[6]; r.seq = t[9]; r.qual = t[10];
+            if (t[5] != "*") {
+                const char* s = t[5].c_str();
+                while (*s) { char* e; long len = strtol(s, &e, 10); if (!*e) break; r.cigar.emplace_back(*e, (uint32_t)len); s = e + 1; }
+            }
+            for (size_t k = 11; k < t.size(); ++k) {
+                if (!t[k].compare(0, 5, "NM:i:")) { r.nm = atoi(t[k].c_str() + 5); r.has_nm = true; }
+                else if (!t[k].compare(0, 5, "XS:A:")) r.xs = t[k][5];
+                else if (!t[k].compare(0, 5, "XF:Z:")) r.has_xf = true;
+            }
+            return true;
+        }
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------ BAMHitFactory::get_hit_from_buf (bwt_map.cpp:1101-1452)
+struct Hit {
+    uint32_t insert_id = 0;
+    thj_hit h16{};           // segment_juncs form
+    thj_span_hit h32{};      // long_spanning_reads form
+};
+
+// returns false when the reference's factory returns false (record dropped) or the record is unmapped
+inline bool parse_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& out) {
+    bool end = true;
+    std::string q = r.qname;
+    size_t pipe = q.rfind('|');
+    if (pipe != std::string::npos) {
+        const char* tag = q.c_str() + pipe + 1;
+        if (strchr(tag, ':')) { unsigned a = 0, b = 0, c = 0; sscanf(tag, "%u:%u:%u", &a, &b, &c); end = (b + 1 == c); }
+        q.resize(pipe);
+    }
+    out.insert_id = (uint32_t)atoi(q.c_str());
+    if (r.rname == "*" || (r.flag & 4)) return false;    // unmapped: the maps this path is fed hold mapped records only
+    if (r.has_xf) die("Error: fusion (XF) alignments in %s are not supported by this build\n", r.qname.c_str());
+    unsigned char mism = (unsigned char)r.nm;
+    int right = r.pos, read_len = 0, gap = 0;
+    bool spliced = false;
+    int n32 = 0;
+    for (auto& c : r.cigar) {
+        uint32_t len = c.second;
+        if (len == 0) return false;                                            // :1322-1326
+        uint32_t op;
+        switch (c.first) {
+        case 'M': case '=': case 'X': op = THJ_CIG_MATCH; right += (int)len; read_len += (int)len; break;
+        case 'I': op = THJ_CIG_INS; read_len += (int)len; gap += (int)len; mism = (unsigned char)(mism - len); break;
+        case 'D': op = THJ_CIG_DEL; right += (int)len; gap += (int)len; mism = (unsigned char)(mism - len); break;
+        case 'S': op = THJ_CIG_SOFT_CLIP; read_len += (int)len; break;
+        case 'H': continue;
+        case 'P': op = 15; break;
+        case 'N': op = THJ_CIG_REF_SKIP; spliced = true; if ((int)len > p.max_report_intron) return false; right += (int)len; break;   // :1337-1345
+        default: return false;
+        }
+        if (n32 < 5) out.h32.cigar[n32] = (op << 28) | (len & 0x0FFFFFFFu);
+        ++n32;
+    }
+    if (r.rnext != "*" && r.rnext != "=" && r.rnext != r.rname) return false;  // :1409-1415
+    uint32_t ref_id = rt.get_id(r.rname);
+    bool anti = (r.flag & 0x10) != 0;
+    unsigned char ed = (unsigned char)(mism + gap);
+    out.h16.ref_id = ref_id; out.h16.left = r.pos; out.h16.right = right;
+    out.h16.flags = (uint8_t)((anti ? THJ_HIT_ANTISENSE : 0) | (end ? THJ_HIT_END : 0));
+    out.h16.edit_dist = ed; out.h16.mismatches = mism; out.h16.read_len = (uint8_t)(read_len > 255 ? 255 : read_len);
+    if (n32 > 5) die("Error: segment alignment %s has %d CIGAR operations (this build supports 5)\n", r.qname.c_str(), n32);
+    out.h32.ref_id = ref_id; out.h32.left = r.pos;
+    out.h32.flags = (uint8_t)(out.h16.flags | ((spliced && r.xs == '-') ? THJ_HIT_ANTISENSE_SPLICE : 0));
+    out.h32.mismatches = mism; out.h32.edit_dist = ed; out.h32.n_cigar = (uint8_t)n32;
+    return true;
+}
+
+// HitStream (bwt_map.h:1040-1227): groups of consecutive records with equal insert_id, one-record look-ahead
+class HitStream {
+    AlnReader rd_;
+    RefTable* rt_ = nullptr;
+    const thj_params* p_ = nullptr;
+    Hit buffered_;
+    bool have_ = false, eof_ = true;
+    void fill() {
+        have_ = false;
+        AlnRec r;
+        while (!eof_) {
+            if (!rd_.next(r)) { eof_ = true; break; }
+            if (parse_hit(r, *rt_, *p_, buffered_)) { have_ = true; break; }
+        }
+    }
+public:
+    bool open(const std::string& fn, RefTable& rt, const thj_params& p) {
+        rt_ = &rt; p_ = &p;
+        if (fn.empty() || !rd_.open(fn)) return false;
+        eof_ = false;
+        fill();
+        return true;
+    }
+    uint32_t next_group_id() const { return have_ ? buffered_.insert_id : 0; }
+    // appends the next group to `out`; returns its id (0 at end)
+    uint32_t next_group(std::vector<Hit>& out) {
+        if (!have_) return 0;
+        uint32_t id = buffered_.insert_id;
+        while (have_ && buffered_.insert_id == id) { out.push_back(buffered_); fill(); }
+        return id;
+    }
+    void skip_group() { std::vector<Hit> tmp; next_group(tmp); }
+};
+
+// ------------------------------------------------------------------ reads (reads.cpp:94-188, :528-630)
+struct Read { uint32_t id = 0; std::string name, seq, qual; };
+
+class ReadStream {
+    FILE* f_ = nullptr; bool pipe_ = false;
+    AlnReader bam_; bool is_bam_ = false;
+    char* line_ = nullptr; size_t cap_ = 0;
+    std::string pending_;     // pushed-back header line
+    std::map<uint32_t, Read> ahead_;
+    bool eof_ = false;
+    bool getl(std::string& s) {
+        if (!pending_.empty()) { s.swap(pending_); pending_.clear(); return true; }
+        ssize_t n;
+        while ((n = getline(&line_, &cap_, f_)) > 0) {
+            s.assign(line_, (size_t)n);
+            while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+            return true;
+        }
+        return false;
+    }
+    bool next(Read& r) {
+        if (is_bam_) {
+            AlnRec a;
+            if (!bam_.next(a)) return false;
+            r.id = (uint32_t)atoi(a.qname.c_str()); r.name = a.qname; r.seq = a.seq; r.qual = a.qual;
+            return true;
+        }
+        std::string l;
+        do { if (!getl(l)) return false; } while (l.empty());
+        if (l[0] != '@' && l[0] != '>') die("Error: unrecognised reads file format\n");
+        bool fq = l[0] == '@';
+        std::string name = l.substr(1);
+        size_t sp = name.find_first_of(" \t");
+        if (sp != std::string::npos) name.resize(sp);
+        r.id = (uint32_t)atoi(name.c_str());
+        r.name = name;
+        r.seq.clear(); r.qual.clear();
+        while (getl(l)) {
+            if (l.empty()) continue;
+            if ((fq && l[0] == '+') || (!fq && l[0] == '>')) { if (!fq) pending_ = l; break; }
+            r.seq += l;
+        }
+        std::replace(r.seq.begin(), r.seq.end(), '.', 'N');          // reads.cpp:119
+        if (fq) {
+            while (r.qual.size() < r.seq.size() && getl(l)) r.qual += l;
+            if (r.qual.size() != r.seq.size()) die("Error: qual length (%d) differs from seq length (%d) for fastq record %s!\n", (int)r.qual.size(), (int)r.seq.size(), name.c_str());
+        } else r.qual.assign(r.seq.size(), 'I');
+        return !r.seq.empty();
+    }
+public:
+    bool open(const std::string& fn, const std::string& zpacker) {
+        std::string e = file_ext(fn);
+        if (e == "bam") { is_bam_ = true; return bam_.open(fn); }
+        if (e == "z" && !zpacker.empty()) {                          // FZPipe, common.cpp:899-922
+            std::string cmd = zpacker + " -cd '" + fn + "'";
+            f_ = popen(cmd.c_str(), "r"); pipe_ = true;
+        } else f_ = fopen(fn.c_str(), "r");
+        return f_ != nullptr;
+    }
+    ~ReadStream() { if (f_) { if (pipe_) pclose(f_); else fclose(f_); } free(line_); }
+    // monotone fetch: requests arrive in increasing id order (the visiting order of both stages)
+    bool get(uint32_t id, Read& out) {
+        auto it = ahead_.find(id);
+        if (it != ahead_.end()) { out = std::move(it->second); ahead_.erase(ahead_.begin(), std::next(it)); return true; }
+        Read r;
+        while (!eof_) {
+            if (!next(r)) { eof_ = true; break; }
+            if (r.id == id) { out = std::move(r); while (!ahead_.empty() && ahead_.begin()->first < id) ahead_.erase(ahead_.begin()); return true; }
+            if (r.id > id) ahead_[r.id] = r;          // slightly out-of-order files (reads.h:142 keeps a 500k-entry heap)
+        }
+        return false;
+    }
+};
+
+// ------------------------------------------------------------------ BGZF + BAM writer (samtools-0.1.18 bgzf.c, common.cpp:1000-1173)
+class BgzfWriter {
+    FILE* f_ = nullptr;
+    std::vector<uint8_t> in_;
+    int64_t block_addr_ = 0;
+    static const int BLOCK = 0x10000;
+    void deflate_block() {
+        size_t off = 0;
+        while (off < in_.size() || (off == 0 && in_.empty() && false)) {
+            size_t take = in_.size() - off;
+            if (take > (size_t)BLOCK) take = BLOCK;
+            std::vector<uint8_t> out(BLOCK + 1024);
+            size_t clen = 0;
+            for (;;) {
+                z_stream zs; memset(&zs, 0, sizeof zs);
+                deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+                zs.next_in = in_.data() + off; zs.avail_in = (uInt)take;
+                zs.next_out = out.data() + 18; zs.avail_out = (uInt)(BLOCK - 18 - 8);
+                int st = deflate(&zs, Z_FINISH);
+                clen = zs.total_out;
+                deflateEnd(&zs);
+                if (st == Z_STREAM_END) break;
+                take -= 1024;                       // bgzf.c deflate_block: shrink the input and retry
+            }
+            uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in_.data() + off, (uInt)take);
+            write_block(out.data(), clen, crc, (uint32_t)take);
+            off += take;
+        }
+        in_.clear();
+    }
+    void write_block(uint8_t* out, size_t clen, uint32_t crc, uint32_t isize) {
+        static const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
+        memcpy(out, hdr, 12);
+        out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
+        uint16_t bs = (uint16_t)(clen + 18 + 8 - 1);
+        memcpy(out + 16, &bs, 2);
+        memcpy(out + 18 + clen, &crc, 4);
+        memcpy(out + 18 + clen + 4, &isize, 4);
+        fwrite(out, 1, clen + 26, f_);
+        block_addr_ += (int64_t)clen + 26;
+    }
+public:
+    bool open(const std::string& fn) { f_ = fopen(fn.c_str(), "wb"); return f_ != nullptr; }
+    void write(const void* d, size_t n) {
+        const uint8_t* p = (const uint8_t*)d;
+        while (n) {
+            size_t room = (size_t)BLOCK - in_.size();
+            size_t k = n < room ? n : room;
+            in_.insert(in_.end(), p, p + k);
+            p += k; n -= k;
+            if (in_.size() == (size_t)BLOCK) deflate_block();
+        }
+    }
+    int64_t tell() const { return (block_addr_ << 16) | (int64_t)in_.size(); }
+    void close() {
+        if (!f_) return;
+        if (!in_.empty()) deflate_block();
+        uint8_t out[64];
+        uint8_t empty[2] = {3, 0};                   // an empty deflate stream: the BGZF EOF marker block
+        memcpy(out + 18, empty, 2);
+        write_block(out, 2, 0, 0);
+        fclose(f_); f_ = nullptr;
+    }
+    ~BgzfWriter() { close(); }
+};
+
+inline int reg2bin(int beg, int end) {                // bam.h bam_reg2bin
+    --end;
+    if (beg >> 14 == end >> 14) return 4681 + (beg >> 14);
+    if (beg >> 17 == end >> 17) return 585 + (beg >> 17);
+    if (beg >> 20 == end >> 20) return 73 + (beg >> 20);
+    if (beg >> 23 == end >> 23) return 9 + (beg >> 23);
+    if (beg >> 26 == end >> 26) return 1 + (beg >> 26);
+    return 0;
+}
+
+// GBamWriter with the read-id -> BGZF-offset side file (common.h:562-606)
+class BamWriter {
+    BgzfWriter z_;
+    FILE* idx_ = nullptr;
+    std::unordered_map<std::string, int32_t> tid_;
+    uint64_t idxcount_ = 0; int64_t last_id_ = 0;
+    static void put32(std::vector<uint8_t>& v, uint32_t x) { uint8_t b[4]; memcpy(b, &x, 4); v.insert(v.end(), b, b + 4); }
+public:
+    bool open(const std::string& fn, const RefTable& rt, const std::string& idx_fn) {
+        if (!z_.open(fn)) return false;
+        if (!idx_fn.empty()) { idx_ = fopen(idx_fn.c_str(), "w"); if (!idx_) return false; }
+        std::vector<uint8_t> h;
+        h.insert(h.end(), {'B', 'A', 'M', 1});
+        put32(h, (uint32_t)rt.header_text.size());
+        h.insert(h.end(), rt.header_text.begin(), rt.header_text.end());
+        put32(h, (uint32_t)rt.sq.size());
+        for (size_t i = 0; i < rt.sq.size(); ++i) {
+            put32(h, (uint32_t)rt.sq[i].first.size() + 1);
+            h.insert(h.end(), rt.sq[i].first.begin(), rt.sq[i].first.end());
+            h.push_back(0);
+            put32(h, rt.sq[i].second);
+            tid_[rt.sq[i].first] = (int32_t)i;
+        }
+        z_.write(h.data(), h.size());
+        return true;
+    }
+    // one record exactly as GBamRecord builds it: mate fields "*", 0, 0; MAPQ 255
+    void write(const std::string& qname, uint32_t flag, const std::string& rname, int pos1, const std::vector<uint32_t>& cigar /*op<<28|len*/,
+               const std::string& seq, const std::string& qual, const std::vector<std::string>& aux) {
+        static const uint8_t nt16[256] = {
+            15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+            15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 1,2,4,8,15,15,15,15,15,15,15,15,15,0,15,15,
+            15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
+            15,1,14,2,13,15,15,4,11,15,15,12,15,3,15,15, 15,15,5,6,8,15,7,9,15,10,15,15,15,15,15,15,
+            15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+            15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+            15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
+            15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15};
+        static const uint8_t bamop[16] = {0, 0, 0, 1, 1, 2, 2, 0, 0, 0, 0, 3, 3, 4, 5, 6};   // upper-cased letters (set_cigar :1044-1053)
+        std::vector<uint8_t> d;
+        auto it = tid_.find(rname);
+        int32_t tid = it == tid_.end() ? -1 : it->second;
+        int32_t pos = pos1 <= 0 ? -1 : pos1 - 1;
+        int end = pos;
+        for (uint32_t c : cigar) { uint32_t op = bamop[c >> 28]; if (op == 0 || op == 2 || op == 3) end += (int)(c & 0x0FFFFFFF); }
+        uint32_t bin = (uint32_t)reg2bin(pos, cigar.empty() ? pos + 1 : end);
+        uint32_t l_rn = (uint32_t)qname.size() + 1;
+        put32(d, (uint32_t)tid); put32(d, (uint32_t)pos);
+        put32(d, (bin << 16) | (255u << 8) | l_rn);
+        put32(d, (flag << 16) | (uint32_t)cigar.size());
+        put32(d, (uint32_t)seq.size());
+        put32(d, (uint32_t)-1); put32(d, (uint32_t)-1); put32(d, 0);          // mtid, mpos (0-1), isize
+        d.insert(d.end(), qname.begin(), qname.end()); d.push_back(0);
+        for (uint32_t c : cigar) put32(d, ((c & 0x0FFFFFFF) << 4) | bamop[c >> 28]);
+        size_t so = d.size();
+        d.resize(so + (seq.size() + 1) / 2, 0);
+        for (size_t i = 0; i < seq.size(); ++i) d[so + i / 2] |= (uint8_t)(nt16[(uint8_t)seq[i]] << (4 * (1 - i % 2)));
+        for (size_t i = 0; i < seq.size(); ++i) d.push_back((uint8_t)(qual[i] - 33));
+        for (auto& a : aux) {                                                  // add_aux, common.cpp:1092-1173
+            d.push_back((uint8_t)a[0]); d.push_back((uint8_t)a[1]);
+            char ty = a[3];
+            if (ty == 'A' || ty == 'a' || ty == 'c' || ty == 'C') { d.push_back('A'); d.push_back((uint8_t)a[5]); }
+            else if (ty == 'i' || ty == 'I') {
+                long long x = atoll(a.c_str() + 5);
+                if (x < 0) {
+                    if (x >= -127) { d.push_back('c'); d.push_back((uint8_t)(int8_t)x); }
+                    else if (x >= -32767) { d.push_back('s'); int16_t v = (int16_t)x; uint8_t b[2]; memcpy(b, &v, 2); d.insert(d.end(), b, b + 2); }
+                    else { d.push_back('i'); put32(d, (uint32_t)(int32_t)x); }
+                } else {
+                    if (x <= 255) { d.push_back('C'); d.push_back((uint8_t)x); }
+                    else if (x <= 65535) { d.push_back('S'); uint16_t v = (uint16_t)x; uint8_t b[2]; memcpy(b, &v, 2); d.insert(d.end(), b, b + 2); }
+                    else { d.push_back('I'); put32(d, (uint32_t)x); }
+                }
+            } else if (ty == 'Z' || ty == 'H') { d.push_back((uint8_t)ty); d.insert(d.end(), a.begin() + 5, a.end()); d.push_back(0); }
+        }
+        // GBamWriter::write(b, read_id): index line once >= INDEX_REC_COUNT (1000) records have passed and the id changes
+        long read_id = atol(qname.c_str());
+        int64_t pre_pos = 0, pre_addr = 0; bool widx = false;
+        if (idx_ && read_id) {
+            if (idxcount_ >= 1000 && read_id != last_id_) { pre_pos = z_.tell(); pre_addr = (pre_pos >> 16) & 0xFFFFFFFFFFFFLL; widx = true; }
+            last_id_ = read_id; ++idxcount_;
+        }
+        uint32_t bs = (uint32_t)d.size();
+        z_.write(&bs, 4);
+        z_.write(d.data(), d.size());
+        if (widx) {
+            int64_t off = z_.tell();
+            int post_offs = (int)(off & 0xFFFF); int64_t post_addr = (off >> 16) & 0xFFFFFFFFFFFFLL;
+            int data_len = (int)d.size();          // b->data_len + BAM_CORE_SIZE == block_size of the record
+            if (post_addr != pre_addr && post_offs >= data_len) pre_pos = post_addr << 16;
+            fprintf(idx_, "%ld\t%ld\n", read_id, (long)pre_pos);
+            idxcount_ = 0;
+        }
+    }
+    void close() { z_.close(); if (idx_) { fclose(idx_); idx_ = nullptr; } }
+};
+
+inline void reverse_complement(std::string& s) {       // reads.cpp:189-207
+    for (auto& c : s) { switch (c) { case 'A': c = 'T'; break; case 'T': c = 'A'; break; case 'C': c = 'G'; break; case 'G': c = 'C'; break; default: c = 'N'; } }
+    std::reverse(s.begin(), s.end());
+}
+
+}  // namespace thjh
