@@ -114,7 +114,8 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                                 const uint64_t* planes, const uint16_t* read_len, const uint8_t* quals, int32_t qual_stride,
                                 const thj_junction* juncs, int64_t n_juncs,
                                 const uint32_t* ins /* 4 u32 each: ref,left,len,seq3 */, int64_t n_ins,
-                                void** out, int64_t* n_out, int64_t* status_counts /* [3] */) {
+                                int32_t mode /* 0 = lean tier + generic fallback (as the kernels), 1 = generic only */,
+                                void** out, int64_t* n_out, int64_t* status_counts /* [4] */) {
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Params p;
     memcpy(&p, tp, sizeof p);
@@ -127,10 +128,17 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
     SpanSets S{jk.data(), n_juncs, ik.data(), iseq.data(), n_ins};
     std::vector<OutAln> res;
     VecSink sink{&res};
-    status_counts[0] = status_counts[1] = status_counts[2] = 0;
+    status_counts[0] = status_counts[1] = status_counts[2] = status_counts[3] = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
-        int st = span_read(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+        int st = SPAN_NEED_GENERIC;
+        if (mode == 0)
+            st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+        if (st == SPAN_NEED_GENERIC) {
+            status_counts[3]++;
+            st = span_read(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                            read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+        }
         status_counts[st]++;
     }
     *n_out = (int64_t)res.size();

@@ -67,7 +67,7 @@ def segjuncs(p: Params, seqs, b: SegBatch, ordinal_base: int = 0) -> Events:
     return ev
 
 
-def spanning(p: Params, seqs, b, juncs, insertions):
+def spanning(p: Params, seqs, b, juncs, insertions, mode: int = 0):
     """-> (list of Aln, status counts) from the CPU build of thj_span_core.h"""
     l = lib()
     g = host.pack_genome(seqs, lib=l)
@@ -78,13 +78,13 @@ def spanning(p: Params, seqs, b, juncs, insertions):
     t = host._ins_table(insertions)
     out = C.c_void_p()
     n_out = C.c_int64()
-    st = (C.c_int64 * 3)()
+    st = (C.c_int64 * 4)()
     rc = l.hostsim_spanning(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
                             C.c_void_p(clen.ctypes.data), g.n_contigs, d["n_reads"], d["nseg"], d["W"],
                             C.c_void_p(d["seg_off"].ctypes.data), C.c_void_p(d["hits"].ctypes.data),
                             C.c_void_p(d["planes"].ctypes.data), C.c_void_p(d["read_len"].ctypes.data),
                             C.c_void_p(d["quals"].ctypes.data), d["qual_stride"],
-                            C.c_void_p(j.ctypes.data), C.c_int64(len(j)), C.c_void_p(t.ctypes.data), C.c_int64(len(insertions)),
+                            C.c_void_p(j.ctypes.data), C.c_int64(len(j)), C.c_void_p(t.ctypes.data), C.c_int64(len(insertions)), mode,
                             C.byref(out), C.byref(n_out), st)
     assert rc == 0, rc
     a = np.frombuffer((C.c_char * (max(1, n_out.value) * 128)).from_address(out.value), dtype=host.ALN_DTYPE)[:n_out.value].copy()

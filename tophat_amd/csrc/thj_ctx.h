@@ -53,6 +53,7 @@ struct thj_ctx {
     void* d_aln_sort_tmp = nullptr; size_t aln_sort_tmp_bytes = 0;
     unsigned long long* d_aln_count = nullptr; unsigned int* d_span_status = nullptr;
     int64_t n_alns = 0;
+    uint32_t* d_worklist = nullptr; int64_t worklist_cap = 0;
     bool span_profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;
     // profiling

@@ -42,8 +42,24 @@ struct PoolSink {
     }
 };
 
-__global__ __launch_bounds__(128) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink) {
+// Tier 1: every read; reads whose segments each have exactly one hit are finished here with a small private
+// state (streamed merge_chain); the rest are appended to a worklist.
+__global__ __launch_bounds__(256) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
+                                                    uint32_t* worklist, unsigned int* n_work) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < b.n_reads; r += gridDim.x * blockDim.x) {
+        int st = span_read_lean(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                                (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        if (st == SPAN_NEED_GENERIC) worklist[atomicAdd(n_work, 1u)] = (uint32_t)r;
+        else if (st) atomicAdd(&sink.status[st], 1u);
+    }
+}
+
+// Tier 2: the general per-read DFS (multihit segments) over the worklist.
+__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
+                                                             const uint32_t* worklist, const unsigned int* n_work) {
+    const unsigned int n = *n_work;
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = (int)worklist[i];
         int st = span_read(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                            (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
         if (st) atomicAdd(&sink.status[st], 1u);
@@ -74,14 +90,14 @@ void thj_span_free(thj_ctx* c) {
     hipFree(c->d_span_junc); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_aln_keys2);
     hipFree(c->d_aln_idx); hipFree(c->d_aln_idx2); hipFree(c->d_aln_sort_tmp);
-    hipFree(c->d_aln_count); hipFree(c->d_span_status);
+    hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
 static int ensure_span_state(thj_ctx* c) {
     if (!c->d_aln_count) {
         HIPCHK(hipMalloc(&c->d_aln_count, 8));
-        HIPCHK(hipMalloc(&c->d_span_status, 4 * sizeof(unsigned int)));
+        HIPCHK(hipMalloc(&c->d_span_status, 8 * sizeof(unsigned int)));
         HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 8, c->stream));
         HIPCHK(hipMemsetAsync(c->d_span_status, 0, 16, c->stream));
     }
@@ -295,12 +311,22 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     DevSpanBatch b; memcpy(&b, db, sizeof b);
     SpanSets S{c->d_span_junc, c->n_span_junc, c->d_span_ins_key, c->d_span_ins_seq, c->n_span_ins};
     PoolSink sink{(OutAln*)c->d_aln_pool, c->d_aln_count, (unsigned long long)c->aln_cap, c->d_span_status};
-    int64_t blocks = ((int64_t)b.n_reads + 127) / 128;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (c->worklist_cap < b.n_reads) {
+        hipFree(c->d_worklist); c->d_worklist = nullptr;
+        HIPCHK(hipMalloc(&c->d_worklist, (size_t)b.n_reads * 4));
+        c->worklist_cap = b.n_reads;
+    }
+    HIPCHK(hipMemsetAsync(&c->d_span_status[4], 0, 4, c->stream));       // worklist counter
+    int64_t blocks = ((int64_t)b.n_reads + 255) / 256;
+    if (blocks > 256 * 8) blocks = 256 * 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->span_profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
-    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)blocks), dim3(128), 0, c->stream, g, p, S, b, sink);
+    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, S, b, sink, c->d_worklist, &c->d_span_status[4]);
     if (c->span_profile) { HIPCHK(hipEventRecord(e1, c->stream)); c->span_prof_events.emplace_back(e0, e1); }
+    int64_t b2 = ((int64_t)b.n_reads + 127) / 128;
+    if (b2 > 2048) b2 = 2048;
+    hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)b2), dim3(128), 0, c->stream, g, p, S, b, sink,
+                       (const uint32_t*)c->d_worklist, (const unsigned int*)&c->d_span_status[4]);
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }

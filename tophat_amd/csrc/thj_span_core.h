@@ -153,216 +153,237 @@ THJ_HD bool check_editdist(const Genome& g, const Aln& h, const SeqView& sv) {
     return mismatch == (int)h.mm || mismatch + n_mism == (int)h.mm;
 }
 
+// ---- one adjacent pair of merge_chain's main loop (long_spanning_reads.cpp:900-1870) -------------
+// prev covers read bases [.., P) of the chain's forward sequence `sv`, curr covers [P, P+curr.rlen).
+// PAIR_KEEP: the two abut (dist == 0) and stay separate chain elements; PAIR_MERGED: `m` replaces both;
+// PAIR_FAIL: merge_chain returns BowtieHit().
+enum { PAIR_FAIL = 0, PAIR_KEEP = 1, PAIR_MERGED = 2 };
+
+THJ_HD int close_pair(const Genome& g, const Params& p, const SpanSets& S, const SeqView& sv, int P, const Aln& prev,
+                      const Aln& curr, Aln& m) {
+    if (!(op_is_match(cig_op(prev.c[prev.n - 1])) || op_is_match(cig_op(curr.c[0])))) return PAIR_FAIL;     // :924-928
+    const bool psp = aln_spliced(prev), csp = aln_spliced(curr);
+    if (psp && csp && prev.asplice != curr.asplice) return PAIR_FAIL;                                        // :936-943
+    bool found = false;
+    int anti_closure = psp ? prev.asplice : curr.asplice;
+    uint32_t nc[SPAN_MAXC + 8]; int nn = 0;
+    int new_left = -1, mismatch = 0;
+    const int prev_end_len = (int)cig_len(prev.c[prev.n - 1]);
+    const int curr_front_len = (int)cig_len(curr.c[0]);
+    if (prev.ref_id != curr.ref_id) return PAIR_FAIL;      // check_fusion with an empty fusion set (:1596-1818)
+    const uint32_t ref = prev.ref_id;
+    const int prev_right = aln_right(prev);
+    const int lbnd = prev_right - 4, rbnd = curr.left + 4;
+    const int dist = curr.left - prev_right;
+    if (dist < 0 && dist >= -p.max_insertion_length && prev.anti == curr.anti) {
+        // ---- insertion closure :1010-1306
+        if (g_len(g, ref) == 0) return PAIR_FAIL;
+        int64_t lb = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)lbnd, 0));
+        int64_t ub = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)rbnd, p.max_insertion_length));
+        const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
+        for (; lb < ub; ++lb) {
+            const u64 k = S.ins_keys[lb];
+            const int ilen = (int)(k & 15);
+            const int ileft = (int)((int64_t)(k >> 4) - 1 - (int64_t)cbase);
+            if (ilen != prev_right - curr.left) continue;
+            const int itpr = prev_right - ileft - 1;
+            const int clti = ileft - curr.left + 1;
+            if (itpr > prev_end_len || clti > curr_front_len) continue;
+            const uint32_t iseq = S.ins_seq[lb];
+            int trm = 0, ins_mm = 0;
+            if (itpr > 0) {
+                Planes rf = g_fetch(g, ref, (int64_t)ileft + 1);       // ref[ileft+1, prev_right)
+                for (int ri = 0; ri < itpr; ++ri) {
+                    int r = plane_code(rf, ri);
+                    int o = seq_code(sv, P - itpr + ri);
+                    if (r == 4 || r != o) ++trm;
+                    if (ri < ilen) {
+                        int ic = (int)((iseq >> (3 * ri)) & 7u);
+                        if (ic == 4 || ic != o) { ++ins_mm; break; }
+                    } else {
+                        int r2 = plane_code(rf, ri - ilen);
+                        if (r2 == 4 || r2 != o) --trm;
+                    }
+                }
+            }
+            if (clti > 0) {
+                Planes rf = g_fetch(g, ref, curr.left);                 // ref[curr.left, ileft+1)
+                for (int ri = 0; ri < clti; ++ri) {
+                    int sp = clti - ri - 1, ip = ilen - ri - 1;
+                    int r = plane_code(rf, sp);
+                    int o = seq_code(sv, P + sp);
+                    if (r == 4 || r != o) ++trm;
+                    if (ri < ilen) {
+                        int ic = (int)((iseq >> (3 * ip)) & 7u);
+                        if (ic == 4 || ic != o) { ++ins_mm; break; }
+                    } else {
+                        int r2 = plane_code(rf, sp + ilen);
+                        if (r2 == 4 || r2 != o) --trm;
+                    }
+                }
+            }
+            if (found) return PAIR_FAIL;                                               // :1243-1247
+            if (ins_mm == 0) {
+                mismatch = -trm;
+                found = true;
+                new_left = prev.left;
+                nn = prev.n;
+                for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
+                uint32_t bl = (cig_len(nc[nn - 1]) - (uint32_t)itpr) & 0x0FFFFFFFu;
+                if (bl == 0) --nn; else nc[nn - 1] = cig(cig_op(nc[nn - 1]), bl);
+                nc[nn++] = cig(OP_INS, (uint32_t)ilen);
+                uint32_t fl = (cig_len(curr.c[0]) + (uint32_t)(itpr - ilen)) & 0x0FFFFFFFu;
+                for (int q = fl > 0 ? 0 : 1; q < curr.n; ++q) {
+                    if (nn >= SPAN_MAXC + 8) return PAIR_FAIL;
+                    nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), fl) : curr.c[q];
+                }
+            }
+        }
+        if (!found) return PAIR_FAIL;
+    } else if (dist > 0 && dist <= p.max_report_intron && prev.anti == curr.anti) {
+        // ---- junction / deletion closure :1311-1591
+        if (g_len(g, ref) == 0) return PAIR_FAIL;
+        int64_t lb = upper_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true));
+        int64_t ub = lower_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false));
+        const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
+        int best_diff = 0xff;
+        for (; lb < ub; ++lb) {
+            const u64 k = S.junc_keys[lb];
+            const int jl = (int)((int64_t)(k >> 30) - 1 - (int64_t)cbase);
+            const int jr = jl + (int)((k >> 1) & ((1ull << 29) - 1));
+            const int janti = (int)(k & 1ull);
+            const int dtl = jl - prev_right + 1, dtr = jr - curr.left;
+            if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
+            if (dtl > curr_front_len || -dtl > prev_end_len) continue;
+            int new_mm = 0, old_mm = 0;
+            if (dtl > 0) {
+                Planes nr = g_fetch(g, ref, prev_right);      // new_cmp = ref[prev_right, jl+1)
+                Planes orf = g_fetch(g, ref, curr.left);      // old_cmp = ref[curr.left, jr)
+                for (int i = 0; i < dtl; ++i) {
+                    int s = seq_code(sv, P + i);               // curr.seq[i]; raw char vs Dna5: N == N
+                    if (s != plane_code(nr, i)) ++new_mm;
+                    if (s != plane_code(orf, i)) ++old_mm;
+                }
+            } else if (dtl < 0) {
+                int ad = -dtl;
+                Planes nr = g_fetch(g, ref, jr);               // new_cmp = ref[jr, curr.left)
+                Planes orf = g_fetch(g, ref, (int64_t)jl + 1); // old_cmp = ref[jl+1, prev_right)
+                for (int i = 0; i < ad; ++i) {
+                    int s = seq_code(sv, P - ad + i);
+                    if (s != plane_code(nr, i)) ++new_mm;
+                    if (s != plane_code(orf, i)) ++old_mm;
+                }
+            }
+            int diff = new_mm - old_mm;
+            if (diff >= best_diff || new_mm >= 2) continue;
+            best_diff = diff;
+            new_left = prev.left;
+            nn = prev.n;
+            for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
+            int nlb = (int)cig_len(nc[nn - 1]) + dtl;
+            int nrf = (int)cig_len(curr.c[0]) - dtr;
+            if (nlb > 0) nc[nn - 1] = cig(cig_op(nc[nn - 1]), (uint32_t)nlb); else --nn;
+            uint32_t skip = (uint32_t)(jr - jl - 1);
+            if (skip <= (uint32_t)p.max_deletion_length) {
+                nc[nn++] = cig(OP_DEL, skip);
+                anti_closure = psp ? prev.asplice : curr.asplice;
+            } else {
+                nc[nn++] = cig(OP_REF_SKIP, skip);
+                anti_closure = janti;
+            }
+            for (int q = nrf > 0 ? 0 : 1; q < curr.n; ++q) {
+                if (nn >= SPAN_MAXC + 8) return PAIR_FAIL;
+                nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), (uint32_t)nrf) : curr.c[q];
+            }
+            mismatch = best_diff;
+            found = true;
+        }
+        if (!found) return PAIR_FAIL;
+    } else if (!(dist == 0 && prev.anti == curr.anti))
+        return PAIR_FAIL;                                   // check_fusion, empty fusion set
+
+    if (!found) return PAIR_KEEP;
+    if (nn > SPAN_MAXC) return PAIR_FAIL;                   // capacity (documented limit)
+    int mismatches = (int)prev.mm + (int)curr.mm + mismatch;                           // :1822-1870
+    m.ref_id = prev.ref_id; m.left = new_left; m.n = nn;
+    for (int q = 0; q < nn; ++q) m.c[q] = nc[q];
+    m.anti = prev.anti; m.asplice = (uint8_t)anti_closure;
+    m.mm = (uint8_t)mismatches;
+    m.ed = (uint8_t)(mismatches + cig_gap_len(nc, nn));
+    m.rlen = prev.rlen + curr.rlen; m.valid = 1;
+    return PAIR_MERGED;
+}
+
+// the pre-check of merge_chain (:843-891): at most one fusion-like gap
+THJ_HD bool gap_is_fusion_like(const Params& p, int gap) {
+    int maxi = p.max_report_intron < 10000000 ? p.max_report_intron : 10000000;
+    return gap < -p.max_insertion_length || (gap > p.max_deletion_length && (gap < p.min_report_intron || gap > maxi));
+}
+
+// final concatenation state of merge_chain (:1888-1944), fed one chain element at a time
+struct ChainOut {
+    Aln out; bool saw_as, saw_s; int num_mm;
+};
+THJ_HD void chain_out_init(ChainOut& c) { c.out.n = 0; c.saw_as = c.saw_s = false; c.num_mm = 0; }
+THJ_HD bool chain_out_add(ChainOut& c, const Aln& e) {
+    c.num_mm += e.mm;
+    if (aln_spliced(e)) {
+        if (e.asplice) { if (c.saw_s) return false; c.saw_as = true; }
+        else { if (c.saw_as) return false; c.saw_s = true; }
+    }
+    Aln& o = c.out;
+    int b0 = 0;
+    if (o.n > 0 && cig_op(o.c[o.n - 1]) == cig_op(e.c[0])) {
+        o.c[o.n - 1] = cig(cig_op(o.c[o.n - 1]), cig_len(o.c[o.n - 1]) + cig_len(e.c[0]));
+        b0 = 1;
+    }
+    for (int b = b0; b < e.n; ++b) { if (o.n >= SPAN_MAXC) return false; o.c[o.n++] = e.c[b]; }
+    return true;
+}
+THJ_HD void chain_out_finish(ChainOut& c, uint32_t ref_id, int left, int antisense, int rlen) {
+    Aln& o = c.out;
+    o.ref_id = ref_id; o.left = left;
+    o.anti = (uint8_t)antisense; o.asplice = c.saw_as ? 1 : 0;
+    o.mm = (uint8_t)c.num_mm; o.ed = (uint8_t)(c.num_mm + cig_gap_len(o.c, o.n));
+    o.rlen = rlen; o.valid = 1;
+}
+
 // ---- merge_chain (long_spanning_reads.cpp:805-2038), fusion_dir == FUSION_NOTHING ----------
-// chain[0..n) ordered left to right; seq = the chain's forward-orientation sequence.
+// chain[0..n) ordered left to right; sv = the chain's forward-orientation sequence.
 THJ_HD bool merge_chain(const Genome& g, const Params& p, const SpanSets& S, const SeqView& sv, Aln* chain, int n,
                         Aln& out) {
     const int left = chain[0].left;
     int antisense = chain[0].anti;
     int old_read_length = 0;
     for (int i = 0; i < n; ++i) old_read_length += aln_read_len(chain[i]);
-    {   // :843-891
+    {
         int num_fusions = 0;
         for (int k = 1; k < n; ++k) {
             if (chain[k - 1].ref_id != chain[k].ref_id) ++num_fusions;
-            else {
-                int gap = chain[k].left - aln_right(chain[k - 1]);
-                int maxi = p.max_report_intron < 10000000 ? p.max_report_intron : 10000000;
-                if (gap < -p.max_insertion_length ||
-                    (gap > p.max_deletion_length && (gap < p.min_report_intron || gap > maxi)))
-                    ++num_fusions;
-            }
+            else if (gap_is_fusion_like(p, chain[k].left - aln_right(chain[k - 1]))) ++num_fusions;
             if (num_fusions >= 2) return false;
         }
     }
     int pi = 0, ci = 1;
     int P = chain[0].rlen;            // read bases covered by chain[0..pi]
     while (ci < n) {
-        Aln& prev = chain[pi];
-        Aln& curr = chain[ci];
-        antisense = prev.anti;
-        if (!(op_is_match(cig_op(prev.c[prev.n - 1])) || op_is_match(cig_op(curr.c[0])))) return false;   // :924-928
-        const bool psp = aln_spliced(prev), csp = aln_spliced(curr);
-        if (psp && csp && prev.asplice != curr.asplice) return false;                                      // :936-943
-        bool found = false;
-        int anti_closure = psp ? prev.asplice : curr.asplice;
-        uint32_t nc[SPAN_MAXC + 8]; int nn = 0;
-        int new_left = -1, mismatch = 0;
-        const int prev_end_len = (int)cig_len(prev.c[prev.n - 1]);
-        const int curr_front_len = (int)cig_len(curr.c[0]);
-        if (prev.ref_id != curr.ref_id) return false;      // check_fusion with an empty fusion set (:1596-1818)
-        const uint32_t ref = prev.ref_id;
-        const int prev_right = aln_right(prev);
-        const int lbnd = prev_right - 4, rbnd = curr.left + 4;
-        const int dist = curr.left - prev_right;
-        if (dist < 0 && dist >= -p.max_insertion_length && prev.anti == curr.anti) {
-            // ---- insertion closure :1010-1306
-            if (g_len(g, ref) == 0) return false;
-            int64_t lb = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)lbnd, 0));
-            int64_t ub = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)rbnd, p.max_insertion_length));
-            const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
-            for (; lb < ub; ++lb) {
-                const u64 k = S.ins_keys[lb];
-                const int ilen = (int)(k & 15);
-                const int ileft = (int)((int64_t)(k >> 4) - 1 - (int64_t)cbase);
-                if (ilen != prev_right - curr.left) continue;
-                const int itpr = prev_right - ileft - 1;
-                const int clti = ileft - curr.left + 1;
-                if (itpr > prev_end_len || clti > curr_front_len) continue;
-                const uint32_t iseq = S.ins_seq[lb];
-                int trm = 0, ins_mm = 0;
-                if (itpr > 0) {
-                    Planes rf = g_fetch(g, ref, (int64_t)ileft + 1);       // ref[ileft+1, prev_right)
-                    for (int ri = 0; ri < itpr; ++ri) {
-                        int r = plane_code(rf, ri);
-                        int o = seq_code(sv, P - itpr + ri);
-                        if (r == 4 || r != o) ++trm;
-                        if (ri < ilen) {
-                            int ic = (int)((iseq >> (3 * ri)) & 7u);
-                            if (ic == 4 || ic != o) { ++ins_mm; break; }
-                        } else {
-                            int r2 = plane_code(rf, ri - ilen);
-                            if (r2 == 4 || r2 != o) --trm;
-                        }
-                    }
-                }
-                if (clti > 0) {
-                    Planes rf = g_fetch(g, ref, curr.left);                 // ref[curr.left, ileft+1)
-                    for (int ri = 0; ri < clti; ++ri) {
-                        int sp = clti - ri - 1, ip = ilen - ri - 1;
-                        int r = plane_code(rf, sp);
-                        int o = seq_code(sv, P + sp);
-                        if (r == 4 || r != o) ++trm;
-                        if (ri < ilen) {
-                            int ic = (int)((iseq >> (3 * ip)) & 7u);
-                            if (ic == 4 || ic != o) { ++ins_mm; break; }
-                        } else {
-                            int r2 = plane_code(rf, sp + ilen);
-                            if (r2 == 4 || r2 != o) --trm;
-                        }
-                    }
-                }
-                if (found) return false;                                                   // :1243-1247
-                if (ins_mm == 0) {
-                    mismatch = -trm;
-                    found = true;
-                    new_left = prev.left;
-                    nn = prev.n;
-                    for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
-                    uint32_t bl = (cig_len(nc[nn - 1]) - (uint32_t)itpr) & 0x0FFFFFFFu;
-                    if (bl == 0) --nn; else nc[nn - 1] = cig(cig_op(nc[nn - 1]), bl);
-                    nc[nn++] = cig(OP_INS, (uint32_t)ilen);
-                    uint32_t fl = (cig_len(curr.c[0]) + (uint32_t)(itpr - ilen)) & 0x0FFFFFFFu;
-                    for (int q = fl > 0 ? 0 : 1; q < curr.n; ++q) {
-                        if (nn >= SPAN_MAXC + 8) return false;
-                        nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), fl) : curr.c[q];
-                    }
-                }
-            }
-            if (!found) return false;
-        } else if (dist > 0 && dist <= p.max_report_intron && prev.anti == curr.anti) {
-            // ---- junction / deletion closure :1311-1591
-            if (g_len(g, ref) == 0) return false;
-            int64_t lb = upper_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true));
-            int64_t ub = lower_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false));
-            const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
-            int best_diff = 0xff;
-            for (; lb < ub; ++lb) {
-                const u64 k = S.junc_keys[lb];
-                const int jl = (int)((int64_t)(k >> 30) - 1 - (int64_t)cbase);
-                const int jr = jl + (int)((k >> 1) & ((1ull << 29) - 1));
-                const int janti = (int)(k & 1ull);
-                const int dtl = jl - prev_right + 1, dtr = jr - curr.left;
-                if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
-                if (dtl > curr_front_len || -dtl > prev_end_len) continue;
-                int new_mm = 0, old_mm = 0;
-                if (dtl > 0) {
-                    Planes nr = g_fetch(g, ref, prev_right);      // new_cmp = ref[prev_right, jl+1)
-                    Planes orf = g_fetch(g, ref, curr.left);      // old_cmp = ref[curr.left, jr)
-                    for (int i = 0; i < dtl; ++i) {
-                        int s = seq_code(sv, P + i);               // curr.seq[i]; raw char vs Dna5: N == N
-                        if (s != plane_code(nr, i)) ++new_mm;
-                        if (s != plane_code(orf, i)) ++old_mm;
-                    }
-                } else if (dtl < 0) {
-                    int ad = -dtl;
-                    Planes nr = g_fetch(g, ref, jr);               // new_cmp = ref[jr, curr.left)
-                    Planes orf = g_fetch(g, ref, (int64_t)jl + 1); // old_cmp = ref[jl+1, prev_right)
-                    for (int i = 0; i < ad; ++i) {
-                        int s = seq_code(sv, P - ad + i);
-                        if (s != plane_code(nr, i)) ++new_mm;
-                        if (s != plane_code(orf, i)) ++old_mm;
-                    }
-                }
-                int diff = new_mm - old_mm;
-                if (diff >= best_diff || new_mm >= 2) continue;
-                best_diff = diff;
-                new_left = prev.left;
-                nn = prev.n;
-                for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
-                int nlb = (int)cig_len(nc[nn - 1]) + dtl;
-                int nrf = (int)cig_len(curr.c[0]) - dtr;
-                if (nlb > 0) nc[nn - 1] = cig(cig_op(nc[nn - 1]), (uint32_t)nlb); else --nn;
-                uint32_t skip = (uint32_t)(jr - jl - 1);
-                if (skip <= (uint32_t)p.max_deletion_length) {
-                    nc[nn++] = cig(OP_DEL, skip);
-                    anti_closure = psp ? prev.asplice : curr.asplice;
-                } else {
-                    nc[nn++] = cig(OP_REF_SKIP, skip);
-                    anti_closure = janti;
-                }
-                for (int q = nrf > 0 ? 0 : 1; q < curr.n; ++q) {
-                    if (nn >= SPAN_MAXC + 8) return false;
-                    nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), (uint32_t)nrf) : curr.c[q];
-                }
-                mismatch = best_diff;
-                found = true;
-            }
-            if (!found) return false;
-        } else if (!(dist == 0 && prev.anti == curr.anti))
-            return false;                                   // check_fusion, empty fusion set
-
-        if (found) {                                        // :1822-1870
-            if (nn > SPAN_MAXC) return false;               // capacity (documented limit)
-            Aln m;
-            int mismatches = (int)prev.mm + (int)curr.mm + mismatch;
-            m.ref_id = prev.ref_id; m.left = new_left; m.n = nn;
-            for (int q = 0; q < nn; ++q) m.c[q] = nc[q];
-            m.anti = (uint8_t)antisense; m.asplice = (uint8_t)anti_closure;
-            m.mm = (uint8_t)mismatches;
-            m.ed = (uint8_t)(mismatches + cig_gap_len(nc, nn));
-            m.rlen = prev.rlen + curr.rlen; m.valid = 1;
-            P += curr.rlen;
+        antisense = chain[pi].anti;
+        Aln m;
+        int r = close_pair(g, p, S, sv, P, chain[pi], chain[ci], m);
+        if (r == PAIR_FAIL) return false;
+        P += chain[ci].rlen;
+        if (r == PAIR_MERGED) {
             chain[pi] = m;
             for (int q = ci; q + 1 < n; ++q) chain[q] = chain[q + 1];
             --n;
             ci = pi + 1;
-            continue;
-        }
-        P += curr.rlen;
-        ++pi; ++ci;
+        } else { ++pi; ++ci; }
     }
-    // :1888-1944
-    bool saw_as = false, saw_s = false;
-    int num_mm = 0;
-    out.n = 0;
-    for (int s = 0; s < n; ++s) {
-        num_mm += chain[s].mm;
-        if (aln_spliced(chain[s])) {
-            if (chain[s].asplice) { if (saw_s) return false; saw_as = true; }
-            else { if (saw_as) return false; saw_s = true; }
-        }
-        int b0 = 0;
-        if (out.n > 0 && cig_op(out.c[out.n - 1]) == cig_op(chain[s].c[0])) {
-            out.c[out.n - 1] = cig(cig_op(out.c[out.n - 1]), cig_len(out.c[out.n - 1]) + cig_len(chain[s].c[0]));
-            b0 = 1;
-        }
-        for (int b = b0; b < chain[s].n; ++b) { if (out.n >= SPAN_MAXC) return false; out.c[out.n++] = chain[s].c[b]; }
-    }
-    out.ref_id = chain[0].ref_id; out.left = left;
-    out.anti = (uint8_t)antisense; out.asplice = saw_as ? 1 : 0;
-    out.mm = (uint8_t)num_mm; out.ed = (uint8_t)(num_mm + cig_gap_len(out.c, out.n));
-    out.rlen = sv.len; out.valid = 1;
+    ChainOut co;
+    chain_out_init(co);
+    for (int s = 0; s < n; ++s) if (!chain_out_add(co, chain[s])) return false;
+    chain_out_finish(co, chain[0].ref_id, left, antisense, sv.len);
+    out = co.out;
     if (aln_read_len(out) != old_read_length || !check_editdist(g, out, sv)) return false;   // :2014-2033
     return true;
 }
@@ -440,7 +461,8 @@ THJ_HD int put_int(char* dst, int cap, int pos, int v) {
 // joined hit's qual is the reversed read qual (merge_chain :1966-1978).  Returns false when the
 // MD string does not fit.
 THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqView& sv, const uint8_t* qual, int qlen,
-                      bool qual_rev, OutAln& o) {
+                      bool qual_rev, OutAln& o, int* n_both_n = nullptr) {
+    int both_n_total = 0;
     static const char B[5] = {'A', 'C', 'G', 'T', 'N'};
     int pos_seq = 0, pos_mm = 0, mismatch = 0, opens = 0, conts = 0, AS = 0, ml = 0;
     int64_t pos_ref = h.left;
@@ -458,6 +480,7 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqV
                 u64 mm = dna5_mism(r, s, l);
                 u64 bothn = r.nm & s.nm & lowmask(l);
                 AS -= p.bowtie2_penalty_for_N * popc(bothn);        // matching N: still penalised (:2552-2556)
+                both_n_total += popc(bothn);
                 int last = 0;
                 while (mm) {
                     int b = ctz(mm);
@@ -501,10 +524,11 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqV
     o.md_len = (uint8_t)ml;
     for (int k = ml; k < cap; ++k) o.md[k] = 0;
     o.AS = (int16_t)AS; o.XM = (uint8_t)mismatch; o.XO = (uint8_t)opens; o.XG = (uint8_t)conts;
+    if (n_both_n) *n_both_n = both_n_total;
     return true;
 }
 
-enum { SPAN_OK = 0, SPAN_TOO_MANY_JOINED = 1, SPAN_MD_OVERFLOW = 2 };
+enum { SPAN_OK = 0, SPAN_TOO_MANY_JOINED = 1, SPAN_MD_OVERFLOW = 2, SPAN_NEED_GENERIC = 3 };
 
 // One read: JoinSegmentsWorker body (long_spanning_reads.cpp:2767-2831).  Emits through
 // sink.emit(const OutAln&) in output order; returns a SPAN_* status.
@@ -601,6 +625,97 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
         sink.emit(o);
     }
     return status;
+}
+
+
+// ---- lean tier: reads whose segments all have exactly one hit (the overwhelmingly common case) ----------
+// Same results as span_read for those reads with a fraction of the private state: the DFS is a single
+// chain, merge_chain runs as a stream (accumulated output + previous element + current hit), nothing to
+// sort/unique, and the edit-distance consistency check (bwt_map.cpp:2349-2465) shares its plane pass with
+// bowtie_sam_extra (:2467-2648).  Any other read returns SPAN_NEED_GENERIC and goes to span_read.
+template <class Sink>
+THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, const uint32_t* so, int nseg,
+                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+    if (so[1] == so[0]) return SPAN_OK;
+    int nsegs = 0;
+    while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
+    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
+    if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;
+    for (int s = 0; s < nsegs; ++s) if (so[s + 1] - so[s] != 1u) return SPAN_NEED_GENERIC;
+    const int L = p.segment_length;
+    const SpanHit h0 = hits[so[0]];
+    const bool anti = (h0.meta & SH_ANTI) != 0;
+    Aln res;
+    bool have = false;
+    if (nsegs == 1) {
+        res = aln_from_hit(h0, 0, L, rl);
+        have = true;
+    } else {
+        // dfs_seg_hits compatibility of the single candidate per segment (:2352-2378, :2531-2556)
+        int old_read_length = 0, num_fusions = 0;
+        {
+            Aln prev = aln_from_hit(h0, 0, L, rl);
+            old_read_length = aln_read_len(prev);
+            for (int s = 1; s < nsegs; ++s) {
+                Aln cand = aln_from_hit(hits[so[s]], s, L, rl);
+                if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return SPAN_OK;
+                int dist = prev.anti ? prev.left - aln_right(cand) : cand.left - aln_right(prev);
+                if (dist > p.max_report_intron || dist < -p.max_insertion_length) return SPAN_OK;
+                if (gap_is_fusion_like(p, dist)) ++num_fusions;          // merge_chain pre-check (:843-891): same gaps, chain order
+                old_read_length += aln_read_len(cand);
+                prev = cand;
+            }
+        }
+        if (num_fusions >= 2) return SPAN_OK;
+        SeqView sv = anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
+        ChainOut co;
+        chain_out_init(co);
+        int k0 = anti ? nsegs - 1 : 0, step = anti ? -1 : 1;
+        Aln prev = aln_from_hit(hits[so[k0]], k0, L, rl);
+        const int left0 = prev.left;
+        int P = prev.rlen;
+        bool ok = true;
+        for (int q = 1; q < nsegs && ok; ++q) {
+            int k = k0 + q * step;
+            Aln curr = aln_from_hit(hits[so[k]], k, L, rl);
+            Aln m;
+            int r = close_pair(g, p, S, sv, P, prev, curr, m);
+            if (r == PAIR_FAIL) { ok = false; break; }
+            P += curr.rlen;
+            if (r == PAIR_MERGED) prev = m;
+            else { if (!chain_out_add(co, prev)) { ok = false; break; } prev = curr; }
+        }
+        if (!ok || !chain_out_add(co, prev)) return SPAN_OK;
+        chain_out_finish(co, h0.ref_id, left0, anti ? 1 : 0, rl);
+        if (aln_read_len(co.out) != old_read_length) return SPAN_OK;
+        res = co.out;
+        have = true;
+    }
+    if (!have || !valid_hit(p, res)) return SPAN_OK;
+    int gapl = (uint8_t)(res.ed - res.mm);
+    if ((int)res.mm > p.read_mismatches || gapl > p.read_gap_length || (int)res.ed > p.read_edit_dist) return SPAN_OK;
+    OutAln o;
+    o.read_idx = read_idx; o.ref_id = res.ref_id; o.left = res.left;
+    o.flags = (uint8_t)((res.anti ? 1 : 0) | (res.asplice ? 4 : 0));
+    o.mismatches = res.mm; o.edit_dist = res.ed; o.n_cigar = (uint8_t)res.n;
+    for (int q = 0; q < SPAN_MAXC; ++q) o.cigar[q] = q < res.n ? res.c[q] : 0;
+    o.order = 0;
+    SeqView sv = res.anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
+    bool qrev;
+    if (nsegs == 1) qrev = res.anti;
+    else {
+        bool same = true;
+        if (res.anti) for (int q = 0; q < 3 * W; ++q) if (sv.w[q] != rp[q]) same = false;
+        qrev = !same;
+    }
+    int both_n = 0;
+    if (!sam_extra(g, p, res, sv, qual, rl, qrev, o, &both_n)) return SPAN_MD_OVERFLOW;
+    if (nsegs > 1 && !((int)o.XM == (int)res.mm || (int)o.XM + both_n == (int)res.mm)) {
+        // check_editdist_consistency failed.  XM is a uint8 copy of the count; recount exactly when it may have wrapped
+        if (!check_editdist(g, res, sv)) return SPAN_OK;
+    }
+    sink.emit(o);
+    return SPAN_OK;
 }
 
 }  // namespace thj
