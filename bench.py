@@ -130,9 +130,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # THJ_FORCE_COLLECTIVE=1 exercises the RCCL exchange step even at world size 1 (single-GPU boxes)
+    use_dist = world > 1 or os.environ.get("THJ_FORCE_COLLECTIVE") == "1"
+    if use_dist:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -208,7 +212,7 @@ def main():
         ctx.run(p_left, cb_left)
         ctx.run(p_right, cb_right)
         cnt = ctx.finish()
-        if world > 1:
+        if use_dist:
             cnt2 = allgather_merge()
             cnt.n_juncs, cnt.n_deletions, cnt.n_insertions = cnt2.n_juncs, cnt2.n_deletions, cnt2.n_insertions
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
@@ -220,7 +224,7 @@ def main():
         return cnt, n_alns
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -237,7 +241,7 @@ def main():
     elapsed = time.time() - t0
     kern_ms, launches = ctx.profile(False)
     span_ms, span_launches = ctx.profile_span(False)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -300,7 +304,7 @@ def main():
                                    "resident in HBM; both stages on device: segment_juncs (rescue/gap/indel/window kernels, "
                                    "event dedup+sort%s) then long_spanning_reads (stitch kernel fed device-to-device with the "
                                    "junction set, record ordering)" % (args.pairs, args.genome_len,
-                                                                      ", RCCL all-gather of event keys" if world > 1 else ""),
+                                                                      ", RCCL all-gather of event keys" if use_dist else ""),
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -316,7 +320,7 @@ def main():
         }
         print(json.dumps(result))
     ctx.close()
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 
