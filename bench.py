@@ -264,8 +264,11 @@ def main():
     kernels = [
         {"kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms, "launches": launches, "algorithmic_bytes_per_launch": seg_alg,
          "achieved": seg_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0},
-        {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms, "launches": span_launches, "algorithmic_bytes_per_launch": span_alg,
-         "achieved": span_alg / (span_ms * 1e-3) / 1e9 if span_ms > 0 else 0.0},
+        # stage 2 runs as three kernels per batch (contiguous reads / closure reads / multihit reads); their
+        # algorithmic bytes are those of the batch, split by the share of reads each tier finishes
+        {"kernel": "thj_k_stitch_contig+thj_k_stitch+thj_k_stitch_multihit", "avg_kernel_ms": sum(span_ms), "launches": span_launches,
+         "algorithmic_bytes_per_launch": span_alg, "achieved": span_alg / (sum(span_ms) * 1e-3) / 1e9 if sum(span_ms) > 0 else 0.0,
+         "per_kernel_ms": {"thj_k_stitch_contig": span_ms[0], "thj_k_stitch": span_ms[1], "thj_k_stitch_multihit": span_ms[2]}},
     ]
     dom = max(kernels, key=lambda k: k["avg_kernel_ms"])
 

@@ -115,7 +115,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                                 const thj_junction* juncs, int64_t n_juncs,
                                 const uint32_t* ins /* 4 u32 each: ref,left,len,seq3 */, int64_t n_ins,
                                 int32_t mode /* 0 = lean tier + generic fallback (as the kernels), 1 = generic only */,
-                                void** out, int64_t* n_out, int64_t* status_counts /* [4] */) {
+                                void** out, int64_t* n_out, int64_t* status_counts /* [5] */) {
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Params p;
     memcpy(&p, tp, sizeof p);
@@ -128,12 +128,18 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
     SpanSets S{jk.data(), n_juncs, ik.data(), iseq.data(), n_ins};
     std::vector<OutAln> res;
     VecSink sink{&res};
-    status_counts[0] = status_counts[1] = status_counts[2] = status_counts[3] = 0;
+    status_counts[0] = status_counts[1] = status_counts[2] = status_counts[3] = status_counts[4] = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
         int st = SPAN_NEED_GENERIC;
-        if (mode == 0)
-            st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
-                                read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+        if (mode == 0) {
+            st = span_read_contig(g, p, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                  read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+            if (st == SPAN_NEED_LEAN) {
+                status_counts[4]++;
+                st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                    read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+            }
+        }
         if (st == SPAN_NEED_GENERIC) {
             status_counts[3]++;
             st = span_read(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,

@@ -78,7 +78,7 @@ def spanning(p: Params, seqs, b, juncs, insertions, mode: int = 0):
     t = host._ins_table(insertions)
     out = C.c_void_p()
     n_out = C.c_int64()
-    st = (C.c_int64 * 4)()
+    st = (C.c_int64 * 5)()
     rc = l.hostsim_spanning(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
                             C.c_void_p(clen.ctypes.data), g.n_contigs, d["n_reads"], d["nseg"], d["W"],
                             C.c_void_p(d["seg_off"].ctypes.data), C.c_void_p(d["hits"].ctypes.data),

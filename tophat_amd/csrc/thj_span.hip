@@ -42,24 +42,38 @@ struct PoolSink {
     }
 };
 
-// Tier 1: every read; reads whose segments each have exactly one hit are finished here with a small private
-// state (streamed merge_chain); the rest are appended to a worklist.
-__global__ __launch_bounds__(256) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
-                                                    uint32_t* worklist, unsigned int* n_work) {
+// Tier 0: every read.  Reads made of abutting single plain-match hits (unspliced reads cut into segments) are
+// finished here with a handful of registers; the others go to one of two worklists.
+__global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, PoolSink sink,
+                                                           uint32_t* wl_lean, uint32_t* wl_multi, unsigned int* counters) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < b.n_reads; r += gridDim.x * blockDim.x) {
-        int st = span_read_lean(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
-                                (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
-        if (st == SPAN_NEED_GENERIC) worklist[atomicAdd(n_work, 1u)] = (uint32_t)r;
+        int st = span_read_contig(g, p, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                                  (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        if (st == SPAN_NEED_LEAN) wl_lean[atomicAdd(&counters[0], 1u)] = (uint32_t)r;
+        else if (st == SPAN_NEED_GENERIC) wl_multi[atomicAdd(&counters[1], 1u)] = (uint32_t)r;
         else if (st) atomicAdd(&sink.status[st], 1u);
     }
 }
 
-// Tier 2: the general per-read DFS (multihit segments) over the worklist.
-__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
-                                                             const uint32_t* worklist, const unsigned int* n_work) {
-    const unsigned int n = *n_work;
+// Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain.
+__global__ __launch_bounds__(256) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
+                                                    const uint32_t* wl_lean, uint32_t* wl_multi, unsigned int* counters) {
+    const unsigned int n = counters[0];
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int r = (int)worklist[i];
+        const int r = (int)wl_lean[i];
+        int st = span_read_lean(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                                (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        if (st == SPAN_NEED_GENERIC) wl_multi[atomicAdd(&counters[1], 1u)] = (uint32_t)r;
+        else if (st) atomicAdd(&sink.status[st], 1u);
+    }
+}
+
+// Tier 2: the general per-read DFS (multihit segments) over its worklist.
+__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
+                                                             const uint32_t* wl_multi, const unsigned int* counters) {
+    const unsigned int n = counters[1];
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int r = (int)wl_multi[i];
         int st = span_read(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                            (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
         if (st) atomicAdd(&sink.status[st], 1u);
@@ -313,20 +327,31 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     PoolSink sink{(OutAln*)c->d_aln_pool, c->d_aln_count, (unsigned long long)c->aln_cap, c->d_span_status};
     if (c->worklist_cap < b.n_reads) {
         hipFree(c->d_worklist); c->d_worklist = nullptr;
-        HIPCHK(hipMalloc(&c->d_worklist, (size_t)b.n_reads * 4));
+        HIPCHK(hipMalloc(&c->d_worklist, (size_t)b.n_reads * 8));          // two lists
         c->worklist_cap = b.n_reads;
     }
-    HIPCHK(hipMemsetAsync(&c->d_span_status[4], 0, 4, c->stream));       // worklist counter
+    uint32_t* wl_lean = c->d_worklist;
+    uint32_t* wl_multi = c->d_worklist + b.n_reads;
+    unsigned int* counters = &c->d_span_status[4];
+    HIPCHK(hipMemsetAsync(counters, 0, 8, c->stream));
     int64_t blocks = ((int64_t)b.n_reads + 255) / 256;
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->span_profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
-    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, S, b, sink, c->d_worklist, &c->d_span_status[4]);
-    if (c->span_profile) { HIPCHK(hipEventRecord(e1, c->stream)); c->span_prof_events.emplace_back(e0, e1); }
     int64_t b2 = ((int64_t)b.n_reads + 127) / 128;
     if (b2 > 2048) b2 = 2048;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
+    hipLaunchKernelGGL(thj_k_stitch_contig, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b, sink, wl_lean, wl_multi, counters);
+    if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
+    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, S, b, sink, (const uint32_t*)wl_lean, wl_multi, counters);
+    if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
     hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)b2), dim3(128), 0, c->stream, g, p, S, b, sink,
-                       (const uint32_t*)c->d_worklist, (const unsigned int*)&c->d_span_status[4]);
+                       (const uint32_t*)wl_multi, (const unsigned int*)counters);
+    if (c->span_profile) {
+        HIPCHK(hipEventRecord(ev[3], c->stream));
+        c->span_prof_events.emplace_back(ev[0], ev[1]);
+        c->span_prof_events.emplace_back(ev[1], ev[2]);
+        c->span_prof_events.emplace_back(ev[2], ev[3]);
+    }
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
@@ -372,19 +397,24 @@ extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
 }
 
 extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
+    // avg_ms[3]: thj_k_stitch_contig, thj_k_stitch, thj_k_stitch_multihit (one triple per thj_span_run_async)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    double sum = 0;
-    for (auto& pr : c->span_prof_events) {
+    double sum[3] = {0, 0, 0};
+    size_t n = c->span_prof_events.size() / 3;
+    for (size_t i = 0; i < c->span_prof_events.size(); ++i) {
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
-        sum += ms;
-        c->event_pool.push_back(pr.first);
-        c->event_pool.push_back(pr.second);
+        HIPCHK(hipEventElapsedTime(&ms, c->span_prof_events[i].first, c->span_prof_events[i].second));
+        sum[i % 3] += ms;
     }
-    if (launches) *launches = (int64_t)c->span_prof_events.size();
-    if (avg_ms) *avg_ms = c->span_prof_events.empty() ? 0.0 : sum / (double)c->span_prof_events.size();
+    // events are shared between consecutive pairs: return each distinct one to the pool once
+    for (size_t i = 0; i < c->span_prof_events.size(); ++i) {
+        if (i % 3 == 0) c->event_pool.push_back(c->span_prof_events[i].first);
+        c->event_pool.push_back(c->span_prof_events[i].second);
+    }
+    if (launches) *launches = (int64_t)n;
+    if (avg_ms) for (int k = 0; k < 3; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
     c->span_prof_events.clear();
     c->span_profile = enable != 0;
     return THJ_OK;

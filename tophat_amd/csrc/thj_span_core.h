@@ -718,4 +718,64 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     return SPAN_OK;
 }
 
+
+// ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
+// (an unspliced read cut into segments: ~60 % of real data).  merge_chain leaves every pair untouched
+// (dist == 0, :1591), the final concatenation (:1888-1944) fuses the MATCH ops into one, so the joined hit is
+// {leftmost left, [len M], sum of mismatches}.  Returns SPAN_NEED_LEAN when the read is not of that shape.
+enum { SPAN_NEED_LEAN = 4 };
+template <class Sink>
+THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
+                            const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+    if (so[1] == so[0]) return SPAN_OK;
+    int nsegs = 0;
+    while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
+    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
+    if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;
+    for (int s = 0; s < nsegs; ++s) if (so[s + 1] - so[s] != 1u) return SPAN_NEED_GENERIC;
+    const SpanHit h0 = hits[so[0]];
+    const bool anti = (h0.meta & SH_ANTI) != 0;
+    if ((h0.meta >> 24) != 1u || cig_op(h0.cigar[0]) != OP_MATCH) return SPAN_NEED_LEAN;
+    int total = (int)cig_len(h0.cigar[0]);
+    int mm = (int)((h0.meta >> 8) & 0xFF);
+    int left = h0.left, edge = anti ? h0.left : h0.left + total;       // where the next segment must abut
+    for (int s = 1; s < nsegs; ++s) {
+        const SpanHit h = hits[so[s]];
+        if ((h.meta >> 24) != 1u || cig_op(h.cigar[0]) != OP_MATCH) return SPAN_NEED_LEAN;
+        if (h.ref_id != h0.ref_id || ((h.meta & SH_ANTI) != 0) != anti) return SPAN_NEED_LEAN;   // lean path decides (no alignment)
+        int len = (int)cig_len(h.cigar[0]);
+        if (anti) { if (h.left + len != edge) return SPAN_NEED_LEAN; edge = h.left; left = h.left; }
+        else { if (h.left != edge) return SPAN_NEED_LEAN; edge = h.left + len; }
+        total += len;
+        mm += (int)((h.meta >> 8) & 0xFF);
+    }
+    Aln res;
+    res.ref_id = h0.ref_id; res.left = left; res.n = 1; res.c[0] = cig(OP_MATCH, (uint32_t)total);
+    res.anti = anti ? 1 : 0; res.asplice = 0; res.mm = (uint8_t)mm; res.ed = (uint8_t)mm; res.rlen = rl; res.valid = 1;
+    // per-hit segment sequence lengths add up to the read length exactly when the last segment is the END one
+    if ((int)res.mm > p.read_mismatches || 0 > p.read_gap_length || (int)res.ed > p.read_edit_dist) return SPAN_OK;
+    OutAln o;
+    o.read_idx = read_idx; o.ref_id = res.ref_id; o.left = res.left;
+    o.flags = (uint8_t)(anti ? 1 : 0);
+    o.mismatches = res.mm; o.edit_dist = res.ed; o.n_cigar = 1;
+    o.cigar[0] = res.c[0];
+    for (int q = 1; q < SPAN_MAXC; ++q) o.cigar[q] = 0;
+    o.order = 0;
+    SeqView sv = anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
+    bool qrev;
+    if (nsegs == 1) qrev = anti;
+    else {
+        bool same = true;
+        if (anti) for (int q = 0; q < 3 * W; ++q) if (sv.w[q] != rp[q]) same = false;
+        qrev = !same;
+    }
+    int both_n = 0;
+    if (!sam_extra(g, p, res, sv, qual, rl, qrev, o, &both_n)) return SPAN_MD_OVERFLOW;
+    if (nsegs > 1 && !((int)o.XM == (int)res.mm || (int)o.XM + both_n == (int)res.mm)) {
+        if (!check_editdist(g, res, sv)) return SPAN_OK;
+    }
+    sink.emit(o);
+    return SPAN_OK;
+}
+
 }  // namespace thj

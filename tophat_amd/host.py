@@ -382,10 +382,11 @@ def _span_methods():
         return alns_from_array(self.span_download(self.span_finish()))
 
     def profile_span(self, enable: bool = True):
-        ms = C.c_double()
+        """-> ([ms contig, ms lean, ms multihit], launches)"""
+        ms = (C.c_double * 3)()
         n = C.c_int64()
-        _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, C.byref(ms), C.byref(n)), "thj_profile_span")
-        return ms.value, n.value
+        _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, ms, C.byref(n)), "thj_profile_span")
+        return [ms[0], ms[1], ms[2]], n.value
 
     for f in (upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
               span_download, spanning, profile_span):
