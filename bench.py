@@ -256,20 +256,27 @@ def main():
     seg_alg = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1) \
         + (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
-    # thj_k_stitch: 32 B per hit record + CSR + the read once + per output record two 64-B genome lines (consistency
-    # check + MD pass share them), one 64-B line of junction keys per closure and the 128-B record itself
-    span_hits = float(int(w["left"]["span_off"][-1]) + int(w["right"]["span_off"][-1])) / n_launch
-    span_alg = 32.0 * span_hits + 4.0 * (args.pairs * nseg + 1) + args.pairs * rl_bytes \
-        + (n_alns / n_launch) * (128 + 64 + 128)
+    # stage 2, three kernels per launch.  Per finished read: 38 B of read planes, two 64-B genome lines (consistency
+    # check + MD pass share them) and its 128-B record; tier 0 streams every read's CSR row and 32-B hit records;
+    # tiers 1/2 re-read CSR + hits of their worklist reads (4-B list entry each) and one 64-B line of junction keys
+    # per closure.  Counters come from the kernels (tier sizes of the last launch, record count of the step).
+    n_lean, n_multi = ctx.span_tier_counts()
+    hits_per_read = float(int(w["left"]["span_off"][-1]) + int(w["right"]["span_off"][-1])) / (2.0 * args.pairs)
+    rec_per_read = n_alns / (2.0 * args.pairs)
+    per_read_done = rl_bytes + rec_per_read * (128 + 128)
+    n_t0 = args.pairs - n_lean - n_multi
+    t0_alg = 4.0 * (args.pairs * nseg + 1) + 32.0 * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
+    t1_alg = n_lean * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
+    t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     kernels = [
-        {"kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms, "launches": launches, "algorithmic_bytes_per_launch": seg_alg,
-         "achieved": seg_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0},
-        # stage 2 runs as three kernels per batch (contiguous reads / closure reads / multihit reads); their
-        # algorithmic bytes are those of the batch, split by the share of reads each tier finishes
-        {"kernel": "thj_k_stitch_contig+thj_k_stitch+thj_k_stitch_multihit", "avg_kernel_ms": sum(span_ms), "launches": span_launches,
-         "algorithmic_bytes_per_launch": span_alg, "achieved": span_alg / (sum(span_ms) * 1e-3) / 1e9 if sum(span_ms) > 0 else 0.0,
-         "per_kernel_ms": {"thj_k_stitch_contig": span_ms[0], "thj_k_stitch": span_ms[1], "thj_k_stitch_multihit": span_ms[2]}},
+        {"kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms, "launches": launches, "algorithmic_bytes_per_launch": seg_alg},
+        {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
+        {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
+        {"kernel": "thj_k_stitch_multihit", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
     ]
+    for k in kernels:
+        k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0
+        k["frac"] = k["achieved"] / HBM_PEAK_GBS
     dom = max(kernels, key=lambda k: k["avg_kernel_ms"])
 
     result = None

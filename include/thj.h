@@ -279,6 +279,9 @@ int thj_span_run_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* 
  * read) and synchronises.  THJ_EOVERFLOW when a device limit was hit (message says which). */
 int thj_span_finish(thj_ctx* ctx, int64_t* n_alns);
 int thj_span_download(thj_ctx* ctx, thj_aln* out);
+/* counts[0] = reads the last thj_span_run_async sent to the closure kernel thj_k_stitch, counts[1] = to the multihit kernel
+  * thj_k_stitch_multihit; the rest were finished by thj_k_stitch_contig. */
+int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[2]*/);
 /* Average durations (ms) of the three stitch kernels since the last call -- avg_ms[0] thj_k_stitch_contig,
  * [1] thj_k_stitch, [2] thj_k_stitch_multihit -- from HIP events on the context stream. */
 int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[3]*/, int64_t* launches);

@@ -396,6 +396,19 @@ extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
     return THJ_OK;
 }
 
+extern "C" int thj_span_tier_counts(thj_ctx* c, int64_t* counts) {
+    // reads the last thj_span_run_async handed to tier 1 (closure reads) and tier 2 (multihit reads)
+    if (!c || !counts) { thj_set_error("thj_span_tier_counts: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_span_state(c);
+    if (rc) return rc;
+    unsigned int h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, &c->d_span_status[4], 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    counts[0] = h[0]; counts[1] = h[1];
+    return THJ_OK;
+}
+
 extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
     // avg_ms[3]: thj_k_stitch_contig, thj_k_stitch, thj_k_stitch_multihit (one triple per thj_span_run_async)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }

@@ -381,6 +381,11 @@ def _span_methods():
             self.span_run(p, b)
         return alns_from_array(self.span_download(self.span_finish()))
 
+    def span_tier_counts(self):
+        c = (C.c_int64 * 2)()
+        _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
+        return int(c[0]), int(c[1])
+
     def profile_span(self, enable: bool = True):
         """-> ([ms contig, ms lean, ms multihit], launches)"""
         ms = (C.c_double * 3)()
@@ -389,11 +394,12 @@ def _span_methods():
         return [ms[0], ms[1], ms[2]], n.value
 
     for f in (upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
-              span_download, spanning, profile_span):
+              span_download, spanning, profile_span, span_tier_counts):
         setattr(Context, f.__name__, f)
 
 
 _span_methods()
 
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
-                "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span"]
+                "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
+                "thj_span_tier_counts"]
