@@ -106,6 +106,7 @@ extern "C" void hostsim_free(void* p) { free(p); }
 struct VecSink {
     std::vector<OutAln>* v;
     void emit(const OutAln& o) { v->push_back(o); }
+    void emit_words(const uint32_t* w) { OutAln o; memcpy(&o, w, sizeof o); v->push_back(o); }
 };
 
 extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,

@@ -17,9 +17,9 @@ def main():
             continue
         print("%-78s %8d %14d %14.1f %7.2f" % (name[:78], calls, tot, avg, pct))
     try:
-        pm = cur.execute("select k.name, p.counter_name, count(*), sum(p.value) from pmc_events p join kernels k "
-                         "on p.dispatch_id = k.dispatch_id group by k.name, p.counter_name").fetchall()
-    except sqlite3.Error as e:   # no PMC tables in this capture
+        pm = cur.execute("select name, counter_name, count(*), sum(counter_value) from pmc_events "
+                         "group by name, counter_name").fetchall()
+    except sqlite3.Error:   # no PMC rows in this capture
         pm = []
     if pm:
         print()

@@ -40,6 +40,15 @@ struct PoolSink {
         unsigned long long pos = atomicAdd(count, 1ull);
         if (pos < cap) pool[pos] = o; else atomicExch(&status[3], 1u);
     }
+    // a record assembled in registers as 32 words: eight 16-byte stores
+    __device__ __forceinline__ void emit_words(const uint32_t* w) {
+        unsigned long long pos = atomicAdd(count, 1ull);
+        if (pos < cap) {
+            uint4* dst = (uint4*)(pool + pos);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        } else atomicExch(&status[3], 1u);
+    }
 };
 
 // Tier 0: every read.  Reads made of abutting single plain-match hits (unspliced reads cut into segments) are

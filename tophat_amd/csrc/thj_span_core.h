@@ -437,6 +437,23 @@ THJ_HD bool aln_eq(const Aln& a, const Aln& b) {
     return true;
 }
 
+// MD:Z string built in registers: 40 chars in five 64-bit words (little-endian byte order = memory order)
+struct MdBuf { u64 w[5]; int len; };
+THJ_HD void md_init(MdBuf& m) { m.w[0] = m.w[1] = m.w[2] = m.w[3] = m.w[4] = 0; m.len = 0; }
+THJ_HD void md_push(MdBuf& m, char c) {
+    if (m.len < 40) {
+        const int k = m.len >> 3;
+        const u64 v = (u64)(uint8_t)c << ((m.len & 7) * 8);
+        m.w[0] |= k == 0 ? v : 0; m.w[1] |= k == 1 ? v : 0; m.w[2] |= k == 2 ? v : 0; m.w[3] |= k == 3 ? v : 0; m.w[4] |= k == 4 ? v : 0;
+    }
+    ++m.len;
+}
+THJ_HD void md_put_int(MdBuf& m, int v) {
+    if (v >= 100) md_push(m, (char)('0' + (v / 100) % 10));
+    if (v >= 10) md_push(m, (char)('0' + (v / 10) % 10));
+    md_push(m, (char)('0' + v % 10));                 // runs are < 1000: reads are at most 256 bases
+}
+
 struct OutAln {             // == thj_aln, 128 bytes
     uint32_t read_idx;
     uint32_t ref_id;
@@ -749,32 +766,69 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
         total += len;
         mm += (int)((h.meta >> 8) & 0xFF);
     }
-    Aln res;
-    res.ref_id = h0.ref_id; res.left = left; res.n = 1; res.c[0] = cig(OP_MATCH, (uint32_t)total);
-    res.anti = anti ? 1 : 0; res.asplice = 0; res.mm = (uint8_t)mm; res.ed = (uint8_t)mm; res.rlen = rl; res.valid = 1;
-    // per-hit segment sequence lengths add up to the read length exactly when the last segment is the END one
-    if ((int)res.mm > p.read_mismatches || 0 > p.read_gap_length || (int)res.ed > p.read_edit_dist) return SPAN_OK;
-    OutAln o;
-    o.read_idx = read_idx; o.ref_id = res.ref_id; o.left = res.left;
-    o.flags = (uint8_t)(anti ? 1 : 0);
-    o.mismatches = res.mm; o.edit_dist = res.ed; o.n_cigar = 1;
-    o.cigar[0] = res.c[0];
-    for (int q = 1; q < SPAN_MAXC; ++q) o.cigar[q] = 0;
-    o.order = 0;
-    SeqView sv = anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
-    bool qrev;
+    const int mm8 = mm & 0xFF;                       // BowtieHit keeps mismatches / edit_dist in unsigned chars
+    if (mm8 > p.read_mismatches || mm8 > p.read_edit_dist) return SPAN_OK;          // :2810-2813 (gap length 0)
+    if (g_len(g, h0.ref_id) == 0) return SPAN_OK;    // check_editdist_consistency / bowtie_sam_extra need the contig
+    // The read planes are consumed straight from global memory, 64 bases at a time, reverse-complemented on
+    // the fly for antisense reads: no private arrays, everything below lives in registers.
+    bool qrev = false;
     if (nsegs == 1) qrev = anti;
-    else {
+    else if (anti) {
+        // merge_chain :1966-1978: the joined qual is the reversed read qual unless rc(read) == read
         bool same = true;
-        if (anti) for (int q = 0; q < 3 * W; ++q) if (sv.w[q] != rp[q]) same = false;
+        for (int off = 0; off < rl; off += 64) {
+            int l = rl - off < 64 ? rl - off : 64;
+            Planes f = r_fetch(rp, W, off, l);
+            Planes r = rc_piece(r_fetch(rp, W, rl - off - l, l), l);
+            if (f.lo != r.lo || f.hi != r.hi || f.nm != r.nm) same = false;
+        }
         qrev = !same;
     }
-    int both_n = 0;
-    if (!sam_extra(g, p, res, sv, qual, rl, qrev, o, &both_n)) return SPAN_MD_OVERFLOW;
-    if (nsegs > 1 && !((int)o.XM == (int)res.mm || (int)o.XM + both_n == (int)res.mm)) {
-        if (!check_editdist(g, res, sv)) return SPAN_OK;
+    MdBuf md;
+    md_init(md);
+    int mismatch = 0, both_n = 0, AS = 0, pos_mm = 0;
+    for (int off = 0; off < total; off += 64) {                 // bowtie_sam_extra over the single MATCH op
+        int l = total - off < 64 ? total - off : 64;
+        if (off + l > rl) l = rl - off;
+        if (l <= 0) break;
+        Planes r = g_fetch(g, h0.ref_id, (int64_t)left + off);
+        Planes sq = anti ? rc_piece(r_fetch(rp, W, rl - off - l, l), l) : r_fetch(rp, W, off, l);
+        u64 m = dna5_mism(r, sq, l);
+        u64 bn = r.nm & sq.nm & lowmask(l);
+        both_n += popc(bn);
+        AS -= p.bowtie2_penalty_for_N * popc(bn);
+        int last = 0;
+        while (m) {
+            int b = ctz(m);
+            m &= m - 1;
+            ++mismatch;
+            int sp = off + b;
+            if (((r.nm | sq.nm) >> b) & 1ull) AS -= p.bowtie2_penalty_for_N;
+            else {
+                int q = (int)qual[qrev ? rl - 1 - sp : sp] - 33; if (q > 40) q = 40;
+                AS -= p.bowtie2_min_penalty + ((p.bowtie2_max_penalty - p.bowtie2_min_penalty) * q) / 40;
+            }
+            pos_mm += b - last;
+            md_put_int(md, pos_mm);
+            md_push(md, "ACGTN"[plane_code(r, b)]);
+            pos_mm = 0; last = b + 1;
+        }
+        pos_mm += l - last;
     }
-    sink.emit(o);
+    md_put_int(md, pos_mm);
+    if (md.len > 40) return SPAN_MD_OVERFLOW;
+    if (nsegs > 1 && !(mismatch == mm8 || mismatch + both_n == mm8)) return SPAN_OK;   // check_editdist_consistency
+    uint32_t wds[32];
+    wds[0] = read_idx; wds[1] = h0.ref_id; wds[2] = (uint32_t)left;
+    wds[3] = (anti ? 1u : 0u) | ((uint32_t)mm8 << 8) | ((uint32_t)mm8 << 16) | (1u << 24);
+    wds[4] = ((uint32_t)AS & 0xFFFFu) | ((uint32_t)(mismatch & 0xFF) << 16);                 // AS, XM, XO = 0
+    wds[5] = ((uint32_t)md.len << 8);                                                        // XG = 0, md_len, order = 0
+    wds[6] = cig(OP_MATCH, (uint32_t)total);
+#pragma unroll
+    for (int q = 7; q < 22; ++q) wds[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { wds[22 + 2 * q] = (uint32_t)md.w[q]; wds[23 + 2 * q] = (uint32_t)(md.w[q] >> 32); }
+    sink.emit_words(wds);
     return SPAN_OK;
 }
 
