@@ -87,35 +87,32 @@ THJ_HD int64_t upper_bound_u64(const u64* a, int64_t n, u64 k) {   // first i wi
     return lo;
 }
 
-// The chain's sequence in genome-forward orientation: the read, or its reverse complement.
-struct SeqView {
-    u64 w[3 * 4];            // planes lo[W], hi[W], nm[W] (W <= 4)
-    int W, len;
-};
-THJ_HD SeqView seq_forward(const u64* rp, int W, int rl) {
-    SeqView s; s.W = W; s.len = rl;
-    for (int i = 0; i < 3 * W; ++i) s.w[i] = rp[i];
-    return s;
+// The chain's sequence in genome-forward orientation: the read, or its reverse complement.  A view, not a
+// copy: pieces are fetched from the read's planes in global memory (L1/L2-resident) and complemented on the fly.
+struct SeqView { const u64* rp; int W, len; bool rc; };
+THJ_HD SeqView seq_forward(const u64* rp, int W, int rl) { SeqView s; s.rp = rp; s.W = W; s.len = rl; s.rc = false; return s; }
+THJ_HD SeqView seq_revcomp(const u64* rp, int W, int rl) { SeqView s; s.rp = rp; s.W = W; s.len = rl; s.rc = true; return s; }
+THJ_HD Planes seq_fetch(const SeqView& s, int start, int len) {
+    if (!s.rc) return r_fetch(s.rp, s.W, start, len);
+    return rc_piece(r_fetch(s.rp, s.W, s.len - start - len, len), len);
 }
-THJ_HD SeqView seq_revcomp(const u64* rp, int W, int rl) {
-    SeqView s; s.W = W; s.len = rl;
-    // piecewise: output base i = complement of input base rl-1-i
-    for (int w = 0; w < W; ++w) {
-        int start = w * 64;
-        int len = rl - start; if (len > 64) len = 64;
-        if (len <= 0) { s.w[w] = s.w[W + w] = s.w[2 * W + w] = 0; continue; }
-        Planes p = r_fetch(rp, W, rl - start - len, len);   // input bases [rl-start-len, rl-start)
-        Planes q = rc_piece(p, len);
-        s.w[w] = q.lo; s.w[W + w] = q.hi; s.w[2 * W + w] = q.nm;
-    }
-    return s;
-}
-THJ_HD Planes seq_fetch(const SeqView& s, int start, int len) { return r_fetch(s.w, s.W, start, len); }
 // base code 0..3, 4 = N
 THJ_HD int seq_code(const SeqView& s, int i) {
-    int w = i >> 6, b = i & 63;
-    if ((s.w[2 * s.W + w] >> b) & 1ull) return 4;
-    return (int)(((s.w[w] >> b) & 1ull) | (((s.w[s.W + w] >> b) & 1ull) << 1));
+    int j = s.rc ? s.len - 1 - i : i;
+    int w = j >> 6, b = j & 63;
+    if ((s.rp[2 * s.W + w] >> b) & 1ull) return 4;
+    int c = (int)(((s.rp[w] >> b) & 1ull) | (((s.rp[s.W + w] >> b) & 1ull) << 1));
+    return s.rc ? 3 - c : c;
+}
+// rc(read) == read ?  (merge_chain :1966-1978 compares the joined sequence with the read)
+THJ_HD bool read_is_own_revcomp(const u64* rp, int W, int rl) {
+    for (int off = 0; off < rl; off += 64) {
+        int l = rl - off < 64 ? rl - off : 64;
+        Planes f = r_fetch(rp, W, off, l);
+        Planes r = rc_piece(r_fetch(rp, W, rl - off - l, l), l);
+        if (f.lo != r.lo || f.hi != r.hi || f.nm != r.nm) return false;
+    }
+    return true;
 }
 THJ_HD int plane_code(const Planes& p, int b) {
     if ((p.nm >> b) & 1ull) return 4;
@@ -466,29 +463,21 @@ struct OutAln {             // == thj_aln, 128 bytes
     char md[40];
 };
 
-THJ_HD int put_int(char* dst, int cap, int pos, int v) {
-    char tmp[12]; int n = 0;
-    if (v == 0) tmp[n++] = '0';
-    while (v > 0) { tmp[n++] = (char)('0' + v % 10); v /= 10; }
-    while (n > 0 && pos < cap) dst[pos++] = tmp[--n];
-    return n > 0 ? cap + 1 : pos;        // cap+1 signals overflow
-}
+struct Extras { int AS, XM, XO, XG, both_n; MdBuf md; };
 
-// bowtie_sam_extra (bwt_map.cpp:2467-2648).  qual = this read's phred+33 bytes; qual_rev: the
-// joined hit's qual is the reversed read qual (merge_chain :1966-1978).  Returns false when the
-// MD string does not fit.
+// bowtie_sam_extra (bwt_map.cpp:2467-2648).  qual = this read's phred+33 bytes; qual_rev: the joined hit's
+// qual is the reversed read qual (merge_chain :1966-1978).  Also counts the N==N positions, which is what
+// check_editdist_consistency (:2349-2465) needs beside XM.  Returns false when the MD string does not fit.
 THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqView& sv, const uint8_t* qual, int qlen,
-                      bool qual_rev, OutAln& o, int* n_both_n = nullptr) {
-    int both_n_total = 0;
-    static const char B[5] = {'A', 'C', 'G', 'T', 'N'};
-    int pos_seq = 0, pos_mm = 0, mismatch = 0, opens = 0, conts = 0, AS = 0, ml = 0;
+                      bool qual_rev, Extras& e) {
+    int pos_seq = 0, pos_mm = 0, mismatch = 0, opens = 0, conts = 0, AS = 0, both_n = 0;
     int64_t pos_ref = h.left;
-    const int cap = (int)sizeof(o.md);
-    for (int i = 0; i < h.n && ml <= cap; ++i) {
+    md_init(e.md);
+    for (int i = 0; i < h.n; ++i) {
         int op = cig_op(h.c[i]);
         int len = (int)cig_len(h.c[i]);
         if (op == OP_MATCH) {
-            for (int off = 0; off < len && ml <= cap; off += 64) {
+            for (int off = 0; off < len; off += 64) {
                 int l = len - off < 64 ? len - off : 64;
                 if (pos_seq + off + l > sv.len) l = sv.len - pos_seq - off;
                 if (l <= 0) break;
@@ -497,7 +486,7 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqV
                 u64 mm = dna5_mism(r, s, l);
                 u64 bothn = r.nm & s.nm & lowmask(l);
                 AS -= p.bowtie2_penalty_for_N * popc(bothn);        // matching N: still penalised (:2552-2556)
-                both_n_total += popc(bothn);
+                both_n += popc(bothn);
                 int last = 0;
                 while (mm) {
                     int b = ctz(mm);
@@ -513,9 +502,8 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqV
                         }
                     }
                     pos_mm += b - last;
-                    ml = put_int(o.md, cap, ml, pos_mm);
-                    if (ml < cap) o.md[ml] = B[plane_code(r, b)];
-                    ++ml;
+                    md_put_int(e.md, pos_mm);
+                    md_push(e.md, "ACGTN"[plane_code(r, b)]);
                     pos_mm = 0; last = b + 1;
                 }
                 pos_mm += l - last;
@@ -528,21 +516,31 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqV
         } else if (op == OP_DEL) {
             AS -= p.bowtie2_ref_gap_open + p.bowtie2_ref_gap_cont * len;
             ++opens; conts += len;
-            ml = put_int(o.md, cap, ml, pos_mm);
-            if (ml < cap) o.md[ml] = '^';
-            ++ml;
+            md_put_int(e.md, pos_mm);
+            md_push(e.md, '^');
             Planes r = g_fetch(g, h.ref_id, pos_ref);
-            for (int k = 0; k < len && k < 64; ++k) { if (ml < cap) o.md[ml] = B[plane_code(r, k)]; ++ml; }
+            for (int k = 0; k < len && k < 64; ++k) md_push(e.md, "ACGTN"[plane_code(r, k)]);
             pos_ref += len; pos_mm = 0;
         } else if (op == OP_REF_SKIP) pos_ref += len;
     }
-    if (ml <= cap) ml = put_int(o.md, cap, ml, pos_mm);
-    if (ml > cap) return false;
-    o.md_len = (uint8_t)ml;
-    for (int k = ml; k < cap; ++k) o.md[k] = 0;
-    o.AS = (int16_t)AS; o.XM = (uint8_t)mismatch; o.XO = (uint8_t)opens; o.XG = (uint8_t)conts;
-    if (n_both_n) *n_both_n = both_n_total;
-    return true;
+    md_put_int(e.md, pos_mm);
+    e.AS = AS; e.XM = mismatch; e.XO = opens; e.XG = conts; e.both_n = both_n;
+    return e.md.len <= 40;
+}
+
+// one 128-byte thj_aln record assembled in registers (layout of OutAln) and handed to the sink as 32 words
+template <class Sink>
+THJ_HD void emit_aln(Sink& sink, uint32_t read_idx, int order, const Aln& h, const Extras& e) {
+    uint32_t wds[32];
+    wds[0] = read_idx; wds[1] = h.ref_id; wds[2] = (uint32_t)h.left;
+    wds[3] = (h.anti ? 1u : 0u) | (h.asplice ? 4u : 0u) | ((uint32_t)h.mm << 8) | ((uint32_t)h.ed << 16) | ((uint32_t)h.n << 24);
+    wds[4] = ((uint32_t)e.AS & 0xFFFFu) | ((uint32_t)(e.XM & 0xFF) << 16) | ((uint32_t)(e.XO & 0xFF) << 24);
+    wds[5] = (uint32_t)(e.XG & 0xFF) | ((uint32_t)e.md.len << 8) | ((uint32_t)(order & 0xFFFF) << 16);
+#pragma unroll
+    for (int q = 0; q < SPAN_MAXC; ++q) wds[6 + q] = q < h.n ? h.c[q] : 0u;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { wds[22 + 2 * q] = (uint32_t)e.md.w[q]; wds[23 + 2 * q] = (uint32_t)(e.md.w[q] >> 32); }
+    sink.emit_words(wds);
 }
 
 enum { SPAN_OK = 0, SPAN_TOO_MANY_JOINED = 1, SPAN_MD_OVERFLOW = 2, SPAN_NEED_GENERIC = 3 };
@@ -617,29 +615,20 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
     int w = 0;
     for (int i = 0; i < nj; ++i) if (w == 0 || !aln_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];
     nj = w;
-    uint16_t order = 0;
+    int order = 0;
     for (int i = 0; i < nj; ++i) {
         const Aln& h = joined[i];
         int gapl = (uint8_t)(h.ed - h.mm);
         if ((int)h.mm > p.read_mismatches || gapl > p.read_gap_length || (int)h.ed > p.read_edit_dist) continue;   // :2810-2813
-        OutAln o;
-        o.read_idx = read_idx; o.ref_id = h.ref_id; o.left = h.left;
-        o.flags = (uint8_t)((h.anti ? 1 : 0) | (h.asplice ? 4 : 0));
-        o.mismatches = h.mm; o.edit_dist = h.ed; o.n_cigar = (uint8_t)h.n;
-        for (int q = 0; q < SPAN_MAXC; ++q) o.cigar[q] = q < h.n ? h.c[q] : 0;
-        o.order = order++;
         // merge_chain :1966-1978: qual reversed when the joined sequence differs from the read;
         // a single-segment hit carries the BAM record's own SEQ/QUAL (reversed when antisense)
         bool qrev;
         const SeqView& sv = h.anti ? rev : fwd;
         if (nsegs == 1) qrev = h.anti;
-        else {
-            bool same = true;
-            for (int q = 0; q < 3 * W; ++q) if (sv.w[q] != fwd.w[q]) same = false;
-            qrev = !same;
-        }
-        if (!sam_extra(g, p, h, sv, qual, rl, qrev, o)) { status = SPAN_MD_OVERFLOW; continue; }
-        sink.emit(o);
+        else qrev = h.anti ? !read_is_own_revcomp(rp, W, rl) : false;
+        Extras e;
+        if (!sam_extra(g, p, h, sv, qual, rl, qrev, e)) { status = SPAN_MD_OVERFLOW; continue; }
+        emit_aln(sink, read_idx, order++, h, e);
     }
     return status;
 }
@@ -711,27 +700,15 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     if (!have || !valid_hit(p, res)) return SPAN_OK;
     int gapl = (uint8_t)(res.ed - res.mm);
     if ((int)res.mm > p.read_mismatches || gapl > p.read_gap_length || (int)res.ed > p.read_edit_dist) return SPAN_OK;
-    OutAln o;
-    o.read_idx = read_idx; o.ref_id = res.ref_id; o.left = res.left;
-    o.flags = (uint8_t)((res.anti ? 1 : 0) | (res.asplice ? 4 : 0));
-    o.mismatches = res.mm; o.edit_dist = res.ed; o.n_cigar = (uint8_t)res.n;
-    for (int q = 0; q < SPAN_MAXC; ++q) o.cigar[q] = q < res.n ? res.c[q] : 0;
-    o.order = 0;
     SeqView sv = res.anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
     bool qrev;
     if (nsegs == 1) qrev = res.anti;
-    else {
-        bool same = true;
-        if (res.anti) for (int q = 0; q < 3 * W; ++q) if (sv.w[q] != rp[q]) same = false;
-        qrev = !same;
-    }
-    int both_n = 0;
-    if (!sam_extra(g, p, res, sv, qual, rl, qrev, o, &both_n)) return SPAN_MD_OVERFLOW;
-    if (nsegs > 1 && !((int)o.XM == (int)res.mm || (int)o.XM + both_n == (int)res.mm)) {
-        // check_editdist_consistency failed.  XM is a uint8 copy of the count; recount exactly when it may have wrapped
-        if (!check_editdist(g, res, sv)) return SPAN_OK;
-    }
-    sink.emit(o);
+    else qrev = res.anti ? !read_is_own_revcomp(rp, W, rl) : false;
+    Extras e;
+    if (!sam_extra(g, p, res, sv, qual, rl, qrev, e)) return SPAN_MD_OVERFLOW;
+    // check_editdist_consistency (done inside merge_chain in the reference) shares sam_extra's counts
+    if (nsegs > 1 && !(e.XM == (int)res.mm || e.XM + e.both_n == (int)res.mm)) return SPAN_OK;
+    emit_aln(sink, read_idx, 0, res, e);
     return SPAN_OK;
 }
 
@@ -775,14 +752,7 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
     if (nsegs == 1) qrev = anti;
     else if (anti) {
         // merge_chain :1966-1978: the joined qual is the reversed read qual unless rc(read) == read
-        bool same = true;
-        for (int off = 0; off < rl; off += 64) {
-            int l = rl - off < 64 ? rl - off : 64;
-            Planes f = r_fetch(rp, W, off, l);
-            Planes r = rc_piece(r_fetch(rp, W, rl - off - l, l), l);
-            if (f.lo != r.lo || f.hi != r.hi || f.nm != r.nm) same = false;
-        }
-        qrev = !same;
+        qrev = !read_is_own_revcomp(rp, W, rl);
     }
     MdBuf md;
     md_init(md);
