@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-from tophat_amd.bamio import read_bam  # noqa: E402
+from tophat_amd.bamio import read_bam, write_bam_from_sam  # noqa: E402
 from tophat_amd.synth import make_case, write_case  # noqa: E402
 
 REFBIN = os.environ.get("REFBIN", "/tmp/refbuild/src")
@@ -30,6 +30,8 @@ CASES = {
     "se150_multihit": dict(gen=dict(seed=103, paired=False, read_len=150, seg_len=25, n_reads=120, boundary_bias=0.5,
                                     spliced_seg_frac=0.8, repeat_frac=0.5, contig_lens=(30000,), genes_per_contig=6),
                            opts=["--library-type", "fr-firststrand"]),
+    "se100_juncdb": dict(gen=dict(seed=104, paired=False, read_len=100, seg_len=25, n_reads=160, boundary_bias=0.3,
+                                  spliced_seg_frac=1.0, juncdb=True, contig_lens=(30000,), genes_per_contig=6, indel_frac=0.05), opts=[]),
 }
 
 
@@ -53,7 +55,15 @@ def main():
             lsr = [os.path.join(REFBIN, "long_spanning_reads"), "--segment-length", str(cfg["gen"]["seg_len"]),
                    "--sam-header", paths["hdr"], paths["ref"], paths["%s_fq" % sd], outs[0], outs[1], outs[2], "/dev/null",
                    bam, ",".join(paths["%s_segs" % sd])]
+            if "%s_spliced" % sd in paths:        # junction-db maps must be BAM for the reference (samopen "rb")
+                sp = []
+                for f_ in paths["%s_spliced" % sd]:
+                    write_bam_from_sam(f_, f_[:-4] + ".bam")
+                    sp.append(f_[:-4] + ".bam")
+                lsr.append(",".join(sp))
             subprocess.run(lsr, check=True, capture_output=True)
+            for f_ in paths.get("%s_spliced" % sd, []):
+                os.remove(f_[:-4] + ".bam")
             _, recs = read_bam(bam)
             with open(os.path.join(d, "expected.span_%s.sam" % sd), "w") as f:
                 for r in recs:

@@ -1,9 +1,10 @@
 """Loading the fixtures under tests/golden/ through the host parsing rules (tophat_amd.samtext)."""
 import os
+import re
 
 from tophat_amd.batch import build_seg_batch, build_span_batch
 from tophat_amd.params import LIBRARY_TYPES, Params, READ_LEFT, READ_RIGHT
-from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
+from tophat_amd.samtext import parse_header, parse_sam_hits, parse_spliced_sam_hits, read_fasta, read_fastq
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
@@ -42,13 +43,16 @@ def load(name):
     seqs = [dict(zip(fa_names, fa_seqs)).get(n) for n in names]
     ref_ids = {n: i + 1 for i, n in enumerate(names)}
     paired = kv["paired"] == "1"
-    nseg = len([f for f in os.listdir(d) if f.startswith("left_seg")])
+    nseg = len([f for f in os.listdir(d) if re.fullmatch(r"left_seg\d+\.sam", f)])
     sides = {}
     for sd in (("left", "right") if paired else ("left",)):
         sides[sd] = dict(
             reads=read_fastq(os.path.join(d, "%s.fq" % sd)), quals=read_fastq_quals(os.path.join(d, "%s.fq" % sd)),
             segs=[list(parse_sam_hits(os.path.join(d, "%s_seg%d.sam" % (sd, k + 1)), ref_ids, p.max_report_intron)) for k in range(nseg)],
-            full=list(parse_sam_hits(os.path.join(d, "%s_map.sam" % sd), ref_ids, p.max_report_intron)))
+            full=list(parse_sam_hits(os.path.join(d, "%s_map.sam" % sd), ref_ids, p.max_report_intron)),
+            spliced=[list(parse_spliced_sam_hits(os.path.join(d, "%s_seg%d.to_spliced.sam" % (sd, k + 1)), ref_ids,
+                                                 p.max_report_intron, p.min_anchor_len))
+                     if os.path.exists(os.path.join(d, "%s_seg%d.to_spliced.sam" % (sd, k + 1))) else [] for k in range(nseg)])
     seg_batches, span_batches = [], {}
     for sd, side in (("left", READ_LEFT), ("right", READ_RIGHT)):
         if sd not in sides:
@@ -59,7 +63,7 @@ def load(name):
         else:
             b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"])
         seg_batches.append((side, b))
-        span_batches[sd] = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], sides[sd]["quals"])
+        span_batches[sd] = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], sides[sd]["quals"], sides[sd]["spliced"])
     exp = {k: open(os.path.join(d, "expected.%s" % k)).read() for k in ("juncs", "insertions", "deletions")}
     exp_span = {}
     for sd in sides:

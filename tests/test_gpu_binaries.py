@@ -23,7 +23,7 @@ def _inputs(d, tmp_path, as_bam):
         write_bam_from_sam(p, out)
         return out
     files = sorted(os.listdir(d))
-    nseg = len([f for f in files if f.startswith("left_seg")])
+    nseg = len([f for f in files if re.fullmatch(r"left_seg\d+\.sam", f)])
     paired = "right.fq" in files
     r = dict(left_segs=[conv(os.path.join(d, "left_seg%d.sam" % (k + 1))) for k in range(nseg)], left_map=conv(os.path.join(d, "left_map.sam")))
     if paired:
@@ -56,6 +56,16 @@ def test_dropin_binaries_reproduce_fixture(name, as_bam, tmp_path):
         cmd = [os.path.join(BIN, "long_spanning_reads"), "--segment-length", seglen, "--sam-header", os.path.join(d, "hdr.sam"),
                os.path.join(d, "ref.fa"), os.path.join(d, "%s.fq" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null",
                bam, ",".join(inp["%s_segs" % sd])]
+        sp = [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.startswith("%s_seg" % sd) and f.endswith(".to_spliced.sam")]
+        if sp:          # junction-db segment maps (SplicedBAMHitFactory path)
+            if as_bam:
+                conv = []
+                for f in sp:
+                    o_ = str(tmp_path / (os.path.basename(f)[:-4] + ".bam"))
+                    write_bam_from_sam(f, o_)
+                    conv.append(o_)
+                sp = conv
+            cmd.append(",".join(sp))
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
         _, recs = read_bam(bam)

@@ -24,8 +24,8 @@ int main(int argc, char** argv) {
     if (pos.size() < 8) { print_usage(); return 1; }
     if (o.color) die("Error: colour-space reads are not supported by this build\n");
     if (o.fusion_search) die("Error: --fusion-search is not supported by this build yet\n");
-    if (pos.size() >= 9 && !pos[8].empty())
-        die("Error: junction-db (spliced) segment maps are not supported by this build yet (SplicedBAMHitFactory)\n");
+    std::vector<std::string> spliced_segs;
+    if (pos.size() >= 9) spliced_segs = split(pos[8], ',');
     std::vector<std::string> segs = split(pos[7], ',');
     if (segs.empty()) { fprintf(stderr, "No hits to process, exiting\n"); return 0; }           // long_spanning_reads.cpp:2883-2887
 
@@ -118,6 +118,10 @@ int main(int argc, char** argv) {
     std::vector<HitStream> st((size_t)nseg);
     for (int s = 0; s < nseg; ++s)
         if (!st[(size_t)s].open(segs[(size_t)s], rt, o.p)) die("Error opening SAM file %s\n", segs[(size_t)s].c_str());
+    // junction-db ("spliced") segment maps: SplicedBAMHitFactory streams, one per segment (:3110-3123)
+    std::vector<HitStream> sst(spliced_segs.size());
+    for (size_t s = 0; s < spliced_segs.size(); ++s)
+        if (!sst[s].open(spliced_segs[s], rt, o.p, true)) die("Error opening SAM file %s\n", spliced_segs[s].c_str());
     ReadStream reads;
     if (!reads.open(pos[1], o.zpacker)) die("Error: cannot open %s for reading\n", pos[1].c_str());
 
@@ -159,7 +163,9 @@ int main(int argc, char** argv) {
     // looked up by id (look_right_for_hit_group :87-163; the kernel stops at the first empty segment as it does)
     std::vector<Hit> g;
     for (;;) {
+        // first-segment groups of the contig and the spliced stream, merged by id (:2706-2765)
         uint32_t id = st[0].next_group_id();
+        if (!sst.empty()) { uint32_t sid = sst[0].next_group_id(); if (sid && (id == 0 || sid < id)) id = sid; }
         if (id == 0) break;
         Read rd;
         if (!reads.get(id, rd)) die("Error: could not get read # %d from stream\n", (int)id);
@@ -167,6 +173,10 @@ int main(int argc, char** argv) {
             g.clear();
             if (s > 0) while (st[(size_t)s].next_group_id() && st[(size_t)s].next_group_id() < id) st[(size_t)s].skip_group();
             if (st[(size_t)s].next_group_id() == id) st[(size_t)s].next_group(g);
+            if ((size_t)s < sst.size()) {            // spliced hits are appended after the contig hits (:125-147, :2738-2744)
+                while (sst[(size_t)s].next_group_id() && sst[(size_t)s].next_group_id() < id) sst[(size_t)s].skip_group();
+                if (sst[(size_t)s].next_group_id() == id) sst[(size_t)s].next_group(g);
+            }
             for (auto& h : g) hits.push_back(h.h32);
             seg_off.push_back((uint32_t)hits.size());
         }

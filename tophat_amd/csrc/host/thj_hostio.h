@@ -253,6 +253,7 @@ struct AlnRec {
     int nm = 0; bool has_nm = false;
     char xs = 0;
     bool has_xf = false;
+    std::string md; bool has_md = false;
 };
 
 class AlnReader {
@@ -335,7 +336,8 @@ public:
                 case 'I': { uint32_t v; memcpy(&v, d + p, 4); iv = v; isint = true; p += 4; break; }
                 case 'f': p += 4; break;
                 case 'd': p += 8; break;
-                case 'Z': case 'H': if (t0 == 'X' && t1 == 'F') r.has_xf = true; while (p < (size_t)bs && d[p]) ++p; ++p; break;
+                case 'Z': case 'H': { if (t0 == 'X' && t1 == 'F') r.has_xf = true; size_t z0 = p; while (p < (size_t)bs && d[p]) ++p;
+                            if (t0 == 'M' && t1 == 'D') { r.md.assign((const char*)d + z0, p - z0); r.has_md = true; } ++p; break; }
                 case 'B': { char st = (char)d[p]; int32_t cnt; memcpy(&cnt, d + p + 1, 4); int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
                             p += 5 + (size_t)cnt * sz; break; }
                 default: p = (size_t)bs; break;
@@ -364,6 +366,7 @@ public:
                 if (!t[k].compare(0, 5, "NM:i:")) { r.nm = atoi(t[k].c_str() + 5); r.has_nm = true; }
                 else if (!t[k].compare(0, 5, "XS:A:")) r.xs = t[k][5];
                 else if (!t[k].compare(0, 5, "XF:Z:")) r.has_xf = true;
+                else if (!t[k].compare(0, 5, "MD:Z:")) { r.md = t[k].substr(5); r.has_md = true; }
             }
             return true;
         }
@@ -426,24 +429,188 @@ inline bool parse_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& o
     return true;
 }
 
+// ---- SplicedBAMHitFactory::get_hit_from_buf + spliceCigar + getBAMmismatches (bwt_map.cpp:1469-1770, :681-883,
+// :410-475): a segment mapped against a junction-db contig `name|left|l-r|right|type|strand` (juncs_db.cpp:99,:143)
+// becomes a genomic hit with the REF_SKIP / DEL / INS operation spliced into its CIGAR.
+typedef std::vector<std::pair<int, int>> CigVec;      // (CigarOpCode, length)
+inline void cigar_add(CigVec& c, std::pair<int, int> op) {          // bwt_map.cpp:672-678, quirk included:
+    if (op.second <= 0) return;                                      // an op equal to the previous one extends it
+    if (!c.empty() && c.back().first == op.first) c.back().second += op.second;   // AND is appended again
+    c.push_back(op);
+}
+inline bool splice_cigar(CigVec& out, const CigVec& cigar, const std::vector<bool>& mism, int& left, int spl_start, int spl_len,
+                         int spl_code, int& spl_mm, int min_anchor_len) {
+    const int INS = 3, DEL = 5, REF_SKIP = 11, MATCH = 1, PAD = 15, SOFT = 13;
+    int spl_ofs = spl_start - left;
+    int spl_ofs_end = spl_ofs;
+    std::pair<int, int> gapop(spl_code, spl_len);
+    if (spl_code == INS) spl_ofs_end += spl_len;
+    int ref_ofs = 0, read_ofs = 0;
+    bool xfound = false;
+    if (spl_ofs_end > 0) {
+        for (size_t c = 0; c < cigar.size(); ++c) {
+            int prev_read_ofs = read_ofs, cur_op_ofs = ref_ofs;
+            int cur_opcode = cigar[c].first, cur_oplen = cigar[c].second;
+            if (cur_opcode == MATCH) {
+                ref_ofs += cur_oplen; read_ofs += cur_oplen;
+                for (int o = cur_op_ofs; o < ref_ofs; ++o) {
+                    int rofs = prev_read_ofs + (o - cur_op_ofs);
+                    bool mmb = rofs >= 0 && rofs < (int)mism.size() && mism[(size_t)rofs];
+                    if (spl_code == INS) { if (o >= spl_ofs && o < spl_ofs_end && mmb) ++spl_mm; }
+                    else if (abs(spl_ofs - o) < min_anchor_len && mmb) ++spl_mm;
+                }
+            } else if (cur_opcode == DEL || cur_opcode == REF_SKIP || cur_opcode == PAD) ref_ofs += cur_oplen;
+            else if (cur_opcode == SOFT || cur_opcode == INS) read_ofs += cur_oplen;
+            if (cur_op_ofs >= spl_ofs_end || ref_ofs <= spl_ofs) {
+                if (cur_op_ofs == spl_ofs_end && spl_code != INS && cur_opcode != INS) { xfound = true; cigar_add(out, gapop); }
+                cigar_add(out, cigar[c]);
+            } else {
+                xfound = true;
+                if (spl_code == INS) {
+                    std::pair<int, int> op = cigar[c];
+                    op.second = spl_ofs - cur_op_ofs;
+                    if (spl_ofs > cur_op_ofs) cigar_add(out, op);
+                    if (spl_ofs < 0) { std::pair<int, int> t = gapop; t.second += spl_ofs; if (t.second > 0) cigar_add(out, t); }
+                    else cigar_add(out, gapop);
+                    op.second = ref_ofs - spl_ofs_end;
+                    if (ref_ofs > spl_ofs_end) cigar_add(out, op);
+                } else {
+                    std::pair<int, int> op = cigar[c];
+                    op.second = spl_ofs - cur_op_ofs;
+                    cigar_add(out, op);
+                    cigar_add(out, gapop);
+                    op.second = ref_ofs - spl_ofs;
+                    cigar_add(out, op);
+                }
+            }
+        }
+    }
+    (void)xfound;
+    if (spl_ofs_end <= 0) {           // alignment starts after the splice event
+        if (spl_code == INS) left -= spl_len; else left += spl_len;
+        out = cigar;
+    }
+    if (out.size() < cigar.size() + 2) return false;
+    if (out.front().first != MATCH || out.back().first != MATCH) return false;
+    return true;
+}
+
+inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& out) {
+    bool end = true;
+    std::string q = r.qname;
+    size_t pipe = q.rfind('|');
+    if (pipe != std::string::npos) {
+        const char* tag = q.c_str() + pipe + 1;
+        if (strchr(tag, ':')) { unsigned a = 0, b = 0, c = 0; sscanf(tag, "%u:%u:%u", &a, &b, &c); end = (b + 1 == c); }
+        q.resize(pipe);
+    }
+    out.insert_id = (uint32_t)atoi(q.c_str());
+    if (r.rname == "*" || (r.flag & 4)) return false;
+    CigVec samcigar;
+    for (auto& c : r.cigar) {
+        if (c.second == 0) return false;
+        int op;
+        switch (c.first) {
+        case 'M': op = 1; break; case 'I': op = 3; break; case 'D': op = 5; break; case 'S': op = 13; break;
+        case 'H': continue; case 'P': op = 15; break;
+        case 'N': op = 11; if ((int)c.second > p.max_report_intron) return false; break;
+        default: return false;
+        }
+        samcigar.emplace_back(op, (int)c.second);
+    }
+    if (r.rnext != "*" && r.rnext != "=" && r.rnext != r.rname) return false;
+    // getBAMmismatches: mismatch positions from MD
+    std::vector<bool> mism(r.seq.size(), false);
+    int num_mm = 0;
+    if (r.has_md) {
+        const char* s = r.md.c_str();
+        size_t bi = 0;
+        while (*s) {
+            if (isdigit((unsigned char)*s)) { bi += (size_t)atoi(s); while (isdigit((unsigned char)*s)) ++s; }
+            while (isalpha((unsigned char)*s)) { ++s; ++num_mm; if (bi < mism.size()) mism[bi] = true; ++bi; }
+            if (*s == '^') { ++s; while (isalpha((unsigned char)*s)) { ++s; ++bi; } }
+            if (*s && !isdigit((unsigned char)*s) && !isalpha((unsigned char)*s) && *s != '^') ++s;
+        }
+    }
+    // tokenize_strict(text_name, "|")
+    std::vector<std::string> toks;
+    {
+        const std::string& s = r.rname;
+        size_t last = s.find_first_not_of('|', 0), pos = s.find_first_of('|', last);
+        while (last < s.size() || pos < s.size()) {
+            toks.push_back(s.substr(last, pos - last));
+            if (pos == std::string::npos) break;
+            last = pos + 1; pos = s.find_first_of('|', last);
+        }
+    }
+    int ne = (int)toks.size() - 6;
+    if (ne < 0) { fprintf(stderr, "Warning: found malformed splice record, skipping\n"); return false; }
+    std::string contig = toks[0];
+    for (int t = 1; t <= ne; ++t) contig += "|" + toks[(size_t)t];
+    std::vector<std::string> st = split(toks[(size_t)ne + 2], '-');
+    if (st.size() != 2) { fprintf(stderr, "Warning: found malformed splice record, skipping:\n"); return false; }
+    const std::string& jtype = toks[(size_t)ne + 4];
+    const std::string& jstrand = toks[(size_t)ne + 5];
+    int left = atoi(toks[(size_t)ne + 1].c_str()) + r.pos;
+    int lsp = atoi(st[0].c_str());
+    CigVec spl;
+    int spl_mm = 0;
+    if (jtype == "ins") {
+        if (left > lsp) return false;
+        if (!splice_cigar(spl, samcigar, mism, left, lsp + 1, (int)st[1].size(), 3, spl_mm, p.min_anchor_len)) return false;
+        if (spl_mm < 0) return false;
+        num_mm -= spl_mm;
+    } else {
+        if (jtype == "fus") die("Error: fusion junction-db hits are not supported by this build\n");
+        if (!(jstrand == "ff" || jstrand == "fr" || jstrand == "rf" || jstrand == "rr" || jstrand == "rev" || jstrand == "fwd")) {
+            fprintf(stderr, "Warning: found malformed splice record, skipping\n"); return false;
+        }
+        int opcode = jtype == "del" ? 5 : 11;
+        int gap_len = atoi(st[1].c_str()) - lsp - 1;
+        lsp += 1;
+        if (left >= lsp) return false;
+        if (!splice_cigar(spl, samcigar, mism, left, lsp, gap_len, opcode, spl_mm, p.min_anchor_len)) return false;
+    }
+    if (spl.size() > 5) die("Error: spliced segment alignment %s has %d CIGAR operations (this build supports 5)\n", r.qname.c_str(), (int)spl.size());
+    int gap = 0, right = left, read_len = 0;
+    for (size_t k = 0; k < spl.size(); ++k) {
+        int op = spl[k].first, len = spl[k].second;
+        if (op == 3 || op == 5) gap += len;
+        if (op == 1 || op == 5 || op == 11) right += len;
+        if (op == 1 || op == 3 || op == 13) read_len += len;
+        out.h32.cigar[k] = ((uint32_t)op << 28) | ((uint32_t)len & 0x0FFFFFFFu);
+    }
+    uint32_t ref_id = rt.get_id(contig);
+    bool anti = (r.flag & 0x10) != 0;
+    unsigned char mm8 = (unsigned char)num_mm, ed = (unsigned char)(num_mm + gap);
+    out.h16.ref_id = ref_id; out.h16.left = left; out.h16.right = right;
+    out.h16.flags = (uint8_t)((anti ? THJ_HIT_ANTISENSE : 0) | (end ? THJ_HIT_END : 0));
+    out.h16.edit_dist = ed; out.h16.mismatches = mm8; out.h16.read_len = (uint8_t)(read_len > 255 ? 255 : read_len);
+    out.h32.ref_id = ref_id; out.h32.left = left;
+    out.h32.flags = (uint8_t)(out.h16.flags | (jstrand == "rev" ? THJ_HIT_ANTISENSE_SPLICE : 0));
+    out.h32.mismatches = mm8; out.h32.edit_dist = ed; out.h32.n_cigar = (uint8_t)spl.size();
+    return true;
+}
+
 // HitStream (bwt_map.h:1040-1227): groups of consecutive records with equal insert_id, one-record look-ahead
 class HitStream {
     AlnReader rd_;
     RefTable* rt_ = nullptr;
     const thj_params* p_ = nullptr;
     Hit buffered_;
-    bool have_ = false, eof_ = true;
+    bool have_ = false, eof_ = true, spliced_ = false;
     void fill() {
         have_ = false;
         AlnRec r;
         while (!eof_) {
             if (!rd_.next(r)) { eof_ = true; break; }
-            if (parse_hit(r, *rt_, *p_, buffered_)) { have_ = true; break; }
+            buffered_ = Hit();
+            if (spliced_ ? parse_spliced_hit(r, *rt_, *p_, buffered_) : parse_hit(r, *rt_, *p_, buffered_)) { have_ = true; break; }
         }
     }
 public:
-    bool open(const std::string& fn, RefTable& rt, const thj_params& p) {
-        rt_ = &rt; p_ = &p;
+    bool open(const std::string& fn, RefTable& rt, const thj_params& p, bool spliced = false) {
+        rt_ = &rt; p_ = &p; spliced_ = spliced;
         if (fn.empty() || !rd_.open(fn)) return false;
         eof_ = false;
         fill();

@@ -151,3 +151,146 @@ def md_nm(ref: str, rs: str) -> Tuple[int, str]:
 
 def sam_header(names: Sequence[str], lens: Sequence[int]) -> str:
     return "@HD\tVN:1.0\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in zip(names, lens))
+
+
+# ---------------------------------------------------------------------------------------------
+# junction-db ("spliced") segment maps: SplicedBAMHitFactory::get_hit_from_buf + spliceCigar +
+# getBAMmismatches (bwt_map.cpp:1469-1770, :681-883, :410-475).  Python mirror of the C++ host parser
+# (tophat_amd/csrc/host/thj_hostio.h: parse_spliced_hit), intron / deletion / insertion entries.
+# ---------------------------------------------------------------------------------------------
+
+def _cigar_add(c, op):
+    if op[1] <= 0:
+        return
+    if c and c[-1][0] == op[0]:          # bwt_map.cpp:672-678: extends the previous op AND appends (sic)
+        c[-1] = (c[-1][0], c[-1][1] + op[1])
+    c.append(op)
+
+
+def _splice_cigar(cigar, mism, left, spl_start, spl_len, spl_code, min_anchor_len):
+    INS, DEL, SKIP, MATCH, PAD, SOFT = 3, 5, 11, 1, 15, 13
+    out = []
+    spl_ofs = spl_start - left
+    spl_ofs_end = spl_ofs + (spl_len if spl_code == INS else 0)
+    gapop = (spl_code, spl_len)
+    ref_ofs = read_ofs = 0
+    spl_mm = 0
+    if spl_ofs_end > 0:
+        for (op, ln) in cigar:
+            prev_read, cur_ofs = read_ofs, ref_ofs
+            if op == MATCH:
+                ref_ofs += ln
+                read_ofs += ln
+                for o in range(cur_ofs, ref_ofs):
+                    r = prev_read + (o - cur_ofs)
+                    m = 0 <= r < len(mism) and mism[r]
+                    if spl_code == INS:
+                        spl_mm += 1 if (spl_ofs <= o < spl_ofs_end and m) else 0
+                    else:
+                        spl_mm += 1 if (abs(spl_ofs - o) < min_anchor_len and m) else 0
+            elif op in (DEL, SKIP, PAD):
+                ref_ofs += ln
+            elif op in (SOFT, INS):
+                read_ofs += ln
+            if cur_ofs >= spl_ofs_end or ref_ofs <= spl_ofs:
+                if cur_ofs == spl_ofs_end and spl_code != INS and op != INS:
+                    _cigar_add(out, gapop)
+                _cigar_add(out, (op, ln))
+            elif spl_code == INS:
+                if spl_ofs > cur_ofs:
+                    _cigar_add(out, (op, spl_ofs - cur_ofs))
+                if spl_ofs < 0:
+                    if gapop[1] + spl_ofs > 0:
+                        _cigar_add(out, (gapop[0], gapop[1] + spl_ofs))
+                else:
+                    _cigar_add(out, gapop)
+                if ref_ofs > spl_ofs_end:
+                    _cigar_add(out, (op, ref_ofs - spl_ofs_end))
+            else:
+                _cigar_add(out, (op, spl_ofs - cur_ofs))
+                _cigar_add(out, gapop)
+                _cigar_add(out, (op, ref_ofs - spl_ofs))
+    if spl_ofs_end <= 0:
+        left = left - spl_len if spl_code == INS else left + spl_len
+        out = list(cigar)
+    ok = len(out) >= len(cigar) + 2 and out[0][0] == MATCH and out[-1][0] == MATCH
+    return ok, out, left, spl_mm
+
+
+def parse_spliced_sam_hits(path: str, ref_ids: Dict[str, int], max_report_intron: int = 500000,
+                           min_anchor_len: int = 8) -> Iterator[HitRec]:
+    with open(path) as f:
+        for line in f:
+            if line.startswith("@") or not line.strip():
+                continue
+            t = line.rstrip("\n").split("\t")
+            qname, flag, rname, pos, cigar, rnext, seq = t[0], int(t[1]), t[2], int(t[3]), t[5], t[6], t[9]
+            end = True
+            pipe = qname.rfind("|")
+            if pipe >= 0:
+                m = re.match(r"(\d+):(\d+):(\d+)", qname[pipe + 1:])
+                if m:
+                    end = int(m.group(2)) + 1 == int(m.group(3))
+                qname = qname[:pipe]
+            rid = int(re.match(r"\s*[+-]?\d+", qname).group(0))
+            if rname == "*" or (flag & 4):
+                continue
+            ops, ok = [], True
+            for n, o in _CIG.findall(cigar):
+                n = int(n)
+                code = {"M": 1, "I": 3, "D": 5, "N": 11, "S": 13, "P": 15}.get(o)
+                if o == "H":
+                    continue
+                if n <= 0 or code is None or (o == "N" and n > max_report_intron):
+                    ok = False
+                    break
+                ops.append((code, n))
+            if not ok or rnext not in ("*", "=", rname):
+                continue
+            mism = [False] * len(seq)
+            num_mm = 0
+            md = next((x[5:] for x in t[11:] if x.startswith("MD:Z:")), None)
+            if md is not None:
+                bi = 0
+                for tok in re.findall(r"\d+|\^[A-Za-z]+|[A-Za-z]", md):
+                    if tok[0].isdigit():
+                        bi += int(tok)
+                    elif tok[0] == "^":
+                        bi += len(tok) - 1
+                    else:
+                        num_mm += 1
+                        if bi < len(mism):
+                            mism[bi] = True
+                        bi += 1
+            toks = rname.split("|")
+            ne = len(toks) - 6
+            if ne < 0:
+                continue
+            contig = "|".join(toks[:ne + 1])
+            st = [x for x in toks[ne + 2].split("-") if x]
+            if len(st) != 2:
+                continue
+            jtype, jstrand = toks[ne + 4], toks[ne + 5]
+            left = int(toks[ne + 1]) + pos - 1
+            lsp = int(st[0])
+            if jtype == "ins":
+                if left > lsp:
+                    continue
+                ok, spl, left, spl_mm = _splice_cigar(ops, mism, left, lsp + 1, len(st[1]), 3, min_anchor_len)
+                if not ok:
+                    continue
+                num_mm -= spl_mm
+            else:
+                code = 5 if jtype == "del" else 11
+                gap_len = int(st[1]) - lsp - 1
+                lsp += 1
+                if left >= lsp:
+                    continue
+                ok, spl, left, spl_mm = _splice_cigar(ops, mism, left, lsp, gap_len, code, min_anchor_len)
+                if not ok:
+                    continue
+            gap = sum(n for o, n in spl if o in (3, 5))
+            right = left + sum(n for o, n in spl if o in (1, 5, 11))
+            rl = sum(n for o, n in spl if o in (1, 3, 13))
+            yield (rid, ref_ids[contig], left, right, bool(flag & 0x10), end, num_mm & 0xFF, (num_mm + gap) & 0xFF, rl,
+                   spl, jstrand == "rev")

@@ -51,6 +51,8 @@ class SynthCase:
     full_sam: Dict[str, List[str]] = field(default_factory=dict)             # side -> full-read map SAM lines
     full_recs: Dict[str, List[HitRec]] = field(default_factory=dict)
     truth_juncs: set = field(default_factory=set)                            # (ref_id, left, right, strand)
+    spliced_sam: Dict[str, List[List[str]]] = field(default_factory=dict)   # side -> [seg] -> junction-db SAM lines
+    juncdb: Dict[str, int] = field(default_factory=dict)                    # junction-db contig name -> length
 
     @property
     def nseg(self) -> int:
@@ -176,7 +178,7 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
               err: float = 0.01, indel_frac: float = 0.08, n_frac: float = 0.02,
               genes_per_contig: int = 12, intron_range=(60, 3000), inner_mean: int = 50,
               inner_sd: int = 20, repeat_frac: float = 0.0, drop_seg_frac: float = 0.03,
-              overhang: int = 3, spliced_seg_frac: float = 0.0, boundary_bias: float = 0.0) -> SynthCase:
+              overhang: int = 3, spliced_seg_frac: float = 0.0, boundary_bias: float = 0.0, juncdb: bool = False) -> SynthCase:
     rng = random.Random(seed)
     names, seqs, genes = make_genome(rng, contig_lens, genes_per_contig, intron_range)
     # optional planted repeats -> multihits
@@ -210,6 +212,7 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
         case.seg_recs[sd] = [[] for _ in range(nseg)]
         case.full_sam[sd] = []
         case.full_recs[sd] = []
+        case.spliced_sam[sd] = [[] for _ in range(nseg)]
 
     def emit(sd: str, rid: int, frag_exons, t0: int, anti: bool, gref: int, with_indel: bool, gene_strand: str = "+"):
         """fragment = transcript interval [t0, t0+read_len) of the exon chain."""
@@ -277,6 +280,21 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
                         flag = 16 if anti else 0
                         qn = "%d|%d:%d:%d" % (rid, s0, k, nseg)
                         xs = "-" if gene_strand == "-" else "+"
+                        if juncdb:
+                            # the record bowtie would write against the junction database built by juncs_db
+                            # (juncs_db.cpp:109-150): contig name|left_start|l-r|right_end|GTAG|fwd/rev
+                            jl, jr = spos + a_len - 1, spos + a_len + gap
+                            half = seg_len
+                            ls = max(0, jl - half + 1)
+                            re_ = min(jr + half, len(gseq))
+                            dbname = "%s|%d|%d-%d|%d|GTAG|%s" % (names[gref], ls, jl, jr, re_, "rev" if xs == "-" else "fwd")
+                            case.juncdb[dbname] = (ls + half - ls) + (re_ - jr)
+                            dbseq = gseq[ls:ls + half] + gseq[jr:re_]
+                            dpos = spos - ls
+                            nm2, md2 = md_nm(dbseq[dpos:dpos + (f1 - f0)], piece)
+                            case.spliced_sam[sd][k].append("%s\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\n" % (
+                                qn, flag, dbname, dpos + 1, f1 - f0, piece, "I" * (f1 - f0), nm2, md2))
+                            continue
                         case.seg_sam[sd][k].append("%s\t%d\t%s\t%d\t255\t%dM%dN%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\tXS:A:%s\n" % (
                             qn, flag, names[gref], spos + 1, a_len, gap, b_len, piece, "I" * (f1 - f0), nm_, md, xs))
                         case.seg_recs[sd][k].append((rid, gref + 1, spos, spos + a_len + gap + b_len, anti, k == nseg - 1, nm_, nm_,
@@ -377,6 +395,16 @@ def write_case(case: SynthCase, d: str) -> Dict[str, object]:
                 f.writelines(lines)
             segs.append(p)
         paths["%s_segs" % sd] = segs
+        if any(case.spliced_sam.get(sd, [])):
+            dbhdr = "@HD\tVN:1.0\tSO:unsorted\n" + "".join("@SQ\tSN:%s\tLN:%d\n" % (n, l) for n, l in sorted(case.juncdb.items()))
+            sps = []
+            for k, lines in enumerate(case.spliced_sam[sd]):
+                p = os.path.join(d, "%s_seg%d.to_spliced.sam" % (sd, k + 1))
+                with open(p, "w") as f:
+                    f.write(dbhdr)
+                    f.writelines(lines)
+                sps.append(p)
+            paths["%s_spliced" % sd] = sps
         p = os.path.join(d, "%s_map.sam" % sd)
         with open(p, "w") as f:
             f.write(hdr)
