@@ -3,6 +3,7 @@ segment.juncs/.insertions/.deletions byte-identical to the expected files, spann
 and its uncompressed byte stream identical to the reference's BAM (GBamRecord encoding, common.cpp:1000-1173)."""
 import gzip
 import os
+import re
 import subprocess
 
 import pytest
