@@ -277,6 +277,22 @@ def main():
     for k in kernels:
         k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0
         k["frac"] = k["achieved"] / HBM_PEAK_GBS
+    # HBM traffic from the PMC counters cannot be sampled inside this process; it is collected with
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on this same command and committed under
+    # profiles/.  It is reported only when the configuration is the one that was profiled.  Per MI355X_MICROARCH.md
+    # FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950: traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB,
+    # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
+            for k in kernels:
+                c = pm["kernels"].get(k["kernel"])
+                if c:
+                    k["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                    k["traffic_low"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+                    k["traffic_source"] = pm["source"]
+    except (OSError, ValueError, KeyError):
+        pass
     dom = max(kernels, key=lambda k: k["avg_kernel_ms"])
 
     result = None
@@ -318,7 +334,8 @@ def main():
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                         "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"), "traffic_low": dom.get("traffic_low"),
+                         "traffic_source": dom.get("traffic_source"), "kernel": dom["kernel"],
                          "avg_kernel_ms": dom["avg_kernel_ms"], "launches": dom["launches"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
             "kernels": kernels,
