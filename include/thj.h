@@ -79,6 +79,8 @@ typedef struct {
     int32_t bowtie2_read_gap_cont;
     int32_t bowtie2_ref_gap_open;
     int32_t bowtie2_ref_gap_cont;
+    int32_t fusion_anchor_length;  /* common.cpp:172 */
+    int32_t fusion_min_dist;       /* common.cpp:173 */
 } thj_params;
 
 /* Fills `p` with the defaults of common.cpp:79-180. */
@@ -197,6 +199,22 @@ int thj_segjuncs_merge_keys_async(thj_ctx* ctx, int kind, const uint64_t* d_keys
  * value = "earlier insertion wins", insertions.h:52-67 + std::set::insert). */
 int thj_segjuncs_device_insertions(thj_ctx* ctx, const uint64_t** d_keys, const uint64_t** d_vals, int64_t* n);
 int thj_segjuncs_merge_insertions_async(thj_ctx* ctx, const uint64_t* d_keys, const uint64_t* d_vals, int64_t n);
+
+/* ------------------------------------------------ fusion search (--fusion-search) */
+typedef struct { uint32_t ref_id1, ref_id2, left, right, dir, count, edit_dist, reserved; } thj_fusion;   /* fusions.h:24-116 */
+#define THJ_FUSION_FF 7u
+#define THJ_FUSION_FR 8u
+#define THJ_FUSION_RF 9u
+#define THJ_FUSION_RR 10u
+/* find_fusions + detect_fusion (segment_juncs.cpp:2976-3291, :2629-2805) for every read of the batch -- which for
+ * this call must hold ALL visited reads, including those whose only mapped segment is the first
+ * (:3994-4028).  Candidate events accumulate on the device. */
+int thj_fusion_reset_async(thj_ctx* ctx);
+int thj_fusion_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch* dev_batch);
+/* Synchronises and reduces the events to the FusionSimpleSet (count, smallest edit distance) in
+ * Fusion::operator< order (fusions.h:38-69). */
+int thj_fusion_finish(thj_ctx* ctx, int64_t* n_fusions);
+int thj_fusion_download(thj_ctx* ctx, thj_fusion* out);
 
 /* Average duration (ms) of the dominant kernel (`thj_k_segjuncs`) over the
  * launches since the last call, measured with HIP events on the context

@@ -637,3 +637,233 @@ void orc_events_free(orc_events* e)
     free(e->juncs); free(e->deletions); free(e->insertions);
     memset(e, 0, sizeof *e);
 }
+
+/* ================================================================== fusion search */
+
+typedef struct { orc_fusion* v; int64_t n, cap; } fvec;
+static void fpush(fvec* a, orc_fusion f)
+{
+    if (a->n == a->cap) { a->cap = a->cap ? a->cap * 2 : 256; a->v = (orc_fusion*)realloc(a->v, (size_t)a->cap * sizeof(orc_fusion)); }
+    a->v[a->n++] = f;
+}
+/* Fusion::operator< (fusions.h:38-69) */
+static int fcmp(const void* pa, const void* pb)
+{
+    const orc_fusion* a = (const orc_fusion*)pa; const orc_fusion* b = (const orc_fusion*)pb;
+    if (a->ref_id1 != b->ref_id1) return a->ref_id1 < b->ref_id1 ? -1 : 1;
+    if (a->ref_id2 != b->ref_id2) return a->ref_id2 < b->ref_id2 ? -1 : 1;
+    if (a->left != b->left) return a->left < b->left ? -1 : 1;
+    if (a->right != b->right) return a->right < b->right ? -1 : 1;
+    if (a->dir != b->dir) return a->dir < b->dir ? -1 : 1;
+    return 0;
+}
+
+/* detect_fusion, segment_juncs.cpp:2629-2805.  rd = the whole read (reverse-complemented by the caller when
+ * both hits are antisense). */
+static void detect_fusion(const orc_genome* g, int fusion_anchor_length, const char* rd, int read_length,
+                          const orc_hit* lh, const orc_hit* rh, uint32_t dir, fvec* out)
+{
+    int64_t llen, rlen;
+    const char* lref = contig(g, lh->ref_id, &llen);
+    const char* rref = contig(g, rh->ref_id, &rlen);
+    if (!lref || !rref || read_length > 1024) return;
+    char lg[1024], rg[1024], tmp[1024];
+    if (dir == ORC_FUSION_FF || dir == ORC_FUSION_FR) {
+        if (lh->left + read_length > (int)llen) return;
+        if (lh->left < 0) return;
+        memcpy(lg, lref + lh->left, (size_t)read_length);
+    } else {
+        if (lh->right < read_length) return;
+        if (lh->right > llen) return;
+        memcpy(tmp, lref + lh->right - read_length, (size_t)read_length);
+        revcomp(tmp, read_length, lg);                   /* Dna5: N stays N */
+    }
+    if (dir == ORC_FUSION_FF || dir == ORC_FUSION_RF) {
+        if (rh->right < read_length) return;
+        if (rh->right > rlen) return;
+        memcpy(rg, rref + rh->right - read_length, (size_t)read_length);
+    } else {
+        if (rh->left + read_length > (int)rlen) return;
+        if (rh->left < 0) return;
+        memcpy(tmp, rref + rh->left, (size_t)read_length);
+        revcomp(tmp, read_length, rg);
+    }
+    /* simpleSplitAlignment, all tied best positions (:2390-2456) */
+    unsigned short before[1024], after[1024];
+    for (int idx = read_length - 1; idx >= 0; --idx) {
+        unsigned short prev = idx < read_length - 1 ? before[idx + 1] : 0;
+        before[idx] = (unsigned short)(prev + ((rg[idx] == 'N' || rd[idx] == 'N' || rg[idx] != rd[idx]) ? 1 : 0));
+    }
+    for (int idx = 0; idx < read_length; ++idx) {
+        unsigned short prev = idx > 0 ? after[idx - 1] : 0;
+        after[idx] = (unsigned short)(prev + ((lg[idx] == 'N' || rd[idx] == 'N' || lg[idx] != rd[idx]) ? 1 : 0));
+    }
+    int min_err = read_length + 1;
+    for (int pos = 1; pos < read_length; ++pos) { int e = before[pos] + after[pos - 1]; if (e < min_err) min_err = e; }
+    uint32_t total_ed = (uint32_t)lh->edit_dist + (uint32_t)rh->edit_dist;
+    if (min_err > (int)total_ed) return;                                         /* :2697-2699 */
+    if (min_err > 2) return;
+    for (int pos = 1; pos < read_length; ++pos) {                                /* :2704-2713: any tied position too close to an end */
+        if (before[pos] + after[pos - 1] != min_err) continue;
+        if (pos < fusion_anchor_length) return;
+        if (read_length - pos < fusion_anchor_length) return;
+    }
+    for (int pos = 1; pos < read_length; ++pos) {
+        if (before[pos] + after[pos - 1] != min_err) continue;
+        uint32_t left, right;
+        if (dir == ORC_FUSION_FF || dir == ORC_FUSION_FR) left = (uint32_t)(lh->left + pos - 1);
+        else left = (uint32_t)(lh->right - pos);
+        if (dir == ORC_FUSION_FF || dir == ORC_FUSION_RF) right = (uint32_t)(rh->right - (read_length - pos));
+        else right = (uint32_t)(rh->left + (read_length - pos) - 1);
+        uint32_t r1 = lh->ref_id, r2 = rh->ref_id, tdir = dir;
+        if (r2 < r1 || (r1 == r2 && left > right)) {                             /* :2776-2789 */
+            uint32_t t = r1; r1 = r2; r2 = t;
+            t = left; left = right; right = t;
+            if (dir == ORC_FUSION_FF) tdir = ORC_FUSION_RR;
+        }
+        orc_fusion f; f.ref_id1 = r1; f.ref_id2 = r2; f.left = left; f.right = right; f.dir = tdir;
+        f.count = 1; f.edit_dist = total_ed; f.skip = 0;
+        fpush(out, f);
+    }
+}
+
+/* find_fusions, segment_juncs.cpp:2976-3291 */
+static void find_fusions(const orc_params* p, int fusion_anchor_length, int fusion_min_dist, const orc_genome* g,
+                         const orc_batch* b, int r, fvec* out)
+{
+    int nseg = b->nseg;
+    if (nseg == 0) return;
+    const int64_t* so = b->seg_off + (int64_t)r * nseg;
+    const char* seq = b->bases + b->read_off[r];
+    int read_length = (int)(b->read_off[r + 1] - b->read_off[r]);
+    int last = nseg - 1;
+    while (last > 0 && so[last + 1] == so[last]) --last;                        /* :2986-2993 */
+    int n0 = (int)(so[1] - so[0]);
+    if (last == 0 && (n0 == 0 || is_end(&b->hits[so[0]]))) return;               /* :3035-3037 */
+    const orc_hit* mate = NULL; int n_mate = 0;
+    if (b->mate_off) { n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]); mate = b->mate_hits + b->mate_off[r]; }
+    int has_partner = n_mate > 0;
+    if (read_length > 1024) return;
+    char rc[1024];
+    revcomp(seq, read_length, rc);
+    /* right_segment_hits = copy of the last segment's hits when first != last, else empty (:3075-3080) */
+    hlist right = {0, 0, 0};
+    if (last != 0) for (int64_t k = so[last]; k < so[last + 1]; ++k) hl_push(&right, b->hits[k]);
+    int check_partner = 1;
+    if (last != 0) {
+        for (int64_t i = so[0]; i < so[1] && check_partner; ++i)
+            for (int j = 0; j < right.n; ++j) {
+                const orc_hit* lh = &b->hits[i]; const orc_hit* rh = &right.v[j];
+                if (lh->ref_id == rh->ref_id && is_anti(lh) == is_anti(rh)) {
+                    int dist = is_anti(lh) ? lh->left - rh->right : rh->left - lh->right;
+                    if (dist > -p->max_insertion_length && dist <= fusion_min_dist) { check_partner = 0; break; }
+                }
+            }
+    }
+    const int minus_dist = -p->max_insertion_length * 2;
+    if (check_partner && has_partner) {                                          /* :3117-3202 */
+        int check_read_len = 15 < p->segment_length - p->segment_mismatches - 3 ? 15 : p->segment_length - p->segment_mismatches - 3;
+        for (int64_t l = so[0]; l < so[1]; ++l) {
+            const orc_hit* lh = &b->hits[l];
+            for (int m = 0; m < n_mate; ++m) {
+                const orc_hit* rh = &mate[m];
+                if (lh->ref_id == rh->ref_id && is_anti(lh) != is_anti(rh)) {
+                    int dist = is_anti(lh) ? lh->left - rh->right : rh->left - lh->right;
+                    if (dist > minus_dist && dist <= fusion_min_dist) continue;
+                }
+                int64_t ref_len;
+                const char* ref = contig(g, rh->ref_id, &ref_len);
+                if (!ref) continue;
+                int part = p->inner_dist_std_dev > p->inner_dist_mean ? p->inner_dist_std_dev - p->inner_dist_mean : 0;
+                int flank = p->inner_dist_mean + p->inner_dist_std_dev;
+                int64_t left;
+                if (is_anti(rh)) { if (flank <= rh->left) left = rh->left - flank; else break; }
+                else { if (part <= rh->right) left = rh->right - part; else break; }
+                int64_t fe = left + flank + part; if (fe > ref_len) fe = ref_len;
+                int flen = (int)(fe - left); if (flen < 0) flen = 0;
+                if (check_read_len < 1 || check_read_len > read_length) continue;
+                int fwd_pos = orc_map_read_to_contig(ref + left, flen, seq + read_length - check_read_len, check_read_len);
+                if (fwd_pos >= 0) {
+                    orc_hit h; memset(&h, 0, sizeof h);
+                    h.ref_id = rh->ref_id; h.left = (int32_t)(left + fwd_pos); h.right = h.left + check_read_len;
+                    h.flags = ORC_HIT_END; h.read_len = (uint8_t)check_read_len;
+                    hl_push(&right, h);
+                }
+                int rev_pos = orc_map_read_to_contig(ref + left, flen, rc, check_read_len);
+                if (rev_pos >= 0) {
+                    orc_hit h; memset(&h, 0, sizeof h);
+                    h.ref_id = rh->ref_id; h.left = (int32_t)(left + rev_pos); h.right = h.left + check_read_len;
+                    h.flags = ORC_HIT_END | ORC_HIT_ANTISENSE; h.read_len = (uint8_t)check_read_len;
+                    hl_push(&right, h);
+                }
+            }
+        }
+    }
+    for (int64_t li = so[0]; li < so[1]; ++li)                                   /* :3211-3290 */
+        for (int ri = 0; ri < right.n; ++ri) {
+            const orc_hit* lh = &b->hits[li]; const orc_hit* rh = &right.v[ri];
+            if (p->bowtie2 && (int)lh->edit_dist + (int)rh->edit_dist > (p->segment_mismatches << 1)) continue;
+            if (lh->ref_id == rh->ref_id && is_anti(lh) == is_anti(rh)) {
+                int dist = is_anti(lh) ? lh->left - rh->right : rh->left - lh->right;
+                if (dist > minus_dist && dist <= fusion_min_dist) continue;
+            }
+            uint32_t dir = ORC_FUSION_FF;
+            const char* mod = seq;
+            if (is_anti(lh) == is_anti(rh)) {
+                if (is_anti(lh)) { const orc_hit* t = lh; lh = rh; rh = t; mod = rc; }
+            } else if (!is_anti(lh) && is_anti(rh)) dir = ORC_FUSION_FR;
+            else dir = ORC_FUSION_RF;
+            detect_fusion(g, fusion_anchor_length, mod, read_length, lh, rh, dir, out);
+        }
+    free(right.v);
+}
+
+int orc_fusions_batch(const orc_params* p, int fusion_anchor_length, int fusion_min_dist,
+                      const orc_genome* g, const orc_batch* b, orc_fusion** out, int64_t* n_out)
+{
+    fvec ev = {0, 0, 0};
+    for (int r = 0; r < b->n_reads; ++r) find_fusions(p, fusion_anchor_length, fusion_min_dist, g, b, r, &ev);
+    /* FusionSimpleSet: count occurrences, keep the smallest edit distance (:2791-2803) */
+    if (ev.n) qsort(ev.v, (size_t)ev.n, sizeof(orc_fusion), fcmp);
+    int64_t w = 0;
+    for (int64_t i = 0; i < ev.n; ++i) {
+        if (w && fcmp(&ev.v[w - 1], &ev.v[i]) == 0) {
+            ev.v[w - 1].count += 1;
+            if (ev.v[i].edit_dist < ev.v[w - 1].edit_dist) ev.v[w - 1].edit_dist = ev.v[i].edit_dist;
+        } else ev.v[w++] = ev.v[i];
+    }
+    *out = ev.v; *n_out = w;
+    return 0;
+}
+
+static int coord_found(const orc_junction* j, int64_t n, uint32_t ref, uint32_t coord)
+{
+    /* binary_search over the sorted (refid, coord) list built from every junction's left and right (:5048-5054, :5063) */
+    for (int64_t i = 0; i < n; ++i)
+        if (j[i].ref_id == ref && ((int)j[i].left == (int)coord || (int)j[i].right == (int)coord)) return 1;
+    return 0;
+}
+
+void orc_fusion_filter(orc_fusion* f, int64_t n, const orc_junction* juncs, int64_t n_juncs)
+{
+    /* segment_juncs.cpp:5096-5159 */
+    uint8_t* lc = (uint8_t*)calloc((size_t)n + 1, 1); uint8_t* rc_ = (uint8_t*)calloc((size_t)n + 1, 1);
+    for (int64_t i = 0; i < n; ++i) {
+        lc[i] = (uint8_t)coord_found(juncs, n_juncs, f[i].ref_id1, f[i].left);
+        rc_[i] = (uint8_t)coord_found(juncs, n_juncs, f[i].ref_id2, f[i].right);
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        for (int64_t k = i + 1; k < n; ++k) {
+            int left_diff = abs((int)f[i].left - (int)f[k].left);
+            if (!(f[i].ref_id1 == f[k].ref_id1 && f[i].ref_id2 == f[k].ref_id2 && left_diff < 10)) break;
+            if (f[i].dir == f[k].dir && left_diff == abs((int)f[i].right - (int)f[k].right)) {
+                if (f[k].count > f[i].count) f[i].skip = 1;
+                else if (f[k].count == f[i].count) {
+                    int cc = lc[i] + rc_[i], nc = lc[k] + rc_[k];
+                    if (cc < nc) f[i].skip = 1; else f[k].skip = 1;
+                } else f[k].skip = 1;
+            }
+        }
+    }
+    free(lc); free(rc_);
+}

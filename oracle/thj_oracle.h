@@ -121,6 +121,21 @@ int orc_simple_split(const char* shorter, const char* left_ref, const char* righ
 int orc_map_read_to_contig(const char* contig, int contig_len, const char* read, int read_len);
 
 
+/* ===================== fusion search of segment_juncs (segjuncs_oracle.c) ===================== */
+typedef struct { uint32_t ref_id1, ref_id2, left, right, dir, count, edit_dist, skip; } orc_fusion;   /* fusions.h:24-116 */
+#define ORC_FUSION_FF 7u
+#define ORC_FUSION_FR 8u
+#define ORC_FUSION_RF 9u
+#define ORC_FUSION_RR 10u
+/* find_fusions + detect_fusion (segment_juncs.cpp:2976-3291, :2629-2805) over every read of the batch
+ * (ALL visited reads, including those whose only mapped segment is the first).  Returns the FusionSimpleSet
+ * in Fusion::operator< order (fusions.h:38-69); *out is malloc'd. */
+int orc_fusions_batch(const orc_params* p, int fusion_anchor_length, int fusion_min_dist,
+                      const orc_genome* g, const orc_batch* b, orc_fusion** out, int64_t* n_out);
+/* The output filter of the fusion writer (segment_juncs.cpp:5096-5182): marks `skip`; juncs = the final junction
+ * set (sorted).  Returns nothing; entries with skip != 0 are not written. */
+void orc_fusion_filter(orc_fusion* f, int64_t n, const orc_junction* juncs, int64_t n_juncs);
+
 /* ===================== long_spanning_reads (spanning_oracle.c) ===================== */
 
 /* CigarOpCode values of bwt_map.h:36-55 */

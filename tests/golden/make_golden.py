@@ -32,6 +32,10 @@ CASES = {
                            opts=["--library-type", "fr-firststrand"]),
     "se100_juncdb": dict(gen=dict(seed=104, paired=False, read_len=100, seg_len=25, n_reads=160, boundary_bias=0.3,
                                   spliced_seg_frac=1.0, juncdb=True, contig_lens=(30000,), genes_per_contig=6, indel_frac=0.05), opts=[]),
+    "pe100_fusion": dict(gen=dict(seed=105, paired=True, read_len=100, seg_len=25, n_reads=120, fusion_reads=60,
+                                  contig_lens=(24000, 16000), genes_per_contig=4),
+                         opts=["--inner-dist-mean", "50", "--inner-dist-std-dev", "20", "--fusion-search", "--fusion-min-dist", "1500"],
+                         fusion=True),
 }
 
 
@@ -49,6 +53,11 @@ def main():
         if cfg["gen"]["paired"]:
             seg += [paths["right_fq"], paths["right_map"], ",".join(paths["right_segs"])]
         subprocess.run(seg, check=True, capture_output=True)
+        with open(os.path.join(d, "options.txt"), "w") as f:
+            f.write(" ".join(cfg["opts"]) + "\n")
+            f.write("segment_length=%d paired=%d\n" % (cfg["gen"]["seg_len"], cfg["gen"]["paired"]))
+        if cfg.get("fusion"):
+            continue          # long_spanning_reads with --fusion-search is not part of the fixtures yet
         os.remove(outs[3])
         for sd in (("left", "right") if cfg["gen"]["paired"] else ("left",)):
             bam = os.path.join(d, "span_%s.bam" % sd)

@@ -30,13 +30,22 @@ def load(name):
     kv = dict(x.split("=") for x in opts[1].split())
     p = Params(segment_length=int(kv["segment_length"]))
     i = 0
+    fusion = False
     while i < len(argv):
+        if argv[i] == "--fusion-search":
+            fusion = True
+            i += 1
+            continue
         if argv[i] == "--inner-dist-mean":
             p.inner_dist_mean = int(argv[i + 1])
         elif argv[i] == "--inner-dist-std-dev":
             p.inner_dist_std_dev = int(argv[i + 1])
         elif argv[i] == "--library-type":
             p.library_type = LIBRARY_TYPES[argv[i + 1]]
+        elif argv[i] == "--fusion-min-dist":
+            p.fusion_min_dist = int(argv[i + 1])
+        elif argv[i] == "--fusion-anchor-length":
+            p.fusion_anchor_length = int(argv[i + 1])
         i += 2
     names, _ = parse_header(os.path.join(d, "hdr.sam"))
     fa_names, fa_seqs = read_fasta(os.path.join(d, "ref.fa"))
@@ -59,18 +68,24 @@ def load(name):
             continue
         other = "right" if sd == "left" else "left"
         if paired:
-            b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1])
+            b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1], include_top0=fusion)
         else:
-            b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"])
+            b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], include_top0=fusion)
         seg_batches.append((side, b))
         span_batches[sd] = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], sides[sd]["quals"], sides[sd]["spliced"])
     exp = {k: open(os.path.join(d, "expected.%s" % k)).read() for k in ("juncs", "insertions", "deletions")}
     exp_span = {}
+    if fusion:
+        exp["fusions"] = open(os.path.join(d, "expected.fusions")).read()
     for sd in sides:
+        if not os.path.exists(os.path.join(d, "expected.span_%s.sam" % sd)):
+            continue
         rows = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
         # (QNAME FLAG RNAME POS CIGAR tags...) -- drop MAPQ/SEQ/QUAL columns
         exp_span[sd] = [(r[0], int(r[1]), r[2], int(r[3]), r[5]) + r[8:] for r in rows]
-    return dict(p=p, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp=exp, exp_span=exp_span)
+    if fusion:
+        span_batches = {}
+    return dict(p=p, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp=exp, exp_span=exp_span, fusion=fusion)
 
 
 def events_text(ev, names, tmp_path):
@@ -78,3 +93,12 @@ def events_text(ev, names, tmp_path):
     f = {k: str(tmp_path / ("got." + k)) for k in ("juncs", "insertions", "deletions")}
     write_segment_files(ev, names, f["juncs"], f["insertions"], f["deletions"])
     return {k: open(v).read() for k, v in f.items()}
+
+
+def fusions_text(fus, juncs, names, tmp_path):
+    """filter + writer of segment_juncs.cpp:5096-5182 (oracle's restatement) on a reduced fusion set"""
+    import orc
+    f = orc.fusion_filter(fus, juncs)
+    path = str(tmp_path / "got.fusions")
+    orc.write_fusions(f, names, path)
+    return open(path).read()

@@ -100,6 +100,35 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
 
 extern "C" void hostsim_free(void* p) { free(p); }
 
+// ---------------------------------------------------------------- fusion search
+struct FusCollect {
+    std::vector<thj_fusion> v;
+    void fusion(uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) { v.push_back({r1, r2, l, r, dir, 1u, ed, 0u}); }
+};
+
+extern "C" int hostsim_fusions(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len,
+                               int32_t n_contigs, const thj_seg_batch* b, thj_fusion** out, int64_t* n_out) {
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    Params p;
+    memcpy(&p, tp, sizeof p);
+    FusCollect c;
+    for (int32_t r = 0; r < b->n_reads; ++r) {
+        ReadView v;
+        v.hits = (const Hit*)b->hits;
+        v.so = b->seg_off + (int64_t)r * b->nseg;
+        v.nseg = b->nseg; v.W = b->words_per_plane;
+        v.rp = (const u64*)b->read_planes + (int64_t)r * 3 * v.W;
+        v.rl = b->read_len[r];
+        v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+        if (b->mate_off) { v.mate = (const Hit*)b->mate_hits + b->mate_off[r]; v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]); }
+        fusion_read(g, p, v, c);
+    }
+    *n_out = (int64_t)c.v.size();
+    *out = (thj_fusion*)malloc(sizeof(thj_fusion) * (c.v.size() + 1));
+    memcpy(*out, c.v.data(), sizeof(thj_fusion) * c.v.size());
+    return 0;
+}
+
 // ---------------------------------------------------------------- long_spanning_reads
 #include "../../tophat_amd/csrc/thj_span_core.h"
 

@@ -186,3 +186,65 @@ def spanning_count(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> in
     assert rc == 0
     lib.orc_free(out)
     return int(n_out.value)
+
+
+# ---------------------------------------------------------------- fusion search
+FUSION_DTYPE = np.dtype([("ref_id1", "<u4"), ("ref_id2", "<u4"), ("left", "<u4"), ("right", "<u4"), ("dir", "<u4"),
+                         ("count", "<u4"), ("edit_dist", "<u4"), ("skip", "<u4")])
+
+
+def fusions(p: Params, g: Genome, b: SegBatch, fusion_anchor_length: int = 20, fusion_min_dist: int = 10000000) -> np.ndarray:
+    lib = _lib()
+    ob = OrcBatch()
+    ob.n_reads, ob.nseg = b.n_reads, b.nseg
+    keep = [np.ascontiguousarray(b.read_id, dtype=np.uint32), np.ascontiguousarray(b.read_off, dtype=np.int64),
+            np.ascontiguousarray(b.bases, dtype=np.uint8), np.ascontiguousarray(b.seg_off, dtype=np.int64),
+            np.ascontiguousarray(b.hits)]
+    ob.read_id, ob.read_off, ob.bases, ob.seg_off, ob.hits = [a.ctypes.data for a in keep]
+    if b.mate_off is not None:
+        keep += [np.ascontiguousarray(b.mate_off, dtype=np.int64), np.ascontiguousarray(b.mate_hits)]
+        ob.mate_off, ob.mate_hits = keep[-2].ctypes.data, keep[-1].ctypes.data
+    op = orc_params(p)
+    out = C.c_void_p()
+    n = C.c_int64()
+    rc = lib.orc_fusions_batch(C.byref(op), fusion_anchor_length, fusion_min_dist, C.byref(g.c), C.byref(ob), C.byref(out), C.byref(n))
+    assert rc == 0
+    if n.value == 0:
+        return np.zeros(0, dtype=FUSION_DTYPE)
+    a = np.frombuffer((C.c_char * (n.value * 32)).from_address(out.value), dtype=FUSION_DTYPE).copy()
+    lib.orc_free(out)
+    return a
+
+
+def merge_fusions(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """merge_with(FusionSimpleSet&, ...) fusions.cpp:975-990: counts add, edit_dist = min"""
+    d = {}
+    for x in list(a) + list(b):
+        k = (int(x["ref_id1"]), int(x["ref_id2"]), int(x["left"]), int(x["right"]), int(x["dir"]))
+        if k in d:
+            d[k] = (d[k][0] + int(x["count"]), min(d[k][1], int(x["edit_dist"])))
+        else:
+            d[k] = (int(x["count"]), int(x["edit_dist"]))
+    out = np.zeros(len(d), dtype=FUSION_DTYPE)
+    for i, k in enumerate(sorted(d)):
+        out[i] = k + d[k] + (0,)
+    return out
+
+
+def fusion_filter(f: np.ndarray, juncs: np.ndarray) -> np.ndarray:
+    lib = _lib()
+    f = np.ascontiguousarray(f.copy())
+    j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
+    lib.orc_fusion_filter(C.c_void_p(f.ctypes.data), C.c_int64(len(f)), C.c_void_p(j.ctypes.data), C.c_int64(len(j)))
+    return f
+
+
+def write_fusions(f: np.ndarray, names, path: str):
+    """segment_juncs.cpp:5160-5180"""
+    DIR = {7: "ff", 8: "fr", 9: "rf", 10: "rr"}
+    with open(path, "w") as fh:
+        for x in f:
+            if x["skip"]:
+                continue
+            fh.write("%s\t%d\t%s\t%d\t%s\n" % (names[x["ref_id1"] - 1], np.int32(x["left"]), names[x["ref_id2"] - 1], np.int32(x["right"]),
+                                               DIR[int(x["dir"])]))

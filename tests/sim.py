@@ -90,3 +90,23 @@ def spanning(p: Params, seqs, b, juncs, insertions, mode: int = 0):
     a = np.frombuffer((C.c_char * (max(1, n_out.value) * 128)).from_address(out.value), dtype=host.ALN_DTYPE)[:n_out.value].copy()
     l.hostsim_free(out)
     return host.alns_from_array(a), list(st)
+
+
+def fusions(p: Params, seqs, b: SegBatch):
+    """raw fusion events of the kernel logic, reduced like FusionSimpleSet (count, min edit_dist)"""
+    import orc
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    cb, keep, _, _ = host.host_cbatch(b, 0, lib=l)
+    clen = g.lens.astype(np.int32)
+    cp = p.as_ctypes()
+    out = C.c_void_p()
+    n = C.c_int64()
+    rc = l.hostsim_fusions(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
+                           C.c_void_p(clen.ctypes.data), g.n_contigs, C.byref(cb), C.byref(out), C.byref(n))
+    assert rc == 0
+    a = np.zeros(0, dtype=orc.FUSION_DTYPE)
+    if n.value:
+        a = np.frombuffer((C.c_char * (n.value * 32)).from_address(out.value), dtype=orc.FUSION_DTYPE).copy()
+    l.hostsim_free(out)
+    return orc.merge_fusions(a, np.zeros(0, dtype=orc.FUSION_DTYPE))

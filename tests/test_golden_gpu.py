@@ -4,7 +4,7 @@ import copy
 import pytest
 
 import orc
-from golden_util import CASES, events_text, load
+from golden_util import CASES, events_text, fusions_text, load
 from tophat_amd import host
 
 pytestmark = pytest.mark.gpu
@@ -23,7 +23,12 @@ def test_hip_path_reproduces_fixture(name, tmp_path):
             runs.append((p, ctx.upload_batch(b, ordinal_base=base)))
             base += b.n_reads
         ev = ctx.segjuncs(runs)
-        assert events_text(ev, c["names"], tmp_path) == c["exp"]
+        exp = dict(c["exp"])
+        exp_fus = exp.pop("fusions", None)
+        assert events_text(ev, c["names"], tmp_path) == exp
+        if c["fusion"]:
+            fus = ctx.fusions(runs)
+            assert fusions_text(fus, ev.juncs, c["names"], tmp_path) == exp_fus
         ctx.span_sets_from_segjuncs()
         for sd, sb in c["span_batches"].items():
             got = ctx.spanning(c["p"], [ctx.upload_span_batch(sb)])

@@ -52,6 +52,9 @@ def test_dropin_binaries_reproduce_fixture(name, as_bam, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     for k in ("juncs", "insertions", "deletions"):
         assert open(out[k]).read() == open(os.path.join(d, "expected." + k)).read(), k
+    if "--fusion-search" in argv:
+        assert open(out["fusions"]).read() == open(os.path.join(d, "expected.fusions")).read()
+        return
     for sd in (("left", "right") if paired else ("left",)):
         bam = str(tmp_path / ("span_%s.bam" % sd))
         cmd = [os.path.join(BIN, "long_spanning_reads"), "--segment-length", seglen, "--sam-header", os.path.join(d, "hdr.sam"),

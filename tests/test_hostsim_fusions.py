@@ -1,0 +1,46 @@
+"""CPU: fusion-search kernel logic (thj_core.h: fusion_read) against the plain-C oracle."""
+import pytest
+
+import orc
+import sim
+from tophat_amd.batch import build_seg_batch
+from tophat_amd.params import Params
+from tophat_amd.synth import make_case
+
+FUSION_CASES = [
+    dict(seed=1, paired=False, read_len=100, extra=dict(fusion_min_dist=2000), gen=dict(contig_lens=(40000, 30000))),
+    dict(seed=2, paired=True, read_len=150, extra=dict(fusion_min_dist=1000, inner_dist_mean=50, inner_dist_std_dev=20),
+         gen=dict(contig_lens=(40000, 30000, 20000))),
+    dict(seed=3, paired=True, read_len=76, extra=dict(fusion_min_dist=500, fusion_anchor_length=15, inner_dist_mean=50, inner_dist_std_dev=20),
+         gen=dict(contig_lens=(30000, 30000), n_frac=0.2)),
+]
+
+
+def fusion_batches(cfg, n_reads=300):
+    case = make_case(seed=cfg["seed"], paired=cfg["paired"], read_len=cfg["read_len"], seg_len=25, n_reads=n_reads,
+                     fusion_reads=80, **cfg["gen"])
+    out = []
+    for sd, side in (("left", 1), ("right", 2)):
+        if sd not in case.reads:
+            continue
+        other = "right" if sd == "left" else "left"
+        if cfg["paired"]:
+            b = build_seg_batch(case.seg_recs[sd], case.reads[sd], case.full_recs[other], case.seg_recs[other][-1], include_top0=True)
+        else:
+            b = build_seg_batch(case.seg_recs[sd], case.reads[sd], include_top0=True)
+        out.append((Params(read_side=side, **cfg["extra"]), b))
+    return case, out
+
+
+@pytest.mark.parametrize("cfg", FUSION_CASES, ids=lambda c: "seed%d_%s_rl%d" % (c["seed"], "pe" if c["paired"] else "se", c["read_len"]))
+def test_fusion_logic_matches_oracle(cfg):
+    case, batches = fusion_batches(cfg)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    g = orc.Genome(seqs)
+    total = 0
+    for p, b in batches:
+        want = orc.fusions(p, g, b, p.fusion_anchor_length, p.fusion_min_dist)
+        got = sim.fusions(p, seqs, b)
+        assert got.tolist() == want.tolist()
+        total += len(want)
+    assert total > 30

@@ -85,7 +85,7 @@ def group_by_id(recs: Iterable[HitRec]) -> Dict[int, List[HitRec]]:
 def build_seg_batch(seg_recs: Sequence[Iterable[HitRec]],
                     reads: Dict[int, str],
                     mate_map_recs: Optional[Iterable[HitRec]] = None,
-                    mate_lastseg_recs: Optional[Iterable[HitRec]] = None) -> SegBatch:
+                    mate_lastseg_recs: Optional[Iterable[HitRec]] = None, include_top0: bool = False) -> SegBatch:
     """seg_recs[s] = records of segment-s map in file order; reads = id -> sequence.
 
     mate_map_recs / mate_lastseg_recs are the mate side's full-read map and
@@ -110,8 +110,8 @@ def build_seg_batch(seg_recs: Sequence[Iterable[HitRec]],
         if rid == 0:
             continue  # insert_id 0 is "no group" (bwt_map.h:1174-1176)
         top = max(s for s in range(nseg) if rid in groups[s])
-        if top == 0:
-            continue  # only find_fusions runs for these (segment_juncs.cpp:3994-4028)
+        if top == 0 and not include_top0:
+            continue  # only find_fusions runs for these (segment_juncs.cpp:3994-4028); event-neutral for the other finders
         if rid not in reads:
             raise KeyError("could not get read# %d from stream" % rid)  # :3352-3356
         read_id.append(rid)

@@ -1,7 +1,7 @@
 // segment_juncs -- MI355X-native drop-in for TopHat's segment_juncs (same argv + files; tophat.py:3097-3112,
 // parsed like segment_juncs.cpp:5186-5364).  Host C++ over the C ABI in include/thj.h; all per-read work runs in
-// the HIP kernels of libthj_hip.so.  Split-segment search, small indels and the paired-end rescue are supported;
-// coverage / microexon / butterfly / fusion searches are refused loudly.
+// the HIP kernels of libthj_hip.so.  Split-segment search, small indels, the paired-end rescue and --fusion-search
+// are supported; coverage / microexon / butterfly searches are refused loudly.
 #include "thj_hostio.h"
 
 using namespace thjh;
@@ -62,6 +62,7 @@ static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, c
         thj_seg_batch* dev = nullptr;
         if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
         if (thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+        if (o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
         if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
         ordinal += (uint32_t)n;
         reset();
@@ -78,7 +79,9 @@ static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, c
             grp[(size_t)s].clear();
             if (st[(size_t)s].next_group_id() == id) { st[(size_t)s].next_group(grp[(size_t)s]); top = s; }
         }
-        if (top <= 0) continue;                 // only find_fusions runs for these (segment_juncs.cpp:3994-4028)
+        // only find_fusions runs for reads whose highest mapped segment is the first (segment_juncs.cpp:3994-4028);
+        // they are event-neutral for the gap / indel finders, so with --fusion-search they simply ride along
+        if (top < 0 || (top == 0 && !o.fusion_search)) continue;
         Read rd;
         if (!reads.get(id, rd)) die("Error: could not get read# %d from stream!", (int)id);
         for (int s = 0; s < nseg; ++s) { for (auto& h : grp[(size_t)s]) hits.push_back(h.h16); seg_off.push_back((uint32_t)hits.size()); }
@@ -110,7 +113,7 @@ int main(int argc, char** argv) {
     for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
     if (pos.size() < 8 || (pos.size() > 8 && pos.size() < 11)) { print_usage(); return 1; }
     if (o.color) die("Error: colour-space reads are not supported by this build\n");
-    if (o.fusion_search) die("Error: --fusion-search is not supported by this build yet\n");
+    if (o.fusion_search && !o.fusion_ignore.empty()) die("Error: --fusion-ignore-chromosomes is not supported by this build yet\n");
     if (!o.no_coverage_search || !o.no_microexon_search || o.butterfly_search)
         die("Error: coverage / microexon / butterfly searches are not supported by this build yet; "
             "run with --no-coverage-search --no-microexon-search (what tophat passes for reads of >= 3 segments)\n");
@@ -133,6 +136,7 @@ int main(int argc, char** argv) {
     if (thj_ctx_create(device, nullptr, &ctx)) die("Error: %s\n", thj_last_error());
     rt.upload(ctx);
     if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+    if (o.fusion_search && thj_fusion_reset_async(ctx)) die("Error: %s\n", thj_last_error());
     size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
     uint32_t ordinal = 0;
     fprintf(stderr, ">> Performing segment-search:\n");
@@ -154,6 +158,42 @@ int main(int argc, char** argv) {
         fprintf(fd, "%s\t%d\t%d\n", rt.names[d[(size_t)i].ref_id - 1].c_str(), (int)d[(size_t)i].left + 1, (int)d[(size_t)i].right);
     for (int64_t i = 0; i < n.n_insertions; ++i)
         fprintf(fi, "%s\t%d\t%d\t%s\n", rt.names[ins[(size_t)i].ref_id - 1].c_str(), (int)ins[(size_t)i].left, (int)ins[(size_t)i].left, ins[(size_t)i].seq);
+    if (o.fusion_search) {
+        // fusion writer with its neighbour filter (segment_juncs.cpp:5048-5054, :5096-5182)
+        int64_t nf = 0;
+        if (thj_fusion_finish(ctx, &nf)) die("Error: %s\n", thj_last_error());
+        std::vector<thj_fusion> f((size_t)nf + 1);
+        if (thj_fusion_download(ctx, f.data())) die("Error: %s\n", thj_last_error());
+        std::vector<std::pair<uint32_t, int>> coords;          // SpliceJunctionCoord(refid, coord)
+        for (int64_t i = 0; i < n.n_juncs; ++i) {
+            coords.emplace_back(j[(size_t)i].ref_id, (int)j[(size_t)i].left);
+            coords.emplace_back(j[(size_t)i].ref_id, (int)j[(size_t)i].right);
+        }
+        std::sort(coords.begin(), coords.end());
+        std::vector<char> lc((size_t)nf + 1, 0), rc2((size_t)nf + 1, 0), skip((size_t)nf + 1, 0);
+        for (int64_t i = 0; i < nf; ++i) {
+            lc[(size_t)i] = std::binary_search(coords.begin(), coords.end(), std::make_pair(f[(size_t)i].ref_id1, (int)f[(size_t)i].left));
+            rc2[(size_t)i] = std::binary_search(coords.begin(), coords.end(), std::make_pair(f[(size_t)i].ref_id2, (int)f[(size_t)i].right));
+        }
+        for (int64_t i = 0; i < nf; ++i) {
+            const thj_fusion& a = f[(size_t)i];
+            for (int64_t k = i + 1; k < nf; ++k) {
+                const thj_fusion& b = f[(size_t)k];
+                int left_diff = abs((int)a.left - (int)b.left);
+                if (!(a.ref_id1 == b.ref_id1 && a.ref_id2 == b.ref_id2 && left_diff < 10)) break;
+                if (a.dir == b.dir && left_diff == abs((int)a.right - (int)b.right)) {
+                    if (b.count > a.count) skip[(size_t)i] = 1;
+                    else if (b.count == a.count) {
+                        int cc = lc[(size_t)i] + rc2[(size_t)i], nc = lc[(size_t)k] + rc2[(size_t)k];
+                        if (cc < nc) skip[(size_t)i] = 1; else skip[(size_t)k] = 1;
+                    } else skip[(size_t)k] = 1;
+                }
+            }
+            if (skip[(size_t)i] && !o.fusion_do_not_resolve_conflicts) continue;
+            const char* dir = a.dir == THJ_FUSION_FR ? "fr" : a.dir == THJ_FUSION_RF ? "rf" : a.dir == THJ_FUSION_RR ? "rr" : "ff";
+            fprintf(ff, "%s\t%d\t%s\t%d\t%s\n", rt.names[a.ref_id1 - 1].c_str(), (int)a.left, rt.names[a.ref_id2 - 1].c_str(), (int)a.right, dir);
+        }
+    }
     fclose(fj); fclose(fi); fclose(fd); fclose(ff);
     fprintf(stderr, "Reported %d total potential splices\n", (int)n.n_juncs);
     thj_ctx_destroy(ctx);

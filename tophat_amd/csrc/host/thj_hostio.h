@@ -38,7 +38,8 @@ namespace thjh {
 struct Opts {
     thj_params p;
     bool no_coverage_search = false, no_microexon_search = false, butterfly_search = false, fusion_search = false;
-    bool color = false, bowtie2 = true;
+    bool color = false, bowtie2 = true, fusion_do_not_resolve_conflicts = false;
+    std::string fusion_ignore;
     int num_threads = 1;
     std::string sam_header, ium_reads, zpacker;
 };
@@ -130,6 +131,10 @@ inline int parse_options(int argc, char** argv, Opts& o, void (*usage)()) {
         case 'p': case O_THREADS: o.num_threads = parse_int(1, "-p/--num-threads must be at least 1"); break;
         case 'z': case O_ZPACKER: o.zpacker = optarg; break;
         case O_FUSION: o.fusion_search = true; break;
+        case O_FUSION_ANCHOR: o.p.fusion_anchor_length = parse_int(10, "--fusion-anchor-length must be at least 10"); break;
+        case O_FUSION_MIN_DIST: o.p.fusion_min_dist = parse_int(0, "--fusion-min-dist must be at least 0"); break;
+        case O_FUSION_NO_RESOLVE: o.fusion_do_not_resolve_conflicts = true; break;
+        case O_FUSION_IGNORE: o.fusion_ignore = optarg; break;
         case O_BOWTIE1: o.bowtie2 = false; o.p.bowtie2 = 0; break;
         case O_B2_MAX_PEN: o.p.bowtie2_max_penalty = parse_int(0, "--bowtie2-max-penalty must be at least 0"); break;
         case O_B2_MIN_PEN: o.p.bowtie2_min_penalty = parse_int(0, "--bowtie2-min-penalty must be at least 0"); break;

@@ -68,6 +68,7 @@ struct Params {          // == thj_params (include/thj.h)
     int32_t read_mismatches, read_gap_length, read_edit_dist;
     int32_t bowtie2_max_penalty, bowtie2_min_penalty, bowtie2_penalty_for_N;
     int32_t bowtie2_read_gap_open, bowtie2_read_gap_cont, bowtie2_ref_gap_open, bowtie2_ref_gap_cont;
+    int32_t fusion_anchor_length, fusion_min_dist;
 };
 
 struct Planes { u64 lo, hi, nm; };
@@ -517,6 +518,167 @@ THJ_HD u64 ins_prio(uint32_t ordinal, int i, int li, int ri) {
     if (li > 63) li = 63;     // bowtie2 runs with -k 41 (tophat.py:2294): never reached in practice
     if (ri > 63) ri = 63;
     return ((u64)ordinal << 15) | ((u64)(i & 7) << 12) | ((u64)li << 6) | (u64)ri;
+}
+
+
+// ---- fusion search: find_fusions + detect_fusion (segment_juncs.cpp:2976-3291, :2629-2805) -------------------
+enum { FUS_FF = 7, FUS_FR = 8, FUS_RF = 9, FUS_RR = 10 };
+
+// `len` (<= 64) bases of the whole read (forward, or its reverse complement) starting at `off`
+THJ_HD Planes read_piece(const u64* rp, int W, int rl, bool rc, int off, int len) {
+    if (!rc) return r_fetch(rp, W, off, len);
+    return rc_piece(r_fetch(rp, W, rl - off - len, len), len);
+}
+// genomic string of detect_fusion: ref[start, start+rl) forward, or reverse-complemented (then piece `off` of the
+// string comes from the far end)
+THJ_HD Planes genomic_piece(const Genome& g, uint32_t ref, int64_t start, int rl, bool rc, int off, int len) {
+    if (!rc) return g_fetch(g, ref, start + off);
+    Planes p = g_fetch(g, ref, start + rl - off - len);
+    return rc_piece(p, len);
+}
+
+// detect_fusion with the whole-read simpleSplitAlignment (all tied best positions).  Sink: fusion(ref1,ref2,left,right,dir,ed).
+template <class Sink>
+THJ_HD void detect_fusion(const Genome& g, const Params& p, const u64* rp, int W, int rl, bool read_rc, const Hit& lh, const Hit& rh,
+                          int dir, Sink& sink) {
+    const int32_t llen = g_len(g, lh.ref_id), rlen = g_len(g, rh.ref_id);
+    if (llen == 0 || rlen == 0 || rl > 256) return;
+    int64_t lstart, rstart;
+    const bool lrc = !(dir == FUS_FF || dir == FUS_FR), rrc = !(dir == FUS_FF || dir == FUS_RF);
+    if (!lrc) { if (lh.left + rl > llen || lh.left < 0) return; lstart = lh.left; }
+    else { if (lh.right < rl || lh.right > llen) return; lstart = (int64_t)lh.right - rl; }
+    if (!rrc) { if (rh.right < rl || rh.right > rlen) return; rstart = (int64_t)rh.right - rl; }
+    else { if (rh.left + rl > rlen || rh.left < 0) return; rstart = rh.left; }
+    u64 mL[4] = {0, 0, 0, 0}, mR[4] = {0, 0, 0, 0};
+    int tot_r = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int off = w * 64;
+        if (off < rl) {
+            int l = rl - off < 64 ? rl - off : 64;
+            Planes rd = read_piece(rp, W, rl, read_rc, off, l);
+            Planes a = genomic_piece(g, lh.ref_id, lstart, rl, lrc, off, l);
+            Planes b = genomic_piece(g, rh.ref_id, rstart, rl, rrc, off, l);
+            u64 M = lowmask(l);
+            mL[w] = ((a.lo ^ rd.lo) | (a.hi ^ rd.hi) | a.nm | rd.nm) & M;     // 'N' on either side is an error (:2416-2418)
+            mR[w] = ((b.lo ^ rd.lo) | (b.hi ^ rd.hi) | b.nm | rd.nm) & M;
+            tot_r += popc(mR[w]);
+        }
+    }
+    // e(p) = afterErrors[p-1] + beforeErrors[p], p = 1..rl-1
+    auto bitL = [&](int i) { u64 x = i < 64 ? mL[0] : i < 128 ? mL[1] : i < 192 ? mL[2] : mL[3]; return (int)((x >> (i & 63)) & 1ull); };
+    auto bitR = [&](int i) { u64 x = i < 64 ? mR[0] : i < 128 ? mR[1] : i < 192 ? mR[2] : mR[3]; return (int)((x >> (i & 63)) & 1ull); };
+    int e = bitL(0) + tot_r - bitR(0);
+    int min_err = rl + 1;
+    {
+        int ee = e;
+        for (int q = 1; q < rl; ++q) { if (ee < min_err) min_err = ee; ee += bitL(q) - bitR(q); }
+    }
+    const int total_ed = hit_ed(lh) + hit_ed(rh);
+    if (min_err > total_ed) return;                                            // :2697-2699
+    if (min_err > 2) return;
+    {
+        int ee = e;
+        for (int q = 1; q < rl; ++q) {                                         // :2704-2713
+            if (ee == min_err && (q < p.fusion_anchor_length || rl - q < p.fusion_anchor_length)) return;
+            ee += bitL(q) - bitR(q);
+        }
+    }
+    int ee = e;
+    for (int q = 1; q < rl; ++q) {
+        if (ee == min_err) {
+            uint32_t left = !lrc ? (uint32_t)(lh.left + q - 1) : (uint32_t)(lh.right - q);
+            uint32_t right = !rrc ? (uint32_t)(rh.right - (rl - q)) : (uint32_t)(rh.left + (rl - q) - 1);
+            uint32_t r1 = lh.ref_id, r2 = rh.ref_id; int tdir = dir;
+            if (r2 < r1 || (r1 == r2 && left > right)) {                       // :2776-2789
+                uint32_t t = r1; r1 = r2; r2 = t;
+                t = left; left = right; right = t;
+                if (dir == FUS_FF) tdir = FUS_RR;
+            }
+            sink.fusion(r1, r2, left, right, (uint32_t)tdir, (uint32_t)total_ed);
+        }
+        ee += bitL(q) - bitR(q);
+    }
+}
+
+template <class Sink>
+THJ_HD void fusion_pair(const Genome& g, const Params& p, const u64* rp, int W, int rl, Hit lh, Hit rh, Sink& sink) {
+    if (p.bowtie2 && hit_ed(lh) + hit_ed(rh) > (p.segment_mismatches << 1)) return;      // :3222-3226
+    const int minus_dist = -p.max_insertion_length * 2;
+    if (lh.ref_id == rh.ref_id && hit_anti(lh) == hit_anti(rh)) {
+        int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
+        if (dist > minus_dist && dist <= p.fusion_min_dist) return;
+    }
+    int dir = FUS_FF;
+    bool rc = false;
+    if (hit_anti(lh) == hit_anti(rh)) {
+        if (hit_anti(lh)) { Hit t = lh; lh = rh; rh = t; rc = true; }           // :3266-3274
+    } else if (!hit_anti(lh) && hit_anti(rh)) dir = FUS_FR;
+    else dir = FUS_RF;
+    detect_fusion(g, p, rp, W, rl, rc, lh, rh, dir, sink);
+}
+
+// find_fusions for one read (all visited reads, incl. top == 0)
+template <class Sink>
+THJ_HD void fusion_read(const Genome& g, const Params& p, const ReadView& v, Sink& sink) {
+    if (v.nseg == 0) return;
+    int last = v.nseg - 1;
+    while (last > 0 && rv_count_raw(v, last) == 0) --last;
+    const uint32_t l0 = v.so[0], l1 = v.so[1];
+    if (last == 0 && (l0 == l1 || hit_end(v.hits[l0]))) return;                 // :3035-3037
+    const uint32_t r0 = last != 0 ? v.so[last] : 0, r1 = last != 0 ? v.so[last + 1] : 0;   // right_segment_hits (:3075-3080)
+    bool check_partner = true;
+    if (last != 0) {
+        for (uint32_t i = l0; i < l1 && check_partner; ++i) {
+            Hit lh = v.hits[i];
+            for (uint32_t j = r0; j < r1; ++j) {
+                Hit rh = v.hits[j];
+                if (lh.ref_id == rh.ref_id && hit_anti(lh) == hit_anti(rh)) {
+                    int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
+                    if (dist > -p.max_insertion_length && dist <= p.fusion_min_dist) { check_partner = false; break; }
+                }
+            }
+        }
+    }
+    // pairs with the real hits of the last segment
+    for (uint32_t i = l0; i < l1; ++i)
+        for (uint32_t j = r0; j < r1; ++j) fusion_pair(g, p, v.rp, v.W, v.rl, v.hits[i], v.hits[j], sink);
+    // mate-anchored pseudo-hits (:3117-3202): every one of them is then paired with every left hit
+    if (check_partner && v.n_mate > 0) {
+        const int minus_dist = -p.max_insertion_length * 2;
+        int cl = p.segment_length - p.segment_mismatches - 3; if (cl > 15) cl = 15;
+        for (uint32_t l = l0; l < l1; ++l) {
+            Hit lh = v.hits[l];
+            for (int m = 0; m < v.n_mate; ++m) {
+                Hit rh = v.mate[m];
+                if (lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) {
+                    int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
+                    if (dist > minus_dist && dist <= p.fusion_min_dist) continue;
+                }
+                int32_t clen = g_len(g, rh.ref_id);
+                if (clen == 0) continue;
+                int part = p.inner_dist_std_dev > p.inner_dist_mean ? p.inner_dist_std_dev - p.inner_dist_mean : 0;
+                int flank = p.inner_dist_mean + p.inner_dist_std_dev;
+                int64_t left;
+                if (hit_anti(rh)) { if (flank <= rh.left) left = rh.left - flank; else break; }
+                else { if (part <= rh.right) left = rh.right - part; else break; }
+                int64_t fe = left + flank + part; if (fe > clen) fe = clen;
+                int flen = (int)(fe - left); if (flen < 0) flen = 0;
+                if (cl < 1 || cl > v.rl) continue;
+                Planes fwd = r_fetch(v.rp, v.W, v.rl - cl, cl);
+                Planes rev = rc_piece(fwd, cl);
+                int fp = flank_scan(g, rh.ref_id, left, flen, fwd, cl);
+                int rvp = flank_scan(g, rh.ref_id, left, flen, rev, cl);
+                for (int k = 0; k < 2; ++k) {
+                    int pos = k == 0 ? fp : rvp;
+                    if (pos < 0) continue;
+                    Hit ph; ph.ref_id = rh.ref_id; ph.left = (int32_t)(left + pos); ph.right = ph.left + cl;
+                    ph.meta = (k == 0 ? 2u : 3u) | ((uint32_t)cl << 24);
+                    for (uint32_t i = l0; i < l1; ++i) fusion_pair(g, p, v.rp, v.W, v.rl, v.hits[i], ph, sink);
+                }
+            }
+        }
+    }
 }
 
 // ---- packed event keys ------------------------------------------------------

@@ -5,6 +5,7 @@
 #include <utility>
 #include <vector>
 
+#include "../../include/thj.h"
 #include "thj_core.h"
 #include "thj_internal.h"
 
@@ -56,6 +57,9 @@ struct thj_ctx {
     uint32_t* d_worklist = nullptr; int64_t worklist_cap = 0;
     bool span_profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;
+    // fusion search
+    thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
+    std::vector<thj_fusion> h_fusions;
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

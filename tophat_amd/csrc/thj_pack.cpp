@@ -36,6 +36,7 @@ extern "C" void thj_params_default(thj_params* p) {
     p->bowtie2_max_penalty = 6; p->bowtie2_min_penalty = 2; p->bowtie2_penalty_for_N = 1;
     p->bowtie2_read_gap_open = 5; p->bowtie2_read_gap_cont = 3;
     p->bowtie2_ref_gap_open = 5; p->bowtie2_ref_gap_cont = 3;
+    p->fusion_anchor_length = 20; p->fusion_min_dist = 10000000;
 }
 
 extern "C" int thj_genome_layout(int32_t n_contigs, const int64_t* lens, uint32_t* contig_blk, int64_t* n_blocks) {

@@ -20,6 +20,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -293,6 +294,25 @@ __global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBat
     }
 }
 
+// ------------------------------------------------------------------ fusion search
+
+struct FusionSink {
+    thj_fusion* buf; unsigned long long* count; unsigned long long cap; unsigned int* ovf;
+    __device__ __forceinline__ void fusion(uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) {
+        unsigned long long pos = atomicAdd(count, 1ull);
+        if (pos < cap) { thj_fusion f{r1, r2, l, r, dir, 1u, ed, 0u}; buf[pos] = f; }
+        else atomicExch(ovf, 1u);
+    }
+};
+
+// find_fusions + detect_fusion: 1 thread / read; candidate events are rare, they are appended raw and reduced on the host
+__global__ __launch_bounds__(256) void thj_k_fusion(Genome g, Params p, DevBatch b, FusionSink sink) {
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < b.n_reads; r += gridDim.x * blockDim.x) {
+        ReadView v = make_view(b, r);
+        fusion_read(g, p, v, sink);
+    }
+}
+
 // ------------------------------------------------------------------ finish
 
 __global__ __launch_bounds__(256) void thj_k_compact(const u64* tab, const u64* vals, u64 cap, u64* out_keys,
@@ -410,6 +430,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipHostFree(c->h_pinned);
     hipFree(c->d_npairs); hipFree(c->d_pair_off); hipFree(c->d_slots); hipFree(c->d_scan_tmp);
     thj_span_free(c);
+    hipFree(c->d_fus); hipFree(c->d_fus_count);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -641,6 +662,77 @@ extern "C" int thj_segjuncs_merge_keys_async(thj_ctx* c, int kind, const uint64_
         hipLaunchKernelGGL(thj_k_merge_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_del, (u64)c->indel_cap - 1,
                            (const u64*)d_keys, n, &c->d_cnt[CNT_DEL], &c->d_ovf[1]);
     HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_fusion_reset_async(thj_ctx* c) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_fus_count) {
+        HIPCHK(hipMalloc(&c->d_fus_count, 16));
+        c->fus_cap = 1 << 20;
+        HIPCHK(hipMalloc(&c->d_fus, (size_t)c->fus_cap * sizeof(thj_fusion)));
+    }
+    HIPCHK(hipMemsetAsync(c->d_fus_count, 0, 16, c->stream));
+    c->h_fusions.clear();
+    return THJ_OK;
+}
+
+extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db) {
+    if (!c || !tp || !db) { thj_set_error("thj_fusion_run_async: null argument"); return THJ_EINVAL; }
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    int rc = check_params(tp, db);
+    if (rc) return rc;
+    if (db->words_per_plane > 4) { thj_set_error("reads longer than 256 bases are not supported by the fusion kernel"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_fus_count) { rc = thj_fusion_reset_async(c); if (rc) return rc; }
+    if (db->n_reads == 0) return THJ_OK;
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    Params p; memcpy(&p, tp, sizeof p);
+    DevBatch b; memcpy(&b, db, sizeof b);
+    FusionSink sink{c->d_fus, c->d_fus_count, (unsigned long long)c->fus_cap, (unsigned int*)(c->d_fus_count + 1)};
+    int64_t blocks = ((int64_t)b.n_reads + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(thj_k_fusion, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b, sink);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_fusion_finish(thj_ctx* c, int64_t* n_fusions) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    c->h_fusions.clear();
+    if (c->d_fus_count) {
+        unsigned long long h[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(h, c->d_fus_count, 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((unsigned int)h[1]) { thj_set_error("fusion event buffer overflow (%llu candidate events, capacity %lld)", h[0], (long long)c->fus_cap); return THJ_EOVERFLOW; }
+        std::vector<thj_fusion> ev((size_t)h[0]);
+        if (h[0]) HIPCHK(hipMemcpy(ev.data(), c->d_fus, (size_t)h[0] * sizeof(thj_fusion), hipMemcpyDeviceToHost));
+        // FusionSimpleSet (segment_juncs.cpp:2791-2803): count the occurrences, keep the smallest edit distance;
+        // iteration order = Fusion::operator< (fusions.h:38-69)
+        auto less = [](const thj_fusion& a, const thj_fusion& b) {
+            if (a.ref_id1 != b.ref_id1) return a.ref_id1 < b.ref_id1;
+            if (a.ref_id2 != b.ref_id2) return a.ref_id2 < b.ref_id2;
+            if (a.left != b.left) return a.left < b.left;
+            if (a.right != b.right) return a.right < b.right;
+            return a.dir < b.dir;
+        };
+        std::sort(ev.begin(), ev.end(), less);
+        for (auto& e : ev) {
+            if (!c->h_fusions.empty() && !less(c->h_fusions.back(), e) && !less(e, c->h_fusions.back())) {
+                c->h_fusions.back().count += 1;
+                if (e.edit_dist < c->h_fusions.back().edit_dist) c->h_fusions.back().edit_dist = e.edit_dist;
+            } else c->h_fusions.push_back(e);
+        }
+    }
+    if (n_fusions) *n_fusions = (int64_t)c->h_fusions.size();
+    return THJ_OK;
+}
+
+extern "C" int thj_fusion_download(thj_ctx* c, thj_fusion* out) {
+    if (!c || (!c->h_fusions.empty() && !out)) { thj_set_error("thj_fusion_download: bad argument"); return THJ_EINVAL; }
+    if (!c->h_fusions.empty()) memcpy(out, c->h_fusions.data(), c->h_fusions.size() * sizeof(thj_fusion));
     return THJ_OK;
 }
 

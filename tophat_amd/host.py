@@ -20,6 +20,9 @@ LIB_PATH = os.path.join(HERE, "csrc", "libthj_hip.so")
 
 INS_CODE = "ACGTN"
 
+FUSION_DTYPE = np.dtype([("ref_id1", "<u4"), ("ref_id2", "<u4"), ("left", "<u4"), ("right", "<u4"), ("dir", "<u4"),
+                         ("count", "<u4"), ("edit_dist", "<u4"), ("skip", "<u4")])
+
 
 class ThjError(RuntimeError):
     pass
@@ -55,6 +58,7 @@ ABI_SYMBOLS = [
     "thj_segjuncs_finish", "thj_segjuncs_download", "thj_segjuncs_device_keys",
     "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
+    "thj_fusion_reset_async", "thj_fusion_run_async", "thj_fusion_finish", "thj_fusion_download",
 ]
 
 _lib = None
@@ -257,6 +261,19 @@ class Context:
         _check(self.lib, self.lib.thj_segjuncs_device_keys(self._ctx, kind, C.byref(p), C.byref(n)),
                "thj_segjuncs_device_keys")
         return (p.value or 0), n.value
+
+    def fusions(self, runs) -> np.ndarray:
+        """reset; thj_fusion_run_async for every (params, batch); finish; download -> FUSION_DTYPE array"""
+        _check(self.lib, self.lib.thj_fusion_reset_async(self._ctx), "thj_fusion_reset_async")
+        for p, b in runs:
+            cp = p.as_ctypes()
+            arg = C.byref(b) if isinstance(b, CSegBatch) else b
+            _check(self.lib, self.lib.thj_fusion_run_async(self._ctx, C.byref(cp), arg), "thj_fusion_run_async")
+        n = C.c_int64()
+        _check(self.lib, self.lib.thj_fusion_finish(self._ctx, C.byref(n)), "thj_fusion_finish")
+        out = np.zeros(max(1, n.value), dtype=FUSION_DTYPE)
+        _check(self.lib, self.lib.thj_fusion_download(self._ctx, _ptr(out)), "thj_fusion_download")
+        return out[:n.value]
 
     def device_insertions(self) -> Tuple[int, int, int]:
         k, v, n = C.c_void_p(), C.c_void_p(), C.c_int64()

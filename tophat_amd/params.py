@@ -47,6 +47,8 @@ class Params:
     bowtie2_read_gap_cont: int = 3    # common.cpp:91
     bowtie2_ref_gap_open: int = 5     # common.cpp:92
     bowtie2_ref_gap_cont: int = 3     # common.cpp:93
+    fusion_anchor_length: int = 20    # common.cpp:172
+    fusion_min_dist: int = 10000000   # common.cpp:173
 
     def as_ctypes(self) -> "CParams":
         c = CParams()

@@ -178,7 +178,8 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
               err: float = 0.01, indel_frac: float = 0.08, n_frac: float = 0.02,
               genes_per_contig: int = 12, intron_range=(60, 3000), inner_mean: int = 50,
               inner_sd: int = 20, repeat_frac: float = 0.0, drop_seg_frac: float = 0.03,
-              overhang: int = 3, spliced_seg_frac: float = 0.0, boundary_bias: float = 0.0, juncdb: bool = False) -> SynthCase:
+              overhang: int = 3, spliced_seg_frac: float = 0.0, boundary_bias: float = 0.0, juncdb: bool = False,
+              fusion_reads: int = 0) -> SynthCase:
     rng = random.Random(seed)
     names, seqs, genes = make_genome(rng, contig_lens, genes_per_contig, intron_range)
     # optional planted repeats -> multihits
@@ -362,6 +363,47 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
             emit("right", rid, g.exons, r_t0, r_anti, g.ref, rng.random() < indel_frac, g.strand)
         else:
             emit("left", rid, g.exons, t0, rng.random() < 0.5, g.ref, rng.random() < indel_frac, g.strand)
+    # chimeric (fusion) reads built the way fusion_test/testcases/generate_fasta does: two pieces taken from
+    # unrelated loci / strands, glued; segments that lie wholly inside one piece are mapped where that piece is
+    for _ in range(fusion_reads):
+        rid += 1
+        k = rng.randint(seg_len + 2, read_len - seg_len - 2)
+        parts = []
+        for ln in (k, read_len - k):
+            ci = rng.randrange(len(seqs))
+            pp = rng.randint(50, len(seqs[ci]) - read_len - 50)
+            st = rng.choice("+-")
+            g_ = seqs[ci][pp:pp + ln]
+            parts.append((ci, pp, st, ln, g_ if st == "+" else revcomp(g_)))
+        seq = _mutate(rng, parts[0][4] + parts[1][4], err / 2)
+        sd = "left"
+        case.reads[sd][rid] = seq
+        case.quals[sd][rid] = "I" * read_len
+        if paired:
+            case.reads["right"][rid] = "".join(rng.choice("ACGT") for _ in range(read_len))
+            case.quals["right"][rid] = "I" * read_len
+        for kk in range(nseg):
+            s0 = kk * seg_len
+            s1 = read_len if kk == nseg - 1 else (kk + 1) * seg_len
+            if s1 <= k:
+                ci, pp, st, ln, _ = parts[0]
+                o0, o1 = s0, s1
+            elif s0 >= k:
+                ci, pp, st, ln, _ = parts[1]
+                o0, o1 = s0 - k, s1 - k
+            else:
+                continue
+            gp = pp + o0 if st == "+" else pp + ln - o1
+            piece = seqs[ci][gp:gp + (s1 - s0)]
+            readpiece = seq[s0:s1] if st == "+" else revcomp(seq[s0:s1])
+            nm_, md = md_nm(piece, readpiece)
+            if nm_ > 2 or "N" in piece:
+                continue
+            anti = st == "-"
+            qn = "%d|%d:%d:%d" % (rid, s0, kk, nseg)
+            case.seg_sam[sd][kk].append("%s\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\n" % (
+                qn, 16 if anti else 0, names[ci], gp + 1, s1 - s0, readpiece, "I" * (s1 - s0), nm_, md))
+            case.seg_recs[sd][kk].append((rid, ci + 1, gp, gp + (s1 - s0), anti, kk == nseg - 1, nm_, nm_, s1 - s0, [(1, s1 - s0)], False))
     return case
 
 
