@@ -293,10 +293,16 @@ int thj_span_reset_async(thj_ctx* ctx);
 /* join_segments_for_read + sort/unique + filters + bowtie_sam_extra for every read of the
  * batch (long_spanning_reads.cpp:2612-2667, :2767-2831); records accumulate in HBM. */
 int thj_span_run_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* dev_batch);
-/* Orders the records as the reference's BAM (batch order of reads, operator< inside a
- * read) and synchronises.  THJ_EOVERFLOW when a device limit was hit (message says which). */
+/* Synchronises and returns the record count.  THJ_EOVERFLOW when a device limit was hit (message says which).
+ * On the device the records sit in BAM order already: one slot per read of the pass (run order, then read order)
+ * holding the read's first record, a per-read count, and the few extra records of multihit reads keyed by
+ * (slot << 16 | rank) -- rank = BowtieHit::operator< order inside the read (bwt_map.h:180-207). */
 int thj_span_finish(thj_ctx* ctx, int64_t* n_alns);
+/* Compact ordered host copy of the n_alns records. */
 int thj_span_download(thj_ctx* ctx, thj_aln* out);
+/* The device-resident layout described above (DEVICE pointers), for consumers that stay on the GPU. */
+int thj_span_device_records(thj_ctx* ctx, const thj_aln** d_slots, const uint8_t** d_counts, int64_t* n_reads,
+                            const thj_aln** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra);
 /* counts[0] = reads the last thj_span_run_async sent to the closure kernel thj_k_stitch, counts[1] = to the multihit kernel
   * thj_k_stitch_multihit; the rest were finished by thj_k_stitch_contig. */
 int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[2]*/);

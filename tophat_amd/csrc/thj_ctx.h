@@ -50,10 +50,11 @@ struct thj_ctx {
     u64* d_span_junc = nullptr; int64_t n_span_junc = 0; int64_t cap_span_junc = 0;
     u64* d_span_ins_key = nullptr; uint32_t* d_span_ins_seq = nullptr; int64_t n_span_ins = 0; int64_t cap_span_ins = 0;
     void* d_aln_pool = nullptr; void* d_aln_sorted = nullptr; int64_t aln_cap = 0;
-    u64* d_aln_keys = nullptr; u64* d_aln_keys2 = nullptr; uint32_t* d_aln_idx = nullptr; uint32_t* d_aln_idx2 = nullptr;
-    void* d_aln_sort_tmp = nullptr; size_t aln_sort_tmp_bytes = 0;
+    u64* d_aln_keys = nullptr;
     unsigned long long* d_aln_count = nullptr; unsigned int* d_span_status = nullptr;
-    int64_t n_alns = 0;
+    int64_t n_alns = 0, n_ovf = 0, span_reads = 0, ovf_cap = 0;
+    uint8_t* d_nrec = nullptr;
+    std::vector<thj_aln> h_alns;
     uint32_t* d_worklist = nullptr; int64_t worklist_cap = 0;
     bool span_profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;

@@ -1,17 +1,16 @@
 // thj_span.hip -- gfx950 kernel + C ABI for the long_spanning_reads hot path.
 //
-//   thj_k_stitch   1 thread / read   DFS over one hit per segment (dfs_seg_hits), closure of every
-//                                    adjacent pair through the sorted junction / insertion key arrays
-//                                    (merge_chain), edit-distance consistency, sort/unique/filter and
-//                                    the AS/XM/XO/XG/MD pass (bowtie_sam_extra); 128-byte records are
-//                                    appended to an HBM pool.
-//   thj_span_finish: hipcub radix sort of (read_idx, order) keys + thj_k_gather -> output order of
-//                    the reference's BAM (read order, BowtieHit::operator< inside a read).
+//   thj_k_stitch_contig / thj_k_stitch / thj_k_stitch_multihit: 1 thread / read, three tiers of the same
+//   algorithm -- DFS over one hit per segment (dfs_seg_hits), closure of every adjacent pair through the
+//   sorted junction / insertion key arrays (merge_chain), edit-distance consistency, sort/unique/filter and
+//   the AS/XM/XO/XG/MD pass (bowtie_sam_extra).  128-byte records land in one slot per read, so the device
+//   layout is already the order of the reference's BAM (read order, BowtieHit::operator< inside a read).
 // Integer / bit-plane work; no MFMA.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -34,38 +33,48 @@ struct DevSpanBatch {
 };
 static_assert(sizeof(DevSpanBatch) == sizeof(thj_span_batch), "span batch layout");
 
-struct PoolSink {
-    OutAln* pool; unsigned long long* count; unsigned long long cap; unsigned int* status;
-    __device__ __forceinline__ void emit(const OutAln& o) {
-        unsigned long long pos = atomicAdd(count, 1ull);
-        if (pos < cap) pool[pos] = o; else atomicExch(&status[3], 1u);
-    }
-    // a record assembled in registers as 32 words: eight 16-byte stores
+// Output layout: one 128-byte slot per read of the pass (batches in run order, reads in batch order) holding the
+// read's first record, a per-read record count, and a small overflow pool for the 2nd.. records of multihit reads.
+// Walking the slots in order IS the order of the reference's BAM (read order, BowtieHit::operator< inside a read),
+// so no sort or gather of the records is needed.
+struct RecSink {
+    OutAln* slots; uint8_t* nrec; uint32_t base;
+    OutAln* ovf; u64* ovf_key; unsigned long long* ovf_count; unsigned long long ovf_cap;
+    unsigned long long* total; unsigned int* status;
+    int emitted;       // per-thread: records emitted for the current read
     __device__ __forceinline__ void emit_words(const uint32_t* w) {
-        unsigned long long pos = atomicAdd(count, 1ull);
-        if (pos < cap) {
-            uint4* dst = (uint4*)(pool + pos);
+        ++emitted;
+        atomicAdd(total, 1ull);
+        const uint32_t order = w[5] >> 16;
+        uint4* dst;
+        if (order == 0) dst = (uint4*)(slots + (size_t)base + w[0]);
+        else {
+            unsigned long long pos = atomicAdd(ovf_count, 1ull);
+            if (pos >= ovf_cap) { atomicExch(&status[3], 1u); return; }
+            ovf_key[pos] = ((u64)(base + w[0]) << 16) | (u64)order;
+            dst = (uint4*)(ovf + pos);
+        }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
-        } else atomicExch(&status[3], 1u);
+        for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
     }
+    __device__ __forceinline__ void done(uint32_t r) { nrec[(size_t)base + r] = (uint8_t)emitted; emitted = 0; }
 };
 
 // Tier 0: every read.  Reads made of abutting single plain-match hits (unspliced reads cut into segments) are
 // finished here with a handful of registers; the others go to one of two worklists.
-__global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, PoolSink sink,
+__global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, RecSink sink,
                                                            uint32_t* wl_lean, uint32_t* wl_multi, unsigned int* counters) {
     for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < b.n_reads; r += gridDim.x * blockDim.x) {
         int st = span_read_contig(g, p, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                   (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
         if (st == SPAN_NEED_LEAN) wl_lean[atomicAdd(&counters[0], 1u)] = (uint32_t)r;
         else if (st == SPAN_NEED_GENERIC) wl_multi[atomicAdd(&counters[1], 1u)] = (uint32_t)r;
-        else if (st) atomicAdd(&sink.status[st], 1u);
+        else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
     }
 }
 
 // Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain.
-__global__ __launch_bounds__(256) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
+__global__ __launch_bounds__(256) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink,
                                                     const uint32_t* wl_lean, uint32_t* wl_multi, unsigned int* counters) {
     const unsigned int n = counters[0];
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -73,33 +82,21 @@ __global__ __launch_bounds__(256) void thj_k_stitch(Genome g, Params p, SpanSets
         int st = span_read_lean(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
         if (st == SPAN_NEED_GENERIC) wl_multi[atomicAdd(&counters[1], 1u)] = (uint32_t)r;
-        else if (st) atomicAdd(&sink.status[st], 1u);
+        else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
     }
 }
 
 // Tier 2: the general per-read DFS (multihit segments) over its worklist.
-__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, PoolSink sink,
+__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink,
                                                              const uint32_t* wl_multi, const unsigned int* counters) {
     const unsigned int n = counters[1];
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int r = (int)wl_multi[i];
         int st = span_read(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                            (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        sink.done((uint32_t)r);
         if (st) atomicAdd(&sink.status[st], 1u);
     }
-}
-
-__global__ __launch_bounds__(256) void thj_k_aln_keys(const OutAln* pool, int64_t n, u64* keys, uint32_t* idx) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        keys[i] = ((u64)pool[i].read_idx << 16) | (u64)pool[i].order;
-        idx[i] = (uint32_t)i;
-    }
-}
-
-__global__ __launch_bounds__(256) void thj_k_gather(const uint4* pool, const uint32_t* idx, int64_t n, uint4* out) {
-    // one 128-byte record = 8 x 16 B; 8 consecutive lanes move one record
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * 8; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = pool[(int64_t)idx[i >> 3] * 8 + (i & 7)];
 }
 
 __global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u64* vals, int64_t n, u64* okeys, uint32_t* oseq) {
@@ -111,18 +108,17 @@ __global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u6
 
 void thj_span_free(thj_ctx* c) {
     hipFree(c->d_span_junc); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq);
-    hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_aln_keys2);
-    hipFree(c->d_aln_idx); hipFree(c->d_aln_idx2); hipFree(c->d_aln_sort_tmp);
+    hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
 static int ensure_span_state(thj_ctx* c) {
     if (!c->d_aln_count) {
-        HIPCHK(hipMalloc(&c->d_aln_count, 8));
+        HIPCHK(hipMalloc(&c->d_aln_count, 16));
         HIPCHK(hipMalloc(&c->d_span_status, 8 * sizeof(unsigned int)));
-        HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 8, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_span_status, 0, 16, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 16, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_span_status, 0, 32, c->stream));
     }
     return THJ_OK;
 }
@@ -269,41 +265,40 @@ extern "C" int thj_span_reset_async(thj_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_span_state(c);
     if (rc) return rc;
-    HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 16, c->stream));       // [0] total records, [1] overflow-pool records
     HIPCHK(hipMemsetAsync(c->d_span_status, 0, 16, c->stream));
     c->n_alns = 0;
+    c->span_reads = 0;
+    c->h_alns.clear();
     return THJ_OK;
 }
 
-static int ensure_pool(thj_ctx* c, int64_t want) {
+// slots for `want` reads in this pass, preserving what earlier runs of the pass wrote
+static int ensure_slots(thj_ctx* c, int64_t want) {
     if (want <= c->aln_cap) return THJ_OK;
-    // grow, preserving what earlier runs of this pass appended
     HIPCHK(hipStreamSynchronize(c->stream));
-    int64_t ncap = want + want / 2 + 4096;
-    void* np_ = nullptr;
-    HIPCHK(hipMalloc(&np_, (size_t)ncap * 128));
-    if (c->d_aln_pool) {
-        unsigned long long cur = 0;
-        HIPCHK(hipMemcpy(&cur, c->d_aln_count, 8, hipMemcpyDeviceToHost));
-        if ((int64_t)cur > c->aln_cap) cur = (unsigned long long)c->aln_cap;
-        if (cur) HIPCHK(hipMemcpy(np_, c->d_aln_pool, (size_t)cur * 128, hipMemcpyDeviceToDevice));
-        hipFree(c->d_aln_pool);
+    int64_t ncap = want + want / 4 + 4096;
+    void* ns = nullptr; uint8_t* nn = nullptr;
+    HIPCHK(hipMalloc(&ns, (size_t)ncap * 128));
+    HIPCHK(hipMalloc(&nn, (size_t)ncap));
+    if (c->d_aln_pool && c->span_reads) {
+        HIPCHK(hipMemcpy(ns, c->d_aln_pool, (size_t)c->span_reads * 128, hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nn, c->d_nrec, (size_t)c->span_reads, hipMemcpyDeviceToDevice));
     }
-    c->d_aln_pool = np_;
-    hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_aln_keys2); hipFree(c->d_aln_idx); hipFree(c->d_aln_idx2);
-    hipFree(c->d_aln_sort_tmp);
-    c->d_aln_sorted = nullptr; c->d_aln_keys = c->d_aln_keys2 = nullptr; c->d_aln_idx = c->d_aln_idx2 = nullptr; c->d_aln_sort_tmp = nullptr;
-    HIPCHK(hipMalloc(&c->d_aln_sorted, (size_t)ncap * 128));
-    HIPCHK(hipMalloc(&c->d_aln_keys, (size_t)ncap * 8));
-    HIPCHK(hipMalloc(&c->d_aln_keys2, (size_t)ncap * 8));
-    HIPCHK(hipMalloc(&c->d_aln_idx, (size_t)ncap * 4));
-    HIPCHK(hipMalloc(&c->d_aln_idx2, (size_t)ncap * 4));
-    size_t need = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const u64*)nullptr, (u64*)nullptr, (const uint32_t*)nullptr,
-                                              (uint32_t*)nullptr, ncap, 0, 48, c->stream));
-    HIPCHK(hipMalloc(&c->d_aln_sort_tmp, need ? need : 16));
-    c->aln_sort_tmp_bytes = need;
-    c->aln_cap = ncap;
+    hipFree(c->d_aln_pool); hipFree(c->d_nrec);
+    c->d_aln_pool = ns; c->d_nrec = nn; c->aln_cap = ncap;
+    // overflow pool (2nd.. records of multihit reads): as many records again as there are slots
+    {
+        void* no = nullptr; u64* nk = nullptr;
+        HIPCHK(hipMalloc(&no, (size_t)ncap * 128));
+        HIPCHK(hipMalloc(&nk, (size_t)ncap * 8));
+        if (c->d_aln_sorted && c->ovf_cap) {
+            HIPCHK(hipMemcpy(no, c->d_aln_sorted, (size_t)c->ovf_cap * 128, hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(nk, c->d_aln_keys, (size_t)c->ovf_cap * 8, hipMemcpyDeviceToDevice));
+        }
+        hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys);
+        c->d_aln_sorted = no; c->d_aln_keys = nk; c->ovf_cap = ncap;
+    }
     return THJ_OK;
 }
 
@@ -326,14 +321,16 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     if ((rc = ensure_span_state(c))) return rc;
     if (db->n_reads == 0) return THJ_OK;
     if ((rc = ensure_sets_cap(c, c->n_span_junc, c->n_span_ins))) return rc;
-    // room for two records per read of this batch on top of what the pass already holds
-    if ((rc = ensure_pool(c, c->n_alns + 2 * (int64_t)db->n_reads + 1024))) return rc;
-    c->n_alns += 2 * (int64_t)db->n_reads;      // reservation watermark (actual count read back at finish)
+    if (c->span_reads + (int64_t)db->n_reads >= (1ll << 32)) { thj_set_error("more than 2^32 reads in one pass"); return THJ_EINVAL; }
+    if ((rc = ensure_slots(c, c->span_reads + (int64_t)db->n_reads))) return rc;
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevSpanBatch b; memcpy(&b, db, sizeof b);
     SpanSets S{c->d_span_junc, c->n_span_junc, c->d_span_ins_key, c->d_span_ins_seq, c->n_span_ins};
-    PoolSink sink{(OutAln*)c->d_aln_pool, c->d_aln_count, (unsigned long long)c->aln_cap, c->d_span_status};
+    const uint32_t base = (uint32_t)c->span_reads;
+    HIPCHK(hipMemsetAsync(c->d_nrec + base, 0, (size_t)b.n_reads, c->stream));
+    RecSink sink{(OutAln*)c->d_aln_pool, c->d_nrec, base, (OutAln*)c->d_aln_sorted, c->d_aln_keys, c->d_aln_count + 1,
+                 (unsigned long long)c->ovf_cap, c->d_aln_count, c->d_span_status, 0};
     if (c->worklist_cap < b.n_reads) {
         hipFree(c->d_worklist); c->d_worklist = nullptr;
         HIPCHK(hipMalloc(&c->d_worklist, (size_t)b.n_reads * 8));          // two lists
@@ -362,6 +359,7 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         c->span_prof_events.emplace_back(ev[2], ev[3]);
     }
     HIPCHK(hipGetLastError());
+    c->span_reads += b.n_reads;
     return THJ_OK;
 }
 
@@ -370,38 +368,69 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_span_state(c);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[24], c->d_aln_count, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[24], c->d_aln_count, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&c->h_pinned[26], c->d_span_status, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const unsigned int* st = (const unsigned int*)&c->h_pinned[26];
-    if (st[3]) { thj_set_error("alignment pool overflow: more than two spliced alignments per read on average"); return THJ_EOVERFLOW; }
+    if (st[3]) { thj_set_error("overflow pool full: more than %lld extra records from multihit reads in one pass", (long long)c->ovf_cap); return THJ_EOVERFLOW; }
     if (st[SPAN_TOO_MANY_JOINED]) {
         thj_set_error("%u read(s) have more than %d distinct joined alignments (device limit)", st[SPAN_TOO_MANY_JOINED], SPAN_MAXJOIN);
         return THJ_EOVERFLOW;
     }
     if (st[SPAN_MD_OVERFLOW]) { thj_set_error("%u alignment(s) need an MD string longer than 40 characters (device limit)", st[SPAN_MD_OVERFLOW]); return THJ_EOVERFLOW; }
-    const int64_t n = (int64_t)c->h_pinned[24];
-    c->n_alns = n;
-    if (n > 0) {
-        int64_t blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(thj_k_aln_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const OutAln*)c->d_aln_pool, n, c->d_aln_keys, c->d_aln_idx);
-        size_t tmp = c->aln_sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_aln_sort_tmp, tmp, (const u64*)c->d_aln_keys, c->d_aln_keys2,
-                                                  (const uint32_t*)c->d_aln_idx, c->d_aln_idx2, n, 0, 48, c->stream));
-        int64_t gb = (n * 8 + 255) / 256; if (gb > 4096) gb = 4096;
-        hipLaunchKernelGGL(thj_k_gather, dim3((unsigned)gb), dim3(256), 0, c->stream, (const uint4*)c->d_aln_pool,
-                           (const uint32_t*)c->d_aln_idx2, n, (uint4*)c->d_aln_sorted);
-        HIPCHK(hipStreamSynchronize(c->stream));
-    }
-    if (n_alns) *n_alns = n;
+    c->n_alns = (int64_t)c->h_pinned[24];
+    c->n_ovf = (int64_t)c->h_pinned[25];
+    c->h_alns.clear();
+    if (n_alns) *n_alns = c->n_alns;
+    return THJ_OK;
+}
+
+extern "C" int thj_span_device_records(thj_ctx* c, const thj_aln** d_slots, const uint8_t** d_counts, int64_t* n_reads,
+                                       const thj_aln** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra) {
+    if (!c || !d_slots || !d_counts || !n_reads) { thj_set_error("thj_span_device_records: bad argument"); return THJ_EINVAL; }
+    *d_slots = (const thj_aln*)c->d_aln_pool; *d_counts = c->d_nrec; *n_reads = c->span_reads;
+    if (d_extra) *d_extra = (const thj_aln*)c->d_aln_sorted;
+    if (d_extra_keys) *d_extra_keys = (const uint64_t*)c->d_aln_keys;
+    if (n_extra) *n_extra = c->n_ovf;
     return THJ_OK;
 }
 
 extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
+    // compact, ordered host copy: walk the slots, splice in the (rank-ordered) extra records of multihit reads
     if (!c || (c->n_alns > 0 && !out)) { thj_set_error("thj_span_download: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    if (c->n_alns > 0) HIPCHK(hipMemcpyAsync(out, c->d_aln_sorted, (size_t)c->n_alns * 128, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->n_alns == 0) return THJ_OK;
+    const int64_t nr = c->span_reads;
+    std::vector<uint8_t> cnt((size_t)nr);
+    HIPCHK(hipMemcpy(cnt.data(), c->d_nrec, (size_t)nr, hipMemcpyDeviceToHost));
+    std::vector<thj_aln> extra((size_t)c->n_ovf);
+    std::vector<uint64_t> ekey((size_t)c->n_ovf);
+    if (c->n_ovf) {
+        HIPCHK(hipMemcpy(extra.data(), c->d_aln_sorted, (size_t)c->n_ovf * 128, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ekey.data(), c->d_aln_keys, (size_t)c->n_ovf * 8, hipMemcpyDeviceToHost));
+    }
+    std::vector<uint32_t> eord((size_t)c->n_ovf);
+    for (size_t i = 0; i < eord.size(); ++i) eord[i] = (uint32_t)i;
+    std::sort(eord.begin(), eord.end(), [&](uint32_t a, uint32_t b) { return ekey[a] < ekey[b]; });
+    // slots come over in chunks so the staging buffer stays small
+    const int64_t CH = 1 << 20;
+    std::vector<thj_aln> buf((size_t)(nr < CH ? nr : CH));
+    int64_t w = 0; size_t e = 0;
+    for (int64_t r0 = 0; r0 < nr; r0 += CH) {
+        int64_t n = nr - r0 < CH ? nr - r0 : CH;
+        HIPCHK(hipMemcpy(buf.data(), (const thj_aln*)c->d_aln_pool + r0, (size_t)n * 128, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < n; ++k) {
+            if (!cnt[(size_t)(r0 + k)]) continue;
+            if (w >= c->n_alns) { thj_set_error("record count mismatch"); return THJ_ESTATE; }
+            out[w++] = buf[(size_t)k];
+            while (e < eord.size() && (ekey[eord[e]] >> 16) == (uint64_t)(r0 + k)) {
+                if (w >= c->n_alns) { thj_set_error("record count mismatch"); return THJ_ESTATE; }
+                out[w++] = extra[eord[e++]];
+            }
+        }
+    }
+    if (w != c->n_alns) { thj_set_error("record count mismatch (%lld of %lld)", (long long)w, (long long)c->n_alns); return THJ_ESTATE; }
     return THJ_OK;
 }
 

@@ -419,4 +419,4 @@ _span_methods()
 
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
                 "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
-                "thj_span_tier_counts"]
+                "thj_span_tier_counts", "thj_span_device_records"]
