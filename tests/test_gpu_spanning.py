@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("cfg", SPAN_CASES, ids=lambda c: "seed%d_rl%d_L%d" % (c["seed"], c["read_len"], c["seg_len"]))
 def test_spanning_matches_oracle(cfg):
-    case, p, seqs, g, sb, juncs, ins = span_inputs(cfg, n_reads=800)
+    case, p, seqs, g, sb, juncs, ins = span_inputs(cfg, n_reads=max(800, cfg.get("n_reads", 0)))
     want = orc.spanning(p, g, sb, juncs, ins)
     with host.Context(0) as ctx:
         ctx.upload_genome(host.pack_genome(seqs))
@@ -26,7 +26,7 @@ def test_pipeline_on_device_sets(tmp_path):
     """segment_juncs tables feed the stitch kernel device-to-device; same records as going through
     the host lists (what the .juncs/.deletions/.insertions files carry)."""
     cfg = SPAN_CASES[3]
-    case, p, seqs, g, sb, juncs, ins = span_inputs(cfg, n_reads=800)
+    case, p, seqs, g, sb, juncs, ins = span_inputs(cfg, n_reads=max(800, cfg.get("n_reads", 0)))
     want = orc.spanning(p, g, sb, juncs, ins)
     recs = [[h for h in seg if not any(o == 11 and n > p.max_report_intron for o, n in h[9])] for seg in case.seg_recs["left"]]
     b = build_seg_batch(recs, case.reads["left"])

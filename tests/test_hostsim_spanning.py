@@ -16,6 +16,9 @@ SPAN_CASES = [
          gen=dict(boundary_bias=0.7, spliced_seg_frac=0.5, n_frac=0.2, indel_frac=0.25)),
     dict(seed=5, read_len=50, seg_len=25, extra={}, gen=dict(boundary_bias=0.8, indel_frac=0.3)),
     dict(seed=6, read_len=100, seg_len=25, extra={}, gen=dict(boundary_bias=0.6, indel_frac=0.5, n_frac=0.3)),
+    # short exons: joined alignments with 4+ junctions (more cigar ops than the lean tier holds in registers)
+    dict(seed=7, read_len=200, seg_len=25, extra=dict(min_report_intron=30), n_reads=1500,
+         gen=dict(exon_range=(26, 40), intron_range=(40, 300), indel_frac=0.2, err=0.003, spliced_seg_frac=1.0)),
 ]
 
 
@@ -35,9 +38,11 @@ def span_inputs(cfg, n_reads=400):
 
 @pytest.mark.parametrize("cfg", SPAN_CASES, ids=lambda c: "seed%d_rl%d_L%d" % (c["seed"], c["read_len"], c["seg_len"]))
 def test_span_logic_matches_oracle(cfg):
-    case, p, seqs, g, sb, juncs, ins = span_inputs(cfg)
+    case, p, seqs, g, sb, juncs, ins = span_inputs(cfg, cfg.get("n_reads", 400))
     want = orc.spanning(p, g, sb, juncs, ins)
     assert len(want) > 50
+    if cfg["seed"] == 7:
+        assert sum(1 for a in want if sum(1 for c in a.cigar if c) > 8) > 50
     assert any(any((c >> 28) == 11 for c in a.cigar) for a in want), "no spliced alignment in the case"
     for mode in (0, 1):     # lean tier + generic fallback (what the kernels do), and the generic path alone
         got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)

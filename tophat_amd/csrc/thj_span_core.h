@@ -71,6 +71,67 @@ THJ_HD int cig_gap_len(const uint32_t* c, int n) {
     return g;
 }
 
+THJ_HD uint32_t cg(const Aln& a, int i) { return a.c[i]; }
+THJ_HD uint32_t cg_fixed(const Aln& a, int i) { return a.c[i]; }
+
+// ---- register-resident alignment of the lean tier -------------------------------------------------------
+// Up to LEAN_C cigar ops held in named registers: every access is an unrolled compare/select chain, so nothing
+// is indexed dynamically and nothing goes to scratch.  Reads that would need more ops go to the generic tier.
+static constexpr int LEAN_C = 8;
+struct RCig {
+    uint32_t v[LEAN_C];
+    THJ_HD uint32_t get(int i) const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int k = 0; k < LEAN_C; ++k) r = (i == k) ? v[k] : r;
+        return r;
+    }
+    THJ_HD void set(int i, uint32_t x) {
+#pragma unroll
+        for (int k = 0; k < LEAN_C; ++k) v[k] = (i == k) ? x : v[k];
+    }
+};
+struct RAln {
+    uint32_t ref_id; int32_t left, n;
+    RCig c;
+    int anti, asplice, mm, ed, rlen, valid;
+};
+THJ_HD uint32_t cg(const RAln& a, int i) { return a.c.get(i); }
+THJ_HD uint32_t cg_fixed(const RAln& a, int i) { return i < LEAN_C ? a.c.v[i < LEAN_C ? i : 0] : 0u; }
+THJ_HD int rc_ref_span(const RCig& c, int n) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < LEAN_C; ++k) {
+        int op = cig_op(c.v[k]);
+        if (k < n && (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL)) r += (int)cig_len(c.v[k]);
+    }
+    return r;
+}
+THJ_HD int rc_read_span(const RCig& c, int n) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < LEAN_C; ++k) {
+        int op = cig_op(c.v[k]);
+        if (k < n && (op == OP_MATCH || op == OP_INS || op == OP_SOFT_CLIP)) r += (int)cig_len(c.v[k]);
+    }
+    return r;
+}
+THJ_HD bool rc_spliced(const RCig& c, int n) {
+    bool r = false;
+#pragma unroll
+    for (int k = 0; k < LEAN_C; ++k) r = r || (k < n && cig_op(c.v[k]) == OP_REF_SKIP);
+    return r;
+}
+THJ_HD int rc_gap_len(const RCig& c, int n) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < LEAN_C; ++k) {
+        int op = cig_op(c.v[k]);
+        if (k < n && (op == OP_INS || op == OP_DEL)) r += (int)cig_len(c.v[k]);
+    }
+    return r;
+}
+
 struct SpanSets {
     const u64* junc_keys;  int64_t n_juncs;      // junc_key() order == Junction::operator<
     const u64* ins_keys;   const uint32_t* ins_seq; int64_t n_ins;   // ins_key() order; seq 3 bits/base
@@ -152,39 +213,36 @@ THJ_HD bool check_editdist(const Genome& g, const Aln& h, const SeqView& sv) {
 
 // ---- one adjacent pair of merge_chain's main loop (long_spanning_reads.cpp:900-1870) -------------
 // prev covers read bases [.., P) of the chain's forward sequence `sv`, curr covers [P, P+curr.rlen).
-// PAIR_KEEP: the two abut (dist == 0) and stay separate chain elements; PAIR_MERGED: `m` replaces both;
-// PAIR_FAIL: merge_chain returns BowtieHit().
-enum { PAIR_FAIL = 0, PAIR_KEEP = 1, PAIR_MERGED = 2 };
+// The search for the closing event is scalar work shared by every tier; how the two cigars are spliced is
+// left to the caller's representation (arrays in the generic tier, registers in the lean tier).
+enum { CL_FAIL = 0, CL_KEEP = 1, CL_INS = 2, CL_JUNC = 3 };
+struct Closure {
+    int kind;
+    int itpr, ilen;          // CL_INS: bases of prev's tail that move right of the insertion, insertion length
+    int dtl, skip, janti;    // CL_JUNC: boundary shift (-4..4), skipped reference bases, junction strand
+    int mismatch;            // change of the mismatch count
+};
 
-THJ_HD int close_pair(const Genome& g, const Params& p, const SpanSets& S, const SeqView& sv, int P, const Aln& prev,
-                      const Aln& curr, Aln& m) {
-    if (!(op_is_match(cig_op(prev.c[prev.n - 1])) || op_is_match(cig_op(curr.c[0])))) return PAIR_FAIL;     // :924-928
-    const bool psp = aln_spliced(prev), csp = aln_spliced(curr);
-    if (psp && csp && prev.asplice != curr.asplice) return PAIR_FAIL;                                        // :936-943
-    bool found = false;
-    int anti_closure = psp ? prev.asplice : curr.asplice;
-    uint32_t nc[SPAN_MAXC + 8]; int nn = 0;
-    int new_left = -1, mismatch = 0;
-    const int prev_end_len = (int)cig_len(prev.c[prev.n - 1]);
-    const int curr_front_len = (int)cig_len(curr.c[0]);
-    if (prev.ref_id != curr.ref_id) return PAIR_FAIL;      // check_fusion with an empty fusion set (:1596-1818)
-    const uint32_t ref = prev.ref_id;
-    const int prev_right = aln_right(prev);
-    const int lbnd = prev_right - 4, rbnd = curr.left + 4;
-    const int dist = curr.left - prev_right;
-    if (dist < 0 && dist >= -p.max_insertion_length && prev.anti == curr.anti) {
+THJ_HD Closure closure_search(const Genome& g, const Params& p, const SpanSets& S, const SeqView& sv, int P, uint32_t ref,
+                              int prev_right, int prev_end_len, int curr_left, int curr_front_len, bool same_strand) {
+    Closure cl;
+    cl.kind = CL_FAIL; cl.itpr = cl.ilen = cl.dtl = cl.skip = cl.janti = cl.mismatch = 0;
+    const int lbnd = prev_right - 4, rbnd = curr_left + 4;
+    const int dist = curr_left - prev_right;
+    if (dist < 0 && dist >= -p.max_insertion_length && same_strand) {
         // ---- insertion closure :1010-1306
-        if (g_len(g, ref) == 0) return PAIR_FAIL;
+        if (g_len(g, ref) == 0) return cl;
         int64_t lb = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)lbnd, 0));
         int64_t ub = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)rbnd, p.max_insertion_length));
         const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
+        bool found = false;
         for (; lb < ub; ++lb) {
             const u64 k = S.ins_keys[lb];
             const int ilen = (int)(k & 15);
             const int ileft = (int)((int64_t)(k >> 4) - 1 - (int64_t)cbase);
-            if (ilen != prev_right - curr.left) continue;
+            if (ilen != prev_right - curr_left) continue;
             const int itpr = prev_right - ileft - 1;
-            const int clti = ileft - curr.left + 1;
+            const int clti = ileft - curr_left + 1;
             if (itpr > prev_end_len || clti > curr_front_len) continue;
             const uint32_t iseq = S.ins_seq[lb];
             int trm = 0, ins_mm = 0;
@@ -204,7 +262,7 @@ THJ_HD int close_pair(const Genome& g, const Params& p, const SpanSets& S, const
                 }
             }
             if (clti > 0) {
-                Planes rf = g_fetch(g, ref, curr.left);                 // ref[curr.left, ileft+1)
+                Planes rf = g_fetch(g, ref, curr_left);                 // ref[curr.left, ileft+1)
                 for (int ri = 0; ri < clti; ++ri) {
                     int sp = clti - ri - 1, ip = ilen - ri - 1;
                     int r = plane_code(rf, sp);
@@ -219,27 +277,17 @@ THJ_HD int close_pair(const Genome& g, const Params& p, const SpanSets& S, const
                     }
                 }
             }
-            if (found) return PAIR_FAIL;                                               // :1243-1247
+            if (found) { cl.kind = CL_FAIL; return cl; }                               // :1243-1247
             if (ins_mm == 0) {
-                mismatch = -trm;
                 found = true;
-                new_left = prev.left;
-                nn = prev.n;
-                for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
-                uint32_t bl = (cig_len(nc[nn - 1]) - (uint32_t)itpr) & 0x0FFFFFFFu;
-                if (bl == 0) --nn; else nc[nn - 1] = cig(cig_op(nc[nn - 1]), bl);
-                nc[nn++] = cig(OP_INS, (uint32_t)ilen);
-                uint32_t fl = (cig_len(curr.c[0]) + (uint32_t)(itpr - ilen)) & 0x0FFFFFFFu;
-                for (int q = fl > 0 ? 0 : 1; q < curr.n; ++q) {
-                    if (nn >= SPAN_MAXC + 8) return PAIR_FAIL;
-                    nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), fl) : curr.c[q];
-                }
+                cl.kind = CL_INS; cl.itpr = itpr; cl.ilen = ilen; cl.mismatch = -trm;
             }
         }
-        if (!found) return PAIR_FAIL;
-    } else if (dist > 0 && dist <= p.max_report_intron && prev.anti == curr.anti) {
+        return cl;                                                                     // CL_FAIL unless found
+    }
+    if (dist > 0 && dist <= p.max_report_intron && same_strand) {
         // ---- junction / deletion closure :1311-1591
-        if (g_len(g, ref) == 0) return PAIR_FAIL;
+        if (g_len(g, ref) == 0) return cl;
         int64_t lb = upper_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true));
         int64_t ub = lower_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false));
         const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
@@ -248,14 +296,13 @@ THJ_HD int close_pair(const Genome& g, const Params& p, const SpanSets& S, const
             const u64 k = S.junc_keys[lb];
             const int jl = (int)((int64_t)(k >> 30) - 1 - (int64_t)cbase);
             const int jr = jl + (int)((k >> 1) & ((1ull << 29) - 1));
-            const int janti = (int)(k & 1ull);
-            const int dtl = jl - prev_right + 1, dtr = jr - curr.left;
+            const int dtl = jl - prev_right + 1, dtr = jr - curr_left;
             if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
             if (dtl > curr_front_len || -dtl > prev_end_len) continue;
             int new_mm = 0, old_mm = 0;
             if (dtl > 0) {
                 Planes nr = g_fetch(g, ref, prev_right);      // new_cmp = ref[prev_right, jl+1)
-                Planes orf = g_fetch(g, ref, curr.left);      // old_cmp = ref[curr.left, jr)
+                Planes orf = g_fetch(g, ref, curr_left);      // old_cmp = ref[curr.left, jr)
                 for (int i = 0; i < dtl; ++i) {
                     int s = seq_code(sv, P + i);               // curr.seq[i]; raw char vs Dna5: N == N
                     if (s != plane_code(nr, i)) ++new_mm;
@@ -274,35 +321,56 @@ THJ_HD int close_pair(const Genome& g, const Params& p, const SpanSets& S, const
             int diff = new_mm - old_mm;
             if (diff >= best_diff || new_mm >= 2) continue;
             best_diff = diff;
-            new_left = prev.left;
-            nn = prev.n;
-            for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
-            int nlb = (int)cig_len(nc[nn - 1]) + dtl;
-            int nrf = (int)cig_len(curr.c[0]) - dtr;
-            if (nlb > 0) nc[nn - 1] = cig(cig_op(nc[nn - 1]), (uint32_t)nlb); else --nn;
-            uint32_t skip = (uint32_t)(jr - jl - 1);
-            if (skip <= (uint32_t)p.max_deletion_length) {
-                nc[nn++] = cig(OP_DEL, skip);
-                anti_closure = psp ? prev.asplice : curr.asplice;
-            } else {
-                nc[nn++] = cig(OP_REF_SKIP, skip);
-                anti_closure = janti;
-            }
-            for (int q = nrf > 0 ? 0 : 1; q < curr.n; ++q) {
-                if (nn >= SPAN_MAXC + 8) return PAIR_FAIL;
-                nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), (uint32_t)nrf) : curr.c[q];
-            }
-            mismatch = best_diff;
-            found = true;
+            cl.kind = CL_JUNC; cl.dtl = dtl; cl.skip = jr - jl - 1; cl.janti = (int)(k & 1ull); cl.mismatch = diff;
         }
-        if (!found) return PAIR_FAIL;
-    } else if (!(dist == 0 && prev.anti == curr.anti))
-        return PAIR_FAIL;                                   // check_fusion, empty fusion set
+        return cl;                                                                     // CL_FAIL unless found
+    }
+    if (dist == 0 && same_strand) cl.kind = CL_KEEP;       // anything else: check_fusion with an empty fusion set
+    return cl;
+}
 
-    if (!found) return PAIR_KEEP;
+// PAIR_KEEP: the two abut (dist == 0) and stay separate chain elements; PAIR_MERGED: `m` replaces both;
+// PAIR_FAIL: merge_chain returns BowtieHit().
+enum { PAIR_FAIL = 0, PAIR_KEEP = 1, PAIR_MERGED = 2 };
+
+THJ_HD int close_pair(const Genome& g, const Params& p, const SpanSets& S, const SeqView& sv, int P, const Aln& prev,
+                      const Aln& curr, Aln& m) {
+    if (!(op_is_match(cig_op(prev.c[prev.n - 1])) || op_is_match(cig_op(curr.c[0])))) return PAIR_FAIL;     // :924-928
+    const bool psp = aln_spliced(prev), csp = aln_spliced(curr);
+    if (psp && csp && prev.asplice != curr.asplice) return PAIR_FAIL;                                        // :936-943
+    if (prev.ref_id != curr.ref_id) return PAIR_FAIL;      // check_fusion with an empty fusion set (:1596-1818)
+    const Closure cl = closure_search(g, p, S, sv, P, prev.ref_id, aln_right(prev), (int)cig_len(prev.c[prev.n - 1]), curr.left,
+                                      (int)cig_len(curr.c[0]), prev.anti == curr.anti);
+    if (cl.kind == CL_FAIL) return PAIR_FAIL;
+    if (cl.kind == CL_KEEP) return PAIR_KEEP;
+    int anti_closure = psp ? prev.asplice : curr.asplice;
+    uint32_t nc[SPAN_MAXC + 8];
+    int nn = prev.n;
+    for (int q = 0; q < prev.n; ++q) nc[q] = prev.c[q];
+    int first;                 // 0: curr's first op survives (with length `flen`), 1: it is consumed
+    uint32_t flen;
+    if (cl.kind == CL_INS) {
+        uint32_t bl = (cig_len(nc[nn - 1]) - (uint32_t)cl.itpr) & 0x0FFFFFFFu;
+        if (bl == 0) --nn; else nc[nn - 1] = cig(cig_op(nc[nn - 1]), bl);
+        nc[nn++] = cig(OP_INS, (uint32_t)cl.ilen);
+        flen = (cig_len(curr.c[0]) + (uint32_t)(cl.itpr - cl.ilen)) & 0x0FFFFFFFu;
+        first = flen > 0 ? 0 : 1;
+    } else {
+        int nlb = (int)cig_len(nc[nn - 1]) + cl.dtl;
+        int nrf = (int)cig_len(curr.c[0]) - cl.dtl;
+        if (nlb > 0) nc[nn - 1] = cig(cig_op(nc[nn - 1]), (uint32_t)nlb); else --nn;
+        if ((uint32_t)cl.skip <= (uint32_t)p.max_deletion_length) nc[nn++] = cig(OP_DEL, (uint32_t)cl.skip);
+        else { nc[nn++] = cig(OP_REF_SKIP, (uint32_t)cl.skip); anti_closure = cl.janti; }
+        flen = (uint32_t)nrf;
+        first = nrf > 0 ? 0 : 1;
+    }
+    for (int q = first; q < curr.n; ++q) {
+        if (nn >= SPAN_MAXC + 8) return PAIR_FAIL;
+        nc[nn++] = q == 0 ? cig(cig_op(curr.c[0]), flen) : curr.c[q];
+    }
     if (nn > SPAN_MAXC) return PAIR_FAIL;                   // capacity (documented limit)
-    int mismatches = (int)prev.mm + (int)curr.mm + mismatch;                           // :1822-1870
-    m.ref_id = prev.ref_id; m.left = new_left; m.n = nn;
+    int mismatches = (int)prev.mm + (int)curr.mm + cl.mismatch;                        // :1822-1870
+    m.ref_id = prev.ref_id; m.left = prev.left; m.n = nn;
     for (int q = 0; q < nn; ++q) m.c[q] = nc[q];
     m.anti = prev.anti; m.asplice = (uint8_t)anti_closure;
     m.mm = (uint8_t)mismatches;
@@ -386,17 +454,18 @@ THJ_HD bool merge_chain(const Genome& g, const Params& p, const SpanSets& S, con
 }
 
 // valid_hit (long_spanning_reads.cpp:2045-2099)
-THJ_HD bool valid_hit(const Params& p, const Aln& h) {
+template <class A>
+THJ_HD bool valid_hit(const Params& p, const A& h) {
     if (!h.valid) return false;
     for (int i = 1; i < h.n; ++i) {
-        int cop = cig_op(h.c[i]), pop = cig_op(h.c[i - 1]);
-        uint32_t len = cig_len(h.c[i]);
+        int cop = cig_op(cg(h, i)), pop = cig_op(cg(h, i - 1));
+        uint32_t len = cig_len(cg(h, i));
         if (!op_is_match(cop) && !op_is_match(pop)) return false;
         if (cop == OP_INS && len > (uint32_t)p.max_insertion_length) return false;
         if (cop == OP_DEL && len > (uint32_t)p.max_deletion_length) return false;
         if (cop == OP_REF_SKIP && len < (uint32_t)p.min_report_intron) return false;
     }
-    return op_is_match(cig_op(h.c[0])) && op_is_match(cig_op(h.c[h.n - 1]));
+    return op_is_match(cig_op(cg(h, 0))) && op_is_match(cig_op(cg(h, h.n - 1)));
 }
 
 THJ_HD Aln aln_from_hit(const SpanHit& h, int seg, int L, int rl) {
@@ -468,14 +537,16 @@ struct Extras { int AS, XM, XO, XG, both_n; MdBuf md; };
 // bowtie_sam_extra (bwt_map.cpp:2467-2648).  qual = this read's phred+33 bytes; qual_rev: the joined hit's
 // qual is the reversed read qual (merge_chain :1966-1978).  Also counts the N==N positions, which is what
 // check_editdist_consistency (:2349-2465) needs beside XM.  Returns false when the MD string does not fit.
-THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqView& sv, const uint8_t* qual, int qlen,
+template <class A>
+THJ_HD bool sam_extra(const Genome& g, const Params& p, const A& h, const SeqView& sv, const uint8_t* qual, int qlen,
                       bool qual_rev, Extras& e) {
     int pos_seq = 0, pos_mm = 0, mismatch = 0, opens = 0, conts = 0, AS = 0, both_n = 0;
     int64_t pos_ref = h.left;
     md_init(e.md);
     for (int i = 0; i < h.n; ++i) {
-        int op = cig_op(h.c[i]);
-        int len = (int)cig_len(h.c[i]);
+        const uint32_t ci = cg(h, i);
+        int op = cig_op(ci);
+        int len = (int)cig_len(ci);
         if (op == OP_MATCH) {
             for (int off = 0; off < len; off += 64) {
                 int l = len - off < 64 ? len - off : 64;
@@ -529,15 +600,15 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const Aln& h, const SeqV
 }
 
 // one 128-byte thj_aln record assembled in registers (layout of OutAln) and handed to the sink as 32 words
-template <class Sink>
-THJ_HD void emit_aln(Sink& sink, uint32_t read_idx, int order, const Aln& h, const Extras& e) {
+template <class Sink, class A>
+THJ_HD void emit_aln(Sink& sink, uint32_t read_idx, int order, const A& h, const Extras& e) {
     uint32_t wds[32];
     wds[0] = read_idx; wds[1] = h.ref_id; wds[2] = (uint32_t)h.left;
     wds[3] = (h.anti ? 1u : 0u) | (h.asplice ? 4u : 0u) | ((uint32_t)h.mm << 8) | ((uint32_t)h.ed << 16) | ((uint32_t)h.n << 24);
     wds[4] = ((uint32_t)e.AS & 0xFFFFu) | ((uint32_t)(e.XM & 0xFF) << 16) | ((uint32_t)(e.XO & 0xFF) << 24);
     wds[5] = (uint32_t)(e.XG & 0xFF) | ((uint32_t)e.md.len << 8) | ((uint32_t)(order & 0xFFFF) << 16);
 #pragma unroll
-    for (int q = 0; q < SPAN_MAXC; ++q) wds[6 + q] = q < h.n ? h.c[q] : 0u;
+    for (int q = 0; q < SPAN_MAXC; ++q) wds[6 + q] = q < h.n ? cg_fixed(h, q) : 0u;
 #pragma unroll
     for (int q = 0; q < 5; ++q) { wds[22 + 2 * q] = (uint32_t)e.md.w[q]; wds[23 + 2 * q] = (uint32_t)(e.md.w[q] >> 32); }
     sink.emit_words(wds);
@@ -639,6 +710,40 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
 // chain, merge_chain runs as a stream (accumulated output + previous element + current hit), nothing to
 // sort/unique, and the edit-distance consistency check (bwt_map.cpp:2349-2465) shares its plane pass with
 // bowtie_sam_extra (:2467-2648).  Any other read returns SPAN_NEED_GENERIC and goes to span_read.
+THJ_HD RAln raln_from_hit(const SpanHit& h, int seg, int L, int rl) {
+    RAln a;
+    a.ref_id = h.ref_id; a.left = h.left;
+    a.n = (int)(h.meta >> 24); if (a.n > 5) a.n = 5;
+#pragma unroll
+    for (int i = 0; i < LEAN_C; ++i) a.c.v[i] = (i < 5 && i < a.n) ? h.cigar[i < 5 ? i : 0] : 0u;
+    a.anti = (h.meta & SH_ANTI) ? 1 : 0; a.asplice = (h.meta & SH_ASPLICE) ? 1 : 0;
+    a.mm = (int)((h.meta >> 8) & 0xFF); a.ed = (int)((h.meta >> 16) & 0xFF);
+    int st = seg * L; if (st > rl) st = rl;
+    int ln = (h.meta & SH_END) ? rl - st : L; if (ln > rl - st) ln = rl - st;
+    a.rlen = ln; a.valid = 1;
+    return a;
+}
+
+// final concatenation of merge_chain (:1888-1944) on registers; 0 = ok, 1 = merge_chain fails, 2 = out of ops
+struct RChainOut { RCig c; int n; bool saw_as, saw_s; int num_mm; };
+THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
+    o.num_mm += e.mm;
+    if (rc_spliced(e.c, e.n)) {
+        if (e.asplice) { if (o.saw_s) return 1; o.saw_as = true; }
+        else { if (o.saw_as) return 1; o.saw_s = true; }
+    }
+    int b0 = 0;
+    if (o.n > 0) {
+        const uint32_t last = o.c.get(o.n - 1);
+        if (cig_op(last) == cig_op(e.c.v[0])) { o.c.set(o.n - 1, cig(cig_op(last), cig_len(last) + cig_len(e.c.v[0]))); b0 = 1; }
+    }
+    if (o.n + e.n - b0 > LEAN_C) return 2;
+#pragma unroll
+    for (int b = 0; b < LEAN_C; ++b)
+        if (b >= b0 && b < e.n) o.c.set(o.n++, e.c.v[b]);
+    return 0;
+}
+
 template <class Sink>
 THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, const uint32_t* so, int nseg,
                           const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
@@ -651,55 +756,96 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     const int L = p.segment_length;
     const SpanHit h0 = hits[so[0]];
     const bool anti = (h0.meta & SH_ANTI) != 0;
-    Aln res;
-    bool have = false;
+    RAln res;
     if (nsegs == 1) {
-        res = aln_from_hit(h0, 0, L, rl);
-        have = true;
+        res = raln_from_hit(h0, 0, L, rl);
     } else {
         // dfs_seg_hits compatibility of the single candidate per segment (:2352-2378, :2531-2556)
         int old_read_length = 0, num_fusions = 0;
         {
-            Aln prev = aln_from_hit(h0, 0, L, rl);
-            old_read_length = aln_read_len(prev);
+            RAln prev = raln_from_hit(h0, 0, L, rl);
+            int prev_right = prev.left + rc_ref_span(prev.c, prev.n);
+            old_read_length = rc_read_span(prev.c, prev.n);
             for (int s = 1; s < nsegs; ++s) {
-                Aln cand = aln_from_hit(hits[so[s]], s, L, rl);
+                RAln cand = raln_from_hit(hits[so[s]], s, L, rl);
+                const int cand_right = cand.left + rc_ref_span(cand.c, cand.n);
                 if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return SPAN_OK;
-                int dist = prev.anti ? prev.left - aln_right(cand) : cand.left - aln_right(prev);
+                int dist = prev.anti ? prev.left - cand_right : cand.left - prev_right;
                 if (dist > p.max_report_intron || dist < -p.max_insertion_length) return SPAN_OK;
                 if (gap_is_fusion_like(p, dist)) ++num_fusions;          // merge_chain pre-check (:843-891): same gaps, chain order
-                old_read_length += aln_read_len(cand);
-                prev = cand;
+                old_read_length += rc_read_span(cand.c, cand.n);
+                prev.ref_id = cand.ref_id; prev.anti = cand.anti; prev.left = cand.left; prev_right = cand_right;
             }
         }
         if (num_fusions >= 2) return SPAN_OK;
         SeqView sv = anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
-        ChainOut co;
-        chain_out_init(co);
-        int k0 = anti ? nsegs - 1 : 0, step = anti ? -1 : 1;
-        Aln prev = aln_from_hit(hits[so[k0]], k0, L, rl);
+        RChainOut co;
+#pragma unroll
+        for (int k = 0; k < LEAN_C; ++k) co.c.v[k] = 0;
+        co.n = 0; co.saw_as = co.saw_s = false; co.num_mm = 0;
+        const int k0 = anti ? nsegs - 1 : 0, step = anti ? -1 : 1;
+        RAln prev = raln_from_hit(hits[so[k0]], k0, L, rl);
         const int left0 = prev.left;
         int P = prev.rlen;
-        bool ok = true;
-        for (int q = 1; q < nsegs && ok; ++q) {
-            int k = k0 + q * step;
-            Aln curr = aln_from_hit(hits[so[k]], k, L, rl);
-            Aln m;
-            int r = close_pair(g, p, S, sv, P, prev, curr, m);
-            if (r == PAIR_FAIL) { ok = false; break; }
+        for (int q = 1; q < nsegs; ++q) {
+            const int k = k0 + q * step;
+            const RAln curr = raln_from_hit(hits[so[k]], k, L, rl);
+            // merge_chain's main loop, one adjacent pair (:900-1870)
+            const uint32_t plast = prev.c.get(prev.n - 1), cfirst = curr.c.v[0];
+            if (!(op_is_match(cig_op(plast)) || op_is_match(cig_op(cfirst)))) return SPAN_OK;               // :924-928
+            const bool psp = rc_spliced(prev.c, prev.n), csp = rc_spliced(curr.c, curr.n);
+            if (psp && csp && prev.asplice != curr.asplice) return SPAN_OK;                                  // :936-943
+            if (prev.ref_id != curr.ref_id) return SPAN_OK;
+            const Closure cl = closure_search(g, p, S, sv, P, prev.ref_id, prev.left + rc_ref_span(prev.c, prev.n), (int)cig_len(plast),
+                                              curr.left, (int)cig_len(cfirst), prev.anti == curr.anti);
+            if (cl.kind == CL_FAIL) return SPAN_OK;
             P += curr.rlen;
-            if (r == PAIR_MERGED) prev = m;
-            else { if (!chain_out_add(co, prev)) { ok = false; break; } prev = curr; }
+            if (cl.kind == CL_KEEP) {
+                const int rc = rchain_add(co, prev);
+                if (rc) return rc == 2 ? SPAN_NEED_GENERIC : SPAN_OK;
+                prev = curr;
+                continue;
+            }
+            if (prev.n + 1 + curr.n > LEAN_C) return SPAN_NEED_GENERIC;
+            int anti_closure = psp ? prev.asplice : curr.asplice;
+            int nn = prev.n, first;
+            uint32_t flen;
+            if (cl.kind == CL_INS) {
+                const uint32_t bl = (cig_len(plast) - (uint32_t)cl.itpr) & 0x0FFFFFFFu;
+                if (bl == 0) --nn; else prev.c.set(nn - 1, cig(cig_op(plast), bl));
+                prev.c.set(nn++, cig(OP_INS, (uint32_t)cl.ilen));
+                flen = (cig_len(cfirst) + (uint32_t)(cl.itpr - cl.ilen)) & 0x0FFFFFFFu;
+                first = flen > 0 ? 0 : 1;
+            } else {
+                const int nlb = (int)cig_len(plast) + cl.dtl, nrf = (int)cig_len(cfirst) - cl.dtl;
+                if (nlb > 0) prev.c.set(nn - 1, cig(cig_op(plast), (uint32_t)nlb)); else --nn;
+                if ((uint32_t)cl.skip <= (uint32_t)p.max_deletion_length) prev.c.set(nn++, cig(OP_DEL, (uint32_t)cl.skip));
+                else { prev.c.set(nn++, cig(OP_REF_SKIP, (uint32_t)cl.skip)); anti_closure = cl.janti; }
+                flen = (uint32_t)nrf;
+                first = nrf > 0 ? 0 : 1;
+            }
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+                if (b >= first && b < curr.n) prev.c.set(nn++, b == 0 ? cig(cig_op(cfirst), flen) : curr.c.v[b]);
+            const int mismatches = prev.mm + curr.mm + cl.mismatch;                                          // :1822-1870
+            prev.n = nn; prev.asplice = anti_closure;
+            prev.mm = mismatches & 0xFF;
+            prev.ed = (mismatches + rc_gap_len(prev.c, nn)) & 0xFF;
+            prev.rlen += curr.rlen;
         }
-        if (!ok || !chain_out_add(co, prev)) return SPAN_OK;
-        chain_out_finish(co, h0.ref_id, left0, anti ? 1 : 0, rl);
-        if (aln_read_len(co.out) != old_read_length) return SPAN_OK;
-        res = co.out;
-        have = true;
+        {
+            const int rc = rchain_add(co, prev);
+            if (rc) return rc == 2 ? SPAN_NEED_GENERIC : SPAN_OK;
+        }
+        res.c = co.c; res.n = co.n;
+        res.ref_id = h0.ref_id; res.left = left0; res.anti = anti ? 1 : 0; res.asplice = co.saw_as ? 1 : 0;
+        res.mm = co.num_mm & 0xFF; res.ed = (co.num_mm + rc_gap_len(co.c, co.n)) & 0xFF;
+        res.rlen = rl; res.valid = 1;
+        if (rc_read_span(res.c, res.n) != old_read_length) return SPAN_OK;
     }
-    if (!have || !valid_hit(p, res)) return SPAN_OK;
-    int gapl = (uint8_t)(res.ed - res.mm);
-    if ((int)res.mm > p.read_mismatches || gapl > p.read_gap_length || (int)res.ed > p.read_edit_dist) return SPAN_OK;
+    if (!valid_hit(p, res)) return SPAN_OK;
+    int gapl = (res.ed - res.mm) & 0xFF;
+    if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return SPAN_OK;
     SeqView sv = res.anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
     bool qrev;
     if (nsegs == 1) qrev = res.anti;
@@ -707,7 +853,7 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     Extras e;
     if (!sam_extra(g, p, res, sv, qual, rl, qrev, e)) return SPAN_MD_OVERFLOW;
     // check_editdist_consistency (done inside merge_chain in the reference) shares sam_extra's counts
-    if (nsegs > 1 && !(e.XM == (int)res.mm || e.XM + e.both_n == (int)res.mm)) return SPAN_OK;
+    if (nsegs > 1 && !(e.XM == res.mm || e.XM + e.both_n == res.mm)) return SPAN_OK;
     emit_aln(sink, read_idx, 0, res, e);
     return SPAN_OK;
 }

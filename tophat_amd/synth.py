@@ -179,9 +179,9 @@ def make_case(seed: int = 1, contig_lens: Sequence[int] = (60000,), n_reads: int
               genes_per_contig: int = 12, intron_range=(60, 3000), inner_mean: int = 50,
               inner_sd: int = 20, repeat_frac: float = 0.0, drop_seg_frac: float = 0.03,
               overhang: int = 3, spliced_seg_frac: float = 0.0, boundary_bias: float = 0.0, juncdb: bool = False,
-              fusion_reads: int = 0) -> SynthCase:
+              fusion_reads: int = 0, exon_range=(30, 400)) -> SynthCase:
     rng = random.Random(seed)
-    names, seqs, genes = make_genome(rng, contig_lens, genes_per_contig, intron_range)
+    names, seqs, genes = make_genome(rng, contig_lens, genes_per_contig, intron_range, exon_range)
     # optional planted repeats -> multihits
     repeats: List[Tuple[int, int, int]] = []
     if repeat_frac > 0:
