@@ -19,6 +19,15 @@
 #define THJ_HD inline
 #endif
 
+// THJ_EXP: developer-only build (tools/build_exp.sh, tools/exp_bench.py) that can switch parts of a kernel off to
+// see what they cost.  One flag word per translation unit, set from the THJ_EXP_FLAGS environment variable.
+#if defined(THJ_EXP) && defined(__HIPCC__)
+static __device__ int thj_exp_flags;
+#define THJ_EXPF(b) (thj_exp_flags & (b))
+#else
+#define THJ_EXPF(b) 0
+#endif
+
 namespace thj {
 
 typedef unsigned long long u64;

@@ -183,29 +183,30 @@ __global__ __launch_bounds__(256) void thj_k_rescue_scan(Genome g, Params p, Dev
 // ------------------------------------------------------------------ main kernel
 
 static constexpr int TPB = 256;
-static constexpr int QCAP = 1024;
+static constexpr int QCAP = 768;           // task queue entries (LDS); a typical tile of 256 reads adds a few dozen
 
 struct Queue {
-    uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d;
+    uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e;
     unsigned int* n;
 };
 
 struct QueueSink {
     Queue q;
-    uint32_t rloc;
+    uint32_t read;             // batch index of the enumerating read
+    uint32_t hbase;            // what to add to the view's hit indices to get batch hit indices
     unsigned int n_windows, n_indels;
     __device__ __forceinline__ void push(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
         unsigned int k = atomicAdd(q.n, 1u);
-        if (k < (unsigned)QCAP) { q.a[k] = a; q.b[k] = b; q.c[k] = c; q.d[k] = d; }
+        if (k < (unsigned)QCAP) { q.a[k] = a; q.b[k] = b; q.c[k] = c; q.d[k] = d; q.e[k] = read; }
     }
     __device__ __forceinline__ void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
         ++n_windows;
-        push(rloc | (anti ? 1u << 9 : 0u) | ((uint32_t)start << 10) | ((uint32_t)slen << 18), ref, (uint32_t)wl, (uint32_t)wr);
+        push((anti ? 1u << 9 : 0u) | ((uint32_t)start << 10) | ((uint32_t)slen << 18), ref, (uint32_t)wl, (uint32_t)wr);
     }
     __device__ __forceinline__ void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) {
         ++n_indels;
-        push(rloc | (1u << 8) | (anti ? 1u << 9 : 0u) | (is_del ? 1u << 10 : 0u) | ((uint32_t)i << 11) | ((uint32_t)plen << 14),
-             lidx, ridx, (uint32_t)li | ((uint32_t)ri << 16));
+        push((1u << 8) | (anti ? 1u << 9 : 0u) | (is_del ? 1u << 10 : 0u) | ((uint32_t)i << 11) | ((uint32_t)plen << 14),
+             lidx + hbase, ridx + hbase, (uint32_t)li | ((uint32_t)ri << 16));
     }
 };
 
@@ -220,32 +221,76 @@ struct InlineSink {
     }
 };
 
+// view of a read for executing a queued task: only what window_exec / indel_exec touch
+__device__ __forceinline__ ReadView make_task_view(const DevBatch& b, int r) {
+    ReadView v;
+    v.hits = b.hits;
+    v.so = b.seg_off + (size_t)r * b.nseg;
+    v.nseg = b.nseg;
+    v.W = b.W;
+    v.rp = b.planes + (size_t)r * 3 * b.W;
+    v.rl = b.read_len[r];
+    v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+    v.size = 0; v.rescue = false; v.check_len = 0;
+    return v;
+}
+
+// One workgroup walks tiles of 256 consecutive reads.
+//   enumerate: find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
+//              from HBM that is a dozen round trips per read, so a tile's CSR offsets and its (contiguous) hits are
+//              first staged in LDS with two coalesced sweeps and the per-read logic runs on the LDS copy.  The
+//              windows and indel pairs it finds are queued as tasks.
+//   execute:   tasks are rare (a few dozen per tile), so they are left to pile up over several tiles and run in
+//              whole rounds of 256 -- every lane busy -- with the remainder carried over.
+// Dynamic LDS: 5 x QCAP queue words | TPB*nseg+1 offsets | hit_cap hits.
 __global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBatch b, Tables t,
-                                                      const uint32_t* pair_off, const int32_t* slots) {
-    __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP];
+                                                      const uint32_t* pair_off, const int32_t* slots, int hit_cap) {
+    extern __shared__ uint4 dyn_lds[];
+    uint32_t* q_a = (uint32_t*)dyn_lds;
+    uint32_t* q_b = q_a + QCAP; uint32_t* q_c = q_b + QCAP; uint32_t* q_d = q_c + QCAP; uint32_t* q_e = q_d + QCAP;
+    uint32_t* s_so = q_e + QCAP;
+    uint4* s_hits = (uint4*)(s_so + ((TPB * b.nseg + 1 + 3) & ~3));
     __shared__ unsigned int q_n;
     __shared__ unsigned int s_stat[4];
     const int tid = threadIdx.x;
     if (tid < 4) s_stat[tid] = 0;
+    if (tid == 0) q_n = 0;
     EventSink ev{g, t};
     const int n_tiles = (b.n_reads + TPB - 1) / TPB;
     // consecutive tiles go to consecutive workgroups (-> different XCDs): every XCD's L2
     // streams its own contiguous slices of the hit array, the genome lines are shared by L3.
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        if (tid == 0) q_n = 0;
+        // ---- stage this tile's offsets and hits
+        const int r0 = tile * TPB;
+        const int tile_reads = b.n_reads - r0 < TPB ? b.n_reads - r0 : TPB;
+        const int n_so = tile_reads * b.nseg + 1;
+        __syncthreads();                                  // the previous tile's readers are done with the LDS copy
+        for (int i = tid; i < n_so; i += TPB) s_so[i] = b.seg_off[(size_t)r0 * b.nseg + i];
         __syncthreads();
-        const int r = tile * TPB + tid;
+        const unsigned int q_before = q_n;               // tasks carried over from earlier tiles
+        const uint32_t h0 = s_so[0], nh_tile = s_so[n_so - 1] - h0;
+        const bool staged = nh_tile <= (uint32_t)hit_cap;
+        __syncthreads();
+        if (staged) {                                     // offsets become indices into the LDS copy
+            for (int i = tid; i < n_so; i += TPB) s_so[i] -= h0;
+            for (uint32_t i = tid; i < nh_tile; i += TPB) s_hits[i] = ((const uint4*)b.hits)[h0 + i];
+        }
+        __syncthreads();
+        // ---- enumerate
+        const int r = r0 + tid;
         unsigned int nw = 0, ni = 0, nh = 0;
         ReadView v;
         bool active = r < b.n_reads;
         bool do_gaps = false;
         if (active) {
             v = make_view(b, r);
+            v.so = s_so + tid * b.nseg;
+            if (staged) v.hits = (const Hit*)s_hits;
             nh = v.so[v.nseg] - v.so[0];
-            QueueSink qs{{q_a, q_b, q_c, q_d, &q_n}, (uint32_t)tid, 0u, 0u};
-            indels_enumerate(p, v, qs);
+            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, staged ? h0 : 0u, 0u, 0u};
+            if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs);
             bool wants = false;
-            do_gaps = gaps_prepare(p, v, wants);
+            do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants);
             if (do_gaps) {
                 if (wants) { v.slots = slots + 2 * (size_t)pair_off[r]; v.rescue = true; }
                 gaps_enumerate(p, v, qs);
@@ -257,35 +302,44 @@ __global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBat
         if (nh) atomicAdd(&s_stat[2], nh);
         __syncthreads();
         const unsigned int total = q_n;
-        const unsigned int nq = total < (unsigned)QCAP ? total : (unsigned)QCAP;
-        for (unsigned int k = tid; k < nq; k += TPB) {
-            const uint32_t a = q_a[k];
-            const int tr = tile * TPB + (int)(a & 0xFF);
-            ReadView tv = make_view(b, tr);
-            const bool anti = (a >> 9) & 1u;
-            if (a & (1u << 8)) {
-                const bool is_del = (a >> 10) & 1u;
-                const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 127u);
-                const uint32_t d = q_d[k];
-                indel_exec(g, p, tv, i, q_b[k], q_c[k], anti, plen, is_del,
-                           ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(d & 0xFFFF), (int)(d >> 16)), ev);
-            } else {
-                const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 63u);
-                window_exec(g, p, tv, q_b[k], (int32_t)q_c[k], (int32_t)q_d[k], anti, start, slen, ev);
-            }
-        }
         if (total > (unsigned)QCAP) {
-            // the queue overflowed (multihit-heavy tile): redo this tile un-queued.  Events are
-            // set inserts / atomicMin, so re-emitting the ones already done is harmless.
+            // the queue overflowed (multihit-heavy tile): drop this tile's queued tasks and run the tile un-queued.
             if (tid == 0) atomicAdd(&s_stat[3], 1u);
             if (active) {
                 InlineSink is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
                 indels_enumerate(p, v, is);
                 if (do_gaps) gaps_enumerate(p, v, is);
             }
+            __syncthreads();
+            if (tid == 0) q_n = q_before;
+            __syncthreads();
         }
-        __syncthreads();
+        // ---- execute whole rounds; everything on the last tile
+        const unsigned int have = q_n;
+        const bool last_tile = tile + (int)gridDim.x >= n_tiles;
+        const unsigned int keep = last_tile ? 0u : have % (unsigned)TPB;
+        if (have - keep > 0 && !THJ_EXPF(1 << 16)) {
+            for (unsigned int k = keep + tid; k < have; k += TPB) {
+                const uint32_t a = q_a[k];
+                const int tr = (int)q_e[k];
+                ReadView tv = make_task_view(b, tr);
+                const bool anti = (a >> 9) & 1u;
+                if (a & (1u << 8)) {
+                    const bool is_del = (a >> 10) & 1u;
+                    const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 127u);
+                    const uint32_t d = q_d[k];
+                    indel_exec(g, p, tv, i, q_b[k], q_c[k], anti, plen, is_del,
+                               ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(d & 0xFFFF), (int)(d >> 16)), ev);
+                } else {
+                    const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 63u);
+                    window_exec(g, p, tv, q_b[k], (int32_t)q_c[k], (int32_t)q_d[k], anti, start, slen, ev);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) q_n = keep;
+        }
     }
+    __syncthreads();
     if (tid == 0) {
         if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
@@ -619,12 +673,18 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
         if (!c->d_slots) { c->slots_cap = 1024; HIPCHK(hipMalloc(&c->d_slots, (size_t)c->slots_cap * 8)); }
     }
 
+#ifdef THJ_EXP
+    { int f = getenv("THJ_EXP_FLAGS") ? atoi(getenv("THJ_EXP_FLAGS")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(thj_exp_flags), &f, sizeof f)); }
+#endif
     const int n_tiles = (n + TPB - 1) / TPB;
     int grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;       // 256 CUs x 8 resident workgroups, grid-stride the rest
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
-    hipLaunchKernelGGL(thj_k_segjuncs, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t,
-                       (const uint32_t*)c->d_pair_off, (const int32_t*)c->d_slots);
+    // LDS: task queue, the tile's offsets, and room for 1.25 hits per segment (tiles with more read hits from HBM)
+    const int hit_cap = TPB * b.nseg + TPB * b.nseg / 4;
+    const size_t lds = (size_t)5 * QCAP * 4 + (size_t)((TPB * b.nseg + 1 + 3) & ~3) * 4 + (size_t)hit_cap * 16;
+    hipLaunchKernelGGL(thj_k_segjuncs, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t,
+                       (const uint32_t*)c->d_pair_off, (const int32_t*)c->d_slots, hit_cap);
     if (c->profile) { HIPCHK(hipEventRecord(e1, c->stream)); c->prof_events.emplace_back(e0, e1); }
     HIPCHK(hipGetLastError());
     return THJ_OK;

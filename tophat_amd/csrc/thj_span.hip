@@ -11,6 +11,7 @@
 
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -19,6 +20,7 @@
 #include "thj_ctx.h"
 
 using namespace thj;
+
 
 static_assert(sizeof(thj_span_hit) == 32 && sizeof(SpanHit) == 32, "span hit layout");
 static_assert(sizeof(thj_aln) == 128 && sizeof(OutAln) == 128, "aln layout");
@@ -42,9 +44,9 @@ struct RecSink {
     OutAln* ovf; u64* ovf_key; unsigned long long* ovf_count; unsigned long long ovf_cap;
     unsigned long long* total; unsigned int* status;
     int emitted;       // per-thread: records emitted for the current read
+    int acc;           // per-thread: records emitted so far (summed per block at the end of the kernel)
     __device__ __forceinline__ void emit_words(const uint32_t* w) {
         ++emitted;
-        atomicAdd(total, 1ull);
         const uint32_t order = w[5] >> 16;
         uint4* dst;
         if (order == 0) dst = (uint4*)(slots + (size_t)base + w[0]);
@@ -57,46 +59,142 @@ struct RecSink {
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
     }
-    __device__ __forceinline__ void done(uint32_t r) { nrec[(size_t)base + r] = (uint8_t)emitted; emitted = 0; }
+    __device__ __forceinline__ void done(uint32_t r) { nrec[(size_t)base + r] = (uint8_t)emitted; acc += emitted; emitted = 0; }
+};
+
+// The three tiers hand reads down through worklists.  A global append counter would serialise every wave of the
+// launch on one L2 address (measured: 1.5 ms of a 2 ms kernel), so the lists are segmented instead: block b owns
+// reads [b*chunk, (b+1)*chunk) in tier 0 and the slice [b*chunk, ..) of both lists in every tier; positions come
+// from an LDS counter, per-block totals go to blk_lean / blk_multi, and global counters see one add per block.
+struct Tiers {
+    uint32_t* wl_lean; uint32_t* wl_multi;
+    unsigned int* blk_lean; unsigned int* blk_multi;
+    unsigned int* counters;          // [0] reads handed to tier 1, [1] to tier 2 (this run)
+    int chunk;
 };
 
 // Tier 0: every read.  Reads made of abutting single plain-match hits (unspliced reads cut into segments) are
-// finished here with a handful of registers; the others go to one of two worklists.
-__global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, RecSink sink,
-                                                           uint32_t* wl_lean, uint32_t* wl_multi, unsigned int* counters) {
-    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < b.n_reads; r += gridDim.x * blockDim.x) {
-        int st = span_read_contig(g, p, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
-                                  (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
-        if (st == SPAN_NEED_LEAN) wl_lean[atomicAdd(&counters[0], 1u)] = (uint32_t)r;
-        else if (st == SPAN_NEED_GENERIC) wl_multi[atomicAdd(&counters[1], 1u)] = (uint32_t)r;
-        else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
+// finished here with a handful of registers.  A block works on 256 consecutive reads at a time: their records are
+// assembled in LDS (chunk-rotated so the 16-byte writes of a wave spread over all banks) and leave as full
+// 128-byte lines, eight lanes per record.
+struct StageSink {
+    uint4* stage; int rec; int emitted;
+    __device__ __forceinline__ void emit_words(const uint32_t* w) {
+        emitted = 1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) stage[rec * 8 + ((k + rec) & 7)] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+    }
+};
+
+__global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, RecSink sink, Tiers t) {
+    __shared__ uint4 stage[256 * 8];
+    __shared__ uint8_t has_rec[256];
+    __shared__ unsigned int s_cnt[3];          // lean, multihit, records
+    const int tid = threadIdx.x;
+    if (tid < 3) s_cnt[tid] = 0;
+    __syncthreads();
+    const int64_t c0 = (int64_t)blockIdx.x * t.chunk;
+    const int64_t c1 = c0 + t.chunk < b.n_reads ? c0 + t.chunk : b.n_reads;
+    unsigned int my_rec = 0;
+    for (int64_t r0 = c0; r0 < c1; r0 += 256) {
+        const int64_t r = r0 + tid;
+        StageSink ss{stage, tid, 0};
+        if (r < c1) {
+            int st = span_read_contig(g, p, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                                      (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, ss);
+            if (st == SPAN_NEED_LEAN) { if (!THJ_EXPF(64)) t.wl_lean[c0 + atomicAdd(&s_cnt[0], 1u)] = (uint32_t)r; }
+            else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = (uint32_t)r;
+            else {
+                sink.nrec[(size_t)sink.base + r] = (uint8_t)ss.emitted;
+                my_rec += ss.emitted;
+                if (st) atomicAdd(&sink.status[st], 1u);
+            }
+        }
+        has_rec[tid] = (uint8_t)ss.emitted;
+        __syncthreads();
+        uint4* out = (uint4*)(sink.slots + (size_t)sink.base + r0);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int j = tid + 256 * m, i = j >> 3;
+            if (has_rec[i] && !THJ_EXPF(1)) out[i * 8 + (((j & 7) - i) & 7)] = stage[j];
+        }
+        __syncthreads();
+    }
+    if (my_rec) atomicAdd(&s_cnt[2], my_rec);
+    __syncthreads();
+    if (tid == 0) {
+        t.blk_lean[blockIdx.x] = s_cnt[0];
+        t.blk_multi[blockIdx.x] = s_cnt[1];
+        if (s_cnt[0]) atomicAdd(&t.counters[0], s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&t.counters[1], s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(sink.total, (unsigned long long)s_cnt[2]);
     }
 }
 
-// Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain.
-__global__ __launch_bounds__(256) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink,
-                                                    const uint32_t* wl_lean, uint32_t* wl_multi, unsigned int* counters) {
-    const unsigned int n = counters[0];
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int r = (int)wl_lean[i];
+// Tiers 1 and 2 walk the concatenation of the per-block slices so that every lane has work whatever the spread of
+// spliced / multihit reads over the batch: each block scans the (at most 2048) slice lengths into LDS, and entry i
+// of the concatenation is found by a binary search there.
+static constexpr int MAX_SLICES = 2048;
+template <int TPB>
+__device__ unsigned int slice_offsets(const unsigned int* blk_cnt, int G, unsigned int* s_off /* [MAX_SLICES + 1] */) {
+    constexpr int IPT = MAX_SLICES / TPB;
+    typedef hipcub::BlockScan<unsigned int, TPB> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    const int tid = threadIdx.x;
+    unsigned int v[IPT], sum = 0, excl, total;
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) { const int j = tid * IPT + k; v[k] = j < G ? blk_cnt[j] : 0u; sum += v[k]; }
+    Scan(tmp).ExclusiveSum(sum, excl, total);
+#pragma unroll
+    for (int k = 0; k < IPT; ++k) { s_off[tid * IPT + k] = excl; excl += v[k]; }
+    if (tid == 0) s_off[MAX_SLICES] = total;
+    __syncthreads();
+    return total;
+}
+__device__ __forceinline__ int slice_of(const unsigned int* s_off, int G, unsigned int i) {   // last b with s_off[b] <= i
+    int lo = 0, hi = G;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain on registers.
+__global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    __shared__ unsigned int s_off[MAX_SLICES + 1];
+    __shared__ unsigned int s_rec;
+    if (threadIdx.x == 0) s_rec = 0;
+    const unsigned int total = slice_offsets<256>(t.blk_lean, G, s_off);
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int sl = slice_of(s_off, G, i);
+        const int r = (int)t.wl_lean[(int64_t)sl * t.chunk + (i - s_off[sl])];
         int st = span_read_lean(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
-        if (st == SPAN_NEED_GENERIC) wl_multi[atomicAdd(&counters[1], 1u)] = (uint32_t)r;
-        else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
+        if (st == SPAN_NEED_GENERIC) {          // rare: more cigar ops than the registers hold
+            t.wl_multi[(int64_t)sl * t.chunk + atomicAdd(&t.blk_multi[sl], 1u)] = (uint32_t)r;
+            atomicAdd(&t.counters[1], 1u);
+        } else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
     }
+    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
 }
 
-// Tier 2: the general per-read DFS (multihit segments) over its worklist.
-__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink,
-                                                             const uint32_t* wl_multi, const unsigned int* counters) {
-    const unsigned int n = counters[1];
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int r = (int)wl_multi[i];
+// Tier 2: the general per-read DFS (multihit segments) over its list.
+__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    __shared__ unsigned int s_off[MAX_SLICES + 1];
+    __shared__ unsigned int s_rec;
+    if (threadIdx.x == 0) s_rec = 0;
+    const unsigned int total = slice_offsets<128>(t.blk_multi, G, s_off);
+    for (unsigned int i = blockIdx.x * 128 + threadIdx.x; i < total; i += gridDim.x * 128) {
+        const int sl = slice_of(s_off, G, i);
+        const int r = (int)t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])];
         int st = span_read(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                            (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
         sink.done((uint32_t)r);
         if (st) atomicAdd(&sink.status[st], 1u);
     }
+    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
 }
 
 __global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u64* vals, int64_t n, u64* okeys, uint32_t* oseq) {
@@ -328,30 +426,41 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     DevSpanBatch b; memcpy(&b, db, sizeof b);
     SpanSets S{c->d_span_junc, c->n_span_junc, c->d_span_ins_key, c->d_span_ins_seq, c->n_span_ins};
     const uint32_t base = (uint32_t)c->span_reads;
+#ifdef THJ_EXP
+    { int f = getenv("THJ_EXP_FLAGS") ? atoi(getenv("THJ_EXP_FLAGS")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(thj_exp_flags), &f, sizeof f)); }
+#endif
     HIPCHK(hipMemsetAsync(c->d_nrec + base, 0, (size_t)b.n_reads, c->stream));
     RecSink sink{(OutAln*)c->d_aln_pool, c->d_nrec, base, (OutAln*)c->d_aln_sorted, c->d_aln_keys, c->d_aln_count + 1,
-                 (unsigned long long)c->ovf_cap, c->d_aln_count, c->d_span_status, 0};
-    if (c->worklist_cap < b.n_reads) {
+                 (unsigned long long)c->ovf_cap, c->d_aln_count, c->d_span_status, 0, 0};
+    // block-owned slices of the worklists (see Tiers)
+    int64_t G = ((int64_t)b.n_reads + 511) / 512;
+    if (G > 2048) G = 2048;
+    if (G < 1) G = 1;
+    int64_t chunk = ((int64_t)b.n_reads + G - 1) / G;
+    chunk = (chunk + 255) / 256 * 256;
+    G = ((int64_t)b.n_reads + chunk - 1) / chunk;
+    const int64_t wl_need = 2 * G * chunk + 2 * 2048;
+    if (c->worklist_cap < wl_need) {
         hipFree(c->d_worklist); c->d_worklist = nullptr;
-        HIPCHK(hipMalloc(&c->d_worklist, (size_t)b.n_reads * 8));          // two lists
-        c->worklist_cap = b.n_reads;
+        HIPCHK(hipMalloc(&c->d_worklist, (size_t)wl_need * 4));
+        c->worklist_cap = wl_need;
     }
-    uint32_t* wl_lean = c->d_worklist;
-    uint32_t* wl_multi = c->d_worklist + b.n_reads;
-    unsigned int* counters = &c->d_span_status[4];
-    HIPCHK(hipMemsetAsync(counters, 0, 8, c->stream));
-    int64_t blocks = ((int64_t)b.n_reads + 255) / 256;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    int64_t b2 = ((int64_t)b.n_reads + 127) / 128;
-    if (b2 > 2048) b2 = 2048;
+    Tiers t;
+    t.wl_lean = c->d_worklist;
+    t.wl_multi = c->d_worklist + G * chunk;
+    t.blk_lean = c->d_worklist + 2 * G * chunk;
+    t.blk_multi = t.blk_lean + 2048;
+    t.counters = &c->d_span_status[4];
+    t.chunk = (int)chunk;
+    HIPCHK(hipMemsetAsync(t.counters, 0, 8, c->stream));
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
-    hipLaunchKernelGGL(thj_k_stitch_contig, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b, sink, wl_lean, wl_multi, counters);
+    hipLaunchKernelGGL(thj_k_stitch_contig, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
-    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, S, b, sink, (const uint32_t*)wl_lean, wl_multi, counters);
+    const int64_t g1 = G < 1024 ? G : 1024, g2 = G < 2048 ? G : 2048;     // tier 1: 4 resident blocks per CU
+    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)g1), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
-    hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)b2), dim3(128), 0, c->stream, g, p, S, b, sink,
-                       (const uint32_t*)wl_multi, (const unsigned int*)counters);
+    hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)g2), dim3(128), 0, c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) {
         HIPCHK(hipEventRecord(ev[3], c->stream));
         c->span_prof_events.emplace_back(ev[0], ev[1]);

@@ -14,6 +14,7 @@
 #pragma once
 #include "thj_core.h"
 
+
 namespace thj {
 
 enum { OP_MATCH = 1, OP_mATCH = 2, OP_INS = 3, OP_iNS = 4, OP_DEL = 5, OP_dEL = 6, OP_REF_SKIP = 11, OP_rEF_SKIP = 12,
@@ -864,31 +865,65 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
 // (dist == 0, :1591), the final concatenation (:1888-1944) fuses the MATCH ops into one, so the joined hit is
 // {leftmost left, [len M], sum of mismatches}.  Returns SPAN_NEED_LEAN when the read is not of that shape.
 enum { SPAN_NEED_LEAN = 4 };
+// first half of a thj_span_hit: all a single plain-match hit carries
+struct alignas(16) SpanHitHead { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar0; };
+
 template <class Sink>
 THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
                             const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
-    if (so[1] == so[0]) return SPAN_OK;
+    // Memory round trips, not arithmetic, bound this tier: the segment offsets are fetched in one go, then every
+    // hit head in one go, and only then is anything decided.
+    uint32_t sv[SPAN_MAXSEG + 1];
+#pragma unroll
+    for (int s = 0; s <= SPAN_MAXSEG; ++s) sv[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
+    if (sv[1] == sv[0]) return SPAN_OK;
     int nsegs = 0;
-    while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
-    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
-    if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;
-    for (int s = 0; s < nsegs; ++s) if (so[s + 1] - so[s] != 1u) return SPAN_NEED_GENERIC;
-    const SpanHit h0 = hits[so[0]];
+    {
+        bool open = true;
+#pragma unroll
+        for (int s = 0; s < SPAN_MAXSEG; ++s) { open = open && s < nseg && sv[s + 1] > sv[s]; nsegs += open ? 1 : 0; }
+    }
+    bool single = true;
+#pragma unroll
+    for (int s = 0; s < SPAN_MAXSEG; ++s) single = single && (s >= nsegs || sv[s + 1] - sv[s] == 1u);
+    uint32_t last_so = sv[0];
+#pragma unroll
+    for (int s = 1; s < SPAN_MAXSEG; ++s) last_so = (s == nsegs - 1) ? sv[s] : last_so;
+    if (!single) {
+        if (!(hits[last_so].meta & SH_END)) return SPAN_OK;
+        return SPAN_NEED_GENERIC;
+    }
+    // one hit per segment: the read's hits are hits[sv[0] .. sv[0] + nsegs)
+    SpanHitHead hh[SPAN_MAXSEG];
+#pragma unroll
+    for (int s = 0; s < SPAN_MAXSEG; ++s)
+        if (s < nsegs) hh[s] = *(const SpanHitHead*)(hits + sv[0] + s);
+    uint32_t last_meta = hh[0].meta;
+#pragma unroll
+    for (int s = 1; s < SPAN_MAXSEG; ++s) last_meta = (s == nsegs - 1) ? hh[s].meta : last_meta;
+    if (!(last_meta & SH_END)) return SPAN_OK;
+    const SpanHitHead h0 = hh[0];
     const bool anti = (h0.meta & SH_ANTI) != 0;
-    if ((h0.meta >> 24) != 1u || cig_op(h0.cigar[0]) != OP_MATCH) return SPAN_NEED_LEAN;
-    int total = (int)cig_len(h0.cigar[0]);
+    if ((h0.meta >> 24) != 1u || cig_op(h0.cigar0) != OP_MATCH) return SPAN_NEED_LEAN;
+    int total = (int)cig_len(h0.cigar0);
     int mm = (int)((h0.meta >> 8) & 0xFF);
     int left = h0.left, edge = anti ? h0.left : h0.left + total;       // where the next segment must abut
-    for (int s = 1; s < nsegs; ++s) {
-        const SpanHit h = hits[so[s]];
-        if ((h.meta >> 24) != 1u || cig_op(h.cigar[0]) != OP_MATCH) return SPAN_NEED_LEAN;
-        if (h.ref_id != h0.ref_id || ((h.meta & SH_ANTI) != 0) != anti) return SPAN_NEED_LEAN;   // lean path decides (no alignment)
-        int len = (int)cig_len(h.cigar[0]);
-        if (anti) { if (h.left + len != edge) return SPAN_NEED_LEAN; edge = h.left; left = h.left; }
-        else { if (h.left != edge) return SPAN_NEED_LEAN; edge = h.left + len; }
-        total += len;
-        mm += (int)((h.meta >> 8) & 0xFF);
+    bool lean = false;
+#pragma unroll
+    for (int s = 1; s < SPAN_MAXSEG; ++s) {
+        if (s < nsegs) {
+            const SpanHitHead h = hh[s];
+            const int len = (int)cig_len(h.cigar0);
+            lean = lean || (h.meta >> 24) != 1u || cig_op(h.cigar0) != OP_MATCH;
+            lean = lean || h.ref_id != h0.ref_id || ((h.meta & SH_ANTI) != 0) != anti;    // lean path decides (no alignment)
+            if (anti) { lean = lean || h.left + len != edge; edge = h.left; left = h.left; }
+            else { lean = lean || h.left != edge; edge = h.left + len; }
+            total += len;
+            mm += (int)((h.meta >> 8) & 0xFF);
+        }
     }
+    if (lean) return SPAN_NEED_LEAN;
+    if (THJ_EXPF(16)) return SPAN_OK;
     const int mm8 = mm & 0xFF;                       // BowtieHit keeps mismatches / edit_dist in unsigned chars
     if (mm8 > p.read_mismatches || mm8 > p.read_edit_dist) return SPAN_OK;          // :2810-2813 (gap length 0)
     if (g_len(g, h0.ref_id) == 0) return SPAN_OK;    // check_editdist_consistency / bowtie_sam_extra need the contig
@@ -907,9 +942,10 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
         int l = total - off < 64 ? total - off : 64;
         if (off + l > rl) l = rl - off;
         if (l <= 0) break;
-        Planes r = g_fetch(g, h0.ref_id, (int64_t)left + off);
-        Planes sq = anti ? rc_piece(r_fetch(rp, W, rl - off - l, l), l) : r_fetch(rp, W, off, l);
+        Planes r = g_fetch(g, h0.ref_id, THJ_EXPF(4) ? 0 : (int64_t)left + off);
+        Planes sq = anti ? rc_piece(r_fetch(THJ_EXPF(8) ? g.blocks : rp, W, rl - off - l, l), l) : r_fetch(THJ_EXPF(8) ? g.blocks : rp, W, off, l);
         u64 m = dna5_mism(r, sq, l);
+        if (THJ_EXPF(32)) m = 0;
         u64 bn = r.nm & sq.nm & lowmask(l);
         both_n += popc(bn);
         AS -= p.bowtie2_penalty_for_N * popc(bn);
@@ -921,7 +957,7 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
             int sp = off + b;
             if (((r.nm | sq.nm) >> b) & 1ull) AS -= p.bowtie2_penalty_for_N;
             else {
-                int q = (int)qual[qrev ? rl - 1 - sp : sp] - 33; if (q > 40) q = 40;
+                int q = THJ_EXPF(2) ? 30 : (int)qual[qrev ? rl - 1 - sp : sp] - 33; if (q > 40) q = 40;
                 AS -= p.bowtie2_min_penalty + ((p.bowtie2_max_penalty - p.bowtie2_min_penalty) * q) / 40;
             }
             pos_mm += b - last;
