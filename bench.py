@@ -268,8 +268,11 @@ def main():
     t0_alg = 4.0 * (args.pairs * nseg + 1) + 32.0 * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
     t1_alg = n_lean * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
+    # thj_k_segjuncs_rescue: per (hit, mate hit) pair the read, its CSR row + hits, the mate hit and ~3 genome lines of flank
+    resc_alg = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 192)
     kernels = [
-        {"kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms, "launches": launches, "algorithmic_bytes_per_launch": seg_alg},
+        {"kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms[0], "launches": launches, "algorithmic_bytes_per_launch": seg_alg},
+        {"kernel": "thj_k_segjuncs_rescue", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": resc_alg},
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
         {"kernel": "thj_k_stitch_multihit", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},

@@ -37,13 +37,15 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
                                 const int32_t* contig_len, int32_t n_contigs, const thj_seg_batch* b,
                                 thj_junction** juncs, int64_t* n_juncs, thj_junction** dels, int64_t* n_dels,
                                 uint32_t** ins /* 6 u32 per insertion: ref,left,len,seq,prio_lo,prio_hi */, int64_t* n_ins,
-                                int64_t* stats /* windows, indel pairs, rescue pairs */) {
+                                int64_t* stats /* windows, indel pairs, rescue pairs, reads skipped as trivial */) {
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Params p;
     static_assert(sizeof(Params) == sizeof(thj_params), "params layout");
     memcpy(&p, tp, sizeof p);
     Collect c;
-    int64_t nw = 0, ni = 0, nr = 0;
+    int64_t nw = 0, ni = 0, nr = 0, n_trivial = 0;
+    const bool lazy = getenv("THJ_HOSTSIM_LAZY") != nullptr;        // exercise the on-the-fly rescue of rv_foreach
+    const bool no_skip = getenv("THJ_HOSTSIM_NO_SKIP") != nullptr;  // run the general enumeration on every read
     std::vector<int32_t> slots;
     for (int32_t r = 0; r < b->n_reads; ++r) {
         ReadView v;
@@ -59,6 +61,7 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
             v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]);
         }
         ExecSink sink{g, p, v, c, b->ordinal_base + (uint32_t)r};
+        if (!no_skip && read_is_trivial(p, v)) { ++n_trivial; continue; }      // what the kernel does: nothing can come out of this read
         indels_enumerate(p, v, sink);
         bool wants;
         if (gaps_prepare(p, v, wants)) {
@@ -74,7 +77,8 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
                               hit_anti(v.hits[v.so[0] + l]) == hit_anti(v.mate[m])))
                             ++nr;
                     }
-                v.slots = slots.data();
+                v.slots = lazy ? nullptr : slots.data();     // lazy: the kernel's fallback when its LDS slot buffer is full
+                v.lazy_g = &g; v.lazy_p = &p;
                 v.rescue = true;
             }
             gaps_enumerate(p, v, sink);
@@ -94,7 +98,7 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
         o[0] = c.ins[k].ref; o[1] = c.ins[k].left; o[2] = (uint32_t)c.ins[k].len; o[3] = c.ins[k].seq;
         o[4] = (uint32_t)(c.ins[k].prio & 0xffffffffu); o[5] = (uint32_t)(c.ins[k].prio >> 32);
     }
-    stats[0] = nw; stats[1] = ni; stats[2] = nr;
+    stats[0] = nw; stats[1] = ni; stats[2] = nr; stats[3] = n_trivial;
     return 0;
 }
 

@@ -45,7 +45,7 @@ def segjuncs(p: Params, seqs, b: SegBatch, ordinal_base: int = 0) -> Events:
     cp = p.as_ctypes()
     pj, pd, pi = C.c_void_p(), C.c_void_p(), C.c_void_p()
     nj, nd, ni = C.c_int64(), C.c_int64(), C.c_int64()
-    stats = (C.c_int64 * 3)()
+    stats = (C.c_int64 * 4)()
     rc = l.hostsim_segjuncs(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
                             C.c_void_p(clen.ctypes.data), g.n_contigs, C.byref(cb),
                             C.byref(pj), C.byref(nj), C.byref(pd), C.byref(nd), C.byref(pi), C.byref(ni), stats)
@@ -63,7 +63,7 @@ def segjuncs(p: Params, seqs, b: SegBatch, ordinal_base: int = 0) -> Events:
     for ptr in (pj, pd, pi):
         l.hostsim_free(ptr)
     ev = sort_events(j, d, raw)
-    ev.stats = {"windows": stats[0], "indel_pairs": stats[1], "rescue_pairs": stats[2]}
+    ev.stats = {"windows": stats[0], "indel_pairs": stats[1], "rescue_pairs": stats[2], "trivial_reads": stats[3]}
     return ev
 
 

@@ -137,3 +137,51 @@ def test_missing_genome_fails_loudly(lib):
         with pytest.raises(host.ThjError):
             ctx.upload_genome(host.pack_genome(["ACGT" * 100]))
             ctx.run(Params(segment_length=64), h)   # unsupported parameter -> error
+
+
+def rescue_heavy_batch(n_reads=300, seed=11):
+    """Paired reads whose last segment (across an intron) is missing, with several (hit, mate hit) pairs
+    each: every read takes the mate-anchored rescue, a tile has far more pairs than the kernel's LDS slots."""
+    from tophat_amd.batch import HIT_DTYPE, SegBatch
+    rng = np.random.default_rng(seed)
+    L, nseg = 25, 4
+    glen = 900000
+    seq = "".join(rng.choice(list("ACGT"), size=glen))
+    hits, seg_off, bases, read_off, mate_off, mate_hits = [], [0], bytearray(), [0], [0], []
+    for r in range(n_reads):
+        base = 2000 + r * 2500
+        intron = int(rng.integers(80, 900))
+        read = seq[base:base + 75] + seq[base + 75 + intron:base + 100 + intron]
+        n_left = 17 if r == 5 else int(rng.integers(1, 4))
+        n_mate = 17 if r == 5 else int(rng.integers(2, 6))
+        for k in range(n_left):                           # the true hit first, decoys a little upstream
+            hits.append((1, base - 7 * k, base - 7 * k + L, 0, 0, 0, L))
+        seg_off.append(len(hits))
+        for sgi in (1, 2):                                # segments 1 and 2 map next to segment 0, the last one is missing
+            hits.append((1, base + sgi * L, base + (sgi + 1) * L, 0, 0, 0, L))
+            seg_off.append(len(hits))
+        seg_off.append(len(hits))
+        mleft = base + 100 + intron + 30
+        for k in range(n_mate):                           # antisense mates downstream, the first one the true mate
+            mate_hits.append((1, mleft + 11 * k, mleft + 11 * k + 100, 1 | 2, 0, 0, 100))
+        mate_off.append(len(mate_hits))
+        bases += read.encode()
+        read_off.append(len(bases))
+    b = SegBatch(nseg, np.arange(1, n_reads + 1, dtype=np.uint32), np.array(read_off, dtype=np.int64),
+                 np.frombuffer(bytes(bases), dtype=np.uint8).copy(), np.array(seg_off, dtype=np.uint32),
+                 np.array(hits, dtype=HIT_DTYPE), np.array(mate_off, dtype=np.uint32), np.array(mate_hits, dtype=HIT_DTYPE))
+    return seq, b
+
+
+def test_rescue_slot_overflow(lib):
+    """More rescue pairs in a tile than LDS slots: the surplus reads recompute theirs on the fly, same events."""
+    seq, b = rescue_heavy_batch()
+    p = Params()
+    want = orc.segjuncs(p, orc.Genome([seq]), b)
+    assert want.stats["rescue_pairs"] > 1000 and len(want.juncs) > 100 and want.stats["windows"] > 1000
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        got = ctx.segjuncs([(p, ctx.upload_batch(b))])
+    assert got.stats["rescue_pairs"] == want.stats["rescue_pairs"]
+    assert got.stats["windows"] == want.stats["windows"]
+    assert_events_equal(got, want)

@@ -11,7 +11,15 @@ from util import CASES, assert_events_equal, case_batches
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "seed%d_%s_rl%d_L%d" % (c["seed"], "pe" if c["paired"] else "se", c["read_len"], c["seg_len"]))
-def test_kernel_logic_matches_oracle(cfg):
+@pytest.mark.parametrize("variant", ["as_kernel", "lazy_rescue", "no_trivial_skip"])
+def test_kernel_logic_matches_oracle(cfg, variant, monkeypatch):
+    # as_kernel: trivial reads are skipped up front (read_is_trivial), rescue slots precomputed
+    # lazy_rescue: rv_foreach computes rescue_pair on the fly (the kernel's fallback when its LDS slot buffer is full)
+    # no_trivial_skip: the general enumeration on every read
+    if variant == "lazy_rescue":
+        monkeypatch.setenv("THJ_HOSTSIM_LAZY", "1")
+    if variant == "no_trivial_skip":
+        monkeypatch.setenv("THJ_HOSTSIM_NO_SKIP", "1")
     case = make_case(seed=cfg["seed"], paired=cfg["paired"], read_len=cfg["read_len"], seg_len=cfg["seg_len"],
                      n_reads=300, **cfg.get("gen", {}))
     seqs = [orc.fold_genome_char(s) for s in case.seqs]
@@ -23,6 +31,7 @@ def test_kernel_logic_matches_oracle(cfg):
         e2 = sim.segjuncs(p, seqs, b)
         assert e1.stats["windows"] == e2.stats["windows"]
         assert e1.stats["indel_pairs"] == e2.stats["indel_pairs"]
+        assert (e2.stats["trivial_reads"] > 0) == (variant != "no_trivial_skip")
         want = e1 if want is None else merge_events(want, e1)
         got = e2 if got is None else merge_events(got, e2)
     assert len(want.juncs) > 5

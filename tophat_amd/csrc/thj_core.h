@@ -334,7 +334,9 @@ struct ReadView {
     // mates / rescue
     const Hit* mate;          // this read's mate hits (may be null)
     int n_mate;
-    const int32_t* slots;     // this read's rescue slots [n_left*n_mate*2], or null
+    const int32_t* slots;     // this read's rescue slots [n_left*n_mate*2]; null with `rescue` set = compute on the fly
+    const Genome* lazy_g;     // genome / params for the on-the-fly rescue (only read when slots == null)
+    const Params* lazy_p;
     // derived by prepare()
     int size;                 // hits_for_read.size() after the trailing-empty trim
     bool rescue;              // segments 1.. replaced by the pseudo-hit list in `size-1`
@@ -357,8 +359,9 @@ THJ_HD void rv_foreach(const ReadView& v, int s, F f) {
     int n_left = rv_count_raw(v, 0);
     for (int l = 0; l < n_left; ++l)
         for (int m = 0; m < v.n_mate; ++m) {
-            int32_t a = v.slots[2 * (l * v.n_mate + m)];
-            int32_t b = v.slots[2 * (l * v.n_mate + m) + 1];
+            int32_t a, b;
+            if (v.slots) { a = v.slots[2 * (l * v.n_mate + m)]; b = v.slots[2 * (l * v.n_mate + m) + 1]; }
+            else rescue_pair(*v.lazy_g, *v.lazy_p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m], a, b);
             if (a == SLOT_BREAK) break;
             if (a >= 0) {
                 Hit h; h.ref_id = v.mate[m].ref_id; h.left = a; h.right = a + v.check_len;
@@ -411,6 +414,40 @@ THJ_HD bool gaps_prepare(const Params& p, ReadView& v, bool& wants_rescue) {
     }
     wants_rescue = check_partner && v.n_mate > 0;
     return true;
+}
+
+// Most reads are unspliced: one hit per segment, the hits abutting on one strand.  For those neither
+// find_insertions_and_deletions nor find_gaps can produce a task, and unless the mate-anchored rescue applies there is
+// nothing to do.  This is that test, made on a handful of hits before any of the general machinery runs; `true` is a
+// promise that indels_enumerate + gaps_prepare/gaps_enumerate would emit nothing for this read.  (A read without
+// any hit is trivial too.)  Anything else -- and any doubt -- returns false.
+THJ_HD bool read_is_trivial(const Params& p, const ReadView& v) {
+    if (v.nseg < 1) return true;
+    const uint32_t first = v.so[0];
+    if (v.so[v.nseg] == first) return true;                                   // no hit at all
+    for (int s = 0; s < v.nseg; ++s) if (v.so[s + 1] - v.so[s] != 1u) return false;
+    const Hit h0 = v.hits[first];
+    const bool anti = hit_anti(h0);
+    if (v.nseg == 1) return hit_end(h0) || v.n_mate == 0;                     // find_gaps :3316-3318, else rescue decides
+    const int L = p.segment_length;
+    Hit prev = h0;
+    for (int s = 1; s < v.nseg; ++s) {
+        const Hit h = v.hits[first + s];
+        if (h.ref_id != h0.ref_id || hit_anti(h) != anti) return false;
+        if (!((anti && h.right == prev.left) || (!anti && prev.right == h.left))) return false;   // must abut (:3530-3545)
+        if (s + 1 < v.nseg) {                                                 // the pair (s-1, s) of find_insertions_and_deletions
+            const int start = (s - 1) * L;
+            if (start > v.rl) return false;
+            const int plen = v.rl - start < 2 * L ? v.rl - start : 2 * L;
+            const int apparent = anti ? prev.right - h.left : h.right - prev.left;
+            if (apparent != plen) return false;
+        }
+        prev = h;
+    }
+    // rescue decision of find_gaps (:3330-3393): first against last segment
+    const int dist = anti ? h0.left - prev.right : prev.left - h0.right;
+    if (dist >= p.min_segment_intron && dist < p.max_segment_intron) return true;
+    return v.n_mate == 0;
 }
 
 // The body of find_gaps after the rescue (segment_juncs.cpp:3499-3617).

@@ -42,10 +42,7 @@ struct thj_ctx {
     unsigned long long* h_pinned = nullptr;     // [16] pinned staging
     void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     int64_t n_junc = 0, n_del = 0, n_ins = 0;
-    // rescue scratch
-    uint32_t* d_npairs = nullptr; uint32_t* d_pair_off = nullptr; int64_t pairs_cap_reads = 0;
-    int32_t* d_slots = nullptr; int64_t slots_cap = 0;
-    void* d_scan_tmp = nullptr; size_t scan_tmp_bytes = 0;
+    uint32_t* d_rescue_list = nullptr; int64_t rescue_list_cap = 0;      // reads taking the mate-anchored rescue + per-workgroup counts
     // long_spanning_reads (thj_span.hip)
     u64* d_span_junc = nullptr; int64_t n_span_junc = 0; int64_t cap_span_junc = 0;
     u64* d_span_ins_key = nullptr; uint32_t* d_span_ins_seq = nullptr; int64_t n_span_ins = 0; int64_t cap_span_ins = 0;

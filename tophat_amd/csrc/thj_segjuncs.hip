@@ -1,17 +1,11 @@
 // thj_segjuncs.hip -- gfx950 kernels + C ABI for the segment_juncs hot path.
 //
-// Kernel plan for one batch of reads (one thj_segjuncs_run_async call):
-//   thj_k_rescue_count   1 thread / read   head of find_gaps: does the read take the
-//                                          mate-anchored rescue?  -> #(hit, mate-hit) pairs
-//   hipcub ExclusiveSum                    pair slots CSR
-//   thj_k_rescue_scan    1 thread / pair   map_read_to_contig over the mate flank, bit-parallel
-//   thj_k_segjuncs       1 thread / read   (the dominant kernel) phase A: stream the read's hit
-//                                          records, enumerate RefSeg windows and indel pairs into
-//                                          an LDS task queue; phase B: one thread per queued task
-//                                          fetches the two 64-base window ends + the support read
-//                                          and does the whole motif/mismatch scan with 64-bit
-//                                          plane arithmetic; events go to HBM hash tables
-//                                          (set semantics of the reference's std::sets).
+// One kernel per batch of reads (one thj_segjuncs_run_async call): thj_k_segjuncs walks tiles of 256 reads --
+// stage the tile's hits in LDS, drop the unspliced reads, run the mate-anchored rescue (map_read_to_contig) for
+// the reads that take it, enumerate RefSeg windows and indel pairs into an LDS task queue, and execute the
+// queued tasks in full rounds: one thread per task fetches the two 64-base window ends + the support read and
+// does the whole motif/mismatch scan with 64-bit plane arithmetic.  Events go to HBM hash tables (set semantics
+// of the reference's std::sets).
 // thj_segjuncs_finish: thj_k_compact (table -> dense keys) + hipcub radix sort.
 //
 // No MFMA: this is integer compare / popcount work bound by HBM record streaming.
@@ -142,48 +136,10 @@ __device__ __forceinline__ ReadView make_view(const DevBatch& b, int r) {
     return v;
 }
 
-// ------------------------------------------------------------------ rescue
-
-__global__ __launch_bounds__(256) void thj_k_rescue_count(Params p, DevBatch b, uint32_t* npairs) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= b.n_reads) return;
-    ReadView v = make_view(b, r);
-    bool wants = false;
-    uint32_t n = 0;
-    if (gaps_prepare(p, v, wants) && wants) n = (uint32_t)rv_count_raw(v, 0) * (uint32_t)v.n_mate;
-    npairs[r] = n;
-}
-
-__global__ __launch_bounds__(256) void thj_k_rescue_scan(Genome g, Params p, DevBatch b, const uint32_t* pair_off,
-                                                         int32_t* slots, unsigned long long* cnt) {
-    const uint32_t total = pair_off[b.n_reads];
-    unsigned int local = 0;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < total; k += gridDim.x * blockDim.x) {
-        // read owning pair k: last r with pair_off[r] <= k
-        int lo = 0, hi = b.n_reads;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (pair_off[mid] <= k) lo = mid; else hi = mid;
-        }
-        int r = lo;
-        ReadView v = make_view(b, r);
-        uint32_t j = k - pair_off[r];
-        int l = (int)(j / (uint32_t)v.n_mate), m = (int)(j % (uint32_t)v.n_mate);
-        Hit lh = v.hits[v.so[0] + l];
-        Hit rh = v.mate[m];
-        int32_t f, rv;
-        rescue_pair(g, p, v.rp, v.W, v.rl, lh, rh, f, rv);
-        slots[2 * (size_t)k] = f;
-        slots[2 * (size_t)k + 1] = rv;
-        if (f != SLOT_BREAK && lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) ++local;
-    }
-    if (local) atomicAdd(&cnt[CNT_RESCUE_PAIRS], (unsigned long long)local);
-}
-
 // ------------------------------------------------------------------ main kernel
 
 static constexpr int TPB = 256;
-static constexpr int QCAP = 768;           // task queue entries (LDS); a typical tile of 256 reads adds a few dozen
+static constexpr int QCAP = 512;           // task queue entries (LDS); a typical tile of 256 reads adds a few dozen
 
 struct Queue {
     uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e;
@@ -235,27 +191,64 @@ __device__ __forceinline__ ReadView make_task_view(const DevBatch& b, int r) {
     return v;
 }
 
-// One workgroup walks tiles of 256 consecutive reads.
-//   enumerate: find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
+// Queued tasks are rare (a few dozen per 256 reads), so they pile up over several tiles and run in whole rounds
+// of 256 -- every lane busy -- with the remainder (`keep`) carried over; `flush` runs everything.
+struct TaskQueue { uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e; unsigned int* n; };
+
+__device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, const DevBatch& b, EventSink& ev, const TaskQueue& q, bool flush) {
+    const int tid = threadIdx.x;
+    const unsigned int have = *q.n;
+    const unsigned int keep = flush ? 0u : have % (unsigned)TPB;
+    if (have - keep > 0 && !THJ_EXPF(1 << 16)) {
+        for (unsigned int k = keep + tid; k < have; k += TPB) {
+            const uint32_t a = q.a[k];
+            const int tr = (int)q.e[k];
+            ReadView tv = make_task_view(b, tr);
+            const bool anti = (a >> 9) & 1u;
+            if (a & (1u << 8)) {
+                const bool is_del = (a >> 10) & 1u;
+                const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 127u);
+                const uint32_t d = q.d[k];
+                indel_exec(g, p, tv, i, q.b[k], q.c[k], anti, plen, is_del,
+                           ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(d & 0xFFFF), (int)(d >> 16)), ev);
+            } else {
+                const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 63u);
+                window_exec(g, p, tv, q.b[k], (int32_t)q.c[k], (int32_t)q.d[k], anti, start, slen, ev);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) *q.n = keep;
+    }
+}
+
+// Reads that take the mate-anchored rescue (find_gaps :3330-3497) are few and their map_read_to_contig scans long,
+// so the main kernel only lists them -- per workgroup, in its own slice of `list`, no global append counter -- and
+// thj_k_segjuncs_rescue handles them densely afterwards.
+struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; };
+
+// Main kernel.  One workgroup walks tiles of 256 consecutive reads.
+//   stage:     find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
 //              from HBM that is a dozen round trips per read, so a tile's CSR offsets and its (contiguous) hits are
-//              first staged in LDS with two coalesced sweeps and the per-read logic runs on the LDS copy.  The
-//              windows and indel pairs it finds are queued as tasks.
-//   execute:   tasks are rare (a few dozen per tile), so they are left to pile up over several tiles and run in
-//              whole rounds of 256 -- every lane busy -- with the remainder carried over.
-// Dynamic LDS: 5 x QCAP queue words | TPB*nseg+1 offsets | hit_cap hits.
-__global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBatch b, Tables t,
-                                                      const uint32_t* pair_off, const int32_t* slots, int hit_cap) {
+//              first copied to LDS with two coalesced sweeps and the per-read logic runs on the LDS copy.
+//   classify:  most reads are unspliced (read_is_trivial) and are dropped here; rescue reads go to the rescue list,
+//              the rest to a dense work list.
+//   enumerate: the general enumeration over the work list only; windows and indel pairs are queued as tasks.
+//   execute:   run_tasks.
+// Dynamic LDS: 5 x QCAP queue words | TPB*nseg+1 offsets | hit_cap hits | work list.
+__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, DevBatch b, Tables t, RescueList rl, int hit_cap) {
     extern __shared__ uint4 dyn_lds[];
     uint32_t* q_a = (uint32_t*)dyn_lds;
     uint32_t* q_b = q_a + QCAP; uint32_t* q_c = q_b + QCAP; uint32_t* q_d = q_c + QCAP; uint32_t* q_e = q_d + QCAP;
     uint32_t* s_so = q_e + QCAP;
     uint4* s_hits = (uint4*)(s_so + ((TPB * b.nseg + 1 + 3) & ~3));
-    __shared__ unsigned int q_n;
+    uint32_t* s_work = (uint32_t*)(s_hits + hit_cap);
+    __shared__ unsigned int q_n, s_nwork, s_nresc;
     __shared__ unsigned int s_stat[4];
     const int tid = threadIdx.x;
     if (tid < 4) s_stat[tid] = 0;
-    if (tid == 0) q_n = 0;
+    if (tid == 0) { q_n = 0; s_nresc = 0; }
     EventSink ev{g, t};
+    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const int n_tiles = (b.n_reads + TPB - 1) / TPB;
     // consecutive tiles go to consecutive workgroups (-> different XCDs): every XCD's L2
     // streams its own contiguous slices of the hit array, the genome lines are shared by L3.
@@ -266,6 +259,7 @@ __global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBat
         const int n_so = tile_reads * b.nseg + 1;
         __syncthreads();                                  // the previous tile's readers are done with the LDS copy
         for (int i = tid; i < n_so; i += TPB) s_so[i] = b.seg_off[(size_t)r0 * b.nseg + i];
+        if (tid == 0) s_nwork = 0;
         __syncthreads();
         const unsigned int q_before = q_n;               // tasks carried over from earlier tiles
         const uint32_t h0 = s_so[0], nh_tile = s_so[n_so - 1] - h0;
@@ -276,33 +270,43 @@ __global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBat
             for (uint32_t i = tid; i < nh_tile; i += TPB) s_hits[i] = ((const uint4*)b.hits)[h0 + i];
         }
         __syncthreads();
-        // ---- enumerate
-        const int r = r0 + tid;
-        unsigned int nw = 0, ni = 0, nh = 0;
-        ReadView v;
-        bool active = r < b.n_reads;
-        bool do_gaps = false;
-        if (active) {
-            v = make_view(b, r);
+        const Hit* tile_hits = staged ? (const Hit*)s_hits : b.hits;
+        // ---- classify
+        if (tid < tile_reads) {
+            ReadView v = make_view(b, r0 + tid);
             v.so = s_so + tid * b.nseg;
-            if (staged) v.hits = (const Hit*)s_hits;
-            nh = v.so[v.nseg] - v.so[0];
+            v.hits = tile_hits;
+            const unsigned int nh = v.so[v.nseg] - v.so[0];
+            if (nh) atomicAdd(&s_stat[2], nh);
+            if (!read_is_trivial(p, v)) {
+                bool wants = false;
+                if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants)
+                    rl.list[(size_t)blockIdx.x * rl.seg_cap + atomicAdd(&s_nresc, 1u)] = (uint32_t)(r0 + tid);
+                else s_work[atomicAdd(&s_nwork, 1u)] = (uint32_t)tid;
+            }
+        }
+        __syncthreads();
+        // ---- enumerate (work list)
+        const bool active = (unsigned)tid < s_nwork;
+        ReadView v;
+        bool do_gaps = false;
+        int r = 0;
+        if (active) {
+            const int lr = (int)s_work[tid];
+            r = r0 + lr;
+            v = make_view(b, r);
+            v.so = s_so + lr * b.nseg;
+            v.hits = tile_hits;
             QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, staged ? h0 : 0u, 0u, 0u};
             if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs);
             bool wants = false;
             do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants);
-            if (do_gaps) {
-                if (wants) { v.slots = slots + 2 * (size_t)pair_off[r]; v.rescue = true; }
-                gaps_enumerate(p, v, qs);
-            }
-            nw = qs.n_windows; ni = qs.n_indels;
+            if (do_gaps) gaps_enumerate(p, v, qs);
+            if (qs.n_windows) atomicAdd(&s_stat[0], qs.n_windows);
+            if (qs.n_indels) atomicAdd(&s_stat[1], qs.n_indels);
         }
-        if (nw) atomicAdd(&s_stat[0], nw);
-        if (ni) atomicAdd(&s_stat[1], ni);
-        if (nh) atomicAdd(&s_stat[2], nh);
         __syncthreads();
-        const unsigned int total = q_n;
-        if (total > (unsigned)QCAP) {
+        if (q_n > (unsigned)QCAP) {
             // the queue overflowed (multihit-heavy tile): drop this tile's queued tasks and run the tile un-queued.
             if (tid == 0) atomicAdd(&s_stat[3], 1u);
             if (active) {
@@ -314,36 +318,116 @@ __global__ __launch_bounds__(TPB) void thj_k_segjuncs(Genome g, Params p, DevBat
             if (tid == 0) q_n = q_before;
             __syncthreads();
         }
-        // ---- execute whole rounds; everything on the last tile
-        const unsigned int have = q_n;
-        const bool last_tile = tile + (int)gridDim.x >= n_tiles;
-        const unsigned int keep = last_tile ? 0u : have % (unsigned)TPB;
-        if (have - keep > 0 && !THJ_EXPF(1 << 16)) {
-            for (unsigned int k = keep + tid; k < have; k += TPB) {
-                const uint32_t a = q_a[k];
-                const int tr = (int)q_e[k];
-                ReadView tv = make_task_view(b, tr);
-                const bool anti = (a >> 9) & 1u;
-                if (a & (1u << 8)) {
-                    const bool is_del = (a >> 10) & 1u;
-                    const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 127u);
-                    const uint32_t d = q_d[k];
-                    indel_exec(g, p, tv, i, q_b[k], q_c[k], anti, plen, is_del,
-                               ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(d & 0xFFFF), (int)(d >> 16)), ev);
-                } else {
-                    const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 63u);
-                    window_exec(g, p, tv, q_b[k], (int32_t)q_c[k], (int32_t)q_d[k], anti, start, slen, ev);
+        run_tasks(g, p, b, ev, tq, tile + (int)gridDim.x >= n_tiles);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rl.blk_cnt[blockIdx.x] = s_nresc;
+        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd(&t.cnt[CNT_HITS], (unsigned long long)s_stat[2]);
+        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+    }
+}
+
+// Rescue kernel: one thread per listed read, all lanes scanning.  The read's (hit, mate hit) pairs are mapped
+// (map_read_to_contig over the mate flank, rescue_pair) into a small per-thread LDS slot area -- reads with more
+// pairs than fit recompute them as rv_foreach walks the pseudo-hit list -- then the general enumeration runs with the
+// rescued hits in place and its windows are queued and executed as in the main kernel.
+static constexpr int RPT = 4;             // rescue pairs per thread kept in LDS
+static constexpr int MAX_LISTS = 2048;    // workgroups of the main kernel = slices of the rescue list
+
+__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params p, DevBatch b, Tables t, RescueList rl, int n_lists) {
+    __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
+    __shared__ int32_t s_slots[TPB * RPT * 2];
+    __shared__ unsigned int s_off[MAX_LISTS + 1];
+    __shared__ unsigned int q_n;
+    __shared__ unsigned int s_stat[4];
+    __shared__ Genome s_g;            // copies the on-the-fly rescue can point at (kernel arguments have no address)
+    __shared__ Params s_p;
+    typedef hipcub::BlockScan<unsigned int, TPB> Scan;
+    __shared__ typename Scan::TempStorage scan_tmp;
+    const int tid = threadIdx.x;
+    if (tid < 4) s_stat[tid] = 0;
+    if (tid == 0) { q_n = 0; s_g = g; s_p = p; }
+    // offsets of the per-workgroup slices in their concatenation
+    unsigned int total;
+    {
+        constexpr int IPT = MAX_LISTS / TPB;
+        unsigned int cnt[IPT], sum = 0, excl;
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { const int j = tid * IPT + k; cnt[k] = j < n_lists ? rl.blk_cnt[j] : 0u; sum += cnt[k]; }
+        Scan(scan_tmp).ExclusiveSum(sum, excl, total);
+#pragma unroll
+        for (int k = 0; k < IPT; ++k) { s_off[tid * IPT + k] = excl; excl += cnt[k]; }
+        if (tid == 0) s_off[MAX_LISTS] = total;
+    }
+    __syncthreads();
+    EventSink ev{g, t};
+    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const unsigned int per_round = gridDim.x * TPB;
+    const unsigned int rounds = (total + per_round - 1) / per_round;
+    for (unsigned int it = 0; it < rounds; ++it) {
+        const unsigned int i = (it * gridDim.x + blockIdx.x) * TPB + tid;
+        const bool active = i < total;
+        __syncthreads();
+        const unsigned int q_before = q_n;
+        __syncthreads();
+        ReadView v;
+        bool do_gaps = false;
+        int r = 0;
+        if (active) {
+            int lo = 0, hi = n_lists;                    // slice holding entry i: last one with s_off <= i
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+            r = (int)rl.list[(size_t)lo * rl.seg_cap + (i - s_off[lo])];
+            v = make_view(b, r);
+            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
+            indels_enumerate(p, v, qs);
+            bool wants = false;
+            do_gaps = gaps_prepare(p, v, wants);
+            if (do_gaps) {
+                if (wants) {
+                    const int n_left = rv_count_raw(v, 0);
+                    const bool fits = (int64_t)n_left * v.n_mate <= RPT;
+                    int32_t* mine = s_slots + tid * RPT * 2;
+                    unsigned int local = 0;
+                    for (int l = 0; l < n_left; ++l)
+                        for (int m = 0; m < v.n_mate; ++m) {
+                            const Hit lh = v.hits[v.so[0] + l], rh = v.mate[m];
+                            int32_t f, rv;
+                            rescue_pair(g, p, v.rp, v.W, v.rl, lh, rh, f, rv);
+                            if (fits) { mine[2 * (l * v.n_mate + m)] = f; mine[2 * (l * v.n_mate + m) + 1] = rv; }
+                            if (f != SLOT_BREAK && lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) ++local;
+                        }
+                    if (local) atomicAdd(&s_stat[2], local);
+                    v.rescue = true;
+                    v.slots = fits ? mine : nullptr;
+                    v.lazy_g = &s_g; v.lazy_p = &s_p;
                 }
+                gaps_enumerate(p, v, qs);
+            }
+            if (qs.n_windows) atomicAdd(&s_stat[0], qs.n_windows);
+            if (qs.n_indels) atomicAdd(&s_stat[1], qs.n_indels);
+        }
+        __syncthreads();
+        if (q_n > (unsigned)QCAP) {
+            if (tid == 0) atomicAdd(&s_stat[3], 1u);
+            if (active) {
+                InlineSink is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                indels_enumerate(p, v, is);
+                if (do_gaps) gaps_enumerate(p, v, is);
             }
             __syncthreads();
-            if (tid == 0) q_n = keep;
+            if (tid == 0) q_n = q_before;
+            __syncthreads();
         }
+        run_tasks(g, p, b, ev, tq, it + 1 == rounds);
     }
     __syncthreads();
     if (tid == 0) {
         if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
-        if (s_stat[2]) atomicAdd(&t.cnt[CNT_HITS], (unsigned long long)s_stat[2]);
+        if (s_stat[2]) atomicAdd(&t.cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[2]);
         if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
@@ -480,9 +564,8 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     free_tables(c);
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
-    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n);
+    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list);
     hipHostFree(c->h_pinned);
-    hipFree(c->d_npairs); hipFree(c->d_pair_off); hipFree(c->d_slots); hipFree(c->d_scan_tmp);
     thj_span_free(c);
     hipFree(c->d_fus); hipFree(c->d_fus_count);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -639,71 +722,56 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
              (u64)c->indel_cap - 1, c->d_ovf, c->d_cnt};
     const int n = b.n_reads;
 
-    if (b.mate_off) {
-        if (c->pairs_cap_reads < n) {
-            hipFree(c->d_npairs); hipFree(c->d_pair_off); hipFree(c->d_scan_tmp);
-            c->d_npairs = c->d_pair_off = nullptr; c->d_scan_tmp = nullptr;
-            HIPCHK(hipMalloc(&c->d_npairs, (size_t)(n + 1) * 4));
-            HIPCHK(hipMalloc(&c->d_pair_off, (size_t)(n + 1) * 4));
-            size_t need = 0;
-            HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, (uint32_t*)nullptr, (uint32_t*)nullptr, n + 1, c->stream));
-            HIPCHK(hipMalloc(&c->d_scan_tmp, need ? need : 16));
-            c->scan_tmp_bytes = need;
-            c->pairs_cap_reads = n;
-        }
-        HIPCHK(hipMemsetAsync(c->d_npairs + n, 0, 4, c->stream));
-        hipLaunchKernelGGL(thj_k_rescue_count, dim3((n + 255) / 256), dim3(256), 0, c->stream, p, b, c->d_npairs);
-        size_t tmp = c->scan_tmp_bytes;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_scan_tmp, tmp, c->d_npairs, c->d_pair_off, n + 1, c->stream));
-        HIPCHK(hipMemcpyAsync(&c->h_pinned[16], c->d_pair_off + n, 4, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        const int64_t total = (int64_t)(*(uint32_t*)&c->h_pinned[16]);
-        if (total > c->slots_cap) {
-            hipFree(c->d_slots);
-            c->d_slots = nullptr;
-            c->slots_cap = total + total / 4 + 1024;
-            HIPCHK(hipMalloc(&c->d_slots, (size_t)c->slots_cap * 8));
-        }
-        if (total > 0) {
-            int64_t blocks = (total + 255) / 256;
-            if (blocks > 4096) blocks = 4096;
-            hipLaunchKernelGGL(thj_k_rescue_scan, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b,
-                               (const uint32_t*)c->d_pair_off, c->d_slots, c->d_cnt);
-        }
-        if (!c->d_slots) { c->slots_cap = 1024; HIPCHK(hipMalloc(&c->d_slots, (size_t)c->slots_cap * 8)); }
-    }
-
 #ifdef THJ_EXP
     { int f = getenv("THJ_EXP_FLAGS") ? atoi(getenv("THJ_EXP_FLAGS")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(thj_exp_flags), &f, sizeof f)); }
 #endif
     const int n_tiles = (n + TPB - 1) / TPB;
     int grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;       // 256 CUs x 8 resident workgroups, grid-stride the rest
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
-    // LDS: task queue, the tile's offsets, and room for 1.25 hits per segment (tiles with more read hits from HBM)
-    const int hit_cap = TPB * b.nseg + TPB * b.nseg / 4;
-    const size_t lds = (size_t)5 * QCAP * 4 + (size_t)((TPB * b.nseg + 1 + 3) & ~3) * 4 + (size_t)hit_cap * 16;
-    hipLaunchKernelGGL(thj_k_segjuncs, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t,
-                       (const uint32_t*)c->d_pair_off, (const int32_t*)c->d_slots, hit_cap);
-    if (c->profile) { HIPCHK(hipEventRecord(e1, c->stream)); c->prof_events.emplace_back(e0, e1); }
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
+    // LDS: task queue, the tile's offsets, room for 1.125 hits per segment (tiles with more read hits from HBM), work list
+    const int hit_cap = TPB * b.nseg + TPB * b.nseg / 8;
+    const size_t lds = (size_t)5 * QCAP * 4 + (size_t)((TPB * b.nseg + 1 + 3) & ~3) * 4 + (size_t)hit_cap * 16 + (size_t)TPB * 4;
+    // rescue list: one slice per workgroup, sized for all the reads the workgroup visits
+    RescueList rl;
+    rl.seg_cap = (n_tiles + grid - 1) / grid * TPB;
+    const int64_t need = (int64_t)grid * rl.seg_cap + MAX_LISTS;
+    if (c->rescue_list_cap < need) {
+        hipFree(c->d_rescue_list); c->d_rescue_list = nullptr;
+        HIPCHK(hipMalloc(&c->d_rescue_list, (size_t)need * 4));
+        c->rescue_list_cap = need;
+    }
+    rl.list = c->d_rescue_list;
+    rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap;
+    hipLaunchKernelGGL(thj_k_segjuncs, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
+    if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
+    if (b.mate_off) {
+        const int rgrid = grid < 1024 ? grid : 1024;
+        hipLaunchKernelGGL(thj_k_segjuncs_rescue, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
+    }
+    if (c->profile) { HIPCHK(hipEventRecord(e2, c->stream)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(e1, e2); }
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
 
 extern "C" int thj_profile_segjuncs(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
+    // avg_ms[2]: thj_k_segjuncs, thj_k_segjuncs_rescue (one pair per thj_segjuncs_run_async)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    double sum = 0;
-    for (auto& pr : c->prof_events) {
+    double sum[2] = {0, 0};
+    const size_t n = c->prof_events.size() / 2;
+    for (size_t i = 0; i < c->prof_events.size(); ++i) {
         float ms = 0;
-        HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
-        sum += ms;
-        c->event_pool.push_back(pr.first);
-        c->event_pool.push_back(pr.second);
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+        sum[i % 2] += ms;
     }
-    if (launches) *launches = (int64_t)c->prof_events.size();
-    if (avg_ms) *avg_ms = c->prof_events.empty() ? 0.0 : sum / (double)c->prof_events.size();
+    for (size_t i = 0; i < c->prof_events.size(); ++i) {        // the middle event is shared by the two intervals
+        c->event_pool.push_back(c->prof_events[i].first);
+        if (i % 2) c->event_pool.push_back(c->prof_events[i].second);
+    }
+    if (launches) *launches = (int64_t)n;
+    if (avg_ms) { avg_ms[0] = n ? sum[0] / (double)n : 0.0; avg_ms[1] = n ? sum[1] / (double)n : 0.0; }
     c->prof_events.clear();
     c->profile = enable != 0;
     return THJ_OK;

@@ -248,12 +248,13 @@ class Context:
             self.run(p, b)
         return self.download(self.finish())
 
-    def profile(self, enable: bool = True) -> Tuple[float, int]:
-        ms = C.c_double()
+    def profile(self, enable: bool = True) -> Tuple[Tuple[float, float], int]:
+        """((thj_k_segjuncs ms, thj_k_segjuncs_rescue ms), runs) since the last call"""
+        ms = (C.c_double * 2)()
         n = C.c_int64()
-        _check(self.lib, self.lib.thj_profile_segjuncs(self._ctx, 1 if enable else 0, C.byref(ms), C.byref(n)),
+        _check(self.lib, self.lib.thj_profile_segjuncs(self._ctx, 1 if enable else 0, ms, C.byref(n)),
                "thj_profile_segjuncs")
-        return ms.value, n.value
+        return (ms[0], ms[1]), n.value
 
     def device_keys(self, kind: int) -> Tuple[int, int]:
         p = C.c_void_p()
