@@ -159,7 +159,19 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
     for (int64_t i = 0; i < n_ins; ++i) { ik[i] = ins_key(g, ins[4 * i], ins[4 * i + 1], (int)ins[4 * i + 2]); iseq[i] = ins[4 * i + 3]; }
     for (int64_t i = 1; i < n_juncs; ++i) if (jk[i] <= jk[i - 1]) return -10;   // must already be sorted unique
     for (int64_t i = 1; i < n_ins; ++i) if (ik[i] <= ik[i - 1]) return -11;
-    SpanSets S{jk.data(), n_juncs, ik.data(), iseq.data(), n_ins};
+    SpanSets S{jk.data(), n_juncs, ik.data(), iseq.data(), n_ins, nullptr, 0};
+    // mode 0 runs as the kernels do: with the coarse bucket index over the junction keys
+    std::vector<uint32_t> bucket;
+    if (mode == 0) {
+        int64_t n_blocks = 0;
+        for (int32_t k = 0; k < n_contigs; ++k) { int64_t e = (int64_t)contig_blk[k] + (contig_len[k] + 63) / 64 + 2; if (e > n_blocks) n_blocks = e; }
+        const int64_t nb = ((n_blocks * 64 + 2) >> JUNC_BUCKET_SHIFT) + 1;
+        bucket.resize((size_t)nb + 1);
+        for (int64_t bk = 0; bk <= nb; ++bk)
+            bucket[(size_t)bk] = (uint32_t)lower_bound_u64(jk.data(), n_juncs, (u64)bk << (JUNC_BUCKET_SHIFT + 30));
+        bucket[(size_t)nb] = (uint32_t)n_juncs;
+        S.junc_bucket = bucket.data(); S.n_buckets = nb;
+    }
     std::vector<OutAln> res;
     VecSink sink{&res};
     status_counts[0] = status_counts[1] = status_counts[2] = status_counts[3] = status_counts[4] = 0;
@@ -170,8 +182,9 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                                   read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
             if (st == SPAN_NEED_LEAN) {
                 status_counts[4]++;
+                SpanHit stage[SPAN_MAXSEG];
                 st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
-                                    read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+                                    read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
             }
         }
         if (st == SPAN_NEED_GENERIC) {

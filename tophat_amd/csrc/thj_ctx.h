@@ -44,6 +44,7 @@ struct thj_ctx {
     int64_t n_junc = 0, n_del = 0, n_ins = 0;
     uint32_t* d_rescue_list = nullptr; int64_t rescue_list_cap = 0;      // reads taking the mate-anchored rescue + per-workgroup counts
     // long_spanning_reads (thj_span.hip)
+    uint32_t* d_junc_bucket = nullptr; int64_t n_junc_buckets = 0;     // coarse index over d_span_junc (junc_range)
     u64* d_span_junc = nullptr; int64_t n_span_junc = 0; int64_t cap_span_junc = 0;
     u64* d_span_ins_key = nullptr; uint32_t* d_span_ins_seq = nullptr; int64_t n_span_ins = 0; int64_t cap_span_ins = 0;
     void* d_aln_pool = nullptr; void* d_aln_sorted = nullptr; int64_t aln_cap = 0;

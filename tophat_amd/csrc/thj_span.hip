@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, D
 // Tiers 1 and 2 walk the concatenation of the per-block slices so that every lane has work whatever the spread of
 // spliced / multihit reads over the batch: each block scans the (at most 2048) slice lengths into LDS, and entry i
 // of the concatenation is found by a binary search there.
-static constexpr int MAX_SLICES = 2048;
+static constexpr int MAX_SLICES = 1024;
 template <int TPB>
 __device__ unsigned int slice_offsets(const unsigned int* blk_cnt, int G, unsigned int* s_off /* [MAX_SLICES + 1] */) {
     constexpr int IPT = MAX_SLICES / TPB;
@@ -159,15 +159,17 @@ __device__ __forceinline__ int slice_of(const unsigned int* s_off, int G, unsign
 
 // Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain on registers.
 __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    extern __shared__ uint4 lds_stage[];          // nseg hits per thread
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
+    SpanHit* stage = (SpanHit*)lds_stage + (size_t)threadIdx.x * b.nseg;
     const unsigned int total = slice_offsets<256>(t.blk_lean, G, s_off);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_lean[(int64_t)sl * t.chunk + (i - s_off[sl])];
         int st = span_read_lean(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
-                                (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+                                (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, stage, sink);
         if (st == SPAN_NEED_GENERIC) {          // rare: more cigar ops than the registers hold
             t.wl_multi[(int64_t)sl * t.chunk + atomicAdd(&t.blk_multi[sl], 1u)] = (uint32_t)r;
             atomicAdd(&t.counters[1], 1u);
@@ -204,8 +206,30 @@ __global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u6
     }
 }
 
+// junc_bucket[b] = first key whose left position is >= b << JUNC_BUCKET_SHIFT (see junc_range)
+__global__ __launch_bounds__(256) void thj_k_junc_buckets(const u64* keys, int64_t n, uint32_t* bucket, int64_t n_buckets) {
+    for (int64_t bk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; bk <= n_buckets; bk += (int64_t)gridDim.x * blockDim.x)
+        bucket[bk] = bk == n_buckets ? (uint32_t)n : (uint32_t)lower_bound_u64(keys, n, (u64)bk << (JUNC_BUCKET_SHIFT + 30));
+}
+
+static int build_junc_buckets(thj_ctx* c) {
+    const int64_t nb = ((c->n_blocks * 64 + 2) >> JUNC_BUCKET_SHIFT) + 1;
+    if (c->n_span_junc >= (1ll << 32)) { thj_set_error("more than 2^32 junctions"); return THJ_EINVAL; }
+    if (nb != c->n_junc_buckets || !c->d_junc_bucket) {
+        hipFree(c->d_junc_bucket); c->d_junc_bucket = nullptr;
+        HIPCHK(hipMalloc(&c->d_junc_bucket, (size_t)(nb + 1) * 4));
+        c->n_junc_buckets = nb;
+    }
+    int64_t blocks = (nb + 256) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(thj_k_junc_buckets, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const u64*)c->d_span_junc, c->n_span_junc,
+                       c->d_junc_bucket, nb);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
 void thj_span_free(thj_ctx* c) {
-    hipFree(c->d_span_junc); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq);
+    hipFree(c->d_span_junc); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -271,7 +295,7 @@ extern "C" int thj_span_sets_upload(thj_ctx* c, const thj_junction* juncs, int64
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     c->n_span_junc = n_juncs; c->n_span_ins = n_ins;
-    return THJ_OK;
+    return build_junc_buckets(c);
 }
 
 extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
@@ -312,6 +336,7 @@ extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
                            (const u64*)c->d_ins_val_sorted, ni, c->d_span_ins_key, c->d_span_ins_seq);
     }
     c->n_span_ins = ni;
+    if ((rc = build_junc_buckets(c))) return rc;
     HIPCHK(hipStreamSynchronize(c->stream));
     return THJ_OK;
 }
@@ -424,7 +449,7 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevSpanBatch b; memcpy(&b, db, sizeof b);
-    SpanSets S{c->d_span_junc, c->n_span_junc, c->d_span_ins_key, c->d_span_ins_seq, c->n_span_ins};
+    SpanSets S{c->d_span_junc, c->n_span_junc, c->d_span_ins_key, c->d_span_ins_seq, c->n_span_ins, c->d_junc_bucket, c->n_junc_buckets};
     const uint32_t base = (uint32_t)c->span_reads;
 #ifdef THJ_EXP
     { int f = getenv("THJ_EXP_FLAGS") ? atoi(getenv("THJ_EXP_FLAGS")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(thj_exp_flags), &f, sizeof f)); }
@@ -434,12 +459,12 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
                  (unsigned long long)c->ovf_cap, c->d_aln_count, c->d_span_status, 0, 0};
     // block-owned slices of the worklists (see Tiers)
     int64_t G = ((int64_t)b.n_reads + 511) / 512;
-    if (G > 2048) G = 2048;
+    if (G > MAX_SLICES) G = MAX_SLICES;               // 4 resident workgroups per CU: one full wave of equal chunks
     if (G < 1) G = 1;
     int64_t chunk = ((int64_t)b.n_reads + G - 1) / G;
     chunk = (chunk + 255) / 256 * 256;
     G = ((int64_t)b.n_reads + chunk - 1) / chunk;
-    const int64_t wl_need = 2 * G * chunk + 2 * 2048;
+    const int64_t wl_need = 2 * G * chunk + 2 * MAX_SLICES;
     if (c->worklist_cap < wl_need) {
         hipFree(c->d_worklist); c->d_worklist = nullptr;
         HIPCHK(hipMalloc(&c->d_worklist, (size_t)wl_need * 4));
@@ -449,7 +474,7 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     t.wl_lean = c->d_worklist;
     t.wl_multi = c->d_worklist + G * chunk;
     t.blk_lean = c->d_worklist + 2 * G * chunk;
-    t.blk_multi = t.blk_lean + 2048;
+    t.blk_multi = t.blk_lean + MAX_SLICES;
     t.counters = &c->d_span_status[4];
     t.chunk = (int)chunk;
     HIPCHK(hipMemsetAsync(t.counters, 0, 8, c->stream));
@@ -457,8 +482,8 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
     hipLaunchKernelGGL(thj_k_stitch_contig, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
-    const int64_t g1 = G < 1024 ? G : 1024, g2 = G < 2048 ? G : 2048;     // tier 1: 4 resident blocks per CU
-    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)g1), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G);
+    const int64_t g1 = G, g2 = G;
+    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
     hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)g2), dim3(128), 0, c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) {

@@ -24,6 +24,8 @@ THJ_HD int cig_op(uint32_t c) { return (int)(c >> 28); }
 THJ_HD uint32_t cig_len(uint32_t c) { return c & 0x0FFFFFFFu; }
 THJ_HD bool op_is_match(int op) { return op == OP_MATCH || op == OP_mATCH; }
 
+struct alignas(16) Q16 { uint32_t x, y, z, w; };     // one 16-byte load / store
+
 struct SpanHit {            // == thj_span_hit, 32 bytes
     uint32_t ref_id;
     int32_t left;
@@ -136,7 +138,11 @@ THJ_HD int rc_gap_len(const RCig& c, int n) {
 struct SpanSets {
     const u64* junc_keys;  int64_t n_juncs;      // junc_key() order == Junction::operator<
     const u64* ins_keys;   const uint32_t* ins_seq; int64_t n_ins;   // ins_key() order; seq 3 bits/base
+    // optional coarse index over junc_keys: junc_bucket[b] = first key whose left position (key >> 30) is >=
+    // b << JUNC_BUCKET_SHIFT, junc_bucket[n_buckets] = n_juncs.  Null: plain binary searches.
+    const uint32_t* junc_bucket; int64_t n_buckets;
 };
+static constexpr int JUNC_BUCKET_SHIFT = 8;
 
 THJ_HD int64_t lower_bound_u64(const u64* a, int64_t n, u64 k) {   // first i with a[i] >= k
     int64_t lo = 0, hi = n;
@@ -147,6 +153,27 @@ THJ_HD int64_t upper_bound_u64(const u64* a, int64_t n, u64 k) {   // first i wi
     int64_t lo = 0, hi = n;
     while (lo < hi) { int64_t m = (lo + hi) >> 1; if (a[m] <= k) lo = m + 1; else hi = m; }
     return lo;
+}
+
+// [first key > klo, first key >= khi) of the junction keys (klo < khi): what std::set::upper_bound / lower_bound
+// give merge_chain (long_spanning_reads.cpp:1311-1330).  A closure looks at a 9-base span of left positions, so with
+// the bucket index this is one index fetch and a scan of the zero to two keys found there instead of two binary
+// searches of ~15 dependent loads each.
+THJ_HD void junc_range(const SpanSets& S, u64 klo, u64 khi, int64_t& lb, int64_t& ub) {
+    if (!S.junc_bucket) {
+        lb = upper_bound_u64(S.junc_keys, S.n_juncs, klo);
+        ub = lower_bound_u64(S.junc_keys, S.n_juncs, khi);
+        return;
+    }
+    int64_t b0 = (int64_t)((klo >> 30) >> JUNC_BUCKET_SHIFT), b1 = (int64_t)((khi >> 30) >> JUNC_BUCKET_SHIFT) + 1;
+    if (b0 > S.n_buckets) b0 = S.n_buckets;
+    if (b1 > S.n_buckets) b1 = S.n_buckets;
+    int64_t i = S.junc_bucket[b0];
+    const int64_t e = S.junc_bucket[b1];
+    while (i < e && S.junc_keys[i] <= klo) ++i;
+    lb = i;
+    while (i < e && S.junc_keys[i] < khi) ++i;
+    ub = i;
 }
 
 // The chain's sequence in genome-forward orientation: the read, or its reverse complement.  A view, not a
@@ -289,8 +316,8 @@ THJ_HD Closure closure_search(const Genome& g, const Params& p, const SpanSets& 
     if (dist > 0 && dist <= p.max_report_intron && same_strand) {
         // ---- junction / deletion closure :1311-1591
         if (g_len(g, ref) == 0) return cl;
-        int64_t lb = upper_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true));
-        int64_t ub = lower_bound_u64(S.junc_keys, S.n_juncs, junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false));
+        int64_t lb, ub;
+        junc_range(S, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true), junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false), lb, ub);
         const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
         int best_diff = 0xff;
         for (; lb < ub; ++lb) {
@@ -745,17 +772,49 @@ THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
     return 0;
 }
 
+// `stage`: room for the read's nseg hits (LDS in the kernel).  The hits of a one-hit-per-segment read are
+// consecutive records: they are fetched once, back to back, and every later step reads the staged copy instead of
+// paying another HBM round trip.
 template <class Sink>
-THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, const uint32_t* so, int nseg,
-                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
-    if (so[1] == so[0]) return SPAN_OK;
+THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
+                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHit* stage, Sink& sink) {
+    uint32_t sof[SPAN_MAXSEG + 1];
+#pragma unroll
+    for (int s = 0; s <= SPAN_MAXSEG; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
+    if (sof[1] == sof[0]) return SPAN_OK;
     int nsegs = 0;
-    while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
-    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
-    if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;
-    for (int s = 0; s < nsegs; ++s) if (so[s + 1] - so[s] != 1u) return SPAN_NEED_GENERIC;
+    {
+        bool open = true;
+#pragma unroll
+        for (int s = 0; s < SPAN_MAXSEG; ++s) { open = open && s < nseg && sof[s + 1] > sof[s]; nsegs += open ? 1 : 0; }
+    }
+    bool single = true;
+#pragma unroll
+    for (int s = 0; s < SPAN_MAXSEG; ++s) single = single && (s >= nsegs || sof[s + 1] - sof[s] == 1u);
+    if (!single) {
+        uint32_t last_so = sof[0];
+#pragma unroll
+        for (int s = 1; s < SPAN_MAXSEG; ++s) last_so = (s == nsegs - 1) ? sof[s] : last_so;
+        if (!(ghits[last_so].meta & SH_END)) return SPAN_OK;
+        return SPAN_NEED_GENERIC;
+    }
+    {
+        const Q16* src = (const Q16*)(ghits + sof[0]);
+        Q16* dst = (Q16*)stage;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {              // two rounds of up to eight 16-byte loads in flight
+            Q16 tmp[SPAN_MAXSEG];
+#pragma unroll
+            for (int k = 0; k < SPAN_MAXSEG; ++k) if (half * SPAN_MAXSEG + k < 2 * nsegs) tmp[k] = src[half * SPAN_MAXSEG + k];
+#pragma unroll
+            for (int k = 0; k < SPAN_MAXSEG; ++k) if (half * SPAN_MAXSEG + k < 2 * nsegs) dst[half * SPAN_MAXSEG + k] = tmp[k];
+        }
+    }
+    const SpanHit* hits = stage;             // from here on: segment s's hit is hits[s]
+    if (!(hits[nsegs - 1].meta & SH_END)) return SPAN_OK;
+    if (THJ_EXPF(256)) return SPAN_OK;
     const int L = p.segment_length;
-    const SpanHit h0 = hits[so[0]];
+    const SpanHit h0 = hits[0];
     const bool anti = (h0.meta & SH_ANTI) != 0;
     RAln res;
     if (nsegs == 1) {
@@ -768,7 +827,7 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
             int prev_right = prev.left + rc_ref_span(prev.c, prev.n);
             old_read_length = rc_read_span(prev.c, prev.n);
             for (int s = 1; s < nsegs; ++s) {
-                RAln cand = raln_from_hit(hits[so[s]], s, L, rl);
+                RAln cand = raln_from_hit(hits[s], s, L, rl);
                 const int cand_right = cand.left + rc_ref_span(cand.c, cand.n);
                 if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return SPAN_OK;
                 int dist = prev.anti ? prev.left - cand_right : cand.left - prev_right;
@@ -779,18 +838,19 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
             }
         }
         if (num_fusions >= 2) return SPAN_OK;
+        if (THJ_EXPF(512)) return SPAN_OK;
         SeqView sv = anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
         RChainOut co;
 #pragma unroll
         for (int k = 0; k < LEAN_C; ++k) co.c.v[k] = 0;
         co.n = 0; co.saw_as = co.saw_s = false; co.num_mm = 0;
         const int k0 = anti ? nsegs - 1 : 0, step = anti ? -1 : 1;
-        RAln prev = raln_from_hit(hits[so[k0]], k0, L, rl);
+        RAln prev = raln_from_hit(hits[k0], k0, L, rl);
         const int left0 = prev.left;
         int P = prev.rlen;
         for (int q = 1; q < nsegs; ++q) {
             const int k = k0 + q * step;
-            const RAln curr = raln_from_hit(hits[so[k]], k, L, rl);
+            const RAln curr = raln_from_hit(hits[k], k, L, rl);
             // merge_chain's main loop, one adjacent pair (:900-1870)
             const uint32_t plast = prev.c.get(prev.n - 1), cfirst = curr.c.v[0];
             if (!(op_is_match(cig_op(plast)) || op_is_match(cig_op(cfirst)))) return SPAN_OK;               // :924-928
@@ -838,6 +898,7 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
             const int rc = rchain_add(co, prev);
             if (rc) return rc == 2 ? SPAN_NEED_GENERIC : SPAN_OK;
         }
+        if (THJ_EXPF(1024)) return SPAN_OK;
         res.c = co.c; res.n = co.n;
         res.ref_id = h0.ref_id; res.left = left0; res.anti = anti ? 1 : 0; res.asplice = co.saw_as ? 1 : 0;
         res.mm = co.num_mm & 0xFF; res.ed = (co.num_mm + rc_gap_len(co.c, co.n)) & 0xFF;
