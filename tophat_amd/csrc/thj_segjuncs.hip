@@ -510,7 +510,7 @@ static int alloc_tables(thj_ctx* c, int64_t junc_cap, int64_t indel_cap) {
     // a table never holds more than 75 % + one wave of entries
     c->out_cap_junc = c->junc_cap; c->out_cap_indel = c->indel_cap;
     HIPCHK(hipMalloc(&c->d_junc_sorted, (size_t)c->out_cap_junc * 8));
-    HIPCHK(hipMalloc(&c->d_tmp_keys, (size_t)c->out_cap_junc * 8));
+    HIPCHK(hipMalloc(&c->d_tmp_keys, (size_t)(c->out_cap_junc + 2 * c->out_cap_indel) * 8));   // the three compacted tables side by side
     HIPCHK(hipMalloc(&c->d_del_sorted, (size_t)c->out_cap_indel * 8));
     HIPCHK(hipMalloc(&c->d_ins_key_sorted, (size_t)c->out_cap_indel * 8));
     HIPCHK(hipMalloc(&c->d_ins_val_sorted, (size_t)c->out_cap_indel * 8));
@@ -887,9 +887,18 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_out_n, 0, 4 * sizeof(unsigned long long), c->stream));
     auto blocks_for = [](int64_t cap) { int64_t b = (cap + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b); };
+    // the three tables are compacted into disjoint parts of the scratch arrays, then ONE round trip brings the counts
+    u64* jt = c->d_tmp_keys;
+    u64* dt = c->d_tmp_keys + c->junc_cap;
+    u64* it = dt + c->indel_cap;
+    u64* itv = c->d_tmp_vals;
     hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->junc_cap)), dim3(256), 0, c->stream, (const u64*)c->d_junc,
-                       (const u64*)nullptr, (u64)c->junc_cap, c->d_tmp_keys, (u64*)nullptr, &c->d_out_n[0]);
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[0], c->d_out_n, 8, hipMemcpyDeviceToHost, c->stream));
+                       (const u64*)nullptr, (u64)c->junc_cap, jt, (u64*)nullptr, &c->d_out_n[0]);
+    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_del,
+                       (const u64*)nullptr, (u64)c->indel_cap, dt, (u64*)nullptr, &c->d_out_n[1]);
+    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_ins_key,
+                       (const u64*)c->d_ins_val, (u64)c->indel_cap, it, itv, &c->d_out_n[2]);
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[0], c->d_out_n, 24, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&c->h_pinned[4], c->d_ovf, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&c->h_pinned[8], c->d_cnt, CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -900,29 +909,19 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
         return THJ_EOVERFLOW;
     }
     c->n_junc = (int64_t)c->h_pinned[0];
+    c->n_del = (int64_t)c->h_pinned[1];
+    c->n_ins = (int64_t)c->h_pinned[2];
+    // sorted output (stream-ordered: consumers on the context stream need no further synchronisation)
     size_t tmp = c->sort_tmp_bytes;
     if (c->n_junc > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_junc_sorted, c->n_junc, 0, 64, c->stream));
-    // deletions
-    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_del,
-                       (const u64*)nullptr, (u64)c->indel_cap, c->d_tmp_keys, (u64*)nullptr, &c->d_out_n[1]);
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[1], c->d_out_n + 1, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->n_del = (int64_t)c->h_pinned[1];
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)jt, c->d_junc_sorted, c->n_junc, 0, 64, c->stream));
     tmp = c->sort_tmp_bytes;
     if (c->n_del > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_del_sorted, c->n_del, 0, 64, c->stream));
-    // insertions
-    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_ins_key,
-                       (const u64*)c->d_ins_val, (u64)c->indel_cap, c->d_tmp_keys, c->d_tmp_vals, &c->d_out_n[2]);
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[2], c->d_out_n + 2, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->n_ins = (int64_t)c->h_pinned[2];
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)dt, c->d_del_sorted, c->n_del, 0, 64, c->stream));
     tmp = c->sort_tmp_bytes;
     if (c->n_ins > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_ins_key_sorted,
-                                                  (const u64*)c->d_tmp_vals, c->d_ins_val_sorted, c->n_ins, 0, 64, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)it, c->d_ins_key_sorted,
+                                                  (const u64*)itv, c->d_ins_val_sorted, c->n_ins, 0, 64, c->stream));
     if (counts) {
         const unsigned long long* cnt = &c->h_pinned[8];
         counts->n_juncs = c->n_junc; counts->n_deletions = c->n_del; counts->n_insertions = c->n_ins;

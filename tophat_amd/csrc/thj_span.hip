@@ -86,6 +86,8 @@ struct StageSink {
     }
 };
 
+// MS: upper bound of the batch's segments per read (4 covers reads up to 4 x segment_length, e.g. 100 bp at 25)
+template <int MS>
 __global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, RecSink sink, Tiers t) {
     __shared__ uint4 stage[256 * 8];
     __shared__ uint8_t has_rec[256];
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, D
         const int64_t r = r0 + tid;
         StageSink ss{stage, tid, 0};
         if (r < c1) {
-            int st = span_read_contig(g, p, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+            int st = span_read_contig<MS>(g, p, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                       (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, ss);
             if (st == SPAN_NEED_LEAN) { if (!THJ_EXPF(64)) t.wl_lean[c0 + atomicAdd(&s_cnt[0], 1u)] = (uint32_t)r; }
             else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = (uint32_t)r;
@@ -158,6 +160,7 @@ __device__ __forceinline__ int slice_of(const unsigned int* s_off, int G, unsign
 }
 
 // Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain on registers.
+template <int MS>
 __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
     extern __shared__ uint4 lds_stage[];          // nseg hits per thread
     __shared__ unsigned int s_off[MAX_SLICES + 1];
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_lean[(int64_t)sl * t.chunk + (i - s_off[sl])];
-        int st = span_read_lean(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+        int st = span_read_lean<MS>(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, stage, sink);
         if (st == SPAN_NEED_GENERIC) {          // rare: more cigar ops than the registers hold
             t.wl_multi[(int64_t)sl * t.chunk + atomicAdd(&t.blk_multi[sl], 1u)] = (uint32_t)r;
@@ -480,10 +483,12 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     HIPCHK(hipMemsetAsync(t.counters, 0, 8, c->stream));
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
-    hipLaunchKernelGGL(thj_k_stitch_contig, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
+    else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
     const int64_t g1 = G, g2 = G;
-    hipLaunchKernelGGL(thj_k_stitch, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+    else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
     hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)g2), dim3(128), 0, c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) {

@@ -775,26 +775,26 @@ THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
 // `stage`: room for the read's nseg hits (LDS in the kernel).  The hits of a one-hit-per-segment read are
 // consecutive records: they are fetched once, back to back, and every later step reads the staged copy instead of
 // paying another HBM round trip.
-template <class Sink>
+template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
                           const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHit* stage, Sink& sink) {
-    uint32_t sof[SPAN_MAXSEG + 1];
+    uint32_t sof[MS + 1];
 #pragma unroll
-    for (int s = 0; s <= SPAN_MAXSEG; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
+    for (int s = 0; s <= MS; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
     if (sof[1] == sof[0]) return SPAN_OK;
     int nsegs = 0;
     {
         bool open = true;
 #pragma unroll
-        for (int s = 0; s < SPAN_MAXSEG; ++s) { open = open && s < nseg && sof[s + 1] > sof[s]; nsegs += open ? 1 : 0; }
+        for (int s = 0; s < MS; ++s) { open = open && s < nseg && sof[s + 1] > sof[s]; nsegs += open ? 1 : 0; }
     }
     bool single = true;
 #pragma unroll
-    for (int s = 0; s < SPAN_MAXSEG; ++s) single = single && (s >= nsegs || sof[s + 1] - sof[s] == 1u);
+    for (int s = 0; s < MS; ++s) single = single && (s >= nsegs || sof[s + 1] - sof[s] == 1u);
     if (!single) {
         uint32_t last_so = sof[0];
 #pragma unroll
-        for (int s = 1; s < SPAN_MAXSEG; ++s) last_so = (s == nsegs - 1) ? sof[s] : last_so;
+        for (int s = 1; s < MS; ++s) last_so = (s == nsegs - 1) ? sof[s] : last_so;
         if (!(ghits[last_so].meta & SH_END)) return SPAN_OK;
         return SPAN_NEED_GENERIC;
     }
@@ -803,11 +803,11 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
         Q16* dst = (Q16*)stage;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {              // two rounds of up to eight 16-byte loads in flight
-            Q16 tmp[SPAN_MAXSEG];
+            Q16 tmp[MS];
 #pragma unroll
-            for (int k = 0; k < SPAN_MAXSEG; ++k) if (half * SPAN_MAXSEG + k < 2 * nsegs) tmp[k] = src[half * SPAN_MAXSEG + k];
+            for (int k = 0; k < MS; ++k) if (half * MS + k < 2 * nsegs) tmp[k] = src[half * MS + k];
 #pragma unroll
-            for (int k = 0; k < SPAN_MAXSEG; ++k) if (half * SPAN_MAXSEG + k < 2 * nsegs) dst[half * SPAN_MAXSEG + k] = tmp[k];
+            for (int k = 0; k < MS; ++k) if (half * MS + k < 2 * nsegs) dst[half * MS + k] = tmp[k];
         }
     }
     const SpanHit* hits = stage;             // from here on: segment s's hit is hits[s]
@@ -929,39 +929,39 @@ enum { SPAN_NEED_LEAN = 4 };
 // first half of a thj_span_hit: all a single plain-match hit carries
 struct alignas(16) SpanHitHead { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar0; };
 
-template <class Sink>
+template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
                             const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
     // Memory round trips, not arithmetic, bound this tier: the segment offsets are fetched in one go, then every
     // hit head in one go, and only then is anything decided.
-    uint32_t sv[SPAN_MAXSEG + 1];
+    uint32_t sv[MS + 1];
 #pragma unroll
-    for (int s = 0; s <= SPAN_MAXSEG; ++s) sv[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
+    for (int s = 0; s <= MS; ++s) sv[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
     if (sv[1] == sv[0]) return SPAN_OK;
     int nsegs = 0;
     {
         bool open = true;
 #pragma unroll
-        for (int s = 0; s < SPAN_MAXSEG; ++s) { open = open && s < nseg && sv[s + 1] > sv[s]; nsegs += open ? 1 : 0; }
+        for (int s = 0; s < MS; ++s) { open = open && s < nseg && sv[s + 1] > sv[s]; nsegs += open ? 1 : 0; }
     }
     bool single = true;
 #pragma unroll
-    for (int s = 0; s < SPAN_MAXSEG; ++s) single = single && (s >= nsegs || sv[s + 1] - sv[s] == 1u);
+    for (int s = 0; s < MS; ++s) single = single && (s >= nsegs || sv[s + 1] - sv[s] == 1u);
     uint32_t last_so = sv[0];
 #pragma unroll
-    for (int s = 1; s < SPAN_MAXSEG; ++s) last_so = (s == nsegs - 1) ? sv[s] : last_so;
+    for (int s = 1; s < MS; ++s) last_so = (s == nsegs - 1) ? sv[s] : last_so;
     if (!single) {
         if (!(hits[last_so].meta & SH_END)) return SPAN_OK;
         return SPAN_NEED_GENERIC;
     }
     // one hit per segment: the read's hits are hits[sv[0] .. sv[0] + nsegs)
-    SpanHitHead hh[SPAN_MAXSEG];
+    SpanHitHead hh[MS];
 #pragma unroll
-    for (int s = 0; s < SPAN_MAXSEG; ++s)
+    for (int s = 0; s < MS; ++s)
         if (s < nsegs) hh[s] = *(const SpanHitHead*)(hits + sv[0] + s);
     uint32_t last_meta = hh[0].meta;
 #pragma unroll
-    for (int s = 1; s < SPAN_MAXSEG; ++s) last_meta = (s == nsegs - 1) ? hh[s].meta : last_meta;
+    for (int s = 1; s < MS; ++s) last_meta = (s == nsegs - 1) ? hh[s].meta : last_meta;
     if (!(last_meta & SH_END)) return SPAN_OK;
     const SpanHitHead h0 = hh[0];
     const bool anti = (h0.meta & SH_ANTI) != 0;
@@ -971,7 +971,7 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
     int left = h0.left, edge = anti ? h0.left : h0.left + total;       // where the next segment must abut
     bool lean = false;
 #pragma unroll
-    for (int s = 1; s < SPAN_MAXSEG; ++s) {
+    for (int s = 1; s < MS; ++s) {
         if (s < nsegs) {
             const SpanHitHead h = hh[s];
             const int len = (int)cig_len(h.cigar0);
