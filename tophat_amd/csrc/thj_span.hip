@@ -311,27 +311,16 @@ extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
     int rc = ensure_sets_cap(c, nj, ni);
     if (rc) return rc;
     if (nj) {
-        // concatenate into tmp, sort, unique
+        // concatenate into tmp, sort
         HIPCHK(hipMemcpyAsync(c->d_tmp_keys, c->d_junc_sorted, (size_t)c->n_junc * 8, hipMemcpyDeviceToDevice, c->stream));
         if (c->n_del) HIPCHK(hipMemcpyAsync(c->d_tmp_keys + c->n_junc, c->d_del_sorted, (size_t)c->n_del * 8, hipMemcpyDeviceToDevice, c->stream));
         if (nj > c->out_cap_junc) { thj_set_error("junction+deletion set exceeds table capacity"); return THJ_EOVERFLOW; }
-        // sort into d_junc (the hash table is no longer needed after finish; it is reset by the next run)
-        u64* sorted = c->d_junc;
+        // Sorted, NOT made unique: a deletion and a '+' junction with the same ends give the same key twice, and
+        // a repeated key is harmless to its only consumer -- closure_search skips a candidate that does not improve
+        // on the best one (`diff >= best_diff`), which an identical twin never does.
         size_t tmp = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, sorted, nj, 0, 64, c->stream));
-        size_t need = 0;
-        HIPCHK(hipcub::DeviceSelect::Unique(nullptr, need, (const u64*)sorted, c->d_span_junc, c->d_out_n + 3, nj, c->stream));
-        void* dtmp = c->d_sort_tmp;
-        void* extra = nullptr;
-        if (need > c->sort_tmp_bytes) { HIPCHK(hipMalloc(&extra, need)); dtmp = extra; }
-        HIPCHK(hipcub::DeviceSelect::Unique(dtmp, need, (const u64*)sorted, c->d_span_junc, c->d_out_n + 3, nj, c->stream));
-        HIPCHK(hipMemcpyAsync(&c->h_pinned[20], c->d_out_n + 3, 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (extra) hipFree(extra);
-        c->n_span_junc = (int64_t)c->h_pinned[20];
-        // the table memory was used as scratch: mark it dirty so the next segjuncs pass must reset first
-        HIPCHK(hipMemsetAsync(c->d_junc, 0xFF, (size_t)c->junc_cap * 8, c->stream));
-        HIPCHK(hipMemsetAsync(&c->d_cnt[0], 0, 8, c->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_span_junc, nj, 0, 64, c->stream));
+        c->n_span_junc = nj;
     } else c->n_span_junc = 0;
     if (ni) {
         int64_t blocks = (ni + 255) / 256; if (blocks > 1024) blocks = 1024;
@@ -339,9 +328,7 @@ extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
                            (const u64*)c->d_ins_val_sorted, ni, c->d_span_ins_key, c->d_span_ins_seq);
     }
     c->n_span_ins = ni;
-    if ((rc = build_junc_buckets(c))) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    return THJ_OK;
+    return build_junc_buckets(c);          // stream-ordered: thj_span_run_async on this context needs no synchronisation
 }
 
 struct OwnedSpanBatch {
