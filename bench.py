@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
     ap.add_argument("--introns", type=int, default=20000)
     ap.add_argument("--exon-len", type=int, default=300)
+    ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE configs[1]: 100; 150 / 50 are the shapes of configs[3] / [4])")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -151,7 +152,7 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     ctx = host.Context(local_rank, stream=stream.cuda_stream)
     ctx.upload_genome(pg)
-    w = make_device_workload(100 + rank, seqs, genes, None, args.pairs, dev, read_len=100, seg_len=25,
+    w = make_device_workload(100 + rank, seqs, genes, None, args.pairs, dev, read_len=args.read_len, seg_len=25,
                              inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
@@ -248,7 +249,7 @@ def main():
         elapsed = float(tt.item())
 
     # ---- roofline, per launch (one launch = one side's batch of `pairs` reads); DESIGN.md "Roofline" ---------
-    rl_bytes = (100 + 3) // 4 + (100 + 7) // 8            # packed read: 2-bit bases + N mask
+    rl_bytes = (args.read_len + 3) // 4 + (args.read_len + 7) // 8            # packed read: 2-bit bases + N mask
     n_launch = 2
     nseg = w["left"]["nseg"]
     # thj_k_segjuncs: 16 B per hit record + 4 B per (read, segment) CSR offset + per RefSeg window two 64-B genome
@@ -287,7 +288,7 @@ def main():
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
+        if args.read_len == 100 and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
             for k in kernels:
                 c = pm["kernels"].get(k["kernel"])
                 if c:
@@ -329,11 +330,12 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x 2x100 bp PE synthetic vs %d bp chr20-sized genome per GPU, inputs "
-                                   "resident in HBM; both stages on device: segment_juncs (rescue/gap/indel/window kernels, "
-                                   "event dedup+sort%s) then long_spanning_reads (stitch kernel fed device-to-device with the "
-                                   "junction set, record ordering)" % (args.pairs, args.genome_len,
-                                                                      ", RCCL all-gather of event keys" if use_dist else ""),
+            "config": {"workload": ("%s: %d x 2x%d bp PE synthetic vs %d bp chr20-sized genome per GPU, inputs "
+                                    "resident in HBM; both stages on device: segment_juncs (main + rescue kernels, event "
+                                    "dedup+sort%s) then long_spanning_reads (three stitch tiers fed device-to-device with the "
+                                    "junction set; records land in BAM order)"
+                                    % ("configs[1]" if args.read_len == 100 else "read shape of another config", args.pairs,
+                                       args.read_len, args.genome_len, ", RCCL all-gather of event keys" if use_dist else "")),
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -22,7 +22,9 @@ from tophat_amd.params import Params, READ_LEFT, READ_RIGHT
 from tophat_amd.synth import make_device_workload, make_scale_genome
 
 pytestmark = pytest.mark.gpu
-PAIRS = 10_000_000
+# (read length, pairs): configs[1] at full size, and the other read shapes of BASELINE.json's configs (76 bp = 3
+# segments, 150 bp = 6 segments -> the 8-segment kernel variants, 50 bp = 2 segments) at a few million pairs
+SHAPES = [(100, 10_000_000), (150, 2_000_000), (50, 4_000_000), (76, 2_000_000)]
 
 
 def half(w, which):
@@ -45,19 +47,22 @@ def half(w, which):
     return out
 
 
-@pytest.fixture(scope="module")
-def world():
+@pytest.fixture(scope="module", params=SHAPES, ids=lambda s: "%dbp_%dMpairs" % (s[0], s[1] // 1_000_000))
+def world(request):
+    read_len, pairs = request.param
     dev = torch.device("cuda", 0)
     seqs, genes = make_scale_genome(1, [CHR20_LEN], 20000, exon_len=300)
     strs = [s.tobytes().decode() for s in seqs]
-    w = make_device_workload(100, seqs, genes, None, PAIRS, dev, exon_len=300)
+    w = make_device_workload(100, seqs, genes, None, pairs, dev, exon_len=300, read_len=read_len)
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
     ctx = host.Context(0, stream=stream.cuda_stream)
     ctx.upload_genome(host.pack_genome(strs))
     ctx.configure(1 << 22, 1 << 20)
-    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream)
+    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream, read_len=read_len, pairs=pairs)
     ctx.close()
+    del w
+    torch.cuda.empty_cache()
 
 
 def run_stage1(ctx, batches):
@@ -69,6 +74,7 @@ def run_stage1(ctx, batches):
 
 def test_fullsize_properties(world):
     ctx, w, strs, genes = world["ctx"], world["w"], world["strs"], world["genes"]
+    PAIRS, read_len = world["pairs"], world["read_len"]
     pl = Params(read_side=READ_LEFT, inner_dist_mean=50, inner_dist_std_dev=20)
     pr = Params(read_side=READ_RIGHT, inner_dist_mean=50, inner_dist_std_dev=20)
     full = [(pl, cbatch_from_tensors(w["left"], 0)), (pr, cbatch_from_tensors(w["right"], PAIRS))]
@@ -81,7 +87,7 @@ def test_fullsize_properties(world):
     # planted introns recovered
     truth = {(1, int(g[2]) - 1, int(g[3])) for g in genes}
     found = {(k[0], k[1], k[2]) for k in keys}
-    assert len(found & truth) > 0.95 * len(truth)
+    assert len(found & truth) > (0.95 if read_len >= 100 else 0.5) * len(truth)
 
     # idempotence
     ev2 = run_stage1(ctx, full)
@@ -118,9 +124,9 @@ def test_fullsize_properties(world):
         assert (np.diff(key) > 0).all()
         ops, lens = a["cigar"] >> 28, a["cigar"] & 0x0FFFFFFF
         rlen = (lens * np.isin(ops, (1, 3, 13))).sum(1)
-        assert (rlen == 100).all()
+        assert (rlen == read_len).all()
         assert (a["XM"] <= a["mismatches"]).all() and (a["mismatches"] <= 2).all()
-        assert n > 0.8 * PAIRS
+        assert n > (0.8 if read_len <= 100 else 0.6) * PAIRS
         # sample parity, stage 2: records of the first m reads equal the oracle's, given the full junction set
         juncs, ins = events_to_span_inputs(ev)
         want = orc.spanning(p2, og, sample_spanbatch(w[sd], m), juncs, ins)
