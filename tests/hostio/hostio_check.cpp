@@ -1,0 +1,88 @@
+// hostio_check.cpp -- TEST-ONLY: exercises the host I/O layer of the drop-in executables (tophat_amd/csrc/host/
+// thj_hostio.h) without a GPU: the threaded BAM writer and the threaded record readers.
+#include "../../tophat_amd/csrc/host/thj_hostio.h"
+
+using namespace thjh;
+
+static uint64_t mix(uint64_t& s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 2;
+    std::string mode = argv[1];
+    if (mode == "write" && argc >= 5) {
+        // hostio_check write <out.bam> <n_records> <batch>
+        const size_t n = (size_t)atoll(argv[3]), batch = (size_t)atoll(argv[4]);
+        RefTable rt;
+        rt.header_text = "@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:chr1\tLN:5000000\n@SQ\tSN:chr2\tLN:700000\n";
+        rt.sq = {{"chr1", 5000000u}, {"chr2", 700000u}};
+        rt.get_id("chr1"); rt.get_id("chr2");
+        BamWriter bw;
+        std::string out = argv[2];
+        if (!bw.open(out, rt, out + ".index")) return 3;
+        struct Rec { std::string name, seq, qual; uint32_t flag; int ref, pos; std::vector<uint32_t> cig; int as; };
+        std::vector<Rec> recs;
+        uint64_t s = 88172645463325252ull;
+        auto flush = [&]() {
+            bw.write_records(recs.size(), [&](size_t i, std::vector<uint8_t>& d) -> long {
+                const Rec& r = recs[i];
+                std::vector<std::string> aux = {"AS:i:" + std::to_string(r.as), "XM:i:1", "MD:Z:" + std::to_string(r.seq.size()), "NM:i:300"};
+                if (r.cig.size() > 1) aux.push_back("XS:A:+");
+                bw.encode(d, r.name, r.flag, rt.names[(size_t)r.ref], r.pos, r.cig.data(), (int)r.cig.size(), r.seq, r.qual, aux);
+                return atol(r.name.c_str());
+            });
+            recs.clear();
+        };
+        for (size_t i = 0; i < n; ++i) {
+            Rec r;
+            r.name = std::to_string(1 + (i / 2) * 3);             // every id twice: the index rule needs an id CHANGE
+            int len = 50 + (int)(mix(s) % 101);
+            r.seq.resize((size_t)len); r.qual.resize((size_t)len);
+            // half of the records carry incompressible-looking qualities, half very regular ones
+            for (int k = 0; k < len; ++k) { r.seq[(size_t)k] = "ACGTN"[mix(s) % 5]; r.qual[(size_t)k] = (char)(33 + ((i & 1) ? mix(s) % 42 : 40)); }
+            r.flag = (mix(s) & 1) ? 16u : 0u;
+            r.ref = (int)(mix(s) % 2);
+            r.pos = 1 + (int)(mix(s) % 600000);
+            if (mix(s) % 3 == 0) { int a = 10 + (int)(mix(s) % (uint64_t)(len - 20)); r.cig = {(1u << 28) | (uint32_t)a, (11u << 28) | (uint32_t)(50 + mix(s) % 5000), (1u << 28) | (uint32_t)(len - a)}; }
+            else r.cig = {(1u << 28) | (uint32_t)len};
+            r.as = -(int)(mix(s) % 40000);
+            recs.push_back(std::move(r));
+            if (recs.size() >= batch) flush();
+        }
+        flush();
+        bw.close();
+        return 0;
+    }
+    if (mode == "hits" && argc >= 3) {
+        // hostio_check hits <map.sam|bam>  -> "<groups> <hits> <checksum>"
+        RefTable rt;
+        thj_params p;
+        thj_params_default(&p);
+        HitStream hs;
+        if (!hs.open(argv[2], rt, p)) return 3;
+        std::vector<Hit> g;
+        uint64_t groups = 0, hits = 0, sum = 0;
+        uint32_t last = 0;
+        while (hs.next_group_id()) {
+            g.clear();
+            uint32_t id = hs.next_group(g);
+            if (id == last) return 4;                 // a group must hold all consecutive records of its id
+            last = id;
+            ++groups; hits += g.size();
+            for (auto& h : g) sum = sum * 1000003ull + h.insert_id * 31ull + (uint64_t)h.h16.left * 7ull + h.h16.flags + (uint64_t)h.h16.right;
+        }
+        printf("%llu %llu %llu\n", (unsigned long long)groups, (unsigned long long)hits, (unsigned long long)sum);
+        return 0;
+    }
+    if (mode == "reads" && argc >= 3) {
+        // hostio_check reads <reads.fq> <id> [<id> ...]  -> one "<id> <seq> <qual>" line per request
+        ReadStream rs;
+        if (!rs.open(argv[2], "")) return 3;
+        for (int i = 3; i < argc; ++i) {
+            Read r;
+            if (!rs.get((uint32_t)atoi(argv[i]), r)) { printf("%s MISSING\n", argv[i]); continue; }
+            printf("%u %s %s\n", r.id, r.seq.c_str(), r.qual.c_str());
+        }
+        return 0;
+    }
+    return 2;
+}

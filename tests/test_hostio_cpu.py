@@ -1,0 +1,106 @@
+"""CPU: the host I/O layer of the drop-in executables (tophat_amd/csrc/host/thj_hostio.h) through tests/hostio:
+the threaded BGZF/BAM writer (+ its `.index` side file, common.h:562-606) and the threaded record readers."""
+import os
+import struct
+import subprocess
+import zlib
+
+import pytest
+
+from golden_util import CASES, GOLD
+from tophat_amd.bamio import read_bam, write_bam_from_sam
+from tophat_amd.samtext import parse_sam_hits
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EXE = os.path.join(HERE, "hostio", "hostio_check")
+
+
+@pytest.fixture(scope="module")
+def exe():
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostio"), "-s"])
+    return EXE
+
+
+def bgzf_blocks(path):
+    """[(file offset, uncompressed bytes)] of every BGZF member"""
+    data = open(path, "rb").read()
+    out, off = [], 0
+    while off < len(data):
+        assert data[off:off + 4] == b"\x1f\x8b\x08\x04"
+        bsize = struct.unpack_from("<H", data, off + 16)[0] + 1
+        raw = zlib.decompress(data[off + 18:off + bsize - 8], -15)
+        assert struct.unpack_from("<I", data, off + bsize - 4)[0] == len(raw)
+        assert struct.unpack_from("<I", data, off + bsize - 8)[0] == (zlib.crc32(raw) & 0xFFFFFFFF)
+        out.append((off, raw))
+        off += bsize
+    return out
+
+
+def test_bam_writer_is_thread_and_batch_invariant(exe, tmp_path):
+    n = 60000
+    a, b, c = (str(tmp_path / x) for x in ("a.bam", "b.bam", "c.bam"))
+    subprocess.check_call([exe, "write", a, str(n), str(n)], env=dict(os.environ, THJ_HOST_THREADS="1"))
+    subprocess.check_call([exe, "write", b, str(n), "777"], env=dict(os.environ, THJ_HOST_THREADS="7"))
+    subprocess.check_call([exe, "write", c, str(n), "12345"], env=dict(os.environ, THJ_HOST_THREADS="3"))
+    ref = open(a, "rb").read()
+    assert open(b, "rb").read() == ref and open(c, "rb").read() == ref
+    idx = open(a + ".index").read()
+    assert open(b + ".index").read() == idx and open(c + ".index").read() == idx
+    # a well-formed BAM: every record comes back, in order
+    names, recs = read_bam(a)
+    recs = list(recs)
+    assert names == ["chr1", "chr2"] and len(recs) == n
+    assert [int(r[0]) for r in recs] == [1 + (i // 2) * 3 for i in range(n)]
+    # BGZF structure: 64 KiB members (the last data member may be short), then the empty EOF member
+    blocks = bgzf_blocks(a)
+    assert len(blocks[-1][1]) == 0 and all(len(r) == 65536 for _, r in blocks[:-2])
+    # .index: `read_id \\t virtual offset`; every offset is the start of the first record of that read
+    by_off = {off: raw for off, raw in blocks}
+    lines = [l.split("\t") for l in idx.strip().split("\n")]
+    assert len(lines) > 20
+    stream = b"".join(raw for _, raw in blocks)
+    starts = {}
+    pos = 0
+    for off, raw in blocks:
+        starts[off] = pos
+        pos += len(raw)
+    last = 0
+    for rid, voff in lines:
+        rid, voff = int(rid), int(voff)
+        assert rid > last
+        last = rid
+        coff, uoff = voff >> 16, voff & 0xFFFF
+        assert coff in by_off
+        at = starts[coff] + uoff
+        bs, = struct.unpack_from("<i", stream, at)
+        l_rn = stream[at + 4 + 8]
+        qname = stream[at + 4 + 32:at + 4 + 32 + l_rn - 1].decode()
+        assert int(qname) == rid and 32 < bs < 1000
+        # ... and it is the FIRST record of that read: the one before it has another name
+        prev_names = [int(r[0]) for r in recs[max(0, (rid - 1) // 3 * 2 - 2):(rid - 1) // 3 * 2]]
+        assert all(x != rid for x in prev_names)
+
+
+@pytest.mark.parametrize("name", CASES[:2])
+def test_threaded_hit_reader_sam_and_bam(exe, name, tmp_path):
+    d = os.path.join(GOLD, name)
+    sam = os.path.join(d, "left_seg1.sam")
+    bam = str(tmp_path / "left_seg1.bam")
+    write_bam_from_sam(sam, bam)
+    o1 = subprocess.check_output([exe, "hits", sam]).split()
+    o2 = subprocess.check_output([exe, "hits", bam]).split()
+    assert o1 == o2
+    class AnyRef(dict):
+        def __missing__(self, k):
+            return 1
+    hits = list(parse_sam_hits(sam, AnyRef()))
+    assert int(o1[1]) == len(hits) and int(o1[0]) == len({h[0] for h in hits})
+
+
+def test_threaded_read_stream(exe):
+    d = os.path.join(GOLD, CASES[0])
+    fq = open(os.path.join(d, "left.fq")).read().split("\n")
+    recs = {int(fq[i][1:].split()[0]): (fq[i + 1], fq[i + 3]) for i in range(0, len(fq) - 3, 4)}
+    ids = sorted(recs)[::7]
+    out = subprocess.check_output([exe, "reads", os.path.join(d, "left.fq")] + [str(i) for i in ids]).decode().strip().split("\n")
+    assert [tuple(l.split()) for l in out] == [(str(i), recs[i][0], recs[i][1]) for i in ids]

@@ -14,6 +14,8 @@ static void print_usage() {
 
 static const char OPCH[16] = {'?', 'M', 'm', 'I', 'i', 'D', 'd', '?', '?', '?', '?', 'N', 'n', 'S', 'H', 'P'};
 
+static PhaseTimer g_timer;
+
 int main(int argc, char** argv) {
     fprintf(stderr, "long_spanning_reads (MI355X-native, %s)\n--------------------------------------------\n", thj_version());
     Opts o;
@@ -34,6 +36,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Loading reference sequences...\n");
     rt.load_fasta(pos[0]);
     fprintf(stderr, "        reference sequences loaded.\n");
+    g_timer.lap("options + reference FASTA");
 
     // ---- junctions + deletions -> std::set<Junction> (long_spanning_reads.cpp:2897-2944)
     std::vector<thj_junction> juncs;
@@ -101,10 +104,13 @@ int main(int argc, char** argv) {
         ins_tab.insert(ins_tab.end(), {ins[i].ref, ins[i].left, ins[i].len, ins[i].seq});
     }
 
+    g_timer.lap("junction / indel lists");
     int device = getenv("THJ_DEVICE") ? atoi(getenv("THJ_DEVICE")) : 0;
     thj_ctx* ctx = nullptr;
     if (thj_ctx_create(device, nullptr, &ctx)) die("Error: %s\n", thj_last_error());
+    g_timer.lap("device context");
     rt.upload(ctx);
+    g_timer.lap("genome pack + upload");
     // junctions on contigs the device genome does not know cannot be closed anyway: drop them
     {
         std::vector<thj_junction> keep;
@@ -125,9 +131,43 @@ int main(int argc, char** argv) {
     ReadStream reads;
     if (!reads.open(pos[1], o.zpacker)) die("Error: cannot open %s for reading\n", pos[1].c_str());
 
-    // all reads of the run are kept on the host for the writer (names, seq, qual)
-    std::vector<Read> all_reads;
+    // ---- BAM output (print_bamhit, bwt_map.cpp:1888-2093).  One output file: every batch's records are written as soon
+    // as they come back (worker threads encode and deflate).  -p N => <base>{0..N-1}.bam (long_spanning_reads.cpp:
+    // 3056-3064): the records are kept and cut into N files at read boundaries at the end.
+    const std::string out = pos[6];
+    const int parts = o.num_threads > 1 ? o.num_threads : 1;
+    BamWriter bw1;
+    if (parts == 1 && !bw1.open(out, rt, out + ".index")) die("Error: could not create BAM file %s!\n", out.c_str());
+    std::vector<Read> all_reads;                 // reads of the current batch (parts == 1) or of the run (parts > 1)
     std::vector<thj_aln> alns;
+    auto write_range = [&](BamWriter& bw, size_t a0, size_t a1) {
+        bw.write_records(a1 - a0, [&](size_t i, std::vector<uint8_t>& d) -> long {
+            const thj_aln& a = alns[a0 + i];
+            const Read& rd = all_reads[a.read_idx];
+            int rlen = 0, indel = 0; bool spliced = false;
+            for (int k = 0; k < a.n_cigar; ++k) {
+                uint32_t op = a.cigar[k] >> 28, len = a.cigar[k] & 0x0FFFFFFF;
+                if (op == 1 || op == 2 || op == 3 || op == 4 || op == 13) rlen += (int)len;
+                if (op >= 3 && op <= 6) indel += (int)len;
+                if (op == 11 || op == 12) spliced = true;
+            }
+            std::string seq = rd.seq, qual = rd.qual;
+            seq.resize((size_t)rlen); qual.resize((size_t)rlen);
+            uint32_t flag = 0;
+            if (a.flags & THJ_HIT_ANTISENSE) { flag |= 0x10; reverse_complement(seq); std::reverse(qual.begin(), qual.end()); }
+            std::vector<std::string> aux;
+            aux.push_back("AS:i:" + std::to_string((int)a.AS));
+            aux.push_back("XM:i:" + std::to_string((int)a.XM));
+            aux.push_back("XO:i:" + std::to_string((int)a.XO));
+            aux.push_back("XG:i:" + std::to_string((int)a.XG));
+            aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
+            aux.push_back("NM:i:" + std::to_string((int)a.mismatches + indel));
+            if (spliced) aux.push_back(std::string("XS:A:") + ((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'));
+            bw.encode(d, rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
+            return atol(rd.name.c_str());
+        });
+    };
+
     size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
     std::vector<uint32_t> seg_off; std::vector<thj_span_hit> hits; std::vector<int64_t> read_off; std::string bases, quals;
     size_t max_len = 0; size_t batch_first = 0;
@@ -135,6 +175,7 @@ int main(int argc, char** argv) {
     auto flush = [&]() {
         int64_t n = (int64_t)read_off.size() - 1;
         if (n == 0) return;
+        g_timer.lap("ingest (parse + merge by id)");
         int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
         std::vector<uint64_t> planes((size_t)n * 3 * W);
         std::vector<uint16_t> lens((size_t)n);
@@ -156,6 +197,12 @@ int main(int argc, char** argv) {
         if (na && thj_span_download(ctx, alns.data() + base)) die("Error: %s\n", thj_last_error());
         for (size_t k = base; k < alns.size(); ++k) alns[k].read_idx += (uint32_t)batch_first;      // -> index into all_reads
         if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+        g_timer.lap("pack + upload + stitch + download");
+        if (parts == 1) {
+            write_range(bw1, 0, alns.size());
+            alns.clear(); all_reads.clear();
+            g_timer.lap("BAM output (encode + BGZF)");
+        }
         reset();
     };
     reset();
@@ -187,50 +234,29 @@ int main(int argc, char** argv) {
         if (read_off.size() - 1 >= batch_reads) flush();
     }
     flush();
+    g_timer.lap("ingest (parse + merge by id)");
 
-    // ---- BAM output (print_bamhit, bwt_map.cpp:1888-2093); -p N => <base>{0..N-1}.bam (long_spanning_reads.cpp:3056-3064)
-    std::string out = pos[6];
-    int parts = o.num_threads > 1 ? o.num_threads : 1;
-    std::vector<size_t> cut((size_t)parts + 1, alns.size());
-    cut[0] = 0;
-    for (int k = 1; k < parts; ++k) {
-        size_t c = alns.size() * (size_t)k / (size_t)parts;
-        while (c > 0 && c < alns.size() && alns[c].read_idx == alns[c - 1].read_idx) ++c;      // never split a read
-        cut[(size_t)k] = c;
-    }
-    for (int k = 0; k < parts; ++k) {
-        std::string fn = out;
-        if (parts > 1) fn = out.substr(0, out.size() >= 4 ? out.size() - 4 : out.size()) + std::to_string(k) + ".bam";
-        BamWriter bw;
-        if (!bw.open(fn, rt, fn + ".index")) die("Error: could not create BAM file %s!\n", fn.c_str());
-        for (size_t i = cut[(size_t)k]; i < cut[(size_t)k + 1]; ++i) {
-            const thj_aln& a = alns[i];
-            const Read& rd = all_reads[a.read_idx];
-            std::vector<uint32_t> cig(a.cigar, a.cigar + a.n_cigar);
-            int rlen = 0, indel = 0; bool spliced = false;
-            for (uint32_t c : cig) {
-                uint32_t op = c >> 28, len = c & 0x0FFFFFFF;
-                if (op == 1 || op == 2 || op == 3 || op == 4 || op == 13) rlen += (int)len;
-                if (op >= 3 && op <= 6) indel += (int)len;
-                if (op == 11 || op == 12) spliced = true;
-            }
-            std::string seq = rd.seq, qual = rd.qual;
-            seq.resize((size_t)rlen); qual.resize((size_t)rlen);
-            uint32_t flag = 0;
-            if (a.flags & THJ_HIT_ANTISENSE) { flag |= 0x10; reverse_complement(seq); std::reverse(qual.begin(), qual.end()); }
-            std::vector<std::string> aux;
-            aux.push_back("AS:i:" + std::to_string((int)a.AS));
-            aux.push_back("XM:i:" + std::to_string((int)a.XM));
-            aux.push_back("XO:i:" + std::to_string((int)a.XO));
-            aux.push_back("XG:i:" + std::to_string((int)a.XG));
-            aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
-            aux.push_back("NM:i:" + std::to_string((int)a.mismatches + indel));
-            if (spliced) aux.push_back(std::string("XS:A:") + ((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'));
-            bw.write(rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, cig, seq, qual, aux);
+    if (parts == 1) bw1.close();
+    else {
+        std::vector<size_t> cut((size_t)parts + 1, alns.size());
+        cut[0] = 0;
+        for (int k = 1; k < parts; ++k) {
+            size_t c = alns.size() * (size_t)k / (size_t)parts;
+            while (c > 0 && c < alns.size() && alns[c].read_idx == alns[c - 1].read_idx) ++c;      // never split a read
+            cut[(size_t)k] = c;
         }
-        bw.close();
+        for (int k = 0; k < parts; ++k) {
+            std::string fn = out.substr(0, out.size() >= 4 ? out.size() - 4 : out.size()) + std::to_string(k) + ".bam";
+            BamWriter bw;
+            if (!bw.open(fn, rt, fn + ".index")) die("Error: could not create BAM file %s!\n", fn.c_str());
+            write_range(bw, cut[(size_t)k], cut[(size_t)k + 1]);
+            bw.close();
+        }
     }
+    g_timer.lap("BAM output (encode + BGZF)");
     thj_ctx_destroy(ctx);
+    g_timer.lap("teardown");
+    g_timer.report();
     (void)OPCH;
     return 0;
 }

@@ -13,6 +13,7 @@ static void print_usage() {
 }
 
 static const char* CODE = "ACGTN";
+static PhaseTimer g_timer;
 
 struct SideInput {
     std::string reads, map;
@@ -50,6 +51,7 @@ static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, c
     auto flush = [&]() {
         int64_t n = (int64_t)read_off.size() - 1;
         if (n == 0) return;
+        g_timer.lap("ingest (parse + merge by id)");
         int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
         std::vector<uint64_t> planes((size_t)n * 3 * W);
         std::vector<uint16_t> lens((size_t)n);
@@ -66,6 +68,7 @@ static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, c
         if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
         ordinal += (uint32_t)n;
         reset();
+        g_timer.lap("pack + upload + launch");
     };
     reset();
     std::vector<std::vector<Hit>> grp((size_t)nseg);
@@ -130,11 +133,14 @@ int main(int argc, char** argv) {
     rt.load_sam_header(o.sam_header);
     fprintf(stderr, "Loading reference sequences...\n");
     rt.load_fasta(pos[0]);
+    g_timer.lap("options + reference FASTA");
 
     int device = getenv("THJ_DEVICE") ? atoi(getenv("THJ_DEVICE")) : 0;
     thj_ctx* ctx = nullptr;
     if (thj_ctx_create(device, nullptr, &ctx)) die("Error: %s\n", thj_last_error());
+    g_timer.lap("device context");
     rt.upload(ctx);
+    g_timer.lap("genome pack + upload");
     if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
     if (o.fusion_search && thj_fusion_reset_async(ctx)) die("Error: %s\n", thj_last_error());
     size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
@@ -143,11 +149,13 @@ int main(int argc, char** argv) {
     run_side(ctx, o, rt, left, right.segs.empty() ? nullptr : &right, 1, ordinal, batch_reads);
     if (!right.segs.empty()) run_side(ctx, o, rt, right, &left, 2, ordinal, batch_reads);
 
+    g_timer.lap("ingest (parse + merge by id)");
     thj_segjuncs_counts n{};
     if (thj_segjuncs_finish(ctx, &n)) die("Error: %s\n", thj_last_error());
     std::vector<thj_junction> j((size_t)n.n_juncs + 1), d((size_t)n.n_deletions + 1);
     std::vector<thj_insertion> ins((size_t)n.n_insertions + 1);
     if (thj_segjuncs_download(ctx, j.data(), d.data(), ins.data())) die("Error: %s\n", thj_last_error());
+    g_timer.lap("device finish + download");
     fprintf(stderr, "\tfound %ld potential split-segment junctions\n", (long)n.n_juncs);
     fprintf(stderr, "\tfound %ld potential small deletions\n", (long)n.n_deletions);
     fprintf(stderr, "\tfound %ld potential small insertions\n", (long)n.n_insertions);
@@ -196,7 +204,10 @@ int main(int argc, char** argv) {
     }
     fclose(fj); fclose(fi); fclose(fd); fclose(ff);
     fprintf(stderr, "Reported %d total potential splices\n", (int)n.n_juncs);
+    g_timer.lap("write outputs");
     thj_ctx_destroy(ctx);
+    g_timer.lap("teardown");
+    g_timer.report();
     (void)CODE;
     return 0;
 }

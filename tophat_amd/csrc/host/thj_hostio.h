@@ -18,7 +18,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -35,6 +40,26 @@ namespace thjh {
 }
 
 // ------------------------------------------------------------------ options (common.cpp:79-180, :262-720)
+// Wall-clock per phase, printed to stderr at exit when THJ_TIMING is set (developer aid; no effect on results).
+struct PhaseTimer {
+    std::vector<std::pair<std::string, double>> acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char* name) {
+        auto now = std::chrono::steady_clock::now();
+        double dt = std::chrono::duration<double>(now - t0).count();
+        t0 = now;
+        for (auto& a : acc) if (a.first == name) { a.second += dt; return; }
+        acc.emplace_back(name, dt);
+    }
+    void report() const {
+        if (!getenv("THJ_TIMING")) return;
+        double tot = 0;
+        for (auto& a : acc) tot += a.second;
+        for (auto& a : acc) fprintf(stderr, "[timing] %-32s %8.3f s\n", a.first.c_str(), a.second);
+        fprintf(stderr, "[timing] %-32s %8.3f s\n", "total", tot);
+    }
+};
+
 struct Opts {
     thj_params p;
     bool no_coverage_search = false, no_microexon_search = false, butterfly_search = false, fusion_search = false;
@@ -177,7 +202,9 @@ struct RefTable {
     std::string header_text;                        // the '@' lines of --sam-header, verbatim
     std::vector<std::pair<std::string, uint32_t>> sq;   // @SQ (name, LN) in file order: the BAM header targets
 
+    std::mutex mu;                                  // reader threads resolve names concurrently
     uint32_t get_id(const std::string& name) {
+        std::lock_guard<std::mutex> lk(mu);
         auto it = ids.find(name);
         if (it != ids.end()) return it->second;
         names.push_back(name);
@@ -597,39 +624,93 @@ inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p
     return true;
 }
 
-// HitStream (bwt_map.h:1040-1227): groups of consecutive records with equal insert_id, one-record look-ahead
+// Host threading: every input file is inflated / tokenised / parsed by its own reader thread, which hands chunks of
+// finished records to the consumer through a small bounded queue; the consumer (merge by read id, batching) never
+// parses.  THJ_HOST_THREADS bounds the worker count of the parallel stages (default: min(16, hardware threads)).
+inline int host_threads() {
+    int n = getenv("THJ_HOST_THREADS") ? atoi(getenv("THJ_HOST_THREADS")) : 0;
+    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 16) n = 16; }
+    return n < 1 ? 1 : n;
+}
+
+template <class T>
+class ChunkQueue {
+    std::mutex mu_; std::condition_variable cv_;
+    std::vector<std::vector<T>> q_;
+    size_t cap_ = 4;
+    bool closed_ = false, aborted_ = false;
+public:
+    bool push(std::vector<T>&& c) {            // false: the consumer is gone
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return q_.size() < cap_ || aborted_; });
+        if (aborted_) return false;
+        q_.push_back(std::move(c));
+        cv_.notify_all();
+        return true;
+    }
+    void close() { std::lock_guard<std::mutex> lk(mu_); closed_ = true; cv_.notify_all(); }
+    void abort() { std::lock_guard<std::mutex> lk(mu_); aborted_ = true; cv_.notify_all(); }
+    bool pop(std::vector<T>& out) {            // false: end of stream
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return !q_.empty() || closed_; });
+        if (q_.empty()) return false;
+        out = std::move(q_.front());
+        q_.erase(q_.begin());
+        cv_.notify_all();
+        return true;
+    }
+};
+
+// HitStream (bwt_map.h:1040-1227): groups of consecutive records with equal insert_id, one-record look-ahead.
+// Records the factory drops never enter the stream, as in the reference.
 class HitStream {
     AlnReader rd_;
     RefTable* rt_ = nullptr;
     const thj_params* p_ = nullptr;
-    Hit buffered_;
-    bool have_ = false, eof_ = true, spliced_ = false;
-    void fill() {
-        have_ = false;
-        AlnRec r;
-        while (!eof_) {
-            if (!rd_.next(r)) { eof_ = true; break; }
-            buffered_ = Hit();
-            if (spliced_ ? parse_spliced_hit(r, *rt_, *p_, buffered_) : parse_hit(r, *rt_, *p_, buffered_)) { have_ = true; break; }
+    bool spliced_ = false, done_ = true;
+    std::thread th_;
+    ChunkQueue<Hit> q_;
+    std::vector<Hit> cur_; size_t pos_ = 0;
+    void producer() {
+        std::vector<Hit> chunk;
+        chunk.reserve(8192);
+        AlnRec r; Hit h;
+        while (rd_.next(r)) {
+            h = Hit();
+            if (!(spliced_ ? parse_spliced_hit(r, *rt_, *p_, h) : parse_hit(r, *rt_, *p_, h))) continue;
+            chunk.push_back(h);
+            if (chunk.size() >= 8192) { if (!q_.push(std::move(chunk))) return; chunk = std::vector<Hit>(); chunk.reserve(8192); }
         }
+        if (!chunk.empty()) q_.push(std::move(chunk));
+        q_.close();
     }
+    void advance() { while (!done_ && pos_ >= cur_.size()) { pos_ = 0; if (!q_.pop(cur_)) { cur_.clear(); done_ = true; } } }
 public:
+    HitStream() = default;
+    HitStream(const HitStream&) = delete;
+    HitStream& operator=(const HitStream&) = delete;
     bool open(const std::string& fn, RefTable& rt, const thj_params& p, bool spliced = false) {
         rt_ = &rt; p_ = &p; spliced_ = spliced;
         if (fn.empty() || !rd_.open(fn)) return false;
-        eof_ = false;
-        fill();
+        done_ = false;
+        th_ = std::thread([this] { producer(); });
+        advance();
         return true;
     }
-    uint32_t next_group_id() const { return have_ ? buffered_.insert_id : 0; }
+    ~HitStream() { if (th_.joinable()) { q_.abort(); th_.join(); } }
+    uint32_t next_group_id() const { return done_ ? 0 : cur_[pos_].insert_id; }
     // appends the next group to `out`; returns its id (0 at end)
     uint32_t next_group(std::vector<Hit>& out) {
-        if (!have_) return 0;
-        uint32_t id = buffered_.insert_id;
-        while (have_ && buffered_.insert_id == id) { out.push_back(buffered_); fill(); }
+        if (done_) return 0;
+        uint32_t id = cur_[pos_].insert_id;
+        while (!done_ && cur_[pos_].insert_id == id) { out.push_back(cur_[pos_]); ++pos_; advance(); }
         return id;
     }
-    void skip_group() { std::vector<Hit> tmp; next_group(tmp); }
+    void skip_group() {
+        if (done_) return;
+        uint32_t id = cur_[pos_].insert_id;
+        while (!done_ && cur_[pos_].insert_id == id) { ++pos_; advance(); }
+    }
 };
 
 // ------------------------------------------------------------------ reads (reads.cpp:94-188, :528-630)
@@ -642,6 +723,25 @@ class ReadStream {
     std::string pending_;     // pushed-back header line
     std::map<uint32_t, Read> ahead_;
     bool eof_ = false;
+    std::thread th_;
+    ChunkQueue<Read> q_;
+    std::vector<Read> cur_; size_t pos_ = 0;
+    void producer() {
+        std::vector<Read> chunk;
+        Read r;
+        while (next(r)) {
+            chunk.push_back(std::move(r));
+            r = Read();
+            if (chunk.size() >= 4096) { if (!q_.push(std::move(chunk))) return; chunk = std::vector<Read>(); }
+        }
+        if (!chunk.empty()) q_.push(std::move(chunk));
+        q_.close();
+    }
+    bool next_async(Read& r) {
+        while (pos_ >= cur_.size()) { pos_ = 0; if (!q_.pop(cur_)) { cur_.clear(); return false; } }
+        r = std::move(cur_[pos_++]);
+        return true;
+    }
     bool getl(std::string& s) {
         if (!pending_.empty()) { s.swap(pending_); pending_.clear(); return true; }
         ssize_t n;
@@ -684,21 +784,32 @@ class ReadStream {
 public:
     bool open(const std::string& fn, const std::string& zpacker) {
         std::string e = file_ext(fn);
-        if (e == "bam") { is_bam_ = true; return bam_.open(fn); }
-        if (e == "z" && !zpacker.empty()) {                          // FZPipe, common.cpp:899-922
-            std::string cmd = zpacker + " -cd '" + fn + "'";
-            f_ = popen(cmd.c_str(), "r"); pipe_ = true;
-        } else f_ = fopen(fn.c_str(), "r");
-        return f_ != nullptr;
+        if (e == "bam") { is_bam_ = true; if (!bam_.open(fn)) return false; }
+        else {
+            if (e == "z" && !zpacker.empty()) {                      // FZPipe, common.cpp:899-922
+                std::string cmd = zpacker + " -cd '" + fn + "'";
+                f_ = popen(cmd.c_str(), "r"); pipe_ = true;
+            } else f_ = fopen(fn.c_str(), "r");
+            if (!f_) return false;
+        }
+        th_ = std::thread([this] { producer(); });
+        return true;
     }
-    ~ReadStream() { if (f_) { if (pipe_) pclose(f_); else fclose(f_); } free(line_); }
+    ReadStream() = default;
+    ReadStream(const ReadStream&) = delete;
+    ReadStream& operator=(const ReadStream&) = delete;
+    ~ReadStream() {
+        if (th_.joinable()) { q_.abort(); th_.join(); }
+        if (f_) { if (pipe_) pclose(f_); else fclose(f_); }
+        free(line_);
+    }
     // monotone fetch: requests arrive in increasing id order (the visiting order of both stages)
     bool get(uint32_t id, Read& out) {
         auto it = ahead_.find(id);
         if (it != ahead_.end()) { out = std::move(it->second); ahead_.erase(ahead_.begin(), std::next(it)); return true; }
         Read r;
         while (!eof_) {
-            if (!next(r)) { eof_ = true; break; }
+            if (!next_async(r)) { eof_ = true; break; }
             if (r.id == id) { out = std::move(r); while (!ahead_.empty() && ahead_.begin()->first < id) ahead_.erase(ahead_.begin()); return true; }
             if (r.id > id) ahead_[r.id] = r;          // slightly out-of-order files (reads.h:142 keeps a 500k-entry heap)
         }
@@ -707,71 +818,6 @@ public:
 };
 
 // ------------------------------------------------------------------ BGZF + BAM writer (samtools-0.1.18 bgzf.c, common.cpp:1000-1173)
-class BgzfWriter {
-    FILE* f_ = nullptr;
-    std::vector<uint8_t> in_;
-    int64_t block_addr_ = 0;
-    static const int BLOCK = 0x10000;
-    void deflate_block() {
-        size_t off = 0;
-        while (off < in_.size() || (off == 0 && in_.empty() && false)) {
-            size_t take = in_.size() - off;
-            if (take > (size_t)BLOCK) take = BLOCK;
-            std::vector<uint8_t> out(BLOCK + 1024);
-            size_t clen = 0;
-            for (;;) {
-                z_stream zs; memset(&zs, 0, sizeof zs);
-                deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
-                zs.next_in = in_.data() + off; zs.avail_in = (uInt)take;
-                zs.next_out = out.data() + 18; zs.avail_out = (uInt)(BLOCK - 18 - 8);
-                int st = deflate(&zs, Z_FINISH);
-                clen = zs.total_out;
-                deflateEnd(&zs);
-                if (st == Z_STREAM_END) break;
-                take -= 1024;                       // bgzf.c deflate_block: shrink the input and retry
-            }
-            uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in_.data() + off, (uInt)take);
-            write_block(out.data(), clen, crc, (uint32_t)take);
-            off += take;
-        }
-        in_.clear();
-    }
-    void write_block(uint8_t* out, size_t clen, uint32_t crc, uint32_t isize) {
-        static const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
-        memcpy(out, hdr, 12);
-        out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
-        uint16_t bs = (uint16_t)(clen + 18 + 8 - 1);
-        memcpy(out + 16, &bs, 2);
-        memcpy(out + 18 + clen, &crc, 4);
-        memcpy(out + 18 + clen + 4, &isize, 4);
-        fwrite(out, 1, clen + 26, f_);
-        block_addr_ += (int64_t)clen + 26;
-    }
-public:
-    bool open(const std::string& fn) { f_ = fopen(fn.c_str(), "wb"); return f_ != nullptr; }
-    void write(const void* d, size_t n) {
-        const uint8_t* p = (const uint8_t*)d;
-        while (n) {
-            size_t room = (size_t)BLOCK - in_.size();
-            size_t k = n < room ? n : room;
-            in_.insert(in_.end(), p, p + k);
-            p += k; n -= k;
-            if (in_.size() == (size_t)BLOCK) deflate_block();
-        }
-    }
-    int64_t tell() const { return (block_addr_ << 16) | (int64_t)in_.size(); }
-    void close() {
-        if (!f_) return;
-        if (!in_.empty()) deflate_block();
-        uint8_t out[64];
-        uint8_t empty[2] = {3, 0};                   // an empty deflate stream: the BGZF EOF marker block
-        memcpy(out + 18, empty, 2);
-        write_block(out, 2, 0, 0);
-        fclose(f_); f_ = nullptr;
-    }
-    ~BgzfWriter() { close(); }
-};
-
 inline int reg2bin(int beg, int end) {                // bam.h bam_reg2bin
     --end;
     if (beg >> 14 == end >> 14) return 4681 + (beg >> 14);
@@ -782,18 +828,106 @@ inline int reg2bin(int beg, int end) {                // bam.h bam_reg2bin
     return 0;
 }
 
-// GBamWriter with the read-id -> BGZF-offset side file (common.h:562-606)
+// GBamWriter with the read-id -> BGZF-offset side file (common.h:562-606).
+// The uncompressed stream is cut into 64 KiB BGZF blocks exactly as bgzf_write does; records of a batch are
+// encoded by worker threads, the blocks of the batch are deflated by worker threads (blocks are independent
+// members), and one thread writes them in order and replays the `.index` rule on the now-known block addresses.
 class BamWriter {
-    BgzfWriter z_;
+    FILE* f_ = nullptr;
     FILE* idx_ = nullptr;
     std::unordered_map<std::string, int32_t> tid_;
-    uint64_t idxcount_ = 0; int64_t last_id_ = 0;
+    std::vector<uint8_t> carry_;                    // bytes after the last full block (always starts a block)
+    int64_t file_addr_ = 0;                         // compressed bytes written = address of the block `carry_` opens
+    uint64_t idxcount_ = 0; long last_id_ = 0;
+    static const size_t BLOCK = 0x10000;
     static void put32(std::vector<uint8_t>& v, uint32_t x) { uint8_t b[4]; memcpy(b, &x, 4); v.insert(v.end(), b, b + 4); }
+
+    // one BGZF member from `take` input bytes; false when they do not fit (bgzf.c deflate_block then shrinks its input)
+    static bool deflate_member(const uint8_t* in, size_t take, std::vector<uint8_t>& out) {
+        out.resize(BLOCK + 1024);
+        z_stream zs; memset(&zs, 0, sizeof zs);
+        deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        zs.next_in = const_cast<uint8_t*>(in); zs.avail_in = (uInt)take;
+        zs.next_out = out.data() + 18; zs.avail_out = (uInt)(BLOCK - 18 - 8);
+        int st = deflate(&zs, Z_FINISH);
+        size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (st != Z_STREAM_END) return false;
+        static const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
+        memcpy(out.data(), hdr, 12);
+        out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
+        uint16_t bs = (uint16_t)(clen + 18 + 8 - 1);
+        memcpy(out.data() + 16, &bs, 2);
+        uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in, (uInt)take), isize = (uint32_t)take;
+        memcpy(out.data() + 18 + clen, &crc, 4);
+        memcpy(out.data() + 18 + clen + 4, &isize, 4);
+        out.resize(clen + 26);
+        return true;
+    }
+
+    struct Blk { size_t ustart, ulen; int64_t addr; };
+    // Compress and write every full block of `stream` (which starts on a block boundary); returns the block table
+    // including the still-open last block, whose bytes become the new carry.
+    std::vector<Blk> flush_full_blocks(const std::vector<uint8_t>& stream, bool final_flush) {
+        const size_t nfull = stream.size() / BLOCK;
+        std::vector<std::vector<uint8_t>> out(nfull);
+        std::vector<char> ok(nfull, 1);
+        const int T = host_threads();
+        auto work = [&](int t) { for (size_t k = (size_t)t; k < nfull; k += (size_t)T) ok[k] = deflate_member(stream.data() + k * BLOCK, BLOCK, out[k]); };
+        if (nfull > 1 && T > 1) {
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+            for (auto& x : th) x.join();
+        } else for (int t = 0; t < T; ++t) work(t);
+        std::vector<Blk> tab;
+        size_t upos = 0, k = 0;
+        for (; k < nfull && ok[k]; ++k) {
+            tab.push_back({upos, BLOCK, file_addr_});
+            fwrite(out[k].data(), 1, out[k].size(), f_);
+            file_addr_ += (int64_t)out[k].size();
+            upos += BLOCK;
+        }
+        if (k < nfull) {
+            // incompressible data: bgzf.c shrinks the block by 1 KiB steps and the leftover opens the next block;
+            // from here on the block boundaries move, so the rest of this stream goes one block at a time
+            std::vector<uint8_t> o;
+            while (stream.size() - upos >= BLOCK) {
+                size_t take = BLOCK;
+                while (!deflate_member(stream.data() + upos, take, o)) take -= 1024;
+                tab.push_back({upos, take, file_addr_});
+                fwrite(o.data(), 1, o.size(), f_);
+                file_addr_ += (int64_t)o.size();
+                upos += take;
+            }
+        }
+        if (final_flush && upos < stream.size()) {
+            std::vector<uint8_t> o;
+            size_t take = stream.size() - upos;
+            while (!deflate_member(stream.data() + upos, take, o)) take -= 1024;
+            for (;;) {
+                tab.push_back({upos, take, file_addr_});
+                fwrite(o.data(), 1, o.size(), f_);
+                file_addr_ += (int64_t)o.size();
+                upos += take;
+                if (upos >= stream.size()) break;
+                take = stream.size() - upos;
+                while (!deflate_member(stream.data() + upos, take, o)) take -= 1024;
+            }
+        }
+        tab.push_back({upos, stream.size() - upos, file_addr_});       // the open block
+        return tab;
+    }
+    static int64_t tell_at(const std::vector<Blk>& tab, size_t x) {       // bgzf_tell of stream offset x
+        size_t lo = 0, hi = tab.size();
+        while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (tab[mid].ustart <= x) lo = mid; else hi = mid; }
+        return (tab[lo].addr << 16) | (int64_t)(x - tab[lo].ustart);
+    }
 public:
     bool open(const std::string& fn, const RefTable& rt, const std::string& idx_fn) {
-        if (!z_.open(fn)) return false;
+        f_ = fopen(fn.c_str(), "wb");
+        if (!f_) return false;
         if (!idx_fn.empty()) { idx_ = fopen(idx_fn.c_str(), "w"); if (!idx_) return false; }
-        std::vector<uint8_t> h;
+        std::vector<uint8_t>& h = carry_;
         h.insert(h.end(), {'B', 'A', 'M', 1});
         put32(h, (uint32_t)rt.header_text.size());
         h.insert(h.end(), rt.header_text.begin(), rt.header_text.end());
@@ -805,12 +939,12 @@ public:
             put32(h, rt.sq[i].second);
             tid_[rt.sq[i].first] = (int32_t)i;
         }
-        z_.write(h.data(), h.size());
         return true;
     }
-    // one record exactly as GBamRecord builds it: mate fields "*", 0, 0; MAPQ 255
-    void write(const std::string& qname, uint32_t flag, const std::string& rname, int pos1, const std::vector<uint32_t>& cigar /*op<<28|len*/,
-               const std::string& seq, const std::string& qual, const std::vector<std::string>& aux) {
+    // Appends block_size + one record exactly as GBamRecord builds it: mate fields "*", 0, 0; MAPQ 255.  Thread-safe.
+    void encode(std::vector<uint8_t>& d, const std::string& qname, uint32_t flag, const std::string& rname, int pos1,
+                const uint32_t* cigar /*op<<28|len*/, int n_cigar, const std::string& seq, const std::string& qual,
+                const std::vector<std::string>& aux) const {
         static const uint8_t nt16[256] = {
             15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
             15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 1,2,4,8,15,15,15,15,15,15,15,15,15,0,15,15,
@@ -821,21 +955,22 @@ public:
             15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,
             15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15, 15,15,15,15,15,15,15,15,15,15,15,15,15,15,15,15};
         static const uint8_t bamop[16] = {0, 0, 0, 1, 1, 2, 2, 0, 0, 0, 0, 3, 3, 4, 5, 6};   // upper-cased letters (set_cigar :1044-1053)
-        std::vector<uint8_t> d;
+        const size_t at = d.size();
+        put32(d, 0);                                                           // block_size, patched below
         auto it = tid_.find(rname);
         int32_t tid = it == tid_.end() ? -1 : it->second;
         int32_t pos = pos1 <= 0 ? -1 : pos1 - 1;
         int end = pos;
-        for (uint32_t c : cigar) { uint32_t op = bamop[c >> 28]; if (op == 0 || op == 2 || op == 3) end += (int)(c & 0x0FFFFFFF); }
-        uint32_t bin = (uint32_t)reg2bin(pos, cigar.empty() ? pos + 1 : end);
+        for (int i = 0; i < n_cigar; ++i) { uint32_t c = cigar[i], op = bamop[c >> 28]; if (op == 0 || op == 2 || op == 3) end += (int)(c & 0x0FFFFFFF); }
+        uint32_t bin = (uint32_t)reg2bin(pos, n_cigar == 0 ? pos + 1 : end);
         uint32_t l_rn = (uint32_t)qname.size() + 1;
         put32(d, (uint32_t)tid); put32(d, (uint32_t)pos);
         put32(d, (bin << 16) | (255u << 8) | l_rn);
-        put32(d, (flag << 16) | (uint32_t)cigar.size());
+        put32(d, (flag << 16) | (uint32_t)n_cigar);
         put32(d, (uint32_t)seq.size());
         put32(d, (uint32_t)-1); put32(d, (uint32_t)-1); put32(d, 0);          // mtid, mpos (0-1), isize
         d.insert(d.end(), qname.begin(), qname.end()); d.push_back(0);
-        for (uint32_t c : cigar) put32(d, ((c & 0x0FFFFFFF) << 4) | bamop[c >> 28]);
+        for (int i = 0; i < n_cigar; ++i) put32(d, ((cigar[i] & 0x0FFFFFFF) << 4) | bamop[cigar[i] >> 28]);
         size_t so = d.size();
         d.resize(so + (seq.size() + 1) / 2, 0);
         for (size_t i = 0; i < seq.size(); ++i) d[so + i / 2] |= (uint8_t)(nt16[(uint8_t)seq[i]] << (4 * (1 - i % 2)));
@@ -857,26 +992,63 @@ public:
                 }
             } else if (ty == 'Z' || ty == 'H') { d.push_back((uint8_t)ty); d.insert(d.end(), a.begin() + 5, a.end()); d.push_back(0); }
         }
-        // GBamWriter::write(b, read_id): index line once >= INDEX_REC_COUNT (1000) records have passed and the id changes
-        long read_id = atol(qname.c_str());
-        int64_t pre_pos = 0, pre_addr = 0; bool widx = false;
-        if (idx_ && read_id) {
-            if (idxcount_ >= 1000 && read_id != last_id_) { pre_pos = z_.tell(); pre_addr = (pre_pos >> 16) & 0xFFFFFFFFFFFFLL; widx = true; }
-            last_id_ = read_id; ++idxcount_;
-        }
-        uint32_t bs = (uint32_t)d.size();
-        z_.write(&bs, 4);
-        z_.write(d.data(), d.size());
-        if (widx) {
-            int64_t off = z_.tell();
-            int post_offs = (int)(off & 0xFFFF); int64_t post_addr = (off >> 16) & 0xFFFFFFFFFFFFLL;
-            int data_len = (int)d.size();          // b->data_len + BAM_CORE_SIZE == block_size of the record
-            if (post_addr != pre_addr && post_offs >= data_len) pre_pos = post_addr << 16;
-            fprintf(idx_, "%ld\t%ld\n", read_id, (long)pre_pos);
-            idxcount_ = 0;
-        }
+        uint32_t bs = (uint32_t)(d.size() - at - 4);
+        memcpy(d.data() + at, &bs, 4);
     }
-    void close() { z_.close(); if (idx_) { fclose(idx_); idx_ = nullptr; } }
+    // Writes records 0..n-1 in order.  enc(i, bytes) appends record i with encode() and returns its read id (atol(qname)).
+    void write_records(size_t n, const std::function<long(size_t, std::vector<uint8_t>&)>& enc) {
+        int T = host_threads();
+        if ((size_t)T > n / 256 + 1) T = (int)(n / 256 + 1);
+        std::vector<std::vector<uint8_t>> part((size_t)T);
+        std::vector<uint32_t> size(n); std::vector<long> rid(n);
+        auto work = [&](int t) {
+            const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T;
+            std::vector<uint8_t>& d = part[(size_t)t];
+            d.reserve((b - a) * 256);
+            for (size_t i = a; i < b; ++i) { size_t before = d.size(); rid[i] = enc(i, d); size[i] = (uint32_t)(d.size() - before); }
+        };
+        if (T > 1) { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+        else work(0);
+        std::vector<uint8_t> stream;
+        size_t total = carry_.size();
+        for (auto& d : part) total += d.size();
+        stream.reserve(total);
+        stream.insert(stream.end(), carry_.begin(), carry_.end());
+        for (auto& d : part) { stream.insert(stream.end(), d.begin(), d.end()); std::vector<uint8_t>().swap(d); }
+        std::vector<Blk> tab = flush_full_blocks(stream, false);
+        // GBamWriter::write(b, read_id): index line once >= INDEX_REC_COUNT (1000) records have passed and the id changes
+        if (idx_) {
+            size_t x = carry_.size();
+            for (size_t i = 0; i < n; ++i) {
+                const size_t s0 = x, e0 = x + size[i];
+                x = e0;
+                const long read_id = rid[i];
+                if (!read_id) continue;
+                bool widx = idxcount_ >= 1000 && read_id != last_id_;
+                last_id_ = read_id; ++idxcount_;
+                if (!widx) continue;
+                int64_t pre_pos = tell_at(tab, s0), pre_addr = (pre_pos >> 16) & 0xFFFFFFFFFFFFLL;
+                int64_t off = tell_at(tab, e0);
+                int post_offs = (int)(off & 0xFFFF); int64_t post_addr = (off >> 16) & 0xFFFFFFFFFFFFLL;
+                int data_len = (int)size[i] - 4;       // b->data_len + BAM_CORE_SIZE == block_size of the record
+                if (post_addr != pre_addr && post_offs >= data_len) pre_pos = post_addr << 16;
+                fprintf(idx_, "%ld\t%ld\n", read_id, (long)pre_pos);
+                idxcount_ = 0;
+            }
+        }
+        const Blk& open = tab.back();
+        carry_.assign(stream.begin() + (ptrdiff_t)open.ustart, stream.end());
+    }
+    void close() {
+        if (!f_) return;
+        if (!carry_.empty()) { std::vector<uint8_t> s; s.swap(carry_); flush_full_blocks(s, true); }
+        std::vector<uint8_t> eof;
+        deflate_member(nullptr, 0, eof);              // an empty member: the BGZF EOF marker block
+        fwrite(eof.data(), 1, eof.size(), f_);
+        fclose(f_); f_ = nullptr;
+        if (idx_) { fclose(idx_); idx_ = nullptr; }
+    }
+    ~BamWriter() { close(); }
 };
 
 inline void reverse_complement(std::string& s) {       // reads.cpp:189-207
