@@ -44,7 +44,7 @@ cmd = [os.path.join(BIN, "segment_juncs"), "--no-coverage-search", "--no-microex
        f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"],
        f("left.fq"), f("left_map.sam"), segs["left"], f("right.fq"), f("right_map.sam"), segs["right"]]
 t = time.time()
-r = subprocess.run(cmd, capture_output=True, text=True)
+r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, THJ_TIMING="1"))
 dt = time.time() - t
 assert r.returncode == 0, r.stderr[-2000:]
 res["segment_juncs_s"] = round(dt, 3)

@@ -140,7 +140,7 @@ int main(int argc, char** argv) {
     if (parts == 1 && !bw1.open(out, rt, out + ".index")) die("Error: could not create BAM file %s!\n", out.c_str());
     std::vector<Read> all_reads;                 // reads of the current batch (parts == 1) or of the run (parts > 1)
     std::vector<thj_aln> alns;
-    auto write_range = [&](BamWriter& bw, size_t a0, size_t a1) {
+    auto write_range = [&](BamWriter& bw, const std::vector<thj_aln>& alns, const std::vector<Read>& all_reads, size_t a0, size_t a1) {
         bw.write_records(a1 - a0, [&](size_t i, std::vector<uint8_t>& d) -> long {
             const thj_aln& a = alns[a0 + i];
             const Read& rd = all_reads[a.read_idx];
@@ -168,7 +168,12 @@ int main(int argc, char** argv) {
         });
     };
 
-    size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
+    // one output file: a writer thread encodes / deflates / writes batch k while the main thread ingests batch k+1
+    std::thread writer;
+    std::vector<Read> w_reads; std::vector<thj_aln> w_alns;
+    auto writer_join = [&]() { if (writer.joinable()) writer.join(); };
+
+    size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 19;
     std::vector<uint32_t> seg_off; std::vector<thj_span_hit> hits; std::vector<int64_t> read_off; std::string bases, quals;
     size_t max_len = 0; size_t batch_first = 0;
     auto reset = [&]() { seg_off.assign(1, 0); hits.clear(); read_off.assign(1, 0); bases.clear(); quals.clear(); max_len = 0; batch_first = all_reads.size(); };
@@ -199,9 +204,11 @@ int main(int argc, char** argv) {
         if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
         g_timer.lap("pack + upload + stitch + download");
         if (parts == 1) {
-            write_range(bw1, 0, alns.size());
+            writer_join();                          // batch k-1 is on disk (time spent here = the writer is the bottleneck)
+            w_alns.swap(alns); w_reads.swap(all_reads);
             alns.clear(); all_reads.clear();
-            g_timer.lap("BAM output (encode + BGZF)");
+            writer = std::thread([&]() { write_range(bw1, w_alns, w_reads, 0, w_alns.size()); });
+            g_timer.lap("wait for the BAM writer thread");
         }
         reset();
     };
@@ -236,7 +243,7 @@ int main(int argc, char** argv) {
     flush();
     g_timer.lap("ingest (parse + merge by id)");
 
-    if (parts == 1) bw1.close();
+    if (parts == 1) { writer_join(); bw1.close(); g_timer.lap("wait for the BAM writer thread"); }
     else {
         std::vector<size_t> cut((size_t)parts + 1, alns.size());
         cut[0] = 0;
@@ -249,11 +256,11 @@ int main(int argc, char** argv) {
             std::string fn = out.substr(0, out.size() >= 4 ? out.size() - 4 : out.size()) + std::to_string(k) + ".bam";
             BamWriter bw;
             if (!bw.open(fn, rt, fn + ".index")) die("Error: could not create BAM file %s!\n", fn.c_str());
-            write_range(bw, cut[(size_t)k], cut[(size_t)k + 1]);
+            write_range(bw, alns, all_reads, cut[(size_t)k], cut[(size_t)k + 1]);
             bw.close();
         }
+        g_timer.lap("BAM output (encode + BGZF)");
     }
-    g_timer.lap("BAM output (encode + BGZF)");
     thj_ctx_destroy(ctx);
     g_timer.lap("teardown");
     g_timer.report();

@@ -204,7 +204,15 @@ struct RefTable {
 
     std::mutex mu;                                  // reader threads resolve names concurrently
     uint32_t get_id(const std::string& name) {
+        // consecutive records mostly name the same contig: a per-thread one-entry cache keeps the lock out of the way
+        static thread_local RefTable* c_rt = nullptr; static thread_local std::string c_name; static thread_local uint32_t c_id = 0;
+        if (c_rt == this && c_name == name) return c_id;
         std::lock_guard<std::mutex> lk(mu);
+        uint32_t id = get_id_locked(name);
+        c_rt = this; c_name = name; c_id = id;
+        return id;
+    }
+    uint32_t get_id_locked(const std::string& name) {
         auto it = ids.find(name);
         if (it != ids.end()) return it->second;
         names.push_back(name);
@@ -298,6 +306,7 @@ class AlnReader {
     void rd(void* dst, int n, const char* fn) { if (gzread(gz_, dst, (unsigned)n) != n) die("Error: truncated BAM file %s\n", fn); }
 public:
     std::string fname;
+    bool want_seq = true;       // false: SEQ / QUAL are not decoded, r.seq only gets its length (the hit factories' need)
     bool open(const std::string& fn) {
         fname = fn;
         if (file_ext(fn) == "sam") {                 // bwt_map.cpp:170-175
@@ -329,7 +338,9 @@ public:
     ~AlnReader() { close(); }
 
     bool next(AlnRec& r) {
-        r = AlnRec();
+        // reset in place: the strings keep their capacity from record to record
+        r.qname.clear(); r.rname.clear(); r.rnext.clear(); r.pos = -1; r.flag = 0; r.cigar.clear(); r.seq.clear(); r.qual.clear();
+        r.nm = 0; r.has_nm = false; r.xs = 0; r.has_xf = false; r.md.clear(); r.has_md = false;
         if (bam_) {
             int32_t bs;
             int got = gzread(gz_, &bs, 4);
@@ -349,11 +360,13 @@ public:
             static const char CIG[] = "MIDNSHP=X";
             for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + p, 4); p += 4; r.cigar.emplace_back(CIG[c & 0xF], c >> 4); }
             static const char SEQ[] = "=ACMGRSVTWYHKDBN";
-            r.seq.resize((size_t)l_seq); r.qual.resize((size_t)l_seq);
-            for (int i = 0; i < l_seq; ++i) r.seq[i] = SEQ[(d[p + (i >> 1)] >> ((i & 1) ? 0 : 4)) & 0xF];
-            p += (size_t)(l_seq + 1) / 2;
-            for (int i = 0; i < l_seq; ++i) r.qual[i] = (char)(d[p + i] + 33);
-            p += (size_t)l_seq;
+            r.seq.resize((size_t)l_seq);
+            if (want_seq) {
+                r.qual.resize((size_t)l_seq);
+                for (int i = 0; i < l_seq; ++i) r.seq[i] = SEQ[(d[p + (i >> 1)] >> ((i & 1) ? 0 : 4)) & 0xF];
+                for (int i = 0; i < l_seq; ++i) r.qual[i] = (char)(d[p + (size_t)(l_seq + 1) / 2 + i] + 33);
+            }
+            p += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
             while (p + 3 <= (size_t)bs) {                       // bam_aux_get for NM / XS / XF
                 char t0 = (char)d[p], t1 = (char)d[p + 1], ty = (char)d[p + 2];
                 p += 3;
@@ -381,24 +394,35 @@ public:
         ssize_t n;
         while ((n = getline(&line_, &cap_, txt_)) > 0) {
             if (line_[0] == '@') continue;
-            std::string l(line_, (size_t)n);
-            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
-            if (l.empty()) continue;
-            std::vector<std::string> t;
-            size_t i = 0;
-            while (i <= l.size()) { size_t j = l.find('\t', i); if (j == std::string::npos) j = l.size(); t.push_back(l.substr(i, j - i)); i = j + 1; }
-            if (t.size() < 11) die("Error: malformed SAM line in %s\n", fname.c_str());
-            r.qname = t[0]; r.flag = (uint32_t)atoi(t[1].c_str()); r.rname = t[2]; r.pos = atoi(t[3].c_str()) - 1;
-            r.rnext = t[6]; r.seq = t[9]; r.qual = t[10];
-            if (t[5] != "*") {
-                const char* s = t[5].c_str();
-                while (*s) { char* e; long len = strtol(s, &e, 10); if (!*e) break; r.cigar.emplace_back(*e, (uint32_t)len); s = e + 1; }
+            while (n > 0 && (line_[n - 1] == '\n' || line_[n - 1] == '\r')) --n;
+            if (n == 0) continue;
+            line_[n] = 0;
+            // fields in place: f[k] .. f[k] + flen[k]
+            const char* f[64]; size_t flen[64]; int nf = 0;
+            {
+                const char* s0 = line_; const char* end = line_ + n;
+                while (nf < 64) {
+                    const char* t = (const char*)memchr(s0, '\t', (size_t)(end - s0));
+                    f[nf] = s0; flen[nf] = (size_t)((t ? t : end) - s0); ++nf;
+                    if (!t) break;
+                    s0 = t + 1;
+                }
             }
-            for (size_t k = 11; k < t.size(); ++k) {
-                if (!t[k].compare(0, 5, "NM:i:")) { r.nm = atoi(t[k].c_str() + 5); r.has_nm = true; }
-                else if (!t[k].compare(0, 5, "XS:A:")) r.xs = t[k][5];
-                else if (!t[k].compare(0, 5, "XF:Z:")) r.has_xf = true;
-                else if (!t[k].compare(0, 5, "MD:Z:")) { r.md = t[k].substr(5); r.has_md = true; }
+            if (nf < 11) die("Error: malformed SAM line in %s\n", fname.c_str());
+            r.qname.assign(f[0], flen[0]); r.flag = (uint32_t)atoi(f[1]); r.rname.assign(f[2], flen[2]); r.pos = atoi(f[3]) - 1;
+            r.rnext.assign(f[6], flen[6]);
+            if (want_seq) { r.seq.assign(f[9], flen[9]); r.qual.assign(f[10], flen[10]); }
+            else r.seq.resize(flen[9]);
+            if (!(flen[5] == 1 && f[5][0] == '*')) {
+                const char* s = f[5]; const char* e5 = f[5] + flen[5];
+                while (s < e5) { char* e; long len = strtol(s, &e, 10); if (e >= e5) break; r.cigar.emplace_back(*e, (uint32_t)len); s = e + 1; }
+            }
+            for (int k = 11; k < nf; ++k) {
+                if (flen[k] < 5) continue;
+                if (!memcmp(f[k], "NM:i:", 5)) { r.nm = atoi(f[k] + 5); r.has_nm = true; }
+                else if (!memcmp(f[k], "XS:A:", 5)) r.xs = flen[k] > 5 ? f[k][5] : 0;
+                else if (!memcmp(f[k], "XF:Z:", 5)) r.has_xf = true;
+                else if (!memcmp(f[k], "MD:Z:", 5)) { r.md.assign(f[k] + 5, flen[k] - 5); r.has_md = true; }
             }
             return true;
         }
@@ -416,14 +440,20 @@ struct Hit {
 // returns false when the reference's factory returns false (record dropped) or the record is unmapped
 inline bool parse_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& out) {
     bool end = true;
-    std::string q = r.qname;
+    const std::string& q = r.qname;
     size_t pipe = q.rfind('|');
     if (pipe != std::string::npos) {
         const char* tag = q.c_str() + pipe + 1;
-        if (strchr(tag, ':')) { unsigned a = 0, b = 0, c = 0; sscanf(tag, "%u:%u:%u", &a, &b, &c); end = (b + 1 == c); }
-        q.resize(pipe);
+        if (strchr(tag, ':')) {                       // "<offset>:<segment>:<segments>" (tophat.py:2948)
+            char* e;
+            unsigned long b = 0, c = 0;
+            strtoul(tag, &e, 10);
+            if (*e == ':') { b = strtoul(e + 1, &e, 10); if (*e == ':') c = strtoul(e + 1, &e, 10); }
+            end = (b + 1 == c);
+        }
     }
-    out.insert_id = (uint32_t)atoi(q.c_str());
+    out.insert_id = (uint32_t)atoi(q.c_str());          // stops at the '|'
+
     if (r.rname == "*" || (r.flag & 4)) return false;    // unmapped: the maps this path is fed hold mapped records only
     if (r.has_xf) die("Error: fusion (XF) alignments in %s are not supported by this build\n", r.qname.c_str());
     unsigned char mism = (unsigned char)r.nm;
@@ -626,10 +656,10 @@ inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p
 
 // Host threading: every input file is inflated / tokenised / parsed by its own reader thread, which hands chunks of
 // finished records to the consumer through a small bounded queue; the consumer (merge by read id, batching) never
-// parses.  THJ_HOST_THREADS bounds the worker count of the parallel stages (default: min(16, hardware threads)).
+// parses.  THJ_HOST_THREADS bounds the worker count of the parallel stages (default: min(32, hardware threads)).
 inline int host_threads() {
     int n = getenv("THJ_HOST_THREADS") ? atoi(getenv("THJ_HOST_THREADS")) : 0;
-    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 16) n = 16; }
+    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 32) n = 32; }
     return n < 1 ? 1 : n;
 }
 
@@ -691,6 +721,7 @@ public:
     HitStream& operator=(const HitStream&) = delete;
     bool open(const std::string& fn, RefTable& rt, const thj_params& p, bool spliced = false) {
         rt_ = &rt; p_ = &p; spliced_ = spliced;
+        rd_.want_seq = false;                    // neither hit factory looks at the bases, only at their number
         if (fn.empty() || !rd_.open(fn)) return false;
         done_ = false;
         th_ = std::thread([this] { producer(); });

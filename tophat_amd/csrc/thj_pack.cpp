@@ -8,7 +8,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -63,6 +66,22 @@ static inline int base_code(char c) {
     }
 }
 
+// Host-side packing is embarrassingly parallel; THJ_HOST_THREADS bounds the workers (default min(32, hardware threads)).
+static int pack_threads() {
+    int n = getenv("THJ_HOST_THREADS") ? atoi(getenv("THJ_HOST_THREADS")) : 0;
+    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 32) n = 32; }
+    return n < 1 ? 1 : n;
+}
+template <class F>
+static void parallel_ranges(int64_t n, int64_t grain, F f) {       // f(begin, end) over a partition of [0, n)
+    int T = pack_threads();
+    if ((int64_t)T > n / grain + 1) T = (int)(n / grain + 1);
+    if (T <= 1) { f((int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back([=] { f(n * t / T, n * (t + 1) / T); });
+    for (auto& x : th) x.join();
+}
+
 extern "C" int thj_genome_pack(int32_t n_contigs, const char* const* seqs, const int64_t* lens,
                                const uint32_t* contig_blk, uint64_t* blocks, int64_t n_blocks) {
     if (!blocks || !contig_blk || !lens) { thj_set_error("thj_genome_pack: null argument"); return THJ_EINVAL; }
@@ -73,17 +92,19 @@ extern "C" int thj_genome_pack(int32_t n_contigs, const char* const* seqs, const
         const char* s = seqs[c];
         uint64_t* out = blocks + (uint64_t)contig_blk[c] * 4;
         int64_t n = lens[c];
-        for (int64_t b0 = 0; b0 < n; b0 += 64) {
-            uint64_t lo = 0, hi = 0, nm = 0;
-            int lim = n - b0 < 64 ? (int)(n - b0) : 64;
-            for (int k = 0; k < lim; ++k) {
-                int code = base_code(s[b0 + k]);
-                if (code == 4) nm |= 1ull << k;
-                else { lo |= (uint64_t)(code & 1) << k; hi |= (uint64_t)(code >> 1) << k; }
+        parallel_ranges((n + 63) / 64, 1 << 14, [=](int64_t k0, int64_t k1) {
+            for (int64_t b0 = k0 * 64; b0 < k1 * 64 && b0 < n; b0 += 64) {
+                uint64_t lo = 0, hi = 0, nm = 0;
+                int lim = n - b0 < 64 ? (int)(n - b0) : 64;
+                for (int k = 0; k < lim; ++k) {
+                    int code = base_code(s[b0 + k]);
+                    if (code == 4) nm |= 1ull << k;
+                    else { lo |= (uint64_t)(code & 1) << k; hi |= (uint64_t)(code >> 1) << k; }
+                }
+                uint64_t* blk = out + (b0 >> 6) * 4;
+                blk[0] = lo; blk[1] = hi; blk[2] = nm; blk[3] = 0;
             }
-            uint64_t* blk = out + (b0 >> 6) * 4;
-            blk[0] = lo; blk[1] = hi; blk[2] = nm; blk[3] = 0;
-        }
+        });
     }
     return THJ_OK;
 }
@@ -94,17 +115,22 @@ extern "C" int thj_reads_pack(int64_t n_reads, const int64_t* read_off, const ch
     for (int64_t r = 0; r < n_reads; ++r) {
         int64_t n = read_off[r + 1] - read_off[r];
         if (n < 0 || n > (int64_t)W * 64) { thj_set_error("read %lld length %lld exceeds %d bases", (long long)r, (long long)n, W * 64); return THJ_EINVAL; }
-        lens[r] = (uint16_t)n;
-        uint64_t* rp = planes + r * 3 * W;
-        memset(rp, 0, (size_t)(3 * W) * 8);
-        const char* s = bases + read_off[r];
-        for (int64_t k = 0; k < n; ++k) {
-            int code = base_code(s[k]);
-            // reads keep their case in the reference; prep_reads emits upper-case ACGTN
-            int w = (int)(k >> 6), b = (int)(k & 63);
-            if (code == 4) rp[2 * W + w] |= 1ull << b;
-            else { rp[w] |= (uint64_t)(code & 1) << b; rp[W + w] |= (uint64_t)(code >> 1) << b; }
-        }
     }
+    parallel_ranges(n_reads, 1 << 14, [=](int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            int64_t n = read_off[r + 1] - read_off[r];
+            lens[r] = (uint16_t)n;
+            uint64_t* rp = planes + r * 3 * W;
+            memset(rp, 0, (size_t)(3 * W) * 8);
+            const char* s = bases + read_off[r];
+            for (int64_t k = 0; k < n; ++k) {
+                int code = base_code(s[k]);
+                // reads keep their case in the reference; prep_reads emits upper-case ACGTN
+                int w = (int)(k >> 6), b = (int)(k & 63);
+                if (code == 4) rp[2 * W + w] |= 1ull << b;
+                else { rp[w] |= (uint64_t)(code & 1) << b; rp[W + w] |= (uint64_t)(code >> 1) << b; }
+            }
+        }
+    });
     return THJ_OK;
 }
