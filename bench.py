@@ -40,6 +40,10 @@ from tophat_amd.synth import make_device_workload, make_scale_genome  # noqa: E4
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 CHR20_LEN = 64_444_167         # GRCh38 chr20 length (BASELINE.json configs[1])
+# GRCh38 primary assembly, chr1..22, X, Y, M (sum 3 088 286 401 bp)
+GRCH38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+               135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+               46709983, 50818468, 156040895, 57227415, 16569]
 
 
 def cbatch_from_tensors(w, ordinal_base=0) -> host.CSegBatch:
@@ -121,6 +125,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (BASELINE config 2: 10 M)")
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
+    ap.add_argument("--genome", choices=["chr20", "grch38"], default="chr20",
+                    help="chr20: one contig of --genome-len bases (configs[1]); grch38: 25 contigs with the GRCh38 primary-assembly "
+                         "lengths, 3.09 Gb (the genome of configs[2]; pass --introns 300000)")
     ap.add_argument("--introns", type=int, default=20000)
     ap.add_argument("--exon-len", type=int, default=300)
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE configs[1]: 100; 150 / 50 are the shapes of configs[3] / [4])")
@@ -145,7 +152,9 @@ def main():
 
     # ---- workload: BASELINE.json configs[1] shape (per GPU) --------------------------------
     t_gen = time.time()
-    seqs, genes = make_scale_genome(1, [args.genome_len], args.introns, exon_len=args.exon_len)
+    contig_lens = [args.genome_len] if args.genome == "chr20" else GRCH38_LENS
+    args.genome_len = int(sum(contig_lens))
+    seqs, genes = make_scale_genome(1, contig_lens, args.introns, exon_len=args.exon_len)
     lib = host.load_lib()
     strs = [s.tobytes().decode() for s in seqs]
     pg = host.pack_genome(strs, lib=lib)
@@ -288,7 +297,7 @@ def main():
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.read_len == 100 and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
+        if args.read_len == 100 and args.genome == "chr20" and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
             for k in kernels:
                 c = pm["kernels"].get(k["kernel"])
                 if c:
@@ -299,6 +308,12 @@ def main():
         pass
     dom = max(kernels, key=lambda k: k["avg_kernel_ms"])
 
+    workload_text = ("%s: %d x 2x%d bp PE synthetic vs %d bp %s genome per GPU, inputs resident in HBM; both stages on device: "
+                     "segment_juncs (main + rescue kernels, event dedup+sort%s) then long_spanning_reads (three stitch tiers fed "
+                     "device-to-device with the junction set; records land in BAM order)"
+                     % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" else "shape of another config", args.pairs,
+                        args.read_len, args.genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
+                        ", RCCL all-gather of event keys" if use_dist else ""))
     result = None
     if rank == 0:
         cpu = None
@@ -330,12 +345,7 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": ("%s: %d x 2x%d bp PE synthetic vs %d bp chr20-sized genome per GPU, inputs "
-                                    "resident in HBM; both stages on device: segment_juncs (main + rescue kernels, event "
-                                    "dedup+sort%s) then long_spanning_reads (three stitch tiers fed device-to-device with the "
-                                    "junction set; records land in BAM order)"
-                                    % ("configs[1]" if args.read_len == 100 else "read shape of another config", args.pairs,
-                                       args.read_len, args.genome_len, ", RCCL all-gather of event keys" if use_dist else "")),
+            "config": {"workload": workload_text,
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

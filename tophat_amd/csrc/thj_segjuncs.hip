@@ -271,6 +271,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
         }
         __syncthreads();
         const Hit* tile_hits = staged ? (const Hit*)s_hits : b.hits;
+        if (THJ_EXPF(1 << 20)) continue;
         // ---- classify
         if (tid < tile_reads) {
             ReadView v = make_view(b, r0 + tid);
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             }
         }
         __syncthreads();
+        if (THJ_EXPF(1 << 21)) continue;
         // ---- enumerate (work list)
         const bool active = (unsigned)tid < s_nwork;
         ReadView v;
