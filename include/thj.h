@@ -210,6 +210,9 @@ typedef struct { uint32_t ref_id1, ref_id2, left, right, dir, count, edit_dist, 
  * this call must hold ALL visited reads, including those whose only mapped segment is the first
  * (:3994-4028).  Candidate events accumulate on the device. */
 int thj_fusion_reset_async(thj_ctx* ctx);
+/* --fusion-ignore-chromosomes (segment_juncs.cpp:3214-3231): hit pairs touching one of these contigs (1-based ref ids)
+ * are not examined.  Stays in force until called again (n = 0 clears). */
+int thj_fusion_set_ignored(thj_ctx* ctx, const uint32_t* ref_ids, int32_t n);
 int thj_fusion_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch* dev_batch);
 /* Synchronises and reduces the events to the FusionSimpleSet (count, smallest edit distance) in
  * Fusion::operator< order (fusions.h:38-69). */

@@ -728,8 +728,14 @@ static void detect_fusion(const orc_genome* g, int fusion_anchor_length, const c
 }
 
 /* find_fusions, segment_juncs.cpp:2976-3291 */
+static int ref_ignored(const uint32_t* ignore, int n_ignore, uint32_t ref)
+{
+    for (int i = 0; i < n_ignore; ++i) if (ignore[i] == ref) return 1;
+    return 0;
+}
+
 static void find_fusions(const orc_params* p, int fusion_anchor_length, int fusion_min_dist, const orc_genome* g,
-                         const orc_batch* b, int r, fvec* out)
+                         const orc_batch* b, int r, const uint32_t* ignore, int n_ignore, fvec* out)
 {
     int nseg = b->nseg;
     if (nseg == 0) return;
@@ -802,6 +808,8 @@ static void find_fusions(const orc_params* p, int fusion_anchor_length, int fusi
     for (int64_t li = so[0]; li < so[1]; ++li)                                   /* :3211-3290 */
         for (int ri = 0; ri < right.n; ++ri) {
             const orc_hit* lh = &b->hits[li]; const orc_hit* rh = &right.v[ri];
+            /* --fusion-ignore-chromosomes (:3214-3231) */
+            if (ref_ignored(ignore, n_ignore, lh->ref_id) || ref_ignored(ignore, n_ignore, rh->ref_id)) continue;
             if (p->bowtie2 && (int)lh->edit_dist + (int)rh->edit_dist > (p->segment_mismatches << 1)) continue;
             if (lh->ref_id == rh->ref_id && is_anti(lh) == is_anti(rh)) {
                 int dist = is_anti(lh) ? lh->left - rh->right : rh->left - lh->right;
@@ -819,10 +827,11 @@ static void find_fusions(const orc_params* p, int fusion_anchor_length, int fusi
 }
 
 int orc_fusions_batch(const orc_params* p, int fusion_anchor_length, int fusion_min_dist,
-                      const orc_genome* g, const orc_batch* b, orc_fusion** out, int64_t* n_out)
+                      const orc_genome* g, const orc_batch* b, const uint32_t* ignore_ref_ids, int n_ignore,
+                      orc_fusion** out, int64_t* n_out)
 {
     fvec ev = {0, 0, 0};
-    for (int r = 0; r < b->n_reads; ++r) find_fusions(p, fusion_anchor_length, fusion_min_dist, g, b, r, &ev);
+    for (int r = 0; r < b->n_reads; ++r) find_fusions(p, fusion_anchor_length, fusion_min_dist, g, b, r, ignore_ref_ids, n_ignore, &ev);
     /* FusionSimpleSet: count occurrences, keep the smallest edit distance (:2791-2803) */
     if (ev.n) qsort(ev.v, (size_t)ev.n, sizeof(orc_fusion), fcmp);
     int64_t w = 0;

@@ -131,7 +131,8 @@ typedef struct { uint32_t ref_id1, ref_id2, left, right, dir, count, edit_dist, 
  * (ALL visited reads, including those whose only mapped segment is the first).  Returns the FusionSimpleSet
  * in Fusion::operator< order (fusions.h:38-69); *out is malloc'd. */
 int orc_fusions_batch(const orc_params* p, int fusion_anchor_length, int fusion_min_dist,
-                      const orc_genome* g, const orc_batch* b, orc_fusion** out, int64_t* n_out);
+                      const orc_genome* g, const orc_batch* b, const uint32_t* ignore_ref_ids /* --fusion-ignore-chromosomes */,
+                      int n_ignore, orc_fusion** out, int64_t* n_out);
 /* The output filter of the fusion writer (segment_juncs.cpp:5096-5182): marks `skip`; juncs = the final junction
  * set (sorted).  Returns nothing; entries with skip != 0 are not written. */
 void orc_fusion_filter(orc_fusion* f, int64_t n, const orc_junction* juncs, int64_t n_juncs);

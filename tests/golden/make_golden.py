@@ -36,11 +36,19 @@ CASES = {
                                   contig_lens=(24000, 16000), genes_per_contig=4),
                          opts=["--inner-dist-mean", "50", "--inner-dist-std-dev", "20", "--fusion-search", "--fusion-min-dist", "1500"],
                          fusion=True),
+    "pe100_fusion_ignore": dict(gen=dict(seed=106, paired=True, read_len=100, seg_len=25, n_reads=120, fusion_reads=80,
+                                         contig_lens=(24000, 16000, 12000), genes_per_contig=4),
+                                opts=["--inner-dist-mean", "50", "--inner-dist-std-dev", "20", "--fusion-search", "--fusion-min-dist", "1500",
+                                      "--fusion-ignore-chromosomes", "chr3"],
+                                fusion=True),
 }
 
 
 def main():
+    only = sys.argv[1:]
     for name, cfg in CASES.items():
+        if only and name not in only:
+            continue
         d = os.path.join(HERE, name)
         if os.path.exists(d):
             shutil.rmtree(d)

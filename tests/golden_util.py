@@ -31,6 +31,7 @@ def load(name):
     p = Params(segment_length=int(kv["segment_length"]))
     i = 0
     fusion = False
+    ignore_names = []
     while i < len(argv):
         if argv[i] == "--fusion-search":
             fusion = True
@@ -46,6 +47,8 @@ def load(name):
             p.fusion_min_dist = int(argv[i + 1])
         elif argv[i] == "--fusion-anchor-length":
             p.fusion_anchor_length = int(argv[i + 1])
+        elif argv[i] == "--fusion-ignore-chromosomes":
+            ignore_names = argv[i + 1].split(",")
         i += 2
     names, _ = parse_header(os.path.join(d, "hdr.sam"))
     fa_names, fa_seqs = read_fasta(os.path.join(d, "ref.fa"))
@@ -85,7 +88,8 @@ def load(name):
         exp_span[sd] = [(r[0], int(r[1]), r[2], int(r[3]), r[5]) + r[8:] for r in rows]
     if fusion:
         span_batches = {}
-    return dict(p=p, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp=exp, exp_span=exp_span, fusion=fusion)
+    return dict(p=p, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp=exp, exp_span=exp_span, fusion=fusion,
+                fusion_ignore=[ref_ids[n] for n in ignore_names])
 
 
 def events_text(ev, names, tmp_path):

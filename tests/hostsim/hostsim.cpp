@@ -107,15 +107,19 @@ extern "C" void hostsim_free(void* p) { free(p); }
 // ---------------------------------------------------------------- fusion search
 struct FusCollect {
     std::vector<thj_fusion> v;
+    std::vector<uint32_t> ign;
+    bool ignored(uint32_t ref) const { for (uint32_t x : ign) if (x == ref) return true; return false; }
     void fusion(uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) { v.push_back({r1, r2, l, r, dir, 1u, ed, 0u}); }
 };
 
 extern "C" int hostsim_fusions(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len,
-                               int32_t n_contigs, const thj_seg_batch* b, thj_fusion** out, int64_t* n_out) {
+                               int32_t n_contigs, const thj_seg_batch* b, const uint32_t* ignore, int32_t n_ignore,
+                               thj_fusion** out, int64_t* n_out) {
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Params p;
     memcpy(&p, tp, sizeof p);
     FusCollect c;
+    c.ign.assign(ignore, ignore + n_ignore);
     for (int32_t r = 0; r < b->n_reads; ++r) {
         ReadView v;
         v.hits = (const Hit*)b->hits;

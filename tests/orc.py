@@ -193,7 +193,8 @@ FUSION_DTYPE = np.dtype([("ref_id1", "<u4"), ("ref_id2", "<u4"), ("left", "<u4")
                          ("count", "<u4"), ("edit_dist", "<u4"), ("skip", "<u4")])
 
 
-def fusions(p: Params, g: Genome, b: SegBatch, fusion_anchor_length: int = 20, fusion_min_dist: int = 10000000) -> np.ndarray:
+def fusions(p: Params, g: Genome, b: SegBatch, fusion_anchor_length: int = 20, fusion_min_dist: int = 10000000,
+            ignore_ref_ids=()) -> np.ndarray:
     lib = _lib()
     ob = OrcBatch()
     ob.n_reads, ob.nseg = b.n_reads, b.nseg
@@ -207,7 +208,9 @@ def fusions(p: Params, g: Genome, b: SegBatch, fusion_anchor_length: int = 20, f
     op = orc_params(p)
     out = C.c_void_p()
     n = C.c_int64()
-    rc = lib.orc_fusions_batch(C.byref(op), fusion_anchor_length, fusion_min_dist, C.byref(g.c), C.byref(ob), C.byref(out), C.byref(n))
+    ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
+    rc = lib.orc_fusions_batch(C.byref(op), fusion_anchor_length, fusion_min_dist, C.byref(g.c), C.byref(ob),
+                               C.c_void_p(ign.ctypes.data), len(ign), C.byref(out), C.byref(n))
     assert rc == 0
     if n.value == 0:
         return np.zeros(0, dtype=FUSION_DTYPE)

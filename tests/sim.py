@@ -92,7 +92,7 @@ def spanning(p: Params, seqs, b, juncs, insertions, mode: int = 0):
     return host.alns_from_array(a), list(st)
 
 
-def fusions(p: Params, seqs, b: SegBatch):
+def fusions(p: Params, seqs, b: SegBatch, ignore_ref_ids=()):
     """raw fusion events of the kernel logic, reduced like FusionSimpleSet (count, min edit_dist)"""
     import orc
     l = lib()
@@ -102,8 +102,10 @@ def fusions(p: Params, seqs, b: SegBatch):
     cp = p.as_ctypes()
     out = C.c_void_p()
     n = C.c_int64()
+    ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
     rc = l.hostsim_fusions(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
-                           C.c_void_p(clen.ctypes.data), g.n_contigs, C.byref(cb), C.byref(out), C.byref(n))
+                           C.c_void_p(clen.ctypes.data), g.n_contigs, C.byref(cb), C.c_void_p(ign.ctypes.data), len(ign),
+                           C.byref(out), C.byref(n))
     assert rc == 0
     a = np.zeros(0, dtype=orc.FUSION_DTYPE)
     if n.value:

@@ -23,8 +23,8 @@ def test_oracle_and_kernel_logic_reproduce_fixture(name, tmp_path):
         ev = e if ev is None else merge_events(ev, e)
         ev2 = e2 if ev2 is None else merge_events(ev2, e2)
         if c["fusion"]:
-            f = orc.fusions(p, g, b, p.fusion_anchor_length, p.fusion_min_dist)
-            f2 = sim.fusions(p, seqs, b)
+            f = orc.fusions(p, g, b, p.fusion_anchor_length, p.fusion_min_dist, c["fusion_ignore"])
+            f2 = sim.fusions(p, seqs, b, c["fusion_ignore"])
             fus = f if fus is None else orc.merge_fusions(fus, f)
             fus2 = f2 if fus2 is None else orc.merge_fusions(fus2, f2)
     exp = dict(c["exp"])

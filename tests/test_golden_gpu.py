@@ -27,7 +27,7 @@ def test_hip_path_reproduces_fixture(name, tmp_path):
         exp_fus = exp.pop("fusions", None)
         assert events_text(ev, c["names"], tmp_path) == exp
         if c["fusion"]:
-            fus = ctx.fusions(runs)
+            fus = ctx.fusions(runs, c["fusion_ignore"])
             assert fusions_text(fus, ev.juncs, c["names"], tmp_path) == exp_fus
         ctx.span_sets_from_segjuncs()
         for sd, sb in c["span_batches"].items():

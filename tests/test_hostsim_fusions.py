@@ -44,3 +44,21 @@ def test_fusion_logic_matches_oracle(cfg):
         assert got.tolist() == want.tolist()
         total += len(want)
     assert total > 30
+
+
+def test_fusion_ignore_chromosomes():
+    """--fusion-ignore-chromosomes (segment_juncs.cpp:3214-3231): no pair touching an ignored contig is examined"""
+    cfg = FUSION_CASES[1]
+    case, batches = fusion_batches(cfg)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    g = orc.Genome(seqs)
+    dropped = 0
+    for p, b in batches:
+        full = orc.fusions(p, g, b, p.fusion_anchor_length, p.fusion_min_dist)
+        want = orc.fusions(p, g, b, p.fusion_anchor_length, p.fusion_min_dist, ignore_ref_ids=[2])
+        assert all(int(x["ref_id1"]) != 2 and int(x["ref_id2"]) != 2 for x in want)
+        assert want.tolist() == [x for x in full.tolist() if x[0] != 2 and x[1] != 2]
+        got = sim.fusions(p, seqs, b, ignore_ref_ids=[2])
+        assert got.tolist() == want.tolist()
+        dropped += len(full) - len(want)
+    assert dropped > 5

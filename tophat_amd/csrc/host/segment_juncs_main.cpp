@@ -116,7 +116,6 @@ int main(int argc, char** argv) {
     for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
     if (pos.size() < 8 || (pos.size() > 8 && pos.size() < 11)) { print_usage(); return 1; }
     if (o.color) die("Error: colour-space reads are not supported by this build\n");
-    if (o.fusion_search && !o.fusion_ignore.empty()) die("Error: --fusion-ignore-chromosomes is not supported by this build yet\n");
     if (!o.no_coverage_search || !o.no_microexon_search || o.butterfly_search)
         die("Error: coverage / microexon / butterfly searches are not supported by this build yet; "
             "run with --no-coverage-search --no-microexon-search (what tophat passes for reads of >= 3 segments)\n");
@@ -143,6 +142,11 @@ int main(int argc, char** argv) {
     g_timer.lap("genome pack + upload");
     if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
     if (o.fusion_search && thj_fusion_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+    if (o.fusion_search && !o.fusion_ignore.empty()) {                 // segment_juncs.cpp:3214-3219
+        std::vector<uint32_t> ids;
+        for (auto& nm : split(o.fusion_ignore, ',')) if (!nm.empty()) ids.push_back(rt.get_id(nm));
+        if (thj_fusion_set_ignored(ctx, ids.data(), (int32_t)ids.size())) die("Error: %s\n", thj_last_error());
+    }
     size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
     uint32_t ordinal = 0;
     fprintf(stderr, ">> Performing segment-search:\n");

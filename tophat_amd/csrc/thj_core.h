@@ -649,6 +649,7 @@ THJ_HD void detect_fusion(const Genome& g, const Params& p, const u64* rp, int W
 
 template <class Sink>
 THJ_HD void fusion_pair(const Genome& g, const Params& p, const u64* rp, int W, int rl, Hit lh, Hit rh, Sink& sink) {
+    if (sink.ignored(lh.ref_id) || sink.ignored(rh.ref_id)) return;          // --fusion-ignore-chromosomes (:3214-3231)
     if (p.bowtie2 && hit_ed(lh) + hit_ed(rh) > (p.segment_mismatches << 1)) return;      // :3222-3226
     const int minus_dist = -p.max_insertion_length * 2;
     if (lh.ref_id == rh.ref_id && hit_anti(lh) == hit_anti(rh)) {

@@ -42,6 +42,7 @@ struct thj_ctx {
     unsigned long long* h_pinned = nullptr;     // [16] pinned staging
     void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     int64_t n_junc = 0, n_del = 0, n_ins = 0;
+    uint8_t* d_fus_ignore = nullptr; int64_t n_fus_ignore = 0;            // --fusion-ignore-chromosomes flags per ref id
     uint32_t* d_rescue_list = nullptr; int64_t rescue_list_cap = 0;      // reads taking the mate-anchored rescue + per-workgroup counts
     // long_spanning_reads (thj_span.hip)
     uint32_t* d_junc_bucket = nullptr; int64_t n_junc_buckets = 0;     // coarse index over d_span_junc (junc_range)

@@ -438,6 +438,8 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
 
 struct FusionSink {
     thj_fusion* buf; unsigned long long* count; unsigned long long cap; unsigned int* ovf;
+    const uint8_t* ignore; uint32_t n_ignore;             // per ref id: 1 = --fusion-ignore-chromosomes names it
+    __device__ __forceinline__ bool ignored(uint32_t ref) const { return ignore && ref < n_ignore && ignore[ref]; }
     __device__ __forceinline__ void fusion(uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) {
         unsigned long long pos = atomicAdd(count, 1ull);
         if (pos < cap) { thj_fusion f{r1, r2, l, r, dir, 1u, ed, 0u}; buf[pos] = f; }
@@ -566,7 +568,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     free_tables(c);
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
-    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list);
+    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_fus_ignore);
     hipHostFree(c->h_pinned);
     thj_span_free(c);
     hipFree(c->d_fus); hipFree(c->d_fus_count);
@@ -808,6 +810,22 @@ extern "C" int thj_fusion_reset_async(thj_ctx* c) {
     return THJ_OK;
 }
 
+extern "C" int thj_fusion_set_ignored(thj_ctx* c, const uint32_t* ref_ids, int32_t n) {
+    // --fusion-ignore-chromosomes: pairs with a hit on one of these contigs are skipped (segment_juncs.cpp:3214-3231)
+    if (!c || (n > 0 && !ref_ids) || n < 0) { thj_set_error("thj_fusion_set_ignored: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    hipFree(c->d_fus_ignore); c->d_fus_ignore = nullptr; c->n_fus_ignore = 0;
+    if (n == 0) return THJ_OK;
+    uint32_t mx = 0;
+    for (int32_t i = 0; i < n; ++i) if (ref_ids[i] > mx) mx = ref_ids[i];
+    std::vector<uint8_t> flags((size_t)mx + 1, 0);
+    for (int32_t i = 0; i < n; ++i) flags[ref_ids[i]] = 1;
+    HIPCHK(hipMalloc(&c->d_fus_ignore, flags.size()));
+    HIPCHK(hipMemcpy(c->d_fus_ignore, flags.data(), flags.size(), hipMemcpyHostToDevice));
+    c->n_fus_ignore = (int64_t)flags.size();
+    return THJ_OK;
+}
+
 extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db) {
     if (!c || !tp || !db) { thj_set_error("thj_fusion_run_async: null argument"); return THJ_EINVAL; }
     if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
@@ -820,7 +838,8 @@ extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevBatch b; memcpy(&b, db, sizeof b);
-    FusionSink sink{c->d_fus, c->d_fus_count, (unsigned long long)c->fus_cap, (unsigned int*)(c->d_fus_count + 1)};
+    FusionSink sink{c->d_fus, c->d_fus_count, (unsigned long long)c->fus_cap, (unsigned int*)(c->d_fus_count + 1),
+                    c->d_fus_ignore, (uint32_t)c->n_fus_ignore};
     int64_t blocks = ((int64_t)b.n_reads + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(thj_k_fusion, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b, sink);

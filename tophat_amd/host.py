@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "thj_segjuncs_finish", "thj_segjuncs_download", "thj_segjuncs_device_keys",
     "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
-    "thj_fusion_reset_async", "thj_fusion_run_async", "thj_fusion_finish", "thj_fusion_download",
+    "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_fusion_finish", "thj_fusion_download",
 ]
 
 _lib = None
@@ -263,9 +263,11 @@ class Context:
                "thj_segjuncs_device_keys")
         return (p.value or 0), n.value
 
-    def fusions(self, runs) -> np.ndarray:
+    def fusions(self, runs, ignore_ref_ids=()) -> np.ndarray:
         """reset; thj_fusion_run_async for every (params, batch); finish; download -> FUSION_DTYPE array"""
         _check(self.lib, self.lib.thj_fusion_reset_async(self._ctx), "thj_fusion_reset_async")
+        ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
+        _check(self.lib, self.lib.thj_fusion_set_ignored(self._ctx, _ptr(ign) if len(ign) else None, len(ign)), "thj_fusion_set_ignored")
         for p, b in runs:
             cp = p.as_ctypes()
             arg = C.byref(b) if isinstance(b, CSegBatch) else b
