@@ -52,3 +52,18 @@ def test_two_batches_keep_read_order():
         a = ctx.spanning(p, [h])
         b = ctx.spanning(p, [h])        # reset + rerun: identical
     assert a == want and b == want
+
+
+def test_many_joined_alignments_per_read_gpu():
+    """30 joined alignments per read (a 30-copy tandem repeat): multihit tier, overflow pool ordering"""
+    import numpy as np
+    from test_hostsim_spanning import repeat_span_batch
+    from tophat_amd.batch import JUNC_DTYPE
+    seq, sb = repeat_span_batch()
+    p = Params()
+    want = orc.spanning(p, orc.Genome([seq]), sb, np.zeros(0, dtype=JUNC_DTYPE), [])
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        ctx.upload_span_sets(np.zeros(0, dtype=JUNC_DTYPE), [])
+        got = ctx.spanning(p, [ctx.upload_span_batch(sb)])
+    assert len(want) == 30 * sb.n_reads and got == want

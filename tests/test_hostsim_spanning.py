@@ -51,3 +51,46 @@ def test_span_logic_matches_oracle(cfg):
         got.sort(key=lambda a: a.read_idx)
         assert got == want, "mode %d" % mode
     assert 0 < status[3]
+
+
+def repeat_span_batch(copies=30, n_reads=40, seed=5):
+    """Reads from a `copies`-fold tandem repeat: every segment has `copies` hits and the read has `copies` distinct
+    joined alignments (plus a few plain reads) -- the multihit tier with many results per read."""
+    import numpy as np
+    from tophat_amd.batch import SPAN_HIT_DTYPE, SpanBatch
+    rng = np.random.default_rng(seed)
+    unit = "".join(rng.choice(list("ACGT"), size=400))
+    flank = "".join(rng.choice(list("ACGT"), size=3000))
+    seq = flank + unit * copies + flank
+    L, nseg, rl = 25, 4, 100
+    hits, seg_off, bases, quals, read_off = [], [0], bytearray(), bytearray(), [0]
+    for r in range(n_reads):
+        off = int(rng.integers(0, 400 - rl))
+        for s in range(nseg):
+            for c in range(copies):
+                left = 3000 + c * 400 + off + s * L
+                flags = 2 if s == nseg - 1 else 0
+                hits.append((1, left, flags, 0, 0, 1, [(1 << 28) | (L if s < nseg - 1 else rl - s * L), 0, 0, 0, 0]))
+            seg_off.append(len(hits))
+        bases += unit[off:off + rl].encode()
+        quals += b"I" * rl
+        read_off.append(len(bases))
+    sb = SpanBatch(nseg, np.arange(1, n_reads + 1, dtype=np.uint32), np.array(read_off, dtype=np.int64),
+                   np.frombuffer(bytes(bases), dtype=np.uint8).copy(), np.frombuffer(bytes(quals), dtype=np.uint8).copy(),
+                   np.array(seg_off, dtype=np.uint32), np.array(hits, dtype=SPAN_HIT_DTYPE))
+    return seq, sb
+
+
+def test_many_joined_alignments_per_read():
+    import numpy as np
+    seq, sb = repeat_span_batch()
+    p = Params()
+    g = orc.Genome([seq])
+    from tophat_amd.batch import JUNC_DTYPE
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    want = orc.spanning(p, g, sb, nj, [])
+    assert len(want) == 30 * sb.n_reads
+    got, status = sim.spanning(p, [seq], sb, nj, [], 0)
+    assert status[1] == 0
+    got.sort(key=lambda a: a.read_idx)       # stable: the records of one read keep their emission order
+    assert got == want

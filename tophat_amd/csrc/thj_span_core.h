@@ -36,7 +36,7 @@ enum { SH_ANTI = 1, SH_END = 2, SH_ASPLICE = 4 };
 
 static constexpr int SPAN_MAXC = 16;      // cigar ops of a joined alignment
 static constexpr int SPAN_MAXSEG = 8;
-static constexpr int SPAN_MAXJOIN = 16;   // distinct joined alignments kept per read
+static constexpr int SPAN_MAXJOIN = 96;   // joined alignments kept per read before sort+unique (a read in a 40-copy repeat yields 40)
 
 struct Aln {                // working form of a (partially) joined BowtieHit
     uint32_t ref_id;
