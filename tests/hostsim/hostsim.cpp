@@ -70,12 +70,9 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
                 slots.assign((size_t)2 * n_left * v.n_mate, SLOT_NONE);
                 for (int l = 0; l < n_left; ++l)
                     for (int m = 0; m < v.n_mate; ++m) {
-                        rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m],
-                                    slots[2 * (l * v.n_mate + m)], slots[2 * (l * v.n_mate + m) + 1]);
-                        if (slots[2 * (l * v.n_mate + m)] != SLOT_BREAK &&
-                            !(v.hits[v.so[0] + l].ref_id != v.mate[m].ref_id ||
-                              hit_anti(v.hits[v.so[0] + l]) == hit_anti(v.mate[m])))
-                            ++nr;
+                        if (rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m],
+                                        slots[2 * (l * v.n_mate + m)], slots[2 * (l * v.n_mate + m) + 1])) ++nr;
+                        if (slots[2 * (l * v.n_mate + m)] == SLOT_BREAK) break;       // the reference leaves the mate loop here
                     }
                 v.slots = lazy ? nullptr : slots.data();     // lazy: the kernel's fallback when its LDS slot buffer is full
                 v.lazy_g = &g; v.lazy_p = &p;

@@ -293,20 +293,20 @@ enum { SLOT_NONE = -1, SLOT_BREAK = -2 };
 // One (left hit, mate hit) pair of the mate-anchored rescue (segment_juncs.cpp:3406-3492).
 // Writes the two pseudo-hit lefts (fwd, rev) or SLOT_NONE; fwd = SLOT_BREAK when the
 // reference `break`s out of the mate loop at this pair.  rp = the read's planes.
-THJ_HD void rescue_pair(const Genome& g, const Params& p, const u64* rp, int W, int rl, const Hit& lh, const Hit& rh,
+THJ_HD bool rescue_pair(const Genome& g, const Params& p, const u64* rp, int W, int rl, const Hit& lh, const Hit& rh,
                         int32_t& fwd_left, int32_t& rev_left) {
     fwd_left = SLOT_NONE;
     rev_left = SLOT_NONE;
-    if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) return;      // :3414
+    if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) return false;      // :3414
     int32_t clen = g_len(g, rh.ref_id);
-    if (clen == 0) return;
+    if (clen == 0) return false;
     int part = p.inner_dist_std_dev > p.inner_dist_mean ? p.inner_dist_std_dev - p.inner_dist_mean : 0;
     int flank = p.inner_dist_mean + p.inner_dist_std_dev;
     int64_t left;
     if (hit_anti(rh)) {
-        if (flank <= rh.left) left = rh.left - flank; else { fwd_left = SLOT_BREAK; return; }
+        if (flank <= rh.left) left = rh.left - flank; else { fwd_left = SLOT_BREAK; return false; }
     } else {
-        if (part <= rh.right) left = rh.right - part; else { fwd_left = SLOT_BREAK; return; }
+        if (part <= rh.right) left = rh.right - part; else { fwd_left = SLOT_BREAK; return false; }
     }
     int64_t fe = left + flank + part;
     if (fe > clen) fe = clen;
@@ -314,13 +314,14 @@ THJ_HD void rescue_pair(const Genome& g, const Params& p, const u64* rp, int W, 
     if (flen < 0) flen = 0;
     int cl = p.segment_length - p.segment_mismatches - 3;
     if (cl > 15) cl = 15;                                                      // :3451
-    if (cl < 1 || cl > rl) return;
+    if (cl < 1 || cl > rl) return false;
     Planes fwd = r_fetch(rp, W, rl - cl, cl);     // last cl bases of the read
     Planes rev = rc_piece(fwd, cl);               // first cl bases of its reverse complement
     int fp = flank_scan(g, rh.ref_id, left, flen, fwd, cl);
     if (fp >= 0) fwd_left = (int32_t)(left + fp);
     int rvp = flank_scan(g, rh.ref_id, left, flen, rev, cl);
     if (rvp >= 0) rev_left = (int32_t)(left + rvp);
+    return true;                                  // the pair was scanned (what the rescue-pair statistic counts)
 }
 
 // ---- per-read view of hits_for_read -------------------------------------------

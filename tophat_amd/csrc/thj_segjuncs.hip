@@ -395,11 +395,10 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                     unsigned int local = 0;
                     for (int l = 0; l < n_left; ++l)
                         for (int m = 0; m < v.n_mate; ++m) {
-                            const Hit lh = v.hits[v.so[0] + l], rh = v.mate[m];
                             int32_t f, rv;
-                            rescue_pair(g, p, v.rp, v.W, v.rl, lh, rh, f, rv);
+                            if (rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m], f, rv)) ++local;
                             if (fits) { mine[2 * (l * v.n_mate + m)] = f; mine[2 * (l * v.n_mate + m) + 1] = rv; }
-                            if (f != SLOT_BREAK && lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) ++local;
+                            if (f == SLOT_BREAK) break;                  // the reference leaves the mate loop here (:3431-3450)
                         }
                     if (local) atomicAdd(&s_stat[2], local);
                     v.rescue = true;

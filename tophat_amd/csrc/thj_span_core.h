@@ -913,9 +913,10 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     if (nsegs == 1) qrev = res.anti;
     else qrev = res.anti ? !read_is_own_revcomp(rp, W, rl) : false;
     Extras e;
-    if (!sam_extra(g, p, res, sv, qual, rl, qrev, e)) return SPAN_MD_OVERFLOW;
+    const bool md_fits = sam_extra(g, p, res, sv, qual, rl, qrev, e);
     // check_editdist_consistency (done inside merge_chain in the reference) shares sam_extra's counts
     if (nsegs > 1 && !(e.XM == res.mm || e.XM + e.both_n == res.mm)) return SPAN_OK;
+    if (!md_fits) return SPAN_MD_OVERFLOW;          // only for a hit that would really be reported
     emit_aln(sink, read_idx, 0, res, e);
     return SPAN_OK;
 }
@@ -1029,8 +1030,8 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
         pos_mm += l - last;
     }
     md_put_int(md, pos_mm);
-    if (md.len > 40) return SPAN_MD_OVERFLOW;
     if (nsegs > 1 && !(mismatch == mm8 || mismatch + both_n == mm8)) return SPAN_OK;   // check_editdist_consistency
+    if (md.len > 40) return SPAN_MD_OVERFLOW;        // only for a hit that would really be reported
     uint32_t wds[32];
     wds[0] = read_idx; wds[1] = h0.ref_id; wds[2] = (uint32_t)left;
     wds[3] = (anti ? 1u : 0u) | ((uint32_t)mm8 << 8) | ((uint32_t)mm8 << 16) | (1u << 24);
