@@ -360,11 +360,20 @@ def main():
                        "overflow_blocks": cnt.n_overflow_blocks, "spanning_records_per_step": n_alns},
             "gen_seconds": t_gen,
         }
-        print(json.dumps(result))
     ctx.close()
     if use_dist:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
+    # The JSON line must be the last thing on stdout: RCCL writes a version banner through C stdio, which sits in libc's
+    # buffer until exit when stdout is a pipe.  Flush that first, print, flush, and leave without running exit handlers
+    # that could print again.
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    sys.stderr.flush()
+    os._exit(0)
 
 
 if __name__ == "__main__":

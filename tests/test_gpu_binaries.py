@@ -32,9 +32,15 @@ def _inputs(d, tmp_path, as_bam):
     return r, paired
 
 
-@pytest.mark.parametrize("as_bam", [False, True], ids=["sam", "bam"])
+@pytest.mark.parametrize("as_bam,batch_reads,threads", [(False, None, None), (True, None, None), (True, "37", "3"), (False, "1", "1")],
+                         ids=["sam", "bam", "bam_batches_of_37", "sam_batches_of_1_single_thread"])
 @pytest.mark.parametrize("name", CASES)
-def test_dropin_binaries_reproduce_fixture(name, as_bam, tmp_path):
+def test_dropin_binaries_reproduce_fixture(name, as_bam, batch_reads, threads, tmp_path):
+    env = dict(os.environ)
+    if batch_reads:
+        env["THJ_BATCH_READS"] = batch_reads          # many batches: ordinals, writer hand-over, `.index` continuity
+    if threads:
+        env["THJ_HOST_THREADS"] = threads
     assert os.path.exists(os.path.join(BIN, "segment_juncs")), "run __graft_entry__.build() first"
     d = os.path.join(GOLD, name)
     opts = open(os.path.join(d, "options.txt")).read().split("\n")
@@ -48,7 +54,7 @@ def test_dropin_binaries_reproduce_fixture(name, as_bam, tmp_path):
            os.path.join(d, "left.fq"), inp["left_map"], ",".join(inp["left_segs"])]
     if paired:
         cmd += [os.path.join(d, "right.fq"), inp["right_map"], ",".join(inp["right_segs"])]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     for k in ("juncs", "insertions", "deletions"):
         assert open(out[k]).read() == open(os.path.join(d, "expected." + k)).read(), k
@@ -70,7 +76,7 @@ def test_dropin_binaries_reproduce_fixture(name, as_bam, tmp_path):
                     conv.append(o_)
                 sp = conv
             cmd.append(",".join(sp))
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         _, recs = read_bam(bam)
         want = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
@@ -88,3 +94,31 @@ def test_unsupported_modes_fail_loudly(tmp_path):
     assert r.returncode == 1 and "not supported" in r.stderr      # coverage search is on by default for a bare binary run
     r = subprocess.run([os.path.join(BIN, "segment_juncs"), "--no-such-option"], capture_output=True, text=True)
     assert r.returncode == 1
+
+
+def test_long_spanning_reads_parts(tmp_path):
+    """-p N: <base>{0..N-1}.bam, each with its `.index` (long_spanning_reads.cpp:3056-3064); cut at read boundaries,
+    concatenation == the single-file output"""
+    name = "se100"
+    d = os.path.join(GOLD, name)
+    seglen = dict(x.split("=") for x in open(os.path.join(d, "options.txt")).read().split("\n")[1].split())["segment_length"]
+    inp, _ = _inputs(d, tmp_path, False)
+    out = str(tmp_path / "span.bam")
+    cmd = [os.path.join(BIN, "long_spanning_reads"), "-p", "3", "--segment-length", seglen, "--sam-header", os.path.join(d, "hdr.sam"),
+           os.path.join(d, "ref.fa"), os.path.join(d, "left.fq"), os.path.join(d, "expected.juncs"), os.path.join(d, "expected.insertions"),
+           os.path.join(d, "expected.deletions"), "/dev/null", out, ",".join(inp["left_segs"])]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got, names_seen = [], []
+    for k in range(3):
+        part = str(tmp_path / ("span%d.bam" % k))
+        assert os.path.exists(part) and os.path.exists(part + ".index")
+        _, recs = read_bam(part)
+        recs = [tuple(str(x) for x in rec) for rec in recs]
+        assert recs, "empty part"
+        if names_seen:
+            assert recs[0][0] != names_seen[-1]          # a read never straddles two parts
+        names_seen.append(recs[-1][0])
+        got += recs
+    want = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_left.sam"))]
+    assert got == want
