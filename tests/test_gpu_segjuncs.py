@@ -185,3 +185,31 @@ def test_rescue_slot_overflow(lib):
     assert got.stats["rescue_pairs"] == want.stats["rescue_pairs"]
     assert got.stats["windows"] == want.stats["windows"]
     assert_events_equal(got, want)
+
+
+def test_event_tables_grow(lib):
+    """Tables configured far too small for the run grow between batches (rehash into 4x tables); same events."""
+    from tophat_amd.synth import make_case
+    from util import case_batches
+    case = make_case(seed=21, paired=False, read_len=100, seg_len=25, n_reads=1200, contig_lens=(400000,), genes_per_contig=120,
+                     indel_frac=0.3, boundary_bias=0.5)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    g = orc.Genome(seqs)
+    (side, b), = case_batches(case, False)
+    p = Params(read_side=side)
+    want = orc.segjuncs(p, g, b)
+    assert len(want.juncs) > 150 and len(want.deletions) + len(want.insertions) > 40
+    # the same reads as 24 consecutive batches of 50
+    from tophat_amd.batch import SegBatch
+    parts = []
+    for r0 in range(0, b.n_reads, 50):
+        r1 = min(b.n_reads, r0 + 50)
+        so = b.seg_off[r0 * b.nseg:r1 * b.nseg + 1]
+        ro = b.read_off[r0:r1 + 1]
+        parts.append((r0, SegBatch(b.nseg, b.read_id[r0:r1], ro - ro[0], b.bases[ro[0]:ro[-1]], (so - so[0]).astype(np.uint32),
+                                   b.hits[so[0]:so[-1]])))
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        ctx.configure(64, 16)
+        got = ctx.segjuncs([(p, ctx.upload_batch(sb, ordinal_base=r0)) for r0, sb in parts])
+    assert_events_equal(got, want)

@@ -42,6 +42,7 @@ struct thj_ctx {
     unsigned long long* h_pinned = nullptr;     // [16] pinned staging
     void* d_sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     int64_t n_junc = 0, n_del = 0, n_ins = 0;
+    hipEvent_t probe_ev = nullptr; bool probe_pending = false;            // insert counters on their way to h_pinned[32..]
     uint8_t* d_fus_ignore = nullptr; int64_t n_fus_ignore = 0;            // --fusion-ignore-chromosomes flags per ref id
     uint32_t* d_rescue_list = nullptr; int64_t rescue_list_cap = 0;      // reads taking the mate-anchored rescue + per-workgroup counts
     // long_spanning_reads (thj_span.hip)

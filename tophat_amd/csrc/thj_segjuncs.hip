@@ -58,11 +58,7 @@ __device__ __forceinline__ void set_insert(u64* tab, u64 mask, u64 key, unsigned
         if (cur == key) return;
         if (cur == EMPTY) {
             u64 old = atomicCAS((unsigned long long*)&tab[h], EMPTY, key);
-            if (old == EMPTY) {
-                unsigned long long c = atomicAdd(count, 1ull);
-                if (c + 1 > (mask + 1) - ((mask + 1) >> 2)) atomicExch(ovf, 1u);   // > 75 % full
-                return;
-            }
+            if (old == EMPTY) { atomicAdd(count, 1ull); return; }     // fire-and-forget: the load factor is checked by the host
             if (old == key) return;
         }
         h = (h + 1) & mask;
@@ -77,11 +73,8 @@ __device__ __forceinline__ void map_insert_min(u64* keys, u64* vals, u64 mask, u
         u64 cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == EMPTY) {
             u64 old = atomicCAS((unsigned long long*)&keys[h], EMPTY, key);
-            if (old == EMPTY) {
-                unsigned long long c = atomicAdd(count, 1ull);
-                if (c + 1 > (mask + 1) - ((mask + 1) >> 2)) atomicExch(ovf, 1u);
-                cur = key;
-            } else cur = old;
+            if (old == EMPTY) { atomicAdd(count, 1ull); cur = key; }
+            else cur = old;
         }
         if (cur == key) { atomicMin((unsigned long long*)&vals[h], val); return; }
         h = (h + 1) & mask;
@@ -468,6 +461,21 @@ __global__ __launch_bounds__(256) void thj_k_compact(const u64* tab, const u64* 
     }
 }
 
+// table growth: every occupied slot of the old table goes into the new one
+__global__ __launch_bounds__(256) void thj_k_rehash_keys(const u64* old_tab, u64 old_cap, u64* tab, u64 mask, unsigned long long* count, unsigned int* ovf) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = old_tab[i];
+        if (k != EMPTY) set_insert(tab, mask, k, count, ovf);
+    }
+}
+__global__ __launch_bounds__(256) void thj_k_rehash_ins(const u64* old_keys, const u64* old_vals, u64 old_cap, u64* keys, u64* vals, u64 mask,
+                                                        unsigned long long* count, unsigned int* ovf) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
+        const u64 k = old_keys[i];
+        if (k != EMPTY) map_insert_min(keys, vals, mask, k, old_vals[i], count, ovf);
+    }
+}
+
 __global__ __launch_bounds__(256) void thj_k_merge_keys(u64* tab, u64 mask, const u64* keys, int64_t n,
                                                         unsigned long long* count, unsigned int* ovf) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -535,6 +543,7 @@ static int reset_tables_async(thj_ctx* c) {
     HIPCHK(hipMemsetAsync(c->d_ovf, 0, 4 * sizeof(unsigned int), c->stream));
     HIPCHK(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(unsigned long long), c->stream));
     c->n_junc = c->n_del = c->n_ins = 0;
+    c->probe_pending = false;                 // counters of the previous pass say nothing about the emptied tables
     return THJ_OK;
 }
 
@@ -551,7 +560,7 @@ extern "C" int thj_ctx_create(int device, void* stream, thj_ctx** out) {
     HIPCHK(hipMalloc(&c->d_ovf, 4 * sizeof(unsigned int)));
     HIPCHK(hipMalloc(&c->d_cnt, CNT_N * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_out_n, 4 * sizeof(unsigned long long)));
-    HIPCHK(hipHostMalloc(&c->h_pinned, 32 * sizeof(unsigned long long)));
+    HIPCHK(hipHostMalloc(&c->h_pinned, 48 * sizeof(unsigned long long)));
     int rc = alloc_tables(c, 1ll << 24, 1ll << 20);
     if (rc) { delete c; return rc; }
     rc = reset_tables_async(c);
@@ -568,6 +577,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
     hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_fus_ignore);
+    if (c->probe_ev) hipEventDestroy(c->probe_ev);
     hipHostFree(c->h_pinned);
     thj_span_free(c);
     hipFree(c->d_fus); hipFree(c->d_fus_count);
@@ -672,6 +682,42 @@ extern "C" int thj_batch_free(thj_ctx* c, thj_seg_batch* dev) {
 
 // ------------------------------------------------------------------ run
 
+// The event tables grow by themselves: after every run the insert counters are copied to pinned memory (no
+// synchronisation); the next run looks at them and, past 40 % load, rehashes into tables four times the size.
+// thj_segjuncs_finish still refuses a table that ended up more than 75 % full (one batch adding > 35 % of a table).
+static int grow_tables(thj_ctx* c, bool grow_junc, bool grow_indel) {
+    HIPCHK(hipStreamSynchronize(c->stream));
+    u64* oj = c->d_junc; u64* od = c->d_del; u64* oik = c->d_ins_key; u64* oiv = c->d_ins_val;
+    const int64_t ojc = c->junc_cap, oic = c->indel_cap;
+    c->d_junc = c->d_del = c->d_ins_key = c->d_ins_val = nullptr;          // alloc_tables frees what the context still holds
+    int rc = alloc_tables(c, grow_junc ? ojc * 4 : ojc, grow_indel ? oic * 4 : oic);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(c->d_junc, 0xFF, (size_t)c->junc_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_del, 0xFF, (size_t)c->indel_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ins_key, 0xFF, (size_t)c->indel_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ins_val, 0xFF, (size_t)c->indel_cap * 8, c->stream));
+    HIPCHK(hipMemsetAsync(&c->d_cnt[CNT_JUNC], 0, 3 * sizeof(unsigned long long), c->stream));      // JUNC, DEL, INS: recounted by the rehash
+    auto blocks_for = [](int64_t cap) { int64_t b = (cap + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b); };
+    hipLaunchKernelGGL(thj_k_rehash_keys, dim3(blocks_for(ojc)), dim3(256), 0, c->stream, (const u64*)oj, (u64)ojc, c->d_junc,
+                       (u64)c->junc_cap - 1, &c->d_cnt[CNT_JUNC], &c->d_ovf[0]);
+    hipLaunchKernelGGL(thj_k_rehash_keys, dim3(blocks_for(oic)), dim3(256), 0, c->stream, (const u64*)od, (u64)oic, c->d_del,
+                       (u64)c->indel_cap - 1, &c->d_cnt[CNT_DEL], &c->d_ovf[1]);
+    hipLaunchKernelGGL(thj_k_rehash_ins, dim3(blocks_for(oic)), dim3(256), 0, c->stream, (const u64*)oik, (const u64*)oiv, (u64)oic,
+                       c->d_ins_key, c->d_ins_val, (u64)c->indel_cap - 1, &c->d_cnt[CNT_INS], &c->d_ovf[2]);
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(oj); hipFree(od); hipFree(oik); hipFree(oiv);
+    return THJ_OK;
+}
+
+static int maybe_grow_tables(thj_ctx* c) {
+    if (!c->probe_pending || hipEventQuery(c->probe_ev) != hipSuccess) return THJ_OK;
+    c->probe_pending = false;
+    const unsigned long long* n = &c->h_pinned[32];
+    const bool gj = n[CNT_JUNC] * 5 > (unsigned long long)c->junc_cap * 2;
+    const bool gi = (n[CNT_DEL] > n[CNT_INS] ? n[CNT_DEL] : n[CNT_INS]) * 5 > (unsigned long long)c->indel_cap * 2;
+    return (gj || gi) ? grow_tables(c, gj, gi) : THJ_OK;
+}
+
 extern "C" int thj_segjuncs_configure(thj_ctx* c, int64_t junc_capacity, int64_t indel_capacity) {
     if (!c || junc_capacity < 1 || indel_capacity < 1) { thj_set_error("thj_segjuncs_configure: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
@@ -716,6 +762,7 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
     if (db->n_reads == 0) return THJ_OK;
+    if ((rc = maybe_grow_tables(c))) return rc;
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p;
     memcpy(&p, tp, sizeof p);
@@ -754,6 +801,13 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     }
     if (c->profile) { HIPCHK(hipEventRecord(e2, c->stream)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(e1, e2); }
     HIPCHK(hipGetLastError());
+    // insert counters for the next run's growth decision (asynchronous)
+    if (!c->probe_ev) HIPCHK(hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming));
+    if (!c->probe_pending) {
+        HIPCHK(hipMemcpyAsync(&c->h_pinned[32], c->d_cnt, CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->probe_ev, c->stream));
+        c->probe_pending = true;
+    }
     return THJ_OK;
 }
 
@@ -931,6 +985,12 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
     c->n_junc = (int64_t)c->h_pinned[0];
     c->n_del = (int64_t)c->h_pinned[1];
     c->n_ins = (int64_t)c->h_pinned[2];
+    if (c->n_junc > c->junc_cap - c->junc_cap / 4 || c->n_del > c->indel_cap - c->indel_cap / 4 || c->n_ins > c->indel_cap - c->indel_cap / 4) {
+        thj_set_error("event table more than 75 %% full after one batch (junc=%lld/%lld del=%lld ins=%lld/%lld): use smaller batches or "
+                      "thj_segjuncs_configure with larger capacities", (long long)c->n_junc, (long long)c->junc_cap, (long long)c->n_del,
+                      (long long)c->n_ins, (long long)c->indel_cap);
+        return THJ_EOVERFLOW;
+    }
     // sorted output (stream-ordered: consumers on the context stream need no further synchronisation)
     size_t tmp = c->sort_tmp_bytes;
     if (c->n_junc > 0)
