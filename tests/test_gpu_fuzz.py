@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 def test_fuzz_segment_juncs_gpu(seed):
     rng = np.random.default_rng(9000 + seed)
     seqs = rand_genome(rng, int(rng.integers(1, 4)))
-    L = int(rng.choice([20, 25, 25, 32]))
-    nseg = int(rng.choice([2, 3, 4, 6]))
+    L = int(rng.choice([20, 25, 25, 32, 33, 47, 50, 64]))
+    nseg = int(rng.choice([2, 3, 4, 6])) if L <= 32 else int(rng.choice([2, 3]))
     paired = bool(seed % 2)
     b = rand_seg_batch(rng, seqs, 900, L, nseg, paired)
     p = Params(segment_length=L, read_side=1 + seed % 2, library_type=int(rng.choice([0, 0, 1, 2, 3])),

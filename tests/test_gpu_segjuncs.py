@@ -136,7 +136,7 @@ def test_missing_genome_fails_loudly(lib):
             ctx.run(Params(), h)          # no genome resident -> error, never a fallback
         with pytest.raises(host.ThjError):
             ctx.upload_genome(host.pack_genome(["ACGT" * 100]))
-            ctx.run(Params(segment_length=64), h)   # unsupported parameter -> error
+            ctx.run(Params(segment_length=65), h)   # unsupported parameter -> error
 
 
 def rescue_heavy_batch(n_reads=300, seed=11):

@@ -41,4 +41,8 @@ CASES = [
          gen=dict(err=0.03, n_frac=0.2)),
     dict(seed=8, paired=True, read_len=50, seg_len=25, extra=dict(inner_dist_mean=50, inner_dist_std_dev=20)),
     dict(seed=9, paired=False, read_len=100, seg_len=32, extra={}, gen=dict(n_frac=0.3, err=0.02)),
+    # segment_length > 32: 2L read pieces / L+16 support reads on 128-bit plane words
+    dict(seed=10, paired=False, read_len=150, seg_len=50, extra={}, gen=dict(indel_frac=0.3)),
+    dict(seed=11, paired=True, read_len=200, seg_len=64, extra=dict(inner_dist_mean=50, inner_dist_std_dev=20), gen=dict(indel_frac=0.3, n_frac=0.1)),
+    dict(seed=12, paired=False, read_len=160, seg_len=40, extra={}, gen=dict(indel_frac=0.3, err=0.02)),
 ]

@@ -122,17 +122,54 @@ THJ_HD Planes rc_piece(Planes a, int len) {
     return r;
 }
 
+// ---- 128-base variants --------------------------------------------------------------------------------------
+// With segment_length > 32 a 2L read piece (indel search) or an L+16 support read (window scan) no longer fits one
+// 64-bit plane word; the same algorithms then run on 128-bit words (two registers per plane, the compiler splits
+// them).  `WT` below is u64 or u128.
+typedef unsigned __int128 u128;
+THJ_HD int popc(u128 x) { return popc((u64)x) + popc((u64)(x >> 64)); }
+THJ_HD int ctz(u128 x) { return (u64)x ? ctz((u64)x) : 64 + ctz((u64)(x >> 64)); }            // x != 0
+THJ_HD int clz(u128 x) { return (u64)(x >> 64) ? clz((u64)(x >> 64)) : 64 + clz((u64)x); }    // x != 0
+template <class WT> THJ_HD WT lowmask_t(int n) { return n >= (int)(8 * sizeof(WT)) ? ~(WT)0 : (((WT)1 << n) - (WT)1); }
+
+template <class WT> struct PlanesT { WT lo, hi, nm; };
+template <class WT> struct Fetch;
+template <> struct Fetch<u64> {
+    static THJ_HD PlanesT<u64> genome(const Genome& g, uint32_t ref_id, int64_t pos) { Planes a = g_fetch(g, ref_id, pos); return {a.lo, a.hi, a.nm}; }
+    static THJ_HD PlanesT<u64> read(const u64* rp, int W, int start, int len) { Planes a = r_fetch(rp, W, start, len); return {a.lo, a.hi, a.nm}; }
+    static THJ_HD PlanesT<u64> rc(PlanesT<u64> a, int len) { Planes r = rc_piece(Planes{a.lo, a.hi, a.nm}, len); return {r.lo, r.hi, r.nm}; }
+};
+template <> struct Fetch<u128> {
+    static THJ_HD PlanesT<u128> genome(const Genome& g, uint32_t ref_id, int64_t pos) {
+        Planes a = g_fetch(g, ref_id, pos), b = g_fetch(g, ref_id, pos + 64);
+        return {(u128)a.lo | ((u128)b.lo << 64), (u128)a.hi | ((u128)b.hi << 64), (u128)a.nm | ((u128)b.nm << 64)};
+    }
+    static THJ_HD PlanesT<u128> read(const u64* rp, int W, int start, int len) {      // len 1..128
+        Planes a = r_fetch(rp, W, start, len < 64 ? len : 64);
+        Planes b{0, 0, 0};
+        if (len > 64) b = r_fetch(rp, W, start + 64, len - 64);
+        return {(u128)a.lo | ((u128)b.lo << 64), (u128)a.hi | ((u128)b.hi << 64), (u128)a.nm | ((u128)b.nm << 64)};
+    }
+    static THJ_HD PlanesT<u128> rc(PlanesT<u128> a, int len) {
+        const u128 m = lowmask_t<u128>(len);
+        const u128 l = ~a.lo & ~a.nm & m, h = ~a.hi & ~a.nm & m, n = a.nm & m;
+        auto rev = [](u128 x) { return ((u128)brev64((u64)x) << 64) | (u128)brev64((u64)(x >> 64)); };
+        return {rev(l) >> (128 - len), rev(h) >> (128 - len), rev(n) >> (128 - len)};
+    }
+};
+
 // ---- juncs_from_ref_segs<RecordSegmentJuncs>, POINT_DIR_BOTH ----------------
 // One RefSeg window, all three motif pairs fused (segment_juncs.cpp:2052-2377 x
 // :3618-3649).  Only the two window ends are touched.  Sink: junction(ref,left,right,anti).
-template <class Sink>
+template <class WT, class Sink>
 THJ_HD void window_scan(const Genome& g, const Params& p, uint32_t ref_id, int32_t seg_left, int32_t seg_right,
-                        bool antisense, Planes sup, int read_len, Sink& sink) {
+                        bool antisense, PlanesT<WT> sup, int read_len, Sink& sink) {
+    constexpr int BITS = (int)(8 * sizeof(WT));
     int32_t clen = g_len(g, ref_id);
     if (clen == 0) return;                                        // :2105-2108
     if (seg_left < 0 || seg_right >= clen - 1) return;            // :2154
     int seg_len = seg_right - seg_left;
-    if (read_len < 2 || read_len > 62 || seg_len < read_len) return;
+    if (read_len < 2 || read_len > BITS - 2 || seg_len < read_len) return;
     if ((int64_t)seg_left + seg_len - read_len - 2 < 0) return;   // unreachable: find_gaps windows span >= min intron
 
     bool skip_fwd = false, skip_rev = false;                      // :2110-2138
@@ -145,49 +182,49 @@ THJ_HD void window_scan(const Genome& g, const Params& p, uint32_t ref_id, int32
         else if (p.read_side == 2) { if (antisense) skip_rev = true; else skip_fwd = true; }
     }
 
-    Planes gl = g_fetch(g, ref_id, seg_left);                                  // window start (N -> A: mask ignored)
-    Planes gr = g_fetch(g, ref_id, (int64_t)seg_left + seg_len - read_len - 2); // window end, 2 bases early
+    const PlanesT<WT> gl = Fetch<WT>::genome(g, ref_id, seg_left);                                  // window start (N -> A: mask ignored)
+    const PlanesT<WT> gr = Fetch<WT>::genome(g, ref_id, (int64_t)seg_left + seg_len - read_len - 2); // window end, 2 bases early
 
-    u64 M = lowmask(read_len);
+    const WT M = lowmask_t<WT>(read_len);
     // left_mismatches[]: loop runs i in [0, read_len-1) and stops at the third mismatch (:2187-2203)
-    u64 mL = ((gl.lo ^ sup.lo) | (gl.hi ^ sup.hi) | sup.nm) & lowmask(read_len - 1);
+    const WT mL = ((gl.lo ^ sup.lo) | (gl.hi ^ sup.hi) | sup.nm) & lowmask_t<WT>(read_len - 1);
     int to = read_len - 2;
     {
-        u64 t = mL;
+        WT t = mL;
         t &= t - 1;
         t &= t - 1;
         if (t) to = ctz(t);
     }
     // right_mismatches[]: from the top down, stops at the third mismatch and leaves
     // the entries below it at 0 (:2205-2218)
-    u64 mR = (((gr.lo >> 2) ^ sup.lo) | ((gr.hi >> 2) ^ sup.hi) | sup.nm) & M;
+    const WT mR = (((gr.lo >> 2) ^ sup.lo) | ((gr.hi >> 2) ^ sup.hi) | sup.nm) & M;
     int t3 = -1;
     {
-        u64 u = mR;
-        if (u) u &= ~(1ull << (63 - clz(u)));
-        if (u) u &= ~(1ull << (63 - clz(u)));
-        if (u) t3 = 63 - clz(u);
+        WT u = mR;
+        if (u) u &= ~((WT)1 << (BITS - 1 - clz(u)));
+        if (u) u &= ~((WT)1 << (BITS - 1 - clz(u)));
+        if (u) t3 = BITS - 1 - clz(u);
     }
 
     // dinucleotide masks: bit i set <=> bases (i, i+1) spell the dinucleotide
-    u64 lA = ~gl.lo & ~gl.hi, lC = gl.lo & ~gl.hi, lG = ~gl.lo & gl.hi, lT = gl.lo & gl.hi;
-    u64 rA = ~gr.lo & ~gr.hi, rC = gr.lo & ~gr.hi, rG = ~gr.lo & gr.hi, rT = gr.lo & gr.hi;
-    u64 l_GT = lG & (lT >> 1), l_GC = lG & (lC >> 1), l_AT = lA & (lT >> 1), l_CT = lC & (lT >> 1);
-    u64 r_AG = rA & (rG >> 1), r_AC = rA & (rC >> 1), r_GC = rG & (rC >> 1), r_AT = rA & (rT >> 1);
+    const WT lA = ~gl.lo & ~gl.hi, lC = gl.lo & ~gl.hi, lG = ~gl.lo & gl.hi, lT = gl.lo & gl.hi;
+    const WT rA = ~gr.lo & ~gr.hi, rC = gr.lo & ~gr.hi, rG = ~gr.lo & gr.hi, rT = gr.lo & gr.hi;
+    const WT l_GT = lG & (lT >> 1), l_GC = lG & (lC >> 1), l_AT = lA & (lT >> 1), l_CT = lC & (lT >> 1);
+    const WT r_AG = rA & (rG >> 1), r_AC = rA & (rC >> 1), r_GC = rG & (rC >> 1), r_AT = rA & (rT >> 1);
     // partner sits at window offset pos = seg_len-(read_len-i)-2, i.e. index i of `gr`
-    u64 fwd = (l_GT & r_AG) | (l_GC & r_AG) | (l_AT & r_AC);     // donor..acceptor
-    u64 rev = (l_CT & r_AC) | (l_CT & r_GC) | (l_GT & r_AT);     // rc(acceptor)..rc(donor)
+    WT fwd = (l_GT & r_AG) | (l_GC & r_AG) | (l_AT & r_AC);     // donor..acceptor
+    WT rev = (l_CT & r_AC) | (l_CT & r_GC) | (l_GT & r_AT);     // rc(acceptor)..rc(donor)
     if (skip_fwd) fwd = 0;
     if (skip_rev) rev = 0;
-    u64 range = lowmask(to + 1);
-    u64 cand = (fwd | rev) & range;
+    const WT range = lowmask_t<WT>(to + 1);
+    WT cand = (fwd | rev) & range;
     while (cand) {
         int i = ctz(cand);
         cand &= cand - 1;
-        int lm = popc(mL & lowmask(i));                           // left_mismatches[i-1]
+        int lm = popc(mL & lowmask_t<WT>(i));                           // left_mismatches[i-1]
         int rm = i > t3 ? popc(mR >> i) : (i == t3 ? 3 : 0);      // right_mismatches[i]
         if (lm + rm <= 2) {
-            bool is_fwd = ((fwd >> i) & 1ull) != 0;
+            bool is_fwd = ((fwd >> i) & (WT)1) != 0;
             // RecordSegmentJuncs::record :1681-1695
             sink.junction(ref_id, (uint32_t)(seg_left + i - 1), (uint32_t)(seg_left + seg_len - read_len + i),
                           !is_fwd);
@@ -198,13 +235,14 @@ THJ_HD void window_scan(const Genome& g, const Params& p, uint32_t ref_id, int32
 // ---- simpleSplitAlignment (segment_juncs.cpp:2390-2456) ----------------------
 // mL/mR: mismatch masks of the shorter sequence against the left-/right-anchored
 // reference.  Returns the first best insert position, -1 if len < 2.
-THJ_HD int split_bits(u64 mL, u64 mR, int len, int& min_err) {
+template <class WT>
+THJ_HD int split_bits(WT mL, WT mR, int len, int& min_err) {
     int best = len + 1, bp = -1;
     if (len >= 2) {
-        int e = popc((mR & lowmask(len)) >> 1) + (int)(mL & 1ull);
+        int e = popc((mR & lowmask_t<WT>(len)) >> 1) + (int)(mL & (WT)1);
         for (int p = 1; p < len; ++p) {
             if (e < best) { best = e; bp = p; }
-            e += (int)((mL >> p) & 1ull) - (int)((mR >> p) & 1ull);
+            e += (int)((mL >> p) & (WT)1) - (int)((mR >> p) & (WT)1);
         }
     }
     min_err = best;
@@ -212,8 +250,8 @@ THJ_HD int split_bits(u64 mL, u64 mR, int len, int& min_err) {
 }
 
 // detect_small_deletion (segment_juncs.cpp:2557-2627). rd = read piece (rc'd when antisense).
-template <class Sink>
-THJ_HD void small_deletion(const Genome& g, Planes rd, int plen, const Hit& lh, const Hit& rh, Sink& sink) {
+template <class WT, class Sink>
+THJ_HD void small_deletion(const Genome& g, PlanesT<WT> rd, int plen, const Hit& lh, const Hit& rh, Sink& sink) {
     int32_t clen = g_len(g, lh.ref_id);
     if (clen == 0) return;
     if (lh.left < 0) return;
@@ -221,11 +259,11 @@ THJ_HD void small_deletion(const Genome& g, Planes rd, int plen, const Hit& lh, 
     int disc = (rh.right - lh.left) - plen;
     if ((int64_t)lh.left + plen > clen) return;
     if (rh.right > clen) return;
-    Planes lg = g_fetch(g, lh.ref_id, lh.left);
-    Planes rg = g_fetch(g, lh.ref_id, (int64_t)rh.right - plen);
-    u64 M = lowmask(plen);
-    u64 mL = ((lg.lo ^ rd.lo) | (lg.hi ^ rd.hi) | lg.nm | rd.nm) & M;    // 'N' on either side is an error
-    u64 mR = ((rg.lo ^ rd.lo) | (rg.hi ^ rd.hi) | rg.nm | rd.nm) & M;
+    const PlanesT<WT> lg = Fetch<WT>::genome(g, lh.ref_id, lh.left);
+    const PlanesT<WT> rg = Fetch<WT>::genome(g, lh.ref_id, (int64_t)rh.right - plen);
+    const WT M = lowmask_t<WT>(plen);
+    const WT mL = ((lg.lo ^ rd.lo) | (lg.hi ^ rd.hi) | lg.nm | rd.nm) & M;    // 'N' on either side is an error
+    const WT mR = ((rg.lo ^ rd.lo) | (rg.hi ^ rd.hi) | rg.nm | rd.nm) & M;
     int min_err;
     int pos = split_bits(mL, mR, plen, min_err);
     if (pos < 0) return;
@@ -235,8 +273,8 @@ THJ_HD void small_deletion(const Genome& g, Planes rd, int plen, const Hit& lh, 
 }
 
 // detect_small_insertion (segment_juncs.cpp:2470-2543).
-template <class Sink>
-THJ_HD void small_insertion(const Genome& g, Planes rd, int plen, const Hit& lh, const Hit& rh, u64 prio, Sink& sink) {
+template <class WT, class Sink>
+THJ_HD void small_insertion(const Genome& g, PlanesT<WT> rd, int plen, const Hit& lh, const Hit& rh, u64 prio, Sink& sink) {
     int32_t clen = g_len(g, lh.ref_id);
     if (clen == 0) return;
     if (lh.left < 0) return;
@@ -245,13 +283,13 @@ THJ_HD void small_insertion(const Genome& g, Planes rd, int plen, const Hit& lh,
     if (ge > clen) ge = clen;
     int glen = (int)(ge - lh.left);
     if (glen < 0) glen = 0;
-    if (glen > plen || glen > 64) return;
-    Planes gg = g_fetch(g, lh.ref_id, lh.left);          // DnaString: N -> A, mask ignored
-    u64 M = lowmask(glen);
+    if (glen > plen || glen > (int)(8 * sizeof(WT))) return;
+    const PlanesT<WT> gg = Fetch<WT>::genome(g, lh.ref_id, lh.left);          // DnaString: N -> A, mask ignored
+    const WT M = lowmask_t<WT>(glen);
     // left_read = rd[0:glen], right_read = rd[plen-glen:plen]
     int sh = plen - glen;
-    u64 mL = ((gg.lo ^ rd.lo) | (gg.hi ^ rd.hi) | rd.nm) & M;
-    u64 mR = ((gg.lo ^ (rd.lo >> sh)) | (gg.hi ^ (rd.hi >> sh)) | (rd.nm >> sh)) & M;
+    const WT mL = ((gg.lo ^ rd.lo) | (gg.hi ^ rd.hi) | rd.nm) & M;
+    const WT mR = ((gg.lo ^ (rd.lo >> sh)) | (gg.hi ^ (rd.hi >> sh)) | (rd.nm >> sh)) & M;
     int min_err;
     int pos = split_bits(mL, mR, glen, min_err);
     if (pos < 0) return;
@@ -261,7 +299,7 @@ THJ_HD void small_insertion(const Genome& g, Planes rd, int plen, const Hit& lh,
         uint32_t seq = 0;
         for (int k = 0; k < disc; ++k) {
             int b = pos + k;
-            uint32_t c = ((rd.nm >> b) & 1ull) ? 4u : (uint32_t)(((rd.lo >> b) & 1ull) | (((rd.hi >> b) & 1ull) << 1));
+            uint32_t c = ((rd.nm >> b) & (WT)1) ? 4u : (uint32_t)(((rd.lo >> b) & (WT)1) | (((rd.hi >> b) & (WT)1) << 1));
             seq |= c << (3 * k);
         }
         sink.insertion(lh.ref_id, (uint32_t)(lh.left + pos - 1), disc, seq, prio);
@@ -540,24 +578,40 @@ THJ_HD void indels_enumerate(const Params& p, const ReadView& v, Sink& sink) {
 }
 
 // Execute one indel task: fetch the 2L read piece, rc when antisense, run the detector.
-template <class Sink>
+// WIDE = false compiles the 64-bit path only (segment_length <= 32: the default, and what keeps the kernels lean)
+template <bool WIDE = true, class Sink>
 THJ_HD void indel_exec(const Genome& g, const Params& p, const ReadView& v, int i, uint32_t lidx, uint32_t ridx,
                        bool anti, int plen, bool is_del, u64 prio, Sink& sink) {
-    Planes rd = r_fetch(v.rp, v.W, i * p.segment_length, plen);
-    if (anti) rd = rc_piece(rd, plen);
-    Hit lh = v.hits[lidx], rh = v.hits[ridx];
-    if (is_del) small_deletion(g, rd, plen, lh, rh, sink);
-    else small_insertion(g, rd, plen, lh, rh, prio, sink);
+    const Hit lh = v.hits[lidx], rh = v.hits[ridx];
+    if (!WIDE || plen <= 64) {
+        if (plen > 64) return;
+        PlanesT<u64> rd = Fetch<u64>::read(v.rp, v.W, i * p.segment_length, plen);
+        if (anti) rd = Fetch<u64>::rc(rd, plen);
+        if (is_del) small_deletion<u64>(g, rd, plen, lh, rh, sink);
+        else small_insertion<u64>(g, rd, plen, lh, rh, prio, sink);
+    } else if (WIDE) {                            // segment_length > 32
+        PlanesT<u128> rd = Fetch<u128>::read(v.rp, v.W, i * p.segment_length, plen);
+        if (anti) rd = Fetch<u128>::rc(rd, plen);
+        if (is_del) small_deletion<u128>(g, rd, plen, lh, rh, sink);
+        else small_insertion<u128>(g, rd, plen, lh, rh, prio, sink);
+    }
 }
 
 // Execute one window task.
-template <class Sink>
+template <bool WIDE = true, class Sink>
 THJ_HD void window_exec(const Genome& g, const Params& p, const ReadView& v, uint32_t ref_id, int32_t wl, int32_t wr,
                         bool anti, int start, int slen, Sink& sink) {
     if (slen < 2) return;
-    Planes sup = r_fetch(v.rp, v.W, start, slen);
-    if (anti) sup = rc_piece(sup, slen);                                       // :3598-3601
-    window_scan(g, p, ref_id, wl, wr, anti, sup, slen, sink);
+    if (!WIDE || slen <= 62) {
+        if (slen > 62) return;
+        PlanesT<u64> sup = Fetch<u64>::read(v.rp, v.W, start, slen);
+        if (anti) sup = Fetch<u64>::rc(sup, slen);                             // :3598-3601
+        window_scan<u64>(g, p, ref_id, wl, wr, anti, sup, slen, sink);
+    } else if (WIDE) {                            // L + 16 support read with segment_length > 46
+        PlanesT<u128> sup = Fetch<u128>::read(v.rp, v.W, start, slen);
+        if (anti) sup = Fetch<u128>::rc(sup, slen);
+        window_scan<u128>(g, p, ref_id, wl, wr, anti, sup, slen, sink);
+    }
 }
 
 // insertion priority = visiting order inside one batch: read ordinal, segment pair, li, ri

@@ -160,13 +160,14 @@ struct QueueSink {
 };
 
 // Un-queued execution (overflow fallback): tasks run in the enumerating thread.
+template <bool WIDE>
 struct InlineSink {
     const Genome& g; const Params& p; const ReadView& v; EventSink& ev; uint32_t ordinal;
     __device__ __forceinline__ void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
-        window_exec(g, p, v, ref, wl, wr, anti, start, slen, ev);
+        window_exec<WIDE>(g, p, v, ref, wl, wr, anti, start, slen, ev);
     }
     __device__ __forceinline__ void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) {
-        indel_exec(g, p, v, i, lidx, ridx, anti, plen, is_del, ins_prio(ordinal, i, li, ri), ev);
+        indel_exec<WIDE>(g, p, v, i, lidx, ridx, anti, plen, is_del, ins_prio(ordinal, i, li, ri), ev);
     }
 };
 
@@ -188,6 +189,7 @@ __device__ __forceinline__ ReadView make_task_view(const DevBatch& b, int r) {
 // of 256 -- every lane busy -- with the remainder (`keep`) carried over; `flush` runs everything.
 struct TaskQueue { uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e; unsigned int* n; };
 
+template <bool WIDE>
 __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, const DevBatch& b, EventSink& ev, const TaskQueue& q, bool flush) {
     const int tid = threadIdx.x;
     const unsigned int have = *q.n;
@@ -200,13 +202,13 @@ __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, cons
             const bool anti = (a >> 9) & 1u;
             if (a & (1u << 8)) {
                 const bool is_del = (a >> 10) & 1u;
-                const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 127u);
+                const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
                 const uint32_t d = q.d[k];
-                indel_exec(g, p, tv, i, q.b[k], q.c[k], anti, plen, is_del,
+                indel_exec<WIDE>(g, p, tv, i, q.b[k], q.c[k], anti, plen, is_del,
                            ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(d & 0xFFFF), (int)(d >> 16)), ev);
             } else {
-                const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 63u);
-                window_exec(g, p, tv, q.b[k], (int32_t)q.c[k], (int32_t)q.d[k], anti, start, slen, ev);
+                const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
+                window_exec<WIDE>(g, p, tv, q.b[k], (int32_t)q.c[k], (int32_t)q.d[k], anti, start, slen, ev);
             }
         }
         __syncthreads();
@@ -228,6 +230,8 @@ struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; };
 //   enumerate: the general enumeration over the work list only; windows and indel pairs are queued as tasks.
 //   execute:   run_tasks.
 // Dynamic LDS: 5 x QCAP queue words | TPB*nseg+1 offsets | hit_cap hits | work list.
+// WIDE: segment_length > 32 (128-bit read pieces; see thj_core.h)
+template <bool WIDE>
 __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, DevBatch b, Tables t, RescueList rl, int hit_cap) {
     extern __shared__ uint4 dyn_lds[];
     uint32_t* q_a = (uint32_t*)dyn_lds;
@@ -305,7 +309,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             // the queue overflowed (multihit-heavy tile): drop this tile's queued tasks and run the tile un-queued.
             if (tid == 0) atomicAdd(&s_stat[3], 1u);
             if (active) {
-                InlineSink is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
                 indels_enumerate(p, v, is);
                 if (do_gaps) gaps_enumerate(p, v, is);
             }
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             if (tid == 0) q_n = q_before;
             __syncthreads();
         }
-        run_tasks(g, p, b, ev, tq, tile + (int)gridDim.x >= n_tiles);
+        run_tasks<WIDE>(g, p, b, ev, tq, tile + (int)gridDim.x >= n_tiles);
     }
     __syncthreads();
     if (tid == 0) {
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
 static constexpr int RPT = 4;             // rescue pairs per thread kept in LDS
 static constexpr int MAX_LISTS = 2048;    // workgroups of the main kernel = slices of the rescue list
 
+template <bool WIDE>
 __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params p, DevBatch b, Tables t, RescueList rl, int n_lists) {
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
     __shared__ int32_t s_slots[TPB * RPT * 2];
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
         if (q_n > (unsigned)QCAP) {
             if (tid == 0) atomicAdd(&s_stat[3], 1u);
             if (active) {
-                InlineSink is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
                 indels_enumerate(p, v, is);
                 if (do_gaps) gaps_enumerate(p, v, is);
             }
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             if (tid == 0) q_n = q_before;
             __syncthreads();
         }
-        run_tasks(g, p, b, ev, tq, it + 1 == rounds);
+        run_tasks<WIDE>(g, p, b, ev, tq, it + 1 == rounds);
     }
     __syncthreads();
     if (tid == 0) {
@@ -734,9 +739,9 @@ extern "C" int thj_segjuncs_reset_async(thj_ctx* c) {
 }
 
 static int check_params(const thj_params* p, const thj_seg_batch* b) {
-    if (p->segment_length < 10 || p->segment_length > 32) {
-        thj_set_error("segment_length %d unsupported by the device path (10..32: a 2L read piece and an L+16 support "
-                      "read must fit one 64-bit plane word)", p->segment_length);
+    if (p->segment_length < 10 || p->segment_length > 64) {
+        thj_set_error("segment_length %d unsupported by the device path (10..64: a 2L read piece and an L+16 support "
+                      "read must fit one 128-bit plane word)", p->segment_length);
         return THJ_EINVAL;
     }
     if (p->max_insertion_length > 6 || p->max_insertion_length < 0) { thj_set_error("max_insertion_length %d unsupported (0..6)", p->max_insertion_length); return THJ_EINVAL; }
@@ -793,11 +798,14 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     }
     rl.list = c->d_rescue_list;
     rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap;
-    hipLaunchKernelGGL(thj_k_segjuncs, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
+    const bool wide = p.segment_length > 32;
+    if (wide) hipLaunchKernelGGL(thj_k_segjuncs<true>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
+    else hipLaunchKernelGGL(thj_k_segjuncs<false>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
     if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
     if (b.mate_off) {
         const int rgrid = grid < 1024 ? grid : 1024;
-        hipLaunchKernelGGL(thj_k_segjuncs_rescue, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
+        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
+        else hipLaunchKernelGGL(thj_k_segjuncs_rescue<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
     }
     if (c->profile) { HIPCHK(hipEventRecord(e2, c->stream)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(e1, e2); }
     HIPCHK(hipGetLastError());
