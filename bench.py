@@ -366,14 +366,16 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     # The JSON line must be the last thing on stdout: RCCL writes a version banner through C stdio, which sits in libc's
-    # buffer until exit when stdout is a pipe.  Flush that first, print, flush, and leave without running exit handlers
-    # that could print again.
+    # buffer until exit when stdout is a pipe.  Flush that first, print the line, then point fd 1 at /dev/null so that
+    # nothing written later (exit handlers, library destructors) can follow it.  The process still exits normally --
+    # profilers attached to it (rocprofv3) finalise in their exit handlers.
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(result), flush=True)
-    sys.stderr.flush()
-    os._exit(0)
+    sys.stdout.flush()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@ python - "$out/${tag}_pmc_fetch_write_bench10M.txt" "$tag" > $out/${tag}_pmc_tra
 import json, re, sys
 ker = {}
 for line in open(sys.argv[1]):
-    m = re.match(r"(?:void )?(thj_k_\w+)(?:<\d+>)?\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+\d+\s+[\d.]+\s+([\d.]+)\s*$", line)
+    m = re.match(r"(?:void )?(thj_k_\w+)(?:<[^>]*>)?\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+\d+\s+[\d.]+\s+([\d.]+)\s*$", line)
     if m:
         ker.setdefault(m.group(1), {})[m.group(2)] = float(m.group(3))
 print(json.dumps({"config": {"pairs_per_gpu": 10000000, "genome_len": 64444167, "exon_len": 300}, "unit": "KB per dispatch",

@@ -36,7 +36,7 @@ struct thj_ctx {
     unsigned long long* d_cnt = nullptr;
     // sorted outputs
     u64 *d_junc_sorted = nullptr, *d_del_sorted = nullptr, *d_ins_key_sorted = nullptr, *d_ins_val_sorted = nullptr;
-    u64 *d_tmp_keys = nullptr, *d_tmp_vals = nullptr;
+    u64 *d_tmp_keys = nullptr, *d_tmp_vals = nullptr, *d_tmp_keys2 = nullptr;   // event lists (see set_insert) / insertion gather
     int64_t out_cap_junc = 0, out_cap_indel = 0;
     unsigned long long* d_out_n = nullptr;      // [3]
     unsigned long long* h_pinned = nullptr;     // [16] pinned staging
@@ -47,6 +47,7 @@ struct thj_ctx {
     uint32_t* d_rescue_list = nullptr; int64_t rescue_list_cap = 0;      // reads taking the mate-anchored rescue + per-workgroup counts
     // long_spanning_reads (thj_span.hip)
     uint32_t* d_junc_bucket = nullptr; int64_t n_junc_buckets = 0;     // coarse index over d_span_junc (junc_range)
+    u64* d_span_cat = nullptr;                                            // junction ++ deletion keys before their sort
     u64* d_span_junc = nullptr; int64_t n_span_junc = 0; int64_t cap_span_junc = 0;
     u64* d_span_ins_key = nullptr; uint32_t* d_span_ins_seq = nullptr; int64_t n_span_ins = 0; int64_t cap_span_ins = 0;
     void* d_aln_pool = nullptr; void* d_aln_sorted = nullptr; int64_t aln_cap = 0;

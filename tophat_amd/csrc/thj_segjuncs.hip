@@ -39,6 +39,7 @@ struct Tables {
     u64* junc; u64 junc_mask;
     u64* del;  u64 del_mask;
     u64* ins_key; u64* ins_val; u64 ins_mask;
+    u64* junc_list; u64* del_list; u64* ins_list;      // every NEW key (junction / deletion) or slot (insertion), in arrival order
     unsigned int* ovf;              // [3] table-full flags
     unsigned long long* cnt;        // [CNT_N]
 };
@@ -51,14 +52,16 @@ __device__ __forceinline__ u64 mix64(u64 x) {
 }
 
 // Insert into an open-addressing set; idempotent, so re-emitting an event is harmless.
-__device__ __forceinline__ void set_insert(u64* tab, u64 mask, u64 key, unsigned long long* count, unsigned int* ovf) {
+// A key that was not there yet is also appended to `list` (its position is the insert counter): the distinct
+// events are then already dense when the pass ends, and nobody has to scan the whole table for them.
+__device__ __forceinline__ void set_insert(u64* tab, u64 mask, u64 key, unsigned long long* count, unsigned int* ovf, u64* list) {
     u64 h = mix64(key) & mask;
     for (u64 probe = 0; probe <= mask; ++probe) {
         u64 cur = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == key) return;
         if (cur == EMPTY) {
             u64 old = atomicCAS((unsigned long long*)&tab[h], EMPTY, key);
-            if (old == EMPTY) { atomicAdd(count, 1ull); return; }     // fire-and-forget: the load factor is checked by the host
+            if (old == EMPTY) { const unsigned long long pos = atomicAdd(count, 1ull); if (pos <= mask) list[pos] = key; return; }   // rare
             if (old == key) return;
         }
         h = (h + 1) & mask;
@@ -67,13 +70,13 @@ __device__ __forceinline__ void set_insert(u64* tab, u64 mask, u64 key, unsigned
 }
 
 __device__ __forceinline__ void map_insert_min(u64* keys, u64* vals, u64 mask, u64 key, u64 val,
-                                               unsigned long long* count, unsigned int* ovf) {
+                                               unsigned long long* count, unsigned int* ovf, u64* list) {
     u64 h = mix64(key) & mask;
     for (u64 probe = 0; probe <= mask; ++probe) {
         u64 cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == EMPTY) {
             u64 old = atomicCAS((unsigned long long*)&keys[h], EMPTY, key);
-            if (old == EMPTY) { atomicAdd(count, 1ull); cur = key; }
+            if (old == EMPTY) { const unsigned long long pos = atomicAdd(count, 1ull); if (pos <= mask) list[pos] = h; cur = key; }
             else cur = old;
         }
         if (cur == key) { atomicMin((unsigned long long*)&vals[h], val); return; }
@@ -86,14 +89,14 @@ struct EventSink {
     const Genome& g;
     const Tables& t;
     __device__ __forceinline__ void junction(uint32_t ref, uint32_t l, uint32_t r, bool a) {
-        set_insert(t.junc, t.junc_mask, junc_key(g, ref, l, r, a), &t.cnt[CNT_JUNC], &t.ovf[0]);
+        set_insert(t.junc, t.junc_mask, junc_key(g, ref, l, r, a), &t.cnt[CNT_JUNC], &t.ovf[0], t.junc_list);
     }
     __device__ __forceinline__ void deletion(uint32_t ref, uint32_t l, uint32_t r) {
-        set_insert(t.del, t.del_mask, junc_key(g, ref, l, r, false), &t.cnt[CNT_DEL], &t.ovf[1]);
+        set_insert(t.del, t.del_mask, junc_key(g, ref, l, r, false), &t.cnt[CNT_DEL], &t.ovf[1], t.del_list);
     }
     __device__ __forceinline__ void insertion(uint32_t ref, uint32_t l, int len, uint32_t seq, u64 prio) {
         map_insert_min(t.ins_key, t.ins_val, t.ins_mask, ins_key(g, ref, l, len), (prio << 20) | (u64)(seq & 0xFFFFFu),
-                       &t.cnt[CNT_INS], &t.ovf[2]);
+                       &t.cnt[CNT_INS], &t.ovf[2], t.ins_list);
     }
 };
 
@@ -454,43 +457,41 @@ __global__ __launch_bounds__(256) void thj_k_fusion(Genome g, Params p, DevBatch
 
 // ------------------------------------------------------------------ finish
 
-__global__ __launch_bounds__(256) void thj_k_compact(const u64* tab, const u64* vals, u64 cap, u64* out_keys,
-                                                     u64* out_vals, unsigned long long* out_n) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (u64)gridDim.x * blockDim.x) {
-        u64 k = tab[i];
-        if (k != EMPTY) {
-            unsigned long long pos = atomicAdd(out_n, 1ull);   // hipcc folds this into one atomic per wave
-            out_keys[pos] = k;
-            if (vals) out_vals[pos] = vals[i];
-        }
+// insertions are listed by table slot (their value keeps changing under atomicMin): fetch (key, value) at the end
+__global__ __launch_bounds__(256) void thj_k_ins_gather(const u64* slots, int64_t n, const u64* keys, const u64* vals, u64* out_keys, u64* out_vals) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const u64 h = slots[i];
+        out_keys[i] = keys[h];
+        out_vals[i] = vals[h];
     }
 }
 
 // table growth: every occupied slot of the old table goes into the new one
-__global__ __launch_bounds__(256) void thj_k_rehash_keys(const u64* old_tab, u64 old_cap, u64* tab, u64 mask, unsigned long long* count, unsigned int* ovf) {
+__global__ __launch_bounds__(256) void thj_k_rehash_keys(const u64* old_tab, u64 old_cap, u64* tab, u64 mask, unsigned long long* count, unsigned int* ovf,
+                                                         u64* list) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
         const u64 k = old_tab[i];
-        if (k != EMPTY) set_insert(tab, mask, k, count, ovf);
+        if (k != EMPTY) set_insert(tab, mask, k, count, ovf, list);
     }
 }
 __global__ __launch_bounds__(256) void thj_k_rehash_ins(const u64* old_keys, const u64* old_vals, u64 old_cap, u64* keys, u64* vals, u64 mask,
-                                                        unsigned long long* count, unsigned int* ovf) {
+                                                        unsigned long long* count, unsigned int* ovf, u64* list) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
         const u64 k = old_keys[i];
-        if (k != EMPTY) map_insert_min(keys, vals, mask, k, old_vals[i], count, ovf);
+        if (k != EMPTY) map_insert_min(keys, vals, mask, k, old_vals[i], count, ovf, list);
     }
 }
 
 __global__ __launch_bounds__(256) void thj_k_merge_keys(u64* tab, u64 mask, const u64* keys, int64_t n,
-                                                        unsigned long long* count, unsigned int* ovf) {
+                                                        unsigned long long* count, unsigned int* ovf, u64* list) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        set_insert(tab, mask, keys[i], count, ovf);
+        set_insert(tab, mask, keys[i], count, ovf, list);
 }
 
 __global__ __launch_bounds__(256) void thj_k_merge_ins(u64* keys, u64* vals, u64 mask, const u64* in_keys, const u64* in_vals,
-                                                       int64_t n, unsigned long long* count, unsigned int* ovf) {
+                                                       int64_t n, unsigned long long* count, unsigned int* ovf, u64* list) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        map_insert_min(keys, vals, mask, in_keys[i], in_vals[i], count, ovf);
+        map_insert_min(keys, vals, mask, in_keys[i], in_vals[i], count, ovf, list);
 }
 
 // ------------------------------------------------------------------ context
@@ -505,13 +506,18 @@ static int next_pow2(int64_t x, int64_t* out) {
     return 0;
 }
 
+// dense lists of the distinct events, side by side in d_tmp_keys: junctions | deletions | insertion slots
+static inline u64* junc_list(thj_ctx* c) { return c->d_tmp_keys; }
+static inline u64* del_list(thj_ctx* c) { return c->d_tmp_keys + c->junc_cap; }
+static inline u64* ins_list(thj_ctx* c) { return c->d_tmp_keys + c->junc_cap + c->indel_cap; }
+
 static int free_tables(thj_ctx* c) {
     hipFree(c->d_junc); hipFree(c->d_del); hipFree(c->d_ins_key); hipFree(c->d_ins_val);
     hipFree(c->d_junc_sorted); hipFree(c->d_del_sorted); hipFree(c->d_ins_key_sorted); hipFree(c->d_ins_val_sorted);
-    hipFree(c->d_tmp_keys); hipFree(c->d_tmp_vals); hipFree(c->d_sort_tmp);
+    hipFree(c->d_tmp_keys); hipFree(c->d_tmp_vals); hipFree(c->d_tmp_keys2); hipFree(c->d_sort_tmp);
     c->d_junc = c->d_del = c->d_ins_key = c->d_ins_val = nullptr;
     c->d_junc_sorted = c->d_del_sorted = c->d_ins_key_sorted = c->d_ins_val_sorted = nullptr;
-    c->d_tmp_keys = c->d_tmp_vals = nullptr; c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0;
+    c->d_tmp_keys = c->d_tmp_vals = c->d_tmp_keys2 = nullptr; c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0;
     return 0;
 }
 
@@ -526,11 +532,12 @@ static int alloc_tables(thj_ctx* c, int64_t junc_cap, int64_t indel_cap) {
     // a table never holds more than 75 % + one wave of entries
     c->out_cap_junc = c->junc_cap; c->out_cap_indel = c->indel_cap;
     HIPCHK(hipMalloc(&c->d_junc_sorted, (size_t)c->out_cap_junc * 8));
-    HIPCHK(hipMalloc(&c->d_tmp_keys, (size_t)(c->out_cap_junc + 2 * c->out_cap_indel) * 8));   // the three compacted tables side by side
+    HIPCHK(hipMalloc(&c->d_tmp_keys, (size_t)(c->out_cap_junc + 2 * c->out_cap_indel) * 8));   // the three event lists side by side
     HIPCHK(hipMalloc(&c->d_del_sorted, (size_t)c->out_cap_indel * 8));
     HIPCHK(hipMalloc(&c->d_ins_key_sorted, (size_t)c->out_cap_indel * 8));
     HIPCHK(hipMalloc(&c->d_ins_val_sorted, (size_t)c->out_cap_indel * 8));
     HIPCHK(hipMalloc(&c->d_tmp_vals, (size_t)c->out_cap_indel * 8));
+    HIPCHK(hipMalloc(&c->d_tmp_keys2, (size_t)c->out_cap_indel * 8));
     size_t need = 0, need2 = 0;
     HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, (const u64*)nullptr, (u64*)nullptr, (int64_t)c->out_cap_junc, 0, 64, c->stream));
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need2, (const u64*)nullptr, (u64*)nullptr, (const u64*)nullptr, (u64*)nullptr,
@@ -704,11 +711,11 @@ static int grow_tables(thj_ctx* c, bool grow_junc, bool grow_indel) {
     HIPCHK(hipMemsetAsync(&c->d_cnt[CNT_JUNC], 0, 3 * sizeof(unsigned long long), c->stream));      // JUNC, DEL, INS: recounted by the rehash
     auto blocks_for = [](int64_t cap) { int64_t b = (cap + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b); };
     hipLaunchKernelGGL(thj_k_rehash_keys, dim3(blocks_for(ojc)), dim3(256), 0, c->stream, (const u64*)oj, (u64)ojc, c->d_junc,
-                       (u64)c->junc_cap - 1, &c->d_cnt[CNT_JUNC], &c->d_ovf[0]);
+                       (u64)c->junc_cap - 1, &c->d_cnt[CNT_JUNC], &c->d_ovf[0], junc_list(c));
     hipLaunchKernelGGL(thj_k_rehash_keys, dim3(blocks_for(oic)), dim3(256), 0, c->stream, (const u64*)od, (u64)oic, c->d_del,
-                       (u64)c->indel_cap - 1, &c->d_cnt[CNT_DEL], &c->d_ovf[1]);
+                       (u64)c->indel_cap - 1, &c->d_cnt[CNT_DEL], &c->d_ovf[1], del_list(c));
     hipLaunchKernelGGL(thj_k_rehash_ins, dim3(blocks_for(oic)), dim3(256), 0, c->stream, (const u64*)oik, (const u64*)oiv, (u64)oic,
-                       c->d_ins_key, c->d_ins_val, (u64)c->indel_cap - 1, &c->d_cnt[CNT_INS], &c->d_ovf[2]);
+                       c->d_ins_key, c->d_ins_val, (u64)c->indel_cap - 1, &c->d_cnt[CNT_INS], &c->d_ovf[2], ins_list(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     hipFree(oj); hipFree(od); hipFree(oik); hipFree(oiv);
     return THJ_OK;
@@ -774,7 +781,7 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     DevBatch b;
     memcpy(&b, db, sizeof b);
     Tables t{c->d_junc, (u64)c->junc_cap - 1, c->d_del, (u64)c->indel_cap - 1, c->d_ins_key, c->d_ins_val,
-             (u64)c->indel_cap - 1, c->d_ovf, c->d_cnt};
+             (u64)c->indel_cap - 1, junc_list(c), del_list(c), ins_list(c), c->d_ovf, c->d_cnt};
     const int n = b.n_reads;
 
 #ifdef THJ_EXP
@@ -850,10 +857,10 @@ extern "C" int thj_segjuncs_merge_keys_async(thj_ctx* c, int kind, const uint64_
     if (blocks > 2048) blocks = 2048;
     if (kind == 0)
         hipLaunchKernelGGL(thj_k_merge_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_junc, (u64)c->junc_cap - 1,
-                           (const u64*)d_keys, n, &c->d_cnt[CNT_JUNC], &c->d_ovf[0]);
+                           (const u64*)d_keys, n, &c->d_cnt[CNT_JUNC], &c->d_ovf[0], junc_list(c));
     else
         hipLaunchKernelGGL(thj_k_merge_keys, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_del, (u64)c->indel_cap - 1,
-                           (const u64*)d_keys, n, &c->d_cnt[CNT_DEL], &c->d_ovf[1]);
+                           (const u64*)d_keys, n, &c->d_cnt[CNT_DEL], &c->d_ovf[1], del_list(c));
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
@@ -959,7 +966,7 @@ extern "C" int thj_segjuncs_merge_insertions_async(thj_ctx* c, const uint64_t* d
     int64_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(thj_k_merge_ins, dim3((unsigned)blocks), dim3(256), 0, c->stream, c->d_ins_key, c->d_ins_val,
-                       (u64)c->indel_cap - 1, (const u64*)d_keys, (const u64*)d_vals, n, &c->d_cnt[CNT_INS], &c->d_ovf[2]);
+                       (u64)c->indel_cap - 1, (const u64*)d_keys, (const u64*)d_vals, n, &c->d_cnt[CNT_INS], &c->d_ovf[2], ins_list(c));
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
@@ -967,20 +974,7 @@ extern "C" int thj_segjuncs_merge_insertions_async(thj_ctx* c, const uint64_t* d
 extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->d_out_n, 0, 4 * sizeof(unsigned long long), c->stream));
-    auto blocks_for = [](int64_t cap) { int64_t b = (cap + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b); };
-    // the three tables are compacted into disjoint parts of the scratch arrays, then ONE round trip brings the counts
-    u64* jt = c->d_tmp_keys;
-    u64* dt = c->d_tmp_keys + c->junc_cap;
-    u64* it = dt + c->indel_cap;
-    u64* itv = c->d_tmp_vals;
-    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->junc_cap)), dim3(256), 0, c->stream, (const u64*)c->d_junc,
-                       (const u64*)nullptr, (u64)c->junc_cap, jt, (u64*)nullptr, &c->d_out_n[0]);
-    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_del,
-                       (const u64*)nullptr, (u64)c->indel_cap, dt, (u64*)nullptr, &c->d_out_n[1]);
-    hipLaunchKernelGGL(thj_k_compact, dim3(blocks_for(c->indel_cap)), dim3(256), 0, c->stream, (const u64*)c->d_ins_key,
-                       (const u64*)c->d_ins_val, (u64)c->indel_cap, it, itv, &c->d_out_n[2]);
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[0], c->d_out_n, 24, hipMemcpyDeviceToHost, c->stream));
+    // the distinct events are already dense (see set_insert): ONE round trip brings their counts
     HIPCHK(hipMemcpyAsync(&c->h_pinned[4], c->d_ovf, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&c->h_pinned[8], c->d_cnt, CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -990,6 +984,7 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
                       ovf[0], ovf[1], ovf[2]);
         return THJ_EOVERFLOW;
     }
+    c->h_pinned[0] = c->h_pinned[8 + CNT_JUNC]; c->h_pinned[1] = c->h_pinned[8 + CNT_DEL]; c->h_pinned[2] = c->h_pinned[8 + CNT_INS];
     c->n_junc = (int64_t)c->h_pinned[0];
     c->n_del = (int64_t)c->h_pinned[1];
     c->n_ins = (int64_t)c->h_pinned[2];
@@ -1002,14 +997,18 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
     // sorted output (stream-ordered: consumers on the context stream need no further synchronisation)
     size_t tmp = c->sort_tmp_bytes;
     if (c->n_junc > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)jt, c->d_junc_sorted, c->n_junc, 0, 64, c->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)junc_list(c), c->d_junc_sorted, c->n_junc, 0, 64, c->stream));
     tmp = c->sort_tmp_bytes;
     if (c->n_del > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)dt, c->d_del_sorted, c->n_del, 0, 64, c->stream));
-    tmp = c->sort_tmp_bytes;
-    if (c->n_ins > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)it, c->d_ins_key_sorted,
-                                                  (const u64*)itv, c->d_ins_val_sorted, c->n_ins, 0, 64, c->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)del_list(c), c->d_del_sorted, c->n_del, 0, 64, c->stream));
+    if (c->n_ins > 0) {
+        int64_t blocks = (c->n_ins + 255) / 256; if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(thj_k_ins_gather, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const u64*)ins_list(c), c->n_ins,
+                           (const u64*)c->d_ins_key, (const u64*)c->d_ins_val, c->d_tmp_keys2, c->d_tmp_vals);
+        tmp = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys2, c->d_ins_key_sorted,
+                                                  (const u64*)c->d_tmp_vals, c->d_ins_val_sorted, c->n_ins, 0, 64, c->stream));
+    }
     if (counts) {
         const unsigned long long* cnt = &c->h_pinned[8];
         counts->n_juncs = c->n_junc; counts->n_deletions = c->n_del; counts->n_insertions = c->n_ins;

@@ -232,7 +232,7 @@ static int build_junc_buckets(thj_ctx* c) {
 }
 
 void thj_span_free(thj_ctx* c) {
-    hipFree(c->d_span_junc); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket);
+    hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -250,9 +250,10 @@ static int ensure_span_state(thj_ctx* c) {
 
 static int ensure_sets_cap(thj_ctx* c, int64_t nj, int64_t ni) {
     if (nj + 1 > c->cap_span_junc) {
-        hipFree(c->d_span_junc); c->d_span_junc = nullptr;
+        hipFree(c->d_span_junc); hipFree(c->d_span_cat); c->d_span_junc = c->d_span_cat = nullptr;
         c->cap_span_junc = nj + nj / 4 + 1024;
         HIPCHK(hipMalloc(&c->d_span_junc, (size_t)c->cap_span_junc * 8));
+        HIPCHK(hipMalloc(&c->d_span_cat, (size_t)c->cap_span_junc * 8));
     }
     if (ni + 1 > c->cap_span_ins) {
         hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); c->d_span_ins_key = nullptr; c->d_span_ins_seq = nullptr;
@@ -312,14 +313,13 @@ extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
     if (rc) return rc;
     if (nj) {
         // concatenate into tmp, sort
-        HIPCHK(hipMemcpyAsync(c->d_tmp_keys, c->d_junc_sorted, (size_t)c->n_junc * 8, hipMemcpyDeviceToDevice, c->stream));
-        if (c->n_del) HIPCHK(hipMemcpyAsync(c->d_tmp_keys + c->n_junc, c->d_del_sorted, (size_t)c->n_del * 8, hipMemcpyDeviceToDevice, c->stream));
-        if (nj > c->out_cap_junc) { thj_set_error("junction+deletion set exceeds table capacity"); return THJ_EOVERFLOW; }
+        HIPCHK(hipMemcpyAsync(c->d_span_cat, c->d_junc_sorted, (size_t)c->n_junc * 8, hipMemcpyDeviceToDevice, c->stream));
+        if (c->n_del) HIPCHK(hipMemcpyAsync(c->d_span_cat + c->n_junc, c->d_del_sorted, (size_t)c->n_del * 8, hipMemcpyDeviceToDevice, c->stream));
         // Sorted, NOT made unique: a deletion and a '+' junction with the same ends give the same key twice, and
         // a repeated key is harmless to its only consumer -- closure_search skips a candidate that does not improve
         // on the best one (`diff >= best_diff`), which an identical twin never does.
         size_t tmp = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys, c->d_span_junc, nj, 0, 64, c->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_span_cat, c->d_span_junc, nj, 0, 64, c->stream));
         c->n_span_junc = nj;
     } else c->n_span_junc = 0;
     if (ni) {
