@@ -2,6 +2,8 @@
 strands, multihits, random mates, odd parameters -- through the kernel logic (tests/hostsim) against the plain-C
 oracle.  Every window / split / flank scan of the bit-plane code touches genome words near contig boundaries and
 guard blocks here, which the generator-shaped cases never do."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,9 @@ import sim
 from tophat_amd.batch import HIT_DTYPE, JUNC_DTYPE, SPAN_HIT_DTYPE, SegBatch, SpanBatch, events_to_span_inputs
 from tophat_amd.params import Params
 from util import assert_events_equal
+
+# THJ_FUZZ_SEEDS=<n> widens the sweep (e.g. a few thousand seeds before a release)
+N_SEEDS = int(os.environ.get("THJ_FUZZ_SEEDS", "60"))
 
 
 def rand_genome(rng, n_contigs):
@@ -80,7 +85,7 @@ def rand_seg_batch(rng, seqs, n_reads, L, nseg, paired):
     return SegBatch(*args)
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_fuzz_segment_juncs(seed):
     rng = np.random.default_rng(1000 + seed)
     seqs = rand_genome(rng, int(rng.integers(1, 4)))
@@ -152,7 +157,7 @@ def rand_span_batch(rng, seqs, n_reads, L, nseg):
                      np.array(seg_off, dtype=np.uint32), np.array(hits, dtype=SPAN_HIT_DTYPE))
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_fuzz_long_spanning_reads(seed):
     rng = np.random.default_rng(5000 + seed)
     seqs = rand_genome(rng, int(rng.integers(1, 3)))

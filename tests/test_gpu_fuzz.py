@@ -1,5 +1,7 @@
 """GPU: the adversarial batches of test_fuzz_cpu.py through the real kernels and the C ABI (several tiles per batch:
 LDS staging, work lists, rescue list, task queue, the three stitch tiers and their worklists) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,9 +13,10 @@ from tophat_amd.params import Params
 from util import assert_events_equal
 
 pytestmark = pytest.mark.gpu
+N_SEEDS = int(os.environ.get("THJ_FUZZ_SEEDS", "12"))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_fuzz_segment_juncs_gpu(seed):
     rng = np.random.default_rng(9000 + seed)
     seqs = rand_genome(rng, int(rng.integers(1, 4)))
@@ -40,7 +43,7 @@ def test_fuzz_segment_juncs_gpu(seed):
     assert gf.tolist() == wf.tolist()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_fuzz_long_spanning_reads_gpu(seed):
     rng = np.random.default_rng(9500 + seed)
     seqs = rand_genome(rng, int(rng.integers(1, 3)))
