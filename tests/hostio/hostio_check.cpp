@@ -73,6 +73,17 @@ int main(int argc, char** argv) {
         printf("%llu %llu %llu\n", (unsigned long long)groups, (unsigned long long)hits, (unsigned long long)sum);
         return 0;
     }
+    if (mode == "fasta" && argc >= 3) {
+        // hostio_check fasta <ref.fa>  -> one "<name> <length> <checksum>" line per contig
+        RefTable rt;
+        rt.load_fasta(argv[2]);
+        for (size_t i = 0; i < rt.names.size(); ++i) {
+            uint64_t sum = 0;
+            for (char c : rt.seqs[i]) sum = sum * 131ull + (unsigned char)c;
+            printf("%s %zu %llu\n", rt.names[i].c_str(), rt.seqs[i].size(), (unsigned long long)sum);
+        }
+        return 0;
+    }
     if (mode == "reads" && argc >= 3) {
         // hostio_check reads <reads.fq> <id> [<id> ...]  -> one "<id> <seq> <qual>" line per request
         ReadStream rs;

@@ -104,3 +104,28 @@ def test_threaded_read_stream(exe):
     ids = sorted(recs)[::7]
     out = subprocess.check_output([exe, "reads", os.path.join(d, "left.fq")] + [str(i) for i in ids]).decode().strip().split("\n")
     assert [tuple(l.split()) for l in out] == [(str(i), recs[i][0], recs[i][1]) for i in ids]
+
+
+def test_fasta_loader_awkward_input(exe, tmp_path):
+    """get_seqs (segment_juncs.cpp:64-88): names cut at the first blank, bases folded to ACGTN; CRLF, lower case, IUPAC
+    codes, blank lines, an empty record and a missing final newline"""
+    recs = [("chrA desc here", "acgtNNRYacgt" * 50), ("chrB", ""), ("chrC\tx", "ACGT" * 300000 + "nnnn"), ("chrD", "GATTACA")]
+    txt = ""
+    for name, seq in recs:
+        txt += ">" + name + "\r\n"
+        for i in range(0, len(seq), 61):
+            txt += seq[i:i + 61] + ("\r\n" if name.startswith("chrA") else "\n")
+        txt += "\n"
+    fa = str(tmp_path / "awkward.fa")
+    open(fa, "w", newline="").write(txt.rstrip("\n"))
+
+    def cks(s):
+        x = 0
+        for c in s:
+            x = (x * 131 + ord(c)) & 0xFFFFFFFFFFFFFFFF
+        return x
+    fold = lambda s: "".join(c.upper() if c.upper() in "ACGT" else "N" for c in s)
+    exp = ["%s %d %d" % (n.split()[0], len(seq), cks(fold(seq))) for n, seq in recs]
+    for threads in ("1", "5"):
+        out = subprocess.check_output([exe, "fasta", fa], env=dict(os.environ, THJ_HOST_THREADS=threads)).decode().strip().split("\n")
+        assert out == exp

@@ -194,6 +194,15 @@ inline std::string file_ext(const std::string& f) {
     return e;
 }
 
+// Host threading: every input file is inflated / tokenised / parsed by its own reader thread, which hands chunks of
+// finished records to the consumer through a small bounded queue; the consumer (merge by read id, batching) never
+// parses.  THJ_HOST_THREADS bounds the worker count of the parallel stages (default: min(32, hardware threads)).
+inline int host_threads() {
+    int n = getenv("THJ_HOST_THREADS") ? atoi(getenv("THJ_HOST_THREADS")) : 0;
+    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 32) n = 32; }
+    return n < 1 ? 1 : n;
+}
+
 // ------------------------------------------------------------------ reference table (bwt_map.h:579-788)
 struct RefTable {
     std::vector<std::string> names;                 // id-1 -> name, @SQ order then FASTA-only names
@@ -242,32 +251,73 @@ struct RefTable {
         free(line);
         fclose(f);
     }
-    // get_seqs (segment_juncs.cpp:64-88): names cut at the first blank; sequences folded to ACGTN
+    // get_seqs (segment_juncs.cpp:64-88): names cut at the first blank; sequences folded to ACGTN.
+    // The file is read in one piece; record boundaries are found with memchr, every record is folded by its own
+    // share of the worker threads (a 3 Gb genome is a few seconds instead of a char-at-a-time minute).
     void load_fasta(const std::string& fn) {
-        FILE* f = fopen(fn.c_str(), "r");
+        FILE* f = fopen(fn.c_str(), "rb");
         if (!f) die("Error: cannot open %s for reading\n", fn.c_str());
-        char* line = nullptr; size_t cap = 0; ssize_t n;
-        std::string* cur = nullptr;
-        while ((n = getline(&line, &cap, f)) > 0) {
-            if (line[0] == '>') {
-                std::string name(line + 1, (size_t)n - 1);
+        std::vector<char> buf;
+        {
+            fseek(f, 0, SEEK_END);
+            long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            if (sz > 0) {
+                buf.resize((size_t)sz);
+                if (fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) die("Error: cannot read %s\n", fn.c_str());
+            } else {                                  // not seekable (a pipe): read to the end
+                char tmp[1 << 16]; size_t n;
+                while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+            }
+        }
+        fclose(f);
+        struct Rec { uint32_t id; size_t b, e; };                 // sequence text [b, e) of one record
+        std::vector<Rec> recs;
+        const char* d = buf.data(); const size_t n = buf.size();
+        size_t i = 0;
+        while (i < n) {
+            if (d[i] == '>') {
+                const char* nl = (const char*)memchr(d + i, '\n', n - i);
+                size_t le = nl ? (size_t)(nl - d) : n;
+                std::string name(d + i + 1, le - i - 1);
                 size_t e = name.find_first_of(" \t\r\n");
                 if (e != std::string::npos) name.resize(e);
                 uint32_t id = get_id(name);
-                cur = &seqs[id - 1];
-                cur->clear();
-            } else if (cur) {
-                for (ssize_t i = 0; i < n; ++i) {
-                    char c = line[i];
-                    if (c == '\n' || c == '\r' || c == ' ' || c == '\t') continue;
-                    switch (c) { case 'a': case 'A': c = 'A'; break; case 'c': case 'C': c = 'C'; break;
-                                 case 'g': case 'G': c = 'G'; break; case 't': case 'T': c = 'T'; break; default: c = 'N'; }
-                    cur->push_back(c);
+                if (!recs.empty()) recs.back().e = i;
+                recs.push_back({id, le < n ? le + 1 : n, n});
+                i = le < n ? le + 1 : n;
+            } else {                                              // next header: a '>' at the start of a line
+                const char* p = d + i;
+                for (;;) {
+                    const char* nl = (const char*)memchr(p, '\n', (size_t)(d + n - p));
+                    if (!nl || nl + 1 >= d + n) { i = n; break; }
+                    if (nl[1] == '>') { i = (size_t)(nl + 1 - d); break; }
+                    p = nl + 1;
                 }
             }
         }
-        free(line);
-        fclose(f);
+        static const struct Fold { char t[256]; Fold() { for (int c = 0; c < 256; ++c) t[c] = 'N'; t['a'] = t['A'] = 'A'; t['c'] = t['C'] = 'C';
+                                                          t['g'] = t['G'] = 'G'; t['t'] = t['T'] = 'T'; t['\n'] = t['\r'] = t[' '] = t['\t'] = 0; } } fold;
+        const int T = host_threads();
+        for (auto& r : recs) {
+            // pass 1: bases per slice; pass 2: fold into place
+            const size_t len = r.e - r.b;
+            const int parts = (int)std::min<size_t>((size_t)T, len / (1 << 20) + 1);
+            std::vector<size_t> cnt((size_t)parts + 1, 0);
+            auto slice = [&](int k, size_t& a, size_t& b) { a = r.b + len * (size_t)k / (size_t)parts; b = r.b + len * (size_t)(k + 1) / (size_t)parts; };
+            auto run = [&](const std::function<void(int)>& fn) {
+                if (parts == 1) { fn(0); return; }
+                std::vector<std::thread> th;
+                for (int k = 0; k < parts; ++k) th.emplace_back(fn, k);
+                for (auto& x : th) x.join();
+            };
+            run([&](int k) { size_t a, b, c = 0; slice(k, a, b); for (size_t q = a; q < b; ++q) c += fold.t[(unsigned char)d[q]] != 0; cnt[(size_t)k + 1] = c; });
+            for (int k = 0; k < parts; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+            std::string& out = seqs[r.id - 1];
+            out.assign(cnt[(size_t)parts], 'N');
+            run([&](int k) { size_t a, b; slice(k, a, b); char* o = &out[0] + cnt[(size_t)k];
+                             for (size_t q = a; q < b; ++q) { char c = fold.t[(unsigned char)d[q]]; if (c) *o++ = c; } });
+        }
     }
     // pack + upload through the C ABI
     void upload(thj_ctx* ctx) {
@@ -652,15 +702,6 @@ inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p
     out.h32.flags = (uint8_t)(out.h16.flags | (jstrand == "rev" ? THJ_HIT_ANTISENSE_SPLICE : 0));
     out.h32.mismatches = mm8; out.h32.edit_dist = ed; out.h32.n_cigar = (uint8_t)spl.size();
     return true;
-}
-
-// Host threading: every input file is inflated / tokenised / parsed by its own reader thread, which hands chunks of
-// finished records to the consumer through a small bounded queue; the consumer (merge by read id, batching) never
-// parses.  THJ_HOST_THREADS bounds the worker count of the parallel stages (default: min(32, hardware threads)).
-inline int host_threads() {
-    int n = getenv("THJ_HOST_THREADS") ? atoi(getenv("THJ_HOST_THREADS")) : 0;
-    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 32) n = 32; }
-    return n < 1 ? 1 : n;
 }
 
 template <class T>
