@@ -84,6 +84,53 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (mode == "merge" && argc >= 5) {
+        // hostio_check merge <reads.fq> <mate_map|-> <seg1,seg2,...>: the ingest loop of segment_juncs without the device
+        RefTable rt;
+        thj_params p;
+        thj_params_default(&p);
+        std::vector<std::string> segs = split(argv[4], ',');
+        const int nseg = (int)segs.size();
+        std::vector<HitStream> st((size_t)nseg);
+        for (int s2 = 0; s2 < nseg; ++s2) if (!st[(size_t)s2].open(segs[(size_t)s2], rt, p)) return 3;
+        HitStream mate;
+        bool have_mate = std::string(argv[3]) != "-" && mate.open(argv[3], rt, p);
+        ReadStream reads;
+        if (!reads.open(argv[2], "")) return 3;
+        std::vector<std::vector<Hit>> grp((size_t)nseg);
+        std::vector<Hit> mg;
+        std::vector<thj_hit> hits, mate_hits; std::vector<uint32_t> seg_off(1, 0), mate_off(1, 0); std::string bases; std::vector<int64_t> read_off(1, 0);
+        uint64_t nreads = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            uint32_t id = 0;
+            for (int s2 = 0; s2 < nseg; ++s2) { uint32_t g = st[(size_t)s2].next_group_id(); if (g && (id == 0 || g < id)) id = g; }
+            if (id == 0) break;
+            int top = -1;
+            for (int s2 = 0; s2 < nseg; ++s2) {
+                grp[(size_t)s2].clear();
+                if (st[(size_t)s2].next_group_id() == id) { st[(size_t)s2].next_group(grp[(size_t)s2]); top = s2; }
+            }
+            if (top <= 0) continue;
+            Read rd;
+            if (!reads.get(id, rd)) return 5;
+            for (int s2 = 0; s2 < nseg; ++s2) { for (auto& h : grp[(size_t)s2]) hits.push_back(h.h16); seg_off.push_back((uint32_t)hits.size()); }
+            if (have_mate) {
+                mg.clear();
+                while (mate.next_group_id() && mate.next_group_id() < id) mate.skip_group();
+                if (mate.next_group_id() == id) mate.next_group(mg);
+                for (auto& h : mg) mate_hits.push_back(h.h16);
+                mate_off.push_back((uint32_t)mate_hits.size());
+            }
+            bases += rd.seq;
+            read_off.push_back((int64_t)bases.size());
+            ++nreads;
+            if (nreads % (1 << 19) == 0) { hits.clear(); mate_hits.clear(); seg_off.assign(1, 0); mate_off.assign(1, 0); bases.clear(); read_off.assign(1, 0); }
+        }
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("%llu reads in %.3f s = %.3f us/read\n", (unsigned long long)nreads, dt, 1e6 * dt / (double)(nreads ? nreads : 1));
+        return 0;
+    }
     if (mode == "reads" && argc >= 3) {
         // hostio_check reads <reads.fq> <id> [<id> ...]  -> one "<id> <seq> <qual>" line per request
         ReadStream rs;
