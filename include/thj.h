@@ -226,6 +226,21 @@ int thj_fusion_download(thj_ctx* ctx, thj_fusion* out);
 int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches);
 
 
+/* --------------------------------------------------- juncs_db
+ * The step between the two executables (juncs_db.cpp:73-233): FASTA records of the sequence around every junction /
+ * deletion / insertion / fusion, cut from the genome.  The resident bit-plane genome makes this a gather: the caller
+ * lists the pieces it wants, the device writes their bases as ASCII (A C G T N; reverse-complemented when asked, N
+ * stays N) at the byte offsets given, and the caller interleaves its header lines. */
+typedef struct thj_piece {
+    uint32_t ref_id;      /* 1-based */
+    int32_t  start;       /* 0-based first base */
+    int32_t  len;         /* bases; the piece must lie inside the contig */
+    uint32_t flags;       /* THJ_PIECE_RC */
+} thj_piece;
+#define THJ_PIECE_RC 1u
+/* HOST arrays in, HOST bytes out: out[out_off[i] .. out_off[i] + pieces[i].len) receives piece i.  Synchronous. */
+int thj_genome_gather(thj_ctx* ctx, const thj_piece* pieces, int64_t n, const int64_t* out_off, char* out, int64_t out_bytes);
+
 /* --------------------------------------------------- long_spanning_reads */
 
 /* CigarOpCode values of bwt_map.h:36-55, packed as (op << 28) | length. */

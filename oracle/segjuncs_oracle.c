@@ -16,6 +16,7 @@
  */
 #include "thj_oracle.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 
 /* ---------------------------------------------------------------- utils */
@@ -875,4 +876,100 @@ void orc_fusion_filter(orc_fusion* f, int64_t n, const orc_junction* juncs, int6
         }
     }
     free(lc); free(rc_);
+}
+
+/* ===================== juncs_db (juncs_db.cpp:73-233, :298-525) =====================
+ * FASTA text of the junction database: junctions (std::set order: refid, left, right, '+' before '-'), deletions,
+ * insertions (first of equal (refid, left, length) wins), fusions.  Test infrastructure like the rest of this file. */
+typedef struct { char* p; size_t n, cap; } sbuf;
+static void sb_put(sbuf* b, const char* s, size_t n)
+{
+    if (b->n + n + 1 > b->cap) { b->cap = (b->n + n + 1) * 2 + 256; b->p = (char*)realloc(b->p, b->cap); }
+    memcpy(b->p + b->n, s, n); b->n += n; b->p[b->n] = 0;
+}
+static void sb_printf_ll(sbuf* b, long long v) { char t[32]; int n = snprintf(t, sizeof t, "%lld", v); sb_put(b, t, (size_t)n); }
+static void sb_printf_ull(sbuf* b, unsigned long long v) { char t[32]; int n = snprintf(t, sizeof t, "%llu", v); sb_put(b, t, (size_t)n); }
+static char d5c(char c) { return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? c : 'N'; }
+static void sb_ref(sbuf* b, const char* ref, int64_t s, int64_t e, int rc)
+{
+    if (!rc) { for (int64_t i = s; i < e; ++i) { char c = d5c(ref[i]); sb_put(b, &c, 1); } }
+    else for (int64_t i = e - 1; i >= s; --i) {
+        char c = d5c(ref[i]);
+        c = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+        sb_put(b, &c, 1);
+    }
+}
+
+/* print_splice :120-164 */
+static void jd_splice(sbuf* b, const orc_genome* g, const char* const* names, uint32_t ref_id, uint32_t left, uint32_t right,
+                      int read_len, const char* tag)
+{
+    int64_t ref_len; const char* ref = contig(g, ref_id, &ref_len);
+    if (!ref) return;
+    int half = read_len;
+    if (!((int64_t)left <= ref_len && (int64_t)right <= ref_len)) return;     /* the >= 0 tests are vacuous on unsigned fields */
+    int64_t left_start = (int)left - half + 1 >= 0 ? (int)left - half + 1 : 0;
+    int64_t left_end = left_start + half;
+    int64_t right_start = right;
+    int64_t right_end = right_start + half < ref_len ? right_start + half : ref_len;
+    if (!(left_start < left_end && left_end <= ref_len && right_start < right_end && right_end <= ref_len)) return;
+    sb_put(b, ">", 1); sb_put(b, names[ref_id - 1], strlen(names[ref_id - 1])); sb_put(b, "|", 1); sb_printf_ll(b, left_start);
+    sb_put(b, "|", 1); sb_printf_ll(b, left); sb_put(b, "-", 1); sb_printf_ll(b, right); sb_put(b, "|", 1); sb_printf_ll(b, right_end);
+    sb_put(b, "|", 1); sb_put(b, tag, strlen(tag)); sb_put(b, "\n", 1);
+    sb_ref(b, ref, left_start, left_end, 0); sb_ref(b, ref, right_start, right_end, 0); sb_put(b, "\n", 1);
+}
+
+/* juncs[] / dels[] / ins[] / fus[] must already be in their std::set orders with duplicates removed (the caller's
+ * parser does what the reference's fgets loops + set inserts do); dels carry left = file_left - 1 (:385). */
+char* orc_juncs_db(const orc_genome* g, const char* const* names, int read_len, int min_anchor_len,
+                   const orc_junction* juncs, int64_t n_juncs, const orc_junction* dels, int64_t n_dels,
+                   const uint32_t* ins_ref, const uint32_t* ins_left, const char* const* ins_seq, int64_t n_ins,
+                   const orc_fusion* fus, int64_t n_fus)
+{
+    sbuf b = {0, 0, 0};
+    sb_put(&b, "", 0);
+    for (int64_t i = 0; i < n_juncs; ++i)
+        jd_splice(&b, g, names, juncs[i].ref_id, juncs[i].left, juncs[i].right, read_len, juncs[i].antisense ? "GTAG|rev" : "GTAG|fwd");
+    for (int64_t i = 0; i < n_dels; ++i)
+        jd_splice(&b, g, names, dels[i].ref_id, dels[i].left, dels[i].right, read_len, dels[i].antisense ? "del|rev" : "del|fwd");
+    for (int64_t i = 0; i < n_ins; ++i) {                                     /* print_insertion :73-108 */
+        int64_t ref_len; const char* ref = contig(g, ins_ref[i], &ref_len);
+        if (!ref) continue;
+        int half = read_len - min_anchor_len;
+        uint32_t left = ins_left[i];
+        if (!((int64_t)left <= ref_len)) continue;
+        int64_t left_start = (int)left - half + 1 >= 0 ? (int)left - half + 1 : 0;
+        int64_t left_end = left_start + half;
+        int64_t right_start = left_end;
+        int64_t right_end = right_start + half < ref_len ? right_start + half : ref_len;
+        if (!(left_start < left_end && left_end <= ref_len && right_start < right_end && right_end <= ref_len)) continue;
+        const char* nm = names[ins_ref[i] - 1];
+        sb_put(&b, ">", 1); sb_put(&b, nm, strlen(nm)); sb_put(&b, "|", 1); sb_printf_ll(&b, left_start); sb_put(&b, "|", 1);
+        sb_printf_ll(&b, left); sb_put(&b, "-", 1); sb_put(&b, ins_seq[i], strlen(ins_seq[i])); sb_put(&b, "|", 1); sb_printf_ll(&b, right_end);
+        sb_put(&b, "|ins|fwd\n", 9);
+        sb_ref(&b, ref, left_start, left_end, 0); sb_put(&b, ins_seq[i], strlen(ins_seq[i])); sb_ref(&b, ref, right_start, right_end, 0);
+        sb_put(&b, "\n", 1);
+    }
+    for (int64_t i = 0; i < n_fus; ++i) {                                     /* print_fusion :166-233 */
+        int64_t llen, rlen; const char* lref = contig(g, fus[i].ref_id1, &llen); const char* rref = contig(g, fus[i].ref_id2, &rlen);
+        if (!lref || !rref) continue;
+        int half = read_len - min_anchor_len;
+        int64_t fl = fus[i].left, fr = fus[i].right; uint32_t dir = fus[i].dir;
+        if (!(fl < llen && fr < rlen)) continue;
+        int64_t left_start, left_end, right_start, right_end;
+        if (dir == ORC_FUSION_FF || dir == ORC_FUSION_FR) { left_start = fl + 1 >= half ? fl - half + 1 : 0; left_end = left_start + half; }
+        else { left_start = fl; left_end = left_start + half < llen ? left_start + half : llen; }
+        if (dir == ORC_FUSION_FF || dir == ORC_FUSION_RF) { right_start = fr; right_end = right_start + half < rlen ? right_start + half : rlen; }
+        else { right_end = fr + 1; right_start = right_end >= half ? right_end - half : 0; }
+        if (!(left_start < left_end && left_end <= llen && right_start < right_end && right_end <= rlen)) continue;
+        int lrc = dir == ORC_FUSION_RF || dir == ORC_FUSION_RR, rrc = dir == ORC_FUSION_FR || dir == ORC_FUSION_RR;
+        int64_t ls_print = lrc ? left_end - 1 : left_start, re_print = rrc ? right_start - 1 : right_end;
+        const char* d = dir == ORC_FUSION_FR ? "fr" : dir == ORC_FUSION_RF ? "rf" : dir == ORC_FUSION_RR ? "rr" : "ff";
+        const char* ln = names[fus[i].ref_id1 - 1]; const char* rn = names[fus[i].ref_id2 - 1];
+        sb_put(&b, ">", 1); sb_put(&b, ln, strlen(ln)); sb_put(&b, "-", 1); sb_put(&b, rn, strlen(rn)); sb_put(&b, "|", 1);
+        sb_printf_ll(&b, ls_print); sb_put(&b, "|", 1); sb_printf_ll(&b, fl); sb_put(&b, "-", 1); sb_printf_ll(&b, fr); sb_put(&b, "|", 1);
+        sb_printf_ull(&b, (unsigned long long)re_print); sb_put(&b, "|fus|", 5);     /* size_t in the reference: 0 - 1 wraps (:214) */ sb_put(&b, d, 2); sb_put(&b, "\n", 1);
+        sb_ref(&b, lref, left_start, left_end, lrc); sb_ref(&b, rref, right_start, right_end, rrc); sb_put(&b, "\n", 1);
+    }
+    return b.p;
 }

@@ -137,6 +137,13 @@ int orc_fusions_batch(const orc_params* p, int fusion_anchor_length, int fusion_
  * set (sorted).  Returns nothing; entries with skip != 0 are not written. */
 void orc_fusion_filter(orc_fusion* f, int64_t n, const orc_junction* juncs, int64_t n_juncs);
 
+/* juncs_db (juncs_db.cpp): FASTA text of the junction database; inputs already in their std::set orders.  Returns a
+ * malloc'd NUL-terminated string (orc_free). */
+char* orc_juncs_db(const orc_genome* g, const char* const* names, int read_len, int min_anchor_len,
+                   const orc_junction* juncs, int64_t n_juncs, const orc_junction* dels, int64_t n_dels,
+                   const uint32_t* ins_ref, const uint32_t* ins_left, const char* const* ins_seq, int64_t n_ins,
+                   const orc_fusion* fus, int64_t n_fus);
+
 /* ===================== long_spanning_reads (spanning_oracle.c) ===================== */
 
 /* CigarOpCode values of bwt_map.h:36-55 */

@@ -64,6 +64,10 @@ def main():
         with open(os.path.join(d, "options.txt"), "w") as f:
             f.write(" ".join(cfg["opts"]) + "\n")
             f.write("segment_length=%d paired=%d\n" % (cfg["gen"]["seg_len"], cfg["gen"]["paired"]))
+        # juncs_db on the lists just produced (tophat.py:2574-2586: min_anchor 8, max segment length)
+        with open(os.path.join(d, "expected.juncs_db.fa"), "w") as f:
+            subprocess.run([os.path.join(REFBIN, "juncs_db"), "8", str(cfg["gen"]["seg_len"]), outs[0], outs[1], outs[2],
+                            outs[3] if cfg.get("fusion") else "/dev/null", paths["ref"]], check=True, stdout=f, stderr=subprocess.DEVNULL)
         if cfg.get("fusion"):
             continue          # long_spanning_reads with --fusion-search is not part of the fixtures yet
         os.remove(outs[3])

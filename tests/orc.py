@@ -251,3 +251,42 @@ def write_fusions(f: np.ndarray, names, path: str):
                 continue
             fh.write("%s\t%d\t%s\t%d\t%s\n" % (names[x["ref_id1"] - 1], np.int32(x["left"]), names[x["ref_id2"] - 1], np.int32(x["right"]),
                                                DIR[int(x["dir"])]))
+
+
+def juncs_db_text(names, g: Genome, juncs_file, ins_file, del_file, fus_file, read_len: int, min_anchor_len: int) -> str:
+    """orc_juncs_db over the coordinate files, read the way juncs_db.cpp:298-470 reads them (std::set orders,
+    first insertion of a (ref, left, length) wins, insertions with ambiguity codes dropped, deletion left - 1)."""
+    lib = _lib()
+    ids = {n: i + 1 for i, n in enumerate(names)}
+
+    def lines(fn):
+        if not fn or fn == "/dev/null":
+            return []
+        return [l.rstrip("\n").split("\t") for l in open(fn) if l.rstrip("\n")]
+    jset = sorted({(ids[t[0]], int(t[1]), int(t[2]), 1 if t[3][0] == "-" else 0) for t in lines(juncs_file)})
+    dset = sorted({(ids[t[0]], int(t[1]) - 1, int(t[2]), 0) for t in lines(del_file)})
+    ins = {}
+    for t in lines(ins_file):
+        seq = t[3].upper()
+        if any(c not in "ACGT" for c in seq):
+            continue
+        ins.setdefault((ids[t[0]], int(t[1]), len(seq)), seq)
+    iset = sorted(ins.items())
+    dirs = {"ff": 7, "fr": 8, "rf": 9, "rr": 10}
+    fset = sorted({(ids[t[0]], ids[t[2]], int(t[1]), int(t[3]), dirs.get(t[4], 7)) for t in lines(fus_file)})
+    ja = np.array(jset, dtype=JUNC_DTYPE) if jset else np.zeros(0, dtype=JUNC_DTYPE)
+    da = np.array(dset, dtype=JUNC_DTYPE) if dset else np.zeros(0, dtype=JUNC_DTYPE)
+    fa = np.zeros(len(fset), dtype=FUSION_DTYPE)
+    for k, f in enumerate(fset):
+        fa[k]["ref_id1"], fa[k]["ref_id2"], fa[k]["left"], fa[k]["right"], fa[k]["dir"] = f
+    iref = np.array([k[0][0] for k in iset], dtype=np.uint32)
+    ileft = np.array([k[0][1] for k in iset], dtype=np.uint32)
+    iseq = (C.c_char_p * max(1, len(iset)))(*[k[1].encode() for k in iset])
+    nm = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    lib.orc_juncs_db.restype = C.c_void_p
+    out = lib.orc_juncs_db(C.byref(g.c), nm, read_len, min_anchor_len, C.c_void_p(ja.ctypes.data), C.c_int64(len(ja)),
+                           C.c_void_p(da.ctypes.data), C.c_int64(len(da)), C.c_void_p(iref.ctypes.data), C.c_void_p(ileft.ctypes.data),
+                           iseq, C.c_int64(len(iset)), C.c_void_p(fa.ctypes.data), C.c_int64(len(fa)))
+    text = C.string_at(out).decode()
+    lib.orc_free(C.c_void_p(out))
+    return text

@@ -122,6 +122,20 @@ THJ_HD Planes rc_piece(Planes a, int len) {
     return r;
 }
 
+// ---- juncs_db: bases of a genome piece as text (juncs_db.cpp:73-233 print_splice / print_insertion / print_fusion) ----
+// out[0..len) = contig[start .. start+len), or its reverse complement (seqan::reverseComplement on Dna5: N stays N)
+THJ_HD void piece_text(const Genome& g, uint32_t ref_id, int32_t start, int32_t len, bool rc, char* out) {
+    for (int32_t off = 0; off < len; off += 64) {
+        const int l = len - off < 64 ? len - off : 64;
+        const Planes p = g_fetch(g, ref_id, (int64_t)start + off);
+        for (int k = 0; k < l; ++k) {
+            int code = ((p.nm >> k) & 1ull) ? 4 : (int)(((p.lo >> k) & 1ull) | (((p.hi >> k) & 1ull) << 1));
+            if (rc) { if (code < 4) code = 3 - code; out[len - 1 - (off + k)] = "ACGTN"[code]; }
+            else out[off + k] = "ACGTN"[code];
+        }
+    }
+}
+
 // ---- 128-base variants --------------------------------------------------------------------------------------
 // With segment_length > 32 a 2L read piece (indel search) or an L+16 support read (window scan) no longer fits one
 // 64-bit plane word; the same algorithms then run on 128-bit words (two registers per plane, the compiler splits

@@ -1082,3 +1082,46 @@ extern "C" int thj_segjuncs_download(thj_ctx* c, thj_junction* juncs, thj_juncti
     }
     return THJ_OK;
 }
+
+// ------------------------------------------------------------------ juncs_db gather
+
+struct DevPiece { uint32_t ref_id; int32_t start, len; uint32_t flags; };
+static_assert(sizeof(DevPiece) == sizeof(thj_piece), "piece layout");
+
+__global__ __launch_bounds__(256) void thj_k_gather_pieces(Genome g, const DevPiece* pieces, int64_t n, const int64_t* out_off, char* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const DevPiece pc = pieces[i];
+        piece_text(g, pc.ref_id, pc.start, pc.len, (pc.flags & THJ_PIECE_RC) != 0, out + out_off[i]);
+    }
+}
+
+extern "C" int thj_genome_gather(thj_ctx* c, const thj_piece* pieces, int64_t n, const int64_t* out_off, char* out, int64_t out_bytes) {
+    if (!c || n < 0 || (n > 0 && (!pieces || !out_off || !out)) || out_bytes < 0) { thj_set_error("thj_genome_gather: bad argument"); return THJ_EINVAL; }
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    if (n == 0) return THJ_OK;
+    for (int64_t i = 0; i < n; ++i) {
+        const thj_piece& p = pieces[i];
+        if (p.ref_id == 0 || (int32_t)p.ref_id > c->n_contigs || p.start < 0 || p.len < 0 || (int64_t)p.start + p.len > c->h_lens[p.ref_id - 1]) {
+            thj_set_error("piece %lld lies outside contig %u", (long long)i, p.ref_id); return THJ_EINVAL;
+        }
+        if (out_off[i] < 0 || out_off[i] + p.len > out_bytes) { thj_set_error("piece %lld does not fit the output buffer", (long long)i); return THJ_EINVAL; }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    DevPiece* d_p = nullptr; int64_t* d_off = nullptr; char* d_out = nullptr;
+    HIPCHK(hipMalloc(&d_p, (size_t)n * sizeof(DevPiece)));
+    HIPCHK(hipMalloc(&d_off, (size_t)n * 8));
+    HIPCHK(hipMalloc(&d_out, (size_t)(out_bytes ? out_bytes : 1)));
+    HIPCHK(hipMemcpyAsync(d_p, pieces, (size_t)n * sizeof(DevPiece), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_off, out_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    int64_t blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(thj_k_gather_pieces, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, (const DevPiece*)d_p, n, (const int64_t*)d_off, d_out);
+    // only the bytes the pieces cover are defined on the device; the caller's other bytes (headers, newlines) stay as they are
+    std::vector<char> tmp((size_t)out_bytes);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < n; ++i) memcpy(out + out_off[i], tmp.data() + out_off[i], (size_t)pieces[i].len);
+    hipFree(d_p); hipFree(d_off); hipFree(d_out);
+    return THJ_OK;
+}
+

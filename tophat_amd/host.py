@@ -58,7 +58,7 @@ ABI_SYMBOLS = [
     "thj_segjuncs_finish", "thj_segjuncs_download", "thj_segjuncs_device_keys",
     "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
-    "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_fusion_finish", "thj_fusion_download",
+    "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_genome_gather", "thj_fusion_finish", "thj_fusion_download",
 ]
 
 _lib = None
