@@ -317,7 +317,7 @@ def main():
     result = None
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N=1 only
             import orc
             from tophat_amd.batch import events_to_span_inputs, merge_events
             m = min(args.cpu_sample, args.pairs)
