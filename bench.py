@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--introns", type=int, default=20000)
     ap.add_argument("--exon-len", type=int, default=300)
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE configs[1]: 100; 150 / 50 are the shapes of configs[3] / [4])")
+    ap.add_argument("--multihit-frac", type=float, default=0.0,
+                    help="fraction of reads whose segment hits are all reported at two loci (the genome's second half becomes a copy "
+                         "of the first): exercises the multihit tier; 0 = BASELINE configs[1] as specified")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -155,6 +158,11 @@ def main():
     contig_lens = [args.genome_len] if args.genome == "chr20" else GRCH38_LENS
     args.genome_len = int(sum(contig_lens))
     seqs, genes = make_scale_genome(1, contig_lens, args.introns, exon_len=args.exon_len)
+    dup_shift = 0
+    if args.multihit_frac > 0:                       # two-copy genome: [H, 2H) := [0, H), genes of the first copy only
+        dup_shift = len(seqs[0]) // 2
+        seqs[0][dup_shift:2 * dup_shift] = seqs[0][:dup_shift]
+        genes = genes[(genes[:, 0] == 0) & (genes[:, 3] + args.exon_len + 1000 < dup_shift)]
     lib = host.load_lib()
     strs = [s.tobytes().decode() for s in seqs]
     pg = host.pack_genome(strs, lib=lib)
@@ -162,7 +170,7 @@ def main():
     ctx = host.Context(local_rank, stream=stream.cuda_stream)
     ctx.upload_genome(pg)
     w = make_device_workload(100 + rank, seqs, genes, None, args.pairs, dev, read_len=args.read_len, seg_len=25,
-                             inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len)
+                             inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len, multi_frac=args.multihit_frac, dup_shift=dup_shift)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     p_left = Params(read_side=READ_LEFT, inner_dist_mean=50, inner_dist_std_dev=20)
@@ -266,18 +274,19 @@ def main():
     seg_alg = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1) \
         + (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
-    # stage 2, three kernels per launch.  Per finished read: 38 B of read planes, two 64-B genome lines (consistency
+    # stage 2, four kernels per launch.  Per finished read: 38 B of read planes, two 64-B genome lines (consistency
     # check + MD pass share them) and its 128-B record; tier 0 streams every read's CSR row and 32-B hit records;
-    # tiers 1/2 re-read CSR + hits of their worklist reads (4-B list entry each) and one 64-B line of junction keys
+    # tiers 1/2/3 re-read CSR + hits of their worklist reads (4-B list entry each) and one 64-B line of junction keys
     # per closure.  Counters come from the kernels (tier sizes of the last launch, record count of the step).
-    n_lean, n_multi = ctx.span_tier_counts()
+    n_lean, n_multi, n_gen = ctx.span_tier_counts()
     hits_per_read = float(int(w["left"]["span_off"][-1]) + int(w["right"]["span_off"][-1])) / (2.0 * args.pairs)
     rec_per_read = n_alns / (2.0 * args.pairs)
     per_read_done = rl_bytes + rec_per_read * (128 + 128)
     n_t0 = args.pairs - n_lean - n_multi
     t0_alg = 4.0 * (args.pairs * nseg + 1) + 32.0 * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
     t1_alg = n_lean * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
-    t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
+    t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64) + 4.0 * n_gen
+    t3_alg = n_gen * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     # thj_k_segjuncs_rescue: per (hit, mate hit) pair the read, its CSR row + hits, the mate hit and ~3 genome lines of flank
     resc_alg = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 192)
     kernels = [
@@ -286,6 +295,7 @@ def main():
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
         {"kernel": "thj_k_stitch_multihit", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
+        {"kernel": "thj_k_stitch_generic", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
     ]
     for k in kernels:
         k["achieved"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0
@@ -297,7 +307,7 @@ def main():
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.read_len == 100 and args.genome == "chr20" and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
+        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
             for k in kernels:
                 c = pm["kernels"].get(k["kernel"])
                 if c:
@@ -309,9 +319,9 @@ def main():
     dom = max(kernels, key=lambda k: k["avg_kernel_ms"])
 
     workload_text = ("%s: %d x 2x%d bp PE synthetic vs %d bp %s genome per GPU, inputs resident in HBM; both stages on device: "
-                     "segment_juncs (main + rescue kernels, event dedup+sort%s) then long_spanning_reads (three stitch tiers fed "
+                     "segment_juncs (main + rescue kernels, event dedup+sort%s) then long_spanning_reads (four stitch tiers fed "
                      "device-to-device with the junction set; records land in BAM order)"
-                     % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" else "shape of another config", args.pairs,
+                     % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 else "shape of another config", args.pairs,
                         args.read_len, args.genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
                         ", RCCL all-gather of event keys" if use_dist else ""))
     result = None

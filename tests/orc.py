@@ -4,6 +4,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+
+from locked_make import locked_make
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -19,7 +21,7 @@ def _lib():
     so = os.path.join(ORC_DIR, "liborc.so")
     srcs = [os.path.join(ORC_DIR, f) for f in os.listdir(ORC_DIR) if f.endswith((".c", ".h"))]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", ORC_DIR, "-s"])
+        locked_make(ORC_DIR)
     return C.CDLL(so)
 
 

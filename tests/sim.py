@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import subprocess
 
+from locked_make import locked_make
+
 import numpy as np
 
 from tophat_amd import host
@@ -16,7 +18,7 @@ HS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
 
 def lib():
     so = os.path.join(HS_DIR, "libhostsim.so")
-    subprocess.check_call(["make", "-C", HS_DIR, "-s"])
+    locked_make(HS_DIR)
     l = C.CDLL(so)
     l.thj_last_error.restype = C.c_char_p
     return l

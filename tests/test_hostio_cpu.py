@@ -3,6 +3,8 @@ the threaded BGZF/BAM writer (+ its `.index` side file, common.h:562-606) and th
 import os
 import struct
 import subprocess
+
+from locked_make import locked_make
 import zlib
 
 import pytest
@@ -17,7 +19,7 @@ EXE = os.path.join(HERE, "hostio", "hostio_check")
 
 @pytest.fixture(scope="module")
 def exe():
-    subprocess.check_call(["make", "-C", os.path.join(HERE, "hostio"), "-s"])
+    locked_make(os.path.join(HERE, "hostio"))
     return EXE
 
 

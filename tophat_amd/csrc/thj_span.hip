@@ -67,9 +67,9 @@ struct RecSink {
 // reads [b*chunk, (b+1)*chunk) in tier 0 and the slice [b*chunk, ..) of both lists in every tier; positions come
 // from an LDS counter, per-block totals go to blk_lean / blk_multi, and global counters see one add per block.
 struct Tiers {
-    uint32_t* wl_lean; uint32_t* wl_multi;
-    unsigned int* blk_lean; unsigned int* blk_multi;
-    unsigned int* counters;          // [0] reads handed to tier 1, [1] to tier 2 (this run)
+    uint32_t* wl_lean; uint32_t* wl_multi; uint32_t* wl_gen;
+    unsigned int* blk_lean; unsigned int* blk_multi; unsigned int* blk_gen;
+    unsigned int* counters;          // reads handed to [0] tier 1, [1] tier 2, [2] tier 3 (this run)
     int chunk;
 };
 
@@ -183,15 +183,41 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
 }
 
-// Tier 2: the general per-read DFS (multihit segments) over its list.
-__global__ __launch_bounds__(128) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+// Tier 2: multihit reads -- the DFS over one hit per segment with every chain joined on the lean machinery
+// (span_read_multi).  Reads it cannot hold (more cigar ops or joined hits than its registers / small arrays) go on
+// to tier 3.
+__global__ __launch_bounds__(256, 4) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    extern __shared__ uint4 lds_stage[];          // nseg hits per thread
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
-    const unsigned int total = slice_offsets<128>(t.blk_multi, G, s_off);
-    for (unsigned int i = blockIdx.x * 128 + threadIdx.x; i < total; i += gridDim.x * 128) {
+    SpanHit* stage = (SpanHit*)lds_stage + (size_t)threadIdx.x * b.nseg;
+    const unsigned int total = slice_offsets<256>(t.blk_multi, G, s_off);
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])];
+        int st = span_read_multi(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, stage, sink);
+        if (st == SPAN_NEED_GENERIC) {
+            t.wl_gen[(int64_t)sl * t.chunk + atomicAdd(&t.blk_gen[sl], 1u)] = (uint32_t)r;
+            atomicAdd(&t.counters[2], 1u);
+        } else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
+    }
+    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
+}
+
+// Tier 3: the general per-read DFS on arrays (span_read) for what is left: joined alignments with more than
+// LEAN_C cigar ops, reads with more than MULTI_MAXJOIN joined hits.
+__global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    __shared__ unsigned int s_off[MAX_SLICES + 1];
+    __shared__ unsigned int s_rec;
+    if (threadIdx.x == 0) s_rec = 0;
+    const unsigned int total = slice_offsets<128>(t.blk_gen, G, s_off);
+    for (unsigned int i = blockIdx.x * 128 + threadIdx.x; i < total; i += gridDim.x * 128) {
+        const int sl = slice_of(s_off, G, i);
+        const int r = (int)t.wl_gen[(int64_t)sl * t.chunk + (i - s_off[sl])];
         int st = span_read(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                            (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
         sink.done((uint32_t)r);
@@ -454,7 +480,7 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     int64_t chunk = ((int64_t)b.n_reads + G - 1) / G;
     chunk = (chunk + 255) / 256 * 256;
     G = ((int64_t)b.n_reads + chunk - 1) / chunk;
-    const int64_t wl_need = 2 * G * chunk + 2 * MAX_SLICES;
+    const int64_t wl_need = 3 * G * chunk + 3 * MAX_SLICES;
     if (c->worklist_cap < wl_need) {
         hipFree(c->d_worklist); c->d_worklist = nullptr;
         HIPCHK(hipMalloc(&c->d_worklist, (size_t)wl_need * 4));
@@ -463,12 +489,15 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     Tiers t;
     t.wl_lean = c->d_worklist;
     t.wl_multi = c->d_worklist + G * chunk;
-    t.blk_lean = c->d_worklist + 2 * G * chunk;
+    t.wl_gen = c->d_worklist + 2 * G * chunk;
+    t.blk_lean = c->d_worklist + 3 * G * chunk;
     t.blk_multi = t.blk_lean + MAX_SLICES;
+    t.blk_gen = t.blk_multi + MAX_SLICES;
     t.counters = &c->d_span_status[4];
     t.chunk = (int)chunk;
-    HIPCHK(hipMemsetAsync(t.counters, 0, 8, c->stream));
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    HIPCHK(hipMemsetAsync(t.counters, 0, 12, c->stream));
+    HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, c->stream));      // tiers 0 / 1 write the other two
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
@@ -477,12 +506,12 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
-    hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)g2), dim3(128), 0, c->stream, g, p, S, b, sink, t, (int)G);
+    hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)g2), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+    if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
+    hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), 0, c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) {
-        HIPCHK(hipEventRecord(ev[3], c->stream));
-        c->span_prof_events.emplace_back(ev[0], ev[1]);
-        c->span_prof_events.emplace_back(ev[1], ev[2]);
-        c->span_prof_events.emplace_back(ev[2], ev[3]);
+        HIPCHK(hipEventRecord(ev[4], c->stream));
+        for (int k = 0; k < 4; ++k) c->span_prof_events.emplace_back(ev[k], ev[k + 1]);
     }
     HIPCHK(hipGetLastError());
     c->span_reads += b.n_reads;
@@ -561,37 +590,37 @@ extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
 }
 
 extern "C" int thj_span_tier_counts(thj_ctx* c, int64_t* counts) {
-    // reads the last thj_span_run_async handed to tier 1 (closure reads) and tier 2 (multihit reads)
+    // reads the last thj_span_run_async handed to tier 1 (closure reads), tier 2 (multihit reads), tier 3 (general arrays)
     if (!c || !counts) { thj_set_error("thj_span_tier_counts: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_span_state(c);
     if (rc) return rc;
-    unsigned int h[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(h, &c->d_span_status[4], 8, hipMemcpyDeviceToHost, c->stream));
+    unsigned int h[3] = {0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, &c->d_span_status[4], 12, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    counts[0] = h[0]; counts[1] = h[1];
+    counts[0] = h[0]; counts[1] = h[1]; counts[2] = h[2];
     return THJ_OK;
 }
 
 extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
-    // avg_ms[3]: thj_k_stitch_contig, thj_k_stitch, thj_k_stitch_multihit (one triple per thj_span_run_async)
+    // avg_ms[4]: thj_k_stitch_contig, thj_k_stitch, thj_k_stitch_multihit, thj_k_stitch_generic (one set per thj_span_run_async)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    double sum[3] = {0, 0, 0};
-    size_t n = c->span_prof_events.size() / 3;
+    double sum[4] = {0, 0, 0, 0};
+    size_t n = c->span_prof_events.size() / 4;
     for (size_t i = 0; i < c->span_prof_events.size(); ++i) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->span_prof_events[i].first, c->span_prof_events[i].second));
-        sum[i % 3] += ms;
+        sum[i % 4] += ms;
     }
     // events are shared between consecutive pairs: return each distinct one to the pool once
     for (size_t i = 0; i < c->span_prof_events.size(); ++i) {
-        if (i % 3 == 0) c->event_pool.push_back(c->span_prof_events[i].first);
+        if (i % 4 == 0) c->event_pool.push_back(c->span_prof_events[i].first);
         c->event_pool.push_back(c->span_prof_events[i].second);
     }
     if (launches) *launches = (int64_t)n;
-    if (avg_ms) for (int k = 0; k < 3; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
+    if (avg_ms) for (int k = 0; k < 4; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
     c->span_prof_events.clear();
     c->span_profile = enable != 0;
     return THJ_OK;

@@ -772,7 +772,128 @@ THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
     return 0;
 }
 
-// `stage`: room for the read's nseg hits (LDS in the kernel).  The hits of a one-hit-per-segment read are
+// ---- lean machinery shared by tiers 1 and 2 -----------------------------------------------------------------
+// lean_join: ONE chain -- hits[s] is the hit chosen for segment s -- through merge_chain on register cigars.
+enum { LJ_NONE = 0, LJ_OK = 1, LJ_PUNT = 2 };       // no alignment / `res` holds the joined hit / needs more cigar ops than LEAN_C
+THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, int nsegs,
+                     const u64* rp, int W, int rl, RAln& res) {
+    const int L = p.segment_length;
+    const SpanHit h0 = hits[0];
+    const bool anti = (h0.meta & SH_ANTI) != 0;
+    if (nsegs == 1) {
+        res = raln_from_hit(h0, 0, L, rl);
+    } else {
+        // dfs_seg_hits compatibility of the single candidate per segment (:2352-2378, :2531-2556)
+        int old_read_length = 0, num_fusions = 0;
+        {
+            RAln prev = raln_from_hit(h0, 0, L, rl);
+            int prev_right = prev.left + rc_ref_span(prev.c, prev.n);
+            old_read_length = rc_read_span(prev.c, prev.n);
+            for (int s = 1; s < nsegs; ++s) {
+                RAln cand = raln_from_hit(hits[s], s, L, rl);
+                const int cand_right = cand.left + rc_ref_span(cand.c, cand.n);
+                if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return LJ_NONE;
+                int dist = prev.anti ? prev.left - cand_right : cand.left - prev_right;
+                if (dist > p.max_report_intron || dist < -p.max_insertion_length) return LJ_NONE;
+                if (gap_is_fusion_like(p, dist)) ++num_fusions;          // merge_chain pre-check (:843-891): same gaps, chain order
+                old_read_length += rc_read_span(cand.c, cand.n);
+                prev.ref_id = cand.ref_id; prev.anti = cand.anti; prev.left = cand.left; prev_right = cand_right;
+            }
+        }
+        if (num_fusions >= 2) return LJ_NONE;
+        if (THJ_EXPF(512)) return LJ_NONE;
+        SeqView sv = anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
+        RChainOut co;
+#pragma unroll
+        for (int k = 0; k < LEAN_C; ++k) co.c.v[k] = 0;
+        co.n = 0; co.saw_as = co.saw_s = false; co.num_mm = 0;
+        const int k0 = anti ? nsegs - 1 : 0, step = anti ? -1 : 1;
+        RAln prev = raln_from_hit(hits[k0], k0, L, rl);
+        const int left0 = prev.left;
+        int P = prev.rlen;
+        for (int q = 1; q < nsegs; ++q) {
+            const int k = k0 + q * step;
+            const RAln curr = raln_from_hit(hits[k], k, L, rl);
+            // merge_chain's main loop, one adjacent pair (:900-1870)
+            const uint32_t plast = prev.c.get(prev.n - 1), cfirst = curr.c.v[0];
+            if (!(op_is_match(cig_op(plast)) || op_is_match(cig_op(cfirst)))) return LJ_NONE;               // :924-928
+            const bool psp = rc_spliced(prev.c, prev.n), csp = rc_spliced(curr.c, curr.n);
+            if (psp && csp && prev.asplice != curr.asplice) return LJ_NONE;                                  // :936-943
+            if (prev.ref_id != curr.ref_id) return LJ_NONE;
+            const Closure cl = closure_search(g, p, S, sv, P, prev.ref_id, prev.left + rc_ref_span(prev.c, prev.n), (int)cig_len(plast),
+                                              curr.left, (int)cig_len(cfirst), prev.anti == curr.anti);
+            if (cl.kind == CL_FAIL) return LJ_NONE;
+            P += curr.rlen;
+            if (cl.kind == CL_KEEP) {
+                const int rc = rchain_add(co, prev);
+                if (rc) return rc == 2 ? LJ_PUNT : LJ_NONE;
+                prev = curr;
+                continue;
+            }
+            if (prev.n + 1 + curr.n > LEAN_C) return LJ_PUNT;
+            int anti_closure = psp ? prev.asplice : curr.asplice;
+            int nn = prev.n, first;
+            uint32_t flen;
+            if (cl.kind == CL_INS) {
+                const uint32_t bl = (cig_len(plast) - (uint32_t)cl.itpr) & 0x0FFFFFFFu;
+                if (bl == 0) --nn; else prev.c.set(nn - 1, cig(cig_op(plast), bl));
+                prev.c.set(nn++, cig(OP_INS, (uint32_t)cl.ilen));
+                flen = (cig_len(cfirst) + (uint32_t)(cl.itpr - cl.ilen)) & 0x0FFFFFFFu;
+                first = flen > 0 ? 0 : 1;
+            } else {
+                const int nlb = (int)cig_len(plast) + cl.dtl, nrf = (int)cig_len(cfirst) - cl.dtl;
+                if (nlb > 0) prev.c.set(nn - 1, cig(cig_op(plast), (uint32_t)nlb)); else --nn;
+                if ((uint32_t)cl.skip <= (uint32_t)p.max_deletion_length) prev.c.set(nn++, cig(OP_DEL, (uint32_t)cl.skip));
+                else { prev.c.set(nn++, cig(OP_REF_SKIP, (uint32_t)cl.skip)); anti_closure = cl.janti; }
+                flen = (uint32_t)nrf;
+                first = nrf > 0 ? 0 : 1;
+            }
+#pragma unroll
+            for (int b = 0; b < 5; ++b)
+                if (b >= first && b < curr.n) prev.c.set(nn++, b == 0 ? cig(cig_op(cfirst), flen) : curr.c.v[b]);
+            const int mismatches = prev.mm + curr.mm + cl.mismatch;                                          // :1822-1870
+            prev.n = nn; prev.asplice = anti_closure;
+            prev.mm = mismatches & 0xFF;
+            prev.ed = (mismatches + rc_gap_len(prev.c, nn)) & 0xFF;
+            prev.rlen += curr.rlen;
+        }
+        {
+            const int rc = rchain_add(co, prev);
+            if (rc) return rc == 2 ? LJ_PUNT : LJ_NONE;
+        }
+        if (THJ_EXPF(1024)) return LJ_NONE;
+        res.c = co.c; res.n = co.n;
+        res.ref_id = h0.ref_id; res.left = left0; res.anti = anti ? 1 : 0; res.asplice = co.saw_as ? 1 : 0;
+        res.mm = co.num_mm & 0xFF; res.ed = (co.num_mm + rc_gap_len(co.c, co.n)) & 0xFF;
+        res.rlen = rl; res.valid = 1;
+        if (rc_read_span(res.c, res.n) != old_read_length) return LJ_NONE;
+    }
+    return LJ_OK;
+}
+
+// lean_finish: filters of JoinSegmentsWorker (:2810-2813), check_editdist_consistency, bowtie_sam_extra, the record.
+// `order` = rank of the record among the read's output records, advanced when one is emitted.
+template <class Sink>
+THJ_HD int lean_finish(const Genome& g, const Params& p, const RAln& res, int nsegs, const u64* rp, int W, int rl,
+                       const uint8_t* qual, uint32_t read_idx, int& order, Sink& sink) {
+    if (!valid_hit(p, res)) return SPAN_OK;
+    int gapl = (res.ed - res.mm) & 0xFF;
+    if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return SPAN_OK;
+    SeqView sv = res.anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
+    bool qrev;
+    if (nsegs == 1) qrev = res.anti;
+    else qrev = res.anti ? !read_is_own_revcomp(rp, W, rl) : false;
+    Extras e;
+    const bool md_fits = sam_extra(g, p, res, sv, qual, rl, qrev, e);
+    // check_editdist_consistency (done inside merge_chain in the reference) shares sam_extra's counts
+    if (nsegs > 1 && !(e.XM == res.mm || e.XM + e.both_n == res.mm)) return SPAN_OK;
+    if (!md_fits) return SPAN_MD_OVERFLOW;          // only for a hit that would really be reported
+    emit_aln(sink, read_idx, order, res, e);
+    ++order;
+    return SPAN_OK;
+}
+
+// Tier 1.  `stage`: room for the read's nseg hits (LDS in the kernel).  The hits of a one-hit-per-segment read are
 // consecutive records: they are fetched once, back to back, and every later step reads the staged copy instead of
 // paying another HBM round trip.
 template <int MS = SPAN_MAXSEG, class Sink>
@@ -813,114 +934,117 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     const SpanHit* hits = stage;             // from here on: segment s's hit is hits[s]
     if (!(hits[nsegs - 1].meta & SH_END)) return SPAN_OK;
     if (THJ_EXPF(256)) return SPAN_OK;
-    const int L = p.segment_length;
-    const SpanHit h0 = hits[0];
-    const bool anti = (h0.meta & SH_ANTI) != 0;
     RAln res;
-    if (nsegs == 1) {
-        res = raln_from_hit(h0, 0, L, rl);
-    } else {
-        // dfs_seg_hits compatibility of the single candidate per segment (:2352-2378, :2531-2556)
-        int old_read_length = 0, num_fusions = 0;
-        {
-            RAln prev = raln_from_hit(h0, 0, L, rl);
-            int prev_right = prev.left + rc_ref_span(prev.c, prev.n);
-            old_read_length = rc_read_span(prev.c, prev.n);
-            for (int s = 1; s < nsegs; ++s) {
-                RAln cand = raln_from_hit(hits[s], s, L, rl);
-                const int cand_right = cand.left + rc_ref_span(cand.c, cand.n);
-                if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return SPAN_OK;
-                int dist = prev.anti ? prev.left - cand_right : cand.left - prev_right;
-                if (dist > p.max_report_intron || dist < -p.max_insertion_length) return SPAN_OK;
-                if (gap_is_fusion_like(p, dist)) ++num_fusions;          // merge_chain pre-check (:843-891): same gaps, chain order
-                old_read_length += rc_read_span(cand.c, cand.n);
-                prev.ref_id = cand.ref_id; prev.anti = cand.anti; prev.left = cand.left; prev_right = cand_right;
-            }
-        }
-        if (num_fusions >= 2) return SPAN_OK;
-        if (THJ_EXPF(512)) return SPAN_OK;
-        SeqView sv = anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
-        RChainOut co;
-#pragma unroll
-        for (int k = 0; k < LEAN_C; ++k) co.c.v[k] = 0;
-        co.n = 0; co.saw_as = co.saw_s = false; co.num_mm = 0;
-        const int k0 = anti ? nsegs - 1 : 0, step = anti ? -1 : 1;
-        RAln prev = raln_from_hit(hits[k0], k0, L, rl);
-        const int left0 = prev.left;
-        int P = prev.rlen;
-        for (int q = 1; q < nsegs; ++q) {
-            const int k = k0 + q * step;
-            const RAln curr = raln_from_hit(hits[k], k, L, rl);
-            // merge_chain's main loop, one adjacent pair (:900-1870)
-            const uint32_t plast = prev.c.get(prev.n - 1), cfirst = curr.c.v[0];
-            if (!(op_is_match(cig_op(plast)) || op_is_match(cig_op(cfirst)))) return SPAN_OK;               // :924-928
-            const bool psp = rc_spliced(prev.c, prev.n), csp = rc_spliced(curr.c, curr.n);
-            if (psp && csp && prev.asplice != curr.asplice) return SPAN_OK;                                  // :936-943
-            if (prev.ref_id != curr.ref_id) return SPAN_OK;
-            const Closure cl = closure_search(g, p, S, sv, P, prev.ref_id, prev.left + rc_ref_span(prev.c, prev.n), (int)cig_len(plast),
-                                              curr.left, (int)cig_len(cfirst), prev.anti == curr.anti);
-            if (cl.kind == CL_FAIL) return SPAN_OK;
-            P += curr.rlen;
-            if (cl.kind == CL_KEEP) {
-                const int rc = rchain_add(co, prev);
-                if (rc) return rc == 2 ? SPAN_NEED_GENERIC : SPAN_OK;
-                prev = curr;
-                continue;
-            }
-            if (prev.n + 1 + curr.n > LEAN_C) return SPAN_NEED_GENERIC;
-            int anti_closure = psp ? prev.asplice : curr.asplice;
-            int nn = prev.n, first;
-            uint32_t flen;
-            if (cl.kind == CL_INS) {
-                const uint32_t bl = (cig_len(plast) - (uint32_t)cl.itpr) & 0x0FFFFFFFu;
-                if (bl == 0) --nn; else prev.c.set(nn - 1, cig(cig_op(plast), bl));
-                prev.c.set(nn++, cig(OP_INS, (uint32_t)cl.ilen));
-                flen = (cig_len(cfirst) + (uint32_t)(cl.itpr - cl.ilen)) & 0x0FFFFFFFu;
-                first = flen > 0 ? 0 : 1;
-            } else {
-                const int nlb = (int)cig_len(plast) + cl.dtl, nrf = (int)cig_len(cfirst) - cl.dtl;
-                if (nlb > 0) prev.c.set(nn - 1, cig(cig_op(plast), (uint32_t)nlb)); else --nn;
-                if ((uint32_t)cl.skip <= (uint32_t)p.max_deletion_length) prev.c.set(nn++, cig(OP_DEL, (uint32_t)cl.skip));
-                else { prev.c.set(nn++, cig(OP_REF_SKIP, (uint32_t)cl.skip)); anti_closure = cl.janti; }
-                flen = (uint32_t)nrf;
-                first = nrf > 0 ? 0 : 1;
-            }
-#pragma unroll
-            for (int b = 0; b < 5; ++b)
-                if (b >= first && b < curr.n) prev.c.set(nn++, b == 0 ? cig(cig_op(cfirst), flen) : curr.c.v[b]);
-            const int mismatches = prev.mm + curr.mm + cl.mismatch;                                          // :1822-1870
-            prev.n = nn; prev.asplice = anti_closure;
-            prev.mm = mismatches & 0xFF;
-            prev.ed = (mismatches + rc_gap_len(prev.c, nn)) & 0xFF;
-            prev.rlen += curr.rlen;
-        }
-        {
-            const int rc = rchain_add(co, prev);
-            if (rc) return rc == 2 ? SPAN_NEED_GENERIC : SPAN_OK;
-        }
-        if (THJ_EXPF(1024)) return SPAN_OK;
-        res.c = co.c; res.n = co.n;
-        res.ref_id = h0.ref_id; res.left = left0; res.anti = anti ? 1 : 0; res.asplice = co.saw_as ? 1 : 0;
-        res.mm = co.num_mm & 0xFF; res.ed = (co.num_mm + rc_gap_len(co.c, co.n)) & 0xFF;
-        res.rlen = rl; res.valid = 1;
-        if (rc_read_span(res.c, res.n) != old_read_length) return SPAN_OK;
-    }
-    if (!valid_hit(p, res)) return SPAN_OK;
-    int gapl = (res.ed - res.mm) & 0xFF;
-    if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return SPAN_OK;
-    SeqView sv = res.anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
-    bool qrev;
-    if (nsegs == 1) qrev = res.anti;
-    else qrev = res.anti ? !read_is_own_revcomp(rp, W, rl) : false;
-    Extras e;
-    const bool md_fits = sam_extra(g, p, res, sv, qual, rl, qrev, e);
-    // check_editdist_consistency (done inside merge_chain in the reference) shares sam_extra's counts
-    if (nsegs > 1 && !(e.XM == res.mm || e.XM + e.both_n == res.mm)) return SPAN_OK;
-    if (!md_fits) return SPAN_MD_OVERFLOW;          // only for a hit that would really be reported
-    emit_aln(sink, read_idx, 0, res, e);
-    return SPAN_OK;
+    const int jr = lean_join(g, p, S, hits, nsegs, rp, W, rl, res);
+    if (jr == LJ_PUNT) return SPAN_NEED_GENERIC;
+    if (jr == LJ_NONE) return SPAN_OK;
+    int order = 0;
+    return lean_finish(g, p, res, nsegs, rp, W, rl, qual, read_idx, order, sink);
 }
 
+
+// ---- tier 2: multihit reads on the lean machinery -----------------------------------------------------------
+// dfs_seg_hits (long_spanning_reads.cpp:2222-2610) over one hit per segment as in the generic span_read, but every
+// complete chain is staged (its nsegs chosen hits) and joined with lean_join on register cigars, and the joined hits
+// are kept as compact RAln records.  Reads that need more cigar ops (LJ_PUNT) or more than MULTI_MAXJOIN joined hits
+// return SPAN_NEED_GENERIC and are redone by span_read, whose arrays have room for them.
+static constexpr int MULTI_MAXJOIN = 16;
+THJ_HD bool raln_less(const RAln& a, const RAln& b) {          // BowtieHit::operator< (bwt_map.h:180-207)
+    if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+    if (a.left != b.left) return a.left < b.left;
+    if (a.anti != b.anti) return a.anti < b.anti;
+    if (a.mm != b.mm) return a.mm < b.mm;
+    if (a.ed != b.ed) return a.ed < b.ed;
+    if (a.n != b.n) return a.n < b.n;
+#pragma unroll
+    for (int i = 0; i < LEAN_C; ++i)
+        if (i < a.n && a.c.v[i] != b.c.v[i]) {
+            const int oa = cig_op(a.c.v[i]), ob = cig_op(b.c.v[i]);
+            return oa < ob || (oa == ob && cig_len(a.c.v[i]) < cig_len(b.c.v[i]));
+        }
+    return false;
+}
+THJ_HD bool raln_eq(const RAln& a, const RAln& b) {            // BowtieHit::operator== (bwt_map.h:167-178)
+    if (a.ref_id != b.ref_id || a.anti != b.anti || a.left != b.left || a.asplice != b.asplice || a.ed != b.ed || a.n != b.n) return false;
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < LEAN_C; ++i) same = same && (i >= a.n || a.c.v[i] == b.c.v[i]);
+    return same;
+}
+
+template <class Sink>
+THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
+                           const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHit* stage, Sink& sink) {
+    if (so[1] == so[0]) return SPAN_OK;                         // worker iterates over first-segment groups
+    int nsegs = 0;
+    while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;   // look_right stops at the first empty segment (:151)
+    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
+    if (!(ghits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;   // :2777-2785
+    if (p.bowtie2)
+        for (int s = 0; s < nsegs; ++s)
+            if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;   // :2625-2632
+    const int L = p.segment_length;
+    RAln joined[MULTI_MAXJOIN]; int nj = 0;
+    uint32_t idx[SPAN_MAXSEG];               // next candidate of each depth
+    int pleft[SPAN_MAXSEG], pright[SPAN_MAXSEG];   // left / right of the hit chosen at each depth
+    for (uint32_t i0 = so[0]; i0 < so[1]; ++i0) {                // :2634-2664
+        stage[0] = ghits[i0];
+        const uint32_t ref0 = stage[0].ref_id;
+        const bool anti0 = (stage[0].meta & SH_ANTI) != 0;
+        {
+            const RAln a0 = raln_from_hit(stage[0], 0, L, rl);
+            pleft[0] = a0.left; pright[0] = a0.left + rc_ref_span(a0.c, a0.n);
+        }
+        int num_try = 10000;
+        int depth = 1;
+        idx[1] = so[1];
+        while (depth >= 1) {
+            if (num_try <= 0) break;
+            if (depth == nsegs) {
+                --num_try;
+                RAln res;
+                const int jr = lean_join(g, p, S, stage, nsegs, rp, W, rl, res);
+                if (jr == LJ_PUNT) return SPAN_NEED_GENERIC;
+                if (jr == LJ_OK && valid_hit(p, res)) {
+                    if (nj >= MULTI_MAXJOIN) return SPAN_NEED_GENERIC;
+                    joined[nj++] = res;
+                }
+                --depth;
+                continue;
+            }
+            if (idx[depth] >= so[depth + 1]) { --depth; continue; }
+            const SpanHit sh = ghits[idx[depth]++];
+            const RAln cand = raln_from_hit(sh, depth, L, rl);
+            const int cright = cand.left + rc_ref_span(cand.c, cand.n);
+            bool okc = false;
+            if (ref0 == cand.ref_id && (int)anti0 == cand.anti) {             // every hit of a chain shares contig and strand
+                const int dist = anti0 ? pleft[depth - 1] - cright : cand.left - pright[depth - 1];   // :2352-2378, :2531-2556
+                okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+            }
+            if (okc) {
+                stage[depth] = sh;
+                pleft[depth] = cand.left; pright[depth] = cright;
+                ++depth;
+                if (depth < nsegs) idx[depth] = so[depth];
+            }
+        }
+    }
+    // sort + unique (:2805-2807): insertion sort (stable; what std::sort does below 16 elements)
+    for (int i = 1; i < nj; ++i) {
+        RAln t = joined[i]; int k = i;
+        while (k > 0 && raln_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
+        joined[k] = t;
+    }
+    int w = 0;
+    for (int i = 0; i < nj; ++i) if (w == 0 || !raln_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];
+    nj = w;
+    int order = 0, status = SPAN_OK;
+    for (int i = 0; i < nj; ++i) {
+        const int st = lean_finish(g, p, joined[i], nsegs, rp, W, rl, qual, read_idx, order, sink);
+        if (st != SPAN_OK) status = st;
+    }
+    return status;
+}
 
 // ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
 // (an unspliced read cut into segments: ~60 % of real data).  merge_chain leaves every pair untouched

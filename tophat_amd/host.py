@@ -402,16 +402,16 @@ def _span_methods():
         return alns_from_array(self.span_download(self.span_finish()))
 
     def span_tier_counts(self):
-        c = (C.c_int64 * 2)()
+        c = (C.c_int64 * 3)()
         _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
-        return int(c[0]), int(c[1])
+        return int(c[0]), int(c[1]), int(c[2])
 
     def profile_span(self, enable: bool = True):
-        """-> ([ms contig, ms lean, ms multihit], launches)"""
-        ms = (C.c_double * 3)()
+        """-> ([ms contig, ms lean, ms multihit, ms generic], launches)"""
+        ms = (C.c_double * 4)()
         n = C.c_int64()
         _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, ms, C.byref(n)), "thj_profile_span")
-        return [ms[0], ms[1], ms[2]], n.value
+        return [ms[0], ms[1], ms[2], ms[3]], n.value
 
     for f in (upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
               span_download, spanning, profile_span, span_tier_counts):

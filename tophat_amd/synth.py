@@ -503,7 +503,7 @@ def make_scale_genome(seed: int, contig_lens: Sequence[int], n_introns: int, int
 
 def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int, device, read_len: int = 100,
                          seg_len: int = 25, inner_mean: float = 50.0, inner_sd: float = 20.0, err: float = 0.01,
-                         exon_len: int = 600, chunk: int = 1 << 20):
+                         exon_len: int = 600, chunk: int = 1 << 20, multi_frac: float = 0.0, dup_shift: int = 0):
     """Synthesises both sides of `n_pairs` paired reads directly as device-resident thj_seg_batch arrays
     (torch tensors).  Model: a fragment of 2*read_len + max(0, N(inner_mean, inner_sd)) bases drawn
     uniformly from a gene's two-exon transcript; left read = its first read_len bases (sense), right
@@ -511,6 +511,9 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
     mapped (one hit) where the truth puts it when it lies wholly in one exon and has <= 2 substitution
     errors; segments that straddle the junction are unmapped.  The mate group of a read is the mate's
     full-read hit when the mate is unspliced with <= 2 errors, else the mate's last-segment hit.
+    multi_frac > 0 (with a genome whose [dup_shift, 2*dup_shift) is a copy of [0, dup_shift) and genes in the first copy
+    only): that fraction of the reads gets every segment hit reported twice, at the locus and at locus + dup_shift --
+    a two-copy repeat, which is what sends reads to the multihit tier of the stitch kernels.
     Returns {side: dict of tensors} with the field names of thj_seg_batch."""
     import torch
     g = torch.Generator(device=device)
@@ -626,21 +629,38 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
             b["full_hit"][c0:c0 + n, 2] = (fl + read_len).to(torch.int32)
             b["full_hit"][c0:c0 + n, 3] = (anti.to(torch.int32) | 2 | (nm_all << 8) | (nm_all << 16) | (read_len << 24)).to(torch.int32)
     del gcodes
+
+    def csr(mapped, rows, multi, left_cols):
+        """CSR offsets + rows of the mapped (read, segment) cells; cells of `multi` reads appear twice, the copy
+        shifted by dup_shift in the columns `left_cols`"""
+        cnt = mapped.to(torch.int32)
+        if multi is not None:
+            cnt = cnt * (1 + multi.repeat_interleave(nseg).to(torch.int32))
+        off = torch.zeros(n_pairs * nseg + 1, dtype=torch.int32, device=device)
+        off[1:] = torch.cumsum(cnt, 0)
+        if multi is None:
+            return off, rows[mapped].contiguous()
+        cell = torch.arange(n_pairs * nseg, device=device).repeat_interleave(cnt.to(torch.int64))
+        copy = torch.arange(cell.shape[0], device=device, dtype=torch.int64) - off[:-1].to(torch.int64)[cell]
+        out_rows = rows[cell].clone()
+        for col in left_cols:
+            out_rows[:, col] += (copy * dup_shift).to(out_rows.dtype)
+        return off, out_rows.contiguous()
+
     for sd in sides:
         b = bufs[sd]
         other = bufs["right" if sd == "left" else "left"]
+        multi = None
+        if multi_frac > 0 and dup_shift > 0:
+            multi = torch.rand(n_pairs, generator=g, device=device) < multi_frac
         mapped = b["seg_mapped"].reshape(-1)
-        seg_off = torch.zeros(n_pairs * nseg + 1, dtype=torch.int32, device=device)
-        seg_off[1:] = torch.cumsum(mapped.to(torch.int32), 0)
-        hits = b["seg_hits"].reshape(-1, 4)[mapped].contiguous()
+        seg_off, hits = csr(mapped, b["seg_hits"].reshape(-1, 4), multi, (1, 2))
         m_has = other["full_ok"] | other["seg_mapped"][:, nseg - 1]
         mate_off = torch.zeros(n_pairs + 1, dtype=torch.int32, device=device)
         mate_off[1:] = torch.cumsum(m_has.to(torch.int32), 0)
         mh = torch.where(other["full_ok"][:, None], other["full_hit"], other["seg_hits"][:, nseg - 1, :])[m_has].contiguous()
         smapped = b["span_mapped"].reshape(-1)
-        span_off = torch.zeros(n_pairs * nseg + 1, dtype=torch.int32, device=device)
-        span_off[1:] = torch.cumsum(smapped.to(torch.int32), 0)
-        span_hits = b["span_hits"].reshape(-1, 8)[smapped].contiguous()
+        span_off, span_hits = csr(smapped, b["span_hits"].reshape(-1, 8), multi, (1,))
         quals = torch.full((n_pairs * read_len,), ord("I"), dtype=torch.uint8, device=device)
         out[sd] = dict(n_reads=n_pairs, nseg=nseg, W=W, seg_off=seg_off, hits=hits,
                        span_off=span_off, span_hits=span_hits, quals=quals, qual_stride=read_len,
