@@ -149,7 +149,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                                 const uint64_t* planes, const uint16_t* read_len, const uint8_t* quals, int32_t qual_stride,
                                 const thj_junction* juncs, int64_t n_juncs,
                                 const uint32_t* ins /* 4 u32 each: ref,left,len,seq3 */, int64_t n_ins,
-                                int32_t mode /* 0 = lean tier + generic fallback (as the kernels), 1 = generic only */,
+                                int32_t mode /* 0 = the four tiers as the kernels run them, 1 = generic only, 2 = as 0 without the LDS-staged multihit tier */,
                                 void** out, int64_t* n_out, int64_t* status_counts /* [5] */) {
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Params p;
@@ -163,7 +163,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
     SpanSets S{jk.data(), n_juncs, ik.data(), iseq.data(), n_ins, nullptr, 0};
     // mode 0 runs as the kernels do: with the coarse bucket index over the junction keys
     std::vector<uint32_t> bucket;
-    if (mode == 0) {
+    if (mode != 1) {
         int64_t n_blocks = 0;
         for (int32_t k = 0; k < n_contigs; ++k) { int64_t e = (int64_t)contig_blk[k] + (contig_len[k] + 63) / 64 + 2; if (e > n_blocks) n_blocks = e; }
         const int64_t nb = ((n_blocks * 64 + 2) >> JUNC_BUCKET_SHIFT) + 1;
@@ -178,7 +178,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
     status_counts[0] = status_counts[1] = status_counts[2] = status_counts[3] = status_counts[4] = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
         int st = SPAN_NEED_GENERIC;
-        if (mode == 0) {
+        if (mode != 1) {
             st = span_read_contig(g, p, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                   read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
             if (st == SPAN_NEED_LEAN) {
@@ -188,7 +188,12 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                                     read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
             }
         }
-        if (st == SPAN_NEED_GENERIC && mode == 0) {          // tier 2: multihit reads on the lean machinery
+        if (st == SPAN_NEED_GENERIC && mode == 0) {          // tier 2: multihit reads, every hit head staged
+            SpanHitHead heads[16];
+            st = span_read_multi_staged(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                        read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, heads, nseg <= 4 ? 12 : 16, sink);
+        }
+        if (st == SPAN_NEED_GENERIC && mode != 1) {          // tier 3, first attempt: DFS over global memory, lean joins
             SpanHit stage[SPAN_MAXSEG];
             st = span_read_multi(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                  read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);

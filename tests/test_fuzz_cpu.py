@@ -188,7 +188,7 @@ def test_fuzz_long_spanning_reads(seed):
     il = [(k[0], k[1], v) for k, v in sorted(ins.items()) if k[1] >= 0]
     g = orc.Genome(seqs)
     want = orc.spanning(p, g, sb, ja, il)
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         got, status = sim.spanning(p, seqs, sb, ja, il, mode)
         assert status[1] == 0
         got.sort(key=lambda a: a.read_idx)

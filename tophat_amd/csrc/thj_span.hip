@@ -51,11 +51,12 @@ struct RecSink {
         uint4* dst;
         if (order == 0) dst = (uint4*)(slots + (size_t)base + w[0]);
         else {
-            unsigned long long pos = atomicAdd(ovf_count, 1ull);
+            unsigned long long pos = THJ_EXPF(8192) ? (unsigned long long)(base + w[0]) : atomicAdd(ovf_count, 1ull);
             if (pos >= ovf_cap) { atomicExch(&status[3], 1u); return; }
             ovf_key[pos] = ((u64)(base + w[0]) << 16) | (u64)order;
             dst = (uint4*)(ovf + pos);
         }
+        if (THJ_EXPF(32768)) { if (w[7] == 0x12345u) dst[0] = make_uint4(w[0], w[9], w[18], w[31]); return; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
     }
@@ -95,17 +96,18 @@ __global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, D
     const int tid = threadIdx.x;
     if (tid < 3) s_cnt[tid] = 0;
     __syncthreads();
-    const int64_t c0 = (int64_t)blockIdx.x * t.chunk;
-    const int64_t c1 = c0 + t.chunk < b.n_reads ? c0 + t.chunk : b.n_reads;
+    // reads are numbered in 32 bits (n_reads < 2^31 is checked on the host); offsets are one 32x32->64 multiply each
+    const uint32_t c0 = blockIdx.x * (uint32_t)t.chunk;
+    const uint32_t c1 = c0 + (uint32_t)t.chunk < (uint32_t)b.n_reads ? c0 + (uint32_t)t.chunk : (uint32_t)b.n_reads;
     unsigned int my_rec = 0;
-    for (int64_t r0 = c0; r0 < c1; r0 += 256) {
-        const int64_t r = r0 + tid;
+    for (uint32_t r0 = c0; r0 < c1; r0 += 256) {
+        const uint32_t r = r0 + (uint32_t)tid;
         StageSink ss{stage, tid, 0};
         if (r < c1) {
-            int st = span_read_contig<MS>(g, p, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
-                                      (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, ss);
-            if (st == SPAN_NEED_LEAN) { if (!THJ_EXPF(64)) t.wl_lean[c0 + atomicAdd(&s_cnt[0], 1u)] = (uint32_t)r; }
-            else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = (uint32_t)r;
+            int st = span_read_contig<MS>(g, p, b.hits, b.seg_off + (u64)r * (uint32_t)b.nseg, b.nseg, b.planes + (u64)r * (uint32_t)(3 * b.W), b.W,
+                                      (int)b.read_len[r], b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss);
+            if (st == SPAN_NEED_LEAN) { if (!THJ_EXPF(64)) t.wl_lean[c0 + atomicAdd(&s_cnt[0], 1u)] = r; }
+            else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = r;
             else {
                 sink.nrec[(size_t)sink.base + r] = (uint8_t)ss.emitted;
                 my_rec += ss.emitted;
@@ -183,21 +185,22 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
 }
 
-// Tier 2: multihit reads -- the DFS over one hit per segment with every chain joined on the lean machinery
-// (span_read_multi).  Reads it cannot hold (more cigar ops or joined hits than its registers / small arrays) go on
-// to tier 3.
-__global__ __launch_bounds__(256, 4) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
-    extern __shared__ uint4 lds_stage[];          // nseg hits per thread
+// Tier 2: multihit reads with at most `caph` hits -- the 16-byte heads of all the read's hits staged in LDS, the DFS
+// over one hit per segment and every chain's join on registers (span_read_multi_staged).  Reads with more hits, more
+// cigar ops or more joined alignments than it holds go on to tier 3.
+template <int MS>
+__global__ __launch_bounds__(256, 3) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, int caph) {
+    extern __shared__ uint4 lds_stage[];          // caph hit heads per thread
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
-    SpanHit* stage = (SpanHit*)lds_stage + (size_t)threadIdx.x * b.nseg;
+    SpanHitHead* heads = (SpanHitHead*)lds_stage + (size_t)threadIdx.x * caph;
     const unsigned int total = slice_offsets<256>(t.blk_multi, G, s_off);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])];
-        int st = span_read_multi(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
-                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, stage, sink);
+        int st = span_read_multi_staged<MS>(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                                            (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, heads, caph, sink);
         if (st == SPAN_NEED_GENERIC) {
             t.wl_gen[(int64_t)sl * t.chunk + atomicAdd(&t.blk_gen[sl], 1u)] = (uint32_t)r;
             atomicAdd(&t.counters[2], 1u);
@@ -208,18 +211,24 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_multihit(Genome g, Params
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
 }
 
-// Tier 3: the general per-read DFS on arrays (span_read) for what is left: joined alignments with more than
-// LEAN_C cigar ops, reads with more than MULTI_MAXJOIN joined hits.
+// Tier 3: what is left.  First the same DFS with its candidates read from global memory (any number of hits) and
+// lean joins (span_read_multi); reads whose joined alignments need more than LEAN_C cigar ops, or that have more than
+// MULTI_MAXJOIN of them, are redone on the general arrays (span_read).
 __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    extern __shared__ uint4 lds_stage[];          // nseg hits per thread: the chain under construction
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
+    SpanHit* stage = (SpanHit*)lds_stage + (size_t)threadIdx.x * b.nseg;
     const unsigned int total = slice_offsets<128>(t.blk_gen, G, s_off);
     for (unsigned int i = blockIdx.x * 128 + threadIdx.x; i < total; i += gridDim.x * 128) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_gen[(int64_t)sl * t.chunk + (i - s_off[sl])];
-        int st = span_read(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
-                           (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        const uint32_t* so = b.seg_off + (size_t)r * b.nseg;
+        const u64* rp = b.planes + (size_t)r * 3 * b.W;
+        const uint8_t* q = b.quals + (size_t)r * b.qual_stride;
+        int st = span_read_multi(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, stage, sink);
+        if (st == SPAN_NEED_GENERIC) st = span_read(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, sink);
         sink.done((uint32_t)r);
         if (st) atomicAdd(&sink.status[st], 1u);
     }
@@ -506,9 +515,11 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
-    hipLaunchKernelGGL(thj_k_stitch_multihit, dim3((unsigned)g2), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+    const int caph = b.nseg <= 4 ? 12 : 16;           // hit heads staged per read in tier 2 (16 bytes each)
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_multihit<4>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
+    else hipLaunchKernelGGL(thj_k_stitch_multihit<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
-    hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), 0, c->stream, g, p, S, b, sink, t, (int)G);
+    hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) {
         HIPCHK(hipEventRecord(ev[4], c->stream));
         for (int k = 0; k < 4; ++k) c->span_prof_events.emplace_back(ev[k], ev[k + 1]);

@@ -542,10 +542,34 @@ THJ_HD void md_push(MdBuf& m, char c) {
     }
     ++m.len;
 }
+// Up to four characters at once (`tok` = the characters in memory order, low byte first).  One masked OR per word
+// of the buffer instead of one per character and word: the MD string is built from <run length><mismatch base> tokens.
+THJ_HD void md_append(MdBuf& m, uint32_t tok, int n) {
+    const int k = m.len >> 3, sh = (m.len & 7) * 8;      // k >= 5 (string already too long): nothing is stored
+    const u64 lo = (u64)tok << sh;
+    const u64 hi = sh > 32 ? (u64)tok >> (64 - sh) : 0ull;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) m.w[i] |= (k == i ? lo : 0ull) | (k + 1 == i ? hi : 0ull);
+    m.len += n;
+}
+// decimal digits of v (0..999: runs are shorter than a read, at most 256 bases) as a token; returns their number
+THJ_HD int md_int_token(int v, uint32_t& tok) {
+    const uint32_t d2 = (uint32_t)v / 100u, r = (uint32_t)v - d2 * 100u, d1 = r / 10u, d0 = r - d1 * 10u;
+    const uint32_t t3 = (0x30u + d2) | ((0x30u + d1) << 8) | ((0x30u + d0) << 16);
+    const uint32_t t2 = (0x30u + d1) | ((0x30u + d0) << 8);
+    tok = v >= 100 ? t3 : (v >= 10 ? t2 : 0x30u + d0);
+    return v >= 100 ? 3 : (v >= 10 ? 2 : 1);
+}
 THJ_HD void md_put_int(MdBuf& m, int v) {
-    if (v >= 100) md_push(m, (char)('0' + (v / 100) % 10));
-    if (v >= 10) md_push(m, (char)('0' + (v / 10) % 10));
-    md_push(m, (char)('0' + v % 10));                 // runs are < 1000: reads are at most 256 bases
+    uint32_t tok;
+    const int n = md_int_token(v, tok);
+    md_append(m, tok, n);
+}
+// <run length><base>: the token of one mismatch
+THJ_HD void md_put_int_char(MdBuf& m, int v, char c) {
+    uint32_t tok;
+    const int n = md_int_token(v, tok);
+    md_append(m, tok | ((uint32_t)(uint8_t)c << (8 * n)), n + 1);
 }
 
 struct OutAln {             // == thj_aln, 128 bytes
@@ -601,8 +625,7 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const A& h, const SeqVie
                         }
                     }
                     pos_mm += b - last;
-                    md_put_int(e.md, pos_mm);
-                    md_push(e.md, "ACGTN"[plane_code(r, b)]);
+                    md_put_int_char(e.md, pos_mm, "ACGTN"[plane_code(r, b)]);
                     pos_mm = 0; last = b + 1;
                 }
                 pos_mm += l - last;
@@ -615,8 +638,7 @@ THJ_HD bool sam_extra(const Genome& g, const Params& p, const A& h, const SeqVie
         } else if (op == OP_DEL) {
             AS -= p.bowtie2_ref_gap_open + p.bowtie2_ref_gap_cont * len;
             ++opens; conts += len;
-            md_put_int(e.md, pos_mm);
-            md_push(e.md, '^');
+            md_put_int_char(e.md, pos_mm, '^');
             Planes r = g_fetch(g, h.ref_id, pos_ref);
             for (int k = 0; k < len && k < 64; ++k) md_push(e.md, "ACGTN"[plane_code(r, k)]);
             pos_ref += len; pos_mm = 0;
@@ -705,6 +727,7 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
             }
         }
     }
+    if (THJ_EXPF(4096)) return SPAN_OK;
     // sort + unique (:2805-2807): insertion sort (stable; what std::sort does below 16 elements)
     for (int i = 1; i < nj; ++i) {
         Aln t = joined[i]; int k = i;
@@ -775,7 +798,8 @@ THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
 // ---- lean machinery shared by tiers 1 and 2 -----------------------------------------------------------------
 // lean_join: ONE chain -- hits[s] is the hit chosen for segment s -- through merge_chain on register cigars.
 enum { LJ_NONE = 0, LJ_OK = 1, LJ_PUNT = 2 };       // no alignment / `res` holds the joined hit / needs more cigar ops than LEAN_C
-THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, int nsegs,
+template <class Hits>      // Hits: `hits[s]` is the hit chosen for segment s (a plain array, or StagedHits)
+THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const Hits& hits, int nsegs,
                      const u64* rp, int W, int rl, RAln& res) {
     const int L = p.segment_length;
     const SpanHit h0 = hits[0];
@@ -877,6 +901,7 @@ template <class Sink>
 THJ_HD int lean_finish(const Genome& g, const Params& p, const RAln& res, int nsegs, const u64* rp, int W, int rl,
                        const uint8_t* qual, uint32_t read_idx, int& order, Sink& sink) {
     if (!valid_hit(p, res)) return SPAN_OK;
+    if (THJ_EXPF(16384)) return SPAN_OK;
     int gapl = (res.ed - res.mm) & 0xFF;
     if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return SPAN_OK;
     SeqView sv = res.anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
@@ -972,6 +997,148 @@ THJ_HD bool raln_eq(const RAln& a, const RAln& b) {            // BowtieHit::ope
     return same;
 }
 
+// sort + unique of the joined hits (:2805-2807), then the per-hit filters and the records
+template <class Sink>
+THJ_HD int multi_finish(const Genome& g, const Params& p, RAln* joined, int nj, int nsegs, const u64* rp, int W, int rl,
+                        const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+    if (THJ_EXPF(4096)) return SPAN_OK;
+    for (int i = 1; i < nj; ++i) {               // insertion sort (stable; what std::sort does below 16 elements)
+        RAln t = joined[i]; int k = i;
+        while (k > 0 && raln_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
+        joined[k] = t;
+    }
+    int w = 0;
+    for (int i = 0; i < nj; ++i) if (w == 0 || !raln_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];
+    nj = w;
+    int order = 0, status = SPAN_OK;
+    for (int i = 0; i < nj; ++i) {
+        const int st = lean_finish(g, p, joined[i], nsegs, rp, W, rl, qual, read_idx, order, sink);
+        if (st != SPAN_OK) status = st;
+    }
+    return status;
+}
+
+// Tier 2 proper: reads with at most `caph` (<= 16) hits in all.  The 16-byte heads of ALL the read's hits -- contig,
+// left, flags, first cigar op: everything a plain-match hit carries -- are fetched back to back into LDS, so the DFS
+// and the joins never wait on HBM again (the global-memory DFS below pays a dependent round trip per candidate, and
+// re-reads a segment's candidates once per parent).  The rare hit with more cigar ops gets its tail from global memory.
+struct alignas(16) SpanHitHead { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar0; };
+THJ_HD SpanHit staged_hit(const SpanHitHead* heads, const SpanHit* g0, int k) {
+    const SpanHitHead hh = heads[k];
+    SpanHit h;
+    h.ref_id = hh.ref_id; h.left = hh.left; h.meta = hh.meta; h.cigar[0] = hh.cigar0;
+    h.cigar[1] = h.cigar[2] = h.cigar[3] = h.cigar[4] = 0;
+    if ((hh.meta >> 24) > 1) {
+        const Q16 t = ((const Q16*)(g0 + k))[1];
+        h.cigar[1] = t.x; h.cigar[2] = t.y; h.cigar[3] = t.z; h.cigar[4] = t.w;
+    }
+    return h;
+}
+struct StagedHits {         // the chain under construction: segment s's hit is staged hit number (sel >> 4s) & 15
+    const SpanHitHead* heads; const SpanHit* g0; u64 sel;
+    THJ_HD SpanHit operator[](int s) const { return staged_hit(heads, g0, (int)((sel >> (4 * s)) & 15)); }
+};
+template <int N> THJ_HD int rsel_get(const int (&a)[N], int i) {
+    int r = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) r = (i == k) ? a[k] : r;
+    return r;
+}
+template <int N> THJ_HD void rsel_set(int (&a)[N], int i, int x) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) a[k] = (i == k) ? x : a[k];
+}
+
+template <int MS = SPAN_MAXSEG, class Sink>
+THJ_HD int span_read_multi_staged(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
+                                  const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, int caph, Sink& sink) {
+    int off[MS + 1];                          // segment offsets relative to the read's first hit
+    {
+        uint32_t sof[MS + 1];
+#pragma unroll
+        for (int s = 0; s <= MS; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
+#pragma unroll
+        for (int s = 0; s <= MS; ++s) off[s] = (int)(sof[s] - sof[0]);
+        ghits += sof[0];
+    }
+    if (off[1] == 0) return SPAN_OK;
+    int nsegs = 0;
+    {
+        bool open = true;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) { open = open && s < nseg && off[s + 1] > off[s]; nsegs += open ? 1 : 0; }
+    }
+    const int total = rsel_get(off, nsegs);
+    if (total > caph) return SPAN_NEED_GENERIC;
+    for (int b0 = 0; b0 < total; b0 += 8) {           // up to eight 16-byte loads in flight
+        Q16 tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (b0 + k < total) tmp[k] = *(const Q16*)(ghits + b0 + k);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (b0 + k < total) ((Q16*)heads)[b0 + k] = tmp[k];
+    }
+    if (!(heads[rsel_get(off, nsegs - 1)].meta & SH_END)) return SPAN_OK;     // :2777-2785
+    if (p.bowtie2) {
+        bool over = false;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) over = over || (s < nsegs && off[s + 1] - off[s] > p.max_seg_multihits);   // :2625-2632
+        if (over) return SPAN_OK;
+    }
+    if (THJ_EXPF(2048)) return SPAN_OK;
+    const int L = p.segment_length;
+    RAln joined[MULTI_MAXJOIN]; int nj = 0;
+    int idx[MS], pleft[MS], pright[MS];       // next candidate / left / right of the chosen hit, per depth (registers)
+#pragma unroll
+    for (int s = 0; s < MS; ++s) idx[s] = pleft[s] = pright[s] = 0;
+    StagedHits chain{heads, ghits, 0};
+    for (int i0 = 0; i0 < off[1]; ++i0) {                // :2634-2664
+        const SpanHit first = staged_hit(heads, ghits, i0);
+        const uint32_t ref0 = first.ref_id;
+        const bool anti0 = (first.meta & SH_ANTI) != 0;
+        {
+            const RAln a0 = raln_from_hit(first, 0, L, rl);
+            pleft[0] = a0.left; pright[0] = a0.left + rc_ref_span(a0.c, a0.n);
+        }
+        chain.sel = (u64)i0;
+        int num_try = 10000;
+        int depth = 1;
+        idx[1 < MS ? 1 : 0] = off[1];
+        while (depth >= 1) {
+            if (num_try <= 0) break;
+            if (depth == nsegs) {
+                --num_try;
+                RAln res;
+                const int jr = lean_join(g, p, S, chain, nsegs, rp, W, rl, res);
+                if (jr == LJ_PUNT) return SPAN_NEED_GENERIC;
+                if (jr == LJ_OK && valid_hit(p, res)) {
+                    if (nj >= MULTI_MAXJOIN) return SPAN_NEED_GENERIC;
+                    joined[nj++] = res;
+                }
+                --depth;
+                continue;
+            }
+            const int cur = rsel_get(idx, depth);
+            if (cur >= rsel_get(off, depth + 1)) { --depth; continue; }
+            rsel_set(idx, depth, cur + 1);
+            const SpanHit sh = staged_hit(heads, ghits, cur);
+            const RAln cand = raln_from_hit(sh, depth, L, rl);
+            const int cright = cand.left + rc_ref_span(cand.c, cand.n);
+            bool okc = false;
+            if (ref0 == cand.ref_id && (int)anti0 == cand.anti) {             // every hit of a chain shares contig and strand
+                const int dist = anti0 ? rsel_get(pleft, depth - 1) - cright : cand.left - rsel_get(pright, depth - 1);   // :2352-2378, :2531-2556
+                okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+            }
+            if (okc) {
+                chain.sel = (chain.sel & ~(15ull << (4 * depth))) | ((u64)cur << (4 * depth));
+                rsel_set(pleft, depth, cand.left); rsel_set(pright, depth, cright);
+                ++depth;
+                if (depth < nsegs) rsel_set(idx, depth, rsel_get(off, depth));
+            }
+        }
+    }
+    return multi_finish(g, p, joined, nj, nsegs, rp, W, rl, qual, read_idx, sink);
+}
+
 template <class Sink>
 THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
                            const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHit* stage, Sink& sink) {
@@ -983,6 +1150,7 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
     if (p.bowtie2)
         for (int s = 0; s < nsegs; ++s)
             if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;   // :2625-2632
+    if (THJ_EXPF(2048)) return SPAN_OK;
     const int L = p.segment_length;
     RAln joined[MULTI_MAXJOIN]; int nj = 0;
     uint32_t idx[SPAN_MAXSEG];               // next candidate of each depth
@@ -1029,21 +1197,7 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
             }
         }
     }
-    // sort + unique (:2805-2807): insertion sort (stable; what std::sort does below 16 elements)
-    for (int i = 1; i < nj; ++i) {
-        RAln t = joined[i]; int k = i;
-        while (k > 0 && raln_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
-        joined[k] = t;
-    }
-    int w = 0;
-    for (int i = 0; i < nj; ++i) if (w == 0 || !raln_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];
-    nj = w;
-    int order = 0, status = SPAN_OK;
-    for (int i = 0; i < nj; ++i) {
-        const int st = lean_finish(g, p, joined[i], nsegs, rp, W, rl, qual, read_idx, order, sink);
-        if (st != SPAN_OK) status = st;
-    }
-    return status;
+    return multi_finish(g, p, joined, nj, nsegs, rp, W, rl, qual, read_idx, sink);
 }
 
 // ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
@@ -1051,8 +1205,6 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
 // (dist == 0, :1591), the final concatenation (:1888-1944) fuses the MATCH ops into one, so the joined hit is
 // {leftmost left, [len M], sum of mismatches}.  Returns SPAN_NEED_LEAN when the read is not of that shape.
 enum { SPAN_NEED_LEAN = 4 };
-// first half of a thj_span_hit: all a single plain-match hit carries
-struct alignas(16) SpanHitHead { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar0; };
 
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
@@ -1147,8 +1299,7 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
                 AS -= p.bowtie2_min_penalty + ((p.bowtie2_max_penalty - p.bowtie2_min_penalty) * q) / 40;
             }
             pos_mm += b - last;
-            md_put_int(md, pos_mm);
-            md_push(md, "ACGTN"[plane_code(r, b)]);
+            md_put_int_char(md, pos_mm, "ACGTN"[plane_code(r, b)]);
             pos_mm = 0; last = b + 1;
         }
         pos_mm += l - last;
