@@ -1206,11 +1206,127 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
 // {leftmost left, [len M], sum of mismatches}.  Returns SPAN_NEED_LEAN when the read is not of that shape.
 enum { SPAN_NEED_LEAN = 4 };
 
+// ---- tier 0 helpers ------------------------------------------------------------------------------------------
+// Where the read's planes come from: global memory (any W), or registers for reads of up to 128 bases (W <= 2), loaded
+// before anything else of the read so that their latency hides behind the offset and hit fetches.
+struct MemRead {
+    const u64* rp; int W;
+    THJ_HD Planes fetch(int start, int len) const { return r_fetch(rp, W, start, len); }
+};
+struct RegRead {
+    u64 v[6];               // lo[0..1], hi[0..1], nm[0..1]; second words 0 when W == 1
+    THJ_HD Planes fetch(int start, int len) const {
+        const bool w1 = (start >> 6) != 0;
+        const unsigned sft = (unsigned)(start & 63);
+        const u64 m = lowmask(len);
+        Planes r;
+        r.lo = funnel(w1 ? v[1] : v[0], w1 ? 0ull : v[1], sft) & m;
+        r.hi = funnel(w1 ? v[3] : v[2], w1 ? 0ull : v[3], sft) & m;
+        r.nm = funnel(w1 ? v[5] : v[4], w1 ? 0ull : v[5], sft) & m;
+        return r;
+    }
+};
+template <class Src>
+THJ_HD bool src_is_own_revcomp(const Src& src, int rl) {         // read_is_own_revcomp on either source
+    for (int off = 0; off < rl; off += 64) {
+        int l = rl - off < 64 ? rl - off : 64;
+        Planes f = src.fetch(off, l);
+        Planes r = rc_piece(src.fetch(rl - off - l, l), l);
+        if (f.lo != r.lo || f.hi != r.hi || f.nm != r.nm) return false;
+    }
+    return true;
+}
+struct ContigAcc { MdBuf md; int mismatch, both_n, AS, pos_mm; };
+// bowtie_sam_extra over one 64-base piece of the single MATCH op (bwt_map.cpp:2467-2648)
+THJ_HD void contig_piece(const Params& p, const Planes& r, const Planes& sq, int l, int off, const uint8_t* qual, bool qrev, int rl, ContigAcc& a) {
+    u64 m = dna5_mism(r, sq, l);
+    if (THJ_EXPF(32)) m = 0;
+    u64 bn = r.nm & sq.nm & lowmask(l);
+    a.both_n += popc(bn);
+    a.AS -= p.bowtie2_penalty_for_N * popc(bn);
+    int last = 0;
+    while (m) {
+        int b = ctz(m);
+        m &= m - 1;
+        ++a.mismatch;
+        int sp = off + b;
+        if (((r.nm | sq.nm) >> b) & 1ull) a.AS -= p.bowtie2_penalty_for_N;
+        else {
+            int q = THJ_EXPF(2) ? 30 : (int)qual[qrev ? rl - 1 - sp : sp] - 33; if (q > 40) q = 40;
+            a.AS -= p.bowtie2_min_penalty + ((p.bowtie2_max_penalty - p.bowtie2_min_penalty) * q) / 40;
+        }
+        a.pos_mm += b - last;
+        md_put_int_char(a.md, a.pos_mm, "ACGTN"[plane_code(r, b)]);
+        a.pos_mm = 0; last = b + 1;
+    }
+    a.pos_mm += l - last;
+}
+template <class Src, class Sink>
+THJ_HD int contig_finish(const Genome& g, const Params& p, const Src& src, uint32_t ref_id, int left, int total, int mm8, bool anti, int nsegs,
+                         int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+    bool qrev = false;
+    if (nsegs == 1) qrev = anti;
+    else if (anti) qrev = !src_is_own_revcomp(src, rl);      // merge_chain :1966-1978: reversed qual unless rc(read) == read
+    ContigAcc a;
+    md_init(a.md);
+    a.mismatch = a.both_n = a.AS = a.pos_mm = 0;
+    // the first two pieces (reads of up to 128 bases: all of it) are fetched together, then consumed
+    {
+        Planes r[2], sq[2]; int l[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int off = 64 * c;
+            int lc = total - off < 64 ? total - off : 64;
+            if (off + lc > rl) lc = rl - off;
+            l[c] = lc;
+            if (lc > 0) {
+                r[c] = g_fetch(g, ref_id, THJ_EXPF(4) ? 0 : (int64_t)left + off);
+                sq[c] = anti ? rc_piece(src.fetch(rl - off - lc, lc), lc) : src.fetch(off, lc);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+            if (l[c] > 0) contig_piece(p, r[c], sq[c], l[c], 64 * c, qual, qrev, rl, a);
+    }
+    for (int off = 128; off < total; off += 64) {
+        int l = total - off < 64 ? total - off : 64;
+        if (off + l > rl) l = rl - off;
+        if (l <= 0) break;
+        Planes r = g_fetch(g, ref_id, (int64_t)left + off);
+        Planes sq = anti ? rc_piece(src.fetch(rl - off - l, l), l) : src.fetch(off, l);
+        contig_piece(p, r, sq, l, off, qual, qrev, rl, a);
+    }
+    md_put_int(a.md, a.pos_mm);
+    const MdBuf& md = a.md;
+    const int mismatch = a.mismatch, both_n = a.both_n, AS = a.AS;
+    if (nsegs > 1 && !(mismatch == mm8 || mismatch + both_n == mm8)) return SPAN_OK;   // check_editdist_consistency
+    if (md.len > 40) return SPAN_MD_OVERFLOW;        // only for a hit that would really be reported
+    uint32_t wds[32];
+    wds[0] = read_idx; wds[1] = ref_id; wds[2] = (uint32_t)left;
+    wds[3] = (anti ? 1u : 0u) | ((uint32_t)mm8 << 8) | ((uint32_t)mm8 << 16) | (1u << 24);
+    wds[4] = ((uint32_t)AS & 0xFFFFu) | ((uint32_t)(mismatch & 0xFF) << 16);                 // AS, XM, XO = 0
+    wds[5] = ((uint32_t)md.len << 8);                                                        // XG = 0, md_len, order = 0
+    wds[6] = cig(OP_MATCH, (uint32_t)total);
+#pragma unroll
+    for (int q = 7; q < 22; ++q) wds[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { wds[22 + 2 * q] = (uint32_t)md.w[q]; wds[23 + 2 * q] = (uint32_t)(md.w[q] >> 32); }
+    sink.emit_words(wds);
+    return SPAN_OK;
+}
+
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
                             const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
-    // Memory round trips, not arithmetic, bound this tier: the segment offsets are fetched in one go, then every
-    // hit head in one go, and only then is anything decided.
+    // Memory round trips, not arithmetic, bound this tier: the read's planes (when they fit six registers) and the
+    // segment offsets are fetched in one go, then every hit head in one go, and only then is anything decided.
+    RegRead rw;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rw.v[k] = 0;
+    if (W == 2) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rw.v[k] = rp[k];
+    } else if (W == 1) { rw.v[0] = rp[0]; rw.v[2] = rp[1]; rw.v[4] = rp[2]; }
     uint32_t sv[MS + 1];
 #pragma unroll
     for (int s = 0; s <= MS; ++s) sv[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
@@ -1265,60 +1381,8 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
     const int mm8 = mm & 0xFF;                       // BowtieHit keeps mismatches / edit_dist in unsigned chars
     if (mm8 > p.read_mismatches || mm8 > p.read_edit_dist) return SPAN_OK;          // :2810-2813 (gap length 0)
     if (g_len(g, h0.ref_id) == 0) return SPAN_OK;    // check_editdist_consistency / bowtie_sam_extra need the contig
-    // The read planes are consumed straight from global memory, 64 bases at a time, reverse-complemented on
-    // the fly for antisense reads: no private arrays, everything below lives in registers.
-    bool qrev = false;
-    if (nsegs == 1) qrev = anti;
-    else if (anti) {
-        // merge_chain :1966-1978: the joined qual is the reversed read qual unless rc(read) == read
-        qrev = !read_is_own_revcomp(rp, W, rl);
-    }
-    MdBuf md;
-    md_init(md);
-    int mismatch = 0, both_n = 0, AS = 0, pos_mm = 0;
-    for (int off = 0; off < total; off += 64) {                 // bowtie_sam_extra over the single MATCH op
-        int l = total - off < 64 ? total - off : 64;
-        if (off + l > rl) l = rl - off;
-        if (l <= 0) break;
-        Planes r = g_fetch(g, h0.ref_id, THJ_EXPF(4) ? 0 : (int64_t)left + off);
-        Planes sq = anti ? rc_piece(r_fetch(THJ_EXPF(8) ? g.blocks : rp, W, rl - off - l, l), l) : r_fetch(THJ_EXPF(8) ? g.blocks : rp, W, off, l);
-        u64 m = dna5_mism(r, sq, l);
-        if (THJ_EXPF(32)) m = 0;
-        u64 bn = r.nm & sq.nm & lowmask(l);
-        both_n += popc(bn);
-        AS -= p.bowtie2_penalty_for_N * popc(bn);
-        int last = 0;
-        while (m) {
-            int b = ctz(m);
-            m &= m - 1;
-            ++mismatch;
-            int sp = off + b;
-            if (((r.nm | sq.nm) >> b) & 1ull) AS -= p.bowtie2_penalty_for_N;
-            else {
-                int q = THJ_EXPF(2) ? 30 : (int)qual[qrev ? rl - 1 - sp : sp] - 33; if (q > 40) q = 40;
-                AS -= p.bowtie2_min_penalty + ((p.bowtie2_max_penalty - p.bowtie2_min_penalty) * q) / 40;
-            }
-            pos_mm += b - last;
-            md_put_int_char(md, pos_mm, "ACGTN"[plane_code(r, b)]);
-            pos_mm = 0; last = b + 1;
-        }
-        pos_mm += l - last;
-    }
-    md_put_int(md, pos_mm);
-    if (nsegs > 1 && !(mismatch == mm8 || mismatch + both_n == mm8)) return SPAN_OK;   // check_editdist_consistency
-    if (md.len > 40) return SPAN_MD_OVERFLOW;        // only for a hit that would really be reported
-    uint32_t wds[32];
-    wds[0] = read_idx; wds[1] = h0.ref_id; wds[2] = (uint32_t)left;
-    wds[3] = (anti ? 1u : 0u) | ((uint32_t)mm8 << 8) | ((uint32_t)mm8 << 16) | (1u << 24);
-    wds[4] = ((uint32_t)AS & 0xFFFFu) | ((uint32_t)(mismatch & 0xFF) << 16);                 // AS, XM, XO = 0
-    wds[5] = ((uint32_t)md.len << 8);                                                        // XG = 0, md_len, order = 0
-    wds[6] = cig(OP_MATCH, (uint32_t)total);
-#pragma unroll
-    for (int q = 7; q < 22; ++q) wds[q] = 0;
-#pragma unroll
-    for (int q = 0; q < 5; ++q) { wds[22 + 2 * q] = (uint32_t)md.w[q]; wds[23 + 2 * q] = (uint32_t)(md.w[q] >> 32); }
-    sink.emit_words(wds);
-    return SPAN_OK;
+    if (W <= 2) return contig_finish(g, p, rw, h0.ref_id, left, total, mm8, anti, nsegs, rl, qual, read_idx, sink);
+    return contig_finish(g, p, MemRead{rp, W}, h0.ref_id, left, total, mm8, anti, nsegs, rl, qual, read_idx, sink);
 }
 
 }  // namespace thj
