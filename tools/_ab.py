@@ -1,0 +1,10 @@
+import sys, json, subprocess, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for lib in sys.argv[1:]:
+    code = ("import sys; sys.path.insert(0, %r); import tophat_amd.host as h; h.LIB_PATH = %r; import bench; "
+            "sys.argv = ['bench.py', '--no-cpu-baseline']; bench.main()" % (ROOT, os.path.join(ROOT, "tophat_amd", "csrc", lib)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    if not line: print(lib, "FAILED", out.stderr[-300:]); continue
+    d = json.loads(line[-1])
+    print(lib, "step=%.3f" % d["ms_per_step"], "  ".join("%s=%.3f" % (k["kernel"][6:], k["avg_kernel_ms"]) for k in d["kernels"]), flush=True)

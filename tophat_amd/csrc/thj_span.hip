@@ -89,7 +89,7 @@ struct StageSink {
 
 // MS: upper bound of the batch's segments per read (4 covers reads up to 4 x segment_length, e.g. 100 bp at 25)
 template <int MS>
-__global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, RecSink sink, Tiers t) {
+__global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, RecSink sink, Tiers t) {
     __shared__ uint4 stage[256 * 8];
     __shared__ uint8_t has_rec[256];
     __shared__ unsigned int s_cnt[3];          // lean, multihit, records
@@ -100,12 +100,24 @@ __global__ __launch_bounds__(256) void thj_k_stitch_contig(Genome g, Params p, D
     const uint32_t c0 = blockIdx.x * (uint32_t)t.chunk;
     const uint32_t c1 = c0 + (uint32_t)t.chunk < (uint32_t)b.n_reads ? c0 + (uint32_t)t.chunk : (uint32_t)b.n_reads;
     unsigned int my_rec = 0;
+    // Segment offsets and read length are fetched one read ahead: one dependent round trip less per read.  (Going one
+    // step further -- hit heads one read ahead, offsets two -- was measured slower: the registers it takes cost more
+    // in occupancy and spills than the round trip it saves.)
+    uint32_t sv_next[MS + 1]; int rl_next = 0;
+#pragma unroll
+    for (int s = 0; s <= MS; ++s) sv_next[s] = 0;
+    if (c0 + (uint32_t)tid < c1) { contig_offsets<MS>(b.seg_off + (u64)(c0 + tid) * (uint32_t)b.nseg, b.nseg, sv_next); rl_next = (int)b.read_len[c0 + tid]; }
     for (uint32_t r0 = c0; r0 < c1; r0 += 256) {
         const uint32_t r = r0 + (uint32_t)tid;
         StageSink ss{stage, tid, 0};
+        uint32_t sv[MS + 1];
+#pragma unroll
+        for (int s = 0; s <= MS; ++s) sv[s] = sv_next[s];
+        const int rl = rl_next;
+        if (r + 256 < c1) { contig_offsets<MS>(b.seg_off + (u64)(r + 256) * (uint32_t)b.nseg, b.nseg, sv_next); rl_next = (int)b.read_len[r + 256]; }
         if (r < c1) {
-            int st = span_read_contig<MS>(g, p, b.hits, b.seg_off + (u64)r * (uint32_t)b.nseg, b.nseg, b.planes + (u64)r * (uint32_t)(3 * b.W), b.W,
-                                      (int)b.read_len[r], b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss);
+            int st = span_read_contig_pre<MS>(g, p, b.hits, sv, b.nseg, b.planes + (u64)r * (uint32_t)(3 * b.W), b.W,
+                                          rl, b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss);
             if (st == SPAN_NEED_LEAN) { if (!THJ_EXPF(64)) t.wl_lean[c0 + atomicAdd(&s_cnt[0], 1u)] = r; }
             else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = r;
             else {

@@ -1315,9 +1315,15 @@ THJ_HD int contig_finish(const Genome& g, const Params& p, const Src& src, uint3
     return SPAN_OK;
 }
 
+// the read's segment offsets, fetched in one go (the kernel does this one read ahead)
+template <int MS>
+THJ_HD void contig_offsets(const uint32_t* so, int nseg, uint32_t (&sv)[MS + 1]) {
+#pragma unroll
+    for (int s = 0; s <= MS; ++s) sv[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
+}
 template <int MS = SPAN_MAXSEG, class Sink>
-THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
-                            const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t (&sv)[MS + 1], int nseg,
+                                const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
     // Memory round trips, not arithmetic, bound this tier: the read's planes (when they fit six registers) and the
     // segment offsets are fetched in one go, then every hit head in one go, and only then is anything decided.
     RegRead rw;
@@ -1327,9 +1333,6 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
 #pragma unroll
         for (int k = 0; k < 6; ++k) rw.v[k] = rp[k];
     } else if (W == 1) { rw.v[0] = rp[0]; rw.v[2] = rp[1]; rw.v[4] = rp[2]; }
-    uint32_t sv[MS + 1];
-#pragma unroll
-    for (int s = 0; s <= MS; ++s) sv[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
     if (sv[1] == sv[0]) return SPAN_OK;
     int nsegs = 0;
     {
@@ -1383,6 +1386,13 @@ THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hit
     if (g_len(g, h0.ref_id) == 0) return SPAN_OK;    // check_editdist_consistency / bowtie_sam_extra need the contig
     if (W <= 2) return contig_finish(g, p, rw, h0.ref_id, left, total, mm8, anti, nsegs, rl, qual, read_idx, sink);
     return contig_finish(g, p, MemRead{rp, W}, h0.ref_id, left, total, mm8, anti, nsegs, rl, qual, read_idx, sink);
+}
+template <int MS = SPAN_MAXSEG, class Sink>
+THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
+                            const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+    uint32_t sv[MS + 1];
+    contig_offsets<MS>(so, nseg, sv);
+    return span_read_contig_pre<MS>(g, p, hits, sv, nseg, rp, W, rl, qual, read_idx, sink);
 }
 
 }  // namespace thj
