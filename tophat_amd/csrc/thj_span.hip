@@ -176,11 +176,11 @@ __device__ __forceinline__ int slice_of(const unsigned int* s_off, int G, unsign
 // Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain on registers.
 template <int MS>
 __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
-    extern __shared__ uint4 lds_stage[];          // nseg hits per thread
+    extern __shared__ uint4 lds_stage[];          // nseg hit heads per thread
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
-    SpanHit* stage = (SpanHit*)lds_stage + (size_t)threadIdx.x * b.nseg;
+    SpanHitHead* stage = (SpanHitHead*)lds_stage + (size_t)threadIdx.x * b.nseg;
     const unsigned int total = slice_offsets<256>(t.blk_lean, G, s_off);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int sl = slice_of(s_off, G, i);
@@ -524,8 +524,8 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
     const int64_t g1 = G, g2 = G;
-    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
-    else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
     const int caph = b.nseg <= 4 ? 12 : 16;           // hit heads staged per read in tier 2 (16 bytes each)
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_multihit<4>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);

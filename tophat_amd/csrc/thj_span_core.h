@@ -795,6 +795,25 @@ THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
     return 0;
 }
 
+// Hits staged as 16-byte heads -- contig, left, flags, first cigar op: everything a plain-match hit carries -- with the
+// rare longer cigar's tail fetched from global memory on demand.
+struct alignas(16) SpanHitHead { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar0; };
+THJ_HD SpanHit staged_hit(const SpanHitHead* heads, const SpanHit* g0, int k) {
+    const SpanHitHead hh = heads[k];
+    SpanHit h;
+    h.ref_id = hh.ref_id; h.left = hh.left; h.meta = hh.meta; h.cigar[0] = hh.cigar0;
+    h.cigar[1] = h.cigar[2] = h.cigar[3] = h.cigar[4] = 0;
+    if ((hh.meta >> 24) > 1) {
+        const Q16 t = ((const Q16*)(g0 + k))[1];
+        h.cigar[1] = t.x; h.cigar[2] = t.y; h.cigar[3] = t.z; h.cigar[4] = t.w;
+    }
+    return h;
+}
+struct StagedHits {         // the chain under construction: segment s's hit is staged hit number (sel >> 4s) & 15
+    const SpanHitHead* heads; const SpanHit* g0; u64 sel;
+    THJ_HD SpanHit operator[](int s) const { return staged_hit(heads, g0, (int)((sel >> (4 * s)) & 15)); }
+};
+
 // ---- lean machinery shared by tiers 1 and 2 -----------------------------------------------------------------
 // lean_join: ONE chain -- hits[s] is the hit chosen for segment s -- through merge_chain on register cigars.
 enum { LJ_NONE = 0, LJ_OK = 1, LJ_PUNT = 2 };       // no alignment / `res` holds the joined hit / needs more cigar ops than LEAN_C
@@ -918,12 +937,13 @@ THJ_HD int lean_finish(const Genome& g, const Params& p, const RAln& res, int ns
     return SPAN_OK;
 }
 
-// Tier 1.  `stage`: room for the read's nseg hits (LDS in the kernel).  The hits of a one-hit-per-segment read are
-// consecutive records: they are fetched once, back to back, and every later step reads the staged copy instead of
-// paying another HBM round trip.
+// Tier 1.  `heads`: room for the heads of the read's nseg hits (LDS in the kernel).  The hits of a one-hit-per-segment
+// read are consecutive records: their heads are fetched once, back to back, and every later step reads the staged
+// copy instead of paying another HBM round trip (fetching the full 32-byte records was measured at 0.23 ms of a
+// 0.81 ms launch; only a segment hit that is itself spliced has a tail to fetch).
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
-                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHit* stage, Sink& sink) {
+                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, Sink& sink) {
     uint32_t sof[MS + 1];
 #pragma unroll
     for (int s = 0; s <= MS; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
@@ -944,20 +964,16 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
         if (!(ghits[last_so].meta & SH_END)) return SPAN_OK;
         return SPAN_NEED_GENERIC;
     }
+    if (THJ_EXPF(65536)) return SPAN_OK;
     {
-        const Q16* src = (const Q16*)(ghits + sof[0]);
-        Q16* dst = (Q16*)stage;
+        Q16 tmp[MS];                            // the heads of the read's (consecutive) hits, all in flight together
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {              // two rounds of up to eight 16-byte loads in flight
-            Q16 tmp[MS];
+        for (int k = 0; k < MS; ++k) if (k < nsegs) tmp[k] = *(const Q16*)(ghits + sof[0] + k);
 #pragma unroll
-            for (int k = 0; k < MS; ++k) if (half * MS + k < 2 * nsegs) tmp[k] = src[half * MS + k];
-#pragma unroll
-            for (int k = 0; k < MS; ++k) if (half * MS + k < 2 * nsegs) dst[half * MS + k] = tmp[k];
-        }
+        for (int k = 0; k < MS; ++k) if (k < nsegs) ((Q16*)heads)[k] = tmp[k];
     }
-    const SpanHit* hits = stage;             // from here on: segment s's hit is hits[s]
-    if (!(hits[nsegs - 1].meta & SH_END)) return SPAN_OK;
+    const StagedHits hits{heads, ghits + sof[0], 0x76543210ull};      // segment s's hit is staged hit s
+    if (!(heads[nsegs - 1].meta & SH_END)) return SPAN_OK;
     if (THJ_EXPF(256)) return SPAN_OK;
     RAln res;
     const int jr = lean_join(g, p, S, hits, nsegs, rp, W, rl, res);
@@ -1022,22 +1038,6 @@ THJ_HD int multi_finish(const Genome& g, const Params& p, RAln* joined, int nj, 
 // left, flags, first cigar op: everything a plain-match hit carries -- are fetched back to back into LDS, so the DFS
 // and the joins never wait on HBM again (the global-memory DFS below pays a dependent round trip per candidate, and
 // re-reads a segment's candidates once per parent).  The rare hit with more cigar ops gets its tail from global memory.
-struct alignas(16) SpanHitHead { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar0; };
-THJ_HD SpanHit staged_hit(const SpanHitHead* heads, const SpanHit* g0, int k) {
-    const SpanHitHead hh = heads[k];
-    SpanHit h;
-    h.ref_id = hh.ref_id; h.left = hh.left; h.meta = hh.meta; h.cigar[0] = hh.cigar0;
-    h.cigar[1] = h.cigar[2] = h.cigar[3] = h.cigar[4] = 0;
-    if ((hh.meta >> 24) > 1) {
-        const Q16 t = ((const Q16*)(g0 + k))[1];
-        h.cigar[1] = t.x; h.cigar[2] = t.y; h.cigar[3] = t.z; h.cigar[4] = t.w;
-    }
-    return h;
-}
-struct StagedHits {         // the chain under construction: segment s's hit is staged hit number (sel >> 4s) & 15
-    const SpanHitHead* heads; const SpanHit* g0; u64 sel;
-    THJ_HD SpanHit operator[](int s) const { return staged_hit(heads, g0, (int)((sel >> (4 * s)) & 15)); }
-};
 template <int N> THJ_HD int rsel_get(const int (&a)[N], int i) {
     int r = 0;
 #pragma unroll
