@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Developer tool (GPU box): bench.py against several builds of the library in one gpurun call (boxes differ by a few
+percent, so A/B in the same call).  Usage: python tools/ab_bench.py libthj_a.so libthj_b.so ... (files in tophat_amd/csrc)"""
 import sys, json, subprocess, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for lib in sys.argv[1:]:
