@@ -11,8 +11,10 @@
  *   map_read_to_contig                :2946-2973
  * Colour-space (`if (color)`) branches are out of scope and omitted.
  *
- * PARITY: unpinned by the reference's own tests (none exist for this
- * boundary); see oracle/README.md for what it was checked against.
+ * PARITY: the junction search is pinned by the reference's regression case
+ * test_SimpleSplicing (tests/golden_ref/); the indel search, the rescue and
+ * the fusion search are unpinned by the reference's own tests; see
+ * oracle/README.md for what they were checked against.
  */
 #include "thj_oracle.h"
 #include <stdlib.h>

@@ -15,7 +15,9 @@
  *   BowtieHit::operator< / ==        bwt_map.h:167-207
  * Colour-space and fusion branches are out of scope and omitted.
  *
- * PARITY: unpinned by the reference's own tests; see oracle/README.md.
+ * PARITY: pinned in part by the reference's regression cases (every recorded
+ * alignment's strand / POS / CIGAR / NM, tests/golden_ref/); tags and record
+ * order are unpinned by the reference's own tests; see oracle/README.md.
  */
 #include "thj_oracle.h"
 #include <stdio.h>

@@ -13,10 +13,16 @@
  * device path (ASCII genome and reads, byte-at-a-time loops) so that agreement
  * between the two is evidence, not tautology.
  *
- * PARITY PINNING STATUS: see oracle/README.md.  The reference's own tests hold
- * no fixture for this boundary and the reference cannot
- * be built in this image without stand-ins for Boost / autotools output, so
- * formally: "parity unpinned".  oracle/README.md describes the informal
+ * PARITY PINNING STATUS: see oracle/README.md.  Pinned in part: the reference's
+ * own regression cases (tests/regression_tests/test_cases, fixtures under
+ * tests/golden_ref/) -- the junction of test_SimpleSplicing is found exactly,
+ * and every recorded alignment of the three cases (spliced, insertion and
+ * deletion records included) is reproduced with its strand, POS, CIGAR and NM.
+ * Everything those cases do not reach (segment_juncs' indel search, the
+ * mate-anchored rescue, paired-end input, fusions, the AS/XM/XO/XG/MD tags,
+ * record order) has no reference fixture, and the reference cannot be built
+ * in this image without stand-ins for Boost / autotools output: for those
+ * parts, formally "parity unpinned".  oracle/README.md describes the informal
  * differential checks that were run against a survey-stage scratch build.
  */
 #ifndef THJ_ORACLE_H
