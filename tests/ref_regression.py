@@ -123,7 +123,7 @@ def load(case: str, tmp_path, juncs_db_text):
     for l in open(os.path.join(d, "accepted_hits.tsv")):
         qn, flag, pos, cigar, nm = l.rstrip("\n").split("\t")
         expected.append((ids[qn], int(flag) & 16, int(pos), cigar, int(nm)))
-    return dict(p=p, names=[name], genome=genome, reads=reads, seg_batch=build_seg_batch(seg_recs, reads),
+    return dict(p=p, names=[name], genome=genome, reads=reads, seg_recs=seg_recs, spliced_sam=spliced, seg_batch=build_seg_batch(seg_recs, reads),
                 span_batch=build_span_batch(seg_recs, reads, quals, spl_recs), span_juncs=span_juncs, span_ins=span_ins,
                 recorded_juncs=sorted(juncs), recorded_dels=sorted(dels), recorded_ins=sorted(ins), expected=expected, files=files)
 
@@ -146,3 +146,29 @@ def check_recorded_alignments(case_data, alns):
         len(missing), missing[0], sorted(ours.get(missing[0][0], ())))
     gapped = sum(1 for e in case_data["expected"] if re.search("[NDI]", e[3]))
     return len(case_data["expected"]), gapped
+
+
+def write_program_inputs(case_data, tmp_path):
+    """the files tophat.py would hand to the two programs: ref.fa, hdr.sam, reads.fq (numbered reads), one id-sorted
+    SAM-text map per segment; -> dict of paths"""
+    name, genome, reads = case_data["names"][0], case_data["genome"], case_data["reads"]
+    f = {k: str(tmp_path / k) for k in ("ref.fa", "hdr.sam", "reads.fq", "left_map.sam")}
+    open(f["ref.fa"], "w").write(">%s\n%s\n" % (name, genome))
+    hdr = "@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:%s\tLN:%d\n" % (name, len(genome))
+    open(f["hdr.sam"], "w").write(hdr)
+    open(f["left_map.sam"], "w").write(hdr)
+    open(f["reads.fq"], "w").write("".join("@%d\n%s\n+\n%s\n" % (rid, r, "I" * len(r)) for rid, r in sorted(reads.items())))
+    segs = []
+    for s, recs in enumerate(case_data["seg_recs"]):
+        path = str(tmp_path / ("left_seg%d.sam" % (s + 1)))
+        with open(path, "w") as out:
+            out.write(hdr)
+            for (rid, _ref, left, right, anti, _end, _mm, _ed, rl) in recs:
+                segs_of = _segments(reads[rid])
+                q = segs_of[s].translate(_COMP)[::-1] if anti else segs_of[s]
+                nm_, md = md_nm(genome[left:right], q)
+                out.write("%d|%d:%d:%d\t%d\t%s\t%d\t255\t%dM\t*\t0\t0\t%s\t%s\tNM:i:%d\tMD:Z:%s\n" % (
+                    rid, s * SEG_LEN, s, len(segs_of), 16 if anti else 0, name, left + 1, rl, q, "I" * rl, nm_, md))
+        segs.append(path)
+    f["segs"] = segs
+    return f
