@@ -23,8 +23,13 @@ struct SideInput {
 // One side (segment_juncs.cpp:4776-4905): walk the nseg id-sorted segment maps in increasing id order -- the
 // visiting order of look_for_hit_group (segment_juncs.cpp:3823-4123; derivation in tophat_amd/batch.py) --
 // join the mate's maps by id (find_gaps :3321-3348), batch, run.
-static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, const SideInput* mate, int read_side,
-                     uint32_t& ordinal, size_t batch_reads) {
+// Both sides are ingested at the same time (two host threads, each with its own reader threads); the device calls of
+// a batch are serialised by `dev_mu`.  `ordinal` = visiting ordinal of the side's first read: the reference visits the
+// left side first (segment_juncs.cpp:4776-4905), so the right side starts at RIGHT_ORDINAL_BASE.
+static std::mutex dev_mu;
+static constexpr uint32_t RIGHT_ORDINAL_BASE = 1u << 28;
+static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, RefTable& rt, const SideInput& in, const SideInput* mate, int read_side,
+                     uint32_t ordinal, uint32_t ordinal_limit, size_t batch_reads) {
     const int nseg = (int)in.segs.size();
     if (nseg <= 1) return;                                  // segment_juncs.cpp:4752 (`size() > 1`)
     std::vector<HitStream> st((size_t)nseg);
@@ -51,7 +56,8 @@ static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, c
     auto flush = [&]() {
         int64_t n = (int64_t)read_off.size() - 1;
         if (n == 0) return;
-        g_timer.lap("ingest (parse + merge by id)");
+        if ((uint64_t)ordinal + (uint64_t)n > ordinal_limit)
+            die("Error: too many reads on the %s side for the device's read ordinals (limit %u)\n", read_side == 1 ? "left" : "right", ordinal_limit);
         int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
         std::vector<uint64_t> planes((size_t)n * 3 * W);
         std::vector<uint16_t> lens((size_t)n);
@@ -61,14 +67,17 @@ static void run_side(thj_ctx* ctx, Opts& o, RefTable& rt, const SideInput& in, c
         hb.seg_off = seg_off.data(); hb.hits = hits.data(); hb.read_planes = planes.data(); hb.read_len = lens.data();
         if (have_mate) { hb.mate_off = mate_off.data(); hb.mate_hits = mate_hits.data(); }
         hb.ordinal_base = ordinal;
-        thj_seg_batch* dev = nullptr;
-        if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
-        if (thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
-        if (o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
-        if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+        {
+            std::lock_guard<std::mutex> lk(dev_mu);
+            thj_ctx* ctx = device_ready();
+            thj_seg_batch* dev = nullptr;
+            if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
+            if (thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+            if (o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+            if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+        }
         ordinal += (uint32_t)n;
         reset();
-        g_timer.lap("pack + upload + launch");
     };
     reset();
     std::vector<std::vector<Hit>> grp((size_t)nseg);
@@ -134,26 +143,43 @@ int main(int argc, char** argv) {
     rt.load_fasta(pos[0]);
     g_timer.lap("options + reference FASTA");
 
+    // HIP start-up runs beside the first batches' ingest: the context is created on its own thread and picked up -- with
+    // the genome going up then -- by whichever side needs the device first (under dev_mu).
     int device = getenv("THJ_DEVICE") ? atoi(getenv("THJ_DEVICE")) : 0;
     thj_ctx* ctx = nullptr;
-    if (thj_ctx_create(device, nullptr, &ctx)) die("Error: %s\n", thj_last_error());
-    g_timer.lap("device context");
-    rt.upload(ctx);
-    g_timer.lap("genome pack + upload");
-    if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-    if (o.fusion_search && thj_fusion_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-    if (o.fusion_search && !o.fusion_ignore.empty()) {                 // segment_juncs.cpp:3214-3219
-        std::vector<uint32_t> ids;
-        for (auto& nm : split(o.fusion_ignore, ',')) if (!nm.empty()) ids.push_back(rt.get_id(nm));
-        if (thj_fusion_set_ignored(ctx, ids.data(), (int32_t)ids.size())) die("Error: %s\n", thj_last_error());
-    }
+    std::future<thj_ctx*> ctx_future = std::async(std::launch::async, [device]() {
+        thj_ctx* c = nullptr;
+        if (thj_ctx_create(device, nullptr, &c)) die("Error: %s\n", thj_last_error());
+        return c;
+    });
+    std::function<thj_ctx*()> device_ready = [&]() -> thj_ctx* {          // call with dev_mu held
+        if (ctx) return ctx;
+        ctx = ctx_future.get();
+        rt.upload(ctx);
+        if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+        if (o.fusion_search && thj_fusion_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+        if (o.fusion_search && !o.fusion_ignore.empty()) {                 // segment_juncs.cpp:3214-3219
+            std::vector<uint32_t> ids;
+            for (auto& nm : split(o.fusion_ignore, ',')) if (!nm.empty()) ids.push_back(rt.get_id(nm));
+            if (thj_fusion_set_ignored(ctx, ids.data(), (int32_t)ids.size())) die("Error: %s\n", thj_last_error());
+        }
+        return ctx;
+    };
     size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
-    uint32_t ordinal = 0;
     fprintf(stderr, ">> Performing segment-search:\n");
-    run_side(ctx, o, rt, left, right.segs.empty() ? nullptr : &right, 1, ordinal, batch_reads);
-    if (!right.segs.empty()) run_side(ctx, o, rt, right, &left, 2, ordinal, batch_reads);
+    const uint32_t ORD_END = (1u << 29) - 1;                 // device limit on read ordinals
+    if (right.segs.empty()) run_side(device_ready, o, rt, left, nullptr, 1, 0, ORD_END, batch_reads);
+    else if (getenv("THJ_SIDES_SEQUENTIAL")) {               // one side after the other (less host memory in flight)
+        run_side(device_ready, o, rt, left, &right, 1, 0, RIGHT_ORDINAL_BASE, batch_reads);
+        run_side(device_ready, o, rt, right, &left, 2, RIGHT_ORDINAL_BASE, ORD_END, batch_reads);
+    } else {
+        std::thread tl([&]() { run_side(device_ready, o, rt, left, &right, 1, 0, RIGHT_ORDINAL_BASE, batch_reads); });
+        run_side(device_ready, o, rt, right, &left, 2, RIGHT_ORDINAL_BASE, ORD_END, batch_reads);
+        tl.join();
+    }
 
-    g_timer.lap("ingest (parse + merge by id)");
+    { std::lock_guard<std::mutex> lk(dev_mu); device_ready(); }
+    g_timer.lap("device start-up + ingest + pack + upload + launch (both sides at once)");
     thj_segjuncs_counts n{};
     if (thj_segjuncs_finish(ctx, &n)) die("Error: %s\n", thj_last_error());
     std::vector<thj_junction> j((size_t)n.n_juncs + 1), d((size_t)n.n_deletions + 1);

@@ -21,6 +21,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <future>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -321,6 +322,7 @@ struct RefTable {
     }
     // pack + upload through the C ABI
     void upload(thj_ctx* ctx) {
+        std::lock_guard<std::mutex> lk(mu);          // reader threads may be adding unknown names by now
         int32_t n = (int32_t)names.size();
         std::vector<int64_t> lens(n); std::vector<const char*> ptrs(n);
         for (int32_t i = 0; i < n; ++i) { lens[i] = (int64_t)seqs[i].size(); ptrs[i] = seqs[i].empty() ? nullptr : seqs[i].data(); }
