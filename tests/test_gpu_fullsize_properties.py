@@ -24,7 +24,8 @@ from tophat_amd.synth import make_device_workload, make_scale_genome
 pytestmark = pytest.mark.gpu
 # (read length, pairs): configs[1] at full size, and the other read shapes of BASELINE.json's configs (76 bp = 3
 # segments, 150 bp = 6 segments -> the 8-segment kernel variants, 50 bp = 2 segments) at a few million pairs
-SHAPES = [(100, 10_000_000), (150, 2_000_000), (50, 4_000_000), (76, 2_000_000)]
+# ... and configs[1]'s shape with 15 % multihit reads (the second half of the genome a copy of the first: tiers 2 / 3)
+SHAPES = [(100, 10_000_000, 0.0), (150, 2_000_000, 0.0), (50, 4_000_000, 0.0), (76, 2_000_000, 0.0), (100, 3_000_000, 0.15)]
 
 
 def half(w, which):
@@ -47,19 +48,24 @@ def half(w, which):
     return out
 
 
-@pytest.fixture(scope="module", params=SHAPES, ids=lambda s: "%dbp_%dMpairs" % (s[0], s[1] // 1_000_000))
+@pytest.fixture(scope="module", params=SHAPES, ids=lambda s: "%dbp_%dMpairs%s" % (s[0], s[1] // 1_000_000, "_multihit" if s[2] else ""))
 def world(request):
-    read_len, pairs = request.param
+    read_len, pairs, multi_frac = request.param
     dev = torch.device("cuda", 0)
     seqs, genes = make_scale_genome(1, [CHR20_LEN], 20000, exon_len=300)
+    dup_shift = 0
+    if multi_frac > 0:
+        dup_shift = len(seqs[0]) // 2
+        seqs[0][dup_shift:2 * dup_shift] = seqs[0][:dup_shift]
+        genes = genes[(genes[:, 0] == 0) & (genes[:, 3] + 300 + 1000 < dup_shift)]
     strs = [s.tobytes().decode() for s in seqs]
-    w = make_device_workload(100, seqs, genes, None, pairs, dev, exon_len=300, read_len=read_len)
+    w = make_device_workload(100, seqs, genes, None, pairs, dev, exon_len=300, read_len=read_len, multi_frac=multi_frac, dup_shift=dup_shift)
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
     ctx = host.Context(0, stream=stream.cuda_stream)
     ctx.upload_genome(host.pack_genome(strs))
     ctx.configure(1 << 22, 1 << 20)
-    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream, read_len=read_len, pairs=pairs)
+    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream, read_len=read_len, pairs=pairs, multi_frac=multi_frac)
     ctx.close()
     del w
     torch.cuda.empty_cache()
@@ -127,6 +133,9 @@ def test_fullsize_properties(world):
         assert (rlen == read_len).all()
         assert (a["XM"] <= a["mismatches"]).all() and (a["mismatches"] <= 2).all()
         assert n > (0.8 if read_len <= 100 else 0.6) * PAIRS
+        if world["multi_frac"]:          # the multihit tier took its share and produced second records
+            assert ctx.span_tier_counts()[1] > 0.5 * world["multi_frac"] * PAIRS
+            assert int((a["order"] > 0).sum()) > 0.5 * world["multi_frac"] * PAIRS
         # sample parity, stage 2: records of the first m reads equal the oracle's, given the full junction set
         juncs, ins = events_to_span_inputs(ev)
         want = orc.spanning(p2, og, sample_spanbatch(w[sd], m), juncs, ins)
