@@ -1,0 +1,298 @@
+/*
+ * covsearch_oracle.c -- CPU oracle for segment_juncs' coverage search.
+ *
+ * TEST INFRASTRUCTURE ONLY (see thj_oracle.h).  Plain-C restatement, on ASCII data and byte-at-a-time loops, of
+ * DaehwanKimLab/tophat v2.1.2 src/segment_juncs.cpp:
+ *   MerExtension, store_read_extensions, index_read_mers    :146-180, :240-360, :396-571   (10-mer extension table of
+ *                                                            the first 32 bases of the initially unmapped reads)
+ *   build_coverage_map                                       :4140-4176
+ *   capture_island_ends                                      :4268-4543   (islands, look-left / look-right windows)
+ *   juncs_from_ref_segs<RecordExtendableJuncs>               :2052-2377   (POINT_DIR_LEFT / POINT_DIR_RIGHT windows)
+ *   IntronMotifs::unique / attach_mers                       :700-833
+ *   junction_key, left/right_extendable_junction,
+ *   extendable_junction, mismatching_bases                   :576-648, :1464-1566
+ *   RecordExtendableJuncs::record                            :1568-1626   (incl. the max_cov_juncs cap, :56)
+ * Colour-space branches are out of scope and omitted.
+ *
+ * PARITY: unpinned by the reference's own tests (none reach the coverage search); checked informally against the
+ * survey-stage scratch build (oracle/README.md).
+ */
+#include "thj_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* charToDna5 & 3 (segment_juncs.cpp:166-211, dna5str_to_idx :218-229): A/a 0, C/c 1, G/g 2, T/t 3, N and anything else 0 */
+static inline uint32_t base2(char c) {
+    switch (c) { case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': return 3; default: return 0; }
+}
+
+/* ---- the extension table (:146-180, :240-360) ----------------------------------------------------------- */
+#define MAX_EXTENSION_BP 14
+typedef struct { uint32_t left_str, right_str; uint8_t left_len, right_len; } mer_ext;
+typedef struct { int64_t* off; mer_ext* ext; } mer_table;      /* CSR over the 4^10 keys */
+#define N_KEYS (1u << 20)
+
+/* one pass of store_read_extensions (:240-360) over the read's first 32 bases; emit(key, ext) per seed position.
+ * seq_key_len = 5: the seed is 10 bases; `left` are the bases before it, `right` the bases after it. */
+static void read_extensions(const char* seq, int len, int64_t* counts, mer_table* t) {
+    if (len > 32) len = 32;                                   /* count_read_mers / store_read_mers :425, :520 */
+    if (len < 10) return;                                     /* the reference reads past the string here: undefined */
+    for (int i = 0; i + 10 <= len; ++i) {
+        uint32_t seed = 0;
+        for (int k = 0; k < 10; ++k) seed = (seed << 2) | base2(seq[i + k]);
+        if (!t) { counts[seed]++; continue; }
+        mer_ext e;
+        /* right: the min(len - 10 - i, 14) bases following the seed, first base most significant (:281-306) */
+        int rl = len - 10 - i; if (rl > MAX_EXTENSION_BP) rl = MAX_EXTENSION_BP;
+        uint32_t r = 0;
+        for (int k = 0; k < rl; ++k) r = (r << 2) | base2(seq[i + 10 + k]);
+        /* left: the low 28 bits of the bases before the seed = the last min(i, 14) of them (:295, :149) */
+        int ll = i < MAX_EXTENSION_BP ? i : MAX_EXTENSION_BP;
+        uint32_t l = 0;
+        for (int k = i - ll; k < i; ++k) l = (l << 2) | base2(seq[k]);
+        e.left_str = l & 0x0FFFFFFFu; e.right_str = r & 0x0FFFFFFFu; e.left_len = (uint8_t)ll; e.right_len = (uint8_t)rl;
+        t->ext[t->off[seed] + counts[seed]++] = e;
+    }
+}
+
+/* junction_key (:1506-1518) */
+static uint32_t junction_key(uint64_t up, uint64_t down) {
+    uint64_t up_half = up & ~(0xFFFFFFFFFFFFFFFFull << 10);
+    uint64_t down_half = (down & ~(0xFFFFFFFFFFFFFFFFull >> 10)) >> (64 - 10);
+    return ((uint32_t)up_half << 10) | (uint32_t)down_half;
+}
+/* mismatching_bases (:598-648) with max_mis = extension_mismatches = 0 (:1464): > 0 iff the low `len` bases differ */
+static int ext_mismatch(uint32_t w1, uint32_t w2, int len) {
+    uint32_t x = w1 ^ w2;
+    if (!x) return 0;
+    int bit = __builtin_ctz(x);
+    return (bit >> 1) < len;
+}
+/* extendable_junction (:1520-1566) = left_extendable_junction || right_extendable_junction (:1467-1504), min_ext_len 7 */
+static int extendable_junction(const mer_table* t, uint64_t up, uint64_t down) {
+    uint32_t key = junction_key(up, down);
+    up >>= 10; down <<= 10;
+    for (int64_t k = t->off[key]; k < t->off[key + 1]; ++k) {
+        const mer_ext* e = &t->ext[k];
+        if (e->left_len < 7) continue;
+        uint64_t u = up & ~(0xFFFFFFFFFFFFFFFFull << (e->left_len << 1));
+        if (!ext_mismatch(e->left_str, (uint32_t)u, e->left_len)) return 1;
+    }
+    for (int64_t k = t->off[key]; k < t->off[key + 1]; ++k) {
+        const mer_ext* e = &t->ext[k];
+        if (e->right_len < 7) continue;
+        uint64_t d = down & ~(0xFFFFFFFFFFFFFFFFull >> (e->right_len << 1));
+        d >>= ((32 - e->right_len) << 1);
+        if (!ext_mismatch(e->right_str, (uint32_t)d, e->right_len)) return 1;
+    }
+    return 0;
+}
+/* rc_dna_str (:650-661) */
+static uint64_t rc_dna_str(uint64_t s) {
+    s = ~s;
+    uint64_t rc = 0;
+    for (int i = 0; i < 32; ++i) { rc = (rc << 2) | (s & 3); s >>= 2; }
+    return rc;
+}
+
+/* ---- sites -------------------------------------------------------------------------------------------------- */
+typedef struct { int64_t pos; uint64_t fwd, rev; } site;
+typedef struct { site* a; int64_t n, cap; } site_vec;
+static void sv_push(site_vec* v, int64_t pos) {
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 256; v->a = (site*)realloc(v->a, (size_t)v->cap * sizeof(site)); }
+    v->a[v->n].pos = pos; v->a[v->n].fwd = 0; v->a[v->n].rev = 0; v->n++;
+}
+static int site_cmp(const void* a, const void* b) { int64_t x = ((const site*)a)->pos, y = ((const site*)b)->pos; return x < y ? -1 : x > y; }
+static void sv_unique(site_vec* v) {                          /* IntronMotifs::unique (:712-724); strings are still (0,0) */
+    if (v->n == 0) return;
+    qsort(v->a, (size_t)v->n, sizeof(site), site_cmp);
+    int64_t w = 1;
+    for (int64_t i = 1; i < v->n; ++i) if (v->a[i].pos != v->a[w - 1].pos) v->a[w++] = v->a[i];
+    v->n = w;
+}
+static uint64_t mer32(const char* s) { uint64_t x = 0; for (int i = 0; i < 32; ++i) x = (x << 2) | base2(s[i]); return x; }
+/* attach_upstream_mers / attach_downstream_mers (:741-833): sites too close to a contig end keep (0, 0) */
+static void attach_upstream(const char* ref, int64_t len, site_vec* v) {
+    for (int64_t i = 0; i < v->n; ++i) {
+        int64_t pos = v->a[i].pos;
+        if (pos <= 32 || pos >= len) continue;
+        v->a[i].fwd = mer32(ref + pos - 32); v->a[i].rev = rc_dna_str(v->a[i].fwd);
+    }
+}
+static void attach_downstream(const char* ref, int64_t len, site_vec* v) {
+    for (int64_t i = 0; i < v->n; ++i) {
+        int64_t pos = v->a[i].pos;
+        if (pos + 2 + 32 >= len) continue;
+        v->a[i].fwd = mer32(ref + pos + 2); v->a[i].rev = rc_dna_str(v->a[i].fwd);
+    }
+}
+
+typedef struct { uint64_t skip; orc_junction j; } cand;
+typedef struct { cand* a; int64_t n, cap; } cand_vec;
+static void cv_push(cand_vec* v, uint32_t ref, int64_t left, int64_t right, int anti, uint64_t skip) {
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 1024; v->a = (cand*)realloc(v->a, (size_t)v->cap * sizeof(cand)); }
+    cand* c = &v->a[v->n++];
+    c->skip = skip; c->j.ref_id = ref; c->j.left = (uint32_t)left; c->j.right = (uint32_t)right; c->j.antisense = (uint32_t)anti;
+}
+/* RecordExtendableJuncs::record (:1568-1626) */
+static void record(const mer_table* t, uint32_t ref, const site_vec* L, const site_vec* R, int antisense, int min_intron, int max_intron, cand_vec* out) {
+    int64_t curr_R = 0;
+    for (int64_t l = 0; l < L->n; ++l) {
+        while (curr_R < R->n && R->a[curr_R].pos < L->a[l].pos + min_intron) curr_R++;
+        int64_t max_right = L->a[l].pos + max_intron;
+        for (int64_t r = curr_R; r < R->n && R->a[r].pos < max_right; ++r)
+            if (extendable_junction(t, L->a[l].fwd, R->a[r].fwd) || extendable_junction(t, R->a[r].rev, L->a[l].rev))
+                cv_push(out, ref, L->a[l].pos - 1, R->a[r].pos + 2, antisense, (uint64_t)(r - curr_R));
+    }
+}
+static int junc_cmp(const orc_junction* a, const orc_junction* b) {     /* Junction::operator< (junctions.h:39-57) */
+    if (a->ref_id != b->ref_id) return a->ref_id < b->ref_id ? -1 : 1;
+    if (a->left != b->left) return a->left < b->left ? -1 : 1;
+    if (a->right != b->right) return a->right < b->right ? -1 : 1;
+    if (a->antisense != b->antisense) return a->antisense < b->antisense ? -1 : 1;
+    return 0;
+}
+static int cand_cmp(const void* a, const void* b) {                      /* skip_count_lt (junctions.h:72-80) */
+    const cand* x = (const cand*)a; const cand* y = (const cand*)b;
+    if (x->skip != y->skip) return x->skip < y->skip ? -1 : 1;
+    return junc_cmp(&x->j, &y->j);
+}
+static int junc_cmp_v(const void* a, const void* b) { return junc_cmp((const orc_junction*)a, (const orc_junction*)b); }
+
+typedef struct { uint32_t ref; int64_t left, right; } window;
+typedef struct { window* a; int64_t n, cap; } win_vec;
+static window* wv_push(win_vec* v, uint32_t ref, int64_t left, int64_t right) {
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 256; v->a = (window*)realloc(v->a, (size_t)v->cap * sizeof(window)); }
+    v->a[v->n].ref = ref; v->a[v->n].left = left; v->a[v->n].right = right;
+    return &v->a[v->n++];
+}
+
+int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits,
+                        const char* ium_bases, const int64_t* ium_off, int64_t n_ium,
+                        int min_cov_length, int min_intron, int max_intron, int64_t max_juncs,
+                        orc_junction** out, int64_t* n_out) {
+    enum { LOOK_LEFT = 1, LOOK_RIGHT = 2 };
+    static const int extend = 45, repeat_tol = 5;              /* :4346-4347 */
+    /* ---- index_read_mers (:548-571): count, size, store */
+    mer_table t;
+    int64_t* counts = (int64_t*)calloc(N_KEYS, sizeof(int64_t));
+    for (int64_t r = 0; r < n_ium; ++r) read_extensions(ium_bases + ium_off[r], (int)(ium_off[r + 1] - ium_off[r]), counts, NULL);
+    t.off = (int64_t*)malloc(((size_t)N_KEYS + 1) * sizeof(int64_t));
+    t.off[0] = 0;
+    for (uint32_t k = 0; k < N_KEYS; ++k) t.off[k + 1] = t.off[k] + counts[k];
+    t.ext = (mer_ext*)malloc((size_t)(t.off[N_KEYS] + 1) * sizeof(mer_ext));
+    memset(counts, 0, (size_t)N_KEYS * sizeof(int64_t));
+    for (int64_t r = 0; r < n_ium; ++r) read_extensions(ium_bases + ium_off[r], (int)(ium_off[r + 1] - ium_off[r]), counts, &t);
+    free(counts);
+
+    /* ---- build_coverage_map (:4140-4176) + capture_island_ends (:4268-4543), contigs in increasing ref_id order */
+    const int nc = g->n_contigs;
+    int64_t* cov_size = (int64_t*)calloc((size_t)nc + 1, sizeof(int64_t));
+    for (int64_t h = 0; h < n_hits; ++h) {
+        uint32_t ref = hits[h].ref_id;
+        if (ref == 0 || ref > (uint32_t)nc) continue;
+        int64_t right = (uint32_t)hits[h].right;              /* size_t right_extent = bh.right() */
+        if (right >= cov_size[ref]) cov_size[ref] = right + 1;
+    }
+    win_vec look_left = {0, 0, 0}, look_right = {0, 0, 0};
+    for (int ref = 1; ref <= nc; ++ref) {
+        /* a contig enters the map when a hit lands on it, even one with right() == 0 (then cov.size() == 1) */
+        int has = 0;
+        for (int64_t h = 0; h < n_hits && !has; ++h) has = hits[h].ref_id == (uint32_t)ref;
+        if (!has) continue;
+        const int64_t n = cov_size[ref] ? cov_size[ref] : 0;
+        uint8_t* cov = (uint8_t*)calloc((size_t)n + 1, 1);
+        for (int64_t h = 0; h < n_hits; ++h)
+            if (hits[h].ref_id == (uint32_t)ref)
+                for (uint32_t c = (uint32_t)hits[h].left; c < (uint32_t)hits[h].right; ++c) cov[c] = 1;
+        uint8_t* long_enough = (uint8_t*)calloc((size_t)n + 1, 1);
+        int64_t last_uncovered = 0;
+        for (int64_t c = 1; c < n; ++c) {                      /* :4368-4394 */
+            if (!cov[c] || c == n - 1) {
+                int putative_exon_length = (int)c - (int)last_uncovered;
+                if (cov[c - 1] && putative_exon_length >= min_cov_length)
+                    for (int64_t l = c; l > last_uncovered; --l) long_enough[l] = 1;
+                last_uncovered = c;
+            }
+        }
+        uint8_t* state = (uint8_t*)calloc((size_t)n + 1, 1);
+        for (int64_t c = 1; c < n; ++c) {                      /* :4426-4455 */
+            if (long_enough[c]) {
+                if (!long_enough[c - 1])
+                    for (int64_t r = c - extend; r >= 0 && r < c + repeat_tol && r < n; ++r) state[r] |= LOOK_LEFT;
+            } else if (long_enough[c - 1])
+                for (int64_t l = c - repeat_tol; l >= 0 && l < c + extend && l < n; ++l) state[l] |= LOOK_RIGHT;
+        }
+        window* cl = NULL; window* cr = NULL;                  /* :4457-4512; indices, not pointers: the vectors may move */
+        int64_t il = -1, ir = -1;
+        (void)cl; (void)cr;
+        for (int64_t c = 1; c < n; ++c) {
+            if (state[c] & LOOK_LEFT) {
+                if (!(state[c - 1] & LOOK_LEFT)) { wv_push(&look_left, (uint32_t)ref, c, c + 1); il = look_left.n - 1; }
+                else if (il >= 0) look_left.a[il].right++;
+            } else if (state[c - 1] & LOOK_LEFT) il = -1;
+            if (state[c] & LOOK_RIGHT) {
+                if (!(state[c - 1] & LOOK_RIGHT)) { wv_push(&look_right, (uint32_t)ref, c, c + 1); ir = look_right.n - 1; }
+                else if (ir >= 0) look_right.a[ir].right++;
+            } else if (state[c - 1] & LOOK_RIGHT) ir = -1;
+        }
+        free(cov); free(long_enough); free(state);
+    }
+    free(cov_size);
+
+    /* ---- juncs_from_ref_segs<RecordExtendableJuncs> (:2052-2377) over look-right then look-left windows, "GT" / "AG" */
+    site_vec* fd = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));    /* fwd_donors   GT  (look right) */
+    site_vec* ra = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));    /* rev_acceptors CT (look right) */
+    site_vec* fa = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));    /* fwd_acceptors AG (look left)  */
+    site_vec* rd = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));    /* rev_donors   AC  (look left)  */
+    uint8_t* in_map = (uint8_t*)calloc((size_t)nc + 1, 1);
+    for (int pass = 0; pass < 2; ++pass) {
+        const win_vec* wv = pass == 0 ? &look_right : &look_left;
+        for (int64_t w = 0; w < wv->n; ++w) {
+            const window* s = &wv->a[w];
+            const char* ref = g->seq[s->ref - 1];
+            if (!ref) continue;                                /* :2105-2106 */
+            in_map[s->ref] = 1;                                /* ims.insert happens before the bounds test (:2140-2143) */
+            const int64_t len = g->len[s->ref - 1];
+            if (s->left < 0 || s->right >= len - 1) continue;  /* :2154 */
+            const int64_t seg_len = s->right - s->left;
+            for (int64_t i = 0; i + 2 <= seg_len; ++i) {       /* to = seg_len - 2 (:2171-2175); DnaString folds N to A */
+                uint32_t b0 = base2(ref[s->left + i]), b1 = base2(ref[s->left + i + 1]);
+                if (pass == 1) {
+                    if (b0 == 0 && b1 == 2) sv_push(&fa[s->ref], s->left + i);          /* AG */
+                    else if (b0 == 0 && b1 == 1) sv_push(&rd[s->ref], s->left + i);     /* rc(GT) = AC */
+                } else {
+                    if (b0 == 2 && b1 == 3) sv_push(&fd[s->ref], s->left + i);          /* GT */
+                    else if (b0 == 1 && b1 == 3) sv_push(&ra[s->ref], s->left + i);     /* rc(AG) = CT */
+                }
+            }
+        }
+    }
+    cand_vec cands = {0, 0, 0};
+    for (int ref = 1; ref <= nc; ++ref) {
+        if (!in_map[ref]) continue;
+        const char* rs = g->seq[ref - 1];
+        const int64_t len = g->len[ref - 1];
+        sv_unique(&fd[ref]); sv_unique(&fa[ref]); sv_unique(&rd[ref]); sv_unique(&ra[ref]);      /* !all_both (:2320-2321) */
+        attach_upstream(rs, len, &fd[ref]); attach_upstream(rs, len, &ra[ref]);                /* :726-732 */
+        attach_downstream(rs, len, &rd[ref]); attach_downstream(rs, len, &fa[ref]);
+        record(&t, (uint32_t)ref, &fd[ref], &fa[ref], 0, min_intron, max_intron, &cands);
+        record(&t, (uint32_t)ref, &ra[ref], &rd[ref], 1, min_intron, max_intron, &cands);
+    }
+    /* the set<Junction, skip_count_lt> with its cap (:1611-1621): what survives is the max_juncs smallest distinct
+     * (skip_count, junction) elements; merged into the coordinate-ordered set afterwards (:5027) */
+    qsort(cands.a, (size_t)cands.n, sizeof(cand), cand_cmp);
+    int64_t m = 0;
+    for (int64_t i = 0; i < cands.n; ++i) if (m == 0 || cand_cmp(&cands.a[m - 1], &cands.a[i]) != 0) cands.a[m++] = cands.a[i];
+    if (m > max_juncs) m = max_juncs;
+    orc_junction* res = (orc_junction*)malloc((size_t)(m + 1) * sizeof(orc_junction));
+    for (int64_t i = 0; i < m; ++i) res[i] = cands.a[i].j;
+    qsort(res, (size_t)m, sizeof(orc_junction), junc_cmp_v);
+    int64_t k = 0;
+    for (int64_t i = 0; i < m; ++i) if (k == 0 || junc_cmp(&res[k - 1], &res[i]) != 0) res[k++] = res[i];
+    *out = res; *n_out = k;
+    for (int ref = 0; ref <= nc; ++ref) { free(fd[ref].a); free(fa[ref].a); free(rd[ref].a); free(ra[ref].a); }
+    free(fd); free(fa); free(rd); free(ra); free(in_map); free(cands.a);
+    free(look_left.a); free(look_right.a); free(t.off); free(t.ext);
+    return 0;
+}

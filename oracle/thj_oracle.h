@@ -150,6 +150,14 @@ char* orc_juncs_db(const orc_genome* g, const char* const* names, int read_len, 
                    const uint32_t* ins_ref, const uint32_t* ins_left, const char* const* ins_seq, int64_t n_ins,
                    const orc_fusion* fus, int64_t n_fus);
 
+/* Coverage search of segment_juncs (covsearch_oracle.c; segment_juncs.cpp:4268-4543 and what it calls): `hits` = every
+ * record of every segment map of both sides (only ref_id / left / right are read); the initially unmapped reads as one
+ * base string with n_ium + 1 offsets; -> junctions in Junction::operator< order (malloc'd, orc_free). */
+int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits,
+                        const char* ium_bases, const int64_t* ium_off, int64_t n_ium,
+                        int min_cov_length, int min_intron, int max_intron, int64_t max_juncs,
+                        orc_junction** out, int64_t* n_out);
+
 /* ===================== long_spanning_reads (spanning_oracle.c) ===================== */
 
 /* CigarOpCode values of bwt_map.h:36-55 */

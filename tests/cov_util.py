@@ -1,0 +1,61 @@
+"""Loading the coverage-search fixtures under tests/golden_cov/ through the host parsing rules.  Test infrastructure."""
+import os
+import re
+
+import numpy as np
+
+from tophat_amd.batch import HIT_DTYPE, build_seg_batch, hit_tuple_to_struct
+from tophat_amd.params import Params, READ_LEFT, READ_RIGHT
+from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_cov")
+CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+
+
+def load(name):
+    d = os.path.join(GOLD, name)
+    opts = open(os.path.join(d, "options.txt")).read().split("\n")
+    argv = opts[0].split()
+    kv = dict(x.split("=") for x in opts[1].split())
+    p = Params(segment_length=int(kv["segment_length"]))
+    cov = dict(min_intron=50, max_intron=20000)                 # common.cpp:112-113
+    for i in range(0, len(argv), 2):
+        if argv[i] == "--inner-dist-mean":
+            p.inner_dist_mean = int(argv[i + 1])
+        elif argv[i] == "--inner-dist-std-dev":
+            p.inner_dist_std_dev = int(argv[i + 1])
+        elif argv[i] == "--min-coverage-intron":
+            cov["min_intron"] = int(argv[i + 1])
+        elif argv[i] == "--max-coverage-intron":
+            cov["max_intron"] = int(argv[i + 1])
+    cov["min_cov_length"] = min(20, p.segment_length - 2)       # segment_juncs.cpp:62, :5350
+    names, _ = parse_header(os.path.join(d, "hdr.sam"))
+    fa_names, fa_seqs = read_fasta(os.path.join(d, "ref.fa"))
+    seqs = [dict(zip(fa_names, fa_seqs)).get(n) for n in names]
+    ref_ids = {n: i + 1 for i, n in enumerate(names)}
+    paired = kv["paired"] == "1"
+    nseg = len([f for f in os.listdir(d) if re.fullmatch(r"left_seg\d+\.sam", f)])
+    sides = {}
+    for sd in (("left", "right") if paired else ("left",)):
+        sides[sd] = dict(reads=read_fastq(os.path.join(d, "%s.fq" % sd)),
+                         segs=[list(parse_sam_hits(os.path.join(d, "%s_seg%d.sam" % (sd, k + 1)), ref_ids, p.max_report_intron)) for k in range(nseg)],
+                         full=list(parse_sam_hits(os.path.join(d, "%s_map.sam" % sd), ref_ids, p.max_report_intron)))
+    seg_batches, hits, ium = [], [], []
+    for sd, side in (("left", READ_LEFT), ("right", READ_RIGHT)):
+        if sd not in sides:
+            continue
+        other = "right" if sd == "left" else "left"
+        b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1]) if paired \
+            else build_seg_batch(sides[sd]["segs"], sides[sd]["reads"])
+        seg_batches.append((side, b))
+        for recs in sides[sd]["segs"]:                          # all_segmap_fnames: left maps then right maps (:4929-4935)
+            hits += [hit_tuple_to_struct(h) for h in recs]
+        ium += [sides[sd]["reads"][rid] for rid in sorted(sides[sd]["reads"])]      # --ium-reads left.fq[,right.fq]
+    return dict(p=p, cov=cov, names=names, seqs=seqs, seg_batches=seg_batches, hits=np.array(hits, dtype=HIT_DTYPE), ium=ium,
+                expected=open(os.path.join(d, "expected.juncs")).read(), expected_seg_only=open(os.path.join(d, "expected.seg_only.juncs")).read(),
+                dir=d, paired=paired, nseg=nseg)
+
+
+def juncs_text(juncs, names):
+    """segment.juncs lines (segment_juncs.cpp:5035-5060) of a set of (ref_id, left, right, antisense)"""
+    return "".join("%s\t%d\t%d\t%s\n" % (names[r - 1], l, rt, "-" if a else "+") for (r, l, rt, a) in sorted(juncs))

@@ -1,0 +1,39 @@
+"""Coverage search, CPU: the oracle's restatement (oracle/covsearch_oracle.c) against the
+fixtures under tests/golden_cov/ (outputs of the survey-stage scratch build of the reference, see oracle/README.md)."""
+import copy
+
+import pytest
+
+import orc
+from cov_util import CASES, juncs_text, load
+from tophat_amd.batch import merge_events
+
+
+def _tuples(a):
+    return {(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"])) for j in a}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_coverage_search_fixture(name):
+    c = load(name)
+    g = orc.Genome([None if s is None else orc.fold_genome_char(s) for s in c["seqs"]])
+    ev = None
+    for side, b in c["seg_batches"]:
+        p = copy.copy(c["p"])
+        p.read_side = side
+        e = orc.segjuncs(p, g, b)
+        ev = e if ev is None else merge_events(ev, e)
+    seg = _tuples(ev.juncs)
+    assert juncs_text(seg, c["names"]) == c["expected_seg_only"]
+    cov = _tuples(orc.coverage_search(g, c["hits"], c["ium"], c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"]))
+    assert len(cov - seg) >= 3, "the case must have junctions only the coverage search finds"
+    assert juncs_text(seg | cov, c["names"]) == c["expected"]
+
+
+def test_cap_keeps_the_lowest_skip_counts():
+    """max_cov_juncs (segment_juncs.cpp:56, :1611-1621): the set ordered by skip count keeps its smallest elements"""
+    c = load(CASES[0])
+    g = orc.Genome([orc.fold_genome_char(s) for s in c["seqs"]])
+    full = _tuples(orc.coverage_search(g, c["hits"], c["ium"], c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"]))
+    capped = _tuples(orc.coverage_search(g, c["hits"], c["ium"], c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"], max_juncs=5))
+    assert len(capped) <= 5 and capped <= full and len(full) > 5
