@@ -329,6 +329,22 @@ int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[3]*/);
  * [2] thj_k_stitch_multihit, [3] thj_k_stitch_generic -- from HIP events on the context stream. */
 int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[4]*/, int64_t* launches);
 
+/* ---- coverage search of segment_juncs (segment_juncs.cpp:4268-4543 capture_island_ends and what it calls: the
+ * coverage map of build_coverage_map :4140-4176, the extension table of index_read_mers :548-571,
+ * juncs_from_ref_segs<RecordExtendableJuncs> :2052-2377 with RecordExtendableJuncs::record :1568-1626).
+ * Call order inside one segment_juncs pass: thj_covsearch_reset_async; thj_covsearch_add_hits_async for every uploaded
+ * batch of both sides (the segment maps `all_segmap_fnames`, :4929-4935); thj_covsearch_add_reads for the initially
+ * unmapped reads (--ium-reads; planes in the thj_reads_pack layout and lengths, host buffers or -- on_device != 0 -- device
+ * buffers; only the first 32 bases of a read are used, :425); thj_covsearch_run_async inserts the junctions it finds into the pass's junction set,
+ * so it goes before thj_segjuncs_finish; thj_covsearch_finish returns their number and fails with THJ_EOVERFLOW when it
+ * exceeds max_cov_juncs (:56 -- the reference then keeps the lowest skip counts, which this path does not restate). */
+int thj_covsearch_reset_async(thj_ctx* ctx);
+int thj_covsearch_add_hits_async(thj_ctx* ctx, const thj_seg_batch* device_batch);
+int thj_covsearch_add_reads(thj_ctx* ctx, int64_t n_reads, int32_t words_per_plane, const uint64_t* planes, const uint16_t* lens,
+                            int32_t on_device);
+int thj_covsearch_run_async(thj_ctx* ctx, int32_t min_cov_length, int32_t min_coverage_intron, int32_t max_coverage_intron);
+int thj_covsearch_finish(thj_ctx* ctx, int64_t max_cov_juncs, int64_t* n_found);
+
 #ifdef __cplusplus
 }
 #endif

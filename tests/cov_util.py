@@ -45,8 +45,10 @@ def load(name):
         if sd not in sides:
             continue
         other = "right" if sd == "left" else "left"
-        b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1]) if paired \
-            else build_seg_batch(sides[sd]["segs"], sides[sd]["reads"])
+        # include_top0: reads mapped in their first segment only are neutral for the segment search, but their hits
+        # are part of the coverage map (build_coverage_map walks every record of every segment map)
+        b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1], include_top0=True) if paired \
+            else build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], include_top0=True)
         seg_batches.append((side, b))
         for recs in sides[sd]["segs"]:                          # all_segmap_fnames: left maps then right maps (:4929-4935)
             hits += [hit_tuple_to_struct(h) for h in recs]

@@ -210,3 +210,44 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
     memcpy(*out, res.data(), sizeof(OutAln) * res.size());
     return 0;
 }
+
+// ---- coverage search (thj_cov_core.h): the kernels of thj_covsearch_impl.h as plain loops over their thread index
+#include "../../tophat_amd/csrc/thj_cov_core.h"
+#include <algorithm>
+
+extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
+                                       int64_t n_blocks, const thj_hit* hits, int64_t n_hits,
+                                       const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
+                                       int32_t min_cov_length, int32_t min_intron, int32_t max_intron,
+                                       thj_junction** out, int64_t* n_out) {
+    using namespace thj::cov;
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    Layout L{contig_blk, contig_len, n_contigs, n_blocks};
+    const int64_t nw = n_blocks;
+    std::vector<u64> bm((size_t)nw * 8, 0);
+    u64 *covb = bm.data(), *le = covb + nw, *ll = le + nw, *lr = ll + nw, *fd = lr + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
+    std::vector<int32_t> cov_size((size_t)n_contigs + 1, 0);
+    for (int64_t i = 0; i < n_hits; ++i)
+        add_hit(L, *(const Hit*)&hits[i], [&](int64_t w, u64 m) { covb[w] |= m; }, [&](int k, int32_t sz) { if (sz > cov_size[(size_t)k]) cov_size[(size_t)k] = sz; });
+    std::vector<uint32_t> keys((size_t)n_ium * 23 + 1); std::vector<u64> vals((size_t)n_ium * 23 + 1);
+    for (int64_t r = 0; r < n_ium; ++r) read_entries((const u64*)ium_planes, ium_lens, W, keys.data(), vals.data(), 0, r);
+    std::vector<size_t> ord((size_t)n_ium * 23);
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+    std::vector<uint32_t> skeys(ord.size() + 1); std::vector<u64> svals(ord.size() + 1);
+    for (size_t i = 0; i < ord.size(); ++i) { skeys[i] = keys[ord[i]]; svals[i] = vals[ord[i]]; }
+    std::vector<uint32_t> off((size_t)N_KEYS + 2);
+    for (uint32_t k = 0; k <= N_KEYS; ++k) key_offset(skeys.data(), (int64_t)ord.size(), off.data(), k);
+    for (int64_t w = 0; w < nw; ++w) long_enough_word(L, covb, le, min_cov_length - 1, w);
+    for (int64_t w = 0; w < nw; ++w) look_word(L, le, cov_size.data(), ll, lr, w);
+    for (int i = 0; i < 2 * n_contigs; ++i) drop_windows(L, cov_size.data(), ll, lr, i);
+    for (int64_t w = 0; w < nw; ++w) site_word(g, L, ll, lr, fd, ra, fa, rd, w);
+    Collect c;
+    ExtTable et{off.data(), svals.data()};
+    for (int64_t w = 0; w < nw; ++w) pair_word(g, L, et, fd, fa, 0, min_intron, max_intron, w, c);
+    for (int64_t w = 0; w < nw; ++w) pair_word(g, L, et, ra, rd, 1, min_intron, max_intron, w, c);
+    *n_out = (int64_t)c.juncs.size();
+    *out = (thj_junction*)malloc(sizeof(thj_junction) * (c.juncs.size() + 1));
+    memcpy(*out, c.juncs.data(), sizeof(thj_junction) * c.juncs.size());
+    return 0;
+}

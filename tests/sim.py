@@ -114,3 +114,32 @@ def fusions(p: Params, seqs, b: SegBatch, ignore_ref_ids=()):
         a = np.frombuffer((C.c_char * (n.value * 32)).from_address(out.value), dtype=orc.FUSION_DTYPE).copy()
     l.hostsim_free(out)
     return orc.merge_fusions(a, np.zeros(0, dtype=orc.FUSION_DTYPE))
+
+
+def coverage_search(seqs, hits, ium_reads, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
+    """the coverage-search kernels (thj_cov_core.h) as host loops -> set of (ref_id, left, right, antisense)"""
+    from tophat_amd.batch import HIT_DTYPE
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    clen = g.lens.astype(np.int32)
+    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    n = len(ium_reads)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in ium_reads], out=off[1:])
+    bases = np.frombuffer("".join(ium_reads).encode(), dtype=np.uint8) if n else np.zeros(0, dtype=np.uint8)
+    W = host.words_per_plane(max([len(r) for r in ium_reads] + [1]))
+    planes = np.zeros(max(1, n * 3 * W), dtype=np.uint64)
+    lens = np.zeros(max(1, n), dtype=np.uint16)
+    if n:
+        assert l.thj_reads_pack(C.c_int64(n), C.c_void_p(off.ctypes.data), C.c_void_p(bases.ctypes.data), W, C.c_void_p(planes.ctypes.data),
+                                C.c_void_p(lens.ctypes.data)) == 0
+    out = C.c_void_p()
+    n_out = C.c_int64()
+    rc = l.hostsim_coverage_search(C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data),
+                                   g.n_contigs, C.c_int64(len(g.blocks) // 4), C.c_void_p(h.ctypes.data), C.c_int64(len(h)),
+                                   C.c_void_p(planes.ctypes.data), C.c_void_p(lens.ctypes.data), C.c_int64(n), W,
+                                   min_cov_length, min_intron, max_intron, C.byref(out), C.byref(n_out))
+    assert rc == 0
+    a = np.frombuffer((C.c_char * (max(1, n_out.value) * 16)).from_address(out.value), dtype=JUNC_DTYPE)[:n_out.value].copy()
+    l.hostsim_free(out)
+    return {(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"])) for j in a}

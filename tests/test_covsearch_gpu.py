@@ -1,0 +1,78 @@
+"""Coverage search, GPU: the HIP path through the C ABI against the fixtures under
+tests/golden_cov/ and, on seeded cases, against the oracle."""
+import copy
+
+import numpy as np
+import pytest
+
+import orc
+from cov_util import CASES, juncs_text, load
+from tophat_amd import host
+from tophat_amd.batch import HIT_DTYPE, build_seg_batch, hit_tuple_to_struct, merge_events
+from tophat_amd.params import Params, READ_LEFT, READ_RIGHT
+from tophat_amd.synth import make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _tuples(a):
+    return {(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"])) for j in a}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_hip_coverage_search_reproduces_fixture(name):
+    c = load(name)
+    seqs = [None if s is None else orc.fold_genome_char(s) for s in c["seqs"]]
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        runs, base = [], 0
+        for side, b in c["seg_batches"]:
+            p = copy.copy(c["p"])
+            p.read_side = side
+            runs.append((p, ctx.upload_batch(b, ordinal_base=base)))
+            base += b.n_reads
+        ev, found = ctx.segjuncs_with_coverage_search(runs, c["ium"], c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"])
+    assert juncs_text(_tuples(ev.juncs), c["names"]) == c["expected"]
+    g = orc.Genome(seqs)
+    assert found == len(orc.coverage_search(g, c["hits"], c["ium"], c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"]))
+
+
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_hip_coverage_search_matches_oracle(seed):
+    """seeded cases: contig ends inside islands, several contigs, N runs, odd segment lengths and intron bounds"""
+    rng = np.random.default_rng(seed)
+    seg_len = int(rng.choice([20, 25, 25, 30]))
+    paired = bool(seed % 2)
+    case = make_case(seed=seed, paired=paired, read_len=2 * seg_len, seg_len=seg_len, n_reads=int(rng.integers(400, 1500)),
+                     contig_lens=tuple(int(x) for x in rng.integers(8000, 30000, size=int(rng.integers(1, 4)))),
+                     genes_per_contig=int(rng.integers(2, 10)), spliced_seg_frac=0.0, n_frac=float(rng.choice([0.0, 0.1])))
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    g = orc.Genome(seqs)
+    min_ci, max_ci = int(rng.choice([50, 60, 100])), int(rng.choice([20000, 5000, 1500]))
+    min_cov = min(20, seg_len - 2)
+    p0 = Params(segment_length=seg_len, inner_dist_mean=50, inner_dist_std_dev=20)
+    want, hits, ium, batches = None, [], [], []
+    for sd, side in (("left", READ_LEFT), ("right", READ_RIGHT)):
+        if sd not in case.reads:
+            continue
+        other = "right" if sd == "left" else "left"
+        b = build_seg_batch(case.seg_recs[sd], case.reads[sd], case.full_recs[other], case.seg_recs[other][-1], include_top0=True) if paired \
+            else build_seg_batch(case.seg_recs[sd], case.reads[sd], include_top0=True)
+        p = copy.copy(p0)
+        p.read_side = side
+        batches.append((p, b))
+        e = orc.segjuncs(p, g, b)
+        want = e if want is None else merge_events(want, e)
+        for recs in case.seg_recs[sd]:
+            hits += [hit_tuple_to_struct(h) for h in recs]
+        ium += [case.reads[sd][rid] for rid in sorted(case.reads[sd])]
+    cov = orc.coverage_search(g, np.array(hits, dtype=HIT_DTYPE), ium, min_cov, min_ci, max_ci)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        runs, base = [], 0
+        for p, b in batches:
+            runs.append((p, ctx.upload_batch(b, ordinal_base=base)))
+            base += b.n_reads
+        ev, found = ctx.segjuncs_with_coverage_search(runs, ium, min_cov, min_ci, max_ci)
+    assert _tuples(ev.juncs) == _tuples(want.juncs) | _tuples(cov)
+    assert found == len(cov)

@@ -1,0 +1,241 @@
+// thj_cov_core.h -- per-thread logic of the coverage search (see thj_covsearch_impl.h for the kernels and the C ABI,
+// tests/hostsim for the CPU build that checks it against the oracle without a GPU).
+#ifndef THJ_COV_CORE_H
+#define THJ_COV_CORE_H
+#include "thj_core.h"
+
+namespace thj {
+namespace cov {
+
+static constexpr int EXTEND = 45, REPEAT_TOL = 5;       // capture_island_ends :4346-4347
+static constexpr int MAX_EXT_BP = 14;                   // MerExtension::MAX_EXTENSION_BP :148
+static constexpr uint32_t N_KEYS = 1u << 20;            // 4^10 seeds
+
+struct Layout { const uint32_t* contig_blk; const int32_t* contig_len; int32_t n_contigs; int64_t n_words; };
+
+// contig (0-based) owning word w: last k with contig_blk[k] <= w
+THJ_HD int contig_of(const Layout& L, int64_t w) {
+    int lo = 0, hi = L.n_contigs;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)L.contig_blk[mid] <= w) lo = mid; else hi = mid; }
+    return lo;
+}
+// word w of a bitmap with its neighbours inside the same contig (0 outside)
+struct W3 { u64 a, b, c; };
+THJ_HD W3 load3(const u64* bm, const Layout& L, int k, int64_t w) {
+    W3 r;
+    r.b = bm[w];
+    r.a = w > (int64_t)L.contig_blk[k] ? bm[w - 1] : 0ull;
+    r.c = w + 1 < (int64_t)L.contig_blk[k + 1] ? bm[w + 1] : 0ull;
+    return r;
+}
+// bits [s, s + 64) of the 128-bit value hi:lo, s in [0, 63]
+THJ_HD u64 shr2(u64 lo, u64 hi, int s) { return s ? (lo >> s) | (hi << (64 - s)) : lo; }
+// (x << s) with the top s bits of `below` shifted in, s in [0, 63]
+THJ_HD u64 shl2(u64 below, u64 x, int s) { return s ? (x << s) | (below >> (64 - s)) : x; }
+THJ_HD u64 below_mask(int64_t n_bits) { return n_bits >= 64 ? ~0ull : (n_bits <= 0 ? 0ull : ((1ull << n_bits) - 1ull)); }
+
+// ---- coverage from hits (build_coverage_map): bits [left, right) of every hit; per contig max(right) + 1
+template <class OrFn, class MaxFn>      // or_word(word index, mask), max_size(contig, size): atomics on the device
+THJ_HD void add_hit(const Layout& L, const Hit& h, OrFn or_word, MaxFn max_size) {
+    if (h.ref_id == 0 || (int32_t)h.ref_id > L.n_contigs) return;
+    const int k = (int)h.ref_id - 1;
+    const int64_t len = L.contig_len[k];
+    int64_t l = h.left, r = h.right;
+    if (r < 0) return;
+    max_size(k, (int32_t)(r > len ? len + 1 : r + 1));       // hits are inside their contig; clamp anyway
+    if (l < 0) l = 0;
+    if (r > len) r = len;
+    const int64_t base = (int64_t)L.contig_blk[k];
+    for (int64_t w = l >> 6; w <= (r - 1) >> 6 && l < r; ++w) {
+        const int64_t lo = w << 6;
+        const int64_t a = l > lo ? l - lo : 0, b = r < lo + 64 ? r - lo : 64;
+        const u64 m = below_mask(b) & ~below_mask(a);
+        if (m) or_word(base + w, m);
+    }
+}
+
+// ---- long_enough (:4368-4394).  A maximal covered run [a, b] qualifies when b - a + 2 >= min_len (b + 1 >= min_len for
+// a run starting at 0) and marks [max(a, 1), b + 1].  m = min_len - 1 >= 1.
+THJ_HD void long_enough_word(const Layout& L, const u64* covbits, u64* le, int m, int64_t w) {
+    const int k = contig_of(L, w);
+    const W3 x = load3(covbits, L, k, w);
+    u64 ea = ~0ull, eb = ~0ull;                      // erosion: a run of m covered bases starts here
+    for (int s = 0; s < m; ++s) { ea &= shr2(x.a, x.b, s); eb &= shr2(x.b, x.c, s); }
+    u64 d = 0, da_top = 0;                           // dilation back over the run
+    for (int s = 0; s < m; ++s) { d |= shl2(ea, eb, s); da_top |= (ea >> (63 - s)) & 1ull; }
+    u64 r = d | (d << 1) | da_top;                   // ... plus the base after it
+    if (w == (int64_t)L.contig_blk[k]) {
+        // position 0: never marked; a run starting at 0 needs one base more than the others
+        const u64 nb = ~x.b;
+        const int run0 = nb ? __builtin_ctzll(nb) : 64;
+        if (run0 == m) r &= ~below_mask(m + 1);
+        r &= ~1ull;
+    }
+    le[w] = r;
+}
+
+// ---- look-left / look-right flags (:4426-4455), clipped to the coverage vector's size
+THJ_HD void look_word(const Layout& L, const u64* le, const int32_t* cov_size, u64* ll, u64* lr, int64_t w) {
+    const int k = contig_of(L, w);
+    const int64_t w0 = (int64_t)L.contig_blk[k], w1 = (int64_t)L.contig_blk[k + 1];
+    // long_enough of words w-2 .. w+2 (0 outside the contig): starts / ends of w-1, w, w+1 need one word further back
+    u64 x[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { const int64_t q = w - 2 + i; x[i] = (q >= w0 && q < w1) ? le[q] : 0ull; }
+    u64 S[3], T[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const u64 prev = (x[i + 1] << 1) | (x[i] >> 63);          // long_enough[c - 1]
+        S[i] = x[i + 1] & ~prev;                                   // island starts
+        T[i] = ~x[i + 1] & prev;                                   // first base after an island
+        const int64_t pos0 = (w - 1 + i - w0) * 64;                // contig position of bit 0 of this word
+        // an island start at c < EXTEND gets no flags (r >= 0 fails at once), an end at c < REPEAT_TOL neither; c >= 1
+        S[i] &= ~below_mask(EXTEND - pos0);
+        T[i] &= ~below_mask(REPEAT_TOL - pos0) & ~below_mask(1 - pos0);
+        // the scan stops at c == size - 1
+        const int64_t n = cov_size[k];
+        S[i] &= below_mask(n - pos0); T[i] &= below_mask(n - pos0);
+        if (w - 1 + i < w0 || w - 1 + i >= w1) { S[i] = 0; T[i] = 0; }
+    }
+    u64 fl = 0, fr = 0;
+    // LOOK_LEFT  on [c - 45, c + 5):  flag[p] = OR S[p + d], d in [-4, 45]
+    for (int d = 0; d <= EXTEND; ++d) fl |= shr2(S[1], S[2], d);
+    for (int d = 1; d < REPEAT_TOL; ++d) fl |= shl2(S[0], S[1], d);
+    // LOOK_RIGHT on [c - 5, c + 45):  flag[p] = OR T[p + d], d in [-44, 5]
+    for (int d = 0; d <= REPEAT_TOL; ++d) fr |= shr2(T[1], T[2], d);
+    for (int d = 1; d < EXTEND; ++d) fr |= shl2(T[0], T[1], d);
+    const int64_t n = cov_size[k], pos0 = (w - w0) * 64;
+    ll[w] = fl & below_mask(n - pos0);
+    lr[w] = fr & below_mask(n - pos0);
+}
+
+// ---- windows that the reference drops (:4457-4512, :2154): a flag run starting at position 0, and a run whose end
+// reaches len - 1.  One thread per (contig, bitmap); walks are as long as the run (a few dozen bits).
+THJ_HD void clear_run(u64* bm, int64_t wbase, int64_t pos, int64_t n) {         // clears the run containing `pos`
+    for (int64_t p = pos; p >= 0 && ((bm[wbase + (p >> 6)] >> (p & 63)) & 1ull); --p) bm[wbase + (p >> 6)] &= ~(1ull << (p & 63));
+    for (int64_t p = pos + 1; p < n && ((bm[wbase + (p >> 6)] >> (p & 63)) & 1ull); ++p) bm[wbase + (p >> 6)] &= ~(1ull << (p & 63));
+}
+THJ_HD void drop_windows(const Layout& L, const int32_t* cov_size, u64* ll, u64* lr, int i) {      // i < 2 * n_contigs
+    const int k = i >> 1;
+    u64* bm = (i & 1) ? lr : ll;
+    const int64_t wbase = (int64_t)L.contig_blk[k], n = cov_size[k], len = L.contig_len[k];
+    if (n <= 0) return;
+    if (bm[wbase] & 1ull) clear_run(bm, wbase, 0, n);
+    for (int64_t p = n - 1; p >= len - 2 && p >= 0; --p)                // window end = last flag + 1 >= len - 1
+        if ((bm[wbase + (p >> 6)] >> (p & 63)) & 1ull) clear_run(bm, wbase, p, n);
+}
+
+// ---- sites (:2290-2318): a dinucleotide at (p, p + 1) counts when both bases are flagged; N reads as A
+THJ_HD void site_word(const Genome& g, const Layout& L, const u64* ll, const u64* lr, u64* fd, u64* ra, u64* fa, u64* rd, int64_t w) {
+    const int k = contig_of(L, w);
+    const bool last = w + 1 >= (int64_t)L.contig_blk[k + 1];
+    const u64* p0 = g.blocks + w * 4;
+    const u64 nm = p0[2], lo = p0[0] & ~nm, hi = p0[1] & ~nm;
+    u64 nlo = 0, nhi = 0, nll = 0, nlr = 0;
+    if (!last) { const u64* p1 = p0 + 4; const u64 nm1 = p1[2]; nlo = p1[0] & ~nm1; nhi = p1[1] & ~nm1; nll = ll[w + 1]; nlr = lr[w + 1]; }
+    const u64 lo1 = (lo >> 1) | (nlo << 63), hi1 = (hi >> 1) | (nhi << 63);          // the next base
+    const u64 A = ~lo & ~hi, C = lo & ~hi, G = ~lo & hi;
+    const u64 C1 = lo1 & ~hi1, G1 = ~lo1 & hi1, T1 = lo1 & hi1;
+    const u64 l = ll[w], r = lr[w];
+    const u64 l2 = l & ((l >> 1) | (nll << 63)), r2 = r & ((r >> 1) | (nlr << 63));
+    fd[w] = r2 & G & T1;          // GT   fwd donor        (look right)
+    ra[w] = r2 & C & T1;          // CT   rev acceptor     (look right)
+    fa[w] = l2 & A & G1;          // AG   fwd acceptor     (look left)
+    rd[w] = l2 & A & C1;          // AC   rev donor        (look left)
+}
+
+// ---- the extension table (:240-360): one entry per 10-mer seed position of a read's first 32 bases
+// value = left_str | left_len << 28 | right_str << 32 | right_len << 60
+THJ_HD void read_entries(const u64* planes, const uint16_t* lens, int W, uint32_t* keys, u64* vals, int64_t base, int64_t r) {
+    int len = lens[r]; if (len > 32) len = 32;
+    const u64* rp = planes + (size_t)r * 3 * W;
+    const u64 nm = rp[2 * W], lo = rp[0] & ~nm, hi = rp[W] & ~nm;          // charToDna5 & 3: N is 0
+    u64 seq = 0;                                                           // base i at bits 2 * (31 - i): first base most significant
+    for (int i = 0; i < 32; ++i) seq |= (((lo >> i) & 1ull) | (((hi >> i) & 1ull) << 1)) << (2 * (31 - i));
+    for (int i = 0; i < 23; ++i) {
+        uint32_t key = 0xFFFFFFFFu; u64 val = 0;                           // unused slots sort to the end
+        if (len >= 10 && i + 10 <= len) {
+            key = (uint32_t)((seq >> (2 * (22 - i))) & 0xFFFFFu);
+            int rl = len - 10 - i; if (rl > MAX_EXT_BP) rl = MAX_EXT_BP;
+            const u64 right = rl ? (seq >> (2 * (32 - (i + 10 + rl)))) & ((1ull << (2 * rl)) - 1ull) : 0ull;
+            const int ln = i < MAX_EXT_BP ? i : MAX_EXT_BP;
+            const u64 left = ln ? (seq >> (2 * (32 - i))) & ((1ull << (2 * ln)) - 1ull) : 0ull;
+            val = left | ((u64)ln << 28) | (right << 32) | ((u64)rl << 60);
+        }
+        keys[base + r * 23 + i] = key; vals[base + r * 23 + i] = val;
+    }
+}
+THJ_HD void key_offset(const uint32_t* sorted_keys, int64_t n, uint32_t* off, uint32_t k) {      // off[k] = first entry with key >= k; k <= N_KEYS
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < k) lo = mid + 1; else hi = mid; }
+    off[k] = (uint32_t)lo;
+}
+
+struct ExtTable { const uint32_t* off; const u64* val; };
+// extendable_junction (:1520-1566), min_ext_len 7, extension_mismatches 0
+THJ_HD bool extendable(const ExtTable& t, u64 up, u64 down) {
+    const uint32_t key = ((uint32_t)(up & 0x3FFull) << 10) | (uint32_t)(down >> 54);
+    up >>= 10; down <<= 10;
+    for (uint32_t i = t.off[key]; i < t.off[key + 1]; ++i) {
+        const u64 v = t.val[i];
+        const int ln = (int)((v >> 28) & 15), rl = (int)(v >> 60);
+        if (ln >= 7 && (uint32_t)(v & 0x0FFFFFFFull) == (uint32_t)(up & ((1ull << (2 * ln)) - 1ull))) return true;
+        if (rl >= 7 && (uint32_t)((v >> 32) & 0x0FFFFFFFull) == (uint32_t)(down >> (2 * (32 - rl)))) return true;
+    }
+    return false;
+}
+// 32 bases of the contig starting at pos as a 2-bit string, first base most significant (dna5str_to_idx :218-229)
+THJ_HD u64 mer32(const Genome& g, uint32_t ref_id, int64_t pos) {
+    const Planes p = g_fetch(g, ref_id, pos);
+    const u64 lo = p.lo & ~p.nm, hi = p.hi & ~p.nm;
+    u64 s = 0;
+    for (int i = 0; i < 32; ++i) s |= (((lo >> i) & 1ull) | (((hi >> i) & 1ull) << 1)) << (2 * (31 - i));
+    return s;
+}
+THJ_HD u64 rc32(u64 s) {                          // rc_dna_str :650-661
+    s = ~s;
+    u64 rc = 0;
+    for (int i = 0; i < 32; ++i) { rc = (rc << 2) | (s & 3ull); s >>= 2; }
+    return rc;
+}
+
+// ---- RecordExtendableJuncs::record (:1568-1626): one thread per word of the left-site bitmap; -> junctions found
+template <class Sink>
+THJ_HD unsigned int pair_word(const Genome& g, const Layout& L, const ExtTable& et, const u64* left_sites, const u64* right_sites, int antisense,
+                              int min_intron, int max_intron, int64_t w, Sink& ev) {
+    u64 bits = left_sites[w];
+    if (!bits) return 0;
+    unsigned int found = 0;
+    const int k = contig_of(L, w);
+    const int64_t wbase = (int64_t)L.contig_blk[k], wend = (int64_t)L.contig_blk[k + 1], len = L.contig_len[k];
+    while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int64_t lp = (w - wbase) * 64 + b;
+        // attach_upstream_mers (:741-784): (0, 0) when too close to a contig end
+        u64 lf = 0, lrv = 0;
+        if (lp > 32 && lp < len) { lf = mer32(g, (uint32_t)k + 1, lp - 32); lrv = rc32(lf); }
+        const int64_t q0 = lp + min_intron, q1 = lp + max_intron;            // right sites in [q0, q1)
+        for (int64_t rw = wbase + (q0 >> 6); rw < wend && (rw - wbase) * 64 < q1; ++rw) {
+            u64 rb = right_sites[rw];
+            const int64_t p0 = (rw - wbase) * 64;
+            rb &= ~below_mask(q0 - p0) & below_mask(q1 - p0);
+            while (rb) {
+                const int c = __builtin_ctzll(rb);
+                rb &= rb - 1;
+                const int64_t rp = p0 + c;
+                u64 rf = 0, rrv = 0;                                          // attach_downstream_mers (:786-832)
+                if (rp + 2 + 32 < len) { rf = mer32(g, (uint32_t)k + 1, rp + 2); rrv = rc32(rf); }
+                if (extendable(et, lf, rf) || extendable(et, rrv, lrv)) {
+                    ev.junction((uint32_t)k + 1, (uint32_t)(lp - 1), (uint32_t)(rp + 2), antisense != 0);
+                    ++found;
+                }
+            }
+        }
+    }
+    return found;
+}
+
+}  // namespace cov
+}  // namespace thj
+#endif

@@ -1,0 +1,201 @@
+// thj_covsearch_impl.h -- coverage search of segment_juncs on the device.
+// Included at the end of thj_segjuncs.hip (it inserts into the same junction table).
+//
+// Reference: segment_juncs.cpp  build_coverage_map :4140-4176, capture_island_ends :4268-4543, the POINT_DIR_LEFT /
+// POINT_DIR_RIGHT windows of juncs_from_ref_segs<RecordExtendableJuncs> :2052-2377, IntronMotifs::unique/attach_mers
+// :700-833, RecordExtendableJuncs::record :1568-1626, extendable_junction :1464-1566, the extension table of the
+// initially unmapped reads :146-180, :240-571.
+//
+// Everything positional is a bitmap with the genome's own block layout: one 64-bit word per 64-base block, word index
+// contig_blk[ref] + pos / 64 (a contig owns ceil(len / 64) + 1 words, so position `len` -- the largest a hit's right()
+// can reach -- still has a bit).  The reference's scans over vector<bool> become word-parallel shift/and/or kernels:
+//   coverage  --(runs of >= min_cov_length - 1 bases, plus the base after them)-->  long_enough
+//   long_enough run starts / ends  --(dilation by [-45, +5) / [-5, +45))-->  look-left / look-right flags
+//   flags & dinucleotides (N reads as A)  -->  four site bitmaps (GT, CT in look-right; AG, AC in look-left)
+// and the pairing of sites within [min, max) coverage intron with the 10-mer extension test runs one thread per site.
+// Quirks of the reference that are kept: position 0 of a contig never counts as covered ground for an island start;
+// an island whose window would start before position 0 gets no window; a flag run starting at position 0 or reaching
+// the last two bases of the contig yields no window at all.
+
+#include "thj_cov_core.h"
+
+namespace cov_k {
+using namespace thj::cov;
+
+__global__ void k_add_hits(Layout L, const Hit* hits, const uint32_t* n_hits_ptr, u64* covbits, int32_t* cov_size) {
+    const int64_t n = (int64_t)*n_hits_ptr;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        add_hit(L, hits[i], [&](int64_t w, u64 m) { atomicOr((unsigned long long*)&covbits[w], (unsigned long long)m); },
+                [&](int k, int32_t sz) { atomicMax(&cov_size[k], sz); });
+}
+__global__ void k_long_enough(Layout L, const u64* covbits, u64* le, int m) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w < L.n_words) long_enough_word(L, covbits, le, m, w);
+}
+__global__ void k_look(Layout L, const u64* le, const int32_t* cov_size, u64* ll, u64* lr) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w < L.n_words) look_word(L, le, cov_size, ll, lr, w);
+}
+__global__ void k_drop_windows(Layout L, const int32_t* cov_size, u64* ll, u64* lr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * L.n_contigs) drop_windows(L, cov_size, ll, lr, i);
+}
+__global__ void k_sites(Genome g, Layout L, const u64* ll, const u64* lr, u64* fd, u64* ra, u64* fa, u64* rd) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w < L.n_words) site_word(g, L, ll, lr, fd, ra, fa, rd, w);
+}
+__global__ void k_ium_entries(const u64* planes, const uint16_t* lens, int64_t n_reads, int W, uint32_t* keys, u64* vals, int64_t base) {
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r < n_reads) read_entries(planes, lens, W, keys, vals, base, r);
+}
+__global__ void k_key_offsets(const uint32_t* sorted_keys, int64_t n, uint32_t* off) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k <= N_KEYS) key_offset(sorted_keys, n, off, k);
+}
+__global__ void k_pair(Genome g, Layout L, Tables t, ExtTable et, const u64* left_sites, const u64* right_sites, int antisense,
+                       int min_intron, int max_intron, unsigned long long* n_found) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w >= L.n_words) return;
+    EventSink ev{g, t};
+    const unsigned int f = pair_word(g, L, et, left_sites, right_sites, antisense, min_intron, max_intron, w, ev);
+    if (f) atomicAdd(n_found, (unsigned long long)f);
+}
+
+}  // namespace cov_k
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static int cov_ensure(thj_ctx* c) {
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    if (!c->d_cov) {
+        HIPCHK(hipMalloc(&c->d_cov, (size_t)c->n_blocks * 8 * 8));             // coverage, long_enough, 2 flag and 4 site bitmaps
+        HIPCHK(hipMalloc(&c->d_cov_size, (size_t)(c->n_contigs + 1) * 4));
+        HIPCHK(hipMalloc(&c->d_ext_off, ((size_t)thj::cov::N_KEYS + 2) * 4));
+        HIPCHK(hipMalloc(&c->d_cov_found, 8));
+    }
+    return THJ_OK;
+}
+
+extern "C" int thj_covsearch_reset_async(thj_ctx* c) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    HIPCHK(hipMemsetAsync(c->d_cov, 0, (size_t)c->n_blocks * 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_cov_size, 0, (size_t)(c->n_contigs + 1) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_cov_found, 0, 8, c->stream));
+    c->n_ext = 0;
+    return THJ_OK;
+}
+
+extern "C" int thj_covsearch_add_hits_async(thj_ctx* c, const thj_seg_batch* db) {
+    if (!c || !db) { thj_set_error("thj_covsearch_add_hits_async: null argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    if (db->n_reads == 0) return THJ_OK;
+    thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, c->n_blocks};
+    // the batch's hit count is the last CSR offset, which lives on the device
+    const uint32_t* n_hits = db->seg_off + (size_t)db->n_reads * db->nseg;
+    hipLaunchKernelGGL(cov_k::k_add_hits, dim3(2048), dim3(256), 0, c->stream, L, (const Hit*)db->hits, n_hits, c->d_cov, c->d_cov_size);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_covsearch_add_reads(thj_ctx* c, int64_t n_reads, int32_t words_per_plane, const uint64_t* planes, const uint16_t* lens,
+                                       int32_t on_device) {
+    if (!c || (n_reads > 0 && (!planes || !lens))) { thj_set_error("thj_covsearch_add_reads: null argument"); return THJ_EINVAL; }
+    if (words_per_plane < 1 || words_per_plane > 4) { thj_set_error("words_per_plane %d unsupported (1..4)", words_per_plane); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    if (n_reads == 0) return THJ_OK;
+    const int64_t need = c->n_ext + n_reads * 23;
+    if (need >= (1ll << 32)) { thj_set_error("more than 2^32 extension-table entries (unmapped reads x 23)"); return THJ_EINVAL; }
+    if (need > c->ext_cap) {
+        const int64_t ncap = need + need / 2 + 1024;
+        uint32_t* nk = nullptr; u64* nv = nullptr;
+        HIPCHK(hipMalloc(&nk, (size_t)ncap * 4)); HIPCHK(hipMalloc(&nv, (size_t)ncap * 8));
+        if (c->n_ext) {
+            HIPCHK(hipMemcpyAsync(nk, c->d_ext_key, (size_t)c->n_ext * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(nv, c->d_ext_val, (size_t)c->n_ext * 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
+        c->d_ext_key = nk; c->d_ext_val = nv; c->ext_cap = ncap;
+        HIPCHK(hipMalloc(&c->d_ext_key_sorted, (size_t)ncap * 4)); HIPCHK(hipMalloc(&c->d_ext_val_sorted, (size_t)ncap * 8));
+    }
+    const u64* d_planes = (const u64*)planes; const uint16_t* d_lens = lens;
+    void *tp = nullptr, *tl = nullptr;
+    if (!on_device) {                     // host buffers (the executables): staged through a temporary device copy
+        const size_t pb = (size_t)n_reads * 3 * words_per_plane * 8, lb = (size_t)n_reads * 2;
+        HIPCHK(hipMalloc(&tp, pb)); HIPCHK(hipMalloc(&tl, lb));
+        HIPCHK(hipMemcpyAsync(tp, planes, pb, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(tl, lens, lb, hipMemcpyHostToDevice, c->stream));
+        d_planes = (const u64*)tp; d_lens = (const uint16_t*)tl;
+    }
+    hipLaunchKernelGGL(cov_k::k_ium_entries, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream,
+                       d_planes, d_lens, n_reads, (int)words_per_plane, c->d_ext_key, c->d_ext_val, c->n_ext);
+    HIPCHK(hipGetLastError());
+    if (!on_device) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(tp); hipFree(tl); }
+    c->n_ext = need;
+    return THJ_OK;
+}
+
+extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32_t min_intron, int32_t max_intron) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    if (min_cov_length < 2 || min_cov_length > 64) { thj_set_error("min_cov_length %d unsupported (2..64)", min_cov_length); return THJ_EINVAL; }
+    if (min_intron < 1 || max_intron < min_intron) { thj_set_error("coverage intron bounds [%d, %d) unsupported", min_intron, max_intron); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    if ((rc = maybe_grow_tables(c))) return rc;
+    const int64_t nw = c->n_blocks;
+    thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, nw};
+    u64 *covb = c->d_cov, *le = covb + nw, *ll = le + nw, *lr = ll + nw, *fd = lr + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
+    // the extension table: sort the entries by seed, then offsets per seed
+    const uint32_t* keys = c->d_ext_key; const u64* vals = c->d_ext_val;
+    if (c->n_ext) {
+        size_t need = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, need, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream);
+        if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+        size_t bytes = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream));
+        keys = c->d_ext_key_sorted; vals = c->d_ext_val_sorted;
+    }
+    hipLaunchKernelGGL(cov_k::k_key_offsets, dim3((thj::cov::N_KEYS + 1 + 255) / 256), dim3(256), 0, c->stream, keys, c->n_ext, c->d_ext_off);
+    const unsigned gw = (unsigned)((nw + 255) / 256);
+    hipLaunchKernelGGL(cov_k::k_long_enough, dim3(gw), dim3(256), 0, c->stream, L, covb, le, (int)min_cov_length - 1);
+    hipLaunchKernelGGL(cov_k::k_look, dim3(gw), dim3(256), 0, c->stream, L, le, c->d_cov_size, ll, lr);
+    hipLaunchKernelGGL(cov_k::k_drop_windows, dim3((unsigned)((2 * c->n_contigs + 63) / 64)), dim3(64), 0, c->stream, L, c->d_cov_size, ll, lr);
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    hipLaunchKernelGGL(cov_k::k_sites, dim3(gw), dim3(256), 0, c->stream, g, L, ll, lr, fd, ra, fa, rd);
+    Tables t{c->d_junc, (u64)c->junc_cap - 1, c->d_del, (u64)c->indel_cap - 1, c->d_ins_key, c->d_ins_val,
+             (u64)c->indel_cap - 1, junc_list(c), del_list(c), ins_list(c), c->d_ovf, c->d_cnt};
+    thj::cov::ExtTable et{c->d_ext_off, vals};
+    hipLaunchKernelGGL(cov_k::k_pair, dim3(gw), dim3(256), 0, c->stream, g, L, t, et, fd, fa, 0, (int)min_intron, (int)max_intron, c->d_cov_found);
+    hipLaunchKernelGGL(cov_k::k_pair, dim3(gw), dim3(256), 0, c->stream, g, L, t, et, ra, rd, 1, (int)min_intron, (int)max_intron, c->d_cov_found);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+extern "C" int thj_covsearch_finish(thj_ctx* c, int64_t max_cov_juncs, int64_t* n_found) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    unsigned long long n = 0;
+    HIPCHK(hipMemcpyAsync(&n, c->d_cov_found, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_found) *n_found = (int64_t)n;
+    if ((int64_t)n > max_cov_juncs) {
+        thj_set_error("coverage search found %lld junctions, more than max_cov_juncs = %lld (the reference's lowest-skip-count cut is not restated on the device)",
+                      (long long)n, (long long)max_cov_juncs);
+        return THJ_EOVERFLOW;
+    }
+    return THJ_OK;
+}
+
+static void cov_free(thj_ctx* c) {
+    hipFree(c->d_cov); hipFree(c->d_cov_size); hipFree(c->d_ext_off); hipFree(c->d_cov_found);
+    hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
+}

@@ -59,6 +59,11 @@ struct thj_ctx {
     uint32_t* d_worklist = nullptr; int64_t worklist_cap = 0;
     bool span_profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;
+    // coverage search (thj_covsearch_impl.h)
+    u64* d_cov = nullptr; int32_t* d_cov_size = nullptr;                  // 8 bitmaps of n_blocks words; max(right) + 1 per contig
+    uint32_t* d_ext_key = nullptr; u64* d_ext_val = nullptr; uint32_t* d_ext_key_sorted = nullptr; u64* d_ext_val_sorted = nullptr;
+    uint32_t* d_ext_off = nullptr; int64_t n_ext = 0, ext_cap = 0;        // extension table of the unmapped reads
+    unsigned long long* d_cov_found = nullptr;
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
     std::vector<thj_fusion> h_fusions;

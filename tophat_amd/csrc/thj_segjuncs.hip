@@ -581,6 +581,7 @@ extern "C" int thj_ctx_create(int device, void* stream, thj_ctx** out) {
     return THJ_OK;
 }
 
+static void cov_free(thj_ctx* c);
 extern "C" void thj_ctx_destroy(thj_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
@@ -592,6 +593,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     if (c->probe_ev) hipEventDestroy(c->probe_ev);
     hipHostFree(c->h_pinned);
     thj_span_free(c);
+    cov_free(c);
     hipFree(c->d_fus); hipFree(c->d_fus_count);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
@@ -1125,3 +1127,4 @@ extern "C" int thj_genome_gather(thj_ctx* c, const thj_piece* pieces, int64_t n,
     return THJ_OK;
 }
 
+#include "thj_covsearch_impl.h"

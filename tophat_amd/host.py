@@ -59,6 +59,7 @@ ABI_SYMBOLS = [
     "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
     "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_genome_gather", "thj_fusion_finish", "thj_fusion_download",
+    "thj_covsearch_reset_async", "thj_covsearch_add_hits_async", "thj_covsearch_add_reads", "thj_covsearch_run_async", "thj_covsearch_finish",
 ]
 
 _lib = None
@@ -247,6 +248,32 @@ class Context:
         for p, b in runs:
             self.run(p, b)
         return self.download(self.finish())
+
+    def segjuncs_with_coverage_search(self, runs: Sequence[Tuple[Params, object]], ium_reads: Sequence[str], min_cov_length: int,
+                                      min_intron: int = 50, max_intron: int = 20000, max_cov_juncs: int = 5000000):
+        """One segment_juncs pass with the coverage search (segment_juncs.cpp:4268-4543) on top of the segment search:
+        runs = (params, uploaded batch) of both sides, ium_reads = the initially unmapped reads (--ium-reads).
+        -> (Events, junctions the coverage search found, counted with those the segment search also found)"""
+        self.reset()
+        _check(self.lib, self.lib.thj_covsearch_reset_async(self._ctx), "thj_covsearch_reset_async")
+        for p, b in runs:
+            self.run(p, b)
+            arg = C.byref(b) if isinstance(b, CSegBatch) else b
+            _check(self.lib, self.lib.thj_covsearch_add_hits_async(self._ctx, arg), "thj_covsearch_add_hits_async")
+        n = len(ium_reads)
+        if n:
+            off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum([len(r) for r in ium_reads], out=off[1:])
+            bases = np.frombuffer("".join(ium_reads).encode(), dtype=np.uint8)
+            W = words_per_plane(max(len(r) for r in ium_reads))
+            planes = np.zeros(n * 3 * W, dtype=np.uint64)
+            lens = np.zeros(n, dtype=np.uint16)
+            _check(self.lib, self.lib.thj_reads_pack(C.c_int64(n), _ptr(off), _ptr(bases), W, _ptr(planes), _ptr(lens)), "thj_reads_pack")
+            _check(self.lib, self.lib.thj_covsearch_add_reads(self._ctx, C.c_int64(n), W, _ptr(planes), _ptr(lens), 0), "thj_covsearch_add_reads")
+        _check(self.lib, self.lib.thj_covsearch_run_async(self._ctx, min_cov_length, min_intron, max_intron), "thj_covsearch_run_async")
+        found = C.c_int64()
+        _check(self.lib, self.lib.thj_covsearch_finish(self._ctx, C.c_int64(max_cov_juncs), C.byref(found)), "thj_covsearch_finish")
+        return self.download(self.finish()), found.value
 
     def profile(self, enable: bool = True) -> Tuple[Tuple[float, float], int]:
         """((thj_k_segjuncs ms, thj_k_segjuncs_rescue ms), runs) since the last call"""
