@@ -74,6 +74,7 @@ static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, Ref
             if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
             if (thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
             if (o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+            if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
             if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
         }
         ordinal += (uint32_t)n;
@@ -93,7 +94,9 @@ static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, Ref
         }
         // only find_fusions runs for reads whose highest mapped segment is the first (segment_juncs.cpp:3994-4028);
         // they are event-neutral for the gap / indel finders, so with --fusion-search they simply ride along
-        if (top < 0 || (top == 0 && !o.fusion_search)) continue;
+        // ... and with the coverage search on their hits belong to the coverage map (build_coverage_map :4140-4176 walks
+        // every record of every segment map)
+        if (top < 0 || (top == 0 && !o.fusion_search && o.no_coverage_search)) continue;
         Read rd;
         if (!reads.get(id, rd)) die("Error: could not get read# %d from stream!", (int)id);
         for (int s = 0; s < nseg; ++s) { for (auto& h : grp[(size_t)s]) hits.push_back(h.h16); seg_off.push_back((uint32_t)hits.size()); }
@@ -125,9 +128,10 @@ int main(int argc, char** argv) {
     for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
     if (pos.size() < 8 || (pos.size() > 8 && pos.size() < 11)) { print_usage(); return 1; }
     if (o.color) die("Error: colour-space reads are not supported by this build\n");
-    if (!o.no_coverage_search || !o.no_microexon_search || o.butterfly_search)
-        die("Error: coverage / microexon / butterfly searches are not supported by this build yet; "
-            "run with --no-coverage-search --no-microexon-search (what tophat passes for reads of >= 3 segments)\n");
+    if (!o.no_microexon_search || o.butterfly_search)
+        die("Error: microexon / butterfly searches are not supported by this build yet; "
+            "run with --no-microexon-search and without --butterfly-search (tophat's defaults)\n");
+    if (o.ium_reads.empty()) o.no_coverage_search = true;             // no unmapped reads: segment_juncs.cpp:4978-4982
     SideInput left{pos[5], pos[6], split(pos[7], ',')}, right;
     if (pos.size() >= 11) right = SideInput{pos[8], pos[9], split(pos[10], ',')};
     if (left.segs.empty()) { fprintf(stderr, "No hits to process, exiting\n"); return 0; }      // segment_juncs.cpp:4724-4728
@@ -158,6 +162,7 @@ int main(int argc, char** argv) {
         rt.upload(ctx);
         if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
         if (o.fusion_search && thj_fusion_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+        if (!o.no_coverage_search && thj_covsearch_reset_async(ctx)) die("Error: %s\n", thj_last_error());
         if (o.fusion_search && !o.fusion_ignore.empty()) {                 // segment_juncs.cpp:3214-3219
             std::vector<uint32_t> ids;
             for (auto& nm : split(o.fusion_ignore, ',')) if (!nm.empty()) ids.push_back(rt.get_id(nm));
@@ -180,6 +185,39 @@ int main(int argc, char** argv) {
 
     { std::lock_guard<std::mutex> lk(dev_mu); device_ready(); }
     g_timer.lap("device start-up + ingest + pack + upload + launch (both sides at once)");
+    int64_t n_cov_juncs = -1;
+    if (!o.no_coverage_search) {
+        // ---- coverage search (segment_juncs.cpp:4955-4996): the extension table of the initially unmapped reads
+        // (index_read_mers :548-571 -- the first 32 bases of every read), then the island pairing on the device
+        fprintf(stderr, ">> Performing coverage-search:\n");
+        const size_t CH = (size_t)1 << 20;
+        for (auto& fn : split(o.ium_reads, ',')) {
+            if (fn.empty()) continue;
+            ReadStream rs;
+            if (!rs.open(fn, o.zpacker)) { fprintf(stderr, "Can't open file %s for reading, skipping...\n", fn.c_str()); continue; }
+            std::string bases; std::vector<int64_t> off(1, 0);
+            auto push = [&]() {
+                const int64_t n = (int64_t)off.size() - 1;
+                if (!n) return;
+                std::vector<uint64_t> planes((size_t)n * 3); std::vector<uint16_t> lens((size_t)n);
+                if (thj_reads_pack(n, off.data(), bases.data(), 1, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
+                if (thj_covsearch_add_reads(ctx, n, 1, planes.data(), lens.data(), 0)) die("Error: %s\n", thj_last_error());
+                bases.clear(); off.assign(1, 0);
+            };
+            Read rd;
+            while (rs.next_direct(rd)) {
+                bases.append(rd.seq, 0, rd.seq.size() < 32 ? rd.seq.size() : 32);      // count_read_mers / store_read_mers :425, :520
+                off.push_back((int64_t)bases.size());
+                if (off.size() - 1 >= CH) push();
+            }
+            push();
+        }
+        int mcl = 20; if (mcl > o.p.segment_length - 2) mcl = o.p.segment_length - 2;          // :62, :5350
+        if (thj_covsearch_run_async(ctx, mcl, o.min_coverage_intron, o.max_coverage_intron)) die("Error: %s\n", thj_last_error());
+        if (thj_covsearch_finish(ctx, 5000000, &n_cov_juncs)) die("Error: %s\n", thj_last_error());        // max_cov_juncs :56
+        fprintf(stderr, "\tfound %d potential junctions\n", (int)n_cov_juncs);
+        g_timer.lap("coverage search (unmapped reads + device)");
+    }
     thj_segjuncs_counts n{};
     if (thj_segjuncs_finish(ctx, &n)) die("Error: %s\n", thj_last_error());
     std::vector<thj_junction> j((size_t)n.n_juncs + 1), d((size_t)n.n_deletions + 1);

@@ -68,6 +68,7 @@ struct Opts {
     std::string fusion_ignore;
     int num_threads = 1;
     std::string sam_header, ium_reads, zpacker;
+    int min_coverage_intron = 50, max_coverage_intron = 20000;      // common.cpp:112-113
 };
 
 enum {
@@ -143,6 +144,8 @@ inline int parse_options(int argc, char** argv, Opts& o, void (*usage)()) {
         case O_MIN_REP_INTRON: o.p.min_report_intron = parse_int(1, "--min-report-intron arg must be at least 1"); break;
         case O_MAX_REP_INTRON: o.p.max_report_intron = parse_int(1, "--max-report-intron arg must be at least 1"); break;
         case O_IUM: o.ium_reads = optarg; break;
+        case O_MIN_COV_INTRON: o.min_coverage_intron = parse_int(1, "--min-coverage-intron arg must be at least 1"); break;
+        case O_MAX_COV_INTRON: o.max_coverage_intron = parse_int(1, "--max-coverage-intron arg must be at least 1"); break;
         case 'C': case O_COLOR: o.color = true; break;
         case O_LIBTYPE:
             if (!strcmp(optarg, "fr-unstranded")) o.p.library_type = 1;
@@ -877,6 +880,8 @@ public:
         if (f_) { if (pipe_) pclose(f_); else fclose(f_); }
         free(line_);
     }
+    // the next read of the file, whatever its id (ReadStream::get_direct, reads.cpp:600-630)
+    bool next_direct(Read& out) { return next_async(out); }
     // monotone fetch: requests arrive in increasing id order (the visiting order of both stages)
     bool get(uint32_t id, Read& out) {
         auto it = ahead_.find(id);
