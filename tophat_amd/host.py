@@ -249,31 +249,54 @@ class Context:
             self.run(p, b)
         return self.download(self.finish())
 
+    # ---- coverage search (thj_covsearch_*): call between reset() and finish() of a segment_juncs pass
+    def covsearch_reset(self):
+        _check(self.lib, self.lib.thj_covsearch_reset_async(self._ctx), "thj_covsearch_reset_async")
+
+    def covsearch_add_hits(self, batch):
+        arg = C.byref(batch) if isinstance(batch, CSegBatch) else batch
+        _check(self.lib, self.lib.thj_covsearch_add_hits_async(self._ctx, arg), "thj_covsearch_add_hits_async")
+
+    def covsearch_add_reads(self, ium_reads: Sequence[str]):
+        n = len(ium_reads)
+        if not n:
+            return
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in ium_reads], out=off[1:])
+        bases = np.frombuffer("".join(ium_reads).encode(), dtype=np.uint8)
+        W = words_per_plane(max(len(r) for r in ium_reads))
+        planes = np.zeros(n * 3 * W, dtype=np.uint64)
+        lens = np.zeros(n, dtype=np.uint16)
+        _check(self.lib, self.lib.thj_reads_pack(C.c_int64(n), _ptr(off), _ptr(bases), W, _ptr(planes), _ptr(lens)), "thj_reads_pack")
+        _check(self.lib, self.lib.thj_covsearch_add_reads(self._ctx, C.c_int64(n), W, _ptr(planes), _ptr(lens), 0), "thj_covsearch_add_reads")
+
+    def covsearch_add_reads_device(self, n: int, W: int, planes_ptr: int, lens_ptr: int):
+        """planes / lengths already on the device (thj_reads_pack layout)"""
+        _check(self.lib, self.lib.thj_covsearch_add_reads(self._ctx, C.c_int64(n), W, C.c_void_p(planes_ptr), C.c_void_p(lens_ptr), 1),
+               "thj_covsearch_add_reads")
+
+    def covsearch_run(self, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
+        _check(self.lib, self.lib.thj_covsearch_run_async(self._ctx, min_cov_length, min_intron, max_intron), "thj_covsearch_run_async")
+
+    def covsearch_finish(self, max_cov_juncs: int = 5000000) -> int:
+        found = C.c_int64()
+        _check(self.lib, self.lib.thj_covsearch_finish(self._ctx, C.c_int64(max_cov_juncs), C.byref(found)), "thj_covsearch_finish")
+        return found.value
+
     def segjuncs_with_coverage_search(self, runs: Sequence[Tuple[Params, object]], ium_reads: Sequence[str], min_cov_length: int,
                                       min_intron: int = 50, max_intron: int = 20000, max_cov_juncs: int = 5000000):
         """One segment_juncs pass with the coverage search (segment_juncs.cpp:4268-4543) on top of the segment search:
         runs = (params, uploaded batch) of both sides, ium_reads = the initially unmapped reads (--ium-reads).
         -> (Events, junctions the coverage search found, counted with those the segment search also found)"""
         self.reset()
-        _check(self.lib, self.lib.thj_covsearch_reset_async(self._ctx), "thj_covsearch_reset_async")
+        self.covsearch_reset()
         for p, b in runs:
             self.run(p, b)
-            arg = C.byref(b) if isinstance(b, CSegBatch) else b
-            _check(self.lib, self.lib.thj_covsearch_add_hits_async(self._ctx, arg), "thj_covsearch_add_hits_async")
-        n = len(ium_reads)
-        if n:
-            off = np.zeros(n + 1, dtype=np.int64)
-            np.cumsum([len(r) for r in ium_reads], out=off[1:])
-            bases = np.frombuffer("".join(ium_reads).encode(), dtype=np.uint8)
-            W = words_per_plane(max(len(r) for r in ium_reads))
-            planes = np.zeros(n * 3 * W, dtype=np.uint64)
-            lens = np.zeros(n, dtype=np.uint16)
-            _check(self.lib, self.lib.thj_reads_pack(C.c_int64(n), _ptr(off), _ptr(bases), W, _ptr(planes), _ptr(lens)), "thj_reads_pack")
-            _check(self.lib, self.lib.thj_covsearch_add_reads(self._ctx, C.c_int64(n), W, _ptr(planes), _ptr(lens), 0), "thj_covsearch_add_reads")
-        _check(self.lib, self.lib.thj_covsearch_run_async(self._ctx, min_cov_length, min_intron, max_intron), "thj_covsearch_run_async")
-        found = C.c_int64()
-        _check(self.lib, self.lib.thj_covsearch_finish(self._ctx, C.c_int64(max_cov_juncs), C.byref(found)), "thj_covsearch_finish")
-        return self.download(self.finish()), found.value
+            self.covsearch_add_hits(b)
+        self.covsearch_add_reads(ium_reads)
+        self.covsearch_run(min_cov_length, min_intron, max_intron)
+        found = self.covsearch_finish(max_cov_juncs)
+        return self.download(self.finish()), found
 
     def profile(self, enable: bool = True) -> Tuple[Tuple[float, float], int]:
         """((thj_k_segjuncs ms, thj_k_segjuncs_rescue ms), runs) since the last call"""
