@@ -35,7 +35,11 @@ THJ_HD u64 shl2(u64 below, u64 x, int s) { return s ? (x << s) | (below >> (64 -
 THJ_HD u64 below_mask(int64_t n_bits) { return n_bits >= 64 ? ~0ull : (n_bits <= 0 ? 0ull : ((1ull << n_bits) - 1ull)); }
 
 // ---- coverage from hits (build_coverage_map): bits [left, right) of every hit; per contig max(right) + 1
-template <class OrFn, class MaxFn>      // or_word(word index, mask), max_size(contig, size): atomics on the device
+// or_word(word index, mask), max_size(contig, size): atomics on the device.  Both targets only ever grow, so the kernel
+// reads them first and skips the atomic when it would change nothing -- deep coverage means thousands of hits per word,
+// and one contig means every hit of the batch raising the same size (measured: 43 ms of same-address atomics per
+// 3.8 M hits without the check).
+template <class OrFn, class MaxFn>
 THJ_HD void add_hit(const Layout& L, const Hit& h, OrFn or_word, MaxFn max_size) {
     if (h.ref_id == 0 || (int32_t)h.ref_id > L.n_contigs) return;
     const int k = (int)h.ref_id - 1;
@@ -144,14 +148,27 @@ THJ_HD void site_word(const Genome& g, const Layout& L, const u64* ll, const u64
     rd[w] = l2 & A & C1;          // AC   rev donor        (look left)
 }
 
+// 2-bit strings with the first base most significant (dna5str_to_idx :218-229)
+THJ_HD u64 spread32(u64 x) {                          // bit i -> bit 2i
+    x &= 0xFFFFFFFFull;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+THJ_HD u64 planes_to_mer32(u64 lo, u64 hi) {          // base i (bit i of the planes) -> bits 2 * (31 - i) + {0, 1}
+    return spread32(brev64(lo) >> 32) | (spread32(brev64(hi) >> 32) << 1);
+}
+
 // ---- the extension table (:240-360): one entry per 10-mer seed position of a read's first 32 bases
 // value = left_str | left_len << 28 | right_str << 32 | right_len << 60
 THJ_HD void read_entries(const u64* planes, const uint16_t* lens, int W, uint32_t* keys, u64* vals, int64_t base, int64_t r) {
     int len = lens[r]; if (len > 32) len = 32;
     const u64* rp = planes + (size_t)r * 3 * W;
     const u64 nm = rp[2 * W], lo = rp[0] & ~nm, hi = rp[W] & ~nm;          // charToDna5 & 3: N is 0
-    u64 seq = 0;                                                           // base i at bits 2 * (31 - i): first base most significant
-    for (int i = 0; i < 32; ++i) seq |= (((lo >> i) & 1ull) | (((hi >> i) & 1ull) << 1)) << (2 * (31 - i));
+    const u64 seq = planes_to_mer32(lo, hi);                               // base i at bits 2 * (31 - i): first base most significant
     for (int i = 0; i < 23; ++i) {
         uint32_t key = 0xFFFFFFFFu; u64 val = 0;                           // unused slots sort to the end
         if (len >= 10 && i + 10 <= len) {
@@ -187,19 +204,44 @@ THJ_HD bool extendable(const ExtTable& t, u64 up, u64 down) {
 // 32 bases of the contig starting at pos as a 2-bit string, first base most significant (dna5str_to_idx :218-229)
 THJ_HD u64 mer32(const Genome& g, uint32_t ref_id, int64_t pos) {
     const Planes p = g_fetch(g, ref_id, pos);
-    const u64 lo = p.lo & ~p.nm, hi = p.hi & ~p.nm;
-    u64 s = 0;
-    for (int i = 0; i < 32; ++i) s |= (((lo >> i) & 1ull) | (((hi >> i) & 1ull) << 1)) << (2 * (31 - i));
-    return s;
+    return planes_to_mer32(p.lo & ~p.nm, p.hi & ~p.nm);
 }
-THJ_HD u64 rc32(u64 s) {                          // rc_dna_str :650-661
-    s = ~s;
-    u64 rc = 0;
-    for (int i = 0; i < 32; ++i) { rc = (rc << 2) | (s & 3ull); s >>= 2; }
-    return rc;
+THJ_HD u64 rc32(u64 s) {                              // rc_dna_str :650-661: complement, reverse the order of the 2-bit groups
+    const u64 r = brev64(~s);
+    return ((r >> 1) & 0x5555555555555555ull) | ((r & 0x5555555555555555ull) << 1);
 }
 
-// ---- RecordExtendableJuncs::record (:1568-1626): one thread per word of the left-site bitmap; -> junctions found
+// ---- RecordExtendableJuncs::record (:1568-1626) for one left site `lp` of contig k; -> junctions found.
+// The words of the right-site bitmap within reach are shared out over `n_lanes` callers (the 64 lanes of a wave on the
+// device, one caller on the CPU): lane `lane` takes words first + lane, first + lane + n_lanes, ...
+template <class Sink>
+THJ_HD unsigned int pair_site(const Genome& g, const Layout& L, const ExtTable& et, const u64* right_sites, int antisense,
+                              int min_intron, int max_intron, int k, int64_t lp, Sink& ev, int lane = 0, int n_lanes = 1) {
+    unsigned int found = 0;
+    const int64_t wbase = (int64_t)L.contig_blk[k], wend = (int64_t)L.contig_blk[k + 1], len = L.contig_len[k];
+    // attach_upstream_mers (:741-784): (0, 0) when too close to a contig end
+    u64 lf = 0, lrv = 0;
+    if (lp > 32 && lp < len) { lf = mer32(g, (uint32_t)k + 1, lp - 32); lrv = rc32(lf); }
+    const int64_t q0 = lp + min_intron, q1 = lp + max_intron;            // right sites in [q0, q1)
+    for (int64_t rw = wbase + (q0 >> 6) + lane; rw < wend && (rw - wbase) * 64 < q1; rw += n_lanes) {
+        u64 rb = right_sites[rw];
+        const int64_t p0 = (rw - wbase) * 64;
+        rb &= ~below_mask(q0 - p0) & below_mask(q1 - p0);
+        while (rb) {
+            const int c = __builtin_ctzll(rb);
+            rb &= rb - 1;
+            const int64_t rp = p0 + c;
+            u64 rf = 0, rrv = 0;                                          // attach_downstream_mers (:786-832)
+            if (rp + 2 + 32 < len) { rf = mer32(g, (uint32_t)k + 1, rp + 2); rrv = rc32(rf); }
+            if (extendable(et, lf, rf) || extendable(et, rrv, lrv)) {
+                ev.junction((uint32_t)k + 1, (uint32_t)(lp - 1), (uint32_t)(rp + 2), antisense != 0);
+                ++found;
+            }
+        }
+    }
+    return found;
+}
+// the left sites of bitmap word w (the CPU build walks words; the device first compacts the sites into a list)
 template <class Sink>
 THJ_HD unsigned int pair_word(const Genome& g, const Layout& L, const ExtTable& et, const u64* left_sites, const u64* right_sites, int antisense,
                               int min_intron, int max_intron, int64_t w, Sink& ev) {
@@ -207,31 +249,10 @@ THJ_HD unsigned int pair_word(const Genome& g, const Layout& L, const ExtTable& 
     if (!bits) return 0;
     unsigned int found = 0;
     const int k = contig_of(L, w);
-    const int64_t wbase = (int64_t)L.contig_blk[k], wend = (int64_t)L.contig_blk[k + 1], len = L.contig_len[k];
     while (bits) {
         const int b = __builtin_ctzll(bits);
         bits &= bits - 1;
-        const int64_t lp = (w - wbase) * 64 + b;
-        // attach_upstream_mers (:741-784): (0, 0) when too close to a contig end
-        u64 lf = 0, lrv = 0;
-        if (lp > 32 && lp < len) { lf = mer32(g, (uint32_t)k + 1, lp - 32); lrv = rc32(lf); }
-        const int64_t q0 = lp + min_intron, q1 = lp + max_intron;            // right sites in [q0, q1)
-        for (int64_t rw = wbase + (q0 >> 6); rw < wend && (rw - wbase) * 64 < q1; ++rw) {
-            u64 rb = right_sites[rw];
-            const int64_t p0 = (rw - wbase) * 64;
-            rb &= ~below_mask(q0 - p0) & below_mask(q1 - p0);
-            while (rb) {
-                const int c = __builtin_ctzll(rb);
-                rb &= rb - 1;
-                const int64_t rp = p0 + c;
-                u64 rf = 0, rrv = 0;                                          // attach_downstream_mers (:786-832)
-                if (rp + 2 + 32 < len) { rf = mer32(g, (uint32_t)k + 1, rp + 2); rrv = rc32(rf); }
-                if (extendable(et, lf, rf) || extendable(et, rrv, lrv)) {
-                    ev.junction((uint32_t)k + 1, (uint32_t)(lp - 1), (uint32_t)(rp + 2), antisense != 0);
-                    ++found;
-                }
-            }
-        }
+        found += pair_site(g, L, et, right_sites, antisense, min_intron, max_intron, k, (w - (int64_t)L.contig_blk[k]) * 64 + b, ev);
     }
     return found;
 }

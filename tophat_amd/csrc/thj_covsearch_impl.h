@@ -25,8 +25,8 @@ using namespace thj::cov;
 __global__ void k_add_hits(Layout L, const Hit* hits, const uint32_t* n_hits_ptr, u64* covbits, int32_t* cov_size) {
     const int64_t n = (int64_t)*n_hits_ptr;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        add_hit(L, hits[i], [&](int64_t w, u64 m) { atomicOr((unsigned long long*)&covbits[w], (unsigned long long)m); },
-                [&](int k, int32_t sz) { atomicMax(&cov_size[k], sz); });
+        add_hit(L, hits[i], [&](int64_t w, u64 m) { if ((covbits[w] & m) != m) atomicOr((unsigned long long*)&covbits[w], (unsigned long long)m); },
+                [&](int k, int32_t sz) { if (cov_size[k] < sz) atomicMax(&cov_size[k], sz); });
 }
 __global__ void k_long_enough(Layout L, const u64* covbits, u64* le, int m) {
     const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -52,12 +52,39 @@ __global__ void k_key_offsets(const uint32_t* sorted_keys, int64_t n, uint32_t* 
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k <= N_KEYS) key_offset(sorted_keys, n, off, k);
 }
-__global__ void k_pair(Genome g, Layout L, Tables t, ExtTable et, const u64* left_sites, const u64* right_sites, int antisense,
-                       int min_intron, int max_intron, unsigned long long* n_found) {
+// left sites of both orientations compacted into one list: entry = contig position | contig << 32 | antisense << 63
+__global__ void k_list_sites(Layout L, const u64* fd, const u64* ra, u64* list, unsigned int* n_list, unsigned int cap) {
     const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (w >= L.n_words) return;
+    const u64 a = fd[w], b = ra[w];
+    const int n = __builtin_popcountll(a) + __builtin_popcountll(b);
+    if (!n) return;
+    const int k = contig_of(L, w);
+    const int64_t pos0 = (w - (int64_t)L.contig_blk[k]) * 64;
+    unsigned int at = atomicAdd(n_list, (unsigned int)n);
+    for (int o = 0; o < 2; ++o) {
+        u64 bits = o ? b : a;
+        while (bits) {
+            const int bit = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            if (at < cap) list[at] = (u64)(pos0 + bit) | ((u64)k << 32) | ((u64)o << 63);
+            ++at;
+        }
+    }
+}
+// one wave per listed left site: its 64 lanes share out the words of the acceptor bitmap within reach, so the candidate
+// acceptors of a donor are tested side by side
+__global__ __launch_bounds__(256) void k_pair(Genome g, Layout L, Tables t, ExtTable et, const u64* list, const unsigned int* n_list, unsigned int cap,
+                                              const u64* fa, const u64* rd, int min_intron, int max_intron, unsigned long long* n_found) {
+    const unsigned int n = *n_list < cap ? *n_list : cap;
+    const int lane = threadIdx.x & 63;
+    unsigned int f = 0;
     EventSink ev{g, t};
-    const unsigned int f = pair_word(g, L, et, left_sites, right_sites, antisense, min_intron, max_intron, w, ev);
+    for (unsigned int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
+        const u64 e = list[i];
+        const int anti = (int)(e >> 63), k = (int)((e >> 32) & 0x7FFFFFFFull);
+        f += pair_site(g, L, et, anti ? rd : fa, anti, min_intron, max_intron, k, (int64_t)(e & 0xFFFFFFFFull), ev, lane, 64);
+    }
     if (f) atomicAdd(n_found, (unsigned long long)f);
 }
 
@@ -70,7 +97,7 @@ static int cov_ensure(thj_ctx* c) {
         HIPCHK(hipMalloc(&c->d_cov, (size_t)c->n_blocks * 8 * 8));             // coverage, long_enough, 2 flag and 4 site bitmaps
         HIPCHK(hipMalloc(&c->d_cov_size, (size_t)(c->n_contigs + 1) * 4));
         HIPCHK(hipMalloc(&c->d_ext_off, ((size_t)thj::cov::N_KEYS + 2) * 4));
-        HIPCHK(hipMalloc(&c->d_cov_found, 8));
+        HIPCHK(hipMalloc(&c->d_cov_found, 16));              // junctions found | left sites listed
     }
     return THJ_OK;
 }
@@ -82,7 +109,7 @@ extern "C" int thj_covsearch_reset_async(thj_ctx* c) {
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->d_cov, 0, (size_t)c->n_blocks * 8, c->stream));
     HIPCHK(hipMemsetAsync(c->d_cov_size, 0, (size_t)(c->n_contigs + 1) * 4, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_cov_found, 0, 8, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_cov_found, 0, 16, c->stream));
     c->n_ext = 0;
     return THJ_OK;
 }
@@ -172,8 +199,13 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
     Tables t{c->d_junc, (u64)c->junc_cap - 1, c->d_del, (u64)c->indel_cap - 1, c->d_ins_key, c->d_ins_val,
              (u64)c->indel_cap - 1, junc_list(c), del_list(c), ins_list(c), c->d_ovf, c->d_cnt};
     thj::cov::ExtTable et{c->d_ext_off, vals};
-    hipLaunchKernelGGL(cov_k::k_pair, dim3(gw), dim3(256), 0, c->stream, g, L, t, et, fd, fa, 0, (int)min_intron, (int)max_intron, c->d_cov_found);
-    hipLaunchKernelGGL(cov_k::k_pair, dim3(gw), dim3(256), 0, c->stream, g, L, t, et, ra, rd, 1, (int)min_intron, (int)max_intron, c->d_cov_found);
+    // left sites -> list (its room: the long_enough bitmap, which nothing reads any more) -> one thread per site
+    u64* list = le; const unsigned int list_cap = (unsigned int)(nw < 0xFFFFFFFFll ? nw : 0xFFFFFFFFll);
+    unsigned int* n_list = (unsigned int*)(c->d_cov_found + 1);
+    HIPCHK(hipMemsetAsync(n_list, 0, 4, c->stream));
+    hipLaunchKernelGGL(cov_k::k_list_sites, dim3(gw), dim3(256), 0, c->stream, L, fd, ra, list, n_list, list_cap);
+    hipLaunchKernelGGL(cov_k::k_pair, dim3(2048), dim3(256), 0, c->stream, g, L, t, et, list, n_list, list_cap, fa, rd,
+                       (int)min_intron, (int)max_intron, c->d_cov_found);
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
