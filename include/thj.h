@@ -344,6 +344,14 @@ int thj_covsearch_add_reads(thj_ctx* ctx, int64_t n_reads, int32_t words_per_pla
                             int32_t on_device);
 int thj_covsearch_run_async(thj_ctx* ctx, int32_t min_cov_length, int32_t min_coverage_intron, int32_t max_coverage_intron);
 int thj_covsearch_finish(thj_ctx* ctx, int64_t max_cov_juncs, int64_t* n_found);
+/* Reads sharded over GPUs: the coverage map of the whole run is the OR of the ranks' maps and the
+ * extension table the concatenation of their entries.  thj_covsearch_device_state exposes a rank's state (device
+ * pointers: n_words coverage words, one size per contig, n_ext key / value entries) for the caller to all-gather;
+ * thj_covsearch_merge_async folds another rank's state in; then every rank runs thj_covsearch_run_async. */
+int thj_covsearch_device_state(thj_ctx* ctx, const uint64_t** d_cov_bits, int64_t* n_words, const int32_t** d_cov_size,
+                               const uint32_t** d_ext_keys, const uint64_t** d_ext_vals, int64_t* n_ext);
+int thj_covsearch_merge_async(thj_ctx* ctx, const uint64_t* d_other_bits, const int32_t* d_other_size,
+                              const uint32_t* d_other_keys, const uint64_t* d_other_vals, int64_t n_other_ext);
 
 #ifdef __cplusplus
 }

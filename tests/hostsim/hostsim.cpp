@@ -215,23 +215,32 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
 #include "../../tophat_amd/csrc/thj_cov_core.h"
 #include <algorithm>
 
-extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
-                                       int64_t n_blocks, const thj_hit* hits, int64_t n_hits,
-                                       const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
-                                       int32_t min_cov_length, int32_t min_intron, int32_t max_intron,
-                                       thj_junction** out, int64_t* n_out) {
+// One shard's coverage-search state (what thj_covsearch_device_state exposes on the device): coverage words, per-contig
+// sizes, extension-table entries of the shard's hits and unmapped reads.
+extern "C" int hostsim_coverage_state(const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs, int64_t n_blocks,
+                                      const thj_hit* hits, int64_t n_hits, const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
+                                      uint64_t* bits /* n_blocks */, int32_t* sizes /* n_contigs */, uint32_t* keys /* 23 n_ium */, uint64_t* vals) {
+    using namespace thj::cov;
+    Layout L{contig_blk, contig_len, n_contigs, n_blocks};
+    for (int64_t i = 0; i < n_hits; ++i)
+        add_hit(L, *(const Hit*)&hits[i], [&](int64_t w, u64 m) { bits[w] |= m; }, [&](int k, int32_t sz) { if (sz > sizes[k]) sizes[k] = sz; });
+    for (int64_t r = 0; r < n_ium; ++r) read_entries((const u64*)ium_planes, ium_lens, W, keys, (u64*)vals, 0, r);
+    return 0;
+}
+
+// The pass from (merged) state: thj_covsearch_merge_async's rule is OR of the coverage words, max of the sizes,
+// concatenation of the entries -- done by the caller -- then thj_covsearch_run_async's kernels as loops.
+extern "C" int hostsim_coverage_run(const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
+                                    int64_t n_blocks, const uint64_t* bits, const int32_t* sizes, const uint32_t* keys, const uint64_t* vals, int64_t n_ext,
+                                    int32_t min_cov_length, int32_t min_intron, int32_t max_intron, thj_junction** out, int64_t* n_out) {
     using namespace thj::cov;
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Layout L{contig_blk, contig_len, n_contigs, n_blocks};
     const int64_t nw = n_blocks;
     std::vector<u64> bm((size_t)nw * 8, 0);
     u64 *covb = bm.data(), *le = covb + nw, *ll = le + nw, *lr = ll + nw, *fd = lr + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
-    std::vector<int32_t> cov_size((size_t)n_contigs + 1, 0);
-    for (int64_t i = 0; i < n_hits; ++i)
-        add_hit(L, *(const Hit*)&hits[i], [&](int64_t w, u64 m) { covb[w] |= m; }, [&](int k, int32_t sz) { if (sz > cov_size[(size_t)k]) cov_size[(size_t)k] = sz; });
-    std::vector<uint32_t> keys((size_t)n_ium * 23 + 1); std::vector<u64> vals((size_t)n_ium * 23 + 1);
-    for (int64_t r = 0; r < n_ium; ++r) read_entries((const u64*)ium_planes, ium_lens, W, keys.data(), vals.data(), 0, r);
-    std::vector<size_t> ord((size_t)n_ium * 23);
+    memcpy(covb, bits, (size_t)nw * 8);
+    std::vector<size_t> ord((size_t)n_ext);
     for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
     std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
     std::vector<uint32_t> skeys(ord.size() + 1); std::vector<u64> svals(ord.size() + 1);
@@ -239,8 +248,8 @@ extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* c
     std::vector<uint32_t> off((size_t)N_KEYS + 2);
     for (uint32_t k = 0; k <= N_KEYS; ++k) key_offset(skeys.data(), (int64_t)ord.size(), off.data(), k);
     for (int64_t w = 0; w < nw; ++w) long_enough_word(L, covb, le, min_cov_length - 1, w);
-    for (int64_t w = 0; w < nw; ++w) look_word(L, le, cov_size.data(), ll, lr, w);
-    for (int i = 0; i < 2 * n_contigs; ++i) drop_windows(L, cov_size.data(), ll, lr, i);
+    for (int64_t w = 0; w < nw; ++w) look_word(L, le, sizes, ll, lr, w);
+    for (int i = 0; i < 2 * n_contigs; ++i) drop_windows(L, sizes, ll, lr, i);
     for (int64_t w = 0; w < nw; ++w) site_word(g, L, ll, lr, fd, ra, fa, rd, w);
     Collect c;
     ExtTable et{off.data(), svals.data()};
@@ -250,4 +259,18 @@ extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* c
     *out = (thj_junction*)malloc(sizeof(thj_junction) * (c.juncs.size() + 1));
     memcpy(*out, c.juncs.data(), sizeof(thj_junction) * c.juncs.size());
     return 0;
+}
+
+// single shard: state, then the pass
+extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
+                                       int64_t n_blocks, const thj_hit* hits, int64_t n_hits,
+                                       const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
+                                       int32_t min_cov_length, int32_t min_intron, int32_t max_intron,
+                                       thj_junction** out, int64_t* n_out) {
+    std::vector<uint64_t> bits((size_t)n_blocks, 0), vals((size_t)n_ium * 23 + 1);
+    std::vector<int32_t> sizes((size_t)n_contigs + 1, 0);
+    std::vector<uint32_t> keys((size_t)n_ium * 23 + 1);
+    hostsim_coverage_state(contig_blk, contig_len, n_contigs, n_blocks, hits, n_hits, ium_planes, ium_lens, n_ium, W, bits.data(), sizes.data(), keys.data(), vals.data());
+    return hostsim_coverage_run(blocks, contig_blk, contig_len, n_contigs, n_blocks, bits.data(), sizes.data(), keys.data(), vals.data(), n_ium * 23,
+                                min_cov_length, min_intron, max_intron, out, n_out);
 }

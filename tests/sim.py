@@ -116,13 +116,7 @@ def fusions(p: Params, seqs, b: SegBatch, ignore_ref_ids=()):
     return orc.merge_fusions(a, np.zeros(0, dtype=orc.FUSION_DTYPE))
 
 
-def coverage_search(seqs, hits, ium_reads, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
-    """the coverage-search kernels (thj_cov_core.h) as host loops -> set of (ref_id, left, right, antisense)"""
-    from tophat_amd.batch import HIT_DTYPE
-    l = lib()
-    g = host.pack_genome(seqs, lib=l)
-    clen = g.lens.astype(np.int32)
-    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+def _pack_ium(l, ium_reads):
     n = len(ium_reads)
     off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum([len(r) for r in ium_reads], out=off[1:])
@@ -133,13 +127,52 @@ def coverage_search(seqs, hits, ium_reads, min_cov_length: int, min_intron: int 
     if n:
         assert l.thj_reads_pack(C.c_int64(n), C.c_void_p(off.ctypes.data), C.c_void_p(bases.ctypes.data), W, C.c_void_p(planes.ctypes.data),
                                 C.c_void_p(lens.ctypes.data)) == 0
+    return planes, lens, W, n
+
+
+def coverage_state(seqs, hits, ium_reads):
+    """one shard's coverage-search state (coverage words, per-contig sizes, extension keys, values) as numpy arrays"""
+    from tophat_amd.batch import HIT_DTYPE
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    clen = g.lens.astype(np.int32)
+    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    planes, lens, W, n = _pack_ium(l, ium_reads)
+    nb = len(g.blocks) // 4
+    bits = np.zeros(nb, dtype=np.uint64)
+    sizes = np.zeros(g.n_contigs + 1, dtype=np.int32)
+    keys = np.zeros(n * 23 + 1, dtype=np.uint32)
+    vals = np.zeros(n * 23 + 1, dtype=np.uint64)
+    rc = l.hostsim_coverage_state(C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data), g.n_contigs, C.c_int64(nb),
+                                  C.c_void_p(h.ctypes.data), C.c_int64(len(h)), C.c_void_p(planes.ctypes.data), C.c_void_p(lens.ctypes.data),
+                                  C.c_int64(n), W, C.c_void_p(bits.ctypes.data), C.c_void_p(sizes.ctypes.data), C.c_void_p(keys.ctypes.data),
+                                  C.c_void_p(vals.ctypes.data))
+    assert rc == 0
+    return bits, sizes, keys[:n * 23], vals[:n * 23]
+
+
+def coverage_run(seqs, states, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
+    """states merged by thj_covsearch_merge_async's rule (OR of the coverage words, max of the sizes, concatenated
+    entries), then the pass -> set of (ref_id, left, right, antisense)"""
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    clen = g.lens.astype(np.int32)
+    bits = np.bitwise_or.reduce([s[0] for s in states])
+    sizes = np.maximum.reduce([s[1] for s in states])
+    keys = np.ascontiguousarray(np.concatenate([s[2] for s in states]))
+    vals = np.ascontiguousarray(np.concatenate([s[3] for s in states]))
     out = C.c_void_p()
     n_out = C.c_int64()
-    rc = l.hostsim_coverage_search(C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data),
-                                   g.n_contigs, C.c_int64(len(g.blocks) // 4), C.c_void_p(h.ctypes.data), C.c_int64(len(h)),
-                                   C.c_void_p(planes.ctypes.data), C.c_void_p(lens.ctypes.data), C.c_int64(n), W,
-                                   min_cov_length, min_intron, max_intron, C.byref(out), C.byref(n_out))
+    rc = l.hostsim_coverage_run(C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data), g.n_contigs,
+                                C.c_int64(len(g.blocks) // 4), C.c_void_p(bits.ctypes.data), C.c_void_p(sizes.ctypes.data),
+                                C.c_void_p(keys.ctypes.data), C.c_void_p(vals.ctypes.data), C.c_int64(len(keys)),
+                                min_cov_length, min_intron, max_intron, C.byref(out), C.byref(n_out))
     assert rc == 0
     a = np.frombuffer((C.c_char * (max(1, n_out.value) * 16)).from_address(out.value), dtype=JUNC_DTYPE)[:n_out.value].copy()
     l.hostsim_free(out)
     return {(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"])) for j in a}
+
+
+def coverage_search(seqs, hits, ium_reads, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
+    """the coverage-search kernels (thj_cov_core.h) as host loops -> set of (ref_id, left, right, antisense)"""
+    return coverage_run(seqs, [coverage_state(seqs, hits, ium_reads)], min_cov_length, min_intron, max_intron)

@@ -109,3 +109,34 @@ def test_segment_juncs_executable_with_coverage_search(name, tmp_path):
     r = subprocess.run(cmd2, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(out["juncs"]).read() == open(os.path.join(d, "expected.seg_only.juncs")).read()
+
+
+def test_two_shards_merged_on_the_device_equal_one():
+    """thj_covsearch_device_state / thj_covsearch_merge_async: the left side's hits and reads in one context, the right
+    side's in another, merged -> the same junctions as everything in one context"""
+    c = load("pe50_cov")
+    seqs = [orc.fold_genome_char(s) for s in c["seqs"]]
+    n_left = sum(1 for _ in open(__import__("os").path.join(c["dir"], "left.fq"))) // 4
+    ium = [c["ium"][:n_left], c["ium"][n_left:]]
+    args = (c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"])
+    with host.Context(0) as a, host.Context(0) as b:
+        for ctx in (a, b):
+            ctx.upload_genome(host.pack_genome(seqs))
+            ctx.reset()
+            ctx.covsearch_reset()
+        base = 0
+        for ctx, (side, sb), reads in zip((a, b), c["seg_batches"], ium):
+            p = copy.copy(c["p"])
+            p.read_side = side
+            ctx.covsearch_add_hits(ctx.upload_batch(sb, ordinal_base=base))       # coverage only: no segment search here
+            ctx.covsearch_add_reads(reads)
+            base += sb.n_reads
+        b.sync()
+        bits, nw, sizes, keys, vals, n_ext = b.covsearch_device_state()
+        a.covsearch_merge(bits, sizes, keys, vals, n_ext)
+        a.covsearch_run(*args)
+        found = a.covsearch_finish()
+        got = _tuples(a.download(a.finish()).juncs)
+    g = orc.Genome(seqs)
+    want = _tuples(orc.coverage_search(g, c["hits"], c["ium"], *args))
+    assert got == want and found == len(want)

@@ -94,3 +94,50 @@ def test_two_rank_shard_merge_equals_single_rank():
     want = [a.sam_fields(int(sb.read_id[a.read_idx]), case.names) for a in orc.spanning(Params(), g, sb, juncs, ins)]
     assert res[0][4] + res[1][4] == want
     assert len(want) > 100 and len(ev.insertions) > 0
+
+
+def cov_worker(rank, world, port, q):
+    """coverage search with the reads sharded: each rank builds the state of its shard (coverage words, sizes, extension
+    entries -- the kernel logic), the ranks all-gather the states and every rank runs the pass on the merged state"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    import sim
+    from cov_util import load
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = load("pe50_cov")
+    seqs = [orc.fold_genome_char(s) for s in c["seqs"]]
+    hits, ium = c["hits"], c["ium"]
+    my_hits = hits[rank::world]                      # any partition of the hits / reads will do: the merge is a union
+    my_ium = ium[rank::world]
+    state = sim.coverage_state(seqs, my_hits, my_ium)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, state)
+    got = sim.coverage_run(seqs, gathered, c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"])
+    q.put((rank, sorted(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_coverage_search_equals_single_rank():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    from cov_util import load
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30500 + os.getpid() % 1000
+    procs = [ctx.Process(target=cov_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted([q.get(timeout=300) for _ in procs])
+    for p_ in procs:
+        p_.join(60)
+    c = load("pe50_cov")
+    g = orc.Genome([orc.fold_genome_char(s) for s in c["seqs"]])
+    want = sorted((int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"]))
+                  for j in orc.coverage_search(g, c["hits"], c["ium"], c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"]))
+    assert len(want) > 10
+    for r in res:
+        assert r[1] == want

@@ -102,6 +102,23 @@ static int cov_ensure(thj_ctx* c) {
     return THJ_OK;
 }
 
+static int cov_reserve_ext(thj_ctx* c, int64_t need) {          // room for `need` extension-table entries, keeping what is there
+    if (need >= (1ll << 32)) { thj_set_error("more than 2^32 extension-table entries (unmapped reads x 23)"); return THJ_EINVAL; }
+    if (need <= c->ext_cap) return THJ_OK;
+    const int64_t ncap = need + need / 2 + 1024;
+    uint32_t* nk = nullptr; u64* nv = nullptr;
+    HIPCHK(hipMalloc(&nk, (size_t)ncap * 4)); HIPCHK(hipMalloc(&nv, (size_t)ncap * 8));
+    if (c->n_ext) {
+        HIPCHK(hipMemcpyAsync(nk, c->d_ext_key, (size_t)c->n_ext * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(nv, c->d_ext_val, (size_t)c->n_ext * 8, hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
+    c->d_ext_key = nk; c->d_ext_val = nv; c->ext_cap = ncap;
+    HIPCHK(hipMalloc(&c->d_ext_key_sorted, (size_t)ncap * 4)); HIPCHK(hipMalloc(&c->d_ext_val_sorted, (size_t)ncap * 8));
+    return THJ_OK;
+}
+
 extern "C" int thj_covsearch_reset_async(thj_ctx* c) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
@@ -137,20 +154,7 @@ extern "C" int thj_covsearch_add_reads(thj_ctx* c, int64_t n_reads, int32_t word
     if (rc) return rc;
     if (n_reads == 0) return THJ_OK;
     const int64_t need = c->n_ext + n_reads * 23;
-    if (need >= (1ll << 32)) { thj_set_error("more than 2^32 extension-table entries (unmapped reads x 23)"); return THJ_EINVAL; }
-    if (need > c->ext_cap) {
-        const int64_t ncap = need + need / 2 + 1024;
-        uint32_t* nk = nullptr; u64* nv = nullptr;
-        HIPCHK(hipMalloc(&nk, (size_t)ncap * 4)); HIPCHK(hipMalloc(&nv, (size_t)ncap * 8));
-        if (c->n_ext) {
-            HIPCHK(hipMemcpyAsync(nk, c->d_ext_key, (size_t)c->n_ext * 4, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(nv, c->d_ext_val, (size_t)c->n_ext * 8, hipMemcpyDeviceToDevice, c->stream));
-        }
-        HIPCHK(hipStreamSynchronize(c->stream));
-        hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
-        c->d_ext_key = nk; c->d_ext_val = nv; c->ext_cap = ncap;
-        HIPCHK(hipMalloc(&c->d_ext_key_sorted, (size_t)ncap * 4)); HIPCHK(hipMalloc(&c->d_ext_val_sorted, (size_t)ncap * 8));
-    }
+    if ((rc = cov_reserve_ext(c, need))) return rc;
     const u64* d_planes = (const u64*)planes; const uint16_t* d_lens = lens;
     void *tp = nullptr, *tl = nullptr;
     if (!on_device) {                     // host buffers (the executables): staged through a temporary device copy
@@ -165,6 +169,41 @@ extern "C" int thj_covsearch_add_reads(thj_ctx* c, int64_t n_reads, int32_t word
     HIPCHK(hipGetLastError());
     if (!on_device) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(tp); hipFree(tl); }
     c->n_ext = need;
+    return THJ_OK;
+}
+
+// ---- multi-GPU (reads sharded over ranks): the coverage map is the OR of the ranks' maps, the extension table the
+// concatenation of their entries.  A rank exposes its state, the caller moves it (RCCL all-gather), and every rank
+// folds the others' in before thj_covsearch_run_async; the pairing is then the same on every rank.
+__global__ void k_merge_cov(u64* bits, const u64* other_bits, int64_t n_words, int32_t* size, const int32_t* other_size, int32_t n_contigs) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n_words) { const u64 o = other_bits[i]; if (o) bits[i] |= o; }
+    if (i < n_contigs && other_size[i] > size[i]) size[i] = other_size[i];
+}
+extern "C" int thj_covsearch_device_state(thj_ctx* c, const uint64_t** d_cov_bits, int64_t* n_words, const int32_t** d_cov_size,
+                                          const uint32_t** d_ext_keys, const uint64_t** d_ext_vals, int64_t* n_ext) {
+    if (!c || !d_cov_bits || !n_words || !d_cov_size || !d_ext_keys || !d_ext_vals || !n_ext) { thj_set_error("thj_covsearch_device_state: null argument"); return THJ_EINVAL; }
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    *d_cov_bits = (const uint64_t*)c->d_cov; *n_words = c->n_blocks; *d_cov_size = c->d_cov_size;
+    *d_ext_keys = c->d_ext_key; *d_ext_vals = (const uint64_t*)c->d_ext_val; *n_ext = c->n_ext;
+    return THJ_OK;
+}
+extern "C" int thj_covsearch_merge_async(thj_ctx* c, const uint64_t* d_other_bits, const int32_t* d_other_size,
+                                         const uint32_t* d_other_keys, const uint64_t* d_other_vals, int64_t n_other_ext) {
+    if (!c || !d_other_bits || !d_other_size || (n_other_ext > 0 && (!d_other_keys || !d_other_vals))) { thj_set_error("thj_covsearch_merge_async: null argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_merge_cov, dim3((unsigned)((c->n_blocks + 255) / 256)), dim3(256), 0, c->stream, c->d_cov, (const u64*)d_other_bits, c->n_blocks,
+                       c->d_cov_size, d_other_size, c->n_contigs);
+    HIPCHK(hipGetLastError());
+    if (n_other_ext > 0) {
+        if ((rc = cov_reserve_ext(c, c->n_ext + n_other_ext))) return rc;
+        HIPCHK(hipMemcpyAsync(c->d_ext_key + c->n_ext, d_other_keys, (size_t)n_other_ext * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(c->d_ext_val + c->n_ext, d_other_vals, (size_t)n_other_ext * 8, hipMemcpyDeviceToDevice, c->stream));
+        c->n_ext += n_other_ext;
+    }
     return THJ_OK;
 }
 

@@ -60,6 +60,7 @@ ABI_SYMBOLS = [
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
     "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_genome_gather", "thj_fusion_finish", "thj_fusion_download",
     "thj_covsearch_reset_async", "thj_covsearch_add_hits_async", "thj_covsearch_add_reads", "thj_covsearch_run_async", "thj_covsearch_finish",
+    "thj_covsearch_device_state", "thj_covsearch_merge_async",
 ]
 
 _lib = None
@@ -274,6 +275,18 @@ class Context:
         """planes / lengths already on the device (thj_reads_pack layout)"""
         _check(self.lib, self.lib.thj_covsearch_add_reads(self._ctx, C.c_int64(n), W, C.c_void_p(planes_ptr), C.c_void_p(lens_ptr), 1),
                "thj_covsearch_add_reads")
+
+    def covsearch_device_state(self):
+        """-> (coverage bits ptr, n_words, sizes ptr, ext keys ptr, ext vals ptr, n_ext): device pointers of this rank's state"""
+        bits, sizes, keys, vals = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nw, ne = C.c_int64(), C.c_int64()
+        _check(self.lib, self.lib.thj_covsearch_device_state(self._ctx, C.byref(bits), C.byref(nw), C.byref(sizes), C.byref(keys), C.byref(vals),
+                                                             C.byref(ne)), "thj_covsearch_device_state")
+        return bits.value, nw.value, sizes.value, keys.value, vals.value, ne.value
+
+    def covsearch_merge(self, bits_ptr: int, sizes_ptr: int, keys_ptr: int, vals_ptr: int, n_ext: int):
+        _check(self.lib, self.lib.thj_covsearch_merge_async(self._ctx, C.c_void_p(bits_ptr), C.c_void_p(sizes_ptr), C.c_void_p(keys_ptr),
+                                                            C.c_void_p(vals_ptr), C.c_int64(n_ext)), "thj_covsearch_merge_async")
 
     def covsearch_run(self, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
         _check(self.lib, self.lib.thj_covsearch_run_async(self._ctx, min_cov_length, min_intron, max_intron), "thj_covsearch_run_async")
