@@ -323,18 +323,31 @@ THJ_HD void small_insertion(const Genome& g, PlanesT<WT> rd, int plen, const Hit
 // ---- map_read_to_contig over the mate's flank (segment_juncs.cpp:2946-2973) ---
 // Returns the first offset with the minimal Hamming distance (< 3), or -1.
 THJ_HD int flank_scan(const Genome& g, uint32_t ref_id, int64_t left, int flen, Planes rd, int rlen) {
+    // Bit-sliced over the offsets: for read base k, one 64-bit word says at which of the (up to 64 - rlen + 1) offsets
+    // served by a 64-base fetch the genome differs from it; the words of the rlen bases are summed in a two-plane
+    // counter with a sticky overflow.  About 26 word operations per read base instead of 25 per offset.
     int pos = -1, best = 3;
     int n_off = flen - rlen;                      // loop is i < contig_len - read_len
-    u64 m = lowmask(rlen);
     int span = 64 - rlen + 1;                     // offsets served by one 64-base fetch
     for (int cs = 0; cs < n_off; cs += span) {
         Planes c = g_fetch(g, ref_id, left + cs);
         int lim = n_off - cs < span ? n_off - cs : span;
-        for (int j = 0; j < lim; ++j) {
-            u64 x = (((c.lo >> j) ^ rd.lo) | ((c.hi >> j) ^ rd.hi) | ((c.nm >> j) ^ rd.nm)) & m;  // 'N'=='N' matches
-            int t = popc(x);
-            if (t < best) { best = t; pos = cs + j; }
+        u64 c0 = 0, c1 = 0, ov = 0;
+        for (int k = 0; k < rlen; ++k) {
+            const u64 ml = 0ull - ((rd.lo >> k) & 1ull), mh = 0ull - ((rd.hi >> k) & 1ull), mn = 0ull - ((rd.nm >> k) & 1ull);
+            const u64 x = ((c.lo >> k) ^ ml) | ((c.hi >> k) ^ mh) | ((c.nm >> k) ^ mn);      // 'N'=='N' matches
+            const u64 k0 = c0 & x;
+            c0 ^= x;
+            const u64 k1 = c1 & k0;
+            c1 ^= k0;
+            ov |= k1;
         }
+        const u64 valid = lowmask(lim) & ~ov;
+        const u64 z0 = ~c0 & ~c1 & valid, z1 = c0 & ~c1 & valid, z2 = ~c0 & c1 & valid;
+        // the first offset with a strictly smaller distance replaces (scan order: ascending offsets)
+        if (z0) { best = 0; pos = cs + ctz(z0); }
+        else if (best > 1 && z1) { best = 1; pos = cs + ctz(z1); }
+        else if (best > 2 && z2) { best = 2; pos = cs + ctz(z2); }
         if (best == 0) break;                     // nothing can replace a perfect match
     }
     return pos;
