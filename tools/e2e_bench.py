@@ -2,7 +2,9 @@
 """End-to-end timing of the drop-in executables (GPU box): generate a seeded paired-end case, write the files
 tophat.py would hand over (FASTA, FASTQ, id-sorted segment maps as SAM text and as BAM), run
 tophat_amd/bin/segment_juncs and long_spanning_reads on them and report wall-clock reads/s per stage.
-Usage: python tools/e2e_bench.py [n_pairs] [--bam]"""
+Usage: python tools/e2e_bench.py [n_pairs] [--bam] [--short]
+--short: 2x50 bp reads in two segments, segment_juncs with the coverage search (every read given as --ium-reads), the
+way tophat.py runs reads of fewer than three segments."""
 import json
 import os
 import subprocess
@@ -17,11 +19,13 @@ from tophat_amd.bamio import write_bam_from_sam  # noqa: E402
 
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200000
 use_bam = "--bam" in sys.argv
+short = "--short" in sys.argv
+RL, NSEG = (50, 2) if short else (100, 4)
 BIN = os.path.join(ROOT, "tophat_amd", "bin")
 d = tempfile.mkdtemp(prefix="thj_e2e_")
 t = time.time()
-case = make_case(seed=7, contig_lens=(8_000_000,), n_reads=n_pairs, paired=True, read_len=100, seg_len=25,
-                 genes_per_contig=1500, spliced_seg_frac=0.5)
+case = make_case(seed=7, contig_lens=(8_000_000,), n_reads=n_pairs, paired=True, read_len=RL, seg_len=25,
+                 genes_per_contig=1500, spliced_seg_frac=0.0 if short else 0.5)
 write_case(case, d)
 gen_s = time.time() - t
 
@@ -36,10 +40,11 @@ def f(name):
     return p
 
 
-segs = {sd: ",".join(f("%s_seg%d.sam" % (sd, k + 1)) for k in range(4)) for sd in ("left", "right")}
+segs = {sd: ",".join(f("%s_seg%d.sam" % (sd, k + 1)) for k in range(NSEG)) for sd in ("left", "right")}
 out = {k: os.path.join(d, "out." + k) for k in ("juncs", "insertions", "deletions", "fusions")}
-res = {"n_pairs": n_pairs, "inputs": "bam" if use_bam else "sam", "gen_seconds": round(gen_s, 1)}
-cmd = [os.path.join(BIN, "segment_juncs"), "--no-coverage-search", "--no-microexon-search", "--segment-length", "25",
+res = {"n_pairs": n_pairs, "read_len": RL, "inputs": "bam" if use_bam else "sam", "gen_seconds": round(gen_s, 1)}
+mode = ["--ium-reads", f("left.fq") + "," + f("right.fq")] if short else ["--no-coverage-search"]
+cmd = [os.path.join(BIN, "segment_juncs")] + mode + ["--no-microexon-search", "--segment-length", "25",
        "--sam-header", f("hdr.sam"), "-p", "1", "--inner-dist-mean", "50", "--inner-dist-std-dev", "20",
        f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"],
        f("left.fq"), f("left_map.sam"), segs["left"], f("right.fq"), f("right_map.sam"), segs["right"]]

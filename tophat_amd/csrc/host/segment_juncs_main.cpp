@@ -171,6 +171,38 @@ int main(int argc, char** argv) {
         return ctx;
     };
     size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
+    // ---- coverage search, part 1 (segment_juncs.cpp:4955-4982): the extension table of the initially unmapped reads
+    // (index_read_mers :548-571 -- the first 32 bases of every read) is fed to the device on its own thread while the
+    // two sides are being ingested
+    std::thread ium_thread;
+    if (!o.no_coverage_search)
+        ium_thread = std::thread([&]() {
+            const size_t CH = (size_t)1 << 19;
+            for (auto& fn : split(o.ium_reads, ',')) {
+                if (fn.empty()) continue;
+                ReadStream rs;
+                if (!rs.open(fn, o.zpacker)) { fprintf(stderr, "Can't open file %s for reading, skipping...\n", fn.c_str()); continue; }
+                std::string bases; std::vector<int64_t> off(1, 0);
+                auto push = [&]() {
+                    const int64_t n = (int64_t)off.size() - 1;
+                    if (!n) return;
+                    std::vector<uint64_t> planes((size_t)n * 3); std::vector<uint16_t> lens((size_t)n);
+                    if (thj_reads_pack(n, off.data(), bases.data(), 1, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
+                    {
+                        std::lock_guard<std::mutex> lk(dev_mu);
+                        if (thj_covsearch_add_reads(device_ready(), n, 1, planes.data(), lens.data(), 0)) die("Error: %s\n", thj_last_error());
+                    }
+                    bases.clear(); off.assign(1, 0);
+                };
+                Read rd;
+                while (rs.next_direct(rd)) {
+                    bases.append(rd.seq, 0, rd.seq.size() < 32 ? rd.seq.size() : 32);      // count_read_mers / store_read_mers :425, :520
+                    off.push_back((int64_t)bases.size());
+                    if (off.size() - 1 >= CH) push();
+                }
+                push();
+            }
+        });
     fprintf(stderr, ">> Performing segment-search:\n");
     const uint32_t ORD_END = (1u << 29) - 1;                 // device limit on read ordinals
     if (right.segs.empty()) run_side(device_ready, o, rt, left, nullptr, 1, 0, ORD_END, batch_reads);
@@ -187,36 +219,13 @@ int main(int argc, char** argv) {
     g_timer.lap("device start-up + ingest + pack + upload + launch (both sides at once)");
     int64_t n_cov_juncs = -1;
     if (!o.no_coverage_search) {
-        // ---- coverage search (segment_juncs.cpp:4955-4996): the extension table of the initially unmapped reads
-        // (index_read_mers :548-571 -- the first 32 bases of every read), then the island pairing on the device
+        ium_thread.join();                                   // the unmapped reads went up beside the segment search
         fprintf(stderr, ">> Performing coverage-search:\n");
-        const size_t CH = (size_t)1 << 20;
-        for (auto& fn : split(o.ium_reads, ',')) {
-            if (fn.empty()) continue;
-            ReadStream rs;
-            if (!rs.open(fn, o.zpacker)) { fprintf(stderr, "Can't open file %s for reading, skipping...\n", fn.c_str()); continue; }
-            std::string bases; std::vector<int64_t> off(1, 0);
-            auto push = [&]() {
-                const int64_t n = (int64_t)off.size() - 1;
-                if (!n) return;
-                std::vector<uint64_t> planes((size_t)n * 3); std::vector<uint16_t> lens((size_t)n);
-                if (thj_reads_pack(n, off.data(), bases.data(), 1, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
-                if (thj_covsearch_add_reads(ctx, n, 1, planes.data(), lens.data(), 0)) die("Error: %s\n", thj_last_error());
-                bases.clear(); off.assign(1, 0);
-            };
-            Read rd;
-            while (rs.next_direct(rd)) {
-                bases.append(rd.seq, 0, rd.seq.size() < 32 ? rd.seq.size() : 32);      // count_read_mers / store_read_mers :425, :520
-                off.push_back((int64_t)bases.size());
-                if (off.size() - 1 >= CH) push();
-            }
-            push();
-        }
         int mcl = 20; if (mcl > o.p.segment_length - 2) mcl = o.p.segment_length - 2;          // :62, :5350
         if (thj_covsearch_run_async(ctx, mcl, o.min_coverage_intron, o.max_coverage_intron)) die("Error: %s\n", thj_last_error());
         if (thj_covsearch_finish(ctx, 5000000, &n_cov_juncs)) die("Error: %s\n", thj_last_error());        // max_cov_juncs :56
         fprintf(stderr, "\tfound %d potential junctions\n", (int)n_cov_juncs);
-        g_timer.lap("coverage search (unmapped reads + device)");
+        g_timer.lap("coverage search (wait for the unmapped reads + device pass)");
     }
     thj_segjuncs_counts n{};
     if (thj_segjuncs_finish(ctx, &n)) die("Error: %s\n", thj_last_error());
