@@ -789,9 +789,21 @@ THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
         if (cig_op(last) == cig_op(e.c.v[0])) { o.c.set(o.n - 1, cig(cig_op(last), cig_len(last) + cig_len(e.c.v[0]))); b0 = 1; }
     }
     if (o.n + e.n - b0 > LEAN_C) return 2;
+    // append e's ops b0.. at o.n..: e's array shifted up by k = o.n - b0 slots with a three-stage barrel shifter (one
+    // select per slot and stage), then merged above o.n -- instead of one eight-way select chain per appended op
+    const int k = o.n - b0, end = o.n + e.n - b0;
+    uint32_t t[LEAN_C];
 #pragma unroll
-    for (int b = 0; b < LEAN_C; ++b)
-        if (b >= b0 && b < e.n) o.c.set(o.n++, e.c.v[b]);
+    for (int i = 0; i < LEAN_C; ++i) t[i] = e.c.v[i];
+#pragma unroll
+    for (int sh = 1; sh < LEAN_C; sh <<= 1) {
+        const bool on = (k & sh) != 0;
+#pragma unroll
+        for (int i = LEAN_C - 1; i >= 0; --i) t[i] = on ? (i >= sh ? t[i - sh] : 0u) : t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < LEAN_C; ++i) o.c.v[i] = (i >= o.n && i < end) ? t[i] : o.c.v[i];
+    o.n = end;
     return 0;
 }
 
