@@ -140,3 +140,44 @@ def test_two_shards_merged_on_the_device_equal_one():
     g = orc.Genome(seqs)
     want = _tuples(orc.coverage_search(g, c["hits"], c["ium"], *args))
     assert got == want and found == len(want)
+
+
+def _device_coverage_only(seqs, hits, ium, args, max_cov_juncs=5000000):
+    """coverage search alone on the device: the hits go up as a one-segment batch that is never run through the segment search"""
+    from tophat_amd.batch import SegBatch
+    n = len(hits)
+    b = SegBatch(1, np.arange(1, n + 1, dtype=np.uint32), np.arange(0, n + 1, dtype=np.int64) * 10,
+                 np.frombuffer(b"ACGTACGTAC" * max(1, n), dtype=np.uint8)[:10 * n].copy(), np.arange(0, n + 1, dtype=np.uint32), hits)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        ctx.reset()
+        ctx.covsearch_reset()
+        if n:
+            ctx.covsearch_add_hits(ctx.upload_batch(b))
+        ctx.covsearch_add_reads(ium)
+        ctx.covsearch_run(*args)
+        found = ctx.covsearch_finish(max_cov_juncs)
+        return _tuples(ctx.download(ctx.finish()).juncs), found
+
+
+@pytest.mark.parametrize("seed", range(400, 430))
+def test_hip_coverage_search_edge_cases(seed):
+    from cov_util import edge_case
+    seqs, h, ium, args = edge_case(seed)
+    folded = [orc.fold_genome_char(s) for s in seqs]
+    want = _tuples(orc.coverage_search(orc.Genome(folded), h, ium, *args))
+    got, found = _device_coverage_only(folded, h, ium, args)
+    assert got == want and found == len(want)
+
+
+def test_hip_coverage_search_empty_inputs_and_cap():
+    from cov_util import edge_case
+    seqs, h, ium, args = edge_case(404)
+    folded = [orc.fold_genome_char(s) for s in seqs]
+    assert _device_coverage_only(folded, h[:0], ium, args) == (set(), 0)          # no hits: no islands
+    assert _device_coverage_only(folded, h, [], args) == (set(), 0)               # no unmapped reads: nothing is extendable
+    assert _device_coverage_only(folded, h, ["ACGT", "A" * 9], args) == (set(), 0)   # reads too short for a 10-mer seed
+    c = load("se50_cov")
+    seqs = [orc.fold_genome_char(s) for s in c["seqs"]]
+    with pytest.raises(host.ThjError, match="max_cov_juncs"):                    # the cap fails loudly
+        _device_coverage_only(seqs, c["hits"], c["ium"], (c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"]), max_cov_juncs=5)
