@@ -23,6 +23,9 @@ from tophat_amd.synth import make_case, write_case  # noqa: E402
 REFBIN = os.environ.get("REFBIN", "/tmp/refbuild/src")
 
 CASES = {
+    # reads of a single segment: no segment search at all, the coverage search alone finds the junctions
+    "se30_cov": dict(gen=dict(seed=203, paired=False, read_len=30, seg_len=25, n_reads=900, contig_lens=(30000,), genes_per_contig=10,
+                              spliced_seg_frac=0.0), opts=[]),
     "se50_cov": dict(gen=dict(seed=201, paired=False, read_len=50, seg_len=25, n_reads=900, contig_lens=(40000,), genes_per_contig=10,
                               spliced_seg_frac=0.0), opts=[]),
     "pe50_cov": dict(gen=dict(seed=202, paired=True, read_len=50, seg_len=25, n_reads=700, contig_lens=(30000, 20000), genes_per_contig=8,
@@ -32,7 +35,10 @@ CASES = {
 
 
 def main():
+    only = sys.argv[1:]
     for name, cfg in CASES.items():
+        if only and name not in only:
+            continue
         d = os.path.join(HERE, name)
         if os.path.exists(d):
             shutil.rmtree(d)

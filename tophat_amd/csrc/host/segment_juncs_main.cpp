@@ -31,7 +31,9 @@ static constexpr uint32_t RIGHT_ORDINAL_BASE = 1u << 28;
 static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, RefTable& rt, const SideInput& in, const SideInput* mate, int read_side,
                      uint32_t ordinal, uint32_t ordinal_limit, size_t batch_reads) {
     const int nseg = (int)in.segs.size();
-    if (nseg <= 1) return;                                  // segment_juncs.cpp:4752 (`size() > 1`)
+    // one segment map: no segment search (segment_juncs.cpp:4752 `size() > 1`), but its hits still belong to the coverage
+    // map (all_segmap_fnames :4929-4935)
+    if (nseg < 1 || (nseg == 1 && o.no_coverage_search)) return;
     std::vector<HitStream> st((size_t)nseg);
     for (int s = 0; s < nseg; ++s)
         if (!st[(size_t)s].open(in.segs[(size_t)s], rt, o.p)) die("Error opening SAM file %s\n", in.segs[(size_t)s].c_str());
@@ -72,8 +74,8 @@ static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, Ref
             thj_ctx* ctx = device_ready();
             thj_seg_batch* dev = nullptr;
             if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
-            if (thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
-            if (o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+            if (nseg > 1 && thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+            if (nseg > 1 && o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
             if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
             if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
         }
