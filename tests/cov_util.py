@@ -4,7 +4,7 @@ import re
 
 import numpy as np
 
-from tophat_amd.batch import HIT_DTYPE, build_seg_batch, hit_tuple_to_struct
+from tophat_amd.batch import HIT_DTYPE, build_seg_batch, build_span_batch, hit_tuple_to_struct
 from tophat_amd.params import Params, READ_LEFT, READ_RIGHT
 from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
 
@@ -53,7 +53,20 @@ def load(name):
         for recs in sides[sd]["segs"]:                          # all_segmap_fnames: left maps then right maps (:4929-4935)
             hits += [hit_tuple_to_struct(h) for h in recs]
         ium += [sides[sd]["reads"][rid] for rid in sorted(sides[sd]["reads"])]      # --ium-reads left.fq[,right.fq]
-    return dict(p=p, cov=cov, names=names, seqs=seqs, seg_batches=seg_batches, hits=np.array(hits, dtype=HIT_DTYPE), ium=ium,
+    span_batches, exp_span = {}, {}
+    for sd in sides:                 # long_spanning_reads of the same reads (fixture: the scratch build on expected.juncs etc.)
+        quals = {}
+        with open(os.path.join(d, "%s.fq" % sd)) as f:
+            while True:
+                h = f.readline()
+                if not h:
+                    break
+                f.readline(); f.readline()
+                quals[int(h[1:].split()[0])] = f.readline().strip()
+        span_batches[sd] = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], quals)
+        rows = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
+        exp_span[sd] = [(r[0], int(r[1]), r[2], int(r[3]), r[5]) + r[8:] for r in rows]       # QNAME FLAG RNAME POS CIGAR tags...
+    return dict(p=p, cov=cov, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp_span=exp_span, hits=np.array(hits, dtype=HIT_DTYPE), ium=ium,
                 expected=open(os.path.join(d, "expected.juncs")).read(), expected_seg_only=open(os.path.join(d, "expected.seg_only.juncs")).read(),
                 dir=d, paired=paired, nseg=nseg)
 

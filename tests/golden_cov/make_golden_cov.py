@@ -18,6 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
+from tophat_amd.bamio import read_bam  # noqa: E402
 from tophat_amd.synth import make_case, write_case  # noqa: E402
 
 REFBIN = os.environ.get("REFBIN", "/tmp/refbuild/src")
@@ -57,6 +58,19 @@ def main():
             os.remove(outs[3])
             if tag:
                 os.remove(outs[1]); os.remove(outs[2])
+        # long_spanning_reads on the junctions of the full run (short reads: one or two segments per read)
+        for sd in sides:
+            bam = os.path.join(d, "span_%s.bam" % sd)
+            subprocess.run([os.path.join(REFBIN, "long_spanning_reads"), "--segment-length", str(cfg["gen"]["seg_len"]), "--sam-header", paths["hdr"],
+                            paths["ref"], paths["%s_fq" % sd], os.path.join(d, "expected.juncs"), os.path.join(d, "expected.insertions"),
+                            os.path.join(d, "expected.deletions"), "/dev/null", bam, ",".join(paths["%s_segs" % sd])], check=True, capture_output=True)
+            _, recs = read_bam(bam)
+            with open(os.path.join(d, "expected.span_%s.sam" % sd), "w") as f:
+                for r in recs:
+                    f.write("\t".join(str(x) for x in r) + "\n")
+            os.remove(bam)
+            if os.path.exists(bam + ".index"):
+                os.remove(bam + ".index")
         with open(os.path.join(d, "options.txt"), "w") as f:
             f.write(" ".join(cfg["opts"]) + "\n")
             f.write("segment_length=%d paired=%d\n" % (cfg["gen"]["seg_len"], cfg["gen"]["paired"]))

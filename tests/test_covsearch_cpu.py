@@ -60,3 +60,28 @@ def test_kernel_logic_matches_oracle_on_seeded_cases(seed):
     folded = [orc.fold_genome_char(s) for s in seqs]
     g = orc.Genome(folded)
     assert sim.coverage_search(folded, h, ium, *args) == _tuples(orc.coverage_search(g, h, ium, *args))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_short_read_spanning_fixture(name):
+    """long_spanning_reads on reads of one and two segments (the shapes the coverage search exists for): the oracle and
+    the CPU build of the stitch tiers against the scratch build's records"""
+    import numpy as np
+    import sim
+    from tophat_amd.batch import Events, JUNC_DTYPE, events_to_span_inputs
+    from tophat_amd.params import Params
+    c = load(name)
+    seqs = [orc.fold_genome_char(s) for s in c["seqs"]]
+    g = orc.Genome(seqs)
+    ids = {n: i + 1 for i, n in enumerate(c["names"])}
+    j = [(ids[t[0]], int(t[1]), int(t[2]), 1 if t[3][0] == "-" else 0) for t in (l.split("\t") for l in c["expected"].splitlines())]
+    ev = Events(np.array(j, dtype=JUNC_DTYPE), np.zeros(0, dtype=JUNC_DTYPE), [], {})
+    juncs, ins = events_to_span_inputs(ev)
+    p = Params(segment_length=c["p"].segment_length)
+    for sd, sb in c["span_batches"].items():
+        alns = orc.spanning(p, g, sb, juncs, ins)
+        assert [a.sam_fields(int(sb.read_id[a.read_idx]), c["names"]) for a in alns] == c["exp_span"][sd]
+        for mode in (0, 1, 2):
+            got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)
+            got.sort(key=lambda a: a.read_idx)
+            assert got == alns, "mode %d" % mode

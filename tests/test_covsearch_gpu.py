@@ -103,6 +103,18 @@ def test_segment_juncs_executable_with_coverage_search(name, tmp_path):
     assert "Performing coverage-search" in r.stderr
     for k in ("juncs", "insertions", "deletions"):
         assert open(out[k]).read() == open(os.path.join(d, "expected." + k)).read(), k
+    # long_spanning_reads on the lists just written (reads of one / two segments)
+    from tophat_amd.bamio import read_bam
+    for sd in sides:
+        bam = str(tmp_path / ("span_%s.bam" % sd))
+        r = subprocess.run([os.path.join(root, "tophat_amd", "bin", "long_spanning_reads"), "--segment-length", kv["segment_length"],
+                            "--sam-header", os.path.join(d, "hdr.sam"), os.path.join(d, "ref.fa"), os.path.join(d, "%s.fq" % sd),
+                            out["juncs"], out["insertions"], out["deletions"], "/dev/null", bam,
+                            ",".join(os.path.join(d, "%s_seg%d.sam" % (sd, k + 1)) for k in range(nseg))], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        _, recs = read_bam(bam)
+        want = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
+        assert [tuple(str(x) for x in rec) for rec in recs] == want
     # without unmapped reads the coverage search is skipped (segment_juncs.cpp:4978-4982): the segment search's set
     cmd2 = [c for c in cmd]
     i = cmd2.index("--ium-reads")
