@@ -131,6 +131,10 @@ def main():
     ap.add_argument("--introns", type=int, default=20000)
     ap.add_argument("--exon-len", type=int, default=300)
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE configs[1]: 100; 150 / 50 are the shapes of configs[3] / [4])")
+    ap.add_argument("--coverage-search", type=float, default=0.0, metavar="FRAC",
+                    help="run segment_juncs' coverage search too (what tophat does for reads of fewer than three segments, "
+                         "e.g. --read-len 50), with the first FRAC of each side's reads playing the initially unmapped reads; "
+                         "single GPU only")
     ap.add_argument("--multihit-frac", type=float, default=0.0,
                     help="fraction of reads whose segment hits are all reported at two loci (the genome's second half becomes a copy "
                          "of the first): exercises the multihit tier; 0 = BASELINE configs[1] as specified")
@@ -224,11 +228,25 @@ def main():
         del gathered
         return cnt2
 
+    n_ium = int(args.coverage_search * args.pairs)
+    if n_ium and use_dist:
+        raise SystemExit("--coverage-search is a single-GPU leg of this bench (the exchange step for it: thj_covsearch_device_state / _merge_async)")
+    cov_found = [0]
+
     def step():
         # ---- segment_juncs stage
         ctx.reset()
+        if n_ium:
+            ctx.covsearch_reset()
         ctx.run(p_left, cb_left)
         ctx.run(p_right, cb_right)
+        if n_ium:                                     # coverage search: coverage map of all hits, extension table, island pairing
+            ctx.covsearch_add_hits(cb_left)
+            ctx.covsearch_add_hits(cb_right)
+            for sd in ("left", "right"):
+                ctx.covsearch_add_reads_device(n_ium, w[sd]["W"], w[sd]["planes"].data_ptr(), w[sd]["read_len"].data_ptr())
+            ctx.covsearch_run(min(20, 25 - 2), 50, 20000)
+            cov_found[0] = ctx.covsearch_finish()
         cnt = ctx.finish()
         if use_dist:
             cnt2 = allgather_merge()
@@ -321,9 +339,11 @@ def main():
     workload_text = ("%s: %d x 2x%d bp PE synthetic vs %d bp %s genome per GPU, inputs resident in HBM; both stages on device: "
                      "segment_juncs (main + rescue kernels, event dedup+sort%s) then long_spanning_reads (four stitch tiers fed "
                      "device-to-device with the junction set; records land in BAM order)"
-                     % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 else "shape of another config", args.pairs,
+                     % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not n_ium else "shape of another config", args.pairs,
                         args.read_len, args.genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
                         ", RCCL all-gather of event keys" if use_dist else ""))
+    if n_ium:
+        workload_text += "; with the coverage search (first %d reads of each side as --ium-reads, %d coverage junctions)" % (n_ium, cov_found[0])
     result = None
     if rank == 0:
         cpu = None
