@@ -252,7 +252,12 @@ extern "C" int hostsim_coverage_run(const uint64_t* blocks, const uint32_t* cont
     for (int i = 0; i < 2 * n_contigs; ++i) drop_windows(L, sizes, ll, lr, i);
     for (int64_t w = 0; w < nw; ++w) site_word(g, L, ll, lr, fd, ra, fa, rd, w);
     Collect c;
-    ExtTable et{off.data(), svals.data()};
+    // the Bloom filter over the entries, deliberately small here (2^16 bits) so that false positives happen too
+    const u64 fmask = (1ull << 16) - 1;
+    std::vector<u64> filter((size_t)((fmask + 1) / 64), 0);
+    for (size_t i = 0; i < ord.size(); ++i)
+        if (skeys[i] < N_KEYS) entry_filter_bits(skeys[i], svals[i], fmask, [&](u64 b) { filter[(size_t)(b >> 6)] |= 1ull << (b & 63); });
+    ExtTable et{off.data(), svals.data(), filter.data(), fmask};
     for (int64_t w = 0; w < nw; ++w) pair_word(g, L, et, fd, fa, 0, min_intron, max_intron, w, c);
     for (int64_t w = 0; w < nw; ++w) pair_word(g, L, et, ra, rd, 1, min_intron, max_intron, w, c);
     *n_out = (int64_t)c.juncs.size();

@@ -188,11 +188,32 @@ THJ_HD void key_offset(const uint32_t* sorted_keys, int64_t n, uint32_t* off, ui
     off[k] = (uint32_t)lo;
 }
 
-struct ExtTable { const uint32_t* off; const u64* val; };
+// The table is looked at once per (donor, acceptor) candidate and orientation, and a seed has about a hundred entries at
+// the scale of a whole run (23 per unmapped read over 4^10 seeds); almost every candidate fails.  A one-hash Bloom filter
+// over (seed, the 7 extension bases next to it, side) answers "no" with one probe: only candidates it lets through scan
+// the seed's entries (measured on the config-5 shard: the pairing kernel went from 247 ms to the numbers in DESIGN.md).
+struct ExtTable { const uint32_t* off; const u64* val; const u64* filter; u64 filter_mask; };      // filter_mask = bits - 1; filter may be null
+THJ_HD u64 filter_bit(uint32_t key, uint32_t ext7, int side) {
+    u64 x = ((u64)key << 15) | ((u64)ext7 << 1) | (u64)side;
+    x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return x;
+}
+// the filter bits of one table entry: set(bit index) for its left side (if it has >= 7 bases there) and its right side
+template <class SetFn>
+THJ_HD void entry_filter_bits(uint32_t key, u64 v, u64 filter_mask, SetFn set) {
+    const int ln = (int)((v >> 28) & 15), rl = (int)(v >> 60);
+    if (ln >= 7) set(filter_bit(key, (uint32_t)(v & 0x3FFFull), 0) & filter_mask);                          // the 7 bases before the seed
+    if (rl >= 7) set(filter_bit(key, (uint32_t)(((v >> 32) & 0x0FFFFFFFull) >> (2 * (rl - 7))), 1) & filter_mask);   // the 7 after it
+}
 // extendable_junction (:1520-1566), min_ext_len 7, extension_mismatches 0
 THJ_HD bool extendable(const ExtTable& t, u64 up, u64 down) {
     const uint32_t key = ((uint32_t)(up & 0x3FFull) << 10) | (uint32_t)(down >> 54);
     up >>= 10; down <<= 10;
+    if (t.filter) {
+        const u64 bl = filter_bit(key, (uint32_t)(up & 0x3FFFull), 0) & t.filter_mask, br = filter_bit(key, (uint32_t)(down >> 50), 1) & t.filter_mask;
+        if (!((t.filter[bl >> 6] >> (bl & 63)) & 1ull) && !((t.filter[br >> 6] >> (br & 63)) & 1ull)) return false;
+    }
     for (uint32_t i = t.off[key]; i < t.off[key + 1]; ++i) {
         const u64 v = t.val[i];
         const int ln = (int)((v >> 28) & 15), rl = (int)(v >> 60);

@@ -48,6 +48,15 @@ __global__ void k_ium_entries(const u64* planes, const uint16_t* lens, int64_t n
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r < n_reads) read_entries(planes, lens, W, keys, vals, base, r);
 }
+__global__ void k_ext_filter(const uint32_t* sorted_keys, const u64* sorted_vals, int64_t n, u64* filter, u64 filter_mask) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t key = sorted_keys[i];
+        if (key >= N_KEYS) continue;                  // slots of reads too short for a seed
+        entry_filter_bits(key, sorted_vals[i], filter_mask, [&](u64 b) {
+            if (!((filter[b >> 6] >> (b & 63)) & 1ull)) atomicOr((unsigned long long*)&filter[b >> 6], 1ull << (b & 63));
+        });
+    }
+}
 __global__ void k_key_offsets(const uint32_t* sorted_keys, int64_t n, uint32_t* off) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k <= N_KEYS) key_offset(sorted_keys, n, off, k);
@@ -237,7 +246,18 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
     hipLaunchKernelGGL(cov_k::k_sites, dim3(gw), dim3(256), 0, c->stream, g, L, ll, lr, fd, ra, fa, rd);
     Tables t{c->d_junc, (u64)c->junc_cap - 1, c->d_del, (u64)c->indel_cap - 1, c->d_ins_key, c->d_ins_val,
              (u64)c->indel_cap - 1, junc_list(c), del_list(c), ins_list(c), c->d_ovf, c->d_cnt};
-    thj::cov::ExtTable et{c->d_ext_off, vals};
+    // Bloom filter over the entries: 64 bits per entry, a power of two between 2^16 and 2^34 bits
+    u64 fbits = 1ull << 16;
+    while (fbits < (u64)c->n_ext * 64 && fbits < (1ull << 34)) fbits <<= 1;
+    if ((int64_t)(fbits / 8) > c->cov_filter_bytes) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->d_cov_filter); c->d_cov_filter = nullptr;
+        HIPCHK(hipMalloc(&c->d_cov_filter, (size_t)(fbits / 8)));
+        c->cov_filter_bytes = (int64_t)(fbits / 8);
+    }
+    HIPCHK(hipMemsetAsync(c->d_cov_filter, 0, (size_t)(fbits / 8), c->stream));
+    if (c->n_ext) hipLaunchKernelGGL(cov_k::k_ext_filter, dim3(4096), dim3(256), 0, c->stream, keys, vals, c->n_ext, c->d_cov_filter, fbits - 1);
+    thj::cov::ExtTable et{c->d_ext_off, vals, c->d_cov_filter, fbits - 1};
     // left sites -> list (its room: the long_enough bitmap, which nothing reads any more) -> one thread per site
     u64* list = le; const unsigned int list_cap = (unsigned int)(nw < 0xFFFFFFFFll ? nw : 0xFFFFFFFFll);
     unsigned int* n_list = (unsigned int*)(c->d_cov_found + 1);
@@ -267,6 +287,6 @@ extern "C" int thj_covsearch_finish(thj_ctx* c, int64_t max_cov_juncs, int64_t* 
 }
 
 static void cov_free(thj_ctx* c) {
-    hipFree(c->d_cov); hipFree(c->d_cov_size); hipFree(c->d_ext_off); hipFree(c->d_cov_found);
+    hipFree(c->d_cov); hipFree(c->d_cov_size); hipFree(c->d_ext_off); hipFree(c->d_cov_found); hipFree(c->d_cov_filter);
     hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
 }

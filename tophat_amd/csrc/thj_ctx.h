@@ -64,6 +64,7 @@ struct thj_ctx {
     uint32_t* d_ext_key = nullptr; u64* d_ext_val = nullptr; uint32_t* d_ext_key_sorted = nullptr; u64* d_ext_val_sorted = nullptr;
     uint32_t* d_ext_off = nullptr; int64_t n_ext = 0, ext_cap = 0;        // extension table of the unmapped reads
     unsigned long long* d_cov_found = nullptr;
+    u64* d_cov_filter = nullptr; int64_t cov_filter_bytes = 0;          // Bloom filter over the extension table
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
     std::vector<thj_fusion> h_fusions;
