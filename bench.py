@@ -145,13 +145,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # THJ_FORCE_COLLECTIVE=1 exercises the RCCL exchange step even at world size 1 (single-GPU boxes)
+    # THJ_FORCE_COLLECTIVE=1 exercises the RCCL exchange step even at world size 1 (single-GPU boxes).
+    # Functional test of the N > 1 path on a box with one GPU: THJ_BENCH_BACKEND=gloo THJ_BENCH_DEVICE=0 lets several ranks
+    # share device 0 and exchange through gloo (not a measurement: the driver's runs are one rank per GPU over RCCL).
     use_dist = world > 1 or os.environ.get("THJ_FORCE_COLLECTIVE") == "1"
+    backend = os.environ.get("THJ_BENCH_BACKEND", "nccl")
+    if os.environ.get("THJ_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["THJ_BENCH_DEVICE"])
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -193,6 +201,16 @@ def main():
             hip.hipMemcpyAsync(ctypes.c_void_p(dst_tensor.data_ptr()), ctypes.c_void_p(src_ptr), ctypes.c_size_t(nbytes), 3,
                                ctypes.c_void_p(stream.cuda_stream))
 
+    def gather_rows(out2d, row):
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.all_gather_into_tensor(out2d, row)
+        else:                                  # gloo (functional test only): through the host
+            rows = [torch.empty_like(row, device="cpu") for _ in range(world)]
+            dist.all_gather(rows, row.cpu())
+            for k_, r_ in enumerate(rows):
+                out2d[k_].copy_(r_)
+
     def allgather_merge():
         """ONE exchange step: all-gather the sorted per-rank event key sets over RCCL/xGMI and merge them into
         every rank's tables (segment_juncs.cpp:4911-4916 across GPUs)."""
@@ -202,19 +220,21 @@ def main():
         ik, iv, inn = ctx.device_insertions()
         nt = torch.tensor([jn, dn, inn], dtype=torch.int64, device=dev)
         sizes = torch.zeros((world, 3), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(sizes, nt)
+        gather_rows(sizes, nt)
         sizes = sizes.cpu()
         mx = int((sizes[:, 0] + sizes[:, 1] + 2 * sizes[:, 2]).max())
         if mx == 0:
             return ctx.finish()
-        mine = torch.zeros(mx, dtype=torch.int64, device=dev)
+        # torch.empty, not zeros: a fill kernel would run on torch's current stream, unordered against the copies below
+        # on the context's stream (found by the two-rank functional test: keys of the row were zeroed after the copy)
+        mine = torch.empty(mx, dtype=torch.int64, device=dev)
         d2d(mine[0:], jp, jn * 8)
         d2d(mine[jn:], dp, dn * 8)
         d2d(mine[jn + dn:], ik, inn * 8)
         d2d(mine[jn + dn + inn:], iv, inn * 8)
         stream.synchronize()
         gathered = torch.empty((world, mx), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(gathered, mine)
+        gather_rows(gathered, mine)
         torch.cuda.synchronize()
         for r_ in range(world):
             if r_ == rank:
@@ -232,6 +252,7 @@ def main():
     if n_ium and use_dist:
         raise SystemExit("--coverage-search is a single-GPU leg of this bench (the exchange step for it: thj_covsearch_device_state / _merge_async)")
     cov_found = [0]
+    local_juncs = [0]                                 # this rank's junction count before the exchange step (THJ_BENCH_VERIFY)
 
     def step():
         # ---- segment_juncs stage
@@ -249,6 +270,7 @@ def main():
             cov_found[0] = ctx.covsearch_finish()
         cnt = ctx.finish()
         if use_dist:
+            local_juncs[0] = cnt.n_juncs
             cnt2 = allgather_merge()
             cnt.n_juncs, cnt.n_deletions, cnt.n_insertions = cnt2.n_juncs, cnt2.n_deletions, cnt2.n_insertions
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
@@ -277,6 +299,23 @@ def main():
     elapsed = time.time() - t0
     kern_ms, launches = ctx.profile(False)
     span_ms, span_launches = ctx.profile_span(False)
+    if use_dist and os.environ.get("THJ_BENCH_VERIFY") == "1":
+        # functional check of the exchange step: every rank must hold the same merged junction set, no smaller than its own
+        jp, jn = ctx.device_keys(0)
+        keys = torch.empty(max(1, jn), dtype=torch.int64, device=dev)      # empty: see allgather_merge
+        torch.cuda.synchronize()
+        d2d(keys, jp, jn * 8)
+        stream.synchronize()
+        keys = keys[:jn]
+        h = torch.tensor([jn, int(keys.sum().item()) & ((1 << 62) - 1), int((keys ^ (keys >> 7)).sum().item()) & ((1 << 62) - 1)],
+                         dtype=torch.int64, device=dev)
+        allh = torch.zeros((world, 3), dtype=torch.int64, device=dev)
+        gather_rows(allh, h)
+        same = bool((allh == allh[0]).all().item()) and jn >= local_juncs[0]
+        print("[verify] rank %d: %d junctions after the exchange step (%d before), sets %s across %d ranks" % (
+            rank, jn, local_juncs[0], "identical" if same else "DIFFER", world), file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit(3)
     if use_dist:
         import torch.distributed as dist
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
