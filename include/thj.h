@@ -335,9 +335,10 @@ int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[4]*/, int64_t* 
  * Call order inside one segment_juncs pass: thj_covsearch_reset_async; thj_covsearch_add_hits_async for every uploaded
  * batch of both sides (the segment maps `all_segmap_fnames`, :4929-4935); thj_covsearch_add_reads for the initially
  * unmapped reads (--ium-reads; planes in the thj_reads_pack layout and lengths, host buffers or -- on_device != 0 -- device
- * buffers; only the first 32 bases of a read are used, :425); thj_covsearch_run_async inserts the junctions it finds into the pass's junction set,
- * so it goes before thj_segjuncs_finish; thj_covsearch_finish returns their number and fails with THJ_EOVERFLOW when it
- * exceeds max_cov_juncs (:56 -- the reference then keeps the lowest skip counts, which this path does not restate). */
+ * buffers; only the first 32 bases of a read are used, :425); thj_covsearch_run_async finds the junctions; thj_covsearch_finish adds them to
+ * the pass's junction set -- all of them, or, when there are more than max_cov_juncs (:56), the max_cov_juncs smallest by
+ * (skip count, junction) as the reference's capped set keeps them (:1611-1621) -- and returns how many; it goes before
+ * thj_segjuncs_finish. */
 int thj_covsearch_reset_async(thj_ctx* ctx);
 int thj_covsearch_add_hits_async(thj_ctx* ctx, const thj_seg_batch* device_batch);
 int thj_covsearch_add_reads(thj_ctx* ctx, int64_t n_reads, int32_t words_per_plane, const uint64_t* planes, const uint16_t* lens,

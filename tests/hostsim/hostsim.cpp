@@ -16,6 +16,8 @@ struct Collect {
     struct Ins { uint32_t ref, left; int len; uint32_t seq; u64 prio; };
     std::vector<Ins> ins;
     void junction(uint32_t ref, uint32_t l, uint32_t r, bool a) { juncs.push_back({ref, l, r, a ? 1u : 0u}); }
+    std::vector<std::pair<uint32_t, thj_junction>> cov;      // (skip count, junction) of the coverage search
+    void cov_junction(uint32_t ref, uint32_t l, uint32_t r, bool a, uint32_t skip) { cov.push_back({skip, {ref, l, r, a ? 1u : 0u}}); }
     void deletion(uint32_t ref, uint32_t l, uint32_t r) { dels.push_back({ref, l, r, 0u}); }
     void insertion(uint32_t ref, uint32_t l, int len, uint32_t seq, u64 prio) { ins.push_back({ref, l, len, seq, prio}); }
 };
@@ -232,7 +234,7 @@ extern "C" int hostsim_coverage_state(const uint32_t* contig_blk, const int32_t*
 // concatenation of the entries -- done by the caller -- then thj_covsearch_run_async's kernels as loops.
 extern "C" int hostsim_coverage_run(const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
                                     int64_t n_blocks, const uint64_t* bits, const int32_t* sizes, const uint32_t* keys, const uint64_t* vals, int64_t n_ext,
-                                    int32_t min_cov_length, int32_t min_intron, int32_t max_intron, thj_junction** out, int64_t* n_out) {
+                                    int32_t min_cov_length, int32_t min_intron, int32_t max_intron, int64_t max_juncs, thj_junction** out, int64_t* n_out) {
     using namespace thj::cov;
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Layout L{contig_blk, contig_len, n_contigs, n_blocks};
@@ -260,9 +262,21 @@ extern "C" int hostsim_coverage_run(const uint64_t* blocks, const uint32_t* cont
     ExtTable et{off.data(), svals.data(), filter.data(), fmask};
     for (int64_t w = 0; w < nw; ++w) pair_word(g, L, et, fd, fa, 0, min_intron, max_intron, w, c);
     for (int64_t w = 0; w < nw; ++w) pair_word(g, L, et, ra, rd, 1, min_intron, max_intron, w, c);
-    *n_out = (int64_t)c.juncs.size();
-    *out = (thj_junction*)malloc(sizeof(thj_junction) * (c.juncs.size() + 1));
-    memcpy(*out, c.juncs.data(), sizeof(thj_junction) * c.juncs.size());
+    // the max_cov_juncs cut as thj_covsearch_finish makes it: the smallest max_juncs by (skip count, junction)
+    auto jl = [](const thj_junction& a, const thj_junction& b) {
+        if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+        if (a.left != b.left) return a.left < b.left;
+        if (a.right != b.right) return a.right < b.right;
+        return a.antisense < b.antisense;
+    };
+    std::sort(c.cov.begin(), c.cov.end(), [&](const std::pair<uint32_t, thj_junction>& a, const std::pair<uint32_t, thj_junction>& b) {
+        if (a.first != b.first) return a.first < b.first;
+        return jl(a.second, b.second);
+    });
+    if ((int64_t)c.cov.size() > max_juncs) c.cov.resize((size_t)max_juncs);
+    *n_out = (int64_t)c.cov.size();
+    *out = (thj_junction*)malloc(sizeof(thj_junction) * (c.cov.size() + 1));
+    for (size_t i = 0; i < c.cov.size(); ++i) (*out)[i] = c.cov[i].second;
     return 0;
 }
 
@@ -270,12 +284,12 @@ extern "C" int hostsim_coverage_run(const uint64_t* blocks, const uint32_t* cont
 extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
                                        int64_t n_blocks, const thj_hit* hits, int64_t n_hits,
                                        const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
-                                       int32_t min_cov_length, int32_t min_intron, int32_t max_intron,
+                                       int32_t min_cov_length, int32_t min_intron, int32_t max_intron, int64_t max_juncs,
                                        thj_junction** out, int64_t* n_out) {
     std::vector<uint64_t> bits((size_t)n_blocks, 0), vals((size_t)n_ium * 23 + 1);
     std::vector<int32_t> sizes((size_t)n_contigs + 1, 0);
     std::vector<uint32_t> keys((size_t)n_ium * 23 + 1);
     hostsim_coverage_state(contig_blk, contig_len, n_contigs, n_blocks, hits, n_hits, ium_planes, ium_lens, n_ium, W, bits.data(), sizes.data(), keys.data(), vals.data());
     return hostsim_coverage_run(blocks, contig_blk, contig_len, n_contigs, n_blocks, bits.data(), sizes.data(), keys.data(), vals.data(), n_ium * 23,
-                                min_cov_length, min_intron, max_intron, out, n_out);
+                                min_cov_length, min_intron, max_intron, max_juncs, out, n_out);
 }

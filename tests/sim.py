@@ -151,7 +151,7 @@ def coverage_state(seqs, hits, ium_reads):
     return bits, sizes, keys[:n * 23], vals[:n * 23]
 
 
-def coverage_run(seqs, states, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
+def coverage_run(seqs, states, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000, max_juncs: int = 5000000):
     """states merged by thj_covsearch_merge_async's rule (OR of the coverage words, max of the sizes, concatenated
     entries), then the pass -> set of (ref_id, left, right, antisense)"""
     l = lib()
@@ -166,13 +166,13 @@ def coverage_run(seqs, states, min_cov_length: int, min_intron: int = 50, max_in
     rc = l.hostsim_coverage_run(C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data), g.n_contigs,
                                 C.c_int64(len(g.blocks) // 4), C.c_void_p(bits.ctypes.data), C.c_void_p(sizes.ctypes.data),
                                 C.c_void_p(keys.ctypes.data), C.c_void_p(vals.ctypes.data), C.c_int64(len(keys)),
-                                min_cov_length, min_intron, max_intron, C.byref(out), C.byref(n_out))
+                                min_cov_length, min_intron, max_intron, C.c_int64(max_juncs), C.byref(out), C.byref(n_out))
     assert rc == 0
     a = np.frombuffer((C.c_char * (max(1, n_out.value) * 16)).from_address(out.value), dtype=JUNC_DTYPE)[:n_out.value].copy()
     l.hostsim_free(out)
     return {(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"])) for j in a}
 
 
-def coverage_search(seqs, hits, ium_reads, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000):
+def coverage_search(seqs, hits, ium_reads, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000, max_juncs: int = 5000000):
     """the coverage-search kernels (thj_cov_core.h) as host loops -> set of (ref_id, left, right, antisense)"""
-    return coverage_run(seqs, [coverage_state(seqs, hits, ium_reads)], min_cov_length, min_intron, max_intron)
+    return coverage_run(seqs, [coverage_state(seqs, hits, ium_reads)], min_cov_length, min_intron, max_intron, max_juncs)

@@ -85,3 +85,17 @@ def test_oracle_reproduces_short_read_spanning_fixture(name):
             got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)
             got.sort(key=lambda a: a.read_idx)
             assert got == alns, "mode %d" % mode
+
+
+@pytest.mark.parametrize("cap", [1, 3, 7, 15])
+def test_kernel_logic_cap_matches_oracle(cap):
+    """max_cov_juncs: the kernel logic's skip counts and cut (smallest by (skip count, junction)) == the oracle's"""
+    import sim
+    for name in CASES:
+        c = load(name)
+        seqs = [orc.fold_genome_char(s) for s in c["seqs"]]
+        g = orc.Genome(seqs)
+        args = (c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"])
+        want = _tuples(orc.coverage_search(g, c["hits"], c["ium"], *args, max_juncs=cap))
+        assert len(want) == cap
+        assert sim.coverage_search(seqs, c["hits"], c["ium"], *args, max_juncs=cap) == want

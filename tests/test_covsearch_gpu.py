@@ -190,7 +190,13 @@ def test_hip_coverage_search_empty_inputs_and_cap():
     assert _device_coverage_only(folded, h[:0], ium, args) == (set(), 0)          # no hits: no islands
     assert _device_coverage_only(folded, h, [], args) == (set(), 0)               # no unmapped reads: nothing is extendable
     assert _device_coverage_only(folded, h, ["ACGT", "A" * 9], args) == (set(), 0)   # reads too short for a 10-mer seed
-    c = load("se50_cov")
-    seqs = [orc.fold_genome_char(s) for s in c["seqs"]]
-    with pytest.raises(host.ThjError, match="max_cov_juncs"):                    # the cap fails loudly
-        _device_coverage_only(seqs, c["hits"], c["ium"], (c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"]), max_cov_juncs=5)
+    # the max_cov_juncs cut (segment_juncs.cpp:56, :1611-1621): the smallest by (skip count, junction), as the oracle makes it
+    for name in CASES:
+        c = load(name)
+        seqs = [orc.fold_genome_char(s) for s in c["seqs"]]
+        args = (c["cov"]["min_cov_length"], c["cov"]["min_intron"], c["cov"]["max_intron"])
+        g = orc.Genome(seqs)
+        for cap in (1, 5, 12):
+            want = _tuples(orc.coverage_search(g, c["hits"], c["ium"], *args, max_juncs=cap))
+            got, found = _device_coverage_only(seqs, c["hits"], c["ium"], args, max_cov_juncs=cap)
+            assert got == want and found == cap == len(want)

@@ -234,20 +234,30 @@ THJ_HD u64 rc32(u64 s) {                              // rc_dna_str :650-661: co
 
 // ---- RecordExtendableJuncs::record (:1568-1626) for one left site `lp` of contig k; -> junctions found.
 // The words of the right-site bitmap within reach are shared out over `n_lanes` callers (the 64 lanes of a wave on the
-// device, one caller on the CPU): lane `lane` takes words first + lane, first + lane + n_lanes, ...
-template <class Sink>
+// device, one caller on the CPU): in round i lane `lane` takes word first + i * n_lanes + lane.  Every junction goes to
+// ev.cov_junction(ref, left, right, antisense, skip) with skip = R - curr_R (:1615), the rank of the acceptor among the
+// right sites from lp + min_intron on -- what the max_cov_juncs cut orders by; `scan(v, total)` = exclusive prefix sum of
+// v over the lanes and its total (ranks of the earlier lanes' sites).
+struct OneLane { THJ_HD int operator()(int v, int& total) const { total = v; return 0; } };
+template <class Sink, class Scan = OneLane>
 THJ_HD unsigned int pair_site(const Genome& g, const Layout& L, const ExtTable& et, const u64* right_sites, int antisense,
-                              int min_intron, int max_intron, int k, int64_t lp, Sink& ev, int lane = 0, int n_lanes = 1) {
+                              int min_intron, int max_intron, int k, int64_t lp, Sink& ev, int lane = 0, int n_lanes = 1, Scan scan = Scan()) {
     unsigned int found = 0;
     const int64_t wbase = (int64_t)L.contig_blk[k], wend = (int64_t)L.contig_blk[k + 1], len = L.contig_len[k];
     // attach_upstream_mers (:741-784): (0, 0) when too close to a contig end
     u64 lf = 0, lrv = 0;
     if (lp > 32 && lp < len) { lf = mer32(g, (uint32_t)k + 1, lp - 32); lrv = rc32(lf); }
     const int64_t q0 = lp + min_intron, q1 = lp + max_intron;            // right sites in [q0, q1)
-    for (int64_t rw = wbase + (q0 >> 6) + lane; rw < wend && (rw - wbase) * 64 < q1; rw += n_lanes) {
-        u64 rb = right_sites[rw];
+    int64_t w_end = wbase + ((q1 + 63) >> 6);                             // words with a position below q1
+    if (w_end > wend) w_end = wend;
+    uint32_t base = 0;                                                    // right sites in [q0, ..) seen in earlier rounds
+    for (int64_t w0 = wbase + (q0 >> 6); w0 < w_end; w0 += n_lanes) {     // the same trip count for every lane
+        const int64_t rw = w0 + lane;
         const int64_t p0 = (rw - wbase) * 64;
-        rb &= ~below_mask(q0 - p0) & below_mask(q1 - p0);
+        u64 rb = rw < w_end ? (right_sites[rw] & ~below_mask(q0 - p0) & below_mask(q1 - p0)) : 0ull;
+        int total = 0;
+        uint32_t rank = base + (uint32_t)scan(__builtin_popcountll(rb), total);
+        base += (uint32_t)total;
         while (rb) {
             const int c = __builtin_ctzll(rb);
             rb &= rb - 1;
@@ -255,9 +265,10 @@ THJ_HD unsigned int pair_site(const Genome& g, const Layout& L, const ExtTable& 
             u64 rf = 0, rrv = 0;                                          // attach_downstream_mers (:786-832)
             if (rp + 2 + 32 < len) { rf = mer32(g, (uint32_t)k + 1, rp + 2); rrv = rc32(rf); }
             if (extendable(et, lf, rf) || extendable(et, rrv, lrv)) {
-                ev.junction((uint32_t)k + 1, (uint32_t)(lp - 1), (uint32_t)(rp + 2), antisense != 0);
+                ev.cov_junction((uint32_t)k + 1, (uint32_t)(lp - 1), (uint32_t)(rp + 2), antisense != 0, rank);
                 ++found;
             }
+            ++rank;
         }
     }
     return found;

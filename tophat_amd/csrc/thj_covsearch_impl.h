@@ -82,19 +82,36 @@ __global__ void k_list_sites(Layout L, const u64* fd, const u64* ra, u64* list, 
     }
 }
 // one wave per listed left site: its 64 lanes share out the words of the acceptor bitmap within reach, so the candidate
-// acceptors of a donor are tested side by side
-__global__ __launch_bounds__(256) void k_pair(Genome g, Layout L, Tables t, ExtTable et, const u64* list, const unsigned int* n_list, unsigned int cap,
-                                              const u64* fa, const u64* rd, int min_intron, int max_intron, unsigned long long* n_found) {
+// acceptors of a donor are tested side by side.  Junctions go to a list (packed key, skip count): the max_cov_juncs cut
+// needs all of them before anything enters the junction set (thj_covsearch_finish).
+struct WaveScan {
+    __device__ int operator()(int v, int& total) const {
+        int x = v;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        total = __shfl(x, 63, 64);
+        return x - v;
+    }
+};
+struct ListSink {
+    const Genome& g; u64* keys; uint32_t* skips; unsigned long long* count; unsigned long long cap;
+    __device__ void cov_junction(uint32_t ref, uint32_t l, uint32_t r, bool a, uint32_t skip) {
+        const unsigned long long at = atomicAdd(count, 1ull);
+        if (at < cap) { keys[at] = junc_key(g, ref, l, r, a); skips[at] = skip; }
+    }
+};
+__global__ __launch_bounds__(256) void k_pair(Genome g, Layout L, ExtTable et, const u64* list, const unsigned int* n_list, unsigned int cap,
+                                              const u64* fa, const u64* rd, int min_intron, int max_intron,
+                                              u64* jkeys, uint32_t* jskips, unsigned long long* n_found, unsigned long long jcap) {
     const unsigned int n = *n_list < cap ? *n_list : cap;
     const int lane = threadIdx.x & 63;
-    unsigned int f = 0;
-    EventSink ev{g, t};
+    ListSink ev{g, jkeys, jskips, n_found, jcap};
     for (unsigned int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < n; i += gridDim.x * 4) {
         const u64 e = list[i];
         const int anti = (int)(e >> 63), k = (int)((e >> 32) & 0x7FFFFFFFull);
-        f += pair_site(g, L, et, anti ? rd : fa, anti, min_intron, max_intron, k, (int64_t)(e & 0xFFFFFFFFull), ev, lane, 64);
+        pair_site(g, L, et, anti ? rd : fa, anti, min_intron, max_intron, k, (int64_t)(e & 0xFFFFFFFFull), ev, lane, 64, WaveScan());
     }
-    if (f) atomicAdd(n_found, (unsigned long long)f);
 }
 
 }  // namespace cov_k
@@ -181,6 +198,27 @@ extern "C" int thj_covsearch_add_reads(thj_ctx* c, int64_t n_reads, int32_t word
     return THJ_OK;
 }
 
+// the pairing pass over the listed left sites into the (key, skip) list; rerun by thj_covsearch_finish when the list was
+// too small (it inserts nothing, so a rerun is harmless)
+static int cov_launch_pair(thj_ctx* c) {
+    if (!c->d_cov_jkey) {
+        c->cov_jcap = 1 << 20;
+        HIPCHK(hipMalloc(&c->d_cov_jkey, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip, (size_t)c->cov_jcap * 4));
+        HIPCHK(hipMalloc(&c->d_cov_jkey2, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip2, (size_t)c->cov_jcap * 4));
+    }
+    const int64_t nw = c->n_blocks;
+    thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, nw};
+    u64 *le = c->d_cov + nw, *fa = c->d_cov + 6 * nw, *rd = c->d_cov + 7 * nw;
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    thj::cov::ExtTable et{c->d_ext_off, c->n_ext ? c->d_ext_val_sorted : c->d_ext_val, c->d_cov_filter, c->cov_filter_mask};
+    const unsigned int list_cap = (unsigned int)(nw < 0xFFFFFFFFll ? nw : 0xFFFFFFFFll);
+    HIPCHK(hipMemsetAsync(c->d_cov_found, 0, 8, c->stream));
+    hipLaunchKernelGGL(cov_k::k_pair, dim3(2048), dim3(256), 0, c->stream, g, L, et, le, (const unsigned int*)(c->d_cov_found + 1), list_cap, fa, rd,
+                       (int)c->cov_min_intron, (int)c->cov_max_intron, c->d_cov_jkey, c->d_cov_jskip, c->d_cov_found, (unsigned long long)c->cov_jcap);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
 // ---- multi-GPU (reads sharded over ranks): the coverage map is the OR of the ranks' maps, the extension table the
 // concatenation of their entries.  A rank exposes its state, the caller moves it (RCCL all-gather), and every rank
 // folds the others' in before thj_covsearch_run_async; the pairing is then the same on every rank.
@@ -244,8 +282,6 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
     hipLaunchKernelGGL(cov_k::k_drop_windows, dim3((unsigned)((2 * c->n_contigs + 63) / 64)), dim3(64), 0, c->stream, L, c->d_cov_size, ll, lr);
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     hipLaunchKernelGGL(cov_k::k_sites, dim3(gw), dim3(256), 0, c->stream, g, L, ll, lr, fd, ra, fa, rd);
-    Tables t{c->d_junc, (u64)c->junc_cap - 1, c->d_del, (u64)c->indel_cap - 1, c->d_ins_key, c->d_ins_val,
-             (u64)c->indel_cap - 1, junc_list(c), del_list(c), ins_list(c), c->d_ovf, c->d_cnt};
     // Bloom filter over the entries: 64 bits per entry, a power of two between 2^16 and 2^34 bits
     u64 fbits = 1ull << 16;
     while (fbits < (u64)c->n_ext * 64 && fbits < (1ull << 34)) fbits <<= 1;
@@ -257,36 +293,62 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
     }
     HIPCHK(hipMemsetAsync(c->d_cov_filter, 0, (size_t)(fbits / 8), c->stream));
     if (c->n_ext) hipLaunchKernelGGL(cov_k::k_ext_filter, dim3(4096), dim3(256), 0, c->stream, keys, vals, c->n_ext, c->d_cov_filter, fbits - 1);
-    thj::cov::ExtTable et{c->d_ext_off, vals, c->d_cov_filter, fbits - 1};
-    // left sites -> list (its room: the long_enough bitmap, which nothing reads any more) -> one thread per site
-    u64* list = le; const unsigned int list_cap = (unsigned int)(nw < 0xFFFFFFFFll ? nw : 0xFFFFFFFFll);
+    // left sites -> list (its room: the long_enough bitmap, which nothing reads any more) -> one wave per site
     unsigned int* n_list = (unsigned int*)(c->d_cov_found + 1);
     HIPCHK(hipMemsetAsync(n_list, 0, 4, c->stream));
-    hipLaunchKernelGGL(cov_k::k_list_sites, dim3(gw), dim3(256), 0, c->stream, L, fd, ra, list, n_list, list_cap);
-    hipLaunchKernelGGL(cov_k::k_pair, dim3(2048), dim3(256), 0, c->stream, g, L, t, et, list, n_list, list_cap, fa, rd,
-                       (int)min_intron, (int)max_intron, c->d_cov_found);
+    const unsigned int list_cap = (unsigned int)(nw < 0xFFFFFFFFll ? nw : 0xFFFFFFFFll);
+    hipLaunchKernelGGL(cov_k::k_list_sites, dim3(gw), dim3(256), 0, c->stream, L, fd, ra, le, n_list, list_cap);
+    c->cov_filter_mask = fbits - 1; c->cov_min_intron = min_intron; c->cov_max_intron = max_intron; c->cov_pending = true;
+    if ((rc = cov_launch_pair(c))) return rc;
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
 
 extern "C" int thj_covsearch_finish(thj_ctx* c, int64_t max_cov_juncs, int64_t* n_found) {
-    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    // The junctions of the pairing pass enter the pass's junction set here.  When there are more than max_cov_juncs
+    // (segment_juncs.cpp:56, :1611-1621) the set ordered by skip count keeps its smallest elements: sort by (skip count,
+    // junction) and take the first max_cov_juncs.
+    if (!c || max_cov_juncs < 0) { thj_set_error("thj_covsearch_finish: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     int rc = cov_ensure(c);
     if (rc) return rc;
+    if (n_found) *n_found = 0;
+    if (!c->cov_pending) return THJ_OK;
     unsigned long long n = 0;
-    HIPCHK(hipMemcpyAsync(&n, c->d_cov_found, 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (n_found) *n_found = (int64_t)n;
-    if ((int64_t)n > max_cov_juncs) {
-        thj_set_error("coverage search found %lld junctions, more than max_cov_juncs = %lld (the reference's lowest-skip-count cut is not restated on the device)",
-                      (long long)n, (long long)max_cov_juncs);
-        return THJ_EOVERFLOW;
+    for (;;) {
+        HIPCHK(hipMemcpyAsync(&n, c->d_cov_found, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if ((int64_t)n <= c->cov_jcap) break;
+        hipFree(c->d_cov_jkey); hipFree(c->d_cov_jskip); hipFree(c->d_cov_jkey2); hipFree(c->d_cov_jskip2);
+        c->cov_jcap = (int64_t)n + (int64_t)n / 8 + 1024;
+        HIPCHK(hipMalloc(&c->d_cov_jkey, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip, (size_t)c->cov_jcap * 4));
+        HIPCHK(hipMalloc(&c->d_cov_jkey2, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip2, (size_t)c->cov_jcap * 4));
+        if ((rc = cov_launch_pair(c))) return rc;
     }
+    c->cov_pending = false;
+    const u64* keys = c->d_cov_jkey;
+    int64_t take = (int64_t)n;
+    if (take > max_cov_juncs) {
+        if (n >= (1ull << 31)) { thj_set_error("more than 2^31 coverage junction candidates"); return THJ_EOVERFLOW; }
+        // stable LSD order: by junction key, then by skip count
+        size_t b1 = 0, b2 = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, b1, c->d_cov_jkey, c->d_cov_jkey2, c->d_cov_jskip, c->d_cov_jskip2, (int)n, 0, 64, c->stream);
+        hipcub::DeviceRadixSort::SortPairs(nullptr, b2, c->d_cov_jskip2, c->d_cov_jskip, c->d_cov_jkey2, c->d_cov_jkey, (int)n, 0, 32, c->stream);
+        const size_t need = b1 > b2 ? b1 : b2;
+        if (need > c->sort_tmp_bytes) { hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+        size_t bytes = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_cov_jkey, c->d_cov_jkey2, c->d_cov_jskip, c->d_cov_jskip2, (int)n, 0, 64, c->stream));
+        bytes = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_cov_jskip2, c->d_cov_jskip, c->d_cov_jkey2, c->d_cov_jkey, (int)n, 0, 32, c->stream));
+        take = max_cov_juncs;
+    }
+    if (n_found) *n_found = take;
+    if (take > 0) return thj_segjuncs_merge_keys_async(c, 0, (const uint64_t*)keys, take);
     return THJ_OK;
 }
 
 static void cov_free(thj_ctx* c) {
     hipFree(c->d_cov); hipFree(c->d_cov_size); hipFree(c->d_ext_off); hipFree(c->d_cov_found); hipFree(c->d_cov_filter);
+    hipFree(c->d_cov_jkey); hipFree(c->d_cov_jskip); hipFree(c->d_cov_jkey2); hipFree(c->d_cov_jskip2);
     hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
 }
