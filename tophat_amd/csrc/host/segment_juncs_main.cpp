@@ -288,5 +288,8 @@ int main(int argc, char** argv) {
     g_timer.lap("teardown");
     g_timer.report();
     (void)CODE;
-    return 0;
+    // Everything is written and closed.  Leave without running the exit handlers: tearing the HIP runtime down after a
+    // context has been used takes ~0.2 s that nobody is waiting for.
+    fflush(nullptr);
+    _exit(0);
 }
