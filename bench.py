@@ -107,7 +107,8 @@ def sample_spanbatch(w, m):
                      np.ascontiguousarray(hits).view(SPAN_HIT_DTYPE).reshape(-1))
 
 
-def span_cbatch_from_tensors(w) -> host.CSpanBatch:
+def span_cbatch_from_tensors(w, ctx=None) -> host.CSpanBatch:
+    """ctx given: also builds the batch's optional dense hit-head array (thj_span_batch.hit_heads), kept in w["span_heads"]"""
     cb = host.CSpanBatch()
     cb.n_reads, cb.nseg, cb.words_per_plane, cb.qual_stride = w["n_reads"], w["nseg"], w["W"], w["qual_stride"]
     cb.seg_off = w["span_off"].data_ptr()
@@ -115,6 +116,13 @@ def span_cbatch_from_tensors(w) -> host.CSpanBatch:
     cb.read_planes = w["planes"].data_ptr()
     cb.read_len = w["read_len"].data_ptr()
     cb.quals = w["quals"].data_ptr()
+    if ctx is not None:
+        n_hits = int(w["span_off"][-1])
+        w["span_heads"] = torch.empty(max(1, n_hits) * 2, dtype=torch.int64, device=w["span_hits"].device)
+        torch.cuda.synchronize()
+        ctx.span_hit_heads(cb.hits, n_hits, w["span_heads"].data_ptr())
+        ctx.sync()
+        cb.hit_heads = w["span_heads"].data_ptr()
     return cb
 
 
@@ -138,6 +146,9 @@ def main():
     ap.add_argument("--multihit-frac", type=float, default=0.0,
                     help="fraction of reads whose segment hits are all reported at two loci (the genome's second half becomes a copy "
                          "of the first): exercises the multihit tier; 0 = BASELINE configs[1] as specified")
+    ap.add_argument("--hit-heads", action="store_true",
+                    help="hand stage 2 the optional dense hit-head array too (built before the timed region: the layout of a "
+                         "producer that writes heads as it goes; NOT the default measurement, see DESIGN.md)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -191,9 +202,10 @@ def main():
     # first-inserted-wins priority of std::set<Insertion>: all left reads (rank order) before all right reads
     cb_left = cbatch_from_tensors(w["left"], rank * args.pairs)
     cb_right = cbatch_from_tensors(w["right"], world * args.pairs + rank * args.pairs)
-    sp_left = span_cbatch_from_tensors(w["left"])
-    sp_right = span_cbatch_from_tensors(w["right"])
     ctx.configure(1 << 22, 1 << 20)
+    use_heads = args.hit_heads
+    sp_left = span_cbatch_from_tensors(w["left"], ctx if use_heads else None)
+    sp_right = span_cbatch_from_tensors(w["right"], ctx if use_heads else None)
     hip = ctypes.cdll.LoadLibrary("libamdhip64.so")
 
     def d2d(dst_tensor, src_ptr, nbytes):
@@ -340,7 +352,8 @@ def main():
     rec_per_read = n_alns / (2.0 * args.pairs)
     per_read_done = rl_bytes + rec_per_read * (128 + 128)
     n_t0 = args.pairs - n_lean - n_multi
-    t0_alg = 4.0 * (args.pairs * nseg + 1) + 32.0 * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
+    hit_b = 16.0 if use_heads else 32.0              # tier 0 streams the dense 16-byte heads when the batch has them
+    t0_alg = 4.0 * (args.pairs * nseg + 1) + hit_b * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
     t1_alg = n_lean * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64) + 4.0 * n_gen
     t3_alg = n_gen * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
@@ -364,7 +377,7 @@ def main():
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
+        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not args.hit_heads and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
             for k in kernels:
                 c = pm["kernels"].get(k["kernel"])
                 if c:
@@ -384,6 +397,8 @@ def main():
                      % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not n_ium else "shape of another config", args.pairs,
                         args.read_len, args.genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
                         ", RCCL all-gather of event keys" if use_dist else ""))
+    if args.hit_heads:
+        workload_text += "; stage 2 batches also carry the optional dense hit-head array (built outside the timed region)"
     if n_ium:
         workload_text += "; with the coverage search (first %d reads of each side as --ium-reads, %d coverage junctions)" % (n_ium, cov_found[0])
     result = None
@@ -425,6 +440,10 @@ def main():
                          "traffic_source": dom.get("traffic_source"), "kernel": dom["kernel"],
                          "avg_kernel_ms": dom["avg_kernel_ms"], "launches": dom["launches"],
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+            # all kernels of a step together: algorithmic bytes of every launch / time spent in them
+            "roofline_all_kernels": {"achieved": sum(k["algorithmic_bytes_per_launch"] * k["launches"] for k in kernels)
+                                     / max(1e-9, sum(k["avg_kernel_ms"] * k["launches"] for k in kernels)) / 1e6,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "kernels": kernels,
             "cpu_baseline": cpu,
             "events": {"junctions": cnt.n_juncs, "deletions": cnt.n_deletions, "insertions": cnt.n_insertions,

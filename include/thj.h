@@ -276,6 +276,10 @@ typedef struct {
     const uint64_t*     read_planes; /* [n_reads*3*W] (thj_reads_pack) */
     const uint16_t*     read_len;
     const uint8_t*      quals;       /* phred+33, qual_stride bytes per read */
+    const void*         hit_heads;   /* optional (NULL: not present): the first 16 bytes of every hit record, densely -- all
+                                      * tier 0 reads of a hit.  For producers that can write it as they go; deriving it from
+                                      * `hits` (thj_span_hit_heads_async) costs more than it saves, so thj_span_batch_upload
+                                      * does not make one */
 } thj_span_batch;
 
 /* One output record: the fields print_bamhit + bowtie_sam_extra write
@@ -306,6 +310,8 @@ int thj_span_sets_from_segjuncs(thj_ctx* ctx);
 
 int thj_span_batch_upload(thj_ctx* ctx, const thj_span_batch* host, int64_t n_hits, thj_span_batch** out);
 int thj_span_batch_free(thj_ctx* ctx, thj_span_batch* dev);
+/* d_heads[i] = first 16 bytes of d_hits[i] (device buffers, n_hits * 16 bytes out): the optional hit_heads array of a batch */
+int thj_span_hit_heads_async(thj_ctx* ctx, const thj_span_hit* d_hits, int64_t n_hits, void* d_heads);
 
 int thj_span_reset_async(thj_ctx* ctx);
 /* join_segments_for_read + sort/unique + filters + bowtie_sam_extra for every read of the

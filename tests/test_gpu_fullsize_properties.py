@@ -144,10 +144,10 @@ def test_fullsize_properties(world):
     # shard-merge, stage 2: two half batches concatenate to the same records (read_idx is per batch)
     for sd, hs in (("left", hl), ("right", hr)):
         ctx.span_reset()
-        ctx.span_run(p2, span_cbatch_from_tensors(hs[0]))
+        ctx.span_run(p2, span_cbatch_from_tensors(hs[0], ctx))   # the halves also carry the optional dense hit-head array
         a0 = ctx.span_download(ctx.span_finish()).copy()
         ctx.span_reset()
-        ctx.span_run(p2, span_cbatch_from_tensors(hs[1]))
+        ctx.span_run(p2, span_cbatch_from_tensors(hs[1], ctx))
         a1 = ctx.span_download(ctx.span_finish()).copy()
         a1["read_idx"] += hs[0]["n_reads"]
         both = np.concatenate([a0, a1])

@@ -810,6 +810,11 @@ THJ_HD int rchain_add(RChainOut& o, const RAln& e) {
 // Hits staged as 16-byte heads -- contig, left, flags, first cigar op: everything a plain-match hit carries -- with the
 // rare longer cigar's tail fetched from global memory on demand.
 struct alignas(16) SpanHitHead { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar0; };
+// the 16-byte head of hit i of the batch: from the dense head array when the batch has one (half the bytes of the 32-byte
+// records, and nothing else in its cache lines), else the first half of the record
+THJ_HD Q16 load_head(const SpanHit* hits, const SpanHitHead* gheads, u64 i) {
+    return gheads ? *(const Q16*)(gheads + i) : *(const Q16*)(hits + i);
+}
 THJ_HD SpanHit staged_hit(const SpanHitHead* heads, const SpanHit* g0, int k) {
     const SpanHitHead hh = heads[k];
     SpanHit h;
@@ -955,7 +960,8 @@ THJ_HD int lean_finish(const Genome& g, const Params& p, const RAln& res, int ns
 // 0.81 ms launch; only a segment hit that is itself spliced has a tail to fetch).
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
-                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, Sink& sink) {
+                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, Sink& sink,
+                          const SpanHitHead* gheads = nullptr) {
     uint32_t sof[MS + 1];
 #pragma unroll
     for (int s = 0; s <= MS; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
@@ -980,7 +986,7 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     {
         Q16 tmp[MS];                            // the heads of the read's (consecutive) hits, all in flight together
 #pragma unroll
-        for (int k = 0; k < MS; ++k) if (k < nsegs) tmp[k] = *(const Q16*)(ghits + sof[0] + k);
+        for (int k = 0; k < MS; ++k) if (k < nsegs) tmp[k] = load_head(ghits, gheads, (u64)sof[0] + k);
 #pragma unroll
         for (int k = 0; k < MS; ++k) if (k < nsegs) ((Q16*)heads)[k] = tmp[k];
     }
@@ -1063,7 +1069,8 @@ template <int N> THJ_HD void rsel_set(int (&a)[N], int i, int x) {
 
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_multi_staged(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
-                                  const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, int caph, Sink& sink) {
+                                  const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, int caph, Sink& sink,
+                                  const SpanHitHead* gheads = nullptr) {
     int off[MS + 1];                          // segment offsets relative to the read's first hit
     {
         uint32_t sof[MS + 1];
@@ -1072,6 +1079,7 @@ THJ_HD int span_read_multi_staged(const Genome& g, const Params& p, const SpanSe
 #pragma unroll
         for (int s = 0; s <= MS; ++s) off[s] = (int)(sof[s] - sof[0]);
         ghits += sof[0];
+        if (gheads) gheads += sof[0];
     }
     if (off[1] == 0) return SPAN_OK;
     int nsegs = 0;
@@ -1085,7 +1093,7 @@ THJ_HD int span_read_multi_staged(const Genome& g, const Params& p, const SpanSe
     for (int b0 = 0; b0 < total; b0 += 8) {           // up to eight 16-byte loads in flight
         Q16 tmp[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (b0 + k < total) tmp[k] = *(const Q16*)(ghits + b0 + k);
+        for (int k = 0; k < 8; ++k) if (b0 + k < total) tmp[k] = load_head(ghits, gheads, (u64)(b0 + k));
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (b0 + k < total) ((Q16*)heads)[b0 + k] = tmp[k];
     }
@@ -1335,7 +1343,8 @@ THJ_HD void contig_offsets(const uint32_t* so, int nseg, uint32_t (&sv)[MS + 1])
 }
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t (&sv)[MS + 1], int nseg,
-                                const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+                                const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink,
+                                const SpanHitHead* gheads = nullptr) {
     // Memory round trips, not arithmetic, bound this tier: the read's planes (when they fit six registers) and the
     // segment offsets are fetched in one go, then every hit head in one go, and only then is anything decided.
     RegRead rw;
@@ -1366,7 +1375,7 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
     SpanHitHead hh[MS];
 #pragma unroll
     for (int s = 0; s < MS; ++s)
-        if (s < nsegs) hh[s] = *(const SpanHitHead*)(hits + sv[0] + s);
+        if (s < nsegs) { const Q16 q = load_head(hits, gheads, (u64)sv[0] + s); hh[s] = SpanHitHead{q.x, (int32_t)q.y, q.z, q.w}; }
     uint32_t last_meta = hh[0].meta;
 #pragma unroll
     for (int s = 1; s < MS; ++s) last_meta = (s == nsegs - 1) ? hh[s].meta : last_meta;

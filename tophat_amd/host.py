@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
     "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_genome_gather", "thj_fusion_finish", "thj_fusion_download",
     "thj_covsearch_reset_async", "thj_covsearch_add_hits_async", "thj_covsearch_add_reads", "thj_covsearch_run_async", "thj_covsearch_finish",
-    "thj_covsearch_device_state", "thj_covsearch_merge_async",
+    "thj_covsearch_device_state", "thj_covsearch_merge_async", "thj_span_hit_heads_async",
 ]
 
 _lib = None
@@ -372,7 +372,7 @@ assert ALN_DTYPE.itemsize == 128
 class CSpanBatch(C.Structure):
     _fields_ = [("n_reads", C.c_int32), ("nseg", C.c_int32), ("words_per_plane", C.c_int32), ("qual_stride", C.c_int32),
                 ("seg_off", C.c_void_p), ("hits", C.c_void_p), ("read_planes", C.c_void_p), ("read_len", C.c_void_p),
-                ("quals", C.c_void_p)]
+                ("quals", C.c_void_p), ("hit_heads", C.c_void_p)]
 
 
 def encode_ins_seq(seq: str) -> int:
@@ -429,6 +429,11 @@ def _span_methods():
     def span_sets_from_segjuncs(self):
         _check(self.lib, self.lib.thj_span_sets_from_segjuncs(self._ctx), "thj_span_sets_from_segjuncs")
 
+    def span_hit_heads(self, d_hits: int, n_hits: int, d_heads: int):
+        """the dense 16-byte head array of device-resident hit records (CSpanBatch.hit_heads)"""
+        _check(self.lib, self.lib.thj_span_hit_heads_async(self._ctx, C.c_void_p(d_hits), C.c_int64(n_hits), C.c_void_p(d_heads)),
+               "thj_span_hit_heads_async")
+
     def upload_span_batch(self, b: SpanBatch):
         d = pack_span_batch(b, self.lib)
         cb = CSpanBatch()
@@ -477,7 +482,7 @@ def _span_methods():
         return [ms[0], ms[1], ms[2], ms[3]], n.value
 
     for f in (upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
-              span_download, spanning, profile_span, span_tier_counts):
+              span_download, spanning, profile_span, span_tier_counts, span_hit_heads):
         setattr(Context, f.__name__, f)
 
 
