@@ -403,6 +403,25 @@ def main():
         workload_text += "; with the coverage search (first %d reads of each side as --ium-reads, %d coverage junctions)" % (n_ium, cov_found[0])
     result = None
     if rank == 0:
+        # what this box's HBM sustains on a plain copy (quote it beside the 8 TB/s spec peak): 2 GiB device-to-device
+        # with torch's copy kernel, bytes = read + written; outside the timed region
+        hbm_copy = None
+        try:
+            src = torch.empty(2 << 30, dtype=torch.uint8, device=dev).random_(0, 255)
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            c0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            c1.record()
+            torch.cuda.synchronize()
+            hbm_copy = 2.0 * src.numel() * 10 / c0.elapsed_time(c1) / 1e6
+            del src, dst
+        except RuntimeError:
+            pass
         cpu = None
         if not args.no_cpu_baseline and world == 1:      # the CPU baseline is timed at N=1 only
             import orc
@@ -439,7 +458,8 @@ def main():
                          "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"), "traffic_low": dom.get("traffic_low"),
                          "traffic_source": dom.get("traffic_source"), "kernel": dom["kernel"],
                          "avg_kernel_ms": dom["avg_kernel_ms"], "launches": dom["launches"],
-                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                         "measured_copy_GBs": hbm_copy, "frac_of_measured_copy": dom["achieved"] / hbm_copy if hbm_copy else None},
             # all kernels of a step together: algorithmic bytes of every launch / time spent in them
             "roofline_all_kernels": {"achieved": sum(k["algorithmic_bytes_per_launch"] * k["launches"] for k in kernels)
                                      / max(1e-9, sum(k["avg_kernel_ms"] * k["launches"] for k in kernels)) / 1e6,
