@@ -183,7 +183,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
         if (mode != 1) {
             st = span_read_contig(g, p, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                   read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
-            if (st == SPAN_NEED_LEAN) {
+            if ((st & 0xFF) == SPAN_NEED_LEAN) {
                 status_counts[4]++;
                 SpanHitHead stage[SPAN_MAXSEG];
                 st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,

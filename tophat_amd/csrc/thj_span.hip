@@ -77,6 +77,10 @@ struct Tiers {
     unsigned int* counters;          // reads handed to [0] tier 1, [1] tier 2, [2] tier 3 (this run)
     int chunk;
 };
+// Tier 1's list is class-major on top of that (SPAN_LEAN_CLASSES x G slices: the reads whose gap lean_join meets in the same
+// loop iteration sit together, so a wave runs the closure code once, not once per gap position); batches of more than
+// four segments per read keep one class -- their kernel has no LDS to spare for the longer offset table.
+__host__ __device__ constexpr int lean_classes(int MS) { return MS <= 4 ? SPAN_LEAN_CLASSES : 1; }
 
 // Tier 0: every read.  Reads made of abutting single plain-match hits (unspliced reads cut into segments) are
 // finished here with a handful of registers.  A block works on 256 consecutive reads at a time: their records are
@@ -96,9 +100,12 @@ template <int MS>
 __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p, DevSpanBatch b, RecSink sink, Tiers t) {
     __shared__ uint4 stage[256 * 8];
     __shared__ uint8_t has_rec[256];
-    __shared__ unsigned int s_cnt[3];          // lean, multihit, records
+    __shared__ unsigned int s_cnt[3];          // (unused), multihit, records
+    __shared__ unsigned int s_lean[SPAN_LEAN_CLASSES];
+    constexpr int NC = lean_classes(MS);
     const int tid = threadIdx.x;
     if (tid < 3) s_cnt[tid] = 0;
+    if (tid < SPAN_LEAN_CLASSES) s_lean[tid] = 0;
     __syncthreads();
     // reads are numbered in 32 bits (n_reads < 2^31 is checked on the host); offsets are one 32x32->64 multiply each
     const uint32_t c0 = blockIdx.x * (uint32_t)t.chunk;
@@ -122,7 +129,10 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
         if (r < c1) {
             int st = span_read_contig_pre<MS>(g, p, b.hits, sv, b.nseg, b.planes + (u64)r * (uint32_t)(3 * b.W), b.W,
                                           rl, b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss, b.heads);
-            if (st == SPAN_NEED_LEAN) { if (!THJ_EXPF(64)) t.wl_lean[c0 + atomicAdd(&s_cnt[0], 1u)] = r; }
+            if ((st & 0xFF) == SPAN_NEED_LEAN) {
+                const unsigned int cls = NC > 1 ? (unsigned int)(st >> 8) : 0u;
+                t.wl_lean[(u64)(cls * gridDim.x + blockIdx.x) * (uint32_t)t.chunk + atomicAdd(&s_lean[cls], 1u)] = r;
+            }
             else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = r;
             else {
                 sink.nrec[(size_t)sink.base + r] = (uint8_t)ss.emitted;
@@ -143,9 +153,10 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
     if (my_rec) atomicAdd(&s_cnt[2], my_rec);
     __syncthreads();
     if (tid == 0) {
-        t.blk_lean[blockIdx.x] = s_cnt[0];
+        unsigned int n_lean = 0;
+        for (int k = 0; k < NC; ++k) { t.blk_lean[k * gridDim.x + blockIdx.x] = s_lean[k]; n_lean += s_lean[k]; }
         t.blk_multi[blockIdx.x] = s_cnt[1];
-        if (s_cnt[0]) atomicAdd(&t.counters[0], s_cnt[0]);
+        if (n_lean) atomicAdd(&t.counters[0], n_lean);
         if (s_cnt[1]) atomicAdd(&t.counters[1], s_cnt[1]);
         if (s_cnt[2]) atomicAdd(sink.total, (unsigned long long)s_cnt[2]);
     }
@@ -155,9 +166,9 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
 // spliced / multihit reads over the batch: each block scans the (at most 2048) slice lengths into LDS, and entry i
 // of the concatenation is found by a binary search there.
 static constexpr int MAX_SLICES = 1024;
-template <int TPB>
-__device__ unsigned int slice_offsets(const unsigned int* blk_cnt, int G, unsigned int* s_off /* [MAX_SLICES + 1] */) {
-    constexpr int IPT = MAX_SLICES / TPB;
+template <int TPB, int NS = MAX_SLICES>
+__device__ unsigned int slice_offsets(const unsigned int* blk_cnt, int G, unsigned int* s_off /* [NS + 1] */) {
+    constexpr int IPT = NS / TPB;
     typedef hipcub::BlockScan<unsigned int, TPB> Scan;
     __shared__ typename Scan::TempStorage tmp;
     const int tid = threadIdx.x;
@@ -167,7 +178,7 @@ __device__ unsigned int slice_offsets(const unsigned int* blk_cnt, int G, unsign
     Scan(tmp).ExclusiveSum(sum, excl, total);
 #pragma unroll
     for (int k = 0; k < IPT; ++k) { s_off[tid * IPT + k] = excl; excl += v[k]; }
-    if (tid == 0) s_off[MAX_SLICES] = total;
+    if (tid == 0) s_off[NS] = total;
     __syncthreads();
     return total;
 }
@@ -181,17 +192,19 @@ __device__ __forceinline__ int slice_of(const unsigned int* s_off, int G, unsign
 template <int MS>
 __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
     extern __shared__ uint4 lds_stage[];          // nseg hit heads per thread
-    __shared__ unsigned int s_off[MAX_SLICES + 1];
+    constexpr int NC = lean_classes(MS);
+    __shared__ unsigned int s_off[NC * MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
     SpanHitHead* stage = (SpanHitHead*)lds_stage + (size_t)threadIdx.x * b.nseg;
-    const unsigned int total = slice_offsets<256>(t.blk_lean, G, s_off);
+    const unsigned int total = slice_offsets<256, NC * MAX_SLICES>(t.blk_lean, NC * G, s_off);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int sl = slice_of(s_off, G, i);
+        int sl = slice_of(s_off, NC * G, i);
         const int r = (int)t.wl_lean[(int64_t)sl * t.chunk + (i - s_off[sl])];
         int st = span_read_lean<MS>(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, stage, sink);
         if (st == SPAN_NEED_GENERIC) {          // rare: more cigar ops than the registers hold
+            sl %= G;                            // the slice of the block of tier 0 that owns the read
             t.wl_multi[(int64_t)sl * t.chunk + atomicAdd(&t.blk_multi[sl], 1u)] = (uint32_t)r;
             atomicAdd(&t.counters[1], 1u);
         } else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
@@ -522,7 +535,8 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     int64_t chunk = ((int64_t)b.n_reads + G - 1) / G;
     chunk = (chunk + 255) / 256 * 256;
     G = ((int64_t)b.n_reads + chunk - 1) / chunk;
-    const int64_t wl_need = 3 * G * chunk + 3 * MAX_SLICES;
+    const int NC = SPAN_LEAN_CLASSES;
+    const int64_t wl_need = (2 + NC) * G * chunk + (2 + NC) * MAX_SLICES;
     if (c->worklist_cap < wl_need) {
         hipFree(c->d_worklist); c->d_worklist = nullptr;
         HIPCHK(hipMalloc(&c->d_worklist, (size_t)wl_need * 4));
@@ -530,10 +544,10 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     }
     Tiers t;
     t.wl_lean = c->d_worklist;
-    t.wl_multi = c->d_worklist + G * chunk;
-    t.wl_gen = c->d_worklist + 2 * G * chunk;
-    t.blk_lean = c->d_worklist + 3 * G * chunk;
-    t.blk_multi = t.blk_lean + MAX_SLICES;
+    t.wl_multi = c->d_worklist + NC * G * chunk;
+    t.wl_gen = t.wl_multi + G * chunk;
+    t.blk_lean = t.wl_gen + G * chunk;
+    t.blk_multi = t.blk_lean + NC * MAX_SLICES;
     t.blk_gen = t.blk_multi + MAX_SLICES;
     t.counters = &c->d_span_status[4];
     t.chunk = (int)chunk;

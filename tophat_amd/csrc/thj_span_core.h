@@ -1224,7 +1224,7 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
 // (an unspliced read cut into segments: ~60 % of real data).  merge_chain leaves every pair untouched
 // (dist == 0, :1591), the final concatenation (:1888-1944) fuses the MATCH ops into one, so the joined hit is
 // {leftmost left, [len M], sum of mismatches}.  Returns SPAN_NEED_LEAN when the read is not of that shape.
-enum { SPAN_NEED_LEAN = 4 };
+enum { SPAN_NEED_LEAN = 4, SPAN_LEAN_CLASSES = 4 };     // NEED_LEAN carries the read's class in bits 8.. of the status
 
 // ---- tier 0 helpers ------------------------------------------------------------------------------------------
 // Where the read's planes come from: global memory (any W), or registers for reads of up to 128 bases (W <= 2), loaded
@@ -1387,6 +1387,7 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
     int mm = (int)((h0.meta >> 8) & 0xFF);
     int left = h0.left, edge = anti ? h0.left : h0.left + total;       // where the next segment must abut
     bool lean = false;
+    int gap_at = 0;                                   // first segment that does not abut its predecessor (0: none / other reason)
 #pragma unroll
     for (int s = 1; s < MS; ++s) {
         if (s < nsegs) {
@@ -1394,13 +1395,17 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
             const int len = (int)cig_len(h.cigar0);
             lean = lean || (h.meta >> 24) != 1u || cig_op(h.cigar0) != OP_MATCH;
             lean = lean || h.ref_id != h0.ref_id || ((h.meta & SH_ANTI) != 0) != anti;    // lean path decides (no alignment)
+            const bool was = lean;
             if (anti) { lean = lean || h.left + len != edge; edge = h.left; left = h.left; }
             else { lean = lean || h.left != edge; edge = h.left + len; }
+            gap_at = (lean && !was && gap_at == 0) ? s : gap_at;
             total += len;
             mm += (int)((h.meta >> 8) & 0xFF);
         }
     }
-    if (lean) return SPAN_NEED_LEAN;
+    // the class of a handed-down read = the step of lean_join's chain loop that will meet its (first) gap: tier 1 walks its
+    // work list class by class, so that the lanes of a wave run the closure code in the same iteration
+    if (lean) return SPAN_NEED_LEAN | ((gap_at ? (anti ? nsegs - gap_at : gap_at) & (SPAN_LEAN_CLASSES - 1) : 0) << 8);
     if (THJ_EXPF(16)) return SPAN_OK;
     const int mm8 = mm & 0xFF;                       // BowtieHit keeps mismatches / edit_dist in unsigned chars
     if (mm8 > p.read_mismatches || mm8 > p.read_edit_dist) return SPAN_OK;          // :2810-2813 (gap length 0)
