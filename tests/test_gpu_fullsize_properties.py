@@ -8,14 +8,15 @@
 * sortedness / structure: keys strictly increasing; records ordered by (read, rank), every CIGAR spans the read,
   NM/XM bookkeeping consistent; planted junctions recovered.
 """
-import ctypes
+
+import os
 
 import numpy as np
 import pytest
 import torch
 
 import orc
-from bench import CHR20_LEN, cbatch_from_tensors, sample_segbatch, sample_spanbatch, span_cbatch_from_tensors
+from bench import CHR20_LEN, GRCH38_LENS, cbatch_from_tensors, sample_segbatch, sample_spanbatch, span_cbatch_from_tensors
 from tophat_amd import host
 from tophat_amd.batch import events_to_span_inputs, merge_events
 from tophat_amd.params import Params, READ_LEFT, READ_RIGHT
@@ -26,6 +27,10 @@ pytestmark = pytest.mark.gpu
 # segments, 150 bp = 6 segments -> the 8-segment kernel variants, 50 bp = 2 segments) at a few million pairs
 # ... and configs[1]'s shape with 15 % multihit reads (the second half of the genome a copy of the first: tiers 2 / 3)
 SHAPES = [(100, 10_000_000, 0.0), (150, 2_000_000, 0.0), (50, 4_000_000, 0.0), (76, 2_000_000, 0.0), (100, 3_000_000, 0.15)]
+# ... and config 3's genome (25 contigs with the GRCh38 lengths, 3.09 Gb: block indices past 2^31 bases, contig boundaries,
+# ref ids > 1); THJ_FULLSIZE_GRCH38=0 skips it (it needs ~10 GB of host memory for the genome text and the oracle's copy)
+if os.environ.get("THJ_FULLSIZE_GRCH38", "1") == "1":
+    SHAPES.append((100, 4_000_000, 0.0, "grch38"))
 
 
 def half(w, which):
@@ -48,11 +53,15 @@ def half(w, which):
     return out
 
 
-@pytest.fixture(scope="module", params=SHAPES, ids=lambda s: "%dbp_%dMpairs%s" % (s[0], s[1] // 1_000_000, "_multihit" if s[2] else ""))
+@pytest.fixture(scope="module", params=SHAPES,
+                ids=lambda s: "%dbp_%dMpairs%s%s" % (s[0], s[1] // 1_000_000, "_multihit" if s[2] else "", "_grch38" if len(s) > 3 else ""))
 def world(request):
-    read_len, pairs, multi_frac = request.param
+    read_len, pairs, multi_frac = request.param[:3]
     dev = torch.device("cuda", 0)
-    seqs, genes = make_scale_genome(1, [CHR20_LEN], 20000, exon_len=300)
+    if len(request.param) > 3:
+        seqs, genes = make_scale_genome(1, GRCH38_LENS, 300000, exon_len=300)
+    else:
+        seqs, genes = make_scale_genome(1, [CHR20_LEN], 20000, exon_len=300)
     dup_shift = 0
     if multi_frac > 0:
         dup_shift = len(seqs[0]) // 2
@@ -91,7 +100,7 @@ def test_fullsize_properties(world):
     keys = [tuple(int(x[k]) for k in ("ref_id", "left", "right", "antisense")) for x in j]
     assert keys == sorted(set(keys))
     # planted introns recovered
-    truth = {(1, int(g[2]) - 1, int(g[3])) for g in genes}
+    truth = {(int(g[0]) + 1, int(g[2]) - 1, int(g[3])) for g in genes}
     found = {(k[0], k[1], k[2]) for k in keys}
     assert len(found & truth) > (0.95 if read_len >= 100 else 0.5) * len(truth)
 
