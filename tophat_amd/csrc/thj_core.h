@@ -487,8 +487,51 @@ THJ_HD bool gaps_prepare(const Params& p, ReadView& v, bool& wants_rescue) {
 // nothing to do.  This is that test, made on a handful of hits before any of the general machinery runs; `true` is a
 // promise that indels_enumerate + gaps_prepare/gaps_enumerate would emit nothing for this read.  (A read without
 // any hit is trivial too.)  Anything else -- and any doubt -- returns false.
+// The same decision for reads of at most NS segments as straight-line code: every test of the loops below becomes one
+// term of `ok` (none of them has a side effect), so a wave runs it once instead of branching out test by test -- on the
+// device the loop form cost 650 scalar instructions per wave of 64 reads, most of the main kernel's issue slots.
+template <int NS>
+THJ_HD bool read_is_trivial_flat(const Params& p, const ReadView& v) {
+    const int nseg = v.nseg;
+    const uint32_t first = v.so[0];
+    if (v.so[nseg] == first) return true;                                     // no hit at all
+    bool single = true;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) single = single && (s >= nseg || v.so[s + 1] - v.so[s] == 1u);
+    if (!single) return false;
+    Hit h[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) if (s < nseg) h[s] = v.hits[first + s];
+    const Hit h0 = h[0];
+    const bool anti = hit_anti(h0);
+    if (nseg == 1) return hit_end(h0) || v.n_mate == 0;
+    const int L = p.segment_length;
+    bool ok = true;
+    Hit prev = h0;
+#pragma unroll
+    for (int s = 1; s < NS; ++s) {
+        if (s < nseg) {
+            const Hit c = h[s];
+            ok = ok && c.ref_id == h0.ref_id && hit_anti(c) == anti;
+            ok = ok && (anti ? c.right == prev.left : prev.right == c.left);
+            if (s + 1 < nseg) {
+                const int start = (s - 1) * L;
+                const int plen = v.rl - start < 2 * L ? v.rl - start : 2 * L;
+                const int apparent = anti ? prev.right - c.left : c.right - prev.left;
+                ok = ok && start <= v.rl && apparent == plen;
+            }
+            prev = c;
+        }
+    }
+    if (!ok) return false;
+    const int dist = anti ? h0.left - prev.right : prev.left - h0.right;
+    if (dist >= p.min_segment_intron && dist < p.max_segment_intron) return true;
+    return v.n_mate == 0;
+}
+
 THJ_HD bool read_is_trivial(const Params& p, const ReadView& v) {
     if (v.nseg < 1) return true;
+    if (v.nseg <= 4) return read_is_trivial_flat<4>(p, v);
     const uint32_t first = v.so[0];
     if (v.so[v.nseg] == first) return true;                                   // no hit at all
     for (int s = 0; s < v.nseg; ++s) if (v.so[s + 1] - v.so[s] != 1u) return false;
