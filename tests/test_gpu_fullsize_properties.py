@@ -27,6 +27,9 @@ pytestmark = pytest.mark.gpu
 # segments, 150 bp = 6 segments -> the 8-segment kernel variants, 50 bp = 2 segments) at a few million pairs
 # ... and configs[1]'s shape with 15 % multihit reads (the second half of the genome a copy of the first: tiers 2 / 3)
 SHAPES = [(100, 10_000_000, 0.0), (150, 2_000_000, 0.0), (50, 4_000_000, 0.0), (76, 2_000_000, 0.0), (100, 3_000_000, 0.15)]
+# THJ_FULLSIZE_PAIRS=N: one extra run of configs[1]'s shape at N pairs (developer runs beyond the default sizes)
+if os.environ.get("THJ_FULLSIZE_PAIRS"):
+    SHAPES.append((100, int(os.environ["THJ_FULLSIZE_PAIRS"]), 0.0))
 # ... and config 3's genome (25 contigs with the GRCh38 lengths, 3.09 Gb: block indices past 2^31 bases, contig boundaries,
 # ref ids > 1); THJ_FULLSIZE_GRCH38=0 skips it (it needs ~10 GB of host memory for the genome text and the oracle's copy)
 if os.environ.get("THJ_FULLSIZE_GRCH38", "1") == "1":
