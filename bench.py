@@ -126,24 +126,97 @@ def span_cbatch_from_tensors(w, ctx=None) -> host.CSpanBatch:
     return cb
 
 
-def main():
+class ProcControl:
+    """control plane of a one-process-per-GPU run: torch.distributed over gloo (TCP on 127.0.0.1) carries the RCCL unique id,
+    the barriers around the timed region and the max-over-ranks of the elapsed time.  The DATA path -- the exchange step --
+    is ncclAllGather called inside libthj_hip.so on each rank's own stream (tophat_amd/csrc/thj_exchange_impl.h)."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        self.dist, self.rank, self.world = dist, rank, world
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    def bcast_bytes(self, b, n):
+        t = torch.zeros(n, dtype=torch.uint8)
+        if self.rank == 0:
+            t = torch.tensor(list(b), dtype=torch.uint8)
+        self.dist.broadcast(t, 0)
+        return bytes(t.tolist())
+
+    def barrier(self):
+        self.dist.barrier()
+
+    def max(self, x):
+        t = torch.tensor([x], dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allgather_ints(self, vals):
+        t = torch.tensor(vals, dtype=torch.int64)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [o.tolist() for o in out]
+
+    def close(self):
+        self.dist.barrier()
+        self.dist.destroy_process_group()
+
+
+class ThreadControl:
+    """the same, for N ranks living in ONE process as threads (functional test of the N > 1 code path on a box with one GPU:
+    the ranks share the device and the exchange step uses the library's loopback transport -- not a measurement)"""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self._bar = threading.Barrier(world)
+        self._slots = [None] * world
+
+    def view(self, rank):
+        v = ThreadControl.__new__(ThreadControl)
+        v.__dict__ = dict(self.__dict__, rank=rank)
+        return v
+
+    def barrier(self):
+        self._bar.wait()
+
+    def max(self, x):
+        return max(self._exchange(x))
+
+    def allgather_ints(self, vals):
+        return self._exchange(list(vals))
+
+    def _exchange(self, x):
+        self._slots[self.rank] = x
+        self._bar.wait()
+        out = list(self._slots)
+        self._bar.wait()
+        return out
+
+    def close(self):
+        pass
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1, help="GPUs of this node to use, one rank (process) each.  Started plainly with N > 1 "
+                    "this script spawns its N ranks itself; under torchrun (WORLD_SIZE set) it is one of them")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (BASELINE config 2: 10 M).  The synthetic generator is validated up to 12.5 M; at 40 M it was "
-                         "seen to plant ~10x fewer reads whose junction falls on a segment boundary (a generator defect, not yet found)")
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (BASELINE config 2: 10 M)")
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
     ap.add_argument("--genome", choices=["chr20", "grch38"], default="chr20",
                     help="chr20: one contig of --genome-len bases (configs[1]); grch38: 25 contigs with the GRCh38 primary-assembly "
                          "lengths, 3.09 Gb (the genome of configs[2]; pass --introns 300000)")
     ap.add_argument("--introns", type=int, default=20000)
+    ap.add_argument("--intron-max", type=int, default=200000, help="longest planted intron (configs[4]: 499999 with --max-intron 500000)")
     ap.add_argument("--exon-len", type=int, default=300)
     ap.add_argument("--read-len", type=int, default=100, help="read length (BASELINE configs[1]: 100; 150 / 50 are the shapes of configs[3] / [4])")
     ap.add_argument("--coverage-search", type=float, default=0.0, metavar="FRAC",
                     help="run segment_juncs' coverage search too (what tophat does for reads of fewer than three segments, "
-                         "e.g. --read-len 50), with the first FRAC of each side's reads playing the initially unmapped reads; "
-                         "single GPU only")
+                         "e.g. --read-len 50), with the first FRAC of each side's reads playing the initially unmapped reads")
     ap.add_argument("--multihit-frac", type=float, default=0.0,
                     help="fraction of reads whose segment hits are all reported at two loci (the genome's second half becomes a copy "
                          "of the first): exercises the multihit tier; 0 = BASELINE configs[1] as specified")
@@ -152,36 +225,95 @@ def main():
                          "producer that writes heads as it goes; NOT the default measurement, see DESIGN.md)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--e2e-pairs", type=int, default=0, help="also run the drop-in executables end to end on files of this many pairs")
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # THJ_FORCE_COLLECTIVE=1 exercises the RCCL exchange step even at world size 1 (single-GPU boxes).
-    # Functional test of the N > 1 path on a box with one GPU: THJ_BENCH_BACKEND=gloo THJ_BENCH_DEVICE=0 lets several ranks
-    # share device 0 and exchange through gloo (not a measurement: the driver's runs are one rank per GPU over RCCL).
-    use_dist = world > 1 or os.environ.get("THJ_FORCE_COLLECTIVE") == "1"
-    backend = os.environ.get("THJ_BENCH_BACKEND", "nccl")
-    if os.environ.get("THJ_BENCH_DEVICE") is not None:
-        local_rank = int(os.environ["THJ_BENCH_DEVICE"])
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU), rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        pr.wait()
+        rc = rc or pr.returncode
+    sys.exit(rc)
+
+
+def main():
+    args = parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if "WORLD_SIZE" in os.environ:                    # one rank of a launched job (torchrun or spawn_ranks)
+        world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+        control = ProcControl(rank, world) if world > 1 else None
+        result = run_rank(args, rank, world, local_rank, control, None)
+        finish_stdout(result if rank == 0 else None)
+        return
+    if args.gpus > 1 and os.environ.get("THJ_BENCH_INPROC") == "1":
+        # functional test on a one-GPU box: N ranks as threads on device 0, loopback exchange
+        import threading
+        tc = ThreadControl(args.gpus)
+        shared = {"ctxs": [None] * args.gpus, "comms": None, "lock": threading.Lock()}
+        results, errs = [None] * args.gpus, []
+
+        def go(r):
+            try:
+                results[r] = run_rank(args, r, args.gpus, int(os.environ.get("THJ_BENCH_DEVICE", "0")), tc.view(r), shared)
+            except BaseException as e:      # noqa: BLE001
+                errs.append(e)
+                tc._bar.abort()
+        th = [threading.Thread(target=go, args=(r,)) for r in range(args.gpus)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        finish_stdout(results[0])
+        return
+    if args.gpus > 1:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--gpus %d asked for, %d visible" % (args.gpus, torch.cuda.device_count()))
+        spawn_ranks(args)
+    result = run_rank(args, 0, 1, 0, None, None)
+    finish_stdout(result)
+
+
+def finish_stdout(result):
+    # The JSON line must be the last thing on stdout: RCCL writes a version banner through C stdio, which sits in libc's
+    # buffer until exit when stdout is a pipe.  Flush that first, print the line, then point fd 1 at /dev/null so that
+    # nothing written later (exit handlers, library destructors) can follow it.  The process still exits normally --
+    # profilers attached to it (rocprofv3) finalise in their exit handlers.
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+    sys.stdout.flush()
+    devnull = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(devnull, 1)
+
+
+def run_rank(args, rank, world, local_rank, control, shared):
+    """one rank = one GPU: workload of --pairs pairs, W + K steps, the exchange step through the C ABI when world > 1"""
+    # THJ_FORCE_COLLECTIVE=1 runs the exchange step through RCCL even at world size 1 (single-GPU boxes).
+    use_comm = world > 1 or os.environ.get("THJ_FORCE_COLLECTIVE") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     # ---- workload: BASELINE.json configs[1] shape (per GPU) --------------------------------
     t_gen = time.time()
     contig_lens = [args.genome_len] if args.genome == "chr20" else GRCH38_LENS
-    args.genome_len = int(sum(contig_lens))
-    seqs, genes = make_scale_genome(1, contig_lens, args.introns, exon_len=args.exon_len)
+    genome_len = int(sum(contig_lens))
+    seqs, genes = make_scale_genome(1, contig_lens, args.introns, exon_len=args.exon_len, intron_max=args.intron_max)
     dup_shift = 0
     if args.multihit_frac > 0:                       # two-copy genome: [H, 2H) := [0, H), genes of the first copy only
         dup_shift = len(seqs[0]) // 2
@@ -197,9 +329,11 @@ def main():
                              inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len, multi_frac=args.multihit_frac, dup_shift=dup_shift)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
-    p_left = Params(read_side=READ_LEFT, inner_dist_mean=50, inner_dist_std_dev=20)
-    p_right = Params(read_side=READ_RIGHT, inner_dist_mean=50, inner_dist_std_dev=20)
-    p_span = Params()
+    max_intron = max(500000, args.intron_max + 1)
+    pk = dict(inner_dist_mean=50, inner_dist_std_dev=20, max_segment_intron=max_intron, max_report_intron=max_intron)
+    p_left = Params(read_side=READ_LEFT, **pk)
+    p_right = Params(read_side=READ_RIGHT, **pk)
+    p_span = Params(max_segment_intron=max_intron, max_report_intron=max_intron)
     # first-inserted-wins priority of std::set<Insertion>: all left reads (rank order) before all right reads
     cb_left = cbatch_from_tensors(w["left"], rank * args.pairs)
     cb_right = cbatch_from_tensors(w["right"], world * args.pairs + rank * args.pairs)
@@ -207,65 +341,26 @@ def main():
     use_heads = args.hit_heads
     sp_left = span_cbatch_from_tensors(w["left"], ctx if use_heads else None)
     sp_right = span_cbatch_from_tensors(w["right"], ctx if use_heads else None)
-    hip = ctypes.cdll.LoadLibrary("libamdhip64.so")
 
-    def d2d(dst_tensor, src_ptr, nbytes):
-        if nbytes:
-            hip.hipMemcpyAsync(ctypes.c_void_p(dst_tensor.data_ptr()), ctypes.c_void_p(src_ptr), ctypes.c_size_t(nbytes), 3,
-                               ctypes.c_void_p(stream.cuda_stream))
-
-    def gather_rows(out2d, row):
-        import torch.distributed as dist
-        if backend == "nccl":
-            dist.all_gather_into_tensor(out2d, row)
-        else:                                  # gloo (functional test only): through the host
-            rows = [torch.empty_like(row, device="cpu") for _ in range(world)]
-            dist.all_gather(rows, row.cpu())
-            for k_, r_ in enumerate(rows):
-                out2d[k_].copy_(r_)
-
-    def allgather_merge():
-        """ONE exchange step: all-gather the sorted per-rank event key sets over RCCL/xGMI and merge them into
-        every rank's tables (segment_juncs.cpp:4911-4916 across GPUs)."""
-        import torch.distributed as dist
-        jp, jn = ctx.device_keys(0)
-        dp, dn = ctx.device_keys(1)
-        ik, iv, inn = ctx.device_insertions()
-        nt = torch.tensor([jn, dn, inn], dtype=torch.int64, device=dev)
-        sizes = torch.zeros((world, 3), dtype=torch.int64, device=dev)
-        gather_rows(sizes, nt)
-        sizes = sizes.cpu()
-        mx = int((sizes[:, 0] + sizes[:, 1] + 2 * sizes[:, 2]).max())
-        if mx == 0:
-            return ctx.finish()
-        # torch.empty, not zeros: a fill kernel would run on torch's current stream, unordered against the copies below
-        # on the context's stream (found by the two-rank functional test: keys of the row were zeroed after the copy)
-        mine = torch.empty(mx, dtype=torch.int64, device=dev)
-        d2d(mine[0:], jp, jn * 8)
-        d2d(mine[jn:], dp, dn * 8)
-        d2d(mine[jn + dn:], ik, inn * 8)
-        d2d(mine[jn + dn + inn:], iv, inn * 8)
-        stream.synchronize()
-        gathered = torch.empty((world, mx), dtype=torch.int64, device=dev)
-        gather_rows(gathered, mine)
-        torch.cuda.synchronize()
-        for r_ in range(world):
-            if r_ == rank:
-                continue
-            a, b_, c_ = (int(x) for x in sizes[r_])
-            base = gathered[r_].data_ptr()
-            ctx.merge_keys(0, base, a)
-            ctx.merge_keys(1, base + 8 * a, b_)
-            ctx.merge_insertions(base + 8 * (a + b_), base + 8 * (a + b_ + c_), c_)
-        cnt2 = ctx.finish()
-        del gathered
-        return cnt2
+    # ---- the communicator: one RCCL rank per GPU (or the loopback transport in the in-process functional mode)
+    comm = None
+    if use_comm:
+        if shared is not None:                        # ranks are threads of this process
+            shared["ctxs"][rank] = ctx
+            control.barrier()
+            if rank == 0:
+                shared["comms"] = host.Comm.create_local(shared["ctxs"])
+            control.barrier()
+            comm = shared["comms"][rank]
+        else:
+            uid = host.comm_unique_id() if rank == 0 else None
+            if control is not None:
+                uid = control.bcast_bytes(uid, host.COMM_ID_BYTES)
+            comm = host.Comm.create(ctx, uid, world, rank)
 
     n_ium = int(args.coverage_search * args.pairs)
-    if n_ium and use_dist:
-        raise SystemExit("--coverage-search is a single-GPU leg of this bench (the exchange step for it: thj_covsearch_device_state / _merge_async)")
     cov_found = [0]
-    local_juncs = [0]                                 # this rank's junction count before the exchange step (THJ_BENCH_VERIFY)
+    local_juncs = [0]
 
     def step():
         # ---- segment_juncs stage
@@ -279,13 +374,13 @@ def main():
             ctx.covsearch_add_hits(cb_right)
             for sd in ("left", "right"):
                 ctx.covsearch_add_reads_device(n_ium, w[sd]["W"], w[sd]["planes"].data_ptr(), w[sd]["read_len"].data_ptr())
+            if comm is not None:
+                comm.covsearch_allgather()            # OR of the ranks' coverage maps, concatenation of their extension tables
             ctx.covsearch_run(min(20, 25 - 2), 50, 20000)
             cov_found[0] = ctx.covsearch_finish()
-        cnt = ctx.finish()
-        if use_dist:
-            local_juncs[0] = cnt.n_juncs
-            cnt2 = allgather_merge()
-            cnt.n_juncs, cnt.n_deletions, cnt.n_insertions = cnt2.n_juncs, cnt2.n_deletions, cnt2.n_insertions
+        if comm is not None:
+            comm.events_allgather()                   # ONE ncclAllGather on the context stream, merge kernels behind it
+        cnt = ctx.finish()                            # the only host round trip of the stage
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
         ctx.span_sets_from_segjuncs()
         ctx.span_reset()
@@ -295,11 +390,15 @@ def main():
         return cnt, n_alns
 
     def barrier():
-        if use_dist:
-            import torch.distributed as dist
-            dist.barrier()
+        if control is not None:
+            control.barrier()
         torch.cuda.synchronize()
 
+    if use_comm and os.environ.get("THJ_BENCH_VERIFY") == "1":
+        ctx.reset()
+        ctx.run(p_left, cb_left)
+        ctx.run(p_right, cb_right)
+        local_juncs[0] = ctx.finish().n_juncs          # what this rank finds alone
     for _ in range(args.warmup):
         cnt, n_alns = step()
     ctx.profile(True)
@@ -312,28 +411,21 @@ def main():
     elapsed = time.time() - t0
     kern_ms, launches = ctx.profile(False)
     span_ms, span_launches = ctx.profile_span(False)
-    if use_dist and os.environ.get("THJ_BENCH_VERIFY") == "1":
-        # functional check of the exchange step: every rank must hold the same merged junction set, no smaller than its own
-        jp, jn = ctx.device_keys(0)
-        keys = torch.empty(max(1, jn), dtype=torch.int64, device=dev)      # empty: see allgather_merge
-        torch.cuda.synchronize()
-        d2d(keys, jp, jn * 8)
-        stream.synchronize()
-        keys = keys[:jn]
-        h = torch.tensor([jn, int(keys.sum().item()) & ((1 << 62) - 1), int((keys ^ (keys >> 7)).sum().item()) & ((1 << 62) - 1)],
-                         dtype=torch.int64, device=dev)
-        allh = torch.zeros((world, 3), dtype=torch.int64, device=dev)
-        gather_rows(allh, h)
-        same = bool((allh == allh[0]).all().item()) and jn >= local_juncs[0]
-        print("[verify] rank %d: %d junctions after the exchange step (%d before), sets %s across %d ranks" % (
-            rank, jn, local_juncs[0], "identical" if same else "DIFFER", world), file=sys.stderr, flush=True)
+    comm_info = comm.info() if comm is not None else None
+    if use_comm and os.environ.get("THJ_BENCH_VERIFY") == "1":
+        # functional check of the exchange step: every rank must hold the same merged sets, no smaller than its own
+        ev = ctx.download(cnt)
+        import zlib
+        h = [len(ev.juncs), zlib.crc32(ev.juncs.tobytes()), len(ev.deletions), zlib.crc32(ev.deletions.tobytes()),
+             len(ev.insertions), zlib.crc32(repr(ev.insertions).encode())]
+        allh = control.allgather_ints(h) if control is not None else [h]
+        same = all(x == allh[0] for x in allh) and h[0] >= local_juncs[0]
+        print("[verify] rank %d: %d junctions after the exchange step (%d alone), sets %s across %d ranks, transport %s" % (
+            rank, h[0], local_juncs[0], "identical" if same else "DIFFER", world, comm_info["transport"]), file=sys.stderr, flush=True)
         if not same:
             raise SystemExit(3)
-    if use_dist:
-        import torch.distributed as dist
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if control is not None:
+        elapsed = control.max(elapsed)
 
     # ---- roofline, per launch (one launch = one side's batch of `pairs` reads); DESIGN.md "Roofline" ---------
     rl_bytes = (args.read_len + 3) // 4 + (args.read_len + 7) // 8            # packed read: 2-bit bases + N mask
@@ -378,7 +470,7 @@ def main():
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not args.hit_heads and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": args.genome_len, "exon_len": args.exon_len}:
+        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not args.hit_heads and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}:
             for k in kernels:
                 c = pm["kernels"].get(k["kernel"])
                 if c:
@@ -396,8 +488,8 @@ def main():
                      "segment_juncs (main + rescue kernels, event dedup+sort%s) then long_spanning_reads (four stitch tiers fed "
                      "device-to-device with the junction set; records land in BAM order)"
                      % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not n_ium else "shape of another config", args.pairs,
-                        args.read_len, args.genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
-                        ", RCCL all-gather of event keys" if use_dist else ""))
+                        args.read_len, genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
+                        ", one RCCL all-gather of the event sets inside the C ABI" if use_comm else ""))
     if args.hit_heads:
         workload_text += "; stage 2 batches also carry the optional dense hit-head array (built outside the timed region)"
     if n_ium:
@@ -466,28 +558,25 @@ def main():
                                      / max(1e-9, sum(k["avg_kernel_ms"] * k["launches"] for k in kernels)) / 1e6,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "kernels": kernels,
+            "exchange": comm_info,
             "cpu_baseline": cpu,
             "events": {"junctions": cnt.n_juncs, "deletions": cnt.n_deletions, "insertions": cnt.n_insertions,
                        "windows_per_step": cnt.n_windows, "rescue_pairs_per_step": cnt.n_rescue_pairs,
                        "overflow_blocks": cnt.n_overflow_blocks, "spanning_records_per_step": n_alns},
             "gen_seconds": t_gen,
         }
+    if comm is not None and shared is None:
+        comm.close()
+    if shared is not None:
+        control.barrier()
+        if rank == 0:
+            for c_ in shared["comms"]:
+                c_.close()
+        control.barrier()
     ctx.close()
-    if use_dist:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
-    # The JSON line must be the last thing on stdout: RCCL writes a version banner through C stdio, which sits in libc's
-    # buffer until exit when stdout is a pipe.  Flush that first, print the line, then point fd 1 at /dev/null so that
-    # nothing written later (exit handlers, library destructors) can follow it.  The process still exits normally --
-    # profilers attached to it (rocprofv3) finalise in their exit handlers.
-    sys.stdout.flush()
-    ctypes.CDLL(None).fflush(None)
-    if rank == 0:
-        print(json.dumps(result), flush=True)
-    sys.stdout.flush()
-    devnull = os.open(os.devnull, os.O_WRONLY)
-    os.dup2(devnull, 1)
+    if control is not None:
+        control.close()
+    return result
 
 
 if __name__ == "__main__":

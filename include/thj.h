@@ -360,6 +360,41 @@ int thj_covsearch_device_state(thj_ctx* ctx, const uint64_t** d_cov_bits, int64_
 int thj_covsearch_merge_async(thj_ctx* ctx, const uint64_t* d_other_bits, const int32_t* d_other_size,
                               const uint32_t* d_other_keys, const uint64_t* d_other_vals, int64_t n_other_ext);
 
+/* ---------------------------------------------------------------- multi-GPU exchange step
+ * Reads shard over GPUs (contiguous read-id ranges, the reference's own thread partition: utils.cpp:22-170,
+ * segment_juncs.cpp:4793-4810), the genome is replicated, and the per-rank event sets are united ONCE before
+ * long_spanning_reads -- what segment_juncs.cpp:4911-4922 does with its per-thread sets -- by one RCCL all-gather
+ * over xGMI.  A communicator binds one rank to one context (its device and stream).  Every rank's collective calls
+ * must be made by its own host thread or process, in the same order on all ranks. */
+typedef struct thj_comm thj_comm;
+#define THJ_COMM_ID_BYTES 128
+#define THJ_COMM_SELF      0   /* one rank, no transport */
+#define THJ_COMM_RCCL      1   /* ncclAllGather on the context stream */
+#define THJ_COMM_LOOPBACK  2   /* ranks of one process sharing a device: stream-ordered device copies (functional tests on a 1-GPU box) */
+/* ncclGetUniqueId: made by one rank, handed to the others by the caller's own means (file, pipe, MPI, torch.distributed) */
+int thj_comm_unique_id(uint8_t* id /*[THJ_COMM_ID_BYTES]*/);
+/* One rank per process (or thread): ncclCommInitRank.  id == NULL with n_ranks == 1 gives a transport-less communicator. */
+int thj_comm_create(thj_ctx* ctx, const uint8_t* id, int32_t n_ranks, int32_t rank, thj_comm** out);
+/* All ranks inside this process, rank i on ctxs[i]: RCCL when the contexts sit on distinct GPUs, loopback otherwise. */
+int thj_comm_create_local(thj_ctx* const* ctxs, int32_t n, thj_comm** out /*[n]*/);
+void thj_comm_destroy(thj_comm* comm);
+/* stats: [0] exchange steps enqueued, [1] of them repeats with larger message sections, [2] bytes one rank sends per step,
+ * [3] junction-section capacity (keys) */
+int thj_comm_info(const thj_comm* comm, int32_t* n_ranks, int32_t* rank, int32_t* transport, int64_t* stats /*[4]*/);
+
+/* After this rank's thj_segjuncs_run_async calls (and thj_covsearch_finish), before thj_segjuncs_finish: packs the distinct
+ * junction / deletion / insertion events, all-gathers them and inserts the other ranks' events into this rank's tables --
+ * all enqueued on the context stream, no host synchronisation.  thj_segjuncs_finish then returns the united sets on every
+ * rank (and repeats the step by itself if a message section or a table turned out too small). */
+int thj_events_allgather_async(thj_ctx* ctx, thj_comm* comm);
+/* After thj_fusion_finish: every rank's FusionSimpleSet becomes the merge_with() of all of them (fusions.cpp:975-990:
+ * counts add up, the smallest edit distance wins); *n_fusions = size of the merged set, which thj_fusion_download then
+ * copies out.  Synchronous. */
+int thj_fusion_allgather(thj_ctx* ctx, thj_comm* comm, int64_t* n_fusions);
+/* Before thj_covsearch_run_async: the coverage map becomes the OR of the ranks' maps, the contig extents their maximum, the
+ * extension table the concatenation of their entries; every rank then runs the same coverage search.  Synchronous. */
+int thj_covsearch_allgather(thj_ctx* ctx, thj_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,28 @@ class SegBatch:
         k = r * self.nseg + s
         return self.hits[self.seg_off[k]:self.seg_off[k + 1]]
 
+    def select(self, mask: np.ndarray) -> "SegBatch":
+        """the sub-batch of the reads where mask is True, order kept (a shard of the reads)"""
+        idx = np.flatnonzero(mask)
+        read_off, seg_off, mate_off = [0], [0], [0]
+        bases, hits, mates = [], [], []
+        for r in idx:
+            bases.append(self.bases[self.read_off[r]:self.read_off[r + 1]])
+            read_off.append(read_off[-1] + len(bases[-1]))
+            for s in range(self.nseg):
+                h = self.seg_hits(int(r), s)
+                hits.append(h)
+                seg_off.append(seg_off[-1] + len(h))
+            if self.mate_off is not None:
+                m = self.mate_hits[self.mate_off[r]:self.mate_off[r + 1]]
+                mates.append(m)
+                mate_off.append(mate_off[-1] + len(m))
+        cat = lambda parts, like: np.concatenate(parts) if parts else like[:0]     # noqa: E731
+        return SegBatch(self.nseg, self.read_id[idx], np.asarray(read_off, dtype=np.int64), cat(bases, self.bases),
+                        np.asarray(seg_off, dtype=np.uint32), cat(hits, self.hits),
+                        None if self.mate_off is None else np.asarray(mate_off, dtype=np.uint32),
+                        None if self.mate_off is None else cat(mates, self.mate_hits))
+
 
 # One parsed alignment record of a segment / read map, before grouping.
 # (read_id, ref_id, left, right, antisense, end, mismatches, edit_dist, read_len)

@@ -71,6 +71,8 @@ struct thj_ctx {
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
     std::vector<thj_fusion> h_fusions;
+    // multi-GPU exchange step pending a look at its gathered headers (thj_exchange_impl.h)
+    struct thj_comm* xchg = nullptr;
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;

@@ -556,6 +556,7 @@ static int reset_tables_async(thj_ctx* c) {
     HIPCHK(hipMemsetAsync(c->d_cnt, 0, CNT_N * sizeof(unsigned long long), c->stream));
     c->n_junc = c->n_del = c->n_ins = 0;
     c->probe_pending = false;                 // counters of the previous pass say nothing about the emptied tables
+    c->xchg = nullptr;
     return THJ_OK;
 }
 
@@ -973,28 +974,43 @@ extern "C" int thj_segjuncs_merge_insertions_async(thj_ctx* c, const uint64_t* d
     return THJ_OK;
 }
 
+static int x_finish_check(thj_ctx* c, const unsigned int* ovf_now);
+static unsigned long long* x_host_headers(thj_ctx* c, const u64** d_hdr, size_t* bytes);
+
 extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    // the distinct events are already dense (see set_insert): ONE round trip brings their counts
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[4], c->d_ovf, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[8], c->d_cnt, CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    const unsigned int* ovf = (const unsigned int*)&c->h_pinned[4];
-    if (ovf[0] || ovf[1] || ovf[2]) {
-        thj_set_error("event table overflow (junc=%u del=%u ins=%u): call thj_segjuncs_configure with larger capacities and re-run",
-                      ovf[0], ovf[1], ovf[2]);
-        return THJ_EOVERFLOW;
-    }
-    c->h_pinned[0] = c->h_pinned[8 + CNT_JUNC]; c->h_pinned[1] = c->h_pinned[8 + CNT_DEL]; c->h_pinned[2] = c->h_pinned[8 + CNT_INS];
-    c->n_junc = (int64_t)c->h_pinned[0];
-    c->n_del = (int64_t)c->h_pinned[1];
-    c->n_ins = (int64_t)c->h_pinned[2];
-    if (c->n_junc > c->junc_cap - c->junc_cap / 4 || c->n_del > c->indel_cap - c->indel_cap / 4 || c->n_ins > c->indel_cap - c->indel_cap / 4) {
-        thj_set_error("event table more than 75 %% full after one batch (junc=%lld/%lld del=%lld ins=%lld/%lld): use smaller batches or "
-                      "thj_segjuncs_configure with larger capacities", (long long)c->n_junc, (long long)c->junc_cap, (long long)c->n_del,
-                      (long long)c->n_ins, (long long)c->indel_cap);
-        return THJ_EOVERFLOW;
+    for (;;) {
+        // the distinct events are already dense (see set_insert): ONE round trip brings their counts -- and, after an
+        // exchange step, the headers every rank gathered
+        HIPCHK(hipMemcpyAsync(&c->h_pinned[4], c->d_ovf, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&c->h_pinned[8], c->d_cnt, CNT_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        if (c->xchg) {
+            const u64* d_hdr = nullptr; size_t hb = 0;
+            unsigned long long* h = x_host_headers(c, &d_hdr, &hb);
+            HIPCHK(hipMemcpyAsync(h, d_hdr, hb, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const unsigned int* ovf = (const unsigned int*)&c->h_pinned[4];
+        if (c->xchg) {
+            const int rc = x_finish_check(c, ovf);
+            if (rc < 0) return rc;
+            if (rc > 0) continue;                 // the step was repeated (larger message / larger table): look again
+        } else if (ovf[0] || ovf[1] || ovf[2]) {
+            thj_set_error("event table overflow (junc=%u del=%u ins=%u): call thj_segjuncs_configure with larger capacities and re-run",
+                          ovf[0], ovf[1], ovf[2]);
+            return THJ_EOVERFLOW;
+        }
+        c->h_pinned[0] = c->h_pinned[8 + CNT_JUNC]; c->h_pinned[1] = c->h_pinned[8 + CNT_DEL]; c->h_pinned[2] = c->h_pinned[8 + CNT_INS];
+        c->n_junc = (int64_t)c->h_pinned[0];
+        c->n_del = (int64_t)c->h_pinned[1];
+        c->n_ins = (int64_t)c->h_pinned[2];
+        // a pass that left a table more than 40 % full (merged key sets of other ranks, a large coverage pass, one huge
+        // batch) moves to tables four times the size now: the rehash keeps every key, and the next pass starts with room
+        const bool gj = c->n_junc * 5 > c->junc_cap * 2;
+        const bool gi = (c->n_del > c->n_ins ? c->n_del : c->n_ins) * 5 > c->indel_cap * 2;
+        if (gj || gi) { int rc = grow_tables(c, gj, gi); if (rc) return rc; continue; }
+        break;
     }
     // sorted output (stream-ordered: consumers on the context stream need no further synchronisation)
     size_t tmp = c->sort_tmp_bytes;
@@ -1128,3 +1144,9 @@ extern "C" int thj_genome_gather(thj_ctx* c, const thj_piece* pieces, int64_t n,
 }
 
 #include "thj_covsearch_impl.h"
+#include "thj_exchange_impl.h"
+
+static unsigned long long* x_host_headers(thj_ctx* c, const u64** d_hdr, size_t* bytes) {
+    *d_hdr = c->xchg->d_hdr; *bytes = (size_t)c->xchg->n * 64;
+    return c->xchg->h_hdr;
+}

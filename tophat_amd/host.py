@@ -61,6 +61,8 @@ ABI_SYMBOLS = [
     "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_genome_gather", "thj_fusion_finish", "thj_fusion_download",
     "thj_covsearch_reset_async", "thj_covsearch_add_hits_async", "thj_covsearch_add_reads", "thj_covsearch_run_async", "thj_covsearch_finish",
     "thj_covsearch_device_state", "thj_covsearch_merge_async", "thj_span_hit_heads_async",
+    "thj_comm_unique_id", "thj_comm_create", "thj_comm_create_local", "thj_comm_destroy", "thj_comm_info",
+    "thj_events_allgather_async", "thj_fusion_allgather", "thj_covsearch_allgather",
 ]
 
 _lib = None
@@ -158,6 +160,66 @@ def host_cbatch(b: SegBatch, ordinal_base: int = 0, lib=None):
     cb.ordinal_base = ordinal_base
     n_mate = 0 if b.mate_hits is None else len(b.mate_hits)
     return cb, keep, len(b.hits), n_mate
+
+
+COMM_ID_BYTES = 128
+COMM_TRANSPORT = {0: "self", 1: "rccl", 2: "loopback"}
+
+
+def comm_unique_id(lib=None) -> bytes:
+    """ncclGetUniqueId through the C ABI: made by one rank, handed to the others by the caller."""
+    lib = lib or load_lib()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib, lib.thj_comm_unique_id(buf), "thj_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """One rank of the exchange step (thj_comm): bound to one Context."""
+
+    def __init__(self, ctx: "Context", handle: C.c_void_p):
+        self.ctx, self._h = ctx, handle
+
+    @staticmethod
+    def create(ctx: "Context", unique_id: Optional[bytes], n_ranks: int, rank: int) -> "Comm":
+        h = C.c_void_p()
+        idbuf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+        _check(ctx.lib, ctx.lib.thj_comm_create(ctx._ctx, idbuf, n_ranks, rank, C.byref(h)), "thj_comm_create")
+        return Comm(ctx, h)
+
+    @staticmethod
+    def create_local(ctxs: Sequence["Context"]) -> List["Comm"]:
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c._ctx for c in ctxs])
+        out = (C.c_void_p * n)()
+        _check(ctxs[0].lib, ctxs[0].lib.thj_comm_create_local(arr, n, out), "thj_comm_create_local")
+        return [Comm(ctxs[i], C.c_void_p(out[i])) for i in range(n)]
+
+    def info(self):
+        n, r, t = C.c_int32(), C.c_int32(), C.c_int32()
+        st = (C.c_int64 * 4)()
+        _check(self.ctx.lib, self.ctx.lib.thj_comm_info(self._h, C.byref(n), C.byref(r), C.byref(t), st), "thj_comm_info")
+        return {"n_ranks": n.value, "rank": r.value, "transport": COMM_TRANSPORT[t.value], "steps": st[0], "repeats": st[1],
+                "bytes_per_rank": st[2], "junction_capacity": st[3]}
+
+    def events_allgather(self):
+        _check(self.ctx.lib, self.ctx.lib.thj_events_allgather_async(self.ctx._ctx, self._h), "thj_events_allgather_async")
+
+    def fusion_allgather(self) -> np.ndarray:
+        """after Context.fusions(...) on every rank: the merged FusionSimpleSet (FUSION_DTYPE array), same on every rank"""
+        n = C.c_int64()
+        _check(self.ctx.lib, self.ctx.lib.thj_fusion_allgather(self.ctx._ctx, self._h, C.byref(n)), "thj_fusion_allgather")
+        out = np.zeros(max(1, n.value), dtype=FUSION_DTYPE)
+        _check(self.ctx.lib, self.ctx.lib.thj_fusion_download(self.ctx._ctx, _ptr(out)), "thj_fusion_download")
+        return out[:n.value]
+
+    def covsearch_allgather(self):
+        _check(self.ctx.lib, self.ctx.lib.thj_covsearch_allgather(self.ctx._ctx, self._h), "thj_covsearch_allgather")
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.thj_comm_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 def decode_ins_seq(code: int, length: int) -> str:
