@@ -91,6 +91,8 @@ const char* thj_version(void);
 
 /* ------------------------------------------------------------ context */
 
+/* Number of HIP devices visible to the process (< 0: error). */
+int  thj_device_count(void);
 /* `stream` is a hipStream_t to launch on (e.g. torch's current stream) or NULL
  * to let the context create its own non-blocking stream. */
 int  thj_ctx_create(int device, void* stream, thj_ctx** out);

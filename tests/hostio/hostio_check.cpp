@@ -131,6 +131,79 @@ int main(int argc, char** argv) {
         printf("%llu reads in %.3f s = %.3f us/read\n", (unsigned long long)nreads, dt, 1e6 * dt / (double)(nreads ? nreads : 1));
         return 0;
     }
+    if (mode == "shardmerge" && argc >= 6) {
+        // hostio_check shardmerge <n_shards> <reads> <mate_map|-> <seg1,seg2,...>: the ingest loop of segment_juncs over the
+        // reference's shard plan (calculate_offsets over the .index files / probed text offsets), shard after shard.
+        // Prints "<shards used> <reads> <hits> <mate hits> <checksum>" -- the last four must not depend on n_shards.
+        RefTable rt;
+        thj_params p;
+        thj_params_default(&p);
+        int want = atoi(argv[2]);
+        const std::string reads_fn = argv[3], mate_fn = argv[4];
+        std::vector<std::string> segs = split(argv[5], ',');
+        const int nseg = (int)segs.size();
+        for (auto& f : segs) register_targets(f, rt);
+        if (mate_fn != "-") register_targets(mate_fn, rt);
+        rt.freeze();
+        struct Sh { uint64_t b = 0, e = ~0ull; int64_t ro = 0, po = 0; std::vector<int64_t> so; };
+        std::vector<Sh> shards(1);
+        shards[0].so.assign((size_t)nseg, 0);
+        if (want > 1) {
+            std::vector<IndexList> lists(1 + (size_t)nseg);
+            load_index(reads_fn, want * 4, lists[0]);
+            for (int k = 0; k < nseg; ++k) load_index(segs[(size_t)k], want * 4, lists[1 + (size_t)k]);
+            size_t smallest = ~(size_t)0;
+            for (auto& l : lists) smallest = std::min(smallest, l.size());
+            if ((size_t)want > smallest) want = (int)smallest;
+            std::vector<uint64_t> ids; std::vector<std::vector<int64_t>> offs;
+            if (calculate_offsets(lists, want, ids, offs)) {
+                std::vector<int64_t> po;
+                if (mate_fn != "-") { IndexList l; load_index(mate_fn, want * 4, l); calculate_offsets_from_ids(l, ids, po); }
+                shards.assign((size_t)want, Sh());
+                for (int i = 0; i < want; ++i) {
+                    Sh& sh = shards[(size_t)i];
+                    sh.so.assign((size_t)nseg, 0);
+                    if (i > 0) { sh.b = ids[(size_t)i - 1]; sh.ro = offs[(size_t)i - 1][0]; sh.so.assign(offs[(size_t)i - 1].begin() + 1, offs[(size_t)i - 1].end()); if (!po.empty()) sh.po = po[(size_t)i - 1]; }
+                    sh.e = i + 1 < want ? ids[(size_t)i] : ~0ull;
+                }
+            }
+        }
+        uint64_t nreads = 0, nhits = 0, nmate = 0, sum = 0;
+        for (auto& sh : shards) {
+            std::vector<HitStream> st((size_t)nseg);
+            for (int k = 0; k < nseg; ++k) if (!st[(size_t)k].open(segs[(size_t)k], rt, p, false, sh.so[(size_t)k], sh.b, sh.e)) return 3;
+            HitStream mate;
+            bool have_mate = mate_fn != "-" && mate.open(mate_fn, rt, p, false, sh.po, sh.b, sh.e);
+            ReadStream reads;
+            if (!reads.open(reads_fn, "", sh.ro)) return 3;
+            std::vector<Hit> g, mg;
+            for (;;) {
+                uint32_t id = 0;
+                for (int k = 0; k < nseg; ++k) { uint32_t x = st[(size_t)k].next_group_id(); if (x && (id == 0 || x < id)) id = x; }
+                if (id == 0) break;
+                Read rd;
+                if (!reads.get(id, rd)) return 5;
+                sum = sum * 1000003ull + id;
+                for (char c : rd.seq) sum = sum * 131ull + (unsigned char)c;
+                for (int k = 0; k < nseg; ++k) {
+                    g.clear();
+                    if (st[(size_t)k].next_group_id() == id) st[(size_t)k].next_group(g);
+                    nhits += g.size();
+                    for (auto& h : g) sum = sum * 1000003ull + (uint64_t)h.h16.left * 7ull + h.h16.flags + (uint64_t)h.h16.right + (uint64_t)k;
+                }
+                if (have_mate) {
+                    mg.clear();
+                    while (mate.next_group_id() && mate.next_group_id() < id) mate.skip_group();
+                    if (mate.next_group_id() == id) mate.next_group(mg);
+                    nmate += mg.size();
+                    for (auto& h : mg) sum = sum * 1000003ull + (uint64_t)h.h16.left;
+                }
+                ++nreads;
+            }
+        }
+        printf("%zu %llu %llu %llu %llu\n", shards.size(), (unsigned long long)nreads, (unsigned long long)nhits, (unsigned long long)nmate, (unsigned long long)sum);
+        return 0;
+    }
     if (mode == "reads" && argc >= 3) {
         // hostio_check reads <reads.fq> <id> [<id> ...]  -> one "<id> <seq> <qual>" line per request
         ReadStream rs;

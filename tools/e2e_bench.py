@@ -1,71 +1,83 @@
 #!/usr/bin/env python3
-"""End-to-end timing of the drop-in executables (GPU box): generate a seeded paired-end case, write the files
-tophat.py would hand over (FASTA, FASTQ, id-sorted segment maps as SAM text and as BAM), run
-tophat_amd/bin/segment_juncs and long_spanning_reads on them and report wall-clock reads/s per stage.
-Usage: python tools/e2e_bench.py [n_pairs] [--bam] [--short]
---short: 2x50 bp reads in two segments, segment_juncs with the coverage search (every read given as --ium-reads), the
-way tophat.py runs reads of fewer than three segments."""
+"""End-to-end timing of the drop-in executables (GPU box): write the files tophat.py would hand over for a synthetic
+paired-end run of BASELINE configs[1]'s shape (tools/bin/thj_gen: FASTA, SAM header, reads as unaligned BAM, whole-read and
+per-segment maps as id-sorted BAM, every BAM with its .index), run tophat_amd/bin/segment_juncs and long_spanning_reads
+(left, then right) on them and report wall-clock pairs/s for both stages together -- the metric of SURVEY.md section 8d.
+
+    python tools/e2e_bench.py [--pairs N] [--read-len R] [--genome-len L] [--introns K] [--keep DIR] [--env K=V ...]
+"""
+import argparse
 import json
 import os
+import shutil
 import subprocess
 import sys
 import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-from tophat_amd.synth import make_case, write_case  # noqa: E402
-from tophat_amd.bamio import write_bam_from_sam  # noqa: E402
-
-n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 200000
-use_bam = "--bam" in sys.argv
-short = "--short" in sys.argv
-RL, NSEG = (50, 2) if short else (100, 4)
 BIN = os.path.join(ROOT, "tophat_amd", "bin")
-d = tempfile.mkdtemp(prefix="thj_e2e_")
-t = time.time()
-case = make_case(seed=7, contig_lens=(8_000_000,), n_reads=n_pairs, paired=True, read_len=RL, seg_len=25,
-                 genes_per_contig=1500, spliced_seg_frac=0.0 if short else 0.5)
-write_case(case, d)
-gen_s = time.time() - t
+GEN = os.path.join(ROOT, "tools", "bin", "thj_gen")
 
 
-def f(name):
-    p = os.path.join(d, name)
-    if use_bam and name.endswith(".sam") and name != "hdr.sam":
-        o = p[:-4] + ".bam"
-        if not os.path.exists(o):
-            write_bam_from_sam(p, o)
-        return o
-    return p
-
-
-segs = {sd: ",".join(f("%s_seg%d.sam" % (sd, k + 1)) for k in range(NSEG)) for sd in ("left", "right")}
-out = {k: os.path.join(d, "out." + k) for k in ("juncs", "insertions", "deletions", "fusions")}
-res = {"n_pairs": n_pairs, "read_len": RL, "inputs": "bam" if use_bam else "sam", "gen_seconds": round(gen_s, 1)}
-mode = ["--ium-reads", f("left.fq") + "," + f("right.fq")] if short else ["--no-coverage-search"]
-cmd = [os.path.join(BIN, "segment_juncs")] + mode + ["--no-microexon-search", "--segment-length", "25",
-       "--sam-header", f("hdr.sam"), "-p", "1", "--inner-dist-mean", "50", "--inner-dist-std-dev", "20",
-       f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"],
-       f("left.fq"), f("left_map.sam"), segs["left"], f("right.fq"), f("right_map.sam"), segs["right"]]
-t = time.time()
-r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, THJ_TIMING="1"))
-dt = time.time() - t
-assert r.returncode == 0, r.stderr[-2000:]
-res["segment_juncs_s"] = round(dt, 3)
-res["segment_juncs_reads_per_s"] = round(2 * n_pairs / dt)
-res["junctions"] = sum(1 for _ in open(out["juncs"]))
-res["segment_juncs_log_tail"] = r.stderr.strip().splitlines()[-14:]
-tot = dt
-for sd in ("left", "right"):
-    cmd = [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"), f("%s.fq" % sd),
-           out["juncs"], out["insertions"], out["deletions"], "/dev/null", os.path.join(d, "span_%s.bam" % sd), segs[sd]]
+def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False):
+    nseg = max(1, read_len // 25)
+    d = workdir or tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    env = dict(os.environ, THJ_TIMING="1", **(env_extra or {}))
+    res = {"pairs": pairs, "read_len": read_len, "genome_len": genome_len, "dir": d}
     t = time.time()
-    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, THJ_TIMING="1"))
+    subprocess.check_call([GEN, "--out", d, "--pairs", str(pairs), "--read-len", str(read_len), "--genome-len", str(genome_len),
+                           "--introns", str(introns)], stdout=subprocess.DEVNULL)
+    res["gen_seconds"] = round(time.time() - t, 2)
+    res["input_bytes"] = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".bam"))
+
+    def f(name):
+        return os.path.join(d, name)
+    segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k + 1)) for k in range(nseg)) for sd in ("left", "right")}
+    out = {k: f("out." + k) for k in ("juncs", "insertions", "deletions", "fusions")}
+    mode = ["--ium-reads", f("left_reads.bam") + "," + f("right_reads.bam")] if coverage_search else ["--no-coverage-search"]
+    cmd = [os.path.join(BIN, "segment_juncs")] + mode + ["--no-microexon-search", "--segment-length", "25",
+           "--sam-header", f("hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20",
+           f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"],
+           f("left_reads.bam"), f("left_map.bam"), segs["left"], f("right_reads.bam"), f("right_map.bam"), segs["right"]]
+    t = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     dt = time.time() - t
-    assert r.returncode == 0, r.stderr[-2000:]
-    res["long_spanning_reads_%s_s" % sd] = round(dt, 3)
-    res["long_spanning_reads_%s_log_tail" % sd] = r.stderr.strip().splitlines()[-14:]
-    tot += dt
-res["pairs_per_s_both_stages"] = round(n_pairs / tot)
-print(json.dumps(res, indent=1))
+    if r.returncode != 0:
+        raise RuntimeError("segment_juncs failed:\n" + r.stderr[-3000:])
+    res["segment_juncs_s"] = round(dt, 3)
+    res["junctions"] = sum(1 for _ in open(out["juncs"]))
+    res["segment_juncs_log_tail"] = r.stderr.strip().splitlines()[-12:]
+    tot = dt
+    for sd in ("left", "right"):
+        cmd = [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
+               f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", f("span_%s.bam" % sd), segs[sd]]
+        t = time.time()
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        dt = time.time() - t
+        if r.returncode != 0:
+            raise RuntimeError("long_spanning_reads failed:\n" + r.stderr[-3000:])
+        res["long_spanning_reads_%s_s" % sd] = round(dt, 3)
+        res["long_spanning_reads_%s_log_tail" % sd] = r.stderr.strip().splitlines()[-8:]
+        res["span_%s_bytes" % sd] = os.path.getsize(f("span_%s.bam" % sd))
+        tot += dt
+    res["both_stages_s"] = round(tot, 3)
+    res["pairs_per_s_both_stages"] = round(pairs / tot)
+    if not keep and workdir is None:
+        shutil.rmtree(d, ignore_errors=True)
+    return res
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pairs", type=int, default=1000000)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--genome-len", type=int, default=64444167)
+    ap.add_argument("--introns", type=int, default=20000)
+    ap.add_argument("--coverage-search", action="store_true")
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("--env", nargs="*", default=[])
+    a = ap.parse_args()
+    res = run_e2e(a.pairs, a.read_len, a.genome_len, a.introns, workdir=a.keep, env_extra=dict(x.split("=", 1) for x in a.env), keep=bool(a.keep),
+                  coverage_search=a.coverage_search)
+    print(json.dumps(res, indent=1))

@@ -1,7 +1,15 @@
 // long_spanning_reads -- MI355X-native drop-in for TopHat's long_spanning_reads (same argv + files;
 // tophat.py:3160-3191, parsed like long_spanning_reads.cpp:3151-3329).  Host C++ over include/thj.h.
-// Contig segment maps (with any CIGAR, incl. N/I/D) are supported; junction-db ("spliced") segment maps
-// (SplicedBAMHitFactory) and --fusion-search are refused loudly.
+// Contig segment maps (with any CIGAR, incl. N/I/D) and junction-db ("spliced") segment maps are supported;
+// --fusion-search is refused loudly.
+//
+// The reads are cut into contiguous read-id shards with the reference's planner (calculate_offsets over the inputs' .index
+// files, utils.cpp:22-127; long_spanning_reads.cpp:2983-3064).  Host workers ingest shards in parallel -- shard k's
+// batches run on GPU k mod n -- and encode their records; with one output file a writer appends the shards' records in
+// shard order (= read order), so the BAM stream and its .index do not depend on the number of shards; with -p N the N
+// parts are the reference's N ranges, one file each (<base>{0..N-1}.bam).
+#include <deque>
+
 #include "thj_hostio.h"
 
 using namespace thjh;
@@ -12,9 +20,105 @@ static void print_usage() {
                     "<possible_fusions1,...,possible_fusionsN> <out.bam> <seg1.bwtout,...,segN.bwtout> [spliced_seg1.bwtout,...,spliced_segN.bwtout]\n");
 }
 
-static const char OPCH[16] = {'?', 'M', 'm', 'I', 'i', 'D', 'd', '?', '?', '?', '?', 'N', 'n', 'S', 'H', 'P'};
-
 static PhaseTimer g_timer;
+
+struct Gpu {
+    int device = 0;
+    thj_ctx* ctx = nullptr;
+    std::future<thj_ctx*> fut;
+    std::mutex mu;
+};
+
+struct Shard {
+    uint64_t begin_id = 0, end_id = ~0ull;
+    int64_t read_off = 0;
+    std::vector<int64_t> seg_off, spliced_off;
+};
+
+// long_spanning_reads.cpp:2983-2991, :3051-3064: index files in the order {reads, spliced maps last..first, contig maps
+// last..first} -- the boundaries come from the FIRST segment's contig map, the stream the worker iterates over
+static std::vector<Shard> plan(const std::string& reads, const std::vector<std::string>& segs, const std::vector<std::string>& spliced, int want) {
+    std::vector<Shard> out(1);
+    out[0].seg_off.assign(segs.size(), 0); out[0].spliced_off.assign(spliced.size(), 0);
+    if (want < 2) return out;
+    std::vector<std::string> fnames;
+    fnames.push_back(reads);
+    fnames.insert(fnames.end(), spliced.rbegin(), spliced.rend());
+    fnames.insert(fnames.end(), segs.rbegin(), segs.rend());
+    std::vector<IndexList> lists(fnames.size());
+    size_t smallest = ~(size_t)0;
+    for (size_t i = 0; i < fnames.size(); ++i) { load_index(fnames[i], want * 4, lists[i]); smallest = std::min(smallest, lists[i].size()); }
+    if ((size_t)want > smallest) want = (int)smallest;
+    std::vector<uint64_t> ids; std::vector<std::vector<int64_t>> offs;
+    if (!calculate_offsets(lists, want, ids, offs)) return out;
+    out.assign((size_t)want, Shard());
+    for (int i = 0; i < want; ++i) {
+        Shard& sh = out[(size_t)i];
+        sh.seg_off.assign(segs.size(), 0); sh.spliced_off.assign(spliced.size(), 0);
+        if (i > 0) {
+            const std::vector<int64_t>& o = offs[(size_t)i - 1];
+            sh.begin_id = ids[(size_t)i - 1];
+            sh.read_off = o[0];
+            for (size_t s = 0; s < spliced.size(); ++s) sh.spliced_off[s] = o[1 + (spliced.size() - 1 - s)];
+            for (size_t s = 0; s < segs.size(); ++s) sh.seg_off[s] = o[1 + spliced.size() + (segs.size() - 1 - s)];
+        }
+        sh.end_id = i + 1 < want ? ids[(size_t)i] : ~0ull;
+    }
+    return out;
+}
+
+// print_bamhit (bwt_map.cpp:1888-2093) for one record
+static long encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a, const Read& rd, std::vector<uint8_t>& d) {
+    int rlen = 0, indel = 0; bool spliced = false;
+    for (int k = 0; k < a.n_cigar; ++k) {
+        uint32_t op = a.cigar[k] >> 28, len = a.cigar[k] & 0x0FFFFFFF;
+        if (op == 1 || op == 2 || op == 3 || op == 4 || op == 13) rlen += (int)len;
+        if (op >= 3 && op <= 6) indel += (int)len;
+        if (op == 11 || op == 12) spliced = true;
+    }
+    std::string seq = rd.seq, qual = rd.qual;
+    seq.resize((size_t)rlen); qual.resize((size_t)rlen);
+    uint32_t flag = 0;
+    if (a.flags & THJ_HIT_ANTISENSE) { flag |= 0x10; reverse_complement(seq); std::reverse(qual.begin(), qual.end()); }
+    std::vector<std::string> aux;
+    aux.push_back("AS:i:" + std::to_string((int)a.AS));
+    aux.push_back("XM:i:" + std::to_string((int)a.XM));
+    aux.push_back("XO:i:" + std::to_string((int)a.XO));
+    aux.push_back("XG:i:" + std::to_string((int)a.XG));
+    aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
+    aux.push_back("NM:i:" + std::to_string((int)a.mismatches + indel));
+    if (spliced) aux.push_back(std::string("XS:A:") + ((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'));
+    bw.encode(d, rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
+    return atol(rd.name.c_str());
+}
+
+static void encode_batch(const BamWriter& bw, const RefTable& rt, const std::vector<thj_aln>& alns, const std::vector<Read>& reads, int threads,
+                         BamWriter::Encoded& e) {
+    const size_t n = alns.size();
+    int T = threads;
+    if ((size_t)T > n / 256 + 1) T = (int)(n / 256 + 1);
+    std::vector<std::vector<uint8_t>> part((size_t)T);
+    e.size.resize(n); e.rid.resize(n);
+    auto work = [&](int t) {
+        const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T;
+        std::vector<uint8_t>& d = part[(size_t)t];
+        d.reserve((b - a) * 256);
+        for (size_t i = a; i < b; ++i) { size_t before = d.size(); e.rid[i] = encode_aln(bw, rt, alns[i], reads[alns[i].read_idx], d); e.size[i] = (uint32_t)(d.size() - before); }
+    };
+    if (T > 1) { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+    else work(0);
+    size_t total = 0;
+    for (auto& d : part) total += d.size();
+    e.bytes.reserve(total);
+    for (auto& d : part) { e.bytes.insert(e.bytes.end(), d.begin(), d.end()); std::vector<uint8_t>().swap(d); }
+}
+
+// records of one shard on their way to the writer
+struct OutShard {
+    std::mutex mu; std::condition_variable cv;
+    std::deque<BamWriter::Encoded> q;
+    bool done = false;
+};
 
 int main(int argc, char** argv) {
     fprintf(stderr, "long_spanning_reads (MI355X-native, %s)\n--------------------------------------------\n", thj_version());
@@ -30,6 +134,24 @@ int main(int argc, char** argv) {
     if (pos.size() >= 9) spliced_segs = split(pos[8], ',');
     std::vector<std::string> segs = split(pos[7], ',');
     if (segs.empty()) { fprintf(stderr, "No hits to process, exiting\n"); return 0; }           // long_spanning_reads.cpp:2883-2887
+
+    std::vector<std::unique_ptr<Gpu>> gpus;
+    {
+        int n_dev = 1, first = 0;
+        if (getenv("THJ_DEVICE")) first = atoi(getenv("THJ_DEVICE"));
+        else { n_dev = thj_device_count(); if (n_dev < 1) die("Error: %s\n", thj_last_error()); if (getenv("THJ_GPUS") && atoi(getenv("THJ_GPUS")) >= 1) n_dev = std::min(n_dev, atoi(getenv("THJ_GPUS"))); }
+        for (int d = 0; d < n_dev; ++d) {
+            gpus.emplace_back(new Gpu());
+            Gpu& g = *gpus.back();
+            g.device = first + d;
+            g.fut = std::async(std::launch::async, [dev = g.device]() {
+                thj_ctx* c = nullptr;
+                if (thj_ctx_create(dev, nullptr, &c)) die("Error: %s\n", thj_last_error());
+                return c;
+            });
+        }
+    }
+    const int n_gpus = (int)gpus.size();
 
     RefTable rt;
     rt.load_sam_header(o.sam_header);
@@ -103,180 +225,191 @@ int main(int argc, char** argv) {
         if (i && ins[i].ref == ins[i - 1].ref && ins[i].left == ins[i - 1].left && ins[i].len == ins[i - 1].len) continue;
         ins_tab.insert(ins_tab.end(), {ins[i].ref, ins[i].left, ins[i].len, ins[i].seq});
     }
-
-    g_timer.lap("junction / indel lists");
-    // HIP start-up (0.15-0.25 s) runs beside the first batch's ingest: the context is created on its own thread and
-    // picked up -- with the genome and the sets going up then -- the first time the device is needed.
-    int device = getenv("THJ_DEVICE") ? atoi(getenv("THJ_DEVICE")) : 0;
-    thj_ctx* ctx = nullptr;
-    std::future<thj_ctx*> ctx_future = std::async(std::launch::async, [device]() {
-        thj_ctx* c = nullptr;
-        if (thj_ctx_create(device, nullptr, &c)) die("Error: %s\n", thj_last_error());
-        return c;
-    });
-    auto ensure_device = [&]() {
-        if (ctx) return;
-        ctx = ctx_future.get();
-        g_timer.lap("device context (what was not hidden by ingest)");
-        rt.upload(ctx);
-        g_timer.lap("genome pack + upload");
-        // junctions on contigs the device genome does not know cannot be closed anyway: drop them
+    for (auto& f : segs) register_targets(f, rt);
+    rt.freeze();
+    {   // junctions on contigs the device genome does not know cannot be closed anyway: drop them
         std::vector<thj_junction> keep;
-        for (auto& j : juncs) if (j.ref_id <= rt.names.size() && (j.right - j.left) < (1u << 29)) keep.push_back(j);
+        for (auto& j : juncs) if (j.ref_id >= 1 && j.ref_id <= rt.names.size() && (j.right - j.left) < (1u << 29)) keep.push_back(j);
         juncs.swap(keep);
-        if (thj_span_sets_upload(ctx, juncs.data(), (int64_t)juncs.size(), ins_tab.data(), (int64_t)ins_tab.size() / 4)) die("Error: %s\n", thj_last_error());
-        if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+    }
+    g_timer.lap("junction / indel lists");
+
+    // HIP start-up (0.15-0.25 s) runs beside the first shards' ingest: a GPU's context is picked up -- with the genome and
+    // the sets going up then -- the first time a worker needs that device (under the GPU's lock).
+    auto device_ready = [&](Gpu& g) -> thj_ctx* {
+        if (g.ctx) return g.ctx;
+        g.ctx = g.fut.get();
+        rt.upload(g.ctx);
+        if (thj_span_sets_upload(g.ctx, juncs.data(), (int64_t)juncs.size(), ins_tab.data(), (int64_t)ins_tab.size() / 4)) die("Error: %s\n", thj_last_error());
+        if (thj_span_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
+        return g.ctx;
     };
 
     const int nseg = (int)segs.size();
-    std::vector<HitStream> st((size_t)nseg);
-    for (int s = 0; s < nseg; ++s)
-        if (!st[(size_t)s].open(segs[(size_t)s], rt, o.p)) die("Error opening SAM file %s\n", segs[(size_t)s].c_str());
-    // junction-db ("spliced") segment maps: SplicedBAMHitFactory streams, one per segment (:3110-3123)
-    std::vector<HitStream> sst(spliced_segs.size());
-    for (size_t s = 0; s < spliced_segs.size(); ++s)
-        if (!sst[s].open(spliced_segs[s], rt, o.p, true)) die("Error opening SAM file %s\n", spliced_segs[s].c_str());
-    ReadStream reads;
-    if (!reads.open(pos[1], o.zpacker)) die("Error: cannot open %s for reading\n", pos[1].c_str());
-
-    // ---- BAM output (print_bamhit, bwt_map.cpp:1888-2093).  One output file: every batch's records are written as soon
-    // as they come back (worker threads encode and deflate).  -p N => <base>{0..N-1}.bam (long_spanning_reads.cpp:
-    // 3056-3064): the records are kept and cut into N files at read boundaries at the end.
     const std::string out = pos[6];
-    const int parts = o.num_threads > 1 ? o.num_threads : 1;
-    BamWriter bw1;
-    if (parts == 1 && !bw1.open(out, rt, out + ".index")) die("Error: could not create BAM file %s!\n", out.c_str());
-    std::vector<Read> all_reads;                 // reads of the current batch (parts == 1) or of the run (parts > 1)
-    std::vector<thj_aln> alns;
-    auto write_range = [&](BamWriter& bw, const std::vector<thj_aln>& alns, const std::vector<Read>& all_reads, size_t a0, size_t a1) {
-        bw.write_records(a1 - a0, [&](size_t i, std::vector<uint8_t>& d) -> long {
-            const thj_aln& a = alns[a0 + i];
-            const Read& rd = all_reads[a.read_idx];
-            int rlen = 0, indel = 0; bool spliced = false;
-            for (int k = 0; k < a.n_cigar; ++k) {
-                uint32_t op = a.cigar[k] >> 28, len = a.cigar[k] & 0x0FFFFFFF;
-                if (op == 1 || op == 2 || op == 3 || op == 4 || op == 13) rlen += (int)len;
-                if (op >= 3 && op <= 6) indel += (int)len;
-                if (op == 11 || op == 12) spliced = true;
-            }
-            std::string seq = rd.seq, qual = rd.qual;
-            seq.resize((size_t)rlen); qual.resize((size_t)rlen);
-            uint32_t flag = 0;
-            if (a.flags & THJ_HIT_ANTISENSE) { flag |= 0x10; reverse_complement(seq); std::reverse(qual.begin(), qual.end()); }
-            std::vector<std::string> aux;
-            aux.push_back("AS:i:" + std::to_string((int)a.AS));
-            aux.push_back("XM:i:" + std::to_string((int)a.XM));
-            aux.push_back("XO:i:" + std::to_string((int)a.XO));
-            aux.push_back("XG:i:" + std::to_string((int)a.XG));
-            aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
-            aux.push_back("NM:i:" + std::to_string((int)a.mismatches + indel));
-            if (spliced) aux.push_back(std::string("XS:A:") + ((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'));
-            bw.encode(d, rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
-            return atol(rd.name.c_str());
-        });
-    };
-
-    // one output file: a writer thread encodes / deflates / writes batch k while the main thread ingests batch k+1
-    std::thread writer;
-    std::vector<Read> w_reads; std::vector<thj_aln> w_alns;
-    auto writer_join = [&]() { if (writer.joinable()) writer.join(); };
-
-    size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 19;
-    std::vector<uint32_t> seg_off; std::vector<thj_span_hit> hits; std::vector<int64_t> read_off; std::string bases, quals;
-    size_t max_len = 0; size_t batch_first = 0;
-    auto reset = [&]() { seg_off.assign(1, 0); hits.clear(); read_off.assign(1, 0); bases.clear(); quals.clear(); max_len = 0; batch_first = all_reads.size(); };
-    auto flush = [&]() {
-        int64_t n = (int64_t)read_off.size() - 1;
-        if (n == 0) return;
-        g_timer.lap("ingest (parse + merge by id)");
-        ensure_device();
-        int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
-        std::vector<uint64_t> planes((size_t)n * 3 * W);
-        std::vector<uint16_t> lens((size_t)n);
-        if (thj_reads_pack(n, read_off.data(), bases.data(), W, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
-        int stride = (int)((max_len + 3) / 4 * 4);
-        std::vector<uint8_t> q((size_t)n * stride, 0);
-        for (int64_t r = 0; r < n; ++r) memcpy(q.data() + (size_t)r * stride, quals.data() + read_off[(size_t)r], (size_t)(read_off[(size_t)r + 1] - read_off[(size_t)r]));
-        thj_span_batch hb{};
-        hb.n_reads = (int32_t)n; hb.nseg = nseg; hb.words_per_plane = W; hb.qual_stride = stride;
-        hb.seg_off = seg_off.data(); hb.hits = hits.data(); hb.read_planes = planes.data(); hb.read_len = lens.data(); hb.quals = q.data();
-        thj_span_batch* dev = nullptr;
-        if (thj_span_batch_upload(ctx, &hb, (int64_t)hits.size(), &dev)) die("Error: %s\n", thj_last_error());
-        if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-        if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
-        int64_t na = 0;
-        if (thj_span_finish(ctx, &na)) die("Error: %s\n", thj_last_error());
-        size_t base = alns.size();
-        alns.resize(base + (size_t)na);
-        if (na && thj_span_download(ctx, alns.data() + base)) die("Error: %s\n", thj_last_error());
-        for (size_t k = base; k < alns.size(); ++k) alns[k].read_idx += (uint32_t)batch_first;      // -> index into all_reads
-        if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
-        g_timer.lap("pack + upload + stitch + download");
-        if (parts == 1) {
-            writer_join();                          // batch k-1 is on disk (time spent here = the writer is the bottleneck)
-            w_alns.swap(alns); w_reads.swap(all_reads);
-            alns.clear(); all_reads.clear();
-            writer = std::thread([&]() { write_range(bw1, w_alns, w_reads, 0, w_alns.size()); });
-            g_timer.lap("wait for the BAM writer thread");
-        }
-        reset();
-    };
-    reset();
-    // the worker iterates over first-segment groups (long_spanning_reads.cpp:2706-2765); segments to the right are
-    // looked up by id (look_right_for_hit_group :87-163; the kernel stops at the first empty segment as it does)
-    std::vector<Hit> g;
-    for (;;) {
-        // first-segment groups of the contig and the spliced stream, merged by id (:2706-2765)
-        uint32_t id = st[0].next_group_id();
-        if (!sst.empty()) { uint32_t sid = sst[0].next_group_id(); if (sid && (id == 0 || sid < id)) id = sid; }
-        if (id == 0) break;
-        Read rd;
-        if (!reads.get(id, rd)) die("Error: could not get read # %d from stream\n", (int)id);
-        for (int s = 0; s < nseg; ++s) {
-            g.clear();
-            if (s > 0) while (st[(size_t)s].next_group_id() && st[(size_t)s].next_group_id() < id) st[(size_t)s].skip_group();
-            if (st[(size_t)s].next_group_id() == id) st[(size_t)s].next_group(g);
-            if ((size_t)s < sst.size()) {            // spliced hits are appended after the contig hits (:125-147, :2738-2744)
-                while (sst[(size_t)s].next_group_id() && sst[(size_t)s].next_group_id() < id) sst[(size_t)s].skip_group();
-                if (sst[(size_t)s].next_group_id() == id) sst[(size_t)s].next_group(g);
-            }
-            for (auto& h : g) hits.push_back(h.h32);
-            seg_off.push_back((uint32_t)hits.size());
-        }
-        bases += rd.seq; quals += rd.qual;
-        read_off.push_back((int64_t)bases.size());
-        if (rd.seq.size() > max_len) max_len = rd.seq.size();
-        all_reads.push_back(std::move(rd));
-        if (read_off.size() - 1 >= batch_reads) flush();
+    // ---- the shard plan.  -p N: the reference's N ranges, one output file each.  One output file: our own number of shards,
+    // written in order.
+    const int hw = (int)std::thread::hardware_concurrency();
+    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 6));
+    if (workers < 1) workers = 1;
+    int parts = o.num_threads > 1 ? o.num_threads : 1;
+    std::vector<Shard> shards;
+    if (parts > 1) {
+        shards = plan(pos[1], segs, spliced_segs, parts);
+        if ((int)shards.size() != parts) { shards.resize(1); shards[0] = Shard(); shards[0].seg_off.assign(segs.size(), 0); shards[0].spliced_off.assign(spliced_segs.size(), 0); parts = 1; }   // not enough data: one thread (:2992-2993)
     }
-    flush();
-    g_timer.lap("ingest (parse + merge by id)");
+    if (parts == 1) shards = plan(pos[1], segs, spliced_segs, getenv("THJ_SHARDS") ? atoi(getenv("THJ_SHARDS")) : 4 * workers);
+    const size_t S = shards.size();
+    fprintf(stderr, "\t%d read-id shard%s, %d host workers, %d GPU%s\n", (int)S, S > 1 ? "s" : "", workers, n_gpus, n_gpus > 1 ? "s" : "");
 
-    if (parts == 1) { writer_join(); bw1.close(); g_timer.lap("wait for the BAM writer thread"); }
-    else {
-        std::vector<size_t> cut((size_t)parts + 1, alns.size());
-        cut[0] = 0;
-        for (int k = 1; k < parts; ++k) {
-            size_t c = alns.size() * (size_t)k / (size_t)parts;
-            while (c > 0 && c < alns.size() && alns[c].read_idx == alns[c - 1].read_idx) ++c;      // never split a read
-            cut[(size_t)k] = c;
-        }
-        for (int k = 0; k < parts; ++k) {
+    std::vector<std::unique_ptr<BamWriter>> bws;
+    if (parts == 1) {
+        bws.emplace_back(new BamWriter());
+        if (!bws[0]->open(out, rt, out + ".index")) die("Error: could not create BAM file %s!\n", out.c_str());
+    } else {
+        for (int k = 0; k < parts; ++k) {                      // long_spanning_reads.cpp:3056-3064
             std::string fn = out.substr(0, out.size() >= 4 ? out.size() - 4 : out.size()) + std::to_string(k) + ".bam";
-            BamWriter bw;
-            if (!bw.open(fn, rt, fn + ".index")) die("Error: could not create BAM file %s!\n", fn.c_str());
-            write_range(bw, alns, all_reads, cut[(size_t)k], cut[(size_t)k + 1]);
-            bw.close();
+            bws.emplace_back(new BamWriter());
+            if (!bws.back()->open(fn, rt, fn + ".index")) die("Error: could not create BAM file %s!\n", fn.c_str());
         }
-        g_timer.lap("BAM output (encode + BGZF)");
     }
-    if (!ctx) ctx = ctx_future.get();             // nothing to process: the context was never needed
-    thj_ctx_destroy(ctx);
-    g_timer.lap("teardown");
+    std::vector<std::unique_ptr<OutShard>> outq;
+    for (size_t k = 0; k < S; ++k) outq.emplace_back(new OutShard());
+    std::mutex win_mu; std::condition_variable win_cv;
+    size_t writer_pos = 0;                                     // shards before this one are on disk
+    const size_t LOOKAHEAD = (size_t)workers + 2;
+    const size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 19;
+    const int enc_threads = S == 1 ? host_threads() : 1;       // many shards: the workers are the parallelism
+
+    // JoinSegmentsWorker (long_spanning_reads.cpp:2669-2845) for one shard
+    auto run_shard = [&](size_t k) {
+        const Shard& sh = shards[k];
+        Gpu& gpu = *gpus[k % (size_t)n_gpus];
+        const BamWriter& enc_bw = *bws[parts == 1 ? 0 : k];
+        std::vector<HitStream> st((size_t)nseg);
+        for (int s = 0; s < nseg; ++s)
+            if (!st[(size_t)s].open(segs[(size_t)s], rt, o.p, false, sh.seg_off[(size_t)s], sh.begin_id, sh.end_id))
+                die("Error opening SAM file %s\n", segs[(size_t)s].c_str());
+        // junction-db ("spliced") segment maps: SplicedBAMHitFactory streams, one per segment (:3110-3123)
+        std::vector<HitStream> sst(spliced_segs.size());
+        for (size_t s = 0; s < spliced_segs.size(); ++s)
+            if (!sst[s].open(spliced_segs[s], rt, o.p, true, sh.spliced_off[s], sh.begin_id, sh.end_id)) die("Error opening SAM file %s\n", spliced_segs[s].c_str());
+        ReadStream reads;
+        if (!reads.open(pos[1], o.zpacker, sh.read_off)) die("Error: cannot open %s for reading\n", pos[1].c_str());
+        std::vector<Read> batch_rd;
+        std::vector<uint32_t> seg_off; std::vector<thj_span_hit> hits; std::vector<int64_t> read_off; std::string bases, quals;
+        size_t max_len = 0;
+        auto reset = [&]() { seg_off.assign(1, 0); hits.clear(); read_off.assign(1, 0); bases.clear(); quals.clear(); max_len = 0; batch_rd.clear(); };
+        auto flush = [&]() {
+            int64_t n = (int64_t)read_off.size() - 1;
+            if (n == 0) return;
+            int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
+            std::vector<uint64_t> planes((size_t)n * 3 * W);
+            std::vector<uint16_t> lens((size_t)n);
+            if (thj_reads_pack(n, read_off.data(), bases.data(), W, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
+            int stride = (int)((max_len + 3) / 4 * 4);
+            std::vector<uint8_t> q((size_t)n * stride, 0);
+            for (int64_t r = 0; r < n; ++r) memcpy(q.data() + (size_t)r * stride, quals.data() + read_off[(size_t)r], (size_t)(read_off[(size_t)r + 1] - read_off[(size_t)r]));
+            thj_span_batch hb{};
+            hb.n_reads = (int32_t)n; hb.nseg = nseg; hb.words_per_plane = W; hb.qual_stride = stride;
+            hb.seg_off = seg_off.data(); hb.hits = hits.data(); hb.read_planes = planes.data(); hb.read_len = lens.data(); hb.quals = q.data();
+            std::vector<thj_aln> alns;
+            {
+                std::lock_guard<std::mutex> lk(gpu.mu);
+                thj_ctx* ctx = device_ready(gpu);
+                thj_span_batch* dev = nullptr;
+                if (thj_span_batch_upload(ctx, &hb, (int64_t)hits.size(), &dev)) die("Error: %s\n", thj_last_error());
+                if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+                if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
+                int64_t na = 0;
+                if (thj_span_finish(ctx, &na)) die("Error: %s\n", thj_last_error());
+                alns.resize((size_t)na);
+                if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
+                if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+            }
+            BamWriter::Encoded e;
+            encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
+            if (parts > 1) bws[k]->write_encoded(e);         // this part's own file
+            else {
+                OutShard& oq = *outq[k];
+                std::unique_lock<std::mutex> lk(oq.mu);
+                oq.cv.wait(lk, [&] { return oq.q.size() < 2; });
+                oq.q.push_back(std::move(e));
+                oq.cv.notify_all();
+            }
+            reset();
+        };
+        reset();
+        // the worker iterates over first-segment groups (long_spanning_reads.cpp:2706-2765); segments to the right are
+        // looked up by id (look_right_for_hit_group :87-163; the kernel stops at the first empty segment as it does)
+        std::vector<Hit> g;
+        for (;;) {
+            // first-segment groups of the contig and the spliced stream, merged by id (:2706-2765)
+            uint32_t id = st[0].next_group_id();
+            if (!sst.empty()) { uint32_t sid = sst[0].next_group_id(); if (sid && (id == 0 || sid < id)) id = sid; }
+            if (id == 0) break;
+            Read rd;
+            if (!reads.get(id, rd)) die("Error: could not get read # %d from stream\n", (int)id);
+            for (int s = 0; s < nseg; ++s) {
+                g.clear();
+                if (s > 0) while (st[(size_t)s].next_group_id() && st[(size_t)s].next_group_id() < id) st[(size_t)s].skip_group();
+                if (st[(size_t)s].next_group_id() == id) st[(size_t)s].next_group(g);
+                if ((size_t)s < sst.size()) {            // spliced hits are appended after the contig hits (:125-147, :2738-2744)
+                    while (sst[(size_t)s].next_group_id() && sst[(size_t)s].next_group_id() < id) sst[(size_t)s].skip_group();
+                    if (sst[(size_t)s].next_group_id() == id) sst[(size_t)s].next_group(g);
+                }
+                for (auto& h : g) hits.push_back(h.h32);
+                seg_off.push_back((uint32_t)hits.size());
+            }
+            bases += rd.seq; quals += rd.qual;
+            read_off.push_back((int64_t)bases.size());
+            if (rd.seq.size() > max_len) max_len = rd.seq.size();
+            batch_rd.push_back(std::move(rd));
+            if (read_off.size() - 1 >= batch_reads) flush();
+        }
+        flush();
+        if (parts == 1) { OutShard& oq = *outq[k]; std::lock_guard<std::mutex> lk(oq.mu); oq.done = true; oq.cv.notify_all(); }
+    };
+
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= S) return;
+            if (parts == 1) { std::unique_lock<std::mutex> lk(win_mu); win_cv.wait(lk, [&] { return k < writer_pos + LOOKAHEAD; }); }
+            run_shard(k);
+        }
+    };
+    const int nthr = (int)std::min<size_t>((size_t)workers, S);
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; ++t) th.emplace_back(work);
+    if (parts == 1) {
+        // the writer: shard after shard, batch after batch -- deflate runs on worker threads inside write_encoded
+        for (size_t k = 0; k < S; ++k) {
+            OutShard& oq = *outq[k];
+            for (;;) {
+                BamWriter::Encoded e;
+                {
+                    std::unique_lock<std::mutex> lk(oq.mu);
+                    oq.cv.wait(lk, [&] { return !oq.q.empty() || oq.done; });
+                    if (oq.q.empty()) break;
+                    e = std::move(oq.q.front());
+                    oq.q.pop_front();
+                    oq.cv.notify_all();
+                }
+                bws[0]->write_encoded(e);
+            }
+            { std::lock_guard<std::mutex> lk(win_mu); writer_pos = k + 1; }
+            win_cv.notify_all();
+        }
+    }
+    for (auto& t : th) t.join();
+    g_timer.lap("ingest + stitch + encode + write (all shards)");
+    for (auto& bw : bws) bw->close();
+    g_timer.lap("BAM close");
     g_timer.report();
-    (void)OPCH;
-    // Everything is written and closed.  Leave without running the exit handlers: tearing the HIP runtime down after a
-    // context has been used takes ~0.2 s that nobody is waiting for.
+    // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
+    // runtime down after a context has been used takes ~0.2 s that nobody is waiting for.
     fflush(nullptr);
     _exit(0);
 }

@@ -1,7 +1,13 @@
 // segment_juncs -- MI355X-native drop-in for TopHat's segment_juncs (same argv + files; tophat.py:3097-3112,
 // parsed like segment_juncs.cpp:5186-5364).  Host C++ over the C ABI in include/thj.h; all per-read work runs in
-// the HIP kernels of libthj_hip.so.  Split-segment search, small indels, the paired-end rescue and --fusion-search
-// are supported; coverage / microexon / butterfly searches are refused loudly.
+// the HIP kernels of libthj_hip.so.  Split-segment search, small indels, the paired-end rescue, --fusion-search and the
+// coverage search are supported; microexon / butterfly searches are refused loudly.
+//
+// One process drives every visible GPU.  The reads are cut into contiguous read-id shards with the
+// reference's own planner (calculate_offsets over the inputs' .index files, utils.cpp:22-170; segment_juncs.cpp:4756-4810);
+// host workers ingest the shards in parallel, shard k runs on GPU k mod n, and when all are done the per-GPU event sets
+// are united by ONE RCCL all-gather (thj_events_allgather_async) -- segment_juncs.cpp:4911-4922 across GPUs.  GPU 0's
+// sets are written.  The result does not depend on the number of shards or GPUs.
 #include "thj_hostio.h"
 
 using namespace thjh;
@@ -12,7 +18,6 @@ static void print_usage() {
                     "[right_reads.fq right_reads.bwtout right_seg1.bwtout,...,right_segN.bwtout]\n");
 }
 
-static const char* CODE = "ACGTN";
 static PhaseTimer g_timer;
 
 struct SideInput {
@@ -20,32 +25,86 @@ struct SideInput {
     std::vector<std::string> segs;
 };
 
-// One side (segment_juncs.cpp:4776-4905): walk the nseg id-sorted segment maps in increasing id order -- the
-// visiting order of look_for_hit_group (segment_juncs.cpp:3823-4123; derivation in tophat_amd/batch.py) --
-// join the mate's maps by id (find_gaps :3321-3348), batch, run.
-// Both sides are ingested at the same time (two host threads, each with its own reader threads); the device calls of
-// a batch are serialised by `dev_mu`.  `ordinal` = visiting ordinal of the side's first read: the reference visits the
-// left side first (segment_juncs.cpp:4776-4905), so the right side starts at RIGHT_ORDINAL_BASE.
-static std::mutex dev_mu;
+// one GPU: its context (created on a side thread while the first shards are parsed) and the lock that serialises the
+// device calls of the host workers feeding it
+struct Gpu {
+    int device = 0;
+    thj_ctx* ctx = nullptr;
+    std::future<thj_ctx*> fut;
+    std::mutex mu;
+};
+
+struct Shard {
+    uint64_t begin_id = 0, end_id = ~0ull;
+    int64_t read_off = 0;
+    std::vector<int64_t> seg_off;                   // one per segment map
+    int64_t partner_off = 0, seg_partner_off = 0;   // the mate's whole-read map / last segment map
+};
+
+// the reference's shard plan for one side: calculate_offsets over {reads, segment maps} + calculate_offsets_from_ids for the
+// mate's two maps (segment_juncs.cpp:4756-4775); one shard when an input has no usable index
+static std::vector<Shard> plan_side(const SideInput& in, const SideInput* mate, int want) {
+    std::vector<Shard> out(1);
+    out[0].seg_off.assign(in.segs.size(), 0);
+    if (want < 2 || in.segs.empty()) return out;
+    std::vector<IndexList> lists(1 + in.segs.size());
+    load_index(in.reads, want * 4, lists[0]);
+    for (size_t s = 0; s < in.segs.size(); ++s) load_index(in.segs[s], want * 4, lists[1 + s]);
+    std::vector<uint64_t> ids; std::vector<std::vector<int64_t>> offs;
+    size_t smallest = ~(size_t)0;
+    for (auto& l : lists) smallest = std::min(smallest, l.size());
+    if ((size_t)want > smallest) want = (int)smallest;
+    if (!calculate_offsets(lists, want, ids, offs)) return out;
+    std::vector<int64_t> po, spo;
+    if (mate) {
+        IndexList l;
+        if (!mate->map.empty()) { load_index(mate->map, want * 4, l); calculate_offsets_from_ids(l, ids, po); }
+        l.clear();
+        if (!mate->segs.empty()) { load_index(mate->segs.back(), want * 4, l); calculate_offsets_from_ids(l, ids, spo); }
+    }
+    out.assign((size_t)want, Shard());
+    for (int i = 0; i < want; ++i) {
+        Shard& sh = out[(size_t)i];
+        if (i == 0) sh.seg_off.assign(in.segs.size(), 0);
+        else {
+            sh.begin_id = ids[(size_t)i - 1];
+            sh.read_off = offs[(size_t)i - 1][0];
+            sh.seg_off.assign(offs[(size_t)i - 1].begin() + 1, offs[(size_t)i - 1].end());
+            if (!po.empty()) sh.partner_off = po[(size_t)i - 1];
+            if (!spo.empty()) sh.seg_partner_off = spo[(size_t)i - 1];
+        }
+        sh.end_id = i + 1 < want ? ids[(size_t)i] : ~0ull;
+    }
+    return out;
+}
+
+// One shard of one side (SegmentSearchWorker, segment_juncs.cpp:4548-4672): walk the nseg id-sorted segment maps in
+// increasing id order -- the visiting order of look_for_hit_group (segment_juncs.cpp:3823-4123; derivation in
+// tophat_amd/batch.py) -- join the mate's maps by id (find_gaps :3321-3348), batch, run.
+// `ordinal` = first-inserted-wins priority of the shard's first read (std::set<Insertion>, insertions.h:52-67): the reference
+// inserts all left reads before all right reads and, inside a side, in read-id order (thread sets are merged in thread
+// order, :4911-4916).  A shard starts at its begin_id -- ids are distinct and increasing, so begin_id + k never exceeds the
+// id of the shard's k-th visited read and every shard's ordinals stay below the next shard's.
 static constexpr uint32_t RIGHT_ORDINAL_BASE = 1u << 28;
-static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, RefTable& rt, const SideInput& in, const SideInput* mate, int read_side,
-                     uint32_t ordinal, uint32_t ordinal_limit, size_t batch_reads) {
+static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gpu, Opts& o, RefTable& rt, const SideInput& in,
+                      const SideInput* mate, int read_side, const Shard& sh, uint32_t ordinal, uint32_t ordinal_limit, size_t batch_reads) {
     const int nseg = (int)in.segs.size();
     // one segment map: no segment search (segment_juncs.cpp:4752 `size() > 1`), but its hits still belong to the coverage
     // map (all_segmap_fnames :4929-4935)
     if (nseg < 1 || (nseg == 1 && o.no_coverage_search)) return;
     std::vector<HitStream> st((size_t)nseg);
     for (int s = 0; s < nseg; ++s)
-        if (!st[(size_t)s].open(in.segs[(size_t)s], rt, o.p)) die("Error opening SAM file %s\n", in.segs[(size_t)s].c_str());
+        if (!st[(size_t)s].open(in.segs[(size_t)s], rt, o.p, false, sh.seg_off[(size_t)s], sh.begin_id, sh.end_id))
+            die("Error opening SAM file %s\n", in.segs[(size_t)s].c_str());
     HitStream mate_full, mate_last;
     bool have_mate = false;
     if (mate && !mate->segs.empty()) {
-        bool a = !mate->map.empty() && mate_full.open(mate->map, rt, o.p);
-        bool b = mate_last.open(mate->segs.back(), rt, o.p);
+        bool a = !mate->map.empty() && mate_full.open(mate->map, rt, o.p, false, sh.partner_off, sh.begin_id, sh.end_id);
+        bool b = mate_last.open(mate->segs.back(), rt, o.p, false, sh.seg_partner_off, sh.begin_id, sh.end_id);
         have_mate = a || b;
     }
     ReadStream reads;
-    if (!reads.open(in.reads, o.zpacker)) die("Error: cannot open %s for reading\n", in.reads.c_str());
+    if (!reads.open(in.reads, o.zpacker, sh.read_off)) die("Error: cannot open %s for reading\n", in.reads.c_str());
 
     thj_params p = o.p;
     p.read_side = read_side;
@@ -59,7 +118,8 @@ static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, Ref
         int64_t n = (int64_t)read_off.size() - 1;
         if (n == 0) return;
         if ((uint64_t)ordinal + (uint64_t)n > ordinal_limit)
-            die("Error: too many reads on the %s side for the device's read ordinals (limit %u)\n", read_side == 1 ? "left" : "right", ordinal_limit);
+            die("Error: too many reads on the %s side for the device's read ordinals (read ids must stay below %u)\n", read_side == 1 ? "left" : "right",
+                RIGHT_ORDINAL_BASE);
         int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
         std::vector<uint64_t> planes((size_t)n * 3 * W);
         std::vector<uint16_t> lens((size_t)n);
@@ -70,8 +130,8 @@ static void run_side(const std::function<thj_ctx*()>& device_ready, Opts& o, Ref
         if (have_mate) { hb.mate_off = mate_off.data(); hb.mate_hits = mate_hits.data(); }
         hb.ordinal_base = ordinal;
         {
-            std::lock_guard<std::mutex> lk(dev_mu);
-            thj_ctx* ctx = device_ready();
+            std::lock_guard<std::mutex> lk(gpu.mu);
+            thj_ctx* ctx = device_ready(gpu);
             thj_seg_batch* dev = nullptr;
             if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
             if (nseg > 1 && thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
@@ -143,43 +203,57 @@ int main(int argc, char** argv) {
     FILE* fd = fopen(pos[3].c_str(), "w"); if (!fd) die("Error: cannot open %s for writing\n", pos[3].c_str());
     FILE* ff = fopen(pos[4].c_str(), "w"); if (!ff) die("Error: cannot open %s for writing\n", pos[4].c_str());
 
+    // ---- GPUs: every visible one (THJ_GPUS caps the count, THJ_DEVICE picks a single device).  HIP start-up runs beside the
+    // FASTA load and the first shards' ingest: each context is created on its own thread and picked up -- with the genome
+    // going up then -- by the first worker that needs the device (under the GPU's lock).
+    std::vector<std::unique_ptr<Gpu>> gpus;
+    {
+        int n_dev = 1, first = 0;
+        if (getenv("THJ_DEVICE")) first = atoi(getenv("THJ_DEVICE"));
+        else { n_dev = thj_device_count(); if (n_dev < 1) die("Error: %s\n", thj_last_error()); if (getenv("THJ_GPUS") && atoi(getenv("THJ_GPUS")) >= 1) n_dev = std::min(n_dev, atoi(getenv("THJ_GPUS"))); }
+        for (int d = 0; d < n_dev; ++d) {
+            gpus.emplace_back(new Gpu());
+            Gpu& g = *gpus.back();
+            g.device = first + d;
+            g.fut = std::async(std::launch::async, [dev = g.device]() {
+                thj_ctx* c = nullptr;
+                if (thj_ctx_create(dev, nullptr, &c)) die("Error: %s\n", thj_last_error());
+                return c;
+            });
+        }
+    }
+    const int n_gpus = (int)gpus.size();
+
     RefTable rt;
     rt.load_sam_header(o.sam_header);
     fprintf(stderr, "Loading reference sequences...\n");
     rt.load_fasta(pos[0]);
+    for (const SideInput* sd : {&left, &right}) { register_targets(sd->map, rt); for (auto& f : sd->segs) register_targets(f, rt); }
+    std::vector<uint32_t> fusion_ignore_ids;
+    if (o.fusion_search && !o.fusion_ignore.empty())                   // segment_juncs.cpp:3214-3219
+        for (auto& nm : split(o.fusion_ignore, ',')) if (!nm.empty()) fusion_ignore_ids.push_back(rt.get_id(nm));
+    rt.freeze();
     g_timer.lap("options + reference FASTA");
 
-    // HIP start-up runs beside the first batches' ingest: the context is created on its own thread and picked up -- with
-    // the genome going up then -- by whichever side needs the device first (under dev_mu).
-    int device = getenv("THJ_DEVICE") ? atoi(getenv("THJ_DEVICE")) : 0;
-    thj_ctx* ctx = nullptr;
-    std::future<thj_ctx*> ctx_future = std::async(std::launch::async, [device]() {
-        thj_ctx* c = nullptr;
-        if (thj_ctx_create(device, nullptr, &c)) die("Error: %s\n", thj_last_error());
-        return c;
-    });
-    std::function<thj_ctx*()> device_ready = [&]() -> thj_ctx* {          // call with dev_mu held
-        if (ctx) return ctx;
-        ctx = ctx_future.get();
-        rt.upload(ctx);
-        if (thj_segjuncs_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-        if (o.fusion_search && thj_fusion_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-        if (!o.no_coverage_search && thj_covsearch_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-        if (o.fusion_search && !o.fusion_ignore.empty()) {                 // segment_juncs.cpp:3214-3219
-            std::vector<uint32_t> ids;
-            for (auto& nm : split(o.fusion_ignore, ',')) if (!nm.empty()) ids.push_back(rt.get_id(nm));
-            if (thj_fusion_set_ignored(ctx, ids.data(), (int32_t)ids.size())) die("Error: %s\n", thj_last_error());
-        }
-        return ctx;
+    std::function<thj_ctx*(Gpu&)> device_ready = [&](Gpu& g) -> thj_ctx* {          // call with g.mu held
+        if (g.ctx) return g.ctx;
+        g.ctx = g.fut.get();
+        rt.upload(g.ctx);
+        if (thj_segjuncs_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
+        if (o.fusion_search && thj_fusion_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
+        if (!o.no_coverage_search && thj_covsearch_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
+        if (!fusion_ignore_ids.empty() && thj_fusion_set_ignored(g.ctx, fusion_ignore_ids.data(), (int32_t)fusion_ignore_ids.size())) die("Error: %s\n", thj_last_error());
+        return g.ctx;
     };
     size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 20;
     // ---- coverage search, part 1 (segment_juncs.cpp:4955-4982): the extension table of the initially unmapped reads
     // (index_read_mers :548-571 -- the first 32 bases of every read) is fed to the device on its own thread while the
-    // two sides are being ingested
+    // two sides are being ingested (chunks go round the GPUs; the exchange step concatenates the tables anyway)
     std::thread ium_thread;
     if (!o.no_coverage_search)
         ium_thread = std::thread([&]() {
             const size_t CH = (size_t)1 << 19;
+            size_t turn = 0;
             for (auto& fn : split(o.ium_reads, ',')) {
                 if (fn.empty()) continue;
                 ReadStream rs;
@@ -191,8 +265,9 @@ int main(int argc, char** argv) {
                     std::vector<uint64_t> planes((size_t)n * 3); std::vector<uint16_t> lens((size_t)n);
                     if (thj_reads_pack(n, off.data(), bases.data(), 1, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
                     {
-                        std::lock_guard<std::mutex> lk(dev_mu);
-                        if (thj_covsearch_add_reads(device_ready(), n, 1, planes.data(), lens.data(), 0)) die("Error: %s\n", thj_last_error());
+                        Gpu& g = *gpus[turn++ % gpus.size()];
+                        std::lock_guard<std::mutex> lk(g.mu);
+                        if (thj_covsearch_add_reads(device_ready(g), n, 1, planes.data(), lens.data(), 0)) die("Error: %s\n", thj_last_error());
                     }
                     bases.clear(); off.assign(1, 0);
                 };
@@ -206,35 +281,95 @@ int main(int argc, char** argv) {
             }
         });
     fprintf(stderr, ">> Performing segment-search:\n");
-    const uint32_t ORD_END = (1u << 29) - 1;                 // device limit on read ordinals
-    if (right.segs.empty()) run_side(device_ready, o, rt, left, nullptr, 1, 0, ORD_END, batch_reads);
-    else if (getenv("THJ_SIDES_SEQUENTIAL")) {               // one side after the other (less host memory in flight)
-        run_side(device_ready, o, rt, left, &right, 1, 0, RIGHT_ORDINAL_BASE, batch_reads);
-        run_side(device_ready, o, rt, right, &left, 2, RIGHT_ORDINAL_BASE, ORD_END, batch_reads);
-    } else {
-        std::thread tl([&]() { run_side(device_ready, o, rt, left, &right, 1, 0, RIGHT_ORDINAL_BASE, batch_reads); });
-        run_side(device_ready, o, rt, right, &left, 2, RIGHT_ORDINAL_BASE, ORD_END, batch_reads);
-        tl.join();
+    // ---- shards and host workers.  THJ_WORKERS host workers (default: hardware threads / 8 -- every worker keeps one reader
+    // thread per input file busy) take (side, shard) items; -p N asks for at least N shards per side, as in the reference.
+    const int hw = (int)std::thread::hardware_concurrency();
+    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 8));
+    if (workers < 1) workers = 1;
+    int want = getenv("THJ_SHARDS") ? atoi(getenv("THJ_SHARDS")) : std::max(std::max(workers, o.num_threads), n_gpus);
+    struct Item { const SideInput* in; const SideInput* mate; int side; Shard sh; uint32_t ordinal, limit; int gpu; };
+    std::vector<Item> items;
+    {
+        const bool paired = !right.segs.empty();
+        std::vector<Shard> ls = plan_side(left, paired ? &right : nullptr, want);
+        std::vector<Shard> rs = paired ? plan_side(right, &left, want) : std::vector<Shard>();
+        // both sides of a read pair have the same id: interleave the sides so that the sets a GPU builds grow evenly
+        for (size_t k = 0; k < std::max(ls.size(), rs.size()); ++k) {
+            if (k < ls.size()) {
+                if (ls[k].begin_id >= RIGHT_ORDINAL_BASE) die("Error: read ids must stay below %u\n", RIGHT_ORDINAL_BASE);
+                items.push_back({&left, paired ? &right : nullptr, 1, ls[k], (uint32_t)ls[k].begin_id, paired ? RIGHT_ORDINAL_BASE : (1u << 29) - 1, 0});
+            }
+            if (k < rs.size()) {
+                if (rs[k].begin_id >= RIGHT_ORDINAL_BASE) die("Error: read ids must stay below %u\n", RIGHT_ORDINAL_BASE);
+                items.push_back({&right, &left, 2, rs[k], RIGHT_ORDINAL_BASE + (uint32_t)rs[k].begin_id, (1u << 29) - 1, 0});
+            }
+        }
+        for (size_t k = 0; k < items.size(); ++k) items[k].gpu = (int)(k % (size_t)n_gpus);
+        fprintf(stderr, "\t%d left + %d right read-id shards, %d host workers, %d GPU%s\n", (int)ls.size(), (int)rs.size(), workers, n_gpus, n_gpus > 1 ? "s" : "");
     }
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= items.size()) return;
+                const Item& it = items[k];
+                run_shard(device_ready, *gpus[(size_t)it.gpu], o, rt, *it.in, it.mate, it.side, it.sh, it.ordinal, it.limit, batch_reads);
+            }
+        };
+        const int nthr = (int)std::min<size_t>((size_t)workers, items.size());
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthr; ++t) th.emplace_back(work);
+        work();
+        for (auto& t : th) t.join();
+    }
+    for (auto& g : gpus) { std::lock_guard<std::mutex> lk(g->mu); device_ready(*g); }
+    g_timer.lap("device start-up + ingest + pack + upload + launch (all shards)");
+    if (!o.no_coverage_search) ium_thread.join();            // the unmapped reads went up beside the segment search
 
-    { std::lock_guard<std::mutex> lk(dev_mu); device_ready(); }
-    g_timer.lap("device start-up + ingest + pack + upload + launch (both sides at once)");
-    int64_t n_cov_juncs = -1;
+    // ---- the exchange step and the end of the pass, one host thread per GPU (each rank's collective calls come from its
+    // own thread, include/thj.h).  With one GPU the same calls run without a communicator.
+    std::vector<thj_comm*> comms((size_t)n_gpus, nullptr);
+    if (n_gpus > 1) {
+        std::vector<thj_ctx*> cs;
+        for (auto& g : gpus) cs.push_back(g->ctx);
+        if (thj_comm_create_local(cs.data(), n_gpus, comms.data())) die("Error: %s\n", thj_last_error());
+    }
+    std::vector<int64_t> n_cov((size_t)n_gpus, -1), n_fus((size_t)n_gpus, 0);
+    std::vector<thj_segjuncs_counts> cnt((size_t)n_gpus);
+    auto end_of_pass = [&](int r) {
+        thj_ctx* ctx = gpus[(size_t)r]->ctx;
+        thj_comm* cm = comms[(size_t)r];
+        if (!o.no_coverage_search) {
+            if (r == 0) fprintf(stderr, ">> Performing coverage-search:\n");
+            if (cm && thj_covsearch_allgather(ctx, cm)) die("Error: %s\n", thj_last_error());
+            int mcl = 20; if (mcl > o.p.segment_length - 2) mcl = o.p.segment_length - 2;          // :62, :5350
+            if (thj_covsearch_run_async(ctx, mcl, o.min_coverage_intron, o.max_coverage_intron)) die("Error: %s\n", thj_last_error());
+            if (thj_covsearch_finish(ctx, 5000000, &n_cov[(size_t)r])) die("Error: %s\n", thj_last_error());        // max_cov_juncs :56
+        }
+        if (cm && thj_events_allgather_async(ctx, cm)) die("Error: %s\n", thj_last_error());
+        if (thj_segjuncs_finish(ctx, &cnt[(size_t)r])) die("Error: %s\n", thj_last_error());
+        if (o.fusion_search) {
+            if (thj_fusion_finish(ctx, &n_fus[(size_t)r])) die("Error: %s\n", thj_last_error());
+            if (cm && thj_fusion_allgather(ctx, cm, &n_fus[(size_t)r])) die("Error: %s\n", thj_last_error());
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int r = 1; r < n_gpus; ++r) th.emplace_back(end_of_pass, r);
+        end_of_pass(0);
+        for (auto& t : th) t.join();
+    }
     if (!o.no_coverage_search) {
-        ium_thread.join();                                   // the unmapped reads went up beside the segment search
-        fprintf(stderr, ">> Performing coverage-search:\n");
-        int mcl = 20; if (mcl > o.p.segment_length - 2) mcl = o.p.segment_length - 2;          // :62, :5350
-        if (thj_covsearch_run_async(ctx, mcl, o.min_coverage_intron, o.max_coverage_intron)) die("Error: %s\n", thj_last_error());
-        if (thj_covsearch_finish(ctx, 5000000, &n_cov_juncs)) die("Error: %s\n", thj_last_error());        // max_cov_juncs :56
-        fprintf(stderr, "\tfound %d potential junctions\n", (int)n_cov_juncs);
+        fprintf(stderr, "\tfound %d potential junctions\n", (int)n_cov[0]);
         g_timer.lap("coverage search (wait for the unmapped reads + device pass)");
     }
-    thj_segjuncs_counts n{};
-    if (thj_segjuncs_finish(ctx, &n)) die("Error: %s\n", thj_last_error());
+    thj_ctx* ctx = gpus[0]->ctx;
+    const thj_segjuncs_counts& n = cnt[0];
     std::vector<thj_junction> j((size_t)n.n_juncs + 1), d((size_t)n.n_deletions + 1);
     std::vector<thj_insertion> ins((size_t)n.n_insertions + 1);
     if (thj_segjuncs_download(ctx, j.data(), d.data(), ins.data())) die("Error: %s\n", thj_last_error());
-    g_timer.lap("device finish + download");
+    g_timer.lap("exchange step + device finish + download");
     fprintf(stderr, "\tfound %ld potential split-segment junctions\n", (long)n.n_juncs);
     fprintf(stderr, "\tfound %ld potential small deletions\n", (long)n.n_deletions);
     fprintf(stderr, "\tfound %ld potential small insertions\n", (long)n.n_insertions);
@@ -247,8 +382,7 @@ int main(int argc, char** argv) {
         fprintf(fi, "%s\t%d\t%d\t%s\n", rt.names[ins[(size_t)i].ref_id - 1].c_str(), (int)ins[(size_t)i].left, (int)ins[(size_t)i].left, ins[(size_t)i].seq);
     if (o.fusion_search) {
         // fusion writer with its neighbour filter (segment_juncs.cpp:5048-5054, :5096-5182)
-        int64_t nf = 0;
-        if (thj_fusion_finish(ctx, &nf)) die("Error: %s\n", thj_last_error());
+        const int64_t nf = n_fus[0];
         std::vector<thj_fusion> f((size_t)nf + 1);
         if (thj_fusion_download(ctx, f.data())) die("Error: %s\n", thj_last_error());
         std::vector<std::pair<uint32_t, int>> coords;          // SpliceJunctionCoord(refid, coord)
@@ -284,12 +418,9 @@ int main(int argc, char** argv) {
     fclose(fj); fclose(fi); fclose(fd); fclose(ff);
     fprintf(stderr, "Reported %d total potential splices\n", (int)n.n_juncs);
     g_timer.lap("write outputs");
-    thj_ctx_destroy(ctx);
-    g_timer.lap("teardown");
     g_timer.report();
-    (void)CODE;
-    // Everything is written and closed.  Leave without running the exit handlers: tearing the HIP runtime down after a
-    // context has been used takes ~0.2 s that nobody is waiting for.
+    // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
+    // runtime (and RCCL) down after use takes tenths of a second that nobody is waiting for.
     fflush(nullptr);
     _exit(0);
 }

@@ -7,17 +7,21 @@
 // bwt_map.cpp:1101-1452 (BAMHitFactory::get_hit_from_buf); bwt_map.h:1155-1220 (HitStream::next_read_hits);
 // common.cpp:1000-1173 + common.h:401-627 (GBamRecord / GBamWriter); samtools-0.1.18 bgzf.c (BGZF framing).
 #pragma once
+#include <fcntl.h>
 #include <getopt.h>
 #include <stdint.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cctype>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -216,6 +220,12 @@ struct RefTable {
     std::vector<std::pair<std::string, uint32_t>> sq;   // @SQ (name, LN) in file order: the BAM header targets
 
     std::mutex mu;                                  // reader threads resolve names concurrently
+    // Once the inputs' headers have been read (register_targets) the table is frozen: the genome goes to the device with
+    // exactly these contigs, writers index `names` without a lock, and a record naming a contig no header knows is
+    // dropped by the hit factories (id 0) instead of growing the table under the readers' feet.
+    bool frozen = false;
+    bool warned_unknown = false;
+    void freeze() { std::lock_guard<std::mutex> lk(mu); frozen = true; }
     uint32_t get_id(const std::string& name) {
         // consecutive records mostly name the same contig: a per-thread one-entry cache keeps the lock out of the way
         static thread_local RefTable* c_rt = nullptr; static thread_local std::string c_name; static thread_local uint32_t c_id = 0;
@@ -228,6 +238,10 @@ struct RefTable {
     uint32_t get_id_locked(const std::string& name) {
         auto it = ids.find(name);
         if (it != ids.end()) return it->second;
+        if (frozen) {
+            if (!warned_unknown) { warned_unknown = true; fprintf(stderr, "Warning: alignment on contig %s, which no header or FASTA record names; such records are skipped\n", name.c_str()); }
+            return 0;
+        }
         names.push_back(name);
         seqs.emplace_back();
         ids[name] = (uint32_t)names.size();
@@ -323,18 +337,25 @@ struct RefTable {
                              for (size_t q = a; q < b; ++q) { char c = fold.t[(unsigned char)d[q]]; if (c) *o++ = c; } });
         }
     }
-    // pack + upload through the C ABI
+    // pack (once) + upload (to every GPU's context) through the C ABI
+    std::once_flag packed_once;
+    std::vector<uint64_t> packed; std::vector<uint32_t> packed_blk; std::vector<int64_t> packed_lens; int64_t packed_nb = 0;
+    void pack() {
+        std::call_once(packed_once, [this] {
+            std::lock_guard<std::mutex> lk(mu);
+            frozen = true;                           // the device genome has exactly the contigs known now
+            int32_t n = (int32_t)names.size();
+            packed_lens.resize(n); std::vector<const char*> ptrs(n);
+            for (int32_t i = 0; i < n; ++i) { packed_lens[i] = (int64_t)seqs[i].size(); ptrs[i] = seqs[i].empty() ? nullptr : seqs[i].data(); }
+            packed_blk.resize(n + 1);
+            if (thj_genome_layout(n, packed_lens.data(), packed_blk.data(), &packed_nb)) die("Error: %s\n", thj_last_error());
+            packed.resize((size_t)packed_nb * 4);
+            if (thj_genome_pack(n, ptrs.data(), packed_lens.data(), packed_blk.data(), packed.data(), packed_nb)) die("Error: %s\n", thj_last_error());
+        });
+    }
     void upload(thj_ctx* ctx) {
-        std::lock_guard<std::mutex> lk(mu);          // reader threads may be adding unknown names by now
-        int32_t n = (int32_t)names.size();
-        std::vector<int64_t> lens(n); std::vector<const char*> ptrs(n);
-        for (int32_t i = 0; i < n; ++i) { lens[i] = (int64_t)seqs[i].size(); ptrs[i] = seqs[i].empty() ? nullptr : seqs[i].data(); }
-        std::vector<uint32_t> blk(n + 1);
-        int64_t nb = 0;
-        if (thj_genome_layout(n, lens.data(), blk.data(), &nb)) die("Error: %s\n", thj_last_error());
-        std::vector<uint64_t> blocks((size_t)nb * 4);
-        if (thj_genome_pack(n, ptrs.data(), lens.data(), blk.data(), blocks.data(), nb)) die("Error: %s\n", thj_last_error());
-        if (thj_genome_upload(ctx, blocks.data(), nb, blk.data(), lens.data(), n)) die("Error: %s\n", thj_last_error());
+        pack();
+        if (thj_genome_upload(ctx, packed.data(), packed_nb, packed_blk.data(), packed_lens.data(), (int32_t)packed_lens.size())) die("Error: %s\n", thj_last_error());
     }
 };
 
@@ -362,10 +383,14 @@ class AlnReader {
 public:
     std::string fname;
     bool want_seq = true;       // false: SEQ / QUAL are not decoded, r.seq only gets its length (the hit factories' need)
-    bool open(const std::string& fn) {
+    const std::vector<std::string>& targets() const { return targets_; }
+    // offset: where to start reading records -- a BGZF virtual offset (compressed block address << 16 | offset inside the
+    // inflated block: what GBamWriter's .index holds and bgzf_seek takes, common.h:277-283) or a byte offset for SAM text
+    bool open(const std::string& fn, int64_t offset = 0) {
         fname = fn;
         if (file_ext(fn) == "sam") {                 // bwt_map.cpp:170-175
             txt_ = fopen(fn.c_str(), "r");
+            if (txt_ && offset > 0) fseek(txt_, (long)offset, SEEK_SET);
             return txt_ != nullptr;
         }
         bam_ = true;
@@ -386,6 +411,18 @@ public:
             rd(nm.data(), l_name, fn.c_str());
             rd(&l_ref, 4, fn.c_str());
             targets_.emplace_back(nm.data());
+        }
+        if (offset > 0) {
+            // a BGZF block is a complete gzip member: start zlib at the block's file address, then skip inside it
+            gzclose(gz_);
+            int fd = ::open(fn.c_str(), O_RDONLY);
+            if (fd < 0 || lseek(fd, (off_t)(offset >> 16), SEEK_SET) < 0) die("Error: cannot seek in %s\n", fn.c_str());
+            gz_ = gzdopen(fd, "rb");
+            if (!gz_) die("Error: cannot reopen %s\n", fn.c_str());
+            gzbuffer(gz_, 1 << 20);
+            char skip[65536];
+            int within = (int)(offset & 0xFFFF);
+            if (within && gzread(gz_, skip, (unsigned)within) != within) die("Error: bad index offset for %s\n", fn.c_str());
         }
         return true;
     }
@@ -534,6 +571,7 @@ inline bool parse_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& o
     }
     if (r.rnext != "*" && r.rnext != "=" && r.rnext != r.rname) return false;  // :1409-1415
     uint32_t ref_id = rt.get_id(r.rname);
+    if (ref_id == 0) return false;                                             // no header names this contig (frozen table)
     bool anti = (r.flag & 0x10) != 0;
     unsigned char ed = (unsigned char)(mism + gap);
     out.h16.ref_id = ref_id; out.h16.left = r.pos; out.h16.right = right;
@@ -698,6 +736,7 @@ inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p
         out.h32.cigar[k] = ((uint32_t)op << 28) | ((uint32_t)len & 0x0FFFFFFFu);
     }
     uint32_t ref_id = rt.get_id(contig);
+    if (ref_id == 0) return false;
     bool anti = (r.flag & 0x10) != 0;
     unsigned char mm8 = (unsigned char)num_mm, ed = (unsigned char)(num_mm + gap);
     out.h16.ref_id = ref_id; out.h16.left = left; out.h16.right = right;
@@ -744,6 +783,7 @@ class HitStream {
     RefTable* rt_ = nullptr;
     const thj_params* p_ = nullptr;
     bool spliced_ = false, done_ = true;
+    uint32_t begin_id_ = 0, end_id_ = 0xFFFFFFFFu;      // a shard: records with begin_id <= insert_id < end_id (segment_juncs.cpp:4005)
     std::thread th_;
     ChunkQueue<Hit> q_;
     std::vector<Hit> cur_; size_t pos_ = 0;
@@ -754,6 +794,8 @@ class HitStream {
         while (rd_.next(r)) {
             h = Hit();
             if (!(spliced_ ? parse_spliced_hit(r, *rt_, *p_, h) : parse_hit(r, *rt_, *p_, h))) continue;
+            if (h.insert_id < begin_id_) continue;       // the index entry the shard starts from lies at or before begin_id
+            if (h.insert_id >= end_id_) break;           // id-sorted file: the shard is over
             chunk.push_back(h);
             if (chunk.size() >= 8192) { if (!q_.push(std::move(chunk))) return; chunk = std::vector<Hit>(); chunk.reserve(8192); }
         }
@@ -765,10 +807,13 @@ public:
     HitStream() = default;
     HitStream(const HitStream&) = delete;
     HitStream& operator=(const HitStream&) = delete;
-    bool open(const std::string& fn, RefTable& rt, const thj_params& p, bool spliced = false) {
+    bool open(const std::string& fn, RefTable& rt, const thj_params& p, bool spliced = false, int64_t offset = 0,
+              uint64_t begin_id = 0, uint64_t end_id = ~0ull) {
         rt_ = &rt; p_ = &p; spliced_ = spliced;
+        begin_id_ = begin_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)begin_id;
+        end_id_ = end_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)end_id;
         rd_.want_seq = false;                    // neither hit factory looks at the bases, only at their number
-        if (fn.empty() || !rd_.open(fn)) return false;
+        if (fn.empty() || !rd_.open(fn, offset)) return false;
         done_ = false;
         th_ = std::thread([this] { producer(); });
         advance();
@@ -859,15 +904,18 @@ class ReadStream {
         return !r.seq.empty();
     }
 public:
-    bool open(const std::string& fn, const std::string& zpacker) {
+    // offset: where the shard's reads start (ReadStream::seek, reads.h:431-434): a BGZF virtual offset for an unaligned
+    // BAM, a byte offset at a record start for FASTA / FASTQ text
+    bool open(const std::string& fn, const std::string& zpacker, int64_t offset = 0) {
         std::string e = file_ext(fn);
-        if (e == "bam") { is_bam_ = true; if (!bam_.open(fn)) return false; }
+        if (e == "bam") { is_bam_ = true; if (!bam_.open(fn, offset)) return false; }
         else {
             if (e == "z" && !zpacker.empty()) {                      // FZPipe, common.cpp:899-922
                 std::string cmd = zpacker + " -cd '" + fn + "'";
                 f_ = popen(cmd.c_str(), "r"); pipe_ = true;
             } else f_ = fopen(fn.c_str(), "r");
             if (!f_) return false;
+            if (offset > 0 && !pipe_) fseek(f_, (long)offset, SEEK_SET);
         }
         th_ = std::thread([this] { producer(); });
         return true;
@@ -895,6 +943,154 @@ public:
         return false;
     }
 };
+
+// ------------------------------------------------------------------ read-id shards (utils.cpp:22-170)
+// The reference's worker threads (-p N) each take a contiguous read-id range [begin_id, end_id) and start reading every
+// input at an offset taken from its `.index` side file (`read_id \t offset` lines, written every >= 1000 records at a
+// read-id change: GBamWriter, common.h:562-606).  The same plan shards the reads over host workers and GPUs here; the
+// results do not depend on the number of shards (events are sets, first-inserted-wins priorities follow the read id).
+typedef std::vector<std::pair<uint64_t, int64_t>> IndexList;
+
+inline bool read_index_file(const std::string& fn, IndexList& out) {
+    FILE* f = fopen(fn.c_str(), "r");
+    if (!f) return false;
+    unsigned long long id; long long off;
+    while (fscanf(f, "%llu %lld", &id, &off) == 2) out.emplace_back((uint64_t)id, (int64_t)off);
+    fclose(f);
+    return true;
+}
+
+// Plain-text inputs (FASTA / FASTQ reads, SAM maps: test fixtures and small runs) have no `.index`.  They are seekable, so
+// an index is made by probing: at evenly spaced byte offsets, the next place where a record GROUP starts and its id.
+inline void probe_text_index(const std::string& fn, int want, IndexList& out) {
+    const std::string ext = file_ext(fn);
+    const bool sam = ext == "sam";
+    FILE* f = fopen(fn.c_str(), "rb");
+    if (!f) return;
+    fseek(f, 0, SEEK_END);
+    const long size = ftell(f);
+    if (size < (long)want * 4096) { fclose(f); return; }            // small file: not worth cutting
+    std::vector<char> buf((size_t)1 << 18);
+    for (int k = 1; k < want; ++k) {
+        const long at = (long)((double)size * k / want);
+        fseek(f, at, SEEK_SET);
+        const size_t n = fread(buf.data(), 1, buf.size(), f);
+        // line starts inside the buffer
+        std::vector<size_t> ls;
+        for (size_t i = 0; i + 1 < n; ++i) if (buf[i] == '\n') ls.push_back(i + 1);
+        auto line_id = [&](size_t b) { return (uint64_t)strtoull(buf.data() + b + (sam ? 0 : 1), nullptr, 10); };
+        bool found = false;
+        if (sam) {
+            // first line whose id differs from the line before it: a group start
+            for (size_t j = 1; j < ls.size() && !found; ++j) {
+                if (buf[ls[j - 1]] == '@' || buf[ls[j]] == '@') continue;
+                if (line_id(ls[j]) != line_id(ls[j - 1])) { out.emplace_back(line_id(ls[j]), (int64_t)(at + (long)ls[j])); found = true; }
+            }
+        } else {
+            for (size_t j = 0; j + 2 < ls.size() && !found; ++j) {
+                const char c = buf[ls[j]];
+                if (c == '>') { out.emplace_back(line_id(ls[j]), (int64_t)(at + (long)ls[j])); found = true; }
+                // four-line FASTQ: a header line is an '@' line whose line after next starts with '+' (a quality line that
+                // happens to start with '@' is followed by a header and a sequence line instead)
+                else if (c == '@' && buf[ls[j + 2]] == '+' && buf[ls[j + 1]] != '@' && buf[ls[j + 1]] != '+') {
+                    out.emplace_back(line_id(ls[j]), (int64_t)(at + (long)ls[j])); found = true;
+                }
+            }
+        }
+        if (!found) { out.clear(); break; }                          // unusual layout (wrapped FASTQ ...): do not shard this file
+    }
+    // ids must increase along the file for the plan to mean anything
+    for (size_t i = 1; i < out.size(); ++i) if (out[i].first <= out[i - 1].first) { out.clear(); break; }
+    fclose(f);
+}
+
+inline void load_index(const std::string& fname, int want, IndexList& out) {
+    // utils.cpp:33-71: "<name>.bam.index", or "<name><j>.bam.index" for j = 0, 1, ... when <name> is not a .bam
+    if (fname.size() >= 4 && fname.substr(fname.size() - 4) == ".bam") { read_index_file(fname + ".index", out); return; }
+    const std::string ext = file_ext(fname);
+    if (ext == "sam" || ext == "fq" || ext == "fastq" || ext == "fa" || ext == "fasta") { probe_text_index(fname, want, out); return; }
+    for (size_t j = 0;; ++j) if (!read_index_file(fname + std::to_string(j) + ".bam.index", out)) break;
+}
+
+// calculate_offsets (utils.cpp:22-127): n - 1 boundary read ids from the LAST file's index, and for every file the offset of
+// its last index entry at or before the boundary (walking the files from the last to the first, each one bounded by the
+// entry chosen in the file after it).  lists[i] = index of file i.  false: "too small for blocking".
+inline bool calculate_offsets(const std::vector<IndexList>& lists, int n, std::vector<uint64_t>& ids, std::vector<std::vector<int64_t>>& offsets) {
+    ids.clear(); offsets.clear();
+    if (n < 2 || lists.empty()) return false;
+    for (auto& l : lists) if (l.size() < (size_t)n) return false;
+    offsets.resize((size_t)n - 1);
+    for (int i = 1; i < n; ++i) {
+        const IndexList& last = lists.back();
+        const size_t index = last.size() / (size_t)n * (size_t)i;
+        uint64_t id = last[index].first;
+        ids.push_back(id);
+        std::vector<int64_t>& off = offsets[(size_t)i - 1];
+        off.push_back(last[index].second);
+        for (int j = (int)lists.size() - 2; j >= 0; --j) {
+            const IndexList& l = lists[(size_t)j];
+            size_t oi = l.size() / (size_t)n * (size_t)i;
+            uint64_t oid = l[oi].first;
+            while (oid > id && oi > 0) { --oi; oid = l[oi].first; }
+            while (oi + 1 < l.size() && l[oi + 1].first < id) { ++oi; oid = l[oi].first; }
+            int64_t ooff = l[oi].second;
+            if (oid > id) { oid = 0; ooff = 0; }
+            id = oid;
+            off.push_back(ooff);
+        }
+        std::reverse(off.begin(), off.end());
+    }
+    // equal boundaries (very uneven indexes) would make empty shards; they are harmless but pointless
+    return true;
+}
+
+// calculate_offsets_from_ids (utils.cpp:129-170): for a file that is only looked up by id (the mate's maps), the offset of
+// its last index entry with id <= the boundary.  An empty result means "read the file from the start".
+inline void calculate_offsets_from_ids(const IndexList& l, const std::vector<uint64_t>& ids, std::vector<int64_t>& offsets) {
+    offsets.clear();
+    size_t k = 0;
+    uint64_t last_id = 0; int64_t last_off = 0;
+    for (size_t i = 0; i < ids.size(); ++i) {
+        const uint64_t ref = ids[i];
+        bool pushed = false;
+        while (k < l.size()) {
+            const uint64_t rid = l[k].first; const int64_t off = l[k].second;
+            ++k;
+            if (rid > ref) { offsets.push_back(last_id <= ref ? last_off : 0); pushed = true; }
+            last_id = rid; last_off = off;
+            if (last_id > ref) break;
+        }
+        if (!pushed) break;
+    }
+    if (ids.size() != offsets.size()) offsets.clear();
+}
+
+// every contig an input's header names enters the reference table before it is frozen (and before any record is parsed)
+inline void register_targets(const std::string& fn, RefTable& rt) {
+    if (fn.empty()) return;
+    if (file_ext(fn) == "sam") {
+        FILE* f = fopen(fn.c_str(), "r");
+        if (!f) return;
+        char* line = nullptr; size_t cap = 0; ssize_t n;
+        while ((n = getline(&line, &cap, f)) > 0 && line[0] == '@') {
+            if (strncmp(line, "@SQ", 3)) continue;
+            std::string l(line, (size_t)n);
+            while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+            for (auto& tok : split(l, '\t')) if (!tok.compare(0, 3, "SN:")) rt.get_id(tok.substr(3));
+        }
+        free(line);
+        fclose(f);
+        return;
+    }
+    if (file_ext(fn) != "bam") return;
+    AlnReader r;
+    if (!r.open(fn)) return;
+    for (auto& t : r.targets()) {
+        // junction-db contigs "name|left|l-r|right|type|strand" are resolved to their genomic contig by the spliced hit factory
+        if (t.find('|') != std::string::npos) continue;
+        rt.get_id(t);
+    }
+}
 
 // ------------------------------------------------------------------ BGZF + BAM writer (samtools-0.1.18 bgzf.c, common.cpp:1000-1173)
 inline int reg2bin(int beg, int end) {                // bam.h bam_reg2bin
@@ -925,7 +1121,9 @@ class BamWriter {
     static bool deflate_member(const uint8_t* in, size_t take, std::vector<uint8_t>& out) {
         out.resize(BLOCK + 1024);
         z_stream zs; memset(&zs, 0, sizeof zs);
-        deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+        // bgzf.c compresses at zlib's default level; THJ_BGZF_LEVEL picks another one (the BAM stream inside is the same)
+        static const int level = getenv("THJ_BGZF_LEVEL") ? atoi(getenv("THJ_BGZF_LEVEL")) : Z_DEFAULT_COMPRESSION;
+        deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
         zs.next_in = const_cast<uint8_t*>(in); zs.avail_in = (uInt)take;
         zs.next_out = out.data() + 18; zs.avail_out = (uInt)(BLOCK - 18 - 8);
         int st = deflate(&zs, Z_FINISH);
@@ -1074,34 +1272,23 @@ public:
         uint32_t bs = (uint32_t)(d.size() - at - 4);
         memcpy(d.data() + at, &bs, 4);
     }
-    // Writes records 0..n-1 in order.  enc(i, bytes) appends record i with encode() and returns its read id (atol(qname)).
-    void write_records(size_t n, const std::function<long(size_t, std::vector<uint8_t>&)>& enc) {
-        int T = host_threads();
-        if ((size_t)T > n / 256 + 1) T = (int)(n / 256 + 1);
-        std::vector<std::vector<uint8_t>> part((size_t)T);
-        std::vector<uint32_t> size(n); std::vector<long> rid(n);
-        auto work = [&](int t) {
-            const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T;
-            std::vector<uint8_t>& d = part[(size_t)t];
-            d.reserve((b - a) * 256);
-            for (size_t i = a; i < b; ++i) { size_t before = d.size(); rid[i] = enc(i, d); size[i] = (uint32_t)(d.size() - before); }
-        };
-        if (T > 1) { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
-        else work(0);
+    // Records already encoded (by encode()) elsewhere: bytes = the records back to back, size[i] / rid[i] = byte count and
+    // read id (atol(qname)) of record i.  Shard workers encode in parallel; one thread appends in read order.
+    struct Encoded { std::vector<uint8_t> bytes; std::vector<uint32_t> size; std::vector<long> rid; };
+    void write_encoded(const Encoded& e) {
+        const size_t n = e.size.size();
         std::vector<uint8_t> stream;
-        size_t total = carry_.size();
-        for (auto& d : part) total += d.size();
-        stream.reserve(total);
+        stream.reserve(carry_.size() + e.bytes.size());
         stream.insert(stream.end(), carry_.begin(), carry_.end());
-        for (auto& d : part) { stream.insert(stream.end(), d.begin(), d.end()); std::vector<uint8_t>().swap(d); }
+        stream.insert(stream.end(), e.bytes.begin(), e.bytes.end());
         std::vector<Blk> tab = flush_full_blocks(stream, false);
         // GBamWriter::write(b, read_id): index line once >= INDEX_REC_COUNT (1000) records have passed and the id changes
         if (idx_) {
             size_t x = carry_.size();
             for (size_t i = 0; i < n; ++i) {
-                const size_t s0 = x, e0 = x + size[i];
+                const size_t s0 = x, e0 = x + e.size[i];
                 x = e0;
-                const long read_id = rid[i];
+                const long read_id = e.rid[i];
                 if (!read_id) continue;
                 bool widx = idxcount_ >= 1000 && read_id != last_id_;
                 last_id_ = read_id; ++idxcount_;
@@ -1109,7 +1296,7 @@ public:
                 int64_t pre_pos = tell_at(tab, s0), pre_addr = (pre_pos >> 16) & 0xFFFFFFFFFFFFLL;
                 int64_t off = tell_at(tab, e0);
                 int post_offs = (int)(off & 0xFFFF); int64_t post_addr = (off >> 16) & 0xFFFFFFFFFFFFLL;
-                int data_len = (int)size[i] - 4;       // b->data_len + BAM_CORE_SIZE == block_size of the record
+                int data_len = (int)e.size[i] - 4;       // b->data_len + BAM_CORE_SIZE == block_size of the record
                 if (post_addr != pre_addr && post_offs >= data_len) pre_pos = post_addr << 16;
                 fprintf(idx_, "%ld\t%ld\n", read_id, (long)pre_pos);
                 idxcount_ = 0;
@@ -1117,6 +1304,27 @@ public:
         }
         const Blk& open = tab.back();
         carry_.assign(stream.begin() + (ptrdiff_t)open.ustart, stream.end());
+    }
+    // Writes records 0..n-1 in order.  enc(i, bytes) appends record i with encode() and returns its read id (atol(qname)).
+    void write_records(size_t n, const std::function<long(size_t, std::vector<uint8_t>&)>& enc) {
+        int T = host_threads();
+        if ((size_t)T > n / 256 + 1) T = (int)(n / 256 + 1);
+        std::vector<std::vector<uint8_t>> part((size_t)T);
+        Encoded e;
+        e.size.resize(n); e.rid.resize(n);
+        auto work = [&](int t) {
+            const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T;
+            std::vector<uint8_t>& d = part[(size_t)t];
+            d.reserve((b - a) * 256);
+            for (size_t i = a; i < b; ++i) { size_t before = d.size(); e.rid[i] = enc(i, d); e.size[i] = (uint32_t)(d.size() - before); }
+        };
+        if (T > 1) { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
+        else work(0);
+        size_t total = 0;
+        for (auto& d : part) total += d.size();
+        e.bytes.reserve(total);
+        for (auto& d : part) { e.bytes.insert(e.bytes.end(), d.begin(), d.end()); std::vector<uint8_t>().swap(d); }
+        write_encoded(e);
     }
     void close() {
         if (!f_) return;

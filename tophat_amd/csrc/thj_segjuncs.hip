@@ -560,6 +560,12 @@ static int reset_tables_async(thj_ctx* c) {
     return THJ_OK;
 }
 
+extern "C" int thj_device_count(void) {
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    return n;
+}
+
 extern "C" int thj_ctx_create(int device, void* stream, thj_ctx** out) {
     if (!out) { thj_set_error("thj_ctx_create: null out"); return THJ_EINVAL; }
     int ndev = 0;

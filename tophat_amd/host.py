@@ -50,7 +50,7 @@ class CCounts(C.Structure):
 
 ABI_SYMBOLS = [
     "thj_params_default", "thj_last_error", "thj_version",
-    "thj_ctx_create", "thj_ctx_destroy", "thj_ctx_sync", "thj_ctx_stream",
+    "thj_device_count", "thj_ctx_create", "thj_ctx_destroy", "thj_ctx_sync", "thj_ctx_stream",
     "thj_genome_layout", "thj_genome_pack", "thj_genome_upload", "thj_genome_adopt",
     "thj_reads_pack",
     "thj_batch_upload", "thj_batch_free",
