@@ -225,7 +225,9 @@ def parse_args():
                          "producer that writes heads as it goes; NOT the default measurement, see DESIGN.md)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-pairs", type=int, default=0, help="also run the drop-in executables end to end on files of this many pairs")
+    ap.add_argument("--e2e-pairs", type=int, default=2_000_000,
+                    help="also run the drop-in executables end to end (files in, files out: the metric as SURVEY 8d words it) on "
+                         "generated files of this many pairs; 0 skips the leg.  Reported as the `e2e` object, never as `value`")
     return ap.parse_args()
 
 
@@ -300,6 +302,96 @@ def finish_stdout(result):
     sys.stdout.flush()
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)
+
+
+def e2e_leg(args):
+    """The metric as BASELINE words it: wall clock of the drop-in executables, files in -> files out (segment_juncs, then
+    long_spanning_reads on each side), on generated configs[1]-shaped files (tools/bin/thj_gen: BAM inputs with .index, the
+    reads as unaligned BAM), plus an equality check of the executables' outputs against the CPU oracle on a sample (the first
+    pairs of the same case, written again as text)."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from e2e_bench import run_e2e
+        res = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns)
+        keep = ("pairs", "input_bytes", "gen_seconds", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s",
+                "both_stages_s", "junctions")
+        out = {k: res[k] for k in keep}
+        out["value"] = res["pairs"] / res["both_stages_s"]
+        out["unit"] = "read-pairs/s (wall clock of both executables, files in -> files out, 1 GPU, host CPUs: %s)" % (_cpu_quota(),)
+        # sample check against the oracle
+        d = tempfile.mkdtemp(prefix="thj_e2e_chk_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            out["sample_check"] = e2e_sample_check(d, args)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        return out
+    except Exception as e:      # noqa: BLE001 -- the leg is reported, it must not take the kernel measurement down with it
+        return {"error": repr(e)[:500]}
+
+
+def _cpu_quota():
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return "%d hardware threads, cgroup quota %s" % (os.cpu_count(), "none" if q == "max" else "%.0f CPUs" % (int(q) / int(p)))
+    except (OSError, ValueError):
+        return "%d hardware threads" % os.cpu_count()
+
+
+def e2e_sample_check(d, args, pairs=20000):
+    """executables on a small text+BAM twin case vs the oracle: the three event files byte for byte, and every spanning record"""
+    import subprocess
+    import orc
+    from golden_util import events_text
+    from tophat_amd.bamio import read_bam
+    from tophat_amd.batch import build_seg_batch, build_span_batch, events_to_span_inputs, merge_events
+    from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
+    gen = os.path.join(ROOT, "tools", "bin", "thj_gen")
+    bind = os.path.join(ROOT, "tophat_amd", "bin")
+    subprocess.check_call([gen, "--out", d, "--pairs", str(pairs), "--genome-len", "4000000", "--introns", "1500", "--text"], stdout=subprocess.DEVNULL)
+    f = lambda n: os.path.join(d, n)      # noqa: E731
+    segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k)) for k in (1, 2, 3, 4)) for sd in ("left", "right")}
+    out = {k: f("out." + k) for k in ("juncs", "insertions", "deletions", "fusions")}
+    subprocess.check_call([os.path.join(bind, "segment_juncs"), "--no-coverage-search", "--no-microexon-search", "--segment-length", "25", "--sam-header",
+                           f("hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20", f("ref.fa"), out["juncs"], out["insertions"],
+                           out["deletions"], out["fusions"], f("left_reads.bam"), f("left_map.bam"), segs["left"], f("right_reads.bam"),
+                           f("right_map.bam"), segs["right"]], stderr=subprocess.DEVNULL)
+    names, _ = parse_header(f("hdr.sam"))
+    fa_names, fa_seqs = read_fasta(f("ref.fa"))
+    seqs = [orc.fold_genome_char(s) for s in fa_seqs]
+    ref_ids = {n: i + 1 for i, n in enumerate(names)}
+    og = orc.Genome(seqs)
+    sides = {}
+    for sd in ("left", "right"):
+        sides[sd] = dict(reads=read_fastq(f("%s.fq" % sd)),
+                         segs=[list(parse_sam_hits(f("%s_seg%d.sam" % (sd, k)), ref_ids, 500000)) for k in (1, 2, 3, 4)],
+                         full=list(parse_sam_hits(f("%s_map.sam" % sd), ref_ids, 500000)))
+    want = None
+    for sd, side, other in (("left", READ_LEFT, "right"), ("right", READ_RIGHT, "left")):
+        b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1])
+        e = orc.segjuncs(Params(read_side=side, inner_dist_mean=50, inner_dist_std_dev=20), og, b)
+        want = e if want is None else merge_events(want, e)
+    import pathlib
+    wt = events_text(want, names, pathlib.Path(d))
+    same_events = all(open(out[k]).read() == wt[k] for k in ("juncs", "insertions", "deletions"))
+    jj, ii = events_to_span_inputs(want)
+    n_rec, same_recs = 0, True
+    for sd in ("left", "right"):
+        bam = f("span_%s.bam" % sd)
+        subprocess.check_call([os.path.join(bind, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
+                               f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", bam, segs[sd]], stderr=subprocess.DEVNULL)
+        quals = {k: "I" * len(v) for k, v in sides[sd]["reads"].items()}
+        sb = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], quals)
+        alns = orc.spanning(Params(), og, sb, jj, ii)
+        wrecs = [tuple(str(x) for x in a.sam_fields(int(sb.read_id[a.read_idx]), names)) for a in alns]
+        _, recs = read_bam(bam)
+        grecs = [tuple(str(x) for x in (r[0], r[1], r[2], r[3], r[5]) + tuple(r[8:])) for r in recs]
+        n_rec += len(grecs)
+        same_recs = same_recs and grecs == wrecs
+    return {"pairs": pairs, "junctions": len(want.juncs), "event_files_identical_to_oracle": bool(same_events),
+            "spanning_records": n_rec, "spanning_records_identical_to_oracle": bool(same_recs)}
 
 
 def run_rank(args, rank, world, local_rank, control, shared):
@@ -536,6 +628,9 @@ def run_rank(args, rank, world, local_rank, control, shared):
                    "sample": "first %d pairs of the same synthetic batch through both stages with oracle/liborc.so "
                              "(plain-C restatement, 1 thread): segment_juncs %.1f s + long_spanning_reads %.1f s, %d records" % (
                                  m, t2 - t1, t3 - t2, n_rec)}
+        e2e = None
+        if args.e2e_pairs > 0 and world == 1 and args.read_len == 100 and args.genome == "chr20":
+            e2e = e2e_leg(args)
         result = {
             "metric": "paired reads/sec through segment_juncs+long_spanning_reads; junctions.bed diff=0",
             "value": args.pairs * world * args.steps / elapsed,
@@ -559,6 +654,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "kernels": kernels,
             "exchange": comm_info,
+            "e2e": e2e,
             "cpu_baseline": cpu,
             "events": {"junctions": cnt.n_juncs, "deletions": cnt.n_deletions, "insertions": cnt.n_insertions,
                        "windows_per_step": cnt.n_windows, "rescue_pairs_per_step": cnt.n_rescue_pairs,

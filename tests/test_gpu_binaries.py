@@ -96,9 +96,9 @@ def test_unsupported_modes_fail_loudly(tmp_path):
     assert r.returncode == 1
 
 
-def test_long_spanning_reads_parts(tmp_path):
-    """-p N: <base>{0..N-1}.bam, each with its `.index` (long_spanning_reads.cpp:3056-3064); cut at read boundaries,
-    concatenation == the single-file output"""
+def test_long_spanning_reads_parts_fall_back_to_one_file_on_small_inputs(tmp_path):
+    """-p N on inputs whose indexes are too small for N ranges: one thread, one file (long_spanning_reads.cpp:2991-2993,
+    utils.cpp:75-80) -- which tophat.py looks for first (tophat.py:3772-3779)"""
     name = "se100"
     d = os.path.join(GOLD, name)
     seglen = dict(x.split("=") for x in open(os.path.join(d, "options.txt")).read().split("\n")[1].split())["segment_length"]
@@ -109,16 +109,66 @@ def test_long_spanning_reads_parts(tmp_path):
            os.path.join(d, "expected.deletions"), "/dev/null", out, ",".join(inp["left_segs"])]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    got, names_seen = [], []
-    for k in range(3):
-        part = str(tmp_path / ("span%d.bam" % k))
-        assert os.path.exists(part) and os.path.exists(part + ".index")
-        _, recs = read_bam(part)
-        recs = [tuple(str(x) for x in rec) for rec in recs]
-        assert recs, "empty part"
-        if names_seen:
-            assert recs[0][0] != names_seen[-1]          # a read never straddles two parts
-        names_seen.append(recs[-1][0])
-        got += recs
+    assert os.path.exists(out) and os.path.exists(out + ".index") and not os.path.exists(str(tmp_path / "span0.bam"))
+    _, recs = read_bam(out)
     want = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_left.sam"))]
-    assert got == want
+    assert [tuple(str(x) for x in rec) for rec in recs] == want
+
+
+def _gen_case(tmp_path, pairs=60000):
+    d = str(tmp_path / "gen")
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "thj_gen"), "--out", d, "--pairs", str(pairs), "--genome-len", "3000000",
+                           "--introns", "1200", "--threads", "8"], stdout=subprocess.DEVNULL)
+    return d
+
+
+def _run_both(d, tmp_path, tag, env_extra, p_arg=()):
+    """segment_juncs, then long_spanning_reads on the left side -> (text outputs, path of the spanning BAM)"""
+    env = dict(os.environ, **env_extra)
+    out = {k: str(tmp_path / ("%s.%s" % (tag, k))) for k in ("juncs", "insertions", "deletions", "fusions")}
+    segs = {sd: ",".join(os.path.join(d, "%s_seg%d.bam" % (sd, k)) for k in (1, 2, 3, 4)) for sd in ("left", "right")}
+    cmd = [os.path.join(BIN, "segment_juncs"), "--no-coverage-search", "--no-microexon-search", "--segment-length", "25", "--sam-header",
+           os.path.join(d, "hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20", os.path.join(d, "ref.fa"), out["juncs"],
+           out["insertions"], out["deletions"], out["fusions"], os.path.join(d, "left_reads.bam"), os.path.join(d, "left_map.bam"), segs["left"],
+           os.path.join(d, "right_reads.bam"), os.path.join(d, "right_map.bam"), segs["right"]]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    bam = str(tmp_path / ("%s.span.bam" % tag))
+    cmd = [os.path.join(BIN, "long_spanning_reads")] + list(p_arg) + ["--segment-length", "25", "--sam-header", os.path.join(d, "hdr.sam"),
+           os.path.join(d, "ref.fa"), os.path.join(d, "left_reads.bam"), out["juncs"], out["insertions"], out["deletions"], "/dev/null", bam, segs["left"]]
+    r2 = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    return {k: open(v).read() for k, v in out.items()}, bam, r.stderr + r2.stderr
+
+
+def test_results_do_not_depend_on_shards_or_workers(tmp_path):
+    """the same files through one shard / one worker and through many: identical text outputs, identical BAM stream and .index"""
+    d = _gen_case(tmp_path)
+    one, bam1, log1 = _run_both(d, tmp_path, "one", {"THJ_SHARDS": "1", "THJ_WORKERS": "1"})
+    many, bam2, log2 = _run_both(d, tmp_path, "many", {"THJ_SHARDS": "13", "THJ_WORKERS": "5", "THJ_BATCH_READS": "3000"})
+    assert "13 left + 13 right read-id shards" in log2 and "1 left + 1 right read-id shards" in log1
+    assert one == many and one["juncs"].count("\n") > 500
+    assert gzip.open(bam1, "rb").read() == gzip.open(bam2, "rb").read()
+    assert open(bam1 + ".index").read() == open(bam2 + ".index").read()
+
+
+def test_long_spanning_reads_parts(tmp_path):
+    """-p N: <base>{0..N-1}.bam, each with its `.index` (long_spanning_reads.cpp:3056-3064), cut where calculate_offsets cuts;
+    their concatenation == the single-file output"""
+    d = _gen_case(tmp_path)
+    _, bam1, _ = _run_both(d, tmp_path, "one", {})
+    _, bam3, _ = _run_both(d, tmp_path, "three", {}, p_arg=("-p", "3"))
+    _, whole = read_bam(bam1)
+    whole = list(whole)
+    got, last = [], None
+    for k in range(3):
+        part = bam3[:-4] + "%d.bam" % k
+        assert os.path.exists(part) and os.path.exists(part + ".index") and not os.path.exists(bam3)
+        _, recs = read_bam(part)
+        recs = list(recs)
+        assert len(recs) > len(whole) // 6, "a part is far smaller than a third"
+        if last is not None:
+            assert recs[0][0] != last                    # a read never straddles two parts
+        last = recs[-1][0]
+        got += recs
+    assert got == whole

@@ -21,6 +21,7 @@ static void print_usage() {
 }
 
 static PhaseTimer g_timer;
+static WorkClock g_work;
 
 struct Gpu {
     int device = 0;
@@ -249,8 +250,8 @@ int main(int argc, char** argv) {
     const std::string out = pos[6];
     // ---- the shard plan.  -p N: the reference's N ranges, one output file each.  One output file: our own number of shards,
     // written in order.
-    const int hw = (int)std::thread::hardware_concurrency();
-    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 6));
+    const int hw = effective_cpus();
+    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 2));
     if (workers < 1) workers = 1;
     int parts = o.num_threads > 1 ? o.num_threads : 1;
     std::vector<Shard> shards;
@@ -283,6 +284,8 @@ int main(int argc, char** argv) {
 
     // JoinSegmentsWorker (long_spanning_reads.cpp:2669-2845) for one shard
     auto run_shard = [&](size_t k) {
+        const long long t_shard = WorkClock::now();
+        struct AtExit { long long t; ~AtExit() { g_work.add(0, t); } } at_exit{t_shard};
         const Shard& sh = shards[k];
         Gpu& gpu = *gpus[k % (size_t)n_gpus];
         const BamWriter& enc_bw = *bws[parts == 1 ? 0 : k];
@@ -315,7 +318,10 @@ int main(int argc, char** argv) {
             hb.seg_off = seg_off.data(); hb.hits = hits.data(); hb.read_planes = planes.data(); hb.read_len = lens.data(); hb.quals = q.data();
             std::vector<thj_aln> alns;
             {
+                const long long tw = WorkClock::now();
                 std::lock_guard<std::mutex> lk(gpu.mu);
+                g_work.add(1, tw);
+                const long long td = WorkClock::now();
                 thj_ctx* ctx = device_ready(gpu);
                 thj_span_batch* dev = nullptr;
                 if (thj_span_batch_upload(ctx, &hb, (int64_t)hits.size(), &dev)) die("Error: %s\n", thj_last_error());
@@ -326,9 +332,12 @@ int main(int argc, char** argv) {
                 alns.resize((size_t)na);
                 if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
                 if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+                g_work.add(2, td);
             }
             BamWriter::Encoded e;
+            const long long te = WorkClock::now();
             encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
+            g_work.add(3, te);
             if (parts > 1) bws[k]->write_encoded(e);         // this part's own file
             else {
                 OutShard& oq = *outq[k];
@@ -408,6 +417,7 @@ int main(int argc, char** argv) {
     for (auto& bw : bws) bw->close();
     g_timer.lap("BAM close");
     g_timer.report();
+    { static const char* const nm[4] = {"shards (ingest + merge + device + encode)", "  waiting for the GPU's lock", "  device calls (upload, stitch, download)", "  record encoding"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime down after a context has been used takes ~0.2 s that nobody is waiting for.
     fflush(nullptr);

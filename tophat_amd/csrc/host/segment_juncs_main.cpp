@@ -19,6 +19,7 @@ static void print_usage() {
 }
 
 static PhaseTimer g_timer;
+static WorkClock g_work;
 
 struct SideInput {
     std::string reads, map;
@@ -92,6 +93,8 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
     // one segment map: no segment search (segment_juncs.cpp:4752 `size() > 1`), but its hits still belong to the coverage
     // map (all_segmap_fnames :4929-4935)
     if (nseg < 1 || (nseg == 1 && o.no_coverage_search)) return;
+    const long long t_shard = WorkClock::now();
+    struct AtExit { long long t; ~AtExit() { g_work.add(0, t); } } at_exit{t_shard};
     std::vector<HitStream> st((size_t)nseg);
     for (int s = 0; s < nseg; ++s)
         if (!st[(size_t)s].open(in.segs[(size_t)s], rt, o.p, false, sh.seg_off[(size_t)s], sh.begin_id, sh.end_id))
@@ -130,7 +133,10 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
         if (have_mate) { hb.mate_off = mate_off.data(); hb.mate_hits = mate_hits.data(); }
         hb.ordinal_base = ordinal;
         {
+            const long long tw = WorkClock::now();
             std::lock_guard<std::mutex> lk(gpu.mu);
+            g_work.add(1, tw);
+            const long long td = WorkClock::now();
             thj_ctx* ctx = device_ready(gpu);
             thj_seg_batch* dev = nullptr;
             if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
@@ -138,6 +144,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
             if (nseg > 1 && o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
             if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
             if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+            g_work.add(2, td);
         }
         ordinal += (uint32_t)n;
         reset();
@@ -281,10 +288,10 @@ int main(int argc, char** argv) {
             }
         });
     fprintf(stderr, ">> Performing segment-search:\n");
-    // ---- shards and host workers.  THJ_WORKERS host workers (default: hardware threads / 8 -- every worker keeps one reader
+    // ---- shards and host workers.  THJ_WORKERS host workers (default: half the usable CPUs -- every worker also keeps one reader
     // thread per input file busy) take (side, shard) items; -p N asks for at least N shards per side, as in the reference.
-    const int hw = (int)std::thread::hardware_concurrency();
-    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 8));
+    const int hw = effective_cpus();
+    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 2));
     if (workers < 1) workers = 1;
     int want = getenv("THJ_SHARDS") ? atoi(getenv("THJ_SHARDS")) : std::max(std::max(workers, o.num_threads), n_gpus);
     struct Item { const SideInput* in; const SideInput* mate; int side; Shard sh; uint32_t ordinal, limit; int gpu; };
@@ -419,6 +426,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Reported %d total potential splices\n", (int)n.n_juncs);
     g_timer.lap("write outputs");
     g_timer.report();
+    { static const char* const nm[4] = {"shards (ingest + merge + pack + device)", "  waiting for the GPU's lock", "  device calls (upload, launch, free)", "  -"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime (and RCCL) down after use takes tenths of a second that nobody is waiting for.
     fflush(nullptr);

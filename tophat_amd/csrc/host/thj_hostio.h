@@ -65,6 +65,17 @@ struct PhaseTimer {
     }
 };
 
+// Per-phase time summed over the shard workers (THJ_TIMING): where a parallel run spends its thread-seconds.
+struct WorkClock {
+    std::atomic<long long> ns[4] = {{0}, {0}, {0}, {0}};     // 0 whole shard, 1 waiting for the GPU's lock, 2 device calls, 3 encode / other
+    static long long now() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void add(int k, long long t0) { ns[k] += now() - t0; }
+    void report(const char* const names[4]) const {
+        if (!getenv("THJ_TIMING")) return;
+        for (int k = 0; k < 4; ++k) fprintf(stderr, "[worker-seconds] %-40s %8.3f\n", names[k], (double)ns[k].load() * 1e-9);
+    }
+};
+
 struct Opts {
     thj_params p;
     bool no_coverage_search = false, no_microexon_search = false, butterfly_search = false, fusion_search = false;
@@ -205,9 +216,30 @@ inline std::string file_ext(const std::string& f) {
 // Host threading: every input file is inflated / tokenised / parsed by its own reader thread, which hands chunks of
 // finished records to the consumer through a small bounded queue; the consumer (merge by read id, batching) never
 // parses.  THJ_HOST_THREADS bounds the worker count of the parallel stages (default: min(32, hardware threads)).
+// CPUs this process may actually use: the hardware threads, capped by the cgroup's CPU quota (containers often show all of
+// a machine's 256 hardware threads and allow 16 CPUs' worth of time; sizing thread pools by the former only adds switches)
+inline int effective_cpus() {
+    static const int n = [] {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        long long quota = -1, period = 100000;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+            char q[64];
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max")) quota = atoll(q);
+            fclose(f);
+        } else if (FILE* f1 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {  // cgroup v1
+            if (fscanf(f1, "%lld", &quota) != 1) quota = -1;
+            fclose(f1);
+            if (FILE* f2 = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(f2, "%lld", &period) != 1) period = 100000; fclose(f2); }
+        }
+        if (quota > 0 && period > 0) { int c = (int)((quota + period - 1) / period); if (c >= 1 && c < hw) hw = c; }
+        return hw;
+    }();
+    return n;
+}
 inline int host_threads() {
     int n = getenv("THJ_HOST_THREADS") ? atoi(getenv("THJ_HOST_THREADS")) : 0;
-    if (n <= 0) { n = (int)std::thread::hardware_concurrency(); if (n > 32) n = 32; }
+    if (n <= 0) { n = effective_cpus(); if (n > 32) n = 32; }
     return n < 1 ? 1 : n;
 }
 
@@ -429,6 +461,15 @@ public:
     void close() { if (gz_) gzclose(gz_); if (txt_) fclose(txt_); gz_ = nullptr; txt_ = nullptr; free(line_); line_ = nullptr; }
     ~AlnReader() { close(); }
 
+    bool is_bam() const { return bam_; }
+    // the next BAM record as raw bytes (after its block_size field); nullptr at the end of the file
+    const uint8_t* next_raw(int32_t& bs) {
+        int got = gzread(gz_, &bs, 4);
+        if (got != 4) return nullptr;
+        buf_.resize((size_t)bs);
+        rd(buf_.data(), bs, fname.c_str());
+        return buf_.data();
+    }
     bool next(AlnRec& r) {
         // reset in place: the strings keep their capacity from record to record
         r.qname.clear(); r.rname.clear(); r.rnext.clear(); r.pos = -1; r.flag = 0; r.cigar.clear(); r.seq.clear(); r.qual.clear();
@@ -580,6 +621,89 @@ inline bool parse_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& o
     if (n32 > 5) die("Error: segment alignment %s has %d CIGAR operations (this build supports 5)\n", r.qname.c_str(), n32);
     out.h32.ref_id = ref_id; out.h32.left = r.pos;
     out.h32.flags = (uint8_t)(out.h16.flags | ((spliced && r.xs == '-') ? THJ_HIT_ANTISENSE_SPLICE : 0));
+    out.h32.mismatches = mism; out.h32.edit_dist = ed; out.h32.n_cigar = (uint8_t)n32;
+    return true;
+}
+
+// The same factory straight from a BAM record's bytes (no intermediate strings; `tid2ref` = the file's targets resolved to
+// reference-table ids once, 0 = unknown contig): what the segment / read maps of a real run go through, record by record.
+inline bool parse_hit_bam(const uint8_t* d, int32_t bs, const std::vector<uint32_t>& tid2ref, const thj_params& p, Hit& out) {
+    int32_t tid, pos, mtid; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
+    memcpy(&tid, d, 4); memcpy(&pos, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4);
+    memcpy(&l_seq, d + 16, 4); memcpy(&mtid, d + 20, 4);
+    const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF, flag = flag_nc >> 16;
+    const char* q = (const char*)d + 32;                       // NUL-terminated
+    bool end = true;
+    const char* pipe = strrchr(q, '|');
+    if (pipe && strchr(pipe + 1, ':')) {
+        char* e;
+        unsigned long b = 0, c = 0;
+        strtoul(pipe + 1, &e, 10);
+        if (*e == ':') { b = strtoul(e + 1, &e, 10); if (*e == ':') c = strtoul(e + 1, &e, 10); }
+        end = (b + 1 == c);
+    }
+    out.insert_id = (uint32_t)atoi(q);
+    if (tid < 0 || (flag & 4)) return false;
+    size_t pp = 32 + l_rn;
+    int right = pos, read_len = 0, gap = 0, n32 = 0, ind = 0;
+    bool spliced = false;
+    for (uint32_t i = 0; i < n_cig; ++i) {
+        uint32_t c; memcpy(&c, d + pp, 4); pp += 4;
+        const uint32_t len = c >> 4, bop = c & 0xF;
+        if (len == 0) return false;
+        uint32_t op;
+        switch (bop) {                                         // "MIDNSHP=X"
+        case 0: case 7: case 8: op = THJ_CIG_MATCH; right += (int)len; read_len += (int)len; break;
+        case 1: op = THJ_CIG_INS; read_len += (int)len; gap += (int)len; ind += (int)len; break;
+        case 2: op = THJ_CIG_DEL; right += (int)len; gap += (int)len; ind += (int)len; break;
+        case 4: op = THJ_CIG_SOFT_CLIP; read_len += (int)len; break;
+        case 5: continue;
+        case 6: op = 15; break;
+        case 3: op = THJ_CIG_REF_SKIP; spliced = true; if ((int)len > p.max_report_intron) return false; right += (int)len; break;
+        default: return false;
+        }
+        if (n32 < 5) out.h32.cigar[n32] = (op << 28) | (len & 0x0FFFFFFFu);
+        ++n32;
+    }
+    if (mtid >= 0 && mtid != tid) return false;                // the mate maps to another contig (:1409-1415)
+    pp += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+    int nm = 0; char xs = 0;
+    while (pp + 3 <= (size_t)bs) {                             // bam_aux_get for NM / XS / XF
+        const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
+        pp += 3;
+        long long iv = 0; bool isint = false;
+        switch (ty) {
+        case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
+        case 'c': iv = (int8_t)d[pp]; isint = true; pp += 1; break;
+        case 'C': iv = d[pp]; isint = true; pp += 1; break;
+        case 's': { int16_t v; memcpy(&v, d + pp, 2); iv = v; isint = true; pp += 2; break; }
+        case 'S': { uint16_t v; memcpy(&v, d + pp, 2); iv = v; isint = true; pp += 2; break; }
+        case 'i': { int32_t v; memcpy(&v, d + pp, 4); iv = v; isint = true; pp += 4; break; }
+        case 'I': { uint32_t v; memcpy(&v, d + pp, 4); iv = v; isint = true; pp += 4; break; }
+        case 'f': pp += 4; break;
+        case 'd': pp += 8; break;
+        case 'Z': case 'H':
+            if (t0 == 'X' && t1 == 'F') die("Error: fusion (XF) alignments in %s are not supported by this build\n", q);
+            while (pp < (size_t)bs && d[pp]) ++pp;
+            ++pp;
+            break;
+        case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                    pp += 5 + (size_t)cnt * sz; break; }
+        default: pp = (size_t)bs; break;
+        }
+        if (isint && t0 == 'N' && t1 == 'M') nm = (int)iv;
+    }
+    const uint32_t ref_id = (size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0;
+    if (ref_id == 0) return false;
+    const unsigned char mism = (unsigned char)((unsigned char)nm - (unsigned char)ind);
+    const bool anti = (flag & 0x10) != 0;
+    const unsigned char ed = (unsigned char)(mism + gap);
+    out.h16.ref_id = ref_id; out.h16.left = pos; out.h16.right = right;
+    out.h16.flags = (uint8_t)((anti ? THJ_HIT_ANTISENSE : 0) | (end ? THJ_HIT_END : 0));
+    out.h16.edit_dist = ed; out.h16.mismatches = mism; out.h16.read_len = (uint8_t)(read_len > 255 ? 255 : read_len);
+    if (n32 > 5) die("Error: segment alignment %s has %d CIGAR operations (this build supports 5)\n", q, n32);
+    out.h32.ref_id = ref_id; out.h32.left = pos;
+    out.h32.flags = (uint8_t)(out.h16.flags | ((spliced && xs == '-') ? THJ_HIT_ANTISENSE_SPLICE : 0));
     out.h32.mismatches = mism; out.h32.edit_dist = ed; out.h32.n_cigar = (uint8_t)n32;
     return true;
 }
@@ -791,9 +915,20 @@ class HitStream {
         std::vector<Hit> chunk;
         chunk.reserve(8192);
         AlnRec r; Hit h;
-        while (rd_.next(r)) {
+        const bool lean = rd_.is_bam() && !spliced_;
+        std::vector<uint32_t> tid2ref;
+        if (lean) for (auto& t : rd_.targets()) tid2ref.push_back(rt_->get_id(t));
+        for (;;) {
             h = Hit();
-            if (!(spliced_ ? parse_spliced_hit(r, *rt_, *p_, h) : parse_hit(r, *rt_, *p_, h))) continue;
+            if (lean) {
+                int32_t bs = 0;
+                const uint8_t* d = rd_.next_raw(bs);
+                if (!d) break;
+                if (!parse_hit_bam(d, bs, tid2ref, *p_, h)) continue;
+            } else {
+                if (!rd_.next(r)) break;
+                if (!(spliced_ ? parse_spliced_hit(r, *rt_, *p_, h) : parse_hit(r, *rt_, *p_, h))) continue;
+            }
             if (h.insert_id < begin_id_) continue;       // the index entry the shard starts from lies at or before begin_id
             if (h.insert_id >= end_id_) break;           // id-sorted file: the shard is over
             chunk.push_back(h);
