@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Mint the fixtures under tests/golden_ref/ from the regression test cases the reference itself ships
-(/root/reference/tests/regression_tests/test_cases: test_SimpleSplicing, test_SimpleIndel, test_IndelWithErrors --
-a 495-base genome, 24-base reads, `tophat --segment-length 12`, and the tophat_out/ the reference's authors recorded).
+(/root/reference/tests/regression_tests/test_cases, all nine of them: a 495-base genome, 24-base reads -- single-end,
+paired-end, reverse-complemented, lower-case -- `tophat --segment-length 12` (or 8: test_3Segment), and the tophat_out/ the
+reference's authors recorded).
 Only DATA is taken over, trimmed to the columns the tests use:
 
   genome.fa          the case's genome (common_genomes/fake.fa), verbatim
-  reads.tsv          read name <tab> bases of input/*.fq, in file order (prep_reads numbers them 1..N in this order)
+  reads.tsv          read name <tab> bases of input/*.fq, in file order (prep_reads numbers them 1..N in this order);
+                     reads_right.tsv = the second mates of a paired-end case
+  input_insertions.bed   the insertions file test_Indel_1 passes with --insertions
   junctions.bed / insertions.bed / deletions.bed     the recorded tophat_out files, verbatim
   accepted_hits.tsv  QNAME FLAG POS CIGAR NM of every record of the recorded accepted_hits.sam
   command.txt        the recorded command line
@@ -17,20 +20,27 @@ import shutil
 
 SRC = "/root/reference/tests/regression_tests/test_cases"
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = {"test_SimpleSplicing": "fakeReads.fq", "test_SimpleIndel": "fakeReads.fq", "test_IndelWithErrors": "fakeReads_errors.fq"}
+# case -> read files (one: single-end; two: the mates of a paired-end run, ids shared by file order)
+CASES = {"test_SimpleSplicing": ["fakeReads.fq"], "test_SimpleIndel": ["fakeReads.fq"], "test_IndelWithErrors": ["fakeReads_errors.fq"],
+         "test_Paired": ["readOne.fq", "readTwo.fq"], "test_3Segment": ["readOne.fq", "readTwo.fq"],
+         "test_ReverseComplementSplicing": ["fakeReads_rc.fq"], "test_ReverseComplementIndel": ["fakeReads_rc.fq"],
+         "test_IndelLowerCase": ["fakeReads.fq"], "test_Indel_1": ["fakeReads_read28.fq"]}
 
-for case, fq in CASES.items():
+for case, fqs in CASES.items():
     d = os.path.join(HERE, case)
     os.makedirs(d, exist_ok=True)
     shutil.copyfile(os.path.join(SRC, "common_genomes", "fake.fa"), os.path.join(d, "genome.fa"))
     shutil.copyfile(os.path.join(SRC, case, "command.txt"), os.path.join(d, "command.txt"))
     for bed in ("junctions.bed", "insertions.bed", "deletions.bed"):
         shutil.copyfile(os.path.join(SRC, case, "tophat_out", bed), os.path.join(d, bed))
-    lines = open(os.path.join(SRC, case, "input", fq)).read().split("\n")
-    with open(os.path.join(d, "reads.tsv"), "w") as f:
-        for i in range(0, len(lines) - 3, 4):
-            assert lines[i].startswith("@") and lines[i + 2].startswith("+")
-            f.write("%s\t%s\n" % (lines[i][1:].split()[0], lines[i + 1].strip()))
+    for k, fq in enumerate(fqs):
+        lines = open(os.path.join(SRC, case, "input", fq)).read().split("\n")
+        with open(os.path.join(d, "reads.tsv" if k == 0 else "reads_right.tsv"), "w") as f:
+            for i in range(0, len(lines) - 3, 4):
+                assert lines[i].startswith("@") and lines[i + 2].startswith("+")
+                f.write("%s\t%s\n" % (lines[i][1:].split()[0], lines[i + 1].strip()))
+    if os.path.exists(os.path.join(SRC, case, "input", "insertions.bed")):      # tophat --insertions <file> (test_Indel_1)
+        shutil.copyfile(os.path.join(SRC, case, "input", "insertions.bed"), os.path.join(d, "input_insertions.bed"))
     with open(os.path.join(d, "accepted_hits.tsv"), "w") as f:
         for l in open(os.path.join(SRC, case, "tophat_out", "accepted_hits.sam")):
             if l.startswith("@"):

@@ -755,9 +755,10 @@ extern "C" int thj_segjuncs_reset_async(thj_ctx* c) {
 }
 
 static int check_params(const thj_params* p, const thj_seg_batch* b) {
-    if (p->segment_length < 10 || p->segment_length > 64) {
-        thj_set_error("segment_length %d unsupported by the device path (10..64: a 2L read piece and an L+16 support "
-                      "read must fit one 128-bit plane word)", p->segment_length);
+    if (p->segment_length < 8 || p->segment_length > 64) {
+        thj_set_error("segment_length %d unsupported by the device path (8..64: the 8 bases either side of a segment boundary "
+                      "that make a support read must lie inside the segments, segment_juncs.cpp:3580-3584; a 2L read piece and an "
+                      "L+16 support read must fit one 128-bit plane word)", p->segment_length);
         return THJ_EINVAL;
     }
     if (p->max_insertion_length > 6 || p->max_insertion_length < 0) { thj_set_error("max_insertion_length %d unsupported (0..6)", p->max_insertion_length); return THJ_EINVAL; }

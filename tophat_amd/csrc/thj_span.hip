@@ -497,7 +497,7 @@ static int ensure_slots(thj_ctx* c, int64_t want) {
 }
 
 static int check_span_params(const thj_params* p, const thj_span_batch* b) {
-    if (p->segment_length < 10 || p->segment_length > 64) { thj_set_error("segment_length %d unsupported by the stitch kernel (10..64)", p->segment_length); return THJ_EINVAL; }
+    if (p->segment_length < 8 || p->segment_length > 64) { thj_set_error("segment_length %d unsupported by the stitch kernel (8..64)", p->segment_length); return THJ_EINVAL; }
     if (p->max_insertion_length < 0 || p->max_insertion_length > 6) { thj_set_error("max_insertion_length %d unsupported (0..6)", p->max_insertion_length); return THJ_EINVAL; }
     if (p->max_report_intron + 64 >= (1 << 29)) { thj_set_error("max_report_intron too large for the packed key"); return THJ_EINVAL; }
     if (b->nseg < 1 || b->nseg > SPAN_MAXSEG) { thj_set_error("nseg %d unsupported (1..8)", b->nseg); return THJ_EINVAL; }
