@@ -362,6 +362,27 @@ int thj_covsearch_device_state(thj_ctx* ctx, const uint64_t** d_cov_bits, int64_
 int thj_covsearch_merge_async(thj_ctx* ctx, const uint64_t* d_other_bits, const int32_t* d_other_size,
                               const uint32_t* d_other_keys, const uint64_t* d_other_vals, int64_t n_other_ext);
 
+/* ---------------------------------------------------------------- junction consensus
+ * What tophat_reports does with the reported alignments to get junctions.bed: every REF_SKIP is a junction observation
+ * (junctions_from_spliced_hit, junctions.cpp:19-97), observations of one junction merge (support adds up, extents take the
+ * maximum: JunctionStats::merge_with, junctions.h:87-101), filter_junctions (accept_if_valid + knockout_shadow_junctions,
+ * junctions.cpp:192-330) judges the set, alignments on a rejected junction are dropped and the rest make the final set
+ * (tophat_reports.cpp:1182-1230), minus junctions whose extents stay below 8 (:2974-2984).  Not included: tophat_reports'
+ * choice of which alignments of a read to report -- every record handed in counts.
+ * Call order: reset; add (any number of times); finish; download. */
+typedef struct { uint32_t ref_id, left, right, antisense, left_extent, right_extent, support, reserved; } thj_juncstat;
+/* Capacity (distinct junctions) of the device table; default: four times the candidate set of the spanning pass, >= 2^20. */
+int thj_juncbed_configure(thj_ctx* ctx, int64_t junction_capacity);
+int thj_juncbed_reset_async(thj_ctx* ctx);
+/* The records of the last long_spanning_reads pass, still resident on the device (after thj_span_finish). */
+int thj_juncbed_add_span_async(thj_ctx* ctx);
+/* Any alignment records (HOST array, or DEVICE array when on_device != 0): ref_id, left, flags & THJ_HIT_ANTISENSE_SPLICE,
+ * n_cigar and cigar are read. */
+int thj_juncbed_add_records(thj_ctx* ctx, const thj_aln* recs, int64_t n, int32_t on_device);
+/* Filters, second pass, final set in Junction::operator< order; synchronises.  min_anchor_len = --min-anchor (common.cpp:105). */
+int thj_juncbed_finish(thj_ctx* ctx, int32_t min_anchor_len, int64_t* n_juncs);
+int thj_juncbed_download(thj_ctx* ctx, thj_juncstat* out);
+
 /* ---------------------------------------------------------------- multi-GPU exchange step
  * Reads shard over GPUs (contiguous read-id ranges, the reference's own thread partition: utils.cpp:22-170,
  * segment_juncs.cpp:4793-4810), the genome is replicated, and the per-rank event sets are united ONCE before

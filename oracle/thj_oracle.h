@@ -223,6 +223,15 @@ int orc_spanning_batch(const orc_span_params* p, const orc_genome* g, const orc_
                        orc_aln** out, int64_t* n_out);
 void orc_free(void* p);
 
+
+/* ---- junction consensus of tophat_reports (juncbed_oracle.c): the reported alignments'
+ * REF_SKIPs reduced to the JunctionSet that becomes junctions.bed.  A record = the fields of an alignment the reduce
+ * reads; cigar = ORC_CIG(op, len) with CigarOpCode values (bwt_map.h:36-55). */
+typedef struct { uint32_t ref_id; int32_t left; uint8_t antisense_splice; uint8_t n_cigar; uint16_t reserved; uint32_t cigar[16]; } orc_jrec;
+typedef struct { uint32_t ref_id, left, right, antisense, left_extent, right_extent, support, reserved; } orc_jstat;
+int   orc_junction_consensus(const orc_jrec* recs, int64_t n_recs, int min_anchor_len, orc_jstat** out, int64_t* n_out);
+char* orc_junctions_bed(const orc_jstat* j, int64_t n, const char* const* names);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,7 +10,7 @@ Only DATA is taken over, trimmed to the columns the tests use:
                      reads_right.tsv = the second mates of a paired-end case
   input_insertions.bed   the insertions file test_Indel_1 passes with --insertions
   junctions.bed / insertions.bed / deletions.bed     the recorded tophat_out files, verbatim
-  accepted_hits.tsv  QNAME FLAG POS CIGAR NM of every record of the recorded accepted_hits.sam
+  accepted_hits.tsv  QNAME FLAG POS CIGAR NM XS of every record of the recorded accepted_hits.sam
   command.txt        the recorded command line
 
 Run in the build container (the reference tree does not exist on the GPU box):  python tests/golden_ref/make_ref_regression.py
@@ -47,5 +47,6 @@ for case, fqs in CASES.items():
                 continue
             t = l.rstrip("\n").split("\t")
             nm = [x[5:] for x in t[11:] if x.startswith("NM:i:")]
-            f.write("\t".join([t[0], t[1], t[3], t[5], nm[0] if nm else "."]) + "\n")
+            xs = [x[5:] for x in t[11:] if x.startswith("XS:A:")]
+            f.write("\t".join([t[0], t[1], t[3], t[5], nm[0] if nm else ".", xs[0] if xs else "."]) + "\n")
     print(case, "->", d)

@@ -314,3 +314,48 @@ def coverage_search(g: Genome, hits: np.ndarray, ium_reads, min_cov_length: int 
         a = np.frombuffer((C.c_char * (n.value * 16)).from_address(out.value), dtype=JUNC_DTYPE).copy()
     lib.orc_free(out)
     return a
+
+
+# ---- junction consensus of tophat_reports (juncbed_oracle.c)
+JREC_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<i4"), ("antisense_splice", "u1"), ("n_cigar", "u1"), ("reserved", "<u2"), ("cigar", "<u4", 16)])
+JSTAT_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<u4"), ("right", "<u4"), ("antisense", "<u4"), ("left_extent", "<u4"),
+                        ("right_extent", "<u4"), ("support", "<u4"), ("reserved", "<u4")])
+
+
+def jrecs_from_tuples(recs) -> np.ndarray:
+    """[(ref_id, left, antisense_splice, [(op, len) ...])] -> JREC_DTYPE array"""
+    a = np.zeros(len(recs), dtype=JREC_DTYPE)
+    for k, (ref, left, anti, cig) in enumerate(recs):
+        a[k]["ref_id"], a[k]["left"], a[k]["antisense_splice"], a[k]["n_cigar"] = ref, left, 1 if anti else 0, len(cig)
+        for i, (op, ln) in enumerate(cig):
+            a[k]["cigar"][i] = (op << 28) | ln
+    return a
+
+
+def jrecs_from_alns(alns) -> np.ndarray:
+    """tophat_amd.batch.Aln list (a long_spanning_reads result) -> JREC_DTYPE array"""
+    return jrecs_from_tuples([(a.ref_id, a.left, a.antisense_splice, [(c >> 28, c & 0x0FFFFFFF) for c in a.cigar]) for a in alns])
+
+
+def junction_consensus(jrecs: np.ndarray, min_anchor_len: int = 8) -> np.ndarray:
+    lib = _lib()
+    out = C.c_void_p()
+    n = C.c_int64()
+    a = np.ascontiguousarray(jrecs, dtype=JREC_DTYPE)
+    rc = lib.orc_junction_consensus(C.c_void_p(a.ctypes.data), C.c_int64(len(a)), min_anchor_len, C.byref(out), C.byref(n))
+    assert rc == 0
+    res = np.ctypeslib.as_array((C.c_uint8 * (n.value * JSTAT_DTYPE.itemsize)).from_address(out.value)).view(JSTAT_DTYPE).copy() if n.value else \
+        np.zeros(0, dtype=JSTAT_DTYPE)
+    lib.orc_free(out)
+    return res
+
+
+def junctions_bed(jstats: np.ndarray, names) -> str:
+    lib = _lib()
+    lib.orc_junctions_bed.restype = C.c_void_p
+    a = np.ascontiguousarray(jstats, dtype=JSTAT_DTYPE)
+    nm = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    p = lib.orc_junctions_bed(C.c_void_p(a.ctypes.data), C.c_int64(len(a)), nm)
+    s = C.string_at(p).decode()
+    lib.orc_free(C.c_void_p(p))
+    return s

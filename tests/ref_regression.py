@@ -135,7 +135,7 @@ def load(case: str, tmp_path, juncs_db_text):
     span_juncs, span_ins = events_to_span_inputs(ev)
     expected = {sd: [] for sd in sides}
     for l in open(os.path.join(d, "accepted_hits.tsv")):
-        qn, flag, pos, cigar, nm = l.rstrip("\n").split("\t")
+        qn, flag, pos, cigar, nm = l.rstrip("\n").split("\t")[:5]
         sd = "right" if (int(flag) & 0x80) else "left"
         expected[sd].append((ids[qn], int(flag) & 16, int(pos), cigar, int(nm)))
     for sd, S in sides.items():
@@ -225,3 +225,14 @@ def write_program_inputs(case_data, tmp_path):
             g["segs"].append(path)
         f[sd] = g
     return f
+
+
+def recorded_alignment_records(case: str):
+    """the recorded accepted hits as junction-consensus input records: [(ref_id, left, antisense_splice, [(op, len) ...])]"""
+    out = []
+    opmap = {"M": 1, "I": 3, "D": 5, "N": 11, "S": 13}
+    for l in open(os.path.join(GOLD, case, "accepted_hits.tsv")):
+        t = l.rstrip("\n").split("\t")
+        cig = [(opmap[o], int(n)) for n, o in re.findall(r"(\d+)([MIDNS])", t[3])]
+        out.append((1, int(t[2]) - 1, t[5] == "-", cig))
+    return out

@@ -63,3 +63,20 @@ def test_no_device_gives_loud_error():
         pass
     with pytest.raises(host.ThjError):
         host.Context(0)
+
+
+def test_genome_layout_refuses_what_the_packed_keys_cannot_hold():
+    """junction / insertion keys keep the global base coordinate in 34 bits: a layout beyond 2^34 bases is refused, not aliased"""
+    import ctypes as C
+    import numpy as np
+    from tophat_amd import host
+    lib = host.load_lib()
+    n = 9
+    lens = np.full(n, 0x7fffffff, dtype=np.int64)          # 9 x 2^31 > 2^34
+    blk = np.zeros(n + 1, dtype=np.uint32)
+    nb = C.c_int64()
+    assert lib.thj_genome_layout(n, lens.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), C.byref(nb)) == -1      # THJ_EINVAL
+    assert b"2^34" in lib.thj_last_error()
+    lens = np.full(7, 0x7fffffff, dtype=np.int64)          # 7 x 2^31 < 2^34: fine
+    blk = np.zeros(8, dtype=np.uint32)
+    assert lib.thj_genome_layout(7, lens.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0

@@ -71,6 +71,11 @@ struct thj_ctx {
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
     std::vector<thj_fusion> h_fusions;
+    // junction consensus (thj_juncbed_impl.h)
+    u64* d_jb_key = nullptr; uint32_t* d_jb_u32 = nullptr; u64* d_jb_list = nullptr; u64* d_jb_sorted = nullptr;
+    unsigned long long* d_jb_cnt = nullptr; void* d_jb_occ = nullptr;
+    int64_t jb_cap = 0, jb_occ_cap = 0, jb_occ_used = 0, jb_want = 0;
+    std::vector<thj_juncstat> h_jb;
     // multi-GPU exchange step pending a look at its gathered headers (thj_exchange_impl.h)
     struct thj_comm* xchg = nullptr;
     // profiling

@@ -49,7 +49,8 @@ extern "C" int thj_genome_layout(int32_t n_contigs, const int64_t* lens, uint32_
         if (lens[i] < 0 || lens[i] > 0x7fffffff) { thj_set_error("contig %d length %lld unsupported", i, (long long)lens[i]); return THJ_EINVAL; }
         contig_blk[i] = (uint32_t)b;
         b += (lens[i] + 63) / 64 + 1;       // one zero guard block after every contig
-        if (b > 0xfffffff0ll) { thj_set_error("genome too large for 32-bit block index"); return THJ_EINVAL; }
+        // the packed event keys keep the global base coordinate (+1) in 34 bits (junc_key / ins_key, thj_core.h)
+        if (b * 64 + 1 >= (1ll << 34)) { thj_set_error("genome too large: %lld bases with guard blocks, the packed event keys hold 2^34", (long long)(b * 64)); return THJ_EINVAL; }
     }
     contig_blk[n_contigs] = (uint32_t)b;
     *n_blocks = b + 1;                      // and one at the very end for the funnel's second load

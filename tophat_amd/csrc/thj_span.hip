@@ -295,7 +295,9 @@ static int build_junc_buckets(thj_ctx* c) {
     return THJ_OK;
 }
 
+static void jb_free(thj_ctx* c);
 void thj_span_free(thj_ctx* c) {
+    jb_free(c);
     hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
@@ -382,6 +384,10 @@ extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
         // Sorted, NOT made unique: a deletion and a '+' junction with the same ends give the same key twice, and
         // a repeated key is harmless to its only consumer -- closure_search skips a candidate that does not improve
         // on the best one (`diff >= best_diff`), which an identical twin never does.
+        // the sort scratch was sized for the larger of the two event tables; junctions + deletions together can exceed it
+        size_t need = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, (const u64*)c->d_span_cat, c->d_span_junc, nj, 0, 64, c->stream));
+        if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
         size_t tmp = c->sort_tmp_bytes;
         HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_span_cat, c->d_span_junc, nj, 0, 64, c->stream));
         c->n_span_junc = nj;
@@ -683,3 +689,5 @@ extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t*
     c->span_profile = enable != 0;
     return THJ_OK;
 }
+
+#include "thj_juncbed_impl.h"

@@ -550,6 +550,66 @@ def _span_methods():
 
 _span_methods()
 
+ABI_SYMBOLS += ["thj_juncbed_configure", "thj_juncbed_reset_async", "thj_juncbed_add_span_async", "thj_juncbed_add_records",
+                "thj_juncbed_finish", "thj_juncbed_download"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
                 "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
+
+
+# ------------------------------------------------------------------ junction consensus (thj_juncbed_*)
+
+JUNCSTAT_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<u4"), ("right", "<u4"), ("antisense", "<u4"), ("left_extent", "<u4"),
+                           ("right_extent", "<u4"), ("support", "<u4"), ("reserved", "<u4")])
+
+
+def junctions_bed_text(js: np.ndarray, names: Sequence[str]) -> str:
+    """print_junctions / print_junction (junctions.cpp:100-120, :330-350)"""
+    out = ['track name=junctions description="TopHat junctions"\n']
+    for k, j in enumerate(js):
+        start = int(j["left"]) + 1 - int(j["left_extent"])
+        end = int(j["right"]) + int(j["right_extent"])
+        out.append("%s\t%d\t%d\tJUNC%08d\t%d\t%s\t%d\t%d\t255,0,0\t2\t%d,%d\t0,%d\n" % (
+            names[int(j["ref_id"]) - 1], start, end, k + 1, int(j["support"]), "-" if j["antisense"] else "+", start, end,
+            int(j["left_extent"]), int(j["right_extent"]), int(j["right"]) - start))
+    return "".join(out)
+
+
+def _juncbed_methods():
+    def juncbed_configure(self, capacity: int):
+        _check(self.lib, self.lib.thj_juncbed_configure(self._ctx, C.c_int64(capacity)), "thj_juncbed_configure")
+
+    def juncbed_reset(self):
+        _check(self.lib, self.lib.thj_juncbed_reset_async(self._ctx), "thj_juncbed_reset_async")
+
+    def juncbed_add_span(self):
+        """folds the records of the last spanning pass (still on the device) in"""
+        _check(self.lib, self.lib.thj_juncbed_add_span_async(self._ctx), "thj_juncbed_add_span_async")
+
+    def juncbed_add_records(self, recs: np.ndarray):
+        """recs: ALN_DTYPE array (ref_id, left, flags & 4 = antisense splice, n_cigar, cigar are read)"""
+        a = np.ascontiguousarray(recs, dtype=ALN_DTYPE)
+        _check(self.lib, self.lib.thj_juncbed_add_records(self._ctx, _ptr(a) if len(a) else None, C.c_int64(len(a)), 0), "thj_juncbed_add_records")
+
+    def juncbed_finish(self, min_anchor_len: int = 8) -> np.ndarray:
+        n = C.c_int64()
+        _check(self.lib, self.lib.thj_juncbed_finish(self._ctx, min_anchor_len, C.byref(n)), "thj_juncbed_finish")
+        out = np.zeros(max(1, n.value), dtype=JUNCSTAT_DTYPE)
+        _check(self.lib, self.lib.thj_juncbed_download(self._ctx, _ptr(out)), "thj_juncbed_download")
+        return out[:n.value]
+
+    for f in (juncbed_configure, juncbed_reset, juncbed_add_span, juncbed_add_records, juncbed_finish):
+        setattr(Context, f.__name__, f)
+
+
+_juncbed_methods()
+
+
+def aln_array_from_tuples(recs) -> np.ndarray:
+    """[(ref_id, left, antisense_splice, [(op, len) ...])] -> ALN_DTYPE array (the fields the junction consensus reads)"""
+    a = np.zeros(len(recs), dtype=ALN_DTYPE)
+    for k, (ref, left, anti, cig) in enumerate(recs):
+        a[k]["ref_id"], a[k]["left"], a[k]["flags"], a[k]["n_cigar"] = ref, left, 4 if anti else 0, len(cig)
+        for i, (op, ln) in enumerate(cig):
+            a[k]["cigar"][i] = (op << 28) | ln
+    return a
