@@ -317,7 +317,7 @@ def e2e_leg(args):
         from e2e_bench import run_e2e
         res = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns)
         keep = ("pairs", "input_bytes", "gen_seconds", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s",
-                "both_stages_s", "junctions")
+                "both_stages_s", "junctions", "junctions_bed_s", "junctions_bed_lines")
         out = {k: res[k] for k in keep}
         out["value"] = res["pairs"] / res["both_stages_s"]
         out["unit"] = "read-pairs/s (wall clock of both executables, files in -> files out, 1 GPU, host CPUs: %s)" % (_cpu_quota(),)
@@ -378,6 +378,7 @@ def e2e_sample_check(d, args, pairs=20000):
     same_events = all(open(out[k]).read() == wt[k] for k in ("juncs", "insertions", "deletions"))
     jj, ii = events_to_span_inputs(want)
     n_rec, same_recs = 0, True
+    all_alns = []
     for sd in ("left", "right"):
         bam = f("span_%s.bam" % sd)
         subprocess.check_call([os.path.join(bind, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
@@ -385,13 +386,20 @@ def e2e_sample_check(d, args, pairs=20000):
         quals = {k: "I" * len(v) for k, v in sides[sd]["reads"].items()}
         sb = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], quals)
         alns = orc.spanning(Params(), og, sb, jj, ii)
+        all_alns += alns
         wrecs = [tuple(str(x) for x in a.sam_fields(int(sb.read_id[a.read_idx]), names)) for a in alns]
         _, recs = read_bam(bam)
         grecs = [tuple(str(x) for x in (r[0], r[1], r[2], r[3], r[5]) + tuple(r[8:])) for r in recs]
         n_rec += len(grecs)
         same_recs = same_recs and grecs == wrecs
+    # junctions.bed: the drop-in consensus program on the two spanning BAMs vs the oracle's consensus of the oracle's records
+    subprocess.check_call([os.path.join(bind, "thj_junctions"), "--sam-header", f("hdr.sam"), f("ref.fa"), f("junctions.bed"),
+                           f("span_left.bam") + "," + f("span_right.bam")], stderr=subprocess.DEVNULL)
+    want_bed = orc.junctions_bed(orc.junction_consensus(orc.jrecs_from_alns(all_alns)), names)
+    same_bed = open(f("junctions.bed")).read() == want_bed
     return {"pairs": pairs, "junctions": len(want.juncs), "event_files_identical_to_oracle": bool(same_events),
-            "spanning_records": n_rec, "spanning_records_identical_to_oracle": bool(same_recs)}
+            "spanning_records": n_rec, "spanning_records_identical_to_oracle": bool(same_recs),
+            "junctions_bed_lines": want_bed.count("\n") - 1, "junctions_bed_identical_to_oracle": bool(same_bed)}
 
 
 def run_rank(args, rank, world, local_rank, control, shared):

@@ -64,6 +64,14 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
         tot += dt
     res["both_stages_s"] = round(tot, 3)
     res["pairs_per_s_both_stages"] = round(pairs / tot)
+    # the junction consensus (tophat_reports' part of the metric's "junctions.bed"): timed on its own, not part of both_stages_s
+    t = time.time()
+    r = subprocess.run([os.path.join(BIN, "thj_junctions"), "--sam-header", f("hdr.sam"), f("ref.fa"), f("junctions.bed"),
+                        f("span_left.bam") + "," + f("span_right.bam")], capture_output=True, text=True, env=env)
+    if r.returncode != 0:
+        raise RuntimeError("thj_junctions failed:\n" + r.stderr[-3000:])
+    res["junctions_bed_s"] = round(time.time() - t, 3)
+    res["junctions_bed_lines"] = sum(1 for _ in open(f("junctions.bed"))) - 1
     if not keep and workdir is None:
         shutil.rmtree(d, ignore_errors=True)
     return res

@@ -1,0 +1,107 @@
+// thj_junctions -- the junction consensus of tophat_reports as a program: reads the alignments
+// tophat_reports would report from BAM files (the spanning BAMs of long_spanning_reads, whole-read maps, an accepted_hits
+// file ...), reduces their REF_SKIPs to the JunctionSet on the device (thj_juncbed_*, include/thj.h) and prints junctions.bed
+// exactly as print_junctions does (junctions.cpp:100-120, :330-350).
+//
+//   thj_junctions [--min-anchor N] [--sam-header hdr.sam] <ref.fa> <junctions.bed> <in1.bam[,in2.bam,...]>
+//
+// Not tophat_reports: the choice among a read's alignments (read_best_alignments, pair grading, realign_reads) is not made
+// here -- every record of the inputs counts as reported.  Records without a REF_SKIP cannot touch the result and are skipped
+// while reading.
+#include "thj_hostio.h"
+
+using namespace thjh;
+
+static void usage() { fprintf(stderr, "Usage:   thj_junctions [--min-anchor N] [--sam-header hdr.sam] <ref.fa> <junctions.bed> <alignments1.bam[,alignments2.bam,...]>\n"); }
+
+int main(int argc, char** argv) {
+    Opts o;
+    int rc = parse_options(argc, argv, o, usage);
+    if (rc) return rc;
+    std::vector<std::string> pos;
+    for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
+    if (pos.size() < 3) { usage(); return 1; }
+    std::future<thj_ctx*> fut = std::async(std::launch::async, []() {
+        thj_ctx* c = nullptr;
+        if (thj_ctx_create(getenv("THJ_DEVICE") ? atoi(getenv("THJ_DEVICE")) : 0, nullptr, &c)) die("Error: %s\n", thj_last_error());
+        return c;
+    });
+    RefTable rt;
+    rt.load_sam_header(o.sam_header);
+    rt.load_fasta(pos[0]);
+    std::vector<std::string> inputs = split(pos[2], ',');
+    for (auto& f : inputs) register_targets(f, rt);
+    rt.freeze();
+    // ---- one reader thread per input: spliced records -> thj_aln (only the fields the reduce reads)
+    std::vector<std::vector<thj_aln>> recs(inputs.size());
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < inputs.size(); ++k) th.emplace_back([&, k]() {
+        AlnReader rd;
+        if (!rd.open(inputs[k])) die("Error: cannot open %s\n", inputs[k].c_str());
+        if (!rd.is_bam()) die("Error: %s: BAM input expected\n", inputs[k].c_str());
+        std::vector<uint32_t> tid2ref;
+        for (auto& t : rd.targets()) tid2ref.push_back(rt.get_id(t));
+        static const uint32_t OPS[9] = {THJ_CIG_MATCH, THJ_CIG_INS, THJ_CIG_DEL, THJ_CIG_REF_SKIP, THJ_CIG_SOFT_CLIP, 14u, 15u, THJ_CIG_MATCH, THJ_CIG_MATCH};
+        int32_t bs = 0;
+        while (const uint8_t* d = rd.next_raw(bs)) {
+            int32_t tid, p0; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
+            memcpy(&tid, d, 4); memcpy(&p0, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4); memcpy(&l_seq, d + 16, 4);
+            const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF;
+            if (tid < 0 || ((flag_nc >> 16) & 4) || n_cig < 3 || n_cig > 16) continue;
+            thj_aln a; memset(&a, 0, sizeof a);
+            bool spliced = false;
+            size_t pp = 32 + l_rn;
+            for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + pp, 4); pp += 4; const uint32_t op = (c & 0xF) < 9 ? OPS[c & 0xF] : 15u; if (op == THJ_CIG_REF_SKIP) spliced = true; a.cigar[i] = (op << 28) | (c >> 4); }
+            if (!spliced) continue;
+            pp += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+            char xs = 0;
+            while (pp + 3 <= (size_t)bs) {                        // XS:A
+                const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
+                pp += 3;
+                switch (ty) {
+                case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
+                case 'c': case 'C': pp += 1; break;
+                case 's': case 'S': pp += 2; break;
+                case 'i': case 'I': case 'f': pp += 4; break;
+                case 'd': pp += 8; break;
+                case 'Z': case 'H': while (pp < (size_t)bs && d[pp]) ++pp; ++pp; break;
+                case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); pp += 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
+                default: pp = (size_t)bs; break;
+                }
+            }
+            a.ref_id = (size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0;
+            if (!a.ref_id) continue;
+            a.left = p0; a.n_cigar = (uint8_t)n_cig;
+            a.flags = (uint8_t)(xs == '-' ? THJ_HIT_ANTISENSE_SPLICE : 0);
+            recs[k].push_back(a);
+        }
+    });
+    for (auto& t : th) t.join();
+    thj_ctx* ctx = fut.get();
+    rt.upload(ctx);
+    int64_t cap = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (cap && thj_juncbed_configure(ctx, cap)) die("Error: %s\n", thj_last_error());
+        if (thj_juncbed_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+        for (auto& v : recs) if (thj_juncbed_add_records(ctx, v.data(), (int64_t)v.size(), 0)) die("Error: %s\n", thj_last_error());
+        int64_t n = 0;
+        rc = thj_juncbed_finish(ctx, o.p.min_anchor_len, &n);
+        if (rc == THJ_EOVERFLOW && attempt < 6) { cap = cap ? cap * 4 : (int64_t)1 << 22; continue; }     // more distinct junctions than the table holds
+        if (rc) die("Error: %s\n", thj_last_error());
+        std::vector<thj_juncstat> js((size_t)n + 1);
+        if (thj_juncbed_download(ctx, js.data())) die("Error: %s\n", thj_last_error());
+        FILE* f = fopen(pos[1].c_str(), "w");
+        if (!f) die("Error: cannot open %s for writing\n", pos[1].c_str());
+        fprintf(f, "track name=junctions description=\"TopHat junctions\"\n");
+        for (int64_t i = 0; i < n; ++i) {
+            const thj_juncstat& j = js[(size_t)i];
+            const int start = (int)j.left + 1 - (int)j.left_extent, end = (int)j.right + (int)j.right_extent;
+            fprintf(f, "%s\t%d\t%d\tJUNC%08d\t%d\t%c\t%d\t%d\t255,0,0\t2\t%d,%d\t0,%d\n", rt.names[j.ref_id - 1].c_str(), start, end, (int)(i + 1), (int)j.support,
+                    j.antisense ? '-' : '+', start, end, (int)j.left_extent, (int)j.right_extent, (int)j.right - start);
+        }
+        fclose(f);
+        break;
+    }
+    fflush(nullptr);
+    _exit(0);
+}

@@ -152,8 +152,11 @@ __global__ __launch_bounds__(256) void thj_k_jb_knockout(JbTable t, const u64* s
         uint32_t ok = t.acc[si];
         if (ok && t.left[si] >= (uint32_t)min_anchor) {        // left < anchor: the reference's unsigned left wraps, the range is empty
             const u64 anti = k & 1ull, len = (k >> 1) & ((1ull << 29) - 1), gp = k >> 30;
-            const u64 lo = ((gp - (u64)min_anchor) << 30) | (len << 1) | (anti ^ 1ull);
-            const u64 hi = (gp << 30) | (((len + (u64)min_anchor) & ((1ull << 29) - 1)) << 1) | (anti ^ 1ull);
+            // fuzzy_left = (left - anchor, right, !strand), fuzzy_right = (left, right + anchor, !strand): in (left, right - left)
+            // key space both have the length field len + anchor
+            const u64 len2 = (len + (u64)min_anchor) & ((1ull << 29) - 1);
+            const u64 lo = ((gp - (u64)min_anchor) << 30) | (len2 << 1) | (anti ^ 1ull);
+            const u64 hi = (gp << 30) | (len2 << 1) | (anti ^ 1ull);
             int64_t a = 0, b = n;                              // lower_bound(lo)
             while (a < b) { const int64_t m = (a + b) >> 1; if (sorted[m] < lo) a = m + 1; else b = m; }
             const uint32_t my_support = t.cnt1[si];
