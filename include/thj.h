@@ -31,6 +31,8 @@ extern "C" {
 #define THJ_EHIP         -3   /* a HIP runtime call failed */
 #define THJ_EOVERFLOW    -4   /* an event table filled up; re-configure larger and re-run */
 #define THJ_ESTATE       -5   /* call sequence violated (e.g. run before genome upload) */
+#define THJ_EFALLBACK    -6   /* the device-side ingest cannot take this input (records straddle BGZF members, reads > 256 bases ...):
+                                 nothing was done, use the host readers */
 
 typedef struct thj_ctx thj_ctx;
 
@@ -361,6 +363,32 @@ int thj_covsearch_device_state(thj_ctx* ctx, const uint64_t** d_cov_bits, int64_
                                const uint32_t** d_ext_keys, const uint64_t** d_ext_vals, int64_t* n_ext);
 int thj_covsearch_merge_async(thj_ctx* ctx, const uint64_t* d_other_bits, const int32_t* d_other_size,
                               const uint32_t* d_other_keys, const uint64_t* d_other_vals, int64_t n_other_ext);
+
+/* ---------------------------------------------------------------- device-side ingest
+ * BGZF members (samtools-0.1.18 bgzf.c) are independent DEFLATE streams of at most 64 KiB; thj_bgzf_inflate inflates many of
+ * them at once on the GPU (one workgroup per member, tables and window in LDS).  in_off / in_len address a member's DEFLATE
+ * payload (after its 18-byte header, before the 8-byte CRC32 / ISIZE trailer) inside `comp`.  Member b's bytes land at
+ * out + b * 65536, out_len[b] = their number (0xFFFFFFFF: corrupt stream).  on_device == 0: host arrays, synchronous;
+ * != 0: device arrays, the call only enqueues on the context stream. */
+typedef struct { uint64_t in_off; uint32_t in_len; uint32_t reserved; } thj_bgzf_block;
+int thj_bgzf_inflate(thj_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, const thj_bgzf_block* blocks, int64_t n_blocks,
+                     uint8_t* out, uint32_t* out_len, int32_t on_device);
+
+/* One input file's share of a read-id shard, still compressed: `comp` = comp_bytes bytes of the BAM file starting at a BGZF member
+ * (HOST memory, e.g. a mapping of the file) and ending at a member boundary; first_skip = bytes of the first member that come
+ * before the shard's first record (the low 16 bits of the .index offset, or the end of the BAM header); tid2ref[t] = ref_id of
+ * the file's target t (0: a contig the run does not know). */
+typedef struct { const uint8_t* comp; int64_t comp_bytes; uint32_t first_skip; int32_t n_tid; const uint32_t* tid2ref; } thj_bam_piece;
+/* The whole ingest of one shard of one side of segment_juncs on the device: inflates the pieces, parses their records
+ * (BAMHitFactory::get_hit_from_buf, bwt_map.cpp:1101-1452; reads: SEQ -> bit planes), keeps read ids in [begin_id, end_id),
+ * merges the nseg segment maps by read id into the visiting set of look_for_hit_group (segment_juncs.cpp:3823-4123; reads whose
+ * highest mapped segment is the first are left out unless include_top0), joins the mate's hits (whole-read map, else last
+ * segment map: find_gaps :3321-3348) and the reads, and returns a device-resident batch for thj_segjuncs_run_async /
+ * thj_fusion_run_async / thj_covsearch_add_hits_async (thj_batch_free releases it).  *out == NULL with THJ_OK: the shard is
+ * empty.  THJ_EFALLBACK: see above.  mate_full / mate_last may be NULL.  Synchronous. */
+int thj_ingest_seg_batch(thj_ctx* ctx, const thj_params* p, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* mate_full,
+                         const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
+                         uint32_t ordinal_base, thj_seg_batch** out, int64_t* n_reads);
 
 /* ---------------------------------------------------------------- junction consensus
  * What tophat_reports does with the reported alignments to get junctions.bed: every REF_SKIP is a junction observation

@@ -117,6 +117,8 @@ def test_long_spanning_reads_parts_fall_back_to_one_file_on_small_inputs(tmp_pat
 
 def _gen_case(tmp_path, pairs=60000):
     d = str(tmp_path / "gen")
+    if os.path.exists(os.path.join(d, "ref.fa")):
+        return d
     subprocess.check_call([os.path.join(ROOT, "tools", "bin", "thj_gen"), "--out", d, "--pairs", str(pairs), "--genome-len", "3000000",
                            "--introns", "1200", "--threads", "8"], stdout=subprocess.DEVNULL)
     return d
@@ -150,6 +152,17 @@ def test_results_do_not_depend_on_shards_or_workers(tmp_path):
     assert one == many and one["juncs"].count("\n") > 500
     assert gzip.open(bam1, "rb").read() == gzip.open(bam2, "rb").read()
     assert open(bam1 + ".index").read() == open(bam2 + ".index").read()
+
+
+def test_device_ingest_equals_host_ingest(tmp_path):
+    """segment_juncs reading its BAM inputs on the device (BGZF inflate + record parse + merge by read id in HBM) against the
+    host readers: identical event files -- with one shard and with many, paired-end with mate maps"""
+    d = _gen_case(tmp_path, pairs=80000)
+    dev, _, log_dev = _run_both(d, tmp_path, "dev", {"THJ_SHARDS": "7", "THJ_WORKERS": "3"})
+    hst, _, log_hst = _run_both(d, tmp_path, "hst", {"THJ_SHARDS": "7", "THJ_WORKERS": "3", "THJ_HOST_INGEST": "1"})
+    one, _, _ = _run_both(d, tmp_path, "one", {"THJ_SHARDS": "1", "THJ_WORKERS": "1"})
+    assert "reading on the host" not in log_dev
+    assert dev == hst == one and dev["juncs"].count("\n") > 500
 
 
 def test_long_spanning_reads_parts(tmp_path):

@@ -1,0 +1,103 @@
+"""GPU: device-side ingest.  thj_bgzf_inflate against zlib: BGZF members of real BAM files written
+by the host I/O layer, and hand-made DEFLATE streams of every block type (stored, fixed, dynamic), compression level and
+edge (empty input, one byte, 64 KiB of one byte, incompressible data, long-distance matches, codes longer than the direct
+lookup tables), plus corrupt input."""
+import ctypes as C
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from tophat_amd import host
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Block(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+def inflate(ctx, payloads):
+    comp = b"".join(payloads)
+    n = len(payloads)
+    blocks = (Block * n)()
+    off = 0
+    for k, p in enumerate(payloads):
+        blocks[k].in_off, blocks[k].in_len = off, len(p)
+        off += len(p)
+    out = np.zeros(n << 16, dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint32)
+    buf = np.frombuffer(comp + b"\0", dtype=np.uint8)
+    rc = ctx.lib.thj_bgzf_inflate(ctx._ctx, buf.ctypes.data_as(C.c_void_p), C.c_int64(len(comp)), blocks, C.c_int64(n),
+                                  out.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), 0)
+    assert rc == 0, ctx.lib.thj_last_error()
+    return [None if lens[k] == 0xFFFFFFFF else out[k << 16:(k << 16) + int(lens[k])].tobytes() for k in range(n)]
+
+
+def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+    return c.compress(data) + c.flush()
+
+
+def test_handmade_streams():
+    rng = np.random.default_rng(1)
+    datas = [b"", b"A", b"A" * 65536, bytes(rng.integers(0, 256, size=65536, dtype=np.uint8)),
+             bytes(rng.integers(0, 4, size=65536, dtype=np.uint8)), (b"ACGTTGCA" * 9000)[:65536],
+             bytes(rng.integers(0, 256, size=300, dtype=np.uint8)) * 200,                      # long-distance matches (up to 32 KiB back)
+             b"".join(bytes([i % 251]) * (i % 37 + 1) for i in range(3000))[:65536]]
+    # a skewed alphabet: Huffman codes well beyond the 10-bit direct table
+    p = np.array([2.0 ** -k for k in range(1, 41)]); p /= p.sum()
+    datas.append(bytes(rng.choice(40, size=60000, p=p).astype(np.uint8)))
+    payloads, want = [], []
+    for d in datas:
+        for level in (0, 1, 6, 9):
+            payloads.append(raw_deflate(d, level)); want.append(d)
+        payloads.append(raw_deflate(d, 6, zlib.Z_FIXED)); want.append(d)
+        payloads.append(raw_deflate(d, 6, zlib.Z_HUFFMAN_ONLY)); want.append(d)
+    with host.Context(0) as ctx:
+        got = inflate(ctx, payloads)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, "stream %d (%d bytes in, %d out)" % (k, len(payloads[k]), len(w))
+
+
+def test_corrupt_streams_are_flagged_not_trusted():
+    good = raw_deflate(b"the quick brown fox jumps over the lazy dog " * 500)
+    bad = [good[:len(good) // 2],                          # truncated
+           b"\x07" + good[1:],                              # reserved block type 3
+           good[:40] + bytes(40) + good[80:],               # damaged middle
+           b""]                                             # nothing at all
+    with host.Context(0) as ctx:
+        got = inflate(ctx, bad + [good])
+    assert got[-1] == b"the quick brown fox jumps over the lazy dog " * 500
+    assert got[0] is None and got[1] is None and got[3] is None
+    assert got[2] is None or got[2] != b"the quick brown fox jumps over the lazy dog " * 500
+
+
+def bgzf_payloads(path, limit=None):
+    data = open(path, "rb").read()
+    out, isize, off = [], [], 0
+    while off < len(data) and (limit is None or len(out) < limit):
+        assert data[off:off + 4] == b"\x1f\x8b\x08\x04"
+        bsize = struct.unpack_from("<H", data, off + 16)[0] + 1
+        out.append(data[off + 18:off + bsize - 8])
+        isize.append(struct.unpack_from("<I", data, off + bsize - 4)[0])
+        off += bsize
+    return out, isize
+
+
+def test_bam_files_inflate_like_zlib(tmp_path):
+    d = str(tmp_path / "gen")
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "thj_gen"), "--out", d, "--pairs", "40000", "--genome-len", "3000000",
+                           "--introns", "1200", "--threads", "8"], stdout=subprocess.DEVNULL)
+    with host.Context(0) as ctx:
+        for fn in ("left_seg1.bam", "right_map.bam", "left_reads.bam"):
+            pl, isize = bgzf_payloads(os.path.join(d, fn))
+            got = inflate(ctx, pl)
+            assert len(pl) > 10
+            for k, p in enumerate(pl):
+                w = zlib.decompress(p, -15)
+                assert len(w) == isize[k] and got[k] == w, (fn, k)

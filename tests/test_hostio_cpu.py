@@ -53,9 +53,22 @@ def test_bam_writer_is_thread_and_batch_invariant(exe, tmp_path):
     recs = list(recs)
     assert names == ["chr1", "chr2"] and len(recs) == n
     assert [int(r[0]) for r in recs] == [1 + (i // 2) * 3 for i in range(n)]
-    # BGZF structure: 64 KiB members (the last data member may be short), then the empty EOF member
+    # BGZF structure as samtools-0.1.18 writes it: the header in a member of its own (bam_header_write ends with bgzf_flush),
+    # then members of at most 64 KiB that hold whole records only (bgzf_flush_try before every record) and are as full as that
+    # allows, then the empty EOF member
     blocks = bgzf_blocks(a)
-    assert len(blocks[-1][1]) == 0 and all(len(r) == 65536 for _, r in blocks[:-2])
+    assert len(blocks[-1][1]) == 0
+    assert blocks[0][1][:4] == b"BAM\x01" and len(blocks[0][1]) < 200
+    sizes = []
+    for _, raw in blocks[1:-1]:
+        assert 0 < len(raw) <= 65536
+        p = 0
+        while p < len(raw):
+            bs = struct.unpack_from("<i", raw, p)[0]
+            p += 4 + bs
+        assert p == len(raw), "a record straddles two members"
+        sizes.append(len(raw))
+    assert all(sz > 65536 - 400 for sz in sizes[:-1])
     # .index: `read_id \\t virtual offset`; every offset is the start of the first record of that read
     by_off = {off: raw for off, raw in blocks}
     lines = [l.split("\t") for l in idx.strip().split("\n")]

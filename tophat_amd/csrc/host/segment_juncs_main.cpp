@@ -40,7 +40,15 @@ struct Shard {
     int64_t read_off = 0;
     std::vector<int64_t> seg_off;                   // one per segment map
     int64_t partner_off = 0, seg_partner_off = 0;   // the mate's whole-read map / last segment map
+    // where the next shard starts in the same files (-1: this is the last one) -- the device-side ingest hands whole pieces over
+    int64_t read_end = -1, partner_end = -1, seg_partner_end = -1;
+    std::vector<int64_t> seg_end;
 };
+
+// BAM inputs mapped once for the device-side ingest (key: file name); a file that is not a BAM, or whose header does not parse,
+// is simply absent and the shards that need it take the host readers
+static std::map<std::string, std::unique_ptr<BamFile>> g_bam;
+static const BamFile* bam_of(const std::string& fn) { auto it = g_bam.find(fn); return it == g_bam.end() ? nullptr : it->second.get(); }
 
 // the reference's shard plan for one side: calculate_offsets over {reads, segment maps} + calculate_offsets_from_ids for the
 // mate's two maps (segment_juncs.cpp:4756-4775); one shard when an input has no usable index
@@ -76,6 +84,17 @@ static std::vector<Shard> plan_side(const SideInput& in, const SideInput* mate, 
         }
         sh.end_id = i + 1 < want ? ids[(size_t)i] : ~0ull;
     }
+    for (int i = 0; i < want; ++i) {
+        Shard& sh = out[(size_t)i];
+        sh.seg_end.assign(in.segs.size(), -1);
+        if (i + 1 < want) {
+            const Shard& nx = out[(size_t)i + 1];
+            sh.read_end = nx.read_off; sh.seg_end = nx.seg_off;
+            // mate maps are only looked up by id: an empty offset list means "from the start" for every shard, i.e. no usable end either
+            sh.partner_end = po.empty() ? -1 : nx.partner_off;
+            sh.seg_partner_end = spo.empty() ? -1 : nx.seg_partner_off;
+        }
+    }
     return out;
 }
 
@@ -95,6 +114,52 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
     if (nseg < 1 || (nseg == 1 && o.no_coverage_search)) return;
     const long long t_shard = WorkClock::now();
     struct AtExit { long long t; ~AtExit() { g_work.add(0, t); } } at_exit{t_shard};
+    // ---- device-side ingest (thj_ingest_seg_batch): every input a mapped BAM -> the host only points at compressed bytes
+    static const bool host_ingest = getenv("THJ_HOST_INGEST") != nullptr;
+    if (!host_ingest) {
+        std::vector<thj_bam_piece> segp;
+        bool ok = true;
+        for (int s = 0; s < nseg && ok; ++s) { const BamFile* bf = bam_of(in.segs[(size_t)s]); if (!bf) ok = false; else segp.push_back(bf->piece(sh.seg_off[(size_t)s], sh.seg_end.empty() ? -1 : sh.seg_end[(size_t)s])); }
+        const BamFile* rf = ok ? bam_of(in.reads) : nullptr;
+        if (!rf) ok = false;
+        thj_bam_piece mf{}, ml{}; bool have_mf = false, have_ml = false;
+        if (ok && mate && !mate->segs.empty()) {
+            if (!mate->map.empty()) { const BamFile* bf = bam_of(mate->map); if (bf) { mf = bf->piece(sh.partner_off, sh.partner_end); have_mf = true; } else ok = false; }
+            const BamFile* bl = ok ? bam_of(mate->segs.back()) : nullptr;
+            if (bl) { ml = bl->piece(sh.seg_partner_off, sh.seg_partner_end); have_ml = true; } else ok = false;
+        }
+        if (ok) {
+            thj_bam_piece rp = rf->piece(sh.read_off, sh.read_end);
+            thj_params p = o.p;
+            p.read_side = read_side;
+            const uint32_t b_id = sh.begin_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.begin_id, e_id = sh.end_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.end_id;
+            const long long tw = WorkClock::now();
+            std::lock_guard<std::mutex> lk(gpu.mu);
+            g_work.add(1, tw);
+            const long long td = WorkClock::now();
+            thj_ctx* ctx = device_ready(gpu);
+            thj_seg_batch* dev = nullptr;
+            int64_t n = 0;
+            const int rc = thj_ingest_seg_batch(ctx, &p, nseg, segp.data(), have_mf ? &mf : nullptr, have_ml ? &ml : nullptr, &rp, b_id, e_id,
+                                                (o.fusion_search || !o.no_coverage_search) ? 1 : 0, ordinal, &dev, &n);
+            if (rc == THJ_OK) {
+                if ((uint64_t)ordinal + (uint64_t)n > ordinal_limit)
+                    die("Error: too many reads on the %s side for the device's read ordinals (read ids must stay below %u)\n", read_side == 1 ? "left" : "right", RIGHT_ORDINAL_BASE);
+                if (dev) {
+                    if (nseg > 1 && thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+                    if (nseg > 1 && o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
+                    if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
+                    if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+                }
+                g_work.add(2, td);
+                return;
+            }
+            if (rc != THJ_EFALLBACK) die("Error: %s\n", thj_last_error());
+            g_work.add(2, td);
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true)) fprintf(stderr, "\tdevice-side ingest not possible (%s); reading on the host\n", thj_last_error());
+        }
+    }
     std::vector<HitStream> st((size_t)nseg);
     for (int s = 0; s < nseg; ++s)
         if (!st[(size_t)s].open(in.segs[(size_t)s], rt, o.p, false, sh.seg_off[(size_t)s], sh.begin_id, sh.end_id))
@@ -236,6 +301,12 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Loading reference sequences...\n");
     rt.load_fasta(pos[0]);
     for (const SideInput* sd : {&left, &right}) { register_targets(sd->map, rt); for (auto& f : sd->segs) register_targets(f, rt); }
+    if (!getenv("THJ_HOST_INGEST"))                                   // map the BAM inputs for the device-side ingest
+        for (const SideInput* sd : {&left, &right}) {
+            std::vector<std::string> fns = sd->segs;
+            fns.push_back(sd->reads); if (!sd->map.empty()) fns.push_back(sd->map);
+            for (auto& fn : fns) if (!fn.empty() && !g_bam.count(fn)) { std::unique_ptr<BamFile> bf(new BamFile()); if (bf->open(fn, rt)) g_bam[fn] = std::move(bf); }
+        }
     std::vector<uint32_t> fusion_ignore_ids;
     if (o.fusion_search && !o.fusion_ignore.empty())                   // segment_juncs.cpp:3214-3219
         for (auto& nm : split(o.fusion_ignore, ',')) if (!nm.empty()) fusion_ignore_ids.push_back(rt.get_id(nm));

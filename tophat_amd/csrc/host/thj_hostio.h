@@ -8,6 +8,7 @@
 // common.cpp:1000-1173 + common.h:401-627 (GBamRecord / GBamWriter); samtools-0.1.18 bgzf.c (BGZF framing).
 #pragma once
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <getopt.h>
 #include <stdint.h>
 #include <unistd.h>
@@ -1227,6 +1228,101 @@ inline void register_targets(const std::string& fn, RefTable& rt) {
     }
 }
 
+// ------------------------------------------------------------------ BAM files for the device-side ingest
+// The host's whole part in the device path: map the file, know where the header ends and what its targets are called,
+// and hand out [member-aligned piece of the mapping, bytes to skip in its first member] for a shard.
+struct BamFile {
+    const uint8_t* data = nullptr; size_t size = 0;
+    std::vector<std::string> targets;
+    std::vector<uint32_t> tid2ref;
+    int64_t first_rec_voff = 0;                       // virtual offset of the first alignment record
+    static uint32_t member_size(const uint8_t* d, size_t n) {            // BSIZE + 1 of the member at d, 0 if d is not one
+        if (n < 28 || d[0] != 31 || d[1] != 139 || d[2] != 8 || !(d[3] & 4)) return 0;
+        const uint32_t xlen = d[10] | (d[11] << 8);
+        size_t x = 12; const size_t xe = 12 + xlen;
+        while (x + 4 <= xe && xe <= n) {
+            const uint32_t slen = d[x + 2] | (d[x + 3] << 8);
+            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2) return (uint32_t)(d[x + 4] | (d[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        return 0;
+    }
+    bool open(const std::string& fn, RefTable& rt) {
+        if (file_ext(fn) != "bam") return false;
+        const int fd = ::open(fn.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        const off_t sz = lseek(fd, 0, SEEK_END);
+        if (sz <= 0) { ::close(fd); return false; }
+        void* m = mmap(nullptr, (size_t)sz, PROT_READ, MAP_SHARED, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return false;
+        data = (const uint8_t*)m; size = (size_t)sz;
+        // header: inflate members from the start until magic, text, n_ref and the n_ref (name, length) entries are in hand
+        std::vector<uint8_t> h;
+        std::vector<std::pair<int64_t, size_t>> mem;              // (file offset, inflated size) of the members read so far
+        size_t off = 0, need = 12;
+        auto have = [&](size_t n) {
+            while (h.size() < n && off < size) {
+                const uint32_t bs = member_size(data + off, size - off);
+                if (!bs || off + bs > size) return false;
+                const uint32_t xlen = data[off + 10] | (data[off + 11] << 8);
+                uint32_t isz; memcpy(&isz, data + off + bs - 4, 4);
+                const size_t at = h.size();
+                h.resize(at + isz);
+                z_stream zs; memset(&zs, 0, sizeof zs);
+                inflateInit2(&zs, -15);
+                zs.next_in = const_cast<uint8_t*>(data + off + 12 + xlen); zs.avail_in = bs - 12 - xlen - 8;
+                zs.next_out = h.data() + at; zs.avail_out = isz;
+                const int st = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (st != Z_STREAM_END && isz) return false;
+                mem.emplace_back((int64_t)off, (size_t)isz);
+                off += bs;
+            }
+            return h.size() >= n;
+        };
+        if (!have(need) || memcmp(h.data(), "BAM\1", 4)) return false;
+        int32_t l_text; memcpy(&l_text, h.data() + 4, 4);
+        need = 8 + (size_t)l_text + 4;
+        if (!have(need)) return false;
+        int32_t n_ref; memcpy(&n_ref, h.data() + 8 + l_text, 4);
+        size_t p = need;
+        for (int32_t i = 0; i < n_ref; ++i) {
+            if (!have(p + 4)) return false;
+            int32_t l_name; memcpy(&l_name, h.data() + p, 4);
+            if (!have(p + 4 + (size_t)l_name + 4)) return false;
+            targets.emplace_back((const char*)h.data() + p + 4);
+            p += 4 + (size_t)l_name + 4;
+        }
+        // p = inflated offset of the first record -> (member, offset inside it)
+        size_t acc = 0;
+        first_rec_voff = (int64_t)off << 16;                  // right after the members read, unless it falls inside one
+        for (auto& me : mem) { if (p < acc + me.second) { first_rec_voff = (me.first << 16) | (int64_t)(p - acc); break; } acc += me.second; }
+        for (auto& t : targets) tid2ref.push_back(t.find('|') == std::string::npos ? rt.get_id(t) : 0u);
+        return true;
+    }
+    // the piece of the file that holds the records from virtual offset `from` up to (not including) those at `to` (< 0: the end)
+    thj_bam_piece piece(int64_t from, int64_t to) const {
+        if (from < first_rec_voff) from = first_rec_voff;
+        thj_bam_piece pc;
+        const size_t a = (size_t)(from >> 16);
+        size_t e = size;
+        if (to >= 0) {
+            e = (size_t)(to >> 16);
+            if ((to & 0xFFFF) && e < size) e += member_size(data + e, size - e);      // the member the boundary falls into belongs to both sides
+            if (e < a) e = a;
+            if (e > size) e = size;
+        }
+        pc.comp = data + (a < size ? a : size); pc.comp_bytes = (int64_t)(e > a ? e - a : 0); pc.first_skip = (uint32_t)(from & 0xFFFF);
+        pc.n_tid = (int32_t)tid2ref.size(); pc.tid2ref = tid2ref.data();
+        return pc;
+    }
+    ~BamFile() { if (data) munmap((void*)data, size); }
+    BamFile() = default;
+    BamFile(const BamFile&) = delete;
+    BamFile& operator=(const BamFile&) = delete;
+};
+
 // ------------------------------------------------------------------ BGZF + BAM writer (samtools-0.1.18 bgzf.c, common.cpp:1000-1173)
 inline int reg2bin(int beg, int end) {                // bam.h bam_reg2bin
     --end;
@@ -1239,7 +1335,9 @@ inline int reg2bin(int beg, int end) {                // bam.h bam_reg2bin
 }
 
 // GBamWriter with the read-id -> BGZF-offset side file (common.h:562-606).
-// The uncompressed stream is cut into 64 KiB BGZF blocks exactly as bgzf_write does; records of a batch are
+// The uncompressed stream is cut into BGZF members exactly as samtools-0.1.18 does: the header in members of its own, and a
+// record that does not fit the rest of a 64 KiB member starts the next one (bgzf_flush_try) -- so no record straddles two
+// members, which is also what lets the device-side ingest parse members independently; records of a batch are
 // encoded by worker threads, the blocks of the batch are deflated by worker threads (blocks are independent
 // members), and one thread writes them in order and replays the `.index` rule on the now-known block addresses.
 class BamWriter {
@@ -1278,53 +1376,80 @@ class BamWriter {
     }
 
     struct Blk { size_t ustart, ulen; int64_t addr; };
-    // Compress and write every full block of `stream` (which starts on a block boundary); returns the block table
-    // including the still-open last block, whose bytes become the new carry.
-    std::vector<Blk> flush_full_blocks(const std::vector<uint8_t>& stream, bool final_flush) {
-        const size_t nfull = stream.size() / BLOCK;
-        std::vector<std::vector<uint8_t>> out(nfull);
-        std::vector<char> ok(nfull, 1);
+    // Where BGZF members end in `stream` (= carry_ + the new records' bytes): bam_write1 first calls
+    // bgzf_flush_try(4 + block_len) -- a record that does not fit what is left of the 64 KiB block starts a new one
+    // (bam.c:225, bgzf.c:587-592) -- then bgzf_write fills the block and flushes whenever it is full (bgzf.c:594-623), which only
+    // happens inside records larger than a block.  `off` = fill of the open block when the first new record arrives.
+    static void plan_cuts(size_t off, size_t pos, const std::vector<uint32_t>& size, size_t first, std::vector<size_t>& cuts, size_t* end_off) {
+        for (size_t i = first; i < size.size(); ++i) {
+            size_t s = size[i];
+            if (off + s > BLOCK && off > 0) { cuts.push_back(pos); off = 0; }
+            while (s > 0) {
+                const size_t c = std::min(BLOCK - off, s);
+                off += c; pos += c; s -= c;
+                if (off == BLOCK) { cuts.push_back(pos); off = 0; }
+            }
+        }
+        *end_off = off;
+    }
+    void write_member(const std::vector<uint8_t>& m) { fwrite(m.data(), 1, m.size(), f_); file_addr_ += (int64_t)m.size(); }
+    // Compresses and writes the closed members of `stream`; returns the block table including the still-open last block, whose
+    // bytes become the new carry.  Members are deflated in parallel; should one not fit its 64 KiB envelope (incompressible
+    // data: bgzf.c deflate_block then shrinks the input by 1 KiB steps and the rest opens the next block) the remainder of the
+    // call is replayed sequentially with that rule, since every later cut moves.
+    std::vector<Blk> flush_blocks(const std::vector<uint8_t>& stream, const std::vector<uint32_t>& size, bool final_flush) {
+        std::vector<size_t> cuts;
+        size_t end_off = 0;
+        plan_cuts(carry_.size(), carry_.size(), size, 0, cuts, &end_off);
+        if (final_flush && (cuts.empty() || cuts.back() != stream.size()) && !stream.empty()) cuts.push_back(stream.size());
+        const size_t nb = cuts.size();
+        std::vector<std::vector<uint8_t>> out(nb);
+        std::vector<char> ok(nb, 1);
         const int T = host_threads();
-        auto work = [&](int t) { for (size_t k = (size_t)t; k < nfull; k += (size_t)T) ok[k] = deflate_member(stream.data() + k * BLOCK, BLOCK, out[k]); };
-        if (nfull > 1 && T > 1) {
+        auto work = [&](int t) { for (size_t k = (size_t)t; k < nb; k += (size_t)T) { const size_t a = k ? cuts[k - 1] : 0; ok[k] = deflate_member(stream.data() + a, cuts[k] - a, out[k]); } };
+        if (nb > 1 && T > 1) {
             std::vector<std::thread> th;
             for (int t = 0; t < T; ++t) th.emplace_back(work, t);
             for (auto& x : th) x.join();
         } else for (int t = 0; t < T; ++t) work(t);
         std::vector<Blk> tab;
         size_t upos = 0, k = 0;
-        for (; k < nfull && ok[k]; ++k) {
-            tab.push_back({upos, BLOCK, file_addr_});
-            fwrite(out[k].data(), 1, out[k].size(), f_);
-            file_addr_ += (int64_t)out[k].size();
-            upos += BLOCK;
+        for (; k < nb && ok[k]; ++k) {
+            tab.push_back({upos, cuts[k] - upos, file_addr_});
+            write_member(out[k]);
+            upos = cuts[k];
         }
-        if (k < nfull) {
-            // incompressible data: bgzf.c shrinks the block by 1 KiB steps and the leftover opens the next block;
-            // from here on the block boundaries move, so the rest of this stream goes one block at a time
+        if (k < nb) {
+            // sequential replay from `upos` with the shrink rule: record ends tell where bgzf_flush_try looks
+            std::vector<size_t> rec_end;
+            { size_t x = carry_.size(); for (auto sz : size) { x += sz; rec_end.push_back(x); } }
+            size_t ri = 0;
+            while (ri < rec_end.size() && rec_end[ri] <= upos) ++ri;
+            size_t blk_start = upos, pos = upos;
             std::vector<uint8_t> o;
-            while (stream.size() - upos >= BLOCK) {
-                size_t take = BLOCK;
-                while (!deflate_member(stream.data() + upos, take, o)) take -= 1024;
-                tab.push_back({upos, take, file_addr_});
-                fwrite(o.data(), 1, o.size(), f_);
-                file_addr_ += (int64_t)o.size();
-                upos += take;
+            auto flush = [&](size_t upto) {                       // bgzf_flush (bgzf.c:568-585): members until the block is empty; what
+                while (blk_start < upto) {                        // deflate_block could not fit stays in the block and goes next
+                    size_t take = upto - blk_start;
+                    while (!deflate_member(stream.data() + blk_start, take, o)) take -= 1024;
+                    tab.push_back({blk_start, take, file_addr_});
+                    write_member(o);
+                    blk_start += take;
+                }
+            };
+            while (pos < stream.size()) {
+                const size_t rend = ri < rec_end.size() ? rec_end[ri] : stream.size();
+                const size_t rsize = rend - pos;
+                if ((pos - blk_start) + rsize > BLOCK && pos > blk_start) flush(pos);
+                size_t left = rsize;
+                while (left > 0) {
+                    const size_t c = std::min(BLOCK - (pos - blk_start), left);
+                    pos += c; left -= c;
+                    if (pos - blk_start == BLOCK) flush(pos);
+                }
+                ++ri;
             }
-        }
-        if (final_flush && upos < stream.size()) {
-            std::vector<uint8_t> o;
-            size_t take = stream.size() - upos;
-            while (!deflate_member(stream.data() + upos, take, o)) take -= 1024;
-            for (;;) {
-                tab.push_back({upos, take, file_addr_});
-                fwrite(o.data(), 1, o.size(), f_);
-                file_addr_ += (int64_t)o.size();
-                upos += take;
-                if (upos >= stream.size()) break;
-                take = stream.size() - upos;
-                while (!deflate_member(stream.data() + upos, take, o)) take -= 1024;
-            }
+            if (final_flush) flush(stream.size());
+            upos = blk_start;
         }
         tab.push_back({upos, stream.size() - upos, file_addr_});       // the open block
         return tab;
@@ -1350,6 +1475,15 @@ public:
             h.push_back(0);
             put32(h, rt.sq[i].second);
             tid_[rt.sq[i].first] = (int32_t)i;
+        }
+        // bam_header_write ends with bgzf_flush (bam.c:144): the header has its members to itself, records start a fresh one
+        std::vector<uint8_t> hb; hb.swap(carry_);
+        std::vector<uint8_t> o;
+        for (size_t at = 0; at < hb.size();) {
+            size_t take = std::min(BLOCK, hb.size() - at);
+            while (!deflate_member(hb.data() + at, take, o)) take -= 1024;
+            write_member(o);
+            at += take;
         }
         return true;
     }
@@ -1416,7 +1550,7 @@ public:
         stream.reserve(carry_.size() + e.bytes.size());
         stream.insert(stream.end(), carry_.begin(), carry_.end());
         stream.insert(stream.end(), e.bytes.begin(), e.bytes.end());
-        std::vector<Blk> tab = flush_full_blocks(stream, false);
+        std::vector<Blk> tab = flush_blocks(stream, e.size, false);
         // GBamWriter::write(b, read_id): index line once >= INDEX_REC_COUNT (1000) records have passed and the id changes
         if (idx_) {
             size_t x = carry_.size();
@@ -1463,7 +1597,7 @@ public:
     }
     void close() {
         if (!f_) return;
-        if (!carry_.empty()) { std::vector<uint8_t> s; s.swap(carry_); flush_full_blocks(s, true); }
+        if (!carry_.empty()) { std::vector<uint8_t> s = carry_; flush_blocks(s, std::vector<uint32_t>(), true); carry_.clear(); }
         std::vector<uint8_t> eof;
         deflate_member(nullptr, 0, eof);              // an empty member: the BGZF EOF marker block
         fwrite(eof.data(), 1, eof.size(), f_);

@@ -71,6 +71,8 @@ struct thj_ctx {
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
     std::vector<thj_fusion> h_fusions;
+    // device-side ingest scratch (thj_ingest.hip)
+    void* d_ing0 = nullptr; size_t ing_cap0 = 0; void* d_ing1 = nullptr; size_t ing_cap1 = 0;
     // junction consensus (thj_juncbed_impl.h)
     u64* d_jb_key = nullptr; uint32_t* d_jb_u32 = nullptr; u64* d_jb_list = nullptr; u64* d_jb_sorted = nullptr;
     unsigned long long* d_jb_cnt = nullptr; void* d_jb_occ = nullptr;

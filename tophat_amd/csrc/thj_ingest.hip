@@ -1,0 +1,841 @@
+// thj_ingest.hip -- device-side ingest: BGZF inflate and BAM record parsing on the GPU, so that
+// the host of the drop-in executables only moves compressed bytes.
+//
+// Why: a tophat run hands segment_juncs / long_spanning_reads ~2.8 KB of (inflated) BAM per read pair; zlib inflates
+// ~0.35 GB/s per core, so 2 M pairs/s would take every core of a 16-CPU container for inflating alone (measured: the CPU
+// path stops at ~0.65 M pairs/s there).  BGZF (samtools-0.1.18 bgzf.c) is a chain of independent <= 64 KiB DEFLATE members and
+// bam_write1 never lets a record straddle two of them (bgzf_flush_try, bam.c:225), so both steps are parallel over blocks.
+//
+// thj_k_inflate: one 64-lane workgroup per BGZF block.  DEFLATE is serial inside a block, so one lane decodes; what makes
+// it fast enough is where its working set lives: Huffman tables (10-bit / 8-bit direct lookup + canonical fallback) and a
+// 32 KiB output window in LDS -- every table lookup and every LZ77 copy is an LDS access -- while the other 63 lanes do the
+// memory work: they stage the compressed bytes into an LDS ring ahead of the decoder and flush finished 16 KiB halves of
+// the window to HBM with coalesced 16-byte stores.  39 KB of LDS per workgroup = 4 blocks in flight per CU, 1024 per GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/thj.h"
+#include "thj_ctx.h"
+
+namespace ing {
+
+static constexpr int WIN = 32768, WIN_MASK = WIN - 1, HALF = 16384;
+static constexpr int INRING = 4096, IN_MASK = INRING - 1;
+static constexpr int LIT_BITS = 10, DIST_BITS = 8;
+
+struct Shared {
+    uint8_t win[WIN];
+    uint8_t in[INRING];
+    uint16_t lit_fast[1 << LIT_BITS];
+    uint16_t dist_fast[1 << DIST_BITS];
+    uint16_t lit_sym[288], dist_sym[32];
+    uint16_t lit_cnt[16], dist_cnt[16];
+    uint8_t lens[320];
+    // decoder <-> helpers
+    uint32_t in_staged;        // compressed bytes staged so far (absolute)
+    uint32_t in_used;          // compressed bytes the decoder no longer needs (absolute, rounded down to 4)
+    uint32_t out_total;        // bytes produced
+    uint32_t out_flushed;      // bytes already in HBM
+    uint32_t done, error;
+};
+
+__constant__ uint16_t LBASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t LEXT[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t DBASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t DEXT[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+__device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+
+// canonical Huffman tables from code lengths: direct lookup for codes <= FAST bits (entry = symbol | length << 12, 0 = longer
+// code), count / symbol arrays for the rest (decoded bit by bit like puff.c)
+__device__ bool build_table(const uint8_t* lens, int n, uint16_t* fast, int fast_bits, uint16_t* sym, uint16_t* cnt) {
+    for (int i = 0; i < 16; ++i) cnt[i] = 0;
+    for (int i = 0; i < n; ++i) cnt[lens[i]]++;
+    for (int i = 0; i < (1 << fast_bits); ++i) fast[i] = 0;
+    if (cnt[0] == n) return true;                    // no codes at all (e.g. a block without distances)
+    int left = 1;
+    for (int l = 1; l < 16; ++l) { left <<= 1; left -= cnt[l]; if (left < 0) return false; }
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + cnt[l];
+    for (int i = 0; i < n; ++i) if (lens[i]) sym[offs[lens[i]]++] = (uint16_t)i;
+    // canonical codes in symbol order per length
+    int code = 0, idx = 0;
+    for (int l = 1; l <= fast_bits; ++l) {
+        for (int k = 0; k < cnt[l]; ++k, ++idx, ++code) {
+            const uint32_t r = rev_bits((uint32_t)code, l);
+            const uint16_t e = (uint16_t)(sym[idx] | (l << 12));
+            for (uint32_t f = r; f < (1u << fast_bits); f += (1u << l)) fast[f] = e;
+        }
+        code <<= 1;
+    }
+    return true;
+}
+
+struct Bits {
+    uint64_t buf; int cnt; uint32_t pos;            // pos = absolute compressed byte index of the next byte to load
+};
+
+__device__ __forceinline__ void refill(Bits& b, const Shared& s) {
+    while (b.cnt <= 56 && b.pos < s.in_staged) { b.buf |= (uint64_t)s.in[b.pos & IN_MASK] << b.cnt; b.cnt += 8; ++b.pos; }
+}
+__device__ __forceinline__ uint32_t take(Bits& b, int n) { const uint32_t v = (uint32_t)(b.buf & ((1ull << n) - 1)); b.buf >>= n; b.cnt -= n; return v; }
+
+__device__ __forceinline__ int decode_sym(Bits& b, const uint16_t* fast, int fast_bits, const uint16_t* sym, const uint16_t* cnt) {
+    const uint16_t e = fast[b.buf & ((1u << fast_bits) - 1)];
+    if (e) { const int l = e >> 12; b.buf >>= l; b.cnt -= l; return e & 0xFFF; }
+    // longer code: canonical decode, one bit at a time, starting past the lengths the direct table covers
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l < 16; ++l) {
+        code |= (int)((b.buf >> (l - 1)) & 1);
+        const int c = cnt[l];
+        if (l > fast_bits && code - c < first) { b.buf >>= l; b.cnt -= l; return sym[index + (code - first)]; }
+        index += c; first += c; first <<= 1; code <<= 1;
+    }
+    return -1;
+}
+
+enum { ST_HEADER = 0, ST_STORED, ST_CODES, ST_DONE };
+
+}  // namespace ing
+
+
+// out: 65536 bytes per block (block b at b << 16); out_len[b] = inflated bytes (0xFFFFFFFF on a corrupt stream)
+__global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
+                                                     uint8_t* __restrict__ out, uint32_t* __restrict__ out_len) {
+    using namespace ing;
+    __shared__ Shared s;
+    const int lane = threadIdx.x;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint8_t* in = comp + blocks[blk].in_off;
+        const uint32_t in_len = blocks[blk].in_len;
+        uint8_t* dst = out + ((size_t)blk << 16);
+        if (lane == 0) { s.in_staged = 0; s.in_used = 0; s.out_total = 0; s.out_flushed = 0; s.done = 0; s.error = 0; }
+        __syncthreads();
+        // decoder state (lane 0)
+        Bits b{0, 0, 0};
+        int state = ST_HEADER, last = 0;
+        uint32_t stored_left = 0;
+        for (;;) {
+            // ---- helpers: stage input ahead of the decoder (the ring holds INRING bytes; keep what is not used yet)
+            {
+                uint32_t staged = s.in_staged;
+                const uint32_t used = s.in_used;
+                while (staged < in_len && staged + 256 <= used + INRING) {
+                    const uint32_t p = staged + (uint32_t)lane * 4;
+                    if (p < in_len) {
+                        // 4 bytes per lane; the source address is only byte-aligned
+                        uint32_t w = 0;
+                        const uint32_t nb = in_len - p < 4 ? in_len - p : 4;
+                        for (uint32_t k = 0; k < nb; ++k) w |= (uint32_t)in[p + k] << (8 * k);
+                        for (uint32_t k = 0; k < nb; ++k) s.in[(p + k) & IN_MASK] = (uint8_t)(w >> (8 * k));
+                    }
+                    staged += 256;
+                }
+                if (staged > in_len) staged = in_len;
+                // ---- helpers: flush finished halves of the window
+                const uint32_t total = s.out_total;
+                uint32_t flushed = s.out_flushed;
+                const bool fin = s.done || s.error;
+                while (flushed + HALF <= total || (fin && flushed < total)) {
+                    const uint32_t n = total - flushed < (uint32_t)HALF ? total - flushed : (uint32_t)HALF;
+                    for (uint32_t o = (uint32_t)lane * 16; o < n; o += 64 * 16) {
+                        if (o + 16 <= n) {
+                            const uint4 v = *(const uint4*)&s.win[(flushed + o) & WIN_MASK];
+                            *(uint4*)(dst + flushed + o) = v;
+                        } else for (uint32_t k = o; k < n; ++k) dst[flushed + k] = s.win[(flushed + k) & WIN_MASK];
+                    }
+                    flushed += n;
+                }
+                __syncthreads();
+                if (lane == 0) { s.in_staged = staged; s.out_flushed = flushed; }
+                __syncthreads();
+                if (fin) break;
+            }
+            // ---- decoder
+            if (lane == 0) {
+                const bool all_in = s.in_staged >= in_len;
+                uint32_t outp = s.out_total;
+                const uint32_t out_limit = s.out_flushed + WIN - 300;           // never overwrite window bytes not yet in HBM
+                bool err = false, fin = false;
+                // work while enough input is staged for the largest thing the state needs
+                for (;;) {
+                    refill(b, s);
+                    if (b.cnt < 0) { err = true; break; }                        // ran past the end of a truncated stream
+                    const uint32_t avail = s.in_staged - b.pos + (uint32_t)(b.cnt >> 3);
+                    if (state == ST_HEADER) {
+                        if (!all_in && avail < 400) break;
+                        last = (int)take(b, 1);
+                        const int type = (int)take(b, 2);
+                        if (type == 0) {
+                            take(b, b.cnt & 7);                                  // to a byte boundary
+                            refill(b, s);
+                            const uint32_t len = take(b, 16), nlen = take(b, 16);
+                            if ((len ^ 0xFFFFu) != nlen) { err = true; break; }
+                            stored_left = len; state = ST_STORED;
+                        } else if (type == 1) {
+                            for (int i = 0; i < 144; ++i) s.lens[i] = 8;
+                            for (int i = 144; i < 256; ++i) s.lens[i] = 9;
+                            for (int i = 256; i < 280; ++i) s.lens[i] = 7;
+                            for (int i = 280; i < 288; ++i) s.lens[i] = 8;
+                            build_table(s.lens, 288, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt);
+                            for (int i = 0; i < 30; ++i) s.lens[i] = 5;
+                            build_table(s.lens, 30, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt);
+                            state = ST_CODES;
+                        } else if (type == 2) {
+                            const int hlit = (int)take(b, 5) + 257, hdist = (int)take(b, 5) + 1, hclen = (int)take(b, 4) + 4;
+                            if (hlit > 286 || hdist > 30) { err = true; break; }
+                            uint8_t cl[19];
+                            for (int i = 0; i < 19; ++i) cl[i] = 0;
+                            for (int i = 0; i < hclen; ++i) { refill(b, s); cl[CLORD[i]] = (uint8_t)take(b, 3); }
+                            // the code-length code uses the distance table's storage (7-bit direct lookup fits its 8 bits)
+                            if (!build_table(cl, 19, s.dist_fast, 7, s.dist_sym, s.dist_cnt)) { err = true; break; }
+                            int i = 0;
+                            while (i < hlit + hdist) {
+                                refill(b, s);
+                                const int sym = decode_sym(b, s.dist_fast, 7, s.dist_sym, s.dist_cnt);
+                                if (sym < 0) { err = true; break; }
+                                if (sym < 16) s.lens[i++] = (uint8_t)sym;
+                                else {
+                                    int rep, val = 0;
+                                    if (sym == 16) { if (i == 0) { err = true; break; } val = s.lens[i - 1]; rep = 3 + (int)take(b, 2); }
+                                    else if (sym == 17) rep = 3 + (int)take(b, 3);
+                                    else rep = 11 + (int)take(b, 7);
+                                    if (i + rep > hlit + hdist) { err = true; break; }
+                                    while (rep--) s.lens[i++] = (uint8_t)val;
+                                }
+                            }
+                            if (err) break;
+                            if (s.lens[256] == 0) { err = true; break; }
+                            // distance lengths first (they sit behind the literal lengths and the literal table build does not touch them)
+                            uint8_t dl[32];
+                            for (int k = 0; k < hdist; ++k) dl[k] = s.lens[hlit + k];
+                            if (!build_table(s.lens, hlit, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt)) { err = true; break; }
+                            if (!build_table(dl, hdist, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt)) { err = true; break; }
+                            state = ST_CODES;
+                        } else { err = true; break; }
+                    } else if (state == ST_STORED) {
+                        if (stored_left == 0) { state = last ? ST_DONE : ST_HEADER; continue; }
+                        if (avail == 0) { if (all_in) err = true; break; }
+                        if (outp >= out_limit) break;
+                        s.win[outp & WIN_MASK] = (uint8_t)take(b, 8); ++outp; --stored_left;
+                    } else if (state == ST_CODES) {
+                        if ((!all_in && avail < 8) || outp >= out_limit) break;
+                        int sym = decode_sym(b, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt);
+                        if (sym < 0) { err = true; break; }
+                        if (sym < 256) { s.win[outp & WIN_MASK] = (uint8_t)sym; ++outp; }
+                        else if (sym == 256) state = last ? ST_DONE : ST_HEADER;
+                        else {
+                            sym -= 257;
+                            if (sym >= 29) { err = true; break; }
+                            const int len = LBASE[sym] + (int)take(b, LEXT[sym]);
+                            refill(b, s);
+                            const int ds = decode_sym(b, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt);
+                            if (ds < 0 || ds >= 30) { err = true; break; }
+                            const uint32_t dist = DBASE[ds] + take(b, DEXT[ds]);
+                            if (dist > outp || outp + (uint32_t)len > 65536u) { err = true; break; }
+                            for (int k = 0; k < len; ++k) s.win[(outp + k) & WIN_MASK] = s.win[(outp + k - dist) & WIN_MASK];
+                            outp += (uint32_t)len;
+                        }
+                    } else { fin = true; break; }
+                    if (outp > 65536u) { err = true; break; }
+                }
+                s.out_total = outp;
+                s.in_used = (b.pos - (uint32_t)(b.cnt >> 3)) & ~3u;
+                if (fin) s.done = 1;
+                if (err) s.error = 1;
+                // no progress possible and not finished: input exhausted in mid-stream
+                if (!fin && !err && all_in && s.in_staged - b.pos + (uint32_t)(b.cnt >> 3) == 0 && state != ST_DONE) s.error = 1;
+                if (state == ST_DONE) s.done = 1;
+            }
+            __syncthreads();
+        }
+        if (lane == 0) out_len[blk] = s.error ? 0xFFFFFFFFu : s.out_total;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ C ABI
+
+extern "C" int thj_bgzf_inflate(thj_ctx* c, const uint8_t* comp, int64_t comp_bytes, const thj_bgzf_block* blocks, int64_t n_blocks,
+                                uint8_t* out, uint32_t* out_len, int32_t on_device) {
+    // Test / tool entry point: inflates n_blocks members.  on_device == 0: comp / blocks are host arrays, out (65536 bytes per
+    // block) and out_len host arrays; != 0: all four are device arrays and the call only enqueues.
+    if (!c || n_blocks < 0 || (n_blocks > 0 && (!comp || !blocks || !out || !out_len))) { thj_set_error("thj_bgzf_inflate: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (n_blocks == 0) return THJ_OK;
+    const uint8_t* d_comp = comp; const thj_bgzf_block* d_blocks = blocks; uint8_t* d_out = out; uint32_t* d_len = out_len;
+    void *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
+    if (!on_device) {
+        HIPCHK(hipMalloc(&t0, (size_t)comp_bytes + 16)); HIPCHK(hipMalloc(&t1, (size_t)n_blocks * sizeof(thj_bgzf_block)));
+        HIPCHK(hipMalloc(&t2, (size_t)n_blocks << 16)); HIPCHK(hipMalloc(&t3, (size_t)n_blocks * 4));
+        HIPCHK(hipMemcpyAsync(t0, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(t1, blocks, (size_t)n_blocks * sizeof(thj_bgzf_block), hipMemcpyHostToDevice, c->stream));
+        d_comp = (const uint8_t*)t0; d_blocks = (const thj_bgzf_block*)t1; d_out = (uint8_t*)t2; d_len = (uint32_t*)t3;
+    }
+    int64_t grid = n_blocks < 256 * 4 * 4 ? n_blocks : 256 * 4 * 4;
+    hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)n_blocks, d_out, d_len);
+    HIPCHK(hipGetLastError());
+    if (!on_device) {
+        HIPCHK(hipMemcpyAsync(out_len, t3, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(out, t2, (size_t)n_blocks << 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(t0); hipFree(t1); hipFree(t2); hipFree(t3);
+    }
+    return THJ_OK;
+}
+
+// ================================================================================================ BAM records on the device
+//
+// After the inflate every member sits in its own 64 KiB slot.  bam_write1 starts a new member rather than let a record
+// straddle two (bgzf_flush_try), so the members of a file can be walked independently:
+//   thj_k_walk        one thread per member follows the block_size chain and notes where records start
+//   thj_k_parse_hits  one workgroup per member, one thread per record: BAMHitFactory::get_hit_from_buf (bwt_map.cpp:1101-1452)
+//                     straight from the record bytes -> (insert_id, thj_hit, thj_span_hit), plus the shard's id-range filter
+//   (scan + scatter)  the records the factory keeps, densely, in file order
+// and then the k-way merge by read id that look_for_hit_group does with stream look-aheads becomes array work over the
+// (dense) id range of the shard: per file "first record / record count of id", a visited flag per id, prefix sums for the
+// rows and the CSR offsets, one scatter per file.
+
+#include <hipcub/hipcub.hpp>
+
+namespace ing {
+
+static constexpr int MAXREC = 1824;             // a BAM record is at least 36 bytes: 65536 / 36
+struct Hit16 { uint32_t ref_id; int32_t left, right; uint32_t meta; };                 // == thj_hit:  flags | edit_dist << 8 | mismatches << 16 | read_len << 24
+struct Hit32 { uint32_t ref_id; int32_t left; uint32_t meta; uint32_t cigar[5]; };     // == thj_span_hit: flags | mismatches << 8 | edit_dist << 16 | n_cigar << 24
+static_assert(sizeof(Hit16) == sizeof(thj_hit) && sizeof(Hit32) == sizeof(thj_span_hit), "hit layouts");
+
+struct FileInfo { uint32_t first_block, n_blocks, first_skip, kind, tid_base, n_tid, rec_base, n_rec; };
+enum { KIND_HITS = 0, KIND_READS = 1 };
+enum { ST_CORRUPT = 0, ST_STRADDLE = 1, ST_XF = 2, ST_CIGAR = 3, ST_MISSING_READ = 4, ST_N };
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+__global__ __launch_bounds__(64) void thj_k_walk(const uint8_t* __restrict__ infl, const uint32_t* __restrict__ len, const uint8_t* __restrict__ blk_file,
+                                                 const FileInfo* __restrict__ files, int n_blocks, uint16_t* __restrict__ rec_off, uint32_t* __restrict__ cnt,
+                                                 unsigned int* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint32_t L = len[b];
+    uint32_t k = 0;
+    if (L == 0xFFFFFFFFu || L > 65536u) { atomicExch(&status[ST_CORRUPT], 1u); cnt[b] = 0; return; }
+    const FileInfo f = files[blk_file[b]];
+    uint32_t p = (uint32_t)b == f.first_block ? f.first_skip : 0u;
+    const uint8_t* base = infl + ((size_t)b << 16);
+    while (p + 4 <= L && k < (uint32_t)MAXREC) {
+        const uint32_t bs = ld32(base + p);
+        if (bs < 32u || p + 4 + bs > L) break;
+        rec_off[(size_t)b * MAXREC + k++] = (uint16_t)p;
+        p += 4 + bs;
+    }
+    if (p != L) atomicExch(&status[ST_STRADDLE], 1u);       // a record runs past the member (or garbage): not samtools' layout
+    cnt[b] = k;
+}
+
+struct ParseOut { uint32_t* id; uint32_t* valid; Hit16* h16; Hit32* h32; uint32_t* loc; };
+
+// get_hit_from_buf for record `d` (after its block_size field, `bs` bytes); false = the factory drops the record
+__device__ bool parse_hit(const uint8_t* d, uint32_t bs, const uint32_t* tid2ref, uint32_t n_tid, int max_report_intron, uint32_t& id, Hit16& h16, Hit32& h32,
+                          unsigned int* status) {
+    const int32_t tid = (int32_t)ld32(d), pos = (int32_t)ld32(d + 4), mtid = (int32_t)ld32(d + 20);
+    const uint32_t bin_mq_nl = ld32(d + 8), flag_nc = ld32(d + 12), l_seq = ld32(d + 16);
+    const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF, flag = flag_nc >> 16;
+    // qname "<id>|<offset>:<segment>:<segments>" (tophat.py:2948): insert_id = atoi, end = (segment + 1 == segments)
+    const uint8_t* q = d + 32;
+    uint32_t v = 0, i = 0;
+    while (i + 1 < l_rn && q[i] >= '0' && q[i] <= '9') { v = v * 10u + (uint32_t)(q[i] - '0'); ++i; }
+    id = v;
+    bool end = true;
+    {
+        int pipe = -1;
+        for (uint32_t k = 0; k + 1 < l_rn; ++k) if (q[k] == '|') pipe = (int)k;
+        if (pipe >= 0) {
+            bool colon = false;
+            for (uint32_t k = (uint32_t)pipe + 1; k + 1 < l_rn; ++k) if (q[k] == ':') colon = true;
+            if (colon) {                                   // strtoul(a) ':' strtoul(b) ':' strtoul(c), missing fields stay 0 (bwt_map.cpp:1125-1143)
+                uint32_t k = (uint32_t)pipe + 1, bb = 0, cc = 0;
+                while (k + 1 < l_rn && q[k] >= '0' && q[k] <= '9') ++k;
+                if (k + 1 < l_rn && q[k] == ':') {
+                    ++k;
+                    while (k + 1 < l_rn && q[k] >= '0' && q[k] <= '9') { bb = bb * 10u + (uint32_t)(q[k] - '0'); ++k; }
+                    if (k + 1 < l_rn && q[k] == ':') { ++k; while (k + 1 < l_rn && q[k] >= '0' && q[k] <= '9') { cc = cc * 10u + (uint32_t)(q[k] - '0'); ++k; } }
+                }
+                end = (bb + 1 == cc);
+            }
+        }
+    }
+    if (tid < 0 || (flag & 4u)) return false;
+    uint32_t pp = 32 + l_rn;
+    int right = pos, read_len = 0, gap = 0, ind = 0, n32 = 0;
+    bool spliced = false;
+    h32.cigar[0] = h32.cigar[1] = h32.cigar[2] = h32.cigar[3] = h32.cigar[4] = 0;
+    for (uint32_t c = 0; c < n_cig; ++c) {
+        const uint32_t w = ld32(d + pp); pp += 4;
+        const uint32_t len = w >> 4, bop = w & 0xF;
+        if (len == 0) return false;
+        uint32_t op;
+        switch (bop) {
+        case 0: case 7: case 8: op = 1; right += (int)len; read_len += (int)len; break;
+        case 1: op = 3; read_len += (int)len; gap += (int)len; ind += (int)len; break;
+        case 2: op = 5; right += (int)len; gap += (int)len; ind += (int)len; break;
+        case 4: op = 13; read_len += (int)len; break;
+        case 5: continue;
+        case 6: op = 15; break;
+        case 3: op = 11; spliced = true; if ((int)len > max_report_intron) return false; right += (int)len; break;
+        default: return false;
+        }
+        if (n32 < 5) h32.cigar[n32] = (op << 28) | (len & 0x0FFFFFFFu);
+        ++n32;
+    }
+    if (mtid >= 0 && mtid != tid) return false;
+    pp += (l_seq + 1) / 2 + l_seq;
+    int nm = 0; char xs = 0;
+    while (pp + 3 <= bs) {
+        const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
+        pp += 3;
+        int iv = 0; bool isint = false;
+        switch (ty) {
+        case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
+        case 'c': iv = (int8_t)d[pp]; isint = true; pp += 1; break;
+        case 'C': iv = d[pp]; isint = true; pp += 1; break;
+        case 's': iv = (int16_t)(d[pp] | (d[pp + 1] << 8)); isint = true; pp += 2; break;
+        case 'S': iv = (int)(d[pp] | (d[pp + 1] << 8)); isint = true; pp += 2; break;
+        case 'i': case 'I': iv = (int)ld32(d + pp); isint = true; pp += 4; break;
+        case 'f': pp += 4; break;
+        case 'd': pp += 8; break;
+        case 'Z': case 'H':
+            if (t0 == 'X' && t1 == 'F') atomicExch(&status[ST_XF], 1u);
+            while (pp < bs && d[pp]) ++pp;
+            ++pp;
+            break;
+        case 'B': { const char st = (char)d[pp]; const uint32_t cnt = ld32(d + pp + 1); pp += 5 + cnt * ((st == 'c' || st == 'C') ? 1u : (st == 's' || st == 'S') ? 2u : 4u); break; }
+        default: pp = bs; break;
+        }
+        if (isint && t0 == 'N' && t1 == 'M') nm = iv;
+    }
+    const uint32_t ref_id = (uint32_t)tid < n_tid ? tid2ref[tid] : 0u;
+    if (ref_id == 0) return false;
+    if (n32 > 5) { atomicExch(&status[ST_CIGAR], 1u); return false; }
+    const uint32_t mism = (uint32_t)(uint8_t)((uint8_t)nm - (uint8_t)ind), ed = (uint32_t)(uint8_t)(mism + (uint32_t)gap);
+    const bool anti = (flag & 0x10u) != 0;
+    const uint32_t fl = (anti ? 1u : 0u) | (end ? 2u : 0u);
+    h16.ref_id = ref_id; h16.left = pos; h16.right = right;
+    h16.meta = fl | (ed << 8) | (mism << 16) | ((uint32_t)(read_len > 255 ? 255 : read_len) << 24);
+    h32.ref_id = ref_id; h32.left = pos;
+    h32.meta = (fl | ((spliced && xs == '-') ? 4u : 0u)) | (mism << 8) | (ed << 16) | ((uint32_t)n32 << 24);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void thj_k_parse(const uint8_t* __restrict__ infl, const uint8_t* __restrict__ blk_file, const FileInfo* __restrict__ files,
+                                                   const uint16_t* __restrict__ rec_off, const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ base,
+                                                   const uint32_t* __restrict__ tid2ref, uint32_t begin_id, uint32_t end_id, int max_report_intron, int want32,
+                                                   ParseOut o, unsigned int* status) {
+    const int b = blockIdx.x;
+    const FileInfo f = files[blk_file[b]];
+    const uint32_t n = cnt[b];
+    const uint8_t* slot = infl + ((size_t)b << 16);
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+        const uint32_t p = rec_off[(size_t)b * MAXREC + k];
+        const uint32_t bs = ld32(slot + p);
+        const uint8_t* d = slot + p + 4;
+        const uint32_t i = base[b] + k;
+        uint32_t id = 0; bool ok;
+        if (f.kind == KIND_READS) {
+            const uint32_t l_rn = ld32(d + 8) & 0xFF;
+            uint32_t v = 0;
+            for (uint32_t c = 0; c + 1 < l_rn && d[32 + c] >= '0' && d[32 + c] <= '9'; ++c) v = v * 10u + (uint32_t)(d[32 + c] - '0');
+            id = v; ok = true;
+            o.loc[i] = ((uint32_t)b << 16) | p;
+        } else {
+            Hit16 h16; Hit32 h32;
+            ok = parse_hit(d, bs, tid2ref + f.tid_base, f.n_tid, max_report_intron, id, h16, h32, status);
+            if (ok) { if (want32) o.h32[i] = h32; else o.h16[i] = h16; }
+        }
+        if (id < begin_id || id >= end_id) ok = false;
+        o.id[i] = id;
+        o.valid[i] = ok ? 1u : 0u;
+    }
+}
+
+// records the factory keeps, densely, file after file (dst = exclusive prefix sum of valid)
+__global__ __launch_bounds__(256) void thj_k_compact(int64_t n, const uint32_t* __restrict__ valid, const uint32_t* __restrict__ dst, ParseOut in, ParseOut out, int want32,
+                                                     const uint32_t* __restrict__ is_reads) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (!valid[i]) continue;
+        const uint32_t j = dst[i];
+        out.id[j] = in.id[i];
+        if (is_reads[i]) out.loc[j] = in.loc[i];
+        else if (want32) out.h32[j] = in.h32[i];
+        else out.h16[j] = in.h16[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void thj_k_mark_reads(const FileInfo* files, int n_files, const uint32_t* base, uint32_t* is_reads, int64_t n) {
+    // record -> "belongs to a reads file" (files are few: linear scan)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t r = 0;
+        for (int f = 0; f < n_files; ++f) if (files[f].kind == KIND_READS && i >= files[f].rec_base && i < (int64_t)files[f].rec_base + files[f].n_rec) r = 1;
+        is_reads[i] = r;
+    }
+    (void)base;
+}
+
+// ---- merge by read id over the dense id range [id0, id0 + span)
+// first[f][idl] = compact index of the first record of that id in file f, cntf[f][idl] = how many
+__global__ __launch_bounds__(256) void thj_k_runs_clipped(const uint32_t* __restrict__ id, uint32_t a, uint32_t b, uint32_t id0, uint32_t span, uint32_t* __restrict__ first,
+                                                            uint32_t* __restrict__ cntf) {
+    for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+        const uint32_t idl = id[i] - id0;
+        if (idl >= span) continue;                               // a mate outside the id range of the shard's segment hits
+        if (i == a || id[i - 1] != id[i]) first[idl] = i;
+        atomicAdd(&cntf[idl], 1u);
+    }
+}
+
+// visited (look_for_hit_group's visiting set, tophat_amd/batch.py): some segment above the first has a hit -- or any segment
+// when first-segment-only reads ride along (fusion / coverage search)
+__global__ __launch_bounds__(256) void thj_k_visited(const uint32_t* __restrict__ cntf, int nseg, uint32_t span, int include_top0, uint32_t* __restrict__ vis) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
+        uint32_t any = 0;
+        for (int s = include_top0 ? 0 : 1; s < nseg; ++s) any |= cntf[(size_t)s * span + i];
+        vis[i] = any ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void thj_k_row_counts(const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, const uint32_t* __restrict__ cntf, int nseg, uint32_t span,
+                                                        uint32_t* __restrict__ cell, const uint32_t* __restrict__ cnt_full, const uint32_t* __restrict__ cnt_last,
+                                                        uint32_t* __restrict__ mcell, uint32_t* __restrict__ row_id, uint32_t id0) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < span; i += gridDim.x * blockDim.x) {
+        if (!vis[i]) continue;
+        const uint32_t r = row[i];
+        for (int s = 0; s < nseg; ++s) cell[(size_t)r * nseg + s] = cntf[(size_t)s * span + i];
+        if (mcell) { const uint32_t cf = cnt_full ? cnt_full[i] : 0u; mcell[r] = cf ? cf : (cnt_last ? cnt_last[i] : 0u); }
+        row_id[r] = id0 + i;
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void thj_k_scatter_hits(const uint32_t* __restrict__ id, const T* __restrict__ src, uint32_t a, uint32_t b, uint32_t id0, const uint32_t* __restrict__ vis,
+                                                          const uint32_t* __restrict__ row, const uint32_t* __restrict__ first, const uint32_t* __restrict__ off, int nseg, int s,
+                                                          T* __restrict__ dst) {
+    for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+        const uint32_t idl = id[i] - id0;
+        if (!vis[idl]) continue;
+        dst[off[(size_t)row[idl] * nseg + s] + (i - first[idl])] = src[i];
+    }
+}
+
+// mate hits: the mate's whole-read map when it has the id, else the mate's last segment map (find_gaps :3321-3348)
+__global__ __launch_bounds__(256) void thj_k_scatter_mates(const uint32_t* __restrict__ id, const Hit16* __restrict__ src, uint32_t a, uint32_t b, uint32_t id0, uint32_t span,
+                                                           const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, const uint32_t* __restrict__ first,
+                                                           const uint32_t* __restrict__ moff, const uint32_t* __restrict__ cnt_full, int is_last, Hit16* __restrict__ dst) {
+    for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+        const uint32_t idl = id[i] - id0;
+        if (idl >= span || !vis[idl]) continue;
+        if (is_last && cnt_full && cnt_full[idl]) continue;
+        dst[moff[row[idl]] + (i - first[idl])] = src[i];
+    }
+}
+
+// reads: SEQ nibbles ("=ACMGRSVTWYHKDBN") -> {lo, hi, N} bit planes of thj_reads_pack; row = the read's row in the batch
+__global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restrict__ infl, const uint32_t* __restrict__ id, const uint32_t* __restrict__ loc, uint32_t a, uint32_t b,
+                                                         uint32_t id0, uint32_t span, const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, int W, u64* __restrict__ planes,
+                                                         uint16_t* __restrict__ rlen, uint32_t* __restrict__ seen, unsigned int* status) {
+    for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+        const uint32_t idl = id[i] - id0;
+        if (idl >= span || !vis[idl]) continue;
+        const uint32_t r = row[idl];
+        if (atomicExch(&seen[r], 1u)) continue;                    // the first record of an id is the read (ReadStream::getRead)
+        const uint8_t* d = infl + ((size_t)(loc[i] >> 16) << 16) + (loc[i] & 0xFFFFu) + 4;
+        const uint32_t l_rn = ld32(d + 8) & 0xFF, n_cig = ld32(d + 12) & 0xFFFF, l_seq = ld32(d + 16);
+        const uint8_t* sq = d + 32 + l_rn + 4 * n_cig;
+        u64* pl = planes + (size_t)r * 3 * W;
+        const uint32_t L = l_seq > (uint32_t)W * 64u ? (uint32_t)W * 64u : l_seq;
+        for (int w = 0; w < W; ++w) {
+            u64 lo = 0, hi = 0, nn = 0;
+            for (uint32_t k = 0; k < 64 && (uint32_t)w * 64 + k < L; ++k) {
+                const uint32_t bi = (uint32_t)w * 64 + k;
+                const uint32_t nib = (sq[bi >> 1] >> ((bi & 1) ? 0 : 4)) & 0xF;
+                uint32_t code; bool isn = false;
+                switch (nib) { case 1: code = 0; break; case 2: code = 1; break; case 4: code = 2; break; case 8: code = 3; break; default: code = 0; isn = true; }
+                lo |= (u64)(code & 1) << k; hi |= (u64)(code >> 1) << k; nn |= (u64)(isn ? 1 : 0) << k;
+            }
+            pl[w] = lo; pl[W + w] = hi; pl[2 * W + w] = nn;
+        }
+        rlen[r] = (uint16_t)l_seq;
+        (void)status;
+    }
+}
+
+__global__ void thj_k_check_seen(const uint32_t* seen, uint32_t n, unsigned int* status) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (!seen[i]) atomicExch(&status[ST_MISSING_READ], 1u);
+}
+
+}  // namespace ing
+
+// ------------------------------------------------------------------------------------------------ host side of the ingest
+
+namespace ing {
+
+// a bump allocator over one device allocation per call site: the ingest of a shard needs two dozen arrays whose sizes are known
+// up front or after one look at a counter; hipMalloc / hipFree per array would cost more than the kernels
+struct Arena {
+    char* base = nullptr; size_t cap = 0, used = 0;
+    template <class T> T* take(size_t n) {
+        const size_t bytes = (n * sizeof(T) + 255) & ~(size_t)255;
+        if (used + bytes > cap) return nullptr;
+        T* p = (T*)(base + used); used += bytes; return p;
+    }
+};
+
+// BGZF member table of a piece of a BAM file: (payload offset, payload length) per member; stops at the EOF member / end of data
+static bool member_table(const uint8_t* d, int64_t n, std::vector<thj_bgzf_block>& out, int64_t base_off) {
+    int64_t off = 0;
+    while (off + 28 <= n) {
+        if (d[off] != 31 || d[off + 1] != 139 || d[off + 2] != 8 || !(d[off + 3] & 4)) return false;
+        const uint32_t xlen = d[off + 10] | (d[off + 11] << 8);
+        // the BC subfield holds BSIZE; samtools writes it first (XLEN 6), others may not
+        int64_t x = off + 12; const int64_t xe = x + xlen; uint32_t bsize = 0;
+        while (x + 4 <= xe) {
+            const uint32_t slen = d[x + 2] | (d[x + 3] << 8);
+            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2) bsize = (uint32_t)(d[x + 4] | (d[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (!bsize || off + bsize > n) return false;
+        const uint32_t payload = bsize - (12 + xlen) - 8;
+        const uint32_t isize = d[off + bsize - 4] | (d[off + bsize - 3] << 8) | (d[off + bsize - 2] << 16) | ((uint32_t)d[off + bsize - 1] << 24);
+        if (isize) out.push_back({(uint64_t)(base_off + off + 12 + xlen), payload, isize});
+        off += bsize;
+    }
+    return off == n;
+}
+
+}  // namespace ing
+
+struct IngestOwned { thj_seg_batch desc; void* ptrs[6]; };          // same layout as the uploaded batches: thj_batch_free releases it
+
+#define ING_TAKE(var, T, n)                                                                         \
+    T* var = ar.take<T>((size_t)(n));                                                               \
+    if (!var) { thj_set_error("thj_ingest: scratch arena too small (%zu of %zu bytes used)", ar.used, ar.cap); return THJ_ENOMEM; }
+
+extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* mate_full,
+                                    const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
+                                    uint32_t ordinal_base, thj_seg_batch** out, int64_t* n_reads_out) {
+    using namespace ing;
+    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out) { thj_set_error("thj_ingest_seg_batch: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    *out = nullptr;
+    if (n_reads_out) *n_reads_out = 0;
+    // ---- the pieces: segment maps, [mate whole-read map], [mate last segment map], reads
+    std::vector<const thj_bam_piece*> pieces;
+    for (int s = 0; s < nseg; ++s) pieces.push_back(&segs[s]);
+    const int f_full = mate_full ? (int)pieces.size() : -1; if (mate_full) pieces.push_back(mate_full);
+    const int f_last = mate_last ? (int)pieces.size() : -1; if (mate_last) pieces.push_back(mate_last);
+    const int f_reads = (int)pieces.size(); pieces.push_back(reads);
+    const int nf = (int)pieces.size();
+    std::vector<thj_bgzf_block> blocks;
+    std::vector<uint8_t> blk_file;
+    std::vector<FileInfo> files((size_t)nf);
+    std::vector<uint32_t> tid2ref;
+    int64_t comp_total = 0;
+    for (int f = 0; f < nf; ++f) {
+        const thj_bam_piece& p = *pieces[(size_t)f];
+        FileInfo& fi = files[(size_t)f];
+        fi.first_block = (uint32_t)blocks.size();
+        if (p.comp_bytes > 0 && !member_table(p.comp, p.comp_bytes, blocks, comp_total)) { thj_set_error("thj_ingest: input %d is not a run of whole BGZF members", f); return THJ_EFALLBACK; }
+        fi.n_blocks = (uint32_t)blocks.size() - fi.first_block;
+        fi.first_skip = p.first_skip; fi.kind = f == f_reads ? KIND_READS : KIND_HITS;
+        fi.tid_base = (uint32_t)tid2ref.size(); fi.n_tid = (uint32_t)p.n_tid; fi.rec_base = 0; fi.n_rec = 0;
+        tid2ref.insert(tid2ref.end(), p.tid2ref, p.tid2ref + p.n_tid);
+        blk_file.insert(blk_file.end(), fi.n_blocks, (uint8_t)f);
+        comp_total += p.comp_bytes;
+    }
+    const int64_t nb = (int64_t)blocks.size();
+    if (nb == 0) return THJ_OK;                                  // nothing in this shard
+    // ---- scratch
+    const size_t need0 = (size_t)comp_total + 64 + (size_t)nb * (65536 + sizeof(thj_bgzf_block) + 1 + 4 + 4 + 4 + (size_t)MAXREC * 2) + (size_t)nf * sizeof(FileInfo) +
+                         tid2ref.size() * 4 + (1 << 20);
+    if (c->ing_cap0 < need0) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_ing0); c->d_ing0 = nullptr; c->ing_cap0 = 0; HIPCHK(hipMalloc(&c->d_ing0, need0 + need0 / 4)); c->ing_cap0 = need0 + need0 / 4; }
+    Arena ar{(char*)c->d_ing0, c->ing_cap0, 0};
+    ING_TAKE(d_comp, uint8_t, comp_total + 64);
+    ING_TAKE(d_blocks, thj_bgzf_block, nb);
+    ING_TAKE(d_blk_file, uint8_t, nb);
+    ING_TAKE(d_files, FileInfo, nf);
+    ING_TAKE(d_tid, uint32_t, tid2ref.size() + 1);
+    ING_TAKE(d_infl, uint8_t, (size_t)nb << 16);
+    ING_TAKE(d_len, uint32_t, nb);
+    ING_TAKE(d_cnt, uint32_t, nb + 1);
+    ING_TAKE(d_base, uint32_t, nb + 1);
+    ING_TAKE(d_recoff, uint16_t, (size_t)nb * MAXREC);
+    ING_TAKE(d_status, unsigned int, 16);
+    {
+        int64_t at = 0;
+        for (int f = 0; f < nf; ++f) { const thj_bam_piece& p = *pieces[(size_t)f]; if (p.comp_bytes) HIPCHK(hipMemcpyAsync(d_comp + at, p.comp, (size_t)p.comp_bytes, hipMemcpyHostToDevice, c->stream)); at += p.comp_bytes; }
+    }
+    HIPCHK(hipMemcpyAsync(d_blocks, blocks.data(), (size_t)nb * sizeof(thj_bgzf_block), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_blk_file, blk_file.data(), (size_t)nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_files, files.data(), (size_t)nf * sizeof(FileInfo), hipMemcpyHostToDevice, c->stream));
+    if (!tid2ref.empty()) HIPCHK(hipMemcpyAsync(d_tid, tid2ref.data(), tid2ref.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(d_status, 0, 64, c->stream));
+    HIPCHK(hipMemsetAsync(d_cnt + nb, 0, 4, c->stream));
+    // ---- inflate, walk, count
+    { const int64_t grid = nb < 4096 ? nb : 4096; hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_infl, d_len); }
+    hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
+    size_t scan_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_cnt, d_base, (int)(nb + 1), c->stream));
+    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
+    size_t sb = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, d_cnt, d_base, (int)(nb + 1), c->stream));
+    std::vector<uint32_t> h_base((size_t)nb + 1);
+    unsigned int h_status[16];
+    HIPCHK(hipMemcpyAsync(h_base.data(), d_base, (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h_status[ST_CORRUPT]) { thj_set_error("thj_ingest: a BGZF member does not inflate (corrupt input)"); return THJ_EINVAL; }
+    if (h_status[ST_STRADDLE]) { thj_set_error("thj_ingest: BAM records straddle BGZF members (not written by samtools' bam_write1): use the host reader"); return THJ_EFALLBACK; }
+    const int64_t T = h_base[(size_t)nb];
+    for (int f = 0; f < nf; ++f) { files[(size_t)f].rec_base = h_base[files[(size_t)f].first_block]; files[(size_t)f].n_rec = h_base[files[(size_t)f].first_block + files[(size_t)f].n_blocks] - files[(size_t)f].rec_base; }
+    HIPCHK(hipMemcpyAsync(d_files, files.data(), (size_t)nf * sizeof(FileInfo), hipMemcpyHostToDevice, c->stream));
+    if (T == 0) return THJ_OK;
+    // ---- parse + compact
+    const size_t need1 = (size_t)T * (4 + 4 + 4 + 4 + 16 + 4 + 4 + 16 + 4) + (size_t)(nf + 4) * 1024 + (1 << 20);
+    if (c->ing_cap1 < need1) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_ing1); c->d_ing1 = nullptr; c->ing_cap1 = 0; HIPCHK(hipMalloc(&c->d_ing1, need1 + need1 / 4)); c->ing_cap1 = need1 + need1 / 4; }
+    Arena a1{(char*)c->d_ing1, c->ing_cap1, 0};
+#define ING_TAKE1(var, T_, n) T_* var = a1.take<T_>((size_t)(n)); if (!var) { thj_set_error("thj_ingest: scratch arena too small"); return THJ_ENOMEM; }
+    ING_TAKE1(p_id, uint32_t, T); ING_TAKE1(p_valid, uint32_t, T + 1); ING_TAKE1(p_dst, uint32_t, T + 1); ING_TAKE1(p_isr, uint32_t, T);
+    ING_TAKE1(p_h16, Hit16, T); ING_TAKE1(p_loc, uint32_t, T);
+    ING_TAKE1(q_id, uint32_t, T); ING_TAKE1(q_h16, Hit16, T); ING_TAKE1(q_loc, uint32_t, T);
+    ParseOut po{p_id, p_valid, p_h16, nullptr, p_loc}, qo{q_id, nullptr, q_h16, nullptr, q_loc};
+    HIPCHK(hipMemsetAsync(p_valid + T, 0, 4, c->stream));
+    hipLaunchKernelGGL(thj_k_parse, dim3((unsigned)nb), dim3(256), 0, c->stream, d_infl, d_blk_file, d_files, d_recoff, d_cnt, d_base, d_tid, begin_id, end_id,
+                       (int)tp->max_report_intron, 0, po, d_status);
+    { int64_t g = (T + 255) / 256; if (g > 4096) g = 4096; hipLaunchKernelGGL(thj_k_mark_reads, dim3((unsigned)g), dim3(256), 0, c->stream, d_files, nf, d_base, p_isr, T); }
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, p_valid, p_dst, (int)(T + 1), c->stream));
+    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
+    sb = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, p_valid, p_dst, (int)(T + 1), c->stream));
+    { int64_t g = (T + 255) / 256; if (g > 4096) g = 4096; hipLaunchKernelGGL(thj_k_compact, dim3((unsigned)g), dim3(256), 0, c->stream, T, p_valid, p_dst, po, qo, 0, p_isr); }
+    // compact range of every file + the id range of the shard: first / last id of the segment maps
+    std::vector<uint32_t> fb((size_t)nf + 1);
+    for (int f = 0; f < nf; ++f) HIPCHK(hipMemcpyAsync(&fb[(size_t)f], p_dst + files[(size_t)f].rec_base, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&fb[(size_t)nf], p_dst + T, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h_status[ST_XF]) { thj_set_error("fusion (XF) alignments are not supported by this build"); return THJ_EINVAL; }
+    if (h_status[ST_CIGAR]) { thj_set_error("a segment alignment has more than 5 CIGAR operations (this build supports 5)"); return THJ_EINVAL; }
+    uint32_t id_lo = 0xFFFFFFFFu, id_hi = 0;
+    {
+        std::vector<uint32_t> ends((size_t)nseg * 2, 0);
+        for (int s = 0; s < nseg; ++s) if (fb[(size_t)s + 1] > fb[(size_t)s]) {
+            HIPCHK(hipMemcpyAsync(&ends[(size_t)s * 2], q_id + fb[(size_t)s], 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(&ends[(size_t)s * 2 + 1], q_id + fb[(size_t)s + 1] - 1, 4, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int s = 0; s < nseg; ++s) if (fb[(size_t)s + 1] > fb[(size_t)s]) { id_lo = std::min(id_lo, ends[(size_t)s * 2]); id_hi = std::max(id_hi, ends[(size_t)s * 2 + 1]); }
+    }
+    if (id_lo > id_hi) return THJ_OK;                            // no segment hit in range
+    const uint32_t span = id_hi - id_lo + 1;
+    // ---- merge by id
+    const int nmaps = nseg + (f_full >= 0 ? 1 : 0) + (f_last >= 0 ? 1 : 0);
+    ING_TAKE1(m_first, uint32_t, (size_t)nmaps * span); ING_TAKE1(m_cnt, uint32_t, (size_t)nmaps * span);
+    ING_TAKE1(m_vis, uint32_t, span + 1); ING_TAKE1(m_row, uint32_t, span + 1);
+    HIPCHK(hipMemsetAsync(m_cnt, 0, (size_t)nmaps * span * 4, c->stream));
+    HIPCHK(hipMemsetAsync(m_vis + span, 0, 4, c->stream));
+    auto grid_for = [](int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); };
+    // mates outside the segment maps' id range cannot belong to a visited read: clip their ranges by id on the device side via `span` tests
+    for (int m = 0; m < nmaps; ++m) {
+        const int f = m < nseg ? m : (m == nseg && f_full >= 0 ? f_full : f_last);
+        const uint32_t a = fb[(size_t)f], b = fb[(size_t)f + 1];
+        if (b > a) hipLaunchKernelGGL(thj_k_runs_clipped, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, a, b, id_lo, span, m_first + (size_t)m * span, m_cnt + (size_t)m * span);
+    }
+    hipLaunchKernelGGL(thj_k_visited, dim3(grid_for(span)), dim3(256), 0, c->stream, m_cnt, nseg, span, (int)include_top0, m_vis);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, m_vis, m_row, (int)(span + 1), c->stream));
+    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
+    sb = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, m_vis, m_row, (int)(span + 1), c->stream));
+    uint32_t n_rows = 0;
+    HIPCHK(hipMemcpyAsync(&n_rows, m_row + span, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_rows == 0) return THJ_OK;
+    // ---- the batch (device arrays of its own: it outlives the scratch)
+    const bool have_mate = f_full >= 0 || f_last >= 0;
+    // words per plane: a read of nseg segments is shorter than (nseg + 1) segment lengths (the last segment takes the remainder)
+    int W = (tp->segment_length * (nseg + 1) - 1 + 63) / 64;
+    if (W < 1) W = 1;
+    if (W > 4) { thj_set_error("thj_ingest: reads longer than 256 bases"); return THJ_EFALLBACK; }
+    IngestOwned* ob = new IngestOwned();
+    memset(ob, 0, sizeof *ob);
+    uint32_t* b_off = nullptr; Hit16* b_hits = nullptr; u64* b_planes = nullptr; uint16_t* b_len = nullptr; uint32_t* b_moff = nullptr; Hit16* b_mh = nullptr;
+    ING_TAKE1(cell, uint32_t, (size_t)n_rows * nseg + 1); ING_TAKE1(mcell, uint32_t, (size_t)n_rows + 1); ING_TAKE1(row_id, uint32_t, n_rows); ING_TAKE1(seen, uint32_t, n_rows);
+    HIPCHK(hipMalloc(&b_off, ((size_t)n_rows * nseg + 1) * 4));
+    HIPCHK(hipMalloc(&b_planes, (size_t)n_rows * 3 * W * 8));
+    HIPCHK(hipMalloc(&b_len, (size_t)n_rows * 2));
+    ob->ptrs[0] = b_off; ob->ptrs[2] = b_planes; ob->ptrs[3] = b_len;
+    HIPCHK(hipMemsetAsync(cell + (size_t)n_rows * nseg, 0, 4, c->stream));
+    HIPCHK(hipMemsetAsync(mcell + n_rows, 0, 4, c->stream));
+    HIPCHK(hipMemsetAsync(seen, 0, (size_t)n_rows * 4, c->stream));
+    HIPCHK(hipMemsetAsync(b_len, 0, (size_t)n_rows * 2, c->stream));
+    hipLaunchKernelGGL(thj_k_row_counts, dim3(grid_for(span)), dim3(256), 0, c->stream, m_vis, m_row, m_cnt, nseg, span, cell,
+                       f_full >= 0 ? m_cnt + (size_t)nseg * span : (const uint32_t*)nullptr,
+                       f_last >= 0 ? m_cnt + (size_t)(nseg + (f_full >= 0 ? 1 : 0)) * span : (const uint32_t*)nullptr, have_mate ? mcell : (uint32_t*)nullptr, row_id, id_lo);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cell, b_off, (int)((size_t)n_rows * nseg + 1), c->stream));
+    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
+    sb = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, cell, b_off, (int)((size_t)n_rows * nseg + 1), c->stream));
+    uint32_t n_hits = 0, n_mh = 0;
+    HIPCHK(hipMemcpyAsync(&n_hits, b_off + (size_t)n_rows * nseg, 4, hipMemcpyDeviceToHost, c->stream));
+    if (have_mate) {
+        HIPCHK(hipMalloc(&b_moff, ((size_t)n_rows + 1) * 4));
+        ob->ptrs[4] = b_moff;
+        sb = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, mcell, b_moff, (int)(n_rows + 1), c->stream));
+        HIPCHK(hipMemcpyAsync(&n_mh, b_moff + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMalloc(&b_hits, (size_t)(n_hits ? n_hits : 1) * 16));
+    ob->ptrs[1] = b_hits;
+    for (int s = 0; s < nseg; ++s) {
+        const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
+        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit16>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, q_h16, a, b, id_lo, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
+    }
+    if (have_mate) {
+        HIPCHK(hipMalloc(&b_mh, (size_t)(n_mh ? n_mh : 1) * 16));
+        ob->ptrs[5] = b_mh;
+        int m = nseg;
+        const uint32_t* cf = f_full >= 0 ? m_cnt + (size_t)nseg * span : nullptr;
+        if (f_full >= 0) {
+            const uint32_t a = fb[(size_t)f_full], b = fb[(size_t)f_full + 1];
+            if (b > a) hipLaunchKernelGGL(thj_k_scatter_mates, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, q_h16, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)m * span, b_moff, cf, 0, b_mh);
+            ++m;
+        }
+        if (f_last >= 0) {
+            const uint32_t a = fb[(size_t)f_last], b = fb[(size_t)f_last + 1];
+            if (b > a) hipLaunchKernelGGL(thj_k_scatter_mates, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, q_h16, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)m * span, b_moff, cf, 1, b_mh);
+        }
+    }
+    {
+        const uint32_t a = fb[(size_t)f_reads], b = fb[(size_t)f_reads + 1];
+        if (b > a) hipLaunchKernelGGL(thj_k_read_planes, dim3(grid_for(b - a)), dim3(256), 0, c->stream, d_infl, q_id, q_loc, a, b, id_lo, span, m_vis, m_row, W, b_planes, b_len, seen, d_status);
+        hipLaunchKernelGGL(thj_k_check_seen, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, seen, n_rows, d_status);
+    }
+    HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
+    if (h_status[ST_MISSING_READ]) {
+        for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]);
+        delete ob;
+        thj_set_error("Error: could not get a read of the shard from the reads file");
+        return THJ_EINVAL;
+    }
+    ob->desc.n_reads = (int32_t)n_rows; ob->desc.nseg = nseg; ob->desc.words_per_plane = W;
+    ob->desc.seg_off = b_off; ob->desc.hits = (const thj_hit*)b_hits; ob->desc.read_planes = (const uint64_t*)b_planes; ob->desc.read_len = b_len;
+    ob->desc.mate_off = b_moff; ob->desc.mate_hits = (const thj_hit*)b_mh; ob->desc.ordinal_base = ordinal_base;
+    *out = &ob->desc;
+    if (n_reads_out) *n_reads_out = n_rows;
+    return THJ_OK;
+}
