@@ -390,6 +390,17 @@ int thj_ingest_seg_batch(thj_ctx* ctx, const thj_params* p, int32_t nseg, const 
                          const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
                          uint32_t ordinal_base, thj_seg_batch** out, int64_t* n_reads);
 
+/* long_spanning_reads: the contig segment maps of one shard on the device -> a batch whose per-(read, segment) hit lists are
+ * set, for the reads with a hit in the FIRST segment map (the groups JoinSegmentsWorker iterates over,
+ * long_spanning_reads.cpp:2706-2765).  *row_ids (HOST, malloc'd: free() it) = their read ids in row order; the caller fetches
+ * those reads -- it needs names, bases and qualities for the BAM records anyway -- and completes the batch with
+ * thj_span_batch_attach_reads (HOST arrays in the layouts of thj_reads_pack / thj_span_batch) before thj_span_run_async.
+ * thj_span_batch_free releases the batch.  *out == NULL with THJ_OK: nothing to do in this shard. */
+int thj_ingest_span_hits(thj_ctx* ctx, const thj_params* p, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
+                         thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows);
+int thj_span_batch_attach_reads(thj_ctx* ctx, thj_span_batch* batch, int32_t words_per_plane, int32_t qual_stride, const uint64_t* planes,
+                                const uint16_t* lens, const uint8_t* quals);
+
 /* ---------------------------------------------------------------- junction consensus
  * What tophat_reports does with the reported alignments to get junctions.bed: every REF_SKIP is a junction observation
  * (junctions_from_spliced_hit, junctions.cpp:19-97), observations of one junction merge (support adds up, extents take the

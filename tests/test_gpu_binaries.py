@@ -158,11 +158,15 @@ def test_device_ingest_equals_host_ingest(tmp_path):
     """segment_juncs reading its BAM inputs on the device (BGZF inflate + record parse + merge by read id in HBM) against the
     host readers: identical event files -- with one shard and with many, paired-end with mate maps"""
     d = _gen_case(tmp_path, pairs=80000)
-    dev, _, log_dev = _run_both(d, tmp_path, "dev", {"THJ_SHARDS": "7", "THJ_WORKERS": "3"})
-    hst, _, log_hst = _run_both(d, tmp_path, "hst", {"THJ_SHARDS": "7", "THJ_WORKERS": "3", "THJ_HOST_INGEST": "1"})
-    one, _, _ = _run_both(d, tmp_path, "one", {"THJ_SHARDS": "1", "THJ_WORKERS": "1"})
+    dev, bam_dev, log_dev = _run_both(d, tmp_path, "dev", {"THJ_SHARDS": "7", "THJ_WORKERS": "3"})
+    hst, bam_hst, log_hst = _run_both(d, tmp_path, "hst", {"THJ_SHARDS": "7", "THJ_WORKERS": "3", "THJ_HOST_INGEST": "1"})
+    one, bam_one, _ = _run_both(d, tmp_path, "one", {"THJ_SHARDS": "1", "THJ_WORKERS": "1"})
     assert "reading on the host" not in log_dev
     assert dev == hst == one and dev["juncs"].count("\n") > 500
+    # long_spanning_reads: segment maps parsed on the device, reads on the host -> the same BAM stream and .index
+    ref = gzip.open(bam_hst, "rb").read()
+    assert gzip.open(bam_dev, "rb").read() == ref and gzip.open(bam_one, "rb").read() == ref and len(ref) > 1000000
+    assert open(bam_dev + ".index").read() == open(bam_hst + ".index").read()
 
 
 def test_long_spanning_reads_parts(tmp_path):

@@ -34,13 +34,14 @@ struct Shard {
     uint64_t begin_id = 0, end_id = ~0ull;
     int64_t read_off = 0;
     std::vector<int64_t> seg_off, spliced_off;
+    std::vector<int64_t> seg_end;                   // where the next shard starts in the segment maps (-1: the end of the file)
 };
 
 // long_spanning_reads.cpp:2983-2991, :3051-3064: index files in the order {reads, spliced maps last..first, contig maps
 // last..first} -- the boundaries come from the FIRST segment's contig map, the stream the worker iterates over
 static std::vector<Shard> plan(const std::string& reads, const std::vector<std::string>& segs, const std::vector<std::string>& spliced, int want) {
     std::vector<Shard> out(1);
-    out[0].seg_off.assign(segs.size(), 0); out[0].spliced_off.assign(spliced.size(), 0);
+    out[0].seg_off.assign(segs.size(), 0); out[0].spliced_off.assign(spliced.size(), 0); out[0].seg_end.assign(segs.size(), -1);
     if (want < 2) return out;
     std::vector<std::string> fnames;
     fnames.push_back(reads);
@@ -65,6 +66,7 @@ static std::vector<Shard> plan(const std::string& reads, const std::vector<std::
         }
         sh.end_id = i + 1 < want ? ids[(size_t)i] : ~0ull;
     }
+    for (int i = 0; i < want; ++i) out[(size_t)i].seg_end = i + 1 < want ? out[(size_t)i + 1].seg_off : std::vector<int64_t>(segs.size(), -1);
     return out;
 }
 
@@ -248,6 +250,11 @@ int main(int argc, char** argv) {
 
     const int nseg = (int)segs.size();
     const std::string out = pos[6];
+    // BAM segment maps mapped for the device-side ingest (contig maps only: junction-db maps go through the spliced hit factory
+    // on the host, and then so does everything)
+    std::vector<std::unique_ptr<BamFile>> bams;
+    bool dev_ingest = !getenv("THJ_HOST_INGEST") && spliced_segs.empty();
+    for (int s = 0; s < nseg && dev_ingest; ++s) { bams.emplace_back(new BamFile()); if (!bams.back()->open(segs[(size_t)s], rt)) dev_ingest = false; }
     // ---- the shard plan.  -p N: the reference's N ranges, one output file each.  One output file: our own number of shards,
     // written in order.
     const int hw = effective_cpus();
@@ -289,6 +296,79 @@ int main(int argc, char** argv) {
         const Shard& sh = shards[k];
         Gpu& gpu = *gpus[k % (size_t)n_gpus];
         const BamWriter& enc_bw = *bws[parts == 1 ? 0 : k];
+        // ---- device-side ingest of the segment maps (thj_ingest_span_hits): the host reads the shard's reads only
+        if (dev_ingest) {
+            std::vector<thj_bam_piece> segp;
+            for (int s = 0; s < nseg; ++s) segp.push_back(bams[(size_t)s]->piece(sh.seg_off[(size_t)s], sh.seg_end.empty() ? -1 : sh.seg_end[(size_t)s]));
+            const uint32_t b_id = sh.begin_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.begin_id, e_id = sh.end_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.end_id;
+            thj_span_batch* dev = nullptr; uint32_t* ids = nullptr; int64_t n = 0;
+            int rc;
+            {
+                const long long tw = WorkClock::now();
+                std::lock_guard<std::mutex> lk(gpu.mu);
+                g_work.add(1, tw);
+                const long long td = WorkClock::now();
+                rc = thj_ingest_span_hits(device_ready(gpu), &o.p, nseg, segp.data(), b_id, e_id, &dev, &ids, &n);
+                g_work.add(2, td);
+            }
+            if (rc == THJ_OK) {
+                if (dev) {
+                    ReadStream reads;
+                    if (!reads.open(pos[1], o.zpacker, sh.read_off)) die("Error: cannot open %s for reading\n", pos[1].c_str());
+                    std::vector<Read> batch_rd((size_t)n);
+                    std::vector<int64_t> read_off(1, 0); std::string bases, quals; size_t max_len = 0;
+                    for (int64_t r = 0; r < n; ++r) {
+                        Read& rd = batch_rd[(size_t)r];
+                        if (!reads.get(ids[r], rd)) die("Error: could not get read # %d from stream\n", (int)ids[r]);
+                        bases += rd.seq; quals += rd.qual;
+                        read_off.push_back((int64_t)bases.size());
+                        if (rd.seq.size() > max_len) max_len = rd.seq.size();
+                    }
+                    free(ids);
+                    int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
+                    std::vector<uint64_t> planes((size_t)n * 3 * W);
+                    std::vector<uint16_t> lens((size_t)n);
+                    if (thj_reads_pack(n, read_off.data(), bases.data(), W, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
+                    const int stride = (int)((max_len + 3) / 4 * 4);
+                    std::vector<uint8_t> q((size_t)n * stride, 0);
+                    for (int64_t r = 0; r < n; ++r) memcpy(q.data() + (size_t)r * stride, quals.data() + read_off[(size_t)r], (size_t)(read_off[(size_t)r + 1] - read_off[(size_t)r]));
+                    std::vector<thj_aln> alns;
+                    {
+                        const long long tw = WorkClock::now();
+                        std::lock_guard<std::mutex> lk(gpu.mu);
+                        g_work.add(1, tw);
+                        const long long td = WorkClock::now();
+                        thj_ctx* ctx = device_ready(gpu);
+                        if (thj_span_batch_attach_reads(ctx, dev, W, stride, planes.data(), lens.data(), q.data())) die("Error: %s\n", thj_last_error());
+                        if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+                        if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
+                        int64_t na = 0;
+                        if (thj_span_finish(ctx, &na)) die("Error: %s\n", thj_last_error());
+                        alns.resize((size_t)na);
+                        if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
+                        if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+                        g_work.add(2, td);
+                    }
+                    BamWriter::Encoded e;
+                    const long long te = WorkClock::now();
+                    encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
+                    g_work.add(3, te);
+                    if (parts > 1) bws[k]->write_encoded(e);
+                    else {
+                        OutShard& oq = *outq[k];
+                        std::unique_lock<std::mutex> lk(oq.mu);
+                        oq.cv.wait(lk, [&] { return oq.q.size() < 2; });
+                        oq.q.push_back(std::move(e));
+                        oq.cv.notify_all();
+                    }
+                }
+                if (parts == 1) { OutShard& oq = *outq[k]; std::lock_guard<std::mutex> lk(oq.mu); oq.done = true; oq.cv.notify_all(); }
+                return;
+            }
+            if (rc != THJ_EFALLBACK) die("Error: %s\n", thj_last_error());
+            static std::atomic<bool> told{false};
+            if (!told.exchange(true)) fprintf(stderr, "\tdevice-side ingest not possible (%s); reading on the host\n", thj_last_error());
+        }
         std::vector<HitStream> st((size_t)nseg);
         for (int s = 0; s < nseg; ++s)
             if (!st[(size_t)s].open(segs[(size_t)s], rt, o.p, false, sh.seg_off[(size_t)s], sh.begin_id, sh.end_id))

@@ -80,8 +80,10 @@ struct Bits {
     uint64_t buf; int cnt; uint32_t pos;            // pos = absolute compressed byte index of the next byte to load
 };
 
+// the ring is filled in whole 32-bit words (zero-padded past the end of the stream) and position 0 of the stream sits at ring
+// offset 0, so the bit buffer takes one aligned LDS word at a time
 __device__ __forceinline__ void refill(Bits& b, const Shared& s) {
-    while (b.cnt <= 56 && b.pos < s.in_staged) { b.buf |= (uint64_t)s.in[b.pos & IN_MASK] << b.cnt; b.cnt += 8; ++b.pos; }
+    if (b.cnt <= 32 && b.pos < s.in_staged) { b.buf |= (uint64_t)((const uint32_t*)s.in)[(b.pos & IN_MASK) >> 2] << b.cnt; b.cnt += 32; b.pos += 4; }
 }
 __device__ __forceinline__ uint32_t take(Bits& b, int n) { const uint32_t v = (uint32_t)(b.buf & ((1ull << n) - 1)); b.buf >>= n; b.cnt -= n; return v; }
 
@@ -128,11 +130,11 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                 while (staged < in_len && staged + 256 <= used + INRING) {
                     const uint32_t p = staged + (uint32_t)lane * 4;
                     if (p < in_len) {
-                        // 4 bytes per lane; the source address is only byte-aligned
+                        // one ring word per lane; the source address is only byte-aligned, the tail is zero-padded
                         uint32_t w = 0;
                         const uint32_t nb = in_len - p < 4 ? in_len - p : 4;
                         for (uint32_t k = 0; k < nb; ++k) w |= (uint32_t)in[p + k] << (8 * k);
-                        for (uint32_t k = 0; k < nb; ++k) s.in[(p + k) & IN_MASK] = (uint8_t)(w >> (8 * k));
+                        ((uint32_t*)s.in)[(p & IN_MASK) >> 2] = w;
                     }
                     staged += 256;
                 }
@@ -166,7 +168,7 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                 for (;;) {
                     refill(b, s);
                     if (b.cnt < 0) { err = true; break; }                        // ran past the end of a truncated stream
-                    const uint32_t avail = s.in_staged - b.pos + (uint32_t)(b.cnt >> 3);
+                    const uint32_t avail = (uint32_t)((int)s.in_staged - (int)b.pos + (b.cnt >> 3) > 0 ? (int)s.in_staged - (int)b.pos + (b.cnt >> 3) : 0);
                     if (state == ST_HEADER) {
                         if (!all_in && avail < 400) break;
                         last = (int)take(b, 1);
@@ -238,18 +240,27 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                             if (ds < 0 || ds >= 30) { err = true; break; }
                             const uint32_t dist = DBASE[ds] + take(b, DEXT[ds]);
                             if (dist > outp || outp + (uint32_t)len > 65536u) { err = true; break; }
-                            for (int k = 0; k < len; ++k) s.win[(outp + k) & WIN_MASK] = s.win[(outp + k - dist) & WIN_MASK];
+                            int k = 0;
+                            if (dist >= 8)                                        // source and destination of a group of 8 cannot overlap: read the
+                                for (; k + 8 <= len; k += 8) {                    // group first (8 LDS reads in flight at once), then write it
+                                    const uint32_t sp = outp + (uint32_t)k - dist, dp = outp + (uint32_t)k;
+                                    const uint8_t t0 = s.win[(sp + 0) & WIN_MASK], t1 = s.win[(sp + 1) & WIN_MASK], t2 = s.win[(sp + 2) & WIN_MASK], t3 = s.win[(sp + 3) & WIN_MASK],
+                                                  t4 = s.win[(sp + 4) & WIN_MASK], t5 = s.win[(sp + 5) & WIN_MASK], t6 = s.win[(sp + 6) & WIN_MASK], t7 = s.win[(sp + 7) & WIN_MASK];
+                                    s.win[(dp + 0) & WIN_MASK] = t0; s.win[(dp + 1) & WIN_MASK] = t1; s.win[(dp + 2) & WIN_MASK] = t2; s.win[(dp + 3) & WIN_MASK] = t3;
+                                    s.win[(dp + 4) & WIN_MASK] = t4; s.win[(dp + 5) & WIN_MASK] = t5; s.win[(dp + 6) & WIN_MASK] = t6; s.win[(dp + 7) & WIN_MASK] = t7;
+                                }
+                            for (; k < len; ++k) s.win[(outp + k) & WIN_MASK] = s.win[(outp + k - dist) & WIN_MASK];
                             outp += (uint32_t)len;
                         }
                     } else { fin = true; break; }
                     if (outp > 65536u) { err = true; break; }
                 }
                 s.out_total = outp;
-                s.in_used = (b.pos - (uint32_t)(b.cnt >> 3)) & ~3u;
+                s.in_used = (uint32_t)((int)b.pos - (b.cnt >> 3) > 0 ? (int)b.pos - (b.cnt >> 3) : 0) & ~3u;
                 if (fin) s.done = 1;
                 if (err) s.error = 1;
                 // no progress possible and not finished: input exhausted in mid-stream
-                if (!fin && !err && all_in && s.in_staged - b.pos + (uint32_t)(b.cnt >> 3) == 0 && state != ST_DONE) s.error = 1;
+                if (!fin && !err && all_in && (int)s.in_staged - (int)b.pos + (b.cnt >> 3) <= 0 && state != ST_DONE) s.error = 1;
                 if (state == ST_DONE) s.done = 1;
             }
             __syncthreads();
@@ -618,25 +629,43 @@ static bool member_table(const uint8_t* d, int64_t n, std::vector<thj_bgzf_block
 }  // namespace ing
 
 struct IngestOwned { thj_seg_batch desc; void* ptrs[6]; };          // same layout as the uploaded batches: thj_batch_free releases it
+struct IngestOwnedSpan { thj_span_batch desc; void* ptrs[6]; };     // ... thj_span_batch_free
 
-#define ING_TAKE(var, T, n)                                                                         \
-    T* var = ar.take<T>((size_t)(n));                                                               \
-    if (!var) { thj_set_error("thj_ingest: scratch arena too small (%zu of %zu bytes used)", ar.used, ar.cap); return THJ_ENOMEM; }
+namespace ing {
 
-extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* mate_full,
-                                    const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
-                                    uint32_t ordinal_base, thj_seg_batch** out, int64_t* n_reads_out) {
-    using namespace ing;
-    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out) { thj_set_error("thj_ingest_seg_batch: bad argument"); return THJ_EINVAL; }
-    HIPCHK(hipSetDevice(c->device));
-    *out = nullptr;
-    if (n_reads_out) *n_reads_out = 0;
-    // ---- the pieces: segment maps, [mate whole-read map], [mate last segment map], reads
-    std::vector<const thj_bam_piece*> pieces;
-    for (int s = 0; s < nseg; ++s) pieces.push_back(&segs[s]);
-    const int f_full = mate_full ? (int)pieces.size() : -1; if (mate_full) pieces.push_back(mate_full);
-    const int f_last = mate_last ? (int)pieces.size() : -1; if (mate_last) pieces.push_back(mate_last);
-    const int f_reads = (int)pieces.size(); pieces.push_back(reads);
+// What the front half of an ingest leaves on the device: the records the hit factory keeps (and the reads' locations), densely,
+// file after file; fb[f] .. fb[f + 1] = file f's range.
+struct Parsed {
+    uint32_t* id = nullptr; Hit16* h16 = nullptr; Hit32* h32 = nullptr; uint32_t* loc = nullptr;
+    std::vector<uint32_t> fb;
+    uint8_t* infl = nullptr; unsigned int* status = nullptr;
+    Arena a1;
+    int64_t n = 0;
+};
+
+static int grow_scan_tmp(thj_ctx* c, size_t need) {
+    if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+    return THJ_OK;
+}
+static int exclusive_sum(thj_ctx* c, const uint32_t* in, uint32_t* out, int64_t n) {
+    size_t need = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, c->stream));
+    int rc = grow_scan_tmp(c, need);
+    if (rc) return rc;
+    size_t sb = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, in, out, (int)n, c->stream));
+    return THJ_OK;
+}
+static unsigned grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+#define ING_TAKE(ar, var, T, n)                                                                                 \
+    T* var = (ar).take<T>((size_t)(n));                                                                         \
+    if (!var) { thj_set_error("thj_ingest: scratch arena too small (%zu of %zu bytes used)", (ar).used, (ar).cap); return THJ_ENOMEM; }
+
+// inflate + walk + parse + compact for a list of pieces (kinds[f]: KIND_HITS / KIND_READS).  extra1 = bytes the caller will still
+// take from the second arena.  Two synchronisations (record total, compact ranges).
+static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<const thj_bam_piece*>& pieces, const std::vector<uint32_t>& kinds, uint32_t begin_id,
+                        uint32_t end_id, int want32, size_t extra1_per_rec, size_t extra1_fixed, Parsed& P) {
     const int nf = (int)pieces.size();
     std::vector<thj_bgzf_block> blocks;
     std::vector<uint8_t> blk_file;
@@ -649,30 +678,32 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
         fi.first_block = (uint32_t)blocks.size();
         if (p.comp_bytes > 0 && !member_table(p.comp, p.comp_bytes, blocks, comp_total)) { thj_set_error("thj_ingest: input %d is not a run of whole BGZF members", f); return THJ_EFALLBACK; }
         fi.n_blocks = (uint32_t)blocks.size() - fi.first_block;
-        fi.first_skip = p.first_skip; fi.kind = f == f_reads ? KIND_READS : KIND_HITS;
+        fi.first_skip = p.first_skip; fi.kind = kinds[(size_t)f];
         fi.tid_base = (uint32_t)tid2ref.size(); fi.n_tid = (uint32_t)p.n_tid; fi.rec_base = 0; fi.n_rec = 0;
         tid2ref.insert(tid2ref.end(), p.tid2ref, p.tid2ref + p.n_tid);
         blk_file.insert(blk_file.end(), fi.n_blocks, (uint8_t)f);
         comp_total += p.comp_bytes;
     }
     const int64_t nb = (int64_t)blocks.size();
-    if (nb == 0) return THJ_OK;                                  // nothing in this shard
-    // ---- scratch
+    P.fb.assign((size_t)nf + 1, 0);
+    P.n = 0;
+    if (nb == 0) return THJ_OK;
     const size_t need0 = (size_t)comp_total + 64 + (size_t)nb * (65536 + sizeof(thj_bgzf_block) + 1 + 4 + 4 + 4 + (size_t)MAXREC * 2) + (size_t)nf * sizeof(FileInfo) +
                          tid2ref.size() * 4 + (1 << 20);
     if (c->ing_cap0 < need0) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_ing0); c->d_ing0 = nullptr; c->ing_cap0 = 0; HIPCHK(hipMalloc(&c->d_ing0, need0 + need0 / 4)); c->ing_cap0 = need0 + need0 / 4; }
     Arena ar{(char*)c->d_ing0, c->ing_cap0, 0};
-    ING_TAKE(d_comp, uint8_t, comp_total + 64);
-    ING_TAKE(d_blocks, thj_bgzf_block, nb);
-    ING_TAKE(d_blk_file, uint8_t, nb);
-    ING_TAKE(d_files, FileInfo, nf);
-    ING_TAKE(d_tid, uint32_t, tid2ref.size() + 1);
-    ING_TAKE(d_infl, uint8_t, (size_t)nb << 16);
-    ING_TAKE(d_len, uint32_t, nb);
-    ING_TAKE(d_cnt, uint32_t, nb + 1);
-    ING_TAKE(d_base, uint32_t, nb + 1);
-    ING_TAKE(d_recoff, uint16_t, (size_t)nb * MAXREC);
-    ING_TAKE(d_status, unsigned int, 16);
+    ING_TAKE(ar, d_comp, uint8_t, comp_total + 64);
+    ING_TAKE(ar, d_blocks, thj_bgzf_block, nb);
+    ING_TAKE(ar, d_blk_file, uint8_t, nb);
+    ING_TAKE(ar, d_files, FileInfo, nf);
+    ING_TAKE(ar, d_tid, uint32_t, tid2ref.size() + 1);
+    ING_TAKE(ar, d_infl, uint8_t, (size_t)nb << 16);
+    ING_TAKE(ar, d_len, uint32_t, nb);
+    ING_TAKE(ar, d_cnt, uint32_t, nb + 1);
+    ING_TAKE(ar, d_base, uint32_t, nb + 1);
+    ING_TAKE(ar, d_recoff, uint16_t, (size_t)nb * MAXREC);
+    ING_TAKE(ar, d_status, unsigned int, 16);
+    P.infl = d_infl; P.status = d_status;
     {
         int64_t at = 0;
         for (int f = 0; f < nf; ++f) { const thj_bam_piece& p = *pieces[(size_t)f]; if (p.comp_bytes) HIPCHK(hipMemcpyAsync(d_comp + at, p.comp, (size_t)p.comp_bytes, hipMemcpyHostToDevice, c->stream)); at += p.comp_bytes; }
@@ -683,159 +714,263 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
     if (!tid2ref.empty()) HIPCHK(hipMemcpyAsync(d_tid, tid2ref.data(), tid2ref.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(d_status, 0, 64, c->stream));
     HIPCHK(hipMemsetAsync(d_cnt + nb, 0, 4, c->stream));
-    // ---- inflate, walk, count
     { const int64_t grid = nb < 4096 ? nb : 4096; hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_infl, d_len); }
     hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
-    size_t scan_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_cnt, d_base, (int)(nb + 1), c->stream));
-    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
-    size_t sb = c->sort_tmp_bytes;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, d_cnt, d_base, (int)(nb + 1), c->stream));
+    int rc = exclusive_sum(c, d_cnt, d_base, nb + 1);
+    if (rc) return rc;
     std::vector<uint32_t> h_base((size_t)nb + 1);
     unsigned int h_status[16];
     HIPCHK(hipMemcpyAsync(h_base.data(), d_base, (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (h_status[ST_CORRUPT]) { thj_set_error("thj_ingest: a BGZF member does not inflate (corrupt input)"); return THJ_EINVAL; }
-    if (h_status[ST_STRADDLE]) { thj_set_error("thj_ingest: BAM records straddle BGZF members (not written by samtools' bam_write1): use the host reader"); return THJ_EFALLBACK; }
+    if (h_status[ST_STRADDLE]) { thj_set_error("BAM records straddle BGZF members (not written by samtools' bam_write1)"); return THJ_EFALLBACK; }
     const int64_t T = h_base[(size_t)nb];
     for (int f = 0; f < nf; ++f) { files[(size_t)f].rec_base = h_base[files[(size_t)f].first_block]; files[(size_t)f].n_rec = h_base[files[(size_t)f].first_block + files[(size_t)f].n_blocks] - files[(size_t)f].rec_base; }
     HIPCHK(hipMemcpyAsync(d_files, files.data(), (size_t)nf * sizeof(FileInfo), hipMemcpyHostToDevice, c->stream));
     if (T == 0) return THJ_OK;
-    // ---- parse + compact
-    const size_t need1 = (size_t)T * (4 + 4 + 4 + 4 + 16 + 4 + 4 + 16 + 4) + (size_t)(nf + 4) * 1024 + (1 << 20);
+    const size_t hit_b = want32 ? sizeof(Hit32) : sizeof(Hit16);
+    const size_t need1 = (size_t)(T + 64) * (4 + 4 + 4 + 4 + hit_b + 4 + 4 + hit_b + 4 + extra1_per_rec) + extra1_fixed + (size_t)(nf + 64) * 1024 + (1 << 20);
     if (c->ing_cap1 < need1) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_ing1); c->d_ing1 = nullptr; c->ing_cap1 = 0; HIPCHK(hipMalloc(&c->d_ing1, need1 + need1 / 4)); c->ing_cap1 = need1 + need1 / 4; }
-    Arena a1{(char*)c->d_ing1, c->ing_cap1, 0};
-#define ING_TAKE1(var, T_, n) T_* var = a1.take<T_>((size_t)(n)); if (!var) { thj_set_error("thj_ingest: scratch arena too small"); return THJ_ENOMEM; }
-    ING_TAKE1(p_id, uint32_t, T); ING_TAKE1(p_valid, uint32_t, T + 1); ING_TAKE1(p_dst, uint32_t, T + 1); ING_TAKE1(p_isr, uint32_t, T);
-    ING_TAKE1(p_h16, Hit16, T); ING_TAKE1(p_loc, uint32_t, T);
-    ING_TAKE1(q_id, uint32_t, T); ING_TAKE1(q_h16, Hit16, T); ING_TAKE1(q_loc, uint32_t, T);
-    ParseOut po{p_id, p_valid, p_h16, nullptr, p_loc}, qo{q_id, nullptr, q_h16, nullptr, q_loc};
+    P.a1 = Arena{(char*)c->d_ing1, c->ing_cap1, 0};
+    ING_TAKE(P.a1, p_id, uint32_t, T); ING_TAKE(P.a1, p_valid, uint32_t, T + 1); ING_TAKE(P.a1, p_dst, uint32_t, T + 1); ING_TAKE(P.a1, p_isr, uint32_t, T);
+    ING_TAKE(P.a1, p_hit, uint8_t, (size_t)T * hit_b); ING_TAKE(P.a1, p_loc, uint32_t, T);
+    ING_TAKE(P.a1, q_id, uint32_t, T); ING_TAKE(P.a1, q_hit, uint8_t, (size_t)T * hit_b); ING_TAKE(P.a1, q_loc, uint32_t, T);
+    ParseOut po{p_id, p_valid, want32 ? nullptr : (Hit16*)p_hit, want32 ? (Hit32*)p_hit : nullptr, p_loc};
+    ParseOut qo{q_id, nullptr, want32 ? nullptr : (Hit16*)q_hit, want32 ? (Hit32*)q_hit : nullptr, q_loc};
     HIPCHK(hipMemsetAsync(p_valid + T, 0, 4, c->stream));
     hipLaunchKernelGGL(thj_k_parse, dim3((unsigned)nb), dim3(256), 0, c->stream, d_infl, d_blk_file, d_files, d_recoff, d_cnt, d_base, d_tid, begin_id, end_id,
-                       (int)tp->max_report_intron, 0, po, d_status);
-    { int64_t g = (T + 255) / 256; if (g > 4096) g = 4096; hipLaunchKernelGGL(thj_k_mark_reads, dim3((unsigned)g), dim3(256), 0, c->stream, d_files, nf, d_base, p_isr, T); }
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, p_valid, p_dst, (int)(T + 1), c->stream));
-    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
-    sb = c->sort_tmp_bytes;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, p_valid, p_dst, (int)(T + 1), c->stream));
-    { int64_t g = (T + 255) / 256; if (g > 4096) g = 4096; hipLaunchKernelGGL(thj_k_compact, dim3((unsigned)g), dim3(256), 0, c->stream, T, p_valid, p_dst, po, qo, 0, p_isr); }
-    // compact range of every file + the id range of the shard: first / last id of the segment maps
-    std::vector<uint32_t> fb((size_t)nf + 1);
-    for (int f = 0; f < nf; ++f) HIPCHK(hipMemcpyAsync(&fb[(size_t)f], p_dst + files[(size_t)f].rec_base, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&fb[(size_t)nf], p_dst + T, 4, hipMemcpyDeviceToHost, c->stream));
+                       (int)tp->max_report_intron, want32, po, d_status);
+    hipLaunchKernelGGL(thj_k_mark_reads, dim3(grid_for(T)), dim3(256), 0, c->stream, d_files, nf, d_base, p_isr, T);
+    if ((rc = exclusive_sum(c, p_valid, p_dst, T + 1))) return rc;
+    hipLaunchKernelGGL(thj_k_compact, dim3(grid_for(T)), dim3(256), 0, c->stream, T, p_valid, p_dst, po, qo, want32, p_isr);
+    for (int f = 0; f < nf; ++f) HIPCHK(hipMemcpyAsync(&P.fb[(size_t)f], p_dst + files[(size_t)f].rec_base, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&P.fb[(size_t)nf], p_dst + T, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipGetLastError());
     if (h_status[ST_XF]) { thj_set_error("fusion (XF) alignments are not supported by this build"); return THJ_EINVAL; }
     if (h_status[ST_CIGAR]) { thj_set_error("a segment alignment has more than 5 CIGAR operations (this build supports 5)"); return THJ_EINVAL; }
+    P.id = q_id; P.h16 = qo.h16; P.h32 = qo.h32; P.loc = q_loc; P.n = P.fb[(size_t)nf];
+    return THJ_OK;
+}
+
+}  // namespace ing
+
+extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* mate_full,
+                                    const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
+                                    uint32_t ordinal_base, thj_seg_batch** out, int64_t* n_reads_out) {
+    using namespace ing;
+    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out) { thj_set_error("thj_ingest_seg_batch: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    *out = nullptr;
+    if (n_reads_out) *n_reads_out = 0;
+    // words per plane: a read of nseg segments is shorter than (nseg + 1) segment lengths (the last segment takes the remainder)
+    int W = (tp->segment_length * (nseg + 1) - 1 + 63) / 64;
+    if (W < 1) W = 1;
+    if (W > 4) { thj_set_error("reads longer than 256 bases"); return THJ_EFALLBACK; }
+    std::vector<const thj_bam_piece*> pieces;
+    std::vector<uint32_t> kinds;
+    for (int s = 0; s < nseg; ++s) { pieces.push_back(&segs[s]); kinds.push_back(KIND_HITS); }
+    const int f_full = mate_full ? (int)pieces.size() : -1; if (mate_full) { pieces.push_back(mate_full); kinds.push_back(KIND_HITS); }
+    const int f_last = mate_last ? (int)pieces.size() : -1; if (mate_last) { pieces.push_back(mate_last); kinds.push_back(KIND_HITS); }
+    const int f_reads = (int)pieces.size(); pieces.push_back(reads); kinds.push_back(KIND_READS);
+    Parsed P;
+    // the merge takes, per id of the shard's id range, two words per map + two; per row a handful more
+    int rc = ingest_front(c, tp, pieces, kinds, begin_id, end_id, 0, 0, 0, P);
+    if (rc) return rc;
+    const std::vector<uint32_t>& fb = P.fb;
+    if (P.n == 0) return THJ_OK;
     uint32_t id_lo = 0xFFFFFFFFu, id_hi = 0;
     {
         std::vector<uint32_t> ends((size_t)nseg * 2, 0);
         for (int s = 0; s < nseg; ++s) if (fb[(size_t)s + 1] > fb[(size_t)s]) {
-            HIPCHK(hipMemcpyAsync(&ends[(size_t)s * 2], q_id + fb[(size_t)s], 4, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipMemcpyAsync(&ends[(size_t)s * 2 + 1], q_id + fb[(size_t)s + 1] - 1, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(&ends[(size_t)s * 2], P.id + fb[(size_t)s], 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipMemcpyAsync(&ends[(size_t)s * 2 + 1], P.id + fb[(size_t)s + 1] - 1, 4, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int s = 0; s < nseg; ++s) if (fb[(size_t)s + 1] > fb[(size_t)s]) { id_lo = std::min(id_lo, ends[(size_t)s * 2]); id_hi = std::max(id_hi, ends[(size_t)s * 2 + 1]); }
     }
     if (id_lo > id_hi) return THJ_OK;                            // no segment hit in range
     const uint32_t span = id_hi - id_lo + 1;
-    // ---- merge by id
+    // ---- merge by id (scratch of its own: sized by the id range)
     const int nmaps = nseg + (f_full >= 0 ? 1 : 0) + (f_last >= 0 ? 1 : 0);
-    ING_TAKE1(m_first, uint32_t, (size_t)nmaps * span); ING_TAKE1(m_cnt, uint32_t, (size_t)nmaps * span);
-    ING_TAKE1(m_vis, uint32_t, span + 1); ING_TAKE1(m_row, uint32_t, span + 1);
+    const size_t need2 = (size_t)span * 4 * (2 * (size_t)nmaps + 2 + (size_t)nseg + 4) + (1 << 20);
+    void* d_merge = nullptr;
+    HIPCHK(hipMalloc(&d_merge, need2));
+    struct Guard { void* p; ~Guard() { hipFree(p); } } guard{d_merge};
+    Arena am{(char*)d_merge, need2, 0};
+    ING_TAKE(am, m_first, uint32_t, (size_t)nmaps * span); ING_TAKE(am, m_cnt, uint32_t, (size_t)nmaps * span);
+    ING_TAKE(am, m_vis, uint32_t, span + 1); ING_TAKE(am, m_row, uint32_t, span + 1);
     HIPCHK(hipMemsetAsync(m_cnt, 0, (size_t)nmaps * span * 4, c->stream));
     HIPCHK(hipMemsetAsync(m_vis + span, 0, 4, c->stream));
-    auto grid_for = [](int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); };
-    // mates outside the segment maps' id range cannot belong to a visited read: clip their ranges by id on the device side via `span` tests
     for (int m = 0; m < nmaps; ++m) {
         const int f = m < nseg ? m : (m == nseg && f_full >= 0 ? f_full : f_last);
         const uint32_t a = fb[(size_t)f], b = fb[(size_t)f + 1];
-        if (b > a) hipLaunchKernelGGL(thj_k_runs_clipped, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, a, b, id_lo, span, m_first + (size_t)m * span, m_cnt + (size_t)m * span);
+        if (b > a) hipLaunchKernelGGL(thj_k_runs_clipped, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, a, b, id_lo, span, m_first + (size_t)m * span, m_cnt + (size_t)m * span);
     }
     hipLaunchKernelGGL(thj_k_visited, dim3(grid_for(span)), dim3(256), 0, c->stream, m_cnt, nseg, span, (int)include_top0, m_vis);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, m_vis, m_row, (int)(span + 1), c->stream));
-    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
-    sb = c->sort_tmp_bytes;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, m_vis, m_row, (int)(span + 1), c->stream));
+    if ((rc = exclusive_sum(c, m_vis, m_row, span + 1))) return rc;
     uint32_t n_rows = 0;
     HIPCHK(hipMemcpyAsync(&n_rows, m_row + span, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (n_rows == 0) return THJ_OK;
     // ---- the batch (device arrays of its own: it outlives the scratch)
     const bool have_mate = f_full >= 0 || f_last >= 0;
-    // words per plane: a read of nseg segments is shorter than (nseg + 1) segment lengths (the last segment takes the remainder)
-    int W = (tp->segment_length * (nseg + 1) - 1 + 63) / 64;
-    if (W < 1) W = 1;
-    if (W > 4) { thj_set_error("thj_ingest: reads longer than 256 bases"); return THJ_EFALLBACK; }
     IngestOwned* ob = new IngestOwned();
     memset(ob, 0, sizeof *ob);
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]); delete ob; return code; };
     uint32_t* b_off = nullptr; Hit16* b_hits = nullptr; u64* b_planes = nullptr; uint16_t* b_len = nullptr; uint32_t* b_moff = nullptr; Hit16* b_mh = nullptr;
-    ING_TAKE1(cell, uint32_t, (size_t)n_rows * nseg + 1); ING_TAKE1(mcell, uint32_t, (size_t)n_rows + 1); ING_TAKE1(row_id, uint32_t, n_rows); ING_TAKE1(seen, uint32_t, n_rows);
-    HIPCHK(hipMalloc(&b_off, ((size_t)n_rows * nseg + 1) * 4));
-    HIPCHK(hipMalloc(&b_planes, (size_t)n_rows * 3 * W * 8));
-    HIPCHK(hipMalloc(&b_len, (size_t)n_rows * 2));
-    ob->ptrs[0] = b_off; ob->ptrs[2] = b_planes; ob->ptrs[3] = b_len;
-    HIPCHK(hipMemsetAsync(cell + (size_t)n_rows * nseg, 0, 4, c->stream));
-    HIPCHK(hipMemsetAsync(mcell + n_rows, 0, 4, c->stream));
-    HIPCHK(hipMemsetAsync(seen, 0, (size_t)n_rows * 4, c->stream));
-    HIPCHK(hipMemsetAsync(b_len, 0, (size_t)n_rows * 2, c->stream));
+    uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* mcell = am.take<uint32_t>((size_t)n_rows + 1);
+    uint32_t* row_id = am.take<uint32_t>(n_rows); uint32_t* seen = am.take<uint32_t>(n_rows);
+    if (!cell || !mcell || !row_id || !seen) { thj_set_error("thj_ingest: merge scratch too small"); return fail(THJ_ENOMEM); }
+#define ING_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { thj_set_error("%s: %s", #expr, hipGetErrorString(e__)); return fail(THJ_EHIP); } } while (0)
+    ING_HIP(hipMalloc(&b_off, ((size_t)n_rows * nseg + 1) * 4)); ob->ptrs[0] = b_off;
+    ING_HIP(hipMalloc(&b_planes, (size_t)n_rows * 3 * W * 8)); ob->ptrs[2] = b_planes;
+    ING_HIP(hipMalloc(&b_len, (size_t)n_rows * 2)); ob->ptrs[3] = b_len;
+    ING_HIP(hipMemsetAsync(cell + (size_t)n_rows * nseg, 0, 4, c->stream));
+    ING_HIP(hipMemsetAsync(mcell + n_rows, 0, 4, c->stream));
+    ING_HIP(hipMemsetAsync(seen, 0, (size_t)n_rows * 4, c->stream));
+    ING_HIP(hipMemsetAsync(b_len, 0, (size_t)n_rows * 2, c->stream));
     hipLaunchKernelGGL(thj_k_row_counts, dim3(grid_for(span)), dim3(256), 0, c->stream, m_vis, m_row, m_cnt, nseg, span, cell,
                        f_full >= 0 ? m_cnt + (size_t)nseg * span : (const uint32_t*)nullptr,
                        f_last >= 0 ? m_cnt + (size_t)(nseg + (f_full >= 0 ? 1 : 0)) * span : (const uint32_t*)nullptr, have_mate ? mcell : (uint32_t*)nullptr, row_id, id_lo);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, cell, b_off, (int)((size_t)n_rows * nseg + 1), c->stream));
-    if (scan_bytes > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, scan_bytes)); c->sort_tmp_bytes = scan_bytes; }
-    sb = c->sort_tmp_bytes;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, cell, b_off, (int)((size_t)n_rows * nseg + 1), c->stream));
+    if ((rc = exclusive_sum(c, cell, b_off, (int64_t)n_rows * nseg + 1))) return fail(rc);
     uint32_t n_hits = 0, n_mh = 0;
-    HIPCHK(hipMemcpyAsync(&n_hits, b_off + (size_t)n_rows * nseg, 4, hipMemcpyDeviceToHost, c->stream));
+    ING_HIP(hipMemcpyAsync(&n_hits, b_off + (size_t)n_rows * nseg, 4, hipMemcpyDeviceToHost, c->stream));
     if (have_mate) {
-        HIPCHK(hipMalloc(&b_moff, ((size_t)n_rows + 1) * 4));
-        ob->ptrs[4] = b_moff;
-        sb = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, mcell, b_moff, (int)(n_rows + 1), c->stream));
-        HIPCHK(hipMemcpyAsync(&n_mh, b_moff + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
+        ING_HIP(hipMalloc(&b_moff, ((size_t)n_rows + 1) * 4)); ob->ptrs[4] = b_moff;
+        if ((rc = exclusive_sum(c, mcell, b_moff, (int64_t)n_rows + 1))) return fail(rc);
+        ING_HIP(hipMemcpyAsync(&n_mh, b_moff + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMalloc(&b_hits, (size_t)(n_hits ? n_hits : 1) * 16));
-    ob->ptrs[1] = b_hits;
+    ING_HIP(hipStreamSynchronize(c->stream));
+    ING_HIP(hipMalloc(&b_hits, (size_t)(n_hits ? n_hits : 1) * 16)); ob->ptrs[1] = b_hits;
     for (int s = 0; s < nseg; ++s) {
         const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
-        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit16>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, q_h16, a, b, id_lo, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
+        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit16>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h16, a, b, id_lo, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
     }
     if (have_mate) {
-        HIPCHK(hipMalloc(&b_mh, (size_t)(n_mh ? n_mh : 1) * 16));
-        ob->ptrs[5] = b_mh;
+        ING_HIP(hipMalloc(&b_mh, (size_t)(n_mh ? n_mh : 1) * 16)); ob->ptrs[5] = b_mh;
         int m = nseg;
         const uint32_t* cf = f_full >= 0 ? m_cnt + (size_t)nseg * span : nullptr;
         if (f_full >= 0) {
             const uint32_t a = fb[(size_t)f_full], b = fb[(size_t)f_full + 1];
-            if (b > a) hipLaunchKernelGGL(thj_k_scatter_mates, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, q_h16, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)m * span, b_moff, cf, 0, b_mh);
+            if (b > a) hipLaunchKernelGGL(thj_k_scatter_mates, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h16, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)m * span, b_moff, cf, 0, b_mh);
             ++m;
         }
         if (f_last >= 0) {
             const uint32_t a = fb[(size_t)f_last], b = fb[(size_t)f_last + 1];
-            if (b > a) hipLaunchKernelGGL(thj_k_scatter_mates, dim3(grid_for(b - a)), dim3(256), 0, c->stream, q_id, q_h16, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)m * span, b_moff, cf, 1, b_mh);
+            if (b > a) hipLaunchKernelGGL(thj_k_scatter_mates, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h16, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)m * span, b_moff, cf, 1, b_mh);
         }
     }
     {
         const uint32_t a = fb[(size_t)f_reads], b = fb[(size_t)f_reads + 1];
-        if (b > a) hipLaunchKernelGGL(thj_k_read_planes, dim3(grid_for(b - a)), dim3(256), 0, c->stream, d_infl, q_id, q_loc, a, b, id_lo, span, m_vis, m_row, W, b_planes, b_len, seen, d_status);
-        hipLaunchKernelGGL(thj_k_check_seen, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, seen, n_rows, d_status);
+        if (b > a) hipLaunchKernelGGL(thj_k_read_planes, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.infl, P.id, P.loc, a, b, id_lo, span, m_vis, m_row, W, b_planes, b_len, seen, P.status);
+        hipLaunchKernelGGL(thj_k_check_seen, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, seen, n_rows, P.status);
     }
-    HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipGetLastError());
-    if (h_status[ST_MISSING_READ]) {
-        for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]);
-        delete ob;
-        thj_set_error("Error: could not get a read of the shard from the reads file");
-        return THJ_EINVAL;
-    }
+    unsigned int h_status[16];
+    ING_HIP(hipMemcpyAsync(h_status, P.status, 64, hipMemcpyDeviceToHost, c->stream));
+    ING_HIP(hipStreamSynchronize(c->stream));
+    ING_HIP(hipGetLastError());
+    if (h_status[ST_MISSING_READ]) { thj_set_error("Error: could not get a read of the shard from the reads file"); return fail(THJ_EINVAL); }
     ob->desc.n_reads = (int32_t)n_rows; ob->desc.nseg = nseg; ob->desc.words_per_plane = W;
     ob->desc.seg_off = b_off; ob->desc.hits = (const thj_hit*)b_hits; ob->desc.read_planes = (const uint64_t*)b_planes; ob->desc.read_len = b_len;
     ob->desc.mate_off = b_moff; ob->desc.mate_hits = (const thj_hit*)b_mh; ob->desc.ordinal_base = ordinal_base;
     *out = &ob->desc;
     if (n_reads_out) *n_reads_out = n_rows;
+    return THJ_OK;
+}
+
+// long_spanning_reads: the contig segment maps of one shard -> per (read, segment) CSR of thj_span_hit for the reads that have
+// a hit in the first segment map (the groups JoinSegmentsWorker iterates over, long_spanning_reads.cpp:2706-2765); hits of a
+// later segment whose read has none in the first are dropped, as look_right_for_hit_group never asks for them.  row_ids (host,
+// n_rows entries, caller frees with free()) = the reads' ids in row order: the caller fetches these reads (it needs their
+// names, bases and qualities for the BAM records anyway) and completes the batch with thj_span_batch_attach_reads.
+extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
+                                    thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out) {
+    using namespace ing;
+    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !out || !row_ids || !n_rows_out) { thj_set_error("thj_ingest_span_hits: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    *out = nullptr; *row_ids = nullptr; *n_rows_out = 0;
+    std::vector<const thj_bam_piece*> pieces;
+    std::vector<uint32_t> kinds;
+    for (int s = 0; s < nseg; ++s) { pieces.push_back(&segs[s]); kinds.push_back(KIND_HITS); }
+    Parsed P;
+    int rc = ingest_front(c, tp, pieces, kinds, begin_id, end_id, 1, 0, 0, P);
+    if (rc) return rc;
+    const std::vector<uint32_t>& fb = P.fb;
+    if (P.n == 0 || fb[1] == fb[0]) return THJ_OK;               // no first-segment hit in range
+    uint32_t ends[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(&ends[0], P.id + fb[0], 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&ends[1], P.id + fb[1] - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const uint32_t id_lo = ends[0], span = ends[1] - ends[0] + 1;
+    const size_t need2 = (size_t)span * 4 * (2 * (size_t)nseg + 2 + (size_t)nseg + 4) + (1 << 20);
+    void* d_merge = nullptr;
+    HIPCHK(hipMalloc(&d_merge, need2));
+    struct Guard { void* p; ~Guard() { hipFree(p); } } guard{d_merge};
+    Arena am{(char*)d_merge, need2, 0};
+    ING_TAKE(am, m_first, uint32_t, (size_t)nseg * span); ING_TAKE(am, m_cnt, uint32_t, (size_t)nseg * span);
+    ING_TAKE(am, m_vis, uint32_t, span + 1); ING_TAKE(am, m_row, uint32_t, span + 1);
+    HIPCHK(hipMemsetAsync(m_cnt, 0, (size_t)nseg * span * 4, c->stream));
+    HIPCHK(hipMemsetAsync(m_vis + span, 0, 4, c->stream));
+    for (int s = 0; s < nseg; ++s) {
+        const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
+        if (b > a) hipLaunchKernelGGL(thj_k_runs_clipped, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, a, b, id_lo, span, m_first + (size_t)s * span, m_cnt + (size_t)s * span);
+    }
+    // visited = has a hit in segment 0: thj_k_visited over that one map
+    hipLaunchKernelGGL(thj_k_visited, dim3(grid_for(span)), dim3(256), 0, c->stream, m_cnt, 1, span, 1, m_vis);
+    if ((rc = exclusive_sum(c, m_vis, m_row, span + 1))) return rc;
+    uint32_t n_rows = 0;
+    HIPCHK(hipMemcpyAsync(&n_rows, m_row + span, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_rows == 0) return THJ_OK;
+    IngestOwnedSpan* ob = new IngestOwnedSpan();
+    memset(ob, 0, sizeof *ob);
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]); delete ob; return code; };
+    uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* row_id = am.take<uint32_t>(n_rows);
+    if (!cell || !row_id) { thj_set_error("thj_ingest: merge scratch too small"); return fail(THJ_ENOMEM); }
+    uint32_t* b_off = nullptr; Hit32* b_hits = nullptr;
+    ING_HIP(hipMalloc(&b_off, ((size_t)n_rows * nseg + 1) * 4)); ob->ptrs[0] = b_off;
+    ING_HIP(hipMemsetAsync(cell + (size_t)n_rows * nseg, 0, 4, c->stream));
+    hipLaunchKernelGGL(thj_k_row_counts, dim3(grid_for(span)), dim3(256), 0, c->stream, m_vis, m_row, m_cnt, nseg, span, cell, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
+                       (uint32_t*)nullptr, row_id, id_lo);
+    if ((rc = exclusive_sum(c, cell, b_off, (int64_t)n_rows * nseg + 1))) return fail(rc);
+    uint32_t n_hits = 0;
+    ING_HIP(hipMemcpyAsync(&n_hits, b_off + (size_t)n_rows * nseg, 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t* h_ids = (uint32_t*)malloc((size_t)n_rows * 4);
+    if (!h_ids) return fail(THJ_ENOMEM);
+    ING_HIP(hipMemcpyAsync(h_ids, row_id, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+    ING_HIP(hipStreamSynchronize(c->stream));
+    ING_HIP(hipMalloc(&b_hits, (size_t)(n_hits ? n_hits : 1) * 32)); ob->ptrs[1] = b_hits;
+    for (int s = 0; s < nseg; ++s) {
+        const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
+        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit32>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h32, a, b, id_lo, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
+    }
+    ING_HIP(hipStreamSynchronize(c->stream));
+    ING_HIP(hipGetLastError());
+    ob->desc.n_reads = (int32_t)n_rows; ob->desc.nseg = nseg;
+    ob->desc.seg_off = b_off; ob->desc.hits = (const thj_span_hit*)b_hits;
+    *out = &ob->desc; *row_ids = h_ids; *n_rows_out = n_rows;
+    return THJ_OK;
+}
+
+// the reads of a batch made by thj_ingest_span_hits, in row order (HOST arrays as thj_reads_pack / thj_span_batch describe them)
+extern "C" int thj_span_batch_attach_reads(thj_ctx* c, thj_span_batch* batch, int32_t words_per_plane, int32_t qual_stride, const uint64_t* planes,
+                                           const uint16_t* lens, const uint8_t* quals) {
+    if (!c || !batch || !planes || !lens || !quals || words_per_plane < 1 || words_per_plane > 4 || qual_stride < 0) { thj_set_error("thj_span_batch_attach_reads: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    IngestOwnedSpan* ob = (IngestOwnedSpan*)batch;
+    const size_t n = (size_t)batch->n_reads;
+    const size_t sizes[3] = {n * 3 * (size_t)words_per_plane * 8, n * 2, n * (size_t)qual_stride};
+    const void* src[3] = {planes, lens, quals};
+    for (int i = 0; i < 3; ++i) {
+        hipFree(ob->ptrs[2 + i]); ob->ptrs[2 + i] = nullptr;
+        HIPCHK(hipMalloc(&ob->ptrs[2 + i], sizes[i] ? sizes[i] : 16));
+        if (sizes[i]) HIPCHK(hipMemcpyAsync(ob->ptrs[2 + i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    batch->words_per_plane = words_per_plane; batch->qual_stride = qual_stride;
+    batch->read_planes = (const uint64_t*)ob->ptrs[2]; batch->read_len = (const uint16_t*)ob->ptrs[3]; batch->quals = (const uint8_t*)ob->ptrs[4];
     return THJ_OK;
 }

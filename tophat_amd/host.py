@@ -550,7 +550,7 @@ def _span_methods():
 
 _span_methods()
 
-ABI_SYMBOLS += ["thj_bgzf_inflate", "thj_ingest_seg_batch"]
+ABI_SYMBOLS += ["thj_bgzf_inflate", "thj_ingest_seg_batch", "thj_ingest_span_hits", "thj_span_batch_attach_reads"]
 ABI_SYMBOLS += ["thj_juncbed_configure", "thj_juncbed_reset_async", "thj_juncbed_add_span_async", "thj_juncbed_add_records",
                 "thj_juncbed_finish", "thj_juncbed_download"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
