@@ -66,7 +66,12 @@ static std::vector<Shard> plan(const std::string& reads, const std::vector<std::
         }
         sh.end_id = i + 1 < want ? ids[(size_t)i] : ~0ull;
     }
-    for (int i = 0; i < want; ++i) out[(size_t)i].seg_end = i + 1 < want ? out[(size_t)i + 1].seg_off : std::vector<int64_t>(segs.size(), -1);
+    for (int i = 0; i < want; ++i) {
+        Shard& sh = out[(size_t)i];
+        sh.seg_end.assign(segs.size(), -1);
+        // lists = {reads, spliced maps last..first, contig maps last..first}
+        if (i + 1 < want) for (size_t s = 0; s < segs.size(); ++s) sh.seg_end[s] = shard_end_offset(lists[1 + spliced.size() + (segs.size() - 1 - s)], sh.end_id);
+    }
     return out;
 }
 

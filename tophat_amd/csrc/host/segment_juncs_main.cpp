@@ -84,16 +84,18 @@ static std::vector<Shard> plan_side(const SideInput& in, const SideInput* mate, 
         }
         sh.end_id = i + 1 < want ? ids[(size_t)i] : ~0ull;
     }
+    // ends of the shards' shares of every file (whole pieces go to the device-side ingest)
+    IndexList l_full, l_last;
+    if (mate && !mate->map.empty()) load_index(mate->map, want * 4, l_full);
+    if (mate && !mate->segs.empty()) load_index(mate->segs.back(), want * 4, l_last);
     for (int i = 0; i < want; ++i) {
         Shard& sh = out[(size_t)i];
         sh.seg_end.assign(in.segs.size(), -1);
-        if (i + 1 < want) {
-            const Shard& nx = out[(size_t)i + 1];
-            sh.read_end = nx.read_off; sh.seg_end = nx.seg_off;
-            // mate maps are only looked up by id: an empty offset list means "from the start" for every shard, i.e. no usable end either
-            sh.partner_end = po.empty() ? -1 : nx.partner_off;
-            sh.seg_partner_end = spo.empty() ? -1 : nx.seg_partner_off;
-        }
+        if (i + 1 == want) continue;
+        sh.read_end = shard_end_offset(lists[0], sh.end_id);
+        for (size_t s = 0; s < in.segs.size(); ++s) sh.seg_end[s] = shard_end_offset(lists[1 + s], sh.end_id);
+        sh.partner_end = shard_end_offset(l_full, sh.end_id);
+        sh.seg_partner_end = shard_end_offset(l_last, sh.end_id);
     }
     return out;
 }

@@ -1201,6 +1201,14 @@ inline void calculate_offsets_from_ids(const IndexList& l, const std::vector<uin
     if (ids.size() != offsets.size()) offsets.clear();
 }
 
+// Where a shard's share of a file ends, for readers that take a whole piece of the file at once (the device-side ingest): the
+// offset of the first index entry whose read id is >= end_id -- every record of a smaller id lies before it.  -1: up to the end.
+inline int64_t shard_end_offset(const IndexList& l, uint64_t end_id) {
+    size_t lo = 0, hi = l.size();
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (l[mid].first < end_id) lo = mid + 1; else hi = mid; }
+    return lo < l.size() ? l[lo].second : -1;
+}
+
 // every contig an input's header names enters the reference table before it is frozen (and before any record is parsed)
 inline void register_targets(const std::string& fn, RefTable& rt) {
     if (fn.empty()) return;

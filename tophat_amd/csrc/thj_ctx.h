@@ -71,6 +71,10 @@ struct thj_ctx {
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
     std::vector<thj_fusion> h_fusions;
+    // batch arrays come and go once per shard / batch: hipMalloc and (synchronising) hipFree per array cost more than the
+    // kernels of a small shard, so released blocks are kept and handed out again (thj_dev_alloc / thj_dev_release)
+    struct DevBlock { void* p; size_t cap; bool used; };
+    std::vector<DevBlock> dev_cache; size_t dev_cache_bytes = 0;
     // device-side ingest scratch (thj_ingest.hip)
     void* d_ing0 = nullptr; size_t ing_cap0 = 0; void* d_ing1 = nullptr; size_t ing_cap1 = 0;
     // junction consensus (thj_juncbed_impl.h)
@@ -86,4 +90,7 @@ struct thj_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 hipEvent_t thj_get_event(struct thj_ctx* c);
+int thj_dev_alloc(struct thj_ctx* c, void** out, size_t bytes);     // like hipMalloc, from the context's block cache
+void thj_dev_release(struct thj_ctx* c, void* p);                  // like hipFree, but the block stays with the context
+void thj_dev_cache_free(struct thj_ctx* c);
 void thj_span_free(struct thj_ctx* c);

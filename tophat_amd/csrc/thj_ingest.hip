@@ -10,7 +10,7 @@
 // it fast enough is where its working set lives: Huffman tables (10-bit / 8-bit direct lookup + canonical fallback) and a
 // 32 KiB output window in LDS -- every table lookup and every LZ77 copy is an LDS access -- while the other 63 lanes do the
 // memory work: they stage the compressed bytes into an LDS ring ahead of the decoder and flush finished 16 KiB halves of
-// the window to HBM with coalesced 16-byte stores.  39 KB of LDS per workgroup = 4 blocks in flight per CU, 1024 per GPU.
+// the window to HBM with coalesced 16-byte stores.  38 KB of LDS per workgroup = 4 blocks in flight per CU, 1024 per GPU.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -23,7 +23,7 @@
 namespace ing {
 
 static constexpr int WIN = 32768, WIN_MASK = WIN - 1, HALF = 16384;
-static constexpr int INRING = 4096, IN_MASK = INRING - 1;
+static constexpr int INRING = 2048, IN_MASK = INRING - 1;
 static constexpr int LIT_BITS = 10, DIST_BITS = 8;
 
 struct Shared {
@@ -34,6 +34,8 @@ struct Shared {
     uint16_t lit_sym[288], dist_sym[32];
     uint16_t lit_cnt[16], dist_cnt[16];
     uint8_t lens[320];
+    uint16_t lbase[32], dbase[32];                    // length / distance bases and extra-bit counts (RFC 1951, 3.2.5): in LDS, the
+    uint8_t lext[32], dext[32];                       // decoder looks one up per match
     // decoder <-> helpers
     uint32_t in_staged;        // compressed bytes staged so far (absolute)
     uint32_t in_used;          // compressed bytes the decoder no longer needs (absolute, rounded down to 4)
@@ -82,8 +84,8 @@ struct Bits {
 
 // the ring is filled in whole 32-bit words (zero-padded past the end of the stream) and position 0 of the stream sits at ring
 // offset 0, so the bit buffer takes one aligned LDS word at a time
-__device__ __forceinline__ void refill(Bits& b, const Shared& s) {
-    if (b.cnt <= 32 && b.pos < s.in_staged) { b.buf |= (uint64_t)((const uint32_t*)s.in)[(b.pos & IN_MASK) >> 2] << b.cnt; b.cnt += 32; b.pos += 4; }
+__device__ __forceinline__ void refill(Bits& b, const Shared& s, uint32_t staged) {
+    if (b.cnt <= 32 && b.pos < staged) { b.buf |= (uint64_t)((const uint32_t*)s.in)[(b.pos & IN_MASK) >> 2] << b.cnt; b.cnt += 32; b.pos += 4; }
 }
 __device__ __forceinline__ uint32_t take(Bits& b, int n) { const uint32_t v = (uint32_t)(b.buf & ((1ull << n) - 1)); b.buf >>= n; b.cnt -= n; return v; }
 
@@ -112,6 +114,9 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
     using namespace ing;
     __shared__ Shared s;
     const int lane = threadIdx.x;
+    if (lane < 29) { s.lbase[lane] = LBASE[lane]; s.lext[lane] = LEXT[lane]; }
+    if (lane < 30) { s.dbase[lane] = DBASE[lane]; s.dext[lane] = DEXT[lane]; }
+    __syncthreads();
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint8_t* in = comp + blocks[blk].in_off;
         const uint32_t in_len = blocks[blk].in_len;
@@ -160,22 +165,24 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
             }
             // ---- decoder
             if (lane == 0) {
-                const bool all_in = s.in_staged >= in_len;
+                const uint32_t staged0 = s.in_staged;                            // fixed while the decoder runs
+                const bool all_in = staged0 >= in_len;
                 uint32_t outp = s.out_total;
                 const uint32_t out_limit = s.out_flushed + WIN - 300;           // never overwrite window bytes not yet in HBM
                 bool err = false, fin = false;
                 // work while enough input is staged for the largest thing the state needs
                 for (;;) {
-                    refill(b, s);
+                    refill(b, s, staged0);
                     if (b.cnt < 0) { err = true; break; }                        // ran past the end of a truncated stream
-                    const uint32_t avail = (uint32_t)((int)s.in_staged - (int)b.pos + (b.cnt >> 3) > 0 ? (int)s.in_staged - (int)b.pos + (b.cnt >> 3) : 0);
+                    const int avail_i = (int)staged0 - (int)b.pos + (b.cnt >> 3);
+                    const uint32_t avail = avail_i > 0 ? (uint32_t)avail_i : 0u;
                     if (state == ST_HEADER) {
                         if (!all_in && avail < 400) break;
                         last = (int)take(b, 1);
                         const int type = (int)take(b, 2);
                         if (type == 0) {
                             take(b, b.cnt & 7);                                  // to a byte boundary
-                            refill(b, s);
+                            refill(b, s, staged0);
                             const uint32_t len = take(b, 16), nlen = take(b, 16);
                             if ((len ^ 0xFFFFu) != nlen) { err = true; break; }
                             stored_left = len; state = ST_STORED;
@@ -193,12 +200,12 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                             if (hlit > 286 || hdist > 30) { err = true; break; }
                             uint8_t cl[19];
                             for (int i = 0; i < 19; ++i) cl[i] = 0;
-                            for (int i = 0; i < hclen; ++i) { refill(b, s); cl[CLORD[i]] = (uint8_t)take(b, 3); }
+                            for (int i = 0; i < hclen; ++i) { refill(b, s, staged0); cl[CLORD[i]] = (uint8_t)take(b, 3); }
                             // the code-length code uses the distance table's storage (7-bit direct lookup fits its 8 bits)
                             if (!build_table(cl, 19, s.dist_fast, 7, s.dist_sym, s.dist_cnt)) { err = true; break; }
                             int i = 0;
                             while (i < hlit + hdist) {
-                                refill(b, s);
+                                refill(b, s, staged0);
                                 const int sym = decode_sym(b, s.dist_fast, 7, s.dist_sym, s.dist_cnt);
                                 if (sym < 0) { err = true; break; }
                                 if (sym < 16) s.lens[i++] = (uint8_t)sym;
@@ -229,16 +236,27 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                         if ((!all_in && avail < 8) || outp >= out_limit) break;
                         int sym = decode_sym(b, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt);
                         if (sym < 0) { err = true; break; }
-                        if (sym < 256) { s.win[outp & WIN_MASK] = (uint8_t)sym; ++outp; }
+                        if (sym < 256) {
+                            s.win[outp & WIN_MASK] = (uint8_t)sym; ++outp;
+                            // runs of literals: stay in a loop of lookup + store (the direct table only; anything else goes round again)
+                            for (;;) {
+                                refill(b, s, staged0);
+                                if (b.cnt < 24 || outp >= out_limit) break;
+                                const uint16_t e = s.lit_fast[b.buf & ((1u << LIT_BITS) - 1)];
+                                if (!e || (e & 0xFFF) >= 256) break;
+                                const int l = e >> 12; b.buf >>= l; b.cnt -= l;
+                                s.win[outp & WIN_MASK] = (uint8_t)(e & 0xFF); ++outp;
+                            }
+                        }
                         else if (sym == 256) state = last ? ST_DONE : ST_HEADER;
                         else {
                             sym -= 257;
                             if (sym >= 29) { err = true; break; }
-                            const int len = LBASE[sym] + (int)take(b, LEXT[sym]);
-                            refill(b, s);
+                            const int len = s.lbase[sym] + (int)take(b, s.lext[sym]);
+                            refill(b, s, staged0);
                             const int ds = decode_sym(b, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt);
                             if (ds < 0 || ds >= 30) { err = true; break; }
-                            const uint32_t dist = DBASE[ds] + take(b, DEXT[ds]);
+                            const uint32_t dist = s.dbase[ds] + take(b, s.dext[ds]);
                             if (dist > outp || outp + (uint32_t)len > 65536u) { err = true; break; }
                             int k = 0;
                             if (dist >= 8)                                        // source and destination of a group of 8 cannot overlap: read the
@@ -260,7 +278,7 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                 if (fin) s.done = 1;
                 if (err) s.error = 1;
                 // no progress possible and not finished: input exhausted in mid-stream
-                if (!fin && !err && all_in && (int)s.in_staged - (int)b.pos + (b.cnt >> 3) <= 0 && state != ST_DONE) s.error = 1;
+                if (!fin && !err && all_in && (int)staged0 - (int)b.pos + (b.cnt >> 3) <= 0 && state != ST_DONE) s.error = 1;
                 if (state == ST_DONE) s.done = 1;
             }
             __syncthreads();
@@ -531,12 +549,12 @@ __global__ __launch_bounds__(256) void thj_k_row_counts(const uint32_t* __restri
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void thj_k_scatter_hits(const uint32_t* __restrict__ id, const T* __restrict__ src, uint32_t a, uint32_t b, uint32_t id0, const uint32_t* __restrict__ vis,
-                                                          const uint32_t* __restrict__ row, const uint32_t* __restrict__ first, const uint32_t* __restrict__ off, int nseg, int s,
-                                                          T* __restrict__ dst) {
+__global__ __launch_bounds__(256) void thj_k_scatter_hits(const uint32_t* __restrict__ id, const T* __restrict__ src, uint32_t a, uint32_t b, uint32_t id0, uint32_t span,
+                                                          const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, const uint32_t* __restrict__ first,
+                                                          const uint32_t* __restrict__ off, int nseg, int s, T* __restrict__ dst) {
     for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
         const uint32_t idl = id[i] - id0;
-        if (!vis[idl]) continue;
+        if (idl >= span || !vis[idl]) continue;                  // (long_spanning_reads: the id range is the first segment map's)
         dst[off[(size_t)row[idl] * nseg + s] + (i - first[idl])] = src[i];
     }
 }
@@ -797,8 +815,8 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
     const int nmaps = nseg + (f_full >= 0 ? 1 : 0) + (f_last >= 0 ? 1 : 0);
     const size_t need2 = (size_t)span * 4 * (2 * (size_t)nmaps + 2 + (size_t)nseg + 4) + (1 << 20);
     void* d_merge = nullptr;
-    HIPCHK(hipMalloc(&d_merge, need2));
-    struct Guard { void* p; ~Guard() { hipFree(p); } } guard{d_merge};
+    { int rc_ = thj_dev_alloc(c, &d_merge, need2); if (rc_) return rc_; }
+    struct Guard { thj_ctx* c; void* p; ~Guard() { hipStreamSynchronize(c->stream); thj_dev_release(c, p); } } guard{c, d_merge};
     Arena am{(char*)d_merge, need2, 0};
     ING_TAKE(am, m_first, uint32_t, (size_t)nmaps * span); ING_TAKE(am, m_cnt, uint32_t, (size_t)nmaps * span);
     ING_TAKE(am, m_vis, uint32_t, span + 1); ING_TAKE(am, m_row, uint32_t, span + 1);
@@ -819,15 +837,15 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
     const bool have_mate = f_full >= 0 || f_last >= 0;
     IngestOwned* ob = new IngestOwned();
     memset(ob, 0, sizeof *ob);
-    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]); delete ob; return code; };
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
     uint32_t* b_off = nullptr; Hit16* b_hits = nullptr; u64* b_planes = nullptr; uint16_t* b_len = nullptr; uint32_t* b_moff = nullptr; Hit16* b_mh = nullptr;
     uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* mcell = am.take<uint32_t>((size_t)n_rows + 1);
     uint32_t* row_id = am.take<uint32_t>(n_rows); uint32_t* seen = am.take<uint32_t>(n_rows);
     if (!cell || !mcell || !row_id || !seen) { thj_set_error("thj_ingest: merge scratch too small"); return fail(THJ_ENOMEM); }
 #define ING_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { thj_set_error("%s: %s", #expr, hipGetErrorString(e__)); return fail(THJ_EHIP); } } while (0)
-    ING_HIP(hipMalloc(&b_off, ((size_t)n_rows * nseg + 1) * 4)); ob->ptrs[0] = b_off;
-    ING_HIP(hipMalloc(&b_planes, (size_t)n_rows * 3 * W * 8)); ob->ptrs[2] = b_planes;
-    ING_HIP(hipMalloc(&b_len, (size_t)n_rows * 2)); ob->ptrs[3] = b_len;
+    { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, ((size_t)n_rows * nseg + 1) * 4)) return fail(THJ_EHIP); b_off = (decltype(b_off))v_; ob->ptrs[0] = b_off; }
+    { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, (size_t)n_rows * 3 * W * 8)) return fail(THJ_EHIP); b_planes = (decltype(b_planes))v_; ob->ptrs[2] = b_planes; }
+    { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, (size_t)n_rows * 2)) return fail(THJ_EHIP); b_len = (decltype(b_len))v_; ob->ptrs[3] = b_len; }
     ING_HIP(hipMemsetAsync(cell + (size_t)n_rows * nseg, 0, 4, c->stream));
     ING_HIP(hipMemsetAsync(mcell + n_rows, 0, 4, c->stream));
     ING_HIP(hipMemsetAsync(seen, 0, (size_t)n_rows * 4, c->stream));
@@ -839,18 +857,18 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
     uint32_t n_hits = 0, n_mh = 0;
     ING_HIP(hipMemcpyAsync(&n_hits, b_off + (size_t)n_rows * nseg, 4, hipMemcpyDeviceToHost, c->stream));
     if (have_mate) {
-        ING_HIP(hipMalloc(&b_moff, ((size_t)n_rows + 1) * 4)); ob->ptrs[4] = b_moff;
+        { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, ((size_t)n_rows + 1) * 4)) return fail(THJ_EHIP); b_moff = (decltype(b_moff))v_; ob->ptrs[4] = b_moff; }
         if ((rc = exclusive_sum(c, mcell, b_moff, (int64_t)n_rows + 1))) return fail(rc);
         ING_HIP(hipMemcpyAsync(&n_mh, b_moff + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
     }
     ING_HIP(hipStreamSynchronize(c->stream));
-    ING_HIP(hipMalloc(&b_hits, (size_t)(n_hits ? n_hits : 1) * 16)); ob->ptrs[1] = b_hits;
+    { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, (size_t)(n_hits ? n_hits : 1) * 16)) return fail(THJ_EHIP); b_hits = (decltype(b_hits))v_; ob->ptrs[1] = b_hits; }
     for (int s = 0; s < nseg; ++s) {
         const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
-        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit16>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h16, a, b, id_lo, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
+        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit16>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h16, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
     }
     if (have_mate) {
-        ING_HIP(hipMalloc(&b_mh, (size_t)(n_mh ? n_mh : 1) * 16)); ob->ptrs[5] = b_mh;
+        { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, (size_t)(n_mh ? n_mh : 1) * 16)) return fail(THJ_EHIP); b_mh = (decltype(b_mh))v_; ob->ptrs[5] = b_mh; }
         int m = nseg;
         const uint32_t* cf = f_full >= 0 ? m_cnt + (size_t)nseg * span : nullptr;
         if (f_full >= 0) {
@@ -907,8 +925,8 @@ extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t ns
     const uint32_t id_lo = ends[0], span = ends[1] - ends[0] + 1;
     const size_t need2 = (size_t)span * 4 * (2 * (size_t)nseg + 2 + (size_t)nseg + 4) + (1 << 20);
     void* d_merge = nullptr;
-    HIPCHK(hipMalloc(&d_merge, need2));
-    struct Guard { void* p; ~Guard() { hipFree(p); } } guard{d_merge};
+    { int rc_ = thj_dev_alloc(c, &d_merge, need2); if (rc_) return rc_; }
+    struct Guard { thj_ctx* c; void* p; ~Guard() { hipStreamSynchronize(c->stream); thj_dev_release(c, p); } } guard{c, d_merge};
     Arena am{(char*)d_merge, need2, 0};
     ING_TAKE(am, m_first, uint32_t, (size_t)nseg * span); ING_TAKE(am, m_cnt, uint32_t, (size_t)nseg * span);
     ING_TAKE(am, m_vis, uint32_t, span + 1); ING_TAKE(am, m_row, uint32_t, span + 1);
@@ -927,11 +945,11 @@ extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t ns
     if (n_rows == 0) return THJ_OK;
     IngestOwnedSpan* ob = new IngestOwnedSpan();
     memset(ob, 0, sizeof *ob);
-    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]); delete ob; return code; };
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
     uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* row_id = am.take<uint32_t>(n_rows);
     if (!cell || !row_id) { thj_set_error("thj_ingest: merge scratch too small"); return fail(THJ_ENOMEM); }
     uint32_t* b_off = nullptr; Hit32* b_hits = nullptr;
-    ING_HIP(hipMalloc(&b_off, ((size_t)n_rows * nseg + 1) * 4)); ob->ptrs[0] = b_off;
+    { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, ((size_t)n_rows * nseg + 1) * 4)) return fail(THJ_EHIP); b_off = (decltype(b_off))v_; ob->ptrs[0] = b_off; }
     ING_HIP(hipMemsetAsync(cell + (size_t)n_rows * nseg, 0, 4, c->stream));
     hipLaunchKernelGGL(thj_k_row_counts, dim3(grid_for(span)), dim3(256), 0, c->stream, m_vis, m_row, m_cnt, nseg, span, cell, (const uint32_t*)nullptr, (const uint32_t*)nullptr,
                        (uint32_t*)nullptr, row_id, id_lo);
@@ -942,10 +960,10 @@ extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t ns
     if (!h_ids) return fail(THJ_ENOMEM);
     ING_HIP(hipMemcpyAsync(h_ids, row_id, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
     ING_HIP(hipStreamSynchronize(c->stream));
-    ING_HIP(hipMalloc(&b_hits, (size_t)(n_hits ? n_hits : 1) * 32)); ob->ptrs[1] = b_hits;
+    { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, (size_t)(n_hits ? n_hits : 1) * 32)) return fail(THJ_EHIP); b_hits = (decltype(b_hits))v_; ob->ptrs[1] = b_hits; }
     for (int s = 0; s < nseg; ++s) {
         const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
-        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit32>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h32, a, b, id_lo, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
+        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit32>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h32, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
     }
     ING_HIP(hipStreamSynchronize(c->stream));
     ING_HIP(hipGetLastError());
@@ -965,8 +983,8 @@ extern "C" int thj_span_batch_attach_reads(thj_ctx* c, thj_span_batch* batch, in
     const size_t sizes[3] = {n * 3 * (size_t)words_per_plane * 8, n * 2, n * (size_t)qual_stride};
     const void* src[3] = {planes, lens, quals};
     for (int i = 0; i < 3; ++i) {
-        hipFree(ob->ptrs[2 + i]); ob->ptrs[2 + i] = nullptr;
-        HIPCHK(hipMalloc(&ob->ptrs[2 + i], sizes[i] ? sizes[i] : 16));
+        thj_dev_release(c, ob->ptrs[2 + i]); ob->ptrs[2 + i] = nullptr;
+        { int rc_ = thj_dev_alloc(c, &ob->ptrs[2 + i], sizes[i] ? sizes[i] : 16); if (rc_) return rc_; }
         if (sizes[i]) HIPCHK(hipMemcpyAsync(ob->ptrs[2 + i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -601,7 +601,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipHostFree(c->h_pinned);
     thj_span_free(c);
     cov_free(c);
-    hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1);
+    hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); thj_dev_cache_free(c);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
@@ -677,7 +677,7 @@ extern "C" int thj_batch_upload(thj_ctx* c, const thj_seg_batch* h, int64_t n_hi
     const void* src[6] = {h->seg_off, h->hits, h->read_planes, h->read_len, h->mate_off, h->mate_hits};
     for (int i = 0; i < 6; ++i) {
         if (i >= 4 && !h->mate_off) { ob->ptrs[i] = nullptr; continue; }
-        HIPCHK(hipMalloc(&ob->ptrs[i], sizes[i] ? sizes[i] : 16));
+        { int rc_ = thj_dev_alloc(c, &ob->ptrs[i], sizes[i] ? sizes[i] : 16); if (rc_) return rc_; }
         if (sizes[i]) HIPCHK(hipMemcpyAsync(ob->ptrs[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
     }
     ob->desc.seg_off = (const uint32_t*)ob->ptrs[0];
@@ -696,7 +696,7 @@ extern "C" int thj_batch_free(thj_ctx* c, thj_seg_batch* dev) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     OwnedBatch* ob = (OwnedBatch*)dev;
-    for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]);
+    for (int i = 0; i < 6; ++i) thj_dev_release(c, ob->ptrs[i]);
     delete ob;
     return THJ_OK;
 }
@@ -768,6 +768,39 @@ static int check_params(const thj_params* p, const thj_seg_batch* b) {
     if (b->words_per_plane < 1 || b->words_per_plane > 4) { thj_set_error("words_per_plane %d unsupported (1..4)", b->words_per_plane); return THJ_EINVAL; }
     if (b->n_reads < 0 || (int64_t)b->n_reads + b->ordinal_base >= (1ll << 29)) { thj_set_error("batch too large: read ordinals must stay below 2^29"); return THJ_EINVAL; }
     return THJ_OK;
+}
+
+int thj_dev_alloc(thj_ctx* c, void** out, size_t bytes) {
+    if (bytes < 256) bytes = 256;
+    int best = -1;
+    for (size_t i = 0; i < c->dev_cache.size(); ++i) {
+        const thj_ctx::DevBlock& b = c->dev_cache[i];
+        if (!b.used && b.cap >= bytes && b.cap <= 2 * bytes + 65536 && (best < 0 || b.cap < c->dev_cache[(size_t)best].cap)) best = (int)i;
+    }
+    if (best >= 0) { c->dev_cache[(size_t)best].used = true; *out = c->dev_cache[(size_t)best].p; return THJ_OK; }
+    // keep the cache bounded: drop idle blocks once it holds more than 16 GiB
+    if (c->dev_cache_bytes > ((size_t)16 << 30)) {
+        for (size_t i = 0; i < c->dev_cache.size();) {
+            if (!c->dev_cache[i].used) { hipFree(c->dev_cache[i].p); c->dev_cache_bytes -= c->dev_cache[i].cap; c->dev_cache.erase(c->dev_cache.begin() + (ptrdiff_t)i); }
+            else ++i;
+        }
+    }
+    const size_t cap = bytes + bytes / 8;
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, cap));
+    c->dev_cache.push_back({p, cap, true});
+    c->dev_cache_bytes += cap;
+    *out = p;
+    return THJ_OK;
+}
+void thj_dev_release(thj_ctx* c, void* p) {
+    if (!p) return;
+    for (auto& b : c->dev_cache) if (b.p == p) { b.used = false; return; }
+    hipFree(p);                                 // not one of ours
+}
+void thj_dev_cache_free(thj_ctx* c) {
+    for (auto& b : c->dev_cache) hipFree(b.p);
+    c->dev_cache.clear(); c->dev_cache_bytes = 0;
 }
 
 hipEvent_t thj_get_event(thj_ctx* c) {

@@ -434,7 +434,7 @@ extern "C" int thj_span_batch_upload(thj_ctx* c, const thj_span_batch* h, int64_
                              (size_t)n * 2, (size_t)n * h->qual_stride};
     const void* src[5] = {h->seg_off, h->hits, h->read_planes, h->read_len, h->quals};
     for (int i = 0; i < 5; ++i) {
-        HIPCHK(hipMalloc(&ob->ptrs[i], sizes[i] ? sizes[i] : 16));
+        { int rc_ = thj_dev_alloc(c, &ob->ptrs[i], sizes[i] ? sizes[i] : 16); if (rc_) return rc_; }
         if (sizes[i]) HIPCHK(hipMemcpyAsync(ob->ptrs[i], src[i], sizes[i], hipMemcpyHostToDevice, c->stream));
     }
     ob->desc.seg_off = (const uint32_t*)ob->ptrs[0];
@@ -455,7 +455,7 @@ extern "C" int thj_span_batch_free(thj_ctx* c, thj_span_batch* dev) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     OwnedSpanBatch* ob = (OwnedSpanBatch*)dev;
-    for (int i = 0; i < 6; ++i) hipFree(ob->ptrs[i]);
+    for (int i = 0; i < 6; ++i) thj_dev_release(c, ob->ptrs[i]);
     delete ob;
     return THJ_OK;
 }
