@@ -9,13 +9,13 @@ export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
-python bench.py > $out/${tag}_bench10M.json 2> $out/${tag}_bench10M.err
+timeout 900 python bench.py > $out/${tag}_bench10M.json 2> $out/${tag}_bench10M.err
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
-(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o res -- python $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /tmp/prof_ks.log 2>&1)
-{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline   (MI355X, $tag)";
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o res -- python $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 > /tmp/prof_ks.log 2>&1)
+{ echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0   (MI355X, $tag)";
   echo "# durations in microseconds"; python tools/rocpd_summary.py $(find /tmp/prof_ks -name '*.db' | head -1); } > $out/${tag}_kernel_stats_bench10M.txt
-(cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o res -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /tmp/prof_f.log 2>&1)
-(cd /tmp && rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o res -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /tmp/prof_w.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o res -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 > /tmp/prof_f.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o res -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 > /tmp/prof_w.log 2>&1)
 { echo "# rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline  (separate pass; KB per dispatch)";
   python tools/rocpd_summary.py $(find /tmp/prof_f -name '*.db' | head -1) thj_k;
   echo; echo "# rocprofv3 --pmc WRITE_SIZE --kernel-trace -- (same command, separate pass)";
