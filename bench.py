@@ -220,9 +220,10 @@ def parse_args():
     ap.add_argument("--multihit-frac", type=float, default=0.0,
                     help="fraction of reads whose segment hits are all reported at two loci (the genome's second half becomes a copy "
                          "of the first): exercises the multihit tier; 0 = BASELINE configs[1] as specified")
-    ap.add_argument("--hit-heads", action="store_true",
-                    help="hand stage 2 the optional dense hit-head array too (built before the timed region: the layout of a "
-                         "producer that writes heads as it goes; NOT the default measurement, see DESIGN.md)")
+    ap.add_argument("--no-hit-heads", action="store_true",
+                    help="hand stage 2 the 32-byte hit records only, without the dense 16-byte head array every batch of the library carries "
+                         "(thj_span_batch.hit_heads: derived once when a batch is made -- thj_span_batch_upload, the device-side ingest -- so "
+                         "part of the resident layout, not of a step)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-pairs", type=int, default=8_000_000,
@@ -438,7 +439,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     cb_left = cbatch_from_tensors(w["left"], rank * args.pairs)
     cb_right = cbatch_from_tensors(w["right"], world * args.pairs + rank * args.pairs)
     ctx.configure(1 << 22, 1 << 20)
-    use_heads = args.hit_heads
+    use_heads = not args.no_hit_heads
     sp_left = span_cbatch_from_tensors(w["left"], ctx if use_heads else None)
     sp_right = span_cbatch_from_tensors(w["right"], ctx if use_heads else None)
 
@@ -588,7 +589,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r02_pmc_traffic.json"))))
-        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not args.hit_heads and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}:
+        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and use_heads and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}:
             for k in kernels:
                 c = pm["kernels"].get(k["kernel"])
                 if c:
@@ -608,8 +609,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
                      % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not n_ium else "shape of another config", args.pairs,
                         args.read_len, genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
                         ", one RCCL all-gather of the event sets inside the C ABI" if use_comm else ""))
-    if args.hit_heads:
-        workload_text += "; stage 2 batches also carry the optional dense hit-head array (built outside the timed region)"
+    if not use_heads:
+        workload_text += "; stage 2 batches WITHOUT the dense hit-head array (32-byte records only)"
     if n_ium:
         workload_text += "; with the coverage search (first %d reads of each side as --ium-reads, %d coverage junctions)" % (n_ium, cov_found[0])
     result = None

@@ -280,10 +280,11 @@ typedef struct {
     const uint64_t*     read_planes; /* [n_reads*3*W] (thj_reads_pack) */
     const uint16_t*     read_len;
     const uint8_t*      quals;       /* phred+33, qual_stride bytes per read */
-    const void*         hit_heads;   /* optional (NULL: not present): the first 16 bytes of every hit record, densely -- all
-                                      * tier 0 reads of a hit.  For producers that can write it as they go; deriving it from
-                                      * `hits` (thj_span_hit_heads_async) costs more than it saves, so thj_span_batch_upload
-                                      * does not make one */
+    const void*         hit_heads;   /* the first 16 bytes of every hit record, densely (contig, position, flags, first cigar op: all
+                                      * the first stitch tier reads of a hit, so it streams 16 B per hit).  Every batch this library
+                                      * makes has one -- thj_span_batch_upload derives it once at upload, the device-side ingest
+                                      * writes it beside the records; NULL is accepted from other producers (the tier then reads
+                                      * the 32-byte records) */
 } thj_span_batch;
 
 /* One output record: the fields print_bamhit + bowtie_sam_extra write

@@ -559,6 +559,20 @@ __global__ __launch_bounds__(256) void thj_k_scatter_hits(const uint32_t* __rest
     }
 }
 
+// long_spanning_reads' records and, beside them, the dense array of their first 16 bytes (thj_span_batch.hit_heads)
+__global__ __launch_bounds__(256) void thj_k_scatter_span(const uint32_t* __restrict__ id, const Hit32* __restrict__ src, uint32_t a, uint32_t b, uint32_t id0, uint32_t span,
+                                                          const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, const uint32_t* __restrict__ first,
+                                                          const uint32_t* __restrict__ off, int nseg, int s, Hit32* __restrict__ dst, uint4* __restrict__ heads) {
+    for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
+        const uint32_t idl = id[i] - id0;
+        if (idl >= span || !vis[idl]) continue;
+        const uint32_t at = off[(size_t)row[idl] * nseg + s] + (i - first[idl]);
+        const Hit32 h = src[i];
+        dst[at] = h;
+        heads[at] = make_uint4(h.ref_id, (uint32_t)h.left, h.meta, h.cigar[0]);
+    }
+}
+
 // mate hits: the mate's whole-read map when it has the id, else the mate's last segment map (find_gaps :3321-3348)
 __global__ __launch_bounds__(256) void thj_k_scatter_mates(const uint32_t* __restrict__ id, const Hit16* __restrict__ src, uint32_t a, uint32_t b, uint32_t id0, uint32_t span,
                                                            const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, const uint32_t* __restrict__ first,
@@ -961,14 +975,16 @@ extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t ns
     ING_HIP(hipMemcpyAsync(h_ids, row_id, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
     ING_HIP(hipStreamSynchronize(c->stream));
     { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, (size_t)(n_hits ? n_hits : 1) * 32)) return fail(THJ_EHIP); b_hits = (decltype(b_hits))v_; ob->ptrs[1] = b_hits; }
+    uint4* b_heads = nullptr;
+    { void* v_ = nullptr; if (thj_dev_alloc(c, &v_, (size_t)(n_hits ? n_hits : 1) * 16)) return fail(THJ_EHIP); b_heads = (uint4*)v_; ob->ptrs[5] = b_heads; }
     for (int s = 0; s < nseg; ++s) {
         const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
-        if (b > a) hipLaunchKernelGGL(thj_k_scatter_hits<Hit32>, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h32, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits);
+        if (b > a) hipLaunchKernelGGL(thj_k_scatter_span, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h32, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits, b_heads);
     }
     ING_HIP(hipStreamSynchronize(c->stream));
     ING_HIP(hipGetLastError());
     ob->desc.n_reads = (int32_t)n_rows; ob->desc.nseg = nseg;
-    ob->desc.seg_off = b_off; ob->desc.hits = (const thj_span_hit*)b_hits;
+    ob->desc.seg_off = b_off; ob->desc.hits = (const thj_span_hit*)b_hits; ob->desc.hit_heads = b_heads;
     *out = &ob->desc; *row_ids = h_ids; *n_rows_out = n_rows;
     return THJ_OK;
 }

@@ -442,9 +442,15 @@ extern "C" int thj_span_batch_upload(thj_ctx* c, const thj_span_batch* h, int64_
     ob->desc.read_planes = (const uint64_t*)ob->ptrs[2];
     ob->desc.read_len = (const uint16_t*)ob->ptrs[3];
     ob->desc.quals = (const uint8_t*)ob->ptrs[4];
-    // no dense head array for uploaded batches: building one costs more (0.39 ms per 20 M hits) than tier 0 gains from it
-    // (0.12 ms); it pays only for a producer that writes heads as it goes (thj_span_batch.hit_heads)
-    ob->desc.hit_heads = nullptr;
+    // Every batch carries the dense head array (the first 16 bytes of each record: contig, position, flags, first cigar op --
+    // all tier 0 reads of a hit), so tier 0 streams 16 B per hit.  For an uploaded batch it is derived here, once, when the
+    // batch is made; the device-side ingest writes it while it scatters the records.
+    { int rc_ = thj_dev_alloc(c, &ob->ptrs[5], (size_t)(n_hits ? n_hits : 1) * 16); if (rc_) return rc_; }
+    if (n_hits > 0) {
+        int64_t blocks = (n_hits + 255) / 256; if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(thj_k_hit_heads, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const Q16*)ob->ptrs[1], n_hits, (Q16*)ob->ptrs[5]);
+    }
+    ob->desc.hit_heads = ob->ptrs[5];
     HIPCHK(hipStreamSynchronize(c->stream));
     *out = &ob->desc;
     return THJ_OK;
