@@ -31,6 +31,7 @@ extern "C" {
 #define THJ_EHIP         -3   /* a HIP runtime call failed */
 #define THJ_EOVERFLOW    -4   /* an event table filled up; re-configure larger and re-run */
 #define THJ_ESTATE       -5   /* call sequence violated (e.g. run before genome upload) */
+#define THJ_ERETRY       -7   /* a device pool was too small for this pass and has been enlarged: make the same calls again */
 #define THJ_EFALLBACK    -6   /* the device-side ingest cannot take this input (records straddle BGZF members, reads > 256 bases ...):
                                  nothing was done, use the host readers */
 
@@ -301,8 +302,14 @@ typedef struct {
     uint8_t  XM, XO, XG, md_len;
     uint16_t order;        /* rank among the read's records (BowtieHit::operator<, bwt_map.h:180-207) */
     uint32_t cigar[16];
-    char     md[40];       /* MD:Z value, md_len characters */
+    char     md[40];       /* MD:Z value, md_len characters; md_len == THJ_MD_ON_HOST: longer than the record holds -- thj_md_string */
 } thj_aln;
+#define THJ_MD_ON_HOST 255
+/* MD:Z of one alignment as bowtie_sam_extra writes it (bwt_map.cpp:2467-2648), on the host: ref = the contig's bases (any
+ * case, non-ACGT = N), seq = the read bases in the orientation of the alignment, cigar = op << 28 | length.  Writes a
+ * NUL-terminated string, returns its length (< 0: error).  For the records the device flags with THJ_MD_ON_HOST. */
+int thj_md_string(const char* ref, int64_t ref_len, const char* seq, int32_t seq_len, int32_t left, const uint32_t* cigar, int32_t n_cigar,
+                  char* out, int32_t out_cap);
 
 /* The junction (+deletion) and insertion sets long_spanning_reads loads from its list
  * files (long_spanning_reads.cpp:2897-2980).  juncs: sorted unique in Junction::operator<

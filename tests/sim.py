@@ -91,7 +91,7 @@ def spanning(p: Params, seqs, b, juncs, insertions, mode: int = 0):
     assert rc == 0, rc
     a = np.frombuffer((C.c_char * (max(1, n_out.value) * 128)).from_address(out.value), dtype=host.ALN_DTYPE)[:n_out.value].copy()
     l.hostsim_free(out)
-    return host.alns_from_array(a), list(st)
+    return host.alns_from_array(a, host.span_md_resolver(list(seqs), [b])), list(st)
 
 
 def fusions(p: Params, seqs, b: SegBatch, ignore_ref_ids=()):

@@ -192,7 +192,7 @@ def test_fuzz_long_spanning_reads(seed):
         got, status = sim.spanning(p, seqs, sb, ja, il, mode)
         assert status[1] == 0
         got.sort(key=lambda a: a.read_idx)
-        # MD strings over 40 characters are a documented device limit (THJ_EOVERFLOW at finish): the record is not produced
-        exp = [a for a in want if len(a.MD) <= 40]
-        assert (status[2] > 0) == (len(want) != len(exp))          # counted per read, not per record
-        assert got == exp, "seed %d mode %d" % (seed, mode)
+        # MD strings over 40 characters do not fit a device record: the kernels flag them (THJ_MD_ON_HOST) and the host
+        # rebuilds them (thj_md_string) -- the records must come out all the same
+        assert status[2] == 0
+        assert got == want, "seed %d mode %d" % (seed, mode)

@@ -5,7 +5,10 @@ import orc
 from tophat_amd import host
 from tophat_amd.batch import build_seg_batch
 from tophat_amd.params import Params
-from test_hostsim_spanning import SPAN_CASES, span_inputs
+import numpy as np
+
+from test_hostsim_spanning import SPAN_CASES, repeat_span_batch, span_inputs
+from tophat_amd.batch import JUNC_DTYPE
 
 pytestmark = pytest.mark.gpu
 
@@ -67,3 +70,45 @@ def test_many_joined_alignments_per_read_gpu():
         ctx.upload_span_sets(np.zeros(0, dtype=JUNC_DTYPE), [])
         got = ctx.spanning(p, [ctx.upload_span_batch(sb)])
     assert len(want) == 30 * sb.n_reads and got == want
+
+
+def test_extra_record_pool_grows_and_the_pass_is_rerun():
+    """200 reads of a 30-copy tandem repeat give 5800 second-and-later records, more than the pool sized for the pass
+    (reads x 1.25 + 4096): thj_span_finish enlarges it and answers THJ_ERETRY, the rerun delivers everything"""
+    seq, sb = repeat_span_batch(copies=30, n_reads=200, seed=9)
+    p = Params()
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    want = orc.spanning(p, orc.Genome([seq]), sb, nj, [])
+    assert len(want) == 30 * 200
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        ctx.upload_span_sets(nj, [])
+        h = ctx.upload_span_batch(sb)
+        # the plain call sequence sees the retry code once ...
+        import ctypes as C
+        ctx.span_reset()
+        ctx.span_run(p, h)
+        n = C.c_int64()
+        assert ctx.lib.thj_span_finish(ctx._ctx, C.byref(n)) == -7 and b"run the pass again" in ctx.lib.thj_last_error()
+        # ... and the wrapper's loop gets the records
+        assert ctx.spanning(p, [h]) == want
+
+
+def test_long_md_strings_are_rebuilt_on_the_host():
+    """reads with many mismatches under relaxed limits: MD strings beyond the 40 characters of a device record"""
+    import sim  # noqa: F401
+    from tophat_amd.synth import make_case
+    from tophat_amd.batch import build_seg_batch, build_span_batch, events_to_span_inputs
+    case = make_case(seed=21, paired=False, read_len=150, seg_len=25, n_reads=300, err=0.06, boundary_bias=0.5, indel_frac=0.3)
+    p = Params(read_mismatches=14, read_edit_dist=16, read_gap_length=3)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    g = orc.Genome(seqs)
+    ev = orc.segjuncs(p, g, build_seg_batch(case.seg_recs["left"], case.reads["left"]))
+    juncs, ins = events_to_span_inputs(ev)
+    sb = build_span_batch(case.seg_recs["left"], case.reads["left"], case.quals["left"])
+    want = orc.spanning(p, g, sb, juncs, ins)
+    assert sum(1 for a in want if len(a.MD) > 40) > 5
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        ctx.upload_span_sets(juncs, ins)
+        assert ctx.spanning(p, [ctx.upload_span_batch(sb)]) == want

@@ -93,7 +93,13 @@ static long encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a
     aux.push_back("XM:i:" + std::to_string((int)a.XM));
     aux.push_back("XO:i:" + std::to_string((int)a.XO));
     aux.push_back("XG:i:" + std::to_string((int)a.XG));
-    aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
+    if (a.md_len == THJ_MD_ON_HOST) {                       // longer than a device record holds: rebuilt here from the same inputs
+        char md[2048];
+        const std::string& ref = rt.seqs[a.ref_id - 1];
+        const int n = thj_md_string(ref.data(), (int64_t)ref.size(), seq.data(), (int32_t)seq.size(), a.left, a.cigar, a.n_cigar, md, (int32_t)sizeof md);
+        if (n < 0) die("Error: %s\n", thj_last_error());
+        aux.push_back("MD:Z:" + std::string(md, (size_t)n));
+    } else aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
     aux.push_back("NM:i:" + std::to_string((int)a.mismatches + indel));
     if (spliced) aux.push_back(std::string("XS:A:") + ((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'));
     bw.encode(d, rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
@@ -345,10 +351,15 @@ int main(int argc, char** argv) {
                         const long long td = WorkClock::now();
                         thj_ctx* ctx = device_ready(gpu);
                         if (thj_span_batch_attach_reads(ctx, dev, W, stride, planes.data(), lens.data(), q.data())) die("Error: %s\n", thj_last_error());
-                        if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-                        if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
                         int64_t na = 0;
-                        if (thj_span_finish(ctx, &na)) die("Error: %s\n", thj_last_error());
+                        for (int attempt = 0;; ++attempt) {   // THJ_ERETRY: a device pool was enlarged, the pass runs again
+                            if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+                            if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
+                            const int frc = thj_span_finish(ctx, &na);
+                            if (frc == THJ_ERETRY && attempt < 4) continue;
+                            if (frc) die("Error: %s\n", thj_last_error());
+                            break;
+                        }
                         alns.resize((size_t)na);
                         if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
                         if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
@@ -410,10 +421,15 @@ int main(int argc, char** argv) {
                 thj_ctx* ctx = device_ready(gpu);
                 thj_span_batch* dev = nullptr;
                 if (thj_span_batch_upload(ctx, &hb, (int64_t)hits.size(), &dev)) die("Error: %s\n", thj_last_error());
-                if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
-                if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
                 int64_t na = 0;
-                if (thj_span_finish(ctx, &na)) die("Error: %s\n", thj_last_error());
+                for (int attempt = 0;; ++attempt) {           // THJ_ERETRY: a device pool was enlarged, the pass runs again
+                    if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
+                    if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
+                    const int frc = thj_span_finish(ctx, &na);
+                    if (frc == THJ_ERETRY && attempt < 4) continue;
+                    if (frc) die("Error: %s\n", thj_last_error());
+                    break;
+                }
                 alns.resize((size_t)na);
                 if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
                 if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());

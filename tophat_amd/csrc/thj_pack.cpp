@@ -135,3 +135,37 @@ extern "C" int thj_reads_pack(int64_t n_reads, const int64_t* read_off, const ch
     });
     return THJ_OK;
 }
+
+// MD:Z of one alignment, the way bowtie_sam_extra builds it (bwt_map.cpp:2467-2648) -- the host's part for the few records
+// whose MD string does not fit the 40 characters a device record holds (thj_aln.md_len == THJ_MD_ON_HOST).
+extern "C" int thj_md_string(const char* ref, int64_t ref_len, const char* seq, int32_t seq_len, int32_t left, const uint32_t* cigar, int32_t n_cigar,
+                             char* out, int32_t out_cap) {
+    if (!ref || !seq || !cigar || !out || out_cap < 2 || n_cigar < 0) { thj_set_error("thj_md_string: bad argument"); return THJ_EINVAL; }
+    auto fold = [](char c) { switch (c) { case 'A': case 'a': return 'A'; case 'C': case 'c': return 'C'; case 'G': case 'g': return 'G'; case 'T': case 't': return 'T'; default: return 'N'; } };
+    int n = 0;
+    auto put = [&](char c) { if (n + 1 < out_cap) out[n] = c; ++n; };
+    auto put_int = [&](int v) { char b[16]; int k = snprintf(b, sizeof b, "%d", v); for (int i = 0; i < k; ++i) put(b[i]); };
+    int64_t pos_ref = left;
+    int pos_seq = 0, pos_mm = 0;
+    for (int i = 0; i < n_cigar; ++i) {
+        const uint32_t op = cigar[i] >> 28; const int len = (int)(cigar[i] & 0x0FFFFFFFu);
+        if (op == THJ_CIG_MATCH) {
+            for (int k = 0; k < len && pos_seq + k < seq_len; ++k) {
+                const int64_t rp = pos_ref + k;
+                const char r = rp >= 0 && rp < ref_len ? fold(ref[rp]) : 'A';         // past the contig: the device genome's zero guard block
+                const char s = fold(seq[pos_seq + k]);
+                if (r != s) { put_int(pos_mm); put(r); pos_mm = 0; } else ++pos_mm;
+            }
+            pos_seq += len; pos_ref += len;
+        } else if (op == THJ_CIG_INS) pos_seq += len;
+        else if (op == THJ_CIG_DEL) {
+            put_int(pos_mm); put('^');
+            for (int k = 0; k < len && k < 64; ++k) { const int64_t rp = pos_ref + k; put(rp >= 0 && rp < ref_len ? fold(ref[rp]) : 'A'); }
+            pos_ref += len; pos_mm = 0;
+        } else if (op == THJ_CIG_REF_SKIP) pos_ref += len;
+    }
+    put_int(pos_mm);
+    if (n + 1 > out_cap) { thj_set_error("thj_md_string: %d characters do not fit the buffer", n); return THJ_EINVAL; }
+    out[n] = 0;
+    return n;
+}

@@ -597,12 +597,24 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
     HIPCHK(hipMemcpyAsync(&c->h_pinned[26], c->d_span_status, 16, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const unsigned int* st = (const unsigned int*)&c->h_pinned[26];
-    if (st[3]) { thj_set_error("overflow pool full: more than %lld extra records from multihit reads in one pass", (long long)c->ovf_cap); return THJ_EOVERFLOW; }
+    if (st[3]) {
+        // more 2nd.. records of multihit reads than the pool holds.  The counter kept counting, so the need is known: make the
+        // pool that large (and then some) and ask for the pass again -- the slots are rewritten by the rerun, nothing is kept
+        const int64_t need = (int64_t)c->h_pinned[25];
+        const int64_t ncap = need + need / 4 + 4096;
+        hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys);
+        c->d_aln_sorted = nullptr; c->d_aln_keys = nullptr; c->ovf_cap = 0;
+        HIPCHK(hipMalloc(&c->d_aln_sorted, (size_t)ncap * 128));
+        HIPCHK(hipMalloc(&c->d_aln_keys, (size_t)ncap * 8));
+        c->ovf_cap = ncap;
+        thj_set_error("the pool for the extra records of multihit reads was too small (%lld needed); it has been enlarged: run the pass again "
+                      "(thj_span_reset_async, the thj_span_run_async calls, thj_span_finish)", (long long)need);
+        return THJ_ERETRY;
+    }
     if (st[SPAN_TOO_MANY_JOINED]) {
         thj_set_error("%u read(s) have more than %d distinct joined alignments (device limit)", st[SPAN_TOO_MANY_JOINED], SPAN_MAXJOIN);
         return THJ_EOVERFLOW;
     }
-    if (st[SPAN_MD_OVERFLOW]) { thj_set_error("%u alignment(s) need an MD string longer than 40 characters (device limit)", st[SPAN_MD_OVERFLOW]); return THJ_EOVERFLOW; }
     c->n_alns = (int64_t)c->h_pinned[24];
     c->n_ovf = (int64_t)c->h_pinned[25];
     c->h_alns.clear();

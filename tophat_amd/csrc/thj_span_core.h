@@ -656,7 +656,8 @@ THJ_HD void emit_aln(Sink& sink, uint32_t read_idx, int order, const A& h, const
     wds[0] = read_idx; wds[1] = h.ref_id; wds[2] = (uint32_t)h.left;
     wds[3] = (h.anti ? 1u : 0u) | (h.asplice ? 4u : 0u) | ((uint32_t)h.mm << 8) | ((uint32_t)h.ed << 16) | ((uint32_t)h.n << 24);
     wds[4] = ((uint32_t)e.AS & 0xFFFFu) | ((uint32_t)(e.XM & 0xFF) << 16) | ((uint32_t)(e.XO & 0xFF) << 24);
-    wds[5] = (uint32_t)(e.XG & 0xFF) | ((uint32_t)e.md.len << 8) | ((uint32_t)(order & 0xFFFF) << 16);
+    // an MD string that does not fit the record's 40 characters is left to the host (md_len = THJ_MD_ON_HOST: thj_md_string)
+    wds[5] = (uint32_t)(e.XG & 0xFF) | ((uint32_t)(e.md.len > 40 ? 255 : e.md.len) << 8) | ((uint32_t)(order & 0xFFFF) << 16);
 #pragma unroll
     for (int q = 0; q < SPAN_MAXC; ++q) wds[6 + q] = q < h.n ? cg_fixed(h, q) : 0u;
 #pragma unroll
@@ -749,7 +750,7 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
         if (nsegs == 1) qrev = h.anti;
         else qrev = h.anti ? !read_is_own_revcomp(rp, W, rl) : false;
         Extras e;
-        if (!sam_extra(g, p, h, sv, qual, rl, qrev, e)) { status = SPAN_MD_OVERFLOW; continue; }
+        sam_extra(g, p, h, sv, qual, rl, qrev, e);
         emit_aln(sink, read_idx, order++, h, e);
     }
     return status;
@@ -945,10 +946,9 @@ THJ_HD int lean_finish(const Genome& g, const Params& p, const RAln& res, int ns
     if (nsegs == 1) qrev = res.anti;
     else qrev = res.anti ? !read_is_own_revcomp(rp, W, rl) : false;
     Extras e;
-    const bool md_fits = sam_extra(g, p, res, sv, qual, rl, qrev, e);
+    sam_extra(g, p, res, sv, qual, rl, qrev, e);
     // check_editdist_consistency (done inside merge_chain in the reference) shares sam_extra's counts
     if (nsegs > 1 && !(e.XM == res.mm || e.XM + e.both_n == res.mm)) return SPAN_OK;
-    if (!md_fits) return SPAN_MD_OVERFLOW;          // only for a hit that would really be reported
     emit_aln(sink, read_idx, order, res, e);
     ++order;
     return SPAN_OK;
@@ -1320,12 +1320,11 @@ THJ_HD int contig_finish(const Genome& g, const Params& p, const Src& src, uint3
     const MdBuf& md = a.md;
     const int mismatch = a.mismatch, both_n = a.both_n, AS = a.AS;
     if (nsegs > 1 && !(mismatch == mm8 || mismatch + both_n == mm8)) return SPAN_OK;   // check_editdist_consistency
-    if (md.len > 40) return SPAN_MD_OVERFLOW;        // only for a hit that would really be reported
     uint32_t wds[32];
     wds[0] = read_idx; wds[1] = ref_id; wds[2] = (uint32_t)left;
     wds[3] = (anti ? 1u : 0u) | ((uint32_t)mm8 << 8) | ((uint32_t)mm8 << 16) | (1u << 24);
     wds[4] = ((uint32_t)AS & 0xFFFFu) | ((uint32_t)(mismatch & 0xFF) << 16);                 // AS, XM, XO = 0
-    wds[5] = ((uint32_t)md.len << 8);                                                        // XG = 0, md_len, order = 0
+    wds[5] = ((uint32_t)(md.len > 40 ? 255 : md.len) << 8);                                  // XG = 0, md_len (255: on the host), order = 0
     wds[6] = cig(OP_MATCH, (uint32_t)total);
 #pragma unroll
     for (int q = 7; q < 22; ++q) wds[q] = 0;

@@ -125,7 +125,9 @@ def pack_genome(seqs: Sequence[Optional[str]], lib=None) -> PackedGenome:
     bufs = [None if s is None else s.encode() for s in seqs]
     arr = (C.c_char_p * n)(*bufs)
     _check(lib, lib.thj_genome_pack(n, arr, _ptr(lens), _ptr(contig_blk), _ptr(blocks), nb), "thj_genome_pack")
-    return PackedGenome(blocks, contig_blk, lens)
+    pg = PackedGenome(blocks, contig_blk, lens)
+    pg.seqs = list(seqs)            # the host keeps the bases: MD strings the device leaves to it are rebuilt from them
+    return pg
 
 
 def words_per_plane(max_len: int) -> int:
@@ -258,6 +260,7 @@ class Context:
         _check(self.lib, self.lib.thj_genome_upload(self._ctx, _ptr(g.blocks), C.c_int64(g.n_blocks), _ptr(g.contig_blk),
                                                     _ptr(g.lens), g.n_contigs), "thj_genome_upload")
         self.genome = g
+        self.host_seqs = getattr(g, "seqs", None)
 
     def adopt_genome(self, d_blocks: int, g: PackedGenome):
         _check(self.lib, self.lib.thj_genome_adopt(self._ctx, C.c_void_p(d_blocks), C.c_int64(g.n_blocks),
@@ -464,14 +467,56 @@ def pack_span_batch(b: SpanBatch, lib=None):
                 hits=np.ascontiguousarray(b.hits), planes=planes, read_len=lens, quals=quals)
 
 
-def alns_from_array(a: np.ndarray) -> List[Aln]:
+MD_ON_HOST = 255
+_RC = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")
+
+
+def md_on_host(seq_of_contig, read_seq: str, antisense: bool, left: int, cigar, lib=None) -> str:
+    """thj_md_string: the MD:Z of an alignment whose string does not fit a device record.  seq_of_contig: the contig's bases
+    (str / bytes); read_seq: the read as sequenced"""
+    lib = lib or load_lib()
+    ref = seq_of_contig if isinstance(seq_of_contig, bytes) else seq_of_contig.encode()
+    s = read_seq.encode()
+    if antisense:
+        s = s.translate(_RC)[::-1]
+    cig = (C.c_uint32 * max(1, len(cigar)))(*cigar)
+    buf = C.create_string_buffer(4096)
+    n = lib.thj_md_string(ref, C.c_int64(len(ref)), s, len(s), int(left), cig, len(cigar), buf, 4096)
+    if n < 0:
+        raise ThjError("thj_md_string: %s" % lib.thj_last_error().decode())
+    return buf.value.decode()
+
+
+def alns_from_array(a: np.ndarray, md_resolver=None) -> List[Aln]:
+    """md_resolver(read_idx, ref_id, antisense, left, cigar) -> MD string, for records flagged THJ_MD_ON_HOST"""
     out = []
     for x in a:
         n = int(x["n_cigar"])
+        cig = tuple(int(c) for c in x["cigar"][:n])
+        if int(x["md_len"]) == MD_ON_HOST:
+            if md_resolver is None:
+                raise ThjError("a record's MD string is left to the host (THJ_MD_ON_HOST) and no resolver was given")
+            md = md_resolver(int(x["read_idx"]), int(x["ref_id"]), bool(x["flags"] & 1), int(x["left"]), cig)
+        else:
+            md = x["md"][:int(x["md_len"])].decode()
         out.append(Aln(int(x["read_idx"]), int(x["ref_id"]), int(x["left"]), bool(x["flags"] & 1), bool(x["flags"] & 4),
-                       int(x["mismatches"]), int(x["edit_dist"]), tuple(int(c) for c in x["cigar"][:n]),
-                       int(x["AS"]), int(x["XM"]), int(x["XO"]), int(x["XG"]), x["md"][:int(x["md_len"])].decode()))
+                       int(x["mismatches"]), int(x["edit_dist"]), cig, int(x["AS"]), int(x["XM"]), int(x["XO"]), int(x["XG"]), md))
     return out
+
+
+def span_md_resolver(seqs, batches, lib=None):
+    """resolver over the host copies of a pass: seqs[ref_id - 1] = contig bases, batches = the SpanBatch objects in run order
+    (read_idx counts through them)"""
+    starts = [0]
+    for b in batches:
+        starts.append(starts[-1] + b.n_reads)
+
+    def resolve(read_idx, ref_id, antisense, left, cigar):
+        k = max(i for i in range(len(batches)) if starts[i] <= read_idx)
+        b = batches[k]
+        r = read_idx - starts[k]
+        return md_on_host(seqs[ref_id - 1], b.bases[b.read_off[r]:b.read_off[r + 1]].tobytes().decode(), antisense, left, cigar, lib)
+    return resolve
 
 
 def _ins_table(insertions) -> np.ndarray:
@@ -505,6 +550,9 @@ def _span_methods():
         _check(self.lib, self.lib.thj_span_batch_upload(self._ctx, C.byref(cb), C.c_int64(len(d["hits"])), C.byref(out)),
                "thj_span_batch_upload")
         self._span_batches = getattr(self, "_span_batches", []) + [out]
+        if not hasattr(self, "_span_host"):
+            self._span_host = {}
+        self._span_host[out.value] = b
         return out
 
     def span_reset(self):
@@ -525,11 +573,24 @@ def _span_methods():
         _check(self.lib, self.lib.thj_span_download(self._ctx, _ptr(a)), "thj_span_download")
         return a[:n]
 
-    def spanning(self, p: Params, batches) -> List[Aln]:
-        self.span_reset()
-        for b in batches:
-            self.span_run(p, b)
-        return alns_from_array(self.span_download(self.span_finish()))
+    def spanning(self, p: Params, batches, md_resolver=None) -> List[Aln]:
+        """md_resolver: see alns_from_array; built automatically when the genome was uploaded from strings kept by the caller
+        (Context.host_seqs) and the batches came from upload_span_batch"""
+        for attempt in range(4):
+            self.span_reset()
+            for b in batches:
+                self.span_run(p, b)
+            n = C.c_int64()
+            rc = self.lib.thj_span_finish(self._ctx, C.byref(n))
+            if rc != -7:                       # THJ_ERETRY: the extra-record pool was enlarged, the pass runs again
+                break
+        _check(self.lib, rc, "thj_span_finish")
+        a = self.span_download(n.value)
+        if md_resolver is None and getattr(self, "host_seqs", None) is not None:
+            hb = [self._span_host.get(getattr(b, "value", None)) for b in batches]
+            if all(x is not None for x in hb):
+                md_resolver = span_md_resolver(self.host_seqs, hb, self.lib)
+        return alns_from_array(a, md_resolver)
 
     def span_tier_counts(self):
         c = (C.c_int64 * 3)()
@@ -553,6 +614,7 @@ _span_methods()
 ABI_SYMBOLS += ["thj_bgzf_inflate", "thj_ingest_seg_batch", "thj_ingest_span_hits", "thj_span_batch_attach_reads"]
 ABI_SYMBOLS += ["thj_juncbed_configure", "thj_juncbed_reset_async", "thj_juncbed_add_span_async", "thj_juncbed_add_records",
                 "thj_juncbed_finish", "thj_juncbed_download"]
+ABI_SYMBOLS += ["thj_md_string"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
                 "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
