@@ -43,8 +43,8 @@ def test_fuzz_segment_juncs_gpu(seed):
     assert gf.tolist() == wf.tolist()
 
 
-@pytest.mark.parametrize("seed", range(N_SEEDS))
-def test_fuzz_long_spanning_reads_gpu(seed):
+def span_fuzz_case(seed):
+    """-> (contig strings, SpanBatch, Params, junction array): one adversarial long_spanning_reads batch"""
     rng = np.random.default_rng(9500 + seed)
     seqs = rand_genome(rng, int(rng.integers(1, 3)))
     L = int(rng.choice([20, 25, 25, 40]))
@@ -68,6 +68,12 @@ def test_fuzz_long_spanning_reads_gpu(seed):
                 juncs.add((int(a["ref_id"]), l_, r_, int(rng.integers(0, 2))))
     jl = sorted(juncs)
     ja = np.array(jl, dtype=JUNC_DTYPE) if jl else np.zeros(0, dtype=JUNC_DTYPE)
+    return seqs, sb, p, ja
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_long_spanning_reads_gpu(seed):
+    seqs, sb, p, ja = span_fuzz_case(seed)
     want = orc.spanning(p, orc.Genome(seqs), sb, ja, [])
     with host.Context(0) as ctx:
         ctx.upload_genome(host.pack_genome(seqs))

@@ -95,20 +95,14 @@ def test_extra_record_pool_grows_and_the_pass_is_rerun():
 
 
 def test_long_md_strings_are_rebuilt_on_the_host():
-    """reads with many mismatches under relaxed limits: MD strings beyond the 40 characters of a device record"""
-    import sim  # noqa: F401
-    from tophat_amd.synth import make_case
-    from tophat_amd.batch import build_seg_batch, build_span_batch, events_to_span_inputs
-    case = make_case(seed=21, paired=False, read_len=150, seg_len=25, n_reads=300, err=0.06, boundary_bias=0.5, indel_frac=0.3)
-    p = Params(read_mismatches=14, read_edit_dist=16, read_gap_length=3)
-    seqs = [orc.fold_genome_char(s) for s in case.seqs]
-    g = orc.Genome(seqs)
-    ev = orc.segjuncs(p, g, build_seg_batch(case.seg_recs["left"], case.reads["left"]))
-    juncs, ins = events_to_span_inputs(ev)
-    sb = build_span_batch(case.seg_recs["left"], case.reads["left"], case.quals["left"])
-    want = orc.spanning(p, g, sb, juncs, ins)
-    assert sum(1 for a in want if len(a.MD) > 40) > 5
+    """an adversarial batch (the fuzz generator, seed 24: N-rich genome, deletions up to 10 bases) whose alignments need MD
+    strings of up to 51 characters: beyond the 40 a device record holds, they come back flagged THJ_MD_ON_HOST and are
+    rebuilt with thj_md_string -- record for record what the oracle says"""
+    from test_gpu_fuzz import span_fuzz_case
+    seqs, sb, p, ja = span_fuzz_case(24)
+    want = orc.spanning(p, orc.Genome(seqs), sb, ja, [])
+    assert sum(1 for a in want if len(a.MD) > 40) > 100
     with host.Context(0) as ctx:
         ctx.upload_genome(host.pack_genome(seqs))
-        ctx.upload_span_sets(juncs, ins)
+        ctx.upload_span_sets(ja, [])
         assert ctx.spanning(p, [ctx.upload_span_batch(sb)]) == want
