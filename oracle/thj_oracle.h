@@ -179,6 +179,11 @@ typedef struct {
     uint32_t cigar[5];     /* ORC_CIG(op, len) */
 } orc_span_hit;
 #define ORC_HIT_ANTISENSE_SPLICE 4u
+/* a segment hit on an rf / rr fusion contig of the junction database: antisense_align is the opposite of the record's own
+ * strand flag (bwt_map.cpp:1744-1745), so the record's SEQ is the read piece reverse-complemented iff antisense ^ this bit.
+ * A hit with a fusion op (ORC_FUSION_*, length = the position on the second contig) has at most 4 ops and keeps ref_id2
+ * in cigar[4]. */
+#define ORC_HIT_STRAND_FLIPPED 8u
 
 typedef struct {
     int32_t segment_length;
@@ -222,6 +227,23 @@ int orc_spanning_batch(const orc_span_params* p, const orc_genome* g, const orc_
                        const orc_junction* juncs, int64_t n_juncs, const orc_ins_in* ins, int64_t n_ins,
                        orc_aln** out, int64_t* n_out);
 void orc_free(void* p);
+
+/* ---- the same with the fusion branches (spanning_fusion_oracle.c): --fusion-search of long_spanning_reads.
+ * fusions = the .fusions list (long_spanning_reads.cpp:2998-3040) sorted by Fusion::operator< (fusions.h:44-71), dir = ORC_FUSION_*. */
+typedef struct { uint32_t ref1, ref2, left, right, dir; } orc_fusion_in;
+typedef struct {
+    int32_t  read_idx;
+    uint32_t ref_id, ref_id2;
+    int32_t  left;
+    uint8_t  antisense, antisense_splice, mismatches, edit_dist;
+    int32_t  n_cigar;
+    uint32_t cigar[32];
+    int32_t  AS, XM, XO, XG;
+    char     md[128];
+} orc_faln;
+int orc_spanning_batch_fusion(const orc_span_params* p, int fusion_search, int fusion_min_dist, const orc_genome* g, const orc_span_batch* b,
+                              const orc_junction* juncs, int64_t n_juncs, const orc_ins_in* ins, int64_t n_ins,
+                              const orc_fusion_in* fusions, int64_t n_fusions, orc_faln** out, int64_t* n_out);
 
 
 /* ---- junction consensus of tophat_reports (juncbed_oracle.c): the reported alignments'

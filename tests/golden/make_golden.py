@@ -44,8 +44,34 @@ CASES = {
 }
 
 
+FUSION_SPAN_CASES = {
+    # the whole --fusion-search path incl. long_spanning_reads (tools/fusion_diff.py: segments without a genome hit are placed on
+    # the junction database exhaustively, the fusion contigs included)
+    "pe100_fusion_span": dict(seed=105, n_reads=120, fusion_reads=60),
+    "pe100_fusion_span3": dict(seed=301, n_reads=100, fusion_reads=80, all_segments=True,
+                               gen_extra=dict(contig_lens=(20000, 14000, 9000), genes_per_contig=5, indel_frac=0.15, boundary_bias=0.4)),
+}
+
+
+def fusion_span_cases(only):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fusion_diff
+    for name, cfg in FUSION_SPAN_CASES.items():
+        if only and name not in only:
+            continue
+        d = os.path.join(HERE, name)
+        if os.path.exists(d):
+            shutil.rmtree(d)
+        fusion_diff.run_case(d, **cfg)
+        for f_ in os.listdir(d):
+            if f_.endswith(".to_spliced.bam"):
+                os.remove(os.path.join(d, f_))
+        print(name, sum(os.path.getsize(os.path.join(d, x)) for x in os.listdir(d)) // 1024, "KiB")
+
+
 def main():
     only = sys.argv[1:]
+    fusion_span_cases(only)
     for name, cfg in CASES.items():
         if only and name not in only:
             continue

@@ -7,7 +7,9 @@ from tophat_amd.params import LIBRARY_TYPES, Params, READ_LEFT, READ_RIGHT
 from tophat_amd.samtext import parse_header, parse_sam_hits, parse_spliced_sam_hits, read_fasta, read_fastq
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+_ALL = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+FUSION_SPAN_CASES = [d for d in _ALL if "fusion_span" in d]     # the whole --fusion-search path incl. long_spanning_reads
+CASES = [d for d in _ALL if d not in FUSION_SPAN_CASES]
 
 
 def read_fastq_quals(path):
@@ -86,9 +88,15 @@ def load(name):
         rows = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
         # (QNAME FLAG RNAME POS CIGAR tags...) -- drop MAPQ/SEQ/QUAL columns
         exp_span[sd] = [(r[0], int(r[1]), r[2], int(r[3]), r[5]) + r[8:] for r in rows]
-    if fusion:
+    exp_span_full = {}
+    if name in FUSION_SPAN_CASES:
+        # (QNAME FLAG RNAME POS CIGAR SEQ QUAL tags...): fusion alignments are two records with the whole alignment in XF:Z
+        for sd in sides:
+            rows = [l.rstrip("\n").split("\t") for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
+            exp_span_full[sd] = [(r[0], r[1], r[2], r[3], r[5], r[6], r[7]) + tuple(r[8:]) for r in rows]
+    elif fusion:
         span_batches = {}
-    return dict(p=p, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp=exp, exp_span=exp_span, fusion=fusion,
+    return dict(sides=sides, exp_span_full=exp_span_full, ref_ids=ref_ids, dir=d, p=p, names=names, seqs=seqs, seg_batches=seg_batches, span_batches=span_batches, exp=exp, exp_span=exp_span, fusion=fusion,
                 fusion_ignore=[ref_ids[n] for n in ignore_names])
 
 

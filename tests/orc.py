@@ -164,6 +164,63 @@ def spanning(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> list:
     return res
 
 
+class OrcFAln(C.Structure):
+    _fields_ = [("read_idx", C.c_int32), ("ref_id", C.c_uint32), ("ref_id2", C.c_uint32), ("left", C.c_int32),
+                ("antisense", C.c_uint8), ("antisense_splice", C.c_uint8), ("mismatches", C.c_uint8), ("edit_dist", C.c_uint8),
+                ("n_cigar", C.c_int32), ("cigar", C.c_uint32 * 32),
+                ("AS", C.c_int32), ("XM", C.c_int32), ("XO", C.c_int32), ("XG", C.c_int32), ("md", C.c_char * 128)]
+
+
+SPAN_FUSION_DTYPE = np.dtype([("ref_id1", "<u4"), ("ref_id2", "<u4"), ("left", "<u4"), ("right", "<u4"), ("dir", "<u4")])
+
+
+def read_fusions_file(path: str, ref_ids) -> np.ndarray:
+    """the .fusions list as long_spanning_reads loads it (long_spanning_reads.cpp:2998-3040), in Fusion::operator< order"""
+    rows = set()
+    for line in open(path):
+        t = line.rstrip("\n").split("\t")
+        if len(t) < 5:
+            continue
+        d = {"fr": 8, "rf": 9, "rr": 10}.get(t[4], 7)
+        rows.add((ref_ids.get(t[0], 0), ref_ids.get(t[2], 0), int(t[1]) & 0xFFFFFFFF, int(t[3]) & 0xFFFFFFFF, d))
+    return np.array(sorted(rows), dtype=SPAN_FUSION_DTYPE) if rows else np.zeros(0, dtype=SPAN_FUSION_DTYPE)
+
+
+def spanning_fusion(p: Params, g: Genome, b, juncs: np.ndarray, insertions, fusions: np.ndarray, fusion_search: bool = True) -> list:
+    """long_spanning_reads with its fusion branches (spanning_fusion_oracle.c) -> list of tophat_amd.batch.Aln"""
+    from tophat_amd.batch import Aln
+    lib = _lib()
+    op = OrcSpanParams()
+    for n, _ in OrcSpanParams._fields_:
+        setattr(op, n, int(getattr(p, n)))
+    ob = OrcSpanBatch()
+    ob.n_reads, ob.nseg = b.n_reads, b.nseg
+    keep = [np.ascontiguousarray(b.read_off, dtype=np.int64), np.ascontiguousarray(b.bases, dtype=np.uint8),
+            np.ascontiguousarray(b.quals, dtype=np.uint8), np.ascontiguousarray(b.seg_off, dtype=np.int64),
+            np.ascontiguousarray(b.hits)]
+    ob.read_off, ob.bases, ob.quals, ob.seg_off, ob.hits = [a.ctypes.data for a in keep]
+    j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
+    ins = (OrcInsIn * max(1, len(insertions)))()
+    for k, (ref, left, seq) in enumerate(insertions):
+        ins[k].ref_id, ins[k].left, ins[k].seq = ref, left, seq.encode()
+    f = np.ascontiguousarray(fusions, dtype=SPAN_FUSION_DTYPE)
+    out = C.POINTER(OrcFAln)()
+    n_out = C.c_int64()
+    rc = lib.orc_spanning_batch_fusion(C.byref(op), C.c_int(1 if fusion_search else 0), C.c_int(int(p.fusion_min_dist)), C.byref(g.c),
+                                       C.byref(ob), C.c_void_p(j.ctypes.data), C.c_int64(len(j)), ins, C.c_int64(len(insertions)),
+                                       C.c_void_p(f.ctypes.data), C.c_int64(len(f)), C.byref(out), C.byref(n_out))
+    assert rc == 0
+    res = []
+    for k in range(n_out.value):
+        a = out[k]
+        cig = tuple(a.cigar[i] for i in range(a.n_cigar))
+        fused = any((c >> 28) in (7, 8, 9, 10) for c in cig)
+        res.append(Aln(a.read_idx, a.ref_id, a.left, bool(a.antisense), bool(a.antisense_splice), a.mismatches, a.edit_dist,
+                       cig, a.AS, a.XM, a.XO, a.XG, a.md.decode(), a.ref_id2 if fused else 0))
+    lib.orc_free(out)
+    return res
+
+
 def spanning_count(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> int:
     """Runs the spanning oracle and returns only the record count (bench.py's cpu_baseline leg:
     avoids building Python objects for millions of records)."""

@@ -188,6 +188,8 @@ def test_fuzz_long_spanning_reads(seed):
     il = [(k[0], k[1], v) for k, v in sorted(ins.items()) if k[1] >= 0]
     g = orc.Genome(seqs)
     want = orc.spanning(p, g, sb, ja, il)
+    # the second restatement (spanning_fusion_oracle.c, the one with the fusion branches) agrees when fusion search is off
+    assert orc.spanning_fusion(p, g, sb, ja, il, np.zeros(0, dtype=orc.SPAN_FUSION_DTYPE), False) == want
     for mode in (0, 1, 2):
         got, status = sim.spanning(p, seqs, sb, ja, il, mode)
         assert status[1] == 0

@@ -41,3 +41,49 @@ def test_oracle_and_kernel_logic_reproduce_fixture(name, tmp_path):
         assert got == want
         got2, st = sim.spanning(c["p"], seqs, sb, juncs, ins)
         assert [a.sam_fields(int(sb.read_id[a.read_idx]), c["names"]) for a in got2] == want
+
+
+def fusion_span_inputs(c):
+    """junction / insertion / fusion sets of a --fusion-search fixture as long_spanning_reads loads them from the list files"""
+    import numpy as np
+    from tophat_amd.host import JUNC_DTYPE
+    d, ref_ids = c["dir"], c["ref_ids"]
+    rows = set()
+    for line in open(d + "/expected.juncs"):
+        t = line.split("\t")
+        rows.add((ref_ids[t[0]], int(t[1]), int(t[2]), 1 if t[3].strip() == "-" else 0))
+    for line in open(d + "/expected.deletions"):
+        t = line.split("\t")
+        rows.add((ref_ids[t[0]], int(t[1]) - 1, int(t[2]), 0))
+    ins = set()
+    for line in open(d + "/expected.insertions"):
+        t = line.rstrip("\n").split("\t")
+        ins.add((ref_ids[t[0]], int(t[1]), t[3]))
+    juncs = np.array(sorted(rows), dtype=JUNC_DTYPE) if rows else np.zeros(0, dtype=JUNC_DTYPE)
+    return juncs, sorted(ins, key=lambda x: (x[0], x[1], len(x[2]))), orc.read_fusions_file(d + "/expected.fusions", ref_ids)
+
+
+def span_records(c, sd, sb, alns):
+    out = []
+    for a in alns:
+        rid = int(sb.read_id[a.read_idx])
+        out += [tuple(str(x) for x in r) for r in a.sam_records(rid, c["names"], c["sides"][sd]["reads"][rid], c["sides"][sd]["quals"][rid])]
+    return out
+
+
+from golden_util import FUSION_SPAN_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", FUSION_SPAN_CASES)
+def test_fusion_spanning_oracle_reproduces_fixture(name):
+    """long_spanning_reads --fusion-search: fused segment hits from the fusion contigs of the junction database, all four
+    directions, two-record XF output -- record for record (SEQ, QUAL and tags included) what the scratch build wrote"""
+    c = load(name)
+    g = orc.Genome(c["seqs"])
+    juncs, ins, fus = fusion_span_inputs(c)
+    n_fused = 0
+    for sd, sb in c["span_batches"].items():
+        alns = orc.spanning_fusion(c["p"], g, sb, juncs, ins, fus, True)
+        n_fused += sum(1 for a in alns if a.is_fusion())
+        assert span_records(c, sd, sb, alns) == c["exp_span_full"][sd]
+    assert n_fused >= 20

@@ -229,9 +229,12 @@ SPAN_HIT_DTYPE = np.dtype([
 ])
 assert SPAN_HIT_DTYPE.itemsize == 32
 HIT_ANTISENSE_SPLICE = 4
+HIT_STRAND_FLIPPED = 8          # hit on an rf / rr fusion contig: antisense_align is the opposite of the record's strand flag
+CIG_FUSION_FF, CIG_FUSION_FR, CIG_FUSION_RF, CIG_FUSION_RR = 7, 8, 9, 10
+FUSION_OPS = (7, 8, 9, 10)
 
 CIG_MATCH, CIG_INS, CIG_DEL, CIG_REF_SKIP, CIG_SOFT_CLIP = 1, 3, 5, 11, 13   # bwt_map.h:36-55
-CIG_CHARS = {1: "M", 2: "m", 3: "I", 4: "i", 5: "D", 6: "d", 11: "N", 12: "n", 13: "S"}
+CIG_CHARS = {1: "M", 2: "m", 3: "I", 4: "i", 5: "D", 6: "d", 7: "F", 8: "F", 9: "F", 10: "F", 11: "N", 12: "n", 13: "S"}
 
 
 def cig_pack(op: int, length: int) -> int:
@@ -265,11 +268,16 @@ def span_hit_struct(h: HitRec) -> tuple:
     _, ref_id, left, _right, anti, end, mm, ed, _rl = h[:9]
     cigar = h[9] if len(h) > 9 else [(CIG_MATCH, _rl)]
     asp = bool(h[10]) if len(h) > 10 else False
-    if len(cigar) > 5:
-        raise ValueError("segment hit with %d CIGAR ops (device path supports <= 5)" % len(cigar))
+    fused = any(o in FUSION_OPS for (o, _n) in cigar)
+    if len(cigar) > (4 if fused else 5):
+        raise ValueError("segment hit with %d CIGAR ops (device path supports <= 5, <= 4 for a fused hit)" % len(cigar))
     cig = [cig_pack(o, n) for (o, n) in cigar] + [0] * (5 - len(cigar))
-    return (ref_id, left, (HIT_ANTISENSE if anti else 0) | (HIT_END if end else 0) | (HIT_ANTISENSE_SPLICE if asp else 0),
-            mm & 0xFF, ed & 0xFF, len(cigar), cig)
+    flipped = False
+    if fused:
+        cig[4] = int(h[11])        # ref_id2 rides in the last cigar slot
+        flipped = bool(h[12])
+    return (ref_id, left, (HIT_ANTISENSE if anti else 0) | (HIT_END if end else 0) | (HIT_ANTISENSE_SPLICE if asp else 0) |
+            (HIT_STRAND_FLIPPED if flipped else 0), mm & 0xFF, ed & 0xFF, len(cigar), cig)
 
 
 def build_span_batch(seg_recs: Sequence[Iterable[HitRec]], reads: Dict[int, str], quals: Dict[int, str],
@@ -315,16 +323,74 @@ class Aln:
     XO: int
     XG: int
     MD: str
+    ref_id2: int = 0           # second contig of a fusion alignment (0: none)
 
-    def sam_fields(self, read_id: int, ref_names: Sequence[str]) -> tuple:
-        """(QNAME, FLAG, RNAME, POS, CIGAR, tags...) as in the BAM record"""
+    def _tags(self):
         indel = sum(c & 0x0FFFFFFF for c in self.cigar if (c >> 28) in (3, 4, 5, 6))
         tags = ["AS:i:%d" % self.AS, "XM:i:%d" % self.XM, "XO:i:%d" % self.XO, "XG:i:%d" % self.XG,
                 "MD:Z:%s" % self.MD, "NM:i:%d" % (self.mismatches + indel)]
         if any((c >> 28) in (11, 12) for c in self.cigar):
             tags.append("XS:A:%s" % ("-" if self.antisense_splice else "+"))
+        return tags
+
+    def sam_fields(self, read_id: int, ref_names: Sequence[str]) -> tuple:
+        """(QNAME, FLAG, RNAME, POS, CIGAR, tags...) as in the BAM record"""
         return (str(read_id), 16 if self.antisense else 0, ref_names[self.ref_id - 1], self.left + 1,
-                cigar_string(self.cigar)) + tuple(tags)
+                cigar_string(self.cigar)) + tuple(self._tags())
+
+    def is_fusion(self) -> bool:
+        return any((c >> 28) in FUSION_OPS for c in self.cigar)
+
+    def sam_records(self, read_id: int, ref_names: Sequence[str], read_seq: str, read_qual: str) -> list:
+        """The record(s) print_bamhit writes (bwt_map.cpp:1888-2093) as (QNAME, FLAG, RNAME, POS, CIGAR, SEQ, QUAL, tags...):
+        one for a plain alignment, two for a fusion alignment (extract_partial_hits, :2148-2347), each carrying the whole
+        alignment in XF:Z."""
+        seq, qual = read_seq, read_qual
+        if self.antisense:
+            seq = seq.translate(_RC)[::-1]
+            qual = qual[::-1]
+        if not self.is_fusion():
+            f = self.sam_fields(read_id, ref_names)
+            return [f[:5] + (seq, qual) + f[5:]]
+        ops = [(c >> 28, c & 0x0FFFFFFF) for c in self.cigar]
+        fi = next(i for i, (o, _n) in enumerate(ops) if o in FUSION_OPS)
+        fdir = ops[fi][0]
+        right = self.left
+        left_part_len = 0
+        fusion_left = fusion_right = -1
+        for i, (o, n) in enumerate(ops):
+            if o in (1, 11, 5):
+                right += n
+            elif o in (2, 12, 6):
+                right -= n
+            elif o in FUSION_OPS:
+                fusion_left = right - 1 if o in (7, 8) else right + 1
+                fusion_right = right = n
+            if i < fi and o in (1, 2, 3, 4):
+                left_part_len += n
+        up = {1: "M", 2: "M", 3: "I", 4: "I", 5: "D", 6: "D", 11: "N", 12: "N"}
+        first = ops[:fi] if fdir in (7, 8) else ops[:fi][::-1]
+        second = ops[fi + 1:] if fdir in (7, 9) else ops[fi + 1:][::-1]
+        cigar1 = "".join("%d%s" % (n, up[o]) for o, n in first)
+        cigar2 = "".join("%d%s" % (n, up[o]) for o, n in second)
+        seq1, qual1 = seq[:left_part_len], qual[:left_part_len]
+        seq2, qual2 = seq[left_part_len:], qual[left_part_len:]
+        if fdir in (9, 10):
+            seq1, qual1 = seq1.translate(_RC)[::-1], qual1[::-1]
+        if fdir in (8, 10):
+            seq2, qual2 = seq2.translate(_RC)[::-1], qual2[::-1]
+        left1 = self.left if fdir in (7, 8) else fusion_left
+        left2 = fusion_right if fdir in (7, 9) else right + 1
+        n1, n2 = ref_names[self.ref_id - 1], ref_names[self.ref_id2 - 1]
+        full = "".join("%d%s" % (n + 1 if o in FUSION_OPS else n, CIG_CHARS[o]) for o, n in ops)
+        xf = "%s-%s %d %s %s %s" % (n1, n2, self.left + 1, full, seq, qual)
+        flag = 16 if self.antisense else 0
+        tags = self._tags()
+        return [(str(read_id), flag, n1, left1 + 1, cigar1, seq1, qual1) + tuple(tags) + ("XF:Z:1 " + xf,),
+                (str(read_id), flag, n2, left2 + 1, cigar2, seq2, qual2) + tuple(tags) + ("XF:Z:2 " + xf,)]
+
+
+_RC = str.maketrans("ACGTNacgtn", "TGCANtgcan")
 
 
 def events_to_span_inputs(ev: Events):

@@ -167,14 +167,26 @@ def _cigar_add(c, op):
     c.append(op)
 
 
+_FUSION_CODES = (7, 8, 9, 10)          # FUSION_FF, FUSION_FR, FUSION_RF, FUSION_RR (bwt_map.h:36-55)
+_LOWER = {1: 2, 3: 4, 5: 6, 11: 12}    # MATCH -> mATCH, INS -> iNS, DEL -> dEL, REF_SKIP -> rEF_SKIP
+
+
 def _splice_cigar(cigar, mism, left, spl_start, spl_len, spl_code, min_anchor_len):
+    """spliceCigar (bwt_map.cpp:681-865).  For the fusion codes the pieces before an rf / rr break and after an fr / rr break
+    come out in their lower-case (reversed) forms."""
     INS, DEL, SKIP, MATCH, PAD, SOFT = 3, 5, 11, 1, 15, 13
+    fus = spl_code in _FUSION_CODES
+    low_before = spl_code in (9, 10)
+    low_after = spl_code in (8, 10)
     out = []
     spl_ofs = spl_start - left
+    if fus:
+        spl_ofs = abs(spl_ofs)
     spl_ofs_end = spl_ofs + (spl_len if spl_code == INS else 0)
     gapop = (spl_code, spl_len)
     ref_ofs = read_ofs = 0
     spl_mm = 0
+    xfound = False
     if spl_ofs_end > 0:
         for (op, ln) in cigar:
             prev_read, cur_ofs = read_ofs, ref_ofs
@@ -194,9 +206,14 @@ def _splice_cigar(cigar, mism, left, spl_start, spl_len, spl_code, min_anchor_le
                 read_ofs += ln
             if cur_ofs >= spl_ofs_end or ref_ofs <= spl_ofs:
                 if cur_ofs == spl_ofs_end and spl_code != INS and op != INS:
+                    xfound = True
                     _cigar_add(out, gapop)
-                _cigar_add(out, (op, ln))
+                o2 = op
+                if (xfound and low_after) or (not xfound and low_before):
+                    o2 = _LOWER.get(op, op)
+                _cigar_add(out, (o2, ln))
             elif spl_code == INS:
+                xfound = True
                 if spl_ofs > cur_ofs:
                     _cigar_add(out, (op, spl_ofs - cur_ofs))
                 if spl_ofs < 0:
@@ -207,13 +224,14 @@ def _splice_cigar(cigar, mism, left, spl_start, spl_len, spl_code, min_anchor_le
                 if ref_ofs > spl_ofs_end:
                     _cigar_add(out, (op, ref_ofs - spl_ofs_end))
             else:
-                _cigar_add(out, (op, spl_ofs - cur_ofs))
+                xfound = True
+                _cigar_add(out, (_LOWER.get(op, op) if low_before else op, spl_ofs - cur_ofs))
                 _cigar_add(out, gapop)
-                _cigar_add(out, (op, ref_ofs - spl_ofs))
+                _cigar_add(out, (_LOWER.get(op, op) if low_after else op, ref_ofs - spl_ofs))
     if spl_ofs_end <= 0:
         left = left - spl_len if spl_code == INS else left + spl_len
         out = list(cigar)
-    ok = len(out) >= len(cigar) + 2 and out[0][0] == MATCH and out[-1][0] == MATCH
+    ok = len(out) >= len(cigar) + 2 and out[0][0] in (1, 2) and out[-1][0] in (1, 2)
     return ok, out, left, spl_mm
 
 
@@ -271,9 +289,11 @@ def parse_spliced_sam_hits(path: str, ref_ids: Dict[str, int], max_report_intron
             if len(st) != 2:
                 continue
             jtype, jstrand = toks[ne + 4], toks[ne + 5]
-            left = int(toks[ne + 1]) + pos - 1
             lsp = int(st[0])
+            ref_id2, flipped = None, False
+            antisense = bool(flag & 0x10)
             if jtype == "ins":
+                left = int(toks[ne + 1]) + pos - 1
                 if left > lsp:
                     continue
                 ok, spl, left, spl_mm = _splice_cigar(ops, mism, left, lsp + 1, len(st[1]), 3, min_anchor_len)
@@ -281,16 +301,51 @@ def parse_spliced_sam_hits(path: str, ref_ids: Dict[str, int], max_report_intron
                     continue
                 num_mm -= spl_mm
             else:
-                code = 5 if jtype == "del" else 11
-                gap_len = int(st[1]) - lsp - 1
-                lsp += 1
-                if left >= lsp:
+                if jstrand not in ("ff", "fr", "rf", "rr", "rev", "fwd"):
                     continue
+                fus = jtype == "fus"
+                # bwt_map.cpp:1672-1677: on rf / rr fusion contigs the first piece runs down the genome
+                if fus and jstrand in ("rf", "rr"):
+                    left = int(toks[ne + 1]) - (pos - 1)
+                else:
+                    left = int(toks[ne + 1]) + pos - 1
+                if jtype == "del":
+                    code = 5
+                elif fus:
+                    code = {"ff": 7, "fr": 8, "rf": 9}.get(jstrand, 10)
+                else:
+                    code = 11
+                gap_len = int(st[1]) if fus else int(st[1]) - lsp - 1
+                if code in (9, 10):
+                    lsp -= 1
+                    if left <= lsp:
+                        continue
+                else:
+                    lsp += 1
+                    if left >= lsp:
+                        continue
                 ok, spl, left, spl_mm = _splice_cigar(ops, mism, left, lsp, gap_len, code, min_anchor_len)
                 if not ok:
                     continue
-            gap = sum(n for o, n in spl if o in (3, 5))
-            right = left + sum(n for o, n in spl if o in (1, 5, 11))
-            rl = sum(n for o, n in spl if o in (1, 3, 13))
-            yield (rid, ref_ids[contig], left, right, bool(flag & 0x10), end, num_mm & 0xFF, (num_mm + gap) & 0xFF, rl,
-                   spl, jstrand == "rev")
+                if fus:
+                    cs = contig.split("-")
+                    if len(cs) != 2:
+                        continue
+                    contig, ref_id2 = cs[0], ref_ids[cs[1]]
+                    if jstrand in ("rf", "rr"):
+                        antisense = not antisense
+                        flipped = True
+            gap = sum(n for o, n in spl if o in (3, 4, 5, 6))
+            right = left
+            for o, n in spl:
+                if o in (1, 5, 11):
+                    right += n
+                elif o in (2, 6, 12):
+                    right -= n
+                elif o in _FUSION_CODES:
+                    right = n
+            rl = sum(n for o, n in spl if o in (1, 2, 3, 4, 13))
+            rec = (rid, ref_ids[contig], left, right, antisense, end, num_mm & 0xFF, (num_mm + gap) & 0xFF, rl, spl, jstrand == "rev")
+            if ref_id2 is not None:
+                rec += (ref_id2, flipped)
+            yield rec
