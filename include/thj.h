@@ -84,6 +84,7 @@ typedef struct {
     int32_t bowtie2_ref_gap_cont;
     int32_t fusion_anchor_length;  /* common.cpp:172 */
     int32_t fusion_min_dist;       /* common.cpp:173 */
+    int32_t fusion_search;         /* common.cpp:171 (--fusion-search); long_spanning_reads only: thj_span_run_async */
 } thj_params;
 
 /* Fills `p` with the defaults of common.cpp:79-180. */
@@ -254,6 +255,16 @@ int thj_genome_gather(thj_ctx* ctx, const thj_piece* pieces, int64_t n, const in
 #define THJ_CIG_DEL       5u
 #define THJ_CIG_REF_SKIP 11u
 #define THJ_CIG_SOFT_CLIP 13u
+/* --fusion-search: the lower-case (running down the genome) forms and the four fusion ops, whose length is the 0-based
+ * position on the second contig (bwt_map.h:36-55; print_bamhit writes them as m / i / d / n and <pos + 1>F) */
+#define THJ_CIG_mATCH     2u
+#define THJ_CIG_iNS       4u
+#define THJ_CIG_dEL       6u
+#define THJ_CIG_FUSION_FF 7u
+#define THJ_CIG_FUSION_FR 8u
+#define THJ_CIG_FUSION_RF 9u
+#define THJ_CIG_FUSION_RR 10u
+#define THJ_CIG_rEF_SKIP 12u
 
 /* A segment alignment with its CIGAR: BowtieHit as produced by BAMHitFactory /
  * SplicedBAMHitFactory (bwt_map.cpp:1101-1452, :1469-1770). 32 bytes. */
@@ -267,6 +278,11 @@ typedef struct {
     uint32_t cigar[5];
 } thj_span_hit;
 #define THJ_HIT_ANTISENSE_SPLICE 4u
+/* A segment hit on a fusion contig of the junction database (SplicedBAMHitFactory, bwt_map.cpp:1655-1760) has a fusion op in
+ * its cigar, at most 4 ops, and its second contig (ref_id2) in cigar[4].  On rf / rr contigs antisense_align is the opposite
+ * of the record's strand flag (:1744-1745): THJ_HIT_STRAND_FLIPPED says so, i.e. the record's SEQ is the read piece
+ * reverse-complemented iff THJ_HIT_ANTISENSE xor THJ_HIT_STRAND_FLIPPED. */
+#define THJ_HIT_STRAND_FLIPPED 8u
 
 /* Per-read segment hit lists of JoinSegmentsWorker (long_spanning_reads.cpp:2669-2845):
  * for every read with a hit in the first segment map, segment s holds the contig
@@ -301,7 +317,8 @@ typedef struct {
     int16_t  AS;
     uint8_t  XM, XO, XG, md_len;
     uint16_t order;        /* rank among the read's records (BowtieHit::operator<, bwt_map.h:180-207) */
-    uint32_t cigar[16];
+    uint32_t cigar[16];    /* a fusion alignment (one of its ops is THJ_CIG_FUSION_*) has at most 15 ops and its second contig,
+                              ref_id2, in cigar[15] */
     char     md[40];       /* MD:Z value, md_len characters; md_len == THJ_MD_ON_HOST: longer than the record holds -- thj_md_string */
 } thj_aln;
 #define THJ_MD_ON_HOST 255
@@ -310,6 +327,10 @@ typedef struct {
  * NUL-terminated string, returns its length (< 0: error).  For the records the device flags with THJ_MD_ON_HOST. */
 int thj_md_string(const char* ref, int64_t ref_len, const char* seq, int32_t seq_len, int32_t left, const uint32_t* cigar, int32_t n_cigar,
                   char* out, int32_t out_cap);
+/* The same for an alignment that may run down the genome (lower-case ops) and change contigs at a fusion op: ref2 = the
+ * second contig (= ref for a plain alignment). */
+int thj_md_string2(const char* ref, int64_t ref_len, const char* ref2, int64_t ref2_len, const char* seq, int32_t seq_len, int32_t left,
+                   const uint32_t* cigar, int32_t n_cigar, char* out, int32_t out_cap);
 
 /* The junction (+deletion) and insertion sets long_spanning_reads loads from its list
  * files (long_spanning_reads.cpp:2897-2980).  juncs: sorted unique in Junction::operator<
@@ -319,6 +340,13 @@ int thj_md_string(const char* ref, int64_t ref_len, const char* seq, int32_t seq
 int thj_span_sets_upload(thj_ctx* ctx, const thj_junction* juncs, int64_t n_juncs, const uint32_t* insertions, int64_t n_ins);
 /* Same, taken device-to-device from the context's own finished segment_juncs tables. */
 int thj_span_sets_from_segjuncs(thj_ctx* ctx);
+
+/* --fusion-search: the .fusions list long_spanning_reads loads (long_spanning_reads.cpp:2998-3040), sorted unique in
+ * Fusion::operator< order (fusions.h:44-71); dir = THJ_CIG_FUSION_*.  HOST pointer.  thj_span_run_async consults it when
+ * thj_params.fusion_search is set; the reads that are not plain runs of abutting single hits then go through the fusion
+ * branches of dfs_seg_hits / merge_chain (:2222-2610, :805-2038) in thj_k_stitch_fusion. */
+typedef struct { uint32_t ref_id1, ref_id2, left, right, dir; } thj_span_fusion;
+int thj_span_fusions_upload(thj_ctx* ctx, const thj_span_fusion* fusions, int64_t n);
 
 int thj_span_batch_upload(thj_ctx* ctx, const thj_span_batch* host, int64_t n_hits, thj_span_batch** out);
 int thj_span_batch_free(thj_ctx* ctx, thj_span_batch* dev);

@@ -213,6 +213,49 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
     return 0;
 }
 
+// ---- --fusion-search: tier 0 as the kernel runs it, then thj_span_fusion.h for every read it does not finish
+#include "../../tophat_amd/csrc/thj_span_fusion.h"
+
+extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
+                                       const int32_t* contig_len, int32_t n_contigs,
+                                       int32_t n_reads, int32_t nseg, int32_t W, const uint32_t* seg_off, const void* hits,
+                                       const uint64_t* planes, const uint16_t* read_len, const uint8_t* quals, int32_t qual_stride,
+                                       const thj_junction* juncs, int64_t n_juncs, const uint32_t* ins, int64_t n_ins,
+                                       const thj_span_fusion* fus, int64_t n_fus, int32_t skip_tier0,
+                                       void** out, int64_t* n_out, int64_t* status_counts /* [5] */) {
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    Params p;
+    memcpy(&p, tp, sizeof p);
+    std::vector<u64> jk((size_t)n_juncs), ik((size_t)n_ins);
+    std::vector<uint32_t> iseq((size_t)n_ins);
+    for (int64_t i = 0; i < n_juncs; ++i) jk[i] = junc_key(g, juncs[i].ref_id, juncs[i].left, juncs[i].right, juncs[i].antisense != 0);
+    for (int64_t i = 0; i < n_ins; ++i) { ik[i] = ins_key(g, ins[4 * i], ins[4 * i + 1], (int)ins[4 * i + 2]); iseq[i] = ins[4 * i + 3]; }
+    for (int64_t i = 1; i < n_juncs; ++i) if (jk[i] <= jk[i - 1]) return -10;
+    for (int64_t i = 1; i < n_ins; ++i) if (ik[i] <= ik[i - 1]) return -11;
+    SpanSets S{jk.data(), n_juncs, ik.data(), iseq.data(), n_ins, nullptr, 0};
+    FusionSet F{(const FusKey*)fus, n_fus};
+    std::vector<OutAln> res;
+    VecSink sink{&res};
+    for (int k = 0; k < 5; ++k) status_counts[k] = 0;
+    for (int32_t r = 0; r < n_reads; ++r) {
+        int st = SPAN_NEED_GENERIC;
+        if (!skip_tier0)
+            st = span_read_contig(g, p, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                  read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+        if ((st & 0xFF) == SPAN_NEED_LEAN) st = SPAN_NEED_GENERIC;
+        if (st == SPAN_NEED_GENERIC) {
+            status_counts[3]++;
+            st = span_read_fusion(g, p, S, F, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                  read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+        }
+        status_counts[st]++;
+    }
+    *n_out = (int64_t)res.size();
+    *out = malloc(sizeof(OutAln) * (res.size() + 1));
+    memcpy(*out, res.data(), sizeof(OutAln) * res.size());
+    return 0;
+}
+
 // ---- coverage search (thj_cov_core.h): the kernels of thj_covsearch_impl.h as plain loops over their thread index
 #include "../../tophat_amd/csrc/thj_cov_core.h"
 #include <algorithm>

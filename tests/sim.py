@@ -94,6 +94,34 @@ def spanning(p: Params, seqs, b, juncs, insertions, mode: int = 0):
     return host.alns_from_array(a, host.span_md_resolver(list(seqs), [b])), list(st)
 
 
+def spanning_fusion(p: Params, seqs, b, juncs, insertions, fusions, skip_tier0: bool = False):
+    """-> (list of Aln, status counts): tier 0 + the fusion tier (thj_span_fusion.h) compiled for the CPU; p.fusion_search decides
+    whether the fusion branches are taken"""
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    d = host.pack_span_batch(b, lib=l)
+    clen = g.lens.astype(np.int32)
+    cp = p.as_ctypes()
+    j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
+    t = host._ins_table(insertions)
+    f = np.ascontiguousarray(fusions, dtype=host.SPAN_FUSION_DTYPE)
+    out = C.c_void_p()
+    n_out = C.c_int64()
+    st = (C.c_int64 * 5)()
+    rc = l.hostsim_spanning_fusion(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
+                                   C.c_void_p(clen.ctypes.data), g.n_contigs, d["n_reads"], d["nseg"], d["W"],
+                                   C.c_void_p(d["seg_off"].ctypes.data), C.c_void_p(d["hits"].ctypes.data),
+                                   C.c_void_p(d["planes"].ctypes.data), C.c_void_p(d["read_len"].ctypes.data),
+                                   C.c_void_p(d["quals"].ctypes.data), d["qual_stride"],
+                                   C.c_void_p(j.ctypes.data), C.c_int64(len(j)), C.c_void_p(t.ctypes.data), C.c_int64(len(insertions)),
+                                   C.c_void_p(f.ctypes.data), C.c_int64(len(f)), 1 if skip_tier0 else 0,
+                                   C.byref(out), C.byref(n_out), st)
+    assert rc == 0, rc
+    a = np.frombuffer((C.c_char * (max(1, n_out.value) * 128)).from_address(out.value), dtype=host.ALN_DTYPE)[:n_out.value].copy()
+    l.hostsim_free(out)
+    return host.alns_from_array(a, host.span_md_resolver(list(seqs), [b])), list(st)
+
+
 def fusions(p: Params, seqs, b: SegBatch, ignore_ref_ids=()):
     """raw fusion events of the kernel logic, reduced like FusionSimpleSet (count, min edit_dist)"""
     import orc

@@ -198,3 +198,65 @@ def test_fuzz_long_spanning_reads(seed):
         # rebuilds them (thj_md_string) -- the records must come out all the same
         assert status[2] == 0
         assert got == want, "seed %d mode %d" % (seed, mode)
+
+
+def fusion_set_near_hits(rng, sb):
+    """fusions whose break points sit where two hits of neighbouring segments of a read end / start, in every direction and in
+    both contig orders, a few bases off as well -- what segment_juncs --fusion-search would have reported, and noise"""
+    rows = set()
+    h = sb.hits
+    for k in range(0, len(h) - 1):
+        a, b_ = h[k], h[k + 1]
+        ra = int(a["left"]) + sum(int(c & 0x0FFFFFFF) for c in a["cigar"][:a["n_cigar"]] if (c >> 28) in (1, 5, 11))
+        for d in (-2, 0, 1):
+            for (x, y) in ((ra - 1 + d, int(b_["left"]) + d), (int(a["left"]) + d, int(b_["left"]) + d), (ra - 1 + d, int(b_["left"]) + 24 + d)):
+                if x < 0 or y < 0:
+                    continue
+                dr = int(rng.integers(7, 11))
+                r1, r2 = int(a["ref_id"]), int(b_["ref_id"])
+                rows.add((r1, r2, x, y, dr))
+                if rng.random() < 0.5:
+                    rows.add((r2, r1, y, x, int(rng.integers(7, 11))))
+    return np.array(sorted(rows), dtype=orc.SPAN_FUSION_DTYPE) if rows else np.zeros(0, dtype=orc.SPAN_FUSION_DTYPE)
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_fuzz_fusion_tier(seed):
+    """the fusion tier's logic (thj_span_fusion.h compiled for the CPU) against the oracle on adversarial batches: with fusion
+    search off it is a third implementation of the plain path, with it on the fusion branches run on random hit geometry"""
+    rng = np.random.default_rng(7100 + seed)
+    seqs = rand_genome(rng, int(rng.integers(1, 4)))
+    L = int(rng.choice([20, 25, 25, 40]))
+    nseg = int(rng.choice([1, 2, 3, 4, 6]))
+    if L * (nseg + 1) > 256:
+        nseg = 256 // L - 1
+    sb = rand_span_batch(rng, seqs, 60, L, nseg)
+    p = Params(segment_length=L, max_insertion_length=int(rng.choice([1, 3])), max_deletion_length=int(rng.choice([1, 3, 10])),
+               min_report_intron=int(rng.choice([10, 50])), max_report_intron=int(rng.choice([300, 5000, 500000])),
+               read_mismatches=int(rng.choice([2, 4])), read_edit_dist=int(rng.choice([2, 5])), read_gap_length=int(rng.choice([2, 3])))
+    p.fusion_min_dist = int(rng.choice([100, 1500, 10000000]))
+    juncs = set()
+    h = sb.hits
+    for k in range(0, len(h) - 1):
+        a, b_ = h[k], h[k + 1]
+        if a["ref_id"] != b_["ref_id"]:
+            continue
+        ra = int(a["left"]) + sum(int(c & 0x0FFFFFFF) for c in a["cigar"] if (c >> 28) in (1, 5, 11))
+        for d in (-2, 0, 1):
+            l_, r_ = ra - 1 + d, int(b_["left"]) + d
+            if r_ > l_ + 1 and l_ >= 0:
+                juncs.add((int(a["ref_id"]), l_, r_, int(rng.integers(0, 2))))
+    jl = sorted(juncs)
+    ja = np.array(jl, dtype=JUNC_DTYPE) if jl else np.zeros(0, dtype=JUNC_DTYPE)
+    g = orc.Genome(seqs)
+    fus = fusion_set_near_hits(rng, sb)
+    for fs in (0, 1):
+        p.fusion_search = fs
+        want = orc.spanning_fusion(p, g, sb, ja, [], fus, bool(fs))
+        if fs == 0:
+            assert want == orc.spanning(p, g, sb, ja, [])
+        for skip0 in (False, True):
+            got, status = sim.spanning_fusion(p, seqs, sb, ja, [], fus, skip0)
+            assert status[1] == 0
+            got.sort(key=lambda a: a.read_idx)
+            assert got == want, "seed %d fusion_search %d skip_tier0 %s" % (seed, fs, skip0)

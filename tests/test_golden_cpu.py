@@ -87,3 +87,17 @@ def test_fusion_spanning_oracle_reproduces_fixture(name):
         n_fused += sum(1 for a in alns if a.is_fusion())
         assert span_records(c, sd, sb, alns) == c["exp_span_full"][sd]
     assert n_fused >= 20
+
+
+@pytest.mark.parametrize("name", FUSION_SPAN_CASES)
+def test_fusion_tier_logic_reproduces_fixture(name):
+    """the kernel headers of the fusion tier (thj_span_fusion.h behind tier 0) compiled for the CPU, on the same fixtures"""
+    c = load(name)
+    juncs, ins, fus = fusion_span_inputs(c)
+    p = copy.copy(c["p"])
+    p.fusion_search = 1
+    for sd, sb in c["span_batches"].items():
+        for skip0 in (False, True):
+            alns, st = sim.spanning_fusion(p, c["seqs"], sb, juncs, ins, fus, skip0)
+            assert st[1] == 0
+            assert span_records(c, sd, sb, alns) == c["exp_span_full"][sd]

@@ -77,7 +77,7 @@ struct Params {          // == thj_params (include/thj.h)
     int32_t read_mismatches, read_gap_length, read_edit_dist;
     int32_t bowtie2_max_penalty, bowtie2_min_penalty, bowtie2_penalty_for_N;
     int32_t bowtie2_read_gap_open, bowtie2_read_gap_cont, bowtie2_ref_gap_open, bowtie2_ref_gap_cont;
-    int32_t fusion_anchor_length, fusion_min_dist;
+    int32_t fusion_anchor_length, fusion_min_dist, fusion_search;
 };
 
 struct Planes { u64 lo, hi, nm; };

@@ -39,7 +39,7 @@ extern "C" void thj_params_default(thj_params* p) {
     p->bowtie2_max_penalty = 6; p->bowtie2_min_penalty = 2; p->bowtie2_penalty_for_N = 1;
     p->bowtie2_read_gap_open = 5; p->bowtie2_read_gap_cont = 3;
     p->bowtie2_ref_gap_open = 5; p->bowtie2_ref_gap_cont = 3;
-    p->fusion_anchor_length = 20; p->fusion_min_dist = 10000000;
+    p->fusion_anchor_length = 20; p->fusion_min_dist = 10000000; p->fusion_search = 0;
 }
 
 extern "C" int thj_genome_layout(int32_t n_contigs, const int64_t* lens, uint32_t* contig_blk, int64_t* n_blocks) {
@@ -138,34 +138,47 @@ extern "C" int thj_reads_pack(int64_t n_reads, const int64_t* read_off, const ch
 
 // MD:Z of one alignment, the way bowtie_sam_extra builds it (bwt_map.cpp:2467-2648) -- the host's part for the few records
 // whose MD string does not fit the 40 characters a device record holds (thj_aln.md_len == THJ_MD_ON_HOST).
-extern "C" int thj_md_string(const char* ref, int64_t ref_len, const char* seq, int32_t seq_len, int32_t left, const uint32_t* cigar, int32_t n_cigar,
-                             char* out, int32_t out_cap) {
-    if (!ref || !seq || !cigar || !out || out_cap < 2 || n_cigar < 0) { thj_set_error("thj_md_string: bad argument"); return THJ_EINVAL; }
+extern "C" int thj_md_string2(const char* ref, int64_t ref_len, const char* ref2, int64_t ref2_len, const char* seq, int32_t seq_len, int32_t left,
+                              const uint32_t* cigar, int32_t n_cigar, char* out, int32_t out_cap) {
+    if (!ref || !ref2 || !seq || !cigar || !out || out_cap < 2 || n_cigar < 0) { thj_set_error("thj_md_string: bad argument"); return THJ_EINVAL; }
     auto fold = [](char c) { switch (c) { case 'A': case 'a': return 'A'; case 'C': case 'c': return 'C'; case 'G': case 'g': return 'G'; case 'T': case 't': return 'T'; default: return 'N'; } };
+    auto comp = [](char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } };
     int n = 0;
     auto put = [&](char c) { if (n + 1 < out_cap) out[n] = c; ++n; };
     auto put_int = [&](int v) { char b[16]; int k = snprintf(b, sizeof b, "%d", v); for (int i = 0; i < k; ++i) put(b[i]); };
+    const bool plain = ref2 == ref;
+    // past the contig: the device genome's zero guard block for the plain tiers, N (seqan's infix) for the fusion tier
+    auto at = [&](const char* r, int64_t rl, int64_t pos) { return pos >= 0 && pos < rl ? fold(r[pos]) : (plain ? 'A' : 'N'); };
     int64_t pos_ref = left;
     int pos_seq = 0, pos_mm = 0;
+    bool saw = false;
     for (int i = 0; i < n_cigar; ++i) {
         const uint32_t op = cigar[i] >> 28; const int len = (int)(cigar[i] & 0x0FFFFFFFu);
-        if (op == THJ_CIG_MATCH) {
+        if (op == THJ_CIG_MATCH || op == THJ_CIG_mATCH) {
             for (int k = 0; k < len && pos_seq + k < seq_len; ++k) {
-                const int64_t rp = pos_ref + k;
-                const char r = rp >= 0 && rp < ref_len ? fold(ref[rp]) : 'A';         // past the contig: the device genome's zero guard block
+                const char r = op == THJ_CIG_MATCH ? at(ref, ref_len, pos_ref + k) : comp(at(ref, ref_len, pos_ref - k));
                 const char s = fold(seq[pos_seq + k]);
                 if (r != s) { put_int(pos_mm); put(r); pos_mm = 0; } else ++pos_mm;
             }
-            pos_seq += len; pos_ref += len;
-        } else if (op == THJ_CIG_INS) pos_seq += len;
-        else if (op == THJ_CIG_DEL) {
+            pos_seq += len; pos_ref += op == THJ_CIG_MATCH ? len : -len;
+        } else if (op == THJ_CIG_INS || op == THJ_CIG_iNS) pos_seq += len;
+        else if (op == THJ_CIG_DEL || op == THJ_CIG_dEL) {
             put_int(pos_mm); put('^');
-            for (int k = 0; k < len && k < 64; ++k) { const int64_t rp = pos_ref + k; put(rp >= 0 && rp < ref_len ? fold(ref[rp]) : 'A'); }
-            pos_ref += len; pos_mm = 0;
+            for (int k = 0; k < len && k < 64; ++k) put(op == THJ_CIG_DEL ? at(ref, ref_len, pos_ref + k) : comp(at(ref, ref_len, pos_ref - k)));
+            pos_ref += op == THJ_CIG_DEL ? len : -len; pos_mm = 0;
         } else if (op == THJ_CIG_REF_SKIP) pos_ref += len;
+        else if (op == THJ_CIG_rEF_SKIP) pos_ref -= len;
+        else if (op >= THJ_CIG_FUSION_FF && op <= THJ_CIG_FUSION_RR) {
+            if (saw) { n = 0; break; }
+            ref = ref2; ref_len = ref2_len; pos_ref = len; saw = true;
+        }
     }
     put_int(pos_mm);
     if (n + 1 > out_cap) { thj_set_error("thj_md_string: %d characters do not fit the buffer", n); return THJ_EINVAL; }
     out[n] = 0;
     return n;
+}
+extern "C" int thj_md_string(const char* ref, int64_t ref_len, const char* seq, int32_t seq_len, int32_t left, const uint32_t* cigar, int32_t n_cigar,
+                             char* out, int32_t out_cap) {
+    return thj_md_string2(ref, ref_len, ref, ref_len, seq, seq_len, left, cigar, n_cigar, out, out_cap);
 }

@@ -17,6 +17,7 @@
 
 #include "../../include/thj.h"
 #include "thj_span_core.h"
+#include "thj_span_fusion.h"
 #include "thj_ctx.h"
 
 using namespace thj;
@@ -129,6 +130,7 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
         if (r < c1) {
             int st = span_read_contig_pre<MS>(g, p, b.hits, sv, b.nseg, b.planes + (u64)r * (uint32_t)(3 * b.W), b.W,
                                           rl, b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss, b.heads);
+            if (p.fusion_search && (st & 0xFF) == SPAN_NEED_LEAN) st = SPAN_NEED_GENERIC;     // fusion search: thj_k_stitch_fusion takes every read tier 0 does not finish
             if ((st & 0xFF) == SPAN_NEED_LEAN) {
                 const unsigned int cls = NC > 1 ? (unsigned int)(st >> 8) : 0u;
                 t.wl_lean[(u64)(cls * gridDim.x + blockIdx.x) * (uint32_t)t.chunk + atomicAdd(&s_lean[cls], 1u)] = r;
@@ -266,6 +268,26 @@ __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, 
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
 }
 
+// --fusion-search: every read tier 0 did not finish (the multihit list holds them all), through the fusion branches of
+// dfs_seg_hits / merge_chain on general per-thread arrays (thj_span_fusion.h).
+__global__ __launch_bounds__(64) void thj_k_stitch_fusion(Genome g, Params p, SpanSets S, FusionSet F, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    __shared__ unsigned int s_off[MAX_SLICES + 1];
+    __shared__ unsigned int s_rec;
+    if (threadIdx.x == 0) s_rec = 0;
+    const unsigned int total = slice_offsets<64>(t.blk_multi, G, s_off);
+    for (unsigned int i = blockIdx.x * 64 + threadIdx.x; i < total; i += gridDim.x * 64) {
+        const int sl = slice_of(s_off, G, i);
+        const int r = (int)t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])];
+        int st = span_read_fusion(g, p, S, F, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
+                                  (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        sink.done((uint32_t)r);
+        if (st) atomicAdd(&sink.status[st], 1u);
+    }
+    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
+}
+
 __global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u64* vals, int64_t n, u64* okeys, uint32_t* oseq) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         okeys[i] = keys[i];
@@ -298,7 +320,7 @@ static int build_junc_buckets(thj_ctx* c) {
 static void jb_free(thj_ctx* c);
 void thj_span_free(thj_ctx* c) {
     jb_free(c);
-    hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket);
+    hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket); hipFree(c->d_span_fus);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -518,6 +540,26 @@ static int check_span_params(const thj_params* p, const thj_span_batch* b) {
     return THJ_OK;
 }
 
+extern "C" int thj_span_fusions_upload(thj_ctx* c, const thj_span_fusion* f, int64_t n) {
+    if (!c || n < 0 || (n > 0 && !f)) { thj_set_error("thj_span_fusions_upload: bad argument"); return THJ_EINVAL; }
+    static_assert(sizeof(thj_span_fusion) == sizeof(FusKey), "fusion key layout");
+    for (int64_t i = 1; i < n; ++i) {
+        const FusKey a{f[i - 1].ref_id1, f[i - 1].ref_id2, f[i - 1].left, f[i - 1].right, f[i - 1].dir}, b{f[i].ref_id1, f[i].ref_id2, f[i].left, f[i].right, f[i].dir};
+        if (f_fus_cmp(a, b) >= 0) { thj_set_error("thj_span_fusions_upload: the list must be sorted unique in Fusion::operator< order"); return THJ_EINVAL; }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->cap_span_fus < n || !c->d_span_fus) {
+        hipFree(c->d_span_fus); c->d_span_fus = nullptr; c->cap_span_fus = 0;
+        const int64_t cap = n + n / 4 + 64;
+        HIPCHK(hipMalloc(&c->d_span_fus, (size_t)cap * sizeof(FusKey)));
+        c->cap_span_fus = cap;
+    }
+    if (n) HIPCHK(hipMemcpyAsync(c->d_span_fus, f, (size_t)n * sizeof(FusKey), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_span_fus = n;
+    return THJ_OK;
+}
+
 extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db) {
     if (!c || !tp || !db) { thj_set_error("thj_span_run_async: null argument"); return THJ_EINVAL; }
     if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
@@ -570,15 +612,23 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
-    const int64_t g1 = G, g2 = G;
-    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
-    else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
-    if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
-    const int caph = b.nseg <= 4 ? 12 : 16;           // hit heads staged per read in tier 2 (16 bytes each)
-    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_multihit<4>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
-    else hipLaunchKernelGGL(thj_k_stitch_multihit<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
-    if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
-    hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+    if (p.fusion_search) {
+        FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
+        int64_t gf = ((int64_t)b.n_reads + 63) / 64;
+        if (gf > 8192) gf = 8192;
+        if (c->span_profile) { HIPCHK(hipEventRecord(ev[2], c->stream)); HIPCHK(hipEventRecord(ev[3], c->stream)); }
+        hipLaunchKernelGGL(thj_k_stitch_fusion, dim3((unsigned)gf), dim3(64), 0, c->stream, g, p, S, F, b, sink, t, (int)G);
+    } else {
+        const int64_t g1 = G, g2 = G;
+        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+        else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+        if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
+        const int caph = b.nseg <= 4 ? 12 : 16;           // hit heads staged per read in tier 2 (16 bytes each)
+        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_multihit<4>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
+        else hipLaunchKernelGGL(thj_k_stitch_multihit<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
+        if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
+        hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+    }
     if (c->span_profile) {
         HIPCHK(hipEventRecord(ev[4], c->stream));
         for (int k = 0; k < 4; ++k) c->span_prof_events.emplace_back(ev[k], ev[k + 1]);

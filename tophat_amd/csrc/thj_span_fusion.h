@@ -1,0 +1,887 @@
+// long_spanning_reads --fusion-search: the fusion branches of dfs_seg_hits / merge_segment_chain / merge_chain
+// (long_spanning_reads.cpp:2222-2610, :2101-2220, :805-2038), BowtieHit::reverse (bwt_map.h:331-442) and the
+// two-contig forms of check_editdist_consistency / bowtie_sam_extra (bwt_map.cpp:2349-2648).
+//
+// One thread per read, general arrays: this is the tier the stitch kernels hand a read to when fusion search is on and
+// the read is not a plain run of abutting single hits (those come out the same with or without fusion search and stay in
+// tier 0).  What differs from the other tiers' data model:
+//   * a hit has two contigs (ref_id, ref_id2) and its cigar may run down the genome (lower-case ops) or jump (a fusion op
+//     whose length is the position on the second contig);
+//   * hits are reversed one by one (BowtieHit::reverse), so "the chain's sequence" is no longer the read or its reverse
+//     complement: a hit's sequence is a list of whole read segments, each forward or reverse-complemented -- 4 bits per
+//     segment in one 64-bit word (FHit::sq), read through f_seq_code().
+// Genome bases are read one at a time with the contig bounds checked (outside = N, as seqan's infix gives the oracle).
+#pragma once
+#include "thj_span_core.h"
+
+namespace thj {
+
+enum { OP_FUS_FF = 7, OP_FUS_FR = 8, OP_FUS_RF = 9, OP_FUS_RR = 10 };
+enum { SH_FLIPPED = 8 };                      // == THJ_HIT_STRAND_FLIPPED
+static constexpr int FUS_MAXC = 16;           // cigar ops of a (joined) hit; cigar[15] of an output record carries ref_id2
+static constexpr int FUS_MAXJOIN = 24;        // joined alignments kept per read before sort + unique
+
+struct FusKey { uint32_t ref1, ref2, left, right, dir; };      // == thj_span_fusion; Fusion::operator< order (fusions.h:44-71)
+struct FusionSet { const FusKey* keys; int64_t n; };
+
+struct FHit {
+    uint32_t ref_id, ref_id2;
+    int32_t left;
+    int32_t n;                 // 0 = BowtieHit()
+    uint32_t c[FUS_MAXC];
+    uint8_t anti, asplice, mm, ed;
+    uint8_t end, nsq, pad0, pad1;
+    u64 sq;                    // nsq pieces, 4 bits each, first piece in the low nibble: segment index | rc << 3
+};
+
+struct FRead {                 // the read a thread works on
+    const u64* rp; int W, rl, L, nsegs;
+    const uint8_t* qual;
+};
+
+THJ_HD bool f_is_fusion_op(int op) { return op >= OP_FUS_FF && op <= OP_FUS_RR; }
+THJ_HD int f_comp(int c) { return c >= 4 ? 4 : 3 - c; }
+THJ_HD int f_read_code(const FRead& r, int j) {           // base j of the read: 0..3, 4 = N, 5 = out of range
+    if (j < 0 || j >= r.rl) return 5;
+    const int w = j >> 6, b = j & 63;
+    if ((r.rp[2 * r.W + w] >> b) & 1ull) return 4;
+    return (int)(((r.rp[w] >> b) & 1ull) | (((r.rp[r.W + w] >> b) & 1ull) << 1));
+}
+THJ_HD int f_piece_len(const FRead& r, int seg) { return seg == r.nsegs - 1 ? r.rl - seg * r.L : r.L; }
+THJ_HD int f_seq_len(const FRead& r, const FHit& h) {
+    int l = 0;
+    for (int k = 0; k < h.nsq; ++k) l += f_piece_len(r, (int)((h.sq >> (4 * k)) & 7));
+    return l;
+}
+// base i of the hit's sequence; 5 when i is outside it
+THJ_HD int f_seq_code(const FRead& r, const FHit& h, int i) {
+    if (i < 0) return 5;
+    for (int k = 0; k < h.nsq; ++k) {
+        const int e = (int)((h.sq >> (4 * k)) & 15), seg = e & 7, pl = f_piece_len(r, seg);
+        if (i < pl) {
+            if (e & 8) return f_comp(f_read_code(r, seg * r.L + pl - 1 - i));
+            return f_read_code(r, seg * r.L + i);
+        }
+        i -= pl;
+    }
+    return 5;
+}
+// position in the read (for the quality string) of base i of the hit's sequence, -1 outside
+THJ_HD void f_seq_reverse(FHit& h) {
+    u64 o = 0;
+    for (int k = 0; k < h.nsq; ++k) o |= (((h.sq >> (4 * k)) & 15) ^ 8ull) << (4 * (h.nsq - 1 - k));
+    h.sq = o;
+}
+THJ_HD bool f_seq_is_read(const FRead& r, const FHit& h) {          // new_hit.seq() == read_seq
+    if (f_seq_len(r, h) != r.rl) return false;
+    bool ident = h.nsq == r.nsegs;
+    for (int k = 0; ident && k < h.nsq; ++k) ident = ((h.sq >> (4 * k)) & 15) == (u64)k;
+    if (ident) return true;
+    for (int i = 0; i < r.rl; ++i) if (f_seq_code(r, h, i) != f_read_code(r, i)) return false;
+    return true;
+}
+THJ_HD int g_code(const Genome& g, uint32_t ref_id, int64_t pos) {   // Dna5 of the contig at pos, N outside
+    if (pos < 0 || pos >= (int64_t)g_len(g, ref_id)) return 4;
+    return plane_code(g_fetch(g, ref_id, pos), 0);
+}
+THJ_HD int g_code_rc(const Genome& g, uint32_t ref_id, int64_t pos) { return f_comp(g_code(g, ref_id, pos)); }
+
+THJ_HD int f_right(const FHit& h) {                                  // bwt_map.h:213-243
+    int r = h.left;
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]), len = (int)cig_len(h.c[i]);
+        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) r += len;
+        else if (op == OP_mATCH || op == OP_rEF_SKIP || op == OP_dEL) r -= len;
+        else if (f_is_fusion_op(op)) r = len;
+    }
+    return r;
+}
+THJ_HD int f_read_len(const FHit& h) {                               // bwt_map.h:141-163
+    int l = 0;
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]);
+        if (op == OP_MATCH || op == OP_mATCH || op == OP_INS || op == OP_iNS || op == OP_SOFT_CLIP) l += (int)cig_len(h.c[i]);
+    }
+    return l;
+}
+THJ_HD bool f_spliced(const FHit& h) {
+    for (int i = 0; i < h.n; ++i) { const int op = cig_op(h.c[i]); if (op == OP_REF_SKIP || op == OP_rEF_SKIP) return true; }
+    return false;
+}
+THJ_HD int f_fusion_opcode(const FHit& h) {
+    for (int i = 0; i < h.n; ++i) if (f_is_fusion_op(cig_op(h.c[i]))) return cig_op(h.c[i]);
+    return 0;
+}
+THJ_HD bool f_fwd_op(int op) { return op == OP_MATCH || op == OP_REF_SKIP || op == OP_INS || op == OP_DEL; }
+THJ_HD bool f_rev_op(int op) { return op == OP_mATCH || op == OP_rEF_SKIP || op == OP_iNS || op == OP_dEL; }
+THJ_HD bool f_forwarding_left(const FHit& h) {                       // bwt_map.h:271-289
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]);
+        if (f_fwd_op(op)) return true;
+        if (f_rev_op(op)) return false;
+        if (f_is_fusion_op(op)) break;
+    }
+    return true;
+}
+THJ_HD bool f_forwarding_right(const FHit& h) {                      // bwt_map.h:295-313
+    for (int i = h.n - 1; i >= 0; --i) {
+        const int op = cig_op(h.c[i]);
+        if (f_fwd_op(op)) return true;
+        if (f_rev_op(op)) return false;
+        if (f_is_fusion_op(op)) break;
+    }
+    return true;
+}
+THJ_HD bool f_anti2(const FHit& h) {                                 // bwt_map.h:319-329
+    const int f = f_fusion_opcode(h);
+    if (f == 0 || f == OP_FUS_FF || f == OP_FUS_RR) return h.anti != 0;
+    return h.anti == 0;
+}
+THJ_HD int f_flip_case(int op) {
+    switch (op) {
+    case OP_MATCH: return OP_mATCH; case OP_mATCH: return OP_MATCH;
+    case OP_INS: return OP_iNS; case OP_iNS: return OP_INS;
+    case OP_DEL: return OP_dEL; case OP_dEL: return OP_DEL;
+    case OP_REF_SKIP: return OP_rEF_SKIP; case OP_rEF_SKIP: return OP_REF_SKIP;
+    default: return op;
+    }
+}
+// BowtieHit::reverse, bwt_map.h:331-442 (in place)
+THJ_HD void f_reverse(FHit& h) {
+    uint32_t right = (uint32_t)h.left, fusion_pos = (uint32_t)h.left;
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]); const uint32_t len = cig_len(h.c[i]);
+        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) right += len;
+        else if (op == OP_mATCH || op == OP_rEF_SKIP || op == OP_dEL) right -= len;
+        else if (f_is_fusion_op(op)) { fusion_pos = right; right = len; }
+    }
+    const bool fl = f_forwarding_left(h);
+    if (fl) fusion_pos -= 1; else fusion_pos += 1;
+    const int f = f_fusion_opcode(h);
+    int32_t nleft;
+    if (f == 0 || f == OP_FUS_FF || f == OP_FUS_RR) nleft = fl ? (int32_t)(right - 1) : (int32_t)(right + 1);
+    else nleft = f == OP_FUS_FR ? (int32_t)(right + 1) : (int32_t)(right - 1);
+    for (int i = 0, k = h.n - 1; i <= k; ++i, --k) {
+        const uint32_t a = h.c[i], b = h.c[k];
+        const int oa = cig_op(a), ob = cig_op(b);
+        h.c[i] = f_is_fusion_op(ob) ? cig(ob, fusion_pos) : cig(f_flip_case(ob), cig_len(b));
+        if (k != i) h.c[k] = f_is_fusion_op(oa) ? cig(oa, fusion_pos) : cig(f_flip_case(oa), cig_len(a));
+    }
+    const uint32_t t = h.ref_id; h.ref_id = h.ref_id2; h.ref_id2 = t;
+    h.left = nleft;
+    if (f == OP_FUS_FR || f == OP_FUS_RF) h.anti = h.anti ? 0 : 1;
+    f_seq_reverse(h);
+}
+THJ_HD int f_gap_length(const uint32_t* c, int n) {                  // bwt_map.cpp:32-43
+    int e = 0;
+    for (int i = 0; i < n; ++i) { const int op = cig_op(c[i]); if (op == OP_INS || op == OP_iNS || op == OP_DEL || op == OP_dEL) e += (int)cig_len(c[i]); }
+    return e;
+}
+// fusions_from_spliced_hit(bh, fusions, auto_sort = false)[0] (fusions.cpp:441-495)
+THJ_HD bool f_first_fusion(const FHit& h, uint32_t& fl, uint32_t& fr) {
+    uint32_t pos = (uint32_t)h.left;
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]); const uint32_t len = cig_len(h.c[i]);
+        if (op == OP_REF_SKIP || op == OP_MATCH || op == OP_DEL) pos += len;
+        else if (op == OP_rEF_SKIP || op == OP_mATCH || op == OP_dEL) pos -= len;
+        else if (f_is_fusion_op(op)) { pos = (op == OP_FUS_RF || op == OP_FUS_RR) ? pos + 1 : pos - 1; fl = pos; fr = len; return true; }
+    }
+    return false;
+}
+THJ_HD void f_reverse_if_needed(FHit& h) {                           // :1985-1999, :2201-2216
+    bool rev = h.ref_id > h.ref_id2;
+    if (h.ref_id == h.ref_id2) { uint32_t fl, fr; if (f_first_fusion(h, fl, fr)) rev = fl > fr; }
+    if (rev) f_reverse(h);
+}
+
+// check_editdist_consistency, bwt_map.cpp:2349-2465
+THJ_HD bool f_check_editdist(const Genome& g, const FRead& rd, const FHit& h) {
+    if (g_len(g, h.ref_id) == 0 || g_len(g, h.ref_id2) == 0) return false;
+    uint32_t ref = h.ref_id;
+    int pos_seq = 0, mismatch = 0, n_mism = 0;
+    int64_t pos_ref = h.left;
+    bool saw = false;
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]); const int len = (int)cig_len(h.c[i]);
+        if (op == OP_MATCH || op == OP_mATCH) {
+            for (int j = 0; j < len; ++j) {
+                int s = f_seq_code(rd, h, pos_seq); if (s > 4) s = 4;
+                const int r = op == OP_MATCH ? g_code(g, ref, pos_ref + j) : g_code_rc(g, ref, pos_ref - j);
+                if (s != r) ++mismatch;
+                if (s == r && s == 4) ++n_mism;
+                ++pos_seq;
+            }
+            pos_ref += op == OP_MATCH ? len : -len;
+        } else if (op == OP_INS || op == OP_iNS) pos_seq += len;
+        else if (op == OP_DEL || op == OP_REF_SKIP) pos_ref += len;
+        else if (op == OP_dEL || op == OP_rEF_SKIP) pos_ref -= len;
+        else if (f_is_fusion_op(op)) {
+            if (saw) return false;
+            ref = h.ref_id2; pos_ref = len; saw = true;
+        }
+    }
+    return mismatch == (int)h.mm || mismatch + n_mism == (int)h.mm;
+}
+
+// Fusion::operator< bounds over the sorted fusion list (std::set::upper_bound / lower_bound, :1631-1632)
+THJ_HD int f_fus_cmp(const FusKey& a, const FusKey& b) {
+    if (a.ref1 != b.ref1) return a.ref1 < b.ref1 ? -1 : 1;
+    if (a.ref2 != b.ref2) return a.ref2 < b.ref2 ? -1 : 1;
+    if (a.left != b.left) return a.left < b.left ? -1 : 1;
+    if (a.right != b.right) return a.right < b.right ? -1 : 1;
+    if (a.dir != b.dir) return a.dir < b.dir ? -1 : 1;
+    return 0;
+}
+THJ_HD int64_t f_fus_upper(const FusionSet& F, const FusKey& k) {
+    int64_t lo = 0, hi = F.n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (f_fus_cmp(k, F.keys[m]) < 0) hi = m; else lo = m + 1; }
+    return lo;
+}
+THJ_HD int64_t f_fus_lower(const FusionSet& F, const FusKey& k) {
+    int64_t lo = 0, hi = F.n;
+    while (lo < hi) { const int64_t m = (lo + hi) >> 1; if (f_fus_cmp(F.keys[m], k) < 0) lo = m + 1; else hi = m; }
+    return lo;
+}
+
+// the cigar of a closed pair: prev's ops with the last one set to `back_len` (dropped when <= 0), the closing op, curr's ops
+// with the first one set to `front_len` (dropped when <= 0)
+THJ_HD int f_splice(uint32_t* out, const FHit& prev, int back_len, bool back_u32_zero_drop, uint32_t mid, const FHit& curr, int64_t front_len) {
+    int n = 0;
+    for (int q = 0; q < prev.n; ++q) out[n++] = prev.c[q];
+    if (back_u32_zero_drop ? ((uint32_t)back_len & 0x0FFFFFFFu) == 0 : back_len <= 0) --n;
+    else out[n - 1] = cig(cig_op(out[n - 1]), (uint32_t)back_len);
+    out[n++] = mid;
+    for (int q = (front_len > 0 ? 0 : 1); q < curr.n; ++q) out[n++] = q == 0 ? cig(cig_op(curr.c[0]), (uint32_t)front_len) : curr.c[q];
+    return n;
+}
+
+// merge_chain, long_spanning_reads.cpp:805-2038.  chain[0..n) in chain order; false = BowtieHit().
+THJ_HD bool f_merge_chain(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const FRead& rd, FHit* chain, int n,
+                          int fusion_dir, FHit& out) {
+    const int L = p.segment_length;
+    int antisense = chain[0].anti;
+    const int left = chain[0].left;
+    u64 seq_sq = 0; int seq_nsq = 0;
+    int old_read_length = 0;
+    for (int i = 0; i < n; ++i) {                                             // :826-831
+        if (seq_nsq + chain[i].nsq > 16) return false;
+        seq_sq |= chain[i].sq << (4 * seq_nsq); seq_nsq += chain[i].nsq;
+        old_read_length += f_read_len(chain[i]);
+    }
+    {                                                                         // :843-897
+        int num_fusions = f_fusion_opcode(chain[0]) == 0 ? 0 : 1;
+        bool passed = false;
+        for (int k = 1; k < n; ++k) {
+            const FHit& prev = chain[k - 1]; const FHit& curr = chain[k];
+            if (prev.ref_id != prev.ref_id2 || prev.ref_id2 != curr.ref_id) passed = true;
+            if (prev.ref_id2 != curr.ref_id) ++num_fusions;
+            if (f_fusion_opcode(curr) != 0) ++num_fusions;
+            if (prev.ref_id2 == curr.ref_id) {
+                const bool reversed = (fusion_dir == OP_FUS_FR && passed) || (fusion_dir == OP_FUS_RF && !passed);
+                const int gap = reversed ? f_right(prev) - curr.left : curr.left - f_right(prev);
+                const int maxi = p.max_report_intron < p.fusion_min_dist ? p.max_report_intron : p.fusion_min_dist;
+                if (gap < -p.max_insertion_length || (gap > p.max_deletion_length && (gap < p.min_report_intron || gap > maxi))) {
+                    passed = true; ++num_fusions;
+                }
+            }
+            if (num_fusions >= 2) return false;
+        }
+    }
+    int pi = 0, ci = 1, curr_seg_index = 1;
+    bool fusion_passed = false;
+    while (ci < n) {
+        FHit& prev = chain[pi]; FHit& curr = chain[ci];
+        antisense = prev.anti;
+        if (f_fusion_opcode(prev) != 0 || prev.ref_id2 != curr.ref_id) fusion_passed = true;
+        if (!(op_is_match(cig_op(prev.c[prev.n - 1])) || op_is_match(cig_op(curr.c[0])))) return false;
+        if (f_spliced(prev) && f_spliced(curr) && prev.asplice != curr.asplice) return false;
+        bool found = false;
+        int antisense_closure = f_spliced(prev) ? prev.asplice : curr.asplice;
+        uint32_t nc[2 * FUS_MAXC + 2]; int nn = 0;
+        int mismatch = 0;
+        const int prev_end = (int)cig_len(prev.c[prev.n - 1]);
+        const int curr_front = (int)cig_len(curr.c[0]);
+        bool check_fusion = prev.ref_id2 != curr.ref_id;
+        const int prev_right = f_right(prev);
+        if (prev.ref_id2 == curr.ref_id) {
+            const bool reversed = (fusion_dir == OP_FUS_FR && fusion_passed) || (fusion_dir == OP_FUS_RF && !fusion_passed);
+            const uint32_t ref = prev.ref_id2;
+            const bool have_ref = g_len(g, ref) != 0;
+            int lbnd, rbnd;
+            if (reversed) { lbnd = curr.left - 4; rbnd = prev_right + 4; } else { lbnd = prev_right - 4; rbnd = curr.left + 4; }
+            const int dist = reversed ? prev_right - curr.left : curr.left - prev_right;
+            const bool same_strand = f_anti2(prev) == (curr.anti != 0);
+            if (dist < 0 && dist >= -p.max_insertion_length && same_strand) {
+                // ---- insertion closure :1010-1306
+                if (!have_ref) return false;
+                int64_t lb = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)lbnd, 0));
+                const int64_t ub = upper_bound_u64(S.ins_keys, S.n_ins, ins_key(g, ref, (uint32_t)rbnd, p.max_insertion_length));
+                const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
+                for (; lb < ub; ++lb) {
+                    const u64 k = S.ins_keys[lb];
+                    const int ilen = (int)(k & 15);
+                    const int ileft = (int)((int64_t)(k >> 4) - 1 - (int64_t)cbase);
+                    if (ilen != (reversed ? curr.left - prev_right : prev_right - curr.left)) continue;
+                    int itpr, clti;
+                    if (reversed) { itpr = ileft - prev_right; clti = curr.left - ileft; }
+                    else { itpr = prev_right - ileft - 1; clti = ileft - curr.left + 1; }
+                    if (itpr > prev_end || clti > curr_front) continue;
+                    const uint32_t iseq = S.ins_seq[lb];
+                    int trm = 0, ins_mm = 0;
+                    const int prev_sl = f_seq_len(rd, prev);
+                    for (int ri = 0; ri < itpr; ++ri) {
+                        int r, o, r2;
+                        if (reversed) {
+                            r = g_code_rc(g, ref, (int64_t)ileft - ri);
+                            o = f_read_code(rd, curr_seg_index * L - itpr + ri);
+                            r2 = g_code_rc(g, ref, (int64_t)ileft - (ri - ilen));
+                        } else {
+                            r = g_code(g, ref, (int64_t)ileft + 1 + ri);
+                            o = f_seq_code(rd, prev, prev_sl - itpr + ri);
+                            r2 = g_code(g, ref, (int64_t)ileft + 1 + ri - ilen);
+                        }
+                        if (o > 4) o = 4;
+                        if (r == 4 || r != o) ++trm;
+                        if (ri < ilen) {
+                            int ic = reversed ? f_comp((int)((iseq >> (3 * (ilen - 1 - ri))) & 7u)) : (int)((iseq >> (3 * ri)) & 7u);
+                            if (ic == 4 || ic != o) { ++ins_mm; break; }
+                        } else if (r2 == 4 || r2 != o) --trm;
+                    }
+                    for (int ri = 0; ri < clti; ++ri) {
+                        const int sp = clti - ri - 1, ip = ilen - ri - 1;
+                        int r, o, r2;
+                        if (reversed) {
+                            r = g_code_rc(g, ref, (int64_t)curr.left - sp);
+                            o = f_read_code(rd, curr_seg_index * L + sp);
+                            r2 = g_code_rc(g, ref, (int64_t)curr.left - (sp + ilen));
+                        } else {
+                            r = g_code(g, ref, (int64_t)curr.left + sp);
+                            o = f_seq_code(rd, curr, sp);
+                            r2 = g_code(g, ref, (int64_t)curr.left + sp + ilen);
+                        }
+                        if (o > 4) o = 4;
+                        if (r == 4 || r != o) ++trm;
+                        if (ri < ilen) {
+                            int ic = reversed ? f_comp((int)((iseq >> (3 * (ilen - 1 - ip))) & 7u)) : (int)((iseq >> (3 * ip)) & 7u);
+                            if (ic == 4 || ic != o) { ++ins_mm; break; }
+                        } else if (r2 == 4 || r2 != o) --trm;
+                    }
+                    if (found) return false;                                           // :1243-1247
+                    if (ins_mm == 0) {
+                        mismatch = -trm;
+                        found = true;
+                        nn = f_splice(nc, prev, prev_end - itpr, true, cig(reversed ? OP_iNS : OP_INS, (uint32_t)ilen), curr,
+                                      (int64_t)((cig_len(curr.c[0]) + (uint32_t)(itpr - ilen)) & 0x0FFFFFFFu));
+                    }
+                }
+                if (!found) return false;
+            } else if (dist > 0 && dist <= p.max_report_intron && same_strand) {
+                // ---- junction / deletion closure :1311-1591
+                if (!have_ref) return false;
+                int64_t lb, ub;
+                junc_range(S, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true), junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false), lb, ub);
+                const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
+                int best = 0xff;
+                const int prev_sl = f_seq_len(rd, prev);
+                for (; lb < ub; ++lb) {
+                    const u64 k = S.junc_keys[lb];
+                    const int jl = (int)((int64_t)(k >> 30) - 1 - (int64_t)cbase);
+                    const int jr = jl + (int)((k >> 1) & ((1ull << 29) - 1));
+                    int dtl, dtr;
+                    if (reversed) { dtl = jl - curr.left; dtr = jr - prev_right - 1; } else { dtl = jl - prev_right + 1; dtr = jr - curr.left; }
+                    if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
+                    if ((reversed && (dtl > prev_end || -dtl > curr_front)) || (!reversed && (dtl > curr_front || -dtl > prev_end))) continue;
+                    int new_mm = 0, old_mm = 0;
+                    if (dtl > 0) {
+                        for (int i = 0; i < dtl; ++i) {
+                            int s, a, b;
+                            if (reversed) {
+                                s = f_read_code(rd, curr_seg_index * L - dtl + i);
+                                a = g_code_rc(g, ref, (int64_t)jl - i); b = g_code_rc(g, ref, (int64_t)jr - 1 - i);
+                            } else {
+                                s = f_seq_code(rd, curr, i);
+                                a = g_code(g, ref, (int64_t)prev_right + i); b = g_code(g, ref, (int64_t)curr.left + i);
+                            }
+                            if (s != a) ++new_mm;
+                            if (s != b) ++old_mm;
+                        }
+                    } else if (dtl < 0) {
+                        const int ad = -dtl;
+                        for (int i = 0; i < ad; ++i) {
+                            int s, a, b;
+                            if (reversed) {
+                                int avail = rd.rl - curr_seg_index * L; if (avail > ad) avail = ad; if (avail < 0) avail = 0;
+                                s = f_read_code(rd, curr_seg_index * L + avail - (ad - i));
+                                a = g_code_rc(g, ref, (int64_t)prev_right - i); b = g_code_rc(g, ref, (int64_t)curr.left - i);
+                            } else {
+                                s = f_seq_code(rd, prev, prev_sl - (ad - i));
+                                a = g_code(g, ref, (int64_t)jr + i); b = g_code(g, ref, (int64_t)jl + 1 + i);
+                            }
+                            if (s != a) ++new_mm;
+                            if (s != b) ++old_mm;
+                        }
+                    }
+                    const int diff = new_mm - old_mm;
+                    if (diff >= best || new_mm >= 2) continue;
+                    best = diff;
+                    const int skip = jr - jl - 1;
+                    uint32_t mid;
+                    if ((uint32_t)skip <= (uint32_t)p.max_deletion_length) {
+                        mid = cig(reversed ? OP_dEL : OP_DEL, (uint32_t)skip);
+                        antisense_closure = f_spliced(prev) ? prev.asplice : curr.asplice;
+                    } else {
+                        mid = cig(reversed ? OP_rEF_SKIP : OP_REF_SKIP, (uint32_t)skip);
+                        antisense_closure = (int)(k & 1ull);
+                    }
+                    nn = f_splice(nc, prev, reversed ? prev_end - dtl : prev_end + dtl, false, mid, curr, reversed ? curr_front + dtr : curr_front - dtr);
+                    mismatch = diff;
+                    found = true;
+                }
+                if (!found) return false;
+            } else if (!(dist == 0 && same_strand)) check_fusion = true;
+        }
+        if (check_fusion) {                                                            // :1596-1818
+            uint32_t r1 = prev.ref_id2, r2 = curr.ref_id;
+            uint32_t fl = (uint32_t)prev_right - 4u, fr = (uint32_t)curr.left - 4u;
+            bool reversed = false;
+            if (fusion_dir != OP_FUS_FF && (r2 < r1 || (r1 == r2 && fl > fr))) {
+                reversed = true;
+                uint32_t t = r1; r1 = r2; r2 = t;
+                t = fl; fl = fr; fr = t;
+            }
+            FusKey k1{r1, r2, fl, fr, (uint32_t)OP_FUS_FF}, k2{r1, r2, fl + 8u, fr + 8u, (uint32_t)OP_FUS_FF};
+            int64_t lb = f_fus_upper(F, k1);
+            const int64_t ub = f_fus_lower(F, k2);
+            const uint32_t ref1 = prev.ref_id2, ref2 = curr.ref_id;
+            const bool have = g_len(g, ref1) != 0 && g_len(g, ref2) != 0;
+            int best = 0xff;
+            const int prev_sl = f_seq_len(rd, prev);
+            for (; lb < ub; ++lb) {
+                int lb_left = (int)F.keys[lb].left, lb_right = (int)F.keys[lb].right;
+                if (reversed) { lb_left = (int)F.keys[lb].right; lb_right = (int)F.keys[lb].left; }
+                const int dtl = fusion_dir == OP_FUS_RF ? prev_right - lb_left + 1 : lb_left - prev_right + 1;
+                const int dtr = fusion_dir == OP_FUS_FR ? curr.left - lb_right : lb_right - curr.left;
+                if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
+                if (dtl > curr_front || -dtl > prev_end) continue;
+                if (!have) return false;
+                int new_mm = 0, old_mm = 0;
+                const bool own_seq = fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR;
+                if (dtl > 0) {
+                    for (int i = 0; i < dtl; ++i) {
+                        const int a = fusion_dir == OP_FUS_RF ? g_code_rc(g, ref1, (int64_t)prev_right - i) : g_code(g, ref1, (int64_t)prev_right + i);
+                        const int b = fusion_dir == OP_FUS_FR ? g_code_rc(g, ref2, (int64_t)curr.left - i) : g_code(g, ref2, (int64_t)curr.left + i);
+                        const int s = own_seq ? f_seq_code(rd, curr, i) : (i < L ? f_read_code(rd, curr_seg_index * L + i) : 5);
+                        if (s != a) ++new_mm;
+                        if (s != b) ++old_mm;
+                    }
+                } else if (dtl < 0) {
+                    const int ad = -dtl;
+                    for (int i = 0; i < ad; ++i) {
+                        const int a = fusion_dir == OP_FUS_FR ? g_code_rc(g, ref2, (int64_t)lb_right - i) : g_code(g, ref2, (int64_t)lb_right + i);
+                        const int b = fusion_dir == OP_FUS_RF ? g_code_rc(g, ref1, (int64_t)lb_left - 1 - i) : g_code(g, ref1, (int64_t)lb_left + 1 + i);
+                        int s;
+                        if (own_seq) s = f_seq_code(rd, prev, prev_sl - (ad - i));
+                        else {
+                            const int st = (curr_seg_index - 1) * L;
+                            int plen = rd.rl - st; if (plen > L) plen = L; if (plen < 0) plen = 0;
+                            s = f_read_code(rd, st + plen - (ad - i));
+                        }
+                        if (s != a) ++new_mm;
+                        if (s != b) ++old_mm;
+                    }
+                }
+                const int diff = new_mm - old_mm;
+                if (diff >= best || new_mm >= 2) continue;
+                best = diff;
+                nn = f_splice(nc, prev, prev_end + dtl, false, cig(fusion_dir, (uint32_t)lb_right), curr, curr_front - dtr);
+                antisense_closure = f_spliced(prev) ? prev.asplice : curr.asplice;
+                mismatch = diff;
+                found = true;
+            }
+            if (!found) return false;
+        }
+        if (found) {                                                                   // :1822-1870
+            if (nn > FUS_MAXC - 1) return false;        // device capacity (the record keeps its last cigar slot for ref_id2)
+            FHit m;
+            const int mismatches = (int)prev.mm + (int)curr.mm + mismatch;
+            m.ref_id = prev.ref_id; m.ref_id2 = curr.ref_id2; m.left = prev.left;
+            m.n = nn;
+            for (int q = 0; q < FUS_MAXC; ++q) m.c[q] = q < nn ? nc[q] : 0u;
+            m.anti = (uint8_t)antisense; m.asplice = (uint8_t)antisense_closure;
+            m.mm = (uint8_t)mismatches; m.ed = (uint8_t)(mismatches + f_gap_length(nc, nn));
+            m.end = 0; m.pad0 = m.pad1 = 0;
+            if (prev.nsq + curr.nsq > 16) return false;
+            m.sq = prev.sq | (curr.sq << (4 * prev.nsq)); m.nsq = (uint8_t)(prev.nsq + curr.nsq);
+            chain[pi] = m;
+            for (int q = ci; q + 1 < n; ++q) chain[q] = chain[q + 1];
+            --n;
+            ci = pi + 1;
+            ++curr_seg_index;
+            continue;
+        }
+        ++pi; ++ci; ++curr_seg_index;
+    }
+    // :1888-1944 concatenate
+    bool saw_as = false, saw_s = false;
+    int num_mm = 0;
+    FHit nh;
+    nh.n = 0;
+    for (int s = 0; s < n; ++s) {
+        num_mm += chain[s].mm;
+        if (f_spliced(chain[s])) {
+            if (chain[s].asplice) { if (saw_s) return false; saw_as = true; }
+            else { if (saw_as) return false; saw_s = true; }
+        }
+        int b0 = 0;
+        if (nh.n > 0 && cig_op(nh.c[nh.n - 1]) == cig_op(chain[s].c[0])) {
+            nh.c[nh.n - 1] = cig(cig_op(nh.c[nh.n - 1]), cig_len(nh.c[nh.n - 1]) + cig_len(chain[s].c[0]));
+            b0 = 1;
+        }
+        for (int b = b0; b < chain[s].n; ++b) { if (nh.n >= FUS_MAXC - 1) return false; nh.c[nh.n++] = chain[s].c[b]; }
+    }
+    for (int q = nh.n; q < FUS_MAXC; ++q) nh.c[q] = 0;
+    nh.ref_id = chain[0].ref_id; nh.ref_id2 = chain[n - 1].ref_id2; nh.left = left;
+    nh.anti = (uint8_t)antisense; nh.asplice = saw_as ? 1 : 0;
+    nh.mm = (uint8_t)num_mm; nh.ed = (uint8_t)(num_mm + f_gap_length(nh.c, nh.n));
+    nh.end = 0; nh.pad0 = nh.pad1 = 0;
+    if (fusion_dir == 0 || fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) { nh.sq = seq_sq; nh.nsq = (uint8_t)seq_nsq; }   // :1959-1978
+    else {                                                                               // :1979-1983: the read itself
+        nh.sq = 0; nh.nsq = (uint8_t)rd.nsegs;
+        for (int k = 0; k < rd.nsegs; ++k) nh.sq |= (u64)k << (4 * k);
+    }
+    // the quality string is the read's, reversed when the joined sequence is not the read (bowtie2 mode); a later reverse()
+    // turns it once more.  pad0 = 1: reversed.
+    nh.pad0 = (fusion_dir == 0 || fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) ? (f_seq_is_read(rd, nh) ? 0 : 1) : 0;
+    {
+        bool rev = nh.ref_id > nh.ref_id2;
+        if (nh.ref_id == nh.ref_id2) { uint32_t fl, fr; if (f_first_fusion(nh, fl, fr)) rev = fl > fr; }
+        if (rev) { f_reverse(nh); nh.pad0 ^= 1; }
+    }
+    if (fusion_dir != 0) nh.anti = f_seq_is_read(rd, nh) ? 0 : 1;                        // :2007-2013
+    if (f_read_len(nh) != old_read_length || !f_check_editdist(g, rd, nh)) return false;  // :2022-2034
+    out = nh;
+    return true;
+}
+
+THJ_HD bool f_valid_hit(const Params& p, const FHit& h) {                                // :2045-2099
+    if (h.n == 0) return false;
+    for (int i = 1; i < h.n; ++i) {
+        const int cop = cig_op(h.c[i]), pop = cig_op(h.c[i - 1]);
+        const uint32_t clen = cig_len(h.c[i]);
+        if (!op_is_match(cop) && !op_is_match(pop)) return false;
+        if ((cop == OP_INS || cop == OP_iNS) && clen > (uint32_t)p.max_insertion_length) return false;
+        if ((cop == OP_DEL || cop == OP_dEL) && clen > (uint32_t)p.max_deletion_length) return false;
+        if ((cop == OP_REF_SKIP || cop == OP_rEF_SKIP) && clen < (uint32_t)p.min_report_intron) return false;
+    }
+    return op_is_match(cig_op(h.c[0])) && op_is_match(cig_op(h.c[h.n - 1]));
+}
+
+// merge_segment_chain, :2101-2220.  -> the joined hit in `bh` (n == 0: none)
+THJ_HD void f_merge_segment_chain(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const FRead& rd,
+                                  const FHit* hits, int n, int fusion_dir, FHit* chain /* [SPAN_MAXSEG + 1] */, FHit& bh) {
+    bh.n = 0;
+    if (n > 1) {
+        if (fusion_dir == 0 || fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) {
+            for (int i = 0; i < n; ++i) chain[i] = hits[0].anti ? hits[n - 1 - i] : hits[i];
+        } else {
+            bool saw = false;
+            int m = 0;
+            for (int i = 0; i < n; ++i) {
+                bool pushed = false;
+                if (!saw && i > 0) {
+                    if (hits[i - 1].ref_id != hits[i].ref_id) saw = true;
+                    else if (hits[i - 1].anti != hits[i].anti) saw = true;
+                    else {
+                        const int dist = hits[i].anti ? hits[i - 1].left - f_right(hits[i]) : hits[i].left - f_right(hits[i - 1]);
+                        if (dist >= p.max_report_intron || dist < -p.max_insertion_length) saw = true;
+                    }
+                }
+                if (f_fusion_opcode(hits[i]) == 0 && ((fusion_dir == OP_FUS_FR && saw) || (fusion_dir == OP_FUS_RF && !saw)) &&
+                    hits[i].left < f_right(hits[i])) {
+                    if (m > SPAN_MAXSEG) return;
+                    chain[m] = hits[i]; f_reverse(chain[m]); ++m;
+                    pushed = true;
+                }
+                if (i > 0 && f_fusion_opcode(hits[i]) != 0 && hits[i].ref_id != hits[i - 1].ref_id) {
+                    if (m > SPAN_MAXSEG) return;
+                    chain[m] = hits[i]; f_reverse(chain[m]); ++m;
+                    pushed = true;
+                }
+                if (!saw && f_fusion_opcode(hits[i]) != 0) saw = true;
+                if (!pushed) { if (m > SPAN_MAXSEG) return; chain[m++] = hits[i]; }
+            }
+            n = m;
+        }
+        if (!f_merge_chain(g, p, S, F, rd, chain, n, fusion_dir, bh)) { bh.n = 0; return; }
+    } else {
+        bh = hits[0];
+        bh.pad0 = bh.nsq ? (uint8_t)((bh.sq >> 3) & 1) : 0;     // the record's own QUAL: reversed when its SEQ is the reverse complement
+        f_reverse_if_needed(bh);
+        if (bh.nsq) bh.pad0 = (uint8_t)((bh.sq >> 3) & 1);
+    }
+    if (!f_valid_hit(p, bh)) bh.n = 0;
+}
+
+THJ_HD FHit fhit_from(const SpanHit& h, int seg, bool last_seg) {
+    FHit x;
+    x.ref_id = h.ref_id; x.ref_id2 = h.ref_id; x.left = h.left;
+    x.n = (int)(h.meta >> 24);
+    bool fused = false;
+    for (int q = 0; q < FUS_MAXC; ++q) {
+        x.c[q] = q < x.n && q < 5 ? h.cigar[q] : 0u;
+        if (q < x.n && q < 5 && f_is_fusion_op(cig_op(h.cigar[q]))) fused = true;
+    }
+    if (fused) x.ref_id2 = h.cigar[4];
+    x.anti = (h.meta & SH_ANTI) ? 1 : 0; x.asplice = (h.meta & SH_ASPLICE) ? 1 : 0;
+    x.mm = (uint8_t)(h.meta >> 8); x.ed = (uint8_t)(h.meta >> 16);
+    x.end = (h.meta & SH_END) ? 1 : 0; x.pad0 = x.pad1 = 0;
+    (void)last_seg;
+    const bool rec_rev = (x.anti != 0) != ((h.meta & SH_FLIPPED) != 0);
+    x.sq = (u64)(seg & 7) | (rec_rev ? 8ull : 0ull); x.nsq = 1;
+    return x;
+}
+
+THJ_HD bool fhit_less(const FHit& a, const FHit& b) {                  // bwt_map.h:180-207
+    if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+    if (a.ref_id2 != b.ref_id2) return a.ref_id2 < b.ref_id2;
+    if (a.left != b.left) return a.left < b.left;
+    if (a.anti != b.anti) return a.anti < b.anti;
+    if (a.mm != b.mm) return a.mm < b.mm;
+    if (a.ed != b.ed) return a.ed < b.ed;
+    if (a.n != b.n) return a.n < b.n;
+    for (int i = 0; i < a.n; ++i)
+        if (a.c[i] != b.c[i]) {
+            const int oa = cig_op(a.c[i]), ob = cig_op(b.c[i]);
+            return oa < ob || (oa == ob && cig_len(a.c[i]) < cig_len(b.c[i]));
+        }
+    return false;
+}
+THJ_HD bool fhit_eq(const FHit& a, const FHit& b) {                    // bwt_map.h:167-178
+    if (a.ref_id != b.ref_id || a.ref_id2 != b.ref_id2 || a.anti != b.anti || a.left != b.left || a.asplice != b.asplice ||
+        a.ed != b.ed || a.n != b.n) return false;
+    for (int i = 0; i < a.n; ++i) if (a.c[i] != b.c[i]) return false;
+    return true;
+}
+
+// bowtie_sam_extra, bwt_map.cpp:2467-2648, on a hit that may run down the genome and change contigs.  h.pad0: the hit's
+// quality string is the read's reversed.
+THJ_HD void f_sam_extra(const Genome& g, const Params& p, const FRead& rd, const FHit& h, Extras& e) {
+    int pos_seq = 0, pos_mm = 0, mismatch = 0, opens = 0, conts = 0, AS = 0;
+    int64_t pos_ref = h.left;
+    uint32_t ref = h.ref_id;
+    bool saw = false;
+    md_init(e.md);
+    e.AS = e.XM = e.XO = e.XG = e.both_n = 0;
+    if (g_len(g, h.ref_id) == 0 || g_len(g, h.ref_id2) == 0) return;
+    const int slen = f_seq_len(rd, h);
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]); const int len = (int)cig_len(h.c[i]);
+        if (op == OP_MATCH || op == OP_mATCH) {
+            for (int j = 0; j < len; ++j) {
+                const int r = op == OP_MATCH ? g_code(g, ref, pos_ref + j) : g_code_rc(g, ref, pos_ref - j);
+                int s = f_seq_code(rd, h, pos_seq); if (s > 4) s = 4;
+                if (s != r) {
+                    ++mismatch;
+                    if (pos_seq < slen) {
+                        if (s == 4 || r == 4) AS -= p.bowtie2_penalty_for_N;
+                        else {
+                            int q = (int)rd.qual[h.pad0 ? rd.rl - 1 - pos_seq : pos_seq] - 33; if (q > 40) q = 40;
+                            AS -= p.bowtie2_min_penalty + ((p.bowtie2_max_penalty - p.bowtie2_min_penalty) * q) / 40;
+                        }
+                    }
+                    md_put_int_char(e.md, pos_mm, "ACGTN"[r]);
+                    pos_mm = 0;
+                } else {
+                    if (r == 4) AS -= p.bowtie2_penalty_for_N;
+                    ++pos_mm;
+                }
+                ++pos_seq;
+            }
+            pos_ref += op == OP_MATCH ? len : -len;
+        } else if (op == OP_INS || op == OP_iNS) {
+            pos_seq += len;
+            AS -= p.bowtie2_read_gap_open + p.bowtie2_read_gap_cont * len;
+            ++opens; conts += len;
+        } else if (op == OP_DEL || op == OP_dEL) {
+            AS -= p.bowtie2_ref_gap_open + p.bowtie2_ref_gap_cont * len;
+            ++opens; conts += len;
+            md_put_int_char(e.md, pos_mm, '^');
+            for (int k = 0; k < len && k < 64; ++k) md_push(e.md, "ACGTN"[op == OP_DEL ? g_code(g, ref, pos_ref + k) : g_code_rc(g, ref, pos_ref - k)]);
+            pos_ref += op == OP_DEL ? len : -len;
+            pos_mm = 0;
+        } else if (op == OP_REF_SKIP) pos_ref += len;
+        else if (op == OP_rEF_SKIP) pos_ref -= len;
+        else if (f_is_fusion_op(op)) {
+            if (saw) { md_init(e.md); return; }
+            ref = h.ref_id2; pos_ref = len; saw = true;
+        }
+    }
+    md_put_int(e.md, pos_mm);
+    e.AS = AS; e.XM = mismatch; e.XO = opens; e.XG = conts;
+}
+
+template <class Sink>
+THJ_HD void f_emit(Sink& sink, uint32_t read_idx, int order, const FHit& h, const Extras& e) {
+    uint32_t wds[32];
+    wds[0] = read_idx; wds[1] = h.ref_id; wds[2] = (uint32_t)h.left;
+    wds[3] = (h.anti ? 1u : 0u) | (h.asplice ? 4u : 0u) | ((uint32_t)h.mm << 8) | ((uint32_t)h.ed << 16) | ((uint32_t)h.n << 24);
+    wds[4] = ((uint32_t)e.AS & 0xFFFFu) | ((uint32_t)(e.XM & 0xFF) << 16) | ((uint32_t)(e.XO & 0xFF) << 24);
+    wds[5] = (uint32_t)(e.XG & 0xFF) | ((uint32_t)(e.md.len > 40 ? 255 : e.md.len) << 8) | ((uint32_t)(order & 0xFFFF) << 16);
+    for (int q = 0; q < SPAN_MAXC; ++q) wds[6 + q] = q < h.n ? h.c[q] : 0u;
+    if (f_fusion_opcode(h) != 0) wds[6 + SPAN_MAXC - 1] = h.ref_id2;      // a fusion alignment: ref_id2 rides in the last cigar slot
+    for (int q = 0; q < 5; ++q) { wds[22 + 2 * q] = (uint32_t)e.md.w[q]; wds[23 + 2 * q] = (uint32_t)(e.md.w[q] >> 32); }
+    sink.emit_words(wds);
+}
+
+// One read: JoinSegmentsWorker body (long_spanning_reads.cpp:2767-2831) with fusion search on.
+// work: FHit[3 * (SPAN_MAXSEG + 1)] of per-thread memory (stack, saved stack tops, chain).
+template <class Sink>
+THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
+                            int nseg, const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+    if (so[1] == so[0]) return SPAN_OK;
+    int nsegs = 0;
+    while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
+    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
+    if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;
+    if (p.bowtie2)
+        for (int s = 0; s < nsegs; ++s)
+            if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;
+    const int fs = p.fusion_search;
+    FRead rd{rp, W, rl, p.segment_length, nsegs, qual};
+    FHit joined[FUS_MAXJOIN]; int nj = 0;
+    FHit stack[SPAN_MAXSEG + 1], saved[SPAN_MAXSEG + 1], chain[SPAN_MAXSEG + 1];
+    uint32_t idx[SPAN_MAXSEG + 1];
+    int fdir[SPAN_MAXSEG + 2];
+    int status = SPAN_OK;
+    for (uint32_t i0 = so[0]; i0 < so[1]; ++i0) {                           // :2634-2664
+        stack[0] = fhit_from(hits[i0], 0, nsegs == 1);
+        if (f_fusion_opcode(stack[0]) == OP_FUS_RR) f_reverse(stack[0]);
+        int num_try = 10000;
+        int d = 1;
+        fdir[1] = 0;
+        if (nsegs > 1) idx[1] = so[1];
+        while (d >= 1) {
+            if (num_try <= 0) break;
+            if (d == nsegs) {                                               // leaf: :2592-2606
+                --num_try;
+                FHit bh;
+                f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
+                if (bh.n) { if (nj < FUS_MAXJOIN) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED; }
+                --d;
+                if (d >= 1) stack[d - 1] = saved[d];
+                continue;
+            }
+            if (idx[d] >= so[d + 1]) {
+                --d;
+                if (d >= 1) stack[d - 1] = saved[d];
+                continue;
+            }
+            const int fusion_dir = fdir[d];
+            FHit bh = fhit_from(hits[idx[d]++], d, d == nsegs - 1);
+            FHit bh_prev = stack[d - 1];
+            FHit* prevHit = &bh_prev;
+            FHit* currHit = &bh;
+            const bool prev_fused = f_fusion_opcode(*prevHit) != 0, curr_fused = f_fusion_opcode(*currHit) != 0;
+            const int num_fusions = (prev_fused ? 1 : 0) + (curr_fused ? 1 : 0);
+            int dir = prev_fused ? f_fusion_opcode(*prevHit) : f_fusion_opcode(*currHit);
+            if (!fs && num_fusions > 0) continue;
+            if (num_fusions >= 2) continue;
+            if (fusion_dir != 0 && curr_fused) continue;
+            if (fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) {
+                if ((currHit->anti && currHit->ref_id != prevHit->ref_id) || (!currHit->anti && currHit->ref_id != prevHit->ref_id2)) continue;
+            }
+            if ((fusion_dir == OP_FUS_FR || fusion_dir == OP_FUS_RF) && prevHit->ref_id2 != currHit->ref_id) continue;
+            if ((fusion_dir == OP_FUS_FR && !currHit->anti) || (fusion_dir == OP_FUS_RF && currHit->anti)) continue;
+            if (curr_fused && dir == OP_FUS_RR) f_reverse(*currHit);
+            if (fusion_dir == OP_FUS_FR || fusion_dir == OP_FUS_RF ||
+                (curr_fused && currHit->ref_id == currHit->ref_id2 && (dir == OP_FUS_FR || dir == OP_FUS_RF))) {
+                if (curr_fused) {
+                    if ((dir == OP_FUS_FR && currHit->anti) || (dir == OP_FUS_RF && !currHit->anti)) f_reverse(*currHit);
+                } else if (fusion_dir == OP_FUS_FR && currHit->anti) f_reverse(*currHit);
+            } else if ((num_fusions == 0 && prevHit->anti && currHit->anti && prevHit->ref_id == currHit->ref_id &&
+                        (!fs || (prevHit->left <= f_right(*currHit) + p.max_report_intron &&
+                                 prevHit->left + p.max_insertion_length >= f_right(*currHit)))) ||
+                       (num_fusions == 1 && (dir == OP_FUS_FF || dir == OP_FUS_RR) &&
+                        ((!prev_fused && prevHit->anti) || (!curr_fused && currHit->anti)))) {
+                FHit* t = prevHit; prevHit = currHit; currHit = t;
+            } else if (num_fusions == 0) {
+                if (prevHit->ref_id2 == currHit->ref_id && prevHit->anti == currHit->anti) {
+                    const int dist = prevHit->anti ? prevHit->left - f_right(*currHit) : currHit->left - f_right(*prevHit);
+                    if (dist > p.max_report_intron || dist < -p.max_insertion_length) {
+                        if ((prevHit->anti && prevHit->left > currHit->left) || (!prevHit->anti && prevHit->left < currHit->left)) dir = OP_FUS_FF;
+                        else dir = OP_FUS_RR;
+                    }
+                } else {
+                    if (prevHit->anti == currHit->anti) {
+                        if ((prevHit->anti && prevHit->ref_id > currHit->ref_id) || (!prevHit->anti && prevHit->ref_id < currHit->ref_id)) dir = OP_FUS_FF;
+                        else dir = OP_FUS_RR;
+                    } else if (!prevHit->anti) dir = OP_FUS_FR;
+                    else dir = OP_FUS_RF;
+                    if (dir == OP_FUS_FR) f_reverse(*currHit);
+                    else if (dir == OP_FUS_RF) f_reverse(*prevHit);
+                }
+            }
+            if (!fs && dir != 0) continue;
+            if (num_fusions == 1 && dir != OP_FUS_FF && dir != OP_FUS_RR) {       // :2442-2514
+                bool prev_rep = false, curr_rep = false;
+                if (prev_fused) {
+                    if ((dir == OP_FUS_FR && !currHit->anti) || (dir == OP_FUS_RF && currHit->anti)) continue;
+                    if (prevHit->ref_id2 != currHit->ref_id) prev_rep = true;
+                    else if ((dir == OP_FUS_FR && prevHit->anti) || (dir == OP_FUS_RF && !prevHit->anti)) prev_rep = true;
+                }
+                if (curr_fused) {
+                    if ((dir == OP_FUS_FR && prevHit->anti) || (dir == OP_FUS_RF && !prevHit->anti)) continue;
+                    if (currHit->ref_id != prevHit->ref_id2) curr_rep = true;
+                }
+                if (prev_rep) f_reverse(*prevHit);
+                if (curr_rep) f_reverse(*currHit);
+                prev_rep = curr_rep = false;
+                if (f_forwarding_right(*prevHit) != f_forwarding_left(*currHit)) { if (prev_fused) curr_rep = true; else prev_rep = true; }
+                if (prev_rep) f_reverse(*prevHit);
+                if (curr_rep) f_reverse(*currHit);
+            }
+            const bool same_contig = prevHit->ref_id2 == currHit->ref_id;
+            if (!same_contig && num_fusions > 0) continue;
+            if (!fs && (!same_contig || num_fusions > 0)) continue;
+            if (same_contig && num_fusions >= 1 && f_anti2(*prevHit) != (currHit->anti != 0)) continue;
+            int dist = 0;
+            if (same_contig) {
+                int bh_l, back_right;
+                if ((fusion_dir == OP_FUS_FR || fusion_dir == OP_FUS_RF || dir == OP_FUS_FR || dir == OP_FUS_RF) && f_anti2(*prevHit)) {
+                    bh_l = f_right(*prevHit) + 1; back_right = currHit->left + 1;
+                } else { bh_l = currHit->left; back_right = f_right(*prevHit); }
+                dist = bh_l - back_right;
+            }
+            if (!same_contig || (same_contig && num_fusions == 0 && dir != 0 && fusion_dir == 0) ||
+                (same_contig && dist <= p.max_report_intron && dist >= -p.max_insertion_length &&
+                 f_forwarding_right(*prevHit) == f_forwarding_left(*currHit))) {
+                saved[d] = stack[d - 1];
+                stack[d - 1] = bh_prev;
+                stack[d] = bh;
+                fdir[d + 1] = dir == 0 ? fusion_dir : dir;
+                ++d;
+                if (d < nsegs) idx[d] = so[d];
+            }
+        }
+    }
+    for (int i = 1; i < nj; ++i) {                        // sort + unique (:2805-2807); stable insertion sort
+        FHit t = joined[i]; int k = i;
+        while (k > 0 && fhit_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
+        joined[k] = t;
+    }
+    int w = 0;
+    for (int i = 0; i < nj; ++i) if (w == 0 || !fhit_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];
+    nj = w;
+    int order = 0;
+    for (int i = 0; i < nj; ++i) {
+        const FHit& h = joined[i];
+        const int gapl = (uint8_t)(h.ed - h.mm);
+        if ((int)h.mm > p.read_mismatches || gapl > p.read_gap_length || (int)h.ed > p.read_edit_dist) continue;     // :2810-2813
+        Extras e;
+        f_sam_extra(g, p, rd, h, e);
+        f_emit(sink, read_idx, order++, h, e);
+    }
+    return status;
+}
+
+}  // namespace thj

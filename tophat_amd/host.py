@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "thj_covsearch_reset_async", "thj_covsearch_add_hits_async", "thj_covsearch_add_reads", "thj_covsearch_run_async", "thj_covsearch_finish",
     "thj_covsearch_device_state", "thj_covsearch_merge_async", "thj_span_hit_heads_async",
     "thj_comm_unique_id", "thj_comm_create", "thj_comm_create_local", "thj_comm_destroy", "thj_comm_info",
-    "thj_events_allgather_async", "thj_fusion_allgather", "thj_covsearch_allgather",
+    "thj_events_allgather_async", "thj_fusion_allgather", "thj_covsearch_allgather", "thj_span_fusions_upload", "thj_md_string2",
 ]
 
 _lib = None
@@ -471,9 +471,9 @@ MD_ON_HOST = 255
 _RC = bytes.maketrans(b"ACGTNacgtn", b"TGCANtgcan")
 
 
-def md_on_host(seq_of_contig, read_seq: str, antisense: bool, left: int, cigar, lib=None) -> str:
-    """thj_md_string: the MD:Z of an alignment whose string does not fit a device record.  seq_of_contig: the contig's bases
-    (str / bytes); read_seq: the read as sequenced"""
+def md_on_host(seq_of_contig, read_seq: str, antisense: bool, left: int, cigar, lib=None, seq_of_contig2=None) -> str:
+    """thj_md_string / thj_md_string2: the MD:Z of an alignment whose string does not fit a device record.  seq_of_contig: the
+    contig's bases (str / bytes), seq_of_contig2: the second contig of a fusion alignment; read_seq: the read as sequenced"""
     lib = lib or load_lib()
     ref = seq_of_contig if isinstance(seq_of_contig, bytes) else seq_of_contig.encode()
     s = read_seq.encode()
@@ -481,10 +481,18 @@ def md_on_host(seq_of_contig, read_seq: str, antisense: bool, left: int, cigar, 
         s = s.translate(_RC)[::-1]
     cig = (C.c_uint32 * max(1, len(cigar)))(*cigar)
     buf = C.create_string_buffer(4096)
-    n = lib.thj_md_string(ref, C.c_int64(len(ref)), s, len(s), int(left), cig, len(cigar), buf, 4096)
+    if seq_of_contig2 is not None:
+        ref2 = seq_of_contig2 if isinstance(seq_of_contig2, bytes) else seq_of_contig2.encode()
+        n = lib.thj_md_string2(ref, C.c_int64(len(ref)), ref2, C.c_int64(len(ref2)), s, len(s), int(left), cig, len(cigar), buf, 4096)
+    else:
+        n = lib.thj_md_string(ref, C.c_int64(len(ref)), s, len(s), int(left), cig, len(cigar), buf, 4096)
     if n < 0:
         raise ThjError("thj_md_string: %s" % lib.thj_last_error().decode())
     return buf.value.decode()
+
+
+SPAN_FUSION_DTYPE = np.dtype([("ref_id1", "<u4"), ("ref_id2", "<u4"), ("left", "<u4"), ("right", "<u4"), ("dir", "<u4")])   # thj_span_fusion
+_FUSION_OPS = (7, 8, 9, 10)
 
 
 def alns_from_array(a: np.ndarray, md_resolver=None) -> List[Aln]:
@@ -493,14 +501,18 @@ def alns_from_array(a: np.ndarray, md_resolver=None) -> List[Aln]:
     for x in a:
         n = int(x["n_cigar"])
         cig = tuple(int(c) for c in x["cigar"][:n])
+        ref_id2 = int(x["cigar"][15]) if any((c >> 28) in _FUSION_OPS for c in cig) else 0     # fusion alignment: ref_id2 in the last slot
         if int(x["md_len"]) == MD_ON_HOST:
             if md_resolver is None:
                 raise ThjError("a record's MD string is left to the host (THJ_MD_ON_HOST) and no resolver was given")
-            md = md_resolver(int(x["read_idx"]), int(x["ref_id"]), bool(x["flags"] & 1), int(x["left"]), cig)
+            if ref_id2:
+                md = md_resolver(int(x["read_idx"]), int(x["ref_id"]), bool(x["flags"] & 1), int(x["left"]), cig, ref_id2)
+            else:
+                md = md_resolver(int(x["read_idx"]), int(x["ref_id"]), bool(x["flags"] & 1), int(x["left"]), cig)
         else:
             md = x["md"][:int(x["md_len"])].decode()
         out.append(Aln(int(x["read_idx"]), int(x["ref_id"]), int(x["left"]), bool(x["flags"] & 1), bool(x["flags"] & 4),
-                       int(x["mismatches"]), int(x["edit_dist"]), cig, int(x["AS"]), int(x["XM"]), int(x["XO"]), int(x["XG"]), md))
+                       int(x["mismatches"]), int(x["edit_dist"]), cig, int(x["AS"]), int(x["XM"]), int(x["XO"]), int(x["XG"]), md, ref_id2))
     return out
 
 
@@ -511,11 +523,12 @@ def span_md_resolver(seqs, batches, lib=None):
     for b in batches:
         starts.append(starts[-1] + b.n_reads)
 
-    def resolve(read_idx, ref_id, antisense, left, cigar):
+    def resolve(read_idx, ref_id, antisense, left, cigar, ref_id2=0):
         k = max(i for i in range(len(batches)) if starts[i] <= read_idx)
         b = batches[k]
         r = read_idx - starts[k]
-        return md_on_host(seqs[ref_id - 1], b.bases[b.read_off[r]:b.read_off[r + 1]].tobytes().decode(), antisense, left, cigar, lib)
+        return md_on_host(seqs[ref_id - 1], b.bases[b.read_off[r]:b.read_off[r + 1]].tobytes().decode(), antisense, left, cigar, lib,
+                          seqs[ref_id2 - 1] if ref_id2 else None)
     return resolve
 
 
@@ -527,6 +540,11 @@ def _ins_table(insertions) -> np.ndarray:
 
 
 def _span_methods():
+    def upload_span_fusions(self, fusions: np.ndarray):
+        """--fusion-search: the .fusions list (SPAN_FUSION_DTYPE, Fusion::operator< order) for runs with Params.fusion_search"""
+        f = np.ascontiguousarray(fusions, dtype=SPAN_FUSION_DTYPE)
+        _check(self.lib, self.lib.thj_span_fusions_upload(self._ctx, _ptr(f) if len(f) else None, C.c_int64(len(f))), "thj_span_fusions_upload")
+
     def upload_span_sets(self, juncs: np.ndarray, insertions):
         j = np.ascontiguousarray(juncs, dtype=JUNC_DTYPE)
         t = _ins_table(insertions)
@@ -604,7 +622,7 @@ def _span_methods():
         _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, ms, C.byref(n)), "thj_profile_span")
         return [ms[0], ms[1], ms[2], ms[3]], n.value
 
-    for f in (upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
+    for f in (upload_span_fusions, upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
               span_download, spanning, profile_span, span_tier_counts, span_hit_heads):
         setattr(Context, f.__name__, f)
 

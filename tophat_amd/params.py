@@ -49,6 +49,7 @@ class Params:
     bowtie2_ref_gap_cont: int = 3     # common.cpp:93
     fusion_anchor_length: int = 20    # common.cpp:172
     fusion_min_dist: int = 10000000   # common.cpp:173
+    fusion_search: int = 0            # common.cpp:171
 
     def as_ctypes(self) -> "CParams":
         c = CParams()
