@@ -189,3 +189,40 @@ def test_long_spanning_reads_parts(tmp_path):
         last = recs[-1][0]
         got += recs
     assert got == whole
+
+
+from golden_util import FUSION_SPAN_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("threads", [None, "1"], ids=["default_threads", "single_thread"])
+@pytest.mark.parametrize("name", FUSION_SPAN_CASES)
+def test_long_spanning_reads_fusion_search(name, threads, tmp_path):
+    """long_spanning_reads --fusion-search as a drop-in: the .fusions list, fused segment hits from the fusion contigs of the
+    junction database (BAM maps: the SAM hit factory of the reference drops them), two-record XF output -- every record and the
+    uncompressed BAM stream identical to what the scratch build wrote"""
+    env = dict(os.environ)
+    if threads:
+        env["THJ_HOST_THREADS"] = threads
+    d = os.path.join(GOLD, name)
+    opts = open(os.path.join(d, "options.txt")).read().split("\n")
+    argv = opts[0].split()
+    seglen = dict(x.split("=") for x in opts[1].split())["segment_length"]
+    nseg = len([f for f in os.listdir(d) if f.startswith("left_seg") and f.endswith(".to_spliced.sam")])
+    for sd in ("left", "right"):
+        sp = []
+        for k in range(nseg):
+            o_ = str(tmp_path / ("%s_seg%d.to_spliced.bam" % (sd, k + 1)))
+            write_bam_from_sam(os.path.join(d, "%s_seg%d.to_spliced.sam" % (sd, k + 1)), o_)
+            sp.append(o_)
+        bam = str(tmp_path / ("span_%s.bam" % sd))
+        cmd = [os.path.join(BIN, "long_spanning_reads"), "--segment-length", seglen, "--sam-header", os.path.join(d, "hdr.sam")] + argv + [
+            os.path.join(d, "ref.fa"), os.path.join(d, "%s.fq" % sd), os.path.join(d, "expected.juncs"), os.path.join(d, "expected.insertions"),
+            os.path.join(d, "expected.deletions"), os.path.join(d, "expected.fusions"), bam,
+            ",".join(os.path.join(d, "%s_seg%d.sam" % (sd, k + 1)) for k in range(nseg)), ",".join(sp)]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        _, recs = read_bam(bam)
+        want = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
+        assert [tuple(str(x) for x in rec) for rec in recs] == want
+        assert sum(1 for rec in recs if any(str(x).startswith("XF:Z:") for x in rec)) >= 20
+        assert gzip.open(bam, "rb").read() == gzip.open(os.path.join(d, "expected.span_%s.bam" % sd), "rb").read()

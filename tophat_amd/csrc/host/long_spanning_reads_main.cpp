@@ -1,7 +1,8 @@
 // long_spanning_reads -- MI355X-native drop-in for TopHat's long_spanning_reads (same argv + files;
 // tophat.py:3160-3191, parsed like long_spanning_reads.cpp:3151-3329).  Host C++ over include/thj.h.
-// Contig segment maps (with any CIGAR, incl. N/I/D) and junction-db ("spliced") segment maps are supported;
-// --fusion-search is refused loudly.
+// Contig segment maps (with any CIGAR, incl. N/I/D) and junction-db ("spliced") segment maps are supported, and so is
+// --fusion-search: the .fusions list goes to the device, fused segment hits come from the fusion contigs of the junction
+// database (BAM maps), fusion alignments leave as two records with XF:Z (print_bamhit / extract_partial_hits).
 //
 // The reads are cut into contiguous read-id shards with the reference's planner (calculate_offsets over the inputs' .index
 // files, utils.cpp:22-127; long_spanning_reads.cpp:2983-3064).  Host workers ingest shards in parallel -- shard k's
@@ -75,19 +76,24 @@ static std::vector<Shard> plan(const std::string& reads, const std::vector<std::
     return out;
 }
 
-// print_bamhit (bwt_map.cpp:1888-2093) for one record
-static long encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a, const Read& rd, std::vector<uint8_t>& d) {
+// print_bamhit (bwt_map.cpp:1888-2093) for one alignment: one record, or -- a fusion alignment -- the two partial records of
+// extract_partial_hits (:2148-2347), each carrying the whole alignment in XF:Z.  Appends (size, read id) per record.
+static void encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a, const Read& rd, std::vector<uint8_t>& d,
+                       std::vector<uint32_t>& sizes, std::vector<long>& rids) {
     int rlen = 0, indel = 0; bool spliced = false;
+    int fi = -1;
     for (int k = 0; k < a.n_cigar; ++k) {
         uint32_t op = a.cigar[k] >> 28, len = a.cigar[k] & 0x0FFFFFFF;
         if (op == 1 || op == 2 || op == 3 || op == 4 || op == 13) rlen += (int)len;
         if (op >= 3 && op <= 6) indel += (int)len;
         if (op == 11 || op == 12) spliced = true;
+        if (op >= THJ_CIG_FUSION_FF && op <= THJ_CIG_FUSION_RR && fi < 0) fi = k;
     }
     std::string seq = rd.seq, qual = rd.qual;
     seq.resize((size_t)rlen); qual.resize((size_t)rlen);
     uint32_t flag = 0;
     if (a.flags & THJ_HIT_ANTISENSE) { flag |= 0x10; reverse_complement(seq); std::reverse(qual.begin(), qual.end()); }
+    const uint32_t ref_id2 = fi >= 0 ? a.cigar[15] : a.ref_id;
     std::vector<std::string> aux;
     aux.push_back("AS:i:" + std::to_string((int)a.AS));
     aux.push_back("XM:i:" + std::to_string((int)a.XM));
@@ -96,14 +102,59 @@ static long encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a
     if (a.md_len == THJ_MD_ON_HOST) {                       // longer than a device record holds: rebuilt here from the same inputs
         char md[2048];
         const std::string& ref = rt.seqs[a.ref_id - 1];
-        const int n = thj_md_string(ref.data(), (int64_t)ref.size(), seq.data(), (int32_t)seq.size(), a.left, a.cigar, a.n_cigar, md, (int32_t)sizeof md);
+        const std::string& ref2 = rt.seqs[ref_id2 - 1];
+        const int n = fi >= 0 ? thj_md_string2(ref.data(), (int64_t)ref.size(), ref2.data(), (int64_t)ref2.size(), seq.data(), (int32_t)seq.size(), a.left,
+                                               a.cigar, a.n_cigar, md, (int32_t)sizeof md)
+                              : thj_md_string(ref.data(), (int64_t)ref.size(), seq.data(), (int32_t)seq.size(), a.left, a.cigar, a.n_cigar, md, (int32_t)sizeof md);
         if (n < 0) die("Error: %s\n", thj_last_error());
         aux.push_back("MD:Z:" + std::string(md, (size_t)n));
     } else aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
     aux.push_back("NM:i:" + std::to_string((int)a.mismatches + indel));
     if (spliced) aux.push_back(std::string("XS:A:") + ((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'));
-    bw.encode(d, rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
-    return atol(rd.name.c_str());
+    const long rid = atol(rd.name.c_str());
+    size_t before = d.size();
+    if (fi < 0) {
+        bw.encode(d, rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
+        sizes.push_back((uint32_t)(d.size() - before)); rids.push_back(rid);
+        return;
+    }
+    // ---- fusion alignment
+    static const char letter[16] = {0, 'M', 'm', 'I', 'i', 'D', 'd', 'F', 'F', 'F', 'F', 'N', 'n', 'S', 0, 0};
+    const uint32_t fdir = a.cigar[fi] >> 28;
+    std::string full;
+    int right = a.left, fusion_left = -1, fusion_right = -1;
+    size_t left_part_len = 0;
+    for (int k = 0; k < a.n_cigar; ++k) {
+        const uint32_t op = a.cigar[k] >> 28, len = a.cigar[k] & 0x0FFFFFFF;
+        full += std::to_string(op >= 7 && op <= 10 ? len + 1 : len); full += letter[op];
+        if (op == 1 || op == 11 || op == 5) right += (int)len;
+        else if (op == 2 || op == 12 || op == 6) right -= (int)len;
+        else if (op >= 7 && op <= 10) { fusion_left = (op == 7 || op == 8) ? right - 1 : right + 1; fusion_right = right = (int)len; }
+        if (k < fi && (op == 1 || op == 2 || op == 3 || op == 4)) left_part_len += len;
+    }
+    auto upper = [](uint32_t c) { const uint32_t op = c >> 28; return (op == 2 || op == 4 || op == 6 || op == 12) ? (((op - 1) << 28) | (c & 0x0FFFFFFF)) : c; };
+    uint32_t c1[16], c2[16]; int n1 = 0, n2 = 0;
+    if (fdir == 7 || fdir == 8) for (int k = 0; k < fi; ++k) c1[n1++] = upper(a.cigar[k]);
+    else for (int k = fi - 1; k >= 0; --k) c1[n1++] = upper(a.cigar[k]);
+    if (fdir == 7 || fdir == 9) for (int k = fi + 1; k < a.n_cigar; ++k) c2[n2++] = upper(a.cigar[k]);
+    else for (int k = a.n_cigar - 1; k > fi; --k) c2[n2++] = upper(a.cigar[k]);
+    if (left_part_len > seq.size()) left_part_len = seq.size();
+    std::string seq1 = seq.substr(0, left_part_len), qual1 = qual.substr(0, left_part_len);
+    std::string seq2 = seq.substr(left_part_len), qual2 = qual.substr(left_part_len);
+    if (fdir == 9 || fdir == 10) { reverse_complement(seq1); std::reverse(qual1.begin(), qual1.end()); }
+    if (fdir == 8 || fdir == 10) { reverse_complement(seq2); std::reverse(qual2.begin(), qual2.end()); }
+    const int left1 = (fdir == 7 || fdir == 8) ? a.left : fusion_left;
+    const int left2 = (fdir == 7 || fdir == 9) ? fusion_right : right + 1;
+    const std::string& n1s = rt.names[a.ref_id - 1];
+    const std::string& n2s = rt.names[ref_id2 - 1];
+    const std::string xf = " " + n1s + "-" + n2s + " " + std::to_string(a.left + 1) + " " + full + " " + seq + " " + qual;
+    aux.push_back("XF:Z:1" + xf);
+    bw.encode(d, rd.name, flag, n1s, left1 + 1, c1, n1, seq1, qual1, aux);
+    sizes.push_back((uint32_t)(d.size() - before)); rids.push_back(rid);
+    before = d.size();
+    aux.back() = "XF:Z:2" + xf;
+    bw.encode(d, rd.name, flag, n2s, left2 + 1, c2, n2, seq2, qual2, aux);
+    sizes.push_back((uint32_t)(d.size() - before)); rids.push_back(rid);
 }
 
 static void encode_batch(const BamWriter& bw, const RefTable& rt, const std::vector<thj_aln>& alns, const std::vector<Read>& reads, int threads,
@@ -112,19 +163,26 @@ static void encode_batch(const BamWriter& bw, const RefTable& rt, const std::vec
     int T = threads;
     if ((size_t)T > n / 256 + 1) T = (int)(n / 256 + 1);
     std::vector<std::vector<uint8_t>> part((size_t)T);
-    e.size.resize(n); e.rid.resize(n);
+    std::vector<std::vector<uint32_t>> psize((size_t)T);
+    std::vector<std::vector<long>> prid((size_t)T);
     auto work = [&](int t) {
         const size_t a = n * (size_t)t / (size_t)T, b = n * (size_t)(t + 1) / (size_t)T;
         std::vector<uint8_t>& d = part[(size_t)t];
         d.reserve((b - a) * 256);
-        for (size_t i = a; i < b; ++i) { size_t before = d.size(); e.rid[i] = encode_aln(bw, rt, alns[i], reads[alns[i].read_idx], d); e.size[i] = (uint32_t)(d.size() - before); }
+        psize[(size_t)t].reserve(b - a); prid[(size_t)t].reserve(b - a);
+        for (size_t i = a; i < b; ++i) encode_aln(bw, rt, alns[i], reads[alns[i].read_idx], d, psize[(size_t)t], prid[(size_t)t]);
     };
     if (T > 1) { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, t); for (auto& x : th) x.join(); }
     else work(0);
-    size_t total = 0;
+    size_t total = 0, nrec = 0;
     for (auto& d : part) total += d.size();
-    e.bytes.reserve(total);
-    for (auto& d : part) { e.bytes.insert(e.bytes.end(), d.begin(), d.end()); std::vector<uint8_t>().swap(d); }
+    for (auto& v : psize) nrec += v.size();
+    e.bytes.reserve(total); e.size.reserve(nrec); e.rid.reserve(nrec);
+    for (size_t t = 0; t < (size_t)T; ++t) {
+        e.bytes.insert(e.bytes.end(), part[t].begin(), part[t].end()); std::vector<uint8_t>().swap(part[t]);
+        e.size.insert(e.size.end(), psize[t].begin(), psize[t].end());
+        e.rid.insert(e.rid.end(), prid[t].begin(), prid[t].end());
+    }
 }
 
 // records of one shard on their way to the writer
@@ -143,7 +201,7 @@ int main(int argc, char** argv) {
     for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
     if (pos.size() < 8) { print_usage(); return 1; }
     if (o.color) die("Error: colour-space reads are not supported by this build\n");
-    if (o.fusion_search) die("Error: --fusion-search is not supported by this build yet\n");
+    o.p.fusion_search = o.fusion_search ? 1 : 0;
     std::vector<std::string> spliced_segs;
     if (pos.size() >= 9) spliced_segs = split(pos[8], ',');
     std::vector<std::string> segs = split(pos[7], ',');
@@ -239,6 +297,34 @@ int main(int argc, char** argv) {
         if (i && ins[i].ref == ins[i - 1].ref && ins[i].left == ins[i - 1].left && ins[i].len == ins[i - 1].len) continue;
         ins_tab.insert(ins_tab.end(), {ins[i].ref, ins[i].left, ins[i].len, ins[i].seq});
     }
+    // ---- --fusion-search: the .fusions lists -> std::set<Fusion> (:2998-3040, fusions.h:44-71)
+    std::vector<thj_span_fusion> fusions;
+    if (o.fusion_search) {
+        for (auto& fn : split(pos[5], ',')) {
+            FILE* f = fopen(fn.c_str(), "r");
+            if (!f) continue;
+            char buf[2048];
+            while (fgets(buf, sizeof buf, f)) {
+                char* nl = strrchr(buf, '\n'); if (nl) *nl = 0;
+                std::vector<std::string> t;                      // strsep: empty fields count
+                { const char* b0 = buf; for (const char* q = buf;; ++q) if (*q == '\t' || !*q) { t.emplace_back(b0, q); if (!*q) break; b0 = q + 1; } }
+                if (t.size() < 5) die("Error: malformed insertion coordinate record\n");
+                uint32_t dir = THJ_CIG_FUSION_FF;
+                if (t[4] == "fr") dir = THJ_CIG_FUSION_FR; else if (t[4] == "rf") dir = THJ_CIG_FUSION_RF; else if (t[4] == "rr") dir = THJ_CIG_FUSION_RR;
+                fusions.push_back({rt.get_id(t[0]), rt.get_id(t[2]), (uint32_t)atoi(t[1].c_str()), (uint32_t)atoi(t[3].c_str()), dir});
+            }
+            fclose(f);
+        }
+        auto fl = [](const thj_span_fusion& a, const thj_span_fusion& b) {
+            if (a.ref_id1 != b.ref_id1) return a.ref_id1 < b.ref_id1;
+            if (a.ref_id2 != b.ref_id2) return a.ref_id2 < b.ref_id2;
+            if (a.left != b.left) return a.left < b.left;
+            if (a.right != b.right) return a.right < b.right;
+            return a.dir < b.dir;
+        };
+        std::sort(fusions.begin(), fusions.end(), fl);
+        fusions.erase(std::unique(fusions.begin(), fusions.end(), [&](const thj_span_fusion& a, const thj_span_fusion& b) { return !fl(a, b) && !fl(b, a); }), fusions.end());
+    }
     for (auto& f : segs) register_targets(f, rt);
     rt.freeze();
     {   // junctions on contigs the device genome does not know cannot be closed anyway: drop them
@@ -255,6 +341,7 @@ int main(int argc, char** argv) {
         g.ctx = g.fut.get();
         rt.upload(g.ctx);
         if (thj_span_sets_upload(g.ctx, juncs.data(), (int64_t)juncs.size(), ins_tab.data(), (int64_t)ins_tab.size() / 4)) die("Error: %s\n", thj_last_error());
+        if (o.fusion_search && thj_span_fusions_upload(g.ctx, fusions.data(), (int64_t)fusions.size())) die("Error: %s\n", thj_last_error());
         if (thj_span_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
         return g.ctx;
     };

@@ -721,7 +721,13 @@ inline void cigar_add(CigVec& c, std::pair<int, int> op) {          // bwt_map.c
 inline bool splice_cigar(CigVec& out, const CigVec& cigar, const std::vector<bool>& mism, int& left, int spl_start, int spl_len,
                          int spl_code, int& spl_mm, int min_anchor_len) {
     const int INS = 3, DEL = 5, REF_SKIP = 11, MATCH = 1, PAD = 15, SOFT = 13;
+    // fusion ops (7 ff, 8 fr, 9 rf, 10 rr): the piece before an rf / rr break and the piece after an fr / rr break run down the
+    // genome and come out as the lower-case ops (MATCH -> mATCH ..., bwt_map.cpp:753-790, :822-853)
+    const bool fus = spl_code >= 7 && spl_code <= 10;
+    const bool low_before = spl_code == 9 || spl_code == 10, low_after = spl_code == 8 || spl_code == 10;
+    auto lower = [](std::pair<int, int> op) { if (op.first == 1 || op.first == 3 || op.first == 5 || op.first == 11) ++op.first; return op; };
     int spl_ofs = spl_start - left;
+    if (fus) spl_ofs = abs(spl_ofs);
     int spl_ofs_end = spl_ofs;
     std::pair<int, int> gapop(spl_code, spl_len);
     if (spl_code == INS) spl_ofs_end += spl_len;
@@ -743,7 +749,7 @@ inline bool splice_cigar(CigVec& out, const CigVec& cigar, const std::vector<boo
             else if (cur_opcode == SOFT || cur_opcode == INS) read_ofs += cur_oplen;
             if (cur_op_ofs >= spl_ofs_end || ref_ofs <= spl_ofs) {
                 if (cur_op_ofs == spl_ofs_end && spl_code != INS && cur_opcode != INS) { xfound = true; cigar_add(out, gapop); }
-                cigar_add(out, cigar[c]);
+                cigar_add(out, ((xfound && low_after) || (!xfound && low_before)) ? lower(cigar[c]) : cigar[c]);
             } else {
                 xfound = true;
                 if (spl_code == INS) {
@@ -757,10 +763,10 @@ inline bool splice_cigar(CigVec& out, const CigVec& cigar, const std::vector<boo
                 } else {
                     std::pair<int, int> op = cigar[c];
                     op.second = spl_ofs - cur_op_ofs;
-                    cigar_add(out, op);
+                    cigar_add(out, low_before ? lower(op) : op);
                     cigar_add(out, gapop);
                     op.second = ref_ofs - spl_ofs;
-                    cigar_add(out, op);
+                    cigar_add(out, low_after ? lower(op) : op);
                 }
             }
         }
@@ -771,11 +777,13 @@ inline bool splice_cigar(CigVec& out, const CigVec& cigar, const std::vector<boo
         out = cigar;
     }
     if (out.size() < cigar.size() + 2) return false;
-    if (out.front().first != MATCH || out.back().first != MATCH) return false;
+    if ((out.front().first != MATCH && out.front().first != 2) || (out.back().first != MATCH && out.back().first != 2)) return false;
     return true;
 }
 
-inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& out) {
+// from_bam: SplicedBAMHitFactory understands the fusion contigs of the junction database (strand ff / fr / rf / rr), the SAM
+// factory drops every record whose strand field is not fwd / rev (bwt_map.cpp:972-975)
+inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& out, bool from_bam = true) {
     bool end = true;
     std::string q = r.qname;
     size_t pipe = q.rfind('|');
@@ -831,44 +839,62 @@ inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p
     if (st.size() != 2) { fprintf(stderr, "Warning: found malformed splice record, skipping:\n"); return false; }
     const std::string& jtype = toks[(size_t)ne + 4];
     const std::string& jstrand = toks[(size_t)ne + 5];
+    if (!from_bam && jstrand != "rev" && jstrand != "fwd") { fprintf(stderr, "Malformed insertion record\n"); return false; }
     int left = atoi(toks[(size_t)ne + 1].c_str()) + r.pos;
     int lsp = atoi(st[0].c_str());
     CigVec spl;
     int spl_mm = 0;
+    bool anti = (r.flag & 0x10) != 0, flipped = false;
+    uint32_t ref_id2 = 0;
     if (jtype == "ins") {
         if (left > lsp) return false;
         if (!splice_cigar(spl, samcigar, mism, left, lsp + 1, (int)st[1].size(), 3, spl_mm, p.min_anchor_len)) return false;
         if (spl_mm < 0) return false;
         num_mm -= spl_mm;
     } else {
-        if (jtype == "fus") die("Error: fusion junction-db hits are not supported by this build\n");
         if (!(jstrand == "ff" || jstrand == "fr" || jstrand == "rf" || jstrand == "rr" || jstrand == "rev" || jstrand == "fwd")) {
             fprintf(stderr, "Warning: found malformed splice record, skipping\n"); return false;
         }
+        const bool fus = jtype == "fus";
+        // :1672-1677: on rf / rr fusion contigs the first piece runs down the genome from the contig's left edge
+        if (fus && (jstrand == "rf" || jstrand == "rr")) left = atoi(toks[(size_t)ne + 1].c_str()) - r.pos;
         int opcode = jtype == "del" ? 5 : 11;
-        int gap_len = atoi(st[1].c_str()) - lsp - 1;
-        lsp += 1;
-        if (left >= lsp) return false;
+        if (fus) opcode = jstrand == "ff" ? 7 : (jstrand == "fr" ? 8 : (jstrand == "rf" ? 9 : 10));
+        int gap_len = fus ? atoi(st[1].c_str()) : atoi(st[1].c_str()) - lsp - 1;
+        if (opcode == 9 || opcode == 10) { lsp -= 1; if (left <= lsp) return false; }
+        else { lsp += 1; if (left >= lsp) return false; }
         if (!splice_cigar(spl, samcigar, mism, left, lsp, gap_len, opcode, spl_mm, p.min_anchor_len)) return false;
+        if (fus) {
+            std::vector<std::string> cs = split(contig, '-');
+            if (cs.size() != 2) return false;
+            contig = cs[0];
+            ref_id2 = rt.get_id(cs[1]);
+            if (ref_id2 == 0) return false;
+            if (jstrand == "rf" || jstrand == "rr") { anti = !anti; flipped = true; }
+        }
     }
-    if (spl.size() > 5) die("Error: spliced segment alignment %s has %d CIGAR operations (this build supports 5)\n", r.qname.c_str(), (int)spl.size());
+    if (spl.size() > (ref_id2 ? 4u : 5u))
+        die("Error: spliced segment alignment %s has %d CIGAR operations (this build supports 5, 4 on a fusion contig)\n", r.qname.c_str(), (int)spl.size());
     int gap = 0, right = left, read_len = 0;
+    for (int k = 0; k < 5; ++k) out.h32.cigar[k] = 0;
     for (size_t k = 0; k < spl.size(); ++k) {
         int op = spl[k].first, len = spl[k].second;
-        if (op == 3 || op == 5) gap += len;
+        if (op >= 3 && op <= 6) gap += len;
         if (op == 1 || op == 5 || op == 11) right += len;
-        if (op == 1 || op == 3 || op == 13) read_len += len;
+        else if (op == 2 || op == 6 || op == 12) right -= len;
+        else if (op >= 7 && op <= 10) right = len;
+        if (op == 1 || op == 2 || op == 3 || op == 4 || op == 13) read_len += len;
         out.h32.cigar[k] = ((uint32_t)op << 28) | ((uint32_t)len & 0x0FFFFFFFu);
     }
+    if (ref_id2) out.h32.cigar[4] = ref_id2;          // a fused hit keeps its second contig in the last cigar slot (include/thj.h)
     uint32_t ref_id = rt.get_id(contig);
     if (ref_id == 0) return false;
-    bool anti = (r.flag & 0x10) != 0;
     unsigned char mm8 = (unsigned char)num_mm, ed = (unsigned char)(num_mm + gap);
     out.h16.ref_id = ref_id; out.h16.left = left; out.h16.right = right;
     out.h16.flags = (uint8_t)((anti ? THJ_HIT_ANTISENSE : 0) | (end ? THJ_HIT_END : 0));
     out.h16.edit_dist = ed; out.h16.mismatches = mm8; out.h16.read_len = (uint8_t)(read_len > 255 ? 255 : read_len);
     out.h32.ref_id = ref_id; out.h32.left = left;
-    out.h32.flags = (uint8_t)(out.h16.flags | (jstrand == "rev" ? THJ_HIT_ANTISENSE_SPLICE : 0));
+    out.h32.flags = (uint8_t)(out.h16.flags | (jstrand == "rev" ? THJ_HIT_ANTISENSE_SPLICE : 0) | (flipped ? THJ_HIT_STRAND_FLIPPED : 0));
     out.h32.mismatches = mm8; out.h32.edit_dist = ed; out.h32.n_cigar = (uint8_t)spl.size();
     return true;
 }
@@ -928,7 +954,7 @@ class HitStream {
                 if (!parse_hit_bam(d, bs, tid2ref, *p_, h)) continue;
             } else {
                 if (!rd_.next(r)) break;
-                if (!(spliced_ ? parse_spliced_hit(r, *rt_, *p_, h) : parse_hit(r, *rt_, *p_, h))) continue;
+                if (!(spliced_ ? parse_spliced_hit(r, *rt_, *p_, h, rd_.is_bam()) : parse_hit(r, *rt_, *p_, h))) continue;
             }
             if (h.insert_id < begin_id_) continue;       // the index entry the shard starts from lies at or before begin_id
             if (h.insert_id >= end_id_) break;           // id-sorted file: the shard is over
