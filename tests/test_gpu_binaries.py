@@ -208,6 +208,7 @@ def test_long_spanning_reads_fusion_search(name, threads, tmp_path):
     argv = opts[0].split()
     seglen = dict(x.split("=") for x in opts[1].split())["segment_length"]
     nseg = len([f for f in os.listdir(d) if f.startswith("left_seg") and f.endswith(".to_spliced.sam")])
+    n_xf = 0
     for sd in ("left", "right"):
         sp = []
         for k in range(nseg):
@@ -224,5 +225,6 @@ def test_long_spanning_reads_fusion_search(name, threads, tmp_path):
         _, recs = read_bam(bam)
         want = [tuple(l.rstrip("\n").split("\t")) for l in open(os.path.join(d, "expected.span_%s.sam" % sd))]
         assert [tuple(str(x) for x in rec) for rec in recs] == want
-        assert sum(1 for rec in recs if any(str(x).startswith("XF:Z:") for x in rec)) >= 20
+        n_xf += sum(1 for rec in recs if any(str(x).startswith("XF:Z:") for x in rec))
         assert gzip.open(bam, "rb").read() == gzip.open(os.path.join(d, "expected.span_%s.bam" % sd), "rb").read()
+    assert n_xf >= 40
