@@ -220,6 +220,9 @@ def parse_args():
     ap.add_argument("--multihit-frac", type=float, default=0.0,
                     help="fraction of reads whose segment hits are all reported at two loci (the genome's second half becomes a copy "
                          "of the first): exercises the multihit tier; 0 = BASELINE configs[1] as specified")
+    ap.add_argument("--fusion-search", action="store_true",
+                    help="run long_spanning_reads' stage with fusion search on (the shape of configs[3]): reads tiers 0 / 1 cannot join go "
+                         "through the fusion branches (thj_k_stitch_fusion) against an empty fusion list")
     ap.add_argument("--no-hit-heads", action="store_true",
                     help="hand stage 2 the 32-byte hit records only, without the dense 16-byte head array every batch of the library carries "
                          "(thj_span_batch.hit_heads: derived once when a batch is made -- thj_span_batch_upload, the device-side ingest -- so "
@@ -434,7 +437,9 @@ def run_rank(args, rank, world, local_rank, control, shared):
     pk = dict(inner_dist_mean=50, inner_dist_std_dev=20, max_segment_intron=max_intron, max_report_intron=max_intron)
     p_left = Params(read_side=READ_LEFT, **pk)
     p_right = Params(read_side=READ_RIGHT, **pk)
-    p_span = Params(max_segment_intron=max_intron, max_report_intron=max_intron)
+    p_span = Params(max_segment_intron=max_intron, max_report_intron=max_intron, fusion_search=1 if args.fusion_search else 0)
+    if args.fusion_search:
+        ctx.upload_span_fusions(np.zeros(0, dtype=host.SPAN_FUSION_DTYPE))
     # first-inserted-wins priority of std::set<Insertion>: all left reads (rank order) before all right reads
     cb_left = cbatch_from_tensors(w["left"], rank * args.pairs)
     cb_right = cbatch_from_tensors(w["right"], world * args.pairs + rank * args.pairs)
@@ -668,6 +673,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_text,
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
+                       "fusion_search": bool(args.fusion_search), "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"), "traffic_low": dom.get("traffic_low"),

@@ -283,6 +283,7 @@ typedef struct {
  * of the record's strand flag (:1744-1745): THJ_HIT_STRAND_FLIPPED says so, i.e. the record's SEQ is the read piece
  * reverse-complemented iff THJ_HIT_ANTISENSE xor THJ_HIT_STRAND_FLIPPED. */
 #define THJ_HIT_STRAND_FLIPPED 8u
+#define THJ_HIT_FUSED 16u          /* the hit's cigar holds a fusion op (set by whoever builds the record; the stitch kernels route on it) */
 
 /* Per-read segment hit lists of JoinSegmentsWorker (long_spanning_reads.cpp:2669-2845):
  * for every read with a hit in the first segment map, segment s holds the contig

@@ -242,7 +242,14 @@ extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blo
         if (!skip_tier0)
             st = span_read_contig(g, p, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                   read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
-        if ((st & 0xFF) == SPAN_NEED_LEAN) st = SPAN_NEED_GENERIC;
+        if ((st & 0xFF) == SPAN_NEED_LEAN) {            // tier 1 as the kernel runs it: a read it cannot join goes on to the fusion tier
+            status_counts[4]++;
+            SpanHitHead stage[SPAN_MAXSEG];
+            const size_t before = res.size();
+            st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
+            if (p.fusion_search && st == SPAN_OK && res.size() == before) st = SPAN_NEED_GENERIC;
+        }
         if (st == SPAN_NEED_GENERIC) {
             status_counts[3]++;
             st = span_read_fusion(g, p, S, F, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,

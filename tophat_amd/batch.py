@@ -229,6 +229,7 @@ SPAN_HIT_DTYPE = np.dtype([
 ])
 assert SPAN_HIT_DTYPE.itemsize == 32
 HIT_ANTISENSE_SPLICE = 4
+HIT_FUSED = 16                  # the hit's cigar holds a fusion op
 HIT_STRAND_FLIPPED = 8          # hit on an rf / rr fusion contig: antisense_align is the opposite of the record's strand flag
 CIG_FUSION_FF, CIG_FUSION_FR, CIG_FUSION_RF, CIG_FUSION_RR = 7, 8, 9, 10
 FUSION_OPS = (7, 8, 9, 10)
@@ -277,7 +278,7 @@ def span_hit_struct(h: HitRec) -> tuple:
         cig[4] = int(h[11])        # ref_id2 rides in the last cigar slot
         flipped = bool(h[12])
     return (ref_id, left, (HIT_ANTISENSE if anti else 0) | (HIT_END if end else 0) | (HIT_ANTISENSE_SPLICE if asp else 0) |
-            (HIT_STRAND_FLIPPED if flipped else 0), mm & 0xFF, ed & 0xFF, len(cigar), cig)
+            (HIT_STRAND_FLIPPED if flipped else 0) | (HIT_FUSED if fused else 0), mm & 0xFF, ed & 0xFF, len(cigar), cig)
 
 
 def build_span_batch(seg_recs: Sequence[Iterable[HitRec]], reads: Dict[int, str], quals: Dict[int, str],

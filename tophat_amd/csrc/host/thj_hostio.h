@@ -894,7 +894,8 @@ inline bool parse_spliced_hit(const AlnRec& r, RefTable& rt, const thj_params& p
     out.h16.flags = (uint8_t)((anti ? THJ_HIT_ANTISENSE : 0) | (end ? THJ_HIT_END : 0));
     out.h16.edit_dist = ed; out.h16.mismatches = mm8; out.h16.read_len = (uint8_t)(read_len > 255 ? 255 : read_len);
     out.h32.ref_id = ref_id; out.h32.left = left;
-    out.h32.flags = (uint8_t)(out.h16.flags | (jstrand == "rev" ? THJ_HIT_ANTISENSE_SPLICE : 0) | (flipped ? THJ_HIT_STRAND_FLIPPED : 0));
+    out.h32.flags = (uint8_t)(out.h16.flags | (jstrand == "rev" ? THJ_HIT_ANTISENSE_SPLICE : 0) | (flipped ? THJ_HIT_STRAND_FLIPPED : 0) |
+                              (ref_id2 ? THJ_HIT_FUSED : 0));
     out.h32.mismatches = mm8; out.h32.edit_dist = ed; out.h32.n_cigar = (uint8_t)spl.size();
     return true;
 }

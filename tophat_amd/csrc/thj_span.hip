@@ -130,7 +130,6 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
         if (r < c1) {
             int st = span_read_contig_pre<MS>(g, p, b.hits, sv, b.nseg, b.planes + (u64)r * (uint32_t)(3 * b.W), b.W,
                                           rl, b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss, b.heads);
-            if (p.fusion_search && (st & 0xFF) == SPAN_NEED_LEAN) st = SPAN_NEED_GENERIC;     // fusion search: thj_k_stitch_fusion takes every read tier 0 does not finish
             if ((st & 0xFF) == SPAN_NEED_LEAN) {
                 const unsigned int cls = NC > 1 ? (unsigned int)(st >> 8) : 0u;
                 t.wl_lean[(u64)(cls * gridDim.x + blockIdx.x) * (uint32_t)t.chunk + atomicAdd(&s_lean[cls], 1u)] = r;
@@ -205,6 +204,9 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
         const int r = (int)t.wl_lean[(int64_t)sl * t.chunk + (i - s_off[sl])];
         int st = span_read_lean<MS>(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, stage, sink);
+        // fusion search: a one-hit-per-segment read that joins the plain way joins the same way with fusion search on (its only
+        // chain never takes a fusion direction); one that does not may be a fusion read -- thj_k_stitch_fusion decides
+        if (p.fusion_search && st == SPAN_OK && sink.emitted == 0) st = SPAN_NEED_GENERIC;
         if (st == SPAN_NEED_GENERIC) {          // rare: more cigar ops than the registers hold
             sl %= G;                            // the slice of the block of tier 0 that owns the read
             t.wl_multi[(int64_t)sl * t.chunk + atomicAdd(&t.blk_multi[sl], 1u)] = (uint32_t)r;
@@ -612,17 +614,19 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
+    const int64_t g1 = G, g2 = G;
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
     if (p.fusion_search) {
+        // tiers 0 and 1 keep the reads that join without a fusion; multihit reads, reads with a fused segment hit and reads tier 1
+        // could not join are on the multihit list and go through the fusion branches
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
         int64_t gf = ((int64_t)b.n_reads + 63) / 64;
         if (gf > 8192) gf = 8192;
-        if (c->span_profile) { HIPCHK(hipEventRecord(ev[2], c->stream)); HIPCHK(hipEventRecord(ev[3], c->stream)); }
+        if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
         hipLaunchKernelGGL(thj_k_stitch_fusion, dim3((unsigned)gf), dim3(64), 0, c->stream, g, p, S, F, b, sink, t, (int)G);
     } else {
-        const int64_t g1 = G, g2 = G;
-        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
-        else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
-        if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
         const int caph = b.nseg <= 4 ? 12 : 16;           // hit heads staged per read in tier 2 (16 bytes each)
         if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_multihit<4>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
         else hipLaunchKernelGGL(thj_k_stitch_multihit<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);

@@ -32,7 +32,7 @@ struct SpanHit {            // == thj_span_hit, 32 bytes
     uint32_t meta;          // flags | mismatches<<8 | edit_dist<<16 | n_cigar<<24
     uint32_t cigar[5];
 };
-enum { SH_ANTI = 1, SH_END = 2, SH_ASPLICE = 4 };
+enum { SH_ANTI = 1, SH_END = 2, SH_ASPLICE = 4, SH_FUSED = 16 };
 
 static constexpr int SPAN_MAXC = 16;      // cigar ops of a joined alignment
 static constexpr int SPAN_MAXSEG = 8;
@@ -1379,6 +1379,12 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
 #pragma unroll
     for (int s = 1; s < MS; ++s) last_meta = (s == nsegs - 1) ? hh[s].meta : last_meta;
     if (!(last_meta & SH_END)) return SPAN_OK;
+    if (p.fusion_search) {                 // a fused segment hit (junction-db fusion contig): only the fusion tier reads its cigar
+        uint32_t any = 0;
+#pragma unroll
+        for (int s = 0; s < MS; ++s) any |= s < nsegs ? hh[s].meta : 0u;
+        if (any & SH_FUSED) return SPAN_NEED_GENERIC;
+    }
     const SpanHitHead h0 = hh[0];
     const bool anti = (h0.meta & SH_ANTI) != 0;
     if ((h0.meta >> 24) != 1u || cig_op(h0.cigar0) != OP_MATCH) return SPAN_NEED_LEAN;

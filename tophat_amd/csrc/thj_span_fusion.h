@@ -17,7 +17,7 @@
 namespace thj {
 
 enum { OP_FUS_FF = 7, OP_FUS_FR = 8, OP_FUS_RF = 9, OP_FUS_RR = 10 };
-enum { SH_FLIPPED = 8 };                      // == THJ_HIT_STRAND_FLIPPED
+enum { SH_FLIPPED = 8 };                      // == THJ_HIT_STRAND_FLIPPED (SH_FUSED = 16 == THJ_HIT_FUSED: thj_span_core.h)
 static constexpr int FUS_MAXC = 16;           // cigar ops of a (joined) hit; cigar[15] of an output record carries ref_id2
 static constexpr int FUS_MAXJOIN = 24;        // joined alignments kept per read before sort + unique
 
