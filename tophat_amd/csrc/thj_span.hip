@@ -195,8 +195,9 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
     extern __shared__ uint4 lds_stage[];          // nseg hit heads per thread
     constexpr int NC = lean_classes(MS);
     __shared__ unsigned int s_off[NC * MAX_SLICES + 1];
-    __shared__ unsigned int s_rec;
-    if (threadIdx.x == 0) s_rec = 0;
+    __shared__ unsigned int s_rec, s_fwd;
+    if (threadIdx.x == 0) { s_rec = 0; s_fwd = 0; }
+    unsigned int n_fwd = 0;
     SpanHitHead* stage = (SpanHitHead*)lds_stage + (size_t)threadIdx.x * b.nseg;
     const unsigned int total = slice_offsets<256, NC * MAX_SLICES>(t.blk_lean, NC * G, s_off);
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
@@ -210,12 +211,14 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
         if (st == SPAN_NEED_GENERIC) {          // rare: more cigar ops than the registers hold
             sl %= G;                            // the slice of the block of tier 0 that owns the read
             t.wl_multi[(int64_t)sl * t.chunk + atomicAdd(&t.blk_multi[sl], 1u)] = (uint32_t)r;
-            atomicAdd(&t.counters[1], 1u);
-        } else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
+            ++n_fwd;                            // (one global counter hit per read would serialise the launch: with fusion search
+        } else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }   //  on every unjoined read comes this way)
     }
     if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    if (n_fwd) atomicAdd(&s_fwd, n_fwd);
     __syncthreads();
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
+    if (threadIdx.x == 0 && s_fwd) atomicAdd(&t.counters[1], s_fwd);
 }
 
 // Tier 2: multihit reads with at most `caph` hits -- the 16-byte heads of all the read's hits staged in LDS, the DFS
