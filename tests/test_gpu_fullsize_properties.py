@@ -34,6 +34,9 @@ if os.environ.get("THJ_FULLSIZE_PAIRS"):
 # ref ids > 1); THJ_FULLSIZE_GRCH38=0 skips it (it needs ~10 GB of host memory for the genome text and the oracle's copy)
 if os.environ.get("THJ_FULLSIZE_GRCH38", "1") == "1":
     SHAPES.append((100, 4_000_000, 0.0, "grch38"))
+# ... and configs[4] as written: 2 x 50 bp reads (two segments: the mate-anchored rescue does the work), --max-intron-length
+# 500000 with introns planted up to 499 999 bases -- the widest windows the path allows
+SHAPES.append((50, 4_000_000, 0.0, "chr20", 499_999))
 
 
 def half(w, which):
@@ -57,14 +60,16 @@ def half(w, which):
 
 
 @pytest.fixture(scope="module", params=SHAPES,
-                ids=lambda s: "%dbp_%dMpairs%s%s" % (s[0], s[1] // 1_000_000, "_multihit" if s[2] else "", "_grch38" if len(s) > 3 else ""))
+                ids=lambda s: "%dbp_%dMpairs%s%s%s" % (s[0], s[1] // 1_000_000, "_multihit" if s[2] else "",
+                                                       "_grch38" if len(s) > 3 and s[3] == "grch38" else "", "_intron%dk" % (s[4] // 1000) if len(s) > 4 else ""))
 def world(request):
     read_len, pairs, multi_frac = request.param[:3]
     dev = torch.device("cuda", 0)
-    if len(request.param) > 3:
-        seqs, genes = make_scale_genome(1, GRCH38_LENS, 300000, exon_len=300)
+    intron_max = request.param[4] if len(request.param) > 4 else 200000
+    if len(request.param) > 3 and request.param[3] == "grch38":
+        seqs, genes = make_scale_genome(1, GRCH38_LENS, 300000, exon_len=300, intron_max=intron_max)
     else:
-        seqs, genes = make_scale_genome(1, [CHR20_LEN], 20000, exon_len=300)
+        seqs, genes = make_scale_genome(1, [CHR20_LEN], 20000, exon_len=300, intron_max=intron_max)
     dup_shift = 0
     if multi_frac > 0:
         dup_shift = len(seqs[0]) // 2
@@ -77,7 +82,7 @@ def world(request):
     ctx = host.Context(0, stream=stream.cuda_stream)
     ctx.upload_genome(host.pack_genome(strs))
     ctx.configure(1 << 22, 1 << 20)
-    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream, read_len=read_len, pairs=pairs, multi_frac=multi_frac)
+    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream, read_len=read_len, pairs=pairs, multi_frac=multi_frac, intron_max=intron_max)
     ctx.close()
     del w
     torch.cuda.empty_cache()
@@ -106,6 +111,9 @@ def test_fullsize_properties(world):
     truth = {(int(g[0]) + 1, int(g[2]) - 1, int(g[3])) for g in genes}
     found = {(k[0], k[1], k[2]) for k in keys}
     assert len(found & truth) > (0.95 if read_len >= 100 else 0.5) * len(truth)
+    if world["intron_max"] > 400_000:        # configs[4]: the longest planted introns are there and they are found
+        assert max(k[2] - k[1] for k in truth) > 450_000
+        assert max(k[2] - k[1] for k in found & truth) > 400_000
 
     # idempotence
     ev2 = run_stage1(ctx, full)
