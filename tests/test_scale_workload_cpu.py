@@ -39,3 +39,45 @@ def test_scale_workload_both_stages():
         n_spliced += sum(1 for a in want if any((c >> 28) == 11 for c in a.cigar))
         assert len(want) > 0.5 * n
     assert n_spliced > 0.1 * n
+
+
+def fusion_list_from_events(f):
+    """what long_spanning_reads would load from the .fusions file: (ref1, ref2, left, right, dir) sorted unique"""
+    rows = sorted({(int(x["ref_id1"]), int(x["ref_id2"]), int(x["left"]), int(x["right"]), int(x["dir"])) for x in f})
+    return np.array(rows, dtype=orc.SPAN_FUSION_DTYPE) if rows else np.zeros(0, dtype=orc.SPAN_FUSION_DTYPE)
+
+
+def test_scale_workload_with_fusion_pairs():
+    """the shape of BASELINE configs[3] (2 x 150 bp, chimeric left reads): segment_juncs --fusion-search finds the planted
+    fusions, long_spanning_reads --fusion-search joins the chimeric reads through them -- oracle and kernel logic agree"""
+    seqs, genes = make_scale_genome(1, [2_000_000, 1_000_000], 1500, intron_max=4000, exon_len=300)
+    strs = [s.tobytes().decode() for s in seqs]
+    n = 3000
+    w = make_device_workload(7, seqs, genes, None, n, "cpu", exon_len=300, read_len=150, fusion_frac=0.04)
+    fz = set(w["left"]["fusion_reads"].tolist())
+    assert 60 < len(fz) < 200
+    og = orc.Genome(strs)
+    ev = fus = None
+    for sd, side in (("left", 1), ("right", 2)):
+        p = Params(read_side=side, inner_dist_mean=50, inner_dist_std_dev=20, fusion_min_dist=100000)
+        sb = sample_segbatch(w[sd], n)
+        e = orc.segjuncs(p, og, sb)
+        ev = e if ev is None else merge_events(ev, e)
+        f = orc.fusions(p, og, sb, p.fusion_anchor_length, p.fusion_min_dist)
+        f2 = sim.fusions(p, strs, sb)
+        assert f.tolist() == f2.tolist()
+        fus = f if fus is None else orc.merge_fusions(fus, f)
+    assert len(fus) > 0.8 * len(fz)
+    juncs, ins = events_to_span_inputs(ev)
+    fl = fusion_list_from_events(fus)
+    p = Params(fusion_search=1, fusion_min_dist=100000)
+    spb = sample_spanbatch(w["left"], n)
+    want = orc.spanning_fusion(p, og, spb, juncs, ins, fl, True)
+    got, status = sim.spanning_fusion(p, strs, spb, juncs, ins, fl)
+    assert status[1] == 0
+    assert got == want
+    fused = [a for a in want if a.is_fusion()]
+    assert len({a.read_idx for a in fused}) > 0.8 * len(fz) and {a.read_idx for a in fused} <= fz
+    # the reads that are not chimeric come out as they do without fusion search
+    plain = orc.spanning(Params(), og, spb, juncs, ins)
+    assert [a for a in want if a.read_idx not in fz] == [a for a in plain if a.read_idx not in fz]

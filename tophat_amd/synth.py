@@ -503,7 +503,8 @@ def make_scale_genome(seed: int, contig_lens: Sequence[int], n_introns: int, int
 
 def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int, device, read_len: int = 100,
                          seg_len: int = 25, inner_mean: float = 50.0, inner_sd: float = 20.0, err: float = 0.01,
-                         exon_len: int = 600, chunk: int = 1 << 20, multi_frac: float = 0.0, dup_shift: int = 0):
+                         exon_len: int = 600, chunk: int = 1 << 20, multi_frac: float = 0.0, dup_shift: int = 0,
+                         fusion_frac: float = 0.0):
     """Synthesises both sides of `n_pairs` paired reads directly as device-resident thj_seg_batch arrays
     (torch tensors).  Model: a fragment of 2*read_len + max(0, N(inner_mean, inner_sd)) bases drawn
     uniformly from a gene's two-exon transcript; left read = its first read_len bases (sense), right
@@ -514,6 +515,10 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
     multi_frac > 0 (with a genome whose [dup_shift, 2*dup_shift) is a copy of [0, dup_shift) and genes in the first copy
     only): that fraction of the reads gets every segment hit reported twice, at the locus and at locus + dup_shift --
     a two-copy repeat, which is what sends reads to the multihit tier of the stitch kernels.
+    fusion_frac > 0: that fraction of the pairs gets a chimeric LEFT read (the shape of BASELINE configs[3]): its first kb
+    segments are the start of one gene's first exon read forward, the rest comes from another gene's first exon (any contig),
+    forward or reverse-complemented, the break exactly on a segment boundary -- every segment maps where its part lies, no
+    full-read hit; the pair's right read is left as it was.  out["left"]["fusion_reads"] = their row numbers.
     Returns {side: dict of tensors} with the field names of thj_seg_batch."""
     import torch
     g = torch.Generator(device=device)
@@ -628,6 +633,58 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
             b["full_hit"][c0:c0 + n, 1] = fl.to(torch.int32)
             b["full_hit"][c0:c0 + n, 2] = (fl + read_len).to(torch.int32)
             b["full_hit"][c0:c0 + n, 3] = (anti.to(torch.int32) | 2 | (nm_all << 8) | (nm_all << 16) | (read_len << 24)).to(torch.int32)
+    fusion_rows = None
+    if fusion_frac > 0 and nseg >= 2:
+        fz = torch.nonzero(torch.rand(n_pairs, generator=g, device=device) < fusion_frac).squeeze(1)
+        nf = int(fz.shape[0])
+        if nf:
+            b = bufs["left"]
+            ga = genes_t[torch.randint(0, genes_t.shape[0], (nf,), generator=g, device=device)]
+            gb = genes_t[torch.randint(0, genes_t.shape[0], (nf,), generator=g, device=device)]
+            kb = torch.randint(1, nseg, (nf,), generator=g, device=device)              # segments taken from locus A
+            len1 = kb * seg_len
+            len2 = read_len - len1
+            pa = ga[:, 1] + torch.randint(0, max(1, E - read_len), (nf,), generator=g, device=device)
+            pb = gb[:, 1] + torch.randint(0, max(1, E - read_len), (nf,), generator=g, device=device)
+            rcb = torch.rand(nf, generator=g, device=device) < 0.5                      # part B reverse-complemented
+            in_a = ar[None, :] < len1[:, None]
+            ib = ar[None, :] - len1[:, None]                                            # index into part B
+            gp_a = coff[ga[:, 0]][:, None] + pa[:, None] + ar[None, :]
+            gp_b = coff[gb[:, 0]][:, None] + pb[:, None] + torch.where(rcb[:, None], len2[:, None] - 1 - ib, ib)
+            codes = gcodes[torch.where(in_a, gp_a, gp_b).clamp(min=0, max=gcodes.shape[0] - 1)]
+            codes = torch.where(~in_a & rcb[:, None] & (codes < 4), 3 - codes, codes)
+            codes = torch.where(codes > 3, torch.zeros_like(codes), codes)              # (first exons hold no N: make_scale_genome)
+            pad = torch.zeros((nf, W * 64), dtype=torch.int64, device=device)
+            pad[:, :read_len] = codes.to(torch.int64)
+            pw = pad.view(nf, W, 64)
+            b["planes"][fz, 0:W] = ((pw & 1) * bitw).sum(-1)
+            b["planes"][fz, W:2 * W] = (((pw >> 1) & 1) * bitw).sum(-1)
+            b["planes"][fz, 2 * W:3 * W] = 0
+            b["full_ok"][fz] = False
+            for k in range(nseg):
+                s0, s1 = k * seg_len, (read_len if k == nseg - 1 else (k + 1) * seg_len)
+                ln = s1 - s0
+                a_side = kb > k
+                o0 = s0 - len1                                                           # offset of the segment inside part B
+                left_b = torch.where(rcb, pb + len2 - (o0 + ln), pb + o0)
+                ctgk = torch.where(a_side, ga[:, 0], gb[:, 0])
+                leftk = torch.where(a_side, pa + s0, left_b)
+                antik = (~a_side & rcb).to(torch.int32)
+                meta = antik | (2 if k == nseg - 1 else 0) | (ln << 24)
+                b["seg_mapped"][fz, k] = True
+                b["seg_hits"][fz, k, 0] = (ctgk + 1).to(torch.int32)
+                b["seg_hits"][fz, k, 1] = leftk.to(torch.int32)
+                b["seg_hits"][fz, k, 2] = (leftk + ln).to(torch.int32)
+                b["seg_hits"][fz, k, 3] = meta.to(torch.int32)
+                b["span_mapped"][fz, k] = True
+                sh = b["span_hits"]
+                sh[fz, k, 0] = (ctgk + 1).to(torch.int32)
+                sh[fz, k, 1] = leftk.to(torch.int32)
+                sh[fz, k, 2] = (antik | (2 if k == nseg - 1 else 0) | (1 << 24)).to(torch.int32)
+                sh[fz, k, 3] = (1 << 28) | ln
+                sh[fz, k, 4] = 0
+                sh[fz, k, 5] = 0
+            fusion_rows = fz
     del gcodes
 
     def csr(mapped, rows, multi, left_cols):
@@ -666,4 +723,6 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
                        span_off=span_off, span_hits=span_hits, quals=quals, qual_stride=read_len,
                        planes=b["planes"].reshape(-1).contiguous(), read_len=b["read_len"],
                        mate_off=mate_off, mate_hits=mh)
+    if fusion_rows is not None:
+        out["left"]["fusion_reads"] = fusion_rows
     return out
