@@ -223,6 +223,9 @@ def parse_args():
     ap.add_argument("--fusion-search", action="store_true",
                     help="run long_spanning_reads' stage with fusion search on (the shape of configs[3]): reads tiers 0 / 1 cannot join go "
                          "through the fusion branches (thj_k_stitch_fusion) against an empty fusion list")
+    ap.add_argument("--fusion-frac", type=float, default=0.0, metavar="FRAC",
+                    help="with --fusion-search: this fraction of the pairs gets a chimeric left read (configs[3]: 0.02); the step then "
+                         "also runs segment_juncs' fusion kernel and hands its fusions to the spanning stage")
     ap.add_argument("--no-hit-heads", action="store_true",
                     help="hand stage 2 the 32-byte hit records only, without the dense 16-byte head array every batch of the library carries "
                          "(thj_span_batch.hit_heads: derived once when a batch is made -- thj_span_batch_upload, the device-side ingest -- so "
@@ -430,14 +433,19 @@ def run_rank(args, rank, world, local_rank, control, shared):
     ctx = host.Context(local_rank, stream=stream.cuda_stream)
     ctx.upload_genome(pg)
     w = make_device_workload(100 + rank, seqs, genes, None, args.pairs, dev, read_len=args.read_len, seg_len=25,
-                             inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len, multi_frac=args.multihit_frac, dup_shift=dup_shift)
+                             inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len, multi_frac=args.multihit_frac, dup_shift=dup_shift,
+                             fusion_frac=args.fusion_frac if args.fusion_search else 0.0)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     max_intron = max(500000, args.intron_max + 1)
     pk = dict(inner_dist_mean=50, inner_dist_std_dev=20, max_segment_intron=max_intron, max_report_intron=max_intron)
+    if args.fusion_search:
+        pk["fusion_min_dist"] = 100000
     p_left = Params(read_side=READ_LEFT, **pk)
     p_right = Params(read_side=READ_RIGHT, **pk)
-    p_span = Params(max_segment_intron=max_intron, max_report_intron=max_intron, fusion_search=1 if args.fusion_search else 0)
+    p_span = Params(max_segment_intron=max_intron, max_report_intron=max_intron, fusion_search=1 if args.fusion_search else 0,
+                    fusion_min_dist=100000 if args.fusion_search else 10000000)
+    n_fusions = [0]
     if args.fusion_search:
         ctx.upload_span_fusions(np.zeros(0, dtype=host.SPAN_FUSION_DTYPE))
     # first-inserted-wins priority of std::set<Insertion>: all left reads (rank order) before all right reads
@@ -487,6 +495,15 @@ def run_rank(args, rank, world, local_rank, control, shared):
         if comm is not None:
             comm.events_allgather()                   # ONE ncclAllGather on the context stream, merge kernels behind it
         cnt = ctx.finish()                            # the only host round trip of the stage
+        if args.fusion_search and args.fusion_frac > 0:
+            # segment_juncs --fusion-search: find_fusions over both sides; the (small) list goes to the spanning stage the way the
+            # .fusions file would carry it
+            fus = ctx.fusions([(p_left, cb_left), (p_right, cb_right)])
+            fl = np.zeros(len(fus), dtype=host.SPAN_FUSION_DTYPE)          # thj_fusion_download: already in Fusion::operator< order
+            for k in ("ref_id1", "ref_id2", "left", "right", "dir"):
+                fl[k] = fus[k]
+            ctx.upload_span_fusions(fl)
+            n_fusions[0] = len(fl)
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
         ctx.span_sets_from_segjuncs()
         ctx.span_reset()
@@ -673,7 +690,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_text,
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
-                       "fusion_search": bool(args.fusion_search), "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
+                       "fusion_search": bool(args.fusion_search), "fusion_frac": args.fusion_frac, "fusions_found": n_fusions[0], "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"), "traffic_low": dom.get("traffic_low"),
