@@ -435,6 +435,14 @@ int thj_ingest_seg_batch(thj_ctx* ctx, const thj_params* p, int32_t nseg, const 
  * thj_span_batch_free releases the batch.  *out == NULL with THJ_OK: nothing to do in this shard. */
 int thj_ingest_span_hits(thj_ctx* ctx, const thj_params* p, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
                          thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows);
+/* The same with the shard's piece of the READS file (unaligned BAM, id-sorted) riding along: its members are inflated and its
+ * records located with the maps', the batch leaves complete (read planes, lengths and quality strings written on the device:
+ * no thj_span_batch_attach_reads), and the inflated read records come back for the BAM output -- *reads_infl (HOST, malloc'd:
+ * free() it): reads_infl_bytes bytes, BGZF member m of the piece at m << 16; row_loc[r] (HOST, malloc'd) = (m << 16 | offset)
+ * of the block_size field of row r's record.  Replaces ReadStream::getRead per row (reads.cpp:528-630). */
+int thj_ingest_span_batch(thj_ctx* ctx, const thj_params* p, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* reads,
+                          uint32_t begin_id, uint32_t end_id, thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows,
+                          uint8_t** reads_infl, int64_t* reads_infl_bytes, uint32_t** row_loc);
 int thj_span_batch_attach_reads(thj_ctx* ctx, thj_span_batch* batch, int32_t words_per_plane, int32_t qual_stride, const uint64_t* planes,
                                 const uint16_t* lens, const uint8_t* quals);
 

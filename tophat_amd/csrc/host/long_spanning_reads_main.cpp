@@ -24,6 +24,9 @@ static void print_usage() {
 static PhaseTimer g_timer;
 static WorkClock g_work;
 
+#ifndef THJ_DEFAULT_CTX_PER_GPU
+#define THJ_DEFAULT_CTX_PER_GPU 2
+#endif
 struct Gpu {
     int device = 0;
     thj_ctx* ctx = nullptr;
@@ -33,7 +36,7 @@ struct Gpu {
 
 struct Shard {
     uint64_t begin_id = 0, end_id = ~0ull;
-    int64_t read_off = 0;
+    int64_t read_off = 0, read_end = -1;            // read_end: where the next shard starts in the reads file (-1: the end)
     std::vector<int64_t> seg_off, spliced_off;
     std::vector<int64_t> seg_end;                   // where the next shard starts in the segment maps (-1: the end of the file)
 };
@@ -72,8 +75,103 @@ static std::vector<Shard> plan(const std::string& reads, const std::vector<std::
         sh.seg_end.assign(segs.size(), -1);
         // lists = {reads, spliced maps last..first, contig maps last..first}
         if (i + 1 < want) for (size_t s = 0; s < segs.size(); ++s) sh.seg_end[s] = shard_end_offset(lists[1 + spliced.size() + (segs.size() - 1 - s)], sh.end_id);
+        if (i + 1 < want) sh.read_end = shard_end_offset(lists[0], sh.end_id);
     }
     return out;
+}
+
+// names, bases and qualities of a read from its own BAM record (bam1_t layout after block_size)
+static void read_from_raw(const Read& rd, Read& out) {
+    static const char nt16[] = "=ACMGRSVTWYHKDBN";
+    const uint8_t* d = rd.raw;
+    uint32_t w2, w3, lseq;
+    memcpy(&w2, d + 8, 4); memcpy(&w3, d + 12, 4); memcpy(&lseq, d + 16, 4);
+    const uint32_t l_rn = w2 & 0xFF, n_cig = w3 & 0xFFFF;
+    out.id = rd.id; out.raw = rd.raw;
+    out.name.assign((const char*)d + 32, l_rn ? l_rn - 1 : 0);
+    const uint8_t* sq = d + 32 + l_rn + 4 * n_cig;
+    const uint8_t* ql = sq + ((lseq + 1) >> 1);
+    out.seq.resize(lseq); out.qual.resize(lseq);
+    for (uint32_t k = 0; k < lseq; ++k) { out.seq[k] = nt16[(sq[k >> 1] >> ((k & 1) ? 0 : 4)) & 0xF]; out.qual[k] = (char)(ql[k] + 33); }
+}
+
+// print_bamhit for a plain (one-record) alignment whose read came as a BAM record: name, packed bases and qualities are copied
+// (reversed / complemented nibble-wise for an antisense alignment) instead of going through strings.  Byte for byte what
+// BamWriter::encode writes for the same record; false = take the general path.
+static bool encode_plain_from_raw(const BamWriter& bw, const RefTable& rt, const thj_aln& a, const Read& rd, int rlen, int indel, bool spliced,
+                                  std::vector<uint8_t>& d, std::vector<uint32_t>& sizes, std::vector<long>& rids) {
+    static const uint8_t bamop[16] = {0, 0, 0, 1, 1, 2, 2, 0, 0, 0, 0, 3, 3, 4, 5, 6};
+    static const uint8_t comp16[16] = {15, 8, 4, 15, 2, 15, 15, 15, 1, 15, 15, 15, 15, 15, 15, 15};    // A<->T, C<->G, anything else N
+    const uint8_t* r = rd.raw;
+    uint32_t w2, w3, lseq;
+    memcpy(&w2, r + 8, 4); memcpy(&w3, r + 12, 4); memcpy(&lseq, r + 16, 4);
+    const uint32_t l_rn = w2 & 0xFF, n_cig_in = w3 & 0xFFFF;
+    if ((int)lseq != rlen || l_rn == 0) return false;
+    const uint8_t* sq = r + 32 + l_rn + 4 * n_cig_in;
+    const uint8_t* ql = sq + ((lseq + 1) >> 1);
+    const bool anti = (a.flags & THJ_HIT_ANTISENSE) != 0;
+    const size_t at = d.size();
+    const int32_t tid = bw.tid_of(rt.names[a.ref_id - 1]);
+    const int32_t pos = a.left + 1 <= 0 ? -1 : a.left;
+    int end = pos;
+    for (int i = 0; i < a.n_cigar; ++i) { const uint32_t c = a.cigar[i], op = bamop[c >> 28]; if (op == 0 || op == 2 || op == 3) end += (int)(c & 0x0FFFFFFF); }
+    const uint32_t bin = (uint32_t)reg2bin(pos, a.n_cigar == 0 ? pos + 1 : end);
+    const size_t seq_b = (lseq + 1) >> 1;
+    d.resize(at + 36 + l_rn + 4 * (size_t)a.n_cigar + seq_b + lseq);
+    uint8_t* o = d.data() + at;
+    auto w32 = [&](size_t off, uint32_t v) { memcpy(o + off, &v, 4); };
+    w32(4, (uint32_t)tid); w32(8, (uint32_t)pos); w32(12, (bin << 16) | (255u << 8) | l_rn);
+    w32(16, ((anti ? 0x10u : 0u) << 16) | (uint32_t)a.n_cigar); w32(20, lseq); w32(24, (uint32_t)-1); w32(28, (uint32_t)-1); w32(32, 0);
+    memcpy(o + 36, r + 32, l_rn);
+    uint8_t* oc = o + 36 + l_rn;
+    for (int i = 0; i < a.n_cigar; ++i) { const uint32_t v = ((a.cigar[i] & 0x0FFFFFFF) << 4) | bamop[a.cigar[i] >> 28]; memcpy(oc + 4 * i, &v, 4); }
+    uint8_t* os = oc + 4 * (size_t)a.n_cigar;
+    uint8_t* oq = os + seq_b;
+    if (!anti) {                                      // (decoding a nibble to its letter and encoding it again is the identity)
+        memcpy(os, sq, seq_b);
+        if (lseq & 1) os[seq_b - 1] &= 0xF0;
+        memcpy(oq, ql, lseq);
+    } else {                                          // reverse_complement (reads.cpp:189-207): anything but A C G T becomes N
+        memset(os, 0, seq_b);
+        for (uint32_t k = 0; k < lseq; ++k) {
+            const uint32_t j = lseq - 1 - k;
+            const uint8_t nib = (sq[j >> 1] >> ((j & 1) ? 0 : 4)) & 0xF;
+            os[k >> 1] |= (uint8_t)(comp16[nib] << ((k & 1) ? 0 : 4));
+            oq[k] = ql[j];
+        }
+    }
+    // aux: AS XM XO XG MD NM [XS] (add_aux, common.cpp:1092-1173: the smallest integer type that holds the value)
+    auto put_int = [&](char t0, char t1, long long x) {
+        d.push_back((uint8_t)t0); d.push_back((uint8_t)t1);
+        if (x < 0) {
+            if (x >= -127) { d.push_back('c'); d.push_back((uint8_t)(int8_t)x); }
+            else if (x >= -32767) { d.push_back('s'); int16_t v = (int16_t)x; uint8_t b[2]; memcpy(b, &v, 2); d.insert(d.end(), b, b + 2); }
+            else { d.push_back('i'); uint32_t v = (uint32_t)(int32_t)x; uint8_t b[4]; memcpy(b, &v, 4); d.insert(d.end(), b, b + 4); }
+        } else {
+            if (x <= 255) { d.push_back('C'); d.push_back((uint8_t)x); }
+            else if (x <= 65535) { d.push_back('S'); uint16_t v = (uint16_t)x; uint8_t b[2]; memcpy(b, &v, 2); d.insert(d.end(), b, b + 2); }
+            else { d.push_back('I'); uint32_t v = (uint32_t)x; uint8_t b[4]; memcpy(b, &v, 4); d.insert(d.end(), b, b + 4); }
+        }
+    };
+    put_int('A', 'S', (int)a.AS); put_int('X', 'M', (int)a.XM); put_int('X', 'O', (int)a.XO); put_int('X', 'G', (int)a.XG);
+    d.push_back('M'); d.push_back('D'); d.push_back('Z'); d.insert(d.end(), a.md, a.md + a.md_len); d.push_back(0);
+    put_int('N', 'M', (int)a.mismatches + indel);
+    if (spliced) { d.push_back('X'); d.push_back('S'); d.push_back('A'); d.push_back((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'); }
+    const uint32_t bs = (uint32_t)(d.size() - at - 4);
+    memcpy(d.data() + at, &bs, 4);
+    sizes.push_back((uint32_t)(d.size() - at));
+    long rid = 0;                                     // atol(qname)
+    {
+        const char* q = (const char*)r + 32;
+        bool neg = false;
+        size_t k = 0;
+        while (k + 1 < l_rn && (q[k] == ' ' || q[k] == '\t')) ++k;
+        if (q[k] == '-') { neg = true; ++k; } else if (q[k] == '+') ++k;
+        for (; k + 1 < l_rn && q[k] >= '0' && q[k] <= '9'; ++k) rid = rid * 10 + (q[k] - '0');
+        if (neg) rid = -rid;
+    }
+    rids.push_back(rid);
+    return true;
 }
 
 // print_bamhit (bwt_map.cpp:1888-2093) for one alignment: one record, or -- a fusion alignment -- the two partial records of
@@ -89,7 +187,10 @@ static void encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a
         if (op == 11 || op == 12) spliced = true;
         if (op >= THJ_CIG_FUSION_FF && op <= THJ_CIG_FUSION_RR && fi < 0) fi = k;
     }
-    std::string seq = rd.seq, qual = rd.qual;
+    if (rd.raw && fi < 0 && a.md_len != THJ_MD_ON_HOST && encode_plain_from_raw(bw, rt, a, rd, rlen, indel, spliced, d, sizes, rids)) return;
+    Read tmp;
+    const Read& rdx = rd.raw && rd.seq.empty() ? (read_from_raw(rd, tmp), tmp) : rd;
+    std::string seq = rdx.seq, qual = rdx.qual;
     seq.resize((size_t)rlen); qual.resize((size_t)rlen);
     uint32_t flag = 0;
     if (a.flags & THJ_HIT_ANTISENSE) { flag |= 0x10; reverse_complement(seq); std::reverse(qual.begin(), qual.end()); }
@@ -111,10 +212,10 @@ static void encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a
     } else aux.push_back("MD:Z:" + std::string(a.md, a.md_len));
     aux.push_back("NM:i:" + std::to_string((int)a.mismatches + indel));
     if (spliced) aux.push_back(std::string("XS:A:") + ((a.flags & THJ_HIT_ANTISENSE_SPLICE) ? '-' : '+'));
-    const long rid = atol(rd.name.c_str());
+    const long rid = atol(rdx.name.c_str());
     size_t before = d.size();
     if (fi < 0) {
-        bw.encode(d, rd.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
+        bw.encode(d, rdx.name, flag, rt.names[a.ref_id - 1], a.left + 1, a.cigar, a.n_cigar, seq, qual, aux);
         sizes.push_back((uint32_t)(d.size() - before)); rids.push_back(rid);
         return;
     }
@@ -149,11 +250,11 @@ static void encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a
     const std::string& n2s = rt.names[ref_id2 - 1];
     const std::string xf = " " + n1s + "-" + n2s + " " + std::to_string(a.left + 1) + " " + full + " " + seq + " " + qual;
     aux.push_back("XF:Z:1" + xf);
-    bw.encode(d, rd.name, flag, n1s, left1 + 1, c1, n1, seq1, qual1, aux);
+    bw.encode(d, rdx.name, flag, n1s, left1 + 1, c1, n1, seq1, qual1, aux);
     sizes.push_back((uint32_t)(d.size() - before)); rids.push_back(rid);
     before = d.size();
     aux.back() = "XF:Z:2" + xf;
-    bw.encode(d, rd.name, flag, n2s, left2 + 1, c2, n2, seq2, qual2, aux);
+    bw.encode(d, rdx.name, flag, n2s, left2 + 1, c2, n2, seq2, qual2, aux);
     sizes.push_back((uint32_t)(d.size() - before)); rids.push_back(rid);
 }
 
@@ -212,10 +313,18 @@ int main(int argc, char** argv) {
         int n_dev = 1, first = 0;
         if (getenv("THJ_DEVICE")) first = atoi(getenv("THJ_DEVICE"));
         else { n_dev = thj_device_count(); if (n_dev < 1) die("Error: %s\n", thj_last_error()); if (getenv("THJ_GPUS") && atoi(getenv("THJ_GPUS")) >= 1) n_dev = std::min(n_dev, atoi(getenv("THJ_GPUS"))); }
-        for (int d = 0; d < n_dev; ++d) {
+        // THJ_CTX_PER_GPU=k: k contexts (streams, arenas, tables) on every device, each a rank of its own -- a shard's host-to-device
+        // copies and stream round trips then overlap another shard's kernels on the same GPU
+        // (default: 2 on a single GPU -- measured 2.4 -> 2.0 s for segment_juncs on 8 M pairs -- and 1 per device on several: a
+        // communicator is either all-RCCL or all-loopback)
+        int per = getenv("THJ_CTX_PER_GPU") ? atoi(getenv("THJ_CTX_PER_GPU")) : (n_dev > 1 ? 1 : THJ_DEFAULT_CTX_PER_GPU);
+        if (n_dev > 1) per = 1;
+        if (per < 1) per = 1;
+        if (per > 8) per = 8;
+        for (int d = 0; d < n_dev * per; ++d) {
             gpus.emplace_back(new Gpu());
             Gpu& g = *gpus.back();
-            g.device = first + d;
+            g.device = first + d / per;
             g.fut = std::async(std::launch::async, [dev = g.device]() {
                 thj_ctx* c = nullptr;
                 if (thj_ctx_create(dev, nullptr, &c)) die("Error: %s\n", thj_last_error());
@@ -353,6 +462,10 @@ int main(int argc, char** argv) {
     std::vector<std::unique_ptr<BamFile>> bams;
     bool dev_ingest = !getenv("THJ_HOST_INGEST") && spliced_segs.empty();
     for (int s = 0; s < nseg && dev_ingest; ++s) { bams.emplace_back(new BamFile()); if (!bams.back()->open(segs[(size_t)s], rt)) dev_ingest = false; }
+    // the reads file too when it is an (unaligned) BAM: its members are then inflated on the device with the maps' and the read
+    // records come back ready to be copied into the output (THJ_HOST_READS=1: the host ReadStream instead)
+    BamFile reads_bam;
+    const bool dev_reads = dev_ingest && !getenv("THJ_HOST_READS") && reads_bam.open(pos[1], rt);
     // ---- the shard plan.  -p N: the reference's N ranges, one output file each.  One output file: our own number of shards,
     // written in order.
     const int hw = effective_cpus();
@@ -400,20 +513,36 @@ int main(int argc, char** argv) {
             for (int s = 0; s < nseg; ++s) segp.push_back(bams[(size_t)s]->piece(sh.seg_off[(size_t)s], sh.seg_end.empty() ? -1 : sh.seg_end[(size_t)s]));
             const uint32_t b_id = sh.begin_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.begin_id, e_id = sh.end_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.end_id;
             thj_span_batch* dev = nullptr; uint32_t* ids = nullptr; int64_t n = 0;
+            uint8_t* rinfl = nullptr; int64_t rinfl_bytes = 0; uint32_t* rloc = nullptr;
             int rc;
             {
                 const long long tw = WorkClock::now();
                 std::lock_guard<std::mutex> lk(gpu.mu);
                 g_work.add(1, tw);
                 const long long td = WorkClock::now();
-                rc = thj_ingest_span_hits(device_ready(gpu), &o.p, nseg, segp.data(), b_id, e_id, &dev, &ids, &n);
+                if (dev_reads) {
+                    const thj_bam_piece rp = reads_bam.piece(sh.read_off, sh.read_end);
+                    rc = thj_ingest_span_batch(device_ready(gpu), &o.p, nseg, segp.data(), &rp, b_id, e_id, &dev, &ids, &n, &rinfl, &rinfl_bytes, &rloc);
+                } else
+                    rc = thj_ingest_span_hits(device_ready(gpu), &o.p, nseg, segp.data(), b_id, e_id, &dev, &ids, &n);
                 g_work.add(2, td);
             }
             if (rc == THJ_OK) {
                 if (dev) {
+                    std::vector<Read> batch_rd((size_t)n);
+                    int W = 1, stride = 0;
+                    std::vector<uint64_t> planes; std::vector<uint16_t> lens; std::vector<uint8_t> q;
+                    if (dev_reads) {
+                        // the rows' own BAM records, where the encoder copies names, bases and qualities from
+                        for (int64_t r = 0; r < n; ++r) {
+                            const uint32_t loc = rloc[r];
+                            batch_rd[(size_t)r].id = ids[r];
+                            batch_rd[(size_t)r].raw = rinfl + ((size_t)(loc >> 16) << 16) + (loc & 0xFFFFu) + 4;
+                        }
+                        free(rloc); free(ids);
+                    } else {
                     ReadStream reads;
                     if (!reads.open(pos[1], o.zpacker, sh.read_off)) die("Error: cannot open %s for reading\n", pos[1].c_str());
-                    std::vector<Read> batch_rd((size_t)n);
                     std::vector<int64_t> read_off(1, 0); std::string bases, quals; size_t max_len = 0;
                     for (int64_t r = 0; r < n; ++r) {
                         Read& rd = batch_rd[(size_t)r];
@@ -423,13 +552,14 @@ int main(int argc, char** argv) {
                         if (rd.seq.size() > max_len) max_len = rd.seq.size();
                     }
                     free(ids);
-                    int W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
-                    std::vector<uint64_t> planes((size_t)n * 3 * W);
-                    std::vector<uint16_t> lens((size_t)n);
+                    W = (int)((max_len + 63) / 64); if (W < 1) W = 1;
+                    planes.resize((size_t)n * 3 * W);
+                    lens.resize((size_t)n);
                     if (thj_reads_pack(n, read_off.data(), bases.data(), W, planes.data(), lens.data())) die("Error: %s\n", thj_last_error());
-                    const int stride = (int)((max_len + 3) / 4 * 4);
-                    std::vector<uint8_t> q((size_t)n * stride, 0);
+                    stride = (int)((max_len + 3) / 4 * 4);
+                    q.assign((size_t)n * stride, 0);
                     for (int64_t r = 0; r < n; ++r) memcpy(q.data() + (size_t)r * stride, quals.data() + read_off[(size_t)r], (size_t)(read_off[(size_t)r + 1] - read_off[(size_t)r]));
+                    }
                     std::vector<thj_aln> alns;
                     {
                         const long long tw = WorkClock::now();
@@ -437,7 +567,7 @@ int main(int argc, char** argv) {
                         g_work.add(1, tw);
                         const long long td = WorkClock::now();
                         thj_ctx* ctx = device_ready(gpu);
-                        if (thj_span_batch_attach_reads(ctx, dev, W, stride, planes.data(), lens.data(), q.data())) die("Error: %s\n", thj_last_error());
+                        if (!dev_reads && thj_span_batch_attach_reads(ctx, dev, W, stride, planes.data(), lens.data(), q.data())) die("Error: %s\n", thj_last_error());
                         int64_t na = 0;
                         for (int attempt = 0;; ++attempt) {   // THJ_ERETRY: a device pool was enlarged, the pass runs again
                             if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
@@ -456,6 +586,7 @@ int main(int argc, char** argv) {
                     const long long te = WorkClock::now();
                     encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
                     g_work.add(3, te);
+                    free(rinfl);
                     if (parts > 1) bws[k]->write_encoded(e);
                     else {
                         OutShard& oq = *outq[k];

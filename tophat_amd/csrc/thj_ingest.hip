@@ -588,7 +588,8 @@ __global__ __launch_bounds__(256) void thj_k_scatter_mates(const uint32_t* __res
 // reads: SEQ nibbles ("=ACMGRSVTWYHKDBN") -> {lo, hi, N} bit planes of thj_reads_pack; row = the read's row in the batch
 __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restrict__ infl, const uint32_t* __restrict__ id, const uint32_t* __restrict__ loc, uint32_t a, uint32_t b,
                                                          uint32_t id0, uint32_t span, const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, int W, u64* __restrict__ planes,
-                                                         uint16_t* __restrict__ rlen, uint32_t* __restrict__ seen, unsigned int* status) {
+                                                         uint16_t* __restrict__ rlen, uint32_t* __restrict__ seen, unsigned int* status,
+                                                         uint8_t* __restrict__ quals = nullptr, int qstride = 0, uint32_t* __restrict__ row_loc = nullptr) {
     for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
         const uint32_t idl = id[i] - id0;
         if (idl >= span || !vis[idl]) continue;
@@ -611,6 +612,12 @@ __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restri
             pl[w] = lo; pl[W + w] = hi; pl[2 * W + w] = nn;
         }
         rlen[r] = (uint16_t)l_seq;
+        if (quals) {                                               // phred+33 text, as thj_span_batch.quals wants it
+            const uint8_t* q = sq + ((l_seq + 1) >> 1);
+            uint8_t* dq = quals + (size_t)r * qstride;
+            for (uint32_t k = 0; k < l_seq && (int)k < qstride; ++k) dq[k] = (uint8_t)(q[k] + 33);
+        }
+        if (row_loc) row_loc[r] = loc[i];
         (void)status;
     }
 }
@@ -670,6 +677,7 @@ namespace ing {
 struct Parsed {
     uint32_t* id = nullptr; Hit16* h16 = nullptr; Hit32* h32 = nullptr; uint32_t* loc = nullptr;
     std::vector<uint32_t> fb;
+    std::vector<uint32_t> file_first_block, file_blocks;           // where each file's members sit in `infl` (64 KiB slots)
     uint8_t* infl = nullptr; unsigned int* status = nullptr;
     Arena a1;
     int64_t n = 0;
@@ -717,6 +725,8 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
         comp_total += p.comp_bytes;
     }
     const int64_t nb = (int64_t)blocks.size();
+    P.file_first_block.clear(); P.file_blocks.clear();
+    for (int f = 0; f < nf; ++f) { P.file_first_block.push_back(files[(size_t)f].first_block); P.file_blocks.push_back(files[(size_t)f].n_blocks); }
     P.fb.assign((size_t)nf + 1, 0);
     P.n = 0;
     if (nb == 0) return THJ_OK;
@@ -918,15 +928,21 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
 // later segment whose read has none in the first are dropped, as look_right_for_hit_group never asks for them.  row_ids (host,
 // n_rows entries, caller frees with free()) = the reads' ids in row order: the caller fetches these reads (it needs their
 // names, bases and qualities for the BAM records anyway) and completes the batch with thj_span_batch_attach_reads.
-extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
-                                    thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out) {
+// reads != nullptr: the shard's piece of the reads file rides along -- its records are inflated and located with the maps', the
+// batch gets its read planes / lengths / quality strings on the device, and the inflated read records come back to the host
+// (*reads_infl, malloc'd, member m at m << 16; row_loc[r] = location of row r's record in it) for the BAM output
+static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* reads, uint32_t begin_id,
+                            uint32_t end_id, thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out, uint8_t** reads_infl, int64_t* reads_infl_bytes,
+                            uint32_t** row_loc_out) {
     using namespace ing;
-    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !out || !row_ids || !n_rows_out) { thj_set_error("thj_ingest_span_hits: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     *out = nullptr; *row_ids = nullptr; *n_rows_out = 0;
+    if (reads_infl) { *reads_infl = nullptr; *reads_infl_bytes = 0; *row_loc_out = nullptr; }
     std::vector<const thj_bam_piece*> pieces;
     std::vector<uint32_t> kinds;
     for (int s = 0; s < nseg; ++s) { pieces.push_back(&segs[s]); kinds.push_back(KIND_HITS); }
+    const int f_reads = reads ? nseg : -1;
+    if (reads) { pieces.push_back(reads); kinds.push_back(KIND_READS); }
     Parsed P;
     int rc = ingest_front(c, tp, pieces, kinds, begin_id, end_id, 1, 0, 0, P);
     if (rc) return rc;
@@ -937,7 +953,7 @@ extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t ns
     HIPCHK(hipMemcpyAsync(&ends[1], P.id + fb[1] - 1, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const uint32_t id_lo = ends[0], span = ends[1] - ends[0] + 1;
-    const size_t need2 = (size_t)span * 4 * (2 * (size_t)nseg + 2 + (size_t)nseg + 4) + (1 << 20);
+    const size_t need2 = (size_t)span * 4 * (2 * (size_t)nseg + 2 + (size_t)nseg + 8) + (1 << 20);
     void* d_merge = nullptr;
     { int rc_ = thj_dev_alloc(c, &d_merge, need2); if (rc_) return rc_; }
     struct Guard { thj_ctx* c; void* p; ~Guard() { hipStreamSynchronize(c->stream); thj_dev_release(c, p); } } guard{c, d_merge};
@@ -981,12 +997,61 @@ extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t ns
         const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
         if (b > a) hipLaunchKernelGGL(thj_k_scatter_span, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h32, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits, b_heads);
     }
+    uint32_t* h_loc = nullptr; uint8_t* h_infl = nullptr;
+    auto fail2 = [&](int code) { free(h_ids); free(h_loc); free(h_infl); return fail(code); };
+    if (reads) {
+        // the reads of the rows: planes / lengths / quality strings straight from the BAM records, where the kernels will read them
+        int W = (tp->segment_length * (nseg + 1) - 1 + 63) / 64;
+        if (W < 1) W = 1;
+        if (W > 4) { thj_set_error("reads longer than 256 bases"); return fail2(THJ_EFALLBACK); }
+        const int qstride = (tp->segment_length * (nseg + 1) + 3) / 4 * 4;
+        uint32_t* seen = am.take<uint32_t>(n_rows); uint32_t* d_loc = am.take<uint32_t>(n_rows);
+        if (!seen || !d_loc) { thj_set_error("thj_ingest: merge scratch too small"); return fail2(THJ_ENOMEM); }
+        if (thj_dev_alloc(c, &ob->ptrs[2], (size_t)n_rows * 3 * W * 8) || thj_dev_alloc(c, &ob->ptrs[3], (size_t)n_rows * 2) ||
+            thj_dev_alloc(c, &ob->ptrs[4], (size_t)n_rows * qstride)) return fail2(THJ_EHIP);
+        ING_HIP(hipMemsetAsync(seen, 0, (size_t)n_rows * 4, c->stream));
+        ING_HIP(hipMemsetAsync(ob->ptrs[3], 0, (size_t)n_rows * 2, c->stream));
+        ING_HIP(hipMemsetAsync(ob->ptrs[4], 0, (size_t)n_rows * qstride, c->stream));
+        const uint32_t a = fb[(size_t)f_reads], b = fb[(size_t)f_reads + 1];
+        if (b > a) hipLaunchKernelGGL(thj_k_read_planes, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.infl, P.id, P.loc, a, b, id_lo, span, m_vis, m_row, W,
+                                      (u64*)ob->ptrs[2], (uint16_t*)ob->ptrs[3], seen, P.status, (uint8_t*)ob->ptrs[4], qstride, d_loc);
+        hipLaunchKernelGGL(thj_k_check_seen, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, seen, n_rows, P.status);
+        h_loc = (uint32_t*)malloc((size_t)n_rows * 4);
+        const size_t ib = (size_t)P.file_blocks[(size_t)f_reads] << 16;
+        h_infl = (uint8_t*)malloc(ib ? ib : 16);
+        if (!h_loc || !h_infl) return fail2(THJ_ENOMEM);
+        unsigned int h_status[16];
+        ING_HIP(hipMemcpyAsync(h_loc, d_loc, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+        ING_HIP(hipMemcpyAsync(h_status, P.status, 64, hipMemcpyDeviceToHost, c->stream));
+        if (ib) ING_HIP(hipMemcpyAsync(h_infl, P.infl + ((size_t)P.file_first_block[(size_t)f_reads] << 16), ib, hipMemcpyDeviceToHost, c->stream));
+        ING_HIP(hipStreamSynchronize(c->stream));
+        if (h_status[ST_MISSING_READ]) { thj_set_error("Error: could not get a read of the shard from the reads file"); return fail2(THJ_EINVAL); }
+        const uint32_t base = P.file_first_block[(size_t)f_reads] << 16;
+        for (uint32_t r = 0; r < n_rows; ++r) h_loc[r] -= base;
+        ob->desc.words_per_plane = W; ob->desc.qual_stride = qstride;
+        ob->desc.read_planes = (const uint64_t*)ob->ptrs[2]; ob->desc.read_len = (const uint16_t*)ob->ptrs[3]; ob->desc.quals = (const uint8_t*)ob->ptrs[4];
+        *reads_infl = h_infl; *reads_infl_bytes = (int64_t)ib; *row_loc_out = h_loc;
+    }
     ING_HIP(hipStreamSynchronize(c->stream));
     ING_HIP(hipGetLastError());
     ob->desc.n_reads = (int32_t)n_rows; ob->desc.nseg = nseg;
     ob->desc.seg_off = b_off; ob->desc.hits = (const thj_span_hit*)b_hits; ob->desc.hit_heads = b_heads;
     *out = &ob->desc; *row_ids = h_ids; *n_rows_out = n_rows;
     return THJ_OK;
+}
+
+extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
+                                    thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out) {
+    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !out || !row_ids || !n_rows_out) { thj_set_error("thj_ingest_span_hits: bad argument"); return THJ_EINVAL; }
+    return span_ingest_impl(c, tp, nseg, segs, nullptr, begin_id, end_id, out, row_ids, n_rows_out, nullptr, nullptr, nullptr);
+}
+extern "C" int thj_ingest_span_batch(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* reads, uint32_t begin_id,
+                                     uint32_t end_id, thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out, uint8_t** reads_infl,
+                                     int64_t* reads_infl_bytes, uint32_t** row_loc) {
+    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out || !row_ids || !n_rows_out || !reads_infl || !reads_infl_bytes || !row_loc) {
+        thj_set_error("thj_ingest_span_batch: bad argument"); return THJ_EINVAL;
+    }
+    return span_ingest_impl(c, tp, nseg, segs, reads, begin_id, end_id, out, row_ids, n_rows_out, reads_infl, reads_infl_bytes, row_loc);
 }
 
 // the reads of a batch made by thj_ingest_span_hits, in row order (HOST arrays as thj_reads_pack / thj_span_batch describe them)
