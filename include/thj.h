@@ -423,6 +423,9 @@ typedef struct { const uint8_t* comp; int64_t comp_bytes; uint32_t first_skip; i
  * segment map: find_gaps :3321-3348) and the reads, and returns a device-resident batch for thj_segjuncs_run_async /
  * thj_fusion_run_async / thj_covsearch_add_hits_async (thj_batch_free releases it).  *out == NULL with THJ_OK: the shard is
  * empty.  THJ_EFALLBACK: see above.  mate_full / mate_last may be NULL.  Synchronous. */
+/* THJ_INGEST_TIMING=1 in the environment: the ingest calls time their phases (with a stream synchronisation at every mark: a
+ * diagnosis mode), this prints the sums to stderr. */
+void thj_ingest_timing_report(void);
 int thj_ingest_seg_batch(thj_ctx* ctx, const thj_params* p, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* mate_full,
                          const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
                          uint32_t ordinal_base, thj_seg_batch** out, int64_t* n_reads);

@@ -469,7 +469,7 @@ int main(int argc, char** argv) {
     // ---- the shard plan.  -p N: the reference's N ranges, one output file each.  One output file: our own number of shards,
     // written in order.
     const int hw = effective_cpus();
-    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 2));
+    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw * 3 / 4));
     if (workers < 1) workers = 1;
     int parts = o.num_threads > 1 ? o.num_threads : 1;
     std::vector<Shard> shards;
@@ -736,6 +736,7 @@ int main(int argc, char** argv) {
     for (auto& bw : bws) bw->close();
     g_timer.lap("BAM close");
     g_timer.report();
+    thj_ingest_timing_report();
     { static const char* const nm[4] = {"shards (ingest + merge + device + encode)", "  waiting for the GPU's lock", "  device calls (upload, stitch, download)", "  record encoding"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime down after a context has been used takes ~0.2 s that nobody is waiting for.

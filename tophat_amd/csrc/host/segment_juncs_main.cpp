@@ -375,7 +375,7 @@ int main(int argc, char** argv) {
     // ---- shards and host workers.  THJ_WORKERS host workers (default: half the usable CPUs -- every worker also keeps one reader
     // thread per input file busy) take (side, shard) items; -p N asks for at least N shards per side, as in the reference.
     const int hw = effective_cpus();
-    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw / 2));
+    int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw * 3 / 4));
     if (workers < 1) workers = 1;
     int want = getenv("THJ_SHARDS") ? atoi(getenv("THJ_SHARDS")) : std::max(std::max(workers, o.num_threads), n_gpus);
     struct Item { const SideInput* in; const SideInput* mate; int side; Shard sh; uint32_t ordinal, limit; int gpu; };
@@ -510,6 +510,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "Reported %d total potential splices\n", (int)n.n_juncs);
     g_timer.lap("write outputs");
     g_timer.report();
+    thj_ingest_timing_report();
     { static const char* const nm[4] = {"shards (ingest + merge + pack + device)", "  waiting for the GPU's lock", "  device calls (upload, launch, free)", "  -"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime (and RCCL) down after use takes tenths of a second that nobody is waiting for.

@@ -10,7 +10,8 @@
 // it fast enough is where its working set lives: Huffman tables (10-bit / 8-bit direct lookup + canonical fallback) and a
 // 32 KiB output window in LDS -- every table lookup and every LZ77 copy is an LDS access -- while the other 63 lanes do the
 // memory work: they stage the compressed bytes into an LDS ring ahead of the decoder and flush finished 16 KiB halves of
-// the window to HBM with coalesced 16-byte stores.  38 KB of LDS per workgroup = 4 blocks in flight per CU, 1024 per GPU.
+// the window to HBM with coalesced 16-byte stores.  The LDS window is 8 KiB (far matches read the flushed output): 14 KB of LDS
+// per workgroup = 11 blocks in flight per CU, 2800 per GPU (with the full 32 KiB window: 4 and 1024, measured 2x slower).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -22,7 +23,13 @@
 
 namespace ing {
 
-static constexpr int WIN = 32768, WIN_MASK = WIN - 1, HALF = 16384;
+#ifndef THJ_INFLATE_WIN
+#define THJ_INFLATE_WIN 8192
+#endif
+// the LDS part of the LZ77 window: matches that reach further back (rare in BAM: neighbouring records resemble each other) read
+// the block's own output in HBM, which the helper lanes have flushed by then.  8 KiB instead of the full 32 KiB = 14 KB of LDS per
+// workgroup = 11 blocks in flight per CU instead of 4
+static constexpr int WIN = THJ_INFLATE_WIN, WIN_MASK = WIN - 1, HALF = WIN / 2;
 static constexpr int INRING = 2048, IN_MASK = INRING - 1;
 static constexpr int LIT_BITS = 10, DIST_BITS = 8;
 
@@ -259,6 +266,17 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                             const uint32_t dist = s.dbase[ds] + take(b, s.dext[ds]);
                             if (dist > outp || outp + (uint32_t)len > 65536u) { err = true; break; }
                             int k = 0;
+                            if (dist > (uint32_t)WIN - 8u) {                      // beyond the LDS window: from the flushed output (see out_limit)
+                                const uint8_t* gsrc = dst + outp - dist;
+                                for (; k + 8 <= len; k += 8) {
+                                    uint8_t t[8];
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q) t[q] = gsrc[k + q];
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q) s.win[(outp + (uint32_t)(k + q)) & WIN_MASK] = t[q];
+                                }
+                                for (; k < len; ++k) s.win[(outp + (uint32_t)k) & WIN_MASK] = gsrc[k];
+                            } else
                             if (dist >= 8)                                        // source and destination of a group of 8 cannot overlap: read the
                                 for (; k + 8 <= len; k += 8) {                    // group first (8 LDS reads in flight at once), then write it
                                     const uint32_t sp = outp + (uint32_t)k - dist, dp = outp + (uint32_t)k;
@@ -288,6 +306,239 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
     }
 }
 
+// thj_k_inflate_lanes: one LANE per BGZF block -- 64 independent inflaters per wave.  A block decodes at a few MB/s whoever does it
+// (every symbol is a chain of dependent table lookups), so throughput is the number of blocks in flight: 64 per wave instead of
+// one.  Per lane: a 256-entry literal / 32-entry distance direct-lookup table plus the canonical symbol lists in LDS (1220 bytes,
+// an odd word stride so that the lanes' tables start in different banks), the limits of the longer codes in registers (a
+// compare chain, no memory), the compressed stream read in aligned words, and the lane's own 64 KiB output slot as the LZ77
+// window -- a lane always sees its own stores.  Output bytes gather in a register and leave four at a time.
+namespace ing {
+static constexpr int LF = 8, DF = 5;                                   // direct-lookup bits
+static constexpr int LANE_WORDS = 305;                                 // 128 + 16 + 144 + 16 words of tables, +1: odd (78 KB per wave: two per CU)
+struct LaneTab {
+    uint16_t* lit_fast; uint16_t* dist_fast; uint16_t* lit_sym; uint16_t* dist_sym;
+};
+struct Canon { uint32_t limit[16]; int32_t base[16]; };                // per code length: left-justified exclusive code limit, symbol index base
+
+// the per-length counters / scatter offsets are a dynamically indexed private array (scratch): touched once per block header
+__device__ __noinline__ bool lane_build(const uint8_t* lens, int n, uint16_t* fast, int fast_bits, uint16_t* sym, Canon& cn) {
+    uint32_t tmp[16];
+    for (int i = 0; i < 16; ++i) tmp[i] = 0;
+    for (int i = 0; i < n; ++i) tmp[lens[i]]++;
+    for (int i = 0; i < (1 << fast_bits); ++i) fast[i] = 0;
+    uint32_t cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) cnt[l] = tmp[l];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { cn.limit[l] = 0; cn.base[l] = 0; }
+    if ((int)cnt[0] == n) return true;
+    int left = 1;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) { left <<= 1; left -= (int)cnt[l]; }
+    {   // over-subscribed at some length?
+        int lf = 1; bool bad = false;
+#pragma unroll
+        for (int l = 1; l < 16; ++l) { lf <<= 1; lf -= (int)cnt[l]; bad = bad || lf < 0; }
+        if (bad) return false;
+    }
+    // offsets of each length's symbols in sym[] (kept in tmp for the scatter), first canonical code per length
+    uint32_t off = 0, code = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        tmp[l] = off;
+        cn.base[l] = (int32_t)off - (int32_t)code;
+        cn.limit[l] = (code + cnt[l]) << (15 - l);
+        off += cnt[l];
+        code = (code + cnt[l]) << 1;
+    }
+    for (int i = 0; i < n; ++i) { const int l = lens[i]; if (l) sym[tmp[l]++] = (uint16_t)i; }
+    // direct table for the codes of up to fast_bits bits
+    uint32_t c2 = 0, idx = 0;
+#pragma unroll
+    for (int l = 1; l < 16; ++l) {
+        if (l <= fast_bits) {
+            for (uint32_t k = 0; k < cnt[l]; ++k, ++idx, ++c2) {
+                const uint32_t r = rev_bits(c2, l);
+                const uint16_t e = (uint16_t)(sym[idx] | (l << 12));
+                for (uint32_t f = r; f < (1u << fast_bits); f += (1u << l)) fast[f] = e;
+            }
+            c2 <<= 1;
+        }
+    }
+    return true;
+}
+__device__ __forceinline__ uint32_t lane_take(uint64_t& buf, int& cnt, int n) {
+    const uint32_t v = (uint32_t)(buf & ((1ull << n) - 1));
+    buf >>= n; cnt -= n;
+    return v;
+}
+template <int FB>
+__device__ __forceinline__ int lane_decode(uint64_t& buf, int& cnt, const uint16_t* fast, const uint16_t* sym, const Canon& cn) {
+    const uint16_t e = fast[buf & ((1u << FB) - 1)];
+    if (e) { const int l = e >> 12; buf >>= l; cnt -= l; return e & 0xFFF; }
+    const uint32_t c15 = __brev((uint32_t)buf) >> 17;                   // the next 15 bits, first bit most significant
+    int res = -1;
+#pragma unroll
+    for (int l = 15; l > FB; --l)                                       // the shortest length whose limit the code is under
+        if (c15 < cn.limit[l]) res = l;
+    if (res < 0) return -1;
+    int l = res; int32_t b = 0;
+#pragma unroll
+    for (int q = FB + 1; q < 16; ++q) b = (q == l) ? cn.base[q] : b;
+    const int s_ = sym[b + (int32_t)(c15 >> (15 - l))];
+    buf >>= l; cnt -= l;
+    return s_;
+}
+}  // namespace ing
+
+__global__ __launch_bounds__(64) void thj_k_inflate_lanes(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
+                                                           uint8_t* __restrict__ out, uint32_t* __restrict__ out_len) {
+    using namespace ing;
+    __shared__ uint32_t lds[64 * LANE_WORDS];
+    const int lane = threadIdx.x;
+    const int blk = blockIdx.x * 64 + lane;
+    if (blk >= n_blocks) return;
+    uint32_t* my = lds + lane * LANE_WORDS;
+    uint16_t* lit_fast = (uint16_t*)my;                 // 256 entries = 128 words
+    uint16_t* dist_fast = (uint16_t*)(my + 128);        // 32 entries = 16 words
+    uint16_t* lit_sym = (uint16_t*)(my + 144);          // 288 entries = 144 words
+    uint16_t* dist_sym = (uint16_t*)(my + 288);         // 32 entries = 16 words  (+1 pad word)
+    const uint8_t* in = comp + blocks[blk].in_off;
+    const uint32_t in_len = blocks[blk].in_len;
+    uint8_t* dst = out + ((size_t)blk << 16);
+    // compressed stream in aligned words
+    const uint32_t mis = (uint32_t)((uintptr_t)in & 3u);
+    const uint32_t* wp = (const uint32_t*)(in - mis);
+    const uint32_t n_words = (in_len + mis + 3) >> 2;
+    uint32_t wi = 0;
+    uint64_t buf = 0; int cnt = 0;
+    if (n_words) { buf = (uint64_t)(wp[0] >> (8 * mis)); cnt = 32 - 8 * (int)mis; wi = 1; }
+#define LREFILL() do { if (cnt <= 32) { const uint32_t w_ = wi < n_words ? wp[wi] : 0u; buf |= (uint64_t)w_ << cnt; cnt += 32; ++wi; } } while (0)
+#define LTAKE(n_) lane_take(buf, cnt, (n_))
+    uint32_t outp = 0, acc = 0;
+#define LPUT(byte_) do { acc |= (uint32_t)(uint8_t)(byte_) << (8 * (outp & 3u)); ++outp; if ((outp & 3u) == 0) { *(uint32_t*)(dst + outp - 4) = acc; acc = 0; } } while (0)
+    // the long-code limits stay in registers: the build fills a scratch copy (its address goes to a call), this copies it over
+#define LCOPY(dst_, src_) do { _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) { dst_.limit[q_] = src_.limit[q_]; dst_.base[q_] = src_.base[q_]; } } while (0)
+    Canon lc, dc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { lc.limit[q] = dc.limit[q] = 0; lc.base[q] = dc.base[q] = 0; }
+    uint8_t lens[320];
+    bool err = false;
+    int last = 0;
+    while (!last && !err) {
+        LREFILL();
+        last = (int)LTAKE(1);
+        const int type = (int)LTAKE(2);
+        if (type == 0) {
+            LTAKE(cnt & 7);
+            LREFILL();
+            const uint32_t len = LTAKE(16);
+            LREFILL();
+            const uint32_t nlen = LTAKE(16);
+            if ((len ^ 0xFFFFu) != nlen || outp + len > 65536u) { err = true; break; }
+            for (uint32_t k = 0; k < len; ++k) { LREFILL(); const uint32_t v = LTAKE(8); LPUT(v); }
+            continue;
+        }
+        if (type == 3) { err = true; break; }
+        if (type == 1) {
+            for (int i = 0; i < 144; ++i) lens[i] = 8;
+            for (int i = 144; i < 256; ++i) lens[i] = 9;
+            for (int i = 256; i < 280; ++i) lens[i] = 7;
+            for (int i = 280; i < 288; ++i) lens[i] = 8;
+            Canon t;
+            lane_build(lens, 288, lit_fast, LF, lit_sym, t); LCOPY(lc, t);
+            for (int i = 0; i < 30; ++i) lens[i] = 5;
+            lane_build(lens, 30, dist_fast, DF, dist_sym, t); LCOPY(dc, t);
+        } else {
+            const int hlit = (int)LTAKE(5) + 257, hdist = (int)LTAKE(5) + 1, hclen = (int)LTAKE(4) + 4;
+            if (hlit > 286 || hdist > 30) { err = true; break; }
+            uint8_t cl[19];
+            for (int i = 0; i < 19; ++i) cl[i] = 0;
+            for (int i = 0; i < hclen; ++i) { LREFILL(); cl[CLORD[i]] = (uint8_t)LTAKE(3); }
+            // the code-length code borrows the literal table's storage (19 symbols, codes of at most 7 bits: all direct)
+            Canon cc;
+            if (!lane_build(cl, 19, lit_fast, 7, dist_sym, cc)) { err = true; break; }
+            int i = 0;
+            while (i < hlit + hdist) {
+                LREFILL();
+                const uint16_t e = lit_fast[buf & 127u];
+                if (!e) { err = true; break; }
+                { const int l = e >> 12; buf >>= l; cnt -= l; }
+                const int sym = e & 0xFFF;
+                if (sym < 16) lens[i++] = (uint8_t)sym;
+                else {
+                    int rep, val = 0;
+                    if (sym == 16) { if (i == 0) { err = true; break; } val = lens[i - 1]; rep = 3 + (int)LTAKE(2); }
+                    else if (sym == 17) rep = 3 + (int)LTAKE(3);
+                    else rep = 11 + (int)LTAKE(7);
+                    if (i + rep > hlit + hdist) { err = true; break; }
+                    while (rep--) lens[i++] = (uint8_t)val;
+                }
+            }
+            if (err) break;
+            if (lens[256] == 0) { err = true; break; }
+            Canon t;
+            if (!lane_build(lens + hlit, hdist, dist_fast, DF, dist_sym, t)) { err = true; break; }
+            LCOPY(dc, t);
+            if (!lane_build(lens, hlit, lit_fast, LF, lit_sym, t)) { err = true; break; }
+            LCOPY(lc, t);
+        }
+        // ---- the block's symbols
+        for (;;) {
+            LREFILL();
+            int sym = lane_decode<LF>(buf, cnt, lit_fast, lit_sym, lc);
+            if (sym < 0) { err = true; break; }
+            if (sym < 256) { if (outp >= 65536u) { err = true; break; } LPUT(sym); continue; }
+            if (sym == 256) break;
+            sym -= 257;
+            if (sym >= 29) { err = true; break; }
+            const int len = (int)LBASE[sym] + (int)LTAKE(LEXT[sym]);
+            LREFILL();
+            const int ds = lane_decode<DF>(buf, cnt, dist_fast, dist_sym, dc);
+            if (ds < 0 || ds >= 30) { err = true; break; }
+            LREFILL();
+            const uint32_t dist = (uint32_t)DBASE[ds] + LTAKE(DEXT[ds]);
+            if (dist > outp || outp + (uint32_t)len > 65536u) { err = true; break; }
+            int k = 0;
+            if (dist >= 12) {
+                // four bytes at a time: the source words were stored at least two words ago (the lane reads its own stores back)
+                for (; k + 4 <= len; k += 4) {
+                    const uint32_t sp = outp - dist, sh = 8 * (sp & 3u);
+                    const uint32_t* swp = (const uint32_t*)(dst + (sp & ~3u));
+                    uint32_t v = swp[0];
+                    if (sh) v = (v >> sh) | (swp[1] << (32 - sh));
+                    const uint32_t os = 8 * (outp & 3u);
+                    if (os == 0) *(uint32_t*)(dst + outp) = v;
+                    else { acc |= v << os; *(uint32_t*)(dst + (outp & ~3u)) = acc; acc = v >> (32 - os); }
+                    outp += 4;
+                }
+            }
+            for (; k < len; ++k) {                                    // bytes below outp & ~3 are in memory, the rest in acc
+                const uint32_t sp = outp - dist;
+                const uint32_t v = sp >= (outp & ~3u) ? (acc >> (8 * (sp & 3u))) & 0xFFu : (uint32_t)dst[sp];
+                LPUT(v);
+            }
+        }
+        if (cnt < 0) err = true;
+    }
+    if (!err && (outp & 3u)) { for (uint32_t k = 0; k < (outp & 3u); ++k) dst[(outp & ~3u) + k] = (uint8_t)(acc >> (8 * k)); }
+    out_len[blk] = err ? 0xFFFFFFFFu : outp;
+#undef LREFILL
+#undef LTAKE
+#undef LPUT
+#undef LCOPY
+}
+
+// Which inflater: the workgroup-per-block kernel.  THJ_INFLATE=lanes selects the lane-per-block experiment (measured 3.5 GB/s
+// against 12: divergent lanes wait for each other's match copies and table builds; it would need a one-step-per-iteration
+// state machine and tens of thousands of blocks in flight -- kept for that work, not used).
+static void launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_block* d_blocks, int64_t nb, uint8_t* d_out, uint32_t* d_len) {
+    static const char* force = getenv("THJ_INFLATE");
+    const bool lanes = force && force[0] == 'l';
+    if (lanes) hipLaunchKernelGGL(thj_k_inflate_lanes, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len);
+    else { const int64_t grid = nb < 4096 ? nb : 4096; hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len); }
+}
+
 // ------------------------------------------------------------------------------------------------ C ABI
 
 extern "C" int thj_bgzf_inflate(thj_ctx* c, const uint8_t* comp, int64_t comp_bytes, const thj_bgzf_block* blocks, int64_t n_blocks,
@@ -306,8 +557,7 @@ extern "C" int thj_bgzf_inflate(thj_ctx* c, const uint8_t* comp, int64_t comp_by
         HIPCHK(hipMemcpyAsync(t1, blocks, (size_t)n_blocks * sizeof(thj_bgzf_block), hipMemcpyHostToDevice, c->stream));
         d_comp = (const uint8_t*)t0; d_blocks = (const thj_bgzf_block*)t1; d_out = (uint8_t*)t2; d_len = (uint32_t*)t3;
     }
-    int64_t grid = n_blocks < 256 * 4 * 4 ? n_blocks : 256 * 4 * 4;
-    hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)n_blocks, d_out, d_len);
+    launch_inflate(c, d_comp, d_blocks, n_blocks, d_out, d_len);
     HIPCHK(hipGetLastError());
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(out_len, t3, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, c->stream));
@@ -331,6 +581,8 @@ extern "C" int thj_bgzf_inflate(thj_ctx* c, const uint8_t* comp, int64_t comp_by
 // rows and the CSR offsets, one scatter per file.
 
 #include <hipcub/hipcub.hpp>
+#include <atomic>
+#include <chrono>
 
 namespace ing {
 
@@ -704,6 +956,17 @@ static unsigned grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (unsig
 
 // inflate + walk + parse + compact for a list of pieces (kinds[f]: KIND_HITS / KIND_READS).  extra1 = bytes the caller will still
 // take from the second arena.  Two synchronisations (record total, compact ranges).
+// THJ_INGEST_TIMING=1: wall clock per phase of the ingest (a stream synchronisation at every mark, so only for diagnosis);
+// thj_ingest_timing_report() prints the sums
+struct PhaseClock {
+    static std::atomic<long long>& slot(int k) { static std::atomic<long long> ns[12]; return ns[k]; }
+    static bool on() { static const bool v = getenv("THJ_INGEST_TIMING") != nullptr; return v; }
+    thj_ctx* c; long long t;
+    explicit PhaseClock(thj_ctx* c_) : c(c_), t(0) { if (on()) { hipStreamSynchronize(c->stream); t = now(); } }
+    static long long now() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void mark(int k) { if (!on()) return; hipStreamSynchronize(c->stream); const long long n = now(); slot(k) += n - t; t = n; }
+};
+
 static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<const thj_bam_piece*>& pieces, const std::vector<uint32_t>& kinds, uint32_t begin_id,
                         uint32_t end_id, int want32, size_t extra1_per_rec, size_t extra1_fixed, Parsed& P) {
     const int nf = (int)pieces.size();
@@ -746,6 +1009,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     ING_TAKE(ar, d_recoff, uint16_t, (size_t)nb * MAXREC);
     ING_TAKE(ar, d_status, unsigned int, 16);
     P.infl = d_infl; P.status = d_status;
+    PhaseClock pc(c);
     {
         int64_t at = 0;
         for (int f = 0; f < nf; ++f) { const thj_bam_piece& p = *pieces[(size_t)f]; if (p.comp_bytes) HIPCHK(hipMemcpyAsync(d_comp + at, p.comp, (size_t)p.comp_bytes, hipMemcpyHostToDevice, c->stream)); at += p.comp_bytes; }
@@ -756,7 +1020,9 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     if (!tid2ref.empty()) HIPCHK(hipMemcpyAsync(d_tid, tid2ref.data(), tid2ref.size() * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(d_status, 0, 64, c->stream));
     HIPCHK(hipMemsetAsync(d_cnt + nb, 0, 4, c->stream));
-    { const int64_t grid = nb < 4096 ? nb : 4096; hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_infl, d_len); }
+    pc.mark(0);
+    launch_inflate(c, d_comp, d_blocks, nb, d_infl, d_len);
+    pc.mark(1);
     hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
     int rc = exclusive_sum(c, d_cnt, d_base, nb + 1);
     if (rc) return rc;
@@ -765,6 +1031,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipMemcpyAsync(h_base.data(), d_base, (size_t)(nb + 1) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    pc.mark(2);
     if (h_status[ST_CORRUPT]) { thj_set_error("thj_ingest: a BGZF member does not inflate (corrupt input)"); return THJ_EINVAL; }
     if (h_status[ST_STRADDLE]) { thj_set_error("BAM records straddle BGZF members (not written by samtools' bam_write1)"); return THJ_EFALLBACK; }
     const int64_t T = h_base[(size_t)nb];
@@ -783,6 +1050,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipMemsetAsync(p_valid + T, 0, 4, c->stream));
     hipLaunchKernelGGL(thj_k_parse, dim3((unsigned)nb), dim3(256), 0, c->stream, d_infl, d_blk_file, d_files, d_recoff, d_cnt, d_base, d_tid, begin_id, end_id,
                        (int)tp->max_report_intron, want32, po, d_status);
+    pc.mark(3);
     hipLaunchKernelGGL(thj_k_mark_reads, dim3(grid_for(T)), dim3(256), 0, c->stream, d_files, nf, d_base, p_isr, T);
     if ((rc = exclusive_sum(c, p_valid, p_dst, T + 1))) return rc;
     hipLaunchKernelGGL(thj_k_compact, dim3(grid_for(T)), dim3(256), 0, c->stream, T, p_valid, p_dst, po, qo, want32, p_isr);
@@ -791,6 +1059,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
+    pc.mark(4);
     if (h_status[ST_XF]) { thj_set_error("fusion (XF) alignments are not supported by this build"); return THJ_EINVAL; }
     if (h_status[ST_CIGAR]) { thj_set_error("a segment alignment has more than 5 CIGAR operations (this build supports 5)"); return THJ_EINVAL; }
     P.id = q_id; P.h16 = qo.h16; P.h32 = qo.h32; P.loc = q_loc; P.n = P.fb[(size_t)nf];
@@ -798,6 +1067,13 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
 }
 
 }  // namespace ing
+
+extern "C" void thj_ingest_timing_report(void) {
+    if (!ing::PhaseClock::on()) return;
+    static const char* const nm[8] = {"host-to-device copies of the compressed pieces", "inflate kernel", "record walk + scan + round trip", "parse kernel",
+                                      "compact + round trip", "merge by read id + scatter (seg batch)", "merge by read id + scatter (span batch)", "reads: planes + device-to-host"};
+    for (int k = 0; k < 8; ++k) fprintf(stderr, "[ingest-seconds] %-52s %8.3f\n", nm[k], (double)ing::PhaseClock::slot(k).load() * 1e-9);
+}
 
 extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* mate_full,
                                     const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
@@ -821,6 +1097,8 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
     // the merge takes, per id of the shard's id range, two words per map + two; per row a handful more
     int rc = ingest_front(c, tp, pieces, kinds, begin_id, end_id, 0, 0, 0, P);
     if (rc) return rc;
+    PhaseClock pc(c);
+    struct PcEnd { PhaseClock& p; ~PcEnd() { p.mark(5); } } pc_end{pc};
     const std::vector<uint32_t>& fb = P.fb;
     if (P.n == 0) return THJ_OK;
     uint32_t id_lo = 0xFFFFFFFFu, id_hi = 0;
@@ -946,6 +1224,7 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
     Parsed P;
     int rc = ingest_front(c, tp, pieces, kinds, begin_id, end_id, 1, 0, 0, P);
     if (rc) return rc;
+    PhaseClock pc(c);
     const std::vector<uint32_t>& fb = P.fb;
     if (P.n == 0 || fb[1] == fb[0]) return THJ_OK;               // no first-segment hit in range
     uint32_t ends[2] = {0, 0};
@@ -997,6 +1276,7 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
         const uint32_t a = fb[(size_t)s], b = fb[(size_t)s + 1];
         if (b > a) hipLaunchKernelGGL(thj_k_scatter_span, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.id, P.h32, a, b, id_lo, span, m_vis, m_row, m_first + (size_t)s * span, b_off, nseg, s, b_hits, b_heads);
     }
+    pc.mark(6);
     uint32_t* h_loc = nullptr; uint8_t* h_infl = nullptr;
     auto fail2 = [&](int code) { free(h_ids); free(h_loc); free(h_infl); return fail(code); };
     if (reads) {
@@ -1031,6 +1311,7 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
         ob->desc.words_per_plane = W; ob->desc.qual_stride = qstride;
         ob->desc.read_planes = (const uint64_t*)ob->ptrs[2]; ob->desc.read_len = (const uint16_t*)ob->ptrs[3]; ob->desc.quals = (const uint8_t*)ob->ptrs[4];
         *reads_infl = h_infl; *reads_infl_bytes = (int64_t)ib; *row_loc_out = h_loc;
+        pc.mark(7);
     }
     ING_HIP(hipStreamSynchronize(c->stream));
     ING_HIP(hipGetLastError());
