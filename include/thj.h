@@ -358,7 +358,9 @@ int thj_span_reset_async(thj_ctx* ctx);
 /* join_segments_for_read + sort/unique + filters + bowtie_sam_extra for every read of the
  * batch (long_spanning_reads.cpp:2612-2667, :2767-2831); records accumulate in HBM. */
 int thj_span_run_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* dev_batch);
-/* Synchronises and returns the record count.  THJ_EOVERFLOW when a device limit was hit (message says which).
+/* Synchronises and returns the record count.  THJ_EOVERFLOW when a device limit was hit (message says which); THJ_ERETRY when
+ * a pool or workspace had to be enlarged (extra records of multihit reads; reads with more joined alignments than a thread keeps):
+ * run the pass again.
  * On the device the records sit in BAM order already: one slot per read of the pass (run order, then read order)
  * holding the read's first record, a per-read count, and the few extra records of multihit reads keyed by
  * (slot << 16 | rank) -- rank = BowtieHit::operator< order inside the read (bwt_map.h:180-207). */

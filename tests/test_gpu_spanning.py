@@ -106,3 +106,35 @@ def test_long_md_strings_are_rebuilt_on_the_host():
         ctx.upload_genome(host.pack_genome(seqs))
         ctx.upload_span_sets(ja, [])
         assert ctx.spanning(p, [ctx.upload_span_batch(sb)]) == want
+
+
+def test_reads_with_more_joined_alignments_than_a_thread_keeps():
+    """120 joined alignments per read (a 120-copy tandem repeat, --max-seg-multihits raised so that the reads are not dropped):
+    more than the 96 a thread of the generic tier keeps.  The first pass reports them, thj_span_finish sets up the big
+    workspace and answers THJ_ERETRY, the rerun sends such reads through thj_k_stitch_huge -- every record the oracle gives.
+    With fusion search on the fusion tier's smaller array (24) overflows the same way on a 30-copy repeat."""
+    import ctypes as C
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    seq, sb = repeat_span_batch(copies=120, n_reads=12, seed=11)
+    p = Params(max_seg_multihits=200)
+    want = orc.spanning(p, orc.Genome([seq]), sb, nj, [])
+    assert len(want) == 120 * 12
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        ctx.upload_span_sets(nj, [])
+        h = ctx.upload_span_batch(sb)
+        ctx.span_reset()
+        ctx.span_run(p, h)
+        n = C.c_int64()
+        assert ctx.lib.thj_span_finish(ctx._ctx, C.byref(n)) == -7 and b"run the pass again" in ctx.lib.thj_last_error()
+        assert ctx.spanning(p, [h]) == want
+        assert ctx.spanning(p, [h]) == want                 # and again, the workspace now in place from the start
+        # fusion search: 30 joined alignments per read are already more than the fusion tier keeps per thread
+        seq2, sb2 = repeat_span_batch(copies=30, n_reads=10, seed=12)
+        ctx.upload_genome(host.pack_genome([seq2]))
+        ctx.upload_span_sets(nj, [])
+        ctx.upload_span_fusions(np.zeros(0, dtype=host.SPAN_FUSION_DTYPE))
+        pf = Params(fusion_search=1)
+        wantf = orc.spanning_fusion(pf, orc.Genome([seq2]), sb2, nj, [], np.zeros(0, dtype=orc.SPAN_FUSION_DTYPE), True)
+        assert len(wantf) == 30 * 10
+        assert ctx.spanning(pf, [ctx.upload_span_batch(sb2)]) == wantf

@@ -65,7 +65,7 @@ struct RecSink {
 #pragma unroll
         for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
     }
-    __device__ __forceinline__ void done(uint32_t r) { nrec[(size_t)base + r] = (uint8_t)emitted; acc += emitted; emitted = 0; }
+    __device__ __forceinline__ void done(uint32_t r) { nrec[(size_t)base + r] = (uint8_t)(emitted > 255 ? 255 : emitted); acc += emitted; emitted = 0; }   // the count saturates: consumers test it for zero
 };
 
 // The three tiers hand reads down through worklists.  A global append counter would serialise every wave of the
@@ -77,7 +77,17 @@ struct Tiers {
     unsigned int* blk_lean; unsigned int* blk_multi; unsigned int* blk_gen;
     unsigned int* counters;          // reads handed to [0] tier 1, [1] tier 2, [2] tier 3 (this run)
     int chunk;
+    // reads with more joined alignments than a thread's own array holds (a read in a large repeat family): listed here when the
+    // context owns the big workspace (thj_k_stitch_huge does them again with room), else reported (SPAN_TOO_MANY_JOINED)
+    uint32_t* huge_list; unsigned int* huge_cnt; int huge_list_cap;
 };
+__device__ __forceinline__ bool defer_huge(const Tiers& t, uint32_t r) {
+    if (!t.huge_list) return false;
+    const unsigned int k = atomicAdd(t.huge_cnt, 1u);
+    if (k >= (unsigned int)t.huge_list_cap) return false;
+    t.huge_list[k] = r;
+    return true;
+}
 // Tier 1's list is class-major on top of that (SPAN_LEAN_CLASSES x G slices: the reads whose gap lean_join meets in the same
 // loop iteration sit together, so a wave runs the closure code once, not once per gap position); batches of more than
 // four segments per read keep one class -- their kernel has no LDS to spare for the longer offset table.
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, 
         const uint8_t* q = b.quals + (size_t)r * b.qual_stride;
         int st = span_read_multi(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, stage, sink);
         if (st == SPAN_NEED_GENERIC) st = span_read(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, sink);
+        if (st == SPAN_TOO_MANY_JOINED && defer_huge(t, (uint32_t)r)) continue;
         sink.done((uint32_t)r);
         if (st) atomicAdd(&sink.status[st], 1u);
     }
@@ -285,12 +296,36 @@ __global__ __launch_bounds__(64) void thj_k_stitch_fusion(Genome g, Params p, Sp
         const int r = (int)t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])];
         int st = span_read_fusion(g, p, S, F, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                   (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
+        if (st == SPAN_TOO_MANY_JOINED && defer_huge(t, (uint32_t)r)) continue;
         sink.done((uint32_t)r);
         if (st) atomicAdd(&sink.status[st], 1u);
     }
     if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
     __syncthreads();
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
+}
+
+// The reads the generic / fusion kernels listed: one at a time per workgroup (lane 0), joined alignments in the workgroup's slice
+// of the context's big workspace (2 * cap records: the list and the merge sort's scratch).  Rare by construction.
+static constexpr int HUGE_BLOCKS = 64, HUGE_CAP = 8192, HUGE_LIST_CAP = 1 << 16;
+static constexpr int HUGE_REC_BYTES = 128;               // >= sizeof(Aln), sizeof(FHit)
+static_assert(sizeof(Aln) <= HUGE_REC_BYTES && sizeof(FHit) <= HUGE_REC_BYTES, "workspace record size");
+__global__ __launch_bounds__(64) void thj_k_stitch_huge(Genome g, Params p, SpanSets S, FusionSet F, DevSpanBatch b, RecSink sink, Tiers t, char* ws, int cap) {
+    if (threadIdx.x != 0) return;
+    const unsigned int n = *t.huge_cnt < (unsigned int)t.huge_list_cap ? *t.huge_cnt : (unsigned int)t.huge_list_cap;
+    char* mine = ws + (size_t)blockIdx.x * 2 * (size_t)cap * HUGE_REC_BYTES;
+    for (unsigned int i = blockIdx.x; i < n; i += gridDim.x) {
+        const int r = (int)t.huge_list[i];
+        const uint32_t* so = b.seg_off + (size_t)r * b.nseg;
+        const u64* rp = b.planes + (size_t)r * 3 * b.W;
+        const uint8_t* q = b.quals + (size_t)r * b.qual_stride;
+        int st;
+        if (p.fusion_search) st = span_read_fusion(g, p, S, F, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, sink, (FHit*)mine, cap);
+        else st = span_read(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, sink, (Aln*)mine, cap);
+        sink.done((uint32_t)r);
+        if (st) atomicAdd(&sink.status[st], 1u);
+    }
+    if (sink.acc) atomicAdd(sink.total, (unsigned long long)sink.acc);
 }
 
 __global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u64* vals, int64_t n, u64* okeys, uint32_t* oseq) {
@@ -325,7 +360,7 @@ static int build_junc_buckets(thj_ctx* c) {
 static void jb_free(thj_ctx* c);
 void thj_span_free(thj_ctx* c) {
     jb_free(c);
-    hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket); hipFree(c->d_span_fus);
+    hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket); hipFree(c->d_span_fus); hipFree(c->d_huge_ws); hipFree(c->d_huge_list);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -334,9 +369,9 @@ void thj_span_free(thj_ctx* c) {
 static int ensure_span_state(thj_ctx* c) {
     if (!c->d_aln_count) {
         HIPCHK(hipMalloc(&c->d_aln_count, 16));
-        HIPCHK(hipMalloc(&c->d_span_status, 8 * sizeof(unsigned int)));
+        HIPCHK(hipMalloc(&c->d_span_status, 16 * sizeof(unsigned int)));
         HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 16, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_span_status, 0, 32, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_span_status, 0, 64, c->stream));
     }
     return THJ_OK;
 }
@@ -610,7 +645,9 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     t.blk_gen = t.blk_multi + MAX_SLICES;
     t.counters = &c->d_span_status[4];
     t.chunk = (int)chunk;
+    t.huge_list = c->d_huge_list; t.huge_cnt = &c->d_span_status[8]; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
     HIPCHK(hipMemsetAsync(t.counters, 0, 12, c->stream));
+    HIPCHK(hipMemsetAsync(t.huge_cnt, 0, 4, c->stream));
     HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, c->stream));      // tiers 0 / 1 write the other two
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
@@ -639,6 +676,10 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     if (c->span_profile) {
         HIPCHK(hipEventRecord(ev[4], c->stream));
         for (int k = 0; k < 4; ++k) c->span_prof_events.emplace_back(ev[k], ev[k + 1]);
+    }
+    if (c->d_huge_ws) {        // a pass that met a read with too many joined alignments runs with the workspace from then on
+        FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
+        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, c->stream, g, p, S, F, b, sink, t, (char*)c->d_huge_ws, HUGE_CAP);
     }
     HIPCHK(hipGetLastError());
     c->span_reads += b.n_reads;
@@ -669,7 +710,17 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
         return THJ_ERETRY;
     }
     if (st[SPAN_TOO_MANY_JOINED]) {
-        thj_set_error("%u read(s) have more than %d distinct joined alignments (device limit)", st[SPAN_TOO_MANY_JOINED], SPAN_MAXJOIN);
+        if (!c->d_huge_ws) {
+            // a read has more joined alignments than a thread's own array holds: get the big workspace (HUGE_BLOCKS slices of
+            // 2 * HUGE_CAP records) and ask for the pass again -- thj_k_stitch_huge then takes such reads one by one
+            HIPCHK(hipMalloc(&c->d_huge_ws, (size_t)HUGE_BLOCKS * 2 * HUGE_CAP * HUGE_REC_BYTES));
+            HIPCHK(hipMalloc(&c->d_huge_list, (size_t)HUGE_LIST_CAP * 4));
+            thj_set_error("%u read(s) have more joined alignments than the stitch kernels keep per thread (%d, %d with fusion search); a workspace "
+                          "for them has been set up: run the pass again (thj_span_reset_async, the thj_span_run_async calls, thj_span_finish)",
+                          st[SPAN_TOO_MANY_JOINED], SPAN_MAXJOIN, FUS_MAXJOIN);
+            return THJ_ERETRY;
+        }
+        thj_set_error("%u read(s) have more than %d joined alignments before sort + unique (device limit)", st[SPAN_TOO_MANY_JOINED], HUGE_CAP);
         return THJ_EOVERFLOW;
     }
     c->n_alns = (int64_t)c->h_pinned[24];

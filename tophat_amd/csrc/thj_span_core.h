@@ -671,7 +671,7 @@ enum { SPAN_OK = 0, SPAN_TOO_MANY_JOINED = 1, SPAN_MD_OVERFLOW = 2, SPAN_NEED_GE
 // sink.emit(const OutAln&) in output order; returns a SPAN_* status.
 template <class Sink>
 THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, const uint32_t* so, int nseg,
-                     const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+                     const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink, Aln* ext = nullptr, int ext_cap = 0) {
     if (so[1] == so[0]) return SPAN_OK;                         // worker iterates over first-segment groups
     int nsegs = 0;
     while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;   // look_right stops at the first empty segment (:151)
@@ -681,7 +681,12 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
         for (int s = 0; s < nsegs; ++s)
             if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;   // :2625-2632
     const int L = p.segment_length;
-    Aln joined[SPAN_MAXJOIN]; int nj = 0;
+    // ext: a caller-owned buffer of 2 * ext_cap alignments for the reads whose joined alignments do not fit SPAN_MAXJOIN (the
+    // second half is the merge sort's scratch); without it such a read reports SPAN_TOO_MANY_JOINED and emits nothing
+    Aln joined_local[SPAN_MAXJOIN];
+    Aln* joined = ext ? ext : joined_local;
+    const int cap = ext ? ext_cap : SPAN_MAXJOIN;
+    int nj = 0;
     int status = SPAN_OK;
     SeqView fwd = seq_forward(rp, W, rl);
     SeqView rev = seq_revcomp(rp, W, rl);
@@ -707,7 +712,7 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
                     ok = merge_chain(g, p, S, anti ? rev : fwd, chain, nsegs, bh);
                 } else { bh = stack[0]; ok = true; }
                 if (ok && valid_hit(p, bh)) {
-                    if (nj < SPAN_MAXJOIN) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED;
+                    if (nj < cap) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED;
                 }
                 --depth;
                 continue;
@@ -729,11 +734,28 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
         }
     }
     if (THJ_EXPF(4096)) return SPAN_OK;
-    // sort + unique (:2805-2807): insertion sort (stable; what std::sort does below 16 elements)
-    for (int i = 1; i < nj; ++i) {
-        Aln t = joined[i]; int k = i;
-        while (k > 0 && aln_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
-        joined[k] = t;
+    if (status == SPAN_TOO_MANY_JOINED) return status;          // nothing is emitted: the read is done again with room (or reported)
+    // sort + unique (:2805-2807): insertion sort (stable; what std::sort does below 16 elements); a stable merge sort for the
+    // long lists of the external buffer
+    if (!ext || nj <= 64) {
+        for (int i = 1; i < nj; ++i) {
+            Aln t = joined[i]; int k = i;
+            while (k > 0 && aln_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
+            joined[k] = t;
+        }
+    } else {
+        Aln* a = joined; Aln* b = joined + ext_cap;
+        for (int width = 1; width < nj; width <<= 1) {
+            for (int lo = 0; lo < nj; lo += 2 * width) {
+                const int mid = lo + width < nj ? lo + width : nj, hi = lo + 2 * width < nj ? lo + 2 * width : nj;
+                int i = lo, j = mid, k = lo;
+                while (i < mid && j < hi) b[k++] = aln_less(a[j], a[i]) ? a[j++] : a[i++];
+                while (i < mid) b[k++] = a[i++];
+                while (j < hi) b[k++] = a[j++];
+            }
+            Aln* t = a; a = b; b = t;
+        }
+        if (a != joined) for (int i = 0; i < nj; ++i) joined[i] = a[i];
     }
     int w = 0;
     for (int i = 0; i < nj; ++i) if (w == 0 || !aln_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];

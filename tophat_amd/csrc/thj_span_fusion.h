@@ -737,7 +737,7 @@ THJ_HD void f_emit(Sink& sink, uint32_t read_idx, int order, const FHit& h, cons
 // work: FHit[3 * (SPAN_MAXSEG + 1)] of per-thread memory (stack, saved stack tops, chain).
 template <class Sink>
 THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
-                            int nseg, const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+                            int nseg, const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink, FHit* ext = nullptr, int ext_cap = 0) {
     if (so[1] == so[0]) return SPAN_OK;
     int nsegs = 0;
     while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
@@ -748,7 +748,10 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;
     const int fs = p.fusion_search;
     FRead rd{rp, W, rl, p.segment_length, nsegs, qual};
-    FHit joined[FUS_MAXJOIN]; int nj = 0;
+    FHit joined_local[FUS_MAXJOIN];               // ext: see span_read
+    FHit* joined = ext ? ext : joined_local;
+    const int cap = ext ? ext_cap : FUS_MAXJOIN;
+    int nj = 0;
     FHit stack[SPAN_MAXSEG + 1], saved[SPAN_MAXSEG + 1], chain[SPAN_MAXSEG + 1];
     uint32_t idx[SPAN_MAXSEG + 1];
     int fdir[SPAN_MAXSEG + 2];
@@ -766,7 +769,7 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
                 --num_try;
                 FHit bh;
                 f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
-                if (bh.n) { if (nj < FUS_MAXJOIN) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED; }
+                if (bh.n) { if (nj < cap) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED; }
                 --d;
                 if (d >= 1) stack[d - 1] = saved[d];
                 continue;
@@ -864,10 +867,26 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             }
         }
     }
-    for (int i = 1; i < nj; ++i) {                        // sort + unique (:2805-2807); stable insertion sort
-        FHit t = joined[i]; int k = i;
-        while (k > 0 && fhit_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
-        joined[k] = t;
+    if (status == SPAN_TOO_MANY_JOINED) return status;
+    if (!ext || nj <= 64) {
+        for (int i = 1; i < nj; ++i) {                    // sort + unique (:2805-2807); stable insertion sort
+            FHit t = joined[i]; int k = i;
+            while (k > 0 && fhit_less(t, joined[k - 1])) { joined[k] = joined[k - 1]; --k; }
+            joined[k] = t;
+        }
+    } else {                                              // long lists (external buffer): stable merge sort
+        FHit* a = joined; FHit* b = joined + ext_cap;
+        for (int width = 1; width < nj; width <<= 1) {
+            for (int lo = 0; lo < nj; lo += 2 * width) {
+                const int mid = lo + width < nj ? lo + width : nj, hi = lo + 2 * width < nj ? lo + 2 * width : nj;
+                int i = lo, j = mid, k = lo;
+                while (i < mid && j < hi) b[k++] = fhit_less(a[j], a[i]) ? a[j++] : a[i++];
+                while (i < mid) b[k++] = a[i++];
+                while (j < hi) b[k++] = a[j++];
+            }
+            FHit* t = a; a = b; b = t;
+        }
+        if (a != joined) for (int i = 0; i < nj; ++i) joined[i] = a[i];
     }
     int w = 0;
     for (int i = 0; i < nj; ++i) if (w == 0 || !fhit_eq(joined[w - 1], joined[i])) joined[w++] = joined[i];
