@@ -534,7 +534,8 @@ __global__ __launch_bounds__(64) void thj_k_inflate_lanes(const uint8_t* __restr
 // state machine and tens of thousands of blocks in flight -- kept for that work, not used).
 static void launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_block* d_blocks, int64_t nb, uint8_t* d_out, uint32_t* d_len) {
     static const char* force = getenv("THJ_INFLATE");
-    const bool lanes = force && force[0] == 'l';
+    static const int lanes_min = getenv("THJ_INFLATE_LANES_MIN") ? atoi(getenv("THJ_INFLATE_LANES_MIN")) : 0;
+    const bool lanes = force ? force[0] == 'l' : (lanes_min > 0 && nb >= lanes_min);
     if (lanes) hipLaunchKernelGGL(thj_k_inflate_lanes, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len);
     else { const int64_t grid = nb < 4096 ? nb : 4096; hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len); }
 }
