@@ -367,9 +367,22 @@ int thj_span_run_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* 
 int thj_span_finish(thj_ctx* ctx, int64_t* n_alns);
 /* Compact ordered host copy of the n_alns records. */
 int thj_span_download(thj_ctx* ctx, thj_aln* out);
+/* A record as the stitch kernels leave it in HBM: the same 128 bytes as thj_aln in two 64-byte lines, ordered so that an
+ * ordinary alignment needs only the first.  The lead line: the 24-byte header of thj_aln, cigar ops 0..3, MD characters 0..23.
+ * The tail line: cigar ops 4..15, MD characters 24..39 -- written, and THJ_SLOT_TAIL set in `flags`, only for a record with more
+ * than four cigar ops, an MD string of more than 24 characters, or a fusion alignment; otherwise its bytes are undefined
+ * (left over from an earlier pass) and the fields it would hold are zero.  thj_span_download converts to thj_aln. */
+typedef struct {
+    uint32_t read_idx, ref_id; int32_t left;
+    uint8_t  flags, mismatches, edit_dist, n_cigar;
+    int16_t  AS; uint8_t XM, XO, XG, md_len; uint16_t order;
+    uint32_t cigar_lo[4];  char md_lo[24];     /* lead line ends here (64 bytes) */
+    uint32_t cigar_hi[12]; char md_hi[16];     /* tail line: valid only with THJ_SLOT_TAIL */
+} thj_aln_slot;
+#define THJ_SLOT_TAIL 0x80u
 /* The device-resident layout described above (DEVICE pointers), for consumers that stay on the GPU. */
-int thj_span_device_records(thj_ctx* ctx, const thj_aln** d_slots, const uint8_t** d_counts, int64_t* n_reads,
-                            const thj_aln** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra);
+int thj_span_device_records(thj_ctx* ctx, const thj_aln_slot** d_slots, const uint8_t** d_counts, int64_t* n_reads,
+                            const thj_aln_slot** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra);
 /* counts[0] = reads the last thj_span_run_async sent to the closure kernel thj_k_stitch, counts[1] = to the multihit kernel
  * thj_k_stitch_multihit, counts[2] = on to the general kernel thj_k_stitch_generic; the rest were finished by
  * thj_k_stitch_contig. */

@@ -45,14 +45,17 @@ __device__ __forceinline__ uint32_t jb_insert(const JbTable& t, u64 k, uint32_t 
 }
 
 // the junctions of one record (junctions_from_spliced_hit): calls f(left, right, left_extent, right_extent) per REF_SKIP
+// slot: the record is in the stitch kernels' slot layout (RecSink, thj_span.hip: cigar ops 4.. live in the tail line)
 template <class F>
-__device__ __forceinline__ int jb_rec_juncs(const OutAln& a, F f) {
+__device__ __forceinline__ int jb_rec_juncs(const OutAln& a, bool slot, F f) {
     int n = 0;
     int64_t j = a.left;
+    const uint32_t* w = (const uint32_t*)&a;
+    auto cg = [&](int c) { return w[slot && c >= 4 ? 12 + c : 6 + c]; };
     for (int c = 0; c < a.n_cigar && c < SPAN_MAXC; ++c) {
-        const uint32_t op = a.cigar[c] >> 28, len = a.cigar[c] & 0x0FFFFFFFu;
+        const uint32_t op = cg(c) >> 28, len = cg(c) & 0x0FFFFFFFu;
         if (op == 11) {
-            const uint32_t le = c > 0 ? (a.cigar[c - 1] & 0x0FFFFFFFu) : 0u, re = c + 1 < a.n_cigar ? (a.cigar[c + 1] & 0x0FFFFFFFu) : 0u;
+            const uint32_t le = c > 0 ? (cg(c - 1) & 0x0FFFFFFFu) : 0u, re = c + 1 < a.n_cigar ? (cg(c + 1) & 0x0FFFFFFFu) : 0u;
             f((uint32_t)(j - 1), (uint32_t)(j + len), le, re);
             ++n;
             j += len;
@@ -62,7 +65,7 @@ __device__ __forceinline__ int jb_rec_juncs(const OutAln& a, F f) {
 }
 
 // record i of a pass: slots (first record of every read that has one) then the extra pool; or a plain array
-struct JbRecs { const OutAln* slots; const uint8_t* nrec; int64_t n_slots; const OutAln* extra; int64_t n_extra; };
+struct JbRecs { const OutAln* slots; const uint8_t* nrec; int64_t n_slots; const OutAln* extra; int64_t n_extra; bool slot_layout; };
 __device__ __forceinline__ const OutAln* jb_rec(const JbRecs& r, int64_t i) {
     if (i < r.n_slots) return (!r.nrec || r.nrec[i]) ? &r.slots[i] : nullptr;
     return &r.extra[i - r.n_slots];
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void thj_k_jb_count(JbRecs r, unsigned long lo
     unsigned int mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.n_slots + r.n_extra; i += (int64_t)gridDim.x * blockDim.x) {
         const OutAln* a = jb_rec(r, i);
-        if (a) mine += (unsigned)jb_rec_juncs(*a, [](uint32_t, uint32_t, uint32_t, uint32_t) {});
+        if (a) mine += (unsigned)jb_rec_juncs(*a, r.slot_layout, [](uint32_t, uint32_t, uint32_t, uint32_t) {});
     }
     if (mine) atomicAdd(&s_n, mine);
     __syncthreads();
@@ -90,7 +93,7 @@ __global__ __launch_bounds__(256) void thj_k_jb_add(Genome g, JbRecs r, JbTable 
     for (int64_t it = 0; it < n_iter; ++it) {
         const int64_t i = it * (int64_t)gridDim.x * blockDim.x + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const OutAln* a = i < total ? jb_rec(r, i) : nullptr;
-        unsigned int nj = a ? (unsigned)jb_rec_juncs(*a, [](uint32_t, uint32_t, uint32_t, uint32_t) {}) : 0u;
+        unsigned int nj = a ? (unsigned)jb_rec_juncs(*a, r.slot_layout, [](uint32_t, uint32_t, uint32_t, uint32_t) {}) : 0u;
         // one reservation per wave: inclusive scan of nj over the lanes, the last lane adds the total
         unsigned int incl = nj;
         for (int d = 1; d < 64; d <<= 1) { const unsigned int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void thj_k_jb_add(Genome g, JbRecs r, JbTable 
         const bool anti = (a->flags & 4u) != 0;             // THJ_HIT_ANTISENSE_SPLICE
         uint8_t idx = 0;
         const uint8_t n8 = (uint8_t)nj;
-        jb_rec_juncs(*a, [&](uint32_t left, uint32_t right, uint32_t le, uint32_t re) {
+        jb_rec_juncs(*a, r.slot_layout, [&](uint32_t left, uint32_t right, uint32_t le, uint32_t re) {
             const uint32_t slot = jb_insert(t, junc_key(g, a->ref_id, left, right, anti), left);
             if (slot != 0xFFFFFFFFu) {
                 atomicAdd(&t.cnt1[slot], 1u);
@@ -284,7 +287,7 @@ static int jb_add(thj_ctx* c, const JbRecs& r) {
 extern "C" int thj_juncbed_add_span_async(thj_ctx* c) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    JbRecs r{(const OutAln*)c->d_aln_pool, c->d_nrec, c->span_reads, (const OutAln*)c->d_aln_sorted, c->n_ovf};
+    JbRecs r{(const OutAln*)c->d_aln_pool, c->d_nrec, c->span_reads, (const OutAln*)c->d_aln_sorted, c->n_ovf, true};
     return jb_add(c, r);
 }
 
@@ -301,7 +304,7 @@ extern "C" int thj_juncbed_add_records(thj_ctx* c, const thj_aln* recs, int64_t 
         HIPCHK(hipMemcpyAsync(tmp, recs, (size_t)n * sizeof(thj_aln), hipMemcpyHostToDevice, c->stream));
         d = (const thj_aln*)tmp;
     }
-    JbRecs r{(const OutAln*)d, nullptr, n, nullptr, 0};
+    JbRecs r{(const OutAln*)d, nullptr, n, nullptr, 0, false};
     int rc = jb_add(c, r);
     if (tmp) { hipStreamSynchronize(c->stream); hipFree(tmp); }
     return rc;

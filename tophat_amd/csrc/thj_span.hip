@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <cstddef>
 #include <vector>
 
 #include "../../include/thj.h"
@@ -24,7 +25,7 @@ using namespace thj;
 
 
 static_assert(sizeof(thj_span_hit) == 32 && sizeof(SpanHit) == 32, "span hit layout");
-static_assert(sizeof(thj_aln) == 128 && sizeof(OutAln) == 128, "aln layout");
+static_assert(sizeof(thj_aln) == 128 && sizeof(OutAln) == 128 && sizeof(thj_aln_slot) == 128 && offsetof(thj_aln_slot, cigar_hi) == 64, "aln layout");
 
 struct DevSpanBatch {
     int32_t n_reads, nseg, W, qual_stride;
@@ -44,6 +45,26 @@ static_assert(sizeof(DevSpanBatch) == sizeof(thj_span_batch), "span batch layout
 // read's first record, a per-read record count, and a small overflow pool for the 2nd.. records of multihit reads.
 // Walking the slots in order IS the order of the reference's BAM (read order, BowtieHit::operator< inside a read),
 // so no sort or gather of the records is needed.
+//
+// A slot is two 64-byte lines (thj_aln_slot, include/thj.h).  The lead line holds everything an ordinary alignment has:
+// the 24-byte header, cigar ops 0..3, MD characters 0..23.  The tail line (cigar ops 4..15, MD characters 24..39) is
+// written -- and THJ_SLOT_TAIL set in the lead line's flags -- only by a record that needs it: more than four cigar
+// ops, an MD string of more than 24 characters, or a fusion alignment (second contig in the last cigar slot).  A plain
+// `100M` / `60M2000N40M` record therefore costs one 64-byte line of HBM write traffic, not two; the tail line of such a
+// slot is never touched and holds whatever an earlier pass left there.  thj_span_download hands out API-layout thj_aln.
+static constexpr uint32_t SLOT_TAIL = 0x80u;     // == THJ_SLOT_TAIL, in the flags byte (word 3, bits 0..7)
+__device__ __forceinline__ bool slot_needs_tail(const uint32_t* w) {     // w: the 32 words of an API-layout record
+    const uint32_t n_cigar = w[3] >> 24, md_len = (w[5] >> 8) & 0xFFu;
+    return n_cigar > 4u || (md_len > 24u && md_len != 255u) || w[21] != 0u;
+}
+// slot word k of an API-layout record (compile-time k after unrolling)
+__device__ __forceinline__ uint32_t slot_word(const uint32_t* w, int k, bool tail) {
+    if (k == 3) return w[3] | (tail ? SLOT_TAIL : 0u);
+    if (k < 10) return w[k];                 // header, cigar 0..3
+    if (k < 16) return w[k + 12];            // md bytes 0..23  (API words 22..27)
+    if (k < 28) return w[k - 6];             // cigar 4..15     (API words 10..21)
+    return w[k];                             // md bytes 24..39 (API words 28..31)
+}
 struct RecSink {
     OutAln* slots; uint8_t* nrec; uint32_t base;
     OutAln* ovf; u64* ovf_key; unsigned long long* ovf_count; unsigned long long ovf_cap;
@@ -62,8 +83,13 @@ struct RecSink {
             dst = (uint4*)(ovf + pos);
         }
         if (THJ_EXPF(32768)) { if (w[7] == 0x12345u) dst[0] = make_uint4(w[0], w[9], w[18], w[31]); return; }
+        const bool tail = slot_needs_tail(w);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        for (int k = 0; k < 4; ++k) dst[k] = make_uint4(slot_word(w, 4 * k, tail), slot_word(w, 4 * k + 1, tail), slot_word(w, 4 * k + 2, tail), slot_word(w, 4 * k + 3, tail));
+        if (tail) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) dst[k] = make_uint4(slot_word(w, 4 * k, true), slot_word(w, 4 * k + 1, true), slot_word(w, 4 * k + 2, true), slot_word(w, 4 * k + 3, true));
+        }
     }
     __device__ __forceinline__ void done(uint32_t r) { nrec[(size_t)base + r] = (uint8_t)(emitted > 255 ? 255 : emitted); acc += emitted; emitted = 0; }   // the count saturates: consumers test it for zero
 };
@@ -98,11 +124,16 @@ __host__ __device__ constexpr int lean_classes(int MS) { return MS <= 4 ? SPAN_L
 // assembled in LDS (chunk-rotated so the 16-byte writes of a wave spread over all banks) and leave as full
 // 128-byte lines, eight lanes per record.
 struct StageSink {
-    uint4* stage; int rec; int emitted;
+    uint4* stage; int rec; int emitted;      // emitted: 0 none, 1 lead line only, 2 lead + tail
     __device__ __forceinline__ void emit_words(const uint32_t* w) {
-        emitted = 1;
+        const bool tail = slot_needs_tail(w);
+        emitted = tail ? 2 : 1;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) stage[rec * 8 + ((k + rec) & 7)] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+        for (int k = 0; k < 4; ++k) stage[rec * 8 + ((k + rec) & 7)] = make_uint4(slot_word(w, 4 * k, tail), slot_word(w, 4 * k + 1, tail), slot_word(w, 4 * k + 2, tail), slot_word(w, 4 * k + 3, tail));
+        if (tail) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) stage[rec * 8 + ((k + rec) & 7)] = make_uint4(slot_word(w, 4 * k, true), slot_word(w, 4 * k + 1, true), slot_word(w, 4 * k + 2, true), slot_word(w, 4 * k + 3, true));
+        }
     }
 };
 
@@ -146,18 +177,25 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
             }
             else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = r;
             else {
-                sink.nrec[(size_t)sink.base + r] = (uint8_t)ss.emitted;
-                my_rec += ss.emitted;
+                sink.nrec[(size_t)sink.base + r] = (uint8_t)(ss.emitted != 0);
+                my_rec += ss.emitted != 0;
                 if (st) atomicAdd(&sink.status[st], 1u);
             }
         }
         has_rec[tid] = (uint8_t)ss.emitted;
         __syncthreads();
         uint4* out = (uint4*)(sink.slots + (size_t)sink.base + r0);
+        // lead lines: four lanes per record, 64 contiguous bytes each
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int j = tid + 256 * m, i = j >> 3;
-            if (has_rec[i] && !THJ_EXPF(1)) out[i * 8 + (((j & 7) - i) & 7)] = stage[j];
+        for (int m = 0; m < 4; ++m) {
+            const int j = tid + 256 * m, i = j >> 2, ch = j & 3;
+            if (has_rec[i] && !THJ_EXPF(1)) out[i * 8 + ch] = stage[i * 8 + ((ch + i) & 7)];
+        }
+        // tail lines of the few records that have one
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int j = tid + 256 * m, i = j >> 2, ch = 4 + (j & 3);
+            if (has_rec[i] == 2 && !THJ_EXPF(1)) out[i * 8 + ch] = stage[i * 8 + ((ch + i) & 7)];
         }
         __syncthreads();
     }
@@ -730,14 +768,27 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
     return THJ_OK;
 }
 
-extern "C" int thj_span_device_records(thj_ctx* c, const thj_aln** d_slots, const uint8_t** d_counts, int64_t* n_reads,
-                                       const thj_aln** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra) {
+extern "C" int thj_span_device_records(thj_ctx* c, const thj_aln_slot** d_slots, const uint8_t** d_counts, int64_t* n_reads,
+                                       const thj_aln_slot** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra) {
     if (!c || !d_slots || !d_counts || !n_reads) { thj_set_error("thj_span_device_records: bad argument"); return THJ_EINVAL; }
-    *d_slots = (const thj_aln*)c->d_aln_pool; *d_counts = c->d_nrec; *n_reads = c->span_reads;
-    if (d_extra) *d_extra = (const thj_aln*)c->d_aln_sorted;
+    *d_slots = (const thj_aln_slot*)c->d_aln_pool; *d_counts = c->d_nrec; *n_reads = c->span_reads;
+    if (d_extra) *d_extra = (const thj_aln_slot*)c->d_aln_sorted;
     if (d_extra_keys) *d_extra_keys = (const uint64_t*)c->d_aln_keys;
     if (n_extra) *n_extra = c->n_ovf;
     return THJ_OK;
+}
+
+// one slot (device layout, see RecSink) -> the API record; fields the record does not use read as zero
+static inline void slot_to_aln(const thj_aln& slot, thj_aln& out) {
+    uint32_t s[32], w[32];
+    memcpy(s, &slot, 128);
+    const bool tail = (s[3] & SLOT_TAIL) != 0;
+    for (int k = 0; k < 10; ++k) w[k] = s[k];
+    w[3] &= ~SLOT_TAIL;
+    for (int k = 10; k < 16; ++k) w[k + 12] = s[k];
+    for (int k = 16; k < 28; ++k) w[k - 6] = tail ? s[k] : 0u;
+    for (int k = 28; k < 32; ++k) w[k] = tail ? s[k] : 0u;
+    memcpy(&out, w, 128);
 }
 
 extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
@@ -768,10 +819,10 @@ extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
         for (int64_t k = 0; k < n; ++k) {
             if (!cnt[(size_t)(r0 + k)]) continue;
             if (w >= c->n_alns) { thj_set_error("record count mismatch"); return THJ_ESTATE; }
-            out[w++] = buf[(size_t)k];
+            slot_to_aln(buf[(size_t)k], out[w++]);
             while (e < eord.size() && (ekey[eord[e]] >> 16) == (uint64_t)(r0 + k)) {
                 if (w >= c->n_alns) { thj_set_error("record count mismatch"); return THJ_ESTATE; }
-                out[w++] = extra[eord[e++]];
+                slot_to_aln(extra[eord[e++]], out[w++]);
             }
         }
     }
