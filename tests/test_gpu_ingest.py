@@ -52,6 +52,12 @@ def test_handmade_streams():
     # a skewed alphabet: Huffman codes well beyond the 10-bit direct table
     p = np.array([2.0 ** -k for k in range(1, 41)]); p /= p.sum()
     datas.append(bytes(rng.choice(40, size=60000, p=p).astype(np.uint8)))
+    # short periods (match distances 1..9, every length up to the maximum): the decoder copies these as wider periods
+    per = []
+    while sum(map(len, per)) < 65536:
+        pl, rl = int(rng.integers(1, 10)), int(rng.integers(3, 400))
+        per.append((bytes(rng.integers(0, 256, size=pl, dtype=np.uint8)) * (rl // pl + 1))[:rl])
+    datas.append(b"".join(per)[:65536])
     payloads, want = [], []
     for d in datas:
         for level in (0, 1, 6, 9):

@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tophat_amd import host  # noqa: E402
 
+if os.environ.get("THJ_LIB"):                         # developer A/B: another build of the library
+    host.LIB_PATH = os.environ["THJ_LIB"]
+
 path = sys.argv[1]
 rep = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 data = open(path, "rb").read()

@@ -23,14 +23,25 @@
 
 namespace ing {
 
-#ifndef THJ_INFLATE_WIN
-#define THJ_INFLATE_WIN 8192
+// Sizing (round 2, measured on 8 M pairs' maps, tools/inflate_ab.sh): the decoder is one lane of a wave, so the rate of the
+// kernel is the number of members in flight, and that is set by LDS and registers per workgroup.  32 KiB window: 4 per CU,
+// 6.8 GB/s of inflated bytes.  8 KiB: 8 per CU (the kernel then held 176 VGPRs -- the header parser's arrays -- so two waves per
+// SIMD, not the 11 its LDS allowed), 12.5 GB/s.  With the header arrays in LDS and build_table out of line the decode loop
+// needs 78 VGPRs (6 waves per SIMD), and: 4 KiB window + 2 KiB input ring 16 per CU 22 GB/s; 2 KiB + 2 KiB 20 per CU 21.8;
+// 2 KiB + 1 KiB 23 per CU 23.4; 1 KiB + 1 KiB 24 per CU 24.3.  A match that reaches behind the LDS window reads the member's own
+// output in HBM (flushed by then, see out_limit) -- half of all matches with a 2 KiB window on level-1 BAM, and still the better
+// trade.
+#ifndef THJ_INFLATE_INRING
+#define THJ_INFLATE_INRING 1024
 #endif
-// the LDS part of the LZ77 window: matches that reach further back (rare in BAM: neighbouring records resemble each other) read
-// the block's own output in HBM, which the helper lanes have flushed by then.  8 KiB instead of the full 32 KiB = 14 KB of LDS per
-// workgroup = 11 blocks in flight per CU instead of 4
+#ifndef THJ_INFLATE_WAVES
+#define THJ_INFLATE_WAVES 6     /* waves per SIMD the register budget is set for */
+#endif
+#ifndef THJ_INFLATE_WIN
+#define THJ_INFLATE_WIN 2048
+#endif
 static constexpr int WIN = THJ_INFLATE_WIN, WIN_MASK = WIN - 1, HALF = WIN / 2;
-static constexpr int INRING = 2048, IN_MASK = INRING - 1;
+static constexpr int INRING = THJ_INFLATE_INRING, IN_MASK = INRING - 1;
 static constexpr int LIT_BITS = 10, DIST_BITS = 8;
 
 struct Shared {
@@ -41,6 +52,8 @@ struct Shared {
     uint16_t lit_sym[288], dist_sym[32];
     uint16_t lit_cnt[16], dist_cnt[16];
     uint8_t lens[320];
+    uint8_t cl[20], dl[32];                           // code-length code lengths, distance code lengths (header parsing)
+    uint16_t offs[16];                                // build_table's per-length offsets
     uint16_t lbase[32], dbase[32];                    // length / distance bases and extra-bit counts (RFC 1951, 3.2.5): in LDS, the
     uint8_t lext[32], dext[32];                       // decoder looks one up per match
     // decoder <-> helpers
@@ -61,14 +74,13 @@ __device__ __forceinline__ uint32_t rev_bits(uint32_t v, int n) { return __brev(
 
 // canonical Huffman tables from code lengths: direct lookup for codes <= FAST bits (entry = symbol | length << 12, 0 = longer
 // code), count / symbol arrays for the rest (decoded bit by bit like puff.c)
-__device__ bool build_table(const uint8_t* lens, int n, uint16_t* fast, int fast_bits, uint16_t* sym, uint16_t* cnt) {
+__device__ __noinline__ bool build_table(const uint8_t* lens, int n, uint16_t* fast, int fast_bits, uint16_t* sym, uint16_t* cnt, uint16_t* offs) {
     for (int i = 0; i < 16; ++i) cnt[i] = 0;
     for (int i = 0; i < n; ++i) cnt[lens[i]]++;
     for (int i = 0; i < (1 << fast_bits); ++i) fast[i] = 0;
     if (cnt[0] == n) return true;                    // no codes at all (e.g. a block without distances)
     int left = 1;
     for (int l = 1; l < 16; ++l) { left <<= 1; left -= cnt[l]; if (left < 0) return false; }
-    uint16_t offs[16];
     offs[1] = 0;
     for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + cnt[l];
     for (int i = 0; i < n; ++i) if (lens[i]) sym[offs[lens[i]]++] = (uint16_t)i;
@@ -116,7 +128,7 @@ enum { ST_HEADER = 0, ST_STORED, ST_CODES, ST_DONE };
 
 
 // out: 65536 bytes per block (block b at b << 16); out_len[b] = inflated bytes (0xFFFFFFFF on a corrupt stream)
-__global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
+__global__ __launch_bounds__(64, THJ_INFLATE_WAVES) void thj_k_inflate(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ out_len) {
     using namespace ing;
     __shared__ Shared s;
@@ -198,18 +210,18 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                             for (int i = 144; i < 256; ++i) s.lens[i] = 9;
                             for (int i = 256; i < 280; ++i) s.lens[i] = 7;
                             for (int i = 280; i < 288; ++i) s.lens[i] = 8;
-                            build_table(s.lens, 288, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt);
+                            build_table(s.lens, 288, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt, s.offs);
                             for (int i = 0; i < 30; ++i) s.lens[i] = 5;
-                            build_table(s.lens, 30, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt);
+                            build_table(s.lens, 30, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt, s.offs);
                             state = ST_CODES;
                         } else if (type == 2) {
                             const int hlit = (int)take(b, 5) + 257, hdist = (int)take(b, 5) + 1, hclen = (int)take(b, 4) + 4;
                             if (hlit > 286 || hdist > 30) { err = true; break; }
-                            uint8_t cl[19];
+                            uint8_t* cl = s.cl;
                             for (int i = 0; i < 19; ++i) cl[i] = 0;
                             for (int i = 0; i < hclen; ++i) { refill(b, s, staged0); cl[CLORD[i]] = (uint8_t)take(b, 3); }
                             // the code-length code uses the distance table's storage (7-bit direct lookup fits its 8 bits)
-                            if (!build_table(cl, 19, s.dist_fast, 7, s.dist_sym, s.dist_cnt)) { err = true; break; }
+                            if (!build_table(cl, 19, s.dist_fast, 7, s.dist_sym, s.dist_cnt, s.offs)) { err = true; break; }
                             int i = 0;
                             while (i < hlit + hdist) {
                                 refill(b, s, staged0);
@@ -228,10 +240,10 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                             if (err) break;
                             if (s.lens[256] == 0) { err = true; break; }
                             // distance lengths first (they sit behind the literal lengths and the literal table build does not touch them)
-                            uint8_t dl[32];
+                            uint8_t* dl = s.dl;
                             for (int k = 0; k < hdist; ++k) dl[k] = s.lens[hlit + k];
-                            if (!build_table(s.lens, hlit, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt)) { err = true; break; }
-                            if (!build_table(dl, hdist, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt)) { err = true; break; }
+                            if (!build_table(s.lens, hlit, s.lit_fast, LIT_BITS, s.lit_sym, s.lit_cnt, s.offs)) { err = true; break; }
+                            if (!build_table(dl, hdist, s.dist_fast, DIST_BITS, s.dist_sym, s.dist_cnt, s.offs)) { err = true; break; }
                             state = ST_CODES;
                         } else { err = true; break; }
                     } else if (state == ST_STORED) {
@@ -276,16 +288,35 @@ __global__ __launch_bounds__(64) void thj_k_inflate(const uint8_t* __restrict__ 
                                     for (int q = 0; q < 8; ++q) s.win[(outp + (uint32_t)(k + q)) & WIN_MASK] = t[q];
                                 }
                                 for (; k < len; ++k) s.win[(outp + (uint32_t)k) & WIN_MASK] = gsrc[k];
-                            } else
-                            if (dist >= 8)                                        // source and destination of a group of 8 cannot overlap: read the
-                                for (; k + 8 <= len; k += 8) {                    // group first (8 LDS reads in flight at once), then write it
-                                    const uint32_t sp = outp + (uint32_t)k - dist, dp = outp + (uint32_t)k;
-                                    const uint8_t t0 = s.win[(sp + 0) & WIN_MASK], t1 = s.win[(sp + 1) & WIN_MASK], t2 = s.win[(sp + 2) & WIN_MASK], t3 = s.win[(sp + 3) & WIN_MASK],
-                                                  t4 = s.win[(sp + 4) & WIN_MASK], t5 = s.win[(sp + 5) & WIN_MASK], t6 = s.win[(sp + 6) & WIN_MASK], t7 = s.win[(sp + 7) & WIN_MASK];
-                                    s.win[(dp + 0) & WIN_MASK] = t0; s.win[(dp + 1) & WIN_MASK] = t1; s.win[(dp + 2) & WIN_MASK] = t2; s.win[(dp + 3) & WIN_MASK] = t3;
-                                    s.win[(dp + 4) & WIN_MASK] = t4; s.win[(dp + 5) & WIN_MASK] = t5; s.win[(dp + 6) & WIN_MASK] = t6; s.win[(dp + 7) & WIN_MASK] = t7;
+                            } else {
+                                // Copies go eight bytes at a time through unaligned 64-bit LDS accesses (one ds_read_b64 + one ds_write_b64
+                                // per group instead of sixteen byte accesses with their address arithmetic: the decoder lane is bound by the
+                                // instructions it issues).  A group may run up to seven bytes past the match: those ring positions are
+                                // ahead of the output pointer, rewritten by whatever comes next, and never flushed (out_limit keeps 300
+                                // bytes of slack).  A distance below 8 is a period: the first m * dist >= 8 bytes go byte by byte, the rest is
+                                // the same copy at distance m * dist.
+                                uint32_t d8 = dist;
+                                if (dist < 8u) {
+                                    const uint32_t m = (8u + dist - 1u) / dist;
+                                    d8 = m * dist;
+                                    const int head = len < (int)d8 ? len : (int)d8;
+                                    for (; k < head; ++k) s.win[(outp + (uint32_t)k) & WIN_MASK] = s.win[(outp + (uint32_t)k - dist) & WIN_MASK];
                                 }
-                            for (; k < len; ++k) s.win[(outp + k) & WIN_MASK] = s.win[(outp + k - dist) & WIN_MASK];
+                                for (; k < len; k += 8) {
+                                    const uint32_t sp = (outp + (uint32_t)k - d8) & WIN_MASK, dp = (outp + (uint32_t)k) & WIN_MASK;
+                                    if (sp <= (uint32_t)WIN - 8u && dp <= (uint32_t)WIN - 8u) {
+                                        uint64_t t;
+                                        __builtin_memcpy(&t, &s.win[sp], 8);
+                                        __builtin_memcpy(&s.win[dp], &t, 8);
+                                    } else {                                       // the group wraps round the ring
+                                        uint8_t t[8];
+#pragma unroll
+                                        for (int q = 0; q < 8; ++q) t[q] = s.win[(sp + (uint32_t)q) & WIN_MASK];
+#pragma unroll
+                                        for (int q = 0; q < 8; ++q) s.win[(dp + (uint32_t)q) & WIN_MASK] = t[q];
+                                    }
+                                }
+                            }
                             outp += (uint32_t)len;
                         }
                     } else { fin = true; break; }
@@ -537,7 +568,8 @@ static void launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_blo
     static const int lanes_min = getenv("THJ_INFLATE_LANES_MIN") ? atoi(getenv("THJ_INFLATE_LANES_MIN")) : 0;
     const bool lanes = force ? force[0] == 'l' : (lanes_min > 0 && nb >= lanes_min);
     if (lanes) hipLaunchKernelGGL(thj_k_inflate_lanes, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len);
-    else { const int64_t grid = nb < 4096 ? nb : 4096; hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len); }
+    else { const int64_t grid = nb < (1 << 20) ? nb : (1 << 20);      // a workgroup per member: the dispatcher balances the tail
+           hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len); }
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI

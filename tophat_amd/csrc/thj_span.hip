@@ -791,12 +791,91 @@ static inline void slot_to_aln(const thj_aln& slot, thj_aln& out) {
     memcpy(&out, w, 128);
 }
 
+// Compaction on the device: the position of a read's first record in the compact, ordered array is the exclusive prefix sum of the
+// per-read record counts; its 2nd.. records (the extra pool, keyed slot << 16 | rank) follow at + rank.  One thread per record
+// converts the slot layout to thj_aln on the way.  (The per-read count saturates at 255: a pass with such a read does not add up
+// to n_alns and takes the host path below.)
+struct NrecToU32 { __host__ __device__ uint32_t operator()(uint8_t v) const { return (uint32_t)v; } };
+__device__ __forceinline__ void slot_to_aln_dev(const uint4* src, uint4* dst) {
+    uint32_t s[32], w[32];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const uint4 v = src[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+    const bool tail = (s[3] & SLOT_TAIL) != 0;
+    if (tail) {
+#pragma unroll
+        for (int k = 4; k < 8; ++k) { const uint4 v = src[k]; s[4 * k] = v.x; s[4 * k + 1] = v.y; s[4 * k + 2] = v.z; s[4 * k + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int k = 16; k < 32; ++k) s[k] = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) w[k] = s[k];
+    w[3] &= ~SLOT_TAIL;
+#pragma unroll
+    for (int k = 10; k < 16; ++k) w[k + 12] = s[k];
+#pragma unroll
+    for (int k = 16; k < 28; ++k) w[k - 6] = s[k];
+#pragma unroll
+    for (int k = 28; k < 32; ++k) w[k] = s[k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+}
+__global__ __launch_bounds__(256) void thj_k_compact_records(const OutAln* slots, const uint8_t* nrec, const uint32_t* off, int64_t n_slots,
+                                                             const OutAln* extra, const u64* extra_key, int64_t n_extra, OutAln* out, int64_t n_out,
+                                                             unsigned int* bad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots + n_extra; i += (int64_t)gridDim.x * blockDim.x) {
+        const OutAln* src; int64_t at;
+        if (i < n_slots) {
+            if (i == n_slots - 1 && (int64_t)off[i] + nrec[i] != n_out) atomicExch(bad, 1u);     // the counts do not add up (a saturated count)
+            if (!nrec[i]) continue;
+            src = slots + i; at = off[i];
+        } else {
+            const u64 k = extra_key[i - n_slots];
+            src = extra + (i - n_slots); at = (int64_t)off[k >> 16] + (int64_t)(k & 0xFFFFu);
+        }
+        if (at >= n_out) { atomicExch(bad, 1u); continue; }
+        slot_to_aln_dev((const uint4*)src, (uint4*)(out + at));
+    }
+}
+
+static int span_download_host(thj_ctx* c, thj_aln* out);
+
 extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
-    // compact, ordered host copy: walk the slots, splice in the (rank-ordered) extra records of multihit reads
+    // compact, ordered host copy: compacted on the device, one copy down
     if (!c || (c->n_alns > 0 && !out)) { thj_set_error("thj_span_download: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->n_alns == 0) return THJ_OK;
+    const int64_t nr = c->span_reads, n = c->n_alns;
+    static const bool host_path = getenv("THJ_DOWNLOAD_ON_HOST") != nullptr;
+    if (host_path || n >= (1ll << 32) || nr < 1) return span_download_host(c, out);
+    void *d_off = nullptr, *d_out = nullptr, *d_tmp = nullptr;
+    hipcub::TransformInputIterator<uint32_t, NrecToU32, const uint8_t*> in(c->d_nrec, NrecToU32());
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, (uint32_t*)nullptr, (int)nr, c->stream));
+    int rc = thj_dev_alloc(c, &d_off, (size_t)nr * 4 + 16);
+    if (!rc) rc = thj_dev_alloc(c, &d_out, (size_t)n * 128);
+    if (!rc) rc = thj_dev_alloc(c, &d_tmp, tmp_bytes + 16);
+    if (rc) { if (d_off) thj_dev_release(c, d_off); if (d_out) thj_dev_release(c, d_out); if (d_tmp) thj_dev_release(c, d_tmp); return span_download_host(c, out); }
+    unsigned int* d_bad = (unsigned int*)((char*)d_off + (size_t)nr * 4);
+    HIPCHK(hipMemsetAsync(d_bad, 0, 4, c->stream));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, in, (uint32_t*)d_off, (int)nr, c->stream));
+    const int64_t items = nr + c->n_ovf;
+    int64_t grid = (items + 255) / 256; if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(thj_k_compact_records, dim3((unsigned)grid), dim3(256), 0, c->stream, (const OutAln*)c->d_aln_pool, (const uint8_t*)c->d_nrec, (const uint32_t*)d_off, nr,
+                       (const OutAln*)c->d_aln_sorted, (const u64*)c->d_aln_keys, c->n_ovf, (OutAln*)d_out, n, d_bad);
+    HIPCHK(hipGetLastError());
+    unsigned int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!bad) HIPCHK(hipMemcpy(out, d_out, (size_t)n * 128, hipMemcpyDeviceToHost));
+    thj_dev_release(c, d_off); thj_dev_release(c, d_out); thj_dev_release(c, d_tmp);
+    if (bad) return span_download_host(c, out);
+    return THJ_OK;
+}
+
+static int span_download_host(thj_ctx* c, thj_aln* out) {
+    // the same on the host: walk the slots, splice in the (rank-ordered) extra records of multihit reads
     const int64_t nr = c->span_reads;
     std::vector<uint8_t> cnt((size_t)nr);
     HIPCHK(hipMemcpy(cnt.data(), c->d_nrec, (size_t)nr, hipMemcpyDeviceToHost));
