@@ -10,7 +10,11 @@ int main(int argc, char** argv) {
     if (argc < 2) return 2;
     std::string mode = argv[1];
     if (mode == "write" && argc >= 5) {
-        // hostio_check write <out.bam> <n_records> <batch>
+        // hostio_check write <out.bam> <n_records> <batch> [planned]
+        // planned: the batches go through BamWriter::plan / compress / commit (all planned first, deflated in reverse order, committed in order)
+        const bool fail = argc >= 6 && std::string(argv[5]) == "planned-fail";      // as planned, and a batch in the middle reports a member that did not fit
+        const bool planned = fail || (argc >= 6 && std::string(argv[5]) == "planned");
+        std::vector<BamWriter::Prepared> prepared; std::vector<uint8_t> carry;
         const size_t n = (size_t)atoll(argv[3]), batch = (size_t)atoll(argv[4]);
         RefTable rt;
         rt.header_text = "@HD\tVN:1.0\tSO:unsorted\n@SQ\tSN:chr1\tLN:5000000\n@SQ\tSN:chr2\tLN:700000\n";
@@ -23,6 +27,20 @@ int main(int argc, char** argv) {
         std::vector<Rec> recs;
         uint64_t s = 88172645463325252ull;
         auto flush = [&]() {
+            if (planned) {
+                BamWriter::Encoded e;
+                for (const Rec& r : recs) {
+                    std::vector<std::string> aux = {"AS:i:" + std::to_string(r.as), "XM:i:1", "MD:Z:" + std::to_string(r.seq.size()), "NM:i:300"};
+                    if (r.cig.size() > 1) aux.push_back("XS:A:+");
+                    const size_t before = e.bytes.size();
+                    bw.encode(e.bytes, r.name, r.flag, rt.names[(size_t)r.ref], r.pos, r.cig.data(), (int)r.cig.size(), r.seq, r.qual, aux);
+                    e.size.push_back((uint32_t)(e.bytes.size() - before)); e.rid.push_back(atol(r.name.c_str()));
+                }
+                prepared.emplace_back();
+                BamWriter::plan(carry, std::move(e), prepared.back());
+                recs.clear();
+                return;
+            }
             bw.write_records(recs.size(), [&](size_t i, std::vector<uint8_t>& d) -> long {
                 const Rec& r = recs[i];
                 std::vector<std::string> aux = {"AS:i:" + std::to_string(r.as), "XM:i:1", "MD:Z:" + std::to_string(r.seq.size()), "NM:i:300"};
@@ -49,7 +67,35 @@ int main(int argc, char** argv) {
             if (recs.size() >= batch) flush();
         }
         flush();
+        for (size_t k = prepared.size(); k-- > 0;) BamWriter::compress(prepared[k]);
+        if (fail && prepared.size() > 2) prepared[prepared.size() / 2].ok = false;
+        for (auto& pr : prepared) bw.commit(pr);
         bw.close();
+        return 0;
+    }
+    if (mode == "fdz" && argc >= 4) {
+        // hostio_check fdz <in> <out> [bench]: <in> = (u32 length, bytes)*; <out> = (u32 compressed length | 0xFFFFFFFF = declined, bytes)*
+        // from thj_fastdeflate.h with the room a BGZF member has; bench: MB/s over ten passes on stderr
+        FILE* fi = fopen(argv[2], "rb"); FILE* fo = fopen(argv[3], "wb");
+        if (!fi || !fo) return 3;
+        std::vector<std::vector<uint8_t>> ins;
+        for (;;) { uint32_t n; if (fread(&n, 4, 1, fi) != 1) break; std::vector<uint8_t> b(n); if (n && fread(b.data(), 1, n, fi) != n) return 4; ins.push_back(std::move(b)); }
+        std::vector<uint8_t> out(70000);
+        size_t tin = 0, tout = 0;
+        for (auto& b : ins) {
+            size_t cl = 0;
+            const bool ok = fdz::deflate_fast(b.data(), b.size(), out.data(), 65536 - 18 - 8, &cl);
+            uint32_t w = ok ? (uint32_t)cl : 0xFFFFFFFFu;
+            fwrite(&w, 4, 1, fo);
+            if (ok) { fwrite(out.data(), 1, cl, fo); tin += b.size(); tout += cl; }
+        }
+        fclose(fi); fclose(fo);
+        if (argc >= 5) {
+            auto t0 = std::chrono::steady_clock::now();
+            for (int rep = 0; rep < 10; ++rep) for (auto& b : ins) { size_t cl = 0; fdz::deflate_fast(b.data(), b.size(), out.data(), 65536 - 18 - 8, &cl); }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            fprintf(stderr, "fdz: %.1f MB/s, ratio %.3f\n", 10.0 * (double)tin / dt / 1e6, tin ? (double)tout / (double)tin : 0.0);
+        }
         return 0;
     }
     if (mode == "hits" && argc >= 3) {

@@ -44,10 +44,16 @@ def test_bam_writer_is_thread_and_batch_invariant(exe, tmp_path):
     subprocess.check_call([exe, "write", a, str(n), str(n)], env=dict(os.environ, THJ_HOST_THREADS="1"))
     subprocess.check_call([exe, "write", b, str(n), "777"], env=dict(os.environ, THJ_HOST_THREADS="7"))
     subprocess.check_call([exe, "write", c, str(n), "12345"], env=dict(os.environ, THJ_HOST_THREADS="3"))
+    # the shard workers' path: batches planned in order, deflated independently (here in reverse order), committed in order
+    d, e = str(tmp_path / "d.bam"), str(tmp_path / "e.bam")
+    subprocess.check_call([exe, "write", d, str(n), "777", "planned"])
+    subprocess.check_call([exe, "write", e, str(n), "5", "planned-fail"])      # ... and the writer falls back to write_encoded half way
     ref = open(a, "rb").read()
     assert open(b, "rb").read() == ref and open(c, "rb").read() == ref
+    assert open(d, "rb").read() == ref and open(e, "rb").read() == ref
     idx = open(a + ".index").read()
     assert open(b + ".index").read() == idx and open(c + ".index").read() == idx
+    assert open(d + ".index").read() == idx and open(e + ".index").read() == idx
     # a well-formed BAM: every record comes back, in order
     names, recs = read_bam(a)
     recs = list(recs)
@@ -144,3 +150,46 @@ def test_fasta_loader_awkward_input(exe, tmp_path):
     for threads in ("1", "5"):
         out = subprocess.check_output([exe, "fasta", fa], env=dict(os.environ, THJ_HOST_THREADS=threads)).decode().strip().split("\n")
         assert out == exp
+
+
+def test_fast_deflate_members_inflate_with_zlib(exe, tmp_path):
+    """thj_fastdeflate.h (the BAM writer's default compressor): every stream it makes is inflated by zlib to the input; inputs it
+    declines (it must never write past a member's room) are left to zlib by the writer."""
+    import zlib
+    import numpy as np
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(40000):                       # BAM-record-like bytes: counters, short names, 4-bit bases, flat and noisy qualities
+        ln = int(rng.integers(50, 151))
+        recs.append(struct.pack("<iiIIiiii", 100 + ln, int(rng.integers(0, 3)), int(rng.integers(0, 1 << 26)), 0x12340000 | (i & 0xFF), 1, ln, -1, -1)
+                    + str(1 + i // 2).encode() + b"\0" + bytes(rng.integers(0, 256, size=(ln + 1) // 2, dtype=np.uint8))
+                    + (bytes([40]) * ln if i & 1 else bytes(rng.integers(2, 42, size=ln, dtype=np.uint8))) + b"NMC\x01MDZ" + str(ln).encode() + b"\0")
+    raw = b"".join(recs)
+    ins = [raw[i:i + 65280] for i in range(0, len(raw), 65280)]
+    p = np.array([2.0 ** -k for k in range(1, 41)]); p /= p.sum()
+    ins += [b"A" * 64, b"A" * 65536, bytes(rng.integers(0, 256, size=65536, dtype=np.uint8)), bytes(rng.integers(0, 4, size=65536, dtype=np.uint8)),
+            (b"ACGTTGCA" * 9000)[:65536], bytes(rng.integers(0, 256, size=300, dtype=np.uint8)) * 200,
+            b"".join(bytes([i % 251]) * (i % 37 + 1) for i in range(3000))[:65536], bytes(range(64)), b"ab" * 40, raw[:100], raw[5:70], raw[:7], b"",
+            bytes(rng.choice(40, size=60000, p=p).astype(np.uint8)),                      # a skewed alphabet: codes that need the length limit
+            bytes(rng.choice(256, size=65536, p=np.r_[[0.5], np.full(255, 0.5 / 255)]).astype(np.uint8))]
+    fi, fo = str(tmp_path / "in"), str(tmp_path / "out")
+    with open(fi, "wb") as f:
+        for b in ins:
+            f.write(struct.pack("<I", len(b))); f.write(b)
+    subprocess.check_call([exe, "fdz", fi, fo])
+    o = open(fo, "rb").read()
+    pos = declined = 0
+    tin = tout = 0
+    for k, b in enumerate(ins):
+        cl, = struct.unpack_from("<I", o, pos); pos += 4
+        if cl == 0xFFFFFFFF:
+            declined += 1
+            continue
+        assert cl <= 65536 - 26
+        assert zlib.decompress(o[pos:pos + cl], -15) == b, "stream %d (%d bytes)" % (k, len(b))
+        pos += cl
+        if k < len(ins) - 15:
+            tin += len(b); tout += cl
+    assert pos == len(o)
+    assert declined <= 2                          # only the incompressible 64 KiB blocks
+    assert tout < 0.6 * tin                       # and it does compress records

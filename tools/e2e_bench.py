@@ -59,7 +59,10 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
         if r.returncode != 0:
             raise RuntimeError("long_spanning_reads failed:\n" + r.stderr[-3000:])
         res["long_spanning_reads_%s_s" % sd] = round(dt, 3)
-        res["long_spanning_reads_%s_log_tail" % sd] = r.stderr.strip().splitlines()[-8:]
+        res["long_spanning_reads_%s_log_tail" % sd] = [l for l in r.stderr.strip().splitlines() if not l.startswith("[trace]")][-8:]
+        if env.get("THJ_TRACE"):                     # the per-shard timeline for tools/lsr_trace.py
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", "lsr_%s.trace" % sd), "w").write(r.stderr)
         res["span_%s_bytes" % sd] = os.path.getsize(f("span_%s.bam" % sd))
         tot += dt
     res["both_stages_s"] = round(tot, 3)

@@ -23,6 +23,10 @@ static void print_usage() {
 
 static PhaseTimer g_timer;
 static WorkClock g_work;
+// THJ_TRACE=1: one line per shard event on stderr (seconds since start): where a shard's time goes, for tools/lsr_trace.py
+static const bool g_trace = getenv("THJ_TRACE") != nullptr;
+static const long long g_trace_t0 = WorkClock::now();
+static void trace(size_t shard, const char* what) { if (g_trace) fprintf(stderr, "[trace] %zu %s %.4f\n", shard, what, (double)(WorkClock::now() - g_trace_t0) * 1e-9); }
 
 #ifndef THJ_DEFAULT_CTX_PER_GPU
 #define THJ_DEFAULT_CTX_PER_GPU 2
@@ -289,7 +293,7 @@ static void encode_batch(const BamWriter& bw, const RefTable& rt, const std::vec
 // records of one shard on their way to the writer
 struct OutShard {
     std::mutex mu; std::condition_variable cv;
-    std::deque<BamWriter::Encoded> q;
+    std::deque<BamWriter::Prepared> q;
     bool done = false;
 };
 
@@ -479,7 +483,7 @@ int main(int argc, char** argv) {
     }
     if (parts == 1) shards = plan(pos[1], segs, spliced_segs, getenv("THJ_SHARDS") ? atoi(getenv("THJ_SHARDS")) : 4 * workers);
     const size_t S = shards.size();
-    fprintf(stderr, "\t%d read-id shard%s, %d host workers, %d GPU%s\n", (int)S, S > 1 ? "s" : "", workers, n_gpus, n_gpus > 1 ? "s" : "");
+    fprintf(stderr, "\t%d read-id shard%s, %d host CPUs, %d GPU context%s\n", (int)S, S > 1 ? "s" : "", hw, n_gpus, n_gpus > 1 ? "s" : "");
 
     std::vector<std::unique_ptr<BamWriter>> bws;
     if (parts == 1) {
@@ -496,14 +500,60 @@ int main(int argc, char** argv) {
     for (size_t k = 0; k < S; ++k) outq.emplace_back(new OutShard());
     std::mutex win_mu; std::condition_variable win_cv;
     size_t writer_pos = 0;                                     // shards before this one are on disk
-    const size_t LOOKAHEAD = (size_t)workers + 2;
+    const size_t LOOKAHEAD = getenv("THJ_LOOKAHEAD") ? (size_t)atoll(getenv("THJ_LOOKAHEAD")) : (size_t)std::max(workers + 2, 32);      // shards in flight (memory bound)
     const size_t batch_reads = getenv("THJ_BATCH_READS") ? (size_t)atoll(getenv("THJ_BATCH_READS")) : (size_t)1 << 19;
     const int enc_threads = S == 1 ? host_threads() : 1;       // many shards: the workers are the parallelism
+
+    // The run is a pipeline of three kinds of threads (one output file; with -p N every part writes its own file from its feeder):
+    //   feeders   a few per GPU context: a shard's device work (ingest, stitch, download), shard after shard -- they wait on the
+    //             GPU, not on the CPU;
+    //   the pool  record encoding and BGZF deflate as independent jobs: the CPU-heavy part, never waiting for anything;
+    //   writer    the main thread: appends the deflated members in shard order, computes `.index` lines.
+    // Where BGZF members end depends on the bytes still open from the shard before, so shards are PLANNED in output order -- cheap,
+    // record sizes only, done by whichever thread delivers the encoded shard that was missing (on_encoded) -- and DEFLATED
+    // independently afterwards (BamWriter::plan / compress / commit).  Before this split every worker did all of it for its shard
+    // and the run moved in waves: all workers on the GPU's lock, then all deflating while the GPU idled (THJ_TRACE, tools/lsr_trace.py).
+    struct Pool {
+        std::mutex mu; std::condition_variable cv; std::deque<std::function<void()>> q; bool stop = false; std::vector<std::thread> th;
+        void start(int n) { for (int t = 0; t < n; ++t) th.emplace_back([this] { for (;;) { std::function<void()> f; { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return stop || !q.empty(); }); if (q.empty()) return; f = std::move(q.front()); q.pop_front(); } f(); } }); }
+        void submit(std::function<void()> f) { { std::lock_guard<std::mutex> lk(mu); q.push_back(std::move(f)); } cv.notify_one(); }
+        void finish() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& t : th) t.join(); th.clear(); }
+    } pool;
+    struct ShardOut { BamWriter::Encoded e; bool ready = false; BamWriter::Prepared p; };
+    std::vector<ShardOut> so(S);
+    std::mutex plan_mu;
+    size_t plan_next = 0;                                      // the first shard not planned yet
+    std::vector<uint8_t> plan_carry;                           // bytes of the open block after the last planned shard
+    auto deflate_shard = [&](size_t j) {
+        BamWriter::compress(so[j].p);
+        trace(j, "deflated");
+        OutShard& oq = *outq[j];
+        std::lock_guard<std::mutex> lk(oq.mu);
+        oq.q.push_back(std::move(so[j].p));
+        oq.done = true;
+        oq.cv.notify_all();
+    };
+    // shard k's records are encoded (all of them: one call per shard, an empty one for a shard without records)
+    auto on_encoded = [&](size_t k, BamWriter::Encoded&& e) {
+        std::vector<size_t> planned;
+        {
+            std::lock_guard<std::mutex> lk(plan_mu);
+            so[k].e = std::move(e); so[k].ready = true;
+            while (plan_next < S && so[plan_next].ready) {
+                BamWriter::plan(plan_carry, std::move(so[plan_next].e), so[plan_next].p);
+                trace(plan_next, "planned");
+                planned.push_back(plan_next++);
+            }
+        }
+        for (size_t i = 1; i < planned.size(); ++i) pool.submit([&deflate_shard, j = planned[i]] { deflate_shard(j); });
+        if (!planned.empty()) deflate_shard(planned[0]);
+    };
 
     // JoinSegmentsWorker (long_spanning_reads.cpp:2669-2845) for one shard
     auto run_shard = [&](size_t k) {
         const long long t_shard = WorkClock::now();
         struct AtExit { long long t; ~AtExit() { g_work.add(0, t); } } at_exit{t_shard};
+        trace(k, "start");
         const Shard& sh = shards[k];
         Gpu& gpu = *gpus[k % (size_t)n_gpus];
         const BamWriter& enc_bw = *bws[parts == 1 ? 0 : k];
@@ -519,6 +569,7 @@ int main(int argc, char** argv) {
                 const long long tw = WorkClock::now();
                 std::lock_guard<std::mutex> lk(gpu.mu);
                 g_work.add(1, tw);
+                trace(k, "ingest_begin");
                 const long long td = WorkClock::now();
                 if (dev_reads) {
                     const thj_bam_piece rp = reads_bam.piece(sh.read_off, sh.read_end);
@@ -526,6 +577,7 @@ int main(int argc, char** argv) {
                 } else
                     rc = thj_ingest_span_hits(device_ready(gpu), &o.p, nseg, segp.data(), b_id, e_id, &dev, &ids, &n);
                 g_work.add(2, td);
+                trace(k, "ingest_end");
             }
             if (rc == THJ_OK) {
                 if (dev) {
@@ -565,6 +617,7 @@ int main(int argc, char** argv) {
                         const long long tw = WorkClock::now();
                         std::lock_guard<std::mutex> lk(gpu.mu);
                         g_work.add(1, tw);
+                        trace(k, "stitch_begin");
                         const long long td = WorkClock::now();
                         thj_ctx* ctx = device_ready(gpu);
                         if (!dev_reads && thj_span_batch_attach_reads(ctx, dev, W, stride, planes.data(), lens.data(), q.data())) die("Error: %s\n", thj_last_error());
@@ -581,22 +634,32 @@ int main(int argc, char** argv) {
                         if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
                         if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
                         g_work.add(2, td);
+                        trace(k, "stitch_end");
                     }
-                    BamWriter::Encoded e;
-                    const long long te = WorkClock::now();
-                    encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
-                    g_work.add(3, te);
-                    free(rinfl);
-                    if (parts > 1) bws[k]->write_encoded(e);
-                    else {
-                        OutShard& oq = *outq[k];
-                        std::unique_lock<std::mutex> lk(oq.mu);
-                        oq.cv.wait(lk, [&] { return oq.q.size() < 2; });
-                        oq.q.push_back(std::move(e));
-                        oq.cv.notify_all();
+                    if (parts > 1) {
+                        BamWriter::Encoded e;
+                        const long long te = WorkClock::now();
+                        encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
+                        g_work.add(3, te);
+                        free(rinfl);
+                        bws[k]->write_encoded(e);
+                    } else {
+                        // the CPU part of the shard goes to the pool; this feeder moves on to the next shard's device work
+                        auto job = std::make_shared<std::pair<std::vector<thj_aln>, std::vector<Read>>>(std::move(alns), std::move(batch_rd));
+                        pool.submit([&, k, job, rinfl] {
+                            BamWriter::Encoded e;
+                            const long long te = WorkClock::now();
+                            encode_batch(*bws[0], rt, job->first, job->second, 1, e);
+                            g_work.add(3, te);
+                            trace(k, "encoded");
+                            free(rinfl);
+                            job->first = std::vector<thj_aln>(); job->second = std::vector<Read>();
+                            on_encoded(k, std::move(e));
+                        });
                     }
+                    return;
                 }
-                if (parts == 1) { OutShard& oq = *outq[k]; std::lock_guard<std::mutex> lk(oq.mu); oq.done = true; oq.cv.notify_all(); }
+                if (parts == 1) on_encoded(k, BamWriter::Encoded());
                 return;
             }
             if (rc != THJ_EFALLBACK) die("Error: %s\n", thj_last_error());
@@ -616,6 +679,7 @@ int main(int argc, char** argv) {
         std::vector<Read> batch_rd;
         std::vector<uint32_t> seg_off; std::vector<thj_span_hit> hits; std::vector<int64_t> read_off; std::string bases, quals;
         size_t max_len = 0;
+        BamWriter::Encoded shard_e;
         auto reset = [&]() { seg_off.assign(1, 0); hits.clear(); read_off.assign(1, 0); bases.clear(); quals.clear(); max_len = 0; batch_rd.clear(); };
         auto flush = [&]() {
             int64_t n = (int64_t)read_off.size() - 1;
@@ -658,12 +722,10 @@ int main(int argc, char** argv) {
             encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
             g_work.add(3, te);
             if (parts > 1) bws[k]->write_encoded(e);         // this part's own file
-            else {
-                OutShard& oq = *outq[k];
-                std::unique_lock<std::mutex> lk(oq.mu);
-                oq.cv.wait(lk, [&] { return oq.q.size() < 2; });
-                oq.q.push_back(std::move(e));
-                oq.cv.notify_all();
+            else {                                           // one output file: the shard's batches gather, the planner takes whole shards
+                shard_e.bytes.insert(shard_e.bytes.end(), e.bytes.begin(), e.bytes.end());
+                shard_e.size.insert(shard_e.size.end(), e.size.begin(), e.size.end());
+                shard_e.rid.insert(shard_e.rid.end(), e.rid.begin(), e.rid.end());
             }
             reset();
         };
@@ -696,7 +758,7 @@ int main(int argc, char** argv) {
             if (read_off.size() - 1 >= batch_reads) flush();
         }
         flush();
-        if (parts == 1) { OutShard& oq = *outq[k]; std::lock_guard<std::mutex> lk(oq.mu); oq.done = true; oq.cv.notify_all(); }
+        if (parts == 1) on_encoded(k, std::move(shard_e));
     };
 
     std::atomic<size_t> next{0};
@@ -708,15 +770,23 @@ int main(int argc, char** argv) {
             run_shard(k);
         }
     };
-    const int nthr = (int)std::min<size_t>((size_t)workers, S);
+    // thread counts: with the device-side ingest a feeder mostly waits for the GPU (a few per context keep it fed) and the pool has the
+    // CPUs; with the host readers the feeders parse, so they are the old workers and the pool gets what is left
+    const bool split = dev_ingest && parts == 1;
+    int feeders = split ? 2 * n_gpus + 2 : workers;
+    if (getenv("THJ_FEEDERS") && atoi(getenv("THJ_FEEDERS")) >= 1) feeders = atoi(getenv("THJ_FEEDERS"));
+    int pool_threads = split ? std::max(2, hw - 2) : std::max(2, hw - workers);
+    if (getenv("THJ_POOL") && atoi(getenv("THJ_POOL")) >= 1) pool_threads = atoi(getenv("THJ_POOL"));
+    if (parts == 1) pool.start(pool_threads);
+    const int nthr = (int)std::min<size_t>((size_t)feeders, S);
     std::vector<std::thread> th;
     for (int t = 0; t < nthr; ++t) th.emplace_back(work);
     if (parts == 1) {
-        // the writer: shard after shard, batch after batch -- deflate runs on worker threads inside write_encoded
+        // the writer: shard after shard, batch after batch -- the members arrive deflated, this thread appends them
         for (size_t k = 0; k < S; ++k) {
             OutShard& oq = *outq[k];
             for (;;) {
-                BamWriter::Encoded e;
+                BamWriter::Prepared e;
                 {
                     std::unique_lock<std::mutex> lk(oq.mu);
                     oq.cv.wait(lk, [&] { return !oq.q.empty() || oq.done; });
@@ -725,13 +795,15 @@ int main(int argc, char** argv) {
                     oq.q.pop_front();
                     oq.cv.notify_all();
                 }
-                bws[0]->write_encoded(e);
+                bws[0]->commit(e);
+                trace(k, "written");
             }
             { std::lock_guard<std::mutex> lk(win_mu); writer_pos = k + 1; }
             win_cv.notify_all();
         }
     }
     for (auto& t : th) t.join();
+    pool.finish();
     g_timer.lap("ingest + stitch + encode + write (all shards)");
     for (auto& bw : bws) bw->close();
     g_timer.lap("BAM close");

@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <unistd.h>
 #include <zlib.h>
+#include "thj_fastdeflate.h"
 
 #include <algorithm>
 #include <atomic>
@@ -1391,6 +1392,15 @@ class BamWriter {
     // one BGZF member from `take` input bytes; false when they do not fit (bgzf.c deflate_block then shrinks its input)
     static bool deflate_member(const uint8_t* in, size_t take, std::vector<uint8_t>& out) {
         out.resize(BLOCK + 1024);
+        // The default compressor is thj_fastdeflate.h (greedy LZ77 + one dynamic-Huffman block per member: zlib level 1's ratio on BAM
+        // records at several times its speed); setting THJ_BGZF_LEVEL selects zlib at that level (-1: zlib's default, what bgzf.c
+        // uses).  Members the fast path declines (tiny ones -- the 28-byte EOF marker must be zlib's --, output that does not fit)
+        // go to zlib as well.
+        static const bool use_zlib = getenv("THJ_BGZF_LEVEL") != nullptr;
+        if (!use_zlib && take >= 64) {
+            size_t clen = 0;
+            if (fdz::deflate_fast(in, take, out.data() + 18, BLOCK - 18 - 8, &clen)) { finish_member(in, take, clen, out); return true; }
+        }
         z_stream zs; memset(&zs, 0, sizeof zs);
         // bgzf.c compresses at zlib's default level (6); this writer defaults to level 1 -- the BAM stream inside is the same, the
         // file 9 % larger, the deflate 3x cheaper (measured: 0.6 s of a 2.7 s long_spanning_reads run); THJ_BGZF_LEVEL=-1 restores zlib's default
@@ -1402,6 +1412,11 @@ class BamWriter {
         size_t clen = zs.total_out;
         deflateEnd(&zs);
         if (st != Z_STREAM_END) return false;
+        finish_member(in, take, clen, out);
+        return true;
+    }
+    // BGZF envelope round the clen bytes of DEFLATE data already at out[18..)
+    static void finish_member(const uint8_t* in, size_t take, size_t clen, std::vector<uint8_t>& out) {
         static const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
         memcpy(out.data(), hdr, 12);
         out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
@@ -1411,7 +1426,6 @@ class BamWriter {
         memcpy(out.data() + 18 + clen, &crc, 4);
         memcpy(out.data() + 18 + clen + 4, &isize, 4);
         out.resize(clen + 26);
-        return true;
     }
 
     struct Blk { size_t ustart, ulen; int64_t addr; };
@@ -1585,35 +1599,93 @@ public:
     // read id (atol(qname)) of record i.  Shard workers encode in parallel; one thread appends in read order.
     struct Encoded { std::vector<uint8_t> bytes; std::vector<uint32_t> size; std::vector<long> rid; };
     void write_encoded(const Encoded& e) {
-        const size_t n = e.size.size();
         std::vector<uint8_t> stream;
         stream.reserve(carry_.size() + e.bytes.size());
         stream.insert(stream.end(), carry_.begin(), carry_.end());
         stream.insert(stream.end(), e.bytes.begin(), e.bytes.end());
         std::vector<Blk> tab = flush_blocks(stream, e.size, false);
-        // GBamWriter::write(b, read_id): index line once >= INDEX_REC_COUNT (1000) records have passed and the id changes
-        if (idx_) {
-            size_t x = carry_.size();
-            for (size_t i = 0; i < n; ++i) {
-                const size_t s0 = x, e0 = x + e.size[i];
-                x = e0;
-                const long read_id = e.rid[i];
-                if (!read_id) continue;
-                bool widx = idxcount_ >= 1000 && read_id != last_id_;
-                last_id_ = read_id; ++idxcount_;
-                if (!widx) continue;
-                int64_t pre_pos = tell_at(tab, s0), pre_addr = (pre_pos >> 16) & 0xFFFFFFFFFFFFLL;
-                int64_t off = tell_at(tab, e0);
-                int post_offs = (int)(off & 0xFFFF); int64_t post_addr = (off >> 16) & 0xFFFFFFFFFFFFLL;
-                int data_len = (int)e.size[i] - 4;       // b->data_len + BAM_CORE_SIZE == block_size of the record
-                if (post_addr != pre_addr && post_offs >= data_len) pre_pos = post_addr << 16;
-                fprintf(idx_, "%ld\t%ld\n", read_id, (long)pre_pos);
-                idxcount_ = 0;
-            }
-        }
+        index_lines(tab, carry_.size(), e.size, e.rid);
         const Blk& open = tab.back();
         carry_.assign(stream.begin() + (ptrdiff_t)open.ustart, stream.end());
     }
+    // The same in three steps, so that shard workers deflate their own members and the ordered writer only appends:
+    //   plan      where the members end depends on the bytes still open from the batch before (`carry`) and on record sizes alone, so
+    //             batches are planned one after the other as soon as they are ENCODED (cheap, the caller serialises it), not written;
+    //   compress  the batch's members, by whoever holds the batch, in parallel with other batches;
+    //   commit    in order: members to the file, `.index` lines on the now-known addresses.
+    // Should a member not fit its envelope (incompressible data: bgzf.c then shrinks the block and every later cut moves) the
+    // writer drops the plans from that batch on and goes back to write_encoded.
+    struct Prepared {
+        std::vector<uint8_t> stream;                 // carry + the batch's records
+        size_t carry_in = 0;
+        std::vector<uint32_t> size; std::vector<long> rid;
+        std::vector<size_t> cuts;                    // member ends in `stream`
+        std::vector<std::vector<uint8_t>> members;
+        bool ok = true;
+    };
+    static void plan(std::vector<uint8_t>& carry, Encoded&& e, Prepared& p) {
+        p.carry_in = carry.size();
+        p.stream.reserve(carry.size() + e.bytes.size());
+        p.stream.insert(p.stream.end(), carry.begin(), carry.end());
+        p.stream.insert(p.stream.end(), e.bytes.begin(), e.bytes.end());
+        std::vector<uint8_t>().swap(e.bytes);
+        p.size = std::move(e.size); p.rid = std::move(e.rid);
+        size_t end_off = 0;
+        plan_cuts(p.carry_in, p.carry_in, p.size, 0, p.cuts, &end_off);
+        const size_t last = p.cuts.empty() ? 0 : p.cuts.back();
+        carry.assign(p.stream.begin() + (ptrdiff_t)last, p.stream.end());
+    }
+    static void compress(Prepared& p) {
+        p.members.resize(p.cuts.size());
+        for (size_t k = 0; k < p.cuts.size() && p.ok; ++k) {
+            const size_t a = k ? p.cuts[k - 1] : 0;
+            if (!deflate_member(p.stream.data() + a, p.cuts[k] - a, p.members[k])) p.ok = false;
+        }
+    }
+    void commit(Prepared& p) {
+        if (!p.ok) replay_ = true;
+        if (replay_) {
+            Encoded e;
+            e.bytes.assign(p.stream.begin() + (ptrdiff_t)p.carry_in, p.stream.end());
+            e.size = std::move(p.size); e.rid = std::move(p.rid);
+            write_encoded(e);
+            return;
+        }
+        std::vector<Blk> tab;
+        size_t upos = 0;
+        for (size_t k = 0; k < p.cuts.size(); ++k) {
+            tab.push_back({upos, p.cuts[k] - upos, file_addr_});
+            write_member(p.members[k]);
+            upos = p.cuts[k];
+        }
+        tab.push_back({upos, p.stream.size() - upos, file_addr_});       // the open block
+        index_lines(tab, p.carry_in, p.size, p.rid);
+        carry_.assign(p.stream.begin() + (ptrdiff_t)upos, p.stream.end());
+    }
+private:
+    bool replay_ = false;
+    // GBamWriter::write(b, read_id): index line once >= INDEX_REC_COUNT (1000) records have passed and the id changes
+    void index_lines(const std::vector<Blk>& tab, size_t carry_len, const std::vector<uint32_t>& size, const std::vector<long>& rid) {
+        if (!idx_) return;
+        size_t x = carry_len;
+        for (size_t i = 0; i < size.size(); ++i) {
+            const size_t s0 = x, e0 = x + size[i];
+            x = e0;
+            const long read_id = rid[i];
+            if (!read_id) continue;
+            bool widx = idxcount_ >= 1000 && read_id != last_id_;
+            last_id_ = read_id; ++idxcount_;
+            if (!widx) continue;
+            int64_t pre_pos = tell_at(tab, s0), pre_addr = (pre_pos >> 16) & 0xFFFFFFFFFFFFLL;
+            int64_t off = tell_at(tab, e0);
+            int post_offs = (int)(off & 0xFFFF); int64_t post_addr = (off >> 16) & 0xFFFFFFFFFFFFLL;
+            int data_len = (int)size[i] - 4;       // b->data_len + BAM_CORE_SIZE == block_size of the record
+            if (post_addr != pre_addr && post_offs >= data_len) pre_pos = post_addr << 16;
+            fprintf(idx_, "%ld\t%ld\n", read_id, (long)pre_pos);
+            idxcount_ = 0;
+        }
+    }
+public:
     // Writes records 0..n-1 in order.  enc(i, bytes) appends record i with encode() and returns its read id (atol(qname)).
     void write_records(size_t n, const std::function<long(size_t, std::vector<uint8_t>&)>& enc) {
         int T = host_threads();
