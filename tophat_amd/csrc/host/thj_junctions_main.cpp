@@ -32,49 +32,106 @@ int main(int argc, char** argv) {
     std::vector<std::string> inputs = split(pos[2], ',');
     for (auto& f : inputs) register_targets(f, rt);
     rt.freeze();
-    // ---- one reader thread per input: spliced records -> thj_aln (only the fields the reduce reads)
+    // ---- spliced records -> thj_aln (only the fields the reduce reads).  BGZF members inflate independently, so every input is cut
+    // into runs of members, one per host thread; a run must end on a record boundary (true of every BAM written through
+    // bgzf_flush_try: samtools 0.1.18's writer, this build's) -- if one does not, that input is read again by the sequential reader.
     std::vector<std::vector<thj_aln>> recs(inputs.size());
+    auto parse_record = [](const uint8_t* d, int32_t bs, const std::vector<uint32_t>& tid2ref, std::vector<thj_aln>& out) {
+        static const uint32_t OPS[9] = {THJ_CIG_MATCH, THJ_CIG_INS, THJ_CIG_DEL, THJ_CIG_REF_SKIP, THJ_CIG_SOFT_CLIP, 14u, 15u, THJ_CIG_MATCH, THJ_CIG_MATCH};
+        int32_t tid, p0; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
+        memcpy(&tid, d, 4); memcpy(&p0, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4); memcpy(&l_seq, d + 16, 4);
+        const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF;
+        if (tid < 0 || ((flag_nc >> 16) & 4) || n_cig < 3 || n_cig > 16) return;
+        thj_aln a; memset(&a, 0, sizeof a);
+        bool spliced = false;
+        size_t pp = 32 + l_rn;
+        for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + pp, 4); pp += 4; const uint32_t op = (c & 0xF) < 9 ? OPS[c & 0xF] : 15u; if (op == THJ_CIG_REF_SKIP) spliced = true; a.cigar[i] = (op << 28) | (c >> 4); }
+        if (!spliced) return;
+        pp += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+        char xs = 0;
+        while (pp + 3 <= (size_t)bs) {                        // XS:A
+            const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
+            pp += 3;
+            switch (ty) {
+            case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
+            case 'c': case 'C': pp += 1; break;
+            case 's': case 'S': pp += 2; break;
+            case 'i': case 'I': case 'f': pp += 4; break;
+            case 'd': pp += 8; break;
+            case 'Z': case 'H': while (pp < (size_t)bs && d[pp]) ++pp; ++pp; break;
+            case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); pp += 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
+            default: pp = (size_t)bs; break;
+            }
+        }
+        a.ref_id = (size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0;
+        if (!a.ref_id) return;
+        a.left = p0; a.n_cigar = (uint8_t)n_cig;
+        a.flags = (uint8_t)(xs == '-' ? THJ_HIT_ANTISENSE_SPLICE : 0);
+        out.push_back(a);
+    };
+    auto read_parallel = [&](const std::string& fn, std::vector<thj_aln>& out) -> bool {
+        BamFile bf;
+        if (getenv("THJ_SEQUENTIAL_READ") || !bf.open(fn, rt)) return false;
+        std::vector<size_t> moff;
+        for (size_t off = (size_t)(bf.first_rec_voff >> 16); off < bf.size;) {
+            const uint32_t bs = BamFile::member_size(bf.data + off, bf.size - off);
+            if (!bs || off + bs > bf.size) return false;
+            moff.push_back(off); off += bs;
+        }
+        const size_t nm = moff.size();
+        if (!nm) return true;
+        const size_t T = std::min<size_t>((size_t)std::max(1, host_threads()), nm);
+        std::vector<std::vector<thj_aln>> part(T);
+        std::vector<char> bad(T, 0);
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < T; ++t) th.emplace_back([&, t]() {
+            std::vector<uint8_t> buf; size_t have = 0;
+            z_stream zs; memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = 1; return; }
+            for (size_t m = nm * t / T; m < nm * (t + 1) / T && !bad[t]; ++m) {
+                const uint8_t* d = bf.data + moff[m];
+                const uint32_t bs = BamFile::member_size(d, bf.size - moff[m]), xlen = d[10] | (d[11] << 8);
+                uint32_t isz; memcpy(&isz, d + bs - 4, 4);
+                if (buf.size() < have + isz) buf.resize(have + isz + 65536);
+                inflateReset(&zs);
+                zs.next_in = const_cast<uint8_t*>(d + 12 + xlen); zs.avail_in = bs - 12 - xlen - 8;
+                zs.next_out = buf.data() + have; zs.avail_out = isz;
+                if (inflate(&zs, Z_FINISH) != Z_STREAM_END && isz) { bad[t] = 1; break; }
+                size_t end = have + isz;
+                size_t pos = m == 0 ? (size_t)(bf.first_rec_voff & 0xFFFF) : 0;      // the first member may still hold the end of the header
+                if (m == 0 && pos > end) { bad[t] = 1; break; }
+                while (pos + 4 <= end) {
+                    int32_t rs; memcpy(&rs, buf.data() + pos, 4);
+                    if (rs < 32) { bad[t] = 1; break; }
+                    if (pos + 4 + (size_t)rs > end) break;
+                    parse_record(buf.data() + pos + 4, rs, bf.tid2ref, part[t]);
+                    pos += 4 + (size_t)rs;
+                }
+                have = end - pos;
+                if (have) memmove(buf.data(), buf.data() + pos, have);
+            }
+            inflateEnd(&zs);
+            if (have) bad[t] = 1;                                  // a record straddles the end of this run
+        });
+        for (auto& x : th) x.join();
+        for (char b : bad) if (b) return false;
+        size_t tot = 0;
+        for (auto& v : part) tot += v.size();
+        out.reserve(tot);
+        for (auto& v : part) out.insert(out.end(), v.begin(), v.end());
+        return true;
+    };
     std::vector<std::thread> th;
     for (size_t k = 0; k < inputs.size(); ++k) th.emplace_back([&, k]() {
+        if (read_parallel(inputs[k], recs[k])) return;
+        recs[k].clear();
         AlnReader rd;
         if (!rd.open(inputs[k])) die("Error: cannot open %s\n", inputs[k].c_str());
         if (!rd.is_bam()) die("Error: %s: BAM input expected\n", inputs[k].c_str());
         std::vector<uint32_t> tid2ref;
         for (auto& t : rd.targets()) tid2ref.push_back(rt.get_id(t));
-        static const uint32_t OPS[9] = {THJ_CIG_MATCH, THJ_CIG_INS, THJ_CIG_DEL, THJ_CIG_REF_SKIP, THJ_CIG_SOFT_CLIP, 14u, 15u, THJ_CIG_MATCH, THJ_CIG_MATCH};
         int32_t bs = 0;
-        while (const uint8_t* d = rd.next_raw(bs)) {
-            int32_t tid, p0; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
-            memcpy(&tid, d, 4); memcpy(&p0, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4); memcpy(&l_seq, d + 16, 4);
-            const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF;
-            if (tid < 0 || ((flag_nc >> 16) & 4) || n_cig < 3 || n_cig > 16) continue;
-            thj_aln a; memset(&a, 0, sizeof a);
-            bool spliced = false;
-            size_t pp = 32 + l_rn;
-            for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + pp, 4); pp += 4; const uint32_t op = (c & 0xF) < 9 ? OPS[c & 0xF] : 15u; if (op == THJ_CIG_REF_SKIP) spliced = true; a.cigar[i] = (op << 28) | (c >> 4); }
-            if (!spliced) continue;
-            pp += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
-            char xs = 0;
-            while (pp + 3 <= (size_t)bs) {                        // XS:A
-                const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
-                pp += 3;
-                switch (ty) {
-                case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
-                case 'c': case 'C': pp += 1; break;
-                case 's': case 'S': pp += 2; break;
-                case 'i': case 'I': case 'f': pp += 4; break;
-                case 'd': pp += 8; break;
-                case 'Z': case 'H': while (pp < (size_t)bs && d[pp]) ++pp; ++pp; break;
-                case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); pp += 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
-                default: pp = (size_t)bs; break;
-                }
-            }
-            a.ref_id = (size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0;
-            if (!a.ref_id) continue;
-            a.left = p0; a.n_cigar = (uint8_t)n_cig;
-            a.flags = (uint8_t)(xs == '-' ? THJ_HIT_ANTISENSE_SPLICE : 0);
-            recs[k].push_back(a);
-        }
+        while (const uint8_t* d = rd.next_raw(bs)) parse_record(d, bs, tid2ref, recs[k]);
     });
     for (auto& t : th) t.join();
     thj_ctx* ctx = fut.get();
