@@ -576,13 +576,15 @@ def run_rank(args, rank, world, local_rank, control, shared):
         + (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
     # stage 2, four kernels per launch.  Per finished read: 38 B of read planes, two 64-B genome lines (consistency
-    # check + MD pass share them) and its 128-B record; tier 0 streams every read's CSR row and 32-B hit records;
+    # check + MD pass share them) and the 64-B lead line of its record; tier 0 streams every read's CSR row and 32-B hit records;
     # tiers 1/2/3 re-read CSR + hits of their worklist reads (4-B list entry each) and one 64-B line of junction keys
     # per closure.  Counters come from the kernels (tier sizes of the last launch, record count of the step).
     n_lean, n_multi, n_gen = ctx.span_tier_counts()
     hits_per_read = float(int(w["left"]["span_off"][-1]) + int(w["right"]["span_off"][-1])) / (2.0 * args.pairs)
     rec_per_read = n_alns / (2.0 * args.pairs)
-    per_read_done = rl_bytes + rec_per_read * (128 + 128)
+    # the record: one 64-B lead line (thj_aln_slot); the tail line is written only for > 4 cigar ops or an MD string of > 24
+    # characters, which this workload's reads do not have
+    per_read_done = rl_bytes + rec_per_read * (128 + 64)
     n_t0 = args.pairs - n_lean - n_multi
     hit_b = 16.0 if use_heads else 32.0              # tier 0 streams the dense 16-byte heads when the batch has them
     t0_alg = 4.0 * (args.pairs * nseg + 1) + hit_b * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
@@ -602,7 +604,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # The same kernels in SURVEY 8(d)'s byte terms -- what the ALGORITHM has to move, whatever layout a build chose: 16 B per hit
     # record (this build's stage-2 record is 32 B), the packed read, <= 128 B of genome per window / per joined hit, one 64-B
     # line of junction keys per closure, 16 B per candidate event, 32 + 8 x ncigar B per joined alignment (this build writes a
-    # 128-B record).  `frac` below is computed from THESE; the layout-byte figure stays next to it as frac_layout.
+    # 64-B line, two for a long record).  `frac` below is computed from THESE; the layout-byte figure stays next to it as frac_layout.
     cig_per_rec = 1.0 + 2.0 * (n_lean + n_multi) / max(1.0, float(args.pairs))         # contiguous: 1 op; one closure: 3
     out_rec = 32.0 + 8.0 * cig_per_rec
     done_8d = rl_bytes + rec_per_read * (128.0 + out_rec)

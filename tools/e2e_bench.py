@@ -59,6 +59,10 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
         if r.returncode != 0:
             raise RuntimeError("long_spanning_reads failed:\n" + r.stderr[-3000:])
         res["long_spanning_reads_%s_s" % sd] = round(dt, 3)
+        for l in r.stderr.splitlines():                     # time before main() and after the report: loader, process teardown
+            if "unix time at start / report" in l:
+                a, b = map(float, l.split()[-2:])
+                res["long_spanning_reads_%s_before_main_after_report_s" % sd] = [round(a - t, 3), round(t + dt - b, 3)]
         res["long_spanning_reads_%s_log_tail" % sd] = [l for l in r.stderr.strip().splitlines() if not l.startswith("[trace]")][-8:]
         if env.get("THJ_TRACE"):                     # the per-shard timeline for tools/lsr_trace.py
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -297,7 +297,7 @@ struct OutShard {
     bool done = false;
 };
 
-int main(int argc, char** argv) {
+static int real_main(int argc, char** argv) {
     fprintf(stderr, "long_spanning_reads (MI355X-native, %s)\n--------------------------------------------\n", thj_version());
     Opts o;
     int rc = parse_options(argc, argv, o, print_usage);
@@ -812,6 +812,7 @@ int main(int argc, char** argv) {
     { static const char* const nm[4] = {"shards (ingest + merge + device + encode)", "  waiting for the GPU's lock", "  device calls (upload, stitch, download)", "  record encoding"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime down after a context has been used takes ~0.2 s that nobody is waiting for.
-    fflush(nullptr);
-    _exit(0);
+    finish_outputs_complete(0);
 }
+
+int main(int argc, char** argv) { return run_with_handoff(argc, argv, real_main); }

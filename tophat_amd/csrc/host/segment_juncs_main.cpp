@@ -258,7 +258,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
     flush();
 }
 
-int main(int argc, char** argv) {
+static int real_main(int argc, char** argv) {
     fprintf(stderr, "segment_juncs (MI355X-native, %s)\n---------------------------\n", thj_version());
     Opts o;
     int rc = parse_options(argc, argv, o, print_usage);
@@ -514,6 +514,7 @@ int main(int argc, char** argv) {
     { static const char* const nm[4] = {"shards (ingest + merge + pack + device)", "  waiting for the GPU's lock", "  device calls (upload, launch, free)", "  -"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime (and RCCL) down after use takes tenths of a second that nobody is waiting for.
-    fflush(nullptr);
-    _exit(0);
+    finish_outputs_complete(0);
 }
+
+int main(int argc, char** argv) { return run_with_handoff(argc, argv, real_main); }

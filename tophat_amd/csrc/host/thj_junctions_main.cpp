@@ -14,7 +14,7 @@ using namespace thjh;
 
 static void usage() { fprintf(stderr, "Usage:   thj_junctions [--min-anchor N] [--sam-header hdr.sam] <ref.fa> <junctions.bed> <alignments1.bam[,alignments2.bam,...]>\n"); }
 
-int main(int argc, char** argv) {
+static int real_main(int argc, char** argv) {
     Opts o;
     int rc = parse_options(argc, argv, o, usage);
     if (rc) return rc;
@@ -159,6 +159,7 @@ int main(int argc, char** argv) {
         fclose(f);
         break;
     }
-    fflush(nullptr);
-    _exit(0);
+    finish_outputs_complete(0);
 }
+
+int main(int argc, char** argv) { return run_with_handoff(argc, argv, real_main); }
