@@ -237,7 +237,7 @@ def parse_args():
                          "part of the resident layout, not of a step)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--e2e-pairs", type=int, default=8_000_000,
+    ap.add_argument("--e2e-pairs", type=int, default=10_000_000,
                     help="also run the drop-in executables end to end (files in, files out: the metric as SURVEY 8d words it) on "
                          "generated files of this many pairs; 0 skips the leg.  Reported as the `e2e` object, never as `value`")
     return ap.parse_args()

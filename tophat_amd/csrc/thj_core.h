@@ -34,6 +34,7 @@ typedef unsigned long long u64;
 
 // ---- bit helpers ---------------------------------------------------------
 THJ_HD int popc(u64 x) { return __builtin_popcountll(x); }
+THJ_HD int popc32(uint32_t x) { return __builtin_popcount(x); }
 THJ_HD int ctz(u64 x) { return __builtin_ctzll(x); }   // x != 0
 THJ_HD int clz(u64 x) { return __builtin_clzll(x); }   // x != 0
 THJ_HD u64 lowmask(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }   // n >= 0
@@ -353,6 +354,52 @@ THJ_HD int flank_scan(const Genome& g, uint32_t ref_id, int64_t left, int flen, 
     return pos;
 }
 
+// The same scan for the two patterns of a rescue pair at once (the read's last bases and their reverse complement), offset by
+// offset on 32-bit words.  flank_scan's bit-slicing pays for 64-bit operations on a 15-base pattern (~37 instructions per base,
+// chunk and pattern: ~2200 per pair, 70 % of thj_k_segjuncs_rescue); here an offset costs two funnel shifts for the genome
+// window plus, per pattern, two XORs, a masked OR, a popcount and a min over (distance << 16 | offset) keys -- the smallest key is
+// the first offset with the smallest distance -- ~16 instructions, ~900 per pair, and the genome words of a 64-offset chunk are
+// fetched together instead of one dependent fetch per 50 offsets and pattern.  Only for patterns of at most 16 bases without N
+// and windows without N ('N' == 'N' is a match in the reference, which the planes-XOR of flank_scan handles): returns false
+// otherwise and the caller takes flank_scan.
+THJ_HD uint32_t funnel32(uint32_t w0, uint32_t w1, int s) { return (uint32_t)(((((u64)w1) << 32) | (u64)w0) >> s); }     // s in 0..31
+THJ_HD bool flank_scan_pair(const Genome& g, uint32_t ref_id, int64_t left, int flen, const Planes& f, const Planes& r, int rlen, int& fpos, int& rpos) {
+    const int n_off = flen - rlen;
+    fpos = -1; rpos = -1;
+    if (n_off <= 0) return true;
+    if (rlen > 16 || n_off >= 65536 || (f.nm | r.nm) != 0) return false;
+    const uint32_t m = (uint32_t)lowmask(rlen);
+    const uint32_t fl = (uint32_t)f.lo, fh = (uint32_t)f.hi, rl = (uint32_t)r.lo, rh = (uint32_t)r.hi;
+    uint32_t bf = 0xFFFFFFFFu, br = 0xFFFFFFFFu;
+    for (int cs = 0; cs < n_off; cs += 64) {
+        const int lim = n_off - cs < 64 ? n_off - cs : 64;          // offsets of this chunk; they read bases [0, lim + rlen - 1)
+        const int need = lim + rlen - 1;
+        const Planes a = g_fetch(g, ref_id, left + cs);
+        Planes b; b.lo = 0; b.hi = 0; b.nm = 0;
+        if (need > 64) b = g_fetch(g, ref_id, left + cs + 64);
+        if (((need >= 64 ? a.nm : a.nm & lowmask(need)) | (need > 64 ? b.nm & lowmask(need - 64) : 0ull)) != 0) return false;
+        const uint32_t wl[4] = {(uint32_t)a.lo, (uint32_t)(a.lo >> 32), (uint32_t)b.lo, (uint32_t)(b.lo >> 32)};
+        const uint32_t wh[4] = {(uint32_t)a.hi, (uint32_t)(a.hi >> 32), (uint32_t)b.hi, (uint32_t)(b.hi >> 32)};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int smax = lim - 32 * j < 32 ? lim - 32 * j : 32;
+#pragma unroll 4
+            for (int sft = 0; sft < smax; ++sft) {
+                const uint32_t gl = funnel32(wl[j], wl[j + 1], sft), gh = funnel32(wh[j], wh[j + 1], sft);
+                const uint32_t o = (uint32_t)(cs + 32 * j + sft);
+                const uint32_t kf = ((uint32_t)popc32(((gl ^ fl) | (gh ^ fh)) & m) << 16) | o;
+                const uint32_t kr = ((uint32_t)popc32(((gl ^ rl) | (gh ^ rh)) & m) << 16) | o;
+                bf = kf < bf ? kf : bf;
+                br = kr < br ? kr : br;
+            }
+        }
+        if ((bf >> 16) == 0 && (br >> 16) == 0) break;              // nothing replaces two perfect matches
+    }
+    if ((bf >> 16) < 3u) fpos = (int)(bf & 0xFFFFu);
+    if ((br >> 16) < 3u) rpos = (int)(br & 0xFFFFu);
+    return true;
+}
+
 enum { SLOT_NONE = -1, SLOT_BREAK = -2 };
 
 // One (left hit, mate hit) pair of the mate-anchored rescue (segment_juncs.cpp:3406-3492).
@@ -382,9 +429,12 @@ THJ_HD bool rescue_pair(const Genome& g, const Params& p, const u64* rp, int W, 
     if (cl < 1 || cl > rl) return false;
     Planes fwd = r_fetch(rp, W, rl - cl, cl);     // last cl bases of the read
     Planes rev = rc_piece(fwd, cl);               // first cl bases of its reverse complement
-    int fp = flank_scan(g, rh.ref_id, left, flen, fwd, cl);
+    int fp, rvp;
+    if (!flank_scan_pair(g, rh.ref_id, left, flen, fwd, rev, cl, fp, rvp)) {
+        fp = flank_scan(g, rh.ref_id, left, flen, fwd, cl);
+        rvp = flank_scan(g, rh.ref_id, left, flen, rev, cl);
+    }
     if (fp >= 0) fwd_left = (int32_t)(left + fp);
-    int rvp = flank_scan(g, rh.ref_id, left, flen, rev, cl);
     if (rvp >= 0) rev_left = (int32_t)(left + rvp);
     return true;                                  // the pair was scanned (what the rescue-pair statistic counts)
 }

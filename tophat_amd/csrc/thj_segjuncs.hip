@@ -397,7 +397,8 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                     for (int l = 0; l < n_left; ++l)
                         for (int m = 0; m < v.n_mate; ++m) {
                             int32_t f, rv;
-                            if (rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m], f, rv)) ++local;
+                            if (THJ_EXPF(1 << 22)) { f = SLOT_NONE; rv = SLOT_NONE; }
+                            else if (rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m], f, rv)) ++local;
                             if (fits) { mine[2 * (l * v.n_mate + m)] = f; mine[2 * (l * v.n_mate + m) + 1] = rv; }
                             if (f == SLOT_BREAK) break;                  // the reference leaves the mate loop here (:3431-3450)
                         }
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                     v.slots = fits ? mine : nullptr;
                     v.lazy_g = &s_g; v.lazy_p = &s_p;
                 }
-                gaps_enumerate(p, v, qs);
+                if (!THJ_EXPF(1 << 23)) gaps_enumerate(p, v, qs);
             }
             if (qs.n_windows) atomicAdd(&s_stat[0], qs.n_windows);
             if (qs.n_indels) atomicAdd(&s_stat[1], qs.n_indels);
