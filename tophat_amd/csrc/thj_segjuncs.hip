@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <cstddef>
 #include <vector>
 
 #include "../../include/thj.h"
@@ -959,6 +960,84 @@ extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_
     return THJ_OK;
 }
 
+// FusionSimpleSet (segment_juncs.cpp:2791-2803) on the device: the raw candidate events are ordered by Fusion::operator<
+// (fusions.h:38-69: ref1, ref2, left, right, dir) with three stable radix sorts of an index (least significant key first), runs of
+// equal keys are numbered by a prefix sum over their heads, and every event adds itself to its run's record (count += 1, the
+// smallest edit distance wins).  Only the distinct fusions come down.  (Round 1 brought every raw event to the host and sorted
+// there: 36 of the 62 ms of a fusion-search step on configs[3]'s shape.)
+__global__ __launch_bounds__(256) void thj_k_fus_keys(const thj_fusion* ev, int64_t n, uint32_t* kdir, uint32_t* idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) { kdir[i] = ev[i].dir; idx[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(256) void thj_k_fus_gather(const thj_fusion* ev, const uint32_t* idx, int64_t n, int which, u64* key) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const thj_fusion e = ev[idx[i]];
+        key[i] = which == 0 ? ((u64)e.left << 32) | (u64)e.right : ((u64)e.ref_id1 << 32) | (u64)e.ref_id2;
+    }
+}
+__global__ __launch_bounds__(256) void thj_k_fus_heads(const thj_fusion* ev, const uint32_t* idx, int64_t n, uint32_t* head) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = 1;
+        if (i > 0) {
+            const thj_fusion a = ev[idx[i - 1]], b = ev[idx[i]];
+            h = (a.ref_id1 != b.ref_id1 || a.ref_id2 != b.ref_id2 || a.left != b.left || a.right != b.right || a.dir != b.dir) ? 1u : 0u;
+        }
+        head[i] = h;
+    }
+}
+__global__ __launch_bounds__(256) void thj_k_fus_reduce(const thj_fusion* ev, const uint32_t* idx, const uint32_t* head, const uint32_t* run, int64_t n, thj_fusion* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const thj_fusion e = ev[idx[i]];
+        thj_fusion* o = out + (run[i] - 1);                           // run[] = inclusive prefix sum of the heads
+        if (head[i]) { o->ref_id1 = e.ref_id1; o->ref_id2 = e.ref_id2; o->left = e.left; o->right = e.right; o->dir = e.dir; o->reserved = 0; }
+        atomicAdd(&o->count, 1u);
+        atomicMin(&o->edit_dist, e.edit_dist);
+    }
+}
+
+static int fusion_reduce_on_device(thj_ctx* c, int64_t n) {
+    void *d_kdir = nullptr, *d_kdir2 = nullptr, *d_idx = nullptr, *d_idx2 = nullptr, *d_key = nullptr, *d_key2 = nullptr, *d_out = nullptr;
+    auto release = [&]() { for (void* p : {d_kdir, d_kdir2, d_idx, d_idx2, d_key, d_key2, d_out}) if (p) thj_dev_release(c, p); };
+    int rc = 0;
+    for (void** p : {&d_kdir, &d_kdir2, &d_idx, &d_idx2}) if (!rc) rc = thj_dev_alloc(c, p, (size_t)n * 4);
+    for (void** p : {&d_key, &d_key2}) if (!rc) rc = thj_dev_alloc(c, p, (size_t)n * 8);
+    if (!rc) rc = thj_dev_alloc(c, &d_out, (size_t)n * sizeof(thj_fusion));
+    if (rc) { release(); return rc; }
+    size_t need32 = 0, need64 = 0, needscan = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need32, (const uint32_t*)d_kdir, (uint32_t*)d_kdir2, (const uint32_t*)d_idx, (uint32_t*)d_idx2, (int)n, 0, 8, c->stream));
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, need64, (const u64*)d_key, (u64*)d_key2, (const uint32_t*)d_idx, (uint32_t*)d_idx2, (int)n, 0, 64, c->stream));
+    HIPCHK(hipcub::DeviceScan::InclusiveSum(nullptr, needscan, (const uint32_t*)d_kdir, (uint32_t*)d_kdir2, (int)n, c->stream));
+    size_t need = std::max(need32, std::max(need64, needscan));
+    if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+    int64_t grid = (n + 255) / 256; if (grid > 8192) grid = 8192;
+    const thj_fusion* ev = c->d_fus;
+    size_t tmp = c->sort_tmp_bytes;
+    hipLaunchKernelGGL(thj_k_fus_keys, dim3((unsigned)grid), dim3(256), 0, c->stream, ev, n, (uint32_t*)d_kdir, (uint32_t*)d_idx);
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const uint32_t*)d_kdir, (uint32_t*)d_kdir2, (const uint32_t*)d_idx, (uint32_t*)d_idx2, (int)n, 0, 8, c->stream));
+    hipLaunchKernelGGL(thj_k_fus_gather, dim3((unsigned)grid), dim3(256), 0, c->stream, ev, (const uint32_t*)d_idx2, n, 0, (u64*)d_key);
+    tmp = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)d_key, (u64*)d_key2, (const uint32_t*)d_idx2, (uint32_t*)d_idx, (int)n, 0, 64, c->stream));
+    hipLaunchKernelGGL(thj_k_fus_gather, dim3((unsigned)grid), dim3(256), 0, c->stream, ev, (const uint32_t*)d_idx, n, 1, (u64*)d_key);
+    tmp = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)d_key, (u64*)d_key2, (const uint32_t*)d_idx, (uint32_t*)d_idx2, (int)n, 0, 64, c->stream));
+    // d_idx2: the events in Fusion::operator< order
+    hipLaunchKernelGGL(thj_k_fus_heads, dim3((unsigned)grid), dim3(256), 0, c->stream, ev, (const uint32_t*)d_idx2, n, (uint32_t*)d_kdir);
+    tmp = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::InclusiveSum(c->d_sort_tmp, tmp, (const uint32_t*)d_kdir, (uint32_t*)d_kdir2, (int)n, c->stream));
+    uint32_t n_runs = 0;
+    HIPCHK(hipMemcpyAsync(&n_runs, (const uint32_t*)d_kdir2 + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // count = 0, edit_dist = all ones, the rest is written by each run's head
+    HIPCHK(hipMemsetAsync(d_out, 0, (size_t)n_runs * sizeof(thj_fusion), c->stream));
+    HIPCHK(hipMemset2DAsync((char*)d_out + offsetof(thj_fusion, edit_dist), sizeof(thj_fusion), 0xFF, 4, n_runs, c->stream));
+    hipLaunchKernelGGL(thj_k_fus_reduce, dim3((unsigned)grid), dim3(256), 0, c->stream, ev, (const uint32_t*)d_idx2, (const uint32_t*)d_kdir, (const uint32_t*)d_kdir2, n, (thj_fusion*)d_out);
+    HIPCHK(hipGetLastError());
+    c->h_fusions.resize(n_runs);
+    HIPCHK(hipMemcpyAsync(c->h_fusions.data(), d_out, (size_t)n_runs * sizeof(thj_fusion), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    release();
+    return THJ_OK;
+}
+
 extern "C" int thj_fusion_finish(thj_ctx* c, int64_t* n_fusions) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
@@ -968,10 +1047,14 @@ extern "C" int thj_fusion_finish(thj_ctx* c, int64_t* n_fusions) {
         HIPCHK(hipMemcpyAsync(h, c->d_fus_count, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if ((unsigned int)h[1]) { thj_set_error("fusion event buffer overflow (%llu candidate events, capacity %lld)", h[0], (long long)c->fus_cap); return THJ_EOVERFLOW; }
+        static const bool on_host = getenv("THJ_FUSION_REDUCE_ON_HOST") != nullptr;
+        if (h[0] && !on_host && h[0] < (1ull << 31)) {
+            const int rc = fusion_reduce_on_device(c, (int64_t)h[0]);
+            if (rc) return rc;
+        } else if (h[0]) {
         std::vector<thj_fusion> ev((size_t)h[0]);
-        if (h[0]) HIPCHK(hipMemcpy(ev.data(), c->d_fus, (size_t)h[0] * sizeof(thj_fusion), hipMemcpyDeviceToHost));
-        // FusionSimpleSet (segment_juncs.cpp:2791-2803): count the occurrences, keep the smallest edit distance;
-        // iteration order = Fusion::operator< (fusions.h:38-69)
+        HIPCHK(hipMemcpy(ev.data(), c->d_fus, (size_t)h[0] * sizeof(thj_fusion), hipMemcpyDeviceToHost));
+        // the same on the host: count the occurrences, keep the smallest edit distance; iteration order = Fusion::operator<
         auto less = [](const thj_fusion& a, const thj_fusion& b) {
             if (a.ref_id1 != b.ref_id1) return a.ref_id1 < b.ref_id1;
             if (a.ref_id2 != b.ref_id2) return a.ref_id2 < b.ref_id2;
@@ -985,6 +1068,7 @@ extern "C" int thj_fusion_finish(thj_ctx* c, int64_t* n_fusions) {
                 c->h_fusions.back().count += 1;
                 if (e.edit_dist < c->h_fusions.back().edit_dist) c->h_fusions.back().edit_dist = e.edit_dist;
             } else c->h_fusions.push_back(e);
+        }
         }
     }
     if (n_fusions) *n_fusions = (int64_t)c->h_fusions.size();
