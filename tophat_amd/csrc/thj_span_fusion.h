@@ -85,6 +85,18 @@ THJ_HD int g_code(const Genome& g, uint32_t ref_id, int64_t pos) {   // Dna5 of 
     return plane_code(g_fetch(g, ref_id, pos), 0);
 }
 THJ_HD int g_code_rc(const Genome& g, uint32_t ref_id, int64_t pos) { return f_comp(g_code(g, ref_id, pos)); }
+// The same through a one-block cache, for the passes that walk a whole alignment base by base (check_editdist_consistency,
+// bowtie_sam_extra): g_code costs two table look-ups and six plane loads per base, the cache one block fetch per 64 bases.
+struct GCache { uint32_t ref; int32_t clen; int64_t base; Planes p; };
+THJ_HD void gc_init(GCache& c) { c.ref = 0; c.clen = 0; c.base = -1; c.p.lo = c.p.hi = c.p.nm = 0; }
+THJ_HD int g_code_c(const Genome& g, GCache& c, uint32_t ref_id, int64_t pos) {
+    if (ref_id != c.ref) { c.ref = ref_id; c.clen = g_len(g, ref_id); c.base = -1; }
+    if (pos < 0 || pos >= (int64_t)c.clen) return 4;
+    const int64_t b = pos & ~(int64_t)63;
+    if (b != c.base) { c.base = b; c.p = g_fetch(g, ref_id, b); }
+    return plane_code(c.p, (int)(pos - b));
+}
+THJ_HD int g_code_rc_c(const Genome& g, GCache& c, uint32_t ref_id, int64_t pos) { return f_comp(g_code_c(g, c, ref_id, pos)); }
 
 THJ_HD int f_right(const FHit& h) {                                  // bwt_map.h:213-243
     int r = h.left;
@@ -196,6 +208,7 @@ THJ_HD void f_reverse_if_needed(FHit& h) {                           // :1985-19
 
 // check_editdist_consistency, bwt_map.cpp:2349-2465
 THJ_HD bool f_check_editdist(const Genome& g, const FRead& rd, const FHit& h) {
+    GCache gcache; gc_init(gcache);
     if (g_len(g, h.ref_id) == 0 || g_len(g, h.ref_id2) == 0) return false;
     uint32_t ref = h.ref_id;
     int pos_seq = 0, mismatch = 0, n_mism = 0;
@@ -206,7 +219,7 @@ THJ_HD bool f_check_editdist(const Genome& g, const FRead& rd, const FHit& h) {
         if (op == OP_MATCH || op == OP_mATCH) {
             for (int j = 0; j < len; ++j) {
                 int s = f_seq_code(rd, h, pos_seq); if (s > 4) s = 4;
-                const int r = op == OP_MATCH ? g_code(g, ref, pos_ref + j) : g_code_rc(g, ref, pos_ref - j);
+                const int r = op == OP_MATCH ? g_code_c(g, gcache, ref, pos_ref + j) : g_code_rc_c(g, gcache, ref, pos_ref - j);
                 if (s != r) ++mismatch;
                 if (s == r && s == 4) ++n_mism;
                 ++pos_seq;
@@ -666,6 +679,7 @@ THJ_HD bool fhit_eq(const FHit& a, const FHit& b) {                    // bwt_ma
 // bowtie_sam_extra, bwt_map.cpp:2467-2648, on a hit that may run down the genome and change contigs.  h.pad0: the hit's
 // quality string is the read's reversed.
 THJ_HD void f_sam_extra(const Genome& g, const Params& p, const FRead& rd, const FHit& h, Extras& e) {
+    GCache gcache; gc_init(gcache);
     int pos_seq = 0, pos_mm = 0, mismatch = 0, opens = 0, conts = 0, AS = 0;
     int64_t pos_ref = h.left;
     uint32_t ref = h.ref_id;
@@ -678,7 +692,7 @@ THJ_HD void f_sam_extra(const Genome& g, const Params& p, const FRead& rd, const
         const int op = cig_op(h.c[i]); const int len = (int)cig_len(h.c[i]);
         if (op == OP_MATCH || op == OP_mATCH) {
             for (int j = 0; j < len; ++j) {
-                const int r = op == OP_MATCH ? g_code(g, ref, pos_ref + j) : g_code_rc(g, ref, pos_ref - j);
+                const int r = op == OP_MATCH ? g_code_c(g, gcache, ref, pos_ref + j) : g_code_rc_c(g, gcache, ref, pos_ref - j);
                 int s = f_seq_code(rd, h, pos_seq); if (s > 4) s = 4;
                 if (s != r) {
                     ++mismatch;
