@@ -822,7 +822,9 @@ THJ_HD void detect_fusion(const Genome& g, const Params& p, const u64* rp, int W
     }
 }
 
-template <class Sink>
+// DEFER: the pair is handed to sink.defer() instead of running detect_fusion here (the device kernel queues such pairs -- a few
+// per hundred reads -- and runs them densely; see thj_k_fusion)
+template <bool DEFER = false, class Sink>
 THJ_HD void fusion_pair(const Genome& g, const Params& p, const u64* rp, int W, int rl, Hit lh, Hit rh, Sink& sink) {
     if (sink.ignored(lh.ref_id) || sink.ignored(rh.ref_id)) return;          // --fusion-ignore-chromosomes (:3214-3231)
     if (p.bowtie2 && hit_ed(lh) + hit_ed(rh) > (p.segment_mismatches << 1)) return;      // :3222-3226
@@ -837,11 +839,12 @@ THJ_HD void fusion_pair(const Genome& g, const Params& p, const u64* rp, int W, 
         if (hit_anti(lh)) { Hit t = lh; lh = rh; rh = t; rc = true; }           // :3266-3274
     } else if (!hit_anti(lh) && hit_anti(rh)) dir = FUS_FR;
     else dir = FUS_RF;
-    detect_fusion(g, p, rp, W, rl, rc, lh, rh, dir, sink);
+    if constexpr (DEFER) sink.defer(rc, lh, rh, dir);
+    else detect_fusion(g, p, rp, W, rl, rc, lh, rh, dir, sink);
 }
 
 // find_fusions for one read (all visited reads, incl. top == 0)
-template <class Sink>
+template <bool DEFER = false, class Sink>
 THJ_HD void fusion_read(const Genome& g, const Params& p, const ReadView& v, Sink& sink) {
     if (v.nseg == 0) return;
     int last = v.nseg - 1;
@@ -864,7 +867,7 @@ THJ_HD void fusion_read(const Genome& g, const Params& p, const ReadView& v, Sin
     }
     // pairs with the real hits of the last segment
     for (uint32_t i = l0; i < l1; ++i)
-        for (uint32_t j = r0; j < r1; ++j) fusion_pair(g, p, v.rp, v.W, v.rl, v.hits[i], v.hits[j], sink);
+        for (uint32_t j = r0; j < r1; ++j) fusion_pair<DEFER>(g, p, v.rp, v.W, v.rl, v.hits[i], v.hits[j], sink);
     // mate-anchored pseudo-hits (:3117-3202): every one of them is then paired with every left hit
     if (check_partner && v.n_mate > 0) {
         const int minus_dist = -p.max_insertion_length * 2;
@@ -896,7 +899,7 @@ THJ_HD void fusion_read(const Genome& g, const Params& p, const ReadView& v, Sin
                     if (pos < 0) continue;
                     Hit ph; ph.ref_id = rh.ref_id; ph.left = (int32_t)(left + pos); ph.right = ph.left + cl;
                     ph.meta = (k == 0 ? 2u : 3u) | ((uint32_t)cl << 24);
-                    for (uint32_t i = l0; i < l1; ++i) fusion_pair(g, p, v.rp, v.W, v.rl, v.hits[i], ph, sink);
+                    for (uint32_t i = l0; i < l1; ++i) fusion_pair<DEFER>(g, p, v.rp, v.W, v.rl, v.hits[i], ph, sink);
                 }
             }
         }
