@@ -61,12 +61,13 @@ inline int run_with_handoff(int argc, char** argv, int (*body)(int, char**)) {
     int fd[2];
     if (getenv("THJ_NO_HANDOFF") || pipe(fd) != 0) return body(argc, argv);
     fflush(nullptr);
+    const pid_t self = getpid();
     const pid_t pid = fork();
     if (pid < 0) { close(fd[0]); close(fd[1]); return body(argc, argv); }
     if (pid == 0) {
         close(fd[0]);
         prctl(PR_SET_PDEATHSIG, SIGKILL);                 // never outlive the process the caller knows about, except to finish dying
-        if (getppid() == 1) _exit(1);
+        if (getppid() != self) _exit(1);                  // the parent went away before the line above took effect
         handoff_fd() = fd[1];
         const int rc = body(argc, argv);
         fflush(nullptr);
