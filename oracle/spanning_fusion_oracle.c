@@ -964,7 +964,7 @@ static void sam_extra(const fctx* c, const BH* bh, orc_faln* o)
     size_t pos_seq = 0, pos_mismatch = 0, mismatch = 0, opens = 0, conts = 0;
     int64_t pos_ref = bh->left;
     int AS = 0, saw_fusion = 0;
-    char md[640]; int ml = 0;
+    char md[2048]; int ml = 0;
     const int qual_len = bh->seq_len;
     for (int i = 0; i < bh->n; ++i) {
         int op = ORC_CIG_OP(bh->cig[i]);
@@ -990,7 +990,7 @@ static void sam_extra(const fctx* c, const BH* bh, orc_faln* o)
                     ++pos_mismatch;
                 }
                 ++pos_seq;
-                if (ml > 500) break;
+                if (ml > 1900) break;
             }
             if (op == ORC_MATCH) pos_ref += len; else pos_ref -= len;
         } else if (op == ORC_INS || op == ORC_iNS) {
@@ -1013,12 +1013,13 @@ static void sam_extra(const fctx* c, const BH* bh, orc_faln* o)
             pos_ref = len;
             saw_fusion = 1;
         }
-        if (ml > 500) break;
+        if (ml > 1900) break;
     }
     ml += sprintf(md + ml, "%d", (int)pos_mismatch);
     md[ml] = 0;
     o->AS = AS; o->XM = (int)mismatch; o->XO = (int)opens; o->XG = (int)conts;
-    strncpy(o->md, md, sizeof o->md - 1); o->md[sizeof o->md - 1] = 0;
+    if (ml < (int)sizeof o->md) strcpy(o->md, md);
+    else snprintf(o->md, sizeof o->md, "\x01%lld", (long long)orc_long_md_put(md));
 }
 
 int orc_spanning_batch_fusion(const orc_span_params* p, int fusion_search, int fusion_min_dist, const orc_genome* g, const orc_span_batch* b,

@@ -529,7 +529,7 @@ static void sam_extra(const sctx* c, const BH* bh, const char* qual, int qual_le
     size_t pos_seq = 0, pos_mismatch = 0, mismatch = 0, opens = 0, conts = 0;
     int64_t pos_ref = bh->left;
     int AS = 0;
-    char md[512]; int ml = 0;
+    char md[2048]; int ml = 0;
     for (int i = 0; i < bh->n; ++i) {
         int op = ORC_CIG_OP(bh->cig[i]);
         uint32_t len = ORC_CIG_LEN(bh->cig[i]);
@@ -568,12 +568,13 @@ static void sam_extra(const sctx* c, const BH* bh, const char* qual, int qual_le
             pos_ref += len;
             pos_mismatch = 0;
         } else if (op == ORC_REF_SKIP) pos_ref += len;
-        if (ml > 400) break;
+        if (ml > 1900) break;
     }
     ml += sprintf(md + ml, "%d", (int)pos_mismatch);
     md[ml] = 0;
     o->AS = AS; o->XM = (int)mismatch; o->XO = (int)opens; o->XG = (int)conts;
-    strncpy(o->md, md, sizeof o->md - 1); o->md[sizeof o->md - 1] = 0;
+    if (ml < (int)sizeof o->md) strcpy(o->md, md);
+    else snprintf(o->md, sizeof o->md, "\x01%lld", (long long)orc_long_md_put(md));
 }
 
 int orc_spanning_batch(const orc_span_params* p, const orc_genome* g, const orc_span_batch* b,
@@ -669,3 +670,18 @@ int orc_spanning_batch(const orc_span_params* p, const orc_genome* g, const orc_
 }
 
 void orc_free(void* p) { free(p); }
+
+/* per-thread pool for the MD strings that do not fit a record (see thj_oracle.h) */
+static __thread char* lmd_pool = NULL;
+static __thread size_t lmd_n = 0, lmd_cap = 0;
+void orc_long_md_reset(void) { lmd_n = 0; }
+int64_t orc_long_md_put(const char* s)
+{
+    size_t l = strlen(s) + 1;
+    if (lmd_n + l > lmd_cap) { lmd_cap = (lmd_n + l) * 2 + 4096; lmd_pool = (char*)realloc(lmd_pool, lmd_cap); }
+    memcpy(lmd_pool + lmd_n, s, l);
+    int64_t off = (int64_t)lmd_n;
+    lmd_n += l;
+    return off;
+}
+const char* orc_long_md(int64_t off) { return (off >= 0 && (size_t)off < lmd_n) ? lmd_pool + off : ""; }

@@ -227,6 +227,11 @@ int orc_spanning_batch(const orc_span_params* p, const orc_genome* g, const orc_
                        const orc_junction* juncs, int64_t n_juncs, const orc_ins_in* ins, int64_t n_ins,
                        orc_aln** out, int64_t* n_out);
 void orc_free(void* p);
+/* An MD string that does not fit a record's md field goes to a per-thread pool; the field then holds "\x01<offset>".
+ * (Adversarial test batches only: a real alignment's MD is a few dozen characters.) */
+void orc_long_md_reset(void);
+int64_t orc_long_md_put(const char* s);
+const char* orc_long_md(int64_t off);
 
 /* ---- the same with the fusion branches (spanning_fusion_oracle.c): --fusion-search of long_spanning_reads.
  * fusions = the .fusions list (long_spanning_reads.cpp:2998-3040) sorted by Fusion::operator< (fusions.h:44-71), dir = ORC_FUSION_*. */

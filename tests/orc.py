@@ -133,6 +133,15 @@ class OrcAln(C.Structure):
                 ("AS", C.c_int32), ("XM", C.c_int32), ("XO", C.c_int32), ("XG", C.c_int32), ("md", C.c_char * 96)]
 
 
+def _md(lib, raw: bytes) -> str:
+    """a record's MD: in the record, or -- longer than its field -- in the oracle's per-thread pool (thj_oracle.h)"""
+    if raw[:1] != b"\x01":
+        return raw.decode()
+    lib.orc_long_md.restype = C.c_char_p
+    lib.orc_long_md.argtypes = [C.c_int64]
+    return lib.orc_long_md(int(raw[1:])).decode()
+
+
 def spanning(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> list:
     """-> list of tophat_amd.batch.Aln in output order"""
     from tophat_amd.batch import Aln
@@ -152,6 +161,7 @@ def spanning(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> list:
         ins[k].ref_id, ins[k].left, ins[k].seq = ref, left, seq.encode()
     out = C.POINTER(OrcAln)()
     n_out = C.c_int64()
+    lib.orc_long_md_reset()
     rc = lib.orc_spanning_batch(C.byref(op), C.byref(g.c), C.byref(ob), C.c_void_p(j.ctypes.data), C.c_int64(len(j)),
                                 ins, C.c_int64(len(insertions)), C.byref(out), C.byref(n_out))
     assert rc == 0
@@ -159,7 +169,7 @@ def spanning(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> list:
     for k in range(n_out.value):
         a = out[k]
         res.append(Aln(a.read_idx, a.ref_id, a.left, bool(a.antisense), bool(a.antisense_splice), a.mismatches, a.edit_dist,
-                       tuple(a.cigar[i] for i in range(a.n_cigar)), a.AS, a.XM, a.XO, a.XG, a.md.decode()))
+                       tuple(a.cigar[i] for i in range(a.n_cigar)), a.AS, a.XM, a.XO, a.XG, _md(lib, a.md)))
     lib.orc_free(out)
     return res
 
@@ -206,6 +216,7 @@ def spanning_fusion(p: Params, g: Genome, b, juncs: np.ndarray, insertions, fusi
     f = np.ascontiguousarray(fusions, dtype=SPAN_FUSION_DTYPE)
     out = C.POINTER(OrcFAln)()
     n_out = C.c_int64()
+    lib.orc_long_md_reset()
     rc = lib.orc_spanning_batch_fusion(C.byref(op), C.c_int(1 if fusion_search else 0), C.c_int(int(p.fusion_min_dist)), C.byref(g.c),
                                        C.byref(ob), C.c_void_p(j.ctypes.data), C.c_int64(len(j)), ins, C.c_int64(len(insertions)),
                                        C.c_void_p(f.ctypes.data), C.c_int64(len(f)), C.byref(out), C.byref(n_out))
@@ -216,7 +227,7 @@ def spanning_fusion(p: Params, g: Genome, b, juncs: np.ndarray, insertions, fusi
         cig = tuple(a.cigar[i] for i in range(a.n_cigar))
         fused = any((c >> 28) in (7, 8, 9, 10) for c in cig)
         res.append(Aln(a.read_idx, a.ref_id, a.left, bool(a.antisense), bool(a.antisense_splice), a.mismatches, a.edit_dist,
-                       cig, a.AS, a.XM, a.XO, a.XG, a.md.decode(), a.ref_id2 if fused else 0))
+                       cig, a.AS, a.XM, a.XO, a.XG, _md(lib, a.md), a.ref_id2 if fused else 0))
     lib.orc_free(out)
     return res
 
@@ -240,6 +251,7 @@ def spanning_count(p: Params, g: Genome, b, juncs: np.ndarray, insertions) -> in
         ins[k].ref_id, ins[k].left, ins[k].seq = ref, left, seq.encode()
     out = C.POINTER(OrcAln)()
     n_out = C.c_int64()
+    lib.orc_long_md_reset()
     rc = lib.orc_spanning_batch(C.byref(op), C.byref(g.c), C.byref(ob), C.c_void_p(j.ctypes.data), C.c_int64(len(j)),
                                 ins, C.c_int64(len(insertions)), C.byref(out), C.byref(n_out))
     assert rc == 0
