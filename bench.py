@@ -262,6 +262,9 @@ def spawn_ranks(args):
     sys.exit(rc)
 
 
+_E2E_EARLY = None
+
+
 def main():
     args = parse_args()
     if not torch.cuda.is_available():
@@ -298,6 +301,12 @@ def main():
         if torch.cuda.device_count() < args.gpus:
             raise SystemExit("--gpus %d asked for, %d visible" % (args.gpus, torch.cuda.device_count()))
         spawn_ranks(args)
+    # the files-in -> files-out leg first, while this process holds nothing: run after the resident-data bench (a context with
+    # tens of GB of device memory, the workload's host arrays and the oracle's records still allocated) the same executables
+    # took ~30 % longer
+    global _E2E_EARLY
+    if args.e2e_pairs > 0 and args.read_len == 100 and args.genome == "chr20":
+        _E2E_EARLY = e2e_leg(args)
     result = run_rank(args, 0, 1, 0, None, None)
     finish_stdout(result)
 
@@ -719,8 +728,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
                                     "sample": "the same %d pairs in %d chunks on %d threads: segment_juncs %.1f s + long_spanning_reads %.1f s, %d records" % (
                                         m, len(chunks), C, t5 - t4, t6 - t5, n_rec2)}
                 del pre
-        e2e = None
-        if args.e2e_pairs > 0 and world == 1 and args.read_len == 100 and args.genome == "chr20":
+        e2e = _E2E_EARLY
+        if e2e is None and args.e2e_pairs > 0 and world == 1 and args.read_len == 100 and args.genome == "chr20":
             e2e = e2e_leg(args)
         result = {
             "metric": "paired reads/sec through segment_juncs+long_spanning_reads; junctions.bed diff=0",

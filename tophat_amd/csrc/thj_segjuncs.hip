@@ -250,6 +250,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
     if (tid == 0) { q_n = 0; s_nresc = 0; }
     EventSink ev{g, t};
     const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    unsigned int my_hits = 0, my_windows = 0, my_indels = 0;     // statistics: per thread, added to LDS once at the end
     const int n_tiles = (b.n_reads + TPB - 1) / TPB;
     // consecutive tiles go to consecutive workgroups (-> different XCDs): every XCD's L2
     // streams its own contiguous slices of the hit array, the genome lines are shared by L3.
@@ -274,18 +275,28 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
         const Hit* tile_hits = staged ? (const Hit*)s_hits : b.hits;
         if (THJ_EXPF(1 << 20)) continue;
         // ---- classify
+        bool to_work = false, to_rescue = false;
         if (tid < tile_reads) {
             ReadView v = make_view(b, r0 + tid);
             v.so = s_so + tid * b.nseg;
             v.hits = tile_hits;
-            const unsigned int nh = v.so[v.nseg] - v.so[0];
-            if (nh) atomicAdd(&s_stat[2], nh);
+            my_hits += v.so[v.nseg] - v.so[0];                // summed per thread, one LDS add at the end of the kernel
             if (!read_is_trivial(p, v)) {
                 bool wants = false;
-                if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants)
-                    rl.list[(size_t)blockIdx.x * rl.seg_cap + atomicAdd(&s_nresc, 1u)] = (uint32_t)(r0 + tid);
-                else s_work[atomicAdd(&s_nwork, 1u)] = (uint32_t)tid;
+                if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants) to_rescue = true;
+                else to_work = true;
             }
+        }
+        {   // positions in the work list / the rescue slice: one LDS atomic per wave and list, not one per read (a third of the
+            // lanes would otherwise queue on the same LDS address)
+            const unsigned long long mw = __ballot(to_work), mr = __ballot(to_rescue);
+            const int lane = tid & 63;
+            const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+            unsigned int bw = 0, br = 0;
+            if (lane == 0) { if (mw) bw = atomicAdd(&s_nwork, (unsigned int)__popcll(mw)); if (mr) br = atomicAdd(&s_nresc, (unsigned int)__popcll(mr)); }
+            bw = __shfl(bw, 0); br = __shfl(br, 0);
+            if (to_work) s_work[bw + (unsigned int)__popcll(mw & below)] = (uint32_t)tid;
+            if (to_rescue) rl.list[(size_t)blockIdx.x * rl.seg_cap + br + (unsigned int)__popcll(mr & below)] = (uint32_t)(r0 + tid);
         }
         __syncthreads();
         if (THJ_EXPF(1 << 21)) continue;
@@ -305,8 +316,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             bool wants = false;
             do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants);
             if (do_gaps) gaps_enumerate(p, v, qs);
-            if (qs.n_windows) atomicAdd(&s_stat[0], qs.n_windows);
-            if (qs.n_indels) atomicAdd(&s_stat[1], qs.n_indels);
+            my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
         __syncthreads();
         if (q_n > (unsigned)QCAP) {
@@ -323,6 +333,9 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
         }
         run_tasks<WIDE>(g, p, b, ev, tq, tile + (int)gridDim.x >= n_tiles);
     }
+    if (my_hits) atomicAdd(&s_stat[2], my_hits);
+    if (my_windows) atomicAdd(&s_stat[0], my_windows);
+    if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
     if (tid == 0) {
         rl.blk_cnt[blockIdx.x] = s_nresc;
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
     const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int per_round = gridDim.x * TPB;
     const unsigned int rounds = (total + per_round - 1) / per_round;
+    unsigned int my_pairs = 0, my_windows = 0, my_indels = 0;      // statistics: per thread, added to LDS once at the end
     for (unsigned int it = 0; it < rounds; ++it) {
         const unsigned int i = (it * gridDim.x + blockIdx.x) * TPB + tid;
         const bool active = i < total;
@@ -403,15 +417,14 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                             if (fits) { mine[2 * (l * v.n_mate + m)] = f; mine[2 * (l * v.n_mate + m) + 1] = rv; }
                             if (f == SLOT_BREAK) break;                  // the reference leaves the mate loop here (:3431-3450)
                         }
-                    if (local) atomicAdd(&s_stat[2], local);
+                    my_pairs += local;
                     v.rescue = true;
                     v.slots = fits ? mine : nullptr;
                     v.lazy_g = &s_g; v.lazy_p = &s_p;
                 }
                 if (!THJ_EXPF(1 << 23)) gaps_enumerate(p, v, qs);
             }
-            if (qs.n_windows) atomicAdd(&s_stat[0], qs.n_windows);
-            if (qs.n_indels) atomicAdd(&s_stat[1], qs.n_indels);
+            my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
         __syncthreads();
         if (q_n > (unsigned)QCAP) {
@@ -427,6 +440,9 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
         }
         run_tasks<WIDE>(g, p, b, ev, tq, it + 1 == rounds);
     }
+    if (my_pairs) atomicAdd(&s_stat[2], my_pairs);
+    if (my_windows) atomicAdd(&s_stat[0], my_windows);
+    if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
     if (tid == 0) {
         if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
