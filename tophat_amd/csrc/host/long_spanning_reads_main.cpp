@@ -12,6 +12,7 @@
 #include <deque>
 
 #include "thj_hostio.h"
+#include <sys/stat.h>
 
 using namespace thjh;
 
@@ -481,7 +482,21 @@ static int real_main(int argc, char** argv) {
         shards = plan(pos[1], segs, spliced_segs, parts);
         if ((int)shards.size() != parts) { shards.resize(1); shards[0] = Shard(); shards[0].seg_off.assign(segs.size(), 0); shards[0].spliced_off.assign(spliced_segs.size(), 0); parts = 1; }   // not enough data: one thread (:2992-2993)
     }
-    if (parts == 1) shards = plan(pos[1], segs, spliced_segs, getenv("THJ_SHARDS") ? atoi(getenv("THJ_SHARDS")) : 4 * workers);
+    if (parts == 1) {
+        // shards of ~24 MB of compressed input (~160 k reads of 100 bases with four segment maps): measured best for the pipeline below --
+        // 48 shards for 8 M pairs, 64 for 10 M (1.32 -> 1.10 s per side there) -- and at least four per host worker
+        int n_shards = 4 * workers;
+        if (getenv("THJ_SHARDS")) n_shards = atoi(getenv("THJ_SHARDS"));
+        else {
+            uint64_t bytes = 0;
+            struct stat st;
+            for (auto& f : segs) if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size;
+            if (stat(pos[1].c_str(), &st) == 0) bytes += (uint64_t)st.st_size;
+            const uint64_t by_size = bytes / (24ull << 20);
+            if (by_size > (uint64_t)n_shards) n_shards = (int)std::min<uint64_t>(by_size, 4096);
+        }
+        shards = plan(pos[1], segs, spliced_segs, n_shards);
+    }
     const size_t S = shards.size();
     fprintf(stderr, "\t%d read-id shard%s, %d host CPUs, %d GPU context%s\n", (int)S, S > 1 ? "s" : "", hw, n_gpus, n_gpus > 1 ? "s" : "");
 
@@ -626,12 +641,15 @@ static int real_main(int argc, char** argv) {
                             if (thj_span_reset_async(ctx)) die("Error: %s\n", thj_last_error());
                             if (thj_span_run_async(ctx, &o.p, dev)) die("Error: %s\n", thj_last_error());
                             const int frc = thj_span_finish(ctx, &na);
-                            if (frc == THJ_ERETRY && attempt < 4) continue;
+                            if (frc == THJ_ERETRY && attempt < 4) { trace(k, "stitch_retry"); continue; }
                             if (frc) die("Error: %s\n", thj_last_error());
                             break;
                         }
+                        trace(k, "stitch_finished");
                         alns.resize((size_t)na);
+                        trace(k, "stitch_resized");
                         if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
+                        trace(k, "stitch_downloaded");
                         if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
                         g_work.add(2, td);
                         trace(k, "stitch_end");
