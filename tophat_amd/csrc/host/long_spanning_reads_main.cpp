@@ -322,7 +322,9 @@ static int real_main(int argc, char** argv) {
         // copies and stream round trips then overlap another shard's kernels on the same GPU
         // (default: 2 on a single GPU -- measured 2.4 -> 2.0 s for segment_juncs on 8 M pairs -- and 1 per device on several: a
         // communicator is either all-RCCL or all-loopback)
-        int per = getenv("THJ_CTX_PER_GPU") ? atoi(getenv("THJ_CTX_PER_GPU")) : (n_dev > 1 ? 1 : THJ_DEFAULT_CTX_PER_GPU);
+        // (three here: a shard's inflate launch is ~1500 members, a quarter of what the GPU holds, so three contexts' launches overlap:
+        // 1.22 -> 1.09 s per side on 10 M pairs; segment_juncs, with ten times larger shards, keeps two)
+        int per = getenv("THJ_CTX_PER_GPU") ? atoi(getenv("THJ_CTX_PER_GPU")) : (n_dev > 1 ? 1 : 3);
         if (n_dev > 1) per = 1;
         if (per < 1) per = 1;
         if (per > 8) per = 8;
