@@ -455,9 +455,13 @@ int thj_ingest_span_hits(thj_ctx* ctx, const thj_params* p, int32_t nseg, const 
                          thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows);
 /* The same with the shard's piece of the READS file (unaligned BAM, id-sorted) riding along: its members are inflated and its
  * records located with the maps', the batch leaves complete (read planes, lengths and quality strings written on the device:
- * no thj_span_batch_attach_reads), and the inflated read records come back for the BAM output -- *reads_infl (HOST, malloc'd:
- * free() it): reads_infl_bytes bytes, BGZF member m of the piece at m << 16; row_loc[r] (HOST, malloc'd) = (m << 16 | offset)
+ * no thj_span_batch_attach_reads), and the inflated read records come back for the BAM output -- *reads_infl (HOST, page-locked,
+ * from thj_pinned_alloc: thj_pinned_free() it): reads_infl_bytes bytes, BGZF member m of the piece at m << 16; row_loc[r] (HOST, malloc'd) = (m << 16 | offset)
  * of the block_size field of row r's record.  Replaces ReadStream::getRead per row (reads.cpp:528-630). */
+/* Page-locked host buffers from a pool of the process (locking pages is slow, copies from and to them are plain DMA): for what a
+ * caller hands to thj_ingest_* (thj_bam_piece.comp may point into one) and for what thj_ingest_span_batch hands back. */
+void* thj_pinned_alloc(size_t bytes);
+void thj_pinned_free(void* p);
 int thj_ingest_span_batch(thj_ctx* ctx, const thj_params* p, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* reads,
                           uint32_t begin_id, uint32_t end_id, thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows,
                           uint8_t** reads_infl, int64_t* reads_infl_bytes, uint32_t** row_loc);

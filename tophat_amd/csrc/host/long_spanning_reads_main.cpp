@@ -582,6 +582,21 @@ static int real_main(int argc, char** argv) {
             thj_span_batch* dev = nullptr; uint32_t* ids = nullptr; int64_t n = 0;
             uint8_t* rinfl = nullptr; int64_t rinfl_bytes = 0; uint32_t* rloc = nullptr;
             int rc;
+            // the shard's compressed pieces go into one page-locked buffer first -- here, beside the other feeders and outside the GPU's
+            // lock: from the mapped files the copy up runs through the runtime's staging buffers at ~3 GB/s while the pool keeps the
+            // CPUs busy, from page-locked memory it is DMA
+            thj_bam_piece rp = dev_reads ? reads_bam.piece(sh.read_off, sh.read_end) : thj_bam_piece{};
+            uint8_t* stage = nullptr;
+            if (!getenv("THJ_NO_STAGING")) {
+                size_t total = dev_reads ? (size_t)rp.comp_bytes : 0;
+                for (auto& pc : segp) total += (size_t)pc.comp_bytes;
+                stage = (uint8_t*)thj_pinned_alloc(total + 64);
+                if (stage) {
+                    size_t at = 0;
+                    for (auto& pc : segp) { if (pc.comp_bytes) memcpy(stage + at, pc.comp, (size_t)pc.comp_bytes); pc.comp = stage + at; at += (size_t)pc.comp_bytes; }
+                    if (dev_reads) { if (rp.comp_bytes) memcpy(stage + at, rp.comp, (size_t)rp.comp_bytes); rp.comp = stage + at; }
+                }
+            }
             {
                 const long long tw = WorkClock::now();
                 std::lock_guard<std::mutex> lk(gpu.mu);
@@ -589,13 +604,13 @@ static int real_main(int argc, char** argv) {
                 trace(k, "ingest_begin");
                 const long long td = WorkClock::now();
                 if (dev_reads) {
-                    const thj_bam_piece rp = reads_bam.piece(sh.read_off, sh.read_end);
                     rc = thj_ingest_span_batch(device_ready(gpu), &o.p, nseg, segp.data(), &rp, b_id, e_id, &dev, &ids, &n, &rinfl, &rinfl_bytes, &rloc);
                 } else
                     rc = thj_ingest_span_hits(device_ready(gpu), &o.p, nseg, segp.data(), b_id, e_id, &dev, &ids, &n);
                 g_work.add(2, td);
                 trace(k, "ingest_end");
             }
+            thj_pinned_free(stage);
             if (rc == THJ_OK) {
                 if (dev) {
                     std::vector<Read> batch_rd((size_t)n);
@@ -661,7 +676,7 @@ static int real_main(int argc, char** argv) {
                         const long long te = WorkClock::now();
                         encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
                         g_work.add(3, te);
-                        free(rinfl);
+                        thj_pinned_free(rinfl);
                         bws[k]->write_encoded(e);
                     } else {
                         // the CPU part of the shard goes to the pool; this feeder moves on to the next shard's device work
@@ -672,7 +687,7 @@ static int real_main(int argc, char** argv) {
                             encode_batch(*bws[0], rt, job->first, job->second, 1, e);
                             g_work.add(3, te);
                             trace(k, "encoded");
-                            free(rinfl);
+                            thj_pinned_free(rinfl);
                             job->first = std::vector<thj_aln>(); job->second = std::vector<Read>();
                             on_encoded(k, std::move(e));
                         });

@@ -17,9 +17,13 @@
 #include <cstdint>
 #include <cstring>
 #include <vector>
+#include <mutex>
 
 #include "../../include/thj.h"
 #include "thj_ctx.h"
+
+extern "C" void* thj_pinned_alloc(size_t bytes);
+extern "C" void thj_pinned_free(void* p);
 
 namespace ing {
 
@@ -1311,7 +1315,7 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
     }
     pc.mark(6);
     uint32_t* h_loc = nullptr; uint8_t* h_infl = nullptr;
-    auto fail2 = [&](int code) { free(h_ids); free(h_loc); free(h_infl); return fail(code); };
+    auto fail2 = [&](int code) { free(h_ids); free(h_loc); thj_pinned_free(h_infl); return fail(code); };
     if (reads) {
         // the reads of the rows: planes / lengths / quality strings straight from the BAM records, where the kernels will read them
         int W = (tp->segment_length * (nseg + 1) - 1 + 63) / 64;
@@ -1331,7 +1335,7 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
         hipLaunchKernelGGL(thj_k_check_seen, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, seen, n_rows, P.status);
         h_loc = (uint32_t*)malloc((size_t)n_rows * 4);
         const size_t ib = (size_t)P.file_blocks[(size_t)f_reads] << 16;
-        h_infl = (uint8_t*)malloc(ib ? ib : 16);
+        h_infl = (uint8_t*)thj_pinned_alloc(ib ? ib : 16);
         if (!h_loc || !h_infl) return fail2(THJ_ENOMEM);
         unsigned int h_status[16];
         ING_HIP(hipMemcpyAsync(h_loc, d_loc, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1353,6 +1357,42 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
     *out = &ob->desc; *row_ids = h_ids; *n_rows_out = n_rows;
     return THJ_OK;
 }
+
+// ---- page-locked host buffers, pooled for the process.  Copies to and from pageable memory go through the runtime's staging
+// buffers on one thread (measured in long_spanning_reads with its CPUs busy encoding: 2.9 GB/s up, 6 GB/s down, half of a
+// shard's time under the GPU's lock); from page-locked memory they are plain DMA.  Locking pages costs ~0.2 ms per MB, so
+// buffers are kept and handed out again.
+namespace {
+struct PinnedPool {
+    struct Blk { void* p; size_t cap; bool used; bool pinned; };
+    std::mutex mu; std::vector<Blk> blks; size_t bytes = 0;
+    void* get(size_t n) {
+        if (n < 4096) n = 4096;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (size_t i = 0; i < blks.size(); ++i)
+                if (!blks[i].used && blks[i].cap >= n && blks[i].cap <= 2 * n + (1 << 20) && (best < 0 || blks[i].cap < blks[(size_t)best].cap)) best = (int)i;
+            if (best >= 0) { blks[(size_t)best].used = true; return blks[(size_t)best].p; }
+        }
+        const size_t cap = n + n / 8;
+        void* p = nullptr; bool pinned = true;
+        if (bytes > ((size_t)24 << 30) || hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) { (void)hipGetLastError(); p = malloc(cap); pinned = false; }
+        if (!p) return nullptr;
+        std::lock_guard<std::mutex> lk(mu);
+        blks.push_back({p, cap, true, pinned}); bytes += cap;
+        return p;
+    }
+    void put(void* p) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& b : blks) if (b.p == p) { b.used = false; return; }
+    }
+};
+PinnedPool& pinned_pool() { static PinnedPool* pp = new PinnedPool(); return *pp; }      // never destroyed: the process leaves with _exit
+}  // namespace
+extern "C" void* thj_pinned_alloc(size_t bytes) { return pinned_pool().get(bytes); }
+extern "C" void thj_pinned_free(void* p) { pinned_pool().put(p); }
 
 extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
                                     thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out) {
