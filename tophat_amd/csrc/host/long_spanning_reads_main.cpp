@@ -263,9 +263,8 @@ static void encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a
     sizes.push_back((uint32_t)(d.size() - before)); rids.push_back(rid);
 }
 
-static void encode_batch(const BamWriter& bw, const RefTable& rt, const std::vector<thj_aln>& alns, const std::vector<Read>& reads, int threads,
+static void encode_batch(const BamWriter& bw, const RefTable& rt, const thj_aln* alns, const size_t n, const std::vector<Read>& reads, int threads,
                          BamWriter::Encoded& e) {
-    const size_t n = alns.size();
     int T = threads;
     if ((size_t)T > n / 256 + 1) T = (int)(n / 256 + 1);
     std::vector<std::vector<uint8_t>> part((size_t)T);
@@ -645,6 +644,7 @@ static int real_main(int argc, char** argv) {
                     for (int64_t r = 0; r < n; ++r) memcpy(q.data() + (size_t)r * stride, quals.data() + read_off[(size_t)r], (size_t)(read_off[(size_t)r + 1] - read_off[(size_t)r]));
                     }
                     std::vector<thj_aln> alns;
+                    thj_aln* alns_pinned = nullptr; int64_t n_alns = 0;       // one output file: the records come down into a page-locked buffer
                     {
                         const long long tw = WorkClock::now();
                         std::lock_guard<std::mutex> lk(gpu.mu);
@@ -663,9 +663,11 @@ static int real_main(int argc, char** argv) {
                             break;
                         }
                         trace(k, "stitch_finished");
-                        alns.resize((size_t)na);
+                        n_alns = na;
+                        if (parts == 1) { alns_pinned = (thj_aln*)thj_pinned_alloc((size_t)(na ? na : 1) * sizeof(thj_aln)); if (!alns_pinned) die("Error: out of memory\n"); }
+                        else alns.resize((size_t)na);
                         trace(k, "stitch_resized");
-                        if (na && thj_span_download(ctx, alns.data())) die("Error: %s\n", thj_last_error());
+                        if (na && thj_span_download(ctx, parts == 1 ? alns_pinned : alns.data())) die("Error: %s\n", thj_last_error());
                         trace(k, "stitch_downloaded");
                         if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
                         g_work.add(2, td);
@@ -674,21 +676,21 @@ static int real_main(int argc, char** argv) {
                     if (parts > 1) {
                         BamWriter::Encoded e;
                         const long long te = WorkClock::now();
-                        encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
+                        encode_batch(enc_bw, rt, alns.data(), alns.size(), batch_rd, enc_threads, e);
                         g_work.add(3, te);
                         thj_pinned_free(rinfl);
                         bws[k]->write_encoded(e);
                     } else {
                         // the CPU part of the shard goes to the pool; this feeder moves on to the next shard's device work
-                        auto job = std::make_shared<std::pair<std::vector<thj_aln>, std::vector<Read>>>(std::move(alns), std::move(batch_rd));
-                        pool.submit([&, k, job, rinfl] {
+                        auto job = std::make_shared<std::vector<Read>>(std::move(batch_rd));
+                        pool.submit([&, k, job, rinfl, alns_pinned, n_alns] {
                             BamWriter::Encoded e;
                             const long long te = WorkClock::now();
-                            encode_batch(*bws[0], rt, job->first, job->second, 1, e);
+                            encode_batch(*bws[0], rt, alns_pinned, (size_t)n_alns, *job, 1, e);
                             g_work.add(3, te);
                             trace(k, "encoded");
-                            thj_pinned_free(rinfl);
-                            job->first = std::vector<thj_aln>(); job->second = std::vector<Read>();
+                            thj_pinned_free(rinfl); thj_pinned_free(alns_pinned);
+                            *job = std::vector<Read>();
                             on_encoded(k, std::move(e));
                         });
                     }
@@ -754,7 +756,7 @@ static int real_main(int argc, char** argv) {
             }
             BamWriter::Encoded e;
             const long long te = WorkClock::now();
-            encode_batch(enc_bw, rt, alns, batch_rd, enc_threads, e);
+            encode_batch(enc_bw, rt, alns.data(), alns.size(), batch_rd, enc_threads, e);
             g_work.add(3, te);
             if (parts > 1) bws[k]->write_encoded(e);         // this part's own file
             else {                                           // one output file: the shard's batches gather, the planner takes whole shards
