@@ -47,6 +47,7 @@ namespace ing {
 static constexpr int WIN = THJ_INFLATE_WIN, WIN_MASK = WIN - 1, HALF = WIN / 2;
 static constexpr int INRING = THJ_INFLATE_INRING, IN_MASK = INRING - 1;
 static constexpr int LIT_BITS = 10, DIST_BITS = 8;
+static constexpr int NEAR_MAX = WIN - 40;             // longest match distance served from the LDS piece of the window (copies overshoot by < 32 bytes)
 
 struct Shared {
     uint8_t win[WIN];
@@ -282,16 +283,25 @@ __global__ __launch_bounds__(64, THJ_INFLATE_WAVES) void thj_k_inflate(const uin
                             const uint32_t dist = s.dbase[ds] + take(b, s.dext[ds]);
                             if (dist > outp || outp + (uint32_t)len > 65536u) { err = true; break; }
                             int k = 0;
-                            if (dist > (uint32_t)WIN - 8u) {                      // beyond the LDS window: from the flushed output (see out_limit)
+                            if (dist > (uint32_t)NEAR_MAX) {                      // beyond the LDS window: from the flushed output (see out_limit)
+                                // Half of all matches come this way with a 2 KiB window, and a global load is a ~1 us round trip for the one
+                                // decoding lane: 32 bytes are fetched per trip (four unaligned 64-bit loads in flight together), whatever the
+                                // match needs of them.  (The first version read eight bytes per trip and the last 1..7 bytes one trip each.)
+                                // Like the LDS copies below, a group may write past the match: up to 31 ring positions ahead of the output
+                                // pointer, which is why matches this close to the window's far edge (NEAR_MAX) are served from here.
                                 const uint8_t* gsrc = dst + outp - dist;
-                                for (; k + 8 <= len; k += 8) {
-                                    uint8_t t[8];
+                                for (; k < len; k += 32) {
+                                    uint64_t t[4];
 #pragma unroll
-                                    for (int q = 0; q < 8; ++q) t[q] = gsrc[k + q];
+                                    for (int q = 0; q < 4; ++q) __builtin_memcpy(&t[q], gsrc + k + 8 * q, 8);
 #pragma unroll
-                                    for (int q = 0; q < 8; ++q) s.win[(outp + (uint32_t)(k + q)) & WIN_MASK] = t[q];
+                                    for (int q = 0; q < 4; ++q) {
+                                        if (k + 8 * q >= len) break;
+                                        const uint32_t dp = (outp + (uint32_t)(k + 8 * q)) & WIN_MASK;
+                                        if (dp <= (uint32_t)WIN - 8u) __builtin_memcpy(&s.win[dp], &t[q], 8);
+                                        else for (int b8 = 0; b8 < 8; ++b8) s.win[(dp + (uint32_t)b8) & WIN_MASK] = (uint8_t)(t[q] >> (8 * b8));
+                                    }
                                 }
-                                for (; k < len; ++k) s.win[(outp + (uint32_t)k) & WIN_MASK] = gsrc[k];
                             } else {
                                 // Copies go eight bytes at a time through unaligned 64-bit LDS accesses (one ds_read_b64 + one ds_write_b64
                                 // per group instead of sixteen byte accesses with their address arithmetic: the decoder lane is bound by the
