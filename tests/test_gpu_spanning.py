@@ -138,3 +138,36 @@ def test_reads_with_more_joined_alignments_than_a_thread_keeps():
         wantf = orc.spanning_fusion(pf, orc.Genome([seq2]), sb2, nj, [], np.zeros(0, dtype=orc.SPAN_FUSION_DTYPE), True)
         assert len(wantf) == 30 * 10
         assert ctx.spanning(pf, [ctx.upload_span_batch(sb2)]) == wantf
+
+
+def test_more_records_per_read_than_the_count_byte_holds():
+    """300 records per read (single-segment reads with 300 hits each): the per-read record count the device keeps saturates at 255,
+    so the prefix sum thj_span_download compacts with does not add up to the pass's record count -- the kernel notices and the
+    download walks the slots on the host instead (span_download_host).  Every record, in order."""
+    from tophat_amd.batch import SPAN_HIT_DTYPE, SpanBatch
+    rng = np.random.default_rng(13)
+    copies, n_reads, rl = 300, 6, 25
+    unit = "".join(rng.choice(list("ACGT"), size=400))
+    flank = "".join(rng.choice(list("ACGT"), size=3000))
+    seq = flank + unit * copies + flank
+    hits, seg_off, bases, quals, read_off = [], [0], bytearray(), bytearray(), [0]
+    for r in range(n_reads):
+        off = int(rng.integers(0, 400 - rl))
+        n = copies if r % 2 == 0 else 3                  # every other read is an ordinary one
+        for c in range(n):
+            hits.append((1, 3000 + c * 400 + off, 2, 0, 0, 1, [(1 << 28) | rl, 0, 0, 0, 0]))
+        seg_off.append(len(hits))
+        bases += unit[off:off + rl].encode()
+        quals += b"I" * rl
+        read_off.append(len(bases))
+    sb = SpanBatch(1, np.arange(1, n_reads + 1, dtype=np.uint32), np.array(read_off, dtype=np.int64),
+                   np.frombuffer(bytes(bases), dtype=np.uint8).copy(), np.frombuffer(bytes(quals), dtype=np.uint8).copy(),
+                   np.array(seg_off, dtype=np.uint32), np.array(hits, dtype=SPAN_HIT_DTYPE))
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    p = Params(max_seg_multihits=400)
+    want = orc.spanning(p, orc.Genome([seq]), sb, nj, [])
+    assert len(want) == 3 * copies + 3 * 3
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        ctx.upload_span_sets(nj, [])
+        assert ctx.spanning(p, [ctx.upload_span_batch(sb)]) == want
