@@ -20,6 +20,7 @@
 #ifndef THJ_H
 #define THJ_H
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
