@@ -231,6 +231,9 @@ def parse_args():
     ap.add_argument("--fusion-frac", type=float, default=0.0, metavar="FRAC",
                     help="with --fusion-search: this fraction of the pairs gets a chimeric left read (configs[3]: 0.02); the step then "
                          "also runs segment_juncs' fusion kernel and hands its fusions to the spanning stage")
+    ap.add_argument("--indel-frac", type=float, default=0.0, metavar="FRAC",
+                    help="this fraction of the pairs gets a left read with a 1..3-base deletion near the end of a segment (found by the indel "
+                         "search of stage 1, closed with a D op in stage 2)")
     ap.add_argument("--no-hit-heads", action="store_true",
                     help="hand stage 2 the 32-byte hit records only, without the dense 16-byte head array every batch of the library carries "
                          "(thj_span_batch.hit_heads: derived once when a batch is made -- thj_span_batch_upload, the device-side ingest -- so "
@@ -459,7 +462,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     ctx.upload_genome(pg)
     w = make_device_workload(100 + rank, seqs, genes, None, args.pairs, dev, read_len=args.read_len, seg_len=25,
                              inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len, multi_frac=args.multihit_frac, dup_shift=dup_shift,
-                             fusion_frac=args.fusion_frac if args.fusion_search else 0.0)
+                             fusion_frac=args.fusion_frac if args.fusion_search else 0.0, indel_frac=args.indel_frac)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     max_intron = max(500000, args.intron_max + 1)
@@ -741,7 +744,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_text,
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
-                       "fusion_search": bool(args.fusion_search), "fusion_frac": args.fusion_frac, "fusions_found": n_fusions[0], "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
+                       "fusion_search": bool(args.fusion_search), "fusion_frac": args.fusion_frac, "indel_frac": args.indel_frac, "fusions_found": n_fusions[0], "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"), "traffic_low": dom.get("traffic_low"),

@@ -81,3 +81,36 @@ def test_scale_workload_with_fusion_pairs():
     # the reads that are not chimeric come out as they do without fusion search
     plain = orc.spanning(Params(), og, spb, juncs, ins)
     assert [a for a in want if a.read_idx not in fz] == [a for a in plain if a.read_idx not in fz]
+
+
+def test_scale_workload_with_deletion_reads():
+    """bench.py --indel-frac: left reads with a small deletion, on a segment boundary or inside a segment.  segment_juncs finds the
+    planted deletions, long_spanning_reads joins the reads through them (nD in the CIGAR) -- oracle and kernel logic agree."""
+    seqs, genes = make_scale_genome(1, [2_000_000], 1500, intron_max=4000, exon_len=300)
+    strs = [s.tobytes().decode() for s in seqs]
+    n = 4000
+    w = make_device_workload(9, seqs, genes, None, n, "cpu", exon_len=300, indel_frac=0.05)
+    dz = set(w["left"]["deletion_reads"].tolist())
+    truth = {tuple(int(v) for v in row) for row in w["left"]["deletions"].tolist()}
+    assert 120 < len(dz) < 300
+    og = orc.Genome(strs)
+    ev = None
+    for sd, side in (("left", 1), ("right", 2)):
+        p = Params(read_side=side, inner_dist_mean=50, inner_dist_std_dev=20)
+        sb = sample_segbatch(w[sd], n)
+        e = orc.segjuncs(p, og, sb)
+        assert_events_equal(sim.segjuncs(p, strs, sb), e)
+        ev = e if ev is None else merge_events(ev, e)
+    found = {(int(d["ref_id"]), int(d["left"]), int(d["right"])) for d in ev.deletions}
+    # a deletion inside a run of equal bases has several equivalent positions: compare by (contig, length, position within 3)
+    hit = sum(1 for (c, l, r) in truth if any((c, l + s, r + s) in found for s in range(-3, 4)))
+    assert hit > 0.7 * len(truth), (hit, len(truth), len(found))
+    juncs, ins = events_to_span_inputs(ev)
+    p = Params()
+    spb = sample_spanbatch(w["left"], n)
+    want = orc.spanning(p, og, spb, juncs, ins)
+    got, status = sim.spanning(p, strs, spb, juncs, ins)
+    assert status[1] == 0 and status[2] == 0
+    assert got == want
+    with_del = {a.read_idx for a in want if any((c >> 28) == 5 for c in a.cigar)}
+    assert len(with_del & dz) > 0.35 * len(dz), (len(with_del & dz), len(dz))      # not every planted deletion leaves mismatches to explain

@@ -504,7 +504,7 @@ def make_scale_genome(seed: int, contig_lens: Sequence[int], n_introns: int, int
 def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int, device, read_len: int = 100,
                          seg_len: int = 25, inner_mean: float = 50.0, inner_sd: float = 20.0, err: float = 0.01,
                          exon_len: int = 600, chunk: int = 1 << 20, multi_frac: float = 0.0, dup_shift: int = 0,
-                         fusion_frac: float = 0.0):
+                         fusion_frac: float = 0.0, indel_frac: float = 0.0):
     """Synthesises both sides of `n_pairs` paired reads directly as device-resident thj_seg_batch arrays
     (torch tensors).  Model: a fragment of 2*read_len + max(0, N(inner_mean, inner_sd)) bases drawn
     uniformly from a gene's two-exon transcript; left read = its first read_len bases (sense), right
@@ -519,6 +519,12 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
     segments are the start of one gene's first exon read forward, the rest comes from another gene's first exon (any contig),
     forward or reverse-complemented, the break exactly on a segment boundary -- every segment maps where its part lies, no
     full-read hit; the pair's right read is left as it was.  out["left"]["fusion_reads"] = their row numbers.
+    indel_frac > 0: that fraction of the pairs gets a LEFT read with a small deletion (1..3 reference bases missing from the read,
+    inside a gene's first exon), one to three bases before the end of a segment: that segment is placed ungapped in the frame
+    before the deletion with the mismatches its last bases then show (unmapped with more than two), the following segments
+    d bases further on -- the picture find_insertions_and_deletions works from (it records a deletion only where the split
+    alignment explains mismatches of the two hits, segment_juncs.cpp:2589-2627).  No full-read hit.
+    out["left"]["deletion_reads"] = their row numbers, out["left"]["deletions"] = (contig, left, right) rows.
     Returns {side: dict of tensors} with the field names of thj_seg_batch."""
     import torch
     g = torch.Generator(device=device)
@@ -685,6 +691,59 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
                 sh[fz, k, 4] = 0
                 sh[fz, k, 5] = 0
             fusion_rows = fz
+    deletion_rows = deletion_truth = None
+    if indel_frac > 0 and nseg >= 3:
+        pick = torch.rand(n_pairs, generator=g, device=device) < indel_frac
+        if fusion_rows is not None:
+            pick[fusion_rows] = False
+        dz = torch.nonzero(pick).squeeze(1)
+        nd = int(dz.shape[0])
+        if nd:
+            b = bufs["left"]
+            ga = genes_t[torch.randint(0, genes_t.shape[0], (nd,), generator=g, device=device)]
+            pa = ga[:, 1] + torch.randint(0, max(1, E - read_len - 4), (nd,), generator=g, device=device)
+            dl = torch.randint(1, 4, (nd,), generator=g, device=device)                 # deleted reference bases
+            kb = torch.randint(1, max(2, nseg - 1), (nd,), generator=g, device=device)  # the deletion sits at the end of segment kb - 1 ...
+            m = torch.randint(1, 4, (nd,), generator=g, device=device)                  # ... m bases before its end
+            x = kb * seg_len - m
+            shift = torch.where(ar[None, :] >= x[:, None], dl[:, None], torch.zeros_like(dl)[:, None])
+            base0 = coff[ga[:, 0]][:, None] + pa[:, None] + ar[None, :]
+            codes = gcodes[(base0 + shift).clamp(min=0, max=gcodes.shape[0] - 1)]       # the read
+            refc = gcodes[base0.clamp(min=0, max=gcodes.shape[0] - 1)]                  # the reference in the frame before the deletion
+            codes = torch.where(codes > 3, torch.zeros_like(codes), codes)
+            # the segment that holds the deletion is placed ungapped in that frame: its last m bases are read against shifted ones
+            in_tail = (ar[None, :] >= x[:, None]) & (ar[None, :] < (kb * seg_len)[:, None])
+            nm_tail = (in_tail & (codes != refc)).sum(1).to(torch.int32)
+            pad = torch.zeros((nd, W * 64), dtype=torch.int64, device=device)
+            pad[:, :read_len] = codes.to(torch.int64)
+            pw = pad.view(nd, W, 64)
+            b["planes"][dz, 0:W] = ((pw & 1) * bitw).sum(-1)
+            b["planes"][dz, W:2 * W] = (((pw >> 1) & 1) * bitw).sum(-1)
+            b["planes"][dz, 2 * W:3 * W] = 0
+            b["full_ok"][dz] = False
+            for k in range(nseg):
+                s0, s1 = k * seg_len, (read_len if k == nseg - 1 else (k + 1) * seg_len)
+                ln = s1 - s0
+                holds = kb - 1 == k
+                nmk = torch.where(holds, nm_tail, torch.zeros_like(nm_tail))
+                ok = nmk <= 2                                                            # an ungapped mapper with two mismatches allowed
+                leftk = torch.where(kb <= k, pa + s0 + dl, pa + s0)
+                endf = 2 if k == nseg - 1 else 0
+                b["seg_mapped"][dz, k] = ok
+                b["seg_hits"][dz, k, 0] = (ga[:, 0] + 1).to(torch.int32)
+                b["seg_hits"][dz, k, 1] = leftk.to(torch.int32)
+                b["seg_hits"][dz, k, 2] = (leftk + ln).to(torch.int32)
+                b["seg_hits"][dz, k, 3] = (endf | (nmk << 8) | (nmk << 16) | (ln << 24)).to(torch.int32)
+                b["span_mapped"][dz, k] = ok
+                sh = b["span_hits"]
+                sh[dz, k, 0] = (ga[:, 0] + 1).to(torch.int32)
+                sh[dz, k, 1] = leftk.to(torch.int32)
+                sh[dz, k, 2] = (endf | (nmk << 8) | (nmk << 16) | (1 << 24)).to(torch.int32)
+                sh[dz, k, 3] = (1 << 28) | ln
+                sh[dz, k, 4] = 0
+                sh[dz, k, 5] = 0
+            deletion_rows = dz
+            deletion_truth = torch.stack([ga[:, 0] + 1, pa + x - 1, pa + x + dl], 1)
     del gcodes
 
     def csr(mapped, rows, multi, left_cols):
@@ -725,4 +784,7 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
                        mate_off=mate_off, mate_hits=mh)
     if fusion_rows is not None:
         out["left"]["fusion_reads"] = fusion_rows
+    if deletion_rows is not None:
+        out["left"]["deletion_reads"] = deletion_rows
+        out["left"]["deletions"] = deletion_truth
     return out
