@@ -39,6 +39,9 @@ static void md_nm(const char* ref, const char* rs, int n, int& nm, std::string& 
 }
 
 int main(int argc, char** argv) {
+    // the files stand for what tophat.py hands over: BAM written through samtools' bgzf.c, i.e. zlib at its default level -- not this
+    // build's own fast DEFLATE, which the executables' OUTPUT uses (inflate kernels see different match statistics)
+    setenv("THJ_BGZF_LEVEL", "-1", 0);
     std::string out; int64_t pairs = 100000, genome_len = 64444167; std::vector<int64_t> contigs;
     int introns = 20000, intron_max = 200000, exon_len = 300, read_len = 100, seg_len = 25, threads = host_threads();
     uint64_t seed = 1; double err = 0.01, drop = 0.03; bool text = false;
