@@ -80,3 +80,21 @@ def test_genome_layout_refuses_what_the_packed_keys_cannot_hold():
     lens = np.full(7, 0x7fffffff, dtype=np.int64)          # 7 x 2^31 < 2^34: fine
     blk = np.zeros(8, dtype=np.uint32)
     assert lib.thj_genome_layout(7, lens.ctypes.data_as(C.c_void_p), blk.ctypes.data_as(C.c_void_p), C.byref(nb)) == 0
+
+
+def test_executables_pass_errors_through_the_output_handoff():
+    """The executables run their work in a child process and return when it reports its outputs complete (run_with_handoff); a
+    child that ends without reporting -- usage errors, die() -- is waited for, its exit code and messages passed on."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    bindir = os.path.join(ROOT, "tophat_amd", "bin")
+    for exe in ("segment_juncs", "long_spanning_reads", "thj_junctions"):
+        for env in (dict(os.environ), dict(os.environ, THJ_NO_HANDOFF="1")):
+            r = subprocess.run([os.path.join(bindir, exe)], capture_output=True, text=True, env=env, timeout=60)
+            assert r.returncode == 1 and "sage" in r.stderr, (exe, r.returncode, r.stderr[-200:])
+    # a die() after option parsing: inputs that do not exist
+    args = ["--no-coverage-search", "--no-microexon-search", "/nonexistent/ref.fa", "/tmp/j", "/tmp/i", "/tmp/d", "/tmp/f",
+            "/nonexistent/reads.bam", "/nonexistent/map.bam", "/nonexistent/seg1.bam,/nonexistent/seg2.bam"]
+    r = subprocess.run([os.path.join(bindir, "segment_juncs")] + args, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "rror" in r.stderr, (r.returncode, r.stderr[-300:])
