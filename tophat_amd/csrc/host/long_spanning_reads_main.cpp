@@ -312,6 +312,11 @@ static int real_main(int argc, char** argv) {
     std::vector<std::string> segs = split(pos[7], ',');
     if (segs.empty()) { fprintf(stderr, "No hits to process, exiting\n"); return 0; }           // long_spanning_reads.cpp:2883-2887
 
+    // the reference is read on its own thread(s) while the HIP runtime starts (the device count below is its first call, ~50 ms)
+    RefTable rt;
+    rt.load_sam_header(o.sam_header);
+    fprintf(stderr, "Loading reference sequences...\n");
+    std::future<void> fasta_loaded = std::async(std::launch::async, [&rt, &pos]() { rt.load_fasta(pos[0]); });
     std::vector<std::unique_ptr<Gpu>> gpus;
     {
         int n_dev = 1, first = 0;
@@ -340,10 +345,7 @@ static int real_main(int argc, char** argv) {
     }
     const int n_gpus = (int)gpus.size();
 
-    RefTable rt;
-    rt.load_sam_header(o.sam_header);
-    fprintf(stderr, "Loading reference sequences...\n");
-    rt.load_fasta(pos[0]);
+    fasta_loaded.get();
     fprintf(stderr, "        reference sequences loaded.\n");
     g_timer.lap("options + reference FASTA");
 

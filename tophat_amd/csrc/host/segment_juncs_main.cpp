@@ -283,6 +283,11 @@ static int real_main(int argc, char** argv) {
     // ---- GPUs: every visible one (THJ_GPUS caps the count, THJ_DEVICE picks a single device).  HIP start-up runs beside the
     // FASTA load and the first shards' ingest: each context is created on its own thread and picked up -- with the genome
     // going up then -- by the first worker that needs the device (under the GPU's lock).
+    // the reference is read on its own thread(s) while the HIP runtime starts (the device count below is its first call, ~50 ms)
+    RefTable rt;
+    rt.load_sam_header(o.sam_header);
+    fprintf(stderr, "Loading reference sequences...\n");
+    std::future<void> fasta_loaded = std::async(std::launch::async, [&rt, &pos]() { rt.load_fasta(pos[0]); });
     std::vector<std::unique_ptr<Gpu>> gpus;
     {
         int n_dev = 1, first = 0;
@@ -309,10 +314,7 @@ static int real_main(int argc, char** argv) {
     }
     const int n_gpus = (int)gpus.size();
 
-    RefTable rt;
-    rt.load_sam_header(o.sam_header);
-    fprintf(stderr, "Loading reference sequences...\n");
-    rt.load_fasta(pos[0]);
+    fasta_loaded.get();
     for (const SideInput* sd : {&left, &right}) { register_targets(sd->map, rt); for (auto& f : sd->segs) register_targets(f, rt); }
     if (!getenv("THJ_HOST_INGEST"))                                   // map the BAM inputs for the device-side ingest
         for (const SideInput* sd : {&left, &right}) {
