@@ -154,6 +154,21 @@ def test_results_do_not_depend_on_shards_or_workers(tmp_path):
     assert open(bam1 + ".index").read() == open(bam2 + ".index").read()
 
 
+def test_process_and_compressor_choices_do_not_change_the_results(tmp_path):
+    """one process instead of the output hand-off (THJ_NO_HANDOFF), zlib instead of the writer's own DEFLATE (THJ_BGZF_LEVEL), no
+    page-locked staging (THJ_NO_STAGING): the same event files and the same BAM stream"""
+    d = _gen_case(tmp_path)
+    ref, bam0, _ = _run_both(d, tmp_path, "dflt", {})
+    stream = gzip.open(bam0, "rb").read()
+    assert len(stream) > 1000000
+    for tag, env in (("oneproc", {"THJ_NO_HANDOFF": "1"}), ("zlib", {"THJ_BGZF_LEVEL": "6"}), ("nostage", {"THJ_NO_STAGING": "1", "THJ_CTX_PER_GPU": "1"})):
+        got, bam, _ = _run_both(d, tmp_path, tag, env)
+        assert got == ref, tag
+        assert gzip.open(bam, "rb").read() == stream, tag
+    # the own compressor's file is about the size zlib's level 1 would give (and smaller than twice level 6's)
+    assert os.path.getsize(bam0) < 2 * os.path.getsize(str(tmp_path / "zlib.span.bam"))
+
+
 def test_device_ingest_equals_host_ingest(tmp_path):
     """segment_juncs reading its BAM inputs on the device (BGZF inflate + record parse + merge by read id in HBM) against the
     host readers: identical event files -- with one shard and with many, paired-end with mate maps"""
