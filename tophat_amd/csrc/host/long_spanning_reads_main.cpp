@@ -486,16 +486,17 @@ static int real_main(int argc, char** argv) {
         if ((int)shards.size() != parts) { shards.resize(1); shards[0] = Shard(); shards[0].seg_off.assign(segs.size(), 0); shards[0].spliced_off.assign(spliced_segs.size(), 0); parts = 1; }   // not enough data: one thread (:2992-2993)
     }
     if (parts == 1) {
-        // shards of ~24 MB of compressed input (~160 k reads of 100 bases with four segment maps): measured best for the pipeline below --
-        // 48 shards for 8 M pairs, 64 for 10 M (1.32 -> 1.10 s per side there) -- and at least four per host worker
-        int n_shards = 4 * workers;
+        // shards of ~16 MB of compressed input (~110 k reads of 100 bases with four segment maps): measured best for the pipeline below
+        // (10 M pairs: 24 MB 1.02-1.15 s per side, 16 MB 0.83-0.93, 12 MB 0.80-0.92, 8 MB 0.96-1.11, 48 MB 1.49) -- and at least four per host worker
+        int n_shards = getenv("THJ_SHARD_MB") ? 1 : 4 * workers;
         if (getenv("THJ_SHARDS")) n_shards = atoi(getenv("THJ_SHARDS"));
         else {
             uint64_t bytes = 0;
             struct stat st;
             for (auto& f : segs) if (stat(f.c_str(), &st) == 0) bytes += (uint64_t)st.st_size;
             if (stat(pos[1].c_str(), &st) == 0) bytes += (uint64_t)st.st_size;
-            const uint64_t by_size = bytes / (24ull << 20);
+            const uint64_t shard_mb = getenv("THJ_SHARD_MB") && atoi(getenv("THJ_SHARD_MB")) >= 1 ? (uint64_t)atoi(getenv("THJ_SHARD_MB")) : 16;
+            const uint64_t by_size = bytes / (shard_mb << 20);
             if (by_size > (uint64_t)n_shards) n_shards = (int)std::min<uint64_t>(by_size, 4096);
         }
         shards = plan(pos[1], segs, spliced_segs, n_shards);
