@@ -1,0 +1,79 @@
+// inflate_sim.cpp -- TEST-ONLY: compiles tophat_amd/csrc/thj_inflate_core.h (the lane logic of thj_k_huff) for the CPU, one lane at a
+// time, and restates thj_k_lz's batch algorithm (64 tokens, prefix sum, rounds behind a high-water mark, sliding 40 KiB buffer)
+// with explicit lane loops, so that both halves of the device inflater can be checked against zlib without a GPU.
+// Never linked into libthj_hip.so.
+#include "../../tophat_amd/csrc/thj_inflate_core.h"
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+using namespace inf2;
+
+struct WaveCpu { bool any(bool p) const { return p; } };
+
+// one member through the lane logic.  comp / in_len: the raw DEFLATE stream; skew (0..15): how far into a 16-byte granule it starts.
+// Returns 0 and fills tokens / ntok / outp, or 1 when the lane hands the member to the fallback.
+extern "C" int inflate_sim_huff(const uint8_t* comp, uint32_t in_len, uint32_t skew, uint32_t* tokens, uint32_t* ntok, uint32_t* outp) {
+    std::vector<uint8_t> lds((size_t)STRIDE_WORDS * 4, 0xA5);                    // stale LDS
+    std::vector<uint8_t> stream((size_t)skew + in_len + 64, 0x5A);                // bytes around the member are someone else's
+    memcpy(stream.data() + skew, comp, in_len);
+    Lane L;
+    memset(&L, 0, sizeof L);
+    L.lit = (uint16_t*)lds.data(); L.A = lds.data() + OFF_A; L.B = lds.data() + OFF_B; L.C = (uint16_t*)(lds.data() + OFF_C); L.ring = (uint32_t*)(lds.data() + OFF_RING);
+    L.src = stream.data(); L.total = skew + in_len; L.rd = 4; L.tok = tokens;
+    run_member(L, true, skew, WaveCpu{});
+    const bool good = L.state == ST_DONE && !overrun(L);
+    *ntok = good ? L.ntok : NTOK_FALLBACK; *outp = good ? L.outp : 0;
+    return good ? 0 : 1;
+}
+
+// thj_k_lz restated: returns the number of bytes written to out (65536 bytes), or -1 on an inconsistency
+extern "C" int64_t inflate_sim_lz(const uint32_t* tokens, uint32_t n, uint8_t* out, int64_t* rounds_out) {
+    constexpr uint32_t HIST = 32768, CAP = 32768 + 8192;
+    std::vector<uint8_t> buf(CAP + 64, 0xEE);
+    uint32_t origin = 0, flushed = 0, pos = 0, i0 = 0;
+    int64_t rounds = 0;
+    auto slide = [&]() {
+        for (uint32_t o = flushed; o + 16 <= pos; o += 16) memcpy(out + o, &buf[o - origin], 16);
+        flushed = std::max(flushed, pos & ~15u);
+        const uint32_t no = pos > HIST ? (pos - HIST) & ~15u : 0u;
+        if (no > origin) { memmove(buf.data(), buf.data() + (no - origin), pos - no); origin = no; }
+    };
+    while (i0 < n) {
+        uint32_t len[64], incl[64], a[64], dist[64]; bool valid[64], ism[64], take[64];
+        uint32_t run = 0;
+        for (int l = 0; l < 64; ++l) {
+            valid[l] = i0 + l < n;
+            const uint32_t t = valid[l] ? tokens[i0 + l] : 0;
+            ism[l] = valid[l] && (t >> 31);
+            len[l] = !valid[l] ? 0 : ism[l] ? ((t >> 15) & 255u) + 3u : 1u;
+            dist[l] = (t & 0x7FFFu) + 1u;
+            run += len[l]; incl[l] = run;
+        }
+        const uint32_t room = origin + CAP - pos;
+        int ntake = 0;
+        for (int l = 0; l < 64; ++l) { take[l] = valid[l] && incl[l] <= room; if (take[l]) ++ntake; }
+        if (ntake == 0) { slide(); if (origin + CAP - pos < 258) return -1; continue; }
+        for (int l = 0; l < 64; ++l) a[l] = pos + incl[l] - len[l] - origin;
+        for (int l = 0; l < ntake; ++l) if (!ism[l]) buf[a[l]] = (uint8_t)tokens[i0 + l];
+        uint64_t pend = 0;
+        for (int l = 0; l < ntake; ++l) if (ism[l]) { if (dist[l] > a[l] + origin) return -1; pend |= 1ull << l; }
+        while (pend) {
+            ++rounds;
+            const int f = __builtin_ctzll(pend);
+            const uint32_t hwm = a[f];
+            uint64_t rdy = 0;
+            for (int l = 0; l < ntake; ++l) if ((pend >> l) & 1) { const uint32_t s = a[l] - dist[l]; if (s + std::min(len[l], dist[l]) <= hwm) rdy |= 1ull << l; }
+            // every ready lane reads before any writes (the lanes' sources are final bytes, their destinations disjoint)
+            std::vector<std::vector<uint8_t>> tmp(64);
+            for (int l = 0; l < ntake; ++l) if ((rdy >> l) & 1) { const uint32_t s = a[l] - dist[l]; tmp[l].resize(len[l]); for (uint32_t k = 0; k < len[l]; ++k) tmp[l][k] = buf[s + (dist[l] >= len[l] ? k : k % dist[l])]; }
+            for (int l = 0; l < ntake; ++l) if ((rdy >> l) & 1) memcpy(&buf[a[l]], tmp[l].data(), len[l]);
+            pend &= ~rdy;
+        }
+        pos += incl[ntake - 1]; i0 += (uint32_t)ntake;
+    }
+    for (uint32_t o = flushed; o < pos; ++o) out[o] = buf[o - origin];
+    if (rounds_out) *rounds_out = rounds;
+    return pos;
+}

@@ -107,3 +107,39 @@ def test_bam_files_inflate_like_zlib(tmp_path):
             for k, p in enumerate(pl):
                 w = zlib.decompress(p, -15)
                 assert len(w) == isize[k] and got[k] == w, (fn, k)
+
+
+def test_two_kernel_inflater_mixed_launch():
+    """One launch holding members of every kind at once -- several dynamic blocks per member, fixed and stored blocks, members of more
+    symbols than the token stream keeps (those and the stored ones take the one-lane kernel), empty members, corrupt ones -- in an
+    order that spreads them over the lanes of the lane-per-member kernel."""
+    import random
+    rng = random.Random(7)
+    payloads, want = [], []
+    for k in range(330):
+        kind = k % 11
+        n = rng.choice((1, 40, 3000, 30000, 65536))
+        if kind < 4:
+            words = [bytes(rng.randrange(97, 123) for _ in range(rng.randrange(2, 9))) for _ in range(rng.randrange(3, 300))]
+            d = b" ".join(rng.choice(words) for _ in range(n // 4 + 1))[:n]
+        elif kind < 6:
+            d = bytes(rng.randrange(rng.randrange(2, 256)) for _ in range(n))
+        elif kind < 8:
+            piece = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 500)))
+            d = (piece * (n // len(piece) + 1))[:n]
+        else:
+            d = bytes(min(255, int(rng.expovariate(rng.choice((0.02, 0.1, 0.5))))) for _ in range(n))
+        c = zlib.compressobj(rng.choice((0, 1, 6, 9)) if kind != 10 else 6, zlib.DEFLATED, -15, rng.choice((1, 3, 8, 9)),
+                             rng.choice((zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_RLE, zlib.Z_FIXED)))
+        p = c.compress(d) + c.flush()
+        if kind == 10 and len(p) > 20:                       # a damaged member among the good ones
+            p = p[:len(p) // 2]
+            d = None
+        payloads.append(p); want.append(d)
+    with host.Context(0) as ctx:
+        got = inflate(ctx, payloads)
+    for k, (g, w) in enumerate(zip(got, want)):
+        if w is None:
+            assert g is None or g != w
+        else:
+            assert g == w, "member %d (%d bytes in, %d out)" % (k, len(payloads[k]), len(w))

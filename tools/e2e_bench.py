@@ -20,6 +20,12 @@ BIN = os.path.join(ROOT, "tophat_amd", "bin")
 GEN = os.path.join(ROOT, "tools", "bin", "thj_gen")
 
 
+def _prefix(env, stage):
+    """THJ_EXEC_PREFIX='rocprofv3 --kernel-trace --stats -d /tmp/p_{stage} -o res --' runs each executable under a profiler"""
+    pre = env.get("THJ_EXEC_PREFIX", "")
+    return pre.replace("{stage}", stage).split() if pre else []
+
+
 def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False):
     nseg = max(1, read_len // 25)
     d = workdir or tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -37,7 +43,7 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
     segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k + 1)) for k in range(nseg)) for sd in ("left", "right")}
     out = {k: f("out." + k) for k in ("juncs", "insertions", "deletions", "fusions")}
     mode = ["--ium-reads", f("left_reads.bam") + "," + f("right_reads.bam")] if coverage_search else ["--no-coverage-search"]
-    cmd = [os.path.join(BIN, "segment_juncs")] + mode + ["--no-microexon-search", "--segment-length", "25",
+    cmd = _prefix(env, "segment_juncs") + [os.path.join(BIN, "segment_juncs")] + mode + ["--no-microexon-search", "--segment-length", "25",
            "--sam-header", f("hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20",
            f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"],
            f("left_reads.bam"), f("left_map.bam"), segs["left"], f("right_reads.bam"), f("right_map.bam"), segs["right"]]
@@ -51,7 +57,7 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
     res["segment_juncs_log_tail"] = r.stderr.strip().splitlines()[-12:]
     tot = dt
     for sd in ("left", "right"):
-        cmd = [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
+        cmd = _prefix(env, "lsr_" + sd) + [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
                f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", f("span_%s.bam" % sd), segs[sd]]
         t = time.time()
         r = subprocess.run(cmd, capture_output=True, text=True, env=env)

@@ -59,7 +59,7 @@ namespace thjh {
 inline int& handoff_fd() { static int fd = -1; return fd; }
 inline int run_with_handoff(int argc, char** argv, int (*body)(int, char**)) {
     int fd[2];
-    if (getenv("THJ_NO_HANDOFF") || pipe(fd) != 0) return body(argc, argv);
+    if (getenv("THJ_NO_HANDOFF") || pipe2(fd, O_CLOEXEC) != 0) return body(argc, argv);   // O_CLOEXEC: a popen'd packer must not hold the write end
     fflush(nullptr);
     const pid_t self = getpid();
     const pid_t pid = fork();
@@ -96,7 +96,7 @@ inline int run_with_handoff(int argc, char** argv, int (*body)(int, char**)) {
         const unsigned char c = (unsigned char)rc;
         if (write(handoff_fd(), &c, 1) != 1) {}
         if (linger_ms > 0) usleep((useconds_t)linger_ms * 1000u);
-    }
+    } else if (getenv("THJ_NO_HANDOFF")) exit(rc);                // one process (profilers, debuggers): leave through the exit handlers
     _exit(rc);
 }
 

@@ -79,6 +79,7 @@ struct thj_ctx {
     std::vector<DevBlock> dev_cache; size_t dev_cache_bytes = 0;
     // device-side ingest scratch (thj_ingest.hip)
     void* d_ing0 = nullptr; size_t ing_cap0 = 0; void* d_ing1 = nullptr; size_t ing_cap1 = 0;
+    void* d_infl_tmp = nullptr; size_t infl_tmp_cap = 0;                  // token streams of the two-kernel inflater
     // junction consensus (thj_juncbed_impl.h)
     u64* d_jb_key = nullptr; uint32_t* d_jb_u32 = nullptr; u64* d_jb_list = nullptr; u64* d_jb_sorted = nullptr;
     unsigned long long* d_jb_cnt = nullptr; void* d_jb_occ = nullptr;

@@ -1,0 +1,340 @@
+// thj_inflate_core.h -- the per-member logic of the two-kernel BGZF inflater (replaces what
+// samtools-0.1.18/bgzf.c:inflate_block hands to zlib).  DEFLATE (RFC 1951) splits cleanly in two:
+//
+//   1. entropy decoding -- a chain of dependent table look-ups, serial inside a member, that never looks at the bytes it
+//      produced: thj_k_huff runs ONE MEMBER PER LANE (64 members per wave, every lane busy: the round-2 kernel decoded on one lane
+//      of 64 and was bound by the issue latency of a single wave) and writes a stream of 32-bit tokens, literal or (length, distance);
+//   2. LZ77 resolution -- copies inside the member's own output, parallel except where a match reads what an earlier one of the
+//      same batch writes: thj_k_lz runs ONE WAVE PER MEMBER over 64 tokens at a time (prefix sum of the lengths = output
+//      positions, literals scattered, matches copied in rounds behind a high-water mark) with the last 32 KiB of output in LDS.
+//
+// This header is the lane logic of kernel 1, written so that tests/hostsim can compile it for the CPU (one lane at a time) and
+// check it against zlib before it ever runs on a GPU.  Everything a member needs sits in a private LDS slice:
+//
+//   lit[852]   u16  two-level literal/length table: 9-bit root + sub-tables (zlib's inftrees.h bound ENOUGH_LENS for a 9-bit root)
+//   A[320]     u8   code lengths while a header is parsed; afterwards the 8-bit distance root table in A[0..256)
+//   B[64]           distance codes longer than 8 bits: per length {first code, count, list base} + the symbols in canonical order
+//   C[64]      u16  count / next-code per length while tables are built
+//   ring[256]  u8   compressed input, topped up 16 bytes at a time at uniform points of the loop (loads land one top-up later)
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#define THJ_IHD __host__ __device__ __forceinline__
+#else
+#define THJ_IHD inline
+#endif
+
+namespace inf2 {
+
+constexpr int ROOT = 9, ROOT_SIZE = 1 << ROOT, LIT_ENTRIES = 852;
+constexpr int DROOT = 8, DROOT_SIZE = 1 << DROOT;
+constexpr int RING = 256;
+constexpr int OFF_A = LIT_ENTRIES * 2, OFF_B = OFF_A + 320, OFF_C = OFF_B + 64, OFF_RING = OFF_C + 64, LANE_BYTES = OFF_RING + RING;   // 2408
+constexpr int STRIDE_WORDS = 603;                          // >= LANE_BYTES / 4, odd: the lanes' slices start in different banks
+static_assert(STRIDE_WORDS * 4 >= LANE_BYTES && (STRIDE_WORDS & 1), "LDS slice");
+constexpr uint32_t TOKCAP = 20480;                         // tokens kept per member (zlib closes a block at 16383 symbols; typical BAM members: 11-14 k)
+constexpr uint32_t NTOK_FALLBACK = 0xFFFFFFFFu;            // ntok[]: this member goes to the one-lane kernel (stored blocks, too many tokens, corrupt streams)
+
+// token: literal = byte; match = 1 << 31 | (len - 3) << 15 | (dist - 1)
+THJ_IHD uint32_t tok_match(uint32_t len, uint32_t dist) { return 0x80000000u | ((len - 3u) << 15) | (dist - 1u); }
+
+// lit[] entry: bits 0..3 = n (code bits this level consumes; 0 = no such code), bits 4..15 = payload:
+//   < 256 literal | 256 end of block | 512 + i: sub-table at lit[i], n = its index bits | 0x800 | extra << 8 | (base - 3): a length code
+enum { P_EOB = 256, P_SUB = 512, P_LEN = 0x800 };
+// A[] (distance root) entry: symbol | (code length - 1) << 5; 0xFF = longer than 8 bits or no such code
+enum { ST_HEADER = 0, ST_DECODE = 1, ST_DONE = 2, ST_FALLBACK = 3 };
+
+struct Lane {
+    uint64_t buf; int cnt;                 // bit buffer (next bit = bit 0)
+    uint32_t nextw;                        // the ring word in front of rd, not yet in buf
+    uint32_t rd;                           // read position in the aligned stream (bytes, multiple of 4)
+    uint32_t ld;                           // bytes of the aligned stream landed in the ring (multiple of 16)
+    uint32_t total;                        // skew + compressed length: where the member's bytes end in the aligned stream
+    uint32_t outp, ntok;
+    int state, last;
+    bool inflight; uint32_t pend[4];       // a 16-byte piece on its way
+    const uint8_t* src;                    // the aligned stream (16-byte aligned address at or before the member's first byte)
+    uint16_t* lit; uint8_t* A; uint8_t* B; uint16_t* C; uint32_t* ring;
+    uint32_t* tok;
+};
+
+THJ_IHD uint32_t rev_bits(uint32_t v, int n) {             // the low n bits of v reversed, 1 <= n <= 15
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(v) >> (32 - n);
+#else
+    uint32_t r = 0; for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i); return r;
+#endif
+}
+
+// ---- input
+THJ_IHD void topup(Lane& L) {                               // uniform points only: lands the piece asked for at the previous point, asks for the next
+    if (L.inflight) {
+        uint32_t* r = L.ring + ((L.ld & (RING - 1)) >> 2);
+        r[0] = L.pend[0]; r[1] = L.pend[1]; r[2] = L.pend[2]; r[3] = L.pend[3];
+        L.ld += 16; L.inflight = false;
+    }
+    if (L.ld < L.total && L.ld + 16 - (L.rd - 4) <= (uint32_t)RING) {       // the word at rd - 4 (nextw) has been read already, but keep it simple and safe
+        uint32_t v[4];
+        memcpy(v, L.src + L.ld, 16);
+        L.pend[0] = v[0]; L.pend[1] = v[1]; L.pend[2] = v[2]; L.pend[3] = v[3];
+        L.inflight = true;
+    }
+}
+THJ_IHD bool input_ok(const Lane& L) { return L.rd + 8 <= L.ld || L.ld >= L.total; }       // two more ring words may be read (or all there is has landed)
+THJ_IHD void refill(Lane& L) {
+    if (L.cnt <= 32) { L.buf |= (uint64_t)L.nextw << L.cnt; L.cnt += 32; L.nextw = L.ring[(L.rd & (RING - 1)) >> 2]; L.rd += 4; }
+}
+THJ_IHD uint32_t take(Lane& L, int n) { const uint32_t v = (uint32_t)L.buf & ((1u << n) - 1u); L.buf >>= n; L.cnt -= n; return v; }
+THJ_IHD void lane_start(Lane& L, uint32_t skew) {          // after the ring's first pieces have landed
+    L.rd = skew & ~3u;
+    const uint32_t w = L.ring[(L.rd & (RING - 1)) >> 2]; L.rd += 4;
+    L.buf = (uint64_t)(w >> (8 * (skew & 3u))); L.cnt = 32 - 8 * (int)(skew & 3u);
+    L.nextw = L.ring[(L.rd & (RING - 1)) >> 2]; L.rd += 4;
+}
+// bits of the member consumed so far must not exceed what it has (a stream that runs off its end decodes the zero / stale padding)
+THJ_IHD bool overrun(const Lane& L) { return (int64_t)(L.rd - 4) * 8 - L.cnt > (int64_t)L.total * 8; }
+
+// ---- length / distance arithmetic (RFC 1951, 3.2.5) without tables
+THJ_IHD uint32_t len_payload(uint32_t k) {                  // k = symbol - 257; 0 = no such code (286, 287)
+    if (k >= 29u) return 0;
+    uint32_t ext, base;
+    if (k < 8u) { ext = 0; base = 3u + k; } else if (k == 28u) { ext = 0; base = 258u; } else { ext = (k - 4u) >> 2; base = 3u + ((4u + (k & 3u)) << ext); }
+    return (uint32_t)P_LEN | (ext << 8) | (base - 3u);
+}
+THJ_IHD void dist_base_ext(uint32_t ds, uint32_t& base, uint32_t& ext) {
+    ext = ds < 2u ? 0u : (ds >> 1) - 1u;
+    base = ds < 2u ? 1u + ds : 1u + ((2u + (ds & 1u)) << ext);
+}
+
+// ---- tables.  Every loop below runs in lock step over the lanes of a wave: trip counts are uniform or bounded by a small maximum.
+// counts per length -> C[0..16); returns false when over-subscribed
+THJ_IHD bool count_lengths(Lane& L, const uint8_t* lens, int n) {
+    for (int l = 0; l < 16; ++l) L.C[l] = 0;
+    for (int i = 0; i < n; ++i) L.C[lens[i]]++;
+    int left = 1; bool ok = true;
+    for (int l = 1; l < 16; ++l) { left = (left << 1) - (int)L.C[l]; ok = ok && left >= 0; }
+    return ok;
+}
+// first canonical code per length -> C[16..32)
+THJ_IHD void first_codes(Lane& L) {
+    uint32_t code = 0;
+    for (int l = 1; l < 16; ++l) { L.C[16 + l] = (uint16_t)code; code = (code + L.C[l]) << 1; }
+}
+
+// literal/length table from lens[0..n), n <= 288 (symbols 286 / 287 of the fixed code get codes but no entries: no stream may use them)
+template <class W>
+THJ_IHD bool build_lit(Lane& L, const uint8_t* lens, int n, bool live, const W& wave) {
+    bool ok = count_lengths(L, lens, live ? n : 0);
+    first_codes(L);
+    for (int i = 0; i < LIT_ENTRIES; ++i) L.lit[i] = 0;
+    // sub-tables: the codes longer than 9 bits in canonical order; codes that share their first 9 bits are neighbours there, and
+    // the sub-table of such a run is indexed by as many bits as its longest code has beyond the root
+    uint32_t used = ROOT_SIZE; int cur_prefix = -1, cur_max = 0;
+    for (int l = ROOT + 1; l < 16; ++l) {
+        const uint32_t first = L.C[16 + l], c = live ? L.C[l] : 0u;
+        for (uint32_t k = 0; wave.any(k < c); ++k) {
+            if (k < c) {
+                const int prefix = (int)((first + k) >> (l - ROOT));
+                if (prefix != cur_prefix) {
+                    if (cur_prefix >= 0) { const int b = cur_max - ROOT; if (used + (1u << b) > (uint32_t)LIT_ENTRIES) ok = false; else { L.lit[rev_bits((uint32_t)cur_prefix, ROOT)] = (uint16_t)(((uint32_t)P_SUB + used) << 4 | (uint32_t)b); used += 1u << b; } }
+                    cur_prefix = prefix;
+                }
+                cur_max = l;
+            }
+        }
+    }
+    if (cur_prefix >= 0) { const int b = cur_max - ROOT; if (used + (1u << b) > (uint32_t)LIT_ENTRIES) ok = false; else { L.lit[rev_bits((uint32_t)cur_prefix, ROOT)] = (uint16_t)(((uint32_t)P_SUB + used) << 4 | (uint32_t)b); used += 1u << b; } }
+    // the symbols in order: canonical code = next code of its length
+    for (int s = 0; wave.any(s < n); ++s) {
+        const int l = (live && s < n) ? lens[s] : 0;
+        uint32_t f = 0, end = 0, step = 1, e = 0; uint16_t* t = L.lit;
+        if (l) {
+            const uint32_t code = L.C[16 + l]; L.C[16 + l] = (uint16_t)(code + 1);
+            const uint32_t payload = s < 256 ? (uint32_t)s : s == 256 ? (uint32_t)P_EOB : len_payload((uint32_t)s - 257u);
+            if (l <= ROOT) { f = rev_bits(code, l); end = ROOT_SIZE; step = 1u << l; e = payload << 4 | (uint32_t)l; }
+            else {
+                const uint32_t r = L.lit[rev_bits(code >> (l - ROOT), ROOT)];
+                const int j = l - ROOT, b = (int)(r & 15u);
+                if ((r >> 4) >= (uint32_t)P_SUB && (r >> 4) < (uint32_t)P_LEN && j <= b) { t = L.lit + ((r >> 4) - (uint32_t)P_SUB); f = rev_bits(code & ((1u << j) - 1u), j); end = 1u << b; step = 1u << j; e = payload << 4 | (uint32_t)j; }
+                else ok = false;
+            }
+            if (payload == 0 && s > 256) end = 0;                            // 286 / 287: leave the entries empty
+        }
+        for (; wave.any(f < end); f += step) if (f < end) t[f] = (uint16_t)e;
+    }
+    return ok;
+}
+
+// distance tables from dl[0..n), n <= 32 (the fixed code has 32 five-bit codes; symbols 30 / 31 are looked up and refused when used)
+template <class W>
+THJ_IHD bool build_dist(Lane& L, const uint8_t* dl, int n, bool live, const W& wave) {
+    // dl = A + hlit with hlit >= 257: the lengths sit beyond the 256 bytes of the root table built below
+    for (int l = 0; l < 16; ++l) L.C[l] = 0;
+    for (int i = 0; i < 32; ++i) L.C[(live && i < n) ? dl[i] : 0]++;
+    int left = 1; bool ok = true;
+    for (int l = 1; l < 16; ++l) { left = (left << 1) - (int)L.C[l]; ok = ok && left >= 0; }
+    first_codes(L);
+    for (int i = 0; i < DROOT_SIZE; ++i) L.A[i] = 0xFF;
+    // long codes: B as u32[7] {first code : 15 | count : 6 << 15 | list base : 6 << 21} for lengths 9..15, then u8[32] symbols
+    uint32_t* bl = (uint32_t*)L.B; uint8_t* bsym = L.B + 28;
+    uint32_t lbase[16]; { uint32_t acc = 0; for (int l = DROOT + 1; l < 16; ++l) { lbase[l] = acc; bl[l - DROOT - 1] = (uint32_t)L.C[16 + l] | (uint32_t)L.C[l] << 15 | acc << 21; acc += L.C[l]; } }
+    for (int s = 0; s < 32; ++s) {
+        const int l = (live && s < n) ? dl[s] : 0;
+        uint32_t f = 0, end = 0, step = 1, e = 0;
+        if (l) {
+            const uint32_t code = L.C[16 + l]; L.C[16 + l] = (uint16_t)(code + 1);
+            if (l <= DROOT) { f = rev_bits(code, l); end = DROOT_SIZE; step = 1u << l; e = (uint32_t)s | (uint32_t)(l - 1) << 5; }
+            else { uint32_t lb = 0;
+#pragma unroll
+                   for (int q = DROOT + 1; q < 16; ++q) lb = q == l ? lbase[q] : lb;
+                   const uint32_t firstc = bl[l - DROOT - 1] & 0x7FFFu; bsym[lb + (code - firstc)] = (uint8_t)s; }
+        }
+        for (; wave.any(f < end); f += step) if (f < end) L.A[f] = (uint8_t)e;
+    }
+    return ok;
+}
+
+// a distance code of more than 8 bits (the root said 0xFF): canonical decode over lengths 9..15.  Returns the symbol or -1; n = its length
+THJ_IHD int dist_long(const Lane& L, int& n) {
+    const uint32_t* bl = (const uint32_t*)L.B; const uint8_t* bsym = L.B + 28;
+    uint32_t code = rev_bits((uint32_t)L.buf & 0xFFu, 8);            // the first 8 bits, first bit most significant
+    int res = -1; n = 0;
+#pragma unroll
+    for (int l = DROOT + 1; l < 16; ++l) {
+        code = code << 1 | (uint32_t)((L.buf >> (l - 1)) & 1u);
+        const uint32_t w = bl[l - DROOT - 1];
+        const uint32_t d = code - (w & 0x7FFFu);
+        if (res < 0 && d < ((w >> 15) & 63u)) { res = (int)bsym[(w >> 21) + d]; n = l; }
+    }
+    return res;
+}
+
+// ---- one block header (lane in ST_HEADER): BFINAL, BTYPE, code lengths, tables.  Lock step: lanes not in ST_HEADER idle through it.
+template <class W>
+THJ_IHD void parse_header(Lane& L, const W& wave) {
+    const bool live = L.state == ST_HEADER;
+    int type = -1;
+    if (live) { refill(L); L.last = (int)take(L, 1); type = (int)take(L, 2); }
+    bool dyn = live && type == 2, fixed = live && type == 1;
+    if (live && !dyn && !fixed) L.state = ST_FALLBACK;                       // stored blocks (and BTYPE 3) go to the one-lane kernel
+    int hlit = 288, hdist = 32, hclen = 0;
+    bool ok = true;
+    if (dyn) { refill(L); hlit = (int)take(L, 5) + 257; hdist = (int)take(L, 5) + 1; hclen = (int)take(L, 4) + 4; if (hlit > 286 || hdist > 30) { ok = false; dyn = false; } }
+    // the code-length code: 19 symbols of up to 7 bits, a 7-bit direct table in lit[0..128) (the real table is built afterwards)
+    uint8_t* cl = L.B;                                                       // 19 lengths, scratch
+    for (int i = 0; i < 19; ++i) cl[i] = 0;
+    {
+        static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (int i = 0; i < 19; ++i) if (dyn && i < hclen) { refill(L); cl[CLORD[i]] = (uint8_t)take(L, 3); }
+    }
+    {
+        for (int l = 0; l < 8; ++l) L.C[l] = 0;
+        for (int i = 0; i < 19; ++i) L.C[cl[i]]++;
+        int left = 1; for (int l = 1; l < 8; ++l) { left = (left << 1) - (int)L.C[l]; ok = ok && left >= 0; }
+        uint32_t code = 0; for (int l = 1; l < 8; ++l) { L.C[16 + l] = (uint16_t)code; code = (code + L.C[l]) << 1; }
+        for (int i = 0; i < 128; ++i) L.lit[i] = 0;
+        for (int s = 0; s < 19; ++s) {
+            const int l = cl[s]; uint32_t f = 0, end = 0, step = 1;
+            if (l) { const uint32_t c2 = L.C[16 + l]; L.C[16 + l] = (uint16_t)(c2 + 1); f = rev_bits(c2, l); end = 128; step = 1u << l; }
+            for (; wave.any(f < end); f += step) if (f < end) L.lit[f] = (uint16_t)((uint32_t)s << 4 | (uint32_t)l);
+        }
+    }
+    // the hlit + hdist code lengths -> A
+    {
+        const int n = hlit + hdist; int i = 0, it = 0; int prev = 0;
+        bool run = dyn && ok;
+        while (wave.any(run && i < n)) {
+            if ((it++ & 7) == 0) topup(L);
+            if (run && i < n && input_ok(L)) {
+                refill(L);
+                const uint32_t e = L.lit[(uint32_t)L.buf & 127u];
+                const int l = (int)(e & 15u), sym = (int)(e >> 4);
+                if (!l) { ok = false; run = false; }
+                else {
+                    L.buf >>= l; L.cnt -= l;
+                    if (sym < 16) { L.A[i++] = (uint8_t)sym; prev = sym; }
+                    else {
+                        int rep, val = 0;
+                        if (sym == 16) { if (i == 0) { ok = false; run = false; } val = prev; rep = 3 + (int)take(L, 2); }
+                        else if (sym == 17) { rep = 3 + (int)take(L, 3); prev = 0; }
+                        else { rep = 11 + (int)take(L, 7); prev = 0; }
+                        if (i + rep > n) { ok = false; run = false; rep = 0; }
+                        for (int k = 0; k < rep; ++k) L.A[i + k] = (uint8_t)val;      // at most 138: divergent but short, once per run
+                        i += rep;
+                    }
+                }
+            }
+        }
+        if (dyn && ok && L.A[256] == 0) ok = false;
+    }
+    if (fixed) {
+        for (int i = 0; i < 144; ++i) L.A[i] = 8;
+        for (int i = 144; i < 256; ++i) L.A[i] = 9;
+        for (int i = 256; i < 280; ++i) L.A[i] = 7;
+        for (int i = 280; i < 288; ++i) L.A[i] = 8;
+        for (int i = 0; i < 32; ++i) L.A[288 + i] = 5;
+    }
+    const bool build = (dyn && ok) || fixed;
+    ok = build_lit(L, L.A, hlit, build, wave) && ok;          // the fixed code counts its symbols 286 / 287 (they shape the canonical codes) and enters neither
+    ok = build_dist(L, L.A + hlit, hdist, build, wave) && ok;
+    if (live && L.state == ST_HEADER) L.state = (build && ok && !overrun(L)) ? ST_DECODE : ST_FALLBACK;
+}
+
+// ---- one symbol (lane in ST_DECODE with input_ok).  any_sub / any_long: wave-uniform "some lane needs the second level / the long
+// distance codes" (the caller's ballot), so that the rare paths cost nothing when no lane takes them.
+template <class W>
+THJ_IHD void decode_one(Lane& L, bool live, const W& wave) {
+    uint32_t e = 0, n = 0, p = 0;
+    if (live) { refill(L); e = L.lit[(uint32_t)L.buf & (ROOT_SIZE - 1)]; n = e & 15u; p = e >> 4; }
+    const bool sub = live && p >= (uint32_t)P_SUB && p < (uint32_t)P_LEN;
+    if (wave.any(sub)) {
+        if (sub) {
+            const uint32_t e2 = L.lit[(p - (uint32_t)P_SUB) + (((uint32_t)(L.buf >> ROOT)) & ((1u << n) - 1u))];
+            L.buf >>= ROOT; L.cnt -= ROOT;
+            n = e2 & 15u; p = e2 >> 4;
+            if (p >= (uint32_t)P_SUB && p < (uint32_t)P_LEN) n = 0;          // a sub-table never points on
+        }
+    }
+    if (!live) return;
+    if (n == 0) { L.state = ST_FALLBACK; return; }
+    L.buf >>= n; L.cnt -= (int)n;
+    if (p < 256u) { L.tok[L.ntok++] = p; L.outp += 1; return; }
+    if (p == (uint32_t)P_EOB) { L.state = L.last ? ST_DONE : ST_HEADER; return; }
+    const uint32_t ext = (p >> 8) & 7u;
+    const uint32_t len = (p & 255u) + 3u + ((uint32_t)L.buf & ((1u << ext) - 1u));
+    L.buf >>= ext; L.cnt -= (int)ext;
+    refill(L);
+    uint32_t d = L.A[(uint32_t)L.buf & (DROOT_SIZE - 1)];
+    int dn = (int)(d >> 5) + 1; int ds = (int)(d & 31u);
+    if (d == 0xFFu) ds = dist_long(L, dn);
+    if (ds < 0 || ds >= 30) { L.state = ST_FALLBACK; return; }
+    L.buf >>= dn; L.cnt -= dn;
+    uint32_t dbase, dext; dist_base_ext((uint32_t)ds, dbase, dext);
+    const uint32_t dist = dbase + ((uint32_t)L.buf & ((1u << dext) - 1u));
+    L.buf >>= dext; L.cnt -= (int)dext;
+    if (dist > L.outp) { L.state = ST_FALLBACK; return; }
+    L.tok[L.ntok++] = tok_match(len, dist); L.outp += len;
+}
+
+// the whole member: the kernel's loop (and the CPU check's).  CHUNK decode steps between looks at the lanes' states.
+template <class W>
+THJ_IHD void run_member(Lane& L, bool present, uint32_t skew, const W& wave) {
+    // the ring's first 64 bytes before anything is read
+    for (int k = 0; k < 5; ++k) topup(L);
+    if (present) lane_start(L, skew);
+    L.state = present ? ST_HEADER : ST_DONE;
+    for (;;) {
+        if (wave.any(L.state == ST_HEADER)) parse_header(L, wave);
+        if (!wave.any(L.state == ST_DECODE)) break;
+        for (int it = 0; it < 64; ++it) {
+            if ((it & 3) == 0) topup(L);
+            const bool live = L.state == ST_DECODE && input_ok(L);
+            decode_one(L, live, wave);
+            if (L.state == ST_DECODE && (L.outp > 65536u || L.ntok + 1 > TOKCAP || overrun(L))) L.state = ST_FALLBACK;
+        }
+    }
+}
+
+}  // namespace inf2

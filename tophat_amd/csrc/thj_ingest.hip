@@ -133,15 +133,19 @@ enum { ST_HEADER = 0, ST_STORED, ST_CODES, ST_DONE };
 
 
 // out: 65536 bytes per block (block b at b << 16); out_len[b] = inflated bytes (0xFFFFFFFF on a corrupt stream)
+// list / list_n (optional): the members to do are list[0 .. *list_n) -- the ones the two-kernel inflater below handed back
 __global__ __launch_bounds__(64, THJ_INFLATE_WAVES) void thj_k_inflate(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
-                                                     uint8_t* __restrict__ out, uint32_t* __restrict__ out_len) {
+                                                     uint8_t* __restrict__ out, uint32_t* __restrict__ out_len,
+                                                     const uint32_t* __restrict__ list, const uint32_t* __restrict__ list_n) {
     using namespace ing;
     __shared__ Shared s;
     const int lane = threadIdx.x;
     if (lane < 29) { s.lbase[lane] = LBASE[lane]; s.lext[lane] = LEXT[lane]; }
     if (lane < 30) { s.dbase[lane] = DBASE[lane]; s.dext[lane] = DEXT[lane]; }
     __syncthreads();
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int n_todo = list ? (int)*list_n : n_blocks;
+    for (int idx = blockIdx.x; idx < n_todo; idx += gridDim.x) {
+        const int blk = list ? (int)list[idx] : idx;
         const uint8_t* in = comp + blocks[blk].in_off;
         const uint32_t in_len = blocks[blk].in_len;
         uint8_t* dst = out + ((size_t)blk << 16);
@@ -574,16 +578,170 @@ __global__ __launch_bounds__(64) void thj_k_inflate_lanes(const uint8_t* __restr
 #undef LCOPY
 }
 
-// Which inflater: the workgroup-per-block kernel.  THJ_INFLATE=lanes selects the lane-per-block experiment (measured 3.5 GB/s
-// against 12: divergent lanes wait for each other's match copies and table builds; it would need a one-step-per-iteration
-// state machine and tens of thousands of blocks in flight -- kept for that work, not used).
-static void launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_block* d_blocks, int64_t nb, uint8_t* d_out, uint32_t* d_len) {
+
+// ================================================================================================ the two-kernel inflater (round 3)
+// thj_inflate_core.h has the design: entropy decoding one member per lane (thj_k_huff), LZ77 resolution one wave per member (thj_k_lz).
+#include "thj_inflate_core.h"
+
+namespace inf2 {
+struct WaveGpu { __device__ __forceinline__ bool any(bool p) const { return __any((int)p) != 0; } };
+static constexpr int LZ_HIST = 32768, LZ_SLACK = 8192 - 64, LZ_CAP = LZ_HIST + LZ_SLACK;     // + 64 bytes of read slack = 40 KiB: four waves per CU
+
+// wave-wide inclusive prefix sum in DPP steps (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast 15 and 31 across them)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+}  // namespace inf2
+
+// LPW = lanes used per wave: a workgroup always holds 64 members (the LDS of one CU), as 64 / LPW waves
+template <int LPW>
+__global__ __launch_bounds__(64 * (64 / LPW)) void thj_k_huff(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
+                                                              uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok, uint32_t* __restrict__ out_len) {
+    using namespace inf2;
+    __shared__ uint32_t lds[64 * STRIDE_WORDS];
+    const int lane = threadIdx.x & 63, slot = (int)(threadIdx.x >> 6) * LPW + lane;
+    const int m = (int)blockIdx.x * 64 + slot;
+    if (lane >= LPW || m >= n_blocks) return;                              // the wave-wide votes below only count the lanes that stay
+    uint8_t* base = (uint8_t*)(lds + slot * STRIDE_WORDS);
+    Lane L;
+    L.lit = (uint16_t*)base; L.A = base + OFF_A; L.B = base + OFF_B; L.C = (uint16_t*)(base + OFF_C); L.ring = (uint32_t*)(base + OFF_RING);
+    const uint8_t* in = comp + blocks[m].in_off;
+    const uint32_t skew = (uint32_t)((uintptr_t)in & 15u);
+    L.src = in - skew; L.total = skew + blocks[m].in_len;
+    L.buf = 0; L.cnt = 0; L.nextw = 0; L.rd = 4; L.ld = 0; L.outp = 0; L.ntok = 0; L.state = ST_HEADER; L.last = 0; L.inflight = false;
+    L.pend[0] = L.pend[1] = L.pend[2] = L.pend[3] = 0;
+    L.tok = tokens + (size_t)m * TOKCAP;
+    run_member(L, true, skew, WaveGpu{});
+    const bool good = L.state == ST_DONE && !overrun(L);
+    ntok[m] = good ? L.ntok : NTOK_FALLBACK;
+    out_len[m] = good ? L.outp : 0xFFFFFFFFu;
+}
+
+// one wave per member.  buf = the member's output from `origin` on (at least the last 32 KiB: DEFLATE's reach); when a batch does not
+// fit, what is complete goes to HBM in 16-byte pieces and the buffer slides down.  Members kernel 1 refused are listed for the one-lane kernel.
+__global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ tokens, const uint32_t* __restrict__ ntok, int n_blocks, uint8_t* __restrict__ out,
+                                               uint32_t* __restrict__ out_len, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
+    using namespace inf2;
+    __shared__ __attribute__((aligned(16))) uint8_t buf[LZ_CAP + 64];
+    const int m = (int)blockIdx.x, lane = (int)threadIdx.x;
+    const uint32_t n = ntok[m];
+    if (n == NTOK_FALLBACK) { if (lane == 0) fb_list[atomicAdd(fb_count, 1u)] = (uint32_t)m; return; }
+    const uint32_t* tk = tokens + (size_t)m * TOKCAP;
+    uint8_t* dst = out + ((size_t)m << 16);
+    uint32_t origin = 0, flushed = 0, pos = 0, i0 = 0;
+    bool slid = false;
+    uint32_t tok = (uint32_t)lane < n ? tk[lane] : 0u;
+    while (i0 < n) {
+        const uint32_t tok_next = i0 + 64u + (uint32_t)lane < n ? tk[i0 + 64u + (uint32_t)lane] : 0u;      // on its way while this batch is done
+        const bool valid = i0 + (uint32_t)lane < n;
+        const bool is_m = valid && (tok >> 31);
+        const uint32_t len = !valid ? 0u : is_m ? ((tok >> 15) & 255u) + 3u : 1u;
+        const uint32_t incl = wave_incl_scan(len);
+        const uint32_t room = origin + (uint32_t)LZ_CAP - pos;
+        const uint64_t takes = __ballot(valid && incl <= room);                  // a prefix of the lanes
+        const int ntake = __popcll(takes);
+        const int nvalid = (int)(n - i0 < 64u ? n - i0 : 64u);
+        if (ntake < nvalid && !slid) {
+            // ---- no room for the whole batch: what is complete goes out, the buffer slides down, and the batch is looked at again
+            // (room after a slide: at least 8 KiB less 15 bytes; a batch that is longer still is done in pieces)
+            for (uint32_t o = flushed + (uint32_t)lane * 16u; o + 16u <= pos; o += 1024u) *(uint4*)(dst + o) = *(const uint4*)&buf[o - origin];
+            if ((pos & ~15u) > flushed) flushed = pos & ~15u;
+            const uint32_t no = pos > (uint32_t)LZ_HIST ? (pos - (uint32_t)LZ_HIST) & ~15u : 0u;
+            if (no > origin) {
+                const uint32_t shift = no - origin, keep = pos - no;
+                for (uint32_t o = (uint32_t)lane * 16u; o < keep; o += 1024u) { const uint4 v = *(const uint4*)&buf[shift + o]; *(uint4*)&buf[o] = v; }
+                origin = no;
+            }
+            slid = true;
+            continue;
+        }
+        slid = false;
+        if (ntake == 0) break;                                                   // cannot happen (a token is at most 258 bytes); reported below as a failure
+        const bool take = ((takes >> lane) & 1ull) != 0;
+        const uint32_t a = pos + incl - len - origin;                            // where this lane's bytes go in buf
+        if (take && !is_m) buf[a] = (uint8_t)tok;
+        const uint32_t dist = (tok & 0x7FFFu) + 1u;
+        const uint32_t s = a - dist;                                             // >= 0: kernel 1 checked dist <= position, and origin keeps 32 KiB
+        const uint32_t send = s + (len < dist ? len : dist);
+        uint64_t pend = __ballot(take && is_m);
+        while (pend) {
+            const int f = __builtin_ctzll(pend);
+            const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)a, f);        // everything below the first open match is final
+            const bool mine = ((pend >> lane) & 1ull) != 0;
+            const bool rdy = mine && send <= hwm;
+            const bool small = rdy && len <= 16u && dist >= len;
+            if (small) {
+                // up to 16 bytes, source and destination apart: two (unaligned) 8-byte reads, then exactly len bytes written
+                uint64_t lo, hi;
+                __builtin_memcpy(&lo, &buf[s], 8); __builtin_memcpy(&hi, &buf[s + 8], 8);
+                uint32_t w = a; uint32_t rest = len; uint64_t v = lo;
+                if (rest >= 8u) { __builtin_memcpy(&buf[w], &lo, 8); w += 8u; rest -= 8u; v = hi; }
+                if (rest == 8u) __builtin_memcpy(&buf[w], &v, 8);
+                else {
+                    if (rest & 4u) { const uint32_t x = (uint32_t)v; __builtin_memcpy(&buf[w], &x, 4); w += 4u; v >>= 32; }
+                    if (rest & 2u) { const uint16_t x = (uint16_t)v; __builtin_memcpy(&buf[w], &x, 2); w += 2u; v >>= 16; }
+                    if (rest & 1u) buf[w] = (uint8_t)v;
+                }
+            }
+            // the long and the self-overlapping ones: the whole wave on each, 64 bytes a step; a match that overlaps itself repeats its
+            // first dist bytes, so every byte is read from those (all lanes read before any writes)
+            uint64_t big = __ballot(rdy && !small);
+            while (big) {
+                const int g = __builtin_ctzll(big); big &= big - 1;
+                const uint32_t ga = (uint32_t)__builtin_amdgcn_readlane((int)a, g), gs = (uint32_t)__builtin_amdgcn_readlane((int)s, g);
+                const uint32_t gl = (uint32_t)__builtin_amdgcn_readlane((int)len, g), gd = (uint32_t)__builtin_amdgcn_readlane((int)dist, g);
+                if (gd >= gl) { for (uint32_t k = (uint32_t)lane; k < gl; k += 64u) { const uint8_t b = buf[gs + k]; buf[ga + k] = b; } }
+                else { for (uint32_t k = (uint32_t)lane; k < gl; k += 64u) { const uint8_t b = buf[gs + k % gd]; buf[ga + k] = b; } }
+            }
+            pend &= ~__ballot(rdy);
+        }
+        pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, ntake - 1);
+        i0 += (uint32_t)ntake;
+        tok = ntake == 64 ? tok_next : (i0 + (uint32_t)lane < n ? tk[i0 + (uint32_t)lane] : 0u);
+    }
+    // ---- what is left: whole 16-byte pieces, then the tail
+    for (uint32_t o = flushed + (uint32_t)lane * 16u; o + 16u <= pos; o += 1024u) *(uint4*)(dst + o) = *(const uint4*)&buf[o - origin];
+    if ((pos & ~15u) > flushed) flushed = pos & ~15u;
+    if (flushed + (uint32_t)lane < pos) dst[flushed + (uint32_t)lane] = buf[flushed + (uint32_t)lane - origin];
+    if (lane == 0) out_len[m] = i0 < n ? 0xFFFFFFFFu : pos;
+}
+
+// Which inflater.  Default: the two kernels above, then the one-lane kernel over whatever members they handed back (stored blocks,
+// members of more than TOKCAP symbols, corrupt streams -- normally none: its workgroups read a zero count and leave).
+// THJ_INFLATE=one: the round-2 kernel alone; =lanes: the round-2 lane-per-member experiment; THJ_HUFF_LPW=16|32|64: lanes per wave of kernel 1.
+static int launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_block* d_blocks, int64_t nb, uint8_t* d_out, uint32_t* d_len) {
     static const char* force = getenv("THJ_INFLATE");
-    static const int lanes_min = getenv("THJ_INFLATE_LANES_MIN") ? atoi(getenv("THJ_INFLATE_LANES_MIN")) : 0;
-    const bool lanes = force ? force[0] == 'l' : (lanes_min > 0 && nb >= lanes_min);
-    if (lanes) hipLaunchKernelGGL(thj_k_inflate_lanes, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len);
-    else { const int64_t grid = nb < (1 << 20) ? nb : (1 << 20);      // a workgroup per member: the dispatcher balances the tail
-           hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len); }
+    static const int lpw = getenv("THJ_HUFF_LPW") ? atoi(getenv("THJ_HUFF_LPW")) : 64;
+    if (force && force[0] == 'l') { hipLaunchKernelGGL(thj_k_inflate_lanes, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len); return THJ_OK; }
+    const int64_t grid1 = nb < (1 << 20) ? nb : (1 << 20);                    // a workgroup per member: the dispatcher balances the tail
+    if (force && force[0] == 'o') {
+        hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid1), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
+        return THJ_OK;
+    }
+    const size_t need = (size_t)nb * ((size_t)inf2::TOKCAP * 4 + 8) + 256;
+    if (c->infl_tmp_cap < need) {
+        HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_infl_tmp); c->d_infl_tmp = nullptr; c->infl_tmp_cap = 0;
+        HIPCHK(hipMalloc(&c->d_infl_tmp, need + need / 4)); c->infl_tmp_cap = need + need / 4;
+    }
+    uint32_t* d_tok = (uint32_t*)c->d_infl_tmp;
+    uint32_t* d_ntok = d_tok + (size_t)nb * inf2::TOKCAP;
+    uint32_t* d_fb = d_ntok + nb;
+    uint32_t* d_fbn = d_fb + nb;
+    HIPCHK(hipMemsetAsync(d_fbn, 0, 4, c->stream));
+    const dim3 g((unsigned)((nb + 63) / 64));
+    if (lpw == 16) hipLaunchKernelGGL(thj_k_huff<16>, g, dim3(256), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
+    else if (lpw == 32) hipLaunchKernelGGL(thj_k_huff<32>, g, dim3(128), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
+    else hipLaunchKernelGGL(thj_k_huff<64>, g, dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
+    hipLaunchKernelGGL(thj_k_lz, dim3((unsigned)nb), dim3(64), 0, c->stream, d_tok, d_ntok, (int)nb, d_out, d_len, d_fb, d_fbn);
+    hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len, (const uint32_t*)d_fb, (const uint32_t*)d_fbn);
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -598,13 +756,13 @@ extern "C" int thj_bgzf_inflate(thj_ctx* c, const uint8_t* comp, int64_t comp_by
     const uint8_t* d_comp = comp; const thj_bgzf_block* d_blocks = blocks; uint8_t* d_out = out; uint32_t* d_len = out_len;
     void *t0 = nullptr, *t1 = nullptr, *t2 = nullptr, *t3 = nullptr;
     if (!on_device) {
-        HIPCHK(hipMalloc(&t0, (size_t)comp_bytes + 16)); HIPCHK(hipMalloc(&t1, (size_t)n_blocks * sizeof(thj_bgzf_block)));
+        HIPCHK(hipMalloc(&t0, (size_t)comp_bytes + 64)); HIPCHK(hipMalloc(&t1, (size_t)n_blocks * sizeof(thj_bgzf_block)));
         HIPCHK(hipMalloc(&t2, (size_t)n_blocks << 16)); HIPCHK(hipMalloc(&t3, (size_t)n_blocks * 4));
         HIPCHK(hipMemcpyAsync(t0, comp, (size_t)comp_bytes, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(t1, blocks, (size_t)n_blocks * sizeof(thj_bgzf_block), hipMemcpyHostToDevice, c->stream));
         d_comp = (const uint8_t*)t0; d_blocks = (const thj_bgzf_block*)t1; d_out = (uint8_t*)t2; d_len = (uint32_t*)t3;
     }
-    launch_inflate(c, d_comp, d_blocks, n_blocks, d_out, d_len);
+    { const int rc_ = launch_inflate(c, d_comp, d_blocks, n_blocks, d_out, d_len); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(out_len, t3, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1068,7 +1226,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipMemsetAsync(d_status, 0, 64, c->stream));
     HIPCHK(hipMemsetAsync(d_cnt + nb, 0, 4, c->stream));
     pc.mark(0);
-    launch_inflate(c, d_comp, d_blocks, nb, d_infl, d_len);
+    { const int rc_ = launch_inflate(c, d_comp, d_blocks, nb, d_infl, d_len); if (rc_) return rc_; }
     pc.mark(1);
     hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
     int rc = exclusive_sum(c, d_cnt, d_base, nb + 1);

@@ -654,7 +654,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipHostFree(c->h_pinned);
     thj_span_free(c);
     cov_free(c);
-    hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); thj_dev_cache_free(c);
+    hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); hipFree(c->d_infl_tmp); thj_dev_cache_free(c);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
     if (c->own_stream) hipStreamDestroy(c->stream);
