@@ -20,7 +20,7 @@ extern "C" int inflate_sim_huff(const uint8_t* comp, uint32_t in_len, uint32_t s
     memcpy(stream.data() + skew, comp, in_len);
     Lane L;
     memset(&L, 0, sizeof L);
-    L.lit = (uint16_t*)lds.data(); L.A = lds.data() + OFF_A; L.B = lds.data() + OFF_B; L.C = (uint16_t*)(lds.data() + OFF_C); L.ring = (uint32_t*)(lds.data() + OFF_RING);
+    L.lit = (uint16_t*)lds.data(); L.A = lds.data() + OFF_A; L.B = lds.data() + OFF_B; L.C = (uint16_t*)(lds.data() + OFF_C); L.ring = (uint32_t*)(lds.data() + OFF_RING); L.stage = (uint32_t*)(lds.data() + OFF_STAGE);
     L.src = stream.data(); L.total = skew + in_len; L.rd = 4; L.tok = tokens;
     run_member(L, true, skew, WaveCpu{});
     const bool good = L.state == ST_DONE && !overrun(L);

@@ -16,6 +16,7 @@
 //   B[64]           distance codes longer than 8 bits: per length {first code, count, list base} + the symbols in canonical order
 //   C[64]      u16  count / next-code per length while tables are built
 //   ring[256]  u8   compressed input, topped up 16 bytes at a time at uniform points of the loop (loads land one top-up later)
+//   stage[8]   u32  the newest tokens; they leave for HBM four at a time (16-byte stores) at the same uniform points
 #pragma once
 #include <cstdint>
 #include <cstring>
@@ -31,8 +32,9 @@ namespace inf2 {
 constexpr int ROOT = 9, ROOT_SIZE = 1 << ROOT, LIT_ENTRIES = 852;
 constexpr int DROOT = 8, DROOT_SIZE = 1 << DROOT;
 constexpr int RING = 256;
-constexpr int OFF_A = LIT_ENTRIES * 2, OFF_B = OFF_A + 320, OFF_C = OFF_B + 64, OFF_RING = OFF_C + 64, LANE_BYTES = OFF_RING + RING;   // 2408
-constexpr int STRIDE_WORDS = 603;                          // >= LANE_BYTES / 4, odd: the lanes' slices start in different banks
+constexpr int STAGE = 8;                                   // tokens staged per member before they leave 16 bytes at a time
+constexpr int OFF_A = LIT_ENTRIES * 2, OFF_B = OFF_A + 320, OFF_C = OFF_B + 64, OFF_RING = OFF_C + 64, OFF_STAGE = OFF_RING + RING, LANE_BYTES = OFF_STAGE + STAGE * 4;   // 2440
+constexpr int STRIDE_WORDS = 611;                          // >= LANE_BYTES / 4, odd: the lanes' slices start in different banks
 static_assert(STRIDE_WORDS * 4 >= LANE_BYTES && (STRIDE_WORDS & 1), "LDS slice");
 constexpr uint32_t TOKCAP = 20480;                         // tokens kept per member (zlib closes a block at 16383 symbols; typical BAM members: 11-14 k)
 constexpr uint32_t NTOK_FALLBACK = 0xFFFFFFFFu;            // ntok[]: this member goes to the one-lane kernel (stored blocks, too many tokens, corrupt streams)
@@ -52,11 +54,11 @@ struct Lane {
     uint32_t rd;                           // read position in the aligned stream (bytes, multiple of 4)
     uint32_t ld;                           // bytes of the aligned stream landed in the ring (multiple of 16)
     uint32_t total;                        // skew + compressed length: where the member's bytes end in the aligned stream
-    uint32_t outp, ntok;
+    uint32_t outp, ntok, nflushed;         // tokens made / tokens already in HBM (multiple of 4 until the end)
     int state, last;
     bool inflight; uint32_t pend[4];       // a 16-byte piece on its way
     const uint8_t* src;                    // the aligned stream (16-byte aligned address at or before the member's first byte)
-    uint16_t* lit; uint8_t* A; uint8_t* B; uint16_t* C; uint32_t* ring;
+    uint16_t* lit; uint8_t* A; uint8_t* B; uint16_t* C; uint32_t* ring; uint32_t* stage;
     uint32_t* tok;
 };
 
@@ -82,10 +84,31 @@ THJ_IHD void topup(Lane& L) {                               // uniform points on
         L.inflight = true;
     }
 }
+THJ_IHD void flush_tokens(Lane& L) {                        // uniform points only, before topup(): the store is older than the load topup() issues
+    if (L.ntok - L.nflushed >= 4u) {
+        const uint32_t* st = L.stage + (L.nflushed & (STAGE - 1));
+        uint32_t v[4] = {st[0], st[1], st[2], st[3]};
+        memcpy(L.tok + L.nflushed, v, 16);
+        L.nflushed += 4;
+    }
+}
+THJ_IHD void flush_tokens_end(Lane& L) {
+    flush_tokens(L);
+    for (; L.nflushed < L.ntok; ++L.nflushed) L.tok[L.nflushed] = L.stage[L.nflushed & (STAGE - 1)];
+}
 THJ_IHD bool input_ok(const Lane& L) { return L.rd + 8 <= L.ld || L.ld >= L.total; }       // two more ring words may be read (or all there is has landed)
 THJ_IHD void refill(Lane& L) {
     if (L.cnt <= 32) { L.buf |= (uint64_t)L.nextw << L.cnt; L.cnt += 32; L.nextw = L.ring[(L.rd & (RING - 1)) >> 2]; L.rd += 4; }
 }
+// the same without a branch (the decode loop): lanes that are not live keep their state; the ring read always happens, its address is always valid
+THJ_IHD void refill_bf(Lane& L, bool live) {
+    const bool need = live && L.cnt <= 32;
+    const uint32_t w = L.ring[(L.rd & (RING - 1)) >> 2];
+    L.buf |= need ? (uint64_t)L.nextw << (L.cnt & 63) : 0ull;
+    L.cnt += need ? 32 : 0; L.rd += need ? 4u : 0u;
+    L.nextw = need ? w : L.nextw;
+}
+THJ_IHD uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { return (x >> off) & ((1u << width) - 1u); }
 THJ_IHD uint32_t take(Lane& L, int n) { const uint32_t v = (uint32_t)L.buf & ((1u << n) - 1u); L.buf >>= n; L.cnt -= n; return v; }
 THJ_IHD void lane_start(Lane& L, uint32_t skew) {          // after the ring's first pieces have landed
     L.rd = skew & ~3u;
@@ -94,7 +117,7 @@ THJ_IHD void lane_start(Lane& L, uint32_t skew) {          // after the ring's f
     L.nextw = L.ring[(L.rd & (RING - 1)) >> 2]; L.rd += 4;
 }
 // bits of the member consumed so far must not exceed what it has (a stream that runs off its end decodes the zero / stale padding)
-THJ_IHD bool overrun(const Lane& L) { return (int64_t)(L.rd - 4) * 8 - L.cnt > (int64_t)L.total * 8; }
+THJ_IHD bool overrun(const Lane& L) { return (int32_t)((L.rd - 4u) * 8u) - L.cnt > (int32_t)(L.total * 8u); }      // members are at most 64 KiB: 32 bits do
 
 // ---- length / distance arithmetic (RFC 1951, 3.2.5) without tables
 THJ_IHD uint32_t len_payload(uint32_t k) {                  // k = symbol - 257; 0 = no such code (286, 287)
@@ -196,19 +219,24 @@ THJ_IHD bool build_dist(Lane& L, const uint8_t* dl, int n, bool live, const W& w
     return ok;
 }
 
-// a distance code of more than 8 bits (the root said 0xFF): canonical decode over lengths 9..15.  Returns the symbol or -1; n = its length
+// a distance code of more than 8 bits (the root said 0xFF): canonical decode over lengths 9..15.  Returns the symbol or -1; n = its length.
+// Straight-line: the seven per-length words are read together, the shortest length whose code range holds the next bits is selected.
 THJ_IHD int dist_long(const Lane& L, int& n) {
     const uint32_t* bl = (const uint32_t*)L.B; const uint8_t* bsym = L.B + 28;
-    uint32_t code = rev_bits((uint32_t)L.buf & 0xFFu, 8);            // the first 8 bits, first bit most significant
-    int res = -1; n = 0;
+    uint32_t w[7];
 #pragma unroll
-    for (int l = DROOT + 1; l < 16; ++l) {
-        code = code << 1 | (uint32_t)((L.buf >> (l - 1)) & 1u);
-        const uint32_t w = bl[l - DROOT - 1];
-        const uint32_t d = code - (w & 0x7FFFu);
-        if (res < 0 && d < ((w >> 15) & 63u)) { res = (int)bsym[(w >> 21) + d]; n = l; }
+    for (int q = 0; q < 7; ++q) w[q] = bl[q];
+    const uint32_t c15 = rev_bits((uint32_t)L.buf & 0x7FFFu, 15);      // the next 15 bits, first bit most significant
+    uint32_t idx = 0; n = 0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int l = DROOT + 1 + q;
+        const uint32_t d = (c15 >> (15 - l)) - (w[q] & 0x7FFFu);
+        const bool hit = n == 0 && d < ((w[q] >> 15) & 63u);
+        idx = hit ? (w[q] >> 21) + d : idx; n = hit ? l : n;
     }
-    return res;
+    const int sym = (int)bsym[idx & 31u];
+    return n ? sym : -1;
 }
 
 // ---- one block header (lane in ST_HEADER): BFINAL, BTYPE, code lengths, tables.  Lock step: lanes not in ST_HEADER idle through it.
@@ -282,43 +310,50 @@ THJ_IHD void parse_header(Lane& L, const W& wave) {
     if (live && L.state == ST_HEADER) L.state = (build && ok && !overrun(L)) ? ST_DECODE : ST_FALLBACK;
 }
 
-// ---- one symbol (lane in ST_DECODE with input_ok).  any_sub / any_long: wave-uniform "some lane needs the second level / the long
-// distance codes" (the caller's ballot), so that the rare paths cost nothing when no lane takes them.
+// ---- one symbol (live = lane in ST_DECODE with input_ok).  Straight-line: every lane computes the match path (a literal lane's
+// distance look-up reads some entry of its own table and is thrown away), results are selected at the end -- no divergent branches
+// for the compiler to serialise, and the look-ups of a step overlap.  Only the rare paths (second table level, distance codes
+// beyond the root table) are branches, taken when some lane of the wave needs them.
 template <class W>
 THJ_IHD void decode_one(Lane& L, bool live, const W& wave) {
-    uint32_t e = 0, n = 0, p = 0;
-    if (live) { refill(L); e = L.lit[(uint32_t)L.buf & (ROOT_SIZE - 1)]; n = e & 15u; p = e >> 4; }
-    const bool sub = live && p >= (uint32_t)P_SUB && p < (uint32_t)P_LEN;
-    if (wave.any(sub)) {
-        if (sub) {
-            const uint32_t e2 = L.lit[(p - (uint32_t)P_SUB) + (((uint32_t)(L.buf >> ROOT)) & ((1u << n) - 1u))];
-            L.buf >>= ROOT; L.cnt -= ROOT;
-            n = e2 & 15u; p = e2 >> 4;
-            if (p >= (uint32_t)P_SUB && p < (uint32_t)P_LEN) n = 0;          // a sub-table never points on
-        }
+    refill_bf(L, live);
+    const uint32_t lo = (uint32_t)L.buf;
+    const uint32_t e = L.lit[lo & (ROOT_SIZE - 1)];
+    uint32_t n = e & 15u, p = e >> 4, nl = n;
+    const bool sub = (p - (uint32_t)P_SUB) < (uint32_t)(P_LEN - P_SUB);
+    if (wave.any(live && sub)) {
+        const uint32_t idx = sub ? (p - (uint32_t)P_SUB) + bfe(lo >> ROOT, 0, n) : 0u;
+        const uint32_t e2 = L.lit[idx];
+        const uint32_t n2 = e2 & 15u, p2 = e2 >> 4;
+        const bool ok2 = !((p2 - (uint32_t)P_SUB) < (uint32_t)(P_LEN - P_SUB)) && n2 != 0u;      // a sub-table never points on
+        n = sub ? (ok2 ? n2 : 0u) : n;
+        nl = sub ? (uint32_t)ROOT + n2 : nl;
+        p = sub ? p2 : p;
     }
-    if (!live) return;
-    if (n == 0) { L.state = ST_FALLBACK; return; }
-    L.buf >>= n; L.cnt -= (int)n;
-    if (p < 256u) { L.tok[L.ntok++] = p; L.outp += 1; return; }
-    if (p == (uint32_t)P_EOB) { L.state = L.last ? ST_DONE : ST_HEADER; return; }
+    const bool is_lit = p < 256u, is_eob = p == (uint32_t)P_EOB, is_len = p >= (uint32_t)P_LEN;
     const uint32_t ext = (p >> 8) & 7u;
-    const uint32_t len = (p & 255u) + 3u + ((uint32_t)L.buf & ((1u << ext) - 1u));
-    L.buf >>= ext; L.cnt -= (int)ext;
-    refill(L);
-    uint32_t d = L.A[(uint32_t)L.buf & (DROOT_SIZE - 1)];
-    int dn = (int)(d >> 5) + 1; int ds = (int)(d & 31u);
-    if (d == 0xFFu) ds = dist_long(L, dn);
-    if (ds < 0 || ds >= 30) { L.state = ST_FALLBACK; return; }
-    L.buf >>= dn; L.cnt -= dn;
-    uint32_t dbase, dext; dist_base_ext((uint32_t)ds, dbase, dext);
-    const uint32_t dist = dbase + ((uint32_t)L.buf & ((1u << dext) - 1u));
-    L.buf >>= dext; L.cnt -= (int)dext;
-    if (dist > L.outp) { L.state = ST_FALLBACK; return; }
-    L.tok[L.ntok++] = tok_match(len, dist); L.outp += len;
+    const uint32_t len = (p & 255u) + 3u + bfe(lo, nl, ext);                 // nl + ext <= 20: inside the low word
+    const uint32_t used1 = live ? nl + (is_len ? ext : 0u) : 0u;
+    L.buf >>= used1; L.cnt -= (int)used1;
+    refill_bf(L, live && is_len);
+    const uint32_t lo2 = (uint32_t)L.buf;
+    const uint32_t d = L.A[lo2 & (DROOT_SIZE - 1)];
+    int dn = (int)(d >> 5) + 1, ds = (int)(d & 31u);
+    if (wave.any(live && is_len && d == 0xFFu)) { int n2; const int s2 = dist_long(L, n2); if (d == 0xFFu) { ds = s2; dn = n2; } }
+    uint32_t dbase, dext; dist_base_ext((uint32_t)(ds < 0 ? 0 : ds), dbase, dext);
+    const uint32_t dist = dbase + bfe(lo2, (uint32_t)dn, dext);              // dn + dext <= 28
+    const uint32_t used2 = (live && is_len) ? (uint32_t)dn + dext : 0u;
+    L.buf >>= used2; L.cnt -= (int)used2;
+    const uint32_t adv = is_lit ? 1u : len;
+    const bool bad = n == 0u || (is_len && (ds < 0 || ds >= 30 || dist > L.outp)) || (!is_eob && (L.outp + adv > 65536u || L.ntok + 1u > TOKCAP));
+    const bool emit = live && !bad && !is_eob;
+    if (emit) L.stage[L.ntok & (STAGE - 1)] = is_lit ? p : tok_match(len, dist);
+    L.ntok += emit ? 1u : 0u; L.outp += emit ? adv : 0u;
+    if (live) L.state = bad ? ST_FALLBACK : is_eob ? ((L.last && !overrun(L)) ? ST_DONE : (L.last ? ST_FALLBACK : ST_HEADER)) : ST_DECODE;
 }
 
-// the whole member: the kernel's loop (and the CPU check's).  CHUNK decode steps between looks at the lanes' states.
+// the whole member: the kernel's loop (and the CPU check's).  Sixteen uniform points (tokens out, input in), four symbols after each,
+// between two looks at the lanes' states.
 template <class W>
 THJ_IHD void run_member(Lane& L, bool present, uint32_t skew, const W& wave) {
     // the ring's first 64 bytes before anything is read
@@ -328,13 +363,14 @@ THJ_IHD void run_member(Lane& L, bool present, uint32_t skew, const W& wave) {
     for (;;) {
         if (wave.any(L.state == ST_HEADER)) parse_header(L, wave);
         if (!wave.any(L.state == ST_DECODE)) break;
-        for (int it = 0; it < 64; ++it) {
-            if ((it & 3) == 0) topup(L);
-            const bool live = L.state == ST_DECODE && input_ok(L);
-            decode_one(L, live, wave);
-            if (L.state == ST_DECODE && (L.outp > 65536u || L.ntok + 1 > TOKCAP || overrun(L))) L.state = ST_FALLBACK;
+        for (int it = 0; it < 16; ++it) {
+            flush_tokens(L);
+            topup(L);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) decode_one(L, L.state == ST_DECODE && input_ok(L), wave);
         }
     }
+    flush_tokens_end(L);
 }
 
 }  // namespace inf2

@@ -610,11 +610,11 @@ __global__ __launch_bounds__(64 * (64 / LPW)) void thj_k_huff(const uint8_t* __r
     if (lane >= LPW || m >= n_blocks) return;                              // the wave-wide votes below only count the lanes that stay
     uint8_t* base = (uint8_t*)(lds + slot * STRIDE_WORDS);
     Lane L;
-    L.lit = (uint16_t*)base; L.A = base + OFF_A; L.B = base + OFF_B; L.C = (uint16_t*)(base + OFF_C); L.ring = (uint32_t*)(base + OFF_RING);
+    L.lit = (uint16_t*)base; L.A = base + OFF_A; L.B = base + OFF_B; L.C = (uint16_t*)(base + OFF_C); L.ring = (uint32_t*)(base + OFF_RING); L.stage = (uint32_t*)(base + OFF_STAGE);
     const uint8_t* in = comp + blocks[m].in_off;
     const uint32_t skew = (uint32_t)((uintptr_t)in & 15u);
     L.src = in - skew; L.total = skew + blocks[m].in_len;
-    L.buf = 0; L.cnt = 0; L.nextw = 0; L.rd = 4; L.ld = 0; L.outp = 0; L.ntok = 0; L.state = ST_HEADER; L.last = 0; L.inflight = false;
+    L.buf = 0; L.cnt = 0; L.nextw = 0; L.rd = 4; L.ld = 0; L.outp = 0; L.ntok = 0; L.nflushed = 0; L.state = ST_HEADER; L.last = 0; L.inflight = false;
     L.pend[0] = L.pend[1] = L.pend[2] = L.pend[3] = 0;
     L.tok = tokens + (size_t)m * TOKCAP;
     run_member(L, true, skew, WaveGpu{});
