@@ -5,6 +5,7 @@
 #include "../../tophat_amd/csrc/thj_inflate_core.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -26,6 +27,74 @@ extern "C" int inflate_sim_huff(const uint8_t* comp, uint32_t in_len, uint32_t s
     const bool good = L.state == ST_DONE && !overrun(L);
     *ntok = good ? L.ntok : NTOK_FALLBACK; *outp = good ? L.outp : 0;
     return good ? 0 : 1;
+}
+
+// thj_k_huffp restated around the shared lane code: lane 0's header parse (Lane / parse_header), then the 64 lanes' segment passes
+// (decode_segment) with the wave's shuffles and votes as loops over a lane array.  passes_out: segment passes run (statistics).
+extern "C" int inflate_sim_huffp(const uint8_t* comp, uint32_t in_len, uint32_t skew, uint32_t* tokens, uint32_t* ntok, uint32_t* outp, int64_t* passes_out) {
+    std::vector<uint8_t> lds((size_t)STRIDE_WORDS * 4, 0xA5);
+    std::vector<uint8_t> stream((size_t)skew + in_len + 64 + 16, 0x5A);
+    uint8_t* st0 = stream.data() + ((16 - ((uintptr_t)stream.data() & 15)) & 15);      // 16-byte aligned like Lane::src on the device
+    memcpy(st0 + skew, comp, in_len);
+    Lane H;
+    memset(&H, 0, sizeof H);
+    H.lit = (uint16_t*)lds.data(); H.A = lds.data() + OFF_A; H.B = lds.data() + OFF_B; H.C = (uint16_t*)(lds.data() + OFF_C); H.ring = (uint32_t*)(lds.data() + OFF_RING); H.stage = (uint32_t*)(lds.data() + OFF_STAGE);
+    H.src = st0; H.total = skew + in_len; H.tok = tokens;
+    const uint32_t* w = (const uint32_t*)st0;
+    const uint32_t limit = H.total * 8;
+    uint32_t tok_base = 0, out_base = 0, hpos = skew * 8;
+    int64_t passes = 0;
+    *ntok = NTOK_FALLBACK; *outp = 0;
+    for (;;) {
+        lane_seek(H, hpos); H.state = ST_HEADER;
+        parse_header(H, WaveCpu{});
+        if (H.state != ST_DECODE) return 1;
+        const uint32_t dstart = lane_bitpos(H);
+        const uint32_t rem = limit > dstart ? limit - dstart : 0;
+        uint32_t seg = (rem + 63) / 64; if (seg < 64) seg = 64;
+        uint32_t s[64], bn[64]; Seg r[64]; bool ch[64];
+        for (int l = 0; l < 64; ++l) { s[l] = dstart + (uint32_t)l * seg; bn[l] = l == 63 ? MARK : s[l] + seg; ch[l] = true; }
+        {   // warm-up: lane l > 0 enters the stream some segments early and takes the first symbol at or beyond its border as its start
+            static const int wseg = getenv("THJ_SIM_WARMUP") ? atoi(getenv("THJ_SIM_WARMUP")) : 2;
+            for (int l = 1; l < 64 && wseg > 0; ++l) {
+                const uint32_t border = s[l];
+                const uint32_t back = (uint32_t)std::min(l, wseg) * seg;
+                const Seg wu = decode_segment<false>(H.lit, H.A, H.B, w, limit, border - back, border, nullptr, 0, WaveCpu{});
+                if (wu.e < MARK) s[l] = wu.e;
+            }
+            if (wseg > 0) ++passes;
+        }
+        for (;;) {
+            for (int l = 0; l < 64; ++l) if (ch[l]) r[l] = decode_segment<false>(H.lit, H.A, H.B, w, limit, s[l], bn[l], nullptr, 0, WaveCpu{});
+            ++passes;
+            bool any = false;
+            uint32_t ns[64];
+            for (int l = 0; l < 64; ++l) { ns[l] = l ? r[l - 1].e : s[0]; ch[l] = ns[l] < MARK && ns[l] != s[l]; any = any || ch[l]; }       // a lane that failed says nothing about the next one's start
+            if (!any) break;
+            if (getenv("THJ_SIM_TRACE")) { fprintf(stderr, "round %lld changed:", (long long)passes); for (int l = 0; l < 64; ++l) if (ch[l]) fprintf(stderr, " %d(%+d)", l, (int)(ns[l] - s[l])); fprintf(stderr, "\n"); }
+            for (int l = 0; l < 64; ++l) if (ch[l]) s[l] = ns[l];
+        }
+        // the first lane that did not reach its border ended the block (or the stream is bad); the lanes behind it decoded nothing real
+        int el = -1; uint32_t tot_nt = 0, tot_ob = 0, off_nt[64], off_ob[64];
+        for (int l = 0; l < 64 && el < 0; ++l) if (r[l].e >= MARK) el = l;
+        if (el < 0 || r[el].e != MARK_EOB) return 1;
+        for (int l = 0; l < 64; ++l) {
+            if (l > el) { s[l] = MARK_NONE; r[l].nt = r[l].ob = 0; }
+            off_nt[l] = tot_nt; off_ob[l] = tot_ob; tot_nt += r[l].nt; tot_ob += r[l].ob;
+        }
+        if (tok_base + tot_nt > TOKCAP || out_base + tot_ob > 65536u) return 1;
+        for (int l = 0; l < 64; ++l) {
+            const Seg f = decode_segment<true>(H.lit, H.A, H.B, w, limit, s[l], bn[l], tokens + tok_base + off_nt[l], out_base + off_ob[l], WaveCpu{});
+            if ((l <= el && f.e == MARK_ERR) || f.nt != r[l].nt || f.ob != r[l].ob) return 1;
+        }
+        ++passes;
+        tok_base += tot_nt; out_base += tot_ob;
+        hpos = r[el].eob_pos;
+        if (H.last) break;
+    }
+    *ntok = tok_base; *outp = out_base;
+    if (passes_out) *passes_out = passes;
+    return 0;
 }
 
 // thj_k_lz restated: returns the number of bytes written to out (65536 bytes), or -1 on an inconsistency

@@ -42,11 +42,22 @@ def raw_deflate(data, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, mem=8, flush_ev
     return out + c.flush()
 
 
+PASSES = []          # segment passes per member of the wave-per-member design (statistics)
+
+
 def run(lib, comp, skew=0):
     tokens = np.zeros(TOKCAP + 8, dtype=np.uint32)
     ntok, outp = C.c_uint32(0), C.c_uint32(0)
     cb = (C.c_uint8 * len(comp)).from_buffer_copy(comp)
     rc = lib.inflate_sim_huff(cb, C.c_uint32(len(comp)), C.c_uint32(skew), C.c_void_p(tokens.ctypes.data), C.byref(ntok), C.byref(outp))
+    # the wave-per-member kernel's logic must produce the very same token stream
+    tokens2 = np.zeros(TOKCAP + 8, dtype=np.uint32)
+    ntok2, outp2, passes = C.c_uint32(0), C.c_uint32(0), C.c_int64(0)
+    rc2 = lib.inflate_sim_huffp(cb, C.c_uint32(len(comp)), C.c_uint32(skew), C.c_void_p(tokens2.ctypes.data), C.byref(ntok2), C.byref(outp2), C.byref(passes))
+    assert rc2 == rc, (rc, rc2)
+    if not rc:
+        assert ntok2.value == ntok.value and outp2.value == outp.value and (tokens2[:ntok.value] == tokens[:ntok.value]).all()
+        PASSES.append(passes.value)
     if rc:
         assert ntok.value == FALLBACK
         return None, 0

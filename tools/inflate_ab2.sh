@@ -4,7 +4,8 @@ set -u
 d=/dev/shm/thj_infl_ab
 rm -rf $d; mkdir -p $d
 tools/bin/thj_gen --out $d --pairs ${1:-4000000} > /dev/null
-for cfg in "THJ_INFLATE=one" "THJ_HUFF_LPW=64" "THJ_HUFF_LPW=32" "THJ_HUFF_LPW=16"; do
+shift
+for cfg in "$@"; do
   for f in left_seg1 left_map left_reads; do
     echo -n "$cfg $f: "; env $cfg timeout 300 python tools/inflate_bench.py $d/$f.bam 5 2>/dev/null | tail -1
   done

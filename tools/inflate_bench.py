@@ -25,6 +25,8 @@ while off < len(data):
     bsize = struct.unpack_from("<H", data, off + 16)[0] + 1
     offs.append(off + 18); lens.append(bsize - 26); isz.append(struct.unpack_from("<I", data, off + bsize - 4)[0])
     off += bsize
+if len(sys.argv) > 3:                                  # only the first N members (how the rate depends on the size of a launch)
+    k = int(sys.argv[3]); offs, lens, isz = offs[:k], lens[:k], isz[:k]
 n = len(offs)
 blk = np.zeros(n, dtype=[("in_off", "<u8"), ("in_len", "<u4"), ("r", "<u4")])
 blk["in_off"], blk["in_len"] = offs, lens

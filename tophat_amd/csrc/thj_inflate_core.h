@@ -221,12 +221,12 @@ THJ_IHD bool build_dist(Lane& L, const uint8_t* dl, int n, bool live, const W& w
 
 // a distance code of more than 8 bits (the root said 0xFF): canonical decode over lengths 9..15.  Returns the symbol or -1; n = its length.
 // Straight-line: the seven per-length words are read together, the shortest length whose code range holds the next bits is selected.
-THJ_IHD int dist_long(const Lane& L, int& n) {
-    const uint32_t* bl = (const uint32_t*)L.B; const uint8_t* bsym = L.B + 28;
+THJ_IHD int dist_long_raw(const uint8_t* Bt, uint32_t lo, int& n) {
+    const uint32_t* bl = (const uint32_t*)Bt; const uint8_t* bsym = Bt + 28;
     uint32_t w[7];
 #pragma unroll
     for (int q = 0; q < 7; ++q) w[q] = bl[q];
-    const uint32_t c15 = rev_bits((uint32_t)L.buf & 0x7FFFu, 15);      // the next 15 bits, first bit most significant
+    const uint32_t c15 = rev_bits(lo & 0x7FFFu, 15);                  // the next 15 bits, first bit most significant
     uint32_t idx = 0; n = 0;
 #pragma unroll
     for (int q = 0; q < 7; ++q) {
@@ -238,6 +238,7 @@ THJ_IHD int dist_long(const Lane& L, int& n) {
     const int sym = (int)bsym[idx & 31u];
     return n ? sym : -1;
 }
+THJ_IHD int dist_long(const Lane& L, int& n) { return dist_long_raw(L.B, (uint32_t)L.buf, n); }
 
 // ---- one block header (lane in ST_HEADER): BFINAL, BTYPE, code lengths, tables.  Lock step: lanes not in ST_HEADER idle through it.
 template <class W>
@@ -372,5 +373,94 @@ THJ_IHD void run_member(Lane& L, bool present, uint32_t skew, const W& wave) {
     }
     flush_tokens_end(L);
 }
+
+
+// ================================================================================================ one member per WAVE (round 3, second design)
+// The lane-per-member kernel above is bound by the latency of one member's decode chain: ~11 000 symbols at ~1300 cycles each are 7 ms
+// however few members a launch holds, and the launches of the executables hold 1 500 - 10 000.  A Huffman stream can be entered
+// anywhere: a decoder started at a wrong bit falls into step with the right one after a few dozen symbols (the codes are
+// self-synchronising).  So the block's bits are cut into 64 equal segments, lane i decodes the symbols that START in segment i,
+// and the lanes agree on the starts by iteration: lane i's start is where lane i - 1 stopped (the first symbol at or beyond the
+// segment border); after a first pass from the borders themselves, passes repeat for the lanes whose start changed, until none
+// does -- by induction from lane 0, whose start is exact, every start is then the true one.  Usually two passes, because a lane
+// that started wrong has long fallen into step when it crosses its far border.  A last pass stores the tokens at the offsets a
+// prefix sum over the lanes' counts gives.  ~4 passes over 1/64 of the symbols instead of one over all: ~0.4 ms a member.
+//
+// Positions are bit offsets in the aligned stream (Lane::src, 32-bit words).  The header is parsed by lane 0 with the Lane code above.
+constexpr uint32_t MARK = 0xFFFFFF00u;                     // segment results >= MARK: no position
+constexpr uint32_t MARK_EOB = 0xFFFFFF01u, MARK_ERR = 0xFFFFFF02u, MARK_NONE = 0xFFFFFF03u;
+struct Seg { uint32_t e, nt, ob, eob_pos; };              // e: where the next lane starts (or a mark); tokens, bytes; the bit after an end-of-block code
+
+struct PIn { uint64_t buf; int cnt; uint32_t nextw, widx; const uint32_t* w; };
+THJ_IHD void pin_start(PIn& I, const uint32_t* w, uint32_t s) {
+    const uint32_t k = s >> 5, b = s & 31u;
+    I.w = w; I.buf = (uint64_t)(w[k] >> b); I.cnt = 32 - (int)b; I.nextw = w[k + 1]; I.widx = k + 2;
+}
+THJ_IHD uint32_t pin_pos(const PIn& I) { return (I.widx - 1u) * 32u - (uint32_t)I.cnt; }
+THJ_IHD void pin_refill(PIn& I, bool want) { if (want && I.cnt <= 32) { I.buf |= (uint64_t)I.nextw << I.cnt; I.cnt += 32; I.nextw = I.w[I.widx++]; } }
+
+// the symbols that start in [s, bnext), from tables lit / A / B.  STORE: the last pass -- tokens go to tok[], outp0 = the output position
+// of the first, and distances are checked against it.  limit = bits the member has.
+template <bool STORE, class W>
+THJ_IHD Seg decode_segment(const uint16_t* lit, const uint8_t* A, const uint8_t* Bt, const uint32_t* w, uint32_t limit, uint32_t s, uint32_t bnext,
+                           uint32_t* tok, uint32_t outp0, const W& wave) {
+    Seg r{s, 0, 0, 0};
+    if (s >= MARK) return r;                               // the lane before ended the block (or failed): nothing starts here
+    PIn I; pin_start(I, w, s);
+    uint32_t pos = s, nt = 0, ob = 0;
+    r.e = MARK_NONE;
+    while (pos < bnext) {
+        pin_refill(I, true);
+        const uint32_t lo = (uint32_t)I.buf;
+        const uint32_t e = lit[lo & (ROOT_SIZE - 1)];
+        uint32_t n = e & 15u, p = e >> 4, nl = n;
+        const bool sub = (p - (uint32_t)P_SUB) < (uint32_t)(P_LEN - P_SUB);
+        if (wave.any(sub)) {
+            const uint32_t idx = sub ? (p - (uint32_t)P_SUB) + bfe(lo >> ROOT, 0, n) : 0u;
+            const uint32_t e2 = lit[idx];
+            const uint32_t n2 = e2 & 15u, p2 = e2 >> 4;
+            const bool ok2 = !((p2 - (uint32_t)P_SUB) < (uint32_t)(P_LEN - P_SUB)) && n2 != 0u;
+            n = sub ? (ok2 ? n2 : 0u) : n; nl = sub ? (uint32_t)ROOT + n2 : nl; p = sub ? p2 : p;
+        }
+        const bool is_lit = p < 256u, is_eob = p == (uint32_t)P_EOB, is_len = p >= (uint32_t)P_LEN;
+        const uint32_t ext = (p >> 8) & 7u;
+        const uint32_t len = (p & 255u) + 3u + bfe(lo, nl, ext);
+        const uint32_t used1 = nl + (is_len ? ext : 0u);
+        I.buf >>= used1; I.cnt -= (int)used1;
+        pin_refill(I, is_len);
+        const uint32_t lo2 = (uint32_t)I.buf;
+        const uint32_t d = A[lo2 & (DROOT_SIZE - 1)];
+        int dn = (int)(d >> 5) + 1, ds = (int)(d & 31u);
+        if (wave.any(is_len && d == 0xFFu)) { int n2; const int s2 = dist_long_raw(Bt, lo2, n2); if (d == 0xFFu) { ds = s2; dn = n2; } }
+        uint32_t dbase, dext; dist_base_ext((uint32_t)(ds < 0 ? 0 : ds), dbase, dext);
+        const uint32_t dist = dbase + bfe(lo2, (uint32_t)dn, dext);
+        const uint32_t used2 = is_len ? (uint32_t)dn + dext : 0u;
+        I.buf >>= used2; I.cnt -= (int)used2;
+        pos = pin_pos(I);
+        const uint32_t adv = is_lit ? 1u : len;
+        bool bad = n == 0u || (is_len && (ds < 0 || ds >= 30)) || pos > limit;
+        if (STORE) bad = bad || (is_len && dist > outp0 + ob) || (!is_eob && outp0 + ob + adv > 65536u);
+        if (bad) { r.e = MARK_ERR; break; }
+        if (is_eob) { r.e = MARK_EOB; r.eob_pos = pos; break; }
+        if (STORE) tok[nt] = is_lit ? p : tok_match(len, dist);
+        ++nt; ob += adv;
+    }
+    if (r.e == MARK_NONE) r.e = pos;                       // the first symbol at or beyond the border
+    r.nt = nt; r.ob = ob;
+    return r;
+}
+
+// lane 0's Lane at a bit position of the aligned stream (the first block: skew * 8; later blocks: the bit after the end-of-block code)
+THJ_IHD void lane_seek(Lane& L, uint32_t bitpos) {
+    const uint32_t byte = bitpos >> 3;
+    L.ld = byte & ~15u; L.rd = L.ld + 4; L.inflight = false;
+    for (int k = 0; k < 5; ++k) topup(L);
+    L.rd = byte & ~3u;
+    const uint32_t wd = L.ring[(L.rd & (RING - 1)) >> 2]; L.rd += 4;
+    const uint32_t sh = 8u * (byte & 3u) + (bitpos & 7u);
+    L.buf = (uint64_t)(wd >> sh); L.cnt = 32 - (int)sh;
+    L.nextw = L.ring[(L.rd & (RING - 1)) >> 2]; L.rd += 4;
+}
+THJ_IHD uint32_t lane_bitpos(const Lane& L) { return (L.rd - 4u) * 8u - (uint32_t)L.cnt; }
 
 }  // namespace inf2

@@ -623,6 +623,78 @@ __global__ __launch_bounds__(64 * (64 / LPW)) void thj_k_huff(const uint8_t* __r
     out_len[m] = good ? L.outp : 0xFFFFFFFFu;
 }
 
+// One wave per member (the design note is in thj_inflate_core.h): lane 0 parses the block header and builds the tables, then the 64
+// lanes decode 64 segments of the block's bits -- a warm-up pass from one segment before each border, passes until the lanes agree on
+// where each segment's first symbol starts, and a last pass that stores the tokens.
+namespace inf2 { struct WaveOne { __device__ __forceinline__ bool any(bool p) const { return p; } }; }
+__global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
+                                                  uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok, uint32_t* __restrict__ out_len, uint32_t comp_cap) {
+    using namespace inf2;
+    // [tables and lane 0's input ring: STRIDE_WORDS words][the member's compressed bytes, from the 16-byte granule its first byte is in: comp_cap bytes]
+    // The 64 lanes read 64 places of the stream at once: from HBM that is 64 cache lines per load and, with a few waves on a CU, an L1
+    // that holds none of them by the time they are wanted again (measured: 10 L2 requests per load, the kernel 4 x slower at two waves
+    // per SIMD than at one).  In LDS every look at the stream is a ds_read.
+    extern __shared__ uint32_t lds[];
+    const int m = (int)blockIdx.x, lane = (int)threadIdx.x;
+    uint8_t* base = (uint8_t*)lds;
+    uint32_t* cw = lds + STRIDE_WORDS + 1;                                 // + 1: 16-byte aligned (STRIDE_WORDS is odd... 612 words = 2448 bytes)
+    Lane H;
+    H.lit = (uint16_t*)base; H.A = base + OFF_A; H.B = base + OFF_B; H.C = (uint16_t*)(base + OFF_C); H.ring = (uint32_t*)(base + OFF_RING); H.stage = (uint32_t*)(base + OFF_STAGE);
+    const uint8_t* in = comp + blocks[m].in_off;
+    const uint32_t skew = (uint32_t)((uintptr_t)in & 15u);
+    H.src = in - skew; H.total = skew + blocks[m].in_len;
+    H.buf = 0; H.cnt = 0; H.nextw = 0; H.rd = 4; H.ld = 0; H.outp = 0; H.ntok = 0; H.nflushed = 0; H.state = ST_HEADER; H.last = 0; H.inflight = false;
+    H.pend[0] = H.pend[1] = H.pend[2] = H.pend[3] = 0;
+    uint32_t* tk = tokens + (size_t)m * TOKCAP;
+    H.tok = tk;
+    const uint32_t limit = H.total * 8u;
+    const uint32_t staged = (H.total + 15u + 16u) & ~15u;                   // the lanes read up to two words past the last byte
+    if (staged > comp_cap) { if (lane == 0) { ntok[m] = NTOK_FALLBACK; out_len[m] = 0xFFFFFFFFu; } return; }      // an incompressible member: the one-lane kernel
+    for (uint32_t o = (uint32_t)lane * 16u; o < staged; o += 1024u) *(uint4*)((uint8_t*)cw + o) = *(const uint4*)(H.src + o);
+    const uint32_t* w = cw;
+    uint32_t tok_base = 0, out_base = 0, hpos = skew * 8u;
+    bool fail = false;
+    __syncthreads();
+    for (;;) {
+        // ---- the block's header: lane 0
+        int st = ST_FALLBACK, last = 0; uint32_t dstart = 0;
+        if (lane == 0) { lane_seek(H, hpos); H.state = ST_HEADER; parse_header(H, WaveOne{}); st = H.state; last = H.last; dstart = lane_bitpos(H); }
+        __syncthreads();
+        st = __builtin_amdgcn_readfirstlane(st); last = __builtin_amdgcn_readfirstlane(last); dstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)dstart);
+        if (st != ST_DECODE) { fail = true; break; }
+        // ---- segments
+        const uint32_t rem = limit > dstart ? limit - dstart : 0u;
+        uint32_t seg = (rem + 63u) / 64u; if (seg < 64u) seg = 64u;
+        const uint32_t border = dstart + (uint32_t)lane * seg, bnext = lane == 63 ? MARK : border + seg;
+        uint32_t s = border;
+        bool ch = lane > 0; int phase = 0;
+        Seg r{border, 0, 0, 0};
+        for (;;) {
+            if (ch) r = decode_segment<false>(H.lit, H.A, H.B, w, limit, phase == 0 ? border - seg : s, phase == 0 ? border : bnext, (uint32_t*)nullptr, 0u, WaveGpu{});
+            if (phase == 0) { if (ch && r.e < MARK) s = r.e; ch = true; phase = 1; continue; }
+            uint32_t ns = (uint32_t)__shfl_up((int)r.e, 1); if (lane == 0) ns = s;
+            ch = ns < MARK && ns != s;                                        // a lane that failed says nothing about the next one's start
+            if (!__any((int)ch)) break;
+            s = ch ? ns : s;
+        }
+        // the first lane that did not reach its border ended the block (or the stream is bad); the lanes behind it decoded nothing real
+        const uint64_t markm = __ballot(r.e >= MARK);
+        const int el = markm ? __builtin_ctzll(markm) : 64;
+        if (el == 64 || (uint32_t)__builtin_amdgcn_readlane((int)r.e, el & 63) != MARK_EOB) { fail = true; break; }
+        if (lane > el) { s = MARK_NONE; r.nt = 0; r.ob = 0; }
+        const uint32_t inc_nt = wave_incl_scan(r.nt), inc_ob = wave_incl_scan(r.ob);
+        const uint32_t tot_nt = (uint32_t)__builtin_amdgcn_readlane((int)inc_nt, 63), tot_ob = (uint32_t)__builtin_amdgcn_readlane((int)inc_ob, 63);
+        if (tok_base + tot_nt > TOKCAP || out_base + tot_ob > 65536u) { fail = true; break; }
+        const Seg f = decode_segment<true>(H.lit, H.A, H.B, w, limit, s, bnext, tk + tok_base + inc_nt - r.nt, out_base + inc_ob - r.ob, WaveGpu{});
+        if (__any((int)((lane <= el && f.e == MARK_ERR) || f.nt != r.nt || f.ob != r.ob))) { fail = true; break; }
+        tok_base += tot_nt; out_base += tot_ob;
+        hpos = (uint32_t)__builtin_amdgcn_readlane((int)r.eob_pos, el);
+        if (last) break;
+        __syncthreads();                                                  // the tables are about to be rebuilt
+    }
+    if (lane == 0) { ntok[m] = fail ? NTOK_FALLBACK : tok_base; out_len[m] = fail ? 0xFFFFFFFFu : out_base; }
+}
+
 // one wave per member.  buf = the member's output from `origin` on (at least the last 32 KiB: DEFLATE's reach); when a batch does not
 // fit, what is complete goes to HBM in 16-byte pieces and the buffer slides down.  Members kernel 1 refused are listed for the one-lane kernel.
 __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ tokens, const uint32_t* __restrict__ ntok, int n_blocks, uint8_t* __restrict__ out,
@@ -714,8 +786,9 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
 
 // Which inflater.  Default: the two kernels above, then the one-lane kernel over whatever members they handed back (stored blocks,
 // members of more than TOKCAP symbols, corrupt streams -- normally none: its workgroups read a zero count and leave).
-// THJ_INFLATE=one: the round-2 kernel alone; =lanes: the round-2 lane-per-member experiment; THJ_HUFF_LPW=16|32|64: lanes per wave of kernel 1.
-static int launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_block* d_blocks, int64_t nb, uint8_t* d_out, uint32_t* d_len) {
+// THJ_INFLATE=one: the round-2 kernel alone; =lanes: the round-2 lane-per-member experiment; =member: entropy decoding one member per LANE
+// (thj_k_huff, THJ_HUFF_LPW=16|32|64 lanes per wave) instead of one per wave (thj_k_huffp).
+static int launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_block* d_blocks, int64_t nb, uint8_t* d_out, uint32_t* d_len, uint32_t max_in_len = 0) {
     static const char* force = getenv("THJ_INFLATE");
     static const int lpw = getenv("THJ_HUFF_LPW") ? atoi(getenv("THJ_HUFF_LPW")) : 64;
     if (force && force[0] == 'l') { hipLaunchKernelGGL(thj_k_inflate_lanes, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len); return THJ_OK; }
@@ -735,7 +808,15 @@ static int launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_bloc
     uint32_t* d_fbn = d_fb + nb;
     HIPCHK(hipMemsetAsync(d_fbn, 0, 4, c->stream));
     const dim3 g((unsigned)((nb + 63) / 64));
-    if (lpw == 16) hipLaunchKernelGGL(thj_k_huff<16>, g, dim3(256), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
+    if (!(force && force[0] == 'm')) {
+        // LDS per wave: the tables + the largest member's compressed bytes (max_in_len = 0: the caller does not know -- 24 KiB, what a
+        // 64 KiB BAM member comes to at worst in practice); members beyond 60 KiB of LDS go to the one-lane kernel
+        uint32_t cap = max_in_len ? max_in_len + 64u : 24576u;
+        cap = (cap + 255u) & ~255u;
+        if (cap > 61440u - 2560u) cap = 61440u - 2560u;
+        hipLaunchKernelGGL(thj_k_huffp, dim3((unsigned)nb), dim3(64), (size_t)(inf2::STRIDE_WORDS + 1) * 4 + cap, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len, cap);
+    }
+    else if (lpw == 16) hipLaunchKernelGGL(thj_k_huff<16>, g, dim3(256), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
     else if (lpw == 32) hipLaunchKernelGGL(thj_k_huff<32>, g, dim3(128), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
     else hipLaunchKernelGGL(thj_k_huff<64>, g, dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
     hipLaunchKernelGGL(thj_k_lz, dim3((unsigned)nb), dim3(64), 0, c->stream, d_tok, d_ntok, (int)nb, d_out, d_len, d_fb, d_fbn);
@@ -762,7 +843,8 @@ extern "C" int thj_bgzf_inflate(thj_ctx* c, const uint8_t* comp, int64_t comp_by
         HIPCHK(hipMemcpyAsync(t1, blocks, (size_t)n_blocks * sizeof(thj_bgzf_block), hipMemcpyHostToDevice, c->stream));
         d_comp = (const uint8_t*)t0; d_blocks = (const thj_bgzf_block*)t1; d_out = (uint8_t*)t2; d_len = (uint32_t*)t3;
     }
-    { const int rc_ = launch_inflate(c, d_comp, d_blocks, n_blocks, d_out, d_len); if (rc_) return rc_; }
+    { uint32_t mx = 0; if (!on_device) for (int64_t k = 0; k < n_blocks; ++k) mx = blocks[k].in_len > mx ? blocks[k].in_len : mx;
+      const int rc_ = launch_inflate(c, d_comp, d_blocks, n_blocks, d_out, d_len, mx); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     if (!on_device) {
         HIPCHK(hipMemcpyAsync(out_len, t3, (size_t)n_blocks * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1226,7 +1308,8 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipMemsetAsync(d_status, 0, 64, c->stream));
     HIPCHK(hipMemsetAsync(d_cnt + nb, 0, 4, c->stream));
     pc.mark(0);
-    { const int rc_ = launch_inflate(c, d_comp, d_blocks, nb, d_infl, d_len); if (rc_) return rc_; }
+    { uint32_t mx = 0; for (const auto& bk : blocks) mx = bk.in_len > mx ? bk.in_len : mx;
+      const int rc_ = launch_inflate(c, d_comp, d_blocks, nb, d_infl, d_len, mx); if (rc_) return rc_; }
     pc.mark(1);
     hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
     int rc = exclusive_sum(c, d_cnt, d_base, nb + 1);
