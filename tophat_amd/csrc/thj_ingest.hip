@@ -747,19 +747,20 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
             const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)a, f);        // everything below the first open match is final
             const bool mine = ((pend >> lane) & 1ull) != 0;
             const bool rdy = mine && send <= hwm;
-            const bool small = rdy && len <= 16u && dist >= len;
+            const bool small = rdy && len <= 32u && dist >= len;
             if (small) {
-                // up to 16 bytes, source and destination apart: two (unaligned) 8-byte reads, then exactly len bytes written
-                uint64_t lo, hi;
-                __builtin_memcpy(&lo, &buf[s], 8); __builtin_memcpy(&hi, &buf[s + 8], 8);
-                uint32_t w = a; uint32_t rest = len; uint64_t v = lo;
-                if (rest >= 8u) { __builtin_memcpy(&buf[w], &lo, 8); w += 8u; rest -= 8u; v = hi; }
-                if (rest == 8u) __builtin_memcpy(&buf[w], &v, 8);
-                else {
-                    if (rest & 4u) { const uint32_t x = (uint32_t)v; __builtin_memcpy(&buf[w], &x, 4); w += 4u; v >>= 32; }
-                    if (rest & 2u) { const uint16_t x = (uint16_t)v; __builtin_memcpy(&buf[w], &x, 2); w += 2u; v >>= 16; }
-                    if (rest & 1u) buf[w] = (uint8_t)v;
-                }
+                // up to 32 bytes, source and destination apart: (unaligned) 8-byte reads, then exactly len bytes written
+                uint64_t v0, v1, v2, v3;
+                __builtin_memcpy(&v0, &buf[s], 8); __builtin_memcpy(&v1, &buf[s + 8], 8);
+                __builtin_memcpy(&v2, &buf[s + 16], 8); __builtin_memcpy(&v3, &buf[s + 24], 8);
+                uint32_t w = a, rest = len;
+                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; v1 = v2; v2 = v3; }
+                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; v1 = v2; }
+                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; }
+                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; }
+                if (rest & 4u) { const uint32_t x = (uint32_t)v0; __builtin_memcpy(&buf[w], &x, 4); w += 4u; v0 >>= 32; }
+                if (rest & 2u) { const uint16_t x = (uint16_t)v0; __builtin_memcpy(&buf[w], &x, 2); w += 2u; v0 >>= 16; }
+                if (rest & 1u) buf[w] = (uint8_t)v0;
             }
             // the long and the self-overlapping ones: the whole wave on each, 64 bytes a step; a match that overlaps itself repeats its
             // first dist bytes, so every byte is read from those (all lanes read before any writes)
