@@ -8,6 +8,7 @@
 // host workers ingest the shards in parallel, shard k runs on GPU k mod n, and when all are done the per-GPU event sets
 // are united by ONE RCCL all-gather (thj_events_allgather_async) -- segment_juncs.cpp:4911-4922 across GPUs.  GPU 0's
 // sets are written.  The result does not depend on the number of shards or GPUs.
+#include <sys/stat.h>
 #include "thj_hostio.h"
 
 using namespace thjh;
@@ -380,6 +381,13 @@ static int real_main(int argc, char** argv) {
     int workers = getenv("THJ_WORKERS") ? atoi(getenv("THJ_WORKERS")) : std::max(1, std::min(32, hw * 3 / 4));
     if (workers < 1) workers = 1;
     int want = getenv("THJ_SHARDS") ? atoi(getenv("THJ_SHARDS")) : std::max(std::max(workers, o.num_threads), n_gpus);
+    {   // ... and a shard's inputs stay below 384 MB of BGZF: the device-side ingest addresses a shard's members with 16 bits (~1 GB at
+        // BAM's compression) and keeps 64 KiB of inflated bytes and a token stream per member
+        auto fsize = [](const std::string& f) -> uint64_t { struct stat st; return (!f.empty() && stat(f.c_str(), &st) == 0) ? (uint64_t)st.st_size : 0; };
+        auto side_bytes = [&](const SideInput& a, const SideInput& b) { uint64_t n = fsize(a.reads); for (auto& f : a.segs) n += fsize(f); n += fsize(b.map); if (!b.segs.empty()) n += fsize(b.segs.back()); return n; };
+        const uint64_t by_size = (std::max(side_bytes(left, right), side_bytes(right, left)) >> 20) / 384 + 1;
+        if (!getenv("THJ_SHARDS") && by_size > (uint64_t)want) want = (int)std::min<uint64_t>(by_size, 1 << 16);
+    }
     struct Item { const SideInput* in; const SideInput* mate; int side; Shard sh; uint32_t ordinal, limit; int gpu; };
     std::vector<Item> items;
     {
@@ -508,7 +516,7 @@ static int real_main(int argc, char** argv) {
             fprintf(ff, "%s\t%d\t%s\t%d\t%s\n", rt.names[a.ref_id1 - 1].c_str(), (int)a.left, rt.names[a.ref_id2 - 1].c_str(), (int)a.right, dir);
         }
     }
-    fclose(fj); fclose(fi); fclose(fd); fclose(ff);
+    close_output(fj, "the junctions file"); close_output(fi, "the insertions file"); close_output(fd, "the deletions file"); close_output(ff, "the fusions file");
     fprintf(stderr, "Reported %d total potential splices\n", (int)n.n_juncs);
     g_timer.lap("write outputs");
     g_timer.report();

@@ -50,6 +50,13 @@ namespace thjh {
     exit(1);
 }
 
+// an output file is complete only if every write and the close succeeded (a full disk shows up here, not at fprintf)
+inline void close_output(FILE* f, const char* what) {
+    if (!f) return;
+    const bool bad = ferror(f) != 0;
+    if (fclose(f) != 0 || bad) die("Error: writing %s failed (%s)\n", what, strerror(errno));
+}
+
 // ------------------------------------------------------------------ "outputs are complete" hand-off
 // A process that has used the GPU takes ~0.2 s to leave after its last instruction (the driver frees its device memory, queues and
 // pinned pages; measured with the time stamps of PhaseTimer::report): three processes per run, 0.6 of 3.2 s on 8 M pairs.  Nobody
@@ -688,7 +695,22 @@ inline bool parse_hit(const AlnRec& r, RefTable& rt, const thj_params& p, Hit& o
 
 // The same factory straight from a BAM record's bytes (no intermediate strings; `tid2ref` = the file's targets resolved to
 // reference-table ids once, 0 = unknown contig): what the segment / read maps of a real run go through, record by record.
+// A BAM record's own header must describe something that fits its block_size (name, CIGAR, bases, qualities; the name NUL-terminated
+// inside it) before anybody walks it: a truncated or damaged file is an error, not a read past the buffer.
+inline bool bam_record_shape_ok(const uint8_t* d, int32_t bs) {
+    if (bs < 32) return false;
+    uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
+    memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4); memcpy(&l_seq, d + 16, 4);
+    const uint64_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF;
+    if (l_seq < 0 || l_rn == 0) return false;
+    if (32 + l_rn + 4 * n_cig + ((uint64_t)l_seq + 1) / 2 + (uint64_t)l_seq > (uint64_t)bs) return false;
+    return d[32 + l_rn - 1] == 0;
+}
+inline size_t bam_aux_fixed_size(char ty) {                   // bytes a tag of this type has at least after its three-byte key
+    switch (ty) { case 'A': case 'c': case 'C': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; case 'd': return 8; case 'B': return 5; default: return 0; }
+}
 inline bool parse_hit_bam(const uint8_t* d, int32_t bs, const std::vector<uint32_t>& tid2ref, const thj_params& p, Hit& out) {
+    if (!bam_record_shape_ok(d, bs)) die("Error: malformed BAM record (its header does not fit its %d bytes)\n", (int)bs);
     int32_t tid, pos, mtid; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
     memcpy(&tid, d, 4); memcpy(&pos, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4);
     memcpy(&l_seq, d + 16, 4); memcpy(&mtid, d + 20, 4);
@@ -732,6 +754,7 @@ inline bool parse_hit_bam(const uint8_t* d, int32_t bs, const std::vector<uint32
     while (pp + 3 <= (size_t)bs) {                             // bam_aux_get for NM / XS / XF
         const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
         pp += 3;
+        if (bam_aux_fixed_size(ty) > (size_t)bs - pp) die("Error: malformed BAM record (a tag runs past its end)\n");
         long long iv = 0; bool isint = false;
         switch (ty) {
         case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
@@ -749,6 +772,7 @@ inline bool parse_hit_bam(const uint8_t* d, int32_t bs, const std::vector<uint32
             ++pp;
             break;
         case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); int sz = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4;
+                    if (cnt < 0 || (uint64_t)cnt * (uint64_t)sz > (uint64_t)bs) die("Error: malformed BAM record (an array tag runs past its end)\n");
                     pp += 5 + (size_t)cnt * sz; break; }
         default: pp = (size_t)bs; break;
         }
@@ -1772,8 +1796,8 @@ public:
         std::vector<uint8_t> eof;
         deflate_member(nullptr, 0, eof);              // an empty member: the BGZF EOF marker block
         fwrite(eof.data(), 1, eof.size(), f_);
-        fclose(f_); f_ = nullptr;
-        if (idx_) { fclose(idx_); idx_ = nullptr; }
+        close_output(f_, "the BAM output"); f_ = nullptr;
+        if (idx_) { close_output(idx_, "the BAM output's .index"); idx_ = nullptr; }
     }
     ~BamWriter() { close(); }
 };

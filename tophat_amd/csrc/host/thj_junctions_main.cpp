@@ -40,18 +40,22 @@ static int real_main(int argc, char** argv) {
         static const uint32_t OPS[9] = {THJ_CIG_MATCH, THJ_CIG_INS, THJ_CIG_DEL, THJ_CIG_REF_SKIP, THJ_CIG_SOFT_CLIP, 14u, 15u, THJ_CIG_MATCH, THJ_CIG_MATCH};
         int32_t tid, p0; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
         memcpy(&tid, d, 4); memcpy(&p0, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4); memcpy(&l_seq, d + 16, 4);
+        if (!bam_record_shape_ok(d, bs)) die("Error: malformed BAM record (its header does not fit its %d bytes)\n", (int)bs);
         const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF;
-        if (tid < 0 || ((flag_nc >> 16) & 4) || n_cig < 3 || n_cig > 16) return;
+        if (tid < 0 || ((flag_nc >> 16) & 4) || n_cig < 3) return;
         thj_aln a; memset(&a, 0, sizeof a);
         bool spliced = false;
         size_t pp = 32 + l_rn;
-        for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + pp, 4); pp += 4; const uint32_t op = (c & 0xF) < 9 ? OPS[c & 0xF] : 15u; if (op == THJ_CIG_REF_SKIP) spliced = true; a.cigar[i] = (op << 28) | (c >> 4); }
+        for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + pp, 4); pp += 4; const uint32_t op = (c & 0xF) < 9 ? OPS[c & 0xF] : 15u; if (op == THJ_CIG_REF_SKIP) spliced = true; if (i < 16) a.cigar[i] = (op << 28) | (c >> 4); }
         if (!spliced) return;
+        // a spliced alignment the consensus cannot hold must not vanish from the support counts silently
+        if (n_cig > 16) die("Error: a spliced alignment of %u CIGAR operations (at most 16 are supported)\n", n_cig);
         pp += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
         char xs = 0;
         while (pp + 3 <= (size_t)bs) {                        // XS:A
             const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
             pp += 3;
+            if (bam_aux_fixed_size(ty) > (size_t)bs - pp) die("Error: malformed BAM record (a tag runs past its end)\n");
             switch (ty) {
             case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
             case 'c': case 'C': pp += 1; break;
@@ -59,7 +63,8 @@ static int real_main(int argc, char** argv) {
             case 'i': case 'I': case 'f': pp += 4; break;
             case 'd': pp += 8; break;
             case 'Z': case 'H': while (pp < (size_t)bs && d[pp]) ++pp; ++pp; break;
-            case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); pp += 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
+            case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); if (cnt < 0 || (int64_t)cnt > (int64_t)bs) die("Error: malformed BAM record (an array tag runs past its end)\n");
+                        pp += 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
             default: pp = (size_t)bs; break;
             }
         }
@@ -156,7 +161,7 @@ static int real_main(int argc, char** argv) {
             fprintf(f, "%s\t%d\t%d\tJUNC%08d\t%d\t%c\t%d\t%d\t255,0,0\t2\t%d,%d\t0,%d\n", rt.names[j.ref_id - 1].c_str(), start, end, (int)(i + 1), (int)j.support,
                     j.antisense ? '-' : '+', start, end, (int)j.left_extent, (int)j.right_extent, (int)j.right - start);
         }
-        fclose(f);
+        close_output(f, "junctions.bed");
         break;
     }
     finish_outputs_complete(0);

@@ -914,6 +914,8 @@ __device__ bool parse_hit(const uint8_t* d, uint32_t bs, const uint32_t* tid2ref
     const int32_t tid = (int32_t)ld32(d), pos = (int32_t)ld32(d + 4), mtid = (int32_t)ld32(d + 20);
     const uint32_t bin_mq_nl = ld32(d + 8), flag_nc = ld32(d + 12), l_seq = ld32(d + 16);
     const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF, flag = flag_nc >> 16;
+    // the record's own header must fit its block_size before anything walks it (a damaged file is an error, not a wild read)
+    if (bs < 32u || l_rn == 0u || l_seq > 0x7FFFFFFFu || 32ull + l_rn + 4ull * n_cig + ((unsigned long long)l_seq + 1ull) / 2ull + l_seq > (unsigned long long)bs) { atomicAdd(&status[ST_CORRUPT], 1u); id = 0; return false; }
     // qname "<id>|<offset>:<segment>:<segments>" (tophat.py:2948): insert_id = atoi, end = (segment + 1 == segments)
     const uint8_t* q = d + 32;
     uint32_t v = 0, i = 0;
@@ -967,6 +969,10 @@ __device__ bool parse_hit(const uint8_t* d, uint32_t bs, const uint32_t* tid2ref
     while (pp + 3 <= bs) {
         const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
         pp += 3;
+        {   // a tag's value must lie inside the record
+            const uint32_t fixed = (ty == 'A' || ty == 'c' || ty == 'C') ? 1u : (ty == 's' || ty == 'S') ? 2u : (ty == 'i' || ty == 'I' || ty == 'f') ? 4u : ty == 'd' ? 8u : ty == 'B' ? 5u : 0u;
+            if (fixed > bs - pp) { atomicAdd(&status[ST_CORRUPT], 1u); return false; }
+        }
         int iv = 0; bool isint = false;
         switch (ty) {
         case 'A': if (t0 == 'X' && t1 == 'S') xs = (char)d[pp]; pp += 1; break;
@@ -1276,6 +1282,9 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
         comp_total += p.comp_bytes;
     }
     const int64_t nb = (int64_t)blocks.size();
+    // a record's place is kept as member << 16 | offset in 32 bits (ParseOut::loc, thj_k_read_planes, the host's rinfl + loc): a shard of
+    // more members than that takes the host readers -- the executables size their shards well below it (bytes of input per shard)
+    if (nb > 65535) { thj_set_error("thj_ingest: %lld BGZF members in one shard (at most 65535)", (long long)nb); return THJ_EFALLBACK; }
     P.file_first_block.clear(); P.file_blocks.clear();
     for (int f = 0; f < nf; ++f) { P.file_first_block.push_back(files[(size_t)f].first_block); P.file_blocks.push_back(files[(size_t)f].n_blocks); }
     P.fb.assign((size_t)nf + 1, 0);
@@ -1349,6 +1358,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
     pc.mark(4);
+    if (h_status[ST_CORRUPT]) { thj_set_error("thj_ingest: malformed BAM record (its header or a tag does not fit its block_size)"); return THJ_EINVAL; }
     if (h_status[ST_XF]) { thj_set_error("fusion (XF) alignments are not supported by this build"); return THJ_EINVAL; }
     if (h_status[ST_CIGAR]) { thj_set_error("a segment alignment has more than 5 CIGAR operations (this build supports 5)"); return THJ_EINVAL; }
     P.id = q_id; P.h16 = qo.h16; P.h32 = qo.h32; P.loc = q_loc; P.n = P.fb[(size_t)nf];
@@ -1616,23 +1626,40 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
 // buffers are kept and handed out again.
 namespace {
 struct PinnedPool {
-    struct Blk { void* p; size_t cap; bool used; bool pinned; };
-    std::mutex mu; std::vector<Blk> blks; size_t bytes = 0;
+    struct Blk { void* p; size_t cap; bool used; bool pinned; uint64_t stamp; };
+    std::mutex mu; std::vector<Blk> blks; size_t bytes = 0; uint64_t clock = 0;
+    static constexpr size_t PIN_LIMIT = (size_t)24 << 30, KEEP_LIMIT = (size_t)32 << 30;
+    static void release(const Blk& b) { if (b.pinned) (void)hipHostFree(b.p); else free(b.p); }
     void* get(size_t n) {
         if (n < 4096) n = 4096;
+        const size_t cap = n + n / 8;
+        std::vector<Blk> drop;
+        bool pin;
         {
             std::lock_guard<std::mutex> lk(mu);
             int best = -1;
             for (size_t i = 0; i < blks.size(); ++i)
                 if (!blks[i].used && blks[i].cap >= n && blks[i].cap <= 2 * n + (1 << 20) && (best < 0 || blks[i].cap < blks[(size_t)best].cap)) best = (int)i;
-            if (best >= 0) { blks[(size_t)best].used = true; return blks[(size_t)best].p; }
+            if (best >= 0) { blks[(size_t)best].used = true; blks[(size_t)best].stamp = ++clock; return blks[(size_t)best].p; }
+            // nothing fits: before growing past the limits, let go of the idle blocks that were used longest ago (shards of varying
+            // size would otherwise leave a trail of blocks nobody asks for again)
+            while (bytes + cap > KEEP_LIMIT) {
+                int old = -1;
+                for (size_t i = 0; i < blks.size(); ++i) if (!blks[i].used && (old < 0 || blks[i].stamp < blks[(size_t)old].stamp)) old = (int)i;
+                if (old < 0) break;
+                drop.push_back(blks[(size_t)old]); bytes -= blks[(size_t)old].cap;
+                blks.erase(blks.begin() + old);
+            }
+            size_t pinned_bytes = 0; for (auto& b : blks) if (b.pinned) pinned_bytes += b.cap;
+            pin = pinned_bytes + cap <= PIN_LIMIT;
+            bytes += cap;                                     // reserved under the lock; the allocation itself runs outside it
         }
-        const size_t cap = n + n / 8;
-        void* p = nullptr; bool pinned = true;
-        if (bytes > ((size_t)24 << 30) || hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) { (void)hipGetLastError(); p = malloc(cap); pinned = false; }
-        if (!p) return nullptr;
+        for (auto& b : drop) release(b);
+        void* p = nullptr; bool pinned = pin;
+        if (!pin || hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess || !p) { (void)hipGetLastError(); p = malloc(cap); pinned = false; }
         std::lock_guard<std::mutex> lk(mu);
-        blks.push_back({p, cap, true, pinned}); bytes += cap;
+        if (!p) { bytes -= cap; return nullptr; }
+        blks.push_back({p, cap, true, pinned, ++clock});
         return p;
     }
     void put(void* p) {

@@ -593,17 +593,19 @@ static int ensure_slots(thj_ctx* c, int64_t want) {
     }
     hipFree(c->d_aln_pool); hipFree(c->d_nrec);
     c->d_aln_pool = ns; c->d_nrec = nn; c->aln_cap = ncap;
-    // overflow pool (2nd.. records of multihit reads): as many records again as there are slots
+    // overflow pool (2nd.. records of multihit reads): as many records again as there are slots -- never smaller than it already is
+    // (thj_span_finish enlarges it on its own when a pass needed more), and nothing to keep when no pass is open
     {
+        const int64_t ocap = ncap > c->ovf_cap ? ncap : c->ovf_cap;
         void* no = nullptr; u64* nk = nullptr;
-        HIPCHK(hipMalloc(&no, (size_t)ncap * 128));
-        HIPCHK(hipMalloc(&nk, (size_t)ncap * 8));
-        if (c->d_aln_sorted && c->ovf_cap) {
+        HIPCHK(hipMalloc(&no, (size_t)ocap * 128));
+        HIPCHK(hipMalloc(&nk, (size_t)ocap * 8));
+        if (c->d_aln_sorted && c->ovf_cap && c->span_reads) {
             HIPCHK(hipMemcpy(no, c->d_aln_sorted, (size_t)c->ovf_cap * 128, hipMemcpyDeviceToDevice));
             HIPCHK(hipMemcpy(nk, c->d_aln_keys, (size_t)c->ovf_cap * 8, hipMemcpyDeviceToDevice));
         }
         hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys);
-        c->d_aln_sorted = no; c->d_aln_keys = nk; c->ovf_cap = ncap;
+        c->d_aln_sorted = no; c->d_aln_keys = nk; c->ovf_cap = ocap;
     }
     return THJ_OK;
 }
