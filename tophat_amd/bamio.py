@@ -28,41 +28,45 @@ def read_bam(path: str) -> Tuple[List[str], Iterator[tuple]]:
     while off < len(data):
         bs, = struct.unpack_from("<i", data, off)
         off += 4
-        rec = data[off:off + bs]
+        recs.append(parse_bam_record(data[off:off + bs], names))
         off += bs
-        tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
-        p = 32
-        qname = rec[p:p + l_rn - 1].decode()
-        p += l_rn
-        cig = struct.unpack_from("<%dI" % n_cig, rec, p)
-        p += 4 * n_cig
-        cigar = "".join("%d%s" % (c >> 4, _CIG[c & 0xF]) for c in cig) or "*"
-        sb = rec[p:p + (l_seq + 1) // 2]
-        p += (l_seq + 1) // 2
-        seq = "".join(_SEQ[(sb[i >> 1] >> (4 if (i & 1) == 0 else 0)) & 0xF] for i in range(l_seq))
-        qual = "".join(chr(min(q, 93) + 33) for q in rec[p:p + l_seq])
-        p += l_seq
-        tags = []
-        while p < len(rec):
-            tag = rec[p:p + 2].decode()
-            ty = chr(rec[p + 2])
-            p += 3
-            if ty == "A":
-                tags.append("%s:A:%s" % (tag, chr(rec[p])))
-                p += 1
-            elif ty in "cCsSiI":
-                fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[ty]
-                v, = struct.unpack_from(fmt, rec, p)
-                p += struct.calcsize(fmt)
-                tags.append("%s:i:%d" % (tag, v))
-            elif ty == "Z":
-                e = rec.index(b"\0", p)
-                tags.append("%s:Z:%s" % (tag, rec[p:e].decode()))
-                p = e + 1
-            else:
-                raise ValueError("unsupported aux type %s" % ty)
-        recs.append((qname, flag, names[tid] if tid >= 0 else "*", pos + 1, mapq, cigar, seq, qual) + tuple(tags))
     return names, recs
+
+
+def parse_bam_record(rec: bytes, names: List[str]) -> tuple:
+    """one BAM record (without its block_size word) -> (qname, flag, rname, pos, mapq, cigar, seq, qual, tags...)"""
+    tid, pos, l_rn, mapq, _bin, n_cig, flag, l_seq, mtid, mpos, tlen = struct.unpack_from("<iiBBHHHiiii", rec, 0)
+    p = 32
+    qname = rec[p:p + l_rn - 1].decode()
+    p += l_rn
+    cig = struct.unpack_from("<%dI" % n_cig, rec, p)
+    p += 4 * n_cig
+    cigar = "".join("%d%s" % (c >> 4, _CIG[c & 0xF]) for c in cig) or "*"
+    sb = rec[p:p + (l_seq + 1) // 2]
+    p += (l_seq + 1) // 2
+    seq = "".join(_SEQ[(sb[i >> 1] >> (4 if (i & 1) == 0 else 0)) & 0xF] for i in range(l_seq))
+    qual = "".join(chr(min(q, 93) + 33) for q in rec[p:p + l_seq])
+    p += l_seq
+    tags = []
+    while p < len(rec):
+        tag = rec[p:p + 2].decode()
+        ty = chr(rec[p + 2])
+        p += 3
+        if ty == "A":
+            tags.append("%s:A:%s" % (tag, chr(rec[p])))
+            p += 1
+        elif ty in "cCsSiI":
+            fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I"}[ty]
+            v, = struct.unpack_from(fmt, rec, p)
+            p += struct.calcsize(fmt)
+            tags.append("%s:i:%d" % (tag, v))
+        elif ty == "Z":
+            e = rec.index(b"\0", p)
+            tags.append("%s:Z:%s" % (tag, rec[p:e].decode()))
+            p = e + 1
+        else:
+            raise ValueError("unsupported aux type %s" % ty)
+    return (qname, flag, names[tid] if tid >= 0 else "*", pos + 1, mapq, cigar, seq, qual) + tuple(tags)
 
 
 def write_bam_from_sam(sam_path: str, bam_path: str) -> None:
