@@ -73,6 +73,32 @@ int main(int argc, char** argv) {
         bw.close();
         return 0;
     }
+    if (mode == "sam2bam" && argc >= 5) {
+        // hostio_check sam2bam <hdr.sam> <records.sam> <out.bam>: every line of records.sam (QNAME FLAG RNAME POS MAPQ CIGAR SEQ QUAL tags...,
+        // the trimmed form of tests/golden/*/expected.span_*.sam) through BamWriter::encode, the encoder of the executables' general path
+        RefTable rt;
+        rt.load_sam_header(argv[2]);
+        BamWriter bw;
+        if (!bw.open(argv[4], rt, std::string(argv[4]) + ".index")) return 3;
+        std::vector<std::vector<std::string>> lines;
+        {
+            FILE* f = fopen(argv[3], "r"); if (!f) return 3;
+            char* ln = nullptr; size_t cap = 0; ssize_t n;
+            while ((n = getline(&ln, &cap, f)) > 0) { std::string l(ln, (size_t)n); while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back(); if (!l.empty() && l[0] != '@') lines.push_back(split(l, '\t')); }
+            free(ln); fclose(f);
+        }
+        bw.write_records(lines.size(), [&](size_t i, std::vector<uint8_t>& d) -> long {
+            const auto& c = lines[i];
+            std::vector<uint32_t> cig;
+            for (size_t k = 0; k < c[5].size();) { uint32_t v = 0; while (k < c[5].size() && isdigit((unsigned char)c[5][k])) v = v * 10 + (uint32_t)(c[5][k++] - '0');
+                const char o = c[5][k++]; const uint32_t op = o == 'M' ? 1u : o == 'I' ? 3u : o == 'D' ? 5u : o == 'N' ? 11u : o == 'S' ? 13u : 15u; cig.push_back(op << 28 | v); }
+            std::vector<std::string> aux(c.begin() + 8, c.end());
+            bw.encode(d, c[0], (uint32_t)atoi(c[1].c_str()), c[2], atoi(c[3].c_str()), cig.data(), (int)cig.size(), c[6], c[7], aux);
+            return atol(c[0].c_str());
+        });
+        bw.close();
+        return 0;
+    }
     if (mode == "fdz" && argc >= 4) {
         // hostio_check fdz <in> <out> [bench]: <in> = (u32 length, bytes)*; <out> = (u32 compressed length | 0xFFFFFFFF = declined, bytes)*
         // from thj_fastdeflate.h with the room a BGZF member has; bench: MB/s over ten passes on stderr

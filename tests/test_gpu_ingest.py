@@ -143,3 +143,20 @@ def test_two_kernel_inflater_mixed_launch():
             assert g is None or g != w
         else:
             assert g == w, "member %d (%d bytes in, %d out)" % (k, len(payloads[k]), len(w))
+
+
+def test_members_written_by_the_references_bgzf_c():
+    """fixed inputs made by REFERENCE code (tests/golden/ref_samtools/, samtools 0.1.18's bgzf.c at zlib's default level, see mint.py)"""
+    import json
+    ref = os.path.join(ROOT, "tests", "golden", "ref_samtools")
+    man = json.load(open(os.path.join(ref, "MANIFEST.json")))
+    files = [man["bgzf_members"]["file"]] + sorted(k + ".samtools.bam" for k in man["cases"])
+    with host.Context(0) as ctx:
+        for fn in files:
+            pl, isize = bgzf_payloads(os.path.join(ref, fn))
+            got = inflate(ctx, pl)
+            for k, p in enumerate(pl):
+                w = zlib.decompress(p, -15)
+                assert len(w) == isize[k]
+                if isize[k]:
+                    assert got[k] == w, (fn, k)
