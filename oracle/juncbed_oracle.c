@@ -10,7 +10,7 @@
  *
  * Not restated (tophat_reports' alignment selection, outside the hot path): read_best_alignments, realign_reads, pair
  * grading -- every record handed in counts as a reported alignment.  splice_mms is 0 for records parsed from BAM
- * (bwt_map.cpp:1176), so max_splice_mismatches never rejects.  Non-fusion records only.
+ * (bwt_map.cpp:1176), so max_splice_mismatches never rejects.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -30,21 +30,28 @@ static int jcmp(const void* a, const void* b) {                 /* Junction::ope
     return 0;
 }
 
-/* junctions of one record appended to out[] (<= 8); returns their number */
+/* junctions of one record appended to out[] (<= 8); returns their number.  junctions_from_spliced_hit (junctions.cpp:19-92) with its
+ * fusion branches: pieces that run down the genome (lower-case ops mATCH 2, dEL 6, rEF_SKIP 12) walk backwards and swap the extents;
+ * a fusion op (FF 7, FR 8, RF 9) jumps to its length = the position on the second contig and the junctions behind it belong to that
+ * contig (the record keeps it in cigar[15], as thj_aln does); FUSION_RR (10) has no case there -- the walk neither jumps nor switches
+ * contigs -- and none here. */
 static int rec_juncs(const orc_jrec* r, jent* out) {
     int n = 0;
     int64_t j = r->left;
+    int saw_fusion = 0;
     for (int c = 0; c < r->n_cigar; ++c) {
         const uint32_t op = r->cigar[c] >> 28, len = r->cigar[c] & 0x0FFFFFFFu;
-        if (op == 11) {                                         /* REF_SKIP */
+        if (op == 11 || op == 12) {                             /* REF_SKIP, rEF_SKIP */
             jent e; memset(&e, 0, sizeof e);
-            e.ref = r->ref_id; e.left = (uint32_t)(j - 1); e.right = (uint32_t)(j + len); e.anti = r->antisense_splice ? 1u : 0u;
-            e.le = c > 0 ? (int)(r->cigar[c - 1] & 0x0FFFFFFFu) : 0;
-            e.re = c + 1 < r->n_cigar ? (int)(r->cigar[c + 1] & 0x0FFFFFFFu) : 0;
+            const int prev = c > 0 ? (int)(r->cigar[c - 1] & 0x0FFFFFFFu) : 0, next = c + 1 < r->n_cigar ? (int)(r->cigar[c + 1] & 0x0FFFFFFFu) : 0;
+            e.ref = saw_fusion ? r->cigar[15] : r->ref_id; e.anti = r->antisense_splice ? 1u : 0u;
+            if (op == 11) { e.left = (uint32_t)(j - 1); e.right = (uint32_t)(j + len); e.le = prev; e.re = next; j += len; }
+            else { e.right = (uint32_t)(j + 1); e.left = (uint32_t)(j - len); e.re = prev; e.le = next; j -= len; }
             e.support = 1;
             if (n < 8) out[n++] = e;
-            j += len;
         } else if (op == 1 || op == 5) j += len;                /* MATCH, DEL */
+        else if (op == 2 || op == 6) j -= len;                  /* mATCH, dEL */
+        else if (op == 7 || op == 8 || op == 9) { j = len; saw_fusion = 1; }
     }
     return n;
 }

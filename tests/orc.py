@@ -392,18 +392,23 @@ JSTAT_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<u4"), ("right", "<u4"), ("
 
 
 def jrecs_from_tuples(recs) -> np.ndarray:
-    """[(ref_id, left, antisense_splice, [(op, len) ...])] -> JREC_DTYPE array"""
+    """[(ref_id, left, antisense_splice, [(op, len) ...][, ref_id2])] -> JREC_DTYPE array (a fusion record: at most 15 ops, its second
+    contig in cigar[15] as in thj_aln)"""
     a = np.zeros(len(recs), dtype=JREC_DTYPE)
-    for k, (ref, left, anti, cig) in enumerate(recs):
+    for k, rec in enumerate(recs):
+        ref, left, anti, cig = rec[:4]
         a[k]["ref_id"], a[k]["left"], a[k]["antisense_splice"], a[k]["n_cigar"] = ref, left, 1 if anti else 0, len(cig)
         for i, (op, ln) in enumerate(cig):
             a[k]["cigar"][i] = (op << 28) | ln
+        if len(rec) > 4 and rec[4]:
+            assert len(cig) <= 15
+            a[k]["cigar"][15] = rec[4]
     return a
 
 
 def jrecs_from_alns(alns) -> np.ndarray:
     """tophat_amd.batch.Aln list (a long_spanning_reads result) -> JREC_DTYPE array"""
-    return jrecs_from_tuples([(a.ref_id, a.left, a.antisense_splice, [(c >> 28, c & 0x0FFFFFFF) for c in a.cigar]) for a in alns])
+    return jrecs_from_tuples([(a.ref_id, a.left, a.antisense_splice, [(c >> 28, c & 0x0FFFFFFF) for c in a.cigar], a.ref_id2) for a in alns])
 
 
 def junction_consensus(jrecs: np.ndarray, min_anchor_len: int = 8) -> np.ndarray:

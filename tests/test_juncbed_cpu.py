@@ -53,3 +53,17 @@ def test_filters():
     assert [(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"]), int(j["left_extent"]), int(j["right_extent"])) for j in js] == \
         [(2, 1022, 1123, 1, 10, 15)]
     assert orc.junctions_bed(js, ["a", "b"]).split("\n")[1] == "b\t1013\t1138\tJUNC00000001\t1\t-\t1013\t1138\t255,0,0\t2\t10,15\t0,110"
+
+
+def test_fusion_alignment_walk_by_hand():
+    """junctions_from_spliced_hit (junctions.cpp:19-92) on fusion alignments, values worked out by hand: a junction behind an FF / FR / RF
+    fusion lies on the second contig at the position the F op names; pieces that run down the genome (m, n) give right = j + 1,
+    left = j - length with the extents swapped; an RR fusion neither jumps nor switches contigs (it has no case in the reference)"""
+    M, m, N, n, FR, RR = 1, 2, 11, 12, 8, 10
+    recs = [(1, 1000, False, [(M, 30), (N, 200), (M, 20), (FR, 9000), (m, 25), (n, 300), (m, 22)], 2)] * 2
+    got = orc.junction_consensus(orc.jrecs_from_tuples(recs))
+    assert [tuple(int(x) for x in r)[:7] for r in got.tolist()] == [(1, 1029, 1230, 0, 30, 20, 2), (2, 8675, 8976, 0, 22, 25, 2)]
+    recs = [(2, 4000, False, [(m, 20), (n, 150), (m, 30), (RR, 700), (m, 30), (n, 90), (m, 20)], 1)] * 2
+    got = orc.junction_consensus(orc.jrecs_from_tuples(recs))
+    # j: 4000 -> 3980 -n150-> (3830, 3981) -> 3830 -> 3800 [RR: nothing] -> 3770 -n90-> (3680, 3771); both on the FIRST contig
+    assert [tuple(int(x) for x in r)[:7] for r in got.tolist()] == [(2, 3680, 3771, 0, 20, 30, 2), (2, 3830, 3981, 0, 30, 20, 2)]

@@ -36,23 +36,25 @@ static int real_main(int argc, char** argv) {
     // into runs of members, one per host thread; a run must end on a record boundary (true of every BAM written through
     // bgzf_flush_try: samtools 0.1.18's writer, this build's) -- if one does not, that input is read again by the sequential reader.
     std::vector<std::vector<thj_aln>> recs(inputs.size());
-    auto parse_record = [](const uint8_t* d, int32_t bs, const std::vector<uint32_t>& tid2ref, std::vector<thj_aln>& out) {
+    // One record -> thj_aln, or nothing.  A fusion alignment comes as two records that both carry the whole alignment in an XF:Z tag
+    // ("1|2 <contig1>-<contig2> <pos> <cigar with an F op> <bases> <qualities>", print_bamhit, bwt_map.cpp:2047-2083): the first one is
+    // rebuilt from the tag the way BAMHitFactory::get_hit_from_buf does (bwt_map.cpp:1208-1318 -- lower-case ops for pieces that run down
+    // the genome, F = position on the second contig + 1, its direction FF / FR / RF / RR from the ops around it), the second is dropped.
+    const int max_report_intron = o.p.max_report_intron;
+    auto parse_record = [&rt, max_report_intron](const uint8_t* d, int32_t bs, const std::vector<uint32_t>& tid2ref, std::vector<thj_aln>& out) {
         static const uint32_t OPS[9] = {THJ_CIG_MATCH, THJ_CIG_INS, THJ_CIG_DEL, THJ_CIG_REF_SKIP, THJ_CIG_SOFT_CLIP, 14u, 15u, THJ_CIG_MATCH, THJ_CIG_MATCH};
         int32_t tid, p0; uint32_t bin_mq_nl, flag_nc; int32_t l_seq;
         memcpy(&tid, d, 4); memcpy(&p0, d + 4, 4); memcpy(&bin_mq_nl, d + 8, 4); memcpy(&flag_nc, d + 12, 4); memcpy(&l_seq, d + 16, 4);
         if (!bam_record_shape_ok(d, bs)) die("Error: malformed BAM record (its header does not fit its %d bytes)\n", (int)bs);
         const uint32_t l_rn = bin_mq_nl & 0xFF, n_cig = flag_nc & 0xFFFF;
-        if (tid < 0 || ((flag_nc >> 16) & 4) || n_cig < 3) return;
+        if (tid < 0 || ((flag_nc >> 16) & 4)) return;
         thj_aln a; memset(&a, 0, sizeof a);
         bool spliced = false;
         size_t pp = 32 + l_rn;
         for (uint32_t i = 0; i < n_cig; ++i) { uint32_t c; memcpy(&c, d + pp, 4); pp += 4; const uint32_t op = (c & 0xF) < 9 ? OPS[c & 0xF] : 15u; if (op == THJ_CIG_REF_SKIP) spliced = true; if (i < 16) a.cigar[i] = (op << 28) | (c >> 4); }
-        if (!spliced) return;
-        // a spliced alignment the consensus cannot hold must not vanish from the support counts silently
-        if (n_cig > 16) die("Error: a spliced alignment of %u CIGAR operations (at most 16 are supported)\n", n_cig);
         pp += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
-        char xs = 0;
-        while (pp + 3 <= (size_t)bs) {                        // XS:A
+        char xs = 0; const char* xf = nullptr;
+        while (pp + 3 <= (size_t)bs) {                        // XS:A, XF:Z
             const char t0 = (char)d[pp], t1 = (char)d[pp + 1], ty = (char)d[pp + 2];
             pp += 3;
             if (bam_aux_fixed_size(ty) > (size_t)bs - pp) die("Error: malformed BAM record (a tag runs past its end)\n");
@@ -62,16 +64,58 @@ static int real_main(int argc, char** argv) {
             case 's': case 'S': pp += 2; break;
             case 'i': case 'I': case 'f': pp += 4; break;
             case 'd': pp += 8; break;
-            case 'Z': case 'H': while (pp < (size_t)bs && d[pp]) ++pp; ++pp; break;
+            case 'Z': case 'H': { const size_t at = pp; while (pp < (size_t)bs && d[pp]) ++pp; if (pp < (size_t)bs && ty == 'Z' && t0 == 'X' && t1 == 'F') xf = (const char*)d + at; ++pp; break; }
             case 'B': { char st = (char)d[pp]; int32_t cnt; memcpy(&cnt, d + pp + 1, 4); if (cnt < 0 || (int64_t)cnt > (int64_t)bs) die("Error: malformed BAM record (an array tag runs past its end)\n");
                         pp += 5 + (size_t)cnt * ((st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : 4); break; }
             default: pp = (size_t)bs; break;
             }
         }
+        a.flags = (uint8_t)(xs == '-' ? THJ_HIT_ANTISENSE_SPLICE : 0);
+        if (xf) {
+            if (xf[0] == '2') return;                          // "ignore the second part of a fusion alignment" (:1214-1216)
+            std::vector<std::string> f = split(xf, ' ');
+            if (f.size() < 4) return;
+            std::vector<std::string> cs = split(f[1], '-');
+            const uint32_t r1 = cs.size() >= 2 ? rt.get_id(cs[0]) : ((size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0), r2 = cs.size() >= 2 ? rt.get_id(cs[1]) : 0;
+            if (!r1 || !r2) return;
+            int n = 0; bool spl = false;
+            uint32_t op[16];
+            for (const char* q = f[3].c_str(); *q;) {
+                char* t; const long len0 = strtol(q, &t, 10); long len = len0;
+                if (len <= 0) return;
+                uint32_t code;
+                switch (*t) {
+                case 'M': code = 1; break; case 'm': code = 2; break; case 'I': code = 3; break; case 'i': code = 4; break;
+                case 'D': code = 5; break; case 'd': code = 6; break;
+                case 'N': case 'n': if (len > max_report_intron) return; code = *t == 'N' ? 11 : 12; spl = true; break;
+                case 'F': code = 7; len = len - 1; break;
+                case 'S': code = 13; break; case 'H': code = 14; break; case 'P': code = 15; break;
+                default: return;
+                }
+                q = t + 1;
+                if (n >= 15) die("Error: a fusion alignment of more than 15 CIGAR operations (XF:Z:%s)\n", xf);
+                op[n++] = code << 28 | ((uint32_t)len & 0x0FFFFFFFu);
+                if (n >= 3 && (op[n - 2] >> 28) == 7) {         // the direction of the fusion from the pieces around it (:1283-1301)
+                    auto up = [](uint32_t c) { c >>= 28; return c == 1 || c == 5 || c == 3 || c == 11; };
+                    const bool i1 = up(op[n - 3]), i2 = up(op[n - 1]);
+                    const uint32_t dir = (i1 && !i2) ? 8u : (!i1 && i2) ? 9u : (!i1 && !i2) ? 10u : 7u;
+                    op[n - 2] = dir << 28 | (op[n - 2] & 0x0FFFFFFFu);
+                }
+            }
+            if (!spl) return;
+            memset(a.cigar, 0, sizeof a.cigar);
+            for (int i = 0; i < n; ++i) a.cigar[i] = op[i];
+            a.cigar[15] = r2;
+            a.ref_id = r1; a.left = atoi(f[2].c_str()) - 1; a.n_cigar = (uint8_t)n;
+            out.push_back(a);
+            return;
+        }
+        if (!spliced || n_cig < 3) return;
+        // a spliced alignment the consensus cannot hold must not vanish from the support counts silently
+        if (n_cig > 16) die("Error: a spliced alignment of %u CIGAR operations (at most 16 are supported)\n", n_cig);
         a.ref_id = (size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0;
         if (!a.ref_id) return;
         a.left = p0; a.n_cigar = (uint8_t)n_cig;
-        a.flags = (uint8_t)(xs == '-' ? THJ_HIT_ANTISENSE_SPLICE : 0);
         out.push_back(a);
     };
     auto read_parallel = [&](const std::string& fn, std::vector<thj_aln>& out) -> bool {

@@ -44,7 +44,10 @@ __device__ __forceinline__ uint32_t jb_insert(const JbTable& t, u64 k, uint32_t 
     return 0xFFFFFFFFu;
 }
 
-// the junctions of one record (junctions_from_spliced_hit): calls f(left, right, left_extent, right_extent) per REF_SKIP
+// the junctions of one record (junctions_from_spliced_hit, junctions.cpp:19-92): calls f(ref_id, left, right, left_extent, right_extent)
+// per REF_SKIP / rEF_SKIP.  Pieces that run down the genome (lower-case ops 2, 6, 12) walk backwards and swap the extents; a fusion op
+// (FF 7, FR 8, RF 9) jumps to its length = the position on the second contig (cigar[15] of the record) and the junctions behind it belong
+// to that contig; FUSION_RR (10) has no case in the reference and none here.
 // slot: the record is in the stitch kernels' slot layout (RecSink, thj_span.hip: cigar ops 4.. live in the tail line)
 template <class F>
 __device__ __forceinline__ int jb_rec_juncs(const OutAln& a, bool slot, F f) {
@@ -52,14 +55,17 @@ __device__ __forceinline__ int jb_rec_juncs(const OutAln& a, bool slot, F f) {
     int64_t j = a.left;
     const uint32_t* w = (const uint32_t*)&a;
     auto cg = [&](int c) { return w[slot && c >= 4 ? 12 + c : 6 + c]; };
+    uint32_t ref = a.ref_id;
     for (int c = 0; c < a.n_cigar && c < SPAN_MAXC; ++c) {
         const uint32_t op = cg(c) >> 28, len = cg(c) & 0x0FFFFFFFu;
-        if (op == 11) {
-            const uint32_t le = c > 0 ? (cg(c - 1) & 0x0FFFFFFFu) : 0u, re = c + 1 < a.n_cigar ? (cg(c + 1) & 0x0FFFFFFFu) : 0u;
-            f((uint32_t)(j - 1), (uint32_t)(j + len), le, re);
+        if (op == 11 || op == 12) {
+            const uint32_t prev = c > 0 ? (cg(c - 1) & 0x0FFFFFFFu) : 0u, next = c + 1 < a.n_cigar ? (cg(c + 1) & 0x0FFFFFFFu) : 0u;
+            if (op == 11) { f(ref, (uint32_t)(j - 1), (uint32_t)(j + len), prev, next); j += len; }
+            else { f(ref, (uint32_t)(j - len), (uint32_t)(j + 1), next, prev); j -= len; }
             ++n;
-            j += len;
         } else if (op == 1 || op == 5) j += len;
+        else if (op == 2 || op == 6) j -= len;
+        else if (op == 7 || op == 8 || op == 9) { j = len; ref = cg(SPAN_MAXC - 1); }
     }
     return n;
 }
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256) void thj_k_jb_count(JbRecs r, unsigned long lo
     unsigned int mine = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < r.n_slots + r.n_extra; i += (int64_t)gridDim.x * blockDim.x) {
         const OutAln* a = jb_rec(r, i);
-        if (a) mine += (unsigned)jb_rec_juncs(*a, r.slot_layout, [](uint32_t, uint32_t, uint32_t, uint32_t) {});
+        if (a) mine += (unsigned)jb_rec_juncs(*a, r.slot_layout, [](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {});
     }
     if (mine) atomicAdd(&s_n, mine);
     __syncthreads();
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256) void thj_k_jb_add(Genome g, JbRecs r, JbTable 
     for (int64_t it = 0; it < n_iter; ++it) {
         const int64_t i = it * (int64_t)gridDim.x * blockDim.x + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
         const OutAln* a = i < total ? jb_rec(r, i) : nullptr;
-        unsigned int nj = a ? (unsigned)jb_rec_juncs(*a, r.slot_layout, [](uint32_t, uint32_t, uint32_t, uint32_t) {}) : 0u;
+        unsigned int nj = a ? (unsigned)jb_rec_juncs(*a, r.slot_layout, [](uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) {}) : 0u;
         // one reservation per wave: inclusive scan of nj over the lanes, the last lane adds the total
         unsigned int incl = nj;
         for (int d = 1; d < 64; d <<= 1) { const unsigned int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
@@ -106,8 +112,8 @@ __global__ __launch_bounds__(256) void thj_k_jb_add(Genome g, JbRecs r, JbTable 
         const bool anti = (a->flags & 4u) != 0;             // THJ_HIT_ANTISENSE_SPLICE
         uint8_t idx = 0;
         const uint8_t n8 = (uint8_t)nj;
-        jb_rec_juncs(*a, r.slot_layout, [&](uint32_t left, uint32_t right, uint32_t le, uint32_t re) {
-            const uint32_t slot = jb_insert(t, junc_key(g, a->ref_id, left, right, anti), left);
+        jb_rec_juncs(*a, r.slot_layout, [&](uint32_t ref, uint32_t left, uint32_t right, uint32_t le, uint32_t re) {
+            const uint32_t slot = jb_insert(t, junc_key(g, ref, left, right, anti), left);
             if (slot != 0xFFFFFFFFu) {
                 atomicAdd(&t.cnt1[slot], 1u);
                 atomicMax(&t.le1[slot], le);

@@ -687,10 +687,14 @@ _juncbed_methods()
 
 
 def aln_array_from_tuples(recs) -> np.ndarray:
-    """[(ref_id, left, antisense_splice, [(op, len) ...])] -> ALN_DTYPE array (the fields the junction consensus reads)"""
+    """[(ref_id, left, antisense_splice, [(op, len) ...][, ref_id2])] -> ALN_DTYPE array (the fields the junction consensus reads; a fusion
+    alignment has at most 15 ops and its second contig in cigar[15])"""
     a = np.zeros(len(recs), dtype=ALN_DTYPE)
-    for k, (ref, left, anti, cig) in enumerate(recs):
+    for k, rec in enumerate(recs):
+        ref, left, anti, cig = rec[:4]
         a[k]["ref_id"], a[k]["left"], a[k]["flags"], a[k]["n_cigar"] = ref, left, 4 if anti else 0, len(cig)
         for i, (op, ln) in enumerate(cig):
             a[k]["cigar"][i] = (op << 28) | ln
+        if len(rec) > 4 and rec[4]:
+            a[k]["cigar"][15] = rec[4]
     return a
