@@ -408,6 +408,24 @@ int thj_covsearch_add_reads(thj_ctx* ctx, int64_t n_reads, int32_t words_per_pla
                             int32_t on_device);
 int thj_covsearch_run_async(thj_ctx* ctx, int32_t min_cov_length, int32_t min_coverage_intron, int32_t max_coverage_intron);
 int thj_covsearch_finish(thj_ctx* ctx, int64_t max_cov_juncs, int64_t* n_found);
+/* Microexon search (segment_juncs.cpp:3737-3941; replaces align_microexon_segs and the window registration inside look_for_hit_group).
+ * A read whose first segment has no hit while every other segment has some may begin in a microexon: every hit of its second segment
+ * registers a window of 2000 bases beside it with the read's first segment_length bases.  thj_microexon_collect finds those
+ * candidates on the device for an uploaded / ingested batch (read_side 1 = left, 2 = right; ordinals = the batch's ordinal_base + row);
+ * thj_microexon_candidates hands all of them to the host (malloc'd: free()), which merges overlapping windows in the reference's
+ * visiting order -- sequential std::map logic, csrc/host/thj_mx_host.h; thj_microexon_run then builds every window's own extension
+ * table, pairs the GT / CT sites of a window with its AG / AC sites (one wave per window), applies the max_cov_juncs cut
+ * (segment_juncs.cpp:5021-5024) and adds the junctions to the pass's set.  Run it after thj_covsearch_finish (they share buffers).
+ * str = the 2-bit string, first base most significant; strings of a window in the order the reference pooled them (the table is a set:
+ * the order does not matter).  segment_length 10..32. */
+typedef struct { uint32_t ordinal; uint16_t rank; uint8_t side, len; uint32_t ref_id; int32_t left, right; uint32_t reserved; uint64_t str; } thj_mx_cand;
+typedef struct { uint32_t ref_id; int32_t left, right; int32_t side; } thj_mx_window;
+int thj_microexon_reset_async(thj_ctx* ctx);
+int thj_microexon_collect(thj_ctx* ctx, const thj_params* p, const thj_seg_batch* device_batch, int32_t read_side);
+int thj_microexon_candidates(thj_ctx* ctx, thj_mx_cand** out, int64_t* n);
+int thj_microexon_run(thj_ctx* ctx, const thj_mx_window* windows, int64_t n_windows, const uint64_t* strs, const uint8_t* str_len, const uint32_t* str_window,
+                      int64_t n_strs, int32_t min_coverage_intron, int32_t library_type, int64_t max_cov_juncs, int64_t* n_found);
+
 /* Reads sharded over GPUs: the coverage map of the whole run is the OR of the ranks' maps and the
  * extension table the concatenation of their entries.  thj_covsearch_device_state exposes a rank's state (device
  * pointers: n_words coverage words, one size per contig, n_ext key / value entries) for the caller to all-gather;

@@ -17,6 +17,7 @@
  * PARITY: unpinned by the reference's own tests (none reach the coverage search); checked informally against the
  * survey-stage scratch build (oracle/README.md).
  */
+#define _POSIX_C_SOURCE 200809L          /* strdup */
 #include "thj_oracle.h"
 #include <stdlib.h>
 #include <string.h>
@@ -294,5 +295,176 @@ int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits
     for (int ref = 0; ref <= nc; ++ref) { free(fd[ref].a); free(fa[ref].a); free(rd[ref].a); free(ra[ref].a); }
     free(fd); free(fa); free(rd); free(ra); free(in_map); free(cands.a);
     free(look_left.a); free(look_right.a); free(t.off); free(t.ext);
+    return 0;
+}
+
+
+/* ================================================================================================ microexon search
+ * segment_juncs.cpp:3880-3941 (window registration inside look_for_hit_group), :3671-3735 (add_to_microexon_windows),
+ * :3737-3815 (align_microexon_segs).  A read whose FIRST segment has no hit while every other segment has some may start in a
+ * microexon: for each hit of its second segment a window of max_microexon_stretch (2000, :60) bases next to that hit is
+ * registered with the read's first segment_length bases (reverse-complemented for antisense hits); overlapping windows merge,
+ * pooling their strings.  Each window is then searched like a coverage-search island pair, with an extension table made of ITS
+ * strings only: every GT / CT in it is a left site, every AG / AC a right site (juncs_from_ref_segs with a POINT_DIR_DONTCARE
+ * and a POINT_DIR_LEFT copy of the window, :3788-3806, :2289-2318), pairs within [min_coverage_intron, 2000) kept when a
+ * string extends across them (RecordExtendableJuncs, :1568-1626).  All windows share one skip-count-ordered junction set
+ * capped at max_cov_juncs (:5021-5024). */
+typedef struct { uint32_t ref; int32_t left, right; int side; char** str; int64_t n_str, cap_str; } mx_window;
+typedef struct { mx_window* a; int64_t n, cap; } mx_map;                         /* std::map<RefSeg, vector<string>*>, kept sorted */
+
+static int mx_key_cmp(uint32_t ref, int32_t l, int32_t r, const mx_window* w) {    /* RefSeg::operator< (segments.h:50-58) */
+    if (ref != w->ref) return ref < w->ref ? -1 : 1;
+    if (l != w->left) return l < w->left ? -1 : 1;
+    if (r != w->right) return r < w->right ? -1 : 1;
+    return 0;
+}
+static int64_t mx_lower_bound(const mx_map* m, uint32_t ref, int32_t l, int32_t r) {
+    int64_t lo = 0, hi = m->n;
+    while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (mx_key_cmp(ref, l, r, &m->a[mid]) > 0) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+static void mx_push_str(mx_window* w, const char* s) {
+    if (w->n_str == w->cap_str) { w->cap_str = w->cap_str ? 2 * w->cap_str : 4; w->str = (char**)realloc(w->str, (size_t)w->cap_str * sizeof(char*)); }
+    w->str[w->n_str++] = strdup(s);
+}
+/* map::insert: nothing happens when the key is there already (the reference then leaks the vector it made) */
+static void mx_insert(mx_map* m, mx_window w) {
+    int64_t at = mx_lower_bound(m, w.ref, w.left, w.right);
+    if (at < m->n && mx_key_cmp(w.ref, w.left, w.right, &m->a[at]) == 0) { for (int64_t i = 0; i < w.n_str; ++i) free(w.str[i]); free(w.str); return; }
+    if (m->n == m->cap) { m->cap = m->cap ? 2 * m->cap : 64; m->a = (mx_window*)realloc(m->a, (size_t)m->cap * sizeof(mx_window)); }
+    memmove(&m->a[at + 1], &m->a[at], (size_t)(m->n - at) * sizeof(mx_window));
+    m->a[at] = w; m->n++;
+}
+static int overlap_in_genome(int ll, int lr, int rl, int rr) {                    /* :3662-3673 */
+    if (ll >= rl && ll < rr) return 1;
+    if (lr > rl && lr < rr) return 1;
+    if (rl >= ll && rl < lr) return 1;
+    if (rr > ll && rr < lr) return 1;
+    return 0;
+}
+/* add_to_microexon_windows (:3675-3735), statement for statement */
+static void mx_add(mx_map* m, uint32_t ref, int left_boundary, int right_boundary, const char* dna, int side) {
+    mx_window nw; memset(&nw, 0, sizeof nw);
+    nw.ref = ref; nw.left = left_boundary; nw.right = right_boundary; nw.side = side;          /* left_dummy */
+    int64_t lb = mx_lower_bound(m, ref, left_boundary, right_boundary);
+    const int64_t ub = mx_lower_bound(m, ref, right_boundary, right_boundary + 1);
+    if (lb == m->n) { mx_push_str(&nw, dna); mx_insert(m, nw); return; }
+    int64_t first_erased = -1, last_erased = ub;
+    int have_new = 0;
+    for (; lb < ub; ++lb) {
+        if (overlap_in_genome(m->a[lb].left, m->a[lb].right, left_boundary, right_boundary)) {
+            have_new = 1;
+            if (first_erased < 0) first_erased = lb;
+            nw.left = m->a[lb].left < left_boundary ? m->a[lb].left : left_boundary;
+            nw.right = m->a[lb].right > right_boundary ? m->a[lb].right : right_boundary;
+            for (int64_t i = 0; i < m->a[lb].n_str; ++i) { mx_push_str(&nw, m->a[lb].str[i]); free(m->a[lb].str[i]); }
+            free(m->a[lb].str); m->a[lb].str = NULL; m->a[lb].n_str = 0;
+        } else if (first_erased >= 0) last_erased = lb;
+    }
+    if (first_erased >= 0) {
+        memmove(&m->a[first_erased], &m->a[last_erased], (size_t)(m->n - last_erased) * sizeof(mx_window));
+        m->n -= last_erased - first_erased;
+    }
+    (void)have_new;
+    mx_push_str(&nw, dna);                                   /* a window of its own, or the merged one with the new string last */
+    mx_insert(m, nw);
+}
+static char mx_comp(char c) { switch (c) { case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; default: return 'N'; } }
+
+int orc_microexon_search(const orc_params* p, int min_anchor_len, int min_intron, int64_t max_juncs, const orc_genome* g,
+                         const orc_batch* const* batches, const int* sides, int n_batches, orc_junction** out, int64_t* n_out, int64_t* n_windows) {
+    static const int max_microexon_stretch = 2000;            /* :60 */
+    const int L = p->segment_length;
+    const int seq_key_len = min_anchor_len < 6 ? min_anchor_len : 6;   /* :3848 */
+    mx_map map = {0, 0, 0};
+    char* fwd = (char*)malloc((size_t)L + 1); char* rev = (char*)malloc((size_t)L + 1);
+    for (int bi = 0; bi < n_batches; ++bi) {
+        const orc_batch* b = batches[bi];
+        if (b->nseg < 2) continue;                             /* look_for_hit_group starts at the file before the last */
+        for (int r = 0; r < b->n_reads; ++r) {
+            const int64_t* so = b->seg_off + (int64_t)r * b->nseg;
+            if (so[1] != so[0]) continue;                      /* the leftmost segment has hits */
+            int empty_seg = 0;
+            for (int h = 1; h < b->nseg; ++h) if (so[h + 1] == so[h]) empty_seg = h;
+            if (empty_seg != 0) continue;                      /* :3902-3910 */
+            const char* rs = b->bases + b->read_off[r];
+            const int rl = (int)(b->read_off[r + 1] - b->read_off[r]);
+            const int n = rl < L ? rl : L;                     /* substr(0, segment_length) */
+            for (int i = 0; i < n; ++i) { fwd[i] = rs[i]; rev[n - 1 - i] = mx_comp(rs[i]); }
+            fwd[n] = rev[n] = 0;
+            for (int64_t h = so[1]; h < so[2]; ++h) {          /* hits_for_read[empty_seg + 1] */
+                const orc_hit* bh = &b->hits[h];
+                if (bh->ref_id == 0 || bh->ref_id > (uint32_t)g->n_contigs || !g->seq[bh->ref_id - 1]) continue;
+                const int ref_len = (int)g->len[bh->ref_id - 1];
+                int lb, rb;
+                if (bh->flags & ORC_HIT_ANTISENSE) {
+                    lb = bh->right - min_anchor_len; if (lb < 0) lb = 0;
+                    rb = lb + max_microexon_stretch; if (rb > ref_len - 2) rb = ref_len - 2;
+                    if (rb - lb < 2 * seq_key_len) continue;
+                    mx_add(&map, bh->ref_id, lb, rb, rev, sides[bi]);
+                } else {
+                    rb = bh->left + min_anchor_len; if (rb > ref_len - 2) rb = ref_len - 2;
+                    lb = rb - max_microexon_stretch; if (lb < 0) lb = 0;
+                    if (rb - lb < 2 * seq_key_len) continue;
+                    mx_add(&map, bh->ref_id, lb, rb, fwd, sides[bi]);
+                }
+            }
+        }
+    }
+    free(fwd); free(rev);
+    if (n_windows) *n_windows = map.n;
+    /* ---- align_microexon_segs */
+    cand_vec cands = {0, 0, 0};
+    int64_t* counts = (int64_t*)calloc(N_KEYS, sizeof(int64_t));
+    for (int64_t wi = 0; wi < map.n; ++wi) {
+        const mx_window* w = &map.a[wi];
+        /* the window's own extension table: store_read_extensions(extensions, 5, 5, s, false) per string (:3775-3780) */
+        mer_table t;
+        memset(counts, 0, (size_t)N_KEYS * sizeof(int64_t));
+        for (int64_t k = 0; k < w->n_str; ++k) read_extensions(w->str[k], (int)strlen(w->str[k]), counts, NULL);
+        t.off = (int64_t*)malloc(((size_t)N_KEYS + 1) * sizeof(int64_t));
+        t.off[0] = 0;
+        for (uint32_t k = 0; k < N_KEYS; ++k) t.off[k + 1] = t.off[k] + counts[k];
+        t.ext = (mer_ext*)malloc((size_t)(t.off[N_KEYS] + 1) * sizeof(mer_ext));
+        memset(counts, 0, (size_t)N_KEYS * sizeof(int64_t));
+        for (int64_t k = 0; k < w->n_str; ++k) read_extensions(w->str[k], (int)strlen(w->str[k]), counts, &t);
+        const char* ref = g->seq[w->ref - 1];
+        const int64_t len = g->len[w->ref - 1];
+        int skip_fwd = 0, skip_rev = 0;                        /* :2112-2138, seg.antisense == false */
+        if (p->library_type == 2) { if (w->side == 1) skip_fwd = 1; else if (w->side == 2) skip_rev = 1; }
+        if (p->library_type == 3) { if (w->side == 1) skip_rev = 1; else if (w->side == 2) skip_fwd = 1; }
+        site_vec fd = {0, 0, 0}, ra = {0, 0, 0}, fa = {0, 0, 0}, rd = {0, 0, 0};
+        if (ref && !(w->left < 0 || w->right >= len - 1)) {    /* :2154, for both copies of the window */
+            const int64_t seg_len = w->right - w->left;
+            for (int64_t i = 0; i + 2 <= seg_len; ++i) {       /* i <= to = seg_len - 2 */
+                const uint32_t b0 = base2(ref[w->left + i]), b1 = base2(ref[w->left + i + 1]);
+                /* the POINT_DIR_DONTCARE copy takes the "right pointing" branch (:2304-2318): GT, else CT */
+                if (b0 == 2 && b1 == 3) { if (!skip_fwd) sv_push(&fd, w->left + i); }
+                else if (b0 == 1 && b1 == 3) { if (!skip_rev) sv_push(&ra, w->left + i); }
+                /* the POINT_DIR_LEFT copy (:2289-2303): AG, else AC */
+                if (b0 == 0 && b1 == 2) { if (!skip_fwd) sv_push(&fa, w->left + i); }
+                else if (b0 == 0 && b1 == 1) { if (!skip_rev) sv_push(&rd, w->left + i); }
+            }
+            sv_unique(&fd); sv_unique(&fa); sv_unique(&rd); sv_unique(&ra);
+            attach_upstream(ref, len, &fd); attach_upstream(ref, len, &ra);
+            attach_downstream(ref, len, &rd); attach_downstream(ref, len, &fa);
+            record(&t, w->ref, &fd, &fa, 0, min_intron, max_microexon_stretch, &cands);
+            record(&t, w->ref, &ra, &rd, 1, min_intron, max_microexon_stretch, &cands);
+        }
+        free(fd.a); free(fa.a); free(rd.a); free(ra.a); free(t.off); free(t.ext);
+    }
+    free(counts);
+    qsort(cands.a, (size_t)cands.n, sizeof(cand), cand_cmp);
+    int64_t m = 0;
+    for (int64_t i = 0; i < cands.n; ++i) if (m == 0 || cand_cmp(&cands.a[m - 1], &cands.a[i]) != 0) cands.a[m++] = cands.a[i];
+    if (m > max_juncs) m = max_juncs;
+    orc_junction* res = (orc_junction*)malloc((size_t)(m + 1) * sizeof(orc_junction));
+    for (int64_t i = 0; i < m; ++i) res[i] = cands.a[i].j;
+    qsort(res, (size_t)m, sizeof(orc_junction), junc_cmp_v);
+    int64_t k = 0;
+    for (int64_t i = 0; i < m; ++i) if (k == 0 || junc_cmp(&res[k - 1], &res[i]) != 0) res[k++] = res[i];
+    *out = res; *n_out = k;
+    for (int64_t wi = 0; wi < map.n; ++wi) { for (int64_t i = 0; i < map.a[wi].n_str; ++i) free(map.a[wi].str[i]); free(map.a[wi].str); }
+    free(map.a); free(cands.a);
     return 0;
 }

@@ -158,6 +158,13 @@ int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits
                         int min_cov_length, int min_intron, int max_intron, int64_t max_juncs,
                         orc_junction** out, int64_t* n_out);
 
+/* Microexon search of segment_juncs (covsearch_oracle.c; segment_juncs.cpp:3880-3941 window registration, :3675-3735 merging,
+ * :3737-3815 per-window pairing): the batches of both sides in the order the reference visits them (all left reads, then all right
+ * reads), sides[i] = 1 (READ_LEFT) / 2 (READ_RIGHT); p->segment_length and p->library_type are read; min_intron =
+ * min_coverage_intron_length, max_juncs = max_cov_juncs.  -> junctions in Junction::operator< order (malloc'd, orc_free). */
+int orc_microexon_search(const orc_params* p, int min_anchor_len, int min_intron, int64_t max_juncs, const orc_genome* g,
+                         const orc_batch* const* batches, const int* sides, int n_batches, orc_junction** out, int64_t* n_out, int64_t* n_windows);
+
 /* ===================== long_spanning_reads (spanning_oracle.c) ===================== */
 
 /* CigarOpCode values of bwt_map.h:36-55 */

@@ -343,3 +343,69 @@ extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* c
     return hostsim_coverage_run(blocks, contig_blk, contig_len, n_contigs, n_blocks, bits.data(), sizes.data(), keys.data(), vals.data(), n_ium * 23,
                                 min_cov_length, min_intron, max_intron, max_juncs, out, n_out);
 }
+
+
+// ---- microexon search: the kernel logic of thj_cov_core.h (candidates, table entries, per-window pairing) as host loops around the
+// product's own window merge (csrc/host/thj_mx_host.h) -- the path thj_microexon_collect / _candidates / _run take on the device
+#include "../../tophat_amd/csrc/host/thj_mx_host.h"
+extern "C" int hostsim_microexon(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
+                                 const thj_seg_batch* const* batches, const int32_t* sides, int32_t n_batches, int32_t min_intron, int64_t max_juncs,
+                                 thj_junction** out, int64_t* n_out, int64_t* n_windows) {
+    using namespace thj::cov;
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    std::vector<thj_mx_cand> cands;
+    for (int bi = 0; bi < n_batches; ++bi) {
+        const thj_seg_batch* b = batches[bi];
+        for (int32_t r = 0; r < b->n_reads; ++r)
+            mx_read_candidates(g, (const Hit*)b->hits, b->seg_off + (int64_t)r * b->nseg, b->nseg, (const u64*)b->read_planes + (int64_t)r * 3 * b->words_per_plane,
+                               b->words_per_plane, (int)b->read_len[r], tp->segment_length, tp->min_anchor_len,
+                               [&](int rank, uint32_t ref, int lb, int rb, u64 str, int n) {
+                                   cands.push_back(thj_mx_cand{b->ordinal_base + (uint32_t)r, (uint16_t)rank, (uint8_t)sides[bi], (uint8_t)n, ref, lb, rb, 0u, str});
+                               });
+    }
+    std::reverse(cands.begin(), cands.end());                     // the device appends in any order: the merge must sort
+    thjh::MxWindows mw = thjh::mx_merge_windows(cands);
+    if (n_windows) *n_windows = (int64_t)mw.windows.size();
+    std::vector<std::pair<u64, u64>> ent;
+    for (size_t i = 0; i < mw.strs.size(); ++i) mx_string_entries(mw.strs[i], (int)mw.str_len[i], (u64)mw.str_window[i], [&](u64 k, u64 v) { ent.push_back({k, v}); });
+    std::stable_sort(ent.begin(), ent.end(), [](const std::pair<u64, u64>& a, const std::pair<u64, u64>& b) { return a.first < b.first; });
+    std::vector<u64> keys(ent.size() + 1), vals(ent.size() + 1);
+    for (size_t i = 0; i < ent.size(); ++i) { keys[i] = ent[i].first; vals[i] = ent[i].second; }
+    MxTable t{keys.data(), vals.data(), (int64_t)ent.size()};
+    Collect c;
+    for (size_t wi = 0; wi < mw.windows.size(); ++wi) {
+        const thj_mx_window& w = mw.windows[wi];
+        const int64_t len = g_len(g, w.ref_id);
+        if (w.left < 0 || w.right >= len - 1) continue;
+        const int64_t w0 = w.left >> 6;
+        const int n_words = (int)mx_window_words(w.left, w.right);
+        std::vector<u64> bm[4];
+        for (auto& v : bm) v.assign((size_t)n_words, 0);
+        for (int j = 0; j < n_words; ++j) { const MxSites s = mx_site_word(g, w.ref_id, w.left, w.right, tp->library_type, w.side, j); bm[0][j] = s.fd; bm[1][j] = s.ra; bm[2][j] = s.fa; bm[3][j] = s.rd; }
+        for (int o = 0; o < 2; ++o)
+            for (int j = 0; j < n_words; ++j) {
+                u64 bits = bm[o][j];
+                while (bits) {
+                    const int b = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    mx_pair_site(g, t, (u64)wi, w.ref_id, len, bm[2 + o].data(), w0, n_words, o, min_intron, (w0 + j) * 64 + b, c);
+                }
+            }
+    }
+    auto jl = [](const thj_junction& a, const thj_junction& b) {
+        if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+        if (a.left != b.left) return a.left < b.left;
+        if (a.right != b.right) return a.right < b.right;
+        return a.antisense < b.antisense;
+    };
+    std::sort(c.cov.begin(), c.cov.end(), [&](const std::pair<uint32_t, thj_junction>& a, const std::pair<uint32_t, thj_junction>& b) {
+        if (a.first != b.first) return a.first < b.first;
+        return jl(a.second, b.second);
+    });
+    c.cov.erase(std::unique(c.cov.begin(), c.cov.end(), [&](const std::pair<uint32_t, thj_junction>& a, const std::pair<uint32_t, thj_junction>& b) { return a.first == b.first && !jl(a.second, b.second) && !jl(b.second, a.second); }), c.cov.end());
+    if ((int64_t)c.cov.size() > max_juncs) c.cov.resize((size_t)max_juncs);
+    *n_out = (int64_t)c.cov.size();
+    *out = (thj_junction*)malloc(sizeof(thj_junction) * (c.cov.size() + 1));
+    for (size_t i = 0; i < c.cov.size(); ++i) (*out)[i] = c.cov[i].second;
+    return 0;
+}

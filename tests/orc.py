@@ -385,6 +385,36 @@ def coverage_search(g: Genome, hits: np.ndarray, ium_reads, min_cov_length: int 
     return a
 
 
+def _orc_batch(b: SegBatch):
+    ob = OrcBatch()
+    ob.n_reads, ob.nseg = b.n_reads, b.nseg
+    keep = [np.ascontiguousarray(b.read_id, dtype=np.uint32), np.ascontiguousarray(b.read_off, dtype=np.int64),
+            np.ascontiguousarray(b.bases, dtype=np.uint8), np.ascontiguousarray(b.seg_off, dtype=np.int64),
+            np.ascontiguousarray(b.hits)]
+    ob.read_id, ob.read_off, ob.bases, ob.seg_off, ob.hits = [a.ctypes.data for a in keep]
+    return ob, keep
+
+
+def microexon_search(p: Params, g: Genome, batches, min_anchor_len: int = 8, min_intron: int = 50, max_juncs: int = 5000000):
+    """orc_microexon_search (segment_juncs.cpp:3737-3941): batches = [(SegBatch, side)] in visiting order (left side first)
+    -> (JUNC_DTYPE array in Junction order, number of windows)"""
+    lib = _lib()
+    obs = [_orc_batch(b) for b, _ in batches]
+    arr = (C.POINTER(OrcBatch) * max(1, len(obs)))(*[C.pointer(o[0]) for o in obs])
+    sides = (C.c_int * max(1, len(obs)))(*[sd for _, sd in batches])
+    op = orc_params(p)
+    out = C.c_void_p()
+    n, nw = C.c_int64(), C.c_int64()
+    rc = lib.orc_microexon_search(C.byref(op), int(min_anchor_len), int(min_intron), C.c_int64(max_juncs), C.byref(g.c), arr, sides, len(obs),
+                                  C.byref(out), C.byref(n), C.byref(nw))
+    assert rc == 0
+    a = np.zeros(0, dtype=JUNC_DTYPE)
+    if n.value:
+        a = np.frombuffer((C.c_char * (n.value * 16)).from_address(out.value), dtype=JUNC_DTYPE).copy()
+    lib.orc_free(out)
+    return a, nw.value
+
+
 # ---- junction consensus of tophat_reports (juncbed_oracle.c)
 JREC_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<i4"), ("antisense_splice", "u1"), ("n_cigar", "u1"), ("reserved", "<u2"), ("cigar", "<u4", 16)])
 JSTAT_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<u4"), ("right", "<u4"), ("antisense", "<u4"), ("left_extent", "<u4"),

@@ -69,6 +69,31 @@ def segjuncs(p: Params, seqs, b: SegBatch, ordinal_base: int = 0) -> Events:
     return ev
 
 
+def microexon_search(p: Params, seqs, batches, min_intron: int = 50, max_juncs: int = 5000000):
+    """the microexon kernels' logic (thj_cov_core.h) as host loops around the product's window merge (csrc/host/thj_mx_host.h);
+    batches = [(SegBatch, side, ordinal_base)] -> (JUNC_DTYPE array in Junction order, number of windows)"""
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    clen = g.lens.astype(np.int32)
+    cbs = [host.host_cbatch(b, base, lib=l) for b, _sd, base in batches]
+    arr = (C.POINTER(type(cbs[0][0])) * len(cbs))(*[C.pointer(x[0]) for x in cbs]) if cbs else None
+    sides = (C.c_int32 * max(1, len(cbs)))(*[sd for _b, sd, _base in batches])
+    cp = p.as_ctypes()
+    out = C.c_void_p()
+    n, nw = C.c_int64(), C.c_int64()
+    rc = l.hostsim_microexon(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data), g.n_contigs,
+                             arr, sides, len(cbs), int(min_intron), C.c_int64(max_juncs), C.byref(out), C.byref(n), C.byref(nw))
+    assert rc == 0
+    a = np.zeros(0, dtype=JUNC_DTYPE)
+    if n.value:
+        a = np.frombuffer((C.c_char * (n.value * 16)).from_address(out.value), dtype=JUNC_DTYPE).copy()
+    l.hostsim_free(out)
+    a = np.unique(a) if len(a) else a
+    if len(a):
+        a = a[np.lexsort((a["antisense"], a["right"], a["left"], a["ref_id"]))]
+    return a, nw.value
+
+
 def spanning(p: Params, seqs, b, juncs, insertions, mode: int = 0):
     """-> (list of Aln, status counts) from the CPU build of thj_span_core.h"""
     l = lib()

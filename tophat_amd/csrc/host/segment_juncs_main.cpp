@@ -1,7 +1,7 @@
 // segment_juncs -- MI355X-native drop-in for TopHat's segment_juncs (same argv + files; tophat.py:3097-3112,
 // parsed like segment_juncs.cpp:5186-5364).  Host C++ over the C ABI in include/thj.h; all per-read work runs in
 // the HIP kernels of libthj_hip.so.  Split-segment search, small indels, the paired-end rescue, --fusion-search and the
-// coverage search are supported; microexon / butterfly searches are refused loudly.
+// coverage search and the microexon search are supported; the butterfly search is refused loudly.
 //
 // One process drives every visible GPU.  The reads are cut into contiguous read-id shards with the
 // reference's own planner (calculate_offsets over the inputs' .index files, utils.cpp:22-170; segment_juncs.cpp:4756-4810);
@@ -10,6 +10,7 @@
 // sets are written.  The result does not depend on the number of shards or GPUs.
 #include <sys/stat.h>
 #include "thj_hostio.h"
+#include "thj_mx_host.h"
 
 using namespace thjh;
 
@@ -155,6 +156,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
                     if (nseg > 1 && thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
                     if (nseg > 1 && o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
                     if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
+                    if (!o.no_microexon_search && thj_microexon_collect(ctx, &p, dev, read_side)) die("Error: %s\n", thj_last_error());
                     if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
                 }
                 g_work.add(2, td);
@@ -214,6 +216,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
             if (nseg > 1 && thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
             if (nseg > 1 && o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
             if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
+            if (!o.no_microexon_search && thj_microexon_collect(ctx, &p, dev, read_side)) die("Error: %s\n", thj_last_error());
             if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
             g_work.add(2, td);
         }
@@ -268,9 +271,8 @@ static int real_main(int argc, char** argv) {
     for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
     if (pos.size() < 8 || (pos.size() > 8 && pos.size() < 11)) { print_usage(); return 1; }
     if (o.color) die("Error: colour-space reads are not supported by this build\n");
-    if (!o.no_microexon_search || o.butterfly_search)
-        die("Error: microexon / butterfly searches are not supported by this build yet; "
-            "run with --no-microexon-search and without --butterfly-search (tophat's defaults)\n");
+    if (o.butterfly_search)
+        die("Error: the butterfly search is not supported by this build; run without --butterfly-search (tophat.py never passes it, tophat.py:1088)\n");
     if (o.ium_reads.empty()) o.no_coverage_search = true;             // no unmapped reads: segment_juncs.cpp:4978-4982
     SideInput left{pos[5], pos[6], split(pos[7], ',')}, right;
     if (pos.size() >= 11) right = SideInput{pos[8], pos[9], split(pos[10], ',')};
@@ -438,6 +440,21 @@ static int real_main(int argc, char** argv) {
     }
     std::vector<int64_t> n_cov((size_t)n_gpus, -1), n_fus((size_t)n_gpus, 0);
     std::vector<thj_segjuncs_counts> cnt((size_t)n_gpus);
+    // microexon search (segment_juncs.cpp:3737-3941): the candidate windows every GPU found among its reads come down, merge on the
+    // host in the order the reference visits the reads (add_to_microexon_windows, thj_mx_host.h), and GPU 0 searches the windows
+    // before the exchange step spreads what it found
+    MxWindows mxw;
+    int64_t n_mx = -1;
+    if (!o.no_microexon_search) {
+        std::vector<thj_mx_cand> all;
+        for (auto& g : gpus) {
+            thj_mx_cand* h = nullptr; int64_t nc = 0;
+            if (thj_microexon_candidates(g->ctx, &h, &nc)) die("Error: %s\n", thj_last_error());
+            all.insert(all.end(), h, h + nc);
+            free(h);
+        }
+        mxw = mx_merge_windows(std::move(all));
+    }
     auto end_of_pass = [&](int r) {
         thj_ctx* ctx = gpus[(size_t)r]->ctx;
         thj_comm* cm = comms[(size_t)r];
@@ -447,6 +464,13 @@ static int real_main(int argc, char** argv) {
             int mcl = 20; if (mcl > o.p.segment_length - 2) mcl = o.p.segment_length - 2;          // :62, :5350
             if (thj_covsearch_run_async(ctx, mcl, o.min_coverage_intron, o.max_coverage_intron)) die("Error: %s\n", thj_last_error());
             if (thj_covsearch_finish(ctx, 5000000, &n_cov[(size_t)r])) die("Error: %s\n", thj_last_error());        // max_cov_juncs :56
+        }
+        if (!o.no_microexon_search && r == 0) {
+            fprintf(stderr, ">> Performing microexon-search: \n");
+            fprintf(stderr, "Aligning %d microexon segments in %lu windows\n", (int)mxw.strs.size(), (unsigned long)mxw.windows.size());
+            if (thj_microexon_run(ctx, mxw.windows.data(), (int64_t)mxw.windows.size(), mxw.strs.data(), mxw.str_len.data(), mxw.str_window.data(), (int64_t)mxw.strs.size(),
+                                  o.min_coverage_intron, o.p.library_type, 5000000, &n_mx)) die("Error: %s\n", thj_last_error());
+            fprintf(stderr, "\tfound %d potential junctions\n", (int)n_mx);
         }
         if (cm && thj_events_allgather_async(ctx, cm)) die("Error: %s\n", thj_last_error());
         if (thj_segjuncs_finish(ctx, &cnt[(size_t)r])) die("Error: %s\n", thj_last_error());

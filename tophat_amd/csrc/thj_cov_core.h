@@ -289,6 +289,141 @@ THJ_HD unsigned int pair_word(const Genome& g, const Layout& L, const ExtTable& 
     return found;
 }
 
+
+// ================================================================================================ microexon search
+// segment_juncs.cpp:3880-3941 (window registration in look_for_hit_group), :3675-3735 (add_to_microexon_windows -- host code,
+// csrc/host/thj_mx_host.h), :3737-3815 (align_microexon_segs).  Per merged window: an extension table made of the window's own
+// strings, every GT / CT in it a left site, every AG / AC a right site, pairs within [min_coverage_intron, 2000) kept when a string
+// extends across them -- the coverage search's pairing with a table per window.
+static constexpr int MX_STRETCH = 2000;                    // max_microexon_stretch (:60)
+// A merged window can be wide: its left end is the newest candidate's, its right end the furthest of the windows that started inside it,
+// and such merges chain.  Its site bitmaps therefore live in global memory: words [win_off[w], win_off[w + 1]) of four arrays.
+THJ_HD int64_t mx_window_words(int32_t left, int32_t right) { return (((int64_t)right - 1) >> 6) - ((int64_t)left >> 6) + 1; }
+
+// One candidate window of a read (what look_for_hit_group hands to add_to_microexon_windows): the read's first segment_length bases as
+// a 2-bit string, first base most significant (N reads as A, :24 of the oracle: charToDna5 & 3), reverse-complemented for antisense hits.
+struct MxCand { uint32_t ordinal; uint16_t rank; uint8_t side, len; uint32_t ref_id; int32_t left, right; uint32_t pad; u64 str; };
+static_assert(sizeof(MxCand) == 32, "candidate record");
+
+// the read's candidates: its first segment has no hit, every other segment has some (:3893-3910); one per hit of the second segment
+template <class Emit>
+THJ_HD void mx_read_candidates(const Genome& g, const Hit* hits, const uint32_t* so, int nseg, const u64* rp, int W, int rl, int seg_len, int min_anchor,
+                               Emit emit) {
+    if (nseg < 2 || so[1] != so[0]) return;
+    for (int h = 1; h < nseg; ++h) if (so[h + 1] == so[h]) return;
+    const int n = rl < seg_len ? rl : seg_len;                   // substr(0, segment_length); n <= 32 (checked by the caller)
+    const u64 lo = rp[0], hi = rp[W], nm = rp[2 * W];
+    u64 fwd = 0, rev = 0;
+    for (int i = 0; i < n; ++i) {
+        const u64 isn = (nm >> i) & 1ull;
+        const u64 code = isn ? 0ull : (((hi >> i) & 1ull) << 1 | ((lo >> i) & 1ull));
+        fwd = (fwd << 2) | code;                                  // base i at bits 2 * (n - 1 - i)
+        rev |= (isn ? 0ull : (3ull - code)) << (2 * i);           // reverse complement: base i lands at string position n - 1 - i
+    }
+    const int seq_key_len = min_anchor < 6 ? min_anchor : 6;
+    for (uint32_t h = so[1]; h < so[2]; ++h) {
+        const Hit& bh = hits[h];
+        if (bh.ref_id == 0 || (int32_t)bh.ref_id > g.n_contigs) continue;
+        const int ref_len = (int)g_len(g, bh.ref_id);
+        if (ref_len <= 0) continue;                               // no FASTA record for the contig (rt.get_seq == NULL)
+        int lb, rb;
+        if (hit_anti(bh)) { lb = bh.right - min_anchor; if (lb < 0) lb = 0; rb = lb + MX_STRETCH; if (rb > ref_len - 2) rb = ref_len - 2; }
+        else { rb = bh.left + min_anchor; if (rb > ref_len - 2) rb = ref_len - 2; lb = rb - MX_STRETCH; if (lb < 0) lb = 0; }
+        if (rb - lb < 2 * seq_key_len) continue;
+        emit((int)(h - so[1]), bh.ref_id, lb, rb, hit_anti(bh) ? rev : fwd, n);
+    }
+}
+
+// the extension-table entries of one string (store_read_extensions(extensions, 5, 5, s, false), :240-360): seed i = bases [i, i + 10);
+// value as in read_entries above.  key = window << 20 | seed.
+template <class Emit>
+THJ_HD void mx_string_entries(u64 str, int len, u64 window, Emit emit) {
+    for (int i = 0; i + 10 <= len; ++i) {
+        const auto base = [&](int k) -> u64 { return (str >> (2 * (len - 1 - k))) & 3ull; };
+        u64 seed = 0;
+        for (int k = 0; k < 10; ++k) seed = (seed << 2) | base(i + k);
+        int rl = len - 10 - i; if (rl > 14) rl = 14;
+        u64 r = 0;
+        for (int k = 0; k < rl; ++k) r = (r << 2) | base(i + 10 + k);
+        const int ll = i < 14 ? i : 14;
+        u64 l = 0;
+        for (int k = i - ll; k < i; ++k) l = (l << 2) | base(k);
+        emit(window << 20 | seed, (l & 0x0FFFFFFFull) | ((u64)ll << 28) | ((r & 0x0FFFFFFFull) << 32) | ((u64)rl << 60));
+    }
+}
+
+// the window's table: entries of all windows sorted by key; extendable_junction against the entries of `window` only
+struct MxTable { const u64* keys; const u64* vals; int64_t n; };
+THJ_HD bool mx_extendable(const MxTable& t, u64 window, u64 up, u64 down) {
+    const u64 key = window << 20 | ((up & 0x3FFull) << 10) | (down >> 54);
+    up >>= 10; down <<= 10;
+    int64_t lo = 0, hi = t.n;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (t.keys[mid] < key) lo = mid + 1; else hi = mid; }
+    for (int64_t i = lo; i < t.n && t.keys[i] == key; ++i) {
+        const u64 v = t.vals[i];
+        const int ln = (int)((v >> 28) & 15), rl = (int)(v >> 60);
+        if (ln >= 7 && (uint32_t)(v & 0x0FFFFFFFull) == (uint32_t)(up & ((1ull << (2 * ln)) - 1ull))) return true;
+        if (rl >= 7 && (uint32_t)((v >> 32) & 0x0FFFFFFFull) == (uint32_t)(down >> (2 * (32 - rl)))) return true;
+    }
+    return false;
+}
+
+// word j of the window's four site bitmaps (bit b = contig position (w0 + j) * 64 + b, w0 = left / 64): dinucleotides starting at
+// positions [left, right - 2] (i <= to = seg_len - 2, :2171-2175); N reads as A; library-type skips as for a sense window (:2112-2138)
+struct MxSites { u64 fd, ra, fa, rd; };
+THJ_HD MxSites mx_site_word(const Genome& g, uint32_t ref_id, int32_t left, int32_t right, int library_type, int side, int j) {
+    const int64_t p0 = ((int64_t)(left >> 6) + j) * 64;
+    const Planes a = g_fetch(g, ref_id, p0), b = g_fetch(g, ref_id, p0 + 1);
+    const u64 lo0 = a.lo & ~a.nm, hi0 = a.hi & ~a.nm, lo1 = b.lo & ~b.nm, hi1 = b.hi & ~b.nm;
+    u64 valid = ~0ull;
+    if (p0 < left) valid &= ~below_mask((int64_t)left - p0);
+    valid &= below_mask((int64_t)right - 1 - p0);                // positions <= right - 2
+    bool skip_fwd = false, skip_rev = false;
+    if (library_type == 2) { if (side == 1) skip_fwd = true; else if (side == 2) skip_rev = true; }
+    if (library_type == 3) { if (side == 1) skip_rev = true; else if (side == 2) skip_fwd = true; }
+    MxSites s;
+    s.fd = skip_fwd ? 0ull : (~lo0 & hi0 & lo1 & hi1 & valid);   // GT
+    s.ra = skip_rev ? 0ull : (lo0 & ~hi0 & lo1 & hi1 & valid);   // CT
+    s.fa = skip_fwd ? 0ull : (~lo0 & ~hi0 & ~lo1 & hi1 & valid); // AG
+    s.rd = skip_rev ? 0ull : (~lo0 & ~hi0 & lo1 & ~hi1 & valid); // AC
+    return s;
+}
+
+// RecordExtendableJuncs::record for one left site lp of the window against its right-site words rs[0 .. n_words) (word 0 = contig word w0);
+// the words within reach are shared out over the lanes as in pair_site above
+template <class Sink, class Scan = OneLane>
+THJ_HD unsigned int mx_pair_site(const Genome& g, const MxTable& t, u64 window, uint32_t ref_id, int64_t len, const u64* rs, int64_t w0, int n_words, int antisense,
+                                 int min_intron, int64_t lp, Sink& ev, int lane = 0, int n_lanes = 1, Scan scan = Scan()) {
+    unsigned int found = 0;
+    u64 lf = 0, lrv = 0;
+    if (lp > 32 && lp < len) { lf = mer32(g, ref_id, lp - 32); lrv = rc32(lf); }
+    const int64_t q0 = lp + min_intron, q1 = lp + MX_STRETCH;
+    int64_t w_end = (q1 + 63) >> 6;
+    if (w_end > w0 + n_words) w_end = w0 + n_words;
+    uint32_t base = 0;
+    for (int64_t wa = q0 >> 6; wa < w_end; wa += n_lanes) {
+        const int64_t rw = wa + lane;
+        const int64_t p0 = rw * 64;
+        u64 rb = (rw < w_end && rw >= w0) ? (rs[rw - w0] & ~below_mask(q0 - p0) & below_mask(q1 - p0)) : 0ull;
+        int total = 0;
+        uint32_t rank = base + (uint32_t)scan(__builtin_popcountll(rb), total);
+        base += (uint32_t)total;
+        while (rb) {
+            const int c = __builtin_ctzll(rb);
+            rb &= rb - 1;
+            const int64_t rp = p0 + c;
+            u64 rf = 0, rrv = 0;
+            if (rp + 2 + 32 < len) { rf = mer32(g, ref_id, rp + 2); rrv = rc32(rf); }
+            if (mx_extendable(t, window, lf, rf) || mx_extendable(t, window, rrv, lrv)) {
+                ev.cov_junction(ref_id, (uint32_t)(lp - 1), (uint32_t)(rp + 2), antisense != 0, rank);
+                ++found;
+            }
+            ++rank;
+        }
+    }
+    return found;
+}
+
 }  // namespace cov
 }  // namespace thj
 #endif

@@ -114,6 +114,73 @@ __global__ __launch_bounds__(256) void k_pair(Genome g, Layout L, ExtTable et, c
     }
 }
 
+
+// ---- microexon search (thj_cov_core.h): candidates of a batch's reads, table entries of the windows' strings, one wave per window
+__global__ __launch_bounds__(256) void k_mx_cands(Genome g, const Hit* hits, const uint32_t* seg_off, const u64* planes, const uint16_t* read_len, int n_reads, int nseg, int W,
+                                                  uint32_t ordinal_base, int seg_len, int min_anchor, int side, MxCand* out, unsigned long long* count, unsigned long long cap) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    mx_read_candidates(g, hits, seg_off + (size_t)r * nseg, nseg, planes + (size_t)r * 3 * W, W, (int)read_len[r], seg_len, min_anchor,
+                       [&](int rank, uint32_t ref, int lb, int rb, u64 str, int n) {
+                           const unsigned long long at = atomicAdd(count, 1ull);
+                           if (out && at < cap) out[at] = MxCand{ordinal_base + (uint32_t)r, (uint16_t)rank, (uint8_t)side, (uint8_t)n, ref, lb, rb, 0u, str};
+                       });
+}
+__global__ __launch_bounds__(256) void k_mx_entries(const u64* strs, const uint8_t* str_len, const uint32_t* str_window, const uint32_t* ent_off, int64_t n_strs, u64* keys, u64* vals) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_strs) return;
+    uint32_t at = ent_off[i];
+    mx_string_entries(strs[i], (int)str_len[i], (u64)str_window[i], [&](u64 k, u64 v) { keys[at] = k; vals[at] = v; ++at; });
+}
+__global__ void k_cut_heads(const u64* keys, const uint32_t* skips, int64_t n, uint32_t* flags) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1] || skips[i] != skips[i - 1]) ? 1u : 0u;
+}
+__global__ void k_cut_compact(const u64* keys, const uint32_t* flags, const uint32_t* pos, int64_t n, u64* out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n && flags[i]) out[pos[i]] = keys[i];
+}
+struct MxWin { uint32_t ref_id; int32_t left, right; int32_t side; };
+// item = one word of one window's site bitmaps; the window of an item: the last w with win_off[w] <= item
+__device__ __forceinline__ int64_t mx_item_window(const uint32_t* win_off, int64_t n_wins, uint32_t item) {
+    int64_t lo = 0, hi = n_wins;
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (win_off[mid] <= item) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(256) void k_mx_sites(Genome g, const MxWin* wins, const uint32_t* win_off, int64_t n_wins, int64_t n_items, int library_type, u64* fd, u64* ra, u64* fa, u64* rd) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const int64_t wi = mx_item_window(win_off, n_wins, (uint32_t)i);
+    const MxWin w = wins[wi];
+    MxSites s{0, 0, 0, 0};
+    if (!(w.left < 0 || w.right >= g_len(g, w.ref_id) - 1)) s = mx_site_word(g, w.ref_id, w.left, w.right, library_type, w.side, (int)(i - win_off[wi]));      // :2154
+    fd[i] = s.fd; ra[i] = s.ra; fa[i] = s.fa; rd[i] = s.rd;
+}
+// one wave per bitmap word: the left sites in it (a handful), each against the right sites of its window within reach
+__global__ __launch_bounds__(256) void k_mx_pair(Genome g, MxTable t, const MxWin* wins, const uint32_t* win_off, int64_t n_wins, int64_t n_items, int min_intron,
+                                                 const u64* fd, const u64* ra, const u64* fa, const u64* rd,
+                                                 u64* jkeys, uint32_t* jskips, unsigned long long* n_found, unsigned long long jcap) {
+    const int lane = threadIdx.x & 63;
+    ListSink ev{g, jkeys, jskips, n_found, jcap};
+    for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < n_items; i += (int64_t)gridDim.x * 4) {
+        const u64 a = fd[i], b = ra[i];
+        if (!(a | b)) continue;
+        const int64_t wi = mx_item_window(win_off, n_wins, (uint32_t)i);
+        const MxWin w = wins[wi];
+        const int64_t len = g_len(g, w.ref_id), w0 = w.left >> 6;
+        const int n_words = (int)(win_off[wi + 1] - win_off[wi]);
+        const int j = (int)(i - win_off[wi]);
+        for (int o = 0; o < 2; ++o) {                                      // record(fwd_donors, fwd_acceptors, false), then (rev_acceptors, rev_donors, true)
+            u64 bits = o ? b : a;
+            while (bits) {
+                const int bb = __builtin_ctzll(bits);
+                bits &= bits - 1;
+                mx_pair_site(g, t, (u64)wi, w.ref_id, len, (o ? rd : fa) + win_off[wi], w0, n_words, o, min_intron, (w0 + j) * 64 + bb, ev, lane, 64, WaveScan());
+            }
+        }
+    }
+}
+
 }  // namespace cov_k
 
 // ------------------------------------------------------------------------------------------------ C ABI
@@ -304,6 +371,52 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
     return THJ_OK;
 }
 
+// the (junction key, skip count) list of a pairing pass -> the pass's junction set; more than max_juncs: the set ordered by skip count
+// keeps its smallest elements (segment_juncs.cpp:1611-1621): sort by (skip count, junction), take the first max_juncs
+static int cov_cut_and_merge(thj_ctx* c, int64_t n, int64_t max_juncs, int64_t* n_found) {
+    const u64* keys = c->d_cov_jkey;
+    int64_t take = n;
+    if (take > max_juncs) {
+        if (n >= (1ll << 31)) { thj_set_error("more than 2^31 junction candidates"); return THJ_EOVERFLOW; }
+        // stable LSD order: by junction key, then by skip count
+        size_t b1 = 0, b2 = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, b1, c->d_cov_jkey, c->d_cov_jkey2, c->d_cov_jskip, c->d_cov_jskip2, (int)n, 0, 64, c->stream);
+        hipcub::DeviceRadixSort::SortPairs(nullptr, b2, c->d_cov_jskip2, c->d_cov_jskip, c->d_cov_jkey2, c->d_cov_jkey, (int)n, 0, 32, c->stream);
+        const size_t need = b1 > b2 ? b1 : b2;
+        if (need > c->sort_tmp_bytes) { hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+        size_t bytes = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_cov_jkey, c->d_cov_jkey2, c->d_cov_jskip, c->d_cov_jskip2, (int)n, 0, 64, c->stream));
+        bytes = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_cov_jskip2, c->d_cov_jskip, c->d_cov_jkey2, c->d_cov_jkey, (int)n, 0, 32, c->stream));
+        // the set holds DISTINCT (skip count, junction) elements: overlapping microexon windows find the same pair more than once (the
+        // coverage search never does).  Heads of runs -> positions -> compacted keys.
+        uint32_t* flags = c->d_cov_jskip2;                      // free again after the second sort
+        uint32_t* posn = (uint32_t*)c->d_cov_jkey2;             // n * 8 bytes: room for n positions
+        hipLaunchKernelGGL(cov_k::k_cut_heads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64*)c->d_cov_jkey, (const uint32_t*)c->d_cov_jskip, n, flags);
+        size_t b3 = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, b3, flags, posn, (int)n, c->stream);
+        if (b3 > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0; HIPCHK(hipMalloc(&c->d_sort_tmp, b3)); c->sort_tmp_bytes = b3; }
+        bytes = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, bytes, flags, posn, (int)n, c->stream));
+        uint32_t last_pos = 0, last_flag = 0;
+        HIPCHK(hipMemcpyAsync(&last_pos, posn + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        const int64_t n_unique = (int64_t)last_pos + last_flag;
+        // compact in place is not safe (a thread may overwrite what another still reads): through the skip buffer's sibling, 8 bytes per key
+        u64* packed = nullptr;
+        HIPCHK(hipMalloc(&packed, (size_t)(n_unique + 1) * 8));
+        hipLaunchKernelGGL(cov_k::k_cut_compact, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, (const u64*)c->d_cov_jkey, (const uint32_t*)flags, (const uint32_t*)posn, n, packed);
+        take = n_unique < max_juncs ? n_unique : max_juncs;
+        HIPCHK(hipMemcpyAsync(c->d_cov_jkey, packed, (size_t)take * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(packed);
+    }
+    if (n_found) *n_found = take;
+    if (take > 0) return thj_segjuncs_merge_keys_async(c, 0, (const uint64_t*)keys, take);
+    return THJ_OK;
+}
+
 extern "C" int thj_covsearch_finish(thj_ctx* c, int64_t max_cov_juncs, int64_t* n_found) {
     // The junctions of the pairing pass enter the pass's junction set here.  When there are more than max_cov_juncs
     // (segment_juncs.cpp:56, :1611-1621) the set ordered by skip count keeps its smallest elements: sort by (skip count,
@@ -326,29 +439,147 @@ extern "C" int thj_covsearch_finish(thj_ctx* c, int64_t max_cov_juncs, int64_t* 
         if ((rc = cov_launch_pair(c))) return rc;
     }
     c->cov_pending = false;
-    const u64* keys = c->d_cov_jkey;
-    int64_t take = (int64_t)n;
-    if (take > max_cov_juncs) {
-        if (n >= (1ull << 31)) { thj_set_error("more than 2^31 coverage junction candidates"); return THJ_EOVERFLOW; }
-        // stable LSD order: by junction key, then by skip count
-        size_t b1 = 0, b2 = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, b1, c->d_cov_jkey, c->d_cov_jkey2, c->d_cov_jskip, c->d_cov_jskip2, (int)n, 0, 64, c->stream);
-        hipcub::DeviceRadixSort::SortPairs(nullptr, b2, c->d_cov_jskip2, c->d_cov_jskip, c->d_cov_jkey2, c->d_cov_jkey, (int)n, 0, 32, c->stream);
-        const size_t need = b1 > b2 ? b1 : b2;
-        if (need > c->sort_tmp_bytes) { hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
-        size_t bytes = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_cov_jkey, c->d_cov_jkey2, c->d_cov_jskip, c->d_cov_jskip2, (int)n, 0, 64, c->stream));
-        bytes = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_cov_jskip2, c->d_cov_jskip, c->d_cov_jkey2, c->d_cov_jkey, (int)n, 0, 32, c->stream));
-        take = max_cov_juncs;
-    }
-    if (n_found) *n_found = take;
-    if (take > 0) return thj_segjuncs_merge_keys_async(c, 0, (const uint64_t*)keys, take);
+    return cov_cut_and_merge(c, (int64_t)n, max_cov_juncs, n_found);
+}
+
+
+// ------------------------------------------------------------------------------------------------ microexon search
+static_assert(sizeof(thj_mx_cand) == sizeof(thj::cov::MxCand) && sizeof(thj_mx_window) == sizeof(cov_k::MxWin), "microexon record layouts");
+
+extern "C" int thj_microexon_reset_async(thj_ctx* c) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    c->n_mx_cand = 0;
     return THJ_OK;
+}
+extern "C" int thj_microexon_collect(thj_ctx* c, const thj_params* p, const thj_seg_batch* db, int32_t read_side) {
+    if (!c || !p || !db) { thj_set_error("thj_microexon_collect: null argument"); return THJ_EINVAL; }
+    if (p->segment_length < 10 || p->segment_length > 32) { thj_set_error("microexon search: segment_length %d unsupported (10..32: the first segment is kept as one 64-bit string)", p->segment_length); return THJ_EINVAL; }
+    if (db->words_per_plane < 1) { thj_set_error("bad batch"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    if (db->n_reads == 0 || db->nseg < 2) return THJ_OK;
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    unsigned long long* cnt = c->d_cov_found + 1;
+    const unsigned grid = (unsigned)((db->n_reads + 255) / 256);
+    // count, make room, fill (an opt-in mode the reference runs on one thread: a round trip per batch is in the noise)
+    HIPCHK(hipMemsetAsync(cnt, 0, 8, c->stream));
+    hipLaunchKernelGGL(cov_k::k_mx_cands, dim3(grid), dim3(256), 0, c->stream, g, (const Hit*)db->hits, db->seg_off, (const u64*)db->read_planes, db->read_len, db->n_reads, db->nseg,
+                       db->words_per_plane, db->ordinal_base, p->segment_length, p->min_anchor_len, read_side, (thj::cov::MxCand*)nullptr, cnt, 0ull);
+    unsigned long long n = 0;
+    HIPCHK(hipMemcpyAsync(&n, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n == 0) return THJ_OK;
+    if (c->n_mx_cand + (int64_t)n > c->mx_cand_cap) {
+        const int64_t ncap = (c->n_mx_cand + (int64_t)n) * 2 + 1024;
+        void* nb = nullptr;
+        HIPCHK(hipMalloc(&nb, (size_t)ncap * sizeof(thj_mx_cand)));
+        if (c->n_mx_cand) HIPCHK(hipMemcpy(nb, c->d_mx_cand, (size_t)c->n_mx_cand * sizeof(thj_mx_cand), hipMemcpyDeviceToDevice));
+        hipFree(c->d_mx_cand); c->d_mx_cand = nb; c->mx_cand_cap = ncap;
+    }
+    HIPCHK(hipMemsetAsync(cnt, 0, 8, c->stream));
+    hipLaunchKernelGGL(cov_k::k_mx_cands, dim3(grid), dim3(256), 0, c->stream, g, (const Hit*)db->hits, db->seg_off, (const u64*)db->read_planes, db->read_len, db->n_reads, db->nseg,
+                       db->words_per_plane, db->ordinal_base, p->segment_length, p->min_anchor_len, read_side, (thj::cov::MxCand*)c->d_mx_cand + c->n_mx_cand, cnt, n);
+    HIPCHK(hipGetLastError());
+    c->n_mx_cand += (int64_t)n;
+    return THJ_OK;
+}
+extern "C" int thj_microexon_candidates(thj_ctx* c, thj_mx_cand** out, int64_t* n_out) {
+    if (!c || !out || !n_out) { thj_set_error("thj_microexon_candidates: null argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    *out = nullptr; *n_out = c->n_mx_cand;
+    if (!c->n_mx_cand) return THJ_OK;
+    thj_mx_cand* h = (thj_mx_cand*)malloc((size_t)c->n_mx_cand * sizeof(thj_mx_cand));
+    if (!h) { thj_set_error("out of memory"); return THJ_ENOMEM; }
+    HIPCHK(hipMemcpyAsync(h, c->d_mx_cand, (size_t)c->n_mx_cand * sizeof(thj_mx_cand), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = h;
+    return THJ_OK;
+}
+extern "C" int thj_microexon_run(thj_ctx* c, const thj_mx_window* windows, int64_t n_windows, const uint64_t* strs, const uint8_t* str_len, const uint32_t* str_window,
+                                 int64_t n_strs, int32_t min_intron, int32_t library_type, int64_t max_juncs, int64_t* n_found) {
+    if (!c || n_windows < 0 || n_strs < 0 || (n_windows > 0 && !windows) || (n_strs > 0 && (!strs || !str_len || !str_window)) || max_juncs < 0 || min_intron < 1) {
+        thj_set_error("thj_microexon_run: bad argument"); return THJ_EINVAL; }
+    if (n_windows >= (1ll << 31) || n_strs >= (1ll << 28)) { thj_set_error("thj_microexon_run: too many windows / strings"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    if (n_found) *n_found = 0;
+    if (n_windows == 0) return THJ_OK;
+    if ((rc = maybe_grow_tables(c))) return rc;
+    // entries per string, their offsets (host: a prefix sum over a byte array)
+    std::vector<uint32_t> off((size_t)n_strs + 1, 0);
+    for (int64_t i = 0; i < n_strs; ++i) {
+        if (str_len[i] > 32 || str_window[i] >= (uint32_t)n_windows) { thj_set_error("thj_microexon_run: string %lld out of range", (long long)i); return THJ_EINVAL; }
+        off[(size_t)i + 1] = off[(size_t)i] + (str_len[i] >= 10 ? (uint32_t)str_len[i] - 9u : 0u);
+    }
+    const int64_t n_ent = off[(size_t)n_strs];
+    // the windows' site bitmaps: words [woff[w], woff[w + 1]) of four arrays
+    std::vector<uint32_t> woff((size_t)n_windows + 1, 0);
+    for (int64_t w = 0; w < n_windows; ++w) {
+        const int64_t nw = windows[w].right > windows[w].left ? thj::cov::mx_window_words(windows[w].left, windows[w].right) : 0;
+        if (nw < 0 || (int64_t)woff[(size_t)w] + nw >= (1ll << 32)) { thj_set_error("thj_microexon_run: windows too wide"); return THJ_EINVAL; }
+        woff[(size_t)w + 1] = woff[(size_t)w] + (uint32_t)nw;
+    }
+    const int64_t n_items = woff[(size_t)n_windows];
+    void *d_win = nullptr, *d_str = nullptr, *d_len = nullptr, *d_sw = nullptr, *d_off = nullptr, *d_k = nullptr, *d_v = nullptr, *d_k2 = nullptr, *d_v2 = nullptr, *d_woff = nullptr, *d_bm = nullptr;
+    auto cleanup = [&]() { hipFree(d_win); hipFree(d_str); hipFree(d_len); hipFree(d_sw); hipFree(d_off); hipFree(d_k); hipFree(d_v); hipFree(d_k2); hipFree(d_v2); hipFree(d_woff); hipFree(d_bm); };
+#define MX_HIP(e) do { hipError_t e__ = (e); if (e__ != hipSuccess) { thj_set_error("%s: %s", #e, hipGetErrorString(e__)); cleanup(); return THJ_EHIP; } } while (0)
+    MX_HIP(hipMalloc(&d_win, (size_t)n_windows * sizeof(thj_mx_window)));
+    MX_HIP(hipMalloc(&d_str, (size_t)(n_strs + 1) * 8)); MX_HIP(hipMalloc(&d_len, (size_t)n_strs + 1)); MX_HIP(hipMalloc(&d_sw, (size_t)(n_strs + 1) * 4)); MX_HIP(hipMalloc(&d_off, (size_t)(n_strs + 1) * 4));
+    MX_HIP(hipMalloc(&d_k, (size_t)(n_ent + 1) * 8)); MX_HIP(hipMalloc(&d_v, (size_t)(n_ent + 1) * 8)); MX_HIP(hipMalloc(&d_k2, (size_t)(n_ent + 1) * 8)); MX_HIP(hipMalloc(&d_v2, (size_t)(n_ent + 1) * 8));
+    MX_HIP(hipMalloc(&d_woff, (size_t)(n_windows + 1) * 4)); MX_HIP(hipMalloc(&d_bm, (size_t)(n_items + 1) * 8 * 4));
+    MX_HIP(hipMemcpyAsync(d_woff, woff.data(), (size_t)(n_windows + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    MX_HIP(hipMemcpyAsync(d_win, windows, (size_t)n_windows * sizeof(thj_mx_window), hipMemcpyHostToDevice, c->stream));
+    if (n_strs) {
+        MX_HIP(hipMemcpyAsync(d_str, strs, (size_t)n_strs * 8, hipMemcpyHostToDevice, c->stream));
+        MX_HIP(hipMemcpyAsync(d_len, str_len, (size_t)n_strs, hipMemcpyHostToDevice, c->stream));
+        MX_HIP(hipMemcpyAsync(d_sw, str_window, (size_t)n_strs * 4, hipMemcpyHostToDevice, c->stream));
+        MX_HIP(hipMemcpyAsync(d_off, off.data(), (size_t)(n_strs + 1) * 4, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(cov_k::k_mx_entries, dim3((unsigned)((n_strs + 255) / 256)), dim3(256), 0, c->stream, (const u64*)d_str, (const uint8_t*)d_len, (const uint32_t*)d_sw, (const uint32_t*)d_off, n_strs,
+                           (u64*)d_k, (u64*)d_v);
+    }
+    const u64* keys = (const u64*)d_k; const u64* vals = (const u64*)d_v;
+    if (n_ent > 1) {
+        int bits = 21; while (bits < 52 && (1ll << (bits - 20)) < n_windows) ++bits;
+        size_t need = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, need, (const u64*)d_k, (u64*)d_k2, (const u64*)d_v, (u64*)d_v2, (int)n_ent, 0, bits, c->stream);
+        if (need > c->sort_tmp_bytes) { MX_HIP(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0; MX_HIP(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+        size_t bytes = c->sort_tmp_bytes;
+        MX_HIP(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, (const u64*)d_k, (u64*)d_k2, (const u64*)d_v, (u64*)d_v2, (int)n_ent, 0, bits, c->stream));
+        keys = (const u64*)d_k2; vals = (const u64*)d_v2;
+    }
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    thj::cov::MxTable t{keys, vals, n_ent};
+    u64 *fd = (u64*)d_bm, *ra = fd + n_items, *fa = ra + n_items, *rd = fa + n_items;
+    if (n_items) hipLaunchKernelGGL(cov_k::k_mx_sites, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, c->stream, g, (const cov_k::MxWin*)d_win, (const uint32_t*)d_woff, n_windows, n_items,
+                                    (int)library_type, fd, ra, fa, rd);
+    unsigned long long n = 0;
+    for (;;) {
+        MX_HIP(hipMemsetAsync(c->d_cov_found, 0, 8, c->stream));
+        const int64_t blocks_wanted = (n_items + 3) / 4;
+        const unsigned grid = (unsigned)(blocks_wanted < 1 ? 1 : blocks_wanted < 65536 ? blocks_wanted : 65536);
+        hipLaunchKernelGGL(cov_k::k_mx_pair, dim3(grid), dim3(256), 0, c->stream, g, t, (const cov_k::MxWin*)d_win, (const uint32_t*)d_woff, n_windows, n_items, (int)min_intron,
+                           (const u64*)fd, (const u64*)ra, (const u64*)fa, (const u64*)rd, c->d_cov_jkey, c->d_cov_jskip, c->d_cov_found, (unsigned long long)c->cov_jcap);
+        MX_HIP(hipMemcpyAsync(&n, c->d_cov_found, 8, hipMemcpyDeviceToHost, c->stream));
+        MX_HIP(hipStreamSynchronize(c->stream));
+        if ((int64_t)n <= c->cov_jcap) break;
+        hipFree(c->d_cov_jkey); hipFree(c->d_cov_jskip); hipFree(c->d_cov_jkey2); hipFree(c->d_cov_jskip2);
+        c->d_cov_jkey = c->d_cov_jkey2 = nullptr; c->d_cov_jskip = c->d_cov_jskip2 = nullptr;
+        c->cov_jcap = (int64_t)n + (int64_t)n / 8 + 1024;
+        MX_HIP(hipMalloc(&c->d_cov_jkey, (size_t)c->cov_jcap * 8)); MX_HIP(hipMalloc(&c->d_cov_jskip, (size_t)c->cov_jcap * 4));
+        MX_HIP(hipMalloc(&c->d_cov_jkey2, (size_t)c->cov_jcap * 8)); MX_HIP(hipMalloc(&c->d_cov_jskip2, (size_t)c->cov_jcap * 4));
+    }
+    rc = cov_cut_and_merge(c, (int64_t)n, max_juncs, n_found);
+    hipStreamSynchronize(c->stream);
+    cleanup();
+#undef MX_HIP
+    return rc;
 }
 
 static void cov_free(thj_ctx* c) {
     hipFree(c->d_cov); hipFree(c->d_cov_size); hipFree(c->d_ext_off); hipFree(c->d_cov_found); hipFree(c->d_cov_filter);
     hipFree(c->d_cov_jkey); hipFree(c->d_cov_jskip); hipFree(c->d_cov_jkey2); hipFree(c->d_cov_jskip2);
     hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
+    hipFree(c->d_mx_cand);
 }

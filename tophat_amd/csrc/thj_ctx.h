@@ -69,6 +69,7 @@ struct thj_ctx {
     u64* d_cov_filter = nullptr; int64_t cov_filter_bytes = 0;          // Bloom filter over the extension table
     u64* d_cov_jkey = nullptr; uint32_t* d_cov_jskip = nullptr; int64_t cov_jcap = 0;      // junctions found: key, skip count
     u64* d_cov_jkey2 = nullptr; uint32_t* d_cov_jskip2 = nullptr;                           // ... sort buffers for the cut
+    void* d_mx_cand = nullptr; int64_t n_mx_cand = 0, mx_cand_cap = 0;        // microexon search: candidate windows of the pass's reads
     u64 cov_filter_mask = 0; int32_t cov_min_intron = 0, cov_max_intron = 0; bool cov_pending = false;
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;

@@ -361,6 +361,34 @@ class Context:
         _check(self.lib, self.lib.thj_covsearch_finish(self._ctx, C.c_int64(max_cov_juncs), C.byref(found)), "thj_covsearch_finish")
         return found.value
 
+    # ---- microexon search (thj_microexon_*): candidates on the device, window merge on the host, per-window pairing on the device
+    def microexon_reset(self):
+        _check(self.lib, self.lib.thj_microexon_reset_async(self._ctx), "thj_microexon_reset_async")
+
+    def microexon_collect(self, p: Params, batch, read_side: int):
+        arg = C.byref(batch) if isinstance(batch, CSegBatch) else batch
+        cp = p.as_ctypes()
+        _check(self.lib, self.lib.thj_microexon_collect(self._ctx, C.byref(cp), arg, int(read_side)), "thj_microexon_collect")
+
+    def microexon_candidates(self) -> np.ndarray:
+        ptr, n = C.c_void_p(), C.c_int64()
+        _check(self.lib, self.lib.thj_microexon_candidates(self._ctx, C.byref(ptr), C.byref(n)), "thj_microexon_candidates")
+        a = np.zeros(0, dtype=MX_CAND_DTYPE)
+        if n.value:
+            a = np.frombuffer((C.c_char * (n.value * MX_CAND_DTYPE.itemsize)).from_address(ptr.value), dtype=MX_CAND_DTYPE).copy()
+            C.CDLL(None).free(ptr)
+        return a
+
+    def microexon_run(self, windows: np.ndarray, strs: np.ndarray, str_len: np.ndarray, str_window: np.ndarray, min_intron: int = 50, library_type: int = 0,
+                      max_juncs: int = 5000000) -> int:
+        w = np.ascontiguousarray(windows, dtype=MX_WINDOW_DTYPE)
+        a, b, c_ = np.ascontiguousarray(strs, dtype=np.uint64), np.ascontiguousarray(str_len, dtype=np.uint8), np.ascontiguousarray(str_window, dtype=np.uint32)
+        found = C.c_int64()
+        _check(self.lib, self.lib.thj_microexon_run(self._ctx, C.c_void_p(w.ctypes.data), C.c_int64(len(w)), C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data),
+                                                    C.c_void_p(c_.ctypes.data), C.c_int64(len(a)), int(min_intron), int(library_type), C.c_int64(max_juncs), C.byref(found)),
+               "thj_microexon_run")
+        return found.value
+
     def segjuncs_with_coverage_search(self, runs: Sequence[Tuple[Params, object]], ium_reads: Sequence[str], min_cov_length: int,
                                       min_intron: int = 50, max_intron: int = 20000, max_cov_juncs: int = 5000000):
         """One segment_juncs pass with the coverage search (segment_juncs.cpp:4268-4543) on top of the segment search:
@@ -633,6 +661,7 @@ ABI_SYMBOLS += ["thj_bgzf_inflate", "thj_ingest_seg_batch", "thj_ingest_span_hit
 ABI_SYMBOLS += ["thj_juncbed_configure", "thj_juncbed_reset_async", "thj_juncbed_add_span_async", "thj_juncbed_add_records",
                 "thj_juncbed_finish", "thj_juncbed_download"]
 ABI_SYMBOLS += ["thj_md_string"]
+ABI_SYMBOLS += ["thj_microexon_reset_async", "thj_microexon_collect", "thj_microexon_candidates", "thj_microexon_run"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
                 "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
@@ -684,6 +713,56 @@ def _juncbed_methods():
 
 
 _juncbed_methods()
+
+
+MX_CAND_DTYPE = np.dtype([("ordinal", "<u4"), ("rank", "<u2"), ("side", "u1"), ("len", "u1"), ("ref_id", "<u4"), ("left", "<i4"), ("right", "<i4"),
+                          ("reserved", "<u4"), ("str", "<u8")])
+MX_WINDOW_DTYPE = np.dtype([("ref_id", "<u4"), ("left", "<i4"), ("right", "<i4"), ("side", "<i4")])
+assert MX_CAND_DTYPE.itemsize == 32 and MX_WINDOW_DTYPE.itemsize == 16
+
+
+def microexon_merge_windows(cands: np.ndarray):
+    """add_to_microexon_windows (segment_juncs.cpp:3675-3735) over the candidates in visiting order -- the Python mirror of
+    csrc/host/thj_mx_host.h (the executables use that one) -> (windows, strs, str_len, str_window) for Context.microexon_run"""
+    import bisect
+    order = np.lexsort((cands["rank"], cands["ordinal"], cands["side"]))
+    keys, vals = [], []                                   # sorted (ref, left, right) -> (side, [candidate indices])
+
+    def overlap(ll, lr, rl, rr):
+        return (rl <= ll < rr) or (rl < lr < rr) or (ll <= rl < lr) or (ll < rr < lr)
+    for ci in order:
+        c = cands[ci]
+        ref, lbd, rbd, side = int(c["ref_id"]), int(c["left"]), int(c["right"]), int(c["side"])
+        key = (ref, lbd, rbd)
+        lb = bisect.bisect_left(keys, key)
+        ub = bisect.bisect_left(keys, (ref, rbd, rbd + 1))
+        if lb == len(keys):
+            keys.append(key); vals.append((side, [int(ci)]))
+            continue
+        first, last, new_vec, have = None, ub, [], False
+        for k in range(lb, ub):
+            if overlap(keys[k][1], keys[k][2], lbd, rbd):
+                have = True
+                if first is None:
+                    first = k
+                key = (ref, min(keys[k][1], lbd), max(keys[k][2], rbd))
+                new_vec += vals[k][1]
+            elif first is not None:
+                last = k
+        if first is not None:
+            del keys[first:last]; del vals[first:last]
+        new_vec = new_vec + [int(ci)] if have else [int(ci)]
+        at = bisect.bisect_left(keys, key)
+        if at < len(keys) and keys[at] == key:
+            continue                                       # map::insert leaves an existing key alone
+        keys.insert(at, key); vals.insert(at, (side, new_vec))
+    windows = np.zeros(len(keys), dtype=MX_WINDOW_DTYPE)
+    strs, lens, wins = [], [], []
+    for w, (k, (side, idx)) in enumerate(zip(keys, vals)):
+        windows[w] = (k[0], k[1], k[2], side)
+        for ci in idx:
+            strs.append(int(cands[ci]["str"])); lens.append(int(cands[ci]["len"])); wins.append(w)
+    return windows, np.array(strs, dtype=np.uint64), np.array(lens, dtype=np.uint8), np.array(wins, dtype=np.uint32)
 
 
 def aln_array_from_tuples(recs) -> np.ndarray:
