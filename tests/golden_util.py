@@ -7,7 +7,7 @@ from tophat_amd.params import LIBRARY_TYPES, Params, READ_LEFT, READ_RIGHT
 from tophat_amd.samtext import parse_header, parse_sam_hits, parse_spliced_sam_hits, read_fasta, read_fastq
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-_ALL = sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)))
+_ALL = sorted(d for d in os.listdir(GOLD) if os.path.isfile(os.path.join(GOLD, d, "options.txt")))      # (tests/golden/ref_samtools holds vectors, not a case)
 FUSION_SPAN_CASES = [d for d in _ALL if "fusion_span" in d]     # the whole --fusion-search path incl. long_spanning_reads
 CASES = [d for d in _ALL if d not in FUSION_SPAN_CASES]
 
