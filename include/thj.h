@@ -486,6 +486,35 @@ int thj_ingest_span_batch(thj_ctx* ctx, const thj_params* p, int32_t nseg, const
                           uint8_t** reads_infl, int64_t* reads_infl_bytes, uint32_t** row_loc);
 int thj_span_batch_attach_reads(thj_ctx* ctx, thj_span_batch* batch, int32_t words_per_plane, int32_t qual_stride, const uint64_t* planes,
                                 const uint16_t* lens, const uint8_t* quals);
+/* reads_infl, reads_infl_bytes and row_loc may all three be NULL: the read records then stay on the device with the batch only
+ * (thj_span_bam_encode reads them there).  A caller that needs the host copy after all asks for it here (same buffers as above). */
+int thj_span_batch_reads_host(thj_ctx* ctx, const thj_span_batch* batch, uint8_t** reads_infl, int64_t* reads_infl_bytes, uint32_t** row_loc);
+
+/* ---------------------------------------------------------------- the BAM writer's device side (the output format)
+ * long_spanning_reads prints every alignment with print_bamhit (bwt_map.cpp:1888-2093: GBamRecord with the mate fields "*", 0, 0,
+ * MAPQ 255 and the tags AS XM XO XG MD NM [XS], add_aux common.cpp:1092-1173) through bam_write1 -> bgzf_write -> deflate_block
+ * (samtools-0.1.18 bam.c:207-236, bgzf.c:287-349, :587-623).  Here the records are built and deflated where the alignments already
+ * are; the host decides where BGZF members end (bam_write1's bgzf_flush_try rule needs record sizes only), wraps the deflated
+ * members in their 18 + 8 bytes and writes them.
+ *
+ * thj_span_bam_encode: after thj_span_finish.  The pass's alignments (thj_span_finish's count n, thj_span_download's order) as BAM
+ *   records, block_size fields included, back to back in a buffer the context keeps until the next call.  batch: the pass's batch
+ *   from thj_ingest_span_batch (it holds the reads' own BAM records, where names, bases and qualities are copied from);
+ *   tid_of_ref[ref_id - 1] = the contig's index in the output header; rec_size[i] / rec_id[i] (HOST, n entries) = byte count and
+ *   read id (atol of the name) of record i; *total_bytes = the stream's length.  THJ_EFALLBACK: a record of the pass needs the host
+ *   encoder (a fusion alignment: two records with XF:Z; an MD string the device record does not hold; a read whose length differs
+ *   from the alignment's) or the batch has no read records -- nothing was encoded, thj_span_download still works.
+ * thj_bgzf_deflate: the context's stream cut at member_end[k] (exclusive, rising; every member 1..65536 bytes).  comp (HOST,
+ *   comp_cap bytes) receives the members' raw DEFLATE streams back to back, comp_len[k] bytes each; crc[k] = CRC-32 of member k's
+ *   bytes.  One dynamic-Huffman block per member.  THJ_EFALLBACK: a member's DEFLATE stream exceeds 65536 - 26 bytes
+ *   (incompressible data; bgzf.c then shrinks the member, which moves every later cut -- the caller replays on the host).
+ * thj_bam_stream_upload / _download: set / fetch the context's stream (other producers; the host fallback; tests). */
+int thj_span_bam_encode(thj_ctx* ctx, const thj_span_batch* batch, const int32_t* tid_of_ref, int32_t n_ref, uint32_t* rec_size, int64_t* rec_id,
+                        int64_t* total_bytes);
+int thj_bgzf_deflate(thj_ctx* ctx, int64_t n_members, const int64_t* member_end, uint8_t* comp, int64_t comp_cap, uint32_t* comp_len, uint32_t* crc,
+                     int64_t* comp_bytes);
+int thj_bam_stream_upload(thj_ctx* ctx, const uint8_t* bytes, int64_t n);
+int thj_bam_stream_download(thj_ctx* ctx, uint8_t* bytes);
 
 /* ---------------------------------------------------------------- junction consensus
  * What tophat_reports does with the reported alignments to get junctions.bed: every REF_SKIP is a junction observation

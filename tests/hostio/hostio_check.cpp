@@ -12,8 +12,13 @@ int main(int argc, char** argv) {
     if (mode == "write" && argc >= 5) {
         // hostio_check write <out.bam> <n_records> <batch> [planned]
         // planned: the batches go through BamWriter::plan / compress / commit (all planned first, deflated in reverse order, committed in order)
-        const bool fail = argc >= 6 && std::string(argv[5]) == "planned-fail";      // as planned, and a batch in the middle reports a member that did not fit
-        const bool planned = fail || (argc >= 6 && std::string(argv[5]) == "planned");
+        // planned-device[-fail]: as planned, and every other batch arrives the way the device path delivers it -- members deflated elsewhere
+        // (here: zlib), cut by plan_cuts_closed, no record bytes (BamWriter::plan_device / wrap_member)
+        const std::string variant = argc >= 6 ? argv[5] : "";
+        const bool device = variant == "planned-device" || variant == "planned-device-fail";
+        const bool fail = variant == "planned-fail" || variant == "planned-device-fail";      // a batch in the middle reports a member that did not fit
+        const bool planned = fail || device || variant == "planned";
+        size_t n_batches = 0;
         std::vector<BamWriter::Prepared> prepared; std::vector<uint8_t> carry;
         const size_t n = (size_t)atoll(argv[3]), batch = (size_t)atoll(argv[4]);
         RefTable rt;
@@ -37,6 +42,25 @@ int main(int argc, char** argv) {
                     e.size.push_back((uint32_t)(e.bytes.size() - before)); e.rid.push_back(atol(r.name.c_str()));
                 }
                 prepared.emplace_back();
+                if (device && (n_batches++ & 1)) {
+                    BamWriter::Prepared& p = prepared.back();
+                    p.device = true;
+                    BamWriter::plan_cuts_closed(e.size, p.cuts);
+                    p.members.resize(p.cuts.size());
+                    for (size_t m = 0; m < p.cuts.size(); ++m) {
+                        const size_t a = m ? p.cuts[m - 1] : 0, len = p.cuts[m] - a;
+                        std::vector<uint8_t> c(len + 1024);
+                        z_stream zs; memset(&zs, 0, sizeof zs);
+                        deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY);
+                        zs.next_in = e.bytes.data() + a; zs.avail_in = (uInt)len; zs.next_out = c.data(); zs.avail_out = (uInt)c.size();
+                        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) return;
+                        const size_t clen = zs.total_out;
+                        deflateEnd(&zs);
+                        BamWriter::wrap_member(c.data(), clen, (uint32_t)crc32(crc32(0L, Z_NULL, 0), e.bytes.data() + a, (uInt)len), (uint32_t)len, p.members[m]);
+                    }
+                    p.size = std::move(e.size); p.rid = std::move(e.rid);
+                    BamWriter::plan_device(carry, p);
+                } else
                 BamWriter::plan(carry, std::move(e), prepared.back());
                 recs.clear();
                 return;

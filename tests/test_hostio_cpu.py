@@ -193,3 +193,45 @@ def test_fast_deflate_members_inflate_with_zlib(exe, tmp_path):
     assert pos == len(o)
     assert declined <= 2                          # only the incompressible 64 KiB blocks
     assert tout < 0.6 * tin                       # and it does compress records
+
+
+@pytest.mark.parametrize("variant", ["planned-device", "planned-device-fail"])
+def test_bam_writer_takes_batches_deflated_elsewhere(exe, tmp_path, variant):
+    """every other batch arrives as the device path delivers it (BamWriter::plan_device / wrap_member: members ready, no record bytes):
+    the BAM stream inside is the one the sequential writer makes, members end at the batch's ends in addition, and the `.index`
+    offsets point at the first record of their read; -fail: a member of a host batch does not fit and the writer replays"""
+    n = 60000
+    a, d = str(tmp_path / "a.bam"), str(tmp_path / "d.bam")
+    subprocess.check_call([exe, "write", a, str(n), str(n)])
+    subprocess.check_call([exe, "write", d, str(n), "777", variant])
+    A, D = bgzf_blocks(a), bgzf_blocks(d)
+    stream = b"".join(raw for _, raw in D)
+    assert stream == b"".join(raw for _, raw in A)
+    assert len(D) > len(A) and len(D[-1][1]) == 0
+    for _, raw in D[1:-1]:                                  # whole records only
+        p = 0
+        while p < len(raw):
+            p += 4 + struct.unpack_from("<i", raw, p)[0]
+        assert p == len(raw)
+    # record starts in the inflated stream, by name
+    hdr = len(D[0][1])
+    starts, p = [], hdr
+    while p < len(stream):
+        bs, = struct.unpack_from("<i", stream, p)
+        l_rn = stream[p + 12]
+        starts.append((p, int(stream[p + 36:p + 36 + l_rn - 1])))
+        p += 4 + bs
+    first_of = {}
+    for at, rid in starts:
+        first_of.setdefault(rid, at)
+    at_of, pos = {}, 0
+    for off, raw in D:
+        at_of[off] = pos
+        pos += len(raw)
+    lines = [l.split("\t") for l in open(d + ".index").read().strip().split("\n")]
+    assert len(lines) > 20
+    for rid, voff in lines:
+        rid, voff = int(rid), int(voff)
+        assert at_of[voff >> 16] + (voff & 0xFFFF) == first_of[rid]
+    # the same reads are indexed as in the sequential writer's file (the rule counts records, not bytes)
+    assert [l.split("\t")[0] for l in open(a + ".index").read().strip().split("\n")] == [x[0] for x in lines]

@@ -474,6 +474,9 @@ static int real_main(int argc, char** argv) {
     // records come back ready to be copied into the output (THJ_HOST_READS=1: the host ReadStream instead)
     BamFile reads_bam;
     const bool dev_reads = dev_ingest && !getenv("THJ_HOST_READS") && reads_bam.open(pos[1], rt);
+    // ... and with the reads on the device the records are built and deflated there too (thj_span_bam_encode, thj_bgzf_deflate): the
+    // host wraps the members and writes them.  THJ_HOST_BAM=1 (or a zlib level asked for with THJ_BGZF_LEVEL): the host encoder.
+    const bool dev_out_wanted = dev_reads && !getenv("THJ_HOST_BAM") && !getenv("THJ_BGZF_LEVEL");
     // ---- the shard plan.  -p N: the reference's N ranges, one output file each.  One output file: our own number of shards,
     // written in order.
     const int hw = effective_cpus();
@@ -559,7 +562,8 @@ static int real_main(int argc, char** argv) {
             std::lock_guard<std::mutex> lk(plan_mu);
             so[k].e = std::move(e); so[k].ready = true;
             while (plan_next < S && so[plan_next].ready) {
-                BamWriter::plan(plan_carry, std::move(so[plan_next].e), so[plan_next].p);
+                if (so[plan_next].p.device) BamWriter::plan_device(plan_carry, so[plan_next].p);
+                else BamWriter::plan(plan_carry, std::move(so[plan_next].e), so[plan_next].p);
                 trace(plan_next, "planned");
                 planned.push_back(plan_next++);
             }
@@ -567,6 +571,27 @@ static int real_main(int argc, char** argv) {
         for (size_t i = 1; i < planned.size(); ++i) pool.submit([&deflate_shard, j = planned[i]] { deflate_shard(j); });
         if (!planned.empty()) deflate_shard(planned[0]);
     };
+
+    // shard k's records were encoded and deflated on the device: the planner only closes what the shard before left open
+    auto on_device_shard = [&](size_t k, BamWriter::Prepared&& dp) {
+        std::vector<size_t> planned;
+        {
+            std::lock_guard<std::mutex> lk(plan_mu);
+            so[k].p = std::move(dp); so[k].ready = true;
+            while (plan_next < S && so[plan_next].ready) {
+                if (so[plan_next].p.device) BamWriter::plan_device(plan_carry, so[plan_next].p);
+                else BamWriter::plan(plan_carry, std::move(so[plan_next].e), so[plan_next].p);
+                trace(plan_next, "planned");
+                planned.push_back(plan_next++);
+            }
+        }
+        for (size_t i = 1; i < planned.size(); ++i) pool.submit([&deflate_shard, j = planned[i]] { deflate_shard(j); });
+        if (!planned.empty()) deflate_shard(planned[0]);
+    };
+    const bool dev_out = dev_out_wanted && parts == 1;
+    std::vector<int32_t> tid_of_ref(rt.names.size());
+    if (dev_out) for (size_t i = 0; i < rt.names.size(); ++i) tid_of_ref[i] = bws[0]->tid_of(rt.names[i]);
+    std::atomic<long long> dev_out_shards{0}, host_out_shards{0};
 
     // JoinSegmentsWorker (long_spanning_reads.cpp:2669-2845) for one shard
     auto run_shard = [&](size_t k) {
@@ -605,7 +630,8 @@ static int real_main(int argc, char** argv) {
                 g_work.add(1, tw);
                 trace(k, "ingest_begin");
                 const long long td = WorkClock::now();
-                if (dev_reads) {
+                if (dev_reads && dev_out) rc = thj_ingest_span_batch(device_ready(gpu), &o.p, nseg, segp.data(), &rp, b_id, e_id, &dev, &ids, &n, nullptr, nullptr, nullptr);
+                else if (dev_reads) {
                     rc = thj_ingest_span_batch(device_ready(gpu), &o.p, nseg, segp.data(), &rp, b_id, e_id, &dev, &ids, &n, &rinfl, &rinfl_bytes, &rloc);
                 } else
                     rc = thj_ingest_span_hits(device_ready(gpu), &o.p, nseg, segp.data(), b_id, e_id, &dev, &ids, &n);
@@ -618,14 +644,18 @@ static int real_main(int argc, char** argv) {
                     std::vector<Read> batch_rd((size_t)n);
                     int W = 1, stride = 0;
                     std::vector<uint64_t> planes; std::vector<uint16_t> lens; std::vector<uint8_t> q;
-                    if (dev_reads) {
-                        // the rows' own BAM records, where the encoder copies names, bases and qualities from
+                    // the rows' own BAM records, where the host encoder copies names, bases and qualities from
+                    auto rows_from_raw = [&]() {
                         for (int64_t r = 0; r < n; ++r) {
                             const uint32_t loc = rloc[r];
-                            batch_rd[(size_t)r].id = ids[r];
                             batch_rd[(size_t)r].raw = rinfl + ((size_t)(loc >> 16) << 16) + (loc & 0xFFFFu) + 4;
                         }
-                        free(rloc); free(ids);
+                        free(rloc); rloc = nullptr;
+                    };
+                    if (dev_reads) {
+                        for (int64_t r = 0; r < n; ++r) batch_rd[(size_t)r].id = ids[r];
+                        free(ids);
+                        if (!dev_out) rows_from_raw();
                     } else {
                     ReadStream reads;
                     if (!reads.open(pos[1], o.zpacker, sh.read_off)) die("Error: cannot open %s for reading\n", pos[1].c_str());
@@ -648,6 +678,9 @@ static int real_main(int argc, char** argv) {
                     }
                     std::vector<thj_aln> alns;
                     thj_aln* alns_pinned = nullptr; int64_t n_alns = 0;       // one output file: the records come down into a page-locked buffer
+                    bool on_device = false;                                    // the shard's records were encoded and deflated on the device
+                    std::vector<uint32_t> dsize; std::vector<int64_t> drid; std::vector<size_t> dcuts; std::vector<uint32_t> dclen, dcrc;
+                    uint8_t* dcomp = nullptr; int64_t dcomp_bytes = 0;
                     {
                         const long long tw = WorkClock::now();
                         std::lock_guard<std::mutex> lk(gpu.mu);
@@ -667,15 +700,69 @@ static int real_main(int argc, char** argv) {
                         }
                         trace(k, "stitch_finished");
                         n_alns = na;
+                        if (dev_out) {
+                            // records and BGZF members on the device; the host gets record sizes, read ids and the deflated members
+                            dsize.resize((size_t)na); drid.resize((size_t)na);
+                            int64_t total = 0;
+                            int erc = thj_span_bam_encode(ctx, dev, tid_of_ref.data(), (int32_t)tid_of_ref.size(), dsize.data(), drid.data(), &total);
+                            if (erc == THJ_OK) {
+                                trace(k, "bam_encoded");
+                                BamWriter::plan_cuts_closed(dsize, dcuts);
+                                std::vector<int64_t> ends(dcuts.begin(), dcuts.end());
+                                dclen.resize(dcuts.size()); dcrc.resize(dcuts.size());
+                                dcomp = (uint8_t*)thj_pinned_alloc(dcuts.size() * (size_t)65536 + 64);
+                                if (!dcomp) die("Error: out of memory\n");
+                                erc = thj_bgzf_deflate(ctx, (int64_t)dcuts.size(), ends.data(), dcomp, (int64_t)(dcuts.size() * (size_t)65536), dclen.data(), dcrc.data(), &dcomp_bytes);
+                                trace(k, "bam_deflated");
+                            }
+                            if (erc == THJ_OK) on_device = true;
+                            else if (erc != THJ_EFALLBACK) die("Error: %s\n", thj_last_error());
+                            else {
+                                static std::atomic<bool> told{false};
+                                if (!told.exchange(true)) fprintf(stderr, "\tdevice-side BAM output not possible for a shard (%s); encoding on the host\n", thj_last_error());
+                                thj_pinned_free(dcomp); dcomp = nullptr;
+                                if (thj_span_batch_reads_host(ctx, dev, &rinfl, &rinfl_bytes, &rloc)) die("Error: %s\n", thj_last_error());
+                                rows_from_raw();
+                            }
+                        }
+                        if (on_device) {
+                            if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
+                            g_work.add(2, td);
+                            trace(k, "stitch_end");
+                        } else
                         if (parts == 1) { alns_pinned = (thj_aln*)thj_pinned_alloc((size_t)(na ? na : 1) * sizeof(thj_aln)); if (!alns_pinned) die("Error: out of memory\n"); }
                         else alns.resize((size_t)na);
+                        if (!on_device) {
                         trace(k, "stitch_resized");
                         if (na && thj_span_download(ctx, parts == 1 ? alns_pinned : alns.data())) die("Error: %s\n", thj_last_error());
                         trace(k, "stitch_downloaded");
                         if (thj_span_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
                         g_work.add(2, td);
                         trace(k, "stitch_end");
+                        }
                     }
+                    if (on_device) {
+                        // outside the GPU's lock: the members into their BGZF envelopes
+                        ++dev_out_shards;
+                        BamWriter::Prepared dp;
+                        dp.device = true;
+                        dp.size = std::move(dsize);
+                        dp.rid.assign(drid.begin(), drid.end());
+                        dp.cuts = std::move(dcuts);
+                        dp.members.resize(dp.cuts.size());
+                        size_t at = 0;
+                        for (size_t m = 0; m < dp.cuts.size(); ++m) {
+                            const size_t ulen = dp.cuts[m] - (m ? dp.cuts[m - 1] : 0);
+                            BamWriter::wrap_member(dcomp + at, dclen[m], dcrc[m], (uint32_t)ulen, dp.members[m]);
+                            at += dclen[m];
+                        }
+                        if ((int64_t)at != dcomp_bytes) die("Error: the device deflater's member sizes do not add up\n");
+                        thj_pinned_free(dcomp);
+                        trace(k, "wrapped");
+                        on_device_shard(k, std::move(dp));
+                        return;
+                    }
+                    ++host_out_shards;
                     if (parts > 1) {
                         BamWriter::Encoded e;
                         const long long te = WorkClock::now();
@@ -845,6 +932,7 @@ static int real_main(int argc, char** argv) {
     for (auto& t : th) t.join();
     pool.finish();
     g_timer.lap("ingest + stitch + encode + write (all shards)");
+    if (dev_out) fprintf(stderr, "\tBAM records and BGZF members made on the device for %lld shard%s, on the host for %lld\n", dev_out_shards.load(), dev_out_shards.load() == 1 ? "" : "s", host_out_shards.load());
     for (auto& bw : bws) bw->close();
     g_timer.lap("BAM close");
     g_timer.report();

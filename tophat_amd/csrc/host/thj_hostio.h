@@ -1705,7 +1705,43 @@ public:
         std::vector<size_t> cuts;                    // member ends in `stream`
         std::vector<std::vector<uint8_t>> members;
         bool ok = true;
+        // A batch whose records were encoded AND deflated on the device (thj_span_bam_encode, thj_bgzf_deflate): `members` come
+        // ready, `stream` holds at most the carry (the records' bytes never reach the host).  Such a batch starts a member and
+        // closes its last one at its end, like a bgzf_flush on either side: the BAM stream inside is the same, members are cut at
+        // the batch's ends in addition to where bam_write1 cuts them.
+        bool device = false;
+        bool carry_member = false;                   // members[0] is the carry of the batch before, closed by plan_device
     };
+    // BGZF envelope round clen bytes of DEFLATE data made elsewhere (crc / isize: of the member's uncompressed bytes)
+    static void wrap_member(const uint8_t* cdata, size_t clen, uint32_t crc, uint32_t isize, std::vector<uint8_t>& out) {
+        static const uint8_t hdr[12] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0};
+        out.resize(clen + 26);
+        memcpy(out.data(), hdr, 12);
+        out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
+        const uint16_t bs = (uint16_t)(clen + 18 + 8 - 1);
+        memcpy(out.data() + 16, &bs, 2);
+        memcpy(out.data() + 18, cdata, clen);
+        memcpy(out.data() + 18 + clen, &crc, 4);
+        memcpy(out.data() + 18 + clen + 4, &isize, 4);
+    }
+    // member ends for a batch that starts a member and ends one (the device batches): bam_write1's rule inside, a cut at the end
+    static void plan_cuts_closed(const std::vector<uint32_t>& size, std::vector<size_t>& cuts) {
+        size_t end_off = 0, total = 0;
+        for (auto s : size) total += s;
+        plan_cuts(0, 0, size, 0, cuts, &end_off);
+        if (total && (cuts.empty() || cuts.back() != total)) cuts.push_back(total);
+    }
+    // the planner's step for a device batch (p.device, p.size / p.rid / p.cuts / p.members filled, cuts counted from the batch's
+    // first byte): what is still open from the batch before becomes a member of its own, deflated by compress()
+    static void plan_device(std::vector<uint8_t>& carry, Prepared& p) {
+        p.carry_in = carry.size();
+        if (!p.carry_in) return;
+        p.stream = std::move(carry); carry.clear();
+        for (auto& c : p.cuts) c += p.carry_in;
+        p.cuts.insert(p.cuts.begin(), p.carry_in);
+        p.members.insert(p.members.begin(), std::vector<uint8_t>());
+        p.carry_member = true;
+    }
     static void plan(std::vector<uint8_t>& carry, Encoded&& e, Prepared& p) {
         p.carry_in = carry.size();
         p.stream.reserve(carry.size() + e.bytes.size());
@@ -1719,6 +1755,10 @@ public:
         carry.assign(p.stream.begin() + (ptrdiff_t)last, p.stream.end());
     }
     static void compress(Prepared& p) {
+        if (p.device) {
+            if (p.carry_member && !deflate_member(p.stream.data(), p.carry_in, p.members[0])) p.ok = false;
+            return;
+        }
         p.members.resize(p.cuts.size());
         for (size_t k = 0; k < p.cuts.size() && p.ok; ++k) {
             const size_t a = k ? p.cuts[k - 1] : 0;
@@ -1727,6 +1767,28 @@ public:
     }
     void commit(Prepared& p) {
         if (!p.ok) replay_ = true;
+        if (p.device) {
+            // In replay mode (a member of an earlier batch did not fit its envelope, so the cuts planned since then are void) what
+            // is open goes out here with bgzf.c's shrink rule and the planned carry member is dropped; the batch's own members do
+            // not depend on anything before them.
+            size_t first = 0, shift = 0;
+            if (replay_) {
+                if (!carry_.empty()) { std::vector<uint8_t> st = carry_; flush_blocks(st, std::vector<uint32_t>(), true); }
+                first = p.carry_member ? 1 : 0; shift = p.carry_in;
+            }
+            std::vector<Blk> tab;
+            size_t upos = 0;
+            for (size_t k = first; k < p.cuts.size(); ++k) {
+                const size_t end = p.cuts[k] - shift;
+                tab.push_back({upos, end - upos, file_addr_});
+                write_member(p.members[k]);
+                upos = end;
+            }
+            tab.push_back({upos, 0, file_addr_});
+            index_lines(tab, p.carry_in - shift, p.size, p.rid);
+            carry_.clear();
+            return;
+        }
         if (replay_) {
             Encoded e;
             e.bytes.assign(p.stream.begin() + (ptrdiff_t)p.carry_in, p.stream.end());

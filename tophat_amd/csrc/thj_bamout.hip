@@ -1,0 +1,268 @@
+// thj_bamout.hip -- the device side of long_spanning_reads' BAM writer (print_bamhit, bwt_map.cpp:1888-2093; bam_write1 ->
+// bgzf_write -> deflate_block, samtools-0.1.18 bam.c:207-236, bgzf.c:287-349):
+//   thj_k_bam_shapes / thj_k_bam_write   the pass's alignments as BAM records, from the device records and the reads' own BAM
+//                                        records (both already in HBM), back to back in output order;
+//   thj_k_deflate                        one workgroup of 16 waves per BGZF member: DEFLATE stream + CRC-32 (thj_deflate_core.h);
+//   thj_k_pack_members                   the members' compressed bytes back to back for one copy down.
+// The host plans where members end (bam_write1's bgzf_flush_try rule needs only record sizes), adds the 18 + 8 bytes of BGZF
+// envelope and writes; it never sees the uncompressed records.  HBM-bound byte work; no MFMA.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/thj.h"
+#include "thj_ctx.h"
+
+#define THJ_DFN __device__ __forceinline__
+#include "thj_deflate_core.h"
+#include "thj_bamenc_core.h"
+
+namespace {
+
+struct GpuX {
+    int tid, lane, wave;
+    __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+    __device__ __forceinline__ uint32_t shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src); }
+    __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
+    __device__ __forceinline__ uint32_t incl_scan(uint32_t v) {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+        for (int o = 32; o; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o); v = w > v ? w : v; }
+        return v;
+    }
+    // lanes of a wave run in lockstep and the LDS serves a wave's requests in order: only the compiler has to be kept from moving
+    // memory operations across the point
+    __device__ __forceinline__ void wsync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+    __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ void glb_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+};
+
+// member m of the launch = stream[ends[first + m - 1] .. ends[first + m]) (0 before the first)
+__global__ __launch_bounds__(dfl::NT) void thj_k_deflate(const uint8_t* __restrict__ stream, const int64_t* __restrict__ ends, int first, uint32_t* __restrict__ tokens,
+                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ results) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[dfl::L_END];
+    const int m = (int)blockIdx.x;
+    const int64_t b = first + m ? ends[first + m - 1] : 0, e = ends[first + m];
+    GpuX x{(int)threadIdx.x, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6)};
+    dfl::deflate_member(x, lds, stream + b, (uint32_t)(e - b), tokens + ((size_t)m << 16), out + ((size_t)m << 14), results + 4 * (size_t)m);
+}
+
+// results[4m + 3] = where member m's bytes start in the packed buffer (one workgroup; n <= 4096)
+__global__ __launch_bounds__(1024) void thj_k_member_offsets(uint32_t* __restrict__ results, int n) {
+    __shared__ uint32_t part[1024];
+    const int t = (int)threadIdx.x;
+    uint32_t v[4], s = 0;
+    for (int k = 0; k < 4; ++k) { const int m = 4 * t + k; v[k] = m < n ? results[4 * m] : 0u; s += v[k]; }
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const uint32_t a = t >= o ? part[t - o] : 0u; __syncthreads(); part[t] += a; __syncthreads(); }
+    uint32_t at = part[t] - s;
+    for (int k = 0; k < 4; ++k) { const int m = 4 * t + k; if (m < n) results[4 * m + 3] = at; at += v[k]; }
+}
+__global__ __launch_bounds__(256) void thj_k_pack_members(const uint8_t* __restrict__ out, const uint32_t* __restrict__ results, uint8_t* __restrict__ packed) {
+    const int m = (int)blockIdx.x;
+    const uint32_t n = results[4 * m], at = results[4 * m + 3];
+    const uint8_t* src = out + ((size_t)m << 16);
+    uint8_t* dst = packed + at;
+    // word copies where the destination allows
+    const uint32_t head = (uint32_t)((4 - ((uintptr_t)dst & 3u)) & 3u) < n ? (uint32_t)((4 - ((uintptr_t)dst & 3u)) & 3u) : n;
+    if (threadIdx.x < head) dst[threadIdx.x] = src[threadIdx.x];
+    const uint32_t words = (n - head) >> 2;
+    for (uint32_t w = threadIdx.x; w < words; w += 256) { uint32_t v; memcpy(&v, src + head + 4 * w, 4); *(uint32_t*)(dst + head + 4 * w) = v; }
+    const uint32_t done = head + 4 * words;
+    if (threadIdx.x < n - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void thj_k_bam_shapes(const thj_aln* __restrict__ alns, int64_t n, const uint8_t* __restrict__ infl, const uint32_t* __restrict__ loc, int32_t n_rows,
+                                                        size_t infl_bytes, int32_t n_ref, uint32_t* __restrict__ size, long long* __restrict__ rid, unsigned int* __restrict__ flag) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const thj_aln& a = alns[i];
+        if (a.read_idx >= (uint32_t)n_rows || a.ref_id < 1 || a.ref_id > (uint32_t)n_ref || (size_t)loc[a.read_idx] + 36 > infl_bytes) { atomicOr(flag, 2u); size[i] = 0; rid[i] = 0; continue; }
+        const bamenc::Shape s = bamenc::record_shape(a, infl + loc[a.read_idx] + 4);
+        if (s.host_only) atomicOr(flag, 1u);
+        size[i] = s.size; rid[i] = s.rid;
+    }
+}
+__global__ __launch_bounds__(256) void thj_k_bam_write(const thj_aln* __restrict__ alns, int64_t n, const uint8_t* __restrict__ infl, const uint32_t* __restrict__ loc,
+                                                       const int32_t* __restrict__ tid_of_ref, const unsigned long long* __restrict__ off, uint8_t* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const thj_aln& a = alns[i];
+        const uint8_t* raw = infl + loc[a.read_idx] + 4;
+        const bamenc::Shape s = bamenc::record_shape(a, raw);
+        bamenc::record_write(a, raw, s, tid_of_ref[a.ref_id - 1], out + off[i]);
+    }
+}
+
+struct SizeToU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
+
+int ensure_bam(thj_ctx* c, size_t bytes) {
+    if (bytes <= c->bam_cap) return THJ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_bam) (void)hipFree(c->d_bam);
+    c->d_bam = nullptr; c->bam_cap = 0;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc((void**)&c->d_bam, cap));
+    c->bam_cap = cap;
+    return THJ_OK;
+}
+int ensure_tmp(thj_ctx* c, size_t bytes) {
+    if (bytes <= c->bam_tmp_cap) return THJ_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_bam_tmp) (void)hipFree(c->d_bam_tmp);
+    c->d_bam_tmp = nullptr; c->bam_tmp_cap = 0;
+    HIPCHK(hipMalloc(&c->d_bam_tmp, bytes));
+    c->bam_tmp_cap = bytes;
+    return THJ_OK;
+}
+
+}  // namespace
+
+void thj_bamout_free(thj_ctx* c) {
+    if (c->d_bam) (void)hipFree(c->d_bam);
+    if (c->d_bam_tmp) (void)hipFree(c->d_bam_tmp);
+    c->d_bam = nullptr; c->d_bam_tmp = nullptr; c->bam_cap = c->bam_tmp_cap = 0; c->bam_bytes = 0;
+}
+
+extern "C" int thj_span_bam_encode(thj_ctx* c, const thj_span_batch* batch, const int32_t* tid_of_ref, int32_t n_ref, uint32_t* rec_size, int64_t* rec_id,
+                                   int64_t* total_bytes) {
+    if (!c || !batch || !tid_of_ref || n_ref < 1 || !total_bytes || (c->n_alns > 0 && (!rec_size || !rec_id))) { thj_set_error("thj_span_bam_encode: bad argument"); return THJ_EINVAL; }
+    const OwnedSpanBatch* ob = (const OwnedSpanBatch*)batch;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->bam_bytes = 0; *total_bytes = 0;
+    const int64_t n = c->n_alns;
+    if (n == 0) return THJ_OK;
+    if (!ob->ptrs[6] || !ob->ptrs[7]) { thj_set_error("thj_span_bam_encode: the batch holds no read records (thj_ingest_span_batch makes the batches this takes)"); return THJ_EFALLBACK; }
+    void* d_alns = nullptr;
+    int rc = thj_span_compact_device(c, &d_alns);
+    if (rc == THJ_EFALLBACK) { thj_set_error("thj_span_bam_encode: the pass's records could not be compacted on the device"); return THJ_EFALLBACK; }
+    if (rc) return rc;
+    void *d_size = nullptr, *d_rid = nullptr, *d_off = nullptr, *d_tid = nullptr, *d_tmp = nullptr;
+    auto done = [&](int code) {
+        (void)hipStreamSynchronize(c->stream);
+        thj_dev_release(c, d_alns); thj_dev_release(c, d_size); thj_dev_release(c, d_rid); thj_dev_release(c, d_off); thj_dev_release(c, d_tid); thj_dev_release(c, d_tmp);
+        return code;
+    };
+#define BAM_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { thj_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return done(THJ_EHIP); } } while (0)
+    hipcub::TransformInputIterator<unsigned long long, SizeToU64, const uint32_t*> in((const uint32_t*)nullptr, SizeToU64());
+    size_t tmp_bytes = 0;
+    BAM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, (unsigned long long*)nullptr, (int)n, c->stream));
+    if (thj_dev_alloc(c, &d_size, (size_t)n * 4 + 16) || thj_dev_alloc(c, &d_rid, (size_t)n * 8) || thj_dev_alloc(c, &d_off, (size_t)n * 8) ||
+        thj_dev_alloc(c, &d_tid, (size_t)n_ref * 4) || thj_dev_alloc(c, &d_tmp, tmp_bytes + 16)) return done(THJ_EHIP);
+    unsigned int* d_flag = (unsigned int*)((char*)d_size + (size_t)n * 4);
+    BAM_HIP(hipMemsetAsync(d_flag, 0, 4, c->stream));
+    BAM_HIP(hipMemcpyAsync(d_tid, tid_of_ref, (size_t)n_ref * 4, hipMemcpyHostToDevice, c->stream));
+    int64_t grid = (n + 255) / 256; if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(thj_k_bam_shapes, dim3((unsigned)grid), dim3(256), 0, c->stream, (const thj_aln*)d_alns, n, (const uint8_t*)ob->ptrs[6], (const uint32_t*)ob->ptrs[7],
+                       batch->n_reads, ob->reads_infl_bytes, n_ref, (uint32_t*)d_size, (long long*)d_rid, d_flag);
+    BAM_HIP(hipGetLastError());
+    hipcub::TransformInputIterator<unsigned long long, SizeToU64, const uint32_t*> in2((const uint32_t*)d_size, SizeToU64());
+    BAM_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, in2, (unsigned long long*)d_off, (int)n, c->stream));
+    unsigned int flag = 0; unsigned long long last_off = 0;
+    BAM_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
+    BAM_HIP(hipMemcpyAsync(&last_off, (unsigned long long*)d_off + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));
+    BAM_HIP(hipMemcpyAsync(rec_size, d_size, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    BAM_HIP(hipMemcpyAsync(rec_id, d_rid, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    BAM_HIP(hipStreamSynchronize(c->stream));
+    if (flag & 2u) { thj_set_error("thj_span_bam_encode: a record points outside the batch (read index, contig or read record)"); return done(THJ_EINVAL); }
+    if (flag & 1u) { thj_set_error("thj_span_bam_encode: a record of the batch needs the host encoder (fusion alignment, long MD string, read length)"); return done(THJ_EFALLBACK); }
+    const size_t total = (size_t)last_off + rec_size[n - 1];
+    rc = ensure_bam(c, total + 64);
+    if (rc) return done(rc);
+    hipLaunchKernelGGL(thj_k_bam_write, dim3((unsigned)grid), dim3(256), 0, c->stream, (const thj_aln*)d_alns, n, (const uint8_t*)ob->ptrs[6], (const uint32_t*)ob->ptrs[7],
+                       (const int32_t*)d_tid, (const unsigned long long*)d_off, c->d_bam);
+    BAM_HIP(hipGetLastError());
+    BAM_HIP(hipStreamSynchronize(c->stream));
+#undef BAM_HIP
+    c->bam_bytes = (int64_t)total; *total_bytes = (int64_t)total;
+    return done(THJ_OK);
+}
+
+extern "C" int thj_bam_stream_upload(thj_ctx* c, const uint8_t* bytes, int64_t n) {
+    if (!c || n < 0 || (n > 0 && !bytes)) { thj_set_error("thj_bam_stream_upload: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ensure_bam(c, (size_t)n + 64);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpyAsync(c->d_bam, bytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->bam_bytes = n;
+    return THJ_OK;
+}
+extern "C" int thj_bam_stream_download(thj_ctx* c, uint8_t* bytes) {
+    if (!c || (c->bam_bytes > 0 && !bytes)) { thj_set_error("thj_bam_stream_download: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (c->bam_bytes) HIPCHK(hipMemcpyAsync(bytes, c->d_bam, (size_t)c->bam_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return THJ_OK;
+}
+
+extern "C" int thj_bgzf_deflate(thj_ctx* c, int64_t n_members, const int64_t* member_end, uint8_t* comp, int64_t comp_cap, uint32_t* comp_len, uint32_t* crc,
+                                int64_t* comp_bytes) {
+    if (!c || n_members < 0 || (n_members > 0 && (!member_end || !comp || !comp_len || !crc)) || !comp_bytes) { thj_set_error("thj_bgzf_deflate: bad argument"); return THJ_EINVAL; }
+    *comp_bytes = 0;
+    if (n_members == 0) return THJ_OK;
+    for (int64_t k = 0; k < n_members; ++k) {
+        const int64_t b = k ? member_end[k - 1] : 0, e = member_end[k];
+        if (e <= b || e - b > 65536 || e > c->bam_bytes) { thj_set_error("thj_bgzf_deflate: member %lld is empty, larger than 64 KiB or outside the encoded stream", (long long)k); return THJ_EINVAL; }
+    }
+    HIPCHK(hipSetDevice(c->device));
+    static const int MC = getenv("THJ_DEFLATE_LAUNCH") ? atoi(getenv("THJ_DEFLATE_LAUNCH")) : 1024;       // members per launch
+    const int64_t mc = n_members < MC ? n_members : (MC < 1 ? 1 : MC > 4096 ? 4096 : MC);
+    // scratch: ends, then per member of a launch: tokens (256 KiB), output (64 KiB), results (16 B); the packed output
+    const size_t ends_b = ((size_t)n_members * 8 + 255) & ~(size_t)255;
+    const size_t need = ends_b + (size_t)mc * ((256u << 10) + (64u << 10) + 16u + (64u << 10)) + 256;
+    int rc = ensure_tmp(c, need);
+    if (rc) return rc;
+    uint8_t* base = (uint8_t*)c->d_bam_tmp;
+    int64_t* d_ends = (int64_t*)base;
+    uint32_t* d_tok = (uint32_t*)(base + ends_b);
+    uint32_t* d_out = (uint32_t*)((uint8_t*)d_tok + (size_t)mc * (256u << 10));
+    uint8_t* d_packed = (uint8_t*)d_out + (size_t)mc * (64u << 10);
+    uint32_t* d_res = (uint32_t*)(d_packed + (size_t)mc * (64u << 10));
+    HIPCHK(hipMemcpyAsync(d_ends, member_end, (size_t)n_members * 8, hipMemcpyHostToDevice, c->stream));
+    std::vector<uint32_t> res((size_t)mc * 4);
+    int64_t written = 0;
+    for (int64_t first = 0; first < n_members; first += mc) {
+        const int nm = (int)(n_members - first < mc ? n_members - first : mc);
+        HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nm * (64u << 10), c->stream));
+        hipLaunchKernelGGL(thj_k_deflate, dim3((unsigned)nm), dim3(dfl::NT), 0, c->stream, (const uint8_t*)c->d_bam, (const int64_t*)d_ends, (int)first, d_tok, d_out, d_res);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(thj_k_member_offsets, dim3(1), dim3(1024), 0, c->stream, d_res, nm);
+        hipLaunchKernelGGL(thj_k_pack_members, dim3((unsigned)nm), dim3(256), 0, c->stream, (const uint8_t*)d_out, (const uint32_t*)d_res, d_packed);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(res.data(), d_res, (size_t)nm * 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        size_t total = 0;
+        for (int m = 0; m < nm; ++m) {
+            if (res[4 * (size_t)m + 2] != dfl::ST_OK) {
+                thj_set_error("thj_bgzf_deflate: member %lld does not fit a BGZF block when deflated (status %u)", (long long)(first + m), res[4 * (size_t)m + 2]);
+                return THJ_EFALLBACK;
+            }
+            comp_len[first + m] = res[4 * (size_t)m]; crc[first + m] = res[4 * (size_t)m + 1];
+            total += res[4 * (size_t)m];
+        }
+        if (written + (int64_t)total > comp_cap) { thj_set_error("thj_bgzf_deflate: the output buffer is too small"); return THJ_EINVAL; }
+        HIPCHK(hipMemcpyAsync(comp + written, d_packed, total, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        written += (int64_t)total;
+    }
+    *comp_bytes = written;
+    return THJ_OK;
+}

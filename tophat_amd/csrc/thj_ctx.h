@@ -20,6 +20,14 @@ using thj::u64;
         }                                                                                     \
     } while (0)
 
+// a span batch this library made (thj_span_batch_upload, thj_ingest_span_*): the API descriptor first, then what it owns
+struct OwnedSpanBatch {
+    thj_span_batch desc;
+    void* ptrs[8];               // 0 seg_off, 1 hits, 2 read planes, 3 read lengths, 4 qualities, 5 hit heads,
+                                 // 6 the reads' own (inflated) BAM records, 7 uint32 per row: where its record starts in [6]
+    size_t reads_infl_bytes;     // size of [6]
+};
+
 struct thj_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -80,6 +88,9 @@ struct thj_ctx {
     std::vector<DevBlock> dev_cache; size_t dev_cache_bytes = 0;
     // device-side ingest scratch (thj_ingest.hip)
     void* d_ing0 = nullptr; size_t ing_cap0 = 0; void* d_ing1 = nullptr; size_t ing_cap1 = 0;
+    // the BAM writer's device side (thj_bamout.hip): the pass's encoded records, their offsets; the deflater's scratch
+    uint8_t* d_bam = nullptr; size_t bam_cap = 0; int64_t bam_bytes = 0;
+    void* d_bam_tmp = nullptr; size_t bam_tmp_cap = 0;
     void* d_infl_tmp = nullptr; size_t infl_tmp_cap = 0;                  // token streams of the two-kernel inflater
     // junction consensus (thj_juncbed_impl.h)
     u64* d_jb_key = nullptr; uint32_t* d_jb_u32 = nullptr; u64* d_jb_list = nullptr; u64* d_jb_sorted = nullptr;
@@ -98,3 +109,5 @@ int thj_dev_alloc(struct thj_ctx* c, void** out, size_t bytes);     // like hipM
 void thj_dev_release(struct thj_ctx* c, void* p);                  // like hipFree, but the block stays with the context
 void thj_dev_cache_free(struct thj_ctx* c);
 void thj_span_free(struct thj_ctx* c);
+int thj_span_compact_device(struct thj_ctx* c, void** d_out);       // thj_span.hip: the pass's records, ordered, on the device
+void thj_bamout_free(struct thj_ctx* c);                            // thj_bamout.hip

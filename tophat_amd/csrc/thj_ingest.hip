@@ -1214,7 +1214,10 @@ static bool member_table(const uint8_t* d, int64_t n, std::vector<thj_bgzf_block
 }  // namespace ing
 
 struct IngestOwned { thj_seg_batch desc; void* ptrs[6]; };          // same layout as the uploaded batches: thj_batch_free releases it
-struct IngestOwnedSpan { thj_span_batch desc; void* ptrs[6]; };     // ... thj_span_batch_free
+using IngestOwnedSpan = OwnedSpanBatch;     // ... thj_span_batch_free
+__global__ void thj_k_rebase_u32(const uint32_t* __restrict__ in, uint32_t n, uint32_t base, uint32_t* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] - base;
+}
 
 namespace ing {
 
@@ -1438,7 +1441,7 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
     const bool have_mate = f_full >= 0 || f_last >= 0;
     IngestOwned* ob = new IngestOwned();
     memset(ob, 0, sizeof *ob);
-    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 8; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
     uint32_t* b_off = nullptr; Hit16* b_hits = nullptr; u64* b_planes = nullptr; uint16_t* b_len = nullptr; uint32_t* b_moff = nullptr; Hit16* b_mh = nullptr;
     uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* mcell = am.take<uint32_t>((size_t)n_rows + 1);
     uint32_t* row_id = am.take<uint32_t>(n_rows); uint32_t* seen = am.take<uint32_t>(n_rows);
@@ -1553,7 +1556,7 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
     if (n_rows == 0) return THJ_OK;
     IngestOwnedSpan* ob = new IngestOwnedSpan();
     memset(ob, 0, sizeof *ob);
-    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 6; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 8; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
     uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* row_id = am.take<uint32_t>(n_rows);
     if (!cell || !row_id) { thj_set_error("thj_ingest: merge scratch too small"); return fail(THJ_ENOMEM); }
     uint32_t* b_off = nullptr; Hit32* b_hits = nullptr;
@@ -1595,21 +1598,28 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
         if (b > a) hipLaunchKernelGGL(thj_k_read_planes, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.infl, P.id, P.loc, a, b, id_lo, span, m_vis, m_row, W,
                                       (u64*)ob->ptrs[2], (uint16_t*)ob->ptrs[3], seen, P.status, (uint8_t*)ob->ptrs[4], qstride, d_loc);
         hipLaunchKernelGGL(thj_k_check_seen, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, seen, n_rows, P.status);
-        h_loc = (uint32_t*)malloc((size_t)n_rows * 4);
+        // the rows' own BAM records stay on the device with the batch (thj_span_bam_encode copies names, bases and qualities from
+        // them); the host copy is made only for a caller that asks for it
         const size_t ib = (size_t)P.file_blocks[(size_t)f_reads] << 16;
-        h_infl = (uint8_t*)thj_pinned_alloc(ib ? ib : 16);
-        if (!h_loc || !h_infl) return fail2(THJ_ENOMEM);
+        const uint32_t base = P.file_first_block[(size_t)f_reads] << 16;
+        if (thj_dev_alloc(c, &ob->ptrs[6], ib ? ib : 16) || thj_dev_alloc(c, &ob->ptrs[7], (size_t)n_rows * 4)) return fail2(THJ_EHIP);
+        ob->reads_infl_bytes = ib;
+        if (ib) ING_HIP(hipMemcpyAsync(ob->ptrs[6], P.infl + (size_t)base, ib, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(thj_k_rebase_u32, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, (const uint32_t*)d_loc, n_rows, base, (uint32_t*)ob->ptrs[7]);
         unsigned int h_status[16];
-        ING_HIP(hipMemcpyAsync(h_loc, d_loc, (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
         ING_HIP(hipMemcpyAsync(h_status, P.status, 64, hipMemcpyDeviceToHost, c->stream));
-        if (ib) ING_HIP(hipMemcpyAsync(h_infl, P.infl + ((size_t)P.file_first_block[(size_t)f_reads] << 16), ib, hipMemcpyDeviceToHost, c->stream));
+        if (reads_infl) {
+            h_loc = (uint32_t*)malloc((size_t)n_rows * 4);
+            h_infl = (uint8_t*)thj_pinned_alloc(ib ? ib : 16);
+            if (!h_loc || !h_infl) return fail2(THJ_ENOMEM);
+            ING_HIP(hipMemcpyAsync(h_loc, ob->ptrs[7], (size_t)n_rows * 4, hipMemcpyDeviceToHost, c->stream));
+            if (ib) ING_HIP(hipMemcpyAsync(h_infl, ob->ptrs[6], ib, hipMemcpyDeviceToHost, c->stream));
+        }
         ING_HIP(hipStreamSynchronize(c->stream));
         if (h_status[ST_MISSING_READ]) { thj_set_error("Error: could not get a read of the shard from the reads file"); return fail2(THJ_EINVAL); }
-        const uint32_t base = P.file_first_block[(size_t)f_reads] << 16;
-        for (uint32_t r = 0; r < n_rows; ++r) h_loc[r] -= base;
         ob->desc.words_per_plane = W; ob->desc.qual_stride = qstride;
         ob->desc.read_planes = (const uint64_t*)ob->ptrs[2]; ob->desc.read_len = (const uint16_t*)ob->ptrs[3]; ob->desc.quals = (const uint8_t*)ob->ptrs[4];
-        *reads_infl = h_infl; *reads_infl_bytes = (int64_t)ib; *row_loc_out = h_loc;
+        if (reads_infl) { *reads_infl = h_infl; *reads_infl_bytes = (int64_t)ib; *row_loc_out = h_loc; }
         pc.mark(7);
     }
     ING_HIP(hipStreamSynchronize(c->stream));
@@ -1681,10 +1691,28 @@ extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t ns
 extern "C" int thj_ingest_span_batch(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, const thj_bam_piece* reads, uint32_t begin_id,
                                      uint32_t end_id, thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out, uint8_t** reads_infl,
                                      int64_t* reads_infl_bytes, uint32_t** row_loc) {
-    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out || !row_ids || !n_rows_out || !reads_infl || !reads_infl_bytes || !row_loc) {
+    const int host_copy = (reads_infl != nullptr) + (reads_infl_bytes != nullptr) + (row_loc != nullptr);       // all three or none
+    if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out || !row_ids || !n_rows_out || (host_copy != 0 && host_copy != 3)) {
         thj_set_error("thj_ingest_span_batch: bad argument"); return THJ_EINVAL;
     }
     return span_ingest_impl(c, tp, nseg, segs, reads, begin_id, end_id, out, row_ids, n_rows_out, reads_infl, reads_infl_bytes, row_loc);
+}
+
+// the host copy of a batch's read records, for a caller that let thj_ingest_span_batch keep them on the device and needs them after all
+extern "C" int thj_span_batch_reads_host(thj_ctx* c, const thj_span_batch* batch, uint8_t** reads_infl, int64_t* reads_infl_bytes, uint32_t** row_loc) {
+    if (!c || !batch || !reads_infl || !reads_infl_bytes || !row_loc) { thj_set_error("thj_span_batch_reads_host: bad argument"); return THJ_EINVAL; }
+    const OwnedSpanBatch* ob = (const OwnedSpanBatch*)batch;
+    if (!ob->ptrs[6] || !ob->ptrs[7]) { thj_set_error("thj_span_batch_reads_host: the batch holds no read records"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t ib = ob->reads_infl_bytes, n = (size_t)batch->n_reads;
+    uint32_t* h_loc = (uint32_t*)malloc((n ? n : 1) * 4);
+    uint8_t* h_infl = (uint8_t*)thj_pinned_alloc(ib ? ib : 16);
+    if (!h_loc || !h_infl) { free(h_loc); thj_pinned_free(h_infl); thj_set_error("out of memory"); return THJ_ENOMEM; }
+    if (n) HIPCHK(hipMemcpyAsync(h_loc, ob->ptrs[7], n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (ib) HIPCHK(hipMemcpyAsync(h_infl, ob->ptrs[6], ib, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *reads_infl = h_infl; *reads_infl_bytes = (int64_t)ib; *row_loc = h_loc;
+    return THJ_OK;
 }
 
 // the reads of a batch made by thj_ingest_span_hits, in row order (HOST arrays as thj_reads_pack / thj_span_batch describe them)

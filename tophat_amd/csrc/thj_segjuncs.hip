@@ -652,7 +652,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_fus_ignore);
     if (c->probe_ev) hipEventDestroy(c->probe_ev);
     hipHostFree(c->h_pinned);
-    thj_span_free(c);
+    thj_span_free(c); thj_bamout_free(c);
     cov_free(c);
     hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); hipFree(c->d_infl_tmp); thj_dev_cache_free(c);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }

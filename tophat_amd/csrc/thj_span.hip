@@ -501,10 +501,6 @@ extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
     return build_junc_buckets(c);          // stream-ordered: thj_span_run_async on this context needs no synchronisation
 }
 
-struct OwnedSpanBatch {
-    thj_span_batch desc;     // first member
-    void* ptrs[6];
-};
 
 // the dense head array of a batch: the first 16 bytes of every 32-byte hit record
 __global__ void thj_k_hit_heads(const Q16* hits, int64_t n, Q16* heads) {
@@ -561,7 +557,7 @@ extern "C" int thj_span_batch_free(thj_ctx* c, thj_span_batch* dev) {
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     OwnedSpanBatch* ob = (OwnedSpanBatch*)dev;
-    for (int i = 0; i < 6; ++i) thj_dev_release(c, ob->ptrs[i]);
+    for (int i = 0; i < 8; ++i) thj_dev_release(c, ob->ptrs[i]);
     delete ob;
     return THJ_OK;
 }
@@ -842,15 +838,13 @@ __global__ __launch_bounds__(256) void thj_k_compact_records(const OutAln* slots
 
 static int span_download_host(thj_ctx* c, thj_aln* out);
 
-extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
-    // compact, ordered host copy: compacted on the device, one copy down
-    if (!c || (c->n_alns > 0 && !out)) { thj_set_error("thj_span_download: bad argument"); return THJ_EINVAL; }
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->n_alns == 0) return THJ_OK;
+// the pass's records compacted and ordered on the device: *d_out = n_alns API-layout records (the caller releases it with
+// thj_dev_release); THJ_EFALLBACK when the device compaction cannot be used (the caller then takes span_download_host's way)
+int thj_span_compact_device(thj_ctx* c, void** d_out_p) {
+    *d_out_p = nullptr;
     const int64_t nr = c->span_reads, n = c->n_alns;
     static const bool host_path = getenv("THJ_DOWNLOAD_ON_HOST") != nullptr;
-    if (host_path || n >= (1ll << 32) || nr < 1) return span_download_host(c, out);
+    if (host_path || n >= (1ll << 32) || nr < 1) return THJ_EFALLBACK;
     void *d_off = nullptr, *d_out = nullptr, *d_tmp = nullptr;
     hipcub::TransformInputIterator<uint32_t, NrecToU32, const uint8_t*> in(c->d_nrec, NrecToU32());
     size_t tmp_bytes = 0;
@@ -858,7 +852,7 @@ extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
     int rc = thj_dev_alloc(c, &d_off, (size_t)nr * 4 + 16);
     if (!rc) rc = thj_dev_alloc(c, &d_out, (size_t)n * 128);
     if (!rc) rc = thj_dev_alloc(c, &d_tmp, tmp_bytes + 16);
-    if (rc) { if (d_off) thj_dev_release(c, d_off); if (d_out) thj_dev_release(c, d_out); if (d_tmp) thj_dev_release(c, d_tmp); return span_download_host(c, out); }
+    if (rc) { if (d_off) thj_dev_release(c, d_off); if (d_out) thj_dev_release(c, d_out); if (d_tmp) thj_dev_release(c, d_tmp); return THJ_EFALLBACK; }
     unsigned int* d_bad = (unsigned int*)((char*)d_off + (size_t)nr * 4);
     HIPCHK(hipMemsetAsync(d_bad, 0, 4, c->stream));
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, in, (uint32_t*)d_off, (int)nr, c->stream));
@@ -870,9 +864,25 @@ extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
     unsigned int bad = 0;
     HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (!bad) HIPCHK(hipMemcpy(out, d_out, (size_t)n * 128, hipMemcpyDeviceToHost));
-    thj_dev_release(c, d_off); thj_dev_release(c, d_out); thj_dev_release(c, d_tmp);
-    if (bad) return span_download_host(c, out);
+    thj_dev_release(c, d_off); thj_dev_release(c, d_tmp);
+    if (bad) { thj_dev_release(c, d_out); return THJ_EFALLBACK; }
+    *d_out_p = d_out;
+    return THJ_OK;
+}
+
+extern "C" int thj_span_download(thj_ctx* c, thj_aln* out) {
+    // compact, ordered host copy: compacted on the device, one copy down
+    if (!c || (c->n_alns > 0 && !out)) { thj_set_error("thj_span_download: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->n_alns == 0) return THJ_OK;
+    void* d_out = nullptr;
+    const int rc = thj_span_compact_device(c, &d_out);
+    if (rc == THJ_EFALLBACK) return span_download_host(c, out);
+    if (rc) return rc;
+    const hipError_t e = hipMemcpy(out, d_out, (size_t)c->n_alns * 128, hipMemcpyDeviceToHost);
+    thj_dev_release(c, d_out);
+    HIPCHK(e);
     return THJ_OK;
 }
 

@@ -777,3 +777,59 @@ def aln_array_from_tuples(recs) -> np.ndarray:
         if len(rec) > 4 and rec[4]:
             a[k]["cigar"][15] = rec[4]
     return a
+
+
+# ------------------------------------------------------------------ the BAM writer's device side (thj_bamout.hip)
+
+ABI_SYMBOLS += ["thj_span_bam_encode", "thj_bgzf_deflate", "thj_bam_stream_upload", "thj_bam_stream_download", "thj_span_batch_reads_host"]
+
+
+def bgzf_plan_cuts(sizes: Sequence[int], block: int = 0x10000) -> List[int]:
+    """where BGZF members end in a stream of records that starts a member: bam_write1 calls bgzf_flush_try(4 + block_len) -- a record
+    that does not fit what is left of the 64 KiB block starts a new one (bam.c:225, bgzf.c:587-592) -- and bgzf_write flushes a full
+    block (bgzf.c:594-623).  The last member is closed at the end of the stream.  The Python mirror of BamWriter::plan_cuts."""
+    cuts, off, pos = [], 0, 0
+    for s in sizes:
+        if off + s > block and off > 0:
+            cuts.append(pos); off = 0
+        while s > 0:
+            c = min(block - off, s)
+            off += c; pos += c; s -= c
+            if off == block:
+                cuts.append(pos); off = 0
+    if off:
+        cuts.append(pos)
+    return cuts
+
+
+def _bamout_methods():
+    def bam_stream_upload(self, data: bytes):
+        buf = np.frombuffer(data, dtype=np.uint8)
+        _check(self.lib, self.lib.thj_bam_stream_upload(self._ctx, _ptr(buf) if len(data) else None, C.c_int64(len(data))), "thj_bam_stream_upload")
+        self._bam_bytes = len(data)
+
+    def bam_stream_download(self, n: int) -> bytes:
+        buf = np.zeros(max(1, n), dtype=np.uint8)
+        _check(self.lib, self.lib.thj_bam_stream_download(self._ctx, _ptr(buf)), "thj_bam_stream_download")
+        return buf[:n].tobytes()
+
+    def bgzf_deflate(self, member_end: Sequence[int]):
+        """the context's stream cut at member_end -> ([raw DEFLATE stream per member], [CRC-32 per member])"""
+        ends = np.asarray(member_end, dtype=np.int64)
+        n = len(ends)
+        comp = np.zeros(max(1, n) * 65536, dtype=np.uint8)
+        clen = np.zeros(max(1, n), dtype=np.uint32); crc = np.zeros(max(1, n), dtype=np.uint32)
+        total = C.c_int64()
+        _check(self.lib, self.lib.thj_bgzf_deflate(self._ctx, C.c_int64(n), _ptr(ends), _ptr(comp), C.c_int64(comp.size), _ptr(clen), _ptr(crc), C.byref(total)),
+               "thj_bgzf_deflate")
+        out, at = [], 0
+        for k in range(n):
+            out.append(comp[at:at + int(clen[k])].tobytes()); at += int(clen[k])
+        assert at == total.value
+        return out, [int(x) for x in crc[:n]]
+
+    for f in (bam_stream_upload, bam_stream_download, bgzf_deflate):
+        setattr(Context, f.__name__, f)
+
+
+_bamout_methods()
