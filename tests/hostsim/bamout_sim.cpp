@@ -16,11 +16,13 @@ struct SimX {
     uint32_t bcast(uint32_t v, int src) { return b->exchange(tid, v)[src & 63]; }
     uint32_t incl_scan(uint32_t v) { const uint32_t* a = b->exchange(tid, v); uint32_t s = 0; for (int i = 0; i <= lane; ++i) s += a[i]; return s; }
     uint32_t wave_max(uint32_t v) { const uint32_t* a = b->exchange(tid, v); uint32_t s = 0; for (int i = 0; i < 64; ++i) s = a[i] > s ? a[i] : s; return s; }
+    uint32_t wave_xor(uint32_t v) { const uint32_t* a = b->exchange(tid, v); uint32_t s = 0; for (int i = 0; i < 64; ++i) s ^= a[i]; return s; }
     void wsync() { b->exchange(tid, 0); }
     void sync() { b->barrier(); }
     uint32_t lds_add(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
     void lds_or(uint32_t* p, uint32_t v) { *p |= v; }
     void glb_or(uint32_t* p, uint32_t v) { *p |= v; }
+    unsigned long long clock() { return 0; }
 };
 }  // namespace
 

@@ -21,11 +21,11 @@ from tophat_amd.bamio import parse_bam_record  # noqa: E402
 ST_OK, ST_TOO_BIG = 0, 1
 
 
-@pytest.fixture(scope="module")
-def lib():
+@pytest.fixture(scope="module", params=["libbamoutsim.so", "libbamoutsim_exact.so"], ids=["shannon_slack_lengths", "huffman_lengths"])
+def lib(request):
     d = os.path.join(HERE, "hostsim")
     locked_make(d)
-    l = C.CDLL(os.path.join(d, "libbamoutsim.so"))
+    l = C.CDLL(os.path.join(d, request.param))
     l.deflate_sim_member.restype = C.c_int
     l.bamenc_sim_records.restype = C.c_int64
     return l

@@ -14,7 +14,7 @@ d=/dev/shm/thj_prof_exec
 rm -rf $d; mkdir -p $d
 python tools/e2e_bench.py --pairs $pairs --keep $d > $out/${tag}_exec_e2e_plain.json 2> $out/${tag}_exec_e2e_plain.err
 rm -rf /tmp/p_segment_juncs /tmp/p_lsr_left /tmp/p_lsr_right
-(cd /tmp && python $root/tools/e2e_bench.py --pairs $pairs --keep $d --env THJ_NO_HANDOFF=1 "THJ_EXEC_PREFIX=rocprofv3 --kernel-trace --stats -d /tmp/p_{stage} -o res --" > $out/${tag}_exec_e2e_profiled.json 2> $out/${tag}_exec_e2e_profiled.err)
+(cd /tmp && python $root/tools/e2e_bench.py --pairs $pairs --keep $d --env THJ_NO_HANDOFF=1 THJ_EXIT_HANDLERS=1 "THJ_EXEC_PREFIX=rocprofv3 --kernel-trace --stats -d /tmp/p_{stage} -o res --" > $out/${tag}_exec_e2e_profiled.json 2> $out/${tag}_exec_e2e_profiled.err)
 for st in segment_juncs lsr_left; do
   db=$(find /tmp/p_$st -name '*.db' | head -1)
   [ -n "$db" ] && { echo "# rocprofv3 --kernel-trace --stats -- $st (THJ_NO_HANDOFF=1), $pairs pairs of 2x100 bp, MI355X, $tag; durations in microseconds";

@@ -62,7 +62,8 @@ inline void close_output(FILE* f, const char* what) {
 // pinned pages; measured with the time stamps of PhaseTimer::report): three processes per run, 0.6 of 3.2 s on 8 M pairs.  Nobody
 // has to wait for that: main() runs the real work in a child, the process the caller started returns the moment the child
 // reports that every output file is written and closed, and the child's teardown overlaps whatever the caller does next.  A child
-// that ends without reporting (usage errors, die()) is waited for and its exit code passed on.  THJ_NO_HANDOFF=1: one process.
+// that ends without reporting (usage errors, die()) is waited for and its exit code passed on.  THJ_NO_HANDOFF=1: one process
+// (it still leaves with _exit: the kernel frees what the runtime's exit handlers would walk through; THJ_EXIT_HANDLERS=1 runs them, for profilers).
 inline int& handoff_fd() { static int fd = -1; return fd; }
 inline int run_with_handoff(int argc, char** argv, int (*body)(int, char**)) {
     int fd[2];
@@ -103,7 +104,7 @@ inline int run_with_handoff(int argc, char** argv, int (*body)(int, char**)) {
         const unsigned char c = (unsigned char)rc;
         if (write(handoff_fd(), &c, 1) != 1) {}
         if (linger_ms > 0) usleep((useconds_t)linger_ms * 1000u);
-    } else if (getenv("THJ_NO_HANDOFF")) exit(rc);                // one process (profilers, debuggers): leave through the exit handlers
+    } else if (getenv("THJ_EXIT_HANDLERS")) exit(rc);             // a profiler wants the process to leave through the exit handlers (with THJ_NO_HANDOFF=1: one process)
     _exit(rc);
 }
 

@@ -41,6 +41,10 @@ struct GpuX {
         for (int o = 32; o; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o); v = w > v ? w : v; }
         return v;
     }
+    __device__ __forceinline__ uint32_t wave_xor(uint32_t v) {
+        for (int o = 32; o; o >>= 1) v ^= (uint32_t)__shfl_xor((int)v, o);
+        return v;
+    }
     // lanes of a wave run in lockstep and the LDS serves a wave's requests in order: only the compiler has to be kept from moving
     // memory operations across the point
     __device__ __forceinline__ void wsync() {
@@ -52,16 +56,17 @@ struct GpuX {
     __device__ __forceinline__ uint32_t lds_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
     __device__ __forceinline__ void lds_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
     __device__ __forceinline__ void glb_or(uint32_t* p, uint32_t v) { atomicOr(p, v); }
+    __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }
 };
 
 // member m of the launch = stream[ends[first + m - 1] .. ends[first + m]) (0 before the first)
 __global__ __launch_bounds__(dfl::NT) void thj_k_deflate(const uint8_t* __restrict__ stream, const int64_t* __restrict__ ends, int first, uint32_t* __restrict__ tokens,
-                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ results) {
+                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ results, unsigned long long* __restrict__ tm) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[dfl::L_END];
     const int m = (int)blockIdx.x;
     const int64_t b = first + m ? ends[first + m - 1] : 0, e = ends[first + m];
     GpuX x{(int)threadIdx.x, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6)};
-    dfl::deflate_member(x, lds, stream + b, (uint32_t)(e - b), tokens + ((size_t)m << 16), out + ((size_t)m << 14), results + 4 * (size_t)m);
+    dfl::deflate_member(x, lds, stream + b, (uint32_t)(e - b), tokens + ((size_t)m << 16), out + ((size_t)m << 14), results + 4 * (size_t)m, tm ? tm + 16 * (size_t)m : nullptr);
 }
 
 // results[4m + 3] = where member m's bytes start in the packed buffer (one workgroup; n <= 4096)
@@ -242,8 +247,26 @@ extern "C" int thj_bgzf_deflate(thj_ctx* c, int64_t n_members, const int64_t* me
     for (int64_t first = 0; first < n_members; first += mc) {
         const int nm = (int)(n_members - first < mc ? n_members - first : mc);
         HIPCHK(hipMemsetAsync(d_out, 0, (size_t)nm * (64u << 10), c->stream));
-        hipLaunchKernelGGL(thj_k_deflate, dim3((unsigned)nm), dim3(dfl::NT), 0, c->stream, (const uint8_t*)c->d_bam, (const int64_t*)d_ends, (int)first, d_tok, d_out, d_res);
+        // THJ_DEFLATE_TIMING=1: the phases' durations (wall_clock64 at the phase boundaries, thread 0 of every member), mean over the launch
+        static const bool timing = getenv("THJ_DEFLATE_TIMING") != nullptr;
+        unsigned long long* d_tm = nullptr;
+        if (timing) HIPCHK(hipMalloc((void**)&d_tm, (size_t)nm * 16 * 8));
+        hipLaunchKernelGGL(thj_k_deflate, dim3((unsigned)nm), dim3(dfl::NT), 0, c->stream, (const uint8_t*)c->d_bam, (const int64_t*)d_ends, (int)first, d_tok, d_out, d_res, d_tm);
         HIPCHK(hipGetLastError());
+        if (timing) {
+            std::vector<unsigned long long> tm((size_t)nm * 16);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(tm.data(), d_tm, tm.size() * 8, hipMemcpyDeviceToHost));
+            (void)hipFree(d_tm);
+            double ph[8] = {0}; unsigned long long t0 = ~0ull, t1 = 0;
+            for (int m = 0; m < nm; ++m) {
+                for (int k = 0; k < 8; ++k) ph[k] += (double)(tm[(size_t)m * 16 + k + 1] - tm[(size_t)m * 16 + k]);
+                if (tm[(size_t)m * 16] < t0) t0 = tm[(size_t)m * 16];
+                if (tm[(size_t)m * 16 + 8] > t1) t1 = tm[(size_t)m * 16 + 8];
+            }
+            fprintf(stderr, "[deflate] %d members, first start to last end %.1f us; mean per member (us at 100 MHz): load %.1f match %.1f totals+crc %.1f lengths %.1f crc-tree %.1f codes+header %.1f bits %.1f emit %.1f\n",
+                    nm, (double)(t1 - t0) / 100.0, ph[0] / nm / 100.0, ph[1] / nm / 100.0, ph[2] / nm / 100.0, ph[3] / nm / 100.0, ph[4] / nm / 100.0, ph[5] / nm / 100.0, ph[6] / nm / 100.0, ph[7] / nm / 100.0);
+        }
         hipLaunchKernelGGL(thj_k_member_offsets, dim3(1), dim3(1024), 0, c->stream, d_res, nm);
         hipLaunchKernelGGL(thj_k_pack_members, dim3((unsigned)nm), dim3(256), 0, c->stream, (const uint8_t*)d_out, (const uint32_t*)d_res, d_packed);
         HIPCHK(hipGetLastError());

@@ -29,9 +29,16 @@ namespace dfl {
 
 constexpr int NW = 16;                       // waves per member
 constexpr int NT = NW * 64;
-constexpr int TB = 11;                       // log2 hash-table entries per wave
+#ifndef DFL_TB
+#define DFL_TB 11
+#endif
+#ifndef DFL_WARM
+#define DFL_WARM 4096
+#endif
+constexpr int TB = DFL_TB;                   // log2 hash-table entries per wave
 constexpr uint32_t MAXN = 65536;
-constexpr uint32_t WARM = 1024;              // bytes of the previous slice whose positions a wave enters into its table first
+constexpr uint32_t WARM = DFL_WARM;              // bytes of the previous slice whose positions a wave enters into its table first
+constexpr uint32_t CAP = 20;                 // bytes of a match a lane measures by itself
 constexpr uint32_t NSYM = 320;               // histogram row: literal/length symbols at 0..285, distance symbols at 288..317
 constexpr uint32_t DSYM = 288;
 
@@ -44,18 +51,21 @@ constexpr uint32_t L_LEN = L_TOT + NSYM * 4;                 // u8  [NSYM] code 
 constexpr uint32_t L_CODE = L_LEN + NSYM;                    // u16 [NSYM] codes, bit-reversed
 constexpr uint32_t L_CL = L_CODE + NSYM * 2;                 // code-length alphabet: u32 freq[32], u8 len[32], u16 code[32]
 constexpr uint32_t L_MISC = L_CL + 32 * 4 + 32 + 32 * 2;     // u32 [64]
-constexpr uint32_t L_CRCT = L_MISC + 64 * 4;                 // u32 [256] CRC table
-constexpr uint32_t L_END = L_CRCT + 1024;
+constexpr uint32_t L_CRCT = L_MISC + 64 * 4;                 // u32 [4][256] CRC tables (slicing by four)
+constexpr uint32_t L_XP = L_CRCT + 4096;                    // u32 [64] x^(512 j) mod p, then u32 [16] x^(32768 j) mod p
+constexpr uint32_t L_END = L_XP + 80 * 4;
+#ifndef DFL_EXPERIMENT
 static_assert(L_END <= 160 * 1024, "LDS of one CU");
+#endif
 // inside L_TAB once the tables are dead
 constexpr uint32_t A_STAGE = 0;                              // u32 [NW][128]
-constexpr uint32_t A_CRC = A_STAGE + NW * 512;               // u32 [NT]
+constexpr uint32_t A_CRC = A_STAGE + NW * 512;               // u32 [NW] (room for NT)
 constexpr uint32_t A_HUF = A_CRC + NT * 4;                   // two Huffman builds side by side, HUF_BYTES each
 constexpr uint32_t HUF_BYTES = 576 * 4 + 576 * 2 + 288 * 2 + 288;
 constexpr uint32_t A_HDR = A_HUF + 2 * HUF_BYTES;            // u32 [128] header staging (a bit sink like the slices')
 static_assert(A_HDR + 512 <= ((uint32_t)NW << TB) * 2, "aliases fit the table area");
 // L_MISC words
-enum { M_NTOK = 0 /*[NW]*/, M_BITS = 16 /*[NW]*/, M_HDRBITS = 32, M_HLIT = 33, M_HDIST = 34, M_FAIL = 35, M_X2N = 40 /*[10]: x^(2^(k+9))*/ };
+enum { M_NTOK = 0 /*[NW]*/, M_BITS = 16 /*[NW]*/, M_HDRBITS = 32, M_HLIT = 33, M_HDIST = 34, M_FAIL = 35, M_CRC = 36 };
 
 enum { ST_OK = 0, ST_TOO_BIG = 1, ST_HUFF = 2 };
 
@@ -92,7 +102,7 @@ THJ_DFN uint32_t sym_extra_bits(uint32_t s) {     // by histogram index
 
 // ---- CRC-32 (the gzip polynomial, reflected)
 constexpr uint32_t CRC_POLY = 0xEDB88320u;
-THJ_DFN uint32_t crc_multmodp(uint32_t a, uint32_t b) {           // a(x) * b(x) mod p(x); a != 0
+constexpr uint32_t crc_multmodp_c(uint32_t a, uint32_t b) {         // a(x) * b(x) mod p(x); a != 0
     uint32_t m = 1u << 31, p = 0;
     for (;;) {
         if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
@@ -101,8 +111,24 @@ THJ_DFN uint32_t crc_multmodp(uint32_t a, uint32_t b) {           // a(x) * b(x)
     }
     return p;
 }
-// x^(2^k) mod p
-THJ_DFN uint32_t crc_x2n(int k) { uint32_t v = 1u << 30; for (int i = 0; i < k; ++i) v = crc_multmodp(v, v); return v; }
+THJ_DFN uint32_t crc_multmodp(uint32_t a, uint32_t b) {
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ CRC_POLY : b >> 1;
+    }
+    return p;
+}
+// x^(2^k) mod p, at compile time
+constexpr uint32_t crc_x2n_c(int k) { uint32_t v = 1u << 30; for (int i = 0; i < k; ++i) v = crc_multmodp_c(v, v); return v; }
+// x^(2^(k + 9)) mod p: what level k of the CRC tree multiplies with (its right-hand operand is 2^(k+9) bits long)
+THJ_DFN uint32_t crc_level_factor(int k) {
+    constexpr uint32_t F0 = crc_x2n_c(9), F1 = crc_x2n_c(10), F2 = crc_x2n_c(11), F3 = crc_x2n_c(12), F4 = crc_x2n_c(13), F5 = crc_x2n_c(14), F6 = crc_x2n_c(15),
+                       F7 = crc_x2n_c(16), F8 = crc_x2n_c(17), F9 = crc_x2n_c(18);
+    switch (k) { case 0: return F0; case 1: return F1; case 2: return F2; case 3: return F3; case 4: return F4; case 5: return F5; case 6: return F6;
+                 case 7: return F7; case 8: return F8; default: return F9; }
+}
 
 // ---- a wave's bit string on its way to HBM.  stg: 128 zeroed LDS words; word 0 holds global word w0's bits from `sb` on.
 struct BitSink {
@@ -224,6 +250,78 @@ THJ_DFN int cl_order(int k) {
     const uint64_t hi = 12ull | (3ull << 5) | (13ull << 10) | (2ull << 15) | (14ull << 20) | (1ull << 25) | (15ull << 30);
     return k < 12 ? (int)((lo >> (5 * k)) & 31u) : k < 19 ? (int)((hi >> (5 * (k - 12))) & 31u) : 0;
 }
+// The same contract, without the tree: Shannon lengths ceil(log2(total / count)) -- a prefix code by Kraft's inequality --, then the
+// slack of the Kraft sum given back: first to the symbols whose count is largest for their length (a threshold on count << length,
+// found by bisection), the rest class by class from the longest codes up.  Everything is wave-wide sums over five symbols a lane;
+// the code is complete (Kraft sum exactly 1) and on BAM members within a fraction of a percent of Huffman's.
+template <class X>
+THJ_DFN bool huff_lengths_fast(X& x, const uint32_t* freq, int n, int maxbits, uint8_t* len) {
+    uint32_t f[5], l[5];
+    uint32_t sum = 0, cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int i = x.lane + 64 * k; f[k] = i < n ? freq[i] : 0u; l[k] = 0; sum += f[k]; cnt += f[k] ? 1u : 0u; }
+    const uint32_t T = x.bcast(x.incl_scan(sum), 63), m = x.bcast(x.incl_scan(cnt), 63);
+    const uint32_t B = (uint32_t)maxbits, one = 1u << B;
+    if (m >= 2) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (f[k]) {
+            const uint32_t q = (T + f[k] - 1) / f[k];
+            uint32_t v = q <= 1 ? 1u : 32u - (uint32_t)__builtin_clz(q - 1);
+            l[k] = v < 1 ? 1u : v > B ? B : v;
+        }
+        uint32_t K;
+        for (;;) {
+            uint32_t kk = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (f[k]) kk += one >> l[k];
+            K = x.bcast(x.incl_scan(kk), 63);
+            if (K <= one) break;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (f[k] && l[k] < B) ++l[k];     // the clamp at maxbits overfilled the code: everything else one longer
+        }
+        uint32_t S = one - K;
+        if (S) {
+            uint32_t mx = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (f[k] && l[k] > 1) { const uint32_t key = f[k] << l[k]; mx = key > mx ? key : mx; }
+            uint32_t lo = 0, hi = x.wave_max(mx) + 1;                     // cost(hi) = 0 fits; the smallest threshold that still fits
+            while (hi - lo > 1) {
+                const uint32_t mid = lo + (hi - lo) / 2;
+                uint32_t c = 0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) if (f[k] && l[k] > 1 && (f[k] << l[k]) >= mid) c += one >> l[k];
+                if (x.bcast(x.incl_scan(c), 63) <= S) hi = mid; else lo = mid;
+            }
+            uint32_t c = 0;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) if (f[k] && l[k] > 1 && (f[k] << l[k]) >= hi) { c += one >> l[k]; --l[k]; }
+            S -= x.bcast(x.incl_scan(c), 63);
+            for (uint32_t L = B; L >= 2 && S; --L) {
+                const uint32_t unit = one >> L;
+                uint32_t mine = 0;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) mine += (f[k] && l[k] == L) ? 1u : 0u;
+                const uint32_t incl = x.incl_scan(mine), tot = x.bcast(incl, 63);
+                const uint32_t t = tot < S / unit ? tot : S / unit;
+                if (!t) continue;
+                const uint32_t before = incl - mine;
+                uint32_t quota = t > before ? (t - before < mine ? t - before : mine) : 0u;
+#pragma unroll
+                for (int k = 0; k < 5; ++k) if (quota && f[k] && l[k] == L) { --l[k]; --quota; }
+                S -= t * unit;
+            }
+        }
+        if (S) return false;
+    } else if (m == 1) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) if (f[k]) l[k] = 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { const int i = x.lane + 64 * k; if (i < n) len[i] = (uint8_t)l[k]; }
+    x.wsync();
+    return true;
+}
+
 THJ_DFN uint32_t bitrev(uint32_t v, uint32_t l) {
     uint32_t r = 0;
     for (uint32_t k = 0; k < l; ++k) { r = (r << 1) | (v & 1u); v >>= 1; }
@@ -272,10 +370,18 @@ THJ_DFN void tab_insert(X& x, uint16_t* tab, uint32_t h, uint32_t p, bool active
     }
 }
 
+#ifdef DFL_EXACT_HUFFMAN
+#define DFL_LENGTHS(x, f, n, b, l, scr) huff_lengths(x, f, n, b, l, scr)
+#else
+#define DFL_LENGTHS(x, f, n, b, l, scr) huff_lengths_fast(x, f, n, b, l)
+#endif
+
 // ---- the member.  lds: L_END bytes; in: n (1..65536) bytes; tokens: 65536 words of scratch; out: 16384 words, zeroed before the
 // launch; result[0..2] = compressed bytes, CRC-32, status (ST_*).
 template <class X>
-THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, uint32_t* tokens, uint32_t* out, uint32_t* result) {
+THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, uint32_t* tokens, uint32_t* out, uint32_t* result, unsigned long long* tm = nullptr) {
+#define DFL_MARK(k) do { if (tm && x.tid == 0) tm[k] = x.clock(); } while (0)
+    DFL_MARK(0);
     uint8_t* data = lds + L_DATA;
     uint16_t* tab = (uint16_t*)(lds + L_TAB) + ((size_t)x.wave << TB);
     uint32_t* hist = (uint32_t*)(lds + L_HIST) + (size_t)x.wave * NSYM;
@@ -287,6 +393,7 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
     uint16_t* cl_code = (uint16_t*)(lds + L_CL + 160);
     uint32_t* misc = (uint32_t*)(lds + L_MISC);
     uint32_t* crct = (uint32_t*)(lds + L_CRCT);
+    uint32_t* xp = (uint32_t*)(lds + L_XP);
     uint8_t* alias = lds + L_TAB;
 
     // ---- phase 0: the member into LDS, tables empty, histograms zero, the CRC table
@@ -298,11 +405,25 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
     }
     for (uint32_t i = (uint32_t)x.lane; i < (1u << TB); i += 64) tab[i] = 0xFFFFu;
     for (uint32_t i = (uint32_t)x.lane; i < NSYM; i += 64) hist[i] = 0;
-    if (x.tid < 256) { uint32_t c = (uint32_t)x.tid; for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1; crct[x.tid] = c; }
+    if (x.tid < 256) {
+        uint32_t c = (uint32_t)x.tid, t0[4];
+        for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+        t0[0] = c;
+        // table j: the CRC of byte tid followed by j zero bytes (bitwise here: the other tables' entries are not written yet)
+        for (int j = 1; j < 4; ++j) { for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1; t0[j] = c; }
+        for (int j = 0; j < 4; ++j) crct[j * 256 + x.tid] = t0[j];
+    }
     if (x.tid < 40) misc[x.tid] = 0;
-    if (x.tid >= 64 && x.tid < 74) misc[M_X2N + x.tid - 64] = crc_x2n(x.tid - 64 + 9);
+    if (x.wave == 2 || (x.wave == 3 && x.lane < 16)) {
+        // what a piece's (a wave's) CRC is multiplied with to stand j pieces (waves) further left: products of the level factors
+        uint32_t v = 1u << 31;
+        const int base = x.wave == 2 ? 0 : 6, nb = x.wave == 2 ? 6 : 4;
+        for (int k = 0; k < nb; ++k) if ((x.lane >> k) & 1) v = crc_multmodp(crc_level_factor(base + k), v);
+        xp[(x.wave == 2 ? 0 : 64) + x.lane] = v;
+    }
     x.sync();
 
+    DFL_MARK(1);
     // ---- phase 1: matches and the greedy parse, one slice per wave
     const uint32_t SL = (((n + NW - 1) / NW) + 63u) & ~63u;
     const uint32_t sbeg = (uint32_t)x.wave * SL < n ? (uint32_t)x.wave * SL : n;
@@ -327,15 +448,17 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
             tab_insert(x, tab, h, p, can);
             bool ok = can && cand != 0xFFFFu && cand < p && p - cand <= 32768u && ld32(data + cand) == v;
             if (!ok && can && p >= 1 && ld32(data + p - 1) == v) { cand = p - 1; ok = true; }
+            // every lane looks CAP bytes far on its own; a longer match is measured by the whole wave, and only if the parse takes it
+            // (in a run of equal bytes every lane has one: sixty-four private loops of thirty rounds each otherwise)
             uint32_t l = 1;
+            bool sat = false;
             if (ok) {
                 l = 4;
-                while (l < maxl) {
-                    const uint64_t d = ld64(data + cand + l) ^ ld64(data + p + l);
-                    if (d) { l += (uint32_t)ctz64(d) >> 3; break; }
-                    l += 8;
-                }
-                if (l > maxl) l = maxl;
+                const uint64_t d0 = ld64(data + cand + 4) ^ ld64(data + p + 4), d1 = ld64(data + cand + 12) ^ ld64(data + p + 12);
+                if (d0) l += (uint32_t)ctz64(d0) >> 3;
+                else if (d1) l += 8 + ((uint32_t)ctz64(d1) >> 3);
+                else l = CAP;
+                if (l >= maxl) l = maxl; else sat = l == CAP;
             }
             const uint32_t nvalid = send - p0 < 64u ? send - p0 : 64u;
             const uint64_t litmask = x.ballot(l == 1);
@@ -350,7 +473,17 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
                     f += run;
                 } else {
                     start |= 1ull << f;
-                    f += x.bcast(l, (int)f);
+                    uint32_t lf = x.bcast(l, (int)f);
+                    if (x.bcast(sat ? 1u : 0u, (int)f)) {
+                        const uint32_t cf = x.bcast(cand, (int)f), pf = p0 + f, mf = x.bcast(maxl, (int)f), off = CAP + 8u * (uint32_t)x.lane;
+                        uint64_t d = 0;
+                        if (off < mf) d = ld64(data + cf + off) ^ ld64(data + pf + off);
+                        const uint64_t mism = x.ballot(d != 0);
+                        if (mism) { const int fl = ctz64(mism); lf = CAP + 8u * (uint32_t)fl + x.bcast((uint32_t)(d ? ctz64(d) >> 3 : 0), fl); } else lf = mf;
+                        if (lf > mf) lf = mf;
+                        if ((uint32_t)x.lane == f) l = lf;
+                    }
+                    f += lf;
                 }
             }
             e = f - nvalid;                            // (only a step that is not the slice's last can leave a remainder)
@@ -372,6 +505,7 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
     if (x.lane == 0) misc[M_NTOK + x.wave] = ntok;
     x.sync();
 
+    DFL_MARK(2);
     // ---- phase 2: member totals; CRC pieces (the tables are dead from here on)
     for (uint32_t i = (uint32_t)x.tid; i < NSYM; i += NT) {
         uint32_t s = 0;
@@ -380,40 +514,48 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
         tot[i] = s; clen_all[i] = 0;
     }
     uint32_t* crcp = (uint32_t*)(alias + A_CRC);
-    {   // pieces aligned to the END of the member, so that every right-hand operand of a combine is a whole piece
+    {   // pieces aligned to the END of the member, so that every right-hand operand of a combine is a whole piece: level k joins
+        // groups of 2^k pieces, the right one 2^(k+9) bits long (crc_level_factor).  Here in one step per wave, the waves' results in phase 4.
         const int64_t pe = (int64_t)n - (int64_t)(NT - 1 - x.tid) * 64, pb = pe - 64;
         uint32_t c = 0;
         if (pe > 0) {
             c = 0xFFFFFFFFu;
-            for (int64_t k = pb < 0 ? 0 : pb; k < pe; ++k) c = crct[(c ^ data[k]) & 0xFFu] ^ (c >> 8);
+            if (pb >= 0) {                            // a whole piece: four bytes a step, four independent look-ups
+                const uint8_t* q = data + pb;
+                for (int k = 0; k < 16; ++k) {
+                    c ^= ld32(q + 4 * k);
+                    c = crct[768 + (c & 0xFFu)] ^ crct[512 + ((c >> 8) & 0xFFu)] ^ crct[256 + ((c >> 16) & 0xFFu)] ^ crct[c >> 24];
+                }
+            } else for (int64_t k = 0; k < pe; ++k) c = crct[(c ^ data[k]) & 0xFFu] ^ (c >> 8);
             c ^= 0xFFFFFFFFu;
         }
-        crcp[x.tid] = c;
+        // crc(A || B) = crc(A) * x^(bits of B) ^ crc(B): every piece moved to the end of its wave's range, then XORed together
+        c = x.wave_xor(crc_multmodp(xp[63 - x.lane], c));
+        if (x.lane == 0) crcp[x.wave] = c;
     }
     if (x.tid < 128) ((uint32_t*)(alias + A_HDR))[x.tid] = 0;
     x.sync();
 
-    // ---- phase 3: code lengths (wave 0: literal/length, wave 1: distance), then the CRC tree
-    if (x.wave == 0) { if (!huff_lengths(x, tot, 286, 15, clen_all, alias + A_HUF) && x.lane == 0) misc[M_FAIL] = ST_HUFF; }
+    DFL_MARK(3);
+    // ---- phase 3: code lengths (wave 0: literal/length, wave 1: distance)
+    if (x.wave == 0) { if (!DFL_LENGTHS(x, tot, 286, 15, clen_all, alias + A_HUF) && x.lane == 0) misc[M_FAIL] = ST_HUFF; }
     else if (x.wave == 1) {
-        if (!huff_lengths(x, tot + DSYM, 30, 15, clen_all + DSYM, alias + A_HUF + HUF_BYTES) && x.lane == 0) misc[M_FAIL] = ST_HUFF;
+        if (!DFL_LENGTHS(x, tot + DSYM, 30, 15, clen_all + DSYM, alias + A_HUF + HUF_BYTES) && x.lane == 0) misc[M_FAIL] = ST_HUFF;
         // no distance symbol at all: one unused 1-bit code (an inflater accepts that; an empty distance alphabet not every one does)
         bool any = false;
         for (int i = 0; i < 30; ++i) any = any || clen_all[DSYM + i] != 0;
         if (!any && x.lane == 0) clen_all[DSYM] = 1;
     }
-    for (int k = 0; k < 10; ++k) {                     // level k joins groups of 2^k pieces; the right one is 2^(k+9) bits long
-        const int s = 1 << k;
-        if ((x.tid & (2 * s - 1)) == 0) {
-            const uint32_t a = crcp[x.tid], b = crcp[x.tid + s];
-            crcp[x.tid] = crc_multmodp(misc[M_X2N + k], a) ^ b;
-        }
-        x.sync();
-    }
-
+    x.sync();
+    DFL_MARK(4);
+    DFL_MARK(5);
     // ---- phase 4: the codes (waves 1, 2), and on wave 0 the code-length code and the block header
     if (x.wave == 1) huff_codes(x, clen_all, 286, code_all);
     else if (x.wave == 2) huff_codes(x, clen_all + DSYM, 30, code_all + DSYM);
+    else if (x.wave == 3) {
+        uint32_t c = x.wave_xor(x.lane < NW ? crc_multmodp(xp[64 + NW - 1 - x.lane], crcp[x.lane]) : 0u);
+        if (x.lane == 0) misc[M_CRC] = c;
+    }
     else if (x.wave == 0) {
         int hlit = 257, hdist = 1;
         {
@@ -436,7 +578,7 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
             if (popc64(used) == 1 && x.lane == 0) cl_freq[(used & 1ull) ? 1 : 0] = 1;
             x.wsync();
         }
-        if (!huff_lengths(x, cl_freq, 19, 7, cl_len, alias + A_HUF) && x.lane == 0) misc[M_FAIL] = ST_HUFF;
+        if (!DFL_LENGTHS(x, cl_freq, 19, 7, cl_len, alias + A_HUF) && x.lane == 0) misc[M_FAIL] = ST_HUFF;
         huff_codes(x, cl_len, 19, cl_code);
         int hclen = 4;
         {
@@ -464,6 +606,7 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
     }
     x.sync();
 
+    DFL_MARK(6);
     // ---- phase 5: every slice's bit length
     {
         uint32_t bits = 0;
@@ -480,6 +623,7 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
     const uint32_t cbytes = (total_bits + 7) >> 3;
     const bool fits = cbytes <= MAXN - 26 && misc[M_FAIL] == 0;      // bgzf.c: a member is at most 64 KiB with its 26 bytes of envelope
 
+    DFL_MARK(7);
     // ---- phase 6: the slices' bits, in parallel at their final places
     if (fits) {
         BitSink s;
@@ -504,7 +648,10 @@ THJ_DFN void deflate_member(X& x, uint8_t* lds, const uint8_t* in, uint32_t n, u
         if (x.wave == NW - 1) sink_put(x, s, x.lane == 0 ? code_all[256] : 0, x.lane == 0 ? clen_all[256] : 0);
         sink_close(x, s);
     }
-    if (x.tid == 0) { result[0] = cbytes; result[1] = crcp[0]; result[2] = misc[M_FAIL] ? misc[M_FAIL] : (uint32_t)(fits ? ST_OK : ST_TOO_BIG); }
+    x.sync();
+    DFL_MARK(8);
+    if (x.tid == 0) { result[0] = cbytes; result[1] = misc[M_CRC]; result[2] = misc[M_FAIL] ? misc[M_FAIL] : (uint32_t)(fits ? ST_OK : ST_TOO_BIG); }
+#undef DFL_MARK
 }
 
 }  // namespace dfl
