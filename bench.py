@@ -222,16 +222,21 @@ def parse_args():
     ap.add_argument("--coverage-search", type=float, default=0.0, metavar="FRAC",
                     help="run segment_juncs' coverage search too (what tophat does for reads of fewer than three segments, "
                          "e.g. --read-len 50), with the first FRAC of each side's reads playing the initially unmapped reads")
-    ap.add_argument("--multihit-frac", type=float, default=0.0,
-                    help="fraction of reads whose segment hits are all reported at two loci (the genome's second half becomes a copy "
-                         "of the first): exercises the multihit tier; 0 = BASELINE configs[1] as specified")
+    ap.add_argument("--plain", action="store_true",
+                    help="the workload of rounds 1-2: no multihits, no indel reads (--multihit-frac 0 --indel-frac 0)")
+    ap.add_argument("--multihit-frac", type=float, default=0.05,
+                    help="fraction of the pairs drawn from a planted repeat family (SURVEY 8d: multihits from planted repeats up to 41): every "
+                         "segment hit of such a read is reported at 2..41 copies (see --max-copies); 0 = none")
+    ap.add_argument("--max-copies", type=int, default=41,
+                    help="copies of the repeat family in the genome (41: 80 %% of the family's reads have 2 hits per segment, 15 %% 3..8, 4 %% "
+                         "9..40, 1 %% 41 -- dropped whole by max_seg_multihits); 2: the two-copy genome of round 2 (second half = first half)")
     ap.add_argument("--fusion-search", action="store_true",
                     help="run long_spanning_reads' stage with fusion search on (the shape of configs[3]): reads tiers 0 / 1 cannot join go "
                          "through the fusion branches (thj_k_stitch_fusion) against an empty fusion list")
     ap.add_argument("--fusion-frac", type=float, default=0.0, metavar="FRAC",
                     help="with --fusion-search: this fraction of the pairs gets a chimeric left read (configs[3]: 0.02); the step then "
                          "also runs segment_juncs' fusion kernel and hands its fusions to the spanning stage")
-    ap.add_argument("--indel-frac", type=float, default=0.0, metavar="FRAC",
+    ap.add_argument("--indel-frac", type=float, default=0.03, metavar="FRAC",
                     help="this fraction of the pairs gets a left read with a 1..3-base deletion near the end of a segment (found by the indel "
                          "search of stage 1, closed with a D op in stage 2)")
     ap.add_argument("--no-hit-heads", action="store_true",
@@ -243,7 +248,11 @@ def parse_args():
     ap.add_argument("--e2e-pairs", type=int, default=10_000_000,
                     help="also run the drop-in executables end to end (files in, files out: the metric as SURVEY 8d words it) on "
                          "generated files of this many pairs; 0 skips the leg.  Reported as the `e2e` object, never as `value`")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.plain:
+        a.multihit_frac = 0.0
+        a.indel_frac = 0.0
+    return a
 
 
 def spawn_ranks(args):
@@ -354,6 +363,8 @@ def e2e_leg(args):
         keep = ("pairs", "input_bytes", "gen_seconds", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s",
                 "both_stages_s", "junctions", "junctions_bed_s", "junctions_bed_lines")
         out = {k: res[k] for k in keep}
+        out["stage_timing"] = {st: [l for l in res.get(st + "_log_tail", []) if l.startswith("[timing]") or l.startswith("[worker-seconds]") or "made on the device" in l]
+                               for st in ("segment_juncs", "long_spanning_reads_left", "long_spanning_reads_right")}
         out["value"] = res["pairs"] / res["both_stages_s"]
         out["unit"] = "read-pairs/s (wall clock of both executables, files in -> files out, 1 GPU, host CPUs: %s)" % (_cpu_quota(),)
         outs = ("out.juncs", "out.insertions", "out.deletions", "span_left.bam", "span_right.bam", "junctions.bed")
@@ -648,7 +659,18 @@ def run_rank(args, rank, world, local_rank, control, shared):
     genome_len = int(sum(contig_lens))
     seqs, genes = make_scale_genome(1, contig_lens, args.introns, exon_len=args.exon_len, intron_max=args.intron_max)
     dup_shift = 0
-    if args.multihit_frac > 0:                       # two-copy genome: [H, 2H) := [0, H), genes of the first copy only
+    if args.multihit_frac > 0 and args.max_copies > 2:
+        # a planted repeat family: the first 1/96 of contig 0, max_copies copies back to back; its genes are the family,
+        # the genes behind the last copy stay unique, the ones in between are overwritten and dropped
+        dup_shift = len(seqs[0]) // 96
+        if dup_shift <= max(500000, args.intron_max + 1) + 2 * args.exon_len:
+            raise SystemExit("--max-copies: the genome is too small for a repeat family whose copies lie further apart than the longest intron")
+        for k in range(1, args.max_copies):
+            seqs[0][k * dup_shift:(k + 1) * dup_shift] = seqs[0][:dup_shift]
+        fam = (genes[:, 0] == 0) & (genes[:, 3] + args.exon_len + 1000 < dup_shift)
+        uniq = (genes[:, 0] != 0) | (genes[:, 1] >= args.max_copies * dup_shift + 1000)
+        genes = genes[fam | uniq]
+    elif args.multihit_frac > 0:                     # two-copy genome: [H, 2H) := [0, H), genes of the first copy only
         dup_shift = len(seqs[0]) // 2
         seqs[0][dup_shift:2 * dup_shift] = seqs[0][:dup_shift]
         genes = genes[(genes[:, 0] == 0) & (genes[:, 3] + args.exon_len + 1000 < dup_shift)]
@@ -660,7 +682,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     ctx.upload_genome(pg)
     w = make_device_workload(100 + rank, seqs, genes, None, args.pairs, dev, read_len=args.read_len, seg_len=25,
                              inner_mean=50.0, inner_sd=20.0, exon_len=args.exon_len, multi_frac=args.multihit_frac, dup_shift=dup_shift,
-                             fusion_frac=args.fusion_frac if args.fusion_search else 0.0, indel_frac=args.indel_frac)
+                             fusion_frac=args.fusion_frac if args.fusion_search else 0.0, indel_frac=args.indel_frac, max_copies=args.max_copies)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     max_intron = max(500000, args.intron_max + 1)
@@ -791,6 +813,16 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # per closure.  Counters come from the kernels (tier sizes of the last launch, record count of the step).
     n_lean, n_multi, n_gen = ctx.span_tier_counts()
     hits_per_read = float(int(w["left"]["span_off"][-1]) + int(w["right"]["span_off"][-1])) / (2.0 * args.pairs)
+    # reads with a segment that has several hits carry most of the hit records of a mixed workload: the multihit tier's share of
+    # the hit bytes is counted from them, not from the average read
+    multi_reads = multi_hits = 0
+    for sd in ("left", "right"):
+        cells = (w[sd]["span_off"][1:] - w[sd]["span_off"][:-1]).reshape(args.pairs, nseg)
+        mr = (cells.max(dim=1).values > 1)
+        multi_reads += int(mr.sum())
+        multi_hits += int(cells[mr].sum())
+    hits_single = (hits_per_read * 2.0 * args.pairs - multi_hits) / max(1.0, 2.0 * args.pairs - multi_reads)      # per read without multihits
+    hits_multi = multi_hits / max(1.0, float(multi_reads))                                                       # per read with
     rec_per_read = n_alns / (2.0 * args.pairs)
     # the record: one 64-B lead line (thj_aln_slot); the tail line is written only for > 4 cigar ops or an MD string of > 24
     # characters, which this workload's reads do not have
@@ -798,8 +830,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
     n_t0 = args.pairs - n_lean - n_multi
     hit_b = 16.0 if use_heads else 32.0              # tier 0 streams the dense 16-byte heads when the batch has them
     t0_alg = 4.0 * (args.pairs * nseg + 1) + hit_b * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
-    t1_alg = n_lean * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
-    t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64) + 4.0 * n_gen
+    t1_alg = n_lean * (4 + 4.0 * (nseg + 1) + 32.0 * hits_single + per_read_done + 64)
+    t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * (hits_multi if multi_reads else hits_per_read) + per_read_done + 64) + 4.0 * n_gen
     t3_alg = n_gen * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     # thj_k_segjuncs_rescue: per (hit, mate hit) pair the read, its CSR row + hits, the mate hit and ~3 genome lines of flank
     resc_alg = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 192)
@@ -821,8 +853,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
     seg_8d = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1) + (cnt.n_windows / n_launch) * (128 + rl_bytes) \
         + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) + 16.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
     t0_8d = 4.0 * (args.pairs * nseg + 1) + 16.0 * hits_per_read * args.pairs + n_t0 * done_8d + 4.0 * (n_lean + n_multi)
-    t1_8d = n_lean * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64)
-    t2_8d = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64) + 4.0 * n_gen
+    t1_8d = n_lean * (4 + 4.0 * (nseg + 1) + 16.0 * hits_single + done_8d + 64)
+    t2_8d = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read) + done_8d + 64) + 4.0 * n_gen
     t3_8d = n_gen * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64)
     resc_8d = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 128)
     for k, b8 in zip(kernels, (seg_8d, resc_8d, t0_8d, t1_8d, t2_8d, t3_8d)):
@@ -838,8 +870,11 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950: traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB,
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r02_pmc_traffic.json"))))
-        if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and use_heads and pm["config"] == {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}:
+        pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r02_pmc_traffic.json" if args.multihit_frac == 0 and args.indel_frac == 0 else "r03_pmc_traffic.json"))))
+        want_cfg = {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}
+        if args.multihit_frac > 0 or args.indel_frac > 0:
+            want_cfg.update(multihit_frac=args.multihit_frac, indel_frac=args.indel_frac, max_copies=args.max_copies)
+        if args.read_len == 100 and args.genome == "chr20" and use_heads and not args.fusion_search and not n_ium and pm["config"] == want_cfg:
             for k in kernels:
                 c = pm["kernels"].get(k["kernel"])
                 if c:
@@ -850,13 +885,19 @@ def run_rank(args, rank, world, local_rank, control, shared):
         pass
     # the dominant kernel: the longest launch; kernels within 5 % of it count as tied (tiers 0 and 1 trade places from
     # run to run) and the tie goes to the one that moves the most bytes -- all kernels are listed under "kernels" anyway
-    t_max = max(k["avg_kernel_ms"] for k in kernels)
-    dom = max((k for k in kernels if k["avg_kernel_ms"] >= 0.95 * t_max), key=lambda k: k["algorithmic_bytes_8d_per_launch"])
+    # (a tier nothing was routed to still launches, on an empty work-list: it is listed with "no_work" and cannot be the dominant kernel)
+    for k in kernels:
+        if k["algorithmic_bytes_8d_per_launch"] <= 0:
+            k["no_work"] = True
+    t_max = max(k["avg_kernel_ms"] for k in kernels if not k.get("no_work"))
+    dom = max((k for k in kernels if not k.get("no_work") and k["avg_kernel_ms"] >= 0.95 * t_max), key=lambda k: k["algorithmic_bytes_8d_per_launch"])
 
     workload_text = ("%s: %d x 2x%d bp PE synthetic vs %d bp %s genome per GPU, inputs resident in HBM; both stages on device: "
                      "segment_juncs (main + rescue kernels, event dedup+sort%s) then long_spanning_reads (four stitch tiers fed "
                      "device-to-device with the junction set; records land in BAM order)"
-                     % ("configs[1]" if args.read_len == 100 and args.genome == "chr20" and args.multihit_frac == 0 and not n_ium else "shape of another config", args.pairs,
+                     % (("configs[1]" + ("" if args.multihit_frac == 0 and args.indel_frac == 0 else " with SURVEY 8(d)'s mix (%g %% of the pairs from a %d-copy repeat family, "
+                                          "%g %% deletion reads)" % (100 * args.multihit_frac, args.max_copies, 100 * args.indel_frac)))
+                        if args.read_len == 100 and args.genome == "chr20" and not n_ium and not args.fusion_search else "shape of another config", args.pairs,
                         args.read_len, genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
                         ", one RCCL all-gather of the event sets inside the C ABI" if use_comm else ""))
     if not use_heads:
@@ -942,7 +983,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_text,
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
-                       "fusion_search": bool(args.fusion_search), "fusion_frac": args.fusion_frac, "indel_frac": args.indel_frac, "fusions_found": n_fusions[0], "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
+                       "fusion_search": bool(args.fusion_search), "fusion_frac": args.fusion_frac, "indel_frac": args.indel_frac, "multihit_frac": args.multihit_frac, "max_copies": args.max_copies if args.multihit_frac > 0 else 1, "fusions_found": n_fusions[0], "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"), "traffic_low": dom.get("traffic_low"),

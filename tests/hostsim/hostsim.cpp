@@ -197,7 +197,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
         }
         if (st == SPAN_NEED_GENERIC && mode != 1) {          // tier 3, first attempt: DFS over global memory, lean joins
             SpanHit stage[SPAN_MAXSEG];
-            st = span_read_multi(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+            st = span_read_multi<48>(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                  read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
         }
         if (st == SPAN_NEED_GENERIC) {                       // tier 3: the general arrays

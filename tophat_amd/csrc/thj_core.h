@@ -405,11 +405,19 @@ enum { SLOT_NONE = -1, SLOT_BREAK = -2 };
 // One (left hit, mate hit) pair of the mate-anchored rescue (segment_juncs.cpp:3406-3492).
 // Writes the two pseudo-hit lefts (fwd, rev) or SLOT_NONE; fwd = SLOT_BREAK when the
 // reference `break`s out of the mate loop at this pair.  rp = the read's planes.
+// The part that does not look at the left hit: where the read's last bases (or their reverse complement) lie in the mate hit's
+// flank.  A read with forty hits in its first segment and one mate hit asks forty times for the same answer: callers keep it.
+THJ_HD bool rescue_scan(const Genome& g, const Params& p, const u64* rp, int W, int rl, const Hit& rh, int32_t& fwd_left, int32_t& rev_left);
 THJ_HD bool rescue_pair(const Genome& g, const Params& p, const u64* rp, int W, int rl, const Hit& lh, const Hit& rh,
                         int32_t& fwd_left, int32_t& rev_left) {
     fwd_left = SLOT_NONE;
     rev_left = SLOT_NONE;
     if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) return false;      // :3414
+    return rescue_scan(g, p, rp, W, rl, rh, fwd_left, rev_left);
+}
+THJ_HD bool rescue_scan(const Genome& g, const Params& p, const u64* rp, int W, int rl, const Hit& rh, int32_t& fwd_left, int32_t& rev_left) {
+    fwd_left = SLOT_NONE;
+    rev_left = SLOT_NONE;
     int32_t clen = g_len(g, rh.ref_id);
     if (clen == 0) return false;
     int part = p.inner_dist_std_dev > p.inner_dist_mean ? p.inner_dist_std_dev - p.inner_dist_mean : 0;
@@ -490,6 +498,18 @@ THJ_HD void rv_foreach(const ReadView& v, int s, F f) {
                 if (!f(h)) return;
             }
         }
+}
+
+// every stride-th hit of the list, from the first-th on (a wave sharing one read's enumeration: lane, 64); f cannot stop it
+template <class F>
+THJ_HD void rv_foreach_strided(const ReadView& v, int s, int first, int stride, F f) {
+    if (stride == 1) { rv_foreach(v, s, [&](const Hit& h) { f(h); return true; }); return; }
+    if (!v.rescue || s == 0) {
+        for (uint32_t k = v.so[s] + (uint32_t)first; k < v.so[s + 1]; k += (uint32_t)stride) { Hit h = v.hits[k]; f(h); }
+        return;
+    }
+    int idx = 0;
+    rv_foreach(v, s, [&](const Hit& h) { if (idx++ % stride == first) f(h); return true; });
 }
 
 THJ_HD int rv_count(const ReadView& v, int s) {
@@ -612,15 +632,16 @@ THJ_HD bool read_is_trivial(const Params& p, const ReadView& v) {
 // The body of find_gaps after the rescue (segment_juncs.cpp:3499-3617).
 // Sink: window(ref, wl, wr, antisense, support_start, support_len).
 template <class Sink>
-THJ_HD void gaps_enumerate(const Params& p, const ReadView& v, Sink& sink) {
+THJ_HD void gaps_enumerate(const Params& p, const ReadView& v, Sink& sink, int first = 0, int stride = 1) {
     const int L = p.segment_length;
     if (p.bowtie2)                                                            // :3499-3506
         for (int s = 0; s < v.size; ++s) {
             int n = (!v.rescue || s == 0) ? rv_count_raw(v, s) : rv_count(v, s);
             if (n > p.max_seg_multihits) return;
         }
+    // (first, stride): the hits `bh` this caller takes -- every hit is handled on its own, so a wave can share a read with many
     for (int s = 0; s < v.size; ++s) {
-        rv_foreach(v, s, [&](const Hit& bh) {
+        rv_foreach_strided(v, s, first, stride, [&](const Hit& bh) {
             bool found = (s == v.size - 1);
             int n_drs = 0, n_rrs = 0;
             const bool banti = hit_anti(bh);
@@ -661,7 +682,6 @@ THJ_HD void gaps_enumerate(const Params& p, const ReadView& v, Sink& sink) {
                     });
                 }
             }
-            return true;
         });
     }
 }
@@ -670,7 +690,7 @@ THJ_HD void gaps_enumerate(const Params& p, const ReadView& v, Sink& sink) {
 // Sink: indel(i, left_idx, right_idx, li, ri, antisense, plen, is_deletion)
 // with left/right already swapped for antisense pairs (:2914-2920).
 template <class Sink>
-THJ_HD void indels_enumerate(const Params& p, const ReadView& v, Sink& sink) {
+THJ_HD void indels_enumerate(const Params& p, const ReadView& v, Sink& sink, int first = 0, int stride = 1) {
     const int L = p.segment_length;
     if (v.nseg < 2) return;
     for (int i = 0; i + 2 < v.nseg; ++i) {                                    // :2856
@@ -679,7 +699,7 @@ THJ_HD void indels_enumerate(const Params& p, const ReadView& v, Sink& sink) {
         int start = i * L;
         if (start > v.rl) return;
         int plen = v.rl - start < 2 * L ? v.rl - start : 2 * L;
-        for (uint32_t li = lb; li < le; ++li) {
+        for (uint32_t li = lb + (uint32_t)first; li < le; li += (uint32_t)stride) {
             Hit lh = v.hits[li];
             for (uint32_t ri = le; ri < re; ++ri) {
                 Hit rh = v.hits[ri];

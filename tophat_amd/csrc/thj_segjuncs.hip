@@ -137,6 +137,7 @@ __device__ __forceinline__ ReadView make_view(const DevBatch& b, int r) {
 
 static constexpr int TPB = 256;
 static constexpr int QCAP = 512;           // task queue entries (LDS); a typical tile of 256 reads adds a few dozen
+static constexpr int HEAVY_HITS = 24;      // a read with more hits than this is enumerated by a wave, not by a thread
 
 struct Queue {
     uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e;
@@ -223,7 +224,7 @@ __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, cons
 // Reads that take the mate-anchored rescue (find_gaps :3330-3497) are few and their map_read_to_contig scans long,
 // so the main kernel only lists them -- per workgroup, in its own slice of `list`, no global append counter -- and
 // thj_k_segjuncs_rescue handles them densely afterwards.
-struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; };
+struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; int32_t* slot_pool; };
 
 // Main kernel.  One workgroup walks tiles of 256 consecutive reads.
 //   stage:     find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
     uint32_t* s_so = q_e + QCAP;
     uint4* s_hits = (uint4*)(s_so + ((TPB * b.nseg + 1 + 3) & ~3));
     uint32_t* s_work = (uint32_t*)(s_hits + hit_cap);
-    __shared__ unsigned int q_n, s_nwork, s_nresc;
+    __shared__ unsigned int q_n, s_nwork, s_nresc, s_nheavy;
     __shared__ unsigned int s_stat[4];
+    __shared__ uint16_t s_heavy[TPB];                 // reads of the tile with more than HEAVY_HITS hits: enumerated by a wave each
     const int tid = threadIdx.x;
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) { q_n = 0; s_nresc = 0; }
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
         const int n_so = tile_reads * b.nseg + 1;
         __syncthreads();                                  // the previous tile's readers are done with the LDS copy
         for (int i = tid; i < n_so; i += TPB) s_so[i] = b.seg_off[(size_t)r0 * b.nseg + i];
-        if (tid == 0) s_nwork = 0;
+        if (tid == 0) { s_nwork = 0; s_nheavy = 0; }
         __syncthreads();
         const unsigned int q_before = q_n;               // tasks carried over from earlier tiles
         const uint32_t h0 = s_so[0], nh_tile = s_so[n_so - 1] - h0;
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             if (!read_is_trivial(p, v)) {
                 bool wants = false;
                 if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants) to_rescue = true;
+                else if (v.so[v.nseg] - v.so[0] > (uint32_t)HEAVY_HITS && !THJ_EXPF(1 << 24)) s_heavy[atomicAdd(&s_nheavy, 1u)] = (uint16_t)tid;
                 else to_work = true;
             }
         }
@@ -318,6 +321,19 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             if (do_gaps) gaps_enumerate(p, v, qs);
             my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
+        // ---- reads with many hits (multihits: up to 41 a segment, pairs of them by the hundred): a wave shares one, lane = hit.
+        // One thread walking 40 x 40 pairs three times over held its whole tile up (39 ms a step with 0.25 % such reads).
+        for (unsigned int h = (unsigned int)tid >> 6; h < s_nheavy; h += TPB / 64) {
+            const int lr = (int)s_heavy[h], hr = r0 + lr;
+            ReadView hv = make_view(b, hr);
+            hv.so = s_so + lr * b.nseg;
+            hv.hits = tile_hits;
+            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)hr, staged ? h0 : 0u, 0u, 0u};
+            if (!THJ_EXPF(1 << 17)) indels_enumerate(p, hv, qs, tid & 63, 64);
+            bool wants = false;
+            if (!THJ_EXPF(1 << 18) && gaps_prepare(p, hv, wants)) gaps_enumerate(p, hv, qs, tid & 63, 64);
+            my_windows += qs.n_windows; my_indels += qs.n_indels;
+        }
         __syncthreads();
         if (q_n > (unsigned)QCAP) {
             // the queue overflowed (multihit-heavy tile): drop this tile's queued tasks and run the tile un-queued.
@@ -326,6 +342,16 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
                 InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
                 indels_enumerate(p, v, is);
                 if (do_gaps) gaps_enumerate(p, v, is);
+            }
+            for (unsigned int h = (unsigned int)tid >> 6; h < s_nheavy; h += TPB / 64) {
+                const int lr = (int)s_heavy[h], hr = r0 + lr;
+                ReadView hv = make_view(b, hr);
+                hv.so = s_so + lr * b.nseg;
+                hv.hits = tile_hits;
+                InlineSink<WIDE> is{g, p, hv, ev, b.ordinal_base + (uint32_t)hr};
+                indels_enumerate(p, hv, is, tid & 63, 64);
+                bool wants = false;
+                if (gaps_prepare(p, hv, wants)) gaps_enumerate(p, hv, is, tid & 63, 64);
             }
             __syncthreads();
             if (tid == 0) q_n = q_before;
@@ -351,6 +377,8 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
 // pairs than fit recompute them as rv_foreach walks the pseudo-hit list -- then the general enumeration runs with the
 // rescued hits in place and its windows are queued and executed as in the main kernel.
 static constexpr int RPT = 4;             // rescue pairs per thread kept in LDS
+static constexpr int GPT = 64;            // ... and in the thread's slice of an HBM pool, for reads with more (a read with 41 hits in its first segment: multihits)
+static constexpr int RESCUE_GRID = 1024;  // workgroups of the rescue kernel at the most
 static constexpr int MAX_LISTS = 2048;    // workgroups of the main kernel = slices of the rescue list
 
 template <bool WIDE>
@@ -406,14 +434,29 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             if (do_gaps) {
                 if (wants) {
                     const int n_left = rv_count_raw(v, 0);
-                    const bool fits = (int64_t)n_left * v.n_mate <= RPT;
-                    int32_t* mine = s_slots + tid * RPT * 2;
+                    // the pairs' outcomes are kept (LDS, or HBM for a read with many hits): gaps_enumerate asks for them once per
+                    // (hit, partner) it looks at, and recomputing a flank scan each time made a 16-copy read cost 200 of them
+                    const bool fits = (int64_t)n_left * v.n_mate <= GPT;
+                    int32_t* mine = (int64_t)n_left * v.n_mate <= RPT ? s_slots + tid * RPT * 2 : rl.slot_pool + ((size_t)blockIdx.x * TPB + tid) * (GPT * 2);
                     unsigned int local = 0;
+                    // the scan of a mate hit's flank is the same for every left hit on the mate's contig and opposite strand: kept
+                    // for the first four mate hits (a read of a repeat family has tens of left hits and one or two mate hits)
+                    int32_t sc_f[4], sc_rv[4]; bool sc_ok[4]; unsigned int sc_have = 0;
                     for (int l = 0; l < n_left; ++l)
                         for (int m = 0; m < v.n_mate; ++m) {
-                            int32_t f, rv;
-                            if (THJ_EXPF(1 << 22)) { f = SLOT_NONE; rv = SLOT_NONE; }
-                            else if (rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m], f, rv)) ++local;
+                            int32_t f = SLOT_NONE, rv = SLOT_NONE;
+                            if (THJ_EXPF(1 << 22)) { }
+                            else {
+                                const Hit lh = v.hits[v.so[0] + l], rh = v.mate[m];
+                                if (lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) {        // :3414
+                                    bool scanned;
+                                    if (m < 4) {
+                                        if (!((sc_have >> m) & 1u)) { sc_ok[m] = rescue_scan(g, p, v.rp, v.W, v.rl, rh, sc_f[m], sc_rv[m]); sc_have |= 1u << m; }
+                                        f = sc_f[m]; rv = sc_rv[m]; scanned = sc_ok[m];
+                                    } else scanned = rescue_scan(g, p, v.rp, v.W, v.rl, rh, f, rv);
+                                    if (scanned) ++local;
+                                }
+                            }
                             if (fits) { mine[2 * (l * v.n_mate + m)] = f; mine[2 * (l * v.n_mate + m) + 1] = rv; }
                             if (f == SLOT_BREAK) break;                  // the reference leaves the mate loop here (:3431-3450)
                         }
@@ -649,7 +692,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     free_tables(c);
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
-    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_fus_ignore);
+    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_rescue_slots); hipFree(c->d_fus_ignore);
     if (c->probe_ev) hipEventDestroy(c->probe_ev);
     hipHostFree(c->h_pinned);
     thj_span_free(c); thj_bamout_free(c);
@@ -901,12 +944,14 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     }
     rl.list = c->d_rescue_list;
     rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap;
+    if (b.mate_off && !c->d_rescue_slots) HIPCHK(hipMalloc((void**)&c->d_rescue_slots, (size_t)RESCUE_GRID * TPB * GPT * 2 * sizeof(int32_t)));
+    rl.slot_pool = c->d_rescue_slots;
     const bool wide = p.segment_length > 32;
     if (wide) hipLaunchKernelGGL(thj_k_segjuncs<true>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
     else hipLaunchKernelGGL(thj_k_segjuncs<false>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
     if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
     if (b.mate_off) {
-        const int rgrid = grid < 1024 ? grid : 1024;
+        const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
         if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
         else hipLaunchKernelGGL(thj_k_segjuncs_rescue<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
     }

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256, 3) void thj_k_stitch_multihit(Genome g, Params
 // Tier 3: what is left.  First the same DFS with its candidates read from global memory (any number of hits) and
 // lean joins (span_read_multi); reads whose joined alignments need more than LEAN_C cigar ops, or that have more than
 // MULTI_MAXJOIN of them, are redone on the general arrays (span_read).
+static constexpr int GENERIC_MAXJOIN = 48;     // joined alignments of a read on tier 3's lean pass (40 copies of a repeat and some)
 __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
     extern __shared__ uint4 lds_stage[];          // nseg hits per thread: the chain under construction
     __shared__ unsigned int s_off[MAX_SLICES + 1];
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, 
         const uint32_t* so = b.seg_off + (size_t)r * b.nseg;
         const u64* rp = b.planes + (size_t)r * 3 * b.W;
         const uint8_t* q = b.quals + (size_t)r * b.qual_stride;
-        int st = span_read_multi(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, stage, sink);
+        int st = span_read_multi<GENERIC_MAXJOIN>(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, stage, sink);
         if (st == SPAN_NEED_GENERIC) st = span_read(g, p, S, b.hits, so, b.nseg, rp, b.W, (int)b.read_len[r], q, (uint32_t)r, sink);
         if (st == SPAN_TOO_MANY_JOINED && defer_huge(t, (uint32_t)r)) continue;
         sink.done((uint32_t)r);

@@ -1181,7 +1181,9 @@ THJ_HD int span_read_multi_staged(const Genome& g, const Params& p, const SpanSe
     return multi_finish(g, p, joined, nj, nsegs, rp, W, rl, qual, read_idx, sink);
 }
 
-template <class Sink>
+// MAXJ: joined alignments a read may have here.  Tier 3 gives every copy of a 40-copy repeat its alignment (max_seg_multihits = 40):
+// with room for 16 such a read ran the whole search, gave up at the 17th and ran it again through span_read's general arrays.
+template <int MAXJ = MULTI_MAXJOIN, class Sink>
 THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
                            const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHit* stage, Sink& sink) {
     if (so[1] == so[0]) return SPAN_OK;                         // worker iterates over first-segment groups
@@ -1194,7 +1196,7 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
             if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;   // :2625-2632
     if (THJ_EXPF(2048)) return SPAN_OK;
     const int L = p.segment_length;
-    RAln joined[MULTI_MAXJOIN]; int nj = 0;
+    RAln joined[MAXJ]; int nj = 0;
     uint32_t idx[SPAN_MAXSEG];               // next candidate of each depth
     int pleft[SPAN_MAXSEG], pright[SPAN_MAXSEG];   // left / right of the hit chosen at each depth
     for (uint32_t i0 = so[0]; i0 < so[1]; ++i0) {                // :2634-2664
@@ -1216,7 +1218,7 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
                 const int jr = lean_join(g, p, S, stage, nsegs, rp, W, rl, res);
                 if (jr == LJ_PUNT) return SPAN_NEED_GENERIC;
                 if (jr == LJ_OK && valid_hit(p, res)) {
-                    if (nj >= MULTI_MAXJOIN) return SPAN_NEED_GENERIC;
+                    if (nj >= MAXJ) return SPAN_NEED_GENERIC;
                     joined[nj++] = res;
                 }
                 --depth;

@@ -504,7 +504,7 @@ def make_scale_genome(seed: int, contig_lens: Sequence[int], n_introns: int, int
 def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int, device, read_len: int = 100,
                          seg_len: int = 25, inner_mean: float = 50.0, inner_sd: float = 20.0, err: float = 0.01,
                          exon_len: int = 600, chunk: int = 1 << 20, multi_frac: float = 0.0, dup_shift: int = 0,
-                         fusion_frac: float = 0.0, indel_frac: float = 0.0):
+                         fusion_frac: float = 0.0, indel_frac: float = 0.0, max_copies: int = 2):
     """Synthesises both sides of `n_pairs` paired reads directly as device-resident thj_seg_batch arrays
     (torch tensors).  Model: a fragment of 2*read_len + max(0, N(inner_mean, inner_sd)) bases drawn
     uniformly from a gene's two-exon transcript; left read = its first read_len bases (sense), right
@@ -515,6 +515,11 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
     multi_frac > 0 (with a genome whose [dup_shift, 2*dup_shift) is a copy of [0, dup_shift) and genes in the first copy
     only): that fraction of the reads gets every segment hit reported twice, at the locus and at locus + dup_shift --
     a two-copy repeat, which is what sends reads to the multihit tier of the stitch kernels.
+    max_copies > 2 (planted repeat family, SURVEY 8d: "multihits from planted repeats up to 41"): the genome holds max_copies copies of
+    [0, dup_shift) back to back; the genes inside the first copy are the family, the genes behind the last copy are unique, and
+    multi_frac is the share of PAIRS drawn from family genes.  Both reads of such a pair get every segment hit reported at the
+    first c copies, c = 2 for 80 % of them, 3..8 for 15 %, 9..40 for 4 %, 41 for 1 % (those reads are dropped whole by
+    max_seg_multihits = 40, segment_juncs.cpp:3499-3506, long_spanning_reads.cpp:2625-2632), capped at max_copies.
     fusion_frac > 0: that fraction of the pairs gets a chimeric LEFT read (the shape of BASELINE configs[3]): its first kb
     segments are the start of one gene's first exon read forward, the rest comes from another gene's first exon (any contig),
     forward or reverse-complemented, the break exactly on a segment boundary -- every segment maps where its part lies, no
@@ -557,9 +562,28 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
                      full_hit=torch.zeros((n_pairs, 4), dtype=torch.int32, device=device)) for sd in sides}
     ar = torch.arange(read_len, device=device)
     bitw = (torch.ones(64, dtype=torch.int64, device=device) << torch.arange(64, device=device))
+    family = max_copies > 2 and multi_frac > 0 and dup_shift > 0
+    ncopy = None
+    if family:
+        in_fam = (genes_t[:, 0] == 0) & (genes_t[:, 3] + E + 1000 < dup_shift)
+        in_uniq = (genes_t[:, 0] != 0) | (genes_t[:, 1] >= max_copies * dup_shift + 1000)
+        fam_idx, uniq_idx = torch.nonzero(in_fam).reshape(-1), torch.nonzero(in_uniq).reshape(-1)
+        if fam_idx.numel() == 0 or uniq_idx.numel() == 0:
+            raise ValueError("the repeat family needs genes inside the first copy and behind the last one")
+        ncopy = torch.ones(n_pairs, dtype=torch.int32, device=device)
     for c0 in range(0, n_pairs, chunk):
         n = min(chunk, n_pairs - c0)
-        gi = torch.randint(0, genes_t.shape[0], (n,), generator=g, device=device)
+        if family:
+            is_multi = torch.rand(n, generator=g, device=device) < multi_frac
+            gi = torch.where(is_multi, fam_idx[torch.randint(0, fam_idx.numel(), (n,), generator=g, device=device)],
+                             uniq_idx[torch.randint(0, uniq_idx.numel(), (n,), generator=g, device=device)])
+            u = torch.rand(n, generator=g, device=device)
+            c = torch.where(u < 0.80, torch.full((n,), 2, device=device),
+                            torch.where(u < 0.95, 3 + torch.randint(0, 6, (n,), generator=g, device=device),
+                                        torch.where(u < 0.99, 9 + torch.randint(0, 32, (n,), generator=g, device=device), torch.full((n,), 41, device=device))))
+            ncopy[c0:c0 + n] = torch.where(is_multi, c.clamp(max=max_copies), torch.ones_like(c)).to(torch.int32)
+        else:
+            gi = torch.randint(0, genes_t.shape[0], (n,), generator=g, device=device)
         gene = genes_t[gi]                                   # contig, exon1_start, intron_start, intron_end
         inner = torch.clamp(torch.randn(n, generator=g, device=device) * inner_sd + inner_mean, min=0).to(torch.int64)
         frag = 2 * read_len + inner
@@ -751,7 +775,7 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
         shifted by dup_shift in the columns `left_cols`"""
         cnt = mapped.to(torch.int32)
         if multi is not None:
-            cnt = cnt * (1 + multi.repeat_interleave(nseg).to(torch.int32))
+            cnt = cnt * (multi if multi.dtype == torch.int32 else 1 + multi.to(torch.int32)).repeat_interleave(nseg)
         off = torch.zeros(n_pairs * nseg + 1, dtype=torch.int32, device=device)
         off[1:] = torch.cumsum(cnt, 0)
         if multi is None:
@@ -767,7 +791,14 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
         b = bufs[sd]
         other = bufs["right" if sd == "left" else "left"]
         multi = None
-        if multi_frac > 0 and dup_shift > 0:
+        if family:
+            multi = ncopy.clone()                            # copies per pair (int32): both reads of a family pair are multihits
+            if sd == "left":                                 # ... but not a left read that was replaced by a chimeric / deletion read
+                if fusion_rows is not None:
+                    multi[fusion_rows] = 1
+                if deletion_rows is not None:
+                    multi[deletion_rows] = 1
+        elif multi_frac > 0 and dup_shift > 0:
             multi = torch.rand(n_pairs, generator=g, device=device) < multi_frac
         mapped = b["seg_mapped"].reshape(-1)
         seg_off, hits = csr(mapped, b["seg_hits"].reshape(-1, 4), multi, (1, 2))
