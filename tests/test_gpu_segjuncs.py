@@ -139,7 +139,7 @@ def test_missing_genome_fails_loudly(lib):
             ctx.run(Params(segment_length=65), h)   # unsupported parameter -> error
 
 
-def rescue_heavy_batch(n_reads=300, seed=11):
+def rescue_heavy_batch(n_reads=300, seed=11, big=()):
     """Paired reads whose last segment (across an intron) is missing, with several (hit, mate hit) pairs
     each: every read takes the mate-anchored rescue, a tile has far more pairs than the kernel's LDS slots."""
     from tophat_amd.batch import HIT_DTYPE, SegBatch
@@ -154,6 +154,9 @@ def rescue_heavy_batch(n_reads=300, seed=11):
         read = seq[base:base + 75] + seq[base + 75 + intron:base + 100 + intron]
         n_left = 17 if r == 5 else int(rng.integers(1, 4))
         n_mate = 17 if r == 5 else int(rng.integers(2, 6))
+        for (rr, nl, nm) in big:                          # (read, left hits, mate hits) of reads with many pairs
+            if r == rr:
+                n_left, n_mate = nl, nm
         for k in range(n_left):                           # the true hit first, decoys a little upstream
             hits.append((1, base - 7 * k, base - 7 * k + L, 0, 0, 0, L))
         seg_off.append(len(hits))
@@ -184,6 +187,51 @@ def test_rescue_slot_overflow(lib):
         got = ctx.segjuncs([(p, ctx.upload_batch(b))])
     assert got.stats["rescue_pairs"] == want.stats["rescue_pairs"]
     assert got.stats["windows"] == want.stats["windows"]
+    assert_events_equal(got, want)
+
+
+def test_reads_with_many_hits_share_a_wave(lib):
+    """Reads with more than 24 hits are enumerated by a wave (lane = hit) in both kernels, reads with 5..64 (hit, mate hit) pairs
+    keep their rescue outcomes in the HBM pool, more than 64 recompute them: the same events and counters as the oracle's loops.
+    Multihits up to max_seg_multihits = 40 a segment; a read with 41 is dropped whole (segment_juncs.cpp:3499-3506)."""
+    from tophat_amd.batch import HIT_DTYPE, SegBatch
+    rng = np.random.default_rng(17)
+    L, nseg, n_reads = 25, 4, 300
+    glen = 900000
+    seq = "".join(rng.choice(list("ACGT"), size=glen))
+    hits, seg_off, bases, read_off = [], [0], bytearray(), [0]
+    for r in range(n_reads):
+        base = 2000 + r * 2900
+        mh = (40, 41, 13, 26, 1, 2)[r % 6]               # hits per mapped segment
+        intron = int(rng.integers(80, 700))
+        read = seq[base:base + 50] + seq[base + 50 + intron:base + 100 + intron]
+        for sgi, at in ((0, base), (1, base + L), (2, base + 50 + intron), (3, base + 75 + intron)):
+            if sgi == 1 and r % 4 == 0:                   # a missing segment: the window comes from the segment after it
+                seg_off.append(len(hits))
+                continue
+            for k in range(mh):                           # the true hit and decoys a few bases off (no two at the same place)
+                hits.append((1, at + 3 * k, at + 3 * k + L, 2 if sgi == 3 else 0, 0, 0, L))
+            seg_off.append(len(hits))
+        bases += read.encode()
+        read_off.append(len(bases))
+    b = SegBatch(nseg, np.arange(1, n_reads + 1, dtype=np.uint32), np.array(read_off, dtype=np.int64),
+                 np.frombuffer(bytes(bases), dtype=np.uint8).copy(), np.array(seg_off, dtype=np.uint32),
+                 np.array(hits, dtype=HIT_DTYPE))
+    p = Params()
+    want = orc.segjuncs(p, orc.Genome([seq]), b)
+    assert want.stats["windows"] > 100000 and len(want.juncs) > 100
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        got = ctx.segjuncs([(p, ctx.upload_batch(b))])
+    assert got.stats["windows"] == want.stats["windows"] and got.stats["indel_pairs"] == want.stats["indel_pairs"]
+    assert_events_equal(got, want)
+    # the mate-anchored rescue with 40 x 1, 30 x 2 (pool) and 40 x 3 (recomputed) pairs among ordinary reads
+    seq, b = rescue_heavy_batch(big=((7, 40, 1), (70, 30, 2), (140, 40, 3), (141, 5, 1), (290, 64, 1)))
+    want = orc.segjuncs(p, orc.Genome([seq]), b)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        got = ctx.segjuncs([(p, ctx.upload_batch(b))])
+    assert got.stats["rescue_pairs"] == want.stats["rescue_pairs"] and got.stats["windows"] == want.stats["windows"]
     assert_events_equal(got, want)
 
 

@@ -224,7 +224,7 @@ __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, cons
 // Reads that take the mate-anchored rescue (find_gaps :3330-3497) are few and their map_read_to_contig scans long,
 // so the main kernel only lists them -- per workgroup, in its own slice of `list`, no global append counter -- and
 // thj_k_segjuncs_rescue handles them densely afterwards.
-struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; int32_t* slot_pool; };
+struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; int32_t* slot_pool; unsigned int* heavy_count; uint32_t* heavy_list; };
 
 // Main kernel.  One workgroup walks tiles of 256 consecutive reads.
 //   stage:     find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
@@ -379,6 +379,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
 static constexpr int RPT = 4;             // rescue pairs per thread kept in LDS
 static constexpr int GPT = 64;            // ... and in the thread's slice of an HBM pool, for reads with more (a read with 41 hits in its first segment: multihits)
 static constexpr int RESCUE_GRID = 1024;  // workgroups of the rescue kernel at the most
+static constexpr int HEAVY_CAP = 1 << 18;  // rescue reads of one launch that can have a pool slice (the rest recompute their pairs as they go)
 static constexpr int MAX_LISTS = 2048;    // workgroups of the main kernel = slices of the rescue list
 
 template <bool WIDE>
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
         const unsigned int q_before = q_n;
         __syncthreads();
         ReadView v;
-        bool do_gaps = false;
+        bool do_gaps = false, heavy = false;
         int r = 0;
         if (active) {
             int lo = 0, hi = n_lists;                    // slice holding entry i: last one with s_off <= i
@@ -428,7 +429,13 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             r = (int)rl.list[(size_t)lo * rl.seg_cap + (i - s_off[lo])];
             v = make_view(b, r);
             QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
-            indels_enumerate(p, v, qs);
+            // a read with more pairs than the LDS slots hold (multihits) only has its pairs' outcomes computed here, into its slice of
+            // the HBM pool; thj_k_segjuncs_rescue_shared enumerates it with a wave (one thread walking 40 x 40 pairs held its tile up)
+            unsigned int hk = 0;
+            heavy = (int64_t)rv_count_raw(v, 0) * v.n_mate > RPT && (int64_t)rv_count_raw(v, 0) * v.n_mate <= GPT && !THJ_EXPF(1 << 24);
+            if (heavy) { hk = atomicAdd(rl.heavy_count, 1u); heavy = hk < (unsigned int)HEAVY_CAP; }
+            if (heavy) rl.heavy_list[hk] = (uint32_t)r;
+            if (!heavy) indels_enumerate(p, v, qs);
             bool wants = false;
             do_gaps = gaps_prepare(p, v, wants);
             if (do_gaps) {
@@ -436,12 +443,12 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                     const int n_left = rv_count_raw(v, 0);
                     // the pairs' outcomes are kept (LDS, or HBM for a read with many hits): gaps_enumerate asks for them once per
                     // (hit, partner) it looks at, and recomputing a flank scan each time made a 16-copy read cost 200 of them
-                    const bool fits = (int64_t)n_left * v.n_mate <= GPT;
-                    int32_t* mine = (int64_t)n_left * v.n_mate <= RPT ? s_slots + tid * RPT * 2 : rl.slot_pool + ((size_t)blockIdx.x * TPB + tid) * (GPT * 2);
+                    const bool fits = (int64_t)n_left * v.n_mate <= RPT || heavy;
+                    int32_t* mine = heavy ? rl.slot_pool + (size_t)hk * (GPT * 2) : s_slots + tid * RPT * 2;
                     unsigned int local = 0;
                     // the scan of a mate hit's flank is the same for every left hit on the mate's contig and opposite strand: kept
-                    // for the first four mate hits (a read of a repeat family has tens of left hits and one or two mate hits)
-                    int32_t sc_f[4], sc_rv[4]; bool sc_ok[4]; unsigned int sc_have = 0;
+                    // for the first two mate hits (a read of a repeat family has tens of left hits and one or two mate hits)
+                    int32_t c0_f = SLOT_NONE, c0_rv = SLOT_NONE, c1_f = SLOT_NONE, c1_rv = SLOT_NONE; bool c0_ok = false, c1_ok = false; unsigned int sc_have = 0;
                     for (int l = 0; l < n_left; ++l)
                         for (int m = 0; m < v.n_mate; ++m) {
                             int32_t f = SLOT_NONE, rv = SLOT_NONE;
@@ -450,9 +457,12 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                                 const Hit lh = v.hits[v.so[0] + l], rh = v.mate[m];
                                 if (lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) {        // :3414
                                     bool scanned;
-                                    if (m < 4) {
-                                        if (!((sc_have >> m) & 1u)) { sc_ok[m] = rescue_scan(g, p, v.rp, v.W, v.rl, rh, sc_f[m], sc_rv[m]); sc_have |= 1u << m; }
-                                        f = sc_f[m]; rv = sc_rv[m]; scanned = sc_ok[m];
+                                    if (m == 0) {
+                                        if (!(sc_have & 1u)) { c0_ok = rescue_scan(g, p, v.rp, v.W, v.rl, rh, c0_f, c0_rv); sc_have |= 1u; }
+                                        f = c0_f; rv = c0_rv; scanned = c0_ok;
+                                    } else if (m == 1) {
+                                        if (!(sc_have & 2u)) { c1_ok = rescue_scan(g, p, v.rp, v.W, v.rl, rh, c1_f, c1_rv); sc_have |= 2u; }
+                                        f = c1_f; rv = c1_rv; scanned = c1_ok;
                                     } else scanned = rescue_scan(g, p, v.rp, v.W, v.rl, rh, f, rv);
                                     if (scanned) ++local;
                                 }
@@ -465,14 +475,14 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                     v.slots = fits ? mine : nullptr;
                     v.lazy_g = &s_g; v.lazy_p = &s_p;
                 }
-                if (!THJ_EXPF(1 << 23)) gaps_enumerate(p, v, qs);
+                if (!heavy && !THJ_EXPF(1 << 23)) gaps_enumerate(p, v, qs);
             }
             my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
         __syncthreads();
         if (q_n > (unsigned)QCAP) {
             if (tid == 0) atomicAdd(&s_stat[3], 1u);
-            if (active) {
+            if (active && !heavy) {
                 InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
                 indels_enumerate(p, v, is);
                 if (do_gaps) gaps_enumerate(p, v, is);
@@ -491,6 +501,69 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
         if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
         if (s_stat[2]) atomicAdd(&t.cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[2]);
+        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+    }
+}
+
+// The rescue reads with many pairs (listed by thj_k_segjuncs_rescue, their pairs' outcomes in the pool): one wave per read,
+// lane = hit, then the same queue and execution as everywhere.
+template <bool WIDE>
+__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g, Params p, DevBatch b, Tables t, RescueList rl) {
+    __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
+    __shared__ unsigned int q_n;
+    __shared__ unsigned int s_stat[4];
+    __shared__ Genome s_g;
+    __shared__ Params s_p;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 4) s_stat[tid] = 0;
+    if (tid == 0) { q_n = 0; s_g = g; s_p = p; }
+    __syncthreads();
+    EventSink ev{g, t};
+    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const unsigned int n = *rl.heavy_count < (unsigned int)HEAVY_CAP ? *rl.heavy_count : (unsigned int)HEAVY_CAP;
+    constexpr unsigned int WPB = TPB / 64;
+    unsigned int my_windows = 0, my_indels = 0;
+    for (unsigned int base = blockIdx.x * WPB; base < n; base += gridDim.x * WPB) {
+        __syncthreads();
+        const unsigned int q_before = q_n;
+        __syncthreads();
+        const unsigned int h = base + (unsigned int)wave;
+        const bool active = h < n;
+        const int r = active ? (int)rl.heavy_list[h] : 0;
+        ReadView v;
+        bool do_gaps = false;
+        if (active) {
+            v = make_view(b, r);
+            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
+            indels_enumerate(p, v, qs, lane, 64);
+            bool wants = false;
+            do_gaps = gaps_prepare(p, v, wants);
+            if (do_gaps) {
+                if (wants) { v.rescue = true; v.slots = rl.slot_pool + (size_t)h * (GPT * 2); v.lazy_g = &s_g; v.lazy_p = &s_p; }
+                gaps_enumerate(p, v, qs, lane, 64);
+            }
+            my_windows += qs.n_windows; my_indels += qs.n_indels;
+        }
+        __syncthreads();
+        if (q_n > (unsigned)QCAP) {
+            if (tid == 0) atomicAdd(&s_stat[3], 1u);
+            if (active) {
+                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                indels_enumerate(p, v, is, lane, 64);
+                if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
+            }
+            __syncthreads();
+            if (tid == 0) q_n = q_before;
+            __syncthreads();
+        }
+        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * WPB >= n);
+    }
+    if (my_windows) atomicAdd(&s_stat[0], my_windows);
+    if (my_indels) atomicAdd(&s_stat[1], my_indels);
+    __syncthreads();
+    if (tid == 0) {
+        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
         if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
@@ -944,8 +1017,12 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     }
     rl.list = c->d_rescue_list;
     rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap;
-    if (b.mate_off && !c->d_rescue_slots) HIPCHK(hipMalloc((void**)&c->d_rescue_slots, (size_t)RESCUE_GRID * TPB * GPT * 2 * sizeof(int32_t)));
-    rl.slot_pool = c->d_rescue_slots;
+    // [16 bytes: the count of listed reads][HEAVY_CAP read indices][HEAVY_CAP slices of GPT pairs' outcomes]
+    if (b.mate_off && !c->d_rescue_slots) HIPCHK(hipMalloc((void**)&c->d_rescue_slots, 16 + (size_t)HEAVY_CAP * 4 + (size_t)HEAVY_CAP * GPT * 2 * sizeof(int32_t)));
+    rl.heavy_count = (unsigned int*)c->d_rescue_slots;
+    rl.heavy_list = c->d_rescue_slots ? (uint32_t*)c->d_rescue_slots + 4 : nullptr;
+    rl.slot_pool = c->d_rescue_slots ? c->d_rescue_slots + 4 + HEAVY_CAP : nullptr;
+    if (b.mate_off) HIPCHK(hipMemsetAsync(c->d_rescue_slots, 0, 16, c->stream));
     const bool wide = p.segment_length > 32;
     if (wide) hipLaunchKernelGGL(thj_k_segjuncs<true>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
     else hipLaunchKernelGGL(thj_k_segjuncs<false>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
@@ -954,6 +1031,8 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
         const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
         if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
         else hipLaunchKernelGGL(thj_k_segjuncs_rescue<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
+        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
+        else hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
     }
     if (c->profile) { HIPCHK(hipEventRecord(e2, c->stream)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(e1, e2); }
     HIPCHK(hipGetLastError());
