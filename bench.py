@@ -228,8 +228,8 @@ def parse_args():
                     help="fraction of the pairs drawn from a planted repeat family (SURVEY 8d: multihits from planted repeats up to 41): every "
                          "segment hit of such a read is reported at 2..41 copies (see --max-copies); 0 = none")
     ap.add_argument("--max-copies", type=int, default=41,
-                    help="copies of the repeat family in the genome (41: 80 %% of the family's reads have 2 hits per segment, 15 %% 3..8, 4 %% "
-                         "9..40, 1 %% 41 -- dropped whole by max_seg_multihits); 2: the two-copy genome of round 2 (second half = first half)")
+                    help="copies of the repeat family in the genome (41: 85 %% of the family's reads have 2 hits per segment, 12 %% 3..8, 2.7 %% "
+                         "9..40, 0.3 %% 41 -- dropped whole by max_seg_multihits); 2: the two-copy genome of round 2 (second half = first half)")
     ap.add_argument("--fusion-search", action="store_true",
                     help="run long_spanning_reads' stage with fusion search on (the shape of configs[3]): reads tiers 0 / 1 cannot join go "
                          "through the fusion branches (thj_k_stitch_fusion) against an empty fusion list")
@@ -278,12 +278,22 @@ _E2E_EARLY = None
 
 
 def main():
+    global _E2E_EARLY
     args = parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if "WORLD_SIZE" in os.environ:                    # one rank of a launched job (torchrun or spawn_ranks)
         world, rank, local_rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
         control = ProcControl(rank, world) if world > 1 else None
+        if world > 1 and args.e2e_pairs > 0 and args.read_len == 100 and args.genome == "chr20":
+            # the executables over all the job's GPUs, before any rank holds device memory; the other ranks wait.  An error is
+            # reported in the line (e2e.error) and does not stop the scaling measurement.
+            if rank == 0:
+                try:
+                    _E2E_EARLY = e2e_leg(args, n_gpus=world)
+                except Exception as e:      # noqa: BLE001
+                    _E2E_EARLY = {"error": repr(e)[:2000], "ok": False, "n_gpus": world}
+            control.barrier()
         result = run_rank(args, rank, world, local_rank, control, None)
         finish_stdout(result if rank == 0 else None)
         return
@@ -316,7 +326,6 @@ def main():
     # the files-in -> files-out leg first, while this process holds nothing: run after the resident-data bench (a context with
     # tens of GB of device memory, the workload's host arrays and the oracle's records still allocated) the same executables
     # took ~30 % longer
-    global _E2E_EARLY
     e2e_failed = False
     if args.e2e_pairs > 0 and args.read_len == 100 and args.genome == "chr20":
         try:
@@ -345,7 +354,7 @@ def finish_stdout(result):
     os.dup2(devnull, 1)
 
 
-def e2e_leg(args):
+def e2e_leg(args, n_gpus=1):
     """The metric as BASELINE words it: wall clock of the drop-in executables, files in -> files out (segment_juncs, then
     long_spanning_reads on each side), on generated configs[1]-shaped files (tools/bin/thj_gen: BAM inputs with .index, the
     reads as unaligned BAM).  What is checked is what was timed: SHA-256 of the five outputs of the timed run, and the oracle on
@@ -359,14 +368,17 @@ def e2e_leg(args):
     from e2e_bench import run_e2e
     d = tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
-        res = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True)
+        # the executables drive every GPU they can see (read-id shards round-robin over the contexts): the first n_gpus devices here
+        gpu_env = {"HIP_VISIBLE_DEVICES": ",".join(str(k) for k in range(n_gpus))}
+        res = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=gpu_env)
         keep = ("pairs", "input_bytes", "gen_seconds", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s",
                 "both_stages_s", "junctions", "junctions_bed_s", "junctions_bed_lines")
         out = {k: res[k] for k in keep}
         out["stage_timing"] = {st: [l for l in res.get(st + "_log_tail", []) if l.startswith("[timing]") or l.startswith("[worker-seconds]") or "made on the device" in l]
                                for st in ("segment_juncs", "long_spanning_reads_left", "long_spanning_reads_right")}
         out["value"] = res["pairs"] / res["both_stages_s"]
-        out["unit"] = "read-pairs/s (wall clock of both executables, files in -> files out, 1 GPU, host CPUs: %s)" % (_cpu_quota(),)
+        out["n_gpus"] = n_gpus
+        out["unit"] = "read-pairs/s (wall clock of both executables, files in -> files out, %d GPU%s, host CPUs: %s)" % (n_gpus, "" if n_gpus == 1 else "s", _cpu_quota())
         outs = ("out.juncs", "out.insertions", "out.deletions", "span_left.bam", "span_right.bam", "junctions.bed")
 
         def sha(name):
@@ -377,11 +389,18 @@ def e2e_leg(args):
             return h.hexdigest()
         out["sha256"] = {n: sha(n) for n in outs}
         out["timed_run_check"] = e2e_timed_run_check(d, args)
-        # the same files again with every process waiting for its own teardown (THJ_NO_HANDOFF=1): the default run hands over when the
-        # outputs are complete and leaves ~0.2 s of GPU teardown per process to overlap the caller's next step
-        r2 = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra={"THJ_NO_HANDOFF": "1"})
+        # the same files again.  Every process is one process and waits for its own teardown (the default since round 3; until then the
+        # executables handed over to a child when the outputs were complete -- THJ_HANDOFF=1 still does): both runs are that figure
+        r2 = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=dict(gpu_env, THJ_NO_HANDOFF="1"))
         out["value_no_handoff"] = r2["pairs"] / r2["both_stages_s"]
         out["no_handoff_seconds"] = [r2["segment_juncs_s"], r2["long_spanning_reads_left_s"], r2["long_spanning_reads_right_s"]]
+        # the host's share: CPU seconds (user + system) of the three processes of that run against wall clock x CPUs available.  With the
+        # BAM records and BGZF members made on the device the host parses options and FASTA, plans shards, stages compressed input
+        # and writes members; the busy fraction says how far that is from being the limit when GPUs are added
+        cpu_s = [r2["segment_juncs_cpu_s"], r2["long_spanning_reads_left_cpu_s"], r2["long_spanning_reads_right_cpu_s"]]
+        ncpu = _cpu_count()
+        out["host"] = {"cpu_seconds": cpu_s, "cpus": ncpu, "busy_fraction": sum(cpu_s) / max(1e-9, r2["both_stages_s"] * ncpu),
+                       "cpu_seconds_per_million_pairs": sum(cpu_s) / (res["pairs"] / 1e6)}
         out["outputs_identical_without_handoff"] = all(sha(n) == out["sha256"][n] for n in outs[:5])
         out["inflate"] = e2e_inflate_roofline(os.path.join(d, "left_seg1.bam"))
     finally:
@@ -795,7 +814,9 @@ def run_rank(args, rank, world, local_rank, control, shared):
             rank, h[0], local_juncs[0], "identical" if same else "DIFFER", world, comm_info["transport"]), file=sys.stderr, flush=True)
         if not same:
             raise SystemExit(3)
+    per_rank_ms = [elapsed * 1e3 / args.steps]
     if control is not None:
+        per_rank_ms = [x[0] / 1e3 / args.steps for x in control.allgather_ints([int(elapsed * 1e6)])]
         elapsed = control.max(elapsed)
 
     # ---- roofline, per launch (one launch = one side's batch of `pairs` reads); DESIGN.md "Roofline" ---------
@@ -895,7 +916,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     workload_text = ("%s: %d x 2x%d bp PE synthetic vs %d bp %s genome per GPU, inputs resident in HBM; both stages on device: "
                      "segment_juncs (main + rescue kernels, event dedup+sort%s) then long_spanning_reads (four stitch tiers fed "
                      "device-to-device with the junction set; records land in BAM order)"
-                     % (("configs[1]" + ("" if args.multihit_frac == 0 and args.indel_frac == 0 else " with SURVEY 8(d)'s mix (%g %% of the pairs from a %d-copy repeat family, "
+                     % (("configs[1]" + ("" if args.multihit_frac == 0 and args.indel_frac == 0 else " with SURVEY 8(d)'s mix (%g %% of the pairs from a %d-copy repeat family -- 2 hits a segment for 85 %% of them, 3..8 for 12 %%, 9..40 for 2.7 %%, 41 for 0.3 %% --, "
                                           "%g %% deletion reads)" % (100 * args.multihit_frac, args.max_copies, 100 * args.indel_frac)))
                         if args.read_len == 100 and args.genome == "chr20" and not n_ium and not args.fusion_search else "shape of another config", args.pairs,
                         args.read_len, genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
@@ -1001,10 +1022,13 @@ def run_rank(args, rank, world, local_rank, control, shared):
                                      / max(1e-9, sum(k["avg_kernel_ms"] * k["launches"] for k in kernels)) / 1e6,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "kernels": kernels,
-            "exchange": comm_info,
+            # the exchange step as it ran: ranks, transport ("rccl" across processes / GPUs, "loopback" for contexts on one device), calls and
+            # bytes; per-rank step times (the line's ms_per_step is their maximum)
+            "exchange": None if comm_info is None else dict(comm_info, ranks=comm_info["n_ranks"]),
+            "per_rank_ms_per_step": per_rank_ms,
             # the metric as BASELINE words it (wall clock of the executables, files in -> files out); "value" above is the rate of the
             # kernels on data resident in HBM, as the bench contract defines it
-            "metric_e2e": None if not e2e else {"value": e2e.get("value"), "unit": "read-pairs/s, files in -> files out, both executables, 1 GPU",
+            "metric_e2e": None if not e2e else {"value": e2e.get("value"), "unit": "read-pairs/s, files in -> files out, both executables, %d GPU%s" % (e2e.get("n_gpus", 1), "" if e2e.get("n_gpus", 1) == 1 else "s"),
                                                 "value_no_handoff": e2e.get("value_no_handoff"), "checked_against_oracle": e2e.get("ok")},
             "e2e": e2e,
             "cpu_baseline": cpu,

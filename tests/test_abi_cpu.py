@@ -90,7 +90,7 @@ def test_executables_pass_errors_through_the_output_handoff():
     g.build()
     bindir = os.path.join(ROOT, "tophat_amd", "bin")
     for exe in ("segment_juncs", "long_spanning_reads", "thj_junctions"):
-        for env in (dict(os.environ), dict(os.environ, THJ_NO_HANDOFF="1")):
+        for env in (dict(os.environ), dict(os.environ, THJ_HANDOFF="1")):
             r = subprocess.run([os.path.join(bindir, exe)], capture_output=True, text=True, env=env, timeout=60)
             assert r.returncode == 1 and "sage" in r.stderr, (exe, r.returncode, r.stderr[-200:])
     # a die() after option parsing: inputs that do not exist

@@ -179,13 +179,13 @@ def test_results_do_not_depend_on_shards_or_workers(tmp_path):
 
 
 def test_process_and_compressor_choices_do_not_change_the_results(tmp_path):
-    """one process instead of the output hand-off (THJ_NO_HANDOFF), zlib instead of the writer's own DEFLATE (THJ_BGZF_LEVEL), no
+    """the output hand-off to a child process (THJ_HANDOFF=1; one process is the default), zlib instead of the writer's own DEFLATE (THJ_BGZF_LEVEL), no
     page-locked staging (THJ_NO_STAGING): the same event files and the same BAM stream"""
     d = _gen_case(tmp_path)
     ref, bam0, _ = _run_both(d, tmp_path, "dflt", {})
     stream = gzip.open(bam0, "rb").read()
     assert len(stream) > 1000000
-    for tag, env in (("oneproc", {"THJ_NO_HANDOFF": "1"}), ("zlib", {"THJ_BGZF_LEVEL": "6"}), ("nostage", {"THJ_NO_STAGING": "1", "THJ_CTX_PER_GPU": "1"})):
+    for tag, env in (("handoff", {"THJ_HANDOFF": "1"}), ("zlib", {"THJ_BGZF_LEVEL": "6"}), ("nostage", {"THJ_NO_STAGING": "1", "THJ_CTX_PER_GPU": "1"})):
         got, bam, _ = _run_both(d, tmp_path, tag, env)
         assert got == ref, tag
         assert gzip.open(bam, "rb").read() == stream, tag

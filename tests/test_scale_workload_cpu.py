@@ -114,3 +114,49 @@ def test_scale_workload_with_deletion_reads():
     assert got == want
     with_del = {a.read_idx for a in want if any((c >> 28) == 5 for c in a.cigar)}
     assert len(with_del & dz) > 0.35 * len(dz), (len(with_del & dz), len(dz))      # not every planted deletion leaves mismatches to explain
+
+
+def test_scale_workload_with_a_repeat_family():
+    """bench.py's default mix (multihits from planted repeats up to 41): family pairs have every segment hit at 2..41
+    copies, a read with 41 is dropped whole by max_seg_multihits in both stages, deletion reads are found -- oracle and kernel logic
+    agree on both stages (the stage-2 tiers included: reads with few hits, many hits, too many joined alignments)"""
+    seqs, genes = make_scale_genome(1, [4_000_000], 3000, intron_max=1500, exon_len=300)
+    S, copies = 40_000, 41
+    for k in range(1, copies):
+        seqs[0][k * S:(k + 1) * S] = seqs[0][:S]
+    fam = (genes[:, 3] + 300 + 1000 < S)
+    uniq = genes[:, 1] >= copies * S + 1000
+    assert fam.sum() > 5 and uniq.sum() > 100
+    genes = genes[fam | uniq]
+    strs = [s.tobytes().decode() for s in seqs]
+    n = 4000
+    w = make_device_workload(9, seqs, genes, None, n, "cpu", exon_len=300, multi_frac=0.3, dup_shift=S, indel_frac=0.05, max_copies=copies)
+    og = orc.Genome(strs)
+    # copies per read: the hits of segment 0 of every read with a mapped first segment
+    cells = (w["right"]["seg_off"][1:] - w["right"]["seg_off"][:-1]).reshape(n, 4)
+    per_read = cells.max(dim=1).values
+    assert int((per_read == 2).sum()) > 0.15 * n and int(((per_read >= 3) & (per_read <= 8)).sum()) > 0.01 * n
+    assert int((per_read >= 9).sum()) > 5 and int(per_read.max()) == 41
+    ev = None
+    pk = dict(inner_dist_mean=50, inner_dist_std_dev=20, max_segment_intron=20000, max_report_intron=20000)
+    for sd, side in (("left", 1), ("right", 2)):
+        p = Params(read_side=side, **pk)
+        sb = sample_segbatch(w[sd], n)
+        e = orc.segjuncs(p, og, sb)
+        assert_events_equal(sim.segjuncs(p, strs, sb), e)
+        ev = e if ev is None else merge_events(ev, e)
+    assert len(ev.deletions) > 20
+    juncs, ins = events_to_span_inputs(ev)
+    p = Params(max_segment_intron=20000, max_report_intron=20000)
+    for sd in ("left", "right"):
+        spb = sample_spanbatch(w[sd], n)
+        want = orc.spanning(p, og, spb, juncs, ins)
+        for mode in (0, 2):
+            got, status = sim.spanning(p, strs, spb, juncs, ins, mode)
+            got.sort(key=lambda a: a.read_idx)
+            assert status[1] == 0 and status[2] == 0
+            assert got == want
+        by_read = {}
+        for a in want:
+            by_read[a.read_idx] = by_read.get(a.read_idx, 0) + 1
+        assert max(by_read.values()) >= 20           # a read of a 20+-copy repeat has an alignment in every copy

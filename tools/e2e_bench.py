@@ -47,24 +47,33 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
            "--sam-header", f("hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20",
            f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"],
            f("left_reads.bam"), f("left_map.bam"), segs["left"], f("right_reads.bam"), f("right_map.bam"), segs["right"]]
-    t = time.time()
+    import resource
+
+    def child_cpu():
+        ru = resource.getrusage(resource.RUSAGE_CHILDREN)
+        return ru.ru_utime + ru.ru_stime
+    t = time.time(); c0 = child_cpu()
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     dt = time.time() - t
     if r.returncode != 0:
         raise RuntimeError("segment_juncs failed:\n" + r.stderr[-3000:])
     res["segment_juncs_s"] = round(dt, 3)
+    # CPU seconds (user + system) of the process and what it waited for; with the output hand-off the working child outlives its parent
+    # and is not counted -- run with THJ_NO_HANDOFF=1 for this figure
+    res["segment_juncs_cpu_s"] = round(child_cpu() - c0, 3)
     res["junctions"] = sum(1 for _ in open(out["juncs"]))
     res["segment_juncs_log_tail"] = r.stderr.strip().splitlines()[-12:]
     tot = dt
     for sd in ("left", "right"):
         cmd = _prefix(env, "lsr_" + sd) + [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
                f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", f("span_%s.bam" % sd), segs[sd]]
-        t = time.time()
+        t = time.time(); c0 = child_cpu()
         r = subprocess.run(cmd, capture_output=True, text=True, env=env)
         dt = time.time() - t
         if r.returncode != 0:
             raise RuntimeError("long_spanning_reads failed:\n" + r.stderr[-3000:])
         res["long_spanning_reads_%s_s" % sd] = round(dt, 3)
+        res["long_spanning_reads_%s_cpu_s" % sd] = round(child_cpu() - c0, 3)
         for l in r.stderr.splitlines():                     # time before main() and after the report: loader, process teardown
             if "unix time at start / report" in l:
                 a, b = map(float, l.split()[-2:])

@@ -67,7 +67,9 @@ inline void close_output(FILE* f, const char* what) {
 inline int& handoff_fd() { static int fd = -1; return fd; }
 inline int run_with_handoff(int argc, char** argv, int (*body)(int, char**)) {
     int fd[2];
-    if (getenv("THJ_NO_HANDOFF") || pipe2(fd, O_CLOEXEC) != 0) return body(argc, argv);   // O_CLOEXEC: a popen'd packer must not hold the write end
+    // Off by default since round 3: with the BAM records made on the device the process holds little page-locked memory and leaves with
+    // _exit, and one process (1.28 s for the three stages of 10 M pairs) beat parent + child (1.40 s).  THJ_HANDOFF=1 turns it on.
+    if (!getenv("THJ_HANDOFF") || getenv("THJ_NO_HANDOFF") || pipe2(fd, O_CLOEXEC) != 0) return body(argc, argv);   // O_CLOEXEC: a popen'd packer must not hold the write end
     fflush(nullptr);
     const pid_t self = getpid();
     const pid_t pid = fork();

@@ -1225,20 +1225,36 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
                 continue;
             }
             if (idx[depth] >= so[depth + 1]) { --depth; continue; }
-            const SpanHit sh = ghits[idx[depth]++];
-            const RAln cand = raln_from_hit(sh, depth, L, rl);
-            const int cright = cand.left + rc_ref_span(cand.c, cand.n);
-            bool okc = false;
-            if (ref0 == cand.ref_id && (int)anti0 == cand.anti) {             // every hit of a chain shares contig and strand
+            // the next candidates four at a time (their heads: contig, left, flags, first cigar op): a read of a 40-copy repeat walks
+            // 40 candidates per parent and level and takes one -- one dependent HBM round trip each when they are fetched singly
+            const uint32_t i0c = idx[depth];
+            const uint32_t nb = so[depth + 1] - i0c < 4u ? so[depth + 1] - i0c : 4u;
+            Q16 hd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if ((uint32_t)k < nb) hd[k] = *(const Q16*)(ghits + i0c + k);
+            bool took = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (took || (uint32_t)k >= nb) continue;
+                const bool canti = (hd[k].z & SH_ANTI) != 0;
+                if (ref0 != hd[k].x || anti0 != canti) continue;              // every hit of a chain shares contig and strand
+                SpanHit sh;
+                sh.ref_id = hd[k].x; sh.left = (int32_t)hd[k].y; sh.meta = hd[k].z; sh.cigar[0] = hd[k].w;
+                sh.cigar[1] = sh.cigar[2] = sh.cigar[3] = sh.cigar[4] = 0;
+                if ((hd[k].z >> 24) > 1) sh = ghits[i0c + k];
+                const RAln cand = raln_from_hit(sh, depth, L, rl);
+                const int cright = cand.left + rc_ref_span(cand.c, cand.n);
                 const int dist = anti0 ? pleft[depth - 1] - cright : cand.left - pright[depth - 1];   // :2352-2378, :2531-2556
-                okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+                if (dist <= p.max_report_intron && dist >= -p.max_insertion_length) {
+                    took = true;
+                    idx[depth] = i0c + (uint32_t)k + 1;
+                    stage[depth] = sh;
+                    pleft[depth] = cand.left; pright[depth] = cright;
+                    ++depth;
+                    if (depth < nsegs) idx[depth] = so[depth];
+                }
             }
-            if (okc) {
-                stage[depth] = sh;
-                pleft[depth] = cand.left; pright[depth] = cright;
-                ++depth;
-                if (depth < nsegs) idx[depth] = so[depth];
-            }
+            if (!took) idx[depth] = i0c + nb;
         }
     }
     return multi_finish(g, p, joined, nj, nsegs, rp, W, rl, qual, read_idx, sink);

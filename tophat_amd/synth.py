@@ -518,7 +518,7 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
     max_copies > 2 (planted repeat family, SURVEY 8d: "multihits from planted repeats up to 41"): the genome holds max_copies copies of
     [0, dup_shift) back to back; the genes inside the first copy are the family, the genes behind the last copy are unique, and
     multi_frac is the share of PAIRS drawn from family genes.  Both reads of such a pair get every segment hit reported at the
-    first c copies, c = 2 for 80 % of them, 3..8 for 15 %, 9..40 for 4 %, 41 for 1 % (those reads are dropped whole by
+    first c copies, c = 2 for 85 % of them, 3..8 for 12 %, 9..40 for 2.7 %, 41 for 0.3 % (those reads are dropped whole by
     max_seg_multihits = 40, segment_juncs.cpp:3499-3506, long_spanning_reads.cpp:2625-2632), capped at max_copies.
     fusion_frac > 0: that fraction of the pairs gets a chimeric LEFT read (the shape of BASELINE configs[3]): its first kb
     segments are the start of one gene's first exon read forward, the rest comes from another gene's first exon (any contig),
@@ -578,9 +578,9 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
             gi = torch.where(is_multi, fam_idx[torch.randint(0, fam_idx.numel(), (n,), generator=g, device=device)],
                              uniq_idx[torch.randint(0, uniq_idx.numel(), (n,), generator=g, device=device)])
             u = torch.rand(n, generator=g, device=device)
-            c = torch.where(u < 0.80, torch.full((n,), 2, device=device),
-                            torch.where(u < 0.95, 3 + torch.randint(0, 6, (n,), generator=g, device=device),
-                                        torch.where(u < 0.99, 9 + torch.randint(0, 32, (n,), generator=g, device=device), torch.full((n,), 41, device=device))))
+            c = torch.where(u < 0.85, torch.full((n,), 2, device=device),
+                            torch.where(u < 0.97, 3 + torch.randint(0, 6, (n,), generator=g, device=device),
+                                        torch.where(u < 0.997, 9 + torch.randint(0, 32, (n,), generator=g, device=device), torch.full((n,), 41, device=device))))
             ncopy[c0:c0 + n] = torch.where(is_multi, c.clamp(max=max_copies), torch.ones_like(c)).to(torch.int32)
         else:
             gi = torch.randint(0, genes_t.shape[0], (n,), generator=g, device=device)
