@@ -891,7 +891,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950: traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB,
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r02_pmc_traffic.json" if args.multihit_frac == 0 and args.indel_frac == 0 else "r03_pmc_traffic.json"))))
+        pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r03_plain_pmc_traffic.json" if args.multihit_frac == 0 and args.indel_frac == 0 else "r03_pmc_traffic.json"))))
         want_cfg = {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}
         if args.multihit_frac > 0 or args.indel_frac > 0:
             want_cfg.update(multihit_frac=args.multihit_frac, indel_frac=args.indel_frac, max_copies=args.max_copies)
