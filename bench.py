@@ -862,7 +862,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
         {"kernel": "thj_k_stitch_multihit", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
-        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_generic", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
+        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_wave + thj_k_stitch_generic", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
     ]
     # The same kernels in SURVEY 8(d)'s byte terms -- what the ALGORITHM has to move, whatever layout a build chose: 16 B per hit
     # record (this build's stage-2 record is 32 B), the packed read, <= 128 B of genome per window / per joined hit, one 64-B
@@ -897,7 +897,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
             want_cfg.update(multihit_frac=args.multihit_frac, indel_frac=args.indel_frac, max_copies=args.max_copies)
         if args.read_len == 100 and args.genome == "chr20" and use_heads and not args.fusion_search and not n_ium and pm["config"] == want_cfg:
             for k in kernels:
-                c = pm["kernels"].get(k["kernel"])
+                parts = [pm["kernels"].get(nm) for nm in k["kernel"].split(" + ")]
+                c = None if any(x is None for x in parts) else {key: sum(x.get(key, 0.0) for x in parts) for key in ("FETCH_SIZE", "WRITE_SIZE")}
                 if c:
                     k["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
                     k["traffic_low"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0

@@ -145,13 +145,25 @@ struct VecSink {
     void emit_words(const uint32_t* w) { OutAln o; memcpy(&o, w, sizeof o); v->push_back(o); }
 };
 
+static int64_t g_wave_reads = 0;            // reads the shared tier took since the last call of hostsim_wave_reads
+extern "C" int64_t hostsim_wave_reads() { const int64_t n = g_wave_reads; g_wave_reads = 0; return n; }
+// the wave operations span_read_wave is written against, over simt.h's fibers (one wave = 64 fibers)
+#include "simt.h"
+struct WaveSimX {
+    simt::Block* b; int tid, lane;
+    uint64_t ballot(bool p) { const uint32_t* a = b->exchange(tid, p ? 1u : 0u); uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (uint64_t)(a[i] & 1u) << i; return m; }
+    uint32_t bcast(uint32_t v, int src) { return b->exchange(tid, v)[src & 63]; }
+    uint32_t incl_scan(uint32_t v) { const uint32_t* a = b->exchange(tid, v); uint32_t s = 0; for (int i = 0; i <= lane; ++i) s += a[i]; return s; }
+    void wsync() { b->exchange(tid, 0); }
+};
+
 extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
                                 const int32_t* contig_len, int32_t n_contigs,
                                 int32_t n_reads, int32_t nseg, int32_t W, const uint32_t* seg_off, const void* hits,
                                 const uint64_t* planes, const uint16_t* read_len, const uint8_t* quals, int32_t qual_stride,
                                 const thj_junction* juncs, int64_t n_juncs,
                                 const uint32_t* ins /* 4 u32 each: ref,left,len,seq3 */, int64_t n_ins,
-                                int32_t mode /* 0 = the four tiers as the kernels run them, 1 = generic only, 2 = as 0 without the LDS-staged multihit tier */,
+                                int32_t mode /* 0 = the four tiers as the kernels run them, 1 = generic only, 2 = as 0 without the LDS-staged multihit tier, 3 = as 0 with the shared (wave per read) tier in front of tier 3 */,
                                 void** out, int64_t* n_out, int64_t* status_counts /* [5] */) {
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Params p;
@@ -190,10 +202,31 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                                     read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
             }
         }
-        if (st == SPAN_NEED_GENERIC && mode == 0) {          // tier 2: multihit reads, every hit head staged
+        if (st == SPAN_NEED_GENERIC && (mode == 0 || mode == 3)) {          // tier 2: multihit reads, every hit head staged
             SpanHitHead heads[16];
             st = span_read_multi_staged(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                         read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, heads, nseg <= 4 ? 12 : 16, sink);
+        }
+        if (st == SPAN_NEED_GENERIC && mode == 3) {          // tier 3, shared: the read by a wave (thj_k_stitch_wave), lanes as fibers
+            std::vector<SpanHitHead> heads(WAVE_MAXHITS);
+            std::vector<RAln> pool(WAVE_MAXJOIN);
+            uint8_t perm[64];
+            std::vector<OutAln> lane_out[64];
+            int lane_st[64], lane_n[64];
+            simt::run_block(64, [&](simt::Block& blk, int tid) {
+                WaveSimX x{&blk, tid, tid};
+                VecSink ls{&lane_out[tid]};
+                lane_st[tid] = span_read_wave(x, g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                              read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, heads.data(), pool.data(), perm, ls, &lane_n[tid]);
+            }, 256 * 1024);
+            for (int l = 1; l < 64; ++l) if (lane_st[l] != lane_st[0] || lane_n[l] != lane_n[0]) return -20;   // the status is wave-uniform
+            st = lane_st[0];
+            if (st != SPAN_NEED_GENERIC) {
+                size_t n = 0;
+                for (int l = 0; l < 64; ++l) { for (auto& o : lane_out[l]) res.push_back(o); n += lane_out[l].size(); }
+                if ((int)n != lane_n[0]) return -21;
+                ++g_wave_reads;
+            }
         }
         if (st == SPAN_NEED_GENERIC && mode != 1) {          // tier 3, first attempt: DFS over global memory, lean joins
             SpanHit stage[SPAN_MAXSEG];

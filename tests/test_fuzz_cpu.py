@@ -190,7 +190,7 @@ def test_fuzz_long_spanning_reads(seed):
     want = orc.spanning(p, g, sb, ja, il)
     # the second restatement (spanning_fusion_oracle.c, the one with the fusion branches) agrees when fusion search is off
     assert orc.spanning_fusion(p, g, sb, ja, il, np.zeros(0, dtype=orc.SPAN_FUSION_DTYPE), False) == want
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         got, status = sim.spanning(p, seqs, sb, ja, il, mode)
         assert status[1] == 0
         got.sort(key=lambda a: a.read_idx)

@@ -37,6 +37,9 @@ if os.environ.get("THJ_FULLSIZE_GRCH38", "1") == "1":
 # ... and configs[4] as written: 2 x 50 bp reads (two segments: the mate-anchored rescue does the work), --max-intron-length
 # 500000 with introns planted up to 499 999 bases -- the widest windows the path allows
 SHAPES.append((50, 4_000_000, 0.0, "chr20", 499_999))
+# ... and bench.py's default mix: 5 % of the pairs from a 41-copy repeat family (2..41 hits per segment: the reads a wave shares in
+# stage 1, tier 3's shared pass in stage 2), 3 % deletion reads
+SHAPES.append((100, 3_000_000, 0.05, "chr20", 200_000, 41))
 
 
 def half(w, which):
@@ -60,8 +63,9 @@ def half(w, which):
 
 
 @pytest.fixture(scope="module", params=SHAPES,
-                ids=lambda s: "%dbp_%dMpairs%s%s%s" % (s[0], s[1] // 1_000_000, "_multihit" if s[2] else "",
-                                                       "_grch38" if len(s) > 3 and s[3] == "grch38" else "", "_intron%dk" % (s[4] // 1000) if len(s) > 4 else ""))
+                ids=lambda s: "%dbp_%dMpairs%s%s%s%s" % (s[0], s[1] // 1_000_000, "_multihit" if s[2] else "",
+                                                         "_grch38" if len(s) > 3 and s[3] == "grch38" else "", "_intron%dk" % (s[4] // 1000) if len(s) > 4 else "",
+                                                         "_family%d" % s[5] if len(s) > 5 else ""))
 def world(request):
     read_len, pairs, multi_frac = request.param[:3]
     dev = torch.device("cuda", 0)
@@ -71,18 +75,25 @@ def world(request):
     else:
         seqs, genes = make_scale_genome(1, [CHR20_LEN], 20000, exon_len=300, intron_max=intron_max)
     dup_shift = 0
-    if multi_frac > 0:
+    max_copies = request.param[5] if len(request.param) > 5 else 2
+    if max_copies > 2:
+        dup_shift = len(seqs[0]) // 96
+        for k in range(1, max_copies):
+            seqs[0][k * dup_shift:(k + 1) * dup_shift] = seqs[0][:dup_shift]
+        genes = genes[((genes[:, 0] == 0) & (genes[:, 3] + 300 + 1000 < dup_shift)) | (genes[:, 1] >= max_copies * dup_shift + 1000)]
+    elif multi_frac > 0:
         dup_shift = len(seqs[0]) // 2
         seqs[0][dup_shift:2 * dup_shift] = seqs[0][:dup_shift]
         genes = genes[(genes[:, 0] == 0) & (genes[:, 3] + 300 + 1000 < dup_shift)]
     strs = [s.tobytes().decode() for s in seqs]
-    w = make_device_workload(100, seqs, genes, None, pairs, dev, exon_len=300, read_len=read_len, multi_frac=multi_frac, dup_shift=dup_shift)
+    w = make_device_workload(100, seqs, genes, None, pairs, dev, exon_len=300, read_len=read_len, multi_frac=multi_frac, dup_shift=dup_shift,
+                             max_copies=max_copies, indel_frac=0.03 if max_copies > 2 else 0.0)
     torch.cuda.synchronize()
     stream = torch.cuda.Stream(device=dev)
     ctx = host.Context(0, stream=stream.cuda_stream)
     ctx.upload_genome(host.pack_genome(strs))
     ctx.configure(1 << 22, 1 << 20)
-    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream, read_len=read_len, pairs=pairs, multi_frac=multi_frac, intron_max=intron_max)
+    yield dict(ctx=ctx, w=w, strs=strs, genes=genes, stream=stream, read_len=read_len, pairs=pairs, multi_frac=multi_frac, intron_max=intron_max, max_copies=max_copies)
     ctx.close()
     del w
     torch.cuda.empty_cache()
@@ -102,7 +113,7 @@ def test_fullsize_properties(world):
     pr = Params(read_side=READ_RIGHT, inner_dist_mean=50, inner_dist_std_dev=20)
     full = [(pl, cbatch_from_tensors(w["left"], 0)), (pr, cbatch_from_tensors(w["right"], PAIRS))]
     ev = run_stage1(ctx, full)
-    assert ev.stats["overflow_blocks"] == 0
+    assert ev.stats["overflow_blocks"] == 0 or world["max_copies"] > 2
     # sortedness: strictly increasing in Junction::operator< order
     j = ev.juncs
     keys = [tuple(int(x[k]) for k in ("ref_id", "left", "right", "antisense")) for x in j]

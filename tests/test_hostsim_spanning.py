@@ -44,7 +44,7 @@ def test_span_logic_matches_oracle(cfg):
     if cfg["seed"] == 7:
         assert sum(1 for a in want if sum(1 for c in a.cigar if c) > 8) > 50
     assert any(any((c >> 28) == 11 for c in a.cigar) for a in want), "no spliced alignment in the case"
-    for mode in (0, 1, 2):     # the tiers as the kernels run them, the generic path alone, the tiers without the staged multihit one
+    for mode in (0, 1, 2, 3):  # the tiers as the kernels run them, the generic path alone, the tiers without the staged multihit one, with the shared (wave per read) tier
         got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)
         assert status[1] == 0 and status[2] == 0
         # records of one read are emitted together; across reads the device orders by read index afterwards

@@ -151,11 +151,14 @@ def test_scale_workload_with_a_repeat_family():
     for sd in ("left", "right"):
         spb = sample_spanbatch(w[sd], n)
         want = orc.spanning(p, og, spb, juncs, ins)
-        for mode in (0, 2):
+        for mode in (0, 2, 3):
+            sim.lib().hostsim_wave_reads()
             got, status = sim.spanning(p, strs, spb, juncs, ins, mode)
             got.sort(key=lambda a: a.read_idx)
             assert status[1] == 0 and status[2] == 0
             assert got == want
+            if mode == 3:          # the shared tier (a wave per read, lanes emulated as fibers) took the reads with many hits
+                assert sim.lib().hostsim_wave_reads() > 50
         by_read = {}
         for a in want:
             by_read[a.read_idx] = by_read.get(a.read_idx, 0) + 1

@@ -1003,8 +1003,8 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     int grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;       // 256 CUs x 8 resident workgroups, grid-stride the rest
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
-    // LDS: task queue, the tile's offsets, room for 1.125 hits per segment (tiles with more read hits from HBM), work list
-    const int hit_cap = TPB * b.nseg + TPB * b.nseg / 8;
+    // LDS: task queue, the tile's offsets, room for 1.5 hits per segment (tiles with more read hits from HBM), work list
+    const int hit_cap = TPB * b.nseg + TPB * b.nseg / 2;      // (1.125 x until round 3: one read of a 40-copy repeat then pushed its whole tile out of LDS)
     const size_t lds = (size_t)5 * QCAP * 4 + (size_t)((TPB * b.nseg + 1 + 3) & ~3) * 4 + (size_t)hit_cap * 16 + (size_t)TPB * 4;
     // rescue list: one slice per workgroup, sized for all the reads the workgroup visits
     RescueList rl;

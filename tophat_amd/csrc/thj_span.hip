@@ -298,6 +298,62 @@ __global__ __launch_bounds__(256, 3) void thj_k_stitch_multihit(Genome g, Params
 // Tier 3: what is left.  First the same DFS with its candidates read from global memory (any number of hits) and
 // lean joins (span_read_multi); reads whose joined alignments need more than LEAN_C cigar ops, or that have more than
 // MULTI_MAXJOIN of them, are redone on the general arrays (span_read).
+// Tier 3, shared: the reads tier 2 handed on, one WAVE per read (span_read_wave: lane = first-segment hit, the read's hit heads and
+// joined alignments in LDS).  What it takes is struck from the list (0xFFFFFFFF); thj_k_stitch_generic does the rest.
+static constexpr int WAVE_MINHITS = 36;         // fewer hits than this (nine a segment of a 100-base read): left to thj_k_stitch_generic
+struct WaveOps {
+    int lane;
+    __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+    __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
+    __device__ __forceinline__ uint32_t incl_scan(uint32_t v) {
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+        return v;
+    }
+    __device__ __forceinline__ void wsync() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+__global__ __launch_bounds__(256) void thj_k_stitch_wave(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+    __shared__ unsigned int s_off[MAX_SLICES + 1];
+    __shared__ unsigned int s_rec;
+    __shared__ SpanHitHead s_heads[4][WAVE_MAXHITS];
+    __shared__ RAln s_pool[4][WAVE_MAXJOIN];
+    __shared__ uint8_t s_perm[4][64];
+    if (threadIdx.x == 0) s_rec = 0;
+    const int wave = (int)(threadIdx.x >> 6);
+    WaveOps x{(int)(threadIdx.x & 63)};
+    const unsigned int total = slice_offsets<256>(t.blk_gen, G, s_off);
+    for (unsigned int i = blockIdx.x * 4 + (unsigned int)wave; i < total; i += gridDim.x * 4) {
+        const int sl = slice_of(s_off, G, i);
+        const int64_t at = (int64_t)sl * t.chunk + (i - s_off[sl]);
+        const int r = (int)t.wl_gen[at];
+        // a read with a few hits per segment is cheaper as one of 64 on a wave of tier 3 proper than alone on this one
+        if (b.seg_off[(size_t)r * b.nseg + b.nseg] - b.seg_off[(size_t)r * b.nseg] < (uint32_t)WAVE_MINHITS) continue;
+        int n_emitted = 0;
+        const int st = span_read_wave(x, g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W, (int)b.read_len[r],
+                                      b.quals + (size_t)r * b.qual_stride, (uint32_t)r, s_heads[wave], s_pool[wave], s_perm[wave], sink, &n_emitted);
+        x.wsync();                                   // the LDS arrays are free for the wave's next read
+        if (st == SPAN_NEED_GENERIC) continue;
+        // the read's record count is kept by lane 0 (every lane counted the records it wrote itself)
+        sink.emitted = x.lane == 0 ? n_emitted : 0;
+        if (x.lane == 0) {
+            t.wl_gen[at] = 0xFFFFFFFFu;
+            sink.done((uint32_t)r);
+            if (st) atomicAdd(&sink.status[st], 1u);
+        }
+    }
+    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
+}
+
 static constexpr int GENERIC_MAXJOIN = 48;     // joined alignments of a read on tier 3's lean pass (40 copies of a repeat and some)
 __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
     extern __shared__ uint4 lds_stage[];          // nseg hits per thread: the chain under construction
@@ -309,6 +365,7 @@ __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, 
     for (unsigned int i = blockIdx.x * 128 + threadIdx.x; i < total; i += gridDim.x * 128) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_gen[(int64_t)sl * t.chunk + (i - s_off[sl])];
+        if ((uint32_t)r == 0xFFFFFFFFu) continue;              // thj_k_stitch_wave took it
         const uint32_t* so = b.seg_off + (size_t)r * b.nseg;
         const u64* rp = b.planes + (size_t)r * 3 * b.W;
         const uint8_t* q = b.quals + (size_t)r * b.qual_stride;
@@ -708,6 +765,8 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_multihit<4>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
         else hipLaunchKernelGGL(thj_k_stitch_multihit<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
         if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
+        static const bool no_wave_tier = getenv("THJ_NO_WAVE_TIER") != nullptr;
+        if (!no_wave_tier) hipLaunchKernelGGL(thj_k_stitch_wave, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G);
         hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     }
     if (c->span_profile) {

@@ -956,21 +956,26 @@ THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const 
 
 // lean_finish: filters of JoinSegmentsWorker (:2810-2813), check_editdist_consistency, bowtie_sam_extra, the record.
 // `order` = rank of the record among the read's output records, advanced when one is emitted.
-template <class Sink>
-THJ_HD int lean_finish(const Genome& g, const Params& p, const RAln& res, int nsegs, const u64* rp, int W, int rl,
-                       const uint8_t* qual, uint32_t read_idx, int& order, Sink& sink) {
-    if (!valid_hit(p, res)) return SPAN_OK;
-    if (THJ_EXPF(16384)) return SPAN_OK;
+// the filters of a joined hit and its tags: false = the hit is not reported
+THJ_HD bool lean_finish_check(const Genome& g, const Params& p, const RAln& res, int nsegs, const u64* rp, int W, int rl, const uint8_t* qual, Extras& e) {
+    if (!valid_hit(p, res)) return false;
+    if (THJ_EXPF(16384)) return false;
     int gapl = (res.ed - res.mm) & 0xFF;
-    if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return SPAN_OK;
+    if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return false;
     SeqView sv = res.anti ? seq_revcomp(rp, W, rl) : seq_forward(rp, W, rl);
     bool qrev;
     if (nsegs == 1) qrev = res.anti;
     else qrev = res.anti ? !read_is_own_revcomp(rp, W, rl) : false;
-    Extras e;
     sam_extra(g, p, res, sv, qual, rl, qrev, e);
     // check_editdist_consistency (done inside merge_chain in the reference) shares sam_extra's counts
-    if (nsegs > 1 && !(e.XM == res.mm || e.XM + e.both_n == res.mm)) return SPAN_OK;
+    if (nsegs > 1 && !(e.XM == res.mm || e.XM + e.both_n == res.mm)) return false;
+    return true;
+}
+template <class Sink>
+THJ_HD int lean_finish(const Genome& g, const Params& p, const RAln& res, int nsegs, const u64* rp, int W, int rl,
+                       const uint8_t* qual, uint32_t read_idx, int& order, Sink& sink) {
+    Extras e;
+    if (!lean_finish_check(g, p, res, nsegs, rp, W, rl, qual, e)) return SPAN_OK;
     emit_aln(sink, read_idx, order, res, e);
     ++order;
     return SPAN_OK;
@@ -1258,6 +1263,128 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
         }
     }
     return multi_finish(g, p, joined, nj, nsegs, rp, W, rl, qual, read_idx, sink);
+}
+
+// ---- tier 3, shared: ONE read by a wave.  A read of a repeat family has tens of hits per segment (bowtie -k 41) and an alignment
+// in every copy: for one thread that is a DFS of thousands of dependent loads, tens of joins, a sort and tens of tag passes in a row
+// (5 ms for a 40-copy read, which is then what the whole launch takes).  Here the heads of all the read's hits are staged in LDS,
+// lane i runs the DFS from first-segment hit i (dfs_seg_hits' outer loop, long_spanning_reads.cpp:2634-2664, is independent per
+// first hit: num_try is reset for each), the joined hits are gathered in visiting order by a prefix sum, ranked (stable: what the
+// insertion sort of multi_finish yields), adjacent duplicates dropped, and every kept hit's filters and tags run on a lane of its
+// own; record ranks come from a prefix sum over the hits that pass.  X: wave operations (lane, ballot, bcast, incl_scan, wsync).
+// Returns SPAN_NEED_GENERIC (nothing emitted) for what it does not take: more than WAVE_MAXHITS hits, a lane with more than
+// two joined hits, more than WAVE_MAXJOIN in all, a join that needs more cigar ops.  *n_emitted: records written (all lanes).
+static constexpr int WAVE_MAXHITS = 256, WAVE_MAXJOIN = 64;
+struct StagedHits8 {        // as StagedHits, eight bits per segment
+    const SpanHitHead* heads; const SpanHit* g0; u64 sel;
+    THJ_HD SpanHit operator[](int s) const { return staged_hit(heads, g0, (int)((sel >> (8 * s)) & 255)); }
+};
+template <class X, class Sink>
+THJ_HD int span_read_wave(X& x, const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
+                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, RAln* pool, uint8_t* perm,
+                          Sink& sink, int* n_emitted) {
+    constexpr int MS = SPAN_MAXSEG;
+    *n_emitted = 0;
+    if (so[1] == so[0]) return SPAN_OK;
+    int nsegs = 0;
+    while (nsegs < nseg && nsegs < MS && so[nsegs + 1] > so[nsegs]) ++nsegs;
+    int off[MS + 1];
+#pragma unroll
+    for (int s = 0; s <= MS; ++s) off[s] = s <= nsegs ? (int)(so[s <= nsegs ? s : 0] - so[0]) : 0;
+    const int total = (int)(so[nsegs] - so[0]);
+    if (total > WAVE_MAXHITS || off[1] > 64) return SPAN_NEED_GENERIC;
+    ghits += so[0];
+    for (int i = x.lane; i < total; i += 64) ((Q16*)heads)[i] = *(const Q16*)(ghits + i);
+    x.wsync();
+    if (!(heads[(int)(so[nsegs - 1] - so[0])].meta & SH_END)) return SPAN_OK;     // :2777-2785
+    if (p.bowtie2)
+        for (int s = 0; s < nsegs; ++s)
+            if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;      // :2625-2632
+    const int L = p.segment_length;
+    RAln r0, r1;
+    r0.valid = 0; r1.valid = 0;
+    uint32_t cnt = 0; bool punt = false;
+    if (x.lane < off[1]) {
+        int idx[MS], pleft[MS], pright[MS];
+#pragma unroll
+        for (int s = 0; s < MS; ++s) idx[s] = pleft[s] = pright[s] = 0;
+        StagedHits8 chain{heads, ghits, (u64)x.lane};
+        const SpanHit first = staged_hit(heads, ghits, x.lane);
+        const uint32_t ref0 = first.ref_id;
+        const bool anti0 = (first.meta & SH_ANTI) != 0;
+        {
+            const RAln a0 = raln_from_hit(first, 0, L, rl);
+            pleft[0] = a0.left; pright[0] = a0.left + rc_ref_span(a0.c, a0.n);
+        }
+        int num_try = 10000;
+        int depth = 1;
+        idx[1 < MS ? 1 : 0] = off[1];
+        while (depth >= 1 && !punt) {
+            if (num_try <= 0) break;
+            if (depth == nsegs) {
+                --num_try;
+                RAln res;
+                const int jr = lean_join(g, p, S, chain, nsegs, rp, W, rl, res);
+                if (jr == LJ_PUNT) { punt = true; break; }
+                if (jr == LJ_OK && valid_hit(p, res)) {
+                    if (cnt == 0) r0 = res; else if (cnt == 1) r1 = res; else { punt = true; break; }
+                    ++cnt;
+                }
+                --depth;
+                continue;
+            }
+            const int cur = rsel_get(idx, depth);
+            if (cur >= rsel_get(off, depth + 1)) { --depth; continue; }
+            rsel_set(idx, depth, cur + 1);
+            const SpanHit sh = staged_hit(heads, ghits, cur);
+            const RAln cand = raln_from_hit(sh, depth, L, rl);
+            const int cright = cand.left + rc_ref_span(cand.c, cand.n);
+            bool okc = false;
+            if (ref0 == cand.ref_id && (int)anti0 == cand.anti) {             // every hit of a chain shares contig and strand
+                const int dist = anti0 ? rsel_get(pleft, depth - 1) - cright : cand.left - rsel_get(pright, depth - 1);   // :2352-2378, :2531-2556
+                okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+            }
+            if (okc) {
+                chain.sel = (chain.sel & ~(255ull << (8 * depth))) | ((u64)cur << (8 * depth));
+                rsel_set(pleft, depth, cand.left); rsel_set(pright, depth, cright);
+                ++depth;
+                if (depth < nsegs) rsel_set(idx, depth, rsel_get(off, depth));
+            }
+        }
+    }
+    if (x.ballot(punt)) return SPAN_NEED_GENERIC;
+    const uint32_t incl = x.incl_scan(cnt), nj = x.bcast(incl, 63);
+    if (nj > (uint32_t)WAVE_MAXJOIN) return SPAN_NEED_GENERIC;
+    if (nj == 0) return SPAN_OK;
+    if (cnt > 0) pool[incl - cnt] = r0;
+    if (cnt > 1) pool[incl - cnt + 1] = r1;
+    x.wsync();
+    // rank = position after a stable sort by BowtieHit::operator<
+    if ((uint32_t)x.lane < nj) {
+        const RAln me = pool[x.lane];
+        int rank = 0;
+        for (int k = 0; k < (int)nj; ++k) {
+            if (k == x.lane) continue;
+            const RAln o = pool[k];
+            if (raln_less(o, me) || (k < x.lane && !raln_less(me, o))) ++rank;
+        }
+        perm[rank] = (uint8_t)x.lane;
+    }
+    x.wsync();
+    // sort + unique (:2805-2807), the per-hit filters and the records: lane k has the k-th hit of the sorted list
+    RAln el; el.valid = 0;
+    bool emit = false;
+    Extras e;
+    if ((uint32_t)x.lane < nj) {
+        el = pool[perm[x.lane]];
+        bool keep = true;
+        if (x.lane > 0) { const RAln prev = pool[perm[x.lane - 1]]; keep = !raln_eq(prev, el); }
+        if (keep) emit = lean_finish_check(g, p, el, nsegs, rp, W, rl, qual, e);
+    }
+    const uint32_t ei = x.incl_scan(emit ? 1u : 0u);
+    if (emit) emit_aln(sink, read_idx, (int)ei - 1, el, e);
+    *n_emitted = (int)x.bcast(ei, 63);
+    return SPAN_OK;
 }
 
 // ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
