@@ -750,9 +750,13 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
             const bool small = rdy && len <= 32u && dist >= len;
             if (small) {
                 // up to 32 bytes, source and destination apart: (unaligned) 8-byte reads, then exactly len bytes written
-                uint64_t v0, v1, v2, v3;
-                __builtin_memcpy(&v0, &buf[s], 8); __builtin_memcpy(&v1, &buf[s + 8], 8);
-                __builtin_memcpy(&v2, &buf[s + 16], 8); __builtin_memcpy(&v3, &buf[s + 24], 8);
+                // (only the words the match needs: the resolver is bound by LDS conflicts of these scattered unaligned accesses -- four waves on
+                // a member's window ran exactly as fast as one, 1.58 against 1.62 ms per 5.9 k members --, and a lane that does not read does not collide)
+                uint64_t v0, v1 = 0, v2 = 0, v3 = 0;
+                __builtin_memcpy(&v0, &buf[s], 8);
+                if (len > 8u) __builtin_memcpy(&v1, &buf[s + 8], 8);
+                if (len > 16u) __builtin_memcpy(&v2, &buf[s + 16], 8);
+                if (len > 24u) __builtin_memcpy(&v3, &buf[s + 24], 8);
                 uint32_t w = a, rest = len;
                 if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; v1 = v2; v2 = v3; }
                 if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; v1 = v2; }
@@ -860,7 +864,7 @@ extern "C" int thj_bgzf_inflate(thj_ctx* c, const uint8_t* comp, int64_t comp_by
 //
 // After the inflate every member sits in its own 64 KiB slot.  bam_write1 starts a new member rather than let a record
 // straddle two (bgzf_flush_try), so the members of a file can be walked independently:
-//   thj_k_walk        one thread per member follows the block_size chain and notes where records start
+//   thj_k_walk        one wave per member follows the block_size chain (through a 4 KiB LDS window) and notes where records start
 //   thj_k_parse_hits  one workgroup per member, one thread per record: BAMHitFactory::get_hit_from_buf (bwt_map.cpp:1101-1452)
 //                     straight from the record bytes -> (insert_id, thj_hit, thj_span_hit), plus the shard's id-range filter
 //   (scan + scatter)  the records the factory keeps, densely, in file order
@@ -885,25 +889,43 @@ enum { ST_CORRUPT = 0, ST_STRADDLE = 1, ST_XF = 2, ST_CIGAR = 3, ST_MISSING_READ
 
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
+// One WAVE per member: the block_size chain is a chain of dependent loads (~280 records a member), from HBM 0.44 ms per launch with a
+// thread per member.  The wave copies the member through a 4 KiB LDS window (one coalesced sweep per window), lane 0 follows the chain
+// in LDS.
 __global__ __launch_bounds__(64) void thj_k_walk(const uint8_t* __restrict__ infl, const uint32_t* __restrict__ len, const uint8_t* __restrict__ blk_file,
                                                  const FileInfo* __restrict__ files, int n_blocks, uint16_t* __restrict__ rec_off, uint32_t* __restrict__ cnt,
                                                  unsigned int* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr uint32_t WIN = 4096, WINX = WIN + 16;               // a block_size field may begin in the window's last bytes
+    __shared__ __attribute__((aligned(16))) uint8_t win[WINX];
+    const int b = (int)blockIdx.x, lane = (int)threadIdx.x;
     if (b >= n_blocks) return;
     const uint32_t L = len[b];
-    uint32_t k = 0;
-    if (L == 0xFFFFFFFFu || L > 65536u) { atomicExch(&status[ST_CORRUPT], 1u); cnt[b] = 0; return; }
+    if (L == 0xFFFFFFFFu || L > 65536u) { if (lane == 0) { atomicExch(&status[ST_CORRUPT], 1u); cnt[b] = 0; } return; }
     const FileInfo f = files[blk_file[b]];
-    uint32_t p = (uint32_t)b == f.first_block ? f.first_skip : 0u;
+    uint32_t p = (uint32_t)b == f.first_block ? f.first_skip : 0u, k = 0;
     const uint8_t* base = infl + ((size_t)b << 16);
     while (p + 4 <= L && k < (uint32_t)MAXREC) {
-        const uint32_t bs = ld32(base + p);
-        if (bs < 32u || p + 4 + bs > L) break;
-        rec_off[(size_t)b * MAXREC + k++] = (uint16_t)p;
-        p += 4 + bs;
+        const uint32_t c0 = p & ~(WIN - 1);
+        for (uint32_t i = (uint32_t)lane * 16u; i < WINX && c0 + i + 16u <= 65536u; i += 1024u) *(uint4*)&win[i] = *(const uint4*)(base + c0 + i);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t stop = 0;
+        if (lane == 0) {
+            while (p + 4 <= L && k < (uint32_t)MAXREC && p + 4 <= c0 + WINX) {
+                const uint32_t bs = ld32(&win[p - c0]);
+                if (bs < 32u || p + 4 + bs > L) { stop = 1; break; }
+                rec_off[(size_t)b * MAXREC + k++] = (uint16_t)p;
+                p += 4 + bs;
+            }
+        }
+        p = (uint32_t)__builtin_amdgcn_readfirstlane((int)p); k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+        stop = (uint32_t)__builtin_amdgcn_readfirstlane((int)stop);
+        __builtin_amdgcn_wave_barrier();                          // the window is free again
+        if (stop) break;
     }
-    if (p != L) atomicExch(&status[ST_STRADDLE], 1u);       // a record runs past the member (or garbage): not samtools' layout
-    cnt[b] = k;
+    if (lane == 0) {
+        if (p != L) atomicExch(&status[ST_STRADDLE], 1u);       // a record runs past the member (or garbage): not samtools' layout
+        cnt[b] = k;
+    }
 }
 
 struct ParseOut { uint32_t* id; uint32_t* valid; Hit16* h16; Hit32* h32; uint32_t* loc; };
@@ -1148,12 +1170,28 @@ __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restri
         const uint32_t L = l_seq > (uint32_t)W * 64u ? (uint32_t)W * 64u : l_seq;
         for (int w = 0; w < W; ++w) {
             u64 lo = 0, hi = 0, nn = 0;
-            for (uint32_t k = 0; k < 64 && (uint32_t)w * 64 + k < L; ++k) {
+            // sixteen bases a step while whole groups are left, then base by base (a dependent byte load per two bases was 1.6 ms per launch)
+            for (uint32_t k = 0; k < 64 && (uint32_t)w * 64 + k < L; ) {
                 const uint32_t bi = (uint32_t)w * 64 + k;
-                const uint32_t nib = (sq[bi >> 1] >> ((bi & 1) ? 0 : 4)) & 0xF;
-                uint32_t code; bool isn = false;
-                switch (nib) { case 1: code = 0; break; case 2: code = 1; break; case 4: code = 2; break; case 8: code = 3; break; default: code = 0; isn = true; }
-                lo |= (u64)(code & 1) << k; hi |= (u64)(code >> 1) << k; nn |= (u64)(isn ? 1 : 0) << k;
+                if (bi + 16 <= L) {
+                    // eight byte loads in flight, not one 8-byte load: as `global_load_dwordx2` from these byte-aligned addresses the group came back
+                    // wrong now and then (a run of 80 000 pairs lost ~200 alignments, different ones each time; byte loads: none in ten runs)
+                    u64 v = 0;
+#pragma unroll
+                    for (int bb = 0; bb < 8; ++bb) v |= (u64)sq[(bi >> 1) + bb] << (8 * bb);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const uint32_t nib = (uint32_t)(v >> (8 * (j >> 1) + ((j & 1) ? 0 : 4))) & 0xFu;
+                        const u64 b0 = (nib == 2u) | (nib == 8u), b1 = (nib == 4u) | (nib == 8u), isn = !((nib == 1u) | (nib == 2u) | (nib == 4u) | (nib == 8u));
+                        lo |= b0 << (k + j); hi |= b1 << (k + j); nn |= isn << (k + j);
+                    }
+                    k += 16;
+                } else {
+                    const uint32_t nib = (sq[bi >> 1] >> ((bi & 1) ? 0 : 4)) & 0xF;
+                    const u64 b0 = (nib == 2u) | (nib == 8u), b1 = (nib == 4u) | (nib == 8u), isn = !((nib == 1u) | (nib == 2u) | (nib == 4u) | (nib == 8u));
+                    lo |= b0 << k; hi |= b1 << k; nn |= isn << k;
+                    ++k;
+                }
             }
             pl[w] = lo; pl[W + w] = hi; pl[2 * W + w] = nn;
         }
@@ -1161,7 +1199,10 @@ __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restri
         if (quals) {                                               // phred+33 text, as thj_span_batch.quals wants it
             const uint8_t* q = sq + ((l_seq + 1) >> 1);
             uint8_t* dq = quals + (size_t)r * qstride;
-            for (uint32_t k = 0; k < l_seq && (int)k < qstride; ++k) dq[k] = (uint8_t)(q[k] + 33);
+            const uint32_t nq = l_seq < (uint32_t)qstride ? l_seq : (uint32_t)qstride;
+            uint32_t k = 0;
+            for (; k + 8 <= nq; k += 8) { u64 v; __builtin_memcpy(&v, q + k, 8); v += 0x2121212121212121ull; __builtin_memcpy(dq + k, &v, 8); }   // (a quality is < 94: no carry between bytes)
+            for (; k < nq; ++k) dq[k] = (uint8_t)(q[k] + 33);
         }
         if (row_loc) row_loc[r] = loc[i];
         (void)status;
@@ -1169,7 +1210,12 @@ __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restri
 }
 
 __global__ void thj_k_check_seen(const uint32_t* seen, uint32_t n, unsigned int* status) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (!seen[i]) atomicExch(&status[ST_MISSING_READ], 1u);
+    // (one atomic per wave that has something to report, and none once it is reported: thousands of lanes on one address took 0.4 ms)
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const uint32_t i = i0 + threadIdx.x;
+        const bool miss = i < n && !seen[i];
+        if (__ballot(miss) && (threadIdx.x & 63) == 0 && !__atomic_load_n(&status[ST_MISSING_READ], __ATOMIC_RELAXED)) atomicExch(&status[ST_MISSING_READ], 1u);
+    }
 }
 
 }  // namespace ing
@@ -1324,7 +1370,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     { uint32_t mx = 0; for (const auto& bk : blocks) mx = bk.in_len > mx ? bk.in_len : mx;
       const int rc_ = launch_inflate(c, d_comp, d_blocks, nb, d_infl, d_len, mx); if (rc_) return rc_; }
     pc.mark(1);
-    hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
+    hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)nb), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
     int rc = exclusive_sum(c, d_cnt, d_base, nb + 1);
     if (rc) return rc;
     std::vector<uint32_t> h_base((size_t)nb + 1);
