@@ -1201,7 +1201,13 @@ __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restri
             uint8_t* dq = quals + (size_t)r * qstride;
             const uint32_t nq = l_seq < (uint32_t)qstride ? l_seq : (uint32_t)qstride;
             uint32_t k = 0;
-            for (; k + 8 <= nq; k += 8) { u64 v; __builtin_memcpy(&v, q + k, 8); v += 0x2121212121212121ull; __builtin_memcpy(dq + k, &v, 8); }   // (a quality is < 94: no carry between bytes)
+            for (; k + 8 <= nq; k += 8) {                          // eight bytes in flight (byte accesses: see the note on the bases above)
+                uint8_t t[8];
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) t[bb] = q[k + bb];
+#pragma unroll
+                for (int bb = 0; bb < 8; ++bb) dq[k + bb] = (uint8_t)(t[bb] + 33);
+            }
             for (; k < nq; ++k) dq[k] = (uint8_t)(q[k] + 33);
         }
         if (row_loc) row_loc[r] = loc[i];
