@@ -858,7 +858,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     resc_alg = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 192)
     kernels = [
         {"kernel": "thj_k_segjuncs", "avg_kernel_ms": kern_ms[0], "launches": launches, "algorithmic_bytes_per_launch": seg_alg},
-        {"kernel": "thj_k_segjuncs_rescue", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": resc_alg},
+        {"kernel": "thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": resc_alg},
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
         {"kernel": "thj_k_stitch_multihit", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
@@ -898,7 +898,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
         if args.read_len == 100 and args.genome == "chr20" and use_heads and not args.fusion_search and not n_ium and pm["config"] == want_cfg:
             for k in kernels:
                 parts = [pm["kernels"].get(nm) for nm in k["kernel"].split(" + ")]
-                c = None if any(x is None for x in parts) else {key: sum(x.get(key, 0.0) for x in parts) for key in ("FETCH_SIZE", "WRITE_SIZE")}
+                c = None if parts[0] is None else {key: sum(x.get(key, 0.0) for x in parts if x) for key in ("FETCH_SIZE", "WRITE_SIZE")}
                 if c:
                     k["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
                     k["traffic_low"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
