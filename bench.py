@@ -389,19 +389,36 @@ def e2e_leg(args, n_gpus=1):
             return h.hexdigest()
         out["sha256"] = {n: sha(n) for n in outs}
         out["timed_run_check"] = e2e_timed_run_check(d, args)
-        # the same files again.  Every process is one process and waits for its own teardown (the default since round 3; until then the
-        # executables handed over to a child when the outputs were complete -- THJ_HANDOFF=1 still does): both runs are that figure
-        r2 = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=dict(gpu_env, THJ_NO_HANDOFF="1"))
-        out["value_no_handoff"] = r2["pairs"] / r2["both_stages_s"]
-        out["no_handoff_seconds"] = [r2["segment_juncs_s"], r2["long_spanning_reads_left_s"], r2["long_spanning_reads_right_s"]]
-        # the host's share: CPU seconds (user + system) of the three processes of that run against wall clock x CPUs available.  With the
-        # BAM records and BGZF members made on the device the host parses options and FASTA, plans shards, stages compressed input
-        # and writes members; the busy fraction says how far that is from being the limit when GPUs are added
-        cpu_s = [r2["segment_juncs_cpu_s"], r2["long_spanning_reads_left_cpu_s"], r2["long_spanning_reads_right_cpu_s"]]
+        # every process of the timed run was ONE process that waited for its own exit (the default since round 3: the output hand-off
+        # to a child of rounds 1-2 is opt-in now, THJ_HANDOFF=1), so the figure above is also the figure without hand-off
+        out["value_no_handoff"] = out["value"]
+        out["no_handoff_seconds"] = [res["segment_juncs_s"], res["long_spanning_reads_left_s"], res["long_spanning_reads_right_s"]]
+        # the host's share: CPU seconds (user + system) of the three processes against wall clock x CPUs available.  With the BAM records
+        # and BGZF members made on the device the host parses options and FASTA, plans shards, stages compressed input and writes
+        # members; the busy fraction says how far that is from being the limit when GPUs are added
+        cpu_s = [res["segment_juncs_cpu_s"], res["long_spanning_reads_left_cpu_s"], res["long_spanning_reads_right_cpu_s"]]
         ncpu = _cpu_count()
-        out["host"] = {"cpu_seconds": cpu_s, "cpus": ncpu, "busy_fraction": sum(cpu_s) / max(1e-9, r2["both_stages_s"] * ncpu),
+        out["host"] = {"cpu_seconds": cpu_s, "cpus": ncpu, "busy_fraction": sum(cpu_s) / max(1e-9, res["both_stages_s"] * ncpu),
                        "cpu_seconds_per_million_pairs": sum(cpu_s) / (res["pairs"] / 1e6)}
-        out["outputs_identical_without_handoff"] = all(sha(n) == out["sha256"][n] for n in outs[:5])
+
+        def inflated_sha(name):          # SHA-256 of the BAM stream inside the BGZF members (gzip reads them)
+            import subprocess
+            h = hashlib.sha256()
+            with subprocess.Popen(["zcat", os.path.join(d, name)], stdout=subprocess.PIPE) as pr:
+                for blk in iter(lambda: pr.stdout.read(1 << 24), b""):
+                    h.update(blk)
+            if pr.returncode != 0:
+                raise RuntimeError("zcat could not read %s" % name)
+            return h.hexdigest()
+        # the same files again through the HOST's record encoder and compressor (THJ_HOST_BAM=1): at full size the BAM streams inside the
+        # two writers' files must be the same bytes (members are cut and deflated differently), the event files the same files
+        dev_stream = {n: inflated_sha(n) for n in ("span_left.bam", "span_right.bam")}
+        r2 = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=dict(gpu_env, THJ_HOST_BAM="1"))
+        out["value_host_writer"] = r2["pairs"] / r2["both_stages_s"]
+        out["host_writer_seconds"] = [r2["segment_juncs_s"], r2["long_spanning_reads_left_s"], r2["long_spanning_reads_right_s"]]
+        out["bam_stream_sha256"] = dev_stream
+        out["device_writer_stream_equals_host_writer"] = all(inflated_sha(n) == dev_stream[n] for n in dev_stream)
+        out["outputs_identical_without_handoff"] = all(sha(n) == out["sha256"][n] for n in outs[:3]) and out["device_writer_stream_equals_host_writer"]
         out["inflate"] = e2e_inflate_roofline(os.path.join(d, "left_seg1.bam"))
     finally:
         shutil.rmtree(d, ignore_errors=True)

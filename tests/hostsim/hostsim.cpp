@@ -155,6 +155,7 @@ struct WaveSimX {
     uint32_t bcast(uint32_t v, int src) { return b->exchange(tid, v)[src & 63]; }
     uint32_t incl_scan(uint32_t v) { const uint32_t* a = b->exchange(tid, v); uint32_t s = 0; for (int i = 0; i <= lane; ++i) s += a[i]; return s; }
     void wsync() { b->exchange(tid, 0); }
+    unsigned long long clock() { return 0; }
 };
 
 extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,

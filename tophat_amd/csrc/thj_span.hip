@@ -319,8 +319,9 @@ struct WaveOps {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }
 };
-__global__ __launch_bounds__(256) void thj_k_stitch_wave(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+__global__ __launch_bounds__(256) void thj_k_stitch_wave(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, int min_hits, unsigned long long* dbg) {
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     __shared__ SpanHitHead s_heads[4][WAVE_MAXHITS];
@@ -335,10 +336,15 @@ __global__ __launch_bounds__(256) void thj_k_stitch_wave(Genome g, Params p, Spa
         const int64_t at = (int64_t)sl * t.chunk + (i - s_off[sl]);
         const int r = (int)t.wl_gen[at];
         // a read with a few hits per segment is cheaper as one of 64 on a wave of tier 3 proper than alone on this one
-        if (b.seg_off[(size_t)r * b.nseg + b.nseg] - b.seg_off[(size_t)r * b.nseg] < (uint32_t)WAVE_MINHITS) continue;
+        if (b.seg_off[(size_t)r * b.nseg + b.nseg] - b.seg_off[(size_t)r * b.nseg] < (uint32_t)min_hits) continue;
         int n_emitted = 0;
+        unsigned long long tmk[6] = {0, 0, 0, 0, 0, 0};
         const int st = span_read_wave(x, g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W, (int)b.read_len[r],
-                                      b.quals + (size_t)r * b.qual_stride, (uint32_t)r, s_heads[wave], s_pool[wave], s_perm[wave], sink, &n_emitted);
+                                      b.quals + (size_t)r * b.qual_stride, (uint32_t)r, s_heads[wave], s_pool[wave], s_perm[wave], sink, &n_emitted, dbg ? tmk : nullptr);
+        if (dbg && x.lane == 0 && st != SPAN_NEED_GENERIC && tmk[5] > tmk[0]) {       // THJ_WAVE_TIMING: sums and maxima of the phases (10 ns ticks), reads counted in [15]
+            for (int k = 0; k < 5; ++k) { const unsigned long long dt = tmk[k + 1] - tmk[k]; atomicAdd(&dbg[k], dt); atomicMax(&dbg[8 + k], dt); }
+            atomicAdd(&dbg[15], 1ull);
+        }
         x.wsync();                                   // the LDS arrays are free for the wave's next read
         if (st == SPAN_NEED_GENERIC) continue;
         // the read's record count is kept by lane 0 (every lane counted the records it wrote itself)
@@ -766,7 +772,20 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         else hipLaunchKernelGGL(thj_k_stitch_multihit<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
         if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
         static const bool no_wave_tier = getenv("THJ_NO_WAVE_TIER") != nullptr;
-        if (!no_wave_tier) hipLaunchKernelGGL(thj_k_stitch_wave, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G);
+        static const int wave_min_hits = getenv("THJ_WAVE_MINHITS") ? atoi(getenv("THJ_WAVE_MINHITS")) : WAVE_MINHITS;
+        static const bool wave_timing = getenv("THJ_WAVE_TIMING") != nullptr;
+        unsigned long long* d_dbg = nullptr;
+        if (wave_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, c->stream)); }
+        if (!no_wave_tier) hipLaunchKernelGGL(thj_k_stitch_wave, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, wave_min_hits, d_dbg);
+        if (wave_timing) {
+            unsigned long long h[16];
+            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipMemcpy(h, d_dbg, 128, hipMemcpyDeviceToHost));
+            (void)hipFree(d_dbg);
+            const double n = h[15] ? (double)h[15] : 1.0;
+            fprintf(stderr, "[wave tier] %llu reads; mean / max us: stage + per-hit %.1f / %.1f, search + joins %.1f / %.1f, vote %.1f / %.1f, gather + rank %.1f / %.1f, filters + tags + records %.1f / %.1f\n", h[15],
+                    h[0] / n / 100.0, h[8] / 100.0, h[1] / n / 100.0, h[9] / 100.0, h[2] / n / 100.0, h[10] / 100.0, h[3] / n / 100.0, h[11] / 100.0, h[4] / n / 100.0, h[12] / 100.0);
+        }
         hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     }
     if (c->span_profile) {

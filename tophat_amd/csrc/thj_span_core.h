@@ -1274,7 +1274,7 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
 // own; record ranks come from a prefix sum over the hits that pass.  X: wave operations (lane, ballot, bcast, incl_scan, wsync).
 // Returns SPAN_NEED_GENERIC (nothing emitted) for what it does not take: more than WAVE_MAXHITS hits, a lane with more than
 // two joined hits, more than WAVE_MAXJOIN in all, a join that needs more cigar ops.  *n_emitted: records written (all lanes).
-static constexpr int WAVE_MAXHITS = 256, WAVE_MAXJOIN = 64;
+static constexpr int WAVE_MAXHITS = 256, WAVE_MAXJOIN = 64, WAVE_LANE_CHAINS = 4;
 struct StagedHits8 {        // as StagedHits, eight bits per segment
     const SpanHitHead* heads; const SpanHit* g0; u64 sel;
     THJ_HD SpanHit operator[](int s) const { return staged_hit(heads, g0, (int)((sel >> (8 * s)) & 255)); }
@@ -1282,7 +1282,9 @@ struct StagedHits8 {        // as StagedHits, eight bits per segment
 template <class X, class Sink>
 THJ_HD int span_read_wave(X& x, const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
                           const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, RAln* pool, uint8_t* perm,
-                          Sink& sink, int* n_emitted) {
+                          Sink& sink, int* n_emitted, unsigned long long* tm = nullptr) {
+#define WV_MARK(k) do { if (tm) tm[k] = x.clock(); } while (0)
+    WV_MARK(0);
     constexpr int MS = SPAN_MAXSEG;
     *n_emitted = 0;
     if (so[1] == so[0]) return SPAN_OK;
@@ -1301,58 +1303,87 @@ THJ_HD int span_read_wave(X& x, const Genome& g, const Params& p, const SpanSets
         for (int s = 0; s < nsegs; ++s)
             if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;      // :2625-2632
     const int L = p.segment_length;
+    // what the search asks of a candidate -- contig and strand, left, right -- once per hit, in the LDS the joined hits will use later
+    // (building the register cigar of a candidate to get its right end was most of a 40 x 40 x 3 walk)
+    int32_t* hleft = (int32_t*)pool;
+    int32_t* hright = hleft + WAVE_MAXHITS;
+    uint32_t* hkey = (uint32_t*)(hright + WAVE_MAXHITS);
+    static_assert(3 * WAVE_MAXHITS * 4 <= WAVE_MAXJOIN * (int)sizeof(RAln), "the per-hit arrays fit the pool");
+    for (int i = x.lane; i < total; i += 64) {
+        const SpanHit sh = staged_hit(heads, ghits, i);
+        const RAln c0 = raln_from_hit(sh, 0, L, rl);
+        hleft[i] = c0.left; hright[i] = c0.left + rc_ref_span(c0.c, c0.n); hkey[i] = (sh.ref_id << 1) | ((sh.meta & SH_ANTI) ? 1u : 0u);
+    }
+    x.wsync();
+    WV_MARK(1);
     RAln r0, r1;
     r0.valid = 0; r1.valid = 0;
     uint32_t cnt = 0; bool punt = false;
+    u64 sels[WAVE_LANE_CHAINS];
+#pragma unroll
+    for (int j = 0; j < WAVE_LANE_CHAINS; ++j) sels[j] = 0;
+    int nch = 0;
+    StagedHits8 chain0{heads, ghits, 0};
     if (x.lane < off[1]) {
         int idx[MS], pleft[MS], pright[MS];
 #pragma unroll
         for (int s = 0; s < MS; ++s) idx[s] = pleft[s] = pright[s] = 0;
         StagedHits8 chain{heads, ghits, (u64)x.lane};
-        const SpanHit first = staged_hit(heads, ghits, x.lane);
-        const uint32_t ref0 = first.ref_id;
-        const bool anti0 = (first.meta & SH_ANTI) != 0;
-        {
-            const RAln a0 = raln_from_hit(first, 0, L, rl);
-            pleft[0] = a0.left; pright[0] = a0.left + rc_ref_span(a0.c, a0.n);
-        }
+        const uint32_t key0 = hkey[x.lane];
+        const bool anti0 = (key0 & 1u) != 0;
+        pleft[0] = hleft[x.lane]; pright[0] = hright[x.lane];
         int num_try = 10000;
         int depth = 1;
         idx[1 < MS ? 1 : 0] = off[1];
+        chain0 = chain;
         while (depth >= 1 && !punt) {
             if (num_try <= 0) break;
             if (depth == nsegs) {
                 --num_try;
-                RAln res;
-                const int jr = lean_join(g, p, S, chain, nsegs, rp, W, rl, res);
-                if (jr == LJ_PUNT) { punt = true; break; }
-                if (jr == LJ_OK && valid_hit(p, res)) {
-                    if (cnt == 0) r0 = res; else if (cnt == 1) r1 = res; else { punt = true; break; }
-                    ++cnt;
-                }
+                // a complete chain: noted, joined after the search -- the lanes reach this point at different turns of the loop, and
+                // a join done here ran once per lane, forty in a row (75 us of a 96 us read)
+                if (nch < WAVE_LANE_CHAINS) {
+#pragma unroll
+                    for (int j = 0; j < WAVE_LANE_CHAINS; ++j) sels[j] = (j == nch) ? chain.sel : sels[j];
+                    ++nch;
+                } else { punt = true; break; }
                 --depth;
                 continue;
             }
             const int cur = rsel_get(idx, depth);
             if (cur >= rsel_get(off, depth + 1)) { --depth; continue; }
             rsel_set(idx, depth, cur + 1);
-            const SpanHit sh = staged_hit(heads, ghits, cur);
-            const RAln cand = raln_from_hit(sh, depth, L, rl);
-            const int cright = cand.left + rc_ref_span(cand.c, cand.n);
+            const int cleft = hleft[cur], cright = hright[cur];
             bool okc = false;
-            if (ref0 == cand.ref_id && (int)anti0 == cand.anti) {             // every hit of a chain shares contig and strand
-                const int dist = anti0 ? rsel_get(pleft, depth - 1) - cright : cand.left - rsel_get(pright, depth - 1);   // :2352-2378, :2531-2556
+            if (hkey[cur] == key0) {                                          // every hit of a chain shares contig and strand
+                const int dist = anti0 ? rsel_get(pleft, depth - 1) - cright : cleft - rsel_get(pright, depth - 1);   // :2352-2378, :2531-2556
                 okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
             }
             if (okc) {
                 chain.sel = (chain.sel & ~(255ull << (8 * depth))) | ((u64)cur << (8 * depth));
-                rsel_set(pleft, depth, cand.left); rsel_set(pright, depth, cright);
+                rsel_set(pleft, depth, cleft); rsel_set(pright, depth, cright);
                 ++depth;
                 if (depth < nsegs) rsel_set(idx, depth, rsel_get(off, depth));
             }
         }
     }
+    // the joins, every lane's j-th chain at the same time
+#pragma unroll
+    for (int j = 0; j < WAVE_LANE_CHAINS; ++j) {
+        if (j < nch && !punt) {
+            chain0.sel = sels[j];
+            RAln res;
+            const int jr = lean_join(g, p, S, chain0, nsegs, rp, W, rl, res);
+            if (jr == LJ_PUNT) punt = true;
+            else if (jr == LJ_OK && valid_hit(p, res)) {
+                if (cnt == 0) r0 = res; else if (cnt == 1) r1 = res; else punt = true;
+                ++cnt;
+            }
+        }
+    }
+    WV_MARK(2);
     if (x.ballot(punt)) return SPAN_NEED_GENERIC;
+    WV_MARK(3);
     const uint32_t incl = x.incl_scan(cnt), nj = x.bcast(incl, 63);
     if (nj > (uint32_t)WAVE_MAXJOIN) return SPAN_NEED_GENERIC;
     if (nj == 0) return SPAN_OK;
@@ -1371,6 +1402,7 @@ THJ_HD int span_read_wave(X& x, const Genome& g, const Params& p, const SpanSets
         perm[rank] = (uint8_t)x.lane;
     }
     x.wsync();
+    WV_MARK(4);
     // sort + unique (:2805-2807), the per-hit filters and the records: lane k has the k-th hit of the sorted list
     RAln el; el.valid = 0;
     bool emit = false;
@@ -1384,7 +1416,9 @@ THJ_HD int span_read_wave(X& x, const Genome& g, const Params& p, const SpanSets
     const uint32_t ei = x.incl_scan(emit ? 1u : 0u);
     if (emit) emit_aln(sink, read_idx, (int)ei - 1, el, e);
     *n_emitted = (int)x.bcast(ei, 63);
+    WV_MARK(5);
     return SPAN_OK;
+#undef WV_MARK
 }
 
 // ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
