@@ -552,6 +552,40 @@ THJ_HD bool gaps_prepare(const Params& p, ReadView& v, bool& wants_rescue) {
     return true;
 }
 
+// The same by a group of callers sharing one read (a wave: lane, 64): each takes every stride-th first-segment hit of the partner
+// search, `any` (called once by all of them) tells whether any found one.
+template <class Any>
+THJ_HD bool gaps_prepare_shared(const Params& p, ReadView& v, bool& wants_rescue, int first, int stride, Any any) {
+    wants_rescue = false;
+    v.rescue = false;
+    v.check_len = p.segment_length - p.segment_mismatches - 3;
+    if (v.check_len > 15) v.check_len = 15;
+    if (v.nseg == 0) return false;
+    int last = v.nseg - 1;
+    while (last > 0 && rv_count_raw(v, last) == 0) --last;
+    v.size = last + 1;
+    if (last == 0) {
+        if (rv_count_raw(v, 0) == 0) return false;
+        Hit h0 = v.hits[v.so[0]];
+        if (hit_end(h0)) return false;                                        // :3316-3318
+    }
+    bool found = false;
+    if (last != 0) {
+        for (uint32_t i = v.so[0] + (uint32_t)first; i < v.so[1] && !found; i += (uint32_t)stride) {
+            Hit lh = v.hits[i];
+            for (uint32_t j = v.so[last]; j < v.so[last + 1]; ++j) {
+                Hit rh = v.hits[j];
+                if (lh.ref_id == rh.ref_id && hit_anti(lh) == hit_anti(rh)) {
+                    int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
+                    if (dist >= p.min_segment_intron && dist < p.max_segment_intron) { found = true; break; }
+                }
+            }
+        }
+    }
+    wants_rescue = !any(found) && v.n_mate > 0;
+    return true;
+}
+
 // Most reads are unspliced: one hit per segment, the hits abutting on one strand.  For those neither
 // find_insertions_and_deletions nor find_gaps can produce a task, and unless the mate-anchored rescue applies there is
 // nothing to do.  This is that test, made on a handful of hits before any of the general machinery runs; `true` is a

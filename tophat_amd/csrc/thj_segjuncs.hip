@@ -137,7 +137,9 @@ __device__ __forceinline__ ReadView make_view(const DevBatch& b, int r) {
 
 static constexpr int TPB = 256;
 static constexpr int QCAP = 512;           // task queue entries (LDS); a typical tile of 256 reads adds a few dozen
-static constexpr int HEAVY_HITS = 24;      // a read with more hits than this is enumerated by a wave, not by a thread
+static constexpr int HEAVY_HITS = 24;      // a read with more hits than this is done by a wave (thj_k_segjuncs_shared), not by a thread
+static constexpr int MANY_CAP = 1 << 20;   // such reads of one launch that can be listed (the rest stay with their threads)
+static constexpr int MANY_HITS_LDS = 256;  // hits of such a read staged in LDS (more: read from HBM)
 
 struct Queue {
     uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e;
@@ -224,7 +226,8 @@ __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, cons
 // Reads that take the mate-anchored rescue (find_gaps :3330-3497) are few and their map_read_to_contig scans long,
 // so the main kernel only lists them -- per workgroup, in its own slice of `list`, no global append counter -- and
 // thj_k_segjuncs_rescue handles them densely afterwards.
-struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; int32_t* slot_pool; unsigned int* heavy_count; uint32_t* heavy_list; };
+struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; int32_t* slot_pool; unsigned int* heavy_count; uint32_t* heavy_list;
+                    unsigned int* many_count; uint32_t* many_list; int own_slice; };    // many_*: reads with many hits, for thj_k_segjuncs_shared; own_slice: its slice of `list`
 
 // Main kernel.  One workgroup walks tiles of 256 consecutive reads.
 //   stage:     find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
@@ -244,9 +247,8 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
     uint32_t* s_so = q_e + QCAP;
     uint4* s_hits = (uint4*)(s_so + ((TPB * b.nseg + 1 + 3) & ~3));
     uint32_t* s_work = (uint32_t*)(s_hits + hit_cap);
-    __shared__ unsigned int q_n, s_nwork, s_nresc, s_nheavy;
+    __shared__ unsigned int q_n, s_nwork, s_nresc;
     __shared__ unsigned int s_stat[4];
-    __shared__ uint16_t s_heavy[TPB];                 // reads of the tile with more than HEAVY_HITS hits: enumerated by a wave each
     const int tid = threadIdx.x;
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) { q_n = 0; s_nresc = 0; }
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
         const int n_so = tile_reads * b.nseg + 1;
         __syncthreads();                                  // the previous tile's readers are done with the LDS copy
         for (int i = tid; i < n_so; i += TPB) s_so[i] = b.seg_off[(size_t)r0 * b.nseg + i];
-        if (tid == 0) { s_nwork = 0; s_nheavy = 0; }
+        if (tid == 0) s_nwork = 0;
         __syncthreads();
         const unsigned int q_before = q_n;               // tasks carried over from earlier tiles
         const uint32_t h0 = s_so[0], nh_tile = s_so[n_so - 1] - h0;
@@ -285,8 +287,13 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             my_hits += v.so[v.nseg] - v.so[0];                // summed per thread, one LDS add at the end of the kernel
             if (!read_is_trivial(p, v)) {
                 bool wants = false;
-                if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants) to_rescue = true;
-                else if (v.so[v.nseg] - v.so[0] > (uint32_t)HEAVY_HITS && !THJ_EXPF(1 << 24)) s_heavy[atomicAdd(&s_nheavy, 1u)] = (uint16_t)tid;
+                // a read with many hits (multihits: tens a segment) is not even classified here -- its partner search alone is a
+                // 40 x 40 loop -- but listed for thj_k_segjuncs_shared, which gives it a wave
+                unsigned int mk = 0;
+                bool many = v.so[v.nseg] - v.so[0] > (uint32_t)HEAVY_HITS && !THJ_EXPF(1 << 24);
+                if (many) { mk = atomicAdd(rl.many_count, 1u); many = mk < (unsigned int)MANY_CAP; }
+                if (many) rl.many_list[mk] = (uint32_t)(r0 + tid);
+                else if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants) to_rescue = true;
                 else to_work = true;
             }
         }
@@ -321,19 +328,6 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             if (do_gaps) gaps_enumerate(p, v, qs);
             my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
-        // ---- reads with many hits (multihits: up to 41 a segment, pairs of them by the hundred): a wave shares one, lane = hit.
-        // One thread walking 40 x 40 pairs three times over held its whole tile up (39 ms a step with 0.25 % such reads).
-        for (unsigned int h = (unsigned int)tid >> 6; h < s_nheavy; h += TPB / 64) {
-            const int lr = (int)s_heavy[h], hr = r0 + lr;
-            ReadView hv = make_view(b, hr);
-            hv.so = s_so + lr * b.nseg;
-            hv.hits = tile_hits;
-            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)hr, staged ? h0 : 0u, 0u, 0u};
-            if (!THJ_EXPF(1 << 17)) indels_enumerate(p, hv, qs, tid & 63, 64);
-            bool wants = false;
-            if (!THJ_EXPF(1 << 18) && gaps_prepare(p, hv, wants)) gaps_enumerate(p, hv, qs, tid & 63, 64);
-            my_windows += qs.n_windows; my_indels += qs.n_indels;
-        }
         __syncthreads();
         if (q_n > (unsigned)QCAP) {
             // the queue overflowed (multihit-heavy tile): drop this tile's queued tasks and run the tile un-queued.
@@ -342,16 +336,6 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
                 InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
                 indels_enumerate(p, v, is);
                 if (do_gaps) gaps_enumerate(p, v, is);
-            }
-            for (unsigned int h = (unsigned int)tid >> 6; h < s_nheavy; h += TPB / 64) {
-                const int lr = (int)s_heavy[h], hr = r0 + lr;
-                ReadView hv = make_view(b, hr);
-                hv.so = s_so + lr * b.nseg;
-                hv.hits = tile_hits;
-                InlineSink<WIDE> is{g, p, hv, ev, b.ordinal_base + (uint32_t)hr};
-                indels_enumerate(p, hv, is, tid & 63, 64);
-                bool wants = false;
-                if (gaps_prepare(p, hv, wants)) gaps_enumerate(p, hv, is, tid & 63, 64);
             }
             __syncthreads();
             if (tid == 0) q_n = q_before;
@@ -368,6 +352,79 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
         if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
         if (s_stat[2]) atomicAdd(&t.cnt[CNT_HITS], (unsigned long long)s_stat[2]);
+        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+    }
+}
+
+// The reads with many hits (listed by the main kernel, unclassified): one WAVE per read.  The read's hits are staged in LDS, the partner
+// search of find_gaps' head is shared over the lanes; a read that takes the mate-anchored rescue goes to this kernel's own slice of
+// the rescue list (the rescue kernels run next), the others are enumerated here, lane = hit, into the usual queue.
+template <bool WIDE>
+__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params p, DevBatch b, Tables t, RescueList rl) {
+    __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
+    __shared__ unsigned int q_n;
+    __shared__ unsigned int s_stat[4];
+    __shared__ Hit s_h[TPB / 64][MANY_HITS_LDS];
+    __shared__ uint32_t s_o[TPB / 64][12];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 4) s_stat[tid] = 0;
+    if (tid == 0) q_n = 0;
+    __syncthreads();
+    EventSink ev{g, t};
+    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const unsigned int n = *rl.many_count < (unsigned int)MANY_CAP ? *rl.many_count : (unsigned int)MANY_CAP;
+    constexpr unsigned int WPB = TPB / 64;
+    unsigned int my_windows = 0, my_indels = 0;
+    for (unsigned int base = blockIdx.x * WPB; base < n; base += gridDim.x * WPB) {
+        __syncthreads();
+        const unsigned int q_before = q_n;
+        __syncthreads();
+        const unsigned int h = base + (unsigned int)wave;
+        const bool active = h < n;
+        const int r = active ? (int)rl.many_list[h] : 0;
+        ReadView v;
+        bool do_gaps = false, wants = false;
+        uint32_t hbase = 0;
+        if (active) {
+            v = make_view(b, r);
+            const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
+            if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 12) {                 // the hits and their offsets into LDS
+                for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
+                if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
+            }
+            do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
+            if (do_gaps && wants) {
+                // the rescue kernels take it from here (their list, this kernel's slice)
+                if (lane == 0) rl.list[(size_t)rl.own_slice * rl.seg_cap + atomicAdd(&rl.blk_cnt[rl.own_slice], 1u)] = (uint32_t)r;
+            } else {
+                QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, hbase, 0u, 0u};
+                if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, lane, 64);
+                if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
+                my_windows += qs.n_windows; my_indels += qs.n_indels;
+            }
+        }
+        __syncthreads();
+        if (q_n > (unsigned)QCAP) {
+            if (tid == 0) atomicAdd(&s_stat[3], 1u);
+            if (active && !(do_gaps && wants)) {
+                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                indels_enumerate(p, v, is, lane, 64);
+                if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
+            }
+            __syncthreads();
+            if (tid == 0) q_n = q_before;
+            __syncthreads();
+        }
+        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * WPB >= n);
+    }
+    if (my_windows) atomicAdd(&s_stat[0], my_windows);
+    if (my_indels) atomicAdd(&s_stat[1], my_indels);
+    __syncthreads();
+    if (tid == 0) {
+        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
         if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
@@ -765,7 +822,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     free_tables(c);
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
-    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_rescue_slots); hipFree(c->d_fus_ignore);
+    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_rescue_slots); hipFree(c->d_many); hipFree(c->d_fus_ignore);
     if (c->probe_ev) hipEventDestroy(c->probe_ev);
     hipHostFree(c->h_pinned);
     thj_span_free(c); thj_bamout_free(c);
@@ -1000,7 +1057,7 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     { int f = getenv("THJ_EXP_FLAGS") ? atoi(getenv("THJ_EXP_FLAGS")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(thj_exp_flags), &f, sizeof f)); }
 #endif
     const int n_tiles = (n + TPB - 1) / TPB;
-    int grid = n_tiles < 256 * 8 ? n_tiles : 256 * 8;       // 256 CUs x 8 resident workgroups, grid-stride the rest
+    int grid = n_tiles < 256 * 8 - 1 ? n_tiles : 256 * 8 - 1;       // 256 CUs x 8 resident workgroups, grid-stride the rest (one rescue-list slice is thj_k_segjuncs_shared's)
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
     // LDS: task queue, the tile's offsets, room for 1.5 hits per segment (tiles with more read hits from HBM), work list
@@ -1009,14 +1066,20 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     // rescue list: one slice per workgroup, sized for all the reads the workgroup visits
     RescueList rl;
     rl.seg_cap = (n_tiles + grid - 1) / grid * TPB;
-    const int64_t need = (int64_t)grid * rl.seg_cap + MAX_LISTS;
+    const int64_t need = (int64_t)grid * rl.seg_cap + MANY_CAP + MAX_LISTS;       // the workgroups' slices, the shared kernel's (room for every read it may get), the counts
     if (c->rescue_list_cap < need) {
         hipFree(c->d_rescue_list); c->d_rescue_list = nullptr;
         HIPCHK(hipMalloc(&c->d_rescue_list, (size_t)need * 4));
         c->rescue_list_cap = need;
     }
     rl.list = c->d_rescue_list;
-    rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap;
+    rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap + MANY_CAP;
+    rl.own_slice = grid;
+    if (!c->d_many) HIPCHK(hipMalloc((void**)&c->d_many, 16 + (size_t)MANY_CAP * 4));
+    rl.many_count = (unsigned int*)c->d_many;
+    rl.many_list = c->d_many + 4;
+    HIPCHK(hipMemsetAsync(c->d_many, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(rl.blk_cnt + grid, 0, 4, c->stream));
     // [16 bytes: the count of listed reads][HEAVY_CAP read indices][HEAVY_CAP slices of GPT pairs' outcomes]
     if (b.mate_off && !c->d_rescue_slots) HIPCHK(hipMalloc((void**)&c->d_rescue_slots, 16 + (size_t)HEAVY_CAP * 4 + (size_t)HEAVY_CAP * GPT * 2 * sizeof(int32_t)));
     rl.heavy_count = (unsigned int*)c->d_rescue_slots;
@@ -1026,11 +1089,16 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     const bool wide = p.segment_length > 32;
     if (wide) hipLaunchKernelGGL(thj_k_segjuncs<true>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
     else hipLaunchKernelGGL(thj_k_segjuncs<false>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
+    {   // the reads with many hits the main kernel listed: a wave each
+        const int sgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
+        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_shared<true>, dim3(sgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
+        else hipLaunchKernelGGL(thj_k_segjuncs_shared<false>, dim3(sgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
+    }
     if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
     if (b.mate_off) {
         const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
-        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
-        else hipLaunchKernelGGL(thj_k_segjuncs_rescue<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid);
+        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid + 1);
+        else hipLaunchKernelGGL(thj_k_segjuncs_rescue<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid + 1);
         if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
         else hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
     }
