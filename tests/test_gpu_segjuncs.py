@@ -191,7 +191,7 @@ def test_rescue_slot_overflow(lib):
 
 
 def test_reads_with_many_hits_share_a_wave(lib):
-    """Reads with more than 24 hits are enumerated by a wave (lane = hit) in both kernels, reads with 5..64 (hit, mate hit) pairs
+    """Reads with more than 12 hits are done by a wave (thj_k_segjuncs_shared, lane = hit; the rescue kernels for those that take the rescue), reads with 5..64 (hit, mate hit) pairs
     keep their rescue outcomes in the HBM pool, more than 64 recompute them: the same events and counters as the oracle's loops.
     Multihits up to max_seg_multihits = 40 a segment; a read with 41 is dropped whole (segment_juncs.cpp:3499-3506)."""
     from tophat_amd.batch import HIT_DTYPE, SegBatch

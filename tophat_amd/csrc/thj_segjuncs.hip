@@ -137,7 +137,7 @@ __device__ __forceinline__ ReadView make_view(const DevBatch& b, int r) {
 
 static constexpr int TPB = 256;
 static constexpr int QCAP = 512;           // task queue entries (LDS); a typical tile of 256 reads adds a few dozen
-static constexpr int HEAVY_HITS = 24;      // a read with more hits than this is done by a wave (thj_k_segjuncs_shared), not by a thread
+static constexpr int HEAVY_HITS = 12;      // a read with more hits than this is done by a wave (thj_k_segjuncs_shared), not by a thread
 static constexpr int MANY_CAP = 1 << 20;   // such reads of one launch that can be listed (the rest stay with their threads)
 static constexpr int MANY_HITS_LDS = 256;  // hits of such a read staged in LDS (more: read from HBM)
 
@@ -227,7 +227,7 @@ __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, cons
 // so the main kernel only lists them -- per workgroup, in its own slice of `list`, no global append counter -- and
 // thj_k_segjuncs_rescue handles them densely afterwards.
 struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; int32_t* slot_pool; unsigned int* heavy_count; uint32_t* heavy_list;
-                    unsigned int* many_count; uint32_t* many_list; int own_slice; };    // many_*: reads with many hits, for thj_k_segjuncs_shared; own_slice: its slice of `list`
+                    unsigned int* many_count; uint32_t* many_list; int own_slice; int many_min; };    // many_*: reads with many hits, for thj_k_segjuncs_shared; own_slice: its slice of `list`
 
 // Main kernel.  One workgroup walks tiles of 256 consecutive reads.
 //   stage:     find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
                 // a read with many hits (multihits: tens a segment) is not even classified here -- its partner search alone is a
                 // 40 x 40 loop -- but listed for thj_k_segjuncs_shared, which gives it a wave
                 unsigned int mk = 0;
-                bool many = v.so[v.nseg] - v.so[0] > (uint32_t)HEAVY_HITS && !THJ_EXPF(1 << 24);
+                bool many = v.so[v.nseg] - v.so[0] > (uint32_t)rl.many_min && !THJ_EXPF(1 << 24);
                 if (many) { mk = atomicAdd(rl.many_count, 1u); many = mk < (unsigned int)MANY_CAP; }
                 if (many) rl.many_list[mk] = (uint32_t)(r0 + tid);
                 else if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants) to_rescue = true;
@@ -1075,6 +1075,8 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     rl.list = c->d_rescue_list;
     rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap + MANY_CAP;
     rl.own_slice = grid;
+    static const int many_min = getenv("THJ_MANY_HITS") ? atoi(getenv("THJ_MANY_HITS")) : HEAVY_HITS;
+    rl.many_min = many_min;
     if (!c->d_many) HIPCHK(hipMalloc((void**)&c->d_many, 16 + (size_t)MANY_CAP * 4));
     rl.many_count = (unsigned int*)c->d_many;
     rl.many_list = c->d_many + 4;
