@@ -26,6 +26,14 @@ def _prefix(env, stage):
     return pre.replace("{stage}", stage).split() if pre else []
 
 
+def _run(cmd, env):
+    """a stage with a deadline: a process that hangs (a collective that never completes, say) is an error here, not a hung bench"""
+    try:
+        return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=float(os.environ.get("THJ_STAGE_TIMEOUT", "600")))
+    except subprocess.TimeoutExpired as e:
+        raise RuntimeError("%s did not finish within %s s" % (os.path.basename(cmd[0]), e.timeout))
+
+
 def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False):
     nseg = max(1, read_len // 25)
     d = workdir or tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -53,7 +61,7 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
         ru = resource.getrusage(resource.RUSAGE_CHILDREN)
         return ru.ru_utime + ru.ru_stime
     t = time.time(); c0 = child_cpu()
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    r = _run(cmd, env)
     dt = time.time() - t
     if r.returncode != 0:
         raise RuntimeError("segment_juncs failed:\n" + r.stderr[-3000:])
@@ -68,7 +76,7 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
         cmd = _prefix(env, "lsr_" + sd) + [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
                f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", f("span_%s.bam" % sd), segs[sd]]
         t = time.time(); c0 = child_cpu()
-        r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+        r = _run(cmd, env)
         dt = time.time() - t
         if r.returncode != 0:
             raise RuntimeError("long_spanning_reads failed:\n" + r.stderr[-3000:])
