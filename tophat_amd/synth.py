@@ -770,6 +770,14 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
             deletion_truth = torch.stack([ga[:, 0] + 1, pa + x - 1, pa + x + dl], 1)
     del gcodes
 
+    def take(rows, mask):
+        # torch's masked / indexed row selection returns wrong rows on this ROCm build once the result passes 2^29 elements
+        # (tools/gen40_probe2.py): select in pieces of 2^24 rows
+        P = 1 << 24
+        if rows.shape[0] <= P:
+            return rows[mask].contiguous()
+        return torch.cat([rows[i:i + P][mask[i:i + P]] for i in range(0, rows.shape[0], P)]).contiguous()
+
     def csr(mapped, rows, multi, left_cols):
         """CSR offsets + rows of the mapped (read, segment) cells; cells of `multi` reads appear twice, the copy
         shifted by dup_shift in the columns `left_cols`"""
@@ -778,11 +786,12 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
             cnt = cnt * (multi if multi.dtype == torch.int32 else 1 + multi.to(torch.int32)).repeat_interleave(nseg)
         off = torch.zeros(n_pairs * nseg + 1, dtype=torch.int32, device=device)
         off[1:] = torch.cumsum(cnt, 0)
+        PIECE = 1 << 24
         if multi is None:
-            return off, rows[mapped].contiguous()
+            return off, take(rows, mapped)
         cell = torch.arange(n_pairs * nseg, device=device).repeat_interleave(cnt.to(torch.int64))
         copy = torch.arange(cell.shape[0], device=device, dtype=torch.int64) - off[:-1].to(torch.int64)[cell]
-        out_rows = rows[cell].clone()
+        out_rows = torch.cat([rows[cell[i:i + PIECE]] for i in range(0, cell.shape[0], PIECE)]) if cell.shape[0] > PIECE else rows[cell].clone()
         for col in left_cols:
             out_rows[:, col] += (copy * dup_shift).to(out_rows.dtype)
         return off, out_rows.contiguous()
@@ -805,7 +814,7 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
         m_has = other["full_ok"] | other["seg_mapped"][:, nseg - 1]
         mate_off = torch.zeros(n_pairs + 1, dtype=torch.int32, device=device)
         mate_off[1:] = torch.cumsum(m_has.to(torch.int32), 0)
-        mh = torch.where(other["full_ok"][:, None], other["full_hit"], other["seg_hits"][:, nseg - 1, :])[m_has].contiguous()
+        mh = take(torch.where(other["full_ok"][:, None], other["full_hit"], other["seg_hits"][:, nseg - 1, :]), m_has)
         smapped = b["span_mapped"].reshape(-1)
         span_off, span_hits = csr(smapped, b["span_hits"].reshape(-1, 8), multi, (1,))
         quals = torch.full((n_pairs * read_len,), ord("I"), dtype=torch.uint8, device=device)
