@@ -812,22 +812,28 @@ THJ_HD Planes genomic_piece(const Genome& g, uint32_t ref, int64_t start, int rl
     return rc_piece(p, len);
 }
 
-// detect_fusion with the whole-read simpleSplitAlignment (all tied best positions).  Sink: fusion(ref1,ref2,left,right,dir,ed).
-template <class Sink>
-THJ_HD void detect_fusion(const Genome& g, const Params& p, const u64* rp, int W, int rl, bool read_rc, const Hit& lh, const Hit& rh,
-                          int dir, Sink& sink) {
+// detect_fusion with the whole-read simpleSplitAlignment (all tied best positions), in two steps so that a wave can reserve the
+// room for all its lanes' events with one atomic: fusion_eval -> how many events the pair gives (0: none), fusion_emit -> the
+// k-th of them to f(k, ref1, ref2, left, right, dir, ed).
+// e(q) = errors of the left hit's string before q + errors of the right hit's string from q on, q = 1..rl-1; the events are the
+// q with the smallest e, unless that exceeds the hits' edit distances or 2, or one of them leaves a side shorter than
+// fusion_anchor_length (:2697-2713).  One walk over the two mismatch masks finds the minimum, how often it is reached and
+// the minimum over the forbidden ends; a second walk, only for the pairs that pass, emits.
+struct FusEval { u64 mL[4], mR[4]; int e1, min_err, total_ed; bool lrc, rrc; };
+THJ_HD int fusion_eval(const Genome& g, const Params& p, const u64* rp, int W, int rl, bool read_rc, const Hit& lh, const Hit& rh, int dir, FusEval& ev) {
     const int32_t llen = g_len(g, lh.ref_id), rlen = g_len(g, rh.ref_id);
-    if (llen == 0 || rlen == 0 || rl > 256) return;
+    if (llen == 0 || rlen == 0 || rl > 256) return 0;
     int64_t lstart, rstart;
     const bool lrc = !(dir == FUS_FF || dir == FUS_FR), rrc = !(dir == FUS_FF || dir == FUS_RF);
-    if (!lrc) { if (lh.left + rl > llen || lh.left < 0) return; lstart = lh.left; }
-    else { if (lh.right < rl || lh.right > llen) return; lstart = (int64_t)lh.right - rl; }
-    if (!rrc) { if (rh.right < rl || rh.right > rlen) return; rstart = (int64_t)rh.right - rl; }
-    else { if (rh.left + rl > rlen || rh.left < 0) return; rstart = rh.left; }
-    u64 mL[4] = {0, 0, 0, 0}, mR[4] = {0, 0, 0, 0};
+    ev.lrc = lrc; ev.rrc = rrc;
+    if (!lrc) { if (lh.left + rl > llen || lh.left < 0) return 0; lstart = lh.left; }
+    else { if (lh.right < rl || lh.right > llen) return 0; lstart = (int64_t)lh.right - rl; }
+    if (!rrc) { if (rh.right < rl || rh.right > rlen) return 0; rstart = (int64_t)rh.right - rl; }
+    else { if (rh.left + rl > rlen || rh.left < 0) return 0; rstart = rh.left; }
     int tot_r = 0;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
+        ev.mL[w] = 0; ev.mR[w] = 0;
         int off = w * 64;
         if (off < rl) {
             int l = rl - off < 64 ? rl - off : 64;
@@ -835,45 +841,61 @@ THJ_HD void detect_fusion(const Genome& g, const Params& p, const u64* rp, int W
             Planes a = genomic_piece(g, lh.ref_id, lstart, rl, lrc, off, l);
             Planes b = genomic_piece(g, rh.ref_id, rstart, rl, rrc, off, l);
             u64 M = lowmask(l);
-            mL[w] = ((a.lo ^ rd.lo) | (a.hi ^ rd.hi) | a.nm | rd.nm) & M;     // 'N' on either side is an error (:2416-2418)
-            mR[w] = ((b.lo ^ rd.lo) | (b.hi ^ rd.hi) | b.nm | rd.nm) & M;
-            tot_r += popc(mR[w]);
+            ev.mL[w] = ((a.lo ^ rd.lo) | (a.hi ^ rd.hi) | a.nm | rd.nm) & M;     // 'N' on either side is an error (:2416-2418)
+            ev.mR[w] = ((b.lo ^ rd.lo) | (b.hi ^ rd.hi) | b.nm | rd.nm) & M;
+            tot_r += popc(ev.mR[w]);
         }
     }
-    // e(p) = afterErrors[p-1] + beforeErrors[p], p = 1..rl-1
-    auto bitL = [&](int i) { u64 x = i < 64 ? mL[0] : i < 128 ? mL[1] : i < 192 ? mL[2] : mL[3]; return (int)((x >> (i & 63)) & 1ull); };
-    auto bitR = [&](int i) { u64 x = i < 64 ? mR[0] : i < 128 ? mR[1] : i < 192 ? mR[2] : mR[3]; return (int)((x >> (i & 63)) & 1ull); };
-    int e = bitL(0) + tot_r - bitR(0);
-    int min_err = rl + 1;
-    {
-        int ee = e;
-        for (int q = 1; q < rl; ++q) { if (ee < min_err) min_err = ee; ee += bitL(q) - bitR(q); }
-    }
-    const int total_ed = hit_ed(lh) + hit_ed(rh);
-    if (min_err > total_ed) return;                                            // :2697-2699
-    if (min_err > 2) return;
-    {
-        int ee = e;
-        for (int q = 1; q < rl; ++q) {                                         // :2704-2713
-            if (ee == min_err && (q < p.fusion_anchor_length || rl - q < p.fusion_anchor_length)) return;
-            ee += bitL(q) - bitR(q);
+    // e(1) = bitL(0) + tot_r - bitR(0); e(q + 1) = e(q) + bitL(q) - bitR(q)
+    ev.e1 = (int)(ev.mL[0] & 1ull) + tot_r - (int)(ev.mR[0] & 1ull);
+    ev.total_ed = hit_ed(lh) + hit_ed(rh);
+    const int A = p.fusion_anchor_length;
+    int mn = rl + 1, cnt = 0, mn_ends = rl + 1, ee = ev.e1;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int q0 = w == 0 ? 1 : w * 64, q1 = rl < (w + 1) * 64 ? rl : (w + 1) * 64;
+        u64 l = ev.mL[w] >> (q0 & 63), r = ev.mR[w] >> (q0 & 63);
+        for (int q = q0; q < q1; ++q) {
+            if (ee < mn) { mn = ee; cnt = 1; } else if (ee == mn) ++cnt;
+            if ((q < A || rl - q < A) && ee < mn_ends) mn_ends = ee;
+            ee += (int)(l & 1ull) - (int)(r & 1ull);
+            l >>= 1; r >>= 1;
         }
     }
-    int ee = e;
-    for (int q = 1; q < rl; ++q) {
-        if (ee == min_err) {
-            uint32_t left = !lrc ? (uint32_t)(lh.left + q - 1) : (uint32_t)(lh.right - q);
-            uint32_t right = !rrc ? (uint32_t)(rh.right - (rl - q)) : (uint32_t)(rh.left + (rl - q) - 1);
-            uint32_t r1 = lh.ref_id, r2 = rh.ref_id; int tdir = dir;
-            if (r2 < r1 || (r1 == r2 && left > right)) {                       // :2776-2789
-                uint32_t t = r1; r1 = r2; r2 = t;
-                t = left; left = right; right = t;
-                if (dir == FUS_FF) tdir = FUS_RR;
+    ev.min_err = mn;
+    if (mn > ev.total_ed || mn > 2 || mn_ends == mn) return 0;
+    return cnt;
+}
+template <class F>
+THJ_HD void fusion_emit(const FusEval& ev, int rl, const Hit& lh, const Hit& rh, int dir, F f) {
+    int ee = ev.e1, k = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int q0 = w == 0 ? 1 : w * 64, q1 = rl < (w + 1) * 64 ? rl : (w + 1) * 64;
+        u64 l = ev.mL[w] >> (q0 & 63), r = ev.mR[w] >> (q0 & 63);
+        for (int q = q0; q < q1; ++q) {
+            if (ee == ev.min_err) {
+                uint32_t left = !ev.lrc ? (uint32_t)(lh.left + q - 1) : (uint32_t)(lh.right - q);
+                uint32_t right = !ev.rrc ? (uint32_t)(rh.right - (rl - q)) : (uint32_t)(rh.left + (rl - q) - 1);
+                uint32_t r1 = lh.ref_id, r2 = rh.ref_id; int tdir = dir;
+                if (r2 < r1 || (r1 == r2 && left > right)) {                       // :2776-2789
+                    uint32_t t = r1; r1 = r2; r2 = t;
+                    t = left; left = right; right = t;
+                    if (dir == FUS_FF) tdir = FUS_RR;
+                }
+                f(k++, r1, r2, left, right, (uint32_t)tdir, (uint32_t)ev.total_ed);
             }
-            sink.fusion(r1, r2, left, right, (uint32_t)tdir, (uint32_t)total_ed);
+            ee += (int)(l & 1ull) - (int)(r & 1ull);
+            l >>= 1; r >>= 1;
         }
-        ee += bitL(q) - bitR(q);
     }
+}
+template <class Sink>
+THJ_HD void detect_fusion(const Genome& g, const Params& p, const u64* rp, int W, int rl, bool read_rc, const Hit& lh, const Hit& rh,
+                          int dir, Sink& sink) {
+    FusEval ev;
+    if (fusion_eval(g, p, rp, W, rl, read_rc, lh, rh, dir, ev) == 0) return;
+    fusion_emit(ev, rl, lh, rh, dir, [&](int, uint32_t r1, uint32_t r2, uint32_t left, uint32_t right, uint32_t tdir, uint32_t ed) { sink.fusion(r1, r2, left, right, tdir, ed); });
 }
 
 // DEFER: the pair is handed to sink.defer() instead of running detect_fusion here (the device kernel queues such pairs -- a few
@@ -897,14 +919,16 @@ THJ_HD void fusion_pair(const Genome& g, const Params& p, const u64* rp, int W, 
     else detect_fusion(g, p, rp, W, rl, rc, lh, rh, dir, sink);
 }
 
-// find_fusions for one read (all visited reads, incl. top == 0)
+// find_fusions for one read (all visited reads, incl. top == 0), in two parts: the pairs of real hits -- returns whether the
+// read also wants the mate-anchored part -- and that part.  (The device kernel runs the second part densely over a queue of
+// such reads: it holds the flank scans.)
 template <bool DEFER = false, class Sink>
-THJ_HD void fusion_read(const Genome& g, const Params& p, const ReadView& v, Sink& sink) {
-    if (v.nseg == 0) return;
+THJ_HD bool fusion_read_pairs(const Genome& g, const Params& p, const ReadView& v, Sink& sink) {
+    if (v.nseg == 0) return false;
     int last = v.nseg - 1;
     while (last > 0 && rv_count_raw(v, last) == 0) --last;
     const uint32_t l0 = v.so[0], l1 = v.so[1];
-    if (last == 0 && (l0 == l1 || hit_end(v.hits[l0]))) return;                 // :3035-3037
+    if (last == 0 && (l0 == l1 || hit_end(v.hits[l0]))) return false;           // :3035-3037
     const uint32_t r0 = last != 0 ? v.so[last] : 0, r1 = last != 0 ? v.so[last + 1] : 0;   // right_segment_hits (:3075-3080)
     bool check_partner = true;
     if (last != 0) {
@@ -922,42 +946,46 @@ THJ_HD void fusion_read(const Genome& g, const Params& p, const ReadView& v, Sin
     // pairs with the real hits of the last segment
     for (uint32_t i = l0; i < l1; ++i)
         for (uint32_t j = r0; j < r1; ++j) fusion_pair<DEFER>(g, p, v.rp, v.W, v.rl, v.hits[i], v.hits[j], sink);
-    // mate-anchored pseudo-hits (:3117-3202): every one of them is then paired with every left hit
-    if (check_partner && v.n_mate > 0) {
-        const int minus_dist = -p.max_insertion_length * 2;
-        int cl = p.segment_length - p.segment_mismatches - 3; if (cl > 15) cl = 15;
-        for (uint32_t l = l0; l < l1; ++l) {
-            Hit lh = v.hits[l];
-            for (int m = 0; m < v.n_mate; ++m) {
-                Hit rh = v.mate[m];
-                if (lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) {
-                    int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
-                    if (dist > minus_dist && dist <= p.fusion_min_dist) continue;
-                }
-                int32_t clen = g_len(g, rh.ref_id);
-                if (clen == 0) continue;
-                int part = p.inner_dist_std_dev > p.inner_dist_mean ? p.inner_dist_std_dev - p.inner_dist_mean : 0;
-                int flank = p.inner_dist_mean + p.inner_dist_std_dev;
-                int64_t left;
-                if (hit_anti(rh)) { if (flank <= rh.left) left = rh.left - flank; else break; }
-                else { if (part <= rh.right) left = rh.right - part; else break; }
-                int64_t fe = left + flank + part; if (fe > clen) fe = clen;
-                int flen = (int)(fe - left); if (flen < 0) flen = 0;
-                if (cl < 1 || cl > v.rl) continue;
-                Planes fwd = r_fetch(v.rp, v.W, v.rl - cl, cl);
-                Planes rev = rc_piece(fwd, cl);
-                int fp = flank_scan(g, rh.ref_id, left, flen, fwd, cl);
-                int rvp = flank_scan(g, rh.ref_id, left, flen, rev, cl);
-                for (int k = 0; k < 2; ++k) {
-                    int pos = k == 0 ? fp : rvp;
-                    if (pos < 0) continue;
-                    Hit ph; ph.ref_id = rh.ref_id; ph.left = (int32_t)(left + pos); ph.right = ph.left + cl;
-                    ph.meta = (k == 0 ? 2u : 3u) | ((uint32_t)cl << 24);
-                    for (uint32_t i = l0; i < l1; ++i) fusion_pair<DEFER>(g, p, v.rp, v.W, v.rl, v.hits[i], ph, sink);
-                }
+    return check_partner && v.n_mate > 0 && l1 > l0;
+}
+// mate-anchored pseudo-hits (:3117-3202): every one of them is then paired with every left hit.  Where the read's last bases lie
+// in a mate hit's flank does not depend on the left hit (rescue_scan, the same scan as find_gaps' rescue): kept per mate hit
+// for the first two.
+template <bool DEFER = false, class Sink>
+THJ_HD void fusion_read_mates(const Genome& g, const Params& p, const ReadView& v, Sink& sink) {
+    const uint32_t l0 = v.so[0], l1 = v.so[1];
+    const int minus_dist = -p.max_insertion_length * 2;
+    int cl = p.segment_length - p.segment_mismatches - 3; if (cl > 15) cl = 15;
+    int32_t c0_f = SLOT_NONE, c0_r = SLOT_NONE, c1_f = SLOT_NONE, c1_r = SLOT_NONE;
+    bool c0_ok = false, c1_ok = false;
+    uint32_t have = 0;
+    for (uint32_t l = l0; l < l1; ++l) {
+        Hit lh = v.hits[l];
+        for (int m = 0; m < v.n_mate; ++m) {
+            Hit rh = v.mate[m];
+            if (lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) {
+                int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
+                if (dist > minus_dist && dist <= p.fusion_min_dist) continue;
+            }
+            int32_t f, rv; bool scanned;
+            if (m == 0) { if (!(have & 1u)) { c0_ok = rescue_scan(g, p, v.rp, v.W, v.rl, rh, c0_f, c0_r); have |= 1u; } f = c0_f; rv = c0_r; scanned = c0_ok; }
+            else if (m == 1) { if (!(have & 2u)) { c1_ok = rescue_scan(g, p, v.rp, v.W, v.rl, rh, c1_f, c1_r); have |= 2u; } f = c1_f; rv = c1_r; scanned = c1_ok; }
+            else scanned = rescue_scan(g, p, v.rp, v.W, v.rl, rh, f, rv);
+            if (f == SLOT_BREAK) break;                                        // the flank would start before the contig: the mate loop ends
+            if (!scanned) continue;                                            // unknown contig, or a pattern longer than the read
+            for (int k = 0; k < 2; ++k) {
+                const int32_t pos = k == 0 ? f : rv;
+                if (pos == SLOT_NONE) continue;
+                Hit ph; ph.ref_id = rh.ref_id; ph.left = pos; ph.right = ph.left + cl;
+                ph.meta = (k == 0 ? 2u : 3u) | ((uint32_t)cl << 24);
+                for (uint32_t i = l0; i < l1; ++i) fusion_pair<DEFER>(g, p, v.rp, v.W, v.rl, v.hits[i], ph, sink);
             }
         }
     }
+}
+template <bool DEFER = false, class Sink>
+THJ_HD void fusion_read(const Genome& g, const Params& p, const ReadView& v, Sink& sink) {
+    if (fusion_read_pairs<DEFER>(g, p, v, sink)) fusion_read_mates<DEFER>(g, p, v, sink);
 }
 
 // ---- packed event keys ------------------------------------------------------

@@ -644,7 +644,11 @@ struct FusionSink {
 // where the pair is found, 2 % chimeric reads meant three waves in four ran it with one or two lanes active (4.6 ms per launch of
 // 6.25 M reads; PMC: 1.4 G VALU wave-instructions).  Candidate events are appended raw and reduced in thj_fusion_finish.
 struct FusTask { uint32_t read; uint32_t flags; Hit lh; Hit rh; };        // flags: rc | dir << 1
-static constexpr int FUS_QCAP = 768;
+// the queue is full (a tile of multihit reads): the pair where it is found, out of line so that the kernel's registers are not sized for it
+__device__ __noinline__ void detect_fusion_now(const Genome* g, const Params* p, const u64* rp, int W, int rl, bool rc, const Hit* lh, const Hit* rh, int dir, FusionSink* out) {
+    detect_fusion(*g, *p, rp, W, rl, rc, *lh, *rh, dir, *out);
+}
+static constexpr int FUS_QCAP = 1024;
 struct FusDeferSink {
     FusionSink& out; FusTask* q; unsigned int* q_n; uint32_t read;
     const Genome& g; const Params& p; const u64* rp; int W; int rl;
@@ -652,30 +656,81 @@ struct FusDeferSink {
     __device__ __forceinline__ void defer(bool rc, const Hit& lh, const Hit& rh, int dir) {
         const unsigned int k = atomicAdd(q_n, 1u);
         if (k < (unsigned)FUS_QCAP) { FusTask t; t.read = read; t.flags = (rc ? 1u : 0u) | ((uint32_t)dir << 1); t.lh = lh; t.rh = rh; q[k] = t; }
-        else detect_fusion(g, p, rp, W, rl, rc, lh, rh, dir, out);         // queue full (a tile of multihit reads): here and now
+        else detect_fusion_now(&g, &p, rp, W, rl, rc, &lh, &rh, dir, &out);
     }
 };
-__global__ __launch_bounds__(256) void thj_k_fusion(Genome g, Params p, DevBatch b, FusionSink sink) {
+// Three phases per tile of 256 reads: (a) every thread looks at its read's pairs of real hits (a few comparisons for almost every
+// read) and queues the candidate pairs; a read that also wants the mate-anchored search -- two flank scans per mate hit -- is
+// only listed; (b) once ~200 such reads are listed, they are searched with every lane busy (their candidate pairs join the
+// queue); (c) once ~200 pairs are queued, detect_fusion runs over them.  With the flank scans where the read is met, configs[3]'s
+// shape (--fusion-min-dist 100000: one read in ten is a candidate) ran them at one lane in ten: 1.9-2.5 ms per launch.
+static constexpr int FUS_RCAP = 512;
+__global__ __launch_bounds__(256, 3) void thj_k_fusion(Genome g, Params p, DevBatch b, FusionSink sink) {
     __shared__ FusTask q[FUS_QCAP];
-    __shared__ unsigned int q_n;
+    __shared__ uint32_t rq[FUS_RCAP];
+    __shared__ unsigned int q_n, rq_n;
     const int tid = threadIdx.x;
-    if (tid == 0) q_n = 0;
+    if (tid == 0) { q_n = 0; rq_n = 0; }
     __syncthreads();
     const int n_tiles = (b.n_reads + 255) / 256;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int r = tile * 256 + tid;
+        const bool last = tile + (int)gridDim.x >= n_tiles;
+        bool wants = false;
         if (r < b.n_reads) {
             ReadView v = make_view(b, r);
             FusDeferSink ds{sink, q, &q_n, (uint32_t)r, g, p, v.rp, v.W, v.rl};
-            fusion_read<true>(g, p, v, ds);
+            if (!THJ_EXPF(1 << 25)) wants = fusion_read_pairs<true>(g, p, v, ds);
+        }
+        {   // one LDS atomic per wave
+            const unsigned long long mw = __ballot(wants);
+            const int lane = tid & 63;
+            unsigned int base = 0;
+            if (lane == 0 && mw) base = atomicAdd(&rq_n, (unsigned int)__popcll(mw));
+            base = __shfl(base, 0);
+            if (wants) rq[base + (unsigned int)__popcll(mw & (lane ? (~0ull >> (64 - lane)) : 0ull))] = (uint32_t)r;   // < 192 + 256 entries
         }
         __syncthreads();
+        const unsigned int have_r = rq_n;
+        if (have_r >= 192u || (last && have_r > 0u)) {
+            for (unsigned int k = tid; k < have_r; k += 256) {
+                const int rr = (int)rq[k];
+                ReadView v = make_view(b, rr);
+                FusDeferSink ds{sink, q, &q_n, (uint32_t)rr, g, p, v.rp, v.W, v.rl};
+                if (!THJ_EXPF(1 << 26)) fusion_read_mates<true>(g, p, v, ds);
+            }
+            __syncthreads();
+            if (tid == 0) rq_n = 0;
+            __syncthreads();
+        }
         const unsigned int have = q_n < (unsigned)FUS_QCAP ? q_n : (unsigned)FUS_QCAP;
-        const bool last = tile + (int)gridDim.x >= n_tiles;
         if (have >= 192u || (last && have > 0u)) {
-            for (unsigned int k = tid; k < have; k += 256) {
-                const FusTask t = q[k];
-                detect_fusion(g, p, b.planes + (size_t)t.read * 3 * b.W, b.W, (int)b.read_len[t.read], (t.flags & 1u) != 0, t.lh, t.rh, (int)(t.flags >> 1), sink);
+            // every lane evaluates one pair; the wave then takes the room for all its events with one atomic (one per event was
+            // 7 x 10^5 returning atomics on one address per launch) and the lanes write theirs
+            const int lane = tid & 63;
+            for (unsigned int k0 = 0; k0 < have; k0 += 256) {
+                const unsigned int k = k0 + (unsigned int)tid;
+                FusTask t; FusEval fe; int n = 0, rl = 0;
+                if (k < have && !THJ_EXPF(1 << 27)) {
+                    t = q[k];
+                    rl = (int)b.read_len[t.read];
+                    n = fusion_eval(g, p, b.planes + (size_t)t.read * 3 * b.W, b.W, rl, (t.flags & 1u) != 0, t.lh, t.rh, (int)(t.flags >> 1), fe);
+                }
+                int incl = n;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+                const int tot = __shfl(incl, 63);
+                unsigned long long base = 0;
+                if (lane == 0 && tot) base = atomicAdd(sink.count, (unsigned long long)tot);
+                base = ((unsigned long long)(unsigned int)__shfl((int)(base >> 32), 0) << 32) | (unsigned long long)(unsigned int)__shfl((int)(base & 0xFFFFFFFFull), 0);
+                if (n) {
+                    const unsigned long long first = base + (unsigned long long)(incl - n);
+                    fusion_emit(fe, rl, t.lh, t.rh, (int)(t.flags >> 1), [&](int kk, uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) {
+                        const unsigned long long pos = first + (unsigned long long)kk;
+                        if (pos < sink.cap) { thj_fusion f{r1, r2, l, r, dir, 1u, ed, 0u}; sink.buf[pos] = f; }
+                        else atomicExch(sink.ovf, 1u);
+                    });
+                }
             }
             __syncthreads();
             if (tid == 0) q_n = 0;
@@ -1199,7 +1254,7 @@ extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_
     FusionSink sink{c->d_fus, c->d_fus_count, (unsigned long long)c->fus_cap, (unsigned int*)(c->d_fus_count + 1),
                     c->d_fus_ignore, (uint32_t)c->n_fus_ignore};
     int64_t blocks = ((int64_t)b.n_reads + 255) / 256;
-    if (blocks > 1024) blocks = 1024;       // four workgroups per CU; each walks ~n_tiles / 1024 tiles, its candidate pairs pile up
+    if (blocks > 768) blocks = 768;         // three workgroups per CU (168 VGPRs); each walks ~n_tiles / 768 tiles, its candidate pairs pile up
     hipLaunchKernelGGL(thj_k_fusion, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b, sink);
     HIPCHK(hipGetLastError());
     return THJ_OK;

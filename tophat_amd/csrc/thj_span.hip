@@ -763,7 +763,8 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         // could not join are on the multihit list and go through the fusion branches
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
         int64_t gf = ((int64_t)b.n_reads + 63) / 64;
-        if (gf > 8192) gf = 8192;
+        static const int fusion_grid = getenv("THJ_FUSION_GRID") ? atoi(getenv("THJ_FUSION_GRID")) : 8192;      // developer switch
+        if (gf > fusion_grid) gf = fusion_grid;
         if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
         hipLaunchKernelGGL(thj_k_stitch_fusion, dim3((unsigned)gf), dim3(64), 0, c->stream, g, p, S, F, b, sink, t, (int)G);
     } else {

@@ -760,6 +760,7 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
     if (p.bowtie2)
         for (int s = 0; s < nsegs; ++s)
             if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;
+    if (THJ_EXPF(1 << 30)) return SPAN_OK;
     const int fs = p.fusion_search;
     FRead rd{rp, W, rl, p.segment_length, nsegs, qual};
     FHit joined_local[FUS_MAXJOIN];               // ext: see span_read
@@ -782,6 +783,7 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             if (d == nsegs) {                                               // leaf: :2592-2606
                 --num_try;
                 FHit bh;
+                if (THJ_EXPF(1 << 29)) bh.n = 0; else
                 f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
                 if (bh.n) { if (nj < cap) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED; }
                 --d;
@@ -910,6 +912,7 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
         const FHit& h = joined[i];
         const int gapl = (uint8_t)(h.ed - h.mm);
         if ((int)h.mm > p.read_mismatches || gapl > p.read_gap_length || (int)h.ed > p.read_edit_dist) continue;     // :2810-2813
+        if (THJ_EXPF(1 << 28)) continue;
         Extras e;
         f_sam_extra(g, p, rd, h, e);
         f_emit(sink, read_idx, order++, h, e);
