@@ -782,12 +782,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
         if args.fusion_search and args.fusion_frac > 0:
             # segment_juncs --fusion-search: find_fusions over both sides; the (small) list goes to the spanning stage the way the
             # .fusions file would carry it
-            fus = ctx.fusions([(p_left, cb_left), (p_right, cb_right)])
-            fl = np.zeros(len(fus), dtype=host.SPAN_FUSION_DTYPE)          # thj_fusion_download: already in Fusion::operator< order
-            for k in ("ref_id1", "ref_id2", "left", "right", "dir"):
-                fl[k] = fus[k]
-            ctx.upload_span_fusions(fl)
-            n_fusions[0] = len(fl)
+            n_fusions[0] = ctx.fusion_search([(p_left, cb_left), (p_right, cb_right)])
+            ctx.span_fusions_from_segjuncs()                             # device to device, like the junction set below
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
         ctx.span_sets_from_segjuncs()
         ctx.span_reset()

@@ -342,6 +342,10 @@ int thj_md_string2(const char* ref, int64_t ref_len, const char* ref2, int64_t r
 int thj_span_sets_upload(thj_ctx* ctx, const thj_junction* juncs, int64_t n_juncs, const uint32_t* insertions, int64_t n_ins);
 /* Same, taken device-to-device from the context's own finished segment_juncs tables. */
 int thj_span_sets_from_segjuncs(thj_ctx* ctx);
+/* The same for --fusion-search: the fusion list thj_fusion_finish left in this context (segment_juncs' .fusions output, what
+ * long_spanning_reads reads back with --fusion-search) becomes the spanning stage's list without leaving the device.  Replaces
+ * thj_fusion_download + thj_span_fusions_upload when both stages run in one process. */
+int thj_span_fusions_from_segjuncs(thj_ctx* ctx);
 
 /* --fusion-search: the .fusions list long_spanning_reads loads (long_spanning_reads.cpp:2998-3040), sorted unique in
  * Fusion::operator< order (fusions.h:44-71); dir = THJ_CIG_FUSION_*.  HOST pointer.  thj_span_run_async consults it when

@@ -87,6 +87,13 @@ def test_fullsize_fusion_search():
         ctx.span_reset()
         ctx.span_run(p2, sp)
         assert ctx.span_download(ctx.span_finish()).tobytes() == a.tobytes()
+        # the fusion list handed over on the device (thj_span_fusions_from_segjuncs) instead of downloaded and uploaded
+        assert ctx.fusion_search(runs) == len(fus)
+        ctx.span_fusions_from_segjuncs()
+        ctx.span_reset()
+        ctx.span_run(p2, sp)
+        assert ctx.span_download(ctx.span_finish()).tobytes() == a.tobytes()
+        assert ctx.fusions(runs).tolist() == fus.tolist()                                     # ... and it still comes down afterwards
         # shard merge
         hs = [half(w["left"], k) for k in (0, 1)]
         parts = []

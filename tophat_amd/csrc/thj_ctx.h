@@ -84,6 +84,8 @@ struct thj_ctx {
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
     std::vector<thj_fusion> h_fusions;
+    thj_fusion* d_fus_out = nullptr; int64_t n_fus_out = 0;            // the reduced set on the device (Fusion::operator< order); null: only h_fusions holds it
+    bool h_fus_stale = false;                                          // h_fusions not yet copied down from d_fus_out
     // batch arrays come and go once per shard / batch: hipMalloc and (synchronising) hipFree per array cost more than the
     // kernels of a small shard, so released blocks are kept and handed out again (thj_dev_alloc / thj_dev_release)
     struct DevBlock { void* p; size_t cap; bool used; };
@@ -113,3 +115,5 @@ void thj_dev_cache_free(struct thj_ctx* c);
 void thj_span_free(struct thj_ctx* c);
 int thj_span_compact_device(struct thj_ctx* c, void** d_out);       // thj_span.hip: the pass's records, ordered, on the device
 void thj_bamout_free(struct thj_ctx* c);                            // thj_bamout.hip
+
+int thj_fusions_to_host(struct thj_ctx* c);        // h_fusions <- d_fus_out when it has not come down yet (thj_segjuncs.hip)

@@ -344,9 +344,10 @@ static int x_finish_check(thj_ctx* c, const unsigned int* ovf_now) {
 extern "C" int thj_fusion_allgather(thj_ctx* c, thj_comm* m, int64_t* n_fusions) {
     if (!c || !m || m->ctx != c) { thj_set_error("thj_fusion_allgather: the communicator does not belong to this context"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
-    if (n_fusions) *n_fusions = (int64_t)c->h_fusions.size();
-    if (m->n == 1) return THJ_OK;
-    // thj_fusion_finish has reduced this rank's events on the host; sizes first, then the padded sets
+    if (m->n == 1) { if (n_fusions) *n_fusions = c->h_fus_stale ? c->n_fus_out : (int64_t)c->h_fusions.size(); return THJ_OK; }
+    { const int rc0 = thj_fusions_to_host(c); if (rc0) return rc0; }
+    fusion_drop_device_set(c);                  // the merged set is made on the host below
+    // thj_fusion_finish has reduced this rank's events; sizes first, then the padded sets
     u64 *d_n = nullptr, *d_all = nullptr;
     HIPCHK(hipMalloc(&d_n, 8)); HIPCHK(hipMalloc(&d_all, (size_t)m->n * 8));
     unsigned long long mine = c->h_fusions.size();

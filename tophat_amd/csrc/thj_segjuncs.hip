@@ -1210,6 +1210,7 @@ extern "C" int thj_segjuncs_merge_keys_async(thj_ctx* c, int kind, const uint64_
     return THJ_OK;
 }
 
+static void fusion_drop_device_set(thj_ctx* c);
 extern "C" int thj_fusion_reset_async(thj_ctx* c) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
@@ -1220,6 +1221,7 @@ extern "C" int thj_fusion_reset_async(thj_ctx* c) {
     }
     HIPCHK(hipMemsetAsync(c->d_fus_count, 0, 16, c->stream));
     c->h_fusions.clear();
+    fusion_drop_device_set(c);
     return THJ_OK;
 }
 
@@ -1331,17 +1333,32 @@ static int fusion_reduce_on_device(thj_ctx* c, int64_t n) {
     HIPCHK(hipMemset2DAsync((char*)d_out + offsetof(thj_fusion, edit_dist), sizeof(thj_fusion), 0xFF, 4, n_runs, c->stream));
     hipLaunchKernelGGL(thj_k_fus_reduce, dim3((unsigned)grid), dim3(256), 0, c->stream, ev, (const uint32_t*)d_idx2, (const uint32_t*)d_kdir, (const uint32_t*)d_kdir2, n, (thj_fusion*)d_out);
     HIPCHK(hipGetLastError());
-    c->h_fusions.resize(n_runs);
-    HIPCHK(hipMemcpyAsync(c->h_fusions.data(), d_out, (size_t)n_runs * sizeof(thj_fusion), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    // the set stays on the device (thj_span_fusions_from_segjuncs hands it to the spanning stage); it comes down when asked for
+    c->d_fus_out = (thj_fusion*)d_out; d_out = nullptr;
+    c->n_fus_out = (int64_t)n_runs;
+    c->h_fus_stale = true;
     release();
     return THJ_OK;
+}
+
+int thj_fusions_to_host(thj_ctx* c) {
+    if (!c->h_fus_stale) return THJ_OK;
+    c->h_fusions.resize((size_t)c->n_fus_out);
+    if (c->n_fus_out) HIPCHK(hipMemcpyAsync(c->h_fusions.data(), c->d_fus_out, (size_t)c->n_fus_out * sizeof(thj_fusion), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->h_fus_stale = false;
+    return THJ_OK;
+}
+static void fusion_drop_device_set(thj_ctx* c) {
+    if (c->d_fus_out) thj_dev_release(c, c->d_fus_out);
+    c->d_fus_out = nullptr; c->n_fus_out = 0; c->h_fus_stale = false;
 }
 
 extern "C" int thj_fusion_finish(thj_ctx* c, int64_t* n_fusions) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     c->h_fusions.clear();
+    fusion_drop_device_set(c);
     if (c->d_fus_count) {
         unsigned long long h[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(h, c->d_fus_count, 16, hipMemcpyDeviceToHost, c->stream));
@@ -1371,12 +1388,15 @@ extern "C" int thj_fusion_finish(thj_ctx* c, int64_t* n_fusions) {
         }
         }
     }
-    if (n_fusions) *n_fusions = (int64_t)c->h_fusions.size();
+    if (n_fusions) *n_fusions = c->h_fus_stale ? c->n_fus_out : (int64_t)c->h_fusions.size();
     return THJ_OK;
 }
 
 extern "C" int thj_fusion_download(thj_ctx* c, thj_fusion* out) {
-    if (!c || (!c->h_fusions.empty() && !out)) { thj_set_error("thj_fusion_download: bad argument"); return THJ_EINVAL; }
+    if (!c) { thj_set_error("thj_fusion_download: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    { const int rc = thj_fusions_to_host(c); if (rc) return rc; }
+    if (!c->h_fusions.empty() && !out) { thj_set_error("thj_fusion_download: bad argument"); return THJ_EINVAL; }
     if (!c->h_fusions.empty()) memcpy(out, c->h_fusions.data(), c->h_fusions.size() * sizeof(thj_fusion));
     return THJ_OK;
 }

@@ -700,6 +700,41 @@ extern "C" int thj_span_fusions_upload(thj_ctx* c, const thj_span_fusion* f, int
     return THJ_OK;
 }
 
+// the fusion list of this context's own fusion search (thj_fusion_finish), handed over on the device the way
+// thj_span_sets_from_segjuncs hands over the junctions: what the .fusions file carries between the two programs
+__global__ __launch_bounds__(256) void thj_k_fus_to_keys(const thj_fusion* f, int64_t n, FusKey* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const thj_fusion e = f[i];
+        out[i] = FusKey{e.ref_id1, e.ref_id2, e.left, e.right, e.dir};
+    }
+}
+extern "C" int thj_span_fusions_from_segjuncs(thj_ctx* c) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->d_fus_out) {
+        // no device copy (reduced on the host, or merged across ranks): up from the host list
+        std::vector<thj_span_fusion> f(c->h_fusions.size());
+        for (size_t i = 0; i < f.size(); ++i) { const thj_fusion& e = c->h_fusions[i]; f[i] = thj_span_fusion{e.ref_id1, e.ref_id2, e.left, e.right, e.dir}; }
+        return thj_span_fusions_upload(c, f.data(), (int64_t)f.size());
+    }
+    const int64_t n = c->n_fus_out;
+    if (c->cap_span_fus < n || !c->d_span_fus) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->d_span_fus); c->d_span_fus = nullptr; c->cap_span_fus = 0;
+        const int64_t cap = n + n / 4 + 64;
+        HIPCHK(hipMalloc(&c->d_span_fus, (size_t)cap * sizeof(FusKey)));
+        c->cap_span_fus = cap;
+    }
+    if (n) {
+        int64_t grid = (n + 255) / 256; if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(thj_k_fus_to_keys, dim3((unsigned)grid), dim3(256), 0, c->stream, (const thj_fusion*)c->d_fus_out, n, (FusKey*)c->d_span_fus);
+        HIPCHK(hipGetLastError());
+    }
+    c->n_span_fus = n;
+    return THJ_OK;
+}
+
+
 extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db) {
     if (!c || !tp || !db) { thj_set_error("thj_span_run_async: null argument"); return THJ_EINVAL; }
     if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }

@@ -582,6 +582,23 @@ def _span_methods():
     def span_sets_from_segjuncs(self):
         _check(self.lib, self.lib.thj_span_sets_from_segjuncs(self._ctx), "thj_span_sets_from_segjuncs")
 
+    def span_fusions_from_segjuncs(self):
+        """--fusion-search: the list of the last fusion_search() / fusions() of this context, handed over on the device"""
+        _check(self.lib, self.lib.thj_span_fusions_from_segjuncs(self._ctx), "thj_span_fusions_from_segjuncs")
+
+    def fusion_search(self, runs, ignore_ref_ids=()) -> int:
+        """fusions() without the download: reset; thj_fusion_run_async for every (params, batch); finish -> number of fusions"""
+        _check(self.lib, self.lib.thj_fusion_reset_async(self._ctx), "thj_fusion_reset_async")
+        ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
+        _check(self.lib, self.lib.thj_fusion_set_ignored(self._ctx, _ptr(ign) if len(ign) else None, len(ign)), "thj_fusion_set_ignored")
+        for p, b in runs:
+            cp = p.as_ctypes()
+            arg = C.byref(b) if isinstance(b, CSegBatch) else b
+            _check(self.lib, self.lib.thj_fusion_run_async(self._ctx, C.byref(cp), arg), "thj_fusion_run_async")
+        n = C.c_int64()
+        _check(self.lib, self.lib.thj_fusion_finish(self._ctx, C.byref(n)), "thj_fusion_finish")
+        return int(n.value)
+
     def span_hit_heads(self, d_hits: int, n_hits: int, d_heads: int):
         """the dense 16-byte head array of device-resident hit records (CSpanBatch.hit_heads)"""
         _check(self.lib, self.lib.thj_span_hit_heads_async(self._ctx, C.c_void_p(d_hits), C.c_int64(n_hits), C.c_void_p(d_heads)),
@@ -650,7 +667,7 @@ def _span_methods():
         _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, ms, C.byref(n)), "thj_profile_span")
         return [ms[0], ms[1], ms[2], ms[3]], n.value
 
-    for f in (upload_span_fusions, upload_span_sets, span_sets_from_segjuncs, upload_span_batch, span_reset, span_run, span_finish,
+    for f in (upload_span_fusions, upload_span_sets, span_sets_from_segjuncs, span_fusions_from_segjuncs, fusion_search, upload_span_batch, span_reset, span_run, span_finish,
               span_download, spanning, profile_span, span_tier_counts, span_hit_heads):
         setattr(Context, f.__name__, f)
 
@@ -662,7 +679,7 @@ ABI_SYMBOLS += ["thj_juncbed_configure", "thj_juncbed_reset_async", "thj_juncbed
                 "thj_juncbed_finish", "thj_juncbed_download"]
 ABI_SYMBOLS += ["thj_md_string"]
 ABI_SYMBOLS += ["thj_microexon_reset_async", "thj_microexon_collect", "thj_microexon_candidates", "thj_microexon_run"]
-ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
+ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_fusions_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
                 "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
 
