@@ -812,6 +812,7 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
     FHit stack[SPAN_MAXSEG + 1], saved[SPAN_MAXSEG + 1], chain[SPAN_MAXSEG + 1];
     uint32_t idx[SPAN_MAXSEG + 1];
     int fdir[SPAN_MAXSEG + 2];
+    bool dirty[SPAN_MAXSEG + 2];
     int status = SPAN_OK;
     for (uint32_t i0 = so[0]; i0 < so[1]; ++i0) {                           // :2634-2664
         stack[0] = fhit_from(hits[i0], 0, nsegs == 1);
@@ -829,17 +830,24 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
                 f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
                 if (bh.n) { if (nj < cap) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED; }
                 --d;
-                if (d >= 1) stack[d - 1] = saved[d];
+                if (d >= 1 && dirty[d]) stack[d - 1] = saved[d];
                 continue;
             }
             if (idx[d] >= so[d + 1]) {
                 --d;
-                if (d >= 1) stack[d - 1] = saved[d];
+                if (d >= 1 && dirty[d]) stack[d - 1] = saved[d];
                 continue;
             }
             const int fusion_dir = fdir[d];
-            FHit bh = fhit_from(hits[idx[d]++], d, d == nsegs - 1);
-            FHit bh_prev = stack[d - 1];
+            // The reference works on copies of the two hits and stores them when the pair is accepted; here the new hit is built in
+            // its stack slot (free until it is pushed) and the previous one is worked on where it lies: its first change saves the
+            // original (saved[d], dirty[d]), a rejected pair puts it back.  (Five 100-byte copies per step through scratch before.)
+            FHit& bh = stack[d];
+            bh = fhit_from(hits[idx[d]++], d, d == nsegs - 1);
+            FHit& bh_prev = stack[d - 1];
+            bool prev_dirty = false, pushed = false;
+#define FUS_REV(x) do { if ((x) == &bh_prev && !prev_dirty) { saved[d] = bh_prev; prev_dirty = true; } f_reverse(*(x)); } while (0)
+            do {
             FHit* prevHit = &bh_prev;
             FHit* currHit = &bh;
             const bool prev_fused = f_fusion_opcode(*prevHit) != 0, curr_fused = f_fusion_opcode(*currHit) != 0;
@@ -853,12 +861,12 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             }
             if ((fusion_dir == OP_FUS_FR || fusion_dir == OP_FUS_RF) && prevHit->ref_id2 != currHit->ref_id) continue;
             if ((fusion_dir == OP_FUS_FR && !currHit->anti) || (fusion_dir == OP_FUS_RF && currHit->anti)) continue;
-            if (curr_fused && dir == OP_FUS_RR) f_reverse(*currHit);
+            if (curr_fused && dir == OP_FUS_RR) FUS_REV(currHit);
             if (fusion_dir == OP_FUS_FR || fusion_dir == OP_FUS_RF ||
                 (curr_fused && currHit->ref_id == currHit->ref_id2 && (dir == OP_FUS_FR || dir == OP_FUS_RF))) {
                 if (curr_fused) {
-                    if ((dir == OP_FUS_FR && currHit->anti) || (dir == OP_FUS_RF && !currHit->anti)) f_reverse(*currHit);
-                } else if (fusion_dir == OP_FUS_FR && currHit->anti) f_reverse(*currHit);
+                    if ((dir == OP_FUS_FR && currHit->anti) || (dir == OP_FUS_RF && !currHit->anti)) FUS_REV(currHit);
+                } else if (fusion_dir == OP_FUS_FR && currHit->anti) FUS_REV(currHit);
             } else if ((num_fusions == 0 && prevHit->anti && currHit->anti && prevHit->ref_id == currHit->ref_id &&
                         (!fs || (prevHit->left <= f_right(*currHit) + p.max_report_intron &&
                                  prevHit->left + p.max_insertion_length >= f_right(*currHit)))) ||
@@ -878,8 +886,8 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
                         else dir = OP_FUS_RR;
                     } else if (!prevHit->anti) dir = OP_FUS_FR;
                     else dir = OP_FUS_RF;
-                    if (dir == OP_FUS_FR) f_reverse(*currHit);
-                    else if (dir == OP_FUS_RF) f_reverse(*prevHit);
+                    if (dir == OP_FUS_FR) FUS_REV(currHit);
+                    else if (dir == OP_FUS_RF) FUS_REV(prevHit);
                 }
             }
             if (!fs && dir != 0) continue;
@@ -894,12 +902,12 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
                     if ((dir == OP_FUS_FR && prevHit->anti) || (dir == OP_FUS_RF && !prevHit->anti)) continue;
                     if (currHit->ref_id != prevHit->ref_id2) curr_rep = true;
                 }
-                if (prev_rep) f_reverse(*prevHit);
-                if (curr_rep) f_reverse(*currHit);
+                if (prev_rep) FUS_REV(prevHit);
+                if (curr_rep) FUS_REV(currHit);
                 prev_rep = curr_rep = false;
                 if (f_forwarding_right(*prevHit) != f_forwarding_left(*currHit)) { if (prev_fused) curr_rep = true; else prev_rep = true; }
-                if (prev_rep) f_reverse(*prevHit);
-                if (curr_rep) f_reverse(*currHit);
+                if (prev_rep) FUS_REV(prevHit);
+                if (curr_rep) FUS_REV(currHit);
             }
             const bool same_contig = prevHit->ref_id2 == currHit->ref_id;
             if (!same_contig && num_fusions > 0) continue;
@@ -916,13 +924,15 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             if (!same_contig || (same_contig && num_fusions == 0 && dir != 0 && fusion_dir == 0) ||
                 (same_contig && dist <= p.max_report_intron && dist >= -p.max_insertion_length &&
                  f_forwarding_right(*prevHit) == f_forwarding_left(*currHit))) {
-                saved[d] = stack[d - 1];
-                stack[d - 1] = bh_prev;
-                stack[d] = bh;
+                dirty[d] = prev_dirty;
                 fdir[d + 1] = dir == 0 ? fusion_dir : dir;
                 ++d;
                 if (d < nsegs) idx[d] = so[d];
+                pushed = true;
             }
+            } while (0);
+#undef FUS_REV
+            if (!pushed && prev_dirty) stack[d - 1] = saved[d];
         }
     }
     if (status == SPAN_TOO_MANY_JOINED) return status;
