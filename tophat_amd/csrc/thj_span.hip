@@ -256,11 +256,25 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
         // fusion search: a one-hit-per-segment read that joins the plain way joins the same way with fusion search on (its only
         // chain never takes a fusion direction); one that does not may be a fusion read -- thj_k_stitch_fusion decides
         if (p.fusion_search && st == SPAN_OK && sink.emitted == 0) st = SPAN_NEED_GENERIC;
-        if (st == SPAN_NEED_GENERIC) {          // rare: more cigar ops than the registers hold
-            sl %= G;                            // the slice of the block of tier 0 that owns the read
-            t.wl_multi[(int64_t)sl * t.chunk + atomicAdd(&t.blk_multi[sl], 1u)] = (uint32_t)r;
-            ++n_fwd;                            // (one global counter hit per read would serialise the launch: with fusion search
-        } else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }   //  on every unjoined read comes this way)
+        const bool fwd = st == SPAN_NEED_GENERIC;       // rare without fusion search: more cigar ops than the registers hold
+        if (!fwd) { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
+        sl %= G;                                // the slice of the block of tier 0 that owns the read
+        // with fusion search on every unjoined read comes this way (one read in eight of this tier on configs[3]'s shape): the lanes
+        // of a wave that forward to the same slice -- neighbours in the list almost always do -- take their places with one atomic
+        for (unsigned long long todo = __ballot(fwd); todo;) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int sl_l = __shfl(sl, leader);
+            const unsigned long long same = __ballot(fwd && sl == sl_l);
+            const int lane = (int)(threadIdx.x & 63u);
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(&t.blk_multi[sl_l], (unsigned int)__popcll(same));
+            base = (unsigned int)__shfl((int)base, leader);
+            if (fwd && sl == sl_l) {
+                t.wl_multi[(int64_t)sl * t.chunk + base + (unsigned int)__popcll(same & (lane ? (~0ull >> (64 - lane)) : 0ull))] = (uint32_t)r;
+                ++n_fwd;
+            }
+            todo &= ~same;
+        }
     }
     if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
     if (n_fwd) atomicAdd(&s_fwd, n_fwd);

@@ -332,8 +332,11 @@ THJ_HD bool f_merge_chain(const Genome& g, const Params& p, const SpanSets& S, c
     if (THJ_EXPF(1 << 19)) return false;
     int pi = 0, ci = 1, curr_seg_index = 1;
     bool fusion_passed = false;
+    // chain[0..pi] holds the hits done, chain[ti..] those to come (ci = pi + 1 counts them as if they followed at once: a closed pair
+    // leaves a hole instead of moving every later hit down one place -- up to four 100-byte copies through scratch per closure)
+    int ti = 1;
     while (ci < n) {
-        FHit& prev = chain[pi]; FHit& curr = chain[ci];
+        FHit& prev = chain[pi]; FHit& curr = chain[ti];
         antisense = prev.anti;
         if (f_fusion_opcode(prev) != 0 || prev.ref_id2 != curr.ref_id) fusion_passed = true;
         if (!(op_is_match(cig_op(prev.c[prev.n - 1])) || op_is_match(cig_op(curr.c[0])))) return false;
@@ -557,18 +560,19 @@ THJ_HD bool f_merge_chain(const Genome& g, const Params& p, const SpanSets& S, c
             if (prev.nsq + curr.nsq > 16) return false;
             m.sq = prev.sq | (curr.sq << (4 * prev.nsq)); m.nsq = (uint8_t)(prev.nsq + curr.nsq);
             chain[pi] = m;
-            for (int q = ci; q + 1 < n; ++q) chain[q] = chain[q + 1];
+            ++ti;
             --n;
             ci = pi + 1;
             ++curr_seg_index;
             continue;
         }
-        ++pi; ++ci; ++curr_seg_index;
+        if (pi + 1 != ti) chain[pi + 1] = chain[ti];
+        ++pi; ++ci; ++ti; ++curr_seg_index;
     }
     // :1888-1944 concatenate
     bool saw_as = false, saw_s = false;
     int num_mm = 0;
-    FHit nh;
+    FHit& nh = out;                 // built where the caller wants it (the caller clears it when this returns false)
     nh.n = 0;
     for (int s = 0; s < n; ++s) {
         num_mm += chain[s].mm;
@@ -603,7 +607,6 @@ THJ_HD bool f_merge_chain(const Genome& g, const Params& p, const SpanSets& S, c
     }
     if (fusion_dir != 0) nh.anti = f_seq_is_read(rd, nh) ? 0 : 1;                        // :2007-2013
     if (f_read_len(nh) != old_read_length || (!THJ_EXPF(64) && !f_check_editdist(g, rd, nh))) return false;  // :2022-2034
-    out = nh;
     return true;
 }
 
@@ -825,10 +828,16 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             if (num_try <= 0) break;
             if (d == nsegs) {                                               // leaf: :2592-2606
                 --num_try;
-                FHit bh;
-                if (THJ_EXPF(1 << 29)) bh.n = 0; else
-                f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
-                if (bh.n) { if (nj < cap) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED; }
+                if (nj < cap) {                                             // joined where it is kept
+                    FHit& bh = joined[nj];
+                    if (THJ_EXPF(1 << 29)) bh.n = 0; else
+                    f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
+                    if (bh.n) ++nj;
+                } else {
+                    FHit bh;
+                    f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
+                    if (bh.n) status = SPAN_TOO_MANY_JOINED;
+                }
                 --d;
                 if (d >= 1 && dirty[d]) stack[d - 1] = saved[d];
                 continue;
