@@ -201,6 +201,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                 SpanHitHead stage[SPAN_MAXSEG];
                 st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                     read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
+                if (st == SPAN_INCOMPAT) st = SPAN_OK;
             }
         }
         if (st == SPAN_NEED_GENERIC && (mode == 0 || mode == 3)) {          // tier 2: multihit reads, every hit head staged
@@ -282,7 +283,8 @@ extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blo
             const size_t before = res.size();
             st = span_read_lean(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                 read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
-            if (p.fusion_search && st == SPAN_OK && res.size() == before) st = SPAN_NEED_GENERIC;
+            (void)before;
+            if (st == SPAN_INCOMPAT) st = p.fusion_search ? SPAN_NEED_GENERIC : SPAN_OK;
         }
         if (st == SPAN_NEED_GENERIC) {
             status_counts[3]++;

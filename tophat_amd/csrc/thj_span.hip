@@ -255,7 +255,10 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
                                 (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, stage, sink);
         // fusion search: a one-hit-per-segment read that joins the plain way joins the same way with fusion search on (its only
         // chain never takes a fusion direction); one that does not may be a fusion read -- thj_k_stitch_fusion decides
-        if (p.fusion_search && st == SPAN_OK && sink.emitted == 0) st = SPAN_NEED_GENERIC;
+        // -- its only chain takes a fusion direction exactly when two neighbours are not compatible the plain way (SPAN_INCOMPAT);
+        // a compatible chain that does not join fails the same way there, so only the former go on (a third of what went on when
+        // every read without a record did)
+        if (st == SPAN_INCOMPAT) st = p.fusion_search ? SPAN_NEED_GENERIC : SPAN_OK;
         const bool fwd = st == SPAN_NEED_GENERIC;       // rare without fusion search: more cigar ops than the registers hold
         if (!fwd) { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
         sl %= G;                                // the slice of the block of tier 0 that owns the read

@@ -666,6 +666,7 @@ THJ_HD void emit_aln(Sink& sink, uint32_t read_idx, int order, const A& h, const
 }
 
 enum { SPAN_OK = 0, SPAN_TOO_MANY_JOINED = 1, SPAN_MD_OVERFLOW = 2, SPAN_NEED_GENERIC = 3 };
+enum { SPAN_INCOMPAT = 5 };    // span_read_lean only, never counted as a status: nothing joined because the read's only chain is not compatible the plain way
 
 // One read: JoinSegmentsWorker body (long_spanning_reads.cpp:2767-2831).  Emits through
 // sink.emit(const OutAln&) in output order; returns a SPAN_* status.
@@ -856,7 +857,9 @@ struct StagedHits {         // the chain under construction: segment s's hit is 
 
 // ---- lean machinery shared by tiers 1 and 2 -----------------------------------------------------------------
 // lean_join: ONE chain -- hits[s] is the hit chosen for segment s -- through merge_chain on register cigars.
-enum { LJ_NONE = 0, LJ_OK = 1, LJ_PUNT = 2 };       // no alignment / `res` holds the joined hit / needs more cigar ops than LEAN_C
+enum { LJ_NONE = 0, LJ_OK = 1, LJ_PUNT = 2, LJ_INCOMPAT = 3 };   // no alignment / `res` holds the joined hit / needs more cigar ops than LEAN_C /
+                                                                  // no alignment because two neighbours are not compatible the plain way (with fusion search on
+                                                                  // such a chain takes a fusion direction; every other failure is the same failure there)
 template <class Hits>      // Hits: `hits[s]` is the hit chosen for segment s (a plain array, or StagedHits)
 THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const Hits& hits, int nsegs,
                      const u64* rp, int W, int rl, RAln& res) {
@@ -875,9 +878,9 @@ THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const 
             for (int s = 1; s < nsegs; ++s) {
                 RAln cand = raln_from_hit(hits[s], s, L, rl);
                 const int cand_right = cand.left + rc_ref_span(cand.c, cand.n);
-                if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return LJ_NONE;
+                if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return LJ_INCOMPAT;
                 int dist = prev.anti ? prev.left - cand_right : cand.left - prev_right;
-                if (dist > p.max_report_intron || dist < -p.max_insertion_length) return LJ_NONE;
+                if (dist > p.max_report_intron || dist < -p.max_insertion_length) return LJ_INCOMPAT;
                 if (gap_is_fusion_like(p, dist)) ++num_fusions;          // merge_chain pre-check (:843-891): same gaps, chain order
                 old_read_length += rc_read_span(cand.c, cand.n);
                 prev.ref_id = cand.ref_id; prev.anti = cand.anti; prev.left = cand.left; prev_right = cand_right;
@@ -1023,6 +1026,7 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     RAln res;
     const int jr = lean_join(g, p, S, hits, nsegs, rp, W, rl, res);
     if (jr == LJ_PUNT) return SPAN_NEED_GENERIC;
+    if (jr == LJ_INCOMPAT) return SPAN_INCOMPAT;
     if (jr == LJ_NONE) return SPAN_OK;
     int order = 0;
     return lean_finish(g, p, res, nsegs, rp, W, rl, qual, read_idx, order, sink);
