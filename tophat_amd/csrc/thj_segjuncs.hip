@@ -373,51 +373,56 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params
     EventSink ev{g, t};
     const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int n = *rl.many_count < (unsigned int)MANY_CAP ? *rl.many_count : (unsigned int)MANY_CAP;
-    constexpr unsigned int WPB = TPB / 64;
+    // A workgroup takes SHARED_BATCH reads at a time and its waves draw them one by one (s_next): a read with forty hits a segment
+    // costs a hundred times one with four, and with one read per wave and a barrier per read three waves in four waited for it
+    // (0.64 ms per launch for 65 k reads, of which the barrier-bound waiting was most).
+    const unsigned int SHARED_BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;      // a few reads per wave and turn; small launches spread over the chip
+    __shared__ unsigned int s_next;
     unsigned int my_windows = 0, my_indels = 0;
-    for (unsigned int base = blockIdx.x * WPB; base < n; base += gridDim.x * WPB) {
+    for (unsigned int base = blockIdx.x * SHARED_BATCH; base < n; base += gridDim.x * SHARED_BATCH) {
         __syncthreads();
         const unsigned int q_before = q_n;
+        if (tid == 0) s_next = 0;
         __syncthreads();
-        const unsigned int h = base + (unsigned int)wave;
-        const bool active = h < n;
-        const int r = active ? (int)rl.many_list[h] : 0;
-        ReadView v;
-        bool do_gaps = false, wants = false;
-        uint32_t hbase = 0;
-        if (active) {
-            v = make_view(b, r);
-            const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
-            if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 12) {                 // the hits and their offsets into LDS
-                for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
-                if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
-            }
-            do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
-            if (do_gaps && wants) {
-                // the rescue kernels take it from here (their list, this kernel's slice)
-                if (lane == 0) rl.list[(size_t)rl.own_slice * rl.seg_cap + atomicAdd(&rl.blk_cnt[rl.own_slice], 1u)] = (uint32_t)r;
-            } else {
-                QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, hbase, 0u, 0u};
-                if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, lane, 64);
-                if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
-                my_windows += qs.n_windows; my_indels += qs.n_indels;
-            }
-        }
-        __syncthreads();
-        if (q_n > (unsigned)QCAP) {
-            if (tid == 0) atomicAdd(&s_stat[3], 1u);
-            if (active && !(do_gaps && wants)) {
-                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
-                indels_enumerate(p, v, is, lane, 64);
-                if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
+        for (int pass = 0; pass < 2; ++pass) {               // pass 1 only when the queue overflowed: the batch again, executed where it is found
+            for (;;) {
+                unsigned int k = 0;
+                if (lane == 0) k = atomicAdd(&s_next, 1u);
+                k = (unsigned int)__shfl((int)k, 0);
+                if (k >= SHARED_BATCH || base + k >= n) break;
+                const int r = (int)rl.many_list[base + k];
+                ReadView v = make_view(b, r);
+                bool do_gaps = false, wants = false;
+                uint32_t hbase = 0;
+                const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with s_h
+                if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 12) {                 // the hits and their offsets into LDS
+                    for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
+                    if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
+                }
+                do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
+                if (do_gaps && wants) {
+                    // the rescue kernels take it from here (their list, this kernel's slice)
+                    if (pass == 0 && lane == 0) rl.list[(size_t)rl.own_slice * rl.seg_cap + atomicAdd(&rl.blk_cnt[rl.own_slice], 1u)] = (uint32_t)r;
+                } else if (pass == 0) {
+                    QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, hbase, 0u, 0u};
+                    if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, lane, 64);
+                    if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
+                    my_windows += qs.n_windows; my_indels += qs.n_indels;
+                } else {
+                    InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                    indels_enumerate(p, v, is, lane, 64);
+                    if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
+                }
             }
             __syncthreads();
-            if (tid == 0) q_n = q_before;
+            if (pass == 1 || q_n <= (unsigned)QCAP) break;
+            if (tid == 0) { atomicAdd(&s_stat[3], 1u); s_next = 0; q_n = q_before; }
             __syncthreads();
         }
-        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * WPB >= n);
+        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * SHARED_BATCH >= n);
     }
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
@@ -578,42 +583,44 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
     EventSink ev{g, t};
     const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int n = *rl.heavy_count < (unsigned int)HEAVY_CAP ? *rl.heavy_count : (unsigned int)HEAVY_CAP;
-    constexpr unsigned int WPB = TPB / 64;
+    // the waves of a workgroup draw the reads of its batch one by one, as in thj_k_segjuncs_shared
+    const unsigned int BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;
+    __shared__ unsigned int s_next;
     unsigned int my_windows = 0, my_indels = 0;
-    for (unsigned int base = blockIdx.x * WPB; base < n; base += gridDim.x * WPB) {
+    for (unsigned int base = blockIdx.x * BATCH; base < n; base += gridDim.x * BATCH) {
         __syncthreads();
         const unsigned int q_before = q_n;
+        if (tid == 0) s_next = 0;
         __syncthreads();
-        const unsigned int h = base + (unsigned int)wave;
-        const bool active = h < n;
-        const int r = active ? (int)rl.heavy_list[h] : 0;
-        ReadView v;
-        bool do_gaps = false;
-        if (active) {
-            v = make_view(b, r);
-            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
-            indels_enumerate(p, v, qs, lane, 64);
-            bool wants = false;
-            do_gaps = gaps_prepare(p, v, wants);
-            if (do_gaps) {
-                if (wants) { v.rescue = true; v.slots = rl.slot_pool + (size_t)h * (GPT * 2); v.lazy_g = &s_g; v.lazy_p = &s_p; }
-                gaps_enumerate(p, v, qs, lane, 64);
-            }
-            my_windows += qs.n_windows; my_indels += qs.n_indels;
-        }
-        __syncthreads();
-        if (q_n > (unsigned)QCAP) {
-            if (tid == 0) atomicAdd(&s_stat[3], 1u);
-            if (active) {
-                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
-                indels_enumerate(p, v, is, lane, 64);
-                if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
+        for (int pass = 0; pass < 2; ++pass) {               // pass 1 only when the queue overflowed
+            for (;;) {
+                unsigned int k = 0;
+                if (lane == 0) k = atomicAdd(&s_next, 1u);
+                k = (unsigned int)__shfl((int)k, 0);
+                if (k >= BATCH || base + k >= n) break;
+                const unsigned int h = base + k;
+                const int r = (int)rl.heavy_list[h];
+                ReadView v = make_view(b, r);
+                bool wants = false;
+                const bool do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });      // the partner search over the lanes
+                if (do_gaps && wants) { v.rescue = true; v.slots = rl.slot_pool + (size_t)h * (GPT * 2); v.lazy_g = &s_g; v.lazy_p = &s_p; }
+                if (pass == 0) {
+                    QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
+                    indels_enumerate(p, v, qs, lane, 64);
+                    if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
+                    my_windows += qs.n_windows; my_indels += qs.n_indels;
+                } else {
+                    InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
+                    indels_enumerate(p, v, is, lane, 64);
+                    if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
+                }
             }
             __syncthreads();
-            if (tid == 0) q_n = q_before;
+            if (pass == 1 || q_n <= (unsigned)QCAP) break;
+            if (tid == 0) { atomicAdd(&s_stat[3], 1u); s_next = 0; q_n = q_before; }
             __syncthreads();
         }
-        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * WPB >= n);
+        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * BATCH >= n);
     }
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
