@@ -348,7 +348,15 @@ __global__ __launch_bounds__(256) void thj_k_stitch_wave(Genome g, Params p, Spa
     const int wave = (int)(threadIdx.x >> 6);
     WaveOps x{(int)(threadIdx.x & 63)};
     const unsigned int total = slice_offsets<256>(t.blk_gen, G, s_off);
-    for (unsigned int i = blockIdx.x * 4 + (unsigned int)wave; i < total; i += gridDim.x * 4) {
+    // The waves draw the list eight entries at a time from one counter: the reads this kernel takes are one in ten of the list and
+    // cost anything between a nine-hit and a forty-hit read's c-squared, so a fixed share per wave left the launch waiting for the
+    // waves that happened to get three or four of the big ones.
+    for (;;) {
+      unsigned int i0 = 0;
+      if (x.lane == 0) i0 = atomicAdd(&t.counters[3], 8u);
+      i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
+      if (i0 >= total) break;
+      for (unsigned int i = i0; i < i0 + 8u && i < total; ++i) {
         const int sl = slice_of(s_off, G, i);
         const int64_t at = (int64_t)sl * t.chunk + (i - s_off[sl]);
         const int r = (int)t.wl_gen[at];
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(256) void thj_k_stitch_wave(Genome g, Params p, Spa
             sink.done((uint32_t)r);
             if (st) atomicAdd(&sink.status[st], 1u);
         }
+      }
     }
     if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
     __syncthreads();
@@ -798,7 +807,7 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     t.counters = &c->d_span_status[4];
     t.chunk = (int)chunk;
     t.huge_list = c->d_huge_list; t.huge_cnt = &c->d_span_status[8]; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
-    HIPCHK(hipMemsetAsync(t.counters, 0, 12, c->stream));
+    HIPCHK(hipMemsetAsync(t.counters, 0, 16, c->stream));                    // [3]: thj_k_stitch_wave's place in its list
     HIPCHK(hipMemsetAsync(t.huge_cnt, 0, 4, c->stream));
     HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, c->stream));      // tiers 0 / 1 write the other two
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
