@@ -377,13 +377,15 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params
     // costs a hundred times one with four, and with one read per wave and a barrier per read three waves in four waited for it
     // (0.64 ms per launch for 65 k reads, of which the barrier-bound waiting was most).
     const unsigned int SHARED_BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;      // a few reads per wave and turn; small launches spread over the chip
-    __shared__ unsigned int s_next;
+    __shared__ unsigned int s_next, s_batch;
     unsigned int my_windows = 0, my_indels = 0;
-    for (unsigned int base = blockIdx.x * SHARED_BATCH; base < n; base += gridDim.x * SHARED_BATCH) {
+    for (;;) {                                              // ... and the workgroups draw the batches (the word after the list's count)
         __syncthreads();
         const unsigned int q_before = q_n;
-        if (tid == 0) s_next = 0;
+        if (tid == 0) { s_next = 0; s_batch = atomicAdd(rl.many_count + 1, 1u); }
         __syncthreads();
+        const unsigned int base = s_batch * SHARED_BATCH;
+        if (base >= n) break;
         for (int pass = 0; pass < 2; ++pass) {               // pass 1 only when the queue overflowed: the batch again, executed where it is found
             for (;;) {
                 unsigned int k = 0;
@@ -422,8 +424,9 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params
             if (tid == 0) { atomicAdd(&s_stat[3], 1u); s_next = 0; q_n = q_before; }
             __syncthreads();
         }
-        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * SHARED_BATCH >= n);
+        run_tasks<WIDE>(g, p, b, ev, tq, false);
     }
+    run_tasks<WIDE>(g, p, b, ev, tq, true);              // what is still queued
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
