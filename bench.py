@@ -874,8 +874,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
         {"kernel": "thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": resc_alg},
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
-        {"kernel": "thj_k_stitch_multihit", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
-        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_wave + thj_k_stitch_generic", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
+        {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
+        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_generic", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
     ]
     # The same kernels in SURVEY 8(d)'s byte terms -- what the ALGORITHM has to move, whatever layout a build chose: 16 B per hit
     # record (this build's stage-2 record is 32 B), the packed read, <= 128 B of genome per window / per joined hit, one 64-B

@@ -389,11 +389,11 @@ typedef struct {
 int thj_span_device_records(thj_ctx* ctx, const thj_aln_slot** d_slots, const uint8_t** d_counts, int64_t* n_reads,
                             const thj_aln_slot** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra);
 /* counts[0] = reads the last thj_span_run_async sent to the closure kernel thj_k_stitch, counts[1] = to the multihit kernel
- * thj_k_stitch_multihit, counts[2] = on to the general kernel thj_k_stitch_generic; the rest were finished by
+ * thj_k_stitch_pack, counts[2] = on to the general kernel thj_k_stitch_generic; the rest were finished by
  * thj_k_stitch_contig. */
 int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[3]*/);
 /* Average durations (ms) of the stitch kernels since the last call -- avg_ms[0] thj_k_stitch_contig, [1] thj_k_stitch,
- * [2] thj_k_stitch_multihit, [3] thj_k_stitch_generic -- from HIP events on the context stream. */
+ * [2] thj_k_stitch_pack, [3] thj_k_stitch_generic -- from HIP events on the context stream. */
 int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[4]*/, int64_t* launches);
 
 /* ---- coverage search of segment_juncs (segment_juncs.cpp:4268-4543 capture_island_ends and what it calls: the

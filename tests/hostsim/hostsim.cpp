@@ -143,20 +143,51 @@ struct VecSink {
     std::vector<OutAln>* v;
     void emit(const OutAln& o) { v->push_back(o); }
     void emit_words(const uint32_t* w) { OutAln o; memcpy(&o, w, sizeof o); v->push_back(o); }
+    void set_count(uint32_t, int) {}
 };
 
-static int64_t g_wave_reads = 0;            // reads the shared tier took since the last call of hostsim_wave_reads
+static int64_t g_wave_reads = 0;            // reads the packed tier finished since the last call of hostsim_wave_reads
 extern "C" int64_t hostsim_wave_reads() { const int64_t n = g_wave_reads; g_wave_reads = 0; return n; }
-// the wave operations span_read_wave is written against, over simt.h's fibers (one wave = 64 fibers)
+// the wave operations span_pack_wave is written against, over simt.h's fibers (one wave = 64 fibers)
 #include "simt.h"
 struct WaveSimX {
     simt::Block* b; int tid, lane;
     uint64_t ballot(bool p) { const uint32_t* a = b->exchange(tid, p ? 1u : 0u); uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (uint64_t)(a[i] & 1u) << i; return m; }
     uint32_t bcast(uint32_t v, int src) { return b->exchange(tid, v)[src & 63]; }
+    uint32_t shfl(uint32_t v, int src) { return b->exchange(tid, v)[src & 63]; }
     uint32_t incl_scan(uint32_t v) { const uint32_t* a = b->exchange(tid, v); uint32_t s = 0; for (int i = 0; i <= lane; ++i) s += a[i]; return s; }
+    uint32_t wmax(uint32_t v) { const uint32_t* a = b->exchange(tid, v); uint32_t m = 0; for (int i = 0; i < 64; ++i) m = a[i] > m ? a[i] : m; return m; }
     void wsync() { b->exchange(tid, 0); }
     unsigned long long clock() { return 0; }
 };
+
+// the packed multihit tier over `list` (64 entries per wave at a time, as thj_k_stitch_pack draws them): records into outs[read],
+// the entries it hands on into `fwd`
+template <int MS, int MAXROOTS, int MAXHITS, int CL>
+static int run_pack(const Genome& g, const Params& p, const SpanSets& S, int32_t nseg, int32_t W, const uint32_t* seg_off, const void* hits,
+                    const uint64_t* planes, const uint16_t* read_len, const uint8_t* quals, int32_t qual_stride,
+                    const std::vector<uint32_t>& list, std::vector<std::vector<OutAln>>& outs, std::vector<uint32_t>& fwd) {
+    static PackLds<MS, MAXHITS, CL> lds;
+    for (size_t i0 = 0; i0 < list.size(); i0 += 64) {
+        std::vector<OutAln> lane_out[64];
+        bool lane_fwd[64];
+        simt::run_block(64, [&](simt::Block& blk, int tid) {
+            WaveSimX x{&blk, tid, tid};
+            VecSink ls{&lane_out[tid]};
+            const bool has = i0 + (size_t)tid < list.size();
+            lane_fwd[tid] = span_pack_wave<MS, MAXROOTS, MAXHITS, CL>(x, g, p, S, (const SpanHit*)hits, (const SpanHitHead*)nullptr, seg_off, nseg, (const u64*)planes, W,
+                                                                      read_len, quals, qual_stride, has ? list[i0 + (size_t)tid] : 0u, has, lds, ls);
+        }, 256 * 1024);
+        for (int l = 0; l < 64; ++l) {
+            if (i0 + (size_t)l >= list.size()) { if (lane_fwd[l]) return -22; continue; }
+            if (lane_fwd[l]) fwd.push_back(list[i0 + (size_t)l]); else ++g_wave_reads;
+        }
+        for (int l = 0; l < 64; ++l)
+            for (auto& o : lane_out[l]) outs[o.read_idx].push_back(o);
+    }
+    for (uint32_t r : fwd) if (!outs[r].empty()) return -23;       // a read that goes on has emitted nothing here
+    return 0;
+}
 
 extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
                                 const int32_t* contig_len, int32_t n_contigs,
@@ -164,7 +195,7 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                                 const uint64_t* planes, const uint16_t* read_len, const uint8_t* quals, int32_t qual_stride,
                                 const thj_junction* juncs, int64_t n_juncs,
                                 const uint32_t* ins /* 4 u32 each: ref,left,len,seq3 */, int64_t n_ins,
-                                int32_t mode /* 0 = the four tiers as the kernels run them, 1 = generic only, 2 = as 0 without the LDS-staged multihit tier, 3 = as 0 with the shared (wave per read) tier in front of tier 3 */,
+                                int32_t mode /* 0 = the four tiers as the kernels run them, 1 = generic only, 2 = as 0 without the packed multihit tier, 3 = as 0 with the packed tier's limits (roots, hits per round) made tiny: many rounds, many hand-overs */,
                                 void** out, int64_t* n_out, int64_t* status_counts /* [5] */) {
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Params p;
@@ -188,10 +219,11 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
         bucket[(size_t)nb] = (uint32_t)n_juncs;
         S.junc_bucket = bucket.data(); S.n_buckets = nb;
     }
-    std::vector<OutAln> res;
-    VecSink sink{&res};
+    std::vector<std::vector<OutAln>> outs((size_t)n_reads);
+    std::vector<uint32_t> multi, gen;
     status_counts[0] = status_counts[1] = status_counts[2] = status_counts[3] = status_counts[4] = 0;
     for (int32_t r = 0; r < n_reads; ++r) {
+        VecSink sink{&outs[(size_t)r]};
         int st = SPAN_NEED_GENERIC;
         if (mode != 1) {
             st = span_read_contig(g, p, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
@@ -204,43 +236,38 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                 if (st == SPAN_INCOMPAT) st = SPAN_OK;
             }
         }
-        if (st == SPAN_NEED_GENERIC && (mode == 0 || mode == 3)) {          // tier 2: multihit reads, every hit head staged
-            SpanHitHead heads[16];
-            st = span_read_multi_staged(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
-                                        read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, heads, nseg <= 4 ? 12 : 16, sink);
-        }
-        if (st == SPAN_NEED_GENERIC && mode == 3) {          // tier 3, shared: the read by a wave (thj_k_stitch_wave), lanes as fibers
-            std::vector<SpanHitHead> heads(WAVE_MAXHITS);
-            std::vector<RAln> pool(WAVE_MAXJOIN);
-            uint8_t perm[64];
-            std::vector<OutAln> lane_out[64];
-            int lane_st[64], lane_n[64];
-            simt::run_block(64, [&](simt::Block& blk, int tid) {
-                WaveSimX x{&blk, tid, tid};
-                VecSink ls{&lane_out[tid]};
-                lane_st[tid] = span_read_wave(x, g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
-                                              read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, heads.data(), pool.data(), perm, ls, &lane_n[tid]);
-            }, 256 * 1024);
-            for (int l = 1; l < 64; ++l) if (lane_st[l] != lane_st[0] || lane_n[l] != lane_n[0]) return -20;   // the status is wave-uniform
-            st = lane_st[0];
-            if (st != SPAN_NEED_GENERIC) {
-                size_t n = 0;
-                for (int l = 0; l < 64; ++l) { for (auto& o : lane_out[l]) res.push_back(o); n += lane_out[l].size(); }
-                if ((int)n != lane_n[0]) return -21;
-                ++g_wave_reads;
-            }
-        }
-        if (st == SPAN_NEED_GENERIC && mode != 1) {          // tier 3, first attempt: DFS over global memory, lean joins
+        if (st == SPAN_NEED_GENERIC) ((mode == 0 || mode == 3) ? multi : gen).push_back((uint32_t)r);
+        else status_counts[st]++;
+    }
+    if (!multi.empty()) {          // tier 2: the multihit list in batches of 64 entries, lanes as fibers
+        int rc;
+        if (mode == 3) rc = run_pack<SPAN_MAXSEG, 6, 20, 64>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
+        else if (nseg <= 4) rc = run_pack<4, 64, 256, 128>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
+        else rc = run_pack<SPAN_MAXSEG, 64, 256, 128>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
+        if (rc) return rc;
+        status_counts[SPAN_OK] += (int64_t)(multi.size() - gen.size());
+        std::sort(gen.begin(), gen.end());
+    }
+    for (uint32_t r : gen) {
+        VecSink sink{&outs[(size_t)r]};
+        int st = SPAN_NEED_GENERIC;
+        if (mode != 1) {          // tier 3, first attempt: DFS over global memory, lean joins
             SpanHit stage[SPAN_MAXSEG];
             st = span_read_multi<48>(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
-                                 read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, stage, sink);
+                                     read_len[r], quals + (int64_t)r * qual_stride, r, stage, sink);
         }
         if (st == SPAN_NEED_GENERIC) {                       // tier 3: the general arrays
             status_counts[3]++;
             st = span_read(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
-                           read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+                           read_len[r], quals + (int64_t)r * qual_stride, r, sink);
         }
         status_counts[st]++;
+    }
+    // read order; a read's records in rank order (the packed tier's lanes emit them in lane order)
+    std::vector<OutAln> res;
+    for (auto& v : outs) {
+        std::stable_sort(v.begin(), v.end(), [](const OutAln& a, const OutAln& b) { return a.order < b.order; });
+        for (auto& o : v) res.push_back(o);
     }
     *n_out = (int64_t)res.size();
     *out = malloc(sizeof(OutAln) * (res.size() + 1));

@@ -157,8 +157,12 @@ def test_scale_workload_with_a_repeat_family():
             got.sort(key=lambda a: a.read_idx)
             assert status[1] == 0 and status[2] == 0
             assert got == want
-            if mode == 3:          # the shared tier (a wave per read, lanes emulated as fibers) took the reads with many hits
-                assert sim.lib().hostsim_wave_reads() > 50
+            took = sim.lib().hostsim_wave_reads()
+            print("mode", mode, "packed tier finished", took, "reads; general arrays", status[3])
+            if mode == 0:          # the packed tier (chains over the lanes of a wave, lanes emulated as fibers) finishes the family's reads
+                assert took > 0.2 * n and status[3] == 0
+            if mode == 3:          # ... and with tiny limits still the reads of few hits, in many rounds
+                assert took > 50
         by_read = {}
         for a in want:
             by_read[a.read_idx] = by_read.get(a.read_idx, 0) + 1

@@ -1,6 +1,6 @@
 // thj_span.hip -- gfx950 kernel + C ABI for the long_spanning_reads hot path.
 //
-//   thj_k_stitch_contig / thj_k_stitch / thj_k_stitch_multihit: 1 thread / read, three tiers of the same
+//   thj_k_stitch_contig / thj_k_stitch (1 thread / read), thj_k_stitch_pack (1 lane / chain): three tiers of the same
 //   algorithm -- DFS over one hit per segment (dfs_seg_hits), closure of every adjacent pair through the
 //   sorted junction / insertion key arrays (merge_chain), edit-distance consistency, sort/unique/filter and
 //   the AS/XM/XO/XG/MD pass (bowtie_sam_extra).  128-byte records land in one slot per read, so the device
@@ -91,6 +91,8 @@ struct RecSink {
             for (int k = 4; k < 8; ++k) dst[k] = make_uint4(slot_word(w, 4 * k, true), slot_word(w, 4 * k + 1, true), slot_word(w, 4 * k + 2, true), slot_word(w, 4 * k + 3, true));
         }
     }
+    // the packed tier: the records of read r were written by several lanes, one of them reports their number
+    __device__ __forceinline__ void set_count(uint32_t r, int n) { nrec[(size_t)base + r] = (uint8_t)(n > 255 ? 255 : n); acc += n; }
     __device__ __forceinline__ void done(uint32_t r) { nrec[(size_t)base + r] = (uint8_t)(emitted > 255 ? 255 : emitted); acc += emitted; emitted = 0; }   // the count saturates: consumers test it for zero
 };
 
@@ -286,42 +288,16 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
     if (threadIdx.x == 0 && s_fwd) atomicAdd(&t.counters[1], s_fwd);
 }
 
-// Tier 2: multihit reads with at most `caph` hits -- the 16-byte heads of all the read's hits staged in LDS, the DFS
-// over one hit per segment and every chain's join on registers (span_read_multi_staged).  Reads with more hits, more
-// cigar ops or more joined alignments than it holds go on to tier 3.
-template <int MS>
-__global__ __launch_bounds__(256, 3) void thj_k_stitch_multihit(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, int caph) {
-    extern __shared__ uint4 lds_stage[];          // caph hit heads per thread
-    __shared__ unsigned int s_off[MAX_SLICES + 1];
-    __shared__ unsigned int s_rec;
-    if (threadIdx.x == 0) s_rec = 0;
-    SpanHitHead* heads = (SpanHitHead*)lds_stage + (size_t)threadIdx.x * caph;
-    const unsigned int total = slice_offsets<256>(t.blk_multi, G, s_off);
-    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int sl = slice_of(s_off, G, i);
-        const int r = (int)t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])];
-        int st = span_read_multi_staged<MS>(g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
-                                            (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, heads, caph, sink);
-        if (st == SPAN_NEED_GENERIC) {
-            t.wl_gen[(int64_t)sl * t.chunk + atomicAdd(&t.blk_gen[sl], 1u)] = (uint32_t)r;
-            atomicAdd(&t.counters[2], 1u);
-        } else { sink.done((uint32_t)r); if (st) atomicAdd(&sink.status[st], 1u); }
-    }
-    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
-    __syncthreads();
-    if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
-}
-
-// Tier 3: what is left.  First the same DFS with its candidates read from global memory (any number of hits) and
-// lean joins (span_read_multi); reads whose joined alignments need more than LEAN_C cigar ops, or that have more than
-// MULTI_MAXJOIN of them, are redone on the general arrays (span_read).
-// Tier 3, shared: the reads tier 2 handed on, one WAVE per read (span_read_wave: lane = first-segment hit, the read's hit heads and
-// joined alignments in LDS).  What it takes is struck from the list (0xFFFFFFFF); thj_k_stitch_generic does the rest.
-static constexpr int WAVE_MINHITS = 36;         // fewer hits than this (nine a segment of a 100-base read): left to thj_k_stitch_generic
+// Tier 2, packed: the multihit list, 64 entries per wave at a time, as chains over the lanes (span_pack_wave): a read with its
+// segments in c copies of a repeat is c one-hit-per-segment chains, each joined on registers the way tier 1 joins its reads.  What it
+// does not take (reads with more than 64 first-segment hits, 256 hits or 64 chains, joins of more than LEAN_C cigar ops) goes on to
+// thj_k_stitch_generic.  The waves draw their batches from one counter: a batch of 40-copy reads is several rounds, a batch of
+// two-copy reads two.
 struct WaveOps {
     int lane;
     __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
     __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
+    __device__ __forceinline__ uint32_t shfl(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v); }
     __device__ __forceinline__ uint32_t incl_scan(uint32_t v) {
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
@@ -331,6 +307,11 @@ struct WaveOps {
         v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
         return v;
     }
+    __device__ __forceinline__ uint32_t wmax(uint32_t v) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = shfl(v, lane ^ d); v = o > v ? o : v; }
+        return v;
+    }
     __device__ __forceinline__ void wsync() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -338,48 +319,39 @@ struct WaveOps {
     }
     __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }
 };
-__global__ __launch_bounds__(256) void thj_k_stitch_wave(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, int min_hits, unsigned long long* dbg) {
+static constexpr int PACK_MAXROOTS = 64, PACK_MAXHITS = 256, PACK_CHAINLIST = 128;
+template <int MS>
+__global__ __launch_bounds__(256, 4) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg) {
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
-    __shared__ SpanHitHead s_heads[4][WAVE_MAXHITS];
-    __shared__ RAln s_pool[4][WAVE_MAXJOIN];
-    __shared__ uint8_t s_perm[4][64];
+    __shared__ PackLds<MS, PACK_MAXHITS, PACK_CHAINLIST> s_pack[4];
     if (threadIdx.x == 0) s_rec = 0;
     const int wave = (int)(threadIdx.x >> 6);
     WaveOps x{(int)(threadIdx.x & 63)};
-    const unsigned int total = slice_offsets<256>(t.blk_gen, G, s_off);
-    // The waves draw the list eight entries at a time from one counter: the reads this kernel takes are one in ten of the list and
-    // cost anything between a nine-hit and a forty-hit read's c-squared, so a fixed share per wave left the launch waiting for the
-    // waves that happened to get three or four of the big ones.
+    const unsigned int total = slice_offsets<256>(t.blk_multi, G, s_off);
+    unsigned long long tmk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
     for (;;) {
-      unsigned int i0 = 0;
-      if (x.lane == 0) i0 = atomicAdd(&t.counters[3], 8u);
-      i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
-      if (i0 >= total) break;
-      for (unsigned int i = i0; i < i0 + 8u && i < total; ++i) {
-        const int sl = slice_of(s_off, G, i);
-        const int64_t at = (int64_t)sl * t.chunk + (i - s_off[sl]);
-        const int r = (int)t.wl_gen[at];
-        // a read with a few hits per segment is cheaper as one of 64 on a wave of tier 3 proper than alone on this one
-        if (b.seg_off[(size_t)r * b.nseg + b.nseg] - b.seg_off[(size_t)r * b.nseg] < (uint32_t)min_hits) continue;
-        int n_emitted = 0;
-        unsigned long long tmk[6] = {0, 0, 0, 0, 0, 0};
-        const int st = span_read_wave(x, g, p, S, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W, (int)b.read_len[r],
-                                      b.quals + (size_t)r * b.qual_stride, (uint32_t)r, s_heads[wave], s_pool[wave], s_perm[wave], sink, &n_emitted, dbg ? tmk : nullptr);
-        if (dbg && x.lane == 0 && st != SPAN_NEED_GENERIC && tmk[5] > tmk[0]) {       // THJ_WAVE_TIMING: sums and maxima of the phases (10 ns ticks), reads counted in [15]
-            for (int k = 0; k < 5; ++k) { const unsigned long long dt = tmk[k + 1] - tmk[k]; atomicAdd(&dbg[k], dt); atomicMax(&dbg[8 + k], dt); }
-            atomicAdd(&dbg[15], 1ull);
+        unsigned int i0 = 0;
+        if (x.lane == 0) i0 = atomicAdd(&t.counters[3], (unsigned int)PACK_ENTRIES);
+        i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
+        if (i0 >= total) break;
+        const unsigned int i = i0 + (unsigned int)x.lane;
+        const bool has = i < total;
+        const int sl = has ? slice_of(s_off, G, i) : 0;
+        const uint32_t r = has ? t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])] : 0u;
+        const bool fwd = span_pack_wave<MS, PACK_MAXROOTS, PACK_MAXHITS, PACK_CHAINLIST>(x, g, p, S, b.hits, b.heads, b.seg_off, b.nseg, b.planes, b.W, b.read_len,
+                                                                                         b.quals, b.qual_stride, r, has, s_pack[wave], sink, dbg ? tmk : nullptr);
+        if (fwd) {
+            t.wl_gen[(int64_t)sl * t.chunk + atomicAdd(&t.blk_gen[sl], 1u)] = r;
+            atomicAdd(&t.counters[2], 1u);
         }
-        x.wsync();                                   // the LDS arrays are free for the wave's next read
-        if (st == SPAN_NEED_GENERIC) continue;
-        // the read's record count is kept by lane 0 (every lane counted the records it wrote itself)
-        sink.emitted = x.lane == 0 ? n_emitted : 0;
-        if (x.lane == 0) {
-            t.wl_gen[at] = 0xFFFFFFFFu;
-            sink.done((uint32_t)r);
-            if (st) atomicAdd(&sink.status[st], 1u);
-        }
-      }
+        x.wsync();
+    }
+    if (dbg && x.lane == 0) {             // THJ_PACK_TIMING: the phases' ticks (10 ns) summed over the waves, [8] a wave's whole time: sum, [9] max
+        for (int k = 0; k < 8; ++k) atomicAdd(&dbg[k], tmk[k]);
+        const unsigned long long dt = wall_clock64() - t_start;
+        atomicAdd(&dbg[8], dt); atomicMax(&dbg[9], dt); atomicAdd(&dbg[10], 1ull);
     }
     if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
     __syncthreads();
@@ -397,7 +369,6 @@ __global__ __launch_bounds__(128) void thj_k_stitch_generic(Genome g, Params p, 
     for (unsigned int i = blockIdx.x * 128 + threadIdx.x; i < total; i += gridDim.x * 128) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_gen[(int64_t)sl * t.chunk + (i - s_off[sl])];
-        if ((uint32_t)r == 0xFFFFFFFFu) continue;              // thj_k_stitch_wave took it
         const uint32_t* so = b.seg_off + (size_t)r * b.nseg;
         const u64* rp = b.planes + (size_t)r * 3 * b.W;
         const uint8_t* q = b.quals + (size_t)r * b.qual_stride;
@@ -807,7 +778,7 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     t.counters = &c->d_span_status[4];
     t.chunk = (int)chunk;
     t.huge_list = c->d_huge_list; t.huge_cnt = &c->d_span_status[8]; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
-    HIPCHK(hipMemsetAsync(t.counters, 0, 16, c->stream));                    // [3]: thj_k_stitch_wave's place in its list
+    HIPCHK(hipMemsetAsync(t.counters, 0, 16, c->stream));                    // [3]: thj_k_stitch_pack's place in its list
     HIPCHK(hipMemsetAsync(t.huge_cnt, 0, 4, c->stream));
     HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, c->stream));      // tiers 0 / 1 write the other two
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -829,25 +800,21 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
         hipLaunchKernelGGL(thj_k_stitch_fusion, dim3((unsigned)gf), dim3(64), 0, c->stream, g, p, S, F, b, sink, t, (int)G);
     } else {
-        const int caph = b.nseg <= 4 ? 12 : 16;           // hit heads staged per read in tier 2 (16 bytes each)
-        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_multihit<4>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
-        else hipLaunchKernelGGL(thj_k_stitch_multihit<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), (size_t)256 * caph * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G, caph);
-        if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
-        static const bool no_wave_tier = getenv("THJ_NO_WAVE_TIER") != nullptr;
-        static const int wave_min_hits = getenv("THJ_WAVE_MINHITS") ? atoi(getenv("THJ_WAVE_MINHITS")) : WAVE_MINHITS;
-        static const bool wave_timing = getenv("THJ_WAVE_TIMING") != nullptr;
+        static const bool pack_timing = getenv("THJ_PACK_TIMING") != nullptr;         // developer switch: phase times of the packed tier on stderr
         unsigned long long* d_dbg = nullptr;
-        if (wave_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, c->stream)); }
-        if (!no_wave_tier) hipLaunchKernelGGL(thj_k_stitch_wave, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, wave_min_hits, d_dbg);
-        if (wave_timing) {
+        if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, c->stream)); }
+        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        else hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        if (pack_timing) {
             unsigned long long h[16];
             HIPCHK(hipStreamSynchronize(c->stream));
             HIPCHK(hipMemcpy(h, d_dbg, 128, hipMemcpyDeviceToHost));
             (void)hipFree(d_dbg);
-            const double n = h[15] ? (double)h[15] : 1.0;
-            fprintf(stderr, "[wave tier] %llu reads; mean / max us: stage + per-hit %.1f / %.1f, search + joins %.1f / %.1f, vote %.1f / %.1f, gather + rank %.1f / %.1f, filters + tags + records %.1f / %.1f\n", h[15],
-                    h[0] / n / 100.0, h[8] / 100.0, h[1] / n / 100.0, h[9] / 100.0, h[2] / n / 100.0, h[10] / 100.0, h[3] / n / 100.0, h[11] / 100.0, h[4] / n / 100.0, h[12] / 100.0);
+            const double nw = h[10] ? (double)h[10] : 1.0;
+            fprintf(stderr, "[packed tier] %llu waves, %llu rounds, %llu sub-rounds; per wave us: all %.1f (max %.1f) = entries %.1f + staging %.1f + searches %.1f + joins %.1f + rank %.1f + tags and records %.1f\n",
+                    h[10], h[6], h[7], h[8] / nw / 100.0, h[9] / 100.0, h[0] / nw / 100.0, h[1] / nw / 100.0, h[2] / nw / 100.0, h[3] / nw / 100.0, h[4] / nw / 100.0, h[5] / nw / 100.0);
         }
+        if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
         hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
     }
     if (c->span_profile) {
@@ -1076,7 +1043,7 @@ extern "C" int thj_span_tier_counts(thj_ctx* c, int64_t* counts) {
 }
 
 extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
-    // avg_ms[4]: thj_k_stitch_contig, thj_k_stitch, thj_k_stitch_multihit, thj_k_stitch_generic (one set per thj_span_run_async)
+    // avg_ms[4]: thj_k_stitch_contig, thj_k_stitch, thj_k_stitch_pack, thj_k_stitch_generic (one set per thj_span_run_async)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

@@ -1033,11 +1033,11 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
 }
 
 
-// ---- tier 2: multihit reads on the lean machinery -----------------------------------------------------------
+// ---- multihit reads on the lean machinery -------------------------------------------------------------------
 // dfs_seg_hits (long_spanning_reads.cpp:2222-2610) over one hit per segment as in the generic span_read, but every
-// complete chain is staged (its nsegs chosen hits) and joined with lean_join on register cigars, and the joined hits
-// are kept as compact RAln records.  Reads that need more cigar ops (LJ_PUNT) or more than MULTI_MAXJOIN joined hits
-// return SPAN_NEED_GENERIC and are redone by span_read, whose arrays have room for them.
+// complete chain is joined with lean_join on register cigars and the joined hits are compact RAln records: by the
+// packed tier (span_pack_wave: a chain per lane) and by the generic tier's first attempt (span_read_multi: a read per
+// thread).  Reads that need more cigar ops (LJ_PUNT) or more joined hits than those hold are redone by span_read.
 static constexpr int MULTI_MAXJOIN = 16;
 THJ_HD bool raln_less(const RAln& a, const RAln& b) {          // BowtieHit::operator< (bwt_map.h:180-207)
     if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
@@ -1083,10 +1083,7 @@ THJ_HD int multi_finish(const Genome& g, const Params& p, RAln* joined, int nj, 
     return status;
 }
 
-// Tier 2 proper: reads with at most `caph` (<= 16) hits in all.  The 16-byte heads of ALL the read's hits -- contig,
-// left, flags, first cigar op: everything a plain-match hit carries -- are fetched back to back into LDS, so the DFS
-// and the joins never wait on HBM again (the global-memory DFS below pays a dependent round trip per candidate, and
-// re-reads a segment's candidates once per parent).  The rare hit with more cigar ops gets its tail from global memory.
+// small arrays in registers: every access an unrolled compare / select chain
 template <int N> THJ_HD int rsel_get(const int (&a)[N], int i) {
     int r = 0;
 #pragma unroll
@@ -1096,98 +1093,6 @@ template <int N> THJ_HD int rsel_get(const int (&a)[N], int i) {
 template <int N> THJ_HD void rsel_set(int (&a)[N], int i, int x) {
 #pragma unroll
     for (int k = 0; k < N; ++k) a[k] = (i == k) ? x : a[k];
-}
-
-template <int MS = SPAN_MAXSEG, class Sink>
-THJ_HD int span_read_multi_staged(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
-                                  const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, int caph, Sink& sink,
-                                  const SpanHitHead* gheads = nullptr) {
-    int off[MS + 1];                          // segment offsets relative to the read's first hit
-    {
-        uint32_t sof[MS + 1];
-#pragma unroll
-        for (int s = 0; s <= MS; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
-#pragma unroll
-        for (int s = 0; s <= MS; ++s) off[s] = (int)(sof[s] - sof[0]);
-        ghits += sof[0];
-        if (gheads) gheads += sof[0];
-    }
-    if (off[1] == 0) return SPAN_OK;
-    int nsegs = 0;
-    {
-        bool open = true;
-#pragma unroll
-        for (int s = 0; s < MS; ++s) { open = open && s < nseg && off[s + 1] > off[s]; nsegs += open ? 1 : 0; }
-    }
-    const int total = rsel_get(off, nsegs);
-    if (total > caph) return SPAN_NEED_GENERIC;
-    for (int b0 = 0; b0 < total; b0 += 8) {           // up to eight 16-byte loads in flight
-        Q16 tmp[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (b0 + k < total) tmp[k] = load_head(ghits, gheads, (u64)(b0 + k));
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if (b0 + k < total) ((Q16*)heads)[b0 + k] = tmp[k];
-    }
-    if (!(heads[rsel_get(off, nsegs - 1)].meta & SH_END)) return SPAN_OK;     // :2777-2785
-    if (p.bowtie2) {
-        bool over = false;
-#pragma unroll
-        for (int s = 0; s < MS; ++s) over = over || (s < nsegs && off[s + 1] - off[s] > p.max_seg_multihits);   // :2625-2632
-        if (over) return SPAN_OK;
-    }
-    if (THJ_EXPF(2048)) return SPAN_OK;
-    const int L = p.segment_length;
-    RAln joined[MULTI_MAXJOIN]; int nj = 0;
-    int idx[MS], pleft[MS], pright[MS];       // next candidate / left / right of the chosen hit, per depth (registers)
-#pragma unroll
-    for (int s = 0; s < MS; ++s) idx[s] = pleft[s] = pright[s] = 0;
-    StagedHits chain{heads, ghits, 0};
-    for (int i0 = 0; i0 < off[1]; ++i0) {                // :2634-2664
-        const SpanHit first = staged_hit(heads, ghits, i0);
-        const uint32_t ref0 = first.ref_id;
-        const bool anti0 = (first.meta & SH_ANTI) != 0;
-        {
-            const RAln a0 = raln_from_hit(first, 0, L, rl);
-            pleft[0] = a0.left; pright[0] = a0.left + rc_ref_span(a0.c, a0.n);
-        }
-        chain.sel = (u64)i0;
-        int num_try = 10000;
-        int depth = 1;
-        idx[1 < MS ? 1 : 0] = off[1];
-        while (depth >= 1) {
-            if (num_try <= 0) break;
-            if (depth == nsegs) {
-                --num_try;
-                RAln res;
-                const int jr = lean_join(g, p, S, chain, nsegs, rp, W, rl, res);
-                if (jr == LJ_PUNT) return SPAN_NEED_GENERIC;
-                if (jr == LJ_OK && valid_hit(p, res)) {
-                    if (nj >= MULTI_MAXJOIN) return SPAN_NEED_GENERIC;
-                    joined[nj++] = res;
-                }
-                --depth;
-                continue;
-            }
-            const int cur = rsel_get(idx, depth);
-            if (cur >= rsel_get(off, depth + 1)) { --depth; continue; }
-            rsel_set(idx, depth, cur + 1);
-            const SpanHit sh = staged_hit(heads, ghits, cur);
-            const RAln cand = raln_from_hit(sh, depth, L, rl);
-            const int cright = cand.left + rc_ref_span(cand.c, cand.n);
-            bool okc = false;
-            if (ref0 == cand.ref_id && (int)anti0 == cand.anti) {             // every hit of a chain shares contig and strand
-                const int dist = anti0 ? rsel_get(pleft, depth - 1) - cright : cand.left - rsel_get(pright, depth - 1);   // :2352-2378, :2531-2556
-                okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
-            }
-            if (okc) {
-                chain.sel = (chain.sel & ~(15ull << (4 * depth))) | ((u64)cur << (4 * depth));
-                rsel_set(pleft, depth, cand.left); rsel_set(pright, depth, cright);
-                ++depth;
-                if (depth < nsegs) rsel_set(idx, depth, rsel_get(off, depth));
-            }
-        }
-    }
-    return multi_finish(g, p, joined, nj, nsegs, rp, W, rl, qual, read_idx, sink);
 }
 
 // MAXJ: joined alignments a read may have here.  Tier 3 gives every copy of a 40-copy repeat its alignment (max_seg_multihits = 40):
@@ -1269,160 +1174,296 @@ THJ_HD int span_read_multi(const Genome& g, const Params& p, const SpanSets& S, 
     return multi_finish(g, p, joined, nj, nsegs, rp, W, rl, qual, read_idx, sink);
 }
 
-// ---- tier 3, shared: ONE read by a wave.  A read of a repeat family has tens of hits per segment (bowtie -k 41) and an alignment
-// in every copy: for one thread that is a DFS of thousands of dependent loads, tens of joins, a sort and tens of tag passes in a row
-// (5 ms for a 40-copy read, which is then what the whole launch takes).  Here the heads of all the read's hits are staged in LDS,
-// lane i runs the DFS from first-segment hit i (dfs_seg_hits' outer loop, long_spanning_reads.cpp:2634-2664, is independent per
-// first hit: num_try is reset for each), the joined hits are gathered in visiting order by a prefix sum, ranked (stable: what the
-// insertion sort of multi_finish yields), adjacent duplicates dropped, and every kept hit's filters and tags run on a lane of its
-// own; record ranks come from a prefix sum over the hits that pass.  X: wave operations (lane, ballot, bcast, incl_scan, wsync).
-// Returns SPAN_NEED_GENERIC (nothing emitted) for what it does not take: more than WAVE_MAXHITS hits, a lane with more than
-// two joined hits, more than WAVE_MAXJOIN in all, a join that needs more cigar ops.  *n_emitted: records written (all lanes).
-static constexpr int WAVE_MAXHITS = 256, WAVE_MAXJOIN = 64, WAVE_LANE_CHAINS = 4;
 struct StagedHits8 {        // as StagedHits, eight bits per segment
     const SpanHitHead* heads; const SpanHit* g0; u64 sel;
     THJ_HD SpanHit operator[](int s) const { return staged_hit(heads, g0, (int)((sel >> (8 * s)) & 255)); }
 };
-template <class X, class Sink>
-THJ_HD int span_read_wave(X& x, const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const uint32_t* so, int nseg,
-                          const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, SpanHitHead* heads, RAln* pool, uint8_t* perm,
-                          Sink& sink, int* n_emitted, unsigned long long* tm = nullptr) {
-#define WV_MARK(k) do { if (tm) tm[k] = x.clock(); } while (0)
-    WV_MARK(0);
-    constexpr int MS = SPAN_MAXSEG;
-    *n_emitted = 0;
-    if (so[1] == so[0]) return SPAN_OK;
-    int nsegs = 0;
-    while (nsegs < nseg && nsegs < MS && so[nsegs + 1] > so[nsegs]) ++nsegs;
-    int off[MS + 1];
-#pragma unroll
-    for (int s = 0; s <= MS; ++s) off[s] = s <= nsegs ? (int)(so[s <= nsegs ? s : 0] - so[0]) : 0;
-    const int total = (int)(so[nsegs] - so[0]);
-    if (total > WAVE_MAXHITS || off[1] > 64) return SPAN_NEED_GENERIC;
-    ghits += so[0];
-    for (int i = x.lane; i < total; i += 64) ((Q16*)heads)[i] = *(const Q16*)(ghits + i);
-    x.wsync();
-    if (!(heads[(int)(so[nsegs - 1] - so[0])].meta & SH_END)) return SPAN_OK;     // :2777-2785
-    if (p.bowtie2)
-        for (int s = 0; s < nsegs; ++s)
-            if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;      // :2625-2632
-    const int L = p.segment_length;
-    // what the search asks of a candidate -- contig and strand, left, right -- once per hit, in the LDS the joined hits will use later
-    // (building the register cigar of a candidate to get its right end was most of a 40 x 40 x 3 walk)
-    int32_t* hleft = (int32_t*)pool;
-    int32_t* hright = hleft + WAVE_MAXHITS;
-    uint32_t* hkey = (uint32_t*)(hright + WAVE_MAXHITS);
-    static_assert(3 * WAVE_MAXHITS * 4 <= WAVE_MAXJOIN * (int)sizeof(RAln), "the per-hit arrays fit the pool");
-    for (int i = x.lane; i < total; i += 64) {
-        const SpanHit sh = staged_hit(heads, ghits, i);
-        const RAln c0 = raln_from_hit(sh, 0, L, rl);
-        hleft[i] = c0.left; hright[i] = c0.left + rc_ref_span(c0.c, c0.n); hkey[i] = (sh.ref_id << 1) | ((sh.meta & SH_ANTI) ? 1u : 0u);
+
+// ---- tier 2, packed: multihit reads as CHAINS spread over the lanes of a wave ----------------------------------------------
+// dfs_seg_hits (long_spanning_reads.cpp:2222-2610) only chains hits of one contig and strand that lie within
+// [-max_insertion_length, max_report_intron] of each other (:2352-2378, :2531-2556), and its num_try budget is per first-segment
+// hit and spent at leaves only (:2596, :2634-2664): the searches from different first-segment hits ("roots") never share state.
+// A read whose segments map to c copies of a repeat is therefore c independent one-hit-per-segment chains, and a chain is what tier 1
+// joins on registers.  A wave takes 64 entries of the multihit list at a time:
+//   phase 0  lane = list entry: segment offsets, the worker's early outs (:2777-2785, :2625-2632), root / hit counts, prefix sums;
+//   rounds   consecutive entries with at most MAXROOTS roots and MAXHITS hits in all: the 16-byte heads of all their hits are staged in
+//            LDS (plus each hit's right end), lane = root walks dfs_seg_hits over the staged hits -- comparisons only -- first to count
+//            its complete chains, then (after a prefix sum) to write them to the round's chain list;
+//   sub-rounds of up to 64 chains cut at read boundaries: lane = chain runs lean_join (merge_chain on register cigars) and
+//            valid_hit; the joined hits of a read sit in adjacent lanes and are ranked by BowtieHit::operator< with ties in generation
+//            order (a stable sort, what multi_finish's insertion sort yields), adjacent duplicates are dropped (:2805-2807), filters
+//            and tags run on every kept hit's own lane, record ranks come from a ballot over the sorted positions.
+// What it does not take goes on to the generic tier, whole (nothing of such a read is emitted here): more than MAXROOTS roots or
+// MAXHITS hits, more than 64 chains, a chain list that is full, a join that needs more than LEAN_C cigar ops.
+// X: wave operations (lane, ballot, bcast, incl_scan, shfl, wmax, wsync), all called in wave-uniform control flow.
+static constexpr int PACK_ENTRIES = 64, PACK_MAXCHAINS = 64;
+template <int MS, int MAXHITS, int CL>
+struct PackLds {
+    SpanHitHead heads[MAXHITS];                 // the round's hits, read after read
+    int32_t hright[MAXHITS];                    // their right ends
+    uint32_t rexcl[PACK_ENTRIES + 1], hexcl[PACK_ENTRIES + 1];     // roots / hits of the (active) entries before entry i
+    uint32_t so0[PACK_ENTRIES], rd[PACK_ENTRIES];                  // the entry's first hit in the batch, its read
+    uint16_t segoff[PACK_ENTRIES][MS + 1];      // segment offsets relative to the read's first hit
+    uint16_t cbeg[PACK_ENTRIES], cend[PACK_ENTRIES];               // the entry's chains in the round's chain list
+    uint8_t nsegs[PACK_ENTRIES], punt[PACK_ENTRIES];
+    u64 csel[CL];                               // a chain: eight bits per segment, the hit's number among the read's hits
+    uint8_t cslot[CL];                          // ... and its entry
+    uint8_t perm[64];
+};
+THJ_HD int pack_slot(const uint32_t* excl, int lo, int hi, uint32_t v) {       // last i in [lo, hi) with excl[i] <= v (excl[lo] <= v)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (excl[mid] <= v) lo = mid; else hi = mid; }
+    return lo;
+}
+THJ_HD u64 pack_range_mask(int b, int e) { return lowmask(e) & ~lowmask(b); }  // bits [b, e), 0 <= b <= e <= 64
+// right end of a hit from its head (one-op hits: everything but spliced segment hits) or its record
+THJ_HD int pack_hit_right(const Q16& q, const SpanHit* ghits, u64 i) {
+    int n = (int)(q.z >> 24); if (n > 5) n = 5;
+    int r = (int)q.y;
+    if (n <= 1) {
+        const int op = cig_op(q.w);
+        if (n == 1 && (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL)) r += (int)cig_len(q.w);
+        return r;
     }
-    x.wsync();
-    WV_MARK(1);
-    RAln r0, r1;
-    r0.valid = 0; r1.valid = 0;
-    uint32_t cnt = 0; bool punt = false;
-    u64 sels[WAVE_LANE_CHAINS];
+    const SpanHit sh = ghits[i];
+    for (int k = 0; k < n; ++k) {
+        const int op = cig_op(sh.cigar[k]);
+        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) r += (int)cig_len(sh.cigar[k]);
+    }
+    return r;
+}
+// dfs_seg_hits from root i0 over the staged hits of one read (hd / hr / off relative to its first hit): the complete chains, counted
+// and -- when `store` -- written to csel / cslot from position pos0 on (below pos_lim).  More than `cap` chains: cap + 1.
+template <int MS>
+THJ_HD int pack_dfs(const SpanHitHead* hd, const int32_t* hr, const uint16_t* off, int nsegs, int i0, const Params& p, int cap,
+                    bool store, bool store_sel, u64* csel, uint8_t* cslot, int pos0, int pos_lim, int slot) {
+    int idx[MS], pleft[MS], pright[MS];
 #pragma unroll
-    for (int j = 0; j < WAVE_LANE_CHAINS; ++j) sels[j] = 0;
-    int nch = 0;
-    StagedHits8 chain0{heads, ghits, 0};
-    if (x.lane < off[1]) {
-        int idx[MS], pleft[MS], pright[MS];
-#pragma unroll
-        for (int s = 0; s < MS; ++s) idx[s] = pleft[s] = pright[s] = 0;
-        StagedHits8 chain{heads, ghits, (u64)x.lane};
-        const uint32_t key0 = hkey[x.lane];
-        const bool anti0 = (key0 & 1u) != 0;
-        pleft[0] = hleft[x.lane]; pright[0] = hright[x.lane];
-        int num_try = 10000;
-        int depth = 1;
-        idx[1 < MS ? 1 : 0] = off[1];
-        chain0 = chain;
-        while (depth >= 1 && !punt) {
-            if (num_try <= 0) break;
-            if (depth == nsegs) {
-                --num_try;
-                // a complete chain: noted, joined after the search -- the lanes reach this point at different turns of the loop, and
-                // a join done here ran once per lane, forty in a row (75 us of a 96 us read)
-                if (nch < WAVE_LANE_CHAINS) {
-#pragma unroll
-                    for (int j = 0; j < WAVE_LANE_CHAINS; ++j) sels[j] = (j == nch) ? chain.sel : sels[j];
-                    ++nch;
-                } else { punt = true; break; }
-                --depth;
-                continue;
+    for (int s = 0; s < MS; ++s) idx[s] = pleft[s] = pright[s] = 0;
+    const SpanHitHead h0 = hd[i0];
+    const uint32_t ref0 = h0.ref_id;
+    const bool anti0 = (h0.meta & SH_ANTI) != 0;
+    pleft[0] = h0.left; pright[0] = hr[i0];
+    u64 sel = (u64)i0;
+    int n = 0, depth = 1;
+    idx[1 < MS ? 1 : 0] = (int)off[1];
+    while (depth >= 1) {
+        if (depth == nsegs) {
+            if (n >= cap) return cap + 1;
+            if (store) {
+                const int pos = pos0 + n;
+                if (pos < pos_lim) { cslot[pos] = (uint8_t)slot; if (store_sel) csel[pos] = sel; }
             }
-            const int cur = rsel_get(idx, depth);
-            if (cur >= rsel_get(off, depth + 1)) { --depth; continue; }
-            rsel_set(idx, depth, cur + 1);
-            const int cleft = hleft[cur], cright = hright[cur];
-            bool okc = false;
-            if (hkey[cur] == key0) {                                          // every hit of a chain shares contig and strand
-                const int dist = anti0 ? rsel_get(pleft, depth - 1) - cright : cleft - rsel_get(pright, depth - 1);   // :2352-2378, :2531-2556
-                okc = dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+            ++n; --depth;
+            continue;
+        }
+        const int cur = rsel_get(idx, depth);
+        if (cur >= (int)off[depth + 1]) { --depth; continue; }
+        rsel_set(idx, depth, cur + 1);
+        const SpanHitHead c = hd[cur];
+        if (c.ref_id != ref0 || ((c.meta & SH_ANTI) != 0) != anti0) continue;      // every hit of a chain shares contig and strand
+        const int cright = hr[cur];
+        const int dist = anti0 ? rsel_get(pleft, depth - 1) - cright : c.left - rsel_get(pright, depth - 1);   // :2352-2378, :2531-2556
+        if (dist > p.max_report_intron || dist < -p.max_insertion_length) continue;
+        sel = (sel & ~(255ull << (8 * depth))) | ((u64)cur << (8 * depth));
+        rsel_set(pleft, depth, c.left); rsel_set(pright, depth, cright);
+        ++depth;
+        if (depth < nsegs) rsel_set(idx, depth, (int)off[depth]);
+    }
+    return n;
+}
+template <class X> THJ_HD void pack_shfl_cigar(X& x, const RAln& a, int src, RAln& o) {
+    o.anti = (int)x.shfl((uint32_t)a.anti, src); o.asplice = (int)x.shfl((uint32_t)a.asplice, src);
+    o.mm = (int)x.shfl((uint32_t)a.mm, src); o.ed = (int)x.shfl((uint32_t)a.ed, src); o.n = (int)x.shfl((uint32_t)a.n, src);
+#pragma unroll
+    for (int k = 0; k < LEAN_C; ++k) o.c.v[k] = x.shfl(a.c.v[k], src);
+}
+// One batch of list entries: lane i has entry `my_read` (has_entry).  Returns whether the lane's entry goes on to the generic tier.
+template <int MS, int MAXROOTS, int MAXHITS, int CL, class X, class Sink>
+THJ_HD bool span_pack_wave(X& x, const Genome& g, const Params& p, const SpanSets& S, const SpanHit* ghits, const SpanHitHead* gheads,
+                           const uint32_t* seg_off, int nseg, const u64* planes, int W, const uint16_t* read_len, const uint8_t* quals,
+                           int qual_stride, uint32_t my_read, bool has_entry, PackLds<MS, MAXHITS, CL>& L, Sink& sink,
+                           unsigned long long* tm = nullptr) {
+    // tm (developer timing, THJ_PACK_TIMING): ticks of x.clock() spent in [0] phase 0, [1] staging, [2] the two searches and their prefix
+    // sums, [3] joins, [4] rank + unique, [5] filters + tags + records; [6] rounds, [7] sub-rounds
+#define PK_MARK(k) do { if (tm) { const unsigned long long now_ = x.clock(); tm[k] += now_ - t_last; t_last = now_; } } while (0)
+    unsigned long long t_last = tm ? x.clock() : 0ull;
+    static_assert(MAXROOTS <= 64 && MAXHITS <= 256 && CL >= PACK_MAXCHAINS && CL <= 65535, "pack limits");
+    const int lane = x.lane;
+    // ---- phase 0: lane = entry
+    int status = 0;                             // 0 nothing to do (or no entry), 1 active, 2 generic tier
+    uint32_t roots = 0, nh = 0;
+    if (has_entry) {
+        const uint32_t* so = seg_off + (size_t)my_read * nseg;
+        uint32_t sof[MS + 1];
+#pragma unroll
+        for (int s = 0; s <= MS; ++s) sof[s] = s <= nseg ? so[s <= nseg ? s : 0] : 0u;
+        int nsegs = 0;
+        {
+            bool open = true;
+#pragma unroll
+            for (int s = 0; s < MS; ++s) { open = open && s < nseg && sof[s + 1] > sof[s]; nsegs += open ? 1 : 0; }
+        }
+        if (nsegs > 0) {                        // the worker iterates over first-segment groups
+            uint32_t last_so = sof[0], end_so = sof[0];
+#pragma unroll
+            for (int s = 1; s <= MS; ++s) { last_so = (s == nsegs - 1) ? sof[s] : last_so; end_so = (s == nsegs) ? sof[s] : end_so; }
+            bool ok = (load_head(ghits, gheads, (u64)last_so).z & SH_END) != 0;          // :2777-2785
+            if (ok && p.bowtie2) {
+#pragma unroll
+                for (int s = 0; s < MS; ++s) ok = ok && !(s < nsegs && (int)(sof[s + 1] - sof[s]) > p.max_seg_multihits);   // :2625-2632
             }
-            if (okc) {
-                chain.sel = (chain.sel & ~(255ull << (8 * depth))) | ((u64)cur << (8 * depth));
-                rsel_set(pleft, depth, cleft); rsel_set(pright, depth, cright);
-                ++depth;
-                if (depth < nsegs) rsel_set(idx, depth, rsel_get(off, depth));
+            if (ok) {
+                roots = sof[1] - sof[0]; nh = end_so - sof[0];
+                // one hit per segment: tier 1 has been there and needs more cigar ops than the registers hold
+                status = (roots > (uint32_t)MAXROOTS || nh > (uint32_t)MAXHITS || nh == (uint32_t)nsegs) ? 2 : 1;
             }
         }
-    }
-    // the joins, every lane's j-th chain at the same time
+        L.so0[lane] = sof[0]; L.rd[lane] = my_read; L.nsegs[lane] = (uint8_t)nsegs;
 #pragma unroll
-    for (int j = 0; j < WAVE_LANE_CHAINS; ++j) {
-        if (j < nch && !punt) {
-            chain0.sel = sels[j];
+        for (int s = 0; s <= MS; ++s) L.segoff[lane][s] = (uint16_t)(sof[s] - sof[0]);
+    }
+    L.punt[lane] = 0;
+    const uint32_t rc = status == 1 ? roots : 0u, hc = status == 1 ? nh : 0u;
+    const uint32_t rincl = x.incl_scan(rc), hincl = x.incl_scan(hc);
+    L.rexcl[lane] = rincl - rc; L.hexcl[lane] = hincl - hc;
+    if (lane == 63) { L.rexcl[64] = rincl; L.hexcl[64] = hincl; }
+    x.wsync();
+    PK_MARK(0);
+    // ---- rounds
+    int cur = 0;
+    while (cur < PACK_ENTRIES) {
+        const uint32_t rbase = L.rexcl[cur], hbase = L.hexcl[cur];
+        const u64 m_over = x.ballot(lane >= cur && (rincl - rbase > (uint32_t)MAXROOTS || hincl - hbase > (uint32_t)MAXHITS));
+        const int end = m_over ? ctz(m_over) : PACK_ENTRIES;
+        const uint32_t R = L.rexcl[end] - rbase, H = L.hexcl[end] - hbase;
+        if (R == 0) { cur = end; continue; }
+        // the heads of the round's hits, and each hit's right end
+        for (uint32_t j = (uint32_t)lane; j < H; j += 64u) {
+            const int slot = pack_slot(L.hexcl, cur, end, hbase + j);
+            const u64 gi = (u64)L.so0[slot] + (hbase + j - L.hexcl[slot]);
+            const Q16 q = load_head(ghits, gheads, gi);
+            ((Q16*)L.heads)[j] = q;
+            L.hright[j] = pack_hit_right(q, ghits, gi);
+        }
+        x.wsync();
+        PK_MARK(1);
+        if (tm) tm[6] += 1;
+        // lane = root: count the chains, place them, write them
+        const bool is_root = (uint32_t)lane < R;
+        int slot = 0, i0 = 0, hb = 0, nsg = 0;
+        uint32_t n_roots = 0;
+        if (is_root) {
+            slot = pack_slot(L.rexcl, cur, end, rbase + (uint32_t)lane);
+            i0 = (int)(rbase + (uint32_t)lane - L.rexcl[slot]);
+            hb = (int)(L.hexcl[slot] - hbase);
+            nsg = (int)L.nsegs[slot];
+            n_roots = L.rexcl[slot + 1] - L.rexcl[slot];
+        }
+        int cnt = 0;
+        if (is_root) {
+            cnt = pack_dfs<MS>(L.heads + hb, L.hright + hb, L.segoff[slot], nsg, i0, p, PACK_MAXCHAINS, false, false, nullptr, nullptr, 0, 0, slot);
+            if (cnt > PACK_MAXCHAINS) { L.punt[slot] = 1; cnt = 0; }
+        }
+        x.wsync();
+        if (is_root && L.punt[slot]) cnt = 0;
+        const uint32_t cincl = x.incl_scan((uint32_t)cnt), cexcl = cincl - (uint32_t)cnt;
+        if (is_root && i0 == 0) L.cbeg[slot] = (uint16_t)cexcl;
+        if (is_root && (uint32_t)i0 == n_roots - 1) L.cend[slot] = (uint16_t)cincl;
+        x.wsync();
+        if (is_root && ((uint32_t)L.cend[slot] - (uint32_t)L.cbeg[slot] > (uint32_t)PACK_MAXCHAINS || (uint32_t)L.cend[slot] > (uint32_t)CL)) L.punt[slot] = 1;
+        x.wsync();
+        const uint32_t C = x.bcast(cincl, 63), Cend = C < (uint32_t)CL ? C : (uint32_t)CL;
+        if (is_root && cnt > 0)
+            pack_dfs<MS>(L.heads + hb, L.hright + hb, L.segoff[slot], nsg, i0, p, PACK_MAXCHAINS, true, !L.punt[slot], L.csel, L.cslot, (int)cexcl, CL, slot);
+        x.wsync();
+        PK_MARK(2);
+        // ---- sub-rounds: lane = chain
+        uint32_t c0 = 0;
+        while (c0 < Cend) {
+            const uint32_t j = c0 + (uint32_t)lane;
+            const bool has = j < Cend;
+            const int cs = has ? (int)L.cslot[j] : 0;
+            const uint32_t cb = has ? (uint32_t)L.cbeg[cs] : 0u, ce = has ? (uint32_t)L.cend[cs] : 0u;
+            const bool cut = has && ce > c0 + 64u;
+            const u64 m_cut = x.ballot(cut);
+            uint32_t next = c0 + 64u;
+            if (m_cut) {
+                const int fs = (int)L.cslot[c0 + (uint32_t)ctz(m_cut)];
+                next = (uint32_t)L.cbeg[fs];
+                if (next == c0) next = (uint32_t)L.cend[fs];          // a read with more chains than a sub-round holds (it has punted)
+            }
+            bool live = has && !cut && !L.punt[cs];
             RAln res;
-            const int jr = lean_join(g, p, S, chain0, nsegs, rp, W, rl, res);
-            if (jr == LJ_PUNT) punt = true;
-            else if (jr == LJ_OK && valid_hit(p, res)) {
-                if (cnt == 0) r0 = res; else if (cnt == 1) r1 = res; else punt = true;
-                ++cnt;
+            res.ref_id = 0; res.left = 0; res.n = 0; res.anti = res.asplice = res.mm = res.ed = res.rlen = res.valid = 0;
+#pragma unroll
+            for (int k = 0; k < LEAN_C; ++k) res.c.v[k] = 0;
+            bool okj = false;
+            uint32_t r = 0; int rl = 0, nsj = 0;
+            const u64* rp = planes;
+            if (live) {
+                r = L.rd[cs]; rl = (int)read_len[r]; nsj = (int)L.nsegs[cs];
+                rp = planes + (size_t)r * 3 * W;
+                const StagedHits8 ch{L.heads + (L.hexcl[cs] - hbase), ghits + L.so0[cs], L.csel[j]};
+                const int jr = lean_join(g, p, S, ch, nsj, rp, W, rl, res);
+                if (jr == LJ_PUNT) L.punt[cs] = 1;
+                else okj = jr == LJ_OK && valid_hit(p, res);
             }
+            x.wsync();
+            PK_MARK(3);
+            if (tm) tm[7] += 1;
+            live = live && !L.punt[cs];
+            const bool val = live && okj;
+            const int gb = live ? (int)(cb - c0) : lane, ge = live ? (int)(ce - c0) : lane;
+            // rank among the read's joined hits: BowtieHit::operator<, ties in generation order
+            const uint32_t maxlen = x.wmax((uint32_t)(ge - gb));
+            int rank = 0;
+            for (uint32_t k = 0; k < maxlen; ++k) {
+                const bool in = (int)k < ge - gb;
+                const int src = in ? gb + (int)k : lane;
+                const uint32_t oref = x.shfl(res.ref_id, src), oleft = x.shfl((uint32_t)res.left, src), oval = x.shfl(val ? 1u : 0u, src);
+                const bool cmp = in && val && oval != 0u && src != lane;
+                const bool tie = cmp && oref == res.ref_id && (int32_t)oleft == res.left;
+                if (x.ballot(tie)) {
+                    RAln o;
+                    pack_shfl_cigar(x, res, src, o);
+                    o.ref_id = oref; o.left = (int32_t)oleft;
+                    if (tie) rank += (raln_less(o, res) || (src < lane && !raln_less(res, o))) ? 1 : 0;
+                }
+                if (cmp && !tie) rank += (oref < res.ref_id || (oref == res.ref_id && (int32_t)oleft < res.left)) ? 1 : 0;
+            }
+            const u64 gmask = pack_range_mask(gb, ge);
+            const int nval = popc(x.ballot(val) & gmask);
+            if (val) L.perm[gb + rank] = (uint8_t)lane;
+            x.wsync();
+            // unique: equal to the hit before it in sorted order
+            const int pl = (val && rank > 0) ? (int)L.perm[gb + rank - 1] : lane;
+            const uint32_t pref = x.shfl(res.ref_id, pl), pleft = x.shfl((uint32_t)res.left, pl);
+            const bool maybe = val && rank > 0 && pref == res.ref_id && (int32_t)pleft == res.left;
+            bool dup = false;
+            if (x.ballot(maybe)) {
+                RAln o;
+                pack_shfl_cigar(x, res, pl, o);
+                o.ref_id = pref; o.left = (int32_t)pleft;
+                if (maybe) dup = raln_eq(o, res);
+            }
+            PK_MARK(4);
+            Extras e;
+            bool emit = false;
+            if (val && !dup) emit = lean_finish_check(g, p, res, nsj, rp, W, rl, quals + (size_t)r * qual_stride, e);
+            // which sorted positions emit: the lane at position q asks the lane that holds the q-th hit
+            const bool hosts = live && lane - gb < nval;
+            const uint32_t es = x.shfl(emit ? 1u : 0u, hosts ? (int)L.perm[lane] : lane);
+            const u64 smask = x.ballot(hosts && es != 0u);
+            if (emit) emit_aln(sink, r, popc(smask & pack_range_mask(gb, gb + rank)), res, e);
+            if (live && lane == gb) sink.set_count(r, popc(smask & gmask));
+            x.wsync();
+            PK_MARK(5);
+            c0 = next;
         }
+        cur = end;
     }
-    WV_MARK(2);
-    if (x.ballot(punt)) return SPAN_NEED_GENERIC;
-    WV_MARK(3);
-    const uint32_t incl = x.incl_scan(cnt), nj = x.bcast(incl, 63);
-    if (nj > (uint32_t)WAVE_MAXJOIN) return SPAN_NEED_GENERIC;
-    if (nj == 0) return SPAN_OK;
-    if (cnt > 0) pool[incl - cnt] = r0;
-    if (cnt > 1) pool[incl - cnt + 1] = r1;
-    x.wsync();
-    // rank = position after a stable sort by BowtieHit::operator<
-    if ((uint32_t)x.lane < nj) {
-        const RAln me = pool[x.lane];
-        int rank = 0;
-        for (int k = 0; k < (int)nj; ++k) {
-            if (k == x.lane) continue;
-            const RAln o = pool[k];
-            if (raln_less(o, me) || (k < x.lane && !raln_less(me, o))) ++rank;
-        }
-        perm[rank] = (uint8_t)x.lane;
-    }
-    x.wsync();
-    WV_MARK(4);
-    // sort + unique (:2805-2807), the per-hit filters and the records: lane k has the k-th hit of the sorted list
-    RAln el; el.valid = 0;
-    bool emit = false;
-    Extras e;
-    if ((uint32_t)x.lane < nj) {
-        el = pool[perm[x.lane]];
-        bool keep = true;
-        if (x.lane > 0) { const RAln prev = pool[perm[x.lane - 1]]; keep = !raln_eq(prev, el); }
-        if (keep) emit = lean_finish_check(g, p, el, nsegs, rp, W, rl, qual, e);
-    }
-    const uint32_t ei = x.incl_scan(emit ? 1u : 0u);
-    if (emit) emit_aln(sink, read_idx, (int)ei - 1, el, e);
-    *n_emitted = (int)x.bcast(ei, 63);
-    WV_MARK(5);
-    return SPAN_OK;
-#undef WV_MARK
+#undef PK_MARK
+    return status == 2 || (status == 1 && L.punt[lane] != 0);
 }
 
 // ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
