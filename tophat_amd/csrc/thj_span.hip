@@ -291,8 +291,8 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanS
 // Tier 2, packed: the multihit list, 64 entries per wave at a time, as chains over the lanes (span_pack_wave): a read with its
 // segments in c copies of a repeat is c one-hit-per-segment chains, each joined on registers the way tier 1 joins its reads.  What it
 // does not take (reads with more than 64 first-segment hits, 256 hits or 64 chains, joins of more than LEAN_C cigar ops) goes on to
-// thj_k_stitch_generic.  The waves draw their batches from one counter: a batch of 40-copy reads is several rounds, a batch of
-// two-copy reads two.
+// thj_k_stitch_generic.  The waves draw their batches from one counter: a draw of 40-copy reads is several rounds, a draw of
+// two-copy reads one.
 struct WaveOps {
     int lane;
     __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
@@ -320,24 +320,28 @@ struct WaveOps {
     __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }
 };
 static constexpr int PACK_MAXROOTS = 64, PACK_MAXHITS = 256, PACK_CHAINLIST = 128;
+static constexpr int PACK_DRAW = 32;        // list entries a wave draws at a time: a draw of two-copy reads is one round, and the launch ends one draw's time after its last wave found the list empty
+// Eight waves per workgroup, two workgroups per CU: 16 waves per CU is what 128 VGPRs allow, and a wave's 9 KB of LDS with the
+// workgroup's slice table fit the CU's 160 KB twice over that way (four workgroups of four waves do not: three were resident).
+static constexpr int PACK_TPB = 512;
 template <int MS>
-__global__ __launch_bounds__(256, 4) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg) {
+__global__ __launch_bounds__(PACK_TPB, 4) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg) {
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
-    __shared__ PackLds<MS, PACK_MAXHITS, PACK_CHAINLIST> s_pack[4];
+    __shared__ PackLds<MS, PACK_MAXHITS, PACK_CHAINLIST> s_pack[PACK_TPB / 64];
     if (threadIdx.x == 0) s_rec = 0;
     const int wave = (int)(threadIdx.x >> 6);
     WaveOps x{(int)(threadIdx.x & 63)};
-    const unsigned int total = slice_offsets<256>(t.blk_multi, G, s_off);
+    const unsigned int total = slice_offsets<PACK_TPB>(t.blk_multi, G, s_off);
     unsigned long long tmk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
     for (;;) {
         unsigned int i0 = 0;
-        if (x.lane == 0) i0 = atomicAdd(&t.counters[3], (unsigned int)PACK_ENTRIES);
+        if (x.lane == 0) i0 = atomicAdd(&t.counters[3], (unsigned int)PACK_DRAW);
         i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
         if (i0 >= total) break;
         const unsigned int i = i0 + (unsigned int)x.lane;
-        const bool has = i < total;
+        const bool has = x.lane < PACK_DRAW && i < total;
         const int sl = has ? slice_of(s_off, G, i) : 0;
         const uint32_t r = has ? t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])] : 0u;
         const bool fwd = span_pack_wave<MS, PACK_MAXROOTS, PACK_MAXHITS, PACK_CHAINLIST>(x, g, p, S, b.hits, b.heads, b.seg_off, b.nseg, b.planes, b.W, b.read_len,
@@ -803,8 +807,8 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         static const bool pack_timing = getenv("THJ_PACK_TIMING") != nullptr;         // developer switch: phase times of the packed tier on stderr
         unsigned long long* d_dbg = nullptr;
         if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, c->stream)); }
-        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
-        else hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MAXSEG>, dim3((unsigned)g2), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        else hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MAXSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
         if (pack_timing) {
             unsigned long long h[16];
             HIPCHK(hipStreamSynchronize(c->stream));

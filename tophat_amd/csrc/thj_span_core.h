@@ -1201,6 +1201,8 @@ template <int MS, int MAXHITS, int CL>
 struct PackLds {
     SpanHitHead heads[MAXHITS];                 // the round's hits, read after read
     int32_t hright[MAXHITS];                    // their right ends
+    uint8_t hslot[MAXHITS];                     // their entries
+    uint8_t hnext[MAXHITS], hncomp[MAXHITS];    // the first hit of the next segment a hit chains with (number among the read's hits), and how many do
     uint32_t rexcl[PACK_ENTRIES + 1], hexcl[PACK_ENTRIES + 1];     // roots / hits of the (active) entries before entry i
     uint32_t so0[PACK_ENTRIES], rd[PACK_ENTRIES];                  // the entry's first hit in the batch, its read
     uint16_t segoff[PACK_ENTRIES][MS + 1];      // segment offsets relative to the read's first hit
@@ -1344,10 +1346,38 @@ THJ_HD bool span_pack_wave(X& x, const Genome& g, const Params& p, const SpanSet
             const Q16 q = load_head(ghits, gheads, gi);
             ((Q16*)L.heads)[j] = q;
             L.hright[j] = pack_hit_right(q, ghits, gi);
+            L.hslot[j] = (uint8_t)slot;
         }
         x.wsync();
         PK_MARK(1);
         if (tm) tm[6] += 1;
+        // lane = hit: which hits of the next segment it chains with (:2352-2378, :2531-2556) -- the first one and their number.  A root
+        // whose path meets one such hit per segment has that one chain (the case of reads from c copies of a repeat: c roots, c
+        // chains); dfs_seg_hits proper (pack_dfs) runs only from roots that meet a choice.
+        for (uint32_t j = (uint32_t)lane; j < H; j += 64u) {
+            const int slot = (int)L.hslot[j];
+            const int hb = (int)(L.hexcl[slot] - hbase), nsg = (int)L.nsegs[slot];
+            const int k = (int)j - hb;
+            int d = 0;
+#pragma unroll
+            for (int s = 1; s < MS; ++s) d += (s < nsg && (int)L.segoff[slot][s] <= k) ? 1 : 0;
+            int first = 0, nc = 0;
+            if (d + 1 < nsg) {
+                const SpanHitHead me = L.heads[j];
+                const int myright = L.hright[j];
+                const bool anti = (me.meta & SH_ANTI) != 0;
+                const int c1 = (int)L.segoff[slot][d + 2];
+                for (int c = (int)L.segoff[slot][d + 1]; c < c1; ++c) {
+                    const SpanHitHead o = L.heads[hb + c];
+                    const int dist = anti ? me.left - L.hright[hb + c] : o.left - myright;
+                    const bool okc = o.ref_id == me.ref_id && ((o.meta & SH_ANTI) != 0) == anti && dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+                    first = (okc && nc == 0) ? c : first;
+                    nc += okc ? 1 : 0;
+                }
+            }
+            L.hnext[j] = (uint8_t)first; L.hncomp[j] = (uint8_t)(nc > 255 ? 255 : nc);
+        }
+        x.wsync();
         // lane = root: count the chains, place them, write them
         const bool is_root = (uint32_t)lane < R;
         int slot = 0, i0 = 0, hb = 0, nsg = 0;
@@ -1360,9 +1390,22 @@ THJ_HD bool span_pack_wave(X& x, const Genome& g, const Params& p, const SpanSet
             n_roots = L.rexcl[slot + 1] - L.rexcl[slot];
         }
         int cnt = 0;
+        bool choice = false;                    // the root's search meets a hit with several continuations
+        u64 sel1 = 0;                           // its one chain otherwise
         if (is_root) {
-            cnt = pack_dfs<MS>(L.heads + hb, L.hright + hb, L.segoff[slot], nsg, i0, p, PACK_MAXCHAINS, false, false, nullptr, nullptr, 0, 0, slot);
-            if (cnt > PACK_MAXCHAINS) { L.punt[slot] = 1; cnt = 0; }
+            int k = i0;
+            sel1 = (u64)i0;
+            cnt = 1;
+            for (int d = 1; d < nsg; ++d) {
+                const int nc = (int)L.hncomp[hb + k];
+                if (nc != 1) { cnt = 0; choice = nc > 1; break; }
+                k = (int)L.hnext[hb + k];
+                sel1 |= (u64)k << (8 * d);
+            }
+            if (choice) {
+                cnt = pack_dfs<MS>(L.heads + hb, L.hright + hb, L.segoff[slot], nsg, i0, p, PACK_MAXCHAINS, false, false, nullptr, nullptr, 0, 0, slot);
+                if (cnt > PACK_MAXCHAINS) { L.punt[slot] = 1; cnt = 0; }
+            }
         }
         x.wsync();
         if (is_root && L.punt[slot]) cnt = 0;
@@ -1373,8 +1416,10 @@ THJ_HD bool span_pack_wave(X& x, const Genome& g, const Params& p, const SpanSet
         if (is_root && ((uint32_t)L.cend[slot] - (uint32_t)L.cbeg[slot] > (uint32_t)PACK_MAXCHAINS || (uint32_t)L.cend[slot] > (uint32_t)CL)) L.punt[slot] = 1;
         x.wsync();
         const uint32_t C = x.bcast(cincl, 63), Cend = C < (uint32_t)CL ? C : (uint32_t)CL;
-        if (is_root && cnt > 0)
-            pack_dfs<MS>(L.heads + hb, L.hright + hb, L.segoff[slot], nsg, i0, p, PACK_MAXCHAINS, true, !L.punt[slot], L.csel, L.cslot, (int)cexcl, CL, slot);
+        if (is_root && cnt > 0) {
+            if (choice) pack_dfs<MS>(L.heads + hb, L.hright + hb, L.segoff[slot], nsg, i0, p, PACK_MAXCHAINS, true, !L.punt[slot], L.csel, L.cslot, (int)cexcl, CL, slot);
+            else if (cexcl < (uint32_t)CL) { L.cslot[cexcl] = (uint8_t)slot; L.csel[cexcl] = sel1; }
+        }
         x.wsync();
         PK_MARK(2);
         // ---- sub-rounds: lane = chain
