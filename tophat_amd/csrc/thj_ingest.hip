@@ -1493,7 +1493,7 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
     const bool have_mate = f_full >= 0 || f_last >= 0;
     IngestOwned* ob = new IngestOwned();
     memset(ob, 0, sizeof *ob);
-    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 8; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (size_t i = 0; i < sizeof ob->ptrs / sizeof *ob->ptrs; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
     uint32_t* b_off = nullptr; Hit16* b_hits = nullptr; u64* b_planes = nullptr; uint16_t* b_len = nullptr; uint32_t* b_moff = nullptr; Hit16* b_mh = nullptr;
     uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* mcell = am.take<uint32_t>((size_t)n_rows + 1);
     uint32_t* row_id = am.take<uint32_t>(n_rows); uint32_t* seen = am.take<uint32_t>(n_rows);
@@ -1608,7 +1608,7 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
     if (n_rows == 0) return THJ_OK;
     IngestOwnedSpan* ob = new IngestOwnedSpan();
     memset(ob, 0, sizeof *ob);
-    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (int i = 0; i < 8; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
+    auto fail = [&](int code) { hipStreamSynchronize(c->stream); for (size_t i = 0; i < sizeof ob->ptrs / sizeof *ob->ptrs; ++i) thj_dev_release(c, ob->ptrs[i]); delete ob; return code; };
     uint32_t* cell = am.take<uint32_t>((size_t)n_rows * nseg + 1); uint32_t* row_id = am.take<uint32_t>(n_rows);
     if (!cell || !row_id) { thj_set_error("thj_ingest: merge scratch too small"); return fail(THJ_ENOMEM); }
     uint32_t* b_off = nullptr; Hit32* b_hits = nullptr;
