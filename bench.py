@@ -836,10 +836,11 @@ def run_rank(args, rank, world, local_rank, control, shared):
     rl_bytes = (args.read_len + 3) // 4 + (args.read_len + 7) // 8            # packed read: 2-bit bases + N mask
     n_launch = 2
     nseg = w["left"]["nseg"]
-    # thj_k_segjuncs: 16 B per hit record + 4 B per (read, segment) CSR offset + per RefSeg window two 64-B genome
-    # lines and the read + per indel pair one genome line and the read + 8 B per distinct event emitted
-    seg_alg = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1) \
-        + (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
+    # stage 1.  The classifying kernels (thj_k_sj_flat and, for the reads that are not flat, thj_k_sj_general / thj_k_segjuncs_shared)
+    # stream 16 B per hit record + 4 B per (read, segment) CSR offset; thj_k_sj_tasks reads per RefSeg window two 64-B genome
+    # lines and the read, per indel pair one genome line and the read, and writes 8 B per distinct event emitted
+    cls_alg = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1)
+    task_alg = (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
     # stage 2, four kernels per launch.  Per finished read: 38 B of read planes, two 64-B genome lines (consistency
     # check + MD pass share them) and the 64-B lead line of its record; tier 0 streams every read's CSR row and 32-B hit records;
@@ -870,8 +871,9 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # thj_k_segjuncs_rescue: per (hit, mate hit) pair the read, its CSR row + hits, the mate hit and ~3 genome lines of flank
     resc_alg = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 192)
     kernels = [
-        {"kernel": "thj_k_segjuncs + thj_k_segjuncs_shared", "avg_kernel_ms": kern_ms[0], "launches": launches, "algorithmic_bytes_per_launch": seg_alg},
-        {"kernel": "thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": resc_alg},
+        {"kernel": "thj_k_sj_flat + thj_k_sj_general + thj_k_segjuncs_shared", "avg_kernel_ms": kern_ms[0], "launches": launches, "algorithmic_bytes_per_launch": cls_alg},
+        {"kernel": "thj_k_sj_rescue_scan + thj_k_sj_rescue_flat + thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": resc_alg},
+        {"kernel": "thj_k_sj_tasks", "avg_kernel_ms": kern_ms[2], "launches": launches, "algorithmic_bytes_per_launch": task_alg},
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
         {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
@@ -884,14 +886,15 @@ def run_rank(args, rank, world, local_rank, control, shared):
     cig_per_rec = 1.0 + 2.0 * (n_lean + n_multi) / max(1.0, float(args.pairs))         # contiguous: 1 op; one closure: 3
     out_rec = 32.0 + 8.0 * cig_per_rec
     done_8d = rl_bytes + rec_per_read * (128.0 + out_rec)
-    seg_8d = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1) + (cnt.n_windows / n_launch) * (128 + rl_bytes) \
-        + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) + 16.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
+    cls_8d = cls_alg
+    task_8d = (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
+        + 16.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
     t0_8d = 4.0 * (args.pairs * nseg + 1) + 16.0 * hits_per_read * args.pairs + n_t0 * done_8d + 4.0 * (n_lean + n_multi)
     t1_8d = n_lean * (4 + 4.0 * (nseg + 1) + 16.0 * hits_single + done_8d + 64)
     t2_8d = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read) + done_8d + 64) + 4.0 * n_gen
     t3_8d = n_gen * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64)
     resc_8d = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 128)
-    for k, b8 in zip(kernels, (seg_8d, resc_8d, t0_8d, t1_8d, t2_8d, t3_8d)):
+    for k, b8 in zip(kernels, (cls_8d, resc_8d, task_8d, t0_8d, t1_8d, t2_8d, t3_8d)):
         k["algorithmic_bytes_8d_per_launch"] = b8
     for k in kernels:
         k["achieved_layout"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0

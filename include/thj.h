@@ -226,10 +226,11 @@ int thj_fusion_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch*
 int thj_fusion_finish(thj_ctx* ctx, int64_t* n_fusions);
 int thj_fusion_download(thj_ctx* ctx, thj_fusion* out);
 
-/* Average durations (ms) of the two kernels of a run -- avg_ms[0] `thj_k_segjuncs`,
- * avg_ms[1] `thj_k_segjuncs_rescue` -- over the runs since the last call, measured
- * with HIP events on the context stream; also returns the run count.  Enables event
- * recording when `enable` != 0. */
+/* Average durations (ms) of the three groups of kernels of a run -- avg_ms[0] the classifying
+ * kernels (`thj_k_sj_flat`, `thj_k_sj_general`, `thj_k_segjuncs_shared`), avg_ms[1] the rescue
+ * kernels (`thj_k_sj_rescue_scan`, `thj_k_sj_rescue_flat`, `thj_k_segjuncs_rescue`, `_rescue_shared`),
+ * avg_ms[2] `thj_k_sj_tasks` -- over the runs since the last call, measured with HIP events on the
+ * context stream; also returns the run count.  Enables event recording when `enable` != 0. */
 int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches);
 
 

@@ -35,6 +35,70 @@ struct ExecSink {
     }
 };
 
+// the task words of the kernels' queues, executed where they are emitted (what thj_k_sj_tasks does with them)
+struct DecodeEmit {
+    const Genome& g; const Params& p; const ReadView& v; Collect& c; uint32_t ordinal;
+    void task(bool valid, uint32_t a, uint32_t b, uint32_t cc, uint32_t d) {
+        if (!valid) return;
+        const bool anti = (a >> 9) & 1u;
+        if (a & (1u << 8)) {
+            const bool is_del = (a >> 10) & 1u;
+            const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
+            indel_exec(g, p, v, i, b, cc, anti, plen, is_del, ins_prio(ordinal, i, (int)(d & 0xFFFF), (int)(d >> 16)), c);
+        } else {
+            const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
+            window_exec(g, p, v, b, (int32_t)cc, (int32_t)d, anti, start, slen, c);
+        }
+    }
+};
+
+// a read with at most one hit per segment the way thj_k_sj_flat / thj_k_sj_rescue_flat handle it; false: not such a read
+template <int NS>
+static bool flat_path(const Genome& g, const Params& p, const ReadView& v, Collect& c, uint32_t ordinal, int64_t& nw, int64_t& ni, int64_t& nr, int64_t& n_trivial) {
+    if (v.nseg > NS) return false;
+    uint32_t so[NS + 1];
+    Hit h[NS];
+    for (int s = 0; s <= NS; ++s) so[s] = v.so[s <= v.nseg ? s : v.nseg];
+    for (int s = 0; s < NS; ++s) {
+        if (so[s + 1] - so[s] > 1u) return false;
+        h[s] = Hit{0, 0, 0, 0};
+        if (so[s + 1] != so[s]) h[s] = v.hits[so[s]];
+    }
+    DecodeEmit em{g, p, v, c, ordinal};
+    const FlatResult res = flat_read<NS>(p, v.nseg, so, h, v.rl, v.n_mate, em);
+    nw += res.n_windows; ni += res.n_indels;
+    if (!res.rescue && res.n_windows + res.n_indels == 0) ++n_trivial;
+    if (res.rescue) {
+        if (v.n_mate > 2) {                       // more mate hits than the flat rescue takes: the general rescue, the indel pairs being done
+            ReadView w = v;
+            bool wants;
+            gaps_prepare(p, w, wants);
+            std::vector<int32_t> slots((size_t)2 * rv_count_raw(w, 0) * w.n_mate, SLOT_NONE);
+            const int n_left = rv_count_raw(w, 0);
+            for (int l = 0; l < n_left; ++l)
+                for (int m = 0; m < w.n_mate; ++m) {
+                    if (rescue_pair(g, p, w.rp, w.W, w.rl, w.hits[w.so[0] + l], w.mate[m], slots[2 * (l * w.n_mate + m)], slots[2 * (l * w.n_mate + m) + 1])) ++nr;
+                    if (slots[2 * (l * w.n_mate + m)] == SLOT_BREAK) break;
+                }
+            w.slots = slots.data(); w.rescue = true;
+            ExecSink sink{g, p, w, c, ordinal};
+            gaps_enumerate(p, w, sink);
+            nw += sink.n_windows;
+            return true;
+        }
+        Hit mh[2] = {Hit{0, 0, 0, 0}, Hit{0, 0, 0, 0}};
+        int32_t sc[4] = {SLOT_NONE, SLOT_NONE, SLOT_NONE, SLOT_NONE};
+        for (int m = 0; m < v.n_mate; ++m) {      // thj_k_sj_rescue_scan: every mate hit, whatever the left hit is
+            mh[m] = v.mate[m];
+            if (!rescue_scan(g, p, v.rp, v.W, v.rl, mh[m], sc[2 * m], sc[2 * m + 1]) && sc[2 * m] != SLOT_BREAK) sc[2 * m] = SLOT_UNSCANNED;
+        }
+        int w = 0;
+        nr += flat_rescue<2>(p, so[1] != so[0], h[0], res.size, v.rl, mh, v.n_mate, sc, em, w);
+        nw += w;
+    }
+    return true;
+}
+
 extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
                                 const int32_t* contig_len, int32_t n_contigs, const thj_seg_batch* b,
                                 thj_junction** juncs, int64_t* n_juncs, thj_junction** dels, int64_t* n_dels,
@@ -48,6 +112,7 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
     int64_t nw = 0, ni = 0, nr = 0, n_trivial = 0;
     const bool lazy = getenv("THJ_HOSTSIM_LAZY") != nullptr;        // exercise the on-the-fly rescue of rv_foreach
     const bool no_skip = getenv("THJ_HOSTSIM_NO_SKIP") != nullptr;  // run the general enumeration on every read
+    const bool no_flat = getenv("THJ_HOSTSIM_NO_FLAT") != nullptr;  // ... also on the reads with at most one hit per segment (the kernels give those to flat_read / flat_rescue)
     std::vector<int32_t> slots;
     for (int32_t r = 0; r < b->n_reads; ++r) {
         ReadView v;
@@ -63,7 +128,8 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
             v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]);
         }
         ExecSink sink{g, p, v, c, b->ordinal_base + (uint32_t)r};
-        if (!no_skip && read_is_trivial(p, v)) { ++n_trivial; continue; }      // what the kernel does: nothing can come out of this read
+        if (!no_flat && (v.nseg <= 4 ? flat_path<4>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial) : flat_path<8>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial))) continue;
+        if (!no_skip && read_is_trivial(p, v)) { ++n_trivial; continue; }      // nothing can come out of this read
         indels_enumerate(p, v, sink);
         bool wants;
         if (gaps_prepare(p, v, wants)) {

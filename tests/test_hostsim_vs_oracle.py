@@ -11,11 +11,15 @@ from util import CASES, assert_events_equal, case_batches
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "seed%d_%s_rl%d_L%d" % (c["seed"], "pe" if c["paired"] else "se", c["read_len"], c["seg_len"]))
-@pytest.mark.parametrize("variant", ["as_kernel", "lazy_rescue", "no_trivial_skip"])
+@pytest.mark.parametrize("variant", ["as_kernel", "general", "lazy_rescue", "no_trivial_skip"])
 def test_kernel_logic_matches_oracle(cfg, variant, monkeypatch):
-    # as_kernel: trivial reads are skipped up front (read_is_trivial), rescue slots precomputed
+    # as_kernel: reads with at most one hit per segment take flat_read / flat_rescue (thj_k_sj_flat, thj_k_sj_rescue_flat), the others
+    #            the general enumeration with precomputed rescue slots
+    # general: the general enumeration for every read that read_is_trivial does not drop (thj_k_sj_general)
     # lazy_rescue: rv_foreach computes rescue_pair on the fly (the kernel's fallback when its LDS slot buffer is full)
     # no_trivial_skip: the general enumeration on every read
+    if variant != "as_kernel":
+        monkeypatch.setenv("THJ_HOSTSIM_NO_FLAT", "1")
     if variant == "lazy_rescue":
         monkeypatch.setenv("THJ_HOSTSIM_LAZY", "1")
     if variant == "no_trivial_skip":
@@ -31,6 +35,7 @@ def test_kernel_logic_matches_oracle(cfg, variant, monkeypatch):
         e2 = sim.segjuncs(p, seqs, b)
         assert e1.stats["windows"] == e2.stats["windows"]
         assert e1.stats["indel_pairs"] == e2.stats["indel_pairs"]
+        assert e1.stats["rescue_pairs"] == e2.stats["rescue_pairs"]
         assert (e2.stats["trivial_reads"] > 0) == (variant != "no_trivial_skip")
         want = e1 if want is None else merge_events(want, e1)
         got = e2 if got is None else merge_events(got, e2)

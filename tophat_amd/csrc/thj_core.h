@@ -552,6 +552,16 @@ THJ_HD bool gaps_prepare(const Params& p, ReadView& v, bool& wants_rescue) {
     return true;
 }
 
+// ... for a read that is known to take the rescue (it was listed because gaps_prepare said so): everything but the partner search
+THJ_HD void gaps_prepare_listed(const Params& p, ReadView& v) {
+    v.rescue = false;
+    v.check_len = p.segment_length - p.segment_mismatches - 3;
+    if (v.check_len > 15) v.check_len = 15;
+    int last = v.nseg - 1;
+    while (last > 0 && rv_count_raw(v, last) == 0) --last;
+    v.size = last + 1;
+}
+
 // The same by a group of callers sharing one read (a wave: lane, 64): each takes every stride-th first-segment hit of the partner
 // search, `any` (called once by all of them) tells whether any found one.
 template <class Any>
@@ -661,6 +671,153 @@ THJ_HD bool read_is_trivial(const Params& p, const ReadView& v) {
     const int dist = anti ? h0.left - prev.right : prev.left - h0.right;
     if (dist >= p.min_segment_intron && dist < p.max_segment_intron) return true;
     return v.n_mate == 0;
+}
+
+// ---- reads with at most one hit per segment ("flat" reads) ------------------------------------------------------------------
+// Every read of a uniquely mapping sample is one: its hit lists are registers, not lists, and find_insertions_and_deletions
+// (:2807-2942), the head of find_gaps (:3304-3393) and its body (:3499-3617) become straight-line code in which every test of
+// the loops is one term of a predicate -- no list walk, no divergent loop, a bounded number of tasks (NS-2 indel pairs, NS-1
+// windows).  `emit.task(valid, a, b, c, d)` is called the same number of times by every caller (a wave ballots on `valid`);
+// the task words are those of the kernels' queues (QueueSink in thj_segjuncs.hip).  Hit indices are batch indices: with one hit
+// per segment the hit of segment s is so[s].  Must equal indels_enumerate + gaps_prepare + gaps_enumerate on such reads
+// (tests/hostsim runs both).  The mate-anchored rescue (res.rescue) is left to the caller; nothing of find_gaps is emitted then.
+struct FlatResult { bool rescue; int size; int n_windows, n_indels; };
+
+template <int NS, class Emit>
+THJ_HD FlatResult flat_read(const Params& p, int nseg, const uint32_t (&so)[NS + 1], const Hit (&h)[NS], int rl, int n_mate, Emit& emit) {
+    FlatResult res{false, 0, 0, 0};
+    const int L = p.segment_length;
+    uint32_t present = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) if (s < nseg && so[s + 1] != so[s]) present |= 1u << s;
+    // find_insertions_and_deletions: the pairs (i, i+1), i + 2 < nseg; an empty list or a start past the read ends the function
+    bool go = true;
+#pragma unroll
+    for (int i = 0; i + 2 < NS; ++i) {
+        const int start = i * L;
+        go = go && i + 2 < nseg && ((present >> i) & 3u) == 3u && start <= rl;
+        const int plen = rl - start < 2 * L ? rl - start : 2 * L;
+        const Hit lh = h[i], rh = h[i + 1];
+        const bool anti = hit_anti(lh);
+        const int apparent = anti ? lh.right - rh.left : rh.right - lh.left;
+        const int disc = apparent - plen;
+        const bool is_del = disc > 0 && disc <= p.max_deletion_length;
+        const bool is_ins = disc < 0 && disc >= -p.max_insertion_length;
+        const bool ok = go && lh.ref_id == rh.ref_id && anti == hit_anti(rh) && (is_del || is_ins);
+        emit.task(ok, (1u << 8) | (anti ? 1u << 9 : 0u) | (is_del ? 1u << 10 : 0u) | ((uint32_t)i << 11) | ((uint32_t)(plen & 255) << 14),
+                  anti ? so[i + 1] : so[i], anti ? so[i] : so[i + 1], 0u);
+        res.n_indels += ok ? 1 : 0;
+    }
+    // the head of find_gaps: trailing-empty trim, the single-segment return, the partner test of first against last segment
+    int last = 0;
+    Hit hl = h[0];
+#pragma unroll
+    for (int s = 1; s < NS; ++s) if ((present >> s) & 1u) { last = s; hl = h[s]; }
+    res.size = last + 1;
+    bool run = nseg > 0;
+    if (last == 0) run = run && (present & 1u) && !hit_end(h[0]);
+    bool check_partner = true;
+    if (last != 0 && (present & 1u) && h[0].ref_id == hl.ref_id && hit_anti(h[0]) == hit_anti(hl)) {
+        const int dist = hit_anti(h[0]) ? h[0].left - hl.right : hl.left - h[0].right;
+        if (dist >= p.min_segment_intron && dist < p.max_segment_intron) check_partner = false;
+    }
+    res.rescue = run && check_partner && n_mate > 0;
+    bool en = run && !res.rescue;
+    if (p.bowtie2 && present != 0 && 1 > p.max_seg_multihits) en = false;        // :3499-3506
+    // the body: segment s against s+1 (an abutting hit ends it, one at intron distance gives a 16-base window) and s+2 (L+16 bases)
+#pragma unroll
+    for (int s = 0; s + 1 < NS; ++s) {
+        const bool has = en && s != last && ((present >> s) & 1u);
+        const Hit bh = h[s];
+        const bool banti = hit_anti(bh);
+        const Hit rh = h[s + 1];
+        const bool c1 = ((present >> (s + 1)) & 1u) && banti == hit_anti(rh) && bh.ref_id == rh.ref_id;
+        const bool abut = banti ? rh.right == bh.left : bh.right == rh.left;
+        const int d1 = banti ? bh.left - rh.right : rh.left - bh.right;
+        const bool found = c1 && abut;
+        const bool drs = c1 && !abut && d1 >= p.min_segment_intron && d1 < p.max_segment_intron;
+        bool rrs = false;
+        Hit d = rh;
+        if (s + 2 < NS) {
+            const Hit rrh = h[s + 2];
+            const bool c2 = ((present >> (s + 2)) & 1u) && banti == hit_anti(rrh) && bh.ref_id == rrh.ref_id;
+            const int d2 = banti ? bh.left - rrh.right : rrh.left - bh.right;
+            rrs = !found && c2 && d2 >= p.min_segment_intron + L && d2 < p.max_segment_intron + L;
+            if (rrs) d = rrh;
+        }
+        const int start = (s + 1) * L - 8;                                      // :3583-3586
+        int slen = rrs ? L + 16 : 16;
+        if (slen > rl - start) slen = rl - start;
+        int32_t wl, wr;
+        if (!banti) { wl = bh.right - 8; if (wl < 0) wl = 0; wr = d.left + 8; }   // :3589-3594
+        else { wl = d.right - 8; wr = bh.left + 8; }                              // :3596-3604
+        const bool ok = has && !found && (drs || rrs) && start >= 0 && slen >= 0;
+        emit.task(ok, (banti ? 1u << 9 : 0u) | ((uint32_t)(start & 255) << 10) | ((uint32_t)(slen & 127) << 18), bh.ref_id, (uint32_t)wl, (uint32_t)wr);
+        res.n_windows += ok ? 1 : 0;
+    }
+    return res;
+}
+
+// The mate-anchored rescue (:3330-3497) of a flat read whose mate has at most MAXM hits, after the flank scans: `sc` holds what
+// rescue_scan left for each mate hit (fwd, rev; fwd == SLOT_UNSCANNED where it returned false without asking for the break).
+// The pseudo-hits stand in the read's last kept segment (size - 1) and every segment between is cleared, so only the first
+// segment's hit bh can see them: as its s+1 list (size 2, 16-base windows, an abutting pseudo-hit ends it) or as its s+2 list
+// (size 3, L+16 bases).  Returns the number of scanned pairs (the rescue-pair statistic).  Must equal gaps_enumerate on the
+// rescue view (rv_foreach) for such reads.
+enum { SLOT_UNSCANNED = -3 };
+template <int MAXM, class Emit>
+THJ_HD int flat_rescue(const Params& p, bool has0, const Hit& bh, int size, int rl, const Hit (&mh)[MAXM], int n_mate,
+                       const int32_t (&sc)[2 * MAXM], Emit& emit, int& n_windows) {
+    const int L = p.segment_length;
+    int cl = L - p.segment_mismatches - 3;
+    if (cl > 15) cl = 15;
+    const bool banti = hit_anti(bh);
+    bool alive = has0;
+    int pairs = 0, n_pseudo = 0;
+    int32_t pl[2 * MAXM];
+    bool pv[2 * MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+        const bool compat = alive && m < n_mate && bh.ref_id == mh[m].ref_id && banti != hit_anti(mh[m]);     // :3414
+        const int32_t f = compat ? sc[2 * m] : SLOT_NONE, rv = compat ? sc[2 * m + 1] : SLOT_NONE;
+        if (compat && f == SLOT_BREAK) alive = false;                             // the reference leaves the mate loop (:3431-3450)
+        pairs += (compat && f != SLOT_BREAK && f != SLOT_UNSCANNED) ? 1 : 0;
+        pv[2 * m] = compat && alive && f >= 0; pl[2 * m] = f;
+        pv[2 * m + 1] = compat && alive && rv >= 0; pl[2 * m + 1] = rv;
+        n_pseudo += (pv[2 * m] ? 1 : 0) + (pv[2 * m + 1] ? 1 : 0);
+    }
+    bool en = has0 && (size == 2 || size == 3);
+    if (p.bowtie2 && (1 > p.max_seg_multihits || n_pseudo > p.max_seg_multihits)) en = false;
+    const bool far = size == 3;
+    const int lo = p.min_segment_intron + (far ? L : 0), hi = p.max_segment_intron + (far ? L : 0);
+    bool found = false, inr[2 * MAXM];
+    int n = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * MAXM; ++k) {
+        const bool panti = (k & 1) != 0;                                          // fwd pseudo-hit: sense, rev: antisense
+        const bool c = pv[k] && banti == panti;
+        const int32_t pleft = pl[k], pright = pl[k] + cl;
+        const bool abut = banti ? pright == bh.left : bh.right == pleft;
+        if (c && abut && !far) found = true;
+        const int dist = banti ? bh.left - pright : pleft - bh.right;
+        inr[k] = c && dist >= lo && dist < hi;
+        n += inr[k] ? 1 : 0;
+    }
+    const int start = L - 8;
+    int slen = far ? L + 16 : 16;
+    if (slen > rl - start) slen = rl - start;
+    const bool ok_all = en && !found && n > 0 && start >= 0 && slen >= 0;
+#pragma unroll
+    for (int k = 0; k < 2 * MAXM; ++k) {
+        const int32_t pleft = pl[k], pright = pl[k] + cl;
+        int32_t wl, wr;
+        if (!banti) { wl = bh.right - 8; if (wl < 0) wl = 0; wr = pleft + 8; }
+        else { wl = pright - 8; wr = bh.left + 8; }
+        const bool ok = ok_all && inr[k];
+        emit.task(ok, (banti ? 1u << 9 : 0u) | ((uint32_t)(start & 255) << 10) | ((uint32_t)(slen & 127) << 18), bh.ref_id, (uint32_t)wl, (uint32_t)wr);
+        n_windows += ok ? 1 : 0;
+    }
+    return pairs;
 }
 
 // The body of find_gaps after the rescue (segment_juncs.cpp:3499-3617).

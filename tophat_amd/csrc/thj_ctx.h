@@ -54,6 +54,7 @@ struct thj_ctx {
     uint8_t* d_fus_ignore = nullptr; int64_t n_fus_ignore = 0;            // --fusion-ignore-chromosomes flags per ref id
     uint32_t* d_rescue_list = nullptr; int64_t rescue_list_cap = 0;      // reads taking the mate-anchored rescue + per-workgroup counts
     uint32_t* d_many = nullptr;                                            // reads with many hits of a launch (thj_k_segjuncs_shared): count, list
+    void* d_sj_lists = nullptr; size_t sj_lists_cap = 0;                  // the flat kernels' task / rescue / general-read lists (thj_k_sj_flat)
     int32_t* d_rescue_slots = nullptr;                                    // rescue outcomes of reads with many hits (thj_k_segjuncs_rescue)
     // long_spanning_reads (thj_span.hip)
     uint32_t* d_junc_bucket = nullptr; int64_t n_junc_buckets = 0;     // coarse index over d_span_junc (junc_range)

@@ -137,7 +137,6 @@ __device__ __forceinline__ ReadView make_view(const DevBatch& b, int r) {
 
 static constexpr int TPB = 256;
 static constexpr int QCAP = 512;           // task queue entries (LDS); a typical tile of 256 reads adds a few dozen
-static constexpr int HEAVY_HITS = 12;      // a read with more hits than this is done by a wave (thj_k_segjuncs_shared), not by a thread
 static constexpr int MANY_CAP = 1 << 20;   // such reads of one launch that can be listed (the rest stay with their threads)
 static constexpr int MANY_HITS_LDS = 256;  // hits of such a read staged in LDS (more: read from HBM)
 
@@ -200,9 +199,9 @@ template <bool WIDE>
 __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, const DevBatch& b, EventSink& ev, const TaskQueue& q, bool flush) {
     const int tid = threadIdx.x;
     const unsigned int have = *q.n;
-    const unsigned int keep = flush ? 0u : have % (unsigned)TPB;
+    const unsigned int keep = flush ? 0u : have % blockDim.x;
     if (have - keep > 0 && !THJ_EXPF(1 << 16)) {
-        for (unsigned int k = keep + tid; k < have; k += TPB) {
+        for (unsigned int k = keep + tid; k < have; k += blockDim.x) {
             const uint32_t a = q.a[k];
             const int tr = (int)q.e[k];
             ReadView tv = make_task_view(b, tr);
@@ -227,112 +226,327 @@ __device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, cons
 // so the main kernel only lists them -- per workgroup, in its own slice of `list`, no global append counter -- and
 // thj_k_segjuncs_rescue handles them densely afterwards.
 struct RescueList { uint32_t* list; unsigned int* blk_cnt; int seg_cap; int32_t* slot_pool; unsigned int* heavy_count; uint32_t* heavy_list;
-                    unsigned int* many_count; uint32_t* many_list; int own_slice; int many_min; };    // many_*: reads with many hits, for thj_k_segjuncs_shared; own_slice: its slice of `list`
+                    unsigned int* many_count; uint32_t* many_list; int own_slice; int many_min; int mid_min; };    // many_*: reads with many hits, for thj_k_segjuncs_shared; own_slice: its slice of `list`
 
-// Main kernel.  One workgroup walks tiles of 256 consecutive reads.
-//   stage:     find_gaps / find_insertions_and_deletions walk a read's hit lists over and over with dependent loads;
-//              from HBM that is a dozen round trips per read, so a tile's CSR offsets and its (contiguous) hits are
-//              first copied to LDS with two coalesced sweeps and the per-read logic runs on the LDS copy.
-//   classify:  most reads are unspliced (read_is_trivial) and are dropped here; rescue reads go to the rescue list,
-//              the rest to a dense work list.
-//   enumerate: the general enumeration over the work list only; windows and indel pairs are queued as tasks.
-//   execute:   run_tasks.
-// Dynamic LDS: 5 x QCAP queue words | TPB*nseg+1 offsets | hit_cap hits | work list.
-// WIDE: segment_length > 32 (128-bit read pieces; see thj_core.h)
-template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, DevBatch b, Tables t, RescueList rl, int hit_cap) {
-    extern __shared__ uint4 dyn_lds[];
-    uint32_t* q_a = (uint32_t*)dyn_lds;
-    uint32_t* q_b = q_a + QCAP; uint32_t* q_c = q_b + QCAP; uint32_t* q_d = q_c + QCAP; uint32_t* q_e = q_d + QCAP;
-    uint32_t* s_so = q_e + QCAP;
-    uint4* s_hits = (uint4*)(s_so + ((TPB * b.nseg + 1 + 3) & ~3));
-    uint32_t* s_work = (uint32_t*)(s_hits + hit_cap);
-    __shared__ unsigned int q_n, s_nwork, s_nresc;
-    __shared__ unsigned int s_stat[4];
-    const int tid = threadIdx.x;
-    if (tid < 4) s_stat[tid] = 0;
-    if (tid == 0) { q_n = 0; s_nresc = 0; }
-    EventSink ev{g, t};
-    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
-    unsigned int my_hits = 0, my_windows = 0, my_indels = 0;     // statistics: per thread, added to LDS once at the end
+// Stage 1 since round 4: a pipeline of dense kernels instead of one kernel that does everything for a tile of reads.
+//   thj_k_sj_flat         every read.  A read with at most one hit per segment ("flat": every read of a uniquely mapping sample) is
+//                         finished here -- its hits in registers, find_insertions_and_deletions and find_gaps as straight-line code
+//                         (flat_read), its indel pairs and windows written as tasks to HBM; if it takes the mate-anchored rescue it is
+//                         listed with one scan pair per mate hit.  Other reads are only listed: for thj_k_sj_general, or (many
+//                         hits) for thj_k_segjuncs_shared.
+//   thj_k_sj_general      the listed reads (a few hits a segment), one thread each, the read's hits staged in its own piece of LDS;
+//                         the general enumeration, LDS task queue and execution as before.
+//   thj_k_segjuncs_shared the reads with many hits, a wave each.
+//   thj_k_sj_rescue_scan  one thread per (flat rescue read, mate hit): where the read's last bases lie in the mate hit's flank.
+//   thj_k_sj_rescue_flat  one thread per flat rescue read: the pseudo-hits against its first-segment hit (flat_rescue) -> tasks.
+//   thj_k_segjuncs_rescue(_shared)  the other rescue reads (several hits in the first segment or more than two mate hits).
+//   thj_k_sj_tasks        one thread per task of the flat kernels: the two window ends + the support read, or the indel pair.
+// Every list is a slice per workgroup of thj_k_sj_flat (no global append counter, the position is an LDS counter; a slice holds
+// what the reads its workgroup visits can give at the most, so nothing overflows) and the consumer's workgroup w takes slice w.
+struct SjLists {
+    uint4* tq; uint32_t* te; unsigned int* task_cnt; int task_cap;     // tasks: words a..d, the read; task_cap entries per slice
+    uint32_t* frl; unsigned int* frl_cnt;                              // flat rescue reads: read | (size - 1) << 29; seg_cap per slice
+    uint32_t* pairs; unsigned int* pair_cnt;                           // their scan pairs: slot in the slice << 1 | mate hit; 2 seg_cap per slice
+    int2* scan;                                                        // [(slice * seg_cap + slot) * 2 + mate hit] = rescue_scan's fwd, rev
+    uint32_t* gen; unsigned int* gen_cnt;                              // reads for thj_k_sj_general: read | class << 29; seg_cap per slice
+    unsigned int* mid_count; uint32_t* mid_list;                       // the second instance's reads (one list, filled by the first)
+};
+static constexpr int FLAT_MATES = 2;       // mate hits a flat rescue read can have (more: the general rescue kernel)
+static constexpr uint32_t GEN_READ = (1u << 29) - 1;       // in the general list: the read; above it the class -- 0: at most GEN_HITS hits, 1: up to
+                                                           // MID_HITS, 2: more (thj_k_segjuncs_shared)
+
+// one task per call and lane at the most, in converged code: a ballot, one LDS add per wave, the tasks written side by side
+struct FlatEmit {
+    uint4* tq; uint32_t* te; unsigned int* n; unsigned long long below; uint32_t read;
+    __device__ __forceinline__ void task(bool ok, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+        const unsigned long long m = __ballot(ok);
+        if (m == 0) return;
+        unsigned int base = 0;
+        if ((threadIdx.x & 63) == 0) base = atomicAdd(n, (unsigned int)__popcll(m));
+        base = (unsigned int)__shfl((int)base, 0);
+        if (ok) { const unsigned int k = base + (unsigned int)__popcll(m & below); tq[k] = make_uint4(a, b, c, d); te[k] = read; }
+    }
+};
+// position of a lane's entry in a list kept by an LDS (or global) counter: one add per wave
+__device__ __forceinline__ unsigned int wave_slot(bool want, unsigned int* counter, unsigned long long below) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return 0u;
+    unsigned int base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(counter, (unsigned int)__popcll(m));
+    base = (unsigned int)__shfl((int)base, 0);
+    return base + (unsigned int)__popcll(m & below);
+}
+
+template <int NS>
+__global__ __launch_bounds__(TPB, 4) void thj_k_sj_flat(Params p, DevBatch b, RescueList rl, SjLists sl, unsigned long long* cnt) {
+    __shared__ unsigned int s_n[4];          // this workgroup's tasks, flat rescue reads, scan pairs, general reads
+    __shared__ unsigned int s_stat[3];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 4) s_n[tid] = 0;
+    if (tid < 3) s_stat[tid] = 0;
+    __syncthreads();
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const size_t slice = (size_t)blockIdx.x * rl.seg_cap;
+    uint4* const tq = sl.tq + (size_t)blockIdx.x * sl.task_cap;
+    uint32_t* const te = sl.te + (size_t)blockIdx.x * sl.task_cap;
+    const int nseg = b.nseg;
+    unsigned int my_hits = 0, my_windows = 0, my_indels = 0;
     const int n_tiles = (b.n_reads + TPB - 1) / TPB;
-    // consecutive tiles go to consecutive workgroups (-> different XCDs): every XCD's L2
-    // streams its own contiguous slices of the hit array, the genome lines are shared by L3.
+    // consecutive tiles go to consecutive workgroups (-> different XCDs): every XCD's L2 streams its own slices of the hit array
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        // ---- stage this tile's offsets and hits
-        const int r0 = tile * TPB;
-        const int tile_reads = b.n_reads - r0 < TPB ? b.n_reads - r0 : TPB;
-        const int n_so = tile_reads * b.nseg + 1;
-        __syncthreads();                                  // the previous tile's readers are done with the LDS copy
-        for (int i = tid; i < n_so; i += TPB) s_so[i] = b.seg_off[(size_t)r0 * b.nseg + i];
-        if (tid == 0) s_nwork = 0;
-        __syncthreads();
-        const unsigned int q_before = q_n;               // tasks carried over from earlier tiles
-        const uint32_t h0 = s_so[0], nh_tile = s_so[n_so - 1] - h0;
-        const bool staged = nh_tile <= (uint32_t)hit_cap;
-        __syncthreads();
-        if (staged) {                                     // offsets become indices into the LDS copy
-            for (int i = tid; i < n_so; i += TPB) s_so[i] -= h0;
-            for (uint32_t i = tid; i < nh_tile; i += TPB) s_hits[i] = ((const uint4*)b.hits)[h0 + i];
-        }
-        __syncthreads();
-        const Hit* tile_hits = staged ? (const Hit*)s_hits : b.hits;
-        if (THJ_EXPF(1 << 20)) continue;
-        // ---- classify
-        bool to_work = false, to_rescue = false;
-        if (tid < tile_reads) {
-            ReadView v = make_view(b, r0 + tid);
-            v.so = s_so + tid * b.nseg;
-            v.hits = tile_hits;
-            my_hits += v.so[v.nseg] - v.so[0];                // summed per thread, one LDS add at the end of the kernel
-            if (!read_is_trivial(p, v)) {
-                bool wants = false;
-                // a read with many hits (multihits: tens a segment) is not even classified here -- its partner search alone is a
-                // 40 x 40 loop -- but listed for thj_k_segjuncs_shared, which gives it a wave
-                unsigned int mk = 0;
-                bool many = v.so[v.nseg] - v.so[0] > (uint32_t)rl.many_min && !THJ_EXPF(1 << 24);
-                if (many) { mk = atomicAdd(rl.many_count, 1u); many = mk < (unsigned int)MANY_CAP; }
-                if (many) rl.many_list[mk] = (uint32_t)(r0 + tid);
-                else if (!THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants) && wants) to_rescue = true;
-                else to_work = true;
+        const int r = tile * TPB + tid;
+        const bool active = r < b.n_reads;
+        uint32_t so[NS + 1];
+#pragma unroll
+        for (int k = 0; k <= NS; ++k) so[k] = 0;
+        if (active) {
+            const uint32_t* o = b.seg_off + (size_t)r * nseg;
+            if (NS == 4 && nseg == 4) { const uint4 q = *(const uint4*)o; so[0] = q.x; so[1] = q.y; so[2] = q.z; so[3] = q.w; so[4] = o[4]; }
+            else {
+#pragma unroll
+                for (int k = 0; k <= NS; ++k) so[k] = o[k <= nseg ? k : nseg];
             }
         }
-        {   // positions in the work list / the rescue slice: one LDS atomic per wave and list, not one per read (a third of the
-            // lanes would otherwise queue on the same LDS address)
-            const unsigned long long mw = __ballot(to_work), mr = __ballot(to_rescue);
-            const int lane = tid & 63;
-            const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-            unsigned int bw = 0, br = 0;
-            if (lane == 0) { if (mw) bw = atomicAdd(&s_nwork, (unsigned int)__popcll(mw)); if (mr) br = atomicAdd(&s_nresc, (unsigned int)__popcll(mr)); }
-            bw = __shfl(bw, 0); br = __shfl(br, 0);
-            if (to_work) s_work[bw + (unsigned int)__popcll(mw & below)] = (uint32_t)tid;
-            if (to_rescue) rl.list[(size_t)blockIdx.x * rl.seg_cap + br + (unsigned int)__popcll(mr & below)] = (uint32_t)(r0 + tid);
+        const uint32_t nh = so[NS] - so[0];
+        int n_mate = 0;
+        if (active && b.mate_off) n_mate = (int)(b.mate_off[r + 1] - b.mate_off[r]);
+        // flat: at most one hit per segment, and no more mate hits than the flat rescue takes (a read with more is rare and goes
+        // the general way whether it takes the rescue or not)
+        bool single = n_mate <= FLAT_MATES;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) single = single && so[s + 1] - so[s] <= 1u;
+        my_hits += nh;
+        const bool is_flat = active && single && nh > 0;
+        // the reads that are not flat: listed for the kernel that takes them
+        {   // (a global list here would be one global atomic per wave and tile on one address: 65 k of them in a launch of the mix held
+            // this kernel for 0.4 ms -- they are served one after the other, 6 ns each; thj_k_sj_general moves the reads with many
+            // hits to thj_k_segjuncs_shared's list with one add per workgroup and round)
+            const bool gen = active && !single;
+            const unsigned int gk = wave_slot(gen, &s_n[3], below);
+            if (gen) sl.gen[slice + gk] = (uint32_t)r | (nh > (uint32_t)rl.many_min ? 2u << 29 : nh > (uint32_t)rl.mid_min ? 1u << 29 : 0u);
         }
-        __syncthreads();
-        if (THJ_EXPF(1 << 21)) continue;
-        // ---- enumerate (work list)
-        const bool active = (unsigned)tid < s_nwork;
-        ReadView v;
-        bool do_gaps = false;
-        int r = 0;
+        Hit h[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            uint4 q = make_uint4(0, 0, 0, 0);
+            if (is_flat && so[s + 1] != so[s]) q = ((const uint4*)b.hits)[so[s]];
+            h[s].ref_id = q.x; h[s].left = (int32_t)q.y; h[s].right = (int32_t)q.z; h[s].meta = q.w;
+        }
+        int rlen = 0;
+        if (is_flat) rlen = b.read_len[r];
+        FlatEmit em{tq, te, &s_n[0], below, (uint32_t)r};
+        const FlatResult res = flat_read<NS>(p, is_flat ? nseg : 0, so, h, rlen, n_mate, em);
+        my_windows += (unsigned int)res.n_windows; my_indels += (unsigned int)res.n_indels;
+        // the mate-anchored rescue: a read without a hit in its first segment has no pair to scan and nothing to enumerate
+        const bool resc_flat = res.rescue && so[1] != so[0];
+        const unsigned int fk = wave_slot(resc_flat, &s_n[1], below);
+        if (resc_flat) sl.frl[slice + fk] = (uint32_t)r | ((uint32_t)(res.size - 1) << 29);
+#pragma unroll
+        for (int m = 0; m < FLAT_MATES; ++m) {
+            const bool want = resc_flat && m < n_mate;
+            const unsigned int pk = wave_slot(want, &s_n[2], below);
+            if (want) sl.pairs[slice * FLAT_MATES + pk] = (fk << 1) | (uint32_t)m;
+        }
+    }
+    if (my_hits) atomicAdd(&s_stat[2], my_hits);
+    if (my_windows) atomicAdd(&s_stat[0], my_windows);
+    if (my_indels) atomicAdd(&s_stat[1], my_indels);
+    __syncthreads();
+    if (tid == 0) {
+        sl.task_cnt[blockIdx.x] = s_n[0]; sl.frl_cnt[blockIdx.x] = s_n[1]; sl.pair_cnt[blockIdx.x] = s_n[2]; sl.gen_cnt[blockIdx.x] = s_n[3];
+        rl.blk_cnt[blockIdx.x] = 0;
+        if (s_stat[0]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd(&cnt[CNT_HITS], (unsigned long long)s_stat[2]);
+    }
+}
+
+// The tasks of the flat kernels, one thread each (run_tasks' body without a queue around it): workgroup w takes slice w.
+template <bool WIDE>
+__global__ __launch_bounds__(TPB) void thj_k_sj_tasks(Genome g, Params p, DevBatch b, Tables t, SjLists sl) {
+    const unsigned int n = sl.task_cnt[blockIdx.x];
+    const uint4* tq = sl.tq + (size_t)blockIdx.x * sl.task_cap;
+    const uint32_t* te = sl.te + (size_t)blockIdx.x * sl.task_cap;
+    EventSink ev{g, t};
+    for (unsigned int k = threadIdx.x; k < n; k += TPB) {
+        const uint4 q = tq[k];
+        const int tr = (int)te[k];
+        ReadView tv = make_task_view(b, tr);
+        const uint32_t a = q.x;
+        const bool anti = (a >> 9) & 1u;
+        if (a & (1u << 8)) {
+            const bool is_del = (a >> 10) & 1u;
+            const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
+            indel_exec<WIDE>(g, p, tv, i, q.y, q.z, anti, plen, is_del,
+                       ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(q.w & 0xFFFF), (int)(q.w >> 16)), ev);
+        } else {
+            const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
+            window_exec<WIDE>(g, p, tv, q.y, (int32_t)q.z, (int32_t)q.w, anti, start, slen, ev);
+        }
+    }
+}
+
+// One thread per (flat rescue read, mate hit): rescue_scan, whatever the left hit is (it is the same scan for every left hit;
+// thj_k_sj_rescue_flat applies the left hit's contig / strand test).
+__global__ __launch_bounds__(TPB) void thj_k_sj_rescue_scan(Genome g, Params p, DevBatch b, SjLists sl, int seg_cap) {
+    const unsigned int n = sl.pair_cnt[blockIdx.x];
+    const size_t slice = (size_t)blockIdx.x * seg_cap;
+    for (unsigned int k = threadIdx.x; k < n; k += TPB) {
+        const uint32_t e = sl.pairs[slice * FLAT_MATES + k];
+        const uint32_t slot = e >> 1, m = e & 1u;
+        const int r = (int)(sl.frl[slice + slot] & 0x1FFFFFFFu);
+        const uint4 q = ((const uint4*)b.mate_hits)[b.mate_off[r] + m];
+        Hit rh; rh.ref_id = q.x; rh.left = (int32_t)q.y; rh.right = (int32_t)q.z; rh.meta = q.w;
+        int32_t f, rv;
+        const bool scanned = rescue_scan(g, p, b.planes + (size_t)r * 3 * b.W, b.W, (int)b.read_len[r], rh, f, rv);
+        if (!scanned && f != SLOT_BREAK) f = SLOT_UNSCANNED;
+        sl.scan[(slice + slot) * FLAT_MATES + m] = make_int2(f, rv);
+    }
+}
+
+// One thread per flat rescue read: its first-segment hit against the pseudo-hits of its (at most two) mate hits -> window tasks,
+// appended to the slice thj_k_sj_flat's workgroup w filled (thj_k_sj_tasks runs after this kernel).
+__global__ __launch_bounds__(TPB) void thj_k_sj_rescue_flat(Params p, DevBatch b, SjLists sl, int seg_cap, unsigned long long* cnt) {
+    __shared__ unsigned int s_ntask, s_stat[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned int n = sl.frl_cnt[blockIdx.x];
+    if (tid == 0) { s_ntask = sl.task_cnt[blockIdx.x]; s_stat[0] = 0; s_stat[1] = 0; }
+    __syncthreads();
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const size_t slice = (size_t)blockIdx.x * seg_cap;
+    unsigned int my_pairs = 0, my_windows = 0;
+    for (unsigned int k0 = 0; k0 < n; k0 += TPB) {
+        const unsigned int k = k0 + (unsigned int)tid;
+        const bool active = k < n;
+        int r = 0, size = 0, n_mate = 0, rlen = 0;
+        Hit bh{0, 0, 0, 0}, mh[FLAT_MATES];
+        int32_t sc[2 * FLAT_MATES];
+#pragma unroll
+        for (int m = 0; m < FLAT_MATES; ++m) { mh[m] = Hit{0, 0, 0, 0}; sc[2 * m] = SLOT_NONE; sc[2 * m + 1] = SLOT_NONE; }
         if (active) {
-            const int lr = (int)s_work[tid];
-            r = r0 + lr;
+            const uint32_t e = sl.frl[slice + k];
+            r = (int)(e & 0x1FFFFFFFu); size = (int)(e >> 29) + 1;
+            const uint4 q = ((const uint4*)b.hits)[b.seg_off[(size_t)r * b.nseg]];
+            bh.ref_id = q.x; bh.left = (int32_t)q.y; bh.right = (int32_t)q.z; bh.meta = q.w;
+            rlen = b.read_len[r];
+            const uint32_t m0 = b.mate_off[r];
+            n_mate = (int)(b.mate_off[r + 1] - m0);
+#pragma unroll
+            for (int m = 0; m < FLAT_MATES; ++m)
+                if (m < n_mate) {
+                    const uint4 w = ((const uint4*)b.mate_hits)[m0 + m];
+                    mh[m].ref_id = w.x; mh[m].left = (int32_t)w.y; mh[m].right = (int32_t)w.z; mh[m].meta = w.w;
+                    const int2 o = sl.scan[(slice + k) * FLAT_MATES + m];
+                    sc[2 * m] = o.x; sc[2 * m + 1] = o.y;
+                }
+        }
+        FlatEmit em{sl.tq + (size_t)blockIdx.x * sl.task_cap, sl.te + (size_t)blockIdx.x * sl.task_cap, &s_ntask, below, (uint32_t)r};
+        int nw = 0;
+        my_pairs += (unsigned int)flat_rescue<FLAT_MATES>(p, active, bh, size, rlen, mh, n_mate, sc, em, nw);
+        my_windows += (unsigned int)nw;
+    }
+    if (my_pairs) atomicAdd(&s_stat[0], my_pairs);
+    if (my_windows) atomicAdd(&s_stat[1], my_windows);
+    __syncthreads();
+    if (tid == 0) {
+        sl.task_cnt[blockIdx.x] = s_ntask;
+        if (s_stat[0]) atomicAdd(&cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[1]);
+    }
+}
+
+// The listed reads that are not flat: one thread per read, the read's offsets and hits copied to the thread's own piece of LDS with
+// independent loads, so that the list walks of the general enumeration (dozens of dependent round trips from HBM) run on LDS.
+// Two instances: SLICED (256 threads, reads of at most GEN_HITS hits) takes the slices thj_k_sj_flat filled and hands the reads
+// with more hits on -- up to MID_HITS to the second instance's list (64 threads a workgroup, the same thing with more LDS per
+// thread: a read with eight hits a segment costs a thread 40 us of LDS walks, but 64 of them run side by side; given a wave each
+// in thj_k_segjuncs_shared they cost 25 us apiece, most of it the wave's own chain of global loads), beyond that to
+// thj_k_segjuncs_shared's, one global add per workgroup, round and list.  Rescue reads go on to thj_k_segjuncs_rescue; windows and
+// indel pairs are queued in LDS and executed in whole rounds as before.
+static constexpr int GEN_HITS = 12;        // hits of a read the first instance stages
+static constexpr int MID_HITS = 32;        // ... the second (more: thj_k_segjuncs_shared, or rl.many_min if that is smaller)
+static constexpr int MID_T = 64;
+static constexpr int MID_GRID = 2048;
+template <bool WIDE, int HITS, int T, bool SLICED>
+__global__ __launch_bounds__(T) void thj_k_sj_general(Genome g, Params p, DevBatch b, Tables t, RescueList rl, SjLists sl) {
+    constexpr int STRIDE = HITS + 1;       // uint4 per thread (an odd count: the threads of a wave spread over the banks)
+    __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
+    __shared__ uint4 s_hits[T * STRIDE];
+    __shared__ uint32_t s_so[T * 9];
+    __shared__ unsigned int q_n, s_nresc, s_nlist[2], s_base[3];
+    __shared__ unsigned int s_stat[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < 4) s_stat[tid] = 0;
+    if (tid == 0) { q_n = 0; s_nresc = 0; }
+    __syncthreads();
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    EventSink ev{g, t};
+    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const unsigned int n = SLICED ? sl.gen_cnt[blockIdx.x] : (*sl.mid_count < (unsigned int)MANY_CAP ? *sl.mid_count : (unsigned int)MANY_CAP);
+    const uint32_t* list = SLICED ? sl.gen + (size_t)blockIdx.x * rl.seg_cap : sl.mid_list;
+    const unsigned int first = SLICED ? 0u : blockIdx.x * T, step = SLICED ? (unsigned int)T : gridDim.x * T;
+    unsigned int my_windows = 0, my_indels = 0;
+    for (unsigned int k0 = first; k0 < n; k0 += step) {
+        __syncthreads();
+        const unsigned int q_before = q_n;
+        const unsigned int k = k0 + (unsigned int)tid;
+        bool active = k < n;
+        ReadView v;
+        bool do_gaps = false, to_rescue = false;
+        int r = 0;
+        uint32_t hbase = 0;
+        const uint32_t e = active ? list[k] : 0u;
+        r = (int)(e & GEN_READ);
+        if (SLICED) {   // the reads with more hits go on: one global add per workgroup, round and list
+            const bool mid = active && (e >> 29) == 1u, many = active && (e >> 29) == 2u;
+            if (tid < 2) s_nlist[tid] = 0;
+            __syncthreads();
+            const unsigned int dk = wave_slot(mid, &s_nlist[0], below), mk = wave_slot(many, &s_nlist[1], below);
+            __syncthreads();
+            if (tid == 0 && s_nlist[0]) s_base[0] = atomicAdd(sl.mid_count, s_nlist[0]);
+            if (tid == 64 && s_nlist[1]) s_base[1] = atomicAdd(rl.many_count, s_nlist[1]);
+            __syncthreads();
+            if (mid && s_base[0] + dk < (unsigned int)MANY_CAP) { sl.mid_list[s_base[0] + dk] = (uint32_t)r; active = false; }
+            if (many && s_base[1] + mk < (unsigned int)MANY_CAP) { rl.many_list[s_base[1] + mk] = (uint32_t)r; active = false; }
+        }
+        if (active) {
             v = make_view(b, r);
-            v.so = s_so + lr * b.nseg;
-            v.hits = tile_hits;
-            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, staged ? h0 : 0u, 0u, 0u};
-            if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs);
+            const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
+            if (nh <= (uint32_t)HITS) {              // (a read a full list left here has more: it walks its hits in HBM)
+                for (int i = 0; i <= v.nseg; ++i) s_so[tid * 9 + i] = v.so[i] - h0;
+                for (uint32_t i = 0; i < nh; ++i) s_hits[tid * STRIDE + i] = ((const uint4*)b.hits)[h0 + i];
+                v.so = s_so + tid * 9; v.hits = (const Hit*)(s_hits + tid * STRIDE); hbase = h0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the copy is read back as Hit records
+        if (active) {
             bool wants = false;
             do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants);
-            if (do_gaps) gaps_enumerate(p, v, qs);
-            my_windows += qs.n_windows; my_indels += qs.n_indels;
+            to_rescue = do_gaps && wants;
+            if (!to_rescue) {
+                QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, hbase, 0u, 0u};
+                if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs);
+                if (do_gaps) gaps_enumerate(p, v, qs);
+                my_windows += qs.n_windows; my_indels += qs.n_indels;
+            }
+        }
+        if (SLICED) {        // rescue reads: the slice of the same number (thj_k_sj_flat left it empty)
+            const unsigned int rk = wave_slot(to_rescue, &s_nresc, below);
+            if (to_rescue) rl.list[(size_t)blockIdx.x * rl.seg_cap + rk] = (uint32_t)r;
+        } else {             // ... thj_k_segjuncs_shared's slice, a range of it per round
+            if (tid == 0) s_nresc = 0;
+            __syncthreads();
+            const unsigned int rk = wave_slot(to_rescue, &s_nresc, below);
+            __syncthreads();
+            if (tid == 0 && s_nresc) s_base[2] = atomicAdd(&rl.blk_cnt[rl.own_slice], s_nresc);
+            __syncthreads();
+            if (to_rescue) rl.list[(size_t)rl.own_slice * rl.seg_cap + s_base[2] + rk] = (uint32_t)r;
         }
         __syncthreads();
         if (q_n > (unsigned)QCAP) {
-            // the queue overflowed (multihit-heavy tile): drop this tile's queued tasks and run the tile un-queued.
+            // the queue overflowed: drop this round's queued tasks and run the round un-queued
             if (tid == 0) atomicAdd(&s_stat[3], 1u);
-            if (active) {
+            if (active && !to_rescue) {
                 InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
                 indels_enumerate(p, v, is);
                 if (do_gaps) gaps_enumerate(p, v, is);
@@ -341,17 +555,15 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs(Genome g, Params p, Dev
             if (tid == 0) q_n = q_before;
             __syncthreads();
         }
-        run_tasks<WIDE>(g, p, b, ev, tq, tile + (int)gridDim.x >= n_tiles);
+        run_tasks<WIDE>(g, p, b, ev, tq, k0 + step >= n);
     }
-    if (my_hits) atomicAdd(&s_stat[2], my_hits);
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
     if (tid == 0) {
-        rl.blk_cnt[blockIdx.x] = s_nresc;
+        if (SLICED) rl.blk_cnt[blockIdx.x] = s_nresc;
         if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
-        if (s_stat[2]) atomicAdd(&t.cnt[CNT_HITS], (unsigned long long)s_stat[2]);
         if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
@@ -377,7 +589,9 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params
     // costs a hundred times one with four, and with one read per wave and a barrier per read three waves in four waited for it
     // (0.64 ms per launch for 65 k reads, of which the barrier-bound waiting was most).
     const unsigned int SHARED_BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;      // a few reads per wave and turn; small launches spread over the chip
-    __shared__ unsigned int s_next, s_batch;
+    __shared__ unsigned int s_next, s_batch, s_nr, s_rbase;
+    __shared__ uint32_t s_resc[32];                         // the rescue reads of a batch (SHARED_BATCH <= 32)
+    if (tid == 0) s_nr = 0;
     unsigned int my_windows = 0, my_indels = 0;
     for (;;) {                                              // ... and the workgroups draw the batches (the word after the list's count)
         __syncthreads();
@@ -407,7 +621,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params
                 do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
                 if (do_gaps && wants) {
                     // the rescue kernels take it from here (their list, this kernel's slice)
-                    if (pass == 0 && lane == 0) rl.list[(size_t)rl.own_slice * rl.seg_cap + atomicAdd(&rl.blk_cnt[rl.own_slice], 1u)] = (uint32_t)r;
+                    if (pass == 0 && lane == 0) s_resc[atomicAdd(&s_nr, 1u)] = (uint32_t)r;
                 } else if (pass == 0) {
                     QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, hbase, 0u, 0u};
                     if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, lane, 64);
@@ -420,6 +634,13 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params
                 }
             }
             __syncthreads();
+            if (pass == 0 && s_nr) {                         // the batch's rescue reads: one global add for all of them
+                if (tid == 0) s_rbase = atomicAdd(&rl.blk_cnt[rl.own_slice], s_nr);
+                __syncthreads();
+                if ((unsigned int)tid < s_nr) rl.list[(size_t)rl.own_slice * rl.seg_cap + s_rbase + tid] = s_resc[tid];
+                __syncthreads();
+                if (tid == 0) s_nr = 0;
+            }
             if (pass == 1 || q_n <= (unsigned)QCAP) break;
             if (tid == 0) { atomicAdd(&s_stat[3], 1u); s_next = 0; q_n = q_before; }
             __syncthreads();
@@ -458,7 +679,9 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
     __shared__ Params s_p;
     typedef hipcub::BlockScan<unsigned int, TPB> Scan;
     __shared__ typename Scan::TempStorage scan_tmp;
+    __shared__ unsigned int s_nheavy, s_heavy_base;
     const int tid = threadIdx.x;
+    const unsigned long long below = (tid & 63) ? (~0ull >> (64 - (tid & 63))) : 0ull;
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) { q_n = 0; s_g = g; s_p = p; }
     // offsets of the per-workgroup slices in their concatenation
@@ -493,16 +716,30 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
             r = (int)rl.list[(size_t)lo * rl.seg_cap + (i - s_off[lo])];
             v = make_view(b, r);
-            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
             // a read with more pairs than the LDS slots hold (multihits) only has its pairs' outcomes computed here, into its slice of
             // the HBM pool; thj_k_segjuncs_rescue_shared enumerates it with a wave (one thread walking 40 x 40 pairs held its tile up)
-            unsigned int hk = 0;
             heavy = (int64_t)rv_count_raw(v, 0) * v.n_mate > RPT && (int64_t)rv_count_raw(v, 0) * v.n_mate <= GPT && !THJ_EXPF(1 << 24);
-            if (heavy) { hk = atomicAdd(rl.heavy_count, 1u); heavy = hk < (unsigned int)HEAVY_CAP; }
+        }
+        unsigned int hk = 0;
+        {   // positions in the heavy list: one global add per workgroup and round (per read they queued on one address)
+            if (tid == 0) s_nheavy = 0;
+            __syncthreads();
+            hk = wave_slot(heavy, &s_nheavy, below);
+            __syncthreads();
+            if (tid == 0 && s_nheavy) s_heavy_base = atomicAdd(rl.heavy_count, s_nheavy);
+            __syncthreads();
+            hk += s_heavy_base;
+            heavy = heavy && hk < (unsigned int)HEAVY_CAP;
+        }
+        if (active) {
+            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
             if (heavy) rl.heavy_list[hk] = (uint32_t)r;
             if (!heavy) indels_enumerate(p, v, qs);
-            bool wants = false;
-            do_gaps = gaps_prepare(p, v, wants);
+            // every listed read takes the rescue (that is why it was listed): the partner search -- 40 x 40 dependent loads for one
+            // thread when the read came from thj_k_segjuncs_shared, 0.4 ms of this kernel on the mix -- is not repeated
+            const bool wants = true;
+            gaps_prepare_listed(p, v);
+            do_gaps = true;
             if (do_gaps) {
                 if (wants) {
                     const int n_left = rv_count_raw(v, 0);
@@ -579,7 +816,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
     __shared__ unsigned int s_stat[4];
     __shared__ Genome s_g;
     __shared__ Params s_p;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) { q_n = 0; s_g = g; s_p = p; }
     __syncthreads();
@@ -604,8 +841,8 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
                 const unsigned int h = base + k;
                 const int r = (int)rl.heavy_list[h];
                 ReadView v = make_view(b, r);
-                bool wants = false;
-                const bool do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });      // the partner search over the lanes
+                const bool wants = true, do_gaps = true;            // a listed read takes the rescue: no second partner search
+                gaps_prepare_listed(p, v);
                 if (do_gaps && wants) { v.rescue = true; v.slots = rl.slot_pool + (size_t)h * (GPT * 2); v.lazy_g = &s_g; v.lazy_p = &s_p; }
                 if (pass == 0) {
                     QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
@@ -887,7 +1124,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     free_tables(c);
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
-    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_rescue_slots); hipFree(c->d_many); hipFree(c->d_fus_ignore);
+    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_rescue_slots); hipFree(c->d_many); hipFree(c->d_sj_lists); hipFree(c->d_fus_ignore);
     if (c->probe_ev) hipEventDestroy(c->probe_ev);
     hipHostFree(c->h_pinned);
     thj_span_free(c); thj_bamout_free(c);
@@ -1123,26 +1360,25 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
 #endif
     const int n_tiles = (n + TPB - 1) / TPB;
     int grid = n_tiles < 256 * 8 - 1 ? n_tiles : 256 * 8 - 1;       // 256 CUs x 8 resident workgroups, grid-stride the rest (one rescue-list slice is thj_k_segjuncs_shared's)
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
-    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
-    // LDS: task queue, the tile's offsets, room for 1.5 hits per segment (tiles with more read hits from HBM), work list
-    const int hit_cap = TPB * b.nseg + TPB * b.nseg / 2;      // (1.125 x until round 3: one read of a 40-copy repeat then pushed its whole tile out of LDS)
-    const size_t lds = (size_t)5 * QCAP * 4 + (size_t)((TPB * b.nseg + 1 + 3) & ~3) * 4 + (size_t)hit_cap * 16 + (size_t)TPB * 4;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
+    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); e3 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
     // rescue list: one slice per workgroup, sized for all the reads the workgroup visits
     RescueList rl;
     rl.seg_cap = (n_tiles + grid - 1) / grid * TPB;
-    const int64_t need = (int64_t)grid * rl.seg_cap + MANY_CAP + MAX_LISTS;       // the workgroups' slices, the shared kernel's (room for every read it may get), the counts
+    const int64_t need = (int64_t)grid * rl.seg_cap + 2 * MANY_CAP + MAX_LISTS;   // the workgroups' slices, the one thj_k_segjuncs_shared and thj_k_sj_general's second instance share (room for every read they may get), the counts
     if (c->rescue_list_cap < need) {
         hipFree(c->d_rescue_list); c->d_rescue_list = nullptr;
         HIPCHK(hipMalloc(&c->d_rescue_list, (size_t)need * 4));
         c->rescue_list_cap = need;
     }
     rl.list = c->d_rescue_list;
-    rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap + MANY_CAP;
+    rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap + 2 * MANY_CAP;
     rl.own_slice = grid;
-    static const int many_min = getenv("THJ_MANY_HITS") ? atoi(getenv("THJ_MANY_HITS")) : HEAVY_HITS;
+    static const int many_min = getenv("THJ_MANY_HITS") ? atoi(getenv("THJ_MANY_HITS")) : MID_HITS;
     rl.many_min = many_min;
-    if (!c->d_many) HIPCHK(hipMalloc((void**)&c->d_many, 16 + (size_t)MANY_CAP * 4));
+    rl.mid_min = many_min < GEN_HITS ? many_min : GEN_HITS;
+    // [count of the reads with many hits, the count of batches thj_k_segjuncs_shared has drawn, the count of thj_k_sj_general's second list][the two lists]
+    if (!c->d_many) HIPCHK(hipMalloc((void**)&c->d_many, 16 + (size_t)MANY_CAP * 8));
     rl.many_count = (unsigned int*)c->d_many;
     rl.many_list = c->d_many + 4;
     HIPCHK(hipMemsetAsync(c->d_many, 0, 16, c->stream));
@@ -1153,23 +1389,58 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     rl.heavy_list = c->d_rescue_slots ? (uint32_t*)c->d_rescue_slots + 4 : nullptr;
     rl.slot_pool = c->d_rescue_slots ? c->d_rescue_slots + 4 + HEAVY_CAP : nullptr;
     if (b.mate_off) HIPCHK(hipMemsetAsync(c->d_rescue_slots, 0, 16, c->stream));
+    // the flat kernels' lists: a slice per workgroup, each sized for the most its reads can give (a flat read: nseg - 2 indel
+    // pairs and nseg - 1 windows, or 2 per mate hit when it takes the rescue) -- sparse in a large allocation, never overflowing
+    SjLists sl;
+    {
+        const int64_t S = (int64_t)grid * rl.seg_cap;
+        const int tmax = (b.nseg > 2 ? b.nseg - 2 : 0) + (b.nseg - 1 > 2 * FLAT_MATES ? b.nseg - 1 : 2 * FLAT_MATES);
+        sl.task_cap = rl.seg_cap * tmax;
+        const size_t bytes = (size_t)S * tmax * 20 + (size_t)S * 4 * (1 + FLAT_MATES + 1) + (size_t)S * FLAT_MATES * 8 + (size_t)grid * 16 + 256;
+        if (c->sj_lists_cap < bytes) {
+            hipFree(c->d_sj_lists); c->d_sj_lists = nullptr; c->sj_lists_cap = 0;
+            HIPCHK(hipMalloc(&c->d_sj_lists, bytes + bytes / 8));
+            c->sj_lists_cap = bytes + bytes / 8;
+        }
+        char* q = (char*)c->d_sj_lists;
+        sl.tq = (uint4*)q; q += (size_t)S * tmax * 16;
+        sl.scan = (int2*)q; q += (size_t)S * FLAT_MATES * 8;
+        sl.te = (uint32_t*)q; q += (size_t)S * tmax * 4;
+        sl.frl = (uint32_t*)q; q += (size_t)S * 4;
+        sl.pairs = (uint32_t*)q; q += (size_t)S * FLAT_MATES * 4;
+        sl.gen = (uint32_t*)q; q += (size_t)S * 4;
+        sl.task_cnt = (unsigned int*)q; sl.frl_cnt = sl.task_cnt + grid; sl.pair_cnt = sl.frl_cnt + grid; sl.gen_cnt = sl.pair_cnt + grid;
+        sl.mid_count = (unsigned int*)c->d_many + 2; sl.mid_list = c->d_many + 4 + MANY_CAP;
+    }
     const bool wide = p.segment_length > 32;
-    if (wide) hipLaunchKernelGGL(thj_k_segjuncs<true>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
-    else hipLaunchKernelGGL(thj_k_segjuncs<false>, dim3(grid), dim3(TPB), lds, c->stream, g, p, b, t, rl, hit_cap);
-    {   // the reads with many hits the main kernel listed: a wave each
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_sj_flat<4>, dim3(grid), dim3(TPB), 0, c->stream, p, b, rl, sl, c->d_cnt);
+    else hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, c->stream, p, b, rl, sl, c->d_cnt);
+    if (wide) hipLaunchKernelGGL((thj_k_sj_general<true, GEN_HITS, TPB, true>), dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, rl, sl);
+    else hipLaunchKernelGGL((thj_k_sj_general<false, GEN_HITS, TPB, true>), dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, rl, sl);
+    {
+        const int mgrid = n_tiles * (TPB / MID_T) < MID_GRID ? n_tiles * (TPB / MID_T) : MID_GRID;
+        if (wide) hipLaunchKernelGGL((thj_k_sj_general<true, MID_HITS, MID_T, false>), dim3(mgrid), dim3(MID_T), 0, c->stream, g, p, b, t, rl, sl);
+        else hipLaunchKernelGGL((thj_k_sj_general<false, MID_HITS, MID_T, false>), dim3(mgrid), dim3(MID_T), 0, c->stream, g, p, b, t, rl, sl);
+    }
+    {   // the reads with many hits the flat kernel listed: a wave each
         const int sgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
         if (wide) hipLaunchKernelGGL(thj_k_segjuncs_shared<true>, dim3(sgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
         else hipLaunchKernelGGL(thj_k_segjuncs_shared<false>, dim3(sgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
     }
     if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
     if (b.mate_off) {
+        hipLaunchKernelGGL(thj_k_sj_rescue_scan, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, sl, rl.seg_cap);
+        hipLaunchKernelGGL(thj_k_sj_rescue_flat, dim3(grid), dim3(TPB), 0, c->stream, p, b, sl, rl.seg_cap, c->d_cnt);
         const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
         if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid + 1);
         else hipLaunchKernelGGL(thj_k_segjuncs_rescue<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid + 1);
         if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
         else hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
     }
-    if (c->profile) { HIPCHK(hipEventRecord(e2, c->stream)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(e1, e2); }
+    if (c->profile) HIPCHK(hipEventRecord(e2, c->stream));
+    if (wide) hipLaunchKernelGGL(thj_k_sj_tasks<true>, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, sl);
+    else hipLaunchKernelGGL(thj_k_sj_tasks<false>, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, sl);
+    if (c->profile) { HIPCHK(hipEventRecord(e3, c->stream)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(e1, e2); c->prof_events.emplace_back(e2, e3); }
     HIPCHK(hipGetLastError());
     // insert counters for the next run's growth decision (asynchronous)
     if (!c->probe_ev) HIPCHK(hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming));
@@ -1182,23 +1453,23 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
 }
 
 extern "C" int thj_profile_segjuncs(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
-    // avg_ms[2]: thj_k_segjuncs, thj_k_segjuncs_rescue (one pair per thj_segjuncs_run_async)
+    // avg_ms[3]: thj_k_sj_flat + thj_k_sj_general + thj_k_segjuncs_shared, the rescue kernels, thj_k_sj_tasks (one triple per thj_segjuncs_run_async)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    double sum[2] = {0, 0};
-    const size_t n = c->prof_events.size() / 2;
+    double sum[3] = {0, 0, 0};
+    const size_t n = c->prof_events.size() / 3;
     for (size_t i = 0; i < c->prof_events.size(); ++i) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
-        sum[i % 2] += ms;
+        sum[i % 3] += ms;
     }
-    for (size_t i = 0; i < c->prof_events.size(); ++i) {        // the middle event is shared by the two intervals
+    for (size_t i = 0; i < c->prof_events.size(); ++i) {        // the inner events are shared by neighbouring intervals
         c->event_pool.push_back(c->prof_events[i].first);
-        if (i % 2) c->event_pool.push_back(c->prof_events[i].second);
+        if (i % 3 == 2) c->event_pool.push_back(c->prof_events[i].second);
     }
     if (launches) *launches = (int64_t)n;
-    if (avg_ms) { avg_ms[0] = n ? sum[0] / (double)n : 0.0; avg_ms[1] = n ? sum[1] / (double)n : 0.0; }
+    if (avg_ms) for (int k = 0; k < 3; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
     c->prof_events.clear();
     c->profile = enable != 0;
     return THJ_OK;

@@ -404,13 +404,13 @@ class Context:
         found = self.covsearch_finish(max_cov_juncs)
         return self.download(self.finish()), found
 
-    def profile(self, enable: bool = True) -> Tuple[Tuple[float, float], int]:
-        """((thj_k_segjuncs ms, thj_k_segjuncs_rescue ms), runs) since the last call"""
-        ms = (C.c_double * 2)()
+    def profile(self, enable: bool = True) -> Tuple[Tuple[float, float, float], int]:
+        """((classifying kernels ms, rescue kernels ms, thj_k_sj_tasks ms), runs) since the last call"""
+        ms = (C.c_double * 3)()
         n = C.c_int64()
         _check(self.lib, self.lib.thj_profile_segjuncs(self._ctx, 1 if enable else 0, ms, C.byref(n)),
                "thj_profile_segjuncs")
-        return (ms[0], ms[1]), n.value
+        return (ms[0], ms[1], ms[2]), n.value
 
     def device_keys(self, kind: int) -> Tuple[int, int]:
         p = C.c_void_p()
