@@ -765,8 +765,11 @@ def run_rank(args, rank, world, local_rank, control, shared):
         ctx.reset()
         if n_ium:
             ctx.covsearch_reset()
-        ctx.run(p_left, cb_left)
-        ctx.run(p_right, cb_right)
+        if os.environ.get("THJ_BENCH_NO_PAIR") == "1":
+            ctx.run(p_left, cb_left)
+            ctx.run(p_right, cb_right)
+        else:
+            ctx.run_pair(p_left, cb_left, p_right, cb_right)      # both sides as one call: their side chains run beside each other
         if n_ium:                                     # coverage search: coverage map of all hits, extension table, island pairing
             ctx.covsearch_add_hits(cb_left)
             ctx.covsearch_add_hits(cb_right)
@@ -839,7 +842,16 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # stage 1.  The classifying kernels (thj_k_sj_flat and, for the reads that are not flat, thj_k_sj_general / thj_k_segjuncs_shared)
     # stream 16 B per hit record + 4 B per (read, segment) CSR offset; thj_k_sj_tasks reads per RefSeg window two 64-B genome
     # lines and the read, per indel pair one genome line and the read, and writes 8 B per distinct event emitted
-    cls_alg = 16.0 * cnt.n_hits_read / n_launch + 4.0 * (args.pairs * nseg + 1)
+    # the reads with several hits in a segment (stage 1's second group takes them): their count and hit records, per launch
+    sj_multi_reads = sj_multi_hits = 0
+    for sd in ("left", "right"):
+        cells1 = (w[sd]["seg_off"][1:] - w[sd]["seg_off"][:-1]).reshape(args.pairs, nseg)
+        mr1 = (cells1.max(dim=1).values > 1)
+        sj_multi_reads += int(mr1.sum()) / n_launch
+        sj_multi_hits += int(cells1[mr1].sum()) / n_launch
+    cls_alg = 16.0 * (cnt.n_hits_read / n_launch - sj_multi_hits) + 4.0 * (args.pairs * nseg + 1)
+    # ... that group: the list entry, the CSR row and the hit records of its reads, and its share of the rescue pairs (by read count)
+    multi_share = sj_multi_reads / float(args.pairs)
     task_alg = (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
     # stage 2, four kernels per launch.  Per finished read: 38 B of read planes, two 64-B genome lines (consistency
@@ -870,10 +882,13 @@ def run_rank(args, rank, world, local_rank, control, shared):
     t3_alg = n_gen * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     # thj_k_segjuncs_rescue: per (hit, mate hit) pair the read, its CSR row + hits, the mate hit and ~3 genome lines of flank
     resc_alg = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 192)
+    multi_alg = sj_multi_reads * (4 + 4.0 * (nseg + 1)) + 16.0 * sj_multi_hits + multi_share * resc_alg
+    task_alg += (1.0 - multi_share) * resc_alg
     kernels = [
-        {"kernel": "thj_k_sj_flat + thj_k_sj_general + thj_k_segjuncs_shared", "avg_kernel_ms": kern_ms[0], "launches": launches, "algorithmic_bytes_per_launch": cls_alg},
-        {"kernel": "thj_k_sj_rescue_scan + thj_k_sj_rescue_flat + thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": resc_alg},
-        {"kernel": "thj_k_sj_tasks", "avg_kernel_ms": kern_ms[2], "launches": launches, "algorithmic_bytes_per_launch": task_alg},
+        {"kernel": "thj_k_sj_flat", "avg_kernel_ms": kern_ms[0], "launches": launches, "algorithmic_bytes_per_launch": cls_alg},
+        {"kernel": "thj_k_sj_general + thj_k_segjuncs_shared + thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": multi_alg,
+         "note": "the reads with several hits a segment; runs on a stream of its own beside the next group"},
+        {"kernel": "thj_k_sj_rescue_scan + thj_k_sj_rescue_flat + thj_k_sj_tasks", "avg_kernel_ms": kern_ms[2], "launches": launches, "algorithmic_bytes_per_launch": task_alg},
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
         {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
@@ -894,7 +909,9 @@ def run_rank(args, rank, world, local_rank, control, shared):
     t2_8d = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read) + done_8d + 64) + 4.0 * n_gen
     t3_8d = n_gen * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64)
     resc_8d = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 128)
-    for k, b8 in zip(kernels, (cls_8d, resc_8d, task_8d, t0_8d, t1_8d, t2_8d, t3_8d)):
+    multi_8d = sj_multi_reads * (4 + 4.0 * (nseg + 1)) + 16.0 * sj_multi_hits + multi_share * resc_8d
+    task_8d += (1.0 - multi_share) * resc_8d
+    for k, b8 in zip(kernels, (cls_8d, multi_8d, task_8d, t0_8d, t1_8d, t2_8d, t3_8d)):
         k["algorithmic_bytes_8d_per_launch"] = b8
     for k in kernels:
         k["achieved_layout"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0
@@ -1037,6 +1054,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
                                      / max(1e-9, sum(k["avg_kernel_ms"] * k["launches"] for k in kernels)) / 1e6,
                                      "achieved_layout_bytes": sum(k["algorithmic_bytes_per_launch"] * k["launches"] for k in kernels)
                                      / max(1e-9, sum(k["avg_kernel_ms"] * k["launches"] for k in kernels)) / 1e6,
+                                     # two of stage 1's groups run side by side, so the sum above counts some time twice; the same bytes over the step's wall time:
+                                     "achieved_over_step_time": sum(k["algorithmic_bytes_8d_per_launch"] * k["launches"] for k in kernels) / max(1, args.steps) / max(1e-9, elapsed / args.steps) / 1e9,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"},
             "kernels": kernels,
             # the exchange step as it ran: ranks, transport ("rccl" across processes / GPUs, "loopback" for contexts on one device), calls and

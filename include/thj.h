@@ -175,6 +175,11 @@ int thj_segjuncs_reset_async(thj_ctx* ctx);
  * for every read of the batch; events accumulate in the context's tables the
  * way the reference accumulates into its std::sets (:4911-4916). */
 int thj_segjuncs_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch* dev_batch);
+/* Two batches (the two sides of a pass: find_gaps over left_segmap_fnames, then over right_segmap_fnames,
+ * segment_juncs.cpp:4911-4916) as one call.  The events are those of two thj_segjuncs_run_async calls in this
+ * order; the second batch's kernels do not wait for the first batch's side chains. */
+int thj_segjuncs_run_pair_async(thj_ctx* ctx, const thj_params* p0, const thj_seg_batch* dev_batch0,
+                                const thj_params* p1, const thj_seg_batch* dev_batch1);
 
 typedef struct { uint32_t ref_id, left, right, antisense; } thj_junction;   /* junctions.h:27-57 */
 typedef struct { uint32_t ref_id, left; char seq[8]; uint64_t prio; } thj_insertion; /* insertions.h:31-67 */
@@ -226,11 +231,12 @@ int thj_fusion_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch*
 int thj_fusion_finish(thj_ctx* ctx, int64_t* n_fusions);
 int thj_fusion_download(thj_ctx* ctx, thj_fusion* out);
 
-/* Average durations (ms) of the three groups of kernels of a run -- avg_ms[0] the classifying
- * kernels (`thj_k_sj_flat`, `thj_k_sj_general`, `thj_k_segjuncs_shared`), avg_ms[1] the rescue
- * kernels (`thj_k_sj_rescue_scan`, `thj_k_sj_rescue_flat`, `thj_k_segjuncs_rescue`, `_rescue_shared`),
- * avg_ms[2] `thj_k_sj_tasks` -- over the runs since the last call, measured with HIP events on the
- * context stream; also returns the run count.  Enables event recording when `enable` != 0. */
+/* Average durations (ms) of the three groups of kernels of a run -- avg_ms[0] `thj_k_sj_flat`;
+ * avg_ms[1] the chain of the reads with several hits a segment (`thj_k_sj_general` x 2,
+ * `thj_k_segjuncs_shared`, `thj_k_segjuncs_rescue`, `_rescue_shared`), which runs on a stream of
+ * its own beside the third; avg_ms[2] `thj_k_sj_rescue_scan`, `thj_k_sj_rescue_flat`,
+ * `thj_k_sj_tasks` -- over the runs since the last call, measured with HIP events on the stream
+ * each group runs on; also returns the run count.  Enables event recording when `enable` != 0. */
 int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches);
 
 

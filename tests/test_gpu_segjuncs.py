@@ -261,3 +261,42 @@ def test_event_tables_grow(lib):
         ctx.configure(64, 16)
         got = ctx.segjuncs([(p, ctx.upload_batch(sb, ordinal_base=r0)) for r0, sb in parts])
     assert_events_equal(got, want)
+
+
+def test_run_pair_equals_two_runs(lib):
+    """thj_segjuncs_run_pair_async (both sides as one call, their side chains beside each other on two scratch sets) gives the
+    events and the counters of two thj_segjuncs_run_async calls -- on a multihit-heavy case, where the side chains have work"""
+    cfg = CASES[2]
+    case = make_case(seed=33, paired=True, read_len=100, seg_len=25, n_reads=1500, repeat_frac=0.6)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    og = orc.Genome(seqs)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        runs, want, base = [], None, 0
+        for side, b in case_batches(case, True):
+            p = Params(read_side=side, **cfg["extra"])
+            e = orc.segjuncs(p, og, b)
+            want = e if want is None else merge_events(want, e)
+            runs.append((p, ctx.upload_batch(b, ordinal_base=base)))
+            base += b.n_reads
+        a = ctx.segjuncs(runs)
+        for _ in range(3):
+            ctx.reset()
+            ctx.run_pair(runs[0][0], runs[0][1], runs[1][0], runs[1][1])
+            cnt = ctx.finish()
+            b2 = ctx.download(cnt)
+            assert_events_equal(b2, a)
+            assert (cnt.n_windows, cnt.n_indel_pairs, cnt.n_rescue_pairs) == (a.stats["windows"], a.stats["indel_pairs"], a.stats["rescue_pairs"])
+        assert_events_equal(a, want)
+        assert a.stats["rescue_pairs"] == want.stats["rescue_pairs"]
+
+
+def test_full_task_list_fails_loudly(lib, monkeypatch):
+    """the kernels that enumerate from lists write their tasks to one list in HBM: when it is too small the pass fails
+    (THJ_EOVERFLOW), it does not lose events"""
+    seq, b = rescue_heavy_batch(big=((7, 40, 1), (70, 30, 2), (140, 40, 3), (141, 5, 1), (290, 64, 1)))
+    monkeypatch.setenv("THJ_XTASK_CAP", "8")
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        with pytest.raises(host.ThjError, match="task list"):
+            ctx.segjuncs([(Params(), ctx.upload_batch(b))])

@@ -32,6 +32,7 @@ struct thj_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux_stream[4] = {}; hipEvent_t aux_ev[8] = {};   // stage 1's side chains, two sets (sj_launch in thj_segjuncs.hip)
     // genome
     const u64* d_blocks = nullptr; bool own_blocks = false;
     uint32_t* d_contig_blk = nullptr; int32_t* d_contig_len = nullptr;
@@ -52,10 +53,10 @@ struct thj_ctx {
     int64_t n_junc = 0, n_del = 0, n_ins = 0;
     hipEvent_t probe_ev = nullptr; bool probe_pending = false;            // insert counters on their way to h_pinned[32..]
     uint8_t* d_fus_ignore = nullptr; int64_t n_fus_ignore = 0;            // --fusion-ignore-chromosomes flags per ref id
-    uint32_t* d_rescue_list = nullptr; int64_t rescue_list_cap = 0;      // reads taking the mate-anchored rescue + per-workgroup counts
-    uint32_t* d_many = nullptr;                                            // reads with many hits of a launch (thj_k_segjuncs_shared): count, list
-    void* d_sj_lists = nullptr; size_t sj_lists_cap = 0;                  // the flat kernels' task / rescue / general-read lists (thj_k_sj_flat)
-    int32_t* d_rescue_slots = nullptr;                                    // rescue outcomes of reads with many hits (thj_k_segjuncs_rescue)
+    uint32_t* d_rescue_list[2] = {}; int64_t rescue_list_cap[2] = {};      // reads taking the mate-anchored rescue + per-workgroup counts
+    uint32_t* d_many[2] = {};                                            // reads with many hits of a launch (thj_k_segjuncs_shared): count, list
+    void* d_sj_lists[2] = {}; size_t sj_lists_cap[2] = {};                  // the flat kernels' task / rescue / general-read lists (thj_k_sj_flat)
+    int32_t* d_rescue_slots[2] = {};                                    // rescue outcomes of reads with many hits (thj_k_segjuncs_rescue)
     // long_spanning_reads (thj_span.hip)
     uint32_t* d_junc_bucket = nullptr; int64_t n_junc_buckets = 0;     // coarse index over d_span_junc (junc_range)
     u64* d_span_cat = nullptr;                                            // junction ++ deletion keys before their sort

@@ -144,15 +144,27 @@ struct Queue {
     uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e;
     unsigned int* n;
 };
+// The kernels that enumerate from lists (thj_k_sj_general, thj_k_segjuncs_shared, the rescue kernels) queue their tasks in LDS and
+// move the queue to ONE list in HBM at the end of every round (flush_tasks: one global add per workgroup and round, the tasks written
+// side by side); thj_k_sj_tasks_list executes the list, densely, after the last of them.  None of them holds the code that executes
+// a task any more (until round 4 each ran its own queue in rounds of 256 between barriers, and again un-queued when it overflowed).
+// A task that finds the LDS queue full goes straight to the list (one global add of its own: rare); a full list sets `ovf` and
+// thj_segjuncs_finish fails.
+struct XTasks { uint4* q; uint32_t* e; unsigned int* count; unsigned int cap; unsigned int* ovf; };
 
 struct QueueSink {
     Queue q;
+    XTasks x;
     uint32_t read;             // batch index of the enumerating read
     uint32_t hbase;            // what to add to the view's hit indices to get batch hit indices
     unsigned int n_windows, n_indels;
     __device__ __forceinline__ void push(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
         unsigned int k = atomicAdd(q.n, 1u);
         if (k < (unsigned)QCAP) { q.a[k] = a; q.b[k] = b; q.c[k] = c; q.d[k] = d; q.e[k] = read; }
+        else {
+            const unsigned int pos = atomicAdd(x.count, 1u);
+            if (pos < x.cap) { x.q[pos] = make_uint4(a, b, c, d); x.e[pos] = read; } else atomicExch(x.ovf, 1u);
+        }
     }
     __device__ __forceinline__ void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
         ++n_windows;
@@ -164,18 +176,21 @@ struct QueueSink {
              lidx + hbase, ridx + hbase, (uint32_t)li | ((uint32_t)ri << 16));
     }
 };
-
-// Un-queued execution (overflow fallback): tasks run in the enumerating thread.
-template <bool WIDE>
-struct InlineSink {
-    const Genome& g; const Params& p; const ReadView& v; EventSink& ev; uint32_t ordinal;
-    __device__ __forceinline__ void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
-        window_exec<WIDE>(g, p, v, ref, wl, wr, anti, start, slen, ev);
+// every thread of the workgroup, in converged code: the round's queue to the list
+__device__ __forceinline__ void flush_tasks(const Queue& q, const XTasks& x, unsigned int* s_base, unsigned int* full_rounds) {
+    __syncthreads();
+    const unsigned int have = *q.n, n = have < (unsigned)QCAP ? have : (unsigned)QCAP;
+    if (have == 0) return;
+    if (threadIdx.x == 0) { *s_base = atomicAdd(x.count, n); if (have > (unsigned)QCAP) atomicAdd(full_rounds, 1u); }
+    __syncthreads();
+    const unsigned int base = *s_base;
+    for (unsigned int k = threadIdx.x; k < n; k += blockDim.x) {
+        const unsigned int pos = base + k;
+        if (pos < x.cap) { x.q[pos] = make_uint4(q.a[k], q.b[k], q.c[k], q.d[k]); x.e[pos] = q.e[k]; } else atomicExch(x.ovf, 1u);
     }
-    __device__ __forceinline__ void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) {
-        indel_exec<WIDE>(g, p, v, i, lidx, ridx, anti, plen, is_del, ins_prio(ordinal, i, li, ri), ev);
-    }
-};
+    __syncthreads();
+    if (threadIdx.x == 0) *q.n = 0;
+}
 
 // view of a read for executing a queued task: only what window_exec / indel_exec touch
 __device__ __forceinline__ ReadView make_task_view(const DevBatch& b, int r) {
@@ -189,37 +204,6 @@ __device__ __forceinline__ ReadView make_task_view(const DevBatch& b, int r) {
     v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
     v.size = 0; v.rescue = false; v.check_len = 0;
     return v;
-}
-
-// Queued tasks are rare (a few dozen per 256 reads), so they pile up over several tiles and run in whole rounds
-// of 256 -- every lane busy -- with the remainder (`keep`) carried over; `flush` runs everything.
-struct TaskQueue { uint32_t* a; uint32_t* b; uint32_t* c; uint32_t* d; uint32_t* e; unsigned int* n; };
-
-template <bool WIDE>
-__device__ __forceinline__ void run_tasks(const Genome& g, const Params& p, const DevBatch& b, EventSink& ev, const TaskQueue& q, bool flush) {
-    const int tid = threadIdx.x;
-    const unsigned int have = *q.n;
-    const unsigned int keep = flush ? 0u : have % blockDim.x;
-    if (have - keep > 0 && !THJ_EXPF(1 << 16)) {
-        for (unsigned int k = keep + tid; k < have; k += blockDim.x) {
-            const uint32_t a = q.a[k];
-            const int tr = (int)q.e[k];
-            ReadView tv = make_task_view(b, tr);
-            const bool anti = (a >> 9) & 1u;
-            if (a & (1u << 8)) {
-                const bool is_del = (a >> 10) & 1u;
-                const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
-                const uint32_t d = q.d[k];
-                indel_exec<WIDE>(g, p, tv, i, q.b[k], q.c[k], anti, plen, is_del,
-                           ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(d & 0xFFFF), (int)(d >> 16)), ev);
-            } else {
-                const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
-                window_exec<WIDE>(g, p, tv, q.b[k], (int32_t)q.c[k], (int32_t)q.d[k], anti, start, slen, ev);
-            }
-        }
-        __syncthreads();
-        if (tid == 0) *q.n = keep;
-    }
 }
 
 // Reads that take the mate-anchored rescue (find_gaps :3330-3497) are few and their map_read_to_contig scans long,
@@ -352,6 +336,28 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_sj_flat(Params p, DevBatch b, Re
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
+    // the listed reads with more hits than thj_k_sj_general's first instance stages go on to the second instance's list, or to
+    // thj_k_segjuncs_shared's: one global add per workgroup, round and list (the entries stay in the slice; the first instance skips
+    // them), so that the three kernels can start together when this one ends
+    {
+        __shared__ unsigned int s_nlist[2], s_lbase[2];
+        const unsigned int n_gen = s_n[3];
+        for (unsigned int k0 = 0; k0 < n_gen; k0 += TPB) {
+            const unsigned int k = k0 + (unsigned int)tid;
+            const uint32_t e = k < n_gen ? sl.gen[slice + k] : 0u;
+            const bool mid = (e >> 29) == 1u, many = (e >> 29) == 2u;
+            if (tid < 2) s_nlist[tid] = 0;
+            __syncthreads();
+            const unsigned int dk = wave_slot(mid, &s_nlist[0], below), mk = wave_slot(many, &s_nlist[1], below);
+            __syncthreads();
+            if (tid == 0 && s_nlist[0]) s_lbase[0] = atomicAdd(sl.mid_count, s_nlist[0]);
+            if (tid == 64 && s_nlist[1]) s_lbase[1] = atomicAdd(rl.many_count, s_nlist[1]);
+            __syncthreads();
+            // (a full list: the read stays with the first instance, which walks its hits in HBM)
+            if (mid) { if (s_lbase[0] + dk < (unsigned int)MANY_CAP) sl.mid_list[s_lbase[0] + dk] = e & GEN_READ; else sl.gen[slice + k] = e & GEN_READ; }
+            if (many) { if (s_lbase[1] + mk < (unsigned int)MANY_CAP) rl.many_list[s_lbase[1] + mk] = e & GEN_READ; else sl.gen[slice + k] = e & GEN_READ; }
+        }
+    }
     if (tid == 0) {
         sl.task_cnt[blockIdx.x] = s_n[0]; sl.frl_cnt[blockIdx.x] = s_n[1]; sl.pair_cnt[blockIdx.x] = s_n[2]; sl.gen_cnt[blockIdx.x] = s_n[3];
         rl.blk_cnt[blockIdx.x] = 0;
@@ -361,29 +367,37 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_sj_flat(Params p, DevBatch b, Re
     }
 }
 
-// The tasks of the flat kernels, one thread each (run_tasks' body without a queue around it): workgroup w takes slice w.
+// One task: the two window ends + the support read (window_scan), or the indel pair's read piece and genome pieces.
+template <bool WIDE>
+__device__ __forceinline__ void exec_task(const Genome& g, const Params& p, const DevBatch& b, EventSink& ev, const uint4 q, const int tr) {
+    ReadView tv = make_task_view(b, tr);
+    const uint32_t a = q.x;
+    const bool anti = (a >> 9) & 1u;
+    if (a & (1u << 8)) {
+        const bool is_del = (a >> 10) & 1u;
+        const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
+        indel_exec<WIDE>(g, p, tv, i, q.y, q.z, anti, plen, is_del,
+                   ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(q.w & 0xFFFF), (int)(q.w >> 16)), ev);
+    } else {
+        const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
+        window_exec<WIDE>(g, p, tv, q.y, (int32_t)q.z, (int32_t)q.w, anti, start, slen, ev);
+    }
+}
+// The tasks of the flat kernels, one thread each: workgroup w takes slice w.
 template <bool WIDE>
 __global__ __launch_bounds__(TPB) void thj_k_sj_tasks(Genome g, Params p, DevBatch b, Tables t, SjLists sl) {
     const unsigned int n = sl.task_cnt[blockIdx.x];
     const uint4* tq = sl.tq + (size_t)blockIdx.x * sl.task_cap;
     const uint32_t* te = sl.te + (size_t)blockIdx.x * sl.task_cap;
     EventSink ev{g, t};
-    for (unsigned int k = threadIdx.x; k < n; k += TPB) {
-        const uint4 q = tq[k];
-        const int tr = (int)te[k];
-        ReadView tv = make_task_view(b, tr);
-        const uint32_t a = q.x;
-        const bool anti = (a >> 9) & 1u;
-        if (a & (1u << 8)) {
-            const bool is_del = (a >> 10) & 1u;
-            const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
-            indel_exec<WIDE>(g, p, tv, i, q.y, q.z, anti, plen, is_del,
-                       ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(q.w & 0xFFFF), (int)(q.w >> 16)), ev);
-        } else {
-            const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
-            window_exec<WIDE>(g, p, tv, q.y, (int32_t)q.z, (int32_t)q.w, anti, start, slen, ev);
-        }
-    }
+    for (unsigned int k = threadIdx.x; k < n; k += TPB) exec_task<WIDE>(g, p, b, ev, tq[k], (int)te[k]);
+}
+// ... of the kernels that enumerate from lists: one list.
+template <bool WIDE>
+__global__ __launch_bounds__(TPB) void thj_k_sj_tasks_list(Genome g, Params p, DevBatch b, Tables t, XTasks x) {
+    const unsigned int n = *x.count < x.cap ? *x.count : x.cap;
+    EventSink ev{g, t};
+    for (unsigned int k = blockIdx.x * TPB + threadIdx.x; k < n; k += gridDim.x * TPB) exec_task<WIDE>(g, p, b, ev, x.q[k], (int)x.e[k]);
 }
 
 // One thread per (flat rescue read, mate hit): rescue_scan, whatever the left hit is (it is the same scan for every left hit;
@@ -467,28 +481,26 @@ static constexpr int GEN_HITS = 12;        // hits of a read the first instance 
 static constexpr int MID_HITS = 32;        // ... the second (more: thj_k_segjuncs_shared, or rl.many_min if that is smaller)
 static constexpr int MID_T = 64;
 static constexpr int MID_GRID = 2048;
-template <bool WIDE, int HITS, int T, bool SLICED>
-__global__ __launch_bounds__(T) void thj_k_sj_general(Genome g, Params p, DevBatch b, Tables t, RescueList rl, SjLists sl) {
+template <int HITS, int T, bool SLICED>
+__global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, RescueList rl, SjLists sl, XTasks x, unsigned long long* cnt) {
     constexpr int STRIDE = HITS + 1;       // uint4 per thread (an odd count: the threads of a wave spread over the banks)
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
     __shared__ uint4 s_hits[T * STRIDE];
     __shared__ uint32_t s_so[T * 9];
-    __shared__ unsigned int q_n, s_nresc, s_nlist[2], s_base[3];
+    __shared__ unsigned int q_n, s_nresc, s_base[3], s_xbase;
     __shared__ unsigned int s_stat[4];
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) { q_n = 0; s_nresc = 0; }
     __syncthreads();
     const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-    EventSink ev{g, t};
-    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const Queue qq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int n = SLICED ? sl.gen_cnt[blockIdx.x] : (*sl.mid_count < (unsigned int)MANY_CAP ? *sl.mid_count : (unsigned int)MANY_CAP);
     const uint32_t* list = SLICED ? sl.gen + (size_t)blockIdx.x * rl.seg_cap : sl.mid_list;
     const unsigned int first = SLICED ? 0u : blockIdx.x * T, step = SLICED ? (unsigned int)T : gridDim.x * T;
     unsigned int my_windows = 0, my_indels = 0;
     for (unsigned int k0 = first; k0 < n; k0 += step) {
         __syncthreads();
-        const unsigned int q_before = q_n;
         const unsigned int k = k0 + (unsigned int)tid;
         bool active = k < n;
         ReadView v;
@@ -497,18 +509,7 @@ __global__ __launch_bounds__(T) void thj_k_sj_general(Genome g, Params p, DevBat
         uint32_t hbase = 0;
         const uint32_t e = active ? list[k] : 0u;
         r = (int)(e & GEN_READ);
-        if (SLICED) {   // the reads with more hits go on: one global add per workgroup, round and list
-            const bool mid = active && (e >> 29) == 1u, many = active && (e >> 29) == 2u;
-            if (tid < 2) s_nlist[tid] = 0;
-            __syncthreads();
-            const unsigned int dk = wave_slot(mid, &s_nlist[0], below), mk = wave_slot(many, &s_nlist[1], below);
-            __syncthreads();
-            if (tid == 0 && s_nlist[0]) s_base[0] = atomicAdd(sl.mid_count, s_nlist[0]);
-            if (tid == 64 && s_nlist[1]) s_base[1] = atomicAdd(rl.many_count, s_nlist[1]);
-            __syncthreads();
-            if (mid && s_base[0] + dk < (unsigned int)MANY_CAP) { sl.mid_list[s_base[0] + dk] = (uint32_t)r; active = false; }
-            if (many && s_base[1] + mk < (unsigned int)MANY_CAP) { rl.many_list[s_base[1] + mk] = (uint32_t)r; active = false; }
-        }
+        if (SLICED && (e >> 29) != 0u) active = false;          // thj_k_sj_flat moved it to another kernel's list
         if (active) {
             v = make_view(b, r);
             const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(T) void thj_k_sj_general(Genome g, Params p, DevBat
             do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants);
             to_rescue = do_gaps && wants;
             if (!to_rescue) {
-                QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, hbase, 0u, 0u};
+                QueueSink qs{qq, x, (uint32_t)r, hbase, 0u, 0u};
                 if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs);
                 if (do_gaps) gaps_enumerate(p, v, qs);
                 my_windows += qs.n_windows; my_indels += qs.n_indels;
@@ -542,37 +543,23 @@ __global__ __launch_bounds__(T) void thj_k_sj_general(Genome g, Params p, DevBat
             __syncthreads();
             if (to_rescue) rl.list[(size_t)rl.own_slice * rl.seg_cap + s_base[2] + rk] = (uint32_t)r;
         }
-        __syncthreads();
-        if (q_n > (unsigned)QCAP) {
-            // the queue overflowed: drop this round's queued tasks and run the round un-queued
-            if (tid == 0) atomicAdd(&s_stat[3], 1u);
-            if (active && !to_rescue) {
-                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
-                indels_enumerate(p, v, is);
-                if (do_gaps) gaps_enumerate(p, v, is);
-            }
-            __syncthreads();
-            if (tid == 0) q_n = q_before;
-            __syncthreads();
-        }
-        run_tasks<WIDE>(g, p, b, ev, tq, k0 + step >= n);
+        flush_tasks(qq, x, &s_xbase, &s_stat[3]);
     }
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
     if (tid == 0) {
         if (SLICED) rl.blk_cnt[blockIdx.x] = s_nresc;
-        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
-        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
-        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+        if (s_stat[0]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[3]) atomicAdd(&cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
 
 // The reads with many hits (listed by the main kernel, unclassified): one WAVE per read.  The read's hits are staged in LDS, the partner
 // search of find_gaps' head is shared over the lanes; a read that takes the mate-anchored rescue goes to this kernel's own slice of
 // the rescue list (the rescue kernels run next), the others are enumerated here, lane = hit, into the usual queue.
-template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params p, DevBatch b, Tables t, RescueList rl) {
+__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Params p, DevBatch b, RescueList rl, XTasks x, unsigned long long* cnt) {
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
     __shared__ unsigned int q_n;
     __shared__ unsigned int s_stat[4];
@@ -582,79 +569,67 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Genome g, Params
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) q_n = 0;
     __syncthreads();
-    EventSink ev{g, t};
-    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const Queue qq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int n = *rl.many_count < (unsigned int)MANY_CAP ? *rl.many_count : (unsigned int)MANY_CAP;
     // A workgroup takes SHARED_BATCH reads at a time and its waves draw them one by one (s_next): a read with forty hits a segment
     // costs a hundred times one with four, and with one read per wave and a barrier per read three waves in four waited for it
     // (0.64 ms per launch for 65 k reads, of which the barrier-bound waiting was most).
     const unsigned int SHARED_BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;      // a few reads per wave and turn; small launches spread over the chip
-    __shared__ unsigned int s_next, s_batch, s_nr, s_rbase;
+    __shared__ unsigned int s_next, s_batch, s_nr, s_rbase, s_xbase;
     __shared__ uint32_t s_resc[32];                         // the rescue reads of a batch (SHARED_BATCH <= 32)
     if (tid == 0) s_nr = 0;
     unsigned int my_windows = 0, my_indels = 0;
     for (;;) {                                              // ... and the workgroups draw the batches (the word after the list's count)
         __syncthreads();
-        const unsigned int q_before = q_n;
         if (tid == 0) { s_next = 0; s_batch = atomicAdd(rl.many_count + 1, 1u); }
         __syncthreads();
         const unsigned int base = s_batch * SHARED_BATCH;
         if (base >= n) break;
-        for (int pass = 0; pass < 2; ++pass) {               // pass 1 only when the queue overflowed: the batch again, executed where it is found
-            for (;;) {
-                unsigned int k = 0;
-                if (lane == 0) k = atomicAdd(&s_next, 1u);
-                k = (unsigned int)__shfl((int)k, 0);
-                if (k >= SHARED_BATCH || base + k >= n) break;
-                const int r = (int)rl.many_list[base + k];
-                ReadView v = make_view(b, r);
-                bool do_gaps = false, wants = false;
-                uint32_t hbase = 0;
-                const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with s_h
-                if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 12) {                 // the hits and their offsets into LDS
-                    for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
-                    if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
-                }
-                do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
-                if (do_gaps && wants) {
-                    // the rescue kernels take it from here (their list, this kernel's slice)
-                    if (pass == 0 && lane == 0) s_resc[atomicAdd(&s_nr, 1u)] = (uint32_t)r;
-                } else if (pass == 0) {
-                    QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, hbase, 0u, 0u};
-                    if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, lane, 64);
-                    if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
-                    my_windows += qs.n_windows; my_indels += qs.n_indels;
-                } else {
-                    InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
-                    indels_enumerate(p, v, is, lane, 64);
-                    if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
-                }
+        for (;;) {
+            unsigned int k = 0;
+            if (lane == 0) k = atomicAdd(&s_next, 1u);
+            k = (unsigned int)__shfl((int)k, 0);
+            if (k >= SHARED_BATCH || base + k >= n) break;
+            const int r = (int)rl.many_list[base + k];
+            ReadView v = make_view(b, r);
+            bool do_gaps = false, wants = false;
+            uint32_t hbase = 0;
+            const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with s_h
+            if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 12) {                 // the hits and their offsets into LDS
+                for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
+                if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
             }
-            __syncthreads();
-            if (pass == 0 && s_nr) {                         // the batch's rescue reads: one global add for all of them
-                if (tid == 0) s_rbase = atomicAdd(&rl.blk_cnt[rl.own_slice], s_nr);
-                __syncthreads();
-                if ((unsigned int)tid < s_nr) rl.list[(size_t)rl.own_slice * rl.seg_cap + s_rbase + tid] = s_resc[tid];
-                __syncthreads();
-                if (tid == 0) s_nr = 0;
+            do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
+            if (do_gaps && wants) {
+                // the rescue kernels take it from here (their list, this kernel's slice)
+                if (lane == 0) s_resc[atomicAdd(&s_nr, 1u)] = (uint32_t)r;
+            } else {
+                QueueSink qs{qq, x, (uint32_t)r, hbase, 0u, 0u};
+                if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, lane, 64);
+                if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
+                my_windows += qs.n_windows; my_indels += qs.n_indels;
             }
-            if (pass == 1 || q_n <= (unsigned)QCAP) break;
-            if (tid == 0) { atomicAdd(&s_stat[3], 1u); s_next = 0; q_n = q_before; }
-            __syncthreads();
         }
-        run_tasks<WIDE>(g, p, b, ev, tq, false);
+        __syncthreads();
+        if (s_nr) {                                          // the batch's rescue reads: one global add for all of them
+            if (tid == 0) s_rbase = atomicAdd(&rl.blk_cnt[rl.own_slice], s_nr);
+            __syncthreads();
+            if ((unsigned int)tid < s_nr) rl.list[(size_t)rl.own_slice * rl.seg_cap + s_rbase + tid] = s_resc[tid];
+            __syncthreads();
+            if (tid == 0) s_nr = 0;
+        }
+        flush_tasks(qq, x, &s_xbase, &s_stat[3]);
     }
-    run_tasks<WIDE>(g, p, b, ev, tq, true);              // what is still queued
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
     if (tid == 0) {
-        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
-        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
-        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+        if (s_stat[0]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[3]) atomicAdd(&cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
 
@@ -668,8 +643,7 @@ static constexpr int RESCUE_GRID = 1024;  // workgroups of the rescue kernel at 
 static constexpr int HEAVY_CAP = 1 << 18;  // rescue reads of one launch that can have a pool slice (the rest recompute their pairs as they go)
 static constexpr int MAX_LISTS = 2048;    // workgroups of the main kernel = slices of the rescue list
 
-template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params p, DevBatch b, Tables t, RescueList rl, int n_lists) {
+__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params p, DevBatch b, RescueList rl, int n_lists, XTasks x, unsigned long long* cnt) {
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
     __shared__ int32_t s_slots[TPB * RPT * 2];
     __shared__ unsigned int s_off[MAX_LISTS + 1];
@@ -679,7 +653,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
     __shared__ Params s_p;
     typedef hipcub::BlockScan<unsigned int, TPB> Scan;
     __shared__ typename Scan::TempStorage scan_tmp;
-    __shared__ unsigned int s_nheavy, s_heavy_base;
+    __shared__ unsigned int s_nheavy, s_heavy_base, s_xbase;
     const int tid = threadIdx.x;
     const unsigned long long below = (tid & 63) ? (~0ull >> (64 - (tid & 63))) : 0ull;
     if (tid < 4) s_stat[tid] = 0;
@@ -697,16 +671,13 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
         if (tid == 0) s_off[MAX_LISTS] = total;
     }
     __syncthreads();
-    EventSink ev{g, t};
-    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const Queue qq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int per_round = gridDim.x * TPB;
     const unsigned int rounds = (total + per_round - 1) / per_round;
     unsigned int my_pairs = 0, my_windows = 0, my_indels = 0;      // statistics: per thread, added to LDS once at the end
     for (unsigned int it = 0; it < rounds; ++it) {
         const unsigned int i = (it * gridDim.x + blockIdx.x) * TPB + tid;
         const bool active = i < total;
-        __syncthreads();
-        const unsigned int q_before = q_n;
         __syncthreads();
         ReadView v;
         bool do_gaps = false, heavy = false;
@@ -732,7 +703,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             heavy = heavy && hk < (unsigned int)HEAVY_CAP;
         }
         if (active) {
-            QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
+            QueueSink qs{qq, x, (uint32_t)r, 0u, 0u, 0u};
             if (heavy) rl.heavy_list[hk] = (uint32_t)r;
             if (!heavy) indels_enumerate(p, v, qs);
             // every listed read takes the rescue (that is why it was listed): the partner search -- 40 x 40 dependent loads for one
@@ -781,36 +752,23 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             }
             my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
-        __syncthreads();
-        if (q_n > (unsigned)QCAP) {
-            if (tid == 0) atomicAdd(&s_stat[3], 1u);
-            if (active && !heavy) {
-                InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
-                indels_enumerate(p, v, is);
-                if (do_gaps) gaps_enumerate(p, v, is);
-            }
-            __syncthreads();
-            if (tid == 0) q_n = q_before;
-            __syncthreads();
-        }
-        run_tasks<WIDE>(g, p, b, ev, tq, it + 1 == rounds);
+        flush_tasks(qq, x, &s_xbase, &s_stat[3]);
     }
     if (my_pairs) atomicAdd(&s_stat[2], my_pairs);
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
     if (tid == 0) {
-        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
-        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
-        if (s_stat[2]) atomicAdd(&t.cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[2]);
-        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+        if (s_stat[0]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd(&cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[2]);
+        if (s_stat[3]) atomicAdd(&cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
 
 // The rescue reads with many pairs (listed by thj_k_segjuncs_rescue, their pairs' outcomes in the pool): one wave per read,
 // lane = hit, then the same queue and execution as everywhere.
-template <bool WIDE>
-__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g, Params p, DevBatch b, Tables t, RescueList rl) {
+__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g, Params p, DevBatch b, RescueList rl, XTasks x, unsigned long long* cnt) {
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
     __shared__ unsigned int q_n;
     __shared__ unsigned int s_stat[4];
@@ -820,55 +778,40 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) { q_n = 0; s_g = g; s_p = p; }
     __syncthreads();
-    EventSink ev{g, t};
-    const TaskQueue tq{q_a, q_b, q_c, q_d, q_e, &q_n};
+    const Queue qq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int n = *rl.heavy_count < (unsigned int)HEAVY_CAP ? *rl.heavy_count : (unsigned int)HEAVY_CAP;
     // the waves of a workgroup draw the reads of its batch one by one, as in thj_k_segjuncs_shared
     const unsigned int BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;
-    __shared__ unsigned int s_next;
+    __shared__ unsigned int s_next, s_xbase;
     unsigned int my_windows = 0, my_indels = 0;
     for (unsigned int base = blockIdx.x * BATCH; base < n; base += gridDim.x * BATCH) {
         __syncthreads();
-        const unsigned int q_before = q_n;
         if (tid == 0) s_next = 0;
         __syncthreads();
-        for (int pass = 0; pass < 2; ++pass) {               // pass 1 only when the queue overflowed
-            for (;;) {
-                unsigned int k = 0;
-                if (lane == 0) k = atomicAdd(&s_next, 1u);
-                k = (unsigned int)__shfl((int)k, 0);
-                if (k >= BATCH || base + k >= n) break;
-                const unsigned int h = base + k;
-                const int r = (int)rl.heavy_list[h];
-                ReadView v = make_view(b, r);
-                const bool wants = true, do_gaps = true;            // a listed read takes the rescue: no second partner search
-                gaps_prepare_listed(p, v);
-                if (do_gaps && wants) { v.rescue = true; v.slots = rl.slot_pool + (size_t)h * (GPT * 2); v.lazy_g = &s_g; v.lazy_p = &s_p; }
-                if (pass == 0) {
-                    QueueSink qs{{q_a, q_b, q_c, q_d, q_e, &q_n}, (uint32_t)r, 0u, 0u, 0u};
-                    indels_enumerate(p, v, qs, lane, 64);
-                    if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
-                    my_windows += qs.n_windows; my_indels += qs.n_indels;
-                } else {
-                    InlineSink<WIDE> is{g, p, v, ev, b.ordinal_base + (uint32_t)r};
-                    indels_enumerate(p, v, is, lane, 64);
-                    if (do_gaps) gaps_enumerate(p, v, is, lane, 64);
-                }
-            }
-            __syncthreads();
-            if (pass == 1 || q_n <= (unsigned)QCAP) break;
-            if (tid == 0) { atomicAdd(&s_stat[3], 1u); s_next = 0; q_n = q_before; }
-            __syncthreads();
+        for (;;) {
+            unsigned int k = 0;
+            if (lane == 0) k = atomicAdd(&s_next, 1u);
+            k = (unsigned int)__shfl((int)k, 0);
+            if (k >= BATCH || base + k >= n) break;
+            const unsigned int h = base + k;
+            const int r = (int)rl.heavy_list[h];
+            ReadView v = make_view(b, r);
+            gaps_prepare_listed(p, v);                             // a listed read takes the rescue: no second partner search
+            v.rescue = true; v.slots = rl.slot_pool + (size_t)h * (GPT * 2); v.lazy_g = &s_g; v.lazy_p = &s_p;
+            QueueSink qs{qq, x, (uint32_t)r, 0u, 0u, 0u};
+            indels_enumerate(p, v, qs, lane, 64);
+            gaps_enumerate(p, v, qs, lane, 64);
+            my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
-        run_tasks<WIDE>(g, p, b, ev, tq, base + gridDim.x * BATCH >= n);
+        flush_tasks(qq, x, &s_xbase, &s_stat[3]);
     }
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     __syncthreads();
     if (tid == 0) {
-        if (s_stat[0]) atomicAdd(&t.cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
-        if (s_stat[1]) atomicAdd(&t.cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
-        if (s_stat[3]) atomicAdd(&t.cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
+        if (s_stat[0]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
+        if (s_stat[1]) atomicAdd(&cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[3]) atomicAdd(&cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
 
@@ -1124,7 +1067,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     free_tables(c);
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     hipFree(c->d_contig_blk); hipFree(c->d_contig_len);
-    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); hipFree(c->d_rescue_list); hipFree(c->d_rescue_slots); hipFree(c->d_many); hipFree(c->d_sj_lists); hipFree(c->d_fus_ignore);
+    hipFree(c->d_ovf); hipFree(c->d_cnt); hipFree(c->d_out_n); for (int i = 0; i < 2; ++i) { hipFree(c->d_rescue_list[i]); hipFree(c->d_rescue_slots[i]); hipFree(c->d_many[i]); hipFree(c->d_sj_lists[i]); } hipFree(c->d_fus_ignore);
     if (c->probe_ev) hipEventDestroy(c->probe_ev);
     hipHostFree(c->h_pinned);
     thj_span_free(c); thj_bamout_free(c);
@@ -1132,6 +1075,8 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); hipFree(c->d_infl_tmp); thj_dev_cache_free(c);
     for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : c->event_pool) hipEventDestroy(e);
+    for (int i = 0; i < 4; ++i) if (c->aux_stream[i]) hipStreamDestroy(c->aux_stream[i]);
+    for (int i = 0; i < 8; ++i) if (c->aux_ev[i]) hipEventDestroy(c->aux_ev[i]);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1338,14 +1283,10 @@ hipEvent_t thj_get_event(thj_ctx* c) {
     return e;
 }
 
-extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db) {
-    if (!c || !tp || !db) { thj_set_error("thj_segjuncs_run_async: null argument"); return THJ_EINVAL; }
-    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
-    int rc = check_params(tp, db);
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(c->device));
-    if (db->n_reads == 0) return THJ_OK;
-    if ((rc = maybe_grow_tables(c))) return rc;
+// One batch's kernels.  `set` (0 / 1) names the scratch lists and side streams the launch uses: two batches launched one after
+// the other on different sets run their side chains beside each other (thj_segjuncs_run_pair_async); *joined is set when the
+// launch left work on side streams that sj_join has to bring back to the context's stream.
+static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, int set, bool* joined) {
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p;
     memcpy(&p, tp, sizeof p);
@@ -1360,88 +1301,118 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
 #endif
     const int n_tiles = (n + TPB - 1) / TPB;
     int grid = n_tiles < 256 * 8 - 1 ? n_tiles : 256 * 8 - 1;       // 256 CUs x 8 resident workgroups, grid-stride the rest (one rescue-list slice is thj_k_segjuncs_shared's)
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
-    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); e3 = thj_get_event(c); HIPCHK(hipEventRecord(e0, c->stream)); }
     // rescue list: one slice per workgroup, sized for all the reads the workgroup visits
     RescueList rl;
     rl.seg_cap = (n_tiles + grid - 1) / grid * TPB;
     const int64_t need = (int64_t)grid * rl.seg_cap + 2 * MANY_CAP + MAX_LISTS;   // the workgroups' slices, the one thj_k_segjuncs_shared and thj_k_sj_general's second instance share (room for every read they may get), the counts
-    if (c->rescue_list_cap < need) {
-        hipFree(c->d_rescue_list); c->d_rescue_list = nullptr;
-        HIPCHK(hipMalloc(&c->d_rescue_list, (size_t)need * 4));
-        c->rescue_list_cap = need;
+    if (c->rescue_list_cap[set] < need) {
+        hipFree(c->d_rescue_list[set]); c->d_rescue_list[set] = nullptr;
+        HIPCHK(hipMalloc(&c->d_rescue_list[set], (size_t)need * 4));
+        c->rescue_list_cap[set] = need;
     }
-    rl.list = c->d_rescue_list;
-    rl.blk_cnt = c->d_rescue_list + (int64_t)grid * rl.seg_cap + 2 * MANY_CAP;
+    rl.list = c->d_rescue_list[set];
+    rl.blk_cnt = c->d_rescue_list[set] + (int64_t)grid * rl.seg_cap + 2 * MANY_CAP;
     rl.own_slice = grid;
     static const int many_min = getenv("THJ_MANY_HITS") ? atoi(getenv("THJ_MANY_HITS")) : MID_HITS;
     rl.many_min = many_min;
     rl.mid_min = many_min < GEN_HITS ? many_min : GEN_HITS;
     // [count of the reads with many hits, the count of batches thj_k_segjuncs_shared has drawn, the count of thj_k_sj_general's second list][the two lists]
-    if (!c->d_many) HIPCHK(hipMalloc((void**)&c->d_many, 16 + (size_t)MANY_CAP * 8));
-    rl.many_count = (unsigned int*)c->d_many;
-    rl.many_list = c->d_many + 4;
-    HIPCHK(hipMemsetAsync(c->d_many, 0, 16, c->stream));
+    if (!c->d_many[set]) HIPCHK(hipMalloc((void**)&c->d_many[set], 16 + (size_t)MANY_CAP * 8));
+    rl.many_count = (unsigned int*)c->d_many[set];
+    rl.many_list = c->d_many[set] + 4;
+    HIPCHK(hipMemsetAsync(c->d_many[set], 0, 16, c->stream));
     HIPCHK(hipMemsetAsync(rl.blk_cnt + grid, 0, 4, c->stream));
     // [16 bytes: the count of listed reads][HEAVY_CAP read indices][HEAVY_CAP slices of GPT pairs' outcomes]
-    if (b.mate_off && !c->d_rescue_slots) HIPCHK(hipMalloc((void**)&c->d_rescue_slots, 16 + (size_t)HEAVY_CAP * 4 + (size_t)HEAVY_CAP * GPT * 2 * sizeof(int32_t)));
-    rl.heavy_count = (unsigned int*)c->d_rescue_slots;
-    rl.heavy_list = c->d_rescue_slots ? (uint32_t*)c->d_rescue_slots + 4 : nullptr;
-    rl.slot_pool = c->d_rescue_slots ? c->d_rescue_slots + 4 + HEAVY_CAP : nullptr;
-    if (b.mate_off) HIPCHK(hipMemsetAsync(c->d_rescue_slots, 0, 16, c->stream));
+    if (b.mate_off && !c->d_rescue_slots[set]) HIPCHK(hipMalloc((void**)&c->d_rescue_slots[set], 16 + (size_t)HEAVY_CAP * 4 + (size_t)HEAVY_CAP * GPT * 2 * sizeof(int32_t)));
+    rl.heavy_count = (unsigned int*)c->d_rescue_slots[set];
+    rl.heavy_list = c->d_rescue_slots[set] ? (uint32_t*)c->d_rescue_slots[set] + 4 : nullptr;
+    rl.slot_pool = c->d_rescue_slots[set] ? c->d_rescue_slots[set] + 4 + HEAVY_CAP : nullptr;
+    if (b.mate_off) HIPCHK(hipMemsetAsync(c->d_rescue_slots[set], 0, 16, c->stream));
     // the flat kernels' lists: a slice per workgroup, each sized for the most its reads can give (a flat read: nseg - 2 indel
     // pairs and nseg - 1 windows, or 2 per mate hit when it takes the rescue) -- sparse in a large allocation, never overflowing
     SjLists sl;
+    XTasks x;
+    size_t xcap;
     {
         const int64_t S = (int64_t)grid * rl.seg_cap;
         const int tmax = (b.nseg > 2 ? b.nseg - 2 : 0) + (b.nseg - 1 > 2 * FLAT_MATES ? b.nseg - 1 : 2 * FLAT_MATES);
         sl.task_cap = rl.seg_cap * tmax;
-        const size_t bytes = (size_t)S * tmax * 20 + (size_t)S * 4 * (1 + FLAT_MATES + 1) + (size_t)S * FLAT_MATES * 8 + (size_t)grid * 16 + 256;
-        if (c->sj_lists_cap < bytes) {
-            hipFree(c->d_sj_lists); c->d_sj_lists = nullptr; c->sj_lists_cap = 0;
-            HIPCHK(hipMalloc(&c->d_sj_lists, bytes + bytes / 8));
-            c->sj_lists_cap = bytes + bytes / 8;
+        xcap = (size_t)2 * (size_t)n > ((size_t)1 << 20) ? (size_t)2 * (size_t)n : ((size_t)1 << 20);     // the list of the kernels that enumerate from lists: two tasks per read of the batch
+        if (getenv("THJ_XTASK_CAP")) xcap = (size_t)atoll(getenv("THJ_XTASK_CAP"));                       // (tests: a full list must fail loudly)
+        const size_t bytes = (size_t)S * tmax * 20 + (size_t)S * 4 * (1 + FLAT_MATES + 1) + (size_t)S * FLAT_MATES * 8 + (size_t)grid * 16 + xcap * 20 + 512;
+        if (c->sj_lists_cap[set] < bytes) {
+            hipFree(c->d_sj_lists[set]); c->d_sj_lists[set] = nullptr; c->sj_lists_cap[set] = 0;
+            HIPCHK(hipMalloc(&c->d_sj_lists[set], bytes + bytes / 8));
+            c->sj_lists_cap[set] = bytes + bytes / 8;
         }
-        char* q = (char*)c->d_sj_lists;
+        char* q = (char*)c->d_sj_lists[set];
         sl.tq = (uint4*)q; q += (size_t)S * tmax * 16;
+        x.q = (uint4*)q; q += xcap * 16;
         sl.scan = (int2*)q; q += (size_t)S * FLAT_MATES * 8;
         sl.te = (uint32_t*)q; q += (size_t)S * tmax * 4;
         sl.frl = (uint32_t*)q; q += (size_t)S * 4;
         sl.pairs = (uint32_t*)q; q += (size_t)S * FLAT_MATES * 4;
         sl.gen = (uint32_t*)q; q += (size_t)S * 4;
+        x.e = (uint32_t*)q; q += xcap * 4;
+        x.count = (unsigned int*)c->d_many[set] + 3; x.cap = (unsigned int)(xcap < 0xFFFFFFFFull ? xcap : 0xFFFFFFFFull); x.ovf = c->d_ovf + 3;
         sl.task_cnt = (unsigned int*)q; sl.frl_cnt = sl.task_cnt + grid; sl.pair_cnt = sl.frl_cnt + grid; sl.gen_cnt = sl.pair_cnt + grid;
-        sl.mid_count = (unsigned int*)c->d_many + 2; sl.mid_list = c->d_many + 4 + MANY_CAP;
+        sl.mid_count = (unsigned int*)c->d_many[set] + 2; sl.mid_list = c->d_many[set] + 4 + MANY_CAP;
     }
     const bool wide = p.segment_length > 32;
-    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_sj_flat<4>, dim3(grid), dim3(TPB), 0, c->stream, p, b, rl, sl, c->d_cnt);
-    else hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, c->stream, p, b, rl, sl, c->d_cnt);
-    if (wide) hipLaunchKernelGGL((thj_k_sj_general<true, GEN_HITS, TPB, true>), dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, rl, sl);
-    else hipLaunchKernelGGL((thj_k_sj_general<false, GEN_HITS, TPB, true>), dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, rl, sl);
+    // Two chains after thj_k_sj_flat, side by side on two streams: the flat reads' (rescue scan, rescue enumeration, tasks:
+    // dense, bound by the genome lines they fetch) on the context's stream, and the reads with several hits a segment (general x 2,
+    // shared, rescue x 2: few waves per CU, each waiting on its own chain of loads) on a stream of the context's own, with
+    // thj_k_segjuncs_shared beside thj_k_sj_general's second instance on a third.  Everything is joined on the context's stream
+    // again before this function returns; the event tables take inserts from any of them.  THJ_SJ_SERIAL=1: one stream.
+    static const bool serial = getenv("THJ_SJ_SERIAL") && atoi(getenv("THJ_SJ_SERIAL")) != 0;
+    if (!serial && !c->aux_stream[2 * set]) {
+        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->aux_stream[2 * set + i], hipStreamNonBlocking));
+        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->aux_ev[4 * set + i], hipEventDisableTiming));
+    }
+    hipStream_t sm = c->stream, sa = serial ? c->stream : c->aux_stream[2 * set], sb = serial ? c->stream : c->aux_stream[2 * set + 1];
+    hipEvent_t* const aev = c->aux_ev + 4 * set;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, ea0 = nullptr, ea1 = nullptr;
+    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); ea0 = thj_get_event(c); ea1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, sm)); }
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_sj_flat<4>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
+    else hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
+    if (c->profile) HIPCHK(hipEventRecord(e1, sm));
+    if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); }
+    // ---- the reads with several hits a segment
+    if (c->profile) HIPCHK(hipEventRecord(ea0, sa));
+    if (!serial) HIPCHK(hipStreamWaitEvent(sb, aev[0], 0));
+    const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
+    hipLaunchKernelGGL(thj_k_segjuncs_shared, dim3(rgrid), dim3(TPB), 0, sb, p, b, rl, x, c->d_cnt);     // the reads with many hits: a wave each (the longest of the three: first)
+    if (!serial) HIPCHK(hipEventRecord(aev[2], sb));
+    hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
     {
         const int mgrid = n_tiles * (TPB / MID_T) < MID_GRID ? n_tiles * (TPB / MID_T) : MID_GRID;
-        if (wide) hipLaunchKernelGGL((thj_k_sj_general<true, MID_HITS, MID_T, false>), dim3(mgrid), dim3(MID_T), 0, c->stream, g, p, b, t, rl, sl);
-        else hipLaunchKernelGGL((thj_k_sj_general<false, MID_HITS, MID_T, false>), dim3(mgrid), dim3(MID_T), 0, c->stream, g, p, b, t, rl, sl);
+        hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false>), dim3(mgrid), dim3(MID_T), 0, sa, p, b, rl, sl, x, c->d_cnt);
     }
-    {   // the reads with many hits the flat kernel listed: a wave each
-        const int sgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
-        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_shared<true>, dim3(sgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
-        else hipLaunchKernelGGL(thj_k_segjuncs_shared<false>, dim3(sgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
-    }
-    if (c->profile) HIPCHK(hipEventRecord(e1, c->stream));
+    if (!serial) HIPCHK(hipStreamWaitEvent(sa, aev[2], 0));
     if (b.mate_off) {
-        hipLaunchKernelGGL(thj_k_sj_rescue_scan, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, sl, rl.seg_cap);
-        hipLaunchKernelGGL(thj_k_sj_rescue_flat, dim3(grid), dim3(TPB), 0, c->stream, p, b, sl, rl.seg_cap, c->d_cnt);
-        const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
-        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid + 1);
-        else hipLaunchKernelGGL(thj_k_segjuncs_rescue<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl, grid + 1);
-        if (wide) hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<true>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
-        else hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared<false>, dim3(rgrid), dim3(TPB), 0, c->stream, g, p, b, t, rl);
+        hipLaunchKernelGGL(thj_k_segjuncs_rescue, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, rl, grid + 1, x, c->d_cnt);
+        hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, rl, x, c->d_cnt);
     }
-    if (c->profile) HIPCHK(hipEventRecord(e2, c->stream));
-    if (wide) hipLaunchKernelGGL(thj_k_sj_tasks<true>, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, sl);
-    else hipLaunchKernelGGL(thj_k_sj_tasks<false>, dim3(grid), dim3(TPB), 0, c->stream, g, p, b, t, sl);
-    if (c->profile) { HIPCHK(hipEventRecord(e3, c->stream)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(e1, e2); c->prof_events.emplace_back(e2, e3); }
+    // ... and their tasks
+    if (wide) hipLaunchKernelGGL(thj_k_sj_tasks_list<true>, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, t, x);
+    else hipLaunchKernelGGL(thj_k_sj_tasks_list<false>, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, t, x);
+    if (c->profile) HIPCHK(hipEventRecord(ea1, sa));
+    if (!serial) HIPCHK(hipEventRecord(aev[3], sa));
+    // ---- the flat reads
+    if (b.mate_off) {
+        hipLaunchKernelGGL(thj_k_sj_rescue_scan, dim3(grid), dim3(TPB), 0, sm, g, p, b, sl, rl.seg_cap);
+        hipLaunchKernelGGL(thj_k_sj_rescue_flat, dim3(grid), dim3(TPB), 0, sm, p, b, sl, rl.seg_cap, c->d_cnt);
+    }
+    if (wide) hipLaunchKernelGGL(thj_k_sj_tasks<true>, dim3(grid), dim3(TPB), 0, sm, g, p, b, t, sl);
+    else hipLaunchKernelGGL(thj_k_sj_tasks<false>, dim3(grid), dim3(TPB), 0, sm, g, p, b, t, sl);
+    if (c->profile) { HIPCHK(hipEventRecord(e2, sm)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(ea0, ea1); c->prof_events.emplace_back(serial ? ea1 : e1, e2); }
+    *joined = !serial;
     HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+static int sj_join(thj_ctx* c, int set) { HIPCHK(hipStreamWaitEvent(c->stream, c->aux_ev[4 * set + 3], 0)); return THJ_OK; }
+static int sj_probe(thj_ctx* c) {
     // insert counters for the next run's growth decision (asynchronous)
     if (!c->probe_ev) HIPCHK(hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming));
     if (!c->probe_pending) {
@@ -1452,8 +1423,41 @@ extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const th
     return THJ_OK;
 }
 
+extern "C" int thj_segjuncs_run_async(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db) {
+    if (!c || !tp || !db) { thj_set_error("thj_segjuncs_run_async: null argument"); return THJ_EINVAL; }
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    int rc = check_params(tp, db);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if (db->n_reads == 0) return THJ_OK;
+    if ((rc = maybe_grow_tables(c))) return rc;
+    bool joined = false;
+    if ((rc = sj_launch(c, tp, db, 0, &joined))) return rc;
+    if (joined && (rc = sj_join(c, 0))) return rc;
+    return sj_probe(c);
+}
+
+// Two batches (the two sides of a pass) as one call: the same as two thj_segjuncs_run_async calls in this order, but the second
+// batch's kernels do not wait for the first batch's side chains (the reads with several hits a segment: a long tail of small,
+// latency-bound kernels that leave most of the GPU idle) -- each batch has its own scratch lists and side streams, the event
+// tables take inserts from all of them, and everything is back on the context's stream when the call returns.
+extern "C" int thj_segjuncs_run_pair_async(thj_ctx* c, const thj_params* tp0, const thj_seg_batch* db0, const thj_params* tp1, const thj_seg_batch* db1) {
+    if (!c || !tp0 || !db0 || !tp1 || !db1) { thj_set_error("thj_segjuncs_run_pair_async: null argument"); return THJ_EINVAL; }
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    int rc = check_params(tp0, db0);
+    if (rc || (rc = check_params(tp1, db1))) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = maybe_grow_tables(c))) return rc;
+    bool j0 = false, j1 = false;
+    if (db0->n_reads && (rc = sj_launch(c, tp0, db0, 0, &j0))) return rc;
+    if (db1->n_reads && (rc = sj_launch(c, tp1, db1, 1, &j1))) { if (j0) sj_join(c, 0); return rc; }
+    if (j0 && (rc = sj_join(c, 0))) return rc;
+    if (j1 && (rc = sj_join(c, 1))) return rc;
+    return (db0->n_reads || db1->n_reads) ? sj_probe(c) : THJ_OK;
+}
+
 extern "C" int thj_profile_segjuncs(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
-    // avg_ms[3]: thj_k_sj_flat + thj_k_sj_general + thj_k_segjuncs_shared, the rescue kernels, thj_k_sj_tasks (one triple per thj_segjuncs_run_async)
+    // avg_ms[3]: thj_k_sj_flat; the chain of the reads with several hits a segment (its own stream); rescue scan + flat rescue + tasks
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1464,9 +1468,9 @@ extern "C" int thj_profile_segjuncs(thj_ctx* c, int enable, double* avg_ms, int6
         HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
         sum[i % 3] += ms;
     }
-    for (size_t i = 0; i < c->prof_events.size(); ++i) {        // the inner events are shared by neighbouring intervals
-        c->event_pool.push_back(c->prof_events[i].first);
-        if (i % 3 == 2) c->event_pool.push_back(c->prof_events[i].second);
+    for (size_t i = 0; i < c->prof_events.size(); ++i) {        // (e0, e1), (ea0, ea1), (e1, e2): e1 is in two of them
+        if (i % 3 != 2) c->event_pool.push_back(c->prof_events[i].first);
+        c->event_pool.push_back(c->prof_events[i].second);
     }
     if (launches) *launches = (int64_t)n;
     if (avg_ms) for (int k = 0; k < 3; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
@@ -1722,6 +1726,9 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
             const int rc = x_finish_check(c, ovf);
             if (rc < 0) return rc;
             if (rc > 0) continue;                 // the step was repeated (larger message / larger table): look again
+        } else if (ovf[3]) {
+            thj_set_error("the task list of a thj_segjuncs_run_async call filled up (more than two window / indel tasks per read of the batch): split the batch");
+            return THJ_EOVERFLOW;
         } else if (ovf[0] || ovf[1] || ovf[2]) {
             thj_set_error("event table overflow (junc=%u del=%u ins=%u): call thj_segjuncs_configure with larger capacities and re-run",
                           ovf[0], ovf[1], ovf[2]);

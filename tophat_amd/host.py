@@ -54,7 +54,7 @@ ABI_SYMBOLS = [
     "thj_genome_layout", "thj_genome_pack", "thj_genome_upload", "thj_genome_adopt",
     "thj_reads_pack",
     "thj_batch_upload", "thj_batch_free",
-    "thj_segjuncs_configure", "thj_segjuncs_reset_async", "thj_segjuncs_run_async",
+    "thj_segjuncs_configure", "thj_segjuncs_reset_async", "thj_segjuncs_run_async", "thj_segjuncs_run_pair_async",
     "thj_segjuncs_finish", "thj_segjuncs_download", "thj_segjuncs_device_keys",
     "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
@@ -292,6 +292,13 @@ class Context:
         cp = p.as_ctypes()
         arg = C.byref(batch) if isinstance(batch, CSegBatch) else batch
         _check(self.lib, self.lib.thj_segjuncs_run_async(self._ctx, C.byref(cp), arg), "thj_segjuncs_run_async")
+
+    def run_pair(self, p0: Params, batch0, p1: Params, batch1):
+        """two batches (the two sides of a pass) as one call: see thj_segjuncs_run_pair_async"""
+        c0, c1 = p0.as_ctypes(), p1.as_ctypes()
+        a0 = C.byref(batch0) if isinstance(batch0, CSegBatch) else batch0
+        a1 = C.byref(batch1) if isinstance(batch1, CSegBatch) else batch1
+        _check(self.lib, self.lib.thj_segjuncs_run_pair_async(self._ctx, C.byref(c0), a0, C.byref(c1), a1), "thj_segjuncs_run_pair_async")
 
     def finish(self) -> CCounts:
         cnt = CCounts()
