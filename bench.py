@@ -141,7 +141,14 @@ class ProcControl:
         self.dist, self.rank, self.world = dist, rank, world
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        import datetime
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=int(os.environ.get("THJ_BENCH_JOIN_TIMEOUT", "60"))))
+            dist.barrier()
+        except Exception as e:      # noqa: BLE001  (a peer that never came up: say who is waiting, and where)
+            print("[bench] rank %d of %d could not join the job within %s s at %s:%s (%s)" % (
+                rank, world, os.environ.get("THJ_BENCH_JOIN_TIMEOUT", "60"), os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"], repr(e)[:200]), file=sys.stderr, flush=True)
+            raise SystemExit(4)
 
     def bcast_bytes(self, b, n):
         t = torch.zeros(n, dtype=torch.uint8)
@@ -210,7 +217,11 @@ def parse_args():
                     "this script spawns its N ranks itself; under torchrun (WORLD_SIZE set) it is one of them")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU (BASELINE config 2: 10 M)")
+    ap.add_argument("--config", type=int, choices=[2, 3], default=2,
+                    help="2 (default): BASELINE configs[1] -- 10 M pairs per GPU against the chr20-sized genome, weak scaling.  "
+                         "3: BASELINE configs[2] -- 100 M pairs in all, sharded over the job's GPUs (12.5 M per GPU at --gpus 8), against "
+                         "the 25-contig GRCh38-sized genome: strong scaling over a fixed total.  --pairs overrides the per-GPU count")
+    ap.add_argument("--pairs", type=int, default=None, help="read pairs per GPU (default: 10 M for --config 2, 100 M / GPUs for --config 3)")
     ap.add_argument("--genome-len", type=int, default=CHR20_LEN)
     ap.add_argument("--genome", choices=["chr20", "grch38"], default="chr20",
                     help="chr20: one contig of --genome-len bases (configs[1]); grch38: 25 contigs with the GRCh38 primary-assembly "
@@ -245,14 +256,32 @@ def parse_args():
                          "part of the resident layout, not of a step)")
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="reads per side timed through the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not re-run two steps under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic "
+                    "(the committed table under profiles/ is used instead when the configuration is the one it was taken on)")
     ap.add_argument("--e2e-pairs", type=int, default=10_000_000,
                     help="also run the drop-in executables end to end (files in, files out: the metric as SURVEY 8d words it) on "
                          "generated files of this many pairs; 0 skips the leg.  Reported as the `e2e` object, never as `value`")
     a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", a.gpus))
+    a.pairs_given = a.pairs is not None
+    if a.config == 3:
+        a.genome = "grch38"
+        a.introns = max(a.introns, 300000)
+        if a.pairs is None:
+            a.pairs = 100_000_000 // max(1, world)
+    elif a.pairs is None:
+        a.pairs = 10_000_000
     if a.plain:
         a.multihit_frac = 0.0
         a.indel_frac = 0.0
     return a
+
+
+def rank_commands(n, argv, port):
+    """(command line, environment additions) of each of the n ranks `python bench.py --gpus n` starts: one process per GPU, the
+    variables a launcher would set, rendezvous on 127.0.0.1"""
+    return [([sys.executable, os.path.abspath(__file__)] + list(argv),
+             {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}) for r in range(n)]
 
 
 def spawn_ranks(args):
@@ -263,15 +292,64 @@ def spawn_ranks(args):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    for r, (cmd, env) in enumerate(rank_commands(args.gpus, sys.argv[1:], port)):
+        procs.append(subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    for pr in procs:
+    for r, pr in enumerate(procs):
         pr.wait()
+        if pr.returncode:
+            print("[bench] rank %d of %d exited with code %d" % (r, args.gpus, pr.returncode), file=sys.stderr, flush=True)
         rc = rc or pr.returncode
     sys.exit(rc)
+
+
+def pmc_traffic_in_run(args):
+    """HBM traffic of the kernels, measured in THIS run: the same workload for two steps under `rocprofv3 --kernel-trace --pmc X`,
+    one pass per counter (FETCH_SIZE, WRITE_SIZE; separate passes carrying nothing but --kernel-trace, as MI355X_MICROARCH.md
+    prescribes), per-dispatch averages per kernel in KB.  None when rocprofv3 is not there or a pass fails (the caller falls back
+    to the table committed under profiles/)."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if args.no_pmc or os.environ.get("THJ_BENCH_PMC_CHILD") or not shutil.which("rocprofv3"):
+        return None
+    if any(k.startswith("ROCP") for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None                               # this process is being profiled itself: no profiler inside a profiler
+    fwd = ["--pairs", str(args.pairs), "--genome", args.genome, "--genome-len", str(args.genome_len), "--introns", str(args.introns),
+           "--intron-max", str(args.intron_max), "--exon-len", str(args.exon_len), "--read-len", str(args.read_len),
+           "--multihit-frac", str(args.multihit_frac), "--max-copies", str(args.max_copies), "--indel-frac", str(args.indel_frac),
+           "--fusion-frac", str(args.fusion_frac), "--coverage-search", str(args.coverage_search)]
+    if args.fusion_search:
+        fwd.append("--fusion-search")
+    if args.no_hit_heads:
+        fwd.append("--no-hit-heads")
+    out = {}
+    t0 = time.time()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="thj_pmc_", dir="/tmp")
+        try:
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "res", "--", sys.executable, os.path.abspath(__file__)] + fwd + \
+                  ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--e2e-pairs", "0", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", THJ_BENCH_PMC_CHILD="1"), capture_output=True, text=True, timeout=420)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            rows = sqlite3.connect(dbs[0]).execute("select name, count(*), sum(counter_value) from pmc_events where counter_name = ? group by name", (ctr,)).fetchall()
+            for name, n, sm in rows:
+                m = re.search(r"(thj_k_\w+)(<[^>]*>)?", name)
+                if m and n:      # under the name with its template arguments, and -- the instances together: each is launched once per side -- without
+                    for key in {m.group(1), m.group(1) + (m.group(2) or "")}:
+                        out.setdefault(key, {}).setdefault(ctr, 0.0)
+                        out[key][ctr] += sm / n
+        except (OSError, subprocess.SubprocessError, sqlite3.Error):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return {"kernels": out, "seconds": time.time() - t0,
+            "source": "this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (two passes) -- python bench.py <this workload> --steps 2 --warmup 1"} if out else None
 
 
 _E2E_EARLY = None
@@ -365,15 +443,18 @@ def e2e_leg(args, n_gpus=1):
     import shutil
     import tempfile
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from e2e_bench import run_e2e
+    from e2e_bench import mix_gen_args, run_e2e
+    gen_args = mix_gen_args(args.multihit_frac, args.max_copies, args.indel_frac)      # the same mix as the resident-data line
     d = tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         # the executables drive every GPU they can see (read-id shards round-robin over the contexts): the first n_gpus devices here
         gpu_env = {"HIP_VISIBLE_DEVICES": ",".join(str(k) for k in range(n_gpus))}
-        res = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=gpu_env)
+        res = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=gpu_env, gen_args=gen_args)
         keep = ("pairs", "input_bytes", "gen_seconds", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s",
-                "both_stages_s", "junctions", "junctions_bed_s", "junctions_bed_lines")
-        out = {k: res[k] for k in keep}
+                "both_stages_s", "junctions", "junctions_bed_s", "junctions_bed_lines", "outside_main_s", "span_left_bytes", "span_right_bytes")
+        out = {k: res[k] for k in keep if k in res}
+        out["workload"] = ("configs[1] with SURVEY 8(d)'s mix -- the same as the resident-data line: %g %% of the pairs from a %d-copy repeat family, %g %% deletion reads"
+                           % (100 * args.multihit_frac, args.max_copies, 100 * args.indel_frac)) if gen_args else "configs[1] without the mix (--plain)"
         out["stage_timing"] = {st: [l for l in res.get(st + "_log_tail", []) if l.startswith("[timing]") or l.startswith("[worker-seconds]") or "made on the device" in l]
                                for st in ("segment_juncs", "long_spanning_reads_left", "long_spanning_reads_right")}
         out["value"] = res["pairs"] / res["both_stages_s"]
@@ -413,7 +494,7 @@ def e2e_leg(args, n_gpus=1):
         # the same files again through the HOST's record encoder and compressor (THJ_HOST_BAM=1): at full size the BAM streams inside the
         # two writers' files must be the same bytes (members are cut and deflated differently), the event files the same files
         dev_stream = {n: inflated_sha(n) for n in ("span_left.bam", "span_right.bam")}
-        r2 = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=dict(gpu_env, THJ_HOST_BAM="1"))
+        r2 = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=dict(gpu_env, THJ_HOST_BAM="1"), gen_args=gen_args)
         out["value_host_writer"] = r2["pairs"] / r2["both_stages_s"]
         out["host_writer_seconds"] = [r2["segment_juncs_s"], r2["long_spanning_reads_left_s"], r2["long_spanning_reads_right_s"]]
         out["bam_stream_sha256"] = dev_stream
@@ -544,11 +625,13 @@ def e2e_timed_run_check(d, args, pairs=20000):
     import orc
     from tophat_amd.batch import JUNC_DTYPE, build_seg_batch, build_span_batch, merge_events
     from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from e2e_bench import mix_gen_args
     gen = os.path.join(ROOT, "tools", "bin", "thj_gen")
     t = tempfile.mkdtemp(prefix="thj_e2e_twin_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         subprocess.check_call([gen, "--out", t, "--pairs", str(pairs), "--read-len", str(args.read_len), "--genome-len", str(args.genome_len),
-                               "--introns", str(args.introns), "--text"], stdout=subprocess.DEVNULL)
+                               "--introns", str(args.introns), "--text"] + mix_gen_args(args.multihit_frac, args.max_copies, args.indel_frac), stdout=subprocess.DEVNULL)
         f = lambda n: os.path.join(t, n)      # noqa: E731
         names, _ = parse_header(os.path.join(d, "hdr.sam"))
         same_genome = open(f("ref.fa"), "rb").read(1 << 20) == open(os.path.join(d, "ref.fa"), "rb").read(1 << 20)
@@ -759,6 +842,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     n_ium = int(args.coverage_search * args.pairs)
     cov_found = [0]
     local_juncs = [0]
+    xchg_events = None         # (start, end) events around the exchange step of the timed steps
 
     def step():
         # ---- segment_juncs stage
@@ -780,7 +864,13 @@ def run_rank(args, rank, world, local_rank, control, shared):
             ctx.covsearch_run(min(20, 25 - 2), 50, 20000)
             cov_found[0] = ctx.covsearch_finish()
         if comm is not None:
+            if xchg_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
             comm.events_allgather()                   # ONE ncclAllGather on the context stream, merge kernels behind it
+            if xchg_events is not None:
+                e1.record(stream)
+                xchg_events.append((e0, e1))
         cnt = ctx.finish()                            # the only host round trip of the stage
         if args.fusion_search and args.fusion_frac > 0:
             # segment_juncs --fusion-search: find_fusions over both sides; the (small) list goes to the spanning stage the way the
@@ -809,15 +899,21 @@ def run_rank(args, rank, world, local_rank, control, shared):
         cnt, n_alns = step()
     ctx.profile(True)
     ctx.profile_span(True)
+    xchg_events = [] if comm is not None else None
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
         cnt, n_alns = step()
     barrier()
     elapsed = time.time() - t0
-    kern_ms, launches = ctx.profile(False)
+    kern_ms, launches, sj_stats = ctx.profile(False)
     span_ms, span_launches = ctx.profile_span(False)
+    torch.cuda.synchronize()
     comm_info = comm.info() if comm is not None else None
+    if comm_info is not None and xchg_events:
+        comm_info["us_per_step"] = 1e3 * sum(a.elapsed_time(b) for a, b in xchg_events) / len(xchg_events)      # pack + ncclAllGather + merge kernels, on the context stream
+        comm_info["gathered_bytes_per_step"] = comm_info["bytes_per_rank"] * comm_info["n_ranks"]
+    xchg_events = None
     if use_comm and os.environ.get("THJ_BENCH_VERIFY") == "1":
         # functional check of the exchange step: every rank must hold the same merged sets, no smaller than its own
         ev = ctx.download(cnt)
@@ -844,14 +940,20 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # lines and the read, per indel pair one genome line and the read, and writes 8 B per distinct event emitted
     # the reads with several hits in a segment (stage 1's second group takes them): their count and hit records, per launch
     sj_multi_reads = sj_multi_hits = 0
+    sj_class = [[0.0, 0.0], [0.0, 0.0], [0.0, 0.0]]          # [reads, hits] per launch of the reads with <= 12, <= 32, more hits among them
     for sd in ("left", "right"):
         cells1 = (w[sd]["seg_off"][1:] - w[sd]["seg_off"][:-1]).reshape(args.pairs, nseg)
         mr1 = (cells1.max(dim=1).values > 1)
+        if w[sd].get("mate_off") is not None:                # a read with more than two mate hits goes the general way too
+            mo = w[sd]["mate_off"]
+            mr1 = mr1 | ((mo[1:] - mo[:-1]) > 2)
         sj_multi_reads += int(mr1.sum()) / n_launch
         sj_multi_hits += int(cells1[mr1].sum()) / n_launch
+        nh1 = cells1[mr1].sum(dim=1)
+        for ci, sel in enumerate((nh1 <= 12, (nh1 > 12) & (nh1 <= 32), nh1 > 32)):
+            sj_class[ci][0] += int(sel.sum()) / n_launch
+            sj_class[ci][1] += int(nh1[sel].sum()) / n_launch
     cls_alg = 16.0 * (cnt.n_hits_read / n_launch - sj_multi_hits) + 4.0 * (args.pairs * nseg + 1)
-    # ... that group: the list entry, the CSR row and the hit records of its reads, and its share of the rescue pairs (by read count)
-    multi_share = sj_multi_reads / float(args.pairs)
     task_alg = (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 8.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
     # stage 2, four kernels per launch.  Per finished read: 38 B of read planes, two 64-B genome lines (consistency
@@ -882,13 +984,25 @@ def run_rank(args, rank, world, local_rank, control, shared):
     t3_alg = n_gen * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     # thj_k_segjuncs_rescue: per (hit, mate hit) pair the read, its CSR row + hits, the mate hit and ~3 genome lines of flank
     resc_alg = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 192)
-    multi_alg = sj_multi_reads * (4 + 4.0 * (nseg + 1)) + 16.0 * sj_multi_hits + multi_share * resc_alg
-    task_alg += (1.0 - multi_share) * resc_alg
-    kernels = [
-        {"kernel": "thj_k_sj_flat", "avg_kernel_ms": kern_ms[0], "launches": launches, "algorithmic_bytes_per_launch": cls_alg},
-        {"kernel": "thj_k_sj_general + thj_k_segjuncs_shared + thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "avg_kernel_ms": kern_ms[1], "launches": launches, "algorithmic_bytes_per_launch": multi_alg,
-         "note": "the reads with several hits a segment; runs on a stream of its own beside the next group"},
-        {"kernel": "thj_k_sj_rescue_scan + thj_k_sj_rescue_flat + thj_k_sj_tasks", "avg_kernel_ms": kern_ms[2], "launches": launches, "algorithmic_bytes_per_launch": task_alg},
+    # stage 1's kernels one by one (HIP events around each, on the stream it runs on).  Bytes: the flat kernel streams the CSR and the
+    # hit records of its reads; the kernels of the reads with several hits a segment read the list entry, CSR row and hit records of
+    # theirs (classes by hit count, as thj_k_sj_flat lists them: <= 12, <= 32, more); the rescue pairs and the tasks are split between
+    # the flat reads' kernels and the others' by the counts the kernels keep (flat rescue pairs, tasks in the list)
+    tasks_per_launch = max(1.0, (cnt.n_windows + cnt.n_indel_pairs) / n_launch)
+    list_share = min(1.0, sj_stats["list_tasks"] / tasks_per_launch)
+    resc_pairs = max(1.0, cnt.n_rescue_pairs / n_launch)
+    flat_resc_share = min(1.0, sj_stats["flat_rescue_pairs"] / resc_pairs)
+    per_multi = 4 + 4.0 * (nseg + 1)
+
+    def sj_entries(task_b, resc_b):
+        return [cls_alg, sj_class[0][0] * per_multi + 16.0 * sj_class[0][1], sj_class[1][0] * per_multi + 16.0 * sj_class[1][1],
+                sj_class[2][0] * per_multi + 16.0 * sj_class[2][1], (1.0 - flat_resc_share) * resc_b, list_share * task_b,
+                flat_resc_share * resc_b, (1.0 - list_share) * task_b]
+    kernels = [{"kernel": nm, "avg_kernel_ms": kern_ms[i], "launches": launches, "algorithmic_bytes_per_launch": v}
+               for i, (nm, v) in enumerate(zip(host.Context.SJ_KERNELS, sj_entries(task_alg, resc_alg)))]
+    for i in (1, 2, 3, 4, 5):
+        kernels[i]["stream"] = "side stream: runs beside the flat reads' kernels (the last three entries)"
+    kernels += [
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
         {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
         {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
@@ -909,29 +1023,31 @@ def run_rank(args, rank, world, local_rank, control, shared):
     t2_8d = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read) + done_8d + 64) + 4.0 * n_gen
     t3_8d = n_gen * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64)
     resc_8d = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 128)
-    multi_8d = sj_multi_reads * (4 + 4.0 * (nseg + 1)) + 16.0 * sj_multi_hits + multi_share * resc_8d
-    task_8d += (1.0 - multi_share) * resc_8d
-    for k, b8 in zip(kernels, (cls_8d, multi_8d, task_8d, t0_8d, t1_8d, t2_8d, t3_8d)):
+    for k, b8 in zip(kernels, sj_entries(task_8d, resc_8d) + [t0_8d, t1_8d, t2_8d, t3_8d]):
         k["algorithmic_bytes_8d_per_launch"] = b8
     for k in kernels:
         k["achieved_layout"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0
         k["frac_layout"] = k["achieved_layout"] / HBM_PEAK_GBS
         k["achieved"] = k["algorithmic_bytes_8d_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0
         k["frac"] = k["achieved"] / HBM_PEAK_GBS
-    # HBM traffic from the PMC counters cannot be sampled inside this process; it is collected with
-    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes) on this same command and committed under
-    # profiles/.  It is reported only when the configuration is the one that was profiled.  Per MI355X_MICROARCH.md
+    # HBM traffic from the PMC counters cannot be sampled inside this process: when rocprofv3 is on PATH the same workload is
+    # run again for two steps under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, pmc_traffic_in_run);
+    # otherwise the table committed under profiles/ is used, and only when the configuration is the one it was taken on.  Per MI355X_MICROARCH.md
     # FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950: traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB,
     # traffic_low = (FETCH_SIZE + WRITE_SIZE) KB (exact for narrow accesses; see the calibration note in the profile).
+    traffic_in_run = False
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r03_plain_pmc_traffic.json" if args.multihit_frac == 0 and args.indel_frac == 0 else "r03_pmc_traffic.json"))))
+        pm = pmc_traffic_in_run(args) if rank == 0 and world == 1 else None
+        traffic_in_run = pm is not None
+        if pm is None:
+            pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r04_plain_pmc_traffic.json" if args.multihit_frac == 0 and args.indel_frac == 0 else "r04_pmc_traffic.json"))))
         want_cfg = {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}
         if args.multihit_frac > 0 or args.indel_frac > 0:
             want_cfg.update(multihit_frac=args.multihit_frac, indel_frac=args.indel_frac, max_copies=args.max_copies)
-        if args.read_len == 100 and args.genome == "chr20" and use_heads and not args.fusion_search and not n_ium and pm["config"] == want_cfg:
+        if traffic_in_run or (args.read_len == 100 and args.genome == "chr20" and use_heads and not args.fusion_search and not n_ium and pm["config"] == want_cfg):
             for k in kernels:
                 parts = [pm["kernels"].get(nm) for nm in k["kernel"].split(" + ")]
-                c = None if parts[0] is None else {key: sum(x.get(key, 0.0) for x in parts if x) for key in ("FETCH_SIZE", "WRITE_SIZE")}
+                c = None if not any(parts) else {key: sum(x.get(key, 0.0) for x in parts if x) for key in ("FETCH_SIZE", "WRITE_SIZE")}
                 if c:
                     k["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
                     k["traffic_low"] = (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
@@ -952,7 +1068,9 @@ def run_rank(args, rank, world, local_rank, control, shared):
                      "device-to-device with the junction set; records land in BAM order)"
                      % (("configs[1]" + ("" if args.multihit_frac == 0 and args.indel_frac == 0 else " with SURVEY 8(d)'s mix (%g %% of the pairs from a %d-copy repeat family -- 2 hits a segment for 85 %% of them, 3..8 for 12 %%, 9..40 for 2.7 %%, 41 for 0.3 %% --, "
                                           "%g %% deletion reads)" % (100 * args.multihit_frac, args.max_copies, 100 * args.indel_frac)))
-                        if args.read_len == 100 and args.genome == "chr20" and not n_ium and not args.fusion_search else "shape of another config", args.pairs,
+                        if args.read_len == 100 and args.genome == "chr20" and not n_ium and not args.fusion_search else
+                        ("configs[2]'s shard (100 M pairs over %d GPUs)" % world if args.config == 3 and not args.pairs_given else
+                         "configs[2]'s per-GPU shard at 8 GPUs" if args.config == 3 and args.pairs == 12_500_000 else "shape of another config"), args.pairs,
                         args.read_len, genome_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized (25 contigs)",
                         ", one RCCL all-gather of the event sets inside the C ABI" if use_comm else ""))
     if not use_heads:
@@ -1034,7 +1152,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
             "unit": "read-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.config == 3 and not args.pairs_given else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_text,
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
@@ -1042,7 +1160,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
                        "parallelism": "reads sharded x%d, genome replicated" % world},
             "roofline": {"bound": "hbm", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["achieved"] / HBM_PEAK_GBS, "traffic": dom.get("traffic"), "traffic_low": dom.get("traffic_low"),
-                         "traffic_source": dom.get("traffic_source"), "traffic_measured_in_run": False, "kernel": dom["kernel"],
+                         "traffic_source": dom.get("traffic_source"), "traffic_measured_in_run": bool(traffic_in_run and dom.get("traffic") is not None), "kernel": dom["kernel"],
                          "avg_kernel_ms": dom["avg_kernel_ms"], "launches": dom["launches"],
                          "byte_terms": "SURVEY 8(d): 16 B/hit, packed read, <=128 B genome per window or joined hit, 32+8*ncigar B per alignment",
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_8d_per_launch"],

@@ -231,13 +231,14 @@ int thj_fusion_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch*
 int thj_fusion_finish(thj_ctx* ctx, int64_t* n_fusions);
 int thj_fusion_download(thj_ctx* ctx, thj_fusion* out);
 
-/* Average durations (ms) of the three groups of kernels of a run -- avg_ms[0] `thj_k_sj_flat`;
- * avg_ms[1] the chain of the reads with several hits a segment (`thj_k_sj_general` x 2,
- * `thj_k_segjuncs_shared`, `thj_k_segjuncs_rescue`, `_rescue_shared`), which runs on a stream of
- * its own beside the third; avg_ms[2] `thj_k_sj_rescue_scan`, `thj_k_sj_rescue_flat`,
- * `thj_k_sj_tasks` -- over the runs since the last call, measured with HIP events on the stream
- * each group runs on; also returns the run count.  Enables event recording when `enable` != 0. */
-int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches);
+/* Average durations (ms) of the kernels of a run, measured with HIP events on the stream each runs on (the reads
+ * with several hits a segment have streams of their own beside the flat reads' kernels), over the runs since the
+ * last call (a pair call counts as two).  avg_ms[8]: `thj_k_sj_flat`; `thj_k_sj_general`, first instance; second
+ * instance; `thj_k_segjuncs_shared`; `thj_k_segjuncs_rescue` + `_rescue_shared`; `thj_k_sj_tasks_list`;
+ * `thj_k_sj_rescue_scan` + `thj_k_sj_rescue_flat`; `thj_k_sj_tasks`.  stats[4] (may be null), averages over the
+ * launches whose lists are still there: reads given to `thj_k_segjuncs_shared`, to the second instance of
+ * `thj_k_sj_general`, tasks `thj_k_sj_tasks_list` ran, flat rescue pairs.  Enables event recording when `enable` != 0. */
+int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches, double* stats);
 
 
 /* --------------------------------------------------- juncs_db

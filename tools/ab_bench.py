@@ -5,7 +5,7 @@ import sys, json, subprocess, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for lib in sys.argv[1:]:
     code = ("import sys; sys.path.insert(0, %r); import tophat_amd.host as h; h.LIB_PATH = %r; import bench; "
-            "sys.argv = ['bench.py', '--no-cpu-baseline', '--e2e-pairs', '0'] + %r; bench.main()" % (ROOT, os.path.join(ROOT, "tophat_amd", "csrc", lib), os.environ.get("THJ_AB_ARGS", "").split()))
+            "sys.argv = ['bench.py', '--no-cpu-baseline', '--e2e-pairs', '0', '--no-pmc'] + %r; bench.main()" % (ROOT, os.path.join(ROOT, "tophat_amd", "csrc", lib), os.environ.get("THJ_AB_ARGS", "").split()))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     if not line: print(lib, "FAILED", out.stderr[-300:]); continue

@@ -20,6 +20,16 @@ BIN = os.path.join(ROOT, "tophat_amd", "bin")
 GEN = os.path.join(ROOT, "tools", "bin", "thj_gen")
 
 
+def mix_gen_args(multihit_frac, max_copies, indel_frac):
+    """thj_gen options of SURVEY 8(d)'s mix"""
+    out = []
+    if multihit_frac > 0:
+        out += ["--multihit-frac", repr(float(multihit_frac)), "--max-copies", str(int(max_copies))]
+    if indel_frac > 0:
+        out += ["--indel-frac", repr(float(indel_frac))]
+    return out
+
+
 def _prefix(env, stage):
     """THJ_EXEC_PREFIX='rocprofv3 --kernel-trace --stats -d /tmp/p_{stage} -o res --' runs each executable under a profiler"""
     pre = env.get("THJ_EXEC_PREFIX", "")
@@ -34,7 +44,8 @@ def _run(cmd, env):
         raise RuntimeError("%s did not finish within %s s" % (os.path.basename(cmd[0]), e.timeout))
 
 
-def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False):
+def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False, gen_args=()):
+    """gen_args: further thj_gen options (SURVEY 8d's mix: --multihit-frac F --max-copies C --indel-frac F)"""
     nseg = max(1, read_len // 25)
     d = workdir or tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     env = dict(os.environ, THJ_TIMING="1", **(env_extra or {}))
@@ -42,7 +53,7 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
     t = time.time()
     if not os.path.exists(os.path.join(d, "ref.fa")):
         subprocess.check_call([GEN, "--out", d, "--pairs", str(pairs), "--read-len", str(read_len), "--genome-len", str(genome_len),
-                           "--introns", str(introns)], stdout=subprocess.DEVNULL)
+                           "--introns", str(introns)] + list(gen_args), stdout=subprocess.DEVNULL)
     res["gen_seconds"] = round(time.time() - t, 2)
     res["input_bytes"] = sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".bam"))
 
@@ -66,6 +77,10 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
     if r.returncode != 0:
         raise RuntimeError("segment_juncs failed:\n" + r.stderr[-3000:])
     res["segment_juncs_s"] = round(dt, 3)
+    for l in r.stderr.splitlines():                         # time before main() and after the report: loader, HIP start-up of the static objects, process teardown
+        if "unix time at start / report" in l:
+            a, b = map(float, l.split()[-2:])
+            res["segment_juncs_before_main_after_report_s"] = [round(a - t, 3), round(t + dt - b, 3)]
     # CPU seconds (user + system) of the process and what it waited for; with the output hand-off the working child outlives its parent
     # and is not counted -- run with THJ_NO_HANDOFF=1 for this figure
     res["segment_juncs_cpu_s"] = round(child_cpu() - c0, 3)
@@ -93,6 +108,9 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
         res["span_%s_bytes" % sd] = os.path.getsize(f("span_%s.bam" % sd))
         tot += dt
     res["both_stages_s"] = round(tot, 3)
+    oms = [res.get(k + "_before_main_after_report_s") for k in ("segment_juncs", "long_spanning_reads_left", "long_spanning_reads_right")]
+    if all(oms):
+        res["outside_main_s"] = round(sum(a + b for a, b in oms), 3)          # of both_stages_s: what the three processes spend before main() and after their report
     res["pairs_per_s_both_stages"] = round(pairs / tot)
     # the junction consensus (tophat_reports' part of the metric's "junctions.bed"): timed on its own, not part of both_stages_s
     t = time.time()
@@ -115,8 +133,12 @@ if __name__ == "__main__":
     ap.add_argument("--introns", type=int, default=20000)
     ap.add_argument("--coverage-search", action="store_true")
     ap.add_argument("--keep", default=None)
+    ap.add_argument("--multihit-frac", type=float, default=0.05, help="SURVEY 8(d)'s mix (the default, as bench.py's): share of the pairs from the repeat family")
+    ap.add_argument("--max-copies", type=int, default=41)
+    ap.add_argument("--indel-frac", type=float, default=0.03)
+    ap.add_argument("--plain", action="store_true", help="configs[1] without the mix (rounds 1-3)")
     ap.add_argument("--env", nargs="*", default=[])
     a = ap.parse_args()
     res = run_e2e(a.pairs, a.read_len, a.genome_len, a.introns, workdir=a.keep, env_extra=dict(x.split("=", 1) for x in a.env), keep=bool(a.keep),
-                  coverage_search=a.coverage_search)
+                  coverage_search=a.coverage_search, gen_args=[] if a.plain else mix_gen_args(a.multihit_frac, a.max_copies, a.indel_frac))
     print(json.dumps(res, indent=1))

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = ("import sys; sys.path.insert(0, %r); import tophat_amd.host as h; "
-        "h.LIB_PATH = %r; import bench; sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'] + %r; bench.main()"
+        "h.LIB_PATH = %r; import bench; sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--e2e-pairs', '0', '--no-pmc'] + %r; bench.main()"
         % (ROOT, os.path.join(ROOT, "tophat_amd", "csrc", "libthj_exp.so"), os.environ.get("THJ_EXP_ARGS", "").split()))
 for f in sys.argv[1:]:
     env = dict(os.environ, THJ_EXP_FLAGS=f)

@@ -9,7 +9,7 @@ i=0
 for ctrs in "$@"; do
   out=/tmp/pmc_${tag}_$i
   rm -rf $out
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d $out -o res -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 ${BENCH_ARGS:-} > $out.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $ctrs -d $out -o res -- python $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc ${BENCH_ARGS:-} > $out.log 2>&1)
   db=$(find $out -name '*.db' | head -1)
   echo "# counters: $ctrs" > $root/gpurun_out/pmc_${tag}_$i.txt
   if [ -n "$db" ]; then python $root/tools/rocpd_summary.py $db thj_k >> $root/gpurun_out/pmc_${tag}_$i.txt; else tail -5 $out.log >> $root/gpurun_out/pmc_${tag}_$i.txt; fi

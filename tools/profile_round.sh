@@ -13,11 +13,11 @@ out=$root/gpurun_out
 mkdir -p $out
 timeout 1200 python bench.py $extra > $out/${tag}_bench10M.json 2> $out/${tag}_bench10M.err
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o res -- python $root/bench.py $extra --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 > /tmp/prof_ks.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o res -- python $root/bench.py $extra --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /tmp/prof_ks.log 2>&1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $extra --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0   (MI355X, $tag)";
   echo "# durations in microseconds"; python tools/rocpd_summary.py $(find /tmp/prof_ks -name '*.db' | head -1); } > $out/${tag}_kernel_stats_bench10M.txt
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 > /tmp/prof_f.log 2>&1)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 > /tmp/prof_w.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /tmp/prof_f.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /tmp/prof_w.log 2>&1)
 { echo "# rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline  (separate pass; KB per dispatch)";
   python tools/rocpd_summary.py $(find /tmp/prof_f -name '*.db' | head -1) thj_k;
   echo; echo "# rocprofv3 --pmc WRITE_SIZE --kernel-trace -- (same command, separate pass)";
@@ -26,9 +26,11 @@ python - "$out/${tag}_pmc_fetch_write_bench10M.txt" "$tag" "$cfgx" > $out/${tag}
 import json, re, sys
 ker = {}
 for line in open(sys.argv[1]):
-    m = re.match(r"(?:void )?(thj_k_\w+)(?:<[^>]*>)?\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+\d+\s+[\d.]+\s+([\d.]+)\s*$", line)
-    if m:
-        ker.setdefault(m.group(1), {})[m.group(2)] = float(m.group(3))
+    m = re.match(r"(?:void )?(thj_k_\w+)(<[^>]*>)?\(.*?\s+(FETCH_SIZE|WRITE_SIZE)\s+\d+\s+[\d.]+\s+([\d.]+)\s*$", line)
+    if m:       # under the name with its template arguments, and -- the instances together: each is launched once per side -- without
+        for key in {m.group(1), m.group(1) + (m.group(2) or "")}:
+            d = ker.setdefault(key, {})
+            d[m.group(3)] = d.get(m.group(3), 0.0) + float(m.group(4))
 cfg = json.loads('{"pairs_per_gpu": 10000000, "genome_len": 64444167, "exon_len": 300' + sys.argv[3] + '}')
 print(json.dumps({"config": cfg, "unit": "KB per dispatch",
                   "source": "profiles/%s_pmc_fetch_write_bench10M.txt" % sys.argv[2], "kernels": ker}, indent=1))

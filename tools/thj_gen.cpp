@@ -8,8 +8,17 @@
 // Pair i is a pure function of (seed, i): `--pairs M` writes exactly the first M pairs of any larger run, so a small sample
 // of a big case can be written again in text form (--text: FASTQ + SAM) for the CPU oracle.
 //
+// SURVEY 8(d)'s mix, with the rules of tophat_amd/synth.py:make_device_workload (what bench.py's resident-data line runs):
+//   --multihit-frac F --max-copies C   the first 1/96 of contig 1 stands C times back to back (a repeat family: its copies lie further
+//                                      apart than the longest intron); F of the pairs come from the genes inside the first copy and
+//                                      both their reads report every hit at the first c copies, c = 2 for 85 % of them, 3..8 for 12 %,
+//                                      9..40 for 2.7 %, 41 for 0.3 % (capped at C); the other pairs come from the genes behind the family
+//   --indel-frac F                     F of the other pairs get a left read with 1..3 reference bases missing, one to three bases before
+//                                      the end of a segment: that segment mapped ungapped with the mismatches its last bases then show
+//                                      (absent with more than two), the following segments further on, no whole-read hit
+//
 //   thj_gen --out DIR --pairs N [--genome-len L | --contigs l1,l2,...] [--introns K] [--intron-max M] [--exon-len E]
-//           [--read-len R] [--seed S] [--err 0.01] [--text] [--threads T]
+//           [--read-len R] [--seed S] [--err 0.01] [--multihit-frac F --max-copies C] [--indel-frac F] [--text] [--threads T]
 #include <cmath>
 
 #include "../tophat_amd/csrc/host/thj_hostio.h"
@@ -44,7 +53,7 @@ int main(int argc, char** argv) {
     setenv("THJ_BGZF_LEVEL", "-1", 0);
     std::string out; int64_t pairs = 100000, genome_len = 64444167; std::vector<int64_t> contigs;
     int introns = 20000, intron_max = 200000, exon_len = 300, read_len = 100, seg_len = 25, threads = host_threads();
-    uint64_t seed = 1; double err = 0.01, drop = 0.03; bool text = false;
+    uint64_t seed = 1; double err = 0.01, drop = 0.03, multihit_frac = 0.0, indel_frac = 0.0; bool text = false; int max_copies = 41;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) die("thj_gen: %s needs a value\n", a.c_str()); return argv[++i]; };
@@ -59,6 +68,9 @@ int main(int argc, char** argv) {
         else if (a == "--seed") seed = (uint64_t)atoll(val());
         else if (a == "--err") err = atof(val());
         else if (a == "--drop") drop = atof(val());
+        else if (a == "--multihit-frac") multihit_frac = atof(val());
+        else if (a == "--max-copies") max_copies = atoi(val());
+        else if (a == "--indel-frac") indel_frac = atof(val());
         else if (a == "--threads") threads = atoi(val());
         else if (a == "--text") text = true;
         else die("thj_gen: unknown option %s\n", a.c_str());
@@ -104,6 +116,20 @@ int main(int argc, char** argv) {
         }
     }
     if (genes.empty()) die("thj_gen: no gene fits the genome\n");
+    // the repeat family: copies of the first 1/96 of contig 1, its genes; the genes behind the last copy stay unique, those in between go
+    int64_t dup_shift = 0;
+    std::vector<Gene> fam, uniq;
+    if (multihit_frac > 0) {
+        if (max_copies < 2) die("thj_gen: --max-copies must be at least 2\n");
+        dup_shift = (int64_t)seqs[0].size() / 96;
+        if (dup_shift <= std::max<int64_t>(500000, intron_max + 1) + 2 * exon_len) die("thj_gen: the genome is too small for a repeat family whose copies lie further apart than the longest intron\n");
+        for (int k = 1; k < max_copies; ++k) memcpy(&seqs[0][(size_t)(k * dup_shift)], &seqs[0][0], (size_t)dup_shift);
+        for (const Gene& g : genes) {
+            if (g.contig == 0 && g.a1 + exon_len + 1000 < dup_shift) fam.push_back(g);
+            else if (g.contig != 0 || g.e1 >= (int64_t)max_copies * dup_shift + 1000) uniq.push_back(g);
+        }
+        if (fam.empty() || uniq.empty()) die("thj_gen: the repeat family needs genes inside the first copy and behind the last one\n");
+    }
     std::string cmd = "mkdir -p '" + out + "'";
     if (system(cmd.c_str())) die("thj_gen: cannot create %s\n", out.c_str());
     // FASTA + header
@@ -158,7 +184,17 @@ int main(int argc, char** argv) {
         for (int64_t i = b * BLK; i < std::min(pairs, (b + 1) * BLK); ++i) {
             const long rid = (long)i + 1;
             Rng r(seed * 0x100000001B3ull + (uint64_t)i);
-            const Gene& g = genes[(size_t)r.below(genes.size())];
+            int ncopy = 1;
+            const Gene* gp;
+            if (dup_shift) {
+                const bool is_multi = r.uni() < multihit_frac;
+                gp = is_multi ? &fam[(size_t)r.below(fam.size())] : &uniq[(size_t)r.below(uniq.size())];
+                const double u = r.uni();
+                const int c = u < 0.85 ? 2 : u < 0.97 ? 3 + (int)r.below(6) : u < 0.997 ? 9 + (int)r.below(32) : 41;
+                if (is_multi) ncopy = std::min(c, max_copies);
+            } else gp = &genes[(size_t)r.below(genes.size())];
+            const Gene& g = *gp;
+            const bool del_pair = indel_frac > 0 && nseg >= 3 && ncopy == 1 && r.uni() < indel_frac;
             const std::string& gs = seqs[(size_t)g.contig];
             memcpy(&tx[0], gs.data() + g.e1, (size_t)exon_len);
             memcpy(&tx[(size_t)exon_len], gs.data() + g.a1, (size_t)exon_len);
@@ -175,7 +211,7 @@ int main(int argc, char** argv) {
                 seq = F;
                 if (anti) reverse_complement(seq);
                 const int base_f = sd * (2 + nseg);
-                auto emit = [&](int f, const std::string& qname, uint32_t flag, int contig, int64_t pos0, int len, const std::string& s, bool mapped, const std::string& mdv, int nm) {
+                auto emit1 = [&](int f, const std::string& qname, uint32_t flag, int contig, int64_t pos0, int len, const std::string& s, bool mapped, const std::string& mdv, int nm) {
                     BamWriter::Encoded& e = blk.enc[(size_t)(base_f + f)];
                     const size_t before = e.bytes.size();
                     uint32_t cig = (1u << 28) | (uint32_t)len;
@@ -192,6 +228,30 @@ int main(int argc, char** argv) {
                                   "M\t*\t0\t0\t" + s + "\t" + qual_read.substr(0, (size_t)len) + "\tNM:i:" + std::to_string(nm) + "\tMD:Z:" + mdv + "\n";
                     }
                 };
+                // a read of the family reports every hit at its first ncopy copies (bowtie -k: one record each, the read's records together)
+                auto emit = [&](int f, const std::string& qname, uint32_t flag, int contig, int64_t pos0, int len, const std::string& s, bool mapped, const std::string& mdv, int nm) {
+                    for (int c = 0; c < (mapped ? ncopy : 1); ++c) emit1(f, qname, flag, contig, pos0 + (int64_t)c * dup_shift, len, s, mapped, mdv, nm);
+                };
+                if (del_pair && sd == 0) {
+                    // the deletion read: forward, from the gene's first exon, dl reference bases missing at read offset x
+                    const int64_t pa = g.e1 + (int64_t)r.below((uint64_t)std::max(1, exon_len - read_len - 4));
+                    const int dl = 1 + (int)r.below(3), kb = 1 + (int)r.below((uint64_t)std::max(1, nseg - 2)), m = 1 + (int)r.below(3);
+                    const int x = kb * seg_len - m;
+                    F.resize((size_t)read_len);
+                    for (int k = 0; k < read_len; ++k) F[(size_t)k] = gs[(size_t)(pa + k + (k >= x ? dl : 0))];
+                    emit(0, std::to_string(rid), 4, 0, 0, read_len, F, false, "", 0);
+                    for (int k = 0; k < nseg; ++k) {
+                        const int s0 = k * seg_len, s1 = k == nseg - 1 ? read_len : (k + 1) * seg_len;
+                        const int64_t pos = pa + s0 + (k >= kb ? dl : 0);       // the segment that holds the deletion: in the frame before it
+                        int nm;
+                        md_nm(gs.data() + pos, F.data() + s0, s1 - s0, nm, md);
+                        if (nm > 2) continue;
+                        piece.assign(F, (size_t)s0, (size_t)(s1 - s0));
+                        qn = std::to_string(rid) + "|" + std::to_string(s0) + ":" + std::to_string(k) + ":" + std::to_string(nseg);
+                        emit(2 + k, qn, 0u, g.contig, pos, s1 - s0, piece, true, md, nm);
+                    }
+                    continue;
+                }
                 emit(0, std::to_string(rid), 4, 0, 0, read_len, seq, false, "", 0);
                 // place a transcript interval [a, a + len) contiguously: inside one exon, or overhanging the junction by <= `oh`
                 auto place = [&](int a, int len, const char* bases, int oh, int64_t& pos, int& nm) -> bool {

@@ -108,6 +108,7 @@ struct thj_ctx {
     // profiling
     bool profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    std::vector<hipEvent_t> prof_all; std::vector<int> prof_sets;       // every event of prof_events once; the scratch set of each profiled launch
     std::vector<hipEvent_t> event_pool;
 };
 hipEvent_t thj_get_event(struct thj_ctx* c);

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(TPB) void thj_k_sj_rescue_scan(Genome g, Params p, 
 
 // One thread per flat rescue read: its first-segment hit against the pseudo-hits of its (at most two) mate hits -> window tasks,
 // appended to the slice thj_k_sj_flat's workgroup w filled (thj_k_sj_tasks runs after this kernel).
-__global__ __launch_bounds__(TPB) void thj_k_sj_rescue_flat(Params p, DevBatch b, SjLists sl, int seg_cap, unsigned long long* cnt) {
+__global__ __launch_bounds__(TPB) void thj_k_sj_rescue_flat(Params p, DevBatch b, SjLists sl, int seg_cap, unsigned long long* cnt, unsigned int* n_flat_pairs) {
     __shared__ unsigned int s_ntask, s_stat[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const unsigned int n = sl.frl_cnt[blockIdx.x];
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(TPB) void thj_k_sj_rescue_flat(Params p, DevBatch b
     __syncthreads();
     if (tid == 0) {
         sl.task_cnt[blockIdx.x] = s_ntask;
-        if (s_stat[0]) atomicAdd(&cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[0]);
+        if (s_stat[0]) { atomicAdd(&cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[0]); atomicAdd(n_flat_pairs, s_stat[0]); }
         if (s_stat[1]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[1]);
     }
 }
@@ -1073,7 +1073,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     thj_span_free(c); thj_bamout_free(c);
     cov_free(c);
     hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); hipFree(c->d_infl_tmp); thj_dev_cache_free(c);
-    for (auto& pr : c->prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (hipEvent_t e : c->prof_all) hipEventDestroy(e);
     for (auto e : c->event_pool) hipEventDestroy(e);
     for (int i = 0; i < 4; ++i) if (c->aux_stream[i]) hipStreamDestroy(c->aux_stream[i]);
     for (int i = 0; i < 8; ++i) if (c->aux_ev[i]) hipEventDestroy(c->aux_ev[i]);
@@ -1316,11 +1316,12 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     static const int many_min = getenv("THJ_MANY_HITS") ? atoi(getenv("THJ_MANY_HITS")) : MID_HITS;
     rl.many_min = many_min;
     rl.mid_min = many_min < GEN_HITS ? many_min : GEN_HITS;
-    // [count of the reads with many hits, the count of batches thj_k_segjuncs_shared has drawn, the count of thj_k_sj_general's second list][the two lists]
-    if (!c->d_many[set]) HIPCHK(hipMalloc((void**)&c->d_many[set], 16 + (size_t)MANY_CAP * 8));
+    // [8 words: the count of the reads with many hits, of the batches thj_k_segjuncs_shared has drawn, of thj_k_sj_general's second list, of the tasks in the
+    // list, of the flat rescue pairs][the two lists]
+    if (!c->d_many[set]) HIPCHK(hipMalloc((void**)&c->d_many[set], 32 + (size_t)MANY_CAP * 8));
     rl.many_count = (unsigned int*)c->d_many[set];
-    rl.many_list = c->d_many[set] + 4;
-    HIPCHK(hipMemsetAsync(c->d_many[set], 0, 16, c->stream));
+    rl.many_list = c->d_many[set] + 8;
+    HIPCHK(hipMemsetAsync(c->d_many[set], 0, 32, c->stream));
     HIPCHK(hipMemsetAsync(rl.blk_cnt + grid, 0, 4, c->stream));
     // [16 bytes: the count of listed reads][HEAVY_CAP read indices][HEAVY_CAP slices of GPT pairs' outcomes]
     if (b.mate_off && !c->d_rescue_slots[set]) HIPCHK(hipMalloc((void**)&c->d_rescue_slots[set], 16 + (size_t)HEAVY_CAP * 4 + (size_t)HEAVY_CAP * GPT * 2 * sizeof(int32_t)));
@@ -1356,7 +1357,7 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
         x.e = (uint32_t*)q; q += xcap * 4;
         x.count = (unsigned int*)c->d_many[set] + 3; x.cap = (unsigned int)(xcap < 0xFFFFFFFFull ? xcap : 0xFFFFFFFFull); x.ovf = c->d_ovf + 3;
         sl.task_cnt = (unsigned int*)q; sl.frl_cnt = sl.task_cnt + grid; sl.pair_cnt = sl.frl_cnt + grid; sl.gen_cnt = sl.pair_cnt + grid;
-        sl.mid_count = (unsigned int*)c->d_many[set] + 2; sl.mid_list = c->d_many[set] + 4 + MANY_CAP;
+        sl.mid_count = (unsigned int*)c->d_many[set] + 2; sl.mid_list = c->d_many[set] + 8 + MANY_CAP;      // [4]: the launch's flat rescue pairs (statistics)
     }
     const bool wide = p.segment_length > 32;
     // Two chains after thj_k_sj_flat, side by side on two streams: the flat reads' (rescue scan, rescue enumeration, tasks:
@@ -1371,41 +1372,53 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     }
     hipStream_t sm = c->stream, sa = serial ? c->stream : c->aux_stream[2 * set], sb = serial ? c->stream : c->aux_stream[2 * set + 1];
     hipEvent_t* const aev = c->aux_ev + 4 * set;
-    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, ea0 = nullptr, ea1 = nullptr;
-    if (c->profile) { e0 = thj_get_event(c); e1 = thj_get_event(c); e2 = thj_get_event(c); ea0 = thj_get_event(c); ea1 = thj_get_event(c); HIPCHK(hipEventRecord(e0, sm)); }
+    // profiling: one pair of events around every kernel (pairs of kernels where the second is the first's tail), on the stream it runs on;
+    // SJ_PROF_N intervals per launch, in the order thj_profile_segjuncs documents
+    auto mark = [&](hipStream_t st) -> hipEvent_t { if (!c->profile) return nullptr; hipEvent_t e = thj_get_event(c); hipEventRecord(e, st); c->prof_all.push_back(e); return e; };
+    auto span = [&](hipEvent_t a, hipEvent_t z) { if (c->profile) c->prof_events.emplace_back(a, z); };
+    hipEvent_t m0 = mark(sm);
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_sj_flat<4>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
     else hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
-    if (c->profile) HIPCHK(hipEventRecord(e1, sm));
-    if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); }
+    hipEvent_t m1 = mark(sm);
+    if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); HIPCHK(hipStreamWaitEvent(sb, aev[0], 0)); }
     // ---- the reads with several hits a segment
-    if (c->profile) HIPCHK(hipEventRecord(ea0, sa));
-    if (!serial) HIPCHK(hipStreamWaitEvent(sb, aev[0], 0));
     const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
+    hipEvent_t b0 = mark(sb);
     hipLaunchKernelGGL(thj_k_segjuncs_shared, dim3(rgrid), dim3(TPB), 0, sb, p, b, rl, x, c->d_cnt);     // the reads with many hits: a wave each (the longest of the three: first)
+    hipEvent_t b1 = mark(sb);
     if (!serial) HIPCHK(hipEventRecord(aev[2], sb));
+    hipEvent_t a0 = mark(sa);
     hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
+    hipEvent_t a1 = mark(sa);
     {
         const int mgrid = n_tiles * (TPB / MID_T) < MID_GRID ? n_tiles * (TPB / MID_T) : MID_GRID;
         hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false>), dim3(mgrid), dim3(MID_T), 0, sa, p, b, rl, sl, x, c->d_cnt);
     }
+    hipEvent_t a2 = mark(sa);
     if (!serial) HIPCHK(hipStreamWaitEvent(sa, aev[2], 0));
+    hipEvent_t a3 = mark(sa);                    // (after the wait for thj_k_segjuncs_shared)
     if (b.mate_off) {
         hipLaunchKernelGGL(thj_k_segjuncs_rescue, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, rl, grid + 1, x, c->d_cnt);
         hipLaunchKernelGGL(thj_k_segjuncs_rescue_shared, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, rl, x, c->d_cnt);
     }
+    hipEvent_t a4 = mark(sa);
     // ... and their tasks
     if (wide) hipLaunchKernelGGL(thj_k_sj_tasks_list<true>, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, t, x);
     else hipLaunchKernelGGL(thj_k_sj_tasks_list<false>, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, t, x);
-    if (c->profile) HIPCHK(hipEventRecord(ea1, sa));
+    hipEvent_t a5 = mark(sa);
     if (!serial) HIPCHK(hipEventRecord(aev[3], sa));
     // ---- the flat reads
+    hipEvent_t m2 = mark(sm);
     if (b.mate_off) {
         hipLaunchKernelGGL(thj_k_sj_rescue_scan, dim3(grid), dim3(TPB), 0, sm, g, p, b, sl, rl.seg_cap);
-        hipLaunchKernelGGL(thj_k_sj_rescue_flat, dim3(grid), dim3(TPB), 0, sm, p, b, sl, rl.seg_cap, c->d_cnt);
+        hipLaunchKernelGGL(thj_k_sj_rescue_flat, dim3(grid), dim3(TPB), 0, sm, p, b, sl, rl.seg_cap, c->d_cnt, sl.mid_count + 2);
     }
+    hipEvent_t m3 = mark(sm);
     if (wide) hipLaunchKernelGGL(thj_k_sj_tasks<true>, dim3(grid), dim3(TPB), 0, sm, g, p, b, t, sl);
     else hipLaunchKernelGGL(thj_k_sj_tasks<false>, dim3(grid), dim3(TPB), 0, sm, g, p, b, t, sl);
-    if (c->profile) { HIPCHK(hipEventRecord(e2, sm)); c->prof_events.emplace_back(e0, e1); c->prof_events.emplace_back(ea0, ea1); c->prof_events.emplace_back(serial ? ea1 : e1, e2); }
+    hipEvent_t m4 = mark(sm);
+    span(m0, m1); span(a0, a1); span(a1, a2); span(b0, b1); span(a3, a4); span(a4, a5); span(m2, m3); span(m3, m4);
+    if (c->profile) c->prof_sets.push_back(set);
     *joined = !serial;
     HIPCHK(hipGetLastError());
     return THJ_OK;
@@ -1456,25 +1469,37 @@ extern "C" int thj_segjuncs_run_pair_async(thj_ctx* c, const thj_params* tp0, co
     return (db0->n_reads || db1->n_reads) ? sj_probe(c) : THJ_OK;
 }
 
-extern "C" int thj_profile_segjuncs(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
-    // avg_ms[3]: thj_k_sj_flat; the chain of the reads with several hits a segment (its own stream); rescue scan + flat rescue + tasks
+static constexpr int SJ_PROF_N = 8;
+extern "C" int thj_profile_segjuncs(thj_ctx* c, int enable, double* avg_ms, int64_t* launches, double* stats) {
+    // avg_ms[8], per thj_segjuncs_run_async (a pair call counts as two): thj_k_sj_flat; thj_k_sj_general, first instance; second instance;
+    // thj_k_segjuncs_shared; thj_k_segjuncs_rescue + _rescue_shared; thj_k_sj_tasks_list; thj_k_sj_rescue_scan + thj_k_sj_rescue_flat; thj_k_sj_tasks.
+    // stats[4], averages per launch over the launches whose lists are still there (the last on each scratch set): reads in
+    // thj_k_segjuncs_shared's list, in thj_k_sj_general's second list, tasks in the list thj_k_sj_tasks_list ran, flat rescue pairs.
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    double sum[3] = {0, 0, 0};
-    const size_t n = c->prof_events.size() / 3;
+    double sum[SJ_PROF_N] = {0};
+    const size_t n = c->prof_events.size() / SJ_PROF_N;
     for (size_t i = 0; i < c->prof_events.size(); ++i) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
-        sum[i % 3] += ms;
+        sum[i % SJ_PROF_N] += ms;
     }
-    for (size_t i = 0; i < c->prof_events.size(); ++i) {        // (e0, e1), (ea0, ea1), (e1, e2): e1 is in two of them
-        if (i % 3 != 2) c->event_pool.push_back(c->prof_events[i].first);
-        c->event_pool.push_back(c->prof_events[i].second);
-    }
+    for (hipEvent_t e : c->prof_all) c->event_pool.push_back(e);
     if (launches) *launches = (int64_t)n;
-    if (avg_ms) for (int k = 0; k < 3; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
-    c->prof_events.clear();
+    if (avg_ms) for (int k = 0; k < SJ_PROF_N; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
+    if (stats) {
+        bool used[2] = {false, false};
+        for (int st : c->prof_sets) used[st & 1] = true;
+        double acc[4] = {0, 0, 0, 0}; int ns = 0;
+        for (int st = 0; st < 2; ++st) if (used[st] && c->d_many[st]) {
+            unsigned int h[8];
+            HIPCHK(hipMemcpy(h, c->d_many[st], sizeof h, hipMemcpyDeviceToHost));
+            acc[0] += h[0]; acc[1] += h[2]; acc[2] += h[3]; acc[3] += h[4]; ++ns;
+        }
+        for (int k = 0; k < 4; ++k) stats[k] = ns ? acc[k] / ns : 0.0;
+    }
+    c->prof_events.clear(); c->prof_all.clear(); c->prof_sets.clear();
     c->profile = enable != 0;
     return THJ_OK;
 }

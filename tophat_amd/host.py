@@ -411,13 +411,17 @@ class Context:
         found = self.covsearch_finish(max_cov_juncs)
         return self.download(self.finish()), found
 
-    def profile(self, enable: bool = True) -> Tuple[Tuple[float, float, float], int]:
-        """((classifying kernels ms, rescue kernels ms, thj_k_sj_tasks ms), runs) since the last call"""
-        ms = (C.c_double * 3)()
+    SJ_KERNELS = ("thj_k_sj_flat", "thj_k_sj_general<12, 256, true>", "thj_k_sj_general<32, 64, false>", "thj_k_segjuncs_shared",
+                  "thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "thj_k_sj_tasks_list", "thj_k_sj_rescue_scan + thj_k_sj_rescue_flat",
+                  "thj_k_sj_tasks")
+
+    def profile(self, enable: bool = True):
+        """(ms per launch of each entry of SJ_KERNELS, runs, {reads and tasks of the lists}) since the last call"""
+        ms = (C.c_double * 8)()
+        st = (C.c_double * 4)()
         n = C.c_int64()
-        _check(self.lib, self.lib.thj_profile_segjuncs(self._ctx, 1 if enable else 0, ms, C.byref(n)),
-               "thj_profile_segjuncs")
-        return (ms[0], ms[1], ms[2]), n.value
+        _check(self.lib, self.lib.thj_profile_segjuncs(self._ctx, 1 if enable else 0, ms, C.byref(n), st), "thj_profile_segjuncs")
+        return tuple(ms), n.value, {"many_reads": st[0], "mid_reads": st[1], "list_tasks": st[2], "flat_rescue_pairs": st[3]}
 
     def device_keys(self, kind: int) -> Tuple[int, int]:
         p = C.c_void_p()
