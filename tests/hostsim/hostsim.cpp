@@ -113,7 +113,8 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
     const bool lazy = getenv("THJ_HOSTSIM_LAZY") != nullptr;        // exercise the on-the-fly rescue of rv_foreach
     const bool no_skip = getenv("THJ_HOSTSIM_NO_SKIP") != nullptr;  // run the general enumeration on every read
     const bool no_flat = getenv("THJ_HOSTSIM_NO_FLAT") != nullptr;  // ... also on the reads with at most one hit per segment (the kernels give those to flat_read / flat_rescue)
-    std::vector<int32_t> slots;
+    std::vector<int32_t> slots, mscan;
+    const bool mscan_mode = getenv("THJ_HOSTSIM_MSCAN") != nullptr; // the rescue pairs from one scan per mate hit (ReadView::mscan)
     for (int32_t r = 0; r < b->n_reads; ++r) {
         ReadView v;
         v.hits = (const Hit*)b->hits;
@@ -122,7 +123,7 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
         v.W = b->words_per_plane;
         v.rp = (const u64*)b->read_planes + (int64_t)r * 3 * v.W;
         v.rl = b->read_len[r];
-        v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+        v.mate = nullptr; v.n_mate = 0; v.slots = nullptr; v.mscan = nullptr;
         if (b->mate_off) {
             v.mate = (const Hit*)b->mate_hits + b->mate_off[r];
             v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]);
@@ -143,6 +144,12 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
                         if (slots[2 * (l * v.n_mate + m)] == SLOT_BREAK) break;       // the reference leaves the mate loop here
                     }
                 v.slots = lazy ? nullptr : slots.data();     // lazy: the kernel's fallback when its LDS slot buffer is full
+                if (mscan_mode) {                           // thj_k_segjuncs_rescue_shared: one scan per mate hit, the pairs looked up
+                    mscan.assign((size_t)2 * v.n_mate, SLOT_NONE);
+                    for (int m = 0; m < v.n_mate; ++m)
+                        if (!rescue_scan(g, p, v.rp, v.W, v.rl, v.mate[m], mscan[2 * m], mscan[2 * m + 1]) && mscan[2 * m] != SLOT_BREAK) mscan[2 * m] = SLOT_UNSCANNED;
+                    v.slots = nullptr; v.mscan = mscan.data();
+                }
                 v.lazy_g = &g; v.lazy_p = &p;
                 v.rescue = true;
             }
@@ -192,7 +199,7 @@ extern "C" int hostsim_fusions(const thj_params* tp, const uint64_t* blocks, con
         v.nseg = b->nseg; v.W = b->words_per_plane;
         v.rp = (const u64*)b->read_planes + (int64_t)r * 3 * v.W;
         v.rl = b->read_len[r];
-        v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+        v.mate = nullptr; v.n_mate = 0; v.slots = nullptr; v.mscan = nullptr;
         if (b->mate_off) { v.mate = (const Hit*)b->mate_hits + b->mate_off[r]; v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]); }
         fusion_read(g, p, v, c);
     }

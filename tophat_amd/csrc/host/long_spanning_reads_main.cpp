@@ -613,17 +613,10 @@ static int real_main(int argc, char** argv) {
             // lock: from the mapped files the copy up runs through the runtime's staging buffers at ~3 GB/s while the pool keeps the
             // CPUs busy, from page-locked memory it is DMA
             thj_bam_piece rp = dev_reads ? reads_bam.piece(sh.read_off, sh.read_end) : thj_bam_piece{};
-            uint8_t* stage = nullptr;
-            if (!getenv("THJ_NO_STAGING")) {
-                size_t total = dev_reads ? (size_t)rp.comp_bytes : 0;
-                for (auto& pc : segp) total += (size_t)pc.comp_bytes;
-                stage = (uint8_t*)thj_pinned_alloc(total + 64);
-                if (stage) {
-                    size_t at = 0;
-                    for (auto& pc : segp) { if (pc.comp_bytes) memcpy(stage + at, pc.comp, (size_t)pc.comp_bytes); pc.comp = stage + at; at += (size_t)pc.comp_bytes; }
-                    if (dev_reads) { if (rp.comp_bytes) memcpy(stage + at, rp.comp, (size_t)rp.comp_bytes); rp.comp = stage + at; }
-                }
-            }
+            std::vector<std::pair<const BamFile*, thj_bam_piece*>> to_stage;
+            for (int s = 0; s < nseg; ++s) to_stage.emplace_back(bams[(size_t)s].get(), &segp[(size_t)s]);
+            if (dev_reads) to_stage.emplace_back(&reads_bam, &rp);
+            uint8_t* stage = stage_pieces(to_stage);
             {
                 const long long tw = WorkClock::now();
                 std::lock_guard<std::mutex> lk(gpu.mu);
@@ -892,7 +885,7 @@ static int real_main(int argc, char** argv) {
     auto work = [&]() {
         for (;;) {
             const size_t k = next.fetch_add(1);
-            if (k >= S) return;
+            if (k >= S) { if (!getenv("THJ_NO_DRAIN")) thj_pinned_drain(); return; }     // no shard left to start: page-locked buffers go back as they come free, beside the shards still running
             if (parts == 1) { std::unique_lock<std::mutex> lk(win_mu); win_cv.wait(lk, [&] { return k < writer_pos + LOOKAHEAD; }); }
             run_shard(k);
         }

@@ -53,6 +53,7 @@ struct Shard {
 // BAM inputs mapped once for the device-side ingest (key: file name); a file that is not a BAM, or whose header does not parse,
 // is simply absent and the shards that need it take the host readers
 static std::map<std::string, std::unique_ptr<BamFile>> g_bam;
+static std::mutex g_stage_mu; static std::condition_variable g_stage_cv; static int g_stage_free = 4;      // STAGE_SLOTS (THJ_STAGE_SLOTS)
 static const BamFile* bam_of(const std::string& fn) { auto it = g_bam.find(fn); return it == g_bam.end() ? nullptr : it->second.get(); }
 
 // the reference's shard plan for one side: calculate_offsets over {reads, segment maps} + calculate_offsets_from_ids for the
@@ -140,6 +141,21 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
             thj_params p = o.p;
             p.read_side = read_side;
             const uint32_t b_id = sh.begin_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.begin_id, e_id = sh.end_id > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)sh.end_id;
+            // the shard's compressed pieces into one page-locked buffer, outside the GPU's lock (stage_pieces)
+            std::vector<std::pair<const BamFile*, thj_bam_piece*>> to_stage;
+            for (int s = 0; s < nseg; ++s) to_stage.emplace_back(bam_of(in.segs[(size_t)s]), &segp[(size_t)s]);
+            to_stage.emplace_back(rf, &rp);
+            if (have_mf) to_stage.emplace_back(bam_of(mate->map), &mf);
+            if (have_ml) to_stage.emplace_back(bam_of(mate->segs.back()), &ml);
+            // at most STAGE_SLOTS shards hold a buffer at a time (the others wait here instead of at the GPU's lock): locking pages costs
+            // 0.2 s per GB and stalls the device calls of the other threads while it runs, so the pool must stay at a handful of blocks
+            // that go round -- sixteen workers each locking their own 60 MB made the stage twice as slow as reading the mappings
+            struct Staged {
+                uint8_t* p = nullptr;
+                Staged() { std::unique_lock<std::mutex> lk(g_stage_mu); g_stage_cv.wait(lk, [] { return g_stage_free > 0; }); --g_stage_free; }
+                ~Staged() { thj_pinned_free(p); { std::lock_guard<std::mutex> lk(g_stage_mu); ++g_stage_free; } g_stage_cv.notify_one(); }
+            } staged;
+            staged.p = stage_pieces(to_stage);
             const long long tw = WorkClock::now();
             std::lock_guard<std::mutex> lk(gpu.mu);
             g_work.add(1, tw);
@@ -263,6 +279,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
 }
 
 static int real_main(int argc, char** argv) {
+    if (getenv("THJ_STAGE_SLOTS") && atoi(getenv("THJ_STAGE_SLOTS")) >= 1) g_stage_free = atoi(getenv("THJ_STAGE_SLOTS"));
     fprintf(stderr, "segment_juncs (MI355X-native, %s)\n---------------------------\n", thj_version());
     Opts o;
     int rc = parse_options(argc, argv, o, print_usage);

@@ -9,6 +9,7 @@
 #pragma once
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <dlfcn.h>
 #include <getopt.h>
 #include <stdint.h>
 #include <unistd.h>
@@ -93,7 +94,39 @@ inline int run_with_handoff(int argc, char** argv, int (*body)(int, char**)) {
 }
 // Last call of a body whose outputs are all on disk: report, then leave without the exit handlers (the HIP runtime's would only
 // add to the teardown).  The standard streams go to /dev/null first so that a caller reading our pipes sees their end now.
+// THJ_EXIT_PROBE=1 (developer aid): take the process apart by hand before leaving and say what each part costs -- the file mappings,
+// then everything the HIP runtime holds (hipDeviceReset) -- so that the time a caller sees between the report and the process's end
+// can be put down to one of them
+inline void exit_probe() {
+    if (!getenv("THJ_EXIT_PROBE")) return;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    size_t unmapped = 0;
+    {
+        std::vector<std::pair<uintptr_t, uintptr_t>> maps;
+        if (FILE* f = fopen("/proc/self/maps", "r")) {
+            char line[1024];
+            while (fgets(line, sizeof line, f)) {
+                unsigned long a, b; char perms[8], path[768]; path[0] = 0;
+                if (sscanf(line, "%lx-%lx %7s %*s %*s %*s %767s", &a, &b, perms, path) >= 3 && strstr(path, ".bam")) maps.emplace_back(a, b);
+            }
+            fclose(f);
+        }
+        for (auto& m : maps) { munmap((void*)m.first, m.second - m.first); unmapped += m.second - m.first; }
+    }
+    double t1 = now();
+    typedef int (*reset_fn)();
+    void* h = dlopen("libamdhip64.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("libamdhip64.so.7", RTLD_NOW | RTLD_NOLOAD);
+    reset_fn rf = h ? (reset_fn)dlsym(h, "hipDeviceReset") : nullptr;
+    if (rf) rf();
+    double t2 = now();
+    fprintf(stderr, "[exit-probe] munmap of %.2f GB of .bam mappings %.3f s, hipDeviceReset %.3f s%s\n", unmapped / 1073741824.0, t1 - t0, t2 - t1, rf ? "" : " (not found)");
+    const double nowu = std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "[exit-probe] unix time after the probe %.6f\n", nowu);
+}
 [[noreturn]] inline void finish_outputs_complete(int rc) {
+    exit_probe();
     fflush(nullptr);
     if (handoff_fd() >= 0) {
         const int nul = open("/dev/null", O_RDWR);
@@ -1355,6 +1388,7 @@ inline void register_targets(const std::string& fn, RefTable& rt) {
 // and hand out [member-aligned piece of the mapping, bytes to skip in its first member] for a shard.
 struct BamFile {
     const uint8_t* data = nullptr; size_t size = 0;
+    int fd = -1;                                      // kept open: shard pieces are pread() into page-locked staging buffers (stage_pieces)
     std::vector<std::string> targets;
     std::vector<uint32_t> tid2ref;
     int64_t first_rec_voff = 0;                       // virtual offset of the first alignment record
@@ -1376,8 +1410,8 @@ struct BamFile {
         const off_t sz = lseek(fd, 0, SEEK_END);
         if (sz <= 0) { ::close(fd); return false; }
         void* m = mmap(nullptr, (size_t)sz, PROT_READ, MAP_SHARED, fd, 0);
-        ::close(fd);
-        if (m == MAP_FAILED) return false;
+        if (m == MAP_FAILED) { ::close(fd); return false; }
+        this->fd = fd;
         data = (const uint8_t*)m; size = (size_t)sz;
         // header: inflate members from the start until magic, text, n_ref and the n_ref (name, length) entries are in hand
         std::vector<uint8_t> h;
@@ -1439,11 +1473,43 @@ struct BamFile {
         pc.n_tid = (int32_t)tid2ref.size(); pc.tid2ref = tid2ref.data();
         return pc;
     }
-    ~BamFile() { if (data) munmap((void*)data, size); }
+    ~BamFile() { if (data) munmap((void*)data, size); if (fd >= 0) ::close(fd); }
     BamFile() = default;
     BamFile(const BamFile&) = delete;
     BamFile& operator=(const BamFile&) = delete;
 };
+
+// A shard's compressed pieces, read into ONE page-locked buffer (thj_pinned_alloc; the caller thj_pinned_free()s it once the device
+// has them) and the pieces pointed at it.  pread() from the page cache, not a copy out of the mapping: the bulk of the files then
+// never gets page-table entries in this process (a fault per page on the way in, and 0.06 s per GB to take apart when the process
+// leaves -- more when the runtime had to lock the mapping's pages for its own DMA: 0.16 s of segment_juncs' 0.27 s between its report
+// and its end on 10 M pairs), and the copy up is plain DMA inside the GPU's lock.  Runs outside that lock, beside the other workers.
+// Returns null (pieces untouched: they still point into the mappings) when there is no buffer or a read fails.
+inline uint8_t* stage_pieces(const std::vector<std::pair<const BamFile*, thj_bam_piece*>>& pcs) {
+    if (getenv("THJ_NO_STAGING")) return nullptr;
+    size_t total = 0;
+    for (auto& q : pcs) if (q.first && q.second) total += (size_t)q.second->comp_bytes;
+    uint8_t* stage = (uint8_t*)thj_pinned_alloc(total + 64);
+    if (!stage) return nullptr;
+    size_t at = 0;
+    std::vector<size_t> where;
+    for (auto& q : pcs) {
+        where.push_back(at);
+        if (!q.first || !q.second) continue;
+        const thj_bam_piece& pc = *q.second;
+        size_t done = 0; const size_t n = (size_t)pc.comp_bytes;
+        const off_t off0 = (off_t)(pc.comp - q.first->data);
+        while (done < n) {
+            const ssize_t r = q.first->fd >= 0 ? pread(q.first->fd, stage + at + done, n - done, off0 + (off_t)done) : -1;
+            if (r <= 0) { if (r < 0 && errno == EINTR) continue; break; }
+            done += (size_t)r;
+        }
+        if (done < n) memcpy(stage + at + done, pc.comp + done, n - done);       // (a short read: the rest from the mapping)
+        at += n;
+    }
+    for (size_t i = 0; i < pcs.size(); ++i) if (pcs[i].first && pcs[i].second) pcs[i].second->comp = stage + where[i];
+    return stage;
+}
 
 // ------------------------------------------------------------------ BGZF + BAM writer (samtools-0.1.18 bgzf.c, common.cpp:1000-1173)
 inline int reg2bin(int beg, int end) {                // bam.h bam_reg2bin

@@ -458,7 +458,10 @@ struct ReadView {
     // mates / rescue
     const Hit* mate;          // this read's mate hits (may be null)
     int n_mate;
-    const int32_t* slots;     // this read's rescue slots [n_left*n_mate*2]; null with `rescue` set = compute on the fly
+    const int32_t* slots;     // this read's rescue slots [n_left*n_mate*2]; null with `rescue` set = from mscan, or computed on the fly
+    const int32_t* mscan;     // what rescue_scan left for each mate hit [n_mate*2] (fwd = SLOT_UNSCANNED where it returned false without a break);
+                              // the scan does not look at the left hit, so a read with 40 x 80 pairs needs 80 scans, and the pair (l, m) is the
+                              // contig / strand test of its two hits plus a look-up
     const Genome* lazy_g;     // genome / params for the on-the-fly rescue (only read when slots == null)
     const Params* lazy_p;
     // derived by prepare()
@@ -485,6 +488,11 @@ THJ_HD void rv_foreach(const ReadView& v, int s, F f) {
         for (int m = 0; m < v.n_mate; ++m) {
             int32_t a, b;
             if (v.slots) { a = v.slots[2 * (l * v.n_mate + m)]; b = v.slots[2 * (l * v.n_mate + m) + 1]; }
+            else if (v.mscan) {
+                const Hit lh = v.hits[v.so[0] + l], rh = v.mate[m];
+                a = SLOT_NONE; b = SLOT_NONE;
+                if (lh.ref_id == rh.ref_id && hit_anti(lh) != hit_anti(rh)) { a = v.mscan[2 * m]; b = v.mscan[2 * m + 1]; if (a == -3) a = SLOT_NONE; }      // -3: SLOT_UNSCANNED
+            }
             else rescue_pair(*v.lazy_g, *v.lazy_p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m], a, b);
             if (a == SLOT_BREAK) break;
             if (a >= 0) {

@@ -1724,16 +1724,37 @@ struct PinnedPool {
         blks.push_back({p, cap, true, pinned, ++clock});
         return p;
     }
+    bool draining = false;
     void put(void* p) {
         if (!p) return;
-        std::lock_guard<std::mutex> lk(mu);
-        for (auto& b : blks) if (b.p == p) { b.used = false; return; }
+        Blk gone{nullptr, 0, false, false, 0};
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < blks.size(); ++i) if (blks[i].p == p) {
+                if (!draining) { blks[i].used = false; return; }
+                gone = blks[i]; bytes -= gone.cap; blks.erase(blks.begin() + (ptrdiff_t)i);
+                break;
+            }
+        }
+        if (gone.p) release(gone);                         // outside the lock: unlocking pages takes its time
+    }
+    void drain() {
+        std::vector<Blk> idle;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            draining = true;
+            for (size_t i = 0; i < blks.size();) {
+                if (!blks[i].used) { idle.push_back(blks[i]); bytes -= blks[i].cap; blks.erase(blks.begin() + (ptrdiff_t)i); } else ++i;
+            }
+        }
+        for (auto& b : idle) release(b);
     }
 };
 PinnedPool& pinned_pool() { static PinnedPool* pp = new PinnedPool(); return *pp; }      // never destroyed: the process leaves with _exit
 }  // namespace
 extern "C" void* thj_pinned_alloc(size_t bytes) { return pinned_pool().get(bytes); }
 extern "C" void thj_pinned_free(void* p) { pinned_pool().put(p); }
+extern "C" void thj_pinned_drain(void) { pinned_pool().drain(); }
 
 extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
                                     thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out) {

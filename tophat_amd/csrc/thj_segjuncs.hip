@@ -123,7 +123,7 @@ __device__ __forceinline__ ReadView make_view(const DevBatch& b, int r) {
     v.W = b.W;
     v.rp = b.planes + (size_t)r * 3 * b.W;
     v.rl = b.read_len[r];
-    v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+    v.mate = nullptr; v.n_mate = 0; v.slots = nullptr; v.mscan = nullptr;
     if (b.mate_off) {
         uint32_t m0 = b.mate_off[r], m1 = b.mate_off[r + 1];
         v.mate = b.mate_hits + m0;
@@ -201,7 +201,7 @@ __device__ __forceinline__ ReadView make_task_view(const DevBatch& b, int r) {
     v.W = b.W;
     v.rp = b.planes + (size_t)r * 3 * b.W;
     v.rl = b.read_len[r];
-    v.mate = nullptr; v.n_mate = 0; v.slots = nullptr;
+    v.mate = nullptr; v.n_mate = 0; v.slots = nullptr; v.mscan = nullptr;
     v.size = 0; v.rescue = false; v.check_len = 0;
     return v;
 }
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Params p, DevBat
 // pairs than fit recompute them as rv_foreach walks the pseudo-hit list -- then the general enumeration runs with the
 // rescued hits in place and its windows are queued and executed as in the main kernel.
 static constexpr int RPT = 4;             // rescue pairs per thread kept in LDS
-static constexpr int GPT = 64;            // ... and in the thread's slice of an HBM pool, for reads with more (a read with 41 hits in its first segment: multihits)
+static constexpr int MSCAN = 128;          // mate hits of a read with more pairs that a wave keeps the scans of (thj_k_segjuncs_rescue_shared)
 static constexpr int RESCUE_GRID = 1024;  // workgroups of the rescue kernel at the most
 static constexpr int HEAVY_CAP = 1 << 18;  // rescue reads of one launch that can have a pool slice (the rest recompute their pairs as they go)
 static constexpr int MAX_LISTS = 2048;    // workgroups of the main kernel = slices of the rescue list
@@ -689,7 +689,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             v = make_view(b, r);
             // a read with more pairs than the LDS slots hold (multihits) only has its pairs' outcomes computed here, into its slice of
             // the HBM pool; thj_k_segjuncs_rescue_shared enumerates it with a wave (one thread walking 40 x 40 pairs held its tile up)
-            heavy = (int64_t)rv_count_raw(v, 0) * v.n_mate > RPT && (int64_t)rv_count_raw(v, 0) * v.n_mate <= GPT && !THJ_EXPF(1 << 24);
+            heavy = (int64_t)rv_count_raw(v, 0) * v.n_mate > RPT && v.n_mate <= MSCAN && !THJ_EXPF(1 << 24);
         }
         unsigned int hk = 0;
         {   // positions in the heavy list: one global add per workgroup and round (per read they queued on one address)
@@ -711,13 +711,13 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
             const bool wants = true;
             gaps_prepare_listed(p, v);
             do_gaps = true;
-            if (do_gaps) {
+            if (do_gaps && !heavy) {
                 if (wants) {
                     const int n_left = rv_count_raw(v, 0);
                     // the pairs' outcomes are kept (LDS, or HBM for a read with many hits): gaps_enumerate asks for them once per
                     // (hit, partner) it looks at, and recomputing a flank scan each time made a 16-copy read cost 200 of them
-                    const bool fits = (int64_t)n_left * v.n_mate <= RPT || heavy;
-                    int32_t* mine = heavy ? rl.slot_pool + (size_t)hk * (GPT * 2) : s_slots + tid * RPT * 2;
+                    const bool fits = (int64_t)n_left * v.n_mate <= RPT;          // (more, and more mate hits than a wave's table holds: computed as they are asked for)
+                    int32_t* mine = s_slots + tid * RPT * 2;
                     unsigned int local = 0;
                     // the scan of a mate hit's flank is the same for every left hit on the mate's contig and opposite strand: kept
                     // for the first two mate hits (a read of a repeat family has tens of left hits and one or two mate hits)
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
                     v.slots = fits ? mine : nullptr;
                     v.lazy_g = &s_g; v.lazy_p = &s_p;
                 }
-                if (!heavy && !THJ_EXPF(1 << 23)) gaps_enumerate(p, v, qs);
+                if (!THJ_EXPF(1 << 23)) gaps_enumerate(p, v, qs);
             }
             my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
@@ -783,7 +783,9 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
     // the waves of a workgroup draw the reads of its batch one by one, as in thj_k_segjuncs_shared
     const unsigned int BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;
     __shared__ unsigned int s_next, s_xbase;
-    unsigned int my_windows = 0, my_indels = 0;
+    __shared__ int32_t s_mscan[TPB / 64][2 * MSCAN];
+    const int wave = tid >> 6;
+    unsigned int my_windows = 0, my_indels = 0, my_pairs = 0;
     for (unsigned int base = blockIdx.x * BATCH; base < n; base += gridDim.x * BATCH) {
         __syncthreads();
         if (tid == 0) s_next = 0;
@@ -797,7 +799,33 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
             const int r = (int)rl.heavy_list[h];
             ReadView v = make_view(b, r);
             gaps_prepare_listed(p, v);                             // a listed read takes the rescue: no second partner search
-            v.rescue = true; v.slots = rl.slot_pool + (size_t)h * (GPT * 2); v.lazy_g = &s_g; v.lazy_p = &s_p;
+            // where the read's last bases lie in each mate hit's flank: one scan per mate hit, a lane each -- the scan does not look at
+            // the left hit, so the n_left x n_mate pairs of the reference's loop (:3406-3492) are n_mate scans and a contig / strand test
+            // per pair (until round 4 a read with more than 64 pairs scanned again for every pair its enumeration looked at: 0.3 s per
+            // launch of thj_k_segjuncs_rescue on files with a 41-copy family whose mates carry 82 hits)
+            int32_t* ms = s_mscan[wave];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with the table
+            for (int m = lane; m < v.n_mate; m += 64) {
+                int32_t f, rv;
+                const bool scanned = rescue_scan(g, p, v.rp, v.W, v.rl, v.mate[m], f, rv);
+                if (!scanned && f != SLOT_BREAK) f = SLOT_UNSCANNED;
+                ms[2 * m] = f; ms[2 * m + 1] = rv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            {   // the rescue-pair statistic: the pairs the reference's loop scans (a break ends a left hit's mate loop)
+                const int n_left = rv_count_raw(v, 0);
+                for (int l = lane; l < n_left; l += 64) {
+                    const Hit lh = v.hits[v.so[0] + l];
+                    for (int m = 0; m < v.n_mate; ++m) {
+                        const Hit rh = v.mate[m];
+                        if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) continue;
+                        const int32_t f = ms[2 * m];
+                        if (f == SLOT_BREAK) break;
+                        if (f != SLOT_UNSCANNED) ++my_pairs;
+                    }
+                }
+            }
+            v.rescue = true; v.slots = nullptr; v.mscan = ms; v.lazy_g = &s_g; v.lazy_p = &s_p;
             QueueSink qs{qq, x, (uint32_t)r, 0u, 0u, 0u};
             indels_enumerate(p, v, qs, lane, 64);
             gaps_enumerate(p, v, qs, lane, 64);
@@ -807,10 +835,12 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
     }
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
+    if (my_pairs) atomicAdd(&s_stat[2], my_pairs);
     __syncthreads();
     if (tid == 0) {
         if (s_stat[0]) atomicAdd(&cnt[CNT_WINDOWS], (unsigned long long)s_stat[0]);
         if (s_stat[1]) atomicAdd(&cnt[CNT_INDEL_PAIRS], (unsigned long long)s_stat[1]);
+        if (s_stat[2]) atomicAdd(&cnt[CNT_RESCUE_PAIRS], (unsigned long long)s_stat[2]);
         if (s_stat[3]) atomicAdd(&cnt[CNT_OVF_BLOCKS], (unsigned long long)s_stat[3]);
     }
 }
@@ -1323,11 +1353,11 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     rl.many_list = c->d_many[set] + 8;
     HIPCHK(hipMemsetAsync(c->d_many[set], 0, 32, c->stream));
     HIPCHK(hipMemsetAsync(rl.blk_cnt + grid, 0, 4, c->stream));
-    // [16 bytes: the count of listed reads][HEAVY_CAP read indices][HEAVY_CAP slices of GPT pairs' outcomes]
-    if (b.mate_off && !c->d_rescue_slots[set]) HIPCHK(hipMalloc((void**)&c->d_rescue_slots[set], 16 + (size_t)HEAVY_CAP * 4 + (size_t)HEAVY_CAP * GPT * 2 * sizeof(int32_t)));
+    // [16 bytes: the count of listed reads][HEAVY_CAP read indices]
+    if (b.mate_off && !c->d_rescue_slots[set]) HIPCHK(hipMalloc((void**)&c->d_rescue_slots[set], 16 + (size_t)HEAVY_CAP * 4));
     rl.heavy_count = (unsigned int*)c->d_rescue_slots[set];
     rl.heavy_list = c->d_rescue_slots[set] ? (uint32_t*)c->d_rescue_slots[set] + 4 : nullptr;
-    rl.slot_pool = c->d_rescue_slots[set] ? c->d_rescue_slots[set] + 4 + HEAVY_CAP : nullptr;
+    rl.slot_pool = nullptr;
     if (b.mate_off) HIPCHK(hipMemsetAsync(c->d_rescue_slots[set], 0, 16, c->stream));
     // the flat kernels' lists: a slice per workgroup, each sized for the most its reads can give (a flat read: nseg - 2 indel
     // pairs and nseg - 1 windows, or 2 per mate hit when it takes the rescue) -- sparse in a large allocation, never overflowing
