@@ -289,3 +289,19 @@ def test_long_spanning_reads_fusion_search(name, threads, tmp_path):
         n_xf += sum(1 for rec in recs if any(str(x).startswith("XF:Z:") for x in rec))
         assert gzip.open(bam, "rb").read() == gzip.open(os.path.join(d, "expected.span_%s.bam" % sd), "rb").read()
     assert n_xf >= 40
+
+
+def test_repeated_runs_are_identical_on_the_mix(tmp_path):
+    """SURVEY 8(d)'s mix through both executables (a repeat family of up to 41 copies whose mates carry up to 82 hits, deletion reads:
+    every kernel of stage 1's pipeline and the packed multihit tier have work) six times over: the same event files and the same bytes
+    in the spanning BAM every time -- nothing depends on how the streams, the waves drawing from lists or the workers interleave"""
+    d = str(tmp_path / "mix")
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "thj_gen"), "--out", d, "--pairs", "60000", "--genome-len", "52000000", "--introns", "16000",
+                           "--multihit-frac", "0.08", "--max-copies", "41", "--indel-frac", "0.03", "--threads", "8"], stdout=subprocess.DEVNULL)
+    ref, bam0, _ = _run_both(d, tmp_path, "r0", {"THJ_SHARDS": "7"})
+    first = open(bam0, "rb").read()
+    assert ref["deletions"].count("\n") > 200 and ref["juncs"].count("\n") > 500 and len(first) > 1000000
+    for k in range(1, 6):
+        got, bam, _ = _run_both(d, tmp_path, "r%d" % k, {"THJ_SHARDS": "7"})
+        assert got == ref, k
+        assert open(bam, "rb").read() == first, k

@@ -109,6 +109,21 @@ def test_bam_files_inflate_like_zlib(tmp_path):
                 assert len(w) == isize[k] and got[k] == w, (fn, k)
 
 
+def test_a_launch_of_many_members_goes_through_in_pieces(tmp_path, monkeypatch):
+    """the token scratch between the two inflate kernels is bounded: a launch of more members than a piece holds (THJ_INFLATE_CHUNK, 8192
+    by default) runs piece by piece over the same scratch -- the same bytes"""
+    d = str(tmp_path / "gen")
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "thj_gen"), "--out", d, "--pairs", "20000", "--genome-len", "3000000",
+                           "--introns", "1200", "--threads", "8"], stdout=subprocess.DEVNULL)
+    pl, isize = bgzf_payloads(os.path.join(d, "left_reads.bam"))
+    assert len(pl) > 20
+    monkeypatch.setenv("THJ_INFLATE_CHUNK", "7")
+    with host.Context(0) as ctx:
+        got = inflate(ctx, pl)
+    for k, p in enumerate(pl):
+        assert got[k] == zlib.decompress(p, -15), k
+
+
 def test_two_kernel_inflater_mixed_launch():
     """One launch holding members of every kind at once -- several dynamic blocks per member, fixed and stored blocks, members of more
     symbols than the token stream keeps (those and the stored ones take the one-lane kernel), empty members, corrupt ones -- in an

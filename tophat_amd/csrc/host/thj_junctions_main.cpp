@@ -76,7 +76,9 @@ static int real_main(int argc, char** argv) {
             std::vector<std::string> f = split(xf, ' ');
             if (f.size() < 4) return;
             std::vector<std::string> cs = split(f[1], '-');
-            const uint32_t r1 = cs.size() >= 2 ? rt.get_id(cs[0]) : ((size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0), r2 = cs.size() >= 2 ? rt.get_id(cs[1]) : 0;
+            // fewer than two names in the contig field: the reference keeps the record's own target as the first contig and an empty name as
+            // the second (bwt_map.cpp:1219-1225: text_name / text_name2 stay as they were) and goes on; so does this
+            const uint32_t r1 = cs.size() >= 2 ? rt.get_id(cs[0]) : ((size_t)tid < tid2ref.size() ? tid2ref[(size_t)tid] : 0), r2 = cs.size() >= 2 ? rt.get_id(cs[1]) : rt.get_id(std::string());
             if (!r1 || !r2) return;
             int n = 0; bool spl = false;
             uint32_t op[16];

@@ -406,6 +406,7 @@ THJ_IHD Seg decode_segment(const uint16_t* lit, const uint8_t* A, const uint8_t*
                            uint32_t* tok, uint32_t outp0, const W& wave) {
     Seg r{s, 0, 0, 0};
     if (s >= MARK) return r;                               // the lane before ended the block (or failed): nothing starts here
+    if (s >= limit) { r.e = MARK_ERR; return r; }          // a start past the member's bits (a member of a few bytes cut into 64 segments): nothing to read there
     PIn I; pin_start(I, w, s);
     uint32_t pos = s, nt = 0, ob = 0;
     r.e = MARK_NONE;

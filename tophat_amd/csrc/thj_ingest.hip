@@ -802,30 +802,41 @@ static int launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_bloc
         hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)grid1), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len, (const uint32_t*)nullptr, (const uint32_t*)nullptr);
         return THJ_OK;
     }
-    const size_t need = (size_t)nb * ((size_t)inf2::TOKCAP * 4 + 8) + 256;
+    // the token streams between the two kernels take TOKCAP words per member (more than the member's 64 KiB of output): a launch of
+    // many members goes through in pieces of INFL_CHUNK of them over one scratch buffer, so that the scratch stays bounded (0.7 GB)
+    // whatever the caller hands over
+    const int64_t INFL_CHUNK = getenv("THJ_INFLATE_CHUNK") && atoll(getenv("THJ_INFLATE_CHUNK")) > 0 ? atoll(getenv("THJ_INFLATE_CHUNK")) : 8192;      // (the variable: tests)
+    const int64_t per = nb < INFL_CHUNK ? nb : INFL_CHUNK;
+    const size_t need = (size_t)per * ((size_t)inf2::TOKCAP * 4 + 8) + 256;
     if (c->infl_tmp_cap < need) {
         HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_infl_tmp); c->d_infl_tmp = nullptr; c->infl_tmp_cap = 0;
         HIPCHK(hipMalloc(&c->d_infl_tmp, need + need / 4)); c->infl_tmp_cap = need + need / 4;
     }
     uint32_t* d_tok = (uint32_t*)c->d_infl_tmp;
-    uint32_t* d_ntok = d_tok + (size_t)nb * inf2::TOKCAP;
-    uint32_t* d_fb = d_ntok + nb;
-    uint32_t* d_fbn = d_fb + nb;
-    HIPCHK(hipMemsetAsync(d_fbn, 0, 4, c->stream));
-    const dim3 g((unsigned)((nb + 63) / 64));
-    if (!(force && force[0] == 'm')) {
-        // LDS per wave: the tables + the largest member's compressed bytes (max_in_len = 0: the caller does not know -- 24 KiB, what a
-        // 64 KiB BAM member comes to at worst in practice); members beyond 60 KiB of LDS go to the one-lane kernel
-        uint32_t cap = max_in_len ? max_in_len + 64u : 24576u;
-        cap = (cap + 255u) & ~255u;
-        if (cap > 61440u - 2560u) cap = 61440u - 2560u;
-        hipLaunchKernelGGL(thj_k_huffp, dim3((unsigned)nb), dim3(64), (size_t)(inf2::STRIDE_WORDS + 1) * 4 + cap, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len, cap);
+    uint32_t* d_ntok = d_tok + (size_t)per * inf2::TOKCAP;
+    uint32_t* d_fb = d_ntok + per;
+    uint32_t* d_fbn = d_fb + per;
+    for (int64_t at = 0; at < nb; at += per) {
+        const int64_t n = nb - at < per ? nb - at : per;
+        const thj_bgzf_block* blk = d_blocks + at;
+        uint8_t* out = d_out + ((size_t)at << 16);
+        uint32_t* len = d_len + at;
+        HIPCHK(hipMemsetAsync(d_fbn, 0, 4, c->stream));
+        const dim3 g((unsigned)((n + 63) / 64));
+        if (!(force && force[0] == 'm')) {
+            // LDS per wave: the tables + the largest member's compressed bytes (max_in_len = 0: the caller does not know -- 24 KiB, what a
+            // 64 KiB BAM member comes to at worst in practice); members beyond 60 KiB of LDS go to the one-lane kernel
+            uint32_t cap = max_in_len ? max_in_len + 64u : 24576u;
+            cap = (cap + 255u) & ~255u;
+            if (cap > 61440u - 2560u) cap = 61440u - 2560u;
+            hipLaunchKernelGGL(thj_k_huffp, dim3((unsigned)n), dim3(64), (size_t)(inf2::STRIDE_WORDS + 1) * 4 + cap, c->stream, d_comp, blk, (int)n, d_tok, d_ntok, len, cap);
+        }
+        else if (lpw == 16) hipLaunchKernelGGL(thj_k_huff<16>, g, dim3(256), 0, c->stream, d_comp, blk, (int)n, d_tok, d_ntok, len);
+        else if (lpw == 32) hipLaunchKernelGGL(thj_k_huff<32>, g, dim3(128), 0, c->stream, d_comp, blk, (int)n, d_tok, d_ntok, len);
+        else hipLaunchKernelGGL(thj_k_huff<64>, g, dim3(64), 0, c->stream, d_comp, blk, (int)n, d_tok, d_ntok, len);
+        hipLaunchKernelGGL(thj_k_lz, dim3((unsigned)n), dim3(64), 0, c->stream, d_tok, d_ntok, (int)n, out, len, d_fb, d_fbn);
+        hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)(n < 256 ? n : 256)), dim3(64), 0, c->stream, d_comp, blk, (int)n, out, len, (const uint32_t*)d_fb, (const uint32_t*)d_fbn);
     }
-    else if (lpw == 16) hipLaunchKernelGGL(thj_k_huff<16>, g, dim3(256), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
-    else if (lpw == 32) hipLaunchKernelGGL(thj_k_huff<32>, g, dim3(128), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
-    else hipLaunchKernelGGL(thj_k_huff<64>, g, dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_tok, d_ntok, d_len);
-    hipLaunchKernelGGL(thj_k_lz, dim3((unsigned)nb), dim3(64), 0, c->stream, d_tok, d_ntok, (int)nb, d_out, d_len, d_fb, d_fbn);
-    hipLaunchKernelGGL(thj_k_inflate, dim3((unsigned)(nb < 256 ? nb : 256)), dim3(64), 0, c->stream, d_comp, d_blocks, (int)nb, d_out, d_len, (const uint32_t*)d_fb, (const uint32_t*)d_fbn);
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
