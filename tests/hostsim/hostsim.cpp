@@ -40,15 +40,12 @@ struct DecodeEmit {
     const Genome& g; const Params& p; const ReadView& v; Collect& c; uint32_t ordinal;
     void task(bool valid, uint32_t a, uint32_t b, uint32_t cc, uint32_t d) {
         if (!valid) return;
-        const bool anti = (a >> 9) & 1u;
-        if (a & (1u << 8)) {
-            const bool is_del = (a >> 10) & 1u;
-            const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
-            indel_exec(g, p, v, i, b, cc, anti, plen, is_del, ins_prio(ordinal, i, (int)(d & 0xFFFF), (int)(d >> 16)), c);
-        } else {
-            const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
-            window_exec(g, p, v, b, (int32_t)cc, (int32_t)d, anti, start, slen, c);
-        }
+        const bool anti = task_anti(a);
+        if (task_is_indel(a)) {
+            const int i = task_indel_i(a);
+            indel_exec(g, p, v, i, b, cc, anti, task_indel_plen(a), task_is_del(a), ins_prio(ordinal, i, (int)(d & 0xFFFF), (int)(d >> 16)), c);
+        } else
+            window_exec(g, p, v, b, (int32_t)cc, (int32_t)d, anti, task_window_start(a), task_window_slen(a), c);
     }
 };
 
@@ -129,7 +126,9 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
             v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]);
         }
         ExecSink sink{g, p, v, c, b->ordinal_base + (uint32_t)r};
-        if (!no_flat && (v.nseg <= 4 ? flat_path<4>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial) : flat_path<8>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial))) continue;
+        if (!no_flat && (v.nseg <= 4 ? flat_path<4>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial)
+                         : v.nseg <= 8 ? flat_path<8>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial)
+                         : flat_path<16>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial))) continue;
         if (!no_skip && read_is_trivial(p, v)) { ++n_trivial; continue; }      // nothing can come out of this read
         indels_enumerate(p, v, sink);
         bool wants;

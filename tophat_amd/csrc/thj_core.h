@@ -689,6 +689,21 @@ THJ_HD bool read_is_trivial(const Params& p, const ReadView& v) {
 // the task words are those of the kernels' queues (QueueSink in thj_segjuncs.hip).  Hit indices are batch indices: with one hit
 // per segment the hit of segment s is so[s].  Must equal indels_enumerate + gaps_prepare + gaps_enumerate on such reads
 // (tests/hostsim runs both).  The mate-anchored rescue (res.rescue) is left to the caller; nothing of find_gaps is emitted then.
+// The first word of a queued task (the kernels' LDS queues and HBM task lists; words b..d: the contig / the two hit indices, the window's
+// ends / li | ri << 16).  Reads of up to 16 segments and 512 bases: a window's support read starts below 512 (9 bits) and is at most
+// L + 16 <= 80 bases long (7 bits); an indel pair is one of 14 (4 bits) and its read piece at most 2L <= 128 bases (8 bits).
+THJ_HD uint32_t task_window_word(bool anti, int start, int slen) { return (anti ? 1u << 9 : 0u) | ((uint32_t)(start & 511) << 10) | ((uint32_t)(slen & 127) << 19); }
+THJ_HD uint32_t task_indel_word(bool anti, bool is_del, int i, int plen) {
+    return (1u << 8) | (anti ? 1u << 9 : 0u) | (is_del ? 1u << 10 : 0u) | ((uint32_t)(i & 15) << 11) | ((uint32_t)(plen & 255) << 15);
+}
+THJ_HD bool task_is_indel(uint32_t a) { return (a & (1u << 8)) != 0; }
+THJ_HD bool task_anti(uint32_t a) { return ((a >> 9) & 1u) != 0; }
+THJ_HD bool task_is_del(uint32_t a) { return ((a >> 10) & 1u) != 0; }
+THJ_HD int task_indel_i(uint32_t a) { return (int)((a >> 11) & 15u); }
+THJ_HD int task_indel_plen(uint32_t a) { return (int)((a >> 15) & 255u); }
+THJ_HD int task_window_start(uint32_t a) { return (int)((a >> 10) & 511u); }
+THJ_HD int task_window_slen(uint32_t a) { return (int)((a >> 19) & 127u); }
+
 struct FlatResult { bool rescue; int size; int n_windows, n_indels; };
 
 template <int NS, class Emit>
@@ -712,8 +727,7 @@ THJ_HD FlatResult flat_read(const Params& p, int nseg, const uint32_t (&so)[NS +
         const bool is_del = disc > 0 && disc <= p.max_deletion_length;
         const bool is_ins = disc < 0 && disc >= -p.max_insertion_length;
         const bool ok = go && lh.ref_id == rh.ref_id && anti == hit_anti(rh) && (is_del || is_ins);
-        emit.task(ok, (1u << 8) | (anti ? 1u << 9 : 0u) | (is_del ? 1u << 10 : 0u) | ((uint32_t)i << 11) | ((uint32_t)(plen & 255) << 14),
-                  anti ? so[i + 1] : so[i], anti ? so[i] : so[i + 1], 0u);
+        emit.task(ok, task_indel_word(anti, is_del, i, plen), anti ? so[i + 1] : so[i], anti ? so[i] : so[i + 1], 0u);
         res.n_indels += ok ? 1 : 0;
     }
     // the head of find_gaps: trailing-empty trim, the single-segment return, the partner test of first against last segment
@@ -760,7 +774,7 @@ THJ_HD FlatResult flat_read(const Params& p, int nseg, const uint32_t (&so)[NS +
         if (!banti) { wl = bh.right - 8; if (wl < 0) wl = 0; wr = d.left + 8; }   // :3589-3594
         else { wl = d.right - 8; wr = bh.left + 8; }                              // :3596-3604
         const bool ok = has && !found && (drs || rrs) && start >= 0 && slen >= 0;
-        emit.task(ok, (banti ? 1u << 9 : 0u) | ((uint32_t)(start & 255) << 10) | ((uint32_t)(slen & 127) << 18), bh.ref_id, (uint32_t)wl, (uint32_t)wr);
+        emit.task(ok, task_window_word(banti, start, slen), bh.ref_id, (uint32_t)wl, (uint32_t)wr);
         res.n_windows += ok ? 1 : 0;
     }
     return res;
@@ -822,7 +836,7 @@ THJ_HD int flat_rescue(const Params& p, bool has0, const Hit& bh, int size, int 
         if (!banti) { wl = bh.right - 8; if (wl < 0) wl = 0; wr = pleft + 8; }
         else { wl = pright - 8; wr = bh.left + 8; }
         const bool ok = ok_all && inr[k];
-        emit.task(ok, (banti ? 1u << 9 : 0u) | ((uint32_t)(start & 255) << 10) | ((uint32_t)(slen & 127) << 18), bh.ref_id, (uint32_t)wl, (uint32_t)wr);
+        emit.task(ok, task_window_word(banti, start, slen), bh.ref_id, (uint32_t)wl, (uint32_t)wr);
         n_windows += ok ? 1 : 0;
     }
     return pairs;
@@ -953,11 +967,13 @@ THJ_HD void window_exec(const Genome& g, const Params& p, const ReadView& v, uin
     }
 }
 
-// insertion priority = visiting order inside one batch: read ordinal, segment pair, li, ri
+// insertion priority = visiting order inside one batch: read ordinal (< 2^29), segment pair (< 16), li, ri: 45 bits.  In the
+// insertion table it sits above the inserted bases: value = prio << INS_SEQ_BITS | bases (3 bits each, at most 6 of them).
+static constexpr int INS_SEQ_BITS = 18;
 THJ_HD u64 ins_prio(uint32_t ordinal, int i, int li, int ri) {
     if (li > 63) li = 63;     // bowtie2 runs with -k 41 (tophat.py:2294): never reached in practice
     if (ri > 63) ri = 63;
-    return ((u64)ordinal << 15) | ((u64)(i & 7) << 12) | ((u64)li << 6) | (u64)ri;
+    return ((u64)ordinal << 16) | ((u64)(i & 15) << 12) | ((u64)li << 6) | (u64)ri;
 }
 
 
@@ -1161,7 +1177,7 @@ THJ_HD u64 junc_key(const Genome& g, uint32_t ref_id, uint32_t left, uint32_t ri
     u64 len = (u64)(right - left) & ((1ull << 29) - 1);
     return (gpos << 30) | (len << 1) | (anti ? 1ull : 0ull);
 }
-// insertion key: [gpos(left)+1 : 34][len : 4]; value: [prio : 44][seq : 20] (atomicMin => first wins)
+// insertion key: [gpos(left)+1 : 34][len : 4]; value: [prio : 46][seq : 18] (atomicMin => first wins)
 THJ_HD u64 ins_key(const Genome& g, uint32_t ref_id, uint32_t left, int len) {
     u64 gpos = (u64)g.contig_blk[ref_id - 1] * 64ull + (u64)(int64_t)(int32_t)left + 1ull;
     return (gpos << 4) | (u64)(len & 15);

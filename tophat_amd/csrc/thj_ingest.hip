@@ -1444,6 +1444,7 @@ extern "C" int thj_ingest_seg_batch(thj_ctx* c, const thj_params* tp, int32_t ns
                                     const thj_bam_piece* mate_last, const thj_bam_piece* reads, uint32_t begin_id, uint32_t end_id, int32_t include_top0,
                                     uint32_t ordinal_base, thj_seg_batch** out, int64_t* n_reads_out) {
     using namespace ing;
+    if (nseg > 8 && nseg <= 16) { thj_set_error("reads of more than eight segments"); return THJ_EFALLBACK; }       // the host readers take them (the kernels do up to 16)
     if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out) { thj_set_error("thj_ingest_seg_batch: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     *out = nullptr;
@@ -1769,6 +1770,7 @@ extern "C" void thj_pinned_drain(void) { pinned_pool().drain(); }
 
 extern "C" int thj_ingest_span_hits(thj_ctx* c, const thj_params* tp, int32_t nseg, const thj_bam_piece* segs, uint32_t begin_id, uint32_t end_id,
                                     thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out) {
+    if (nseg > 8 && nseg <= 16) { thj_set_error("reads of more than eight segments"); return THJ_EFALLBACK; }
     if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !out || !row_ids || !n_rows_out) { thj_set_error("thj_ingest_span_hits: bad argument"); return THJ_EINVAL; }
     return span_ingest_impl(c, tp, nseg, segs, nullptr, begin_id, end_id, out, row_ids, n_rows_out, nullptr, nullptr, nullptr);
 }
@@ -1776,6 +1778,7 @@ extern "C" int thj_ingest_span_batch(thj_ctx* c, const thj_params* tp, int32_t n
                                      uint32_t end_id, thj_span_batch** out, uint32_t** row_ids, int64_t* n_rows_out, uint8_t** reads_infl,
                                      int64_t* reads_infl_bytes, uint32_t** row_loc) {
     const int host_copy = (reads_infl != nullptr) + (reads_infl_bytes != nullptr) + (row_loc != nullptr);       // all three or none
+    if (nseg > 8 && nseg <= 16) { thj_set_error("reads of more than eight segments"); return THJ_EFALLBACK; }
     if (!c || !tp || nseg < 1 || nseg > 8 || !segs || !reads || !out || !row_ids || !n_rows_out || (host_copy != 0 && host_copy != 3)) {
         thj_set_error("thj_ingest_span_batch: bad argument"); return THJ_EINVAL;
     }

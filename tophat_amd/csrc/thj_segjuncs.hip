@@ -96,7 +96,7 @@ struct EventSink {
         set_insert(t.del, t.del_mask, junc_key(g, ref, l, r, false), &t.cnt[CNT_DEL], &t.ovf[1], t.del_list);
     }
     __device__ __forceinline__ void insertion(uint32_t ref, uint32_t l, int len, uint32_t seq, u64 prio) {
-        map_insert_min(t.ins_key, t.ins_val, t.ins_mask, ins_key(g, ref, l, len), (prio << 20) | (u64)(seq & 0xFFFFFu),
+        map_insert_min(t.ins_key, t.ins_val, t.ins_mask, ins_key(g, ref, l, len), (prio << INS_SEQ_BITS) | (u64)(seq & ((1u << INS_SEQ_BITS) - 1u)),
                        &t.cnt[CNT_INS], &t.ovf[2], t.ins_list);
     }
 };
@@ -168,12 +168,11 @@ struct QueueSink {
     }
     __device__ __forceinline__ void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) {
         ++n_windows;
-        push((anti ? 1u << 9 : 0u) | ((uint32_t)start << 10) | ((uint32_t)slen << 18), ref, (uint32_t)wl, (uint32_t)wr);
+        push(task_window_word(anti, start, slen), ref, (uint32_t)wl, (uint32_t)wr);
     }
     __device__ __forceinline__ void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) {
         ++n_indels;
-        push((1u << 8) | (anti ? 1u << 9 : 0u) | (is_del ? 1u << 10 : 0u) | ((uint32_t)i << 11) | ((uint32_t)plen << 14),
-             lidx + hbase, ridx + hbase, (uint32_t)li | ((uint32_t)ri << 16));
+        push(task_indel_word(anti, is_del, i, plen), lidx + hbase, ridx + hbase, (uint32_t)li | ((uint32_t)ri << 16));
     }
 };
 // every thread of the workgroup, in converged code: the round's queue to the list
@@ -324,7 +323,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_sj_flat(Params p, DevBatch b, Re
         // the mate-anchored rescue: a read without a hit in its first segment has no pair to scan and nothing to enumerate
         const bool resc_flat = res.rescue && so[1] != so[0];
         const unsigned int fk = wave_slot(resc_flat, &s_n[1], below);
-        if (resc_flat) sl.frl[slice + fk] = (uint32_t)r | ((uint32_t)(res.size - 1) << 29);
+        if (resc_flat) sl.frl[slice + fk] = (uint32_t)r | ((uint32_t)(res.size - 1 < 7 ? res.size - 1 : 7) << 29);      // (only sizes 2 and 3 give windows: flat_rescue)
 #pragma unroll
         for (int m = 0; m < FLAT_MATES; ++m) {
             const bool want = resc_flat && m < n_mate;
@@ -372,16 +371,13 @@ template <bool WIDE>
 __device__ __forceinline__ void exec_task(const Genome& g, const Params& p, const DevBatch& b, EventSink& ev, const uint4 q, const int tr) {
     ReadView tv = make_task_view(b, tr);
     const uint32_t a = q.x;
-    const bool anti = (a >> 9) & 1u;
-    if (a & (1u << 8)) {
-        const bool is_del = (a >> 10) & 1u;
-        const int i = (int)((a >> 11) & 7u), plen = (int)((a >> 14) & 255u);
-        indel_exec<WIDE>(g, p, tv, i, q.y, q.z, anti, plen, is_del,
+    const bool anti = task_anti(a);
+    if (task_is_indel(a)) {
+        const int i = task_indel_i(a);
+        indel_exec<WIDE>(g, p, tv, i, q.y, q.z, anti, task_indel_plen(a), task_is_del(a),
                    ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(q.w & 0xFFFF), (int)(q.w >> 16)), ev);
-    } else {
-        const int start = (int)((a >> 10) & 255u), slen = (int)((a >> 18) & 127u);
-        window_exec<WIDE>(g, p, tv, q.y, (int32_t)q.z, (int32_t)q.w, anti, start, slen, ev);
-    }
+    } else
+        window_exec<WIDE>(g, p, tv, q.y, (int32_t)q.z, (int32_t)q.w, anti, task_window_start(a), task_window_slen(a), ev);
 }
 // The tasks of the flat kernels, one thread each: workgroup w takes slice w.
 template <bool WIDE>
@@ -481,12 +477,12 @@ static constexpr int GEN_HITS = 12;        // hits of a read the first instance 
 static constexpr int MID_HITS = 32;        // ... the second (more: thj_k_segjuncs_shared, or rl.many_min if that is smaller)
 static constexpr int MID_T = 64;
 static constexpr int MID_GRID = 2048;
-template <int HITS, int T, bool SLICED>
+template <int HITS, int T, bool SLICED, int SO>
 __global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, RescueList rl, SjLists sl, XTasks x, unsigned long long* cnt) {
     constexpr int STRIDE = HITS + 1;       // uint4 per thread (an odd count: the threads of a wave spread over the banks)
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
     __shared__ uint4 s_hits[T * STRIDE];
-    __shared__ uint32_t s_so[T * 9];
+    __shared__ uint32_t s_so[T * SO];                       // SO: words of a read's CSR row (nseg + 1 <= 9, or <= 17 for reads of more than eight segments)
     __shared__ unsigned int q_n, s_nresc, s_base[3], s_xbase;
     __shared__ unsigned int s_stat[4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -514,9 +510,9 @@ __global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, Resc
             v = make_view(b, r);
             const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
             if (nh <= (uint32_t)HITS) {              // (a read a full list left here has more: it walks its hits in HBM)
-                for (int i = 0; i <= v.nseg; ++i) s_so[tid * 9 + i] = v.so[i] - h0;
+                for (int i = 0; i <= v.nseg; ++i) s_so[tid * SO + i] = v.so[i] - h0;
                 for (uint32_t i = 0; i < nh; ++i) s_hits[tid * STRIDE + i] = ((const uint4*)b.hits)[h0 + i];
-                v.so = s_so + tid * 9; v.hits = (const Hit*)(s_hits + tid * STRIDE); hbase = h0;
+                v.so = s_so + tid * SO; v.hits = (const Hit*)(s_hits + tid * STRIDE); hbase = h0;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the copy is read back as Hit records
@@ -564,7 +560,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Params p, DevBat
     __shared__ unsigned int q_n;
     __shared__ unsigned int s_stat[4];
     __shared__ Hit s_h[TPB / 64][MANY_HITS_LDS];
-    __shared__ uint32_t s_o[TPB / 64][12];
+    __shared__ uint32_t s_o[TPB / 64][20];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) q_n = 0;
@@ -596,7 +592,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Params p, DevBat
             uint32_t hbase = 0;
             const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with s_h
-            if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 12) {                 // the hits and their offsets into LDS
+            if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 20) {                 // the hits and their offsets into LDS
                 for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
                 if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1169,7 +1165,7 @@ struct OwnedBatch {
 
 extern "C" int thj_batch_upload(thj_ctx* c, const thj_seg_batch* h, int64_t n_hits, int64_t n_mate_hits, thj_seg_batch** out) {
     if (!c || !h || !out) { thj_set_error("thj_batch_upload: null argument"); return THJ_EINVAL; }
-    if (h->n_reads < 0 || h->nseg < 1 || h->nseg > 8 || h->words_per_plane < 1) { thj_set_error("thj_batch_upload: bad shape (nseg must be 1..8)"); return THJ_EINVAL; }
+    if (h->n_reads < 0 || h->nseg < 1 || h->nseg > 16 || h->words_per_plane < 1) { thj_set_error("thj_batch_upload: bad shape (nseg must be 1..16)"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     OwnedBatch* ob = new OwnedBatch();
     memset(ob, 0, sizeof *ob);
@@ -1267,8 +1263,8 @@ static int check_params(const thj_params* p, const thj_seg_batch* b) {
     if (p->max_insertion_length > 6 || p->max_insertion_length < 0) { thj_set_error("max_insertion_length %d unsupported (0..6)", p->max_insertion_length); return THJ_EINVAL; }
     if (p->max_deletion_length < 0 || p->max_deletion_length > 1000000) { thj_set_error("max_deletion_length out of range"); return THJ_EINVAL; }
     if (p->max_segment_intron + p->segment_length + 64 >= (1 << 29)) { thj_set_error("max_segment_intron too large for the packed key"); return THJ_EINVAL; }
-    if (b->nseg < 1 || b->nseg > 8) { thj_set_error("nseg %d unsupported (1..8)", b->nseg); return THJ_EINVAL; }
-    if (b->words_per_plane < 1 || b->words_per_plane > 4) { thj_set_error("words_per_plane %d unsupported (1..4)", b->words_per_plane); return THJ_EINVAL; }
+    if (b->nseg < 1 || b->nseg > 16) { thj_set_error("nseg %d unsupported (1..16)", b->nseg); return THJ_EINVAL; }
+    if (b->words_per_plane < 1 || b->words_per_plane > 8) { thj_set_error("words_per_plane %d unsupported (1..8: reads of up to 512 bases)", b->words_per_plane); return THJ_EINVAL; }
     if (b->n_reads < 0 || (int64_t)b->n_reads + b->ordinal_base >= (1ll << 29)) { thj_set_error("batch too large: read ordinals must stay below 2^29"); return THJ_EINVAL; }
     return THJ_OK;
 }
@@ -1408,7 +1404,8 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     auto span = [&](hipEvent_t a, hipEvent_t z) { if (c->profile) c->prof_events.emplace_back(a, z); };
     hipEvent_t m0 = mark(sm);
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_sj_flat<4>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
-    else hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
+    else if (b.nseg <= 8) hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
+    else hipLaunchKernelGGL(thj_k_sj_flat<16>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
     hipEvent_t m1 = mark(sm);
     if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); HIPCHK(hipStreamWaitEvent(sb, aev[0], 0)); }
     // ---- the reads with several hits a segment
@@ -1418,11 +1415,13 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     hipEvent_t b1 = mark(sb);
     if (!serial) HIPCHK(hipEventRecord(aev[2], sb));
     hipEvent_t a0 = mark(sa);
-    hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
+    if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 9>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
+    else hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 17>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
     hipEvent_t a1 = mark(sa);
     {
         const int mgrid = n_tiles * (TPB / MID_T) < MID_GRID ? n_tiles * (TPB / MID_T) : MID_GRID;
-        hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false>), dim3(mgrid), dim3(MID_T), 0, sa, p, b, rl, sl, x, c->d_cnt);
+        if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 9>), dim3(mgrid), dim3(MID_T), 0, sa, p, b, rl, sl, x, c->d_cnt);
+        else hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 17>), dim3(mgrid), dim3(MID_T), 0, sa, p, b, rl, sl, x, c->d_cnt);
     }
     hipEvent_t a2 = mark(sa);
     if (!serial) HIPCHK(hipStreamWaitEvent(sa, aev[2], 0));
@@ -1586,7 +1585,7 @@ extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_
     if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
     int rc = check_params(tp, db);
     if (rc) return rc;
-    if (db->words_per_plane > 4) { thj_set_error("reads longer than 256 bases are not supported by the fusion kernel"); return THJ_EINVAL; }
+    if (db->words_per_plane > 4 || db->nseg > 8) { thj_set_error("reads longer than 256 bases or of more than eight segments are not supported by the fusion kernel"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_fus_count) { rc = thj_fusion_reset_async(c); if (rc) return rc; }
     if (db->n_reads == 0) return THJ_OK;
@@ -1882,9 +1881,9 @@ extern "C" int thj_segjuncs_download(thj_ctx* c, thj_junction* juncs, thj_juncti
         int len = (int)(k[i] & 15);
         memset(&ins[i], 0, sizeof ins[i]);
         ins[i].ref_id = ref; ins[i].left = pos;
-        uint32_t seq = (uint32_t)(v[i] & 0xFFFFFu);
+        uint32_t seq = (uint32_t)(v[i] & ((1u << INS_SEQ_BITS) - 1u));
         for (int b = 0; b < len && b < 7; ++b) ins[i].seq[b] = code[(seq >> (3 * b)) & 7];
-        ins[i].prio = v[i] >> 20;
+        ins[i].prio = v[i] >> INS_SEQ_BITS;
     }
     return THJ_OK;
 }

@@ -434,7 +434,7 @@ __global__ __launch_bounds__(64) void thj_k_stitch_huge(Genome g, Params p, Span
 __global__ __launch_bounds__(256) void thj_k_ins_split(const u64* keys, const u64* vals, int64_t n, u64* okeys, uint32_t* oseq) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         okeys[i] = keys[i];
-        oseq[i] = (uint32_t)(vals[i] & 0xFFFFFu);
+        oseq[i] = (uint32_t)(vals[i] & ((1u << INS_SEQ_BITS) - 1u));
     }
 }
 
