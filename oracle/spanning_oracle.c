@@ -25,7 +25,7 @@
 #include <string.h>
 
 #define MAXC 24
-#define MAXSEQ 320
+#define MAXSEQ 1024   /* bases of a read (a longer one is skipped); the device path takes up to 512 */
 
 typedef struct {
     uint32_t insert_id;        /* 0 = the empty BowtieHit() */

@@ -308,14 +308,14 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                 if (st == SPAN_INCOMPAT) st = SPAN_OK;
             }
         }
-        if (st == SPAN_NEED_GENERIC) ((mode == 0 || mode == 3) ? multi : gen).push_back((uint32_t)r);
+        if (st == SPAN_NEED_GENERIC) (((mode == 0 || mode == 3) && nseg <= SPAN_MIDSEG) ? multi : gen).push_back((uint32_t)r);      // (reads of more than eight segments skip the packed tier, as in thj_span_run_async)
         else status_counts[st]++;
     }
     if (!multi.empty()) {          // tier 2: the multihit list in batches of 64 entries, lanes as fibers
         int rc;
-        if (mode == 3) rc = run_pack<SPAN_MAXSEG, 6, 20, 64>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
+        if (mode == 3) rc = run_pack<SPAN_MIDSEG, 6, 20, 64>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
         else if (nseg <= 4) rc = run_pack<4, 64, 256, 128>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
-        else rc = run_pack<SPAN_MAXSEG, 64, 256, 128>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
+        else rc = run_pack<SPAN_MIDSEG, 64, 256, 128>(g, p, S, nseg, W, seg_off, hits, planes, read_len, quals, qual_stride, multi, outs, gen);
         if (rc) return rc;
         status_counts[SPAN_OK] += (int64_t)(multi.size() - gen.size());
         std::sort(gen.begin(), gen.end());

@@ -305,3 +305,63 @@ def test_repeated_runs_are_identical_on_the_mix(tmp_path):
         got, bam, _ = _run_both(d, tmp_path, "r%d" % k, {"THJ_SHARDS": "7"})
         assert got == ref, k
         assert open(bam, "rb").read() == first, k
+
+
+def test_reads_of_ten_segments_through_both_executables(tmp_path):
+    """2 x 250 bp at --segment-length 25 (ten segments, four plane words: tophat.py:3486-3492 cuts reads that way): the device-side ingest
+    hands such shards to the host readers, the kernels take them -- event files byte for byte and every spanning record as the oracle has them"""
+    import pathlib
+    import orc
+    from golden_util import events_text
+    from tophat_amd.bamio import read_bam
+    from tophat_amd.batch import build_seg_batch, build_span_batch, events_to_span_inputs, merge_events
+    from tophat_amd.params import Params
+    from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
+    d = str(tmp_path / "long")
+    nseg = 10
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "thj_gen"), "--out", d, "--pairs", "6000", "--genome-len", "4000000", "--introns", "1200",
+                           "--read-len", "250", "--exon-len", "450", "--text", "--threads", "8"], stdout=subprocess.DEVNULL)
+    f = lambda n: os.path.join(d, n)      # noqa: E731
+    segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k + 1)) for k in range(nseg)) for sd in ("left", "right")}
+    out = {k: f("out." + k) for k in ("juncs", "insertions", "deletions", "fusions")}
+    r = subprocess.run([os.path.join(BIN, "segment_juncs"), "--no-coverage-search", "--no-microexon-search", "--segment-length", "25", "--sam-header",
+                        f("hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20", f("ref.fa"), out["juncs"], out["insertions"],
+                        out["deletions"], out["fusions"], f("left_reads.bam"), f("left_map.bam"), segs["left"], f("right_reads.bam"),
+                        f("right_map.bam"), segs["right"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names, _ = parse_header(f("hdr.sam"))
+    _, fa_seqs = read_fasta(f("ref.fa"))
+    seqs = [orc.fold_genome_char(s) for s in fa_seqs]
+    ref_ids = {n: i + 1 for i, n in enumerate(names)}
+    og = orc.Genome(seqs)
+    sides = {}
+    for sd in ("left", "right"):
+        sides[sd] = dict(reads=read_fastq(f("%s.fq" % sd)),
+                         segs=[list(parse_sam_hits(f("%s_seg%d.sam" % (sd, k + 1)), ref_ids, 500000)) for k in range(nseg)],
+                         full=list(parse_sam_hits(f("%s_map.sam" % sd), ref_ids, 500000)))
+    want = None
+    for sd, side, other in (("left", 1, "right"), ("right", 2, "left")):
+        b = build_seg_batch(sides[sd]["segs"], sides[sd]["reads"], sides[other]["full"], sides[other]["segs"][-1])
+        assert b.nseg == nseg
+        e = orc.segjuncs(Params(read_side=side, inner_dist_mean=50, inner_dist_std_dev=20), og, b)
+        want = e if want is None else merge_events(want, e)
+    assert len(want.juncs) > 300
+    wt = events_text(want, names, pathlib.Path(d))
+    for k in ("juncs", "insertions", "deletions"):
+        assert open(out[k]).read() == wt[k], k
+    jj, ii = events_to_span_inputs(want)
+    n_rec = 0
+    for sd in ("left", "right"):
+        bam = f("span_%s.bam" % sd)
+        r = subprocess.run([os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
+                            f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", bam, segs[sd]], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        quals = {k: "I" * len(v) for k, v in sides[sd]["reads"].items()}
+        sb = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], quals)
+        alns = orc.spanning(Params(), og, sb, jj, ii)
+        wrecs = [tuple(str(x) for x in a.sam_fields(int(sb.read_id[a.read_idx]), names)) for a in alns]
+        _, recs = read_bam(bam)
+        grecs = [tuple(str(x) for x in (rr[0], rr[1], rr[2], rr[3], rr[5]) + tuple(rr[8:])) for rr in recs]
+        n_rec += len(grecs)
+        assert grecs == wrecs, sd
+    assert n_rec > 3000

@@ -19,6 +19,13 @@ SPAN_CASES = [
     # short exons: joined alignments with 4+ junctions (more cigar ops than the lean tier holds in registers)
     dict(seed=7, read_len=200, seg_len=25, extra=dict(min_report_intron=30), n_reads=1500,
          gen=dict(exon_range=(26, 40), intron_range=(40, 300), indel_frac=0.2, err=0.003, spliced_seg_frac=1.0)),
+    # more than eight segments / more than 256 bases (2 x 250 bp at --segment-length 25 is ten segments)
+    dict(seed=8, read_len=250, seg_len=25, extra={}, gen=dict(exon_range=(120, 700), boundary_bias=0.5, spliced_seg_frac=0.6, repeat_frac=0.2)),
+    # (a read of 400 bases with 1 % errors has four: --read-mismatches 2 would drop nearly all of them)
+    dict(seed=9, read_len=400, seg_len=25, extra=dict(read_mismatches=8, read_edit_dist=8, read_gap_length=3),
+         gen=dict(exon_range=(150, 900), boundary_bias=0.5, indel_frac=0.2, err=0.004)),
+    dict(seed=10, read_len=500, seg_len=32, extra=dict(read_mismatches=8, read_edit_dist=8),
+         gen=dict(exon_range=(200, 1200), boundary_bias=0.6, spliced_seg_frac=0.5, err=0.003)),
 ]
 
 

@@ -45,4 +45,8 @@ CASES = [
     dict(seed=10, paired=False, read_len=150, seg_len=50, extra={}, gen=dict(indel_frac=0.3)),
     dict(seed=11, paired=True, read_len=200, seg_len=64, extra=dict(inner_dist_mean=50, inner_dist_std_dev=20), gen=dict(indel_frac=0.3, n_frac=0.1)),
     dict(seed=12, paired=False, read_len=160, seg_len=40, extra={}, gen=dict(indel_frac=0.3, err=0.02)),
+    # more than eight segments, more than 256 bases (2 x 250 bp at --segment-length 25: ten segments, tophat.py:3486-3492)
+    dict(seed=13, paired=True, read_len=250, seg_len=25, extra=dict(inner_dist_mean=50, inner_dist_std_dev=20), gen=dict(exon_range=(150, 900), repeat_frac=0.2)),
+    dict(seed=14, paired=False, read_len=400, seg_len=25, extra={}, gen=dict(exon_range=(200, 1200), indel_frac=0.2)),
+    dict(seed=15, paired=True, read_len=500, seg_len=32, extra=dict(inner_dist_mean=80, inner_dist_std_dev=30), gen=dict(exon_range=(200, 1500), err=0.02)),
 ]

@@ -32,7 +32,7 @@ struct thj_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t aux_stream[4] = {}; hipEvent_t aux_ev[8] = {};   // stage 1's side chains, two sets (sj_launch in thj_segjuncs.hip)
+    hipStream_t aux_stream[6] = {}; hipEvent_t aux_ev[10] = {};   // stage 1's side chains, two sets (sj_launch in thj_segjuncs.hip)
     // genome
     const u64* d_blocks = nullptr; bool own_blocks = false;
     uint32_t* d_contig_blk = nullptr; int32_t* d_contig_len = nullptr;

@@ -1805,7 +1805,7 @@ extern "C" int thj_span_batch_reads_host(thj_ctx* c, const thj_span_batch* batch
 // the reads of a batch made by thj_ingest_span_hits, in row order (HOST arrays as thj_reads_pack / thj_span_batch describe them)
 extern "C" int thj_span_batch_attach_reads(thj_ctx* c, thj_span_batch* batch, int32_t words_per_plane, int32_t qual_stride, const uint64_t* planes,
                                            const uint16_t* lens, const uint8_t* quals) {
-    if (!c || !batch || !planes || !lens || !quals || words_per_plane < 1 || words_per_plane > 4 || qual_stride < 0) { thj_set_error("thj_span_batch_attach_reads: bad argument"); return THJ_EINVAL; }
+    if (!c || !batch || !planes || !lens || !quals || words_per_plane < 1 || words_per_plane > 8 || qual_stride < 0) { thj_set_error("thj_span_batch_attach_reads: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     IngestOwnedSpan* ob = (IngestOwnedSpan*)batch;
     const size_t n = (size_t)batch->n_reads;

@@ -1101,8 +1101,8 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); hipFree(c->d_infl_tmp); thj_dev_cache_free(c);
     for (hipEvent_t e : c->prof_all) hipEventDestroy(e);
     for (auto e : c->event_pool) hipEventDestroy(e);
-    for (int i = 0; i < 4; ++i) if (c->aux_stream[i]) hipStreamDestroy(c->aux_stream[i]);
-    for (int i = 0; i < 8; ++i) if (c->aux_ev[i]) hipEventDestroy(c->aux_ev[i]);
+    for (int i = 0; i < 6; ++i) if (c->aux_stream[i]) hipStreamDestroy(c->aux_stream[i]);
+    for (int i = 0; i < 10; ++i) if (c->aux_ev[i]) hipEventDestroy(c->aux_ev[i]);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1312,7 +1312,13 @@ hipEvent_t thj_get_event(thj_ctx* c) {
 // One batch's kernels.  `set` (0 / 1) names the scratch lists and side streams the launch uses: two batches launched one after
 // the other on different sets run their side chains beside each other (thj_segjuncs_run_pair_async); *joined is set when the
 // launch left work on side streams that sj_join has to bring back to the context's stream.
-static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, int set, bool* joined) {
+struct SjState {
+    Genome g; Params p; DevBatch b; Tables t; RescueList rl; SjLists sl; XTasks x;
+    int grid, n_tiles; bool wide, serial;
+    hipStream_t sm, sa, sb, sc; hipEvent_t* aev; hipEvent_t m0, m1;
+};
+// first half: the scratch lists, thj_k_sj_flat on the context's stream, the side streams told to wait for it
+static int sj_launch_flat(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, int set, SjState& st) {
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p;
     memcpy(&p, tp, sizeof p);
@@ -1392,22 +1398,40 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     // thj_k_segjuncs_shared beside thj_k_sj_general's second instance on a third.  Everything is joined on the context's stream
     // again before this function returns; the event tables take inserts from any of them.  THJ_SJ_SERIAL=1: one stream.
     static const bool serial = getenv("THJ_SJ_SERIAL") && atoi(getenv("THJ_SJ_SERIAL")) != 0;
-    if (!serial && !c->aux_stream[2 * set]) {
-        for (int i = 0; i < 2; ++i) HIPCHK(hipStreamCreateWithFlags(&c->aux_stream[2 * set + i], hipStreamNonBlocking));
-        for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->aux_ev[4 * set + i], hipEventDisableTiming));
+    if (!serial && !c->aux_stream[3 * set]) {
+        // (THJ_SJ_PRIO=1: the side streams at the highest priority the device has -- measured worse, 7.0 against 6.6 ms per step: the flat reads'
+        // rescue scan then waits for them)
+        int lo = 0, hi = 0;
+        static const bool prio = getenv("THJ_SJ_PRIO") && atoi(getenv("THJ_SJ_PRIO")) != 0;
+        if (prio) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->aux_stream[3 * set + i], hipStreamNonBlocking, prio ? hi : 0));
+        for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&c->aux_ev[5 * set + i], hipEventDisableTiming));
     }
-    hipStream_t sm = c->stream, sa = serial ? c->stream : c->aux_stream[2 * set], sb = serial ? c->stream : c->aux_stream[2 * set + 1];
-    hipEvent_t* const aev = c->aux_ev + 4 * set;
+    hipStream_t sm = c->stream, sa = serial ? c->stream : c->aux_stream[3 * set], sb = serial ? c->stream : c->aux_stream[3 * set + 1],
+                sc = serial ? c->stream : c->aux_stream[3 * set + 2];
+    hipEvent_t* const aev = c->aux_ev + 5 * set;
     // profiling: one pair of events around every kernel (pairs of kernels where the second is the first's tail), on the stream it runs on;
     // SJ_PROF_N intervals per launch, in the order thj_profile_segjuncs documents
     auto mark = [&](hipStream_t st) -> hipEvent_t { if (!c->profile) return nullptr; hipEvent_t e = thj_get_event(c); hipEventRecord(e, st); c->prof_all.push_back(e); return e; };
-    auto span = [&](hipEvent_t a, hipEvent_t z) { if (c->profile) c->prof_events.emplace_back(a, z); };
     hipEvent_t m0 = mark(sm);
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_sj_flat<4>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
     else if (b.nseg <= 8) hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
     else hipLaunchKernelGGL(thj_k_sj_flat<16>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
     hipEvent_t m1 = mark(sm);
-    if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); HIPCHK(hipStreamWaitEvent(sb, aev[0], 0)); }
+    if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); HIPCHK(hipStreamWaitEvent(sb, aev[0], 0)); HIPCHK(hipStreamWaitEvent(sc, aev[0], 0)); }
+    st.g = g; st.p = p; st.b = b; st.t = t; st.rl = rl; st.sl = sl; st.x = x; st.grid = grid; st.n_tiles = n_tiles; st.wide = wide; st.serial = serial;
+    st.sm = sm; st.sa = sa; st.sb = sb; st.sc = sc; st.aev = aev; st.m0 = m0; st.m1 = m1;
+    HIPCHK(hipGetLastError());
+    return THJ_OK;
+}
+
+// second half: the side chains on their streams, the flat reads' rescue and tasks on the context's
+static int sj_launch_rest(thj_ctx* c, SjState& st, int set, bool* joined) {
+    Genome& g = st.g; Params& p = st.p; DevBatch& b = st.b; Tables& t = st.t; RescueList& rl = st.rl; SjLists& sl = st.sl; XTasks& x = st.x;
+    const int grid = st.grid, n_tiles = st.n_tiles; const bool wide = st.wide, serial = st.serial;
+    hipStream_t sm = st.sm, sa = st.sa, sb = st.sb, sc = st.sc; hipEvent_t* const aev = st.aev; hipEvent_t m0 = st.m0, m1 = st.m1;
+    auto mark = [&](hipStream_t s_) -> hipEvent_t { if (!c->profile) return nullptr; hipEvent_t e = thj_get_event(c); hipEventRecord(e, s_); c->prof_all.push_back(e); return e; };
+    auto span = [&](hipEvent_t a, hipEvent_t z) { if (c->profile) c->prof_events.emplace_back(a, z); };
     // ---- the reads with several hits a segment
     const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
     hipEvent_t b0 = mark(sb);
@@ -1418,13 +1442,14 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 9>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
     else hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 17>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
     hipEvent_t a1 = mark(sa);
+    hipEvent_t c0 = mark(sc);
     {
         const int mgrid = n_tiles * (TPB / MID_T) < MID_GRID ? n_tiles * (TPB / MID_T) : MID_GRID;
-        if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 9>), dim3(mgrid), dim3(MID_T), 0, sa, p, b, rl, sl, x, c->d_cnt);
-        else hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 17>), dim3(mgrid), dim3(MID_T), 0, sa, p, b, rl, sl, x, c->d_cnt);
+        if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 9>), dim3(mgrid), dim3(MID_T), 0, sc, p, b, rl, sl, x, c->d_cnt);
+        else hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 17>), dim3(mgrid), dim3(MID_T), 0, sc, p, b, rl, sl, x, c->d_cnt);
     }
-    hipEvent_t a2 = mark(sa);
-    if (!serial) HIPCHK(hipStreamWaitEvent(sa, aev[2], 0));
+    hipEvent_t c1 = mark(sc);
+    if (!serial) { HIPCHK(hipEventRecord(aev[4], sc)); HIPCHK(hipStreamWaitEvent(sa, aev[2], 0)); HIPCHK(hipStreamWaitEvent(sa, aev[4], 0)); }
     hipEvent_t a3 = mark(sa);                    // (after the wait for thj_k_segjuncs_shared)
     if (b.mate_off) {
         hipLaunchKernelGGL(thj_k_segjuncs_rescue, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, rl, grid + 1, x, c->d_cnt);
@@ -1446,14 +1471,20 @@ static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, 
     if (wide) hipLaunchKernelGGL(thj_k_sj_tasks<true>, dim3(grid), dim3(TPB), 0, sm, g, p, b, t, sl);
     else hipLaunchKernelGGL(thj_k_sj_tasks<false>, dim3(grid), dim3(TPB), 0, sm, g, p, b, t, sl);
     hipEvent_t m4 = mark(sm);
-    span(m0, m1); span(a0, a1); span(a1, a2); span(b0, b1); span(a3, a4); span(a4, a5); span(m2, m3); span(m3, m4);
+    span(m0, m1); span(a0, a1); span(c0, c1); span(b0, b1); span(a3, a4); span(a4, a5); span(m2, m3); span(m3, m4);
     if (c->profile) c->prof_sets.push_back(set);
     *joined = !serial;
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
 
-static int sj_join(thj_ctx* c, int set) { HIPCHK(hipStreamWaitEvent(c->stream, c->aux_ev[4 * set + 3], 0)); return THJ_OK; }
+static int sj_launch(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, int set, bool* joined) {
+    SjState st;
+    int rc = sj_launch_flat(c, tp, db, set, st);
+    return rc ? rc : sj_launch_rest(c, st, set, joined);
+}
+
+static int sj_join(thj_ctx* c, int set) { HIPCHK(hipStreamWaitEvent(c->stream, c->aux_ev[5 * set + 3], 0)); return THJ_OK; }
 static int sj_probe(thj_ctx* c) {
     // insert counters for the next run's growth decision (asynchronous)
     if (!c->probe_ev) HIPCHK(hipEventCreateWithFlags(&c->probe_ev, hipEventDisableTiming));
@@ -1491,8 +1522,12 @@ extern "C" int thj_segjuncs_run_pair_async(thj_ctx* c, const thj_params* tp0, co
     HIPCHK(hipSetDevice(c->device));
     if ((rc = maybe_grow_tables(c))) return rc;
     bool j0 = false, j1 = false;
-    if (db0->n_reads && (rc = sj_launch(c, tp0, db0, 0, &j0))) return rc;
-    if (db1->n_reads && (rc = sj_launch(c, tp1, db1, 1, &j1))) { if (j0) sj_join(c, 0); return rc; }
+    // both thj_k_sj_flat first, then the rest of each: the second batch's side chains start as early as they can
+    SjState s0, s1;
+    if (db0->n_reads && (rc = sj_launch_flat(c, tp0, db0, 0, s0))) return rc;
+    if (db1->n_reads && (rc = sj_launch_flat(c, tp1, db1, 1, s1))) return rc;
+    if (db0->n_reads && (rc = sj_launch_rest(c, s0, 0, &j0))) return rc;
+    if (db1->n_reads && (rc = sj_launch_rest(c, s1, 1, &j1))) { if (j0) sj_join(c, 0); return rc; }
     if (j0 && (rc = sj_join(c, 0))) return rc;
     if (j1 && (rc = sj_join(c, 1))) return rc;
     return (db0->n_reads || db1->n_reads) ? sj_probe(c) : THJ_OK;

@@ -583,8 +583,8 @@ extern "C" int thj_span_hit_heads_async(thj_ctx* c, const thj_span_hit* d_hits, 
 
 extern "C" int thj_span_batch_upload(thj_ctx* c, const thj_span_batch* h, int64_t n_hits, thj_span_batch** out) {
     if (!c || !h || !out) { thj_set_error("thj_span_batch_upload: null argument"); return THJ_EINVAL; }
-    if (h->n_reads < 0 || h->nseg < 1 || h->nseg > SPAN_MAXSEG || h->words_per_plane < 1 || h->words_per_plane > 4 || h->qual_stride < 0) {
-        thj_set_error("thj_span_batch_upload: bad shape (nseg 1..8, words_per_plane 1..4)"); return THJ_EINVAL;
+    if (h->n_reads < 0 || h->nseg < 1 || h->nseg > SPAN_MAXSEG || h->words_per_plane < 1 || h->words_per_plane > 8 || h->qual_stride < 0) {
+        thj_set_error("thj_span_batch_upload: bad shape (nseg 1..16, words_per_plane 1..8)"); return THJ_EINVAL;
     }
     HIPCHK(hipSetDevice(c->device));
     OwnedSpanBatch* ob = new OwnedSpanBatch();
@@ -675,8 +675,9 @@ static int check_span_params(const thj_params* p, const thj_span_batch* b) {
     if (p->segment_length < 8 || p->segment_length > 64) { thj_set_error("segment_length %d unsupported by the stitch kernel (8..64)", p->segment_length); return THJ_EINVAL; }
     if (p->max_insertion_length < 0 || p->max_insertion_length > 6) { thj_set_error("max_insertion_length %d unsupported (0..6)", p->max_insertion_length); return THJ_EINVAL; }
     if (p->max_report_intron + 64 >= (1 << 29)) { thj_set_error("max_report_intron too large for the packed key"); return THJ_EINVAL; }
-    if (b->nseg < 1 || b->nseg > SPAN_MAXSEG) { thj_set_error("nseg %d unsupported (1..8)", b->nseg); return THJ_EINVAL; }
-    if (b->words_per_plane < 1 || b->words_per_plane > 4) { thj_set_error("words_per_plane %d unsupported (1..4)", b->words_per_plane); return THJ_EINVAL; }
+    if (b->nseg < 1 || b->nseg > SPAN_MAXSEG) { thj_set_error("nseg %d unsupported (1..16)", b->nseg); return THJ_EINVAL; }
+    if (b->words_per_plane < 1 || b->words_per_plane > 8) { thj_set_error("words_per_plane %d unsupported (1..8: reads of up to 512 bases)", b->words_per_plane); return THJ_EINVAL; }
+    if (p->fusion_search && (b->nseg > FUS_MAXSEG || b->words_per_plane > 4)) { thj_set_error("--fusion-search takes reads of at most eight segments and 256 bases"); return THJ_EINVAL; }
     if ((int64_t)b->n_reads >= (1ll << 31)) { thj_set_error("batch too large"); return THJ_EINVAL; }
     return THJ_OK;
 }
@@ -788,11 +789,18 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
+    else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MIDSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
     const int64_t g1 = G, g2 = G;
     if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
-    else hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch<SPAN_MIDSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    else {
+        // a workgroup's staging area passes the 64 KB a launch may ask for by default: say so once
+        static const hipError_t big1 = hipFuncSetAttribute((const void*)thj_k_stitch<SPAN_MAXSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * SPAN_MAXSEG * (int)sizeof(SpanHitHead));
+        HIPCHK(big1);
+        hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    }
     if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
     if (p.fusion_search) {
         // tiers 0 and 1 keep the reads that join without a fusion; multihit reads, reads with a fused segment hit and reads tier 1
@@ -808,7 +816,8 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         unsigned long long* d_dbg = nullptr;
         if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, c->stream)); }
         if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
-        else hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MAXSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        // (reads of more than eight segments: the packed tier keeps a chain's choices in eight bytes -- the general kernel takes the multihit list as it is)
         if (pack_timing) {
             unsigned long long h[16];
             HIPCHK(hipStreamSynchronize(c->stream));
@@ -819,7 +828,13 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
                     h[10], h[6], h[7], h[8] / nw / 100.0, h[9] / 100.0, h[0] / nw / 100.0, h[1] / nw / 100.0, h[2] / nw / 100.0, h[3] / nw / 100.0, h[4] / nw / 100.0, h[5] / nw / 100.0);
         }
         if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
-        hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, t, (int)G);
+        Tiers tg = t;
+        if (b.nseg > SPAN_MIDSEG) {
+            tg.wl_gen = t.wl_multi; tg.blk_gen = t.blk_multi;
+            static const hipError_t big3 = hipFuncSetAttribute((const void*)thj_k_stitch_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * SPAN_MAXSEG * (int)sizeof(SpanHit));
+            HIPCHK(big3);
+        }
+        hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, tg, (int)G);
     }
     if (c->span_profile) {
         HIPCHK(hipEventRecord(ev[4], c->stream));

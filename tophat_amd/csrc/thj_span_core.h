@@ -35,7 +35,8 @@ struct SpanHit {            // == thj_span_hit, 32 bytes
 enum { SH_ANTI = 1, SH_END = 2, SH_ASPLICE = 4, SH_FUSED = 16 };
 
 static constexpr int SPAN_MAXC = 16;      // cigar ops of a joined alignment
-static constexpr int SPAN_MAXSEG = 8;
+static constexpr int SPAN_MAXSEG = 16;        // segments of a read (a 2 x 250 bp run at --segment-length 25 has ten)
+static constexpr int SPAN_MIDSEG = 8;         // ... of the instances the tiers keep for reads of five to eight (2 x 150 bp: six)
 static constexpr int SPAN_MAXJOIN = 96;   // joined alignments kept per read before sort+unique (a read in a 40-copy repeat yields 40)
 
 struct Aln {                // working form of a (partially) joined BowtieHit
@@ -1020,7 +1021,7 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
 #pragma unroll
         for (int k = 0; k < MS; ++k) if (k < nsegs) ((Q16*)heads)[k] = tmp[k];
     }
-    const StagedHits hits{heads, ghits + sof[0], 0x76543210ull};      // segment s's hit is staged hit s
+    const StagedHits hits{heads, ghits + sof[0], 0xFEDCBA9876543210ull};      // segment s's hit is staged hit s
     if (!(heads[nsegs - 1].meta & SH_END)) return SPAN_OK;
     if (THJ_EXPF(256)) return SPAN_OK;
     RAln res;

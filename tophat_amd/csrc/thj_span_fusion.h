@@ -15,6 +15,7 @@
 #include "thj_span_core.h"
 
 namespace thj {
+static constexpr int FUS_MAXSEG = 8;          // segments of a read the fusion branches take (thj_span_run_async refuses --fusion-search beyond)
 
 enum { OP_FUS_FF = 7, OP_FUS_FR = 8, OP_FUS_RF = 9, OP_FUS_RR = 10 };
 enum { SH_FLIPPED = 8 };                      // == THJ_HIT_STRAND_FLIPPED (SH_FUSED = 16 == THJ_HIT_FUSED: thj_span_core.h)
@@ -625,7 +626,7 @@ THJ_HD bool f_valid_hit(const Params& p, const FHit& h) {                       
 
 // merge_segment_chain, :2101-2220.  -> the joined hit in `bh` (n == 0: none)
 THJ_HD void f_merge_segment_chain(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const FRead& rd,
-                                  const FHit* hits, int n, int fusion_dir, FHit* chain /* [SPAN_MAXSEG + 1] */, FHit& bh) {
+                                  const FHit* hits, int n, int fusion_dir, FHit* chain /* [FUS_MAXSEG + 1] */, FHit& bh) {
     bh.n = 0;
     if (n > 1) {
         if (fusion_dir == 0 || fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) {
@@ -645,17 +646,17 @@ THJ_HD void f_merge_segment_chain(const Genome& g, const Params& p, const SpanSe
                 }
                 if (f_fusion_opcode(hits[i]) == 0 && ((fusion_dir == OP_FUS_FR && saw) || (fusion_dir == OP_FUS_RF && !saw)) &&
                     hits[i].left < f_right(hits[i])) {
-                    if (m > SPAN_MAXSEG) return;
+                    if (m > FUS_MAXSEG) return;
                     chain[m] = hits[i]; f_reverse(chain[m]); ++m;
                     pushed = true;
                 }
                 if (i > 0 && f_fusion_opcode(hits[i]) != 0 && hits[i].ref_id != hits[i - 1].ref_id) {
-                    if (m > SPAN_MAXSEG) return;
+                    if (m > FUS_MAXSEG) return;
                     chain[m] = hits[i]; f_reverse(chain[m]); ++m;
                     pushed = true;
                 }
                 if (!saw && f_fusion_opcode(hits[i]) != 0) saw = true;
-                if (!pushed) { if (m > SPAN_MAXSEG) return; chain[m++] = hits[i]; }
+                if (!pushed) { if (m > FUS_MAXSEG) return; chain[m++] = hits[i]; }
             }
             n = m;
         }
@@ -793,14 +794,14 @@ THJ_HD void f_emit(Sink& sink, uint32_t read_idx, int order, const FHit& h, cons
 }
 
 // One read: JoinSegmentsWorker body (long_spanning_reads.cpp:2767-2831) with fusion search on.
-// work: FHit[3 * (SPAN_MAXSEG + 1)] of per-thread memory (stack, saved stack tops, chain).
+// work: FHit[3 * (FUS_MAXSEG + 1)] of per-thread memory (stack, saved stack tops, chain).
 template <class Sink>
 THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
                             int nseg, const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink, FHit* ext = nullptr, int ext_cap = 0) {
     if (so[1] == so[0]) return SPAN_OK;
     int nsegs = 0;
     while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
-    if (nsegs > SPAN_MAXSEG) nsegs = SPAN_MAXSEG;
+    if (nsegs > FUS_MAXSEG) nsegs = FUS_MAXSEG;
     if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;
     if (p.bowtie2)
         for (int s = 0; s < nsegs; ++s)
@@ -812,10 +813,10 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
     FHit* joined = ext ? ext : joined_local;
     const int cap = ext ? ext_cap : FUS_MAXJOIN;
     int nj = 0;
-    FHit stack[SPAN_MAXSEG + 1], saved[SPAN_MAXSEG + 1], chain[SPAN_MAXSEG + 1];
-    uint32_t idx[SPAN_MAXSEG + 1];
-    int fdir[SPAN_MAXSEG + 2];
-    bool dirty[SPAN_MAXSEG + 2];
+    FHit stack[FUS_MAXSEG + 1], saved[FUS_MAXSEG + 1], chain[FUS_MAXSEG + 1];
+    uint32_t idx[FUS_MAXSEG + 1];
+    int fdir[FUS_MAXSEG + 2];
+    bool dirty[FUS_MAXSEG + 2];
     int status = SPAN_OK;
     for (uint32_t i0 = so[0]; i0 < so[1]; ++i0) {                           // :2634-2664
         stack[0] = fhit_from(hits[i0], 0, nsegs == 1);
