@@ -144,8 +144,8 @@ int thj_reads_pack(int64_t n_reads, const int64_t* read_off, const char* bases,
  * (increasing id) order.  All array pointers are DEVICE pointers. */
 typedef struct {
     int32_t n_reads;
-    int32_t nseg;                /* number of segment maps (hits_for_read.size()) */
-    int32_t words_per_plane;     /* W of thj_reads_pack */
+    int32_t nseg;                /* number of segment maps (hits_for_read.size()): 1..16 */
+    int32_t words_per_plane;     /* W of thj_reads_pack: 1..8 (reads of up to 512 bases) */
     int32_t reserved;
     const uint32_t* seg_off;     /* [n_reads*nseg+1] CSR into hits, index r*nseg+s */
     const thj_hit*  hits;
