@@ -258,6 +258,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run two steps under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic "
                     "(the committed table under profiles/ is used instead when the configuration is the one it was taken on)")
+    ap.add_argument("--e2e-pairs-large", type=int, default=0, metavar="N",
+                    help="run the e2e leg a second time on N pairs (timing only; e.g. 40000000) so that the fixed cost of the three processes "
+                         "and their rate separate: `e2e.large`, `e2e.fixed_s` and `e2e.rate_pairs_per_s` from the two points")
     ap.add_argument("--e2e-pairs", type=int, default=10_000_000,
                     help="also run the drop-in executables end to end (files in, files out: the metric as SURVEY 8d words it) on "
                          "generated files of this many pairs; 0 skips the leg.  Reported as the `e2e` object, never as `value`")
@@ -451,7 +454,7 @@ def e2e_leg(args, n_gpus=1):
         gpu_env = {"HIP_VISIBLE_DEVICES": ",".join(str(k) for k in range(n_gpus))}
         res = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=gpu_env, gen_args=gen_args)
         keep = ("pairs", "input_bytes", "gen_seconds", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s",
-                "both_stages_s", "junctions", "junctions_bed_s", "junctions_bed_lines", "outside_main_s", "span_left_bytes", "span_right_bytes")
+                "both_stages_s", "junctions", "junctions_bed_s", "junctions_bed_lines", "outside_main_s", "span_left_bytes", "span_right_bytes", "host_ingest_fallback_shards")
         out = {k: res[k] for k in keep if k in res}
         out["workload"] = ("configs[1] with SURVEY 8(d)'s mix -- the same as the resident-data line: %g %% of the pairs from a %d-copy repeat family, %g %% deletion reads"
                            % (100 * args.multihit_frac, args.max_copies, 100 * args.indel_frac)) if gen_args else "configs[1] without the mix (--plain)"
@@ -503,6 +506,15 @@ def e2e_leg(args, n_gpus=1):
         out["inflate"] = e2e_inflate_roofline(os.path.join(d, "left_seg1.bam"))
     finally:
         shutil.rmtree(d, ignore_errors=True)
+    if getattr(args, "e2e_pairs_large", 0) > args.e2e_pairs:
+        # a second point: t(n) = fixed + n / rate through (e2e_pairs, both_stages_s) and (e2e_pairs_large, ...)
+        big = run_e2e(args.e2e_pairs_large, args.read_len, args.genome_len, args.introns, env_extra=gpu_env, gen_args=gen_args)
+        n0, t0, n1, t1 = float(out["pairs"]), float(out["both_stages_s"]), float(big["pairs"]), float(big["both_stages_s"])
+        out["large"] = {k: big[k] for k in ("pairs", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s", "both_stages_s", "outside_main_s") if k in big}
+        out["large"]["value"] = n1 / t1
+        if t1 > t0:
+            out["rate_pairs_per_s"] = (n1 - n0) / (t1 - t0)
+            out["fixed_s"] = t0 - n0 / out["rate_pairs_per_s"]
     # a small case through the oracle whole (event files byte for byte, every spanning record, junctions.bed)
     d = tempfile.mkdtemp(prefix="thj_e2e_chk_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:

@@ -101,6 +101,13 @@ int  thj_device_count(void);
 /* `stream` is a hipStream_t to launch on (e.g. torch's current stream) or NULL
  * to let the context create its own non-blocking stream. */
 int  thj_ctx_create(int device, void* stream, thj_ctx** out);
+/* Loads the kernels of the named parts now (an empty launch from each translation unit) instead of at their first use; blocks
+ * until they are there.  For a process that has something else to do meanwhile.  No effect on results. */
+#define THJ_WARM_SEGJUNCS 1   /* stage 1, event sets, juncs_db gather, exchange */
+#define THJ_WARM_SPAN     2   /* stage 2, junction consensus */
+#define THJ_WARM_INGEST   4   /* BGZF inflate, BAM parse */
+#define THJ_WARM_BAMOUT   8   /* BAM record encoding, DEFLATE */
+int  thj_ctx_warm(thj_ctx* ctx, int parts);
 void thj_ctx_destroy(thj_ctx* ctx);
 int  thj_ctx_sync(thj_ctx* ctx);            /* hipStreamSynchronize on the context stream */
 void* thj_ctx_stream(thj_ctx* ctx);         /* the hipStream_t in use */

@@ -86,6 +86,7 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
     res["segment_juncs_cpu_s"] = round(child_cpu() - c0, 3)
     res["junctions"] = sum(1 for _ in open(out["juncs"]))
     res["segment_juncs_log_tail"] = r.stderr.strip().splitlines()[-12:]
+    res["segment_juncs_log_all"] = [l for l in r.stderr.splitlines() if "declined" in l]
     tot = dt
     for sd in ("left", "right"):
         cmd = _prefix(env, "lsr_" + sd) + [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
@@ -102,12 +103,16 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
                 a, b = map(float, l.split()[-2:])
                 res["long_spanning_reads_%s_before_main_after_report_s" % sd] = [round(a - t, 3), round(t + dt - b, 3)]
         res["long_spanning_reads_%s_log_tail" % sd] = [l for l in r.stderr.strip().splitlines() if not l.startswith("[trace]")][-8:]
+        res["long_spanning_reads_%s_log_all" % sd] = [l for l in r.stderr.splitlines() if "declined" in l]
         if env.get("THJ_TRACE"):                     # the per-shard timeline for tools/lsr_trace.py
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             open(os.path.join(ROOT, "gpurun_out", "lsr_%s.trace" % sd), "w").write(r.stderr)
         res["span_%s_bytes" % sd] = os.path.getsize(f("span_%s.bam" % sd))
         tot += dt
     res["both_stages_s"] = round(tot, 3)
+    import re as _re
+    res["host_ingest_fallback_shards"] = sum(int(m.group(1)) for st in ("segment_juncs", "long_spanning_reads_left", "long_spanning_reads_right")
+                                             for l in res.get(st + "_log_all", []) for m in [_re.search(r"device-side ingest declined them: (\d+)", l)] if m)
     oms = [res.get(k + "_before_main_after_report_s") for k in ("segment_juncs", "long_spanning_reads_left", "long_spanning_reads_right")]
     if all(oms):
         res["outside_main_s"] = round(sum(a + b for a, b in oms), 3)          # of both_stages_s: what the three processes spend before main() and after their report

@@ -16,6 +16,7 @@
 
 using namespace thjh;
 
+static std::atomic<long long> g_host_ingest_shards{0};      // shards the device-side ingest declined (the host readers took them)
 static void print_usage() {
     fprintf(stderr, "Usage:   long_spanning_reads <reference.fasta> <reads.fq> <possible_juncs1,...,possible_juncsN> "
                     "<possible_insertions1,...,possible_insertionsN> <possible_deletions1,...,possible_deletionsN> "
@@ -339,6 +340,7 @@ static int real_main(int argc, char** argv) {
             g.fut = std::async(std::launch::async, [dev = g.device]() {
                 thj_ctx* c = nullptr;
                 if (thj_ctx_create(dev, nullptr, &c)) die("Error: %s\n", thj_last_error());
+                if (!getenv("THJ_NO_WARM") && thj_ctx_warm(c, THJ_WARM_SPAN | THJ_WARM_INGEST | THJ_WARM_BAMOUT)) die("Error: %s\n", thj_last_error());
                 return c;
             });
         }
@@ -784,6 +786,7 @@ static int real_main(int argc, char** argv) {
             }
             if (rc != THJ_EFALLBACK) die("Error: %s\n", thj_last_error());
             static std::atomic<bool> told{false};
+            g_host_ingest_shards.fetch_add(1);
             if (!told.exchange(true)) fprintf(stderr, "\tdevice-side ingest not possible (%s); reading on the host\n", thj_last_error());
         }
         std::vector<HitStream> st((size_t)nseg);
@@ -925,6 +928,7 @@ static int real_main(int argc, char** argv) {
     for (auto& t : th) t.join();
     pool.finish();
     g_timer.lap("ingest + stitch + encode + write (all shards)");
+    fprintf(stderr, "\tshards read on the host because the device-side ingest declined them: %lld\n", g_host_ingest_shards.load());
     if (dev_out) fprintf(stderr, "\tBAM records and BGZF members made on the device for %lld shard%s, on the host for %lld\n", dev_out_shards.load(), dev_out_shards.load() == 1 ? "" : "s", host_out_shards.load());
     for (auto& bw : bws) bw->close();
     g_timer.lap("BAM close");

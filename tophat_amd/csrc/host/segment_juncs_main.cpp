@@ -14,6 +14,7 @@
 
 using namespace thjh;
 
+static std::atomic<long long> g_host_ingest_shards{0};      // shards the device-side ingest declined (the host readers took them)
 static void print_usage() {
     fprintf(stderr, "Usage:   segment_juncs <ref.fa> <segment.juncs> <segment.insertions> <segment.deletions> <segment.fusions> "
                     "<left_reads.fq> <left_reads.bwtout> <left_seg1.bwtout,...,segN.bwtout> "
@@ -181,6 +182,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
             if (rc != THJ_EFALLBACK) die("Error: %s\n", thj_last_error());
             g_work.add(2, td);
             static std::atomic<bool> told{false};
+            g_host_ingest_shards.fetch_add(1);
             if (!told.exchange(true)) fprintf(stderr, "\tdevice-side ingest not possible (%s); reading on the host\n", thj_last_error());
         }
     }
@@ -328,6 +330,9 @@ static int real_main(int argc, char** argv) {
             g.fut = std::async(std::launch::async, [dev = g.device]() {
                 thj_ctx* c = nullptr;
                 if (thj_ctx_create(dev, nullptr, &c)) die("Error: %s\n", thj_last_error());
+                // (thj_ctx_warm here was measured at nothing: the runtime's start-up on this thread is what the first shard waits for, and
+                // the code objects loaded behind it only make that longer; long_spanning_reads, with three of them, gains 0.05 s)
+                if (getenv("THJ_WARM") && thj_ctx_warm(c, THJ_WARM_SEGJUNCS | THJ_WARM_INGEST)) die("Error: %s\n", thj_last_error());
                 return c;
             });
         }
@@ -445,6 +450,7 @@ static int real_main(int argc, char** argv) {
     }
     for (auto& g : gpus) { std::lock_guard<std::mutex> lk(g->mu); device_ready(*g); }
     g_timer.lap("device start-up + ingest + pack + upload + launch (all shards)");
+    fprintf(stderr, "\tshards read on the host because the device-side ingest declined them: %lld\n", g_host_ingest_shards.load());
     if (!o.no_coverage_search) ium_thread.join();            // the unmapped reads went up beside the segment search
 
     // ---- the exchange step and the end of the pass, one host thread per GPU (each rank's collective calls come from its

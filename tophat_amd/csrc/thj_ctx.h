@@ -112,6 +112,7 @@ struct thj_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 hipEvent_t thj_get_event(struct thj_ctx* c);
+void thj_warm_span(hipStream_t s); void thj_warm_ingest(hipStream_t s); void thj_warm_bamout(hipStream_t s);      // one empty launch from the translation unit: its code object is loaded now
 int thj_dev_alloc(struct thj_ctx* c, void** out, size_t bytes);     // like hipMalloc, from the context's block cache
 void thj_dev_release(struct thj_ctx* c, void* p);                  // like hipFree, but the block stays with the context
 void thj_dev_cache_free(struct thj_ctx* c);

@@ -1821,3 +1821,7 @@ extern "C" int thj_span_batch_attach_reads(thj_ctx* c, thj_span_batch* batch, in
     batch->read_planes = (const uint64_t*)ob->ptrs[2]; batch->read_len = (const uint16_t*)ob->ptrs[3]; batch->quals = (const uint8_t*)ob->ptrs[4];
     return THJ_OK;
 }
+
+// the runtime loads a translation unit's code object at its first launch (tens of milliseconds): thj_ctx_warm makes that happen early
+__global__ void thj_k_warm_ingest(int* p) { if (p) *p = 0; }
+void thj_warm_ingest(hipStream_t s) { hipLaunchKernelGGL(thj_k_warm_ingest, dim3(1), dim3(64), 0, s, (int*)nullptr); }

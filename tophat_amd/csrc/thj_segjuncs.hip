@@ -1085,6 +1085,23 @@ extern "C" int thj_ctx_create(int device, void* stream, thj_ctx** out) {
     return THJ_OK;
 }
 
+// The code objects of the translation units `parts` names (THJ_WARM_*), loaded now by an empty launch from each instead of at the
+// first real launch: an executable calls this on the thread that creates the context, while its other threads still read the
+// reference and plan the shards (each code object is tens of milliseconds the first shard would otherwise wait for under the
+// GPU's lock).  No effect on results.
+__global__ void thj_k_warm_segjuncs(int* p) { if (p) *p = 0; }
+extern "C" int thj_ctx_warm(thj_ctx* c, int parts) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (parts & 1) hipLaunchKernelGGL(thj_k_warm_segjuncs, dim3(1), dim3(64), 0, c->stream, (int*)nullptr);
+    if (parts & 2) thj_warm_span(c->stream);
+    if (parts & 4) thj_warm_ingest(c->stream);
+    if (parts & 8) thj_warm_bamout(c->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return THJ_OK;
+}
+
 static void cov_free(thj_ctx* c);
 extern "C" void thj_ctx_destroy(thj_ctx* c) {
     if (!c) return;

@@ -1086,3 +1086,7 @@ extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t*
 }
 
 #include "thj_juncbed_impl.h"
+
+// the runtime loads a translation unit's code object at its first launch (tens of milliseconds): thj_ctx_warm makes that happen early
+__global__ void thj_k_warm_span(int* p) { if (p) *p = 0; }
+void thj_warm_span(hipStream_t s) { hipLaunchKernelGGL(thj_k_warm_span, dim3(1), dim3(64), 0, s, (int*)nullptr); }

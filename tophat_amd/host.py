@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "thj_covsearch_reset_async", "thj_covsearch_add_hits_async", "thj_covsearch_add_reads", "thj_covsearch_run_async", "thj_covsearch_finish",
     "thj_covsearch_device_state", "thj_covsearch_merge_async", "thj_span_hit_heads_async",
     "thj_comm_unique_id", "thj_comm_create", "thj_comm_create_local", "thj_comm_destroy", "thj_comm_info",
-    "thj_events_allgather_async", "thj_fusion_allgather", "thj_covsearch_allgather", "thj_span_fusions_upload", "thj_md_string2", "thj_ingest_span_batch", "thj_ingest_timing_report", "thj_pinned_alloc", "thj_pinned_free", "thj_pinned_drain",
+    "thj_events_allgather_async", "thj_fusion_allgather", "thj_covsearch_allgather", "thj_span_fusions_upload", "thj_md_string2", "thj_ingest_span_batch", "thj_ingest_timing_report", "thj_pinned_alloc", "thj_pinned_free", "thj_pinned_drain", "thj_ctx_warm",
 ]
 
 _lib = None
