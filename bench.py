@@ -504,6 +504,8 @@ def e2e_leg(args, n_gpus=1):
         out["device_writer_stream_equals_host_writer"] = all(inflated_sha(n) == dev_stream[n] for n in dev_stream)
         out["outputs_identical_without_handoff"] = all(sha(n) == out["sha256"][n] for n in outs[:3]) and out["device_writer_stream_equals_host_writer"]
         out["inflate"] = e2e_inflate_roofline(os.path.join(d, "left_seg1.bam"))
+        if not getattr(args, "no_cpu_baseline", False) and n_gpus == 1:
+            out["cpu_files_to_files"] = e2e_cpu_port(d, args, gen_args, run_e2e, sha, inflated_sha, out["sha256"], dev_stream)
     finally:
         shutil.rmtree(d, ignore_errors=True)
     if getattr(args, "e2e_pairs_large", 0) > args.e2e_pairs:
@@ -527,6 +529,42 @@ def e2e_leg(args, n_gpus=1):
                      and sc["event_files_identical_to_oracle"] and sc["spanning_records_identical_to_oracle"] and sc["junctions_bed_identical_to_oracle"])
     if not out["ok"]:
         raise RuntimeError("e2e leg: outputs differ from the oracle: %s" % json.dumps(out)[:1500])
+    return out
+
+
+def e2e_cpu_port(d, args, gen_args, run_e2e, sha, inflated_sha, gpu_sha, gpu_stream):
+    """A CPU figure that is like for like with `e2e`: the SAME files through tools/bin/cpuport/{segment_juncs,long_spanning_reads} --
+    the executables' own host sources (BGZF inflate, BAM parse, batching, BAM encode, BGZF deflate: tophat_amd/csrc/host/) linked
+    against tools/cpuport/thj_cpuport.cpp, which answers the C ABI's compute calls with oracle/liborc.so on host threads (the
+    plain-C restatement of the reference; kind "port").  Its outputs on the timed files must be the GPU executables' outputs (event
+    files byte for byte, the BAM streams inside the BGZF members): the oracle against the device at full size, every record.
+    One thread of the oracle is timed on the files' first pairs cut to a bounded sample."""
+    import shutil
+    import tempfile
+    cpu_bin = os.path.join(ROOT, "tools", "bin", "cpuport")
+    if not os.path.exists(os.path.join(cpu_bin, "segment_juncs")):
+        return {"error": "tools/bin/cpuport not built (__graft_entry__.build())"}
+    C = max(1, min(64, _cpu_count()))
+    env = {"THJ_HOST_INGEST": "1", "THJ_CTX_PER_GPU": "1", "THJ_NO_HANDOFF": "1", "THJ_CPUPORT_THREADS": str(C)}
+    r = run_e2e(args.e2e_pairs, args.read_len, args.genome_len, args.introns, workdir=d, keep=True, env_extra=env, gen_args=gen_args, bindir=cpu_bin)
+    same = all(sha(n) == gpu_sha[n] for n in ("out.juncs", "out.insertions", "out.deletions")) and all(inflated_sha(n) == gpu_stream[n] for n in gpu_stream)
+    out = {"value": r["pairs"] / r["both_stages_s"], "unit": "read-pairs/s, files in -> files out", "cores": C, "kind": "port, files to files",
+           "sample": "the e2e leg's own %d-pair files through the executables' host code over oracle/liborc.so, %d oracle threads: segment_juncs %.1f s + "
+                     "long_spanning_reads %.1f + %.1f s" % (r["pairs"], C, r["segment_juncs_s"], r["long_spanning_reads_left_s"], r["long_spanning_reads_right_s"]),
+           "seconds": [r["segment_juncs_s"], r["long_spanning_reads_left_s"], r["long_spanning_reads_right_s"]],
+           "outputs_identical_to_the_gpu_executables": bool(same)}
+    if not same:
+        raise RuntimeError("e2e leg: the CPU port's outputs on the timed files differ from the GPU executables'")
+    # one oracle thread, on files of their own (a tenth of the pairs, at most a million)
+    m = max(1000, min(1000000, args.e2e_pairs // 10))
+    d1 = tempfile.mkdtemp(prefix="thj_e2e_cpu1_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        r1 = run_e2e(m, args.read_len, args.genome_len, args.introns, workdir=d1, keep=True, env_extra=dict(env, THJ_CPUPORT_THREADS="1"), gen_args=gen_args, bindir=cpu_bin)
+        out["one_oracle_thread"] = {"value": r1["pairs"] / r1["both_stages_s"], "unit": "read-pairs/s, files in -> files out", "cores": 1,
+                                    "sample": "%d pairs generated the same way, one oracle thread (the host readers and writers keep their threads): %.1f + %.1f + %.1f s"
+                                              % (m, r1["segment_juncs_s"], r1["long_spanning_reads_left_s"], r1["long_spanning_reads_right_s"])}
+    finally:
+        shutil.rmtree(d1, ignore_errors=True)
     return out
 
 
@@ -715,7 +753,7 @@ def _cpu_quota():
         return "%d hardware threads" % os.cpu_count()
 
 
-def e2e_sample_check(d, args, pairs=20000):
+def e2e_sample_check(d, args, pairs=20000, bind=None, env=None):
     """executables on a small text+BAM twin case vs the oracle: the three event files byte for byte, and every spanning record"""
     import subprocess
     import orc
@@ -724,7 +762,9 @@ def e2e_sample_check(d, args, pairs=20000):
     from tophat_amd.batch import build_seg_batch, build_span_batch, events_to_span_inputs, merge_events
     from tophat_amd.samtext import parse_header, parse_sam_hits, read_fasta, read_fastq
     gen = os.path.join(ROOT, "tools", "bin", "thj_gen")
-    bind = os.path.join(ROOT, "tophat_amd", "bin")
+    # bind / env: other builds of the two executables (tools/bin/cpuport: the CPU port of the cpu_baseline leg; no thj_junctions there)
+    bind = bind or os.path.join(ROOT, "tophat_amd", "bin")
+    env = dict(os.environ, **(env or {}))
     subprocess.check_call([gen, "--out", d, "--pairs", str(pairs), "--genome-len", "4000000", "--introns", "1500", "--text"], stdout=subprocess.DEVNULL)
     f = lambda n: os.path.join(d, n)      # noqa: E731
     segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k)) for k in (1, 2, 3, 4)) for sd in ("left", "right")}
@@ -732,7 +772,7 @@ def e2e_sample_check(d, args, pairs=20000):
     subprocess.check_call([os.path.join(bind, "segment_juncs"), "--no-coverage-search", "--no-microexon-search", "--segment-length", "25", "--sam-header",
                            f("hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20", f("ref.fa"), out["juncs"], out["insertions"],
                            out["deletions"], out["fusions"], f("left_reads.bam"), f("left_map.bam"), segs["left"], f("right_reads.bam"),
-                           f("right_map.bam"), segs["right"]], stderr=subprocess.DEVNULL)
+                           f("right_map.bam"), segs["right"]], stderr=subprocess.DEVNULL, env=env)
     names, _ = parse_header(f("hdr.sam"))
     fa_names, fa_seqs = read_fasta(f("ref.fa"))
     seqs = [orc.fold_genome_char(s) for s in fa_seqs]
@@ -757,7 +797,7 @@ def e2e_sample_check(d, args, pairs=20000):
     for sd in ("left", "right"):
         bam = f("span_%s.bam" % sd)
         subprocess.check_call([os.path.join(bind, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
-                               f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", bam, segs[sd]], stderr=subprocess.DEVNULL)
+                               f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", bam, segs[sd]], stderr=subprocess.DEVNULL, env=env)
         quals = {k: "I" * len(v) for k, v in sides[sd]["reads"].items()}
         sb = build_span_batch(sides[sd]["segs"], sides[sd]["reads"], quals)
         alns = orc.spanning(Params(), og, sb, jj, ii)
@@ -768,13 +808,15 @@ def e2e_sample_check(d, args, pairs=20000):
         n_rec += len(grecs)
         same_recs = same_recs and grecs == wrecs
     # junctions.bed: the drop-in consensus program on the two spanning BAMs vs the oracle's consensus of the oracle's records
-    subprocess.check_call([os.path.join(bind, "thj_junctions"), "--sam-header", f("hdr.sam"), f("ref.fa"), f("junctions.bed"),
-                           f("span_left.bam") + "," + f("span_right.bam")], stderr=subprocess.DEVNULL)
     want_bed = orc.junctions_bed(orc.junction_consensus(orc.jrecs_from_alns(all_alns)), names)
-    same_bed = open(f("junctions.bed")).read() == want_bed
+    same_bed = None
+    if os.path.exists(os.path.join(bind, "thj_junctions")):
+        subprocess.check_call([os.path.join(bind, "thj_junctions"), "--sam-header", f("hdr.sam"), f("ref.fa"), f("junctions.bed"),
+                               f("span_left.bam") + "," + f("span_right.bam")], stderr=subprocess.DEVNULL, env=env)
+        same_bed = open(f("junctions.bed")).read() == want_bed
     return {"pairs": pairs, "junctions": len(want.juncs), "event_files_identical_to_oracle": bool(same_events),
             "spanning_records": n_rec, "spanning_records_identical_to_oracle": bool(same_recs),
-            "junctions_bed_lines": want_bed.count("\n") - 1, "junctions_bed_identical_to_oracle": bool(same_bed)}
+            "junctions_bed_lines": want_bed.count("\n") - 1, "junctions_bed_identical_to_oracle": None if same_bed is None else bool(same_bed)}
 
 
 def run_rank(args, rank, world, local_rank, control, shared):
@@ -1158,6 +1200,9 @@ def run_rank(args, rank, world, local_rank, control, shared):
         e2e = _E2E_EARLY
         if e2e is None and args.e2e_pairs > 0 and world == 1 and args.read_len == 100 and args.genome == "chr20":
             e2e = e2e_leg(args)
+        if cpu is not None and e2e and e2e.get("cpu_files_to_files"):
+            # beside `e2e`: the same files through the same host code with the oracle in the device's place
+            cpu["files_to_files"] = e2e["cpu_files_to_files"]
         result = {
             "metric": "paired reads/sec through segment_juncs+long_spanning_reads; junctions.bed diff=0",
             "value": args.pairs * world * args.steps / elapsed,

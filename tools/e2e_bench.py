@@ -44,8 +44,11 @@ def _run(cmd, env):
         raise RuntimeError("%s did not finish within %s s" % (os.path.basename(cmd[0]), e.timeout))
 
 
-def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False, gen_args=()):
-    """gen_args: further thj_gen options (SURVEY 8d's mix: --multihit-frac F --max-copies C --indel-frac F)"""
+def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False, gen_args=(), bindir=None):
+    """gen_args: further thj_gen options (SURVEY 8d's mix: --multihit-frac F --max-copies C --indel-frac F)
+    bindir: where segment_juncs / long_spanning_reads are taken from (default: the product executables; tools/bin/cpuport =
+    the same host sources over the CPU oracle, bench.py's files-to-files CPU figure -- no thj_junctions there, that leg is skipped)"""
+    BIN = bindir or globals()["BIN"]
     nseg = max(1, read_len // 25)
     d = workdir or tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     env = dict(os.environ, THJ_TIMING="1", **(env_extra or {}))
@@ -118,6 +121,10 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
         res["outside_main_s"] = round(sum(a + b for a, b in oms), 3)          # of both_stages_s: what the three processes spend before main() and after their report
     res["pairs_per_s_both_stages"] = round(pairs / tot)
     # the junction consensus (tophat_reports' part of the metric's "junctions.bed"): timed on its own, not part of both_stages_s
+    if not os.path.exists(os.path.join(BIN, "thj_junctions")):
+        if not keep and workdir is None:
+            shutil.rmtree(d, ignore_errors=True)
+        return res
     t = time.time()
     r = subprocess.run([os.path.join(BIN, "thj_junctions"), "--sam-header", f("hdr.sam"), f("ref.fa"), f("junctions.bed"),
                         f("span_left.bam") + "," + f("span_right.bam")], capture_output=True, text=True, env=env)
