@@ -427,6 +427,16 @@ int thj_covsearch_add_reads(thj_ctx* ctx, int64_t n_reads, int32_t words_per_pla
                             int32_t on_device);
 int thj_covsearch_run_async(thj_ctx* ctx, int32_t min_cov_length, int32_t min_coverage_intron, int32_t max_coverage_intron);
 int thj_covsearch_finish(thj_ctx* ctx, int64_t max_cov_juncs, int64_t* n_found);
+/* Butterfly search (--butterfly-search; replaces prune_extension_table + compact_extension_table + pair_covered_sites with
+ * juncs_from_ref_segs<RecordButterflyJuncs>, segment_juncs.cpp:466-501, :4178-4249, :1698-2049): works from the same state as the
+ * coverage search -- the coverage map of thj_covsearch_add_hits_async and the extension table of thj_covsearch_add_reads (after
+ * thj_covsearch_allgather when ranks share the reads); neither is changed.  Every island of the coverage map, widened by 45 bases,
+ * is searched for GT / CT and AG / AC; a donor and an acceptor min..max_coverage_intron apart make a junction when an unmapped read's
+ * seed next to the one and a seed next to the other show the same twelve bases across the gap.  The junctions -- all, or the
+ * max_cov_juncs with the shortest introns (the capped set of :2031-2041) -- are added to the pass's junction set; *n_found = their
+ * number.  Synchronous.  Run it after thj_covsearch_finish (when the coverage search runs at all: they share buffers) and before
+ * thj_segjuncs_finish. */
+int thj_butterfly_run(thj_ctx* ctx, int32_t min_coverage_intron, int32_t max_coverage_intron, int64_t max_cov_juncs, int64_t* n_found);
 /* Microexon search (segment_juncs.cpp:3737-3941; replaces align_microexon_segs and the window registration inside look_for_hit_group).
  * A read whose first segment has no hit while every other segment has some may begin in a microexon: every hit of its second segment
  * registers a window of 2000 bases beside it with the read's first segment_length bases.  thj_microexon_collect finds those

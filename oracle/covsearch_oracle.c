@@ -168,13 +168,8 @@ static window* wv_push(win_vec* v, uint32_t ref, int64_t left, int64_t right) {
     return &v->a[v->n++];
 }
 
-int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits,
-                        const char* ium_bases, const int64_t* ium_off, int64_t n_ium,
-                        int min_cov_length, int min_intron, int max_intron, int64_t max_juncs,
-                        orc_junction** out, int64_t* n_out) {
-    enum { LOOK_LEFT = 1, LOOK_RIGHT = 2 };
-    static const int extend = 45, repeat_tol = 5;              /* :4346-4347 */
-    /* ---- index_read_mers (:548-571): count, size, store */
+/* index_read_mers (:548-571): count, size, store */
+static mer_table index_read_mers(const char* ium_bases, const int64_t* ium_off, int64_t n_ium) {
     mer_table t;
     int64_t* counts = (int64_t*)calloc(N_KEYS, sizeof(int64_t));
     for (int64_t r = 0; r < n_ium; ++r) read_extensions(ium_bases + ium_off[r], (int)(ium_off[r + 1] - ium_off[r]), counts, NULL);
@@ -185,6 +180,16 @@ int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits
     memset(counts, 0, (size_t)N_KEYS * sizeof(int64_t));
     for (int64_t r = 0; r < n_ium; ++r) read_extensions(ium_bases + ium_off[r], (int)(ium_off[r + 1] - ium_off[r]), counts, &t);
     free(counts);
+    return t;
+}
+
+int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits,
+                        const char* ium_bases, const int64_t* ium_off, int64_t n_ium,
+                        int min_cov_length, int min_intron, int max_intron, int64_t max_juncs,
+                        orc_junction** out, int64_t* n_out) {
+    enum { LOOK_LEFT = 1, LOOK_RIGHT = 2 };
+    static const int extend = 45, repeat_tol = 5;              /* :4346-4347 */
+    mer_table t = index_read_mers(ium_bases, ium_off, n_ium);
 
     /* ---- build_coverage_map (:4140-4176) + capture_island_ends (:4268-4543), contigs in increasing ref_id order */
     const int nc = g->n_contigs;
@@ -298,6 +303,219 @@ int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits
     return 0;
 }
 
+
+/* ================================================================================================ butterfly search
+ * segment_juncs.cpp (opt-in, --butterfly-search; tophat.py never passes it):
+ *   prune_extension_table(butterfly_overhang = 6) :478-501, compact_extension_table :466-476   (driver :5002-5003)
+ *   pair_covered_sites                               :4178-4249   (islands of the coverage map, each widened by 45 bases, as one
+ *                                                                 POINT_DIR_LEFT and one POINT_DIR_RIGHT window)
+ *   juncs_from_ref_segs<RecordButterflyJuncs>        :2052-2377   ("GT" / "AG", max / min_coverage_intron_length, max_cov_juncs)
+ *   ButterflyKey, RecordButterflyJuncs::record       :1698-2049
+ * A junction (donor, acceptor) is proposed when some unmapped read's 10-mer seed ends 6 bases short of the donor with the 6 bases
+ * after the seed unknown to the genome there, and some read's seed starts 6 bases past the acceptor, and the 6 + 6 bases either read
+ * shows across the gap agree ("butterfly": the two 12-base keys meet in the middle).  skip_count = intron length.
+ * PARITY: unpinned (no reference test reaches it). */
+typedef struct { uint32_t key, pos; } bkey;
+typedef struct { bkey* a; int64_t n, cap; } bkey_vec;
+static void bk_push(bkey_vec* v, uint32_t pos, uint32_t key) {
+    if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 1024; v->a = (bkey*)realloc(v->a, (size_t)v->cap * sizeof(bkey)); }
+    v->a[v->n].key = key; v->a[v->n].pos = pos; v->n++;
+}
+static int bk_cmp(const void* a, const void* b) {               /* ButterflyKey::operator< (:1705-1712): key, then pos */
+    const bkey* x = (const bkey*)a; const bkey* y = (const bkey*)b;
+    if (x->key != y->key) return x->key < y->key ? -1 : 1;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    return 0;
+}
+static void bk_sort_unique(bkey_vec* v) {
+    if (v->n == 0) return;
+    qsort(v->a, (size_t)v->n, sizeof(bkey), bk_cmp);
+    int64_t w = 1;
+    for (int64_t i = 1; i < v->n; ++i) if (bk_cmp(&v->a[i], &v->a[w - 1]) != 0) v->a[w++] = v->a[i];
+    v->n = w;
+}
+static int ext_cmp(const void* a, const void* b) {              /* MerExtension::operator< (:158-168) */
+    const mer_ext* x = (const mer_ext*)a; const mer_ext* y = (const mer_ext*)b;
+    if (x->left_str != y->left_str) return x->left_str < y->left_str ? -1 : 1;
+    if (x->left_len != y->left_len) return x->left_len < y->left_len ? -1 : 1;
+    if (x->right_str != y->right_str) return x->right_str < y->right_str ? -1 : 1;
+    if (x->right_len != y->right_len) return x->right_len < y->right_len ? -1 : 1;
+    return 0;
+}
+/* RecordButterflyJuncs::record (:1742-2049), half_splice_mer_len = 5, colour space omitted */
+static void butterfly_record(const mer_table* t, const int64_t* bucket_n, uint32_t ref, const site_vec* all_left, const site_vec* all_right,
+                             int antisense, int min_intron, int max_intron, cand_vec* out) {
+    const int key_length = 10, ext_len = 6;
+    const uint64_t bottom_bit_mask = ~(0xFFFFFFFFFFFFFFFFull << (key_length << 1));
+    const uint64_t top_bit_mask = ~(0xFFFFFFFFFFFFFFFFull >> (key_length << 1));
+    const uint64_t mask = ~(0xFFFFFFFFFFFFFFFFull << (ext_len << 1));
+    if (all_left->n == 0 || all_right->n == 0) return;
+    const int64_t last_site = all_left->a[all_left->n - 1].pos > all_right->a[all_right->n - 1].pos ? all_left->a[all_left->n - 1].pos : all_right->a[all_right->n - 1].pos;
+    int64_t curr_left = 0, curr_right = 0;
+    for (int64_t edge = 0; edge < last_site; edge += max_intron) {
+        while (curr_left < all_left->n && all_left->a[curr_left].pos < edge) curr_left++;
+        while (curr_right < all_right->n && all_right->a[curr_right].pos < edge) curr_right++;
+        bkey_vec lk = {0, 0, 0}, rk = {0, 0, 0};
+        for (int64_t L = curr_left; L < all_left->n; ++L) {
+            if (!(all_left->a[L].pos < edge + 2 * (int64_t)max_intron)) continue;
+            const site* s = &all_left->a[L];
+            const uint64_t fwd_up = s->fwd & bottom_bit_mask;
+            for (int64_t i = t->off[fwd_up]; i < t->off[fwd_up] + bucket_n[fwd_up]; ++i) {
+                const mer_ext* e = &t->ext[i];
+                if (e->right_len < ext_len) continue;
+                uint64_t key = (uint64_t)e->right_str >> ((e->right_len - ext_len) << 1);
+                key |= (fwd_up & mask) << (ext_len << 1);
+                bk_push(&lk, (uint32_t)s->pos, (uint32_t)key);
+            }
+            const uint64_t rev_up = (s->rev & top_bit_mask) >> (64 - (key_length << 1));
+            for (int64_t i = t->off[rev_up]; i < t->off[rev_up] + bucket_n[rev_up]; ++i) {
+                const mer_ext* e = &t->ext[i];
+                if (e->left_len < ext_len) continue;
+                uint64_t x = rc_dna_str((uint64_t)e->left_str);
+                x >>= 64 - (e->left_len << 1);
+                uint64_t key = x >> ((e->left_len - ext_len) << 1);
+                key |= (fwd_up & mask) << (ext_len << 1);        /* the reference takes the forward key's bases here too */
+                bk_push(&lk, (uint32_t)s->pos, (uint32_t)key);
+            }
+        }
+        bk_sort_unique(&lk);
+        for (int64_t R = curr_right; R < all_right->n; ++R) {
+            if (!(all_right->a[R].pos < edge + 2 * (int64_t)max_intron)) continue;
+            const site* s = &all_right->a[R];
+            const uint64_t fwd_down = (s->fwd & top_bit_mask) >> (64 - (key_length << 1));
+            for (int64_t i = t->off[fwd_down]; i < t->off[fwd_down] + bucket_n[fwd_down]; ++i) {
+                const mer_ext* e = &t->ext[i];
+                if (e->left_len < ext_len) continue;
+                uint64_t key = ((uint64_t)e->left_str & mask) << (ext_len << 1);
+                key |= fwd_down >> ((key_length - ext_len) << 1);
+                bk_push(&rk, (uint32_t)s->pos, (uint32_t)key);
+            }
+            const uint64_t rev_down = s->rev & bottom_bit_mask;
+            for (int64_t i = t->off[rev_down]; i < t->off[rev_down] + bucket_n[rev_down]; ++i) {
+                const mer_ext* e = &t->ext[i];
+                if (e->right_len < ext_len) continue;
+                uint64_t x = rc_dna_str((uint64_t)e->right_str);
+                x >>= 64 - (e->right_len << 1);
+                uint64_t key = x << (ext_len << 1);
+                key |= fwd_down >> ((key_length - ext_len) << 1);
+                bk_push(&rk, (uint32_t)s->pos, (uint32_t)key);
+            }
+        }
+        bk_sort_unique(&rk);
+        int64_t l = 0, r = 0;
+        while (l < lk.n && r < rk.n) {
+            while (l < lk.n && lk.a[l].key < rk.a[r].key) ++l;
+            if (l == lk.n) break;
+            while (r < rk.n && rk.a[r].key < lk.a[l].key) ++r;
+            if (r == rk.n) break;
+            if (rk.a[r].key == lk.a[l].key) {
+                const uint32_t k = rk.a[r].key;
+                int64_t le = l, re = r;
+                while (re < rk.n && rk.a[re].key == k) ++re;
+                while (le < lk.n && lk.a[le].key == k) ++le;
+                for (int64_t a = l; a < le; ++a)
+                    for (int64_t b = r; b < re; ++b) {
+                        const int donor = (int)lk.a[a].pos - 1, acceptor = (int)rk.a[b].pos + 2;
+                        if (acceptor - donor > min_intron && acceptor - donor < max_intron)
+                            cv_push(out, ref, donor, acceptor, antisense, (uint64_t)(acceptor - donor));      /* "just prefer shorter introns" */
+                    }
+                l = le; r = re;
+            }
+        }
+        free(lk.a); free(rk.a);
+    }
+}
+
+int orc_butterfly_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits,
+                         const char* ium_bases, const int64_t* ium_off, int64_t n_ium,
+                         int min_intron, int max_intron, int64_t max_juncs,
+                         orc_junction** out, int64_t* n_out) {
+    static const int extend = 45, overhang = 6;                /* :4190, butterfly_overhang :61 */
+    mer_table t = index_read_mers(ium_bases, ium_off, n_ium);
+    /* prune_extension_table(6) (:478-501), then compact_extension_table (:466-476): sort + unique inside every bucket */
+    int64_t* bucket_n = (int64_t*)malloc((size_t)N_KEYS * sizeof(int64_t));
+    for (uint32_t k = 0; k < N_KEYS; ++k) {
+        mer_ext* e = t.ext + t.off[k];
+        const int64_t n = t.off[k + 1] - t.off[k];
+        const uint32_t m = ~(0xFFFFFFFFu << (overhang << 1));
+        for (int64_t j = 0; j < n; ++j) {
+            if (e[j].left_len > overhang) { e[j].left_len = overhang; e[j].left_str &= m; }
+            if (e[j].right_len > overhang) { e[j].right_str >>= ((e[j].right_len - overhang) << 1); e[j].right_len = overhang; }
+        }
+        qsort(e, (size_t)n, sizeof(mer_ext), ext_cmp);
+        int64_t w = n ? 1 : 0;
+        for (int64_t j = 1; j < n; ++j) if (ext_cmp(&e[j], &e[w - 1]) != 0) e[w++] = e[j];
+        bucket_n[k] = w;
+    }
+    /* build_coverage_map (:4140-4176) + the island walk of pair_covered_sites (:4195-4231), contigs in increasing ref_id order */
+    const int nc = g->n_contigs;
+    site_vec* fd = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));
+    site_vec* ra = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));
+    site_vec* fa = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));
+    site_vec* rd = (site_vec*)calloc((size_t)nc + 1, sizeof(site_vec));
+    uint8_t* in_map = (uint8_t*)calloc((size_t)nc + 1, 1);
+    for (int ref = 1; ref <= nc; ++ref) {
+        int64_t n = 0; int has = 0;
+        for (int64_t h = 0; h < n_hits; ++h)
+            if (hits[h].ref_id == (uint32_t)ref) { has = 1; const int64_t right = (uint32_t)hits[h].right; if (right >= n) n = right + 1; }
+        if (!has) continue;
+        uint8_t* cov = (uint8_t*)calloc((size_t)n + 1, 1);
+        for (int64_t h = 0; h < n_hits; ++h)
+            if (hits[h].ref_id == (uint32_t)ref)
+                for (uint32_t c = (uint32_t)hits[h].left; c < (uint32_t)hits[h].right; ++c) cov[c] = 1;
+        win_vec wins = {0, 0, 0};
+        int64_t island_left_edge = 0;
+        for (int64_t c = 1; c < n; ++c) {
+            if (cov[c]) {
+                if (!cov[c - 1]) { int64_t edge = c - extend; if (edge < 0) edge = 0; island_left_edge = edge; }
+            } else if (cov[c - 1]) wv_push(&wins, (uint32_t)ref, island_left_edge, c + extend);      /* once LEFT, once RIGHT */
+        }
+        free(cov);
+        const char* rs = g->seq[ref - 1];
+        if (rs) {                                              /* :2105-2106 */
+            const int64_t len = g->len[ref - 1];
+            for (int64_t w = 0; w < wins.n; ++w) {
+                const window* s = &wins.a[w];
+                in_map[ref] = 1;
+                if (s->left < 0 || s->right >= len - 1) continue;                      /* :2154 */
+                const int64_t seg_len = s->right - s->left;
+                for (int64_t i = 0; i + 2 <= seg_len; ++i) {
+                    const uint32_t b0 = base2(rs[s->left + i]), b1 = base2(rs[s->left + i + 1]);
+                    if (b0 == 0 && b1 == 2) sv_push(&fa[ref], s->left + i);            /* POINT_DIR_LEFT: AG */
+                    else if (b0 == 0 && b1 == 1) sv_push(&rd[ref], s->left + i);       /*                 AC */
+                    if (b0 == 2 && b1 == 3) sv_push(&fd[ref], s->left + i);            /* POINT_DIR_RIGHT: GT */
+                    else if (b0 == 1 && b1 == 3) sv_push(&ra[ref], s->left + i);       /*                  CT */
+                }
+            }
+        }
+        free(wins.a);
+    }
+    cand_vec cands = {0, 0, 0};
+    for (int ref = 1; ref <= nc; ++ref) {
+        if (!in_map[ref]) continue;
+        const char* rs = g->seq[ref - 1];
+        const int64_t len = g->len[ref - 1];
+        sv_unique(&fd[ref]); sv_unique(&fa[ref]); sv_unique(&rd[ref]); sv_unique(&ra[ref]);
+        attach_upstream(rs, len, &fd[ref]); attach_upstream(rs, len, &ra[ref]);
+        attach_downstream(rs, len, &rd[ref]); attach_downstream(rs, len, &fa[ref]);
+        butterfly_record(&t, bucket_n, (uint32_t)ref, &fd[ref], &fa[ref], 0, min_intron, max_intron, &cands);
+        butterfly_record(&t, bucket_n, (uint32_t)ref, &ra[ref], &rd[ref], 1, min_intron, max_intron, &cands);
+    }
+    /* set<Junction, skip_count_lt> with its cap (:2031-2041), then the coordinate-ordered set (:5031) */
+    qsort(cands.a, (size_t)cands.n, sizeof(cand), cand_cmp);
+    int64_t m = 0;
+    for (int64_t i = 0; i < cands.n; ++i) if (m == 0 || cand_cmp(&cands.a[m - 1], &cands.a[i]) != 0) cands.a[m++] = cands.a[i];
+    if (m > max_juncs) m = max_juncs;
+    orc_junction* res = (orc_junction*)malloc((size_t)(m + 1) * sizeof(orc_junction));
+    for (int64_t i = 0; i < m; ++i) res[i] = cands.a[i].j;
+    qsort(res, (size_t)m, sizeof(orc_junction), junc_cmp_v);
+    int64_t k = 0;
+    for (int64_t i = 0; i < m; ++i) if (k == 0 || junc_cmp(&res[k - 1], &res[i]) != 0) res[k++] = res[i];
+    *out = res; *n_out = k;
+    for (int ref = 0; ref <= nc; ++ref) { free(fd[ref].a); free(fa[ref].a); free(rd[ref].a); free(ra[ref].a); }
+    free(fd); free(fa); free(rd); free(ra); free(in_map); free(cands.a); free(bucket_n); free(t.off); free(t.ext);
+    return 0;
+}
 
 /* ================================================================================================ microexon search
  * segment_juncs.cpp:3880-3941 (window registration inside look_for_hit_group), :3671-3735 (add_to_microexon_windows),

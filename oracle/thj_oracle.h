@@ -158,6 +158,14 @@ int orc_coverage_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits
                         int min_cov_length, int min_intron, int max_intron, int64_t max_juncs,
                         orc_junction** out, int64_t* n_out);
 
+/* Butterfly search of segment_juncs (covsearch_oracle.c; --butterfly-search: segment_juncs.cpp:4178-4249 pair_covered_sites,
+ * :1698-2049 RecordButterflyJuncs, :466-501 the pruned and compacted extension table): same inputs as the coverage search; min_intron /
+ * max_intron = min / max_coverage_intron_length, max_juncs = max_cov_juncs.  -> junctions in Junction::operator< order (malloc'd, orc_free). */
+int orc_butterfly_search(const orc_genome* g, const orc_hit* hits, int64_t n_hits,
+                         const char* ium_bases, const int64_t* ium_off, int64_t n_ium,
+                         int min_intron, int max_intron, int64_t max_juncs,
+                         orc_junction** out, int64_t* n_out);
+
 /* Microexon search of segment_juncs (covsearch_oracle.c; segment_juncs.cpp:3880-3941 window registration, :3675-3735 merging,
  * :3737-3815 per-window pairing): the batches of both sides in the order the reference visits them (all left reads, then all right
  * reads), sides[i] = 1 (READ_LEFT) / 2 (READ_RIGHT); p->segment_length and p->library_type are read; min_intron =

@@ -106,3 +106,58 @@ def edge_case(seed):
             ium.append(r.replace("N", "A") if seed % 2 else r)
     args = (min_cov, int(rng.choice([1, 20, 50])), int(rng.choice([300, 2000, 20000])))
     return seqs, np.array(hits, dtype=HIT_DTYPE), ium, args
+
+
+def butterfly_case(seed):
+    """hits, unmapped reads and a genome made for the butterfly search: introns planted with GT..AG (forward) or CT..AC (reverse strand)
+    between covered exon ends, unmapped reads spliced across them in either orientation (so that left and right keys meet), islands at
+    contig starts, islands reaching the last 47 bases (dropped windows), islands 90 bases apart (abutting windows), sites within 32 bases
+    of a contig end (no mer attached), N runs, a second copy of an exon end (several sites under one key)
+    -> (seqs, hits, ium reads, (min_intron, max_intron))"""
+    rng = np.random.default_rng(seed)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+    n_contigs = int(rng.integers(1, 4))
+    seqs, hits, ium = [], [], []
+    for k in range(n_contigs):
+        n = int(rng.integers(400, 5000))
+        s = list(rng.choice(list("ACGT"), size=n))
+        n_introns = int(rng.integers(1, 6))
+        cuts = sorted(int(x) for x in rng.integers(40, n - 40, size=2 * n_introns))
+        introns = []
+        for i in range(0, len(cuts) - 1, 2):
+            d, a = cuts[i], cuts[i + 1]                 # intron = [d, a): s[d:d+2] = donor motif, s[a-2:a] = acceptor motif
+            if a - d < 8:
+                continue
+            rev = bool(rng.integers(0, 2))
+            s[d:d + 2] = "CT" if rev else "GT"
+            s[a - 2:a] = "AC" if rev else "AG"
+            introns.append((d, a, rev))
+        if seed % 4 == 0 and n > 200:                   # an N run somewhere
+            a0 = int(rng.integers(0, n - 60)); s[a0:a0 + int(rng.integers(1, 50))] = "N" * len(s[a0:a0 + int(rng.integers(1, 50))])
+        if seed % 5 == 0 and introns:                   # a second copy of the bases before a donor, with its own GT: two sites, one key
+            d = introns[0][0]
+            if d >= 20 and n - 80 > d + 40:
+                at = int(rng.integers(d + 40, n - 40)); s[at - 16:at + 2] = s[d - 16:d + 2]
+        s = "".join(s)
+        seqs.append(s)
+        for d, a, rev in introns:                       # islands on both exon ends, of assorted extents and distances from the sites
+            for end, lo, hi in ((d, max(0, d - int(rng.integers(10, 120))), d - int(rng.integers(0, 50))), (a, a + int(rng.integers(0, 50)), min(n, a + int(rng.integers(10, 120))))):
+                if hi > lo >= 0:
+                    hits.append((k + 1, lo, min(n, hi), 0, 0, 0, min(255, hi - lo)))
+            for _ in range(int(rng.integers(1, 6))):    # reads spliced across the intron, either orientation, cut to assorted lengths
+                la, lb = int(rng.integers(6, 30)), int(rng.integers(6, 30))
+                r = s[max(0, d - la):d] + s[a:a + lb]
+                if rng.integers(0, 2):
+                    r = "".join(comp[c] for c in reversed(r))
+                ium.append(r[:int(rng.choice([12, 20, 32, 40, 64]))])
+        extra = [(0, int(rng.integers(1, 60))), (max(0, n - int(rng.integers(1, 60))), n), (max(0, n - 47 - int(rng.integers(0, 30))), max(1, n - 47 + int(rng.integers(-2, 3))))]
+        if n > 400:
+            e0 = int(rng.integers(50, n - 300)); extra += [(e0, e0 + 30), (e0 + 30 + 90, e0 + 150)]        # windows that abut exactly
+        for lo, hi in extra:
+            if rng.integers(0, 3) and hi > lo:
+                hits.append((k + 1, lo, hi, 0, 0, 0, min(255, hi - lo)))
+        for _ in range(int(rng.integers(0, 20))):       # reads joining random places
+            a0, b0 = int(rng.integers(0, n - 20)), int(rng.integers(0, n - 20))
+            ium.append((s[a0:a0 + 16] + s[b0:b0 + 16]).replace("N", "A"))
+    args = (int(rng.choice([1, 6, 50])), int(rng.choice([300, 2000, 20000])))
+    return seqs, np.array(hits, dtype=HIT_DTYPE), ium, args

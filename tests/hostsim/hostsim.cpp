@@ -480,6 +480,73 @@ extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* c
 }
 
 
+// ---- butterfly search: thj_butterfly_run's kernels as loops (islands -> candidate positions -> sites -> (site, extension) keys sorted and
+// made distinct -> join -> the cut by (intron length, junction))
+extern "C" int hostsim_butterfly_search(const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs,
+                                        int64_t n_blocks, const thj_hit* hits, int64_t n_hits,
+                                        const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
+                                        int32_t min_intron, int32_t max_intron, int64_t max_juncs, thj_junction** out, int64_t* n_out) {
+    using namespace thj::cov;
+    std::vector<uint64_t> bits((size_t)n_blocks, 0), vals((size_t)n_ium * 23 + 1);
+    std::vector<int32_t> sizes((size_t)n_contigs + 1, 0);
+    std::vector<uint32_t> keys((size_t)n_ium * 23 + 1);
+    hostsim_coverage_state(contig_blk, contig_len, n_contigs, n_blocks, hits, n_hits, ium_planes, ium_lens, n_ium, W, bits.data(), sizes.data(), keys.data(), vals.data());
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    Layout L{contig_blk, contig_len, n_contigs, n_blocks};
+    const int64_t nw = n_blocks, n_ext = n_ium * 23;
+    std::vector<size_t> ord((size_t)n_ext);
+    for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
+    std::vector<uint32_t> skeys(ord.size() + 1); std::vector<u64> svals(ord.size() + 1);
+    for (size_t i = 0; i < ord.size(); ++i) { skeys[i] = keys[ord[i]]; svals[i] = vals[ord[i]]; }
+    std::vector<uint32_t> off((size_t)N_KEYS + 2);
+    for (uint32_t k = 0; k <= N_KEYS; ++k) key_offset(skeys.data(), (int64_t)ord.size(), off.data(), k);
+    ExtTable et{off.data(), svals.data(), nullptr, 0};
+    std::vector<u64> bm((size_t)nw * 6, 0);
+    u64 *V = bm.data(), *E = V + nw, *fd = E + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
+    memcpy(V, bits.data(), (size_t)nw * 8);
+    for (int k = 0; k < n_contigs; ++k) bf_drop_tail(L, V, k);
+    for (int64_t w = 0; w < nw; ++w) bf_eligible_word(L, V, E, w);
+    for (int64_t w = 0; w < nw; ++w) bf_site_word(g, L, E, fd, ra, fa, rd, w);
+    std::vector<u64> lk, rk;
+    for (int side = 0; side < 2; ++side)
+        for (int o = 0; o < 2; ++o) {
+            const u64* sites = side ? (o ? rd : fa) : (o ? ra : fd);
+            for (int64_t w = 0; w < nw; ++w) {
+                u64 b = sites[w];
+                if (!b) continue;
+                const int k = contig_of(L, w);
+                const int64_t pos0 = (w - (int64_t)contig_blk[k]) * 64;
+                while (b) {
+                    const int bit = __builtin_ctzll(b);
+                    b &= b - 1;
+                    bf_site_keys(g, L, et, (u64)(pos0 + bit) | ((u64)k << 32) | ((u64)o << 63), side != 0, [&](u64 key) { (side ? rk : lk).push_back(key); });
+                }
+            }
+        }
+    std::sort(lk.begin(), lk.end()); lk.erase(std::unique(lk.begin(), lk.end()), lk.end());
+    std::sort(rk.begin(), rk.end()); rk.erase(std::unique(rk.begin(), rk.end()), rk.end());
+    Collect c;
+    for (u64 key : lk) { const BfRange m = bf_match_range(L, rk.data(), (int64_t)rk.size(), key, min_intron, max_intron); bf_emit_pairs(m, rk.data(), key, c); }
+    auto jl = [](const thj_junction& a, const thj_junction& b) {
+        if (a.ref_id != b.ref_id) return a.ref_id < b.ref_id;
+        if (a.left != b.left) return a.left < b.left;
+        if (a.right != b.right) return a.right < b.right;
+        return a.antisense < b.antisense;
+    };
+    std::sort(c.cov.begin(), c.cov.end(), [&](const std::pair<uint32_t, thj_junction>& a, const std::pair<uint32_t, thj_junction>& b) {
+        if (a.first != b.first) return a.first < b.first;
+        return jl(a.second, b.second);
+    });
+    c.cov.erase(std::unique(c.cov.begin(), c.cov.end(), [&](const std::pair<uint32_t, thj_junction>& a, const std::pair<uint32_t, thj_junction>& b) { return a.first == b.first && !jl(a.second, b.second) && !jl(b.second, a.second); }), c.cov.end());
+    if ((int64_t)c.cov.size() > max_juncs) c.cov.resize((size_t)max_juncs);
+    *n_out = (int64_t)c.cov.size();
+    *out = (thj_junction*)malloc(sizeof(thj_junction) * (c.cov.size() + 1));
+    for (size_t i = 0; i < c.cov.size(); ++i) (*out)[i] = c.cov[i].second;
+    return 0;
+}
+
+
 // ---- microexon search: the kernel logic of thj_cov_core.h (candidates, table entries, per-window pairing) as host loops around the
 // product's own window merge (csrc/host/thj_mx_host.h) -- the path thj_microexon_collect / _candidates / _run take on the device
 #include "../../tophat_amd/csrc/host/thj_mx_host.h"

@@ -385,6 +385,26 @@ def coverage_search(g: Genome, hits: np.ndarray, ium_reads, min_cov_length: int 
     return a
 
 
+def butterfly_search(g: Genome, hits: np.ndarray, ium_reads, min_intron: int = 50, max_intron: int = 20000, max_juncs: int = 5000000) -> np.ndarray:
+    """orc_butterfly_search (segment_juncs.cpp:4178-4249, :1698-2049): the inputs of coverage_search -> JUNC_DTYPE array in Junction order"""
+    from tophat_amd.batch import HIT_DTYPE
+    lib = _lib()
+    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    bases = "".join(ium_reads).encode()
+    off = np.zeros(len(ium_reads) + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in ium_reads], out=off[1:])
+    out = C.c_void_p()
+    n = C.c_int64()
+    rc = lib.orc_butterfly_search(C.byref(g.c), C.c_void_p(h.ctypes.data), C.c_int64(len(h)), C.c_char_p(bases), C.c_void_p(off.ctypes.data),
+                                  C.c_int64(len(ium_reads)), int(min_intron), int(max_intron), C.c_int64(max_juncs), C.byref(out), C.byref(n))
+    assert rc == 0
+    a = np.zeros(0, dtype=JUNC_DTYPE)
+    if n.value:
+        a = np.frombuffer((C.c_char * (n.value * 16)).from_address(out.value), dtype=JUNC_DTYPE).copy()
+    lib.orc_free(out)
+    return a
+
+
 def _orc_batch(b: SegBatch):
     ob = OrcBatch()
     ob.n_reads, ob.nseg = b.n_reads, b.nseg

@@ -226,6 +226,25 @@ def coverage_run(seqs, states, min_cov_length: int, min_intron: int = 50, max_in
     return {(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"])) for j in a}
 
 
+def butterfly_search(seqs, hits, ium_reads, min_intron: int = 50, max_intron: int = 20000, max_juncs: int = 5000000):
+    """the butterfly-search kernels (thj_cov_core.h: bf_*) as host loops -> set of (ref_id, left, right, antisense)"""
+    from tophat_amd.batch import HIT_DTYPE
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    clen = g.lens.astype(np.int32)
+    h = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    planes, lens, W, n = _pack_ium(l, ium_reads)
+    out = C.c_void_p()
+    n_out = C.c_int64()
+    rc = l.hostsim_butterfly_search(C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data), g.n_contigs,
+                                    C.c_int64(len(g.blocks) // 4), C.c_void_p(h.ctypes.data), C.c_int64(len(h)), C.c_void_p(planes.ctypes.data),
+                                    C.c_void_p(lens.ctypes.data), C.c_int64(n), W, int(min_intron), int(max_intron), C.c_int64(max_juncs), C.byref(out), C.byref(n_out))
+    assert rc == 0
+    a = np.frombuffer((C.c_char * (max(1, n_out.value) * 16)).from_address(out.value), dtype=JUNC_DTYPE)[:n_out.value].copy()
+    l.hostsim_free(out)
+    return {(int(j["ref_id"]), int(j["left"]), int(j["right"]), int(j["antisense"])) for j in a}
+
+
 def coverage_search(seqs, hits, ium_reads, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000, max_juncs: int = 5000000):
     """the coverage-search kernels (thj_cov_core.h) as host loops -> set of (ref_id, left, right, antisense)"""
     return coverage_run(seqs, [coverage_state(seqs, hits, ium_reads)], min_cov_length, min_intron, max_intron, max_juncs)

@@ -1,7 +1,7 @@
 // segment_juncs -- MI355X-native drop-in for TopHat's segment_juncs (same argv + files; tophat.py:3097-3112,
 // parsed like segment_juncs.cpp:5186-5364).  Host C++ over the C ABI in include/thj.h; all per-read work runs in
 // the HIP kernels of libthj_hip.so.  Split-segment search, small indels, the paired-end rescue, --fusion-search and the
-// coverage search and the microexon search are supported; the butterfly search is refused loudly.
+// coverage search, the microexon search and the (opt-in) butterfly search are supported.
 //
 // One process drives every visible GPU.  The reads are cut into contiguous read-id shards with the
 // reference's own planner (calculate_offsets over the inputs' .index files, utils.cpp:22-170; segment_juncs.cpp:4756-4810);
@@ -120,7 +120,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
     const int nseg = (int)in.segs.size();
     // one segment map: no segment search (segment_juncs.cpp:4752 `size() > 1`), but its hits still belong to the coverage
     // map (all_segmap_fnames :4929-4935)
-    if (nseg < 1 || (nseg == 1 && o.no_coverage_search)) return;
+    if (nseg < 1 || (nseg == 1 && !o.cov_state)) return;
     const long long t_shard = WorkClock::now();
     struct AtExit { long long t; ~AtExit() { g_work.add(0, t); } } at_exit{t_shard};
     // ---- device-side ingest (thj_ingest_seg_batch): every input a mapped BAM -> the host only points at compressed bytes
@@ -165,14 +165,14 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
             thj_seg_batch* dev = nullptr;
             int64_t n = 0;
             const int rc = thj_ingest_seg_batch(ctx, &p, nseg, segp.data(), have_mf ? &mf : nullptr, have_ml ? &ml : nullptr, &rp, b_id, e_id,
-                                                (o.fusion_search || !o.no_coverage_search) ? 1 : 0, ordinal, &dev, &n);
+                                                (o.fusion_search || o.cov_state) ? 1 : 0, ordinal, &dev, &n);
             if (rc == THJ_OK) {
                 if ((uint64_t)ordinal + (uint64_t)n > ordinal_limit)
                     die("Error: too many reads on the %s side for the device's read ordinals (read ids must stay below %u)\n", read_side == 1 ? "left" : "right", RIGHT_ORDINAL_BASE);
                 if (dev) {
                     if (nseg > 1 && thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
                     if (nseg > 1 && o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
-                    if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
+                    if (o.cov_state && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
                     if (!o.no_microexon_search && thj_microexon_collect(ctx, &p, dev, read_side)) die("Error: %s\n", thj_last_error());
                     if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
                 }
@@ -233,7 +233,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
             if (thj_batch_upload(ctx, &hb, (int64_t)hits.size(), (int64_t)mate_hits.size(), &dev)) die("Error: %s\n", thj_last_error());
             if (nseg > 1 && thj_segjuncs_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
             if (nseg > 1 && o.fusion_search && thj_fusion_run_async(ctx, &p, dev)) die("Error: %s\n", thj_last_error());
-            if (!o.no_coverage_search && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
+            if (o.cov_state && thj_covsearch_add_hits_async(ctx, dev)) die("Error: %s\n", thj_last_error());
             if (!o.no_microexon_search && thj_microexon_collect(ctx, &p, dev, read_side)) die("Error: %s\n", thj_last_error());
             if (thj_batch_free(ctx, dev)) die("Error: %s\n", thj_last_error());
             g_work.add(2, td);
@@ -257,7 +257,7 @@ static void run_shard(const std::function<thj_ctx*(Gpu&)>& device_ready, Gpu& gp
         // they are event-neutral for the gap / indel finders, so with --fusion-search they simply ride along
         // ... and with the coverage search on their hits belong to the coverage map (build_coverage_map :4140-4176 walks
         // every record of every segment map)
-        if (top < 0 || (top == 0 && !o.fusion_search && o.no_coverage_search)) continue;
+        if (top < 0 || (top == 0 && !o.fusion_search && !o.cov_state)) continue;
         Read rd;
         if (!reads.get(id, rd)) die("Error: could not get read# %d from stream!", (int)id);
         for (int s = 0; s < nseg; ++s) { for (auto& h : grp[(size_t)s]) hits.push_back(h.h16); seg_off.push_back((uint32_t)hits.size()); }
@@ -290,9 +290,9 @@ static int real_main(int argc, char** argv) {
     for (int i = optind; i < argc; ++i) pos.push_back(argv[i]);
     if (pos.size() < 8 || (pos.size() > 8 && pos.size() < 11)) { print_usage(); return 1; }
     if (o.color) die("Error: colour-space reads are not supported by this build\n");
-    if (o.butterfly_search)
-        die("Error: the butterfly search is not supported by this build; run without --butterfly-search (tophat.py never passes it, tophat.py:1088)\n");
-    if (o.ium_reads.empty()) o.no_coverage_search = true;             // no unmapped reads: segment_juncs.cpp:4978-4982
+    if (o.ium_reads.empty()) { o.no_coverage_search = true; o.butterfly_search = false; }      // no unmapped reads: segment_juncs.cpp:4978-4982
+    // the coverage map and the extension table are what both the coverage search and the butterfly search work from (:4955)
+    o.cov_state = !o.no_coverage_search || o.butterfly_search;
     SideInput left{pos[5], pos[6], split(pos[7], ',')}, right;
     if (pos.size() >= 11) right = SideInput{pos[8], pos[9], split(pos[10], ',')};
     if (left.segs.empty()) { fprintf(stderr, "No hits to process, exiting\n"); return 0; }      // segment_juncs.cpp:4724-4728
@@ -359,7 +359,7 @@ static int real_main(int argc, char** argv) {
         rt.upload(g.ctx);
         if (thj_segjuncs_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
         if (o.fusion_search && thj_fusion_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
-        if (!o.no_coverage_search && thj_covsearch_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
+        if (o.cov_state && thj_covsearch_reset_async(g.ctx)) die("Error: %s\n", thj_last_error());
         if (!fusion_ignore_ids.empty() && thj_fusion_set_ignored(g.ctx, fusion_ignore_ids.data(), (int32_t)fusion_ignore_ids.size())) die("Error: %s\n", thj_last_error());
         return g.ctx;
     };
@@ -368,7 +368,7 @@ static int real_main(int argc, char** argv) {
     // (index_read_mers :548-571 -- the first 32 bases of every read) is fed to the device on its own thread while the
     // two sides are being ingested (chunks go round the GPUs; the exchange step concatenates the tables anyway)
     std::thread ium_thread;
-    if (!o.no_coverage_search)
+    if (o.cov_state)
         ium_thread = std::thread([&]() {
             const size_t CH = (size_t)1 << 19;
             size_t turn = 0;
@@ -451,7 +451,7 @@ static int real_main(int argc, char** argv) {
     for (auto& g : gpus) { std::lock_guard<std::mutex> lk(g->mu); device_ready(*g); }
     g_timer.lap("device start-up + ingest + pack + upload + launch (all shards)");
     fprintf(stderr, "\tshards read on the host because the device-side ingest declined them: %lld\n", g_host_ingest_shards.load());
-    if (!o.no_coverage_search) ium_thread.join();            // the unmapped reads went up beside the segment search
+    if (o.cov_state) ium_thread.join();            // the unmapped reads went up beside the segment search
 
     // ---- the exchange step and the end of the pass, one host thread per GPU (each rank's collective calls come from its
     // own thread, include/thj.h).  With one GPU the same calls run without a communicator.
@@ -481,12 +481,20 @@ static int real_main(int argc, char** argv) {
     auto end_of_pass = [&](int r) {
         thj_ctx* ctx = gpus[(size_t)r]->ctx;
         thj_comm* cm = comms[(size_t)r];
+        if (o.cov_state && cm && thj_covsearch_allgather(ctx, cm)) die("Error: %s\n", thj_last_error());
         if (!o.no_coverage_search) {
             if (r == 0) fprintf(stderr, ">> Performing coverage-search:\n");
-            if (cm && thj_covsearch_allgather(ctx, cm)) die("Error: %s\n", thj_last_error());
             int mcl = 20; if (mcl > o.p.segment_length - 2) mcl = o.p.segment_length - 2;          // :62, :5350
             if (thj_covsearch_run_async(ctx, mcl, o.min_coverage_intron, o.max_coverage_intron)) die("Error: %s\n", thj_last_error());
             if (thj_covsearch_finish(ctx, 5000000, &n_cov[(size_t)r])) die("Error: %s\n", thj_last_error());        // max_cov_juncs :56
+        }
+        if (o.butterfly_search && r == 0) {
+            // pair_covered_sites (segment_juncs.cpp:4998-5012) over the gathered coverage map and extension table: one rank does it, the
+            // exchange step below hands its junctions to the others
+            int64_t n_bf = 0;
+            fprintf(stderr, ">> Performing butterfly-search: \n");
+            if (thj_butterfly_run(ctx, o.min_coverage_intron, o.max_coverage_intron, 5000000, &n_bf)) die("Error: %s\n", thj_last_error());
+            fprintf(stderr, "\tfound %d potential junctions\n", (int)n_bf);
         }
         if (!o.no_microexon_search && r == 0) {
             fprintf(stderr, ">> Performing microexon-search: \n");

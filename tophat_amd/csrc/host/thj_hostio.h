@@ -183,6 +183,7 @@ struct WorkClock {
 struct Opts {
     thj_params p;
     bool no_coverage_search = false, no_microexon_search = false, butterfly_search = false, fusion_search = false;
+    bool cov_state = false;         // segment_juncs: the coverage map and the extension table are kept (coverage or butterfly search)
     bool color = false, bowtie2 = true, fusion_do_not_resolve_conflicts = false;
     std::string fusion_ignore;
     int num_threads = 1;

@@ -290,6 +290,140 @@ THJ_HD unsigned int pair_word(const Genome& g, const Layout& L, const ExtTable& 
 }
 
 
+// ================================================================================================ butterfly search
+// segment_juncs.cpp:4178-4249 (pair_covered_sites), :1698-2049 (ButterflyKey, RecordButterflyJuncs::record), :466-501 (the extension
+// table pruned to butterfly_overhang = 6 bases a side and compacted).  Opt-in (--butterfly-search).
+// Every island of the coverage map (a maximal covered run [s, e)) is one window [max(s - 45, 0), e + 45) searched for all four
+// dinucleotides; a window reaching the contig's last base but one is dropped whole (:2154).  A position p is therefore a candidate
+// site iff some kept island has a covered base within [p - 44, p + 45]: the dilation below.  The reference's windows of
+// 2 * max_intron bases over the sorted sites only bound its working set -- every (donor, acceptor) pair within (min, max) intron
+// shares a window -- so the pairing here is one join over the whole genome: all (site, extension) keys of the left sites and of
+// the right sites sorted, equal keys within reach paired.
+static constexpr int BF_OVERHANG = 6;
+static constexpr u64 BF_POS_MASK = (1ull << 34) - 1ull;
+
+// islands whose window the reference drops: those whose last covered base lies at len - 47 or beyond.  V = the coverage bitmap's
+// copy; one call per contig.
+THJ_HD void bf_drop_tail(const Layout& L, u64* V, int k) {
+    const int64_t wbase = (int64_t)L.contig_blk[k], nwords = (int64_t)L.contig_blk[k + 1] - wbase, len = L.contig_len[k];
+    int64_t T = len - (EXTEND + 2);
+    if (T < 0) T = 0;
+    const bool straddles = T > 0 && ((V[wbase + (T >> 6)] >> (T & 63)) & 1ull);
+    for (int64_t w = T >> 6; w < nwords; ++w) V[wbase + w] &= below_mask(T - (w << 6));
+    if (!straddles) return;
+    int64_t p = T - 1;                                  // the island that reaches T: cleared back to its first base
+    while (p >= 0) {
+        const int64_t w = p >> 6; const int b = (int)(p & 63);
+        const u64 m = below_mask(b + 1), zeros = ~V[wbase + w] & m;
+        if (!zeros) { V[wbase + w] &= ~m; p = (w << 6) - 1; continue; }
+        const int hz = 63 - __builtin_clzll(zeros);     // the highest uncovered base at or below p
+        V[wbase + w] &= ~(m & ~below_mask(hz + 1));
+        break;
+    }
+}
+// candidate positions: E[p] = OR of V[p - 44 .. p + 45]
+THJ_HD void bf_eligible_word(const Layout& L, const u64* V, u64* E, int64_t w) {
+    const int k = contig_of(L, w);
+    const W3 x = load3(V, L, k, w);
+    u64 e = 0;
+    for (int d = 0; d <= EXTEND; ++d) e |= shr2(x.b, x.c, d);
+    for (int d = 1; d < EXTEND; ++d) e |= shl2(x.a, x.b, d);
+    E[w] = e;
+}
+// sites: a dinucleotide whose first base is a candidate position (both scans of a window cover the same bases); N reads as A
+THJ_HD void bf_site_word(const Genome& g, const Layout& L, const u64* E, u64* fd, u64* ra, u64* fa, u64* rd, int64_t w) {
+    const int k = contig_of(L, w);
+    const bool last = w + 1 >= (int64_t)L.contig_blk[k + 1];
+    const u64* p0 = g.blocks + w * 4;
+    const u64 nm = p0[2], lo = p0[0] & ~nm, hi = p0[1] & ~nm;
+    u64 nlo = 0, nhi = 0;
+    if (!last) { const u64* p1 = p0 + 4; const u64 nm1 = p1[2]; nlo = p1[0] & ~nm1; nhi = p1[1] & ~nm1; }
+    const u64 lo1 = (lo >> 1) | (nlo << 63), hi1 = (hi >> 1) | (nhi << 63);
+    const u64 A = ~lo & ~hi, C = lo & ~hi, G = ~lo & hi;
+    const u64 C1 = lo1 & ~hi1, G1 = ~lo1 & hi1, T1 = lo1 & hi1;
+    const u64 e = E[w];
+    fd[w] = e & G & T1;           // GT   fwd donor
+    ra[w] = e & C & T1;           // CT   rev acceptor
+    fa[w] = e & A & G1;           // AG   fwd acceptor
+    rd[w] = e & A & C1;           // AC   rev donor
+}
+// The keys of one listed site (entry = contig position | contig << 32 | antisense << 63, as k_list_sites writes it): one per entry of
+// the two seeds' buckets that has six bases on the side wanted.  emit(antisense << 58 | key << 34 | global position); the 24-bit key
+// = the six seed bases next to the splice site and the six bases the read shows beyond it (:1803-1870 left sites, :1874-1980 right
+// sites; the table is read unpruned: six bases of a longer extension are what pruning leaves).
+template <class Emit>
+THJ_HD void bf_site_keys(const Genome& g, const Layout& L, const ExtTable& t, u64 entry, bool right_side, Emit emit) {
+    const int k = (int)((entry >> 32) & 0x7FFFFFFFull);
+    const int64_t pos = (int64_t)(entry & 0xFFFFFFFFull), len = L.contig_len[k];
+    const u64 head = ((entry >> 63) << 58), gpos = (u64)L.contig_blk[k] * 64ull + (u64)pos;
+    u64 f = 0, r = 0;
+    if (!right_side) {
+        if (pos > 32 && pos < len) { f = mer32(g, (uint32_t)k + 1, pos - 32); r = rc32(f); }          // attach_upstream_mers
+        const uint32_t fwd_up = (uint32_t)(f & 0xFFFFFull), rev_up = (uint32_t)(r >> 44);
+        const u64 top = (u64)(fwd_up & 0xFFFu) << 12;
+        for (uint32_t i = t.off[fwd_up]; i < t.off[fwd_up + 1]; ++i) {
+            const u64 v = t.val[i];
+            const int rl = (int)(v >> 60);
+            if (rl < BF_OVERHANG) continue;
+            emit(head | ((((v >> 32) & 0x0FFFFFFFull) >> (2 * (rl - BF_OVERHANG))) | top) << 34 | gpos);
+        }
+        for (uint32_t i = t.off[rev_up]; i < t.off[rev_up + 1]; ++i) {
+            const u64 v = t.val[i];
+            if ((int)((v >> 28) & 15) < BF_OVERHANG) continue;
+            emit(head | ((rc32(v & 0xFFFull) >> 52) | top) << 34 | gpos);                          // the forward seed's bases here too, as the reference has it
+        }
+    } else {
+        if (pos + 2 + 32 < len) { f = mer32(g, (uint32_t)k + 1, pos + 2); r = rc32(f); }              // attach_downstream_mers
+        const uint32_t fwd_down = (uint32_t)(f >> 44), rev_down = (uint32_t)(r & 0xFFFFFull);
+        const u64 bottom = (u64)(fwd_down >> 8);
+        for (uint32_t i = t.off[fwd_down]; i < t.off[fwd_down + 1]; ++i) {
+            const u64 v = t.val[i];
+            if ((int)((v >> 28) & 15) < BF_OVERHANG) continue;
+            emit(head | (((v & 0xFFFull) << 12) | bottom) << 34 | gpos);
+        }
+        for (uint32_t i = t.off[rev_down]; i < t.off[rev_down + 1]; ++i) {
+            const u64 v = t.val[i];
+            const int rl = (int)(v >> 60);
+            if (rl < BF_OVERHANG) continue;
+            const u64 six = ((v >> 32) & 0x0FFFFFFFull) >> (2 * (rl - BF_OVERHANG));
+            emit(head | (((rc32(six) >> 52) << 12) | bottom) << 34 | gpos);
+        }
+    }
+}
+// the right keys a left key pairs with: the same antisense and key, the same contig, acceptor - donor within (min_intron, max_intron)
+// where donor = left position - 1 and acceptor = right position + 2 (:2013-2041).  rkeys sorted, distinct.
+struct BfRange { int64_t lo, hi; int k; int64_t cstart; };
+THJ_HD BfRange bf_match_range(const Layout& L, const u64* rkeys, int64_t n_r, u64 lkey, int min_intron, int max_intron) {
+    BfRange o{0, 0, 0, 0};
+    const u64 gk = lkey >> 34;
+    const int64_t lg = (int64_t)(lkey & BF_POS_MASK);
+    o.k = contig_of(L, lg >> 6);
+    o.cstart = (int64_t)L.contig_blk[o.k] * 64;
+    int64_t a = lg + min_intron - 2, b = lg + (int64_t)max_intron - 4;
+    const int64_t cend = o.cstart + L.contig_len[o.k];
+    if (a < o.cstart) a = o.cstart;
+    if (b > cend - 1) b = cend - 1;
+    if (a > b) return o;
+    const u64 ka = (gk << 34) | (u64)a, kb = (gk << 34) | (u64)b;
+    int64_t lo = 0, hi = n_r;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] < ka) lo = mid + 1; else hi = mid; }
+    o.lo = lo;
+    hi = n_r;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (rkeys[mid] <= kb) lo = mid + 1; else hi = mid; }
+    o.hi = lo;
+    return o;
+}
+template <class Sink>
+THJ_HD void bf_emit_pairs(const BfRange& m, const u64* rkeys, u64 lkey, Sink& ev) {
+    const int64_t lpos = (int64_t)(lkey & BF_POS_MASK) - m.cstart;
+    for (int64_t j = m.lo; j < m.hi; ++j) {
+        const int64_t rpos = (int64_t)(rkeys[j] & BF_POS_MASK) - m.cstart;
+        const int64_t donor = lpos - 1, acceptor = rpos + 2;
+        ev.cov_junction((uint32_t)m.k + 1, (uint32_t)donor, (uint32_t)acceptor, ((lkey >> 58) & 1ull) != 0, (uint32_t)(acceptor - donor));      // skip count = the intron's length
+    }
+}
+
+
 // ================================================================================================ microexon search
 // segment_juncs.cpp:3880-3941 (window registration in look_for_hit_group), :3675-3735 (add_to_microexon_windows -- host code,
 // csrc/host/thj_mx_host.h), :3737-3815 (align_microexon_segs).  Per merged window: an extension table made of the window's own

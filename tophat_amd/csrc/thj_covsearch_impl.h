@@ -115,6 +115,55 @@ __global__ __launch_bounds__(256) void k_pair(Genome g, Layout L, ExtTable et, c
 }
 
 
+// ---- butterfly search (thj_cov_core.h: bf_*)
+__global__ void k_bf_drop_tail(Layout L, u64* V) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < L.n_contigs) bf_drop_tail(L, V, k);
+}
+__global__ void k_bf_eligible(Layout L, const u64* V, u64* E) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w < L.n_words) bf_eligible_word(L, V, E, w);
+}
+__global__ void k_bf_sites(Genome g, Layout L, const u64* E, u64* fd, u64* ra, u64* fa, u64* rd) {
+    const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (w < L.n_words) bf_site_word(g, L, E, fd, ra, fa, rd, w);
+}
+// one thread per listed site: its keys counted, their places taken with one atomic, then written (nothing is written past `cap`;
+// the counter still says how many there are)
+__global__ void k_bf_keys(Genome g, Layout L, ExtTable et, const u64* list, unsigned int n, int right_side, u64* out, unsigned long long* count, unsigned long long cap) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const u64 e = list[i];
+        unsigned int m = 0;
+        bf_site_keys(g, L, et, e, right_side != 0, [&](u64) { ++m; });
+        if (!m) continue;
+        unsigned long long at = atomicAdd(count, (unsigned long long)m);
+        if (at + m > cap) continue;
+        bf_site_keys(g, L, et, e, right_side != 0, [&](u64 key) { out[at++] = key; });
+    }
+}
+__global__ void k_bf_join_count(Layout L, const u64* lk, int64_t nl, const u64* rk, int64_t nr, int min_intron, int max_intron, unsigned long long* total) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nl; i += (int64_t)gridDim.x * blockDim.x) {
+        const BfRange m = bf_match_range(L, rk, nr, lk[i], min_intron, max_intron);
+        if (m.hi > m.lo) atomicAdd(total, (unsigned long long)(m.hi - m.lo));
+    }
+}
+struct ReservedSink {
+    const Genome& g; u64* keys; uint32_t* skips; unsigned long long at, end;
+    __device__ void cov_junction(uint32_t ref, uint32_t l, uint32_t r, bool a, uint32_t skip) {
+        if (at < end) { keys[at] = junc_key(g, ref, l, r, a); skips[at] = skip; }
+        ++at;
+    }
+};
+__global__ void k_bf_join_emit(Genome g, Layout L, const u64* lk, int64_t nl, const u64* rk, int64_t nr, int min_intron, int max_intron,
+                               u64* jkeys, uint32_t* jskips, unsigned long long* count, unsigned long long cap) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nl; i += (int64_t)gridDim.x * blockDim.x) {
+        const BfRange m = bf_match_range(L, rk, nr, lk[i], min_intron, max_intron);
+        if (m.hi <= m.lo) continue;
+        const unsigned long long at = atomicAdd(count, (unsigned long long)(m.hi - m.lo));
+        ReservedSink ev{g, jkeys, jskips, at, cap};
+        bf_emit_pairs(m, rk, lk[i], ev);
+    }
+}
 // ---- microexon search (thj_cov_core.h): candidates of a batch's reads, table entries of the windows' strings, one wave per window
 __global__ __launch_bounds__(256) void k_mx_cands(Genome g, const Hit* hits, const uint32_t* seg_off, const u64* planes, const uint16_t* read_len, int n_reads, int nseg, int W,
                                                   uint32_t ordinal_base, int seg_len, int min_anchor, int side, MxCand* out, unsigned long long* count, unsigned long long cap) {
@@ -321,6 +370,22 @@ extern "C" int thj_covsearch_merge_async(thj_ctx* c, const uint64_t* d_other_bit
     return THJ_OK;
 }
 
+// the extension table: the entries sorted by seed, then offsets per seed (d_ext_off)
+static int cov_sort_table(thj_ctx* c, const uint32_t** keys_out, const u64** vals_out) {
+    const uint32_t* keys = c->d_ext_key; const u64* vals = c->d_ext_val;
+    if (c->n_ext) {
+        size_t need = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, need, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream);
+        if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+        size_t bytes = c->sort_tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream));
+        keys = c->d_ext_key_sorted; vals = c->d_ext_val_sorted;
+    }
+    hipLaunchKernelGGL(cov_k::k_key_offsets, dim3((thj::cov::N_KEYS + 1 + 255) / 256), dim3(256), 0, c->stream, keys, c->n_ext, c->d_ext_off);
+    *keys_out = keys; *vals_out = vals;
+    return THJ_OK;
+}
+
 extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32_t min_intron, int32_t max_intron) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     if (min_cov_length < 2 || min_cov_length > 64) { thj_set_error("min_cov_length %d unsupported (2..64)", min_cov_length); return THJ_EINVAL; }
@@ -332,17 +397,8 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
     const int64_t nw = c->n_blocks;
     thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, nw};
     u64 *covb = c->d_cov, *le = covb + nw, *ll = le + nw, *lr = ll + nw, *fd = lr + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
-    // the extension table: sort the entries by seed, then offsets per seed
-    const uint32_t* keys = c->d_ext_key; const u64* vals = c->d_ext_val;
-    if (c->n_ext) {
-        size_t need = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, need, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream);
-        if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
-        size_t bytes = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream));
-        keys = c->d_ext_key_sorted; vals = c->d_ext_val_sorted;
-    }
-    hipLaunchKernelGGL(cov_k::k_key_offsets, dim3((thj::cov::N_KEYS + 1 + 255) / 256), dim3(256), 0, c->stream, keys, c->n_ext, c->d_ext_off);
+    const uint32_t* keys = nullptr; const u64* vals = nullptr;
+    if ((rc = cov_sort_table(c, &keys, &vals))) return rc;
     const unsigned gw = (unsigned)((nw + 255) / 256);
     hipLaunchKernelGGL(cov_k::k_long_enough, dim3(gw), dim3(256), 0, c->stream, L, covb, le, (int)min_cov_length - 1);
     hipLaunchKernelGGL(cov_k::k_look, dim3(gw), dim3(256), 0, c->stream, L, le, c->d_cov_size, ll, lr);
@@ -373,10 +429,11 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
 
 // the (junction key, skip count) list of a pairing pass -> the pass's junction set; more than max_juncs: the set ordered by skip count
 // keeps its smallest elements (segment_juncs.cpp:1611-1621): sort by (skip count, junction), take the first max_juncs
-static int cov_cut_and_merge(thj_ctx* c, int64_t n, int64_t max_juncs, int64_t* n_found) {
+static int cov_cut_and_merge(thj_ctx* c, int64_t n, int64_t max_juncs, int64_t* n_found, bool distinct = false) {
+    // distinct: the list may hold a junction twice (the butterfly search finds a pair under more than one key): count and cut over distinct elements
     const u64* keys = c->d_cov_jkey;
     int64_t take = n;
-    if (take > max_juncs) {
+    if (take > max_juncs || (distinct && take > 0)) {
         if (n >= (1ll << 31)) { thj_set_error("more than 2^31 junction candidates"); return THJ_EOVERFLOW; }
         // stable LSD order: by junction key, then by skip count
         size_t b1 = 0, b2 = 0;
@@ -440,6 +497,115 @@ extern "C" int thj_covsearch_finish(thj_ctx* c, int64_t max_cov_juncs, int64_t* 
     }
     c->cov_pending = false;
     return cov_cut_and_merge(c, (int64_t)n, max_cov_juncs, n_found);
+}
+
+
+// ------------------------------------------------------------------------------------------------ butterfly search
+static int bf_sorted_distinct(thj_ctx* c, u64* in, u64* tmp, int64_t n, int64_t* n_out) {          // result in `in`
+    if (n == 0) { *n_out = 0; return THJ_OK; }
+    if (n >= (1ll << 31)) { thj_set_error("butterfly search: more than 2^31 (site, extension) keys"); return THJ_EOVERFLOW; }
+    size_t b1 = 0, b2 = 0;
+    int* d_num = nullptr;
+    hipcub::DeviceRadixSort::SortKeys(nullptr, b1, in, tmp, (int)n, 0, 59, c->stream);
+    hipcub::DeviceSelect::Unique(nullptr, b2, tmp, in, d_num, (int)n, c->stream);
+    const size_t need = (b1 > b2 ? b1 : b2);
+    if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+    HIPCHK(hipMalloc(&d_num, sizeof(int)));
+    size_t bytes = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, bytes, in, tmp, (int)n, 0, 59, c->stream));
+    bytes = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceSelect::Unique(c->d_sort_tmp, bytes, tmp, in, d_num, (int)n, c->stream));
+    int h = 0;
+    HIPCHK(hipMemcpyAsync(&h, d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    hipFree(d_num);
+    *n_out = h;
+    return THJ_OK;
+}
+
+extern "C" int thj_butterfly_run(thj_ctx* c, int32_t min_intron, int32_t max_intron, int64_t max_juncs, int64_t* n_found) {
+    if (!c || max_juncs < 0) { thj_set_error("thj_butterfly_run: bad argument"); return THJ_EINVAL; }
+    if (max_intron < 1 || max_intron > (1 << 29)) { thj_set_error("coverage intron bounds [%d, %d) unsupported", min_intron, max_intron); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    if (c->cov_pending) { thj_set_error("thj_butterfly_run: thj_covsearch_finish first (the passes share buffers)"); return THJ_ESTATE; }
+    if ((rc = maybe_grow_tables(c))) return rc;
+    if (n_found) *n_found = 0;
+    const int64_t nw = c->n_blocks;
+    thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, nw};
+    Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
+    u64 *covb = c->d_cov, *V = covb + nw, *E = V + nw, *fd = covb + 4 * nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
+    const uint32_t* keys = nullptr; const u64* vals = nullptr;
+    if ((rc = cov_sort_table(c, &keys, &vals))) return rc;
+    thj::cov::ExtTable et{c->d_ext_off, vals, nullptr, 0};
+    const unsigned gw = (unsigned)((nw + 255) / 256);
+    HIPCHK(hipMemcpyAsync(V, covb, (size_t)nw * 8, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(cov_k::k_bf_drop_tail, dim3((unsigned)((c->n_contigs + 63) / 64)), dim3(64), 0, c->stream, L, V);
+    hipLaunchKernelGGL(cov_k::k_bf_eligible, dim3(gw), dim3(256), 0, c->stream, L, (const u64*)V, E);
+    hipLaunchKernelGGL(cov_k::k_bf_sites, dim3(gw), dim3(256), 0, c->stream, g, L, (const u64*)E, fd, ra, fa, rd);
+    // the sites of each side as a list, their keys, sorted and distinct
+    unsigned long long* d_cnt = nullptr;            // [0] sites listed / keys written, [1] pairs
+    HIPCHK(hipMalloc(&d_cnt, 16));
+    u64* side_keys[2] = {nullptr, nullptr}; int64_t side_n[2] = {0, 0};
+    auto cleanup = [&]() { hipFree(d_cnt); hipFree(side_keys[0]); hipFree(side_keys[1]); };
+    for (int side = 0; side < 2; ++side) {
+        const u64 *b0 = side ? fa : fd, *b1 = side ? rd : ra;
+        unsigned int* n_list = (unsigned int*)d_cnt;
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
+        hipLaunchKernelGGL(cov_k::k_list_sites, dim3(gw), dim3(256), 0, c->stream, L, b0, b1, (u64*)nullptr, n_list, 0u);        // counts only
+        unsigned int n_sites = 0;
+        HIPCHK(hipMemcpyAsync(&n_sites, n_list, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (!n_sites) continue;
+        u64* list = nullptr;
+        HIPCHK(hipMalloc(&list, (size_t)n_sites * 8));
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
+        hipLaunchKernelGGL(cov_k::k_list_sites, dim3(gw), dim3(256), 0, c->stream, L, b0, b1, list, n_list, n_sites);
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
+        hipLaunchKernelGGL(cov_k::k_bf_keys, dim3(2048), dim3(256), 0, c->stream, g, L, et, (const u64*)list, n_sites, side, (u64*)nullptr, d_cnt, 0ull);      // counts only
+        unsigned long long n_keys = 0;
+        HIPCHK(hipMemcpyAsync(&n_keys, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (n_keys) {
+            u64* tmp = nullptr;
+            if (hipMalloc(&side_keys[side], (size_t)n_keys * 8) != hipSuccess || hipMalloc(&tmp, (size_t)n_keys * 8) != hipSuccess) {
+                hipFree(tmp); hipFree(list); cleanup();
+                thj_set_error("butterfly search: no device memory for %llu (site, extension) keys", n_keys); return THJ_ENOMEM;
+            }
+            HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
+            hipLaunchKernelGGL(cov_k::k_bf_keys, dim3(2048), dim3(256), 0, c->stream, g, L, et, (const u64*)list, n_sites, side, side_keys[side], d_cnt, n_keys);
+            rc = bf_sorted_distinct(c, side_keys[side], tmp, (int64_t)n_keys, &side_n[side]);
+            hipFree(tmp);
+            if (rc) { hipFree(list); cleanup(); return rc; }
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(list);
+    }
+    if (!side_n[0] || !side_n[1]) { cleanup(); return THJ_OK; }
+    // the join: pairs counted, room made in the (junction key, skip count) list, pairs written
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
+    hipLaunchKernelGGL(cov_k::k_bf_join_count, dim3(2048), dim3(256), 0, c->stream, L, (const u64*)side_keys[0], side_n[0], (const u64*)side_keys[1], side_n[1],
+                       (int)min_intron, (int)max_intron, d_cnt + 1);
+    unsigned long long n_pairs = 0;
+    HIPCHK(hipMemcpyAsync(&n_pairs, d_cnt + 1, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_pairs >= (1ull << 31)) { cleanup(); thj_set_error("butterfly search: %llu candidate pairs (more than 2^31)", n_pairs); return THJ_EOVERFLOW; }
+    if (!n_pairs) { cleanup(); return THJ_OK; }
+    if (!c->d_cov_jkey || (int64_t)n_pairs > c->cov_jcap) {
+        hipFree(c->d_cov_jkey); hipFree(c->d_cov_jskip); hipFree(c->d_cov_jkey2); hipFree(c->d_cov_jskip2);
+        c->d_cov_jkey = c->d_cov_jkey2 = nullptr; c->d_cov_jskip = c->d_cov_jskip2 = nullptr;
+        c->cov_jcap = (int64_t)n_pairs + (int64_t)n_pairs / 8 + 1024;
+        HIPCHK(hipMalloc(&c->d_cov_jkey, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip, (size_t)c->cov_jcap * 4));
+        HIPCHK(hipMalloc(&c->d_cov_jkey2, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip2, (size_t)c->cov_jcap * 4));
+    }
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
+    hipLaunchKernelGGL(cov_k::k_bf_join_emit, dim3(2048), dim3(256), 0, c->stream, g, L, (const u64*)side_keys[0], side_n[0], (const u64*)side_keys[1], side_n[1],
+                       (int)min_intron, (int)max_intron, c->d_cov_jkey, c->d_cov_jskip, d_cnt, (unsigned long long)c->cov_jcap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    cleanup();
+    return cov_cut_and_merge(c, (int64_t)n_pairs, max_juncs, n_found, true);
 }
 
 

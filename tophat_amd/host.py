@@ -368,6 +368,13 @@ class Context:
         _check(self.lib, self.lib.thj_covsearch_finish(self._ctx, C.c_int64(max_cov_juncs), C.byref(found)), "thj_covsearch_finish")
         return found.value
 
+    def butterfly_run(self, min_intron: int = 50, max_intron: int = 20000, max_cov_juncs: int = 5000000) -> int:
+        """--butterfly-search (segment_juncs.cpp:4178-4249, :1698-2049) from the coverage map and the extension table of the
+        covsearch_add_* calls; after covsearch_finish when the coverage search runs too.  -> junctions added to the pass's set"""
+        found = C.c_int64()
+        _check(self.lib, self.lib.thj_butterfly_run(self._ctx, int(min_intron), int(max_intron), C.c_int64(max_cov_juncs), C.byref(found)), "thj_butterfly_run")
+        return found.value
+
     # ---- microexon search (thj_microexon_*): candidates on the device, window merge on the host, per-window pairing on the device
     def microexon_reset(self):
         _check(self.lib, self.lib.thj_microexon_reset_async(self._ctx), "thj_microexon_reset_async")
@@ -690,6 +697,7 @@ ABI_SYMBOLS += ["thj_juncbed_configure", "thj_juncbed_reset_async", "thj_juncbed
                 "thj_juncbed_finish", "thj_juncbed_download"]
 ABI_SYMBOLS += ["thj_md_string"]
 ABI_SYMBOLS += ["thj_microexon_reset_async", "thj_microexon_collect", "thj_microexon_candidates", "thj_microexon_run"]
+ABI_SYMBOLS += ["thj_butterfly_run"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_fusions_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
                 "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
