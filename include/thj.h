@@ -425,6 +425,11 @@ int thj_covsearch_reset_async(thj_ctx* ctx);
 int thj_covsearch_add_hits_async(thj_ctx* ctx, const thj_seg_batch* device_batch);
 int thj_covsearch_add_reads(thj_ctx* ctx, int64_t n_reads, int32_t words_per_plane, const uint64_t* planes, const uint16_t* lens,
                             int32_t on_device);
+/* The same for a piece (whole BGZF members; thj_bam_piece below) of an UNALIGNED BAM of reads -- what tophat.py passes as --ium-reads --:
+ * inflated and parsed on the device (thj_bgzf_inflate's kernels, the record walk of the ingest), every record a read
+ * (ReadStream::get_direct).  *n_reads = records taken.  THJ_EFALLBACK as for thj_ingest_*: read the piece on the host.  Synchronous. */
+struct thj_bam_piece;
+int thj_covsearch_add_reads_bam(thj_ctx* ctx, const struct thj_bam_piece* reads, int64_t* n_reads);
 int thj_covsearch_run_async(thj_ctx* ctx, int32_t min_cov_length, int32_t min_coverage_intron, int32_t max_coverage_intron);
 int thj_covsearch_finish(thj_ctx* ctx, int64_t max_cov_juncs, int64_t* n_found);
 /* Butterfly search (--butterfly-search; replaces prune_extension_table + compact_extension_table + pair_covered_sites with
@@ -478,7 +483,7 @@ int thj_bgzf_inflate(thj_ctx* ctx, const uint8_t* comp, int64_t comp_bytes, cons
  * (HOST memory, e.g. a mapping of the file) and ending at a member boundary; first_skip = bytes of the first member that come
  * before the shard's first record (the low 16 bits of the .index offset, or the end of the BAM header); tid2ref[t] = ref_id of
  * the file's target t (0: a contig the run does not know). */
-typedef struct { const uint8_t* comp; int64_t comp_bytes; uint32_t first_skip; int32_t n_tid; const uint32_t* tid2ref; } thj_bam_piece;
+typedef struct thj_bam_piece { const uint8_t* comp; int64_t comp_bytes; uint32_t first_skip; int32_t n_tid; const uint32_t* tid2ref; } thj_bam_piece;
 /* The whole ingest of one shard of one side of segment_juncs on the device: inflates the pieces, parses their records
  * (BAMHitFactory::get_hit_from_buf, bwt_map.cpp:1101-1452; reads: SEQ -> bit planes), keeps read ids in [begin_id, end_id),
  * merges the nseg segment maps by read id into the visiting set of look_for_hit_group (segment_juncs.cpp:3823-4123; reads whose

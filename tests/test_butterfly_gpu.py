@@ -103,3 +103,25 @@ def test_segment_juncs_executable_with_butterfly_search(name, coverage, tmp_path
     r = subprocess.run(cmd[:i] + cmd[i + 2:], capture_output=True, text=True)
     assert r.returncode == 0 and "butterfly-search" not in r.stderr
     assert open(out["juncs"]).read() == open(os.path.join(d, "expected.seg_only.juncs")).read()
+
+
+def test_unmapped_reads_from_bam_on_the_device_equal_the_host_stream(tmp_path):
+    """--ium-reads as unaligned BAM files (what tophat.py passes): the device-side ingest of those files (thj_covsearch_add_reads_bam) gives the
+    coverage and butterfly searches the same table as the host's ReadStream does"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = os.path.join(root, "tools", "bin", "thj_gen")
+    d = str(tmp_path)
+    subprocess.check_call([gen, "--out", d, "--pairs", "60000", "--read-len", "50", "--genome-len", "4000000", "--introns", "1500"], stdout=subprocess.DEVNULL)
+    f = lambda n: os.path.join(d, n)      # noqa: E731
+    segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k)) for k in (1, 2)) for sd in ("left", "right")}
+    outs = {}
+    for mode, env in (("device", {}), ("host", {"THJ_HOST_INGEST": "1"})):
+        out = {k: f("%s.%s" % (mode, k)) for k in ("juncs", "insertions", "deletions", "fusions")}
+        r = subprocess.run([os.path.join(root, "tophat_amd", "bin", "segment_juncs"), "--butterfly-search", "--no-microexon-search", "--segment-length", "25", "--sam-header", f("hdr.sam"),
+                            "--inner-dist-mean", "50", "--inner-dist-std-dev", "20", "--ium-reads", f("left_reads.bam") + "," + f("right_reads.bam"),
+                            f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"], f("left_reads.bam"), f("left_map.bam"), segs["left"],
+                            f("right_reads.bam"), f("right_map.bam"), segs["right"]], capture_output=True, text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Performing coverage-search" in r.stderr and "Performing butterfly-search" in r.stderr
+        outs[mode] = open(out["juncs"]).read()
+    assert outs["device"] == outs["host"] and outs["device"].count("\n") > 100

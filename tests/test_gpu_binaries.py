@@ -96,7 +96,12 @@ def test_unsupported_modes_fail_loudly(tmp_path):
     r = subprocess.run([os.path.join(BIN, "segment_juncs"), "--butterfly-search", "--segment-length", "25", "--sam-header", os.path.join(d, "hdr.sam"),
                         os.path.join(d, "ref.fa"), "a", "b", "c", "d", os.path.join(d, "left.fq"), os.path.join(d, "left_map.sam"),
                         os.path.join(d, "left_seg1.sam")], capture_output=True, text=True, cwd=str(tmp_path))
-    assert r.returncode == 1 and "not supported" in r.stderr      # the one search that is not built (tophat.py never asks for it, tophat.py:1088)
+    # built since round 4; without --ium-reads neither it nor the coverage search runs (segment_juncs.cpp:4978-4982)
+    assert r.returncode == 0 and "butterfly-search" not in r.stderr
+    r = subprocess.run([os.path.join(BIN, "segment_juncs"), "--color", "--segment-length", "25", "--sam-header", os.path.join(d, "hdr.sam"),
+                        os.path.join(d, "ref.fa"), "a", "b", "c", "d", os.path.join(d, "left.fq"), os.path.join(d, "left_map.sam"),
+                        os.path.join(d, "left_seg1.sam")], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "not supported" in r.stderr      # colour space: the mode that is not built
     r = subprocess.run([os.path.join(BIN, "segment_juncs"), "--no-such-option"], capture_output=True, text=True)
     assert r.returncode == 1
 

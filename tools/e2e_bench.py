@@ -44,10 +44,11 @@ def _run(cmd, env):
         raise RuntimeError("%s did not finish within %s s" % (os.path.basename(cmd[0]), e.timeout))
 
 
-def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False, gen_args=(), bindir=None):
+def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=None, env_extra=None, keep=False, coverage_search=False, gen_args=(), bindir=None, fusion_search=False):
     """gen_args: further thj_gen options (SURVEY 8d's mix: --multihit-frac F --max-copies C --indel-frac F)
     bindir: where segment_juncs / long_spanning_reads are taken from (default: the product executables; tools/bin/cpuport =
-    the same host sources over the CPU oracle, bench.py's files-to-files CPU figure -- no thj_junctions there, that leg is skipped)"""
+    the same host sources over the CPU oracle, bench.py's files-to-files CPU figure -- no thj_junctions there, that leg is skipped)
+    fusion_search: --fusion-search to both executables (long_spanning_reads then reads the .fusions list segment_juncs wrote)"""
     BIN = bindir or globals()["BIN"]
     nseg = max(1, read_len // 25)
     d = workdir or tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -65,7 +66,8 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
     segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k + 1)) for k in range(nseg)) for sd in ("left", "right")}
     out = {k: f("out." + k) for k in ("juncs", "insertions", "deletions", "fusions")}
     mode = ["--ium-reads", f("left_reads.bam") + "," + f("right_reads.bam")] if coverage_search else ["--no-coverage-search"]
-    cmd = _prefix(env, "segment_juncs") + [os.path.join(BIN, "segment_juncs")] + mode + ["--no-microexon-search", "--segment-length", "25",
+    fus = ["--fusion-search"] if fusion_search else []
+    cmd = _prefix(env, "segment_juncs") + [os.path.join(BIN, "segment_juncs")] + mode + fus + ["--no-microexon-search", "--segment-length", "25",
            "--sam-header", f("hdr.sam"), "--inner-dist-mean", "50", "--inner-dist-std-dev", "20",
            f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"],
            f("left_reads.bam"), f("left_map.bam"), segs["left"], f("right_reads.bam"), f("right_map.bam"), segs["right"]]
@@ -92,8 +94,8 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
     res["segment_juncs_log_all"] = [l for l in r.stderr.splitlines() if "declined" in l]
     tot = dt
     for sd in ("left", "right"):
-        cmd = _prefix(env, "lsr_" + sd) + [os.path.join(BIN, "long_spanning_reads"), "--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
-               f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], "/dev/null", f("span_%s.bam" % sd), segs[sd]]
+        cmd = _prefix(env, "lsr_" + sd) + [os.path.join(BIN, "long_spanning_reads")] + fus + ["--segment-length", "25", "--sam-header", f("hdr.sam"), f("ref.fa"),
+               f("%s_reads.bam" % sd), out["juncs"], out["insertions"], out["deletions"], out["fusions"] if fusion_search else "/dev/null", f("span_%s.bam" % sd), segs[sd]]
         t = time.time(); c0 = child_cpu()
         r = _run(cmd, env)
         dt = time.time() - t
@@ -144,6 +146,7 @@ if __name__ == "__main__":
     ap.add_argument("--genome-len", type=int, default=64444167)
     ap.add_argument("--introns", type=int, default=20000)
     ap.add_argument("--coverage-search", action="store_true")
+    ap.add_argument("--fusion-search", action="store_true", help="--fusion-search to both executables (configs[3]'s mode; the generator plants no fusions)")
     ap.add_argument("--keep", default=None)
     ap.add_argument("--multihit-frac", type=float, default=0.05, help="SURVEY 8(d)'s mix (the default, as bench.py's): share of the pairs from the repeat family")
     ap.add_argument("--max-copies", type=int, default=41)
@@ -152,5 +155,5 @@ if __name__ == "__main__":
     ap.add_argument("--env", nargs="*", default=[])
     a = ap.parse_args()
     res = run_e2e(a.pairs, a.read_len, a.genome_len, a.introns, workdir=a.keep, env_extra=dict(x.split("=", 1) for x in a.env), keep=bool(a.keep),
-                  coverage_search=a.coverage_search, gen_args=[] if a.plain else mix_gen_args(a.multihit_frac, a.max_copies, a.indel_frac))
+                  coverage_search=a.coverage_search, fusion_search=a.fusion_search, gen_args=[] if a.plain else mix_gen_args(a.multihit_frac, a.max_copies, a.indel_frac))
     print(json.dumps(res, indent=1))

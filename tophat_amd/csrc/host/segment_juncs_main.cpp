@@ -374,6 +374,41 @@ static int real_main(int argc, char** argv) {
             size_t turn = 0;
             for (auto& fn : split(o.ium_reads, ',')) {
                 if (fn.empty()) continue;
+                // an unaligned BAM (what tophat.py passes): runs of whole BGZF members go up compressed and are inflated and parsed on the
+                // device (thj_covsearch_add_reads_bam); the host stream below takes over -- past the records the device took -- when a
+                // piece is declined (records that straddle members)
+                long long skip = 0;
+                {
+                    BamFile bf;
+                    static const bool host_ingest = getenv("THJ_HOST_INGEST") != nullptr;
+                    if (!host_ingest && bf.open(fn, rt)) {
+                        const size_t MEMBERS = 8192;                       // 512 MB of inflated records a call at most
+                        size_t at = (size_t)(bf.first_rec_voff >> 16);
+                        int64_t from = bf.first_rec_voff;
+                        bool declined = false;
+                        while (at < bf.size && !declined) {
+                            size_t e = at, k = 0;
+                            while (e < bf.size && k < MEMBERS) { const uint32_t bs = BamFile::member_size(bf.data + e, bf.size - e); if (!bs) { e = bf.size; break; } e += bs; ++k; }
+                            thj_bam_piece pc = bf.piece(from, e < bf.size ? (int64_t)e << 16 : -1);
+                            std::vector<std::pair<const BamFile*, thj_bam_piece*>> st{{&bf, &pc}};
+                            uint8_t* staged = stage_pieces(st);
+                            int64_t n = 0;
+                            int rc2;
+                            {
+                                Gpu& g = *gpus[turn++ % gpus.size()];
+                                std::lock_guard<std::mutex> lk(g.mu);
+                                rc2 = thj_covsearch_add_reads_bam(device_ready(g), &pc, &n);
+                            }
+                            thj_pinned_free(staged);
+                            if (rc2 == THJ_EFALLBACK) { declined = true; break; }
+                            if (rc2) die("Error: %s\n", thj_last_error());
+                            skip += n;
+                            at = e; from = (int64_t)e << 16;
+                        }
+                        if (!declined) continue;
+                        g_host_ingest_shards.fetch_add(1);
+                    }
+                }
                 ReadStream rs;
                 if (!rs.open(fn, o.zpacker)) { fprintf(stderr, "Can't open file %s for reading, skipping...\n", fn.c_str()); continue; }
                 std::string bases; std::vector<int64_t> off(1, 0);
@@ -391,6 +426,7 @@ static int real_main(int argc, char** argv) {
                 };
                 Read rd;
                 while (rs.next_direct(rd)) {
+                    if (skip > 0) { --skip; continue; }
                     bases.append(rd.seq, 0, rd.seq.size() < 32 ? rd.seq.size() : 32);      // count_read_mers / store_read_mers :425, :520
                     off.push_back((int64_t)bases.size());
                     if (off.size() - 1 >= CH) push();

@@ -1694,6 +1694,53 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
     return THJ_OK;
 }
 
+// ---- the initially unmapped reads (--ium-reads) of the coverage / butterfly search from an unaligned BAM: every record of the piece is a
+// read (ReadStream::get_direct, reads.cpp:600-630; index_read_mers segment_juncs.cpp:548-571 looks at a read's first 32 bases), its SEQ
+// nibbles become the bit planes thj_covsearch_add_reads takes -- one word per plane: the first 64 bases -- without leaving the device
+namespace ing {
+__global__ __launch_bounds__(256) void thj_k_ium_planes(const uint8_t* __restrict__ infl, const uint32_t* __restrict__ loc, uint32_t n, u64* __restrict__ planes, uint16_t* __restrict__ rlen) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint8_t* d = infl + ((size_t)(loc[i] >> 16) << 16) + (loc[i] & 0xFFFFu) + 4;
+        const uint32_t l_rn = ld32(d + 8) & 0xFF, n_cig = ld32(d + 12) & 0xFFFF, l_seq = ld32(d + 16);
+        const uint8_t* sq = d + 32 + l_rn + 4 * n_cig;
+        const uint32_t L = l_seq > 64u ? 64u : l_seq;
+        u64 lo = 0, hi = 0, nn = 0;
+        for (uint32_t k = 0; k < L; ++k) {
+            const uint32_t nib = (sq[k >> 1] >> ((k & 1) ? 0 : 4)) & 0xF;
+            const u64 b0 = (nib == 2u) | (nib == 8u), b1 = (nib == 4u) | (nib == 8u), isn = !((nib == 1u) | (nib == 2u) | (nib == 4u) | (nib == 8u));
+            lo |= b0 << k; hi |= b1 << k; nn |= isn << k;
+        }
+        planes[(size_t)i * 3] = lo; planes[(size_t)i * 3 + 1] = hi; planes[(size_t)i * 3 + 2] = nn;
+        rlen[i] = (uint16_t)(l_seq > 0xFFFFu ? 0xFFFFu : l_seq);
+    }
+}
+}  // namespace ing
+
+extern "C" int thj_covsearch_add_reads(thj_ctx* c, int64_t n_reads, int32_t words_per_plane, const uint64_t* planes, const uint16_t* lens, int32_t on_device);
+extern "C" int thj_covsearch_add_reads_bam(thj_ctx* c, const thj_bam_piece* reads, int64_t* n_reads_out) {
+    using namespace ing;
+    if (!c || !reads) { thj_set_error("thj_covsearch_add_reads_bam: null argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    if (n_reads_out) *n_reads_out = 0;
+    thj_params p; thj_params_default(&p);
+    std::vector<const thj_bam_piece*> pieces{reads};
+    std::vector<uint32_t> kinds{KIND_READS};
+    Parsed P;
+    int rc = ingest_front(c, &p, pieces, kinds, 0u, 0xFFFFFFFFu, 0, 3 * 8 + 2, 1024, P);
+    if (rc) return rc;
+    const int64_t n = P.n;
+    if (n == 0) return THJ_OK;
+    u64* d_planes = P.a1.take<u64>((size_t)n * 3);
+    uint16_t* d_len = P.a1.take<uint16_t>((size_t)n);
+    if (!d_planes || !d_len) { thj_set_error("thj_covsearch_add_reads_bam: scratch too small"); return THJ_ENOMEM; }
+    hipLaunchKernelGGL(thj_k_ium_planes, dim3(grid_for(n)), dim3(256), 0, c->stream, P.infl, P.loc, (uint32_t)n, d_planes, d_len);
+    HIPCHK(hipGetLastError());
+    if ((rc = thj_covsearch_add_reads(c, n, 1, (const uint64_t*)d_planes, d_len, 1))) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));          // the scratch is the context's: the next ingest call writes over it
+    if (n_reads_out) *n_reads_out = n;
+    return THJ_OK;
+}
+
 // ---- page-locked host buffers, pooled for the process.  Copies to and from pageable memory go through the runtime's staging
 // buffers on one thread (measured in long_spanning_reads with its CPUs busy encoding: 2.9 GB/s up, 6 GB/s down, half of a
 // shard's time under the GPU's lock); from page-locked memory they are plain DMA.  Locking pages costs ~0.2 ms per MB, so
