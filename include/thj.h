@@ -428,6 +428,9 @@ int thj_covsearch_add_reads(thj_ctx* ctx, int64_t n_reads, int32_t words_per_pla
 /* The same for a piece (whole BGZF members; thj_bam_piece below) of an UNALIGNED BAM of reads -- what tophat.py passes as --ium-reads --:
  * inflated and parsed on the device (thj_bgzf_inflate's kernels, the record walk of the ingest), every record a read
  * (ReadStream::get_direct).  *n_reads = records taken.  THJ_EFALLBACK as for thj_ingest_*: read the piece on the host.  Synchronous. */
+/* Room for n_reads more unmapped reads in the extension table now (a caller that knows roughly how many are coming: the table otherwise
+ * grows by half whenever it is full, each time a copy of what it holds). */
+int thj_covsearch_reserve_reads(thj_ctx* ctx, int64_t n_reads);
 struct thj_bam_piece;
 int thj_covsearch_add_reads_bam(thj_ctx* ctx, const struct thj_bam_piece* reads, int64_t* n_reads);
 int thj_covsearch_run_async(thj_ctx* ctx, int32_t min_cov_length, int32_t min_coverage_intron, int32_t max_coverage_intron);

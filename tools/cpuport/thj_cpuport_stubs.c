@@ -26,6 +26,7 @@ int thj_covsearch_run_async() { return refuse("coverage search"); }
 int thj_covsearch_finish() { return refuse("coverage search"); }
 int thj_covsearch_allgather() { return refuse("coverage search"); }
 int thj_covsearch_add_reads_bam() { return decline("ingest"); }
+int thj_covsearch_reserve_reads() { return 0; }
 int thj_butterfly_run() { return refuse("butterfly search"); }
 int thj_microexon_collect() { return refuse("microexon search"); }
 int thj_microexon_candidates() { return refuse("microexon search"); }

@@ -385,7 +385,13 @@ static int real_main(int argc, char** argv) {
                         const size_t MEMBERS = 8192;                       // 512 MB of inflated records a call at most
                         size_t at = (size_t)(bf.first_rec_voff >> 16);
                         int64_t from = bf.first_rec_voff;
-                        bool declined = false;
+                        bool declined = false, reserved = false;
+                        // inflated bytes of the members in [a, e): their ISIZE fields
+                        auto inflated = [&bf](size_t a, size_t e) {
+                            double t = 0;
+                            while (a < e) { const uint32_t bs = BamFile::member_size(bf.data + a, bf.size - a); if (!bs || a + bs > bf.size) break; uint32_t isz; memcpy(&isz, bf.data + a + bs - 4, 4); t += isz; a += bs; }
+                            return t;
+                        };
                         while (at < bf.size && !declined) {
                             size_t e = at, k = 0;
                             while (e < bf.size && k < MEMBERS) { const uint32_t bs = BamFile::member_size(bf.data + e, bf.size - e); if (!bs) { e = bf.size; break; } e += bs; ++k; }
@@ -403,6 +409,16 @@ static int real_main(int argc, char** argv) {
                             if (rc2 == THJ_EFALLBACK) { declined = true; break; }
                             if (rc2) die("Error: %s\n", thj_last_error());
                             skip += n;
+                            if (!reserved && n > 0 && e < bf.size) {
+                                // the file's first piece says how many reads a byte holds: room for the rest of the file in every context's table now
+                                // (the pieces go round the contexts), instead of a table that grows by half -- and is copied -- whenever it is full
+                                reserved = true;
+                                const double here = inflated(at, e), rest = inflated(e, bf.size);
+                                if (here > 0) {
+                                    const int64_t per_ctx = (int64_t)(rest * ((double)n / here) * 1.3 / (double)gpus.size()) + 65536;
+                                    for (auto& gp : gpus) { std::lock_guard<std::mutex> lk(gp->mu); if (thj_covsearch_reserve_reads(device_ready(*gp), per_ctx)) die("Error: %s\n", thj_last_error()); }
+                                }
+                            }
                             at = e; from = (int64_t)e << 16;
                         }
                         if (!declined) continue;

@@ -255,10 +255,17 @@ static int cov_reserve_ext(thj_ctx* c, int64_t need) {          // room for `nee
         HIPCHK(hipMemcpyAsync(nv, c->d_ext_val, (size_t)c->n_ext * 8, hipMemcpyDeviceToDevice, c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(c->d_ext_key); hipFree(c->d_ext_val); hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted);
-    c->d_ext_key = nk; c->d_ext_val = nv; c->ext_cap = ncap;
-    HIPCHK(hipMalloc(&c->d_ext_key_sorted, (size_t)ncap * 4)); HIPCHK(hipMalloc(&c->d_ext_val_sorted, (size_t)ncap * 8));
+    hipFree(c->d_ext_key); hipFree(c->d_ext_val);
+    c->d_ext_key = nk; c->d_ext_val = nv; c->ext_cap = ncap;        // (the sorted copies are made room for when the table is sorted: cov_sort_table)
     return THJ_OK;
+}
+
+extern "C" int thj_covsearch_reserve_reads(thj_ctx* c, int64_t n_reads) {
+    if (!c || n_reads < 0) { thj_set_error("thj_covsearch_reserve_reads: bad argument"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    int rc = cov_ensure(c);
+    if (rc) return rc;
+    return cov_reserve_ext(c, c->n_ext + n_reads * 23);
 }
 
 extern "C" int thj_covsearch_reset_async(thj_ctx* c) {
@@ -374,6 +381,12 @@ extern "C" int thj_covsearch_merge_async(thj_ctx* c, const uint64_t* d_other_bit
 static int cov_sort_table(thj_ctx* c, const uint32_t** keys_out, const u64** vals_out) {
     const uint32_t* keys = c->d_ext_key; const u64* vals = c->d_ext_val;
     if (c->n_ext) {
+        if (c->ext_sorted_cap < c->n_ext) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted); c->d_ext_key_sorted = nullptr; c->d_ext_val_sorted = nullptr; c->ext_sorted_cap = 0;
+            HIPCHK(hipMalloc(&c->d_ext_key_sorted, (size_t)c->ext_cap * 4)); HIPCHK(hipMalloc(&c->d_ext_val_sorted, (size_t)c->ext_cap * 8));
+            c->ext_sorted_cap = c->ext_cap;
+        }
         size_t need = 0;
         hipcub::DeviceRadixSort::SortPairs(nullptr, need, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream);
         if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }

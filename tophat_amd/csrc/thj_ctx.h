@@ -76,7 +76,7 @@ struct thj_ctx {
     // coverage search (thj_covsearch_impl.h)
     u64* d_cov = nullptr; int32_t* d_cov_size = nullptr;                  // 8 bitmaps of n_blocks words; max(right) + 1 per contig
     uint32_t* d_ext_key = nullptr; u64* d_ext_val = nullptr; uint32_t* d_ext_key_sorted = nullptr; u64* d_ext_val_sorted = nullptr;
-    uint32_t* d_ext_off = nullptr; int64_t n_ext = 0, ext_cap = 0;        // extension table of the unmapped reads
+    uint32_t* d_ext_off = nullptr; int64_t n_ext = 0, ext_cap = 0, ext_sorted_cap = 0;        // extension table of the unmapped reads
     unsigned long long* d_cov_found = nullptr;
     u64* d_cov_filter = nullptr; int64_t cov_filter_bytes = 0;          // Bloom filter over the extension table
     u64* d_cov_jkey = nullptr; uint32_t* d_cov_jskip = nullptr; int64_t cov_jcap = 0;      // junctions found: key, skip count

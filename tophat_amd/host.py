@@ -697,7 +697,7 @@ ABI_SYMBOLS += ["thj_juncbed_configure", "thj_juncbed_reset_async", "thj_juncbed
                 "thj_juncbed_finish", "thj_juncbed_download"]
 ABI_SYMBOLS += ["thj_md_string"]
 ABI_SYMBOLS += ["thj_microexon_reset_async", "thj_microexon_collect", "thj_microexon_candidates", "thj_microexon_run"]
-ABI_SYMBOLS += ["thj_butterfly_run", "thj_covsearch_add_reads_bam"]
+ABI_SYMBOLS += ["thj_butterfly_run", "thj_covsearch_add_reads_bam", "thj_covsearch_reserve_reads"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_fusions_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
                 "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
