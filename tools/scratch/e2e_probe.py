@@ -40,10 +40,7 @@ def runp(name, cmd):
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, THJ_EXIT_PROBE="1"))
     print(name, [l for l in r.stderr.splitlines() if "exit-probe" in l and "unix" not in l])
     sys.stdout.flush()
-run("segment_juncs (cold)", sj())
-runp("sj", sj())
-runp("lsr left", lsr("left"))
-import resource
-for nm, cmd in (("sj", sj()), ("lsr", lsr("left"))):
-    r = subprocess.run(["/usr/bin/time", "-v"] + cmd, capture_output=True, text=True, env=env)
-    print(nm, [l.strip() for l in r.stderr.splitlines() if "Maximum resident" in l or "faults" in l or "Elapsed" in l or "System time" in l or "User time" in l])
+for rep in range(2):
+    run("segment_juncs", sj())
+    run("lsr left", lsr("left"))
+    run("lsr right", lsr("right"))

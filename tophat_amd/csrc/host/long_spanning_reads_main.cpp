@@ -341,6 +341,7 @@ static int real_main(int argc, char** argv) {
                 thj_ctx* c = nullptr;
                 if (thj_ctx_create(dev, nullptr, &c)) die("Error: %s\n", thj_last_error());
                 if (!getenv("THJ_NO_WARM") && thj_ctx_warm(c, THJ_WARM_SPAN | THJ_WARM_INGEST | THJ_WARM_BAMOUT)) die("Error: %s\n", thj_last_error());
+                if (getenv("THJ_TIMING")) fprintf(stderr, "[timing] a device context ready after       %8.3f s of the process\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - g_timer.wall0);
                 return c;
             });
         }

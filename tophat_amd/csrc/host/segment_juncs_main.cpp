@@ -333,6 +333,7 @@ static int real_main(int argc, char** argv) {
                 // (thj_ctx_warm here was measured at nothing: the runtime's start-up on this thread is what the first shard waits for, and
                 // the code objects loaded behind it only make that longer; long_spanning_reads, with three of them, gains 0.05 s)
                 if (getenv("THJ_WARM") && thj_ctx_warm(c, THJ_WARM_SEGJUNCS | THJ_WARM_INGEST)) die("Error: %s\n", thj_last_error());
+                if (getenv("THJ_TIMING")) fprintf(stderr, "[timing] a device context ready after       %8.3f s of the process\n", std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count() - g_timer.wall0);
                 return c;
             });
         }
