@@ -125,3 +125,39 @@ def test_unmapped_reads_from_bam_on_the_device_equal_the_host_stream(tmp_path):
         assert "Performing coverage-search" in r.stderr and "Performing butterfly-search" in r.stderr
         outs[mode] = open(out["juncs"]).read()
     assert outs["device"] == outs["host"] and outs["device"].count("\n") > 100
+
+
+def _rechunk_bgzf(src, dst, chunk):
+    """the BAM stream of `src` cut into BGZF members of `chunk` inflated bytes, wherever that falls: records straddle members (a writer
+    other than samtools' bam_write1 may do that)"""
+    import gzip
+    import struct
+    import zlib
+    raw = gzip.open(src, "rb").read()
+    with open(dst, "wb") as f:
+        for a in list(range(0, len(raw), chunk)) + [None]:
+            piece = b"" if a is None else raw[a:a + chunk]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = co.compress(piece) + co.flush()
+            f.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(comp) + 25) + comp + struct.pack("<II", zlib.crc32(piece), len(piece)))
+
+
+def test_unmapped_reads_bam_with_straddling_records_takes_the_host_stream(tmp_path):
+    """a piece the device-side ingest declines (records across member borders) is read by the host stream, past the records the device took"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = os.path.join(root, "tools", "bin", "thj_gen")
+    d = str(tmp_path)
+    subprocess.check_call([gen, "--out", d, "--pairs", "20000", "--read-len", "50", "--genome-len", "4000000", "--introns", "1500"], stdout=subprocess.DEVNULL)
+    f = lambda n: os.path.join(d, n)      # noqa: E731
+    _rechunk_bgzf(f("left_reads.bam"), f("left_ium.bam"), 50021)
+    segs = {sd: ",".join(f("%s_seg%d.bam" % (sd, k)) for k in (1, 2)) for sd in ("left", "right")}
+    outs = {}
+    for mode, ium in (("straddling", f("left_ium.bam") + "," + f("right_reads.bam")), ("plain", f("left_reads.bam") + "," + f("right_reads.bam"))):
+        out = {k: f("%s.%s" % (mode, k)) for k in ("juncs", "insertions", "deletions", "fusions")}
+        r = subprocess.run([os.path.join(root, "tophat_amd", "bin", "segment_juncs"), "--butterfly-search", "--no-microexon-search", "--segment-length", "25", "--sam-header", f("hdr.sam"),
+                            "--inner-dist-mean", "50", "--inner-dist-std-dev", "20", "--ium-reads", ium,
+                            f("ref.fa"), out["juncs"], out["insertions"], out["deletions"], out["fusions"], f("left_reads.bam"), f("left_map.bam"), segs["left"],
+                            f("right_reads.bam"), f("right_map.bam"), segs["right"]], capture_output=True, text=True, env=dict(os.environ, THJ_TIMING="1"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = open(out["juncs"]).read()
+    assert outs["straddling"] == outs["plain"] and outs["plain"].count("\n") > 50
