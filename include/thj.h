@@ -464,8 +464,10 @@ int thj_microexon_run(thj_ctx* ctx, const thj_mx_window* windows, int64_t n_wind
                       int64_t n_strs, int32_t min_coverage_intron, int32_t library_type, int64_t max_cov_juncs, int64_t* n_found);
 
 /* Reads sharded over GPUs: the coverage map of the whole run is the OR of the ranks' maps and the
- * extension table the concatenation of their entries.  thj_covsearch_device_state exposes a rank's state (device
- * pointers: n_words coverage words, one size per contig, n_ext key / value entries) for the caller to all-gather;
+ * extension table that of all their unmapped reads.  thj_covsearch_device_state exposes a rank's state (device
+ * pointers: n_words coverage words, one size per contig, n_ext read records -- d_ext_keys[i] = min(length, 32) of read i,
+ * d_ext_vals[i] = its first 32 bases as a 2-bit string, first base most significant: the table's entries are made from the
+ * records when a pass builds the table) for the caller to all-gather;
  * thj_covsearch_merge_async folds another rank's state in; then every rank runs thj_covsearch_run_async. */
 int thj_covsearch_device_state(thj_ctx* ctx, const uint64_t** d_cov_bits, int64_t* n_words, const int32_t** d_cov_size,
                                const uint32_t** d_ext_keys, const uint64_t** d_ext_vals, int64_t* n_ext);

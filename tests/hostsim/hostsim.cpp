@@ -406,12 +406,12 @@ extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blo
 // sizes, extension-table entries of the shard's hits and unmapped reads.
 extern "C" int hostsim_coverage_state(const uint32_t* contig_blk, const int32_t* contig_len, int32_t n_contigs, int64_t n_blocks,
                                       const thj_hit* hits, int64_t n_hits, const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
-                                      uint64_t* bits /* n_blocks */, int32_t* sizes /* n_contigs */, uint32_t* keys /* 23 n_ium */, uint64_t* vals) {
+                                      uint64_t* bits /* n_blocks */, int32_t* sizes /* n_contigs */, uint32_t* keys /* n_ium: the read records' lengths */, uint64_t* vals /* their 2-bit strings */) {
     using namespace thj::cov;
     Layout L{contig_blk, contig_len, n_contigs, n_blocks};
     for (int64_t i = 0; i < n_hits; ++i)
         add_hit(L, *(const Hit*)&hits[i], [&](int64_t w, u64 m) { bits[w] |= m; }, [&](int k, int32_t sz) { if (sz > sizes[k]) sizes[k] = sz; });
-    for (int64_t r = 0; r < n_ium; ++r) read_entries((const u64*)ium_planes, ium_lens, W, keys, (u64*)vals, 0, r);
+    for (int64_t r = 0; r < n_ium; ++r) read_record((const u64*)ium_planes, ium_lens, W, keys, (u64*)vals, 0, r);
     return 0;
 }
 
@@ -427,13 +427,14 @@ extern "C" int hostsim_coverage_run(const uint64_t* blocks, const uint32_t* cont
     std::vector<u64> bm((size_t)nw * 8, 0);
     u64 *covb = bm.data(), *le = covb + nw, *ll = le + nw, *lr = ll + nw, *fd = lr + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
     memcpy(covb, bits, (size_t)nw * 8);
-    std::vector<size_t> ord((size_t)n_ext);
-    for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
-    std::vector<uint32_t> skeys(ord.size() + 1); std::vector<u64> svals(ord.size() + 1);
-    for (size_t i = 0; i < ord.size(); ++i) { skeys[i] = keys[ord[i]]; svals[i] = vals[ord[i]]; }
+    // the table from the read records (n_ext of them): entries, ordered by seed (the device lays them out by a counting sort)
+    std::vector<std::pair<uint32_t, u64>> ent;
+    for (int64_t i = 0; i < n_ext; ++i) record_entries(keys[i], (u64)vals[i], [&](uint32_t k, u64 v) { ent.push_back({k, v}); });
+    std::stable_sort(ent.begin(), ent.end(), [](const std::pair<uint32_t, u64>& a, const std::pair<uint32_t, u64>& b) { return a.first < b.first; });
+    std::vector<uint32_t> skeys(ent.size() + 1); std::vector<u64> svals(ent.size() + 1);
+    for (size_t i = 0; i < ent.size(); ++i) { skeys[i] = ent[i].first; svals[i] = ent[i].second; }
     std::vector<uint32_t> off((size_t)N_KEYS + 2);
-    for (uint32_t k = 0; k <= N_KEYS; ++k) key_offset(skeys.data(), (int64_t)ord.size(), off.data(), k);
+    for (uint32_t k = 0; k <= N_KEYS; ++k) key_offset(skeys.data(), (int64_t)ent.size(), off.data(), k);
     for (int64_t w = 0; w < nw; ++w) long_enough_word(L, covb, le, min_cov_length - 1, w);
     for (int64_t w = 0; w < nw; ++w) look_word(L, le, sizes, ll, lr, w);
     for (int i = 0; i < 2 * n_contigs; ++i) drop_windows(L, sizes, ll, lr, i);
@@ -442,7 +443,7 @@ extern "C" int hostsim_coverage_run(const uint64_t* blocks, const uint32_t* cont
     // the Bloom filter over the entries, deliberately small here (2^16 bits) so that false positives happen too
     const u64 fmask = (1ull << 16) - 1;
     std::vector<u64> filter((size_t)((fmask + 1) / 64), 0);
-    for (size_t i = 0; i < ord.size(); ++i)
+    for (size_t i = 0; i < ent.size(); ++i)
         if (skeys[i] < N_KEYS) entry_filter_bits(skeys[i], svals[i], fmask, [&](u64 b) { filter[(size_t)(b >> 6)] |= 1ull << (b & 63); });
     ExtTable et{off.data(), svals.data(), filter.data(), fmask};
     for (int64_t w = 0; w < nw; ++w) pair_word(g, L, et, fd, fa, 0, min_intron, max_intron, w, c);
@@ -471,11 +472,11 @@ extern "C" int hostsim_coverage_search(const uint64_t* blocks, const uint32_t* c
                                        const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
                                        int32_t min_cov_length, int32_t min_intron, int32_t max_intron, int64_t max_juncs,
                                        thj_junction** out, int64_t* n_out) {
-    std::vector<uint64_t> bits((size_t)n_blocks, 0), vals((size_t)n_ium * 23 + 1);
+    std::vector<uint64_t> bits((size_t)n_blocks, 0), vals((size_t)n_ium + 1);
     std::vector<int32_t> sizes((size_t)n_contigs + 1, 0);
-    std::vector<uint32_t> keys((size_t)n_ium * 23 + 1);
+    std::vector<uint32_t> keys((size_t)n_ium + 1);
     hostsim_coverage_state(contig_blk, contig_len, n_contigs, n_blocks, hits, n_hits, ium_planes, ium_lens, n_ium, W, bits.data(), sizes.data(), keys.data(), vals.data());
-    return hostsim_coverage_run(blocks, contig_blk, contig_len, n_contigs, n_blocks, bits.data(), sizes.data(), keys.data(), vals.data(), n_ium * 23,
+    return hostsim_coverage_run(blocks, contig_blk, contig_len, n_contigs, n_blocks, bits.data(), sizes.data(), keys.data(), vals.data(), n_ium,
                                 min_cov_length, min_intron, max_intron, max_juncs, out, n_out);
 }
 
@@ -487,20 +488,20 @@ extern "C" int hostsim_butterfly_search(const uint64_t* blocks, const uint32_t* 
                                         const uint64_t* ium_planes, const uint16_t* ium_lens, int64_t n_ium, int32_t W,
                                         int32_t min_intron, int32_t max_intron, int64_t max_juncs, thj_junction** out, int64_t* n_out) {
     using namespace thj::cov;
-    std::vector<uint64_t> bits((size_t)n_blocks, 0), vals((size_t)n_ium * 23 + 1);
+    std::vector<uint64_t> bits((size_t)n_blocks, 0), vals((size_t)n_ium + 1);
     std::vector<int32_t> sizes((size_t)n_contigs + 1, 0);
-    std::vector<uint32_t> keys((size_t)n_ium * 23 + 1);
+    std::vector<uint32_t> keys((size_t)n_ium + 1);
     hostsim_coverage_state(contig_blk, contig_len, n_contigs, n_blocks, hits, n_hits, ium_planes, ium_lens, n_ium, W, bits.data(), sizes.data(), keys.data(), vals.data());
     Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
     Layout L{contig_blk, contig_len, n_contigs, n_blocks};
-    const int64_t nw = n_blocks, n_ext = n_ium * 23;
-    std::vector<size_t> ord((size_t)n_ext);
-    for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });
-    std::vector<uint32_t> skeys(ord.size() + 1); std::vector<u64> svals(ord.size() + 1);
-    for (size_t i = 0; i < ord.size(); ++i) { skeys[i] = keys[ord[i]]; svals[i] = vals[ord[i]]; }
+    const int64_t nw = n_blocks;
+    std::vector<std::pair<uint32_t, u64>> ent;
+    for (int64_t i = 0; i < n_ium; ++i) record_entries(keys[i], (u64)vals[i], [&](uint32_t k, u64 v) { ent.push_back({k, v}); });
+    std::stable_sort(ent.begin(), ent.end(), [](const std::pair<uint32_t, u64>& a, const std::pair<uint32_t, u64>& b) { return a.first < b.first; });
+    std::vector<uint32_t> skeys(ent.size() + 1); std::vector<u64> svals(ent.size() + 1);
+    for (size_t i = 0; i < ent.size(); ++i) { skeys[i] = ent[i].first; svals[i] = ent[i].second; }
     std::vector<uint32_t> off((size_t)N_KEYS + 2);
-    for (uint32_t k = 0; k <= N_KEYS; ++k) key_offset(skeys.data(), (int64_t)ord.size(), off.data(), k);
+    for (uint32_t k = 0; k <= N_KEYS; ++k) key_offset(skeys.data(), (int64_t)ent.size(), off.data(), k);
     ExtTable et{off.data(), svals.data(), nullptr, 0};
     std::vector<u64> bm((size_t)nw * 6, 0);
     u64 *V = bm.data(), *E = V + nw, *fd = E + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;

@@ -194,14 +194,14 @@ def coverage_state(seqs, hits, ium_reads):
     nb = len(g.blocks) // 4
     bits = np.zeros(nb, dtype=np.uint64)
     sizes = np.zeros(g.n_contigs + 1, dtype=np.int32)
-    keys = np.zeros(n * 23 + 1, dtype=np.uint32)
-    vals = np.zeros(n * 23 + 1, dtype=np.uint64)
+    keys = np.zeros(n + 1, dtype=np.uint32)          # one record per read: its length (at most 32) ...
+    vals = np.zeros(n + 1, dtype=np.uint64)          # ... and its first 32 bases as a 2-bit string
     rc = l.hostsim_coverage_state(C.c_void_p(g.contig_blk.ctypes.data), C.c_void_p(clen.ctypes.data), g.n_contigs, C.c_int64(nb),
                                   C.c_void_p(h.ctypes.data), C.c_int64(len(h)), C.c_void_p(planes.ctypes.data), C.c_void_p(lens.ctypes.data),
                                   C.c_int64(n), W, C.c_void_p(bits.ctypes.data), C.c_void_p(sizes.ctypes.data), C.c_void_p(keys.ctypes.data),
                                   C.c_void_p(vals.ctypes.data))
     assert rc == 0
-    return bits, sizes, keys[:n * 23], vals[:n * 23]
+    return bits, sizes, keys[:n], vals[:n]
 
 
 def coverage_run(seqs, states, min_cov_length: int, min_intron: int = 50, max_intron: int = 20000, max_juncs: int = 5000000):

@@ -164,22 +164,30 @@ THJ_HD u64 planes_to_mer32(u64 lo, u64 hi) {          // base i (bit i of the pl
 
 // ---- the extension table (:240-360): one entry per 10-mer seed position of a read's first 32 bases
 // value = left_str | left_len << 28 | right_str << 32 | right_len << 60
-THJ_HD void read_entries(const u64* planes, const uint16_t* lens, int W, uint32_t* keys, u64* vals, int64_t base, int64_t r) {
+// What a context keeps -- and what ranks exchange -- is one record per read: its first 32 bases as a 2-bit string (first base most
+// significant, N as A) and min(length, 32); the up to 23 entries of a read are made from that when the table is built (round 4: twelve
+// bytes a read instead of 276, and the table itself is laid out by a counting sort over the 4^10 seeds -- no sorted copy of the keys, no
+// sort buffers).
+THJ_HD void read_record(const u64* planes, const uint16_t* lens, int W, uint32_t* rec_len, u64* rec_seq, int64_t base, int64_t r) {
     int len = lens[r]; if (len > 32) len = 32;
     const u64* rp = planes + (size_t)r * 3 * W;
     const u64 nm = rp[2 * W], lo = rp[0] & ~nm, hi = rp[W] & ~nm;          // charToDna5 & 3: N is 0
-    const u64 seq = planes_to_mer32(lo, hi);                               // base i at bits 2 * (31 - i): first base most significant
-    for (int i = 0; i < 23; ++i) {
-        uint32_t key = 0xFFFFFFFFu; u64 val = 0;                           // unused slots sort to the end
-        if (len >= 10 && i + 10 <= len) {
-            key = (uint32_t)((seq >> (2 * (22 - i))) & 0xFFFFFu);
-            int rl = len - 10 - i; if (rl > MAX_EXT_BP) rl = MAX_EXT_BP;
-            const u64 right = rl ? (seq >> (2 * (32 - (i + 10 + rl)))) & ((1ull << (2 * rl)) - 1ull) : 0ull;
-            const int ln = i < MAX_EXT_BP ? i : MAX_EXT_BP;
-            const u64 left = ln ? (seq >> (2 * (32 - i))) & ((1ull << (2 * ln)) - 1ull) : 0ull;
-            val = left | ((u64)ln << 28) | (right << 32) | ((u64)rl << 60);
-        }
-        keys[base + r * 23 + i] = key; vals[base + r * 23 + i] = val;
+    u64 seq = planes_to_mer32(lo, hi);                                     // base i at bits 2 * (31 - i)
+    if (len < 32) seq &= ~0ull << (2 * (32 - len));                        // (a producer may hand more bases than the length kept here)
+    rec_len[base + r] = (uint32_t)len; rec_seq[base + r] = len ? seq : 0ull;
+}
+// the entries of one read record: emit(seed, value) per seed position
+template <class Emit>
+THJ_HD void record_entries(uint32_t rec_len, u64 seq, Emit emit) {
+    const int len = (int)rec_len;
+    if (len < 10) return;                                                  // the reference reads past the string here: undefined
+    for (int i = 0; i + 10 <= len; ++i) {
+        const uint32_t key = (uint32_t)((seq >> (2 * (22 - i))) & 0xFFFFFu);
+        int rl = len - 10 - i; if (rl > MAX_EXT_BP) rl = MAX_EXT_BP;
+        const u64 right = rl ? (seq >> (2 * (32 - (i + 10 + rl)))) & ((1ull << (2 * rl)) - 1ull) : 0ull;
+        const int ln = i < MAX_EXT_BP ? i : MAX_EXT_BP;
+        const u64 left = ln ? (seq >> (2 * (32 - i))) & ((1ull << (2 * ln)) - 1ull) : 0ull;
+        emit(key, left | ((u64)ln << 28) | (right << 32) | ((u64)rl << 60));
     }
 }
 THJ_HD void key_offset(const uint32_t* sorted_keys, int64_t n, uint32_t* off, uint32_t k) {      // off[k] = first entry with key >= k; k <= N_KEYS

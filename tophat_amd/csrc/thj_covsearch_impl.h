@@ -44,22 +44,23 @@ __global__ void k_sites(Genome g, Layout L, const u64* ll, const u64* lr, u64* f
     const int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (w < L.n_words) site_word(g, L, ll, lr, fd, ra, fa, rd, w);
 }
-__global__ void k_ium_entries(const u64* planes, const uint16_t* lens, int64_t n_reads, int W, uint32_t* keys, u64* vals, int64_t base) {
+// one record per unmapped read (thj_cov_core.h: read_record); the table is made from the records when a pass needs it:
+// k_ext_count (entries per seed) -> exclusive sum = d_ext_off -> k_ext_scatter (every entry to a place in its seed's range)
+__global__ void k_ium_records(const u64* planes, const uint16_t* lens, int64_t n_reads, int W, uint32_t* rec_len, u64* rec_seq, int64_t base) {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (r < n_reads) read_entries(planes, lens, W, keys, vals, base, r);
+    if (r < n_reads) read_record(planes, lens, W, rec_len, rec_seq, base, r);
 }
-__global__ void k_ext_filter(const uint32_t* sorted_keys, const u64* sorted_vals, int64_t n, u64* filter, u64 filter_mask) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t key = sorted_keys[i];
-        if (key >= N_KEYS) continue;                  // slots of reads too short for a seed
-        entry_filter_bits(key, sorted_vals[i], filter_mask, [&](u64 b) {
-            if (!((filter[b >> 6] >> (b & 63)) & 1ull)) atomicOr((unsigned long long*)&filter[b >> 6], 1ull << (b & 63));
+__global__ void k_ext_count(const uint32_t* rec_len, const u64* rec_seq, int64_t n, uint32_t* counts) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        record_entries(rec_len[i], rec_seq[i], [&](uint32_t key, u64) { atomicAdd(&counts[key], 1u); });
+}
+__global__ void k_ext_scatter(const uint32_t* rec_len, const u64* rec_seq, int64_t n, uint32_t* cursor, u64* vals, u64* filter, u64 filter_mask) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        record_entries(rec_len[i], rec_seq[i], [&](uint32_t key, u64 v) {
+            vals[atomicAdd(&cursor[key], 1u)] = v;
+            // the Bloom filter over the entries (see extendable())
+            entry_filter_bits(key, v, filter_mask, [&](u64 b) { if (!((filter[b >> 6] >> (b & 63)) & 1ull)) atomicOr((unsigned long long*)&filter[b >> 6], 1ull << (b & 63)); });
         });
-    }
-}
-__global__ void k_key_offsets(const uint32_t* sorted_keys, int64_t n, uint32_t* off) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k <= N_KEYS) key_offset(sorted_keys, n, off, k);
 }
 // left sites of both orientations compacted into one list: entry = contig position | contig << 32 | antisense << 63
 __global__ void k_list_sites(Layout L, const u64* fd, const u64* ra, u64* list, unsigned int* n_list, unsigned int cap) {
@@ -238,14 +239,14 @@ static int cov_ensure(thj_ctx* c) {
     if (!c->d_cov) {
         HIPCHK(hipMalloc(&c->d_cov, (size_t)c->n_blocks * 8 * 8));             // coverage, long_enough, 2 flag and 4 site bitmaps
         HIPCHK(hipMalloc(&c->d_cov_size, (size_t)(c->n_contigs + 1) * 4));
-        HIPCHK(hipMalloc(&c->d_ext_off, ((size_t)thj::cov::N_KEYS + 2) * 4));
+        HIPCHK(hipMalloc(&c->d_ext_off, ((size_t)thj::cov::N_KEYS + 2) * 4 * 2));       // per-seed offsets, and the scatter's cursors behind them
         HIPCHK(hipMalloc(&c->d_cov_found, 16));              // junctions found | left sites listed
     }
     return THJ_OK;
 }
 
-static int cov_reserve_ext(thj_ctx* c, int64_t need) {          // room for `need` extension-table entries, keeping what is there
-    if (need >= (1ll << 32)) { thj_set_error("more than 2^32 extension-table entries (unmapped reads x 23)"); return THJ_EINVAL; }
+static int cov_reserve_ext(thj_ctx* c, int64_t need) {          // room for `need` read records, keeping what is there
+    if (need * 23 >= (1ll << 32)) { thj_set_error("more than 2^32 extension-table entries (unmapped reads x 23)"); return THJ_EINVAL; }
     if (need <= c->ext_cap) return THJ_OK;
     const int64_t ncap = need + need / 2 + 1024;
     uint32_t* nk = nullptr; u64* nv = nullptr;
@@ -256,7 +257,7 @@ static int cov_reserve_ext(thj_ctx* c, int64_t need) {          // room for `nee
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     hipFree(c->d_ext_key); hipFree(c->d_ext_val);
-    c->d_ext_key = nk; c->d_ext_val = nv; c->ext_cap = ncap;        // (the sorted copies are made room for when the table is sorted: cov_sort_table)
+    c->d_ext_key = nk; c->d_ext_val = nv; c->ext_cap = ncap;        // (d_ext_key: the records' lengths, d_ext_val: their 2-bit strings; the table itself: cov_build_table)
     return THJ_OK;
 }
 
@@ -265,7 +266,7 @@ extern "C" int thj_covsearch_reserve_reads(thj_ctx* c, int64_t n_reads) {
     HIPCHK(hipSetDevice(c->device));
     int rc = cov_ensure(c);
     if (rc) return rc;
-    return cov_reserve_ext(c, c->n_ext + n_reads * 23);
+    return cov_reserve_ext(c, c->n_ext + n_reads);
 }
 
 extern "C" int thj_covsearch_reset_async(thj_ctx* c) {
@@ -302,7 +303,7 @@ extern "C" int thj_covsearch_add_reads(thj_ctx* c, int64_t n_reads, int32_t word
     int rc = cov_ensure(c);
     if (rc) return rc;
     if (n_reads == 0) return THJ_OK;
-    const int64_t need = c->n_ext + n_reads * 23;
+    const int64_t need = c->n_ext + n_reads;
     if ((rc = cov_reserve_ext(c, need))) return rc;
     const u64* d_planes = (const u64*)planes; const uint16_t* d_lens = lens;
     void *tp = nullptr, *tl = nullptr;
@@ -313,7 +314,7 @@ extern "C" int thj_covsearch_add_reads(thj_ctx* c, int64_t n_reads, int32_t word
         HIPCHK(hipMemcpyAsync(tl, lens, lb, hipMemcpyHostToDevice, c->stream));
         d_planes = (const u64*)tp; d_lens = (const uint16_t*)tl;
     }
-    hipLaunchKernelGGL(cov_k::k_ium_entries, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(cov_k::k_ium_records, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, c->stream,
                        d_planes, d_lens, n_reads, (int)words_per_plane, c->d_ext_key, c->d_ext_val, c->n_ext);
     HIPCHK(hipGetLastError());
     if (!on_device) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(tp); hipFree(tl); }
@@ -333,7 +334,7 @@ static int cov_launch_pair(thj_ctx* c) {
     thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, nw};
     u64 *le = c->d_cov + nw, *fa = c->d_cov + 6 * nw, *rd = c->d_cov + 7 * nw;
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
-    thj::cov::ExtTable et{c->d_ext_off, c->n_ext ? c->d_ext_val_sorted : c->d_ext_val, c->d_cov_filter, c->cov_filter_mask};
+    thj::cov::ExtTable et{c->d_ext_off, c->d_ext_val_sorted, c->d_cov_filter, c->cov_filter_mask};
     const unsigned int list_cap = (unsigned int)(nw < 0xFFFFFFFFll ? nw : 0xFFFFFFFFll);
     HIPCHK(hipMemsetAsync(c->d_cov_found, 0, 8, c->stream));
     hipLaunchKernelGGL(cov_k::k_pair, dim3(2048), dim3(256), 0, c->stream, g, L, et, le, (const unsigned int*)(c->d_cov_found + 1), list_cap, fa, rd,
@@ -377,25 +378,42 @@ extern "C" int thj_covsearch_merge_async(thj_ctx* c, const uint64_t* d_other_bit
     return THJ_OK;
 }
 
-// the extension table: the entries sorted by seed, then offsets per seed (d_ext_off)
-static int cov_sort_table(thj_ctx* c, const uint32_t** keys_out, const u64** vals_out) {
-    const uint32_t* keys = c->d_ext_key; const u64* vals = c->d_ext_val;
-    if (c->n_ext) {
-        if (c->ext_sorted_cap < c->n_ext) {
-            HIPCHK(hipStreamSynchronize(c->stream));
-            hipFree(c->d_ext_key_sorted); hipFree(c->d_ext_val_sorted); c->d_ext_key_sorted = nullptr; c->d_ext_val_sorted = nullptr; c->ext_sorted_cap = 0;
-            HIPCHK(hipMalloc(&c->d_ext_key_sorted, (size_t)c->ext_cap * 4)); HIPCHK(hipMalloc(&c->d_ext_val_sorted, (size_t)c->ext_cap * 8));
-            c->ext_sorted_cap = c->ext_cap;
-        }
-        size_t need = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, need, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream);
-        if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
-        size_t bytes = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, bytes, c->d_ext_key, c->d_ext_key_sorted, c->d_ext_val, c->d_ext_val_sorted, (int)c->n_ext, 0, 32, c->stream));
-        keys = c->d_ext_key_sorted; vals = c->d_ext_val_sorted;
+// the extension table from the read records: entries per seed counted, offsets = their exclusive sum (d_ext_off), every entry scattered into
+// its seed's range of d_ext_val_sorted (the order inside a range is whatever the atomics make it: a seed's entries are a set), the Bloom
+// filter of extendable() set on the way
+static int cov_build_table(thj_ctx* c) {
+    using thj::cov::N_KEYS;
+    uint32_t* off = c->d_ext_off; uint32_t* cursor = c->d_ext_off + (N_KEYS + 2);
+    HIPCHK(hipMemsetAsync(off, 0, ((size_t)N_KEYS + 2) * 4, c->stream));
+    if (c->n_ext) hipLaunchKernelGGL(cov_k::k_ext_count, dim3(4096), dim3(256), 0, c->stream, (const uint32_t*)c->d_ext_key, (const u64*)c->d_ext_val, c->n_ext, off);
+    size_t need = 0;
+    hipcub::DeviceScan::ExclusiveSum(nullptr, need, off, off, (int)(N_KEYS + 1), c->stream);
+    if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+    size_t bytes = c->sort_tmp_bytes;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, bytes, off, off, (int)(N_KEYS + 1), c->stream));
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, off + N_KEYS, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->ext_sorted_cap < (int64_t)total || !c->d_ext_val_sorted) {
+        hipFree(c->d_ext_val_sorted); c->d_ext_val_sorted = nullptr; c->ext_sorted_cap = 0;
+        const int64_t cap = (int64_t)total + (int64_t)total / 8 + 1024;
+        HIPCHK(hipMalloc(&c->d_ext_val_sorted, (size_t)cap * 8));
+        c->ext_sorted_cap = cap;
     }
-    hipLaunchKernelGGL(cov_k::k_key_offsets, dim3((thj::cov::N_KEYS + 1 + 255) / 256), dim3(256), 0, c->stream, keys, c->n_ext, c->d_ext_off);
-    *keys_out = keys; *vals_out = vals;
+    // Bloom filter over the entries: 64 bits per entry, a power of two between 2^16 and 2^34 bits
+    u64 fbits = 1ull << 16;
+    while (fbits < (u64)total * 64 && fbits < (1ull << 34)) fbits <<= 1;
+    if ((int64_t)(fbits / 8) > c->cov_filter_bytes) {
+        hipFree(c->d_cov_filter); c->d_cov_filter = nullptr;
+        HIPCHK(hipMalloc(&c->d_cov_filter, (size_t)(fbits / 8)));
+        c->cov_filter_bytes = (int64_t)(fbits / 8);
+    }
+    HIPCHK(hipMemsetAsync(c->d_cov_filter, 0, (size_t)(fbits / 8), c->stream));
+    c->cov_filter_mask = fbits - 1;
+    HIPCHK(hipMemcpyAsync(cursor, off, ((size_t)N_KEYS + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (c->n_ext) hipLaunchKernelGGL(cov_k::k_ext_scatter, dim3(4096), dim3(256), 0, c->stream, (const uint32_t*)c->d_ext_key, (const u64*)c->d_ext_val, c->n_ext, cursor,
+                                      c->d_ext_val_sorted, c->d_cov_filter, fbits - 1);
+    HIPCHK(hipGetLastError());
     return THJ_OK;
 }
 
@@ -410,31 +428,19 @@ extern "C" int thj_covsearch_run_async(thj_ctx* c, int32_t min_cov_length, int32
     const int64_t nw = c->n_blocks;
     thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, nw};
     u64 *covb = c->d_cov, *le = covb + nw, *ll = le + nw, *lr = ll + nw, *fd = lr + nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
-    const uint32_t* keys = nullptr; const u64* vals = nullptr;
-    if ((rc = cov_sort_table(c, &keys, &vals))) return rc;
+    if ((rc = cov_build_table(c))) return rc;
     const unsigned gw = (unsigned)((nw + 255) / 256);
     hipLaunchKernelGGL(cov_k::k_long_enough, dim3(gw), dim3(256), 0, c->stream, L, covb, le, (int)min_cov_length - 1);
     hipLaunchKernelGGL(cov_k::k_look, dim3(gw), dim3(256), 0, c->stream, L, le, c->d_cov_size, ll, lr);
     hipLaunchKernelGGL(cov_k::k_drop_windows, dim3((unsigned)((2 * c->n_contigs + 63) / 64)), dim3(64), 0, c->stream, L, c->d_cov_size, ll, lr);
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     hipLaunchKernelGGL(cov_k::k_sites, dim3(gw), dim3(256), 0, c->stream, g, L, ll, lr, fd, ra, fa, rd);
-    // Bloom filter over the entries: 64 bits per entry, a power of two between 2^16 and 2^34 bits
-    u64 fbits = 1ull << 16;
-    while (fbits < (u64)c->n_ext * 64 && fbits < (1ull << 34)) fbits <<= 1;
-    if ((int64_t)(fbits / 8) > c->cov_filter_bytes) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        hipFree(c->d_cov_filter); c->d_cov_filter = nullptr;
-        HIPCHK(hipMalloc(&c->d_cov_filter, (size_t)(fbits / 8)));
-        c->cov_filter_bytes = (int64_t)(fbits / 8);
-    }
-    HIPCHK(hipMemsetAsync(c->d_cov_filter, 0, (size_t)(fbits / 8), c->stream));
-    if (c->n_ext) hipLaunchKernelGGL(cov_k::k_ext_filter, dim3(4096), dim3(256), 0, c->stream, keys, vals, c->n_ext, c->d_cov_filter, fbits - 1);
     // left sites -> list (its room: the long_enough bitmap, which nothing reads any more) -> one wave per site
     unsigned int* n_list = (unsigned int*)(c->d_cov_found + 1);
     HIPCHK(hipMemsetAsync(n_list, 0, 4, c->stream));
     const unsigned int list_cap = (unsigned int)(nw < 0xFFFFFFFFll ? nw : 0xFFFFFFFFll);
     hipLaunchKernelGGL(cov_k::k_list_sites, dim3(gw), dim3(256), 0, c->stream, L, fd, ra, le, n_list, list_cap);
-    c->cov_filter_mask = fbits - 1; c->cov_min_intron = min_intron; c->cov_max_intron = max_intron; c->cov_pending = true;
+    c->cov_min_intron = min_intron; c->cov_max_intron = max_intron; c->cov_pending = true;
     if ((rc = cov_launch_pair(c))) return rc;
     HIPCHK(hipGetLastError());
     return THJ_OK;
@@ -549,9 +555,8 @@ extern "C" int thj_butterfly_run(thj_ctx* c, int32_t min_intron, int32_t max_int
     thj::cov::Layout L{c->d_contig_blk, c->d_contig_len, c->n_contigs, nw};
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     u64 *covb = c->d_cov, *V = covb + nw, *E = V + nw, *fd = covb + 4 * nw, *ra = fd + nw, *fa = ra + nw, *rd = fa + nw;
-    const uint32_t* keys = nullptr; const u64* vals = nullptr;
-    if ((rc = cov_sort_table(c, &keys, &vals))) return rc;
-    thj::cov::ExtTable et{c->d_ext_off, vals, nullptr, 0};
+    if ((rc = cov_build_table(c))) return rc;
+    thj::cov::ExtTable et{c->d_ext_off, c->d_ext_val_sorted, nullptr, 0};
     const unsigned gw = (unsigned)((nw + 255) / 256);
     HIPCHK(hipMemcpyAsync(V, covb, (size_t)nw * 8, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(cov_k::k_bf_drop_tail, dim3((unsigned)((c->n_contigs + 63) / 64)), dim3(64), 0, c->stream, L, V);
