@@ -1100,7 +1100,14 @@ def run_rank(args, rank, world, local_rank, control, shared):
             want_cfg.update(multihit_frac=args.multihit_frac, indel_frac=args.indel_frac, max_copies=args.max_copies)
         if traffic_in_run or (args.read_len == 100 and args.genome == "chr20" and use_heads and not args.fusion_search and not n_ium and pm["config"] == want_cfg):
             for k in kernels:
-                parts = [pm["kernels"].get(nm) for nm in k["kernel"].split(" + ")]
+                def _lookup(nm):
+                    # the profiler prints every template argument (thj_k_sj_general<12, 256, true, 9>); the line's names stop at the ones that tell the instances apart
+                    v = pm["kernels"].get(nm)
+                    if v is None and nm.endswith(">"):
+                        cands = [key for key in pm["kernels"] if key.startswith(nm[:-1] + ",")]
+                        v = pm["kernels"][cands[0]] if len(cands) == 1 else None
+                    return v
+                parts = [_lookup(nm) for nm in k["kernel"].split(" + ")]
                 c = None if not any(parts) else {key: sum(x.get(key, 0.0) for x in parts if x) for key in ("FETCH_SIZE", "WRITE_SIZE")}
                 if c:
                     k["traffic"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
