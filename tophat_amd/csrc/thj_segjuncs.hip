@@ -1851,20 +1851,25 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
         if (gj || gi) { int rc = grow_tables(c, gj, gi); if (rc) return rc; continue; }
         break;
     }
-    // sorted output (stream-ordered: consumers on the context stream need no further synchronisation)
+    // sorted output (stream-ordered: consumers on the context stream need no further synchronisation).  Only the bits a key of this
+    // genome can have are sorted on (a radix pass is a kernel or two, and these lists are short: the passes are launch gaps, not work):
+    // junction / deletion keys = global position + 1 above 30 bits of length and strand, insertion keys = the same above 4 bits of length
+    int pos_bits = 1;
+    while (pos_bits < 34 && (1ll << pos_bits) <= c->n_blocks * 64 + 1) ++pos_bits;
+    const int junc_bits = 30 + pos_bits > 64 ? 64 : 30 + pos_bits, ins_bits = 4 + pos_bits;
     size_t tmp = c->sort_tmp_bytes;
     if (c->n_junc > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)junc_list(c), c->d_junc_sorted, c->n_junc, 0, 64, c->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)junc_list(c), c->d_junc_sorted, c->n_junc, 0, junc_bits, c->stream));
     tmp = c->sort_tmp_bytes;
     if (c->n_del > 0)
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)del_list(c), c->d_del_sorted, c->n_del, 0, 64, c->stream));
+        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)del_list(c), c->d_del_sorted, c->n_del, 0, junc_bits, c->stream));
     if (c->n_ins > 0) {
         int64_t blocks = (c->n_ins + 255) / 256; if (blocks > 1024) blocks = 1024;
         hipLaunchKernelGGL(thj_k_ins_gather, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const u64*)ins_list(c), c->n_ins,
                            (const u64*)c->d_ins_key, (const u64*)c->d_ins_val, c->d_tmp_keys2, c->d_tmp_vals);
         tmp = c->sort_tmp_bytes;
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(c->d_sort_tmp, tmp, (const u64*)c->d_tmp_keys2, c->d_ins_key_sorted,
-                                                  (const u64*)c->d_tmp_vals, c->d_ins_val_sorted, c->n_ins, 0, 64, c->stream));
+                                                  (const u64*)c->d_tmp_vals, c->d_ins_val_sorted, c->n_ins, 0, ins_bits, c->stream));
     }
     if (counts) {
         const unsigned long long* cnt = &c->h_pinned[8];

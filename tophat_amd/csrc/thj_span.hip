@@ -543,18 +543,21 @@ extern "C" int thj_span_sets_from_segjuncs(thj_ctx* c) {
     int rc = ensure_sets_cap(c, nj, ni);
     if (rc) return rc;
     if (nj) {
-        // concatenate into tmp, sort
-        HIPCHK(hipMemcpyAsync(c->d_span_cat, c->d_junc_sorted, (size_t)c->n_junc * 8, hipMemcpyDeviceToDevice, c->stream));
-        if (c->n_del) HIPCHK(hipMemcpyAsync(c->d_span_cat + c->n_junc, c->d_del_sorted, (size_t)c->n_del * 8, hipMemcpyDeviceToDevice, c->stream));
-        // Sorted, NOT made unique: a deletion and a '+' junction with the same ends give the same key twice, and
+        // the two sorted lists merged (a sort of their concatenation was eight more radix passes over what thj_segjuncs_finish had just sorted).
+        // Merged, NOT made unique: a deletion and a '+' junction with the same ends give the same key twice, and
         // a repeated key is harmless to its only consumer -- closure_search skips a candidate that does not improve
         // on the best one (`diff >= best_diff`), which an identical twin never does.
-        // the sort scratch was sized for the larger of the two event tables; junctions + deletions together can exceed it
-        size_t need = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, need, (const u64*)c->d_span_cat, c->d_span_junc, nj, 0, 64, c->stream));
-        if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
-        size_t tmp = c->sort_tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortKeys(c->d_sort_tmp, tmp, (const u64*)c->d_span_cat, c->d_span_junc, nj, 0, 64, c->stream));
+        if (c->n_junc == 0 || c->n_del == 0)
+            HIPCHK(hipMemcpyAsync(c->d_span_junc, c->n_junc ? c->d_junc_sorted : c->d_del_sorted, (size_t)nj * 8, hipMemcpyDeviceToDevice, c->stream));
+        else {
+            size_t need = 0;
+            HIPCHK(rocprim::merge(nullptr, need, (const u64*)c->d_junc_sorted, (const u64*)c->d_del_sorted, c->d_span_junc, (size_t)c->n_junc, (size_t)c->n_del,
+                                  rocprim::less<u64>(), c->stream));
+            if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; c->sort_tmp_bytes = 0; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
+            size_t tmp = c->sort_tmp_bytes;
+            HIPCHK(rocprim::merge(c->d_sort_tmp, tmp, (const u64*)c->d_junc_sorted, (const u64*)c->d_del_sorted, c->d_span_junc, (size_t)c->n_junc, (size_t)c->n_del,
+                                  rocprim::less<u64>(), c->stream));
+        }
         c->n_span_junc = nj;
     } else c->n_span_junc = 0;
     if (ni) {
