@@ -697,6 +697,20 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
 
 // one wave per member.  buf = the member's output from `origin` on (at least the last 32 KiB: DEFLATE's reach); when a batch does not
 // fit, what is complete goes to HBM in 16-byte pieces and the buffer slides down.  Members kernel 1 refused are listed for the one-lane kernel.
+#ifdef THJ_EXP
+// developer build: where a wave of thj_k_lz spends its clocks (lane 0's s_memtime deltas, summed over all waves)
+__device__ unsigned long long thj_lz_dbg[16];
+extern "C" int thj_lz_dbg_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(thj_lz_dbg), sizeof thj_lz_dbg) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(thj_lz_dbg), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#define LZ_T(i) do { const unsigned long long t__ = clock64(); dbg[i] += t__ - tl; tl = t__; } while (0)
+#define LZ_N(i, v) do { dbg[i] += (v); } while (0)
+#else
+#define LZ_T(i) do { } while (0)
+#define LZ_N(i, v) do { } while (0)
+#endif
 __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ tokens, const uint32_t* __restrict__ ntok, int n_blocks, uint8_t* __restrict__ out,
                                                uint32_t* __restrict__ out_len, uint32_t* __restrict__ fb_list, uint32_t* __restrict__ fb_count) {
     using namespace inf2;
@@ -709,8 +723,15 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
     uint32_t origin = 0, flushed = 0, pos = 0, i0 = 0;
     bool slid = false;
     uint32_t tok = (uint32_t)lane < n ? tk[lane] : 0u;
+#ifdef THJ_EXP
+    unsigned long long dbg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tl = clock64();
+#endif
     while (i0 < n) {
-        const uint32_t tok_next = i0 + 64u + (uint32_t)lane < n ? tk[i0 + 64u + (uint32_t)lane] : 0u;      // on its way while this batch is done
+        // the next batch's tokens, on their way while this batch is done.  The load is unconditional (the index clamped, a lane past the end
+        // reads the last token and never looks at it): around a load under a branch the compiler put `s_waitcnt vmcnt(0)` right behind it
+        // -- the wave then sat out the whole round trip at the top of every batch, 1 500 of a batch's 4 900 clocks (THJ_EXP build, lz_timing)
+        const uint32_t nx = i0 + 64u + (uint32_t)lane;
+        const uint32_t tok_next = tk[nx < n ? nx : n - 1u];
         const bool valid = i0 + (uint32_t)lane < n;
         const bool is_m = valid && (tok >> 31);
         const uint32_t len = !valid ? 0u : is_m ? ((tok >> 15) & 255u) + 3u : 1u;
@@ -731,6 +752,7 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
                 origin = no;
             }
             slid = true;
+            LZ_T(5);
             continue;
         }
         slid = false;
@@ -742,7 +764,9 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
         const uint32_t s = a - dist;                                             // >= 0: kernel 1 checked dist <= position, and origin keeps 32 KiB
         const uint32_t send = s + (len < dist ? len : dist);
         uint64_t pend = __ballot(take && is_m);
+        LZ_T(0); LZ_N(6, 1);
         while (pend) {
+            LZ_N(7, 1);
             const int f = __builtin_ctzll(pend);
             const uint32_t hwm = (uint32_t)__builtin_amdgcn_readlane((int)a, f);        // everything below the first open match is final
             const bool mine = ((pend >> lane) & 1ull) != 0;
@@ -757,18 +781,28 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
                 if (len > 8u) __builtin_memcpy(&v1, &buf[s + 8], 8);
                 if (len > 16u) __builtin_memcpy(&v2, &buf[s + 16], 8);
                 if (len > 24u) __builtin_memcpy(&v3, &buf[s + 24], 8);
-                uint32_t w = a, rest = len;
-                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; v1 = v2; v2 = v3; }
-                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; v1 = v2; }
-                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; v0 = v1; }
-                if (rest >= 8u) { __builtin_memcpy(&buf[w], &v0, 8); w += 8u; rest -= 8u; }
-                if (rest & 4u) { const uint32_t x = (uint32_t)v0; __builtin_memcpy(&buf[w], &x, 4); w += 4u; v0 >>= 32; }
-                if (rest & 2u) { const uint16_t x = (uint16_t)v0; __builtin_memcpy(&buf[w], &x, 2); w += 2u; v0 >>= 16; }
-                if (rest & 1u) buf[w] = (uint8_t)v0;
+                // every value is in a register of its own before the first write: with the words shifted down through one register pair
+                // (v0 = v1 after v0's write, ...) each write waited for the one before it -- its data register was about to be overwritten --
+                // and a match of 20 bytes was five LDS round trips instead of two (THJ_EXP build, lz_timing: 870 clocks a round)
+                const uint32_t q = len >> 3;                                             // whole 8-byte words
+                const uint64_t vt = q == 0u ? v0 : q == 1u ? v1 : q == 2u ? v2 : v3;     // the word the last len & 7 bytes come from
+                const uint32_t sh2 = (len & 4u) ? 32u : 0u;
+                const uint32_t t4 = (uint32_t)vt;
+                const uint16_t t2 = (uint16_t)(vt >> sh2);
+                const uint8_t t1 = (uint8_t)(vt >> (sh2 + ((len & 2u) ? 16u : 0u)));
+                const uint32_t wt = a + (len & ~7u);
+                if (q >= 1u) __builtin_memcpy(&buf[a], &v0, 8);
+                if (q >= 2u) __builtin_memcpy(&buf[a + 8u], &v1, 8);
+                if (q >= 3u) __builtin_memcpy(&buf[a + 16u], &v2, 8);
+                if (q >= 4u) __builtin_memcpy(&buf[a + 24u], &v3, 8);
+                if (len & 4u) __builtin_memcpy(&buf[wt], &t4, 4);
+                if (len & 2u) __builtin_memcpy(&buf[wt + ((len & 4u) ? 4u : 0u)], &t2, 2);
+                if (len & 1u) buf[wt + (len & 6u)] = t1;
             }
             // the long and the self-overlapping ones: the whole wave on each, 64 bytes a step; a match that overlaps itself repeats its
             // first dist bytes, so every byte is read from those (all lanes read before any writes)
             uint64_t big = __ballot(rdy && !small);
+            LZ_T(1); LZ_N(8, __popcll(big));
             while (big) {
                 const int g = __builtin_ctzll(big); big &= big - 1;
                 const uint32_t ga = (uint32_t)__builtin_amdgcn_readlane((int)a, g), gs = (uint32_t)__builtin_amdgcn_readlane((int)s, g);
@@ -777,16 +811,22 @@ __global__ __launch_bounds__(64) void thj_k_lz(const uint32_t* __restrict__ toke
                 else { for (uint32_t k = (uint32_t)lane; k < gl; k += 64u) { const uint8_t b = buf[gs + k % gd]; buf[ga + k] = b; } }
             }
             pend &= ~__ballot(rdy);
+            LZ_T(2);
         }
         pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, ntake - 1);
         i0 += (uint32_t)ntake;
         tok = ntake == 64 ? tok_next : (i0 + (uint32_t)lane < n ? tk[i0 + (uint32_t)lane] : 0u);
+        { const uint32_t probe = tok; LZ_T(3); if (probe == 0xFFFFFFFFu) LZ_N(9, 1); }        // (the wait for the next batch's tokens lands here)
     }
     // ---- what is left: whole 16-byte pieces, then the tail
     for (uint32_t o = flushed + (uint32_t)lane * 16u; o + 16u <= pos; o += 1024u) *(uint4*)(dst + o) = *(const uint4*)&buf[o - origin];
     if ((pos & ~15u) > flushed) flushed = pos & ~15u;
     if (flushed + (uint32_t)lane < pos) dst[flushed + (uint32_t)lane] = buf[flushed + (uint32_t)lane - origin];
     if (lane == 0) out_len[m] = i0 < n ? 0xFFFFFFFFu : pos;
+#ifdef THJ_EXP
+    LZ_T(4);
+    if (lane == 0) { for (int k = 0; k < 12; ++k) if (dbg[k]) atomicAdd(&thj_lz_dbg[k], dbg[k]); atomicAdd(&thj_lz_dbg[12], 1ull); }
+#endif
 }
 
 // Which inflater.  Default: the two kernels above, then the one-lane kernel over whatever members they handed back (stored blocks,
