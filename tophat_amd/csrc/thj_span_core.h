@@ -1017,7 +1017,7 @@ THJ_HD int span_read_lean(const Genome& g, const Params& p, const SpanSets& S, c
     {
         Q16 tmp[MS];                            // the heads of the read's (consecutive) hits, all in flight together
 #pragma unroll
-        for (int k = 0; k < MS; ++k) if (k < nsegs) tmp[k] = load_head(ghits, gheads, (u64)sof[0] + k);
+        for (int k = 0; k < MS; ++k) tmp[k] = load_head(ghits, gheads, (u64)sof[0] + (u64)(k < nsegs ? k : 0));      // unconditional: see span_read_contig_pre
 #pragma unroll
         for (int k = 0; k < MS; ++k) if (k < nsegs) ((Q16*)heads)[k] = tmp[k];
     }
@@ -1665,8 +1665,12 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
     // one hit per segment: the read's hits are hits[sv[0] .. sv[0] + nsegs)
     SpanHitHead hh[MS];
 #pragma unroll
-    for (int s = 0; s < MS; ++s)
-        if (s < nsegs) { const Q16 q = load_head(hits, gheads, (u64)sv[0] + s); hh[s] = SpanHitHead{q.x, (int32_t)q.y, q.z, q.w}; }
+    for (int s = 0; s < MS; ++s) {
+        // unconditional (a segment the read does not have reads the first hit again and is never looked at): under `if (s < nsegs)` every
+        // load sat in a branch of its own with an s_waitcnt vmcnt(0) behind it -- the heads came one round trip after the other
+        const Q16 q = load_head(hits, gheads, (u64)sv[0] + (u64)(s < nsegs ? s : 0));
+        hh[s] = SpanHitHead{q.x, (int32_t)q.y, q.z, q.w};
+    }
     uint32_t last_meta = hh[0].meta;
 #pragma unroll
     for (int s = 1; s < MS; ++s) last_meta = (s == nsegs - 1) ? hh[s].meta : last_meta;
