@@ -240,8 +240,8 @@ __device__ __forceinline__ int slice_of(const unsigned int* s_off, int G, unsign
 }
 
 // Tier 1: single-hit-per-segment reads that need closures (spliced / indel reads): streamed merge_chain on registers.
-template <int MS>
-__global__ __launch_bounds__(256, 4) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
+template <int MS, int WPE = 4>
+__global__ __launch_bounds__(256, WPE) void thj_k_stitch(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G) {
     extern __shared__ uint4 lds_stage[];          // nseg hit heads per thread
     constexpr int NC = lean_classes(MS);
     __shared__ unsigned int s_off[NC * MAX_SLICES + 1];
@@ -324,8 +324,8 @@ static constexpr int PACK_DRAW = 32;        // list entries a wave draws at a ti
 // Eight waves per workgroup, two workgroups per CU: 16 waves per CU is what 128 VGPRs allow, and a wave's 9 KB of LDS with the
 // workgroup's slice table fit the CU's 160 KB twice over that way (four workgroups of four waves do not: three were resident).
 static constexpr int PACK_TPB = 512;
-template <int MS>
-__global__ __launch_bounds__(PACK_TPB, 4) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg) {
+template <int MS, int PACK_TPB = 512, int PACK_WPE = 4>
+__global__ __launch_bounds__(PACK_TPB, PACK_WPE) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg) {
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     __shared__ PackLds<MS, PACK_MAXHITS, PACK_CHAINLIST> s_pack[PACK_TPB / 64];
@@ -796,7 +796,13 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
     const int64_t g1 = G, g2 = G;
-    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    // reads of up to four segments: three workgroups a CU (168 VGPRs, nothing spilled) instead of four (128 VGPRs, 6 spilled beside 171 SGPRs'
+    // worth of lanes): 0.73 -> 0.70 ms per launch on one box (tools/scratch/stage2_occupancy_ab.sh); THJ_LEAN_WPE = 2 | 4: developer switch
+    static const int lean_wpe = getenv("THJ_LEAN_WPE") ? atoi(getenv("THJ_LEAN_WPE")) : 3;
+    const size_t lean_lds = (size_t)256 * b.nseg * sizeof(SpanHitHead);
+    if (b.nseg <= 4 && lean_wpe == 3) hipLaunchKernelGGL((thj_k_stitch<4, 3>), dim3((unsigned)((g1 * 3 + 3) / 4)), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
+    else if (b.nseg <= 4 && lean_wpe == 2) hipLaunchKernelGGL((thj_k_stitch<4, 2>), dim3((unsigned)((g1 + 1) / 2)), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
+    else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
     else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch<SPAN_MIDSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
     else {
         // a workgroup's staging area passes the 64 KB a launch may ask for by default: say so once
@@ -818,7 +824,12 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         static const bool pack_timing = getenv("THJ_PACK_TIMING") != nullptr;         // developer switch: phase times of the packed tier on stderr
         unsigned long long* d_dbg = nullptr;
         if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, c->stream)); }
-        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        // reads of up to four segments: four waves a workgroup and three workgroups a CU (168 VGPRs, nothing spilled) instead of two
+        // workgroups of eight waves (128 VGPRs, 43 spilled): 0.69 -> 0.635 ms per launch; THJ_PACK_WPE = 2 | 4: developer switch
+        static const int pack_wpe = getenv("THJ_PACK_WPE") ? atoi(getenv("THJ_PACK_WPE")) : 3;
+        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
         else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
         // (reads of more than eight segments: the packed tier keeps a chain's choices in eight bytes -- the general kernel takes the multihit list as it is)
         if (pack_timing) {
