@@ -796,9 +796,10 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
     if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
     const int64_t g1 = G, g2 = G;
-    // reads of up to four segments: three workgroups a CU (168 VGPRs, nothing spilled) instead of four (128 VGPRs, 6 spilled beside 171 SGPRs'
-    // worth of lanes): 0.73 -> 0.70 ms per launch on one box (tools/scratch/stage2_occupancy_ab.sh); THJ_LEAN_WPE = 2 | 4: developer switch
-    static const int lean_wpe = getenv("THJ_LEAN_WPE") ? atoi(getenv("THJ_LEAN_WPE")) : 3;
+    // THJ_LEAN_WPE = 2 | 3: developer switch -- tier 1 with two or three workgroups' worth of registers per CU (256 / 168 VGPRs, nothing
+    // spilled) instead of four (128 VGPRs, 6 spilled): 0.92 / 0.75 ms per launch against 0.70 (profiles/r04_zzz_stage2_occupancy_ab2.txt;
+    // the packed tier below is the other way round)
+    static const int lean_wpe = getenv("THJ_LEAN_WPE") ? atoi(getenv("THJ_LEAN_WPE")) : 4;
     const size_t lean_lds = (size_t)256 * b.nseg * sizeof(SpanHitHead);
     if (b.nseg <= 4 && lean_wpe == 3) hipLaunchKernelGGL((thj_k_stitch<4, 3>), dim3((unsigned)((g1 * 3 + 3) / 4)), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
     else if (b.nseg <= 4 && lean_wpe == 2) hipLaunchKernelGGL((thj_k_stitch<4, 2>), dim3((unsigned)((g1 + 1) / 2)), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
