@@ -934,8 +934,11 @@ def run_rank(args, rank, world, local_rank, control, shared):
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
         ctx.span_sets_from_segjuncs()
         ctx.span_reset()
-        ctx.span_run(p_span, sp_left)
-        ctx.span_run(p_span, sp_right)
+        if os.environ.get("THJ_BENCH_NO_PAIR") == "1":
+            ctx.span_run(p_span, sp_left)
+            ctx.span_run(p_span, sp_right)
+        else:
+            ctx.span_run_pair(p_span, sp_left, sp_right)          # both sides as one call: the two sides' kernels run beside each other
         n_alns = ctx.span_finish()
         return cnt, n_alns
 
@@ -1015,6 +1018,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
     # tiers 1/2/3 re-read CSR + hits of their worklist reads (4-B list entry each) and one 64-B line of junction keys
     # per closure.  Counters come from the kernels (tier sizes of the last launch, record count of the step).
     n_lean, n_multi, n_gen = ctx.span_tier_counts()
+    n_chain = ctx.span_chain_count()                 # those of n_lean that travel as chain entries (tier 0 -> thj_k_join -> thj_k_finish)
     hits_per_read = float(int(w["left"]["span_off"][-1]) + int(w["right"]["span_off"][-1])) / (2.0 * args.pairs)
     # reads with a segment that has several hits carry most of the hit records of a mixed workload: the multihit tier's share of
     # the hit bytes is counted from them, not from the average read
@@ -1033,7 +1037,11 @@ def run_rank(args, rank, world, local_rank, control, shared):
     n_t0 = args.pairs - n_lean - n_multi
     hit_b = 16.0 if use_heads else 32.0              # tier 0 streams the dense 16-byte heads when the batch has them
     t0_alg = 4.0 * (args.pairs * nseg + 1) + hit_b * hits_per_read * args.pairs + n_t0 * per_read_done + 4.0 * (n_lean + n_multi)
-    t1_alg = n_lean * (4 + 4.0 * (nseg + 1) + 32.0 * hits_single + per_read_done + 64)
+    t1_alg = (n_lean - n_chain) * (4 + 4.0 * (nseg + 1) + 32.0 * hits_single + per_read_done + 64)
+    # a chain entry: 32 B written by tier 0 and read by the join, the chain's hit records (32 B each), one 64-B line of junction keys, the
+    # joined hit (32 B) written and read again
+    join_alg = n_chain * (32.0 + 32.0 * hits_single + 64 + 32)
+    fin_alg = n_chain * (32.0 + per_read_done)
     t2_alg = n_multi * (4 + 4.0 * (nseg + 1) + 32.0 * (hits_multi if multi_reads else hits_per_read) + per_read_done + 64) + 4.0 * n_gen
     t3_alg = n_gen * (4 + 4.0 * (nseg + 1) + 32.0 * hits_per_read + per_read_done + 64)
     # thj_k_segjuncs_rescue: per (hit, mate hit) pair the read, its CSR row + hits, the mate hit and ~3 genome lines of flank
@@ -1057,11 +1065,15 @@ def run_rank(args, rank, world, local_rank, control, shared):
     for i in (1, 2, 3, 4, 5):
         kernels[i]["stream"] = "side stream: runs beside the flat reads' kernels (the last three entries)"
     kernels += [
-        {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg},
-        {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
-        {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
-        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_generic", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
+        {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg + 32.0 * n_chain},
+        {"kernel": "thj_k_join", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": join_alg},
+        {"kernel": "thj_k_finish", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": fin_alg},
+        {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
+        {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[4], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
+        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_generic", "avg_kernel_ms": span_ms[5], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
     ]
+    for i in (len(kernels) - 5, len(kernels) - 4):
+        kernels[i]["stream"] = "side stream: runs beside the kernels of the reads that do not travel as chain entries, and beside the other side's"
     # The same kernels in SURVEY 8(d)'s byte terms -- what the ALGORITHM has to move, whatever layout a build chose: 16 B per hit
     # record (this build's stage-2 record is 32 B), the packed read, <= 128 B of genome per window / per joined hit, one 64-B
     # line of junction keys per closure, 16 B per candidate event, 32 + 8 x ncigar B per joined alignment (this build writes a
@@ -1073,11 +1085,15 @@ def run_rank(args, rank, world, local_rank, control, shared):
     task_8d = (cnt.n_windows / n_launch) * (128 + rl_bytes) + (cnt.n_indel_pairs / n_launch) * (64 + rl_bytes) \
         + 16.0 * (cnt.n_juncs + cnt.n_deletions + cnt.n_insertions) / n_launch
     t0_8d = 4.0 * (args.pairs * nseg + 1) + 16.0 * hits_per_read * args.pairs + n_t0 * done_8d + 4.0 * (n_lean + n_multi)
-    t1_8d = n_lean * (4 + 4.0 * (nseg + 1) + 16.0 * hits_single + done_8d + 64)
+    t1_8d = (n_lean - n_chain) * (4 + 4.0 * (nseg + 1) + 16.0 * hits_single + done_8d + 64)
+    # the chain reads in 8(d)'s terms: the join needs the hits (16 B each; the entry carries them) and one line of junction keys, the
+    # finish the read, <= 128 B of genome and the alignment it writes; the joined hit handed from one to the other is layout
+    join_8d = n_chain * (16.0 * hits_single + 64)
+    fin_8d = n_chain * done_8d
     t2_8d = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read) + done_8d + 64) + 4.0 * n_gen
     t3_8d = n_gen * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64)
     resc_8d = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 128)
-    for k, b8 in zip(kernels, sj_entries(task_8d, resc_8d) + [t0_8d, t1_8d, t2_8d, t3_8d]):
+    for k, b8 in zip(kernels, sj_entries(task_8d, resc_8d) + [t0_8d, join_8d, fin_8d, t1_8d, t2_8d, t3_8d]):
         k["algorithmic_bytes_8d_per_launch"] = b8
     for k in kernels:
         k["achieved_layout"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0

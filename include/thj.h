@@ -378,6 +378,11 @@ int thj_span_reset_async(thj_ctx* ctx);
 /* join_segments_for_read + sort/unique + filters + bowtie_sam_extra for every read of the
  * batch (long_spanning_reads.cpp:2612-2667, :2767-2831); records accumulate in HBM. */
 int thj_span_run_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* dev_batch);
+/* Two batches -- the left and the right reads of a pass, or two shards of one side -- as one call: the same records in the same
+ * slots as thj_span_run_async(batch0) followed by thj_span_run_async(batch1), with the kernels of the two batches running beside
+ * each other on streams of the context's own (the latency-bound kernels of one batch overlap the bandwidth-bound ones of the
+ * other).  Joined on the context's stream before it returns. */
+int thj_span_run_pair_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* dev_batch0, const thj_span_batch* dev_batch1);
 /* Synchronises and returns the record count.  THJ_EOVERFLOW when a device limit was hit (message says which); THJ_ERETRY when
  * a pool or workspace had to be enlarged (extra records of multihit reads; reads with more joined alignments than a thread keeps):
  * run the pass again.
@@ -403,13 +408,14 @@ typedef struct {
 /* The device-resident layout described above (DEVICE pointers), for consumers that stay on the GPU. */
 int thj_span_device_records(thj_ctx* ctx, const thj_aln_slot** d_slots, const uint8_t** d_counts, int64_t* n_reads,
                             const thj_aln_slot** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra);
-/* counts[0] = reads the last thj_span_run_async sent to the closure kernel thj_k_stitch, counts[1] = to the multihit kernel
- * thj_k_stitch_pack, counts[2] = on to the general kernel thj_k_stitch_generic; the rest were finished by
- * thj_k_stitch_contig. */
-int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[3]*/);
-/* Average durations (ms) of the stitch kernels since the last call -- avg_ms[0] thj_k_stitch_contig, [1] thj_k_stitch,
- * [2] thj_k_stitch_pack, [3] thj_k_stitch_generic -- from HIP events on the context stream. */
-int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[4]*/, int64_t* launches);
+/* Of the batch launched last: counts[0] = reads sent to the closure kernels (as chain entries to thj_k_join / thj_k_finish, or to
+ * thj_k_stitch), counts[1] = to the multihit kernel thj_k_stitch_pack, counts[2] = on to the general kernel thj_k_stitch_generic,
+ * counts[3] = those of counts[0] that travelled as chain entries; the rest were finished by thj_k_stitch_contig. */
+int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[4]*/);
+/* Average durations (ms) of the stitch kernels since the last call -- avg_ms[0] thj_k_stitch_contig, [1] thj_k_join, [2] thj_k_finish,
+ * [3] thj_k_stitch, [4] thj_k_stitch_pack, [5] thj_k_stitch_generic or, with --fusion-search, thj_k_stitch_fusion -- from HIP events on
+ * the stream each runs on (kernels of batches that run beside each other share the GPU: their durations overlap). */
+int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[6]*/, int64_t* launches);
 
 /* ---- coverage search of segment_juncs (segment_juncs.cpp:4268-4543 capture_island_ends and what it calls: the
  * coverage map of build_coverage_map :4140-4176, the extension table of index_read_mers :548-571,

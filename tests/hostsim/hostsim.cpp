@@ -220,6 +220,8 @@ struct VecSink {
 
 static int64_t g_wave_reads = 0;            // reads the packed tier finished since the last call of hostsim_wave_reads
 extern "C" int64_t hostsim_wave_reads() { const int64_t n = g_wave_reads; g_wave_reads = 0; return n; }
+static int64_t g_chain_reads = 0;           // reads that travelled as chain entries (tier 0 -> join -> finish) since the last call
+extern "C" int64_t hostsim_chain_reads() { const int64_t n = g_chain_reads; g_chain_reads = 0; return n; }
 // the wave operations span_pack_wave is written against, over simt.h's fibers (one wave = 64 fibers)
 #include "simt.h"
 struct WaveSimX {
@@ -298,8 +300,25 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
         VecSink sink{&outs[(size_t)r]};
         int st = SPAN_NEED_GENERIC;
         if (mode != 1) {
+            // modes 0 and 3: plain one-hit-per-segment reads travel as chain entries (tier 0 -> thj_k_join -> thj_k_finish); mode 2 keeps
+            // every such read on span_read_lean
+            ChainEntry ent;
             st = span_read_contig(g, p, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
-                                  read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);
+                                  read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink, (mode == 0 || mode == 3) ? &ent : nullptr);
+            if ((st & 0xFF) == SPAN_NEED_CHAIN) {
+                status_counts[4]++; ++g_chain_reads;
+                RAln res;
+                SpanHit ch[CHAIN_MAXSEG];
+                for (int s = 0; s < CHAIN_MAXSEG; ++s) ch[s] = ((const SpanHit*)hits)[ent.hit[s]];
+                int jr = chain_join(g, p, S, ch, ent.meta, (const u64*)planes + (int64_t)ent.read * 3 * W, W, res);
+                if (jr == LJ_PUNT) { gen.push_back((uint32_t)r); continue; }       // more cigar ops than LEAN_C: thj_k_join hands the read to the general tier
+                if (jr == LJ_OK) {
+                    Q16 ja, jb, jc;
+                    joined_pack(res, ent.read, chain_nsegs(ent.meta) == 1, chain_q(ent.meta), chain_k(ent.meta), ja, jb, jc);
+                    joined_finish(g, p, ja, jb, jc, (const u64*)planes, W, read_len, quals, qual_stride, 0, sink);
+                }
+                st = SPAN_OK;
+            }
             if ((st & 0xFF) == SPAN_NEED_LEAN) {
                 status_counts[4]++;
                 SpanHitHead stage[SPAN_MAXSEG];

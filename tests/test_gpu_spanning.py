@@ -57,6 +57,39 @@ def test_two_batches_keep_read_order():
     assert a == want and b == want
 
 
+def test_pair_call_gives_the_records_of_two_runs():
+    """thj_span_run_pair_async: two batches beside each other on the context's own streams and scratch sets -- the records of
+    thj_span_run_async(batch 0) then thj_span_run_async(batch 1), in the same slots; most one-hit-per-segment reads of the
+    100-base case travel as chain entries (tier 0 -> thj_k_join -> thj_k_finish)"""
+    ca = SPAN_CASES[0]
+    case_a, p, seqs, g, sb_a, juncs, ins = span_inputs(ca, n_reads=900)
+    # the second batch: other reads of the same genome (same seed -> same genome; different read count changes the reads drawn)
+    case_b, p_b, seqs_b, g_b, sb_b, juncs_b, ins_b = span_inputs(ca, n_reads=500)
+    assert seqs_b == seqs
+    want_a = orc.spanning(p, g, sb_a, juncs, ins)
+    want_b = orc.spanning(p, g, sb_b, juncs, ins)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        ctx.upload_span_sets(juncs, ins)
+        ha, hb = ctx.upload_span_batch(sb_a), ctx.upload_span_batch(sb_b)
+        two = ctx.spanning(p, [ha, hb])
+        ctx.span_reset()
+        ctx.span_run_pair(p, ha, hb)
+        n = ctx.span_finish()
+        assert ctx.span_chain_count() > 50                 # of batch b: reads that went through the join and finish kernels
+        from tophat_amd.host import alns_from_array
+        pair = alns_from_array(ctx.span_download(n), None)
+        ctx.span_reset()
+        ctx.span_run_pair(p, hb, ha)
+        n2 = ctx.span_finish()
+        pair2 = alns_from_array(ctx.span_download(n2), None)
+    assert len(two) == len(want_a) + len(want_b)
+    key = lambda a: (a.ref_id, a.left, a.antisense, a.antisense_splice, a.cigar, a.MD, a.AS, a.XM, a.mismatches, a.edit_dist)
+    assert [key(a) for a in pair] == [key(a) for a in two]
+    assert [key(a) for a in pair2[:len(want_b)]] == [key(a) for a in want_b]
+    assert [key(a) for a in pair2[len(want_b):]] == [key(a) for a in want_a]
+
+
 def test_many_joined_alignments_per_read_gpu():
     """30 joined alignments per read (a 30-copy tandem repeat): multihit tier, overflow pool ordering"""
     import numpy as np

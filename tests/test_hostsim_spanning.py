@@ -51,8 +51,11 @@ def test_span_logic_matches_oracle(cfg):
     if cfg["seed"] == 7:
         assert sum(1 for a in want if sum(1 for c in a.cigar if c) > 8) > 50
     assert any(any((c >> 28) == 11 for c in a.cigar) for a in want), "no spliced alignment in the case"
-    for mode in (0, 1, 2, 3):  # the tiers as the kernels run them, the generic path alone, the tiers without the staged multihit one, with the shared (wave per read) tier
+    for mode in (0, 1, 2, 3):  # the tiers as the kernels run them (chain entries -> join -> finish), the generic path alone, the tiers without the packed multihit one and without chain entries, with the packed tier's limits made tiny
+        sim.lib().hostsim_chain_reads()
         got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)
+        chains = sim.lib().hostsim_chain_reads()
+        assert (chains > 0) == (mode in (0, 3) and cfg["read_len"] // cfg["seg_len"] <= 4), (mode, chains)
         assert status[1] == 0 and status[2] == 0
         # records of one read are emitted together; across reads the device orders by read index afterwards
         got.sort(key=lambda a: a.read_idx)

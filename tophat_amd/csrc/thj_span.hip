@@ -108,6 +108,11 @@ struct Tiers {
     // reads with more joined alignments than a thread's own array holds (a read in a large repeat family): listed here when the
     // context owns the big workspace (thj_k_stitch_huge does them again with room), else reported (SPAN_TOO_MANY_JOINED)
     uint32_t* huge_list; unsigned int* huge_cnt; int huge_list_cap;
+    // chain entries (tier 0 -> thj_k_join, see thj_span_core.h): class-major block-owned slices like wl_lean, 32 bytes an entry;
+    // null: every one-hit-per-segment read takes wl_lean.  The joined hits, densely: ja / jb / jc[i] for entry i of the concatenation
+    ChainEntry* ent; unsigned int* blk_chain;
+    Q16* ja; Q16* jb; Q16* jc;
+    unsigned int* n_joined;          // entries thj_k_join went over (what thj_k_finish goes over)
 };
 __device__ __forceinline__ bool defer_huge(const Tiers& t, uint32_t r) {
     if (!t.huge_list) return false;
@@ -145,11 +150,11 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
     __shared__ uint4 stage[256 * 8];
     __shared__ uint8_t has_rec[256];
     __shared__ unsigned int s_cnt[3];          // (unused), multihit, records
-    __shared__ unsigned int s_lean[SPAN_LEAN_CLASSES];
+    __shared__ unsigned int s_lean[SPAN_LEAN_CLASSES], s_chain[SPAN_LEAN_CLASSES];
     constexpr int NC = lean_classes(MS);
     const int tid = threadIdx.x;
     if (tid < 3) s_cnt[tid] = 0;
-    if (tid < SPAN_LEAN_CLASSES) s_lean[tid] = 0;
+    if (tid < SPAN_LEAN_CLASSES) { s_lean[tid] = 0; s_chain[tid] = 0; }
     __syncthreads();
     // reads are numbered in 32 bits (n_reads < 2^31 is checked on the host); offsets are one 32x32->64 multiply each
     const uint32_t c0 = blockIdx.x * (uint32_t)t.chunk;
@@ -171,9 +176,16 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
         const int rl = rl_next;
         if (r + 256 < c1) { contig_offsets<MS>(b.seg_off + (u64)(r + 256) * (uint32_t)b.nseg, b.nseg, sv_next); rl_next = (int)b.read_len[r + 256]; }
         if (r < c1) {
+            ChainEntry ent;
             int st = span_read_contig_pre<MS>(g, p, b.hits, sv, b.nseg, b.planes + (u64)r * (uint32_t)(3 * b.W), b.W,
-                                          rl, b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss, b.heads);
-            if ((st & 0xFF) == SPAN_NEED_LEAN) {
+                                          rl, b.quals + (u64)r * (uint32_t)b.qual_stride, r, ss, b.heads, MS <= CHAIN_MAXSEG ? &ent : nullptr, t.ent != nullptr);
+            if (MS <= CHAIN_MAXSEG && (st & 0xFF) == SPAN_NEED_CHAIN) {
+                const unsigned int cls = (unsigned int)(st >> 8);
+                Q16* dst = (Q16*)(t.ent + (u64)(cls * gridDim.x + blockIdx.x) * (uint32_t)t.chunk + atomicAdd(&s_chain[cls], 1u));
+                dst[0] = Q16{ent.read, ent.meta, ent.spare0, ent.spare1};
+                dst[1] = Q16{ent.hit[0], ent.hit[1], ent.hit[2], ent.hit[3]};
+            }
+            else if ((st & 0xFF) == SPAN_NEED_LEAN) {
                 const unsigned int cls = NC > 1 ? (unsigned int)(st >> 8) : 0u;
                 t.wl_lean[(u64)(cls * gridDim.x + blockIdx.x) * (uint32_t)t.chunk + atomicAdd(&s_lean[cls], 1u)] = r;
             }
@@ -204,10 +216,12 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
     if (my_rec) atomicAdd(&s_cnt[2], my_rec);
     __syncthreads();
     if (tid == 0) {
-        unsigned int n_lean = 0;
+        unsigned int n_lean = 0, n_chain = 0;
         for (int k = 0; k < NC; ++k) { t.blk_lean[k * gridDim.x + blockIdx.x] = s_lean[k]; n_lean += s_lean[k]; }
+        if (t.ent) for (int k = 0; k < SPAN_LEAN_CLASSES; ++k) { t.blk_chain[k * gridDim.x + blockIdx.x] = s_chain[k]; n_chain += s_chain[k]; }
         t.blk_multi[blockIdx.x] = s_cnt[1];
-        if (n_lean) atomicAdd(&t.counters[0], n_lean);
+        if (n_lean + n_chain) atomicAdd(&t.counters[0], n_lean + n_chain);
+        if (n_chain) atomicAdd(&t.counters[6], n_chain);
         if (s_cnt[1]) atomicAdd(&t.counters[1], s_cnt[1]);
         if (s_cnt[2]) atomicAdd(sink.total, (unsigned long long)s_cnt[2]);
     }
@@ -286,6 +300,77 @@ __global__ __launch_bounds__(256, WPE) void thj_k_stitch(Genome g, Params p, Spa
     __syncthreads();
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
     if (threadIdx.x == 0 && s_fwd) atomicAdd(&t.counters[1], s_fwd);
+}
+
+// The join of the chain entries (merge_chain, long_spanning_reads.cpp:805-2038, on register cigars): a thread per entry of the
+// concatenated class-major slices.  The entry names the chain's hit records; they are fetched whole and all together (eight
+// 16-byte loads in flight), parked in the thread's own column of LDS (lean_join picks hits by a running index), and the join
+// touches global memory again only for the junction keys its closures look at and -- when a boundary moves -- a few genome and
+// read words.  Entry i's joined hit is ja / jb / jc[i]; an entry that does not join leaves JOINED_NONE; one that needs more cigar
+// ops than the registers hold goes to the general tier's list.
+struct LdsChainHits {       // word pair (2 s, 2 s + 1) of column `col` = the record of the chain's segment s
+    const Q16* col;
+    __device__ __forceinline__ SpanHit operator[](int s) const {
+        const Q16 a = col[(2 * s) * 256], b = col[(2 * s + 1) * 256];
+        SpanHit h;
+        h.ref_id = a.x; h.left = (int32_t)a.y; h.meta = a.z; h.cigar[0] = a.w;
+        h.cigar[1] = b.x; h.cigar[2] = b.y; h.cigar[3] = b.z; h.cigar[4] = b.w;
+        return h;
+    }
+};
+__global__ __launch_bounds__(256, 4) void thj_k_join(Genome g, Params p, SpanSets S, const SpanHit* hits, const u64* planes, int W, Tiers t, int G) {
+    __shared__ unsigned int s_off[SPAN_LEAN_CLASSES * MAX_SLICES + 1];
+    __shared__ Q16 s_rec[2 * CHAIN_MAXSEG * 256];
+    const unsigned int total = slice_offsets<256, SPAN_LEAN_CLASSES * MAX_SLICES>(t.blk_chain, SPAN_LEAN_CLASSES * G, s_off);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *t.n_joined = total;
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int sl = slice_of(s_off, SPAN_LEAN_CLASSES * G, i);
+        const Q16* src = (const Q16*)(t.ent + (u64)sl * (uint32_t)t.chunk + (i - s_off[sl]));
+        const Q16 e0 = src[0], e1 = src[1];
+        const uint32_t r = e0.x, meta = e0.y;
+        {
+            Q16 rec[2 * CHAIN_MAXSEG];
+            const uint32_t hi[CHAIN_MAXSEG] = {e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+            for (int k = 0; k < CHAIN_MAXSEG; ++k) { const Q16* hp = (const Q16*)(hits + hi[k]); rec[2 * k] = hp[0]; rec[2 * k + 1] = hp[1]; }
+#pragma unroll
+            for (int k = 0; k < 2 * CHAIN_MAXSEG; ++k) s_rec[k * 256 + threadIdx.x] = rec[k];
+        }
+        const LdsChainHits ch{s_rec + threadIdx.x};
+        RAln res;
+        const int jr = chain_join(g, p, S, ch, meta, planes + (u64)r * (uint32_t)(3 * W), W, res);
+        Q16 ja, jb, jc;
+        joined_pack(res, r, chain_nsegs(meta) == 1, chain_q(meta), chain_k(meta), ja, jb, jc);
+        if (jr != LJ_OK) ja.x = JOINED_NONE;
+        t.ja[i] = ja;
+        if (jr == LJ_OK) { t.jb[i] = jb; if (res.n > 4) t.jc[i] = jc; }
+        if (jr == LJ_PUNT) {               // rare: the general tier takes the read (its slice of that list is its tier-0 block's)
+            const uint32_t blk = r / (uint32_t)t.chunk;
+            t.wl_gen[(u64)blk * (uint32_t)t.chunk + atomicAdd(&t.blk_gen[blk], 1u)] = r;
+            atomicAdd(&t.counters[2], 1u);
+        }
+    }
+}
+
+// The finish of the joined hits (check_editdist_consistency, bowtie_sam_extra, the record: bwt_map.cpp:2349-2648, :1888-2093): a
+// thread per joined hit over the dense list thj_k_join wrote.
+__global__ __launch_bounds__(256, 4) void thj_k_finish(Genome g, Params p, DevSpanBatch b, RecSink sink, Tiers t) {
+    __shared__ unsigned int s_rec;
+    if (threadIdx.x == 0) s_rec = 0;
+    __syncthreads();
+    const unsigned int total = *t.n_joined;
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const Q16 ja = t.ja[i];
+        if (ja.x == JOINED_NONE) continue;
+        const Q16 jb = t.jb[i];
+        Q16 jc{0, 0, 0, 0};
+        if ((ja.w & 15u) > 4u) jc = t.jc[i];
+        joined_finish(g, p, ja, jb, jc, b.planes, b.W, b.read_len, b.quals, b.qual_stride, 0, sink);
+        sink.done(ja.x);
+    }
+    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
 }
 
 // Tier 2, packed: the multihit list, 64 entries per wave at a time, as chains over the lanes (span_pack_wave): a read with its
@@ -465,16 +550,19 @@ void thj_span_free(thj_ctx* c) {
     jb_free(c);
     hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket); hipFree(c->d_span_fus); hipFree(c->d_huge_ws); hipFree(c->d_huge_list);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
-    hipFree(c->d_aln_count); hipFree(c->d_span_status); hipFree(c->d_worklist);
+    hipFree(c->d_aln_count); hipFree(c->d_span_status);
+    for (auto& ss : c->span_set) { hipFree(ss.d_worklist); hipFree(ss.d_ent); hipFree(ss.d_joined); }
+    for (auto& st : c->span_stream) if (st) hipStreamDestroy(st);
+    for (auto& e : c->span_ev) if (e) hipEventDestroy(e);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
 
 static int ensure_span_state(thj_ctx* c) {
     if (!c->d_aln_count) {
         HIPCHK(hipMalloc(&c->d_aln_count, 16));
-        HIPCHK(hipMalloc(&c->d_span_status, 16 * sizeof(unsigned int)));
+        HIPCHK(hipMalloc(&c->d_span_status, 64 * sizeof(unsigned int)));      // [0..3] statuses of the pass, [16 + 16 k ..] the counters of scratch set k (span_launch)
         HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 16, c->stream));
-        HIPCHK(hipMemsetAsync(c->d_span_status, 0, 64, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_span_status, 0, 256, c->stream));
     }
     return THJ_OK;
 }
@@ -740,26 +828,63 @@ extern "C" int thj_span_fusions_from_segjuncs(thj_ctx* c) {
 }
 
 
-extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db) {
-    if (!c || !tp || !db) { thj_set_error("thj_span_run_async: null argument"); return THJ_EINVAL; }
-    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
-    int rc = check_span_params(tp, db);
-    if (rc) return rc;
-    HIPCHK(hipSetDevice(c->device));
-    if ((rc = ensure_span_state(c))) return rc;
-    if (db->n_reads == 0) return THJ_OK;
-    if ((rc = ensure_sets_cap(c, c->n_span_junc, c->n_span_ins))) return rc;
-    if (c->span_reads + (int64_t)db->n_reads >= (1ll << 32)) { thj_set_error("more than 2^32 reads in one pass"); return THJ_EINVAL; }
-    if ((rc = ensure_slots(c, c->span_reads + (int64_t)db->n_reads))) return rc;
+// ---- one batch through the tiers -----------------------------------------------------------------------------------------
+// A batch runs on a "set" of scratch (worklists, chain entries, joined hits, counters: c->span_set[k]) and on two streams:
+//   sm  thj_k_stitch_contig -> thj_k_stitch (the one-hit-per-segment reads that cannot travel as chain entries; it may add to the
+//       multihit list) -> thj_k_stitch_pack -> thj_k_stitch_generic   [with --fusion-search: thj_k_stitch_fusion]
+//   sa  (after tier 0)  thj_k_join -> thj_k_finish
+// thj_span_run_async runs one batch on set 0 (sm = the context's stream); thj_span_run_pair_async runs two batches -- the two sides
+// of a pass -- beside each other on both sets: the latency-bound kernels of one side overlap the bandwidth-bound tier 0 of the other.
+// Everything is joined on the context's stream before either call returns.
+static constexpr int SPAN_CNT_WORDS = 16;      // a set's counters: [0] reads to the closure kernels, [1] multihit, [2] general, [3] the packed tier's
+                                               // place in its list, [4] reads for thj_k_stitch_huge, [5] chain entries, [6] reads that travel as chain entries
+enum { SPK_CONTIG = 0, SPK_JOIN, SPK_FINISH, SPK_LEAN, SPK_PACK, SPK_GENERIC, SPK_N };
+
+static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int64_t chunk, bool chains) {
+    thj_ctx::SpanSet& ss = c->span_set[set];
+    const int NC = SPAN_LEAN_CLASSES;
+    const int64_t wl_need = (2 + NC) * G * chunk + (2 + 2 * NC) * MAX_SLICES;
+    if (ss.worklist_cap < wl_need) {
+        HIPCHK(hipDeviceSynchronize());
+        hipFree(ss.d_worklist); ss.d_worklist = nullptr; ss.worklist_cap = 0;
+        HIPCHK(hipMalloc(&ss.d_worklist, (size_t)wl_need * 4));
+        ss.worklist_cap = wl_need;
+    }
+    if (chains) {
+        const int64_t ent_need = NC * G * chunk, j_need = n_reads;
+        if (ss.ent_cap < ent_need) {
+            HIPCHK(hipDeviceSynchronize());
+            hipFree(ss.d_ent); ss.d_ent = nullptr; ss.ent_cap = 0;
+            HIPCHK(hipMalloc(&ss.d_ent, (size_t)ent_need * sizeof(ChainEntry)));
+            ss.ent_cap = ent_need;
+        }
+        if (ss.joined_cap < j_need) {
+            HIPCHK(hipDeviceSynchronize());
+            hipFree(ss.d_joined); ss.d_joined = nullptr; ss.joined_cap = 0;
+            const int64_t cap = j_need + j_need / 8 + 1024;
+            HIPCHK(hipMalloc(&ss.d_joined, (size_t)cap * 3 * sizeof(Q16)));
+            ss.joined_cap = cap;
+        }
+    }
+    return THJ_OK;
+}
+static int ensure_span_streams(thj_ctx* c) {
+    if (c->span_stream[0]) return THJ_OK;
+    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithFlags(&c->span_stream[i], hipStreamNonBlocking));
+    for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreateWithFlags(&c->span_ev[i], hipEventDisableTiming));
+    return THJ_OK;
+}
+
+// the launches of one batch: `base` = its first slot in the pass; sm / sa as above (sa == sm: everything on one stream)
+static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* db, int set, uint32_t base, hipStream_t sm, hipStream_t sa, hipEvent_t ev_fork, hipEvent_t ev_joined) {
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevSpanBatch b; memcpy(&b, db, sizeof b);
     SpanSets S{c->d_span_junc, c->n_span_junc, c->d_span_ins_key, c->d_span_ins_seq, c->n_span_ins, c->d_junc_bucket, c->n_junc_buckets};
-    const uint32_t base = (uint32_t)c->span_reads;
 #ifdef THJ_EXP
     { int f = getenv("THJ_EXP_FLAGS") ? atoi(getenv("THJ_EXP_FLAGS")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(thj_exp_flags), &f, sizeof f)); }
 #endif
-    HIPCHK(hipMemsetAsync(c->d_nrec + base, 0, (size_t)b.n_reads, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_nrec + base, 0, (size_t)b.n_reads, sm));
     RecSink sink{(OutAln*)c->d_aln_pool, c->d_nrec, base, (OutAln*)c->d_aln_sorted, c->d_aln_keys, c->d_aln_count + 1,
                  (unsigned long long)c->ovf_cap, c->d_aln_count, c->d_span_status, 0, 0};
     // block-owned slices of the worklists (see Tiers)
@@ -770,48 +895,69 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
     chunk = (chunk + 255) / 256 * 256;
     G = ((int64_t)b.n_reads + chunk - 1) / chunk;
     const int NC = SPAN_LEAN_CLASSES;
-    const int64_t wl_need = (2 + NC) * G * chunk + (2 + NC) * MAX_SLICES;
-    if (c->worklist_cap < wl_need) {
-        hipFree(c->d_worklist); c->d_worklist = nullptr;
-        HIPCHK(hipMalloc(&c->d_worklist, (size_t)wl_need * 4));
-        c->worklist_cap = wl_need;
-    }
+    // THJ_NO_CHAINS: developer switch -- every one-hit-per-segment read through thj_k_stitch, as before round 5
+    static const bool no_chains = getenv("THJ_NO_CHAINS") != nullptr;
+    const bool chains = !no_chains && !p.fusion_search && b.nseg <= CHAIN_MAXSEG;
+    int rc = ensure_span_set(c, set, b.n_reads, G, chunk, chains);
+    if (rc) return rc;
+    thj_ctx::SpanSet& ss = c->span_set[set];
     Tiers t;
-    t.wl_lean = c->d_worklist;
-    t.wl_multi = c->d_worklist + NC * G * chunk;
+    t.wl_lean = ss.d_worklist;
+    t.wl_multi = ss.d_worklist + NC * G * chunk;
     t.wl_gen = t.wl_multi + G * chunk;
     t.blk_lean = t.wl_gen + G * chunk;
     t.blk_multi = t.blk_lean + NC * MAX_SLICES;
     t.blk_gen = t.blk_multi + MAX_SLICES;
-    t.counters = &c->d_span_status[4];
+    t.blk_chain = t.blk_gen + MAX_SLICES;
+    t.counters = &c->d_span_status[16 + SPAN_CNT_WORDS * set];
     t.chunk = (int)chunk;
-    t.huge_list = c->d_huge_list; t.huge_cnt = &c->d_span_status[8]; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
-    HIPCHK(hipMemsetAsync(t.counters, 0, 16, c->stream));                    // [3]: thj_k_stitch_pack's place in its list
-    HIPCHK(hipMemsetAsync(t.huge_cnt, 0, 4, c->stream));
-    HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, c->stream));      // tiers 0 / 1 write the other two
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (c->span_profile) { for (auto& e : ev) e = thj_get_event(c); HIPCHK(hipEventRecord(ev[0], c->stream)); }
-    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
-    else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MIDSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
-    else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, c->stream, g, p, b, sink, t);
-    if (c->span_profile) HIPCHK(hipEventRecord(ev[1], c->stream));
+    t.huge_list = c->d_huge_list; t.huge_cnt = t.counters + 4; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
+    t.ent = chains ? (ChainEntry*)ss.d_ent : nullptr;
+    t.ja = (Q16*)ss.d_joined; t.jb = t.ja ? t.ja + ss.joined_cap : nullptr; t.jc = t.ja ? t.ja + 2 * ss.joined_cap : nullptr;
+    t.n_joined = t.counters + 5;
+    HIPCHK(hipMemsetAsync(t.counters, 0, SPAN_CNT_WORDS * 4, sm));
+    HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, sm));      // tiers 0 / 1 write the others
+    c->span_last_set = set;
+    hipEvent_t ev[2 * SPK_N];
+    for (auto& e : ev) e = nullptr;
+    const bool prof = c->span_profile;
+    if (prof) for (auto& e : ev) e = thj_get_event(c);
+#define SPK_BEGIN(k, st) do { if (prof) HIPCHK(hipEventRecord(ev[2 * (k)], st)); } while (0)
+#define SPK_END(k, st) do { if (prof) HIPCHK(hipEventRecord(ev[2 * (k) + 1], st)); } while (0)
+    SPK_BEGIN(SPK_CONTIG, sm);
+    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
+    else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MIDSEG>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
+    else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
+    SPK_END(SPK_CONTIG, sm);
+    // ---- the chain entries: join, then finish, beside the kernels of the other reads
+    if (chains) {
+        if (sa != sm) { HIPCHK(hipEventRecord(ev_fork, sm)); HIPCHK(hipStreamWaitEvent(sa, ev_fork, 0)); }
+        SPK_BEGIN(SPK_JOIN, sa);
+        hipLaunchKernelGGL(thj_k_join, dim3((unsigned)G), dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, t, (int)G);
+        if (sa != sm) HIPCHK(hipEventRecord(ev_joined, sa));
+        SPK_END(SPK_JOIN, sa);
+        SPK_BEGIN(SPK_FINISH, sa);
+        hipLaunchKernelGGL(thj_k_finish, dim3((unsigned)G), dim3(256), 0, sa, g, p, b, sink, t);
+        SPK_END(SPK_FINISH, sa);
+    } else { SPK_BEGIN(SPK_JOIN, sm); SPK_END(SPK_JOIN, sm); SPK_BEGIN(SPK_FINISH, sm); SPK_END(SPK_FINISH, sm); }
     const int64_t g1 = G, g2 = G;
     // THJ_LEAN_WPE = 2 | 3: developer switch -- tier 1 with two or three workgroups' worth of registers per CU (256 / 168 VGPRs, nothing
     // spilled) instead of four (128 VGPRs, 6 spilled): 0.92 / 0.75 ms per launch against 0.70 (profiles/r04_zzz_stage2_occupancy_ab2.txt;
     // the packed tier below is the other way round)
     static const int lean_wpe = getenv("THJ_LEAN_WPE") ? atoi(getenv("THJ_LEAN_WPE")) : 4;
     const size_t lean_lds = (size_t)256 * b.nseg * sizeof(SpanHitHead);
-    if (b.nseg <= 4 && lean_wpe == 3) hipLaunchKernelGGL((thj_k_stitch<4, 3>), dim3((unsigned)((g1 * 3 + 3) / 4)), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
-    else if (b.nseg <= 4 && lean_wpe == 2) hipLaunchKernelGGL((thj_k_stitch<4, 2>), dim3((unsigned)((g1 + 1) / 2)), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
-    else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), lean_lds, c->stream, g, p, S, b, sink, t, (int)G);
-    else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch<SPAN_MIDSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+    SPK_BEGIN(SPK_LEAN, sm);
+    if (b.nseg <= 4 && lean_wpe == 3) hipLaunchKernelGGL((thj_k_stitch<4, 3>), dim3((unsigned)((g1 * 3 + 3) / 4)), dim3(256), lean_lds, sm, g, p, S, b, sink, t, (int)G);
+    else if (b.nseg <= 4 && lean_wpe == 2) hipLaunchKernelGGL((thj_k_stitch<4, 2>), dim3((unsigned)((g1 + 1) / 2)), dim3(256), lean_lds, sm, g, p, S, b, sink, t, (int)G);
+    else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), lean_lds, sm, g, p, S, b, sink, t, (int)G);
+    else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch<SPAN_MIDSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), sm, g, p, S, b, sink, t, (int)G);
     else {
         // a workgroup's staging area passes the 64 KB a launch may ask for by default: say so once
         static const hipError_t big1 = hipFuncSetAttribute((const void*)thj_k_stitch<SPAN_MAXSEG>, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * SPAN_MAXSEG * (int)sizeof(SpanHitHead));
         HIPCHK(big1);
-        hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), c->stream, g, p, S, b, sink, t, (int)G);
+        hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), sm, g, p, S, b, sink, t, (int)G);
     }
-    if (c->span_profile) HIPCHK(hipEventRecord(ev[2], c->stream));
+    SPK_END(SPK_LEAN, sm);
     if (p.fusion_search) {
         // tiers 0 and 1 keep the reads that join without a fusion; multihit reads, reads with a fused segment hit and reads tier 1
         // could not join are on the multihit list and go through the fusion branches
@@ -819,49 +965,94 @@ extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_sp
         int64_t gf = ((int64_t)b.n_reads + 63) / 64;
         static const int fusion_grid = getenv("THJ_FUSION_GRID") ? atoi(getenv("THJ_FUSION_GRID")) : 8192;      // developer switch
         if (gf > fusion_grid) gf = fusion_grid;
-        if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
-        hipLaunchKernelGGL(thj_k_stitch_fusion, dim3((unsigned)gf), dim3(64), 0, c->stream, g, p, S, F, b, sink, t, (int)G);
+        SPK_BEGIN(SPK_PACK, sm); SPK_END(SPK_PACK, sm);
+        SPK_BEGIN(SPK_GENERIC, sm);
+        hipLaunchKernelGGL(thj_k_stitch_fusion, dim3((unsigned)gf), dim3(64), 0, sm, g, p, S, F, b, sink, t, (int)G);
+        SPK_END(SPK_GENERIC, sm);
     } else {
         static const bool pack_timing = getenv("THJ_PACK_TIMING") != nullptr;         // developer switch: phase times of the packed tier on stderr
         unsigned long long* d_dbg = nullptr;
-        if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, c->stream)); }
+        if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, sm)); }
         // reads of up to four segments: four waves a workgroup and three workgroups a CU (168 VGPRs, nothing spilled) instead of two
         // workgroups of eight waves (128 VGPRs, 43 spilled): 0.69 -> 0.635 ms per launch; THJ_PACK_WPE = 2 | 4: developer switch
         static const int pack_wpe = getenv("THJ_PACK_WPE") ? atoi(getenv("THJ_PACK_WPE")) : 3;
-        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
-        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
-        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
-        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, c->stream, g, p, S, b, sink, t, (int)G, d_dbg);
+        SPK_BEGIN(SPK_PACK, sm);
+        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
+        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
+        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
+        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
         // (reads of more than eight segments: the packed tier keeps a chain's choices in eight bytes -- the general kernel takes the multihit list as it is)
+        SPK_END(SPK_PACK, sm);
         if (pack_timing) {
             unsigned long long h[16];
-            HIPCHK(hipStreamSynchronize(c->stream));
+            HIPCHK(hipStreamSynchronize(sm));
             HIPCHK(hipMemcpy(h, d_dbg, 128, hipMemcpyDeviceToHost));
             (void)hipFree(d_dbg);
             const double nw = h[10] ? (double)h[10] : 1.0;
             fprintf(stderr, "[packed tier] %llu waves, %llu rounds, %llu sub-rounds; per wave us: all %.1f (max %.1f) = entries %.1f + staging %.1f + searches %.1f + joins %.1f + rank %.1f + tags and records %.1f\n",
                     h[10], h[6], h[7], h[8] / nw / 100.0, h[9] / 100.0, h[0] / nw / 100.0, h[1] / nw / 100.0, h[2] / nw / 100.0, h[3] / nw / 100.0, h[4] / nw / 100.0, h[5] / nw / 100.0);
         }
-        if (c->span_profile) HIPCHK(hipEventRecord(ev[3], c->stream));
         Tiers tg = t;
         if (b.nseg > SPAN_MIDSEG) {
             tg.wl_gen = t.wl_multi; tg.blk_gen = t.blk_multi;
             static const hipError_t big3 = hipFuncSetAttribute((const void*)thj_k_stitch_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * SPAN_MAXSEG * (int)sizeof(SpanHit));
             HIPCHK(big3);
         }
-        hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), c->stream, g, p, S, b, sink, tg, (int)G);
+        if (chains && sa != sm) HIPCHK(hipStreamWaitEvent(sm, ev_joined, 0));      // thj_k_join may add to the general tier's list
+        SPK_BEGIN(SPK_GENERIC, sm);
+        hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), sm, g, p, S, b, sink, tg, (int)G);
+        SPK_END(SPK_GENERIC, sm);
     }
-    if (c->span_profile) {
-        HIPCHK(hipEventRecord(ev[4], c->stream));
-        for (int k = 0; k < 4; ++k) c->span_prof_events.emplace_back(ev[k], ev[k + 1]);
-    }
+#undef SPK_BEGIN
+#undef SPK_END
+    if (prof) for (int k = 0; k < SPK_N; ++k) c->span_prof_events.emplace_back(ev[2 * k], ev[2 * k + 1]);
     if (c->d_huge_ws) {        // a pass that met a read with too many joined alignments runs with the workspace from then on
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
-        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, c->stream, g, p, S, F, b, sink, t, (char*)c->d_huge_ws, HUGE_CAP);
+        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws, HUGE_CAP);
     }
     HIPCHK(hipGetLastError());
-    c->span_reads += b.n_reads;
     return THJ_OK;
+}
+
+static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batch* db0, const thj_span_batch* db1) {
+    if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
+    int rc = check_span_params(tp, db0);
+    if (!rc && db1) rc = check_span_params(tp, db1);
+    if (rc) return rc;
+    HIPCHK(hipSetDevice(c->device));
+    if ((rc = ensure_span_state(c))) return rc;
+    const int64_t n0 = db0->n_reads, n1 = db1 ? db1->n_reads : 0;
+    if (n0 + n1 == 0) return THJ_OK;
+    if ((rc = ensure_sets_cap(c, c->n_span_junc, c->n_span_ins))) return rc;
+    if (c->span_reads + n0 + n1 >= (1ll << 32)) { thj_set_error("more than 2^32 reads in one pass"); return THJ_EINVAL; }
+    if ((rc = ensure_slots(c, c->span_reads + n0 + n1))) return rc;
+    if ((rc = ensure_span_streams(c))) return rc;
+    // THJ_SPAN_SERIAL: developer switch -- every kernel on the context's stream, one after the other
+    static const bool serial = getenv("THJ_SPAN_SERIAL") != nullptr;
+    hipStream_t s0 = c->stream, a0 = serial ? c->stream : c->span_stream[0], s1 = serial ? c->stream : c->span_stream[1], a1 = serial ? c->stream : c->span_stream[2];
+    const uint32_t base0 = (uint32_t)c->span_reads, base1 = (uint32_t)(c->span_reads + n0);
+    if (!serial && n1) { HIPCHK(hipEventRecord(c->span_ev[0], c->stream)); HIPCHK(hipStreamWaitEvent(s1, c->span_ev[0], 0)); }
+    if (n0 && (rc = span_launch(c, tp, db0, 0, base0, s0, a0, c->span_ev[1], c->span_ev[6]))) return rc;
+    if (n1 && (rc = span_launch(c, tp, db1, 1, base1, s1, a1, c->span_ev[2], c->span_ev[7]))) return rc;
+    if (!serial) {
+        if (n0) { HIPCHK(hipEventRecord(c->span_ev[3], a0)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[3], 0)); }
+        if (n1) {
+            HIPCHK(hipEventRecord(c->span_ev[4], s1)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[4], 0));
+            HIPCHK(hipEventRecord(c->span_ev[5], a1)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[5], 0));
+        }
+    }
+    c->span_reads += n0 + n1;
+    return THJ_OK;
+}
+
+extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db) {
+    if (!c || !tp || !db) { thj_set_error("thj_span_run_async: null argument"); return THJ_EINVAL; }
+    return span_run_common(c, tp, db, nullptr);
+}
+
+extern "C" int thj_span_run_pair_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db0, const thj_span_batch* db1) {
+    if (!c || !tp || !db0 || !db1) { thj_set_error("thj_span_run_pair_async: null argument"); return THJ_EINVAL; }
+    return span_run_common(c, tp, db0, db1);
 }
 
 extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
@@ -1064,37 +1255,33 @@ static int span_download_host(thj_ctx* c, thj_aln* out) {
 }
 
 extern "C" int thj_span_tier_counts(thj_ctx* c, int64_t* counts) {
-    // reads the last thj_span_run_async handed to tier 1 (closure reads), tier 2 (multihit reads), tier 3 (general arrays)
+    // reads the last batch launched handed to the closure kernels (chain entries + thj_k_stitch's list), to tier 2 (multihit reads), to tier 3 (general arrays)
     if (!c || !counts) { thj_set_error("thj_span_tier_counts: bad argument"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_span_state(c);
     if (rc) return rc;
-    unsigned int h[3] = {0, 0, 0};
-    HIPCHK(hipMemcpyAsync(h, &c->d_span_status[4], 12, hipMemcpyDeviceToHost, c->stream));
+    unsigned int h[SPAN_CNT_WORDS] = {};
+    HIPCHK(hipMemcpyAsync(h, &c->d_span_status[16 + SPAN_CNT_WORDS * c->span_last_set], sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    counts[0] = h[0]; counts[1] = h[1]; counts[2] = h[2];
+    counts[0] = h[0]; counts[1] = h[1]; counts[2] = h[2]; counts[3] = h[6];
     return THJ_OK;
 }
 
 extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
-    // avg_ms[4]: thj_k_stitch_contig, thj_k_stitch, thj_k_stitch_pack, thj_k_stitch_generic (one set per thj_span_run_async)
+    // avg_ms[6]: thj_k_stitch_contig, thj_k_join, thj_k_finish, thj_k_stitch, thj_k_stitch_pack, thj_k_stitch_generic / _fusion (one set per batch launched)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    double sum[4] = {0, 0, 0, 0};
-    size_t n = c->span_prof_events.size() / 4;
+    double sum[SPK_N] = {};
+    size_t n = c->span_prof_events.size() / SPK_N;
     for (size_t i = 0; i < c->span_prof_events.size(); ++i) {
         float ms = 0;
         HIPCHK(hipEventElapsedTime(&ms, c->span_prof_events[i].first, c->span_prof_events[i].second));
-        sum[i % 4] += ms;
+        sum[i % SPK_N] += ms;
     }
-    // events are shared between consecutive pairs: return each distinct one to the pool once
-    for (size_t i = 0; i < c->span_prof_events.size(); ++i) {
-        if (i % 4 == 0) c->event_pool.push_back(c->span_prof_events[i].first);
-        c->event_pool.push_back(c->span_prof_events[i].second);
-    }
+    for (auto& pr : c->span_prof_events) { c->event_pool.push_back(pr.first); c->event_pool.push_back(pr.second); }
     if (launches) *launches = (int64_t)n;
-    if (avg_ms) for (int k = 0; k < 4; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
+    if (avg_ms) for (int k = 0; k < SPK_N; ++k) avg_ms[k] = n ? sum[k] / (double)n : 0.0;
     c->span_prof_events.clear();
     c->span_profile = enable != 0;
     return THJ_OK;

@@ -1512,11 +1512,60 @@ THJ_HD bool span_pack_wave(X& x, const Genome& g, const Params& p, const SpanSet
     return status == 2 || (status == 1 && L.punt[lane] != 0);
 }
 
+// ---- chains: tier 0 -> thj_k_join -> thj_k_finish ------------------------------------------------------------------------------
+// The reference separates JOINING a chain of segment hits (merge_chain, long_spanning_reads.cpp:805-2038) from FINISHING the joined
+// hit (check_editdist_consistency + bowtie_sam_extra + print_bamhit, bwt_map.cpp:2349-2648, :1888-2093).  So do the kernels: a
+// read of at most four segments with one hit per segment that tier 0 does not finish -- a spliced or indel read: one of its
+// segment hits is spliced (the junction-db mapping's aM gN bM record) or two of them do not abut -- is handed on as a 32-byte
+// CHAIN ENTRY that names its hits; the join fetches those records (all in flight together, no trip through the CSR row), runs
+// merge_chain on register cigars and writes a compact JOINED HIT (contig, left, <= 8 cigar ops, mismatches); the finish kernel
+// runs over the dense list of joined hits.  One chain of a multihit read travels the same way, with its rank among the read's
+// chains (q of k, ordered by contig and left: the joined hits' BowtieHit::operator< order when those differ).  Reads of more
+// segments, and every read under --fusion-search, take span_read_lean.
+struct alignas(16) ChainEntry { uint32_t read, meta, spare0, spare1; uint32_t hit[4]; };     // hit[s]: segment s's hit, its number in the batch
+// meta: [0..2] segments (1..4) | [4..6] q | [7..9] k - 1 | [10..19] read length
+static constexpr int CHAIN_MAXSEG = 4;
+THJ_HD uint32_t chain_meta(int nsegs, int q, int k, int rl) { return (uint32_t)nsegs | ((uint32_t)q << 4) | ((uint32_t)(k - 1) << 7) | ((uint32_t)rl << 10); }
+THJ_HD int chain_nsegs(uint32_t m) { return (int)(m & 7u); }
+THJ_HD int chain_q(uint32_t m) { return (int)((m >> 4) & 7u); }
+THJ_HD int chain_k(uint32_t m) { return (int)((m >> 7) & 7u) + 1; }
+THJ_HD int chain_rl(uint32_t m) { return (int)((m >> 10) & 1023u); }
+// A joined hit on its way to the finish kernel: two 16-byte words (+ one for cigar ops 4..7).
+// a.x = read (0xFFFFFFFF: nothing joined), a.y = contig, a.z = left, a.w = meta; b = cigar ops 0..3; c = ops 4..7 (n > 4 only)
+// meta: [0..3] n | [4] antisense | [5] antisense splice | [6] the read has one segment | [7..9] q | [10..12] k - 1 | [13..20] mismatches | [21..28] edit distance
+static constexpr uint32_t JOINED_NONE = 0xFFFFFFFFu;
+THJ_HD uint32_t joined_meta(const RAln& r, bool one_seg, int q, int k) {
+    return (uint32_t)r.n | (r.anti ? 16u : 0u) | (r.asplice ? 32u : 0u) | (one_seg ? 64u : 0u) | ((uint32_t)q << 7) | ((uint32_t)(k - 1) << 10) |
+           ((uint32_t)(r.mm & 0xFF) << 13) | ((uint32_t)(r.ed & 0xFF) << 21);
+}
+THJ_HD void joined_unpack(const Q16& a, const Q16& b, const Q16& c, RAln& r, bool& one_seg, int& q, int& k) {
+    r.ref_id = a.y; r.left = (int32_t)a.z;
+    const uint32_t m = a.w;
+    r.n = (int)(m & 15u); r.anti = (m & 16u) ? 1 : 0; r.asplice = (m & 32u) ? 1 : 0; one_seg = (m & 64u) != 0;
+    q = (int)((m >> 7) & 7u); k = (int)((m >> 10) & 7u) + 1;
+    r.mm = (int)((m >> 13) & 0xFFu); r.ed = (int)((m >> 21) & 0xFFu);
+    r.c.v[0] = b.x; r.c.v[1] = b.y; r.c.v[2] = b.z; r.c.v[3] = b.w;
+    const bool more = r.n > 4;
+    r.c.v[4] = more ? c.x : 0u; r.c.v[5] = more ? c.y : 0u; r.c.v[6] = more ? c.z : 0u; r.c.v[7] = more ? c.w : 0u;
+    r.rlen = 0; r.valid = 1;
+}
+// the join of one chain: merge_chain on register cigars (lean_join), valid_hit and the filters of JoinSegmentsWorker (:2810-2813) --
+// everything that decides on the cigar alone.  LJ_OK: `res` goes on to the finish kernel.  `hits[s]`: the chain's hit of segment s.
+template <class Hits>
+THJ_HD int chain_join(const Genome& g, const Params& p, const SpanSets& S, const Hits& hits, uint32_t meta, const u64* rp, int W, RAln& res) {
+    const int jr = lean_join(g, p, S, hits, chain_nsegs(meta), rp, W, chain_rl(meta), res);
+    if (jr != LJ_OK) return jr;
+    if (!valid_hit(p, res)) return LJ_NONE;
+    const int gapl = (res.ed - res.mm) & 0xFF;
+    if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return LJ_NONE;
+    return LJ_OK;
+}
+
 // ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
 // (an unspliced read cut into segments: ~60 % of real data).  merge_chain leaves every pair untouched
 // (dist == 0, :1591), the final concatenation (:1888-1944) fuses the MATCH ops into one, so the joined hit is
 // {leftmost left, [len M], sum of mismatches}.  Returns SPAN_NEED_LEAN when the read is not of that shape.
-enum { SPAN_NEED_LEAN = 4, SPAN_LEAN_CLASSES = 4 };     // NEED_LEAN carries the read's class in bits 8.. of the status
+enum { SPAN_NEED_LEAN = 4, SPAN_LEAN_CLASSES = 4, SPAN_NEED_CHAIN = 6 };     // NEED_LEAN / NEED_CHAIN carry the read's class in bits 8.. of the status
 
 // ---- tier 0 helpers ------------------------------------------------------------------------------------------
 // Where the read's planes come from: global memory (any W), or registers for reads of up to 128 bases (W <= 2), loaded
@@ -1626,6 +1675,134 @@ THJ_HD int contig_finish(const Genome& g, const Params& p, const Src& src, uint3
     return SPAN_OK;
 }
 
+// ---- the finish of a joined hit (thj_k_finish) -----------------------------------------------------------------------------------
+// check_editdist_consistency + bowtie_sam_extra (bwt_map.cpp:2349-2648) + the record, as lean_finish_check / sam_extra do them, for
+// a joined hit that has passed valid_hit and the filters (chain_join): tier 0's finishing path generalised from one MATCH run to
+// the runs of a cigar.  The genome pieces of the first FIN_PRE 64-base pieces of its MATCH ops are fetched together (a read with
+// one junction has two or three), then the ops are walked in order.  `src`: the read's planes (registers for reads of up to 128 bases).
+static constexpr int FIN_PRE = 3;
+template <class Src>
+THJ_HD bool joined_extras(const Genome& g, const Params& p, const RAln& h, bool one_seg, const Src& src, int rl, const uint8_t* qual, Extras& e) {
+    const bool anti = h.anti != 0;
+    bool qrev;
+    if (one_seg) qrev = anti;
+    else qrev = anti ? !src_is_own_revcomp(src, rl) : false;        // merge_chain :1966-1978
+    // pass 1: where the first pieces lie
+    int64_t pr[FIN_PRE]; int ps[FIN_PRE], pl[FIN_PRE];
+#pragma unroll
+    for (int k = 0; k < FIN_PRE; ++k) { pr[k] = h.left; ps[k] = 0; pl[k] = 0; }
+    {
+        int np = 0, pos_seq = 0; int64_t pos_ref = h.left;
+#pragma unroll
+        for (int i = 0; i < LEAN_C; ++i) {
+            if (i < h.n) {
+                const int op = cig_op(h.c.v[i]), len = (int)cig_len(h.c.v[i]);
+                if (op == OP_MATCH) {
+#pragma unroll
+                    for (int c = 0; c < FIN_PRE; ++c) {              // an op's first FIN_PRE pieces (the table has no room for more anyway)
+                        const int off = 64 * c;
+                        int l = len - off < 64 ? len - off : 64;
+                        if (pos_seq + off + l > rl) l = rl - pos_seq - off;
+                        if (off < len && l > 0) {
+#pragma unroll
+                            for (int k = 0; k < FIN_PRE; ++k) if (np == k) { pr[k] = pos_ref + off; ps[k] = pos_seq + off; pl[k] = l; }
+                            ++np;
+                        }
+                    }
+                    pos_seq += len; pos_ref += len;
+                } else if (op == OP_INS) pos_seq += len;
+                else if (op == OP_DEL || op == OP_REF_SKIP) pos_ref += len;
+            }
+        }
+    }
+    Planes gp[FIN_PRE], sp[FIN_PRE];
+#pragma unroll
+    for (int k = 0; k < FIN_PRE; ++k) {
+        gp[k] = g_fetch(g, h.ref_id, pr[k]);                         // unconditional: an unused entry reads the alignment's first piece again
+        const int l = pl[k] > 0 ? pl[k] : 1;
+        sp[k] = anti ? rc_piece(src.fetch(rl - ps[k] - l, l), l) : src.fetch(ps[k], l);
+    }
+    // pass 2: bowtie_sam_extra over the ops
+    ContigAcc a;
+    md_init(a.md);
+    a.mismatch = a.both_n = a.AS = a.pos_mm = 0;
+    int opens = 0, conts = 0, piece = 0, pos_seq = 0;
+    int64_t pos_ref = h.left;
+#pragma unroll
+    for (int i = 0; i < LEAN_C; ++i) {
+        if (i < h.n) {
+            const int op = cig_op(h.c.v[i]), len = (int)cig_len(h.c.v[i]);
+            if (op == OP_MATCH) {
+                for (int off = 0; off < len; off += 64) {
+                    int l = len - off < 64 ? len - off : 64;
+                    if (pos_seq + off + l > rl) l = rl - pos_seq - off;
+                    if (l <= 0) break;
+                    Planes r, sq;
+                    if (piece < FIN_PRE && off < 64 * FIN_PRE) {
+                        r = gp[0]; sq = sp[0];
+#pragma unroll
+                        for (int k = 1; k < FIN_PRE; ++k) if (piece == k) { r = gp[k]; sq = sp[k]; }
+                    } else {
+                        r = g_fetch(g, h.ref_id, pos_ref + off);
+                        sq = anti ? rc_piece(src.fetch(rl - (pos_seq + off) - l, l), l) : src.fetch(pos_seq + off, l);
+                    }
+                    ++piece;
+                    contig_piece(p, r, sq, l, pos_seq + off, qual, qrev, rl, a);
+                }
+                pos_seq += len; pos_ref += len;
+            } else if (op == OP_INS) {
+                pos_seq += len;
+                a.AS -= p.bowtie2_read_gap_open + p.bowtie2_read_gap_cont * len;
+                ++opens; conts += len;
+            } else if (op == OP_DEL) {
+                a.AS -= p.bowtie2_ref_gap_open + p.bowtie2_ref_gap_cont * len;
+                ++opens; conts += len;
+                md_put_int_char(a.md, a.pos_mm, '^');
+                const Planes r = g_fetch(g, h.ref_id, pos_ref);
+                for (int k = 0; k < len && k < 64; ++k) md_push(a.md, "ACGTN"[plane_code(r, k)]);
+                pos_ref += len; a.pos_mm = 0;
+            } else if (op == OP_REF_SKIP) pos_ref += len;
+        }
+    }
+    md_put_int(a.md, a.pos_mm);
+    e.md = a.md; e.AS = a.AS; e.XM = a.mismatch; e.XO = opens; e.XG = conts; e.both_n = a.both_n;
+    // check_editdist_consistency (inside merge_chain in the reference) shares the pass's counts
+    if (!one_seg && !(e.XM == h.mm || e.XM + e.both_n == h.mm)) return false;
+    return true;
+}
+
+// one joined hit (its packed words) -> filters' last part, tags, the record with rank `order` among the read's records; false: not reported
+template <class Sink>
+THJ_HD bool joined_finish(const Genome& g, const Params& p, const Q16& ja, const Q16& jb, const Q16& jc, const u64* planes, int W,
+                          const uint16_t* read_len, const uint8_t* quals, int qual_stride, int order, Sink& sink) {
+    RAln res; bool one_seg; int q, k;
+    joined_unpack(ja, jb, jc, res, one_seg, q, k);
+    const uint32_t r = ja.x;
+    const u64* rp = planes + (u64)r * (uint32_t)(3 * W);
+    const int rl = (int)read_len[r];
+    const uint8_t* qual = quals + (u64)r * (uint32_t)qual_stride;
+    Extras e;
+    bool ok;
+    if (W <= 2) {
+        RegRead rw;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) rw.v[i] = 0;
+        if (W == 2) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) rw.v[i] = rp[i];
+        } else { rw.v[0] = rp[0]; rw.v[2] = rp[1]; rw.v[4] = rp[2]; }
+        ok = joined_extras(g, p, res, one_seg, rw, rl, qual, e);
+    } else ok = joined_extras(g, p, res, one_seg, MemRead{rp, W}, rl, qual, e);
+    if (!ok) return false;
+    emit_aln(sink, r, order, res, e);
+    return true;
+}
+THJ_HD void joined_pack(const RAln& res, uint32_t read, bool one_seg, int q, int k, Q16& ja, Q16& jb, Q16& jc) {
+    ja.x = read; ja.y = res.ref_id; ja.z = (uint32_t)res.left; ja.w = joined_meta(res, one_seg, q, k);
+    jb.x = res.c.v[0]; jb.y = res.c.v[1]; jb.z = res.c.v[2]; jb.w = res.c.v[3];
+    jc.x = res.c.v[4]; jc.y = res.c.v[5]; jc.z = res.c.v[6]; jc.w = res.c.v[7];
+}
+
 // the read's segment offsets, fetched in one go (the kernel does this one read ahead)
 template <int MS>
 THJ_HD void contig_offsets(const uint32_t* so, int nseg, uint32_t (&sv)[MS + 1]) {
@@ -1635,7 +1812,7 @@ THJ_HD void contig_offsets(const uint32_t* so, int nseg, uint32_t (&sv)[MS + 1])
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t (&sv)[MS + 1], int nseg,
                                 const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink,
-                                const SpanHitHead* gheads = nullptr) {
+                                const SpanHitHead* gheads = nullptr, ChainEntry* ent = nullptr, bool chains = true) {
     // Memory round trips, not arithmetic, bound this tier: the read's planes (when they fit six registers) and the
     // segment offsets are fetched in one go, then every hit head in one go, and only then is anything decided.
     RegRead rw;
@@ -1683,11 +1860,10 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
     }
     const SpanHitHead h0 = hh[0];
     const bool anti = (h0.meta & SH_ANTI) != 0;
-    if ((h0.meta >> 24) != 1u || cig_op(h0.cigar0) != OP_MATCH) return SPAN_NEED_LEAN;
+    bool lean = (h0.meta >> 24) != 1u || cig_op(h0.cigar0) != OP_MATCH;     // (class 0)
     int total = (int)cig_len(h0.cigar0);
     int mm = (int)((h0.meta >> 8) & 0xFF);
     int left = h0.left, edge = anti ? h0.left : h0.left + total;       // where the next segment must abut
-    bool lean = false;
     int gap_at = 0;                                   // first segment that does not abut its predecessor (0: none / other reason)
 #pragma unroll
     for (int s = 1; s < MS; ++s) {
@@ -1706,7 +1882,17 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
     }
     // the class of a handed-down read = the step of lean_join's chain loop that will meet its (first) gap: tier 1 walks its
     // work list class by class, so that the lanes of a wave run the closure code in the same iteration
-    if (lean) return SPAN_NEED_LEAN | ((gap_at ? (anti ? nsegs - gap_at : gap_at) & (SPAN_LEAN_CLASSES - 1) : 0) << 8);
+    if (lean) {
+        const int cls = gap_at ? (anti ? nsegs - gap_at : gap_at) & (SPAN_LEAN_CLASSES - 1) : 0;
+        // a read of at most CHAIN_MAXSEG segments travels as a chain entry (its hits are consecutive records)
+        if (ent != nullptr && chains && nsegs <= CHAIN_MAXSEG && !p.fusion_search) {
+            ent->read = read_idx; ent->meta = chain_meta(nsegs, 0, 1, rl); ent->spare0 = ent->spare1 = 0;
+#pragma unroll
+            for (int s = 0; s < CHAIN_MAXSEG; ++s) ent->hit[s] = sv[0] + (uint32_t)(s < nsegs ? s : 0);
+            return SPAN_NEED_CHAIN | (cls << 8);
+        }
+        return SPAN_NEED_LEAN | (cls << 8);
+    }
     if (THJ_EXPF(16)) return SPAN_OK;
     const int mm8 = mm & 0xFF;                       // BowtieHit keeps mismatches / edit_dist in unsigned chars
     if (mm8 > p.read_mismatches || mm8 > p.read_edit_dist) return SPAN_OK;          // :2810-2813 (gap length 0)
@@ -1716,10 +1902,10 @@ THJ_HD int span_read_contig_pre(const Genome& g, const Params& p, const SpanHit*
 }
 template <int MS = SPAN_MAXSEG, class Sink>
 THJ_HD int span_read_contig(const Genome& g, const Params& p, const SpanHit* hits, const uint32_t* so, int nseg,
-                            const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink) {
+                            const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink, ChainEntry* ent = nullptr) {
     uint32_t sv[MS + 1];
     contig_offsets<MS>(so, nseg, sv);
-    return span_read_contig_pre<MS>(g, p, hits, sv, nseg, rp, W, rl, qual, read_idx, sink);
+    return span_read_contig_pre<MS>(g, p, hits, sv, nseg, rp, W, rl, qual, read_idx, sink, nullptr, ent);
 }
 
 }  // namespace thj

@@ -673,20 +673,36 @@ def _span_methods():
                 md_resolver = span_md_resolver(self.host_seqs, hb, self.lib)
         return alns_from_array(a, md_resolver)
 
+    def span_run_pair(self, p: Params, batch0, batch1):
+        """two batches (the two sides of a pass) beside each other: thj_span_run_pair_async"""
+        cp = p.as_ctypes()
+        a0 = C.byref(batch0) if isinstance(batch0, CSpanBatch) else batch0
+        a1 = C.byref(batch1) if isinstance(batch1, CSpanBatch) else batch1
+        _check(self.lib, self.lib.thj_span_run_pair_async(self._ctx, C.byref(cp), a0, a1), "thj_span_run_pair_async")
+
     def span_tier_counts(self):
-        c = (C.c_int64 * 3)()
+        """of the batch launched last: reads to the closure kernels, to the multihit kernel, on to the general kernel"""
+        c = (C.c_int64 * 4)()
         _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
         return int(c[0]), int(c[1]), int(c[2])
 
+    def span_chain_count(self):
+        """of the batch launched last: the reads that travelled as chain entries (tier 0 -> thj_k_join -> thj_k_finish)"""
+        c = (C.c_int64 * 4)()
+        _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
+        return int(c[3])
+
+    Context.SPAN_KERNELS = ("thj_k_stitch_contig", "thj_k_join", "thj_k_finish", "thj_k_stitch", "thj_k_stitch_pack", "thj_k_stitch_generic")
+
     def profile_span(self, enable: bool = True):
-        """-> ([ms contig, ms lean, ms multihit, ms generic], launches)"""
-        ms = (C.c_double * 4)()
+        """-> ([ms per launch of each entry of SPAN_KERNELS], launches)"""
+        ms = (C.c_double * 6)()
         n = C.c_int64()
         _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, ms, C.byref(n)), "thj_profile_span")
-        return [ms[0], ms[1], ms[2], ms[3]], n.value
+        return list(ms), n.value
 
     for f in (upload_span_fusions, upload_span_sets, span_sets_from_segjuncs, span_fusions_from_segjuncs, fusion_search, upload_span_batch, span_reset, span_run, span_finish,
-              span_download, spanning, profile_span, span_tier_counts, span_hit_heads):
+              span_download, spanning, profile_span, span_tier_counts, span_hit_heads, span_run_pair, span_chain_count):
         setattr(Context, f.__name__, f)
 
 
@@ -699,7 +715,7 @@ ABI_SYMBOLS += ["thj_md_string"]
 ABI_SYMBOLS += ["thj_microexon_reset_async", "thj_microexon_collect", "thj_microexon_candidates", "thj_microexon_run"]
 ABI_SYMBOLS += ["thj_butterfly_run", "thj_covsearch_add_reads_bam", "thj_covsearch_reserve_reads"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_fusions_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
-                "thj_span_reset_async", "thj_span_run_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
+                "thj_span_reset_async", "thj_span_run_async", "thj_span_run_pair_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
 
 
