@@ -220,6 +220,8 @@ struct VecSink {
 
 static int64_t g_wave_reads = 0;            // reads the packed tier finished since the last call of hostsim_wave_reads
 extern "C" int64_t hostsim_wave_reads() { const int64_t n = g_wave_reads; g_wave_reads = 0; return n; }
+static int64_t g_chain_deferred = 0;        // ... of them, the ones whose join searched a closure
+extern "C" int64_t hostsim_chain_deferred() { const int64_t n = g_chain_deferred; g_chain_deferred = 0; return n; }
 static int64_t g_chain_reads = 0;           // reads that travelled as chain entries (tier 0 -> join -> finish) since the last call
 extern "C" int64_t hostsim_chain_reads() { const int64_t n = g_chain_reads; g_chain_reads = 0; return n; }
 // the wave operations span_pack_wave is written against, over simt.h's fibers (one wave = 64 fibers)
@@ -310,7 +312,9 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
                 RAln res;
                 SpanHit ch[CHAIN_MAXSEG];
                 for (int s = 0; s < CHAIN_MAXSEG; ++s) ch[s] = ((const SpanHit*)hits)[ent.hit[s]];
-                int jr = chain_join(g, p, S, ch, ent.meta, (const u64*)planes + (int64_t)ent.read * 3 * W, W, res);
+                // as thj_k_join runs it: the abutting chains' pass first, the closure search only for what that pass defers
+                int jr = chain_join<true>(g, p, S, ch, ent.meta, (const u64*)planes + (int64_t)ent.read * 3 * W, W, res);
+                if (jr == LJ_DEFER) { jr = chain_join<false>(g, p, S, ch, ent.meta, (const u64*)planes + (int64_t)ent.read * 3 * W, W, res); ++g_chain_deferred; }
                 if (jr == LJ_PUNT) { gen.push_back((uint32_t)r); continue; }       // more cigar ops than LEAN_C: thj_k_join hands the read to the general tier
                 if (jr == LJ_OK) {
                     Q16 ja, jb, jc;

@@ -55,6 +55,10 @@ def test_span_logic_matches_oracle(cfg):
         sim.lib().hostsim_chain_reads()
         got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)
         chains = sim.lib().hostsim_chain_reads()
+        deferred = sim.lib().hostsim_chain_deferred()
+        assert 0 < deferred <= chains or chains == 0, (chains, deferred)
+        if cfg["seed"] == 2 and chains:
+            assert deferred < chains                                 # both passes of the join see reads
         assert (chains > 0) == (mode in (0, 3) and cfg["read_len"] // cfg["seg_len"] <= 4), (mode, chains)
         assert status[1] == 0 and status[2] == 0
         # records of one read are emitted together; across reads the device orders by read index afterwards

@@ -112,7 +112,6 @@ struct Tiers {
     // null: every one-hit-per-segment read takes wl_lean.  The joined hits, densely: ja / jb / jc[i] for entry i of the concatenation
     ChainEntry* ent; unsigned int* blk_chain;
     Q16* ja; Q16* jb; Q16* jc;
-    unsigned int* n_joined;          // entries thj_k_join went over (what thj_k_finish goes over)
 };
 __device__ __forceinline__ bool defer_huge(const Tiers& t, uint32_t r) {
     if (!t.huge_list) return false;
@@ -318,55 +317,116 @@ struct LdsChainHits {       // word pair (2 s, 2 s + 1) of column `col` = the re
         return h;
     }
 };
-__global__ __launch_bounds__(256, 4) void thj_k_join(Genome g, Params p, SpanSets S, const SpanHit* hits, const u64* planes, int W, Tiers t, int G) {
-    __shared__ unsigned int s_off[SPAN_LEAN_CLASSES * MAX_SLICES + 1];
+// (Work distribution: workgroup b takes the entries tier 0's workgroup b wrote -- its four class slices one after the other -- and
+// writes their joined hits to J[b * chunk ..): no table of slice offsets, no search per entry; thj_k_finish walks the same way.)
+struct ChainLists { const ChainEntry* ent; const unsigned int* blk_cnt; int G, chunk; Q16* ja; Q16* jb; Q16* jc; };
+__device__ __forceinline__ unsigned int chain_block_counts(const ChainLists& L, int blk, unsigned int (&c)[SPAN_LEAN_CLASSES]) {
+    unsigned int total = 0;
+#pragma unroll
+    for (int k = 0; k < SPAN_LEAN_CLASSES; ++k) { c[k] = L.blk_cnt[k * L.G + blk]; total += c[k]; }
+    return total;
+}
+// Two passes per workgroup.  Most chains of a sample mapped against a junction database abut everywhere -- the spliced read's
+// junction sits INSIDE a segment hit (aM gN bM) and merge_chain only concatenates -- and need nothing but their records; a chain
+// with a gap between two hits (a junction at a segment boundary, an indel) needs the closure search: dependent loads of junction
+// keys, genome and read words that a wave pays for as a whole even when one lane takes them (one lane in twenty does: nearly every
+// wave would).  So the first pass joins the abutting chains (lean_join<ABUT>: the closure code is not in it) and queues the others
+// in LDS; whenever 256 are queued, and at the end, the workgroup runs the full join over the queue with its lanes dense.
+template <bool ABUT>
+__device__ __forceinline__ int join_entry(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, const u64* planes, int W,
+                                          const ChainLists& L, const Tiers& t, Q16* s_rec, u64 cls_blk_base, unsigned int local, u64 at) {
+    const Q16* src = (const Q16*)(L.ent + cls_blk_base + local);
+    const Q16 e0 = src[0], e1 = src[1];
+    const uint32_t r = e0.x, meta = e0.y;
+    {
+        Q16 rec[2 * CHAIN_MAXSEG];
+        const uint32_t hi[CHAIN_MAXSEG] = {e1.x, e1.y, e1.z, e1.w};
+#pragma unroll
+        for (int k = 0; k < CHAIN_MAXSEG; ++k) { const Q16* hp = (const Q16*)(hits + hi[k]); rec[2 * k] = hp[0]; rec[2 * k + 1] = hp[1]; }
+#pragma unroll
+        for (int k = 0; k < 2 * CHAIN_MAXSEG; ++k) s_rec[k * 256 + threadIdx.x] = rec[k];
+    }
+    const LdsChainHits ch{s_rec + threadIdx.x};
+    RAln res;
+    const int jr = chain_join<ABUT>(g, p, S, ch, meta, planes + (u64)r * (uint32_t)(3 * W), W, res);
+    if (ABUT && jr == LJ_DEFER) return jr;
+    Q16 ja, jb, jc;
+    joined_pack(res, r, chain_nsegs(meta) == 1, chain_q(meta), chain_k(meta), ja, jb, jc);
+    if (jr != LJ_OK) ja.x = JOINED_NONE;
+    L.ja[at] = ja;
+    if (jr == LJ_OK) { L.jb[at] = jb; if (res.n > 4) L.jc[at] = jc; }
+    if (jr == LJ_PUNT) {               // rare: the general tier takes the read (its slice of that list is its tier-0 block's)
+        const uint32_t gb = r / (uint32_t)t.chunk;
+        t.wl_gen[(u64)gb * (uint32_t)t.chunk + atomicAdd(&t.blk_gen[gb], 1u)] = r;
+        atomicAdd(&t.counters[2], 1u);
+    }
+    return jr;
+}
+__device__ __forceinline__ void chain_locate(const unsigned int (&c)[SPAN_LEAN_CLASSES], const ChainLists& L, int blk, unsigned int i, u64& base, unsigned int& local) {
+    unsigned int cls = 0;
+    local = i;
+#pragma unroll
+    for (int k = 0; k < SPAN_LEAN_CLASSES - 1; ++k) { const bool next = cls == (unsigned int)k && local >= c[k]; local -= next ? c[k] : 0u; cls += next ? 1u : 0u; }
+    base = (u64)(cls * (unsigned int)L.G + (unsigned int)blk) * (unsigned int)L.chunk;
+}
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void thj_k_join(Genome g, Params p, SpanSets S, const SpanHit* hits, const u64* planes, int W, ChainLists L, Tiers t) {
     __shared__ Q16 s_rec[2 * CHAIN_MAXSEG * 256];
-    const unsigned int total = slice_offsets<256, SPAN_LEAN_CLASSES * MAX_SLICES>(t.blk_chain, SPAN_LEAN_CLASSES * G, s_off);
-    if (blockIdx.x == 0 && threadIdx.x == 0) *t.n_joined = total;
-    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const int sl = slice_of(s_off, SPAN_LEAN_CLASSES * G, i);
-        const Q16* src = (const Q16*)(t.ent + (u64)sl * (uint32_t)t.chunk + (i - s_off[sl]));
-        const Q16 e0 = src[0], e1 = src[1];
-        const uint32_t r = e0.x, meta = e0.y;
-        {
-            Q16 rec[2 * CHAIN_MAXSEG];
-            const uint32_t hi[CHAIN_MAXSEG] = {e1.x, e1.y, e1.z, e1.w};
-#pragma unroll
-            for (int k = 0; k < CHAIN_MAXSEG; ++k) { const Q16* hp = (const Q16*)(hits + hi[k]); rec[2 * k] = hp[0]; rec[2 * k + 1] = hp[1]; }
-#pragma unroll
-            for (int k = 0; k < 2 * CHAIN_MAXSEG; ++k) s_rec[k * 256 + threadIdx.x] = rec[k];
-        }
-        const LdsChainHits ch{s_rec + threadIdx.x};
-        RAln res;
-        const int jr = chain_join(g, p, S, ch, meta, planes + (u64)r * (uint32_t)(3 * W), W, res);
-        Q16 ja, jb, jc;
-        joined_pack(res, r, chain_nsegs(meta) == 1, chain_q(meta), chain_k(meta), ja, jb, jc);
-        if (jr != LJ_OK) ja.x = JOINED_NONE;
-        t.ja[i] = ja;
-        if (jr == LJ_OK) { t.jb[i] = jb; if (res.n > 4) t.jc[i] = jc; }
-        if (jr == LJ_PUNT) {               // rare: the general tier takes the read (its slice of that list is its tier-0 block's)
-            const uint32_t blk = r / (uint32_t)t.chunk;
-            t.wl_gen[(u64)blk * (uint32_t)t.chunk + atomicAdd(&t.blk_gen[blk], 1u)] = r;
-            atomicAdd(&t.counters[2], 1u);
+    __shared__ unsigned int s_q[512];
+    __shared__ unsigned int s_qn;
+    if (threadIdx.x == 0) s_qn = 0;
+    __syncthreads();
+    for (int blk = blockIdx.x; blk < L.G; blk += gridDim.x) {
+        unsigned int c[SPAN_LEAN_CLASSES];
+        const unsigned int total = chain_block_counts(L, blk, c);
+        const unsigned int rounds = (total + 255u) / 256u;
+        for (unsigned int round = 0; round <= rounds; ++round) {            // the last round only drains the queue
+            const unsigned int i = round * 256u + threadIdx.x;
+            if (i < total) {
+                u64 base; unsigned int local;
+                chain_locate(c, L, blk, i, base, local);
+                const int jr = join_entry<true>(g, p, S, hits, planes, W, L, t, s_rec, base, local, (u64)blk * (uint32_t)L.chunk + i);
+                if (jr == LJ_DEFER) s_q[atomicAdd(&s_qn, 1u)] = i;          // room: fewer than 256 left over + at most 256 new
+            }
+            __syncthreads();
+            unsigned int qn = s_qn;
+            while (qn >= 256u || (round == rounds && qn > 0u)) {
+                const unsigned int take = qn < 256u ? qn : 256u, first = qn - take;
+                if (threadIdx.x < take) {
+                    const unsigned int j = s_q[first + threadIdx.x];
+                    u64 base; unsigned int local;
+                    chain_locate(c, L, blk, j, base, local);
+                    join_entry<false>(g, p, S, hits, planes, W, L, t, s_rec, base, local, (u64)blk * (uint32_t)L.chunk + j);
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) s_qn = first;
+                __syncthreads();
+                qn = first;
+            }
         }
     }
 }
 
 // The finish of the joined hits (check_editdist_consistency, bowtie_sam_extra, the record: bwt_map.cpp:2349-2648, :1888-2093): a
-// thread per joined hit over the dense list thj_k_join wrote.
-__global__ __launch_bounds__(256, 4) void thj_k_finish(Genome g, Params p, DevSpanBatch b, RecSink sink, Tiers t) {
+// thread per joined hit, workgroup b over the joined hits of thj_k_join's workgroup b.
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void thj_k_finish(Genome g, Params p, DevSpanBatch b, RecSink sink, ChainLists L) {
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
     __syncthreads();
-    const unsigned int total = *t.n_joined;
-    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        const Q16 ja = t.ja[i];
-        if (ja.x == JOINED_NONE) continue;
-        const Q16 jb = t.jb[i];
-        Q16 jc{0, 0, 0, 0};
-        if ((ja.w & 15u) > 4u) jc = t.jc[i];
-        joined_finish(g, p, ja, jb, jc, b.planes, b.W, b.read_len, b.quals, b.qual_stride, 0, sink);
-        sink.done(ja.x);
+    for (int blk = blockIdx.x; blk < L.G; blk += gridDim.x) {
+        unsigned int c[SPAN_LEAN_CLASSES];
+        const unsigned int total = chain_block_counts(L, blk, c);
+        for (unsigned int i = threadIdx.x; i < total; i += 256) {
+            const u64 at = (u64)blk * (uint32_t)L.chunk + i;
+            const Q16 ja = L.ja[at];
+            if (ja.x == JOINED_NONE) continue;
+            const Q16 jb = L.jb[at];
+            Q16 jc{0, 0, 0, 0};
+            if ((ja.w & 15u) > 4u) jc = L.jc[at];
+            joined_finish(g, p, ja, jb, jc, b.planes, b.W, b.read_len, b.quals, b.qual_stride, 0, sink);
+            sink.done(ja.x);
+        }
     }
     if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
     __syncthreads();
@@ -851,7 +911,7 @@ static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int6
         ss.worklist_cap = wl_need;
     }
     if (chains) {
-        const int64_t ent_need = NC * G * chunk, j_need = n_reads;
+        const int64_t ent_need = NC * G * chunk, j_need = G * chunk;
         if (ss.ent_cap < ent_need) {
             HIPCHK(hipDeviceSynchronize());
             hipFree(ss.d_ent); ss.d_ent = nullptr; ss.ent_cap = 0;
@@ -914,7 +974,6 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     t.huge_list = c->d_huge_list; t.huge_cnt = t.counters + 4; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
     t.ent = chains ? (ChainEntry*)ss.d_ent : nullptr;
     t.ja = (Q16*)ss.d_joined; t.jb = t.ja ? t.ja + ss.joined_cap : nullptr; t.jc = t.ja ? t.ja + 2 * ss.joined_cap : nullptr;
-    t.n_joined = t.counters + 5;
     HIPCHK(hipMemsetAsync(t.counters, 0, SPAN_CNT_WORDS * 4, sm));
     HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, sm));      // tiers 0 / 1 write the others
     c->span_last_set = set;
@@ -933,11 +992,16 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     if (chains) {
         if (sa != sm) { HIPCHK(hipEventRecord(ev_fork, sm)); HIPCHK(hipStreamWaitEvent(sa, ev_fork, 0)); }
         SPK_BEGIN(SPK_JOIN, sa);
-        hipLaunchKernelGGL(thj_k_join, dim3((unsigned)G), dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, t, (int)G);
+        const ChainLists cl{t.ent, t.blk_chain, (int)G, (int)chunk, t.ja, t.jb, t.jc};
+        // THJ_JOIN_WPE / THJ_FIN_WPE = 3: developer switches -- three workgroups' worth of registers per CU (168 VGPRs) instead of four (128)
+        static const int join_wpe = getenv("THJ_JOIN_WPE") ? atoi(getenv("THJ_JOIN_WPE")) : 4, fin_wpe = getenv("THJ_FIN_WPE") ? atoi(getenv("THJ_FIN_WPE")) : 4;
+        if (join_wpe == 3) hipLaunchKernelGGL(thj_k_join<3>, dim3((unsigned)G), dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t);
+        else hipLaunchKernelGGL(thj_k_join<4>, dim3((unsigned)G), dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t);
         if (sa != sm) HIPCHK(hipEventRecord(ev_joined, sa));
         SPK_END(SPK_JOIN, sa);
         SPK_BEGIN(SPK_FINISH, sa);
-        hipLaunchKernelGGL(thj_k_finish, dim3((unsigned)G), dim3(256), 0, sa, g, p, b, sink, t);
+        if (fin_wpe == 3) hipLaunchKernelGGL(thj_k_finish<3>, dim3((unsigned)G), dim3(256), 0, sa, g, p, b, sink, cl);
+        else hipLaunchKernelGGL(thj_k_finish<4>, dim3((unsigned)G), dim3(256), 0, sa, g, p, b, sink, cl);
         SPK_END(SPK_FINISH, sa);
     } else { SPK_BEGIN(SPK_JOIN, sm); SPK_END(SPK_JOIN, sm); SPK_BEGIN(SPK_FINISH, sm); SPK_END(SPK_FINISH, sm); }
     const int64_t g1 = G, g2 = G;

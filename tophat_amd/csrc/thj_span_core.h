@@ -858,10 +858,13 @@ struct StagedHits {         // the chain under construction: segment s's hit is 
 
 // ---- lean machinery shared by tiers 1 and 2 -----------------------------------------------------------------
 // lean_join: ONE chain -- hits[s] is the hit chosen for segment s -- through merge_chain on register cigars.
-enum { LJ_NONE = 0, LJ_OK = 1, LJ_PUNT = 2, LJ_INCOMPAT = 3 };   // no alignment / `res` holds the joined hit / needs more cigar ops than LEAN_C /
+enum { LJ_NONE = 0, LJ_OK = 1, LJ_PUNT = 2, LJ_INCOMPAT = 3, LJ_DEFER = 4 };   // no alignment / `res` holds the joined hit / needs more cigar ops than LEAN_C /
                                                                   // no alignment because two neighbours are not compatible the plain way (with fusion search on
                                                                   // such a chain takes a fusion direction; every other failure is the same failure there)
-template <class Hits>      // Hits: `hits[s]` is the hit chosen for segment s (a plain array, or StagedHits)
+// ABUT: the caller wants only the chains whose neighbours all abut (dist == 0 for every pair: merge_chain leaves each pair as it is,
+// :1591, and never looks at a junction, an insertion or the genome) -- any other chain returns LJ_DEFER untouched, and the code that
+// searches closures is not even instantiated.  thj_k_join runs its entries this way first and the deferred ones, compacted, afterwards.
+template <bool ABUT = false, class Hits>      // Hits: `hits[s]` is the hit chosen for segment s (a plain array, or StagedHits)
 THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const Hits& hits, int nsegs,
                      const u64* rp, int W, int rl, RAln& res) {
     const int L = p.segment_length;
@@ -882,6 +885,7 @@ THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const 
                 if (prev.ref_id != cand.ref_id || prev.anti != cand.anti) return LJ_INCOMPAT;
                 int dist = prev.anti ? prev.left - cand_right : cand.left - prev_right;
                 if (dist > p.max_report_intron || dist < -p.max_insertion_length) return LJ_INCOMPAT;
+                if (ABUT && dist != 0) return LJ_DEFER;
                 if (gap_is_fusion_like(p, dist)) ++num_fusions;          // merge_chain pre-check (:843-891): same gaps, chain order
                 old_read_length += rc_read_span(cand.c, cand.n);
                 prev.ref_id = cand.ref_id; prev.anti = cand.anti; prev.left = cand.left; prev_right = cand_right;
@@ -907,8 +911,10 @@ THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const 
             const bool psp = rc_spliced(prev.c, prev.n), csp = rc_spliced(curr.c, curr.n);
             if (psp && csp && prev.asplice != curr.asplice) return LJ_NONE;                                  // :936-943
             if (prev.ref_id != curr.ref_id) return LJ_NONE;
-            const Closure cl = closure_search(g, p, S, sv, P, prev.ref_id, prev.left + rc_ref_span(prev.c, prev.n), (int)cig_len(plast),
-                                              curr.left, (int)cig_len(cfirst), prev.anti == curr.anti);
+            Closure cl;
+            if (ABUT) { cl.kind = CL_KEEP; cl.itpr = cl.ilen = cl.dtl = cl.skip = cl.janti = cl.mismatch = 0; }      // dist == 0, one strand (pre-check)
+            else cl = closure_search(g, p, S, sv, P, prev.ref_id, prev.left + rc_ref_span(prev.c, prev.n), (int)cig_len(plast),
+                                     curr.left, (int)cig_len(cfirst), prev.anti == curr.anti);
             if (cl.kind == CL_FAIL) return LJ_NONE;
             P += curr.rlen;
             if (cl.kind == CL_KEEP) {
@@ -917,6 +923,7 @@ THJ_HD int lean_join(const Genome& g, const Params& p, const SpanSets& S, const 
                 prev = curr;
                 continue;
             }
+            if (ABUT) continue;                 // (never reached: every pair is kept)
             if (prev.n + 1 + curr.n > LEAN_C) return LJ_PUNT;
             int anti_closure = psp ? prev.asplice : curr.asplice;
             int nn = prev.n, first;
@@ -1551,9 +1558,9 @@ THJ_HD void joined_unpack(const Q16& a, const Q16& b, const Q16& c, RAln& r, boo
 }
 // the join of one chain: merge_chain on register cigars (lean_join), valid_hit and the filters of JoinSegmentsWorker (:2810-2813) --
 // everything that decides on the cigar alone.  LJ_OK: `res` goes on to the finish kernel.  `hits[s]`: the chain's hit of segment s.
-template <class Hits>
+template <bool ABUT = false, class Hits>
 THJ_HD int chain_join(const Genome& g, const Params& p, const SpanSets& S, const Hits& hits, uint32_t meta, const u64* rp, int W, RAln& res) {
-    const int jr = lean_join(g, p, S, hits, chain_nsegs(meta), rp, W, chain_rl(meta), res);
+    const int jr = lean_join<ABUT>(g, p, S, hits, chain_nsegs(meta), rp, W, chain_rl(meta), res);
     if (jr != LJ_OK) return jr;
     if (!valid_hit(p, res)) return LJ_NONE;
     const int gapl = (res.ed - res.mm) & 0xFF;
@@ -1687,82 +1694,63 @@ THJ_HD bool joined_extras(const Genome& g, const Params& p, const RAln& h, bool 
     bool qrev;
     if (one_seg) qrev = anti;
     else qrev = anti ? !src_is_own_revcomp(src, rl) : false;        // merge_chain :1966-1978
-    // pass 1: where the first pieces lie
-    int64_t pr[FIN_PRE]; int ps[FIN_PRE], pl[FIN_PRE];
-#pragma unroll
-    for (int k = 0; k < FIN_PRE; ++k) { pr[k] = h.left; ps[k] = 0; pl[k] = 0; }
+    // pass 1: where the first FIN_PRE pieces lie (a plain loop over the ops: code size matters more here than a select per op)
+    int64_t pr0 = h.left, pr1 = h.left, pr2 = h.left;
     {
         int np = 0, pos_seq = 0; int64_t pos_ref = h.left;
-#pragma unroll
-        for (int i = 0; i < LEAN_C; ++i) {
-            if (i < h.n) {
-                const int op = cig_op(h.c.v[i]), len = (int)cig_len(h.c.v[i]);
-                if (op == OP_MATCH) {
-#pragma unroll
-                    for (int c = 0; c < FIN_PRE; ++c) {              // an op's first FIN_PRE pieces (the table has no room for more anyway)
-                        const int off = 64 * c;
-                        int l = len - off < 64 ? len - off : 64;
-                        if (pos_seq + off + l > rl) l = rl - pos_seq - off;
-                        if (off < len && l > 0) {
-#pragma unroll
-                            for (int k = 0; k < FIN_PRE; ++k) if (np == k) { pr[k] = pos_ref + off; ps[k] = pos_seq + off; pl[k] = l; }
-                            ++np;
-                        }
-                    }
-                    pos_seq += len; pos_ref += len;
-                } else if (op == OP_INS) pos_seq += len;
-                else if (op == OP_DEL || op == OP_REF_SKIP) pos_ref += len;
-            }
+        for (int i = 0; i < h.n && np < FIN_PRE; ++i) {
+            const uint32_t ci = h.c.get(i);
+            const int op = cig_op(ci), len = (int)cig_len(ci);
+            if (op == OP_MATCH) {
+                for (int off = 0; off < len && np < FIN_PRE; off += 64) {
+                    if (pos_seq + off >= rl) break;                  // (pass 2 leaves the op there too)
+                    pr0 = np == 0 ? pos_ref + off : pr0; pr1 = np == 1 ? pos_ref + off : pr1; pr2 = np == 2 ? pos_ref + off : pr2;
+                    ++np;
+                }
+                pos_seq += len; pos_ref += len;
+            } else if (op == OP_INS) pos_seq += len;
+            else if (op == OP_DEL || op == OP_REF_SKIP) pos_ref += len;
         }
     }
-    Planes gp[FIN_PRE], sp[FIN_PRE];
-#pragma unroll
-    for (int k = 0; k < FIN_PRE; ++k) {
-        gp[k] = g_fetch(g, h.ref_id, pr[k]);                         // unconditional: an unused entry reads the alignment's first piece again
-        const int l = pl[k] > 0 ? pl[k] : 1;
-        sp[k] = anti ? rc_piece(src.fetch(rl - ps[k] - l, l), l) : src.fetch(ps[k], l);
-    }
-    // pass 2: bowtie_sam_extra over the ops
+    // unconditional: an unused entry reads the alignment's first piece again
+    const Planes gp0 = g_fetch(g, h.ref_id, pr0), gp1 = g_fetch(g, h.ref_id, pr1), gp2 = g_fetch(g, h.ref_id, pr2);
+    // pass 2: bowtie_sam_extra over the ops; the pieces of the MATCH ops all go through the one contig_piece below
     ContigAcc a;
     md_init(a.md);
     a.mismatch = a.both_n = a.AS = a.pos_mm = 0;
-    int opens = 0, conts = 0, piece = 0, pos_seq = 0;
+    int opens = 0, conts = 0, piece = 0, pos_seq = 0, i = 0, off = 0;
     int64_t pos_ref = h.left;
-#pragma unroll
-    for (int i = 0; i < LEAN_C; ++i) {
-        if (i < h.n) {
-            const int op = cig_op(h.c.v[i]), len = (int)cig_len(h.c.v[i]);
-            if (op == OP_MATCH) {
-                for (int off = 0; off < len; off += 64) {
-                    int l = len - off < 64 ? len - off : 64;
-                    if (pos_seq + off + l > rl) l = rl - pos_seq - off;
-                    if (l <= 0) break;
-                    Planes r, sq;
-                    if (piece < FIN_PRE && off < 64 * FIN_PRE) {
-                        r = gp[0]; sq = sp[0];
-#pragma unroll
-                        for (int k = 1; k < FIN_PRE; ++k) if (piece == k) { r = gp[k]; sq = sp[k]; }
-                    } else {
-                        r = g_fetch(g, h.ref_id, pos_ref + off);
-                        sq = anti ? rc_piece(src.fetch(rl - (pos_seq + off) - l, l), l) : src.fetch(pos_seq + off, l);
-                    }
-                    ++piece;
-                    contig_piece(p, r, sq, l, pos_seq + off, qual, qrev, rl, a);
-                }
-                pos_seq += len; pos_ref += len;
-            } else if (op == OP_INS) {
-                pos_seq += len;
-                a.AS -= p.bowtie2_read_gap_open + p.bowtie2_read_gap_cont * len;
-                ++opens; conts += len;
-            } else if (op == OP_DEL) {
-                a.AS -= p.bowtie2_ref_gap_open + p.bowtie2_ref_gap_cont * len;
-                ++opens; conts += len;
-                md_put_int_char(a.md, a.pos_mm, '^');
-                const Planes r = g_fetch(g, h.ref_id, pos_ref);
-                for (int k = 0; k < len && k < 64; ++k) md_push(a.md, "ACGTN"[plane_code(r, k)]);
-                pos_ref += len; a.pos_mm = 0;
-            } else if (op == OP_REF_SKIP) pos_ref += len;
+    while (i < h.n) {
+        const uint32_t ci = h.c.get(i);
+        const int op = cig_op(ci), len = (int)cig_len(ci);
+        if (op == OP_MATCH) {
+            int l = len - off < 64 ? len - off : 64;
+            if (pos_seq + off + l > rl) l = rl - pos_seq - off;
+            if (l > 0) {
+                Planes r;
+                if (piece < FIN_PRE) r = piece == 0 ? gp0 : (piece == 1 ? gp1 : gp2);
+                else r = g_fetch(g, h.ref_id, pos_ref + off);
+                const Planes sq = anti ? rc_piece(src.fetch(rl - (pos_seq + off) - l, l), l) : src.fetch(pos_seq + off, l);
+                contig_piece(p, r, sq, l, pos_seq + off, qual, qrev, rl, a);
+                ++piece;
+            }
+            off += 64;
+            if (off >= len || l <= 0) { pos_seq += len; pos_ref += len; off = 0; ++i; }
+            continue;
         }
+        if (op == OP_INS) {
+            pos_seq += len;
+            a.AS -= p.bowtie2_read_gap_open + p.bowtie2_read_gap_cont * len;
+            ++opens; conts += len;
+        } else if (op == OP_DEL) {
+            a.AS -= p.bowtie2_ref_gap_open + p.bowtie2_ref_gap_cont * len;
+            ++opens; conts += len;
+            md_put_int_char(a.md, a.pos_mm, '^');
+            const Planes r = g_fetch(g, h.ref_id, pos_ref);
+            for (int k = 0; k < len && k < 64; ++k) md_push(a.md, "ACGTN"[plane_code(r, k)]);
+            pos_ref += len; a.pos_mm = 0;
+        } else if (op == OP_REF_SKIP) pos_ref += len;
+        ++i;
     }
     md_put_int(a.md, a.pos_mm);
     e.md = a.md; e.AS = a.AS; e.XM = a.mismatch; e.XO = opens; e.XG = conts; e.both_n = a.both_n;
