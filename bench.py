@@ -1064,15 +1064,25 @@ def run_rank(args, rank, world, local_rank, control, shared):
                for i, (nm, v) in enumerate(zip(host.Context.SJ_KERNELS, sj_entries(task_alg, resc_alg)))]
     for i in (1, 2, 3, 4, 5):
         kernels[i]["stream"] = "side stream: runs beside the flat reads' kernels (the last three entries)"
+    # the multihit reads: with the chains on (reads of up to four segments, no fusion search) thj_k_chains looks at every one of them
+    # (CSR row + 16-B heads) and turns those whose chains need no search into chain entries -- their join and finish are thj_k_join's
+    # and thj_k_finish's work from then on, the packed tier keeps the rest.  The split of the multihit reads' bytes between the two
+    # follows the reads (span_ms[6] still brackets the packed tier alone)
+    chains_on = n_chain > 0
+    n_grp = ctx.span_chain_groups() if chains_on else 0          # multihit reads that travel as chain entries
+    grp_share = min(1.0, n_grp / max(1.0, float(n_multi)))
+    ch_alg = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read)) + grp_share * n_multi * 32.0 * (hits_multi / max(1.0, nseg) if multi_reads else 1.0)
     kernels += [
         {"kernel": "thj_k_stitch_contig", "avg_kernel_ms": span_ms[0], "launches": span_launches, "algorithmic_bytes_per_launch": t0_alg + 32.0 * n_chain},
-        {"kernel": "thj_k_join", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": join_alg},
-        {"kernel": "thj_k_finish", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": fin_alg},
-        {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
-        {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[4], "launches": span_launches, "algorithmic_bytes_per_launch": t2_alg},
-        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_generic", "avg_kernel_ms": span_ms[5], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
+        {"kernel": "thj_k_chains", "avg_kernel_ms": span_ms[1], "launches": span_launches, "algorithmic_bytes_per_launch": ch_alg if chains_on else 0.0},
+        {"kernel": "thj_k_join", "avg_kernel_ms": span_ms[2], "launches": span_launches, "algorithmic_bytes_per_launch": join_alg + grp_share * t2_alg * 0.4},
+        {"kernel": "thj_k_join_closure", "avg_kernel_ms": span_ms[3], "launches": span_launches, "algorithmic_bytes_per_launch": 0.15 * join_alg},
+        {"kernel": "thj_k_finish", "avg_kernel_ms": span_ms[4], "launches": span_launches, "algorithmic_bytes_per_launch": fin_alg + grp_share * t2_alg * 0.6},
+        {"kernel": "thj_k_stitch", "avg_kernel_ms": span_ms[5], "launches": span_launches, "algorithmic_bytes_per_launch": t1_alg},
+        {"kernel": "thj_k_stitch_pack", "avg_kernel_ms": span_ms[6], "launches": span_launches, "algorithmic_bytes_per_launch": (1.0 - grp_share) * t2_alg},
+        {"kernel": "thj_k_stitch_fusion" if args.fusion_search else "thj_k_stitch_generic", "avg_kernel_ms": span_ms[7], "launches": span_launches, "algorithmic_bytes_per_launch": t3_alg},
     ]
-    for i in (len(kernels) - 5, len(kernels) - 4):
+    for i in range(len(kernels) - 6, len(kernels) - 3):
         kernels[i]["stream"] = "side stream: runs beside the kernels of the reads that do not travel as chain entries, and beside the other side's"
     # The same kernels in SURVEY 8(d)'s byte terms -- what the ALGORITHM has to move, whatever layout a build chose: 16 B per hit
     # record (this build's stage-2 record is 32 B), the packed read, <= 128 B of genome per window / per joined hit, one 64-B
@@ -1093,7 +1103,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
     t2_8d = n_multi * (4 + 4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read) + done_8d + 64) + 4.0 * n_gen
     t3_8d = n_gen * (4 + 4.0 * (nseg + 1) + 16.0 * hits_per_read + done_8d + 64)
     resc_8d = (cnt.n_rescue_pairs / n_launch) * (4 + 4.0 * (nseg + 1) + 16.0 * cnt.n_hits_read / (2.0 * args.pairs) + 16 + rl_bytes + 128)
-    for k, b8 in zip(kernels, sj_entries(task_8d, resc_8d) + [t0_8d, join_8d, fin_8d, t1_8d, t2_8d, t3_8d]):
+    ch_8d = n_multi * (4.0 * (nseg + 1) + 16.0 * (hits_multi if multi_reads else hits_per_read)) if chains_on else 0.0
+    for k, b8 in zip(kernels, sj_entries(task_8d, resc_8d) + [t0_8d, ch_8d, join_8d + grp_share * t2_8d * 0.4, 0.15 * join_8d, fin_8d + grp_share * t2_8d * 0.6, t1_8d, (1.0 - grp_share) * t2_8d, t3_8d]):
         k["algorithmic_bytes_8d_per_launch"] = b8
     for k in kernels:
         k["achieved_layout"] = k["algorithmic_bytes_per_launch"] / (k["avg_kernel_ms"] * 1e-3) / 1e9 if k["avg_kernel_ms"] > 0 else 0.0

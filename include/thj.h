@@ -410,12 +410,15 @@ int thj_span_device_records(thj_ctx* ctx, const thj_aln_slot** d_slots, const ui
                             const thj_aln_slot** d_extra, const uint64_t** d_extra_keys, int64_t* n_extra);
 /* Of the batch launched last: counts[0] = reads sent to the closure kernels (as chain entries to thj_k_join / thj_k_finish, or to
  * thj_k_stitch), counts[1] = to the multihit kernel thj_k_stitch_pack, counts[2] = on to the general kernel thj_k_stitch_generic,
- * counts[3] = those of counts[0] that travelled as chain entries; the rest were finished by thj_k_stitch_contig. */
-int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[4]*/);
-/* Average durations (ms) of the stitch kernels since the last call -- avg_ms[0] thj_k_stitch_contig, [1] thj_k_join, [2] thj_k_finish,
- * [3] thj_k_stitch, [4] thj_k_stitch_pack, [5] thj_k_stitch_generic or, with --fusion-search, thj_k_stitch_fusion -- from HIP events on
- * the stream each runs on (kernels of batches that run beside each other share the GPU: their durations overlap). */
-int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[6]*/, int64_t* launches);
+ * counts[3] = those of counts[0] that travelled as chain entries, counts[4] = those of counts[1] whose chains thj_k_chains turned into
+ * chain entries (joined and finished by thj_k_join / thj_k_finish instead of the packed tier); the rest were finished by
+ * thj_k_stitch_contig. */
+int thj_span_tier_counts(thj_ctx* ctx, int64_t* counts /*[5]*/);
+/* Average durations (ms) of the stitch kernels since the last call -- avg_ms[0] thj_k_stitch_contig, [1] thj_k_chains, [2] thj_k_join,
+ * [3] thj_k_join_closure, [4] thj_k_finish, [5] thj_k_stitch, [6] thj_k_stitch_pack, [7] thj_k_stitch_generic or, with --fusion-search,
+ * thj_k_stitch_fusion -- from HIP events on the stream each runs on (kernels of batches that run beside each other share the GPU:
+ * their durations overlap). */
+int thj_profile_span(thj_ctx* ctx, int enable, double* avg_ms /*[8]*/, int64_t* launches);
 
 /* ---- coverage search of segment_juncs (segment_juncs.cpp:4268-4543 capture_island_ends and what it calls: the
  * coverage map of build_coverage_map :4140-4176, the extension table of index_read_mers :548-571,

@@ -220,6 +220,8 @@ struct VecSink {
 
 static int64_t g_wave_reads = 0;            // reads the packed tier finished since the last call of hostsim_wave_reads
 extern "C" int64_t hostsim_wave_reads() { const int64_t n = g_wave_reads; g_wave_reads = 0; return n; }
+static int64_t g_chain_groups = 0;          // multihit reads whose chains travelled as chain entries (thj_k_chains)
+extern "C" int64_t hostsim_chain_groups() { const int64_t n = g_chain_groups; g_chain_groups = 0; return n; }
 static int64_t g_chain_deferred = 0;        // ... of them, the ones whose join searched a closure
 extern "C" int64_t hostsim_chain_deferred() { const int64_t n = g_chain_deferred; g_chain_deferred = 0; return n; }
 static int64_t g_chain_reads = 0;           // reads that travelled as chain entries (tier 0 -> join -> finish) since the last call
@@ -333,6 +335,56 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
         }
         if (st == SPAN_NEED_GENERIC) (((mode == 0 || mode == 3) && nseg <= SPAN_MIDSEG) ? multi : gen).push_back((uint32_t)r);      // (reads of more than eight segments skip the packed tier, as in thj_span_run_async)
         else status_counts[st]++;
+    }
+    if (!multi.empty() && mode == 0 && nseg <= CHAIN_MAXSEG) {          // (mode 3 keeps every multihit read on the packed tier)
+        // thj_k_chains: the multihit reads whose chains are known without a search travel as chain entries, each with its rank
+        // among the read's chains; thj_k_finish numbers the records by counting the lower-ranked siblings that were reported
+        std::vector<uint32_t> rest;
+        for (uint32_t r : multi) {
+            const uint32_t* so = seg_off + (int64_t)r * nseg;
+            int nsegs = 0;
+            while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
+            bool ok = nsegs > 0 && (((const SpanHit*)hits)[so[nsegs - 1]].meta & SH_END) != 0;
+            if (ok && p.bowtie2) for (int s2 = 0; s2 < nsegs; ++s2) ok = ok && !((int)(so[s2 + 1] - so[s2]) > p.max_seg_multihits);
+            if (!ok) { status_counts[SPAN_OK]++; continue; }              // the worker's early outs (:2777-2785, :2625-2632): nothing for this read
+            struct HostTab {
+                const SpanHit* h0;
+                SpanHitHead head(int j) const {
+                    const SpanHit& x = h0[j];
+                    int right = x.left; int n = (int)(x.meta >> 24); if (n > 5) n = 5;
+                    for (int i = 0; i < n; ++i) { const int op = cig_op(x.cigar[i]); if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) right += (int)cig_len(x.cigar[i]); }
+                    return SpanHitHead{x.ref_id, x.left, x.meta, (uint32_t)right};
+                }
+            } tab{(const SpanHit*)hits + so[0]};
+            uint32_t off[CHAIN_MAXSEG + 1];
+            for (int s2 = 0; s2 <= nsegs && s2 <= CHAIN_MAXSEG; ++s2) off[s2] = so[s2] - so[0];
+            uint32_t sel[CHAINS_MAX]; int q[CHAINS_MAX];
+            const int k = nsegs <= CHAIN_MAXSEG ? chains_discover(p, tab, off, nsegs, sel, q) : CHAINS_DECLINE;
+            if (k == CHAINS_DECLINE) { rest.push_back(r); continue; }
+            ++g_chain_groups;
+            VecSink sink{&outs[(size_t)r]};
+            int order = 0;
+            bool punt = false;
+            std::vector<OutAln> keep = outs[(size_t)r];
+            for (int rank = 0; rank < k && !punt; ++rank)
+                for (int c = 0; c < k; ++c) {
+                    if (q[c] != rank) continue;
+                    SpanHit ch[CHAIN_MAXSEG];
+                    for (int s2 = 0; s2 < CHAIN_MAXSEG; ++s2) ch[s2] = ((const SpanHit*)hits)[so[0] + ((sel[c] >> (4 * (s2 < nsegs ? s2 : 0))) & 15u)];
+                    const uint32_t meta = chain_meta(nsegs, rank, k, read_len[r]);
+                    RAln res;
+                    int jr = chain_join<true>(g, p, S, ch, meta, (const u64*)planes + (int64_t)r * 3 * W, W, res);
+                    if (jr == LJ_DEFER) jr = chain_join<false>(g, p, S, ch, meta, (const u64*)planes + (int64_t)r * 3 * W, W, res);
+                    if (jr == LJ_PUNT) { punt = true; break; }
+                    if (jr != LJ_OK) continue;
+                    Q16 ja, jb, jc;
+                    joined_pack(res, r, nsegs == 1, rank, k, ja, jb, jc);
+                    if (joined_finish(g, p, ja, jb, jc, (const u64*)planes, W, read_len, quals, qual_stride, order, sink)) ++order;
+                }
+            if (punt) { outs[(size_t)r] = keep; gen.push_back(r); continue; }     // (the kernels: a chain that needs more cigar ops sends the read to the general tier; see thj_k_join)
+            status_counts[SPAN_OK]++;
+        }
+        multi.swap(rest);
     }
     if (!multi.empty()) {          // tier 2: the multihit list in batches of 64 entries, lanes as fibers
         int rc;

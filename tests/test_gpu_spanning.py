@@ -90,6 +90,35 @@ def test_pair_call_gives_the_records_of_two_runs():
     assert [key(a) for a in pair2[len(want_b):]] == [key(a) for a in want_a]
 
 
+def test_multihit_reads_as_chain_groups():
+    """reads from a tandem repeat of two, three, four and eight copies: every segment has that many hits, every first-segment hit
+    starts one chain -- thj_k_chains turns each read into a group of chain entries (rank order known up front), thj_k_join and
+    thj_k_finish join and finish them on lanes of their own, the finish numbering the records by ballot; the 30-copy case stays
+    with the packed tier.  Records and their order = the oracle's"""
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    # (the copies lie 400 bases apart: with introns of up to 300 a hit chains with its own copy's next hit only -- with the default
+    # 500 kb every hit has a choice of successors, dfs_seg_hits searches, and the read stays with the packed tier: the second loop)
+    p = Params(max_report_intron=300, max_segment_intron=300)
+    with host.Context(0) as ctx:
+        for copies, want_groups in ((2, True), (3, True), (4, True), (8, False), (30, False)):
+            seq, sb = repeat_span_batch(copies=copies, n_reads=300, seed=20 + copies)
+            want = orc.spanning(p, orc.Genome([seq]), sb, nj, [])
+            assert len(want) == copies * sb.n_reads
+            ctx.upload_genome(host.pack_genome([seq]))
+            ctx.upload_span_sets(nj, [])
+            got = ctx.spanning(p, [ctx.upload_span_batch(sb)])
+            assert got == want, copies
+            assert (ctx.span_chain_groups() > 0) == want_groups, copies       # (eight copies of four segments are 32 hits: more than thj_k_chains takes)
+        pd = Params()
+        for copies in (2, 4):
+            seq, sb = repeat_span_batch(copies=copies, n_reads=300, seed=40 + copies)
+            want = orc.spanning(pd, orc.Genome([seq]), sb, nj, [])
+            ctx.upload_genome(host.pack_genome([seq]))
+            ctx.upload_span_sets(nj, [])
+            assert ctx.spanning(pd, [ctx.upload_span_batch(sb)]) == want
+            assert ctx.span_chain_groups() == 0
+
+
 def test_many_joined_alignments_per_read_gpu():
     """30 joined alignments per read (a 30-copy tandem repeat): multihit tier, overflow pool ordering"""
     import numpy as np

@@ -153,14 +153,19 @@ def test_scale_workload_with_a_repeat_family():
         want = orc.spanning(p, og, spb, juncs, ins)
         for mode in (0, 2, 3):
             sim.lib().hostsim_wave_reads()
+            sim.lib().hostsim_chain_groups()
             got, status = sim.spanning(p, strs, spb, juncs, ins, mode)
             got.sort(key=lambda a: a.read_idx)
             assert status[1] == 0 and status[2] == 0
             assert got == want
             took = sim.lib().hostsim_wave_reads()
             print("mode", mode, "packed tier finished", took, "reads; general arrays", status[3])
-            if mode == 0:          # the packed tier (chains over the lanes of a wave, lanes emulated as fibers) finishes the family's reads
-                assert took > 0.2 * n and status[3] == 0
+            groups = sim.lib().hostsim_chain_groups()
+            print("mode", mode, "multihit reads as chain entries", groups)
+            if mode == 0:          # most of the family's reads travel as chain entries (thj_k_chains); the packed tier (chains over the lanes of a wave, lanes emulated as fibers) finishes the rest
+                assert groups > 0.2 * n and took > 50 and status[3] == 0
+            if mode == 2:
+                assert groups == 0
             if mode == 3:          # ... and with tiny limits still the reads of few hits, in many rounds
                 assert took > 50
         by_read = {}

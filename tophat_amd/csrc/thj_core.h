@@ -94,6 +94,16 @@ THJ_HD Planes g_fetch(const Genome& g, uint32_t ref_id, int64_t pos) {
     r.nm = funnel(p[2], p[6], s);
     return r;
 }
+// the same at a global base position (contig_blk[ref_id - 1] * 64 + pos: for callers that hold the contig's base already)
+THJ_HD Planes g_fetch_abs(const Genome& g, u64 gpos) {
+    const u64* p = g.blocks + (gpos >> 6) * 4;
+    unsigned s = (unsigned)(gpos & 63);
+    Planes r;
+    r.lo = funnel(p[0], p[4], s);
+    r.hi = funnel(p[1], p[5], s);
+    r.nm = funnel(p[2], p[6], s);
+    return r;
+}
 THJ_HD int32_t g_len(const Genome& g, uint32_t ref_id) {
     return (ref_id == 0 || (int32_t)ref_id > g.n_contigs) ? 0 : g.contig_len[ref_id - 1];
 }

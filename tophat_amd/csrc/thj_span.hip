@@ -112,6 +112,7 @@ struct Tiers {
     // null: every one-hit-per-segment read takes wl_lean.  The joined hits, densely: ja / jb / jc[i] for entry i of the concatenation
     ChainEntry* ent; unsigned int* blk_chain;
     Q16* ja; Q16* jb; Q16* jc;
+    unsigned int* status;            // the pass's status words (RecSink::status)
 };
 __device__ __forceinline__ bool defer_huge(const Tiers& t, uint32_t r) {
     if (!t.huge_list) return false;
@@ -317,27 +318,37 @@ struct LdsChainHits {       // word pair (2 s, 2 s + 1) of column `col` = the re
         return h;
     }
 };
-// (Work distribution: workgroup b takes the entries tier 0's workgroup b wrote -- its four class slices one after the other -- and
-// writes their joined hits to J[b * chunk ..): no table of slice offsets, no search per entry; thj_k_finish walks the same way.)
-struct ChainLists { const ChainEntry* ent; const unsigned int* blk_cnt; int G, chunk; Q16* ja; Q16* jb; Q16* jc; };
+// (Work distribution.  Region A, tier 0's entries: workgroup b takes what tier 0's workgroup b wrote -- its four class slices one
+// after the other -- and writes the joined hits to J[b * chunk ..): no table of slice offsets, no search per entry.  Region B,
+// the chains of multihit reads (thj_k_chains): one dense list of *n2 entries, workgroups G .. G + G2 stride over it, joined hits
+// at J[G * chunk ..).  thj_k_join_closure and thj_k_finish walk the same way.)
+struct ChainLists {
+    const ChainEntry* ent; const unsigned int* blk_cnt; int G, chunk;
+    const ChainEntry* ent2; const unsigned int* n2; int G2; unsigned int cap2, slice2;
+    Q16* ja; Q16* jb; Q16* jc;
+};
 __device__ __forceinline__ unsigned int chain_block_counts(const ChainLists& L, int blk, unsigned int (&c)[SPAN_LEAN_CLASSES]) {
     unsigned int total = 0;
 #pragma unroll
     for (int k = 0; k < SPAN_LEAN_CLASSES; ++k) { c[k] = L.blk_cnt[k * L.G + blk]; total += c[k]; }
     return total;
 }
-// Two passes per workgroup.  Most chains of a sample mapped against a junction database abut everywhere -- the spliced read's
-// junction sits INSIDE a segment hit (aM gN bM) and merge_chain only concatenates -- and need nothing but their records; a chain
-// with a gap between two hits (a junction at a segment boundary, an indel) needs the closure search: dependent loads of junction
-// keys, genome and read words that a wave pays for as a whole even when one lane takes them (one lane in twenty does: nearly every
-// wave would).  So the first pass joins the abutting chains (lean_join<ABUT>: the closure code is not in it) and queues the others
-// in LDS; whenever 256 are queued, and at the end, the workgroup runs the full join over the queue with its lanes dense.
+__device__ __forceinline__ unsigned int chain_dense_count(const ChainLists& L) { const unsigned int n = *L.n2; return n < L.cap2 ? n : L.cap2; }
+// Two kernels.  Most chains of a sample mapped against a junction database abut everywhere -- the spliced read's junction sits
+// INSIDE a segment hit (aM gN bM) and merge_chain only concatenates -- and need nothing but their records; a chain with a gap
+// between two hits (a junction at a segment boundary, an indel) needs the closure search: dependent loads of junction keys,
+// genome and read words that a wave pays for as a whole even when one lane takes them (one lane in seven does here: every wave
+// would).  thj_k_join joins the abutting chains (lean_join<ABUT>: the closure code is not in it) and lists the others, per
+// workgroup; thj_k_join_closure runs the full join over those lists with its lanes dense.  (As two passes of one kernel the
+// second pass ran cold: 230 us per workgroup for some four hundred entries, most of it instruction fetch.)
+struct DeferList { uint32_t* idx; unsigned int* cnt; };      // region A: idx[b * chunk ..), cnt[b]; region B: idx[G * chunk + j * slice2 ..), cnt[G + j]
 template <bool ABUT>
 __device__ __forceinline__ int join_entry(const Genome& g, const Params& p, const SpanSets& S, const SpanHit* hits, const u64* planes, int W,
-                                          const ChainLists& L, const Tiers& t, Q16* s_rec, u64 cls_blk_base, unsigned int local, u64 at) {
-    const Q16* src = (const Q16*)(L.ent + cls_blk_base + local);
+                                          const ChainLists& L, const Tiers& t, Q16* s_rec, const ChainEntry* entry, u64 at) {
+    const Q16* src = (const Q16*)entry;
     const Q16 e0 = src[0], e1 = src[1];
     const uint32_t r = e0.x, meta = e0.y;
+    if (r == JOINED_PAD) { if (ABUT) L.ja[at] = Q16{JOINED_PAD, 0u, 0u, 0u}; return LJ_NONE; }       // padding of a group (thj_k_chains)
     {
         Q16 rec[2 * CHAIN_MAXSEG];
         const uint32_t hi[CHAIN_MAXSEG] = {e1.x, e1.y, e1.z, e1.w};
@@ -352,85 +363,264 @@ __device__ __forceinline__ int join_entry(const Genome& g, const Params& p, cons
     if (ABUT && jr == LJ_DEFER) return jr;
     Q16 ja, jb, jc;
     joined_pack(res, r, chain_nsegs(meta) == 1, chain_q(meta), chain_k(meta), ja, jb, jc);
-    if (jr != LJ_OK) ja.x = JOINED_NONE;
+    if (jr != LJ_OK) ja.w = joined_none_meta(chain_q(meta), chain_k(meta));
     L.ja[at] = ja;
     if (jr == LJ_OK) { L.jb[at] = jb; if (res.n > 4) L.jc[at] = jc; }
-    if (jr == LJ_PUNT) {               // rare: the general tier takes the read (its slice of that list is its tier-0 block's)
-        const uint32_t gb = r / (uint32_t)t.chunk;
-        t.wl_gen[(u64)gb * (uint32_t)t.chunk + atomicAdd(&t.blk_gen[gb], 1u)] = r;
-        atomicAdd(&t.counters[2], 1u);
+    if (jr == LJ_PUNT) {
+        // rare: more cigar ops than the registers hold.  A read on its own goes to the general tier (its slice of that list is its
+        // tier-0 block's); one chain of several cannot take its siblings' records back: the pass fails loudly (status[5])
+        if (chain_k(meta) > 1) atomicExch(&t.status[5], 1u);
+        else {
+            const uint32_t gb = r / (uint32_t)t.chunk;
+            t.wl_gen[(u64)gb * (uint32_t)t.chunk + atomicAdd(&t.blk_gen[gb], 1u)] = r;
+            atomicAdd(&t.counters[2], 1u);
+        }
     }
     return jr;
 }
-__device__ __forceinline__ void chain_locate(const unsigned int (&c)[SPAN_LEAN_CLASSES], const ChainLists& L, int blk, unsigned int i, u64& base, unsigned int& local) {
-    unsigned int cls = 0;
-    local = i;
+__device__ __forceinline__ const ChainEntry* chain_locate(const unsigned int (&c)[SPAN_LEAN_CLASSES], const ChainLists& L, int blk, unsigned int i) {
+    unsigned int cls = 0, local = i;
 #pragma unroll
     for (int k = 0; k < SPAN_LEAN_CLASSES - 1; ++k) { const bool next = cls == (unsigned int)k && local >= c[k]; local -= next ? c[k] : 0u; cls += next ? 1u : 0u; }
-    base = (u64)(cls * (unsigned int)L.G + (unsigned int)blk) * (unsigned int)L.chunk;
+    return L.ent + (u64)(cls * (unsigned int)L.G + (unsigned int)blk) * (unsigned int)L.chunk + local;
 }
 template <int WPE>
-__global__ __launch_bounds__(256, WPE) void thj_k_join(Genome g, Params p, SpanSets S, const SpanHit* hits, const u64* planes, int W, ChainLists L, Tiers t) {
+__global__ __launch_bounds__(256, WPE) void thj_k_join(Genome g, Params p, SpanSets S, const SpanHit* hits, const u64* planes, int W, ChainLists L, Tiers t, DeferList D) {
     __shared__ Q16 s_rec[2 * CHAIN_MAXSEG * 256];
-    __shared__ unsigned int s_q[512];
     __shared__ unsigned int s_qn;
     if (threadIdx.x == 0) s_qn = 0;
     __syncthreads();
-    for (int blk = blockIdx.x; blk < L.G; blk += gridDim.x) {
+    if ((int)blockIdx.x < L.G) {
+        const int blk = (int)blockIdx.x;
         unsigned int c[SPAN_LEAN_CLASSES];
         const unsigned int total = chain_block_counts(L, blk, c);
-        const unsigned int rounds = (total + 255u) / 256u;
-        for (unsigned int round = 0; round <= rounds; ++round) {            // the last round only drains the queue
-            const unsigned int i = round * 256u + threadIdx.x;
-            if (i < total) {
-                u64 base; unsigned int local;
-                chain_locate(c, L, blk, i, base, local);
-                const int jr = join_entry<true>(g, p, S, hits, planes, W, L, t, s_rec, base, local, (u64)blk * (uint32_t)L.chunk + i);
-                if (jr == LJ_DEFER) s_q[atomicAdd(&s_qn, 1u)] = i;          // room: fewer than 256 left over + at most 256 new
-            }
-            __syncthreads();
-            unsigned int qn = s_qn;
-            while (qn >= 256u || (round == rounds && qn > 0u)) {
-                const unsigned int take = qn < 256u ? qn : 256u, first = qn - take;
-                if (threadIdx.x < take) {
-                    const unsigned int j = s_q[first + threadIdx.x];
-                    u64 base; unsigned int local;
-                    chain_locate(c, L, blk, j, base, local);
-                    join_entry<false>(g, p, S, hits, planes, W, L, t, s_rec, base, local, (u64)blk * (uint32_t)L.chunk + j);
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) s_qn = first;
-                __syncthreads();
-                qn = first;
-            }
+        for (unsigned int i = threadIdx.x; i < total; i += 256) {
+            const int jr = join_entry<true>(g, p, S, hits, planes, W, L, t, s_rec, chain_locate(c, L, blk, i), (u64)blk * (uint32_t)L.chunk + i);
+            if (jr == LJ_DEFER) D.idx[(u64)blk * (uint32_t)L.chunk + atomicAdd(&s_qn, 1u)] = i;
+        }
+    } else {
+        const unsigned int j = blockIdx.x - (unsigned int)L.G, n2 = chain_dense_count(L);
+        const u64 jbase = (u64)L.G * (uint32_t)L.chunk;
+        for (unsigned int i = j * 256u + threadIdx.x; i < n2; i += (unsigned int)L.G2 * 256u) {
+            const int jr = join_entry<true>(g, p, S, hits, planes, W, L, t, s_rec, L.ent2 + i, jbase + i);
+            if (jr == LJ_DEFER) D.idx[jbase + (u64)j * L.slice2 + atomicAdd(&s_qn, 1u)] = i;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) D.cnt[blockIdx.x] = s_qn;
+}
+template <int WPE>
+__global__ __launch_bounds__(256, WPE) void thj_k_join_closure(Genome g, Params p, SpanSets S, const SpanHit* hits, const u64* planes, int W, ChainLists L, Tiers t, DeferList D) {
+    __shared__ Q16 s_rec[2 * CHAIN_MAXSEG * 256];
+    const unsigned int n = D.cnt[blockIdx.x];
+    if ((int)blockIdx.x < L.G) {
+        const int blk = (int)blockIdx.x;
+        unsigned int c[SPAN_LEAN_CLASSES];
+        chain_block_counts(L, blk, c);
+        for (unsigned int k = threadIdx.x; k < n; k += 256) {
+            const unsigned int i = D.idx[(u64)blk * (uint32_t)L.chunk + k];
+            join_entry<false>(g, p, S, hits, planes, W, L, t, s_rec, chain_locate(c, L, blk, i), (u64)blk * (uint32_t)L.chunk + i);
+        }
+    } else {
+        const unsigned int j = blockIdx.x - (unsigned int)L.G;
+        const u64 jbase = (u64)L.G * (uint32_t)L.chunk;
+        for (unsigned int k = threadIdx.x; k < n; k += 256) {
+            const unsigned int i = D.idx[jbase + (u64)j * L.slice2 + k];
+            join_entry<false>(g, p, S, hits, planes, W, L, t, s_rec, L.ent2 + i, jbase + i);
         }
     }
 }
 
 // The finish of the joined hits (check_editdist_consistency, bowtie_sam_extra, the record: bwt_map.cpp:2349-2648, :1888-2093): a
-// thread per joined hit, workgroup b over the joined hits of thj_k_join's workgroup b.
+// thread per joined hit, the lists walked as thj_k_join walks them.  The chains of a multihit read sit in adjacent lanes, in rank
+// order (groups never straddle a wave, thj_k_chains): a record's rank among the read's records is the number of lower-ranked
+// siblings that are reported -- a ballot.  Second and later records go to the extra pool; a wave reserves the room for all its lanes'
+// with one atomic.
+struct FinishSink {
+    uint4* dst;
+    __device__ __forceinline__ void emit_words(const uint32_t* w) {
+        const bool tail = slot_needs_tail(w);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dst[k] = make_uint4(slot_word(w, 4 * k, tail), slot_word(w, 4 * k + 1, tail), slot_word(w, 4 * k + 2, tail), slot_word(w, 4 * k + 3, tail));
+        if (tail) {
+#pragma unroll
+            for (int k = 4; k < 8; ++k) dst[k] = make_uint4(slot_word(w, 4 * k, true), slot_word(w, 4 * k + 1, true), slot_word(w, 4 * k + 2, true), slot_word(w, 4 * k + 3, true));
+        }
+    }
+};
+__device__ __forceinline__ unsigned int finish_one(const Genome& g, const Params& p, const DevSpanBatch& b, const RecSink& sink, const ChainLists& L, bool has, u64 at) {
+    const int lane = (int)(threadIdx.x & 63u);
+    Q16 ja{JOINED_PAD, 0u, 0u, 0u};
+    if (has) ja = L.ja[at];
+    const bool real = ja.x != JOINED_PAD;
+    const uint32_t r = ja.x;
+    RAln res; Extras e;
+    bool emit = false;
+    if (real && joined_n(ja.w) > 0) {
+        const Q16 jb = L.jb[at];
+        Q16 jc{0u, 0u, 0u, 0u};
+        if (joined_n(ja.w) > 4) jc = L.jc[at];
+        emit = joined_prepare(g, p, ja, jb, jc, b.planes, b.W, b.read_len, b.quals, b.qual_stride, res, e);
+    }
+    const int q = joined_q(ja.w), kp = chains_padded(joined_k(ja.w));
+    const unsigned long long m = __ballot(emit);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const unsigned long long gmask = (~0ull >> (64 - kp)) << (lane - q);
+    const int order = __popcll(m & gmask & below), cnt = __popcll(m & gmask);
+    const unsigned long long xm = __ballot(emit && order > 0);
+    unsigned long long pbase = 0;
+    if (xm) {                                    // (wave-uniform)
+        const int leader = __ffsll((long long)xm) - 1;
+        if (lane == leader) pbase = atomicAdd(sink.ovf_count, (unsigned long long)__popcll(xm));
+        pbase = ((unsigned long long)(uint32_t)__shfl((int)(pbase >> 32), leader) << 32) | (uint32_t)__shfl((int)(uint32_t)pbase, leader);
+    }
+    if (emit) {
+        uint4* dst = (uint4*)(sink.slots + (size_t)sink.base + r);
+        if (order > 0) {
+            const unsigned long long pos = pbase + (unsigned long long)__popcll(xm & below);
+            if (pos >= sink.ovf_cap) { atomicExch(&sink.status[3], 1u); dst = nullptr; }
+            else { sink.ovf_key[pos] = ((u64)(sink.base + r) << 16) | (u64)order; dst = (uint4*)(sink.ovf + pos); }
+        }
+        if (dst) { FinishSink fs{dst}; emit_aln(fs, r, order, res, e); }
+    }
+    if (real && q == 0) sink.nrec[(size_t)sink.base + r] = (uint8_t)(cnt > 255 ? 255 : cnt);
+    return emit ? 1u : 0u;
+}
 template <int WPE>
 __global__ __launch_bounds__(256, WPE) void thj_k_finish(Genome g, Params p, DevSpanBatch b, RecSink sink, ChainLists L) {
     __shared__ unsigned int s_rec;
     if (threadIdx.x == 0) s_rec = 0;
     __syncthreads();
-    for (int blk = blockIdx.x; blk < L.G; blk += gridDim.x) {
+    unsigned int acc = 0;
+    if ((int)blockIdx.x < L.G) {
+        const int blk = (int)blockIdx.x;
         unsigned int c[SPAN_LEAN_CLASSES];
         const unsigned int total = chain_block_counts(L, blk, c);
-        for (unsigned int i = threadIdx.x; i < total; i += 256) {
-            const u64 at = (u64)blk * (uint32_t)L.chunk + i;
-            const Q16 ja = L.ja[at];
-            if (ja.x == JOINED_NONE) continue;
-            const Q16 jb = L.jb[at];
-            Q16 jc{0, 0, 0, 0};
-            if ((ja.w & 15u) > 4u) jc = L.jc[at];
-            joined_finish(g, p, ja, jb, jc, b.planes, b.W, b.read_len, b.quals, b.qual_stride, 0, sink);
-            sink.done(ja.x);
+        for (unsigned int i0 = 0; i0 < total; i0 += 256) {       // (uniform trip count: the ballots want whole waves)
+            const unsigned int i = i0 + threadIdx.x;
+            acc += finish_one(g, p, b, sink, L, i < total, (u64)blk * (uint32_t)L.chunk + i);
+        }
+    } else {
+        const unsigned int j = blockIdx.x - (unsigned int)L.G, n2 = chain_dense_count(L);
+        const u64 jbase = (u64)L.G * (uint32_t)L.chunk;
+        for (unsigned int i0 = j * 256u; i0 < n2; i0 += (unsigned int)L.G2 * 256u) {
+            const unsigned int i = i0 + threadIdx.x;
+            acc += finish_one(g, p, b, sink, L, i < n2, jbase + i);
         }
     }
-    if (sink.acc) atomicAdd(&s_rec, (unsigned int)sink.acc);
+    if (acc) atomicAdd(&s_rec, acc);
     __syncthreads();
     if (threadIdx.x == 0 && s_rec) atomicAdd(sink.total, (unsigned long long)s_rec);
+}
+
+// The chains of the multihit reads that need no search (chains_discover, thj_span_core.h): a thread per entry of the multihit list,
+// workgroup b over tier 0's workgroup b's slice, the read's hit heads (with each hit's right end in place of its first cigar op) in
+// the thread's own column of LDS.  A read with k chains becomes a group of k chain entries in rank order, padded to 1 / 2 / 4 / 8 and
+// laid out at a multiple of that size in the dense list (a round's groups by size, its room reserved with one atomic per workgroup
+// and round); a read that is declined goes on to thj_k_stitch_pack's list.
+static constexpr int CH_TPB = 128;
+struct LdsHitTab {
+    const Q16* col;
+    __device__ __forceinline__ SpanHitHead head(int j) const { const Q16 v = col[j * CH_TPB]; return SpanHitHead{v.x, (int32_t)v.y, v.z, v.w}; }
+};
+__global__ __launch_bounds__(CH_TPB) void thj_k_chains(Params p, DevSpanBatch b, Tiers t, ChainEntry* ent2, unsigned int* n2, unsigned int cap2, uint32_t* wl_pack, unsigned int* blk_pack, int G) {
+    __shared__ Q16 s_head[CHAINS_MAXHITS * CH_TPB];
+    __shared__ unsigned int s_base;
+    typedef hipcub::BlockScan<u64, CH_TPB> Scan;
+    __shared__ typename Scan::TempStorage tmp;
+    const int tid = (int)threadIdx.x;
+    for (int blk = blockIdx.x; blk < G; blk += gridDim.x) {
+        const unsigned int n_b = t.blk_multi[blk];
+        unsigned int pack_n = 0;
+        for (unsigned int j0 = 0; j0 < n_b; j0 += CH_TPB) {
+            const unsigned int j = j0 + (unsigned int)tid;
+            const bool has = j < n_b;
+            const uint32_t r = has ? t.wl_multi[(u64)blk * (uint32_t)t.chunk + j] : 0u;
+            int k = 0, nsegs = 0;
+            uint32_t sel[CHAINS_MAX]; int q[CHAINS_MAX];
+#pragma unroll
+            for (int c = 0; c < CHAINS_MAX; ++c) { sel[c] = 0; q[c] = 0; }
+            uint32_t sof0 = 0;
+            if (has) {
+                const uint32_t* so = b.seg_off + (u64)r * (uint32_t)b.nseg;
+                uint32_t sof[CHAIN_MAXSEG + 1];
+#pragma unroll
+                for (int s = 0; s <= CHAIN_MAXSEG; ++s) sof[s] = s <= b.nseg ? so[s <= b.nseg ? s : 0] : 0u;
+                {
+                    bool open = true;
+#pragma unroll
+                    for (int s = 0; s < CHAIN_MAXSEG; ++s) { open = open && s < b.nseg && sof[s + 1] > sof[s]; nsegs += open ? 1 : 0; }
+                }
+                sof0 = sof[0];
+                uint32_t last_so = sof[0], end_so = sof[0];
+#pragma unroll
+                for (int s = 1; s <= CHAIN_MAXSEG; ++s) { last_so = (s == nsegs - 1) ? sof[s] : last_so; end_so = (s == nsegs) ? sof[s] : end_so; }
+                bool ok = nsegs > 0 && (load_head(b.hits, b.heads, (u64)last_so).z & SH_END) != 0;          // :2777-2785
+                if (ok && p.bowtie2) {
+#pragma unroll
+                    for (int s = 0; s < CHAIN_MAXSEG; ++s) ok = ok && !(s < nsegs && (int)(sof[s + 1] - sof[s]) > p.max_seg_multihits);   // :2625-2632
+                }
+                if (ok) {                        // (else: nothing for this read, as in every tier)
+                    const uint32_t nh = end_so - sof[0];
+                    k = CHAINS_DECLINE;
+                    if (nh <= (uint32_t)CHAINS_MAXHITS) {
+                        for (uint32_t h = 0; h < nh; ++h) {
+                            const Q16 hq = load_head(b.hits, b.heads, (u64)sof[0] + h);
+                            s_head[h * CH_TPB + tid] = Q16{hq.x, hq.y, hq.z, (uint32_t)pack_hit_right(hq, b.hits, (u64)sof[0] + h)};
+                        }
+                        uint32_t off[CHAIN_MAXSEG + 1];
+#pragma unroll
+                        for (int s = 0; s <= CHAIN_MAXSEG; ++s) off[s] = sof[s] - sof[0];
+                        const LdsHitTab tab{s_head + tid};
+                        k = chains_discover(p, tab, off, nsegs, sel, q);
+                    }
+                }
+            }
+            const int kp = k > 0 ? chains_padded(k) : 0;
+            const bool declined = has && k == CHAINS_DECLINE;
+            const u64 mine = (kp == 8 ? 1ull : 0ull) | (kp == 4 ? 1ull << 8 : 0ull) | (kp == 2 ? 1ull << 16 : 0ull) | (kp == 1 ? 1ull << 24 : 0ull) | (declined ? 1ull << 32 : 0ull);
+            u64 excl, tot;
+            Scan(tmp).ExclusiveSum(mine, excl, tot);
+            const unsigned int N8 = (unsigned int)(tot & 255u), N4 = (unsigned int)((tot >> 8) & 255u), N2 = (unsigned int)((tot >> 16) & 255u), N1 = (unsigned int)((tot >> 24) & 255u);
+            const unsigned int ND = (unsigned int)((tot >> 32) & 255u);
+            const unsigned int T = 8u * N8 + 4u * N4 + 2u * N2 + N1, T8 = (T + 7u) & ~7u;
+            if (tid == 0) s_base = T8 ? atomicAdd(n2, T8) : 0u;
+            __syncthreads();
+            const unsigned int gb = s_base;
+            const bool room = gb + T8 <= cap2 && gb + T8 >= gb;
+            if (tid == 0 && room && T) atomicAdd(&t.counters[7], N8 + N4 + N2 + N1);
+            if (room) {
+                if (kp) {
+                    const unsigned int e8 = (unsigned int)(excl & 255u), e4 = (unsigned int)((excl >> 8) & 255u), e2 = (unsigned int)((excl >> 16) & 255u), e1 = (unsigned int)((excl >> 24) & 255u);
+                    const unsigned int at = gb + (kp == 8 ? 8u * e8 : kp == 4 ? 8u * N8 + 4u * e4 : kp == 2 ? 8u * N8 + 4u * N4 + 2u * e2 : 8u * N8 + 4u * N4 + 2u * N2 + e1);
+                    const uint32_t rl = (uint32_t)b.read_len[r];
+                    for (int c = 0; c < kp; ++c) {
+                        Q16* dst = (Q16*)(ent2 + at + (unsigned int)c);
+                        if (c >= k) { dst[0] = Q16{JOINED_PAD, 0u, 0u, 0u}; continue; }
+                        uint32_t sl = 0;                   // the chain of rank c
+#pragma unroll
+                        for (int d = 0; d < CHAINS_MAX; ++d) sl = (d < k && q[d] == c) ? sel[d] : sl;
+                        uint32_t hx[CHAIN_MAXSEG];
+#pragma unroll
+                        for (int s = 0; s < CHAIN_MAXSEG; ++s) hx[s] = sof0 + ((sl >> (4 * (s < nsegs ? s : 0))) & 15u);
+                        dst[0] = Q16{r, chain_meta(nsegs, c, k, (int)rl), 0u, 0u};
+                        dst[1] = Q16{hx[0], hx[1], hx[2], hx[3]};
+                    }
+                }
+                if ((unsigned int)tid < T8 - T) ((Q16*)(ent2 + gb + T + (unsigned int)tid))[0] = Q16{JOINED_PAD, 0u, 0u, 0u};
+                if (declined) wl_pack[(u64)blk * (uint32_t)t.chunk + pack_n + (unsigned int)((excl >> 32) & 255u)] = r;
+                pack_n += ND;
+            } else {
+                // the dense list is full: what lies below its end is padding, and the round's reads all go on to the packed tier
+                for (unsigned int x = gb + (unsigned int)tid; x < cap2 && x - gb < T8; x += CH_TPB) ((Q16*)(ent2 + x))[0] = Q16{JOINED_PAD, 0u, 0u, 0u};
+                const unsigned int groups_before = (unsigned int)(excl & 255u) + (unsigned int)((excl >> 8) & 255u) + (unsigned int)((excl >> 16) & 255u) + (unsigned int)((excl >> 24) & 255u);
+                if (declined || kp) wl_pack[(u64)blk * (uint32_t)t.chunk + pack_n + (unsigned int)((excl >> 32) & 255u) + groups_before] = r;
+                pack_n += ND + N8 + N4 + N2 + N1;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) blk_pack[blk] = pack_n;
+    }
 }
 
 // Tier 2, packed: the multihit list, 64 entries per wave at a time, as chains over the lanes (span_pack_wave): a read with its
@@ -611,7 +801,7 @@ void thj_span_free(thj_ctx* c) {
     hipFree(c->d_span_junc); hipFree(c->d_span_cat); hipFree(c->d_span_ins_key); hipFree(c->d_span_ins_seq); hipFree(c->d_junc_bucket); hipFree(c->d_span_fus); hipFree(c->d_huge_ws); hipFree(c->d_huge_list);
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status);
-    for (auto& ss : c->span_set) { hipFree(ss.d_worklist); hipFree(ss.d_ent); hipFree(ss.d_joined); }
+    for (auto& ss : c->span_set) { hipFree(ss.d_worklist); hipFree(ss.d_ent); hipFree(ss.d_joined); hipFree(ss.d_defer); }
     for (auto& st : c->span_stream) if (st) hipStreamDestroy(st);
     for (auto& e : c->span_ev) if (e) hipEventDestroy(e);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -784,7 +974,7 @@ extern "C" int thj_span_reset_async(thj_ctx* c) {
     int rc = ensure_span_state(c);
     if (rc) return rc;
     HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 16, c->stream));       // [0] total records, [1] overflow-pool records
-    HIPCHK(hipMemsetAsync(c->d_span_status, 0, 16, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_span_status, 0, 32, c->stream));     // [0..3] statuses, [5] thj_k_join's "cannot happen"
     c->n_alns = 0;
     c->span_reads = 0;
     c->h_alns.clear();
@@ -897,13 +1087,19 @@ extern "C" int thj_span_fusions_from_segjuncs(thj_ctx* c) {
 // of a pass -- beside each other on both sets: the latency-bound kernels of one side overlap the bandwidth-bound tier 0 of the other.
 // Everything is joined on the context's stream before either call returns.
 static constexpr int SPAN_CNT_WORDS = 16;      // a set's counters: [0] reads to the closure kernels, [1] multihit, [2] general, [3] the packed tier's
-                                               // place in its list, [4] reads for thj_k_stitch_huge, [5] chain entries, [6] reads that travel as chain entries
-enum { SPK_CONTIG = 0, SPK_JOIN, SPK_FINISH, SPK_LEAN, SPK_PACK, SPK_GENERIC, SPK_N };
+                                               // place in its list, [4] reads for thj_k_stitch_huge, [5] entries in the dense list of the multihit reads' chains, [6] reads that
+                                               // travel as chain entries from tier 0, [7] multihit reads that travel as groups of chain entries
+enum { SPK_CONTIG = 0, SPK_CHAINS, SPK_JOIN, SPK_CLOSURE, SPK_FINISH, SPK_LEAN, SPK_PACK, SPK_GENERIC, SPK_N };
 
+// the dense list of the multihit reads' chains (thj_k_chains): room for one entry per read of the batch -- three times what SURVEY 8(d)'s
+// mix fills; a workgroup that finds it full hands its reads to the packed tier
+static int64_t chain_cap2(int64_t n_reads) { return (n_reads + 7) / 8 * 8 + 2048; }
+static int64_t chain_g2(int64_t G) { return G >= 4 ? G / 4 : 1; }
+static int64_t chain_slice2(int64_t n_reads, int64_t G) { const int64_t g2 = chain_g2(G); return (chain_cap2(n_reads) + g2 * 256 - 1) / (g2 * 256) * 256; }
 static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int64_t chunk, bool chains) {
     thj_ctx::SpanSet& ss = c->span_set[set];
     const int NC = SPAN_LEAN_CLASSES;
-    const int64_t wl_need = (2 + NC) * G * chunk + (2 + 2 * NC) * MAX_SLICES;
+    const int64_t wl_need = (3 + NC) * G * chunk + (3 + 2 * NC) * MAX_SLICES;
     if (ss.worklist_cap < wl_need) {
         HIPCHK(hipDeviceSynchronize());
         hipFree(ss.d_worklist); ss.d_worklist = nullptr; ss.worklist_cap = 0;
@@ -911,12 +1107,19 @@ static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int6
         ss.worklist_cap = wl_need;
     }
     if (chains) {
-        const int64_t ent_need = NC * G * chunk, j_need = G * chunk;
+        const int64_t cap2 = chain_cap2(n_reads), g2 = chain_g2(G);
+        const int64_t ent_need = NC * G * chunk + cap2, j_need = G * chunk + cap2, d_need = G * chunk + g2 * chain_slice2(n_reads, G) + G + g2 + 16;
         if (ss.ent_cap < ent_need) {
             HIPCHK(hipDeviceSynchronize());
             hipFree(ss.d_ent); ss.d_ent = nullptr; ss.ent_cap = 0;
             HIPCHK(hipMalloc(&ss.d_ent, (size_t)ent_need * sizeof(ChainEntry)));
             ss.ent_cap = ent_need;
+        }
+        if (ss.defer_cap < d_need) {
+            HIPCHK(hipDeviceSynchronize());
+            hipFree(ss.d_defer); ss.d_defer = nullptr; ss.defer_cap = 0;
+            HIPCHK(hipMalloc(&ss.d_defer, (size_t)d_need * 4));
+            ss.defer_cap = d_need;
         }
         if (ss.joined_cap < j_need) {
             HIPCHK(hipDeviceSynchronize());
@@ -965,15 +1168,18 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     t.wl_lean = ss.d_worklist;
     t.wl_multi = ss.d_worklist + NC * G * chunk;
     t.wl_gen = t.wl_multi + G * chunk;
-    t.blk_lean = t.wl_gen + G * chunk;
+    t.blk_lean = t.wl_gen + 2 * G * chunk;
     t.blk_multi = t.blk_lean + NC * MAX_SLICES;
     t.blk_gen = t.blk_multi + MAX_SLICES;
     t.blk_chain = t.blk_gen + MAX_SLICES;
+    uint32_t* const wl_pack = t.wl_gen + G * chunk;                          // what thj_k_chains leaves for the packed tier
+    unsigned int* const blk_pack = t.blk_chain + NC * MAX_SLICES;
     t.counters = &c->d_span_status[16 + SPAN_CNT_WORDS * set];
     t.chunk = (int)chunk;
     t.huge_list = c->d_huge_list; t.huge_cnt = t.counters + 4; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
     t.ent = chains ? (ChainEntry*)ss.d_ent : nullptr;
     t.ja = (Q16*)ss.d_joined; t.jb = t.ja ? t.ja + ss.joined_cap : nullptr; t.jc = t.ja ? t.ja + 2 * ss.joined_cap : nullptr;
+    t.status = c->d_span_status;
     HIPCHK(hipMemsetAsync(t.counters, 0, SPAN_CNT_WORDS * 4, sm));
     HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, sm));      // tiers 0 / 1 write the others
     c->span_last_set = set;
@@ -988,22 +1194,39 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MIDSEG>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
     else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
     SPK_END(SPK_CONTIG, sm);
-    // ---- the chain entries: join, then finish, beside the kernels of the other reads
+    // ---- the chains: those of the multihit reads that need no search join tier 0's entries (thj_k_chains); then join, closure
+    // search, finish on the side stream, beside the kernels of the reads that are left
+    Tiers tpk = t;                // the packed tier's view: the list thj_k_chains leaves
     if (chains) {
+        const int64_t cap2 = chain_cap2(b.n_reads), G2 = chain_g2(G);
+        unsigned int* const n2 = t.counters + 5;
+        ChainEntry* const ent2 = (ChainEntry*)ss.d_ent + NC * G * chunk;
+        SPK_BEGIN(SPK_CHAINS, sm);
+        hipLaunchKernelGGL(thj_k_chains, dim3((unsigned)G), dim3(CH_TPB), 0, sm, p, b, t, ent2, n2, (unsigned int)cap2, wl_pack, blk_pack, (int)G);
+        SPK_END(SPK_CHAINS, sm);
+        tpk.wl_multi = wl_pack; tpk.blk_multi = blk_pack;
         if (sa != sm) { HIPCHK(hipEventRecord(ev_fork, sm)); HIPCHK(hipStreamWaitEvent(sa, ev_fork, 0)); }
-        SPK_BEGIN(SPK_JOIN, sa);
-        const ChainLists cl{t.ent, t.blk_chain, (int)G, (int)chunk, t.ja, t.jb, t.jc};
+        const ChainLists cl{t.ent, t.blk_chain, (int)G, (int)chunk, ent2, n2, (int)G2, (unsigned int)cap2, (unsigned int)chain_slice2(b.n_reads, G), t.ja, t.jb, t.jc};
+        const DeferList dl{ss.d_defer, (unsigned int*)(ss.d_defer + G * chunk + G2 * chain_slice2(b.n_reads, G))};
         // THJ_JOIN_WPE / THJ_FIN_WPE = 3: developer switches -- three workgroups' worth of registers per CU (168 VGPRs) instead of four (128)
         static const int join_wpe = getenv("THJ_JOIN_WPE") ? atoi(getenv("THJ_JOIN_WPE")) : 4, fin_wpe = getenv("THJ_FIN_WPE") ? atoi(getenv("THJ_FIN_WPE")) : 4;
-        if (join_wpe == 3) hipLaunchKernelGGL(thj_k_join<3>, dim3((unsigned)G), dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t);
-        else hipLaunchKernelGGL(thj_k_join<4>, dim3((unsigned)G), dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t);
-        if (sa != sm) HIPCHK(hipEventRecord(ev_joined, sa));
+        const dim3 grid((unsigned)(G + G2));
+        SPK_BEGIN(SPK_JOIN, sa);
+        hipLaunchKernelGGL(thj_k_join<4>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
         SPK_END(SPK_JOIN, sa);
+        SPK_BEGIN(SPK_CLOSURE, sa);
+        if (join_wpe == 3) hipLaunchKernelGGL(thj_k_join_closure<3>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
+        else hipLaunchKernelGGL(thj_k_join_closure<4>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
+        SPK_END(SPK_CLOSURE, sa);
+        if (sa != sm) HIPCHK(hipEventRecord(ev_joined, sa));
         SPK_BEGIN(SPK_FINISH, sa);
-        if (fin_wpe == 3) hipLaunchKernelGGL(thj_k_finish<3>, dim3((unsigned)G), dim3(256), 0, sa, g, p, b, sink, cl);
-        else hipLaunchKernelGGL(thj_k_finish<4>, dim3((unsigned)G), dim3(256), 0, sa, g, p, b, sink, cl);
+        if (fin_wpe == 3) hipLaunchKernelGGL(thj_k_finish<3>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
+        else hipLaunchKernelGGL(thj_k_finish<4>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
         SPK_END(SPK_FINISH, sa);
-    } else { SPK_BEGIN(SPK_JOIN, sm); SPK_END(SPK_JOIN, sm); SPK_BEGIN(SPK_FINISH, sm); SPK_END(SPK_FINISH, sm); }
+    } else {
+        SPK_BEGIN(SPK_CHAINS, sm); SPK_END(SPK_CHAINS, sm); SPK_BEGIN(SPK_JOIN, sm); SPK_END(SPK_JOIN, sm);
+        SPK_BEGIN(SPK_CLOSURE, sm); SPK_END(SPK_CLOSURE, sm); SPK_BEGIN(SPK_FINISH, sm); SPK_END(SPK_FINISH, sm);
+    }
     const int64_t g1 = G, g2 = G;
     // THJ_LEAN_WPE = 2 | 3: developer switch -- tier 1 with two or three workgroups' worth of registers per CU (256 / 168 VGPRs, nothing
     // spilled) instead of four (128 VGPRs, 6 spilled): 0.92 / 0.75 ms per launch against 0.70 (profiles/r04_zzz_stage2_occupancy_ab2.txt;
@@ -1011,7 +1234,8 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     static const int lean_wpe = getenv("THJ_LEAN_WPE") ? atoi(getenv("THJ_LEAN_WPE")) : 4;
     const size_t lean_lds = (size_t)256 * b.nseg * sizeof(SpanHitHead);
     SPK_BEGIN(SPK_LEAN, sm);
-    if (b.nseg <= 4 && lean_wpe == 3) hipLaunchKernelGGL((thj_k_stitch<4, 3>), dim3((unsigned)((g1 * 3 + 3) / 4)), dim3(256), lean_lds, sm, g, p, S, b, sink, t, (int)G);
+    if (chains) { /* every one-hit-per-segment read travels as a chain entry: thj_k_stitch's list is empty */ }
+    else if (b.nseg <= 4 && lean_wpe == 3) hipLaunchKernelGGL((thj_k_stitch<4, 3>), dim3((unsigned)((g1 * 3 + 3) / 4)), dim3(256), lean_lds, sm, g, p, S, b, sink, t, (int)G);
     else if (b.nseg <= 4 && lean_wpe == 2) hipLaunchKernelGGL((thj_k_stitch<4, 2>), dim3((unsigned)((g1 + 1) / 2)), dim3(256), lean_lds, sm, g, p, S, b, sink, t, (int)G);
     else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch<4>, dim3((unsigned)g1), dim3(256), lean_lds, sm, g, p, S, b, sink, t, (int)G);
     else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch<SPAN_MIDSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), sm, g, p, S, b, sink, t, (int)G);
@@ -1041,10 +1265,10 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         // workgroups of eight waves (128 VGPRs, 43 spilled): 0.69 -> 0.635 ms per launch; THJ_PACK_WPE = 2 | 4: developer switch
         static const int pack_wpe = getenv("THJ_PACK_WPE") ? atoi(getenv("THJ_PACK_WPE")) : 3;
         SPK_BEGIN(SPK_PACK, sm);
-        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
-        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
-        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
-        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, t, (int)G, d_dbg);
+        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
+        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
+        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
+        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
         // (reads of more than eight segments: the packed tier keeps a chain's choices in eight bytes -- the general kernel takes the multihit list as it is)
         SPK_END(SPK_PACK, sm);
         if (pack_timing) {
@@ -1125,9 +1349,13 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
     int rc = ensure_span_state(c);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(&c->h_pinned[24], c->d_aln_count, 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&c->h_pinned[26], c->d_span_status, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&c->h_pinned[26], c->d_span_status, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const unsigned int* st = (const unsigned int*)&c->h_pinned[26];
+    if (st[5]) {      // thj_k_chains only lets through chains whose joined hit fits the registers' cigar ops: a chain of a group that does not is a bug, not an input
+        thj_set_error("internal: a chain of a multihit read needed more cigar ops than thj_k_join holds (set THJ_NO_CHAINS=1 and report)");
+        return THJ_ESTATE;
+    }
     if (st[3]) {
         // more 2nd.. records of multihit reads than the pool holds.  The counter kept counting, so the need is known: make the
         // pool that large (and then some) and ask for the pass again -- the slots are rewritten by the rerun, nothing is kept
@@ -1327,12 +1555,12 @@ extern "C" int thj_span_tier_counts(thj_ctx* c, int64_t* counts) {
     unsigned int h[SPAN_CNT_WORDS] = {};
     HIPCHK(hipMemcpyAsync(h, &c->d_span_status[16 + SPAN_CNT_WORDS * c->span_last_set], sizeof h, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    counts[0] = h[0]; counts[1] = h[1]; counts[2] = h[2]; counts[3] = h[6];
+    counts[0] = h[0]; counts[1] = h[1]; counts[2] = h[2]; counts[3] = h[6]; counts[4] = h[7];
     return THJ_OK;
 }
 
 extern "C" int thj_profile_span(thj_ctx* c, int enable, double* avg_ms, int64_t* launches) {
-    // avg_ms[6]: thj_k_stitch_contig, thj_k_join, thj_k_finish, thj_k_stitch, thj_k_stitch_pack, thj_k_stitch_generic / _fusion (one set per batch launched)
+    // avg_ms[8]: thj_k_stitch_contig, thj_k_chains, thj_k_join, thj_k_join_closure, thj_k_finish, thj_k_stitch, thj_k_stitch_pack, thj_k_stitch_generic / _fusion (one set per batch launched)
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));

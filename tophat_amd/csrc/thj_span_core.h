@@ -213,6 +213,10 @@ THJ_HD int plane_code(const Planes& p, int b) {
 THJ_HD u64 dna5_mism(const Planes& a, const Planes& b, int len) {
     return ((a.lo ^ b.lo) | (a.hi ^ b.hi) | (a.nm ^ b.nm)) & lowmask(len);
 }
+// the same whatever the lo / hi bits of an N position hold (base codes 0..3, 4 = N, compared as numbers)
+THJ_HD u64 raw_mism(const Planes& a, const Planes& b, int len) {
+    return ((((a.lo ^ b.lo) | (a.hi ^ b.hi)) & ~(a.nm & b.nm)) | (a.nm ^ b.nm)) & lowmask(len);
+}
 
 // ---- check_editdist_consistency (bwt_map.cpp:2349-2465) ------------------------------------
 THJ_HD bool check_editdist(const Genome& g, const Aln& h, const SeqView& sv) {
@@ -316,8 +320,10 @@ THJ_HD Closure closure_search(const Genome& g, const Params& p, const SpanSets& 
     }
     if (dist > 0 && dist <= p.max_report_intron && same_strand) {
         // ---- junction / deletion closure :1311-1591
+        if (THJ_EXPF(1 << 20)) return cl;
         if (g_len(g, ref) == 0) return cl;
         int64_t lb, ub;
+        if (THJ_EXPF(1 << 22)) return cl;
         junc_range(S, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true), junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false), lb, ub);
         const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
         int best_diff = 0xff;
@@ -329,23 +335,17 @@ THJ_HD Closure closure_search(const Genome& g, const Params& p, const SpanSets& 
             if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
             if (dtl > curr_front_len || -dtl > prev_end_len) continue;
             int new_mm = 0, old_mm = 0;
-            if (dtl > 0) {
-                Planes nr = g_fetch(g, ref, prev_right);      // new_cmp = ref[prev_right, jl+1)
-                Planes orf = g_fetch(g, ref, curr_left);      // old_cmp = ref[curr.left, jr)
-                for (int i = 0; i < dtl; ++i) {
-                    int s = seq_code(sv, P + i);               // curr.seq[i]; raw char vs Dna5: N == N
-                    if (s != plane_code(nr, i)) ++new_mm;
-                    if (s != plane_code(orf, i)) ++old_mm;
-                }
-            } else if (dtl < 0) {
-                int ad = -dtl;
-                Planes nr = g_fetch(g, ref, jr);               // new_cmp = ref[jr, curr.left)
-                Planes orf = g_fetch(g, ref, (int64_t)jl + 1); // old_cmp = ref[jl+1, prev_right)
-                for (int i = 0; i < ad; ++i) {
-                    int s = seq_code(sv, P - ad + i);
-                    if (s != plane_code(nr, i)) ++new_mm;
-                    if (s != plane_code(orf, i)) ++old_mm;
-                }
+            if (dtl != 0 && !THJ_EXPF(1 << 21)) {
+                // the boundary moves by |dtl| <= 4 bases: those bases of the read against the reference on the new side and on the old
+                // one (raw char vs Dna5: N == N, N != a base) -- both genome pieces and the read piece fetched together, compared as planes
+                const int ad = dtl > 0 ? dtl : -dtl;
+                // dtl > 0: new_cmp = ref[prev_right, jl+1), old_cmp = ref[curr.left, jr), the read's bases [P, P + dtl)
+                // dtl < 0: new_cmp = ref[jr, curr.left),    old_cmp = ref[jl+1, prev_right), the read's bases [P - ad, P)
+                const Planes nr = g_fetch_abs(g, cbase + (u64)(dtl > 0 ? prev_right : jr));
+                const Planes orf = g_fetch_abs(g, cbase + (u64)(dtl > 0 ? curr_left : jl + 1));
+                const Planes sq = seq_fetch(sv, dtl > 0 ? P : P - ad, ad);
+                new_mm = popc(raw_mism(nr, sq, ad));
+                old_mm = popc(raw_mism(orf, sq, ad));
             }
             int diff = new_mm - old_mm;
             if (diff >= best_diff || new_mm >= 2) continue;
@@ -1538,9 +1538,13 @@ THJ_HD int chain_q(uint32_t m) { return (int)((m >> 4) & 7u); }
 THJ_HD int chain_k(uint32_t m) { return (int)((m >> 7) & 7u) + 1; }
 THJ_HD int chain_rl(uint32_t m) { return (int)((m >> 10) & 1023u); }
 // A joined hit on its way to the finish kernel: two 16-byte words (+ one for cigar ops 4..7).
-// a.x = read (0xFFFFFFFF: nothing joined), a.y = contig, a.z = left, a.w = meta; b = cigar ops 0..3; c = ops 4..7 (n > 4 only)
-// meta: [0..3] n | [4] antisense | [5] antisense splice | [6] the read has one segment | [7..9] q | [10..12] k - 1 | [13..20] mismatches | [21..28] edit distance
-static constexpr uint32_t JOINED_NONE = 0xFFFFFFFFu;
+// a.x = read (JOINED_PAD: no entry there), a.y = contig, a.z = left, a.w = meta; b = cigar ops 0..3; c = ops 4..7 (n > 4 only)
+// meta: [0..3] n (0: nothing joined) | [4] antisense | [5] antisense splice | [6] the read has one segment | [7..9] q | [10..12] k - 1 | [13..20] mismatches | [21..28] edit distance
+static constexpr uint32_t JOINED_PAD = 0xFFFFFFFFu;
+THJ_HD uint32_t joined_none_meta(int q, int k) { return ((uint32_t)q << 7) | ((uint32_t)(k - 1) << 10); }
+THJ_HD int joined_n(uint32_t m) { return (int)(m & 15u); }
+THJ_HD int joined_q(uint32_t m) { return (int)((m >> 7) & 7u); }
+THJ_HD int joined_k(uint32_t m) { return (int)((m >> 10) & 7u) + 1; }
 THJ_HD uint32_t joined_meta(const RAln& r, bool one_seg, int q, int k) {
     return (uint32_t)r.n | (r.anti ? 16u : 0u) | (r.asplice ? 32u : 0u) | (one_seg ? 64u : 0u) | ((uint32_t)q << 7) | ((uint32_t)(k - 1) << 10) |
            ((uint32_t)(r.mm & 0xFF) << 13) | ((uint32_t)(r.ed & 0xFF) << 21);
@@ -1567,6 +1571,93 @@ THJ_HD int chain_join(const Genome& g, const Params& p, const SpanSets& S, const
     if (res.mm > p.read_mismatches || gapl > p.read_gap_length || res.ed > p.read_edit_dist) return LJ_NONE;
     return LJ_OK;
 }
+
+// ---- the chains of a multihit read without a sort (thj_k_chains) -------------------------------------------------------------
+// dfs_seg_hits (long_spanning_reads.cpp:2222-2610) chains hits of one contig and strand that lie within [-max_insertion_length,
+// max_report_intron] of each other, from every first-segment hit on its own (num_try is per first-segment hit, :2634-2664).  When no
+// hit of the read has more than ONE such successor in the next segment, every first-segment hit starts at most one chain, and a read
+// whose segments map to c copies of a repeat -- the bulk of the multihit reads -- is c independent chains.  JoinSegmentsWorker then
+// sorts the joined hits by BowtieHit::operator< (bwt_map.h:180-207: contig, left, strand, then mismatches ... cigar), drops equal
+// neighbours and numbers what passes the filters (:2805-2813).  A joined hit's contig, left and strand are those of its chain's
+// leftmost hit, known before the join: when the chains of a read differ in (contig, left, strand), their order is known up front (and
+// no two are equal), so each can travel as a chain entry with its rank q among the read's k chains, be joined and finished on a
+// lane of its own, and the finish kernel only has to count the lower-ranked siblings that were reported.  Anything else -- a hit
+// with two successors, more than CHAINS_MAXHITS hits or CHAINS_MAX chains, two chains with one (contig, left, strand) -- is declined
+// and stays with thj_k_stitch_pack.
+static constexpr int CHAINS_MAXHITS = 16, CHAINS_MAX = 8;
+enum { CHAINS_DECLINE = -1 };
+// Tab: the read's hits, numbered from its first (segment s: numbers off[s] .. off[s + 1]): head(j) = {ref_id, left, meta, right end}
+// Out: sel[c] = the hit numbers of chain c, four bits per segment; q[c] = its rank.  Returns the number of chains (0: the read has none).
+template <class Tab>
+THJ_HD int chains_discover(const Params& p, const Tab& tab, const uint32_t* off /* [nsegs + 1], relative */, int nsegs, uint32_t (&sel)[CHAINS_MAX], int (&q)[CHAINS_MAX]) {
+    const int nh = (int)off[nsegs], roots = (int)off[1];
+    if (nh > CHAINS_MAXHITS || roots > CHAINS_MAX || nsegs > CHAIN_MAXSEG) return CHAINS_DECLINE;
+    // every hit's successor in the next segment (four bits each), and whether it has one
+    u64 succ = 0; uint32_t has = 0, gap = 0;        // gap: the hit does not abut its successor (the join will search a closure there: one more cigar op)
+    for (int s = 0; s + 1 < nsegs; ++s)
+        for (int j = (int)off[s]; j < (int)off[s + 1]; ++j) {
+            const SpanHitHead me = tab.head(j);
+            const bool anti = (me.meta & SH_ANTI) != 0;
+            int first = 0, nc = 0; bool fgap = false;
+            for (int c = (int)off[s + 1]; c < (int)off[s + 2]; ++c) {
+                const SpanHitHead o = tab.head(c);
+                const int dist = anti ? me.left - (int32_t)o.cigar0 : o.left - (int32_t)me.cigar0;      // :2352-2378, :2531-2556 (cigar0 holds the right end)
+                const bool okc = o.ref_id == me.ref_id && ((o.meta & SH_ANTI) != 0) == anti && dist <= p.max_report_intron && dist >= -p.max_insertion_length;
+                fgap = (okc && nc == 0) ? dist != 0 : fgap;
+                first = (okc && nc == 0) ? c : first;
+                nc += okc ? 1 : 0;
+            }
+            if (nc > 1) return CHAINS_DECLINE;
+            succ |= (u64)first << (4 * j);
+            has |= nc ? 1u << j : 0u;
+            gap |= fgap ? 1u << j : 0u;
+        }
+    int k = 0;
+    for (int i = 0; i < roots; ++i) {
+        int j = i; uint32_t sl = (uint32_t)i; bool ok = true;
+        int ops = (int)(tab.head(i).meta >> 24);          // cigar ops the joined hit can have at most: the hits' own and one per closure
+        for (int d = 1; d < nsegs; ++d) {
+            if (!((has >> j) & 1u)) { ok = false; break; }
+            ops += (int)((gap >> j) & 1u);
+            const int nx = (int)((succ >> (4 * j)) & 15u);
+            j = nx; sl |= (uint32_t)nx << (4 * d);
+            ops += (int)(tab.head(nx).meta >> 24);
+        }
+        if (ok && ops > LEAN_C) return CHAINS_DECLINE;      // (such a chain could need the general tier: the whole read stays together)
+        if (ok) {
+#pragma unroll
+            for (int c = 0; c < CHAINS_MAX; ++c) sel[c] = c == k ? sl : sel[c];
+            ++k;
+        }
+    }
+    // ranks by (contig, left of the leftmost hit, strand); two chains with one key: declined
+    for (int a = 0; a < k; ++a) {
+        uint32_t sa = 0;
+#pragma unroll
+        for (int c = 0; c < CHAINS_MAX; ++c) sa = c == a ? sel[c] : sa;
+        const SpanHitHead ra = tab.head((int)(sa & 15u));
+        const bool aa = (ra.meta & SH_ANTI) != 0;
+        const int32_t la = aa ? tab.head((int)((sa >> (4 * (nsegs - 1))) & 15u)).left : ra.left;
+        int rank = 0;
+        for (int b = 0; b < k; ++b) {
+            if (b == a) continue;
+            uint32_t sb = 0;
+#pragma unroll
+            for (int c = 0; c < CHAINS_MAX; ++c) sb = c == b ? sel[c] : sb;
+            const SpanHitHead rb = tab.head((int)(sb & 15u));
+            const bool ab = (rb.meta & SH_ANTI) != 0;
+            const int32_t lb = ab ? tab.head((int)((sb >> (4 * (nsegs - 1))) & 15u)).left : rb.left;
+            if (rb.ref_id == ra.ref_id && lb == la && ab == aa) return CHAINS_DECLINE;
+            const bool less = rb.ref_id != ra.ref_id ? rb.ref_id < ra.ref_id : (lb != la ? lb < la : (!ab && aa));
+            rank += less ? 1 : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < CHAINS_MAX; ++c) q[c] = c == a ? rank : q[c];
+    }
+    return k;
+}
+// the padded size of a group of k chains: groups of one size are laid out at multiples of that size, so that none straddles a wave
+THJ_HD int chains_padded(int k) { return k <= 1 ? 1 : (k <= 2 ? 2 : (k <= 4 ? 4 : 8)); }
 
 // ---- tier 0: reads whose single hits per segment are plain matches that abut in read order ----------------
 // (an unspliced read cut into segments: ~60 % of real data).  merge_chain leaves every pair untouched
@@ -1759,18 +1850,16 @@ THJ_HD bool joined_extras(const Genome& g, const Params& p, const RAln& h, bool 
     return true;
 }
 
-// one joined hit (its packed words) -> filters' last part, tags, the record with rank `order` among the read's records; false: not reported
-template <class Sink>
-THJ_HD bool joined_finish(const Genome& g, const Params& p, const Q16& ja, const Q16& jb, const Q16& jc, const u64* planes, int W,
-                          const uint16_t* read_len, const uint8_t* quals, int qual_stride, int order, Sink& sink) {
-    RAln res; bool one_seg; int q, k;
+// one joined hit (its packed words) -> the filters' last part and the tags; false: not reported.  The caller emits the record
+// (emit_aln) once it knows the record's rank among the read's records.
+THJ_HD bool joined_prepare(const Genome& g, const Params& p, const Q16& ja, const Q16& jb, const Q16& jc, const u64* planes, int W,
+                           const uint16_t* read_len, const uint8_t* quals, int qual_stride, RAln& res, Extras& e) {
+    bool one_seg; int q, k;
     joined_unpack(ja, jb, jc, res, one_seg, q, k);
     const uint32_t r = ja.x;
     const u64* rp = planes + (u64)r * (uint32_t)(3 * W);
     const int rl = (int)read_len[r];
     const uint8_t* qual = quals + (u64)r * (uint32_t)qual_stride;
-    Extras e;
-    bool ok;
     if (W <= 2) {
         RegRead rw;
 #pragma unroll
@@ -1779,10 +1868,16 @@ THJ_HD bool joined_finish(const Genome& g, const Params& p, const Q16& ja, const
 #pragma unroll
             for (int i = 0; i < 6; ++i) rw.v[i] = rp[i];
         } else { rw.v[0] = rp[0]; rw.v[2] = rp[1]; rw.v[4] = rp[2]; }
-        ok = joined_extras(g, p, res, one_seg, rw, rl, qual, e);
-    } else ok = joined_extras(g, p, res, one_seg, MemRead{rp, W}, rl, qual, e);
-    if (!ok) return false;
-    emit_aln(sink, r, order, res, e);
+        return joined_extras(g, p, res, one_seg, rw, rl, qual, e);
+    }
+    return joined_extras(g, p, res, one_seg, MemRead{rp, W}, rl, qual, e);
+}
+template <class Sink>
+THJ_HD bool joined_finish(const Genome& g, const Params& p, const Q16& ja, const Q16& jb, const Q16& jc, const u64* planes, int W,
+                          const uint16_t* read_len, const uint8_t* quals, int qual_stride, int order, Sink& sink) {
+    RAln res; Extras e;
+    if (!joined_prepare(g, p, ja, jb, jc, planes, W, read_len, quals, qual_stride, res, e)) return false;
+    emit_aln(sink, ja.x, order, res, e);
     return true;
 }
 THJ_HD void joined_pack(const RAln& res, uint32_t read, bool one_seg, int q, int k, Q16& ja, Q16& jb, Q16& jc) {

@@ -682,27 +682,33 @@ def _span_methods():
 
     def span_tier_counts(self):
         """of the batch launched last: reads to the closure kernels, to the multihit kernel, on to the general kernel"""
-        c = (C.c_int64 * 4)()
+        c = (C.c_int64 * 5)()
         _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
         return int(c[0]), int(c[1]), int(c[2])
 
     def span_chain_count(self):
         """of the batch launched last: the reads that travelled as chain entries (tier 0 -> thj_k_join -> thj_k_finish)"""
-        c = (C.c_int64 * 4)()
+        c = (C.c_int64 * 5)()
         _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
         return int(c[3])
 
-    Context.SPAN_KERNELS = ("thj_k_stitch_contig", "thj_k_join", "thj_k_finish", "thj_k_stitch", "thj_k_stitch_pack", "thj_k_stitch_generic")
+    def span_chain_groups(self):
+        """of the batch launched last: the multihit reads whose chains travelled as chain entries (thj_k_chains)"""
+        c = (C.c_int64 * 5)()
+        _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
+        return int(c[4])
+
+    Context.SPAN_KERNELS = ("thj_k_stitch_contig", "thj_k_chains", "thj_k_join", "thj_k_join_closure", "thj_k_finish", "thj_k_stitch", "thj_k_stitch_pack", "thj_k_stitch_generic")
 
     def profile_span(self, enable: bool = True):
         """-> ([ms per launch of each entry of SPAN_KERNELS], launches)"""
-        ms = (C.c_double * 6)()
+        ms = (C.c_double * 8)()
         n = C.c_int64()
         _check(self.lib, self.lib.thj_profile_span(self._ctx, 1 if enable else 0, ms, C.byref(n)), "thj_profile_span")
         return list(ms), n.value
 
     for f in (upload_span_fusions, upload_span_sets, span_sets_from_segjuncs, span_fusions_from_segjuncs, fusion_search, upload_span_batch, span_reset, span_run, span_finish,
-              span_download, spanning, profile_span, span_tier_counts, span_hit_heads, span_run_pair, span_chain_count):
+              span_download, spanning, profile_span, span_tier_counts, span_hit_heads, span_run_pair, span_chain_count, span_chain_groups):
         setattr(Context, f.__name__, f)
 
 
