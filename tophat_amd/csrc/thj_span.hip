@@ -564,9 +564,15 @@ __global__ __launch_bounds__(CH_TPB) void thj_k_chains(Params p, DevSpanBatch b,
                     const uint32_t nh = end_so - sof[0];
                     k = CHAINS_DECLINE;
                     if (nh <= (uint32_t)CHAINS_MAXHITS) {
-                        for (uint32_t h = 0; h < nh; ++h) {
-                            const Q16 hq = load_head(b.hits, b.heads, (u64)sof[0] + h);
-                            s_head[h * CH_TPB + tid] = Q16{hq.x, hq.y, hq.z, (uint32_t)pack_hit_right(hq, b.hits, (u64)sof[0] + h)};
+                        // the heads eight at a time, all in flight together (one after the other behind pack_hit_right's branch they were
+                        // sixteen round trips)
+                        for (uint32_t h0 = 0; h0 < nh; h0 += 8) {
+                            Q16 hq[8];
+#pragma unroll
+                            for (int x = 0; x < 8; ++x) hq[x] = load_head(b.hits, b.heads, (u64)sof[0] + (h0 + x < nh ? h0 + x : nh - 1));
+#pragma unroll
+                            for (int x = 0; x < 8; ++x)
+                                if (h0 + x < nh) s_head[(h0 + x) * CH_TPB + tid] = Q16{hq[x].x, hq[x].y, hq[x].z, (uint32_t)pack_hit_right(hq[x], b.hits, (u64)sof[0] + h0 + x)};
                         }
                         uint32_t off[CHAIN_MAXSEG + 1];
 #pragma unroll
@@ -1208,8 +1214,9 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         if (sa != sm) { HIPCHK(hipEventRecord(ev_fork, sm)); HIPCHK(hipStreamWaitEvent(sa, ev_fork, 0)); }
         const ChainLists cl{t.ent, t.blk_chain, (int)G, (int)chunk, ent2, n2, (int)G2, (unsigned int)cap2, (unsigned int)chain_slice2(b.n_reads, G), t.ja, t.jb, t.jc};
         const DeferList dl{ss.d_defer, (unsigned int*)(ss.d_defer + G * chunk + G2 * chain_slice2(b.n_reads, G))};
-        // THJ_JOIN_WPE / THJ_FIN_WPE = 3: developer switches -- three workgroups' worth of registers per CU (168 VGPRs) instead of four (128)
-        static const int join_wpe = getenv("THJ_JOIN_WPE") ? atoi(getenv("THJ_JOIN_WPE")) : 4, fin_wpe = getenv("THJ_FIN_WPE") ? atoi(getenv("THJ_FIN_WPE")) : 4;
+        // THJ_JOIN_WPE = 4 / THJ_FIN_WPE = 3: developer switches -- thj_k_join_closure with four workgroups' worth of registers per CU (128 VGPRs,
+        // 44 spilled) instead of three (162, nothing spilled), thj_k_finish the other way round
+        static const int join_wpe = getenv("THJ_JOIN_WPE") ? atoi(getenv("THJ_JOIN_WPE")) : 3, fin_wpe = getenv("THJ_FIN_WPE") ? atoi(getenv("THJ_FIN_WPE")) : 4;
         const dim3 grid((unsigned)(G + G2));
         SPK_BEGIN(SPK_JOIN, sa);
         hipLaunchKernelGGL(thj_k_join<4>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);

@@ -322,35 +322,62 @@ THJ_HD Closure closure_search(const Genome& g, const Params& p, const SpanSets& 
         // ---- junction / deletion closure :1311-1591
         if (THJ_EXPF(1 << 20)) return cl;
         if (g_len(g, ref) == 0) return cl;
-        int64_t lb, ub;
+        // the candidates: the keys in (klo, khi), in order.  With the bucket index: from the first key of klo's 256-base bucket on,
+        // FOUR KEYS A ROUND TRIP (a bucket of a deletion-rich exon holds a dozen keys; walked one dependent load at a time the
+        // scan was 0.14 of thj_k_join_closure's 0.21 ms); without it: the two binary searches
+        const u64 klo = junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true), khi = junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false);
+        int64_t i, e;
         if (THJ_EXPF(1 << 22)) return cl;
-        junc_range(S, junc_key(g, ref, (uint32_t)lbnd, (uint32_t)(rbnd - 8), true), junc_key(g, ref, (uint32_t)(lbnd + 8), (uint32_t)rbnd, false), lb, ub);
+        if (!S.junc_bucket) { i = upper_bound_u64(S.junc_keys, S.n_juncs, klo); e = lower_bound_u64(S.junc_keys, S.n_juncs, khi); }
+        else {
+            int64_t b0 = (int64_t)((klo >> 30) >> JUNC_BUCKET_SHIFT), b1 = (int64_t)((khi >> 30) >> JUNC_BUCKET_SHIFT) + 1;
+            if (b0 > S.n_buckets) b0 = S.n_buckets;
+            if (b1 > S.n_buckets) b1 = S.n_buckets;
+            i = S.junc_bucket[b0]; e = S.junc_bucket[b1];
+            // a crowded bucket (a hundred deletions in one exon of the bench's mix): bisect to the first key past klo instead of walking there
+            if (e - i > 8) i += upper_bound_u64(S.junc_keys + i, e - i, klo);
+        }
         const u64 cbase = (u64)g.contig_blk[ref - 1] * 64ull;
         int best_diff = 0xff;
-        for (; lb < ub; ++lb) {
-            const u64 k = S.junc_keys[lb];
-            const int jl = (int)((int64_t)(k >> 30) - 1 - (int64_t)cbase);
-            const int jr = jl + (int)((k >> 1) & ((1ull << 29) - 1));
-            const int dtl = jl - prev_right + 1, dtr = jr - curr_left;
-            if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
-            if (dtl > curr_front_len || -dtl > prev_end_len) continue;
-            int new_mm = 0, old_mm = 0;
-            if (dtl != 0 && !THJ_EXPF(1 << 21)) {
-                // the boundary moves by |dtl| <= 4 bases: those bases of the read against the reference on the new side and on the old
-                // one (raw char vs Dna5: N == N, N != a base) -- both genome pieces and the read piece fetched together, compared as planes
-                const int ad = dtl > 0 ? dtl : -dtl;
-                // dtl > 0: new_cmp = ref[prev_right, jl+1), old_cmp = ref[curr.left, jr), the read's bases [P, P + dtl)
-                // dtl < 0: new_cmp = ref[jr, curr.left),    old_cmp = ref[jl+1, prev_right), the read's bases [P - ad, P)
-                const Planes nr = g_fetch_abs(g, cbase + (u64)(dtl > 0 ? prev_right : jr));
-                const Planes orf = g_fetch_abs(g, cbase + (u64)(dtl > 0 ? curr_left : jl + 1));
-                const Planes sq = seq_fetch(sv, dtl > 0 ? P : P - ad, ad);
-                new_mm = popc(raw_mism(nr, sq, ad));
-                old_mm = popc(raw_mism(orf, sq, ad));
+        bool past = false;
+        for (; i < e && !past; i += 4) {
+            u64 kk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kk[j] = S.junc_keys[i + j < e ? i + j : e - 1];
+            uint32_t cand = 0;                    // which of the four lie in (klo, khi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = !past && i + j < e && kk[j] > klo;
+                if (in && kk[j] >= khi) past = true;
+                cand |= (in && kk[j] < khi) ? 1u << j : 0u;
             }
-            int diff = new_mm - old_mm;
-            if (diff >= best_diff || new_mm >= 2) continue;
-            best_diff = diff;
-            cl.kind = CL_JUNC; cl.dtl = dtl; cl.skip = jr - jl - 1; cl.janti = (int)(k & 1ull); cl.mismatch = diff;
+            while (cand) {
+                const int j = ctz((u64)cand);
+                cand &= cand - 1;
+                const u64 k = j == 0 ? kk[0] : (j == 1 ? kk[1] : (j == 2 ? kk[2] : kk[3]));
+                const int jl = (int)((int64_t)(k >> 30) - 1 - (int64_t)cbase);
+                const int jr = jl + (int)((k >> 1) & ((1ull << 29) - 1));
+                const int dtl = jl - prev_right + 1, dtr = jr - curr_left;
+                if (!(dtl >= -4 && dtl <= 4 && dtr >= -4 && dtr <= 4 && dtl == dtr)) continue;
+                if (dtl > curr_front_len || -dtl > prev_end_len) continue;
+                int new_mm = 0, old_mm = 0;
+                if (dtl != 0 && !THJ_EXPF(1 << 21)) {
+                    // the boundary moves by |dtl| <= 4 bases: those bases of the read against the reference on the new side and on the old
+                    // one (raw char vs Dna5: N == N, N != a base) -- both genome pieces and the read piece fetched together, compared as planes
+                    const int ad = dtl > 0 ? dtl : -dtl;
+                    // dtl > 0: new_cmp = ref[prev_right, jl+1), old_cmp = ref[curr.left, jr), the read's bases [P, P + dtl)
+                    // dtl < 0: new_cmp = ref[jr, curr.left),    old_cmp = ref[jl+1, prev_right), the read's bases [P - ad, P)
+                    const Planes nr = g_fetch_abs(g, cbase + (u64)(dtl > 0 ? prev_right : jr));
+                    const Planes orf = g_fetch_abs(g, cbase + (u64)(dtl > 0 ? curr_left : jl + 1));
+                    const Planes sq = seq_fetch(sv, dtl > 0 ? P : P - ad, ad);
+                    new_mm = popc(raw_mism(nr, sq, ad));
+                    old_mm = popc(raw_mism(orf, sq, ad));
+                }
+                const int diff = new_mm - old_mm;
+                if (diff >= best_diff || new_mm >= 2) continue;
+                best_diff = diff;
+                cl.kind = CL_JUNC; cl.dtl = dtl; cl.skip = jr - jl - 1; cl.janti = (int)(k & 1ull); cl.mismatch = diff;
+            }
         }
         return cl;                                                                     // CL_FAIL unless found
     }
