@@ -266,3 +266,38 @@ def test_two_rank_coverage_search_through_the_collective():
     for r in (0, 1):
         assert found[r] == want_found
         assert_events_equal(got[r], want, "coverage search, rank %d" % r)
+
+
+def test_full_task_list_fails_loudly_with_an_exchange_step_pending(monkeypatch):
+    """the task list of one rank fills up (THJ_XTASK_CAP = 8): its events are incomplete, so after the exchange step the pass must
+    fail on that rank with the task-list message and on its peer with the overflow verdict of the gathered headers -- never a
+    silently smaller event set (round 4 looked at that flag only without an exchange step)"""
+    from test_gpu_segjuncs import rescue_heavy_batch
+    seq, heavy = rescue_heavy_batch(big=((7, 40, 1), (70, 30, 2), (140, 40, 3), (141, 5, 1), (290, 64, 1)))
+    _, light = rescue_heavy_batch(n_reads=40, seed=12)
+    monkeypatch.setenv("THJ_XTASK_CAP", "8")
+    errs = [None, None]
+    with host.Context(0) as a, host.Context(0) as b:
+        ctxs = (a, b)
+        pg = host.pack_genome([seq])
+        handles = []
+        for ctx, part in zip(ctxs, (heavy, light)):
+            ctx.upload_genome(pg)
+            handles.append(ctx.upload_batch(part))
+        comms = host.Comm.create_local(ctxs)
+
+        def rank(r):
+            def go():
+                ctxs[r].reset()
+                ctxs[r].run(Params(), handles[r])
+                comms[r].events_allgather()
+                try:
+                    ctxs[r].finish()
+                except host.ThjError as e:
+                    errs[r] = str(e)
+            return go
+        _in_threads([rank(0), rank(1)])
+        for c in comms:
+            c.close()
+    assert errs[0] is not None and "task list" in errs[0]
+    assert errs[1] is not None and "overflow" in errs[1]

@@ -56,7 +56,7 @@ def test_span_logic_matches_oracle(cfg):
         got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)
         chains = sim.lib().hostsim_chain_reads()
         deferred = sim.lib().hostsim_chain_deferred()
-        assert 0 < deferred <= chains or chains == 0, (chains, deferred)
+        assert deferred > 0 or chains == 0, (chains, deferred)         # (the chains of multihit reads count among the deferred too)
         if cfg["seed"] == 2 and chains:
             assert deferred < chains                                 # both passes of the join see reads
         assert (chains > 0) == (mode in (0, 3) and cfg["read_len"] // cfg["seg_len"] <= 4), (mode, chains)

@@ -208,8 +208,8 @@ static void encode_aln(const BamWriter& bw, const RefTable& rt, const thj_aln& a
     aux.push_back("XG:i:" + std::to_string((int)a.XG));
     if (a.md_len == THJ_MD_ON_HOST) {                       // longer than a device record holds: rebuilt here from the same inputs
         char md[2048];
-        const std::string& ref = rt.seqs[a.ref_id - 1];
-        const std::string& ref2 = rt.seqs[ref_id2 - 1];
+        const std::string& ref = const_cast<RefTable&>(rt).text(a.ref_id);
+        const std::string& ref2 = const_cast<RefTable&>(rt).text(ref_id2);
         const int n = fi >= 0 ? thj_md_string2(ref.data(), (int64_t)ref.size(), ref2.data(), (int64_t)ref2.size(), seq.data(), (int32_t)seq.size(), a.left,
                                                a.cigar, a.n_cigar, md, (int32_t)sizeof md)
                               : thj_md_string(ref.data(), (int64_t)ref.size(), seq.data(), (int32_t)seq.size(), a.left, a.cigar, a.n_cigar, md, (int32_t)sizeof md);
@@ -317,7 +317,7 @@ static int real_main(int argc, char** argv) {
     RefTable rt;
     rt.load_sam_header(o.sam_header);
     fprintf(stderr, "Loading reference sequences...\n");
-    std::future<void> fasta_loaded = std::async(std::launch::async, [&rt, &pos]() { rt.load_fasta(pos[0]); });
+    std::future<void> fasta_loaded = std::async(std::launch::async, [&rt, &pos]() { rt.load_reference(pos[0], pos[6]); });
     std::vector<std::unique_ptr<Gpu>> gpus;
     {
         int n_dev = 1, first = 0;
@@ -938,6 +938,7 @@ static int real_main(int argc, char** argv) {
     { static const char* const nm[4] = {"shards (ingest + merge + device + encode)", "  waiting for the GPU's lock", "  device calls (upload, stitch, download)", "  record encoding"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime down after a context has been used takes ~0.2 s that nobody is waiting for.
+    rt.finish_cache();                 // (the packed-genome cache's writer, when this process was the one to pack the reference)
     finish_outputs_complete(0);
 }
 

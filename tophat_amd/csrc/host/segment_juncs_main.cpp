@@ -309,7 +309,7 @@ static int real_main(int argc, char** argv) {
     RefTable rt;
     rt.load_sam_header(o.sam_header);
     fprintf(stderr, "Loading reference sequences...\n");
-    std::future<void> fasta_loaded = std::async(std::launch::async, [&rt, &pos]() { rt.load_fasta(pos[0]); });
+    std::future<void> fasta_loaded = std::async(std::launch::async, [&rt, &pos]() { rt.load_reference(pos[0], pos[1]); });
     std::vector<std::unique_ptr<Gpu>> gpus;
     {
         int n_dev = 1, first = 0;
@@ -632,6 +632,7 @@ static int real_main(int argc, char** argv) {
     { static const char* const nm[4] = {"shards (ingest + merge + pack + device)", "  waiting for the GPU's lock", "  device calls (upload, launch, free)", "  -"}; g_work.report(nm); }
     // Everything is written and closed.  Leave without running the exit handlers or freeing the contexts: tearing the HIP
     // runtime (and RCCL) down after use takes tenths of a second that nobody is waiting for.
+    rt.finish_cache();                 // (the packed-genome cache's writer, when this process was the one to pack the reference)
     finish_outputs_complete(0);
 }
 

@@ -9,6 +9,7 @@
 #pragma once
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <dlfcn.h>
 #include <getopt.h>
 #include <stdint.h>
@@ -477,10 +478,142 @@ struct RefTable {
     // pack (once) + upload (to every GPU's context) through the C ABI
     std::once_flag packed_once;
     std::vector<uint64_t> packed; std::vector<uint32_t> packed_blk; std::vector<int64_t> packed_lens; int64_t packed_nb = 0;
+    const uint64_t* packed_ptr = nullptr;           // the blocks: `packed`, or the mapped cache file
+
+    // ---- the packed-genome cache.  tophat.py starts three processes on one reference (segment_juncs, long_spanning_reads per side), and
+    // each of them parses and packs the FASTA (as the reference's do, segment_juncs.cpp:64-88, long_spanning_reads.cpp:2891): seconds
+    // each for a 3 Gb genome, against a budget of seconds for the whole run at north_star's rate.  The first process that packs a
+    // genome writes the blocks beside its outputs (`<cache>`: names, lengths, block offsets, the 32-byte blocks); a later process
+    // whose FASTA has the same size and modification time, and whose @SQ names are a prefix of the cached name table, maps the file
+    // instead -- the page cache serves it -- and never sees the text.  THJ_GENOME_CACHE=0 turns it off, =<dir> puts it elsewhere.
+    std::string fasta_path, cache_file;             // cache_file empty: no cache
+    void* mapped = nullptr; size_t mapped_bytes = 0;
+    bool from_cache = false;
+    size_t cached_names = 0;                        // names in the table when the cache was adopted
+    std::future<void> cache_writer;
+    struct CacheHeader { char magic[8]; uint64_t fasta_size; int64_t fasta_mtime_ns; uint64_t n_names, n_blocks, names_bytes, header_bytes; };
+    static constexpr const char* CACHE_MAGIC = "THJ2BIT\2";
+    static std::string cache_path_for(const std::string& fasta, const std::string& out_file) {
+        const char* e = getenv("THJ_GENOME_CACHE");
+        if (e && !strcmp(e, "0")) return "";
+        std::string dir = e && *e ? std::string(e) : (out_file.find('/') == std::string::npos ? std::string(".") : out_file.substr(0, out_file.rfind('/')));
+        char* rp = realpath(fasta.c_str(), nullptr);
+        const std::string key = rp ? rp : fasta;
+        free(rp);
+        uint64_t h = 1469598103934665603ull;
+        for (unsigned char ch : key) { h ^= ch; h *= 1099511628211ull; }
+        char buf[64]; snprintf(buf, sizeof buf, "/.thj2bit.%016llx", (unsigned long long)h);
+        return dir + buf;
+    }
+    static bool fasta_stat(const std::string& fn, uint64_t& size, int64_t& mtime_ns) {
+        struct stat st;
+        if (stat(fn.c_str(), &st) || !S_ISREG(st.st_mode)) return false;
+        size = (uint64_t)st.st_size; mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+        return true;
+    }
+    // the reference: from the cache when it is there and fits, else from the FASTA (and the cache is written once the genome is packed)
+    void load_reference(const std::string& fasta, const std::string& out_file) {
+        fasta_path = fasta;
+        cache_file = cache_path_for(fasta, out_file);
+        if (!cache_file.empty() && load_cache()) return;
+        load_fasta(fasta);
+    }
+    bool load_cache() {
+        uint64_t fsz; int64_t fmt;
+        if (!fasta_stat(fasta_path, fsz, fmt)) return false;
+        const int fd = open(cache_file.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        CacheHeader h;
+        bool ok = !fstat(fd, &st) && (size_t)st.st_size >= sizeof h && pread(fd, &h, sizeof h, 0) == (ssize_t)sizeof h && !memcmp(h.magic, CACHE_MAGIC, 8) &&
+                  h.fasta_size == fsz && h.fasta_mtime_ns == fmt && h.n_names < (1ull << 31) && (uint64_t)st.st_size == h.header_bytes + h.n_blocks * 32;
+        void* m = MAP_FAILED;
+        if (ok) { m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0); ok = m != MAP_FAILED; }
+        close(fd);
+        if (!ok) return false;
+        const char* base = (const char*)m;
+        const char* nm = base + sizeof h;
+        const int64_t* lens = (const int64_t*)(nm + ((h.names_bytes + 7) & ~7ull));
+        const uint32_t* blk = (const uint32_t*)(lens + h.n_names);
+        // the cached table: the names this process knows so far (--sam-header's @SQ lines, in order) must lead it
+        std::vector<std::string> cn;
+        { const char* q = nm; for (uint64_t i = 0; i < h.n_names; ++i) { cn.emplace_back(q); q += cn.back().size() + 1; } }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            ok = names.size() <= cn.size();
+            for (size_t i = 0; ok && i < names.size(); ++i) ok = names[i] == cn[i];
+            if (ok) for (size_t i = names.size(); i < cn.size(); ++i) get_id_locked(cn[i]);
+        }
+        if (!ok) { munmap(m, (size_t)st.st_size); return false; }
+        packed_lens.assign(lens, lens + h.n_names);
+        packed_blk.assign(blk, blk + h.n_names + 1);
+        packed_nb = (int64_t)h.n_blocks;
+        mapped = m; mapped_bytes = (size_t)st.st_size;
+        packed_ptr = (const uint64_t*)(base + h.header_bytes);
+        madvise(m, mapped_bytes, MADV_WILLNEED);
+        from_cache = true; cached_names = cn.size();
+        if (getenv("THJ_TIMING")) fprintf(stderr, "[timing] reference taken from the packed-genome cache %s\n", cache_file.c_str());
+        return true;
+    }
+    void write_cache() {             // after pack(), on a thread of its own; the file appears under its name only when complete
+        uint64_t fsz; int64_t fmt;
+        if (cache_file.empty() || from_cache || !fasta_stat(fasta_path, fsz, fmt)) return;
+        std::string nm;
+        for (auto& n : names) { nm += n; nm.push_back('\0'); }
+        CacheHeader h;
+        memcpy(h.magic, CACHE_MAGIC, 8);
+        h.fasta_size = fsz; h.fasta_mtime_ns = fmt; h.n_names = names.size(); h.n_blocks = (uint64_t)packed_nb; h.names_bytes = nm.size();
+        const size_t names_pad = (nm.size() + 7) & ~(size_t)7;
+        size_t hb = sizeof h + names_pad + names.size() * 8 + (names.size() + 1) * 4;
+        hb = (hb + 4095) & ~(size_t)4095;
+        h.header_bytes = hb;
+        const std::string tmp = cache_file + ".tmp." + std::to_string((long)getpid());
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return;                          // (a directory we may not write to: no cache)
+        std::vector<char> head(hb, 0);
+        memcpy(head.data(), &h, sizeof h);
+        memcpy(head.data() + sizeof h, nm.data(), nm.size());
+        memcpy(head.data() + sizeof h + names_pad, packed_lens.data(), names.size() * 8);
+        memcpy(head.data() + sizeof h + names_pad + names.size() * 8, packed_blk.data(), (names.size() + 1) * 4);
+        auto put = [&](const char* p, size_t n) { while (n) { const ssize_t w = ::write(fd, p, n > (1u << 30) ? (1u << 30) : n); if (w <= 0) return false; p += w; n -= (size_t)w; } return true; };
+        const bool ok = put(head.data(), hb) && put((const char*)packed.data(), (size_t)packed_nb * 32);
+        close(fd);
+        if (!ok || rename(tmp.c_str(), cache_file.c_str())) unlink(tmp.c_str());
+    }
+    void finish_cache() { if (cache_writer.valid()) cache_writer.get(); }      // before the process leaves
+    ~RefTable() { finish_cache(); if (mapped) munmap(mapped, mapped_bytes); }
+    // a contig's text for the few host-side uses (MD strings longer than a device record holds): decoded from the blocks when the
+    // reference came from the cache
+    const std::string& text(uint32_t ref_id) {
+        std::string& s = seqs[ref_id - 1];
+        if (!from_cache || !s.empty() || ref_id > packed_lens.size() || packed_lens[ref_id - 1] == 0) return s;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!s.empty()) return s;
+        const int64_t n = packed_lens[ref_id - 1];
+        std::string t((size_t)n, 'N');
+        const uint64_t* b = packed_ptr + (size_t)packed_blk[ref_id - 1] * 4;
+        for (int64_t i = 0; i < n; ++i) {
+            const uint64_t* w = b + (size_t)(i >> 6) * 4; const int k = (int)(i & 63);
+            if (!((w[2] >> k) & 1ull)) t[(size_t)i] = "ACGT"[((w[0] >> k) & 1ull) | (((w[1] >> k) & 1ull) << 1)];
+        }
+        s.swap(t);
+        return s;
+    }
     void pack() {
         std::call_once(packed_once, [this] {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                frozen = true;                           // the device genome has exactly the contigs known now
+            }
+            if (from_cache && names.size() != cached_names) {
+                // a map's header named a contig the cached table does not have: the cache does not describe this run.  Parse the FASTA after all
+                from_cache = false; packed_ptr = nullptr;
+                { std::lock_guard<std::mutex> lk(mu); frozen = false; }
+                load_fasta(fasta_path);
+                { std::lock_guard<std::mutex> lk(mu); frozen = true; }
+            }
+            if (from_cache) return;
             std::lock_guard<std::mutex> lk(mu);
-            frozen = true;                           // the device genome has exactly the contigs known now
             int32_t n = (int32_t)names.size();
             packed_lens.resize(n); std::vector<const char*> ptrs(n);
             for (int32_t i = 0; i < n; ++i) { packed_lens[i] = (int64_t)seqs[i].size(); ptrs[i] = seqs[i].empty() ? nullptr : seqs[i].data(); }
@@ -488,11 +621,13 @@ struct RefTable {
             if (thj_genome_layout(n, packed_lens.data(), packed_blk.data(), &packed_nb)) die("Error: %s\n", thj_last_error());
             packed.resize((size_t)packed_nb * 4);
             if (thj_genome_pack(n, ptrs.data(), packed_lens.data(), packed_blk.data(), packed.data(), packed_nb)) die("Error: %s\n", thj_last_error());
+            packed_ptr = packed.data();
+            if (!cache_file.empty()) cache_writer = std::async(std::launch::async, [this] { write_cache(); });
         });
     }
     void upload(thj_ctx* ctx) {
         pack();
-        if (thj_genome_upload(ctx, packed.data(), packed_nb, packed_blk.data(), packed_lens.data(), (int32_t)packed_lens.size())) die("Error: %s\n", thj_last_error());
+        if (thj_genome_upload(ctx, packed_ptr, packed_nb, packed_blk.data(), packed_lens.data(), (int32_t)packed_lens.size())) die("Error: %s\n", thj_last_error());
     }
 };
 

@@ -238,7 +238,7 @@ extern "C" int thj_comm_info(const thj_comm* m, int32_t* n_ranks, int32_t* rank,
 __global__ __launch_bounds__(256) void thj_k_xpack(Tables t, u64* send, u64 cap_j, u64 cap_d, u64 cap_i) {
     const u64 nj = t.cnt[CNT_JUNC], nd = t.cnt[CNT_DEL], ni = t.cnt[CNT_INS];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        send[0] = nj; send[1] = nd; send[2] = ni; send[3] = (u64)(t.ovf[0] | t.ovf[1] | t.ovf[2]);
+        send[0] = nj; send[1] = nd; send[2] = ni; send[3] = (u64)(t.ovf[0] | t.ovf[1] | t.ovf[2] | t.ovf[3]);      // ([3]: a full task list -- events of this rank are missing: every rank must know)
         send[4] = cap_j; send[5] = cap_d; send[6] = cap_i; send[7] = 0;
     }
     u64* pj = send + 8; u64* pd = pj + cap_j; u64* pk = pd + cap_d; u64* pv = pk + cap_i;
@@ -316,7 +316,7 @@ static int x_finish_check(thj_ctx* c, const unsigned int* ovf_now) {
     }
     if (pre_ovf) {
         c->xchg = nullptr;
-        thj_set_error("event table overflow on a rank before the exchange step: call thj_segjuncs_configure with larger capacities and re-run");
+        thj_set_error("event table or task list overflow on a rank before the exchange step: call thj_segjuncs_configure with larger capacities / split the batch and re-run");
         return THJ_EOVERFLOW;
     }
     if (mj > m->cap_j || md > m->cap_d || mi > m->cap_i) {       // a message section was too small somewhere: same verdict on every rank
@@ -331,7 +331,7 @@ static int x_finish_check(thj_ctx* c, const unsigned int* ovf_now) {
     if (ovf_now[0] || ovf_now[1] || ovf_now[2]) {                 // this rank's table filled up while merging: nothing is lost, the
         int rc = grow_tables(c, ovf_now[0] != 0, (ovf_now[1] | ovf_now[2]) != 0);   // gathered keys are still in d_recv
         if (rc) return rc;
-        HIPCHK(hipMemsetAsync(c->d_ovf, 0, 4 * sizeof(unsigned int), c->stream));
+        HIPCHK(hipMemsetAsync(c->d_ovf, 0, 3 * sizeof(unsigned int), c->stream));      // (word 3, the task list's flag, is not the merge's to clear)
         if ((rc = x_merge_launch(c, m))) return rc;
         return 1;
     }

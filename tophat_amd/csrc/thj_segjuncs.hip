@@ -1828,13 +1828,15 @@ extern "C" int thj_segjuncs_finish(thj_ctx* c, thj_segjuncs_counts* counts) {
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         const unsigned int* ovf = (const unsigned int*)&c->h_pinned[4];
+        if (ovf[3]) {            // (before the exchange step's own look at the flags: a full task list has lost tasks on this rank whatever the others say)
+            c->xchg = nullptr;
+            thj_set_error("the task list of a thj_segjuncs_run_async call filled up (more than two window / indel tasks per read of the batch): split the batch");
+            return THJ_EOVERFLOW;
+        }
         if (c->xchg) {
             const int rc = x_finish_check(c, ovf);
             if (rc < 0) return rc;
             if (rc > 0) continue;                 // the step was repeated (larger message / larger table): look again
-        } else if (ovf[3]) {
-            thj_set_error("the task list of a thj_segjuncs_run_async call filled up (more than two window / indel tasks per read of the batch): split the batch");
-            return THJ_EOVERFLOW;
         } else if (ovf[0] || ovf[1] || ovf[2]) {
             thj_set_error("event table overflow (junc=%u del=%u ins=%u): call thj_segjuncs_configure with larger capacities and re-run",
                           ovf[0], ovf[1], ovf[2]);
