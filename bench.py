@@ -24,6 +24,7 @@ import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -258,7 +259,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="do not re-run two steps under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE for roofline.traffic "
                     "(the committed table under profiles/ is used instead when the configuration is the one it was taken on)")
-    ap.add_argument("--e2e-pairs-large", type=int, default=0, metavar="N",
+    ap.add_argument("--e2e-grch38-pairs", type=int, default=12_500_000, metavar="N",
+                    help="run the e2e leg's executables once more on configs[2]'s genome (25 contigs, 3.09 Gb) with N pairs -- its per-GPU shard at "
+                         "8 GPUs -- twice: the first run packs the reference and leaves the packed-genome cache, the second maps it "
+                         "(`e2e.grch38`, timing only; 0: skip)")
+    ap.add_argument("--e2e-pairs-large", type=int, default=40_000_000, metavar="N",
                     help="run the e2e leg a second time on N pairs (timing only; e.g. 40000000) so that the fixed cost of the three processes "
                          "and their rate separate: `e2e.large`, `e2e.fixed_s` and `e2e.rate_pairs_per_s` from the two points")
     ap.add_argument("--e2e-pairs", type=int, default=10_000_000,
@@ -509,14 +514,40 @@ def e2e_leg(args, n_gpus=1):
     finally:
         shutil.rmtree(d, ignore_errors=True)
     if getattr(args, "e2e_pairs_large", 0) > args.e2e_pairs:
-        # a second point: t(n) = fixed + n / rate through (e2e_pairs, both_stages_s) and (e2e_pairs_large, ...)
-        big = run_e2e(args.e2e_pairs_large, args.read_len, args.genome_len, args.introns, env_extra=gpu_env, gen_args=gen_args)
-        n0, t0, n1, t1 = float(out["pairs"]), float(out["both_stages_s"]), float(big["pairs"]), float(big["both_stages_s"])
-        out["large"] = {k: big[k] for k in ("pairs", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s", "both_stages_s", "outside_main_s") if k in big}
-        out["large"]["value"] = n1 / t1
-        if t1 > t0:
-            out["rate_pairs_per_s"] = (n1 - n0) / (t1 - t0)
-            out["fixed_s"] = t0 - n0 / out["rate_pairs_per_s"]
+        # a second point: t(n) = fixed + n / rate through (e2e_pairs, both_stages_s) and (e2e_pairs_large, ...).  Timing only (the
+        # outputs of the first point are the ones checked); a box without the room for its files keeps the first point and says so
+        try:
+            big = run_e2e(args.e2e_pairs_large, args.read_len, args.genome_len, args.introns, env_extra=gpu_env, gen_args=gen_args)
+            n0, t0, n1, t1 = float(out["pairs"]), float(out["both_stages_s"]), float(big["pairs"]), float(big["both_stages_s"])
+            out["large"] = {k: big[k] for k in ("pairs", "input_bytes", "gen_seconds", "segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s", "both_stages_s", "outside_main_s") if k in big}
+            out["large"]["value"] = n1 / t1
+            if t1 > t0:
+                out["rate_pairs_per_s"] = out["marginal_pairs_per_s"] = (n1 - n0) / (t1 - t0)
+                out["fixed_s"] = t0 - n0 / out["rate_pairs_per_s"]
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
+            out["large"] = {"error": str(e)[-300:]}
+    if getattr(args, "e2e_grch38_pairs", 0) > 0:
+        # configs[2]'s genome: where the reference itself costs seconds per process.  Run 1 finds no packed-genome cache (segment_juncs
+        # parses the FASTA, packs it and leaves the cache beside its outputs; the two long_spanning_reads map it), run 2 finds it.
+        from e2e_bench import GRCH38_LENS
+        dg = tempfile.mkdtemp(prefix="thj_e2e_g38_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            ga = gen_args + ["--contigs", ",".join(str(x) for x in GRCH38_LENS)]
+            runs = []
+            for k in range(2):
+                r = run_e2e(args.e2e_grch38_pairs, args.read_len, sum(GRCH38_LENS), 300000, workdir=dg, keep=True, env_extra=gpu_env, gen_args=ga)
+                runs.append({key: r[key] for key in ("segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s", "both_stages_s", "outside_main_s") if key in r})
+                runs[-1]["value"] = r["pairs"] / r["both_stages_s"]
+                runs[-1]["reference_timing"] = {st: [l for l in r.get(st + "_log_tail", []) if "reference" in l]
+                                                for st in ("segment_juncs", "long_spanning_reads_left", "long_spanning_reads_right")}
+                if k == 0:
+                    gen_s, in_bytes = r["gen_seconds"], r["input_bytes"]
+            out["grch38"] = {"pairs": args.e2e_grch38_pairs, "genome": "25 contigs with the GRCh38 primary-assembly lengths, 3 088 286 401 bp, 300 000 introns, the same mix",
+                             "gen_seconds": gen_s, "input_bytes": in_bytes, "first_run_no_cache": runs[0], "second_run_cache": runs[1]}
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
+            out["grch38"] = {"error": str(e)[-300:]}
+        finally:
+            shutil.rmtree(dg, ignore_errors=True)
     # a small case through the oracle whole (event files byte for byte, every spanning record, junctions.bed)
     d = tempfile.mkdtemp(prefix="thj_e2e_chk_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:

@@ -183,6 +183,32 @@ def test_results_do_not_depend_on_shards_or_workers(tmp_path):
     assert index_positions(bam1) == index_positions(bam2) and len(index_positions(bam1)) > 20
 
 
+def test_packed_genome_cache(tmp_path):
+    """segment_juncs packs the reference and leaves the blocks beside its outputs; long_spanning_reads -- and a second segment_juncs --
+    map that file instead of parsing the FASTA: the same results as with the cache off; a FASTA that has changed since (other
+    modification time) is parsed again and the cache rewritten"""
+    import glob
+    import shutil
+    d0 = _gen_case(tmp_path)
+    d = str(tmp_path / "own")
+    shutil.copytree(d0, d)                       # (its own copy: the FASTA's modification time is changed below)
+    off, bam_off, log_off = _run_both(d, tmp_path, "off", {"THJ_GENOME_CACHE": "0", "THJ_TIMING": "1"})
+    assert not glob.glob(str(tmp_path / ".thj2bit.*")) and "packed-genome cache" not in log_off
+    on, bam_on, log_on = _run_both(d, tmp_path, "on", {"THJ_TIMING": "1"})
+    caches = glob.glob(str(tmp_path / ".thj2bit.*"))
+    assert len(caches) == 1 and os.path.getsize(caches[0]) > 3000000 // 4
+    assert log_on.count("reference taken from the packed-genome cache") == 1          # long_spanning_reads took it, segment_juncs wrote it
+    again, bam_again, log_again = _run_both(d, tmp_path, "again", {"THJ_TIMING": "1"})
+    assert log_again.count("reference taken from the packed-genome cache") == 2
+    assert off == on == again and off["juncs"].count("\n") > 500
+    assert gzip.open(bam_off, "rb").read() == gzip.open(bam_on, "rb").read() == gzip.open(bam_again, "rb").read()
+    t = os.path.getmtime(caches[0])
+    os.utime(os.path.join(d, "ref.fa"), (1000000000, 1000000000))
+    stale, bam_stale, log_stale = _run_both(d, tmp_path, "stale", {"THJ_TIMING": "1"})
+    assert log_stale.count("reference taken from the packed-genome cache") == 1 and stale == off      # parsed once, written anew, taken by the second program
+    assert os.path.getmtime(caches[0]) >= t and len(glob.glob(str(tmp_path / ".thj2bit.*"))) == 1
+
+
 def test_process_and_compressor_choices_do_not_change_the_results(tmp_path):
     """the output hand-off to a child process (THJ_HANDOFF=1; one process is the default), zlib instead of the writer's own DEFLATE (THJ_BGZF_LEVEL), no
     page-locked staging (THJ_NO_STAGING): the same event files and the same BAM stream"""

@@ -20,6 +20,11 @@ BIN = os.path.join(ROOT, "tophat_amd", "bin")
 GEN = os.path.join(ROOT, "tools", "bin", "thj_gen")
 
 
+GRCH38_LENS = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422,
+               135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167,
+               46709983, 50818468, 156040895, 57227415, 16569]
+
+
 def mix_gen_args(multihit_frac, max_copies, indel_frac):
     """thj_gen options of SURVEY 8(d)'s mix"""
     out = []
@@ -145,6 +150,7 @@ if __name__ == "__main__":
     ap.add_argument("--read-len", type=int, default=100)
     ap.add_argument("--genome-len", type=int, default=64444167)
     ap.add_argument("--introns", type=int, default=20000)
+    ap.add_argument("--grch38", action="store_true", help="configs[2]'s genome: 25 contigs with the GRCh38 primary-assembly lengths (3.09 Gb; pass --introns 300000)")
     ap.add_argument("--coverage-search", action="store_true")
     ap.add_argument("--fusion-search", action="store_true", help="--fusion-search to both executables (configs[3]'s mode; the generator plants no fusions)")
     ap.add_argument("--keep", default=None)
@@ -154,6 +160,9 @@ if __name__ == "__main__":
     ap.add_argument("--plain", action="store_true", help="configs[1] without the mix (rounds 1-3)")
     ap.add_argument("--env", nargs="*", default=[])
     a = ap.parse_args()
-    res = run_e2e(a.pairs, a.read_len, a.genome_len, a.introns, workdir=a.keep, env_extra=dict(x.split("=", 1) for x in a.env), keep=bool(a.keep),
-                  coverage_search=a.coverage_search, fusion_search=a.fusion_search, gen_args=[] if a.plain else mix_gen_args(a.multihit_frac, a.max_copies, a.indel_frac))
+    ga = [] if a.plain else mix_gen_args(a.multihit_frac, a.max_copies, a.indel_frac)
+    if a.grch38:
+        ga += ["--contigs", ",".join(str(x) for x in GRCH38_LENS)]
+    res = run_e2e(a.pairs, a.read_len, sum(GRCH38_LENS) if a.grch38 else a.genome_len, a.introns, workdir=a.keep, env_extra=dict(x.split("=", 1) for x in a.env), keep=bool(a.keep),
+                  coverage_search=a.coverage_search, fusion_search=a.fusion_search, gen_args=ga)
     print(json.dumps(res, indent=1))

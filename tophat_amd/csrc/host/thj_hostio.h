@@ -414,22 +414,28 @@ struct RefTable {
         FILE* f = fopen(fn.c_str(), "rb");
         if (!f) die("Error: cannot open %s for reading\n", fn.c_str());
         std::vector<char> buf;
+        const char* d = nullptr; size_t n = 0;
+        struct Unmap { void* p = nullptr; size_t n = 0; ~Unmap() { if (p) munmap(p, n); } } um;
         {
             fseek(f, 0, SEEK_END);
             long sz = ftell(f);
             fseek(f, 0, SEEK_SET);
-            if (sz > 0) {
-                buf.resize((size_t)sz);
-                if (fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) die("Error: cannot read %s\n", fn.c_str());
+            if (sz > 0) {                             // a file: mapped (the page cache's pages are read where they lie; copying 3 GB of them took a second)
+                void* m = mmap(nullptr, (size_t)sz, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+                if (m != MAP_FAILED) { um.p = m; um.n = (size_t)sz; d = (const char*)m; n = (size_t)sz; madvise(m, (size_t)sz, MADV_WILLNEED); }
+                else {
+                    buf.resize((size_t)sz);
+                    if (fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) die("Error: cannot read %s\n", fn.c_str());
+                }
             } else {                                  // not seekable (a pipe): read to the end
-                char tmp[1 << 16]; size_t n;
-                while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+                char tmp[1 << 16]; size_t k;
+                while ((k = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + k);
             }
         }
         fclose(f);
+        if (!d) { d = buf.data(); n = buf.size(); }
         struct Rec { uint32_t id; size_t b, e; };                 // sequence text [b, e) of one record
         std::vector<Rec> recs;
-        const char* d = buf.data(); const size_t n = buf.size();
         size_t i = 0;
         while (i < n) {
             if (d[i] == '>') {
@@ -477,8 +483,8 @@ struct RefTable {
     }
     // pack (once) + upload (to every GPU's context) through the C ABI
     std::once_flag packed_once;
-    std::vector<uint64_t> packed; std::vector<uint32_t> packed_blk; std::vector<int64_t> packed_lens; int64_t packed_nb = 0;
-    const uint64_t* packed_ptr = nullptr;           // the blocks: `packed`, or the mapped cache file
+    std::unique_ptr<uint64_t[]> packed_own; std::vector<uint32_t> packed_blk; std::vector<int64_t> packed_lens; int64_t packed_nb = 0;
+    const uint64_t* packed_ptr = nullptr;           // the blocks: packed_own, or the mapped cache file
 
     // ---- the packed-genome cache.  tophat.py starts three processes on one reference (segment_juncs, long_spanning_reads per side), and
     // each of them parses and packs the FASTA (as the reference's do, segment_juncs.cpp:64-88, long_spanning_reads.cpp:2891): seconds
@@ -576,7 +582,7 @@ struct RefTable {
         memcpy(head.data() + sizeof h + names_pad, packed_lens.data(), names.size() * 8);
         memcpy(head.data() + sizeof h + names_pad + names.size() * 8, packed_blk.data(), (names.size() + 1) * 4);
         auto put = [&](const char* p, size_t n) { while (n) { const ssize_t w = ::write(fd, p, n > (1u << 30) ? (1u << 30) : n); if (w <= 0) return false; p += w; n -= (size_t)w; } return true; };
-        const bool ok = put(head.data(), hb) && put((const char*)packed.data(), (size_t)packed_nb * 32);
+        const bool ok = put(head.data(), hb) && put((const char*)packed_own.get(), (size_t)packed_nb * 32);
         close(fd);
         if (!ok || rename(tmp.c_str(), cache_file.c_str())) unlink(tmp.c_str());
     }
@@ -619,9 +625,9 @@ struct RefTable {
             for (int32_t i = 0; i < n; ++i) { packed_lens[i] = (int64_t)seqs[i].size(); ptrs[i] = seqs[i].empty() ? nullptr : seqs[i].data(); }
             packed_blk.resize(n + 1);
             if (thj_genome_layout(n, packed_lens.data(), packed_blk.data(), &packed_nb)) die("Error: %s\n", thj_last_error());
-            packed.resize((size_t)packed_nb * 4);
-            if (thj_genome_pack(n, ptrs.data(), packed_lens.data(), packed_blk.data(), packed.data(), packed_nb)) die("Error: %s\n", thj_last_error());
-            packed_ptr = packed.data();
+            packed_own.reset(new uint64_t[(size_t)packed_nb * 4]);           // (uninitialised: thj_genome_pack writes every block)
+            if (thj_genome_pack(n, ptrs.data(), packed_lens.data(), packed_blk.data(), packed_own.get(), packed_nb)) die("Error: %s\n", thj_last_error());
+            packed_ptr = packed_own.get();
             if (!cache_file.empty()) cache_writer = std::async(std::launch::async, [this] { write_cache(); });
         });
     }
