@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256) void thj_k_scatter_mates(const uint32_t* __res
 __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restrict__ infl, const uint32_t* __restrict__ id, const uint32_t* __restrict__ loc, uint32_t a, uint32_t b,
                                                          uint32_t id0, uint32_t span, const uint32_t* __restrict__ vis, const uint32_t* __restrict__ row, int W, u64* __restrict__ planes,
                                                          uint16_t* __restrict__ rlen, uint32_t* __restrict__ seen, unsigned int* status,
-                                                         uint8_t* __restrict__ quals = nullptr, int qstride = 0, uint32_t* __restrict__ row_loc = nullptr) {
+                                                         uint8_t* __restrict__ quals = nullptr, int qstride = 0, uint32_t* __restrict__ row_loc = nullptr, int wide = 0) {
     for (uint32_t i = a + blockIdx.x * blockDim.x + threadIdx.x; i < b; i += gridDim.x * blockDim.x) {
         const uint32_t idl = id[i] - id0;
         if (idl >= span || !vis[idl]) continue;
@@ -1228,8 +1228,11 @@ __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restri
                     // eight byte loads in flight, not one 8-byte load: as `global_load_dwordx2` from these byte-aligned addresses the group came back
                     // wrong now and then (a run of 80 000 pairs lost ~200 alignments, different ones each time; byte loads: none in ten runs)
                     u64 v = 0;
+                    if (wide) __builtin_memcpy(&v, sq + (bi >> 1), 8);          // THJ_PLANES_LOAD64 (developer switch): the one 8-byte load of round 3, for the reproducer
+                    else {
 #pragma unroll
-                    for (int bb = 0; bb < 8; ++bb) v |= (u64)sq[(bi >> 1) + bb] << (8 * bb);
+                        for (int bb = 0; bb < 8; ++bb) v |= (u64)sq[(bi >> 1) + bb] << (8 * bb);
+                    }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const uint32_t nib = (uint32_t)(v >> (8 * (j >> 1) + ((j & 1) ? 0 : 4))) & 0xFu;
@@ -1699,8 +1702,11 @@ static int span_ingest_impl(thj_ctx* c, const thj_params* tp, int32_t nseg, cons
         ING_HIP(hipMemsetAsync(ob->ptrs[3], 0, (size_t)n_rows * 2, c->stream));
         ING_HIP(hipMemsetAsync(ob->ptrs[4], 0, (size_t)n_rows * qstride, c->stream));
         const uint32_t a = fb[(size_t)f_reads], b = fb[(size_t)f_reads + 1];
+        static const int planes_wide = getenv("THJ_PLANES_LOAD64") ? atoi(getenv("THJ_PLANES_LOAD64")) : 0;
+        static const bool ingest_sync = getenv("THJ_INGEST_SYNC") != nullptr;          // developer switch: the device idle before the reads' planes are made
+        if (ingest_sync) ING_HIP(hipDeviceSynchronize());
         if (b > a) hipLaunchKernelGGL(thj_k_read_planes, dim3(grid_for(b - a)), dim3(256), 0, c->stream, P.infl, P.id, P.loc, a, b, id_lo, span, m_vis, m_row, W,
-                                      (u64*)ob->ptrs[2], (uint16_t*)ob->ptrs[3], seen, P.status, (uint8_t*)ob->ptrs[4], qstride, d_loc);
+                                      (u64*)ob->ptrs[2], (uint16_t*)ob->ptrs[3], seen, P.status, (uint8_t*)ob->ptrs[4], qstride, d_loc, planes_wide);
         hipLaunchKernelGGL(thj_k_check_seen, dim3(grid_for(n_rows)), dim3(256), 0, c->stream, seen, n_rows, P.status);
         // the rows' own BAM records stay on the device with the batch (thj_span_bam_encode copies names, bases and qualities from
         // them); the host copy is made only for a caller that asks for it
