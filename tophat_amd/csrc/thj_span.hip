@@ -661,12 +661,16 @@ struct WaveOps {
     __device__ __forceinline__ unsigned long long clock() { return wall_clock64(); }
 };
 static constexpr int PACK_MAXROOTS = 64, PACK_MAXHITS = 256, PACK_CHAINLIST = 128;
-static constexpr int PACK_DRAW = 32;        // list entries a wave draws at a time: a draw of two-copy reads is one round, and the launch ends one draw's time after its last wave found the list empty
+// list entries a wave draws at a time: the launch ends one draw's time after its last wave found the list empty.  32 while the list
+// held every multihit read (a draw of two-copy reads is one round); since thj_k_chains takes those, what is left are the reads of
+// five and more copies -- a draw of 32 could be ten rounds, and the slowest wave ran 570 us against a mean of 250 (THJ_PACK_TIMING).
+// THJ_PACK_DRAW: developer switch
+static const int PACK_DRAW_DEFAULT = 8;
 // Eight waves per workgroup, two workgroups per CU: 16 waves per CU is what 128 VGPRs allow, and a wave's 9 KB of LDS with the
 // workgroup's slice table fit the CU's 160 KB twice over that way (four workgroups of four waves do not: three were resident).
 static constexpr int PACK_TPB = 512;
 template <int MS, int PACK_TPB = 512, int PACK_WPE = 4>
-__global__ __launch_bounds__(PACK_TPB, PACK_WPE) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg) {
+__global__ __launch_bounds__(PACK_TPB, PACK_WPE) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg, int draw) {
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     __shared__ PackLds<MS, PACK_MAXHITS, PACK_CHAINLIST> s_pack[PACK_TPB / 64];
@@ -678,11 +682,11 @@ __global__ __launch_bounds__(PACK_TPB, PACK_WPE) void thj_k_stitch_pack(Genome g
     const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
     for (;;) {
         unsigned int i0 = 0;
-        if (x.lane == 0) i0 = atomicAdd(&t.counters[3], (unsigned int)PACK_DRAW);
+        if (x.lane == 0) i0 = atomicAdd(&t.counters[3], (unsigned int)draw);
         i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
         if (i0 >= total) break;
         const unsigned int i = i0 + (unsigned int)x.lane;
-        const bool has = x.lane < PACK_DRAW && i < total;
+        const bool has = x.lane < draw && i < total;
         const int sl = has ? slice_of(s_off, G, i) : 0;
         const uint32_t r = has ? t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])] : 0u;
         const bool fwd = span_pack_wave<MS, PACK_MAXROOTS, PACK_MAXHITS, PACK_CHAINLIST>(x, g, p, S, b.hits, b.heads, b.seg_off, b.nseg, b.planes, b.W, b.read_len,
@@ -1271,11 +1275,13 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         // reads of up to four segments: four waves a workgroup and three workgroups a CU (168 VGPRs, nothing spilled) instead of two
         // workgroups of eight waves (128 VGPRs, 43 spilled): 0.69 -> 0.635 ms per launch; THJ_PACK_WPE = 2 | 4: developer switch
         static const int pack_wpe = getenv("THJ_PACK_WPE") ? atoi(getenv("THJ_PACK_WPE")) : 3;
+        static const int pack_draw_env = getenv("THJ_PACK_DRAW") ? atoi(getenv("THJ_PACK_DRAW")) : 0;
+        const int pack_draw = pack_draw_env >= 1 && pack_draw_env <= 64 ? pack_draw_env : (chains ? PACK_DRAW_DEFAULT : 32);
         SPK_BEGIN(SPK_PACK, sm);
-        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
-        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
-        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
-        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg);
+        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
         // (reads of more than eight segments: the packed tier keeps a chain's choices in eight bytes -- the general kernel takes the multihit list as it is)
         SPK_END(SPK_PACK, sm);
         if (pack_timing) {
