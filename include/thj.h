@@ -246,6 +246,10 @@ int thj_fusion_download(thj_ctx* ctx, thj_fusion* out);
  * launches whose lists are still there: reads given to `thj_k_segjuncs_shared`, to the second instance of
  * `thj_k_sj_general`, tasks `thj_k_sj_tasks_list` ran, flat rescue pairs.  Enables event recording when `enable` != 0. */
 int thj_profile_segjuncs(thj_ctx* ctx, int enable, double* avg_ms, int64_t* launches, double* stats);
+/* Measurement aid: with `on` != 0 the stage calls of this context launch every kernel on the context's stream, one after the
+ * other (no side streams) -- the durations thj_profile_segjuncs / thj_profile_span then report are each kernel's own, not those of
+ * kernels sharing the GPU.  Results are the same either way.  Default 0. */
+int thj_profile_serial(thj_ctx* ctx, int on);
 
 
 /* --------------------------------------------------- juncs_db

@@ -110,6 +110,7 @@ struct thj_ctx {
     struct thj_comm* xchg = nullptr;
     // profiling
     bool profile = false;
+    bool serial_launch = false;                 // thj_profile_serial: no side streams
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
     std::vector<hipEvent_t> prof_all; std::vector<int> prof_sets;       // every event of prof_events once; the scratch set of each profiled launch
     std::vector<hipEvent_t> event_pool;

@@ -1414,7 +1414,8 @@ static int sj_launch_flat(thj_ctx* c, const thj_params* tp, const thj_seg_batch*
     // shared, rescue x 2: few waves per CU, each waiting on its own chain of loads) on a stream of the context's own, with
     // thj_k_segjuncs_shared beside thj_k_sj_general's second instance on a third.  Everything is joined on the context's stream
     // again before this function returns; the event tables take inserts from any of them.  THJ_SJ_SERIAL=1: one stream.
-    static const bool serial = getenv("THJ_SJ_SERIAL") && atoi(getenv("THJ_SJ_SERIAL")) != 0;
+    static const bool serial_env = getenv("THJ_SJ_SERIAL") && atoi(getenv("THJ_SJ_SERIAL")) != 0;
+    const bool serial = serial_env || c->serial_launch;
     if (!serial && !c->aux_stream[3 * set]) {
         // (THJ_SJ_PRIO=1: the side streams at the highest priority the device has -- measured worse, 7.0 against 6.6 ms per step: the flat reads'
         // rescue scan then waits for them)
@@ -1548,6 +1549,14 @@ extern "C" int thj_segjuncs_run_pair_async(thj_ctx* c, const thj_params* tp0, co
     if (j0 && (rc = sj_join(c, 0))) return rc;
     if (j1 && (rc = sj_join(c, 1))) return rc;
     return (db0->n_reads || db1->n_reads) ? sj_probe(c) : THJ_OK;
+}
+
+extern "C" int thj_profile_serial(thj_ctx* c, int on) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->serial_launch = on != 0;
+    return THJ_OK;
 }
 
 static constexpr int SJ_PROF_N = 8;

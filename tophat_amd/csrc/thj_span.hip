@@ -1329,7 +1329,8 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     if ((rc = ensure_slots(c, c->span_reads + n0 + n1))) return rc;
     if ((rc = ensure_span_streams(c))) return rc;
     // THJ_SPAN_SERIAL: developer switch -- every kernel on the context's stream, one after the other
-    static const bool serial = getenv("THJ_SPAN_SERIAL") != nullptr;
+    static const bool serial_env = getenv("THJ_SPAN_SERIAL") != nullptr;
+    const bool serial = serial_env || c->serial_launch;
     hipStream_t s0 = c->stream, a0 = serial ? c->stream : c->span_stream[0], s1 = serial ? c->stream : c->span_stream[1], a1 = serial ? c->stream : c->span_stream[2];
     const uint32_t base0 = (uint32_t)c->span_reads, base1 = (uint32_t)(c->span_reads + n0);
     if (!serial && n1) { HIPCHK(hipEventRecord(c->span_ev[0], c->stream)); HIPCHK(hipStreamWaitEvent(s1, c->span_ev[0], 0)); }

@@ -56,7 +56,7 @@ ABI_SYMBOLS = [
     "thj_batch_upload", "thj_batch_free",
     "thj_segjuncs_configure", "thj_segjuncs_reset_async", "thj_segjuncs_run_async", "thj_segjuncs_run_pair_async",
     "thj_segjuncs_finish", "thj_segjuncs_download", "thj_segjuncs_device_keys",
-    "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs",
+    "thj_segjuncs_merge_keys_async", "thj_profile_segjuncs", "thj_profile_serial",
     "thj_segjuncs_device_insertions", "thj_segjuncs_merge_insertions_async",
     "thj_fusion_reset_async", "thj_fusion_set_ignored", "thj_fusion_run_async", "thj_genome_gather", "thj_fusion_finish", "thj_fusion_download",
     "thj_covsearch_reset_async", "thj_covsearch_add_hits_async", "thj_covsearch_add_reads", "thj_covsearch_run_async", "thj_covsearch_finish",
@@ -421,6 +421,10 @@ class Context:
     SJ_KERNELS = ("thj_k_sj_flat", "thj_k_sj_general<12, 256, true>", "thj_k_sj_general<32, 64, false>", "thj_k_segjuncs_shared",
                   "thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "thj_k_sj_tasks_list", "thj_k_sj_rescue_scan + thj_k_sj_rescue_flat",
                   "thj_k_sj_tasks")
+
+    def profile_serial(self, on: bool = True):
+        """every kernel of the stage calls on the context's stream, one after the other: the profiles then give each kernel's own duration"""
+        _check(self.lib, self.lib.thj_profile_serial(self._ctx, 1 if on else 0), "thj_profile_serial")
 
     def profile(self, enable: bool = True):
         """(ms per launch of each entry of SJ_KERNELS, runs, {reads and tasks of the lists}) since the last call"""
