@@ -210,7 +210,10 @@ int thj_segjuncs_download(thj_ctx* ctx, thj_junction* juncs, thj_junction* delet
  * on-device merging / RCCL all-gather): kind 0 junctions, 1 deletions. */
 int thj_segjuncs_device_keys(thj_ctx* ctx, int kind, const uint64_t** d_keys, int64_t* n);
 /* Inserts packed keys (DEVICE pointer) produced by another context/rank into this
- * context's table: the merge step of segment_juncs.cpp:4911-4916 across GPUs. */
+ * context's table: the merge step of segment_juncs.cpp:4911-4916 across GPUs.
+ * Precondition: the keys were made on a context holding the SAME genome layout (their position field lies below this
+ * genome's n_blocks * 64 + 2): thj_segjuncs_finish sorts the event lists on as many key bits as this genome's positions
+ * need, and a key beyond them would be mis-sorted silently. */
 int thj_segjuncs_merge_keys_async(thj_ctx* ctx, int kind, const uint64_t* d_keys, int64_t n);
 
 /* The sorted insertion table after finish: packed keys and values (value = first-wins

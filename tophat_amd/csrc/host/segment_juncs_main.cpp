@@ -444,6 +444,7 @@ static int real_main(int argc, char** argv) {
                 Read rd;
                 while (rs.next_direct(rd)) {
                     if (skip > 0) { --skip; continue; }
+                    if (rd.qc_fail) continue;                 // reads.cpp:556 (the device path gives such a record length 0: thj_k_ium_planes)
                     bases.append(rd.seq, 0, rd.seq.size() < 32 ? rd.seq.size() : 32);      // count_read_mers / store_read_mers :425, :520
                     off.push_back((int64_t)bases.size());
                     if (off.size() - 1 >= CH) push();

@@ -1261,7 +1261,8 @@ public:
 };
 
 // ------------------------------------------------------------------ reads (reads.cpp:94-188, :528-630)
-struct Read { uint32_t id = 0; std::string name, seq, qual; const uint8_t* raw = nullptr; /* the read's own BAM record (after block_size) when it came inflated from the device */ };
+struct Read { uint32_t id = 0; std::string name, seq, qual; const uint8_t* raw = nullptr; /* the read's own BAM record (after block_size) when it came inflated from the device */
+              bool qc_fail = false; /* a BAM record with BAM_FQCFAIL: ReadStream::get_direct (reads.cpp:546-560) reads on past it -- get() does, and next_direct()'s callers look at the flag */ };
 
 class ReadStream {
     FILE* f_ = nullptr; bool pipe_ = false;
@@ -1303,7 +1304,7 @@ class ReadStream {
         if (is_bam_) {
             AlnRec a;
             if (!bam_.next(a)) return false;
-            r.id = (uint32_t)atoi(a.qname.c_str()); r.name = a.qname; r.seq = a.seq; r.qual = a.qual;
+            r.id = (uint32_t)atoi(a.qname.c_str()); r.name = a.qname; r.seq = a.seq; r.qual = a.qual; r.qc_fail = (a.flag & 0x200u) != 0;
             return true;
         }
         std::string l;
@@ -1362,6 +1363,7 @@ public:
         Read r;
         while (!eof_) {
             if (!next_async(r)) { eof_ = true; break; }
+            if (r.qc_fail) continue;                  // reads.cpp:556: a QC-failed record is not a read
             if (r.id == id) { out = std::move(r); while (!ahead_.empty() && ahead_.begin()->first < id) ahead_.erase(ahead_.begin()); return true; }
             if (r.id > id) ahead_[r.id] = r;          // slightly out-of-order files (reads.h:142 keeps a 500k-entry heap)
         }

@@ -173,8 +173,8 @@ THJ_HD void read_record(const u64* planes, const uint16_t* lens, int W, uint32_t
     const u64* rp = planes + (size_t)r * 3 * W;
     const u64 nm = rp[2 * W], lo = rp[0] & ~nm, hi = rp[W] & ~nm;          // charToDna5 & 3: N is 0
     u64 seq = planes_to_mer32(lo, hi);                                     // base i at bits 2 * (31 - i)
-    if (len < 32) seq &= ~0ull << (2 * (32 - len));                        // (a producer may hand more bases than the length kept here)
-    rec_len[base + r] = (uint32_t)len; rec_seq[base + r] = len ? seq : 0ull;
+    if (len > 0 && len < 32) seq &= ~0ull << (2 * (32 - len));             // (a producer may hand more bases than the length kept here)
+    rec_len[base + r] = (uint32_t)len; rec_seq[base + r] = len > 0 ? seq : 0ull;
 }
 // the entries of one read record: emit(seed, value) per seed position
 template <class Emit>

@@ -1213,8 +1213,9 @@ __global__ __launch_bounds__(256) void thj_k_read_planes(const uint8_t* __restri
         const uint32_t idl = id[i] - id0;
         if (idl >= span || !vis[idl]) continue;
         const uint32_t r = row[idl];
-        if (atomicExch(&seen[r], 1u)) continue;                    // the first record of an id is the read (ReadStream::getRead)
         const uint8_t* d = infl + ((size_t)(loc[i] >> 16) << 16) + (loc[i] & 0xFFFFu) + 4;
+        if ((ld32(d + 12) >> 16) & 0x200u) continue;               // BAM_FQCFAIL: ReadStream::get_direct reads on past such a record (reads.cpp:556)
+        if (atomicExch(&seen[r], 1u)) continue;                    // the first record of an id is the read (ReadStream::getRead)
         const uint32_t l_rn = ld32(d + 8) & 0xFF, n_cig = ld32(d + 12) & 0xFFFF, l_seq = ld32(d + 16);
         const uint8_t* sq = d + 32 + l_rn + 4 * n_cig;
         u64* pl = planes + (size_t)r * 3 * W;
@@ -1747,9 +1748,11 @@ namespace ing {
 __global__ __launch_bounds__(256) void thj_k_ium_planes(const uint8_t* __restrict__ infl, const uint32_t* __restrict__ loc, uint32_t n, u64* __restrict__ planes, uint16_t* __restrict__ rlen) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint8_t* d = infl + ((size_t)(loc[i] >> 16) << 16) + (loc[i] & 0xFFFFu) + 4;
-        const uint32_t l_rn = ld32(d + 8) & 0xFF, n_cig = ld32(d + 12) & 0xFFFF, l_seq = ld32(d + 16);
+        const uint32_t l_rn = ld32(d + 8) & 0xFF, flag_nc = ld32(d + 12), n_cig = flag_nc & 0xFFFF, l_seq = ld32(d + 16);
         const uint8_t* sq = d + 32 + l_rn + 4 * n_cig;
-        const uint32_t L = l_seq > 64u ? 64u : l_seq;
+        // a QC-failed record (BAM_FQCFAIL) is not a read (ReadStream::get_direct, reads.cpp:556): length 0, which the extension table ignores
+        const bool qc_fail = ((flag_nc >> 16) & 0x200u) != 0;
+        const uint32_t L = qc_fail ? 0u : (l_seq > 64u ? 64u : l_seq);
         u64 lo = 0, hi = 0, nn = 0;
         for (uint32_t k = 0; k < L; ++k) {
             const uint32_t nib = (sq[k >> 1] >> ((k & 1) ? 0 : 4)) & 0xF;
@@ -1757,7 +1760,7 @@ __global__ __launch_bounds__(256) void thj_k_ium_planes(const uint8_t* __restric
             lo |= b0 << k; hi |= b1 << k; nn |= isn << k;
         }
         planes[(size_t)i * 3] = lo; planes[(size_t)i * 3 + 1] = hi; planes[(size_t)i * 3 + 2] = nn;
-        rlen[i] = (uint16_t)(l_seq > 0xFFFFu ? 0xFFFFu : l_seq);
+        rlen[i] = qc_fail ? (uint16_t)0 : (uint16_t)(l_seq > 0xFFFFu ? 0xFFFFu : l_seq);
     }
 }
 }  // namespace ing
