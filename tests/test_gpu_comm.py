@@ -300,4 +300,5 @@ def test_full_task_list_fails_loudly_with_an_exchange_step_pending(monkeypatch):
         for c in comms:
             c.close()
     assert errs[0] is not None and "task list" in errs[0]
-    assert errs[1] is not None and "overflow" in errs[1]
+    # (its peer: the verdict of the gathered headers -- or, when its own small batch overflows the eight-entry list too, its own message)
+    assert errs[1] is not None and ("overflow" in errs[1] or "task list" in errs[1])

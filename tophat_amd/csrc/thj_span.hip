@@ -318,6 +318,18 @@ struct LdsChainHits {       // word pair (2 s, 2 s + 1) of column `col` = the re
         return h;
     }
 };
+// thj_k_join's own: six words a hit (records of at most three cigar ops: everything but a segment hit with two splices, which the
+// closure kernel takes) -- 24 KB a workgroup instead of 32, six workgroups a CU instead of four
+struct LdsChainHits6 {
+    const Q16* col; const uint2* col2;
+    __device__ __forceinline__ SpanHit operator[](int s) const {
+        const Q16 a = col[s * 256]; const uint2 b = col2[s * 256];
+        SpanHit h;
+        h.ref_id = a.x; h.left = (int32_t)a.y; h.meta = a.z; h.cigar[0] = a.w;
+        h.cigar[1] = b.x; h.cigar[2] = b.y; h.cigar[3] = 0; h.cigar[4] = 0;
+        return h;
+    }
+};
 // (Work distribution.  Region A, tier 0's entries: workgroup b takes what tier 0's workgroup b wrote -- its four class slices one
 // after the other -- and writes the joined hits to J[b * chunk ..): no table of slice offsets, no search per entry.  Region B,
 // the chains of multihit reads (thj_k_chains): one dense list of *n2 entries, workgroups G .. G + G2 stride over it, joined hits
@@ -349,17 +361,30 @@ __device__ __forceinline__ int join_entry(const Genome& g, const Params& p, cons
     const Q16 e0 = src[0], e1 = src[1];
     const uint32_t r = e0.x, meta = e0.y;
     if (r == JOINED_PAD) { if (ABUT) L.ja[at] = Q16{JOINED_PAD, 0u, 0u, 0u}; return LJ_NONE; }       // padding of a group (thj_k_chains)
+    RAln res;
+    int jr;
     {
         Q16 rec[2 * CHAIN_MAXSEG];
         const uint32_t hi[CHAIN_MAXSEG] = {e1.x, e1.y, e1.z, e1.w};
 #pragma unroll
         for (int k = 0; k < CHAIN_MAXSEG; ++k) { const Q16* hp = (const Q16*)(hits + hi[k]); rec[2 * k] = hp[0]; rec[2 * k + 1] = hp[1]; }
+        if (ABUT) {
+            bool wide = false;
 #pragma unroll
-        for (int k = 0; k < 2 * CHAIN_MAXSEG; ++k) s_rec[k * 256 + threadIdx.x] = rec[k];
+            for (int k = 0; k < CHAIN_MAXSEG; ++k) wide = wide || (rec[2 * k].z >> 24) > 3u;
+            if (wide) return LJ_DEFER;
+            uint2* s2 = (uint2*)(s_rec + CHAIN_MAXSEG * 256);
+#pragma unroll
+            for (int k = 0; k < CHAIN_MAXSEG; ++k) { s_rec[k * 256 + threadIdx.x] = rec[2 * k]; s2[k * 256 + threadIdx.x] = make_uint2(rec[2 * k + 1].x, rec[2 * k + 1].y); }
+            const LdsChainHits6 ch{s_rec + threadIdx.x, s2 + threadIdx.x};
+            jr = chain_join<ABUT>(g, p, S, ch, meta, planes + (u64)r * (uint32_t)(3 * W), W, res);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2 * CHAIN_MAXSEG; ++k) s_rec[k * 256 + threadIdx.x] = rec[k];
+            const LdsChainHits ch{s_rec + threadIdx.x};
+            jr = chain_join<ABUT>(g, p, S, ch, meta, planes + (u64)r * (uint32_t)(3 * W), W, res);
+        }
     }
-    const LdsChainHits ch{s_rec + threadIdx.x};
-    RAln res;
-    const int jr = chain_join<ABUT>(g, p, S, ch, meta, planes + (u64)r * (uint32_t)(3 * W), W, res);
     if (ABUT && jr == LJ_DEFER) return jr;
     Q16 ja, jb, jc;
     joined_pack(res, r, chain_nsegs(meta) == 1, chain_q(meta), chain_k(meta), ja, jb, jc);
@@ -386,7 +411,7 @@ __device__ __forceinline__ const ChainEntry* chain_locate(const unsigned int (&c
 }
 template <int WPE>
 __global__ __launch_bounds__(256, WPE) void thj_k_join(Genome g, Params p, SpanSets S, const SpanHit* hits, const u64* planes, int W, ChainLists L, Tiers t, DeferList D) {
-    __shared__ Q16 s_rec[2 * CHAIN_MAXSEG * 256];
+    __shared__ Q16 s_rec[(CHAIN_MAXSEG + CHAIN_MAXSEG / 2) * 256];        // four hits' first four words, then their next two (LdsChainHits6)
     __shared__ unsigned int s_qn;
     if (threadIdx.x == 0) s_qn = 0;
     __syncthreads();
@@ -1223,7 +1248,9 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         static const int join_wpe = getenv("THJ_JOIN_WPE") ? atoi(getenv("THJ_JOIN_WPE")) : 3, fin_wpe = getenv("THJ_FIN_WPE") ? atoi(getenv("THJ_FIN_WPE")) : 4;
         const dim3 grid((unsigned)(G + G2));
         SPK_BEGIN(SPK_JOIN, sa);
-        hipLaunchKernelGGL(thj_k_join<4>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
+        static const int abut_wpe = getenv("THJ_ABUT_WPE") ? atoi(getenv("THJ_ABUT_WPE")) : 6;       // developer switch
+        if (abut_wpe == 4) hipLaunchKernelGGL(thj_k_join<4>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
+        else hipLaunchKernelGGL(thj_k_join<6>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
         SPK_END(SPK_JOIN, sa);
         SPK_BEGIN(SPK_CLOSURE, sa);
         if (join_wpe == 3) hipLaunchKernelGGL(thj_k_join_closure<3>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
@@ -1231,7 +1258,9 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         SPK_END(SPK_CLOSURE, sa);
         if (sa != sm) HIPCHK(hipEventRecord(ev_joined, sa));
         SPK_BEGIN(SPK_FINISH, sa);
-        if (fin_wpe == 3) hipLaunchKernelGGL(thj_k_finish<3>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
+        if (fin_wpe == 5) hipLaunchKernelGGL(thj_k_finish<5>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
+        else if (fin_wpe == 6) hipLaunchKernelGGL(thj_k_finish<6>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
+        else if (fin_wpe == 3) hipLaunchKernelGGL(thj_k_finish<3>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
         else hipLaunchKernelGGL(thj_k_finish<4>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
         SPK_END(SPK_FINISH, sa);
     } else {
