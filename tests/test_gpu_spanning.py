@@ -119,6 +119,23 @@ def test_multihit_reads_as_chain_groups():
             assert ctx.span_chain_groups() == 0
 
 
+def test_full_chain_list_hands_reads_to_the_packed_tier(monkeypatch):
+    """THJ_CHAIN_CAP=1024: the dense list of the multihit reads' chains holds two rounds' entries -- the workgroups of thj_k_chains that find it
+    full pad what is left of it and leave their reads to thj_k_stitch_pack; the records are the oracle's all the same"""
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    p = Params(max_report_intron=300, max_segment_intron=300)
+    seq, sb = repeat_span_batch(copies=3, n_reads=700, seed=77)
+    want = orc.spanning(p, orc.Genome([seq]), sb, nj, [])
+    monkeypatch.setenv("THJ_CHAIN_CAP", "1024")
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome([seq]))
+        ctx.upload_span_sets(nj, [])
+        got = ctx.spanning(p, [ctx.upload_span_batch(sb)])
+        groups = ctx.span_chain_groups()
+    assert got == want and len(want) == 3 * 700
+    assert 0 < groups < 700               # some groups fitted, the other reads went on
+
+
 def test_many_joined_alignments_per_read_gpu():
     """30 joined alignments per read (a 30-copy tandem repeat): multihit tier, overflow pool ordering"""
     import numpy as np

@@ -1128,7 +1128,10 @@ enum { SPK_CONTIG = 0, SPK_CHAINS, SPK_JOIN, SPK_CLOSURE, SPK_FINISH, SPK_LEAN, 
 
 // the dense list of the multihit reads' chains (thj_k_chains): room for one entry per read of the batch -- three times what SURVEY 8(d)'s
 // mix fills; a workgroup that finds it full hands its reads to the packed tier
-static int64_t chain_cap2(int64_t n_reads) { return (n_reads + 7) / 8 * 8 + 2048; }
+static int64_t chain_cap2(int64_t n_reads) {
+    if (const char* e = getenv("THJ_CHAIN_CAP")) { const int64_t v = atoll(e); if (v >= 8) return v / 8 * 8; }      // (tests: a list that fills up)
+    return (n_reads + 7) / 8 * 8 + 2048;
+}
 static int64_t chain_g2(int64_t G) { return G >= 4 ? G / 4 : 1; }
 static int64_t chain_slice2(int64_t n_reads, int64_t G) { const int64_t g2 = chain_g2(G); return (chain_cap2(n_reads) + g2 * 256 - 1) / (g2 * 256) * 256; }
 static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int64_t chunk, bool chains) {
