@@ -627,6 +627,20 @@ __global__ __launch_bounds__(64 * (64 / LPW)) void thj_k_huff(const uint8_t* __r
 // lanes decode 64 segments of the block's bits -- a warm-up pass from one segment before each border, passes until the lanes agree on
 // where each segment's first symbol starts, and a last pass that stores the tokens.
 namespace inf2 { struct WaveOne { __device__ __forceinline__ bool any(bool p) const { return p; } }; }
+#ifdef THJ_EXP
+// developer build: where a wave of thj_k_huffp spends its clocks (lane 0's clock64 deltas, summed over all members)
+__device__ unsigned long long thj_huffp_dbg[16];
+extern "C" int thj_huffp_dbg_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(thj_huffp_dbg), sizeof thj_huffp_dbg) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(thj_huffp_dbg), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#define HP_T(i) do { const unsigned long long t__ = clock64(); hdbg[i] += t__ - htl; htl = t__; } while (0)
+#define HP_N(i, v) do { hdbg[i] += (v); } while (0)
+#else
+#define HP_T(i) do { } while (0)
+#define HP_N(i, v) do { } while (0)
+#endif
 __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
                                                   uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok, uint32_t* __restrict__ out_len, uint32_t comp_cap) {
     using namespace inf2;
@@ -650,17 +664,22 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
     const uint32_t limit = H.total * 8u;
     const uint32_t staged = (H.total + 15u + 16u) & ~15u;                   // the lanes read up to two words past the last byte
     if (staged > comp_cap) { if (lane == 0) { ntok[m] = NTOK_FALLBACK; out_len[m] = 0xFFFFFFFFu; } return; }      // an incompressible member: the one-lane kernel
+#ifdef THJ_EXP
+    unsigned long long hdbg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, htl = clock64();
+#endif
     for (uint32_t o = (uint32_t)lane * 16u; o < staged; o += 1024u) *(uint4*)((uint8_t*)cw + o) = *(const uint4*)(H.src + o);
     const uint32_t* w = cw;
     uint32_t tok_base = 0, out_base = 0, hpos = skew * 8u;
     bool fail = false;
     __syncthreads();
+    HP_T(0);
     for (;;) {
         // ---- the block's header: lane 0
         int st = ST_FALLBACK, last = 0; uint32_t dstart = 0;
         if (lane == 0) { lane_seek(H, hpos); H.state = ST_HEADER; parse_header(H, WaveOne{}); st = H.state; last = H.last; dstart = lane_bitpos(H); }
         __syncthreads();
         st = __builtin_amdgcn_readfirstlane(st); last = __builtin_amdgcn_readfirstlane(last); dstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)dstart);
+        HP_T(1); HP_N(5, 1);
         if (st != ST_DECODE) { fail = true; break; }
         // ---- segments
         const uint32_t rem = limit > dstart ? limit - dstart : 0u;
@@ -671,12 +690,14 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
         Seg r{border, 0, 0, 0};
         for (;;) {
             if (ch) r = decode_segment<false>(H.lit, H.A, H.B, w, limit, phase == 0 ? border - seg : s, phase == 0 ? border : bnext, (uint32_t*)nullptr, 0u, WaveGpu{});
-            if (phase == 0) { if (ch && r.e < MARK) s = r.e; ch = true; phase = 1; continue; }
+            HP_N(6, 1);
+            if (phase == 0) { if (ch && r.e < MARK) s = r.e; ch = true; phase = 1; HP_T(2); continue; }
             uint32_t ns = (uint32_t)__shfl_up((int)r.e, 1); if (lane == 0) ns = s;
             ch = ns < MARK && ns != s;                                        // a lane that failed says nothing about the next one's start
             if (!__any((int)ch)) break;
             s = ch ? ns : s;
         }
+        HP_T(3);
         // the first lane that did not reach its border ended the block (or the stream is bad); the lanes behind it decoded nothing real
         const uint64_t markm = __ballot(r.e >= MARK);
         const int el = markm ? __builtin_ctzll(markm) : 64;
@@ -686,6 +707,7 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
         const uint32_t tot_nt = (uint32_t)__builtin_amdgcn_readlane((int)inc_nt, 63), tot_ob = (uint32_t)__builtin_amdgcn_readlane((int)inc_ob, 63);
         if (tok_base + tot_nt > TOKCAP || out_base + tot_ob > 65536u) { fail = true; break; }
         const Seg f = decode_segment<true>(H.lit, H.A, H.B, w, limit, s, bnext, tk + tok_base + inc_nt - r.nt, out_base + inc_ob - r.ob, WaveGpu{});
+        HP_T(4);
         if (__any((int)((lane <= el && f.e == MARK_ERR) || f.nt != r.nt || f.ob != r.ob))) { fail = true; break; }
         tok_base += tot_nt; out_base += tot_ob;
         hpos = (uint32_t)__builtin_amdgcn_readlane((int)r.eob_pos, el);
@@ -693,6 +715,9 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
         __syncthreads();                                                  // the tables are about to be rebuilt
     }
     if (lane == 0) { ntok[m] = fail ? NTOK_FALLBACK : tok_base; out_len[m] = fail ? 0xFFFFFFFFu : out_base; }
+#ifdef THJ_EXP
+    if (lane == 0) { for (int k = 0; k < 10; ++k) if (hdbg[k]) atomicAdd(&thj_huffp_dbg[k], hdbg[k]); atomicAdd(&thj_huffp_dbg[12], 1ull); atomicAdd(&thj_huffp_dbg[13], (unsigned long long)tok_base); }
+#endif
 }
 
 // one wave per member.  buf = the member's output from `origin` on (at least the last 32 KiB: DEFLATE's reach); when a batch does not

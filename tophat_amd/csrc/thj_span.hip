@@ -191,10 +191,12 @@ __global__ __launch_bounds__(256, 4) void thj_k_stitch_contig(Genome g, Params p
             }
             else if (st == SPAN_NEED_GENERIC) t.wl_multi[c0 + atomicAdd(&s_cnt[1], 1u)] = r;
             else {
-                sink.nrec[(size_t)sink.base + r] = (uint8_t)(ss.emitted != 0);
                 my_rec += ss.emitted != 0;
                 if (st) atomicAdd(&sink.status[st], 1u);
             }
+            // every read's record count starts here (a read handed on: 0 until the kernel that takes it says otherwise) -- a byte a lane, a
+            // wave's 64 side by side; the 10 MB memset in front of the kernel that did this before took 20-500 us of the side's stream
+            sink.nrec[(size_t)sink.base + r] = (uint8_t)(ss.emitted != 0);
         }
         has_rec[tid] = (uint8_t)ss.emitted;
         __syncthreads();
@@ -1171,7 +1173,12 @@ static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int6
 }
 static int ensure_span_streams(thj_ctx* c) {
     if (c->span_stream[0]) return THJ_OK;
-    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithFlags(&c->span_stream[i], hipStreamNonBlocking));
+    // THJ_SPAN_PRIO=1: developer switch -- the side streams (join, closure search, finish) at the highest priority, so that a side's
+    // downstream kernels get the CUs the other side's tier 0 gives back
+    static const bool prio = getenv("THJ_SPAN_PRIO") != nullptr;
+    int lo = 0, hi = 0;
+    if (prio) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->span_stream[i], hipStreamNonBlocking, (prio && i != 1) ? hi : 0));
     for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreateWithFlags(&c->span_ev[i], hipEventDisableTiming));
     return THJ_OK;
 }
@@ -1185,7 +1192,6 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
 #ifdef THJ_EXP
     { int f = getenv("THJ_EXP_FLAGS") ? atoi(getenv("THJ_EXP_FLAGS")) : 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(thj_exp_flags), &f, sizeof f)); }
 #endif
-    HIPCHK(hipMemsetAsync(c->d_nrec + base, 0, (size_t)b.n_reads, sm));
     RecSink sink{(OutAln*)c->d_aln_pool, c->d_nrec, base, (OutAln*)c->d_aln_sorted, c->d_aln_keys, c->d_aln_count + 1,
                  (unsigned long long)c->ovf_cap, c->d_aln_count, c->d_span_status, 0, 0};
     // block-owned slices of the worklists (see Tiers)
