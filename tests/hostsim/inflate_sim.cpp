@@ -9,9 +9,56 @@
 #include <cstdlib>
 #include <vector>
 
+#include "simt.h"
+
 using namespace inf2;
 
 struct WaveCpu { bool any(bool p) const { return p; } };
+// the wave the table builders of thj_k_huffp are written against, over simt.h's fibers
+struct WaveSimT {
+    simt::Block* b; int lane;
+    uint64_t ballot(bool p) { const uint32_t* a = b->exchange(lane, p ? 1u : 0u); uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (uint64_t)(a[i] & 1u) << i; return m; }
+    void sync() { b->exchange(lane, 0); }
+};
+// the block header as thj_k_huffp takes it: lane 0 reads the code lengths, the wave builds the tables -- which must come out byte for
+// byte as the one-lane builders make them.  Returns false on a table mismatch (a test failure, not a fallback).
+static bool header_by_wave(Lane& H, std::vector<uint8_t>& lds) {
+    const HeaderInfo hi = parse_header_lengths(H, WaveCpu{});
+    // the one-lane tables from the same lengths, on a copy of the LDS slice
+    std::vector<uint8_t> ref = lds;
+    Lane R = H;
+    R.lit = (uint16_t*)ref.data(); R.A = ref.data() + OFF_A; R.B = ref.data() + OFF_B; R.C = (uint16_t*)(ref.data() + OFF_C);
+    bool ok_ref = hi.ok;
+    ok_ref = build_lit(R, R.A, hi.hlit, hi.build, WaveCpu{}) && ok_ref;
+    ok_ref = build_dist(R, R.A + hi.hlit, hi.hdist, hi.build, WaveCpu{}) && ok_ref;
+    bool ok_lane[64];
+    simt::run_block(64, [&](simt::Block& blk, int tid) {
+        WaveSimT x{&blk, tid};
+        bool ok = hi.ok;
+        ok = build_lit_wave(H.lit, H.C, H.A, hi.hlit, hi.build, x) && ok;
+        ok = build_dist_wave(H.A, H.B, H.A + hi.hlit, hi.hdist, hi.build, x) && ok;
+        ok_lane[tid] = ok;
+    });
+    for (int l = 1; l < 64; ++l) if (ok_lane[l] != ok_lane[0]) { if (getenv("THJ_SIM_TRACE")) fprintf(stderr, "ok differs between lanes\n"); return false; }
+    const bool ok = ok_lane[0];
+    if (ok != ok_ref) { if (getenv("THJ_SIM_TRACE")) fprintf(stderr, "ok %d ref %d build %d hlit %d hdist %d\n", (int)ok, (int)ok_ref, (int)hi.build, hi.hlit, hi.hdist); return false; }
+    if (hi.build && ok) {
+        if (memcmp(H.lit, R.lit, LIT_ENTRIES * 2) || memcmp(H.A, R.A, DROOT_SIZE)) {
+            if (getenv("THJ_SIM_TRACE")) {
+                for (int i = 0; i < LIT_ENTRIES; ++i) if (H.lit[i] != R.lit[i]) { fprintf(stderr, "lit[%d] = %04x, one lane: %04x\n", i, H.lit[i], R.lit[i]); break; }
+                for (int i = 0; i < DROOT_SIZE; ++i) if (H.A[i] != R.A[i]) { fprintf(stderr, "A[%d] = %02x, one lane: %02x\n", i, H.A[i], R.A[i]); break; }
+            }
+            return false;
+        }
+        // B: the per-length words and the symbol list of the long distance codes (only as many symbols as there are long codes)
+        const uint32_t *bw = (const uint32_t*)H.B, *br = (const uint32_t*)R.B;
+        uint32_t nlong = 0;
+        for (int q = 0; q < 7; ++q) { if (bw[q] != br[q]) { if (getenv("THJ_SIM_TRACE")) fprintf(stderr, "B word %d = %08x, one lane: %08x\n", q, bw[q], br[q]); return false; } nlong += (br[q] >> 15) & 63u; }
+        if (memcmp(H.B + 28, R.B + 28, nlong)) return false;
+    }
+    if (H.state == ST_HEADER) H.state = (hi.build && ok && !overrun(H)) ? ST_DECODE : ST_FALLBACK;
+    return true;
+}
 
 // one member through the lane logic.  comp / in_len: the raw DEFLATE stream; skew (0..15): how far into a 16-byte granule it starts.
 // Returns 0 and fills tokens / ntok / outp, or 1 when the lane hands the member to the fallback.
@@ -47,7 +94,7 @@ extern "C" int inflate_sim_huffp(const uint8_t* comp, uint32_t in_len, uint32_t 
     *ntok = NTOK_FALLBACK; *outp = 0;
     for (;;) {
         lane_seek(H, hpos); H.state = ST_HEADER;
-        parse_header(H, WaveCpu{});
+        if (!header_by_wave(H, lds)) return -9;            // the wave's tables differ from the one-lane builders'
         if (H.state != ST_DECODE) return 1;
         const uint32_t dstart = lane_bitpos(H);
         const uint32_t rem = limit > dstart ? limit - dstart : 0;

@@ -241,8 +241,10 @@ THJ_IHD int dist_long_raw(const uint8_t* Bt, uint32_t lo, int& n) {
 THJ_IHD int dist_long(const Lane& L, int& n) { return dist_long_raw(L.B, (uint32_t)L.buf, n); }
 
 // ---- one block header (lane in ST_HEADER): BFINAL, BTYPE, code lengths, tables.  Lock step: lanes not in ST_HEADER idle through it.
+// what the first half of a header leaves for the table builders: the code lengths in A[0 .. hlit + hdist), `build` = there are tables to build
+struct HeaderInfo { int hlit, hdist; bool build, ok; };
 template <class W>
-THJ_IHD void parse_header(Lane& L, const W& wave) {
+THJ_IHD HeaderInfo parse_header_lengths(Lane& L, const W& wave) {
     const bool live = L.state == ST_HEADER;
     int type = -1;
     if (live) { refill(L); L.last = (int)take(L, 1); type = (int)take(L, 2); }
@@ -305,10 +307,160 @@ THJ_IHD void parse_header(Lane& L, const W& wave) {
         for (int i = 280; i < 288; ++i) L.A[i] = 8;
         for (int i = 0; i < 32; ++i) L.A[288 + i] = 5;
     }
-    const bool build = (dyn && ok) || fixed;
-    ok = build_lit(L, L.A, hlit, build, wave) && ok;          // the fixed code counts its symbols 286 / 287 (they shape the canonical codes) and enters neither
-    ok = build_dist(L, L.A + hlit, hdist, build, wave) && ok;
-    if (live && L.state == ST_HEADER) L.state = (build && ok && !overrun(L)) ? ST_DECODE : ST_FALLBACK;
+    HeaderInfo hi;
+    hi.hlit = hlit; hi.hdist = hdist; hi.build = (dyn && ok) || fixed; hi.ok = ok;
+    return hi;
+}
+template <class W>
+THJ_IHD void parse_header(Lane& L, const W& wave) {
+    const bool live = L.state == ST_HEADER;
+    const HeaderInfo hi = parse_header_lengths(L, wave);
+    bool ok = hi.ok;
+    ok = build_lit(L, L.A, hi.hlit, hi.build, wave) && ok;    // the fixed code counts its symbols 286 / 287 (they shape the canonical codes) and enters neither
+    ok = build_dist(L, L.A + hi.hlit, hi.hdist, hi.build, wave) && ok;
+    if (live && L.state == ST_HEADER) L.state = (hi.build && ok && !overrun(L)) ? ST_DECODE : ST_FALLBACK;
+}
+
+// ---- the same tables built by a WAVE for one member (thj_k_huffp).  Lane 0 has read the code lengths (parse_header_lengths); on one
+// lane the tables after them -- 852 + 256 entries cleared, 286 + 30 symbols entered one after the other, each fill a loop of LDS
+// stores -- were 24-42 % of a member's time (profiles/r05_c_huffp_lz_phase_clocks.txt).  Here the lanes take a symbol each: a
+// symbol's canonical code is the first code of its length plus the number of earlier symbols of that length -- a ballot per length
+// over 64 symbols at a time; counts, first codes and running codes are the same on every lane.  Only the sub-table layout (the few
+// codes longer than the root's 9 bits, in canonical order) stays with lane 0.
+// X: lane, ballot(bool) -> 64-bit mask, sync() (LDS writes of the wave visible to the wave).
+template <class X>
+THJ_IHD bool build_lit_wave(uint16_t* lit, uint16_t* C, const uint8_t* lens, int n, bool build, X& x) {
+    const int lane = x.lane;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (!build) n = 0;
+    uint32_t cnt[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) cnt[l] = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int sy = c0 + lane;
+        const int l = sy < n ? (int)lens[sy] : 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) cnt[q] += (uint32_t)__builtin_popcountll(x.ballot(l == q));
+    }
+    bool ok = true;
+    {
+        int left = 1;
+#pragma unroll
+        for (int l = 1; l < 16; ++l) { left = (left << 1) - (int)cnt[l]; ok = ok && left >= 0; }
+    }
+    uint32_t nxt[16];
+    {
+        uint32_t code = 0;
+        nxt[0] = 0;
+#pragma unroll
+        for (int l = 1; l < 16; ++l) { nxt[l] = code; code = (code + cnt[l]) << 1; }
+    }
+    for (int i = lane; i < LIT_ENTRIES / 2; i += 64) ((uint32_t*)lit)[i] = 0u;
+    if (lane < 16) {                                   // counts and first codes where the sub-table walk below reads them
+        uint32_t c = 0, f = 0;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) { c = lane == l ? cnt[l] : c; f = lane == l ? nxt[l] : f; }
+        C[lane] = (uint16_t)c; C[16 + lane] = (uint16_t)f;
+    }
+    x.sync();
+    // sub-tables (lane 0): the codes longer than 9 bits in canonical order; codes that share their first 9 bits are neighbours there
+    bool ok0 = true;
+    if (lane == 0) {
+        uint32_t used = ROOT_SIZE; int cur_prefix = -1, cur_max = 0;
+        for (int l = ROOT + 1; l < 16; ++l) {
+            const uint32_t first = C[16 + l], c = C[l];
+            for (uint32_t k = 0; k < c; ++k) {
+                const int prefix = (int)((first + k) >> (l - ROOT));
+                if (prefix != cur_prefix) {
+                    if (cur_prefix >= 0) { const int b = cur_max - ROOT; if (used + (1u << b) > (uint32_t)LIT_ENTRIES) ok0 = false; else { lit[rev_bits((uint32_t)cur_prefix, ROOT)] = (uint16_t)(((uint32_t)P_SUB + used) << 4 | (uint32_t)b); used += 1u << b; } }
+                    cur_prefix = prefix;
+                }
+                cur_max = l;
+            }
+        }
+        if (cur_prefix >= 0) { const int b = cur_max - ROOT; if (used + (1u << b) > (uint32_t)LIT_ENTRIES) ok0 = false; else { lit[rev_bits((uint32_t)cur_prefix, ROOT)] = (uint16_t)(((uint32_t)P_SUB + used) << 4 | (uint32_t)b); used += 1u << b; } }
+    }
+    x.sync();
+    // the symbols, 64 at a time
+    bool okl = true;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int sy = c0 + lane;
+        const int l = sy < n ? (int)lens[sy] : 0;
+        uint32_t code = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const uint64_t m = x.ballot(l == q);
+            code = l == q ? nxt[q] + (uint32_t)__builtin_popcountll(m & below) : code;
+            nxt[q] += (uint32_t)__builtin_popcountll(m);
+        }
+        uint32_t f = 0, end = 0, step = 1, e = 0; uint16_t* t = lit;
+        if (l) {
+            const uint32_t payload = sy < 256 ? (uint32_t)sy : sy == 256 ? (uint32_t)P_EOB : len_payload((uint32_t)sy - 257u);
+            if (l <= ROOT) { f = rev_bits(code, l); end = ROOT_SIZE; step = 1u << l; e = payload << 4 | (uint32_t)l; }
+            else {
+                const uint32_t r = lit[rev_bits(code >> (l - ROOT), ROOT)];
+                const int j = l - ROOT, b = (int)(r & 15u);
+                if ((r >> 4) >= (uint32_t)P_SUB && (r >> 4) < (uint32_t)P_LEN && j <= b) { t = lit + ((r >> 4) - (uint32_t)P_SUB); f = rev_bits(code & ((1u << j) - 1u), j); end = 1u << b; step = 1u << j; e = payload << 4 | (uint32_t)j; }
+                else okl = false;
+            }
+            if (payload == 0 && sy > 256) end = 0;                            // 286 / 287: leave the entries empty
+        }
+        for (; x.ballot(f < end); f += step) if (f < end) t[f] = (uint16_t)e;
+    }
+    x.sync();
+    return ok && !x.ballot(!ok0 || !okl);
+}
+template <class X>
+THJ_IHD bool build_dist_wave(uint8_t* A, uint8_t* Bt, const uint8_t* dl, int n, bool build, X& x) {
+    // dl = A + hlit with hlit >= 257: the lengths sit beyond the 256 bytes of the root table built here
+    const int lane = x.lane;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (!build) n = 0;
+    const int l = lane < n && lane < 32 ? (int)dl[lane] : 0;
+    uint32_t cnt[16], first[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cnt[q] = 0;
+    uint32_t code = 0, rank = 0;
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+        const uint64_t m = x.ballot(l == q);
+        cnt[q] = (uint32_t)__builtin_popcountll(m);
+        rank = l == q ? (uint32_t)__builtin_popcountll(m & below) : rank;
+    }
+    bool ok = true;
+    {
+        int left = 1; uint32_t c2 = 0;
+        first[0] = 0;
+#pragma unroll
+        for (int q = 1; q < 16; ++q) { left = (left << 1) - (int)cnt[q]; ok = ok && left >= 0; first[q] = c2; c2 = (c2 + cnt[q]) << 1; }
+    }
+#pragma unroll
+    for (int q = 1; q < 16; ++q) code = l == q ? first[q] + rank : code;
+    for (int i = lane; i < DROOT_SIZE / 4; i += 64) ((uint32_t*)A)[i] = 0xFFFFFFFFu;
+    // long codes: B as u32[7] {first code : 15 | count : 6 << 15 | list base : 6 << 21} for lengths 9..15, then u8[32] symbols
+    uint32_t* bl = (uint32_t*)Bt; uint8_t* bsym = Bt + 28;
+    uint32_t lbase[16];
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) lbase[q] = 0;
+#pragma unroll
+        for (int q = DROOT + 1; q < 16; ++q) { lbase[q] = acc; if (lane == q) bl[q - DROOT - 1] = (first[q] & 0xFFFFu) | cnt[q] << 15 | acc << 21;   /* (the first code as the one-lane builder's u16 holds it) */ acc += cnt[q]; }
+    }
+    x.sync();
+    uint32_t f = 0, end = 0, step = 1, e = 0;
+    if (l) {
+        if (l <= DROOT) { f = rev_bits(code, l); end = DROOT_SIZE; step = 1u << l; e = (uint32_t)lane | (uint32_t)(l - 1) << 5; }
+        else {
+            uint32_t lb = 0, fc = 0;
+#pragma unroll
+            for (int q = DROOT + 1; q < 16; ++q) { lb = q == l ? lbase[q] : lb; fc = q == l ? (first[q] & 0x7FFFu) : fc; }
+            bsym[lb + (code - fc)] = (uint8_t)lane;
+        }
+    }
+    for (; x.ballot(f < end); f += step) if (f < end) A[f] = (uint8_t)e;
+    x.sync();
+    return ok;
 }
 
 // ---- one symbol (live = lane in ST_DECODE with input_ok).  Straight-line: every lane computes the match path (a literal lane's

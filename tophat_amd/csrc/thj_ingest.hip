@@ -626,7 +626,15 @@ __global__ __launch_bounds__(64 * (64 / LPW)) void thj_k_huff(const uint8_t* __r
 // One wave per member (the design note is in thj_inflate_core.h): lane 0 parses the block header and builds the tables, then the 64
 // lanes decode 64 segments of the block's bits -- a warm-up pass from one segment before each border, passes until the lanes agree on
 // where each segment's first symbol starts, and a last pass that stores the tokens.
-namespace inf2 { struct WaveOne { __device__ __forceinline__ bool any(bool p) const { return p; } }; }
+namespace inf2 {
+struct WaveOne { __device__ __forceinline__ bool any(bool p) const { return p; } };
+// the wave the table builders are written against (build_lit_wave / build_dist_wave)
+struct WaveTab {
+    int lane;
+    __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+    __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+};
+}
 #ifdef THJ_EXP
 // developer build: where a wave of thj_k_huffp spends its clocks (lane 0's clock64 deltas, summed over all members)
 __device__ unsigned long long thj_huffp_dbg[16];
@@ -676,7 +684,19 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
     for (;;) {
         // ---- the block's header: lane 0
         int st = ST_FALLBACK, last = 0; uint32_t dstart = 0;
-        if (lane == 0) { lane_seek(H, hpos); H.state = ST_HEADER; parse_header(H, WaveOne{}); st = H.state; last = H.last; dstart = lane_bitpos(H); }
+        // lane 0 reads the code lengths (a serial Huffman stream of its own), the wave builds the tables from them
+        HeaderInfo hi{288, 32, false, false};
+        if (lane == 0) { lane_seek(H, hpos); H.state = ST_HEADER; hi = parse_header_lengths(H, WaveOne{}); }
+        __syncthreads();
+        hi.hlit = __builtin_amdgcn_readfirstlane(hi.hlit); hi.hdist = __builtin_amdgcn_readfirstlane(hi.hdist);
+        hi.build = __builtin_amdgcn_readfirstlane((int)hi.build) != 0; hi.ok = __builtin_amdgcn_readfirstlane((int)hi.ok) != 0;
+        {
+            WaveTab xt{lane};
+            bool ok = hi.ok;
+            ok = build_lit_wave(H.lit, H.C, H.A, hi.hlit, hi.build, xt) && ok;
+            ok = build_dist_wave(H.A, H.B, H.A + hi.hlit, hi.hdist, hi.build, xt) && ok;
+            if (lane == 0) { if (H.state == ST_HEADER) H.state = (hi.build && ok && !overrun(H)) ? ST_DECODE : ST_FALLBACK; st = H.state; last = H.last; dstart = lane_bitpos(H); }
+        }
         __syncthreads();
         st = __builtin_amdgcn_readfirstlane(st); last = __builtin_amdgcn_readfirstlane(last); dstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)dstart);
         HP_T(1); HP_N(5, 1);
