@@ -22,8 +22,30 @@ struct WaveSimT {
 };
 // the block header as thj_k_huffp takes it: lane 0 reads the code lengths, the wave builds the tables -- which must come out byte for
 // byte as the one-lane builders make them.  Returns false on a table mismatch (a test failure, not a fallback).
-static bool header_by_wave(Lane& H, std::vector<uint8_t>& lds) {
-    const HeaderInfo hi = parse_header_lengths(H, WaveCpu{});
+static uint32_t g_hdr_end = 0;          // where the header read from the staged words ended
+static bool header_by_wave(Lane& H, std::vector<uint8_t>& lds, const uint32_t* w, uint32_t hpos, uint32_t limit) {
+    // the code lengths: read from the staged words as thj_k_huffp's lane 0 does, and through the Lane's ring as the lane-per-member
+    // kernel does -- same lengths, same verdict, same place in the stream
+    HeaderInfo hi;
+    {
+        std::vector<uint8_t> l2 = lds;
+        Lane R = H;
+        R.lit = (uint16_t*)l2.data(); R.A = l2.data() + OFF_A; R.B = l2.data() + OFF_B; R.C = (uint16_t*)(l2.data() + OFF_C); R.ring = (uint32_t*)(l2.data() + OFF_RING); R.stage = (uint32_t*)(l2.data() + OFF_STAGE);
+        lane_seek(R, hpos); R.state = ST_HEADER;
+        const HeaderInfo hr = parse_header_lengths(R, WaveCpu{});
+        const bool fb_r = R.state == ST_FALLBACK || overrun(R);
+        const HeaderW hw = parse_header_lengths_w(w, hpos, limit, H.lit, H.A, H.B, H.C);
+        hi = hw.hi;
+        const bool trace = getenv("THJ_SIM_TRACE") != nullptr;
+        if (hw.fallback != fb_r && !(hw.fallback && !hi.ok)) { if (trace) fprintf(stderr, "header: fallback %d, through the ring %d\n", (int)hw.fallback, (int)fb_r); return false; }
+        if (!hw.fallback) {
+            if (hi.hlit != hr.hlit || hi.hdist != hr.hdist || hi.build != hr.build || hi.ok != hr.ok) { if (trace) fprintf(stderr, "header: info differs\n"); return false; }
+            if (hi.build && (memcmp(H.A, R.A, (size_t)(hi.hlit + hi.hdist)) || hw.last != R.last || hw.end_bit != lane_bitpos(R))) { if (trace) fprintf(stderr, "header: lengths / end differ (%u vs %u)\n", hw.end_bit, lane_bitpos(R)); return false; }
+        }
+        H.last = hw.last;
+        H.state = hw.fallback ? ST_FALLBACK : ST_HEADER;
+        g_hdr_end = hw.end_bit;
+    }
     // the one-lane tables from the same lengths, on a copy of the LDS slice
     std::vector<uint8_t> ref = lds;
     Lane R = H;
@@ -56,7 +78,7 @@ static bool header_by_wave(Lane& H, std::vector<uint8_t>& lds) {
         for (int q = 0; q < 7; ++q) { if (bw[q] != br[q]) { if (getenv("THJ_SIM_TRACE")) fprintf(stderr, "B word %d = %08x, one lane: %08x\n", q, bw[q], br[q]); return false; } nlong += (br[q] >> 15) & 63u; }
         if (memcmp(H.B + 28, R.B + 28, nlong)) return false;
     }
-    if (H.state == ST_HEADER) H.state = (hi.build && ok && !overrun(H)) ? ST_DECODE : ST_FALLBACK;
+    if (H.state == ST_HEADER) H.state = (hi.build && ok) ? ST_DECODE : ST_FALLBACK;
     return true;
 }
 
@@ -93,10 +115,10 @@ extern "C" int inflate_sim_huffp(const uint8_t* comp, uint32_t in_len, uint32_t 
     int64_t passes = 0;
     *ntok = NTOK_FALLBACK; *outp = 0;
     for (;;) {
-        lane_seek(H, hpos); H.state = ST_HEADER;
-        if (!header_by_wave(H, lds)) return -9;            // the wave's tables differ from the one-lane builders'
+        H.state = ST_HEADER;
+        if (!header_by_wave(H, lds, w, hpos, limit)) return -9;            // the wave's tables differ from the one-lane builders'
         if (H.state != ST_DECODE) return 1;
-        const uint32_t dstart = lane_bitpos(H);
+        const uint32_t dstart = g_hdr_end;
         const uint32_t rem = limit > dstart ? limit - dstart : 0;
         uint32_t seg = (rem + 63) / 64; if (seg < 64) seg = 64;
         uint32_t s[64], bn[64]; Seg r[64]; bool ch[64];

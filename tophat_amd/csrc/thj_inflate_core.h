@@ -616,4 +616,79 @@ THJ_IHD void lane_seek(Lane& L, uint32_t bitpos) {
 }
 THJ_IHD uint32_t lane_bitpos(const Lane& L) { return (L.rd - 4u) * 8u - (uint32_t)L.cnt; }
 
+// ---- the first half of a block header read from the member's bytes where thj_k_huffp has them anyway: in LDS, as 32-bit words `w`
+// (parse_header_lengths reads through the Lane's ring, topped up from global memory 16 bytes at a time -- right for a lane that owns
+// a member, a detour for lane 0 of a wave whose member is already staged: round trips to HBM in front of a serial decode of some
+// three hundred code lengths).  Same rules, same outputs (A, and lit / B / C as scratch); bitpos / limit: bit offsets in `w`.
+struct HeaderW { HeaderInfo hi; int last; uint32_t end_bit; bool fallback; };
+THJ_IHD uint32_t pin_take(PIn& I, int n) { const uint32_t v = (uint32_t)I.buf & ((1u << n) - 1u); I.buf >>= n; I.cnt -= n; return v; }
+THJ_IHD HeaderW parse_header_lengths_w(const uint32_t* w, uint32_t bitpos, uint32_t limit, uint16_t* lit, uint8_t* A, uint8_t* Bt, uint16_t* C) {
+    HeaderW r;
+    PIn I; pin_start(I, w, bitpos);
+    pin_refill(I, true);
+    r.last = (int)pin_take(I, 1);
+    const int type = (int)pin_take(I, 2);
+    bool dyn = type == 2; const bool fixed = type == 1;
+    r.fallback = !dyn && !fixed;                                           // stored blocks (and BTYPE 3) go to the one-lane kernel
+    int hlit = 288, hdist = 32, hclen = 0;
+    bool ok = true;
+    if (dyn) { pin_refill(I, true); hlit = (int)pin_take(I, 5) + 257; hdist = (int)pin_take(I, 5) + 1; hclen = (int)pin_take(I, 4) + 4; if (hlit > 286 || hdist > 30) { ok = false; dyn = false; } }
+    uint8_t* cl = Bt;                                                      // 19 lengths, scratch
+    for (int i = 0; i < 19; ++i) cl[i] = 0;
+    {
+        static const uint8_t CLORD[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+        for (int i = 0; i < 19; ++i) if (dyn && i < hclen) { pin_refill(I, true); cl[CLORD[i]] = (uint8_t)pin_take(I, 3); }
+    }
+    {
+        for (int l = 0; l < 8; ++l) C[l] = 0;
+        for (int i = 0; i < 19; ++i) C[cl[i]]++;
+        int left = 1; for (int l = 1; l < 8; ++l) { left = (left << 1) - (int)C[l]; ok = ok && left >= 0; }
+        uint32_t code = 0; for (int l = 1; l < 8; ++l) { C[16 + l] = (uint16_t)code; code = (code + C[l]) << 1; }
+        for (int i = 0; i < 128; ++i) lit[i] = 0;
+        for (int s = 0; s < 19; ++s) {
+            const int l = cl[s];
+            if (l) {
+                const uint32_t c2 = C[16 + l]; C[16 + l] = (uint16_t)(c2 + 1);
+                for (uint32_t f = rev_bits(c2, l); f < 128u; f += 1u << l) lit[f] = (uint16_t)((uint32_t)s << 4 | (uint32_t)l);
+            }
+        }
+    }
+    {
+        const int n = hlit + hdist; int i = 0; int prev = 0;
+        bool run = dyn && ok;
+        while (run && i < n) {
+            pin_refill(I, true);
+            const uint32_t e = lit[(uint32_t)I.buf & 127u];
+            const int l = (int)(e & 15u), sym = (int)(e >> 4);
+            if (!l) { ok = false; run = false; }
+            else {
+                I.buf >>= l; I.cnt -= l;
+                if (sym < 16) { A[i++] = (uint8_t)sym; prev = sym; }
+                else {
+                    int rep, val = 0;
+                    if (sym == 16) { if (i == 0) { ok = false; run = false; } val = prev; rep = 3 + (int)pin_take(I, 2); }
+                    else if (sym == 17) { rep = 3 + (int)pin_take(I, 3); prev = 0; }
+                    else { rep = 11 + (int)pin_take(I, 7); prev = 0; }
+                    if (i + rep > n) { ok = false; run = false; rep = 0; }
+                    for (int k = 0; k < rep; ++k) A[i + k] = (uint8_t)val;
+                    i += rep;
+                }
+            }
+            if (pin_pos(I) > limit) { ok = false; run = false; }             // ran off the member's bits: whatever follows is someone else's
+        }
+        if (dyn && ok && A[256] == 0) ok = false;
+    }
+    if (fixed) {
+        for (int i = 0; i < 144; ++i) A[i] = 8;
+        for (int i = 144; i < 256; ++i) A[i] = 9;
+        for (int i = 256; i < 280; ++i) A[i] = 7;
+        for (int i = 280; i < 288; ++i) A[i] = 8;
+        for (int i = 0; i < 32; ++i) A[288 + i] = 5;
+    }
+    r.hi.hlit = hlit; r.hi.hdist = hdist; r.hi.build = (dyn && ok) || fixed; r.hi.ok = ok;
+    r.end_bit = pin_pos(I);
+    if (r.end_bit > limit) r.fallback = true;
+    return r;
+}
+
 }  // namespace inf2

@@ -686,7 +686,8 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
         int st = ST_FALLBACK, last = 0; uint32_t dstart = 0;
         // lane 0 reads the code lengths (a serial Huffman stream of its own), the wave builds the tables from them
         HeaderInfo hi{288, 32, false, false};
-        if (lane == 0) { lane_seek(H, hpos); H.state = ST_HEADER; hi = parse_header_lengths(H, WaveOne{}); }
+        bool hfall = false;
+        if (lane == 0) { const HeaderW hw = parse_header_lengths_w(w, hpos, limit, H.lit, H.A, H.B, H.C); hi = hw.hi; last = hw.last; dstart = hw.end_bit; hfall = hw.fallback; }
         __syncthreads();
         hi.hlit = __builtin_amdgcn_readfirstlane(hi.hlit); hi.hdist = __builtin_amdgcn_readfirstlane(hi.hdist);
         hi.build = __builtin_amdgcn_readfirstlane((int)hi.build) != 0; hi.ok = __builtin_amdgcn_readfirstlane((int)hi.ok) != 0;
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
             bool ok = hi.ok;
             ok = build_lit_wave(H.lit, H.C, H.A, hi.hlit, hi.build, xt) && ok;
             ok = build_dist_wave(H.A, H.B, H.A + hi.hlit, hi.hdist, hi.build, xt) && ok;
-            if (lane == 0) { if (H.state == ST_HEADER) H.state = (hi.build && ok && !overrun(H)) ? ST_DECODE : ST_FALLBACK; st = H.state; last = H.last; dstart = lane_bitpos(H); }
+            if (lane == 0) st = (!hfall && hi.build && ok) ? ST_DECODE : ST_FALLBACK;
         }
         __syncthreads();
         st = __builtin_amdgcn_readfirstlane(st); last = __builtin_amdgcn_readfirstlane(last); dstart = (uint32_t)__builtin_amdgcn_readfirstlane((int)dstart);
