@@ -22,6 +22,8 @@ struct WaveSimT {
 };
 // the block header as thj_k_huffp takes it: lane 0 reads the code lengths, the wave builds the tables -- which must come out byte for
 // byte as the one-lane builders make them.  Returns false on a table mismatch (a test failure, not a fallback).
+static uint32_t g_slot_cap = SLOT_TOKENS;          // tokens of a lane that fit its slot (tests make it small: the pass of the lanes whose tokens do not fit)
+extern "C" void inflate_sim_set_slot(uint32_t n) { g_slot_cap = n && n < SLOT_TOKENS ? n : SLOT_TOKENS; }
 static uint32_t g_hdr_end = 0;          // where the header read from the staged words ended
 static bool header_by_wave(Lane& H, std::vector<uint8_t>& lds, const uint32_t* w, uint32_t hpos, uint32_t limit) {
     // the code lengths: read from the staged words as thj_k_huffp's lane 0 does, and through the Lane's ring as the lane-per-member
@@ -122,19 +124,22 @@ extern "C" int inflate_sim_huffp(const uint8_t* comp, uint32_t in_len, uint32_t 
         const uint32_t rem = limit > dstart ? limit - dstart : 0;
         uint32_t seg = (rem + 63) / 64; if (seg < 64) seg = 64;
         uint32_t s[64], bn[64]; Seg r[64]; bool ch[64];
+        const uint32_t slot_cap = g_slot_cap;
+        std::vector<uint32_t> slots_mem((size_t)64 * SLOT_TOKENS + 4, 0xDEADBEEFu);
+        uint32_t* slots = slots_mem.data() + ((16 - ((uintptr_t)slots_mem.data() & 15)) & 15) / 4;
         for (int l = 0; l < 64; ++l) { s[l] = dstart + (uint32_t)l * seg; bn[l] = l == 63 ? MARK : s[l] + seg; ch[l] = true; }
         {   // warm-up: lane l > 0 enters the stream some segments early and takes the first symbol at or beyond its border as its start
             static const int wseg = getenv("THJ_SIM_WARMUP") ? atoi(getenv("THJ_SIM_WARMUP")) : 2;
             for (int l = 1; l < 64 && wseg > 0; ++l) {
                 const uint32_t border = s[l];
                 const uint32_t back = (uint32_t)std::min(l, wseg) * seg;
-                const Seg wu = decode_segment<false>(H.lit, H.A, H.B, w, limit, border - back, border, nullptr, 0, WaveCpu{});
+                const Seg wu = decode_segment<SEG_COUNT>(H.lit, H.A, H.B, w, limit, border - back, border, nullptr, 0, WaveCpu{});
                 if (wu.e < MARK) s[l] = wu.e;
             }
             if (wseg > 0) ++passes;
         }
         for (;;) {
-            for (int l = 0; l < 64; ++l) if (ch[l]) r[l] = decode_segment<false>(H.lit, H.A, H.B, w, limit, s[l], bn[l], nullptr, 0, WaveCpu{});
+            for (int l = 0; l < 64; ++l) if (ch[l]) r[l] = decode_segment<SEG_SLOT>(H.lit, H.A, H.B, w, limit, s[l], bn[l], slots + (size_t)l * SLOT_TOKENS, slot_cap, WaveCpu{});
             ++passes;
             bool any = false;
             uint32_t ns[64];
@@ -142,6 +147,26 @@ extern "C" int inflate_sim_huffp(const uint8_t* comp, uint32_t in_len, uint32_t 
             if (!any) break;
             if (getenv("THJ_SIM_TRACE")) { fprintf(stderr, "round %lld changed:", (long long)passes); for (int l = 0; l < 64; ++l) if (ch[l]) fprintf(stderr, " %d(%+d)", l, (int)(ns[l] - s[l])); fprintf(stderr, "\n"); }
             for (int l = 0; l < 64; ++l) if (ch[l]) s[l] = ns[l];
+        }
+        if (getenv("THJ_SIM_SYNCSTAT")) {
+            // how long a decoder entered at a segment border takes to fall into step with the true one (tokens of the true stream j, of the false one k)
+            int mj = 0, mjk = 0, nosync = 0, early = 0; long sj = 0;
+            for (int l = 1; l < 64; ++l) {
+                if (s[l] >= MARK) continue;
+                const uint32_t border = dstart + (uint32_t)l * seg;
+                uint32_t px = s[l], py = border; int j = 0, k = 0; bool fail = false;
+                while (px != py) {
+                    const bool ax = px < py;
+                    const uint32_t p0 = ax ? px : py;
+                    if (p0 >= bn[l]) { fail = true; break; }
+                    const Seg one = decode_segment<SEG_COUNT>(H.lit, H.A, H.B, w, limit, p0, p0 + 1, nullptr, 0, WaveCpu{});
+                    if (one.e >= MARK) { if (!ax) ++early; fail = true; break; }
+                    if (ax) { px = one.e; ++j; } else { py = one.e; ++k; }
+                }
+                if (fail) { ++nosync; continue; }
+                mj = std::max(mj, j); mjk = std::max(mjk, j + k); sj += j;
+            }
+            fprintf(stderr, "SYNC seg_bits %u tokens %u maxj %d maxjk %d nosync %d early %d meanj %.1f\n", seg, 0u, mj, mjk, nosync, early, sj / 63.0);
         }
         // the first lane that did not reach its border ended the block (or the stream is bad); the lanes behind it decoded nothing real
         int el = -1; uint32_t tot_nt = 0, tot_ob = 0, off_nt[64], off_ob[64];
@@ -152,11 +177,19 @@ extern "C" int inflate_sim_huffp(const uint8_t* comp, uint32_t in_len, uint32_t 
             off_nt[l] = tot_nt; off_ob[l] = tot_ob; tot_nt += r[l].nt; tot_ob += r[l].ob;
         }
         if (tok_base + tot_nt > TOKCAP || out_base + tot_ob > 65536u) return 1;
-        for (int l = 0; l < 64; ++l) {
-            const Seg f = decode_segment<true>(H.lit, H.A, H.B, w, limit, s[l], bn[l], tokens + tok_base + off_nt[l], out_base + off_ob[l], WaveCpu{});
-            if ((l <= el && f.e == MARK_ERR) || f.nt != r[l].nt || f.ob != r[l].ob) return 1;
+        bool fits = true;
+        for (int l = 0; l < 64; ++l) fits = fits && r[l].nt <= slot_cap;
+        if (fits) {
+            bool ok = true;
+            for (int l = 0; l < 64; ++l) ok = compact_segment(slots + (size_t)l * SLOT_TOKENS, r[l].nt, tokens + tok_base + off_nt[l], out_base + off_ob[l]) && ok;
+            if (!ok) return 1;
+        } else {
+            for (int l = 0; l < 64; ++l) {
+                const Seg f = decode_segment<SEG_FINAL>(H.lit, H.A, H.B, w, limit, s[l], bn[l], tokens + tok_base + off_nt[l], out_base + off_ob[l], WaveCpu{});
+                if ((l <= el && f.e == MARK_ERR) || f.nt != r[l].nt || f.ob != r[l].ob) return 1;
+            }
+            ++passes;
         }
-        ++passes;
         tok_base += tot_nt; out_base += tot_ob;
         hpos = r[el].eob_pos;
         if (H.last) break;

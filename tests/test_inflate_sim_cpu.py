@@ -144,6 +144,22 @@ def test_fuzz_against_zlib(lib):
     assert n_fast > 100
 
 
+def test_lanes_whose_tokens_do_not_fit_their_slots(lib):
+    """thj_k_huffp keeps a lane's tokens in the lane's slot until the lanes before it have counted theirs; a segment with more tokens
+    than a slot holds sends the block through a storing pass instead (inflate_sim_set_slot: the slot made small, so that ordinary
+    streams take that pass) -- the same tokens either way"""
+    lib.inflate_sim_set_slot(C.c_uint32(40))
+    try:
+        test_streams_against_zlib(lib)
+        rng = random.Random(17)
+        for n in (300, 5000, 65536):
+            data = bam_like(rng, n)
+            got, _ = run(lib, raw_deflate(data), rng.randrange(16))
+            assert got == data
+    finally:
+        lib.inflate_sim_set_slot(C.c_uint32(0))
+
+
 def test_refusals(lib):
     rng = random.Random(3)
     data = bam_like(rng, 30000)

@@ -551,9 +551,15 @@ THJ_IHD void pin_start(PIn& I, const uint32_t* w, uint32_t s) {
 THJ_IHD uint32_t pin_pos(const PIn& I) { return (I.widx - 1u) * 32u - (uint32_t)I.cnt; }
 THJ_IHD void pin_refill(PIn& I, bool want) { if (want && I.cnt <= 32) { I.buf |= (uint64_t)I.nextw << I.cnt; I.cnt += 32; I.nextw = I.w[I.widx++]; } }
 
-// the symbols that start in [s, bnext), from tables lit / A / B.  STORE: the last pass -- tokens go to tok[], outp0 = the output position
-// of the first, and distances are checked against it.  limit = bits the member has.
-template <bool STORE, class W>
+// the symbols that start in [s, bnext), from tables lit / A / B.  limit = bits the member has.  MODE:
+//   SEG_COUNT  nothing is stored (the warm-up pass);
+//   SEG_SLOT   tokens go to tok[] while they fit (outp0 = the slot's capacity; the count runs on): the lane's own slot of the member's
+//              scratch, from which compact_segment moves them to their place once the lanes agree and the counts before it are known;
+//   SEG_FINAL  tokens go to tok[] = their final place, outp0 = the output position of the first, distances are checked against it
+//              (a pass of its own after the agreement: only when a lane's tokens did not fit its slot).
+constexpr int SEG_COUNT = 0, SEG_FINAL = 1, SEG_SLOT = 2;
+constexpr uint32_t SLOT_TOKENS = 2u * TOKCAP / 64u;       // a lane's slot: twice an even share of the most a member can hold
+template <int MODE, class W>
 THJ_IHD Seg decode_segment(const uint16_t* lit, const uint8_t* A, const uint8_t* Bt, const uint32_t* w, uint32_t limit, uint32_t s, uint32_t bnext,
                            uint32_t* tok, uint32_t outp0, const W& wave) {
     Seg r{s, 0, 0, 0};
@@ -592,15 +598,43 @@ THJ_IHD Seg decode_segment(const uint16_t* lit, const uint8_t* A, const uint8_t*
         pos = pin_pos(I);
         const uint32_t adv = is_lit ? 1u : len;
         bool bad = n == 0u || (is_len && (ds < 0 || ds >= 30)) || pos > limit;
-        if (STORE) bad = bad || (is_len && dist > outp0 + ob) || (!is_eob && outp0 + ob + adv > 65536u);
+        if (MODE == SEG_FINAL) bad = bad || (is_len && dist > outp0 + ob) || (!is_eob && outp0 + ob + adv > 65536u);
         if (bad) { r.e = MARK_ERR; break; }
         if (is_eob) { r.e = MARK_EOB; r.eob_pos = pos; break; }
-        if (STORE) tok[nt] = is_lit ? p : tok_match(len, dist);
+        if (MODE == SEG_FINAL || (MODE == SEG_SLOT && nt < outp0)) tok[nt] = is_lit ? p : tok_match(len, dist);
         ++nt; ob += adv;
     }
     if (r.e == MARK_NONE) r.e = pos;                       // the first symbol at or beyond the border
     r.nt = nt; r.ob = ob;
     return r;
+}
+
+// a lane's n tokens from its slot to their place in the member's token list, with the checks the decode could not make before the
+// output position of its first token (outp0) was known: no match reaches back beyond the member's first byte, the member ends within
+// 64 KiB.  Returns false when one fails.
+THJ_IHD bool compact_segment(const uint32_t* slot, uint32_t n, uint32_t* dst, uint32_t outp0) {
+    uint32_t outp = outp0; bool ok = true;
+    uint32_t t = 0;
+    for (; t + 4u <= n; t += 4u) {                          // (slots are 16-byte aligned)
+        struct alignas(16) Q { uint32_t x, y, z, w; };
+        const Q q = *(const Q*)(slot + t);
+        const uint32_t v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool m = (v[k] >> 31) != 0u;
+            ok = ok && !(m && (v[k] & 0x7FFFu) + 1u > outp);
+            outp += m ? ((v[k] >> 15) & 255u) + 3u : 1u;
+            dst[t + k] = v[k];
+        }
+    }
+    for (; t < n; ++t) {
+        const uint32_t v = slot[t];
+        const bool m = (v >> 31) != 0u;
+        ok = ok && !(m && (v & 0x7FFFu) + 1u > outp);
+        outp += m ? ((v >> 15) & 255u) + 3u : 1u;
+        dst[t] = v;
+    }
+    return ok && outp <= 65536u;
 }
 
 // lane 0's Lane at a bit position of the aligned stream (the first block: skew * 8; later blocks: the bit after the end-of-block code)

@@ -650,7 +650,7 @@ extern "C" int thj_huffp_dbg_read(unsigned long long* out, int reset) {
 #define HP_N(i, v) do { } while (0)
 #endif
 __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ comp, const thj_bgzf_block* __restrict__ blocks, int n_blocks,
-                                                  uint32_t* __restrict__ tokens, uint32_t* __restrict__ ntok, uint32_t* __restrict__ out_len, uint32_t comp_cap) {
+                                                  uint32_t* __restrict__ tokens, uint32_t* __restrict__ slots, uint32_t* __restrict__ ntok, uint32_t* __restrict__ out_len, uint32_t comp_cap) {
     using namespace inf2;
     // [tables and lane 0's input ring: STRIDE_WORDS words][the member's compressed bytes, from the 16-byte granule its first byte is in: comp_cap bytes]
     // The 64 lanes read 64 places of the stream at once: from HBM that is 64 cache lines per load and, with a few waves on a CU, an L1
@@ -668,6 +668,7 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
     H.buf = 0; H.cnt = 0; H.nextw = 0; H.rd = 4; H.ld = 0; H.outp = 0; H.ntok = 0; H.nflushed = 0; H.state = ST_HEADER; H.last = 0; H.inflight = false;
     H.pend[0] = H.pend[1] = H.pend[2] = H.pend[3] = 0;
     uint32_t* tk = tokens + (size_t)m * TOKCAP;
+    uint32_t* slot = slots + ((size_t)m * 64 + (size_t)lane) * SLOT_TOKENS;    // this lane's tokens until the lanes before it have counted theirs
     H.tok = tk;
     const uint32_t limit = H.total * 8u;
     const uint32_t staged = (H.total + 15u + 16u) & ~15u;                   // the lanes read up to two words past the last byte
@@ -710,7 +711,8 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
         bool ch = lane > 0; int phase = 0;
         Seg r{border, 0, 0, 0};
         for (;;) {
-            if (ch) r = decode_segment<false>(H.lit, H.A, H.B, w, limit, phase == 0 ? border - seg : s, phase == 0 ? border : bnext, (uint32_t*)nullptr, 0u, WaveGpu{});
+            if (phase == 0) { if (ch) r = decode_segment<SEG_COUNT>(H.lit, H.A, H.B, w, limit, border - seg, border, (uint32_t*)nullptr, 0u, WaveGpu{}); }
+            else if (ch) r = decode_segment<SEG_SLOT>(H.lit, H.A, H.B, w, limit, s, bnext, slot, SLOT_TOKENS, WaveGpu{});
             HP_N(6, 1);
             if (phase == 0) { if (ch && r.e < MARK) s = r.e; ch = true; phase = 1; HP_T(2); continue; }
             uint32_t ns = (uint32_t)__shfl_up((int)r.e, 1); if (lane == 0) ns = s;
@@ -727,9 +729,14 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
         const uint32_t inc_nt = wave_incl_scan(r.nt), inc_ob = wave_incl_scan(r.ob);
         const uint32_t tot_nt = (uint32_t)__builtin_amdgcn_readlane((int)inc_nt, 63), tot_ob = (uint32_t)__builtin_amdgcn_readlane((int)inc_ob, 63);
         if (tok_base + tot_nt > TOKCAP || out_base + tot_ob > 65536u) { fail = true; break; }
-        const Seg f = decode_segment<true>(H.lit, H.A, H.B, w, limit, s, bnext, tk + tok_base + inc_nt - r.nt, out_base + inc_ob - r.ob, WaveGpu{});
+        // the tokens to their places: from the slots -- or, when a lane's did not fit its slot, by a pass that decodes them again
+        if (!__any((int)(r.nt > SLOT_TOKENS))) {
+            if (__any((int)!compact_segment(slot, r.nt, tk + tok_base + inc_nt - r.nt, out_base + inc_ob - r.ob))) { fail = true; break; }
+        } else {
+            const Seg f = decode_segment<SEG_FINAL>(H.lit, H.A, H.B, w, limit, s, bnext, tk + tok_base + inc_nt - r.nt, out_base + inc_ob - r.ob, WaveGpu{});
+            if (__any((int)((lane <= el && f.e == MARK_ERR) || f.nt != r.nt || f.ob != r.ob))) { fail = true; break; }
+        }
         HP_T(4);
-        if (__any((int)((lane <= el && f.e == MARK_ERR) || f.nt != r.nt || f.ob != r.ob))) { fail = true; break; }
         tok_base += tot_nt; out_base += tot_ob;
         hpos = (uint32_t)__builtin_amdgcn_readlane((int)r.eob_pos, el);
         if (last) break;
@@ -889,17 +896,18 @@ static int launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_bloc
         return THJ_OK;
     }
     // the token streams between the two kernels take TOKCAP words per member (more than the member's 64 KiB of output): a launch of
-    // many members goes through in pieces of INFL_CHUNK of them over one scratch buffer, so that the scratch stays bounded (0.7 GB)
+    // many members goes through in pieces of INFL_CHUNK of them over one scratch buffer, so that the scratch stays bounded (2 GB: 80 KiB of tokens and 160 KiB of slots a member)
     // whatever the caller hands over
     const int64_t INFL_CHUNK = getenv("THJ_INFLATE_CHUNK") && atoll(getenv("THJ_INFLATE_CHUNK")) > 0 ? atoll(getenv("THJ_INFLATE_CHUNK")) : 8192;      // (the variable: tests)
     const int64_t per = nb < INFL_CHUNK ? nb : INFL_CHUNK;
-    const size_t need = (size_t)per * ((size_t)inf2::TOKCAP * 4 + 8) + 256;
+    const size_t need = (size_t)per * ((size_t)inf2::TOKCAP * 4 + (size_t)64 * inf2::SLOT_TOKENS * 4 + 8) + 256;      // token lists, the lanes' slots, counts
     if (c->infl_tmp_cap < need) {
         HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_infl_tmp); c->d_infl_tmp = nullptr; c->infl_tmp_cap = 0;
         HIPCHK(hipMalloc(&c->d_infl_tmp, need + need / 4)); c->infl_tmp_cap = need + need / 4;
     }
     uint32_t* d_tok = (uint32_t*)c->d_infl_tmp;
-    uint32_t* d_ntok = d_tok + (size_t)per * inf2::TOKCAP;
+    uint32_t* d_slots = d_tok + (size_t)per * inf2::TOKCAP;
+    uint32_t* d_ntok = d_slots + (size_t)per * 64 * inf2::SLOT_TOKENS;
     uint32_t* d_fb = d_ntok + per;
     uint32_t* d_fbn = d_fb + per;
     for (int64_t at = 0; at < nb; at += per) {
@@ -915,7 +923,7 @@ static int launch_inflate(thj_ctx* c, const uint8_t* d_comp, const thj_bgzf_bloc
             uint32_t cap = max_in_len ? max_in_len + 64u : 24576u;
             cap = (cap + 255u) & ~255u;
             if (cap > 61440u - 2560u) cap = 61440u - 2560u;
-            hipLaunchKernelGGL(thj_k_huffp, dim3((unsigned)n), dim3(64), (size_t)(inf2::STRIDE_WORDS + 1) * 4 + cap, c->stream, d_comp, blk, (int)n, d_tok, d_ntok, len, cap);
+            hipLaunchKernelGGL(thj_k_huffp, dim3((unsigned)n), dim3(64), (size_t)(inf2::STRIDE_WORDS + 1) * 4 + cap, c->stream, d_comp, blk, (int)n, d_tok, d_slots, d_ntok, len, cap);
         }
         else if (lpw == 16) hipLaunchKernelGGL(thj_k_huff<16>, g, dim3(256), 0, c->stream, d_comp, blk, (int)n, d_tok, d_ntok, len);
         else if (lpw == 32) hipLaunchKernelGGL(thj_k_huff<32>, g, dim3(128), 0, c->stream, d_comp, blk, (int)n, d_tok, d_ntok, len);
