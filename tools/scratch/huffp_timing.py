@@ -13,8 +13,9 @@ l = host.load_lib()
 out = (C.c_ulonglong * 16)()
 assert l.thj_huffp_dbg_read(out, 0) == 0
 v = list(out)
-mem = max(1, v[12]); names = ["compressed bytes to LDS", "block header + tables (lane 0)", "warm-up pass", "agreement passes", "last pass (tokens out) + scans"]
-tot = sum(v[:5])
+mem = max(1, v[12]); names = ["compressed bytes to LDS", "header: tables built by the wave", "warm-up pass", "agreement passes", "last pass (tokens out) + scans"]
+tot = sum(v[:5]) + v[7]
+print("  %%-36s %%6.1f %%%%  %%.0f clocks per member" %% ("header: code lengths read by lane 0", 100.0 * v[7] / max(1, tot), v[7] / mem))
 print("members", v[12], "blocks/member %%.2f  passes/block %%.2f  tokens/member %%.0f  clocks/member %%.0f" %% (v[5] / mem, v[6] / max(1, v[5]), v[13] / mem, tot / mem))
 for i, nm in enumerate(names): print("  %%-36s %%6.1f %%%%  %%.0f clocks per member" %% (nm, 100.0 * v[i] / max(1, tot), v[i] / mem))
 """ % ROOT

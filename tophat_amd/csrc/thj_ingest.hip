@@ -690,6 +690,7 @@ __global__ __launch_bounds__(64) void thj_k_huffp(const uint8_t* __restrict__ co
         bool hfall = false;
         if (lane == 0) { const HeaderW hw = parse_header_lengths_w(w, hpos, limit, H.lit, H.A, H.B, H.C); hi = hw.hi; last = hw.last; dstart = hw.end_bit; hfall = hw.fallback; }
         __syncthreads();
+        HP_T(7);
         hi.hlit = __builtin_amdgcn_readfirstlane(hi.hlit); hi.hdist = __builtin_amdgcn_readfirstlane(hi.hdist);
         hi.build = __builtin_amdgcn_readfirstlane((int)hi.build) != 0; hi.ok = __builtin_amdgcn_readfirstlane((int)hi.ok) != 0;
         {

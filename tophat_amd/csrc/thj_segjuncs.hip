@@ -473,19 +473,29 @@ __global__ __launch_bounds__(TPB) void thj_k_sj_rescue_flat(Params p, DevBatch b
 // in thj_k_segjuncs_shared they cost 25 us apiece, most of it the wave's own chain of global loads), beyond that to
 // thj_k_segjuncs_shared's, one global add per workgroup, round and list.  Rescue reads go on to thj_k_segjuncs_rescue; windows and
 // indel pairs are queued in LDS and executed in whole rounds as before.
-static constexpr int GEN_HITS = 12;        // hits of a read the first instance stages
+#ifndef THJ_GEN_HITS
+#define THJ_GEN_HITS 8
+#endif
+static constexpr int GEN_HITS = THJ_GEN_HITS;        // hits of a read the first instance stages
 static constexpr int MID_HITS = 32;        // ... the second (more: thj_k_segjuncs_shared, or rl.many_min if that is smaller)
-static constexpr int MID_T = 64;
+static constexpr int MID_T = 256;
+static constexpr int MID_G = 8;            // lanes a read of the second instance's list is shared by
 static constexpr int MID_GRID = 2048;
-template <int HITS, int T, bool SLICED, int SO>
+template <int HITS, int T, bool SLICED, int SO, int G = 1>
 __global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, RescueList rl, SjLists sl, XTasks x, unsigned long long* cnt) {
-    constexpr int STRIDE = HITS + 1;       // uint4 per thread (an odd count: the threads of a wave spread over the banks)
+    // G: lanes that share a read (a power of two <= 64, adjacent lanes of one wave).  1: a thread per read.  More -- the second instance,
+    // reads of three to eight hits a segment --: lane g of the group takes every G-th hit of each sweep (gaps_prepare_shared,
+    // indels_enumerate / gaps_enumerate with (first, stride)), so that a read's sweeps of k x k hit pairs are k steps long, not k x k:
+    // with a thread per read the find_gaps sweeps were 0.18 of this instance's 0.26 ms (THJ_EXP build, flag 1 << 18).
+    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0 && T % G == 0 && (G == 1 || !SLICED), "lanes per read");
+    constexpr int RPR = T / G;             // reads per round
+    constexpr int STRIDE = HITS + 1;       // uint4 per read (an odd count: the threads of a wave spread over the banks)
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
-    __shared__ uint4 s_hits[T * STRIDE];
-    __shared__ uint32_t s_so[T * SO];                       // SO: words of a read's CSR row (nseg + 1 <= 9, or <= 17 for reads of more than eight segments)
+    __shared__ uint4 s_hits[RPR * STRIDE];
+    __shared__ uint32_t s_so[RPR * SO];                     // SO: words of a read's CSR row (nseg + 1 <= 9, or <= 17 for reads of more than eight segments)
     __shared__ unsigned int q_n, s_nresc, s_base[3], s_xbase;
     __shared__ unsigned int s_stat[4];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, slot = tid / G, g = tid % G;
     if (tid < 4) s_stat[tid] = 0;
     if (tid == 0) { q_n = 0; s_nresc = 0; }
     __syncthreads();
@@ -493,11 +503,11 @@ __global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, Resc
     const Queue qq{q_a, q_b, q_c, q_d, q_e, &q_n};
     const unsigned int n = SLICED ? sl.gen_cnt[blockIdx.x] : (*sl.mid_count < (unsigned int)MANY_CAP ? *sl.mid_count : (unsigned int)MANY_CAP);
     const uint32_t* list = SLICED ? sl.gen + (size_t)blockIdx.x * rl.seg_cap : sl.mid_list;
-    const unsigned int first = SLICED ? 0u : blockIdx.x * T, step = SLICED ? (unsigned int)T : gridDim.x * T;
+    const unsigned int first = SLICED ? 0u : blockIdx.x * RPR, step = SLICED ? (unsigned int)RPR : gridDim.x * RPR;
     unsigned int my_windows = 0, my_indels = 0;
     for (unsigned int k0 = first; k0 < n; k0 += step) {
         __syncthreads();
-        const unsigned int k = k0 + (unsigned int)tid;
+        const unsigned int k = k0 + (unsigned int)slot;
         bool active = k < n;
         ReadView v;
         bool do_gaps = false, to_rescue = false;
@@ -510,34 +520,36 @@ __global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, Resc
             v = make_view(b, r);
             const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
             if (nh <= (uint32_t)HITS) {              // (a read a full list left here has more: it walks its hits in HBM)
-                for (int i = 0; i <= v.nseg; ++i) s_so[tid * SO + i] = v.so[i] - h0;
-                for (uint32_t i = 0; i < nh; ++i) s_hits[tid * STRIDE + i] = ((const uint4*)b.hits)[h0 + i];
-                v.so = s_so + tid * SO; v.hits = (const Hit*)(s_hits + tid * STRIDE); hbase = h0;
+                for (int i = g; i <= v.nseg; i += G) s_so[slot * SO + i] = v.so[i] - h0;
+                for (uint32_t i = (uint32_t)g; i < nh; i += (uint32_t)G) s_hits[slot * STRIDE + i] = ((const uint4*)b.hits)[h0 + i];
+                v.so = s_so + slot * SO; v.hits = (const Hit*)(s_hits + slot * STRIDE); hbase = h0;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the copy is read back as Hit records
         if (active) {
             bool wants = false;
-            do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants);
+            if (G == 1) do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare(p, v, wants);
+            else do_gaps = !THJ_EXPF(1 << 18) && gaps_prepare_shared(p, v, wants, g, G, [&](bool f) { return ((__ballot(f) >> (lane - g)) & (~0ull >> (64 - G))) != 0ull; });
             to_rescue = do_gaps && wants;
             if (!to_rescue) {
                 QueueSink qs{qq, x, (uint32_t)r, hbase, 0u, 0u};
-                if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs);
-                if (do_gaps) gaps_enumerate(p, v, qs);
+                if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, g, G);
+                if (do_gaps) gaps_enumerate(p, v, qs, g, G);
                 my_windows += qs.n_windows; my_indels += qs.n_indels;
             }
         }
+        const bool resc = to_rescue && g == 0;                  // (one lane lists the read)
         if (SLICED) {        // rescue reads: the slice of the same number (thj_k_sj_flat left it empty)
-            const unsigned int rk = wave_slot(to_rescue, &s_nresc, below);
-            if (to_rescue) rl.list[(size_t)blockIdx.x * rl.seg_cap + rk] = (uint32_t)r;
+            const unsigned int rk = wave_slot(resc, &s_nresc, below);
+            if (resc) rl.list[(size_t)blockIdx.x * rl.seg_cap + rk] = (uint32_t)r;
         } else {             // ... thj_k_segjuncs_shared's slice, a range of it per round
             if (tid == 0) s_nresc = 0;
             __syncthreads();
-            const unsigned int rk = wave_slot(to_rescue, &s_nresc, below);
+            const unsigned int rk = wave_slot(resc, &s_nresc, below);
             __syncthreads();
             if (tid == 0 && s_nresc) s_base[2] = atomicAdd(&rl.blk_cnt[rl.own_slice], s_nresc);
             __syncthreads();
-            if (to_rescue) rl.list[(size_t)rl.own_slice * rl.seg_cap + s_base[2] + rk] = (uint32_t)r;
+            if (resc) rl.list[(size_t)rl.own_slice * rl.seg_cap + s_base[2] + rk] = (uint32_t)r;
         }
         flush_tasks(qq, x, &s_xbase, &s_stat[3]);
     }
@@ -1462,9 +1474,9 @@ static int sj_launch_rest(thj_ctx* c, SjState& st, int set, bool* joined) {
     hipEvent_t a1 = mark(sa);
     hipEvent_t c0 = mark(sc);
     {
-        const int mgrid = n_tiles * (TPB / MID_T) < MID_GRID ? n_tiles * (TPB / MID_T) : MID_GRID;
-        if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 9>), dim3(mgrid), dim3(MID_T), 0, sc, p, b, rl, sl, x, c->d_cnt);
-        else hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 17>), dim3(mgrid), dim3(MID_T), 0, sc, p, b, rl, sl, x, c->d_cnt);
+        const int mgrid = n_tiles < MID_GRID ? n_tiles : MID_GRID;
+        if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 9, MID_G>), dim3(mgrid), dim3(MID_T), 0, sc, p, b, rl, sl, x, c->d_cnt);
+        else hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 17, MID_G>), dim3(mgrid), dim3(MID_T), 0, sc, p, b, rl, sl, x, c->d_cnt);
     }
     hipEvent_t c1 = mark(sc);
     if (!serial) { HIPCHK(hipEventRecord(aev[4], sc)); HIPCHK(hipStreamWaitEvent(sa, aev[2], 0)); HIPCHK(hipStreamWaitEvent(sa, aev[4], 0)); }
