@@ -32,7 +32,12 @@ struct thj_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t aux_stream[6] = {}; hipEvent_t aux_ev[10] = {};   // stage 1's side chains, two sets (sj_launch in thj_segjuncs.hip)
+    // the side streams for everything that runs beside the context's stream: [0] / [1] = the first / second batch of a pair call, in
+    // stage 1 (sj_launch in thj_segjuncs.hip) and in stage 2 (span_stream below points at the same); [2] only behind developer switches.
+    // Two in use, not one per chain: HIP spreads streams over GPU_MAX_HW_QUEUES (4) hardware queues round robin, two streams on one
+    // queue run one after the other, and a process has other streams too -- with ten streams the second side's chain of stage 1 sat
+    // behind the first side's (profiles/r05_e_timeline.txt)
+    hipStream_t aux_stream[3] = {}; hipEvent_t aux_ev[10] = {};
     // genome
     const u64* d_blocks = nullptr; bool own_blocks = false;
     uint32_t* d_contig_blk = nullptr; int32_t* d_contig_len = nullptr;
@@ -73,7 +78,7 @@ struct thj_ctx {
     // scratch of a batch in flight (span_launch in thj_span.hip): two sets, so that the two sides of a pass can run beside each other
     struct SpanSet { uint32_t* d_worklist = nullptr; int64_t worklist_cap = 0; void* d_ent = nullptr; int64_t ent_cap = 0; void* d_joined = nullptr; int64_t joined_cap = 0; uint32_t* d_defer = nullptr; int64_t defer_cap = 0; };
     SpanSet span_set[2]; int span_last_set = 0;
-    hipStream_t span_stream[3] = {}; hipEvent_t span_ev[8] = {};
+    hipStream_t span_stream[3] = {}; hipEvent_t span_ev[8] = {}; bool span_stream_own = false;      // (= aux_stream unless THJ_SPAN_PRIO)
     bool span_profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;
     // coverage search (thj_covsearch_impl.h)
@@ -116,6 +121,7 @@ struct thj_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 hipEvent_t thj_get_event(struct thj_ctx* c);
+int thj_ensure_aux_streams(struct thj_ctx* c);                      // thj_segjuncs.hip: aux_stream[3], aux_ev[10] (once)
 void thj_warm_span(hipStream_t s); void thj_warm_ingest(hipStream_t s); void thj_warm_bamout(hipStream_t s);      // one empty launch from the translation unit: its code object is loaded now
 int thj_dev_alloc(struct thj_ctx* c, void** out, size_t bytes);     // like hipMalloc, from the context's block cache
 void thj_dev_release(struct thj_ctx* c, void* p);                  // like hipFree, but the block stays with the context

@@ -481,13 +481,17 @@ static constexpr int MID_HITS = 32;        // ... the second (more: thj_k_segjun
 static constexpr int MID_T = 256;
 static constexpr int MID_G = 8;            // lanes a read of the second instance's list is shared by
 static constexpr int MID_GRID = 2048;
+#ifndef THJ_GEN_G
+#define THJ_GEN_G 4
+#endif
+static constexpr int GEN_G = THJ_GEN_G;    // ... of the first instance's
 template <int HITS, int T, bool SLICED, int SO, int G = 1>
 __global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, RescueList rl, SjLists sl, XTasks x, unsigned long long* cnt) {
     // G: lanes that share a read (a power of two <= 64, adjacent lanes of one wave).  1: a thread per read.  More -- the second instance,
     // reads of three to eight hits a segment --: lane g of the group takes every G-th hit of each sweep (gaps_prepare_shared,
     // indels_enumerate / gaps_enumerate with (first, stride)), so that a read's sweeps of k x k hit pairs are k steps long, not k x k:
     // with a thread per read the find_gaps sweeps were 0.18 of this instance's 0.26 ms (THJ_EXP build, flag 1 << 18).
-    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0 && T % G == 0 && (G == 1 || !SLICED), "lanes per read");
+    static_assert(G >= 1 && G <= 64 && (G & (G - 1)) == 0 && T % G == 0, "lanes per read");
     constexpr int RPR = T / G;             // reads per round
     constexpr int STRIDE = HITS + 1;       // uint4 per read (an odd count: the threads of a wave spread over the banks)
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
@@ -1130,7 +1134,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); hipFree(c->d_infl_tmp); thj_dev_cache_free(c);
     for (hipEvent_t e : c->prof_all) hipEventDestroy(e);
     for (auto e : c->event_pool) hipEventDestroy(e);
-    for (int i = 0; i < 6; ++i) if (c->aux_stream[i]) hipStreamDestroy(c->aux_stream[i]);
+    for (int i = 0; i < 3; ++i) if (c->aux_stream[i]) hipStreamDestroy(c->aux_stream[i]);
     for (int i = 0; i < 10; ++i) if (c->aux_ev[i]) hipEventDestroy(c->aux_ev[i]);
     if (c->own_stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1183,6 +1187,18 @@ extern "C" int thj_genome_adopt(thj_ctx* c, const void* d_blocks, int64_t n_bloc
     if (c->own_blocks) hipFree((void*)c->d_blocks);
     c->d_blocks = (const u64*)d_blocks; c->own_blocks = false;
     return set_contigs(c, contig_blk, lens, n_contigs, n_blocks);
+}
+
+int thj_ensure_aux_streams(thj_ctx* c) {
+    if (c->aux_stream[0]) return THJ_OK;
+    // (THJ_SJ_PRIO=1: the side streams at the highest priority the device has -- measured worse, 7.0 against 6.6 ms per step: the flat reads'
+    // rescue scan then waits for them)
+    int lo = 0, hi = 0;
+    static const bool prio = getenv("THJ_SJ_PRIO") && atoi(getenv("THJ_SJ_PRIO")) != 0;
+    if (prio) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->aux_stream[i], hipStreamNonBlocking, prio ? hi : 0));
+    for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming));
+    return THJ_OK;
 }
 
 // ------------------------------------------------------------------ batches
@@ -1423,22 +1439,17 @@ static int sj_launch_flat(thj_ctx* c, const thj_params* tp, const thj_seg_batch*
     const bool wide = p.segment_length > 32;
     // Two chains after thj_k_sj_flat, side by side on two streams: the flat reads' (rescue scan, rescue enumeration, tasks:
     // dense, bound by the genome lines they fetch) on the context's stream, and the reads with several hits a segment (general x 2,
-    // shared, rescue x 2: few waves per CU, each waiting on its own chain of loads) on a stream of the context's own, with
-    // thj_k_segjuncs_shared beside thj_k_sj_general's second instance on a third.  Everything is joined on the context's stream
-    // again before this function returns; the event tables take inserts from any of them.  THJ_SJ_SERIAL=1: one stream.
+    // rescue x 2, tasks: few waves per CU, each waiting on its own chain of loads) on a side stream, with thj_k_segjuncs_shared
+    // beside them on another.  Everything is joined on the context's stream again before the caller returns; the event tables
+    // take inserts from any of them.  THJ_SJ_SERIAL=1: one stream.
     static const bool serial_env = getenv("THJ_SJ_SERIAL") && atoi(getenv("THJ_SJ_SERIAL")) != 0;
     const bool serial = serial_env || c->serial_launch;
-    if (!serial && !c->aux_stream[3 * set]) {
-        // (THJ_SJ_PRIO=1: the side streams at the highest priority the device has -- measured worse, 7.0 against 6.6 ms per step: the flat reads'
-        // rescue scan then waits for them)
-        int lo = 0, hi = 0;
-        static const bool prio = getenv("THJ_SJ_PRIO") && atoi(getenv("THJ_SJ_PRIO")) != 0;
-        if (prio) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->aux_stream[3 * set + i], hipStreamNonBlocking, prio ? hi : 0));
-        for (int i = 0; i < 5; ++i) HIPCHK(hipEventCreateWithFlags(&c->aux_ev[5 * set + i], hipEventDisableTiming));
-    }
-    hipStream_t sm = c->stream, sa = serial ? c->stream : c->aux_stream[3 * set], sb = serial ? c->stream : c->aux_stream[3 * set + 1],
-                sc = serial ? c->stream : c->aux_stream[3 * set + 2];
+    if (!serial) { const int src = thj_ensure_aux_streams(c); if (src) return src; }
+    // the set's chain on the set's side stream: thj_k_segjuncs_shared, both general instances, then the rescue kernels and the tasks.
+    // (THJ_SJ_SHARED_BESIDE: developer switch -- thj_k_segjuncs_shared beside the chain on a third side stream, as before round 5; the third
+    // stream shares a hardware queue with one of the others, and what was enqueued behind it waited: 5.7 against 5.55 ms per step)
+    static const bool beside = getenv("THJ_SJ_SHARED_BESIDE") != nullptr;
+    hipStream_t sm = c->stream, sa = serial ? c->stream : c->aux_stream[set], sb = serial ? c->stream : beside ? c->aux_stream[2] : sa, sc = sa;
     hipEvent_t* const aev = c->aux_ev + 5 * set;
     // profiling: one pair of events around every kernel (pairs of kernels where the second is the first's tail), on the stream it runs on;
     // SJ_PROF_N intervals per launch, in the order thj_profile_segjuncs documents
@@ -1448,7 +1459,7 @@ static int sj_launch_flat(thj_ctx* c, const thj_params* tp, const thj_seg_batch*
     else if (b.nseg <= 8) hipLaunchKernelGGL(thj_k_sj_flat<8>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
     else hipLaunchKernelGGL(thj_k_sj_flat<16>, dim3(grid), dim3(TPB), 0, sm, p, b, rl, sl, c->d_cnt);
     hipEvent_t m1 = mark(sm);
-    if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); HIPCHK(hipStreamWaitEvent(sb, aev[0], 0)); HIPCHK(hipStreamWaitEvent(sc, aev[0], 0)); }
+    if (!serial) { HIPCHK(hipEventRecord(aev[0], sm)); HIPCHK(hipStreamWaitEvent(sa, aev[0], 0)); }      // (sb waits where its kernel is launched: it is shared by the sets)
     st.g = g; st.p = p; st.b = b; st.t = t; st.rl = rl; st.sl = sl; st.x = x; st.grid = grid; st.n_tiles = n_tiles; st.wide = wide; st.serial = serial;
     st.sm = sm; st.sa = sa; st.sb = sb; st.sc = sc; st.aev = aev; st.m0 = m0; st.m1 = m1;
     HIPCHK(hipGetLastError());
@@ -1465,13 +1476,10 @@ static int sj_launch_rest(thj_ctx* c, SjState& st, int set, bool* joined) {
     // ---- the reads with several hits a segment
     const int rgrid = grid < RESCUE_GRID ? grid : RESCUE_GRID;
     hipEvent_t b0 = mark(sb);
+    if (!serial) HIPCHK(hipStreamWaitEvent(sb, aev[0], 0));
     hipLaunchKernelGGL(thj_k_segjuncs_shared, dim3(rgrid), dim3(TPB), 0, sb, p, b, rl, x, c->d_cnt);     // the reads with many hits: a wave each (the longest of the three: first)
     hipEvent_t b1 = mark(sb);
     if (!serial) HIPCHK(hipEventRecord(aev[2], sb));
-    hipEvent_t a0 = mark(sa);
-    if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 9>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
-    else hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 17>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
-    hipEvent_t a1 = mark(sa);
     hipEvent_t c0 = mark(sc);
     {
         const int mgrid = n_tiles < MID_GRID ? n_tiles : MID_GRID;
@@ -1479,7 +1487,11 @@ static int sj_launch_rest(thj_ctx* c, SjState& st, int set, bool* joined) {
         else hipLaunchKernelGGL((thj_k_sj_general<MID_HITS, MID_T, false, 17, MID_G>), dim3(mgrid), dim3(MID_T), 0, sc, p, b, rl, sl, x, c->d_cnt);
     }
     hipEvent_t c1 = mark(sc);
-    if (!serial) { HIPCHK(hipEventRecord(aev[4], sc)); HIPCHK(hipStreamWaitEvent(sa, aev[2], 0)); HIPCHK(hipStreamWaitEvent(sa, aev[4], 0)); }
+    hipEvent_t a0 = mark(sa);
+    if (b.nseg <= 8) hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 9, GEN_G>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
+    else hipLaunchKernelGGL((thj_k_sj_general<GEN_HITS, TPB, true, 17, GEN_G>), dim3(grid), dim3(TPB), 0, sa, p, b, rl, sl, x, c->d_cnt);
+    hipEvent_t a1 = mark(sa);
+    if (!serial) HIPCHK(hipStreamWaitEvent(sa, aev[2], 0));                // (thj_k_segjuncs_shared's reads for the rescue are listed)
     hipEvent_t a3 = mark(sa);                    // (after the wait for thj_k_segjuncs_shared)
     if (b.mate_off) {
         hipLaunchKernelGGL(thj_k_segjuncs_rescue, dim3(rgrid), dim3(TPB), 0, sa, g, p, b, rl, grid + 1, x, c->d_cnt);

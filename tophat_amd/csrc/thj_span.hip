@@ -839,7 +839,7 @@ void thj_span_free(thj_ctx* c) {
     hipFree(c->d_aln_pool); hipFree(c->d_aln_sorted); hipFree(c->d_aln_keys); hipFree(c->d_nrec);
     hipFree(c->d_aln_count); hipFree(c->d_span_status);
     for (auto& ss : c->span_set) { hipFree(ss.d_worklist); hipFree(ss.d_ent); hipFree(ss.d_joined); hipFree(ss.d_defer); }
-    for (auto& st : c->span_stream) if (st) hipStreamDestroy(st);
+    if (c->span_stream_own) for (auto& st : c->span_stream) if (st) hipStreamDestroy(st);
     for (auto& e : c->span_ev) if (e) hipEventDestroy(e);
     for (auto& pr : c->span_prof_events) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
 }
@@ -1173,18 +1173,25 @@ static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int6
 }
 static int ensure_span_streams(thj_ctx* c) {
     if (c->span_stream[0]) return THJ_OK;
-    // THJ_SPAN_PRIO=1: developer switch -- the side streams (join, closure search, finish) at the highest priority, so that a side's
-    // downstream kernels get the CUs the other side's tier 0 gives back
+    // the context's three side streams (thj_ctx.h: shared with stage 1, which is over when this stage runs).  THJ_SPAN_PRIO=1: developer
+    // switch -- streams of this stage's own, the join / closure search / finish ones at the highest priority (measured worse)
     static const bool prio = getenv("THJ_SPAN_PRIO") != nullptr;
-    int lo = 0, hi = 0;
-    if (prio) HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->span_stream[i], hipStreamNonBlocking, (prio && i != 1) ? hi : 0));
+    if (prio) {
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->span_stream[i], hipStreamNonBlocking, i != 1 ? hi : 0));
+        c->span_stream_own = true;
+    } else {
+        int rc = thj_ensure_aux_streams(c);
+        if (rc) return rc;
+        for (int i = 0; i < 3; ++i) c->span_stream[i] = c->aux_stream[i];
+    }
     for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreateWithFlags(&c->span_ev[i], hipEventDisableTiming));
     return THJ_OK;
 }
 
 // the launches of one batch: `base` = its first slot in the pass; sm / sa as above (sa == sm: everything on one stream)
-static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* db, int set, uint32_t base, hipStream_t sm, hipStream_t sa, hipEvent_t ev_fork, hipEvent_t ev_joined) {
+static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* db, int set, uint32_t base, hipStream_t sm, hipStream_t sa, hipStream_t sp, hipEvent_t ev_fork, hipEvent_t ev_joined) {
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevSpanBatch b; memcpy(&b, db, sizeof b);
@@ -1205,6 +1212,7 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     // THJ_NO_CHAINS: developer switch -- every one-hit-per-segment read through thj_k_stitch, as before round 5
     static const bool no_chains = getenv("THJ_NO_CHAINS") != nullptr;
     const bool chains = !no_chains && !p.fusion_search && b.nseg <= CHAIN_MAXSEG;
+    if (!chains) sp = sm;                       // (the packed tier's list is then tier 0's own: no fork to wait for)
     int rc = ensure_span_set(c, set, b.n_reads, G, chunk, chains);
     if (rc) return rc;
     thj_ctx::SpanSet& ss = c->span_set[set];
@@ -1249,7 +1257,9 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         hipLaunchKernelGGL(thj_k_chains, dim3((unsigned)G), dim3(CH_TPB), 0, sm, p, b, t, ent2, n2, (unsigned int)cap2, wl_pack, blk_pack, (int)G);
         SPK_END(SPK_CHAINS, sm);
         tpk.wl_multi = wl_pack; tpk.blk_multi = blk_pack;
-        if (sa != sm) { HIPCHK(hipEventRecord(ev_fork, sm)); HIPCHK(hipStreamWaitEvent(sa, ev_fork, 0)); }
+        if (sa != sm || sp != sm) HIPCHK(hipEventRecord(ev_fork, sm));
+        if (sa != sm) HIPCHK(hipStreamWaitEvent(sa, ev_fork, 0));
+        if (sp != sm) HIPCHK(hipStreamWaitEvent(sp, ev_fork, 0));
         const ChainLists cl{t.ent, t.blk_chain, (int)G, (int)chunk, ent2, n2, (int)G2, (unsigned int)cap2, (unsigned int)chain_slice2(b.n_reads, G), t.ja, t.jb, t.jc};
         const DeferList dl{ss.d_defer, (unsigned int*)(ss.d_defer + G * chunk + G2 * chain_slice2(b.n_reads, G))};
         // THJ_JOIN_WPE = 4 / THJ_FIN_WPE = 3: developer switches -- thj_k_join_closure with four workgroups' worth of registers per CU (128 VGPRs,
@@ -1265,7 +1275,6 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         if (join_wpe == 3) hipLaunchKernelGGL(thj_k_join_closure<3>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
         else hipLaunchKernelGGL(thj_k_join_closure<4>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
         SPK_END(SPK_CLOSURE, sa);
-        if (sa != sm) HIPCHK(hipEventRecord(ev_joined, sa));
         SPK_BEGIN(SPK_FINISH, sa);
         if (fin_wpe == 5) hipLaunchKernelGGL(thj_k_finish<5>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
         else if (fin_wpe == 6) hipLaunchKernelGGL(thj_k_finish<6>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
@@ -1295,6 +1304,7 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         hipLaunchKernelGGL(thj_k_stitch<SPAN_MAXSEG>, dim3((unsigned)g1), dim3(256), (size_t)256 * b.nseg * sizeof(SpanHitHead), sm, g, p, S, b, sink, t, (int)G);
     }
     SPK_END(SPK_LEAN, sm);
+    hipStream_t sg = sm;                         // where the general tier's kernel runs
     if (p.fusion_search) {
         // tiers 0 and 1 keep the reads that join without a fusion; multihit reads, reads with a fused segment hit and reads tier 1
         // could not join are on the multihit list and go through the fusion branches
@@ -1309,22 +1319,22 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     } else {
         static const bool pack_timing = getenv("THJ_PACK_TIMING") != nullptr;         // developer switch: phase times of the packed tier on stderr
         unsigned long long* d_dbg = nullptr;
-        if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, sm)); }
+        if (pack_timing) { HIPCHK(hipMalloc((void**)&d_dbg, 128)); HIPCHK(hipMemsetAsync(d_dbg, 0, 128, sp)); }
         // reads of up to four segments: four waves a workgroup and three workgroups a CU (168 VGPRs, nothing spilled) instead of two
         // workgroups of eight waves (128 VGPRs, 43 spilled): 0.69 -> 0.635 ms per launch; THJ_PACK_WPE = 2 | 4: developer switch
         static const int pack_wpe = getenv("THJ_PACK_WPE") ? atoi(getenv("THJ_PACK_WPE")) : 3;
         static const int pack_draw_env = getenv("THJ_PACK_DRAW") ? atoi(getenv("THJ_PACK_DRAW")) : 0;
         const int pack_draw = pack_draw_env >= 1 && pack_draw_env <= 64 ? pack_draw_env : (chains ? PACK_DRAW_DEFAULT : 32);
-        SPK_BEGIN(SPK_PACK, sm);
-        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
-        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
-        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
-        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sm, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        SPK_BEGIN(SPK_PACK, sp);
+        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
         // (reads of more than eight segments: the packed tier keeps a chain's choices in eight bytes -- the general kernel takes the multihit list as it is)
-        SPK_END(SPK_PACK, sm);
+        SPK_END(SPK_PACK, sp);
         if (pack_timing) {
             unsigned long long h[16];
-            HIPCHK(hipStreamSynchronize(sm));
+            HIPCHK(hipStreamSynchronize(sp));
             HIPCHK(hipMemcpy(h, d_dbg, 128, hipMemcpyDeviceToHost));
             (void)hipFree(d_dbg);
             const double nw = h[10] ? (double)h[10] : 1.0;
@@ -1337,14 +1347,18 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
             static const hipError_t big3 = hipFuncSetAttribute((const void*)thj_k_stitch_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * SPAN_MAXSEG * (int)sizeof(SpanHit));
             HIPCHK(big3);
         }
-        if (chains && sa != sm) HIPCHK(hipStreamWaitEvent(sm, ev_joined, 0));      // thj_k_join may add to the general tier's list
-        SPK_BEGIN(SPK_GENERIC, sm);
-        hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), sm, g, p, S, b, sink, tg, (int)G);
-        SPK_END(SPK_GENERIC, sm);
+        // the general tier's list takes reads from the packed tier (its stream) and from thj_k_join / thj_k_join_closure (the side
+        // stream): its kernel goes behind thj_k_finish on the side stream and waits there for the packed tier
+        if (chains) sg = sa;
+        if (sg != sp) { HIPCHK(hipEventRecord(ev_joined, sp)); HIPCHK(hipStreamWaitEvent(sg, ev_joined, 0)); }
+        SPK_BEGIN(SPK_GENERIC, sg);
+        hipLaunchKernelGGL(thj_k_stitch_generic, dim3((unsigned)g2), dim3(128), (size_t)128 * b.nseg * sizeof(SpanHit), sg, g, p, S, b, sink, tg, (int)G);
+        SPK_END(SPK_GENERIC, sg);
     }
 #undef SPK_BEGIN
 #undef SPK_END
     if (prof) for (int k = 0; k < SPK_N; ++k) c->span_prof_events.emplace_back(ev[2 * k], ev[2 * k + 1]);
+    if (c->d_huge_ws && sg != sm) { HIPCHK(hipEventRecord(ev_fork, sg)); HIPCHK(hipStreamWaitEvent(sm, ev_fork, 0)); }      // (the fork's wait is long enqueued: the event is free)
     if (c->d_huge_ws) {        // a pass that met a read with too many joined alignments runs with the workspace from then on
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
         hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws, HUGE_CAP);
@@ -1369,11 +1383,16 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     // THJ_SPAN_SERIAL: developer switch -- every kernel on the context's stream, one after the other
     static const bool serial_env = getenv("THJ_SPAN_SERIAL") != nullptr;
     const bool serial = serial_env || c->serial_launch;
-    hipStream_t s0 = c->stream, a0 = serial ? c->stream : c->span_stream[0], s1 = serial ? c->stream : c->span_stream[1], a1 = serial ? c->stream : c->span_stream[2];
+    // Three streams, whatever the call holds (HIP maps streams to four hardware queues round robin, and two streams on one queue run
+    // one after the other -- with a stream per chain the second side's packed tier sat behind its own thj_k_finish and ran alone at the
+    // end of the step, profiles/r05_g_timeline.txt): the first side's tier 0, chains and packed tier on the context's stream, its join /
+    // closure search / finish on the first side stream; the second side's tier 0, chains, join, closure search and finish one after
+    // the other on the second side stream, and its packed tier behind the first side's on the context's stream.
+    hipStream_t s0 = c->stream, a0 = serial ? c->stream : c->span_stream[0], s1 = serial ? c->stream : c->span_stream[1], a1 = s1;
     const uint32_t base0 = (uint32_t)c->span_reads, base1 = (uint32_t)(c->span_reads + n0);
     if (!serial && n1) { HIPCHK(hipEventRecord(c->span_ev[0], c->stream)); HIPCHK(hipStreamWaitEvent(s1, c->span_ev[0], 0)); }
-    if (n0 && (rc = span_launch(c, tp, db0, 0, base0, s0, a0, c->span_ev[1], c->span_ev[6]))) return rc;
-    if (n1 && (rc = span_launch(c, tp, db1, 1, base1, s1, a1, c->span_ev[2], c->span_ev[7]))) return rc;
+    if (n0 && (rc = span_launch(c, tp, db0, 0, base0, s0, a0, c->stream, c->span_ev[1], c->span_ev[6]))) return rc;
+    if (n1 && (rc = span_launch(c, tp, db1, 1, base1, s1, a1, c->stream, c->span_ev[2], c->span_ev[7]))) return rc;
     if (!serial) {
         if (n0) { HIPCHK(hipEventRecord(c->span_ev[3], a0)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[3], 0)); }
         if (n1) {
