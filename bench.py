@@ -929,6 +929,16 @@ def run_rank(args, rank, world, local_rank, control, shared):
     local_juncs = [0]
     xchg_events = None         # (start, end) events around the exchange step of the timed steps
 
+    host_t = {} if os.environ.get("THJ_BENCH_HOST_TIMING") == "1" else None      # developer switch: host seconds inside each call of a step, on stderr
+
+    def timed(name, f, *a):
+        if host_t is None:
+            return f(*a)
+        t = time.perf_counter()
+        r = f(*a)
+        host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
+        return r
+
     def step():
         # ---- segment_juncs stage
         ctx.reset()
@@ -938,7 +948,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
             ctx.run(p_left, cb_left)
             ctx.run(p_right, cb_right)
         else:
-            ctx.run_pair(p_left, cb_left, p_right, cb_right)      # both sides as one call: their side chains run beside each other
+            timed("run_pair", ctx.run_pair, p_left, cb_left, p_right, cb_right)      # both sides as one call: their side chains run beside each other
         if n_ium:                                     # coverage search: coverage map of all hits, extension table, island pairing
             ctx.covsearch_add_hits(cb_left)
             ctx.covsearch_add_hits(cb_right)
@@ -956,21 +966,21 @@ def run_rank(args, rank, world, local_rank, control, shared):
             if xchg_events is not None:
                 e1.record(stream)
                 xchg_events.append((e0, e1))
-        cnt = ctx.finish()                            # the only host round trip of the stage
+        cnt = timed("finish", ctx.finish)             # the only host round trip of the stage
         if args.fusion_search and args.fusion_frac > 0:
             # segment_juncs --fusion-search: find_fusions over both sides; the (small) list goes to the spanning stage the way the
             # .fusions file would carry it
             n_fusions[0] = ctx.fusion_search([(p_left, cb_left), (p_right, cb_right)])
             ctx.span_fusions_from_segjuncs()                             # device to device, like the junction set below
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
-        ctx.span_sets_from_segjuncs()
-        ctx.span_reset()
+        timed("span_sets_from_segjuncs", ctx.span_sets_from_segjuncs)
+        timed("span_reset", ctx.span_reset)
         if os.environ.get("THJ_BENCH_NO_PAIR") == "1":
             ctx.span_run(p_span, sp_left)
             ctx.span_run(p_span, sp_right)
         else:
-            ctx.span_run_pair(p_span, sp_left, sp_right)          # both sides as one call: the two sides' kernels run beside each other
-        n_alns = ctx.span_finish()
+            timed("span_run_pair", ctx.span_run_pair, p_span, sp_left, sp_right)          # both sides as one call: the two sides' kernels run beside each other
+        n_alns = timed("span_finish", ctx.span_finish)
         return cnt, n_alns
 
     def barrier():
@@ -988,12 +998,16 @@ def run_rank(args, rank, world, local_rank, control, shared):
     ctx.profile(True)
     ctx.profile_span(True)
     xchg_events = [] if comm is not None else None
+    if host_t is not None:
+        host_t.clear()
     barrier()
     t0 = time.time()
     for _ in range(args.steps):
         cnt, n_alns = step()
     barrier()
     elapsed = time.time() - t0
+    if host_t is not None:
+        print("[host] ms per step inside: " + ", ".join("%s %.3f" % (k, 1e3 * v / args.steps) for k, v in host_t.items()), file=sys.stderr)
     kern_ms, launches, sj_stats = ctx.profile(False)
     span_ms, span_launches = ctx.profile_span(False)
     torch.cuda.synchronize()

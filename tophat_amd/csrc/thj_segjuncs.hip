@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstring>
 #include <cstddef>
+#include <chrono>
 #include <vector>
 
 #include "../../include/thj.h"
@@ -1189,14 +1190,89 @@ extern "C" int thj_genome_adopt(thj_ctx* c, const void* d_blocks, int64_t n_bloc
     return set_contigs(c, contig_blk, lens, n_contigs, n_blocks);
 }
 
+// HIP hands a new stream the next of GPU_MAX_HW_QUEUES (4) hardware queues, round robin over every stream the PROCESS ever made -- and
+// kernels of two streams on one queue leave one after the other.  Which queue the context's stream is on cannot be asked, so it is
+// measured: four streams made in a row sit on four different queues; each runs a short spin kernel beside one on the context's stream,
+// and the one whose pair takes twice as long shares that stream's queue and is not used.  (bench.py's files-in -> files-out leg opens a
+// context of its own for the inflater's figure before the resident-data steps; the streams it made moved the round robin on by one, the
+// second side's stream landed on the context's queue, and the default line's steps were 6.5 ms where a bare run's were 5.55:
+// profiles/r05_default_slow.txt.)  ~1 ms, once per context.
+__global__ void thj_k_spin(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int spin_group_us(thj_ctx* c, hipStream_t a, hipStream_t b, double* us) {        // a spin kernel on the context's stream, on a and on b (null: not there)
+    double best = 1e30;
+    for (int rep = 0; rep < 2; ++rep) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (a) HIPCHK(hipStreamSynchronize(a));
+        if (b) HIPCHK(hipStreamSynchronize(b));
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, c->stream, 15000ull);          // 150 us at the 100 MHz of s_memrealtime
+        if (a) hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, a, 15000ull);
+        if (b) hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, b, 15000ull);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (a) HIPCHK(hipStreamSynchronize(a));
+        if (b) HIPCHK(hipStreamSynchronize(b));
+        const double dt = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (dt < best) best = dt;
+    }
+    *us = best;
+    return THJ_OK;
+}
 int thj_ensure_aux_streams(thj_ctx* c) {
     if (c->aux_stream[0]) return THJ_OK;
     // (THJ_SJ_PRIO=1: the side streams at the highest priority the device has -- measured worse, 7.0 against 6.6 ms per step: the flat reads'
     // rescue scan then waits for them)
     int lo = 0, hi = 0;
     static const bool prio = getenv("THJ_SJ_PRIO") && atoi(getenv("THJ_SJ_PRIO")) != 0;
+    static const bool no_probe = getenv("THJ_NO_QUEUE_PROBE") != nullptr;                       // developer switch: the first three streams as they come
     if (prio) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->aux_stream[i], hipStreamNonBlocking, prio ? hi : 0));
+    constexpr int NC = 5;
+    hipStream_t cand[NC] = {};
+    for (int i = 0; i < NC; ++i) HIPCHK(hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, prio ? hi : 0));
+    int pi = 0, pj = 1;
+    if (!no_probe) {
+        // the first pair of candidates that runs beside the context's stream and beside each other (three spin kernels in the time of one)
+        double alone = 0, best = 1e30;
+        int rc = spin_group_us(c, nullptr, nullptr, &alone);
+        if (rc) return rc;
+        bool found = false;
+        for (int j = 1; j < NC && !found; ++j)
+            for (int i = 0; i < j && !found; ++i) {
+                double us = 0;
+                if ((rc = spin_group_us(c, cand[i], cand[j], &us))) return rc;
+                if (us < best) { best = us; pi = i; pj = j; }
+                found = us < 1.5 * alone;
+            }
+        static const bool trace = getenv("THJ_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[streams] a spin kernel alone %.0f us; with candidates %d and %d beside it %.0f us%s\n", alone, pi, pj, best, found ? "" : " -- no pair of them runs beside the context's stream");
+    }
+    c->aux_stream[0] = cand[pi]; c->aux_stream[1] = cand[pj];
+    int pk = -1;
+    if (!no_probe) {        // a third one beside those (developer switches only): four spin kernels in the time of one, if the process has a queue to spare
+        double alone = 0;
+        int rc = spin_group_us(c, nullptr, nullptr, &alone);
+        if (rc) return rc;
+        for (int k = 0; k < NC && pk < 0; ++k) {
+            if (k == pi || k == pj) continue;
+            HIPCHK(hipStreamSynchronize(cand[k]));
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, c->stream, 15000ull);
+            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, cand[pi], 15000ull);
+            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, cand[pj], 15000ull);
+            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, cand[k], 15000ull);
+            HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(cand[pi])); HIPCHK(hipStreamSynchronize(cand[pj])); HIPCHK(hipStreamSynchronize(cand[k]));
+            const double dt = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (dt < 1.5 * alone) pk = k;
+        }
+        static const bool trace = getenv("THJ_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[streams] a third side stream beside them: %s\n", pk >= 0 ? "yes" : "no");
+    }
+    for (int i = 0; i < NC; ++i) {
+        if (i == pi || i == pj) continue;
+        if (!c->aux_stream[2] && (pk < 0 || i == pk)) c->aux_stream[2] = cand[i]; else (void)hipStreamDestroy(cand[i]);
+    }
     for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming));
     return THJ_OK;
 }

@@ -1388,11 +1388,12 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     // end of the step, profiles/r05_g_timeline.txt): the first side's tier 0, chains and packed tier on the context's stream, its join /
     // closure search / finish on the first side stream; the second side's tier 0, chains, join, closure search and finish one after
     // the other on the second side stream, and its packed tier behind the first side's on the context's stream.
-    hipStream_t s0 = c->stream, a0 = serial ? c->stream : c->span_stream[0], s1 = serial ? c->stream : c->span_stream[1], a1 = s1;
+    static const bool own_a1 = getenv("THJ_SPAN_A1") != nullptr;      // developer switch: the second side's join chain on the third side stream
+    hipStream_t s0 = c->stream, a0 = serial ? c->stream : c->span_stream[0], s1 = serial ? c->stream : c->span_stream[1], a1 = (own_a1 && !serial) ? c->span_stream[2] : s1;
     const uint32_t base0 = (uint32_t)c->span_reads, base1 = (uint32_t)(c->span_reads + n0);
     if (!serial && n1) { HIPCHK(hipEventRecord(c->span_ev[0], c->stream)); HIPCHK(hipStreamWaitEvent(s1, c->span_ev[0], 0)); }
     if (n0 && (rc = span_launch(c, tp, db0, 0, base0, s0, a0, c->stream, c->span_ev[1], c->span_ev[6]))) return rc;
-    if (n1 && (rc = span_launch(c, tp, db1, 1, base1, s1, a1, c->stream, c->span_ev[2], c->span_ev[7]))) return rc;
+    if (n1 && (rc = span_launch(c, tp, db1, 1, base1, s1, a1, (own_a1 && !serial) ? s1 : c->stream, c->span_ev[2], c->span_ev[7]))) return rc;
     if (!serial) {
         if (n0) { HIPCHK(hipEventRecord(c->span_ev[3], a0)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[3], 0)); }
         if (n1) {
