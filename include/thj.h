@@ -99,7 +99,10 @@ const char* thj_version(void);
 /* Number of HIP devices visible to the process (< 0: error). */
 int  thj_device_count(void);
 /* `stream` is a hipStream_t to launch on (e.g. torch's current stream) or NULL
- * to let the context create its own non-blocking stream. */
+ * to let the context create its own non-blocking stream.  Work that runs beside that stream (the side chains of
+ * thj_segjuncs_run*_async and thj_span_run*_async) runs on two side streams of the context's own, made at the first such
+ * call and chosen by a ~2 ms measurement so that they do not share a hardware queue with `stream` or each other (HIP maps
+ * streams to GPU_MAX_HW_QUEUES queues round robin); every call returns with its work joined on `stream` again. */
 int  thj_ctx_create(int device, void* stream, thj_ctx** out);
 /* Loads the kernels of the named parts now (an empty launch from each translation unit) instead of at their first use; blocks
  * until they are there.  For a process that has something else to do meanwhile.  No effect on results. */

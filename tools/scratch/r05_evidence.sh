@@ -9,6 +9,6 @@ root=$(pwd)
   echo "# --plain (no multihit family, no deletion reads)"
   python bench.py --plain --steps 10 --warmup 2 --no-cpu-baseline --e2e-pairs 0 --no-pmc 2>/dev/null > /tmp/z.json; python tools/show_bench.py /tmp/z.json
 } > gpurun_out/r05_b_serial_kernel_ms.txt 2>&1
-rm -rf /tmp/kt; (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /dev/null 2>&1)
+rm -rf /tmp/kt; (cd /tmp && THJ_BENCH_NO_REPLAY=1 rocprofv3 --kernel-trace --stats -d /tmp/kt -o r -- python $root/bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /dev/null 2>&1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc   (MI355X, round 5); durations in microseconds"; python tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) thj_k; } > gpurun_out/r05_b_kernel_stats_bench10M.txt
 cat gpurun_out/r05_b_serial_kernel_ms.txt
