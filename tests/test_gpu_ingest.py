@@ -70,6 +70,24 @@ def test_handmade_streams():
         assert g == w, "stream %d (%d bytes in, %d out)" % (k, len(payloads[k]), len(w))
 
 
+def uneven_token_density(rng):
+    """a Huffman-only block whose first bits hold one token a bit (12 000 literals of one value, a 1-bit code) and whose rest holds one in
+    eleven: cut into 64 equal bit segments, the lanes of the dense part have ~700 tokens each -- more than a lane's slot of thj_k_huffp
+    (inf2::SLOT_TOKENS = 640) holds, so the block takes the storing pass instead of the copy from the slots"""
+    return bytes([7]) * 12000 + bytes((rng.integers(0, 250, size=4300) + 6).astype(np.uint8))
+
+
+def test_a_lane_with_more_tokens_than_its_slot_holds():
+    rng = np.random.default_rng(9)
+    d = uneven_token_density(rng)
+    payloads = [raw_deflate(d, 6, zlib.Z_HUFFMAN_ONLY), raw_deflate(d[::-1], 6, zlib.Z_HUFFMAN_ONLY), raw_deflate(d, 6)]
+    want = [d, d[::-1], d]
+    assert len(payloads[0]) * 8 // 64 > 640          # bits per segment = tokens per dense segment
+    with host.Context(0) as ctx:
+        got = inflate(ctx, payloads)
+    assert got == want
+
+
 def test_corrupt_streams_are_flagged_not_trusted():
     good = raw_deflate(b"the quick brown fox jumps over the lazy dog " * 500)
     bad = [good[:len(good) // 2],                          # truncated

@@ -160,6 +160,17 @@ def test_lanes_whose_tokens_do_not_fit_their_slots(lib):
         lib.inflate_sim_set_slot(C.c_uint32(0))
 
 
+def test_a_lane_with_more_tokens_than_a_real_slot_holds(lib):
+    """the same with the slots at their real size: a block whose first bits hold a token a bit (tests/test_gpu_ingest.py has its twin)"""
+    rng = random.Random(9)
+    data = bytes([7]) * 12000 + bytes(rng.randrange(6, 256) for _ in range(4300))
+    for d in (data, data[::-1]):
+        comp = raw_deflate(d, strategy=zlib.Z_HUFFMAN_ONLY)
+        assert len(comp) * 8 // 64 > 640
+        got, _ = run(lib, comp, 3)
+        assert got == d
+
+
 def test_refusals(lib):
     rng = random.Random(3)
     data = bam_like(rng, 30000)

@@ -1,11 +1,10 @@
 #!/bin/bash
 # GPU box: the e2e leg at 10 M pairs of the mix (twice: the second with warm page cache), the inflater on its files, then the GPU test-suite
 cd "$(dirname "$0")/../.."; mkdir -p gpurun_out; d=/dev/shm/e10
-{ python tools/e2e_bench.py --pairs 10000000 --keep $d 2>&1 | tail -1 | python -c "
-import sys, json, ast
-l = sys.stdin.readline().strip()
-try: r = json.loads(l)
-except Exception: r = ast.literal_eval(l)
+{ python tools/e2e_bench.py --pairs 10000000 --keep $d 2>&1 | python -c "
+import sys, json
+t = sys.stdin.read()
+r = json.loads(t[t.index('{'):])
 print({k: r[k] for k in r if k.endswith('_s') or k in ('pairs', 'both_stages_s', 'value')})
 for k in ('stage_timing',):
     for n, v in (r.get(k) or {}).items():

@@ -520,11 +520,18 @@ extern "C" int thj_covsearch_finish(thj_ctx* c, int64_t max_cov_juncs, int64_t* 
 
 
 // ------------------------------------------------------------------------------------------------ butterfly search
+// device temporaries of a call: freed on every way out (HIPCHK returns from the middle of a function)
+struct DevTemps {
+    std::vector<void**> slots;
+    void own(void** p) { slots.push_back(p); }
+    ~DevTemps() { for (void** p : slots) if (*p) { (void)hipFree(*p); *p = nullptr; } }
+};
 static int bf_sorted_distinct(thj_ctx* c, u64* in, u64* tmp, int64_t n, int64_t* n_out) {          // result in `in`
     if (n == 0) { *n_out = 0; return THJ_OK; }
     if (n >= (1ll << 31)) { thj_set_error("butterfly search: more than 2^31 (site, extension) keys"); return THJ_EOVERFLOW; }
     size_t b1 = 0, b2 = 0;
     int* d_num = nullptr;
+    DevTemps temps; temps.own((void**)&d_num);
     hipcub::DeviceRadixSort::SortKeys(nullptr, b1, in, tmp, (int)n, 0, 59, c->stream);
     hipcub::DeviceSelect::Unique(nullptr, b2, tmp, in, d_num, (int)n, c->stream);
     const size_t need = (b1 > b2 ? b1 : b2);
@@ -537,7 +544,6 @@ static int bf_sorted_distinct(thj_ctx* c, u64* in, u64* tmp, int64_t n, int64_t*
     int h = 0;
     HIPCHK(hipMemcpyAsync(&h, d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    hipFree(d_num);
     *n_out = h;
     return THJ_OK;
 }
@@ -564,9 +570,10 @@ extern "C" int thj_butterfly_run(thj_ctx* c, int32_t min_intron, int32_t max_int
     hipLaunchKernelGGL(cov_k::k_bf_sites, dim3(gw), dim3(256), 0, c->stream, g, L, (const u64*)E, fd, ra, fa, rd);
     // the sites of each side as a list, their keys, sorted and distinct
     unsigned long long* d_cnt = nullptr;            // [0] sites listed / keys written, [1] pairs
-    HIPCHK(hipMalloc(&d_cnt, 16));
     u64* side_keys[2] = {nullptr, nullptr}; int64_t side_n[2] = {0, 0};
-    auto cleanup = [&]() { hipFree(d_cnt); hipFree(side_keys[0]); hipFree(side_keys[1]); };
+    DevTemps temps; temps.own((void**)&d_cnt); temps.own((void**)&side_keys[0]); temps.own((void**)&side_keys[1]);
+    HIPCHK(hipMalloc(&d_cnt, 16));
+    auto cleanup = [&]() { };                       // (the temporaries go with `temps`, on every return)
     for (int side = 0; side < 2; ++side) {
         const u64 *b0 = side ? fa : fd, *b1 = side ? rd : ra;
         unsigned int* n_list = (unsigned int*)d_cnt;
@@ -576,7 +583,8 @@ extern "C" int thj_butterfly_run(thj_ctx* c, int32_t min_intron, int32_t max_int
         HIPCHK(hipMemcpyAsync(&n_sites, n_list, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (!n_sites) continue;
-        u64* list = nullptr;
+        u64 *list = nullptr, *tmp = nullptr;
+        DevTemps side_temps; side_temps.own((void**)&list); side_temps.own((void**)&tmp);
         HIPCHK(hipMalloc(&list, (size_t)n_sites * 8));
         HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
         hipLaunchKernelGGL(cov_k::k_list_sites, dim3(gw), dim3(256), 0, c->stream, L, b0, b1, list, n_list, n_sites);
@@ -586,19 +594,15 @@ extern "C" int thj_butterfly_run(thj_ctx* c, int32_t min_intron, int32_t max_int
         HIPCHK(hipMemcpyAsync(&n_keys, d_cnt, 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (n_keys) {
-            u64* tmp = nullptr;
             if (hipMalloc(&side_keys[side], (size_t)n_keys * 8) != hipSuccess || hipMalloc(&tmp, (size_t)n_keys * 8) != hipSuccess) {
-                hipFree(tmp); hipFree(list); cleanup();
                 thj_set_error("butterfly search: no device memory for %llu (site, extension) keys", n_keys); return THJ_ENOMEM;
             }
             HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
             hipLaunchKernelGGL(cov_k::k_bf_keys, dim3(2048), dim3(256), 0, c->stream, g, L, et, (const u64*)list, n_sites, side, side_keys[side], d_cnt, n_keys);
             rc = bf_sorted_distinct(c, side_keys[side], tmp, (int64_t)n_keys, &side_n[side]);
-            hipFree(tmp);
-            if (rc) { hipFree(list); cleanup(); return rc; }
+            if (rc) return rc;
         }
         HIPCHK(hipStreamSynchronize(c->stream));
-        hipFree(list);
     }
     if (!side_n[0] || !side_n[1]) { cleanup(); return THJ_OK; }
     // the join: pairs counted, room made in the (junction key, skip count) list, pairs written
@@ -613,9 +617,11 @@ extern "C" int thj_butterfly_run(thj_ctx* c, int32_t min_intron, int32_t max_int
     if (!c->d_cov_jkey || (int64_t)n_pairs > c->cov_jcap) {
         hipFree(c->d_cov_jkey); hipFree(c->d_cov_jskip); hipFree(c->d_cov_jkey2); hipFree(c->d_cov_jskip2);
         c->d_cov_jkey = c->d_cov_jkey2 = nullptr; c->d_cov_jskip = c->d_cov_jskip2 = nullptr;
-        c->cov_jcap = (int64_t)n_pairs + (int64_t)n_pairs / 8 + 1024;
-        HIPCHK(hipMalloc(&c->d_cov_jkey, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip, (size_t)c->cov_jcap * 4));
-        HIPCHK(hipMalloc(&c->d_cov_jkey2, (size_t)c->cov_jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip2, (size_t)c->cov_jcap * 4));
+        c->cov_jcap = 0;                             // (set when all four lists are there)
+        const int64_t jcap = (int64_t)n_pairs + (int64_t)n_pairs / 8 + 1024;
+        HIPCHK(hipMalloc(&c->d_cov_jkey, (size_t)jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip, (size_t)jcap * 4));
+        HIPCHK(hipMalloc(&c->d_cov_jkey2, (size_t)jcap * 8)); HIPCHK(hipMalloc(&c->d_cov_jskip2, (size_t)jcap * 4));
+        c->cov_jcap = jcap;
     }
     HIPCHK(hipMemsetAsync(d_cnt, 0, 16, c->stream));
     hipLaunchKernelGGL(cov_k::k_bf_join_emit, dim3(2048), dim3(256), 0, c->stream, g, L, (const u64*)side_keys[0], side_n[0], (const u64*)side_keys[1], side_n[1],
