@@ -78,7 +78,7 @@ struct thj_ctx {
     // scratch of a batch in flight (span_launch in thj_span.hip): two sets, so that the two sides of a pass can run beside each other
     struct SpanSet { uint32_t* d_worklist = nullptr; int64_t worklist_cap = 0; void* d_ent = nullptr; int64_t ent_cap = 0; void* d_joined = nullptr; int64_t joined_cap = 0; uint32_t* d_defer = nullptr; int64_t defer_cap = 0; };
     SpanSet span_set[2]; int span_last_set = 0;
-    hipStream_t span_stream[3] = {}; hipEvent_t span_ev[8] = {}; bool span_stream_own = false;      // (= aux_stream unless THJ_SPAN_PRIO)
+    hipStream_t span_stream[3] = {}; hipEvent_t span_ev[10] = {}; bool span_stream_own = false;      // (= aux_stream unless THJ_SPAN_PRIO)
     bool span_profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;
     // coverage search (thj_covsearch_impl.h)

@@ -1186,12 +1186,16 @@ static int ensure_span_streams(thj_ctx* c) {
         if (rc) return rc;
         for (int i = 0; i < 3; ++i) c->span_stream[i] = c->aux_stream[i];
     }
-    for (int i = 0; i < 8; ++i) HIPCHK(hipEventCreateWithFlags(&c->span_ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreateWithFlags(&c->span_ev[i], hipEventDisableTiming));
     return THJ_OK;
 }
 
 // the launches of one batch: `base` = its first slot in the pass; sm / sa as above (sa == sm: everything on one stream)
-static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* db, int set, uint32_t base, hipStream_t sm, hipStream_t sa, hipStream_t sp, hipEvent_t ev_fork, hipEvent_t ev_joined) {
+// st0: tier 0's stream (the others' work of this batch follows it); phases: 1 = tier 0, 2 = everything behind it, 3 = both (a pair
+// call enqueues both batches' tier 0 before anything else); pe: the batch's profile events
+struct SpanProf { hipEvent_t ev[32]; };
+static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* db, int set, uint32_t base, hipStream_t st0, hipStream_t sm, hipStream_t sa, hipStream_t sp,
+                       hipEvent_t ev_t0, hipEvent_t ev_fork, hipEvent_t ev_joined, int phases, SpanProf& pe) {
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevSpanBatch b; memcpy(&b, db, sizeof b);
@@ -1232,20 +1236,25 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     t.ent = chains ? (ChainEntry*)ss.d_ent : nullptr;
     t.ja = (Q16*)ss.d_joined; t.jb = t.ja ? t.ja + ss.joined_cap : nullptr; t.jc = t.ja ? t.ja + 2 * ss.joined_cap : nullptr;
     t.status = c->d_span_status;
-    HIPCHK(hipMemsetAsync(t.counters, 0, SPAN_CNT_WORDS * 4, sm));
-    HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, sm));      // tiers 0 / 1 write the others
-    c->span_last_set = set;
-    hipEvent_t ev[2 * SPK_N];
-    for (auto& e : ev) e = nullptr;
+    static_assert(2 * SPK_N <= 32, "SpanProf");
+    hipEvent_t* const ev = pe.ev;
     const bool prof = c->span_profile;
-    if (prof) for (auto& e : ev) e = thj_get_event(c);
 #define SPK_BEGIN(k, st) do { if (prof) HIPCHK(hipEventRecord(ev[2 * (k)], st)); } while (0)
 #define SPK_END(k, st) do { if (prof) HIPCHK(hipEventRecord(ev[2 * (k) + 1], st)); } while (0)
-    SPK_BEGIN(SPK_CONTIG, sm);
-    if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
-    else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MIDSEG>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
-    else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, sm, g, p, b, sink, t);
-    SPK_END(SPK_CONTIG, sm);
+    if (phases & 1) {
+        HIPCHK(hipMemsetAsync(t.counters, 0, SPAN_CNT_WORDS * 4, st0));
+        HIPCHK(hipMemsetAsync(t.blk_gen, 0, (size_t)MAX_SLICES * 4, st0));      // tiers 0 / 1 write the others
+        c->span_last_set = set;
+        for (int k = 0; k < 2 * SPK_N; ++k) ev[k] = prof ? thj_get_event(c) : nullptr;
+        SPK_BEGIN(SPK_CONTIG, st0);
+        if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_contig<4>, dim3((unsigned)G), dim3(256), 0, st0, g, p, b, sink, t);
+        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MIDSEG>, dim3((unsigned)G), dim3(256), 0, st0, g, p, b, sink, t);
+        else hipLaunchKernelGGL(thj_k_stitch_contig<SPAN_MAXSEG>, dim3((unsigned)G), dim3(256), 0, st0, g, p, b, sink, t);
+        SPK_END(SPK_CONTIG, st0);
+        if (st0 != sm) { HIPCHK(hipEventRecord(ev_t0, st0)); HIPCHK(hipStreamWaitEvent(sm, ev_t0, 0)); }
+        HIPCHK(hipGetLastError());
+    }
+    if (!(phases & 2)) return THJ_OK;
     // ---- the chains: those of the multihit reads that need no search join tier 0's entries (thj_k_chains); then join, closure
     // search, finish on the side stream, beside the kernels of the reads that are left
     Tiers tpk = t;                // the packed tier's view: the list thj_k_chains leaves
@@ -1383,23 +1392,37 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     // THJ_SPAN_SERIAL: developer switch -- every kernel on the context's stream, one after the other
     static const bool serial_env = getenv("THJ_SPAN_SERIAL") != nullptr;
     const bool serial = serial_env || c->serial_launch;
-    // Three streams, whatever the call holds (HIP maps streams to four hardware queues round robin, and two streams on one queue run
-    // one after the other -- with a stream per chain the second side's packed tier sat behind its own thj_k_finish and ran alone at the
-    // end of the step, profiles/r05_g_timeline.txt): the first side's tier 0, chains and packed tier on the context's stream, its join /
-    // closure search / finish on the first side stream; the second side's tier 0, chains, join, closure search and finish one after
-    // the other on the second side stream, and its packed tier behind the first side's on the context's stream.
-    static const bool own_a1 = getenv("THJ_SPAN_A1") != nullptr;      // developer switch: the second side's join chain on the third side stream
-    hipStream_t s0 = c->stream, a0 = serial ? c->stream : c->span_stream[0], s1 = serial ? c->stream : c->span_stream[1], a1 = (own_a1 && !serial) ? c->span_stream[2] : s1;
+    // Three streams, whatever the call holds (two streams on one hardware queue run one after the other: thj_ensure_aux_streams).  Pair
+    // call: the first batch's tier 0 on the context's stream, the second's beside it on its side stream; behind its tier 0 each batch's
+    // chains / join / closure search / finish / general tier on a side stream of its own, the packed tiers one after the other on the
+    // context's stream.  One batch: its tier 0, chains and packed tier on the context's stream, the join chain on a side stream.
+    // (THJ_SPAN_T0_SERIAL: developer switch -- the second batch's tier 0 behind the first's on the context's stream.  Each fills the HBM on
+    // its own, but behind the first the second runs beside the first batch's chains and join and is the slower for it: 5.65-5.71 against
+    // 5.46-5.50 ms per step, profiles/r05_m_timeline.txt.)
+    static const bool own_a1 = getenv("THJ_SPAN_A1") != nullptr;      // developer switch: the second batch's join chain on the third side stream
+    static const bool t0_beside = getenv("THJ_SPAN_T0_SERIAL") == nullptr;
     const uint32_t base0 = (uint32_t)c->span_reads, base1 = (uint32_t)(c->span_reads + n0);
-    if (!serial && n1) { HIPCHK(hipEventRecord(c->span_ev[0], c->stream)); HIPCHK(hipStreamWaitEvent(s1, c->span_ev[0], 0)); }
-    if (n0 && (rc = span_launch(c, tp, db0, 0, base0, s0, a0, c->stream, c->span_ev[1], c->span_ev[6]))) return rc;
-    if (n1 && (rc = span_launch(c, tp, db1, 1, base1, s1, a1, (own_a1 && !serial) ? s1 : c->stream, c->span_ev[2], c->span_ev[7]))) return rc;
-    if (!serial) {
-        if (n0) { HIPCHK(hipEventRecord(c->span_ev[3], a0)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[3], 0)); }
-        if (n1) {
-            HIPCHK(hipEventRecord(c->span_ev[4], s1)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[4], 0));
-            HIPCHK(hipEventRecord(c->span_ev[5], a1)); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[5], 0));
-        }
+    SpanProf pe0, pe1;
+    hipStream_t cs = c->stream;
+    if (serial) {
+        if (n0 && (rc = span_launch(c, tp, db0, 0, base0, cs, cs, cs, cs, c->span_ev[8], c->span_ev[1], c->span_ev[6], 3, pe0))) return rc;
+        if (n1 && (rc = span_launch(c, tp, db1, 1, base1, cs, cs, cs, cs, c->span_ev[9], c->span_ev[2], c->span_ev[7], 3, pe1))) return rc;
+    } else if (!n1 || !n0) {
+        const thj_span_batch* db = n0 ? db0 : db1;
+        const int set = n0 ? 0 : 1;
+        if ((rc = span_launch(c, tp, db, set, base0, cs, cs, c->span_stream[0], cs, c->span_ev[8], c->span_ev[1], c->span_ev[6], 3, pe0))) return rc;
+        HIPCHK(hipEventRecord(c->span_ev[3], c->span_stream[0])); HIPCHK(hipStreamWaitEvent(cs, c->span_ev[3], 0));
+    } else {
+        hipStream_t x0 = c->span_stream[0], x1 = c->span_stream[1], a1 = own_a1 ? c->span_stream[2] : x1;
+        hipStream_t t1 = t0_beside ? x1 : cs;
+        if (t0_beside) { HIPCHK(hipEventRecord(c->span_ev[0], cs)); HIPCHK(hipStreamWaitEvent(x1, c->span_ev[0], 0)); }
+        if ((rc = span_launch(c, tp, db0, 0, base0, cs, x0, x0, cs, c->span_ev[8], c->span_ev[1], c->span_ev[6], 1, pe0))) return rc;
+        if ((rc = span_launch(c, tp, db1, 1, base1, t1, x1, a1, own_a1 ? x1 : cs, c->span_ev[9], c->span_ev[2], c->span_ev[7], 1, pe1))) return rc;
+        if ((rc = span_launch(c, tp, db0, 0, base0, cs, x0, x0, cs, c->span_ev[8], c->span_ev[1], c->span_ev[6], 2, pe0))) return rc;
+        if ((rc = span_launch(c, tp, db1, 1, base1, t1, x1, a1, own_a1 ? x1 : cs, c->span_ev[9], c->span_ev[2], c->span_ev[7], 2, pe1))) return rc;
+        HIPCHK(hipEventRecord(c->span_ev[3], x0)); HIPCHK(hipStreamWaitEvent(cs, c->span_ev[3], 0));
+        HIPCHK(hipEventRecord(c->span_ev[4], x1)); HIPCHK(hipStreamWaitEvent(cs, c->span_ev[4], 0));
+        if (a1 != x1) { HIPCHK(hipEventRecord(c->span_ev[5], a1)); HIPCHK(hipStreamWaitEvent(cs, c->span_ev[5], 0)); }
     }
     c->span_reads += n0 + n1;
     return THJ_OK;
