@@ -1189,7 +1189,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
         if traffic_in_run or (args.read_len == 100 and args.genome == "chr20" and use_heads and not args.fusion_search and not n_ium and pm["config"] == want_cfg):
             for k in kernels:
                 def _lookup(nm):
-                    # the profiler prints every template argument (thj_k_sj_general<12, 256, true, 9>); the line's names stop at the ones that tell the instances apart
+                    # the profiler prints every template argument (thj_k_sj_general<8, 256, true, 9, 4>); the line's names stop at the ones that tell the instances apart
                     v = pm["kernels"].get(nm)
                     if v is None and nm.endswith(">"):
                         cands = [key for key in pm["kernels"] if key.startswith(nm[:-1] + ",")]

@@ -418,7 +418,7 @@ class Context:
         found = self.covsearch_finish(max_cov_juncs)
         return self.download(self.finish()), found
 
-    SJ_KERNELS = ("thj_k_sj_flat", "thj_k_sj_general<12, 256, true>", "thj_k_sj_general<32, 64, false>", "thj_k_segjuncs_shared",
+    SJ_KERNELS = ("thj_k_sj_flat", "thj_k_sj_general<8, 256, true>", "thj_k_sj_general<32, 256, false>", "thj_k_segjuncs_shared",
                   "thj_k_segjuncs_rescue + thj_k_segjuncs_rescue_shared", "thj_k_sj_tasks_list", "thj_k_sj_rescue_scan + thj_k_sj_rescue_flat",
                   "thj_k_sj_tasks")
 
