@@ -966,6 +966,12 @@ def run_rank(args, rank, world, local_rank, control, shared):
             if xchg_events is not None:
                 e1.record(stream)
                 xchg_events.append((e0, e1))
+        early_t0 = os.environ.get("THJ_BENCH_NO_EARLY_T0") != "1" and os.environ.get("THJ_BENCH_NO_PAIR") != "1" and not args.fusion_search
+        if early_t0:
+            # stage 2's tier 0 (the reads whose hits abut end to end) needs no junction set: it goes out before stage 1's counts are
+            # asked for, and the GPU has it while the host waits and the event lists are sorted (thj_span_tier0_pair_async)
+            timed("span_reset", ctx.span_reset)
+            timed("span_tier0_pair", ctx.span_tier0_pair, p_span, sp_left, sp_right)
         cnt = timed("finish", ctx.finish)             # the only host round trip of the stage
         if args.fusion_search and args.fusion_frac > 0:
             # segment_juncs --fusion-search: find_fusions over both sides; the (small) list goes to the spanning stage the way the
@@ -974,7 +980,8 @@ def run_rank(args, rank, world, local_rank, control, shared):
             ctx.span_fusions_from_segjuncs()                             # device to device, like the junction set below
         # ---- long_spanning_reads stage, fed device-to-device with the (global) junction set
         timed("span_sets_from_segjuncs", ctx.span_sets_from_segjuncs)
-        timed("span_reset", ctx.span_reset)
+        if not early_t0:
+            timed("span_reset", ctx.span_reset)
         if os.environ.get("THJ_BENCH_NO_PAIR") == "1":
             ctx.span_run(p_span, sp_left)
             ctx.span_run(p_span, sp_right)

@@ -393,6 +393,13 @@ int thj_span_run_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* 
  * each other on streams of the context's own (the latency-bound kernels of one batch overlap the bandwidth-bound ones of the
  * other).  Joined on the context's stream before it returns. */
 int thj_span_run_pair_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* dev_batch0, const thj_span_batch* dev_batch1);
+/* Optional, before thj_span_run_pair_async on the same two batches (after thj_span_reset_async): the part of the pair's work
+ * that needs the batches and nothing else -- the reads whose segment hits abut end to end, two thirds of all -- is enqueued
+ * now; the run then only does what is behind it.  Stage 2's junction / indel sets need not exist yet: a caller that holds both
+ * stages resident calls this before thj_segjuncs_finish, and the GPU has that work while the host waits for stage 1's counts
+ * and the event lists are sorted.  Same records as without the call.  Does nothing (the run does everything) for an empty
+ * batch, under --fusion-search or THJ_SPAN_SERIAL.  THJ_ESTATE when anything but that run follows. */
+int thj_span_tier0_pair_async(thj_ctx* ctx, const thj_params* p, const thj_span_batch* dev_batch0, const thj_span_batch* dev_batch1);
 /* Synchronises and returns the record count.  THJ_EOVERFLOW when a device limit was hit (message says which); THJ_ERETRY when
  * a pool or workspace had to be enlarged (extra records of multihit reads; reads with more joined alignments than a thread keeps):
  * run the pass again.

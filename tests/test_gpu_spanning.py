@@ -90,6 +90,41 @@ def test_pair_call_gives_the_records_of_two_runs():
     assert [key(a) for a in pair2[len(want_b):]] == [key(a) for a in want_a]
 
 
+def test_tier0_ahead_of_the_junction_set():
+    """thj_span_tier0_pair_async: the pair's tier 0 enqueued before the junction set exists (a caller with both stages resident calls it
+    before thj_segjuncs_finish) -- the run that follows does the rest; the same records as the run alone.  Anything else after it is a
+    state error"""
+    ca = SPAN_CASES[0]
+    case_a, p, seqs, g, sb_a, juncs, ins = span_inputs(ca, n_reads=900)
+    case_b, p_b, seqs_b, g_b, sb_b, juncs_b, ins_b = span_inputs(ca, n_reads=500)
+    from tophat_amd.host import alns_from_array
+    key = lambda a: (a.ref_id, a.left, a.antisense, a.antisense_splice, a.cigar, a.MD, a.AS, a.XM, a.mismatches, a.edit_dist)
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        ha, hb = ctx.upload_span_batch(sb_a), ctx.upload_span_batch(sb_b)
+        ctx.upload_span_sets(juncs, ins)
+        ctx.span_reset()
+        ctx.span_run_pair(p, ha, hb)
+        n = ctx.span_finish()
+        plain = alns_from_array(ctx.span_download(n), None)
+        # the sets of another pass (none at all) are resident while tier 0 goes out; the real ones arrive before the run
+        ctx.upload_span_sets(juncs[:0], ins[:0])
+        ctx.span_reset()
+        ctx.span_tier0_pair(p, ha, hb)
+        ctx.upload_span_sets(juncs, ins)
+        ctx.span_run_pair(p, ha, hb)
+        n2 = ctx.span_finish()
+        early = alns_from_array(ctx.span_download(n2), None)
+        ctx.span_reset()
+        ctx.span_tier0_pair(p, ha, hb)
+        with pytest.raises(Exception, match="thj_span_tier0_pair_async is followed"):
+            ctx.span_run(p, ha)
+        ctx.span_reset()                                   # (forgets the pending tier 0)
+        ctx.span_run_pair(p, hb, ha)
+        assert ctx.span_finish() == n
+    assert n2 == n and [key(a) for a in early] == [key(a) for a in plain]
+
+
 def test_multihit_reads_as_chain_groups():
     """reads from a tandem repeat of two, three, four and eight copies: every segment has that many hits, every first-segment hit
     starts one chain -- thj_k_chains turns each read into a group of chain entries (rank order known up front), thj_k_join and

@@ -78,6 +78,8 @@ struct thj_ctx {
     // scratch of a batch in flight (span_launch in thj_span.hip): two sets, so that the two sides of a pass can run beside each other
     struct SpanSet { uint32_t* d_worklist = nullptr; int64_t worklist_cap = 0; void* d_ent = nullptr; int64_t ent_cap = 0; void* d_joined = nullptr; int64_t joined_cap = 0; uint32_t* d_defer = nullptr; int64_t defer_cap = 0; };
     SpanSet span_set[2]; int span_last_set = 0;
+    // thj_span_tier0_pair_async ran the pair's tier 0 ahead of thj_span_run_pair_async (which then only does what is behind it)
+    bool span_t0_pending = false; int64_t span_t0_n[2] = {0, 0}; hipEvent_t span_t0_prof[2][32] = {};
     hipStream_t span_stream[3] = {}; hipEvent_t span_ev[10] = {}; bool span_stream_own = false;      // (= aux_stream unless THJ_SPAN_PRIO)
     bool span_profile = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> span_prof_events;

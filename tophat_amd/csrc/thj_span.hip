@@ -1014,6 +1014,7 @@ extern "C" int thj_span_reset_async(thj_ctx* c) {
     HIPCHK(hipMemsetAsync(c->d_span_status, 0, 32, c->stream));     // [0..3] statuses, [5] thj_k_join's "cannot happen"
     c->n_alns = 0;
     c->span_reads = 0;
+    c->span_t0_pending = false;
     c->h_alns.clear();
     return THJ_OK;
 }
@@ -1195,7 +1196,8 @@ static int ensure_span_streams(thj_ctx* c) {
 // call enqueues both batches' tier 0 before anything else); pe: the batch's profile events
 struct SpanProf { hipEvent_t ev[32]; };
 static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* db, int set, uint32_t base, hipStream_t st0, hipStream_t sm, hipStream_t sa, hipStream_t sp,
-                       hipEvent_t ev_t0, hipEvent_t ev_fork, hipEvent_t ev_joined, int phases, SpanProf& pe) {
+                       hipEvent_t ev_t0, hipEvent_t ev_fork, hipEvent_t ev_joined, int phases, SpanProf& pe, hipEvent_t ev_sets = nullptr) {
+    // ev_sets: (tier 0 went out ahead of the junction set) what reads the set waits for this event; thj_k_chains does not
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevSpanBatch b; memcpy(&b, db, sizeof b);
@@ -1275,6 +1277,7 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         // 44 spilled) instead of three (162, nothing spilled), thj_k_finish the other way round
         static const int join_wpe = getenv("THJ_JOIN_WPE") ? atoi(getenv("THJ_JOIN_WPE")) : 3, fin_wpe = getenv("THJ_FIN_WPE") ? atoi(getenv("THJ_FIN_WPE")) : 4;
         const dim3 grid((unsigned)(G + G2));
+        if (ev_sets) HIPCHK(hipStreamWaitEvent(sa, ev_sets, 0));
         SPK_BEGIN(SPK_JOIN, sa);
         static const int abut_wpe = getenv("THJ_ABUT_WPE") ? atoi(getenv("THJ_ABUT_WPE")) : 6;       // developer switch
         if (abut_wpe == 4) hipLaunchKernelGGL(thj_k_join<4>, grid, dim3(256), 0, sa, g, p, S, b.hits, b.planes, b.W, cl, t, dl);
@@ -1291,6 +1294,7 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         else hipLaunchKernelGGL(thj_k_finish<4>, grid, dim3(256), 0, sa, g, p, b, sink, cl);
         SPK_END(SPK_FINISH, sa);
     } else {
+        if (ev_sets) HIPCHK(hipStreamWaitEvent(sm, ev_sets, 0));
         SPK_BEGIN(SPK_CHAINS, sm); SPK_END(SPK_CHAINS, sm); SPK_BEGIN(SPK_JOIN, sm); SPK_END(SPK_JOIN, sm);
         SPK_BEGIN(SPK_CLOSURE, sm); SPK_END(SPK_CLOSURE, sm); SPK_BEGIN(SPK_FINISH, sm); SPK_END(SPK_FINISH, sm);
     }
@@ -1376,7 +1380,8 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     return THJ_OK;
 }
 
-static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batch* db0, const thj_span_batch* db1) {
+// mode: 3 = a whole run; 1 = thj_span_tier0_pair_async (tier 0 of a pair, nothing else); a run that finds tier 0 done only does the rest
+static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batch* db0, const thj_span_batch* db1, int mode = 3) {
     if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
     int rc = check_span_params(tp, db0);
     if (!rc && db1) rc = check_span_params(tp, db1);
@@ -1384,6 +1389,11 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     HIPCHK(hipSetDevice(c->device));
     if ((rc = ensure_span_state(c))) return rc;
     const int64_t n0 = db0->n_reads, n1 = db1 ? db1->n_reads : 0;
+    const bool t0_done = c->span_t0_pending;
+    if (t0_done && (mode == 1 || !db1 || n0 != c->span_t0_n[0] || n1 != c->span_t0_n[1])) {
+        thj_set_error("thj_span_tier0_pair_async is followed by thj_span_run_pair_async on the same two batches");
+        return THJ_ESTATE;
+    }
     if (n0 + n1 == 0) return THJ_OK;
     if ((rc = ensure_sets_cap(c, c->n_span_junc, c->n_span_ins))) return rc;
     if (c->span_reads + n0 + n1 >= (1ll << 32)) { thj_set_error("more than 2^32 reads in one pass"); return THJ_EINVAL; }
@@ -1404,7 +1414,30 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     const uint32_t base0 = (uint32_t)c->span_reads, base1 = (uint32_t)(c->span_reads + n0);
     SpanProf pe0, pe1;
     hipStream_t cs = c->stream;
-    if (serial) {
+    if (mode == 1) {
+        // tier 0 needs the batches and nothing of stage 1: enqueued before the caller asks stage 1 for its counts and sorts its events, it
+        // fills the third of a millisecond the GPU otherwise waits through (one host round trip, twenty small sort kernels).  Both
+        // batches' tier 0 on the side streams, behind what the context's stream holds now; the context's stream stays free for the sorts.
+        if (serial || !n0 || !n1 || tp->fusion_search) return THJ_OK;              // (the run does everything)
+        hipStream_t x0 = c->span_stream[0], x1 = c->span_stream[1];
+        HIPCHK(hipEventRecord(c->span_ev[0], cs)); HIPCHK(hipStreamWaitEvent(x0, c->span_ev[0], 0)); HIPCHK(hipStreamWaitEvent(x1, c->span_ev[0], 0));
+        if ((rc = span_launch(c, tp, db0, 0, base0, x0, x0, x0, cs, c->span_ev[8], c->span_ev[1], c->span_ev[6], 1, pe0))) return rc;
+        if ((rc = span_launch(c, tp, db1, 1, base1, x1, x1, x1, cs, c->span_ev[9], c->span_ev[2], c->span_ev[7], 1, pe1))) return rc;
+        memcpy(c->span_t0_prof[0], pe0.ev, sizeof pe0.ev); memcpy(c->span_t0_prof[1], pe1.ev, sizeof pe1.ev);
+        c->span_t0_pending = true; c->span_t0_n[0] = n0; c->span_t0_n[1] = n1;
+        return THJ_OK;
+    }
+    if (t0_done) {
+        hipStream_t x0 = c->span_stream[0], x1 = c->span_stream[1];
+        memcpy(pe0.ev, c->span_t0_prof[0], sizeof pe0.ev); memcpy(pe1.ev, c->span_t0_prof[1], sizeof pe1.ev);
+        c->span_t0_pending = false;
+        // (the sets were built on the context's stream after tier 0 went out: the kernels that read them wait for this event)
+        HIPCHK(hipEventRecord(c->span_ev[0], cs));
+        if ((rc = span_launch(c, tp, db0, 0, base0, x0, x0, x0, cs, c->span_ev[8], c->span_ev[1], c->span_ev[6], 2, pe0, c->span_ev[0]))) return rc;
+        if ((rc = span_launch(c, tp, db1, 1, base1, x1, x1, x1, cs, c->span_ev[9], c->span_ev[2], c->span_ev[7], 2, pe1, c->span_ev[0]))) return rc;
+        HIPCHK(hipEventRecord(c->span_ev[3], x0)); HIPCHK(hipStreamWaitEvent(cs, c->span_ev[3], 0));
+        HIPCHK(hipEventRecord(c->span_ev[4], x1)); HIPCHK(hipStreamWaitEvent(cs, c->span_ev[4], 0));
+    } else if (serial) {
         if (n0 && (rc = span_launch(c, tp, db0, 0, base0, cs, cs, cs, cs, c->span_ev[8], c->span_ev[1], c->span_ev[6], 3, pe0))) return rc;
         if (n1 && (rc = span_launch(c, tp, db1, 1, base1, cs, cs, cs, cs, c->span_ev[9], c->span_ev[2], c->span_ev[7], 3, pe1))) return rc;
     } else if (!n1 || !n0) {
@@ -1431,6 +1464,11 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
 extern "C" int thj_span_run_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db) {
     if (!c || !tp || !db) { thj_set_error("thj_span_run_async: null argument"); return THJ_EINVAL; }
     return span_run_common(c, tp, db, nullptr);
+}
+
+extern "C" int thj_span_tier0_pair_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db0, const thj_span_batch* db1) {
+    if (!c || !tp || !db0 || !db1) { thj_set_error("thj_span_tier0_pair_async: null argument"); return THJ_EINVAL; }
+    return span_run_common(c, tp, db0, db1, 1);
 }
 
 extern "C" int thj_span_run_pair_async(thj_ctx* c, const thj_params* tp, const thj_span_batch* db0, const thj_span_batch* db1) {

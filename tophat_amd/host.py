@@ -684,6 +684,13 @@ def _span_methods():
         a1 = C.byref(batch1) if isinstance(batch1, CSpanBatch) else batch1
         _check(self.lib, self.lib.thj_span_run_pair_async(self._ctx, C.byref(cp), a0, a1), "thj_span_run_pair_async")
 
+    def span_tier0_pair(self, p: Params, batch0, batch1):
+        """the pair's tier 0 ahead of span_run_pair on the same batches (needs no junction set): thj_span_tier0_pair_async"""
+        cp = p.as_ctypes()
+        a0 = C.byref(batch0) if isinstance(batch0, CSpanBatch) else batch0
+        a1 = C.byref(batch1) if isinstance(batch1, CSpanBatch) else batch1
+        _check(self.lib, self.lib.thj_span_tier0_pair_async(self._ctx, C.byref(cp), a0, a1), "thj_span_tier0_pair_async")
+
     def span_tier_counts(self):
         """of the batch launched last: reads to the closure kernels, to the multihit kernel, on to the general kernel"""
         c = (C.c_int64 * 5)()
@@ -712,7 +719,7 @@ def _span_methods():
         return list(ms), n.value
 
     for f in (upload_span_fusions, upload_span_sets, span_sets_from_segjuncs, span_fusions_from_segjuncs, fusion_search, upload_span_batch, span_reset, span_run, span_finish,
-              span_download, spanning, profile_span, span_tier_counts, span_hit_heads, span_run_pair, span_chain_count, span_chain_groups):
+              span_download, spanning, profile_span, span_tier_counts, span_hit_heads, span_run_pair, span_tier0_pair, span_chain_count, span_chain_groups):
         setattr(Context, f.__name__, f)
 
 
@@ -725,7 +732,7 @@ ABI_SYMBOLS += ["thj_md_string"]
 ABI_SYMBOLS += ["thj_microexon_reset_async", "thj_microexon_collect", "thj_microexon_candidates", "thj_microexon_run"]
 ABI_SYMBOLS += ["thj_butterfly_run", "thj_covsearch_add_reads_bam", "thj_covsearch_reserve_reads"]
 ABI_SYMBOLS += ["thj_span_sets_upload", "thj_span_sets_from_segjuncs", "thj_span_fusions_from_segjuncs", "thj_span_batch_upload", "thj_span_batch_free",
-                "thj_span_reset_async", "thj_span_run_async", "thj_span_run_pair_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
+                "thj_span_reset_async", "thj_span_run_async", "thj_span_run_pair_async", "thj_span_tier0_pair_async", "thj_span_finish", "thj_span_download", "thj_profile_span",
                 "thj_span_tier_counts", "thj_span_device_records"]
 
 
