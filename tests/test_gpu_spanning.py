@@ -119,6 +119,8 @@ def test_tier0_ahead_of_the_junction_set():
         ctx.span_tier0_pair(p, ha, hb)
         with pytest.raises(Exception, match="thj_span_tier0_pair_async is followed"):
             ctx.span_run(p, ha)
+        with pytest.raises(Exception, match="thj_span_tier0_pair_async is followed"):
+            ctx.span_finish()
         ctx.span_reset()                                   # (forgets the pending tier 0)
         ctx.span_run_pair(p, hb, ha)
         assert ctx.span_finish() == n

@@ -1478,6 +1478,7 @@ extern "C" int thj_span_run_pair_async(thj_ctx* c, const thj_params* tp, const t
 
 extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
     if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    if (c->span_t0_pending) { thj_set_error("thj_span_tier0_pair_async is followed by thj_span_run_pair_async on the same two batches"); return THJ_ESTATE; }
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_span_state(c);
     if (rc) return rc;
