@@ -123,7 +123,7 @@ struct thj_ctx {
     std::vector<hipEvent_t> event_pool;
 };
 hipEvent_t thj_get_event(struct thj_ctx* c);
-int thj_ensure_aux_streams(struct thj_ctx* c);                      // thj_segjuncs.hip: aux_stream[3], aux_ev[10] (once)
+int thj_ensure_aux_streams(struct thj_ctx* c, int need);            // thj_streams.hip: aux_stream[0 .. need), aux_ev[10]
 void thj_warm_span(hipStream_t s); void thj_warm_ingest(hipStream_t s); void thj_warm_bamout(hipStream_t s);      // one empty launch from the translation unit: its code object is loaded now
 int thj_dev_alloc(struct thj_ctx* c, void** out, size_t bytes);     // like hipMalloc, from the context's block cache
 void thj_dev_release(struct thj_ctx* c, void* p);                  // like hipFree, but the block stays with the context

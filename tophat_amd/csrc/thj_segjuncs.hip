@@ -1190,92 +1190,7 @@ extern "C" int thj_genome_adopt(thj_ctx* c, const void* d_blocks, int64_t n_bloc
     return set_contigs(c, contig_blk, lens, n_contigs, n_blocks);
 }
 
-// HIP hands a new stream the next of GPU_MAX_HW_QUEUES (4) hardware queues, round robin over every stream the PROCESS ever made -- and
-// kernels of two streams on one queue leave one after the other.  Which queue the context's stream is on cannot be asked, so it is
-// measured: four streams made in a row sit on four different queues; each runs a short spin kernel beside one on the context's stream,
-// and the one whose pair takes twice as long shares that stream's queue and is not used.  (bench.py's files-in -> files-out leg opens a
-// context of its own for the inflater's figure before the resident-data steps; the streams it made moved the round robin on by one, the
-// second side's stream landed on the context's queue, and the default line's steps were 6.5 ms where a bare run's were 5.55:
-// profiles/r05_default_slow.txt.)  ~1 ms, once per context.
-__global__ void thj_k_spin(unsigned long long ticks) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
-}
-static int spin_group_us(thj_ctx* c, hipStream_t a, hipStream_t b, double* us) {        // a spin kernel on the context's stream, on a and on b (null: not there)
-    double best = 1e30;
-    for (int rep = 0; rep < 2; ++rep) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (a) HIPCHK(hipStreamSynchronize(a));
-        if (b) HIPCHK(hipStreamSynchronize(b));
-        const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, c->stream, 15000ull);          // 150 us at the 100 MHz of s_memrealtime
-        if (a) hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, a, 15000ull);
-        if (b) hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, b, 15000ull);
-        HIPCHK(hipStreamSynchronize(c->stream));
-        if (a) HIPCHK(hipStreamSynchronize(a));
-        if (b) HIPCHK(hipStreamSynchronize(b));
-        const double dt = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        if (dt < best) best = dt;
-    }
-    *us = best;
-    return THJ_OK;
-}
-int thj_ensure_aux_streams(thj_ctx* c) {
-    if (c->aux_stream[0]) return THJ_OK;
-    // (THJ_SJ_PRIO=1: the side streams at the highest priority the device has -- measured worse, 7.0 against 6.6 ms per step: the flat reads'
-    // rescue scan then waits for them)
-    int lo = 0, hi = 0;
-    static const bool prio = getenv("THJ_SJ_PRIO") && atoi(getenv("THJ_SJ_PRIO")) != 0;
-    static const bool no_probe = getenv("THJ_NO_QUEUE_PROBE") != nullptr;                       // developer switch: the first three streams as they come
-    if (prio) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    constexpr int NC = 5;
-    hipStream_t cand[NC] = {};
-    for (int i = 0; i < NC; ++i) HIPCHK(hipStreamCreateWithPriority(&cand[i], hipStreamNonBlocking, prio ? hi : 0));
-    int pi = 0, pj = 1;
-    if (!no_probe) {
-        // the first pair of candidates that runs beside the context's stream and beside each other (three spin kernels in the time of one)
-        double alone = 0, best = 1e30;
-        int rc = spin_group_us(c, nullptr, nullptr, &alone);
-        if (rc) return rc;
-        bool found = false;
-        for (int j = 1; j < NC && !found; ++j)
-            for (int i = 0; i < j && !found; ++i) {
-                double us = 0;
-                if ((rc = spin_group_us(c, cand[i], cand[j], &us))) return rc;
-                if (us < best) { best = us; pi = i; pj = j; }
-                found = us < 1.5 * alone;
-            }
-        static const bool trace = getenv("THJ_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[streams] a spin kernel alone %.0f us; with candidates %d and %d beside it %.0f us%s\n", alone, pi, pj, best, found ? "" : " -- no pair of them runs beside the context's stream");
-    }
-    c->aux_stream[0] = cand[pi]; c->aux_stream[1] = cand[pj];
-    int pk = -1;
-    if (!no_probe) {        // a third one beside those (developer switches only): four spin kernels in the time of one, if the process has a queue to spare
-        double alone = 0;
-        int rc = spin_group_us(c, nullptr, nullptr, &alone);
-        if (rc) return rc;
-        for (int k = 0; k < NC && pk < 0; ++k) {
-            if (k == pi || k == pj) continue;
-            HIPCHK(hipStreamSynchronize(cand[k]));
-            const auto t0 = std::chrono::steady_clock::now();
-            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, c->stream, 15000ull);
-            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, cand[pi], 15000ull);
-            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, cand[pj], 15000ull);
-            hipLaunchKernelGGL(thj_k_spin, dim3(1), dim3(64), 0, cand[k], 15000ull);
-            HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(cand[pi])); HIPCHK(hipStreamSynchronize(cand[pj])); HIPCHK(hipStreamSynchronize(cand[k]));
-            const double dt = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-            if (dt < 1.5 * alone) pk = k;
-        }
-        static const bool trace = getenv("THJ_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[streams] a third side stream beside them: %s\n", pk >= 0 ? "yes" : "no");
-    }
-    for (int i = 0; i < NC; ++i) {
-        if (i == pi || i == pj) continue;
-        if (!c->aux_stream[2] && (pk < 0 || i == pk)) c->aux_stream[2] = cand[i]; else (void)hipStreamDestroy(cand[i]);
-    }
-    for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreateWithFlags(&c->aux_ev[i], hipEventDisableTiming));
-    return THJ_OK;
-}
+// (thj_ensure_aux_streams: thj_streams.hip -- a translation unit of its own, so that its spin kernel does not pull this file's code object in)
 
 // ------------------------------------------------------------------ batches
 
@@ -1439,6 +1354,7 @@ struct SjState {
     hipStream_t sm, sa, sb, sc; hipEvent_t* aev; hipEvent_t m0, m1;
 };
 // first half: the scratch lists, thj_k_sj_flat on the context's stream, the side streams told to wait for it
+static bool beside_env() { static const bool v = getenv("THJ_SJ_SHARED_BESIDE") != nullptr; return v; }
 static int sj_launch_flat(thj_ctx* c, const thj_params* tp, const thj_seg_batch* db, int set, SjState& st) {
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p;
@@ -1520,11 +1436,11 @@ static int sj_launch_flat(thj_ctx* c, const thj_params* tp, const thj_seg_batch*
     // take inserts from any of them.  THJ_SJ_SERIAL=1: one stream.
     static const bool serial_env = getenv("THJ_SJ_SERIAL") && atoi(getenv("THJ_SJ_SERIAL")) != 0;
     const bool serial = serial_env || c->serial_launch;
-    if (!serial) { const int src = thj_ensure_aux_streams(c); if (src) return src; }
+    if (!serial) { const int src = thj_ensure_aux_streams(c, beside_env() ? 3 : set + 1); if (src) return src; }
     // the set's chain on the set's side stream: thj_k_segjuncs_shared, both general instances, then the rescue kernels and the tasks.
     // (THJ_SJ_SHARED_BESIDE: developer switch -- thj_k_segjuncs_shared beside the chain on a third side stream, as before round 5; the third
     // stream shares a hardware queue with one of the others, and what was enqueued behind it waited: 5.7 against 5.55 ms per step)
-    static const bool beside = getenv("THJ_SJ_SHARED_BESIDE") != nullptr;
+    static const bool beside = beside_env();
     hipStream_t sm = c->stream, sa = serial ? c->stream : c->aux_stream[set], sb = serial ? c->stream : beside ? c->aux_stream[2] : sa, sc = sa;
     hipEvent_t* const aev = c->aux_ev + 5 * set;
     // profiling: one pair of events around every kernel (pairs of kernels where the second is the first's tail), on the stream it runs on;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cstddef>
+#include <chrono>
 #include <vector>
 
 #include "../../include/thj.h"
@@ -1172,22 +1173,23 @@ static int ensure_span_set(thj_ctx* c, int set, int64_t n_reads, int64_t G, int6
     }
     return THJ_OK;
 }
-static int ensure_span_streams(thj_ctx* c) {
-    if (c->span_stream[0]) return THJ_OK;
-    // the context's three side streams (thj_ctx.h: shared with stage 1, which is over when this stage runs).  THJ_SPAN_PRIO=1: developer
-    // switch -- streams of this stage's own, the join / closure search / finish ones at the highest priority (measured worse)
+static int ensure_span_streams(thj_ctx* c, int need) {
+    // the context's side streams (thj_ctx.h: shared with stage 1, which is over when this stage runs), as many as the call uses.
+    // THJ_SPAN_PRIO=1: developer switch -- streams of this stage's own, the join / closure search / finish ones at the highest priority
+    // (measured worse)
     static const bool prio = getenv("THJ_SPAN_PRIO") != nullptr;
+    if (!c->span_ev[0]) for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreateWithFlags(&c->span_ev[i], hipEventDisableTiming));
     if (prio) {
+        if (c->span_stream[0]) return THJ_OK;
         int lo = 0, hi = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         for (int i = 0; i < 3; ++i) HIPCHK(hipStreamCreateWithPriority(&c->span_stream[i], hipStreamNonBlocking, i != 1 ? hi : 0));
         c->span_stream_own = true;
-    } else {
-        int rc = thj_ensure_aux_streams(c);
-        if (rc) return rc;
-        for (int i = 0; i < 3; ++i) c->span_stream[i] = c->aux_stream[i];
+        return THJ_OK;
     }
-    for (int i = 0; i < 10; ++i) HIPCHK(hipEventCreateWithFlags(&c->span_ev[i], hipEventDisableTiming));
+    const int rc = thj_ensure_aux_streams(c, need);
+    if (rc) return rc;
+    for (int i = 0; i < 3; ++i) c->span_stream[i] = c->aux_stream[i];
     return THJ_OK;
 }
 
@@ -1387,7 +1389,13 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     if (!rc && db1) rc = check_span_params(tp, db1);
     if (rc) return rc;
     HIPCHK(hipSetDevice(c->device));
+    // THJ_TRACE: what a context's first run spends before its kernels go out (seconds since the call began), on stderr
+    static const bool trace_env = getenv("THJ_TRACE") != nullptr;
+    const bool trace_first = trace_env && !c->span_ev[0];
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto lapse = [&](const char* what) { if (trace_first) fprintf(stderr, "[trace] first run of a context: %-28s %.4f\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count()); };
     if ((rc = ensure_span_state(c))) return rc;
+    lapse("state");
     const int64_t n0 = db0->n_reads, n1 = db1 ? db1->n_reads : 0;
     const bool t0_done = c->span_t0_pending;
     if (t0_done && (mode == 1 || !db1 || n0 != c->span_t0_n[0] || n1 != c->span_t0_n[1])) {
@@ -1397,8 +1405,14 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     if (n0 + n1 == 0) return THJ_OK;
     if ((rc = ensure_sets_cap(c, c->n_span_junc, c->n_span_ins))) return rc;
     if (c->span_reads + n0 + n1 >= (1ll << 32)) { thj_set_error("more than 2^32 reads in one pass"); return THJ_EINVAL; }
+    lapse("sets' room");
     if ((rc = ensure_slots(c, c->span_reads + n0 + n1))) return rc;
-    if ((rc = ensure_span_streams(c))) return rc;
+    lapse("slots");
+    {
+        static const bool own_a1_env = getenv("THJ_SPAN_A1") != nullptr;
+        if ((rc = ensure_span_streams(c, (n0 && n1) ? (own_a1_env ? 3 : 2) : 1))) return rc;
+    }
+    lapse("streams (with the queue probe)");
     // THJ_SPAN_SERIAL: developer switch -- every kernel on the context's stream, one after the other
     static const bool serial_env = getenv("THJ_SPAN_SERIAL") != nullptr;
     const bool serial = serial_env || c->serial_launch;
@@ -1458,6 +1472,8 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
         if (a1 != x1) { HIPCHK(hipEventRecord(c->span_ev[5], a1)); HIPCHK(hipStreamWaitEvent(cs, c->span_ev[5], 0)); }
     }
     c->span_reads += n0 + n1;
+    lapse("kernels enqueued");
+    if (trace_first) { (void)hipStreamSynchronize(c->stream); lapse("kernels done"); }
     return THJ_OK;
 }
 
