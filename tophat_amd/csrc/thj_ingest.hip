@@ -1457,6 +1457,11 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     if (nb == 0) return THJ_OK;
     const size_t need0 = (size_t)comp_total + 64 + (size_t)nb * (65536 + sizeof(thj_bgzf_block) + 1 + 4 + 4 + 4 + (size_t)MAXREC * 2) + (size_t)nf * sizeof(FileInfo) +
                          tid2ref.size() * 4 + (1 << 20);
+    // THJ_TRACE: where a context's first ingest spends its time (seconds since here), on stderr
+    static const bool trace_env = getenv("THJ_TRACE") != nullptr;
+    const bool trace_first = trace_env && c->ing_cap0 == 0;
+    const long long tr0 = PhaseClock::now();
+    auto lapse = [&](const char* what) { if (trace_first) { hipStreamSynchronize(c->stream); fprintf(stderr, "[trace] first ingest of a context: %-30s %.4f\n", what, (double)(PhaseClock::now() - tr0) * 1e-9); } };
     if (c->ing_cap0 < need0) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_ing0); c->d_ing0 = nullptr; c->ing_cap0 = 0; HIPCHK(hipMalloc(&c->d_ing0, need0 + need0 / 4)); c->ing_cap0 = need0 + need0 / 4; }
     Arena ar{(char*)c->d_ing0, c->ing_cap0, 0};
     ING_TAKE(ar, d_comp, uint8_t, comp_total + 64);
@@ -1471,6 +1476,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     ING_TAKE(ar, d_recoff, uint16_t, (size_t)nb * MAXREC);
     ING_TAKE(ar, d_status, unsigned int, 16);
     P.infl = d_infl; P.status = d_status;
+    lapse("first arena");
     PhaseClock pc(c);
     {
         int64_t at = 0;
@@ -1483,9 +1489,11 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipMemsetAsync(d_status, 0, 64, c->stream));
     HIPCHK(hipMemsetAsync(d_cnt + nb, 0, 4, c->stream));
     pc.mark(0);
+    lapse("compressed pieces on the device");
     { uint32_t mx = 0; for (const auto& bk : blocks) mx = bk.in_len > mx ? bk.in_len : mx;
       const int rc_ = launch_inflate(c, d_comp, d_blocks, nb, d_infl, d_len, mx); if (rc_) return rc_; }
     pc.mark(1);
+    lapse("inflated (scratch, kernels)");
     hipLaunchKernelGGL(thj_k_walk, dim3((unsigned)nb), dim3(64), 0, c->stream, d_infl, d_len, d_blk_file, d_files, (int)nb, d_recoff, d_cnt, d_status);
     int rc = exclusive_sum(c, d_cnt, d_base, nb + 1);
     if (rc) return rc;
@@ -1495,6 +1503,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipMemcpyAsync(h_status, d_status, 64, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     pc.mark(2);
+    lapse("records walked");
     if (h_status[ST_CORRUPT]) { thj_set_error("thj_ingest: a BGZF member does not inflate (corrupt input)"); return THJ_EINVAL; }
     if (h_status[ST_STRADDLE]) { thj_set_error("BAM records straddle BGZF members (not written by samtools' bam_write1)"); return THJ_EFALLBACK; }
     const int64_t T = h_base[(size_t)nb];
@@ -1523,6 +1532,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipGetLastError());
     pc.mark(4);
+    lapse("parsed and compacted");
     if (h_status[ST_CORRUPT]) { thj_set_error("thj_ingest: malformed BAM record (its header or a tag does not fit its block_size)"); return THJ_EINVAL; }
     if (h_status[ST_XF]) { thj_set_error("fusion (XF) alignments are not supported by this build"); return THJ_EINVAL; }
     if (h_status[ST_CIGAR]) { thj_set_error("a segment alignment has more than 5 CIGAR operations (this build supports 5)"); return THJ_EINVAL; }
