@@ -1513,6 +1513,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     const size_t hit_b = want32 ? sizeof(Hit32) : sizeof(Hit16);
     const size_t need1 = (size_t)(T + 64) * (4 + 4 + 4 + 4 + hit_b + 4 + 4 + hit_b + 4 + extra1_per_rec) + extra1_fixed + (size_t)(nf + 64) * 1024 + (1 << 20);
     if (c->ing_cap1 < need1) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_ing1); c->d_ing1 = nullptr; c->ing_cap1 = 0; HIPCHK(hipMalloc(&c->d_ing1, need1 + need1 / 4)); c->ing_cap1 = need1 + need1 / 4; }
+    lapse("second arena");
     P.a1 = Arena{(char*)c->d_ing1, c->ing_cap1, 0};
     ING_TAKE(P.a1, p_id, uint32_t, T); ING_TAKE(P.a1, p_valid, uint32_t, T + 1); ING_TAKE(P.a1, p_dst, uint32_t, T + 1); ING_TAKE(P.a1, p_isr, uint32_t, T);
     ING_TAKE(P.a1, p_hit, uint8_t, (size_t)T * hit_b); ING_TAKE(P.a1, p_loc, uint32_t, T);
@@ -1523,8 +1524,10 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     hipLaunchKernelGGL(thj_k_parse, dim3((unsigned)nb), dim3(256), 0, c->stream, d_infl, d_blk_file, d_files, d_recoff, d_cnt, d_base, d_tid, begin_id, end_id,
                        (int)tp->max_report_intron, want32, po, d_status);
     pc.mark(3);
+    lapse("parse kernel");
     hipLaunchKernelGGL(thj_k_mark_reads, dim3(grid_for(T)), dim3(256), 0, c->stream, d_files, nf, d_base, p_isr, T);
     if ((rc = exclusive_sum(c, p_valid, p_dst, T + 1))) return rc;
+    lapse("mark + scan");
     hipLaunchKernelGGL(thj_k_compact, dim3(grid_for(T)), dim3(256), 0, c->stream, T, p_valid, p_dst, po, qo, want32, p_isr);
     for (int f = 0; f < nf; ++f) HIPCHK(hipMemcpyAsync(&P.fb[(size_t)f], p_dst + files[(size_t)f].rec_base, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(&P.fb[(size_t)nf], p_dst + T, 4, hipMemcpyDeviceToHost, c->stream));
