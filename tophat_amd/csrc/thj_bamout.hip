@@ -16,6 +16,7 @@
 
 #include "../../include/thj.h"
 #include "thj_ctx.h"
+#include "thj_scan.h"
 
 #define THJ_DFN __device__ __forceinline__
 #include "thj_deflate_core.h"
@@ -115,7 +116,6 @@ __global__ __launch_bounds__(256) void thj_k_bam_write(const thj_aln* __restrict
     }
 }
 
-struct SizeToU64 { __host__ __device__ unsigned long long operator()(uint32_t v) const { return v; } };
 
 int ensure_bam(thj_ctx* c, size_t bytes) {
     if (bytes <= c->bam_cap) return THJ_OK;
@@ -166,9 +166,7 @@ extern "C" int thj_span_bam_encode(thj_ctx* c, const thj_span_batch* batch, cons
         return code;
     };
 #define BAM_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { thj_set_error("%s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); return done(THJ_EHIP); } } while (0)
-    hipcub::TransformInputIterator<unsigned long long, SizeToU64, const uint32_t*> in((const uint32_t*)nullptr, SizeToU64());
-    size_t tmp_bytes = 0;
-    BAM_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, (unsigned long long*)nullptr, (int)n, c->stream));
+    const size_t tmp_bytes = thj_scan::scratch_bytes(n, 8);            // (thj_scan.h: not hipcub::DeviceScan)
     if (thj_dev_alloc(c, &d_size, (size_t)n * 4 + 16) || thj_dev_alloc(c, &d_rid, (size_t)n * 8) || thj_dev_alloc(c, &d_off, (size_t)n * 8) ||
         thj_dev_alloc(c, &d_tid, (size_t)n_ref * 4) || thj_dev_alloc(c, &d_tmp, tmp_bytes + 16)) return done(THJ_EHIP);
     unsigned int* d_flag = (unsigned int*)((char*)d_size + (size_t)n * 4);
@@ -178,8 +176,7 @@ extern "C" int thj_span_bam_encode(thj_ctx* c, const thj_span_batch* batch, cons
     hipLaunchKernelGGL(thj_k_bam_shapes, dim3((unsigned)grid), dim3(256), 0, c->stream, (const thj_aln*)d_alns, n, (const uint8_t*)ob->ptrs[6], (const uint32_t*)ob->ptrs[7],
                        batch->n_reads, ob->reads_infl_bytes, n_ref, (uint32_t*)d_size, (long long*)d_rid, d_flag);
     BAM_HIP(hipGetLastError());
-    hipcub::TransformInputIterator<unsigned long long, SizeToU64, const uint32_t*> in2((const uint32_t*)d_size, SizeToU64());
-    BAM_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, in2, (unsigned long long*)d_off, (int)n, c->stream));
+    thj_scan::exclusive_sum<uint32_t, unsigned long long>(c->stream, (const uint32_t*)d_size, (unsigned long long*)d_off, n, d_tmp);
     unsigned int flag = 0; unsigned long long last_off = 0;
     BAM_HIP(hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, c->stream));
     BAM_HIP(hipMemcpyAsync(&last_off, (unsigned long long*)d_off + (n - 1), 8, hipMemcpyDeviceToHost, c->stream));

@@ -21,6 +21,7 @@
 
 #include "../../include/thj.h"
 #include "thj_ctx.h"
+#include "thj_scan.h"
 
 extern "C" void* thj_pinned_alloc(size_t bytes);
 extern "C" void thj_pinned_free(void* p);
@@ -1395,16 +1396,16 @@ struct Parsed {
 };
 
 static int grow_scan_tmp(thj_ctx* c, size_t need) {
+    if (need < ((size_t)1 << 20)) need = (size_t)1 << 20;        // (once: hipFree waits for the whole device)
     if (need > c->sort_tmp_bytes) { HIPCHK(hipStreamSynchronize(c->stream)); hipFree(c->d_sort_tmp); c->d_sort_tmp = nullptr; HIPCHK(hipMalloc(&c->d_sort_tmp, need)); c->sort_tmp_bytes = need; }
     return THJ_OK;
 }
+// exclusive prefix sum of n 32-bit counts (thj_scan.h: three small kernels, not hipcub::DeviceScan)
 static int exclusive_sum(thj_ctx* c, const uint32_t* in, uint32_t* out, int64_t n) {
-    size_t need = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (int)n, c->stream));
-    int rc = grow_scan_tmp(c, need);
+    if (n <= 0) return THJ_OK;
+    int rc = grow_scan_tmp(c, thj_scan::scratch_bytes(n, 4));
     if (rc) return rc;
-    size_t sb = c->sort_tmp_bytes;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(c->d_sort_tmp, sb, in, out, (int)n, c->stream));
+    thj_scan::exclusive_sum<uint32_t, uint32_t>(c->stream, in, out, n, c->d_sort_tmp);
     return THJ_OK;
 }
 static unsigned grid_for(int64_t n) { int64_t g = (n + 255) / 256; return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
@@ -1526,6 +1527,7 @@ static int ingest_front(thj_ctx* c, const thj_params* tp, const std::vector<cons
     pc.mark(3);
     lapse("parse kernel");
     hipLaunchKernelGGL(thj_k_mark_reads, dim3(grid_for(T)), dim3(256), 0, c->stream, d_files, nf, d_base, p_isr, T);
+    lapse("mark");
     if ((rc = exclusive_sum(c, p_valid, p_dst, T + 1))) return rc;
     lapse("mark + scan");
     hipLaunchKernelGGL(thj_k_compact, dim3(grid_for(T)), dim3(256), 0, c->stream, T, p_valid, p_dst, po, qo, want32, p_isr);

@@ -21,6 +21,7 @@
 #include "thj_span_core.h"
 #include "thj_span_fusion.h"
 #include "thj_ctx.h"
+#include "thj_scan.h"
 
 using namespace thj;
 
@@ -1568,7 +1569,6 @@ static inline void slot_to_aln(const thj_aln& slot, thj_aln& out) {
 // per-read record counts; its 2nd.. records (the extra pool, keyed slot << 16 | rank) follow at + rank.  One thread per record
 // converts the slot layout to thj_aln on the way.  (The per-read count saturates at 255: a pass with such a read does not add up
 // to n_alns and takes the host path below.)
-struct NrecToU32 { __host__ __device__ uint32_t operator()(uint8_t v) const { return (uint32_t)v; } };
 __device__ __forceinline__ void slot_to_aln_dev(const uint4* src, uint4* dst) {
     uint32_t s[32], w[32];
 #pragma unroll
@@ -1621,16 +1621,14 @@ int thj_span_compact_device(thj_ctx* c, void** d_out_p) {
     static const bool host_path = getenv("THJ_DOWNLOAD_ON_HOST") != nullptr;
     if (host_path || n >= (1ll << 32) || nr < 1) return THJ_EFALLBACK;
     void *d_off = nullptr, *d_out = nullptr, *d_tmp = nullptr;
-    hipcub::TransformInputIterator<uint32_t, NrecToU32, const uint8_t*> in(c->d_nrec, NrecToU32());
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, in, (uint32_t*)nullptr, (int)nr, c->stream));
+    const size_t tmp_bytes = thj_scan::scratch_bytes(nr, 4);          // (thj_scan.h: not hipcub::DeviceScan)
     int rc = thj_dev_alloc(c, &d_off, (size_t)nr * 4 + 16);
     if (!rc) rc = thj_dev_alloc(c, &d_out, (size_t)n * 128);
     if (!rc) rc = thj_dev_alloc(c, &d_tmp, tmp_bytes + 16);
     if (rc) { if (d_off) thj_dev_release(c, d_off); if (d_out) thj_dev_release(c, d_out); if (d_tmp) thj_dev_release(c, d_tmp); return THJ_EFALLBACK; }
     unsigned int* d_bad = (unsigned int*)((char*)d_off + (size_t)nr * 4);
     HIPCHK(hipMemsetAsync(d_bad, 0, 4, c->stream));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, in, (uint32_t*)d_off, (int)nr, c->stream));
+    thj_scan::exclusive_sum<uint8_t, uint32_t>(c->stream, (const uint8_t*)c->d_nrec, (uint32_t*)d_off, nr, d_tmp);
     const int64_t items = nr + c->n_ovf;
     int64_t grid = (items + 255) / 256; if (grid > 65536) grid = 65536;
     hipLaunchKernelGGL(thj_k_compact_records, dim3((unsigned)grid), dim3(256), 0, c->stream, (const OutAln*)c->d_aln_pool, (const uint8_t*)c->d_nrec, (const uint32_t*)d_off, nr,
