@@ -329,7 +329,12 @@ static int real_main(int argc, char** argv) {
         // communicator is either all-RCCL or all-loopback)
         // (three here: a shard's inflate launch is ~1500 members, a quarter of what the GPU holds, so three contexts' launches overlap:
         // 1.22 -> 1.09 s per side on 10 M pairs; segment_juncs, with ten times larger shards, keeps two)
-        int per = getenv("THJ_CTX_PER_GPU") ? atoi(getenv("THJ_CTX_PER_GPU")) : (n_dev > 1 ? 1 : 3);
+        // (... when there is enough to overlap: a context costs ~50 ms to start -- its stream, its first launches and allocations -- and a
+        // side of 10 M pairs, 1.4 GB of maps, is through in 0.4 s: two contexts there, 2.22-2.26 s against 2.33-2.48 for the three
+        // processes; at 40 M pairs three, 4.14-4.39 s against 4.50-4.62.  tools/scratch/r05_ctx_ab.sh)
+        int64_t in_bytes = 0;
+        { struct stat sb; for (const std::string& f : segs) if (!stat(f.c_str(), &sb)) in_bytes += (int64_t)sb.st_size; if (!stat(pos[1].c_str(), &sb)) in_bytes += (int64_t)sb.st_size; }
+        int per = getenv("THJ_CTX_PER_GPU") ? atoi(getenv("THJ_CTX_PER_GPU")) : (n_dev > 1 ? 1 : (in_bytes > (3ll << 30) ? 3 : 2));
         if (n_dev > 1) per = 1;
         if (per < 1) per = 1;
         if (per > 8) per = 8;
