@@ -266,6 +266,8 @@ def parse_args():
     ap.add_argument("--e2e-pairs-large", type=int, default=40_000_000, metavar="N",
                     help="run the e2e leg a second time on N pairs (timing only; e.g. 40000000) so that the fixed cost of the three processes "
                          "and their rate separate: `e2e.large`, `e2e.fixed_s` and `e2e.rate_pairs_per_s` from the two points")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"), metavar="PATH",
+                    help="where the whole result goes (per-kernel table, e2e stage timings, checks); stdout carries the contract's line only")
     ap.add_argument("--e2e-pairs", type=int, default=10_000_000,
                     help="also run the drop-in executables end to end (files in, files out: the metric as SURVEY 8d words it) on "
                          "generated files of this many pairs; 0 skips the leg.  Reported as the `e2e` object, never as `value`")
@@ -381,7 +383,7 @@ def main():
                     _E2E_EARLY = {"error": repr(e)[:2000], "ok": False, "n_gpus": world}
             control.barrier()
         result = run_rank(args, rank, world, local_rank, control, None)
-        finish_stdout(result if rank == 0 else None)
+        finish_stdout(result if rank == 0 else None, args.detail)
         return
     if args.gpus > 1 and os.environ.get("THJ_BENCH_INPROC") == "1":
         # functional test on a one-GPU box: N ranks as threads on device 0, loopback exchange
@@ -403,7 +405,7 @@ def main():
             t.join()
         if errs:
             raise errs[0]
-        finish_stdout(results[0])
+        finish_stdout(results[0], args.detail)
         return
     if args.gpus > 1:
         if torch.cuda.device_count() < args.gpus:
@@ -420,13 +422,110 @@ def main():
             _E2E_EARLY = {"error": repr(e)[:2000], "ok": False}
             e2e_failed = True
     result = run_rank(args, 0, 1, 0, None, None)
-    finish_stdout(result)
+    finish_stdout(result, args.detail)
     if e2e_failed:
         sys.stderr.write("bench.py: the files-in -> files-out leg failed: %s\n" % _E2E_EARLY["error"])
         sys.exit(3)
 
 
-def finish_stdout(result):
+LINE_LIMIT = 6144          # the driver parses the final stdout line; 16 KB parsed in round 4, 22.5 KB did not
+
+
+def _r(x, nd=4):
+    """numbers of the line rounded to nd significant digits (the detail file keeps them whole)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float("%.*g" % (nd + 2, x))
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def _pick(d, keys, nd=4):
+    return None if not isinstance(d, dict) else {k: _r(d[k], nd) for k in keys if k in d and not isinstance(d[k], dict)}
+
+
+def compact_line(result):
+    """The ONE JSON line of the bench contract: the contract's keys, `roofline`, `cpu_baseline`, `metric_e2e`, numbers only --
+    under LINE_LIMIT bytes whatever the run produced.  Everything else (the per-kernel table, stage timings, SHA-256s, the prose
+    about samples) is in the detail file (`--detail`, default bench_detail.json beside bench.py and under gpurun_out/) and on
+    stderr.  tests/test_bench_line_cpu.py builds it from a canned result."""
+    r = result
+    cfg = dict(r.get("config") or {})
+    wl = cfg.get("workload", "")
+    if len(wl) > 200:
+        wl = wl[:197] + "..."
+    cfg["workload"] = wl
+    cfg.pop("workload_detail", None)
+    out = {k: _r(r.get(k), 7) for k in ("metric", "value", "value_is", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                         "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {k: _r(v) for k, v in cfg.items()}
+    out["roofline"] = _pick(r.get("roofline"), ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_alone", "frac_step", "traffic",
+                                                "algorithmic_bytes_per_launch", "avg_kernel_ms", "avg_kernel_ms_alone", "launches",
+                                                "traffic_measured_in_run", "share_of_kernel_time", "measured_copy_GBs", "streams_independent"), 5)
+    cpu = r.get("cpu_baseline")
+    if cpu is not None:
+        c = _pick(cpu, ("value", "unit", "cores", "kind"))
+        smp = cpu.get("sample", "")
+        c["sample"] = smp if len(smp) <= 160 else smp[:157] + "..."
+        for sub in ("all_cores", "files_to_files", "reference_calibration"):
+            if isinstance(cpu.get(sub), dict):
+                c[sub] = _pick(cpu[sub], ("value", "cores", "outputs_identical_to_the_gpu_executables"))
+        out["cpu_baseline"] = c
+    else:
+        out["cpu_baseline"] = None
+    e = r.get("e2e")
+    if e:
+        m = _pick(r.get("metric_e2e"), ("value", "unit", "checked_against_oracle")) or {}
+        if e.get("error"):
+            m["error"] = str(e["error"])[:300]
+        m.update(_pick(e, ("pairs", "both_stages_s", "marginal_pairs_per_s", "fixed_s", "n_gpus")))
+        if isinstance(e.get("large"), dict):
+            m["large"] = _pick(e["large"], ("pairs", "value", "both_stages_s"))
+        g = e.get("grch38")
+        if isinstance(g, dict):
+            m["grch38"] = {"pairs": g.get("pairs"),
+                           "cold": _r((g.get("first_run_no_cache") or {}).get("value")), "warm": _r((g.get("second_run_cache") or {}).get("value"))}
+        c3 = e.get("config3_full")
+        if isinstance(c3, dict):
+            m["config3_full"] = _pick(c3, ("pairs", "seconds", "ranks", "outputs_identical", "value", "error"))
+        f2f = e.get("cpu_files_to_files")
+        if isinstance(f2f, dict):
+            m["cpu_files_identical"] = f2f.get("outputs_identical_to_the_gpu_executables")
+        out["metric_e2e"] = m
+    else:
+        out["metric_e2e"] = None
+    out["exchange"] = _pick(r.get("exchange"), ("transport", "ranks", "n_ranks", "calls", "bytes_per_rank", "gathered_bytes_per_step", "us_per_step", "redo"))
+    out["per_rank_ms_per_step"] = _r(r.get("per_rank_ms_per_step"), 5)
+    out["events"] = _pick(r.get("events"), ("junctions", "deletions", "insertions", "spanning_records_per_step"))
+    out["detail"] = r.get("detail_file")
+    line = json.dumps(out, separators=(",", ":"))
+    if len(line) > LINE_LIMIT:             # cannot happen with the keys above; if it ever does, the contract's keys win
+        for k in ("events", "exchange", "per_rank_ms_per_step", "metric_e2e"):
+            out.pop(k, None)
+            line = json.dumps(out, separators=(",", ":"))
+            if len(line) <= LINE_LIMIT:
+                break
+    return line
+
+
+def write_detail(result, path):
+    """The whole result (per-kernel table, e2e stage timings, checks) beside the line: the file named by --detail and, when the
+    repo has a gpurun_out/ directory, a copy there (what travels back from a GPU box)."""
+    txt = json.dumps(result, indent=1)
+    written = []
+    for p in [path] + ([os.path.join(ROOT, "gpurun_out", os.path.basename(path))] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else []):
+        try:
+            with open(p, "w") as f:
+                f.write(txt + "\n")
+            written.append(p)
+        except OSError:
+            pass
+    return written
+
+
+def finish_stdout(result, detail_path=None):
     # The JSON line must be the last thing on stdout: RCCL writes a version banner through C stdio, which sits in libc's
     # buffer until exit when stdout is a pipe.  Flush that first, print the line, then point fd 1 at /dev/null so that
     # nothing written later (exit handlers, library destructors) can follow it.  The process still exits normally --
@@ -434,7 +533,12 @@ def finish_stdout(result):
     sys.stdout.flush()
     ctypes.CDLL(None).fflush(None)
     if result is not None:
-        print(json.dumps(result), flush=True)
+        if detail_path:
+            w = write_detail(result, detail_path)
+            result["detail_file"] = os.path.relpath(w[0], ROOT) if w else None
+        sys.stderr.write("[bench] full result:\n" + json.dumps(result) + "\n")
+        sys.stderr.flush()
+        print(compact_line(result), flush=True)
     sys.stdout.flush()
     devnull = os.open(os.devnull, os.O_WRONLY)
     os.dup2(devnull, 1)
@@ -1244,6 +1348,14 @@ def run_rank(args, rank, world, local_rank, control, shared):
         workload_text += "; stage 2 batches WITHOUT the dense hit-head array (32-byte records only)"
     if n_ium:
         workload_text += "; with the coverage search (first %d reads of each side as --ium-reads, %d coverage junctions)" % (n_ium, cov_found[0])
+    # the line's own name of the workload (<= 200 characters; the long text above is config.workload_detail in the detail file)
+    workload_short = "%s: %d x 2x%d bp PE synthetic vs %s genome (%d bp) per GPU, resident in HBM; segment_juncs then long_spanning_reads on device" % (
+        ("configs[1], SURVEY 8(d) mix" if args.multihit_frac > 0 or args.indel_frac > 0 else "configs[1]") if args.read_len == 100 and args.genome == "chr20" and not n_ium and not args.fusion_search
+        else ("configs[2] shard" if args.config == 3 else "other shape"), args.pairs, args.read_len, "chr20-sized" if args.genome == "chr20" else "GRCh38-sized", genome_len)
+    if n_ium:
+        workload_short += "; coverage search (%d coverage junctions)" % cov_found[0]
+    if args.fusion_search:
+        workload_short += "; --fusion-search"
     result = None
     if rank == 0:
         # what this box's HBM sustains on a plain copy (quote it beside the 8 TB/s spec peak): 2 GiB device-to-device
@@ -1327,14 +1439,13 @@ def run_rank(args, rank, world, local_rank, control, shared):
         result = {
             "metric": "paired reads/sec through segment_juncs+long_spanning_reads; junctions.bed diff=0",
             "value": args.pairs * world * args.steps / elapsed,
-            "value_is": "resident-data kernel rate: both stages on batches already in HBM (the bench contract's timed region); the wall-clock rate "
-                        "of the executables, files in -> files out, is metric_e2e",
+            "value_is": "resident-data kernel rate (both stages, batches in HBM); files in -> files out is metric_e2e",
             "unit": "read-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if args.config == 3 and not args.pairs_given else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload_text,
+            "config": {"workload": workload_short, "workload_detail": workload_text,
                        "pairs_per_gpu": args.pairs, "segment_length": 25, "genes": int(genes.shape[0]),
                        "fusion_search": bool(args.fusion_search), "fusion_frac": args.fusion_frac, "indel_frac": args.indel_frac, "multihit_frac": args.multihit_frac, "max_copies": args.max_copies if args.multihit_frac > 0 else 1, "fusions_found": n_fusions[0], "reads_to_tiers_1_2or_fusion_3": [int(n_lean), int(n_multi), int(n_gen)],
                        "parallelism": "reads sharded x%d, genome replicated" % world},
