@@ -342,7 +342,7 @@ def pmc_traffic_in_run(args):
         d = tempfile.mkdtemp(prefix="thj_pmc_", dir="/tmp")
         try:
             cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "res", "--", sys.executable, os.path.abspath(__file__)] + fwd + \
-                  ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--e2e-pairs", "0", "--no-pmc"]
+                  ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--e2e-pairs", "0", "--no-pmc", "--detail", os.path.join(d, "detail.json")]
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp", THJ_BENCH_PMC_CHILD="1"), capture_output=True, text=True, timeout=420)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
@@ -515,7 +515,8 @@ def write_detail(result, path):
     repo has a gpurun_out/ directory, a copy there (what travels back from a GPU box)."""
     txt = json.dumps(result, indent=1)
     written = []
-    for p in [path] + ([os.path.join(ROOT, "gpurun_out", os.path.basename(path))] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else []):
+    copy_too = os.path.isdir(os.path.join(ROOT, "gpurun_out")) and os.path.dirname(os.path.abspath(path)) == ROOT
+    for p in [path] + ([os.path.join(ROOT, "gpurun_out", os.path.basename(path))] if copy_too else []):
         try:
             with open(p, "w") as f:
                 f.write(txt + "\n")

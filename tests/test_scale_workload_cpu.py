@@ -1,6 +1,7 @@
 """CPU: the torch scale generator (bench.py's workload) is self-consistent: the kernel logic and the oracle
 agree on it for both stages, planted junctions are recovered, spliced reads are stitched."""
 import numpy as np
+import torch
 
 import orc
 import sim
@@ -137,6 +138,23 @@ def test_scale_workload_with_a_repeat_family():
     per_read = cells.max(dim=1).values
     assert int((per_read == 2).sum()) > 0.15 * n and int(((per_read >= 3) & (per_read <= 8)).sum()) > 0.01 * n
     assert int((per_read >= 9).sum()) > 5 and int(per_read.max()) == 41
+    # the mates' hit groups as the e2e leg's files have them (tools/thj_gen.cpp writes a family read's whole-read map and last
+    # segment at every one of its copies): a read's mate group has as many hits as the MATE's segments have copies, each
+    # the first one shifted by a multiple of the copy distance -- the rescue's double loop runs over k x k pairs (segment_juncs.cpp:3406-3412)
+    for sd, osd in (("left", "right"), ("right", "left")):
+        mo = w[sd]["mate_off"].to(torch.int64)
+        mcnt = mo[1:] - mo[:-1]
+        ocells = (w[osd]["seg_off"][1:] - w[osd]["seg_off"][:-1]).reshape(n, 4)
+        ocopies = ocells.max(dim=1).values.to(torch.int64)
+        has = mcnt > 0
+        assert bool((mcnt[has] == ocopies[has]).all()) and int(mcnt.max()) == 41 and int((mcnt == 2).sum()) > 0.1 * n
+        mh = w[sd]["mate_hits"]
+        first = mo[:-1][has]
+        for r in torch.nonzero(mcnt > 1).reshape(-1)[:200].tolist():
+            rows = mh[int(mo[r]):int(mo[r + 1])]
+            assert bool((rows[:, 0] == rows[0, 0]).all()) and bool((rows[:, 3] == rows[0, 3]).all())
+            assert (rows[:, 1] - rows[0, 1]).tolist() == [k * S for k in range(rows.shape[0])]
+            assert bool(((rows[:, 2] - rows[:, 1]) == (rows[0, 2] - rows[0, 1])).all())
     ev = None
     pk = dict(inner_dist_mean=50, inner_dist_std_dev=20, max_segment_intron=20000, max_report_intron=20000)
     for sd, side in (("left", 1), ("right", 2)):

@@ -11,13 +11,13 @@ export TMPDIR=/tmp
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
-timeout 1200 python bench.py $extra > $out/${tag}_bench10M.json 2> $out/${tag}_bench10M.err
+timeout 1500 python bench.py $extra --detail $out/${tag}_bench_detail.json > $out/${tag}_bench10M.json 2> $out/${tag}_bench10M.err
 rm -rf /tmp/prof_ks /tmp/prof_f /tmp/prof_w
-(cd /tmp && THJ_BENCH_NO_REPLAY=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o res -- python $root/bench.py $extra --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /tmp/prof_ks.log 2>&1)
+(cd /tmp && THJ_BENCH_NO_REPLAY=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_ks -o res -- python $root/bench.py $extra --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc --detail /tmp/bench_detail_prof.json > /tmp/prof_ks.log 2>&1)
 { echo "# rocprofv3 --kernel-trace --stats -- python bench.py $extra --steps 5 --warmup 1 --no-cpu-baseline --e2e-pairs 0   (MI355X, $tag)";
   echo "# durations in microseconds"; python tools/rocpd_summary.py $(find /tmp/prof_ks -name '*.db' | head -1); } > $out/${tag}_kernel_stats_bench10M.txt
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /tmp/prof_f.log 2>&1)
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc > /tmp/prof_w.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/prof_f -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc --detail /tmp/bench_detail_prof.json > /tmp/prof_f.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_w -o res -- python $root/bench.py $extra --steps 2 --warmup 1 --no-cpu-baseline --e2e-pairs 0 --no-pmc --detail /tmp/bench_detail_prof.json > /tmp/prof_w.log 2>&1)
 { echo "# rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline  (separate pass; KB per dispatch)";
   python tools/rocpd_summary.py $(find /tmp/prof_f -name '*.db' | head -1) thj_k;
   echo; echo "# rocprofv3 --pmc WRITE_SIZE --kernel-trace -- (same command, separate pass)";

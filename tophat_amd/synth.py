@@ -796,9 +796,7 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
             out_rows[:, col] += (copy * dup_shift).to(out_rows.dtype)
         return off, out_rows.contiguous()
 
-    for sd in sides:
-        b = bufs[sd]
-        other = bufs["right" if sd == "left" else "left"]
+    def side_multi(sd):
         multi = None
         if family:
             multi = ncopy.clone()                            # copies per pair (int32): both reads of a family pair are multihits
@@ -809,12 +807,36 @@ def make_device_workload(seed: int, seqs_ascii, genes, contig_blk, n_pairs: int,
                     multi[deletion_rows] = 1
         elif multi_frac > 0 and dup_shift > 0:
             multi = torch.rand(n_pairs, generator=g, device=device) < multi_frac
+        return multi
+
+    multis = {sd: side_multi(sd) for sd in sides}
+    for sd in sides:
+        b = bufs[sd]
+        osd = "right" if sd == "left" else "left"
+        other = bufs[osd]
+        multi = multis[sd]
         mapped = b["seg_mapped"].reshape(-1)
         seg_off, hits = csr(mapped, b["seg_hits"].reshape(-1, 4), multi, (1, 2))
+        # the mate's hit group (find_gaps, segment_juncs.cpp:3321-3348): its whole-read map when it has one, else its last segment's
+        # hits -- and a family read's mate maps at every one of ITS copies, as tools/thj_gen.cpp writes the map files (the rescue is a
+        # double loop over (left-segment hit, mate hit), :3406-3412).  With a single-sided workload the mate keeps one hit.
         m_has = other["full_ok"] | other["seg_mapped"][:, nseg - 1]
+        m_rows = torch.where(other["full_ok"][:, None], other["full_hit"], other["seg_hits"][:, nseg - 1, :])
+        m_multi = multis.get(osd)
+        if m_multi is not None and m_multi.dtype != torch.int32:
+            m_multi = 1 + m_multi.to(torch.int32)
+        m_cnt = m_has.to(torch.int32) * (m_multi if m_multi is not None else 1)
         mate_off = torch.zeros(n_pairs + 1, dtype=torch.int32, device=device)
-        mate_off[1:] = torch.cumsum(m_has.to(torch.int32), 0)
-        mh = take(torch.where(other["full_ok"][:, None], other["full_hit"], other["seg_hits"][:, nseg - 1, :]), m_has)
+        mate_off[1:] = torch.cumsum(m_cnt, 0)
+        if m_multi is None:
+            mh = take(m_rows, m_has)
+        else:
+            cell = torch.arange(n_pairs, device=device).repeat_interleave(m_cnt.to(torch.int64))
+            copy = torch.arange(cell.shape[0], device=device, dtype=torch.int64) - mate_off[:-1].to(torch.int64)[cell]
+            mh = m_rows[cell].clone()
+            for col in (1, 2):
+                mh[:, col] += (copy * dup_shift).to(mh.dtype)
+            mh = mh.contiguous()
         smapped = b["span_mapped"].reshape(-1)
         span_off, span_hits = csr(smapped, b["span_hits"].reshape(-1, 8), multi, (1,))
         quals = torch.full((n_pairs * read_len,), ord("I"), dtype=torch.uint8, device=device)
