@@ -5,6 +5,7 @@
 #include "../../include/thj.h"
 #include "../../tophat_amd/csrc/thj_core.h"
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -111,7 +112,9 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
     const bool no_skip = getenv("THJ_HOSTSIM_NO_SKIP") != nullptr;  // run the general enumeration on every read
     const bool no_flat = getenv("THJ_HOSTSIM_NO_FLAT") != nullptr;  // ... also on the reads with at most one hit per segment (the kernels give those to flat_read / flat_rescue)
     std::vector<int32_t> slots, mscan;
+    std::vector<PHit> plist;
     const bool mscan_mode = getenv("THJ_HOSTSIM_MSCAN") != nullptr; // the rescue pairs from one scan per mate hit (ReadView::mscan)
+    const bool plist_mode = getenv("THJ_HOSTSIM_PLIST") != nullptr; // ... and the pseudo-hit list built once, a left hit at a time (rescue_pseudo_hits: thj_k_segjuncs_rescue_shared since round 6)
     for (int32_t r = 0; r < b->n_reads; ++r) {
         ReadView v;
         v.hits = (const Hit*)b->hits;
@@ -148,6 +151,31 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
                     for (int m = 0; m < v.n_mate; ++m)
                         if (!rescue_scan(g, p, v.rp, v.W, v.rl, v.mate[m], mscan[2 * m], mscan[2 * m + 1]) && mscan[2 * m] != SLOT_BREAK) mscan[2 * m] = SLOT_UNSCANNED;
                     v.slots = nullptr; v.mscan = mscan.data();
+                }
+                if (plist_mode) {
+                    mscan.assign((size_t)2 * v.n_mate, SLOT_NONE);
+                    for (int m = 0; m < v.n_mate; ++m)
+                        if (!rescue_scan(g, p, v.rp, v.W, v.rl, v.mate[m], mscan[2 * m], mscan[2 * m + 1]) && mscan[2 * m] != SLOT_BREAK) mscan[2 * m] = SLOT_UNSCANNED;
+                    plist.clear();
+                    int64_t scanned_pl = 0;
+                    for (int l = 0; l < n_left; ++l) {           // the kernel: a lane per left hit, count, prefix sum, write
+                        int sc = 0, dummy = 0;
+                        const Hit lh = v.hits[v.so[0] + l];
+                        const int mine = rescue_pseudo_hits(lh, v.mate, v.n_mate, mscan.data(), nullptr, sc);
+                        const size_t at = plist.size();
+                        plist.resize(at + (size_t)mine);
+                        if (mine) rescue_pseudo_hits(lh, v.mate, v.n_mate, mscan.data(), plist.data() + at, dummy);
+                        scanned_pl += sc;
+                    }
+                    int64_t nr_ref = 0;                          // the statistic must be the pair loop's
+                    for (int l = 0; l < n_left; ++l)
+                        for (int m = 0; m < v.n_mate; ++m) {
+                            int32_t a, bb;
+                            if (rescue_pair(g, p, v.rp, v.W, v.rl, v.hits[v.so[0] + l], v.mate[m], a, bb)) ++nr_ref;
+                            if (a == SLOT_BREAK) break;
+                        }
+                    if (nr_ref != scanned_pl) { fprintf(stderr, "hostsim: rescue-pair statistic of the list differs (%lld vs %lld)\n", (long long)scanned_pl, (long long)nr_ref); return 7; }
+                    v.slots = nullptr; v.mscan = nullptr; v.plist = plist.data(); v.n_plist = (int)plist.size();
                 }
                 v.lazy_g = &g; v.lazy_p = &p;
                 v.rescue = true;

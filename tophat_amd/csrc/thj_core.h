@@ -474,6 +474,8 @@ struct ReadView {
                               // contig / strand test of its two hits plus a look-up
     const Genome* lazy_g;     // genome / params for the on-the-fly rescue (only read when slots == null)
     const Params* lazy_p;
+    const struct PHit* plist = nullptr;   // the rescue's pseudo-hit list itself, in the reference's order (rescue_pseudo_hits), n_plist entries:
+    int n_plist = -1;                     // what the mate loops of :3406-3492 push into the last segment; -1: not built (slots / mscan / lazy)
     // derived by prepare()
     int size;                 // hits_for_read.size() after the trailing-empty trim
     bool rescue;              // segments 1.. replaced by the pseudo-hit list in `size-1`
@@ -481,6 +483,30 @@ struct ReadView {
 };
 
 THJ_HD int rv_count_raw(const ReadView& v, int s) { return (int)(v.so[s + 1] - v.so[s]); }
+
+// One pseudo-hit of the mate-anchored rescue: where the read's last bases (anti = 0) or their reverse complement (anti = 1) were
+// found in a mate hit's flank.  8 bytes, so that a wave can keep a read's whole list in LDS.
+struct PHit { int32_t left; uint32_t ref_anti; };          // ref_id << 1 | anti
+// The pseudo-hits ONE left hit contributes, in the order the reference pushes them (segment_juncs.cpp:3409-3492): its mate loop over
+// the mate hits on its contig and the opposite strand, ended by the first of them whose flank would start before the contig (`break`,
+// :3431-3450); per mate hit the forward find, then the reverse one.  The scan of a mate hit's flank does not look at the left hit
+// (rescue_scan), so `mscan` holds it once per mate hit.  Returns the count (and writes them when out != nullptr); `scanned` counts the
+// pairs the reference maps (the rescue-pair statistic).  A read with k left hits and k mate hits has k x k pairs and up to 2 k x k
+// pseudo-hits: a lane per left hit builds the list in k steps where a walk of the pairs by every caller of rv_foreach was k x k
+// dependent loads -- per look at the list (round 6; a 40-copy read held its wave for a millisecond).
+THJ_HD int rescue_pseudo_hits(const Hit& lh, const Hit* mate, int n_mate, const int32_t* mscan, PHit* out, int& scanned) {
+    int n = 0;
+    for (int m = 0; m < n_mate; ++m) {
+        const Hit rh = mate[m];
+        if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) continue;      // :3414
+        const int32_t a = mscan[2 * m], b = mscan[2 * m + 1];
+        if (a == SLOT_BREAK) break;
+        if (a != -3) ++scanned;                                                     // -3: SLOT_UNSCANNED
+        if (a >= 0) { if (out) { out[n].left = a; out[n].ref_anti = rh.ref_id << 1; } ++n; }
+        if (b >= 0) { if (out) { out[n].left = b; out[n].ref_anti = (rh.ref_id << 1) | 1u; } ++n; }
+    }
+    return n;
+}
 
 // Iterate the effective hit list of segment s; f(const Hit&) returns false to stop.
 template <class F>
@@ -493,6 +519,15 @@ THJ_HD void rv_foreach(const ReadView& v, int s, F f) {
         return;
     }
     if (s != v.size - 1) return;            // cleared (:3398-3401)
+    if (v.n_plist >= 0) {                   // the list as built (rescue_pseudo_hits)
+        for (int k = 0; k < v.n_plist; ++k) {
+            const PHit ph = v.plist[k];
+            Hit h; h.ref_id = ph.ref_anti >> 1; h.left = ph.left; h.right = ph.left + v.check_len;
+            h.meta = 2u | (ph.ref_anti & 1u) | ((uint32_t)v.check_len << 24);
+            if (!f(h)) return;
+        }
+        return;
+    }
     int n_left = rv_count_raw(v, 0);
     for (int l = 0; l < n_left; ++l)
         for (int m = 0; m < v.n_mate; ++m) {
@@ -531,6 +566,7 @@ THJ_HD void rv_foreach_strided(const ReadView& v, int s, int first, int stride, 
 }
 
 THJ_HD int rv_count(const ReadView& v, int s) {
+    if (v.rescue && s != 0 && v.n_plist >= 0) return s == v.size - 1 ? v.n_plist : 0;
     int n = 0;
     rv_foreach(v, s, [&](const Hit&) { ++n; return true; });
     return n;

@@ -779,9 +779,14 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue(Genome g, Params
     }
 }
 
-// The rescue reads with many pairs (listed by thj_k_segjuncs_rescue, their pairs' outcomes in the pool): one wave per read,
-// lane = hit, then the same queue and execution as everywhere.
-__global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g, Params p, DevBatch b, RescueList rl, XTasks x, unsigned long long* cnt) {
+// The rescue reads with many pairs (listed by thj_k_segjuncs_rescue): one wave per read.  Round 6: the read's hits, its mate hits,
+// the scan of every mate hit's flank and the pseudo-hit list itself live in the wave's piece of LDS -- a lane per mate hit scans, a
+// lane per left hit walks the mate hits once and writes the pseudo-hits it contributes at its prefix-sum position (the reference's
+// order, rescue_pseudo_hits), then lane = left hit enumerates against that list.  Before, every look at the list (the bowtie2
+// count, the three walks of gaps_enumerate per left hit) re-derived it pair by pair from hit records in HBM: k x k dependent loads
+// a look, k^3 for a read of k copies whose mate has k hits -- 1.0 ms per launch on the e2e files, whatever the number of reads.
+static constexpr int PLIST_CAP = 128;      // pseudo-hits of a read kept in LDS (bowtie2 runs drop a read with more than max_seg_multihits = 40 of them)
+__global__ __launch_bounds__(TPB, 3) void thj_k_segjuncs_rescue_shared(Genome g, Params p, DevBatch b, RescueList rl, XTasks x, unsigned long long* cnt) {
     __shared__ uint32_t q_a[QCAP], q_b[QCAP], q_c[QCAP], q_d[QCAP], q_e[QCAP];
     __shared__ unsigned int q_n;
     __shared__ unsigned int s_stat[4];
@@ -797,7 +802,12 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
     const unsigned int BATCH = n / gridDim.x >= 32u ? 32u : n / gridDim.x >= 4u ? n / gridDim.x : 4u;
     __shared__ unsigned int s_next, s_xbase;
     __shared__ int32_t s_mscan[TPB / 64][2 * MSCAN];
+    __shared__ Hit s_h[TPB / 64][MANY_HITS_LDS];
+    __shared__ uint32_t s_o[TPB / 64][20];
+    __shared__ Hit s_mate[TPB / 64][MSCAN];
+    __shared__ PHit s_pl[TPB / 64][PLIST_CAP];
     const int wave = tid >> 6;
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
     unsigned int my_windows = 0, my_indels = 0, my_pairs = 0;
     for (unsigned int base = blockIdx.x * BATCH; base < n; base += gridDim.x * BATCH) {
         __syncthreads();
@@ -812,40 +822,61 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_rescue_shared(Genome g,
             const int r = (int)rl.heavy_list[h];
             ReadView v = make_view(b, r);
             gaps_prepare_listed(p, v);                             // a listed read takes the rescue: no second partner search
+            uint32_t hbase = 0;
+            const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with its tables
+            if (nh <= (uint32_t)MANY_HITS_LDS && v.nseg < 20) {   // the read's hits and their offsets
+                for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
+                if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
+                v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
+            }
             // where the read's last bases lie in each mate hit's flank: one scan per mate hit, a lane each -- the scan does not look at
             // the left hit, so the n_left x n_mate pairs of the reference's loop (:3406-3492) are n_mate scans and a contig / strand test
             // per pair (until round 4 a read with more than 64 pairs scanned again for every pair its enumeration looked at: 0.3 s per
             // launch of thj_k_segjuncs_rescue on files with a 41-copy family whose mates carry 82 hits)
             int32_t* ms = s_mscan[wave];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with the table
-            for (int m = lane; m < v.n_mate; m += 64) {
+            for (int m = lane; m < v.n_mate; m += 64) {           // (n_mate <= MSCAN: thj_k_segjuncs_rescue lists no other read)
+                const uint4 q = ((const uint4*)v.mate)[m];
+                Hit rh; rh.ref_id = q.x; rh.left = (int32_t)q.y; rh.right = (int32_t)q.z; rh.meta = q.w;
+                s_mate[wave][m] = rh;
                 int32_t f, rv;
-                const bool scanned = rescue_scan(g, p, v.rp, v.W, v.rl, v.mate[m], f, rv);
+                const bool scanned = rescue_scan(g, p, v.rp, v.W, v.rl, rh, f, rv);
                 if (!scanned && f != SLOT_BREAK) f = SLOT_UNSCANNED;
                 ms[2 * m] = f; ms[2 * m + 1] = rv;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            {   // the rescue-pair statistic: the pairs the reference's loop scans (a break ends a left hit's mate loop)
-                const int n_left = rv_count_raw(v, 0);
-                for (int l = lane; l < n_left; l += 64) {
-                    const Hit lh = v.hits[v.so[0] + l];
-                    for (int m = 0; m < v.n_mate; ++m) {
-                        const Hit rh = v.mate[m];
-                        if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) continue;
-                        const int32_t f = ms[2 * m];
-                        if (f == SLOT_BREAK) break;
-                        if (f != SLOT_UNSCANNED) ++my_pairs;
-                    }
-                }
+            v.mate = s_mate[wave];
+            // the pseudo-hit list: lane = left hit, rounds of 64 left hits; a lane's hits land behind those of the left hits before it
+            const int n_left = rv_count_raw(v, 0);
+            int n_pl = 0;
+            bool listed = true;
+            for (int l0 = 0; l0 < n_left; l0 += 64) {
+                const int l = l0 + lane;
+                int mine = 0, sc = 0;
+                Hit lh{0, 0, 0, 0};
+                if (l < n_left) { lh = v.hits[v.so[0] + l]; mine = rescue_pseudo_hits(lh, v.mate, v.n_mate, ms, nullptr, sc); }
+                my_pairs += (unsigned int)sc;
+                int incl = mine;                                   // inclusive prefix sum over the wave
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                const int total = __shfl(incl, 63);
+                const int at = n_pl + incl - mine;
+                if (n_pl + total <= PLIST_CAP) { if (mine) { int dummy = 0; rescue_pseudo_hits(lh, v.mate, v.n_mate, ms, s_pl[wave] + at, dummy); } }
+                else listed = false;
+                n_pl += total;
             }
-            v.rescue = true; v.slots = nullptr; v.mscan = ms; v.lazy_g = &s_g; v.lazy_p = &s_p;
-            QueueSink qs{qq, x, (uint32_t)r, 0u, 0u, 0u};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            v.rescue = true; v.slots = nullptr; v.lazy_g = &s_g; v.lazy_p = &s_p;
+            QueueSink qs{qq, x, (uint32_t)r, hbase, 0u, 0u};
             indels_enumerate(p, v, qs, lane, 64);
-            gaps_enumerate(p, v, qs, lane, 64);
+            if (listed) { v.plist = s_pl[wave]; v.n_plist = n_pl; v.mscan = nullptr; gaps_enumerate(p, v, qs, lane, 64); }
+            else if (p.bowtie2 && n_pl > p.max_seg_multihits) { }  // find_gaps returns at its multihit test (:3499-3506) whatever else the read holds
+            else { v.mscan = ms; gaps_enumerate(p, v, qs, lane, 64); }      // a list beyond the LDS piece (bowtie1, or a raised --max-seg-multihits): the pairs walked as before
             my_windows += qs.n_windows; my_indels += qs.n_indels;
         }
         flush_tasks(qq, x, &s_xbase, &s_stat[3]);
     }
+    (void)below;
     if (my_windows) atomicAdd(&s_stat[0], my_windows);
     if (my_indels) atomicAdd(&s_stat[1], my_indels);
     if (my_pairs) atomicAdd(&s_stat[2], my_pairs);
