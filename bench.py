@@ -1139,6 +1139,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
         span_ms_alone, _ = ctx.profile_span(False)
         ctx.profile_serial(False)
         torch.cuda.synchronize()
+    stream_info = ctx.stream_info()              # what the queue probe measured for the side streams the steps ran on (thj_ctx_stream_info)
     comm_info = comm.info() if comm is not None else None
     if comm_info is not None and xchg_events:
         comm_info["us_per_step"] = 1e3 * sum(a.elapsed_time(b) for a, b in xchg_events) / len(xchg_events)      # pack + ncclAllGather + merge kernels, on the context stream
@@ -1463,7 +1464,10 @@ def run_rank(args, rank, world, local_rank, control, shared):
                          "algorithmic_bytes_per_launch": dom["algorithmic_bytes_8d_per_launch"],
                          "achieved_layout_bytes": dom["achieved_layout"], "frac_layout_bytes": dom["frac_layout"],
                          "layout_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
-                         "measured_copy_GBs": hbm_copy, "frac_of_measured_copy": dom["achieved"] / hbm_copy if hbm_copy else None},
+                         "measured_copy_GBs": hbm_copy, "frac_of_measured_copy": dom["achieved"] / hbm_copy if hbm_copy else None,
+                         # the two sides of a step ran on side streams measured to have hardware queues of their own (false: same results, the
+                         # sides partly one after the other -- the line is then not the build's best)
+                         "streams_independent": bool(stream_info["n_side"] >= 2 and all(stream_info["independent"][:2])), "stream_overlap_ratio": stream_info["ratio"]},
             # all kernels of a step together: algorithmic bytes of every launch / time spent in them
             "roofline_all_kernels": {"achieved": sum(k["algorithmic_bytes_8d_per_launch"] * k["launches"] for k in kernels)
                                      / max(1e-9, sum(k["avg_kernel_ms"] * k["launches"] for k in kernels)) / 1e6,

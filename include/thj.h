@@ -111,6 +111,20 @@ int  thj_ctx_create(int device, void* stream, thj_ctx** out);
 #define THJ_WARM_INGEST   4   /* BGZF inflate, BAM parse */
 #define THJ_WARM_BAMOUT   8   /* BAM record encoding, DEFLATE */
 int  thj_ctx_warm(thj_ctx* ctx, int parts);
+/* The side streams in use and what the measurement found for each: independent[k] = 1 when side stream k was measured to run beside
+ * `stream` and the side streams before it; ratio[k] = (a 150 us spin kernel on each of them at once) / (one alone): 1.0 beside each
+ * other, 2.0 one hardware queue shared, 0 not made yet.  The measurement happens inside the first thj_segjuncs_run*_async /
+ * thj_span_run*_async / thj_span_tier0_pair_async call that needs a side stream (and again when a pair call needs the second):
+ * that call BLOCKS the host for the ~2 ms it takes (it synchronises `stream` and runs spin kernels on it), so `stream` must not be
+ * under graph capture then -- call thj_ctx_probe_streams first in such a setting.  A stream that shares a queue is still used
+ * (same results, the sides partly one after the other); a warning goes to stderr and independent[k] stays 0. */
+int  thj_ctx_stream_info(thj_ctx* ctx, int32_t* n_side, int32_t* independent /*[3]*/, double* ratio /*[3]*/);
+/* Makes and measures `need` (1 or 2) side streams now, blocking, instead of inside the first run call. */
+int  thj_ctx_probe_streams(thj_ctx* ctx, int32_t need);
+/* ABI revision of this header: bumped whenever an entry point's argument layout changes (2: thj_span_tier_counts writes 5 int64,
+ * thj_profile_span 8 doubles).  A caller built against another revision must not call in. */
+#define THJ_ABI_VERSION 2
+int  thj_abi_version(void);
 void thj_ctx_destroy(thj_ctx* ctx);
 int  thj_ctx_sync(thj_ctx* ctx);            /* hipStreamSynchronize on the context stream */
 void* thj_ctx_stream(thj_ctx* ctx);         /* the hipStream_t in use */

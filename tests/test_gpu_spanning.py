@@ -1,4 +1,6 @@
 """GPU parity: thj_k_stitch through the C ABI against the CPU oracle (exact records, exact order)."""
+import os
+
 import pytest
 
 import orc
@@ -11,6 +13,7 @@ from test_hostsim_spanning import SPAN_CASES, repeat_span_batch, span_inputs
 from tophat_amd.batch import JUNC_DTYPE
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("cfg", SPAN_CASES, ids=lambda c: "seed%d_rl%d_L%d" % (c["seed"], c["read_len"], c["seg_len"]))
@@ -245,6 +248,21 @@ def test_reads_with_more_joined_alignments_than_a_thread_keeps():
         assert ctx.lib.thj_span_finish(ctx._ctx, C.byref(n)) == -7 and b"run the pass again" in ctx.lib.thj_last_error()
         assert ctx.spanning(p, [h]) == want
         assert ctx.spanning(p, [h]) == want                 # and again, the workspace now in place from the start
+        # a pair call with the workspace in place: both batches list such reads, from index 0 and with batch-local read
+        # numbers, and their thj_k_stitch_huge launches run beside each other -- a list and a workspace per scratch set
+        seq_b, sb_b = repeat_span_batch(copies=120, n_reads=9, seed=11)
+        assert seq_b == seq
+        want_b = orc.spanning(p, orc.Genome([seq]), sb_b, nj, [])
+        from tophat_amd.host import alns_from_array
+        key = lambda a: (a.ref_id, a.left, a.antisense, a.antisense_splice, a.cigar, a.MD, a.AS, a.XM, a.mismatches, a.edit_dist)
+        hb = ctx.upload_span_batch(sb_b)
+        for first, second, wa, wb in ((h, hb, want, want_b), (hb, h, want_b, want)):
+            ctx.span_reset()
+            ctx.span_run_pair(p, first, second)
+            n2 = ctx.span_finish()
+            got = alns_from_array(ctx.span_download(n2), None)
+            assert n2 == len(wa) + len(wb)
+            assert [key(a) for a in got[:len(wa)]] == [key(a) for a in wa] and [key(a) for a in got[len(wa):]] == [key(a) for a in wb]
         # fusion search: 30 joined alignments per read are already more than the fusion tier keeps per thread
         seq2, sb2 = repeat_span_batch(copies=30, n_reads=10, seed=12)
         ctx.upload_genome(host.pack_genome([seq2]))
@@ -287,3 +305,54 @@ def test_more_records_per_read_than_the_count_byte_holds():
         ctx.upload_genome(host.pack_genome([seq]))
         ctx.upload_span_sets(nj, [])
         assert ctx.spanning(p, [ctx.upload_span_batch(sb)]) == want
+
+
+def test_side_streams_are_measured_and_reported():
+    """thj_ctx_stream_info: the side streams a pair call runs on are chosen by a measurement, and what it found is
+    kept -- with the probe on, both are independent of the context's stream and of each other; forced onto one hardware queue the
+    flags go false, a warning is printed per stream, the records stay the same."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, json
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+import orc
+from tophat_amd import host
+from tophat_amd.host import alns_from_array
+from test_hostsim_spanning import SPAN_CASES, span_inputs
+shift = int(sys.argv[1])
+dummies = [torch.cuda.Stream() for _ in range(shift)]
+ca = SPAN_CASES[0]
+case_a, p, seqs, g, sb_a, juncs, ins = span_inputs(ca, n_reads=700)
+case_b, p_b, seqs_b, g_b, sb_b, juncs_b, ins_b = span_inputs(ca, n_reads=400)
+want = orc.spanning(p, g, sb_a, juncs, ins) + orc.spanning(p, g, sb_b, juncs, ins)
+key = lambda a: (a.ref_id, a.left, a.antisense, a.antisense_splice, a.cigar, a.MD, a.AS, a.XM, a.mismatches, a.edit_dist)
+with host.Context(0) as ctx:
+    ctx.upload_genome(host.pack_genome(seqs))
+    ctx.upload_span_sets(juncs, ins)
+    ha, hb = ctx.upload_span_batch(sb_a), ctx.upload_span_batch(sb_b)
+    assert ctx.stream_info()["n_side"] == 0
+    ctx.span_reset()
+    ctx.span_run_pair(p, ha, hb)
+    n = ctx.span_finish()
+    got = alns_from_array(ctx.span_download(n), None)
+    info = ctx.stream_info()
+assert [key(a) for a in got] == [key(a) for a in want]
+print("INFO " + json.dumps(info))
+''' % (ROOT, os.path.join(ROOT, "tests"))
+
+    def run(shift, env_extra):
+        r = subprocess.run([sys.executable, "-c", code, str(shift)], capture_output=True, text=True, env=dict(os.environ, **env_extra), timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        import json
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("INFO ")][-1][5:]), r.stderr
+    info, err = run(1, {})
+    assert info["n_side"] == 2 and info["independent"] == [True, True] and all(0.5 < x < 1.5 for x in info["ratio"]), info
+    assert "shares a hardware queue" not in err
+    # one hardware queue for the whole process (GPU_MAX_HW_QUEUES=1): no stream can be independent of the context's -- the probe sets four
+    # aside, takes the next as it is and says so; with THJ_NO_QUEUE_PROBE=1 the first stream is taken and still measured
+    for extra in ({"GPU_MAX_HW_QUEUES": "1"}, {"GPU_MAX_HW_QUEUES": "1", "THJ_NO_QUEUE_PROBE": "1"}):
+        info, err = run(0, extra)
+        assert info["n_side"] == 2 and info["independent"] == [False, False] and min(info["ratio"]) >= 1.5, info
+        assert err.count("shares a hardware queue") == 2

@@ -44,11 +44,14 @@
 
 namespace thjh {
 
+// a file under construction that must not outlive a failed process (the packed-genome cache's `.tmp.<pid>`): die() removes it
+inline char* pending_tmp_path() { static char path[4096] = {0}; return path; }
 [[noreturn]] inline void die(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vfprintf(stderr, fmt, ap);
     va_end(ap);
+    if (pending_tmp_path()[0]) unlink(pending_tmp_path());
     exit(1);
 }
 
@@ -539,11 +542,24 @@ struct RefTable {
         if (!ok) return false;
         const char* base = (const char*)m;
         const char* nm = base + sizeof h;
-        const int64_t* lens = (const int64_t*)(nm + ((h.names_bytes + 7) & ~7ull));
+        // the header's own layout must hold what it says it holds (a torn or foreign file must not send the name scan past the mapping)
+        const uint64_t names_pad = (h.names_bytes + 7) & ~7ull;
+        if (h.names_bytes > (1ull << 32) || h.header_bytes > (uint64_t)st.st_size ||
+            h.header_bytes < sizeof h + names_pad + 8 * h.n_names + 4 * (h.n_names + 1)) { munmap(m, (size_t)st.st_size); return false; }
+        const int64_t* lens = (const int64_t*)(nm + names_pad);
         const uint32_t* blk = (const uint32_t*)(lens + h.n_names);
         // the cached table: the names this process knows so far (--sam-header's @SQ lines, in order) must lead it
         std::vector<std::string> cn;
-        { const char* q = nm; for (uint64_t i = 0; i < h.n_names; ++i) { cn.emplace_back(q); q += cn.back().size() + 1; } }
+        {
+            const char* q = nm; const char* const qe = nm + h.names_bytes;
+            bool names_ok = true;
+            for (uint64_t i = 0; i < h.n_names && names_ok; ++i) {
+                const char* z = (const char*)memchr(q, 0, (size_t)(qe - q));
+                if (!z) { names_ok = false; break; }
+                cn.emplace_back(q, (size_t)(z - q)); q = z + 1;
+            }
+            if (!names_ok || blk[h.n_names] > h.n_blocks) { munmap(m, (size_t)st.st_size); return false; }
+        }
         {
             std::lock_guard<std::mutex> lk(mu);
             ok = names.size() <= cn.size();
@@ -576,6 +592,7 @@ struct RefTable {
         const std::string tmp = cache_file + ".tmp." + std::to_string((long)getpid());
         const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) return;                          // (a directory we may not write to: no cache)
+        if (tmp.size() < 4096) strcpy(pending_tmp_path(), tmp.c_str());
         std::vector<char> head(hb, 0);
         memcpy(head.data(), &h, sizeof h);
         memcpy(head.data() + sizeof h, nm.data(), nm.size());
@@ -585,6 +602,7 @@ struct RefTable {
         const bool ok = put(head.data(), hb) && put((const char*)packed_own.get(), (size_t)packed_nb * 32);
         close(fd);
         if (!ok || rename(tmp.c_str(), cache_file.c_str())) unlink(tmp.c_str());
+        pending_tmp_path()[0] = 0;
     }
     void finish_cache() { if (cache_writer.valid()) cache_writer.get(); }      // before the process leaves
     ~RefTable() { finish_cache(); if (mapped) munmap(mapped, mapped_bytes); }
@@ -592,9 +610,9 @@ struct RefTable {
     // reference came from the cache
     const std::string& text(uint32_t ref_id) {
         std::string& s = seqs[ref_id - 1];
-        if (!from_cache || !s.empty() || ref_id > packed_lens.size() || packed_lens[ref_id - 1] == 0) return s;
-        std::lock_guard<std::mutex> lk(mu);
-        if (!s.empty()) return s;
+        if (!from_cache || ref_id > packed_lens.size() || packed_lens[ref_id - 1] == 0) return s;
+        { std::lock_guard<std::mutex> lk(text_mu); if (!s.empty()) return s; }      // (checked under the lock: another thread may be putting the text in place)
+        // decoded outside the lock (a chromosome is a quarter of a second); the first thread done puts its copy in place
         const int64_t n = packed_lens[ref_id - 1];
         std::string t((size_t)n, 'N');
         const uint64_t* b = packed_ptr + (size_t)packed_blk[ref_id - 1] * 4;
@@ -602,9 +620,11 @@ struct RefTable {
             const uint64_t* w = b + (size_t)(i >> 6) * 4; const int k = (int)(i & 63);
             if (!((w[2] >> k) & 1ull)) t[(size_t)i] = "ACGT"[((w[0] >> k) & 1ull) | (((w[1] >> k) & 1ull) << 1)];
         }
-        s.swap(t);
+        std::lock_guard<std::mutex> lk(text_mu);
+        if (s.empty()) s.swap(t);
         return s;
     }
+    std::mutex text_mu;
     void pack() {
         std::call_once(packed_once, [this] {
             {

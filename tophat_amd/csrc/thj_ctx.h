@@ -38,6 +38,10 @@ struct thj_ctx {
     // queue run one after the other, and a process has other streams too -- with ten streams the second side's chain of stage 1 sat
     // behind the first side's (profiles/r05_e_timeline.txt)
     hipStream_t aux_stream[3] = {}; hipEvent_t aux_ev[10] = {};
+    // what the probe measured when it took side stream k: a spin kernel on it beside one on the context's stream and on every side stream
+    // taken before, over a spin kernel alone (1.0 = fully beside each other, 2.0 = one queue shared); 0 = not measured.  aux_independent
+    // = measured and below 1.5 (thj_ctx_stream_info, thj_streams.hip)
+    double aux_ratio[3] = {0, 0, 0}; bool aux_independent[3] = {false, false, false};
     // genome
     const u64* d_blocks = nullptr; bool own_blocks = false;
     uint32_t* d_contig_blk = nullptr; int32_t* d_contig_len = nullptr;

@@ -23,7 +23,8 @@ void thj_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* thj_last_error(void) { return g_err; }
-extern "C" const char* thj_version(void) { return "thj-hip 0.1 (gfx950)"; }
+extern "C" const char* thj_version(void) { return "thj-hip 0.2 (gfx950)"; }
+extern "C" int thj_abi_version(void) { return THJ_ABI_VERSION; }
 
 extern "C" void thj_params_default(thj_params* p) {
     // common.cpp:79-180

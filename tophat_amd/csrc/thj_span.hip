@@ -786,6 +786,7 @@ __global__ __launch_bounds__(64) void thj_k_stitch_fusion(Genome g, Params p, Sp
 // of the context's big workspace (2 * cap records: the list and the merge sort's scratch).  Rare by construction.
 static constexpr int HUGE_BLOCKS = 64, HUGE_CAP = 8192, HUGE_LIST_CAP = 1 << 16;
 static constexpr int HUGE_REC_BYTES = 128;               // >= sizeof(Aln), sizeof(FHit)
+static constexpr size_t HUGE_WS_BYTES = (size_t)HUGE_BLOCKS * 2 * HUGE_CAP * HUGE_REC_BYTES;      // one scratch set's workspace
 static_assert(sizeof(Aln) <= HUGE_REC_BYTES && sizeof(FHit) <= HUGE_REC_BYTES, "workspace record size");
 __global__ __launch_bounds__(64) void thj_k_stitch_huge(Genome g, Params p, SpanSets S, FusionSet F, DevSpanBatch b, RecSink sink, Tiers t, char* ws, int cap) {
     if (threadIdx.x != 0) return;
@@ -1012,6 +1013,12 @@ extern "C" int thj_span_reset_async(thj_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     int rc = ensure_span_state(c);
     if (rc) return rc;
+    if (c->span_t0_pending && c->span_stream[0] && c->span_stream[1] && c->span_ev[3]) {
+        // a pair's tier 0 went out on the side streams (thj_span_tier0_pair_async) and nothing joined it: its kernels still add to the
+        // record count and write slots -- the memsets below wait for them
+        HIPCHK(hipEventRecord(c->span_ev[3], c->span_stream[0])); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[3], 0));
+        HIPCHK(hipEventRecord(c->span_ev[4], c->span_stream[1])); HIPCHK(hipStreamWaitEvent(c->stream, c->span_ev[4], 0));
+    }
     HIPCHK(hipMemsetAsync(c->d_aln_count, 0, 16, c->stream));       // [0] total records, [1] overflow-pool records
     HIPCHK(hipMemsetAsync(c->d_span_status, 0, 32, c->stream));     // [0..3] statuses, [5] thj_k_join's "cannot happen"
     c->n_alns = 0;
@@ -1237,7 +1244,8 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     unsigned int* const blk_pack = t.blk_chain + NC * MAX_SLICES;
     t.counters = &c->d_span_status[16 + SPAN_CNT_WORDS * set];
     t.chunk = (int)chunk;
-    t.huge_list = c->d_huge_list; t.huge_cnt = t.counters + 4; t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
+    t.huge_list = c->d_huge_list ? c->d_huge_list + (size_t)set * HUGE_LIST_CAP : nullptr; t.huge_cnt = t.counters + 4;      // a list and a workspace per scratch set: the two batches of a pair call run beside each other
+    t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
     t.ent = chains ? (ChainEntry*)ss.d_ent : nullptr;
     t.ja = (Q16*)ss.d_joined; t.jb = t.ja ? t.ja + ss.joined_cap : nullptr; t.jc = t.ja ? t.ja + 2 * ss.joined_cap : nullptr;
     t.status = c->d_span_status;
@@ -1377,7 +1385,7 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     if (c->d_huge_ws && sg != sm) { HIPCHK(hipEventRecord(ev_fork, sg)); HIPCHK(hipStreamWaitEvent(sm, ev_fork, 0)); }      // (the fork's wait is long enqueued: the event is free)
     if (c->d_huge_ws) {        // a pass that met a read with too many joined alignments runs with the workspace from then on
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
-        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws, HUGE_CAP);
+        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws + (size_t)set * HUGE_WS_BYTES, HUGE_CAP);
     }
     HIPCHK(hipGetLastError());
     return THJ_OK;
@@ -1525,8 +1533,8 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
         if (!c->d_huge_ws) {
             // a read has more joined alignments than a thread's own array holds: get the big workspace (HUGE_BLOCKS slices of
             // 2 * HUGE_CAP records) and ask for the pass again -- thj_k_stitch_huge then takes such reads one by one
-            HIPCHK(hipMalloc(&c->d_huge_ws, (size_t)HUGE_BLOCKS * 2 * HUGE_CAP * HUGE_REC_BYTES));
-            HIPCHK(hipMalloc(&c->d_huge_list, (size_t)HUGE_LIST_CAP * 4));
+            HIPCHK(hipMalloc(&c->d_huge_ws, 2 * HUGE_WS_BYTES));                  // (one per scratch set)
+            HIPCHK(hipMalloc(&c->d_huge_list, (size_t)2 * HUGE_LIST_CAP * 4));
             thj_set_error("%u read(s) have more joined alignments than the stitch kernels keep per thread (%d, %d with fusion search); a workspace "
                           "for them has been set up: run the pass again (thj_span_reset_async, the thj_span_run_async calls, thj_span_finish)",
                           st[SPAN_TOO_MANY_JOINED], SPAN_MAXJOIN, FUS_MAXJOIN);

@@ -53,24 +53,51 @@ int thj_ensure_aux_streams(thj_ctx* c, int need) {
     static const bool trace = getenv("THJ_TRACE") != nullptr;
     if (prio) (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     double alone = 0;
-    if (!no_probe) { const int rc = spin_group_us(c, nullptr, 0, &alone); if (rc) return rc; }
+    if (!no_probe) { const int rc0 = spin_group_us(c, nullptr, 0, &alone); if (rc0) return rc0; }
     hipStream_t aside[4]; int n_aside = 0;
     int rc = THJ_OK;
     while (have < need && rc == THJ_OK) {
         hipStream_t cand = nullptr;
         if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio ? hi : 0) != hipSuccess) { thj_set_error("hipStreamCreate failed"); rc = THJ_EHIP; break; }
-        bool take = no_probe || n_aside == 4;                 // (four set aside: every queue is shared with something -- the next one as it is)
+        // (four set aside: every queue is shared with something -- the next one as it is, flagged and warned about below)
+        const bool forced = no_probe || n_aside == 4;
         double us = 0;
-        if (!take) {
-            hipStream_t grp[3]; int n = 0;
-            for (int k = 0; k < have; ++k) grp[n++] = c->aux_stream[k];
-            grp[n++] = cand;
-            rc = spin_group_us(c, grp, n, &us);
-            take = rc == THJ_OK && us < 1.5 * alone;
+        hipStream_t grp[3]; int n = 0;
+        for (int k = 0; k < have; ++k) grp[n++] = c->aux_stream[k];
+        grp[n++] = cand;
+        if (no_probe && alone == 0) rc = spin_group_us(c, nullptr, 0, &alone);      // THJ_NO_QUEUE_PROBE: the stream is taken as it comes, but what it shares is still measured
+        if (rc == THJ_OK) rc = spin_group_us(c, grp, n, &us);
+        if (rc != THJ_OK) { (void)hipStreamDestroy(cand); break; }
+        const bool indep = us < 1.5 * alone;
+        if (indep || forced) {
+            c->aux_ratio[have] = alone > 0 ? us / alone : 0.0; c->aux_independent[have] = indep;
+            c->aux_stream[have++] = cand;
+            if (!indep) fprintf(stderr, "thj: warning: side stream %d shares a hardware queue with another stream of this context (a spin kernel beside the others %.0f us, alone %.0f): "
+                                        "the two sides of a pass will partly run one after the other (same results, slower)%s\n", have, us, alone, no_probe ? " [THJ_NO_QUEUE_PROBE]" : "");
+            if (trace) fprintf(stderr, "[streams] side stream %d: beside the others %.0f us (a spin kernel alone %.0f), %d set aside\n", have, us, alone, n_aside);
         }
-        if (take) { c->aux_stream[have++] = cand; if (trace) fprintf(stderr, "[streams] side stream %d: beside the others %.0f us (a spin kernel alone %.0f), %d set aside\n", have, us, alone, n_aside); }
         else aside[n_aside++] = cand;
     }
     for (int k = 0; k < n_aside; ++k) (void)hipStreamDestroy(aside[k]);
     return rc;
+}
+
+// What the probe found (the placement is asserted, not trusted): the side streams in use, and for each
+// whether it was measured to run beside the context's stream and the side streams before it.
+extern "C" int thj_ctx_stream_info(thj_ctx* c, int32_t* n_side, int32_t* independent /* [3] */, double* ratio /* [3] */) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    int have = 0;
+    while (have < 3 && c->aux_stream[have]) ++have;
+    if (n_side) *n_side = have;
+    for (int k = 0; k < 3; ++k) {
+        if (independent) independent[k] = k < have && c->aux_independent[k] ? 1 : 0;
+        if (ratio) ratio[k] = k < have ? c->aux_ratio[k] : 0.0;
+    }
+    return THJ_OK;
+}
+extern "C" int thj_ctx_probe_streams(thj_ctx* c, int32_t need) {
+    if (!c) { thj_set_error("null ctx"); return THJ_EINVAL; }
+    if (need < 1 || need > 2) { thj_set_error("thj_ctx_probe_streams: need must be 1 or 2"); return THJ_EINVAL; }
+    HIPCHK(hipSetDevice(c->device));
+    return thj_ensure_aux_streams(c, need);
 }

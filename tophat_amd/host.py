@@ -48,8 +48,9 @@ class CCounts(C.Structure):
                                          "n_rescue_pairs", "n_overflow_blocks", "n_hits_read")]
 
 
+ABI_VERSION = 2
 ABI_SYMBOLS = [
-    "thj_params_default", "thj_last_error", "thj_version",
+    "thj_params_default", "thj_last_error", "thj_version", "thj_abi_version", "thj_ctx_stream_info", "thj_ctx_probe_streams",
     "thj_device_count", "thj_ctx_create", "thj_ctx_destroy", "thj_ctx_sync", "thj_ctx_stream",
     "thj_genome_layout", "thj_genome_pack", "thj_genome_upload", "thj_genome_adopt",
     "thj_reads_pack",
@@ -79,6 +80,10 @@ def load_lib(path: Optional[str] = None):
     lib = C.CDLL(p)
     lib.thj_last_error.restype = C.c_char_p
     lib.thj_version.restype = C.c_char_p
+    # the argument layouts this module was written against (include/thj.h: THJ_ABI_VERSION)
+    if not hasattr(lib, "thj_abi_version") or lib.thj_abi_version() != ABI_VERSION:
+        raise ThjError("%s has ABI revision %s, this module wants %d: rebuild (python -c 'import __graft_entry__ as g; g.build()')" % (
+            p, lib.thj_abi_version() if hasattr(lib, "thj_abi_version") else "< 2", ABI_VERSION))
     if hasattr(lib, "thj_ctx_stream"):
         lib.thj_ctx_stream.restype = C.c_void_p
     if path is None:
@@ -703,6 +708,18 @@ def _span_methods():
         _check(self.lib, self.lib.thj_span_tier_counts(self._ctx, c), "thj_span_tier_counts")
         return int(c[3])
 
+    def stream_info(self):
+        """thj_ctx_stream_info: {"n_side", "independent": [..], "ratio": [..]} of the side streams made so far"""
+        n = C.c_int32()
+        ind = (C.c_int32 * 3)()
+        ratio = (C.c_double * 3)()
+        _check(self.lib, self.lib.thj_ctx_stream_info(self._ctx, C.byref(n), ind, ratio), "thj_ctx_stream_info")
+        return {"n_side": int(n.value), "independent": [bool(ind[k]) for k in range(n.value)], "ratio": [float(ratio[k]) for k in range(n.value)]}
+
+    def probe_streams(self, need=2):
+        _check(self.lib, self.lib.thj_ctx_probe_streams(self._ctx, int(need)), "thj_ctx_probe_streams")
+        return self.stream_info()
+
     def span_chain_groups(self):
         """of the batch launched last: the multihit reads whose chains travelled as chain entries (thj_k_chains)"""
         c = (C.c_int64 * 5)()
@@ -719,7 +736,7 @@ def _span_methods():
         return list(ms), n.value
 
     for f in (upload_span_fusions, upload_span_sets, span_sets_from_segjuncs, span_fusions_from_segjuncs, fusion_search, upload_span_batch, span_reset, span_run, span_finish,
-              span_download, spanning, profile_span, span_tier_counts, span_hit_heads, span_run_pair, span_tier0_pair, span_chain_count, span_chain_groups):
+              span_download, spanning, profile_span, span_tier_counts, span_hit_heads, span_run_pair, span_tier0_pair, span_chain_count, span_chain_groups, stream_info, probe_streams):
         setattr(Context, f.__name__, f)
 
 
