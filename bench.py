@@ -263,6 +263,10 @@ def parse_args():
                     help="run the e2e leg's executables once more on configs[2]'s genome (25 contigs, 3.09 Gb) with N pairs -- its per-GPU shard at "
                          "8 GPUs -- twice: the first run packs the reference and leaves the packed-genome cache, the second maps it "
                          "(`e2e.grch38`, timing only; 0: skip)")
+    ap.add_argument("--e2e-config3-pairs", type=int, default=0, metavar="N",
+                    help="also run configs[2] at full size through the executables (N = 100000000: 31 GB of BAM against the GRCh38-sized genome; eight contexts "
+                         "on this GPU with the exchange step, then one context, outputs compared; the first 20 000 pairs against the oracle): `e2e.config3_full`.  "
+                         "Takes ~10 minutes and 45 GB of /dev/shm; off by default, its record is profiles/r06_config3_full.json")
     ap.add_argument("--e2e-pairs-large", type=int, default=40_000_000, metavar="N",
                     help="run the e2e leg a second time on N pairs (timing only; e.g. 40000000) so that the fixed cost of the three processes "
                          "and their rate separate: `e2e.large`, `e2e.fixed_s` and `e2e.rate_pairs_per_s` from the two points")
@@ -653,6 +657,11 @@ def e2e_leg(args, n_gpus=1):
             out["grch38"] = {"error": str(e)[-300:]}
         finally:
             shutil.rmtree(dg, ignore_errors=True)
+    if getattr(args, "e2e_config3_pairs", 0) > 0:
+        try:
+            out["config3_full"] = e2e_config3_full(args, args.e2e_config3_pairs)
+        except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
+            out["config3_full"] = {"error": str(e)[-600:], "ok": False}
     # a small case through the oracle whole (event files byte for byte, every spanning record, junctions.bed)
     d = tempfile.mkdtemp(prefix="thj_e2e_chk_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
@@ -666,6 +675,67 @@ def e2e_leg(args, n_gpus=1):
     if not out["ok"]:
         raise RuntimeError("e2e leg: outputs differ from the oracle: %s" % json.dumps(out)[:1500])
     return out
+
+
+def e2e_config3_full(args, pairs=100_000_000, ranks=8, check_pairs=20000):
+    """BASELINE configs[2] at FULL size through the executables on the GPUs this box has: `pairs` pairs of
+    2x100 bp against the 25-contig GRCh38-sized genome (31 GB of BAM in, ~8 GB out: byte offsets past 2^32 inside one input file, 8x the
+    shard count of the per-GPU case).  On one GPU the eight ranks of the 8-GPU run are eight contexts on the device (THJ_CTX_PER_GPU=8:
+    the same shard dealing, the same exchange step with eight sections over the loopback transport -- segment_juncs_main.cpp, what the
+    hardware allows as a rehearsal).  Run a second time with ONE context: the event files must be the same files, the BAM streams inside
+    the spanning files the same bytes.  The first `check_pairs` pairs of the same files go through the oracle as in e2e.timed_run_check."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from e2e_bench import GRCH38_LENS, mix_gen_args, run_e2e
+    ga = mix_gen_args(args.multihit_frac, args.max_copies, args.indel_frac) + ["--contigs", ",".join(str(x) for x in GRCH38_LENS)]
+    d = tempfile.mkdtemp(prefix="thj_e2e_c3_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    outs = ("out.juncs", "out.insertions", "out.deletions")
+
+    def sha(name):
+        h = hashlib.sha256()
+        with open(os.path.join(d, name), "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                h.update(blk)
+        return h.hexdigest()
+
+    def inflated_sha(name):
+        h = hashlib.sha256()
+        n = 0
+        with subprocess.Popen(["zcat", os.path.join(d, name)], stdout=subprocess.PIPE) as pr:
+            for blk in iter(lambda: pr.stdout.read(1 << 24), b""):
+                h.update(blk)
+                n += len(blk)
+        if pr.returncode != 0:
+            raise RuntimeError("zcat could not read %s" % name)
+        return h.hexdigest(), n
+    os.environ.setdefault("THJ_STAGE_TIMEOUT", "1800")
+    try:
+        runs = []
+        for k, per in enumerate((1, ranks)):       # (the one-context run first: it packs the reference and leaves the packed-genome cache, as a tophat run's first process does)
+            r = run_e2e(pairs, args.read_len, sum(GRCH38_LENS), 300000, workdir=d, keep=True, env_extra={"THJ_CTX_PER_GPU": str(per), "HIP_VISIBLE_DEVICES": "0"}, gen_args=ga)
+            one = {key: r[key] for key in ("segment_juncs_s", "long_spanning_reads_left_s", "long_spanning_reads_right_s", "both_stages_s", "junctions", "span_left_bytes", "span_right_bytes",
+                                           "host_ingest_fallback_shards") if key in r}
+            one["contexts"] = per
+            one["value"] = r["pairs"] / r["both_stages_s"]
+            one["sha256"] = {n: sha(n) for n in outs}
+            one["bam_stream"] = {n: inflated_sha(n) for n in ("span_left.bam", "span_right.bam")}
+            one["exchange"] = [l for l in r.get("segment_juncs_log_tail", []) if "exchange" in l or "all-gather" in l][:4]
+            if k == 0:
+                gen_s, in_bytes = r["gen_seconds"], r["input_bytes"]
+                largest = max(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".bam"))
+                chk = e2e_timed_run_check(d, args, pairs=check_pairs, genome_args=["--contigs", ",".join(str(x) for x in GRCH38_LENS)], introns=300000)
+            runs.append(one)
+        same = runs[0]["sha256"] == runs[1]["sha256"] and runs[0]["bam_stream"] == runs[1]["bam_stream"]
+        return {"pairs": pairs, "ranks": ranks, "seconds": runs[1]["both_stages_s"], "value": runs[1]["value"], "outputs_identical": bool(same),
+                "genome": "25 contigs with the GRCh38 primary-assembly lengths, 3 088 286 401 bp, 300 000 introns, the line's mix", "gen_seconds": gen_s,
+                "input_bytes": in_bytes, "largest_input_file_bytes": largest, "offsets_past_2_32": bool(largest > (1 << 32)),
+                "eight_contexts": runs[1], "one_context": runs[0], "first_pairs_against_the_oracle": chk,
+                "ok": bool(same and chk["events_of_the_sample_found_in_the_timed_outputs"] and chk["spanning_records_identical_to_oracle"])}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def e2e_cpu_port(d, args, gen_args, run_e2e, sha, inflated_sha, gpu_sha, gpu_stream):
@@ -799,7 +869,7 @@ def _bam_records_below(path, id_limit):
     return recs
 
 
-def e2e_timed_run_check(d, args, pairs=20000):
+def e2e_timed_run_check(d, args, pairs=20000, genome_args=None, introns=None):
     """The oracle on the first `pairs` pairs of the timed run's own files.  Stage 1: every junction / deletion / insertion the oracle
     finds in those pairs must be in the timed run's event files (set union: a sample's events are a subset; an insertion's bases
     may come from a later read of the left side, so insertions are matched by position and length).  Stage 2: the oracle's
@@ -817,7 +887,8 @@ def e2e_timed_run_check(d, args, pairs=20000):
     t = tempfile.mkdtemp(prefix="thj_e2e_twin_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         subprocess.check_call([gen, "--out", t, "--pairs", str(pairs), "--read-len", str(args.read_len), "--genome-len", str(args.genome_len),
-                               "--introns", str(args.introns), "--text"] + mix_gen_args(args.multihit_frac, args.max_copies, args.indel_frac), stdout=subprocess.DEVNULL)
+                               "--introns", str(introns if introns is not None else args.introns), "--text"] + mix_gen_args(args.multihit_frac, args.max_copies, args.indel_frac)
+                              + list(genome_args or []), stdout=subprocess.DEVNULL)
         f = lambda n: os.path.join(t, n)      # noqa: E731
         names, _ = parse_header(os.path.join(d, "hdr.sam"))
         same_genome = open(f("ref.fa"), "rb").read(1 << 20) == open(os.path.join(d, "ref.fa"), "rb").read(1 << 20)
