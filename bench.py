@@ -725,13 +725,15 @@ def e2e_config3_full(args, pairs=100_000_000, ranks=8, check_pairs=20000):
             one["exchange"] = [l for l in r.get("segment_juncs_log_tail", []) if "exchange" in l or "all-gather" in l][:4]
             if k == 0:
                 gen_s, in_bytes = r["gen_seconds"], r["input_bytes"]
-                largest = max(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".bam"))
+                largest = max(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".bam") and not f.startswith("span_"))
+                largest_out = max(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d) if f.endswith(".bam") and f.startswith("span_"))
                 chk = e2e_timed_run_check(d, args, pairs=check_pairs, genome_args=["--contigs", ",".join(str(x) for x in GRCH38_LENS)], introns=300000)
             runs.append(one)
         same = runs[0]["sha256"] == runs[1]["sha256"] and runs[0]["bam_stream"] == runs[1]["bam_stream"]
         return {"pairs": pairs, "ranks": ranks, "seconds": runs[1]["both_stages_s"], "value": runs[1]["value"], "outputs_identical": bool(same),
                 "genome": "25 contigs with the GRCh38 primary-assembly lengths, 3 088 286 401 bp, 300 000 introns, the line's mix", "gen_seconds": gen_s,
-                "input_bytes": in_bytes, "largest_input_file_bytes": largest, "offsets_past_2_32": bool(largest > (1 << 32)),
+                "input_bytes": in_bytes, "largest_input_file_bytes": largest, "largest_output_file_bytes": largest_out,
+                "offsets_past_2_32": {"in_an_input_file": bool(largest > (1 << 32)), "in_an_output_file": bool(largest_out > (1 << 32))},
                 "eight_contexts": runs[1], "one_context": runs[0], "first_pairs_against_the_oracle": chk,
                 "ok": bool(same and chk["events_of_the_sample_found_in_the_timed_outputs"] and chk["spanning_records_identical_to_oracle"])}
     finally:
@@ -1115,11 +1117,18 @@ def run_rank(args, rank, world, local_rank, control, shared):
         host_t[name] = host_t.get(name, 0.0) + time.perf_counter() - t
         return r
 
+    t0_first = os.environ.get("THJ_BENCH_T0_FIRST", "0") == "1" and os.environ.get("THJ_BENCH_NO_EARLY_T0") != "1" and os.environ.get("THJ_BENCH_NO_PAIR") != "1" and not args.fusion_search
+
     def step():
         # ---- segment_juncs stage
         ctx.reset()
         if n_ium:
             ctx.covsearch_reset()
+        if t0_first:
+            # stage 2's tier 0 needs nothing of stage 1: it goes out FIRST, on the side streams, and streams its 2 x 2.5 GB beside stage 1's
+            # kernels (most of which wait on dependent gathers and leave the HBM idle)
+            timed("span_reset", ctx.span_reset)
+            timed("span_tier0_pair", ctx.span_tier0_pair, p_span, sp_left, sp_right)
         if os.environ.get("THJ_BENCH_NO_PAIR") == "1":
             ctx.run(p_left, cb_left)
             ctx.run(p_right, cb_right)
@@ -1143,7 +1152,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
                 e1.record(stream)
                 xchg_events.append((e0, e1))
         early_t0 = os.environ.get("THJ_BENCH_NO_EARLY_T0") != "1" and os.environ.get("THJ_BENCH_NO_PAIR") != "1" and not args.fusion_search
-        if early_t0:
+        if early_t0 and not t0_first:
             # stage 2's tier 0 (the reads whose hits abut end to end) needs no junction set: it goes out before stage 1's counts are
             # asked for, and the GPU has it while the host waits and the event lists are sorted (thj_span_tier0_pair_async)
             timed("span_reset", ctx.span_reset)

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 code = ("import sys; sys.path.insert(0, %r); import tophat_amd.host as h; "
-        "h.LIB_PATH = %r; import bench; sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--e2e-pairs', '0', '--no-pmc'] + %r; bench.main()"
+        "h.LIB_PATH = %r; import bench; sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--e2e-pairs', '0', '--no-pmc', '--detail', '/tmp/exp_bench_detail.json'] + %r; bench.main()"
         % (ROOT, os.path.join(ROOT, "tophat_amd", "csrc", "libthj_exp.so"), os.environ.get("THJ_EXP_ARGS", "").split()))
 for f in sys.argv[1:]:
     env = dict(os.environ, THJ_EXP_FLAGS=f)
@@ -17,5 +17,5 @@ for f in sys.argv[1:]:
     if not line:
         print(f, "FAILED", out.stderr[-400:])
         continue
-    d = json.loads(line[-1])
-    print("flags=%s step=%.3f ms  " % (f, d["ms_per_step"]) + "  ".join("%s=%.3f" % (k["kernel"][6:], k["avg_kernel_ms"]) for k in d["kernels"]), flush=True)
+    d = json.load(open("/tmp/exp_bench_detail.json"))
+    print("flags=%s step=%.3f ms  " % (f, d["ms_per_step"]) + "  ".join("%s=%.3f/%s" % (k["kernel"][6:28], k["avg_kernel_ms"], ("%.3f" % k["avg_kernel_ms_alone"]) if k.get("avg_kernel_ms_alone") else "-") for k in d["kernels"]), flush=True)

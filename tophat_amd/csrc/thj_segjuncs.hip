@@ -615,14 +615,16 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Params p, DevBat
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
             }
+            if (THJ_EXPF(1 << 26)) continue;                    // (ablation: the draw and the staging alone)
             do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
+            if (THJ_EXPF(1 << 27)) continue;                    // (... and the partner search)
             if (do_gaps && wants) {
                 // the rescue kernels take it from here (their list, this kernel's slice)
                 if (lane == 0) s_resc[atomicAdd(&s_nr, 1u)] = (uint32_t)r;
             } else {
                 QueueSink qs{qq, x, (uint32_t)r, hbase, 0u, 0u};
                 if (!THJ_EXPF(1 << 17)) indels_enumerate(p, v, qs, lane, 64);
-                if (do_gaps) gaps_enumerate(p, v, qs, lane, 64);
+                if (do_gaps && !THJ_EXPF(1 << 25)) gaps_enumerate(p, v, qs, lane, 64);
                 my_windows += qs.n_windows; my_indels += qs.n_indels;
             }
         }
