@@ -97,6 +97,21 @@ static bool flat_path(const Genome& g, const Params& p, const ReadView& v, Colle
     return true;
 }
 
+#include "simt.h"
+// the wave operations wave_read_enumerate is written against, over simt.h's fibers
+struct SjWaveSim {
+    simt::Block* b; int tid, lane;
+    unsigned long long ballot(bool p) { const uint32_t* a = b->exchange(tid, p ? 1u : 0u); unsigned long long m = 0; for (int i = 0; i < 64; ++i) m |= (unsigned long long)(a[i] & 1u) << i; return m; }
+    uint32_t bcast(uint32_t v, int src) { return b->exchange(tid, v)[src & 63]; }
+};
+// tasks of one fiber, executed when the wave is done (the sinks of this file are not shared among fibers while they run)
+struct WaveTaskLog {
+    struct T { bool is_indel; int i; uint32_t lidx, ridx; int li, ri; bool anti; int plen; bool is_del; uint32_t ref; int32_t wl, wr; int start, slen; };
+    std::vector<T> v;
+    void window(uint32_t ref, int32_t wl, int32_t wr, bool anti, int start, int slen) { T t{}; t.is_indel = false; t.ref = ref; t.wl = wl; t.wr = wr; t.anti = anti; t.start = start; t.slen = slen; v.push_back(t); }
+    void indel(int i, uint32_t lidx, uint32_t ridx, int li, int ri, bool anti, int plen, bool is_del) { T t{}; t.is_indel = true; t.i = i; t.lidx = lidx; t.ridx = ridx; t.li = li; t.ri = ri; t.anti = anti; t.plen = plen; t.is_del = is_del; v.push_back(t); }
+};
+
 extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
                                 const int32_t* contig_len, int32_t n_contigs, const thj_seg_batch* b,
                                 thj_junction** juncs, int64_t* n_juncs, thj_junction** dels, int64_t* n_dels,
@@ -114,6 +129,7 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
     std::vector<int32_t> slots, mscan;
     std::vector<PHit> plist;
     const bool mscan_mode = getenv("THJ_HOSTSIM_MSCAN") != nullptr; // the rescue pairs from one scan per mate hit (ReadView::mscan)
+    const bool wave_mode = getenv("THJ_HOSTSIM_WAVE") != nullptr;   // reads with several hits a segment by a wave of fibers with the hits in registers (wave_read_enumerate)
     const bool plist_mode = getenv("THJ_HOSTSIM_PLIST") != nullptr; // ... and the pseudo-hit list built once, a left hit at a time (rescue_pseudo_hits: thj_k_segjuncs_rescue_shared since round 6)
     for (int32_t r = 0; r < b->n_reads; ++r) {
         ReadView v;
@@ -133,6 +149,29 @@ extern "C" int hostsim_segjuncs(const thj_params* tp, const uint64_t* blocks, co
                          : v.nseg <= 8 ? flat_path<8>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial)
                          : flat_path<16>(g, p, v, c, b->ordinal_base + (uint32_t)r, nw, ni, nr, n_trivial))) continue;
         if (!no_skip && read_is_trivial(p, v)) { ++n_trivial; continue; }      // nothing can come out of this read
+        if (wave_mode && wave_read_fits(v)) {
+            // thj_k_segjuncs_shared since round 6: the read by one wave, its hits in registers (wave_read_enumerate); a read that takes
+            // the rescue is handed on (below, as the rescue kernels take it: indel pairs, rescue slots, the enumeration)
+            WaveTaskLog logs[64];
+            bool dg[64], wr[64];
+            ReadView views[64];
+            simt::run_block(64, [&](simt::Block& blk, int tid) {
+                SjWaveSim x{&blk, tid, tid};
+                views[tid] = v;
+                dg[tid] = wave_read_enumerate(x, p, views[tid], logs[tid], wr[tid]);
+            }, 256 * 1024);
+            for (int l = 1; l < 64; ++l) if (dg[l] != dg[0] || wr[l] != wr[0]) return 8;       // the verdicts are the wave's
+            if (!(dg[0] && wr[0])) {
+                for (int l = 0; l < 64; ++l)
+                    for (auto& t : logs[l].v) {
+                        if (t.is_indel) sink.indel(t.i, t.lidx, t.ridx, t.li, t.ri, t.anti, t.plen, t.is_del);
+                        else sink.window(t.ref, t.wl, t.wr, t.anti, t.start, t.slen);
+                    }
+                nw += sink.n_windows; ni += sink.n_indels;
+                continue;
+            }
+            for (int l = 0; l < 64; ++l) if (!logs[l].v.empty()) return 9;                   // a rescue read: nothing enumerated here
+        }
         indels_enumerate(p, v, sink);
         bool wants;
         if (gaps_prepare(p, v, wants)) {
@@ -255,7 +294,6 @@ extern "C" int64_t hostsim_chain_deferred() { const int64_t n = g_chain_deferred
 static int64_t g_chain_reads = 0;           // reads that travelled as chain entries (tier 0 -> join -> finish) since the last call
 extern "C" int64_t hostsim_chain_reads() { const int64_t n = g_chain_reads; g_chain_reads = 0; return n; }
 // the wave operations span_pack_wave is written against, over simt.h's fibers (one wave = 64 fibers)
-#include "simt.h"
 struct WaveSimX {
     simt::Block* b; int tid, lane;
     uint64_t ballot(bool p) { const uint32_t* a = b->exchange(tid, p ? 1u : 0u); uint64_t m = 0; for (int i = 0; i < 64; ++i) m |= (uint64_t)(a[i] & 1u) << i; return m; }

@@ -11,7 +11,7 @@ from util import CASES, assert_events_equal, case_batches
 
 
 @pytest.mark.parametrize("cfg", CASES, ids=lambda c: "seed%d_%s_rl%d_L%d" % (c["seed"], "pe" if c["paired"] else "se", c["read_len"], c["seg_len"]))
-@pytest.mark.parametrize("variant", ["as_kernel", "general", "lazy_rescue", "mate_scans", "pseudo_hit_list", "no_trivial_skip"])
+@pytest.mark.parametrize("variant", ["as_kernel", "general", "lazy_rescue", "mate_scans", "pseudo_hit_list", "wave_registers", "no_trivial_skip"])
 def test_kernel_logic_matches_oracle(cfg, variant, monkeypatch):
     # as_kernel: reads with at most one hit per segment take flat_read / flat_rescue (thj_k_sj_flat, thj_k_sj_rescue_flat), the others
     #            the general enumeration with precomputed rescue slots
@@ -26,6 +26,8 @@ def test_kernel_logic_matches_oracle(cfg, variant, monkeypatch):
         monkeypatch.setenv("THJ_HOSTSIM_MSCAN", "1")
     if variant == "pseudo_hit_list":   # ... since round 6: the pseudo-hit list built once, a left hit at a time (rescue_pseudo_hits), and enumerated against
         monkeypatch.setenv("THJ_HOSTSIM_PLIST", "1")
+    if variant == "wave_registers":    # thj_k_segjuncs_shared since round 6: a wave per read, the sweeps on registers (wave_read_enumerate; the wave = 64 fibers)
+        monkeypatch.setenv("THJ_HOSTSIM_WAVE", "1")
     if variant == "no_trivial_skip":
         monkeypatch.setenv("THJ_HOSTSIM_NO_SKIP", "1")
     case = make_case(seed=cfg["seed"], paired=cfg["paired"], read_len=cfg["read_len"], seg_len=cfg["seg_len"],

@@ -117,7 +117,7 @@ def test_scale_workload_with_deletion_reads():
     assert len(with_del & dz) > 0.35 * len(dz), (len(with_del & dz), len(dz))      # not every planted deletion leaves mismatches to explain
 
 
-def test_scale_workload_with_a_repeat_family():
+def test_scale_workload_with_a_repeat_family(monkeypatch):
     """bench.py's default mix (multihits from planted repeats up to 41): family pairs have every segment hit at 2..41
     copies, a read with 41 is dropped whole by max_seg_multihits in both stages, deletion reads are found -- oracle and kernel logic
     agree on both stages (the stage-2 tiers included: reads with few hits, many hits, too many joined alignments)"""
@@ -162,6 +162,15 @@ def test_scale_workload_with_a_repeat_family():
         sb = sample_segbatch(w[sd], n)
         e = orc.segjuncs(p, og, sb)
         assert_events_equal(sim.segjuncs(p, strs, sb), e)
+        # ... and as the kernels of round 6 take the family's reads: a wave per read with the hits in registers (wave_read_enumerate), the
+        # rescue against the pseudo-hit list built a left hit at a time (rescue_pseudo_hits) -- k x k (left hit, mate hit) pairs for a k-copy read
+        monkeypatch.setenv("THJ_HOSTSIM_WAVE", "1")
+        monkeypatch.setenv("THJ_HOSTSIM_PLIST", "1")
+        e2 = sim.segjuncs(p, strs, sb)
+        monkeypatch.delenv("THJ_HOSTSIM_WAVE")
+        monkeypatch.delenv("THJ_HOSTSIM_PLIST")
+        assert_events_equal(e2, e)
+        assert (e2.stats["windows"], e2.stats["indel_pairs"], e2.stats["rescue_pairs"]) == (e.stats["windows"], e.stats["indel_pairs"], e.stats["rescue_pairs"])
         ev = e if ev is None else merge_events(ev, e)
     assert len(ev.deletions) > 20
     juncs, ins = events_to_span_inputs(ev)

@@ -945,6 +945,151 @@ THJ_HD void gaps_enumerate(const Params& p, const ReadView& v, Sink& sink, int f
     }
 }
 
+// ---- a read with several hits a segment, by ONE WAVE with the hits in registers (round 6) -----------------------------------------
+// The head of find_gaps (:3304-3393), find_insertions_and_deletions' pair enumeration (:2807-2942) and find_gaps' body (:3499-3617) for
+// a read whose segments hold at most 64 hits each: lane j keeps hit j of the segment it enumerates FROM in registers, and every
+// sweep over the hits of another segment is a loop of broadcasts (x.bcast: one v_readlane per word, the loop counter is uniform) --
+// no memory on the way.  gaps_prepare_shared / indels_enumerate / gaps_enumerate with (lane, 64) do the same by walking the staged
+// hit records: one dependent LDS round trip per step, eight sweeps a read, ~25 us for a read of 25 copies (0.25 ms per launch of
+// thj_k_segjuncs_shared on the mix for 15 000 reads).  Same tasks, same counts; their order in the queue differs (it never mattered).
+// X: lane, ballot(bool), bcast(uint32_t, int src).  v.hits / v.so: the read's hits (any memory; read once per lane and segment).
+// Returns what gaps_prepare returns; with wants_rescue set nothing has been enumerated (the rescue kernels take the read, its
+// indel pairs included).
+template <class X>
+THJ_HD Hit wave_bcast_hit(X& x, const Hit& h, int src) {
+    Hit o;
+    o.ref_id = x.bcast(h.ref_id, src); o.left = (int32_t)x.bcast((uint32_t)h.left, src);
+    o.right = (int32_t)x.bcast((uint32_t)h.right, src); o.meta = x.bcast(h.meta, src);
+    return o;
+}
+THJ_HD Hit wave_lane_hit(const ReadView& v, int s, int lane) {
+    Hit h{0, 0, 0, 0};
+    if (lane < rv_count_raw(v, s)) h = v.hits[v.so[s] + (uint32_t)lane];
+    return h;
+}
+THJ_HD bool wave_read_fits(const ReadView& v) {
+    for (int s = 0; s < v.nseg; ++s) if (rv_count_raw(v, s) > 64) return false;
+    return true;
+}
+template <class X, class Sink>
+THJ_HD bool wave_read_enumerate(X& x, const Params& p, ReadView& v, Sink& sink, bool& wants_rescue) {
+    const int lane = x.lane;
+    const int L = p.segment_length;
+    wants_rescue = false;
+    v.rescue = false;
+    v.check_len = p.segment_length - p.segment_mismatches - 3;
+    if (v.check_len > 15) v.check_len = 15;
+    if (v.nseg == 0) return false;
+    int last = v.nseg - 1;
+    while (last > 0 && rv_count_raw(v, last) == 0) --last;
+    v.size = last + 1;
+    if (last == 0) {
+        if (rv_count_raw(v, 0) == 0) return false;
+        const Hit h0 = v.hits[v.so[0]];
+        if (hit_end(h0)) return false;                                        // :3316-3318
+    }
+    // ---- the partner search (:3361-3390): a first-segment hit with a last-segment hit at intron distance
+    {
+        bool found = false;
+        if (last != 0) {
+            const Hit lh = wave_lane_hit(v, 0, lane);
+            const bool have = lane < rv_count_raw(v, 0);
+            const Hit D = wave_lane_hit(v, last, lane);
+            const int nD = rv_count_raw(v, last);
+            for (int j = 0; j < nD; ++j) {
+                const Hit rh = wave_bcast_hit(x, D, j);
+                if (have && lh.ref_id == rh.ref_id && hit_anti(lh) == hit_anti(rh)) {
+                    const int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
+                    if (dist >= p.min_segment_intron && dist < p.max_segment_intron) found = true;
+                }
+            }
+        }
+        wants_rescue = x.ballot(found) == 0ull && v.n_mate > 0;
+    }
+    if (wants_rescue) return true;
+    // ---- find_insertions_and_deletions: the pairs (hit of segment i, hit of segment i + 1), :2856-2940
+    if (v.nseg >= 2)
+        for (int i = 0; i + 2 < v.nseg; ++i) {
+            const uint32_t lb = v.so[i], le = v.so[i + 1], re = v.so[i + 2];
+            if (lb == le || le == re) break;                                  // :2869-2870
+            const int start = i * L;
+            if (start > v.rl) break;
+            const int plen = v.rl - start < 2 * L ? v.rl - start : 2 * L;
+            const Hit lh = wave_lane_hit(v, i, lane);
+            const bool have = (uint32_t)lane < le - lb;
+            const Hit C = wave_lane_hit(v, i + 1, lane);
+            const int nC = (int)(re - le);
+            for (int ri = 0; ri < nC; ++ri) {
+                const Hit rh = wave_bcast_hit(x, C, ri);
+                if (!have || lh.ref_id != rh.ref_id) continue;
+                const bool anti = hit_anti(lh);
+                if (anti != hit_anti(rh)) continue;
+                const int apparent = anti ? lh.right - rh.left : rh.right - lh.left;
+                const int disc = apparent - plen;
+                const bool is_del = disc > 0 && disc <= p.max_deletion_length;
+                const bool is_ins = disc < 0 && disc >= -p.max_insertion_length;
+                if (is_del || is_ins)
+                    sink.indel(i, anti ? le + (uint32_t)ri : lb + (uint32_t)lane, anti ? lb + (uint32_t)lane : le + (uint32_t)ri, lane, ri, anti, plen, is_del);
+            }
+        }
+    // ---- find_gaps' body (:3499-3617)
+    if (p.bowtie2)
+        for (int s = 0; s < v.size; ++s) if (rv_count_raw(v, s) > p.max_seg_multihits) return true;      // :3499-3506
+    for (int s = 0; s + 1 < v.size; ++s) {                  // (a hit of the last segment has nothing to its right: `found` from the start)
+        const Hit bh = wave_lane_hit(v, s, lane);
+        const bool have = lane < rv_count_raw(v, s);
+        const bool banti = hit_anti(bh);
+        const Hit B = wave_lane_hit(v, s + 1, lane);
+        const int nB = rv_count_raw(v, s + 1);
+        bool found = false;
+        int n_drs = 0, n_rrs = 0;
+        for (int c = 0; c < nB; ++c) {
+            const Hit rh = wave_bcast_hit(x, B, c);
+            if (!have || banti != hit_anti(rh) || bh.ref_id != rh.ref_id) continue;
+            if ((banti && rh.right == bh.left) || (!banti && bh.right == rh.left)) found = true;
+            const int dist = banti ? bh.left - rh.right : rh.left - bh.right;
+            if (dist >= p.min_segment_intron && dist < p.max_segment_intron) ++n_drs;
+        }
+        Hit C{0, 0, 0, 0};
+        int nC = 0;
+        if (s < v.size - 2) {
+            C = wave_lane_hit(v, s + 2, lane);
+            nC = rv_count_raw(v, s + 2);
+            if (x.ballot(have && !found) != 0ull)
+                for (int c = 0; c < nC; ++c) {
+                    const Hit rrh = wave_bcast_hit(x, C, c);
+                    if (!have || found || banti != hit_anti(rrh) || bh.ref_id != rrh.ref_id) continue;
+                    const int dist = banti ? bh.left - rrh.right : rrh.left - bh.right;
+                    if (dist >= p.min_segment_intron + L && dist < p.max_segment_intron + L) ++n_rrs;
+                }
+        }
+        const bool emits = have && !found && (n_drs > 0 || n_rrs > 0);
+        const bool use_rrs = n_rrs > 0;
+        const int lo = p.min_segment_intron + (use_rrs ? L : 0), hi = p.max_segment_intron + (use_rrs ? L : 0);
+        const int start = (s + 1) * L - 8;                                    // :3583-3586
+        int slen = use_rrs ? L + 16 : 16;
+        if (slen > v.rl - start) slen = v.rl - start;
+        const bool go = emits && start >= 0 && slen >= 0;
+        // the windows: against the next segment's hits for the lanes that count there, the one after for the others
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool mine = go && (use_rrs ? pass == 1 : pass == 0);
+            if (x.ballot(mine) == 0ull) continue;
+            const int nT = pass == 0 ? nB : nC;
+            for (int c = 0; c < nT; ++c) {
+                const Hit d = wave_bcast_hit(x, pass == 0 ? B : C, c);
+                if (!mine || banti != hit_anti(d) || bh.ref_id != d.ref_id) continue;
+                const int dist = banti ? bh.left - d.right : d.left - bh.right;
+                if (dist < lo || dist >= hi) continue;
+                int32_t wl, wr;
+                if (!banti) { wl = bh.right - 8; if (wl < 0) wl = 0; wr = d.left + 8; }   // :3589-3594
+                else { wl = d.right - 8; wr = bh.left + 8; }                              // :3596-3604
+                sink.window(bh.ref_id, wl, wr, banti, start, slen);
+            }
+        }
+    }
+    return true;
+}
+
 // find_insertions_and_deletions (segment_juncs.cpp:2807-2942) pair enumeration.
 // Sink: indel(i, left_idx, right_idx, li, ri, antisense, plen, is_deletion)
 // with left/right already swapped for antisense pairs (:2914-2920).

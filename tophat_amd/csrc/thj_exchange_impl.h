@@ -329,7 +329,14 @@ static int x_finish_check(thj_ctx* c, const unsigned int* ovf_now) {
         return rc ? rc : 1;
     }
     if (ovf_now[0] || ovf_now[1] || ovf_now[2]) {                 // this rank's table filled up while merging: nothing is lost, the
-        int rc = grow_tables(c, ovf_now[0] != 0, (ovf_now[1] | ovf_now[2]) != 0);   // gathered keys are still in d_recv
+        // gathered keys are still in d_recv.  The headers say how many keys every rank sent: the tables grow in one go to where their sum
+        // (an upper bound of the distinct keys) is at most 40 % of the slots, not by one factor of four per failed merge
+        u64 sj = 0, sd = 0, si = 0;
+        for (int r = 0; r < m->n; ++r) { const unsigned long long* h = m->h_hdr + (size_t)r * 8; sj += h[0]; sd += h[1]; si += h[2]; }
+        const u64 sdi = sd > si ? sd : si;
+        int rc = THJ_OK;
+        const bool gj = ovf_now[0] != 0, gdi = (ovf_now[1] | ovf_now[2]) != 0;
+        do { rc = grow_tables(c, gj, gdi); } while (rc == THJ_OK && ((gj && (u64)c->junc_cap * 2 < sj * 5 && c->junc_cap < (1ll << 34)) || (gdi && (u64)c->indel_cap * 2 < sdi * 5 && c->indel_cap < (1ll << 34))));
         if (rc) return rc;
         HIPCHK(hipMemsetAsync(c->d_ovf, 0, 3 * sizeof(unsigned int), c->stream));      // (word 3, the task list's flag, is not the merge's to clear)
         if ((rc = x_merge_launch(c, m))) return rc;

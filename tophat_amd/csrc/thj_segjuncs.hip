@@ -53,17 +53,50 @@ __device__ __forceinline__ u64 mix64(u64 x) {
     return x;
 }
 
+// The position of a new key in its dense list.  The lanes of a wave that arrive here together (each just won a slot with its own key --
+// whatever branch or loop iteration brought them) take their positions with ONE add on the list's counter: a batch whose reads carry
+// 190 000 distinct deletions (bench.py's mix: every deletion read has its own) was 190 000 returning atomics on one address in one
+// launch of thj_k_sj_tasks (the left side's launch took three times the right side's).  The order of the list does not matter (it is
+// sorted when the pass ends).
+__device__ __forceinline__ unsigned long long list_append_pos(unsigned long long* count) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (;;) {       // (one turn, unless lanes with different lists meet here: each turn serves the list of the first lane still waiting)
+        const unsigned long long mine_p = (unsigned long long)count;
+        const unsigned long long p0 = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(mine_p >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mine_p);
+        const bool now = mine_p == p0;
+        const unsigned long long grp = __ballot(now);                  // the lanes executing this together, for this list
+        if (now) {
+            unsigned long long base = 0;
+            if (lane == __ffsll((long long)grp) - 1) base = atomicAdd(count, (unsigned long long)__popcll(grp));
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));   // (the group's first lane is the first active lane here)
+            return (((unsigned long long)hi << 32) | lo) + (unsigned long long)__popcll(grp & below);
+        }
+    }
+}
+
 // Insert into an open-addressing set; idempotent, so re-emitting an event is harmless.
 // A key that was not there yet is also appended to `list` (its position is the insert counter): the distinct
 // events are then already dense when the pass ends, and nobody has to scan the whole table for them.
+// A table that has filled up is reported through `ovf` and grown by the host (thj_segjuncs_finish: an error for a plain run, grow-and-merge-
+// again after an exchange step): once the flag is up nothing this pass inserts is kept, so an insert that sees it leaves at once, and no
+// insert probes more than PROBE_CAP slots (at the <= 40 % load the host keeps the tables at, a probe sequence is a handful of slots).
+// Before round 6 an insert into a FULL table walked every slot before it gave up: eight ranks' 2.5 M deletions merged into a 1 M-slot table
+// (configs[2] at full size, eight contexts) were 1.5 M walks of a million slots each -- 23 s inside the exchange step.  RESCUE (the rehash of
+// a growing table): the flag may still be up from the pass that filled the old table; every key must go in.
+static constexpr u64 PROBE_CAP = 4096;
+template <bool RESCUE = false>
 __device__ __forceinline__ void set_insert(u64* tab, u64 mask, u64 key, unsigned long long* count, unsigned int* ovf, u64* list) {
+    if (!RESCUE && __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     u64 h = mix64(key) & mask;
-    for (u64 probe = 0; probe <= mask; ++probe) {
+    const u64 limit = RESCUE ? mask : (mask < PROBE_CAP ? mask : PROBE_CAP);
+    for (u64 probe = 0; probe <= limit; ++probe) {
         u64 cur = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == key) return;
         if (cur == EMPTY) {
             u64 old = atomicCAS((unsigned long long*)&tab[h], EMPTY, key);
-            if (old == EMPTY) { const unsigned long long pos = atomicAdd(count, 1ull); if (pos <= mask) list[pos] = key; return; }   // rare
+            if (old == EMPTY) { const unsigned long long pos = list_append_pos(count); if (pos <= mask) list[pos] = key; return; }
             if (old == key) return;
         }
         h = (h + 1) & mask;
@@ -71,14 +104,17 @@ __device__ __forceinline__ void set_insert(u64* tab, u64 mask, u64 key, unsigned
     atomicExch(ovf, 1u);
 }
 
+template <bool RESCUE = false>
 __device__ __forceinline__ void map_insert_min(u64* keys, u64* vals, u64 mask, u64 key, u64 val,
                                                unsigned long long* count, unsigned int* ovf, u64* list) {
+    if (!RESCUE && __hip_atomic_load(ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     u64 h = mix64(key) & mask;
-    for (u64 probe = 0; probe <= mask; ++probe) {
+    const u64 limit = RESCUE ? mask : (mask < PROBE_CAP ? mask : PROBE_CAP);
+    for (u64 probe = 0; probe <= limit; ++probe) {
         u64 cur = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == EMPTY) {
             u64 old = atomicCAS((unsigned long long*)&keys[h], EMPTY, key);
-            if (old == EMPTY) { const unsigned long long pos = atomicAdd(count, 1ull); if (pos <= mask) list[pos] = h; cur = key; }
+            if (old == EMPTY) { const unsigned long long pos = list_append_pos(count); if (pos <= mask) list[pos] = h; cur = key; }
             else cur = old;
         }
         if (cur == key) { atomicMin((unsigned long long*)&vals[h], val); return; }
@@ -380,14 +416,43 @@ __device__ __forceinline__ void exec_task(const Genome& g, const Params& p, cons
     } else
         window_exec<WIDE>(g, p, tv, q.y, (int32_t)q.z, (int32_t)q.w, anti, task_window_start(a), task_window_slen(a), ev);
 }
-// The tasks of the flat kernels, one thread each: workgroup w takes slice w.
+// The tasks of the flat kernels, one thread each: workgroup w takes slice w.  Two passes: the windows as they come, the indel pairs
+// (a deletion read's: other loads, other code, a 50-step split search) set aside in LDS and run densely afterwards -- mixed in one wave
+// (one lane in four on the left side of the mix) every wave ran both paths one after the other.
+static constexpr int TASK_DEFER_CAP = 3072;
 template <bool WIDE>
 __global__ __launch_bounds__(TPB) void thj_k_sj_tasks(Genome g, Params p, DevBatch b, Tables t, SjLists sl) {
+    __shared__ uint32_t s_defer[TASK_DEFER_CAP];
+    __shared__ unsigned int s_nd;
     const unsigned int n = sl.task_cnt[blockIdx.x];
     const uint4* tq = sl.tq + (size_t)blockIdx.x * sl.task_cap;
     const uint32_t* te = sl.te + (size_t)blockIdx.x * sl.task_cap;
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    if (threadIdx.x == 0) s_nd = 0;
+    __syncthreads();
     EventSink ev{g, t};
-    for (unsigned int k = threadIdx.x; k < n; k += TPB) exec_task<WIDE>(g, p, b, ev, tq[k], (int)te[k]);
+    for (unsigned int k0 = 0; k0 < n; k0 += TPB) {
+        const unsigned int k = k0 + threadIdx.x;
+        const bool active = k < n;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        if (active) q = tq[k];
+        const bool indel = active && task_is_indel(q.x);
+        const unsigned int slot = wave_slot(indel, &s_nd, below);
+        if (indel && slot < (unsigned int)TASK_DEFER_CAP) s_defer[slot] = k;
+        else if (active) exec_task<WIDE>(g, p, b, ev, q, (int)te[k]);          // a window -- or an indel pair beyond the room (never on the mix)
+    }
+    __syncthreads();
+    const unsigned int nd = s_nd < (unsigned int)TASK_DEFER_CAP ? s_nd : (unsigned int)TASK_DEFER_CAP;
+    for (unsigned int j = threadIdx.x; j < nd; j += TPB) {
+        const unsigned int k = s_defer[j];
+        const uint4 q = tq[k];
+        const int tr = (int)te[k];
+        ReadView tv = make_task_view(b, tr);
+        const int i = task_indel_i(q.x);
+        indel_exec<WIDE>(g, p, tv, i, q.y, q.z, task_anti(q.x), task_indel_plen(q.x), task_is_del(q.x),
+                         ins_prio(b.ordinal_base + (uint32_t)tr, i, (int)(q.w & 0xFFFF), (int)(q.w >> 16)), ev);
+    }
 }
 // ... of the kernels that enumerate from lists: one list.
 template <bool WIDE>
@@ -569,6 +634,11 @@ __global__ __launch_bounds__(T) void thj_k_sj_general(Params p, DevBatch b, Resc
     }
 }
 
+struct SjWave {            // the wave operations wave_read_enumerate is written against
+    int lane;
+    __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+    __device__ __forceinline__ uint32_t bcast(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(src)); }
+};
 // The reads with many hits (listed by the main kernel, unclassified): one WAVE per read.  The read's hits are staged in LDS, the partner
 // search of find_gaps' head is shared over the lanes; a read that takes the mate-anchored rescue goes to this kernel's own slice of
 // the rescue list (the rescue kernels run next), the others are enumerated here, lane = hit, into the usual queue.
@@ -605,7 +675,7 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Params p, DevBat
             if (k >= SHARED_BATCH || base + k >= n) break;
             const int r = (int)rl.many_list[base + k];
             ReadView v = make_view(b, r);
-            bool do_gaps = false, wants = false;
+            bool do_gaps = false, wants = false, staged = false;
             uint32_t hbase = 0;
             const uint32_t h0 = v.so[0], nh = v.so[v.nseg] - h0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // the wave's last read is done with s_h
@@ -613,9 +683,18 @@ __global__ __launch_bounds__(TPB, 4) void thj_k_segjuncs_shared(Params p, DevBat
                 for (uint32_t i = (uint32_t)lane; i < nh; i += 64u) ((uint4*)s_h[wave])[i] = ((const uint4*)b.hits)[h0 + i];
                 if (lane <= v.nseg) s_o[wave][lane] = v.so[lane] - h0;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0;
+                v.hits = s_h[wave]; v.so = s_o[wave]; hbase = h0; staged = true;
             }
             if (THJ_EXPF(1 << 26)) continue;                    // (ablation: the draw and the staging alone)
+            if (staged && wave_read_fits(v)) {
+                // the hits are staged and no segment holds more than 64: the sweeps run on registers (wave_read_enumerate)
+                SjWave xw{lane};
+                QueueSink qs{qq, x, (uint32_t)r, hbase, 0u, 0u};
+                do_gaps = wave_read_enumerate(xw, p, v, qs, wants);
+                if (do_gaps && wants) { if (lane == 0) s_resc[atomicAdd(&s_nr, 1u)] = (uint32_t)r; }
+                else { my_windows += qs.n_windows; my_indels += qs.n_indels; }
+                continue;
+            }
             do_gaps = gaps_prepare_shared(p, v, wants, lane, 64, [](bool f) { return __any((int)f) != 0; });
             if (THJ_EXPF(1 << 27)) continue;                    // (... and the partner search)
             if (do_gaps && wants) {
@@ -1018,14 +1097,14 @@ __global__ __launch_bounds__(256) void thj_k_rehash_keys(const u64* old_tab, u64
                                                          u64* list) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
         const u64 k = old_tab[i];
-        if (k != EMPTY) set_insert(tab, mask, k, count, ovf, list);
+        if (k != EMPTY) set_insert<true>(tab, mask, k, count, ovf, list);
     }
 }
 __global__ __launch_bounds__(256) void thj_k_rehash_ins(const u64* old_keys, const u64* old_vals, u64 old_cap, u64* keys, u64* vals, u64 mask,
                                                         unsigned long long* count, unsigned int* ovf, u64* list) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < old_cap; i += (u64)gridDim.x * blockDim.x) {
         const u64 k = old_keys[i];
-        if (k != EMPTY) map_insert_min(keys, vals, mask, k, old_vals[i], count, ovf, list);
+        if (k != EMPTY) map_insert_min<true>(keys, vals, mask, k, old_vals[i], count, ovf, list);
     }
 }
 

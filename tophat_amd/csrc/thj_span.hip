@@ -79,7 +79,18 @@ struct RecSink {
         uint4* dst;
         if (order == 0) dst = (uint4*)(slots + (size_t)base + w[0]);
         else {
-            unsigned long long pos = THJ_EXPF(8192) ? (unsigned long long)(base + w[0]) : atomicAdd(ovf_count, 1ull);
+            // (the lanes of a wave that come here together -- the packed tier's chains of a read, a lane each -- take their places in the pool
+            // with one add: a launch of the mix puts half a million records there, on one address)
+            unsigned long long pos;
+            if (THJ_EXPF(8192)) pos = (unsigned long long)(base + w[0]);
+            else {
+                const unsigned long long act = __ballot(1);
+                const int lane = (int)(threadIdx.x & 63u);
+                unsigned long long b0 = 0;
+                if (lane == __ffsll((long long)act) - 1) b0 = atomicAdd(ovf_count, (unsigned long long)__popcll(act));
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b0), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b0 >> 32));
+                pos = (((unsigned long long)hi << 32) | lo) + (unsigned long long)__popcll(act & (lane ? (~0ull >> (64 - lane)) : 0ull));
+            }
             if (pos >= ovf_cap) { atomicExch(&status[3], 1u); return; }
             ovf_key[pos] = ((u64)(base + w[0]) << 16) | (u64)order;
             dst = (uint4*)(ovf + pos);
