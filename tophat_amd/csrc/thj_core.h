@@ -1007,8 +1007,9 @@ THJ_HD bool wave_read_enumerate(X& x, const Params& p, ReadView& v, Sink& sink, 
         wants_rescue = x.ballot(found) == 0ull && v.n_mate > 0;
     }
     if (wants_rescue) return true;
+    if (THJ_EXPF(1 << 27)) return true;
     // ---- find_insertions_and_deletions: the pairs (hit of segment i, hit of segment i + 1), :2856-2940
-    if (v.nseg >= 2)
+    if (v.nseg >= 2 && !THJ_EXPF(1 << 17))
         for (int i = 0; i + 2 < v.nseg; ++i) {
             const uint32_t lb = v.so[i], le = v.so[i + 1], re = v.so[i + 2];
             if (lb == le || le == re) break;                                  // :2869-2870
@@ -1033,6 +1034,7 @@ THJ_HD bool wave_read_enumerate(X& x, const Params& p, ReadView& v, Sink& sink, 
             }
         }
     // ---- find_gaps' body (:3499-3617)
+    if (THJ_EXPF(1 << 25)) return true;
     if (p.bowtie2)
         for (int s = 0; s < v.size; ++s) if (rv_count_raw(v, s) > p.max_seg_multihits) return true;      // :3499-3506
     for (int s = 0; s + 1 < v.size; ++s) {                  // (a hit of the last segment has nothing to its right: `found` from the start)
