@@ -706,11 +706,12 @@ static constexpr int PACK_MAXROOTS = 64, PACK_MAXHITS = 256, PACK_CHAINLIST = 12
 // five and more copies -- a draw of 32 could be ten rounds, and the slowest wave ran 570 us against a mean of 250 (THJ_PACK_TIMING).
 // THJ_PACK_DRAW: developer switch
 static const int PACK_DRAW_DEFAULT = 8;
+static constexpr int PACK_HEAVY_HITS = 48;      // a read with more hits than this is drawn in the first pass (twelve copies of a four-segment read and up)
 // Eight waves per workgroup, two workgroups per CU: 16 waves per CU is what 128 VGPRs allow, and a wave's 9 KB of LDS with the
 // workgroup's slice table fit the CU's 160 KB twice over that way (four workgroups of four waves do not: three were resident).
 static constexpr int PACK_TPB = 512;
 template <int MS, int PACK_TPB = 512, int PACK_WPE = 4>
-__global__ __launch_bounds__(PACK_TPB, PACK_WPE) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg, int draw) {
+__global__ __launch_bounds__(PACK_TPB, PACK_WPE) void thj_k_stitch_pack(Genome g, Params p, SpanSets S, DevSpanBatch b, RecSink sink, Tiers t, int G, unsigned long long* dbg, int draw, int heavy_draw) {
     __shared__ unsigned int s_off[MAX_SLICES + 1];
     __shared__ unsigned int s_rec;
     __shared__ PackLds<MS, PACK_MAXHITS, PACK_CHAINLIST> s_pack[PACK_TPB / 64];
@@ -720,22 +721,34 @@ __global__ __launch_bounds__(PACK_TPB, PACK_WPE) void thj_k_stitch_pack(Genome g
     const unsigned int total = slice_offsets<PACK_TPB>(t.blk_multi, G, s_off);
     unsigned long long tmk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
-    for (;;) {
-        unsigned int i0 = 0;
-        if (x.lane == 0) i0 = atomicAdd(&t.counters[3], (unsigned int)draw);
-        i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
-        if (i0 >= total) break;
-        const unsigned int i = i0 + (unsigned int)x.lane;
-        const bool has = x.lane < draw && i < total;
-        const int sl = has ? slice_of(s_off, G, i) : 0;
-        const uint32_t r = has ? t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])] : 0u;
-        const bool fwd = span_pack_wave<MS, PACK_MAXROOTS, PACK_MAXHITS, PACK_CHAINLIST>(x, g, p, S, b.hits, b.heads, b.seg_off, b.nseg, b.planes, b.W, b.read_len,
-                                                                                         b.quals, b.qual_stride, r, has, s_pack[wave], sink, dbg ? tmk : nullptr);
-        if (fwd) {
-            t.wl_gen[(int64_t)sl * t.chunk + atomicAdd(&t.blk_gen[sl], 1u)] = r;
-            atomicAdd(&t.counters[2], 1u);
+    // heavy_draw > 0: the list is walked twice -- first the reads with many hits (heavy_draw entries a draw, the others passed over), then
+    // the rest.  The launch ends when its last wave does, and a wave that draws a batch of 30-copy reads last is the tail (mean 335 us a
+    // wave, slowest 520: THJ_PACK_TIMING); the long batches go out first.
+    for (int pass = heavy_draw > 0 ? 0 : 1; pass < 2; ++pass) {
+        const int dr = pass == 0 ? heavy_draw : draw;
+        for (;;) {
+            unsigned int i0 = 0;
+            if (x.lane == 0) i0 = atomicAdd(&t.counters[pass == 0 ? 8 : 3], (unsigned int)dr);
+            i0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)i0);
+            if (i0 >= total) break;
+            const unsigned int i = i0 + (unsigned int)x.lane;
+            bool has = x.lane < dr && i < total;
+            const int sl = has ? slice_of(s_off, G, i) : 0;
+            const uint32_t r = has ? t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])] : 0u;
+            if (heavy_draw > 0) {
+                uint32_t nh = 0;
+                if (has) { const uint32_t* so = b.seg_off + (u64)r * (uint32_t)b.nseg; nh = so[b.nseg] - so[0]; }
+                has = has && (nh > (uint32_t)PACK_HEAVY_HITS) == (pass == 0);
+                if (x.ballot(has) == 0ull) continue;
+            }
+            const bool fwd = span_pack_wave<MS, PACK_MAXROOTS, PACK_MAXHITS, PACK_CHAINLIST>(x, g, p, S, b.hits, b.heads, b.seg_off, b.nseg, b.planes, b.W, b.read_len,
+                                                                                             b.quals, b.qual_stride, r, has, s_pack[wave], sink, dbg ? tmk : nullptr);
+            if (fwd) {
+                t.wl_gen[(int64_t)sl * t.chunk + atomicAdd(&t.blk_gen[sl], 1u)] = r;
+                atomicAdd(&t.counters[2], 1u);
+            }
+            x.wsync();
         }
-        x.wsync();
     }
     if (dbg && x.lane == 0) {             // THJ_PACK_TIMING: the phases' ticks (10 ns) summed over the waves, [8] a wave's whole time: sum, [9] max
         for (int k = 0; k < 8; ++k) atomicAdd(&dbg[k], tmk[k]);
@@ -1360,11 +1373,13 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
         static const int pack_wpe = getenv("THJ_PACK_WPE") ? atoi(getenv("THJ_PACK_WPE")) : 3;
         static const int pack_draw_env = getenv("THJ_PACK_DRAW") ? atoi(getenv("THJ_PACK_DRAW")) : 0;
         const int pack_draw = pack_draw_env >= 1 && pack_draw_env <= 64 ? pack_draw_env : (chains ? PACK_DRAW_DEFAULT : 32);
+        static const int pack_heavy_env = getenv("THJ_PACK_HEAVY_DRAW") ? atoi(getenv("THJ_PACK_HEAVY_DRAW")) : 0;          // developer switch (0, the default: one pass; measured 32: 0.42 ms, 16: 0.32, one pass: 0.345)
+        const int pack_heavy = chains && pack_heavy_env >= 1 && pack_heavy_env <= 64 ? pack_heavy_env : 0;
         SPK_BEGIN(SPK_PACK, sp);
-        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
-        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
-        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
-        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw);
+        if (b.nseg <= 4 && pack_wpe == 3) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 3>), dim3((unsigned)((g2 * 3 + 3) / 4)), dim3(256), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw, pack_heavy);
+        else if (b.nseg <= 4 && pack_wpe == 2) hipLaunchKernelGGL((thj_k_stitch_pack<4, 256, 2>), dim3((unsigned)((g2 + 1) / 2)), dim3(256), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw, pack_heavy);
+        else if (b.nseg <= 4) hipLaunchKernelGGL(thj_k_stitch_pack<4>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw, pack_heavy);
+        else if (b.nseg <= SPAN_MIDSEG) hipLaunchKernelGGL(thj_k_stitch_pack<SPAN_MIDSEG>, dim3((unsigned)((g2 + 1) / 2)), dim3(PACK_TPB), 0, sp, g, p, S, b, sink, tpk, (int)G, d_dbg, pack_draw, pack_heavy);
         // (reads of more than eight segments: the packed tier keeps a chain's choices in eight bytes -- the general kernel takes the multihit list as it is)
         SPK_END(SPK_PACK, sp);
         if (pack_timing) {
