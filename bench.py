@@ -1375,7 +1375,7 @@ def run_rank(args, rank, world, local_rank, control, shared):
         pm = pmc_traffic_in_run(args) if rank == 0 and world == 1 else None
         traffic_in_run = pm is not None
         if pm is None:
-            pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r04_plain_pmc_traffic.json" if args.multihit_frac == 0 and args.indel_frac == 0 else "r05_pmc_traffic.json"))))
+            pm = json.load(open(os.path.join(ROOT, "profiles", os.environ.get("THJ_PMC_FILE", "r04_plain_pmc_traffic.json" if args.multihit_frac == 0 and args.indel_frac == 0 else "r06_pmc_traffic.json"))))
         want_cfg = {"pairs_per_gpu": args.pairs, "genome_len": genome_len, "exon_len": args.exon_len}
         if args.multihit_frac > 0 or args.indel_frac > 0:
             want_cfg.update(multihit_frac=args.multihit_frac, indel_frac=args.indel_frac, max_copies=args.max_copies)
