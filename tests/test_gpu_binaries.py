@@ -183,6 +183,24 @@ def test_results_do_not_depend_on_shards_or_workers(tmp_path):
     assert index_positions(bam1) == index_positions(bam2) and len(index_positions(bam1)) > 20
 
 
+def test_eight_contexts_with_the_exchange_step_equal_one(tmp_path):
+    """configs[2]'s rehearsal in small: eight ranks as eight contexts on the device -- the 8-way shard dealing, the exchange
+    step over the loopback transport with eight sections -- against one context: identical event files, identical BAM stream.  With event tables
+    made small (THJ_TABLE_CAPS) every rank's own deletions fit its table and the eight sections together do not: the table fills up while
+    the gathered keys are merged, is reported full (not walked slot by slot: round 6), grows to what the headers ask for and the merge is repeated."""
+    d = str(tmp_path / "gen8")
+    subprocess.check_call([os.path.join(ROOT, "tools", "bin", "thj_gen"), "--out", d, "--pairs", "60000", "--genome-len", "3000000", "--introns", "1200",
+                           "--threads", "8", "--indel-frac", "0.03"], stdout=subprocess.DEVNULL)
+    one, bam1, log1 = _run_both(d, tmp_path, "c1", {"THJ_CTX_PER_GPU": "1", "THJ_TIMING": "1"})
+    eight, bam8, log8 = _run_both(d, tmp_path, "c8", {"THJ_CTX_PER_GPU": "8", "THJ_SHARDS": "16", "THJ_TIMING": "1"})
+    small, bam8s, log8s = _run_both(d, tmp_path, "c8s", {"THJ_CTX_PER_GPU": "8", "THJ_SHARDS": "16", "THJ_TABLE_CAPS": "4096,512", "THJ_TIMING": "1"})
+    n_del = one["deletions"].count("\n")
+    assert n_del > 600 and one["juncs"].count("\n") > 500
+    assert one == eight and one == small
+    assert gzip.open(bam1, "rb").read() == gzip.open(bam8, "rb").read() == gzip.open(bam8s, "rb").read()
+    assert "a table filled up while the ranks' keys were merged" in log8s and "a table filled up" not in log8
+
+
 def test_packed_genome_cache(tmp_path):
     """segment_juncs packs the reference and leaves the blocks beside its outputs; long_spanning_reads -- and a second segment_juncs --
     map that file instead of parsing the FASTA: the same results as with the cache off; a FASTA that has changed since (other

@@ -338,6 +338,8 @@ static int x_finish_check(thj_ctx* c, const unsigned int* ovf_now) {
         const bool gj = ovf_now[0] != 0, gdi = (ovf_now[1] | ovf_now[2]) != 0;
         do { rc = grow_tables(c, gj, gdi); } while (rc == THJ_OK && ((gj && (u64)c->junc_cap * 2 < sj * 5 && c->junc_cap < (1ll << 34)) || (gdi && (u64)c->indel_cap * 2 < sdi * 5 && c->indel_cap < (1ll << 34))));
         if (rc) return rc;
+        if (getenv("THJ_TIMING")) fprintf(stderr, "[exchange] a table filled up while the ranks' keys were merged (%llu junctions, %llu deletions, %llu insertions gathered): grown to %lld / %lld slots, merged again\n",
+                                          (unsigned long long)sj, (unsigned long long)sd, (unsigned long long)si, (long long)c->junc_cap, (long long)c->indel_cap);
         HIPCHK(hipMemsetAsync(c->d_ovf, 0, 3 * sizeof(unsigned int), c->stream));      // (word 3, the task list's flag, is not the merge's to clear)
         if ((rc = x_merge_launch(c, m))) return rc;
         return 1;

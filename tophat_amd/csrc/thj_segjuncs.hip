@@ -1206,7 +1206,13 @@ extern "C" int thj_ctx_create(int device, void* stream, thj_ctx** out) {
     HIPCHK(hipMalloc(&c->d_cnt, CNT_N * sizeof(unsigned long long)));
     HIPCHK(hipMalloc(&c->d_out_n, 4 * sizeof(unsigned long long)));
     HIPCHK(hipHostMalloc(&c->h_pinned, 48 * sizeof(unsigned long long)));
-    int rc = alloc_tables(c, 1ll << 24, 1ll << 20);
+    // THJ_TABLE_CAPS=j,i: test knob -- small event tables (slots, powers of two), so that the growth paths run on a small case
+    int64_t cap_j = 1ll << 24, cap_i = 1ll << 20;
+    if (const char* e = getenv("THJ_TABLE_CAPS")) {
+        long long a = 0, b = 0;
+        if (sscanf(e, "%lld,%lld", &a, &b) == 2 && a >= 64 && b >= 64 && !(a & (a - 1)) && !(b & (b - 1))) { cap_j = a; cap_i = b; }
+    }
+    int rc = alloc_tables(c, cap_j, cap_i);
     if (rc) { delete c; return rc; }
     rc = reset_tables_async(c);
     if (rc) { delete c; return rc; }
