@@ -494,6 +494,14 @@ def compact_line(result):
         c3 = e.get("config3_full")
         if isinstance(c3, dict):
             m["config3_full"] = _pick(c3, ("pairs", "seconds", "ranks", "outputs_identical", "value", "error"))
+        else:
+            # configs[2] at full size takes ten minutes and is not part of a default run (--e2e-config3-pairs): the line points at the committed
+            # record of the last such run, labelled as what it is
+            try:
+                rec = json.load(open(os.path.join(ROOT, "profiles", "r06_config3_full_after_probe_cap.json")))
+                m["config3_full_recorded"] = dict(_pick(rec, ("pairs", "seconds", "ranks", "outputs_identical", "value")), not_measured_in_this_run="profiles/r06_config3_full_after_probe_cap.json")
+            except (OSError, ValueError):
+                pass
         f2f = e.get("cpu_files_to_files")
         if isinstance(f2f, dict):
             m["cpu_files_identical"] = f2f.get("outputs_identical_to_the_gpu_executables")
