@@ -571,6 +571,8 @@ def e2e_leg(args, n_gpus=1):
     from e2e_bench import mix_gen_args, run_e2e
     gen_args = mix_gen_args(args.multihit_frac, args.max_copies, args.indel_frac)      # the same mix as the resident-data line
     d = tempfile.mkdtemp(prefix="thj_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    if n_gpus > 1:
+        os.environ.setdefault("THJ_STAGE_TIMEOUT", "300")       # (an executable that hangs on its first multi-GPU collective is an error after five minutes, not ten)
     try:
         # the executables drive every GPU they can see (read-id shards round-robin over the contexts): the first n_gpus devices here
         gpu_env = {"HIP_VISIBLE_DEVICES": ",".join(str(k) for k in range(n_gpus))}
@@ -643,7 +645,7 @@ def e2e_leg(args, n_gpus=1):
                 out["fixed_s"] = t0 - n0 / out["rate_pairs_per_s"]
         except (RuntimeError, OSError, subprocess.CalledProcessError) as e:
             out["large"] = {"error": str(e)[-300:]}
-    if getattr(args, "e2e_grch38_pairs", 0) > 0:
+    if getattr(args, "e2e_grch38_pairs", 0) > 0 and n_gpus == 1:      # (a multi-GPU job keeps its files leg to the two points above: the other ranks wait for it)
         # configs[2]'s genome: where the reference itself costs seconds per process.  Run 1 finds no packed-genome cache (segment_juncs
         # parses the FASTA, packs it and leaves the cache beside its outputs; the two long_spanning_reads map it), run 2 finds it.
         from e2e_bench import GRCH38_LENS
