@@ -158,9 +158,12 @@ if __name__ == "__main__":
     ap.add_argument("--max-copies", type=int, default=41)
     ap.add_argument("--indel-frac", type=float, default=0.03)
     ap.add_argument("--plain", action="store_true", help="configs[1] without the mix (rounds 1-3)")
+    ap.add_argument("--intron-max", type=int, default=0, help="longest planted intron (configs[4]: 499999); 0: the generator's default")
     ap.add_argument("--env", nargs="*", default=[])
     a = ap.parse_args()
     ga = [] if a.plain else mix_gen_args(a.multihit_frac, a.max_copies, a.indel_frac)
+    if a.intron_max > 0:
+        ga += ["--intron-max", str(a.intron_max)]
     if a.grch38:
         ga += ["--contigs", ",".join(str(x) for x in GRCH38_LENS)]
     res = run_e2e(a.pairs, a.read_len, sum(GRCH38_LENS) if a.grch38 else a.genome_len, a.introns, workdir=a.keep, env_extra=dict(x.split("=", 1) for x in a.env), keep=bool(a.keep),
