@@ -1,4 +1,5 @@
 """GPU parity: thj_k_fusion through the C ABI against the CPU oracle (exact FusionSimpleSet: keys, counts, edit distances)."""
+import numpy as np
 import pytest
 
 import orc
@@ -43,3 +44,43 @@ def test_fusion_ignore_chromosomes_gpu():
         got = ctx.fusions(runs, ignore_ref_ids=[2])
         assert got.tolist() == want.tolist() and len(want) > 10
         assert len(ctx.fusions(runs)) > len(want)          # the ignore set is cleared by passing none
+
+
+def test_fusion_event_buffer_grows(monkeypatch):
+    """the raw candidate events of a pass pile up until thj_fusion_finish reduces them; the buffer grows ahead of the count (round 6: configs[3] at
+    full size had 9.9 M of them in a buffer of 1 M).  THJ_FUSION_CAP=1024 and the same batches twelve times over in one pass: more raw events than
+    the buffer first held, every count twelve times the oracle's -- and a single batch that does not fit half the buffer is still an error"""
+    import ctypes as C
+    cfg = FUSION_CASES[0]
+    case, batches = fusion_batches(cfg, n_reads=500)
+    seqs = [orc.fold_genome_char(s) for s in case.seqs]
+    g = orc.Genome(seqs)
+    want = None
+    for p, b in batches:
+        f = orc.fusions(p, g, b, p.fusion_anchor_length, p.fusion_min_dist)
+        want = f if want is None else orc.merge_fusions(want, f)
+    raw = int(sum(int(x["count"]) for x in want))
+    assert 40 < raw < 500
+    monkeypatch.setenv("THJ_FUSION_CAP", "1024")
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        ups = [(p, ctx.upload_batch(b)) for p, b in batches]
+        host._check(ctx.lib, ctx.lib.thj_fusion_reset_async(ctx._ctx), "thj_fusion_reset_async")
+        for _ in range(12):
+            for p, b in ups:
+                cp = p.as_ctypes()
+                host._check(ctx.lib, ctx.lib.thj_fusion_run_async(ctx._ctx, C.byref(cp), C.byref(b) if isinstance(b, host.CSegBatch) else b), "thj_fusion_run_async")
+                ctx.sync()                   # (the count has arrived when the next call looks: the growth is then certain, not a matter of timing)
+        n = C.c_int64()
+        host._check(ctx.lib, ctx.lib.thj_fusion_finish(ctx._ctx, C.byref(n)), "thj_fusion_finish")
+        assert 12 * raw > 1024 and n.value == len(want)
+        got = np.zeros(max(1, n.value), dtype=host.FUSION_DTYPE)
+        host._check(ctx.lib, ctx.lib.thj_fusion_download(ctx._ctx, host._ptr(got)), "thj_fusion_download")
+    key = lambda x, m: tuple(int(x[k]) for k in ("ref_id1", "ref_id2", "left", "right", "dir")) + (int(x["count"]) * m, int(x["edit_dist"]))
+    assert [key(x, 1) for x in got[:len(want)]] == [key(x, 12) for x in want]
+    monkeypatch.setenv("THJ_FUSION_CAP", "64")
+    with host.Context(0) as ctx:
+        ctx.upload_genome(host.pack_genome(seqs))
+        ups = [(p, ctx.upload_batch(b)) for p, b in batches]
+        with pytest.raises(host.ThjError, match="fusion event buffer overflow"):
+            ctx.fusions(ups)

@@ -99,6 +99,7 @@ struct thj_ctx {
     u64 cov_filter_mask = 0; int32_t cov_min_intron = 0, cov_max_intron = 0; bool cov_pending = false;
     // fusion search
     thj_fusion* d_fus = nullptr; unsigned long long* d_fus_count = nullptr; int64_t fus_cap = 0;
+    hipEvent_t fus_probe_ev = nullptr; bool fus_probe_pending = false;      // the raw event count on its way to h_pinned[44] (the buffer grows ahead of it)
     std::vector<thj_fusion> h_fusions;
     thj_fusion* d_fus_out = nullptr; int64_t n_fus_out = 0;            // the reduced set on the device (Fusion::operator< order); null: only h_fusions holds it
     bool h_fus_stale = false;                                          // h_fusions not yet copied down from d_fus_out

@@ -1250,6 +1250,7 @@ extern "C" void thj_ctx_destroy(thj_ctx* c) {
     hipHostFree(c->h_pinned);
     thj_span_free(c); thj_bamout_free(c);
     cov_free(c);
+    if (c->fus_probe_ev) (void)hipEventDestroy(c->fus_probe_ev);
     hipFree(c->d_fus); hipFree(c->d_fus_count); hipFree(c->d_ing0); hipFree(c->d_ing1); hipFree(c->d_infl_tmp); thj_dev_cache_free(c);
     for (hipEvent_t e : c->prof_all) hipEventDestroy(e);
     for (auto e : c->event_pool) hipEventDestroy(e);
@@ -1750,10 +1751,12 @@ extern "C" int thj_fusion_reset_async(thj_ctx* c) {
     HIPCHK(hipSetDevice(c->device));
     if (!c->d_fus_count) {
         HIPCHK(hipMalloc(&c->d_fus_count, 16));
-        c->fus_cap = 1 << 20;
+        c->fus_cap = 1 << 22;                   // (grows: thj_fusion_run_async)
+        if (const char* e = getenv("THJ_FUSION_CAP")) { const long long v = atoll(e); if (v >= 64) c->fus_cap = v; }      // test knob: a small buffer, so that it has to grow
         HIPCHK(hipMalloc(&c->d_fus, (size_t)c->fus_cap * sizeof(thj_fusion)));
     }
     HIPCHK(hipMemsetAsync(c->d_fus_count, 0, 16, c->stream));
+    if (c->fus_probe_pending) { (void)hipEventSynchronize(c->fus_probe_ev); c->fus_probe_pending = false; }
     c->h_fusions.clear();
     fusion_drop_device_set(c);
     return THJ_OK;
@@ -1787,12 +1790,40 @@ extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_
     Genome g{c->d_blocks, c->d_contig_blk, c->d_contig_len, c->n_contigs};
     Params p; memcpy(&p, tp, sizeof p);
     DevBatch b; memcpy(&b, db, sizeof b);
+    // The raw candidate events of a pass pile up until thj_fusion_finish reduces them (round 6: configs[3] at full size -- 50 M pairs of the
+    // mix -- has 9.9 M of them, the buffer held 1 M: a loud error, but an error).  The buffer now grows ahead of the count: after every launch
+    // the count sets out for the host, the next call looks at what has arrived and, past half the room, moves the events to a buffer four
+    // times the size (one stream synchronisation per growth; no wait otherwise).  A single batch that adds more than half the buffer still
+    // overflows and is reported by thj_fusion_finish.
+    if (!c->fus_probe_ev) HIPCHK(hipEventCreateWithFlags(&c->fus_probe_ev, hipEventDisableTiming));
+    if (c->fus_probe_pending && hipEventQuery(c->fus_probe_ev) == hipSuccess) {
+        c->fus_probe_pending = false;
+        if ((int64_t)c->h_pinned[44] * 2 > c->fus_cap && c->fus_cap < (1ll << 30)) {
+            unsigned long long h[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(h, c->d_fus_count, 16, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (!(unsigned int)h[1]) {                                  // (an overflow that has happened stays one)
+                int64_t ncap = c->fus_cap * 4;
+                while (ncap < (int64_t)h[0] * 4) ncap *= 2;
+                thj_fusion* nb = nullptr;
+                HIPCHK(hipMalloc(&nb, (size_t)ncap * sizeof(thj_fusion)));
+                if (h[0]) HIPCHK(hipMemcpy(nb, c->d_fus, (size_t)h[0] * sizeof(thj_fusion), hipMemcpyDeviceToDevice));
+                hipFree(c->d_fus);
+                c->d_fus = nb; c->fus_cap = ncap;
+            }
+        }
+    }
     FusionSink sink{c->d_fus, c->d_fus_count, (unsigned long long)c->fus_cap, (unsigned int*)(c->d_fus_count + 1),
                     c->d_fus_ignore, (uint32_t)c->n_fus_ignore};
     int64_t blocks = ((int64_t)b.n_reads + 255) / 256;
     if (blocks > 768) blocks = 768;         // three workgroups per CU (168 VGPRs); each walks ~n_tiles / 768 tiles, its candidate pairs pile up
     hipLaunchKernelGGL(thj_k_fusion, dim3((unsigned)blocks), dim3(256), 0, c->stream, g, p, b, sink);
     HIPCHK(hipGetLastError());
+    if (!c->fus_probe_pending) {
+        HIPCHK(hipMemcpyAsync(&c->h_pinned[44], c->d_fus_count, 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipEventRecord(c->fus_probe_ev, c->stream));
+        c->fus_probe_pending = true;
+    }
     return THJ_OK;
 }
 
