@@ -741,7 +741,7 @@ THJ_HD int span_read(const Genome& g, const Params& p, const SpanSets& S, const 
                     ok = merge_chain(g, p, S, anti ? rev : fwd, chain, nsegs, bh);
                 } else { bh = stack[0]; ok = true; }
                 if (ok && valid_hit(p, bh)) {
-                    if (nj < cap) joined[nj++] = bh; else status = SPAN_TOO_MANY_JOINED;
+                    if (nj < cap) joined[nj++] = bh; else return SPAN_TOO_MANY_JOINED;      // (nothing is emitted then: the read is done again with room, or reported)
                 }
                 --depth;
                 continue;

@@ -837,7 +837,7 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
                 } else {
                     FHit bh;
                     f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
-                    if (bh.n) status = SPAN_TOO_MANY_JOINED;
+                    if (bh.n) return SPAN_TOO_MANY_JOINED;       // (nothing is emitted then, whatever the rest of the search finds: the read is done again with room, or reported -- no need to finish 10 000 tries per first-segment hit first)
                 }
                 --d;
                 if (d >= 1 && dirty[d]) stack[d - 1] = saved[d];
