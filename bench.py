@@ -1182,7 +1182,16 @@ def run_rank(args, rank, world, local_rank, control, shared):
             ctx.span_run(p_span, sp_right)
         else:
             timed("span_run_pair", ctx.span_run_pair, p_span, sp_left, sp_right)          # both sides as one call: the two sides' kernels run beside each other
-        n_alns = timed("span_finish", ctx.span_finish)
+        try:
+            n_alns = timed("span_finish", ctx.span_finish)
+        except host.ThjError as e:
+            # THJ_ERETRY: a pool or the workspace for reads with many joined alignments was set up by this call (a repeat family under
+            # --fusion-search): the pass is run again, as the executables and host.Context.spanning do; it happens in the first warm-up step only
+            if "run the pass again" not in str(e):
+                raise
+            ctx.span_reset()
+            ctx.span_run_pair(p_span, sp_left, sp_right)
+            n_alns = ctx.span_finish()
         return cnt, n_alns
 
     def barrier():
