@@ -491,6 +491,13 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
 // ---- --fusion-search: tier 0 as the kernel runs it, then thj_span_fusion.h for every read it does not finish
 #include "../../tophat_amd/csrc/thj_span_fusion.h"
 
+struct FusWaveSim {
+    simt::Block* b; int tid, lane;
+    void sync() { b->barrier(); }
+    uint32_t atomic_add(uint32_t* q, uint32_t v) { const uint32_t o = *q; *q = o + v; return o; }
+    unsigned long long ballot(bool q) { const uint32_t* a = b->exchange(tid, q ? 1u : 0u); unsigned long long m = 0; for (int i = 0; i < 64; ++i) m |= (unsigned long long)(a[i] & 1u) << i; return m; }
+};
+
 extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk,
                                        const int32_t* contig_len, int32_t n_contigs,
                                        int32_t n_reads, int32_t nseg, int32_t W, const uint32_t* seg_off, const void* hits,
@@ -512,6 +519,7 @@ extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blo
     std::vector<OutAln> res;
     VecSink sink{&res};
     for (int k = 0; k < 5; ++k) status_counts[k] = 0;
+    const int fuswave_cap = getenv("THJ_HOSTSIM_FUSWAVE") ? atoi(getenv("THJ_HOSTSIM_FUSWAVE")) : 0;      // joined alignments the wave's workspace holds
     for (int32_t r = 0; r < n_reads; ++r) {
         int st = SPAN_NEED_GENERIC;
         if (!skip_tier0)
@@ -526,7 +534,24 @@ extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blo
             (void)before;
             if (st == SPAN_INCOMPAT) st = p.fusion_search ? SPAN_NEED_GENERIC : SPAN_OK;
         }
-        if (st == SPAN_NEED_GENERIC) {
+        if (st == SPAN_NEED_GENERIC && fuswave_cap > 0) {        // thj_k_stitch_huge's way: the 64 lanes of a wave on the read (fusion_read_wave)
+            status_counts[3]++;
+            std::vector<OutAln> mine;
+            VecSink ws_sink{&mine};
+            std::vector<char> wsp(fus_wave_ws_bytes(fuswave_cap));
+            FusWaveShared sh;
+            int sts[64], nrec[64];
+            simt::run_block(64, [&](simt::Block& blk, int tid) {
+                FusWaveSim x{&blk, tid, tid};
+                sts[tid] = fusion_read_wave(x, g, p, S, F, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                                            read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, ws_sink, wsp.data(), fuswave_cap, sh, nrec[tid]);
+            }, 256 * 1024);
+            for (int l = 1; l < 64; ++l) if (sts[l] != sts[0] || nrec[l] != nrec[0]) return -12;      // the verdict and the count are the wave's
+            if ((size_t)nrec[0] != mine.size()) return -13;
+            std::stable_sort(mine.begin(), mine.end(), [](const OutAln& a, const OutAln& b) { return a.order < b.order; });
+            for (size_t k = 0; k < mine.size(); ++k) { if (mine[k].order != k) return -14; res.push_back(mine[k]); }
+            st = sts[0];
+        } else if (st == SPAN_NEED_GENERIC) {
             status_counts[3]++;
             st = span_read_fusion(g, p, S, F, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                                   read_len[r], quals + (int64_t)r * qual_stride, (uint32_t)r, sink);

@@ -272,6 +272,19 @@ def test_reads_with_more_joined_alignments_than_a_thread_keeps():
         wantf = orc.spanning_fusion(pf, orc.Genome([seq2]), sb2, nj, [], np.zeros(0, dtype=orc.SPAN_FUSION_DTYPE), True)
         assert len(wantf) == 30 * 10
         assert ctx.spanning(pf, [ctx.upload_span_batch(sb2)]) == wantf
+        # ... and with the break points between the copies known (what segment_juncs --fusion-search lists for such reads) every first-segment
+        # hit joins with every other copy's hits: 3 * k * (k - 1) + k alignments a read, found by the 64 lanes of a wave (fusion_read_wave)
+        from test_hostsim_spanning import repeat_fusion_list
+        for copies, n_reads in ((14, 40), (40, 70)):
+            seq3, sb3 = repeat_span_batch(copies=copies, n_reads=n_reads, seed=80 + copies)
+            fl = repeat_fusion_list(sb3)
+            pw = Params(fusion_search=1, fusion_min_dist=300, max_report_intron=300)
+            wantw = orc.spanning_fusion(pw, orc.Genome([seq3]), sb3, nj, [], fl, True)
+            assert len(wantw) == n_reads * (3 * copies * (copies - 1) + copies)
+            ctx.upload_genome(host.pack_genome([seq3]))
+            ctx.upload_span_sets(nj, [])
+            ctx.upload_span_fusions(fl)
+            assert ctx.spanning(pw, [ctx.upload_span_batch(sb3)]) == wantw
 
 
 def test_more_records_per_read_than_the_count_byte_holds():

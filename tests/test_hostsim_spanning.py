@@ -109,3 +109,47 @@ def test_many_joined_alignments_per_read():
     assert status[1] == 0
     got.sort(key=lambda a: a.read_idx)       # stable: the records of one read keep their emission order
     assert got == want
+
+
+def repeat_fusion_list(sb):
+    """what segment_juncs --fusion-search reports for the reads of repeat_span_batch when the copies lie further apart than the longest
+    intron: a break point at every segment boundary, between any two copies, in both orders"""
+    import numpy as np
+    rows = set()
+    h = sb.hits
+    for r in range(sb.n_reads):
+        so = sb.seg_off[r * sb.nseg:(r + 1) * sb.nseg + 1]
+        for s_ in range(sb.nseg - 1):
+            for a in h[so[s_]:so[s_ + 1]]:
+                for b_ in h[so[s_ + 1]:so[s_ + 2]]:
+                    if int(b_["left"]) != int(a["left"]) + 25:
+                        rows.add((1, 1, int(a["left"]) + 24, int(b_["left"]), 7))
+                        rows.add((1, 1, int(b_["left"]), int(a["left"]) + 24, 7))
+    return np.array(sorted(rows), dtype=orc.SPAN_FUSION_DTYPE)
+
+
+def test_fusion_search_of_a_repeat_read_by_the_wave(monkeypatch):
+    """thj_k_stitch_huge under --fusion-search puts the 64 lanes of a wave on one read (fusion_read_wave: a lane a first-segment
+    hit, the common list put back in the one-thread order, index merge sort, a lane a record).  The same function over the fibers
+    of tests/hostsim/simt.h against the oracle, on reads whose every segment hits all copies of a tandem repeat; with a workspace
+    too small for a read's list the read is reported (SPAN_TOO_MANY_JOINED) and nothing of it is emitted."""
+    import numpy as np
+    from tophat_amd.batch import JUNC_DTYPE
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    for copies, n_reads in ((3, 12), (14, 6), (70, 2)):           # (70: more first-segment hits than lanes)
+        seq, sb = repeat_span_batch(copies=copies, n_reads=n_reads, seed=60 + copies)
+        p = Params(fusion_search=1, fusion_min_dist=300, max_report_intron=300, max_seg_multihits=100)         # (the copies lie 400 apart on one contig)
+        nf = repeat_fusion_list(sb)
+        want = orc.spanning_fusion(p, orc.Genome([seq]), sb, nj, [], nf, True)
+        per_read = {}
+        for a in want:
+            per_read[a.read_idx] = per_read.get(a.read_idx, 0) + 1
+        assert max(per_read.values()) > copies
+        monkeypatch.setenv("THJ_HOSTSIM_FUSWAVE", "16384")
+        got, status = sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)
+        assert status[1] == 0 and status[2] == 0
+        assert got == want, copies
+        monkeypatch.setenv("THJ_HOSTSIM_FUSWAVE", str(min(per_read.values()) - 1))       # no read's list fits
+        got, status = sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)
+        assert got == [] and status[1] == sb.n_reads
+        monkeypatch.delenv("THJ_HOSTSIM_FUSWAVE")

@@ -812,10 +812,34 @@ static constexpr int HUGE_BLOCKS = 64, HUGE_CAP = 8192, HUGE_LIST_CAP = 1 << 16;
 static constexpr int HUGE_REC_BYTES = 128;               // >= sizeof(Aln), sizeof(FHit)
 static constexpr size_t HUGE_WS_BYTES = (size_t)HUGE_BLOCKS * 2 * HUGE_CAP * HUGE_REC_BYTES;      // one scratch set's workspace
 static_assert(sizeof(Aln) <= HUGE_REC_BYTES && sizeof(FHit) <= HUGE_REC_BYTES, "workspace record size");
-__global__ __launch_bounds__(64) void thj_k_stitch_huge(Genome g, Params p, SpanSets S, FusionSet F, DevSpanBatch b, RecSink sink, Tiers t, char* ws, int cap) {
-    if (threadIdx.x != 0) return;
+struct FusWaveDev {
+    int lane;
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ uint32_t atomic_add(uint32_t* q, uint32_t v) { return atomicAdd(q, v); }
+    __device__ __forceinline__ unsigned long long ballot(bool q) { return __ballot(q); }
+};
+static_assert(fus_wave_ws_bytes(HUGE_CAP) <= (size_t)2 * HUGE_CAP * HUGE_REC_BYTES, "a workgroup's slice of the workspace holds fusion_read_wave's arrays");
+__global__ __launch_bounds__(64) void thj_k_stitch_huge(Genome g, Params p, SpanSets S, FusionSet F, DevSpanBatch b, RecSink sink, Tiers t, char* ws, int cap, int by_wave) {
     const unsigned int n = *t.huge_cnt < (unsigned int)t.huge_list_cap ? *t.huge_cnt : (unsigned int)t.huge_list_cap;
     char* mine = ws + (size_t)blockIdx.x * 2 * (size_t)cap * HUGE_REC_BYTES;
+    if (p.fusion_search && by_wave) {                                // the wave on a read (fusion_read_wave)
+        __shared__ FusWaveShared sh;
+        FusWaveDev x{(int)threadIdx.x};
+        for (unsigned int i = blockIdx.x; i < n; i += gridDim.x) {
+            const int r = (int)t.huge_list[i];
+            int n_rec = 0;
+            const int st = fusion_read_wave(x, g, p, S, F, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W, (int)b.read_len[r],
+                                            b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink, mine, cap, sh, n_rec);
+            sink.emitted = 0;
+            if (threadIdx.x == 0) {
+                sink.set_count((uint32_t)r, n_rec);
+                if (st) atomicAdd(&sink.status[st], 1u);
+            }
+        }
+        if (sink.acc) atomicAdd(sink.total, (unsigned long long)sink.acc);
+        return;
+    }
+    if (threadIdx.x != 0) return;
     for (unsigned int i = blockIdx.x; i < n; i += gridDim.x) {
         const int r = (int)t.huge_list[i];
         const uint32_t* so = b.seg_off + (size_t)r * b.nseg;
@@ -1411,7 +1435,8 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     if (c->d_huge_ws && sg != sm) { HIPCHK(hipEventRecord(ev_fork, sg)); HIPCHK(hipStreamWaitEvent(sm, ev_fork, 0)); }      // (the fork's wait is long enqueued: the event is free)
     if (c->d_huge_ws) {        // a pass that met a read with too many joined alignments runs with the workspace from then on
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
-        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws + (size_t)set * HUGE_WS_BYTES, HUGE_CAP);
+        static const int huge_by_wave = getenv("THJ_HUGE_ONE_LANE") ? 0 : 1;      // developer switch: the fusion reads of the list by lane 0 alone (rounds 4-5)
+        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws + (size_t)set * HUGE_WS_BYTES, HUGE_CAP, huge_by_wave);
     }
     HIPCHK(hipGetLastError());
     return THJ_OK;

@@ -793,32 +793,40 @@ THJ_HD void f_emit(Sink& sink, uint32_t read_idx, int order, const FHit& h, cons
     sink.emit_words(wds);
 }
 
-// One read: JoinSegmentsWorker body (long_spanning_reads.cpp:2767-2831) with fusion search on.
-// work: FHit[3 * (FUS_MAXSEG + 1)] of per-thread memory (stack, saved stack tops, chain).
-template <class Sink>
-THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
-                            int nseg, const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink, FHit* ext = nullptr, int ext_cap = 0) {
-    if (so[1] == so[0]) return SPAN_OK;
+// One read: JoinSegmentsWorker body (long_spanning_reads.cpp:2767-2831) with fusion search on, in three parts (round 6) so that the search
+// from each first-segment hit -- the reference gives each its own 10 000 tries, :2634-2664, and they share nothing but the list they
+// append to -- can run on a thread of its own (fusion_read_wave below): fusion_read_nsegs (the worker's early outs), fusion_search_roots (the
+// dfs from the first-segment hits [i0_begin, i0_end), appending to joined[nj ..)), fusion_tail (sort, unique, filters, records).
+// span_read_fusion is the three in a row.
+THJ_HD int fusion_read_nsegs(const Params& p, const SpanHit* hits, const uint32_t* so, int nseg) {      // 0: nothing for this read
+    if (so[1] == so[0]) return 0;
     int nsegs = 0;
     while (nsegs < nseg && so[nsegs + 1] > so[nsegs]) ++nsegs;
     if (nsegs > FUS_MAXSEG) nsegs = FUS_MAXSEG;
-    if (!(hits[so[nsegs - 1]].meta & SH_END)) return SPAN_OK;
+    if (!(hits[so[nsegs - 1]].meta & SH_END)) return 0;
     if (p.bowtie2)
         for (int s = 0; s < nsegs; ++s)
-            if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return SPAN_OK;
-    if (THJ_EXPF(1 << 30)) return SPAN_OK;
+            if ((int)(so[s + 1] - so[s]) > p.max_seg_multihits) return 0;
+    if (THJ_EXPF(1 << 30)) return 0;
+    return nsegs;
+}
+// returns SPAN_OK, or SPAN_TOO_MANY_JOINED when a joined alignment found no room (nothing of the read is emitted then)
+// Out: where the joined alignments go.  slot(tmp) = where the next one is built, commit(slot) = it is one (false: no room)
+struct FusListOut {                     // a thread's own list
+    FHit* joined; int cap; int nj;
+    THJ_HD FHit* slot(FHit& tmp) { return nj < cap ? &joined[nj] : &tmp; }
+    THJ_HD bool commit(FHit*) { if (nj >= cap) return false; ++nj; return true; }
+};
+template <class Out>
+THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
+                               const FRead& rd, int nsegs, uint32_t i0_begin, uint32_t i0_end, Out& out) {
     const int fs = p.fusion_search;
-    FRead rd{rp, W, rl, p.segment_length, nsegs, qual};
-    FHit joined_local[FUS_MAXJOIN];               // ext: see span_read
-    FHit* joined = ext ? ext : joined_local;
-    const int cap = ext ? ext_cap : FUS_MAXJOIN;
-    int nj = 0;
     FHit stack[FUS_MAXSEG + 1], saved[FUS_MAXSEG + 1], chain[FUS_MAXSEG + 1];
     uint32_t idx[FUS_MAXSEG + 1];
     int fdir[FUS_MAXSEG + 2];
     bool dirty[FUS_MAXSEG + 2];
     int status = SPAN_OK;
-    for (uint32_t i0 = so[0]; i0 < so[1]; ++i0) {                           // :2634-2664
+    for (uint32_t i0 = i0_begin; i0 < i0_end; ++i0) {                       // :2634-2664
         stack[0] = fhit_from(hits[i0], 0, nsegs == 1);
         if (f_fusion_opcode(stack[0]) == OP_FUS_RR) f_reverse(stack[0]);
         int num_try = 10000;
@@ -829,16 +837,12 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             if (num_try <= 0) break;
             if (d == nsegs) {                                               // leaf: :2592-2606
                 --num_try;
-                if (nj < cap) {                                             // joined where it is kept
-                    FHit& bh = joined[nj];
-                    if (THJ_EXPF(1 << 29)) bh.n = 0; else
-                    f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
-                    if (bh.n) ++nj;
-                } else {
-                    FHit bh;
-                    f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, bh);
-                    if (bh.n) return SPAN_TOO_MANY_JOINED;       // (nothing is emitted then, whatever the rest of the search finds: the read is done again with room, or reported -- no need to finish 10 000 tries per first-segment hit first)
-                }
+                FHit tmp;
+                FHit* bh = out.slot(tmp);                                   // joined where it is kept
+                if (THJ_EXPF(1 << 29)) bh->n = 0; else
+                f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, *bh);
+                // (no room: nothing of the read is emitted, whatever the rest of the search finds -- the read is done again with room, or reported)
+                if (bh->n && !out.commit(bh)) return SPAN_TOO_MANY_JOINED;
                 --d;
                 if (d >= 1 && dirty[d]) stack[d - 1] = saved[d];
                 continue;
@@ -945,7 +949,12 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
             if (!pushed && prev_dirty) stack[d - 1] = saved[d];
         }
     }
-    if (status == SPAN_TOO_MANY_JOINED) return status;
+    return status;
+}
+// joined[0 .. nj) in generation order (first-segment hit by first-segment hit) -> the read's records.  big: joined is a buffer of 2 * big_cap
+// alignments whose second half is the merge sort's scratch (lists of more than 64)
+template <class Sink>
+THJ_HD int fusion_tail(const Genome& g, const Params& p, const FRead& rd, FHit* joined, int nj, bool ext, int ext_cap, uint32_t read_idx, Sink& sink) {
     if (!ext || nj <= 64) {
         for (int i = 1; i < nj; ++i) {                    // sort + unique (:2805-2807); stable insertion sort
             FHit t = joined[i]; int k = i;
@@ -979,7 +988,138 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
         f_sam_extra(g, p, rd, h, e);
         f_emit(sink, read_idx, order++, h, e);
     }
+    return order;                                         // records emitted
+}
+template <class Sink>
+THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
+                            int nseg, const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink, FHit* ext = nullptr, int ext_cap = 0) {
+    const int nsegs = fusion_read_nsegs(p, hits, so, nseg);
+    if (nsegs == 0) return SPAN_OK;
+    FRead rd{rp, W, rl, p.segment_length, nsegs, qual};
+    FHit joined_local[FUS_MAXJOIN];               // ext: see span_read
+    FHit* joined = ext ? ext : joined_local;
+    const int cap = ext ? ext_cap : FUS_MAXJOIN;
+    FusListOut out{joined, cap, 0};
+    const int status = fusion_search_roots(g, p, S, F, hits, so, rd, nsegs, so[0], so[1], out);
+    if (status == SPAN_TOO_MANY_JOINED) return status;
+    fusion_tail(g, p, rd, joined, out.nj, ext != nullptr, ext_cap, read_idx, sink);
     return status;
+}
+
+// ---- a read with a long list of joined alignments, by the 64 lanes of a wave (thj_k_stitch_huge under --fusion-search)
+// A read of a k-copy repeat family has k first-segment hits, every one the root of a search that joins it with the other
+// copies' hits as fusion candidates -- (segments - 1) * (k - 1) + 1 joined alignments a root, 7 800 for k = 40 and six segments --
+// and one thread took 30 ms over such a read (round 6, configs[3] at full size with 5 % of the pairs from a 40-copy family).
+// Here: lane l searches roots l, l + 64, ...; what it finds goes to a common list by an atomic counter, tagged (root, number within
+// the root); the list is put back into the order the one-thread search makes it in (root by root), sorted through an index
+// (merge passes, a lane a merge), and unique / filter / records run a lane an alignment, the records' numbers from a running count.
+// X: lane, sync() (workgroup barrier; the workgroup is the wave), atomic_add(), ballot() -- FusWaveDev in thj_span.hip, the fibers of
+// tests/hostsim.  ws: 2 * cap alignments and 3 * cap words.  sh: the workgroup's (LDS).  The result equals span_read_fusion's with
+// ext = ws, whatever the timing of the lanes.
+static constexpr int FUS_WAVE_MAXROOT = 1024;
+struct FusWaveShared { uint32_t n_app, overflow, base[FUS_WAVE_MAXROOT + 1]; };
+THJ_HD constexpr size_t fus_wave_ws_bytes(int cap) { return (size_t)cap * (2 * sizeof(FHit) + 12); }
+template <class X>
+struct FusWaveOut {
+    X* x; FHit* buf; uint32_t* ord; uint32_t* n_app; uint32_t cap, root, seq;
+    THJ_HD FHit* slot(FHit& tmp) { return &tmp; }
+    THJ_HD bool commit(FHit* h) {
+        const uint32_t k = x->atomic_add(n_app, 1u);
+        if (k >= cap) return false;
+        buf[k] = *h;
+        ord[k] = (root << 16) | seq++;
+        return true;
+    }
+};
+template <class X, class Sink>
+THJ_HD int fusion_read_wave(X& x, const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
+                            int nseg, const u64* rp, int W, int rl, const uint8_t* qual, uint32_t read_idx, Sink& sink, char* ws, int cap,
+                            FusWaveShared& sh, int& n_records /* the read's, on every lane */) {
+    n_records = 0;
+    const int nsegs = fusion_read_nsegs(p, hits, so, nseg);
+    if (nsegs == 0) return SPAN_OK;
+    FRead rd{rp, W, rl, p.segment_length, nsegs, qual};
+    FHit* A = (FHit*)ws;
+    FHit* B = A + cap;
+    uint32_t* ord = (uint32_t*)(B + cap);
+    uint32_t* ia = ord + cap;
+    uint32_t* ib = ia + cap;
+    const uint32_t n_roots = so[1] - so[0];
+    if (n_roots > (uint32_t)FUS_WAVE_MAXROOT || cap > 65536) {                    // (10 000 tries a root: its number within the root fits 16 bits)
+        int status = SPAN_OK;
+        if (x.lane == 0) {
+            FusListOut out{A, cap, 0};
+            status = fusion_search_roots(g, p, S, F, hits, so, rd, nsegs, so[0], so[1], out);
+            sh.overflow = status == SPAN_TOO_MANY_JOINED;
+            sh.n_app = 0;
+            if (!sh.overflow) sh.n_app = (uint32_t)fusion_tail(g, p, rd, A, out.nj, true, cap, read_idx, sink);
+        }
+        x.sync();
+        const bool ovf = sh.overflow != 0;
+        n_records = (int)sh.n_app;
+        x.sync();
+        return ovf ? SPAN_TOO_MANY_JOINED : SPAN_OK;
+    }
+    if (x.lane == 0) { sh.n_app = 0; sh.overflow = 0; }
+    x.sync();
+    for (uint32_t root = (uint32_t)x.lane; root < n_roots; root += 64) {
+        FusWaveOut<X> out{&x, B, ord, &sh.n_app, (uint32_t)cap, root, 0u};
+        if (fusion_search_roots(g, p, S, F, hits, so, rd, nsegs, so[0] + root, so[0] + root + 1, out) == SPAN_TOO_MANY_JOINED) sh.overflow = 1u;
+        sh.base[root] = out.seq;
+    }
+    x.sync();
+    const bool ovf = sh.overflow != 0;
+    const int nj = (int)sh.n_app;
+    x.sync();
+    if (ovf) return SPAN_TOO_MANY_JOINED;
+    if (x.lane == 0) {                                                             // counts -> first places
+        uint32_t acc = 0;
+        for (uint32_t r = 0; r < n_roots; ++r) { const uint32_t c = sh.base[r]; sh.base[r] = acc; acc += c; }
+    }
+    x.sync();
+    for (int k = x.lane; k < nj; k += 64) {
+        const uint32_t o = ord[k];
+        A[sh.base[o >> 16] + (o & 0xFFFFu)] = B[k];
+    }
+    for (int k = x.lane; k < nj; k += 64) ia[k] = (uint32_t)k;
+    x.sync();
+    uint32_t* a = ia; uint32_t* b = ib;
+    for (int width = 1; width < nj; width <<= 1) {                                 // stable, as fusion_tail's (sort + unique, :2805-2807)
+        const int n_merges = (nj + 2 * width - 1) / (2 * width);
+        for (int m = x.lane; m < n_merges; m += 64) {
+            const int lo = m * 2 * width;
+            const int mid = lo + width < nj ? lo + width : nj, hi = lo + 2 * width < nj ? lo + 2 * width : nj;
+            int i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) b[k++] = fhit_less(A[a[j]], A[a[i]]) ? a[j++] : a[i++];
+            while (i < mid) b[k++] = a[i++];
+            while (j < hi) b[k++] = a[j++];
+        }
+        x.sync();
+        uint32_t* t = a; a = b; b = t;
+    }
+    int order0 = 0;
+    for (int i0 = 0; i0 < nj; i0 += 64) {
+        const int i = i0 + x.lane;
+        bool pass = false;
+        if (i < nj) {
+            const FHit& h = A[a[i]];
+            pass = i == 0 || !fhit_eq(A[a[i - 1]], h);
+            const int gapl = (uint8_t)(h.ed - h.mm);
+            if ((int)h.mm > p.read_mismatches || gapl > p.read_gap_length || (int)h.ed > p.read_edit_dist) pass = false;     // :2810-2813
+            if (THJ_EXPF(1 << 28)) pass = false;
+        }
+        const unsigned long long m = x.ballot(pass);
+        if (pass) {
+            const FHit& h = A[a[i]];
+            Extras e;
+            f_sam_extra(g, p, rd, h, e);
+            f_emit(sink, read_idx, order0 + popc((u64)(m & ((1ull << x.lane) - 1ull))), h, e);
+        }
+        order0 += popc((u64)m);
+    }
+    n_records = order0;
+    x.sync();                                                                      // the workspace is the next read's
+    return SPAN_OK;
 }
 
 }  // namespace thj
