@@ -795,6 +795,7 @@ __global__ __launch_bounds__(64) void thj_k_stitch_fusion(Genome g, Params p, Sp
     for (unsigned int i = blockIdx.x * 64 + threadIdx.x; i < total; i += gridDim.x * 64) {
         const int sl = slice_of(s_off, G, i);
         const int r = (int)t.wl_multi[(int64_t)sl * t.chunk + (i - s_off[sl])];
+        if (fusion_read_heavy(b.seg_off + (size_t)r * b.nseg, b.nseg) && defer_huge(t, (uint32_t)r)) continue;
         int st = span_read_fusion(g, p, S, F, b.hits, b.seg_off + (size_t)r * b.nseg, b.nseg, b.planes + (size_t)r * 3 * b.W, b.W,
                                   (int)b.read_len[r], b.quals + (size_t)r * b.qual_stride, (uint32_t)r, sink);
         if (st == SPAN_TOO_MANY_JOINED && defer_huge(t, (uint32_t)r)) continue;
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(64) void thj_k_stitch_fusion(Genome g, Params p, Sp
 
 // The reads the generic / fusion kernels listed: one at a time per workgroup (lane 0), joined alignments in the workgroup's slice
 // of the context's big workspace (2 * cap records: the list and the merge sort's scratch).  Rare by construction.
-static constexpr int HUGE_BLOCKS = 64, HUGE_CAP = 8192, HUGE_LIST_CAP = 1 << 16;
+static constexpr int HUGE_BLOCKS = 256, HUGE_CAP = 8192, HUGE_LIST_CAP = 1 << 18;
 static constexpr int HUGE_REC_BYTES = 128;               // >= sizeof(Aln), sizeof(FHit)
 static constexpr size_t HUGE_WS_BYTES = (size_t)HUGE_BLOCKS * 2 * HUGE_CAP * HUGE_REC_BYTES;      // one scratch set's workspace
 static_assert(sizeof(Aln) <= HUGE_REC_BYTES && sizeof(FHit) <= HUGE_REC_BYTES, "workspace record size");
@@ -1442,6 +1443,13 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     return THJ_OK;
 }
 
+static int ensure_huge_workspace(thj_ctx* c) {
+    if (c->d_huge_ws) return THJ_OK;
+    HIPCHK(hipMalloc(&c->d_huge_ws, 2 * HUGE_WS_BYTES));                  // (one per scratch set)
+    HIPCHK(hipMalloc(&c->d_huge_list, (size_t)2 * HUGE_LIST_CAP * 4));
+    return THJ_OK;
+}
+
 // mode: 3 = a whole run; 1 = thj_span_tier0_pair_async (tier 0 of a pair, nothing else); a run that finds tier 0 done only does the rest
 static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batch* db0, const thj_span_batch* db1, int mode = 3) {
     if (!c->d_blocks) { thj_set_error("no genome resident: call thj_genome_upload/adopt first"); return THJ_ESTATE; }
@@ -1455,6 +1463,8 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     const auto tr0 = std::chrono::steady_clock::now();
     auto lapse = [&](const char* what) { if (trace_first) fprintf(stderr, "[trace] first run of a context: %-28s %.4f\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count()); };
     if ((rc = ensure_span_state(c))) return rc;
+    // --fusion-search: the reads with many hits a segment go to thj_k_stitch_huge from the start (thj_k_stitch_fusion's fusion_read_heavy)
+    if (tp->fusion_search && (rc = ensure_huge_workspace(c))) return rc;
     lapse("state");
     const int64_t n0 = db0->n_reads, n1 = db1 ? db1->n_reads : 0;
     const bool t0_done = c->span_t0_pending;
@@ -1584,8 +1594,8 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
         if (!c->d_huge_ws) {
             // a read has more joined alignments than a thread's own array holds: get the big workspace (HUGE_BLOCKS slices of
             // 2 * HUGE_CAP records) and ask for the pass again -- thj_k_stitch_huge then takes such reads one by one
-            HIPCHK(hipMalloc(&c->d_huge_ws, 2 * HUGE_WS_BYTES));                  // (one per scratch set)
-            HIPCHK(hipMalloc(&c->d_huge_list, (size_t)2 * HUGE_LIST_CAP * 4));
+            int rc2 = ensure_huge_workspace(c);
+            if (rc2) return rc2;
             thj_set_error("%u read(s) have more joined alignments than the stitch kernels keep per thread (%d, %d with fusion search); a workspace "
                           "for them has been set up: run the pass again (thj_span_reset_async, the thj_span_run_async calls, thj_span_finish)",
                           st[SPAN_TOO_MANY_JOINED], SPAN_MAXJOIN, FUS_MAXJOIN);

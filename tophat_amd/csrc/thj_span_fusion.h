@@ -1017,6 +1017,13 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
 // tests/hostsim.  ws: 2 * cap alignments and 3 * cap words.  sh: the workgroup's (LDS).  The result equals span_read_fusion's with
 // ext = ws, whatever the timing of the lanes.
 static constexpr int FUS_WAVE_MAXROOT = 1024;
+// A read for the wave from the start: with fusion search on, every hit of the second segment is a candidate partner of every hit of the
+// first (a fusion when they are not neighbours), so a thread alone would try so[1] x so[2] pairs and what hangs below them -- while the
+// other 63 reads of its wave wait (round 6: 94 % of long_spanning_reads --fusion-search on the mix was thj_k_stitch_fusion waiting so).
+static constexpr uint32_t FUS_HEAVY_PAIRS = 64;
+THJ_HD bool fusion_read_heavy(const uint32_t* so, int nseg) {
+    return nseg >= 2 && (so[1] - so[0]) * (so[2] - so[1]) >= FUS_HEAVY_PAIRS;
+}
 struct FusWaveShared { uint32_t n_app, overflow, base[FUS_WAVE_MAXROOT + 1]; };
 THJ_HD constexpr size_t fus_wave_ws_bytes(int cap) { return (size_t)cap * (2 * sizeof(FHit) + 12); }
 template <class X>
