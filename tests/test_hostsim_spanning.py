@@ -53,6 +53,7 @@ def test_span_logic_matches_oracle(cfg):
     assert any(any((c >> 28) == 11 for c in a.cigar) for a in want), "no spliced alignment in the case"
     for mode in (0, 1, 2, 3):  # the tiers as the kernels run them (chain entries -> join -> finish), the generic path alone, the tiers without the packed multihit one and without chain entries, with the packed tier's limits made tiny
         sim.lib().hostsim_chain_reads()
+        sim.lib().hostsim_chain_deferred()                           # (both counters are the library's: read = reset)
         got, status = sim.spanning(p, seqs, sb, juncs, ins, mode)
         chains = sim.lib().hostsim_chain_reads()
         deferred = sim.lib().hostsim_chain_deferred()

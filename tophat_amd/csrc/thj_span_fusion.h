@@ -811,6 +811,41 @@ THJ_HD int fusion_read_nsegs(const Params& p, const SpanHit* hits, const uint32_
     return nsegs;
 }
 // returns SPAN_OK, or SPAN_TOO_MANY_JOINED when a joined alignment found no room (nothing of the read is emitted then)
+// The quick "no" of dfs_seg_hits' pair test (round 6).  Once a chain has its fusion (fusion_dir FF / RR) a further plain hit only joins it
+// as a neighbour -- same contig, within [-max_insertion_length, max_report_intron] of the previous hit -- and in a k-copy repeat family k - 1
+// of the k candidates of every level are not: 15 800 pair tests per first-segment hit at k = 40 and six segments, a few hundred cigar scans
+// through scratch each.  For a previous hit and a candidate that are both plain and run up the genome the test's answer follows from five
+// words (:2262-2510 read for that case: the contig test :2296-2304, then the distance of :2338-2352 / :2486-2503, whose failure nothing
+// later undoes); everything else takes the whole test.
+struct FusPrev { bool ok, anti; uint32_t ref; int32_t left, right; };
+THJ_HD FusPrev fus_prev_of(const FHit& h) {
+    FusPrev q{true, h.anti != 0, h.ref_id, h.left, h.left};
+    if (h.ref_id2 != h.ref_id) q.ok = false;
+    for (int i = 0; i < h.n; ++i) {
+        const int op = cig_op(h.c[i]);
+        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) q.right += (int32_t)cig_len(h.c[i]);
+        else if (op != OP_INS) q.ok = false;
+    }
+    return q;
+}
+THJ_HD bool fus_quick_reject(const Params& p, const FusPrev& pv, const SpanHit& h) {
+    const int n = (int)(h.meta >> 24);
+    if (n > 5) return false;
+    int32_t right = h.left;
+    for (int i = 0; i < n; ++i) {
+        const int op = cig_op(h.cigar[i]);
+        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) right += (int32_t)cig_len(h.cigar[i]);
+        else if (op != OP_INS) return false;
+    }
+    if (h.ref_id != pv.ref) return true;
+    if (((h.meta & SH_ANTI) != 0) != pv.anti) return false;
+    const int d1 = h.left - pv.right;
+    const bool out1 = d1 > p.max_report_intron || d1 < -p.max_insertion_length;
+    if (!pv.anti) return out1;
+    const int d2 = pv.left - right;
+    return out1 && (d2 > p.max_report_intron || d2 < -p.max_insertion_length);
+}
+
 // Out: where the joined alignments go.  slot(tmp) = where the next one is built, commit(slot) = it is one (false: no room)
 struct FusListOut {                     // a thread's own list
     FHit* joined; int cap; int nj;
@@ -825,6 +860,7 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
     uint32_t idx[FUS_MAXSEG + 1];
     int fdir[FUS_MAXSEG + 2];
     bool dirty[FUS_MAXSEG + 2];
+    FusPrev pv[FUS_MAXSEG + 2];                   // of stack[d - 1] as level d found it (a candidate's changes to it are undone before the next)
     int status = SPAN_OK;
     for (uint32_t i0 = i0_begin; i0 < i0_end; ++i0) {                       // :2634-2664
         stack[0] = fhit_from(hits[i0], 0, nsegs == 1);
@@ -832,7 +868,7 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
         int num_try = 10000;
         int d = 1;
         fdir[1] = 0;
-        if (nsegs > 1) idx[1] = so[1];
+        if (nsegs > 1) { idx[1] = so[1]; pv[1] = fus_prev_of(stack[0]); }
         while (d >= 1) {
             if (num_try <= 0) break;
             if (d == nsegs) {                                               // leaf: :2592-2606
@@ -853,6 +889,7 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
                 continue;
             }
             const int fusion_dir = fdir[d];
+            if (fs && (fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) && pv[d].ok && fus_quick_reject(p, pv[d], hits[idx[d]])) { ++idx[d]; continue; }
             // The reference works on copies of the two hits and stores them when the pair is accepted; here the new hit is built in
             // its stack slot (free until it is pushed) and the previous one is worked on where it lies: its first change saves the
             // original (saved[d], dirty[d]), a rejected pair puts it back.  (Five 100-byte copies per step through scratch before.)
@@ -941,7 +978,7 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
                 dirty[d] = prev_dirty;
                 fdir[d + 1] = dir == 0 ? fusion_dir : dir;
                 ++d;
-                if (d < nsegs) idx[d] = so[d];
+                if (d < nsegs) { idx[d] = so[d]; pv[d] = fus_prev_of(stack[d - 1]); }
                 pushed = true;
             }
             } while (0);
