@@ -113,7 +113,7 @@ def run_e2e(pairs, read_len=100, genome_len=64444167, introns=20000, workdir=Non
                 a, b = map(float, l.split()[-2:])
                 res["long_spanning_reads_%s_before_main_after_report_s" % sd] = [round(a - t, 3), round(t + dt - b, 3)]
         res["long_spanning_reads_%s_log_tail" % sd] = [l for l in r.stderr.strip().splitlines() if not l.startswith("[trace]")][-8:]
-        res["long_spanning_reads_%s_log_all" % sd] = [l for l in r.stderr.splitlines() if "declined" in l]
+        res["long_spanning_reads_%s_log_all" % sd] = [l for l in r.stderr.splitlines() if "declined" in l or l.startswith("[huge timers]")][-40:]
         if env.get("THJ_TRACE"):                     # the per-shard timeline for tools/lsr_trace.py
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             open(os.path.join(ROOT, "gpurun_out", "lsr_%s.trace" % sd), "w").write(r.stderr)

@@ -815,6 +815,14 @@ static constexpr size_t HUGE_WS_BYTES = (size_t)HUGE_BLOCKS * 2 * HUGE_CAP * HUG
 static_assert(sizeof(Aln) <= HUGE_REC_BYTES && sizeof(FHit) <= HUGE_REC_BYTES, "workspace record size");
 struct FusWaveDev {
     int lane;
+    unsigned int* tm; unsigned long long t_last;       // THJ_HUGE_TIMERS (developer): [k] += 10 ns ticks of phase k (search, reorder, sort, records), [4] = longest list, [5] = reads
+    __device__ __forceinline__ void mark(int k, int nj) {
+        if (!tm || lane != 0) return;
+        const unsigned long long now = wall_clock64();
+        if (k >= 0) atomicAdd(&tm[k], (unsigned int)(now - t_last));
+        if (k == 0) { atomicMax(&tm[4], (unsigned int)nj); atomicAdd(&tm[5], 1u); }
+        t_last = now;
+    }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ uint32_t atomic_add(uint32_t* q, uint32_t v) { return atomicAdd(q, v); }
     __device__ __forceinline__ unsigned long long ballot(bool q) { return __ballot(q); }
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(64) void thj_k_stitch_huge(Genome g, Params p, Span
     char* mine = ws + (size_t)blockIdx.x * 2 * (size_t)cap * HUGE_REC_BYTES;
     if (p.fusion_search && by_wave) {                                // the wave on a read (fusion_read_wave)
         __shared__ FusWaveShared sh;
-        FusWaveDev x{(int)threadIdx.x};
+        FusWaveDev x{(int)threadIdx.x, by_wave == 2 ? sink.status + 8 : nullptr, 0ull};
         for (unsigned int i = blockIdx.x; i < n; i += gridDim.x) {
             const int r = (int)t.huge_list[i];
             int n_rec = 0;
@@ -1436,7 +1444,7 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     if (c->d_huge_ws && sg != sm) { HIPCHK(hipEventRecord(ev_fork, sg)); HIPCHK(hipStreamWaitEvent(sm, ev_fork, 0)); }      // (the fork's wait is long enqueued: the event is free)
     if (c->d_huge_ws) {        // a pass that met a read with too many joined alignments runs with the workspace from then on
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
-        static const int huge_by_wave = getenv("THJ_HUGE_ONE_LANE") ? 0 : 1;      // developer switch: the fusion reads of the list by lane 0 alone (rounds 4-5)
+        static const int huge_by_wave = getenv("THJ_HUGE_ONE_LANE") ? 0 : getenv("THJ_HUGE_TIMERS") ? 2 : 1;      // developer switch: the fusion reads of the list by lane 0 alone (rounds 4-5)
         hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws + (size_t)set * HUGE_WS_BYTES, HUGE_CAP, huge_by_wave);
     }
     HIPCHK(hipGetLastError());
@@ -1572,6 +1580,15 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
     HIPCHK(hipMemcpyAsync(&c->h_pinned[26], c->d_span_status, 32, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     const unsigned int* st = (const unsigned int*)&c->h_pinned[26];
+    {
+        static const bool huge_timers = getenv("THJ_HUGE_TIMERS") != nullptr;
+        if (huge_timers) {
+            unsigned int tm[6];
+            HIPCHK(hipMemcpy(tm, c->d_span_status + 8, sizeof tm, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[huge timers] lane-0 ms summed over reads: search %.1f  reorder %.1f  sort %.1f  records %.1f   longest list %u  reads %u\n",
+                    tm[0] * 1e-5, tm[1] * 1e-5, tm[2] * 1e-5, tm[3] * 1e-5, tm[4], tm[5]);
+        }
+    }
     if (st[5]) {      // thj_k_chains only lets through chains whose joined hit fits the registers' cigar ops: a chain of a group that does not is a bug, not an input
         thj_set_error("internal: a chain of a multihit read needed more cigar ops than thj_k_join holds (set THJ_NO_CHAINS=1 and report)");
         return THJ_ESTATE;

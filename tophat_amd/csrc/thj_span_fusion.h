@@ -1050,7 +1050,7 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
 // Here: lane l searches roots l, l + 64, ...; what it finds goes to a common list by an atomic counter, tagged (root, number within
 // the root); the list is put back into the order the one-thread search makes it in (root by root), sorted through an index
 // (merge passes, a lane a merge), and unique / filter / records run a lane an alignment, the records' numbers from a running count.
-// X: lane, sync() (workgroup barrier; the workgroup is the wave), atomic_add(), ballot() -- FusWaveDev in thj_span.hip, the fibers of
+// X: lane, sync() (workgroup barrier; the workgroup is the wave), atomic_add(), ballot(), mark() (a developer's phase timers) -- FusWaveDev in thj_span.hip, the fibers of
 // tests/hostsim.  ws: 2 * cap alignments and 3 * cap words.  sh: the workgroup's (LDS).  The result equals span_read_fusion's with
 // ext = ws, whatever the timing of the lanes.
 static constexpr int FUS_WAVE_MAXROOT = 1024;
@@ -1106,6 +1106,7 @@ THJ_HD int fusion_read_wave(X& x, const Genome& g, const Params& p, const SpanSe
     }
     if (x.lane == 0) { sh.n_app = 0; sh.overflow = 0; }
     x.sync();
+    x.mark(-1, 0);
     for (uint32_t root = (uint32_t)x.lane; root < n_roots; root += 64) {
         FusWaveOut<X> out{&x, B, ord, &sh.n_app, (uint32_t)cap, root, 0u};
         if (fusion_search_roots(g, p, S, F, hits, so, rd, nsegs, so[0] + root, so[0] + root + 1, out) == SPAN_TOO_MANY_JOINED) sh.overflow = 1u;
@@ -1115,6 +1116,7 @@ THJ_HD int fusion_read_wave(X& x, const Genome& g, const Params& p, const SpanSe
     const bool ovf = sh.overflow != 0;
     const int nj = (int)sh.n_app;
     x.sync();
+    x.mark(0, nj);
     if (ovf) return SPAN_TOO_MANY_JOINED;
     if (x.lane == 0) {                                                             // counts -> first places
         uint32_t acc = 0;
@@ -1127,6 +1129,7 @@ THJ_HD int fusion_read_wave(X& x, const Genome& g, const Params& p, const SpanSe
     }
     for (int k = x.lane; k < nj; k += 64) ia[k] = (uint32_t)k;
     x.sync();
+    x.mark(1, 0);
     uint32_t* a = ia; uint32_t* b = ib;
     for (int width = 1; width < nj; width <<= 1) {                                 // stable, as fusion_tail's (sort + unique, :2805-2807)
         const int n_merges = (nj + 2 * width - 1) / (2 * width);
@@ -1141,6 +1144,7 @@ THJ_HD int fusion_read_wave(X& x, const Genome& g, const Params& p, const SpanSe
         x.sync();
         uint32_t* t = a; a = b; b = t;
     }
+    x.mark(2, 0);
     int order0 = 0;
     for (int i0 = 0; i0 < nj; i0 += 64) {
         const int i = i0 + x.lane;
@@ -1163,6 +1167,7 @@ THJ_HD int fusion_read_wave(X& x, const Genome& g, const Params& p, const SpanSe
     }
     n_records = order0;
     x.sync();                                                                      // the workspace is the next read's
+    x.mark(3, 0);
     return SPAN_OK;
 }
 
