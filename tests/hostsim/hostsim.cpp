@@ -496,6 +496,7 @@ struct FusWaveSim {
     void sync() { b->barrier(); }
     uint32_t atomic_add(uint32_t* q, uint32_t v) { const uint32_t o = *q; *q = o + v; return o; }
     void mark(int, int) {}
+    void counts(uint32_t, uint32_t) {}
     unsigned long long ballot(bool q) { const uint32_t* a = b->exchange(tid, q ? 1u : 0u); unsigned long long m = 0; for (int i = 0; i < 64; ++i) m |= (unsigned long long)(a[i] & 1u) << i; return m; }
 };
 

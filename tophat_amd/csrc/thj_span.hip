@@ -823,6 +823,7 @@ struct FusWaveDev {
         if (k == 0) { atomicMax(&tm[4], (unsigned int)nj); atomicAdd(&tm[5], 1u); }
         t_last = now;
     }
+    __device__ __forceinline__ void counts(uint32_t leaves, uint32_t tests) { if (tm) { atomicAdd(&tm[6], leaves); atomicAdd(&tm[7], tests); } }
     __device__ __forceinline__ void sync() { __syncthreads(); }
     __device__ __forceinline__ uint32_t atomic_add(uint32_t* q, uint32_t v) { return atomicAdd(q, v); }
     __device__ __forceinline__ unsigned long long ballot(bool q) { return __ballot(q); }
@@ -1583,10 +1584,10 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
     {
         static const bool huge_timers = getenv("THJ_HUGE_TIMERS") != nullptr;
         if (huge_timers) {
-            unsigned int tm[6];
+            unsigned int tm[8];
             HIPCHK(hipMemcpy(tm, c->d_span_status + 8, sizeof tm, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[huge timers] lane-0 ms summed over reads: search %.1f  reorder %.1f  sort %.1f  records %.1f   longest list %u  reads %u\n",
-                    tm[0] * 1e-5, tm[1] * 1e-5, tm[2] * 1e-5, tm[3] * 1e-5, tm[4], tm[5]);
+            fprintf(stderr, "[huge timers] lane-0 ms summed over reads: search %.1f  reorder %.1f  sort %.1f  records %.1f   longest list %u  reads %u  leaves %u  whole pair tests %u\n",
+                    tm[0] * 1e-5, tm[1] * 1e-5, tm[2] * 1e-5, tm[3] * 1e-5, tm[4], tm[5], tm[6], tm[7]);
         }
     }
     if (st[5]) {      // thj_k_chains only lets through chains whose joined hit fits the registers' cigar ops: a chain of a group that does not is a bug, not an input

@@ -828,21 +828,26 @@ THJ_HD FusPrev fus_prev_of(const FHit& h) {
     }
     return q;
 }
-THJ_HD bool fus_quick_reject(const Params& p, const FusPrev& pv, const SpanHit& h) {
+struct FusCand { uint32_t ref; int32_t left, right; uint32_t flags; };      // a candidate's five words: flags 1 = plain and up the genome, 2 = antisense
+THJ_HD FusCand fus_cand_of(const SpanHit& h) {
+    FusCand c{h.ref_id, h.left, h.left, 1u | ((h.meta & SH_ANTI) ? 2u : 0u)};
     const int n = (int)(h.meta >> 24);
-    if (n > 5) return false;
-    int32_t right = h.left;
-    for (int i = 0; i < n; ++i) {
+    if (n > 5) c.flags &= ~1u;
+    for (int i = 0; i < n && i < 5; ++i) {
         const int op = cig_op(h.cigar[i]);
-        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) right += (int32_t)cig_len(h.cigar[i]);
-        else if (op != OP_INS) return false;
+        if (op == OP_MATCH || op == OP_REF_SKIP || op == OP_DEL) c.right += (int32_t)cig_len(h.cigar[i]);
+        else if (op != OP_INS) c.flags &= ~1u;
     }
-    if (h.ref_id != pv.ref) return true;
-    if (((h.meta & SH_ANTI) != 0) != pv.anti) return false;
-    const int d1 = h.left - pv.right;
+    return c;
+}
+THJ_HD bool fus_quick_reject(const Params& p, const FusPrev& pv, const FusCand& c) {
+    if (!(c.flags & 1u)) return false;
+    if (c.ref != pv.ref) return true;
+    if (((c.flags & 2u) != 0) != pv.anti) return false;
+    const int d1 = c.left - pv.right;
     const bool out1 = d1 > p.max_report_intron || d1 < -p.max_insertion_length;
     if (!pv.anti) return out1;
-    const int d2 = pv.left - right;
+    const int d2 = pv.left - c.right;
     return out1 && (d2 > p.max_report_intron || d2 < -p.max_insertion_length);
 }
 
@@ -851,10 +856,13 @@ struct FusListOut {                     // a thread's own list
     FHit* joined; int cap; int nj;
     THJ_HD FHit* slot(FHit& tmp) { return nj < cap ? &joined[nj] : &tmp; }
     THJ_HD bool commit(FHit*) { if (nj >= cap) return false; ++nj; return true; }
+    THJ_HD void count(int) {}
 };
+// cand: fus_cand_of of the read's hits, [0] = hits[so[0]], where a wave has staged them (a candidate of the quick "no" is then an LDS read,
+// not a trip to memory a wave alone on its SIMD waits a microsecond for -- 16 000 of them per first-segment hit at k = 40); null: from hits
 template <class Out>
 THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets& S, const FusionSet& F, const SpanHit* hits, const uint32_t* so,
-                               const FRead& rd, int nsegs, uint32_t i0_begin, uint32_t i0_end, Out& out) {
+                               const FRead& rd, int nsegs, uint32_t i0_begin, uint32_t i0_end, Out& out, const FusCand* cand = nullptr) {
     const int fs = p.fusion_search;
     FHit stack[FUS_MAXSEG + 1], saved[FUS_MAXSEG + 1], chain[FUS_MAXSEG + 1];
     uint32_t idx[FUS_MAXSEG + 1];
@@ -875,6 +883,7 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
                 --num_try;
                 FHit tmp;
                 FHit* bh = out.slot(tmp);                                   // joined where it is kept
+                out.count(0);
                 if (THJ_EXPF(1 << 29)) bh->n = 0; else
                 f_merge_segment_chain(g, p, S, F, rd, stack, nsegs, fdir[d], chain, *bh);
                 // (no room: nothing of the read is emitted, whatever the rest of the search finds -- the read is done again with room, or reported)
@@ -889,7 +898,14 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
                 continue;
             }
             const int fusion_dir = fdir[d];
-            if (fs && (fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) && pv[d].ok && fus_quick_reject(p, pv[d], hits[idx[d]])) { ++idx[d]; continue; }
+            if (fs && (fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) && pv[d].ok) {
+                uint32_t i = idx[d];
+                const uint32_t end = so[d + 1];
+                if (cand) while (i < end && fus_quick_reject(p, pv[d], cand[i - so[0]])) ++i;
+                else while (i < end && fus_quick_reject(p, pv[d], fus_cand_of(hits[i]))) ++i;
+                if (i != idx[d]) { idx[d] = i; continue; }
+            }
+            out.count(1);
             // The reference works on copies of the two hits and stores them when the pair is accepted; here the new hit is built in
             // its stack slot (free until it is pushed) and the previous one is worked on where it lies: its first change saves the
             // original (saved[d], dirty[d]), a rejected pair puts it back.  (Five 100-byte copies per step through scratch before.)
@@ -1061,11 +1077,14 @@ static constexpr uint32_t FUS_HEAVY_PAIRS = 64;
 THJ_HD bool fusion_read_heavy(const uint32_t* so, int nseg) {
     return nseg >= 2 && (so[1] - so[0]) * (so[2] - so[1]) >= FUS_HEAVY_PAIRS;
 }
-struct FusWaveShared { uint32_t n_app, overflow, base[FUS_WAVE_MAXROOT + 1]; };
+static constexpr int FUS_WAVE_MAXCAND = 1024;     // hits of a read whose five words are staged (16 KB)
+struct FusWaveShared { uint32_t n_app, overflow, base[FUS_WAVE_MAXROOT + 1]; FusCand cand[FUS_WAVE_MAXCAND]; };
 THJ_HD constexpr size_t fus_wave_ws_bytes(int cap) { return (size_t)cap * (2 * sizeof(FHit) + 12); }
 template <class X>
 struct FusWaveOut {
     X* x; FHit* buf; uint32_t* ord; uint32_t* n_app; uint32_t cap, root, seq;
+    uint32_t n_count[2];                   // leaves, whole pair tests (the developer's counters, x.mark)
+    THJ_HD void count(int k) { ++n_count[k]; }
     THJ_HD FHit* slot(FHit& tmp) { return &tmp; }
     THJ_HD bool commit(FHit* h) {
         const uint32_t k = x->atomic_add(n_app, 1u);
@@ -1105,12 +1124,16 @@ THJ_HD int fusion_read_wave(X& x, const Genome& g, const Params& p, const SpanSe
         return ovf ? SPAN_TOO_MANY_JOINED : SPAN_OK;
     }
     if (x.lane == 0) { sh.n_app = 0; sh.overflow = 0; }
+    const uint32_t n_hits = so[nsegs] - so[0];
+    const bool staged = n_hits <= (uint32_t)FUS_WAVE_MAXCAND;
+    if (staged) for (uint32_t k = (uint32_t)x.lane; k < n_hits; k += 64) sh.cand[k] = fus_cand_of(hits[so[0] + k]);
     x.sync();
     x.mark(-1, 0);
     for (uint32_t root = (uint32_t)x.lane; root < n_roots; root += 64) {
-        FusWaveOut<X> out{&x, B, ord, &sh.n_app, (uint32_t)cap, root, 0u};
-        if (fusion_search_roots(g, p, S, F, hits, so, rd, nsegs, so[0] + root, so[0] + root + 1, out) == SPAN_TOO_MANY_JOINED) sh.overflow = 1u;
+        FusWaveOut<X> out{&x, B, ord, &sh.n_app, (uint32_t)cap, root, 0u, {0u, 0u}};
+        if (fusion_search_roots(g, p, S, F, hits, so, rd, nsegs, so[0] + root, so[0] + root + 1, out, staged ? sh.cand : nullptr) == SPAN_TOO_MANY_JOINED) sh.overflow = 1u;
         sh.base[root] = out.seq;
+        x.counts(out.n_count[0], out.n_count[1]);
     }
     x.sync();
     const bool ovf = sh.overflow != 0;
