@@ -1073,7 +1073,7 @@ static constexpr int FUS_WAVE_MAXROOT = 1024;
 // A read for the wave from the start: with fusion search on, every hit of the second segment is a candidate partner of every hit of the
 // first (a fusion when they are not neighbours), so a thread alone would try so[1] x so[2] pairs and what hangs below them -- while the
 // other 63 reads of its wave wait (round 6: 94 % of long_spanning_reads --fusion-search on the mix was thj_k_stitch_fusion waiting so).
-static constexpr uint32_t FUS_HEAVY_PAIRS = 64;
+static constexpr uint32_t FUS_HEAVY_PAIRS = 9;
 THJ_HD bool fusion_read_heavy(const uint32_t* so, int nseg) {
     return nseg >= 2 && (so[1] - so[0]) * (so[2] - so[1]) >= FUS_HEAVY_PAIRS;
 }
