@@ -254,7 +254,8 @@ int thj_fusion_reset_async(thj_ctx* ctx);
 int thj_fusion_set_ignored(thj_ctx* ctx, const uint32_t* ref_ids, int32_t n);
 int thj_fusion_run_async(thj_ctx* ctx, const thj_params* p, const thj_seg_batch* dev_batch);
 /* Synchronises and reduces the events to the FusionSimpleSet (count, smallest edit distance) in
- * Fusion::operator< order (fusions.h:38-69). */
+ * Fusion::operator< order (fusions.h:38-69).  THJ_ERETRY: a batch had more raw candidates than the buffer held (it grows between batches,
+ * ahead of the count); the buffer now has the room the count asked for: thj_fusion_reset_async, the run calls and this again. */
 int thj_fusion_finish(thj_ctx* ctx, int64_t* n_fusions);
 int thj_fusion_download(thj_ctx* ctx, thj_fusion* out);
 

@@ -1793,8 +1793,8 @@ extern "C" int thj_fusion_run_async(thj_ctx* c, const thj_params* tp, const thj_
     // The raw candidate events of a pass pile up until thj_fusion_finish reduces them (round 6: configs[3] at full size -- 50 M pairs of the
     // mix -- has 9.9 M of them, the buffer held 1 M: a loud error, but an error).  The buffer now grows ahead of the count: after every launch
     // the count sets out for the host, the next call looks at what has arrived and, past half the room, moves the events to a buffer four
-    // times the size (one stream synchronisation per growth; no wait otherwise).  A single batch that adds more than half the buffer still
-    // overflows and is reported by thj_fusion_finish.
+    // times the size (one stream synchronisation per growth; no wait otherwise).  A single batch that adds more than the room left still
+    // overflows: thj_fusion_finish then enlarges the buffer to the count and answers THJ_ERETRY.
     if (!c->fus_probe_ev) HIPCHK(hipEventCreateWithFlags(&c->fus_probe_ev, hipEventDisableTiming));
     if (c->fus_probe_pending && hipEventQuery(c->fus_probe_ev) == hipSuccess) {
         c->fus_probe_pending = false;
@@ -1928,7 +1928,19 @@ extern "C" int thj_fusion_finish(thj_ctx* c, int64_t* n_fusions) {
         unsigned long long h[2] = {0, 0};
         HIPCHK(hipMemcpyAsync(h, c->d_fus_count, 16, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if ((unsigned int)h[1]) { thj_set_error("fusion event buffer overflow (%llu candidate events, capacity %lld)", h[0], (long long)c->fus_cap); return THJ_EOVERFLOW; }
+        if ((unsigned int)h[1]) {
+            // a batch added more than the buffer had room for (thj_fusion_run_async grows it ahead of the count, but only between batches).  The
+            // counter kept counting, so the need is known: make the buffer that large and ask for the pass again
+            const int64_t need = (int64_t)h[0], ncap = need + need / 4 + 4096;
+            if (need >= (1ll << 30)) { thj_set_error("fusion event buffer overflow (%llu candidate events, capacity %lld)", h[0], (long long)c->fus_cap); return THJ_EOVERFLOW; }
+            thj_fusion* nb = nullptr;
+            HIPCHK(hipMalloc(&nb, (size_t)ncap * sizeof(thj_fusion)));
+            hipFree(c->d_fus);
+            c->d_fus = nb; c->fus_cap = ncap;
+            thj_set_error("the buffer for raw fusion candidates was too small (%lld needed); it has been enlarged: run the pass again "
+                          "(thj_fusion_reset_async, the thj_fusion_run_async calls, thj_fusion_finish)", (long long)need);
+            return THJ_ERETRY;
+        }
         static const bool on_host = getenv("THJ_FUSION_REDUCE_ON_HOST") != nullptr;
         if (h[0] && !on_host && h[0] < (1ull << 31)) {
             const int rc = fusion_reduce_on_device(c, (int64_t)h[0]);

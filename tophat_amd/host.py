@@ -446,17 +446,28 @@ class Context:
                "thj_segjuncs_device_keys")
         return (p.value or 0), n.value
 
+    def _fusion_pass(self, runs, ignore_ref_ids) -> int:
+        """reset; thj_fusion_run_async for every (params, batch); finish -> number of fusions.  THJ_ERETRY at the finish (a batch had more
+        raw candidates than the buffer held; it has been enlarged) runs the pass again."""
+        runs = list(runs)
+        ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
+        for attempt in range(3):
+            _check(self.lib, self.lib.thj_fusion_reset_async(self._ctx), "thj_fusion_reset_async")
+            _check(self.lib, self.lib.thj_fusion_set_ignored(self._ctx, _ptr(ign) if len(ign) else None, len(ign)), "thj_fusion_set_ignored")
+            for p, b in runs:
+                cp = p.as_ctypes()
+                arg = C.byref(b) if isinstance(b, CSegBatch) else b
+                _check(self.lib, self.lib.thj_fusion_run_async(self._ctx, C.byref(cp), arg), "thj_fusion_run_async")
+            n = C.c_int64()
+            rc = self.lib.thj_fusion_finish(self._ctx, C.byref(n))
+            if rc != -7 or attempt == 2:
+                _check(self.lib, rc, "thj_fusion_finish")
+                return int(n.value)
+        raise AssertionError("unreachable")
+
     def fusions(self, runs, ignore_ref_ids=()) -> np.ndarray:
         """reset; thj_fusion_run_async for every (params, batch); finish; download -> FUSION_DTYPE array"""
-        _check(self.lib, self.lib.thj_fusion_reset_async(self._ctx), "thj_fusion_reset_async")
-        ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
-        _check(self.lib, self.lib.thj_fusion_set_ignored(self._ctx, _ptr(ign) if len(ign) else None, len(ign)), "thj_fusion_set_ignored")
-        for p, b in runs:
-            cp = p.as_ctypes()
-            arg = C.byref(b) if isinstance(b, CSegBatch) else b
-            _check(self.lib, self.lib.thj_fusion_run_async(self._ctx, C.byref(cp), arg), "thj_fusion_run_async")
-        n = C.c_int64()
-        _check(self.lib, self.lib.thj_fusion_finish(self._ctx, C.byref(n)), "thj_fusion_finish")
+        n = C.c_int64(self._fusion_pass(runs, ignore_ref_ids))
         out = np.zeros(max(1, n.value), dtype=FUSION_DTYPE)
         _check(self.lib, self.lib.thj_fusion_download(self._ctx, _ptr(out)), "thj_fusion_download")
         return out[:n.value]
@@ -615,16 +626,7 @@ def _span_methods():
 
     def fusion_search(self, runs, ignore_ref_ids=()) -> int:
         """fusions() without the download: reset; thj_fusion_run_async for every (params, batch); finish -> number of fusions"""
-        _check(self.lib, self.lib.thj_fusion_reset_async(self._ctx), "thj_fusion_reset_async")
-        ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
-        _check(self.lib, self.lib.thj_fusion_set_ignored(self._ctx, _ptr(ign) if len(ign) else None, len(ign)), "thj_fusion_set_ignored")
-        for p, b in runs:
-            cp = p.as_ctypes()
-            arg = C.byref(b) if isinstance(b, CSegBatch) else b
-            _check(self.lib, self.lib.thj_fusion_run_async(self._ctx, C.byref(cp), arg), "thj_fusion_run_async")
-        n = C.c_int64()
-        _check(self.lib, self.lib.thj_fusion_finish(self._ctx, C.byref(n)), "thj_fusion_finish")
-        return int(n.value)
+        return self._fusion_pass(runs, ignore_ref_ids)
 
     def span_hit_heads(self, d_hits: int, n_hits: int, d_heads: int):
         """the dense 16-byte head array of device-resident hit records (CSpanBatch.hit_heads)"""
