@@ -809,9 +809,9 @@ __global__ __launch_bounds__(64) void thj_k_stitch_fusion(Genome g, Params p, Sp
 
 // The reads the generic / fusion kernels listed: one at a time per workgroup (lane 0), joined alignments in the workgroup's slice
 // of the context's big workspace (2 * cap records: the list and the merge sort's scratch).  Rare by construction.
-static constexpr int HUGE_BLOCKS = 256, HUGE_CAP = 8192, HUGE_LIST_CAP = 1 << 18;
+static constexpr int HUGE_BLOCKS = 256, HUGE_BLOCKS_MAX = 1024, HUGE_CAP = 8192, HUGE_LIST_CAP = 1 << 18;
 static constexpr int HUGE_REC_BYTES = 128;               // >= sizeof(Aln), sizeof(FHit)
-static constexpr size_t HUGE_WS_BYTES = (size_t)HUGE_BLOCKS * 2 * HUGE_CAP * HUGE_REC_BYTES;      // one scratch set's workspace
+static constexpr size_t HUGE_BLOCK_BYTES = (size_t)2 * HUGE_CAP * HUGE_REC_BYTES;      // a workgroup's slice (2 MB); a scratch set's workspace is c->huge_blocks of them
 static_assert(sizeof(Aln) <= HUGE_REC_BYTES && sizeof(FHit) <= HUGE_REC_BYTES, "workspace record size");
 struct FusWaveDev {
     int lane;
@@ -1446,16 +1446,23 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     if (c->d_huge_ws) {        // a pass that met a read with too many joined alignments runs with the workspace from then on
         FusionSet F{(const FusKey*)c->d_span_fus, c->n_span_fus};
         static const int huge_by_wave = getenv("THJ_HUGE_ONE_LANE") ? 0 : getenv("THJ_HUGE_TIMERS") ? 2 : 1;      // developer switch: the fusion reads of the list by lane 0 alone (rounds 4-5)
-        hipLaunchKernelGGL(thj_k_stitch_huge, dim3(HUGE_BLOCKS), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws + (size_t)set * HUGE_WS_BYTES, HUGE_CAP, huge_by_wave);
+        hipLaunchKernelGGL(thj_k_stitch_huge, dim3((unsigned)c->huge_blocks), dim3(64), 0, sm, g, p, S, F, b, sink, t, (char*)c->d_huge_ws + (size_t)set * c->huge_blocks * HUGE_BLOCK_BYTES, HUGE_CAP, huge_by_wave);
     }
     HIPCHK(hipGetLastError());
     return THJ_OK;
 }
 
-static int ensure_huge_workspace(thj_ctx* c) {
-    if (c->d_huge_ws) return THJ_OK;
-    HIPCHK(hipMalloc(&c->d_huge_ws, 2 * HUGE_WS_BYTES));                  // (one per scratch set)
-    HIPCHK(hipMalloc(&c->d_huge_list, (size_t)2 * HUGE_LIST_CAP * 4));
+// blocks: the workgroups of thj_k_stitch_huge, each with a slice of the workspace.  Under --fusion-search the reads of the list are many (every
+// read with a few hits a segment: fusion_read_heavy) and each is a wave's work for milliseconds, so a large batch gets up to 1 024 of them
+// (bench.py's 10 M pairs in one batch: 450 000 listed reads, 0.8 -> 0.35 s a launch); a shard of the executables gets 64-256.
+static int ensure_huge_workspace(thj_ctx* c, int blocks) {
+    if (blocks < 64) blocks = 64;
+    if (blocks > HUGE_BLOCKS_MAX) blocks = HUGE_BLOCKS_MAX;
+    if (c->d_huge_ws && c->huge_blocks >= blocks) return THJ_OK;
+    if (c->d_huge_ws) { HIPCHK(hipDeviceSynchronize()); hipFree(c->d_huge_ws); c->d_huge_ws = nullptr; }      // (a launch may still be using the smaller one)
+    HIPCHK(hipMalloc(&c->d_huge_ws, (size_t)2 * blocks * HUGE_BLOCK_BYTES));                  // (one per scratch set)
+    c->huge_blocks = blocks;
+    if (!c->d_huge_list) HIPCHK(hipMalloc(&c->d_huge_list, (size_t)2 * HUGE_LIST_CAP * 4));
     return THJ_OK;
 }
 
@@ -1473,7 +1480,7 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     auto lapse = [&](const char* what) { if (trace_first) fprintf(stderr, "[trace] first run of a context: %-28s %.4f\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count()); };
     if ((rc = ensure_span_state(c))) return rc;
     // --fusion-search: the reads with many hits a segment go to thj_k_stitch_huge from the start (thj_k_stitch_fusion's fusion_read_heavy)
-    if (tp->fusion_search && (rc = ensure_huge_workspace(c))) return rc;
+    if (tp->fusion_search && (rc = ensure_huge_workspace(c, (int)((db0->n_reads + (db1 ? db1->n_reads : 0) + 8191) / 8192)))) return rc;
     lapse("state");
     const int64_t n0 = db0->n_reads, n1 = db1 ? db1->n_reads : 0;
     const bool t0_done = c->span_t0_pending;
@@ -1612,7 +1619,7 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
         if (!c->d_huge_ws) {
             // a read has more joined alignments than a thread's own array holds: get the big workspace (HUGE_BLOCKS slices of
             // 2 * HUGE_CAP records) and ask for the pass again -- thj_k_stitch_huge then takes such reads one by one
-            int rc2 = ensure_huge_workspace(c);
+            int rc2 = ensure_huge_workspace(c, HUGE_BLOCKS);
             if (rc2) return rc2;
             thj_set_error("%u read(s) have more joined alignments than the stitch kernels keep per thread (%d, %d with fusion search); a workspace "
                           "for them has been set up: run the pass again (thj_span_reset_async, the thj_span_run_async calls, thj_span_finish)",
