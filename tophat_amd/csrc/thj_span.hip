@@ -1454,9 +1454,9 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
 
 // blocks: the workgroups of thj_k_stitch_huge, each with a slice of the workspace.  Under --fusion-search the reads of the list are many (every
 // read with a few hits a segment: fusion_read_heavy) and each is a wave's work for milliseconds, so a large batch gets up to 1 024 of them
-// (bench.py's 10 M pairs in one batch: 450 000 listed reads, 0.8 -> 0.35 s a launch); a shard of the executables gets 64-256.
+// (bench.py's 10 M pairs in one batch: 450 000 listed reads, 0.8 -> 0.35 s a launch); a shard of the executables gets 256 and up, a slice per 1 024 reads.
 static int ensure_huge_workspace(thj_ctx* c, int blocks) {
-    if (blocks < 64) blocks = 64;
+    if (blocks < HUGE_BLOCKS) blocks = HUGE_BLOCKS;
     if (blocks > HUGE_BLOCKS_MAX) blocks = HUGE_BLOCKS_MAX;
     if (c->d_huge_ws && c->huge_blocks >= blocks) return THJ_OK;
     if (c->d_huge_ws) { HIPCHK(hipDeviceSynchronize()); hipFree(c->d_huge_ws); c->d_huge_ws = nullptr; }      // (a launch may still be using the smaller one)
@@ -1480,7 +1480,7 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     auto lapse = [&](const char* what) { if (trace_first) fprintf(stderr, "[trace] first run of a context: %-28s %.4f\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count()); };
     if ((rc = ensure_span_state(c))) return rc;
     // --fusion-search: the reads with many hits a segment go to thj_k_stitch_huge from the start (thj_k_stitch_fusion's fusion_read_heavy)
-    if (tp->fusion_search && (rc = ensure_huge_workspace(c, (int)((db0->n_reads + (db1 ? db1->n_reads : 0) + 8191) / 8192)))) return rc;
+    if (tp->fusion_search && (rc = ensure_huge_workspace(c, (int)((db0->n_reads + (db1 ? db1->n_reads : 0) + 1023) / 1024)))) return rc;
     lapse("state");
     const int64_t n0 = db0->n_reads, n1 = db1 ? db1->n_reads : 0;
     const bool t0_done = c->span_t0_pending;
