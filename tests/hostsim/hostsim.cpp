@@ -489,7 +489,13 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
 }
 
 // ---- --fusion-search: tier 0 as the kernel runs it, then thj_span_fusion.h for every read it does not finish
+// THJ_HOSTSIM_QR_VERIFY=1: dfs_seg_hits' quick "no" (fus_quick_reject) is only recorded, the whole pair test runs, and a pair it would have
+// passed over that the whole test accepts is counted (hostsim_qr_counts: how often it said no, how often wrongly)
+#define THJ_QR_VERIFY
+static bool thj_qr_verify = false;
+static int64_t thj_qr_said_no = 0, thj_qr_wrong = 0;
 #include "../../tophat_amd/csrc/thj_span_fusion.h"
+extern "C" void hostsim_qr_counts(int64_t* said_no, int64_t* wrong) { *said_no = thj_qr_said_no; *wrong = thj_qr_wrong; thj_qr_said_no = thj_qr_wrong = 0; }
 
 struct FusWaveSim {
     simt::Block* b; int tid, lane;
@@ -521,6 +527,7 @@ extern "C" int hostsim_spanning_fusion(const thj_params* tp, const uint64_t* blo
     std::vector<OutAln> res;
     VecSink sink{&res};
     for (int k = 0; k < 5; ++k) status_counts[k] = 0;
+    thj_qr_verify = getenv("THJ_HOSTSIM_QR_VERIFY") != nullptr;
     const int fuswave_cap = getenv("THJ_HOSTSIM_FUSWAVE") ? atoi(getenv("THJ_HOSTSIM_FUSWAVE")) : 0;      // joined alignments the wave's workspace holds
     for (int32_t r = 0; r < n_reads; ++r) {
         int st = SPAN_NEED_GENERIC;

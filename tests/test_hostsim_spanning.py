@@ -154,3 +154,45 @@ def test_fusion_search_of_a_repeat_read_by_the_wave(monkeypatch):
         got, status = sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)
         assert got == [] and status[1] == sb.n_reads
         monkeypatch.delenv("THJ_HOSTSIM_FUSWAVE")
+
+
+def test_quick_no_of_the_pair_test_is_never_wrong(monkeypatch):
+    """dfs_seg_hits' pair test has a quick "no" for a plain candidate once the chain has its fusion (fus_quick_reject: five words instead of
+    the cigar scans).  THJ_HOSTSIM_QR_VERIFY: it only predicts, the whole test runs -- over random hit geometry (the fusion fuzz's batches:
+    both strands, several contigs, overlapping and distant hits) and a repeat family it must say no often, and never where the whole test
+    accepts the pair.  The records are the oracle's either way."""
+    import ctypes as C
+    import numpy as np
+    from tophat_amd.batch import JUNC_DTYPE
+    from test_fuzz_cpu import fusion_set_near_hits, rand_genome, rand_span_batch
+    monkeypatch.setenv("THJ_HOSTSIM_QR_VERIFY", "1")
+    said = C.c_int64(); wrong = C.c_int64()
+    sim.lib().hostsim_qr_counts(C.byref(said), C.byref(wrong))
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    total = 0
+    for seed in range(120):
+        rng = np.random.default_rng(9100 + seed)
+        seqs = rand_genome(rng, int(rng.integers(1, 4)))
+        L = int(rng.choice([20, 25, 25, 40]))
+        nseg = int(rng.choice([2, 3, 4, 6]))
+        if L * (nseg + 1) > 256:
+            nseg = 256 // L - 1
+        sb = rand_span_batch(rng, seqs, 60, L, nseg)
+        p = Params(segment_length=L, fusion_search=1, max_insertion_length=int(rng.choice([1, 3])), max_report_intron=int(rng.choice([300, 5000, 500000])),
+                   fusion_min_dist=int(rng.choice([100, 1500, 10000000])))
+        fus = fusion_set_near_hits(rng, sb)
+        want = orc.spanning_fusion(p, orc.Genome(seqs), sb, nj, [], fus, True)
+        got, status = sim.spanning_fusion(p, seqs, sb, nj, [], fus, True)
+        got.sort(key=lambda a: a.read_idx)
+        assert got == want
+        sim.lib().hostsim_qr_counts(C.byref(said), C.byref(wrong))
+        assert wrong.value == 0, seed
+        total += said.value
+    assert total > 1000
+    seq, sb = repeat_span_batch(copies=14, n_reads=6, seed=74)
+    p = Params(fusion_search=1, fusion_min_dist=300, max_report_intron=300)
+    nf = repeat_fusion_list(sb)
+    monkeypatch.setenv("THJ_HOSTSIM_FUSWAVE", "8192")            # (560 joined alignments a read: the wave's workspace holds them)
+    assert sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)[0] == orc.spanning_fusion(p, orc.Genome([seq]), sb, nj, [], nf, True)
+    sim.lib().hostsim_qr_counts(C.byref(said), C.byref(wrong))
+    assert wrong.value == 0 and said.value > 10000

@@ -898,6 +898,13 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
                 continue;
             }
             const int fusion_dir = fdir[d];
+#ifdef THJ_QR_VERIFY                              // tests/hostsim: the quick "no" only predicts; the whole test runs and must agree
+            bool qr_said_no = false;
+            if (thj_qr_verify) {
+                qr_said_no = fs && (fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) && pv[d].ok && fus_quick_reject(p, pv[d], fus_cand_of(hits[idx[d]]));
+                if (qr_said_no) ++thj_qr_said_no;
+            } else
+#endif
             if (fs && (fusion_dir == OP_FUS_FF || fusion_dir == OP_FUS_RR) && pv[d].ok) {
                 uint32_t i = idx[d];
                 const uint32_t end = so[d + 1];
@@ -993,6 +1000,9 @@ THJ_HD int fusion_search_roots(const Genome& g, const Params& p, const SpanSets&
                  f_forwarding_right(*prevHit) == f_forwarding_left(*currHit))) {
                 dirty[d] = prev_dirty;
                 fdir[d + 1] = dir == 0 ? fusion_dir : dir;
+#ifdef THJ_QR_VERIFY
+                if (qr_said_no) ++thj_qr_wrong;
+#endif
                 ++d;
                 if (d < nsegs) { idx[d] = so[d]; pv[d] = fus_prev_of(stack[d - 1]); }
                 pushed = true;
