@@ -150,6 +150,12 @@ def test_fusion_search_of_a_repeat_read_by_the_wave(monkeypatch):
         got, status = sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)
         assert status[1] == 0 and status[2] == 0
         assert got == want, copies
+        if copies == 14:
+            # a workspace of more than 65 536 alignments (a root's number within the list would not fit its 16 bits), like more than 1 024
+            # first-segment hits: lane 0 alone, the list sorted in the workspace (fusion_tail's merge sort)
+            monkeypatch.setenv("THJ_HOSTSIM_FUSWAVE", "70000")
+            got, status = sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)
+            assert status[1] == 0 and got == want
         monkeypatch.setenv("THJ_HOSTSIM_FUSWAVE", str(min(per_read.values()) - 1))       # no read's list fits
         got, status = sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)
         assert got == [] and status[1] == sb.n_reads
