@@ -71,7 +71,7 @@ struct thj_ctx {
     u64* d_span_cat = nullptr;                                            // junction ++ deletion keys before their sort
     u64* d_span_junc = nullptr; int64_t n_span_junc = 0; int64_t cap_span_junc = 0;
     u64* d_span_ins_key = nullptr; uint32_t* d_span_ins_seq = nullptr; int64_t n_span_ins = 0; int64_t cap_span_ins = 0;
-    void* d_huge_ws = nullptr; uint32_t* d_huge_list = nullptr; int huge_blocks = 0;      // reads with too many joined alignments for a thread's array (thj_k_stitch_huge)
+    void* d_huge_ws = nullptr; uint32_t* d_huge_list = nullptr; int huge_blocks = 0, huge_list_cap = 0;      // reads with too many joined alignments for a thread's array (thj_k_stitch_huge)
     void* d_span_fus = nullptr; int64_t n_span_fus = 0; int64_t cap_span_fus = 0;       // --fusion-search: the sorted .fusions list (thj_span_fusions_upload)
     void* d_aln_pool = nullptr; void* d_aln_sorted = nullptr; int64_t aln_cap = 0;
     u64* d_aln_keys = nullptr;

@@ -1302,8 +1302,8 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
     unsigned int* const blk_pack = t.blk_chain + NC * MAX_SLICES;
     t.counters = &c->d_span_status[16 + SPAN_CNT_WORDS * set];
     t.chunk = (int)chunk;
-    t.huge_list = c->d_huge_list ? c->d_huge_list + (size_t)set * HUGE_LIST_CAP : nullptr; t.huge_cnt = t.counters + 4;      // a list and a workspace per scratch set: the two batches of a pair call run beside each other
-    t.huge_list_cap = c->d_huge_list ? HUGE_LIST_CAP : 0;
+    t.huge_list = c->d_huge_list ? c->d_huge_list + (size_t)set * c->huge_list_cap : nullptr; t.huge_cnt = t.counters + 4;      // a list and a workspace per scratch set: the two batches of a pair call run beside each other
+    t.huge_list_cap = c->d_huge_list ? c->huge_list_cap : 0;
     t.ent = chains ? (ChainEntry*)ss.d_ent : nullptr;
     t.ja = (Q16*)ss.d_joined; t.jb = t.ja ? t.ja + ss.joined_cap : nullptr; t.jc = t.ja ? t.ja + 2 * ss.joined_cap : nullptr;
     t.status = c->d_span_status;
@@ -1455,14 +1455,25 @@ static int span_launch(thj_ctx* c, const thj_params* tp, const thj_span_batch* d
 // blocks: the workgroups of thj_k_stitch_huge, each with a slice of the workspace.  Under --fusion-search the reads of the list are many (every
 // read with a few hits a segment: fusion_read_heavy) and each is a wave's work for milliseconds, so a large batch gets up to 1 024 of them
 // (bench.py's 10 M pairs in one batch: 450 000 listed reads, 0.8 -> 0.35 s a launch); a shard of the executables gets 256 and up, a slice per 1 024 reads.
-static int ensure_huge_workspace(thj_ctx* c, int blocks) {
+// list_reads: the reads of the largest batch of the call -- under --fusion-search a good part of them may be listed (a read the list has no
+// room for stays with its thread: correct, and slow when it is a family read)
+static int ensure_huge_workspace(thj_ctx* c, int blocks, int64_t list_reads) {
     if (blocks < HUGE_BLOCKS) blocks = HUGE_BLOCKS;
     if (blocks > HUGE_BLOCKS_MAX) blocks = HUGE_BLOCKS_MAX;
-    if (c->d_huge_ws && c->huge_blocks >= blocks) return THJ_OK;
-    if (c->d_huge_ws) { HIPCHK(hipDeviceSynchronize()); hipFree(c->d_huge_ws); c->d_huge_ws = nullptr; }      // (a launch may still be using the smaller one)
-    HIPCHK(hipMalloc(&c->d_huge_ws, (size_t)2 * blocks * HUGE_BLOCK_BYTES));                  // (one per scratch set)
-    c->huge_blocks = blocks;
-    if (!c->d_huge_list) HIPCHK(hipMalloc(&c->d_huge_list, (size_t)2 * HUGE_LIST_CAP * 4));
+    int list_cap = list_reads > HUGE_LIST_CAP ? (int)(list_reads < (1ll << 30) ? list_reads : (1ll << 30)) : HUGE_LIST_CAP;
+    const bool ws_ok = c->d_huge_ws && c->huge_blocks >= blocks, list_ok = c->d_huge_list && c->huge_list_cap >= list_cap;
+    if (ws_ok && list_ok) return THJ_OK;
+    if (c->d_huge_ws || c->d_huge_list) HIPCHK(hipDeviceSynchronize());       // (a launch may still be using the smaller ones)
+    if (!ws_ok) {
+        hipFree(c->d_huge_ws); c->d_huge_ws = nullptr;
+        HIPCHK(hipMalloc(&c->d_huge_ws, (size_t)2 * blocks * HUGE_BLOCK_BYTES));                  // (one per scratch set)
+        c->huge_blocks = blocks;
+    }
+    if (!list_ok) {
+        hipFree(c->d_huge_list); c->d_huge_list = nullptr;
+        HIPCHK(hipMalloc(&c->d_huge_list, (size_t)2 * list_cap * 4));
+        c->huge_list_cap = list_cap;
+    }
     return THJ_OK;
 }
 
@@ -1480,7 +1491,8 @@ static int span_run_common(thj_ctx* c, const thj_params* tp, const thj_span_batc
     auto lapse = [&](const char* what) { if (trace_first) fprintf(stderr, "[trace] first run of a context: %-28s %.4f\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count()); };
     if ((rc = ensure_span_state(c))) return rc;
     // --fusion-search: the reads with many hits a segment go to thj_k_stitch_huge from the start (thj_k_stitch_fusion's fusion_read_heavy)
-    if (tp->fusion_search && (rc = ensure_huge_workspace(c, (int)((db0->n_reads + (db1 ? db1->n_reads : 0) + 1023) / 1024)))) return rc;
+    if (tp->fusion_search && (rc = ensure_huge_workspace(c, (int)((db0->n_reads + (db1 ? db1->n_reads : 0) + 1023) / 1024),
+                                                         db1 && db1->n_reads > db0->n_reads ? db1->n_reads : db0->n_reads))) return rc;
     lapse("state");
     const int64_t n0 = db0->n_reads, n1 = db1 ? db1->n_reads : 0;
     const bool t0_done = c->span_t0_pending;
@@ -1619,7 +1631,7 @@ extern "C" int thj_span_finish(thj_ctx* c, int64_t* n_alns) {
         if (!c->d_huge_ws) {
             // a read has more joined alignments than a thread's own array holds: get the big workspace (HUGE_BLOCKS slices of
             // 2 * HUGE_CAP records) and ask for the pass again -- thj_k_stitch_huge then takes such reads one by one
-            int rc2 = ensure_huge_workspace(c, HUGE_BLOCKS);
+            int rc2 = ensure_huge_workspace(c, HUGE_BLOCKS, 0);
             if (rc2) return rc2;
             thj_set_error("%u read(s) have more joined alignments than the stitch kernels keep per thread (%d, %d with fusion search); a workspace "
                           "for them has been set up: run the pass again (thj_span_reset_async, the thj_span_run_async calls, thj_span_finish)",
