@@ -275,6 +275,72 @@ extern "C" int hostsim_fusions(const thj_params* tp, const uint64_t* blocks, con
     return 0;
 }
 
+// The same through thj_k_fusion's workgroup algorithm (thj_fusion_block.h) over simt.h's fibers: one workgroup of 256 threads takes all the
+// tiles -- or `blocks` of them take every blocks-th tile, one after the other (their queues and lists carry over from tile to tile as on the
+// device).  The raw events come in another order than hostsim_fusions'; the caller reduces both.
+#include "../../tophat_amd/csrc/thj_fusion_block.h"
+struct FusBlockSim {
+    simt::Block* blk; int tid, lane;
+    void sync() { blk->barrier(); }
+    unsigned long long ballot(bool q) { const uint32_t* a = blk->exchange(tid, q ? 1u : 0u); unsigned long long m = 0; for (int i = 0; i < 64; ++i) m |= (unsigned long long)(a[i] & 1u) << i; return m; }
+    int shfl(int v, int src) { return (int)blk->exchange(tid, (uint32_t)v)[src & 63]; }
+    int shfl_up(int v, int d) { const uint32_t* a = blk->exchange(tid, (uint32_t)v); return lane >= d ? (int)a[lane - d] : v; }
+    uint32_t atomic_add(uint32_t* q, uint32_t v) { const uint32_t o = *q; *q = o + v; return o; }
+    void atomic_or(uint32_t* q, uint32_t v) { *q |= v; }
+    template <class Out>
+    void detect_now(const Genome& g, const Params& p, const u64* rp, int W, int rl, bool rc, const Hit& lh, const Hit& rh, int dir, Out& out) { ++n_now; detect_fusion(g, p, rp, W, rl, rc, lh, rh, dir, out); }
+    static int64_t n_now;
+};
+int64_t FusBlockSim::n_now = 0;
+struct FusBlockCollect {
+    std::vector<thj_fusion> v;
+    std::vector<uint32_t> ign;
+    bool ignored(uint32_t ref) const { for (uint32_t x : ign) if (x == ref) return true; return false; }
+    void fusion(uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) { v.push_back({r1, r2, l, r, dir, 1u, ed, 0u}); }
+    unsigned long long reserve(unsigned long long n) { const unsigned long long at = v.size(); v.resize(v.size() + (size_t)n); return at; }
+    void put(unsigned long long pos, uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) { v[(size_t)pos] = thj_fusion{r1, r2, l, r, dir, 1u, ed, 0u}; }
+};
+struct FusSimBatch {
+    const thj_seg_batch* b; int W;
+    ReadView view(int r) const {
+        ReadView v;
+        v.hits = (const Hit*)b->hits;
+        v.so = b->seg_off + (int64_t)r * b->nseg;
+        v.nseg = b->nseg; v.W = b->words_per_plane;
+        v.rp = (const u64*)b->read_planes + (int64_t)r * 3 * v.W;
+        v.rl = b->read_len[r];
+        v.mate = nullptr; v.n_mate = 0; v.slots = nullptr; v.mscan = nullptr;
+        if (b->mate_off) { v.mate = (const Hit*)b->mate_hits + b->mate_off[r]; v.n_mate = (int)(b->mate_off[r + 1] - b->mate_off[r]); }
+        return v;
+    }
+    int read_len(uint32_t r) const { return b->read_len[r]; }
+    const u64* planes(uint32_t r) const { return (const u64*)b->read_planes + (int64_t)r * 3 * b->words_per_plane; }
+};
+extern "C" int hostsim_fusions_block(const thj_params* tp, const uint64_t* blocks, const uint32_t* contig_blk, const int32_t* contig_len,
+                                     int32_t n_contigs, const thj_seg_batch* b, const uint32_t* ignore, int32_t n_ignore, int32_t n_blocks,
+                                     thj_fusion** out, int64_t* n_out, int64_t* n_evaluated_in_place) {
+    Genome g{(const u64*)blocks, contig_blk, contig_len, n_contigs};
+    Params p;
+    memcpy(&p, tp, sizeof p);
+    FusBlockCollect c;
+    c.ign.assign(ignore, ignore + n_ignore);
+    FusSimBatch sb{b, b->words_per_plane};
+    FusBlockSim::n_now = 0;
+    if (n_blocks < 1) n_blocks = 1;
+    for (int blk_i = 0; blk_i < n_blocks; ++blk_i) {
+        FusBlockShared sh;
+        simt::run_block(256, [&](simt::Block& blk, int tid) {
+            FusBlockSim x{&blk, tid, tid & 63};
+            fusion_block(x, g, p, sb, b->n_reads, blk_i, n_blocks, c, sh);
+        }, 512 * 1024);
+    }
+    *n_evaluated_in_place = FusBlockSim::n_now;
+    *n_out = (int64_t)c.v.size();
+    *out = (thj_fusion*)malloc(sizeof(thj_fusion) * (c.v.size() + 1));
+    memcpy(*out, c.v.data(), sizeof(thj_fusion) * c.v.size());
+    return 0;
+}
+
 // ---------------------------------------------------------------- long_spanning_reads
 #include "../../tophat_amd/csrc/thj_span_core.h"
 

@@ -169,6 +169,31 @@ def fusions(p: Params, seqs, b: SegBatch, ignore_ref_ids=()):
     return orc.merge_fusions(a, np.zeros(0, dtype=orc.FUSION_DTYPE))
 
 
+def fusions_block(p: Params, seqs, b: SegBatch, n_blocks: int = 1, ignore_ref_ids=()):
+    """-> (the fusion set, pairs evaluated where they were found): thj_k_fusion's workgroup algorithm (thj_fusion_block.h: tiles of 256 reads,
+    the queue of candidate pairs, the family reads taken by the whole workgroup) over the fibers of simt.h, `n_blocks` workgroups sharing
+    the tiles as the device's do; reduced like FusionSimpleSet"""
+    import orc
+    l = lib()
+    g = host.pack_genome(seqs, lib=l)
+    cb, keep, _, _ = host.host_cbatch(b, 0, lib=l)
+    clen = g.lens.astype(np.int32)
+    cp = p.as_ctypes()
+    out = C.c_void_p()
+    n = C.c_int64()
+    now = C.c_int64()
+    ign = np.ascontiguousarray(list(ignore_ref_ids), dtype=np.uint32)
+    rc = l.hostsim_fusions_block(C.byref(cp), C.c_void_p(g.blocks.ctypes.data), C.c_void_p(g.contig_blk.ctypes.data),
+                                 C.c_void_p(clen.ctypes.data), g.n_contigs, C.byref(cb), C.c_void_p(ign.ctypes.data), len(ign), int(n_blocks),
+                                 C.byref(out), C.byref(n), C.byref(now))
+    assert rc == 0
+    a = np.zeros(0, dtype=orc.FUSION_DTYPE)
+    if n.value:
+        a = np.frombuffer((C.c_char * (n.value * 32)).from_address(out.value), dtype=orc.FUSION_DTYPE).copy()
+    l.hostsim_free(out)
+    return orc.merge_fusions(a, np.zeros(0, dtype=orc.FUSION_DTYPE)), int(now.value)
+
+
 def _pack_ium(l, ium_reads):
     n = len(ium_reads)
     off = np.zeros(n + 1, dtype=np.int64)

@@ -102,54 +102,23 @@ def test_fusion_event_buffer_grows(monkeypatch):
 
 def test_fusions_of_a_repeat_family():
     """reads of a 41-copy repeat family (bench.py's mix): every hit of the first segment pairs with every hit of the last one, k x k
-    candidates a read, the copies further apart than --fusion-min-dist.  thj_k_fusion takes such reads a pair a thread, the workgroup on
-    one read after the other (round 6; before: the read's own thread, with a queue of 1 024 for a tile's 7 800 pairs) -- the
-    FusionSimpleSet must come out the same: keys, counts, smallest edit distances."""
-    import torch  # noqa: F401
-    from bench import sample_segbatch
-    from tophat_amd.params import Params
-    from tophat_amd.synth import make_device_workload, make_scale_genome
-    seqs, genes = make_scale_genome(1, [4_000_000], 3000, intron_max=1500, exon_len=300)
-    S, copies = 40_000, 41
-    for k in range(1, copies):
-        seqs[0][k * S:(k + 1) * S] = seqs[0][:S]
-    fam = (genes[:, 3] + 300 + 1000 < S)
-    uniq = genes[:, 1] >= copies * S + 1000
-    genes = genes[fam | uniq]
-    strs = [s.tobytes().decode() for s in seqs]
-    n = 3000
-    w = make_device_workload(9, seqs, genes, None, n, "cpu", exon_len=300, multi_frac=0.3, dup_shift=S, max_copies=copies, fusion_frac=0.02)
+    candidates a read, the copies further apart than --fusion-min-dist; and for a third of the reads only the first segment maps, so the
+    mate-anchored part runs over k x k x 2 x k triples.  thj_k_fusion takes such reads a pair (a triple) a thread, the workgroup on one read
+    after the other (round 6; thj_fusion_block.h -- the same code runs on the CPU in test_hostsim_fusions) -- the FusionSimpleSet must come
+    out the same: keys, counts, smallest edit distances."""
+    from test_hostsim_fusions import family_fusion_batches
+    strs, batches, heavy_pairs, heavy_mates = family_fusion_batches()
+    assert heavy_pairs > 20 and heavy_mates > 20
     og = orc.Genome(strs)
     want = None
     runs = []
-    heavy_mates = 0
     with host.Context(0) as ctx:
         ctx.upload_genome(host.pack_genome(strs))
-        for sd, side in (("left", 1), ("right", 2)):
-            p = Params(read_side=side, inner_dist_mean=50, inner_dist_std_dev=20, fusion_min_dist=30000)
-            sb = sample_segbatch(w[sd], n)
-            # ... and for every third read only the first segment maps: no partner among the read's own hits, so the mate-anchored part runs
-            # (find_fusions :3117-3202) -- for a family read over k x k (hit, mate hit) pairs and then k first-segment hits per pseudo-hit; the
-            # workgroup takes such reads a triple a thread
-            so = sb.seg_off.astype(np.int64)
-            keep = np.ones(len(sb.hits), dtype=bool)
-            cnt = []
-            for r in range(0, n, 3):
-                keep[so[r * sb.nseg + 1]:so[(r + 1) * sb.nseg]] = False
-            for k in range(n * sb.nseg):
-                cnt.append(int(keep[so[k]:so[k + 1]].sum()))
-            sb.hits = sb.hits[keep]
-            sb.seg_off = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32)
-            first = np.array(cnt[0::sb.nseg][0::3], dtype=np.int64)
-            nm = np.diff(sb.mate_off.astype(np.int64))[0::3]
-            heavy_mates += int((first * first * nm >= 256).sum())
+        for p, sb in batches:
             f = orc.fusions(p, og, sb, p.fusion_anchor_length, p.fusion_min_dist)
             want = f if want is None else orc.merge_fusions(want, f)
             runs.append((p, ctx.upload_batch(sb)))
         got = ctx.fusions(runs)
-    assert heavy_mates > 20
     cols = ("ref_id1", "ref_id2", "left", "right", "dir", "count", "edit_dist")
-    cells = (w["left"]["seg_off"][1:] - w["left"]["seg_off"][:-1]).reshape(n, 4)
-    assert int(((cells[:, 0] >= 8) & (cells[:, 3] >= 8)).sum()) > 20                 # reads with 64 or more pairs, up to 41 x 41
     assert int(sum(int(x["count"]) for x in want)) > 1000
     assert [tuple(int(x[k]) for k in cols) for x in got] == [tuple(int(x[k]) for k in cols) for x in want]

@@ -22,6 +22,7 @@
 
 #include "../../include/thj.h"
 #include "thj_core.h"
+#include "thj_fusion_block.h"
 #include "thj_internal.h"
 
 using namespace thj;
@@ -981,218 +982,43 @@ struct FusionSink {
         if (pos < cap) { thj_fusion f{r1, r2, l, r, dir, 1u, ed, 0u}; buf[pos] = f; }
         else atomicExch(ovf, 1u);
     }
+    // thj_fusion_block.h's wave-aggregated form: room for n events with one add, then every lane writes its own
+    __device__ __forceinline__ unsigned long long reserve(unsigned long long n) { return atomicAdd(count, n); }
+    __device__ __forceinline__ void put(unsigned long long pos, uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) {
+        if (pos < cap) { thj_fusion f{r1, r2, l, r, dir, 1u, ed, 0u}; buf[pos] = f; }
+        else atomicExch(ovf, 1u);
+    }
 };
 
-// find_fusions + detect_fusion.  One thread per read decides which (left hit, right hit) pairs are fusion candidates -- a few
-// comparisons for almost every read -- and queues those in LDS; detect_fusion (~20 000 instructions: it walks both flanks base by
-// base) then runs over the queue with every lane busy, once ~200 pairs have piled up over the tiles.  With detect_fusion called
-// where the pair is found, 2 % chimeric reads meant three waves in four ran it with one or two lanes active (4.6 ms per launch of
-// 6.25 M reads; PMC: 1.4 G VALU wave-instructions).  Candidate events are appended raw and reduced in thj_fusion_finish.
-struct FusTask { uint32_t read; uint32_t flags; Hit lh; Hit rh; };        // flags: rc | dir << 1
-// the queue is full (a tile of multihit reads): the pair where it is found, out of line so that the kernel's registers are not sized for it
+// find_fusions + detect_fusion: thj_fusion_block.h has the workgroup's algorithm (and the history of its phases); here the device's execution
+// context for it and the kernel.  Candidate events are appended raw and reduced in thj_fusion_finish.
+// (the queue is full -- a tile of multihit reads: the pair where it is found, out of line so that the kernel's registers are not sized for it)
 __device__ __noinline__ void detect_fusion_now(const Genome* g, const Params* p, const u64* rp, int W, int rl, bool rc, const Hit* lh, const Hit* rh, int dir, FusionSink* out) {
     detect_fusion(*g, *p, rp, W, rl, rc, *lh, *rh, dir, *out);
 }
-static constexpr int FUS_QCAP = 1024;
-struct FusDeferSink {
-    FusionSink& out; FusTask* q; unsigned int* q_n; uint32_t read;
-    const Genome& g; const Params& p; const u64* rp; int W; int rl;
-    __device__ __forceinline__ bool ignored(uint32_t ref) const { return out.ignored(ref); }
-    __device__ __forceinline__ void defer(bool rc, const Hit& lh, const Hit& rh, int dir) {
-        const unsigned int k = atomicAdd(q_n, 1u);
-        if (k < (unsigned)FUS_QCAP) { FusTask t; t.read = read; t.flags = (rc ? 1u : 0u) | ((uint32_t)dir << 1); t.lh = lh; t.rh = rh; q[k] = t; }
-        else detect_fusion_now(&g, &p, rp, W, rl, rc, &lh, &rh, dir, &out);
+struct FusBlockDev {
+    int tid, lane;
+    __device__ __forceinline__ void sync() { __syncthreads(); }
+    __device__ __forceinline__ unsigned long long ballot(bool q) { return __ballot(q); }
+    __device__ __forceinline__ int shfl(int v, int src) { return __shfl(v, src); }
+    __device__ __forceinline__ int shfl_up(int v, int d) { return __shfl_up(v, d); }
+    __device__ __forceinline__ uint32_t atomic_add(uint32_t* q, uint32_t v) { return atomicAdd(q, v); }
+    __device__ __forceinline__ void atomic_or(uint32_t* q, uint32_t v) { atomicOr(q, v); }
+    __device__ __forceinline__ void detect_now(const Genome& g, const Params& p, const u64* rp, int W, int rl, bool rc, const Hit& lh, const Hit& rh, int dir, FusionSink& out) {
+        detect_fusion_now(&g, &p, rp, W, rl, rc, &lh, &rh, dir, &out);
     }
 };
-// Three phases per tile of 256 reads: (a) every thread looks at its read's pairs of real hits (a few comparisons for almost every
-// read) and queues the candidate pairs; a read that also wants the mate-anchored search -- two flank scans per mate hit -- is
-// only listed; (b) once ~200 such reads are listed, they are searched with every lane busy (their candidate pairs join the
-// queue); (c) once ~200 pairs are queued, detect_fusion runs over them.  With the flank scans where the read is met, configs[3]'s
-// shape (--fusion-min-dist 100000: one read in ten is a candidate) ran them at one lane in ten: 1.9-2.5 ms per launch.
-static constexpr int FUS_RCAP = 512;
-// A read whose first and last segment have 64 or more (hit, hit) pairs -- a read of a repeat family: k x k -- is not enumerated by its own
-// thread: the workgroup takes such reads one after the other, a pair a thread (round 6: with 5 % of the pairs from a 41-copy family a tile's
-// dozen family reads put 7 800 pairs into a queue of 1 024 and evaluated the rest on their own lanes, the other 240 waiting: 1.17 s a launch
-// of 10 M reads).  The events are counted per key afterwards, so their order in the buffer means nothing.
-static constexpr uint32_t FUS_HEAVY_READ_PAIRS = 64;
-static constexpr uint64_t FUS_HEAVY_MATE_TRIPLES = 256;      // (first-segment hit, mate hit, first-segment hit) triples from which the workgroup takes a read's mate-anchored part
-static constexpr int FUS_MSCAN = 64;                         // ... of reads with at most this many mate hits
-__device__ __forceinline__ bool fusion_pairs_heavy(const ReadView& v) {
-    if (v.nseg == 0) return false;
-    int last = v.nseg - 1;
-    while (last > 0 && rv_count_raw(v, last) == 0) --last;
-    if (last == 0) return false;
-    return (v.so[1] - v.so[0]) * (v.so[last + 1] - v.so[last]) >= FUS_HEAVY_READ_PAIRS;
-}
+struct FusDevBatch {
+    const DevBatch& b; int W;
+    __device__ __forceinline__ ReadView view(int r) const { return make_view(b, r); }
+    __device__ __forceinline__ int read_len(uint32_t r) const { return (int)b.read_len[r]; }
+    __device__ __forceinline__ const u64* planes(uint32_t r) const { return b.planes + (size_t)r * 3 * b.W; }
+};
 __global__ __launch_bounds__(256, 3) void thj_k_fusion(Genome g, Params p, DevBatch b, FusionSink sink) {
-    __shared__ FusTask q[FUS_QCAP];
-    __shared__ uint32_t rq[FUS_RCAP];
-    __shared__ uint32_t hq[256];
-    __shared__ int32_t ms_f[FUS_MSCAN], ms_r[FUS_MSCAN];
-    __shared__ uint8_t ms_ok[FUS_MSCAN];
-    __shared__ unsigned int q_n, rq_n, hq_n, h_partner;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    if (tid == 0) { q_n = 0; rq_n = 0; hq_n = 0; }
-    __syncthreads();
-    // (c) detect_fusion over the queued pairs: every lane evaluates one; the wave then takes the room for all its events with one atomic
-    // (one per event was 7 x 10^5 returning atomics on one address per launch) and the lanes write theirs.  Called by all threads.
-    auto run_queue = [&]() {
-        const unsigned int have = q_n < (unsigned)FUS_QCAP ? q_n : (unsigned)FUS_QCAP;
-        for (unsigned int k0 = 0; k0 < have; k0 += 256) {
-            const unsigned int k = k0 + (unsigned int)tid;
-            FusTask t; FusEval fe; int n = 0, rl = 0;
-            if (k < have && !THJ_EXPF(1 << 27)) {
-                t = q[k];
-                rl = (int)b.read_len[t.read];
-                n = fusion_eval(g, p, b.planes + (size_t)t.read * 3 * b.W, b.W, rl, (t.flags & 1u) != 0, t.lh, t.rh, (int)(t.flags >> 1), fe);
-            }
-            int incl = n;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d); if (lane >= d) incl += y; }
-            const int tot = __shfl(incl, 63);
-            unsigned long long base = 0;
-            if (lane == 0 && tot) base = atomicAdd(sink.count, (unsigned long long)tot);
-            base = ((unsigned long long)(unsigned int)__shfl((int)(base >> 32), 0) << 32) | (unsigned long long)(unsigned int)__shfl((int)(base & 0xFFFFFFFFull), 0);
-            if (n) {
-                const unsigned long long first = base + (unsigned long long)(incl - n);
-                fusion_emit(fe, rl, t.lh, t.rh, (int)(t.flags >> 1), [&](int kk, uint32_t r1, uint32_t r2, uint32_t l, uint32_t r, uint32_t dir, uint32_t ed) {
-                    const unsigned long long pos = first + (unsigned long long)kk;
-                    if (pos < sink.cap) { thj_fusion f{r1, r2, l, r, dir, 1u, ed, 0u}; sink.buf[pos] = f; }
-                    else atomicExch(sink.ovf, 1u);
-                });
-            }
-        }
-        __syncthreads();
-        if (tid == 0) q_n = 0;
-        __syncthreads();
-    };
-    const int n_tiles = (b.n_reads + 255) / 256;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int r = tile * 256 + tid;
-        const bool last = tile + (int)gridDim.x >= n_tiles;
-        bool wants = false, heavy = false;
-        if (r < b.n_reads) {
-            ReadView v = make_view(b, r);
-            heavy = fusion_pairs_heavy(v);
-            FusDeferSink ds{sink, q, &q_n, (uint32_t)r, g, p, v.rp, v.W, v.rl};
-            if (!heavy && !THJ_EXPF(1 << 25)) wants = fusion_read_pairs<true>(g, p, v, ds);
-        }
-        {   // one LDS atomic per wave and list
-            const unsigned long long mw = __ballot(wants), mh = __ballot(heavy);
-            const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
-            unsigned int base = 0, hbase = 0;
-            if (lane == 0 && mw) base = atomicAdd(&rq_n, (unsigned int)__popcll(mw));
-            if (lane == 0 && mh) hbase = atomicAdd(&hq_n, (unsigned int)__popcll(mh));
-            base = __shfl(base, 0); hbase = __shfl(hbase, 0);
-            if (wants) rq[base + (unsigned int)__popcll(mw & below)] = (uint32_t)r;   // < 192 + 256 entries
-            if (heavy) hq[hbase + (unsigned int)__popcll(mh & below)] = (uint32_t)r;
-        }
-        __syncthreads();
-        // (a') the tile's family reads, one after the other: fusion_read_pairs with a pair a thread
-        const unsigned int n_heavy = hq_n;
-        for (unsigned int h = 0; h < n_heavy; ++h) {
-            const int rr = (int)hq[h];
-            ReadView v = make_view(b, rr);
-            int lastseg = v.nseg - 1;
-            while (lastseg > 0 && rv_count_raw(v, lastseg) == 0) --lastseg;
-            const uint32_t l0 = v.so[0], l1 = v.so[1], r0 = v.so[lastseg], r1 = v.so[lastseg + 1];
-            const uint32_t nr = r1 - r0, total = (l1 - l0) * nr;
-            if (tid == 0) h_partner = 0u;
-            __syncthreads();
-            FusDeferSink ds{sink, q, &q_n, (uint32_t)rr, g, p, v.rp, v.W, v.rl};
-            for (uint32_t t0 = 0; t0 < total; t0 += 256u) {
-                const unsigned int queued = q_n;                                  // (nobody adds between the barrier before and the one below)
-                __syncthreads();
-                if (queued > (unsigned)FUS_QCAP - 256u) run_queue();
-                const uint32_t t = t0 + (uint32_t)tid;
-                if (t < total) {
-                    const uint32_t i = t / nr, j = t - i * nr;
-                    const Hit lh = v.hits[l0 + i], rh = v.hits[r0 + j];
-                    if (lh.ref_id == rh.ref_id && hit_anti(lh) == hit_anti(rh)) {           // check_partner (:3082-3100)
-                        const int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
-                        if (dist > -p.max_insertion_length && dist <= p.fusion_min_dist) atomicOr(&h_partner, 1u);
-                    }
-                    fusion_pair<true>(g, p, v.rp, v.W, v.rl, lh, rh, ds);
-                }
-                __syncthreads();
-            }
-            if (tid == 0 && !h_partner && v.n_mate > 0 && l1 > l0) rq[atomicAdd(&rq_n, 1u)] = (uint32_t)rr;      // (a tile's reads: still < 192 + 256)
-            __syncthreads();
-        }
-        if (tid == 0) hq_n = 0;
-        __syncthreads();
-        const unsigned int have_r = rq_n;
-        if (have_r >= 192u || (last && have_r > 0u)) {
-            for (unsigned int k = tid; k < have_r; k += 256) {
-                const int rr = (int)rq[k];
-                ReadView v = make_view(b, rr);
-                // fusion_read_mates pairs every pseudo-hit (two a mate hit) with every hit of the first segment, for every hit of the first
-                // segment: k x k x 2 x k for a family read of which only the first segment mapped -- 137 000 pairs at k = 41, and one thread took
-                // a second over them, the launch waiting (round 6: all of thj_k_fusion's 1.1 s on bench.py's mix).  Such a read is listed for the
-                // workgroup (below); reads with few hits stay with their thread.
-                const uint32_t nl = v.so[1] - v.so[0];
-                if ((uint64_t)nl * nl * (uint32_t)v.n_mate >= FUS_HEAVY_MATE_TRIPLES && v.n_mate <= FUS_MSCAN) {
-                    const unsigned int at = atomicAdd(&hq_n, 1u);
-                    if (at < 256u) { hq[at] = (uint32_t)rr; continue; }
-                }
-                FusDeferSink ds{sink, q, &q_n, (uint32_t)rr, g, p, v.rp, v.W, v.rl};
-                if (!THJ_EXPF(1 << 26)) fusion_read_mates<true>(g, p, v, ds);
-            }
-            __syncthreads();
-            // (b') fusion_read_mates (thj_core.h) by the workgroup, one listed read after the other: the flank scan of every mate hit once (a
-            // thread each: it does not depend on the left hit), then per left hit the (mate hit, pseudo-hit, first-segment hit) triples a thread each
-            const unsigned int n_hm = hq_n < 256u ? hq_n : 256u;
-            for (unsigned int h = 0; h < n_hm && !THJ_EXPF(1 << 26); ++h) {
-                const int rr = (int)hq[h];
-                ReadView v = make_view(b, rr);
-                const uint32_t l0 = v.so[0], nl = v.so[1] - v.so[0];
-                const int nm = v.n_mate;
-                if (tid < nm) {
-                    int32_t f = SLOT_NONE, rv = SLOT_NONE;
-                    const bool ok = rescue_scan(g, p, v.rp, v.W, v.rl, v.mate[tid], f, rv);
-                    ms_f[tid] = f; ms_r[tid] = rv; ms_ok[tid] = ok ? 1u : 0u;
-                }
-                __syncthreads();
-                FusDeferSink ds{sink, q, &q_n, (uint32_t)rr, g, p, v.rp, v.W, v.rl};
-                const int minus_dist = -p.max_insertion_length * 2;
-                int cl = p.segment_length - p.segment_mismatches - 3; if (cl > 15) cl = 15;
-                auto passed_over = [&](const Hit& lh, const Hit& rh) {                   // :3131-3137: a proper pair is no fusion candidate
-                    if (lh.ref_id != rh.ref_id || hit_anti(lh) == hit_anti(rh)) return false;
-                    const int dist = hit_anti(lh) ? lh.left - rh.right : rh.left - lh.right;
-                    return dist > minus_dist && dist <= p.fusion_min_dist;
-                };
-                for (uint32_t l = 0; l < nl; ++l) {
-                    const Hit lh = v.hits[l0 + l];
-                    int m_stop = nm;                                                     // the mate loop ends at a flank that would start before the contig
-                    for (int m = 0; m < nm; ++m) { if (passed_over(lh, v.mate[m])) continue; if (ms_f[m] == SLOT_BREAK) { m_stop = m; break; } }
-                    const uint32_t items = (uint32_t)m_stop * 2u * nl;
-                    for (uint32_t t0 = 0; t0 < items; t0 += 256u) {
-                        const unsigned int queued = q_n;
-                        __syncthreads();
-                        if (queued > (unsigned)FUS_QCAP - 256u) run_queue();
-                        const uint32_t t = t0 + (uint32_t)tid;
-                        if (t < items) {
-                            const uint32_t m = t / (2u * nl), rem = t - m * 2u * nl, k = rem / nl, i = rem - k * nl;
-                            const Hit rh = v.mate[m];
-                            const int32_t pos = k == 0 ? ms_f[m] : ms_r[m];
-                            if (!passed_over(lh, rh) && ms_ok[m] && pos != SLOT_NONE) {
-                                Hit ph; ph.ref_id = rh.ref_id; ph.left = pos; ph.right = ph.left + cl;
-                                ph.meta = (k == 0 ? 2u : 3u) | ((uint32_t)cl << 24);
-                                fusion_pair<true>(g, p, v.rp, v.W, v.rl, v.hits[l0 + i], ph, ds);
-                            }
-                        }
-                        __syncthreads();
-                    }
-                }
-                __syncthreads();
-            }
-            if (tid == 0) { rq_n = 0; hq_n = 0; }
-            __syncthreads();
-        }
-        if (q_n >= 192u || (last && q_n > 0u)) run_queue();
-        __syncthreads();
-    }
+    __shared__ FusBlockShared sh;
+    FusBlockDev x{(int)threadIdx.x, (int)(threadIdx.x & 63u)};
+    FusDevBatch db{b, b.W};
+    fusion_block(x, g, p, db, b.n_reads, (int)blockIdx.x, (int)gridDim.x, sink, sh);
 }
 
 __global__ __launch_bounds__(256) void thj_k_ins_gather(const u64* slots, int64_t n, const u64* keys, const u64* vals, u64* out_keys, u64* out_vals) {

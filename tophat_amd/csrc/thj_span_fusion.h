@@ -1085,7 +1085,7 @@ static constexpr int FUS_WAVE_MAXROOT = 1024;
 // other 63 reads of its wave wait (round 6: 94 % of long_spanning_reads --fusion-search on the mix was thj_k_stitch_fusion waiting so).
 static constexpr uint32_t FUS_HEAVY_PAIRS = 9;
 THJ_HD bool fusion_read_heavy(const uint32_t* so, int nseg) {
-    return nseg >= 2 && (so[1] - so[0]) * (so[2] - so[1]) >= FUS_HEAVY_PAIRS;
+    return nseg >= 2 && (uint64_t)(so[1] - so[0]) * (so[2] - so[1]) >= FUS_HEAVY_PAIRS;
 }
 static constexpr int FUS_WAVE_MAXCAND = 1024;     // hits of a read whose five words are staged (16 KB)
 struct FusWaveShared { uint32_t n_app, overflow, base[FUS_WAVE_MAXROOT + 1]; FusCand cand[FUS_WAVE_MAXCAND]; };
