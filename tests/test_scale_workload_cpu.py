@@ -199,3 +199,61 @@ def test_scale_workload_with_a_repeat_family(monkeypatch):
         for a in want:
             by_read[a.read_idx] = by_read.get(a.read_idx, 0) + 1
         assert max(by_read.values()) >= 20           # a read of a 20+-copy repeat has an alignment in every copy
+
+
+def test_scale_workload_fusion_search_with_a_repeat_family(monkeypatch):
+    """configs[3]'s mode on bench.py's mix in small: 2 x 150 bp, chimeric reads AND a repeat family (nine copies, further apart than
+    --fusion-min-dist, so that segment_juncs --fusion-search lists break points between them and long_spanning_reads' search joins a
+    family read's segments across copies).  Both stages, oracle against the kernel logic as the device runs it: thj_k_fusion's workgroup
+    algorithm, the fusion tier's search one thread a read, and the 64 lanes of a wave on a read (fusion_read_wave) -- with the pair test's
+    quick "no" only predicting and checked (THJ_HOSTSIM_QR_VERIFY) in a last pass."""
+    import ctypes as C
+    seqs, genes = make_scale_genome(1, [3_000_000, 1_000_000], 2500, intron_max=1500, exon_len=300)
+    S, copies = 120_000, 9
+    for k in range(1, copies):
+        seqs[0][k * S:(k + 1) * S] = seqs[0][:S]
+    fam = (genes[:, 0] == 0) & (genes[:, 3] + 300 + 1000 < S)
+    uniq = (genes[:, 0] != 0) | (genes[:, 1] >= copies * S + 1000)
+    assert fam.sum() > 5 and uniq.sum() > 100
+    genes = genes[fam | uniq]
+    strs = [s.tobytes().decode() for s in seqs]
+    n = 1500
+    w = make_device_workload(21, seqs, genes, None, n, "cpu", exon_len=300, read_len=150, multi_frac=0.2, dup_shift=S, max_copies=copies, fusion_frac=0.04)
+    og = orc.Genome(strs)
+    ev = fus = None
+    for sd, side in (("left", 1), ("right", 2)):
+        p = Params(read_side=side, inner_dist_mean=50, inner_dist_std_dev=20, fusion_min_dist=100000)
+        sb = sample_segbatch(w[sd], n)
+        e = orc.segjuncs(p, og, sb)
+        ev = e if ev is None else merge_events(ev, e)
+        f = orc.fusions(p, og, sb, p.fusion_anchor_length, p.fusion_min_dist)
+        assert sim.fusions(p, strs, sb).tolist() == f.tolist()
+        assert sim.fusions_block(p, strs, sb, 2)[0].tolist() == f.tolist()
+        fus = f if fus is None else orc.merge_fusions(fus, f)
+    juncs, ins = events_to_span_inputs(ev)
+    fl = fusion_list_from_events(fus)
+    assert any(int(x["ref_id1"]) == 1 and int(x["ref_id2"]) == 1 and abs(int(x["right"]) - int(x["left"])) > S // 2 for x in fus)      # between copies
+    p = Params(fusion_search=1, fusion_min_dist=100000)
+    for sd in ("left", "right"):
+        spb = sample_spanbatch(w[sd], n)
+        want = orc.spanning_fusion(p, og, spb, juncs, ins, fl, True)
+        per_read = {}
+        for a in want:
+            per_read[a.read_idx] = per_read.get(a.read_idx, 0) + 1
+        assert max(per_read.values()) >= copies
+        got, status = sim.spanning_fusion(p, strs, spb, juncs, ins, fl)
+        fit = {r for r, k in per_read.items() if k <= 20}            # (a thread alone keeps 24 joined alignments before sort + unique)
+        assert [a for a in got if a.read_idx in fit] == [a for a in want if a.read_idx in fit]
+        monkeypatch.setenv("THJ_HOSTSIM_FUSWAVE", "8192")
+        got, status = sim.spanning_fusion(p, strs, spb, juncs, ins, fl)
+        assert status[1] == 0 and got == want
+        monkeypatch.setenv("THJ_HOSTSIM_QR_VERIFY", "1")
+        said, wrong = C.c_int64(), C.c_int64()
+        sim.lib().hostsim_qr_counts(C.byref(said), C.byref(wrong))
+        got, status = sim.spanning_fusion(p, strs, spb, juncs, ins, fl)
+        assert got == want
+        sim.lib().hostsim_qr_counts(C.byref(said), C.byref(wrong))
+        assert wrong.value == 0
+        print(sd, "records", len(want), "most a read", max(per_read.values()), "quick noes", said.value)
+        monkeypatch.delenv("THJ_HOSTSIM_QR_VERIFY")
+        monkeypatch.delenv("THJ_HOSTSIM_FUSWAVE")
