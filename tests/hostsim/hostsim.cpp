@@ -539,6 +539,14 @@ extern "C" int hostsim_spanning(const thj_params* tp, const uint64_t* blocks, co
             status_counts[3]++;
             st = span_read(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
                            read_len[r], quals + (int64_t)r * qual_stride, r, sink);
+            // thj_k_stitch_huge: a read with more joined alignments than a thread's own array holds is done again with a workspace of
+            // 2 * cap records (the list and the merge sort's scratch) -- THJ_HOSTSIM_HUGE_CAP=cap; without it the read is only counted
+            const int huge_cap = getenv("THJ_HOSTSIM_HUGE_CAP") ? atoi(getenv("THJ_HOSTSIM_HUGE_CAP")) : 0;
+            if (st == SPAN_TOO_MANY_JOINED && huge_cap > 0) {
+                std::vector<Aln> ws((size_t)2 * huge_cap);
+                st = span_read(g, p, S, (const SpanHit*)hits, seg_off + (int64_t)r * nseg, nseg, (const u64*)planes + (int64_t)r * 3 * W, W,
+                               read_len[r], quals + (int64_t)r * qual_stride, r, sink, ws.data(), huge_cap);
+            }
         }
         status_counts[st]++;
     }

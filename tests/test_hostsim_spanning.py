@@ -202,3 +202,25 @@ def test_quick_no_of_the_pair_test_is_never_wrong(monkeypatch):
     assert sim.spanning_fusion(p, [seq], sb, nj, [], nf, True)[0] == orc.spanning_fusion(p, orc.Genome([seq]), sb, nj, [], nf, True)
     sim.lib().hostsim_qr_counts(C.byref(said), C.byref(wrong))
     assert wrong.value == 0 and said.value > 10000
+
+
+def test_reads_with_more_joined_alignments_than_a_thread_keeps_cpu(monkeypatch):
+    """120 joined alignments per read (a 120-copy tandem repeat, --max-seg-multihits raised): more than the 96 a thread of the general tier
+    keeps.  span_read reports such a read and emits nothing of it; thj_k_stitch_huge does it again with a workspace (the list and the merge
+    sort's scratch) -- the same call here (THJ_HOSTSIM_HUGE_CAP), every record the oracle gives; a workspace that is too small reports again."""
+    import numpy as np
+    from tophat_amd.batch import JUNC_DTYPE
+    nj = np.zeros(0, dtype=JUNC_DTYPE)
+    seq, sb = repeat_span_batch(copies=120, n_reads=5, seed=11)
+    p = Params(max_seg_multihits=200)
+    want = orc.spanning(p, orc.Genome([seq]), sb, nj, [])
+    assert len(want) == 120 * 5
+    got, status = sim.spanning(p, [seq], sb, nj, [], 0)
+    assert got == [] and status[1] == 5
+    monkeypatch.setenv("THJ_HOSTSIM_HUGE_CAP", "8192")
+    got, status = sim.spanning(p, [seq], sb, nj, [], 0)
+    got.sort(key=lambda a: a.read_idx)
+    assert status[1] == 0 and got == want
+    monkeypatch.setenv("THJ_HOSTSIM_HUGE_CAP", "100")
+    got, status = sim.spanning(p, [seq], sb, nj, [], 0)
+    assert got == [] and status[1] == 5
