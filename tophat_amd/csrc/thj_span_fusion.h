@@ -1072,7 +1072,8 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
 // ---- a read with a long list of joined alignments, by the 64 lanes of a wave (thj_k_stitch_huge under --fusion-search)
 // A read of a k-copy repeat family has k first-segment hits, every one the root of a search that joins it with the other
 // copies' hits as fusion candidates -- (segments - 1) * (k - 1) + 1 joined alignments a root, 7 800 for k = 40 and six segments --
-// and one thread took 30 ms over such a read (round 6, configs[3] at full size with 5 % of the pairs from a 40-copy family).
+// up to 10 000 merge_segment_chain calls each.  With one thread on such a read long_spanning_reads --fusion-search took 1 000 s a side on
+// configs[3] at full size with 5 % of the pairs from a 41-copy family (round 6; 14 s with this, profiles/HISTORY.md).
 // Here: lane l searches roots l, l + 64, ...; what it finds goes to a common list by an atomic counter, tagged (root, number within
 // the root); the list is put back into the order the one-thread search makes it in (root by root), sorted through an index
 // (merge passes, a lane a merge), and unique / filter / records run a lane an alignment, the records' numbers from a running count.
@@ -1082,7 +1083,8 @@ THJ_HD int span_read_fusion(const Genome& g, const Params& p, const SpanSets& S,
 static constexpr int FUS_WAVE_MAXROOT = 1024;
 // A read for the wave from the start: with fusion search on, every hit of the second segment is a candidate partner of every hit of the
 // first (a fusion when they are not neighbours), so a thread alone would try so[1] x so[2] pairs and what hangs below them -- while the
-// other 63 reads of its wave wait (round 6: 94 % of long_spanning_reads --fusion-search on the mix was thj_k_stitch_fusion waiting so).
+// other 63 reads of its wave wait (round 6: 94 % of long_spanning_reads --fusion-search on the mix was thj_k_stitch_fusion waiting so; with
+// 64 pairs as the limit thj_k_stitch_fusion still took 20 ms a launch, with 9: 1.5 ms).
 static constexpr uint32_t FUS_HEAVY_PAIRS = 9;
 THJ_HD bool fusion_read_heavy(const uint32_t* so, int nseg) {
     return nseg >= 2 && (uint64_t)(so[1] - so[0]) * (so[2] - so[1]) >= FUS_HEAVY_PAIRS;
